@@ -1,0 +1,94 @@
+"""ctypes binding of `librectools_hip.so` (C ABI: include/rectools_hip.h).
+
+The product path has NO fallback: if the library is missing or a symbol is absent this module raises.
+PyTorch is used for device memory and streams only: tensors are passed as raw `data_ptr()`s and kernels
+are enqueued on torch's current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import typing as tp
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "librectools_hip.so")
+
+RT_OK, RT_ERR_INVALID_ARG, RT_ERR_WORKSPACE, RT_ERR_LAUNCH, RT_ERR_UNSUPPORTED = 0, 1, 2, 3, 4
+
+c_i32, c_i64, c_f32, c_sz, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
+c_u64 = ctypes.c_uint64
+c_f64 = ctypes.c_double
+
+# name -> (restype, argtypes); MUST list every symbol include/rectools_hip.h declares
+# (tests/test_abi.py parses the header and checks this table and the .so against it).
+SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
+    "rt_version": (c_i32, []),
+    "rt_device_cu_count": (c_i32, []),
+    "rt_topk_workspace_bytes": (c_sz, [c_i32, c_i64, c_i32, c_i32]),
+    "rt_topk_score": (
+        c_i32,
+        [c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
+         c_vp, c_sz, c_i32, c_vp],
+    ),
+}
+
+_lib: tp.Optional[ctypes.CDLL] = None
+
+
+class HipLibraryError(RuntimeError):
+    """Raised when the HIP extension is missing or reports a failure."""
+
+
+def load() -> ctypes.CDLL:
+    """Load the shared library (once).  Fails loudly: there is no CPU / eager fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found. Build it with `python -m rectools_amd.build` "
+            "(or `__graft_entry__.build()`); the MI355X engine has no fallback path."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover
+            raise HipLibraryError(f"symbol {name} missing from {LIB_PATH}") from e
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    """Map C status codes to the reference's exception types (Errors)."""
+    if status == RT_OK:
+        return
+    if status == RT_ERR_INVALID_ARG:
+        raise ValueError(f"{what}: invalid argument")
+    if status == RT_ERR_UNSUPPORTED:
+        raise NotImplementedError(f"{what}: unsupported configuration")
+    if status == RT_ERR_WORKSPACE:
+        raise HipLibraryError(f"{what}: workspace missing or too small")
+    raise HipLibraryError(f"{what}: HIP launch failed (status {status})")
+
+
+def ptr(t) -> tp.Optional[int]:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def current_stream() -> int:
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu() -> None:
+    import torch
+
+    if not torch.cuda.is_available():
+        raise HipLibraryError("no HIP device visible: the MI355X engine cannot run (no CPU fallback)")

@@ -1,0 +1,86 @@
+// Shared device/host helpers for librectools_hip.so (gfx950 / CDNA4 only: 64-wide wavefronts, MFMA, LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RT_OK 0
+#define RT_ERR_INVALID_ARG 1
+#define RT_ERR_WORKSPACE 2
+#define RT_ERR_LAUNCH 3
+#define RT_ERR_UNSUPPORTED 4
+
+#define RT_WAVE 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define RT_CHECK_LAUNCH()                          \
+  do {                                             \
+    hipError_t e__ = hipGetLastError();            \
+    if (e__ != hipSuccess) return RT_ERR_LAUNCH;   \
+  } while (0)
+
+// ---- wave-level reductions (64 lanes) -------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---- order-preserving float <-> uint32 key (for atomicMax on floats) ---------------------------------
+__device__ __forceinline__ unsigned f32_to_key(float f) {
+  unsigned u = __float_as_uint(f);
+  unsigned mask = (u & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u;
+  return u ^ mask;
+}
+__device__ __forceinline__ float key_to_f32(unsigned k) {
+  unsigned mask = (k & 0x80000000u) ? 0x80000000u : 0xFFFFFFFFu;
+  return __uint_as_float(k ^ mask);
+}
+
+// ---- counter-based RNG (Philox4x32-10), used for dropout masks and negative sampling -----------------
+// One call yields 4 x 32 random bits for (seed, offset, subsequence).  Stateless, so backward kernels
+// regenerate exactly the forward mask instead of storing it.
+__device__ __forceinline__ uint4 philox4x32(unsigned long long seed, unsigned long long subseq,
+                                            unsigned long long offset) {
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+  unsigned c0 = (unsigned)offset, c1 = (unsigned)(offset >> 32);
+  unsigned c2 = (unsigned)subseq, c3 = (unsigned)(subseq >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+    unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+    unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
+    unsigned n1 = (unsigned)p1;
+    unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+    unsigned n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return make_uint4(c0, c1, c2, c3);
+}
+__device__ __forceinline__ float u32_to_unit(unsigned x) {  // [0,1)
+  return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+
+static inline int rt_num_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
+      cus = p.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}

@@ -1,0 +1,212 @@
+"""`HipRanker` — drop-in for the reference's `TorchRanker` (rectools/models/rank/rank_torch.py:30-223).
+
+Same constructor arguments, same `rank(subject_ids, k, filter_pairs_csr, sorted_object_whitelist)`
+contract (`Ranker` protocol, rectools/models/rank/rank.py:33-64), same return triplet (flat arrays grouped
+by subject, best first) and the same `ValueError` for a CSR/subject row mismatch (rank_torch.py:107-109).
+
+What differs is *how*: factors stay on the GPU, the viewed-items filter stays in CSR form, and one
+HIP launch sequence (`rt_topk_score`, csrc/rt_topk.hip) streams the catalog once per user batch with
+scores living only in MFMA accumulators — there is no `[batch, n_items]` score matrix, no `toarray()`,
+no per-batch H2D/D2H.  There is no CPU fallback: without the HIP library / a GPU this raises.
+"""
+from __future__ import annotations
+
+import typing as tp
+from enum import Enum
+
+import numpy as np
+import torch
+from scipy import sparse
+
+from . import _lib
+
+
+class Distance(str, Enum):
+    """Distance metric (mirror of rectools/models/rank/rank.py:25-30)."""
+
+    DOT = "dot"  # Bigger value means closer vectors
+    COSINE = "cosine"  # Bigger value means closer vectors
+    EUCLIDEAN = "euclidean"  # Smaller value means closer vectors
+
+
+_DIST_CODE = {Distance.DOT: 0, Distance.COSINE: 1, Distance.EUCLIDEAN: 2}
+
+
+class DeviceCSR:
+    """Viewed-pairs filter kept on the GPU in CSR form (int64 indptr, int32 ascending indices).
+
+    The reference densifies the filter per 128-user batch on the host (`toarray()`, rank_torch.py:141);
+    here it is uploaded once and binary-searched in-kernel only for candidates that beat the threshold.
+    """
+
+    def __init__(self, indptr: torch.Tensor, indices: torch.Tensor, shape: tp.Tuple[int, int]):
+        self.indptr, self.indices, self.shape = indptr, indices, shape
+
+    @classmethod
+    def from_scipy(cls, csr: sparse.csr_matrix, device: tp.Union[torch.device, str]) -> "DeviceCSR":
+        csr = sparse.csr_matrix(csr, copy=True)
+        csr.sum_duplicates()
+        csr.eliminate_zeros()  # reference masks on `toarray() != 0` (rank_torch.py:141-143)
+        csr.sort_indices()
+        indptr = torch.from_numpy(csr.indptr.astype(np.int64)).to(device)
+        indices = torch.from_numpy(csr.indices.astype(np.int32)).to(device)
+        if indices.numel() == 0:
+            indices = torch.zeros((1,), dtype=torch.int32, device=device)
+        return cls(indptr, indices, (int(csr.shape[0]), int(csr.shape[1])))
+
+
+def _pad4(t: torch.Tensor) -> torch.Tensor:
+    """fp32 contiguous [n, d] with d padded to a multiple of 4 floats (16-byte rows for float4 loads)."""
+    d = t.shape[1]
+    if d % 4 != 0:
+        t = torch.nn.functional.pad(t, (0, 4 - d % 4))
+    return t.contiguous()
+
+
+class HipRanker:
+    """
+    Ranker based on the gfx950 top-k scoring kernel.
+
+    Parameters
+    ----------
+    distance : Distance
+        Distance metric.
+    device : torch.device | str
+        HIP device to calculate on (``"cuda"`` / ``"cuda:0"`` on ROCm).
+    subjects_factors : np.ndarray | sparse.csr_matrix | torch.Tensor
+        Subjects embeddings, shape (n_subjects, n_factors).
+    objects_factors : np.ndarray | torch.Tensor
+        Objects embeddings, shape (n_objects, n_factors).
+    batch_size : int, default 128
+        Kept for interface compatibility with `TorchRanker`; here it is the number of users that share one
+        pass over the catalog (32, 64 or 128; other values are rounded).  ``None`` -> library default.
+    dtype : torch.dtype, optional, default ``torch.float32``
+        Only float32 is supported (the reference's default).
+    """
+
+    def __init__(
+        self,
+        distance: Distance,
+        device: tp.Union[torch.device, str],
+        subjects_factors: tp.Union[np.ndarray, sparse.csr_matrix, torch.Tensor],
+        objects_factors: tp.Union[np.ndarray, torch.Tensor],
+        batch_size: tp.Optional[int] = None,
+        dtype: tp.Optional[torch.dtype] = torch.float32,
+    ):
+        if dtype not in (None, torch.float32):
+            raise NotImplementedError("HipRanker computes in float32 only")
+        self.distance = Distance(distance)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.HipLibraryError("HipRanker needs a HIP device (no CPU fallback); got device=%s" % device)
+        _lib.require_gpu()
+        self._lib = _lib.load()
+        self.batch_size = batch_size
+        self.dtype = torch.float32
+        self._higher_is_better = self.distance != Distance.EUCLIDEAN
+        self.subjects_factors = self._to_device(subjects_factors)
+        self.objects_factors = self._to_device(objects_factors)
+        if self.subjects_factors.shape[1] != self.objects_factors.shape[1]:
+            raise ValueError("subjects and objects factors must have the same number of columns")
+        self._workspace: tp.Optional[torch.Tensor] = None
+
+    def _to_device(self, tensor: tp.Union[np.ndarray, sparse.csr_matrix, torch.Tensor]) -> torch.Tensor:
+        # mirrors TorchRanker._normalize_tensor (rank_torch.py:210-223), then moves to the device once
+        if isinstance(tensor, sparse.csr_matrix):
+            tensor = tensor.toarray()
+        if isinstance(tensor, np.ndarray):
+            tensor = torch.from_numpy(np.ascontiguousarray(tensor))
+        tensor = tensor.detach().to(device=self.device, dtype=torch.float32)
+        if tensor.dim() != 2:
+            raise ValueError("factors must be 2-dimensional")
+        return _pad4(tensor)
+
+    def rank(
+        self,
+        subject_ids: tp.Sequence[int],
+        k: tp.Optional[int] = None,
+        filter_pairs_csr: tp.Optional[sparse.csr_matrix] = None,
+        sorted_object_whitelist: tp.Optional[np.ndarray] = None,
+    ) -> tp.Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """Rank objects for every subject; see the `Ranker` protocol (rank.py:33-64 of the reference)."""
+        ids_t, scores_t, counts_t, subject_ids = self.rank_device(
+            subject_ids, k, filter_pairs_csr, sorted_object_whitelist
+        )
+        n_subj, kk = ids_t.shape
+        counts = counts_t.cpu().numpy()
+        ids = ids_t.cpu().numpy()
+        scores = scores_t.cpu().numpy()
+        valid = np.arange(kk)[None, :] < counts[:, None]
+        all_target_ids = np.repeat(subject_ids, kk).reshape(n_subj, kk)[valid]
+        all_reco_ids = ids[valid]
+        all_scores = scores[valid]
+        if filter_pairs_csr is not None:
+            # reference drops -inf rows only when a filter was given (rank_torch.py:167-171)
+            keep = all_scores > -np.inf
+            all_target_ids, all_reco_ids, all_scores = all_target_ids[keep], all_reco_ids[keep], all_scores[keep]
+        return all_target_ids, all_reco_ids, all_scores
+
+    def rank_device(
+        self,
+        subject_ids: tp.Sequence[int],
+        k: tp.Optional[int] = None,
+        filter_pairs_csr: tp.Union[None, sparse.csr_matrix, DeviceCSR] = None,
+        sorted_object_whitelist: tp.Optional[np.ndarray] = None,
+    ) -> tp.Tuple[torch.Tensor, torch.Tensor, torch.Tensor, np.ndarray]:
+        """Device-resident result: (ids [S,k] int64, scores [S,k] f32, counts [S] int32, subject_ids).
+
+        `filter_pairs_csr` may be a `DeviceCSR` prepared once (no per-call upload); nothing here
+        synchronises the device except the small id upload.
+        """
+        subject_ids = np.asarray(subject_ids)
+        if filter_pairs_csr is not None and filter_pairs_csr.shape[0] != len(subject_ids):
+            explanation = "Number of rows in `filter_pairs_csr` must be equal to `len(sublect_ids)`"
+            raise ValueError(explanation)
+
+        dev = self.device
+        n_objects = self.objects_factors.shape[0]
+        whitelist_t = None
+        if sorted_object_whitelist is not None:
+            wl = np.asarray(sorted_object_whitelist, dtype=np.int64)
+            n_cand = len(wl)
+            if not (n_cand == n_objects and n_cand > 0 and wl[0] == 0 and wl[-1] == n_objects - 1):
+                whitelist_t = torch.from_numpy(wl).to(dev)
+        else:
+            n_cand = n_objects
+        if k is None:
+            k = n_cand
+        kk = min(int(k), n_cand)
+        n_subj = len(subject_ids)
+
+        ids_t = torch.empty((n_subj, max(kk, 0)), dtype=torch.int64, device=dev)
+        scores_t = torch.empty((n_subj, max(kk, 0)), dtype=torch.float32, device=dev)
+        counts_t = torch.zeros((n_subj,), dtype=torch.int32, device=dev)
+        if n_subj == 0 or kk <= 0:
+            return ids_t, scores_t, counts_t, subject_ids
+
+        rows_t = None
+        if not (n_subj == self.subjects_factors.shape[0] and np.array_equal(subject_ids, np.arange(n_subj))):
+            rows_t = torch.from_numpy(subject_ids.astype(np.int64)).to(dev)
+
+        indptr_t = indices_t = None
+        if filter_pairs_csr is not None:
+            dcsr = filter_pairs_csr if isinstance(filter_pairs_csr, DeviceCSR) else DeviceCSR.from_scipy(
+                filter_pairs_csr, dev)
+            indptr_t, indices_t = dcsr.indptr, dcsr.indices
+
+        upp = 0 if self.batch_size is None else int(self.batch_size)
+        ws_bytes = self._lib.rt_topk_workspace_bytes(n_subj, n_cand, kk, upp)
+        if self._workspace is None or self._workspace.numel() < ws_bytes:
+            self._workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+
+        with torch.cuda.device(dev):
+            status = self._lib.rt_topk_score(
+                _lib.ptr(self.subjects_factors), self.subjects_factors.stride(0), _lib.ptr(rows_t), n_subj,
+                _lib.ptr(self.objects_factors), self.objects_factors.stride(0), _lib.ptr(whitelist_t), n_cand,
+                self.objects_factors.shape[1], _DIST_CODE[self.distance], kk,
+                _lib.ptr(indptr_t), _lib.ptr(indices_t),
+                _lib.ptr(ids_t), _lib.ptr(scores_t), _lib.ptr(counts_t),
+                _lib.ptr(self._workspace), self._workspace.numel(), upp, _lib.current_stream(),
+            )
+        _lib.check(status, "rt_topk_score")
+        return ids_t, scores_t, counts_t, subject_ids

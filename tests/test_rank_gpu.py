@@ -1,0 +1,141 @@
+"""GPU parity tests of `HipRanker` (csrc/rt_topk.hip through the C ABI) against
+  (1) the reference's own outputs (tests/golden/ranker_golden.npz, produced by the unmodified TorchRanker),
+  (2) the numpy oracle on seeded inputs at sizes it finishes in seconds,
+  (3) size-independent properties at catalog sizes the oracle cannot reach.
+Bar: item ids/order identical on tie-free inputs; scores within rtol 2e-5 / atol 1e-5 (fp32, the
+reference's own 5-decimal tolerance, tests/models/rank/test_rank.py:27).
+"""
+import numpy as np
+import pytest
+import torch
+from scipy import sparse
+
+from conftest import load_ranker_golden
+from oracle import ranker_oracle
+
+pytestmark = pytest.mark.gpu
+
+CASES = load_ranker_golden()
+RTOL, ATOL = 2e-5, 1e-5
+
+
+def _assert_same_ranking(got, exp, rtol=RTOL, atol=ATOL):
+    """ids/order identical; a swap is tolerated only between reference-near-tied neighbours."""
+    gu, gi, gs = got
+    eu, ei, es = exp
+    np.testing.assert_array_equal(gu, eu)
+    assert gi.shape == ei.shape
+    np.testing.assert_allclose(gs, es, rtol=rtol, atol=atol)
+    diff = np.nonzero(gi != ei)[0]
+    for j in diff:  # only exact-order differences between near-equal scores are acceptable
+        same_user = eu == eu[j]
+        # the item we returned must exist in the reference list of that user with a near-equal score
+        cand = np.nonzero(same_user & (ei == gi[j]))[0]
+        assert cand.size == 1, f"item {gi[j]} not in reference top-k of user {eu[j]}"
+        assert abs(es[cand[0]] - es[j]) <= atol + rtol * abs(es[j]), "order differs beyond a near-tie"
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["tag"] for c in CASES])
+def test_golden_reference_outputs(case):
+    from rectools_amd.rank import HipRanker
+
+    ranker = HipRanker(case["distance"], "cuda", case["users"], case["items"])
+    got = ranker.rank(case["sids"], k=case["k"], filter_pairs_csr=case["filt"], sorted_object_whitelist=case["wl"])
+    _assert_same_ranking(got, (case["ref_subjects"], case["ref_items"], case["ref_scores"]))
+
+
+@pytest.mark.parametrize("upp", [32, 64, 128])
+@pytest.mark.parametrize("distance", ["dot", "cosine", "euclidean"])
+def test_vs_oracle_multi_block(distance, upp):
+    """Catalog spanning many item blocks / both launch phases, ragged user count, k-chunk tail (d=72)."""
+    from rectools_amd.rank import HipRanker
+
+    g = torch.Generator().manual_seed(11)
+    users = torch.randn(150, 72, generator=g).numpy()
+    items = torch.randn(20011, 72, generator=g).numpy()
+    rs = np.random.RandomState(3)
+    filt = sparse.random(150, 20011, density=0.01, format="csr", random_state=rs, data_rvs=lambda n: np.ones(n))
+    sids = np.arange(150)
+    ranker = HipRanker(distance, "cuda", users, items, batch_size=upp)
+    got = ranker.rank(sids, k=10, filter_pairs_csr=filt)
+    exp = ranker_oracle.rank(users, items, sids, k=10, filter_pairs_csr=filt, distance=distance)
+    _assert_same_ranking(got, exp, rtol=5e-5, atol=5e-5)
+
+
+def test_two_phase_large_catalog_vs_oracle():
+    """> 2 * 2 * n_CU item blocks forces the prefix-seeded two-phase launch; whitelist + filter on."""
+    from rectools_amd.rank import HipRanker
+
+    g = torch.Generator().manual_seed(5)
+    n_items = 300_000
+    users = torch.randn(70, 32, generator=g).numpy()
+    items = torch.randn(n_items, 32, generator=g).numpy()
+    rs = np.random.RandomState(4)
+    wl = np.sort(rs.choice(n_items, size=n_items - 1234, replace=False))
+    filt = sparse.random(70, n_items, density=0.0005, format="csr", random_state=rs, data_rvs=lambda n: np.ones(n))
+    sids = np.arange(70)
+    ranker = HipRanker("dot", "cuda", users, items)
+    got = ranker.rank(sids, k=10, filter_pairs_csr=filt, sorted_object_whitelist=wl)
+    exp = ranker_oracle.rank(users, items, sids, k=10, filter_pairs_csr=filt, sorted_object_whitelist=wl)
+    _assert_same_ranking(got, exp, rtol=5e-5, atol=5e-5)
+
+
+def test_exact_ties_resolved_to_lower_position():
+    from rectools_amd.rank import HipRanker
+
+    users = np.ones((3, 4), np.float32)
+    items = np.zeros((500, 4), np.float32)
+    items[[7, 130, 131, 499], 0] = 2.0  # four exact ties at the top, rest tie at 0
+    ranker = HipRanker("dot", "cuda", users, items)
+    _, ids, scores = ranker.rank([0, 1, 2], k=6)
+    assert ids.reshape(3, 6).tolist() == [[7, 130, 131, 499, 0, 1]] * 3
+    assert scores.reshape(3, 6).tolist() == [[2, 2, 2, 2, 0, 0]] * 3
+
+
+def test_fewer_than_k_after_filter_and_empty_inputs():
+    from rectools_amd.rank import HipRanker
+
+    users = np.eye(2, 4, dtype=np.float32)
+    items = np.arange(20, dtype=np.float32).reshape(5, 4)
+    filt = sparse.csr_matrix(np.array([[1, 1, 1, 1, 0], [0, 0, 0, 0, 0]]))
+    ranker = HipRanker("dot", "cuda", users, items)
+    su, it, sc = ranker.rank([0, 1], k=3, filter_pairs_csr=filt)
+    assert su.tolist() == [0, 1, 1, 1] and it.tolist() == [4, 4, 3, 2]
+    su, it, sc = ranker.rank([], k=3)
+    assert len(su) == 0 and len(it) == 0 and len(sc) == 0
+    with pytest.raises(ValueError):
+        ranker.rank([0, 1], k=1, filter_pairs_csr=sparse.csr_matrix(np.zeros((3, 5))))
+
+
+def test_large_catalog_properties():
+    """Catalog the oracle cannot score in seconds (1M x 256): size-independent properties.
+    (a) returned scores == recomputed fp32 dot of returned ids; (b) descending order;
+    (c) no non-returned, non-filtered item of a sampled slice beats the k-th score;
+    (d) top-k over the whole catalog == merge of top-k over two whitelist halves (shard idempotence).
+    """
+    from rectools_amd.rank import HipRanker
+
+    g = torch.Generator(device="cuda").manual_seed(2)
+    n_items, d, n_users, k = 1_000_000, 256, 96, 10
+    items = torch.randn(n_items, d, generator=g, device="cuda")
+    users = torch.randn(n_users, d, generator=g, device="cuda")
+    ranker = HipRanker("dot", "cuda", users, items)
+    ids, scores, counts, _ = ranker.rank_device(np.arange(n_users), k=k)
+    torch.cuda.synchronize()
+    assert bool((counts == k).all())
+    rec = (items[ids.reshape(-1)].double() * users.repeat_interleave(k, 0).double()).sum(-1).reshape(n_users, k)
+    torch.testing.assert_close(scores.double(), rec, rtol=2e-5, atol=2e-4)
+    assert bool((scores[:, 1:] <= scores[:, :-1]).all())
+    sl = slice(123_456, 223_456)
+    s_slice = users @ items[sl].T
+    in_sl = (ids >= sl.start) & (ids < sl.stop)
+    rows = torch.arange(n_users, device="cuda")[:, None].expand_as(ids)[in_sl]
+    s_slice[rows, (ids - sl.start)[in_sl]] = float("-inf")  # items we did return are allowed to be higher
+    assert bool((s_slice.max(dim=1).values <= scores[:, -1] + 1e-3).all())
+    half = n_items // 2
+    ia, sa, _, _ = ranker.rank_device(np.arange(n_users), k=k, sorted_object_whitelist=np.arange(0, half))
+    ib, sb, _, _ = ranker.rank_device(np.arange(n_users), k=k, sorted_object_whitelist=np.arange(half, n_items))
+    cat_s, cat_i = torch.cat([sa, sb], 1), torch.cat([ia, ib], 1)
+    top = torch.topk(cat_s, k, dim=1)
+    torch.testing.assert_close(top.values, scores, rtol=0, atol=0)
+    assert bool((cat_i.gather(1, top.indices) == ids).all())
