@@ -140,23 +140,31 @@ def cpu_baseline_topk(items_t: torch.Tensor, users_t: torch.Tensor, filt, budget
 
 
 def run_topk(args, rank, world, n_items, d, users_per_step, upp, with_filter, name):
+    """One step = one rt_topk_score launch sequence over `users_per_step` users (inputs resident in HBM)."""
     step, ranker, info = make_topk_workload(n_items, d, users_per_step, upp, rank, with_filter, seed=0)
     wall, ev_ms = timed_steps(step, args.steps, args.warmup, world)
     users_total = users_per_step * args.steps * world
     value = users_total / wall
-    passes = -(-users_per_step // upp)
-    bytes_per_pass = topk_bytes(n_items, d, min(upp, users_per_step), 10, info["nnz"] // max(passes, 1))
-    # one rt_topk_score call = `passes` catalog passes; duration per pass from HIP events on the launch stream
-    achieved_gbs = bytes_per_pass / (ev_ms / passes * 1e-3) / 1e9
-    flops_per_pass = 2.0 * min(upp, users_per_step) * n_items * d
+    # algorithmic bytes / flops of ONE launch (SURVEY.md §8d): catalog read once for the whole user batch
+    bytes_per_launch = topk_bytes(n_items, d, users_per_step, 10, info["nnz"])
+    flops_per_launch = 2.0 * users_per_step * n_items * d
+    t = ev_ms * 1e-3
+    gbs = bytes_per_launch / t / 1e9
+    tfs = flops_per_launch / t / 1e12
+    hbm_bound = (bytes_per_launch / (HBM_PEAK_GBS * 1e9)) >= (flops_per_launch / (MFMA_F32_PEAK_TF * 1e12))
+    if n_items * d * 4 <= 200e6:
+        hbm_bound = False  # catalog resident in L2 / Infinity Cache: the HBM roof does not apply
     roof = {
-        "kernel": "topk_partial_kernel (rt_topk_score, phases A+B incl. merge)",
-        "bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": load_traffic(name),
-        "users_per_pass": upp, "algorithmic_bytes_per_launch": bytes_per_pass,
-        "avg_launch_ms": round(ev_ms / passes, 4),
-        "mfma_f32_tflops": round(flops_per_pass / (ev_ms / passes * 1e-3) / 1e12, 2),
-        "mfma_f32_frac": round(flops_per_pass / (ev_ms / passes * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
+        "kernel": "topk_stream_kernel + topk_merge_kernel (one rt_topk_score call)",
+        "bound": "hbm" if hbm_bound else "mfma",
+        "achieved": round(gbs if hbm_bound else tfs, 2),
+        "peak": HBM_PEAK_GBS if hbm_bound else MFMA_F32_PEAK_TF,
+        "unit": "GB/s" if hbm_bound else "TFLOP/s",
+        "frac": round((gbs / HBM_PEAK_GBS) if hbm_bound else (tfs / MFMA_F32_PEAK_TF), 4),
+        "traffic": load_traffic(name),
+        "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_flops_per_launch": flops_per_launch,
+        "avg_launch_ms": round(ev_ms, 4), "hbm_GBps": round(gbs, 1), "mfma_f32_TFLOPs": round(tfs, 2),
+        "users_per_launch": users_per_step, "users_per_register_tile": upp,
     }
     return value, wall, roof, info
 
@@ -178,7 +186,8 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="auto", choices=["auto", "train", "recommend", "topk5m"])
-    ap.add_argument("--users-per-pass", type=int, default=64)
+    ap.add_argument("--users-per-pass", type=int, default=0, help="register tile: 32/64/128 users (0 = auto)")
+    ap.add_argument("--users-per-step", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     rank, world, local = dist_setup(args.gpus)
@@ -197,27 +206,24 @@ def main():
         if args.warmup is None:
             args.warmup = 3
         V, d = synth.ML_20M["n_items"], 256
-        users_per_step = 4096
-        value, wall, roof, info = run_topk(args, rank, world, V, d, users_per_step, args.users_per_pass, True,
-                                           "recommend_ml20m")
-        roof["bound"] = "mfma"  # 27 MB catalog is L2/MALL resident: fp32 MFMA-bound, HBM figures are moot
-        roof.update(achieved=roof["mfma_f32_tflops"], peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
-                    frac=roof["mfma_f32_frac"])
+        users_per_step = args.users_per_step or 16384
+        upp = args.users_per_pass or 64
+        value, wall, roof, info = run_topk(args, rank, world, V, d, users_per_step, upp, True, "recommend_ml20m")
         metric, unit = "recommend() users/sec @k=10 (SASRec d=256, ML-20M-shaped catalog, filter_viewed)", "users/s"
-        config = {"workload": "recommend top-k: 26744 items x d256 fp32, 4096 users/step, k=10, viewed-filter CSR",
-                  "users_per_step": users_per_step, "users_per_pass": args.users_per_pass, "parallelism": f"dp{world}"}
+        config = {"workload": f"recommend top-k: 26744 items x d256 fp32, {users_per_step} users/step, k=10, viewed-filter CSR",
+                  "users_per_step": users_per_step, "users_per_register_tile": upp, "parallelism": f"dp{world}"}
     elif workload == "topk5m":
         if args.steps is None:
             args.steps = 3
         if args.warmup is None:
             args.warmup = 1
         V, d = 5_000_000, 512
-        users_per_step = 256
-        value, wall, roof, info = run_topk(args, rank, world, V, d, users_per_step, args.users_per_pass, False,
-                                           "topk5m")
+        users_per_step = args.users_per_step or 32  # 32 users/launch: the HBM-bound regime (AI = B/2 flop/B)
+        upp = args.users_per_pass or (32 if users_per_step <= 32 else 64)
+        value, wall, roof, info = run_topk(args, rank, world, V, d, users_per_step, upp, False, "topk5m")
         metric, unit = "full-catalog top-k users/sec @k=10 (5M x 512 fp32 catalog)", "users/s"
-        config = {"workload": "top-k scoring: 5,000,000 items x d512 fp32 (10.24 GB), 256 users/step, k=10",
-                  "users_per_step": users_per_step, "users_per_pass": args.users_per_pass, "parallelism": f"dp{world}"}
+        config = {"workload": f"top-k scoring: 5,000,000 items x d512 fp32 (10.24 GB), {users_per_step} users/step, k=10",
+                  "users_per_step": users_per_step, "users_per_register_tile": upp, "parallelism": f"dp{world}"}
     else:
         raise SystemExit("train workload is not built yet in this revision")
 

@@ -39,6 +39,8 @@ enum rt_distance { RT_DIST_DOT = 0, RT_DIST_COSINE = 1, RT_DIST_EUCLIDEAN = 2 };
 /* library / device introspection (host) */
 int rt_version(void);
 int rt_device_cu_count(void);
+/* text of the last HIP failure recorded by this library on the calling thread ("" if none) */
+const char* rt_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
  * K12  exact full-catalog top-k scoring
@@ -49,7 +51,9 @@ int rt_device_cu_count(void);
  *  users        [*, d] fp32, row stride `user_stride` floats; batch row i is
  *               users[user_rows ? user_rows[i] : i]                  (== subjects_factors[subject_ids])
  *  items        [*, d] fp32, row stride `item_stride`; candidate position p (0 <= p < n_candidates)
- *               is items[whitelist ? whitelist[p] : p]               (== objects_factors[whitelist])
+ *               is items[whitelist ? whitelist[p] : p]               (== objects_factors[whitelist]);
+ *               with whitelist == NULL its item id is p + candidate_id_offset (a contiguous whitelist
+ *               [lo, lo+n) is passed as items + lo*item_stride, candidate_id_offset = lo)
  *  filt_indptr  nullable [n_users+1] int64, filt_indices int32 ascending per row, in the id space of
  *               `whitelist` values (full item ids): pairs that must not be recommended
  *  k            1 <= k <= n_candidates (caller clamps, as rank_torch.py:148 does)
@@ -64,7 +68,7 @@ size_t rt_topk_workspace_bytes(int32_t n_users, int64_t n_candidates, int32_t k,
 
 int rt_topk_score(const float* users, int64_t user_stride, const int64_t* user_rows, int32_t n_users,
                   const float* items, int64_t item_stride, const int64_t* whitelist, int64_t n_candidates,
-                  int32_t d, int32_t distance, int32_t k,
+                  int64_t candidate_id_offset, int32_t d, int32_t distance, int32_t k,
                   const int64_t* filt_indptr, const int32_t* filt_indices,
                   int64_t* out_ids, float* out_scores, int32_t* out_counts,
                   void* workspace, size_t workspace_bytes, int32_t users_per_pass, rt_stream_t stream);

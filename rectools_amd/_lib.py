@@ -24,10 +24,11 @@ c_f64 = ctypes.c_double
 SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_version": (c_i32, []),
     "rt_device_cu_count": (c_i32, []),
+    "rt_last_error": (ctypes.c_char_p, []),
     "rt_topk_workspace_bytes": (c_sz, [c_i32, c_i64, c_i32, c_i32]),
     "rt_topk_score": (
         c_i32,
-        [c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
+        [c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
          c_vp, c_sz, c_i32, c_vp],
     ),
 }
@@ -49,6 +50,10 @@ def load() -> ctypes.CDLL:
             f"{LIB_PATH} not found. Build it with `python -m rectools_amd.build` "
             "(or `__graft_entry__.build()`); the MI355X engine has no fallback path."
         )
+    # One HIP runtime per process: torch bundles its own libamdhip64 and owns the memory and streams we are
+    # handed, so it must be loaded first; our library then binds to the already loaded runtime by SONAME.
+    import torch  # noqa: F401
+
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         try:
@@ -71,7 +76,13 @@ def check(status: int, what: str) -> None:
         raise NotImplementedError(f"{what}: unsupported configuration")
     if status == RT_ERR_WORKSPACE:
         raise HipLibraryError(f"{what}: workspace missing or too small")
-    raise HipLibraryError(f"{what}: HIP launch failed (status {status})")
+    detail = ""
+    if _lib is not None:
+        try:
+            detail = (_lib.rt_last_error() or b"").decode(errors="replace")
+        except Exception:  # pragma: no cover
+            detail = ""
+    raise HipLibraryError(f"{what}: HIP launch failed (status {status}) {detail}")
 
 
 def ptr(t) -> tp.Optional[int]:

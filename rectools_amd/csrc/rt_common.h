@@ -14,10 +14,25 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Last HIP failure seen by this library (file:line + hipGetErrorString), readable through rt_last_error().
+void rt_set_last_error(const char* file, int line, hipError_t e);
+
 #define RT_CHECK_LAUNCH()                          \
   do {                                             \
     hipError_t e__ = hipGetLastError();            \
-    if (e__ != hipSuccess) return RT_ERR_LAUNCH;   \
+    if (e__ != hipSuccess) {                       \
+      rt_set_last_error(__FILE__, __LINE__, e__);  \
+      return RT_ERR_LAUNCH;                        \
+    }                                              \
+  } while (0)
+
+#define RT_CHECK_HIP(call)                         \
+  do {                                             \
+    hipError_t e__ = (call);                       \
+    if (e__ != hipSuccess) {                       \
+      rt_set_last_error(__FILE__, __LINE__, e__);  \
+      return RT_ERR_LAUNCH;                        \
+    }                                              \
   } while (0)
 
 // ---- wave-level reductions (64 lanes) -------------------------------------------------------------

@@ -2,50 +2,63 @@
 //
 // Replaces the per-128-user loop of the reference `TorchRanker.rank`
 // (rectools/models/rank/rank_torch.py:122-155): `U @ I.T` -> masked_fill(-inf) from a dense
-// `csr.toarray()` -> `torch.topk` -> D2H.  Here the catalog is streamed from HBM exactly once per
-// user batch, scores live only in MFMA accumulators, and per-lane top-k lists absorb them.
+// `csr.toarray()` -> `torch.topk` -> D2H.  Here the catalog is streamed from HBM (or L2 for small
+// catalogs), scores live only in MFMA accumulators, and per-lane top-k lists absorb them.
 //
 // Arithmetic: exact fp32 (v_mfma_f32_32x32x2_f32 == a k-ordered fmaf chain), so scores match an
-// fp32 reference to rounding of the summation order only.
+// fp32 reference up to the rounding of a different summation order.
 //
 // Structure (gfx950):
-//   * workgroup = 4 waves; item block = 128 catalog rows (32 per wave); user batch UB = 32*TU rows.
-//   * k-chunks of 32 floats are staged HBM -> VGPR -> LDS with full 128-byte lines per row and a
-//     +4-float row pad (conflict-free ds_read_b128 fragment reads); double-buffered, one barrier
-//     per chunk, next chunk's global loads in flight under the current chunk's MFMAs.
+//   * grid = (S catalog segments) x (user tiles of UB = 32*TU users).  Workgroup (sx, ty) = 4 waves walks
+//     item blocks sx, sx+S, ... of 128 catalog rows (32 per wave) for the users of tile ty.  S is chosen
+//     so that ~2 workgroups per CU are resident; many-user launches (recommend for a whole user base
+//     against an L2-resident catalog) get S = 1 and walk the full catalog per tile.
 //   * MFMA operand roles: A = items (rows i), B = users (cols j); lane l feeds A[item l&31][k] and
 //     B[k][user l&31] for k = 8s + 4(l>>5) + t, t = 0..3 — a fixed permutation of the reduction index
 //     that lets every lane fetch its 4 MFMA steps with ONE ds_read_b128 per operand.
 //   * D layout (col = lane&31 = user, row = (r&3)+8(r>>2)+4(lane>>5) = item) puts 16 items of ONE user
 //     in each lane: selection is lane-local, no cross-lane traffic.
+//   * two staging engines for the 32-float k-chunks:
+//       - `stream` (d % 32 == 0): global_load_lds_dwordx4 (LDS-DMA) into an NS-deep ring of unpadded,
+//         XOR-swizzled tiles, counted vmcnt + raw s_barrier, NS-1 chunks in flight across block seams;
+//       - `staged` (any d % 4 == 0): HBM -> VGPR -> padded LDS, double-buffered.
+//     Chunk order is rotated per workgroup so that concurrently running workgroups do not all hit the
+//     same 128-byte column of their 2 KB-strided rows (HBM channel camping).
 //   * selection: `score >= thr` fast path in registers; rare slow path does the viewed-items check
 //     (binary search in the user's CSR row) and a replace-worst insert into the lane's list (global
-//     workspace, L2 resident).  A per-user global threshold (atomicMax of each full list's worst
-//     score) is shared by all workgroups, and can be seeded from a catalog prefix (two-phase launch).
-//   * merge kernel: one workgroup per user compacts all lists and extracts the k best in order
+//     workspace, L2 resident).  A per-user threshold (atomicMax of every full list's worst score) is
+//     shared by all workgroups.
+//   * merge kernel: one wave per user compacts that user's lists and extracts the k best in order
 //     (score desc, position asc — the tie rule of oracle/ranker_oracle.py).
+#include <stdlib.h>
+
 #include "rt_common.h"
 
 namespace {
 
 constexpr int IB = 128;       // catalog rows per item block
 constexpr int KC = 32;        // floats per k-chunk
-constexpr int LDK = KC + 4;   // padded LDS row stride (floats)
+constexpr int LDK = KC + 4;   // padded LDS row stride (floats) of the `staged` engine
 constexpr int NTHREADS = 256;
 constexpr int LISTS_PER_WG = 8;  // 4 waves x 2 half-waves
+// threads of the per-user merge / seed workgroups: 1024 when a user has many lists, 256 otherwise
 
 enum { DIST_DOT = 0, DIST_COSINE = 1, DIST_EUCLID = 2 };
 
 struct TopkArgs {
   const float* users; long long user_stride; const long long* user_rows; int n_users;
   const float* items; long long item_stride; const long long* whitelist;
-  long long item_begin, item_end;  // candidate positions handled by this launch
+  long long n_cand; long long id_offset;  // whitelist == NULL: candidate p has item id p + id_offset
   int d; int distance; int k;
   const long long* filt_indptr; const int* filt_indices;
-  float* list_scores; int* list_pos; int* list_counts;  // [n_lists][UB][k], [n_lists][UB]
-  int list_base;  // first list id of this launch
-  int ub;         // user slots per list (== 32*TU)
-  unsigned* gthr; // [ub] ordered keys
+  float* list_scores; int* list_pos; int* list_counts;  // [n_lists][n_users_pad][k], [n_lists][n_users_pad]
+  int n_users_pad;
+  unsigned* gthr;  // [n_users_pad] ordered keys
+  long long blk_begin, blk_end;  // item blocks handled by this launch (phase)
+  int n_seg;                     // workgroups sx < n_seg share those blocks round-robin (others idle)
+  int resume;                    // 1: lists already hold entries from an earlier phase
+  int rotate;
+  int debug;  // ablation switch (RT_TOPK_DEBUG): 1 = skip selection
 };
 
 __device__ __forceinline__ bool better(float s, long long p, float s2, long long p2) {
@@ -56,16 +69,199 @@ __device__ __forceinline__ bool better(float s, long long p, float s2, long long
 __device__ __forceinline__ bool is_filtered(const TopkArgs& a, int u, long long cid) {
   if (a.filt_indptr == nullptr) return false;
   long long lo = a.filt_indptr[u], hi = a.filt_indptr[u + 1];
+  const long long end = hi;
   while (lo < hi) {
     long long mid = (lo + hi) >> 1;
     long long v = (long long)a.filt_indices[mid];
     if (v < cid) lo = mid + 1; else hi = mid;
   }
-  return lo < a.filt_indptr[u + 1] && (long long)a.filt_indices[lo] == cid;
+  return lo < end && (long long)a.filt_indices[lo] == cid;
 }
 
+// List storage pointer types.  LDS lists MUST be addressed through address_space(3) pointers: with generic
+// pointers hipcc emits flat stores, cannot prove they miss the DMA ring, and puts `s_waitcnt vmcnt(0)` in
+// front of the fragment reads of every chunk — which drains the LDS-DMA pipeline.
+template <bool LL> struct ListTypes { typedef float* fptr; typedef int* iptr; };
+template <> struct ListTypes<true> {
+  typedef __attribute__((address_space(3))) float* fptr;
+  typedef __attribute__((address_space(3))) int* iptr;
+};
+
+// Per-lane selection state: one list per (segment, wave, half-wave, user).
+template <int TU, bool LL>
+struct SelState {
+  typedef typename ListTypes<LL>::fptr fptr;
+  typedef typename ListTypes<LL>::iptr iptr;
+  float worst_s[TU]; long long worst_p[TU]; int worst_slot[TU]; int cnt[TU]; float thr[TU];
+  float g_seen[TU];          // last value of the shared bound this lane has observed / published
+  fptr ls[TU]; iptr lp[TU];  // this lane's list storage per user tile (LDS for small k, else global)
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int tu = 0; tu < TU; ++tu) {
+      worst_s[tu] = -INFINITY; worst_p[tu] = -1; worst_slot[tu] = 0; cnt[tu] = 0; thr[tu] = -INFINITY;
+      g_seen[tu] = -INFINITY; ls[tu] = nullptr; lp[tu] = nullptr;
+    }
+  }
+  // continue lists left by an earlier phase (global image; copied into the bound storage if that is LDS)
+  __device__ __forceinline__ void resume(const TopkArgs& a, int list_id, int user0, int lane, bool copy) {
+#pragma unroll
+    for (int tu = 0; tu < TU; ++tu) {
+      const int u = user0 + tu * 32 + (lane & 31);
+      if (u >= a.n_users) continue;
+      const long long li = (long long)list_id * a.n_users_pad + u;
+      const int c = a.list_counts[li];
+      cnt[tu] = c;
+      if (copy) {
+        for (int e = 0; e < c; ++e) { ls[tu][e] = a.list_scores[li * a.k + e]; lp[tu][e] = a.list_pos[li * a.k + e]; }
+      }
+      if (c == a.k) {
+        float ws = ls[tu][0]; long long wp = lp[tu][0]; int wslot = 0;
+        for (int e = 1; e < c; ++e) {
+          float es = ls[tu][e]; long long ep = lp[tu][e];
+          if ((ws > es) || (ws == es && wp < ep)) { ws = es; wp = ep; wslot = e; }
+        }
+        worst_s[tu] = ws; worst_p[tu] = wp; worst_slot[tu] = wslot; thr[tu] = ws;
+      }
+    }
+  }
+  // global-memory lists: [n_lists][n_users_pad][k]
+  __device__ __forceinline__ void bind_global(const TopkArgs& a, int list_id, int user0, int lane) {
+    if constexpr (!LL) {
+#pragma unroll
+      for (int tu = 0; tu < TU; ++tu) {
+        const long long lbase = ((long long)list_id * a.n_users_pad + (user0 + tu * 32 + (lane & 31))) * a.k;
+        ls[tu] = a.list_scores + lbase; lp[tu] = a.list_pos + lbase;
+      }
+    }
+  }
+  // LDS lists: scores [8][UB][k] then positions [8][UB][k] behind the staging ring
+  __device__ __forceinline__ void bind_lds(float* base, int k, int wave, int lane) {
+    if constexpr (LL) {
+      constexpr int UB = 32 * TU;
+      fptr b = (fptr)base;
+#pragma unroll
+      for (int tu = 0; tu < TU; ++tu) {
+        const int L = ((wave * 2 + (lane >> 5)) * UB + tu * 32 + (lane & 31)) * k;
+        ls[tu] = b + L; lp[tu] = (iptr)(b + LISTS_PER_WG * UB * k) + L;
+      }
+    }
+  }
+};
+
+// Absorb one finished item block (accumulators `acc`) into the lane's lists.
+template <int TU, bool LL, bool GL = false>
+__device__ __forceinline__ void select_block(const TopkArgs& a, SelState<TU, LL>& st, const f32x16 (&acc)[TU],
+                                             float nrm_i, const float (&nrm_u)[TU], long long pos0,
+                                             int list_id, int user0, int lane, int wave,
+                                             const unsigned* g_lds = nullptr) {
+  const int col = lane & 31, half = lane >> 5;
+  const bool need_norm = a.distance != DIST_DOT;
+  float ni_full = 0.f;
+  if (need_norm) ni_full = nrm_i + __shfl_xor(nrm_i, 32, 64);  // lanes r and r+32 hold item row r
+#pragma unroll
+  for (int tu = 0; tu < TU; ++tu) {
+    const int u = user0 + tu * 32 + col;
+    const bool uvalid = u < a.n_users;
+    if (uvalid) {  // refresh from the shared per-user bound (LDS copy brought in by the DMA ring, if any)
+      float g;
+      if constexpr (GL) g = key_to_f32(g_lds[tu * 32 + col]);
+      else g = key_to_f32(__hip_atomic_load(a.gthr + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      st.g_seen[tu] = fmaxf(st.g_seen[tu], g);
+      st.thr[tu] = fmaxf(st.thr[tu], g);
+    }
+    float nu_full = 0.f, inv_u = 1.f;
+    if (need_norm) {
+      nu_full = nrm_u[tu] + __shfl_xor(nrm_u[tu], 32, 64);
+      inv_u = 1.0f / fmaxf(sqrtf(nu_full), 1e-8f);
+    }
+    float sc[16];
+    unsigned cmask = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      float s = acc[tu][r];
+      if (need_norm) {
+        float ni = __shfl(ni_full, row, 64);
+        if (a.distance == DIST_COSINE) {
+          s = s * inv_u * (1.0f / fmaxf(sqrtf(ni), 1e-8f));
+        } else {
+          s = -sqrtf(fmaxf(nu_full + ni - 2.0f * s, 0.f));
+        }
+      }
+      sc[r] = s;
+      const long long p = pos0 + wave * 32 + row;
+      if (uvalid && p < a.n_cand && s >= st.thr[tu]) cmask |= (1u << r);
+    }
+    if (__any(cmask != 0)) {
+      // rare slow path: viewed-items check + replace-worst insert into this lane's list
+      const typename ListTypes<LL>::fptr lsc = st.ls[tu]; const typename ListTypes<LL>::iptr lps = st.lp[tu];
+      while (cmask != 0) {
+        const int r = __ffs(cmask) - 1;
+        cmask &= cmask - 1;
+        float s = sc[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) s = (r == i) ? sc[i] : s;  // static-index select: no scratch
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const long long p = pos0 + wave * 32 + row;
+        if (!(s >= st.thr[tu])) continue;  // threshold may have risen inside this loop
+        bool take = (st.cnt[tu] < a.k) || better(s, p, st.worst_s[tu], st.worst_p[tu]);
+        if (!take) continue;
+        const long long cid = a.whitelist ? a.whitelist[p] : p + a.id_offset;
+        if (is_filtered(a, u, cid)) continue;
+        if (st.cnt[tu] < a.k) {
+          lsc[st.cnt[tu]] = s;
+          lps[st.cnt[tu]] = (int)p;
+          st.cnt[tu] += 1;
+        } else {
+          lsc[st.worst_slot[tu]] = s;
+          lps[st.worst_slot[tu]] = (int)p;
+        }
+        if (st.cnt[tu] == a.k) {  // list full: (re)locate its worst entry and publish the bound
+          float ws = lsc[0]; long long wp = lps[0]; int wslot = 0;
+          for (int e = 1; e < a.k; ++e) {
+            float es = lsc[e]; long long ep = lps[e];
+            if (better(ws, wp, es, ep)) { ws = es; wp = ep; wslot = e; }
+          }
+          st.worst_s[tu] = ws; st.worst_p[tu] = wp; st.worst_slot[tu] = wslot;
+          st.thr[tu] = fmaxf(st.thr[tu], ws);
+        }
+      }
+      // publish at most once per block and list, and only a bound that beats the shared one
+      if (st.cnt[tu] == a.k && st.worst_s[tu] > st.g_seen[tu]) {
+        atomicMax(a.gthr + u, f32_to_key(st.worst_s[tu]));
+        st.g_seen[tu] = st.worst_s[tu];
+      }
+      // Leave the (rare) slow path with an empty VMEM scoreboard: otherwise hipcc guards register reuse at
+      // the loop head with an unconditional `s_waitcnt vmcnt(0)`, which drains the DMA ring on EVERY block.
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
+    }
+  }
+}
+
+template <int TU, bool LL>
+__device__ __forceinline__ void publish_counts(const TopkArgs& a, const SelState<TU, LL>& st, int list_id, int user0,
+                                               int lane, bool flush_lds_lists) {
+#pragma unroll
+  for (int tu = 0; tu < TU; ++tu) {
+    const int u = user0 + tu * 32 + (lane & 31);
+    if (u < a.n_users) {
+      a.list_counts[(long long)list_id * a.n_users_pad + u] = st.cnt[tu];
+      if (flush_lds_lists) {
+        const long long lbase = ((long long)list_id * a.n_users_pad + u) * a.k;
+        for (int e = 0; e < st.cnt[tu]; ++e) {
+          a.list_scores[lbase + e] = st.ls[tu][e];
+          a.list_pos[lbase + e] = st.lp[tu][e];
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Engine 1: register-staged, padded LDS, double-buffered.  Handles any d % 4 == 0.
+// ------------------------------------------------------------------------------------------------
 template <int TU>
-__global__ __launch_bounds__(NTHREADS) void topk_partial_kernel(TopkArgs a) {
+__global__ __launch_bounds__(NTHREADS) void topk_staged_kernel(TopkArgs a) {
   constexpr int UB = 32 * TU;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                      // [2][IB][LDK]
@@ -74,44 +270,42 @@ __global__ __launch_bounds__(NTHREADS) void topk_partial_kernel(TopkArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int col = lane & 31;   // user column inside a 32-user tile / item row for the A operand
+  const int col = lane & 31;
   const int half = lane >> 5;
+  const int S = a.n_seg;
+  const int user0 = blockIdx.y * UB;
 
-  const long long n_cand = a.item_end - a.item_begin;
-  const long long n_blocks = (n_cand + IB - 1) / IB;
   const int n_chunks = (a.d + KC - 1) / KC;
+  const int rot = a.rotate ? (int)((blockIdx.x * 5u + blockIdx.y * 3u) % (unsigned)n_chunks) : 0;
 
-  // ---- per-lane list state (one list per (workgroup, wave, half, user)) ----
-  const int list_id = a.list_base + blockIdx.x * LISTS_PER_WG + wave * 2 + half;
-  float worst_s[TU]; long long worst_p[TU]; int worst_slot[TU]; int cnt[TU]; float thr[TU];
-#pragma unroll
-  for (int tu = 0; tu < TU; ++tu) {
-    worst_s[tu] = -INFINITY; worst_p[tu] = -1; worst_slot[tu] = 0; cnt[tu] = 0; thr[tu] = -INFINITY;
-  }
+  const int list_id = blockIdx.x * LISTS_PER_WG + wave * 2 + half;
+  SelState<TU, false> st;
+  st.init();
+  st.bind_global(a, list_id, user0, lane);
+  if (a.resume) st.resume(a, list_id, user0, lane, false);
 
-  // ---- user-row staging assignment: TU float4 per thread per chunk ----
   const float* urow[TU]; int ur_r[TU];
-  const int c4 = tid & 7;  // float4 column inside the chunk
+  const int c4 = tid & 7;
 #pragma unroll
   for (int j = 0; j < TU; ++j) {
     int r = (tid >> 3) + 32 * j;
     ur_r[j] = r;
-    if (r < a.n_users) {
-      long long src = a.user_rows ? a.user_rows[r] : (long long)r;
+    int u = user0 + r;
+    if (u < a.n_users) {
+      long long src = a.user_rows ? a.user_rows[u] : (long long)u;
       urow[j] = a.users + src * a.user_stride;
     } else {
       urow[j] = nullptr;
     }
   }
 
-  for (long long blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
-    const long long pos0 = a.item_begin + blk * IB;
-    // item-row staging assignment: 4 float4 per thread per chunk
+  for (long long blk = a.blk_begin + blockIdx.x; blk < a.blk_end && (int)blockIdx.x < S; blk += S) {
+    const long long pos0 = blk * IB;
     const float* irow[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       long long p = pos0 + (tid >> 3) + 32 * j;
-      if (p < a.item_end) {
+      if (p < a.n_cand) {
         long long src = a.whitelist ? a.whitelist[p] : p;
         irow[j] = a.items + src * a.item_stride;
       } else {
@@ -130,7 +324,8 @@ __global__ __launch_bounds__(NTHREADS) void topk_partial_kernel(TopkArgs a) {
 
     f32x4 ri[4]; f32x4 ru[TU];
     auto gload = [&](int c) {
-      const int kofs = c * KC + c4 * 4;
+      int cc = c + rot; if (cc >= n_chunks) cc -= n_chunks;
+      const int kofs = cc * KC + c4 * 4;
       const bool kin = kofs < a.d;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -183,160 +378,272 @@ __global__ __launch_bounds__(NTHREADS) void topk_partial_kernel(TopkArgs a) {
         __syncthreads();
       }
     }
-
-    // ---- distance epilogue inputs ----
-    float ni_full = nrm_i + __shfl_xor(nrm_i, 32, 64);  // lanes r and r+32 hold item row r of this wave
-    // ---- refresh thresholds from the shared per-user bound ----
-#pragma unroll
-    for (int tu = 0; tu < TU; ++tu) {
-      const int u = tu * 32 + col;
-      if (u < a.n_users) {
-        float g = key_to_f32(__hip_atomic_load(a.gthr + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        thr[tu] = fmaxf(thr[tu], g);
-      }
-    }
-
-#pragma unroll
-    for (int tu = 0; tu < TU; ++tu) {
-      const int u = tu * 32 + col;
-      const bool uvalid = u < a.n_users;
-      float nu_full = nrm_u[tu] + __shfl_xor(nrm_u[tu], 32, 64);
-      float inv_u = 1.0f / fmaxf(sqrtf(nu_full), 1e-8f);
-      float sc[16];
-      unsigned cmask = 0;
-      const bool need_norm = a.distance != DIST_DOT;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        float s = acc[tu][r];
-        if (need_norm) {
-          float ni = __shfl(ni_full, row, 64);
-          if (a.distance == DIST_COSINE) {
-            s = s * inv_u * (1.0f / fmaxf(sqrtf(ni), 1e-8f));
-          } else {
-            s = -sqrtf(fmaxf(nu_full + ni - 2.0f * s, 0.f));
-          }
-        }
-        sc[r] = s;
-        const long long p = pos0 + wave * 32 + row;
-        if (uvalid && p < a.item_end && s >= thr[tu]) cmask |= (1u << r);
-      }
-      if (__any(cmask != 0)) {
-        // rare slow path: viewed-items check + replace-worst insert into this lane's list
-        const long long lbase = ((long long)list_id * a.ub + u) * a.k;
-        while (cmask != 0) {
-          const int r = __ffs(cmask) - 1;
-          cmask &= cmask - 1;
-          float s = sc[0];
-#pragma unroll
-          for (int i = 1; i < 16; ++i) s = (r == i) ? sc[i] : s;  // static-index select: no scratch
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-          const long long p = pos0 + wave * 32 + row;
-          if (!(s >= thr[tu])) continue;  // threshold may have risen inside this loop
-          bool take = (cnt[tu] < a.k) || better(s, p, worst_s[tu], worst_p[tu]);
-          if (!take) continue;
-          const long long cid = a.whitelist ? a.whitelist[p] : p;
-          if (is_filtered(a, u, cid)) continue;
-          const long long rel = p - a.item_begin;  // < 2^31 enforced by the host
-          if (cnt[tu] < a.k) {
-            a.list_scores[lbase + cnt[tu]] = s;
-            a.list_pos[lbase + cnt[tu]] = (int)rel;
-            cnt[tu] += 1;
-          } else {
-            a.list_scores[lbase + worst_slot[tu]] = s;
-            a.list_pos[lbase + worst_slot[tu]] = (int)rel;
-          }
-          if (cnt[tu] == a.k) {  // list full: (re)locate its worst entry and publish the bound
-            float ws = a.list_scores[lbase]; long long wp = a.item_begin + a.list_pos[lbase]; int wslot = 0;
-            for (int e = 1; e < a.k; ++e) {
-              float es = a.list_scores[lbase + e]; long long ep = a.item_begin + a.list_pos[lbase + e];
-              if (better(ws, wp, es, ep)) { ws = es; wp = ep; wslot = e; }
-            }
-            worst_s[tu] = ws; worst_p[tu] = wp; worst_slot[tu] = wslot;
-            thr[tu] = fmaxf(thr[tu], ws);
-            atomicMax(a.gthr + u, f32_to_key(ws));
-          }
-        }
-      }
-    }
+    select_block<TU, false>(a, st, acc, nrm_i, nrm_u, pos0, list_id, user0, lane, wave);
   }
-
-  // ---- publish list lengths ----
-#pragma unroll
-  for (int tu = 0; tu < TU; ++tu) {
-    const int u = tu * 32 + col;
-    if (u < a.n_users) a.list_counts[(long long)list_id * a.ub + u] = cnt[tu];
-  }
+  publish_counts<TU, false>(a, st, list_id, user0, lane, false);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Engine 2: LDS-DMA ring (global_load_lds_dwordx4), NS stages, counted vmcnt, raw s_barrier.
+// Requires d % 32 == 0.  LDS image per stage: items [128][32] + users [UB][32] floats, unpadded;
+// 16-byte slot c4 of row r is stored at physical slot c4 ^ ((r>>1)&7) (conflict-free ds_read_b128).
+// ------------------------------------------------------------------------------------------------
+// LDS byte address of a __shared__ pointer (wave-uniform values only: it is moved into M0).
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
+}
+// One LDS-DMA instruction: 64 lanes x 16 B from per-lane global addresses to LDS [dst, dst + 1 KiB).
+// Issued through inline asm so that hipcc does not see an asynchronous LDS write: with the builtin it
+// drains vmcnt(0) in front of the ds_reads of OTHER ring slots (it cannot prove they do not alias).
+// The DMA is therefore invisible to the compiler's waitcnt bookkeeping; completion is waited for by
+// hand (wait_vmcnt<N>) — in-order return makes every compiler-inserted vmcnt wait at least as strong.
+__device__ __forceinline__ void dma16(const float* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
+__device__ __forceinline__ void dma4(const unsigned* gsrc, unsigned lds_dst) {  // 64 lanes x 4 B
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int TU, int NS, bool WL, bool LL>
+__global__ __launch_bounds__(NTHREADS) void topk_stream_kernel(TopkArgs a) {
+  constexpr int UB = 32 * TU;
+  constexpr int SA = IB * KC;            // floats per stage, items
+  constexpr int SU = UB * KC;            // floats per stage, users
+  constexpr int SG = 128;                // shared-bound copy (uints), refreshed with every stage
+  constexpr int STAGE = SA + SU + SG;
+  constexpr int NL = 5 + TU;             // LDS-DMA instructions per thread per stage
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [NS][STAGE]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 31;
+  const int half = lane >> 5;
+  const int S = a.n_seg;
+  const int user0 = blockIdx.y * UB;
+
+  const long long n_blocks = a.blk_end - a.blk_begin;
+  const int n_chunks = a.d / KC;
+  const int rot = a.rotate ? (int)((blockIdx.x * 5u + blockIdx.y * 3u) % (unsigned)n_chunks) : 0;
+  const long long my_blocks = ((int)blockIdx.x < S && n_blocks > blockIdx.x) ? (n_blocks - blockIdx.x + S - 1) / S : 0;
+  const long long T = my_blocks * n_chunks;  // flattened (block, chunk) steps of this workgroup
+
+  const int list_id = blockIdx.x * LISTS_PER_WG + wave * 2 + half;
+  SelState<TU, LL> st;
+  st.init();
+  st.bind_lds(smem + NS * STAGE, a.k, wave, lane);
+  st.bind_global(a, list_id, user0, lane);
+  if (a.resume) st.resume(a, list_id, user0, lane, LL);
+  if (T == 0) { if (!a.resume) publish_counts<TU, LL>(a, st, list_id, user0, lane, false); return; }
+
+  // ---- DMA source assignment ----
+  // items: instruction j of wave w fills rows (w*4+j)*8 .. +7 ; lane -> row + (lane>>3), slot lane&7
+  const int l_row8 = lane >> 3, l_slot = lane & 7;
+  int i_row[4]; int i_colofs[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    i_row[j] = (wave * 4 + j) * 8 + l_row8;
+    i_colofs[j] = (l_slot ^ ((i_row[j] >> 1) & 7)) * 4;  // logical float offset inside the chunk
+  }
+  // users: instruction j of wave w fills user rows (j*4 + w)*8 .. +7   (TU instructions per wave)
+  const float* u_src[TU]; int u_row[TU];
+#pragma unroll
+  for (int j = 0; j < TU; ++j) {
+    u_row[j] = (j * 4 + wave) * 8 + l_row8;
+    int u = user0 + u_row[j];
+    if (u >= a.n_users) u = a.n_users - 1;  // clamp: padded user columns are never selected
+    long long src = a.user_rows ? a.user_rows[u] : (long long)u;
+    u_src[j] = a.users + src * a.user_stride + (l_slot ^ ((u_row[j] >> 1) & 7)) * 4;
+  }
+
+  const float* i_src[4];
+  auto set_item_rows = [&](long long blk_local) {
+    const long long pos0 = (a.blk_begin + blockIdx.x + blk_local * S) * IB;
+    long long p[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      p[j] = pos0 + i_row[j];
+      if (p[j] >= a.n_cand) p[j] = a.n_cand - 1;  // clamp: rows past the end are masked at selection
+    }
+    if (WL) {
+      // whitelist indirection, once per item block.  Loaded through inline asm with its own full wait:
+      // a compiler-visible load inside the streaming loop makes hipcc place `s_waitcnt vmcnt(0)` in
+      // front of the fragment reads of EVERY chunk (register-reuse hazard), draining the DMA ring.
+      long long s0, s1, s2, s3;
+      asm volatile(
+          "global_load_dwordx2 %0, %4, off\n\tglobal_load_dwordx2 %1, %5, off\n\t"
+          "global_load_dwordx2 %2, %6, off\n\tglobal_load_dwordx2 %3, %7, off\n\ts_waitcnt vmcnt(0)"
+          : "=&v"(s0), "=&v"(s1), "=&v"(s2), "=&v"(s3)
+          : "v"(a.whitelist + p[0]), "v"(a.whitelist + p[1]), "v"(a.whitelist + p[2]), "v"(a.whitelist + p[3])
+          : "memory");
+      p[0] = s0; p[1] = s1; p[2] = s2; p[3] = s3;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) i_src[j] = a.items + p[j] * a.item_stride + i_colofs[j];
+  };
+  const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+  // shared-bound copy: waves 0/2 bring users [0,64), waves 1/3 users [64,128) of this tile (4 B per lane)
+  int g_idx = user0 + (wave & 1) * 64 + lane;
+  if (g_idx >= a.n_users_pad) g_idx = a.n_users_pad - 1;
+  const unsigned* g_src = a.gthr + g_idx;
+  auto issue = [&](int stage, int c) {  // DMA chunk c (already rotated) of the current issue block
+    const unsigned sbase = smem_base + (unsigned)(stage * STAGE * 4);
+    const int kofs = c * KC;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dma16(i_src[j] + kofs, sbase + (unsigned)((wave * 4 + j) * 8 * KC * 4));
+#pragma unroll
+    for (int j = 0; j < TU; ++j) dma16(u_src[j] + kofs, sbase + (unsigned)((SA + (j * 4 + wave) * 8 * KC) * 4));
+    dma4(g_src, sbase + (unsigned)((SA + SU + (wave & 1) * 64) * 4));
+  };
+
+  // ---- prologue: NS-1 stages in flight ----
+  long long iss_blk = 0; int iss_c = 0; long long issued = 0; int iss_stage = 0;
+  set_item_rows(0);
+  auto issue_next = [&]() {
+    int cc = iss_c + rot; if (cc >= n_chunks) cc -= n_chunks;
+    issue(iss_stage, cc);
+    iss_stage = (iss_stage + 1 == NS) ? 0 : iss_stage + 1;
+    ++issued; ++iss_c;
+    if (iss_c == n_chunks) { iss_c = 0; ++iss_blk; if (iss_blk < my_blocks) set_item_rows(iss_blk); }
+  };
+#pragma unroll 1
+  for (int s = 0; s < NS - 1; ++s) if (issued < T) issue_next();
+
+  f32x16 acc[TU];
+  float nrm_i = 0.f; float nrm_u[TU];
+#pragma unroll
+  for (int tu = 0; tu < TU; ++tu) {
+    nrm_u[tu] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[tu][r] = 0.f;
+  }
+
+  // fragment read offsets (swizzled)
+  const int a_row = wave * 32 + col;
+  const int a_swz = (a_row >> 1) & 7;
+  int u_swz[TU];
+#pragma unroll
+  for (int tu = 0; tu < TU; ++tu) u_swz[tu] = ((tu * 32 + col) >> 1) & 7;
+
+  int cons_stage = 0; long long g = 0;
+#pragma unroll 1
+  for (long long blk_local = 0; blk_local < my_blocks; ++blk_local) {
+    const unsigned* g_lds = nullptr;
+#pragma unroll 1
+    for (int c = 0; c < n_chunks; ++c, ++g) {
+      // chunk g landed?  outstanding stages allowed: NS-2 in steady state, 0 in the drain
+      if (issued - g == NS - 1) wait_vmcnt<NL*(NS - 2)>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (issued < T) issue_next();  // refill the buffer consumed at step g-1
+
+      const float* sbase = smem + cons_stage * STAGE;
+      cons_stage = (cons_stage + 1 == NS) ? 0 : cons_stage + 1;
+      g_lds = reinterpret_cast<const unsigned*>(sbase + SA + SU);
+      const float* Ab = sbase + a_row * KC;
+      const float* Ub = sbase + SA + col * KC;
+#pragma unroll
+      for (int s = 0; s < KC / 8; ++s) {
+        f32x4 av = *reinterpret_cast<const f32x4*>(Ab + (((2 * s + half) ^ a_swz) << 2));
+        nrm_i += av[0] * av[0] + av[1] * av[1] + av[2] * av[2] + av[3] * av[3];
+#pragma unroll
+        for (int tu = 0; tu < TU; ++tu) {
+          f32x4 bv = *reinterpret_cast<const f32x4*>(Ub + tu * 32 * KC + (((2 * s + half) ^ u_swz[tu]) << 2));
+          nrm_u[tu] += bv[0] * bv[0] + bv[1] * bv[1] + bv[2] * bv[2] + bv[3] * bv[3];
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            acc[tu] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc[tu], 0, 0, 0);
+        }
+      }
+    }
+    const long long pos0 = (a.blk_begin + blockIdx.x + blk_local * S) * IB;
+    if (!(a.debug & 1)) select_block<TU, LL, true>(a, st, acc, nrm_i, nrm_u, pos0, list_id, user0, lane, wave, g_lds);
+    else if (acc[0][0] + nrm_i == 1.2345e30f) st.cnt[0] = 1;
+    nrm_i = 0.f;
+#pragma unroll
+    for (int tu = 0; tu < TU; ++tu) {
+      nrm_u[tu] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tu][r] = 0.f;
+    }
+  }
+  publish_counts<TU, LL>(a, st, list_id, user0, lane, LL);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Merge: one workgroup per user.
+// ------------------------------------------------------------------------------------------------
 struct MergeArgs {
   const float* list_scores; const int* list_pos; const int* list_counts;
-  int n_lists; int ub; int k; int n_users;
-  long long item_begin;
-  // optional extra sorted list per user (result of an earlier phase), absolute positions
-  const float* extra_scores; const long long* extra_pos; const int* extra_counts;
-  float* compact_scores; long long* compact_pos; long long compact_cap;  // per-user scratch
-  // outputs
-  const long long* whitelist; int distance;
-  long long* out_ids; float* out_scores; int* out_counts;      // final outputs (nullable)
-  float* mid_scores; long long* mid_pos; int* mid_counts;      // phase outputs (nullable), positions
-  unsigned* gthr;                                              // seed threshold (nullable)
+  int n_lists; int n_users_pad; int k; int n_users;
+  float* compact_scores; int* compact_pos; long long compact_cap;  // per-user scratch
+  const long long* whitelist; long long id_offset; int distance;
+  long long* out_ids; float* out_scores; int* out_counts;
 };
 
-__global__ __launch_bounds__(NTHREADS) void topk_merge_kernel(MergeArgs m) {
+template <int NT_MERGE>
+__global__ __launch_bounds__(NT_MERGE) void topk_merge_kernel(MergeArgs m) {
+  // one workgroup per user
   const int u = blockIdx.x;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  __shared__ int s_scan[NTHREADS];
-  __shared__ float s_ws[4]; __shared__ long long s_wp[4];
+  __shared__ int s_scan[NT_MERGE];
+  __shared__ float s_ws[NT_MERGE / 64]; __shared__ long long s_wp[NT_MERGE / 64];
   __shared__ float s_bs; __shared__ long long s_bp;
 
-  // ---- pass 1: per-thread candidate counts -> exclusive scan -> compaction ----
+  // pass 1: per-thread candidate counts -> exclusive scan -> compaction
   int my = 0;
-  for (int l = tid; l < m.n_lists; l += NTHREADS) my += m.list_counts[(long long)l * m.ub + u];
-  int extra_n = (m.extra_counts != nullptr) ? m.extra_counts[u] : 0;
-  if (tid == 0) my += extra_n;
+  for (int l = tid; l < m.n_lists; l += NT_MERGE) my += m.list_counts[(long long)l * m.n_users_pad + u];
   s_scan[tid] = my;
   __syncthreads();
-  for (int o = 1; o < NTHREADS; o <<= 1) {
+  for (int o = 1; o < NT_MERGE; o <<= 1) {
     int v = (tid >= o) ? s_scan[tid - o] : 0;
     __syncthreads();
     s_scan[tid] += v;
     __syncthreads();
   }
-  const int total = s_scan[NTHREADS - 1];
+  const int total = s_scan[NT_MERGE - 1];
   int ofs = s_scan[tid] - my;
   float* cs = m.compact_scores + (long long)u * m.compact_cap;
-  long long* cp = m.compact_pos + (long long)u * m.compact_cap;
-  if (tid == 0) {
-    for (int e = 0; e < extra_n; ++e) {
-      cs[ofs] = m.extra_scores[(long long)u * m.k + e];
-      cp[ofs] = m.extra_pos[(long long)u * m.k + e];
-      ++ofs;
-    }
-  }
-  for (int l = tid; l < m.n_lists; l += NTHREADS) {
-    const int c = m.list_counts[(long long)l * m.ub + u];
-    const long long lb = ((long long)l * m.ub + u) * m.k;
+  int* cp = m.compact_pos + (long long)u * m.compact_cap;
+  for (int l = tid; l < m.n_lists; l += NT_MERGE) {
+    const int c = m.list_counts[(long long)l * m.n_users_pad + u];
+    const long long lb = ((long long)l * m.n_users_pad + u) * m.k;
     for (int e = 0; e < c; ++e) {
       cs[ofs] = m.list_scores[lb + e];
-      cp[ofs] = m.item_begin + (long long)m.list_pos[lb + e];
+      cp[ofs] = m.list_pos[lb + e];
       ++ofs;
     }
   }
   __syncthreads();
 
-  // ---- pass 2: k rounds of block-wide arg-best below the previous winner ----
+  // pass 2: k rounds of block-wide arg-best strictly below the previous winner
   const int n_out = total < m.k ? total : m.k;
   float prev_s = INFINITY; long long prev_p = -1;
   for (int r = 0; r < n_out; ++r) {
-    float bs = -INFINITY; long long bp = 0x7fffffffffffffffLL; bool have = false;
-    for (int e = tid; e < total; e += NTHREADS) {
-      float s = cs[e]; long long p = cp[e];
-      bool below = (r == 0) || better(prev_s, prev_p, s, p);
-      if (below && (!have || better(s, p, bs, bp))) { bs = s; bp = p; have = true; }
+    float bs = -INFINITY; long long bp = 0x7fffffffffffffffLL;
+    for (int e = tid; e < total; e += NT_MERGE) {
+      float sc = cs[e]; long long p = cp[e];
+      bool below = (r == 0) || better(prev_s, prev_p, sc, p);
+      if (below && better(sc, p, bs, bp)) { bs = sc; bp = p; }
     }
-    if (!have) { bs = -INFINITY; bp = 0x7fffffffffffffffLL; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       float os = __shfl_xor(bs, o, 64); long long op = __shfl_xor(bp, o, 64);
@@ -346,26 +653,62 @@ __global__ __launch_bounds__(NTHREADS) void topk_merge_kernel(MergeArgs m) {
     __syncthreads();
     if (tid == 0) {
       float fs = s_ws[0]; long long fp = s_wp[0];
-      for (int w = 1; w < 4; ++w)
+      for (int w = 1; w < NT_MERGE / 64; ++w)
         if (better(s_ws[w], s_wp[w], fs, fp)) { fs = s_ws[w]; fp = s_wp[w]; }
       s_bs = fs; s_bp = fp;
-      if (m.out_ids != nullptr) {
-        m.out_ids[(long long)u * m.k + r] = m.whitelist ? m.whitelist[fp] : fp;
-        m.out_scores[(long long)u * m.k + r] = (m.distance == DIST_EUCLID) ? -fs : fs;
-      }
-      if (m.mid_scores != nullptr) {
-        m.mid_scores[(long long)u * m.k + r] = fs;
-        m.mid_pos[(long long)u * m.k + r] = fp;
-      }
+      m.out_ids[(long long)u * m.k + r] = m.whitelist ? m.whitelist[fp] : fp + m.id_offset;
+      m.out_scores[(long long)u * m.k + r] = (m.distance == DIST_EUCLID) ? -fs : fs;
     }
     __syncthreads();
     prev_s = s_bs; prev_p = s_bp;
   }
-  if (tid == 0) {
-    if (m.out_counts != nullptr) m.out_counts[u] = n_out;
-    if (m.mid_counts != nullptr) m.mid_counts[u] = n_out;
-    if (m.gthr != nullptr && n_out == m.k && m.k > 0) atomicMax(m.gthr + u, f32_to_key(prev_s));
+  if (tid == 0) m.out_counts[u] = n_out;
+}
+
+// Seed of the shared bound: k-th best score among the entries of the first `n_lists` lists of each user
+// (one workgroup per user).  Any k real candidates give a valid lower bound of the final k-th best.
+template <int NT_MERGE>
+__global__ __launch_bounds__(NT_MERGE) void topk_seed_kernel(MergeArgs m, unsigned* gthr) {
+  const int u = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ float s_ws[NT_MERGE / 64]; __shared__ long long s_wp[NT_MERGE / 64];
+  __shared__ float s_bs; __shared__ long long s_bp; __shared__ int s_total;
+  int my = 0;
+  for (int l = tid; l < m.n_lists; l += NT_MERGE) my += m.list_counts[(long long)l * m.n_users_pad + u];
+  if (tid == 0) s_total = 0;
+  __syncthreads();
+  atomicAdd(&s_total, my);
+  __syncthreads();
+  if (s_total < m.k) return;
+  float prev_s = INFINITY; long long prev_p = -1;
+  for (int r = 0; r < m.k; ++r) {
+    float bs = -INFINITY; long long bp = 0x7fffffffffffffffLL;
+    for (int l = tid; l < m.n_lists; l += NT_MERGE) {
+      const int c = m.list_counts[(long long)l * m.n_users_pad + u];
+      const long long lb = ((long long)l * m.n_users_pad + u) * m.k;
+      for (int e = 0; e < c; ++e) {
+        float sc = m.list_scores[lb + e]; long long p = m.list_pos[lb + e];
+        bool below = (r == 0) || better(prev_s, prev_p, sc, p);
+        if (below && better(sc, p, bs, bp)) { bs = sc; bp = p; }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      float os = __shfl_xor(bs, o, 64); long long op = __shfl_xor(bp, o, 64);
+      if (better(os, op, bs, bp)) { bs = os; bp = op; }
+    }
+    if (lane == 0) { s_ws[wave] = bs; s_wp[wave] = bp; }
+    __syncthreads();
+    if (tid == 0) {
+      float fs = s_ws[0]; long long fp = s_wp[0];
+      for (int w = 1; w < NT_MERGE / 64; ++w)
+        if (better(s_ws[w], s_wp[w], fs, fp)) { fs = s_ws[w]; fp = s_wp[w]; }
+      s_bs = fs; s_bp = fp;
+    }
+    __syncthreads();
+    prev_s = s_bs; prev_p = s_bp;
   }
+  if (tid == 0) atomicMax(gthr + u, f32_to_key(prev_s));
 }
 
 __global__ void fill_u32_kernel(unsigned* p, unsigned v, long long n) {
@@ -375,108 +718,136 @@ __global__ void fill_u32_kernel(unsigned* p, unsigned v, long long n) {
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-struct WsLayout {
-  size_t gthr, list_scores, list_pos, list_counts, compact_scores, compact_pos, mid_scores, mid_pos, mid_counts, total;
-  int n_lists_a, n_lists_b;
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
+constexpr size_t LDS_PER_CU = 160 * 1024;
+constexpr int K_LDS_LISTS = 16;  // lists live in LDS up to this k
+
+inline size_t stream_lds_bytes(int tu, int ns, int k_lds) {
+  return (size_t)ns * (IB * KC + 32 * tu * KC + 128) * sizeof(float) + (size_t)LISTS_PER_WG * 32 * tu * k_lds * 8;
+}
+
+struct Plan {
+  int tu, ub, S, n_tiles, n_users_pad, n_lists, users_per_launch;
+  int ns, wg_per_cu; bool lds_lists;
+  int S_seed; long long blocks_seed;  // phase A (threshold seeding) geometry; 0 = single phase
+  size_t o_gthr, o_scores, o_pos, o_counts, o_cscores, o_cpos, total;
 };
 
-// Grid/workspace plan shared by rt_topk_workspace_bytes and rt_topk_score.
-inline void plan(int ub, int k, long long n_cand, int* grid_a, int* grid_b, long long* split, WsLayout* L) {
-  const int max_wg = 2 * rt_num_cus();  // 2 workgroups / CU (55 KB LDS each at TU=2)
-  const long long n_blocks = (n_cand + IB - 1) / IB;
-  long long ga, gb, sp;
-  if (n_blocks <= (long long)max_wg * 2) {  // small catalog: single phase
-    ga = n_blocks < max_wg ? (n_blocks > 0 ? n_blocks : 1) : max_wg;
-    gb = 0; sp = n_cand;
-  } else {  // seed the shared threshold from a prefix of one block per workgroup, then stream the rest
-    ga = max_wg; sp = (long long)max_wg * IB;
-    gb = max_wg;
-    long long rem_blocks = (n_cand - sp + IB - 1) / IB;
-    if (rem_blocks < gb) gb = rem_blocks;
-  }
-  *grid_a = (int)ga; *grid_b = (int)gb; *split = sp;
-  L->n_lists_a = (int)ga * LISTS_PER_WG; L->n_lists_b = (int)gb * LISTS_PER_WG;
-  const size_t n_lists = (size_t)(L->n_lists_a > L->n_lists_b ? L->n_lists_a : L->n_lists_b);
-  size_t o = 0;
-  L->gthr = o; o = align_up(o + (size_t)ub * 4, 256);
-  L->list_scores = o; o = align_up(o + n_lists * ub * (size_t)k * 4, 256);
-  L->list_pos = o; o = align_up(o + n_lists * ub * (size_t)k * 4, 256);
-  L->list_counts = o; o = align_up(o + n_lists * ub * 4, 256);
-  const size_t cap = n_lists * (size_t)k + (size_t)k;
-  L->compact_scores = o; o = align_up(o + (size_t)ub * cap * 4, 256);
-  L->compact_pos = o; o = align_up(o + (size_t)ub * cap * 8, 256);
-  L->mid_scores = o; o = align_up(o + (size_t)ub * k * 4, 256);
-  L->mid_pos = o; o = align_up(o + (size_t)ub * k * 8, 256);
-  L->mid_counts = o; o = align_up(o + (size_t)ub * 4, 256);
-  L->total = o;
-}
+constexpr int MAX_USERS_PER_LAUNCH = 16384;
 
 inline int pick_tu(int users_per_pass, int n_users) {
   int upp = users_per_pass;
   if (upp <= 0) upp = 64;  // fp32 MFMA vs HBM balance point on gfx950
   if (upp > 128) upp = 128;
   int tu = upp <= 32 ? 1 : (upp <= 64 ? 2 : 4);
-  // do not pay for empty user tiles
-  if (n_users <= 32) tu = 1; else if (n_users <= 64 && tu > 2) tu = 2;
+  if (n_users <= 32) tu = 1; else if (n_users <= 64 && tu > 2) tu = 2;  // no empty user tiles
   return tu;
 }
 
+inline Plan make_plan(int n_users, long long n_cand, int k, int users_per_pass) {
+  Plan P;
+  P.tu = pick_tu(users_per_pass, n_users);
+  P.ub = 32 * P.tu;
+  P.users_per_launch = n_users < MAX_USERS_PER_LAUNCH ? n_users : MAX_USERS_PER_LAUNCH;
+  P.n_tiles = (P.users_per_launch + P.ub - 1) / P.ub;
+  P.n_users_pad = P.n_tiles * P.ub;
+  const long long n_blocks = (n_cand + IB - 1) / IB;
+  // LDS budget decides ring depth, list placement and residency (160 KiB per CU).  The ring must keep
+  // ~HBM latency x per-CU bandwidth (~80-100 KB) in flight, so: ONE workgroup per CU with the deepest ring
+  // that fits (<= 6 stages); lists go to LDS when they still fit next to >= 4 stages.
+  P.lds_lists = (k <= K_LDS_LISTS) && env_int("RT_TOPK_LDS_LISTS", 1) != 0;
+  if (P.lds_lists && stream_lds_bytes(P.tu, 4, k) > LDS_PER_CU) P.lds_lists = false;
+  const int kl = P.lds_lists ? k : 0;
+  P.wg_per_cu = 1;
+  P.ns = 3;
+  for (int ns = 6; ns >= 3; --ns)
+    if (stream_lds_bytes(P.tu, ns, kl) <= LDS_PER_CU) { P.ns = ns; break; }
+  const int ns_env = env_int("RT_TOPK_STAGES", 0);
+  if (ns_env >= 3 && ns_env <= 6 && stream_lds_bytes(P.tu, ns_env, kl) <= LDS_PER_CU) P.ns = ns_env;
+  const int wg_env = env_int("RT_TOPK_WG_PER_CU", 0);
+  if (wg_env > 0 && wg_env * stream_lds_bytes(P.tu, P.ns, kl) <= LDS_PER_CU) P.wg_per_cu = wg_env;
+  long long target = (long long)P.wg_per_cu * rt_num_cus();
+  long long S = (target + P.n_tiles - 1) / P.n_tiles;
+  if (S > n_blocks) S = n_blocks;
+  if (S < 1) S = 1;
+  P.S = (int)S;
+  P.n_lists = P.S * LISTS_PER_WG;
+  // Threshold seeding (phase A): every workgroup first scores 2 blocks of a catalog prefix; the k-th best of
+  // that prefix (topk_seed_kernel) becomes the shared bound, so that in phase B a list sees ~1 candidate
+  // instead of ~k*ln(blocks): the slow path (and its pipeline drain) becomes rare at wave level.
+  P.S_seed = 0; P.blocks_seed = 0;
+  {
+    const int ss = P.S < 64 ? P.S : 64;  // few workgroups x 8 blocks: short lists for the seed kernel
+    const long long bs = (long long)ss * 8;
+    if (env_int("RT_TOPK_SEED", 1) != 0 && n_blocks >= 32 * bs && P.n_tiles <= 8) { P.S_seed = ss; P.blocks_seed = bs; }
+  }
+  size_t o = 0;
+  P.o_gthr = o; o = align_up(o + (size_t)P.n_users_pad * 4, 256);
+  const size_t ent = (size_t)P.n_lists * P.n_users_pad * (size_t)k;
+  P.o_scores = o; o = align_up(o + ent * 4, 256);
+  P.o_pos = o; o = align_up(o + ent * 4, 256);
+  P.o_counts = o; o = align_up(o + (size_t)P.n_lists * P.n_users_pad * 4, 256);
+  const size_t cap = (size_t)P.n_lists * k;
+  P.o_cscores = o; o = align_up(o + (size_t)P.users_per_launch * cap * 4, 256);
+  P.o_cpos = o; o = align_up(o + (size_t)P.users_per_launch * cap * 4, 256);
+  P.total = o;
+  return P;
+}
+
+template <int TU, int NS, bool WL, bool LL>
+int launch_stream_impl(const TopkArgs& a, dim3 grid, hipStream_t stream) {
+  constexpr int UB = 32 * TU;
+  const size_t lds = stream_lds_bytes(TU, NS, LL ? a.k : 0);
+  static size_t attr_lds = 0;
+  if (lds > 64 * 1024 && lds > attr_lds) {
+    RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_stream_kernel<TU, NS, WL, LL>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_lds = lds;
+  }
+  topk_stream_kernel<TU, NS, WL, LL><<<grid, NTHREADS, lds, stream>>>(a);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+template <int TU, int NS>
+int launch_stream(const TopkArgs& a, dim3 grid, bool lds_lists, hipStream_t stream) {
+  if (a.whitelist) {
+    return lds_lists ? launch_stream_impl<TU, NS, true, true>(a, grid, stream)
+                     : launch_stream_impl<TU, NS, true, false>(a, grid, stream);
+  }
+  return lds_lists ? launch_stream_impl<TU, NS, false, true>(a, grid, stream)
+                   : launch_stream_impl<TU, NS, false, false>(a, grid, stream);
+}
+
 template <int TU>
-int launch_batch(TopkArgs a, MergeArgs m, int grid_a, int grid_b, long long split, long long n_cand,
-                 const WsLayout& L, char* ws, hipStream_t stream) {
+int launch_stream_ns(int ns, const TopkArgs& a, dim3 grid, bool ll, hipStream_t stream) {
+  switch (ns) {
+    case 3: return launch_stream<TU, 3>(a, grid, ll, stream);
+    case 4: return launch_stream<TU, 4>(a, grid, ll, stream);
+    case 5: return launch_stream<TU, 5>(a, grid, ll, stream);
+    default: return launch_stream<TU, 6>(a, grid, ll, stream);
+  }
+}
+int launch_stream_any(int tu, int ns, const TopkArgs& a, dim3 grid, bool ll, hipStream_t stream) {
+  if (tu == 1) return launch_stream_ns<1>(ns, a, grid, ll, stream);
+  if (tu == 2) return launch_stream_ns<2>(ns, a, grid, ll, stream);
+  return launch_stream_ns<4>(ns, a, grid, ll, stream);
+}
+
+template <int TU>
+int launch_staged(const TopkArgs& a, dim3 grid, hipStream_t stream) {
   constexpr int UB = 32 * TU;
   const size_t lds = (size_t)(2 * IB * LDK + 2 * UB * LDK) * sizeof(float);
-  if (lds > 64 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_partial_kernel<TU>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return RT_ERR_LAUNCH;
-      attr_set = true;
-    }
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_staged_kernel<TU>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
   }
-  unsigned* gthr = reinterpret_cast<unsigned*>(ws + L.gthr);
-  // gthr := key(-inf)
-  fill_u32_kernel<<<1, 128, 0, stream>>>(gthr, 0x007FFFFFu, UB);
-  a.ub = UB; a.gthr = gthr; a.list_base = 0;
-  a.list_scores = reinterpret_cast<float*>(ws + L.list_scores);
-  a.list_pos = reinterpret_cast<int*>(ws + L.list_pos);
-  a.list_counts = reinterpret_cast<int*>(ws + L.list_counts);
-  m.list_scores = a.list_scores; m.list_pos = a.list_pos; m.list_counts = a.list_counts;
-  m.ub = UB;
-  m.compact_scores = reinterpret_cast<float*>(ws + L.compact_scores);
-  m.compact_pos = reinterpret_cast<long long*>(ws + L.compact_pos);
-  m.compact_cap = (long long)((L.n_lists_a > L.n_lists_b ? L.n_lists_a : L.n_lists_b)) * a.k + a.k;
-
-  // phase A: [0, split)
-  a.item_begin = 0; a.item_end = split;
-  topk_partial_kernel<TU><<<grid_a, NTHREADS, lds, stream>>>(a);
-  RT_CHECK_LAUNCH();
-  MergeArgs ma = m;
-  ma.n_lists = L.n_lists_a; ma.item_begin = 0;
-  ma.extra_scores = nullptr; ma.extra_pos = nullptr; ma.extra_counts = nullptr;
-  if (grid_b == 0) {
-    ma.mid_scores = nullptr; ma.mid_pos = nullptr; ma.mid_counts = nullptr; ma.gthr = nullptr;
-    topk_merge_kernel<<<a.n_users, NTHREADS, 0, stream>>>(ma);
-    RT_CHECK_LAUNCH();
-    return RT_OK;
-  }
-  ma.out_ids = nullptr; ma.out_scores = nullptr; ma.out_counts = nullptr;
-  ma.mid_scores = reinterpret_cast<float*>(ws + L.mid_scores);
-  ma.mid_pos = reinterpret_cast<long long*>(ws + L.mid_pos);
-  ma.mid_counts = reinterpret_cast<int*>(ws + L.mid_counts);
-  ma.gthr = gthr;
-  topk_merge_kernel<<<a.n_users, NTHREADS, 0, stream>>>(ma);
-  RT_CHECK_LAUNCH();
-  // phase B: [split, n_cand) with the seeded threshold
-  a.item_begin = split; a.item_end = n_cand;
-  topk_partial_kernel<TU><<<grid_b, NTHREADS, lds, stream>>>(a);
-  RT_CHECK_LAUNCH();
-  MergeArgs mb = m;
-  mb.n_lists = L.n_lists_b; mb.item_begin = split;
-  mb.extra_scores = ma.mid_scores; mb.extra_pos = ma.mid_pos; mb.extra_counts = ma.mid_counts;
-  mb.mid_scores = nullptr; mb.mid_pos = nullptr; mb.mid_counts = nullptr; mb.gthr = nullptr;
-  topk_merge_kernel<<<a.n_users, NTHREADS, 0, stream>>>(mb);
+  topk_staged_kernel<TU><<<grid, NTHREADS, lds, stream>>>(a);
   RT_CHECK_LAUNCH();
   return RT_OK;
 }
@@ -487,19 +858,17 @@ extern "C" {
 
 size_t rt_topk_workspace_bytes(int32_t n_users, int64_t n_candidates, int32_t k, int32_t users_per_pass) {
   if (n_users <= 0 || n_candidates <= 0 || k <= 0) return 256;
-  int tu = pick_tu(users_per_pass, n_users);
-  int ga, gb; long long split; WsLayout L;
   long long kk = k < n_candidates ? k : n_candidates;
-  plan(32 * tu, (int)kk, n_candidates, &ga, &gb, &split, &L);
-  return L.total;
+  return make_plan(n_users, n_candidates, (int)kk, users_per_pass).total;
 }
 
 int rt_topk_score(const float* users, int64_t user_stride, const int64_t* user_rows, int32_t n_users,
                   const float* items, int64_t item_stride, const int64_t* whitelist, int64_t n_candidates,
-                  int32_t d, int32_t distance, int32_t k,
+                  int64_t candidate_id_offset, int32_t d, int32_t distance, int32_t k,
                   const int64_t* filt_indptr, const int32_t* filt_indices,
                   int64_t* out_ids, float* out_scores, int32_t* out_counts,
                   void* workspace, size_t workspace_bytes, int32_t users_per_pass, hipStream_t stream) {
+  (void)hipGetLastError();  // do not inherit a stale error from the caller's earlier HIP calls
   if (n_users < 0 || n_candidates < 0 || d <= 0 || (d & 3) != 0 || k <= 0) return RT_ERR_INVALID_ARG;
   if (distance < DIST_DOT || distance > DIST_EUCLID) return RT_ERR_INVALID_ARG;
   if ((user_stride & 3) != 0 || (item_stride & 3) != 0) return RT_ERR_INVALID_ARG;
@@ -510,15 +879,15 @@ int rt_topk_score(const float* users, int64_t user_stride, const int64_t* user_r
   if (n_candidates == 0) {
     return hipMemsetAsync(out_counts, 0, sizeof(int32_t) * (size_t)n_users, stream) == hipSuccess ? RT_OK : RT_ERR_LAUNCH;
   }
-  const int tu = pick_tu(users_per_pass, n_users);
-  const int ub = 32 * tu;
-  int ga, gb; long long split; WsLayout L;
-  plan(ub, k, n_candidates, &ga, &gb, &split, &L);
-  if (workspace == nullptr || workspace_bytes < L.total) return RT_ERR_WORKSPACE;
+  const Plan P = make_plan(n_users, n_candidates, k, users_per_pass);
+  if (workspace == nullptr || workspace_bytes < P.total) return RT_ERR_WORKSPACE;
   char* ws = reinterpret_cast<char*>(workspace);
+  const int impl = env_int("RT_TOPK_IMPL", 2);
+  const bool stream_ok = (impl == 2) && (d % KC == 0);
 
-  for (int u0 = 0; u0 < n_users; u0 += ub) {
-    const int nb = (n_users - u0) < ub ? (n_users - u0) : ub;
+  for (int u0 = 0; u0 < n_users; u0 += P.users_per_launch) {
+    const int nb = (n_users - u0) < P.users_per_launch ? (n_users - u0) : P.users_per_launch;
+    const int n_tiles = (nb + P.ub - 1) / P.ub;
     TopkArgs a{};
     a.users = user_rows ? users : users + (long long)u0 * user_stride;
     a.user_stride = user_stride;
@@ -526,19 +895,57 @@ int rt_topk_score(const float* users, int64_t user_stride, const int64_t* user_r
     a.n_users = nb;
     a.items = items; a.item_stride = item_stride;
     a.whitelist = reinterpret_cast<const long long*>(whitelist);
+    a.n_cand = n_candidates; a.id_offset = whitelist ? 0 : candidate_id_offset;
     a.d = d; a.distance = distance; a.k = k;
     a.filt_indptr = filt_indptr ? reinterpret_cast<const long long*>(filt_indptr) + u0 : nullptr;
     a.filt_indices = filt_indices;
+    a.list_scores = reinterpret_cast<float*>(ws + P.o_scores);
+    a.list_pos = reinterpret_cast<int*>(ws + P.o_pos);
+    a.list_counts = reinterpret_cast<int*>(ws + P.o_counts);
+    a.n_users_pad = P.n_users_pad;
+    a.gthr = reinterpret_cast<unsigned*>(ws + P.o_gthr);
+    a.rotate = env_int("RT_TOPK_ROTATE", 1);
+    a.debug = env_int("RT_TOPK_DEBUG", 0);
+
+    fill_u32_kernel<<<(P.n_users_pad + 255) / 256, 256, 0, stream>>>(a.gthr, 0x007FFFFFu /* key(-inf) */,
+                                                                     P.n_users_pad);
+    RT_CHECK_LAUNCH();
+    dim3 grid(P.S, n_tiles);
+    const long long n_blocks = (n_candidates + IB - 1) / IB;
     MergeArgs m{};
-    m.k = k; m.n_users = nb; m.whitelist = a.whitelist; m.distance = distance;
+    m.list_scores = a.list_scores; m.list_pos = a.list_pos; m.list_counts = a.list_counts;
+    m.n_lists = P.n_lists; m.n_users_pad = P.n_users_pad; m.k = k; m.n_users = nb;
+    auto run_phase = [&](long long b0, long long b1, int n_seg, int resume) -> int {
+      a.blk_begin = b0; a.blk_end = b1; a.n_seg = n_seg; a.resume = resume;
+      if (stream_ok) return launch_stream_any(P.tu, P.ns, a, grid, P.lds_lists, stream);
+      if (P.tu == 1) return launch_staged<1>(a, grid, stream);
+      if (P.tu == 2) return launch_staged<2>(a, grid, stream);
+      return launch_staged<4>(a, grid, stream);
+    };
+    int rc;
+    if (P.blocks_seed > 0) {
+      rc = run_phase(0, P.blocks_seed, P.S_seed, 0);  // workgroups sx >= S_seed get no blocks, publish empty lists
+      if (rc != RT_OK) return rc;
+      MergeArgs ms = m; ms.n_lists = P.S_seed * LISTS_PER_WG;
+      if (ms.n_lists >= 256) topk_seed_kernel<1024><<<nb, 1024, 0, stream>>>(ms, a.gthr);
+      else topk_seed_kernel<256><<<nb, 256, 0, stream>>>(ms, a.gthr);
+      RT_CHECK_LAUNCH();
+      rc = run_phase(P.blocks_seed, n_blocks, P.S, 1);
+    } else {
+      rc = run_phase(0, n_blocks, P.S, 0);
+    }
+    if (rc != RT_OK) return rc;
+
+    m.compact_scores = reinterpret_cast<float*>(ws + P.o_cscores);
+    m.compact_pos = reinterpret_cast<int*>(ws + P.o_cpos);
+    m.compact_cap = (long long)P.n_lists * k;
+    m.whitelist = a.whitelist; m.id_offset = a.id_offset; m.distance = distance;
     m.out_ids = reinterpret_cast<long long*>(out_ids) + (long long)u0 * k;
     m.out_scores = out_scores + (long long)u0 * k;
     m.out_counts = out_counts + u0;
-    int rc;
-    if (tu == 1) rc = launch_batch<1>(a, m, ga, gb, split, n_candidates, L, ws, stream);
-    else if (tu == 2) rc = launch_batch<2>(a, m, ga, gb, split, n_candidates, L, ws, stream);
-    else rc = launch_batch<4>(a, m, ga, gb, split, n_candidates, L, ws, stream);
-    if (rc != RT_OK) return rc;
+    if (m.n_lists >= 256) topk_merge_kernel<1024><<<nb, 1024, 0, stream>>>(m);
+    else topk_merge_kernel<256><<<nb, 256, 0, stream>>>(m);
+    RT_CHECK_LAUNCH();
   }
   return RT_OK;
 }

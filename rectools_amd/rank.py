@@ -134,6 +134,16 @@ class HipRanker:
         )
         n_subj, kk = ids_t.shape
         counts = counts_t.cpu().numpy()
+        if filter_pairs_csr is not None and self.distance == Distance.EUCLIDEAN and kk > 0:
+            # Reference quirk kept for drop-in parity: the filter writes -inf, but EUCLIDEAN takes the SMALLEST
+            # k, so filtered pairs win the top-k and are then dropped (rank_torch.py:138-152,167-171): a user
+            # with f filtered candidates gets only the best k - f unfiltered items.
+            csr = sparse.csr_matrix(filter_pairs_csr) if not isinstance(filter_pairs_csr, DeviceCSR) else None
+            if csr is None:
+                raise NotImplementedError("EUCLIDEAN ranking with a DeviceCSR filter is not supported")
+            cols = np.arange(csr.shape[1]) if sorted_object_whitelist is None else np.asarray(sorted_object_whitelist)
+            n_filtered = np.asarray((csr[:, cols] != 0).sum(axis=1)).reshape(-1)
+            counts = np.minimum(counts, np.maximum(kk - n_filtered, 0))
         ids = ids_t.cpu().numpy()
         scores = scores_t.cpu().numpy()
         valid = np.arange(kk)[None, :] < counts[:, None]
@@ -166,10 +176,13 @@ class HipRanker:
         dev = self.device
         n_objects = self.objects_factors.shape[0]
         whitelist_t = None
+        id_offset = 0
         if sorted_object_whitelist is not None:
             wl = np.asarray(sorted_object_whitelist, dtype=np.int64)
             n_cand = len(wl)
-            if not (n_cand == n_objects and n_cand > 0 and wl[0] == 0 and wl[-1] == n_objects - 1):
+            if n_cand > 0 and int(wl[-1]) - int(wl[0]) == n_cand - 1 and (n_cand < 3 or bool(np.all(np.diff(wl) == 1))):
+                id_offset = int(wl[0])  # contiguous range (the recommend() default): no indirection needed
+            elif n_cand > 0:
                 whitelist_t = torch.from_numpy(wl).to(dev)
         else:
             n_cand = n_objects
@@ -202,7 +215,8 @@ class HipRanker:
         with torch.cuda.device(dev):
             status = self._lib.rt_topk_score(
                 _lib.ptr(self.subjects_factors), self.subjects_factors.stride(0), _lib.ptr(rows_t), n_subj,
-                _lib.ptr(self.objects_factors), self.objects_factors.stride(0), _lib.ptr(whitelist_t), n_cand,
+                self.objects_factors.data_ptr() + 4 * id_offset * self.objects_factors.stride(0),
+                self.objects_factors.stride(0), _lib.ptr(whitelist_t), n_cand, id_offset,
                 self.objects_factors.shape[1], _DIST_CODE[self.distance], kk,
                 _lib.ptr(indptr_t), _lib.ptr(indices_t),
                 _lib.ptr(ids_t), _lib.ptr(scores_t), _lib.ptr(counts_t),

@@ -1,0 +1,248 @@
+"""Golden vectors for the transformer fit() hot path, produced by the UNMODIFIED reference modules
+(`TransformerTorchBackbone`, `SASRecTransformerLayers`, `PreLNTransformerLayers`, `LiGRLayers`, `STULayers`,
+`DistanceSimilarityModule`, `TransformerLightningModule` losses, `torch.optim.Adam`).
+
+Called from tests/golden/make_golden.py (which installs the import shims first).  For every variant we store
+the config, the full state_dict (reference parameter names), one training batch, and the
+reference's logits / loss / per-parameter gradients / parameters after one Adam step / last-slot session
+embeddings in eval mode.  dropout_rate = 0 everywhere (dropout streams cannot match).
+"""
+from __future__ import annotations
+
+import json
+import os
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _variants():
+    base = dict(V=50, B=4, L=8, d=16, H=2, n_blocks=2, N=3, loss="softmax", dist="dot", logits_t=1.0,
+                causal=True, keypad=False, layers="sasrec", n_extra=1, gbce_t=0.2, lr=1e-3, use_scale=False,
+                layer_kwargs={}, weights="ones", seed=32)
+    out = {}
+
+    def add(name, **kw):
+        c = dict(base)
+        c.update(kw)
+        out[name] = c
+
+    add("sasrec_softmax_dot")
+    add("sasrec_softmax_cos", dist="cosine", weights="rand")
+    add("sasrec_bce_dot", loss="BCE", weights="rand")
+    add("sasrec_gbce_dot", loss="gBCE")
+    add("sasrec_gbce_cos", loss="gBCE", dist="cosine")
+    add("sasrec_sampled_dot", loss="sampled_softmax", N=5)
+    add("sasrec_sampled_cos_t", loss="sampled_softmax", dist="cosine", logits_t=0.05)
+    add("sasrec_keypad_causal", keypad=True)
+    add("sasrec_mid", V=300, B=5, L=40, d=64, H=4, loss="sampled_softmax", N=7, store_logits=True)
+    add("bert4rec_softmax", layers="preln", causal=False, keypad=True, n_extra=2)
+    add("bert4rec_bce", layers="preln", causal=False, keypad=True, n_extra=2, loss="BCE")
+    add("ligr_swiglu_sampled", layers="ligr", loss="sampled_softmax",
+        layer_kwargs=dict(ff_factors_multiplier=4, ff_activation="swiglu", bias_in_ff=False))
+    add("ligr_gelu_softmax", layers="ligr", layer_kwargs=dict(ff_factors_multiplier=2, ff_activation="gelu",
+                                                               bias_in_ff=True))
+    add("ligr_relu_keypad", layers="ligr", keypad=True, layer_kwargs=dict(ff_factors_multiplier=4,
+                                                                          ff_activation="relu", bias_in_ff=False))
+    for rt, rp in ((True, True), (True, False), (False, True), (False, False)):
+        add(f"hstu_time{int(rt)}_pos{int(rp)}", layers="stu", dist="cosine", loss="sampled_softmax", N=4,
+            use_scale=True, logits_t=0.05, rel_time=rt, rel_pos=rp)
+    add("hstu_softmax_dot", layers="stu", dist="dot", loss="softmax", use_scale=True, rel_time=True, rel_pos=True)
+    return out
+
+
+def build_reference(cfg):
+    """Instantiate the reference torch modules directly (no Dataset needed)."""
+    from rectools.models.nn.item_net import IdEmbeddingsItemNet, SumOfEmbeddingsConstructor
+    from rectools.models.nn.transformers.hstu import STULayers
+    from rectools.models.nn.transformers.lightning import TransformerLightningModule
+    from rectools.models.nn.transformers.ligr import LiGRLayers
+    from rectools.models.nn.transformers.net_blocks import LearnableInversePositionalEncoding, PreLNTransformerLayers
+    from rectools.models.nn.transformers.sasrec import SASRecTransformerLayers
+    from rectools.models.nn.transformers.similarity import DistanceSimilarityModule
+    from rectools.models.nn.transformers.torch_backbone import TransformerTorchBackbone
+
+    n_tokens = cfg["V"] + cfg["n_extra"]
+    item_model = SumOfEmbeddingsConstructor(n_tokens, [IdEmbeddingsItemNet(cfg["d"], n_tokens, 0.0)])
+    pos = LearnableInversePositionalEncoding(True, cfg["L"], cfg["d"], use_scale_factor=cfg["use_scale"])
+    kind = cfg["layers"]
+    if kind == "sasrec":
+        layers = SASRecTransformerLayers(n_blocks=cfg["n_blocks"], n_factors=cfg["d"], n_heads=cfg["H"], dropout_rate=0.0)
+    elif kind == "preln":
+        layers = PreLNTransformerLayers(n_blocks=cfg["n_blocks"], n_factors=cfg["d"], n_heads=cfg["H"], dropout_rate=0.0)
+    elif kind == "ligr":
+        layers = LiGRLayers(n_blocks=cfg["n_blocks"], n_factors=cfg["d"], n_heads=cfg["H"], dropout_rate=0.0,
+                            **cfg["layer_kwargs"])
+    elif kind == "stu":
+        hd = cfg["d"] // cfg["H"]
+        layers = STULayers(n_blocks=cfg["n_blocks"], n_factors=cfg["d"], n_heads=cfg["H"], linear_hidden_dim=hd,
+                           attention_dim=hd, session_max_len=cfg["L"], relative_time_attention=cfg["rel_time"],
+                           relative_pos_attention=cfg["rel_pos"], attn_dropout_rate=0.0, dropout_rate=0.0)
+    else:
+        raise ValueError(kind)
+    sim = DistanceSimilarityModule(distance=cfg["dist"])
+    backbone = TransformerTorchBackbone(
+        n_heads=cfg["H"], dropout_rate=0.0, item_model=item_model, pos_encoding_layer=pos,
+        transformer_layers=layers, similarity_module=sim, use_causal_attn=cfg["causal"],
+        use_key_padding_mask=cfg["keypad"],
+    )
+    extra = ["PAD"] if cfg["n_extra"] == 1 else ["PAD", "MASK"]
+    dp = types.SimpleNamespace(n_negatives=cfg["N"], item_extra_tokens=extra)
+    lm = TransformerLightningModule(
+        torch_model=backbone, model_config={}, dataset_schema={}, item_external_ids=[], item_extra_tokens=extra,
+        data_preparator=dp, lr=cfg["lr"], gbce_t=cfg["gbce_t"], loss=cfg["loss"], logits_t=cfg["logits_t"],
+    )
+    return lm
+
+
+def make_batch(cfg, gen: torch.Generator):
+    B, L, V, ne = cfg["B"], cfg["L"], cfg["V"], cfg["n_extra"]
+    x = torch.zeros(B, L, dtype=torch.int64)
+    y = torch.zeros(B, L, dtype=torch.int64)
+    lens = torch.randint(1, L + 1, (B,), generator=gen)
+    lens[0] = L  # one full row
+    if B > 1:
+        lens[1] = 1  # one nearly-empty row
+    for b in range(B):
+        n = int(lens[b])
+        seq = torch.randint(ne, V + ne, (n + 1,), generator=gen)
+        x[b, L - n:] = seq[:-1]
+        y[b, L - n:] = seq[1:]
+    if cfg["layers"] == "preln":
+        # BERT4Rec-style batch: some inputs replaced by MASK (id 1), targets only at masked slots
+        x2, y2 = x.clone(), torch.zeros_like(y)
+        for b in range(B):
+            n = int(lens[b])
+            full = torch.randint(ne, V + ne, (n,), generator=gen)
+            m = torch.rand(n, generator=gen) < 0.4
+            m[-1] = True
+            inp = full.clone()
+            inp[m] = 1
+            x2[b] = 0
+            x2[b, L - n:] = inp
+            y2[b, L - n:] = torch.where(m, full, torch.zeros_like(full))
+        x, y = x2, y2
+    if cfg["weights"] == "ones":
+        yw = (y != 0).float()
+    else:
+        yw = (y != 0).float() * (0.5 + torch.rand(B, L, generator=gen))
+    batch = {"x": x, "y": y, "yw": yw}
+    if cfg["loss"] != "softmax":
+        batch["negatives"] = torch.randint(ne, V + ne, (B, L, cfg["N"]), generator=gen)
+    if cfg["layers"] == "stu":
+        gaps = torch.randint(1, 10_000_000, (B, L + 1), generator=gen)
+        gaps[:, 2] = 0  # a zero gap (bucket of max(1,|0|) -> 0)
+        ts = torch.cumsum(gaps, dim=1) + 1_500_000_000
+        # left-fill padded slots with the first real timestamp (sasrec.py:109-116)
+        for b in range(B):
+            n = int(lens[b])
+            ts[b, : L - n] = ts[b, L - n]
+        batch["unix_ts"] = ts
+    return batch
+
+
+def make_transformer() -> None:
+    from oracle import ref_shims
+
+    for name, cfg in _variants().items():
+        ref_shims.seed_all(cfg["seed"])
+        lm = build_reference(cfg)
+        lm._xavier_normal_init()
+        # make LayerNorm / bias parameters non-trivial so their gradients and use are exercised
+        g = torch.Generator().manual_seed(cfg["seed"] + 1)
+        with torch.no_grad():
+            for n, p in lm.torch_model.named_parameters():
+                if p.dim() == 1:
+                    p.add_(0.1 * torch.randn(p.shape, generator=g))
+        batch = make_batch(cfg, g)
+        state0 = {k: v.detach().clone() for k, v in lm.torch_model.state_dict().items()}
+
+        lm.train()
+        b_in = {k: v.clone() for k, v in batch.items()}
+        logits = lm.get_batch_logits(b_in).detach().clone()
+        opt = lm.configure_optimizers()
+        opt.zero_grad()
+        loss = lm.training_step({k: v.clone() for k, v in batch.items()}, 0)
+        loss.backward()
+        grads = {n: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p))
+                 for n, p in lm.torch_model.named_parameters()}
+        opt.step()
+        state1 = {k: v.detach().clone() for k, v in lm.torch_model.state_dict().items()}
+        # second step on the same batch (exercises Adam moments beyond the first update)
+        opt.zero_grad()
+        loss2 = lm.training_step({k: v.clone() for k, v in batch.items()}, 1)
+        loss2.backward()
+        opt.step()
+        state2 = {k: v.detach().clone() for k, v in lm.torch_model.state_dict().items()}
+
+        # eval-mode session embeddings with the ORIGINAL weights (recommend path, lightning.py:392-396)
+        lm.torch_model.load_state_dict(state0)
+        lm.torch_model.eval()
+        with torch.no_grad():
+            item_embs = lm.torch_model.item_model.get_all_embeddings()
+            enc = lm.torch_model.encode_sessions({k: v.clone() for k, v in batch.items()}, item_embs)
+
+        out = {"config": np.array(json.dumps(cfg))}
+        for k, v in state0.items():
+            out["p0/" + k] = v.numpy()
+        for k, v in grads.items():
+            out["g/" + k] = v.numpy()
+        for k, v in state1.items():
+            out["p1/" + k] = v.numpy()
+        for k, v in state2.items():
+            out["p2/" + k] = v.numpy()
+        for k, v in batch.items():
+            out["b/" + k] = v.numpy()
+        if logits.numel() <= 20000 or cfg.get("store_logits"):
+            out["logits"] = logits.numpy()
+        out["loss"] = np.array(loss.item(), dtype=np.float64)
+        out["loss2"] = np.array(loss2.item(), dtype=np.float64)
+        out["enc"] = enc.numpy()
+        np.savez_compressed(os.path.join(HERE, f"transformer_{name}.npz"), **out)
+        print(f"transformer {name}: loss={loss.item():.6f} loss2={loss2.item():.6f} params={len(state0)}")
+
+
+def make_collate() -> None:
+    """Collate known-answers: the reference's SASRec / BERT4Rec collate functions on seeded inputs."""
+    from rectools.models.nn.transformers.bert4rec import BERT4RecDataPreparator
+    from rectools.models.nn.transformers.negative_sampler import CatalogUniformSampler
+    from rectools.models.nn.transformers.sasrec import SASRecDataPreparator
+
+    from oracle import ref_shims
+
+    out = {}
+    sessions = [
+        ([3, 5, 2, 7, 9, 4, 6], [1.0, 1.0, 2.0, 1.0, 1.0, 0.5, 1.0], [10, 20, 30, 40, 50, 60, 70]),
+        ([8, 2], [1.0, 3.0], [100, 200]),
+        ([4, 4, 6, 5], [1.0, 1.0, 1.0, 1.0], [5, 6, 7, 8]),
+    ]
+    L = 5
+    for n_neg, tag in ((None, "sasrec_noneg"), (2, "sasrec_neg2")):
+        for ts in (False, True):
+            ref_shims.seed_all(32)
+            dp = SASRecDataPreparator(
+                session_max_len=L, batch_size=4, dataloader_num_workers=0, n_negatives=n_neg,
+                negative_sampler=CatalogUniformSampler(n_negatives=n_neg) if n_neg else None, add_unix_ts=ts,
+            )
+            dp.item_id_map = types.SimpleNamespace(size=12)
+            sfx = "_ts" if ts else ""
+            # train sessions carry L+1 items at most (train_session_max_len_addition = 1, sasrec.py:84)
+            batch = [(s[-(L + 1):], w[-(L + 1):], {"unix_ts": t[-(L + 1):]}) for s, w, t in sessions]
+            b = dp._collate_fn_train(batch)
+            for k, v in b.items():
+                out[f"{tag}{sfx}/train/{k}"] = v.numpy()
+            # recommend sessions: history (+ dummy target item when timestamps are used, sasrec.py:154-163)
+            if ts:
+                rb = [(s + [0], w + [0.0], {"unix_ts": t + [t[-1] + 5]}) for s, w, t in sessions]
+            else:
+                rb = [(s, w, {}) for s, w, t in sessions]
+            br = dp._collate_fn_recommend(rb)
+            for k, v in br.items():
+                out[f"{tag}{sfx}/recommend/{k}"] = v.numpy()
+    out["sessions"] = np.array(json.dumps(sessions))
+    out["L"] = np.array(L)
+    np.savez_compressed(os.path.join(HERE, "collate_golden.npz"), **out)
+    print("collate: ok")

@@ -137,5 +137,11 @@ def test_large_catalog_properties():
     ib, sb, _, _ = ranker.rank_device(np.arange(n_users), k=k, sorted_object_whitelist=np.arange(half, n_items))
     cat_s, cat_i = torch.cat([sa, sb], 1), torch.cat([ia, ib], 1)
     top = torch.topk(cat_s, k, dim=1)
-    torch.testing.assert_close(top.values, scores, rtol=0, atol=0)
-    assert bool((cat_i.gather(1, top.indices) == ids).all())
+    # different launch geometries sum the 256 products in a different (rotated) chunk order: equal to rounding
+    torch.testing.assert_close(top.values, scores, rtol=2e-5, atol=2e-4)
+    same = cat_i.gather(1, top.indices) == ids
+    near_tie = (scores[:, 1:] - scores[:, :-1]).abs() < 5e-4
+    near = torch.zeros_like(same)
+    near[:, 1:] |= near_tie
+    near[:, :-1] |= near_tie
+    assert bool((same | near).all())
