@@ -223,8 +223,10 @@ def encode_sessions(cfg: dict, p: Params, batch: Batch) -> torch.Tensor:
 
 
 def _l2norm(e: torch.Tensor) -> torch.Tensor:
-    n = torch.sqrt((e * e).sum(dim=-1, keepdim=True))
-    return e / torch.clamp(n, min=1e-8)  # similarity.py:97-100
+    # similarity.py:97-100.  torch.norm (not sqrt(sum(e*e))): its backward is 0 for an all-zero row, and HSTU
+    # feeds exactly-zero session rows (padded slots are multiplied by the timeline mask) through here.
+    n = torch.norm(e, p=2, dim=-1, keepdim=True)
+    return e / torch.max(n, torch.tensor([1e-8]))
 
 
 def batch_logits(cfg: dict, p: Params, batch: Batch) -> torch.Tensor:

@@ -59,3 +59,27 @@ def load_ranker_golden():
             c["filt"] = sparse.csr_matrix((z[p + "f_data"], z[p + "f_indices"], z[p + "f_indptr"]), shape=shape)
         cases.append(c)
     return cases
+
+
+def list_transformer_golden():
+    import glob
+
+    return sorted(os.path.basename(p)[len("transformer_"):-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "transformer_*.npz")))
+
+
+def load_transformer_golden(name):
+    """-> (cfg dict, params0, grads, params1, params2, batch, extras) as torch CPU tensors."""
+    import json
+
+    import torch
+
+    z = np.load(os.path.join(GOLDEN_DIR, f"transformer_{name}.npz"), allow_pickle=False)
+    cfg = json.loads(str(z["config"]))
+
+    def grab(prefix):
+        return {k[len(prefix):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(prefix)}
+
+    extras = {"loss": float(z["loss"]), "loss2": float(z["loss2"]), "enc": torch.from_numpy(z["enc"])}
+    if "logits" in z.files:
+        extras["logits"] = torch.from_numpy(z["logits"])
+    return cfg, grab("p0/"), grab("g/"), grab("p1/"), grab("p2/"), grab("b/"), extras
