@@ -73,6 +73,129 @@ int rt_topk_score(const float* users, int64_t user_stride, const int64_t* user_r
                   int64_t* out_ids, float* out_scores, int32_t* out_counts,
                   void* workspace, size_t workspace_bytes, int32_t users_per_pass, rt_stream_t stream);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * K7  dense fp32 GEMM (f32-input MFMA):  C[M,N] = A . B^T (+ bias[n]) (+ R[m,n]) (relu)
+ * Replaces nn.Linear / MultiheadAttention in_proj & out_proj / `normed_x @ uvqk_proj` / `session_embs @ item_embs.T`
+ * (net_blocks.py:63-64,108-109; sasrec.py:191; ligr.py:56,99-105; hstu.py:258,293; similarity.py:85) and their
+ * autograd products.  a_kc / b_kc = 1: operand is [rows, K] row-major with row stride ld ("k-contiguous");
+ * = 0: element (r, k) lives at r + k*ld (a transposed view).  split_k > 1 splits the reduction over the grid
+ * and atomically adds into C, which the caller must have zero-filled (R / relu then not allowed).
+ * ------------------------------------------------------------------------------------------------ */
+int rt_gemm(const float* A, int64_t lda, int32_t a_kc, const float* B, int64_t ldb, int32_t b_kc,
+            float* C, int64_t ldc, const float* bias, const float* R, int64_t ldr,
+            int32_t M, int32_t N, int32_t K, int32_t relu, int32_t split_k, rt_stream_t stream);
+/* out[n] += sum_m X[m,n]  (bias gradients; caller zero-fills out) */
+int rt_colsum(const float* X, int64_t ld, int32_t M, int32_t N, float* out, rt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K2  embedding gather + inverse positional encoding + dropout
+ * out[m,:] = dropout(table[ids[m]] * scale + pos[L-1-(m mod L)])     (pos may be NULL)
+ * Replaces `item_embs[sessions]` (torch_backbone.py:245), LearnableInversePositionalEncoding.forward
+ * (net_blocks.py:388-399) and emb_dropout (torch_backbone.py:247); the full-table copy of
+ * get_all_embeddings (item_net.py:361-368) is not needed.  Backward: gtable rows are accumulated with
+ * atomics, row 0 (padding_idx) excluded (item_net.py:260-264); gpos accumulated.  Dropout masks are
+ * regenerated from (seed, stream_id).
+ * ------------------------------------------------------------------------------------------------ */
+int rt_embed_fwd(const int64_t* ids, const float* table, const float* pos, float scale, int32_t M, int32_t L,
+                 int32_t d, float p, uint64_t seed, uint64_t stream_id, float* out, rt_stream_t stream);
+int rt_embed_bwd(const int64_t* ids, const float* gout, float scale, int32_t M, int32_t L, int32_t d, float p,
+                 uint64_t seed, uint64_t stream_id, float* gtable, float* gpos, rt_stream_t stream);
+
+/* K3  LayerNorm over rows of [M,d] (nn.LayerNorm call sites: sasrec.py:221,226,303; net_blocks.py:247,257;
+ * ligr.py:90,102; hstu.py:256,291).  mean/rstd [M] are saved for the backward; dw/db are accumulated. */
+int rt_layernorm_fwd(const float* x, const float* w, const float* b, float eps, int32_t M, int32_t d, float* y,
+                     float* mean, float* rstd, rt_stream_t stream);
+int rt_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rstd, int32_t M,
+                     int32_t d, float* dx, float* dw, float* db, rt_stream_t stream);
+
+/* element-wise streams (n = number of floats, multiple of 4).  kind: 0 none, 1 relu, 2 gelu(erf), 3 silu, 4 sigmoid.
+ * y = dropout(act(z)) and its backward (net_blocks.py:63-64; hstu.py:257; dropouts at sasrec.py:228, net_blocks.py:258-260) */
+int rt_act_dropout_fwd(const float* z, int32_t kind, float p, uint64_t seed, uint64_t stream_id, int64_t n, float* y,
+                       rt_stream_t stream);
+int rt_act_dropout_bwd(const float* dy, const float* z, int32_t kind, float p, uint64_t seed, uint64_t stream_id,
+                       int64_t n, float* dz, rt_stream_t stream);
+/* y = dropout(silu(a) * b)   (SwigluFeedForward, net_blocks.py:108) */
+int rt_swiglu_fwd(const float* a, const float* b, float p, uint64_t seed, uint64_t stream_id, int64_t n, float* y,
+                  rt_stream_t stream);
+int rt_swiglu_bwd(const float* dy, const float* a, const float* b, float p, uint64_t seed, uint64_t stream_id, int64_t n,
+                  float* da, float* db, rt_stream_t stream);
+/* y = x + sigmoid(gz) * dropout(a)   (LiGR gated residual, ligr.py:99-100,104-105); backward gives dgz, da (dx = dy) */
+int rt_gate_fwd(const float* x, const float* gz, const float* a, float p, uint64_t seed, uint64_t stream_id, int64_t n,
+                float* y, rt_stream_t stream);
+int rt_gate_bwd(const float* dy, const float* gz, const float* a, float p, uint64_t seed, uint64_t stream_id, int64_t n,
+                float* dgz, float* da, rt_stream_t stream);
+/* y = a * alpha + b (b may be NULL) */
+int rt_axpy(const float* a, float alpha, const float* b, int64_t n, float* y, rt_stream_t stream);
+/* y = a * b * (ids[row] != 0); b, ids optional  (`seqs *= timeline_mask`, sasrec.py:300; hstu.py:256,291) */
+int rt_mul_mask(const float* a, const float* b, const int64_t* ids, int32_t d, int64_t n, float* y, rt_stream_t stream);
+
+/* K13 one dense Adam step over flat fp32 buffers (torch.optim.Adam semantics, lightning.py:214-218);
+ * grad_scale multiplies g first (1/world_size after a sum all-reduce). */
+int rt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, float lr, float beta1, float beta2,
+                 float eps, float grad_scale, rt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K4  softmax multi-head attention, forward / backward (torch.nn.MultiheadAttention as called at sasrec.py:222-224,
+ * net_blocks.py:248-255, ligr.py:91-98).  q/k/v/o: [B*L, ld] fp32, head h at columns [h*hd, (h+1)*hd); hd % 8 == 0,
+ * hd <= 128.  Masks are derived from ids [B,L] (0 = PAD): causal (torch_backbone.py:249-252), keypad (:254), both =
+ * merged mask with unmasked diagonal (:172-218).  Dropout (p_drop, seed) acts on the probabilities.
+ * lse: [B,H,L] saved log-sum-exp; delta: [B,H,L] workspace.
+ * ------------------------------------------------------------------------------------------------ */
+int rt_mha_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+               const int64_t* ids, int32_t B, int32_t H, int32_t L, int32_t hd, int32_t causal, int32_t keypad,
+               float p_drop, uint64_t seed, float* o, int64_t ldo, float* lse, rt_stream_t stream);
+int rt_mha_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+               const float* o, int64_t ldo, const float* dout, int64_t lddo, const float* lse, const int64_t* ids,
+               int32_t B, int32_t H, int32_t L, int32_t hd, int32_t causal, int32_t keypad, float p_drop, uint64_t seed,
+               float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv, float* delta,
+               rt_stream_t stream);
+
+/* K5/K6  HSTU pointwise attention with in-kernel relative time/position bias (hstu.py:84-128, 270-288).
+ * ts [B,L+1] int64 (NULL: no time bias); time_w [129]; time_thr [129] = smallest |dt| of each bucket, computed on
+ * the host with the reference's float32 log(|dt|)/0.301 truncation; pos_w [2L-1] (NULL: no position bias).
+ * Backward accumulates d_time_w [129] / d_pos_w [2L-1] (caller zero-fills). */
+int rt_hstu_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                     const int64_t* ids, const int64_t* ts, const float* time_w, const int64_t* time_thr,
+                     const float* pos_w, int32_t B, int32_t H, int32_t L, int32_t hd, float* o, int64_t ldo,
+                     rt_stream_t stream);
+int rt_hstu_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                     const float* dout, int64_t lddo, const int64_t* ids, const int64_t* ts, const float* time_w,
+                     const int64_t* time_thr, const float* pos_w, int32_t B, int32_t H, int32_t L, int32_t hd,
+                     float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv, float* d_time_w,
+                     float* d_pos_w, rt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K8/K9  negative-sampled losses without the [B,L,1+N,d] gather (similarity.py:88-95 + lightning.py:164-212).
+ * loss: 0 BCE, 1 gBCE, 2 sampled_softmax.  sess [M,d]; table [V,d]; y [M] (0 = position ignored); neg [M,N]; w [M].
+ * Forward writes logits [M,1+N] (already divided by logits_t) and the weighted per-position loss.
+ * Backward overwrites d_sess [M,d] and accumulates into d_table [V,d]; norm = rt_loss_reduce's out+1.
+ * ------------------------------------------------------------------------------------------------ */
+int rt_sampled_loss_fwd(const float* sess, int64_t ld_sess, const float* table, const int64_t* y, const int64_t* neg,
+                        const float* w, int32_t M, int32_t N, int32_t d, int32_t loss, int32_t cosine, float logits_t,
+                        double gbce_beta, float* logits, float* loss_pos, rt_stream_t stream);
+int rt_sampled_loss_bwd(const float* sess, int64_t ld_sess, const float* table, const int64_t* y, const int64_t* neg,
+                        const float* w, int32_t M, int32_t N, int32_t d, int32_t loss, int32_t cosine, float logits_t,
+                        double gbce_beta, float* logits, const float* norm, float gscale, float* d_sess, int64_t ld_dsess,
+                        float* d_table, rt_stream_t stream);
+/* out[0] = sum(loss_pos)/normaliser, out[1] = normaliser; mode 0: count(loss_pos > 0) (lightning.py:159-161),
+ * mode 1: count(y != 0) (lightning.py:197-198) */
+int rt_loss_reduce(const float* loss_pos, const int64_t* y, int32_t M, int32_t mode, float* out, rt_stream_t stream);
+/* K10 full-catalog softmax rows (lightning.py:145-162) on the logits of the R active positions produced by rt_gemm:
+ * grad = 0: loss_pos[r] = (lse - z_y) * w, lse[r];  grad = 1: logits := (softmax - onehot) * w * gscale / (norm * t) */
+int rt_softmax_ce_rows(float* logits, int64_t ld, int32_t R, int32_t V, const int64_t* y_act, const float* w_act,
+                       float logits_t, int32_t grad, const float* norm, float gscale, float* loss_pos, float* lse,
+                       rt_stream_t stream);
+/* K11 L2 row normalisation with max(||x||, 1e-8) (similarity.py:97-100) and its backward */
+int rt_l2norm_fwd(const float* x, int64_t ldx, int32_t M, int32_t d, float* y, int64_t ldy, float* nrm, rt_stream_t stream);
+int rt_l2norm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, int32_t M, int32_t d, int32_t accumulate,
+                  float* dx, int64_t lddx, rt_stream_t stream);
+/* dst[r] = src[idx[r]] ; dst[idx[r]] = src[r] (idx unique) */
+int rt_gather_rows(const float* src, int64_t ld_src, const int64_t* idx, int32_t R, int32_t d, float* dst, int64_t ld_dst,
+                   rt_stream_t stream);
+int rt_scatter_rows(const float* src, int64_t ld_src, const int64_t* idx, int32_t R, int32_t d, float* dst, int64_t ld_dst,
+                    rt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,11 +26,34 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_device_cu_count": (c_i32, []),
     "rt_last_error": (ctypes.c_char_p, []),
     "rt_topk_workspace_bytes": (c_sz, [c_i32, c_i64, c_i32, c_i32]),
-    "rt_topk_score": (
-        c_i32,
-        [c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
-         c_vp, c_sz, c_i32, c_vp],
-    ),
+    "rt_topk_score": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_i32, c_vp]),
+    "rt_gemm": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "rt_colsum": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
+    "rt_embed_fwd": (c_i32, [c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_f32, c_u64, c_u64, c_vp, c_vp]),
+    "rt_embed_bwd": (c_i32, [c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_f32, c_u64, c_u64, c_vp, c_vp, c_vp]),
+    "rt_layernorm_fwd": (c_i32, [c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "rt_layernorm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "rt_act_dropout_fwd": (c_i32, [c_vp, c_i32, c_f32, c_u64, c_u64, c_i64, c_vp, c_vp]),
+    "rt_act_dropout_bwd": (c_i32, [c_vp, c_vp, c_i32, c_f32, c_u64, c_u64, c_i64, c_vp, c_vp]),
+    "rt_swiglu_fwd": (c_i32, [c_vp, c_vp, c_f32, c_u64, c_u64, c_i64, c_vp, c_vp]),
+    "rt_swiglu_bwd": (c_i32, [c_vp, c_vp, c_vp, c_f32, c_u64, c_u64, c_i64, c_vp, c_vp, c_vp]),
+    "rt_gate_fwd": (c_i32, [c_vp, c_vp, c_vp, c_f32, c_u64, c_u64, c_i64, c_vp, c_vp]),
+    "rt_gate_bwd": (c_i32, [c_vp, c_vp, c_vp, c_f32, c_u64, c_u64, c_i64, c_vp, c_vp, c_vp]),
+    "rt_axpy": (c_i32, [c_vp, c_f32, c_vp, c_i64, c_vp, c_vp]),
+    "rt_mul_mask": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_vp]),
+    "rt_adam_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp]),
+    "rt_mha_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_vp, c_i64, c_vp, c_vp]),
+    "rt_mha_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    "rt_hstu_attn_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
+    "rt_hstu_attn_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "rt_sampled_loss_fwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f64, c_vp, c_vp, c_vp]),
+    "rt_sampled_loss_bwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f64, c_vp, c_vp, c_f32, c_vp, c_i64, c_vp, c_vp]),
+    "rt_loss_reduce": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
+    "rt_softmax_ce_rows": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_f32, c_i32, c_vp, c_f32, c_vp, c_vp, c_vp]),
+    "rt_l2norm_fwd": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp]),
+    "rt_l2norm_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
+    "rt_gather_rows": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp]),
+    "rt_scatter_rows": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp]),
 }
 
 _lib: tp.Optional[ctypes.CDLL] = None

@@ -1,0 +1,707 @@
+// K4 / K5 / K6 — fused attention for the sequential-recommender blocks, fp32 on v_mfma_f32_32x32x2_f32.
+//
+//  MODE_SOFTMAX  torch.nn.MultiheadAttention as the reference calls it (sasrec.py:222-224, net_blocks.py:248-255,
+//                ligr.py:91-98): softmax(q k^T / sqrt(hd) + mask) with the causal `~tril` mask
+//                (torch_backbone.py:249-252), the key-padding mask `sessions == 0` (:254) or both merged with an
+//                unmasked diagonal (:172-218), dropout on the probabilities, times v.
+//  MODE_HSTU     pointwise attention of the STU layer (hstu.py:270-288): silu(q k^T + rab) / L * causal * m_i m_j,
+//                with the relative time/position bias rab (hstu.py:84-128) computed in-kernel from the
+//                timestamps and the two small weight tables (K6): no [B, L+1, L+1] bucket tensor, no [B,H,L,L] scores.
+//
+// No mask tensor and no score matrix ever exists in HBM: masks come from the item ids and indices, scores live
+// in MFMA accumulators.  Q/K/V/O are addressed as [B*L, ld] row-major with the head at column h*hd, so packed
+// in_proj outputs are consumed in place.
+//
+// Work split: forward and dQ kernels give each wave 32 queries (one MFMA tile) and loop over 32-key tiles
+// staged in LDS; the dK/dV kernel gives each wave 32 keys and loops over query tiles.  "Swapped" products
+// (keys or queries on the MFMA row index so that a lane owns ONE query / key column) keep every row
+// reduction lane-local plus a single cross-half shuffle, and let the probability / dS accumulator registers be
+// fed straight back as the B operand of the second product (reduction index permuted consistently, as in K7/K12).
+#include "rt_common.h"
+
+namespace {
+
+enum { MODE_SOFTMAX = 0, MODE_HSTU = 1 };
+constexpr int AT = 256;        // threads per workgroup (4 waves)
+constexpr int TK = 32;         // keys / queries per tile
+constexpr int NBUCK = 129;     // hstu time buckets (num_buckets + 1)
+
+struct AttnArgs {
+  const float* q; const float* k; const float* v; long long ldq, ldk, ldv;
+  float* o; long long ldo;                 // forward output
+  const float* dout; long long lddo;       // backward input
+  float* dq; float* dk; float* dv; long long lddq, lddk, lddv;
+  float* lse;                              // [B,H,L] (softmax mode)
+  const float* delta;                      // [B,H,L] rowsum(dO * O) (softmax backward)
+  const long long* ids;                    // [B,L] item ids (0 = PAD)
+  int B, H, L, hd;
+  int causal, keypad;
+  float scale;                             // 1/sqrt(hd) (softmax) ; unused for hstu
+  float p_drop; unsigned long long seed;
+  // hstu relative bias
+  const long long* ts;                     // [B, L+1] unix timestamps (null: no time bias)
+  const float* time_w;                     // [129]
+  const long long* time_thr;               // [129] smallest |dt| that falls in bucket >= b (host-computed)
+  const float* pos_w;                      // [2L-1] (null: no position bias)
+  float* d_time_w; float* d_pos_w;         // backward accumulators
+};
+
+__device__ __forceinline__ int row_of(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// Is (query qq, key kk) masked out?  Mirrors torch_backbone.py:249-257 and _merge_masks (:172-218).
+__device__ __forceinline__ bool masked(const AttnArgs& a, int qq, int kk, bool key_is_pad) {
+  bool m = false;
+  if (a.causal) m = kk > qq;
+  if (a.keypad) {
+    m = m || key_is_pad;
+    if (a.causal && kk == qq) m = false;  // merged mask: diagonal forced to 0
+  }
+  return m;
+}
+
+__device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
+__device__ __forceinline__ float silu_df(float z) { float s = 1.f / (1.f + __expf(-z)); return s * (1.f + z * (1.f - s)); }
+
+// hstu bucket of |dt| via the host-computed thresholds (exactly the reference's float32 log/0.301 truncation)
+__device__ __forceinline__ int time_bucket(const long long* thr, long long dt) {
+  long long x = dt < 0 ? -dt : dt;
+  int lo = 0, hi = NBUCK - 1;  // largest b with thr[b] <= x
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (thr[mid] <= x) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+// load the B-operand fragments (rows of Q / dO / K / V for `row`), hd/8 float4 per lane, zero past `L`
+template <int HDV>
+__device__ __forceinline__ void load_row_frags(const float* base, long long ld, int row, int n_rows, int hd, int half,
+                                               f32x4 (&f)[HDV]) {
+#pragma unroll
+  for (int s = 0; s < HDV; ++s) {
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const int c = 8 * s + 4 * half;
+    f[s] = (row < n_rows && c < hd) ? *reinterpret_cast<const f32x4*>(base + (long long)row * ld + c) : z;
+  }
+}
+
+// stage a [32 rows][hd] tile (rows row0..row0+31 of `base`) into LDS with row stride lds_ld (= hd + 4)
+__device__ __forceinline__ void stage_tile(const float* base, long long ld, int row0, int n_rows, int hd, int lds_ld,
+                                           float* dst, int tid) {
+  const int per_row = hd >> 2;
+  for (int i = tid; i < TK * per_row; i += AT) {
+    const int r = i / per_row, c = (i % per_row) * 4;
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 v = (row0 + r < n_rows) ? *reinterpret_cast<const f32x4*>(base + (long long)(row0 + r) * ld + c) : z;
+    *reinterpret_cast<f32x4*>(dst + r * lds_ld + c) = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// forward:  grid = (ceil(L/128), B*H); wave w of a workgroup owns queries q0 = (blockIdx.x*4 + w)*32 ..
+// ---------------------------------------------------------------------------------------------------
+template <int MODE, int HD>   // HD = head dim padded up to a multiple of 32 (32, 64, 128)
+__global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs a) {
+  constexpr int HDV = HD / 8;   // float4 fragments per row (upper bound)
+  constexpr int NT = HD / 32;   // output dd tiles
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lds_ld = a.hd + 4;
+  float* Ks = smem;                       // [32][hd+4]
+  float* Vs = Ks + TK * lds_ld;           // [32][hd+4]
+  float* aux = Vs + TK * lds_ld;          // [32] key pad flags (as float) | hstu tables
+  float* s_tw = aux + TK;                 // [129]
+  float* s_pw = s_tw + NBUCK + 3;         // [2L-1]
+  long long* s_thr = reinterpret_cast<long long*>(s_pw + ((2 * a.L + 3) & ~3));  // [129]
+  long long* s_ts = s_thr + NBUCK + 1;    // [L+1]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
+  const int q0 = (blockIdx.x * 4 + wave) * TK;
+  const int qq = q0 + col;
+  const long long rowbase = (long long)b * a.L;
+  const float* qb = a.q + rowbase * a.ldq + h * a.hd;
+  const float* kb = a.k + rowbase * a.ldk + h * a.hd;
+  const float* vb = a.v + rowbase * a.ldv + h * a.hd;
+  const long long* idb = a.ids + rowbase;
+
+  if (MODE == MODE_HSTU) {
+    if (a.time_w) for (int i = tid; i < NBUCK; i += AT) { s_tw[i] = a.time_w[i]; s_thr[i] = a.time_thr[i]; }
+    if (a.pos_w) for (int i = tid; i < 2 * a.L - 1; i += AT) s_pw[i] = a.pos_w[i];
+    if (a.ts) for (int i = tid; i < a.L + 1; i += AT) s_ts[i] = a.ts[(long long)b * (a.L + 1) + i];
+  }
+
+  f32x4 qf[HDV];
+  load_row_frags<HDV>(qb, a.ldq, qq, a.L, a.hd, half, qf);
+  const bool q_is_pad = (qq < a.L) ? (idb[qq] == 0) : true;
+  long long t_q1 = 0;
+
+  f32x16 oacc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // key range of this workgroup: causal => keys <= last query of the workgroup
+  const int wg_q_last = min(a.L, (blockIdx.x * 4 + 4) * TK) - 1;
+  const int n_kt = a.causal ? (wg_q_last / TK + 1) : ((a.L + TK - 1) / TK);
+  const int my_last_kt = a.causal ? min(n_kt - 1, (q0 + TK - 1) / TK) : n_kt - 1;
+  const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+
+  __syncthreads();
+  if (MODE == MODE_HSTU && a.ts && qq < a.L) t_q1 = s_ts[qq + 1];
+
+  for (int kt = 0; kt < n_kt; ++kt) {
+    __syncthreads();
+    stage_tile(kb, a.ldk, kt * TK, a.L, a.hd, lds_ld, Ks, tid);
+    stage_tile(vb, a.ldv, kt * TK, a.L, a.hd, lds_ld, Vs, tid);
+    if (tid < TK) { const int kk = kt * TK + tid; aux[tid] = (kk < a.L && idb[kk] != 0) ? 0.f : 1.f; }
+    __syncthreads();
+    if (q0 >= a.L || kt > my_last_kt) continue;  // this wave has nothing to do for the tile (barriers above are uniform)
+
+    // S^T tile: rows = keys (A operand from LDS), cols = queries (B operand = Q fragments)
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < HDV; ++s) {
+      if (8 * s < a.hd) {
+        f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + col * lds_ld + 8 * s + 4 * half);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t], qf[s][t], sacc, 0, 0, 0);
+      }
+    }
+
+    float p[16];
+    if (MODE == MODE_SOFTMAX) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kk = kt * TK + row_of(r, half);
+        const bool msk = (kk >= a.L) || masked(a, qq, kk, aux[row_of(r, half)] != 0.f);
+        const float sv = msk ? -INFINITY : sacc[r] * a.scale;
+        p[r] = sv;
+        mx = fmaxf(mx, sv);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = (m_new == -INFINITY) ? 1.f : __expf(m_run - m_new);
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        p[r] = (p[r] == -INFINITY) ? 0.f : __expf(p[r] - m_new);
+        ps += p[r];
+      }
+      ps += __shfl_xor(ps, 32, 64);
+      l_run = l_run * alpha + ps;
+      m_run = m_new;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+      if (a.p_drop > 0.f) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          // keys row_of(4*r4 .. 4*r4+3, half) are 4 consecutive keys starting at 8*r4 + 4*half
+          const unsigned long long e4 = ((unsigned long long)qq * ((a.L + 3) & ~3) + kt * TK + 8 * r4 + 4 * half) >> 2;
+          uint4 rnd = philox4x32(a.seed, (unsigned long long)bh, e4 | (1ull << 40));
+          p[4 * r4 + 0] = (u32_to_unit(rnd.x) >= a.p_drop) ? p[4 * r4 + 0] * inv_keep : 0.f;
+          p[4 * r4 + 1] = (u32_to_unit(rnd.y) >= a.p_drop) ? p[4 * r4 + 1] * inv_keep : 0.f;
+          p[4 * r4 + 2] = (u32_to_unit(rnd.z) >= a.p_drop) ? p[4 * r4 + 2] * inv_keep : 0.f;
+          p[4 * r4 + 3] = (u32_to_unit(rnd.w) >= a.p_drop) ? p[4 * r4 + 3] * inv_keep : 0.f;
+        }
+      }
+    } else {
+      const float inv_l = 1.0f / (float)a.L;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kk = kt * TK + row_of(r, half);
+        const bool dead = (kk >= a.L) || (qq >= a.L) || (kk > qq) || q_is_pad || (aux[row_of(r, half)] != 0.f);
+        float bias = 0.f;
+        if (!dead) {
+          if (a.time_w) bias += s_tw[time_bucket(s_thr, t_q1 - s_ts[kk])];
+          if (a.pos_w) bias += s_pw[(a.L - 1) + kk - qq];
+        }
+        p[r] = dead ? 0.f : silu_f(sacc[r] + bias) * inv_l;
+      }
+    }
+
+    // O^T tile(s): rows = dd (A operand: V from LDS), cols = queries (B operand = p registers)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int krow = row_of(t, half);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int dd = nt * 32 + col;
+        const float vv = (dd < a.hd) ? Vs[krow * lds_ld + dd] : 0.f;
+        oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, p[t], oacc[nt], 0, 0, 0);
+      }
+    }
+  }
+
+  if (q0 >= a.L || qq >= a.L) return;
+  float inv = 1.f;
+  if (MODE == MODE_SOFTMAX) {
+    inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    if (half == 0) a.lse[((long long)bh) * a.L + qq] = (l_run > 0.f) ? m_run + __logf(l_run) : -INFINITY;
+  }
+  float* ob = a.o + (rowbase + qq) * a.ldo + h * a.hd;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dd = nt * 32 + row_of(r, half);
+      if (dd < a.hd) ob[dd] = oacc[nt][r] * inv;
+    }
+}
+
+// delta[b,h,q] = sum_dd dO[q][dd] * O[q][dd]
+__global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ dout, long long lddo,
+                                                         const float* __restrict__ o, long long ldo, int B, int H, int L,
+                                                         int hd, float* __restrict__ delta) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over B*H*L
+  if (idx >= (long long)B * H * L) return;
+  const int qq = idx % L; const int h = (idx / L) % H; const int b = idx / ((long long)L * H);
+  const float* g = dout + ((long long)b * L + qq) * lddo + h * hd;
+  const float* oo = o + ((long long)b * L + qq) * ldo + h * hd;
+  float s = 0.f;
+  for (int c = 0; c < hd; c += 4) {
+    f32x4 x = *reinterpret_cast<const f32x4*>(g + c), y = *reinterpret_cast<const f32x4*>(oo + c);
+    s += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+  }
+  delta[idx] = s;
+}
+
+// probability / derivative helpers shared by the two backward kernels ---------------------------------
+// returns P (softmax: normalised, undropped; hstu: silu(.)/L * masks) and writes g = dS given dP (already dropped)
+template <int MODE>
+__device__ __forceinline__ void tile_p_ds(const AttnArgs& a, float s_raw, float dp, float lse_q, float delta_q, bool dead,
+                                          float bias, float drop_scale, float& p_used, float& ds) {
+  if (MODE == MODE_SOFTMAX) {
+    const float pn = dead ? 0.f : __expf(s_raw * a.scale - lse_q);
+    p_used = pn * drop_scale;                       // what multiplied V in the forward pass
+    ds = pn * (dp * drop_scale - delta_q) * a.scale; // d/d(raw q.k)
+  } else {
+    const float inv_l = 1.0f / (float)a.L;
+    const float z = s_raw + bias;
+    p_used = dead ? 0.f : silu_f(z) * inv_l;
+    ds = dead ? 0.f : dp * inv_l * silu_df(z);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward, dQ:  same decomposition as the forward kernel.
+// ---------------------------------------------------------------------------------------------------
+template <int MODE, int HD>
+__global__ __launch_bounds__(AT) void attn_bwd_dq_kernel(AttnArgs a) {
+  constexpr int HDV = HD / 8;
+  constexpr int NT = HD / 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lds_ld = a.hd + 4;
+  float* Ks = smem;
+  float* Vs = Ks + TK * lds_ld;
+  float* aux = Vs + TK * lds_ld;
+  float* s_tw = aux + TK;
+  float* s_pw = s_tw + NBUCK + 3;
+  long long* s_thr = reinterpret_cast<long long*>(s_pw + ((2 * a.L + 3) & ~3));
+  long long* s_ts = s_thr + NBUCK + 1;
+  float* s_dtw = reinterpret_cast<float*>(s_ts + a.L + 1);   // [132] bias-gradient accumulators of this workgroup
+  float* s_dpw = s_dtw + NBUCK + 3;                          // [2L-1]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
+  const int q0 = (blockIdx.x * 4 + wave) * TK;
+  const int qq = q0 + col;
+  const long long rowbase = (long long)b * a.L;
+  const float* qb = a.q + rowbase * a.ldq + h * a.hd;
+  const float* kb = a.k + rowbase * a.ldk + h * a.hd;
+  const float* vb = a.v + rowbase * a.ldv + h * a.hd;
+  const float* gb = a.dout + rowbase * a.lddo + h * a.hd;
+  const long long* idb = a.ids + rowbase;
+
+  if (MODE == MODE_HSTU) {
+    if (a.time_w) for (int i = tid; i < NBUCK; i += AT) { s_tw[i] = a.time_w[i]; s_thr[i] = a.time_thr[i]; }
+    if (a.pos_w) for (int i = tid; i < 2 * a.L - 1; i += AT) s_pw[i] = a.pos_w[i];
+    if (a.ts) for (int i = tid; i < a.L + 1; i += AT) s_ts[i] = a.ts[(long long)b * (a.L + 1) + i];
+    for (int i = tid; i < NBUCK + 3 + 2 * a.L; i += AT) s_dtw[i] = 0.f;
+  }
+  f32x4 qf[HDV], gf[HDV];
+  load_row_frags<HDV>(qb, a.ldq, qq, a.L, a.hd, half, qf);
+  load_row_frags<HDV>(gb, a.lddo, qq, a.L, a.hd, half, gf);
+  const bool q_is_pad = (qq < a.L) ? (idb[qq] == 0) : true;
+  float lse_q = 0.f, delta_q = 0.f;
+  if (MODE == MODE_SOFTMAX && qq < a.L) { lse_q = a.lse[(long long)bh * a.L + qq]; delta_q = a.delta[(long long)bh * a.L + qq]; }
+  long long t_q1 = 0;
+
+  f32x16 dqacc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqacc[t][r] = 0.f;
+
+  const int wg_q_last = min(a.L, (blockIdx.x * 4 + 4) * TK) - 1;
+  const int n_kt = a.causal ? (wg_q_last / TK + 1) : ((a.L + TK - 1) / TK);
+  const int my_last_kt = a.causal ? min(n_kt - 1, (q0 + TK - 1) / TK) : n_kt - 1;
+  const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+  __syncthreads();
+  if (MODE == MODE_HSTU && a.ts && qq < a.L) t_q1 = s_ts[qq + 1];
+
+  for (int kt = 0; kt < n_kt; ++kt) {
+    __syncthreads();
+    stage_tile(kb, a.ldk, kt * TK, a.L, a.hd, lds_ld, Ks, tid);
+    stage_tile(vb, a.ldv, kt * TK, a.L, a.hd, lds_ld, Vs, tid);
+    if (tid < TK) { const int kk = kt * TK + tid; aux[tid] = (kk < a.L && idb[kk] != 0) ? 0.f : 1.f; }
+    __syncthreads();
+    if (q0 >= a.L || kt > my_last_kt) continue;
+
+    f32x16 sacc, pacc;   // S^T and dP^T tiles (rows = keys, cols = queries)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < HDV; ++s) {
+      if (8 * s < a.hd) {
+        f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + col * lds_ld + 8 * s + 4 * half);
+        f32x4 vf = *reinterpret_cast<const f32x4*>(Vs + col * lds_ld + 8 * s + 4 * half);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t], qf[s][t], sacc, 0, 0, 0);
+          pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[t], gf[s][t], pacc, 0, 0, 0);
+        }
+      }
+    }
+    float ds[16];
+    float dtw_bucket_dummy = 0.f; (void)dtw_bucket_dummy;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      float dsc[4] = {1.f, 1.f, 1.f, 1.f};
+      if (MODE == MODE_SOFTMAX && a.p_drop > 0.f) {
+        const unsigned long long e4 = ((unsigned long long)qq * ((a.L + 3) & ~3) + kt * TK + 8 * r4 + 4 * half) >> 2;
+        uint4 rnd = philox4x32(a.seed, (unsigned long long)bh, e4 | (1ull << 40));
+        dsc[0] = (u32_to_unit(rnd.x) >= a.p_drop) ? inv_keep : 0.f;
+        dsc[1] = (u32_to_unit(rnd.y) >= a.p_drop) ? inv_keep : 0.f;
+        dsc[2] = (u32_to_unit(rnd.z) >= a.p_drop) ? inv_keep : 0.f;
+        dsc[3] = (u32_to_unit(rnd.w) >= a.p_drop) ? inv_keep : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 4 * r4 + j;
+        const int kk = kt * TK + row_of(r, half);
+        const bool kpad = aux[row_of(r, half)] != 0.f;
+        bool dead; float bias = 0.f;
+        if (MODE == MODE_SOFTMAX) {
+          dead = (kk >= a.L) || (qq >= a.L) || masked(a, qq, kk, kpad);
+        } else {
+          dead = (kk >= a.L) || (qq >= a.L) || (kk > qq) || q_is_pad || kpad;
+          if (!dead) {
+            if (a.time_w) bias += s_tw[time_bucket(s_thr, t_q1 - s_ts[kk])];
+            if (a.pos_w) bias += s_pw[(a.L - 1) + kk - qq];
+          }
+        }
+        float pu;
+        tile_p_ds<MODE>(a, sacc[r], pacc[r], lse_q, delta_q, dead, bias, dsc[j], pu, ds[r]);
+        if (MODE == MODE_HSTU && !dead && half >= 0) {
+          // relative-bias gradients: rab is shared by the heads, so every head adds its dS (hstu.py:276)
+          if (a.d_time_w) atomicAdd(s_dtw + time_bucket(s_thr, t_q1 - s_ts[kk]), ds[r]);
+          if (a.d_pos_w) atomicAdd(s_dpw + (a.L - 1) + kk - qq, ds[r]);
+        }
+      }
+    }
+    // dQ^T += K^T dS^T : rows = dd (A operand: K from LDS), cols = queries (B operand = dS registers)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int krow = row_of(t, half);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int dd = nt * 32 + col;
+        const float kv = (dd < a.hd) ? Ks[krow * lds_ld + dd] : 0.f;
+        dqacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, ds[t], dqacc[nt], 0, 0, 0);
+      }
+    }
+  }
+  if (MODE == MODE_HSTU) {
+    __syncthreads();
+    if (a.d_time_w) for (int i = tid; i < NBUCK; i += AT) if (s_dtw[i] != 0.f) atomicAdd(a.d_time_w + i, s_dtw[i]);
+    if (a.d_pos_w) for (int i = tid; i < 2 * a.L - 1; i += AT) if (s_dpw[i] != 0.f) atomicAdd(a.d_pos_w + i, s_dpw[i]);
+  }
+  if (q0 >= a.L || qq >= a.L) return;
+  float* ob = a.dq + (rowbase + qq) * a.lddq + h * a.hd;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dd = nt * 32 + row_of(r, half);
+      if (dd < a.hd) ob[dd] = dqacc[nt][r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward, dK / dV:  wave owns 32 keys, loops over query tiles (rows = queries, cols = keys).
+// ---------------------------------------------------------------------------------------------------
+template <int MODE, int HD>
+__global__ __launch_bounds__(AT) void attn_bwd_dkv_kernel(AttnArgs a) {
+  constexpr int HDV = HD / 8;
+  constexpr int NT = HD / 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lds_ld = a.hd + 4;
+  float* Qs = smem;                        // [32][hd+4]  queries of the current tile
+  float* Gs = Qs + TK * lds_ld;            // [32][hd+4]  dO of the current tile
+  float* aux = Gs + TK * lds_ld;           // [32] lse | [32] delta | [32] q pad flag
+  float* s_tw = aux + 3 * TK;
+  float* s_pw = s_tw + NBUCK + 3;
+  long long* s_thr = reinterpret_cast<long long*>(s_pw + ((2 * a.L + 3) & ~3));
+  long long* s_ts = s_thr + NBUCK + 1;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
+  const int k0 = (blockIdx.x * 4 + wave) * TK;
+  const int kk = k0 + col;                 // this lane's key column
+  const long long rowbase = (long long)b * a.L;
+  const float* qb = a.q + rowbase * a.ldq + h * a.hd;
+  const float* kb = a.k + rowbase * a.ldk + h * a.hd;
+  const float* vb = a.v + rowbase * a.ldv + h * a.hd;
+  const float* gb = a.dout + rowbase * a.lddo + h * a.hd;
+  const long long* idb = a.ids + rowbase;
+
+  if (MODE == MODE_HSTU) {
+    if (a.time_w) for (int i = tid; i < NBUCK; i += AT) { s_tw[i] = a.time_w[i]; s_thr[i] = a.time_thr[i]; }
+    if (a.pos_w) for (int i = tid; i < 2 * a.L - 1; i += AT) s_pw[i] = a.pos_w[i];
+    if (a.ts) for (int i = tid; i < a.L + 1; i += AT) s_ts[i] = a.ts[(long long)b * (a.L + 1) + i];
+  }
+  f32x4 kf[HDV], vf[HDV];
+  load_row_frags<HDV>(kb, a.ldk, kk, a.L, a.hd, half, kf);
+  load_row_frags<HDV>(vb, a.ldv, kk, a.L, a.hd, half, vf);
+  const bool k_is_pad = (kk < a.L) ? (idb[kk] == 0) : true;
+
+  f32x16 dkacc[NT], dvacc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dkacc[t][r] = 0.f; dvacc[t][r] = 0.f; }
+
+  const int n_qt = (a.L + TK - 1) / TK;
+  const int first_qt = a.causal ? (blockIdx.x * 4 * TK) / TK : 0;   // queries >= first key of the workgroup
+  const int my_first_qt = a.causal ? k0 / TK : 0;
+  const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+  __syncthreads();
+  long long t_k = 0;
+  if (MODE == MODE_HSTU && a.ts && kk < a.L) t_k = s_ts[kk];
+
+  for (int qt = first_qt; qt < n_qt; ++qt) {
+    __syncthreads();
+    stage_tile(qb, a.ldq, qt * TK, a.L, a.hd, lds_ld, Qs, tid);
+    stage_tile(gb, a.lddo, qt * TK, a.L, a.hd, lds_ld, Gs, tid);
+    if (tid < TK) {
+      const int q = qt * TK + tid;
+      aux[tid] = (MODE == MODE_SOFTMAX && q < a.L) ? a.lse[(long long)bh * a.L + q] : 0.f;
+      aux[TK + tid] = (MODE == MODE_SOFTMAX && q < a.L) ? a.delta[(long long)bh * a.L + q] : 0.f;
+      aux[2 * TK + tid] = (q < a.L && idb[q] != 0) ? 0.f : 1.f;
+    }
+    __syncthreads();
+    if (k0 >= a.L || qt < my_first_qt) continue;
+
+    f32x16 sacc, pacc;   // S and dP tiles: rows = queries (A operand from LDS), cols = keys (B = K / V fragments)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < HDV; ++s) {
+      if (8 * s < a.hd) {
+        f32x4 qf = *reinterpret_cast<const f32x4*>(Qs + col * lds_ld + 8 * s + 4 * half);
+        f32x4 gf = *reinterpret_cast<const f32x4*>(Gs + col * lds_ld + 8 * s + 4 * half);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[t], kf[s][t], sacc, 0, 0, 0);
+          pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(gf[t], vf[s][t], pacc, 0, 0, 0);
+        }
+      }
+    }
+    float pu[16], ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qrow = row_of(r, half);
+      const int q = qt * TK + qrow;
+      float dsc = 1.f;
+      if (MODE == MODE_SOFTMAX && a.p_drop > 0.f) {
+        // same (query, key) -> random mapping as the forward kernel: element e = q*L + kk, group e>>2, lane e&3
+        const unsigned long long e = (unsigned long long)q * ((a.L + 3) & ~3) + kk;
+        uint4 rnd = philox4x32(a.seed, (unsigned long long)bh, (e >> 2) | (1ull << 40));
+        const unsigned w = (e & 3) == 0 ? rnd.x : ((e & 3) == 1 ? rnd.y : ((e & 3) == 2 ? rnd.z : rnd.w));
+        dsc = (u32_to_unit(w) >= a.p_drop) ? inv_keep : 0.f;
+      }
+      bool dead; float bias = 0.f;
+      if (MODE == MODE_SOFTMAX) {
+        dead = (kk >= a.L) || (q >= a.L) || masked(a, q, kk, k_is_pad);
+      } else {
+        dead = (kk >= a.L) || (q >= a.L) || (kk > q) || k_is_pad || (aux[2 * TK + qrow] != 0.f);
+        if (!dead) {
+          if (a.time_w) bias += s_tw[time_bucket(s_thr, s_ts[q + 1] - t_k)];
+          if (a.pos_w) bias += s_pw[(a.L - 1) + kk - q];
+        }
+      }
+      tile_p_ds<MODE>(a, sacc[r], pacc[r], aux[qrow], aux[TK + qrow], dead, bias, dsc, pu[r], ds[r]);
+    }
+    // dV^T += dO^T P ; dK^T += Q^T dS : rows = dd (A operand from LDS), cols = keys (B = registers)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int qrow = row_of(t, half);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int dd = nt * 32 + col;
+        const float gv = (dd < a.hd) ? Gs[qrow * lds_ld + dd] : 0.f;
+        const float qv = (dd < a.hd) ? Qs[qrow * lds_ld + dd] : 0.f;
+        dvacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, pu[t], dvacc[nt], 0, 0, 0);
+        dkacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qv, ds[t], dkacc[nt], 0, 0, 0);
+      }
+    }
+  }
+  if (k0 >= a.L || kk >= a.L) return;
+  float* dkb = a.dk + (rowbase + kk) * a.lddk + h * a.hd;
+  float* dvb = a.dv + (rowbase + kk) * a.lddv + h * a.hd;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dd = nt * 32 + row_of(r, half);
+      if (dd < a.hd) { dkb[dd] = dkacc[nt][r]; dvb[dd] = dvacc[nt][r]; }
+    }
+}
+
+inline size_t attn_lds_bytes(int hd, int L, int aux_floats, bool hstu) {
+  size_t f = (size_t)2 * TK * (hd + 4) + aux_floats;
+  if (hstu) {
+    f += NBUCK + 3 + ((2 * L + 3) & ~3);
+    return f * 4 + 8 + (size_t)(NBUCK + 1 + L + 1) * 8;
+  }
+  return f * 4 + 64;
+}
+
+template <int MODE, int HD>
+int launch_fwd(const AttnArgs& a, hipStream_t stream) {
+  const size_t lds = attn_lds_bytes(a.hd, a.L, TK, MODE == MODE_HSTU) + 64;
+  static size_t attr = 0;
+  if (lds > 64 * 1024 && lds > attr) {
+    RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<MODE, HD>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = lds;
+  }
+  dim3 grid((a.L + 4 * TK - 1) / (4 * TK), a.B * a.H);
+  attn_fwd_kernel<MODE, HD><<<grid, AT, lds, stream>>>(a);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+template <int MODE, int HD>
+int launch_bwd(const AttnArgs& a, hipStream_t stream) {
+  dim3 grid((a.L + 4 * TK - 1) / (4 * TK), a.B * a.H);
+  const size_t lds1 = attn_lds_bytes(a.hd, a.L, TK, MODE == MODE_HSTU) + 64 +
+                      (MODE == MODE_HSTU ? (size_t)(NBUCK + 3 + ((2 * a.L + 3) & ~3)) * 4 : 0);
+  const size_t lds2 = attn_lds_bytes(a.hd, a.L, 3 * TK, MODE == MODE_HSTU) + 64;
+  static size_t attr1 = 0, attr2 = 0;
+  if (lds1 > 64 * 1024 && lds1 > attr1) {
+    RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<MODE, HD>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    attr1 = lds1;
+  }
+  if (lds2 > 64 * 1024 && lds2 > attr2) {
+    RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<MODE, HD>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    attr2 = lds2;
+  }
+  attn_bwd_dq_kernel<MODE, HD><<<grid, AT, lds1, stream>>>(a);
+  RT_CHECK_LAUNCH();
+  attn_bwd_dkv_kernel<MODE, HD><<<grid, AT, lds2, stream>>>(a);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+template <int MODE>
+int dispatch_fwd(const AttnArgs& a, hipStream_t s) {
+  if (a.hd <= 32) return launch_fwd<MODE, 32>(a, s);
+  if (a.hd <= 64) return launch_fwd<MODE, 64>(a, s);
+  return launch_fwd<MODE, 128>(a, s);
+}
+template <int MODE>
+int dispatch_bwd(const AttnArgs& a, hipStream_t s) {
+  if (a.hd <= 32) return launch_bwd<MODE, 32>(a, s);
+  if (a.hd <= 64) return launch_bwd<MODE, 64>(a, s);
+  return launch_bwd<MODE, 128>(a, s);
+}
+
+inline bool bad_common(int B, int H, int L, int hd, int64_t ldq, int64_t ldk, int64_t ldv) {
+  return B <= 0 || H <= 0 || L <= 0 || hd <= 0 || (hd & 7) != 0 || hd > 128 || (ldq & 3) || (ldk & 3) || (ldv & 3);
+}
+
+}  // namespace
+
+extern "C" {
+
+// softmax attention forward.  q,k,v: [B*L, ld*] with head h at columns [h*hd, (h+1)*hd).  ids: [B,L].
+int rt_mha_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+               const int64_t* ids, int32_t B, int32_t H, int32_t L, int32_t hd, int32_t causal, int32_t keypad,
+               float p_drop, uint64_t seed, float* o, int64_t ldo, float* lse, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (bad_common(B, H, L, hd, ldq, ldk, ldv) || (ldo & 3)) return RT_ERR_INVALID_ARG;
+  AttnArgs a{};
+  a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.o = o; a.ldo = ldo; a.lse = lse;
+  a.ids = reinterpret_cast<const long long*>(ids); a.B = B; a.H = H; a.L = L; a.hd = hd;
+  a.causal = causal; a.keypad = keypad; a.scale = 1.0f / sqrtf((float)hd); a.p_drop = p_drop; a.seed = seed;
+  return dispatch_fwd<MODE_SOFTMAX>(a, stream);
+}
+
+// softmax attention backward.  delta: [B,H,L] workspace (filled here).  dq/dk/dv fully overwritten.
+int rt_mha_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+               const float* o, int64_t ldo, const float* dout, int64_t lddo, const float* lse, const int64_t* ids,
+               int32_t B, int32_t H, int32_t L, int32_t hd, int32_t causal, int32_t keypad, float p_drop, uint64_t seed,
+               float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv, float* delta,
+               hipStream_t stream) {
+  (void)hipGetLastError();
+  if (bad_common(B, H, L, hd, ldq, ldk, ldv) || (ldo & 3) || (lddo & 3)) return RT_ERR_INVALID_ARG;
+  const long long n = (long long)B * H * L;
+  attn_delta_kernel<<<(int)((n + 255) / 256), 256, 0, stream>>>(dout, lddo, o, ldo, B, H, L, hd, delta);
+  RT_CHECK_LAUNCH();
+  AttnArgs a{};
+  a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.dout = dout; a.lddo = lddo;
+  a.lse = const_cast<float*>(lse); a.delta = delta;
+  a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+  a.ids = reinterpret_cast<const long long*>(ids); a.B = B; a.H = H; a.L = L; a.hd = hd;
+  a.causal = causal; a.keypad = keypad; a.scale = 1.0f / sqrtf((float)hd); a.p_drop = p_drop; a.seed = seed;
+  return dispatch_bwd<MODE_SOFTMAX>(a, stream);
+}
+
+// HSTU pointwise attention forward (always causal, padded queries and keys masked).
+// ts: [B, L+1] int64 or null; time_w [129] / time_thr [129] or null; pos_w [2L-1] or null.
+int rt_hstu_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                     const int64_t* ids, const int64_t* ts, const float* time_w, const int64_t* time_thr,
+                     const float* pos_w, int32_t B, int32_t H, int32_t L, int32_t hd, float* o, int64_t ldo,
+                     hipStream_t stream) {
+  (void)hipGetLastError();
+  if (bad_common(B, H, L, hd, ldq, ldk, ldv) || (ldo & 3)) return RT_ERR_INVALID_ARG;
+  if ((time_w != nullptr) != (ts != nullptr) || (time_w != nullptr) != (time_thr != nullptr)) return RT_ERR_INVALID_ARG;
+  AttnArgs a{};
+  a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.o = o; a.ldo = ldo;
+  a.ids = reinterpret_cast<const long long*>(ids); a.B = B; a.H = H; a.L = L; a.hd = hd; a.causal = 1; a.keypad = 0;
+  a.ts = reinterpret_cast<const long long*>(ts); a.time_w = time_w;
+  a.time_thr = reinterpret_cast<const long long*>(time_thr); a.pos_w = pos_w;
+  return dispatch_fwd<MODE_HSTU>(a, stream);
+}
+
+// HSTU attention backward: dq/dk/dv overwritten; d_time_w [129] / d_pos_w [2L-1] are ACCUMULATED into (caller zeroes).
+int rt_hstu_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                     const float* dout, int64_t lddo, const int64_t* ids, const int64_t* ts, const float* time_w,
+                     const int64_t* time_thr, const float* pos_w, int32_t B, int32_t H, int32_t L, int32_t hd,
+                     float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv, float* d_time_w,
+                     float* d_pos_w, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (bad_common(B, H, L, hd, ldq, ldk, ldv) || (lddo & 3)) return RT_ERR_INVALID_ARG;
+  AttnArgs a{};
+  a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.dout = dout; a.lddo = lddo;
+  a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+  a.ids = reinterpret_cast<const long long*>(ids); a.B = B; a.H = H; a.L = L; a.hd = hd; a.causal = 1; a.keypad = 0;
+  a.ts = reinterpret_cast<const long long*>(ts); a.time_w = time_w;
+  a.time_thr = reinterpret_cast<const long long*>(time_thr); a.pos_w = pos_w;
+  a.d_time_w = d_time_w; a.d_pos_w = d_pos_w;
+  return dispatch_bwd<MODE_HSTU>(a, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,287 @@
+// K7 — dense fp32 GEMM on the f32-input MFMA (v_mfma_f32_32x32x2_f32: exact fp32, 157 TF peak on gfx950).
+//
+// One kernel family serves every dense product of the transformer blocks and of the full-softmax loss:
+//     C[m, n] (+)= sum_k A(m, k) * B(n, k)   [+ bias[n]] [+ R[m, n]] [relu]
+// with A and B each either "k-contiguous" (row-major [rows, K], e.g. x and nn.Linear.weight in y = x W^T) or
+// "row-contiguous" (the element (r, k) lives at r + k * ld — a transposed view), which covers
+//     forward   y  = x W^T            A = x  [M,K] kc      B = W  [N,K] kc
+//     dgrad     dx = dy W             A = dy [M,N] kc      B = W^T      rc   (B(kk, n) = W[n*K + kk])
+//     wgrad     dW = dy^T x           A = dy^T     rc      B = x^T      rc   (reduction over M, split-K)
+// Replaces the ATen call sites `nn.Linear` / `in_proj` / `out_proj` / `torch.matmul(normed_x, uvqk_proj)` /
+// `session_embs @ item_embs.T` (net_blocks.py:63-64,108-109; sasrec.py:191; hstu.py:258; similarity.py:85).
+//
+// Tiling: 128x128 output tile per 256-thread workgroup, 2x2 waves, each wave 2x2 MFMA tiles of 32x32
+// (4 accumulators = 64 VGPRs), BK = 32, HBM -> VGPR -> LDS double buffering (one barrier per k-step).
+// Same reduction-index permutation as the top-k kernel: lane l consumes k = 8s + 4(l>>5) + t, so a
+// k-contiguous operand is fetched from LDS with one ds_read_b128 per 4 MFMAs.
+#include "rt_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDK = BK + 4;    // k-contiguous tile: [128][36]
+constexpr int LDM = BM + 4;    // row-contiguous tile: [32][132]
+constexpr int GT = 256;
+
+struct GemmArgs {
+  const float* A; long long lda;  // kc: A(m,k) = A[m*lda + k];  rc: A(m,k) = A[m + k*lda]
+  const float* B; long long ldb;
+  float* C; long long ldc;
+  const float* bias;              // [N] or null
+  const float* R; long long ldr;  // residual [M,N] or null
+  int M, N, K;
+  int relu;
+  int k_per_split;                // split-K: grid.z slices of the reduction; >0 => atomicAdd into C
+};
+
+template <bool KC>
+__device__ __forceinline__ void load_tile(const float* __restrict__ P, long long ld, int row0, int n_rows, int k0,
+                                          int k_end, int tid, f32x4 (&v)[4], bool vec_ok) {
+  // 128 rows x 32 k = 1024 float4; thread handles 4 of them
+  if (KC) {
+    const int c4 = tid & 7;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = row0 + (tid >> 3) + 32 * j;
+      const int k = k0 + c4 * 4;
+      f32x4 x = {0.f, 0.f, 0.f, 0.f};
+      if (r < n_rows) {
+        const float* p = P + (long long)r * ld + k;
+        if (vec_ok && k + 3 < k_end) {
+          x = *reinterpret_cast<const f32x4*>(p);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) if (k + i < k_end) x[i] = p[i];
+        }
+      }
+      v[j] = x;
+    }
+  } else {
+    const int m4 = tid & 31;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + (tid >> 5) + 8 * j;
+      const int r = row0 + m4 * 4;
+      f32x4 x = {0.f, 0.f, 0.f, 0.f};
+      if (k < k_end) {
+        const float* p = P + (long long)k * ld + r;
+        if (vec_ok && r + 3 < n_rows) {
+          x = *reinterpret_cast<const f32x4*>(p);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) if (r + i < n_rows) x[i] = p[i];
+        }
+      }
+      v[j] = x;
+    }
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_tile(float* S, int tid, const f32x4 (&v)[4]) {
+  if (KC) {
+    const int c4 = tid & 7;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(S + ((tid >> 3) + 32 * j) * LDK + c4 * 4) = v[j];
+  } else {
+    const int m4 = tid & 31;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(S + ((tid >> 5) + 8 * j) * LDM + m4 * 4) = v[j];
+  }
+}
+
+// fragment of 4 consecutive (permuted) k values for row `row` at k-step s, half h
+template <bool KC>
+__device__ __forceinline__ f32x4 read_frag(const float* S, int row, int s, int h) {
+  if (KC) {
+    return *reinterpret_cast<const f32x4*>(S + row * LDK + 8 * s + 4 * h);
+  } else {
+    f32x4 x;
+    const float* p = S + (8 * s + 4 * h) * LDM + row;
+    x[0] = p[0]; x[1] = p[LDM]; x[2] = p[2 * LDM]; x[3] = p[3 * LDM];
+    return x;
+  }
+}
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(GT) void gemm_kernel(GemmArgs g) {
+  constexpr int SA = AKC ? BM * LDK : BK * LDM;
+  constexpr int SB = BKC ? BN * LDK : BK * LDM;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;             // [2][SA]
+  float* Bs = smem + 2 * SA;    // [2][SB]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware tile order: consecutive tile ids (sharing the A row panel) stay on one XCD's L2
+  const int n_tn = (g.N + BN - 1) / BN;
+  const int n_tm = (g.M + BM - 1) / BM;
+  const int n_tiles = n_tm * n_tn;
+  int t = blockIdx.x;
+  {
+    const int nx = 8, q = n_tiles / nx, r = n_tiles % nx, xcd = t % nx, idx = t / nx;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = (t / n_tn) * BM, n0 = (t % n_tn) * BN;
+
+  int k_begin = 0, k_end = g.K;
+  if (g.k_per_split > 0) {
+    k_begin = blockIdx.z * g.k_per_split;
+    k_end = k_begin + g.k_per_split;
+    if (k_end > g.K) k_end = g.K;
+    if (k_begin >= k_end) return;
+  }
+  const bool a_vec = ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
+  const bool b_vec = ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ra[4], rb[4];
+  const int n_steps = (k_end - k_begin + BK - 1) / BK;
+  load_tile<AKC>(g.A, g.lda, m0, g.M, k_begin, k_end, tid, ra, a_vec);
+  load_tile<BKC>(g.B, g.ldb, n0, g.N, k_begin, k_end, tid, rb, b_vec);
+  store_tile<AKC>(As, tid, ra);
+  store_tile<BKC>(Bs, tid, rb);
+  __syncthreads();
+
+  for (int st = 0; st < n_steps; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < n_steps) {
+      load_tile<AKC>(g.A, g.lda, m0, g.M, k_begin + (st + 1) * BK, k_end, tid, ra, a_vec);
+      load_tile<BKC>(g.B, g.ldb, n0, g.N, k_begin + (st + 1) * BK, k_end, tid, rb, b_vec);
+    }
+    const float* Ab = As + buf * SA;
+    const float* Bb = Bs + buf * SB;
+#pragma unroll
+    for (int s = 0; s < BK / 8; ++s) {
+      f32x4 af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = read_frag<AKC>(Ab, wm * 64 + i * 32 + col, s, half);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = read_frag<BKC>(Bb, wn * 64 + j * 32 + col, s, half);
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][tt], bf[j][tt], acc[i][j], 0, 0, 0);
+    }
+    if (st + 1 < n_steps) {
+      store_tile<AKC>(As + (buf ^ 1) * SA, tid, ra);
+      store_tile<BKC>(Bs + (buf ^ 1) * SB, tid, rb);
+      __syncthreads();
+    }
+  }
+
+  // epilogue.  D layout: MFMA rows index A (m), columns index B (n):
+  //   acc[i][j][r] = C[m0 + wm*64 + i*32 + (r&3) + 8*(r>>2) + 4*half][n0 + wn*64 + j*32 + col]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + col;
+      if (n >= g.N) continue;
+      const float bv = (g.bias != nullptr && (g.k_per_split == 0 || blockIdx.z == 0)) ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m >= g.M) continue;
+        float v = acc[i][j][r] + bv;
+        if (g.k_per_split > 0) {
+          atomicAdd(g.C + (long long)m * g.ldc + n, v);
+        } else {
+          if (g.R != nullptr) v += g.R[(long long)m * g.ldr + n];
+          if (g.relu) v = fmaxf(v, 0.f);
+          g.C[(long long)m * g.ldc + n] = v;
+        }
+      }
+    }
+}
+
+// column sums: out[n] = sum_m X[m, n]   (bias gradients)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long long ld, int M, int N,
+                                                     float* __restrict__ out) {
+  // block handles 64 columns x a slice of rows; 4 waves stride the rows, lanes own columns
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  const int rows_per_block = (M + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * rows_per_block;
+  int r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
+  float s = 0.f;
+  if (n < N)
+    for (int m = r0 + w; m < r1; m += 4) s += X[(long long)m * ld + n];
+  __shared__ float red[4][64];
+  red[w][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (w == 0 && n < N) { const int l = threadIdx.x & 63; atomicAdd(out + n, red[0][l] + red[1][l] + red[2][l] + red[3][l]); }
+}
+
+template <bool AKC, bool BKC>
+int launch_gemm(const GemmArgs& g, int splits, hipStream_t stream) {
+  constexpr int SA = AKC ? BM * LDK : BK * LDM;
+  constexpr int SB = BKC ? BN * LDK : BK * LDM;
+  const size_t lds = (size_t)(2 * SA + 2 * SB) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<AKC, BKC>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  const int n_tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+  dim3 grid(n_tiles, 1, splits);
+  gemm_kernel<AKC, BKC><<<grid, GT, lds, stream>>>(g);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// C[M,N] = A . B^T (+bias) (+R) (relu);  a_kc/b_kc: 1 = k-contiguous ([rows,K] row-major, ld = row stride),
+// 0 = row-contiguous (element (r,k) at r + k*ld).  split_k > 1: reduction split over grid.z with atomicAdd
+// into C, which the caller must have zero-filled (bias is added once; R / relu are not allowed).
+int rt_gemm(const float* A, int64_t lda, int32_t a_kc, const float* B, int64_t ldb, int32_t b_kc,
+            float* C, int64_t ldc, const float* bias, const float* R, int64_t ldr,
+            int32_t M, int32_t N, int32_t K, int32_t relu, int32_t split_k, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (M < 0 || N < 0 || K < 0 || A == nullptr || B == nullptr || C == nullptr) return RT_ERR_INVALID_ARG;
+  if (M == 0 || N == 0) return RT_OK;
+  if (split_k > 1 && (R != nullptr || relu)) return RT_ERR_INVALID_ARG;
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.bias = bias; g.R = R; g.ldr = ldr;
+  g.M = M; g.N = N; g.K = K; g.relu = relu;
+  int splits = 1;
+  if (split_k > 1) {
+    int kps = (K + split_k - 1) / split_k;
+    kps = (kps + BK - 1) / BK * BK;
+    splits = (K + kps - 1) / kps;
+    g.k_per_split = kps;
+  }
+  if (a_kc && b_kc) return launch_gemm<true, true>(g, splits, stream);
+  if (a_kc && !b_kc) return launch_gemm<true, false>(g, splits, stream);
+  if (!a_kc && b_kc) return launch_gemm<false, true>(g, splits, stream);
+  return launch_gemm<false, false>(g, splits, stream);
+}
+
+// out[n] += sum_m X[m,n]  (caller zero-fills `out`)
+int rt_colsum(const float* X, int64_t ld, int32_t M, int32_t N, float* out, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (M <= 0 || N <= 0) return RT_OK;
+  int gy = (M + 511) / 512; if (gy > 256) gy = 256; if (gy < 1) gy = 1;
+  dim3 grid((N + 63) / 64, gy);
+  colsum_kernel<<<grid, 256, 0, stream>>>(X, ld, M, N, out);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,546 @@
+// K8 / K9 / K10 / K11 — similarity logits and losses of the training step (fp32; gBCE transform in fp64).
+//
+//  sampled losses   `DistanceSimilarityModule._get_pos_neg_logits` (similarity.py:88-95) materialises the gather
+//                   item_embs[candidates] as a [B, L, 1+N, d] tensor (3.4 GB at B128 L200 N128 d256) before a batched
+//                   mat-vec; `_calc_bce_loss` / `_calc_gbce_loss` / `_calc_sampled_softmax_loss`
+//                   (lightning.py:164-212) then reduce it.  Here one wave per position keeps the session row in
+//                   registers, streams the 1+N candidate rows (16 lanes per row, 4 rows per step), and writes only
+//                   the [M, 1+N] logits and one loss value per position; the backward kernel turns dlogits into
+//                   d(session) in registers and atomically scatters d(item rows) into the dense table gradient.
+//  full softmax     logits come from the MFMA GEMM (rt_gemm) over the ACTIVE positions only (y != 0; the others
+//                   have zero loss and zero gradient, ignore_index=0 at lightning.py:157); `softmax_ce_rows`
+//                   converts each logits row in place into (softmax - onehot) * weight / norm and the two gradient
+//                   GEMMs consume it.
+//  cosine           L2 row normalisation with the reference's max(||x||, 1e-8) denominator (similarity.py:97-100),
+//                   forward and backward; the sampled kernels normalise only the rows they read (K11).
+//  loss reduction   sum(loss) / sum(loss > 0) for the softmax family (lightning.py:159-161), sum(loss) / sum(y != 0)
+//                   for BCE / gBCE (lightning.py:197-198).
+#include "rt_common.h"
+
+namespace {
+
+enum { LOSS_BCE = 0, LOSS_GBCE = 1, LOSS_SAMPLED_SOFTMAX = 2 };
+constexpr float EPS_COS = 1e-8f;
+
+struct SampledArgs {
+  const float* sess; long long ld_sess;   // [M, d]
+  const float* table;                     // [V, d]
+  const long long* y;                     // [M] positives (0 = inactive position)
+  const long long* neg;                   // [M, N]
+  const float* w;                         // [M] weights
+  int M, N, d;
+  int loss, cosine;
+  float inv_t;                            // 1 / logits_t
+  double gbce_beta;
+  float* logits;                          // [M, 1+N] saved logits (already / logits_t)
+  float* loss_pos;                        // [M] weighted loss per position
+  // backward
+  const float* norm;                      // [1] normaliser produced by the reduction kernel
+  float gscale;                           // upstream dL/dloss
+  float* d_sess; long long ld_dsess;      // [M, d] overwritten
+  float* d_table;                         // [V, d] accumulated (atomicAdd)
+};
+
+__device__ __forceinline__ float group16_sum(float v) {  // sum over the 16 lanes of a quarter-wave
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double softplus_d(double z) { return z > 0 ? z + log1p(exp(-z)) : log1p(exp(z)); }
+__device__ __forceinline__ double sigmoid_d(double z) { return 1.0 / (1.0 + exp(-z)); }
+
+// gBCE transform of the positive logit and its derivative (lightning.py:164-186), fp64.
+__device__ __forceinline__ void gbce_transform(double z, double beta, double& f, double& df) {
+  const double eps = 1e-10, fmax_d = 1.7976931348623157e308;
+  const double sg = sigmoid_d(z);
+  double p = sg, dp = sg * (1.0 - sg);
+  if (p < eps) { p = eps; dp = 0; } else if (p > 1 - eps) { p = 1 - eps; dp = 0; }
+  double a = pow(p, -beta), da = -beta * pow(p, -beta - 1.0) * dp;
+  if (a < 1 + eps) { a = 1 + eps; da = 0; } else if (a > fmax_d) { a = fmax_d; da = 0; }
+  double bq = 1.0 / (a - 1.0), db = -da / ((a - 1.0) * (a - 1.0));
+  if (bq < eps) { bq = eps; db = 0; } else if (bq > fmax_d) { bq = fmax_d; db = 0; }
+  f = log(bq); df = db / bq;
+}
+
+// one wave per position; D4 = number of float4 per lane for a d-wide row split over 16 lanes (d <= 64*D4)
+template <int D4>
+__global__ __launch_bounds__(256) void sampled_fwd_kernel(SampledArgs a) {
+  __shared__ float s_z[4][260];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = blockIdx.x * 4 + wave;
+  if (m >= a.M) return;
+  const int C = a.N + 1;
+  const long long yy = a.y[m];
+  float* zrow = a.logits + (long long)m * C;
+  if (yy == 0) {  // inactive: zero loss; logits are never read for it
+    if (lane == 0) a.loss_pos[m] = 0.f;
+    return;
+  }
+  const int sub = lane & 15, grp = lane >> 4;
+  // session slice of this lane: float4 index sub + 16*i
+  f32x4 sv[D4];
+  float ss = 0.f;
+  const float* srow = a.sess + (long long)m * a.ld_sess;
+#pragma unroll
+  for (int i = 0; i < D4; ++i) {
+    const int c = (sub + 16 * i) * 4;
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    sv[i] = (c < a.d) ? *reinterpret_cast<const f32x4*>(srow + c) : z;
+    ss += sv[i][0] * sv[i][0] + sv[i][1] * sv[i][1] + sv[i][2] * sv[i][2] + sv[i][3] * sv[i][3];
+  }
+  ss = group16_sum(ss);
+  const float inv_ns = a.cosine ? 1.0f / fmaxf(sqrtf(ss), EPS_COS) : 1.0f;
+
+  for (int j0 = 0; j0 < C; j0 += 4) {
+    const int j = j0 + grp;
+    float dot = 0.f, ee = 0.f;
+    if (j < C) {
+      const long long cid = (j == 0) ? yy : a.neg[(long long)m * a.N + (j - 1)];
+      const float* er = a.table + cid * (long long)a.d;
+#pragma unroll
+      for (int i = 0; i < D4; ++i) {
+        const int c = (sub + 16 * i) * 4;
+        if (c < a.d) {
+          f32x4 e = *reinterpret_cast<const f32x4*>(er + c);
+          dot += e[0] * sv[i][0] + e[1] * sv[i][1] + e[2] * sv[i][2] + e[3] * sv[i][3];
+          ee += e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3];
+        }
+      }
+    }
+    dot = group16_sum(dot);
+    ee = group16_sum(ee);
+    if (j < C && sub == 0) {
+      float z = dot;
+      if (a.cosine) z = z * inv_ns * (1.0f / fmaxf(sqrtf(ee), EPS_COS));
+      z *= a.inv_t;
+      if (j < 260) s_z[wave][j] = z;
+      zrow[j] = z;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+  const float wgt = a.w[m];
+  auto zat = [&](int j) -> float { return j < 260 ? s_z[wave][j] : zrow[j]; };
+  float out;
+  if (a.loss == LOSS_SAMPLED_SOFTMAX) {
+    float mx = -INFINITY;
+    for (int j = lane; j < C; j += 64) mx = fmaxf(mx, zat(j));
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int j = lane; j < C; j += 64) se += __expf(zat(j) - mx);
+    se = wave_sum(se);
+    out = (mx + __logf(se) - zat(0)) * wgt;
+  } else {
+    double acc = 0.0;
+    for (int j = lane; j < C; j += 64) {
+      double z = (double)zat(j);
+      if (j == 0) {
+        if (a.loss == LOSS_GBCE) { double f, df; gbce_transform(z, a.gbce_beta, f, df); z = f; }
+        acc += softplus_d(-z);
+      } else {
+        acc += softplus_d(z);
+      }
+    }
+    acc = wave_sum_d(acc);
+    out = (float)(acc / (double)C) * wgt;
+  }
+  if (lane == 0) a.loss_pos[m] = out;
+}
+
+template <int D4>
+__global__ __launch_bounds__(256) void sampled_bwd_kernel(SampledArgs a) {
+  __shared__ float s_g[4][260];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = blockIdx.x * 4 + wave;
+  if (m >= a.M) return;
+  const int C = a.N + 1;
+  const long long yy = a.y[m];
+  const int sub = lane & 15, grp = lane >> 4;
+  float* drow = a.d_sess + (long long)m * a.ld_dsess;
+  if (yy == 0) {
+#pragma unroll
+    for (int i = 0; i < D4; ++i) {
+      const int c = (sub + 16 * i) * 4;
+      if (grp == 0 && c < a.d) *reinterpret_cast<f32x4*>(drow + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    return;
+  }
+  const float* zrow = a.logits + (long long)m * C;
+  float* grow = const_cast<float*>(zrow);  // dlogits overwrite the saved logits beyond the LDS window
+  const float wgt = a.w[m];
+  const float gs = a.gscale / a.norm[0] * wgt;
+
+  // ---- dL/dz_j for this position ----
+  if (a.loss == LOSS_SAMPLED_SOFTMAX) {
+    float mx = -INFINITY;
+    for (int j = lane; j < C; j += 64) mx = fmaxf(mx, zrow[j]);
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int j = lane; j < C; j += 64) se += __expf(zrow[j] - mx);
+    se = wave_sum(se);
+    // positions whose weighted loss is not > 0 are outside the normaliser but still carry gradient in the
+    // reference (sum(loss) / sum(loss > 0)); keep that.
+    for (int j = lane; j < C; j += 64) {
+      float g = (__expf(zrow[j] - mx) / se - (j == 0 ? 1.f : 0.f)) * gs;
+      if (j < 260) s_g[wave][j] = g; else grow[j] = g;
+    }
+  } else {
+    for (int j = lane; j < C; j += 64) {
+      double z = (double)zrow[j];
+      double g;
+      if (j == 0) {
+        double df = 1.0;
+        if (a.loss == LOSS_GBCE) { double f; gbce_transform(z, a.gbce_beta, f, df); z = f; }
+        g = (sigmoid_d(z) - 1.0) * df;
+      } else {
+        g = sigmoid_d(z);
+      }
+      float gf = (float)(g / (double)C) * gs;
+      if (j < 260) s_g[wave][j] = gf; else grow[j] = gf;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+  // ---- chain rule into the session row (registers) and the table rows (atomics) ----
+  f32x4 sv[D4], ds[D4];
+  float ss = 0.f;
+  const float* srow = a.sess + (long long)m * a.ld_sess;
+#pragma unroll
+  for (int i = 0; i < D4; ++i) {
+    const int c = (sub + 16 * i) * 4;
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    sv[i] = (c < a.d) ? *reinterpret_cast<const f32x4*>(srow + c) : z;
+    ds[i] = z;
+    ss += sv[i][0] * sv[i][0] + sv[i][1] * sv[i][1] + sv[i][2] * sv[i][2] + sv[i][3] * sv[i][3];
+  }
+  ss = group16_sum(ss);
+  const float ns = sqrtf(ss);
+  const float inv_ns = a.cosine ? 1.0f / fmaxf(ns, EPS_COS) : 1.0f;
+
+  for (int j0 = 0; j0 < C; j0 += 4) {
+    const int j = j0 + grp;
+    if (j < C) {  // uniform inside a 16-lane group
+      const long long cid = (j == 0) ? yy : a.neg[(long long)m * a.N + (j - 1)];
+      const float g = (j < 260 ? s_g[wave][j] : grow[j]) * a.inv_t;   // dL/d(raw similarity)
+      const float* er = a.table + cid * (long long)a.d;
+      float* dr = a.d_table + cid * (long long)a.d;
+      f32x4 ev[D4];
+      float ee = 0.f, dot = 0.f;
+#pragma unroll
+      for (int i = 0; i < D4; ++i) {
+        const int c = (sub + 16 * i) * 4;
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        ev[i] = (c < a.d) ? *reinterpret_cast<const f32x4*>(er + c) : z;
+        if (a.cosine) {
+          ee += ev[i][0] * ev[i][0] + ev[i][1] * ev[i][1] + ev[i][2] * ev[i][2] + ev[i][3] * ev[i][3];
+          dot += ev[i][0] * sv[i][0] + ev[i][1] * sv[i][1] + ev[i][2] * sv[i][2] + ev[i][3] * sv[i][3];
+        }
+      }
+      if (!a.cosine) {
+#pragma unroll
+        for (int i = 0; i < D4; ++i) {
+          const int c = (sub + 16 * i) * 4;
+          ds[i] += ev[i] * g;
+          if (c < a.d && cid != 0) {
+            atomicAdd(dr + c + 0, g * sv[i][0]); atomicAdd(dr + c + 1, g * sv[i][1]);
+            atomicAdd(dr + c + 2, g * sv[i][2]); atomicAdd(dr + c + 3, g * sv[i][3]);
+          }
+        }
+      } else {
+        ee = group16_sum(ee); dot = group16_sum(dot);
+        const float ne = sqrtf(ee);
+        const float inv_ne = 1.0f / fmaxf(ne, EPS_COS);
+        const float cosv = dot * inv_ns * inv_ne;   // s_hat . e_hat
+        // z = s_hat . e_hat ;  d s_hat = g e_hat ;  d e = (g s_hat - e_hat (e_hat . g s_hat)) / ne  (ne > eps)
+#pragma unroll
+        for (int i = 0; i < D4; ++i) {
+          const int c = (sub + 16 * i) * 4;
+          f32x4 eh = ev[i] * inv_ne, sh = sv[i] * inv_ns;
+          ds[i] += eh * g;  // accumulates d s_hat; projected after the loop
+          if (c < a.d && cid != 0) {
+            f32x4 de = (ne > EPS_COS) ? (sh * g - eh * (g * cosv)) * inv_ne : sh * (g * inv_ne);
+            atomicAdd(dr + c + 0, de[0]); atomicAdd(dr + c + 1, de[1]);
+            atomicAdd(dr + c + 2, de[2]); atomicAdd(dr + c + 3, de[3]);
+          }
+        }
+      }
+    }
+  }
+  // combine the 4 candidate groups: lanes with equal `sub` hold the same slice
+#pragma unroll
+  for (int i = 0; i < D4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = ds[i][e];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      ds[i][e] = v;
+    }
+  if (a.cosine) {  // d s = (d s_hat - s_hat (s_hat . d s_hat)) / ns
+    float proj = 0.f;
+#pragma unroll
+    for (int i = 0; i < D4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) proj += ds[i][e] * sv[i][e] * inv_ns;
+    proj = group16_sum(proj);
+#pragma unroll
+    for (int i = 0; i < D4; ++i) {
+      f32x4 sh = sv[i] * inv_ns;
+      ds[i] = (ns > EPS_COS) ? (ds[i] - sh * proj) * inv_ns : ds[i] * inv_ns;
+    }
+  }
+  if (grp == 0) {
+#pragma unroll
+    for (int i = 0; i < D4; ++i) {
+      const int c = (sub + 16 * i) * 4;
+      if (c < a.d) *reinterpret_cast<f32x4*>(drow + c) = ds[i];
+    }
+  }
+}
+
+// ---- loss reduction: out[0] = loss, out[1] = normaliser -------------------------------------------
+// mode 0: sum(l) / count(l > 0)  (softmax family)     mode 1: sum(l) / count(y != 0)  (BCE family)
+__global__ __launch_bounds__(1024) void loss_reduce_kernel(const float* __restrict__ loss_pos, const long long* __restrict__ y,
+                                                           int M, int mode, float* __restrict__ out) {
+  __shared__ double s_sum[16]; __shared__ double s_cnt[16];
+  double s = 0.0, c = 0.0;
+  for (int i = threadIdx.x; i < M; i += 1024) {
+    const float l = loss_pos[i];
+    s += (double)l;
+    if (mode == 0) c += (l > 0.f) ? 1.0 : 0.0; else c += (y[i] != 0) ? 1.0 : 0.0;
+  }
+  s = wave_sum_d(s); c = wave_sum_d(c);
+  if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = s; s_cnt[threadIdx.x >> 6] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ts = 0, tc = 0;
+    for (int i = 0; i < 16; ++i) { ts += s_sum[i]; tc += s_cnt[i]; }
+    out[0] = (float)(ts / tc);
+    out[1] = (float)tc;
+  }
+}
+
+// ---- full-softmax rows: logits row -> loss and (softmax - onehot) * w * gscale / norm in place ------------
+// pass A (grad == 0): loss_pos[r] = (lse - z_y) * w ; pass B (grad == 1): row := (softmax - onehot) * coef
+__global__ __launch_bounds__(256) void softmax_ce_rows_kernel(float* __restrict__ logits, long long ld, int R, int V,
+                                                              const long long* __restrict__ y_act, const float* __restrict__ w_act,
+                                                              float inv_t, int grad, const float* __restrict__ norm, float gscale,
+                                                              float* __restrict__ loss_pos, float* __restrict__ lse_out) {
+  const int r = blockIdx.x;
+  if (r >= R) return;
+  float* row = logits + (long long)r * ld;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ float red[4];
+  __shared__ float s_b;
+  const long long yy = y_act[r];
+  if (!grad) {
+    float mx = -INFINITY;
+    for (int j = tid; j < V; j += 256) mx = fmaxf(mx, row[j] * inv_t);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    if (tid == 0) s_b = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    mx = s_b;
+    float se = 0.f;
+    for (int j = tid; j < V; j += 256) se += __expf(row[j] * inv_t - mx);
+    se = wave_sum(se);
+    __syncthreads();
+    if (lane == 0) red[wave] = se;
+    __syncthreads();
+    if (tid == 0) {
+      const float lse = mx + __logf(red[0] + red[1] + red[2] + red[3]);
+      lse_out[r] = lse;
+      loss_pos[r] = (lse - row[yy] * inv_t) * w_act[r];
+    }
+  } else {
+    const float lse = lse_out[r];
+    const float coef = w_act[r] * gscale / norm[0] * inv_t;
+    for (int j = tid; j < V; j += 256) {
+      float p = __expf(row[j] * inv_t - lse);
+      row[j] = (p - (j == yy ? 1.f : 0.f)) * coef;
+    }
+  }
+}
+
+// ---- L2 row normalisation (cosine), forward / backward ----------------------------------------------
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, long long ldx, int M, int d,
+                                                         float* __restrict__ y, long long ldy, float* __restrict__ nrm) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const float* xr = x + (long long)m * ldx;
+  float s = 0.f;
+  for (int c = lane * 4; c < d; c += 256) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  const float n = sqrtf(wave_sum(s));
+  const float inv = 1.0f / fmaxf(n, EPS_COS);
+  for (int c = lane * 4; c < d; c += 256)
+    *reinterpret_cast<f32x4*>(y + (long long)m * ldy + c) = *reinterpret_cast<const f32x4*>(xr + c) * inv;
+  if (lane == 0 && nrm) nrm[m] = n;
+}
+// dx = (dy - xhat (xhat . dy)) / n   (n > eps);   dy / eps otherwise.  `accumulate`: dx += (table gradients)
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dy, long long lddy, const float* __restrict__ x,
+                                                         long long ldx, int M, int d, int accumulate,
+                                                         float* __restrict__ dx, long long lddx) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const float* xr = x + (long long)m * ldx;
+  const float* gr = dy + (long long)m * lddy;
+  float s = 0.f, t = 0.f;
+  for (int c = lane * 4; c < d; c += 256) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(xr + c), g = *reinterpret_cast<const f32x4*>(gr + c);
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    t += v[0] * g[0] + v[1] * g[1] + v[2] * g[2] + v[3] * g[3];
+  }
+  s = wave_sum(s); t = wave_sum(t);
+  const float n = sqrtf(s);
+  const float inv = 1.0f / fmaxf(n, EPS_COS);
+  for (int c = lane * 4; c < d; c += 256) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(xr + c), g = *reinterpret_cast<const f32x4*>(gr + c);
+    f32x4 o = (n > EPS_COS) ? (g - v * (t * inv * inv)) * inv : g * inv;
+    float* dst = dx + (long long)m * lddx + c;
+    if (accumulate) o += *reinterpret_cast<const f32x4*>(dst);
+    *reinterpret_cast<f32x4*>(dst) = o;
+  }
+}
+
+// ---- row gather / scatter-add (active positions of the full-softmax loss) ---------------------------
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, long long lds_, const long long* __restrict__ idx,
+                                                          int R, int d, float* __restrict__ dst, long long ldd) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const float* s = src + idx[r] * lds_;
+  for (int c = lane * 4; c < d; c += 256)
+    *reinterpret_cast<f32x4*>(dst + (long long)r * ldd + c) = *reinterpret_cast<const f32x4*>(s + c);
+}
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ src, long long lds_, const long long* __restrict__ idx,
+                                                           int R, int d, float* __restrict__ dst, long long ldd) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  float* o = dst + idx[r] * ldd;   // indices are unique: plain stores
+  for (int c = lane * 4; c < d; c += 256)
+    *reinterpret_cast<f32x4*>(o + c) = *reinterpret_cast<const f32x4*>(src + (long long)r * lds_ + c);
+}
+
+template <int D4>
+int launch_sampled(const SampledArgs& a, bool bwd, hipStream_t stream) {
+  const int blocks = (a.M + 3) / 4;
+  if (!bwd) sampled_fwd_kernel<D4><<<blocks, 256, 0, stream>>>(a);
+  else sampled_bwd_kernel<D4><<<blocks, 256, 0, stream>>>(a);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+int dispatch_sampled(const SampledArgs& a, bool bwd, hipStream_t stream) {
+  if (a.d <= 64) return launch_sampled<1>(a, bwd, stream);
+  if (a.d <= 128) return launch_sampled<2>(a, bwd, stream);
+  if (a.d <= 256) return launch_sampled<4>(a, bwd, stream);
+  if (a.d <= 512) return launch_sampled<8>(a, bwd, stream);
+  return RT_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" {
+
+// sess [M,d], table [V,d], y [M], neg [M,N], w [M]  ->  logits [M,1+N], loss_pos [M]
+int rt_sampled_loss_fwd(const float* sess, int64_t ld_sess, const float* table, const int64_t* y, const int64_t* neg,
+                        const float* w, int32_t M, int32_t N, int32_t d, int32_t loss, int32_t cosine, float logits_t,
+                        double gbce_beta, float* logits, float* loss_pos, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (M <= 0) return RT_OK;
+  if ((d & 3) || N < 0 || loss < LOSS_BCE || loss > LOSS_SAMPLED_SOFTMAX || (ld_sess & 3)) return RT_ERR_INVALID_ARG;
+  SampledArgs a{};
+  a.sess = sess; a.ld_sess = ld_sess; a.table = table; a.y = reinterpret_cast<const long long*>(y);
+  a.neg = reinterpret_cast<const long long*>(neg); a.w = w; a.M = M; a.N = N; a.d = d; a.loss = loss; a.cosine = cosine;
+  a.inv_t = 1.0f / logits_t; a.gbce_beta = gbce_beta; a.logits = logits; a.loss_pos = loss_pos;
+  return dispatch_sampled(a, false, stream);
+}
+
+// d_sess [M,d] overwritten; d_table [V,d] accumulated.  `logits` is clobbered beyond column 260.
+int rt_sampled_loss_bwd(const float* sess, int64_t ld_sess, const float* table, const int64_t* y, const int64_t* neg,
+                        const float* w, int32_t M, int32_t N, int32_t d, int32_t loss, int32_t cosine, float logits_t,
+                        double gbce_beta, float* logits, const float* norm, float gscale, float* d_sess, int64_t ld_dsess,
+                        float* d_table, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (M <= 0) return RT_OK;
+  if ((d & 3) || N < 0 || loss < LOSS_BCE || loss > LOSS_SAMPLED_SOFTMAX || (ld_sess & 3) || (ld_dsess & 3)) return RT_ERR_INVALID_ARG;
+  SampledArgs a{};
+  a.sess = sess; a.ld_sess = ld_sess; a.table = table; a.y = reinterpret_cast<const long long*>(y);
+  a.neg = reinterpret_cast<const long long*>(neg); a.w = w; a.M = M; a.N = N; a.d = d; a.loss = loss; a.cosine = cosine;
+  a.inv_t = 1.0f / logits_t; a.gbce_beta = gbce_beta; a.logits = logits; a.norm = norm; a.gscale = gscale;
+  a.d_sess = d_sess; a.ld_dsess = ld_dsess; a.d_table = d_table;
+  return dispatch_sampled(a, true, stream);
+}
+
+// out[0] = sum(loss_pos) / normaliser, out[1] = normaliser;  mode 0: count(loss_pos > 0), mode 1: count(y != 0)
+int rt_loss_reduce(const float* loss_pos, const int64_t* y, int32_t M, int32_t mode, float* out, hipStream_t stream) {
+  (void)hipGetLastError();
+  loss_reduce_kernel<<<1, 1024, 0, stream>>>(loss_pos, reinterpret_cast<const long long*>(y), M, mode, out);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+// logits [R,V] (raw similarities of the R active rows) -> loss_pos [R], lse [R]  (grad = 0)
+//                                                      -> logits := (softmax - onehot) * w * gscale / (norm * t)  (grad = 1)
+int rt_softmax_ce_rows(float* logits, int64_t ld, int32_t R, int32_t V, const int64_t* y_act, const float* w_act,
+                       float logits_t, int32_t grad, const float* norm, float gscale, float* loss_pos, float* lse,
+                       hipStream_t stream) {
+  (void)hipGetLastError();
+  if (R <= 0) return RT_OK;
+  softmax_ce_rows_kernel<<<R, 256, 0, stream>>>(logits, ld, R, V, reinterpret_cast<const long long*>(y_act), w_act,
+                                                1.0f / logits_t, grad, norm, gscale, loss_pos, lse);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+int rt_l2norm_fwd(const float* x, int64_t ldx, int32_t M, int32_t d, float* y, int64_t ldy, float* nrm, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (M <= 0) return RT_OK;
+  if ((d & 3) || (ldx & 3) || (ldy & 3)) return RT_ERR_INVALID_ARG;
+  l2norm_fwd_kernel<<<(M + 3) / 4, 256, 0, stream>>>(x, ldx, M, d, y, ldy, nrm);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+int rt_l2norm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, int32_t M, int32_t d, int32_t accumulate,
+                  float* dx, int64_t lddx, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (M <= 0) return RT_OK;
+  if ((d & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3)) return RT_ERR_INVALID_ARG;
+  l2norm_bwd_kernel<<<(M + 3) / 4, 256, 0, stream>>>(dy, lddy, x, ldx, M, d, accumulate, dx, lddx);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+int rt_gather_rows(const float* src, int64_t ld_src, const int64_t* idx, int32_t R, int32_t d, float* dst, int64_t ld_dst,
+                   hipStream_t stream) {
+  (void)hipGetLastError();
+  if (R <= 0) return RT_OK;
+  if ((d & 3) || (ld_src & 3) || (ld_dst & 3)) return RT_ERR_INVALID_ARG;
+  gather_rows_kernel<<<(R + 3) / 4, 256, 0, stream>>>(src, ld_src, reinterpret_cast<const long long*>(idx), R, d, dst, ld_dst);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+// dst[idx[r]] = src[r]  (idx unique; other rows of dst untouched — the caller zero-fills them)
+int rt_scatter_rows(const float* src, int64_t ld_src, const int64_t* idx, int32_t R, int32_t d, float* dst, int64_t ld_dst,
+                    hipStream_t stream) {
+  (void)hipGetLastError();
+  if (R <= 0) return RT_OK;
+  if ((d & 3) || (ld_src & 3) || (ld_dst & 3)) return RT_ERR_INVALID_ARG;
+  scatter_rows_kernel<<<(R + 3) / 4, 256, 0, stream>>>(src, ld_src, reinterpret_cast<const long long*>(idx), R, d, dst, ld_dst);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+}  // extern "C"

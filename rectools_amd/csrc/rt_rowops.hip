@@ -1,0 +1,468 @@
+// Row-wise / element-wise kernels of the transformer path (all fp32, HBM-bound; one wave per row or
+// float4 grid-stride streams).  Reference call sites:
+//   K2  embed + inverse positions + dropout      torch_backbone.py:245-247, net_blocks.py:388-399, item_net.py:280
+//   K3  LayerNorm                                sasrec.py:221,226,303; net_blocks.py:247,257; ligr.py:90,102; hstu.py:256,291
+//   K13 Adam                                     lightning.py:214-218 (torch.optim.Adam, betas (0.9,0.98), eps 1e-8)
+//   dropout / activations / gates / row masks    net_blocks.py:63-64,108-109; ligr.py:99-105; sasrec.py:228,300; hstu.py:257,291
+// Dropout masks are counter-based (Philox4x32 keyed by (seed, element/4)): the backward kernels regenerate
+// the forward mask from the same (seed, stream) pair instead of storing it.
+#include "rt_common.h"
+
+namespace {
+
+__device__ __forceinline__ f32x4 drop4(f32x4 v, unsigned long long seed, unsigned long long stream,
+                                        unsigned long long idx4, float p, float inv_keep) {
+  uint4 r = philox4x32(seed, stream, idx4);
+  v[0] = (u32_to_unit(r.x) >= p) ? v[0] * inv_keep : 0.f;
+  v[1] = (u32_to_unit(r.y) >= p) ? v[1] * inv_keep : 0.f;
+  v[2] = (u32_to_unit(r.z) >= p) ? v[2] * inv_keep : 0.f;
+  v[3] = (u32_to_unit(r.w) >= p) ? v[3] * inv_keep : 0.f;
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K2 embed: out[m,:] = drop( table[ids[m]] * scale + pos[L-1-(m % L)] )
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restrict__ ids, const float* __restrict__ table,
+                                                        const float* __restrict__ pos, float scale, int M, int L, int d,
+                                                        float p, unsigned long long seed, unsigned long long stream,
+                                                        float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const long long id = ids[m];
+  const int l = m % L;
+  const float* trow = table + id * (long long)d;
+  const float* prow = pos ? pos + (long long)(L - 1 - l) * d : nullptr;
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  for (int c = lane * 4; c < d; c += 256) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(trow + c);
+    v *= scale;
+    if (prow) v += *reinterpret_cast<const f32x4*>(prow + c);
+    if (p > 0.f) v = drop4(v, seed, stream, ((unsigned long long)m * d + c) >> 2, p, inv_keep);
+    *reinterpret_cast<f32x4*>(out + (long long)m * d + c) = v;
+  }
+}
+
+// gtable[ids[m]] += g * scale (ids != 0: nn.Embedding(padding_idx=0)); gpos[L-1-l] += g   (g = dropped gout)
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restrict__ ids, const float* __restrict__ gout,
+                                                        float scale, int M, int L, int d, float p,
+                                                        unsigned long long seed, unsigned long long stream,
+                                                        float* __restrict__ gtable, float* __restrict__ gpos) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const long long id = ids[m];
+  const int l = m % L;
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  for (int c = lane * 4; c < d; c += 256) {
+    f32x4 g = *reinterpret_cast<const f32x4*>(gout + (long long)m * d + c);
+    if (p > 0.f) g = drop4(g, seed, stream, ((unsigned long long)m * d + c) >> 2, p, inv_keep);
+    if (gpos) {
+      float* pr = gpos + (long long)(L - 1 - l) * d + c;
+      atomicAdd(pr + 0, g[0]); atomicAdd(pr + 1, g[1]); atomicAdd(pr + 2, g[2]); atomicAdd(pr + 3, g[3]);
+    }
+    if (id != 0) {
+      float* tr = gtable + id * (long long)d + c;
+      atomicAdd(tr + 0, g[0] * scale); atomicAdd(tr + 1, g[1] * scale);
+      atomicAdd(tr + 2, g[2] * scale); atomicAdd(tr + 3, g[3] * scale);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K3 LayerNorm (one wave per row).  Optional fused multiplier: y = LN(x) * mul (HSTU: u * LN(attn), hstu.py:291)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ b, float eps, int M, int d,
+                                                            float* __restrict__ y, float* __restrict__ mean,
+                                                            float* __restrict__ rstd) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const float* xr = x + (long long)m * d;
+  float s = 0.f;
+  for (int c = lane * 4; c < d; c += 256) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+    s += v[0] + v[1] + v[2] + v[3];
+  }
+  const float mu = wave_sum(s) / d;
+  float q = 0.f;
+  for (int c = lane * 4; c < d; c += 256) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+    v -= mu;
+    q += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  const float rs = 1.0f / sqrtf(wave_sum(q) / d + eps);
+  for (int c = lane * 4; c < d; c += 256) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+    f32x4 ww = *reinterpret_cast<const f32x4*>(w + c);
+    f32x4 bb = *reinterpret_cast<const f32x4*>(b + c);
+    v = (v - mu) * rs * ww + bb;
+    *reinterpret_cast<f32x4*>(y + (long long)m * d + c) = v;
+  }
+  if (lane == 0) { mean[m] = mu; rstd[m] = rs; }
+}
+
+// dx = rstd * (dy*w - mean(dy*w) - xhat * mean(dy*w*xhat));  dw += sum dy*xhat;  db += sum dy
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ w, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, int M, int d, int rows_per_block,
+                                                            float* __restrict__ dx, float* __restrict__ dw,
+                                                            float* __restrict__ db) {
+  extern __shared__ float red[];  // [2][d] partial dw / db of this block
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = threadIdx.x; c < 2 * d; c += 256) red[c] = 0.f;
+  __syncthreads();
+  const int r0 = blockIdx.x * rows_per_block;
+  int r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
+  for (int m = r0 + wave; m < r1; m += 4) {
+    const float mu = mean[m], rs = rstd[m];
+    const float* xr = x + (long long)m * d;
+    const float* gr = dy + (long long)m * d;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane * 4; c < d; c += 256) {
+      f32x4 g = *reinterpret_cast<const f32x4*>(gr + c);
+      f32x4 xh = (*reinterpret_cast<const f32x4*>(xr + c) - mu) * rs;
+      f32x4 gw = g * *reinterpret_cast<const f32x4*>(w + c);
+      s1 += gw[0] + gw[1] + gw[2] + gw[3];
+      s2 += gw[0] * xh[0] + gw[1] * xh[1] + gw[2] * xh[2] + gw[3] * xh[3];
+    }
+    s1 = wave_sum(s1) / d; s2 = wave_sum(s2) / d;
+    for (int c = lane * 4; c < d; c += 256) {
+      f32x4 g = *reinterpret_cast<const f32x4*>(gr + c);
+      f32x4 xh = (*reinterpret_cast<const f32x4*>(xr + c) - mu) * rs;
+      f32x4 gw = g * *reinterpret_cast<const f32x4*>(w + c);
+      f32x4 o = (gw - s1 - xh * s2) * rs;
+      *reinterpret_cast<f32x4*>(dx + (long long)m * d + c) = o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        atomicAdd(&red[c + i], g[i] * xh[i]);
+        atomicAdd(&red[d + c + i], g[i]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += 256) {
+    atomicAdd(dw + c, red[c]);
+    atomicAdd(db + c, red[d + c]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// element-wise streams (n4 = number of float4 groups)
+// ---------------------------------------------------------------------------------------------------
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SILU = 3, ACT_SIGMOID = 4 };
+
+__device__ __forceinline__ float act_f(float z, int kind) {
+  switch (kind) {
+    case ACT_RELU: return fmaxf(z, 0.f);
+    case ACT_GELU: return 0.5f * z * (1.f + erff(z * 0.70710678118654752f));
+    case ACT_SILU: return z / (1.f + __expf(-z));
+    case ACT_SIGMOID: return 1.f / (1.f + __expf(-z));
+    default: return z;
+  }
+}
+__device__ __forceinline__ float act_df(float z, int kind) {
+  switch (kind) {
+    case ACT_RELU: return z > 0.f ? 1.f : 0.f;
+    case ACT_GELU: return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * __expf(-0.5f * z * z);
+    case ACT_SILU: { float s = 1.f / (1.f + __expf(-z)); return s * (1.f + z * (1.f - s)); }
+    case ACT_SIGMOID: { float s = 1.f / (1.f + __expf(-z)); return s * (1.f - s); }
+    default: return 1.f;
+  }
+}
+
+// y = drop(act(z))            (dz = drop(dy) * act'(z) with the same seed/stream)
+__global__ void act_dropout_fwd_kernel(const f32x4* __restrict__ z, int kind, float p, unsigned long long seed,
+                                       unsigned long long stream, long long n4, f32x4* __restrict__ y) {
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 v = z[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = act_f(v[j], kind);
+    if (p > 0.f) v = drop4(v, seed, stream, (unsigned long long)i, p, inv_keep);
+    y[i] = v;
+  }
+}
+__global__ void act_dropout_bwd_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__ z, int kind, float p,
+                                       unsigned long long seed, unsigned long long stream, long long n4,
+                                       f32x4* __restrict__ dz) {
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 g = dy[i];
+    if (p > 0.f) g = drop4(g, seed, stream, (unsigned long long)i, p, inv_keep);
+    if (kind != ACT_NONE) {
+      f32x4 v = z[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] *= act_df(v[j], kind);
+    }
+    dz[i] = g;
+  }
+}
+
+// swiglu: y = drop(silu(a) * b)   (net_blocks.py:108)
+__global__ void swiglu_fwd_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b, float p,
+                                  unsigned long long seed, unsigned long long stream, long long n4, f32x4* __restrict__ y) {
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 va = a[i], vb = b[i], v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = act_f(va[j], ACT_SILU) * vb[j];
+    if (p > 0.f) v = drop4(v, seed, stream, (unsigned long long)i, p, inv_keep);
+    y[i] = v;
+  }
+}
+__global__ void swiglu_bwd_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__ a, const f32x4* __restrict__ b,
+                                  float p, unsigned long long seed, unsigned long long stream, long long n4,
+                                  f32x4* __restrict__ da, f32x4* __restrict__ db) {
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 g = dy[i];
+    if (p > 0.f) g = drop4(g, seed, stream, (unsigned long long)i, p, inv_keep);
+    f32x4 va = a[i], vb = b[i], ga, gb;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ga[j] = g[j] * vb[j] * act_df(va[j], ACT_SILU);
+      gb[j] = g[j] * act_f(va[j], ACT_SILU);
+    }
+    da[i] = ga; db[i] = gb;
+  }
+}
+
+// gated residual: y = x + sigmoid(gz) * drop(a)   (ligr.py:99-100, 104-105)
+__global__ void gate_fwd_kernel(const f32x4* __restrict__ x, const f32x4* __restrict__ gz, const f32x4* __restrict__ a,
+                                float p, unsigned long long seed, unsigned long long stream, long long n4,
+                                f32x4* __restrict__ y) {
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 va = a[i];
+    if (p > 0.f) va = drop4(va, seed, stream, (unsigned long long)i, p, inv_keep);
+    f32x4 vx = x[i], vg = gz[i], v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = vx[j] + act_f(vg[j], ACT_SIGMOID) * va[j];
+    y[i] = v;
+  }
+}
+// dgz = dy * drop(a) * s(1-s);  da = drop(dy * s)   (dx = dy is returned by the caller as-is)
+__global__ void gate_bwd_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__ gz, const f32x4* __restrict__ a,
+                                float p, unsigned long long seed, unsigned long long stream, long long n4,
+                                f32x4* __restrict__ dgz, f32x4* __restrict__ da) {
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 g = dy[i], vg = gz[i], va = a[i], o1, o2;
+    if (p > 0.f) va = drop4(va, seed, stream, (unsigned long long)i, p, inv_keep);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float s = act_f(vg[j], ACT_SIGMOID);
+      o1[j] = g[j] * va[j] * s * (1.f - s);
+      o2[j] = g[j] * s;
+    }
+    if (p > 0.f) o2 = drop4(o2, seed, stream, (unsigned long long)i, p, inv_keep);
+    dgz[i] = o1; da[i] = o2;
+  }
+}
+
+// y = a*alpha + b (residual add); b may be null
+__global__ void axpy_kernel(const f32x4* __restrict__ a, float alpha, const f32x4* __restrict__ b, long long n4,
+                            f32x4* __restrict__ y) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 v = a[i] * alpha;
+    if (b) v += b[i];
+    y[i] = v;
+  }
+}
+// y = a * b (* rowmask)
+__global__ void mul_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b, const long long* __restrict__ ids,
+                           int d4, long long n4, f32x4* __restrict__ y) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 v = a[i];
+    if (b) v *= b[i];
+    if (ids && ids[i / d4] == 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    y[i] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K13 Adam on flat buffers
+// ---------------------------------------------------------------------------------------------------
+__global__ void adam_kernel(f32x4* __restrict__ p, const f32x4* __restrict__ g, f32x4* __restrict__ m, f32x4* __restrict__ v,
+                            long long n4, float lr_bc1, float inv_sqrt_bc2, float b1, float b2, float eps,
+                            float grad_scale) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 gg = g[i] * grad_scale, mm = m[i], vv = v[i], pp = p[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mm[j] = b1 * mm[j] + (1.f - b1) * gg[j];
+      vv[j] = b2 * vv[j] + (1.f - b2) * gg[j] * gg[j];
+      const float denom = sqrtf(vv[j]) * inv_sqrt_bc2 + eps;
+      pp[j] -= lr_bc1 * (mm[j] / denom);
+    }
+    m[i] = mm; v[i] = vv; p[i] = pp;
+  }
+}
+
+inline int stream_grid(long long n4) {
+  long long b = (n4 + 255) / 256;
+  long long cap = (long long)rt_num_cus() * 8;
+  return (int)(b < cap ? (b > 0 ? b : 1) : cap);
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_embed_fwd(const int64_t* ids, const float* table, const float* pos, float scale, int32_t M, int32_t L,
+                 int32_t d, float p, uint64_t seed, uint64_t stream_id, float* out, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (M <= 0) return RT_OK;
+  if ((d & 3) != 0 || L <= 0) return RT_ERR_INVALID_ARG;
+  embed_fwd_kernel<<<(M + 3) / 4, 256, 0, stream>>>(reinterpret_cast<const long long*>(ids), table, pos, scale, M, L, d, p,
+                                                     seed, stream_id, out);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+int rt_embed_bwd(const int64_t* ids, const float* gout, float scale, int32_t M, int32_t L, int32_t d, float p,
+                 uint64_t seed, uint64_t stream_id, float* gtable, float* gpos, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (M <= 0) return RT_OK;
+  if ((d & 3) != 0 || L <= 0) return RT_ERR_INVALID_ARG;
+  embed_bwd_kernel<<<(M + 3) / 4, 256, 0, stream>>>(reinterpret_cast<const long long*>(ids), gout, scale, M, L, d, p, seed,
+                                                     stream_id, gtable, gpos);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+int rt_layernorm_fwd(const float* x, const float* w, const float* b, float eps, int32_t M, int32_t d, float* y,
+                     float* mean, float* rstd, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (M <= 0) return RT_OK;
+  if ((d & 3) != 0) return RT_ERR_INVALID_ARG;
+  layernorm_fwd_kernel<<<(M + 3) / 4, 256, 0, stream>>>(x, w, b, eps, M, d, y, mean, rstd);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+int rt_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rstd, int32_t M,
+                     int32_t d, float* dx, float* dw, float* db, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (M <= 0) return RT_OK;
+  if ((d & 3) != 0 || d > 8192) return RT_ERR_INVALID_ARG;
+  int blocks = rt_num_cus() * 2;
+  int rpb = (M + blocks - 1) / blocks;
+  if (rpb < 4) rpb = 4;
+  blocks = (M + rpb - 1) / rpb;
+  layernorm_bwd_kernel<<<blocks, 256, 2 * d * sizeof(float), stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, dw, db);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+int rt_act_dropout_fwd(const float* z, int32_t kind, float p, uint64_t seed, uint64_t stream_id, int64_t n, float* y,
+                       hipStream_t stream) {
+  (void)hipGetLastError();
+  if (n <= 0) return RT_OK;
+  if ((n & 3) != 0) return RT_ERR_INVALID_ARG;
+  act_dropout_fwd_kernel<<<stream_grid(n / 4), 256, 0, stream>>>(reinterpret_cast<const f32x4*>(z), kind, p, seed, stream_id,
+                                                                 n / 4, reinterpret_cast<f32x4*>(y));
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+int rt_act_dropout_bwd(const float* dy, const float* z, int32_t kind, float p, uint64_t seed, uint64_t stream_id,
+                       int64_t n, float* dz, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (n <= 0) return RT_OK;
+  if ((n & 3) != 0) return RT_ERR_INVALID_ARG;
+  act_dropout_bwd_kernel<<<stream_grid(n / 4), 256, 0, stream>>>(reinterpret_cast<const f32x4*>(dy),
+                                                                 reinterpret_cast<const f32x4*>(z), kind, p, seed, stream_id,
+                                                                 n / 4, reinterpret_cast<f32x4*>(dz));
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+int rt_swiglu_fwd(const float* a, const float* b, float p, uint64_t seed, uint64_t stream_id, int64_t n, float* y,
+                  hipStream_t stream) {
+  (void)hipGetLastError();
+  if (n <= 0) return RT_OK;
+  if ((n & 3) != 0) return RT_ERR_INVALID_ARG;
+  swiglu_fwd_kernel<<<stream_grid(n / 4), 256, 0, stream>>>(reinterpret_cast<const f32x4*>(a), reinterpret_cast<const f32x4*>(b),
+                                                            p, seed, stream_id, n / 4, reinterpret_cast<f32x4*>(y));
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+int rt_swiglu_bwd(const float* dy, const float* a, const float* b, float p, uint64_t seed, uint64_t stream_id, int64_t n,
+                  float* da, float* db, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (n <= 0) return RT_OK;
+  if ((n & 3) != 0) return RT_ERR_INVALID_ARG;
+  swiglu_bwd_kernel<<<stream_grid(n / 4), 256, 0, stream>>>(reinterpret_cast<const f32x4*>(dy), reinterpret_cast<const f32x4*>(a),
+                                                            reinterpret_cast<const f32x4*>(b), p, seed, stream_id, n / 4,
+                                                            reinterpret_cast<f32x4*>(da), reinterpret_cast<f32x4*>(db));
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+int rt_gate_fwd(const float* x, const float* gz, const float* a, float p, uint64_t seed, uint64_t stream_id, int64_t n,
+                float* y, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (n <= 0) return RT_OK;
+  if ((n & 3) != 0) return RT_ERR_INVALID_ARG;
+  gate_fwd_kernel<<<stream_grid(n / 4), 256, 0, stream>>>(reinterpret_cast<const f32x4*>(x), reinterpret_cast<const f32x4*>(gz),
+                                                          reinterpret_cast<const f32x4*>(a), p, seed, stream_id, n / 4,
+                                                          reinterpret_cast<f32x4*>(y));
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+int rt_gate_bwd(const float* dy, const float* gz, const float* a, float p, uint64_t seed, uint64_t stream_id, int64_t n,
+                float* dgz, float* da, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (n <= 0) return RT_OK;
+  if ((n & 3) != 0) return RT_ERR_INVALID_ARG;
+  gate_bwd_kernel<<<stream_grid(n / 4), 256, 0, stream>>>(reinterpret_cast<const f32x4*>(dy), reinterpret_cast<const f32x4*>(gz),
+                                                          reinterpret_cast<const f32x4*>(a), p, seed, stream_id, n / 4,
+                                                          reinterpret_cast<f32x4*>(dgz), reinterpret_cast<f32x4*>(da));
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+int rt_axpy(const float* a, float alpha, const float* b, int64_t n, float* y, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (n <= 0) return RT_OK;
+  if ((n & 3) != 0) return RT_ERR_INVALID_ARG;
+  axpy_kernel<<<stream_grid(n / 4), 256, 0, stream>>>(reinterpret_cast<const f32x4*>(a), alpha, reinterpret_cast<const f32x4*>(b),
+                                                      n / 4, reinterpret_cast<f32x4*>(y));
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+// y = a * b * (ids[row] != 0);  b and ids are optional (null)
+int rt_mul_mask(const float* a, const float* b, const int64_t* ids, int32_t d, int64_t n, float* y, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (n <= 0) return RT_OK;
+  if ((n & 3) != 0 || (d & 3) != 0) return RT_ERR_INVALID_ARG;
+  mul_kernel<<<stream_grid(n / 4), 256, 0, stream>>>(reinterpret_cast<const f32x4*>(a), reinterpret_cast<const f32x4*>(b),
+                                                     reinterpret_cast<const long long*>(ids), d / 4, n / 4,
+                                                     reinterpret_cast<f32x4*>(y));
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+// One Adam step over flat fp32 buffers (n padded to a multiple of 4).  step >= 1.
+int rt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, float lr, float beta1, float beta2,
+                 float eps, float grad_scale, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (n <= 0) return RT_OK;
+  if ((n & 3) != 0 || step < 1) return RT_ERR_INVALID_ARG;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  adam_kernel<<<stream_grid(n / 4), 256, 0, stream>>>(reinterpret_cast<f32x4*>(p), reinterpret_cast<const f32x4*>(g),
+                                                      reinterpret_cast<f32x4*>(m), reinterpret_cast<f32x4*>(v), n / 4,
+                                                      (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, grad_scale);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,163 @@
+"""Training / inference glue of the transformer models on the HIP engine — mirror of the reference's
+`TransformerLightningModule` (rectools/models/nn/transformers/lightning.py:259-449) without PyTorch-Lightning.
+
+  * `training_loss(batch)`      == `training_step` (lightning.py:311-321): logits / logits_t -> loss
+  * `batch_logits(batch)`       == `get_batch_logits` (lightning.py:301-309) — parity / validation only
+  * `FlatAdam`                  == `configure_optimizers` (lightning.py:214-218): dense Adam(lr, betas=(0.9,0.98)),
+                                   as ONE fused kernel over a flat parameter buffer; with world_size > 1 the flat
+                                   gradient is summed with ONE RCCL all-reduce (DDP's averaging is folded into the
+                                   Adam kernel's grad_scale)
+  * `xavier_normal_init`        == `_xavier_normal_init` (lightning.py:366-369)
+"""
+from __future__ import annotations
+
+import typing as tp
+
+import torch
+from torch import nn
+
+from . import ops
+from .nn import TransformerTorchBackbone
+from .rank import Distance
+
+Batch = tp.Dict[str, torch.Tensor]
+LOSSES = ("softmax", "BCE", "gBCE", "sampled_softmax")
+
+
+def requires_negatives(loss: str) -> tp.Optional[bool]:
+    """lightning.py:115-124"""
+    if loss == "softmax":
+        return False
+    if loss in ("BCE", "gBCE", "sampled_softmax"):
+        return True
+    return None
+
+
+def xavier_normal_init(model: nn.Module) -> None:
+    for _, param in model.named_parameters():
+        if param.data.dim() > 1:
+            torch.nn.init.xavier_normal_(param.data)
+
+
+def gbce_beta(n_negatives: int, n_items: int, gbce_t: float) -> float:
+    """lightning.py:170-177: alpha = N / (n_items - 1); beta = alpha * (t * (1 - 1/alpha) + 1/alpha)."""
+    alpha = n_negatives / (n_items - 1)
+    return alpha * (gbce_t * (1 - 1 / alpha) + 1 / alpha)
+
+
+class TransformerLossModule(nn.Module):
+    """Backbone + loss.  `n_item_extra_tokens` real-item offset is only needed for gBCE (lightning.py:202)."""
+
+    def __init__(self, torch_model: TransformerTorchBackbone, loss: str = "softmax", n_negatives: tp.Optional[int] = None,
+                 gbce_t: float = 0.2, logits_t: float = 1.0, n_item_extra_tokens: int = 1) -> None:
+        super().__init__()
+        if loss not in LOSSES:
+            raise ValueError(f"loss {loss} is not supported")  # lightning.py:328
+        self.torch_model = torch_model
+        self.loss = loss
+        self.n_negatives = n_negatives
+        self.gbce_t = gbce_t
+        self.logits_t = logits_t
+        self.n_item_extra_tokens = n_item_extra_tokens
+
+    @property
+    def cosine(self) -> bool:
+        return self.torch_model.similarity_module.distance == Distance.COSINE
+
+    def _loss_from_sessions(self, sess2d: torch.Tensor, y: torch.Tensor, w: torch.Tensor,
+                            negatives: tp.Optional[torch.Tensor]) -> tp.Tuple[torch.Tensor, tp.Optional[torch.Tensor]]:
+        table = self.torch_model.item_model.table
+        y = y.reshape(-1)
+        w = w.reshape(-1).contiguous()
+        if self.loss == "softmax":
+            if self.cosine:
+                sess2d, table = ops.l2norm(sess2d), ops.l2norm(table)
+            act = torch.nonzero(y, as_tuple=False).reshape(-1)  # positions with a target (ignore_index = 0)
+            return ops.softmax_loss(sess2d, table, act, y[act].contiguous(), w[act].contiguous(), self.logits_t), None
+        kind = {"BCE": ops.LOSS_BCE, "gBCE": ops.LOSS_GBCE, "sampled_softmax": ops.LOSS_SAMPLED_SOFTMAX}[self.loss]
+        beta = 0.0
+        if self.loss == "gBCE":
+            n_items = table.shape[0] - self.n_item_extra_tokens
+            beta = gbce_beta(int(negatives.shape[-1]), n_items, self.gbce_t)
+        return ops.sampled_loss(sess2d, table, y, negatives, w, kind, self.cosine, self.logits_t, beta)
+
+    def training_loss(self, batch: Batch) -> torch.Tensor:
+        sess = self.torch_model.encode_sessions(batch)
+        B, L, d = sess.shape
+        loss, _ = self._loss_from_sessions(sess.view(B * L, d), batch["y"], batch["yw"], batch.get("negatives"))
+        return loss
+
+    def validation_loss(self, batch: Batch) -> torch.Tensor:
+        """Last position only (lightning.py:340-349): y, yw [B,1]; negatives [B,1,N]."""
+        sess = self.torch_model.encode_sessions(batch)
+        last = sess[:, -1, :]
+        loss, _ = self._loss_from_sessions(last, batch["y"], batch["yw"], batch.get("negatives"))
+        return loss
+
+    def batch_logits(self, batch: Batch) -> torch.Tensor:
+        """[B, L, 1+N] (sampled losses) — the values the reference's get_batch_logits returns; parity checks only."""
+        if self.loss == "softmax":
+            raise NotImplementedError("full-catalog logits are never materialised for all positions; use training_loss")
+        sess = self.torch_model.encode_sessions(batch)
+        B, L, d = sess.shape
+        _, logits = self._loss_from_sessions(sess.view(B * L, d), batch["y"], batch["yw"], batch["negatives"])
+        return logits.view(B, L, -1)
+
+
+class FlatAdam:
+    """All parameters (and gradients, Adam moments) live in flat fp32 buffers; one kernel per step."""
+
+    def __init__(self, module: nn.Module, lr: float, betas: tp.Tuple[float, float] = (0.9, 0.98), eps: float = 1e-8) -> None:
+        params = [p for p in module.parameters() if p.requires_grad]
+        if not params:
+            raise ValueError("no parameters to optimise")
+        dev = params[0].device
+        sizes = [(p.numel() + 3) // 4 * 4 for p in params]  # 16-byte aligned segments
+        total = sum(sizes)
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.params = params
+        self._grad_views = []
+        ofs = 0
+        for p, sz in zip(params, sizes):
+            view = self.flat_p[ofs:ofs + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            gview = self.flat_g[ofs:ofs + p.numel()].view_as(p)
+            p.grad = gview
+            self._grad_views.append(gview)
+            ofs += sz
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.step_count = 0
+
+    def zero_grad(self) -> None:
+        self.flat_g.zero_()
+        for p, g in zip(self.params, self._grad_views):
+            p.grad = g  # autograd accumulates in place into the flat gradient buffer
+
+    def _sync_grads(self) -> None:
+        for p, g in zip(self.params, self._grad_views):
+            if p.grad is not None and p.grad.data_ptr() != g.data_ptr():
+                g.copy_(p.grad)
+                p.grad = g
+
+    def step(self, world_size: int = 1) -> None:
+        self._sync_grads()
+        scale = 1.0
+        if world_size > 1:
+            import torch.distributed as dist
+
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)  # ONE collective per step (RCCL over xGMI)
+            scale = 1.0 / world_size                           # DDP averages gradients
+        self.step_count += 1
+        ops._c("rt_adam_step", self.flat_p, self.flat_g, self.m, self.v, self.flat_p.numel(), self.step_count, float(self.lr),
+               float(self.betas[0]), float(self.betas[1]), float(self.eps), float(scale))
+
+    def state_dict(self) -> tp.Dict[str, tp.Any]:
+        return {"m": self.m.clone(), "v": self.v.clone(), "step": self.step_count, "lr": self.lr, "betas": self.betas,
+                "eps": self.eps}
+
+    def load_state_dict(self, sd: tp.Dict[str, tp.Any]) -> None:
+        self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.step_count = int(sd["step"])

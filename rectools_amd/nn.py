@@ -1,0 +1,397 @@
+"""Torch-model mirror of the reference's transformer backbone, computing with the HIP ops (`rectools_amd.ops`).
+
+Module / parameter names and shapes are IDENTICAL to the reference, so `state_dict`s
+interchange with `rectools.models.nn.transformers.*`:
+
+  item_model.item_net_blocks.0.ids_emb.weight            IdEmbeddingsItemNet            item_net.py:236-281
+  pos_encoding_layer.pos_emb.weight                      LearnableInversePositionalEncoding  net_blocks.py:346-400
+  transformer_layers.transformer_blocks.i.*              SASRecTransformerLayers        sasrec.py:169-304
+                                                         PreLNTransformerLayers         net_blocks.py:188-335
+                                                         LiGRLayers                     ligr.py:25-191
+  transformer_layers.stu_blocks.i.*                      STULayers                      hstu.py:156-399
+  similarity_module                                      DistanceSimilarityModule       similarity.py:67-140
+
+What differs from the reference's plug-in signatures: layer stacks receive the flattened `[B*L, d]` activations
+plus the item ids (masks are derived in-kernel from ids and indices; no `[B*H, L, L]` mask tensor is ever
+built, torch_backbone.py:172-218,249-257), and the item table is read in place (no `get_all_embeddings()` copy,
+item_net.py:361-368).
+"""
+from __future__ import annotations
+
+import math
+import typing as tp
+
+import torch
+from torch import nn
+
+from . import ops
+from .rank import Distance
+
+Batch = tp.Dict[str, torch.Tensor]
+
+
+# ---- parameter holders with the reference's names -----------------------------------------------------
+class LinearParams(nn.Module):
+    def __init__(self, n_in: int, n_out: int, bias: bool = True) -> None:
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(n_out, n_in))
+        self.bias = nn.Parameter(torch.empty(n_out)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))  # nn.Linear default; 1-D params keep it
+        if bias:
+            bound = 1 / math.sqrt(n_in)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x: torch.Tensor, residual: tp.Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
+        return ops.linear(x, self.weight, self.bias, residual, relu)
+
+
+class LayerNormParams(nn.Module):
+    def __init__(self, d: int, eps: float = 1e-5) -> None:
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(d))
+        self.bias = nn.Parameter(torch.zeros(d))
+        self.eps = eps
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return ops.layer_norm(x, self.weight, self.bias, self.eps)
+
+
+class MultiheadAttnParams(nn.Module):
+    """Parameters of torch.nn.MultiheadAttention(d, H, batch_first=True) (packed in_proj), SURVEY.md A.4."""
+
+    def __init__(self, d: int, n_heads: int) -> None:
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d, d))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d))
+        self.out_proj = LinearParams(d, d)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.zeros_(self.out_proj.bias)
+        self.d, self.n_heads = d, n_heads
+
+    def forward(self, q_in: torch.Tensor, kv_in: tp.Optional[torch.Tensor], ids: torch.Tensor, B: int, L: int,
+                causal: bool, keypad: bool, p: float, residual: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
+        d = self.d
+        if kv_in is None:  # self-attention on one input: one packed GEMM
+            qkv = ops.linear(q_in, self.in_proj_weight, self.in_proj_bias)
+            q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+        else:  # SASRec: Q from LN(x), K/V from x (sasrec.py:221-224)
+            q = ops.linear(q_in, self.in_proj_weight[:d], self.in_proj_bias[:d])
+            kv = ops.linear(kv_in, self.in_proj_weight[d:], self.in_proj_bias[d:])
+            k, v = kv[:, :d], kv[:, d:]
+        o = ops.mha(q, k, v, ids, B, self.n_heads, L, causal, keypad, p)
+        return self.out_proj(o, residual=residual)
+
+
+# ---- item net / positions -----------------------------------------------------------------------------
+class EmbeddingParams(nn.Module):
+    def __init__(self, n: int, d: int) -> None:
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(n, d))
+        nn.init.normal_(self.weight)
+
+
+class IdEmbeddingsItemNet(nn.Module):
+    """Item embeddings based on item ids only (item_net.py:236-281)."""
+
+    def __init__(self, n_factors: int, n_items: int, dropout_rate: float = 0.0, **kwargs: tp.Any) -> None:
+        super().__init__()
+        self.n_items = n_items
+        self.ids_emb = EmbeddingParams(n_items, n_factors)
+
+    @property
+    def out_dim(self) -> int:
+        return self.ids_emb.weight.shape[1]
+
+
+class SumOfEmbeddingsConstructor(nn.Module):
+    """Item-net constructor (item_net.py:451-487).  Only id embeddings are accelerated (one block)."""
+
+    def __init__(self, n_items: int, item_net_blocks: tp.Sequence[nn.Module]) -> None:
+        super().__init__()
+        if len(item_net_blocks) != 1 or not isinstance(item_net_blocks[0], IdEmbeddingsItemNet):
+            raise NotImplementedError("the MI355X engine implements IdEmbeddingsItemNet item nets only")
+        self.n_items = n_items
+        self.n_item_blocks = 1
+        self.item_net_blocks = nn.ModuleList(item_net_blocks)
+
+    @property
+    def table(self) -> torch.Tensor:
+        return self.item_net_blocks[0].ids_emb.weight
+
+    def get_all_embeddings(self) -> torch.Tensor:
+        """The table itself (the reference re-materialises it with a gather every call, item_net.py:361-368)."""
+        return self.table
+
+
+class LearnableInversePositionalEncoding(nn.Module):
+    def __init__(self, use_pos_emb: bool, session_max_len: int, n_factors: int, use_scale_factor: bool = False,
+                 **kwargs: tp.Any) -> None:
+        super().__init__()
+        self.pos_emb = EmbeddingParams(session_max_len, n_factors) if use_pos_emb else None
+        self.use_scale_factor = use_scale_factor
+
+
+# ---- feed-forward networks ----------------------------------------------------------------------------
+class PointWiseFeedForward(nn.Module):
+    def __init__(self, n_factors: int, n_factors_ff: int, dropout_rate: float, activation: str, bias: bool = True) -> None:
+        super().__init__()
+        self.ff_linear_1 = LinearParams(n_factors, n_factors_ff, bias)
+        self.ff_linear_2 = LinearParams(n_factors_ff, n_factors, bias)
+        self.activation = activation
+        self.p = dropout_rate
+
+    def forward(self, x: torch.Tensor, residual: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
+        if self.activation == "relu":
+            h = self.ff_linear_1(x, relu=True)
+            h = ops.dropout(h, self.p if self.training else 0.0)
+        else:
+            z = self.ff_linear_1(x)
+            h = ops.act_dropout(z, ops.ACT_GELU, self.p if self.training else 0.0)
+        return self.ff_linear_2(h, residual=residual)
+
+
+class SwigluFeedForward(nn.Module):
+    def __init__(self, n_factors: int, n_factors_ff: int, dropout_rate: float, bias: bool = True) -> None:
+        super().__init__()
+        self.ff_linear_1 = LinearParams(n_factors, n_factors_ff, bias)
+        self.ff_linear_2 = LinearParams(n_factors_ff, n_factors, bias)
+        self.ff_linear_3 = LinearParams(n_factors, n_factors_ff, bias)
+        self.p = dropout_rate
+
+    def forward(self, x: torch.Tensor, residual: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
+        h = ops.swiglu(self.ff_linear_1(x), self.ff_linear_3(x), self.p if self.training else 0.0)
+        return self.ff_linear_2(h, residual=residual)
+
+
+def init_feed_forward(n_factors: int, ff_factors_multiplier: int, dropout_rate: float, ff_activation: str,
+                      bias: bool = True) -> nn.Module:
+    if ff_activation == "swiglu":
+        return SwigluFeedForward(n_factors, n_factors * ff_factors_multiplier, dropout_rate, bias=bias)
+    if ff_activation in ("gelu", "relu"):
+        return PointWiseFeedForward(n_factors, n_factors * ff_factors_multiplier, dropout_rate, ff_activation, bias=bias)
+    raise ValueError(f"Unsupported ff_activation: {ff_activation}")  # net_blocks.py:151
+
+
+# ---- layer stacks ---------------------------------------------------------------------------------------
+class TransformerLayersBase(nn.Module):
+    def forward(self, seqs: torch.Tensor, ids: torch.Tensor, B: int, L: int, causal: bool, keypad: bool,
+                batch: Batch) -> torch.Tensor:
+        raise NotImplementedError()
+
+
+class SASRecTransformerLayer(nn.Module):
+    def __init__(self, n_factors: int, n_heads: int, dropout_rate: float) -> None:
+        super().__init__()
+        self.multi_head_attn = MultiheadAttnParams(n_factors, n_heads)
+        self.q_layer_norm = LayerNormParams(n_factors)
+        self.ff_layer_norm = LayerNormParams(n_factors)
+        self.feed_forward = PointWiseFeedForward(n_factors, n_factors, dropout_rate, "relu")
+        self.p = dropout_rate
+
+    def forward(self, seqs, ids, B, L, causal, keypad):
+        p = self.p if self.training else 0.0
+        q = self.q_layer_norm(seqs)
+        seqs = self.multi_head_attn(q, seqs, ids, B, L, causal, keypad, p, residual=q)   # q + mha(q, x, x)
+        ff_in = self.ff_layer_norm(seqs)
+        if p > 0:
+            return ops.add(ops.dropout(self.feed_forward(ff_in), p), ff_in)
+        return self.feed_forward(ff_in, residual=ff_in)
+
+
+class SASRecTransformerLayers(TransformerLayersBase):
+    def __init__(self, n_blocks: int, n_factors: int, n_heads: int, dropout_rate: float, **kwargs: tp.Any) -> None:
+        super().__init__()
+        self.n_blocks = n_blocks
+        self.transformer_blocks = nn.ModuleList(
+            [SASRecTransformerLayer(n_factors, n_heads, dropout_rate) for _ in range(n_blocks)])
+        self.last_layernorm = LayerNormParams(n_factors, eps=1e-8)
+
+    def forward(self, seqs, ids, B, L, causal, keypad, batch):
+        for blk in self.transformer_blocks:
+            seqs = ops.mul_mask(seqs, None, ids)  # seqs *= timeline_mask (sasrec.py:300)
+            seqs = blk(seqs, ids, B, L, causal, keypad)
+        seqs = ops.mul_mask(seqs, None, ids)
+        return self.last_layernorm(seqs)
+
+
+class PreLNTransformerLayer(nn.Module):
+    def __init__(self, n_factors: int, n_heads: int, dropout_rate: float, ff_factors_multiplier: int = 4) -> None:
+        super().__init__()
+        self.multi_head_attn = MultiheadAttnParams(n_factors, n_heads)
+        self.layer_norm_1 = LayerNormParams(n_factors)
+        self.layer_norm_2 = LayerNormParams(n_factors)
+        self.feed_forward = PointWiseFeedForward(n_factors, n_factors * ff_factors_multiplier, dropout_rate, "gelu")
+        self.p = dropout_rate
+
+    def forward(self, seqs, ids, B, L, causal, keypad):
+        p = self.p if self.training else 0.0
+        h = self.layer_norm_1(seqs)
+        if p > 0:
+            seqs = ops.add(seqs, ops.dropout(self.multi_head_attn(h, None, ids, B, L, causal, keypad, p), p))
+            f = self.feed_forward(self.layer_norm_2(seqs))
+            seqs = ops.add(seqs, ops.dropout(f, p))
+            return ops.dropout(seqs, p)  # dropout_3 (net_blocks.py:260)
+        seqs = self.multi_head_attn(h, None, ids, B, L, causal, keypad, 0.0, residual=seqs)
+        return self.feed_forward(self.layer_norm_2(seqs), residual=seqs)
+
+
+class PreLNTransformerLayers(TransformerLayersBase):
+    def __init__(self, n_blocks: int, n_factors: int, n_heads: int, dropout_rate: float, ff_factors_multiplier: int = 4,
+                 **kwargs: tp.Any) -> None:
+        super().__init__()
+        self.n_blocks = n_blocks
+        self.transformer_blocks = nn.ModuleList(
+            [PreLNTransformerLayer(n_factors, n_heads, dropout_rate, ff_factors_multiplier) for _ in range(n_blocks)])
+
+    def forward(self, seqs, ids, B, L, causal, keypad, batch):
+        for blk in self.transformer_blocks:
+            seqs = blk(seqs, ids, B, L, causal, keypad)
+        return seqs
+
+
+class LiGRLayer(nn.Module):
+    def __init__(self, n_factors: int, n_heads: int, dropout_rate: float, ff_factors_multiplier: int = 4,
+                 bias_in_ff: bool = False, ff_activation: str = "swiglu") -> None:
+        super().__init__()
+        self.multi_head_attn = MultiheadAttnParams(n_factors, n_heads)
+        self.layer_norm_1 = LayerNormParams(n_factors)
+        self.layer_norm_2 = LayerNormParams(n_factors)
+        self.feed_forward = init_feed_forward(n_factors, ff_factors_multiplier, dropout_rate, ff_activation, bias_in_ff)
+        self.gating_linear_1 = LinearParams(n_factors, n_factors)
+        self.gating_linear_2 = LinearParams(n_factors, n_factors)
+        self.p = dropout_rate
+
+    def forward(self, seqs, ids, B, L, causal, keypad):
+        p = self.p if self.training else 0.0
+        h = self.layer_norm_1(seqs)
+        a = self.multi_head_attn(h, None, ids, B, L, causal, keypad, p)
+        seqs = ops.gate(seqs, self.gating_linear_1(seqs), a, p)      # seqs + sigmoid(Wg1 seqs) * drop(mha)
+        f = self.feed_forward(self.layer_norm_2(seqs))
+        return ops.gate(seqs, self.gating_linear_2(seqs), f, p)      # seqs + sigmoid(Wg2 seqs) * drop(ffn)
+
+
+class LiGRLayers(TransformerLayersBase):
+    def __init__(self, n_blocks: int, n_factors: int, n_heads: int, dropout_rate: float, ff_factors_multiplier: int = 4,
+                 ff_activation: str = "swiglu", bias_in_ff: bool = False, **kwargs: tp.Any) -> None:
+        super().__init__()
+        self.n_blocks = n_blocks
+        self.transformer_blocks = nn.ModuleList(
+            [LiGRLayer(n_factors, n_heads, dropout_rate, ff_factors_multiplier, bias_in_ff, ff_activation)
+             for _ in range(n_blocks)])
+
+    def forward(self, seqs, ids, B, L, causal, keypad, batch):
+        for blk in self.transformer_blocks:
+            seqs = blk(seqs, ids, B, L, causal, keypad)
+        return seqs
+
+
+class RelativeAttentionBias(nn.Module):
+    """Parameter holder for the HSTU relative bias (hstu.py:47-82); the bias itself is computed in-kernel."""
+
+    def __init__(self, session_max_len: int, relative_time_attention: bool, relative_pos_attention: bool,
+                 num_buckets: int = 128) -> None:
+        super().__init__()
+        if num_buckets != 128:
+            raise NotImplementedError("the HIP HSTU kernel is built for num_buckets = 128")
+        if relative_time_attention:
+            self.time_weights = nn.Parameter(torch.empty(num_buckets + 1).normal_(mean=0, std=0.02))
+        if relative_pos_attention:
+            self.pos_weights = nn.Parameter(torch.empty(2 * session_max_len - 1).normal_(mean=0, std=0.02))
+        self.relative_time_attention = relative_time_attention
+        self.relative_pos_attention = relative_pos_attention
+
+
+class STULayer(nn.Module):
+    def __init__(self, n_factors: int, n_heads: int, linear_hidden_dim: int, attention_dim: int, session_max_len: int,
+                 relative_time_attention: bool, relative_pos_attention: bool, attn_dropout_rate: float, dropout_rate: float,
+                 epsilon: float) -> None:
+        super().__init__()
+        if linear_hidden_dim != attention_dim:
+            raise NotImplementedError("the HIP HSTU kernel needs linear_hidden_dim == attention_dim")
+        self.rel_attn = RelativeAttentionBias(session_max_len, relative_time_attention, relative_pos_attention)
+        self.n_heads, self.hd, self.L = n_heads, attention_dim, session_max_len
+        self.uvqk_proj = nn.Parameter(torch.empty(n_factors, 4 * n_heads * attention_dim))
+        nn.init.normal_(self.uvqk_proj, std=0.02)
+        self.output_mlp = LinearParams(n_heads * linear_hidden_dim, n_factors)
+        self.norm_input = LayerNormParams(n_factors, eps=epsilon)
+        self.norm_attn_output = LayerNormParams(n_heads * linear_hidden_dim, eps=epsilon)
+        self.p_mlp, self.p_attn = dropout_rate, attn_dropout_rate
+
+    def forward(self, seqs, ids, B, L, batch, thr):
+        hh = self.n_heads * self.hd
+        normed = ops.mul_mask(self.norm_input(seqs), None, ids)
+        uvqk = ops.act_dropout(ops.matmul_nn(normed, self.uvqk_proj), ops.ACT_SILU, 0.0)
+        u, v, q, k = uvqk[:, :hh], uvqk[:, hh:2 * hh], uvqk[:, 2 * hh:3 * hh], uvqk[:, 3 * hh:]
+        tw = self.rel_attn.time_weights if self.rel_attn.relative_time_attention else None
+        pw = self.rel_attn.pos_weights if self.rel_attn.relative_pos_attention else None
+        attn = ops.hstu_attn(q, k, v, tw, pw, ids, batch.get("unix_ts") if tw is not None else None, thr, B, self.n_heads, L)
+        attn = ops.dropout(attn, self.p_attn if self.training else 0.0)
+        o_in = ops.mul_mask(u, self.norm_attn_output(attn), ids)          # u * LN(attn) * mask
+        o_in = ops.dropout(o_in, self.p_mlp if self.training else 0.0)
+        return self.output_mlp(o_in, residual=seqs)
+
+
+class STULayers(TransformerLayersBase):
+    def __init__(self, n_blocks: int, n_factors: int, n_heads: int, linear_hidden_dim: int, attention_dim: int,
+                 session_max_len: int, relative_time_attention: bool, relative_pos_attention: bool,
+                 attn_dropout_rate: float = 0.0, dropout_rate: float = 0.2, epsilon: float = 1e-6, **kwargs: tp.Any) -> None:
+        super().__init__()
+        self.n_blocks = n_blocks
+        self.stu_blocks = nn.ModuleList([
+            STULayer(n_factors, n_heads, linear_hidden_dim, attention_dim, session_max_len, relative_time_attention,
+                     relative_pos_attention, attn_dropout_rate, dropout_rate, epsilon) for _ in range(n_blocks)])
+        self.register_buffer("time_thr", ops.hstu_time_thresholds(), persistent=False)
+
+    def forward(self, seqs, ids, B, L, causal, keypad, batch):
+        for blk in self.stu_blocks:
+            seqs = ops.mul_mask(seqs, None, ids)
+            seqs = blk(seqs, ids, B, L, batch, self.time_thr)
+        return ops.mul_mask(seqs, None, ids)
+
+
+# ---- similarity + backbone ------------------------------------------------------------------------------
+class DistanceSimilarityModule(nn.Module):
+    dist_available = [Distance.DOT, Distance.COSINE]
+
+    def __init__(self, distance: str = "dot", **kwargs: tp.Any) -> None:
+        super().__init__()
+        if distance not in self.dist_available:
+            raise ValueError("`dist` can only be either `dot` or `cosine`.")  # similarity.py:79-80
+        self.distance = Distance(distance)
+
+    def session_tower_forward(self, session_embs: torch.Tensor) -> torch.Tensor:
+        return session_embs
+
+    def item_tower_forward(self, item_embs: torch.Tensor) -> torch.Tensor:
+        return item_embs
+
+
+class TransformerTorchBackbone(nn.Module):
+    """encode_sessions / training loss of the reference backbone (torch_backbone.py:118-286) on the HIP ops."""
+
+    def __init__(self, n_heads: int, dropout_rate: float, item_model: SumOfEmbeddingsConstructor,
+                 pos_encoding_layer: LearnableInversePositionalEncoding, transformer_layers: TransformerLayersBase,
+                 similarity_module: DistanceSimilarityModule, use_causal_attn: bool = True,
+                 use_key_padding_mask: bool = False, **kwargs: tp.Any) -> None:
+        super().__init__()
+        self.item_model = item_model
+        self.pos_encoding_layer = pos_encoding_layer
+        self.transformer_layers = transformer_layers
+        self.similarity_module = similarity_module
+        self.use_causal_attn = use_causal_attn
+        self.use_key_padding_mask = use_key_padding_mask
+        self.n_heads = n_heads
+        self.dropout_rate = dropout_rate
+
+    def encode_sessions(self, batch: Batch, item_embs: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
+        """-> [B, L, d] session encodings (torch_backbone.py:220-260)."""
+        x = batch["x"]
+        B, L = x.shape
+        table = self.item_model.table if item_embs is None else item_embs
+        d = table.shape[1]
+        pos = self.pos_encoding_layer.pos_emb.weight if self.pos_encoding_layer.pos_emb is not None else None
+        scale = float(d) ** 0.5 if self.pos_encoding_layer.use_scale_factor else 1.0
+        ids = x.reshape(-1)
+        seqs = ops.embed(table, pos, ids, L, scale, self.dropout_rate if self.training else 0.0)
+        seqs = self.transformer_layers(seqs, ids, B, L, self.use_causal_attn, self.use_key_padding_mask, batch)
+        return seqs.view(B, L, d)

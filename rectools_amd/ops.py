@@ -1,0 +1,529 @@
+"""torch.autograd bindings of the HIP kernels (C ABI: include/rectools_hip.h).
+
+PyTorch is plumbing here: it owns the buffers (caching allocator), the stream and the autograd tape; every
+forward/backward below is one or a few `rt_*` launches on torch's current HIP stream.  There is no eager /
+CPU fallback: tensors must be fp32, contiguous where stated, and on a HIP device.
+
+All activations are 2-D `[M, d]` (M = batch * session_max_len).
+"""
+from __future__ import annotations
+
+import math
+import typing as tp
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_SILU, ACT_SIGMOID = 0, 1, 2, 3, 4
+LOSS_BCE, LOSS_GBCE, LOSS_SAMPLED_SOFTMAX = 0, 1, 2
+
+
+def _c(name: str, *args: tp.Any) -> None:
+    """Call `rt_<name>(*args, stream)`; tensors are passed as raw device pointers."""
+    lib = _lib.load()
+    conv = [a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args]
+    status = getattr(lib, name)(*conv, _lib.current_stream())
+    _lib.check(status, name)
+
+
+def _chk(t: torch.Tensor, what: str) -> torch.Tensor:
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise _lib.HipLibraryError(f"{what}: expected a float32 HIP tensor (no CPU fallback), got {t.dtype} on {t.device}")
+    return t
+
+
+class DropoutRng:
+    """Counter-based dropout streams: (seed, stream_id) pairs; the backward kernels regenerate the masks."""
+
+    def __init__(self, seed: int = 0) -> None:
+        self.seed = seed & 0xFFFFFFFFFFFFFFFF
+        self.step = 0
+        self._stream = 0
+
+    def next_step(self) -> None:
+        self.step += 1
+        self._stream = 0
+
+    def next(self) -> tp.Tuple[int, int]:
+        self._stream += 1
+        return (self.seed + 0x9E3779B97F4A7C15 * self.step) & 0xFFFFFFFFFFFFFFFF, self._stream
+
+
+RNG = DropoutRng(0)
+
+
+# --------------------------------------------------------------------------------------------------
+# dense
+# --------------------------------------------------------------------------------------------------
+def _gemm(A, lda, a_kc, B, ldb, b_kc, C, ldc, bias, R, ldr, M, N, K, relu=0, split_k=1) -> None:
+    _c("rt_gemm", A, lda, a_kc, B, ldb, b_kc, C, ldc, bias, R, ldr, M, N, K, relu, split_k)
+
+
+def _wgrad_splits(k_rows: int) -> int:
+    return max(1, min(128, k_rows // 256))
+
+
+class _Linear(torch.autograd.Function):
+    """y = x @ W^T (+ b) (+ residual) (relu).  x [M,K] (row stride free), W [N,K] contiguous."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, relu):
+        _chk(x, "linear")
+        M, K = x.shape
+        N = weight.shape[0]
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        _gemm(x, x.stride(0), 1, weight, weight.stride(0), 1, y, N, bias, residual,
+              0 if residual is None else residual.stride(0), M, N, K, 1 if relu else 0)
+        ctx.save_for_backward(x, weight, y if relu else None)
+        ctx.has_bias, ctx.has_res, ctx.relu = bias is not None, residual is not None, relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        M, K = x.shape
+        N = weight.shape[0]
+        dy = dy.contiguous()
+        if ctx.relu:
+            dz = torch.empty_like(dy)
+            _c("rt_act_dropout_bwd", dy, y, ACT_RELU, 0.0, 0, 0, dy.numel(), dz)
+            dy = dz
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+            _gemm(dy, N, 1, weight, weight.stride(0), 0, dx, K, None, None, 0, M, K, N)  # dx = dy @ W
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros((N, K), dtype=torch.float32, device=dy.device)
+            _gemm(dy, N, 0, x, x.stride(0), 0, dw, K, None, None, 0, N, K, M, 0, _wgrad_splits(M))  # dW = dy^T @ x
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.zeros((N,), dtype=torch.float32, device=dy.device)
+            _c("rt_colsum", dy, N, M, N, db)
+        dres = dy if (ctx.has_res and ctx.needs_input_grad[3]) else None
+        return dx, dw, db, dres, None
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: tp.Optional[torch.Tensor] = None,
+           residual: tp.Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
+    return _Linear.apply(x, weight, bias, residual, relu)
+
+
+class _MatmulNN(torch.autograd.Function):
+    """y = x @ P with P [K,N] contiguous (hstu.py:258, `torch.matmul(normed_x, self.uvqk_proj)`)."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        M, K = x.shape
+        N = p.shape[1]
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        _gemm(x, x.stride(0), 1, p, N, 0, y, N, None, None, 0, M, N, K)
+        ctx.save_for_backward(x, p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, p = ctx.saved_tensors
+        M, K = x.shape
+        N = p.shape[1]
+        dy = dy.contiguous()
+        dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+        _gemm(dy, N, 1, p, N, 1, dx, K, None, None, 0, M, K, N)  # dx = dy @ P^T : B(k', n) = P[k'*N + n] (kc)
+        dp = torch.zeros((K, N), dtype=torch.float32, device=dy.device)
+        _gemm(x, x.stride(0), 0, dy, N, 0, dp, N, None, None, 0, K, N, M, 0, _wgrad_splits(M))  # dP = x^T @ dy
+        return dx, dp
+
+
+def matmul_nn(x: torch.Tensor, p: torch.Tensor) -> torch.Tensor:
+    return _MatmulNN.apply(x, p)
+
+
+# --------------------------------------------------------------------------------------------------
+# row-wise
+# --------------------------------------------------------------------------------------------------
+class _Embed(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, pos, ids, L, scale, p):
+        M = ids.numel()
+        d = table.shape[1]
+        out = torch.empty((M, d), dtype=torch.float32, device=table.device)
+        seed, sid = RNG.next() if p > 0 else (0, 0)
+        _c("rt_embed_fwd", ids, table, pos, float(scale), M, L, d, float(p), seed, sid, out)
+        ctx.save_for_backward(ids)
+        ctx.meta = (table.shape, None if pos is None else pos.shape, L, scale, p, seed, sid)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (ids,) = ctx.saved_tensors
+        tshape, pshape, L, scale, p, seed, sid = ctx.meta
+        gout = gout.contiguous()
+        gtable = torch.zeros(tshape, dtype=torch.float32, device=gout.device)
+        gpos = None if pshape is None else torch.zeros(pshape, dtype=torch.float32, device=gout.device)
+        _c("rt_embed_bwd", ids, gout, float(scale), ids.numel(), L, tshape[1], float(p), seed, sid, gtable, gpos)
+        return gtable, gpos, None, None, None, None
+
+
+def embed(table: torch.Tensor, pos: tp.Optional[torch.Tensor], ids: torch.Tensor, L: int, scale: float,
+          p: float) -> torch.Tensor:
+    """[M,d] = dropout(table[ids] * scale + pos[L-1-l]); ids int64 [M] (or [B,L])."""
+    return _Embed.apply(table, pos, ids.reshape(-1), L, scale, p)
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        x = x.contiguous()
+        M, d = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty((M,), dtype=torch.float32, device=x.device)
+        rstd = torch.empty((M,), dtype=torch.float32, device=x.device)
+        _c("rt_layernorm_fwd", x, w, b, float(eps), M, d, y, mean, rstd)
+        ctx.save_for_backward(x, w, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, rstd = ctx.saved_tensors
+        M, d = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dw = torch.zeros_like(w)
+        db = torch.zeros_like(w)
+        _c("rt_layernorm_bwd", dy, x, w, mean, rstd, M, d, dx, dw, db)
+        return dx, dw, db, None
+
+
+def layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float) -> torch.Tensor:
+    return _LayerNorm.apply(x, w, b, eps)
+
+
+class _ActDropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, kind, p):
+        z = z.contiguous()
+        y = torch.empty_like(z)
+        seed, sid = RNG.next() if p > 0 else (0, 0)
+        _c("rt_act_dropout_fwd", z, kind, float(p), seed, sid, z.numel(), y)
+        ctx.save_for_backward(z)
+        ctx.meta = (kind, p, seed, sid)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (z,) = ctx.saved_tensors
+        kind, p, seed, sid = ctx.meta
+        dy = dy.contiguous()
+        dz = torch.empty_like(z)
+        _c("rt_act_dropout_bwd", dy, z, kind, float(p), seed, sid, z.numel(), dz)
+        return dz, None, None
+
+
+def act_dropout(z: torch.Tensor, kind: int, p: float) -> torch.Tensor:
+    if kind == ACT_NONE and p <= 0:
+        return z
+    return _ActDropout.apply(z, kind, p)
+
+
+def dropout(x: torch.Tensor, p: float) -> torch.Tensor:
+    return act_dropout(x, ACT_NONE, p)
+
+
+class _Swiglu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, p):
+        a, b = a.contiguous(), b.contiguous()
+        y = torch.empty_like(a)
+        seed, sid = RNG.next() if p > 0 else (0, 0)
+        _c("rt_swiglu_fwd", a, b, float(p), seed, sid, a.numel(), y)
+        ctx.save_for_backward(a, b)
+        ctx.meta = (p, seed, sid)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b = ctx.saved_tensors
+        p, seed, sid = ctx.meta
+        dy = dy.contiguous()
+        da, db = torch.empty_like(a), torch.empty_like(b)
+        _c("rt_swiglu_bwd", dy, a, b, float(p), seed, sid, a.numel(), da, db)
+        return da, db, None
+
+
+def swiglu(a: torch.Tensor, b: torch.Tensor, p: float) -> torch.Tensor:
+    return _Swiglu.apply(a, b, p)
+
+
+class _Gate(torch.autograd.Function):
+    """y = x + sigmoid(gz) * dropout(a)"""
+
+    @staticmethod
+    def forward(ctx, x, gz, a, p):
+        x, gz, a = x.contiguous(), gz.contiguous(), a.contiguous()
+        y = torch.empty_like(x)
+        seed, sid = RNG.next() if p > 0 else (0, 0)
+        _c("rt_gate_fwd", x, gz, a, float(p), seed, sid, x.numel(), y)
+        ctx.save_for_backward(gz, a)
+        ctx.meta = (p, seed, sid)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        gz, a = ctx.saved_tensors
+        p, seed, sid = ctx.meta
+        dy = dy.contiguous()
+        dgz, da = torch.empty_like(gz), torch.empty_like(a)
+        _c("rt_gate_bwd", dy, gz, a, float(p), seed, sid, gz.numel(), dgz, da)
+        return dy, dgz, da, None
+
+
+def gate(x: torch.Tensor, gz: torch.Tensor, a: torch.Tensor, p: float) -> torch.Tensor:
+    return _Gate.apply(x, gz, a, p)
+
+
+class _MulMask(torch.autograd.Function):
+    """y = a * b * (ids != 0); b / ids optional"""
+
+    @staticmethod
+    def forward(ctx, a, b, ids):
+        a = a.contiguous()
+        b = None if b is None else b.contiguous()
+        y = torch.empty_like(a)
+        _c("rt_mul_mask", a, b, ids, a.shape[1], a.numel(), y)
+        ctx.save_for_backward(a if b is not None else None, b, ids)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b, ids = ctx.saved_tensors
+        dy = dy.contiguous()
+        da = torch.empty_like(dy)
+        _c("rt_mul_mask", dy, b, ids, dy.shape[1], dy.numel(), da)
+        db = None
+        if b is not None:
+            db = torch.empty_like(dy)
+            _c("rt_mul_mask", dy, a, ids, dy.shape[1], dy.numel(), db)
+        return da, db, None
+
+
+def mul_mask(a: torch.Tensor, b: tp.Optional[torch.Tensor], ids: tp.Optional[torch.Tensor]) -> torch.Tensor:
+    return _MulMask.apply(a, b, None if ids is None else ids.reshape(-1))
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        y = torch.empty_like(a)
+        _c("rt_axpy", a, 1.0, b, a.numel(), y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    return _Add.apply(a, b)
+
+
+class _L2Norm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        M, d = x.shape
+        y = torch.empty((M, d), dtype=torch.float32, device=x.device)
+        _c("rt_l2norm_fwd", x, x.stride(0), M, d, y, d, None)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        M, d = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty((M, d), dtype=torch.float32, device=dy.device)
+        _c("rt_l2norm_bwd", dy, d, x, x.stride(0), M, d, 0, dx, d)
+        return dx
+
+
+def l2norm(x: torch.Tensor) -> torch.Tensor:
+    return _L2Norm.apply(x)
+
+
+# --------------------------------------------------------------------------------------------------
+# attention
+# --------------------------------------------------------------------------------------------------
+class _MHA(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, ids, B, H, L, causal, keypad, p):
+        d = q.shape[1]
+        hd = d // H
+        o = torch.empty((B * L, d), dtype=torch.float32, device=q.device)
+        lse = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
+        seed = 0
+        if p > 0:
+            s0, sid = RNG.next()
+            seed = (s0 + 0xD1B54A32D192ED03 * sid) & 0xFFFFFFFFFFFFFFFF
+        _c("rt_mha_fwd", q, q.stride(0), k, k.stride(0), v, v.stride(0), ids, B, H, L, hd, int(causal), int(keypad),
+           float(p), seed, o, d, lse)
+        ctx.save_for_backward(q, k, v, o, lse, ids)
+        ctx.meta = (B, H, L, hd, causal, keypad, p, seed)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse, ids = ctx.saved_tensors
+        B, H, L, hd, causal, keypad, p, seed = ctx.meta
+        d = H * hd
+        do = do.contiguous()
+        dqkv = torch.empty((3, B * L, d), dtype=torch.float32, device=do.device)
+        delta = torch.empty((B, H, L), dtype=torch.float32, device=do.device)
+        _c("rt_mha_bwd", q, q.stride(0), k, k.stride(0), v, v.stride(0), o, d, do, d, lse, ids, B, H, L, hd, int(causal),
+           int(keypad), float(p), seed, dqkv[0], d, dqkv[1], d, dqkv[2], d, delta)
+        return dqkv[0], dqkv[1], dqkv[2], None, None, None, None, None, None, None
+
+
+def mha(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, ids: torch.Tensor, B: int, H: int, L: int, causal: bool,
+        keypad: bool, p: float) -> torch.Tensor:
+    """Softmax attention over [B*L, d] projections (column slices of packed buffers are fine)."""
+    return _MHA.apply(q, k, v, ids.reshape(-1), B, H, L, causal, keypad, p)
+
+
+def hstu_time_thresholds(num_buckets: int = 128) -> torch.Tensor:
+    """thr[b] = smallest |dt| >= 0 whose reference bucket clamp(trunc(log(max(1,|dt|)) / 0.301), 0, nb) is >= b.
+
+    Computed with the reference's own float32 torch ops (hstu.py:84-86) so that bucket edges are bit-identical.
+    """
+    def bucket(x: torch.Tensor) -> torch.Tensor:
+        return torch.clamp((torch.log(torch.abs(x).clamp(min=1)) / 0.301).long(), 0, num_buckets)
+
+    thr = torch.zeros(num_buckets + 1, dtype=torch.int64)
+    for b in range(1, num_buckets + 1):
+        guess = math.exp(0.301 * b)
+        if guess > 4e18:
+            thr[b] = torch.iinfo(torch.int64).max
+            continue
+        lo, hi = max(1, int(guess * 0.5)), int(guess * 2.0) + 2
+        while int(bucket(torch.tensor([hi]))[0]) < b and hi < 4e18:
+            hi *= 2
+        while lo < hi:  # smallest x in [lo, hi] with bucket(x) >= b (bucket is monotone in x)
+            mid = (lo + hi) // 2
+            if int(bucket(torch.tensor([mid]))[0]) >= b:
+                hi = mid
+            else:
+                lo = mid + 1
+        thr[b] = lo
+    return thr
+
+
+class _HstuAttn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, time_w, pos_w, ids, ts, thr, B, H, L):
+        d = q.shape[1]
+        hd = d // H
+        o = torch.empty((B * L, d), dtype=torch.float32, device=q.device)
+        _c("rt_hstu_attn_fwd", q, q.stride(0), k, k.stride(0), v, v.stride(0), ids, ts if time_w is not None else None,
+           time_w, thr if time_w is not None else None, pos_w, B, H, L, hd, o, d)
+        ctx.save_for_backward(q, k, v, time_w, pos_w, ids, ts, thr)
+        ctx.meta = (B, H, L, hd)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, time_w, pos_w, ids, ts, thr = ctx.saved_tensors
+        B, H, L, hd = ctx.meta
+        d = H * hd
+        do = do.contiguous()
+        dqkv = torch.empty((3, B * L, d), dtype=torch.float32, device=do.device)
+        dtw = None if time_w is None else torch.zeros_like(time_w)
+        dpw = None if pos_w is None else torch.zeros_like(pos_w)
+        _c("rt_hstu_attn_bwd", q, q.stride(0), k, k.stride(0), v, v.stride(0), do, d, ids,
+           ts if time_w is not None else None, time_w, thr if time_w is not None else None, pos_w, B, H, L, hd,
+           dqkv[0], d, dqkv[1], d, dqkv[2], d, dtw, dpw)
+        return dqkv[0], dqkv[1], dqkv[2], dtw, dpw, None, None, None, None, None, None
+
+
+def hstu_attn(q, k, v, time_w, pos_w, ids, ts, thr, B: int, H: int, L: int) -> torch.Tensor:
+    return _HstuAttn.apply(q, k, v, time_w, pos_w, ids.reshape(-1), ts, thr, B, H, L)
+
+
+# --------------------------------------------------------------------------------------------------
+# losses
+# --------------------------------------------------------------------------------------------------
+class _SampledLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sess, table, y, neg, w, loss, cosine, logits_t, beta):
+        M, d = sess.shape
+        N = neg.shape[-1]
+        logits = torch.empty((M, N + 1), dtype=torch.float32, device=sess.device)
+        loss_pos = torch.empty((M,), dtype=torch.float32, device=sess.device)
+        out = torch.empty((2,), dtype=torch.float32, device=sess.device)
+        _c("rt_sampled_loss_fwd", sess, sess.stride(0), table, y, neg, w, M, N, d, loss, int(cosine), float(logits_t),
+           float(beta), logits, loss_pos)
+        _c("rt_loss_reduce", loss_pos, y, M, 0 if loss == LOSS_SAMPLED_SOFTMAX else 1, out)
+        ctx.save_for_backward(sess, table, y, neg, w, logits, out)
+        ctx.meta = (loss, cosine, logits_t, beta)
+        ctx.mark_non_differentiable(logits)
+        return out[0], logits
+
+    @staticmethod
+    def backward(ctx, gloss, _glogits):
+        sess, table, y, neg, w, logits, out = ctx.saved_tensors
+        loss, cosine, logits_t, beta = ctx.meta
+        M, d = sess.shape
+        N = neg.shape[-1]
+        d_sess = torch.empty((M, d), dtype=torch.float32, device=sess.device)
+        d_table = torch.zeros_like(table)
+        _c("rt_sampled_loss_bwd", sess, sess.stride(0), table, y, neg, w, M, N, d, loss, int(cosine), float(logits_t),
+           float(beta), logits.clone() if N + 1 > 260 else logits, out[1:], float(gloss), d_sess, d, d_table)
+        return d_sess, d_table, None, None, None, None, None, None, None
+
+
+def sampled_loss(sess: torch.Tensor, table: torch.Tensor, y: torch.Tensor, neg: torch.Tensor, w: torch.Tensor, loss: int,
+                 cosine: bool, logits_t: float, gbce_beta: float = 0.0) -> tp.Tuple[torch.Tensor, torch.Tensor]:
+    """-> (scalar loss, logits [M, 1+N] / logits_t).  y/w [M], neg [M,N]; positions with y == 0 are ignored."""
+    M = sess.shape[0]
+    return _SampledLoss.apply(sess, table, y.reshape(-1), neg.reshape(M, -1), w.reshape(-1).contiguous(), loss, cosine,
+                              logits_t, gbce_beta)
+
+
+class _SoftmaxLoss(torch.autograd.Function):
+    """Full-catalog softmax CE over the active positions (lightning.py:145-162)."""
+
+    @staticmethod
+    def forward(ctx, sess, table, act_idx, y_act, w_act, logits_t, M_total):
+        R = act_idx.numel()
+        V, d = table.shape
+        s_act = torch.empty((R, d), dtype=torch.float32, device=sess.device)
+        _c("rt_gather_rows", sess, sess.stride(0), act_idx, R, d, s_act, d)
+        logits = torch.empty((R, V), dtype=torch.float32, device=sess.device)
+        _gemm(s_act, d, 1, table, table.stride(0), 1, logits, V, None, None, 0, R, V, d)
+        loss_pos = torch.empty((R,), dtype=torch.float32, device=sess.device)
+        lse = torch.empty((R,), dtype=torch.float32, device=sess.device)
+        out = torch.empty((2,), dtype=torch.float32, device=sess.device)
+        _c("rt_softmax_ce_rows", logits, V, R, V, y_act, w_act, float(logits_t), 0, None, 1.0, loss_pos, lse)
+        _c("rt_loss_reduce", loss_pos, y_act, R, 0, out)
+        ctx.save_for_backward(s_act, table, act_idx, y_act, w_act, logits, lse, out)
+        ctx.meta = (logits_t, M_total, sess.shape[1])
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, gloss):
+        s_act, table, act_idx, y_act, w_act, logits, lse, out = ctx.saved_tensors
+        logits_t, M_total, d = ctx.meta
+        R, V = logits.shape
+        # logits := (softmax - onehot) * w * g / (norm * t), in place (the buffer is ours)
+        _c("rt_softmax_ce_rows", logits, V, R, V, y_act, w_act, float(logits_t), 1, out[1:], float(gloss), None, lse)
+        ds_act = torch.empty((R, d), dtype=torch.float32, device=logits.device)
+        _gemm(logits, V, 1, table, table.stride(0), 0, ds_act, d, None, None, 0, R, d, V)       # dS = G @ E
+        d_table = torch.zeros_like(table)
+        _gemm(logits, V, 0, s_act, d, 0, d_table, d, None, None, 0, V, d, R, 0, _wgrad_splits(R))  # dE = G^T @ S
+        d_table[0].zero_()  # padding_idx row never receives gradient (item_net.py:260-264)
+        d_sess = torch.zeros((M_total, d), dtype=torch.float32, device=logits.device)
+        _c("rt_scatter_rows", ds_act, d, act_idx, R, d, d_sess, d)
+        return d_sess, d_table, None, None, None, None, None
+
+
+def softmax_loss(sess: torch.Tensor, table: torch.Tensor, act_idx: torch.Tensor, y_act: torch.Tensor, w_act: torch.Tensor,
+                 logits_t: float) -> torch.Tensor:
+    """sess [M,d] (already L2-normalised for cosine), table [V,d]; act_idx = positions with y != 0 (int64, ascending)."""
+    return _SoftmaxLoss.apply(sess, table, act_idx, y_act, w_act, logits_t, sess.shape[0])

@@ -1,0 +1,245 @@
+"""Per-kernel GPU parity: every `rt_*` training kernel (through rectools_amd.ops / the C ABI) against the plain
+torch fp32 restatement of the same op on CPU (functions of oracle/transformer_oracle.py where they exist).
+fp32 tolerances stated per test."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import transformer_oracle as T
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def grads_of(fn, inputs):
+    ins = [t.detach().clone().requires_grad_(True) for t in inputs]
+    out = fn(*ins)
+    g = rnd(*out.shape, seed=99).to(out.device)
+    out.backward(g)
+    return out.detach(), [t.grad for t in ins]
+
+
+def close(a, b, rtol=2e-4, atol_rel=2e-5, msg=""):
+    b = b.to(a.device)
+    torch.testing.assert_close(a, b, rtol=rtol, atol=atol_rel * (float(b.abs().max()) + 1e-12), msg=lambda m: f"{msg}: {m}")
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 77, 40), (1000, 256, 256), (33, 51, 16), (130, 520, 132)])
+def test_linear_fwd_bwd(M, N, K):
+    from rectools_amd import ops
+
+    x, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2), rnd(N, seed=3), rnd(M, N, seed=4)
+    for relu, res in ((False, False), (True, False), (False, True)):
+        if relu and N % 4:  # element-wise kernels stream float4 groups: feature dims are multiples of 4 (ABI)
+            continue
+        ref, gref = grads_of(lambda x, w, b, r: (F.relu(x @ w.T + b) if relu else x @ w.T + b + (r if res else 0)), [x, w, b, r])
+        got, ggot = grads_of(lambda x, w, b, r: ops.linear(x, w, b, r if res else None, relu), [t.cuda() for t in (x, w, b, r)])
+        close(got, ref, msg=f"linear fwd relu={relu} res={res}")
+        for i, name in enumerate(("dx", "dw", "db")):
+            close(ggot[i], gref[i], rtol=1e-3, atol_rel=1e-4, msg=f"linear {name} relu={relu} res={res}")
+        if res:
+            close(ggot[3], gref[3], msg="linear dres")
+
+
+def test_linear_strided_views_and_matmul_nn():
+    from rectools_amd import ops
+
+    buf = rnd(200, 96, seed=5)
+    w = rnd(48, 32, seed=6, scale=0.3)
+    ref, gref = grads_of(lambda bf, w: bf[:, 32:64] @ w.T, [buf, w])
+    got, ggot = grads_of(lambda bf, w: ops.linear(bf[:, 32:64], w), [buf.cuda(), w.cuda()])
+    close(got, ref, msg="strided fwd"); close(ggot[0], gref[0], rtol=1e-3, msg="strided dx"); close(ggot[1], gref[1], rtol=1e-3, msg="strided dw")
+    x, p = rnd(150, 24, seed=7), rnd(24, 100, seed=8, scale=0.3)
+    ref, gref = grads_of(lambda x, p: x @ p, [x, p])
+    got, ggot = grads_of(lambda x, p: ops.matmul_nn(x, p), [x.cuda(), p.cuda()])
+    close(got, ref, msg="nn fwd"); close(ggot[0], gref[0], rtol=1e-3, msg="nn dx"); close(ggot[1], gref[1], rtol=1e-3, msg="nn dp")
+
+
+@pytest.mark.parametrize("M,d,eps", [(37, 16, 1e-5), (500, 256, 1e-8), (129, 512, 1e-6)])
+def test_layernorm(M, d, eps):
+    from rectools_amd import ops
+
+    x, w, b = rnd(M, d, seed=1) * 2 + 0.3, rnd(d, seed=2) * 0.1 + 1, rnd(d, seed=3) * 0.1
+    x[3] = 0  # a fully masked (all-zero) row, as SASRec feeds after `seqs *= timeline_mask`
+    ref, gref = grads_of(lambda x, w, b: T.layer_norm(x, w, b, eps), [x, w, b])
+    got, ggot = grads_of(lambda x, w, b: ops.layer_norm(x, w, b, eps), [x.cuda(), w.cuda(), b.cuda()])
+    close(got, ref, msg="ln fwd")
+    sane = torch.ones(M, dtype=torch.bool); sane[3] = eps >= 1e-6  # rstd of a zero row is 1e4 at eps=1e-8: dx there is noise-scaled
+    close(ggot[0][sane.cuda()], gref[0][sane], rtol=2e-3, atol_rel=2e-4, msg="ln dx")
+    close(ggot[1], gref[1], rtol=2e-3, atol_rel=2e-4, msg="ln dw"); close(ggot[2], gref[2], rtol=2e-3, msg="ln db")
+
+
+def test_embed_and_masks():
+    from rectools_amd import ops
+
+    V, L, B, d = 60, 10, 5, 32
+    table, pos = rnd(V, d, seed=1), rnd(L, d, seed=2)
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, V, (B, L), generator=g); ids[:, :3] = 0
+    for scale in (1.0, math.sqrt(d)):
+        ref, gref = grads_of(lambda t, p: T.embed_sessions({T.ITEM_EMB: t, T.POS_EMB: p}, ids, scale != 1.0).reshape(B * L, d), [table, pos])
+        got, ggot = grads_of(lambda t, p: ops.embed(t, p, ids.cuda(), L, scale, 0.0), [table.cuda(), pos.cuda()])
+        close(got, ref, msg="embed fwd")
+        gref[0][0] = 0  # nn.Embedding(padding_idx=0): PAD row gets no gradient (item_net.py:260-264)
+        close(ggot[0], gref[0], rtol=1e-3, msg="embed dtable"); close(ggot[1], gref[1], rtol=1e-3, msg="embed dpos")
+    a, b = rnd(B * L, d, seed=4), rnd(B * L, d, seed=5)
+    m = (ids.reshape(-1, 1) != 0).float()
+    ref, gref = grads_of(lambda a, b: a * b * m, [a, b])
+    got, ggot = grads_of(lambda a, b: ops.mul_mask(a, b, ids.cuda()), [a.cuda(), b.cuda()])
+    close(got, ref, msg="mulmask"); close(ggot[0], gref[0], msg="mulmask da"); close(ggot[1], gref[1], msg="mulmask db")
+
+
+@pytest.mark.parametrize("kind,fn", [(1, F.relu), (2, F.gelu), (3, F.silu), (4, torch.sigmoid)])
+def test_activations_swiglu_gate(kind, fn):
+    from rectools_amd import ops
+
+    z = rnd(64, 48, seed=kind) * 2
+    ref, gref = grads_of(lambda z: fn(z), [z])
+    got, ggot = grads_of(lambda z: ops.act_dropout(z, kind, 0.0), [z.cuda()])
+    close(got, ref, msg="act fwd"); close(ggot[0], gref[0], rtol=1e-3, msg="act bwd")
+    a, b, x = rnd(64, 48, seed=7), rnd(64, 48, seed=8), rnd(64, 48, seed=9)
+    ref, gref = grads_of(lambda a, b: F.silu(a) * b, [a, b])
+    got, ggot = grads_of(lambda a, b: ops.swiglu(a, b, 0.0), [a.cuda(), b.cuda()])
+    close(got, ref, msg="swiglu"); close(ggot[0], gref[0], rtol=1e-3, msg="swiglu da"); close(ggot[1], gref[1], rtol=1e-3, msg="swiglu db")
+    ref, gref = grads_of(lambda x, g, a: x + torch.sigmoid(g) * a, [x, a, b])
+    got, ggot = grads_of(lambda x, g, a: ops.gate(x, g, a, 0.0), [x.cuda(), a.cuda(), b.cuda()])
+    close(got, ref, msg="gate")
+    for i in range(3):
+        close(ggot[i], gref[i], rtol=1e-3, msg=f"gate grad {i}")
+
+
+@pytest.mark.parametrize("L,d,H,causal,keypad", [(8, 16, 2, True, False), (40, 64, 2, True, True), (70, 128, 4, False, True),
+                                                   (200, 256, 4, True, False), (33, 64, 1, True, False)])
+def test_mha(L, d, H, causal, keypad):
+    from rectools_amd import ops
+
+    B = 3
+    g = torch.Generator().manual_seed(L)
+    ids = torch.randint(1, 50, (B, L), generator=g)
+    ids[0, : L // 3] = 0; ids[1, : L - 1] = 0
+    q, k, v = rnd(B * L, d, seed=1), rnd(B * L, d, seed=2), rnd(B * L, d, seed=3)
+    mask = T.attention_mask(ids, causal, keypad)
+    hd = d // H
+
+    def ref_fn(q, k, v):
+        qh, kh, vh = (t.view(B, L, H, hd).transpose(1, 2) for t in (q, k, v))
+        s = qh @ kh.transpose(-1, -2) / math.sqrt(hd)
+        if mask is not None:
+            s = s + mask[:, None]
+        return (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B * L, d)
+
+    ref, gref = grads_of(ref_fn, [q, k, v])
+    got, ggot = grads_of(lambda q, k, v: ops.mha(q, k, v, ids.cuda(), B, H, L, causal, keypad, 0.0), [q.cuda(), k.cuda(), v.cuda()])
+    close(got, ref, rtol=5e-4, atol_rel=5e-5, msg="mha fwd")
+    for i, n in enumerate("qkv"):
+        close(ggot[i], gref[i], rtol=2e-3, atol_rel=2e-4, msg=f"mha d{n}")
+
+
+@pytest.mark.parametrize("L,d,H,rt,rp", [(8, 16, 2, True, True), (50, 64, 2, True, False), (96, 128, 4, False, True), (130, 64, 2, True, True)])
+def test_hstu_attention(L, d, H, rt, rp):
+    from rectools_amd import ops
+
+    B, hd = 2, d // H
+    g = torch.Generator().manual_seed(L)
+    ids = torch.randint(1, 50, (B, L), generator=g); ids[0, : L // 4] = 0
+    ts = torch.cumsum(torch.randint(0, 3_000_000, (B, L + 1), generator=g), 1) + 1_300_000_000
+    q, k, v = rnd(B * L, d, seed=1) * 0.5, rnd(B * L, d, seed=2) * 0.5, rnd(B * L, d, seed=3)
+    tw, pw = rnd(129, seed=4) * 0.5, rnd(2 * L - 1, seed=5) * 0.5
+    m = (ids != 0).float()
+
+    def ref_fn(q, k, v, tw, pw):
+        p = {}
+        if rt: p["x.time_weights"] = tw
+        if rp: p["x.pos_weights"] = pw
+        rab = T.rel_attn_bias(p, "x.", {"x": ids, "unix_ts": ts}, L)
+        qh, kh, vh = (t.view(B, L, H, hd) for t in (q, k, v))
+        a = F.silu(torch.einsum("bnhd,bmhd->bhnm", qh, kh) + rab[:, None]) / L
+        a = a * torch.tril(torch.ones(L, L))[None, None] * (m[:, None, :, None] * m[:, None, None, :])
+        return torch.einsum("bhnm,bmhd->bnhd", a, vh).reshape(B * L, d)
+
+    ref, gref = grads_of(ref_fn, [q, k, v, tw, pw])
+    thr = ops.hstu_time_thresholds().cuda()
+    got, ggot = grads_of(lambda q, k, v, tw, pw: ops.hstu_attn(q, k, v, tw if rt else None, pw if rp else None, ids.cuda(), ts.cuda(), thr, B, H, L),
+                         [t.cuda() for t in (q, k, v, tw, pw)])
+    close(got, ref, rtol=5e-4, atol_rel=5e-5, msg="hstu fwd")
+    for i, n in enumerate(("dq", "dk", "dv")):
+        close(ggot[i], gref[i], rtol=2e-3, atol_rel=2e-4, msg=f"hstu {n}")
+    if rt: close(ggot[3], gref[3], rtol=2e-3, atol_rel=2e-4, msg="hstu dtw")
+    if rp: close(ggot[4], gref[4], rtol=2e-3, atol_rel=2e-4, msg="hstu dpw")
+
+
+def test_hstu_time_thresholds_match_reference_formula():
+    from rectools_amd import ops
+
+    thr = ops.hstu_time_thresholds()
+    x = torch.cat([torch.arange(0, 5000), (torch.rand(200000, generator=torch.Generator().manual_seed(0), dtype=torch.float64) * 40).exp().long(),
+                   thr[thr < 2 ** 62], (thr[(thr > 1) & (thr < 2 ** 62)] - 1)])
+    ref = torch.clamp((torch.log(torch.abs(x).clamp(min=1)) / 0.301).long(), 0, 128)
+    got = (thr[None, :] <= x[:, None]).sum(1) - 1
+    assert torch.equal(ref, got)
+
+
+@pytest.mark.parametrize("loss", ["BCE", "gBCE", "sampled_softmax"])
+@pytest.mark.parametrize("cosine", [False, True])
+def test_sampled_losses(loss, cosine):
+    from rectools_amd import lightning as hl
+    from rectools_amd import ops
+
+    M, d, V, N = 150, 64, 90, 37
+    g = torch.Generator().manual_seed(1)
+    sess, table = rnd(M, d, seed=2), rnd(V, d, seed=3)
+    y = torch.randint(1, V, (M,), generator=g); y[::5] = 0
+    neg = torch.randint(1, V, (M, N), generator=g)
+    w = (0.5 + torch.rand(M, generator=g)) * (y != 0)
+    t = 0.7
+    beta = hl.gbce_beta(N, V - 1, 0.2)
+
+    def ref_fn(sess, table):
+        s, e = (T._l2norm(sess), T._l2norm(table)) if cosine else (sess, table)
+        cand = torch.cat([y[:, None], neg], 1)
+        lg = ((e[cand] @ s.unsqueeze(-1)).squeeze(-1) / t)[None]
+        yy, ww = y[None], w[None]
+        if loss == "BCE": return T.bce_loss(lg, yy, ww).reshape(1)
+        if loss == "gBCE": return T.bce_loss(T.gbce_logits(lg, V - 1, N, 0.2), yy, ww).float().reshape(1)
+        return T.sampled_softmax_loss(lg, yy, ww).reshape(1)
+
+    kind = {"BCE": 0, "gBCE": 1, "sampled_softmax": 2}[loss]
+    ref, gref = grads_of(ref_fn, [sess, table])
+    got, ggot = grads_of(lambda s, e: ops.sampled_loss(s, e, y.cuda(), neg.cuda(), w.cuda(), kind, cosine, t, beta)[0].reshape(1),
+                         [sess.cuda(), table.cuda()])
+    close(got, ref, rtol=2e-5, atol_rel=1e-6, msg="loss")
+    gref[1][0] = 0
+    close(ggot[0], gref[0], rtol=2e-3, atol_rel=2e-4, msg="d_sess"); close(ggot[1], gref[1], rtol=2e-3, atol_rel=2e-4, msg="d_table")
+
+
+@pytest.mark.parametrize("cosine", [False, True])
+def test_full_softmax_loss(cosine):
+    from rectools_amd import ops
+
+    M, d, V = 120, 32, 301
+    g = torch.Generator().manual_seed(1)
+    sess, table = rnd(M, d, seed=2), rnd(V, d, seed=3)
+    y = torch.randint(1, V, (M,), generator=g); y[::3] = 0
+    w = (0.5 + torch.rand(M, generator=g)) * (y != 0)
+
+    def ref_fn(sess, table):
+        s, e = (T._l2norm(sess), T._l2norm(table)) if cosine else (sess, table)
+        return T.softmax_loss((s @ e.T / 0.5)[None], y[None], w[None]).reshape(1)
+
+    def hip_fn(s, e):
+        if cosine: s, e = ops.l2norm(s), ops.l2norm(e)
+        act = torch.nonzero(y).reshape(-1).cuda()
+        return ops.softmax_loss(s, e, act, y.cuda()[act].contiguous(), w.cuda()[act].contiguous(), 0.5).reshape(1)
+
+    ref, gref = grads_of(ref_fn, [sess, table])
+    got, ggot = grads_of(hip_fn, [sess.cuda(), table.cuda()])
+    close(got, ref, rtol=2e-5, atol_rel=1e-6, msg="softmax loss")
+    if not cosine: gref[1][0] = 0
+    close(ggot[0], gref[0], rtol=2e-3, atol_rel=2e-4, msg="d_sess")
+    if not cosine: close(ggot[1], gref[1], rtol=2e-3, atol_rel=2e-4, msg="d_table")

@@ -1,0 +1,193 @@
+"""GPU parity of the HIP transformer path (rectools_amd.nn / ops / lightning through the C ABI) against
+  (1) vectors of the UNMODIFIED reference (tests/golden/transformer_*.npz): loss, every parameter gradient,
+      parameters after one Adam step, eval-mode encodings, sampled logits;
+  (2) the torch oracle (oracle/transformer_oracle.py) on larger seeded configurations (L not a multiple of 32,
+      hd = 32/64, several heads), incl. the BASELINE head size.
+Tolerances (fp32, different summation orders): loss rtol 2e-5; logits/encodings rtol 2e-4 atol 2e-5;
+gradients rtol 5e-3 atol 5e-6 relative to each tensor's scale.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import list_transformer_golden, load_transformer_golden
+from oracle import transformer_oracle as T
+
+pytestmark = pytest.mark.gpu
+NAMES = list_transformer_golden()
+
+
+def build_hip_model(cfg, params=None):
+    from rectools_amd import lightning as hl
+    from rectools_amd import nn as hnn
+
+    n_tokens = cfg["V"] + cfg["n_extra"]
+    item_model = hnn.SumOfEmbeddingsConstructor(n_tokens, [hnn.IdEmbeddingsItemNet(cfg["d"], n_tokens, 0.0)])
+    pos = hnn.LearnableInversePositionalEncoding(True, cfg["L"], cfg["d"], use_scale_factor=cfg.get("use_scale", False))
+    kind = cfg["layers"]
+    p = cfg.get("dropout", 0.0)
+    if kind == "sasrec":
+        layers = hnn.SASRecTransformerLayers(cfg["n_blocks"], cfg["d"], cfg["H"], p)
+    elif kind == "preln":
+        layers = hnn.PreLNTransformerLayers(cfg["n_blocks"], cfg["d"], cfg["H"], p)
+    elif kind == "ligr":
+        layers = hnn.LiGRLayers(cfg["n_blocks"], cfg["d"], cfg["H"], p, **cfg["layer_kwargs"])
+    else:
+        hd = cfg["d"] // cfg["H"]
+        layers = hnn.STULayers(cfg["n_blocks"], cfg["d"], cfg["H"], hd, hd, cfg["L"], cfg["rel_time"], cfg["rel_pos"],
+                               attn_dropout_rate=0.0, dropout_rate=p)
+    sim = hnn.DistanceSimilarityModule(cfg["dist"])
+    bb = hnn.TransformerTorchBackbone(cfg["H"], p, item_model, pos, layers, sim, cfg["causal"], cfg["keypad"])
+    lm = hl.TransformerLossModule(bb, cfg["loss"], cfg["N"], cfg["gbce_t"], cfg.get("logits_t", 1.0), cfg["n_extra"])
+    lm = lm.cuda()
+    if params is not None:
+        missing, unexpected = lm.torch_model.load_state_dict({k: v.cuda() for k, v in params.items()}, strict=True)
+    return lm
+
+
+def _close(got, exp, rtol, atol_rel, name):
+    exp = exp.to(got.device)
+    scale = float(exp.abs().max()) + 1e-12
+    torch.testing.assert_close(got, exp, rtol=rtol, atol=atol_rel * scale + 1e-9, msg=lambda m: f"{name}: {m}")
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_golden_reference_vectors(name):
+    from rectools_amd import lightning as hl
+
+    cfg, p0, g_ref, p1_ref, _p2, batch, ex = load_transformer_golden(name)
+    lm = build_hip_model(cfg, p0)
+    dbatch = {k: v.cuda() for k, v in batch.items()}
+    lm.eval()
+    with torch.no_grad():
+        enc = lm.torch_model.encode_sessions(dbatch)
+    _close(enc, ex["enc"], 2e-4, 2e-5, "encode_sessions")
+    lm.train()
+    if "logits" in ex and cfg["loss"] != "softmax":
+        with torch.no_grad():
+            lg = lm.batch_logits(dbatch)
+        active = (dbatch["y"] != 0)
+        _close(lg[active], ex["logits"].cuda()[active], 2e-4, 2e-5, "logits")
+    opt = hl.FlatAdam(lm.torch_model, lr=cfg["lr"])
+    opt.zero_grad()
+    loss = lm.training_loss(dbatch)
+    loss.backward()
+    assert abs(float(loss) - ex["loss"]) <= 2e-5 * abs(ex["loss"]) + 2e-6, (float(loss), ex["loss"])
+    grads = {n: p.grad.detach().clone() for n, p in lm.torch_model.named_parameters()}
+    assert set(grads) == set(g_ref)
+    for k in g_ref:
+        _close(grads[k], g_ref[k], 5e-3, 5e-6 if g_ref[k].abs().max() > 1e-6 else 1.0, f"grad {k}")
+    # Adam: fed with the reference's own gradients the fused kernel must land on the reference's parameters
+    opt.zero_grad()
+    for n, p in lm.torch_model.named_parameters():
+        p.grad.copy_(g_ref[n].cuda())
+    opt.step()
+    for n, p in lm.torch_model.named_parameters():
+        torch.testing.assert_close(p.detach().cpu(), p1_ref[n], rtol=1e-5, atol=1e-7, msg=lambda m, n=n: f"adam {n}: {m}")
+
+
+def _random_case(layers, loss, dist, L, d, H, B, V, N, seed, **kw):
+    cfg = dict(V=V, B=B, L=L, d=d, H=H, n_blocks=2, N=N, loss=loss, dist=dist, logits_t=kw.pop("logits_t", 1.0),
+               causal=kw.pop("causal", True), keypad=kw.pop("keypad", False), layers=layers,
+               n_extra=2 if layers == "preln" else 1, gbce_t=0.2, lr=1e-3, use_scale=layers == "stu",
+               layer_kwargs=kw.pop("layer_kwargs", {}), rel_time=True, rel_pos=True)
+    cfg.update(kw)
+    g = torch.Generator().manual_seed(seed)
+    ne = cfg["n_extra"]
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    lens[0] = L
+    x = torch.zeros(B, L, dtype=torch.int64)
+    y = torch.zeros(B, L, dtype=torch.int64)
+    for b in range(B):
+        n = int(lens[b])
+        seq = torch.randint(ne, V + ne, (n + 1,), generator=g)
+        x[b, L - n:] = seq[:-1]
+        y[b, L - n:] = seq[1:]
+    batch = {"x": x, "y": y, "yw": (y != 0).float() * (0.5 + torch.rand(B, L, generator=g))}
+    if loss != "softmax":
+        batch["negatives"] = torch.randint(ne, V + ne, (B, L, N), generator=g)
+    if layers == "stu":
+        ts = torch.cumsum(torch.randint(1, 5_000_000, (B, L + 1), generator=g), dim=1) + 1_400_000_000
+        for b in range(B):
+            n = int(lens[b])
+            ts[b, : L - n] = ts[b, L - n]
+        batch["unix_ts"] = ts
+    return cfg, batch
+
+
+CASES = [
+    ("sasrec_L200_d256", _random_case("sasrec", "sampled_softmax", "dot", 200, 256, 4, 3, 500, 16, 1)),
+    ("sasrec_L50_d64_softmax", _random_case("sasrec", "softmax", "dot", 50, 64, 4, 4, 300, 1, 2)),
+    ("sasrec_L70_gbce_cos", _random_case("sasrec", "gBCE", "cosine", 70, 64, 2, 3, 400, 9, 3)),
+    ("bert_L100_d128", _random_case("preln", "softmax", "dot", 100, 128, 4, 3, 300, 1, 4, causal=False, keypad=True)),
+    ("ligr_L64_d128", _random_case("ligr", "sampled_softmax", "cosine", 64, 128, 4, 3, 300, 8, 5, logits_t=0.1,
+                                   layer_kwargs=dict(ff_factors_multiplier=4, ff_activation="swiglu", bias_in_ff=False))),
+    ("hstu_L96_d128", _random_case("stu", "sampled_softmax", "cosine", 96, 128, 4, 3, 300, 8, 6, logits_t=0.05)),
+    ("hstu_L130_d64", _random_case("stu", "BCE", "dot", 130, 64, 2, 2, 300, 4, 7)),
+]
+
+
+@pytest.mark.parametrize("name,case", CASES, ids=[c[0] for c in CASES])
+def test_vs_oracle_larger_shapes(name, case):
+    cfg, batch = case
+    torch.manual_seed(100)
+    lm = build_hip_model(cfg)
+    from rectools_amd import lightning as hl
+
+    hl.xavier_normal_init(lm.torch_model)
+    with torch.no_grad():
+        for n, p in lm.torch_model.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    params = {k: v.detach().cpu().clone() for k, v in lm.torch_model.state_dict().items()}
+    loss_ref, g_ref = T.loss_and_grads(cfg, params, batch)
+    with torch.no_grad():
+        enc_ref = T.encode_sessions(cfg, params, batch)
+    dbatch = {k: v.cuda() for k, v in batch.items()}
+    lm.eval()
+    with torch.no_grad():
+        enc = lm.torch_model.encode_sessions(dbatch)
+    _close(enc, enc_ref, 5e-4, 5e-5, "encode_sessions")
+    lm.train()
+    lm.zero_grad()
+    loss = lm.training_loss(dbatch)
+    loss.backward()
+    assert abs(float(loss) - float(loss_ref)) <= 5e-5 * abs(float(loss_ref)) + 5e-6, (float(loss), float(loss_ref))
+    for n, p in lm.torch_model.named_parameters():
+        _close(p.grad, g_ref[n], 1e-2, 2e-5 if g_ref[n].abs().max() > 1e-6 else 1.0, f"grad {n}")
+
+
+def test_dropout_is_consistent_between_forward_and_backward():
+    """With dropout on, d(loss)/d(param) from the HIP backward must match a finite-difference probe of the HIP
+    forward run with the SAME dropout streams (masks are regenerated, not stored)."""
+    from rectools_amd import ops
+
+    cfg, batch = _random_case("sasrec", "sampled_softmax", "dot", 40, 64, 2, 3, 200, 4, 11)
+    cfg["dropout"] = 0.3
+    torch.manual_seed(5)
+    lm = build_hip_model(cfg)
+    dbatch = {k: v.cuda() for k, v in batch.items()}
+    lm.train()
+
+    def run():
+        ops.RNG.step, ops.RNG._stream = 7, 0
+        return lm.training_loss(dbatch)
+
+    lm.zero_grad()
+    loss = run()
+    loss.backward()
+    w = lm.torch_model.transformer_layers.transformer_blocks[0].feed_forward.ff_linear_1.weight
+    g = w.grad.detach().clone()
+    direction = torch.randn_like(w)
+    direction /= direction.norm()
+    eps = 1e-2
+    with torch.no_grad():
+        w.add_(eps * direction); lp = float(run()); w.sub_(2 * eps * direction); lm_ = float(run()); w.add_(eps * direction)
+    fd = (lp - lm_) / (2 * eps)
+    an = float((g * direction).sum())
+    assert abs(fd - an) <= 5e-2 * max(abs(fd), abs(an)) + 1e-4, (fd, an)
+    # and the same streams reproduce the same loss, different steps do not
+    a, b = float(run()), float(run())
+    assert a == b
+    ops.RNG.step, ops.RNG._stream = 8, 0
+    assert float(lm.training_loss(dbatch)) != a
