@@ -169,6 +169,145 @@ def run_topk(args, rank, world, n_items, d, users_per_step, upp, with_filter, na
     return value, wall, roof, info
 
 
+# ---------------------------------------------------------------------------------------------------
+# training workload (BASELINE.json configs[1]: SASRec d=256, 2 blocks, L=200, sampled_softmax, ML-20M-shaped)
+# ---------------------------------------------------------------------------------------------------
+def make_sasrec(V, d, H, n_blocks, L, dropout, loss, n_neg, device="cuda"):
+    from rectools_amd import lightning as hl
+    from rectools_amd import nn as hnn
+
+    n_tokens = V + 1
+    item_model = hnn.SumOfEmbeddingsConstructor(n_tokens, [hnn.IdEmbeddingsItemNet(d, n_tokens, 0.0)])
+    pos = hnn.LearnableInversePositionalEncoding(True, L, d)
+    layers = hnn.SASRecTransformerLayers(n_blocks, d, H, dropout)
+    bb = hnn.TransformerTorchBackbone(H, dropout, item_model, pos, layers, hnn.DistanceSimilarityModule("dot"), True, False)
+    lm = hl.TransformerLossModule(bb, loss, n_neg, 0.2, 1.0, 1).to(device)
+    torch.manual_seed(32)
+    hl.xavier_normal_init(lm.torch_model)
+    return lm
+
+
+def make_train_batches(n_batches, B, L, V, n_neg, rank, seed=0):
+    """SASRec training batches (x, y, yw, negatives) from ML-20M-shaped synthetic histories, collated exactly as
+    SASRecDataPreparator._collate_fn_train does (sasrec.py:86-104): last L+1 items, left padding, shift by one."""
+    from rectools_amd import synth
+
+    n_users = n_batches * B
+    u, it, _ = synth.gen_interactions(n_users, V, mean_len=144.0, min_len=20, max_len=9254, seed=seed + 17 * rank)
+    it = it + 1  # internal ids: 0 is PAD
+    bounds = np.concatenate([[0], np.cumsum(np.bincount(u, minlength=n_users))])
+    x = np.zeros((n_users, L), np.int64)
+    y = np.zeros((n_users, L), np.int64)
+    for i in range(n_users):
+        ses = it[bounds[i]:bounds[i + 1]][-(L + 1):]
+        x[i, L - (len(ses) - 1):] = ses[:-1]
+        y[i, L - (len(ses) - 1):] = ses[1:]
+    rng = np.random.default_rng(seed + 5 + rank)
+    out = []
+    for b in range(n_batches):
+        sl = slice(b * B, (b + 1) * B)
+        yb = torch.from_numpy(y[sl])
+        batch = {"x": torch.from_numpy(x[sl]).cuda(), "y": yb.cuda(), "yw": (yb != 0).float().cuda()}
+        if n_neg:
+            batch["negatives"] = torch.from_numpy(rng.integers(1, V + 1, size=(B, L, n_neg))).cuda()
+        out.append(batch)
+    return out
+
+
+def sasrec_step_flops(B, L, d, n_blocks, n_neg):
+    """Dense algorithmic flops of one training step (fwd + bwd = 3x fwd): SASRec block 12 L d^2 + 4 L^2 d."""
+    blk = 12.0 * L * d * d + 4.0 * L * L * d
+    loss = 2.0 * L * (1 + n_neg) * d
+    return 3.0 * B * (n_blocks * blk + loss)
+
+
+def run_train(args, rank, world):
+    from rectools_amd import lightning as hl
+    from rectools_amd import ops, synth
+
+    V, d, H, nb, L, B = synth.ML_20M["n_items"], 256, 4, 2, 200, 128
+    n_neg = args.n_negatives
+    lm = make_sasrec(V, d, H, nb, L, 0.2, "sampled_softmax", n_neg)
+    lm.train()
+    opt = hl.FlatAdam(lm.torch_model, lr=1e-3)
+    n_batches = min(args.steps + args.warmup, 24)
+    batches = make_train_batches(n_batches, B, L, V, n_neg, rank)
+    state = {"i": 0, "loss": None}
+
+    def step():
+        batch = batches[state["i"] % n_batches]
+        state["i"] += 1
+        ops.RNG.next_step()
+        opt.zero_grad()
+        loss = lm.training_loss(batch)
+        loss.backward()
+        opt.step(world)
+        state["loss"] = loss
+
+    wall, ev_ms = timed_steps(step, args.steps, args.warmup, world)
+    value = B * args.steps * world / wall
+    # ---- roofline pass: 3 more steps with HIP events around every rt_* launch (on the launch stream) ----
+    ops.start_timing()
+    for _ in range(3):
+        step()
+    rec = ops.stop_timing()
+    per_kernel = {k: (sum(t for t, _ in v) / 3.0, len(v) / 3.0) for k, v in rec.items()}
+    total_k = sum(t for t, _ in per_kernel.values())
+    dom = max(per_kernel, key=lambda k: per_kernel[k][0])
+    breakdown = {k: {"ms_per_step": round(t, 4), "calls_per_step": c} for k, (t, c) in
+                 sorted(per_kernel.items(), key=lambda kv: -kv[1][0])}
+    roof = None
+    if dom == "rt_gemm":
+        calls = rec["rt_gemm"]
+        fl = sum(2.0 * m * n * k for _, (m, n, k) in calls)
+        ms = sum(t for t, _ in calls)
+        tf = fl / (ms * 1e-3) / 1e12
+        roof = {"kernel": "gemm_kernel (rt_gemm: all forward/dgrad/wgrad products of the step)", "bound": "mfma",
+                "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),
+                "traffic": load_traffic("train_gemm"), "avg_launch_ms": round(ms / len(calls), 4),
+                "algorithmic_flops_per_launch": fl / len(calls), "launches_per_step": len(calls) / 3.0}
+    else:
+        M = B * L
+        if dom in ("rt_sampled_loss_fwd", "rt_sampled_loss_bwd"):
+            byts = M * 0.72 * (1 + n_neg) * (4.0 * d + 8.0) * (2.0 if dom.endswith("bwd") else 1.0) + 4.0 * M * d
+        else:
+            byts = 8.0 * M * d
+        ms = per_kernel[dom][0] / per_kernel[dom][1]
+        gbs = byts / (ms * 1e-3) / 1e9
+        roof = {"kernel": dom, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": load_traffic("train_" + dom), "avg_launch_ms": round(ms, 4),
+                "algorithmic_bytes_per_launch": byts}
+    roof["kernel_ms_per_step"] = round(total_k, 3)
+    roof["step_flops_dense"] = sasrec_step_flops(B, L, d, nb, n_neg)
+    info = dict(lm=lm, batches=batches, V=V, d=d, H=H, nb=nb, L=L, B=B, n_neg=n_neg, breakdown=breakdown,
+                loss=float(state["loss"]))
+    return value, wall, roof, info
+
+
+def cpu_baseline_train(info, budget_s=25.0):
+    """The oracle (plain torch fp32 restatement of the reference step, CPU) on the same model/batches:
+    forward + backward + dense Adam, timed on the host cores."""
+    from oracle import transformer_oracle as T
+
+    cfg = dict(V=info["V"], B=info["B"], L=info["L"], d=info["d"], H=info["H"], n_blocks=info["nb"], N=info["n_neg"],
+               loss="sampled_softmax", dist="dot", logits_t=1.0, causal=True, keypad=False, layers="sasrec", n_extra=1,
+               gbce_t=0.2, lr=1e-3)
+    params = {k: v.detach().cpu().clone() for k, v in info["lm"].torch_model.state_dict().items()}
+    adam = T.AdamState(lr=1e-3)
+    bsub = 32  # bounded sample: 32 sequences per CPU step
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        b = {k: v[:bsub].cpu() for k, v in info["batches"][n % len(info["batches"])].items()}
+        _, grads = T.loss_and_grads(cfg, params, b)
+        params = adam.step(params, grads)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 6:
+            break
+    return bsub * n / el, f"oracle/transformer_oracle (torch CPU fp32) fwd+bwd+Adam, {n} steps of {bsub} sequences"
+
+
 def load_traffic(name: str):
     """PMC-measured HBM bytes per launch (profiles/traffic.json, written from rocprofv3 --pmc passes)."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
@@ -188,6 +327,7 @@ def main():
     ap.add_argument("--workload", default="auto", choices=["auto", "train", "recommend", "topk5m"])
     ap.add_argument("--users-per-pass", type=int, default=0, help="register tile: 32/64/128 users (0 = auto)")
     ap.add_argument("--users-per-step", type=int, default=0)
+    ap.add_argument("--n-negatives", type=int, default=128, help="sampled_softmax negatives (tutorial setting 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     rank, world, local = dist_setup(args.gpus)
@@ -197,10 +337,26 @@ def main():
     _lib.load()  # fail loudly if the HIP extension is missing
     workload = args.workload
     if workload == "auto":
-        workload = "recommend"
+        workload = "train"
 
     extra = {}
-    if workload == "recommend":
+    cpu = None
+    if workload == "train":
+        if args.steps is None:
+            args.steps = 30
+        if args.warmup is None:
+            args.warmup = 5
+        value, wall, roof, info = run_train(args, rank, world)
+        metric, unit = "train seqs/sec (SASRec d=256 n_blocks=2 L=200 sampled_softmax, ML-20M-shaped)", "seqs/s"
+        config = {"workload": f"SASRec fit() step: B=128/GPU x L=200, d=256, 2 blocks, 4 heads, dropout 0.2, sampled_softmax "
+                              f"N={args.n_negatives}, V=26744 items, fwd+bwd+Adam" + (" + RCCL all-reduce" if world > 1 else ""),
+                  "global_batch": 128 * world, "seq_len": 200, "parallelism": f"dp{world}", "n_negatives": args.n_negatives}
+        extra["kernel_breakdown"] = info["breakdown"]
+        extra["final_loss"] = round(info["loss"], 5)
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            v, what = cpu_baseline_train(info)
+            cpu = {"value": round(v, 2), "unit": unit, "cores": torch.get_num_threads(), "kind": "port", "sample": what}
+    elif workload == "recommend":
         if args.steps is None:
             args.steps = 20
         if args.warmup is None:
@@ -227,8 +383,7 @@ def main():
     else:
         raise SystemExit("train workload is not built yet in this revision")
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if workload != "train" and rank == 0 and world == 1 and not args.no_cpu_baseline:
         torch.cuda.synchronize()
         v, n = cpu_baseline_topk(info["items"] if info["n_items"] <= 100_000 else info["items"][:200_000],
                                  info["users_t"], info["filt"])

@@ -19,11 +19,35 @@ ACT_NONE, ACT_RELU, ACT_GELU, ACT_SILU, ACT_SIGMOID = 0, 1, 2, 3, 4
 LOSS_BCE, LOSS_GBCE, LOSS_SAMPLED_SOFTMAX = 0, 1, 2
 
 
-def _c(name: str, *args: tp.Any) -> None:
+# Optional per-call HIP-event instrumentation (bench.py's roofline pass): name -> [(start, stop, tag), ...]
+_TIMING: tp.Optional[tp.Dict[str, tp.List[tp.Tuple[torch.cuda.Event, torch.cuda.Event, tp.Any]]]] = None
+
+
+def start_timing() -> None:
+    global _TIMING
+    _TIMING = {}
+
+
+def stop_timing() -> tp.Dict[str, tp.List[tp.Tuple[float, tp.Any]]]:
+    """-> {kernel entry point: [(milliseconds, tag), ...]} for every call since start_timing()."""
+    global _TIMING
+    rec, _TIMING = _TIMING or {}, None
+    torch.cuda.synchronize()
+    return {k: [(a.elapsed_time(b), tag) for a, b, tag in v] for k, v in rec.items()}
+
+
+def _c(name: str, *args: tp.Any, tag: tp.Any = None) -> None:
     """Call `rt_<name>(*args, stream)`; tensors are passed as raw device pointers."""
     lib = _lib.load()
     conv = [a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args]
-    status = getattr(lib, name)(*conv, _lib.current_stream())
+    if _TIMING is None:
+        status = getattr(lib, name)(*conv, _lib.current_stream())
+    else:  # events on the stream the kernel is launched on (torch's current stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        status = getattr(lib, name)(*conv, _lib.current_stream())
+        e1.record()
+        _TIMING.setdefault(name, []).append((e0, e1, tag))
     _lib.check(status, name)
 
 
@@ -57,7 +81,7 @@ RNG = DropoutRng(0)
 # dense
 # --------------------------------------------------------------------------------------------------
 def _gemm(A, lda, a_kc, B, ldb, b_kc, C, ldc, bias, R, ldr, M, N, K, relu=0, split_k=1) -> None:
-    _c("rt_gemm", A, lda, a_kc, B, ldb, b_kc, C, ldc, bias, R, ldr, M, N, K, relu, split_k)
+    _c("rt_gemm", A, lda, a_kc, B, ldb, b_kc, C, ldc, bias, R, ldr, M, N, K, relu, split_k, tag=(M, N, K))
 
 
 def _wgrad_splits(k_rows: int) -> int:
