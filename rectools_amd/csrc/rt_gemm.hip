@@ -77,6 +77,22 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, long long
   }
 }
 
+// branch-free variant for tiles that lie fully inside the operand and are 16-byte aligned (the common case):
+// the 4 float4 loads of a thread issue back to back and stay in flight under the MFMAs of the current step
+template <bool KC>
+__device__ __forceinline__ void load_tile_fast(const float* __restrict__ P, long long ld, int row0, int k0, int tid,
+                                               f32x4 (&v)[4]) {
+  if (KC) {
+    const float* p = P + (long long)(row0 + (tid >> 3)) * ld + k0 + (tid & 7) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(p + (long long)(32 * j) * ld);
+  } else {
+    const float* p = P + (long long)(k0 + (tid >> 5)) * ld + row0 + (tid & 31) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(p + (long long)(8 * j) * ld);
+  }
+}
+
 template <bool KC>
 __device__ __forceinline__ void store_tile(float* S, int tid, const f32x4 (&v)[4]) {
   if (KC) {
@@ -146,18 +162,23 @@ __global__ __launch_bounds__(GT) void gemm_kernel(GemmArgs g) {
 
   f32x4 ra[4], rb[4];
   const int n_steps = (k_end - k_begin + BK - 1) / BK;
-  load_tile<AKC>(g.A, g.lda, m0, g.M, k_begin, k_end, tid, ra, a_vec);
-  load_tile<BKC>(g.B, g.ldb, n0, g.N, k_begin, k_end, tid, rb, b_vec);
+  const bool a_full = a_vec && (m0 + BM <= g.M);
+  const bool b_full = b_vec && (n0 + BN <= g.N);
+  auto fetch = [&](int k0) {
+    const bool k_full = k0 + BK <= k_end;
+    if (a_full && k_full) load_tile_fast<AKC>(g.A, g.lda, m0, k0, tid, ra);
+    else load_tile<AKC>(g.A, g.lda, m0, g.M, k0, k_end, tid, ra, a_vec);
+    if (b_full && k_full) load_tile_fast<BKC>(g.B, g.ldb, n0, k0, tid, rb);
+    else load_tile<BKC>(g.B, g.ldb, n0, g.N, k0, k_end, tid, rb, b_vec);
+  };
+  fetch(k_begin);
   store_tile<AKC>(As, tid, ra);
   store_tile<BKC>(Bs, tid, rb);
   __syncthreads();
 
   for (int st = 0; st < n_steps; ++st) {
     const int buf = st & 1;
-    if (st + 1 < n_steps) {
-      load_tile<AKC>(g.A, g.lda, m0, g.M, k_begin + (st + 1) * BK, k_end, tid, ra, a_vec);
-      load_tile<BKC>(g.B, g.ldb, n0, g.N, k_begin + (st + 1) * BK, k_end, tid, rb, b_vec);
-    }
+    if (st + 1 < n_steps) fetch(k_begin + (st + 1) * BK);
     const float* Ab = As + buf * SA;
     const float* Bb = Bs + buf * SB;
 #pragma unroll
@@ -184,13 +205,41 @@ __global__ __launch_bounds__(GT) void gemm_kernel(GemmArgs g) {
 
   // epilogue.  D layout: MFMA rows index A (m), columns index B (n):
   //   acc[i][j][r] = C[m0 + wm*64 + i*32 + (r&3) + 8*(r>>2) + 4*half][n0 + wn*64 + j*32 + col]
+  const bool full_tile = (m0 + BM <= g.M) && (n0 + BN <= g.N);
+  const bool add_bias = g.bias != nullptr && (g.k_per_split == 0 || blockIdx.z == 0);
+  if (full_tile && g.k_per_split == 0) {
+    // branch-free: residual values are fetched in one batch per accumulator tile
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + col;
+        const int mb = m0 + wm * 64 + i * 32 + 4 * half;
+        const float bv = add_bias ? g.bias[n] : 0.f;
+        float rv[16];
+        if (g.R != nullptr) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rv[r] = g.R[(long long)(mb + (r & 3) + 8 * (r >> 2)) * g.ldr + n];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][j][r] + bv + rv[r];
+          if (g.relu) v = fmaxf(v, 0.f);
+          g.C[(long long)(mb + (r & 3) + 8 * (r >> 2)) * g.ldc + n] = v;
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int n = n0 + wn * 64 + j * 32 + col;
       if (n >= g.N) continue;
-      const float bv = (g.bias != nullptr && (g.k_per_split == 0 || blockIdx.z == 0)) ? g.bias[n] : 0.f;
+      const float bv = add_bias ? g.bias[n] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -277,7 +326,7 @@ int rt_gemm(const float* A, int64_t lda, int32_t a_kc, const float* B, int64_t l
 int rt_colsum(const float* X, int64_t ld, int32_t M, int32_t N, float* out, hipStream_t stream) {
   (void)hipGetLastError();
   if (M <= 0 || N <= 0) return RT_OK;
-  int gy = (M + 511) / 512; if (gy > 256) gy = 256; if (gy < 1) gy = 1;
+  int gy = (M + 63) / 64; if (gy > 2048) gy = 2048; if (gy < 1) gy = 1;
   dim3 grid((N + 63) / 64, gy);
   colsum_kernel<<<grid, 256, 0, stream>>>(X, ld, M, N, out);
   RT_CHECK_LAUNCH();

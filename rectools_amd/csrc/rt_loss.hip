@@ -38,7 +38,13 @@ struct SampledArgs {
   const float* norm;                      // [1] normaliser produced by the reduction kernel
   float gscale;                           // upstream dL/dloss
   float* d_sess; long long ld_dsess;      // [M, d] overwritten
-  float* d_table;                         // [V, d] accumulated (atomicAdd)
+  float* d_table;                         // [V, d] overwritten (every row written exactly once)
+  int V;
+  float* glog;                            // [M, 1+N] dL/d(raw similarity) of every (position, candidate)
+  float* inv_ns;                          // [M] 1 / max(||session||, eps)   (cosine)
+  int* count; int* offsets; int* cursor;  // [V+1] counting-sort state over candidate ids
+  int* pairs;                             // [M*(1+N)] (position, candidate) pairs grouped by candidate id
+  int* blocksum;                          // scan scratch
 };
 
 __device__ __forceinline__ float group16_sum(float v) {  // sum over the 16 lanes of a quarter-wave
@@ -149,8 +155,11 @@ __global__ __launch_bounds__(256) void sampled_fwd_kernel(SampledArgs a) {
   if (lane == 0) a.loss_pos[m] = out;
 }
 
+// Backward, part 1 (one wave per position): dL/dz for the 1+N candidates -> glog (already / logits_t), the
+// session gradient d_sess = sum_j g_j * d z_j / d s (gather of candidate rows, no atomics), and the histogram of
+// candidate ids for the counting sort that groups the table-gradient work by row (part 2).
 template <int D4>
-__global__ __launch_bounds__(256) void sampled_bwd_kernel(SampledArgs a) {
+__global__ __launch_bounds__(256) void sampled_bwd_pos_kernel(SampledArgs a) {
   __shared__ float s_g[4][260];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = blockIdx.x * 4 + wave;
@@ -168,11 +177,11 @@ __global__ __launch_bounds__(256) void sampled_bwd_kernel(SampledArgs a) {
     return;
   }
   const float* zrow = a.logits + (long long)m * C;
-  float* grow = const_cast<float*>(zrow);  // dlogits overwrite the saved logits beyond the LDS window
+  float* grow = a.glog + (long long)m * C;
   const float wgt = a.w[m];
-  const float gs = a.gscale / a.norm[0] * wgt;
+  const float gs = a.gscale / a.norm[0] * wgt * a.inv_t;   // includes d z / d(raw similarity) = 1 / logits_t
 
-  // ---- dL/dz_j for this position ----
+  // ---- dL/d(raw similarity) for this position ----
   if (a.loss == LOSS_SAMPLED_SOFTMAX) {
     float mx = -INFINITY;
     for (int j = lane; j < C; j += 64) mx = fmaxf(mx, zrow[j]);
@@ -184,7 +193,8 @@ __global__ __launch_bounds__(256) void sampled_bwd_kernel(SampledArgs a) {
     // reference (sum(loss) / sum(loss > 0)); keep that.
     for (int j = lane; j < C; j += 64) {
       float g = (__expf(zrow[j] - mx) / se - (j == 0 ? 1.f : 0.f)) * gs;
-      if (j < 260) s_g[wave][j] = g; else grow[j] = g;
+      if (j < 260) s_g[wave][j] = g;
+      grow[j] = g;
     }
   } else {
     for (int j = lane; j < C; j += 64) {
@@ -198,14 +208,20 @@ __global__ __launch_bounds__(256) void sampled_bwd_kernel(SampledArgs a) {
         g = sigmoid_d(z);
       }
       float gf = (float)(g / (double)C) * gs;
-      if (j < 260) s_g[wave][j] = gf; else grow[j] = gf;
+      if (j < 260) s_g[wave][j] = gf;
+      grow[j] = gf;
     }
+  }
+  // histogram of candidate ids (counting sort, pass 1)
+  for (int j = lane; j < C; j += 64) {
+    const long long cid = (j == 0) ? yy : a.neg[(long long)m * a.N + (j - 1)];
+    if (cid != 0) atomicAdd(a.count + cid, 1);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
-  // ---- chain rule into the session row (registers) and the table rows (atomics) ----
+  // ---- session gradient (registers) ----
   f32x4 sv[D4], ds[D4];
   float ss = 0.f;
   const float* srow = a.sess + (long long)m * a.ld_sess;
@@ -220,54 +236,27 @@ __global__ __launch_bounds__(256) void sampled_bwd_kernel(SampledArgs a) {
   ss = group16_sum(ss);
   const float ns = sqrtf(ss);
   const float inv_ns = a.cosine ? 1.0f / fmaxf(ns, EPS_COS) : 1.0f;
+  if (lane == 0) a.inv_ns[m] = inv_ns;
 
   for (int j0 = 0; j0 < C; j0 += 4) {
     const int j = j0 + grp;
     if (j < C) {  // uniform inside a 16-lane group
       const long long cid = (j == 0) ? yy : a.neg[(long long)m * a.N + (j - 1)];
-      const float g = (j < 260 ? s_g[wave][j] : grow[j]) * a.inv_t;   // dL/d(raw similarity)
+      const float g = (j < 260) ? s_g[wave][j] : grow[j];
       const float* er = a.table + cid * (long long)a.d;
-      float* dr = a.d_table + cid * (long long)a.d;
       f32x4 ev[D4];
-      float ee = 0.f, dot = 0.f;
+      float ee = 0.f;
 #pragma unroll
       for (int i = 0; i < D4; ++i) {
         const int c = (sub + 16 * i) * 4;
         f32x4 z = {0.f, 0.f, 0.f, 0.f};
         ev[i] = (c < a.d) ? *reinterpret_cast<const f32x4*>(er + c) : z;
-        if (a.cosine) {
-          ee += ev[i][0] * ev[i][0] + ev[i][1] * ev[i][1] + ev[i][2] * ev[i][2] + ev[i][3] * ev[i][3];
-          dot += ev[i][0] * sv[i][0] + ev[i][1] * sv[i][1] + ev[i][2] * sv[i][2] + ev[i][3] * sv[i][3];
-        }
+        if (a.cosine) ee += ev[i][0] * ev[i][0] + ev[i][1] * ev[i][1] + ev[i][2] * ev[i][2] + ev[i][3] * ev[i][3];
       }
-      if (!a.cosine) {
+      float ge = g;
+      if (a.cosine) { ee = group16_sum(ee); ge = g / fmaxf(sqrtf(ee), EPS_COS); }   // d s_hat += g * e_hat
 #pragma unroll
-        for (int i = 0; i < D4; ++i) {
-          const int c = (sub + 16 * i) * 4;
-          ds[i] += ev[i] * g;
-          if (c < a.d && cid != 0) {
-            atomicAdd(dr + c + 0, g * sv[i][0]); atomicAdd(dr + c + 1, g * sv[i][1]);
-            atomicAdd(dr + c + 2, g * sv[i][2]); atomicAdd(dr + c + 3, g * sv[i][3]);
-          }
-        }
-      } else {
-        ee = group16_sum(ee); dot = group16_sum(dot);
-        const float ne = sqrtf(ee);
-        const float inv_ne = 1.0f / fmaxf(ne, EPS_COS);
-        const float cosv = dot * inv_ns * inv_ne;   // s_hat . e_hat
-        // z = s_hat . e_hat ;  d s_hat = g e_hat ;  d e = (g s_hat - e_hat (e_hat . g s_hat)) / ne  (ne > eps)
-#pragma unroll
-        for (int i = 0; i < D4; ++i) {
-          const int c = (sub + 16 * i) * 4;
-          f32x4 eh = ev[i] * inv_ne, sh = sv[i] * inv_ns;
-          ds[i] += eh * g;  // accumulates d s_hat; projected after the loop
-          if (c < a.d && cid != 0) {
-            f32x4 de = (ne > EPS_COS) ? (sh * g - eh * (g * cosv)) * inv_ne : sh * (g * inv_ne);
-            atomicAdd(dr + c + 0, de[0]); atomicAdd(dr + c + 1, de[1]);
-            atomicAdd(dr + c + 2, de[2]); atomicAdd(dr + c + 3, de[3]);
-          }
-        }
-      }
+      for (int i = 0; i < D4; ++i) ds[i] += ev[i] * ge;
     }
   }
   // combine the 4 candidate groups: lanes with equal `sub` hold the same slice
@@ -299,6 +288,127 @@ __global__ __launch_bounds__(256) void sampled_bwd_kernel(SampledArgs a) {
       const int c = (sub + 16 * i) * 4;
       if (c < a.d) *reinterpret_cast<f32x4*>(drow + c) = ds[i];
     }
+  }
+}
+
+// ---- counting sort over candidate ids: exclusive scan of count[0..V] (3 phases), then scatter of the pairs ----
+constexpr int SCAN_T = 1024, SCAN_E = 4;   // 4096 elements per block
+__global__ __launch_bounds__(SCAN_T) void scan_local_kernel(const int* __restrict__ count, int n, int* __restrict__ offsets,
+                                                            int* __restrict__ blocksum) {
+  __shared__ int s_w[SCAN_T / 64];
+  const int base = (blockIdx.x * SCAN_T + threadIdx.x) * SCAN_E;
+  int v[SCAN_E], t = 0;
+#pragma unroll
+  for (int e = 0; e < SCAN_E; ++e) { v[e] = (base + e < n) ? count[base + e] : 0; t += v[e]; }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = t;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  if (wave == 0) {
+    int x = (lane < SCAN_T / 64) ? s_w[lane] : 0, inc = x;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+    if (lane < SCAN_T / 64) s_w[lane] = inc - x;   // exclusive prefix of the wave totals
+    if (lane == SCAN_T / 64 - 1) blocksum[blockIdx.x] = inc;
+  }
+  __syncthreads();
+  int run = s_w[wave] + incl - t;
+#pragma unroll
+  for (int e = 0; e < SCAN_E; ++e) { if (base + e < n) offsets[base + e] = run; run += v[e]; }
+}
+__global__ __launch_bounds__(1024) void scan_blocksums_kernel(int* __restrict__ blocksum, int nb) {
+  __shared__ int s_w[16]; __shared__ int s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int b0 = 0; b0 < nb; b0 += 1024) {
+    const int i = b0 + threadIdx.x;
+    const int x = (i < nb) ? blocksum[i] : 0;
+    int inc = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+      int y = (lane < 16) ? s_w[lane] : 0, yi = y;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { int u = __shfl_up(yi, o, 64); if (lane >= o) yi += u; }
+      if (lane < 16) s_w[lane] = yi - y;
+    }
+    __syncthreads();
+    const int excl = s_carry + s_w[wave] + inc - x;
+    if (i < nb) blocksum[i] = excl;
+    __syncthreads();
+    if (threadIdx.x == 1023) s_carry = excl + x;
+    __syncthreads();
+  }
+}
+__global__ void scan_add_kernel(int* __restrict__ offsets, int* __restrict__ cursor, const int* __restrict__ blocksum, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const int o = offsets[i] + blocksum[i / (SCAN_T * SCAN_E)]; offsets[i] = o; cursor[i] = o; }
+}
+__global__ __launch_bounds__(256) void pairs_scatter_kernel(SampledArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= a.M) return;
+  const long long yy = a.y[m];
+  if (yy == 0) return;
+  const int C = a.N + 1;
+  for (int j = lane; j < C; j += 64) {
+    const long long cid = (j == 0) ? yy : a.neg[(long long)m * a.N + (j - 1)];
+    if (cid != 0) a.pairs[atomicAdd(a.cursor + cid, 1)] = m * C + j;
+  }
+}
+
+// Backward, part 2 (one wave per table row): d_table[id] = sum over the pairs of that id — written once, no atomics.
+template <int D4>
+__global__ __launch_bounds__(256) void sampled_bwd_rows_kernel(SampledArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int id = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (id >= a.V) return;
+  const int C = a.N + 1;
+  const int beg = a.offsets[id], end = a.offsets[id + 1];
+  // lane owns floats [4*lane + 256*i, +4)
+  f32x4 acc[(D4 + 3) / 4];
+#pragma unroll
+  for (int i = 0; i < (D4 + 3) / 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  for (int k = beg; k < end; ++k) {
+    const int pr = a.pairs[k];
+    const int m = pr / C;
+    float g = a.glog[pr];
+    if (a.cosine) { bsum += g * (a.logits[pr] / a.inv_t); g *= a.inv_ns[m]; }   // logits = cos / t
+    const float* srow = a.sess + (long long)m * a.ld_sess;
+#pragma unroll
+    for (int i = 0; i < (D4 + 3) / 4; ++i) {
+      const int c = lane * 4 + 256 * i;
+      if (c < a.d) acc[i] += *reinterpret_cast<const f32x4*>(srow + c) * g;
+    }
+  }
+  float* dr = a.d_table + (long long)id * a.d;
+  if (a.cosine && end > beg) {
+    const float* er = a.table + (long long)id * a.d;
+    float ee = 0.f;
+    f32x4 ev[(D4 + 3) / 4];
+#pragma unroll
+    for (int i = 0; i < (D4 + 3) / 4; ++i) {
+      const int c = lane * 4 + 256 * i;
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      ev[i] = (c < a.d) ? *reinterpret_cast<const f32x4*>(er + c) : z;
+      ee += ev[i][0] * ev[i][0] + ev[i][1] * ev[i][1] + ev[i][2] * ev[i][2] + ev[i][3] * ev[i][3];
+    }
+    const float ne = sqrtf(wave_sum(ee));
+    const float inv_ne = 1.0f / fmaxf(ne, EPS_COS);
+#pragma unroll
+    for (int i = 0; i < (D4 + 3) / 4; ++i)
+      acc[i] = (ne > EPS_COS) ? (acc[i] - ev[i] * (inv_ne * bsum)) * inv_ne : acc[i] * inv_ne;
+  }
+#pragma unroll
+  for (int i = 0; i < (D4 + 3) / 4; ++i) {
+    const int c = lane * 4 + 256 * i;
+    if (c < a.d) *reinterpret_cast<f32x4*>(dr + c) = acc[i];
   }
 }
 
@@ -435,8 +545,25 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
 template <int D4>
 int launch_sampled(const SampledArgs& a, bool bwd, hipStream_t stream) {
   const int blocks = (a.M + 3) / 4;
-  if (!bwd) sampled_fwd_kernel<D4><<<blocks, 256, 0, stream>>>(a);
-  else sampled_bwd_kernel<D4><<<blocks, 256, 0, stream>>>(a);
+  if (!bwd) {
+    sampled_fwd_kernel<D4><<<blocks, 256, 0, stream>>>(a);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+  }
+  const int n = a.V + 1;
+  RT_CHECK_HIP(hipMemsetAsync(a.count, 0, sizeof(int) * (size_t)n, stream));
+  sampled_bwd_pos_kernel<D4><<<blocks, 256, 0, stream>>>(a);
+  RT_CHECK_LAUNCH();
+  const int nb = (n + SCAN_T * SCAN_E - 1) / (SCAN_T * SCAN_E);
+  scan_local_kernel<<<nb, SCAN_T, 0, stream>>>(a.count, n, a.offsets, a.blocksum);
+  RT_CHECK_LAUNCH();
+  scan_blocksums_kernel<<<1, 1024, 0, stream>>>(a.blocksum, nb);
+  RT_CHECK_LAUNCH();
+  scan_add_kernel<<<(n + 255) / 256, 256, 0, stream>>>(a.offsets, a.cursor, a.blocksum, n);
+  RT_CHECK_LAUNCH();
+  pairs_scatter_kernel<<<blocks, 256, 0, stream>>>(a);
+  RT_CHECK_LAUNCH();
+  sampled_bwd_rows_kernel<D4><<<(a.V + 3) / 4, 256, 0, stream>>>(a);
   RT_CHECK_LAUNCH();
   return RT_OK;
 }
@@ -466,19 +593,40 @@ int rt_sampled_loss_fwd(const float* sess, int64_t ld_sess, const float* table, 
   return dispatch_sampled(a, false, stream);
 }
 
-// d_sess [M,d] overwritten; d_table [V,d] accumulated.  `logits` is clobbered beyond column 260.
+// Host arithmetic: bytes of the int/float scratch rt_sampled_loss_bwd needs.
+size_t rt_sampled_loss_bwd_workspace_bytes(int32_t M, int32_t N, int32_t V) {
+  const size_t C = (size_t)N + 1, n = (size_t)V + 1;
+  const size_t nb = (n + SCAN_T * SCAN_E - 1) / (SCAN_T * SCAN_E);
+  return 4 * ((size_t)M * C * 2 + (size_t)M + 3 * n + nb + 64);
+}
+
+// d_sess [M,d] and d_table [V,d] are fully overwritten (no atomics on floats: the (position, candidate) pairs are
+// counting-sorted by candidate id and each table row is reduced by one wave).  workspace: see the query above.
 int rt_sampled_loss_bwd(const float* sess, int64_t ld_sess, const float* table, const int64_t* y, const int64_t* neg,
-                        const float* w, int32_t M, int32_t N, int32_t d, int32_t loss, int32_t cosine, float logits_t,
-                        double gbce_beta, float* logits, const float* norm, float gscale, float* d_sess, int64_t ld_dsess,
-                        float* d_table, hipStream_t stream) {
+                        const float* w, int32_t M, int32_t N, int32_t d, int32_t V, int32_t loss, int32_t cosine,
+                        float logits_t, double gbce_beta, const float* logits, const float* norm, float gscale,
+                        float* d_sess, int64_t ld_dsess, float* d_table, void* workspace, size_t workspace_bytes,
+                        hipStream_t stream) {
   (void)hipGetLastError();
   if (M <= 0) return RT_OK;
   if ((d & 3) || N < 0 || loss < LOSS_BCE || loss > LOSS_SAMPLED_SOFTMAX || (ld_sess & 3) || (ld_dsess & 3)) return RT_ERR_INVALID_ARG;
+  if ((long long)M * (N + 1) >= (1LL << 31)) return RT_ERR_UNSUPPORTED;
+  if (workspace == nullptr || workspace_bytes < rt_sampled_loss_bwd_workspace_bytes(M, N, V)) return RT_ERR_WORKSPACE;
   SampledArgs a{};
   a.sess = sess; a.ld_sess = ld_sess; a.table = table; a.y = reinterpret_cast<const long long*>(y);
-  a.neg = reinterpret_cast<const long long*>(neg); a.w = w; a.M = M; a.N = N; a.d = d; a.loss = loss; a.cosine = cosine;
-  a.inv_t = 1.0f / logits_t; a.gbce_beta = gbce_beta; a.logits = logits; a.norm = norm; a.gscale = gscale;
+  a.neg = reinterpret_cast<const long long*>(neg); a.w = w; a.M = M; a.N = N; a.d = d; a.V = V; a.loss = loss; a.cosine = cosine;
+  a.inv_t = 1.0f / logits_t; a.gbce_beta = gbce_beta; a.logits = const_cast<float*>(logits); a.norm = norm; a.gscale = gscale;
   a.d_sess = d_sess; a.ld_dsess = ld_dsess; a.d_table = d_table;
+  const size_t C = (size_t)N + 1, n = (size_t)V + 1;
+  float* f = reinterpret_cast<float*>(workspace);
+  a.glog = f; f += (size_t)M * C;
+  a.inv_ns = f; f += M;
+  int* ip = reinterpret_cast<int*>(f);
+  a.pairs = ip; ip += (size_t)M * C;
+  a.count = ip; ip += n;
+  a.offsets = ip; ip += n;
+  a.cursor = ip; ip += n;
+  a.blocksum = ip;
   return dispatch_sampled(a, true, stream);
 }
 

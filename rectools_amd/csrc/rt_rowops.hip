@@ -105,47 +105,65 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 }
 
 // dx = rstd * (dy*w - mean(dy*w) - xhat * mean(dy*w*xhat));  dw += sum dy*xhat;  db += sum dy
+// Each wave keeps the dw/db partial sums of its columns in registers over its rows (NDV float4 per lane,
+// d <= 256*NDV); the 4 waves are combined through LDS and one atomicAdd per column leaves the block.
+template <int NDV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ w, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, int M, int d, int rows_per_block,
                                                             float* __restrict__ dx, float* __restrict__ dw,
                                                             float* __restrict__ db) {
-  extern __shared__ float red[];  // [2][d] partial dw / db of this block
+  extern __shared__ float red[];  // [4 waves][2][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int c = threadIdx.x; c < 2 * d; c += 256) red[c] = 0.f;
-  __syncthreads();
   const int r0 = blockIdx.x * rows_per_block;
   int r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
+  f32x4 pw[NDV], pb[NDV], wv[NDV];
+#pragma unroll
+  for (int i = 0; i < NDV; ++i) {
+    const int c = lane * 4 + 256 * i;
+    pw[i] = f32x4{0.f, 0.f, 0.f, 0.f}; pb[i] = pw[i];
+    wv[i] = (c < d) ? *reinterpret_cast<const f32x4*>(w + c) : pw[i];
+  }
   for (int m = r0 + wave; m < r1; m += 4) {
     const float mu = mean[m], rs = rstd[m];
     const float* xr = x + (long long)m * d;
     const float* gr = dy + (long long)m * d;
+    f32x4 g[NDV], xh[NDV];
     float s1 = 0.f, s2 = 0.f;
-    for (int c = lane * 4; c < d; c += 256) {
-      f32x4 g = *reinterpret_cast<const f32x4*>(gr + c);
-      f32x4 xh = (*reinterpret_cast<const f32x4*>(xr + c) - mu) * rs;
-      f32x4 gw = g * *reinterpret_cast<const f32x4*>(w + c);
+#pragma unroll
+    for (int i = 0; i < NDV; ++i) {
+      const int c = lane * 4 + 256 * i;
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      g[i] = (c < d) ? *reinterpret_cast<const f32x4*>(gr + c) : z;
+      xh[i] = (c < d) ? (*reinterpret_cast<const f32x4*>(xr + c) - mu) * rs : z;
+      f32x4 gw = g[i] * wv[i];
       s1 += gw[0] + gw[1] + gw[2] + gw[3];
-      s2 += gw[0] * xh[0] + gw[1] * xh[1] + gw[2] * xh[2] + gw[3] * xh[3];
+      s2 += gw[0] * xh[i][0] + gw[1] * xh[i][1] + gw[2] * xh[i][2] + gw[3] * xh[i][3];
     }
     s1 = wave_sum(s1) / d; s2 = wave_sum(s2) / d;
-    for (int c = lane * 4; c < d; c += 256) {
-      f32x4 g = *reinterpret_cast<const f32x4*>(gr + c);
-      f32x4 xh = (*reinterpret_cast<const f32x4*>(xr + c) - mu) * rs;
-      f32x4 gw = g * *reinterpret_cast<const f32x4*>(w + c);
-      f32x4 o = (gw - s1 - xh * s2) * rs;
-      *reinterpret_cast<f32x4*>(dx + (long long)m * d + c) = o;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        atomicAdd(&red[c + i], g[i] * xh[i]);
-        atomicAdd(&red[d + c + i], g[i]);
+    for (int i = 0; i < NDV; ++i) {
+      const int c = lane * 4 + 256 * i;
+      if (c < d) {
+        f32x4 o = (g[i] * wv[i] - s1 - xh[i] * s2) * rs;
+        *reinterpret_cast<f32x4*>(dx + (long long)m * d + c) = o;
+        pw[i] += g[i] * xh[i];
+        pb[i] += g[i];
       }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NDV; ++i) {
+    const int c = lane * 4 + 256 * i;
+    if (c < d) {
+      *reinterpret_cast<f32x4*>(red + (wave * 2 + 0) * d + c) = pw[i];
+      *reinterpret_cast<f32x4*>(red + (wave * 2 + 1) * d + c) = pb[i];
     }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < d; c += 256) {
-    atomicAdd(dw + c, red[c]);
-    atomicAdd(db + c, red[d + c]);
+    atomicAdd(dw + c, red[0 * d + c] + red[2 * d + c] + red[4 * d + c] + red[6 * d + c]);
+    atomicAdd(db + c, red[1 * d + c] + red[3 * d + c] + red[5 * d + c] + red[7 * d + c]);
   }
 }
 
@@ -348,12 +366,16 @@ int rt_layernorm_bwd(const float* dy, const float* x, const float* w, const floa
                      int32_t d, float* dx, float* dw, float* db, hipStream_t stream) {
   (void)hipGetLastError();
   if (M <= 0) return RT_OK;
-  if ((d & 3) != 0 || d > 8192) return RT_ERR_INVALID_ARG;
-  int blocks = rt_num_cus() * 2;
+  if ((d & 3) != 0) return RT_ERR_INVALID_ARG;
+  if (d > 1024) return RT_ERR_UNSUPPORTED;
+  int blocks = rt_num_cus() * 4;
   int rpb = (M + blocks - 1) / blocks;
   if (rpb < 4) rpb = 4;
   blocks = (M + rpb - 1) / rpb;
-  layernorm_bwd_kernel<<<blocks, 256, 2 * d * sizeof(float), stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, dw, db);
+  const size_t lds = 8 * (size_t)d * sizeof(float);
+  if (d <= 256) layernorm_bwd_kernel<1><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, dw, db);
+  else if (d <= 512) layernorm_bwd_kernel<2><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, dw, db);
+  else layernorm_bwd_kernel<4><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, dw, db);
   RT_CHECK_LAUNCH();
   return RT_OK;
 }

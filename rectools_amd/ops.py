@@ -495,10 +495,13 @@ class _SampledLoss(torch.autograd.Function):
         loss, cosine, logits_t, beta = ctx.meta
         M, d = sess.shape
         N = neg.shape[-1]
+        V = table.shape[0]
         d_sess = torch.empty((M, d), dtype=torch.float32, device=sess.device)
-        d_table = torch.zeros_like(table)
-        _c("rt_sampled_loss_bwd", sess, sess.stride(0), table, y, neg, w, M, N, d, loss, int(cosine), float(logits_t),
-           float(beta), logits.clone() if N + 1 > 260 else logits, out[1:], float(gloss), d_sess, d, d_table)
+        d_table = torch.empty_like(table)
+        ws_bytes = _lib.load().rt_sampled_loss_bwd_workspace_bytes(M, N, V)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=sess.device)
+        _c("rt_sampled_loss_bwd", sess, sess.stride(0), table, y, neg, w, M, N, d, V, loss, int(cosine), float(logits_t),
+           float(beta), logits, out[1:], float(gloss), d_sess, d, d_table, ws, ws_bytes)
         return d_sess, d_table, None, None, None, None, None, None, None
 
 
