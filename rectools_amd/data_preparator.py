@@ -1,0 +1,353 @@
+"""Host data path of the transformer models: dataset processing, CSR sequence store, collates.
+
+Mirrors `TransformerDataPreparatorBase` / `SASRecDataPreparator` / `BERT4RecDataPreparator`
+(rectools/models/nn/transformers/data_preparator.py:102-469, sasrec.py:51-166, bert4rec.py:51-193), with one
+structural change: user sessions are NOT Python `List[List[int]]` (data_preparator.py:73-99, infeasible at 10 M
+users) but a CSR store — `offsets[n_users+1]` + flat `items / weights / unix_ts` arrays — and the collates are
+vectorised numpy over a batch of CSR slices, producing exactly the tensors the reference's collates produce
+(pinned by tests/golden/collate_golden.npz).  Negatives are drawn on the device (uniform over real items,
+negative_sampler.py:58-73; parity is distributional, as the reference itself resamples every batch).
+"""
+from __future__ import annotations
+
+import typing as tp
+import warnings
+
+import numpy as np
+import pandas as pd
+import torch
+
+from .dataset import Columns, Dataset, IdMap, Interactions
+
+PADDING_VALUE = "PAD"
+MASKING_VALUE = "MASK"
+
+
+class SequenceStore:
+    """CSR store of user sessions, ordered by user (in order of first appearance or sorted) then by time."""
+
+    def __init__(self, offsets: np.ndarray, items: np.ndarray, weights: np.ndarray, unix_ts: tp.Optional[np.ndarray],
+                 users: np.ndarray) -> None:
+        self.offsets, self.items, self.weights, self.unix_ts, self.users = offsets, items, weights, unix_ts, users
+
+    def __len__(self) -> int:
+        return len(self.offsets) - 1
+
+    @classmethod
+    def from_interactions(cls, df: pd.DataFrame, sort_users: bool = False) -> "SequenceStore":
+        """Same grouping as SequenceDataset.from_interactions (data_preparator.py:73-99): stable sort by datetime,
+        group by user (in order of appearance unless `sort_users`)."""
+        d = df.sort_values(Columns.Datetime, kind="stable")
+        users = d[Columns.User].values
+        if sort_users:
+            order = np.argsort(users, kind="stable")
+        else:
+            first_pos = pd.Series(np.arange(len(users))).groupby(users, sort=False).transform("min").values
+            order = np.argsort(first_pos, kind="stable")
+        users = users[order]
+        items = d[Columns.Item].values[order].astype(np.int64)
+        weights = d[Columns.Weight].values[order].astype(np.float32)
+        ts = d["unix_ts"].values[order].astype(np.int64) if "unix_ts" in d.columns else None
+        change = np.flatnonzero(np.r_[True, users[1:] != users[:-1]])
+        offsets = np.r_[change, len(users)].astype(np.int64)
+        return cls(offsets, items, weights, ts, users[change])
+
+    def session(self, i: int) -> tp.Tuple[np.ndarray, np.ndarray]:
+        return self.items[self.offsets[i]:self.offsets[i + 1]], self.weights[self.offsets[i]:self.offsets[i + 1]]
+
+
+def _tail_layout(lengths: np.ndarray, keep: int) -> tp.Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """For sessions truncated to their last `keep` elements: (row index, position inside the kept tail, kept length)."""
+    kept = np.minimum(lengths, keep)
+    rows = np.repeat(np.arange(len(lengths)), kept)
+    starts = np.repeat(np.cumsum(kept) - kept, kept)
+    pos = np.arange(int(kept.sum())) - starts
+    return rows, pos, kept
+
+
+class TransformerDataPreparatorBase:
+    train_session_max_len_addition: int = 0
+    item_extra_tokens: tp.Sequence[tp.Hashable] = (PADDING_VALUE,)
+
+    def __init__(self, session_max_len: int, batch_size: int, dataloader_num_workers: int = 0,
+                 train_min_user_interactions: int = 2, get_val_mask_func: tp.Optional[tp.Callable] = None,
+                 shuffle_train: bool = True, n_negatives: tp.Optional[int] = None, negative_sampler: tp.Any = None,
+                 get_val_mask_func_kwargs: tp.Optional[dict] = None, extra_cols: tp.Optional[tp.List[str]] = None,
+                 add_unix_ts: bool = False, **kwargs: tp.Any) -> None:
+        self.session_max_len = session_max_len
+        self.batch_size = batch_size
+        self.dataloader_num_workers = dataloader_num_workers
+        self.train_min_user_interactions = train_min_user_interactions
+        self.get_val_mask_func = get_val_mask_func
+        self.get_val_mask_func_kwargs = get_val_mask_func_kwargs or {}
+        self.shuffle_train = shuffle_train
+        self.n_negatives = n_negatives
+        self.negative_sampler = negative_sampler
+        self.extra_cols = extra_cols
+        self.add_unix_ts = add_unix_ts
+        self.item_id_map: IdMap
+        self.train_dataset: Dataset
+        self.val_interactions: tp.Optional[pd.DataFrame] = None
+        self.extra_token_ids: tp.Dict[tp.Hashable, int] = {}
+
+    # ---- id bookkeeping -------------------------------------------------------------------------------
+    @property
+    def n_item_extra_tokens(self) -> int:
+        return len(self.item_extra_tokens)
+
+    def get_known_items_sorted_internal_ids(self) -> np.ndarray:
+        return self.item_id_map.get_sorted_internal()[self.n_item_extra_tokens:]
+
+    def get_known_item_ids(self) -> np.ndarray:
+        return self.item_id_map.get_external_sorted_by_internal()[self.n_item_extra_tokens:]
+
+    @staticmethod
+    def _to_unix_ts(datetime: pd.Series) -> np.ndarray:
+        return (pd.to_datetime(datetime).values.astype("datetime64[ns]").astype("int64") / 10**9).astype("int64")
+
+    # ---- train dataset --------------------------------------------------------------------------------
+    def _filter_train_interactions(self, df: pd.DataFrame) -> pd.DataFrame:
+        stats = df[Columns.User].value_counts()
+        users = stats[stats >= self.train_min_user_interactions].index
+        df = df[df[Columns.User].isin(users)]
+        return (df.sort_values(Columns.Datetime, kind="stable").groupby(Columns.User, sort=False)
+                .tail(self.session_max_len + self.train_session_max_len_addition))
+
+    def process_dataset_train(self, dataset: tp.Any) -> None:
+        """data_preparator.py:229-284 — PAD (and MASK) first in the item id map so that PAD == 0."""
+        raw = dataset.get_raw_interactions()
+        if self.add_unix_ts:
+            raw["unix_ts"] = self._to_unix_ts(raw[Columns.Datetime])
+        interactions = raw
+        val_mask = None
+        if self.get_val_mask_func is not None:
+            val_mask = self.get_val_mask_func(raw, **self.get_val_mask_func_kwargs)
+            interactions = raw[~val_mask].reset_index(drop=True)
+        interactions = self._filter_train_interactions(interactions)
+        user_id_map = IdMap.from_values(interactions[Columns.User].values)
+        item_id_map = IdMap.from_values(np.array(list(self.item_extra_tokens), dtype=object))
+        item_id_map = item_id_map.add_ids(interactions[Columns.Item])
+        final = Interactions.from_raw(interactions, user_id_map, item_id_map, keep_extra_cols=True)
+        self.train_dataset = Dataset(user_id_map, item_id_map, final)
+        self.item_id_map = item_id_map
+        self.extra_token_ids = dict(zip(self.item_extra_tokens, item_id_map.convert_to_internal(list(self.item_extra_tokens))))
+        self.val_interactions = None
+        if val_mask is not None:
+            val_targets = raw[val_mask]
+            val_targets = val_targets[val_targets[Columns.User].isin(user_id_map.external_ids)
+                                      & val_targets[Columns.Item].isin(item_id_map.external_ids)]
+            val_inter = interactions[interactions[Columns.User].isin(val_targets[Columns.User].unique())].copy()
+            val_inter[Columns.Weight] = 0
+            val_inter = pd.concat([val_inter, val_targets], axis=0)
+            self.val_interactions = Interactions.from_raw(val_inter, user_id_map, item_id_map, keep_extra_cols=True).df
+
+    def train_store(self) -> SequenceStore:
+        return SequenceStore.from_interactions(self.train_dataset.interactions.df)
+
+    def val_store(self) -> tp.Optional[SequenceStore]:
+        return None if self.val_interactions is None else SequenceStore.from_interactions(self.val_interactions)
+
+    # ---- recommend datasets ---------------------------------------------------------------------------
+    def transform_dataset_u2i(self, dataset: tp.Any, users: tp.Any, context: tp.Optional[pd.DataFrame] = None) -> Dataset:
+        """data_preparator.py:354-424"""
+        df = dataset.interactions.df
+        cols = Columns.Interactions + [c for c in (self.extra_cols or []) if c in df.columns]
+        interactions = df[cols]
+        users_internal = dataset.user_id_map.convert_to_internal(users, strict=False)
+        items_internal = dataset.item_id_map.convert_to_internal(self.get_known_item_ids(), strict=False)
+        interactions = interactions[interactions[Columns.User].isin(users_internal)]
+        interactions = interactions[interactions[Columns.Item].isin(items_internal)].copy()
+        interactions[Columns.Item] = dataset.item_id_map.convert_to_external(interactions[Columns.Item].values)
+        interactions[Columns.User] = dataset.user_id_map.convert_to_external(interactions[Columns.User].values)
+        rec_user_id_map = IdMap.from_values(interactions[Columns.User].values)
+        if context is not None:
+            if not pd.Series(np.asarray(users)).isin(context[Columns.User].unique()).all():
+                raise ValueError("No context for some target users")
+            if context.duplicated(subset=Columns.User).any():
+                raise ValueError("Duplicated user entries found in context. Each user must have exactly one context row.")
+            context = context.copy()
+            context[Columns.Item] = PADDING_VALUE
+            if Columns.Weight not in context.columns:
+                context[Columns.Weight] = 0.0
+            context = context[context[Columns.User].isin(interactions[Columns.User].unique())]
+            interactions = pd.concat([interactions, context[[c for c in interactions.columns if c in context.columns]]])
+        if self.add_unix_ts:
+            interactions["unix_ts"] = self._to_unix_ts(interactions[Columns.Datetime])
+        n_filtered = len(np.asarray(users)) - rec_user_id_map.size
+        if n_filtered > 0:
+            warnings.warn(f"{n_filtered} target users were considered cold because of missing known items")
+        filtered = Interactions.from_raw(interactions, rec_user_id_map, self.item_id_map, keep_extra_cols=True)
+        return Dataset(rec_user_id_map, self.item_id_map, filtered)
+
+    def transform_dataset_i2i(self, dataset: tp.Any) -> Dataset:
+        """data_preparator.py:426-451"""
+        raw = dataset.get_raw_interactions()
+        raw = raw[raw[Columns.Item].isin(self.get_known_item_ids())]
+        return Dataset(dataset.user_id_map, self.item_id_map, Interactions.from_raw(raw, dataset.user_id_map, self.item_id_map, True))
+
+    # ---- batches ----------------------------------------------------------------------------------------
+    def sample_negatives(self, shape: tp.Tuple[int, ...], device: tp.Any, generator: tp.Optional[torch.Generator] = None) -> torch.Tensor:
+        """CatalogUniformSampler.get_negatives (negative_sampler.py:58-73): uniform over real items, no rejection."""
+        return torch.randint(self.n_item_extra_tokens, self.item_id_map.size, shape, device=device, generator=generator)
+
+    def collate_train(self, store: SequenceStore, idx: np.ndarray) -> tp.Dict[str, np.ndarray]:
+        raise NotImplementedError()
+
+    def collate_val(self, store: SequenceStore, idx: np.ndarray) -> tp.Dict[str, np.ndarray]:
+        raise NotImplementedError()
+
+    def collate_recommend(self, store: SequenceStore, idx: np.ndarray) -> tp.Dict[str, np.ndarray]:
+        raise NotImplementedError()
+
+
+def _gather_tails(store: SequenceStore, idx: np.ndarray, keep: int):
+    """Flat views of the last `keep` elements of the selected sessions."""
+    lo, hi = store.offsets[idx], store.offsets[idx + 1]
+    lengths = hi - lo
+    rows, pos, kept = _tail_layout(lengths, keep)
+    src = np.repeat(hi - kept, kept) + pos
+    return rows, pos, kept, src
+
+
+class SASRecDataPreparator(TransformerDataPreparatorBase):
+    """Shifted-sequence objective: x = session[:-1], y = session[1:] (sasrec.py:51-166)."""
+
+    train_session_max_len_addition: int = 1
+
+    def collate_train(self, store: SequenceStore, idx: np.ndarray) -> tp.Dict[str, np.ndarray]:
+        B, L = len(idx), self.session_max_len
+        rows, pos, kept, src = _gather_tails(store, idx, L + 1)
+        n = np.repeat(kept, kept)
+        x = np.zeros((B, L), np.int64); y = np.zeros((B, L), np.int64); yw = np.zeros((B, L), np.float32)
+        col = L - (n - 1) + pos              # column of element `pos` when used as an input
+        m_in = pos < n - 1
+        x[rows[m_in], col[m_in]] = store.items[src[m_in]]
+        m_out = pos >= 1
+        y[rows[m_out], col[m_out] - 1] = store.items[src[m_out]]
+        yw[rows[m_out], col[m_out] - 1] = store.weights[src[m_out]]
+        out = {"x": x, "y": y, "yw": yw}
+        if self.add_unix_ts:
+            t = np.zeros((B, L + 1), np.int64)
+            t[rows, (L + 1) - n + pos] = store.unix_ts[src]
+            first = t[np.arange(B), (L + 1) - kept]
+            pad = np.arange(L + 1)[None, :] < ((L + 1) - kept)[:, None]
+            t = np.where(pad, first[:, None], t)
+            out["unix_ts"] = t
+        return out
+
+    def collate_val(self, store: SequenceStore, idx: np.ndarray) -> tp.Dict[str, np.ndarray]:
+        """sasrec.py:118-147: inputs are the zero-weight interactions, target the first non-zero-weight one."""
+        B, L = len(idx), self.session_max_len
+        x = np.zeros((B, L), np.int64); y = np.zeros((B, 1), np.int64); yw = np.zeros((B, 1), np.float32)
+        t = np.zeros((B, L + 1), np.int64)
+        for i, u in enumerate(idx):
+            ses, w = store.session(int(u))
+            inp = ses[w == 0][-L:]
+            tgt = int(np.flatnonzero(w != 0)[0])
+            x[i, L - len(inp):] = inp
+            y[i, 0], yw[i, 0] = ses[tgt], w[tgt]
+            if self.add_unix_ts:
+                ts = store.unix_ts[store.offsets[u]:store.offsets[u + 1]]
+                t[i, L + 1 - (len(ses) - 1):] = ts[1:][-(L + 1):] if len(ses) - 1 <= L + 1 else ts[-(L + 1):]
+                n_pad = L + 2 - len(ses)
+                if n_pad > 0:
+                    t[i, :n_pad] = t[i, n_pad]
+        out = {"x": x, "y": y, "yw": yw}
+        if self.add_unix_ts:
+            out["unix_ts"] = t
+        return out
+
+    def collate_recommend(self, store: SequenceStore, idx: np.ndarray) -> tp.Dict[str, np.ndarray]:
+        B, L = len(idx), self.session_max_len
+        x = np.zeros((B, L), np.int64)
+        if self.add_unix_ts:  # last element of every session is the dummy context row (sasrec.py:154-163)
+            rows, pos, kept, src = _gather_tails(store, idx, L + 1)
+            n = np.repeat(kept, kept)
+            m_in = pos < n - 1
+            x[rows[m_in], (L - (n - 1) + pos)[m_in]] = store.items[src[m_in]]
+            t = np.zeros((B, L + 1), np.int64)
+            t[rows, (L + 1) - n + pos] = store.unix_ts[src]
+            first = t[np.arange(B), (L + 1) - kept]
+            pad = np.arange(L + 1)[None, :] < ((L + 1) - kept)[:, None]
+            return {"x": x, "unix_ts": np.where(pad, first[:, None], t)}
+        rows, pos, kept, src = _gather_tails(store, idx, L)
+        n = np.repeat(kept, kept)
+        x[rows, L - n + pos] = store.items[src]
+        return {"x": x}
+
+
+class BERT4RecDataPreparator(TransformerDataPreparatorBase):
+    """Masked-item objective (bert4rec.py:51-193).  MASK is the second extra token (id 1)."""
+
+    train_session_max_len_addition: int = 0
+    item_extra_tokens: tp.Sequence[tp.Hashable] = (PADDING_VALUE, MASKING_VALUE)
+
+    def __init__(self, *args: tp.Any, mask_prob: float = 0.15, **kwargs: tp.Any) -> None:
+        super().__init__(*args, **kwargs)
+        self.mask_prob = mask_prob
+
+    def _mask_session(self, ses: np.ndarray, first_border: float = 0.8, second_border: float = 0.9):
+        """bert4rec.py:109-127 with the reference's exact np.random call order (rand per session, randint per
+        randomly replaced element), so that a seeded run masks the same positions."""
+        masked, target = ses.copy(), ses.copy()
+        probs = np.random.rand(len(ses))
+        for j in range(len(ses)):
+            if probs[j] < self.mask_prob:
+                pj = probs[j] / self.mask_prob
+                if pj < first_border:
+                    masked[j] = self.extra_token_ids[MASKING_VALUE]
+                elif pj < second_border:
+                    masked[j] = np.random.randint(low=self.n_item_extra_tokens, high=self.item_id_map.size)
+            else:
+                target[j] = 0
+        return masked, target
+
+    def collate_train(self, store: SequenceStore, idx: np.ndarray) -> tp.Dict[str, np.ndarray]:
+        B, L = len(idx), self.session_max_len
+        x = np.zeros((B, L), np.int64); y = np.zeros((B, L), np.int64); yw = np.zeros((B, L), np.float32)
+        for i, u in enumerate(idx):
+            ses, w = store.session(int(u))
+            ses, w = ses[-L:], w[-L:]   # train sessions already hold at most L items (addition = 0)
+            masked, target = self._mask_session(ses)
+            x[i, L - len(ses):] = masked
+            y[i, L - len(ses):] = target
+            yw[i, L - len(ses):] = w
+        return {"x": x, "y": y, "yw": yw}
+
+    def collate_val(self, store: SequenceStore, idx: np.ndarray) -> tp.Dict[str, np.ndarray]:
+        B, L = len(idx), self.session_max_len
+        x = np.zeros((B, L), np.int64); y = np.zeros((B, 1), np.int64); yw = np.zeros((B, 1), np.float32)
+        for i, u in enumerate(idx):
+            ses, w = store.session(int(u))
+            inp = np.r_[ses[w == 0], self.extra_token_ids[MASKING_VALUE]][-L:]
+            tgt = int(np.flatnonzero(w != 0)[0])
+            x[i, L - len(inp):] = inp
+            y[i, 0], yw[i, 0] = ses[tgt], w[tgt]
+        return {"x": x, "y": y, "yw": yw}
+
+    def collate_recommend(self, store: SequenceStore, idx: np.ndarray) -> tp.Dict[str, np.ndarray]:
+        """history[-(L-1):] + [MASK], left padded (bert4rec.py:182-193)."""
+        B, L = len(idx), self.session_max_len
+        x = np.zeros((B, L), np.int64)
+        rows, pos, kept, src = _gather_tails(store, idx, L - 1)
+        n = np.repeat(kept, kept)
+        x[rows, (L - 1) - n + pos] = store.items[src]
+        x[:, L - 1] = self.extra_token_ids[MASKING_VALUE]
+        return {"x": x}
+
+
+def epoch_permutation(n: int, epoch: int, seed: int, shuffle: bool) -> np.ndarray:
+    """Sample order of one epoch; identical on every rank (then sharded as perm[rank::world], DistributedSampler-style)."""
+    if not shuffle:
+        return np.arange(n)
+    return np.random.default_rng(seed + 1000003 * epoch).permutation(n)
+
+
+def shard_indices(perm: np.ndarray, rank: int, world: int) -> np.ndarray:
+    """DistributedSampler semantics: pad to a multiple of `world` by wrapping, then take every world-th sample."""
+    if world <= 1:
+        return perm
+    total = -(-len(perm) // world) * world
+    if total > len(perm):
+        perm = np.r_[perm, perm[: total - len(perm)]]
+    return perm[rank::world]

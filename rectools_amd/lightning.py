@@ -143,14 +143,20 @@ class FlatAdam:
                 g.copy_(p.grad)
                 p.grad = g
 
-    def step(self, world_size: int = 1) -> None:
+    def reduce_gradients(self, world_size: int = 1) -> float:
+        """Data-parallel gradient exchange: ONE sum all-reduce of the flat gradient buffer (RCCL over xGMI on GPUs,
+        gloo in the CPU tests).  Returns the scale that turns the sum into DDP's mean; it is folded into the Adam
+        kernel instead of a separate pass over the buffer."""
         self._sync_grads()
-        scale = 1.0
-        if world_size > 1:
-            import torch.distributed as dist
+        if world_size <= 1:
+            return 1.0
+        import torch.distributed as dist
 
-            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)  # ONE collective per step (RCCL over xGMI)
-            scale = 1.0 / world_size                           # DDP averages gradients
+        dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
+        return 1.0 / world_size
+
+    def step(self, world_size: int = 1) -> None:
+        scale = self.reduce_gradients(world_size)
         self.step_count += 1
         ops._c("rt_adam_step", self.flat_p, self.flat_g, self.m, self.v, self.flat_p.numel(), self.step_count, float(self.lr),
                float(self.betas[0]), float(self.betas[1]), float(self.eps), float(scale))

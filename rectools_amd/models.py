@@ -1,0 +1,527 @@
+"""`SASRecModel`, `BERT4RecModel`, `HSTUModel` — the reference's public model API on the MI355X engine.
+
+Same constructor arguments, `fit` / `fit_partial` / `recommend` / `recommend_to_items` / `get_config` / `from_config` /
+`get_params` / `save` / `load` contract and result frames as `rectools.models.SASRecModel` etc.
+(rectools/models/nn/transformers/base.py:241-724, sasrec.py:315-541, bert4rec.py:204-452, hstu.py:412-729,
+rectools/models/base.py:326-519), with PyTorch-Lightning replaced by a native loop (`_run_epochs`): per batch
+vectorised collate -> H2D -> HIP forward/backward (rectools_amd.ops) -> one fused Adam kernel, and — under
+torch.distributed — DistributedSampler-style sharding plus ONE RCCL all-reduce of the flat gradient per step.
+recommend() keeps user and item embeddings on the device and ranks them with the exact top-k HIP kernel.
+"""
+from __future__ import annotations
+
+import importlib
+import io
+import pickle
+import typing as tp
+import warnings
+
+import numpy as np
+import pandas as pd
+import torch
+
+from . import lightning as hl
+from . import nn as hnn
+from . import ops
+from .data_preparator import (BERT4RecDataPreparator, SASRecDataPreparator, SequenceStore, TransformerDataPreparatorBase,
+                              epoch_permutation, shard_indices)
+from .dataset import Columns
+from .rank import DeviceCSR, Distance, HipRanker
+
+
+class NotFittedError(Exception):
+    """Raised when `recommend` is called before `fit` (rectools/exceptions.py)."""
+
+    def __init__(self, model_name: str) -> None:
+        super().__init__(f"{model_name} isn't fitted, call method `fit` first.")
+
+
+def _full_path(obj: tp.Any) -> str:
+    return f"{obj.__module__}.{obj.__qualname__}"
+
+
+def _import_object(path: tp.Union[str, tp.Any]) -> tp.Any:
+    if not isinstance(path, str):
+        return path
+    module, name = path.rsplit(".", 1)
+    return getattr(importlib.import_module(module), name)
+
+
+def _dist_info() -> tp.Tuple[int, int]:
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+class TransformerModelBase:
+    """Config shell + native training loop + device-resident recommend."""
+
+    train_loss_name = "train_loss"
+    val_loss_name = "val_loss"
+    u2i_dist_default = "dot"
+    use_scale_factor_default = False
+    recommends_for_warm = False
+    recommends_for_cold = False
+
+    def __init__(  # pylint: disable=too-many-arguments, too-many-locals
+        self,
+        data_preparator_type: tp.Type[TransformerDataPreparatorBase],
+        transformer_layers_type: tp.Type[hnn.TransformerLayersBase] = hnn.PreLNTransformerLayers,
+        n_blocks: int = 2, n_heads: int = 4, n_factors: int = 256, use_pos_emb: bool = True, use_causal_attn: bool = False,
+        use_key_padding_mask: bool = False, dropout_rate: float = 0.2, session_max_len: int = 100,
+        dataloader_num_workers: int = 0, batch_size: int = 128, loss: str = "softmax", n_negatives: int = 1,
+        gbce_t: float = 0.2, lr: float = 0.001, epochs: int = 3, verbose: int = 0, deterministic: bool = False,
+        recommend_batch_size: int = 256, recommend_torch_device: tp.Optional[str] = None,
+        train_min_user_interactions: int = 2,
+        similarity_module_type: tp.Type[hnn.DistanceSimilarityModule] = hnn.DistanceSimilarityModule,
+        get_val_mask_func: tp.Optional[tp.Callable] = None, get_val_mask_func_kwargs: tp.Optional[dict] = None,
+        data_preparator_kwargs: tp.Optional[dict] = None, transformer_layers_kwargs: tp.Optional[dict] = None,
+        pos_encoding_kwargs: tp.Optional[dict] = None, lightning_module_kwargs: tp.Optional[dict] = None,
+        similarity_module_kwargs: tp.Optional[dict] = None, seed: tp.Optional[int] = None,
+        **kwargs: tp.Any,
+    ) -> None:
+        self._params = dict(
+            n_blocks=n_blocks, n_heads=n_heads, n_factors=n_factors, use_pos_emb=use_pos_emb, use_causal_attn=use_causal_attn,
+            use_key_padding_mask=use_key_padding_mask, dropout_rate=dropout_rate, session_max_len=session_max_len,
+            dataloader_num_workers=dataloader_num_workers, batch_size=batch_size, loss=loss, n_negatives=n_negatives,
+            gbce_t=gbce_t, lr=lr, epochs=epochs, verbose=verbose, deterministic=deterministic,
+            recommend_batch_size=recommend_batch_size, recommend_torch_device=recommend_torch_device,
+            train_min_user_interactions=train_min_user_interactions, get_val_mask_func=get_val_mask_func,
+            get_val_mask_func_kwargs=get_val_mask_func_kwargs, data_preparator_kwargs=data_preparator_kwargs,
+            transformer_layers_kwargs=transformer_layers_kwargs, pos_encoding_kwargs=pos_encoding_kwargs,
+            lightning_module_kwargs=lightning_module_kwargs, similarity_module_kwargs=similarity_module_kwargs, seed=seed,
+            data_preparator_type=data_preparator_type, transformer_layers_type=transformer_layers_type,
+            similarity_module_type=similarity_module_type,
+        )
+        self._params.update(kwargs)
+        for k, v in self._params.items():
+            setattr(self, k, v)
+        if hl.requires_negatives(loss) is None:
+            raise ValueError(f"loss {loss} is not supported")
+        self.is_fitted = False
+        self.lightning_model: tp.Optional[hl.TransformerLossModule] = None
+        self.optimizer: tp.Optional[hl.FlatAdam] = None
+        self.epochs_done = 0
+        self.history: tp.List[tp.Dict[str, float]] = []
+        self._init_data_preparator()
+
+    # ---- wiring -------------------------------------------------------------------------------------------
+    def _kw(self, d: tp.Optional[dict]) -> dict:
+        return dict(d) if d else {}
+
+    def _init_data_preparator(self) -> None:
+        self.data_preparator = self.data_preparator_type(
+            session_max_len=self.session_max_len, batch_size=self.batch_size, dataloader_num_workers=self.dataloader_num_workers,
+            train_min_user_interactions=self.train_min_user_interactions,
+            n_negatives=self.n_negatives if hl.requires_negatives(self.loss) else None,
+            get_val_mask_func=self.get_val_mask_func, get_val_mask_func_kwargs=self.get_val_mask_func_kwargs,
+            **self._kw(self.data_preparator_kwargs),
+        )
+
+    def _init_transformer_layers(self) -> hnn.TransformerLayersBase:
+        return self.transformer_layers_type(n_blocks=self.n_blocks, n_factors=self.n_factors, n_heads=self.n_heads,
+                                            dropout_rate=self.dropout_rate, **self._kw(self.transformer_layers_kwargs))
+
+    def _init_similarity_module(self) -> hnn.DistanceSimilarityModule:
+        kw = self._kw(self.similarity_module_kwargs)
+        kw.setdefault("distance", self.u2i_dist_default)
+        return self.similarity_module_type(**kw)
+
+    def _build_model_from_dataset(self, dataset: tp.Any) -> None:
+        self.data_preparator.process_dataset_train(dataset)
+        n_tokens = self.data_preparator.item_id_map.size
+        item_model = hnn.SumOfEmbeddingsConstructor(n_tokens, [hnn.IdEmbeddingsItemNet(self.n_factors, n_tokens, self.dropout_rate)])
+        pkw = self._kw(self.pos_encoding_kwargs)
+        pkw.setdefault("use_scale_factor", self.use_scale_factor_default)
+        pos = hnn.LearnableInversePositionalEncoding(self.use_pos_emb, self.session_max_len, self.n_factors, **pkw)
+        backbone = hnn.TransformerTorchBackbone(
+            n_heads=self.n_heads, dropout_rate=self.dropout_rate, item_model=item_model, pos_encoding_layer=pos,
+            transformer_layers=self._init_transformer_layers(), similarity_module=self._init_similarity_module(),
+            use_causal_attn=self.use_causal_attn, use_key_padding_mask=self.use_key_padding_mask)
+        lkw = self._kw(self.lightning_module_kwargs)
+        self.lightning_model = hl.TransformerLossModule(
+            backbone, self.loss, self.n_negatives if hl.requires_negatives(self.loss) else None, self.gbce_t,
+            lkw.get("logits_t", 1.0), self.data_preparator.n_item_extra_tokens)
+        device = torch.device(self._device())
+        self.lightning_model.to(device)
+        if self.seed is not None:
+            torch.manual_seed(self.seed)
+        hl.xavier_normal_init(self.lightning_model.torch_model)  # on_train_start (lightning.py:296-299)
+        self.optimizer = hl.FlatAdam(self.lightning_model.torch_model, lr=self.lr, betas=(0.9, 0.98))
+        self.epochs_done = 0
+        self.history = []
+
+    def _device(self) -> str:
+        if self.recommend_torch_device is not None and str(self.recommend_torch_device) != "cpu":
+            return str(self.recommend_torch_device)
+        import os
+
+        if torch.cuda.is_available():
+            return f"cuda:{os.environ.get('LOCAL_RANK', '0')}" if "LOCAL_RANK" in os.environ else "cuda"
+        from . import _lib
+
+        raise _lib.HipLibraryError("no HIP device visible: the MI355X engine cannot run (no CPU fallback)")
+
+    @property
+    def torch_model(self) -> hnn.TransformerTorchBackbone:
+        if self.lightning_model is None:
+            raise NotFittedError(type(self).__name__)
+        return self.lightning_model.torch_model
+
+    @property
+    def require_recommend_context(self) -> bool:
+        return False
+
+    # ---- training -----------------------------------------------------------------------------------------
+    def _to_device(self, batch: tp.Dict[str, np.ndarray], device: torch.device, train: bool) -> tp.Dict[str, torch.Tensor]:
+        out = {k: torch.from_numpy(v).to(device, non_blocking=True) for k, v in batch.items()}
+        if hl.requires_negatives(self.loss) and "y" in out:
+            B = out["x"].shape[0]
+            shape = (B, self.session_max_len if out["y"].shape[1] > 1 else 1, self.n_negatives)
+            out["negatives"] = self.data_preparator.sample_negatives(shape, device)
+        return out
+
+    def _run_epochs(self, first: int, last: int) -> None:
+        lm, opt, dp = self.lightning_model, self.optimizer, self.data_preparator
+        assert lm is not None and opt is not None
+        device = next(lm.parameters()).device
+        rank, world = _dist_info()
+        store = dp.train_store()
+        val_store = dp.val_store()
+        seed = 0 if self.seed is None else int(self.seed)
+        for epoch in range(first, last):
+            lm.train()
+            perm = epoch_permutation(len(store), epoch, seed, dp.shuffle_train)
+            mine = shard_indices(perm, rank, world)
+            total = torch.zeros((), device=device)
+            n_batches = 0
+            for b0 in range(0, len(mine), self.batch_size):
+                batch = self._to_device(dp.collate_train(store, mine[b0:b0 + self.batch_size]), device, True)
+                ops.RNG.next_step()
+                opt.zero_grad()
+                loss = lm.training_loss(batch)
+                loss.backward()
+                opt.step(world)
+                total += loss.detach()
+                n_batches += 1
+            rec = {"epoch": epoch, self.train_loss_name: float(total) / max(n_batches, 1)}
+            if val_store is not None:
+                lm.eval()
+                vt, vn = torch.zeros((), device=device), 0
+                with torch.no_grad():
+                    for b0 in range(0, len(val_store), self.batch_size):
+                        vb = self._to_device(dp.collate_val(val_store, np.arange(b0, min(b0 + self.batch_size, len(val_store)))), device, False)
+                        vt += lm.validation_loss(vb)
+                        vn += 1
+                rec[self.val_loss_name] = float(vt) / max(vn, 1)
+            self.history.append(rec)
+            if self.verbose and rank == 0:
+                print(rec)
+            self.epochs_done = epoch + 1
+
+    def fit(self, dataset: tp.Any) -> "TransformerModelBase":
+        """Fit from scratch (models/base.py:326-341 -> transformers/base.py:481-489)."""
+        self._build_model_from_dataset(dataset)
+        self._run_epochs(0, self.epochs)
+        self.is_fitted = True
+        return self
+
+    def fit_partial(self, dataset: tp.Any, min_epochs: int = 1, max_epochs: int = 1) -> "TransformerModelBase":
+        """Continue training for `max_epochs` more epochs (transformers/base.py:505-533)."""
+        if not self.is_fitted:
+            self._build_model_from_dataset(dataset)
+        else:
+            self.data_preparator.process_dataset_train(dataset)
+        self._run_epochs(self.epochs_done, self.epochs_done + max_epochs)
+        self.is_fitted = True
+        return self
+
+    # ---- inference ----------------------------------------------------------------------------------------
+    def _user_embeddings(self, store: SequenceStore, device: torch.device) -> torch.Tensor:
+        """Last-slot encodings of every session, eval mode, kept on the device (lightning.py:378-400)."""
+        lm = self.lightning_model
+        assert lm is not None
+        lm.eval()
+        outs = []
+        with torch.no_grad():
+            for b0 in range(0, len(store), self.recommend_batch_size):
+                idx = np.arange(b0, min(b0 + self.recommend_batch_size, len(store)))
+                batch = {k: torch.from_numpy(v).to(device) for k, v in self.data_preparator.collate_recommend(store, idx).items()}
+                enc = lm.torch_model.encode_sessions(batch)
+                outs.append(enc[:, -1, :].contiguous())
+        return torch.cat(outs) if outs else torch.zeros((0, self.n_factors), device=device)
+
+    def _check(self, k: int) -> None:
+        if not self.is_fitted:
+            raise NotFittedError(type(self).__name__)
+        if k <= 0:
+            raise ValueError("`k` must be positive integer")
+
+    def _whitelist(self, items_to_recommend: tp.Optional[tp.Any]) -> np.ndarray:
+        dp = self.data_preparator
+        if items_to_recommend is None:
+            return dp.get_known_items_sorted_internal_ids()
+        internal = dp.item_id_map.convert_to_internal(items_to_recommend, strict=False)
+        internal = internal[internal >= dp.n_item_extra_tokens]
+        return np.unique(internal)
+
+    def recommend(self, users: tp.Any, dataset: tp.Any, k: int, filter_viewed: bool, items_to_recommend: tp.Optional[tp.Any] = None,
+                  add_rank_col: bool = True, on_unsupported_targets: str = "raise",
+                  context: tp.Optional[pd.DataFrame] = None) -> pd.DataFrame:
+        """Top-k items for `users` (models/base.py:385-519)."""
+        self._check(k)
+        if on_unsupported_targets not in ("raise", "warn", "ignore"):
+            raise ValueError("`on_unsupported_targets` must be one of 'raise', 'warn', 'ignore'")
+        if self.require_recommend_context and context is None:
+            raise ValueError("This model requires `context` to be provided for recommendations generation")
+        if not self.require_recommend_context and context is not None:
+            context = None
+        users = np.asarray(users)
+        known = pd.Series(users).isin(dataset.user_id_map.external_ids).values
+        if not known.all():
+            if on_unsupported_targets == "raise":
+                raise ValueError("Model doesn't support recommendations for cold users, but some of given users are cold")
+            if on_unsupported_targets == "warn":
+                warnings.warn("Model doesn't support recommendations for cold users, but some of given users are cold")
+            users = users[known]
+        with warnings.catch_warnings():
+            if on_unsupported_targets == "ignore":
+                warnings.simplefilter("ignore")
+            rec_ds = self.data_preparator.transform_dataset_u2i(dataset, users, context)
+        user_ids = rec_ds.user_id_map.convert_to_internal(users, strict=False)
+        whitelist = self._whitelist(items_to_recommend)
+        device = next(self.lightning_model.parameters()).device
+        store = SequenceStore.from_interactions(rec_ds.interactions.df, sort_users=True)  # session i <-> internal user i
+        if len(user_ids) == 0 or len(whitelist) == 0:
+            return self._frame(np.array([], users.dtype), np.array([], object), np.array([], np.float32), add_rank_col, Columns.User)
+        user_embs = self._user_embeddings(store, device)
+        item_embs = self.lightning_model.torch_model.item_model.table.detach()
+        ranker = HipRanker(self.lightning_model.torch_model.similarity_module.distance, device, user_embs, item_embs)
+        filt = None
+        if filter_viewed:
+            filt = DeviceCSR.from_scipy(rec_ds.get_user_item_matrix(include_weights=False)[user_ids], device)
+        ids, scores, counts, _ = ranker.rank_device(user_ids, k=k, filter_pairs_csr=filt, sorted_object_whitelist=whitelist)
+        return self._assemble(rec_ds.user_id_map.convert_to_external(user_ids), ids, scores, counts, add_rank_col, Columns.User)
+
+    def recommend_to_items(self, target_items: tp.Any, dataset: tp.Any, k: int, filter_itself: bool = True,
+                           items_to_recommend: tp.Optional[tp.Any] = None, add_rank_col: bool = True,
+                           on_unsupported_targets: str = "raise") -> pd.DataFrame:
+        """Item-to-item by cosine over the item table (lightning.py:428-449, models/base.py:521-646)."""
+        self._check(k)
+        dp = self.data_preparator
+        target_items = np.asarray(target_items)
+        known = pd.Series(target_items).isin(dp.get_known_item_ids()).values
+        if not known.all():
+            if on_unsupported_targets == "raise":
+                raise ValueError("Model doesn't support recommendations for cold items, but some of given items are cold")
+            if on_unsupported_targets == "warn":
+                warnings.warn("Model doesn't support recommendations for cold items, but some of given items are cold")
+            target_items = target_items[known]
+        target_ids = dp.item_id_map.convert_to_internal(target_items)
+        whitelist = self._whitelist(items_to_recommend)
+        device = next(self.lightning_model.parameters()).device
+        item_embs = self.lightning_model.torch_model.item_model.table.detach()
+        ranker = HipRanker(Distance.COSINE, device, item_embs, item_embs)
+        kk = k + 1 if filter_itself else k
+        ids, scores, counts, _ = ranker.rank_device(target_ids, k=kk, sorted_object_whitelist=whitelist)
+        ids, scores, counts = ids.cpu().numpy(), scores.cpu().numpy(), counts.cpu().numpy()
+        t_out, i_out, s_out = [], [], []
+        for r, t in enumerate(target_ids):
+            row_ids, row_sc = ids[r, :counts[r]], scores[r, :counts[r]]
+            if filter_itself:
+                keep = row_ids != t
+                row_ids, row_sc = row_ids[keep][:k], row_sc[keep][:k]
+            t_out.append(np.repeat(target_items[r], len(row_ids))); i_out.append(row_ids); s_out.append(row_sc)
+        tt = np.concatenate(t_out) if t_out else np.array([], target_items.dtype)
+        ii = dp.item_id_map.convert_to_external(np.concatenate(i_out).astype(np.int64)) if i_out else np.array([], object)
+        return self._frame(tt, ii, np.concatenate(s_out) if s_out else np.array([], np.float32), add_rank_col, Columns.TargetItem)
+
+    def _assemble(self, ext_users: np.ndarray, ids: torch.Tensor, scores: torch.Tensor, counts: torch.Tensor, add_rank_col: bool,
+                  target_col: str) -> pd.DataFrame:
+        ids, scores, counts = ids.cpu().numpy(), scores.cpu().numpy(), counts.cpu().numpy()
+        kk = ids.shape[1]
+        valid = (np.arange(kk)[None, :] < counts[:, None]) & (scores > -np.inf)
+        tt = np.repeat(ext_users, kk).reshape(len(ext_users), kk)[valid]
+        ii = self.data_preparator.item_id_map.convert_to_external(ids[valid])
+        return self._frame(tt, ii, scores[valid], add_rank_col, target_col)
+
+    @staticmethod
+    def _frame(targets: np.ndarray, items: np.ndarray, scores: np.ndarray, add_rank_col: bool, target_col: str) -> pd.DataFrame:
+        df = pd.DataFrame({target_col: targets, Columns.Item: items, Columns.Score: scores.astype(np.float32)})
+        if add_rank_col:
+            df[Columns.Rank] = df.groupby(target_col, sort=False).cumcount() + 1  # models/base.py:788-789
+        return df
+
+    # ---- config / persistence -----------------------------------------------------------------------------
+    def get_config(self, simple_types: bool = True) -> tp.Dict[str, tp.Any]:
+        cfg = {"cls": _full_path(type(self)) if simple_types else type(self)}
+        for k, v in self._params.items():
+            if isinstance(v, type) or callable(v) and not isinstance(v, (int, float, str, bool)) and v is not None:
+                cfg[k] = _full_path(v) if simple_types else v
+            else:
+                cfg[k] = v
+        return cfg
+
+    def get_params(self, simple_types: bool = True, sep: str = ".") -> tp.Dict[str, tp.Any]:
+        flat: tp.Dict[str, tp.Any] = {}
+        for k, v in self.get_config(simple_types).items():
+            if isinstance(v, dict):
+                for kk, vv in v.items():
+                    flat[f"{k}{sep}{kk}"] = vv
+            else:
+                flat[k] = v
+        return flat
+
+    @classmethod
+    def from_config(cls, config: tp.Dict[str, tp.Any]) -> "TransformerModelBase":
+        cfg = dict(config)
+        klass = _import_object(cfg.pop("cls", cls))
+        for key in ("data_preparator_type", "transformer_layers_type", "similarity_module_type", "get_val_mask_func"):
+            if cfg.get(key) is not None:
+                cfg[key] = _import_object(cfg[key])
+        return klass(**cfg)
+
+    def __getstate__(self) -> tp.Dict[str, tp.Any]:
+        state = {"config": self.get_config(simple_types=False), "is_fitted": self.is_fitted, "epochs_done": self.epochs_done,
+                 "history": self.history}
+        if self.lightning_model is not None:
+            buf = io.BytesIO()
+            torch.save({"state_dict": {k: v.detach().cpu() for k, v in self.lightning_model.torch_model.state_dict().items()},
+                        "optimizer": {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in self.optimizer.state_dict().items()},
+                        "item_external_ids": self.data_preparator.item_id_map.external_ids,
+                        "extra_token_ids": self.data_preparator.extra_token_ids}, buf)
+            state["checkpoint"] = buf.getvalue()
+        return state
+
+    def __setstate__(self, state: tp.Dict[str, tp.Any]) -> None:
+        cfg = dict(state["config"])
+        cfg.pop("cls", None)
+        self.__init__(**cfg)
+        self.is_fitted, self.epochs_done, self.history = state["is_fitted"], state["epochs_done"], state["history"]
+        if "checkpoint" in state:
+            from .dataset import IdMap
+
+            ck = torch.load(io.BytesIO(state["checkpoint"]), map_location="cpu", weights_only=False)
+            self.data_preparator.item_id_map = IdMap(ck["item_external_ids"])
+            self.data_preparator.extra_token_ids = ck["extra_token_ids"]
+            self._build_from_item_map()
+            self.lightning_model.torch_model.load_state_dict({k: v.to(self._device()) for k, v in ck["state_dict"].items()})
+            self.optimizer.load_state_dict({k: (v.to(self._device()) if isinstance(v, torch.Tensor) else v) for k, v in ck["optimizer"].items()})
+
+    def _build_from_item_map(self) -> None:
+        class _Stub:  # builds modules of the right sizes without re-processing a dataset
+            pass
+
+        n_tokens = self.data_preparator.item_id_map.size
+        dp_process = self.data_preparator.process_dataset_train
+        self.data_preparator.process_dataset_train = lambda ds: None  # type: ignore
+        try:
+            self._build_model_from_dataset(None)
+        finally:
+            self.data_preparator.process_dataset_train = dp_process  # type: ignore
+        assert self.lightning_model.torch_model.item_model.table.shape[0] == n_tokens
+
+    def save(self, path: str) -> int:
+        data = pickle.dumps(self)
+        with open(path, "wb") as f:
+            return f.write(data)
+
+    @classmethod
+    def load(cls, path: str) -> "TransformerModelBase":
+        with open(path, "rb") as f:
+            return pickle.load(f)
+
+    def dumps(self) -> bytes:
+        return pickle.dumps(self)
+
+    @classmethod
+    def loads(cls, data: bytes) -> "TransformerModelBase":
+        return pickle.loads(data)
+
+
+class SASRecModel(TransformerModelBase):
+    """SASRec (sasrec.py:315-541): causal attention, shifted-sequence objective, SASRec blocks by default."""
+
+    def __init__(self, n_blocks: int = 2, n_heads: int = 4, n_factors: int = 256, use_pos_emb: bool = True,
+                 use_causal_attn: bool = True, use_key_padding_mask: bool = False, dropout_rate: float = 0.2,
+                 session_max_len: int = 100, dataloader_num_workers: int = 0, batch_size: int = 128, loss: str = "softmax",
+                 n_negatives: int = 1, gbce_t: float = 0.2, lr: float = 0.001, epochs: int = 3, verbose: int = 0,
+                 deterministic: bool = False, recommend_batch_size: int = 256, recommend_torch_device: tp.Optional[str] = None,
+                 train_min_user_interactions: int = 2,
+                 transformer_layers_type: tp.Type[hnn.TransformerLayersBase] = hnn.SASRecTransformerLayers,
+                 data_preparator_type: tp.Type[TransformerDataPreparatorBase] = SASRecDataPreparator, **kwargs: tp.Any) -> None:
+        super().__init__(
+            data_preparator_type=data_preparator_type, transformer_layers_type=transformer_layers_type, n_blocks=n_blocks,
+            n_heads=n_heads, n_factors=n_factors, use_pos_emb=use_pos_emb, use_causal_attn=use_causal_attn,
+            use_key_padding_mask=use_key_padding_mask, dropout_rate=dropout_rate, session_max_len=session_max_len,
+            dataloader_num_workers=dataloader_num_workers, batch_size=batch_size, loss=loss, n_negatives=n_negatives, gbce_t=gbce_t,
+            lr=lr, epochs=epochs, verbose=verbose, deterministic=deterministic, recommend_batch_size=recommend_batch_size,
+            recommend_torch_device=recommend_torch_device, train_min_user_interactions=train_min_user_interactions, **kwargs)
+
+
+class BERT4RecModel(TransformerModelBase):
+    """BERT4Rec (bert4rec.py:204-452): key-padding mask only, masked-item objective, Pre-LN blocks."""
+
+    def __init__(self, n_blocks: int = 2, n_heads: int = 4, n_factors: int = 256, use_pos_emb: bool = True,
+                 use_causal_attn: bool = False, use_key_padding_mask: bool = True, dropout_rate: float = 0.2,
+                 session_max_len: int = 100, dataloader_num_workers: int = 0, batch_size: int = 128, loss: str = "softmax",
+                 n_negatives: int = 1, gbce_t: float = 0.2, lr: float = 0.001, epochs: int = 3, verbose: int = 0,
+                 mask_prob: float = 0.15, deterministic: bool = False, recommend_batch_size: int = 256,
+                 recommend_torch_device: tp.Optional[str] = None, train_min_user_interactions: int = 2,
+                 transformer_layers_type: tp.Type[hnn.TransformerLayersBase] = hnn.PreLNTransformerLayers,
+                 data_preparator_type: tp.Type[TransformerDataPreparatorBase] = BERT4RecDataPreparator, **kwargs: tp.Any) -> None:
+        self.mask_prob = mask_prob
+        dkw = dict(kwargs.pop("data_preparator_kwargs", None) or {})
+        dkw.setdefault("mask_prob", mask_prob)
+        super().__init__(
+            data_preparator_type=data_preparator_type, transformer_layers_type=transformer_layers_type, n_blocks=n_blocks,
+            n_heads=n_heads, n_factors=n_factors, use_pos_emb=use_pos_emb, use_causal_attn=use_causal_attn,
+            use_key_padding_mask=use_key_padding_mask, dropout_rate=dropout_rate, session_max_len=session_max_len,
+            dataloader_num_workers=dataloader_num_workers, batch_size=batch_size, loss=loss, n_negatives=n_negatives, gbce_t=gbce_t,
+            lr=lr, epochs=epochs, verbose=verbose, deterministic=deterministic, recommend_batch_size=recommend_batch_size,
+            recommend_torch_device=recommend_torch_device, train_min_user_interactions=train_min_user_interactions,
+            data_preparator_kwargs=dkw, mask_prob=mask_prob, **kwargs)
+
+
+class HSTUModel(TransformerModelBase):
+    """HSTU (hstu.py:412-729): STU blocks, relative time/position bias, cosine similarity, sqrt(d) embedding scale."""
+
+    u2i_dist_default = "cosine"
+    use_scale_factor_default = True
+
+    def __init__(self, n_blocks: int = 2, n_heads: int = 4, n_factors: int = 256, use_pos_emb: bool = True,
+                 use_causal_attn: bool = True, use_key_padding_mask: bool = False, dropout_rate: float = 0.2,
+                 session_max_len: int = 100, dataloader_num_workers: int = 0, batch_size: int = 128, loss: str = "softmax",
+                 n_negatives: int = 1, gbce_t: float = 0.2, lr: float = 0.001, epochs: int = 3, verbose: int = 0,
+                 relative_time_attention: bool = True, relative_pos_attention: bool = True, deterministic: bool = False,
+                 recommend_batch_size: int = 256, recommend_torch_device: tp.Optional[str] = None,
+                 train_min_user_interactions: int = 2,
+                 transformer_layers_type: tp.Type[hnn.TransformerLayersBase] = hnn.STULayers,
+                 data_preparator_type: tp.Type[TransformerDataPreparatorBase] = SASRecDataPreparator, **kwargs: tp.Any) -> None:
+        if n_factors % n_heads != 0:
+            raise ValueError("n_factors must be divisible by n_heads without remainder")  # hstu.py:606-607
+        if use_key_padding_mask:
+            warnings.warn("'use_key_padding_mask' is not supported for HSTU and enforced to False.")  # hstu.py:608-612
+            use_key_padding_mask = False
+        self.relative_time_attention, self.relative_pos_attention = relative_time_attention, relative_pos_attention
+        hd = n_factors // n_heads
+        tkw = dict(kwargs.pop("transformer_layers_kwargs", None) or {})
+        tkw.update(dict(linear_hidden_dim=hd, attention_dim=hd, session_max_len=session_max_len,
+                        relative_time_attention=relative_time_attention, relative_pos_attention=relative_pos_attention))
+        dkw = dict(kwargs.pop("data_preparator_kwargs", None) or {})
+        dkw.setdefault("add_unix_ts", relative_time_attention)
+        super().__init__(
+            data_preparator_type=data_preparator_type, transformer_layers_type=transformer_layers_type, n_blocks=n_blocks,
+            n_heads=n_heads, n_factors=n_factors, use_pos_emb=use_pos_emb, use_causal_attn=use_causal_attn,
+            use_key_padding_mask=use_key_padding_mask, dropout_rate=dropout_rate, session_max_len=session_max_len,
+            dataloader_num_workers=dataloader_num_workers, batch_size=batch_size, loss=loss, n_negatives=n_negatives, gbce_t=gbce_t,
+            lr=lr, epochs=epochs, verbose=verbose, deterministic=deterministic, recommend_batch_size=recommend_batch_size,
+            recommend_torch_device=recommend_torch_device, train_min_user_interactions=train_min_user_interactions,
+            transformer_layers_kwargs=tkw, data_preparator_kwargs=dkw, relative_time_attention=relative_time_attention,
+            relative_pos_attention=relative_pos_attention, **kwargs)
+
+    @property
+    def require_recommend_context(self) -> bool:
+        return bool(self.relative_time_attention)  # hstu.py:719-729

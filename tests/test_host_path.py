@@ -1,0 +1,123 @@
+"""CPU tests of the host side: dataset mirror, CSR sequence store + vectorised collates (pinned to the reference's
+collate outputs, tests/golden/collate_golden.npz), sharded sampling, config round trip, fail-loudly behaviour."""
+import json
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR
+
+
+def _interactions():
+    return pd.DataFrame(
+        [[10, 13, 1, "2021-11-30"], [10, 11, 1, "2021-11-29"], [10, 12, 1, "2021-11-29"], [30, 11, 1, "2021-11-27"],
+         [30, 12, 2, "2021-11-26"], [30, 15, 1, "2021-11-25"], [40, 11, 1, "2021-11-25"], [40, 17, 1, "2021-11-26"],
+         [50, 16, 1, "2021-11-25"], [10, 14, 1, "2021-11-28"], [10, 16, 1, "2021-11-27"], [20, 13, 9, "2021-11-28"]],
+        columns=["user_id", "item_id", "weight", "datetime"])
+
+
+def test_dataset_and_train_processing_pad_first():
+    from rectools_amd.data_preparator import SASRecDataPreparator, SequenceStore
+    from rectools_amd.dataset import Dataset
+
+    ds = Dataset.construct(_interactions())
+    assert ds.user_id_map.external_ids.tolist() == [10, 30, 40, 50, 20]
+    dp = SASRecDataPreparator(session_max_len=3, batch_size=4)
+    dp.process_dataset_train(ds)
+    assert dp.item_id_map.external_ids[0] == "PAD" and dp.extra_token_ids["PAD"] == 0
+    # users with < 2 interactions are dropped; every kept user holds at most L+1 = 4 items (data_preparator.py:214-224)
+    store = dp.train_store()
+    lens = np.diff(store.offsets)
+    assert len(store) == 3 and lens.max() <= 4
+    users = dp.train_dataset.user_id_map.convert_to_external(store.users)
+    assert set(users.tolist()) == {10, 30, 40}
+    b = dp.collate_train(store, np.arange(len(store)))
+    assert b["x"].shape == (3, 3) and (b["x"][:, -1] != 0).all()
+    assert ((b["y"] != 0) == (b["yw"] != 0)).all()
+
+
+def test_collates_match_reference_outputs():
+    from rectools_amd.data_preparator import SASRecDataPreparator, SequenceStore
+
+    z = np.load(os.path.join(GOLDEN_DIR, "collate_golden.npz"), allow_pickle=False)
+    sessions = json.loads(str(z["sessions"]))
+    L = int(z["L"])
+    for ts in (False, True):
+        sfx = "_ts" if ts else ""
+        dp = SASRecDataPreparator(session_max_len=L, batch_size=4, add_unix_ts=ts)
+        # train store: sessions truncated to their last L+1 items as _filter_train_interactions does
+        items = [np.array(s[-(L + 1):]) for s, _, _ in sessions]
+        weights = [np.array(w[-(L + 1):], np.float32) for _, w, _ in sessions]
+        tss = [np.array(t[-(L + 1):]) for _, _, t in sessions]
+        offs = np.r_[0, np.cumsum([len(i) for i in items])]
+        store = SequenceStore(offs, np.concatenate(items), np.concatenate(weights), np.concatenate(tss), np.arange(len(items)))
+        got = dp.collate_train(store, np.arange(len(items)))
+        for k in ("x", "y", "yw") + (("unix_ts",) if ts else ()):
+            np.testing.assert_array_equal(got[k], z[f"sasrec_noneg{sfx}/train/{k}"], err_msg=f"train {k} ts={ts}")
+        if ts:
+            items = [np.array(s + [0]) for s, _, _ in sessions]
+            tss = [np.array(t + [t[-1] + 5]) for _, _, t in sessions]
+        else:
+            items = [np.array(s) for s, _, _ in sessions]
+            tss = [np.array(t) for _, _, t in sessions]
+        offs = np.r_[0, np.cumsum([len(i) for i in items])]
+        store = SequenceStore(offs, np.concatenate(items), np.ones(offs[-1], np.float32), np.concatenate(tss), np.arange(len(items)))
+        got = dp.collate_recommend(store, np.arange(len(items)))
+        for k in got:
+            np.testing.assert_array_equal(got[k], z[f"sasrec_noneg{sfx}/recommend/{k}"], err_msg=f"recommend {k} ts={ts}")
+
+
+def test_bert4rec_collates():
+    from rectools_amd.data_preparator import BERT4RecDataPreparator, SequenceStore
+    from rectools_amd.dataset import IdMap
+
+    dp = BERT4RecDataPreparator(session_max_len=5, batch_size=2, mask_prob=0.5)
+    dp.item_id_map = IdMap(np.array(["PAD", "MASK"] + list(range(10)), dtype=object))
+    dp.extra_token_ids = {"PAD": 0, "MASK": 1}
+    store = SequenceStore(np.array([0, 3, 9]), np.array([2, 3, 4, 5, 6, 7, 8, 9, 10]), np.ones(9, np.float32), None, np.arange(2))
+    r = dp.collate_recommend(store, np.arange(2))
+    assert r["x"].tolist() == [[0, 2, 3, 4, 1], [7, 8, 9, 10, 1]]  # last L-1 items + MASK (bert4rec.py:182-193)
+    np.random.seed(3)
+    b = dp.collate_train(store, np.array([0]))
+    assert b["x"].shape == (1, 5) and (b["x"][0, :2] == 0).all()
+    kept = b["y"][0] == 0
+    assert ((b["x"][0] == [0, 0, 2, 3, 4]) | ~kept)[2:].all()  # unmasked positions keep their item and have no target
+
+
+def test_shard_indices_is_distributed_sampler_like():
+    from rectools_amd.data_preparator import epoch_permutation, shard_indices
+
+    perm = epoch_permutation(10, epoch=3, seed=1, shuffle=True)
+    assert sorted(perm.tolist()) == list(range(10))
+    assert not np.array_equal(perm, epoch_permutation(10, 4, 1, True))
+    parts = [shard_indices(perm, r, 4) for r in range(4)]
+    assert all(len(p) == 3 for p in parts)                      # padded to 12 by wrapping
+    assert len(np.concatenate(parts)) == 12
+    assert set(np.concatenate(parts).tolist()) == set(range(10))
+
+
+def test_config_roundtrip_and_errors():
+    from rectools_amd import _lib
+    from rectools_amd.models import BERT4RecModel, HSTUModel, NotFittedError, SASRecModel
+
+    m = SASRecModel(n_factors=32, n_blocks=1, session_max_len=7, loss="gBCE", n_negatives=4, epochs=2)
+    cfg = m.get_config()
+    assert cfg["cls"] == "rectools_amd.models.SASRecModel" and cfg["transformer_layers_type"] == "rectools_amd.nn.SASRecTransformerLayers"
+    m2 = SASRecModel.from_config(cfg)
+    assert m2.get_config() == cfg
+    assert BERT4RecModel(mask_prob=0.3).data_preparator.mask_prob == 0.3
+    assert HSTUModel().require_recommend_context and not SASRecModel().require_recommend_context
+    with pytest.raises(ValueError):
+        SASRecModel(loss="hinge")
+    with pytest.raises(ValueError):
+        HSTUModel(n_factors=30, n_heads=4)
+    with pytest.raises(NotFittedError):
+        m.recommend([1], None, 3, False)
+    if not torch.cuda.is_available():
+        from rectools_amd.dataset import Dataset
+
+        with pytest.raises(_lib.HipLibraryError):  # no silent CPU fallback
+            m.fit(Dataset.construct(_interactions()))

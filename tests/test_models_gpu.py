@@ -1,0 +1,107 @@
+"""GPU end-to-end tests of the public model API (fit / fit_partial / recommend / recommend_to_items / save-load) on the
+tiny interaction frames the reference's own tests use (tests/models/nn/transformers/test_sasrec.py:60-143), checked
+for the contract the reference pins: frame columns and dtypes, rank = 1..k per user, scores sorted descending,
+viewed items filtered, whitelist respected — and for exact agreement of recommend() with an oracle ranking computed
+from the model's own (device) embeddings."""
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from oracle import ranker_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def interactions():
+    return pd.DataFrame(
+        [[10, 13, 1, "2021-11-30"], [10, 11, 1, "2021-11-29"], [10, 12, 1, "2021-11-29"], [30, 11, 1, "2021-11-27"],
+         [30, 12, 2, "2021-11-26"], [30, 15, 1, "2021-11-25"], [40, 11, 1, "2021-11-25"], [40, 17, 1, "2021-11-26"],
+         [50, 16, 1, "2021-11-25"], [10, 14, 1, "2021-11-28"], [10, 16, 1, "2021-11-27"], [20, 13, 9, "2021-11-28"]],
+        columns=["user_id", "item_id", "weight", "datetime"])
+
+
+def _check_frame(df, k, users):
+    assert list(df.columns) == ["user_id", "item_id", "score", "rank"]
+    assert df["score"].dtype == np.float32
+    for u, g in df.groupby("user_id", sort=False):
+        assert g["rank"].tolist() == list(range(1, len(g) + 1)) and len(g) <= k
+        assert (np.diff(g["score"].values) <= 1e-6).all()   # test_sasrec.py:302-305
+    assert set(df["user_id"]) <= set(users)
+
+
+@pytest.mark.parametrize("kind,loss", [("sasrec", "softmax"), ("sasrec", "sampled_softmax"), ("sasrec", "gBCE"), ("bert", "softmax"),
+                                       ("bert", "BCE"), ("hstu", "sampled_softmax"), ("ligr", "sampled_softmax")])
+def test_fit_recommend_contract(kind, loss):
+    from rectools_amd import nn as hnn
+    from rectools_amd.dataset import Dataset
+    from rectools_amd.models import BERT4RecModel, HSTUModel, SASRecModel
+
+    ds = Dataset.construct(interactions())
+    common = dict(n_factors=32, n_blocks=2, n_heads=2, session_max_len=4, lr=0.01, batch_size=4, epochs=3, loss=loss, n_negatives=3,
+                  seed=32)
+    if kind == "sasrec":
+        model = SASRecModel(**common)
+    elif kind == "bert":
+        model = BERT4RecModel(**common)
+    elif kind == "ligr":
+        model = SASRecModel(transformer_layers_type=hnn.LiGRLayers, transformer_layers_kwargs=dict(ff_activation="swiglu"), **common)
+    else:
+        model = HSTUModel(**common)
+    model.fit(ds)
+    assert model.is_fitted and len(model.history) == 3 and all(np.isfinite(h["train_loss"]) for h in model.history)
+    users = np.array([10, 30, 40])
+    context = None
+    if kind == "hstu":
+        context = pd.DataFrame({"user_id": users, "datetime": ["2021-12-12"] * 3})
+    reco = model.recommend(users=users, dataset=ds, k=3, filter_viewed=True, context=context)
+    _check_frame(reco, 3, users)
+    viewed = set(map(tuple, interactions()[["user_id", "item_id"]].values.tolist()))
+    assert not (set(map(tuple, reco[["user_id", "item_id"]].values.tolist())) & viewed)
+    wl = np.array([11, 13, 17])
+    reco_wl = model.recommend(users=users, dataset=ds, k=2, filter_viewed=False, items_to_recommend=wl, context=context)
+    assert set(reco_wl["item_id"]) <= set(wl.tolist())
+    _check_frame(reco_wl, 2, users)
+
+    # exact agreement with an oracle ranking over the model's own embeddings
+    dev = next(model.lightning_model.parameters()).device
+    rec_ds = model.data_preparator.transform_dataset_u2i(ds, users, context.copy() if context is not None else None)
+    from rectools_amd.data_preparator import SequenceStore
+
+    store = SequenceStore.from_interactions(rec_ds.interactions.df, sort_users=True)
+    ue = model._user_embeddings(store, dev).cpu().numpy()
+    ie = model.torch_model.item_model.table.detach().cpu().numpy()
+    uids = rec_ds.user_id_map.convert_to_internal(users, strict=False)
+    csr = rec_ds.get_user_item_matrix(include_weights=False)[uids]
+    dist = "cosine" if kind == "hstu" else "dot"
+    su, it, sc = ranker_oracle.rank(ue, ie, uids, k=3, filter_pairs_csr=csr, distance=dist,
+                                    sorted_object_whitelist=model.data_preparator.get_known_items_sorted_internal_ids())
+    exp_items = model.data_preparator.item_id_map.convert_to_external(it)
+    assert reco["item_id"].tolist() == exp_items.tolist()
+    np.testing.assert_allclose(reco["score"].values, sc, rtol=1e-4, atol=1e-5)
+
+    # i2i + persistence
+    i2i = model.recommend_to_items(target_items=np.array([11, 12]), dataset=ds, k=2)
+    assert list(i2i.columns) == ["target_item_id", "item_id", "score", "rank"] and not (i2i["target_item_id"] == i2i["item_id"]).any()
+    clone = type(model).loads(model.dumps())
+    reco2 = clone.recommend(users=users, dataset=ds, k=3, filter_viewed=True, context=context)
+    pd.testing.assert_frame_equal(reco, reco2)
+
+
+def test_fit_partial_equals_fit_and_cold_users():
+    from rectools_amd.dataset import Dataset
+    from rectools_amd.models import SASRecModel
+
+    ds = Dataset.construct(interactions())
+    kw = dict(n_factors=32, n_blocks=1, n_heads=2, session_max_len=3, lr=0.01, batch_size=4, dropout_rate=0.0, loss="softmax", seed=7)
+    a = SASRecModel(epochs=3, **kw).fit(ds)
+    b = SASRecModel(epochs=3, **kw)
+    b.fit_partial(ds, max_epochs=2); b.fit_partial(ds, max_epochs=1)    # test_base.py:351-383 (3 epochs == 2 + 1)
+    for (n1, p1), (n2, p2) in zip(a.torch_model.state_dict().items(), b.torch_model.state_dict().items()):
+        torch.testing.assert_close(p1, p2, rtol=1e-4, atol=1e-6, msg=lambda m: f"{n1}: {m}")
+    with pytest.raises(ValueError):
+        a.recommend(users=[10, 999], dataset=ds, k=2, filter_viewed=False)
+    r = a.recommend(users=[10, 999], dataset=ds, k=2, filter_viewed=False, on_unsupported_targets="ignore")
+    assert set(r["user_id"]) == {10}
+    with pytest.raises(ValueError):
+        a.recommend(users=[10], dataset=ds, k=0, filter_viewed=False)
