@@ -303,8 +303,9 @@ int rt_gemm(const float* A, int64_t lda, int32_t a_kc, const float* B, int64_t l
             float* C, int64_t ldc, const float* bias, const float* R, int64_t ldr,
             int32_t M, int32_t N, int32_t K, int32_t relu, int32_t split_k, hipStream_t stream) {
   (void)hipGetLastError();
-  if (M < 0 || N < 0 || K < 0 || A == nullptr || B == nullptr || C == nullptr) return RT_ERR_INVALID_ARG;
+  if (M < 0 || N < 0 || K < 0) return RT_ERR_INVALID_ARG;
   if (M == 0 || N == 0) return RT_OK;
+  if (A == nullptr || B == nullptr || C == nullptr) return RT_ERR_INVALID_ARG;
   if (split_k > 1 && (R != nullptr || relu)) return RT_ERR_INVALID_ARG;
   GemmArgs g{};
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.bias = bias; g.R = R; g.ldr = ldr;

@@ -131,6 +131,8 @@ class TransformerModelBase:
 
     def _build_model_from_dataset(self, dataset: tp.Any) -> None:
         self.data_preparator.process_dataset_train(dataset)
+        if self.seed is not None:  # before ANY parameter is created: 1-D parameters keep their constructor init
+            torch.manual_seed(self.seed)
         n_tokens = self.data_preparator.item_id_map.size
         item_model = hnn.SumOfEmbeddingsConstructor(n_tokens, [hnn.IdEmbeddingsItemNet(self.n_factors, n_tokens, self.dropout_rate)])
         pkw = self._kw(self.pos_encoding_kwargs)
@@ -146,8 +148,6 @@ class TransformerModelBase:
             lkw.get("logits_t", 1.0), self.data_preparator.n_item_extra_tokens)
         device = torch.device(self._device())
         self.lightning_model.to(device)
-        if self.seed is not None:
-            torch.manual_seed(self.seed)
         hl.xavier_normal_init(self.lightning_model.torch_model)  # on_train_start (lightning.py:296-299)
         self.optimizer = hl.FlatAdam(self.lightning_model.torch_model, lr=self.lr, betas=(0.9, 0.98))
         self.epochs_done = 0
