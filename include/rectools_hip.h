@@ -79,12 +79,15 @@ int rt_topk_score(const float* users, int64_t user_stride, const int64_t* user_r
  * Replaces nn.Linear / MultiheadAttention in_proj & out_proj / `normed_x @ uvqk_proj` / `session_embs @ item_embs.T`
  * (net_blocks.py:63-64,108-109; sasrec.py:191; ligr.py:56,99-105; hstu.py:258,293; similarity.py:85) and their
  * autograd products.  a_kc / b_kc = 1: operand is [rows, K] row-major with row stride ld ("k-contiguous");
- * = 0: element (r, k) lives at r + k*ld (a transposed view).  split_k > 1 splits the reduction over the grid
- * and atomically adds into C, which the caller must have zero-filled (R / relu then not allowed).
+ * = 0: element (r, k) lives at r + k*ld (a transposed view).  split_k > 1 splits the reduction over the grid:
+ * every slice writes an [M,N] slab into `workspace` (rt_gemm_workspace_bytes) and a second kernel sums the
+ * slabs in a fixed order into C (deterministic, no float atomics; R / relu then not allowed).
  * ------------------------------------------------------------------------------------------------ */
+size_t rt_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t split_k);
 int rt_gemm(const float* A, int64_t lda, int32_t a_kc, const float* B, int64_t ldb, int32_t b_kc,
             float* C, int64_t ldc, const float* bias, const float* R, int64_t ldr,
-            int32_t M, int32_t N, int32_t K, int32_t relu, int32_t split_k, rt_stream_t stream);
+            int32_t M, int32_t N, int32_t K, int32_t relu, int32_t split_k, void* workspace, size_t workspace_bytes,
+            rt_stream_t stream);
 /* out[n] += sum_m X[m,n]  (bias gradients; caller zero-fills out) */
 int rt_colsum(const float* X, int64_t ld, int32_t M, int32_t N, float* out, rt_stream_t stream);
 

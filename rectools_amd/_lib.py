@@ -27,7 +27,8 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_last_error": (ctypes.c_char_p, []),
     "rt_topk_workspace_bytes": (c_sz, [c_i32, c_i64, c_i32, c_i32]),
     "rt_topk_score": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_i32, c_vp]),
-    "rt_gemm": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "rt_gemm_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
+    "rt_gemm": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_sz, c_vp]),
     "rt_colsum": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "rt_embed_fwd": (c_i32, [c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_f32, c_u64, c_u64, c_vp, c_vp]),
     "rt_embed_bwd": (c_i32, [c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_f32, c_u64, c_u64, c_vp, c_vp, c_vp]),

@@ -59,6 +59,16 @@ __device__ __forceinline__ bool masked(const AttnArgs& a, int qq, int kk, bool k
   return m;
 }
 
+// Attention dropout mask: one 32-bit mix per (head, query, key) element (murmur3 finaliser over a seeded counter).
+// Philox costs ~70 VALU per call and made the dK/dV kernel VALU-bound (16 calls per 32x32 tile per lane);
+// this is ~10 VALU per element and identical in all three kernels.
+__device__ __forceinline__ float drop_keep(unsigned long long seed, unsigned bh, unsigned q, unsigned key, float p,
+                                           float inv_keep) {
+  unsigned x = (unsigned)seed ^ (q * 0x9E3779B1u) ^ (key * 0x85EBCA77u) ^ (bh * 0xC2B2AE3Du) ^ (unsigned)(seed >> 32);
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return ((float)(x >> 8) * (1.0f / 16777216.0f) >= p) ? inv_keep : 0.f;
+}
+
 __device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
 __device__ __forceinline__ float silu_df(float z) { float s = 1.f / (1.f + __expf(-z)); return s * (1.f + z * (1.f - s)); }
 
@@ -202,15 +212,8 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
       if (a.p_drop > 0.f) {
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          // keys row_of(4*r4 .. 4*r4+3, half) are 4 consecutive keys starting at 8*r4 + 4*half
-          const unsigned long long e4 = ((unsigned long long)qq * ((a.L + 3) & ~3) + kt * TK + 8 * r4 + 4 * half) >> 2;
-          uint4 rnd = philox4x32(a.seed, (unsigned long long)bh, e4 | (1ull << 40));
-          p[4 * r4 + 0] = (u32_to_unit(rnd.x) >= a.p_drop) ? p[4 * r4 + 0] * inv_keep : 0.f;
-          p[4 * r4 + 1] = (u32_to_unit(rnd.y) >= a.p_drop) ? p[4 * r4 + 1] * inv_keep : 0.f;
-          p[4 * r4 + 2] = (u32_to_unit(rnd.z) >= a.p_drop) ? p[4 * r4 + 2] * inv_keep : 0.f;
-          p[4 * r4 + 3] = (u32_to_unit(rnd.w) >= a.p_drop) ? p[4 * r4 + 3] * inv_keep : 0.f;
-        }
+        for (int r = 0; r < 16; ++r)
+          p[r] *= drop_keep(a.seed, (unsigned)bh, (unsigned)qq, (unsigned)(kt * TK + row_of(r, half)), a.p_drop, inv_keep);
       }
     } else {
       const float inv_l = 1.0f / (float)a.L;
@@ -377,12 +380,9 @@ __global__ __launch_bounds__(AT) void attn_bwd_dq_kernel(AttnArgs a) {
     for (int r4 = 0; r4 < 4; ++r4) {
       float dsc[4] = {1.f, 1.f, 1.f, 1.f};
       if (MODE == MODE_SOFTMAX && a.p_drop > 0.f) {
-        const unsigned long long e4 = ((unsigned long long)qq * ((a.L + 3) & ~3) + kt * TK + 8 * r4 + 4 * half) >> 2;
-        uint4 rnd = philox4x32(a.seed, (unsigned long long)bh, e4 | (1ull << 40));
-        dsc[0] = (u32_to_unit(rnd.x) >= a.p_drop) ? inv_keep : 0.f;
-        dsc[1] = (u32_to_unit(rnd.y) >= a.p_drop) ? inv_keep : 0.f;
-        dsc[2] = (u32_to_unit(rnd.z) >= a.p_drop) ? inv_keep : 0.f;
-        dsc[3] = (u32_to_unit(rnd.w) >= a.p_drop) ? inv_keep : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          dsc[j] = drop_keep(a.seed, (unsigned)bh, (unsigned)qq, (unsigned)(kt * TK + row_of(4 * r4 + j, half)), a.p_drop, inv_keep);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -523,13 +523,7 @@ __global__ __launch_bounds__(AT) void attn_bwd_dkv_kernel(AttnArgs a) {
       const int qrow = row_of(r, half);
       const int q = qt * TK + qrow;
       float dsc = 1.f;
-      if (MODE == MODE_SOFTMAX && a.p_drop > 0.f) {
-        // same (query, key) -> random mapping as the forward kernel: element e = q*L + kk, group e>>2, lane e&3
-        const unsigned long long e = (unsigned long long)q * ((a.L + 3) & ~3) + kk;
-        uint4 rnd = philox4x32(a.seed, (unsigned long long)bh, (e >> 2) | (1ull << 40));
-        const unsigned w = (e & 3) == 0 ? rnd.x : ((e & 3) == 1 ? rnd.y : ((e & 3) == 2 ? rnd.z : rnd.w));
-        dsc = (u32_to_unit(w) >= a.p_drop) ? inv_keep : 0.f;
-      }
+      if (MODE == MODE_SOFTMAX && a.p_drop > 0.f) dsc = drop_keep(a.seed, (unsigned)bh, (unsigned)q, (unsigned)kk, a.p_drop, inv_keep);
       bool dead; float bias = 0.f;
       if (MODE == MODE_SOFTMAX) {
         dead = (kk >= a.L) || (q >= a.L) || masked(a, q, kk, k_is_pad);

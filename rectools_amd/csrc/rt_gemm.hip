@@ -31,7 +31,8 @@ struct GemmArgs {
   const float* R; long long ldr;  // residual [M,N] or null
   int M, N, K;
   int relu;
-  int k_per_split;                // split-K: grid.z slices of the reduction; >0 => atomicAdd into C
+  int k_per_split;                // split-K: grid.z slices of the reduction; >0 => each slice writes its own slab
+  float* slabs;                   // [splits][M][N] partial products (split-K)
 };
 
 template <bool KC>
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(GT) void gemm_kernel(GemmArgs g) {
   // epilogue.  D layout: MFMA rows index A (m), columns index B (n):
   //   acc[i][j][r] = C[m0 + wm*64 + i*32 + (r&3) + 8*(r>>2) + 4*half][n0 + wn*64 + j*32 + col]
   const bool full_tile = (m0 + BM <= g.M) && (n0 + BN <= g.N);
-  const bool add_bias = g.bias != nullptr && (g.k_per_split == 0 || blockIdx.z == 0);
+  const bool add_bias = g.bias != nullptr && g.k_per_split == 0;   // split-K: bias is added by the reduce kernel
   if (full_tile && g.k_per_split == 0) {
     // branch-free: residual values are fetched in one batch per accumulator tile
 #pragma unroll
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(GT) void gemm_kernel(GemmArgs g) {
         if (m >= g.M) continue;
         float v = acc[i][j][r] + bv;
         if (g.k_per_split > 0) {
-          atomicAdd(g.C + (long long)m * g.ldc + n, v);
+          g.slabs[((long long)blockIdx.z * g.M + m) * g.N + n] = v;
         } else {
           if (g.R != nullptr) v += g.R[(long long)m * g.ldr + n];
           if (g.relu) v = fmaxf(v, 0.f);
@@ -254,6 +255,18 @@ __global__ __launch_bounds__(GT) void gemm_kernel(GemmArgs g) {
         }
       }
     }
+}
+
+// split-K combine: C[m,n] = sum_z slabs[z][m][n] (+ bias[n]) — fixed summation order (deterministic), no atomics
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int splits, long long mn, int N,
+                                                            const float* __restrict__ bias, float* __restrict__ C, long long ldc) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= mn) return;
+  float s = 0.f;
+  for (int z = 0; z < splits; ++z) s += slabs[(long long)z * mn + i];
+  const int n = (int)(i % N);
+  if (bias) s += bias[n];
+  C[(i / N) * ldc + n] = s;
 }
 
 // column sums: out[n] = sum_m X[m, n]   (bias gradients)
@@ -296,12 +309,23 @@ int launch_gemm(const GemmArgs& g, int splits, hipStream_t stream) {
 
 extern "C" {
 
+// Host arithmetic: scratch bytes rt_gemm needs for a given split_k (0 when split_k <= 1).
+size_t rt_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t split_k) {
+  if (split_k <= 1 || M <= 0 || N <= 0) return 0;
+  int kps = (K + split_k - 1) / split_k;
+  kps = (kps + BK - 1) / BK * BK;
+  const int splits = (K + kps - 1) / kps;
+  return (size_t)splits * M * N * sizeof(float);
+}
+
 // C[M,N] = A . B^T (+bias) (+R) (relu);  a_kc/b_kc: 1 = k-contiguous ([rows,K] row-major, ld = row stride),
-// 0 = row-contiguous (element (r,k) at r + k*ld).  split_k > 1: reduction split over grid.z with atomicAdd
-// into C, which the caller must have zero-filled (bias is added once; R / relu are not allowed).
+// 0 = row-contiguous (element (r,k) at r + k*ld).  split_k > 1: the reduction is split over grid.z, every slice
+// writes its own [M,N] slab into `workspace` and a second kernel sums the slabs in a fixed order (+ bias) into C
+// (deterministic; R / relu are not allowed).
 int rt_gemm(const float* A, int64_t lda, int32_t a_kc, const float* B, int64_t ldb, int32_t b_kc,
             float* C, int64_t ldc, const float* bias, const float* R, int64_t ldr,
-            int32_t M, int32_t N, int32_t K, int32_t relu, int32_t split_k, hipStream_t stream) {
+            int32_t M, int32_t N, int32_t K, int32_t relu, int32_t split_k, void* workspace, size_t workspace_bytes,
+            hipStream_t stream) {
   (void)hipGetLastError();
   if (M < 0 || N < 0 || K < 0) return RT_ERR_INVALID_ARG;
   if (M == 0 || N == 0) return RT_OK;
@@ -315,12 +339,22 @@ int rt_gemm(const float* A, int64_t lda, int32_t a_kc, const float* B, int64_t l
     int kps = (K + split_k - 1) / split_k;
     kps = (kps + BK - 1) / BK * BK;
     splits = (K + kps - 1) / kps;
-    g.k_per_split = kps;
+    if (splits > 1) {
+      if (workspace == nullptr || workspace_bytes < (size_t)splits * M * N * sizeof(float)) return RT_ERR_WORKSPACE;
+      g.k_per_split = kps;
+      g.slabs = reinterpret_cast<float*>(workspace);
+    }
   }
-  if (a_kc && b_kc) return launch_gemm<true, true>(g, splits, stream);
-  if (a_kc && !b_kc) return launch_gemm<true, false>(g, splits, stream);
-  if (!a_kc && b_kc) return launch_gemm<false, true>(g, splits, stream);
-  return launch_gemm<false, false>(g, splits, stream);
+  int rc;
+  if (a_kc && b_kc) rc = launch_gemm<true, true>(g, splits, stream);
+  else if (a_kc && !b_kc) rc = launch_gemm<true, false>(g, splits, stream);
+  else if (!a_kc && b_kc) rc = launch_gemm<false, true>(g, splits, stream);
+  else rc = launch_gemm<false, false>(g, splits, stream);
+  if (rc != RT_OK || g.k_per_split == 0) return rc;
+  const long long mn = (long long)M * N;
+  splitk_reduce_kernel<<<(int)((mn + 255) / 256), 256, 0, stream>>>(g.slabs, splits, mn, N, bias, C, ldc);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
 }
 
 // out[n] += sum_m X[m,n]  (caller zero-fills `out`)

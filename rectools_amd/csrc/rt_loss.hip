@@ -72,6 +72,7 @@ __device__ __forceinline__ void gbce_transform(double z, double beta, double& f,
 template <int D4>
 __global__ __launch_bounds__(256) void sampled_fwd_kernel(SampledArgs a) {
   __shared__ float s_z[4][260];
+  __shared__ int s_cid[4][260];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = blockIdx.x * 4 + wave;
   if (m >= a.M) return;
@@ -82,6 +83,11 @@ __global__ __launch_bounds__(256) void sampled_fwd_kernel(SampledArgs a) {
     if (lane == 0) a.loss_pos[m] = 0.f;
     return;
   }
+  // candidate ids of this position -> LDS (coalesced), so the row gathers below do not wait on an id load each
+  for (int j = lane; j < C && j < 260; j += 64) s_cid[wave][j] = (j == 0) ? (int)yy : (int)a.neg[(long long)m * a.N + (j - 1)];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   const int sub = lane & 15, grp = lane >> 4;
   // session slice of this lane: float4 index sub + 16*i
   f32x4 sv[D4];
@@ -97,11 +103,12 @@ __global__ __launch_bounds__(256) void sampled_fwd_kernel(SampledArgs a) {
   ss = group16_sum(ss);
   const float inv_ns = a.cosine ? 1.0f / fmaxf(sqrtf(ss), EPS_COS) : 1.0f;
 
+#pragma unroll 2
   for (int j0 = 0; j0 < C; j0 += 4) {
     const int j = j0 + grp;
     float dot = 0.f, ee = 0.f;
     if (j < C) {
-      const long long cid = (j == 0) ? yy : a.neg[(long long)m * a.N + (j - 1)];
+      const long long cid = (j < 260) ? (long long)s_cid[wave][j] : ((j == 0) ? yy : a.neg[(long long)m * a.N + (j - 1)]);
       const float* er = a.table + cid * (long long)a.d;
 #pragma unroll
       for (int i = 0; i < D4; ++i) {
@@ -161,6 +168,7 @@ __global__ __launch_bounds__(256) void sampled_fwd_kernel(SampledArgs a) {
 template <int D4>
 __global__ __launch_bounds__(256) void sampled_bwd_pos_kernel(SampledArgs a) {
   __shared__ float s_g[4][260];
+  __shared__ int s_cid[4][260];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = blockIdx.x * 4 + wave;
   if (m >= a.M) return;
@@ -212,9 +220,10 @@ __global__ __launch_bounds__(256) void sampled_bwd_pos_kernel(SampledArgs a) {
       grow[j] = gf;
     }
   }
-  // histogram of candidate ids (counting sort, pass 1)
+  // histogram of candidate ids (counting sort, pass 1); ids also staged in LDS for the gather loop
   for (int j = lane; j < C; j += 64) {
     const long long cid = (j == 0) ? yy : a.neg[(long long)m * a.N + (j - 1)];
+    if (j < 260) s_cid[wave][j] = (int)cid;
     if (cid != 0) atomicAdd(a.count + cid, 1);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -238,10 +247,11 @@ __global__ __launch_bounds__(256) void sampled_bwd_pos_kernel(SampledArgs a) {
   const float inv_ns = a.cosine ? 1.0f / fmaxf(ns, EPS_COS) : 1.0f;
   if (lane == 0) a.inv_ns[m] = inv_ns;
 
+#pragma unroll 2
   for (int j0 = 0; j0 < C; j0 += 4) {
     const int j = j0 + grp;
     if (j < C) {  // uniform inside a 16-lane group
-      const long long cid = (j == 0) ? yy : a.neg[(long long)m * a.N + (j - 1)];
+      const long long cid = (j < 260) ? (long long)s_cid[wave][j] : ((j == 0) ? yy : a.neg[(long long)m * a.N + (j - 1)]);
       const float g = (j < 260) ? s_g[wave][j] : grow[j];
       const float* er = a.table + cid * (long long)a.d;
       f32x4 ev[D4];
@@ -375,14 +385,41 @@ __global__ __launch_bounds__(256) void sampled_bwd_rows_kernel(SampledArgs a) {
 #pragma unroll
   for (int i = 0; i < (D4 + 3) / 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
-  for (int k = beg; k < end; ++k) {
+  constexpr int NA = (D4 + 3) / 4;
+  int k = beg;
+  for (; k + 4 <= end; k += 4) {   // 4 independent (pair -> gradient -> session row) chains in flight
+    int pr[4]; float g[4]; const float* sr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pr[u] = a.pairs[k + u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int m = pr[u] / C;
+      g[u] = a.glog[pr[u]];
+      if (a.cosine) { bsum += g[u] * (a.logits[pr[u]] / a.inv_t); g[u] *= a.inv_ns[m]; }
+      sr[u] = a.sess + (long long)m * a.ld_sess;
+    }
+    f32x4 v[4][NA];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int c = lane * 4 + 256 * i;
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        v[u][i] = (c < a.d) ? *reinterpret_cast<const f32x4*>(sr[u] + c) : z;
+      }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < NA; ++i) acc[i] += v[u][i] * g[u];
+  }
+  for (; k < end; ++k) {
     const int pr = a.pairs[k];
     const int m = pr / C;
     float g = a.glog[pr];
     if (a.cosine) { bsum += g * (a.logits[pr] / a.inv_t); g *= a.inv_ns[m]; }   // logits = cos / t
     const float* srow = a.sess + (long long)m * a.ld_sess;
 #pragma unroll
-    for (int i = 0; i < (D4 + 3) / 4; ++i) {
+    for (int i = 0; i < NA; ++i) {
       const int c = lane * 4 + 256 * i;
       if (c < a.d) acc[i] += *reinterpret_cast<const f32x4*>(srow + c) * g;
     }

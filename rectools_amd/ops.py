@@ -80,12 +80,21 @@ RNG = DropoutRng(0)
 # --------------------------------------------------------------------------------------------------
 # dense
 # --------------------------------------------------------------------------------------------------
+_GEMM_WS: tp.Dict[torch.device, torch.Tensor] = {}
+
+
 def _gemm(A, lda, a_kc, B, ldb, b_kc, C, ldc, bias, R, ldr, M, N, K, relu=0, split_k=1) -> None:
-    _c("rt_gemm", A, lda, a_kc, B, ldb, b_kc, C, ldc, bias, R, ldr, M, N, K, relu, split_k, tag=(M, N, K))
+    ws, ws_bytes = None, 0
+    if split_k > 1:
+        ws_bytes = _lib.load().rt_gemm_workspace_bytes(M, N, K, split_k)
+        ws = _GEMM_WS.get(C.device)
+        if ws is None or ws.numel() < ws_bytes:  # one growing scratch per device (stream-ordered reuse)
+            ws = _GEMM_WS[C.device] = torch.empty((max(ws_bytes, 1 << 24),), dtype=torch.uint8, device=C.device)
+    _c("rt_gemm", A, lda, a_kc, B, ldb, b_kc, C, ldc, bias, R, ldr, M, N, K, relu, split_k, ws, ws_bytes, tag=(M, N, K))
 
 
 def _wgrad_splits(k_rows: int) -> int:
-    return max(1, min(128, k_rows // 256))
+    return max(1, min(64, k_rows // 384))
 
 
 class _Linear(torch.autograd.Function):
@@ -118,7 +127,7 @@ class _Linear(torch.autograd.Function):
             dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
             _gemm(dy, N, 1, weight, weight.stride(0), 0, dx, K, None, None, 0, M, K, N)  # dx = dy @ W
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros((N, K), dtype=torch.float32, device=dy.device)
+            dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
             _gemm(dy, N, 0, x, x.stride(0), 0, dw, K, None, None, 0, N, K, M, 0, _wgrad_splits(M))  # dW = dy^T @ x
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.zeros((N,), dtype=torch.float32, device=dy.device)
@@ -152,7 +161,7 @@ class _MatmulNN(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
         _gemm(dy, N, 1, p, N, 1, dx, K, None, None, 0, M, K, N)  # dx = dy @ P^T : B(k', n) = P[k'*N + n] (kc)
-        dp = torch.zeros((K, N), dtype=torch.float32, device=dy.device)
+        dp = torch.empty((K, N), dtype=torch.float32, device=dy.device)
         _gemm(x, x.stride(0), 0, dy, N, 0, dp, N, None, None, 0, K, N, M, 0, _wgrad_splits(M))  # dP = x^T @ dy
         return dx, dp
 
@@ -542,7 +551,7 @@ class _SoftmaxLoss(torch.autograd.Function):
         _c("rt_softmax_ce_rows", logits, V, R, V, y_act, w_act, float(logits_t), 1, out[1:], float(gloss), None, lse)
         ds_act = torch.empty((R, d), dtype=torch.float32, device=logits.device)
         _gemm(logits, V, 1, table, table.stride(0), 0, ds_act, d, None, None, 0, R, d, V)       # dS = G @ E
-        d_table = torch.zeros_like(table)
+        d_table = torch.empty_like(table)
         _gemm(logits, V, 0, s_act, d, 0, d_table, d, None, None, 0, V, d, R, 0, _wgrad_splits(R))  # dE = G^T @ S
         d_table[0].zero_()  # padding_idx row never receives gradient (item_net.py:260-264)
         d_sess = torch.zeros((M_total, d), dtype=torch.float32, device=logits.device)
