@@ -15,6 +15,7 @@
 // Same reduction-index permutation as the top-k kernel: lane l consumes k = 8s + 4(l>>5) + t, so a
 // k-contiguous operand is fetched from LDS with one ds_read_b128 per 4 MFMAs.
 #include "rt_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -257,6 +258,177 @@ __global__ __launch_bounds__(GT) void gemm_kernel(GemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Fast path: LDS-DMA ring.  Taken when the tile grid is exact (M, N multiples of 128; every k-range a multiple
+// of 32) and the operands are 16-byte aligned — i.e. every product of a training step.  HBM/L2 -> LDS goes through
+// global_load_lds_dwordx4 (no VGPR staging, no ds_write), NS stages, counted vmcnt, one raw s_barrier per k-step.
+// LDS images are unpadded; bank conflicts are removed by swizzling the SOURCE address of each DMA lane:
+//   k-contiguous   [128 rows][8 x 16 B]: chunk c of row r is stored at c ^ ((r>>1)&7)
+//   row-contiguous [32 k][32 x 16 B]   : chunk rc of k-row k is stored at rc ^ (((k>>2)&1)<<3)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
+}
+// 64 lanes x 16 B from per-lane global addresses to LDS [dst, dst + 1 KiB); inline asm keeps the asynchronous LDS
+// write out of hipcc's waitcnt bookkeeping (with the builtin it drains vmcnt(0) before unrelated ds_reads).
+__device__ __forceinline__ void dma16(const float* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+constexpr int TILE_F = BM * BK;   // floats per operand tile per stage (16 KiB)
+
+// per-lane source pointers of the 4 DMA instructions this wave issues for one operand tile (k0 = 0)
+template <bool KC>
+__device__ __forceinline__ void dma_sources(const float* P, long long ld, int row0, int wave, int lane, const float* (&src)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (KC) {
+      const int row = (wave * 4 + j) * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((row >> 1) & 7);
+      src[j] = P + (long long)(row0 + row) * ld + c * 4;
+    } else {
+      const int k = (wave * 4 + j) * 2 + (lane >> 5);
+      const int rc = (lane & 31) ^ (((k >> 2) & 1) << 3);
+      src[j] = P + (long long)k * ld + row0 + rc * 4;
+    }
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ f32x4 read_frag_swz(const float* S, int row, int s, int h) {
+  if (KC) {
+    return *reinterpret_cast<const f32x4*>(S + row * BK + (((2 * s + h) ^ ((row >> 1) & 7)) << 2));
+  } else {
+    f32x4 x;
+    const float* p = S + (8 * s + 4 * h) * BM + ((((row >> 2) ^ (h << 3)) << 2) | (row & 3));
+    x[0] = p[0]; x[1] = p[BM]; x[2] = p[2 * BM]; x[3] = p[3 * BM];
+    return x;
+  }
+}
+
+template <bool AKC, bool BKC, int NS>
+__global__ __launch_bounds__(GT) void gemm_dma_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [NS][A tile | B tile]
+  constexpr int STAGE_F = 2 * TILE_F;
+  constexpr int NL = 8;   // DMA instructions per wave per stage
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int n_tn = g.N / BN;
+  const int n_tiles = (g.M / BM) * n_tn;
+  int t = blockIdx.x;
+  {
+    const int nx = 8, q = n_tiles / nx, r = n_tiles % nx, xcd = t % nx, idx = t / nx;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = (t / n_tn) * BM, n0 = (t % n_tn) * BN;
+
+  int k_begin = 0, k_end = g.K;
+  if (g.k_per_split > 0) {
+    k_begin = blockIdx.z * g.k_per_split;
+    k_end = min(k_begin + g.k_per_split, g.K);
+    if (k_begin >= k_end) return;
+  }
+  const int n_steps = (k_end - k_begin) / BK;
+
+  const float* a_src[4]; const float* b_src[4];
+  dma_sources<AKC>(g.A + (AKC ? (long long)k_begin : (long long)k_begin * g.lda), g.lda, m0, wave, lane, a_src);
+  dma_sources<BKC>(g.B + (BKC ? (long long)k_begin : (long long)k_begin * g.ldb), g.ldb, n0, wave, lane, b_src);
+  const long long a_step = AKC ? BK : (long long)BK * g.lda;
+  const long long b_step = BKC ? BK : (long long)BK * g.ldb;
+  const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+  const unsigned wave_ofs = __builtin_amdgcn_readfirstlane((unsigned)(wave * 4 * 1024));   // SGPR: goes into M0
+
+  int issued = 0, iss_stage = 0;
+  auto issue_next = [&]() {
+    const unsigned sb = smem_base + (unsigned)(iss_stage * STAGE_F * 4) + wave_ofs;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { dma16(a_src[j], sb + j * 1024); a_src[j] += a_step; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { dma16(b_src[j], sb + TILE_F * 4 + j * 1024); b_src[j] += b_step; }
+    iss_stage = (iss_stage + 1 == NS) ? 0 : iss_stage + 1;
+    ++issued;
+  };
+#pragma unroll 1
+  for (int s = 0; s < NS - 1; ++s) if (issued < n_steps) issue_next();
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int cons_stage = 0;
+#pragma unroll 1
+  for (int st = 0; st < n_steps; ++st) {
+    // stage st landed?  NS-2 stages may stay in flight in steady state, none in the drain
+    if (issued - st == NS - 1) wait_vmcnt<NL*(NS - 2)>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (issued < n_steps) issue_next();   // refills the buffer consumed at step st-1
+
+    const float* Ab = smem + cons_stage * STAGE_F;
+    const float* Bb = Ab + TILE_F;
+    cons_stage = (cons_stage + 1 == NS) ? 0 : cons_stage + 1;
+#pragma unroll
+    for (int s = 0; s < BK / 8; ++s) {
+      f32x4 af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = read_frag_swz<AKC>(Ab, wm * 64 + i * 32 + col, s, half);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = read_frag_swz<BKC>(Bb, wn * 64 + j * 32 + col, s, half);
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][tt], bf[j][tt], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // epilogue (tiles are exact).  Split-K slices write their slab; bias / residual / relu only on the direct path.
+  const bool direct = g.k_per_split == 0;
+  float* dst = direct ? g.C : g.slabs + (long long)blockIdx.z * g.M * g.N;
+  const long long ldd = direct ? g.ldc : g.N;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + col;
+      const int mb = m0 + wm * 64 + i * 32 + 4 * half;
+      const float bv = (direct && g.bias != nullptr) ? g.bias[n] : 0.f;
+      float rv[16];
+      if (direct && g.R != nullptr) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = g.R[(long long)(mb + (r & 3) + 8 * (r >> 2)) * g.ldr + n];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[i][j][r] + bv + rv[r];
+        if (direct && g.relu) v = fmaxf(v, 0.f);
+        dst[(long long)(mb + (r & 3) + 8 * (r >> 2)) * ldd + n] = v;
+      }
+    }
+}
+
 // split-K combine: C[m,n] = sum_z slabs[z][m][n] (+ bias[n]) — fixed summation order (deterministic), no atomics
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int splits, long long mn, int N,
                                                             const float* __restrict__ bias, float* __restrict__ C, long long ldc) {
@@ -305,6 +477,39 @@ int launch_gemm(const GemmArgs& g, int splits, hipStream_t stream) {
   return RT_OK;
 }
 
+template <bool AKC, bool BKC, int NS>
+int launch_gemm_dma(const GemmArgs& g, int splits, hipStream_t stream) {
+  const size_t lds = (size_t)NS * 2 * TILE_F * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_kernel<AKC, BKC, NS>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  dim3 grid((g.M / BM) * (g.N / BN), 1, splits);
+  gemm_dma_kernel<AKC, BKC, NS><<<grid, GT, lds, stream>>>(g);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+template <int NS>
+int launch_gemm_dma_ns(const GemmArgs& g, bool a_kc, bool b_kc, int splits, hipStream_t stream) {
+  if (a_kc && b_kc) return launch_gemm_dma<true, true, NS>(g, splits, stream);
+  if (a_kc && !b_kc) return launch_gemm_dma<true, false, NS>(g, splits, stream);
+  if (!a_kc && b_kc) return launch_gemm_dma<false, true, NS>(g, splits, stream);
+  return launch_gemm_dma<false, false, NS>(g, splits, stream);
+}
+
+// RT_GEMM_IMPL: 0 = generic register-staged kernel only; 2/3/4 = stages of the DMA ring on exact tile grids
+int gemm_impl() {
+  static int impl = -1;
+  if (impl < 0) {
+    const char* e = getenv("RT_GEMM_IMPL");
+    impl = e ? atoi(e) : 2;
+    if (impl != 0 && (impl < 2 || impl > 4)) impl = 2;
+  }
+  return impl;
+}
+
 }  // namespace
 
 extern "C" {
@@ -346,6 +551,15 @@ int rt_gemm(const float* A, int64_t lda, int32_t a_kc, const float* B, int64_t l
     }
   }
   int rc;
+  const int impl = gemm_impl();
+  const bool exact = impl != 0 && (M % BM) == 0 && (N % BN) == 0 && (K % BK) == 0 && (g.k_per_split % BK) == 0 &&
+                     (lda & 3) == 0 && (ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(B) & 15) == 0;
+  if (exact) {
+    rc = impl == 2   ? launch_gemm_dma_ns<2>(g, a_kc != 0, b_kc != 0, splits, stream)
+         : impl == 3 ? launch_gemm_dma_ns<3>(g, a_kc != 0, b_kc != 0, splits, stream)
+                     : launch_gemm_dma_ns<4>(g, a_kc != 0, b_kc != 0, splits, stream);
+  } else
   if (a_kc && b_kc) rc = launch_gemm<true, true>(g, splits, stream);
   else if (a_kc && !b_kc) rc = launch_gemm<true, false>(g, splits, stream);
   else if (!a_kc && b_kc) rc = launch_gemm<false, true>(g, splits, stream);

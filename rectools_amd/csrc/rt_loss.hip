@@ -45,6 +45,7 @@ struct SampledArgs {
   int* count; int* offsets; int* cursor;  // [V+1] counting-sort state over candidate ids
   int* pairs;                             // [M*(1+N)] (position, candidate) pairs grouped by candidate id
   int* blocksum;                          // scan scratch
+  int* heavy_count; int* heavy_ids;       // rows with > HEAVY_T pairs, reduced by a whole workgroup each
 };
 
 __device__ __forceinline__ float group16_sum(float v) {  // sum over the 16 lanes of a quarter-wave
@@ -372,22 +373,19 @@ __global__ __launch_bounds__(256) void pairs_scatter_kernel(SampledArgs a) {
   }
 }
 
-// Backward, part 2 (one wave per table row): d_table[id] = sum over the pairs of that id — written once, no atomics.
+// Backward, part 2: d_table[id] = sum over the pairs of that id — written once, no float atomics.
+// A wave accumulates the pairs [beg, end) with stride-free contiguous access, 4 gather chains in flight.
+constexpr int HEAVY_T = 512;     // ids with more pairs than this go to the workgroup-per-id kernel (popularity skew:
+                                 // a Zipf catalog gives its top item ~9% of all positives -> one wave would serialise them)
+constexpr int HEAVY_WAVES = 16;
+
 template <int D4>
-__global__ __launch_bounds__(256) void sampled_bwd_rows_kernel(SampledArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int id = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (id >= a.V) return;
-  const int C = a.N + 1;
-  const int beg = a.offsets[id], end = a.offsets[id + 1];
-  // lane owns floats [4*lane + 256*i, +4)
-  f32x4 acc[(D4 + 3) / 4];
-#pragma unroll
-  for (int i = 0; i < (D4 + 3) / 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float bsum = 0.f;
+__device__ __forceinline__ void accumulate_pairs(const SampledArgs& a, int beg, int end, int lane,
+                                                 f32x4 (&acc)[(D4 + 3) / 4], float& bsum) {
   constexpr int NA = (D4 + 3) / 4;
+  const int C = a.N + 1;
   int k = beg;
-  for (; k + 4 <= end; k += 4) {   // 4 independent (pair -> gradient -> session row) chains in flight
+  for (; k + 4 <= end; k += 4) {
     int pr[4]; float g[4]; const float* sr[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) pr[u] = a.pairs[k + u];
@@ -395,7 +393,7 @@ __global__ __launch_bounds__(256) void sampled_bwd_rows_kernel(SampledArgs a) {
     for (int u = 0; u < 4; ++u) {
       const int m = pr[u] / C;
       g[u] = a.glog[pr[u]];
-      if (a.cosine) { bsum += g[u] * (a.logits[pr[u]] / a.inv_t); g[u] *= a.inv_ns[m]; }
+      if (a.cosine) { bsum += g[u] * (a.logits[pr[u]] / a.inv_t); g[u] *= a.inv_ns[m]; }   // logits = cos / t
       sr[u] = a.sess + (long long)m * a.ld_sess;
     }
     f32x4 v[4][NA];
@@ -416,7 +414,7 @@ __global__ __launch_bounds__(256) void sampled_bwd_rows_kernel(SampledArgs a) {
     const int pr = a.pairs[k];
     const int m = pr / C;
     float g = a.glog[pr];
-    if (a.cosine) { bsum += g * (a.logits[pr] / a.inv_t); g *= a.inv_ns[m]; }   // logits = cos / t
+    if (a.cosine) { bsum += g * (a.logits[pr] / a.inv_t); g *= a.inv_ns[m]; }
     const float* srow = a.sess + (long long)m * a.ld_sess;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -424,13 +422,20 @@ __global__ __launch_bounds__(256) void sampled_bwd_rows_kernel(SampledArgs a) {
       if (c < a.d) acc[i] += *reinterpret_cast<const f32x4*>(srow + c) * g;
     }
   }
+}
+
+// cosine: e -> e/|e| chain rule, then the single store of the row
+template <int D4>
+__device__ __forceinline__ void finish_table_row(const SampledArgs& a, int id, int lane, bool any,
+                                                 f32x4 (&acc)[(D4 + 3) / 4], float bsum) {
+  constexpr int NA = (D4 + 3) / 4;
   float* dr = a.d_table + (long long)id * a.d;
-  if (a.cosine && end > beg) {
+  if (a.cosine && any) {
     const float* er = a.table + (long long)id * a.d;
     float ee = 0.f;
-    f32x4 ev[(D4 + 3) / 4];
+    f32x4 ev[NA];
 #pragma unroll
-    for (int i = 0; i < (D4 + 3) / 4; ++i) {
+    for (int i = 0; i < NA; ++i) {
       const int c = lane * 4 + 256 * i;
       f32x4 z = {0.f, 0.f, 0.f, 0.f};
       ev[i] = (c < a.d) ? *reinterpret_cast<const f32x4*>(er + c) : z;
@@ -439,13 +444,70 @@ __global__ __launch_bounds__(256) void sampled_bwd_rows_kernel(SampledArgs a) {
     const float ne = sqrtf(wave_sum(ee));
     const float inv_ne = 1.0f / fmaxf(ne, EPS_COS);
 #pragma unroll
-    for (int i = 0; i < (D4 + 3) / 4; ++i)
+    for (int i = 0; i < NA; ++i)
       acc[i] = (ne > EPS_COS) ? (acc[i] - ev[i] * (inv_ne * bsum)) * inv_ne : acc[i] * inv_ne;
   }
 #pragma unroll
-  for (int i = 0; i < (D4 + 3) / 4; ++i) {
+  for (int i = 0; i < NA; ++i) {
     const int c = lane * 4 + 256 * i;
     if (c < a.d) *reinterpret_cast<f32x4*>(dr + c) = acc[i];
+  }
+}
+
+// one wave per table row; rows with more than HEAVY_T pairs are queued for the heavy kernel instead
+template <int D4>
+__global__ __launch_bounds__(256) void sampled_bwd_rows_kernel(SampledArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int id = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (id >= a.V) return;
+  const int beg = a.offsets[id], end = a.offsets[id + 1];
+  if (end - beg > HEAVY_T) {
+    if (lane == 0) a.heavy_ids[atomicAdd(a.heavy_count, 1)] = id;
+    return;
+  }
+  f32x4 acc[(D4 + 3) / 4];
+#pragma unroll
+  for (int i = 0; i < (D4 + 3) / 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  accumulate_pairs<D4>(a, beg, end, lane, acc, bsum);
+  finish_table_row<D4>(a, id, lane, end > beg, acc, bsum);
+}
+
+// one 16-wave workgroup per heavy row: every wave reduces a contiguous slice, partials combined through LDS in a
+// fixed order by wave 0
+template <int D4>
+__global__ __launch_bounds__(HEAVY_WAVES * 64) void sampled_bwd_heavy_kernel(SampledArgs a) {
+  constexpr int NA = (D4 + 3) / 4;
+  __shared__ f32x4 s_part[HEAVY_WAVES][NA][64];
+  __shared__ float s_bsum[HEAVY_WAVES];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n_heavy = *a.heavy_count;
+  for (int h = blockIdx.x; h < n_heavy; h += gridDim.x) {
+    const int id = a.heavy_ids[h];
+    const int beg = a.offsets[id], end = a.offsets[id + 1];
+    const int per = ((end - beg + HEAVY_WAVES - 1) / HEAVY_WAVES + 3) & ~3;
+    const int wb = min(beg + wave * per, end), we = min(wb + per, end);
+    f32x4 acc[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    accumulate_pairs<D4>(a, wb, we, lane, acc, bsum);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) s_part[wave][i][lane] = acc[i];
+    if (lane == 0) s_bsum[wave] = bsum;
+    __syncthreads();
+    if (wave == 0) {
+      bsum = 0.f;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int w = 0; w < HEAVY_WAVES; ++w) {
+        bsum += s_bsum[w];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) acc[i] += s_part[w][i][lane];
+      }
+      finish_table_row<D4>(a, id, lane, true, acc, bsum);
+    }
+    __syncthreads();
   }
 }
 
@@ -588,7 +650,7 @@ int launch_sampled(const SampledArgs& a, bool bwd, hipStream_t stream) {
     return RT_OK;
   }
   const int n = a.V + 1;
-  RT_CHECK_HIP(hipMemsetAsync(a.count, 0, sizeof(int) * (size_t)n, stream));
+  RT_CHECK_HIP(hipMemsetAsync(a.count, 0, sizeof(int) * ((size_t)n + 1), stream));   // + heavy_count
   sampled_bwd_pos_kernel<D4><<<blocks, 256, 0, stream>>>(a);
   RT_CHECK_LAUNCH();
   const int nb = (n + SCAN_T * SCAN_E - 1) / (SCAN_T * SCAN_E);
@@ -602,6 +664,11 @@ int launch_sampled(const SampledArgs& a, bool bwd, hipStream_t stream) {
   RT_CHECK_LAUNCH();
   sampled_bwd_rows_kernel<D4><<<(a.V + 3) / 4, 256, 0, stream>>>(a);
   RT_CHECK_LAUNCH();
+  const long long max_heavy = (long long)a.M * (a.N + 1) / HEAVY_T;
+  if (max_heavy > 0) {
+    sampled_bwd_heavy_kernel<D4><<<(int)min(max_heavy, (long long)rt_num_cus()), HEAVY_WAVES * 64, 0, stream>>>(a);
+    RT_CHECK_LAUNCH();
+  }
   return RT_OK;
 }
 int dispatch_sampled(const SampledArgs& a, bool bwd, hipStream_t stream) {
@@ -634,7 +701,7 @@ int rt_sampled_loss_fwd(const float* sess, int64_t ld_sess, const float* table, 
 size_t rt_sampled_loss_bwd_workspace_bytes(int32_t M, int32_t N, int32_t V) {
   const size_t C = (size_t)N + 1, n = (size_t)V + 1;
   const size_t nb = (n + SCAN_T * SCAN_E - 1) / (SCAN_T * SCAN_E);
-  return 4 * ((size_t)M * C * 2 + (size_t)M + 3 * n + nb + 64);
+  return 4 * ((size_t)M * C * 2 + (size_t)M + 3 * n + nb + 64 + 2 + (size_t)M * C / HEAVY_T);
 }
 
 // d_sess [M,d] and d_table [V,d] are fully overwritten (no atomics on floats: the (position, candidate) pairs are
@@ -661,6 +728,8 @@ int rt_sampled_loss_bwd(const float* sess, int64_t ld_sess, const float* table, 
   int* ip = reinterpret_cast<int*>(f);
   a.pairs = ip; ip += (size_t)M * C;
   a.count = ip; ip += n;
+  a.heavy_count = ip; ip += 1;   // directly behind count: one memset clears both
+  a.heavy_ids = ip; ip += (size_t)M * C / HEAVY_T + 1;
   a.offsets = ip; ip += n;
   a.cursor = ip; ip += n;
   a.blocksum = ip;

@@ -188,13 +188,25 @@ def test_hstu_time_thresholds_match_reference_formula():
 @pytest.mark.parametrize("loss", ["BCE", "gBCE", "sampled_softmax"])
 @pytest.mark.parametrize("cosine", [False, True])
 def test_sampled_losses(loss, cosine):
+    _sampled_case(loss, cosine, M=150, d=64, V=90, N=37, hot=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cosine", [False, True])
+def test_sampled_loss_popularity_skew(cosine):
+    """One item is the target of most positions: its table row takes the workgroup-per-row reduction path."""
+    _sampled_case("sampled_softmax", cosine, M=1500, d=128, V=400, N=5, hot=True)
+
+
+def _sampled_case(loss, cosine, M, d, V, N, hot):
     from rectools_amd import lightning as hl
     from rectools_amd import ops
 
-    M, d, V, N = 150, 64, 90, 37
     g = torch.Generator().manual_seed(1)
     sess, table = rnd(M, d, seed=2), rnd(V, d, seed=3)
     y = torch.randint(1, V, (M,), generator=g); y[::5] = 0
+    if hot:
+        y[torch.rand(M, generator=g) < 0.7] = 7
     neg = torch.randint(1, V, (M, N), generator=g)
     w = (0.5 + torch.rand(M, generator=g)) * (y != 0)
     t = 0.7
