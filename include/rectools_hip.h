@@ -82,10 +82,12 @@ int rt_topk_score(const float* users, int64_t user_stride, const int64_t* user_r
  * = 0: element (r, k) lives at r + k*ld (a transposed view).  split_k > 1 splits the reduction over the grid:
  * every slice writes an [M,N] slab into `workspace` (rt_gemm_workspace_bytes) and a second kernel sums the
  * slabs in a fixed order into C (deterministic, no float atomics; R / relu then not allowed).
+ * a_rowsum (optional, [M]; row-contiguous A only): also returns sum_k A(m,k) — the bias gradient db = colsum(dy)
+ * of a wgrad product dW = dy^T x, taken from the A tiles already staged in LDS (no second pass over dy).
  * ------------------------------------------------------------------------------------------------ */
 size_t rt_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t split_k);
 int rt_gemm(const float* A, int64_t lda, int32_t a_kc, const float* B, int64_t ldb, int32_t b_kc,
-            float* C, int64_t ldc, const float* bias, const float* R, int64_t ldr,
+            float* C, int64_t ldc, const float* bias, const float* R, int64_t ldr, float* a_rowsum,
             int32_t M, int32_t N, int32_t K, int32_t relu, int32_t split_k, void* workspace, size_t workspace_bytes,
             rt_stream_t stream);
 /* out[n] += sum_m X[m,n]  (bias gradients; caller zero-fills out) */
@@ -96,21 +98,27 @@ int rt_colsum(const float* X, int64_t ld, int32_t M, int32_t N, float* out, rt_s
  * out[m,:] = dropout(table[ids[m]] * scale + pos[L-1-(m mod L)])     (pos may be NULL)
  * Replaces `item_embs[sessions]` (torch_backbone.py:245), LearnableInversePositionalEncoding.forward
  * (net_blocks.py:388-399) and emb_dropout (torch_backbone.py:247); the full-table copy of
- * get_all_embeddings (item_net.py:361-368) is not needed.  Backward: gtable rows are accumulated with
- * atomics, row 0 (padding_idx) excluded (item_net.py:260-264); gpos accumulated.  Dropout masks are
- * regenerated from (seed, stream_id).
+ * get_all_embeddings (item_net.py:361-368) is not needed.  Backward: positions are counting-sorted by item id
+ * and every gtable row [V,d] / gpos row [L,d] is written exactly once (no float atomics; row 0 = padding_idx
+ * stays zero, item_net.py:260-264); workspace from rt_embed_bwd_workspace_bytes.  Dropout masks are regenerated
+ * from (seed, stream_id).
  * ------------------------------------------------------------------------------------------------ */
 int rt_embed_fwd(const int64_t* ids, const float* table, const float* pos, float scale, int32_t M, int32_t L,
                  int32_t d, float p, uint64_t seed, uint64_t stream_id, float* out, rt_stream_t stream);
-int rt_embed_bwd(const int64_t* ids, const float* gout, float scale, int32_t M, int32_t L, int32_t d, float p,
-                 uint64_t seed, uint64_t stream_id, float* gtable, float* gpos, rt_stream_t stream);
+size_t rt_embed_bwd_workspace_bytes(int32_t M, int32_t V);
+int rt_embed_bwd(const int64_t* ids, const float* gout, float scale, int32_t M, int32_t L, int32_t d, int32_t V, float p,
+                 uint64_t seed, uint64_t stream_id, float* gtable, float* gpos, void* workspace, size_t workspace_bytes,
+                 rt_stream_t stream);
 
 /* K3  LayerNorm over rows of [M,d] (nn.LayerNorm call sites: sasrec.py:221,226,303; net_blocks.py:247,257;
- * ligr.py:90,102; hstu.py:256,291).  mean/rstd [M] are saved for the backward; dw/db are accumulated. */
+ * ligr.py:90,102; hstu.py:256,291).  mean/rstd [M] are saved for the backward; dx/dw/db are overwritten
+ * (per-block partial sums in `workspace`, then a fixed-order reduction: deterministic, no float atomics). */
 int rt_layernorm_fwd(const float* x, const float* w, const float* b, float eps, int32_t M, int32_t d, float* y,
                      float* mean, float* rstd, rt_stream_t stream);
+size_t rt_layernorm_bwd_workspace_bytes(int32_t M, int32_t d);
 int rt_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rstd, int32_t M,
-                     int32_t d, float* dx, float* dw, float* db, rt_stream_t stream);
+                     int32_t d, float* dx, float* dw, float* db, void* workspace, size_t workspace_bytes,
+                     rt_stream_t stream);
 
 /* element-wise streams (n = number of floats, multiple of 4).  kind: 0 none, 1 relu, 2 gelu(erf), 3 silu, 4 sigmoid.
  * y = dropout(act(z)) and its backward (net_blocks.py:63-64; hstu.py:257; dropouts at sasrec.py:228, net_blocks.py:258-260) */

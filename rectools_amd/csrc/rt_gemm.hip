@@ -33,7 +33,8 @@ struct GemmArgs {
   int M, N, K;
   int relu;
   int k_per_split;                // split-K: grid.z slices of the reduction; >0 => each slice writes its own slab
-  float* slabs;                   // [splits][M][N] partial products (split-K)
+  float* slabs;                   // [splits][M][N] partial products (split-K), then [splits][M] partial row sums
+  float* a_rowsum;                // [M] or null: sum_k A(m,k) (bias gradient of a wgrad product; row-contiguous A only)
 };
 
 template <bool KC>
@@ -371,6 +372,8 @@ __global__ __launch_bounds__(GT) void gemm_dma_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  const bool want_rowsum = g.a_rowsum != nullptr && n0 == 0;   // one column of tiles owns the A row sums
+  float rowsum = 0.f;
   int cons_stage = 0;
 #pragma unroll 1
   for (int st = 0; st < n_steps; ++st) {
@@ -384,6 +387,11 @@ __global__ __launch_bounds__(GT) void gemm_dma_kernel(GemmArgs g) {
     const float* Ab = smem + cons_stage * STAGE_F;
     const float* Bb = Ab + TILE_F;
     cons_stage = (cons_stage + 1 == NS) ? 0 : cons_stage + 1;
+    if (!AKC && want_rowsum && tid < BM) {   // column sums of the A stage (thread = row m0 + tid), conflict-free
+#pragma unroll
+      for (int kk = 0; kk < BK; ++kk)
+        rowsum += Ab[kk * BM + ((((tid >> 2) ^ (((kk >> 2) & 1) << 3)) << 2) | (tid & 3))];
+    }
 #pragma unroll
     for (int s = 0; s < BK / 8; ++s) {
       f32x4 af[2], bf[2];
@@ -403,6 +411,10 @@ __global__ __launch_bounds__(GT) void gemm_dma_kernel(GemmArgs g) {
 
   // epilogue (tiles are exact).  Split-K slices write their slab; bias / residual / relu only on the direct path.
   const bool direct = g.k_per_split == 0;
+  if (!AKC && want_rowsum && tid < BM) {
+    if (direct) g.a_rowsum[m0 + tid] = rowsum;
+    else g.slabs[(long long)gridDim.z * g.M * g.N + (long long)blockIdx.z * g.M + m0 + tid] = rowsum;
+  }
   float* dst = direct ? g.C : g.slabs + (long long)blockIdx.z * g.M * g.N;
   const long long ldd = direct ? g.ldc : g.N;
 #pragma unroll
@@ -429,27 +441,34 @@ __global__ __launch_bounds__(GT) void gemm_dma_kernel(GemmArgs g) {
     }
 }
 
-// split-K combine: C[m,n] = sum_z slabs[z][m][n] (+ bias[n]) — fixed summation order (deterministic), no atomics
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int splits, long long mn, int N,
-                                                            const float* __restrict__ bias, float* __restrict__ C, long long ldc) {
+// split-K combine: C[m,n] = sum_z slabs[z][m][n] (+ bias[n]) — fixed summation order (deterministic), no atomics;
+// the trailing M threads combine the partial A row sums the same way
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int splits, long long mn, int M, int N,
+                                                            const float* __restrict__ bias, float* __restrict__ C, long long ldc,
+                                                            float* __restrict__ a_rowsum) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= mn) return;
-  float s = 0.f;
-  for (int z = 0; z < splits; ++z) s += slabs[(long long)z * mn + i];
-  const int n = (int)(i % N);
-  if (bias) s += bias[n];
-  C[(i / N) * ldc + n] = s;
+  if (i < mn) {
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += slabs[(long long)z * mn + i];
+    const int n = (int)(i % N);
+    if (bias) s += bias[n];
+    C[(i / N) * ldc + n] = s;
+  } else if (a_rowsum != nullptr && i < mn + M) {
+    const float* rs = slabs + (long long)splits * mn + (i - mn);
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += rs[(long long)z * M];
+    a_rowsum[i - mn] = s;
+  }
 }
 
-// column sums: out[n] = sum_m X[m, n]   (bias gradients)
+// column sums: out[n] += sum_m X[m, n]  (`out` zero-filled by the caller); lanes own single columns
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long long ld, int M, int N,
-                                                     float* __restrict__ out) {
-  // block handles 64 columns x a slice of rows; 4 waves stride the rows, lanes own columns
+                                                            float* __restrict__ out) {
   const int n = blockIdx.x * 64 + (threadIdx.x & 63);
   const int w = threadIdx.x >> 6;
   const int rows_per_block = (M + gridDim.y - 1) / gridDim.y;
   const int r0 = blockIdx.y * rows_per_block;
-  int r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
+  const int r1 = min(r0 + rows_per_block, M);
   float s = 0.f;
   if (n < N)
     for (int m = r0 + w; m < r1; m += 4) s += X[(long long)m * ld + n];
@@ -520,7 +539,7 @@ size_t rt_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t split_k)
   int kps = (K + split_k - 1) / split_k;
   kps = (kps + BK - 1) / BK * BK;
   const int splits = (K + kps - 1) / kps;
-  return (size_t)splits * M * N * sizeof(float);
+  return (size_t)splits * ((size_t)M * N + M) * sizeof(float);
 }
 
 // C[M,N] = A . B^T (+bias) (+R) (relu);  a_kc/b_kc: 1 = k-contiguous ([rows,K] row-major, ld = row stride),
@@ -529,8 +548,8 @@ size_t rt_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t split_k)
 // (deterministic; R / relu are not allowed).
 int rt_gemm(const float* A, int64_t lda, int32_t a_kc, const float* B, int64_t ldb, int32_t b_kc,
             float* C, int64_t ldc, const float* bias, const float* R, int64_t ldr,
-            int32_t M, int32_t N, int32_t K, int32_t relu, int32_t split_k, void* workspace, size_t workspace_bytes,
-            hipStream_t stream) {
+            float* a_rowsum, int32_t M, int32_t N, int32_t K, int32_t relu, int32_t split_k, void* workspace,
+            size_t workspace_bytes, hipStream_t stream) {
   (void)hipGetLastError();
   if (M < 0 || N < 0 || K < 0) return RT_ERR_INVALID_ARG;
   if (M == 0 || N == 0) return RT_OK;
@@ -545,7 +564,7 @@ int rt_gemm(const float* A, int64_t lda, int32_t a_kc, const float* B, int64_t l
     kps = (kps + BK - 1) / BK * BK;
     splits = (K + kps - 1) / kps;
     if (splits > 1) {
-      if (workspace == nullptr || workspace_bytes < (size_t)splits * M * N * sizeof(float)) return RT_ERR_WORKSPACE;
+      if (workspace == nullptr || workspace_bytes < (size_t)splits * ((size_t)M * N + M) * sizeof(float)) return RT_ERR_WORKSPACE;
       g.k_per_split = kps;
       g.slabs = reinterpret_cast<float*>(workspace);
     }
@@ -555,6 +574,16 @@ int rt_gemm(const float* A, int64_t lda, int32_t a_kc, const float* B, int64_t l
   const bool exact = impl != 0 && (M % BM) == 0 && (N % BN) == 0 && (K % BK) == 0 && (g.k_per_split % BK) == 0 &&
                      (lda & 3) == 0 && (ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
                      (reinterpret_cast<uintptr_t>(B) & 15) == 0;
+  if (a_rowsum != nullptr) {
+    if (a_kc) return RT_ERR_UNSUPPORTED;   // row sums ride on the row-contiguous A stage (wgrad: A = dy^T)
+    if (exact) g.a_rowsum = a_rowsum;
+    else {  // generic kernel: separate column-sum pass over A viewed as [K, M]
+      RT_CHECK_HIP(hipMemsetAsync(a_rowsum, 0, sizeof(float) * (size_t)M, stream));
+      int gy = (K + 63) / 64; if (gy > 512) gy = 512;
+      colsum_kernel<<<dim3((M + 63) / 64, gy), 256, 0, stream>>>(A, lda, K, M, a_rowsum);
+      RT_CHECK_LAUNCH();
+    }
+  }
   if (exact) {
     rc = impl == 2   ? launch_gemm_dma_ns<2>(g, a_kc != 0, b_kc != 0, splits, stream)
          : impl == 3 ? launch_gemm_dma_ns<3>(g, a_kc != 0, b_kc != 0, splits, stream)
@@ -566,7 +595,7 @@ int rt_gemm(const float* A, int64_t lda, int32_t a_kc, const float* B, int64_t l
   else rc = launch_gemm<false, false>(g, splits, stream);
   if (rc != RT_OK || g.k_per_split == 0) return rc;
   const long long mn = (long long)M * N;
-  splitk_reduce_kernel<<<(int)((mn + 255) / 256), 256, 0, stream>>>(g.slabs, splits, mn, N, bias, C, ldc);
+  splitk_reduce_kernel<<<(int)((mn + M + 255) / 256), 256, 0, stream>>>(g.slabs, splits, mn, M, N, bias, C, ldc, g.a_rowsum);
   RT_CHECK_LAUNCH();
   return RT_OK;
 }
@@ -575,9 +604,8 @@ int rt_gemm(const float* A, int64_t lda, int32_t a_kc, const float* B, int64_t l
 int rt_colsum(const float* X, int64_t ld, int32_t M, int32_t N, float* out, hipStream_t stream) {
   (void)hipGetLastError();
   if (M <= 0 || N <= 0) return RT_OK;
-  int gy = (M + 63) / 64; if (gy > 2048) gy = 2048; if (gy < 1) gy = 1;
-  dim3 grid((N + 63) / 64, gy);
-  colsum_kernel<<<grid, 256, 0, stream>>>(X, ld, M, N, out);
+  int gy = (M + 63) / 64; if (gy > 512) gy = 512;
+  colsum_kernel<<<dim3((N + 63) / 64, gy), 256, 0, stream>>>(X, ld, M, N, out);
   RT_CHECK_LAUNCH();
   return RT_OK;
 }

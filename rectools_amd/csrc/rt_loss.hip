@@ -16,6 +16,7 @@
 //  loss reduction   sum(loss) / sum(loss > 0) for the softmax family (lightning.py:159-161), sum(loss) / sum(y != 0)
 //                   for BCE / gBCE (lightning.py:197-198).
 #include "rt_common.h"
+#include "rt_scan.h"
 
 namespace {
 
@@ -221,11 +222,12 @@ __global__ __launch_bounds__(256) void sampled_bwd_pos_kernel(SampledArgs a) {
       grow[j] = gf;
     }
   }
-  // histogram of candidate ids (counting sort, pass 1); ids also staged in LDS for the gather loop
+  // histogram of the NEGATIVE ids (counting sort, pass 1; uniform samples, plain atomics) — the positives are
+  // popularity-skewed and counted by agg_hist_kernel; ids also staged in LDS for the gather loop
   for (int j = lane; j < C; j += 64) {
     const long long cid = (j == 0) ? yy : a.neg[(long long)m * a.N + (j - 1)];
     if (j < 260) s_cid[wave][j] = (int)cid;
-    if (cid != 0) atomicAdd(a.count + cid, 1);
+    if (j != 0 && cid != 0) atomicAdd(a.count + cid, 1);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
@@ -302,64 +304,7 @@ __global__ __launch_bounds__(256) void sampled_bwd_pos_kernel(SampledArgs a) {
   }
 }
 
-// ---- counting sort over candidate ids: exclusive scan of count[0..V] (3 phases), then scatter of the pairs ----
-constexpr int SCAN_T = 1024, SCAN_E = 4;   // 4096 elements per block
-__global__ __launch_bounds__(SCAN_T) void scan_local_kernel(const int* __restrict__ count, int n, int* __restrict__ offsets,
-                                                            int* __restrict__ blocksum) {
-  __shared__ int s_w[SCAN_T / 64];
-  const int base = (blockIdx.x * SCAN_T + threadIdx.x) * SCAN_E;
-  int v[SCAN_E], t = 0;
-#pragma unroll
-  for (int e = 0; e < SCAN_E; ++e) { v[e] = (base + e < n) ? count[base + e] : 0; t += v[e]; }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int incl = t;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
-  if (lane == 63) s_w[wave] = incl;
-  __syncthreads();
-  if (wave == 0) {
-    int x = (lane < SCAN_T / 64) ? s_w[lane] : 0, inc = x;
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) { int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
-    if (lane < SCAN_T / 64) s_w[lane] = inc - x;   // exclusive prefix of the wave totals
-    if (lane == SCAN_T / 64 - 1) blocksum[blockIdx.x] = inc;
-  }
-  __syncthreads();
-  int run = s_w[wave] + incl - t;
-#pragma unroll
-  for (int e = 0; e < SCAN_E; ++e) { if (base + e < n) offsets[base + e] = run; run += v[e]; }
-}
-__global__ __launch_bounds__(1024) void scan_blocksums_kernel(int* __restrict__ blocksum, int nb) {
-  __shared__ int s_w[16]; __shared__ int s_carry;
-  if (threadIdx.x == 0) s_carry = 0;
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int b0 = 0; b0 < nb; b0 += 1024) {
-    const int i = b0 + threadIdx.x;
-    const int x = (i < nb) ? blocksum[i] : 0;
-    int inc = x;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
-    if (lane == 63) s_w[wave] = inc;
-    __syncthreads();
-    if (wave == 0) {
-      int y = (lane < 16) ? s_w[lane] : 0, yi = y;
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) { int u = __shfl_up(yi, o, 64); if (lane >= o) yi += u; }
-      if (lane < 16) s_w[lane] = yi - y;
-    }
-    __syncthreads();
-    const int excl = s_carry + s_w[wave] + inc - x;
-    if (i < nb) blocksum[i] = excl;
-    __syncthreads();
-    if (threadIdx.x == 1023) s_carry = excl + x;
-    __syncthreads();
-  }
-}
-__global__ void scan_add_kernel(int* __restrict__ offsets, int* __restrict__ cursor, const int* __restrict__ blocksum, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { const int o = offsets[i] + blocksum[i / (SCAN_T * SCAN_E)]; offsets[i] = o; cursor[i] = o; }
-}
+// ---- counting sort over candidate ids: exclusive scan of count[0..V] (rt_scan.h), then scatter of the pairs ----
 __global__ __launch_bounds__(256) void pairs_scatter_kernel(SampledArgs a) {
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -367,8 +312,8 @@ __global__ __launch_bounds__(256) void pairs_scatter_kernel(SampledArgs a) {
   const long long yy = a.y[m];
   if (yy == 0) return;
   const int C = a.N + 1;
-  for (int j = lane; j < C; j += 64) {
-    const long long cid = (j == 0) ? yy : a.neg[(long long)m * a.N + (j - 1)];
+  for (int j = lane + 1; j < C; j += 64) {   // negatives; the positive (j = 0) goes through agg_scatter_kernel
+    const long long cid = a.neg[(long long)m * a.N + (j - 1)];
     if (cid != 0) a.pairs[atomicAdd(a.cursor + cid, 1)] = m * C + j;
   }
 }
@@ -653,14 +598,12 @@ int launch_sampled(const SampledArgs& a, bool bwd, hipStream_t stream) {
   RT_CHECK_HIP(hipMemsetAsync(a.count, 0, sizeof(int) * ((size_t)n + 1), stream));   // + heavy_count
   sampled_bwd_pos_kernel<D4><<<blocks, 256, 0, stream>>>(a);
   RT_CHECK_LAUNCH();
-  const int nb = (n + SCAN_T * SCAN_E - 1) / (SCAN_T * SCAN_E);
-  scan_local_kernel<<<nb, SCAN_T, 0, stream>>>(a.count, n, a.offsets, a.blocksum);
+  agg_hist_kernel<<<(a.M + AGG_T - 1) / AGG_T, AGG_T, 0, stream>>>(a.y, a.M, a.count);
   RT_CHECK_LAUNCH();
-  scan_blocksums_kernel<<<1, 1024, 0, stream>>>(a.blocksum, nb);
-  RT_CHECK_LAUNCH();
-  scan_add_kernel<<<(n + 255) / 256, 256, 0, stream>>>(a.offsets, a.cursor, a.blocksum, n);
-  RT_CHECK_LAUNCH();
+  { const int rc = exclusive_scan_counts(a.count, n, a.offsets, a.cursor, a.blocksum, stream); if (rc != RT_OK) return rc; }
   pairs_scatter_kernel<<<blocks, 256, 0, stream>>>(a);
+  RT_CHECK_LAUNCH();
+  agg_scatter_kernel<<<(a.M + AGG_T - 1) / AGG_T, AGG_T, 0, stream>>>(a.y, a.M, a.cursor, a.pairs, a.N + 1);
   RT_CHECK_LAUNCH();
   sampled_bwd_rows_kernel<D4><<<(a.V + 3) / 4, 256, 0, stream>>>(a);
   RT_CHECK_LAUNCH();

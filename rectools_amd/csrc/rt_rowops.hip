@@ -7,6 +7,7 @@
 // Dropout masks are counter-based (Philox4x32 keyed by (seed, element/4)): the backward kernels regenerate
 // the forward mask from the same (seed, stream) pair instead of storing it.
 #include "rt_common.h"
+#include "rt_scan.h"
 
 namespace {
 
@@ -44,30 +45,170 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restr
   }
 }
 
-// gtable[ids[m]] += g * scale (ids != 0: nn.Embedding(padding_idx=0)); gpos[L-1-l] += g   (g = dropped gout)
-__global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restrict__ ids, const float* __restrict__ gout,
-                                                        float scale, int M, int L, int d, float p,
-                                                        unsigned long long seed, unsigned long long stream,
-                                                        float* __restrict__ gtable, float* __restrict__ gpos) {
-  const int lane = threadIdx.x & 63;
-  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (m >= M) return;
-  const long long id = ids[m];
-  const int l = m % L;
-  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
-  for (int c = lane * 4; c < d; c += 256) {
-    f32x4 g = *reinterpret_cast<const f32x4*>(gout + (long long)m * d + c);
-    if (p > 0.f) g = drop4(g, seed, stream, ((unsigned long long)m * d + c) >> 2, p, inv_keep);
-    if (gpos) {
-      float* pr = gpos + (long long)(L - 1 - l) * d + c;
-      atomicAdd(pr + 0, g[0]); atomicAdd(pr + 1, g[1]); atomicAdd(pr + 2, g[2]); atomicAdd(pr + 3, g[3]);
-    }
-    if (id != 0) {
-      float* tr = gtable + id * (long long)d + c;
-      atomicAdd(tr + 0, g[0] * scale); atomicAdd(tr + 1, g[1] * scale);
-      atomicAdd(tr + 2, g[2] * scale); atomicAdd(tr + 3, g[3] * scale);
+// Backward of K2 without float atomics (device-scope atomics on gfx950 resolve memory-side and made the old scatter
+// 5x slower than the data movement): positions are counting-sorted by item id, one wave reduces each table row
+// (a 16-wave workgroup for rows hit by more than EMB_HEAVY_T positions — popularity skew), and the positional
+// gradient is a strided column sum with one workgroup per position.  g = dropped gout (mask regenerated).
+//   gtable[id] = scale * sum_{m: ids[m] == id} g[m]   (row 0 = padding_idx stays 0: item_net.py:260-264)
+//   gpos[L-1-l] = sum_b g[b*L + l]
+constexpr int EMB_HEAVY_T = 512, EMB_HEAVY_WAVES = 16;
+
+struct EmbBwdArgs {
+  const long long* ids; const float* gout; float scale; int M, L, d, V; float p;
+  unsigned long long seed, stream;
+  float* gtable; float* gpos;
+  int* count; int* offsets; int* cursor; int* blocksum; int* order; int* heavy_count; int* heavy_ids;
+};
+
+template <int NDV>
+__device__ __forceinline__ void embed_accumulate(const EmbBwdArgs& a, int beg, int end, int lane, f32x4 (&acc)[NDV]) {
+  const float inv_keep = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
+  int k = beg;
+  for (; k + 4 <= end; k += 4) {
+    int mm[4]; f32x4 v[4][NDV];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) mm[u] = a.order[k + u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < NDV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        v[u][i] = (c < a.d) ? *reinterpret_cast<const f32x4*>(a.gout + (long long)mm[u] * a.d + c) : z;
+      }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < NDV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (a.p > 0.f && c < a.d) v[u][i] = drop4(v[u][i], a.seed, a.stream, ((unsigned long long)mm[u] * a.d + c) >> 2, a.p, inv_keep);
+        acc[i] += v[u][i];
+      }
+  }
+  for (; k < end; ++k) {
+    const int m = a.order[k];
+#pragma unroll
+    for (int i = 0; i < NDV; ++i) {
+      const int c = lane * 4 + 256 * i;
+      if (c < a.d) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(a.gout + (long long)m * a.d + c);
+        if (a.p > 0.f) v = drop4(v, a.seed, a.stream, ((unsigned long long)m * a.d + c) >> 2, a.p, inv_keep);
+        acc[i] += v;
+      }
     }
   }
+}
+
+template <int NDV>
+__global__ __launch_bounds__(256) void embed_bwd_rows_kernel(EmbBwdArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int id = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (id >= a.V) return;
+  const int beg = a.offsets[id], end = a.offsets[id + 1];
+  if (end - beg > EMB_HEAVY_T) {
+    if (lane == 0) a.heavy_ids[atomicAdd(a.heavy_count, 1)] = id;
+    return;
+  }
+  f32x4 acc[NDV];
+#pragma unroll
+  for (int i = 0; i < NDV; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  embed_accumulate<NDV>(a, beg, end, lane, acc);
+#pragma unroll
+  for (int i = 0; i < NDV; ++i) {
+    const int c = lane * 4 + 256 * i;
+    if (c < a.d) *reinterpret_cast<f32x4*>(a.gtable + (long long)id * a.d + c) = acc[i] * a.scale;
+  }
+}
+
+template <int NDV>
+__global__ __launch_bounds__(EMB_HEAVY_WAVES * 64) void embed_bwd_heavy_kernel(EmbBwdArgs a) {
+  __shared__ f32x4 s_part[EMB_HEAVY_WAVES][NDV][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n_heavy = *a.heavy_count;
+  for (int h = blockIdx.x; h < n_heavy; h += gridDim.x) {
+    const int id = a.heavy_ids[h];
+    const int beg = a.offsets[id], end = a.offsets[id + 1];
+    const int per = ((end - beg + EMB_HEAVY_WAVES - 1) / EMB_HEAVY_WAVES + 3) & ~3;
+    const int wb = min(beg + wave * per, end), we = min(wb + per, end);
+    f32x4 acc[NDV];
+#pragma unroll
+    for (int i = 0; i < NDV; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    embed_accumulate<NDV>(a, wb, we, lane, acc);
+#pragma unroll
+    for (int i = 0; i < NDV; ++i) s_part[wave][i][lane] = acc[i];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int i = 0; i < NDV; ++i) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        for (int w = 0; w < EMB_HEAVY_WAVES; ++w) t += s_part[w][i][lane];
+        const int c = lane * 4 + 256 * i;
+        if (c < a.d) *reinterpret_cast<f32x4*>(a.gtable + (long long)id * a.d + c) = t * a.scale;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// one workgroup per position l: 4 waves stride the batch, lanes own float4 columns; fixed-order LDS combine
+template <int NDV>
+__global__ __launch_bounds__(256) void embed_bwd_pos_kernel(EmbBwdArgs a) {
+  __shared__ f32x4 s_part[4][NDV][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l = blockIdx.x;
+  const int B = a.M / a.L;
+  const float inv_keep = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
+  f32x4 acc[NDV];
+#pragma unroll
+  for (int i = 0; i < NDV; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int b = wave; b < B; b += 4) {
+    const long long m = (long long)b * a.L + l;
+#pragma unroll
+    for (int i = 0; i < NDV; ++i) {
+      const int c = lane * 4 + 256 * i;
+      if (c < a.d) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(a.gout + m * a.d + c);
+        if (a.p > 0.f) v = drop4(v, a.seed, a.stream, ((unsigned long long)m * a.d + c) >> 2, a.p, inv_keep);
+        acc[i] += v;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NDV; ++i) s_part[wave][i][lane] = acc[i];
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int i = 0; i < NDV; ++i) {
+      const int c = lane * 4 + 256 * i;
+      if (c < a.d)
+        *reinterpret_cast<f32x4*>(a.gpos + (long long)(a.L - 1 - l) * a.d + c) =
+            (s_part[0][i][lane] + s_part[1][i][lane]) + (s_part[2][i][lane] + s_part[3][i][lane]);
+    }
+  }
+}
+
+template <int NDV>
+int launch_embed_bwd(const EmbBwdArgs& a, hipStream_t stream) {
+  const int n = a.V + 1;
+  RT_CHECK_HIP(hipMemsetAsync(a.count, 0, sizeof(int) * ((size_t)n + 1), stream));   // + heavy_count
+  agg_hist_kernel<<<(a.M + AGG_T - 1) / AGG_T, AGG_T, 0, stream>>>(a.ids, a.M, a.count);
+  RT_CHECK_LAUNCH();
+  { const int rc = exclusive_scan_counts(a.count, n, a.offsets, a.cursor, a.blocksum, stream); if (rc != RT_OK) return rc; }
+  agg_scatter_kernel<<<(a.M + AGG_T - 1) / AGG_T, AGG_T, 0, stream>>>(a.ids, a.M, a.cursor, a.order, 1);
+  RT_CHECK_LAUNCH();
+  embed_bwd_rows_kernel<NDV><<<(a.V + 3) / 4, 256, 0, stream>>>(a);
+  RT_CHECK_LAUNCH();
+  const int max_heavy = a.M / EMB_HEAVY_T;
+  if (max_heavy > 0) {
+    embed_bwd_heavy_kernel<NDV><<<min(max_heavy, rt_num_cus()), EMB_HEAVY_WAVES * 64, 0, stream>>>(a);
+    RT_CHECK_LAUNCH();
+  }
+  if (a.gpos) {
+    embed_bwd_pos_kernel<NDV><<<a.L, 256, 0, stream>>>(a);
+    RT_CHECK_LAUNCH();
+  }
+  return RT_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -111,8 +252,7 @@ template <int NDV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ w, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, int M, int d, int rows_per_block,
-                                                            float* __restrict__ dx, float* __restrict__ dw,
-                                                            float* __restrict__ db) {
+                                                            float* __restrict__ dx, float* __restrict__ partial) {
   extern __shared__ float red[];  // [4 waves][2][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r0 = blockIdx.x * rows_per_block;
@@ -124,31 +264,49 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     pw[i] = f32x4{0.f, 0.f, 0.f, 0.f}; pb[i] = pw[i];
     wv[i] = (c < d) ? *reinterpret_cast<const f32x4*>(w + c) : pw[i];
   }
-  for (int m = r0 + wave; m < r1; m += 4) {
-    const float mu = mean[m], rs = rstd[m];
-    const float* xr = x + (long long)m * d;
-    const float* gr = dy + (long long)m * d;
-    f32x4 g[NDV], xh[NDV];
-    float s1 = 0.f, s2 = 0.f;
+  // two rows per iteration: their loads are issued together (the row reductions in between are latency chains)
+  for (int m = r0 + wave; m < r1; m += 8) {
+    const int m2 = m + 4;
+    const bool has2 = m2 < r1;
+    const int mb = has2 ? m2 : m;
+    const float mu[2] = {mean[m], mean[mb]}, rs[2] = {rstd[m], rstd[mb]};
+    const long long ro[2] = {(long long)m * d, (long long)mb * d};
+    f32x4 g[2][NDV], xh[2][NDV];
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < NDV; ++i) {
-      const int c = lane * 4 + 256 * i;
-      f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      g[i] = (c < d) ? *reinterpret_cast<const f32x4*>(gr + c) : z;
-      xh[i] = (c < d) ? (*reinterpret_cast<const f32x4*>(xr + c) - mu) * rs : z;
-      f32x4 gw = g[i] * wv[i];
-      s1 += gw[0] + gw[1] + gw[2] + gw[3];
-      s2 += gw[0] * xh[i][0] + gw[1] * xh[i][1] + gw[2] * xh[i][2] + gw[3] * xh[i][3];
-    }
-    s1 = wave_sum(s1) / d; s2 = wave_sum(s2) / d;
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int i = 0; i < NDV; ++i) {
-      const int c = lane * 4 + 256 * i;
-      if (c < d) {
-        f32x4 o = (g[i] * wv[i] - s1 - xh[i] * s2) * rs;
-        *reinterpret_cast<f32x4*>(dx + (long long)m * d + c) = o;
-        pw[i] += g[i] * xh[i];
-        pb[i] += g[i];
+      for (int i = 0; i < NDV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        g[u][i] = (c < d) ? *reinterpret_cast<const f32x4*>(dy + ro[u] + c) : z;
+        xh[u][i] = (c < d) ? *reinterpret_cast<const f32x4*>(x + ro[u] + c) : z;
+      }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < NDV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        xh[u][i] = (c < d) ? (xh[u][i] - mu[u]) * rs[u] : z;
+        f32x4 gw = g[u][i] * wv[i];
+        s1[u] += gw[0] + gw[1] + gw[2] + gw[3];
+        s2[u] += gw[0] * xh[u][i][0] + gw[1] * xh[u][i][1] + gw[2] * xh[u][i][2] + gw[3] * xh[u][i][3];
+      }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { s1[u] = wave_sum(s1[u]) / d; s2[u] = wave_sum(s2[u]) / d; }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (u == 1 && !has2) break;
+#pragma unroll
+      for (int i = 0; i < NDV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < d) {
+          f32x4 o = (g[u][i] * wv[i] - s1[u] - xh[u][i] * s2[u]) * rs[u];
+          *reinterpret_cast<f32x4*>(dx + ro[u] + c) = o;
+          pw[i] += g[u][i] * xh[u][i];
+          pb[i] += g[u][i];
+        }
       }
     }
   }
@@ -161,9 +319,35 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
   }
   __syncthreads();
+  // partials [blocks][2][d]; layernorm_bwd_reduce_kernel sums them in a fixed order (same-address float atomics from
+  // hundreds of blocks serialise memory-side and cost more than the whole streaming pass)
+  float* part = partial + (long long)blockIdx.x * 2 * d;
   for (int c = threadIdx.x; c < d; c += 256) {
-    atomicAdd(dw + c, red[0 * d + c] + red[2 * d + c] + red[4 * d + c] + red[6 * d + c]);
-    atomicAdd(db + c, red[1 * d + c] + red[3 * d + c] + red[5 * d + c] + red[7 * d + c]);
+    part[c] = (red[0 * d + c] + red[2 * d + c]) + (red[4 * d + c] + red[6 * d + c]);
+    part[d + c] = (red[1 * d + c] + red[3 * d + c]) + (red[5 * d + c] + red[7 * d + c]);
+  }
+}
+
+// dw[c] = sum_b partial[b][0][c], db[c] = sum_b partial[b][1][c]; block = 64 columns x 4 row phases
+__global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* __restrict__ partial, int blocks, int d,
+                                                                   float* __restrict__ dw, float* __restrict__ db) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;   // column in [0, 2d): dw then db
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < 2 * d) {
+    int b = w;
+    for (; b + 12 < blocks; b += 16) {
+      s0 += partial[(long long)b * 2 * d + c];        s1 += partial[(long long)(b + 4) * 2 * d + c];
+      s2 += partial[(long long)(b + 8) * 2 * d + c];  s3 += partial[(long long)(b + 12) * 2 * d + c];
+    }
+    for (; b < blocks; b += 4) s0 += partial[(long long)b * 2 * d + c];
+  }
+  red[w][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (w == 0 && c < 2 * d) {
+    const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (c < d) dw[c] = t; else db[c - d] = t;
   }
 }
 
@@ -341,15 +525,34 @@ int rt_embed_fwd(const int64_t* ids, const float* table, const float* pos, float
   return RT_OK;
 }
 
-int rt_embed_bwd(const int64_t* ids, const float* gout, float scale, int32_t M, int32_t L, int32_t d, float p,
-                 uint64_t seed, uint64_t stream_id, float* gtable, float* gpos, hipStream_t stream) {
+// Host arithmetic: bytes of the int scratch rt_embed_bwd needs.
+size_t rt_embed_bwd_workspace_bytes(int32_t M, int32_t V) {
+  const size_t n = (size_t)V + 1;
+  return 4 * (3 * n + 1 + scan_blocks(n) + 64 + (size_t)M + (size_t)M / EMB_HEAVY_T + 2);
+}
+
+// gtable [V,d] and gpos [L,d] (optional) are fully overwritten; M must be a multiple of L when gpos is given.
+int rt_embed_bwd(const int64_t* ids, const float* gout, float scale, int32_t M, int32_t L, int32_t d, int32_t V, float p,
+                 uint64_t seed, uint64_t stream_id, float* gtable, float* gpos, void* workspace, size_t workspace_bytes,
+                 hipStream_t stream) {
   (void)hipGetLastError();
-  if (M <= 0) return RT_OK;
-  if ((d & 3) != 0 || L <= 0) return RT_ERR_INVALID_ARG;
-  embed_bwd_kernel<<<(M + 3) / 4, 256, 0, stream>>>(reinterpret_cast<const long long*>(ids), gout, scale, M, L, d, p, seed,
-                                                     stream_id, gtable, gpos);
-  RT_CHECK_LAUNCH();
-  return RT_OK;
+  if ((d & 3) != 0 || L <= 0 || V <= 0 || M < 0 || d > 1024 || (gpos && (M % L) != 0)) return RT_ERR_INVALID_ARG;
+  if (workspace == nullptr || workspace_bytes < rt_embed_bwd_workspace_bytes(M, V)) return RT_ERR_WORKSPACE;
+  EmbBwdArgs a{};
+  a.ids = reinterpret_cast<const long long*>(ids); a.gout = gout; a.scale = scale; a.M = M; a.L = L; a.d = d; a.V = V; a.p = p;
+  a.seed = seed; a.stream = stream_id; a.gtable = gtable; a.gpos = gpos;
+  const size_t n = (size_t)V + 1;
+  int* ip = reinterpret_cast<int*>(workspace);
+  a.count = ip; ip += n;
+  a.heavy_count = ip; ip += 1;          // directly behind count: one memset clears both
+  a.offsets = ip; ip += n;
+  a.cursor = ip; ip += n;
+  a.blocksum = ip; ip += scan_blocks(n) + 64;
+  a.order = ip; ip += M;
+  a.heavy_ids = ip;
+  if (d <= 256) return launch_embed_bwd<1>(a, stream);
+  if (d <= 512) return launch_embed_bwd<2>(a, stream);
+  return launch_embed_bwd<4>(a, stream);
 }
 
 int rt_layernorm_fwd(const float* x, const float* w, const float* b, float eps, int32_t M, int32_t d, float* y,
@@ -362,20 +565,40 @@ int rt_layernorm_fwd(const float* x, const float* w, const float* b, float eps, 
   return RT_OK;
 }
 
+static int ln_bwd_blocks(int M, int& rpb) {
+  int blocks = rt_num_cus() * 2;
+  rpb = (M + blocks - 1) / blocks;
+  if (rpb < 8) rpb = 8;
+  return (M + rpb - 1) / rpb;
+}
+// Host arithmetic: bytes of the float scratch rt_layernorm_bwd needs (per-block dw/db partial sums).
+size_t rt_layernorm_bwd_workspace_bytes(int32_t M, int32_t d) {
+  if (M <= 0) return 0;
+  int rpb;
+  return (size_t)ln_bwd_blocks(M, rpb) * 2 * (size_t)d * sizeof(float);
+}
+
+// dx [M,d], dw [d], db [d] are fully overwritten (deterministic two-stage reduction, no atomics).
 int rt_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rstd, int32_t M,
-                     int32_t d, float* dx, float* dw, float* db, hipStream_t stream) {
+                     int32_t d, float* dx, float* dw, float* db, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   (void)hipGetLastError();
-  if (M <= 0) return RT_OK;
   if ((d & 3) != 0) return RT_ERR_INVALID_ARG;
   if (d > 1024) return RT_ERR_UNSUPPORTED;
-  int blocks = rt_num_cus() * 4;
-  int rpb = (M + blocks - 1) / blocks;
-  if (rpb < 4) rpb = 4;
-  blocks = (M + rpb - 1) / rpb;
+  if (M <= 0) {
+    RT_CHECK_HIP(hipMemsetAsync(dw, 0, sizeof(float) * d, stream));
+    RT_CHECK_HIP(hipMemsetAsync(db, 0, sizeof(float) * d, stream));
+    return RT_OK;
+  }
+  if (workspace == nullptr || workspace_bytes < rt_layernorm_bwd_workspace_bytes(M, d)) return RT_ERR_WORKSPACE;
+  int rpb;
+  const int blocks = ln_bwd_blocks(M, rpb);
+  float* partial = reinterpret_cast<float*>(workspace);
   const size_t lds = 8 * (size_t)d * sizeof(float);
-  if (d <= 256) layernorm_bwd_kernel<1><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, dw, db);
-  else if (d <= 512) layernorm_bwd_kernel<2><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, dw, db);
-  else layernorm_bwd_kernel<4><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, dw, db);
+  if (d <= 256) layernorm_bwd_kernel<1><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, partial);
+  else if (d <= 512) layernorm_bwd_kernel<2><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, partial);
+  else layernorm_bwd_kernel<4><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, partial);
+  RT_CHECK_LAUNCH();
+  layernorm_bwd_reduce_kernel<<<(2 * d + 63) / 64, 256, 0, stream>>>(partial, blocks, d, dw, db);
   RT_CHECK_LAUNCH();
   return RT_OK;
 }

@@ -83,14 +83,15 @@ RNG = DropoutRng(0)
 _GEMM_WS: tp.Dict[torch.device, torch.Tensor] = {}
 
 
-def _gemm(A, lda, a_kc, B, ldb, b_kc, C, ldc, bias, R, ldr, M, N, K, relu=0, split_k=1) -> None:
+def _gemm(A, lda, a_kc, B, ldb, b_kc, C, ldc, bias, R, ldr, M, N, K, relu=0, split_k=1, a_rowsum=None) -> None:
     ws, ws_bytes = None, 0
     if split_k > 1:
         ws_bytes = _lib.load().rt_gemm_workspace_bytes(M, N, K, split_k)
         ws = _GEMM_WS.get(C.device)
         if ws is None or ws.numel() < ws_bytes:  # one growing scratch per device (stream-ordered reuse)
             ws = _GEMM_WS[C.device] = torch.empty((max(ws_bytes, 1 << 24),), dtype=torch.uint8, device=C.device)
-    _c("rt_gemm", A, lda, a_kc, B, ldb, b_kc, C, ldc, bias, R, ldr, M, N, K, relu, split_k, ws, ws_bytes, tag=(M, N, K))
+    _c("rt_gemm", A, lda, a_kc, B, ldb, b_kc, C, ldc, bias, R, ldr, a_rowsum, M, N, K, relu, split_k, ws, ws_bytes,
+       tag=(M, N, K))
 
 
 def _wgrad_splits(k_rows: int) -> int:
@@ -126,10 +127,13 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
             _gemm(dy, N, 1, weight, weight.stride(0), 0, dx, K, None, None, 0, M, K, N)  # dx = dy @ W
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
-            _gemm(dy, N, 0, x, x.stride(0), 0, dw, K, None, None, 0, N, K, M, 0, _wgrad_splits(M))  # dW = dy^T @ x
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            if want_db:  # db = colsum(dy) rides on the dy^T tiles of the wgrad product
+                db = torch.empty((N,), dtype=torch.float32, device=dy.device)
+            _gemm(dy, N, 0, x, x.stride(0), 0, dw, K, None, None, 0, N, K, M, 0, _wgrad_splits(M), db)  # dW = dy^T @ x
+        elif want_db:
             db = torch.zeros((N,), dtype=torch.float32, device=dy.device)
             _c("rt_colsum", dy, N, M, N, db)
         dres = dy if (ctx.has_res and ctx.needs_input_grad[3]) else None
@@ -190,9 +194,14 @@ class _Embed(torch.autograd.Function):
         (ids,) = ctx.saved_tensors
         tshape, pshape, L, scale, p, seed, sid = ctx.meta
         gout = gout.contiguous()
-        gtable = torch.zeros(tshape, dtype=torch.float32, device=gout.device)
-        gpos = None if pshape is None else torch.zeros(pshape, dtype=torch.float32, device=gout.device)
-        _c("rt_embed_bwd", ids, gout, float(scale), ids.numel(), L, tshape[1], float(p), seed, sid, gtable, gpos)
+        M, V = ids.numel(), tshape[0]
+        gtable = torch.empty(tshape, dtype=torch.float32, device=gout.device)   # every row is written by the kernel
+        gpos = None
+        if pshape is not None:  # rows [0, L) are written; a longer table keeps zero gradient behind them
+            gpos = (torch.empty if pshape[0] == L else torch.zeros)(pshape, dtype=torch.float32, device=gout.device)
+        ws_bytes = _lib.load().rt_embed_bwd_workspace_bytes(M, V)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=gout.device)
+        _c("rt_embed_bwd", ids, gout, float(scale), M, L, tshape[1], V, float(p), seed, sid, gtable, gpos, ws, ws_bytes)
         return gtable, gpos, None, None, None, None
 
 
@@ -220,9 +229,11 @@ class _LayerNorm(torch.autograd.Function):
         M, d = x.shape
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        dw = torch.zeros_like(w)
-        db = torch.zeros_like(w)
-        _c("rt_layernorm_bwd", dy, x, w, mean, rstd, M, d, dx, dw, db)
+        dw = torch.empty_like(w)
+        db = torch.empty_like(w)
+        ws_bytes = _lib.load().rt_layernorm_bwd_workspace_bytes(M, d)
+        ws = torch.empty((max(ws_bytes, 4),), dtype=torch.uint8, device=x.device)
+        _c("rt_layernorm_bwd", dy, x, w, mean, rstd, M, d, dx, dw, db, ws, ws_bytes)
         return dx, dw, db, None
 
 

@@ -30,7 +30,9 @@ def close(a, b, rtol=2e-4, atol_rel=2e-5, msg=""):
     torch.testing.assert_close(a, b, rtol=rtol, atol=atol_rel * (float(b.abs().max()) + 1e-12), msg=lambda m: f"{msg}: {m}")
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 77, 40), (1000, 256, 256), (33, 51, 16), (130, 520, 132)])
+# the last three shapes give exact 128-tile grids: LDS-DMA GEMM path, direct and split-K, bias gradient fused in wgrad
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 77, 40), (1000, 256, 256), (33, 51, 16), (130, 520, 132),
+                                   (256, 128, 128), (2048, 256, 128), (4096, 128, 384)])
 def test_linear_fwd_bwd(M, N, K):
     from rectools_amd import ops
 
@@ -93,6 +95,24 @@ def test_embed_and_masks():
     ref, gref = grads_of(lambda a, b: a * b * m, [a, b])
     got, ggot = grads_of(lambda a, b: ops.mul_mask(a, b, ids.cuda()), [a.cuda(), b.cuda()])
     close(got, ref, msg="mulmask"); close(ggot[0], gref[0], msg="mulmask da"); close(ggot[1], gref[1], msg="mulmask db")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V,L,B,d,hot", [(300, 50, 40, 512, True), (5000, 20, 8, 64, False), (7, 3, 1, 4, False)])
+def test_embed_backward_sorted_reduction(V, L, B, d, hot):
+    """Counting-sort embedding backward: popularity skew (workgroup-per-row path), sparse catalog, tiny shapes."""
+    from rectools_amd import ops
+
+    table, pos = rnd(V, d, seed=1), rnd(L, d, seed=2)
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, V, (B, L), generator=g)
+    if hot:
+        ids[torch.rand(B, L, generator=g) < 0.6] = 5
+    ref, gref = grads_of(lambda t, p: T.embed_sessions({T.ITEM_EMB: t, T.POS_EMB: p}, ids, False).reshape(B * L, d), [table, pos])
+    got, ggot = grads_of(lambda t, p: ops.embed(t, p, ids.cuda(), L, 1.0, 0.0), [table.cuda(), pos.cuda()])
+    gref[0][0] = 0
+    close(got, ref, msg="embed fwd")
+    close(ggot[0], gref[0], rtol=1e-3, msg="embed dtable"); close(ggot[1], gref[1], rtol=1e-3, msg="embed dpos")
 
 
 @pytest.mark.parametrize("kind,fn", [(1, F.relu), (2, F.gelu), (3, F.silu), (4, torch.sigmoid)])
