@@ -441,24 +441,56 @@ __global__ __launch_bounds__(GT) void gemm_dma_kernel(GemmArgs g) {
     }
 }
 
-// split-K combine: C[m,n] = sum_z slabs[z][m][n] (+ bias[n]) — fixed summation order (deterministic), no atomics;
-// the trailing M threads combine the partial A row sums the same way
+// split-K combine: C[m,n] = sum_z slabs[z][m][n] (+ bias[n]) — fixed summation order (deterministic), no atomics.
+// Block = 64 float4 columns x 4 slab phases (wave w sums slabs w, w+4, ...; 8 loads in flight per lane: a dependent
+// round trip costs ~2 us here, the data itself microseconds), combined through LDS.  The trailing blocks combine the
+// partial A row sums the same way.  N % 4 == 0 on this path, otherwise the scalar kernel below is used.
+__device__ __forceinline__ f32x4 sum_slabs(const float* __restrict__ base, long long stride, int splits, int w) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int z = w;
+  for (; z + 28 < splits; z += 32) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(base + (long long)(z + 4 * u) * stride);
+    acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  }
+  for (; z < splits; z += 4) acc += *reinterpret_cast<const f32x4*>(base + (long long)z * stride);
+  return acc;
+}
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int splits, long long mn, int M, int N,
                                                             const float* __restrict__ bias, float* __restrict__ C, long long ldc,
-                                                            float* __restrict__ a_rowsum) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < mn) {
-    float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += slabs[(long long)z * mn + i];
+                                                            float* __restrict__ a_rowsum, int n_main_blocks) {
+  __shared__ f32x4 red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const bool main = (int)blockIdx.x < n_main_blocks;
+  const long long i = ((long long)(main ? blockIdx.x : blockIdx.x - n_main_blocks) * 64 + lane) * 4;
+  const long long count = main ? mn : (long long)M;
+  const float* base = main ? slabs : slabs + (long long)splits * mn;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (i < count) s = sum_slabs(base + i, count, splits, w);
+  red[w][lane] = s;
+  __syncthreads();
+  if (w != 0 || i >= count) return;
+  f32x4 t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  if (main) {
     const int n = (int)(i % N);
-    if (bias) s += bias[n];
-    C[(i / N) * ldc + n] = s;
-  } else if (a_rowsum != nullptr && i < mn + M) {
-    const float* rs = slabs + (long long)splits * mn + (i - mn);
-    float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += rs[(long long)z * M];
-    a_rowsum[i - mn] = s;
+    if (bias) t += *reinterpret_cast<const f32x4*>(bias + n);
+    float* dst = C + (i / N) * ldc + n;
+    dst[0] = t[0]; dst[1] = t[1]; dst[2] = t[2]; dst[3] = t[3];
+  } else {
+    a_rowsum[i] = t[0]; a_rowsum[i + 1] = t[1]; a_rowsum[i + 2] = t[2]; a_rowsum[i + 3] = t[3];
   }
+}
+__global__ __launch_bounds__(256) void splitk_reduce_scalar_kernel(const float* __restrict__ slabs, int splits, long long mn, int N,
+                                                                   const float* __restrict__ bias, float* __restrict__ C,
+                                                                   long long ldc) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= mn) return;
+  float s = 0.f;
+  for (int z = 0; z < splits; ++z) s += slabs[(long long)z * mn + i];
+  const int n = (int)(i % N);
+  if (bias) s += bias[n];
+  C[(i / N) * ldc + n] = s;
 }
 
 // column sums: out[n] += sum_m X[m, n]  (`out` zero-filled by the caller); lanes own single columns
@@ -595,7 +627,13 @@ int rt_gemm(const float* A, int64_t lda, int32_t a_kc, const float* B, int64_t l
   else rc = launch_gemm<false, false>(g, splits, stream);
   if (rc != RT_OK || g.k_per_split == 0) return rc;
   const long long mn = (long long)M * N;
-  splitk_reduce_kernel<<<(int)((mn + M + 255) / 256), 256, 0, stream>>>(g.slabs, splits, mn, M, N, bias, C, ldc, g.a_rowsum);
+  if ((N & 3) == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0) {
+    const int n_main = (int)((mn / 4 + 63) / 64);
+    const int n_rs = g.a_rowsum != nullptr ? (M / 4 + 63) / 64 : 0;   // exact path: M % 128 == 0
+    splitk_reduce_kernel<<<n_main + n_rs, 256, 0, stream>>>(g.slabs, splits, mn, M, N, bias, C, ldc, g.a_rowsum, n_main);
+  } else {
+    splitk_reduce_scalar_kernel<<<(int)((mn + 255) / 256), 256, 0, stream>>>(g.slabs, splits, mn, N, bias, C, ldc);
+  }
   RT_CHECK_LAUNCH();
   return RT_OK;
 }

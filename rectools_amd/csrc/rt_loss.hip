@@ -46,6 +46,7 @@ struct SampledArgs {
   int* count; int* offsets; int* cursor;  // [V+1] counting-sort state over candidate ids
   int* pairs;                             // [M*(1+N)] (position, candidate) pairs grouped by candidate id
   int* blocksum;                          // scan scratch
+  int* rank;                              // [M, 1+N] rank of every pair inside its candidate id
   int* heavy_count; int* heavy_ids;       // rows with > HEAVY_T pairs, reduced by a whole workgroup each
 };
 
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256) void sampled_bwd_pos_kernel(SampledArgs a) {
   for (int j = lane; j < C; j += 64) {
     const long long cid = (j == 0) ? yy : a.neg[(long long)m * a.N + (j - 1)];
     if (j < 260) s_cid[wave][j] = (int)cid;
-    if (j != 0 && cid != 0) atomicAdd(a.count + cid, 1);
+    if (j != 0 && cid != 0) a.rank[m * C + j] = atomicAdd(a.count + cid, 1);   // rank of this pair inside its id
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
@@ -312,38 +313,37 @@ __global__ __launch_bounds__(256) void pairs_scatter_kernel(SampledArgs a) {
   const long long yy = a.y[m];
   if (yy == 0) return;
   const int C = a.N + 1;
-  for (int j = lane + 1; j < C; j += 64) {   // negatives; the positive (j = 0) goes through agg_scatter_kernel
-    const long long cid = a.neg[(long long)m * a.N + (j - 1)];
-    if (cid != 0) a.pairs[atomicAdd(a.cursor + cid, 1)] = m * C + j;
+  for (int j = lane; j < C; j += 64) {   // slot = start of the id's segment + the rank taken when it was counted
+    const long long cid = (j == 0) ? yy : a.neg[(long long)m * a.N + (j - 1)];
+    if (cid != 0) a.pairs[a.offsets[cid] + a.rank[m * C + j]] = m * C + j;
   }
 }
 
 // Backward, part 2: d_table[id] = sum over the pairs of that id — written once, no float atomics.
 // A wave accumulates the pairs [beg, end) with stride-free contiguous access, 4 gather chains in flight.
-constexpr int HEAVY_T = 512;     // ids with more pairs than this go to the workgroup-per-id kernel (popularity skew:
+constexpr int HEAVY_T = 128;     // ids with more pairs than this go to the workgroup-per-id kernel (popularity skew:
                                  // a Zipf catalog gives its top item ~9% of all positives -> one wave would serialise them)
 constexpr int HEAVY_WAVES = 16;
 
-template <int D4>
-__device__ __forceinline__ void accumulate_pairs(const SampledArgs& a, int beg, int end, int lane,
-                                                 f32x4 (&acc)[(D4 + 3) / 4], float& bsum) {
+template <int D4, int U>
+__device__ __forceinline__ void accumulate_pairs_u(const SampledArgs& a, int& k, int end, int lane,
+                                                   f32x4 (&acc)[(D4 + 3) / 4], float& bsum) {
   constexpr int NA = (D4 + 3) / 4;
   const int C = a.N + 1;
-  int k = beg;
-  for (; k + 4 <= end; k += 4) {
-    int pr[4]; float g[4]; const float* sr[4];
+  for (; k + U <= end; k += U) {   // U independent (pair -> gradient -> session row) chains in flight
+    int pr[U]; float g[U]; const float* sr[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) pr[u] = a.pairs[k + u];
+    for (int u = 0; u < U; ++u) pr[u] = a.pairs[k + u];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int m = pr[u] / C;
       g[u] = a.glog[pr[u]];
       if (a.cosine) { bsum += g[u] * (a.logits[pr[u]] / a.inv_t); g[u] *= a.inv_ns[m]; }   // logits = cos / t
       sr[u] = a.sess + (long long)m * a.ld_sess;
     }
-    f32x4 v[4][NA];
+    f32x4 v[U][NA];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         const int c = lane * 4 + 256 * i;
@@ -351,22 +351,19 @@ __device__ __forceinline__ void accumulate_pairs(const SampledArgs& a, int beg, 
         v[u][i] = (c < a.d) ? *reinterpret_cast<const f32x4*>(sr[u] + c) : z;
       }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int i = 0; i < NA; ++i) acc[i] += v[u][i] * g[u];
   }
-  for (; k < end; ++k) {
-    const int pr = a.pairs[k];
-    const int m = pr / C;
-    float g = a.glog[pr];
-    if (a.cosine) { bsum += g * (a.logits[pr] / a.inv_t); g *= a.inv_ns[m]; }
-    const float* srow = a.sess + (long long)m * a.ld_sess;
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int c = lane * 4 + 256 * i;
-      if (c < a.d) acc[i] += *reinterpret_cast<const f32x4*>(srow + c) * g;
-    }
-  }
+}
+// a wave's serial chain is ~1-2 us per round of gathers: 16 pairs per round, then 4, then 1
+template <int D4>
+__device__ __forceinline__ void accumulate_pairs(const SampledArgs& a, int beg, int end, int lane,
+                                                 f32x4 (&acc)[(D4 + 3) / 4], float& bsum) {
+  int k = beg;
+  accumulate_pairs_u<D4, (D4 <= 4 ? 16 : 8)>(a, k, end, lane, acc, bsum);
+  accumulate_pairs_u<D4, 4>(a, k, end, lane, acc, bsum);
+  accumulate_pairs_u<D4, 1>(a, k, end, lane, acc, bsum);
 }
 
 // cosine: e -> e/|e| chain rule, then the single store of the row
@@ -430,7 +427,7 @@ __global__ __launch_bounds__(HEAVY_WAVES * 64) void sampled_bwd_heavy_kernel(Sam
   for (int h = blockIdx.x; h < n_heavy; h += gridDim.x) {
     const int id = a.heavy_ids[h];
     const int beg = a.offsets[id], end = a.offsets[id + 1];
-    const int per = ((end - beg + HEAVY_WAVES - 1) / HEAVY_WAVES + 3) & ~3;
+    const int per = ((end - beg + HEAVY_WAVES - 1) / HEAVY_WAVES + 15) & ~15;
     const int wb = min(beg + wave * per, end), we = min(wb + per, end);
     f32x4 acc[NA];
 #pragma unroll
@@ -598,12 +595,10 @@ int launch_sampled(const SampledArgs& a, bool bwd, hipStream_t stream) {
   RT_CHECK_HIP(hipMemsetAsync(a.count, 0, sizeof(int) * ((size_t)n + 1), stream));   // + heavy_count
   sampled_bwd_pos_kernel<D4><<<blocks, 256, 0, stream>>>(a);
   RT_CHECK_LAUNCH();
-  agg_hist_kernel<<<(a.M + AGG_T - 1) / AGG_T, AGG_T, 0, stream>>>(a.y, a.M, a.count);
+  agg_rank_kernel<<<(a.M + AGG_T - 1) / AGG_T, AGG_T, 0, stream>>>(a.y, a.M, a.count, a.rank, a.N + 1);
   RT_CHECK_LAUNCH();
   { const int rc = exclusive_scan_counts(a.count, n, a.offsets, a.cursor, a.blocksum, stream); if (rc != RT_OK) return rc; }
   pairs_scatter_kernel<<<blocks, 256, 0, stream>>>(a);
-  RT_CHECK_LAUNCH();
-  agg_scatter_kernel<<<(a.M + AGG_T - 1) / AGG_T, AGG_T, 0, stream>>>(a.y, a.M, a.cursor, a.pairs, a.N + 1);
   RT_CHECK_LAUNCH();
   sampled_bwd_rows_kernel<D4><<<(a.V + 3) / 4, 256, 0, stream>>>(a);
   RT_CHECK_LAUNCH();
@@ -644,7 +639,7 @@ int rt_sampled_loss_fwd(const float* sess, int64_t ld_sess, const float* table, 
 size_t rt_sampled_loss_bwd_workspace_bytes(int32_t M, int32_t N, int32_t V) {
   const size_t C = (size_t)N + 1, n = (size_t)V + 1;
   const size_t nb = (n + SCAN_T * SCAN_E - 1) / (SCAN_T * SCAN_E);
-  return 4 * ((size_t)M * C * 2 + (size_t)M + 3 * n + nb + 64 + 2 + (size_t)M * C / HEAVY_T);
+  return 4 * ((size_t)M * C * 3 + (size_t)M + 3 * n + nb + 64 + 2 + (size_t)M * C / HEAVY_T);
 }
 
 // d_sess [M,d] and d_table [V,d] are fully overwritten (no atomics on floats: the (position, candidate) pairs are
@@ -670,6 +665,7 @@ int rt_sampled_loss_bwd(const float* sess, int64_t ld_sess, const float* table, 
   a.inv_ns = f; f += M;
   int* ip = reinterpret_cast<int*>(f);
   a.pairs = ip; ip += (size_t)M * C;
+  a.rank = ip; ip += (size_t)M * C;
   a.count = ip; ip += n;
   a.heavy_count = ip; ip += 1;   // directly behind count: one memset clears both
   a.heavy_ids = ip; ip += (size_t)M * C / HEAVY_T + 1;

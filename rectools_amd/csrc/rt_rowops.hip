@@ -51,25 +51,31 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restr
 // gradient is a strided column sum with one workgroup per position.  g = dropped gout (mask regenerated).
 //   gtable[id] = scale * sum_{m: ids[m] == id} g[m]   (row 0 = padding_idx stays 0: item_net.py:260-264)
 //   gpos[L-1-l] = sum_b g[b*L + l]
-constexpr int EMB_HEAVY_T = 512, EMB_HEAVY_WAVES = 16;
+constexpr int EMB_HEAVY_T = 128, EMB_HEAVY_WAVES = 16;
 
 struct EmbBwdArgs {
   const long long* ids; const float* gout; float scale; int M, L, d, V; float p;
   unsigned long long seed, stream;
   float* gtable; float* gpos;
-  int* count; int* offsets; int* cursor; int* blocksum; int* order; int* heavy_count; int* heavy_ids;
+  int* count; int* offsets; int* cursor; int* blocksum; int* order; int* rank; int* heavy_count; int* heavy_ids;
 };
 
-template <int NDV>
-__device__ __forceinline__ void embed_accumulate(const EmbBwdArgs& a, int beg, int end, int lane, f32x4 (&acc)[NDV]) {
+__global__ __launch_bounds__(256) void embed_order_kernel(EmbBwdArgs a) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= a.M) return;
+  const long long id = a.ids[m];
+  if (id != 0) a.order[a.offsets[id] + a.rank[m]] = m;
+}
+
+template <int NDV, int U>
+__device__ __forceinline__ void embed_accumulate_u(const EmbBwdArgs& a, int& k, int end, int lane, f32x4 (&acc)[NDV]) {
   const float inv_keep = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
-  int k = beg;
-  for (; k + 4 <= end; k += 4) {
-    int mm[4]; f32x4 v[4][NDV];
+  for (; k + U <= end; k += U) {
+    int mm[U]; f32x4 v[U][NDV];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) mm[u] = a.order[k + u];
+    for (int u = 0; u < U; ++u) mm[u] = a.order[k + u];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int i = 0; i < NDV; ++i) {
         const int c = lane * 4 + 256 * i;
@@ -77,7 +83,7 @@ __device__ __forceinline__ void embed_accumulate(const EmbBwdArgs& a, int beg, i
         v[u][i] = (c < a.d) ? *reinterpret_cast<const f32x4*>(a.gout + (long long)mm[u] * a.d + c) : z;
       }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int i = 0; i < NDV; ++i) {
         const int c = lane * 4 + 256 * i;
@@ -85,18 +91,14 @@ __device__ __forceinline__ void embed_accumulate(const EmbBwdArgs& a, int beg, i
         acc[i] += v[u][i];
       }
   }
-  for (; k < end; ++k) {
-    const int m = a.order[k];
-#pragma unroll
-    for (int i = 0; i < NDV; ++i) {
-      const int c = lane * 4 + 256 * i;
-      if (c < a.d) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(a.gout + (long long)m * a.d + c);
-        if (a.p > 0.f) v = drop4(v, a.seed, a.stream, ((unsigned long long)m * a.d + c) >> 2, a.p, inv_keep);
-        acc[i] += v;
-      }
-    }
-  }
+}
+// a wave's serial chain is ~1-2 us per round of gathers: 16 rows per round, then 4, then 1
+template <int NDV>
+__device__ __forceinline__ void embed_accumulate(const EmbBwdArgs& a, int beg, int end, int lane, f32x4 (&acc)[NDV]) {
+  int k = beg;
+  embed_accumulate_u<NDV, (NDV == 1 ? 16 : 8)>(a, k, end, lane, acc);
+  embed_accumulate_u<NDV, 4>(a, k, end, lane, acc);
+  embed_accumulate_u<NDV, 1>(a, k, end, lane, acc);
 }
 
 template <int NDV>
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(EMB_HEAVY_WAVES * 64) void embed_bwd_heavy_kernel(E
   for (int h = blockIdx.x; h < n_heavy; h += gridDim.x) {
     const int id = a.heavy_ids[h];
     const int beg = a.offsets[id], end = a.offsets[id + 1];
-    const int per = ((end - beg + EMB_HEAVY_WAVES - 1) / EMB_HEAVY_WAVES + 3) & ~3;
+    const int per = ((end - beg + EMB_HEAVY_WAVES - 1) / EMB_HEAVY_WAVES + 15) & ~15;
     const int wb = min(beg + wave * per, end), we = min(wb + per, end);
     f32x4 acc[NDV];
 #pragma unroll
@@ -192,10 +194,10 @@ template <int NDV>
 int launch_embed_bwd(const EmbBwdArgs& a, hipStream_t stream) {
   const int n = a.V + 1;
   RT_CHECK_HIP(hipMemsetAsync(a.count, 0, sizeof(int) * ((size_t)n + 1), stream));   // + heavy_count
-  agg_hist_kernel<<<(a.M + AGG_T - 1) / AGG_T, AGG_T, 0, stream>>>(a.ids, a.M, a.count);
+  agg_rank_kernel<<<(a.M + AGG_T - 1) / AGG_T, AGG_T, 0, stream>>>(a.ids, a.M, a.count, a.rank, 1);
   RT_CHECK_LAUNCH();
   { const int rc = exclusive_scan_counts(a.count, n, a.offsets, a.cursor, a.blocksum, stream); if (rc != RT_OK) return rc; }
-  agg_scatter_kernel<<<(a.M + AGG_T - 1) / AGG_T, AGG_T, 0, stream>>>(a.ids, a.M, a.cursor, a.order, 1);
+  embed_order_kernel<<<(a.M + 255) / 256, 256, 0, stream>>>(a);
   RT_CHECK_LAUNCH();
   embed_bwd_rows_kernel<NDV><<<(a.V + 3) / 4, 256, 0, stream>>>(a);
   RT_CHECK_LAUNCH();
@@ -328,25 +330,27 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   }
 }
 
-// dw[c] = sum_b partial[b][0][c], db[c] = sum_b partial[b][1][c]; block = 64 columns x 4 row phases
+// dw[c] = sum_b partial[b][0][c], db[c] = sum_b partial[b][1][c]; block = 16 columns x 16 row phases (short chains)
 __global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* __restrict__ partial, int blocks, int d,
                                                                    float* __restrict__ dw, float* __restrict__ db) {
-  __shared__ float red[4][64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;   // column in [0, 2d): dw then db
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, ph = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;   // column in [0, 2d): dw then db
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (c < 2 * d) {
-    int b = w;
-    for (; b + 12 < blocks; b += 16) {
-      s0 += partial[(long long)b * 2 * d + c];        s1 += partial[(long long)(b + 4) * 2 * d + c];
-      s2 += partial[(long long)(b + 8) * 2 * d + c];  s3 += partial[(long long)(b + 12) * 2 * d + c];
+    int b = ph;
+    for (; b + 48 < blocks; b += 64) {
+      s0 += partial[(long long)b * 2 * d + c];         s1 += partial[(long long)(b + 16) * 2 * d + c];
+      s2 += partial[(long long)(b + 32) * 2 * d + c];  s3 += partial[(long long)(b + 48) * 2 * d + c];
     }
-    for (; b < blocks; b += 4) s0 += partial[(long long)b * 2 * d + c];
+    for (; b < blocks; b += 16) s0 += partial[(long long)b * 2 * d + c];
   }
-  red[w][lane] = (s0 + s1) + (s2 + s3);
+  red[ph][cl] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (w == 0 && c < 2 * d) {
-    const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  if (ph == 0 && c < 2 * d) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][cl];
     if (c < d) dw[c] = t; else db[c - d] = t;
   }
 }
@@ -528,7 +532,7 @@ int rt_embed_fwd(const int64_t* ids, const float* table, const float* pos, float
 // Host arithmetic: bytes of the int scratch rt_embed_bwd needs.
 size_t rt_embed_bwd_workspace_bytes(int32_t M, int32_t V) {
   const size_t n = (size_t)V + 1;
-  return 4 * (3 * n + 1 + scan_blocks(n) + 64 + (size_t)M + (size_t)M / EMB_HEAVY_T + 2);
+  return 4 * (3 * n + 1 + scan_blocks(n) + 64 + 2 * (size_t)M + (size_t)M / EMB_HEAVY_T + 2);
 }
 
 // gtable [V,d] and gpos [L,d] (optional) are fully overwritten; M must be a multiple of L when gpos is given.
@@ -549,6 +553,7 @@ int rt_embed_bwd(const int64_t* ids, const float* gout, float scale, int32_t M, 
   a.cursor = ip; ip += n;
   a.blocksum = ip; ip += scan_blocks(n) + 64;
   a.order = ip; ip += M;
+  a.rank = ip; ip += M;
   a.heavy_ids = ip;
   if (d <= 256) return launch_embed_bwd<1>(a, stream);
   if (d <= 512) return launch_embed_bwd<2>(a, stream);
@@ -598,7 +603,7 @@ int rt_layernorm_bwd(const float* dy, const float* x, const float* w, const floa
   else if (d <= 512) layernorm_bwd_kernel<2><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, partial);
   else layernorm_bwd_kernel<4><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, partial);
   RT_CHECK_LAUNCH();
-  layernorm_bwd_reduce_kernel<<<(2 * d + 63) / 64, 256, 0, stream>>>(partial, blocks, d, dw, db);
+  layernorm_bwd_reduce_kernel<<<(2 * d + 15) / 16, 256, 0, stream>>>(partial, blocks, d, dw, db);
   RT_CHECK_LAUNCH();
   return RT_OK;
 }

@@ -67,8 +67,7 @@ __global__ void scan_add_kernel(int* __restrict__ offsets, int* __restrict__ cur
 // Device-scope atomics on ONE address serialise at ~50-100 ns each on gfx950 (they resolve memory-side), so a popular
 // item (Zipf catalogs: the top id holds ~9% of all targets) turns a plain per-element atomicAdd histogram into a
 // multi-100-us serial chain.  Here a 1024-thread workgroup first counts its keys in an LDS hash table (LDS atomics
-// serialise at a few cycles), then issues ONE global atomic per distinct key; the scatter variant hands every element
-// base + rank.  Keys equal to 0 (PAD) are skipped.
+// serialise at a few cycles), then issues ONE global atomic per distinct key.  Keys equal to 0 (PAD) are skipped.
 constexpr int AGG_T = 1024, AGG_SLOTS = 4096;
 struct AggTable { int keys[AGG_SLOTS]; int cnt[AGG_SLOTS]; int base[AGG_SLOTS]; };
 
@@ -85,31 +84,22 @@ __device__ __forceinline__ int agg_insert(AggTable& t, int key, int& rank) {
     h = (h + 1) & (AGG_SLOTS - 1);
   }
 }
-__global__ __launch_bounds__(AGG_T) void agg_hist_kernel(const long long* __restrict__ keys, int n, int* __restrict__ count) {
+// count[key] += (occurrences in this workgroup); rank[i * stride] = position of element i among ALL elements of its key
+// (the old value of the global counter + the element's rank inside the workgroup) — the scatter that follows the scan
+// is then a plain store to offsets[key] + rank, without a second round of atomics.
+__global__ __launch_bounds__(AGG_T) void agg_rank_kernel(const long long* __restrict__ keys, int n, int* __restrict__ count,
+                                                         int* __restrict__ rank, int stride) {
   __shared__ AggTable t;
   agg_clear(t);
   const int i = blockIdx.x * AGG_T + threadIdx.x;
   const int key = (i < n) ? (int)keys[i] : 0;
-  int rank;
-  if (key != 0) agg_insert(t, key, rank);
+  int r = 0, slot = -1;
+  if (key != 0) slot = agg_insert(t, key, r);
   __syncthreads();
   for (int s = threadIdx.x; s < AGG_SLOTS; s += AGG_T)
-    if (t.keys[s] != -1) atomicAdd(count + t.keys[s], t.cnt[s]);
-}
-// out[cursor[key]++] = i * mul  for every element i with key != 0 (order inside a key is arbitrary)
-__global__ __launch_bounds__(AGG_T) void agg_scatter_kernel(const long long* __restrict__ keys, int n, int* __restrict__ cursor,
-                                                            int* __restrict__ out, int mul) {
-  __shared__ AggTable t;
-  agg_clear(t);
-  const int i = blockIdx.x * AGG_T + threadIdx.x;
-  const int key = (i < n) ? (int)keys[i] : 0;
-  int rank = 0, slot = -1;
-  if (key != 0) slot = agg_insert(t, key, rank);
+    if (t.keys[s] != -1) t.base[s] = atomicAdd(count + t.keys[s], t.cnt[s]);
   __syncthreads();
-  for (int s = threadIdx.x; s < AGG_SLOTS; s += AGG_T)
-    if (t.keys[s] != -1) t.base[s] = atomicAdd(cursor + t.keys[s], t.cnt[s]);
-  __syncthreads();
-  if (slot >= 0) out[t.base[slot] + rank] = i * mul;
+  if (slot >= 0) rank[(long long)i * stride] = t.base[slot] + r;
 }
 
 // offsets[i] = sum(count[0..i)), cursor = copy of offsets (scatter cursors); blocksum: ceil(n/4096) + 1 ints of scratch
