@@ -12,12 +12,18 @@
 // in MFMA accumulators.  Q/K/V/O are addressed as [B*L, ld] row-major with the head at column h*hd, so packed
 // in_proj outputs are consumed in place.
 //
-// Work split: forward and dQ kernels give each wave 32 queries (one MFMA tile) and loop over 32-key tiles
-// staged in LDS; the dK/dV kernel gives each wave 32 keys and loops over query tiles.  "Swapped" products
+// Work split: forward and dQ kernels give each wave 32 queries (one MFMA tile) and loop over 32-key tiles in LDS;
+// the dK/dV kernel gives each wave 32 keys and loops over query tiles.  Two kernel families share the per-tile
+// math (fwd_pair / dq_pair / dkv_pair):
+//   resident  (L_pad * hd small enough for 160 KiB of LDS — every default config of the reference, L <= 288 at hd 64):
+//             one workgroup per (batch, head) loads K,V (or Q,dO) ONCE, then its waves run barrier-free, each owning
+//             whole query (key) tiles; causal tiles are dealt heavy+light per SIMD so the triangle is balanced.
+//   streaming (any L): 4 waves share 32-row tiles staged per step (two barriers per tile).  "Swapped" products
 // (keys or queries on the MFMA row index so that a lane owns ONE query / key column) keep every row
 // reduction lane-local plus a single cross-half shuffle, and let the probability / dS accumulator registers be
 // fed straight back as the B operand of the second product (reduction index permuted consistently, as in K7/K12).
 #include "rt_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -107,143 +113,99 @@ __device__ __forceinline__ void stage_tile(const float* base, long long ld, int 
   }
 }
 
+
+// LDS views of the HSTU relative-bias tables (null pointers in softmax mode)
+struct HstuLds {
+  const float* tw; const float* pw; const long long* thr; const long long* ts;
+  float* dtw; float* dpw;   // backward accumulators (dq kernels only)
+};
+
 // ---------------------------------------------------------------------------------------------------
-// forward:  grid = (ceil(L/128), B*H); wave w of a workgroup owns queries q0 = (blockIdx.x*4 + w)*32 ..
+// per-(query tile, key tile) math.  Kt / Vt / Qt / Gt point at a [32][lds_ld] LDS tile, *flag at its 32 pad flags.
 // ---------------------------------------------------------------------------------------------------
-template <int MODE, int HD>   // HD = head dim padded up to a multiple of 32 (32, 64, 128)
-__global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs a) {
-  constexpr int HDV = HD / 8;   // float4 fragments per row (upper bound)
-  constexpr int NT = HD / 32;   // output dd tiles
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int lds_ld = a.hd + 4;
-  float* Ks = smem;                       // [32][hd+4]
-  float* Vs = Ks + TK * lds_ld;           // [32][hd+4]
-  float* aux = Vs + TK * lds_ld;          // [32] key pad flags (as float) | hstu tables
-  float* s_tw = aux + TK;                 // [129]
-  float* s_pw = s_tw + NBUCK + 3;         // [2L-1]
-  long long* s_thr = reinterpret_cast<long long*>(s_pw + ((2 * a.L + 3) & ~3));  // [129]
-  long long* s_ts = s_thr + NBUCK + 1;    // [L+1]
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int col = lane & 31, half = lane >> 5;
-  const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
-  const int q0 = (blockIdx.x * 4 + wave) * TK;
-  const int qq = q0 + col;
-  const long long rowbase = (long long)b * a.L;
-  const float* qb = a.q + rowbase * a.ldq + h * a.hd;
-  const float* kb = a.k + rowbase * a.ldk + h * a.hd;
-  const float* vb = a.v + rowbase * a.ldv + h * a.hd;
-  const long long* idb = a.ids + rowbase;
-
-  if (MODE == MODE_HSTU) {
-    if (a.time_w) for (int i = tid; i < NBUCK; i += AT) { s_tw[i] = a.time_w[i]; s_thr[i] = a.time_thr[i]; }
-    if (a.pos_w) for (int i = tid; i < 2 * a.L - 1; i += AT) s_pw[i] = a.pos_w[i];
-    if (a.ts) for (int i = tid; i < a.L + 1; i += AT) s_ts[i] = a.ts[(long long)b * (a.L + 1) + i];
-  }
-
-  f32x4 qf[HDV];
-  load_row_frags<HDV>(qb, a.ldq, qq, a.L, a.hd, half, qf);
-  const bool q_is_pad = (qq < a.L) ? (idb[qq] == 0) : true;
-  long long t_q1 = 0;
-
-  f32x16 oacc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-
-  // key range of this workgroup: causal => keys <= last query of the workgroup
-  const int wg_q_last = min(a.L, (blockIdx.x * 4 + 4) * TK) - 1;
-  const int n_kt = a.causal ? (wg_q_last / TK + 1) : ((a.L + TK - 1) / TK);
-  const int my_last_kt = a.causal ? min(n_kt - 1, (q0 + TK - 1) / TK) : n_kt - 1;
+// forward: S^T = K Q^T (rows = keys, cols = queries), online softmax / silu, O^T += V^T P^T
+template <int MODE, int HD>
+__device__ __forceinline__ void fwd_pair(const AttnArgs& a, const float* Kt, const float* Vt, const float* kflag, int lds_ld,
+                                         int kt, int qq, bool q_is_pad, long long t_q1, int bh, int col, int half,
+                                         const f32x4 (&qf)[HD / 8], const HstuLds& hl, f32x16 (&oacc)[HD / 32],
+                                         float& m_run, float& l_run) {
+  constexpr int HDV = HD / 8, NT = HD / 32;
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
-
-  __syncthreads();
-  if (MODE == MODE_HSTU && a.ts && qq < a.L) t_q1 = s_ts[qq + 1];
-
-  for (int kt = 0; kt < n_kt; ++kt) {
-    __syncthreads();
-    stage_tile(kb, a.ldk, kt * TK, a.L, a.hd, lds_ld, Ks, tid);
-    stage_tile(vb, a.ldv, kt * TK, a.L, a.hd, lds_ld, Vs, tid);
-    if (tid < TK) { const int kk = kt * TK + tid; aux[tid] = (kk < a.L && idb[kk] != 0) ? 0.f : 1.f; }
-    __syncthreads();
-    if (q0 >= a.L || kt > my_last_kt) continue;  // this wave has nothing to do for the tile (barriers above are uniform)
-
-    // S^T tile: rows = keys (A operand from LDS), cols = queries (B operand = Q fragments)
-    f32x16 sacc;
+  f32x16 sacc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+  for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
 #pragma unroll
-    for (int s = 0; s < HDV; ++s) {
-      if (8 * s < a.hd) {
-        f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + col * lds_ld + 8 * s + 4 * half);
+  for (int s = 0; s < HDV; ++s) {
+    if (8 * s < a.hd) {
+      f32x4 kf = *reinterpret_cast<const f32x4*>(Kt + col * lds_ld + 8 * s + 4 * half);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t], qf[s][t], sacc, 0, 0, 0);
-      }
-    }
-
-    float p[16];
-    if (MODE == MODE_SOFTMAX) {
-      float mx = -INFINITY;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kk = kt * TK + row_of(r, half);
-        const bool msk = (kk >= a.L) || masked(a, qq, kk, aux[row_of(r, half)] != 0.f);
-        const float sv = msk ? -INFINITY : sacc[r] * a.scale;
-        p[r] = sv;
-        mx = fmaxf(mx, sv);
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = (m_new == -INFINITY) ? 1.f : __expf(m_run - m_new);
-      float ps = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        p[r] = (p[r] == -INFINITY) ? 0.f : __expf(p[r] - m_new);
-        ps += p[r];
-      }
-      ps += __shfl_xor(ps, 32, 64);
-      l_run = l_run * alpha + ps;
-      m_run = m_new;
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
-      if (a.p_drop > 0.f) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          p[r] *= drop_keep(a.seed, (unsigned)bh, (unsigned)qq, (unsigned)(kt * TK + row_of(r, half)), a.p_drop, inv_keep);
-      }
-    } else {
-      const float inv_l = 1.0f / (float)a.L;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kk = kt * TK + row_of(r, half);
-        const bool dead = (kk >= a.L) || (qq >= a.L) || (kk > qq) || q_is_pad || (aux[row_of(r, half)] != 0.f);
-        float bias = 0.f;
-        if (!dead) {
-          if (a.time_w) bias += s_tw[time_bucket(s_thr, t_q1 - s_ts[kk])];
-          if (a.pos_w) bias += s_pw[(a.L - 1) + kk - qq];
-        }
-        p[r] = dead ? 0.f : silu_f(sacc[r] + bias) * inv_l;
-      }
-    }
-
-    // O^T tile(s): rows = dd (A operand: V from LDS), cols = queries (B operand = p registers)
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int krow = row_of(t, half);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int dd = nt * 32 + col;
-        const float vv = (dd < a.hd) ? Vs[krow * lds_ld + dd] : 0.f;
-        oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, p[t], oacc[nt], 0, 0, 0);
-      }
+      for (int t = 0; t < 4; ++t) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t], qf[s][t], sacc, 0, 0, 0);
     }
   }
+  float p[16];
+  if (MODE == MODE_SOFTMAX) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kk = kt * TK + row_of(r, half);
+      const bool msk = (kk >= a.L) || masked(a, qq, kk, kflag[row_of(r, half)] != 0.f);
+      const float sv = msk ? -INFINITY : sacc[r] * a.scale;
+      p[r] = sv;
+      mx = fmaxf(mx, sv);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = (m_new == -INFINITY) ? 1.f : __expf(m_run - m_new);
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      p[r] = (p[r] == -INFINITY) ? 0.f : __expf(p[r] - m_new);
+      ps += p[r];
+    }
+    ps += __shfl_xor(ps, 32, 64);
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+    if (a.p_drop > 0.f) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        p[r] *= drop_keep(a.seed, (unsigned)bh, (unsigned)qq, (unsigned)(kt * TK + row_of(r, half)), a.p_drop, inv_keep);
+    }
+  } else {
+    const float inv_l = 1.0f / (float)a.L;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kk = kt * TK + row_of(r, half);
+      const bool dead = (kk >= a.L) || (qq >= a.L) || (kk > qq) || q_is_pad || (kflag[row_of(r, half)] != 0.f);
+      float bias = 0.f;
+      if (!dead) {
+        if (a.time_w) bias += hl.tw[time_bucket(hl.thr, t_q1 - hl.ts[kk])];
+        if (a.pos_w) bias += hl.pw[(a.L - 1) + kk - qq];
+      }
+      p[r] = dead ? 0.f : silu_f(sacc[r] + bias) * inv_l;
+    }
+  }
+  // O^T tile(s): rows = dd (A operand: V from LDS), cols = queries (B operand = p registers)
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int krow = row_of(t, half);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int dd = nt * 32 + col;
+      const float vv = (dd < a.hd) ? Vt[krow * lds_ld + dd] : 0.f;
+      oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, p[t], oacc[nt], 0, 0, 0);
+    }
+  }
+}
 
-  if (q0 >= a.L || qq >= a.L) return;
+template <int MODE, int HD>
+__device__ __forceinline__ void fwd_store(const AttnArgs& a, int bh, int qq, int half, long long rowbase, int h,
+                                          const f32x16 (&oacc)[HD / 32], float m_run, float l_run) {
+  constexpr int NT = HD / 32;
+  if (qq >= a.L) return;
   float inv = 1.f;
   if (MODE == MODE_SOFTMAX) {
     inv = l_run > 0.f ? 1.f / l_run : 0.f;
@@ -257,6 +219,185 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs a) {
       const int dd = nt * 32 + row_of(r, half);
       if (dd < a.hd) ob[dd] = oacc[nt][r] * inv;
     }
+}
+
+// probability / derivative helper shared by the two backward products --------------------------------
+// returns P (softmax: normalised, dropped; hstu: silu(.)/L * masks) and writes ds = dS given dP
+template <int MODE>
+__device__ __forceinline__ void tile_p_ds(const AttnArgs& a, float s_raw, float dp, float lse_q, float delta_q, bool dead,
+                                          float bias, float drop_scale, float& p_used, float& ds) {
+  if (MODE == MODE_SOFTMAX) {
+    const float pn = dead ? 0.f : __expf(s_raw * a.scale - lse_q);
+    p_used = pn * drop_scale;                       // what multiplied V in the forward pass
+    ds = pn * (dp * drop_scale - delta_q) * a.scale; // d/d(raw q.k)
+  } else {
+    const float inv_l = 1.0f / (float)a.L;
+    const float z = s_raw + bias;
+    p_used = dead ? 0.f : silu_f(z) * inv_l;
+    ds = dead ? 0.f : dp * inv_l * silu_df(z);
+  }
+}
+
+// backward dQ: S^T, dP^T (rows = keys, cols = queries), dS, dQ^T += K^T dS^T
+template <int MODE, int HD>
+__device__ __forceinline__ void dq_pair(const AttnArgs& a, const float* Kt, const float* Vt, const float* kflag, int lds_ld,
+                                        int kt, int qq, bool q_is_pad, long long t_q1, int bh, int col, int half,
+                                        const f32x4 (&qf)[HD / 8], const f32x4 (&gf)[HD / 8], float lse_q, float delta_q,
+                                        const HstuLds& hl, f32x16 (&dqacc)[HD / 32]) {
+  constexpr int HDV = HD / 8, NT = HD / 32;
+  const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+  f32x16 sacc, pacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+#pragma unroll
+  for (int s = 0; s < HDV; ++s) {
+    if (8 * s < a.hd) {
+      f32x4 kf = *reinterpret_cast<const f32x4*>(Kt + col * lds_ld + 8 * s + 4 * half);
+      f32x4 vf = *reinterpret_cast<const f32x4*>(Vt + col * lds_ld + 8 * s + 4 * half);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t], qf[s][t], sacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[t], gf[s][t], pacc, 0, 0, 0);
+      }
+    }
+  }
+  float ds[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int kk = kt * TK + row_of(r, half);
+    const bool kpad = kflag[row_of(r, half)] != 0.f;
+    float dsc = 1.f;
+    if (MODE == MODE_SOFTMAX && a.p_drop > 0.f) dsc = drop_keep(a.seed, (unsigned)bh, (unsigned)qq, (unsigned)kk, a.p_drop, inv_keep);
+    bool dead; float bias = 0.f;
+    if (MODE == MODE_SOFTMAX) {
+      dead = (kk >= a.L) || (qq >= a.L) || masked(a, qq, kk, kpad);
+    } else {
+      dead = (kk >= a.L) || (qq >= a.L) || (kk > qq) || q_is_pad || kpad;
+      if (!dead) {
+        if (a.time_w) bias += hl.tw[time_bucket(hl.thr, t_q1 - hl.ts[kk])];
+        if (a.pos_w) bias += hl.pw[(a.L - 1) + kk - qq];
+      }
+    }
+    float pu;
+    tile_p_ds<MODE>(a, sacc[r], pacc[r], lse_q, delta_q, dead, bias, dsc, pu, ds[r]);
+    if (MODE == MODE_HSTU && !dead) {
+      // relative-bias gradients: rab is shared by the heads, so every head adds its dS (hstu.py:276)
+      if (a.d_time_w) atomicAdd(hl.dtw + time_bucket(hl.thr, t_q1 - hl.ts[kk]), ds[r]);
+      if (a.d_pos_w) atomicAdd(hl.dpw + (a.L - 1) + kk - qq, ds[r]);
+    }
+  }
+  // dQ^T += K^T dS^T : rows = dd (A operand: K from LDS), cols = queries (B operand = dS registers)
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int krow = row_of(t, half);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int dd = nt * 32 + col;
+      const float kv = (dd < a.hd) ? Kt[krow * lds_ld + dd] : 0.f;
+      dqacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, ds[t], dqacc[nt], 0, 0, 0);
+    }
+  }
+}
+
+// backward dK/dV: S, dP (rows = queries from LDS, cols = keys), dV^T += dO^T P, dK^T += Q^T dS
+// qaux: [0,32) lse, [32,64) delta, [64,96) query pad flags of the tile
+template <int MODE, int HD>
+__device__ __forceinline__ void dkv_pair(const AttnArgs& a, const float* Qt, const float* Gt, const float* q_lse,
+                                         const float* q_delta, const float* q_flag, int lds_ld, int qt, int kk, bool k_is_pad,
+                                         long long t_k, int bh, int col, int half, const f32x4 (&kf)[HD / 8],
+                                         const f32x4 (&vf)[HD / 8], const HstuLds& hl, f32x16 (&dkacc)[HD / 32],
+                                         f32x16 (&dvacc)[HD / 32]) {
+  constexpr int HDV = HD / 8, NT = HD / 32;
+  const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+  f32x16 sacc, pacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+#pragma unroll
+  for (int s = 0; s < HDV; ++s) {
+    if (8 * s < a.hd) {
+      f32x4 qf = *reinterpret_cast<const f32x4*>(Qt + col * lds_ld + 8 * s + 4 * half);
+      f32x4 gf = *reinterpret_cast<const f32x4*>(Gt + col * lds_ld + 8 * s + 4 * half);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[t], kf[s][t], sacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(gf[t], vf[s][t], pacc, 0, 0, 0);
+      }
+    }
+  }
+  float pu[16], ds[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int qrow = row_of(r, half);
+    const int q = qt * TK + qrow;
+    float dsc = 1.f;
+    if (MODE == MODE_SOFTMAX && a.p_drop > 0.f) dsc = drop_keep(a.seed, (unsigned)bh, (unsigned)q, (unsigned)kk, a.p_drop, inv_keep);
+    bool dead; float bias = 0.f;
+    if (MODE == MODE_SOFTMAX) {
+      dead = (kk >= a.L) || (q >= a.L) || masked(a, q, kk, k_is_pad);
+    } else {
+      dead = (kk >= a.L) || (q >= a.L) || (kk > q) || k_is_pad || (q_flag[qrow] != 0.f);
+      if (!dead) {
+        if (a.time_w) bias += hl.tw[time_bucket(hl.thr, hl.ts[q + 1] - t_k)];
+        if (a.pos_w) bias += hl.pw[(a.L - 1) + kk - q];
+      }
+    }
+    tile_p_ds<MODE>(a, sacc[r], pacc[r], q_lse[qrow], q_delta[qrow], dead, bias, dsc, pu[r], ds[r]);
+  }
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int qrow = row_of(t, half);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int dd = nt * 32 + col;
+      const float gv = (dd < a.hd) ? Gt[qrow * lds_ld + dd] : 0.f;
+      const float qv = (dd < a.hd) ? Qt[qrow * lds_ld + dd] : 0.f;
+      dvacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, pu[t], dvacc[nt], 0, 0, 0);
+      dkacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qv, ds[t], dkacc[nt], 0, 0, 0);
+    }
+  }
+}
+
+template <int HD>
+__device__ __forceinline__ void store_rows_T(float* base, long long ld, int row, int n_rows, int hd, int half,
+                                             const f32x16 (&acc)[HD / 32]) {
+  if (row >= n_rows) return;
+  float* ob = base + (long long)row * ld;
+#pragma unroll
+  for (int nt = 0; nt < HD / 32; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dd = nt * 32 + row_of(r, half);
+      if (dd < hd) ob[dd] = acc[nt][r];
+    }
+}
+
+// carve the HSTU tables out of LDS behind `p` (floats); returns the first free float
+__device__ __forceinline__ float* hstu_carve(float* p, int L, bool with_grads, HstuLds& hl) {
+  float* tw = p; p += NBUCK + 3;
+  float* pw = p; p += (2 * L + 3) & ~3;
+  long long* thr = reinterpret_cast<long long*>(p); p += 2 * (NBUCK + 1);
+  long long* ts = reinterpret_cast<long long*>(p); p += 2 * (L + 2);
+  hl.tw = tw; hl.pw = pw; hl.thr = thr; hl.ts = ts; hl.dtw = nullptr; hl.dpw = nullptr;
+  if (with_grads) { hl.dtw = p; p += NBUCK + 3; hl.dpw = p; p += (2 * L + 3) & ~3; }
+  return p;
+}
+__device__ __forceinline__ void hstu_fill(const AttnArgs& a, const HstuLds& hl, int b, int tid, int nthreads) {
+  float* tw = const_cast<float*>(hl.tw); float* pw = const_cast<float*>(hl.pw);
+  long long* thr = const_cast<long long*>(hl.thr); long long* ts = const_cast<long long*>(hl.ts);
+  if (a.time_w) for (int i = tid; i < NBUCK; i += nthreads) { tw[i] = a.time_w[i]; thr[i] = a.time_thr[i]; }
+  if (a.pos_w) for (int i = tid; i < 2 * a.L - 1; i += nthreads) pw[i] = a.pos_w[i];
+  if (a.ts) for (int i = tid; i < a.L + 1; i += nthreads) ts[i] = a.ts[(long long)b * (a.L + 1) + i];
+  if (hl.dtw) {
+    for (int i = tid; i < NBUCK + 3; i += nthreads) hl.dtw[i] = 0.f;
+    for (int i = tid; i < ((2 * a.L + 3) & ~3); i += nthreads) hl.dpw[i] = 0.f;
+  }
+}
+__device__ __forceinline__ void hstu_flush_grads(const AttnArgs& a, const HstuLds& hl, int tid, int nthreads) {
+  if (a.d_time_w) for (int i = tid; i < NBUCK; i += nthreads) if (hl.dtw[i] != 0.f) atomicAdd(a.d_time_w + i, hl.dtw[i]);
+  if (a.d_pos_w) for (int i = tid; i < 2 * a.L - 1; i += nthreads) if (hl.dpw[i] != 0.f) atomicAdd(a.d_pos_w + i, hl.dpw[i]);
+}
+constexpr int hstu_lds_floats(int L, bool with_grads) {
+  return (NBUCK + 3) + ((2 * L + 3) & ~3) + 2 * (NBUCK + 1) + 2 * (L + 2) + (with_grads ? (NBUCK + 3) + ((2 * L + 3) & ~3) : 0);
 }
 
 // delta[b,h,q] = sum_dd dO[q][dd] * O[q][dd]
@@ -276,41 +417,73 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
   delta[idx] = s;
 }
 
-// probability / derivative helpers shared by the two backward kernels ---------------------------------
-// returns P (softmax: normalised, undropped; hstu: silu(.)/L * masks) and writes g = dS given dP (already dropped)
-template <int MODE>
-__device__ __forceinline__ void tile_p_ds(const AttnArgs& a, float s_raw, float dp, float lse_q, float delta_q, bool dead,
-                                          float bias, float drop_scale, float& p_used, float& ds) {
-  if (MODE == MODE_SOFTMAX) {
-    const float pn = dead ? 0.f : __expf(s_raw * a.scale - lse_q);
-    p_used = pn * drop_scale;                       // what multiplied V in the forward pass
-    ds = pn * (dp * drop_scale - delta_q) * a.scale; // d/d(raw q.k)
-  } else {
-    const float inv_l = 1.0f / (float)a.L;
-    const float z = s_raw + bias;
-    p_used = dead ? 0.f : silu_f(z) * inv_l;
-    ds = dead ? 0.f : dp * inv_l * silu_df(z);
+// ===================================================================================================
+// streaming family: grid = (ceil(L/128), B*H); wave w of a workgroup owns tile blockIdx.x*4 + w
+// ===================================================================================================
+template <int MODE, int HD>
+__global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs a) {
+  constexpr int HDV = HD / 8, NT = HD / 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lds_ld = a.hd + 4;
+  float* Ks = smem;                       // [32][hd+4]
+  float* Vs = Ks + TK * lds_ld;           // [32][hd+4]
+  float* aux = Vs + TK * lds_ld;          // [32] key pad flags (as float)
+  HstuLds hl{};
+  if (MODE == MODE_HSTU) hstu_carve(aux + TK, a.L, false, hl);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
+  const int q0 = (blockIdx.x * 4 + wave) * TK;
+  const int qq = q0 + col;
+  const long long rowbase = (long long)b * a.L;
+  const float* qb = a.q + rowbase * a.ldq + h * a.hd;
+  const float* kb = a.k + rowbase * a.ldk + h * a.hd;
+  const float* vb = a.v + rowbase * a.ldv + h * a.hd;
+  const long long* idb = a.ids + rowbase;
+  if (MODE == MODE_HSTU) hstu_fill(a, hl, b, tid, AT);
+
+  f32x4 qf[HDV];
+  load_row_frags<HDV>(qb, a.ldq, qq, a.L, a.hd, half, qf);
+  const bool q_is_pad = (qq < a.L) ? (idb[qq] == 0) : true;
+  long long t_q1 = 0;
+  f32x16 oacc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // key range of this workgroup: causal => keys <= last query of the workgroup
+  const int wg_q_last = min(a.L, (blockIdx.x * 4 + 4) * TK) - 1;
+  const int n_kt = a.causal ? (wg_q_last / TK + 1) : ((a.L + TK - 1) / TK);
+  const int my_last_kt = a.causal ? min(n_kt - 1, (q0 + TK - 1) / TK) : n_kt - 1;
+  __syncthreads();
+  if (MODE == MODE_HSTU && a.ts && qq < a.L) t_q1 = hl.ts[qq + 1];
+
+  for (int kt = 0; kt < n_kt; ++kt) {
+    __syncthreads();
+    stage_tile(kb, a.ldk, kt * TK, a.L, a.hd, lds_ld, Ks, tid);
+    stage_tile(vb, a.ldv, kt * TK, a.L, a.hd, lds_ld, Vs, tid);
+    if (tid < TK) { const int kk = kt * TK + tid; aux[tid] = (kk < a.L && idb[kk] != 0) ? 0.f : 1.f; }
+    __syncthreads();
+    if (q0 >= a.L || kt > my_last_kt) continue;  // nothing to do for this wave (barriers above are uniform)
+    fwd_pair<MODE, HD>(a, Ks, Vs, aux, lds_ld, kt, qq, q_is_pad, t_q1, bh, col, half, qf, hl, oacc, m_run, l_run);
   }
+  if (q0 >= a.L) return;
+  fwd_store<MODE, HD>(a, bh, qq, half, rowbase, h, oacc, m_run, l_run);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// backward, dQ:  same decomposition as the forward kernel.
-// ---------------------------------------------------------------------------------------------------
 template <int MODE, int HD>
 __global__ __launch_bounds__(AT) void attn_bwd_dq_kernel(AttnArgs a) {
-  constexpr int HDV = HD / 8;
-  constexpr int NT = HD / 32;
+  constexpr int HDV = HD / 8, NT = HD / 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lds_ld = a.hd + 4;
   float* Ks = smem;
   float* Vs = Ks + TK * lds_ld;
   float* aux = Vs + TK * lds_ld;
-  float* s_tw = aux + TK;
-  float* s_pw = s_tw + NBUCK + 3;
-  long long* s_thr = reinterpret_cast<long long*>(s_pw + ((2 * a.L + 3) & ~3));
-  long long* s_ts = s_thr + NBUCK + 1;
-  float* s_dtw = reinterpret_cast<float*>(s_ts + a.L + 1);   // [132] bias-gradient accumulators of this workgroup
-  float* s_dpw = s_dtw + NBUCK + 3;                          // [2L-1]
+  HstuLds hl{};
+  if (MODE == MODE_HSTU) hstu_carve(aux + TK, a.L, true, hl);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, half = lane >> 5;
@@ -323,13 +496,8 @@ __global__ __launch_bounds__(AT) void attn_bwd_dq_kernel(AttnArgs a) {
   const float* vb = a.v + rowbase * a.ldv + h * a.hd;
   const float* gb = a.dout + rowbase * a.lddo + h * a.hd;
   const long long* idb = a.ids + rowbase;
+  if (MODE == MODE_HSTU) hstu_fill(a, hl, b, tid, AT);
 
-  if (MODE == MODE_HSTU) {
-    if (a.time_w) for (int i = tid; i < NBUCK; i += AT) { s_tw[i] = a.time_w[i]; s_thr[i] = a.time_thr[i]; }
-    if (a.pos_w) for (int i = tid; i < 2 * a.L - 1; i += AT) s_pw[i] = a.pos_w[i];
-    if (a.ts) for (int i = tid; i < a.L + 1; i += AT) s_ts[i] = a.ts[(long long)b * (a.L + 1) + i];
-    for (int i = tid; i < NBUCK + 3 + 2 * a.L; i += AT) s_dtw[i] = 0.f;
-  }
   f32x4 qf[HDV], gf[HDV];
   load_row_frags<HDV>(qb, a.ldq, qq, a.L, a.hd, half, qf);
   load_row_frags<HDV>(gb, a.lddo, qq, a.L, a.hd, half, gf);
@@ -337,7 +505,6 @@ __global__ __launch_bounds__(AT) void attn_bwd_dq_kernel(AttnArgs a) {
   float lse_q = 0.f, delta_q = 0.f;
   if (MODE == MODE_SOFTMAX && qq < a.L) { lse_q = a.lse[(long long)bh * a.L + qq]; delta_q = a.delta[(long long)bh * a.L + qq]; }
   long long t_q1 = 0;
-
   f32x16 dqacc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -347,9 +514,8 @@ __global__ __launch_bounds__(AT) void attn_bwd_dq_kernel(AttnArgs a) {
   const int wg_q_last = min(a.L, (blockIdx.x * 4 + 4) * TK) - 1;
   const int n_kt = a.causal ? (wg_q_last / TK + 1) : ((a.L + TK - 1) / TK);
   const int my_last_kt = a.causal ? min(n_kt - 1, (q0 + TK - 1) / TK) : n_kt - 1;
-  const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   __syncthreads();
-  if (MODE == MODE_HSTU && a.ts && qq < a.L) t_q1 = s_ts[qq + 1];
+  if (MODE == MODE_HSTU && a.ts && qq < a.L) t_q1 = hl.ts[qq + 1];
 
   for (int kt = 0; kt < n_kt; ++kt) {
     __syncthreads();
@@ -358,100 +524,26 @@ __global__ __launch_bounds__(AT) void attn_bwd_dq_kernel(AttnArgs a) {
     if (tid < TK) { const int kk = kt * TK + tid; aux[tid] = (kk < a.L && idb[kk] != 0) ? 0.f : 1.f; }
     __syncthreads();
     if (q0 >= a.L || kt > my_last_kt) continue;
-
-    f32x16 sacc, pacc;   // S^T and dP^T tiles (rows = keys, cols = queries)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
-#pragma unroll
-    for (int s = 0; s < HDV; ++s) {
-      if (8 * s < a.hd) {
-        f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + col * lds_ld + 8 * s + 4 * half);
-        f32x4 vf = *reinterpret_cast<const f32x4*>(Vs + col * lds_ld + 8 * s + 4 * half);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t], qf[s][t], sacc, 0, 0, 0);
-          pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[t], gf[s][t], pacc, 0, 0, 0);
-        }
-      }
-    }
-    float ds[16];
-    float dtw_bucket_dummy = 0.f; (void)dtw_bucket_dummy;
-#pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-      float dsc[4] = {1.f, 1.f, 1.f, 1.f};
-      if (MODE == MODE_SOFTMAX && a.p_drop > 0.f) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          dsc[j] = drop_keep(a.seed, (unsigned)bh, (unsigned)qq, (unsigned)(kt * TK + row_of(4 * r4 + j, half)), a.p_drop, inv_keep);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = 4 * r4 + j;
-        const int kk = kt * TK + row_of(r, half);
-        const bool kpad = aux[row_of(r, half)] != 0.f;
-        bool dead; float bias = 0.f;
-        if (MODE == MODE_SOFTMAX) {
-          dead = (kk >= a.L) || (qq >= a.L) || masked(a, qq, kk, kpad);
-        } else {
-          dead = (kk >= a.L) || (qq >= a.L) || (kk > qq) || q_is_pad || kpad;
-          if (!dead) {
-            if (a.time_w) bias += s_tw[time_bucket(s_thr, t_q1 - s_ts[kk])];
-            if (a.pos_w) bias += s_pw[(a.L - 1) + kk - qq];
-          }
-        }
-        float pu;
-        tile_p_ds<MODE>(a, sacc[r], pacc[r], lse_q, delta_q, dead, bias, dsc[j], pu, ds[r]);
-        if (MODE == MODE_HSTU && !dead && half >= 0) {
-          // relative-bias gradients: rab is shared by the heads, so every head adds its dS (hstu.py:276)
-          if (a.d_time_w) atomicAdd(s_dtw + time_bucket(s_thr, t_q1 - s_ts[kk]), ds[r]);
-          if (a.d_pos_w) atomicAdd(s_dpw + (a.L - 1) + kk - qq, ds[r]);
-        }
-      }
-    }
-    // dQ^T += K^T dS^T : rows = dd (A operand: K from LDS), cols = queries (B operand = dS registers)
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int krow = row_of(t, half);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int dd = nt * 32 + col;
-        const float kv = (dd < a.hd) ? Ks[krow * lds_ld + dd] : 0.f;
-        dqacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, ds[t], dqacc[nt], 0, 0, 0);
-      }
-    }
+    dq_pair<MODE, HD>(a, Ks, Vs, aux, lds_ld, kt, qq, q_is_pad, t_q1, bh, col, half, qf, gf, lse_q, delta_q, hl, dqacc);
   }
   if (MODE == MODE_HSTU) {
     __syncthreads();
-    if (a.d_time_w) for (int i = tid; i < NBUCK; i += AT) if (s_dtw[i] != 0.f) atomicAdd(a.d_time_w + i, s_dtw[i]);
-    if (a.d_pos_w) for (int i = tid; i < 2 * a.L - 1; i += AT) if (s_dpw[i] != 0.f) atomicAdd(a.d_pos_w + i, s_dpw[i]);
+    hstu_flush_grads(a, hl, tid, AT);
   }
-  if (q0 >= a.L || qq >= a.L) return;
-  float* ob = a.dq + (rowbase + qq) * a.lddq + h * a.hd;
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int dd = nt * 32 + row_of(r, half);
-      if (dd < a.hd) ob[dd] = dqacc[nt][r];
-    }
+  if (q0 >= a.L) return;
+  store_rows_T<HD>(a.dq + rowbase * a.lddq + h * a.hd, a.lddq, qq, a.L, a.hd, half, dqacc);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// backward, dK / dV:  wave owns 32 keys, loops over query tiles (rows = queries, cols = keys).
-// ---------------------------------------------------------------------------------------------------
 template <int MODE, int HD>
 __global__ __launch_bounds__(AT) void attn_bwd_dkv_kernel(AttnArgs a) {
-  constexpr int HDV = HD / 8;
-  constexpr int NT = HD / 32;
+  constexpr int HDV = HD / 8, NT = HD / 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lds_ld = a.hd + 4;
   float* Qs = smem;                        // [32][hd+4]  queries of the current tile
   float* Gs = Qs + TK * lds_ld;            // [32][hd+4]  dO of the current tile
   float* aux = Gs + TK * lds_ld;           // [32] lse | [32] delta | [32] q pad flag
-  float* s_tw = aux + 3 * TK;
-  float* s_pw = s_tw + NBUCK + 3;
-  long long* s_thr = reinterpret_cast<long long*>(s_pw + ((2 * a.L + 3) & ~3));
-  long long* s_ts = s_thr + NBUCK + 1;
+  HstuLds hl{};
+  if (MODE == MODE_HSTU) hstu_carve(aux + 3 * TK, a.L, false, hl);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, half = lane >> 5;
@@ -464,17 +556,12 @@ __global__ __launch_bounds__(AT) void attn_bwd_dkv_kernel(AttnArgs a) {
   const float* vb = a.v + rowbase * a.ldv + h * a.hd;
   const float* gb = a.dout + rowbase * a.lddo + h * a.hd;
   const long long* idb = a.ids + rowbase;
+  if (MODE == MODE_HSTU) hstu_fill(a, hl, b, tid, AT);
 
-  if (MODE == MODE_HSTU) {
-    if (a.time_w) for (int i = tid; i < NBUCK; i += AT) { s_tw[i] = a.time_w[i]; s_thr[i] = a.time_thr[i]; }
-    if (a.pos_w) for (int i = tid; i < 2 * a.L - 1; i += AT) s_pw[i] = a.pos_w[i];
-    if (a.ts) for (int i = tid; i < a.L + 1; i += AT) s_ts[i] = a.ts[(long long)b * (a.L + 1) + i];
-  }
   f32x4 kf[HDV], vf[HDV];
   load_row_frags<HDV>(kb, a.ldk, kk, a.L, a.hd, half, kf);
   load_row_frags<HDV>(vb, a.ldv, kk, a.L, a.hd, half, vf);
   const bool k_is_pad = (kk < a.L) ? (idb[kk] == 0) : true;
-
   f32x16 dkacc[NT], dvacc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -482,12 +569,11 @@ __global__ __launch_bounds__(AT) void attn_bwd_dkv_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) { dkacc[t][r] = 0.f; dvacc[t][r] = 0.f; }
 
   const int n_qt = (a.L + TK - 1) / TK;
-  const int first_qt = a.causal ? (blockIdx.x * 4 * TK) / TK : 0;   // queries >= first key of the workgroup
+  const int first_qt = a.causal ? blockIdx.x * 4 : 0;   // queries >= first key of the workgroup
   const int my_first_qt = a.causal ? k0 / TK : 0;
-  const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   __syncthreads();
   long long t_k = 0;
-  if (MODE == MODE_HSTU && a.ts && kk < a.L) t_k = s_ts[kk];
+  if (MODE == MODE_HSTU && a.ts && kk < a.L) t_k = hl.ts[kk];
 
   for (int qt = first_qt; qt < n_qt; ++qt) {
     __syncthreads();
@@ -501,85 +587,254 @@ __global__ __launch_bounds__(AT) void attn_bwd_dkv_kernel(AttnArgs a) {
     }
     __syncthreads();
     if (k0 >= a.L || qt < my_first_qt) continue;
-
-    f32x16 sacc, pacc;   // S and dP tiles: rows = queries (A operand from LDS), cols = keys (B = K / V fragments)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
-#pragma unroll
-    for (int s = 0; s < HDV; ++s) {
-      if (8 * s < a.hd) {
-        f32x4 qf = *reinterpret_cast<const f32x4*>(Qs + col * lds_ld + 8 * s + 4 * half);
-        f32x4 gf = *reinterpret_cast<const f32x4*>(Gs + col * lds_ld + 8 * s + 4 * half);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[t], kf[s][t], sacc, 0, 0, 0);
-          pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(gf[t], vf[s][t], pacc, 0, 0, 0);
-        }
-      }
-    }
-    float pu[16], ds[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int qrow = row_of(r, half);
-      const int q = qt * TK + qrow;
-      float dsc = 1.f;
-      if (MODE == MODE_SOFTMAX && a.p_drop > 0.f) dsc = drop_keep(a.seed, (unsigned)bh, (unsigned)q, (unsigned)kk, a.p_drop, inv_keep);
-      bool dead; float bias = 0.f;
-      if (MODE == MODE_SOFTMAX) {
-        dead = (kk >= a.L) || (q >= a.L) || masked(a, q, kk, k_is_pad);
-      } else {
-        dead = (kk >= a.L) || (q >= a.L) || (kk > q) || k_is_pad || (aux[2 * TK + qrow] != 0.f);
-        if (!dead) {
-          if (a.time_w) bias += s_tw[time_bucket(s_thr, s_ts[q + 1] - t_k)];
-          if (a.pos_w) bias += s_pw[(a.L - 1) + kk - q];
-        }
-      }
-      tile_p_ds<MODE>(a, sacc[r], pacc[r], aux[qrow], aux[TK + qrow], dead, bias, dsc, pu[r], ds[r]);
-    }
-    // dV^T += dO^T P ; dK^T += Q^T dS : rows = dd (A operand from LDS), cols = keys (B = registers)
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int qrow = row_of(t, half);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int dd = nt * 32 + col;
-        const float gv = (dd < a.hd) ? Gs[qrow * lds_ld + dd] : 0.f;
-        const float qv = (dd < a.hd) ? Qs[qrow * lds_ld + dd] : 0.f;
-        dvacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, pu[t], dvacc[nt], 0, 0, 0);
-        dkacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qv, ds[t], dkacc[nt], 0, 0, 0);
-      }
-    }
+    dkv_pair<MODE, HD>(a, Qs, Gs, aux, aux + TK, aux + 2 * TK, lds_ld, qt, kk, k_is_pad, t_k, bh, col, half, kf, vf, hl, dkacc, dvacc);
   }
-  if (k0 >= a.L || kk >= a.L) return;
-  float* dkb = a.dk + (rowbase + kk) * a.lddk + h * a.hd;
-  float* dvb = a.dv + (rowbase + kk) * a.lddv + h * a.hd;
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int dd = nt * 32 + row_of(r, half);
-      if (dd < a.hd) { dkb[dd] = dkacc[nt][r]; dvb[dd] = dvacc[nt][r]; }
-    }
+  if (k0 >= a.L) return;
+  store_rows_T<HD>(a.dk + rowbase * a.lddk + h * a.hd, a.lddk, kk, a.L, a.hd, half, dkacc);
+  store_rows_T<HD>(a.dv + rowbase * a.lddv + h * a.hd, a.lddv, kk, a.L, a.hd, half, dvacc);
 }
 
-inline size_t attn_lds_bytes(int hd, int L, int aux_floats, bool hstu) {
-  size_t f = (size_t)2 * TK * (hd + 4) + aux_floats;
-  if (hstu) {
-    f += NBUCK + 3 + ((2 * L + 3) & ~3);
-    return f * 4 + 8 + (size_t)(NBUCK + 1 + L + 1) * 8;
+// ===================================================================================================
+// resident family: grid = B*H, NW waves; the whole K,V (fwd, dQ) or Q,dO (dK/dV) of one (batch, head) sits in LDS.
+// ===================================================================================================
+// Tile schedule of wave `wave`: step `it` -> tile index or -1 (then every later step is -1 too).  `cost_up`: tile t
+// costs t+1 pairs (causal query tiles) — the first NW/2 waves walk the expensive end, the others the cheap end, so
+// that the two waves sharing a SIMD (w, w + NW/2... w mod 4) carry ~equal work; !cost_up mirrors it (causal key tiles).
+template <int NW>
+__device__ __forceinline__ int tile_for(int it, int wave, int n_t, bool causal, bool cost_up) {
+  if (!causal) { const int t = wave + it * NW; return t < n_t ? t : -1; }
+  constexpr int P = 4;   // SIMDs per CU: waves w and w + 4 of a workgroup share one
+  const int p = wave % P;
+  bool take_hi; int r;
+  if (NW == 8) { take_hi = wave < P; r = it; }          // two waves per SIMD: one walks the heavy end, one the light end
+  else { take_hi = (it & 1) == 0; r = it >> 1; }        // one wave per SIMD: it alternates heavy / light itself
+  const int hi = n_t - 1 - (P * r + p), lo = P * r + p;
+  int t;
+  if (take_hi) t = (hi >= lo) ? hi : -1;
+  else t = (lo < hi) ? lo : -1;
+  if (t < 0) return -1;
+  return cost_up ? t : n_t - 1 - t;
+}
+
+// rows [0, Lp) of a [L, hd] matrix -> LDS [Lp][lds_ld], zero rows past L
+__device__ __forceinline__ void stage_rows(const float* base, long long ld, int L, int Lp, int hd, int lds_ld, float* dst,
+                                           int tid, int nthreads) {
+  const int per_row = hd >> 2;
+  const int total = Lp * per_row;
+  for (int i0 = tid; i0 < total; i0 += 4 * nthreads) {   // 4 loads in flight per thread
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * nthreads;
+      const int r = i / per_row, c = (i - r * per_row) * 4;
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      v[u] = (i < total && r < L) ? *reinterpret_cast<const f32x4*>(base + (long long)r * ld + c) : z;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * nthreads;
+      const int r = i / per_row, c = (i - r * per_row) * 4;
+      if (i < total) *reinterpret_cast<f32x4*>(dst + r * lds_ld + c) = v[u];
+    }
   }
-  return f * 4 + 64;
+}
+
+template <int MODE, int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(AttnArgs a) {
+  constexpr int HDV = HD / 8, NT = HD / 32, NTH = NW * 64;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n_t = (a.L + TK - 1) / TK, Lp = n_t * TK;
+  const int lds_ld = a.hd + 4;
+  float* Ks = smem;                       // [Lp][hd+4]
+  float* Vs = Ks + Lp * lds_ld;           // [Lp][hd+4]
+  float* kflag = Vs + Lp * lds_ld;        // [Lp] key pad flags
+  HstuLds hl{};
+  if (MODE == MODE_HSTU) hstu_carve(kflag + Lp, a.L, false, hl);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
+  const long long rowbase = (long long)b * a.L;
+  const float* qb = a.q + rowbase * a.ldq + h * a.hd;
+  const long long* idb = a.ids + rowbase;
+  stage_rows(a.k + rowbase * a.ldk + h * a.hd, a.ldk, a.L, Lp, a.hd, lds_ld, Ks, tid, NTH);
+  stage_rows(a.v + rowbase * a.ldv + h * a.hd, a.ldv, a.L, Lp, a.hd, lds_ld, Vs, tid, NTH);
+  for (int i = tid; i < Lp; i += NTH) kflag[i] = (i < a.L && idb[i] != 0) ? 0.f : 1.f;
+  if (MODE == MODE_HSTU) hstu_fill(a, hl, b, tid, NTH);
+  __syncthreads();
+
+#pragma unroll 1
+  for (int it = 0;; ++it) {
+    const int qt = tile_for<NW>(it, wave, n_t, a.causal != 0, true);
+    if (qt < 0) break;
+    const int qq = qt * TK + col;
+    f32x4 qf[HDV];
+    load_row_frags<HDV>(qb, a.ldq, qq, a.L, a.hd, half, qf);
+    const bool q_is_pad = (qq < a.L) ? (idb[qq] == 0) : true;
+    long long t_q1 = 0;
+    if (MODE == MODE_HSTU && a.ts && qq < a.L) t_q1 = hl.ts[qq + 1];
+    f32x16 oacc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int last_kt = a.causal ? qt : n_t - 1;
+#pragma unroll 1
+    for (int kt = 0; kt <= last_kt; ++kt)
+      fwd_pair<MODE, HD>(a, Ks + kt * TK * lds_ld, Vs + kt * TK * lds_ld, kflag + kt * TK, lds_ld, kt, qq, q_is_pad, t_q1, bh,
+                         col, half, qf, hl, oacc, m_run, l_run);
+    fwd_store<MODE, HD>(a, bh, qq, half, rowbase, h, oacc, m_run, l_run);
+  }
+}
+
+template <int MODE, int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(AttnArgs a) {
+  constexpr int HDV = HD / 8, NT = HD / 32, NTH = NW * 64;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n_t = (a.L + TK - 1) / TK, Lp = n_t * TK;
+  const int lds_ld = a.hd + 4;
+  float* Ks = smem;
+  float* Vs = Ks + Lp * lds_ld;
+  float* kflag = Vs + Lp * lds_ld;
+  HstuLds hl{};
+  if (MODE == MODE_HSTU) hstu_carve(kflag + Lp, a.L, true, hl);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
+  const long long rowbase = (long long)b * a.L;
+  const float* qb = a.q + rowbase * a.ldq + h * a.hd;
+  const float* gb = a.dout + rowbase * a.lddo + h * a.hd;
+  const long long* idb = a.ids + rowbase;
+  stage_rows(a.k + rowbase * a.ldk + h * a.hd, a.ldk, a.L, Lp, a.hd, lds_ld, Ks, tid, NTH);
+  stage_rows(a.v + rowbase * a.ldv + h * a.hd, a.ldv, a.L, Lp, a.hd, lds_ld, Vs, tid, NTH);
+  for (int i = tid; i < Lp; i += NTH) kflag[i] = (i < a.L && idb[i] != 0) ? 0.f : 1.f;
+  if (MODE == MODE_HSTU) hstu_fill(a, hl, b, tid, NTH);
+  __syncthreads();
+
+#pragma unroll 1
+  for (int it = 0;; ++it) {
+    const int qt = tile_for<NW>(it, wave, n_t, a.causal != 0, true);
+    if (qt < 0) break;
+    const int qq = qt * TK + col;
+    f32x4 qf[HDV], gf[HDV];
+    load_row_frags<HDV>(qb, a.ldq, qq, a.L, a.hd, half, qf);
+    load_row_frags<HDV>(gb, a.lddo, qq, a.L, a.hd, half, gf);
+    const bool q_is_pad = (qq < a.L) ? (idb[qq] == 0) : true;
+    float lse_q = 0.f, delta_q = 0.f;
+    if (MODE == MODE_SOFTMAX && qq < a.L) { lse_q = a.lse[(long long)bh * a.L + qq]; delta_q = a.delta[(long long)bh * a.L + qq]; }
+    long long t_q1 = 0;
+    if (MODE == MODE_HSTU && a.ts && qq < a.L) t_q1 = hl.ts[qq + 1];
+    f32x16 dqacc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dqacc[t][r] = 0.f;
+    const int last_kt = a.causal ? qt : n_t - 1;
+#pragma unroll 1
+    for (int kt = 0; kt <= last_kt; ++kt)
+      dq_pair<MODE, HD>(a, Ks + kt * TK * lds_ld, Vs + kt * TK * lds_ld, kflag + kt * TK, lds_ld, kt, qq, q_is_pad, t_q1, bh,
+                        col, half, qf, gf, lse_q, delta_q, hl, dqacc);
+    store_rows_T<HD>(a.dq + rowbase * a.lddq + h * a.hd, a.lddq, qq, a.L, a.hd, half, dqacc);
+  }
+  if (MODE == MODE_HSTU) {
+    __syncthreads();
+    hstu_flush_grads(a, hl, tid, NTH);
+  }
+}
+
+template <int MODE, int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_res_kernel(AttnArgs a) {
+  constexpr int HDV = HD / 8, NT = HD / 32, NTH = NW * 64;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n_t = (a.L + TK - 1) / TK, Lp = n_t * TK;
+  const int lds_ld = a.hd + 4;
+  float* Qs = smem;                        // [Lp][hd+4]
+  float* Gs = Qs + Lp * lds_ld;            // [Lp][hd+4] dO
+  float* s_lse = Gs + Lp * lds_ld;         // [Lp]
+  float* s_delta = s_lse + Lp;             // [Lp]
+  float* qflag = s_delta + Lp;             // [Lp] query pad flags
+  HstuLds hl{};
+  if (MODE == MODE_HSTU) hstu_carve(qflag + Lp, a.L, false, hl);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
+  const long long rowbase = (long long)b * a.L;
+  const float* kb = a.k + rowbase * a.ldk + h * a.hd;
+  const float* vb = a.v + rowbase * a.ldv + h * a.hd;
+  const long long* idb = a.ids + rowbase;
+  stage_rows(a.q + rowbase * a.ldq + h * a.hd, a.ldq, a.L, Lp, a.hd, lds_ld, Qs, tid, NTH);
+  stage_rows(a.dout + rowbase * a.lddo + h * a.hd, a.lddo, a.L, Lp, a.hd, lds_ld, Gs, tid, NTH);
+  for (int i = tid; i < Lp; i += NTH) {
+    s_lse[i] = (MODE == MODE_SOFTMAX && i < a.L) ? a.lse[(long long)bh * a.L + i] : 0.f;
+    s_delta[i] = (MODE == MODE_SOFTMAX && i < a.L) ? a.delta[(long long)bh * a.L + i] : 0.f;
+    qflag[i] = (i < a.L && idb[i] != 0) ? 0.f : 1.f;
+  }
+  if (MODE == MODE_HSTU) hstu_fill(a, hl, b, tid, NTH);
+  __syncthreads();
+
+#pragma unroll 1
+  for (int it = 0;; ++it) {
+    const int ktile = tile_for<NW>(it, wave, n_t, a.causal != 0, false);
+    if (ktile < 0) break;
+    const int kk = ktile * TK + col;
+    f32x4 kf[HDV], vf[HDV];
+    load_row_frags<HDV>(kb, a.ldk, kk, a.L, a.hd, half, kf);
+    load_row_frags<HDV>(vb, a.ldv, kk, a.L, a.hd, half, vf);
+    const bool k_is_pad = (kk < a.L) ? (idb[kk] == 0) : true;
+    long long t_k = 0;
+    if (MODE == MODE_HSTU && a.ts && kk < a.L) t_k = hl.ts[kk];
+    f32x16 dkacc[NT], dvacc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dkacc[t][r] = 0.f; dvacc[t][r] = 0.f; }
+    const int first_qt = a.causal ? ktile : 0;
+#pragma unroll 1
+    for (int qt = first_qt; qt < n_t; ++qt)
+      dkv_pair<MODE, HD>(a, Qs + qt * TK * lds_ld, Gs + qt * TK * lds_ld, s_lse + qt * TK, s_delta + qt * TK, qflag + qt * TK,
+                         lds_ld, qt, kk, k_is_pad, t_k, bh, col, half, kf, vf, hl, dkacc, dvacc);
+    store_rows_T<HD>(a.dk + rowbase * a.lddk + h * a.hd, a.lddk, kk, a.L, a.hd, half, dkacc);
+    store_rows_T<HD>(a.dv + rowbase * a.lddv + h * a.hd, a.lddv, kk, a.L, a.hd, half, dvacc);
+  }
+}
+
+// ---- launch -----------------------------------------------------------------------------------------
+constexpr size_t LDS_LIMIT = 160 * 1024;
+
+inline size_t stream_lds_bytes(int hd, int L, int aux_floats, bool hstu, bool grads) {
+  return ((size_t)2 * TK * (hd + 4) + aux_floats + (hstu ? hstu_lds_floats(L, grads) : 0)) * 4 + 64;
+}
+inline size_t res_lds_bytes(int hd, int L, int aux_rows, bool hstu, bool grads) {
+  const size_t Lp = (size_t)((L + TK - 1) / TK) * TK;
+  return ((size_t)2 * Lp * (hd + 4) + aux_rows * Lp + (hstu ? hstu_lds_floats(L, grads) : 0)) * 4 + 64;
+}
+// RT_ATTN_IMPL=stream forces the streaming family (tests / A-B measurements)
+inline bool attn_allow_resident() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("RT_ATTN_IMPL"); v = (e && e[0] == 's') ? 0 : 1; }
+  return v == 1;
+}
+template <typename K>
+inline int set_lds(K kernel, size_t lds) {
+  if (lds > 64 * 1024) RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  return RT_OK;
 }
 
 template <int MODE, int HD>
 int launch_fwd(const AttnArgs& a, hipStream_t stream) {
-  const size_t lds = attn_lds_bytes(a.hd, a.L, TK, MODE == MODE_HSTU) + 64;
-  static size_t attr = 0;
-  if (lds > 64 * 1024 && lds > attr) {
-    RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<MODE, HD>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr = lds;
+  constexpr int NW = HD <= 64 ? 8 : 4;
+  const size_t rl = res_lds_bytes(a.hd, a.L, 1, MODE == MODE_HSTU, false);
+  if (rl <= LDS_LIMIT && attn_allow_resident()) {
+    { const int rc = set_lds(&attn_fwd_res_kernel<MODE, HD, NW>, rl); if (rc != RT_OK) return rc; }
+    attn_fwd_res_kernel<MODE, HD, NW><<<a.B * a.H, NW * 64, rl, stream>>>(a);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
   }
+  const size_t lds = stream_lds_bytes(a.hd, a.L, TK, MODE == MODE_HSTU, false);
+  { const int rc = set_lds(&attn_fwd_kernel<MODE, HD>, lds); if (rc != RT_OK) return rc; }
   dim3 grid((a.L + 4 * TK - 1) / (4 * TK), a.B * a.H);
   attn_fwd_kernel<MODE, HD><<<grid, AT, lds, stream>>>(a);
   RT_CHECK_LAUNCH();
@@ -587,21 +842,30 @@ int launch_fwd(const AttnArgs& a, hipStream_t stream) {
 }
 template <int MODE, int HD>
 int launch_bwd(const AttnArgs& a, hipStream_t stream) {
+  constexpr int NW = HD <= 64 ? 8 : 4;
+  const size_t r1 = res_lds_bytes(a.hd, a.L, 1, MODE == MODE_HSTU, true);
+  const size_t r2 = res_lds_bytes(a.hd, a.L, 3, MODE == MODE_HSTU, false);
+  if (r1 <= LDS_LIMIT && r2 <= LDS_LIMIT && attn_allow_resident()) {
+    { const int rc = set_lds(&attn_bwd_dq_res_kernel<MODE, HD, NW>, r1); if (rc != RT_OK) return rc; }
+    { const int rc = set_lds(&attn_bwd_dkv_res_kernel<MODE, HD, NW>, r2); if (rc != RT_OK) return rc; }
+    attn_bwd_dq_res_kernel<MODE, HD, NW><<<a.B * a.H, NW * 64, r1, stream>>>(a);
+    RT_CHECK_LAUNCH();
+    static int dkv_nw = -1;
+    if (dkv_nw < 0) { const char* e = getenv("RT_ATTN_DKV_NW"); dkv_nw = (e && atoi(e) == 4) ? 4 : NW; }
+    if (dkv_nw == 4 && NW == 8) {
+      { const int rc = set_lds(&attn_bwd_dkv_res_kernel<MODE, HD, 4>, r2); if (rc != RT_OK) return rc; }
+      attn_bwd_dkv_res_kernel<MODE, HD, 4><<<a.B * a.H, 256, r2, stream>>>(a);
+    } else {
+      attn_bwd_dkv_res_kernel<MODE, HD, NW><<<a.B * a.H, NW * 64, r2, stream>>>(a);
+    }
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+  }
   dim3 grid((a.L + 4 * TK - 1) / (4 * TK), a.B * a.H);
-  const size_t lds1 = attn_lds_bytes(a.hd, a.L, TK, MODE == MODE_HSTU) + 64 +
-                      (MODE == MODE_HSTU ? (size_t)(NBUCK + 3 + ((2 * a.L + 3) & ~3)) * 4 : 0);
-  const size_t lds2 = attn_lds_bytes(a.hd, a.L, 3 * TK, MODE == MODE_HSTU) + 64;
-  static size_t attr1 = 0, attr2 = 0;
-  if (lds1 > 64 * 1024 && lds1 > attr1) {
-    RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<MODE, HD>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-    attr1 = lds1;
-  }
-  if (lds2 > 64 * 1024 && lds2 > attr2) {
-    RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<MODE, HD>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-    attr2 = lds2;
-  }
+  const size_t lds1 = stream_lds_bytes(a.hd, a.L, TK, MODE == MODE_HSTU, true);
+  const size_t lds2 = stream_lds_bytes(a.hd, a.L, 3 * TK, MODE == MODE_HSTU, false);
+  { const int rc = set_lds(&attn_bwd_dq_kernel<MODE, HD>, lds1); if (rc != RT_OK) return rc; }
+  { const int rc = set_lds(&attn_bwd_dkv_kernel<MODE, HD>, lds2); if (rc != RT_OK) return rc; }
   attn_bwd_dq_kernel<MODE, HD><<<grid, AT, lds1, stream>>>(a);
   RT_CHECK_LAUNCH();
   attn_bwd_dkv_kernel<MODE, HD><<<grid, AT, lds2, stream>>>(a);

@@ -134,8 +134,12 @@ def test_activations_swiglu_gate(kind, fn):
         close(ggot[i], gref[i], rtol=1e-3, msg=f"gate grad {i}")
 
 
+# L_pad * head_dim decides the kernel family: LDS-resident K,V (first 8 cases; 288/300 need two schedule rounds) or the
+# streaming kernels (last 3 cases); RT_ATTN_IMPL=stream forces streaming for every case (second pytest pass on the GPU box)
 @pytest.mark.parametrize("L,d,H,causal,keypad", [(8, 16, 2, True, False), (40, 64, 2, True, True), (70, 128, 4, False, True),
-                                                   (200, 256, 4, True, False), (33, 64, 1, True, False)])
+                                                   (200, 256, 4, True, False), (33, 64, 1, True, False), (288, 64, 1, True, True),
+                                                   (300, 64, 2, False, True), (100, 128, 1, True, False),
+                                                   (320, 128, 2, True, False), (600, 64, 2, False, True), (200, 256, 2, True, True)])
 def test_mha(L, d, H, causal, keypad):
     from rectools_amd import ops
 
@@ -161,7 +165,8 @@ def test_mha(L, d, H, causal, keypad):
         close(ggot[i], gref[i], rtol=2e-3, atol_rel=2e-4, msg=f"mha d{n}")
 
 
-@pytest.mark.parametrize("L,d,H,rt,rp", [(8, 16, 2, True, True), (50, 64, 2, True, False), (96, 128, 4, False, True), (130, 64, 2, True, True)])
+@pytest.mark.parametrize("L,d,H,rt,rp", [(8, 16, 2, True, True), (50, 64, 2, True, False), (96, 128, 4, False, True), (130, 64, 2, True, True),
+                                         (200, 128, 2, True, True), (330, 128, 2, True, True)])
 def test_hstu_attention(L, d, H, rt, rp):
     from rectools_amd import ops
 
