@@ -42,6 +42,7 @@ struct AttnArgs {
   const long long* ids;                    // [B,L] item ids (0 = PAD)
   int B, H, L, hd;
   int causal, keypad;
+  int no_interior;                         // debug knob (RT_ATTN_EDGE=0): always take the masked tile path
   float scale;                             // 1/sqrt(hd) (softmax) ; unused for hstu
   float p_drop; unsigned long long seed;
   // hstu relative bias
@@ -54,15 +55,11 @@ struct AttnArgs {
 
 __device__ __forceinline__ int row_of(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-// Is (query qq, key kk) masked out?  Mirrors torch_backbone.py:249-257 and _merge_masks (:172-218).
+// Is (query qq, key kk) masked out?  Mirrors torch_backbone.py:249-257 and _merge_masks (:172-218): causal `kk > qq`,
+// key padding, and — when both are on — the diagonal forced open.  Branch-free (the flags are wave-uniform 0/1).
 __device__ __forceinline__ bool masked(const AttnArgs& a, int qq, int kk, bool key_is_pad) {
-  bool m = false;
-  if (a.causal) m = kk > qq;
-  if (a.keypad) {
-    m = m || key_is_pad;
-    if (a.causal && kk == qq) m = false;  // merged mask: diagonal forced to 0
-  }
-  return m;
+  const bool c = a.causal != 0, kp = a.keypad != 0;
+  return (c & (kk > qq)) | (kp & key_is_pad & !(c & (kk == qq)));
 }
 
 // Attention dropout mask: one 32-bit mix per (head, query, key) element (murmur3 finaliser over a seeded counter).
@@ -101,18 +98,18 @@ __device__ __forceinline__ void load_row_frags(const float* base, long long ld, 
   }
 }
 
-// stage a [32 rows][hd] tile (rows row0..row0+31 of `base`) into LDS with row stride lds_ld (= hd + 4)
-__device__ __forceinline__ void stage_tile(const float* base, long long ld, int row0, int n_rows, int hd, int lds_ld,
-                                           float* dst, int tid) {
-  const int per_row = hd >> 2;
-  for (int i = tid; i < TK * per_row; i += AT) {
-    const int r = i / per_row, c = (i % per_row) * 4;
+// stage a [32 rows][HD] tile (rows row0..row0+31 of `base`, columns >= hd zero-filled) into LDS with row stride HD + 4:
+// every later LDS read of the tile is unconditional, whatever the real head dim
+template <int HD>
+__device__ __forceinline__ void stage_tile(const float* base, long long ld, int row0, int n_rows, int hd, float* dst, int tid) {
+  constexpr int PER_ROW = HD / 4, LD = HD + 4;
+  for (int i = tid; i < TK * PER_ROW; i += AT) {
+    const int r = i / PER_ROW, c = (i % PER_ROW) * 4;
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    f32x4 v = (row0 + r < n_rows) ? *reinterpret_cast<const f32x4*>(base + (long long)(row0 + r) * ld + c) : z;
-    *reinterpret_cast<f32x4*>(dst + r * lds_ld + c) = v;
+    f32x4 v = (row0 + r < n_rows && c < hd) ? *reinterpret_cast<const f32x4*>(base + (long long)(row0 + r) * ld + c) : z;
+    *reinterpret_cast<f32x4*>(dst + r * LD + c) = v;
   }
 }
-
 
 // LDS views of the HSTU relative-bias tables (null pointers in softmax mode)
 struct HstuLds {
@@ -124,19 +121,21 @@ struct HstuLds {
 // per-(query tile, key tile) math.  Kt / Vt / Qt / Gt point at a [32][lds_ld] LDS tile, *flag at its 32 pad flags.
 // ---------------------------------------------------------------------------------------------------
 // forward: S^T = K Q^T (rows = keys, cols = queries), online softmax / silu, O^T += V^T P^T
-template <int MODE, int HD>
-__device__ __forceinline__ void fwd_pair(const AttnArgs& a, const float* Kt, const float* Vt, const float* kflag, int lds_ld,
+// EDGE = false: the tile pair lies fully inside [0,L) x [0,L) and nothing in it is masked (softmax mode without the
+// key-padding mask, strictly below the causal diagonal) — all mask logic compiles away.
+template <int MODE, int HD, bool EDGE = true>
+__device__ __forceinline__ void fwd_pair(const AttnArgs& a, const float* Kt, const float* Vt, const float* kflag,
                                          int kt, int qq, bool q_is_pad, long long t_q1, int bh, int col, int half,
                                          const f32x4 (&qf)[HD / 8], const HstuLds& hl, f32x16 (&oacc)[HD / 32],
                                          float& m_run, float& l_run) {
-  constexpr int HDV = HD / 8, NT = HD / 32;
+  constexpr int HDV = HD / 8, NT = HD / 32, lds_ld = HD + 4;
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   f32x16 sacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
 #pragma unroll
   for (int s = 0; s < HDV; ++s) {
-    if (8 * s < a.hd) {
+    {
       f32x4 kf = *reinterpret_cast<const f32x4*>(Kt + col * lds_ld + 8 * s + 4 * half);
 #pragma unroll
       for (int t = 0; t < 4; ++t) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t], qf[s][t], sacc, 0, 0, 0);
@@ -148,7 +147,8 @@ __device__ __forceinline__ void fwd_pair(const AttnArgs& a, const float* Kt, con
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int kk = kt * TK + row_of(r, half);
-      const bool msk = (kk >= a.L) || masked(a, qq, kk, kflag[row_of(r, half)] != 0.f);
+      const bool kpad = kflag[row_of(r, half)] != 0.f;   // unconditional LDS read: no short-circuit, no exec-mask branch per element
+      const bool msk = EDGE && ((kk >= a.L) | masked(a, qq, kk, kpad));
       const float sv = msk ? -INFINITY : sacc[r] * a.scale;
       p[r] = sv;
       mx = fmaxf(mx, sv);
@@ -159,7 +159,7 @@ __device__ __forceinline__ void fwd_pair(const AttnArgs& a, const float* Kt, con
     float ps = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      p[r] = (p[r] == -INFINITY) ? 0.f : __expf(p[r] - m_new);
+      p[r] = (EDGE && p[r] == -INFINITY) ? 0.f : __expf(p[r] - m_new);
       ps += p[r];
     }
     ps += __shfl_xor(ps, 32, 64);
@@ -179,7 +179,7 @@ __device__ __forceinline__ void fwd_pair(const AttnArgs& a, const float* Kt, con
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int kk = kt * TK + row_of(r, half);
-      const bool dead = (kk >= a.L) || (qq >= a.L) || (kk > qq) || q_is_pad || (kflag[row_of(r, half)] != 0.f);
+      const bool dead = (kk >= a.L) | (qq >= a.L) | (kk > qq) | q_is_pad | (kflag[row_of(r, half)] != 0.f);
       float bias = 0.f;
       if (!dead) {
         if (a.time_w) bias += hl.tw[time_bucket(hl.thr, t_q1 - hl.ts[kk])];
@@ -195,7 +195,7 @@ __device__ __forceinline__ void fwd_pair(const AttnArgs& a, const float* Kt, con
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int dd = nt * 32 + col;
-      const float vv = (dd < a.hd) ? Vt[krow * lds_ld + dd] : 0.f;
+      const float vv = Vt[krow * lds_ld + dd];
       oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, p[t], oacc[nt], 0, 0, 0);
     }
   }
@@ -239,19 +239,19 @@ __device__ __forceinline__ void tile_p_ds(const AttnArgs& a, float s_raw, float 
 }
 
 // backward dQ: S^T, dP^T (rows = keys, cols = queries), dS, dQ^T += K^T dS^T
-template <int MODE, int HD>
-__device__ __forceinline__ void dq_pair(const AttnArgs& a, const float* Kt, const float* Vt, const float* kflag, int lds_ld,
+template <int MODE, int HD, bool EDGE = true>
+__device__ __forceinline__ void dq_pair(const AttnArgs& a, const float* Kt, const float* Vt, const float* kflag,
                                         int kt, int qq, bool q_is_pad, long long t_q1, int bh, int col, int half,
                                         const f32x4 (&qf)[HD / 8], const f32x4 (&gf)[HD / 8], float lse_q, float delta_q,
                                         const HstuLds& hl, f32x16 (&dqacc)[HD / 32]) {
-  constexpr int HDV = HD / 8, NT = HD / 32;
+  constexpr int HDV = HD / 8, NT = HD / 32, lds_ld = HD + 4;
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   f32x16 sacc, pacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
 #pragma unroll
   for (int s = 0; s < HDV; ++s) {
-    if (8 * s < a.hd) {
+    {
       f32x4 kf = *reinterpret_cast<const f32x4*>(Kt + col * lds_ld + 8 * s + 4 * half);
       f32x4 vf = *reinterpret_cast<const f32x4*>(Vt + col * lds_ld + 8 * s + 4 * half);
 #pragma unroll
@@ -265,14 +265,14 @@ __device__ __forceinline__ void dq_pair(const AttnArgs& a, const float* Kt, cons
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int kk = kt * TK + row_of(r, half);
-    const bool kpad = kflag[row_of(r, half)] != 0.f;
+    const bool kpad = EDGE && kflag[row_of(r, half)] != 0.f;
     float dsc = 1.f;
     if (MODE == MODE_SOFTMAX && a.p_drop > 0.f) dsc = drop_keep(a.seed, (unsigned)bh, (unsigned)qq, (unsigned)kk, a.p_drop, inv_keep);
     bool dead; float bias = 0.f;
     if (MODE == MODE_SOFTMAX) {
-      dead = (kk >= a.L) || (qq >= a.L) || masked(a, qq, kk, kpad);
+      dead = EDGE && ((kk >= a.L) | (qq >= a.L) | masked(a, qq, kk, kpad));
     } else {
-      dead = (kk >= a.L) || (qq >= a.L) || (kk > qq) || q_is_pad || kpad;
+      dead = (kk >= a.L) | (qq >= a.L) | (kk > qq) | q_is_pad | kpad;
       if (!dead) {
         if (a.time_w) bias += hl.tw[time_bucket(hl.thr, t_q1 - hl.ts[kk])];
         if (a.pos_w) bias += hl.pw[(a.L - 1) + kk - qq];
@@ -293,7 +293,7 @@ __device__ __forceinline__ void dq_pair(const AttnArgs& a, const float* Kt, cons
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int dd = nt * 32 + col;
-      const float kv = (dd < a.hd) ? Kt[krow * lds_ld + dd] : 0.f;
+      const float kv = Kt[krow * lds_ld + dd];
       dqacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, ds[t], dqacc[nt], 0, 0, 0);
     }
   }
@@ -301,20 +301,20 @@ __device__ __forceinline__ void dq_pair(const AttnArgs& a, const float* Kt, cons
 
 // backward dK/dV: S, dP (rows = queries from LDS, cols = keys), dV^T += dO^T P, dK^T += Q^T dS
 // qaux: [0,32) lse, [32,64) delta, [64,96) query pad flags of the tile
-template <int MODE, int HD>
+template <int MODE, int HD, bool EDGE = true>
 __device__ __forceinline__ void dkv_pair(const AttnArgs& a, const float* Qt, const float* Gt, const float* q_lse,
-                                         const float* q_delta, const float* q_flag, int lds_ld, int qt, int kk, bool k_is_pad,
+                                         const float* q_delta, const float* q_flag, int qt, int kk, bool k_is_pad,
                                          long long t_k, int bh, int col, int half, const f32x4 (&kf)[HD / 8],
                                          const f32x4 (&vf)[HD / 8], const HstuLds& hl, f32x16 (&dkacc)[HD / 32],
                                          f32x16 (&dvacc)[HD / 32]) {
-  constexpr int HDV = HD / 8, NT = HD / 32;
+  constexpr int HDV = HD / 8, NT = HD / 32, lds_ld = HD + 4;
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   f32x16 sacc, pacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
 #pragma unroll
   for (int s = 0; s < HDV; ++s) {
-    if (8 * s < a.hd) {
+    {
       f32x4 qf = *reinterpret_cast<const f32x4*>(Qt + col * lds_ld + 8 * s + 4 * half);
       f32x4 gf = *reinterpret_cast<const f32x4*>(Gt + col * lds_ld + 8 * s + 4 * half);
 #pragma unroll
@@ -333,9 +333,9 @@ __device__ __forceinline__ void dkv_pair(const AttnArgs& a, const float* Qt, con
     if (MODE == MODE_SOFTMAX && a.p_drop > 0.f) dsc = drop_keep(a.seed, (unsigned)bh, (unsigned)q, (unsigned)kk, a.p_drop, inv_keep);
     bool dead; float bias = 0.f;
     if (MODE == MODE_SOFTMAX) {
-      dead = (kk >= a.L) || (q >= a.L) || masked(a, q, kk, k_is_pad);
+      dead = EDGE && ((kk >= a.L) | (q >= a.L) | masked(a, q, kk, k_is_pad));
     } else {
-      dead = (kk >= a.L) || (q >= a.L) || (kk > q) || k_is_pad || (q_flag[qrow] != 0.f);
+      dead = (kk >= a.L) | (q >= a.L) | (kk > q) | k_is_pad | (q_flag[qrow] != 0.f);
       if (!dead) {
         if (a.time_w) bias += hl.tw[time_bucket(hl.thr, hl.ts[q + 1] - t_k)];
         if (a.pos_w) bias += hl.pw[(a.L - 1) + kk - q];
@@ -349,8 +349,8 @@ __device__ __forceinline__ void dkv_pair(const AttnArgs& a, const float* Qt, con
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int dd = nt * 32 + col;
-      const float gv = (dd < a.hd) ? Gt[qrow * lds_ld + dd] : 0.f;
-      const float qv = (dd < a.hd) ? Qt[qrow * lds_ld + dd] : 0.f;
+      const float gv = Gt[qrow * lds_ld + dd];
+      const float qv = Qt[qrow * lds_ld + dd];
       dvacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, pu[t], dvacc[nt], 0, 0, 0);
       dkacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qv, ds[t], dkacc[nt], 0, 0, 0);
     }
@@ -424,14 +424,15 @@ template <int MODE, int HD>
 __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs a) {
   constexpr int HDV = HD / 8, NT = HD / 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int lds_ld = a.hd + 4;
+  constexpr int lds_ld = HD + 4;
   float* Ks = smem;                       // [32][hd+4]
   float* Vs = Ks + TK * lds_ld;           // [32][hd+4]
   float* aux = Vs + TK * lds_ld;          // [32] key pad flags (as float)
   HstuLds hl{};
   if (MODE == MODE_HSTU) hstu_carve(aux + TK, a.L, false, hl);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile loops and LDS tile bases stay scalar
   const int col = lane & 31, half = lane >> 5;
   const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
   const int q0 = (blockIdx.x * 4 + wave) * TK;
@@ -463,12 +464,12 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs a) {
 
   for (int kt = 0; kt < n_kt; ++kt) {
     __syncthreads();
-    stage_tile(kb, a.ldk, kt * TK, a.L, a.hd, lds_ld, Ks, tid);
-    stage_tile(vb, a.ldv, kt * TK, a.L, a.hd, lds_ld, Vs, tid);
+    stage_tile<HD>(kb, a.ldk, kt * TK, a.L, a.hd, Ks, tid);
+    stage_tile<HD>(vb, a.ldv, kt * TK, a.L, a.hd, Vs, tid);
     if (tid < TK) { const int kk = kt * TK + tid; aux[tid] = (kk < a.L && idb[kk] != 0) ? 0.f : 1.f; }
     __syncthreads();
     if (q0 >= a.L || kt > my_last_kt) continue;  // nothing to do for this wave (barriers above are uniform)
-    fwd_pair<MODE, HD>(a, Ks, Vs, aux, lds_ld, kt, qq, q_is_pad, t_q1, bh, col, half, qf, hl, oacc, m_run, l_run);
+    fwd_pair<MODE, HD>(a, Ks, Vs, aux, kt, qq, q_is_pad, t_q1, bh, col, half, qf, hl, oacc, m_run, l_run);
   }
   if (q0 >= a.L) return;
   fwd_store<MODE, HD>(a, bh, qq, half, rowbase, h, oacc, m_run, l_run);
@@ -478,14 +479,15 @@ template <int MODE, int HD>
 __global__ __launch_bounds__(AT) void attn_bwd_dq_kernel(AttnArgs a) {
   constexpr int HDV = HD / 8, NT = HD / 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int lds_ld = a.hd + 4;
+  constexpr int lds_ld = HD + 4;
   float* Ks = smem;
   float* Vs = Ks + TK * lds_ld;
   float* aux = Vs + TK * lds_ld;
   HstuLds hl{};
   if (MODE == MODE_HSTU) hstu_carve(aux + TK, a.L, true, hl);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile loops and LDS tile bases stay scalar
   const int col = lane & 31, half = lane >> 5;
   const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
   const int q0 = (blockIdx.x * 4 + wave) * TK;
@@ -519,12 +521,12 @@ __global__ __launch_bounds__(AT) void attn_bwd_dq_kernel(AttnArgs a) {
 
   for (int kt = 0; kt < n_kt; ++kt) {
     __syncthreads();
-    stage_tile(kb, a.ldk, kt * TK, a.L, a.hd, lds_ld, Ks, tid);
-    stage_tile(vb, a.ldv, kt * TK, a.L, a.hd, lds_ld, Vs, tid);
+    stage_tile<HD>(kb, a.ldk, kt * TK, a.L, a.hd, Ks, tid);
+    stage_tile<HD>(vb, a.ldv, kt * TK, a.L, a.hd, Vs, tid);
     if (tid < TK) { const int kk = kt * TK + tid; aux[tid] = (kk < a.L && idb[kk] != 0) ? 0.f : 1.f; }
     __syncthreads();
     if (q0 >= a.L || kt > my_last_kt) continue;
-    dq_pair<MODE, HD>(a, Ks, Vs, aux, lds_ld, kt, qq, q_is_pad, t_q1, bh, col, half, qf, gf, lse_q, delta_q, hl, dqacc);
+    dq_pair<MODE, HD>(a, Ks, Vs, aux, kt, qq, q_is_pad, t_q1, bh, col, half, qf, gf, lse_q, delta_q, hl, dqacc);
   }
   if (MODE == MODE_HSTU) {
     __syncthreads();
@@ -538,14 +540,15 @@ template <int MODE, int HD>
 __global__ __launch_bounds__(AT) void attn_bwd_dkv_kernel(AttnArgs a) {
   constexpr int HDV = HD / 8, NT = HD / 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int lds_ld = a.hd + 4;
+  constexpr int lds_ld = HD + 4;
   float* Qs = smem;                        // [32][hd+4]  queries of the current tile
   float* Gs = Qs + TK * lds_ld;            // [32][hd+4]  dO of the current tile
   float* aux = Gs + TK * lds_ld;           // [32] lse | [32] delta | [32] q pad flag
   HstuLds hl{};
   if (MODE == MODE_HSTU) hstu_carve(aux + 3 * TK, a.L, false, hl);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile loops and LDS tile bases stay scalar
   const int col = lane & 31, half = lane >> 5;
   const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
   const int k0 = (blockIdx.x * 4 + wave) * TK;
@@ -577,8 +580,8 @@ __global__ __launch_bounds__(AT) void attn_bwd_dkv_kernel(AttnArgs a) {
 
   for (int qt = first_qt; qt < n_qt; ++qt) {
     __syncthreads();
-    stage_tile(qb, a.ldq, qt * TK, a.L, a.hd, lds_ld, Qs, tid);
-    stage_tile(gb, a.lddo, qt * TK, a.L, a.hd, lds_ld, Gs, tid);
+    stage_tile<HD>(qb, a.ldq, qt * TK, a.L, a.hd, Qs, tid);
+    stage_tile<HD>(gb, a.lddo, qt * TK, a.L, a.hd, Gs, tid);
     if (tid < TK) {
       const int q = qt * TK + tid;
       aux[tid] = (MODE == MODE_SOFTMAX && q < a.L) ? a.lse[(long long)bh * a.L + q] : 0.f;
@@ -587,7 +590,7 @@ __global__ __launch_bounds__(AT) void attn_bwd_dkv_kernel(AttnArgs a) {
     }
     __syncthreads();
     if (k0 >= a.L || qt < my_first_qt) continue;
-    dkv_pair<MODE, HD>(a, Qs, Gs, aux, aux + TK, aux + 2 * TK, lds_ld, qt, kk, k_is_pad, t_k, bh, col, half, kf, vf, hl, dkacc, dvacc);
+    dkv_pair<MODE, HD>(a, Qs, Gs, aux, aux + TK, aux + 2 * TK, qt, kk, k_is_pad, t_k, bh, col, half, kf, vf, hl, dkacc, dvacc);
   }
   if (k0 >= a.L) return;
   store_rows_T<HD>(a.dk + rowbase * a.lddk + h * a.hd, a.lddk, kk, a.L, a.hd, half, dkacc);
@@ -616,25 +619,32 @@ __device__ __forceinline__ int tile_for(int it, int wave, int n_t, bool causal, 
   return cost_up ? t : n_t - 1 - t;
 }
 
-// rows [0, Lp) of a [L, hd] matrix -> LDS [Lp][lds_ld], zero rows past L
-__device__ __forceinline__ void stage_rows(const float* base, long long ld, int L, int Lp, int hd, int lds_ld, float* dst,
-                                           int tid, int nthreads) {
-  const int per_row = hd >> 2;
-  const int total = Lp * per_row;
-  for (int i0 = tid; i0 < total; i0 += 4 * nthreads) {   // 4 loads in flight per thread
-    f32x4 v[4];
+// rows [0, Lp) of two [L, hd] matrices -> LDS [Lp][HD + 4] each; rows past L and columns past hd are zero-filled.
+// A dependent round trip costs ~2 us, so every thread keeps 4 + 4 float4 loads in flight.
+template <int HD>
+__device__ __forceinline__ void stage_rows2(const float* baseA, long long ldA, float* dstA, const float* baseB, long long ldB,
+                                            float* dstB, int L, int Lp, int hd, int tid, int nthreads) {
+  constexpr int U = 4, PER_ROW = HD / 4, LD = HD + 4;
+  const int total = Lp * PER_ROW;
+  for (int i0 = tid; i0 < total; i0 += U * nthreads) {
+    f32x4 va[U], vb[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int i = i0 + u * nthreads;
-      const int r = i / per_row, c = (i - r * per_row) * 4;
+      const int r = i / PER_ROW, c = (i % PER_ROW) * 4;
       f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      v[u] = (i < total && r < L) ? *reinterpret_cast<const f32x4*>(base + (long long)r * ld + c) : z;
+      const bool ok = i < total && r < L && c < hd;
+      va[u] = ok ? *reinterpret_cast<const f32x4*>(baseA + (long long)r * ldA + c) : z;
+      vb[u] = ok ? *reinterpret_cast<const f32x4*>(baseB + (long long)r * ldB + c) : z;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int i = i0 + u * nthreads;
-      const int r = i / per_row, c = (i - r * per_row) * 4;
-      if (i < total) *reinterpret_cast<f32x4*>(dst + r * lds_ld + c) = v[u];
+      const int r = i / PER_ROW, c = (i % PER_ROW) * 4;
+      if (i < total) {
+        *reinterpret_cast<f32x4*>(dstA + r * LD + c) = va[u];
+        *reinterpret_cast<f32x4*>(dstB + r * LD + c) = vb[u];
+      }
     }
   }
 }
@@ -644,21 +654,21 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(AttnArgs a) {
   constexpr int HDV = HD / 8, NT = HD / 32, NTH = NW * 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n_t = (a.L + TK - 1) / TK, Lp = n_t * TK;
-  const int lds_ld = a.hd + 4;
+  constexpr int lds_ld = HD + 4;
   float* Ks = smem;                       // [Lp][hd+4]
   float* Vs = Ks + Lp * lds_ld;           // [Lp][hd+4]
   float* kflag = Vs + Lp * lds_ld;        // [Lp] key pad flags
   HstuLds hl{};
   if (MODE == MODE_HSTU) hstu_carve(kflag + Lp, a.L, false, hl);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile loops and LDS tile bases stay scalar
   const int col = lane & 31, half = lane >> 5;
   const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
   const long long rowbase = (long long)b * a.L;
   const float* qb = a.q + rowbase * a.ldq + h * a.hd;
   const long long* idb = a.ids + rowbase;
-  stage_rows(a.k + rowbase * a.ldk + h * a.hd, a.ldk, a.L, Lp, a.hd, lds_ld, Ks, tid, NTH);
-  stage_rows(a.v + rowbase * a.ldv + h * a.hd, a.ldv, a.L, Lp, a.hd, lds_ld, Vs, tid, NTH);
+  stage_rows2<HD>(a.k + rowbase * a.ldk + h * a.hd, a.ldk, Ks, a.v + rowbase * a.ldv + h * a.hd, a.ldv, Vs, a.L, Lp, a.hd, tid, NTH);
   for (int i = tid; i < Lp; i += NTH) kflag[i] = (i < a.L && idb[i] != 0) ? 0.f : 1.f;
   if (MODE == MODE_HSTU) hstu_fill(a, hl, b, tid, NTH);
   __syncthreads();
@@ -680,10 +690,17 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(AttnArgs a) {
       for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
     const int last_kt = a.causal ? qt : n_t - 1;
+    const bool q_inside = (qt + 1) * TK <= a.L;
 #pragma unroll 1
-    for (int kt = 0; kt <= last_kt; ++kt)
-      fwd_pair<MODE, HD>(a, Ks + kt * TK * lds_ld, Vs + kt * TK * lds_ld, kflag + kt * TK, lds_ld, kt, qq, q_is_pad, t_q1, bh,
-                         col, half, qf, hl, oacc, m_run, l_run);
+    for (int kt = 0; kt <= last_kt; ++kt) {
+      const bool interior = MODE == MODE_SOFTMAX && !a.no_interior && !a.keypad && q_inside && (kt + 1) * TK <= a.L && (!a.causal || kt < qt);
+      if (interior)
+        fwd_pair<MODE, HD, false>(a, Ks + kt * TK * lds_ld, Vs + kt * TK * lds_ld, kflag + kt * TK, kt, qq, q_is_pad, t_q1,
+                                  bh, col, half, qf, hl, oacc, m_run, l_run);
+      else
+        fwd_pair<MODE, HD, true>(a, Ks + kt * TK * lds_ld, Vs + kt * TK * lds_ld, kflag + kt * TK, kt, qq, q_is_pad, t_q1,
+                                 bh, col, half, qf, hl, oacc, m_run, l_run);
+    }
     fwd_store<MODE, HD>(a, bh, qq, half, rowbase, h, oacc, m_run, l_run);
   }
 }
@@ -693,22 +710,22 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(AttnArgs a) {
   constexpr int HDV = HD / 8, NT = HD / 32, NTH = NW * 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n_t = (a.L + TK - 1) / TK, Lp = n_t * TK;
-  const int lds_ld = a.hd + 4;
+  constexpr int lds_ld = HD + 4;
   float* Ks = smem;
   float* Vs = Ks + Lp * lds_ld;
   float* kflag = Vs + Lp * lds_ld;
   HstuLds hl{};
   if (MODE == MODE_HSTU) hstu_carve(kflag + Lp, a.L, true, hl);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile loops and LDS tile bases stay scalar
   const int col = lane & 31, half = lane >> 5;
   const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
   const long long rowbase = (long long)b * a.L;
   const float* qb = a.q + rowbase * a.ldq + h * a.hd;
   const float* gb = a.dout + rowbase * a.lddo + h * a.hd;
   const long long* idb = a.ids + rowbase;
-  stage_rows(a.k + rowbase * a.ldk + h * a.hd, a.ldk, a.L, Lp, a.hd, lds_ld, Ks, tid, NTH);
-  stage_rows(a.v + rowbase * a.ldv + h * a.hd, a.ldv, a.L, Lp, a.hd, lds_ld, Vs, tid, NTH);
+  stage_rows2<HD>(a.k + rowbase * a.ldk + h * a.hd, a.ldk, Ks, a.v + rowbase * a.ldv + h * a.hd, a.ldv, Vs, a.L, Lp, a.hd, tid, NTH);
   for (int i = tid; i < Lp; i += NTH) kflag[i] = (i < a.L && idb[i] != 0) ? 0.f : 1.f;
   if (MODE == MODE_HSTU) hstu_fill(a, hl, b, tid, NTH);
   __syncthreads();
@@ -732,10 +749,17 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) dqacc[t][r] = 0.f;
     const int last_kt = a.causal ? qt : n_t - 1;
+    const bool q_inside = (qt + 1) * TK <= a.L;
 #pragma unroll 1
-    for (int kt = 0; kt <= last_kt; ++kt)
-      dq_pair<MODE, HD>(a, Ks + kt * TK * lds_ld, Vs + kt * TK * lds_ld, kflag + kt * TK, lds_ld, kt, qq, q_is_pad, t_q1, bh,
-                        col, half, qf, gf, lse_q, delta_q, hl, dqacc);
+    for (int kt = 0; kt <= last_kt; ++kt) {
+      const bool interior = MODE == MODE_SOFTMAX && !a.no_interior && !a.keypad && q_inside && (kt + 1) * TK <= a.L && (!a.causal || kt < qt);
+      if (interior)
+        dq_pair<MODE, HD, false>(a, Ks + kt * TK * lds_ld, Vs + kt * TK * lds_ld, kflag + kt * TK, kt, qq, q_is_pad, t_q1,
+                                 bh, col, half, qf, gf, lse_q, delta_q, hl, dqacc);
+      else
+        dq_pair<MODE, HD, true>(a, Ks + kt * TK * lds_ld, Vs + kt * TK * lds_ld, kflag + kt * TK, kt, qq, q_is_pad, t_q1,
+                                bh, col, half, qf, gf, lse_q, delta_q, hl, dqacc);
+    }
     store_rows_T<HD>(a.dq + rowbase * a.lddq + h * a.hd, a.lddq, qq, a.L, a.hd, half, dqacc);
   }
   if (MODE == MODE_HSTU) {
@@ -749,7 +773,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_res_kernel(AttnArgs a) {
   constexpr int HDV = HD / 8, NT = HD / 32, NTH = NW * 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n_t = (a.L + TK - 1) / TK, Lp = n_t * TK;
-  const int lds_ld = a.hd + 4;
+  constexpr int lds_ld = HD + 4;
   float* Qs = smem;                        // [Lp][hd+4]
   float* Gs = Qs + Lp * lds_ld;            // [Lp][hd+4] dO
   float* s_lse = Gs + Lp * lds_ld;         // [Lp]
@@ -758,15 +782,15 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_res_kernel(AttnArgs a) {
   HstuLds hl{};
   if (MODE == MODE_HSTU) hstu_carve(qflag + Lp, a.L, false, hl);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile loops and LDS tile bases stay scalar
   const int col = lane & 31, half = lane >> 5;
   const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
   const long long rowbase = (long long)b * a.L;
   const float* kb = a.k + rowbase * a.ldk + h * a.hd;
   const float* vb = a.v + rowbase * a.ldv + h * a.hd;
   const long long* idb = a.ids + rowbase;
-  stage_rows(a.q + rowbase * a.ldq + h * a.hd, a.ldq, a.L, Lp, a.hd, lds_ld, Qs, tid, NTH);
-  stage_rows(a.dout + rowbase * a.lddo + h * a.hd, a.lddo, a.L, Lp, a.hd, lds_ld, Gs, tid, NTH);
+  stage_rows2<HD>(a.q + rowbase * a.ldq + h * a.hd, a.ldq, Qs, a.dout + rowbase * a.lddo + h * a.hd, a.lddo, Gs, a.L, Lp, a.hd, tid, NTH);
   for (int i = tid; i < Lp; i += NTH) {
     s_lse[i] = (MODE == MODE_SOFTMAX && i < a.L) ? a.lse[(long long)bh * a.L + i] : 0.f;
     s_delta[i] = (MODE == MODE_SOFTMAX && i < a.L) ? a.delta[(long long)bh * a.L + i] : 0.f;
@@ -792,10 +816,17 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_res_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { dkacc[t][r] = 0.f; dvacc[t][r] = 0.f; }
     const int first_qt = a.causal ? ktile : 0;
+    const bool k_inside = (ktile + 1) * TK <= a.L;
 #pragma unroll 1
-    for (int qt = first_qt; qt < n_t; ++qt)
-      dkv_pair<MODE, HD>(a, Qs + qt * TK * lds_ld, Gs + qt * TK * lds_ld, s_lse + qt * TK, s_delta + qt * TK, qflag + qt * TK,
-                         lds_ld, qt, kk, k_is_pad, t_k, bh, col, half, kf, vf, hl, dkacc, dvacc);
+    for (int qt = first_qt; qt < n_t; ++qt) {
+      const bool interior = MODE == MODE_SOFTMAX && !a.no_interior && !a.keypad && k_inside && (qt + 1) * TK <= a.L && (!a.causal || ktile < qt);
+      if (interior)
+        dkv_pair<MODE, HD, false>(a, Qs + qt * TK * lds_ld, Gs + qt * TK * lds_ld, s_lse + qt * TK, s_delta + qt * TK,
+                                  qflag + qt * TK, qt, kk, k_is_pad, t_k, bh, col, half, kf, vf, hl, dkacc, dvacc);
+      else
+        dkv_pair<MODE, HD, true>(a, Qs + qt * TK * lds_ld, Gs + qt * TK * lds_ld, s_lse + qt * TK, s_delta + qt * TK,
+                                 qflag + qt * TK, qt, kk, k_is_pad, t_k, bh, col, half, kf, vf, hl, dkacc, dvacc);
+    }
     store_rows_T<HD>(a.dk + rowbase * a.lddk + h * a.hd, a.lddk, kk, a.L, a.hd, half, dkacc);
     store_rows_T<HD>(a.dv + rowbase * a.lddv + h * a.hd, a.lddv, kk, a.L, a.hd, half, dvacc);
   }
@@ -804,7 +835,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_res_kernel(AttnArgs a) {
 // ---- launch -----------------------------------------------------------------------------------------
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
-inline size_t stream_lds_bytes(int hd, int L, int aux_floats, bool hstu, bool grads) {
+inline size_t stream_lds_bytes(int hd /* padded: HD */, int L, int aux_floats, bool hstu, bool grads) {
   return ((size_t)2 * TK * (hd + 4) + aux_floats + (hstu ? hstu_lds_floats(L, grads) : 0)) * 4 + 64;
 }
 inline size_t res_lds_bytes(int hd, int L, int aux_rows, bool hstu, bool grads) {
@@ -826,14 +857,14 @@ inline int set_lds(K kernel, size_t lds) {
 template <int MODE, int HD>
 int launch_fwd(const AttnArgs& a, hipStream_t stream) {
   constexpr int NW = HD <= 64 ? 8 : 4;
-  const size_t rl = res_lds_bytes(a.hd, a.L, 1, MODE == MODE_HSTU, false);
+  const size_t rl = res_lds_bytes(HD, a.L, 1, MODE == MODE_HSTU, false);
   if (rl <= LDS_LIMIT && attn_allow_resident()) {
     { const int rc = set_lds(&attn_fwd_res_kernel<MODE, HD, NW>, rl); if (rc != RT_OK) return rc; }
     attn_fwd_res_kernel<MODE, HD, NW><<<a.B * a.H, NW * 64, rl, stream>>>(a);
     RT_CHECK_LAUNCH();
     return RT_OK;
   }
-  const size_t lds = stream_lds_bytes(a.hd, a.L, TK, MODE == MODE_HSTU, false);
+  const size_t lds = stream_lds_bytes(HD, a.L, TK, MODE == MODE_HSTU, false);
   { const int rc = set_lds(&attn_fwd_kernel<MODE, HD>, lds); if (rc != RT_OK) return rc; }
   dim3 grid((a.L + 4 * TK - 1) / (4 * TK), a.B * a.H);
   attn_fwd_kernel<MODE, HD><<<grid, AT, lds, stream>>>(a);
@@ -843,8 +874,8 @@ int launch_fwd(const AttnArgs& a, hipStream_t stream) {
 template <int MODE, int HD>
 int launch_bwd(const AttnArgs& a, hipStream_t stream) {
   constexpr int NW = HD <= 64 ? 8 : 4;
-  const size_t r1 = res_lds_bytes(a.hd, a.L, 1, MODE == MODE_HSTU, true);
-  const size_t r2 = res_lds_bytes(a.hd, a.L, 3, MODE == MODE_HSTU, false);
+  const size_t r1 = res_lds_bytes(HD, a.L, 1, MODE == MODE_HSTU, true);
+  const size_t r2 = res_lds_bytes(HD, a.L, 3, MODE == MODE_HSTU, false);
   if (r1 <= LDS_LIMIT && r2 <= LDS_LIMIT && attn_allow_resident()) {
     { const int rc = set_lds(&attn_bwd_dq_res_kernel<MODE, HD, NW>, r1); if (rc != RT_OK) return rc; }
     { const int rc = set_lds(&attn_bwd_dkv_res_kernel<MODE, HD, NW>, r2); if (rc != RT_OK) return rc; }
@@ -862,8 +893,8 @@ int launch_bwd(const AttnArgs& a, hipStream_t stream) {
     return RT_OK;
   }
   dim3 grid((a.L + 4 * TK - 1) / (4 * TK), a.B * a.H);
-  const size_t lds1 = stream_lds_bytes(a.hd, a.L, TK, MODE == MODE_HSTU, true);
-  const size_t lds2 = stream_lds_bytes(a.hd, a.L, 3 * TK, MODE == MODE_HSTU, false);
+  const size_t lds1 = stream_lds_bytes(HD, a.L, TK, MODE == MODE_HSTU, true);
+  const size_t lds2 = stream_lds_bytes(HD, a.L, 3 * TK, MODE == MODE_HSTU, false);
   { const int rc = set_lds(&attn_bwd_dq_kernel<MODE, HD>, lds1); if (rc != RT_OK) return rc; }
   { const int rc = set_lds(&attn_bwd_dkv_kernel<MODE, HD>, lds2); if (rc != RT_OK) return rc; }
   attn_bwd_dq_kernel<MODE, HD><<<grid, AT, lds1, stream>>>(a);
@@ -873,14 +904,21 @@ int launch_bwd(const AttnArgs& a, hipStream_t stream) {
   return RT_OK;
 }
 
+inline int attn_no_interior() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("RT_ATTN_EDGE"); v = (e && e[0] == '0') ? 1 : 0; }
+  return v;
+}
 template <int MODE>
-int dispatch_fwd(const AttnArgs& a, hipStream_t s) {
+int dispatch_fwd(const AttnArgs& a_in, hipStream_t s) {
+  AttnArgs a = a_in; a.no_interior = attn_no_interior();
   if (a.hd <= 32) return launch_fwd<MODE, 32>(a, s);
   if (a.hd <= 64) return launch_fwd<MODE, 64>(a, s);
   return launch_fwd<MODE, 128>(a, s);
 }
 template <int MODE>
-int dispatch_bwd(const AttnArgs& a, hipStream_t s) {
+int dispatch_bwd(const AttnArgs& a_in, hipStream_t s) {
+  AttnArgs a = a_in; a.no_interior = attn_no_interior();
   if (a.hd <= 32) return launch_bwd<MODE, 32>(a, s);
   if (a.hd <= 64) return launch_bwd<MODE, 64>(a, s);
   return launch_bwd<MODE, 128>(a, s);
