@@ -189,6 +189,21 @@ class SASRecTransformerLayer(nn.Module):
         self.p = dropout_rate
 
     def forward(self, seqs, ids, B, L, causal, keypad):
+        """`seqs` comes in unmasked: the timeline mask (sasrec.py:300) is the first step of the fused block."""
+        p = self.p if self.training else 0.0
+        ff = self.feed_forward
+        if ff.ff_linear_1.bias is not None and ff.ff_linear_2.bias is not None and ff.activation == "relu":
+            mha = self.multi_head_attn
+            return ops.sasrec_layer(
+                seqs, ids, B, L, mha.n_heads, causal, keypad, p,
+                (self.q_layer_norm.weight, self.q_layer_norm.bias, self.q_layer_norm.eps),
+                (mha.in_proj_weight, mha.in_proj_bias), (mha.out_proj.weight, mha.out_proj.bias),
+                (self.ff_layer_norm.weight, self.ff_layer_norm.bias, self.ff_layer_norm.eps),
+                (ff.ff_linear_1.weight, ff.ff_linear_1.bias), (ff.ff_linear_2.weight, ff.ff_linear_2.bias))
+        return self.forward_modular(ops.mul_mask(seqs, None, ids), ids, B, L, causal, keypad)
+
+    def forward_modular(self, seqs, ids, B, L, causal, keypad):
+        """Same block out of the individual autograd ops (`seqs` already masked); kept as the cross-check of the fused node."""
         p = self.p if self.training else 0.0
         q = self.q_layer_norm(seqs)
         seqs = self.multi_head_attn(q, seqs, ids, B, L, causal, keypad, p, residual=q)   # q + mha(q, x, x)
@@ -208,8 +223,7 @@ class SASRecTransformerLayers(TransformerLayersBase):
 
     def forward(self, seqs, ids, B, L, causal, keypad, batch):
         for blk in self.transformer_blocks:
-            seqs = ops.mul_mask(seqs, None, ids)  # seqs *= timeline_mask (sasrec.py:300)
-            seqs = blk(seqs, ids, B, L, causal, keypad)
+            seqs = blk(seqs, ids, B, L, causal, keypad)   # seqs *= timeline_mask (sasrec.py:300) happens inside
         seqs = ops.mul_mask(seqs, None, ids)
         return self.last_layernorm(seqs)
 

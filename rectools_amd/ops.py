@@ -432,6 +432,134 @@ def mha(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, ids: torch.Tensor, B:
     return _MHA.apply(q, k, v, ids.reshape(-1), B, H, L, causal, keypad, p)
 
 
+class _SASRecLayer(torch.autograd.Function):
+    """One SASRec block (sasrec.py:186-231, :300) as a single autograd node.
+
+        x0 = x * (ids != 0);  q = LN1(x0);  y = q + out_proj(mha(Wq q, Wkv x0));  f = LN2(y)
+        out = f + dropout(W2 dropout(relu(W1 f + b1)) + b2)
+
+    Same kernels as the modular path (ops.linear / layer_norm / mha / ...); what the fused node adds is control over the
+    backward data flow: every gradient accumulation (the two residuals and the two consumers of x0) rides in the
+    residual epilogue of a dgrad GEMM instead of a separate full-size add kernel issued by autograd.
+    """
+
+    @staticmethod
+    def forward(ctx, x, ids, ln1_w, ln1_b, in_w, in_b, out_w, out_b, ln2_w, ln2_b, w1, b1, w2, b2, meta):
+        B, L, H, causal, keypad, p, eps1, eps2 = meta
+        x = x.contiguous()
+        M, d = x.shape
+        dff = w1.shape[0]
+        dev = x.device
+        new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
+        x0 = new(M, d)
+        _c("rt_mul_mask", x, None, ids, d, x.numel(), x0)
+        q, mean1, rstd1 = new(M, d), new(M), new(M)
+        _c("rt_layernorm_fwd", x0, ln1_w, ln1_b, float(eps1), M, d, q, mean1, rstd1)
+        Q, KV = new(M, d), new(M, 2 * d)
+        _gemm(q, d, 1, in_w, d, 1, Q, d, in_b, None, 0, M, d, d)
+        _gemm(x0, d, 1, in_w[d:], d, 1, KV, 2 * d, in_b[d:], None, 0, M, 2 * d, d)
+        A, lse = new(M, d), new(B, H, L)
+        seed_a = 0
+        if p > 0:
+            s0, sid = RNG.next()
+            seed_a = (s0 + 0xD1B54A32D192ED03 * sid) & 0xFFFFFFFFFFFFFFFF
+        hd = d // H
+        _c("rt_mha_fwd", Q, d, KV, 2 * d, KV[:, d:], 2 * d, ids, B, H, L, hd, int(causal), int(keypad), float(p), seed_a, A, d, lse)
+        y = new(M, d)
+        _gemm(A, d, 1, out_w, d, 1, y, d, out_b, q, d, M, d, d)
+        f, mean2, rstd2 = new(M, d), new(M), new(M)
+        _c("rt_layernorm_fwd", y, ln2_w, ln2_b, float(eps2), M, d, f, mean2, rstd2)
+        h = new(M, dff)
+        _gemm(f, d, 1, w1, d, 1, h, dff, b1, None, 0, M, dff, d, 1)
+        seed_h = seed_o = (0, 0)
+        if p > 0:
+            seed_h = RNG.next()
+            hdrop = new(M, dff)
+            _c("rt_act_dropout_fwd", h, ACT_NONE, float(p), seed_h[0], seed_h[1], h.numel(), hdrop)
+            o = new(M, d)
+            _gemm(hdrop, dff, 1, w2, dff, 1, o, d, b2, None, 0, M, d, dff)
+            seed_o = RNG.next()
+            od = new(M, d)
+            _c("rt_act_dropout_fwd", o, ACT_NONE, float(p), seed_o[0], seed_o[1], o.numel(), od)
+            out = new(M, d)
+            _c("rt_axpy", od, 1.0, f, od.numel(), out)
+        else:
+            hdrop = h
+            out = new(M, d)
+            _gemm(h, dff, 1, w2, dff, 1, out, d, b2, f, d, M, d, dff)
+        ctx.save_for_backward(ids, x0, q, Q, KV, A, lse, y, f, h, hdrop, mean1, rstd1, mean2, rstd2,
+                              ln1_w, in_w, out_w, ln2_w, w1, w2)
+        ctx.meta = (B, L, H, causal, keypad, p, seed_a, seed_h, seed_o)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (ids, x0, q, Q, KV, A, lse, y, f, h, hdrop, mean1, rstd1, mean2, rstd2, ln1_w, in_w, out_w, ln2_w, w1, w2) = ctx.saved_tensors
+        B, L, H, causal, keypad, p, seed_a, seed_h, seed_o = ctx.meta
+        g_out = g_out.contiguous()
+        M, d = g_out.shape
+        dff = w1.shape[0]
+        dev = g_out.device
+        new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
+        sp = _wgrad_splits(M)
+
+        def ln_bwd(dy, x, w, mean, rstd):
+            dx, dw, db = new(M, d), new(d), new(d)
+            ws_bytes = _lib.load().rt_layernorm_bwd_workspace_bytes(M, d)
+            ws = torch.empty((max(ws_bytes, 4),), dtype=torch.uint8, device=dev)
+            _c("rt_layernorm_bwd", dy, x, w, mean, rstd, M, d, dx, dw, db, ws, ws_bytes)
+            return dx, dw, db
+
+        # ---- feed-forward: out = f + dropout(o),  o = W2 hdrop + b2,  hdrop = dropout(relu(W1 f + b1))
+        if p > 0:
+            g_o = new(M, d)
+            _c("rt_act_dropout_bwd", g_out, g_out, ACT_NONE, float(p), seed_o[0], seed_o[1], g_out.numel(), g_o)
+        else:
+            g_o = g_out
+        d_w2, d_b2 = new(d, dff), new(d)
+        _gemm(g_o, d, 0, hdrop, dff, 0, d_w2, dff, None, None, 0, d, dff, M, 0, sp, d_b2)
+        g_hd = new(M, dff)
+        _gemm(g_o, d, 1, w2, dff, 0, g_hd, dff, None, None, 0, M, dff, d)
+        g_h = new(M, dff)   # dropout mask and relu'(h) in one pass (relu'(z) == [h > 0])
+        _c("rt_act_dropout_bwd", g_hd, h, ACT_RELU, float(p), seed_h[0], seed_h[1], g_hd.numel(), g_h)
+        d_w1, d_b1 = new(dff, d), new(dff)
+        _gemm(g_h, dff, 0, f, d, 0, d_w1, d, None, None, 0, dff, d, M, 0, sp, d_b1)
+        g_f = new(M, d)     # residual branch (g_out) added in the dgrad epilogue
+        _gemm(g_h, dff, 1, w1, d, 0, g_f, d, None, g_out, d, M, d, dff)
+        g_y, d_ln2w, d_ln2b = ln_bwd(g_f, y, ln2_w, mean2, rstd2)
+        # ---- attention: y = q + Wo A + bo
+        d_wo, d_bo = new(d, d), new(d)
+        _gemm(g_y, d, 0, A, d, 0, d_wo, d, None, None, 0, d, d, M, 0, sp, d_bo)
+        g_A = new(M, d)
+        _gemm(g_y, d, 1, out_w, d, 0, g_A, d, None, None, 0, M, d, d)
+        gQ, gKV, delta = new(M, d), new(M, 2 * d), new(B, H, L)
+        _c("rt_mha_bwd", Q, d, KV, 2 * d, KV[:, d:], 2 * d, A, d, g_A, d, lse, ids, B, H, L, d // H, int(causal), int(keypad),
+           float(p), seed_a, gQ, d, gKV, 2 * d, gKV[:, d:], 2 * d, delta)
+        d_in_w, d_in_b = new(3 * d, d), new(3 * d)
+        _gemm(gQ, d, 0, q, d, 0, d_in_w, d, None, None, 0, d, d, M, 0, sp, d_in_b)
+        _gemm(gKV, 2 * d, 0, x0, d, 0, d_in_w[d:], d, None, None, 0, 2 * d, d, M, 0, sp, d_in_b[d:])
+        g_q = new(M, d)     # q feeds the query projection and the residual: g_q = gQ Wq + g_y
+        _gemm(gQ, d, 1, in_w, d, 0, g_q, d, None, g_y, d, M, d, d)
+        g_x0a, d_ln1w, d_ln1b = ln_bwd(g_q, x0, ln1_w, mean1, rstd1)
+        g_x0 = new(M, d)    # x0 feeds LN1 and the key/value projection: g_x0 = gKV Wkv + LN1'(g_q)
+        _gemm(gKV, 2 * d, 1, in_w[d:], d, 0, g_x0, d, None, g_x0a, d, M, d, 2 * d)
+        g_x = new(M, d)
+        _c("rt_mul_mask", g_x0, None, ids, d, g_x0.numel(), g_x)
+        return (g_x, None, d_ln1w, d_ln1b, d_in_w, d_in_b, d_wo, d_bo, d_ln2w, d_ln2b, d_w1, d_b1, d_w2, d_b2, None)
+
+
+def sasrec_layer(x: torch.Tensor, ids: torch.Tensor, B: int, L: int, H: int, causal: bool, keypad: bool, p: float,
+                 ln1: tp.Tuple[torch.Tensor, torch.Tensor, float], in_proj: tp.Tuple[torch.Tensor, torch.Tensor],
+                 out_proj: tp.Tuple[torch.Tensor, torch.Tensor], ln2: tp.Tuple[torch.Tensor, torch.Tensor, float],
+                 ff1: tp.Tuple[torch.Tensor, torch.Tensor], ff2: tp.Tuple[torch.Tensor, torch.Tensor]) -> torch.Tensor:
+    """Fused SASRec block on [B*L, d] activations (timeline mask included); parameters as (weight, bias[, eps])."""
+    for t in (x, ln1[0], in_proj[0], out_proj[0], ln2[0], ff1[0], ff2[0]):
+        _chk(t, "sasrec_layer")
+    return _SASRecLayer.apply(x, ids.reshape(-1), ln1[0], ln1[1], in_proj[0], in_proj[1], out_proj[0], out_proj[1],
+                              ln2[0], ln2[1], ff1[0], ff1[1], ff2[0], ff2[1],
+                              (B, L, H, bool(causal), bool(keypad), float(p), ln1[2], ln2[2]))
+
+
 def hstu_time_thresholds(num_buckets: int = 128) -> torch.Tensor:
     """thr[b] = smallest |dt| >= 0 whose reference bucket clamp(trunc(log(max(1,|dt|)) / 0.301), 0, nb) is >= b.
 

@@ -280,3 +280,40 @@ def test_full_softmax_loss(cosine):
     if not cosine: gref[1][0] = 0
     close(ggot[0], gref[0], rtol=2e-3, atol_rel=2e-4, msg="d_sess")
     if not cosine: close(ggot[1], gref[1], rtol=2e-3, atol_rel=2e-4, msg="d_table")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p", [0.0, 0.25])
+@pytest.mark.parametrize("B,L,d,H", [(3, 20, 64, 2), (2, 256, 128, 2)])
+def test_fused_sasrec_layer_matches_modular_ops(B, L, d, H, p):
+    """The single-node SASRec block (ops.sasrec_layer) against the same block built from the individual autograd ops:
+    identical dropout streams, so outputs and every gradient must agree to rounding."""
+    from rectools_amd import nn as hnn
+    from rectools_amd import ops
+
+    torch.manual_seed(0)
+    layer = hnn.SASRecTransformerLayer(d, H, p).cuda().train()
+    for prm in layer.parameters():  # biases / LN params away from their trivial init
+        if prm.ndim == 1:
+            prm.data.add_(0.1 * torch.randn_like(prm))
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(1, 50, (B, L), generator=g); ids[0, : L // 3] = 0
+    ids = ids.cuda()
+    x = rnd(B * L, d, seed=2).cuda()
+    gout = rnd(B * L, d, seed=3).cuda()
+
+    def run(fused):
+        ops.RNG.step, ops.RNG._stream = 7, 0
+        for prm in layer.parameters():
+            prm.grad = None
+        xi = x.clone().requires_grad_(True)
+        out = layer(xi, ids, B, L, True, False) if fused else layer.forward_modular(ops.mul_mask(xi, None, ids), ids, B, L, True, False)
+        out.backward(gout)
+        return out.detach(), xi.grad, {k: v.grad.clone() for k, v in layer.named_parameters()}
+
+    o1, gx1, gp1 = run(True)
+    o2, gx2, gp2 = run(False)
+    close(o1, o2, rtol=1e-5, atol_rel=1e-6, msg="fused fwd")
+    close(gx1, gx2, rtol=1e-4, atol_rel=1e-5, msg="fused dx")
+    for k in gp2:
+        close(gp1[k], gp2[k], rtol=1e-4, atol_rel=1e-5, msg=f"fused d{k}")
