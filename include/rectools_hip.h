@@ -145,6 +145,12 @@ int rt_mul_mask(const float* a, const float* b, const int64_t* ids, int32_t d, i
  * grad_scale multiplies g first (1/world_size after a sum all-reduce). */
 int rt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, float lr, float beta1, float beta2,
                  float eps, float grad_scale, rt_stream_t stream);
+/* Same update over n_seg segments of the flat p/m/v buffers, every segment reading its gradient from its own device
+ * pointer grads[i] (NULL = parameter without gradient: skipped like torch.optim.Adam does).  offsets/lens/grads are
+ * HOST arrays (offsets in floats, multiples of 4).  Lets autograd hand over its gradient tensors as they are. */
+int rt_adam_step_segments(float* p, float* m, float* v, int32_t n_seg, const int64_t* offsets, const int64_t* lens,
+                          const float* const* grads, int32_t step, float lr, float beta1, float beta2, float eps,
+                          float grad_scale, rt_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K4  softmax multi-head attention, forward / backward (torch.nn.MultiheadAttention as called at sasrec.py:222-224,

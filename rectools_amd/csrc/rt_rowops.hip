@@ -508,6 +508,48 @@ __global__ void adam_kernel(f32x4* __restrict__ p, const f32x4* __restrict__ g, 
   }
 }
 
+// Segmented variant: parameters / moments flat, every segment's gradient behind its own pointer (autograd's own
+// output tensors: no AccumulateGrad add into a flat gradient buffer, no zero fill).  Block = one 4 KiB-float4 chunk
+// of one segment; the chunk table travels in the kernel arguments.
+constexpr int ADAM_SEGS = 48, ADAM_CHUNK4 = 1024;
+struct AdamSegs {
+  const float* grad[ADAM_SEGS];
+  long long ofs4[ADAM_SEGS];     // segment start in the flat buffers (float4 units)
+  long long len[ADAM_SEGS];      // floats (any length; a ragged tail is handled element-wise)
+  int first_chunk[ADAM_SEGS + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void adam_segs_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                        AdamSegs sg, float lr_bc1, float inv_sqrt_bc2, float b1, float b2,
+                                                        float eps, float grad_scale) {
+  int s = 0;
+  while (s + 1 < sg.n && (int)blockIdx.x >= sg.first_chunk[s + 1]) ++s;
+  const long long c0 = (long long)(blockIdx.x - sg.first_chunk[s]) * ADAM_CHUNK4;   // float4 index inside the segment
+  const float* __restrict__ g = sg.grad[s];
+  const long long len = sg.len[s];
+  const bool g_vec = (reinterpret_cast<uintptr_t>(g) & 15) == 0;
+#pragma unroll
+  for (int u = 0; u < ADAM_CHUNK4 / 256; ++u) {
+    const long long i4 = c0 + u * 256 + threadIdx.x;
+    const long long e = i4 * 4;
+    if (e >= len) break;
+    f32x4 gg = {0.f, 0.f, 0.f, 0.f};
+    if (g_vec && e + 4 <= len) gg = *reinterpret_cast<const f32x4*>(g + e);
+    else for (int j = 0; j < 4; ++j) if (e + j < len) gg[j] = g[e + j];
+    gg *= grad_scale;
+    const long long f = sg.ofs4[s] + i4;
+    f32x4 mm = reinterpret_cast<f32x4*>(m)[f], vv = reinterpret_cast<f32x4*>(v)[f], pp = reinterpret_cast<f32x4*>(p)[f];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mm[j] = b1 * mm[j] + (1.f - b1) * gg[j];
+      vv[j] = b2 * vv[j] + (1.f - b2) * gg[j] * gg[j];
+      const float denom = sqrtf(vv[j]) * inv_sqrt_bc2 + eps;
+      pp[j] -= lr_bc1 * (mm[j] / denom);
+    }
+    reinterpret_cast<f32x4*>(m)[f] = mm; reinterpret_cast<f32x4*>(v)[f] = vv; reinterpret_cast<f32x4*>(p)[f] = pp;
+  }
+}
+
 inline int stream_grid(long long n4) {
   long long b = (n4 + 255) / 256;
   long long cap = (long long)rt_num_cus() * 8;
@@ -712,6 +754,35 @@ int rt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int32_
                                                       reinterpret_cast<f32x4*>(m), reinterpret_cast<f32x4*>(v), n / 4,
                                                       (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, grad_scale);
   RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+// Adam over `n_seg` parameter segments of the flat buffers p/m/v: segment i covers floats [offsets[i], offsets[i]+lens[i])
+// (offsets multiples of 4; padding between segments is never touched) and reads its gradient from grads[i] (device
+// pointer; the arrays themselves are host memory).  Segments are processed ADAM_SEGS per launch.
+int rt_adam_step_segments(float* p, float* m, float* v, int32_t n_seg, const int64_t* offsets, const int64_t* lens,
+                          const float* const* grads, int32_t step, float lr, float beta1, float beta2, float eps,
+                          float grad_scale, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (n_seg < 0 || step < 1) return RT_ERR_INVALID_ARG;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  for (int s0 = 0; s0 < n_seg; s0 += ADAM_SEGS) {
+    AdamSegs sg{};
+    int chunks = 0, k = 0;
+    for (int s = s0; s < n_seg && k < ADAM_SEGS; ++s) {
+      if ((offsets[s] & 3) != 0 || lens[s] < 0) return RT_ERR_INVALID_ARG;
+      if (lens[s] == 0 || grads[s] == nullptr) continue;
+      sg.grad[k] = grads[s]; sg.ofs4[k] = offsets[s] / 4; sg.len[k] = lens[s];
+      sg.first_chunk[k] = chunks;
+      chunks += (int)((lens[s] + 4 * ADAM_CHUNK4 - 1) / (4 * ADAM_CHUNK4));
+      ++k;
+    }
+    sg.first_chunk[k] = chunks; sg.n = k;
+    if (k == 0) continue;
+    adam_segs_kernel<<<chunks, 256, 0, stream>>>(p, m, v, sg, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, grad_scale);
+    RT_CHECK_LAUNCH();
+  }
   return RT_OK;
 }
 

@@ -105,7 +105,13 @@ class TransformerLossModule(nn.Module):
 
 
 class FlatAdam:
-    """All parameters (and gradients, Adam moments) live in flat fp32 buffers; one kernel per step."""
+    """All parameters and Adam moments live in flat fp32 buffers; one fused kernel per step.
+
+    Gradients are NOT accumulated into a flat buffer on one GPU: `zero_grad()` drops the `.grad` references, autograd
+    then hands over its own output tensors (no AccumulateGrad add, no zero fill) and `rt_adam_step_segments` reads each
+    parameter's gradient through its own pointer.  With data parallelism the gradients are packed into `flat_g` for ONE
+    all-reduce per step and the flat kernel runs on the reduced buffer.
+    """
 
     def __init__(self, module: nn.Module, lr: float, betas: tp.Tuple[float, float] = (0.9, 0.98), eps: float = 1e-8) -> None:
         params = [p for p in module.parameters() if p.requires_grad]
@@ -115,51 +121,74 @@ class FlatAdam:
         sizes = [(p.numel() + 3) // 4 * 4 for p in params]  # 16-byte aligned segments
         total = sum(sizes)
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
         self.m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.v = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._flat_g: tp.Optional[torch.Tensor] = None   # allocated on first use (data-parallel runs only)
         self.params = params
-        self._grad_views = []
+        self._offsets: tp.List[int] = []
         ofs = 0
         for p, sz in zip(params, sizes):
             view = self.flat_p[ofs:ofs + p.numel()].view_as(p)
             view.copy_(p.data)
             p.data = view
-            gview = self.flat_g[ofs:ofs + p.numel()].view_as(p)
-            p.grad = gview
-            self._grad_views.append(gview)
+            p.grad = None
+            self._offsets.append(ofs)
             ofs += sz
         self.lr, self.betas, self.eps = lr, betas, eps
         self.step_count = 0
 
-    def zero_grad(self) -> None:
-        self.flat_g.zero_()
-        for p, g in zip(self.params, self._grad_views):
-            p.grad = g  # autograd accumulates in place into the flat gradient buffer
+    @property
+    def flat_g(self) -> torch.Tensor:
+        if self._flat_g is None:
+            self._flat_g = torch.zeros_like(self.flat_p)
+        return self._flat_g
 
-    def _sync_grads(self) -> None:
-        for p, g in zip(self.params, self._grad_views):
-            if p.grad is not None and p.grad.data_ptr() != g.data_ptr():
-                g.copy_(p.grad)
-                p.grad = g
+    def zero_grad(self) -> None:
+        for p in self.params:
+            p.grad = None  # the next backward's gradient tensors are adopted as they are
+
+    def gather_gradients(self) -> torch.Tensor:
+        """Pack the per-parameter gradients into the flat buffer (zeros where a parameter got none)."""
+        fg = self.flat_g
+        for p, ofs in zip(self.params, self._offsets):
+            seg = fg[ofs:ofs + p.numel()]
+            if p.grad is None:
+                seg.zero_()
+            else:
+                seg.copy_(p.grad.reshape(-1))
+        return fg
 
     def reduce_gradients(self, world_size: int = 1) -> float:
         """Data-parallel gradient exchange: ONE sum all-reduce of the flat gradient buffer (RCCL over xGMI on GPUs,
         gloo in the CPU tests).  Returns the scale that turns the sum into DDP's mean; it is folded into the Adam
         kernel instead of a separate pass over the buffer."""
-        self._sync_grads()
         if world_size <= 1:
             return 1.0
         import torch.distributed as dist
 
-        dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
+        dist.all_reduce(self.gather_gradients(), op=dist.ReduceOp.SUM)
         return 1.0 / world_size
 
     def step(self, world_size: int = 1) -> None:
         scale = self.reduce_gradients(world_size)
         self.step_count += 1
-        ops._c("rt_adam_step", self.flat_p, self.flat_g, self.m, self.v, self.flat_p.numel(), self.step_count, float(self.lr),
-               float(self.betas[0]), float(self.betas[1]), float(self.eps), float(scale))
+        hyper = (self.step_count, float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(scale))
+        if world_size > 1:
+            ops._c("rt_adam_step", self.flat_p, self.flat_g, self.m, self.v, self.flat_p.numel(), *hyper)
+            return
+        import ctypes
+
+        grads = []
+        for p in self.params:  # parameters without a gradient are skipped, as torch.optim.Adam does
+            g = p.grad
+            if g is not None and (g.dtype != torch.float32 or not g.is_contiguous() or g.device != self.flat_p.device):
+                g = g.to(device=self.flat_p.device, dtype=torch.float32).contiguous()
+            grads.append(g)
+        n = len(self.params)
+        offsets = (ctypes.c_int64 * n)(*self._offsets)
+        lens = (ctypes.c_int64 * n)(*[p.numel() for p in self.params])
+        ptrs = (ctypes.c_void_p * n)(*[None if g is None else g.data_ptr() for g in grads])
+        ops._c("rt_adam_step_segments", self.flat_p, self.m, self.v, n, offsets, lens, ptrs, *hyper)
 
     def state_dict(self) -> tp.Dict[str, tp.Any]:
         return {"m": self.m.clone(), "v": self.v.clone(), "step": self.step_count, "lr": self.lr, "betas": self.betas,

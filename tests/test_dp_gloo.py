@@ -26,7 +26,7 @@ def _worker(rank, world, port, out_dir):
     opt.zero_grad()
     x = torch.full((4, 6), float(rank + 1))
     model(x).sum().backward()                                   # rank-dependent gradients
-    local = opt.flat_g.clone()
+    local = opt.gather_gradients().clone()                      # per-parameter gradients packed into the flat buffer
     scale = opt.reduce_gradients(world)
     gathered = [torch.zeros_like(local) for _ in range(world)]
     dist.all_gather(gathered, local)
