@@ -186,18 +186,25 @@ int rt_hstu_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, c
  * K8/K9  negative-sampled losses without the [B,L,1+N,d] gather (similarity.py:88-95 + lightning.py:164-212).
  * loss: 0 BCE, 1 gBCE, 2 sampled_softmax.  sess [M,d]; table [V,d]; y [M] (0 = position ignored); neg [M,N]; w [M].
  * Forward writes logits [M,1+N] (already divided by logits_t) and the weighted per-position loss.
- * Backward overwrites d_sess [M,d] and d_table [V,d] (index_put of the reference, done as a counting sort by item
- * id + one segmented reduction per table row: no float atomics); norm = rt_loss_reduce's out+1.
+ * Training forward (fwd_train) additionally keeps, in `workspace`, the unit gradient of every logit and the
+ * counting-sort ranks of the candidate ids, and writes d_sess_unit [M,d]: the candidate rows are gathered ONCE for
+ * logits, loss and session gradient (the reference materialises the gather in forward and re-reads it in backward).
+ * Backward scales by gscale / norm (norm = rt_loss_reduce's out+1) and overwrites d_sess [M,d] and d_table [V,d]
+ * (index_put of the reference, done as a counting sort by item id + one segmented reduction per table row: no float
+ * atomics).  One backward per training forward.
  * ------------------------------------------------------------------------------------------------ */
 int rt_sampled_loss_fwd(const float* sess, int64_t ld_sess, const float* table, const int64_t* y, const int64_t* neg,
                         const float* w, int32_t M, int32_t N, int32_t d, int32_t loss, int32_t cosine, float logits_t,
                         double gbce_beta, float* logits, float* loss_pos, rt_stream_t stream);
 size_t rt_sampled_loss_bwd_workspace_bytes(int32_t M, int32_t N, int32_t V);
+int rt_sampled_loss_fwd_train(const float* sess, int64_t ld_sess, const float* table, const int64_t* y, const int64_t* neg,
+                              const float* w, int32_t M, int32_t N, int32_t d, int32_t V, int32_t loss, int32_t cosine,
+                              float logits_t, double gbce_beta, float* logits, float* loss_pos, float* d_sess_unit,
+                              int64_t ld_du, void* workspace, size_t workspace_bytes, rt_stream_t stream);
 int rt_sampled_loss_bwd(const float* sess, int64_t ld_sess, const float* table, const int64_t* y, const int64_t* neg,
-                        const float* w, int32_t M, int32_t N, int32_t d, int32_t V, int32_t loss, int32_t cosine,
-                        float logits_t, double gbce_beta, const float* logits, const float* norm, float gscale,
-                        float* d_sess, int64_t ld_dsess, float* d_table, void* workspace, size_t workspace_bytes,
-                        rt_stream_t stream);
+                        int32_t M, int32_t N, int32_t d, int32_t V, int32_t cosine, float logits_t, const float* logits,
+                        const float* norm, float gscale, const float* d_sess_unit, int64_t ld_du, float* d_sess,
+                        int64_t ld_dsess, float* d_table, void* workspace, size_t workspace_bytes, rt_stream_t stream);
 /* out[0] = sum(loss_pos)/normaliser, out[1] = normaliser; mode 0: count(loss_pos > 0) (lightning.py:159-161),
  * mode 1: count(y != 0) (lightning.py:197-198) */
 int rt_loss_reduce(const float* loss_pos, const int64_t* y, int32_t M, int32_t mode, float* out, rt_stream_t stream);

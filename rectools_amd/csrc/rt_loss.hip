@@ -5,8 +5,9 @@
 //                   mat-vec; `_calc_bce_loss` / `_calc_gbce_loss` / `_calc_sampled_softmax_loss`
 //                   (lightning.py:164-212) then reduce it.  Here one wave per position keeps the session row in
 //                   registers, streams the 1+N candidate rows (16 lanes per row, 4 rows per step), and writes only
-//                   the [M, 1+N] logits and one loss value per position; the backward kernel turns dlogits into
-//                   d(session) in registers and atomically scatters d(item rows) into the dense table gradient.
+//                   the [M, 1+N] logits and one loss value per position; in training the same pass also yields
+//                   d(session) (online softmax) and dL/dlogits; the backward groups the (position, candidate) pairs by
+//                   item id (counting sort) and reduces every row of the dense table gradient exactly once.
 //  full softmax     logits come from the MFMA GEMM (rt_gemm) over the ACTIVE positions only (y != 0; the others
 //                   have zero loss and zero gradient, ignore_index=0 at lightning.py:157); `softmax_ce_rows`
 //                   converts each logits row in place into (softmax - onehot) * weight / norm and the two gradient
@@ -16,6 +17,7 @@
 //  loss reduction   sum(loss) / sum(loss > 0) for the softmax family (lightning.py:159-161), sum(loss) / sum(y != 0)
 //                   for BCE / gBCE (lightning.py:197-198).
 #include "rt_common.h"
+#include <cstdlib>
 #include "rt_scan.h"
 
 namespace {
@@ -38,7 +40,7 @@ struct SampledArgs {
   // backward
   const float* norm;                      // [1] normaliser produced by the reduction kernel
   float gscale;                           // upstream dL/dloss
-  float* d_sess; long long ld_dsess;      // [M, d] overwritten
+  float* d_sess; long long ld_dsess;      // [M, d] overwritten (training forward: UNIT gradient, upstream = norm = 1)
   float* d_table;                         // [V, d] overwritten (every row written exactly once)
   int V;
   float* glog;                            // [M, 1+N] dL/d(raw similarity) of every (position, candidate)
@@ -71,8 +73,19 @@ __device__ __forceinline__ void gbce_transform(double z, double beta, double& f,
   f = log(bq); df = db / bq;
 }
 
-// one wave per position; D4 = number of float4 per lane for a d-wide row split over 16 lanes (d <= 64*D4)
-template <int D4>
+// One wave per position; D4 = number of float4 per lane for a d-wide row split over 16 lanes (d <= 64*D4); the 4
+// quarter-waves stream 4 candidate rows per step.
+//
+// TRAIN = true is the training forward: the SAME pass over the candidate rows also produces the position-side half of
+// the backward — the reference's gather (3.4 GB at the C2 shape) is the whole cost of these kernels, and a separate
+// backward kernel for d_sess would read every row a second time.  For the sampled softmax the session gradient
+// sum_j softmax_j e_j is accumulated with an online softmax (running max / sum / rescaled accumulator per
+// quarter-wave, merged at the end — the flash-attention recurrence applied to the loss); BCE / gBCE gradients depend
+// on their own logit only and are accumulated directly.  Gradients are "unit" (upstream = 1, normaliser = 1): the
+// backward scales by gscale / norm once both exist.  Also takes the counting-sort ranks of the negatives.
+// SM = sampled softmax (fp32 only); !SM = BCE / gBCE (fp64 transforms) — separate instances keep the fp64 temporaries out
+// of the softmax kernel's register budget.
+template <int D4, bool TRAIN, bool SM>
 __global__ __launch_bounds__(256) void sampled_fwd_kernel(SampledArgs a) {
   __shared__ float s_z[4][260];
   __shared__ int s_cid[4][260];
@@ -82,8 +95,16 @@ __global__ __launch_bounds__(256) void sampled_fwd_kernel(SampledArgs a) {
   const int C = a.N + 1;
   const long long yy = a.y[m];
   float* zrow = a.logits + (long long)m * C;
-  if (yy == 0) {  // inactive: zero loss; logits are never read for it
-    if (lane == 0) a.loss_pos[m] = 0.f;
+  const int sub = lane & 15, grp = lane >> 4;
+  if (yy == 0) {  // inactive: zero loss and gradient, no pairs; logits are never read for it
+    if (lane == 0) { a.loss_pos[m] = 0.f; if (TRAIN) a.inv_ns[m] = 1.f; }
+    if (TRAIN && grp == 0) {
+#pragma unroll
+      for (int i = 0; i < D4; ++i) {
+        const int c = (sub + 16 * i) * 4;
+        if (c < a.d) *reinterpret_cast<f32x4*>(a.d_sess + (long long)m * a.ld_dsess + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
     return;
   }
   // candidate ids of this position -> LDS (coalesced), so the row gathers below do not wait on an id load each
@@ -91,7 +112,6 @@ __global__ __launch_bounds__(256) void sampled_fwd_kernel(SampledArgs a) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  const int sub = lane & 15, grp = lane >> 4;
   // session slice of this lane: float4 index sub + 16*i
   f32x4 sv[D4];
   float ss = 0.f;
@@ -104,33 +124,71 @@ __global__ __launch_bounds__(256) void sampled_fwd_kernel(SampledArgs a) {
     ss += sv[i][0] * sv[i][0] + sv[i][1] * sv[i][1] + sv[i][2] * sv[i][2] + sv[i][3] * sv[i][3];
   }
   ss = group16_sum(ss);
-  const float inv_ns = a.cosine ? 1.0f / fmaxf(sqrtf(ss), EPS_COS) : 1.0f;
+  const float ns = sqrtf(ss);
+  const float inv_ns = a.cosine ? 1.0f / fmaxf(ns, EPS_COS) : 1.0f;
+
+  // training state of this quarter-wave: accumulator of (weight_j * e_hat_j), online-softmax max / sum
+  f32x4 acc[D4];
+  float m_run = -INFINITY, l_run = 0.f;
+  if (TRAIN) {
+#pragma unroll
+    for (int i = 0; i < D4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
 #pragma unroll 2
   for (int j0 = 0; j0 < C; j0 += 4) {
     const int j = j0 + grp;
+    const bool valid = j < C;
     float dot = 0.f, ee = 0.f;
-    if (j < C) {
-      const long long cid = (j < 260) ? (long long)s_cid[wave][j] : ((j == 0) ? yy : a.neg[(long long)m * a.N + (j - 1)]);
-      const float* er = a.table + cid * (long long)a.d;
+    f32x4 ev[D4];
+    long long cid = 0;
+    if (valid) cid = (j < 260) ? (long long)s_cid[wave][j] : ((j == 0) ? yy : a.neg[(long long)m * a.N + (j - 1)]);
+    {
+      const float* er = a.table + cid * (long long)a.d;   // invalid slots read the PAD row: a valid address, weight 0
 #pragma unroll
       for (int i = 0; i < D4; ++i) {
         const int c = (sub + 16 * i) * 4;
-        if (c < a.d) {
-          f32x4 e = *reinterpret_cast<const f32x4*>(er + c);
-          dot += e[0] * sv[i][0] + e[1] * sv[i][1] + e[2] * sv[i][2] + e[3] * sv[i][3];
-          ee += e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3];
-        }
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        ev[i] = (valid && c < a.d) ? *reinterpret_cast<const f32x4*>(er + c) : z;
+        dot += ev[i][0] * sv[i][0] + ev[i][1] * sv[i][1] + ev[i][2] * sv[i][2] + ev[i][3] * sv[i][3];
+        ee += ev[i][0] * ev[i][0] + ev[i][1] * ev[i][1] + ev[i][2] * ev[i][2] + ev[i][3] * ev[i][3];
       }
     }
     dot = group16_sum(dot);
     ee = group16_sum(ee);
-    if (j < C && sub == 0) {
-      float z = dot;
-      if (a.cosine) z = z * inv_ns * (1.0f / fmaxf(sqrtf(ee), EPS_COS));
-      z *= a.inv_t;
+    const float einv = a.cosine ? 1.0f / fmaxf(sqrtf(ee), EPS_COS) : 1.0f;
+    float z = dot;
+    if (a.cosine) z = z * inv_ns * einv;
+    z *= a.inv_t;
+    if (valid && sub == 0) {
       if (j < 260) s_z[wave][j] = z;
       zrow[j] = z;
+      if (TRAIN && j != 0 && cid != 0) a.rank[m * C + j] = atomicAdd(a.count + cid, 1);   // rank of this pair inside its id
+    }
+    if (TRAIN) {
+      float wj;   // weight of e_hat_j in d s_hat, up to the factors applied after the loop
+      if (SM) {
+        const float m_new = valid ? fmaxf(m_run, z) : m_run;
+        const float alpha = (m_new == -INFINITY) ? 1.f : __expf(m_run - m_new);
+        wj = valid ? __expf(z - m_new) : 0.f;
+        l_run = l_run * alpha + wj;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < D4; ++i) acc[i] *= alpha;
+      } else {
+        double zd = (double)z, gd;
+        if (j == 0) {
+          double df = 1.0;
+          if (a.loss == LOSS_GBCE) { double f; gbce_transform(zd, a.gbce_beta, f, df); zd = f; }
+          gd = (sigmoid_d(zd) - 1.0) * df;
+        } else {
+          gd = sigmoid_d(zd);
+        }
+        wj = valid ? (float)(gd / (double)C) : 0.f;
+      }
+      const float we = wj * einv;
+#pragma unroll
+      for (int i = 0; i < D4; ++i) acc[i] += ev[i] * we;
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -139,150 +197,95 @@ __global__ __launch_bounds__(256) void sampled_fwd_kernel(SampledArgs a) {
 
   const float wgt = a.w[m];
   auto zat = [&](int j) -> float { return j < 260 ? s_z[wave][j] : zrow[j]; };
-  float out;
-  if (a.loss == LOSS_SAMPLED_SOFTMAX) {
-    float mx = -INFINITY;
+  float out, mx = 0.f, se = 1.f;
+  if (SM) {
+    mx = -INFINITY;
     for (int j = lane; j < C; j += 64) mx = fmaxf(mx, zat(j));
     mx = wave_max(mx);
-    float se = 0.f;
+    se = 0.f;
     for (int j = lane; j < C; j += 64) se += __expf(zat(j) - mx);
     se = wave_sum(se);
     out = (mx + __logf(se) - zat(0)) * wgt;
   } else {
-    double acc = 0.0;
+    double accd = 0.0;
     for (int j = lane; j < C; j += 64) {
       double z = (double)zat(j);
       if (j == 0) {
         if (a.loss == LOSS_GBCE) { double f, df; gbce_transform(z, a.gbce_beta, f, df); z = f; }
-        acc += softplus_d(-z);
+        accd += softplus_d(-z);
       } else {
-        acc += softplus_d(z);
+        accd += softplus_d(z);
       }
     }
-    acc = wave_sum_d(acc);
-    out = (float)(acc / (double)C) * wgt;
+    accd = wave_sum_d(accd);
+    out = (float)(accd / (double)C) * wgt;
   }
   if (lane == 0) a.loss_pos[m] = out;
-}
+  if (!TRAIN) return;
 
-// Backward, part 1 (one wave per position): dL/dz for the 1+N candidates -> glog (already / logits_t), the
-// session gradient d_sess = sum_j g_j * d z_j / d s (gather of candidate rows, no atomics), and the histogram of
-// candidate ids for the counting sort that groups the table-gradient work by row (part 2).
-template <int D4>
-__global__ __launch_bounds__(256) void sampled_bwd_pos_kernel(SampledArgs a) {
-  __shared__ float s_g[4][260];
-  __shared__ int s_cid[4][260];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int m = blockIdx.x * 4 + wave;
-  if (m >= a.M) return;
-  const int C = a.N + 1;
-  const long long yy = a.y[m];
-  const int sub = lane & 15, grp = lane >> 4;
-  float* drow = a.d_sess + (long long)m * a.ld_dsess;
-  if (yy == 0) {
-#pragma unroll
-    for (int i = 0; i < D4; ++i) {
-      const int c = (sub + 16 * i) * 4;
-      if (grp == 0 && c < a.d) *reinterpret_cast<f32x4*>(drow + c) = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    return;
-  }
-  const float* zrow = a.logits + (long long)m * C;
+  // ---- unit dL/d(raw similarity) of every candidate (consumed by the table-row reduction of the backward) ----
+  const float gs = wgt * a.inv_t;   // includes d z / d(raw similarity) = 1 / logits_t
   float* grow = a.glog + (long long)m * C;
-  const float wgt = a.w[m];
-  const float gs = a.gscale / a.norm[0] * wgt * a.inv_t;   // includes d z / d(raw similarity) = 1 / logits_t
-
-  // ---- dL/d(raw similarity) for this position ----
-  if (a.loss == LOSS_SAMPLED_SOFTMAX) {
-    float mx = -INFINITY;
-    for (int j = lane; j < C; j += 64) mx = fmaxf(mx, zrow[j]);
-    mx = wave_max(mx);
-    float se = 0.f;
-    for (int j = lane; j < C; j += 64) se += __expf(zrow[j] - mx);
-    se = wave_sum(se);
-    // positions whose weighted loss is not > 0 are outside the normaliser but still carry gradient in the
-    // reference (sum(loss) / sum(loss > 0)); keep that.
-    for (int j = lane; j < C; j += 64) {
-      float g = (__expf(zrow[j] - mx) / se - (j == 0 ? 1.f : 0.f)) * gs;
-      if (j < 260) s_g[wave][j] = g;
-      grow[j] = g;
-    }
-  } else {
-    for (int j = lane; j < C; j += 64) {
-      double z = (double)zrow[j];
-      double g;
+  for (int j = lane; j < C; j += 64) {
+    float g;
+    if (SM) {
+      // positions whose weighted loss is not > 0 are outside the normaliser but still carry gradient in the
+      // reference (sum(loss) / sum(loss > 0)); keep that.
+      g = (__expf(zat(j) - mx) / se - (j == 0 ? 1.f : 0.f)) * gs;
+    } else {
+      double z = (double)zat(j), gd;
       if (j == 0) {
         double df = 1.0;
         if (a.loss == LOSS_GBCE) { double f; gbce_transform(z, a.gbce_beta, f, df); z = f; }
-        g = (sigmoid_d(z) - 1.0) * df;
+        gd = (sigmoid_d(z) - 1.0) * df;
       } else {
-        g = sigmoid_d(z);
+        gd = sigmoid_d(z);
       }
-      float gf = (float)(g / (double)C) * gs;
-      if (j < 260) s_g[wave][j] = gf;
-      grow[j] = gf;
+      g = (float)(gd / (double)C) * gs;
     }
+    grow[j] = g;
   }
-  // histogram of the NEGATIVE ids (counting sort, pass 1; uniform samples, plain atomics) — the positives are
-  // popularity-skewed and counted by agg_hist_kernel; ids also staged in LDS for the gather loop
-  for (int j = lane; j < C; j += 64) {
-    const long long cid = (j == 0) ? yy : a.neg[(long long)m * a.N + (j - 1)];
-    if (j < 260) s_cid[wave][j] = (int)cid;
-    if (j != 0 && cid != 0) a.rank[m * C + j] = atomicAdd(a.count + cid, 1);   // rank of this pair inside its id
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-
-  // ---- session gradient (registers) ----
-  f32x4 sv[D4], ds[D4];
-  float ss = 0.f;
-  const float* srow = a.sess + (long long)m * a.ld_sess;
-#pragma unroll
-  for (int i = 0; i < D4; ++i) {
-    const int c = (sub + 16 * i) * 4;
-    f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    sv[i] = (c < a.d) ? *reinterpret_cast<const f32x4*>(srow + c) : z;
-    ds[i] = z;
-    ss += sv[i][0] * sv[i][0] + sv[i][1] * sv[i][1] + sv[i][2] * sv[i][2] + sv[i][3] * sv[i][3];
-  }
-  ss = group16_sum(ss);
-  const float ns = sqrtf(ss);
-  const float inv_ns = a.cosine ? 1.0f / fmaxf(ns, EPS_COS) : 1.0f;
   if (lane == 0) a.inv_ns[m] = inv_ns;
 
-#pragma unroll 2
-  for (int j0 = 0; j0 < C; j0 += 4) {
-    const int j = j0 + grp;
-    if (j < C) {  // uniform inside a 16-lane group
-      const long long cid = (j < 260) ? (long long)s_cid[wave][j] : ((j == 0) ? yy : a.neg[(long long)m * a.N + (j - 1)]);
-      const float g = (j < 260) ? s_g[wave][j] : grow[j];
-      const float* er = a.table + cid * (long long)a.d;
-      f32x4 ev[D4];
-      float ee = 0.f;
-#pragma unroll
-      for (int i = 0; i < D4; ++i) {
-        const int c = (sub + 16 * i) * 4;
-        f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        ev[i] = (c < a.d) ? *reinterpret_cast<const f32x4*>(er + c) : z;
-        if (a.cosine) ee += ev[i][0] * ev[i][0] + ev[i][1] * ev[i][1] + ev[i][2] * ev[i][2] + ev[i][3] * ev[i][3];
-      }
-      float ge = g;
-      if (a.cosine) { ee = group16_sum(ee); ge = g / fmaxf(sqrtf(ee), EPS_COS); }   // d s_hat += g * e_hat
-#pragma unroll
-      for (int i = 0; i < D4; ++i) ds[i] += ev[i] * ge;
-    }
+  // ---- session gradient: merge the 4 quarter-wave streams (lanes with equal `sub` hold the same columns) ----
+  float scale_g = 1.f;
+  if (SM) {
+    float mall = fmaxf(m_run, __shfl_xor(m_run, 16, 64));
+    mall = fmaxf(mall, __shfl_xor(mall, 32, 64));
+    scale_g = (m_run == -INFINITY) ? 0.f : __expf(m_run - mall);
+    float l = l_run * scale_g;
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    scale_g /= l;   // softmax_j = exp(z_j - mall) / l
   }
-  // combine the 4 candidate groups: lanes with equal `sub` hold the same slice
+  f32x4 ds[D4];
 #pragma unroll
   for (int i = 0; i < D4; ++i)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      float v = ds[i][e];
+      float v = acc[i][e] * scale_g;
       v += __shfl_xor(v, 16, 64);
       v += __shfl_xor(v, 32, 64);
       ds[i][e] = v;
     }
+  if (SM) {   // minus the positive's own row: d s_hat = sum_j softmax_j e_hat_j - e_hat_0
+    const float* er = a.table + yy * (long long)a.d;
+    f32x4 e0[D4];
+    float ee = 0.f;
+#pragma unroll
+    for (int i = 0; i < D4; ++i) {
+      const int c = (sub + 16 * i) * 4;
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      e0[i] = (c < a.d) ? *reinterpret_cast<const f32x4*>(er + c) : z;
+      ee += e0[i][0] * e0[i][0] + e0[i][1] * e0[i][1] + e0[i][2] * e0[i][2] + e0[i][3] * e0[i][3];
+    }
+    ee = group16_sum(ee);
+    const float einv0 = a.cosine ? 1.0f / fmaxf(sqrtf(ee), EPS_COS) : 1.0f;
+#pragma unroll
+    for (int i = 0; i < D4; ++i) ds[i] -= e0[i] * einv0;
+  }
+#pragma unroll
+  for (int i = 0; i < D4; ++i) ds[i] *= gs;
   if (a.cosine) {  // d s = (d s_hat - s_hat (s_hat . d s_hat)) / ns
     float proj = 0.f;
 #pragma unroll
@@ -297,11 +300,25 @@ __global__ __launch_bounds__(256) void sampled_bwd_pos_kernel(SampledArgs a) {
     }
   }
   if (grp == 0) {
+    float* drow = a.d_sess + (long long)m * a.ld_dsess;
 #pragma unroll
     for (int i = 0; i < D4; ++i) {
       const int c = (sub + 16 * i) * 4;
       if (c < a.d) *reinterpret_cast<f32x4*>(drow + c) = ds[i];
     }
+  }
+}
+
+// d_sess = unit gradient * gscale / norm
+__global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict__ src, long long ld_src, float* __restrict__ dst,
+                                                         long long ld_dst, int M, int d, const float* __restrict__ norm,
+                                                         float gscale) {
+  const float sc = gscale / norm[0];
+  const int per_row = d >> 2;
+  const long long n4 = (long long)M * per_row;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const long long r = i / per_row; const int c = (int)(i - r * per_row) * 4;
+    *reinterpret_cast<f32x4*>(dst + r * ld_dst + c) = *reinterpret_cast<const f32x4*>(src + r * ld_src + c) * sc;
   }
 }
 
@@ -372,6 +389,7 @@ __device__ __forceinline__ void finish_table_row(const SampledArgs& a, int id, i
                                                  f32x4 (&acc)[(D4 + 3) / 4], float bsum) {
   constexpr int NA = (D4 + 3) / 4;
   float* dr = a.d_table + (long long)id * a.d;
+  const float sc = a.gscale / a.norm[0];   // glog holds unit gradients (training forward)
   if (a.cosine && any) {
     const float* er = a.table + (long long)id * a.d;
     float ee = 0.f;
@@ -392,7 +410,7 @@ __device__ __forceinline__ void finish_table_row(const SampledArgs& a, int id, i
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const int c = lane * 4 + 256 * i;
-    if (c < a.d) *reinterpret_cast<f32x4*>(dr + c) = acc[i];
+    if (c < a.d) *reinterpret_cast<f32x4*>(dr + c) = acc[i] * sc;
   }
 }
 
@@ -583,18 +601,24 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
     *reinterpret_cast<f32x4*>(o + c) = *reinterpret_cast<const f32x4*>(src + (long long)r * lds_ + c);
 }
 
+// stage: 0 = inference forward, 1 = training forward (logits, loss, unit gradients, ranks), 2 = backward
 template <int D4>
-int launch_sampled(const SampledArgs& a, bool bwd, hipStream_t stream) {
+int launch_sampled(const SampledArgs& a, int stage, hipStream_t stream) {
   const int blocks = (a.M + 3) / 4;
-  if (!bwd) {
-    sampled_fwd_kernel<D4><<<blocks, 256, 0, stream>>>(a);
+  if (stage == 0) {
+    if (a.loss == LOSS_SAMPLED_SOFTMAX) sampled_fwd_kernel<D4, false, true><<<blocks, 256, 0, stream>>>(a);
+    else sampled_fwd_kernel<D4, false, false><<<blocks, 256, 0, stream>>>(a);
     RT_CHECK_LAUNCH();
     return RT_OK;
   }
   const int n = a.V + 1;
-  RT_CHECK_HIP(hipMemsetAsync(a.count, 0, sizeof(int) * ((size_t)n + 1), stream));   // + heavy_count
-  sampled_bwd_pos_kernel<D4><<<blocks, 256, 0, stream>>>(a);
-  RT_CHECK_LAUNCH();
+  if (stage == 1) {
+    RT_CHECK_HIP(hipMemsetAsync(a.count, 0, sizeof(int) * ((size_t)n + 1), stream));   // + heavy_count
+    if (a.loss == LOSS_SAMPLED_SOFTMAX) sampled_fwd_kernel<D4, true, true><<<blocks, 256, 0, stream>>>(a);
+    else sampled_fwd_kernel<D4, true, false><<<blocks, 256, 0, stream>>>(a);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+  }
   agg_rank_kernel<<<(a.M + AGG_T - 1) / AGG_T, AGG_T, 0, stream>>>(a.y, a.M, a.count, a.rank, a.N + 1);
   RT_CHECK_LAUNCH();
   { const int rc = exclusive_scan_counts(a.count, n, a.offsets, a.cursor, a.blocksum, stream); if (rc != RT_OK) return rc; }
@@ -609,12 +633,29 @@ int launch_sampled(const SampledArgs& a, bool bwd, hipStream_t stream) {
   }
   return RT_OK;
 }
-int dispatch_sampled(const SampledArgs& a, bool bwd, hipStream_t stream) {
-  if (a.d <= 64) return launch_sampled<1>(a, bwd, stream);
-  if (a.d <= 128) return launch_sampled<2>(a, bwd, stream);
-  if (a.d <= 256) return launch_sampled<4>(a, bwd, stream);
-  if (a.d <= 512) return launch_sampled<8>(a, bwd, stream);
+int dispatch_sampled(const SampledArgs& a, int stage, hipStream_t stream) {
+  if (a.d <= 64) return launch_sampled<1>(a, stage, stream);
+  if (a.d <= 128) return launch_sampled<2>(a, stage, stream);
+  if (a.d <= 256) return launch_sampled<4>(a, stage, stream);
+  if (a.d <= 512) return launch_sampled<8>(a, stage, stream);
   return RT_ERR_UNSUPPORTED;
+}
+
+// workspace shared by the training forward and the backward
+void carve_workspace(SampledArgs& a, void* workspace, int M, int N, int V) {
+  const size_t C = (size_t)N + 1, n = (size_t)V + 1;
+  float* f = reinterpret_cast<float*>(workspace);
+  a.glog = f; f += (size_t)M * C;
+  a.inv_ns = f; f += M;
+  int* ip = reinterpret_cast<int*>(f);
+  a.pairs = ip; ip += (size_t)M * C;
+  a.rank = ip; ip += (size_t)M * C;
+  a.count = ip; ip += n;
+  a.heavy_count = ip; ip += 1;   // directly behind count: one memset clears both
+  a.heavy_ids = ip; ip += (size_t)M * C / HEAVY_T + 1;
+  a.offsets = ip; ip += n;
+  a.cursor = ip; ip += n;
+  a.blocksum = ip;
 }
 
 }  // namespace
@@ -632,47 +673,58 @@ int rt_sampled_loss_fwd(const float* sess, int64_t ld_sess, const float* table, 
   a.sess = sess; a.ld_sess = ld_sess; a.table = table; a.y = reinterpret_cast<const long long*>(y);
   a.neg = reinterpret_cast<const long long*>(neg); a.w = w; a.M = M; a.N = N; a.d = d; a.loss = loss; a.cosine = cosine;
   a.inv_t = 1.0f / logits_t; a.gbce_beta = gbce_beta; a.logits = logits; a.loss_pos = loss_pos;
-  return dispatch_sampled(a, false, stream);
+  return dispatch_sampled(a, 0, stream);
 }
 
-// Host arithmetic: bytes of the int/float scratch rt_sampled_loss_bwd needs.
+// Host arithmetic: bytes of the scratch that rt_sampled_loss_fwd_train fills and rt_sampled_loss_bwd consumes.
 size_t rt_sampled_loss_bwd_workspace_bytes(int32_t M, int32_t N, int32_t V) {
   const size_t C = (size_t)N + 1, n = (size_t)V + 1;
   const size_t nb = (n + SCAN_T * SCAN_E - 1) / (SCAN_T * SCAN_E);
   return 4 * ((size_t)M * C * 3 + (size_t)M + 3 * n + nb + 64 + 2 + (size_t)M * C / HEAVY_T);
 }
 
-// d_sess [M,d] and d_table [V,d] are fully overwritten (no atomics on floats: the (position, candidate) pairs are
-// counting-sorted by candidate id and each table row is reduced by one wave).  workspace: see the query above.
-int rt_sampled_loss_bwd(const float* sess, int64_t ld_sess, const float* table, const int64_t* y, const int64_t* neg,
-                        const float* w, int32_t M, int32_t N, int32_t d, int32_t V, int32_t loss, int32_t cosine,
-                        float logits_t, double gbce_beta, const float* logits, const float* norm, float gscale,
-                        float* d_sess, int64_t ld_dsess, float* d_table, void* workspace, size_t workspace_bytes,
-                        hipStream_t stream) {
+// Training forward: everything rt_sampled_loss_fwd writes, plus — in `workspace` — the unit gradient of every logit,
+// the counting-sort ranks of the candidate ids and 1/|session| (cosine), and d_sess_unit [M,d] (upstream = norm = 1).
+// One pass over the candidate rows for any 1+N (online softmax for the sampled softmax gradient).
+int rt_sampled_loss_fwd_train(const float* sess, int64_t ld_sess, const float* table, const int64_t* y, const int64_t* neg,
+                              const float* w, int32_t M, int32_t N, int32_t d, int32_t V, int32_t loss, int32_t cosine,
+                              float logits_t, double gbce_beta, float* logits, float* loss_pos, float* d_sess_unit,
+                              int64_t ld_du, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   (void)hipGetLastError();
   if (M <= 0) return RT_OK;
-  if ((d & 3) || N < 0 || loss < LOSS_BCE || loss > LOSS_SAMPLED_SOFTMAX || (ld_sess & 3) || (ld_dsess & 3)) return RT_ERR_INVALID_ARG;
+  if ((d & 3) || N < 0 || loss < LOSS_BCE || loss > LOSS_SAMPLED_SOFTMAX || (ld_sess & 3) || (ld_du & 3)) return RT_ERR_INVALID_ARG;
   if ((long long)M * (N + 1) >= (1LL << 31)) return RT_ERR_UNSUPPORTED;
   if (workspace == nullptr || workspace_bytes < rt_sampled_loss_bwd_workspace_bytes(M, N, V)) return RT_ERR_WORKSPACE;
   SampledArgs a{};
   a.sess = sess; a.ld_sess = ld_sess; a.table = table; a.y = reinterpret_cast<const long long*>(y);
   a.neg = reinterpret_cast<const long long*>(neg); a.w = w; a.M = M; a.N = N; a.d = d; a.V = V; a.loss = loss; a.cosine = cosine;
-  a.inv_t = 1.0f / logits_t; a.gbce_beta = gbce_beta; a.logits = const_cast<float*>(logits); a.norm = norm; a.gscale = gscale;
-  a.d_sess = d_sess; a.ld_dsess = ld_dsess; a.d_table = d_table;
-  const size_t C = (size_t)N + 1, n = (size_t)V + 1;
-  float* f = reinterpret_cast<float*>(workspace);
-  a.glog = f; f += (size_t)M * C;
-  a.inv_ns = f; f += M;
-  int* ip = reinterpret_cast<int*>(f);
-  a.pairs = ip; ip += (size_t)M * C;
-  a.rank = ip; ip += (size_t)M * C;
-  a.count = ip; ip += n;
-  a.heavy_count = ip; ip += 1;   // directly behind count: one memset clears both
-  a.heavy_ids = ip; ip += (size_t)M * C / HEAVY_T + 1;
-  a.offsets = ip; ip += n;
-  a.cursor = ip; ip += n;
-  a.blocksum = ip;
-  return dispatch_sampled(a, true, stream);
+  a.inv_t = 1.0f / logits_t; a.gbce_beta = gbce_beta; a.logits = logits; a.loss_pos = loss_pos;
+  a.norm = nullptr; a.gscale = 1.f; a.d_sess = d_sess_unit; a.ld_dsess = ld_du;
+  carve_workspace(a, workspace, M, N, V);
+  return dispatch_sampled(a, 1, stream);
+}
+
+// Backward of the training forward (call once per forward: it consumes the ranks in `workspace`).  d_sess [M,d] =
+// d_sess_unit * gscale / norm; d_table [V,d] is fully overwritten — the (position, candidate) pairs are counting-sorted
+// by candidate id and each table row is reduced by one wave (a 16-wave workgroup for popular ids): no float atomics.
+int rt_sampled_loss_bwd(const float* sess, int64_t ld_sess, const float* table, const int64_t* y, const int64_t* neg,
+                        int32_t M, int32_t N, int32_t d, int32_t V, int32_t cosine, float logits_t, const float* logits,
+                        const float* norm, float gscale, const float* d_sess_unit, int64_t ld_du, float* d_sess,
+                        int64_t ld_dsess, float* d_table, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (M <= 0) return RT_OK;
+  if ((d & 3) || N < 0 || (ld_sess & 3) || (ld_dsess & 3) || (ld_du & 3)) return RT_ERR_INVALID_ARG;
+  if ((long long)M * (N + 1) >= (1LL << 31)) return RT_ERR_UNSUPPORTED;
+  if (workspace == nullptr || workspace_bytes < rt_sampled_loss_bwd_workspace_bytes(M, N, V)) return RT_ERR_WORKSPACE;
+  SampledArgs a{};
+  a.sess = sess; a.ld_sess = ld_sess; a.table = table; a.y = reinterpret_cast<const long long*>(y);
+  a.neg = reinterpret_cast<const long long*>(neg); a.M = M; a.N = N; a.d = d; a.V = V; a.cosine = cosine;
+  a.inv_t = 1.0f / logits_t; a.logits = const_cast<float*>(logits); a.norm = norm; a.gscale = gscale;
+  a.d_table = d_table;
+  carve_workspace(a, workspace, M, N, V);
+  scale_rows_kernel<<<rt_num_cus() * 4, 256, 0, stream>>>(d_sess_unit, ld_du, d_sess, ld_dsess, M, d, norm, gscale);
+  RT_CHECK_LAUNCH();
+  return dispatch_sampled(a, 2, stream);
 }
 
 // out[0] = sum(loss_pos) / normaliser, out[1] = normaliser;  mode 0: count(loss_pos > 0), mode 1: count(y != 0)

@@ -626,30 +626,38 @@ class _SampledLoss(torch.autograd.Function):
     def forward(ctx, sess, table, y, neg, w, loss, cosine, logits_t, beta):
         M, d = sess.shape
         N = neg.shape[-1]
-        logits = torch.empty((M, N + 1), dtype=torch.float32, device=sess.device)
-        loss_pos = torch.empty((M,), dtype=torch.float32, device=sess.device)
-        out = torch.empty((2,), dtype=torch.float32, device=sess.device)
-        _c("rt_sampled_loss_fwd", sess, sess.stride(0), table, y, neg, w, M, N, d, loss, int(cosine), float(logits_t),
-           float(beta), logits, loss_pos)
+        V = table.shape[0]
+        dev = sess.device
+        logits = torch.empty((M, N + 1), dtype=torch.float32, device=dev)
+        loss_pos = torch.empty((M,), dtype=torch.float32, device=dev)
+        out = torch.empty((2,), dtype=torch.float32, device=dev)
+        train = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        if train:  # one pass over the candidate rows also yields the unit gradients the backward needs
+            ws_bytes = _lib.load().rt_sampled_loss_bwd_workspace_bytes(M, N, V)
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+            du = torch.empty((M, d), dtype=torch.float32, device=dev)
+            _c("rt_sampled_loss_fwd_train", sess, sess.stride(0), table, y, neg, w, M, N, d, V, loss, int(cosine),
+               float(logits_t), float(beta), logits, loss_pos, du, d, ws, ws_bytes)
+            ctx.save_for_backward(sess, table, y, neg, logits, out, du, ws)
+        else:
+            _c("rt_sampled_loss_fwd", sess, sess.stride(0), table, y, neg, w, M, N, d, loss, int(cosine), float(logits_t),
+               float(beta), logits, loss_pos)
         _c("rt_loss_reduce", loss_pos, y, M, 0 if loss == LOSS_SAMPLED_SOFTMAX else 1, out)
-        ctx.save_for_backward(sess, table, y, neg, w, logits, out)
-        ctx.meta = (loss, cosine, logits_t, beta)
+        ctx.meta = (cosine, logits_t)
         ctx.mark_non_differentiable(logits)
         return out[0], logits
 
     @staticmethod
     def backward(ctx, gloss, _glogits):
-        sess, table, y, neg, w, logits, out = ctx.saved_tensors
-        loss, cosine, logits_t, beta = ctx.meta
+        sess, table, y, neg, logits, out, du, ws = ctx.saved_tensors
+        cosine, logits_t = ctx.meta
         M, d = sess.shape
         N = neg.shape[-1]
         V = table.shape[0]
         d_sess = torch.empty((M, d), dtype=torch.float32, device=sess.device)
         d_table = torch.empty_like(table)
-        ws_bytes = _lib.load().rt_sampled_loss_bwd_workspace_bytes(M, N, V)
-        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=sess.device)
-        _c("rt_sampled_loss_bwd", sess, sess.stride(0), table, y, neg, w, M, N, d, V, loss, int(cosine), float(logits_t),
-           float(beta), logits, out[1:], float(gloss), d_sess, d, d_table, ws, ws_bytes)
+        _c("rt_sampled_loss_bwd", sess, sess.stride(0), table, y, neg, M, N, d, V, int(cosine), float(logits_t), logits,
+           out[1:], float(gloss), du, d, d_sess, d, d_table, ws, ws.numel())
         return d_sess, d_table, None, None, None, None, None, None, None
 
 
