@@ -170,6 +170,8 @@ class FlatAdam:
         return 1.0 / world_size
 
     def step(self, world_size: int = 1) -> None:
+        if self.flat_p.is_cuda:
+            ops.join_side_streams()   # weight gradients may still be in flight on the wgrad stream
         scale = self.reduce_gradients(world_size)
         self.step_count += 1
         hyper = (self.step_count, float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(scale))

@@ -78,18 +78,76 @@ RNG = DropoutRng(0)
 
 
 # --------------------------------------------------------------------------------------------------
+# side stream for weight gradients
+# --------------------------------------------------------------------------------------------------
+# dW / db are needed only by the optimiser, while the data-gradient chain is the critical path of the backward pass.
+# Each exact-tile GEMM of the step fills 1.56 "rounds" of the 256 CUs (78% of the machine); issuing the wgrad products
+# on a second HIP stream lets their workgroups occupy the CUs that the dgrad products, the attention kernels and the
+# memory-bound row kernels leave idle.  The main stream re-joins (`join_side_streams`) in a callback the autograd
+# engine runs at the end of the backward pass.  RT_SIDE_STREAM=0 disables the second stream.
+_SIDE: tp.Dict[torch.device, "torch.cuda.Stream"] = {}
+_SIDE_DIRTY: tp.Set[torch.device] = set()
+
+
+def _side_enabled() -> bool:
+    import os
+
+    return os.environ.get("RT_SIDE_STREAM", "1") != "0" and _TIMING is None   # per-call timing needs one stream
+
+
+class _OnSide:
+    """Context: run the enclosed launches on the side stream, ordered after everything issued so far on the current one.
+    Tensors touched inside must be passed to `uses()` so that the caching allocator does not recycle them early."""
+
+    def __init__(self, dev: torch.device) -> None:
+        self.dev = dev
+        self.enabled = _side_enabled()
+
+    def __enter__(self) -> "_OnSide":
+        if self.enabled:
+            side = _SIDE.get(self.dev)
+            if side is None:
+                side = _SIDE[self.dev] = torch.cuda.Stream(device=self.dev)
+            side.wait_event(torch.cuda.current_stream(self.dev).record_event())
+            self.side = side
+            self.ctx = torch.cuda.stream(side)
+            self.ctx.__enter__()
+            if not _SIDE_DIRTY:  # join when the autograd engine has issued the whole backward pass
+                torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+            _SIDE_DIRTY.add(self.dev)
+        return self
+
+    def uses(self, *tensors: torch.Tensor) -> None:
+        if self.enabled:
+            for t in tensors:
+                t.record_stream(self.side)
+
+    def __exit__(self, *exc: tp.Any) -> None:
+        if self.enabled:
+            self.ctx.__exit__(*exc)
+
+
+def join_side_streams() -> None:
+    """Main stream waits for every weight-gradient product issued on a side stream."""
+    for dev in list(_SIDE_DIRTY):
+        torch.cuda.current_stream(dev).wait_event(_SIDE[dev].record_event())
+    _SIDE_DIRTY.clear()
+
+
+# --------------------------------------------------------------------------------------------------
 # dense
 # --------------------------------------------------------------------------------------------------
-_GEMM_WS: tp.Dict[torch.device, torch.Tensor] = {}
+_GEMM_WS: tp.Dict[tp.Tuple[torch.device, int], torch.Tensor] = {}
 
 
 def _gemm(A, lda, a_kc, B, ldb, b_kc, C, ldc, bias, R, ldr, M, N, K, relu=0, split_k=1, a_rowsum=None) -> None:
     ws, ws_bytes = None, 0
     if split_k > 1:
         ws_bytes = _lib.load().rt_gemm_workspace_bytes(M, N, K, split_k)
-        ws = _GEMM_WS.get(C.device)
-        if ws is None or ws.numel() < ws_bytes:  # one growing scratch per device (stream-ordered reuse)
-            ws = _GEMM_WS[C.device] = torch.empty((max(ws_bytes, 1 << 24),), dtype=torch.uint8, device=C.device)
+        key = (C.device, _lib.current_stream())
+        ws = _GEMM_WS.get(key)
+        if ws is None or ws.numel() < ws_bytes:  # one growing scratch per (device, stream): stream-ordered reuse
+            ws = _GEMM_WS[key] = torch.empty((max(ws_bytes, 1 << 24),), dtype=torch.uint8, device=C.device)
     _c("rt_gemm", A, lda, a_kc, B, ldb, b_kc, C, ldc, bias, R, ldr, a_rowsum, M, N, K, relu, split_k, ws, ws_bytes,
        tag=(M, N, K))
 
@@ -517,27 +575,35 @@ class _SASRecLayer(torch.autograd.Function):
         else:
             g_o = g_out
         d_w2, d_b2 = new(d, dff), new(d)
-        _gemm(g_o, d, 0, hdrop, dff, 0, d_w2, dff, None, None, 0, d, dff, M, 0, sp, d_b2)
+        with _OnSide(dev) as sd:   # weight gradients leave the critical path (see _OnSide)
+            sd.uses(g_o, hdrop, d_w2, d_b2)
+            _gemm(g_o, d, 0, hdrop, dff, 0, d_w2, dff, None, None, 0, d, dff, M, 0, sp, d_b2)
         g_hd = new(M, dff)
         _gemm(g_o, d, 1, w2, dff, 0, g_hd, dff, None, None, 0, M, dff, d)
         g_h = new(M, dff)   # dropout mask and relu'(h) in one pass (relu'(z) == [h > 0])
         _c("rt_act_dropout_bwd", g_hd, h, ACT_RELU, float(p), seed_h[0], seed_h[1], g_hd.numel(), g_h)
         d_w1, d_b1 = new(dff, d), new(dff)
-        _gemm(g_h, dff, 0, f, d, 0, d_w1, d, None, None, 0, dff, d, M, 0, sp, d_b1)
+        with _OnSide(dev) as sd:
+            sd.uses(g_h, f, d_w1, d_b1)
+            _gemm(g_h, dff, 0, f, d, 0, d_w1, d, None, None, 0, dff, d, M, 0, sp, d_b1)
         g_f = new(M, d)     # residual branch (g_out) added in the dgrad epilogue
         _gemm(g_h, dff, 1, w1, d, 0, g_f, d, None, g_out, d, M, d, dff)
         g_y, d_ln2w, d_ln2b = ln_bwd(g_f, y, ln2_w, mean2, rstd2)
         # ---- attention: y = q + Wo A + bo
         d_wo, d_bo = new(d, d), new(d)
-        _gemm(g_y, d, 0, A, d, 0, d_wo, d, None, None, 0, d, d, M, 0, sp, d_bo)
+        with _OnSide(dev) as sd:
+            sd.uses(g_y, A, d_wo, d_bo)
+            _gemm(g_y, d, 0, A, d, 0, d_wo, d, None, None, 0, d, d, M, 0, sp, d_bo)
         g_A = new(M, d)
         _gemm(g_y, d, 1, out_w, d, 0, g_A, d, None, None, 0, M, d, d)
         gQ, gKV, delta = new(M, d), new(M, 2 * d), new(B, H, L)
         _c("rt_mha_bwd", Q, d, KV, 2 * d, KV[:, d:], 2 * d, A, d, g_A, d, lse, ids, B, H, L, d // H, int(causal), int(keypad),
            float(p), seed_a, gQ, d, gKV, 2 * d, gKV[:, d:], 2 * d, delta)
         d_in_w, d_in_b = new(3 * d, d), new(3 * d)
-        _gemm(gQ, d, 0, q, d, 0, d_in_w, d, None, None, 0, d, d, M, 0, sp, d_in_b)
-        _gemm(gKV, 2 * d, 0, x0, d, 0, d_in_w[d:], d, None, None, 0, 2 * d, d, M, 0, sp, d_in_b[d:])
+        with _OnSide(dev) as sd:
+            sd.uses(gQ, gKV, q, x0, d_in_w, d_in_b)
+            _gemm(gQ, d, 0, q, d, 0, d_in_w, d, None, None, 0, d, d, M, 0, sp, d_in_b)
+            _gemm(gKV, 2 * d, 0, x0, d, 0, d_in_w[d:], d, None, None, 0, 2 * d, d, M, 0, sp, d_in_b[d:])
         g_q = new(M, d)     # q feeds the query projection and the residual: g_q = gQ Wq + g_y
         _gemm(gQ, d, 1, in_w, d, 0, g_q, d, None, g_y, d, M, d, d)
         g_x0a, d_ln1w, d_ln1b = ln_bwd(g_q, x0, ln1_w, mean1, rstd1)
