@@ -38,7 +38,7 @@ struct AttnArgs {
   const float* dout; long long lddo;       // backward input
   float* dq; float* dk; float* dv; long long lddq, lddk, lddv;
   float* lse;                              // [B,H,L] (softmax mode)
-  const float* delta;                      // [B,H,L] rowsum(dO * O) (softmax backward)
+  float* delta;                            // [B,H,L] rowsum(dO * O): written by the dQ kernel, read by the dK/dV kernel
   const long long* ids;                    // [B,L] item ids (0 = PAD)
   int B, H, L, hd;
   int causal, keypad;
@@ -212,12 +212,17 @@ __device__ __forceinline__ void fwd_store(const AttnArgs& a, int bh, int qq, int
     if (half == 0) a.lse[((long long)bh) * a.L + qq] = (l_run > 0.f) ? m_run + __logf(l_run) : -INFINITY;
   }
   float* ob = a.o + (rowbase + qq) * a.ldo + h * a.hd;
+  // registers 4j..4j+3 of a tile hold the 4 consecutive columns 8j + 4*half ..+3: one 16-byte store each (a scalar
+  // store of this transposed tile touches 64 different rows per instruction and made the epilogue TA-bound)
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int dd = nt * 32 + row_of(r, half);
-      if (dd < a.hd) ob[dd] = oacc[nt][r] * inv;
+    for (int j = 0; j < 4; ++j) {
+      const int dd = nt * 32 + 8 * j + 4 * half;
+      if (dd < a.hd) {   // hd % 8 == 0: all four columns are inside
+        f32x4 v = {oacc[nt][4 * j] * inv, oacc[nt][4 * j + 1] * inv, oacc[nt][4 * j + 2] * inv, oacc[nt][4 * j + 3] * inv};
+        *reinterpret_cast<f32x4*>(ob + dd) = v;
+      }
     }
 }
 
@@ -357,6 +362,21 @@ __device__ __forceinline__ void dkv_pair(const AttnArgs& a, const float* Qt, con
   }
 }
 
+// delta_q = sum_dd dO[q][dd] * O[q][dd] from the dO fragments the dQ kernel holds anyway (one extra row read of O, no
+// separate pass over dO and O); both half-waves end up with the full sum, lanes of half 0 publish it
+template <int HDV>
+__device__ __forceinline__ float delta_from_frags(const AttnArgs& a, const float* ob_head, int qq, int half, int bh,
+                                                  const f32x4 (&gf)[HDV]) {
+  f32x4 of[HDV];
+  load_row_frags<HDV>(ob_head, a.ldo, qq, a.L, a.hd, half, of);
+  float dsum = 0.f;
+#pragma unroll
+  for (int s = 0; s < HDV; ++s) dsum += gf[s][0] * of[s][0] + gf[s][1] * of[s][1] + gf[s][2] * of[s][2] + gf[s][3] * of[s][3];
+  dsum += __shfl_xor(dsum, 32, 64);
+  if (half == 0 && qq < a.L) a.delta[(long long)bh * a.L + qq] = dsum;
+  return dsum;
+}
+
 template <int HD>
 __device__ __forceinline__ void store_rows_T(float* base, long long ld, int row, int n_rows, int hd, int half,
                                              const f32x16 (&acc)[HD / 32]) {
@@ -365,9 +385,12 @@ __device__ __forceinline__ void store_rows_T(float* base, long long ld, int row,
 #pragma unroll
   for (int nt = 0; nt < HD / 32; ++nt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int dd = nt * 32 + row_of(r, half);
-      if (dd < hd) ob[dd] = acc[nt][r];
+    for (int j = 0; j < 4; ++j) {   // 4 consecutive columns per 16-byte store (see fwd_store)
+      const int dd = nt * 32 + 8 * j + 4 * half;
+      if (dd < hd) {
+        f32x4 v = {acc[nt][4 * j], acc[nt][4 * j + 1], acc[nt][4 * j + 2], acc[nt][4 * j + 3]};
+        *reinterpret_cast<f32x4*>(ob + dd) = v;
+      }
     }
 }
 
@@ -398,23 +421,6 @@ __device__ __forceinline__ void hstu_flush_grads(const AttnArgs& a, const HstuLd
 }
 constexpr int hstu_lds_floats(int L, bool with_grads) {
   return (NBUCK + 3) + ((2 * L + 3) & ~3) + 2 * (NBUCK + 1) + 2 * (L + 2) + (with_grads ? (NBUCK + 3) + ((2 * L + 3) & ~3) : 0);
-}
-
-// delta[b,h,q] = sum_dd dO[q][dd] * O[q][dd]
-__global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ dout, long long lddo,
-                                                         const float* __restrict__ o, long long ldo, int B, int H, int L,
-                                                         int hd, float* __restrict__ delta) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over B*H*L
-  if (idx >= (long long)B * H * L) return;
-  const int qq = idx % L; const int h = (idx / L) % H; const int b = idx / ((long long)L * H);
-  const float* g = dout + ((long long)b * L + qq) * lddo + h * hd;
-  const float* oo = o + ((long long)b * L + qq) * ldo + h * hd;
-  float s = 0.f;
-  for (int c = 0; c < hd; c += 4) {
-    f32x4 x = *reinterpret_cast<const f32x4*>(g + c), y = *reinterpret_cast<const f32x4*>(oo + c);
-    s += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
-  }
-  delta[idx] = s;
 }
 
 // ===================================================================================================
@@ -505,7 +511,10 @@ __global__ __launch_bounds__(AT) void attn_bwd_dq_kernel(AttnArgs a) {
   load_row_frags<HDV>(gb, a.lddo, qq, a.L, a.hd, half, gf);
   const bool q_is_pad = (qq < a.L) ? (idb[qq] == 0) : true;
   float lse_q = 0.f, delta_q = 0.f;
-  if (MODE == MODE_SOFTMAX && qq < a.L) { lse_q = a.lse[(long long)bh * a.L + qq]; delta_q = a.delta[(long long)bh * a.L + qq]; }
+  if (MODE == MODE_SOFTMAX) {
+    if (qq < a.L) lse_q = a.lse[(long long)bh * a.L + qq];
+    delta_q = delta_from_frags<HDV>(a, a.o + rowbase * a.ldo + h * a.hd, qq, half, bh, gf);
+  }
   long long t_q1 = 0;
   f32x16 dqacc[NT];
 #pragma unroll
@@ -740,7 +749,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(AttnArgs a) {
     load_row_frags<HDV>(gb, a.lddo, qq, a.L, a.hd, half, gf);
     const bool q_is_pad = (qq < a.L) ? (idb[qq] == 0) : true;
     float lse_q = 0.f, delta_q = 0.f;
-    if (MODE == MODE_SOFTMAX && qq < a.L) { lse_q = a.lse[(long long)bh * a.L + qq]; delta_q = a.delta[(long long)bh * a.L + qq]; }
+    if (MODE == MODE_SOFTMAX) {
+      if (qq < a.L) lse_q = a.lse[(long long)bh * a.L + qq];
+      delta_q = delta_from_frags<HDV>(a, a.o + rowbase * a.ldo + h * a.hd, qq, half, bh, gf);
+    }
     long long t_q1 = 0;
     if (MODE == MODE_HSTU && a.ts && qq < a.L) t_q1 = hl.ts[qq + 1];
     f32x16 dqacc[NT];
@@ -924,6 +936,7 @@ int dispatch_bwd(const AttnArgs& a_in, hipStream_t s) {
   return launch_bwd<MODE, 128>(a, s);
 }
 
+inline bool misaligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
 inline bool bad_common(int B, int H, int L, int hd, int64_t ldq, int64_t ldk, int64_t ldv) {
   return B <= 0 || H <= 0 || L <= 0 || hd <= 0 || (hd & 7) != 0 || hd > 128 || (ldq & 3) || (ldk & 3) || (ldv & 3);
 }
@@ -937,7 +950,7 @@ int rt_mha_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const f
                const int64_t* ids, int32_t B, int32_t H, int32_t L, int32_t hd, int32_t causal, int32_t keypad,
                float p_drop, uint64_t seed, float* o, int64_t ldo, float* lse, hipStream_t stream) {
   (void)hipGetLastError();
-  if (bad_common(B, H, L, hd, ldq, ldk, ldv) || (ldo & 3)) return RT_ERR_INVALID_ARG;
+  if (bad_common(B, H, L, hd, ldq, ldk, ldv) || (ldo & 3) || misaligned16(o)) return RT_ERR_INVALID_ARG;
   AttnArgs a{};
   a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.o = o; a.ldo = ldo; a.lse = lse;
   a.ids = reinterpret_cast<const long long*>(ids); a.B = B; a.H = H; a.L = L; a.hd = hd;
@@ -945,20 +958,18 @@ int rt_mha_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const f
   return dispatch_fwd<MODE_SOFTMAX>(a, stream);
 }
 
-// softmax attention backward.  delta: [B,H,L] workspace (filled here).  dq/dk/dv fully overwritten.
+// softmax attention backward.  delta: [B,H,L] workspace (rowsum(dO*O), filled by the dQ kernel).  dq/dk/dv fully overwritten.
 int rt_mha_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                const float* o, int64_t ldo, const float* dout, int64_t lddo, const float* lse, const int64_t* ids,
                int32_t B, int32_t H, int32_t L, int32_t hd, int32_t causal, int32_t keypad, float p_drop, uint64_t seed,
                float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv, float* delta,
                hipStream_t stream) {
   (void)hipGetLastError();
-  if (bad_common(B, H, L, hd, ldq, ldk, ldv) || (ldo & 3) || (lddo & 3)) return RT_ERR_INVALID_ARG;
-  const long long n = (long long)B * H * L;
-  attn_delta_kernel<<<(int)((n + 255) / 256), 256, 0, stream>>>(dout, lddo, o, ldo, B, H, L, hd, delta);
-  RT_CHECK_LAUNCH();
+  if (bad_common(B, H, L, hd, ldq, ldk, ldv) || (ldo & 3) || (lddo & 3) || (lddq & 3) || (lddk & 3) || (lddv & 3) ||
+      misaligned16(dq) || misaligned16(dk) || misaligned16(dv)) return RT_ERR_INVALID_ARG;
   AttnArgs a{};
   a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.dout = dout; a.lddo = lddo;
-  a.lse = const_cast<float*>(lse); a.delta = delta;
+  a.lse = const_cast<float*>(lse); a.delta = delta; a.o = const_cast<float*>(o); a.ldo = ldo;
   a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   a.ids = reinterpret_cast<const long long*>(ids); a.B = B; a.H = H; a.L = L; a.hd = hd;
   a.causal = causal; a.keypad = keypad; a.scale = 1.0f / sqrtf((float)hd); a.p_drop = p_drop; a.seed = seed;
@@ -972,7 +983,7 @@ int rt_hstu_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, c
                      const float* pos_w, int32_t B, int32_t H, int32_t L, int32_t hd, float* o, int64_t ldo,
                      hipStream_t stream) {
   (void)hipGetLastError();
-  if (bad_common(B, H, L, hd, ldq, ldk, ldv) || (ldo & 3)) return RT_ERR_INVALID_ARG;
+  if (bad_common(B, H, L, hd, ldq, ldk, ldv) || (ldo & 3) || misaligned16(o)) return RT_ERR_INVALID_ARG;
   if ((time_w != nullptr) != (ts != nullptr) || (time_w != nullptr) != (time_thr != nullptr)) return RT_ERR_INVALID_ARG;
   AttnArgs a{};
   a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.o = o; a.ldo = ldo;
@@ -989,7 +1000,8 @@ int rt_hstu_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, c
                      float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv, float* d_time_w,
                      float* d_pos_w, hipStream_t stream) {
   (void)hipGetLastError();
-  if (bad_common(B, H, L, hd, ldq, ldk, ldv) || (lddo & 3)) return RT_ERR_INVALID_ARG;
+  if (bad_common(B, H, L, hd, ldq, ldk, ldv) || (lddo & 3) || (lddq & 3) || (lddk & 3) || (lddv & 3) || misaligned16(dq) ||
+      misaligned16(dk) || misaligned16(dv)) return RT_ERR_INVALID_ARG;
   AttnArgs a{};
   a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.dout = dout; a.lddo = lddo;
   a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
