@@ -420,14 +420,22 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int TU, int NS, bool WL, bool LL>
-__global__ __launch_bounds__(NTHREADS) void topk_stream_kernel(TopkArgs a) {
+// NLD = 0: every wave both issues its share of the DMA ring and computes.  NLD = 2: waves 4,5 are LOADERS — they issue
+// all LDS-DMA pieces and wait for them — and waves 0..3 only compute.  An LDS-DMA instruction costs 60-185 issue
+// cycles in the wave that issues it (address VALU + the piece itself); with 6 pieces per 16 MFMAs that is a third of
+// a compute wave's time at 32 users per launch, exactly the regime where the kernel should be HBM-bound.  A loader
+// shares its SIMD's issue port with one compute wave, but its pieces overlap that wave's MFMA execution.
+template <int TU, int NS, bool WL, bool LL, int NLD>
+__global__ __launch_bounds__(NTHREADS + NLD * 64) void topk_stream_kernel(TopkArgs a) {
+  constexpr int NISS = NLD ? NLD : 4;      // issuing waves
+  constexpr int IPI = 16 / NISS;           // item pieces per issuer and stage (128 rows x 32 floats = 16 KiB = 16 pieces)
+  constexpr int UPI = 4 * TU / NISS;       // user pieces per issuer and stage
   constexpr int UB = 32 * TU;
   constexpr int SA = IB * KC;            // floats per stage, items
   constexpr int SU = UB * KC;            // floats per stage, users
   constexpr int SG = 128;                // shared-bound copy (uints), refreshed with every stage
   constexpr int STAGE = SA + SU + SG;
-  constexpr int NL = 5 + TU;             // LDS-DMA instructions per thread per stage
+  constexpr int NL = IPI + UPI + 1;      // LDS-DMA instructions per issuing wave per stage
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [NS][STAGE]
 
   const int tid = threadIdx.x;
@@ -444,40 +452,46 @@ __global__ __launch_bounds__(NTHREADS) void topk_stream_kernel(TopkArgs a) {
   const long long my_blocks = ((int)blockIdx.x < S && n_blocks > blockIdx.x) ? (n_blocks - blockIdx.x + S - 1) / S : 0;
   const long long T = my_blocks * n_chunks;  // flattened (block, chunk) steps of this workgroup
 
-  const int list_id = blockIdx.x * LISTS_PER_WG + wave * 2 + half;
+  const bool issuer = NLD ? wave >= 4 : true;
+  const bool computes = NLD ? wave < 4 : true;
+  const int iw = NLD ? wave - 4 : wave;   // index among the issuing waves
+  const int cwave = computes ? wave : 0;
+  const int list_id = blockIdx.x * LISTS_PER_WG + cwave * 2 + half;
   SelState<TU, LL> st;
   st.init();
-  st.bind_lds(smem + NS * STAGE, a.k, wave, lane);
-  st.bind_global(a, list_id, user0, lane);
-  if (a.resume) st.resume(a, list_id, user0, lane, LL);
-  if (T == 0) { if (!a.resume) publish_counts<TU, LL>(a, st, list_id, user0, lane, false); return; }
+  if (computes) {
+    st.bind_lds(smem + NS * STAGE, a.k, cwave, lane);
+    st.bind_global(a, list_id, user0, lane);
+    if (a.resume) st.resume(a, list_id, user0, lane, LL);
+  }
+  if (T == 0) { if (computes && !a.resume) publish_counts<TU, LL>(a, st, list_id, user0, lane, false); return; }
 
   // ---- DMA source assignment ----
-  // items: instruction j of wave w fills rows (w*4+j)*8 .. +7 ; lane -> row + (lane>>3), slot lane&7
+  // items: piece j of issuer w fills rows (w*IPI+j)*8 .. +7 ; lane -> row + (lane>>3), slot lane&7
   const int l_row8 = lane >> 3, l_slot = lane & 7;
-  int i_row[4]; int i_colofs[4];
+  int i_row[IPI]; int i_colofs[IPI];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    i_row[j] = (wave * 4 + j) * 8 + l_row8;
+  for (int j = 0; j < IPI; ++j) {
+    i_row[j] = (iw * IPI + j) * 8 + l_row8;
     i_colofs[j] = (l_slot ^ ((i_row[j] >> 1) & 7)) * 4;  // logical float offset inside the chunk
   }
-  // users: instruction j of wave w fills user rows (j*4 + w)*8 .. +7   (TU instructions per wave)
-  const float* u_src[TU]; int u_row[TU];
+  // users: piece j of issuer w fills user rows (j*NISS + w)*8 .. +7   (UPI pieces per issuer)
+  const float* u_src[UPI]; int u_row[UPI];
 #pragma unroll
-  for (int j = 0; j < TU; ++j) {
-    u_row[j] = (j * 4 + wave) * 8 + l_row8;
+  for (int j = 0; j < UPI; ++j) {
+    u_row[j] = (j * NISS + iw) * 8 + l_row8;
     int u = user0 + u_row[j];
     if (u >= a.n_users) u = a.n_users - 1;  // clamp: padded user columns are never selected
     long long src = a.user_rows ? a.user_rows[u] : (long long)u;
     u_src[j] = a.users + src * a.user_stride + (l_slot ^ ((u_row[j] >> 1) & 7)) * 4;
   }
 
-  const float* i_src[4];
+  const float* i_src[IPI];
   auto set_item_rows = [&](long long blk_local) {
     const long long pos0 = (a.blk_begin + blockIdx.x + blk_local * S) * IB;
-    long long p[4];
+    long long p[IPI];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < IPI; ++j) {
       p[j] = pos0 + i_row[j];
       if (p[j] >= a.n_cand) p[j] = a.n_cand - 1;  // clamp: rows past the end are masked at selection
     }
@@ -485,36 +499,40 @@ __global__ __launch_bounds__(NTHREADS) void topk_stream_kernel(TopkArgs a) {
       // whitelist indirection, once per item block.  Loaded through inline asm with its own full wait:
       // a compiler-visible load inside the streaming loop makes hipcc place `s_waitcnt vmcnt(0)` in
       // front of the fragment reads of EVERY chunk (register-reuse hazard), draining the DMA ring.
-      long long s0, s1, s2, s3;
-      asm volatile(
-          "global_load_dwordx2 %0, %4, off\n\tglobal_load_dwordx2 %1, %5, off\n\t"
-          "global_load_dwordx2 %2, %6, off\n\tglobal_load_dwordx2 %3, %7, off\n\ts_waitcnt vmcnt(0)"
-          : "=&v"(s0), "=&v"(s1), "=&v"(s2), "=&v"(s3)
-          : "v"(a.whitelist + p[0]), "v"(a.whitelist + p[1]), "v"(a.whitelist + p[2]), "v"(a.whitelist + p[3])
-          : "memory");
-      p[0] = s0; p[1] = s1; p[2] = s2; p[3] = s3;
+      // (loads and their wait live in ONE asm statement: the results must not be touched before the s_waitcnt)
+#pragma unroll
+      for (int j0 = 0; j0 < IPI; j0 += 4) {
+        long long s0, s1, s2, s3;
+        asm volatile(
+            "global_load_dwordx2 %0, %4, off\n\tglobal_load_dwordx2 %1, %5, off\n\t"
+            "global_load_dwordx2 %2, %6, off\n\tglobal_load_dwordx2 %3, %7, off\n\ts_waitcnt vmcnt(0)"
+            : "=&v"(s0), "=&v"(s1), "=&v"(s2), "=&v"(s3)
+            : "v"(a.whitelist + p[j0]), "v"(a.whitelist + p[j0 + 1]), "v"(a.whitelist + p[j0 + 2]), "v"(a.whitelist + p[j0 + 3])
+            : "memory");
+        p[j0] = s0; p[j0 + 1] = s1; p[j0 + 2] = s2; p[j0 + 3] = s3;
+      }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) i_src[j] = a.items + p[j] * a.item_stride + i_colofs[j];
+    for (int j = 0; j < IPI; ++j) i_src[j] = a.items + p[j] * a.item_stride + i_colofs[j];
   };
   const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
-  // shared-bound copy: waves 0/2 bring users [0,64), waves 1/3 users [64,128) of this tile (4 B per lane)
-  int g_idx = user0 + (wave & 1) * 64 + lane;
+  // shared-bound copy: issuers 0/2 bring users [0,64), issuers 1/3 users [64,128) of this tile (4 B per lane)
+  int g_idx = user0 + (iw & 1) * 64 + lane;
   if (g_idx >= a.n_users_pad) g_idx = a.n_users_pad - 1;
   const unsigned* g_src = a.gthr + g_idx;
   auto issue = [&](int stage, int c) {  // DMA chunk c (already rotated) of the current issue block
     const unsigned sbase = smem_base + (unsigned)(stage * STAGE * 4);
     const int kofs = c * KC;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dma16(i_src[j] + kofs, sbase + (unsigned)((wave * 4 + j) * 8 * KC * 4));
+    for (int j = 0; j < IPI; ++j) dma16(i_src[j] + kofs, sbase + (unsigned)((iw * IPI + j) * 8 * KC * 4));
 #pragma unroll
-    for (int j = 0; j < TU; ++j) dma16(u_src[j] + kofs, sbase + (unsigned)((SA + (j * 4 + wave) * 8 * KC) * 4));
-    dma4(g_src, sbase + (unsigned)((SA + SU + (wave & 1) * 64) * 4));
+    for (int j = 0; j < UPI; ++j) dma16(u_src[j] + kofs, sbase + (unsigned)((SA + (j * NISS + iw) * 8 * KC) * 4));
+    dma4(g_src, sbase + (unsigned)((SA + SU + (iw & 1) * 64) * 4));
   };
 
   // ---- prologue: NS-1 stages in flight ----
   long long iss_blk = 0; int iss_c = 0; long long issued = 0; int iss_stage = 0;
-  set_item_rows(0);
+  if (issuer) set_item_rows(0);
   auto issue_next = [&]() {
     int cc = iss_c + rot; if (cc >= n_chunks) cc -= n_chunks;
     issue(iss_stage, cc);
@@ -522,8 +540,21 @@ __global__ __launch_bounds__(NTHREADS) void topk_stream_kernel(TopkArgs a) {
     ++issued; ++iss_c;
     if (iss_c == n_chunks) { iss_c = 0; ++iss_blk; if (iss_blk < my_blocks) set_item_rows(iss_blk); }
   };
+  if (issuer) {
 #pragma unroll 1
-  for (int s = 0; s < NS - 1; ++s) if (issued < T) issue_next();
+    for (int s = 0; s < NS - 1; ++s) if (issued < T) issue_next();
+  }
+  if (NLD && !computes) {   // loader: keep the ring full, one barrier per chunk in step with the compute waves
+#pragma unroll 1
+    for (long long g = 0; g < T; ++g) {
+      if (issued - g == NS - 1) wait_vmcnt<NL*(NS - 2)>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();   // chunk g is in LDS; the compute waves are done with chunk g-1
+      asm volatile("" ::: "memory");
+      if (issued < T) issue_next();
+    }
+    return;
+  }
 
   f32x16 acc[TU];
   float nrm_i = 0.f; float nrm_u[TU];
@@ -535,7 +566,7 @@ __global__ __launch_bounds__(NTHREADS) void topk_stream_kernel(TopkArgs a) {
   }
 
   // fragment read offsets (swizzled)
-  const int a_row = wave * 32 + col;
+  const int a_row = cwave * 32 + col;
   const int a_swz = (a_row >> 1) & 7;
   int u_swz[TU];
 #pragma unroll
@@ -548,11 +579,13 @@ __global__ __launch_bounds__(NTHREADS) void topk_stream_kernel(TopkArgs a) {
 #pragma unroll 1
     for (int c = 0; c < n_chunks; ++c, ++g) {
       // chunk g landed?  outstanding stages allowed: NS-2 in steady state, 0 in the drain
-      if (issued - g == NS - 1) wait_vmcnt<NL*(NS - 2)>();
-      else wait_vmcnt<0>();
+      if (NLD == 0) {
+        if (issued - g == NS - 1) wait_vmcnt<NL*(NS - 2)>();
+        else wait_vmcnt<0>();
+      }
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (issued < T) issue_next();  // refill the buffer consumed at step g-1
+      if (NLD == 0 && issued < T) issue_next();  // refill the buffer consumed at step g-1
 
       const float* sbase = smem + cons_stage * STAGE;
       cons_stage = (cons_stage + 1 == NS) ? 0 : cons_stage + 1;
@@ -574,7 +607,7 @@ __global__ __launch_bounds__(NTHREADS) void topk_stream_kernel(TopkArgs a) {
       }
     }
     const long long pos0 = (a.blk_begin + blockIdx.x + blk_local * S) * IB;
-    if (!(a.debug & 1)) select_block<TU, LL, true>(a, st, acc, nrm_i, nrm_u, pos0, list_id, user0, lane, wave, g_lds);
+    if (!(a.debug & 1)) select_block<TU, LL, true>(a, st, acc, nrm_i, nrm_u, pos0, list_id, user0, lane, cwave, g_lds);
     else if (acc[0][0] + nrm_i == 1.2345e30f) st.cnt[0] = 1;
     nrm_i = 0.f;
 #pragma unroll
@@ -798,19 +831,28 @@ inline Plan make_plan(int n_users, long long n_cand, int k, int users_per_pass) 
   return P;
 }
 
-template <int TU, int NS, bool WL, bool LL>
-int launch_stream_impl(const TopkArgs& a, dim3 grid, hipStream_t stream) {
-  constexpr int UB = 32 * TU;
+template <int TU, int NS, bool WL, bool LL, int NLD>
+int launch_stream_nld(const TopkArgs& a, dim3 grid, hipStream_t stream) {
   const size_t lds = stream_lds_bytes(TU, NS, LL ? a.k : 0);
   static size_t attr_lds = 0;
   if (lds > 64 * 1024 && lds > attr_lds) {
-    RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_stream_kernel<TU, NS, WL, LL>),
+    RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_stream_kernel<TU, NS, WL, LL, NLD>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_lds = lds;
   }
-  topk_stream_kernel<TU, NS, WL, LL><<<grid, NTHREADS, lds, stream>>>(a);
+  topk_stream_kernel<TU, NS, WL, LL, NLD><<<grid, NTHREADS + NLD * 64, lds, stream>>>(a);
   RT_CHECK_LAUNCH();
   return RT_OK;
+}
+// RT_TOPK_LOADERS: 0 = every wave issues and computes, 2 = two dedicated loader waves (default for the small user tiles
+// that are HBM-bound; the 128-user tile is MFMA-bound and keeps its issue slots for compute waves only)
+template <int TU, int NS, bool WL, bool LL>
+int launch_stream_impl(const TopkArgs& a, dim3 grid, hipStream_t stream) {
+  static const int loaders = env_int("RT_TOPK_LOADERS", TU <= 2 ? 2 : 0);
+  if constexpr (TU <= 2) {   // vmcnt is a 6-bit counter: (8 + 2 TU + 1) pieces x (NS - 2) stages must stay below 64
+    if (loaders == 2) return launch_stream_nld<TU, NS, WL, LL, 2>(a, grid, stream);
+  }
+  return launch_stream_nld<TU, NS, WL, LL, 0>(a, grid, stream);
 }
 template <int TU, int NS>
 int launch_stream(const TopkArgs& a, dim3 grid, bool lds_lists, hipStream_t stream) {
