@@ -56,6 +56,8 @@ const char* rt_last_error(void);
  *               [lo, lo+n) is passed as items + lo*item_stride, candidate_id_offset = lo)
  *  filt_indptr  nullable [n_users+1] int64, filt_indices int32 ascending per row, in the id space of
  *               `whitelist` values (full item ids): pairs that must not be recommended
+ *  filt_hash    nullable: per-user hash sets over the same CSR (rt_filter_hash_build) — membership in 1-2 loads
+ *               instead of a binary search of the row; worth building when many users meet a small catalog
  *  k            1 <= k <= n_candidates (caller clamps, as rank_torch.py:148 does)
  *  out_ids      [n_users, k] int64 item ids (whitelist-mapped), best first; out_scores [n_users, k];
  *               out_counts [n_users] number of valid leading entries (< k only when the filter leaves
@@ -65,11 +67,14 @@ const char* rt_last_error(void);
  *  d, strides must be multiples of 4 floats and base pointers 16-byte aligned.
  * ------------------------------------------------------------------------------------------------ */
 size_t rt_topk_workspace_bytes(int32_t n_users, int64_t n_candidates, int32_t k, int32_t users_per_pass);
+size_t rt_filter_hash_bytes(int32_t n_users, int64_t nnz);
+int rt_filter_hash_build(const int64_t* filt_indptr, const int32_t* filt_indices, int32_t n_users, int64_t nnz, int32_t* hash,
+                         rt_stream_t stream);
 
 int rt_topk_score(const float* users, int64_t user_stride, const int64_t* user_rows, int32_t n_users,
                   const float* items, int64_t item_stride, const int64_t* whitelist, int64_t n_candidates,
                   int64_t candidate_id_offset, int32_t d, int32_t distance, int32_t k,
-                  const int64_t* filt_indptr, const int32_t* filt_indices,
+                  const int64_t* filt_indptr, const int32_t* filt_indices, const int32_t* filt_hash,
                   int64_t* out_ids, float* out_scores, int32_t* out_counts,
                   void* workspace, size_t workspace_bytes, int32_t users_per_pass, rt_stream_t stream);
 

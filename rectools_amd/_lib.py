@@ -26,7 +26,9 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_device_cu_count": (c_i32, []),
     "rt_last_error": (ctypes.c_char_p, []),
     "rt_topk_workspace_bytes": (c_sz, [c_i32, c_i64, c_i32, c_i32]),
-    "rt_topk_score": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_i32, c_vp]),
+    "rt_filter_hash_bytes": (c_sz, [c_i32, c_i64]),
+    "rt_filter_hash_build": (c_i32, [c_vp, c_vp, c_i32, c_i64, c_vp, c_vp]),
+    "rt_topk_score": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_i32, c_vp]),
     "rt_gemm_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
     "rt_gemm": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_sz, c_vp]),
     "rt_colsum": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),

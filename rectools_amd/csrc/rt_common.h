@@ -12,6 +12,7 @@
 #define RT_WAVE 64
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Last HIP failure seen by this library (file:line + hipGetErrorString), readable through rt_last_error().

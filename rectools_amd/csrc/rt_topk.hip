@@ -38,6 +38,7 @@ namespace {
 
 constexpr int IB = 128;       // catalog rows per item block
 constexpr int KC = 32;        // floats per k-chunk
+constexpr int K_LDS_LISTS = 16;  // selection lists live in LDS up to this k
 constexpr int LDK = KC + 4;   // padded LDS row stride (floats) of the `staged` engine
 constexpr int NTHREADS = 256;
 constexpr int LISTS_PER_WG = 8;  // 4 waves x 2 half-waves
@@ -51,6 +52,7 @@ struct TopkArgs {
   long long n_cand; long long id_offset;  // whitelist == NULL: candidate p has item id p + id_offset
   int d; int distance; int k;
   const long long* filt_indptr; const int* filt_indices;
+  const int* filt_hash; int filt_u0;   // optional per-user open-addressing tables (rt_filter_hash_build), first user of the launch
   float* list_scores; int* list_pos; int* list_counts;  // [n_lists][n_users_pad][k], [n_lists][n_users_pad]
   int n_users_pad;
   unsigned* gthr;  // [n_users_pad] ordered keys
@@ -65,10 +67,30 @@ __device__ __forceinline__ bool better(float s, long long p, float s2, long long
   return (s > s2) || (s == s2 && p < p2);
 }
 
-// Is candidate id `cid` among the (ascending) filter indices of this user?
+// Per-user hash set of the filter indices: user u owns the slots [4*indptr[u] + 4*u, +4*cnt_u + 4) of one int array and
+// uses the largest power of two inside them (load factor <= 1/2), linear probing, -1 = empty.  A membership test is
+// 1-2 loads instead of the log2(cnt) DEPENDENT loads of a binary search over the CSR row — the dominant cost of the
+// selection slow path when thousands of users are ranked against a small catalog (recommend()).
+__device__ __forceinline__ unsigned filt_hash_of(unsigned cid, int lg) { return (cid * 0x9E3779B1u) >> (32 - lg); }
+__device__ __forceinline__ int filt_hash_lg(long long cnt) { return 31 - __clz((int)(4 * cnt + 4)); }
+
+// Is candidate id `cid` among the filter indices of this user?
 __device__ __forceinline__ bool is_filtered(const TopkArgs& a, int u, long long cid) {
   if (a.filt_indptr == nullptr) return false;
   long long lo = a.filt_indptr[u], hi = a.filt_indptr[u + 1];
+  if (a.filt_hash != nullptr) {
+    if (hi == lo) return false;
+    const int lg = filt_hash_lg(hi - lo);
+    const int* tab = a.filt_hash + 4 * lo + 4 * (long long)(u + a.filt_u0);
+    unsigned h = filt_hash_of((unsigned)cid, lg);
+    const unsigned mask = (1u << lg) - 1u;
+    for (;;) {
+      const int v = tab[h];
+      if (v == (int)cid) return true;
+      if (v < 0) return false;
+      h = (h + 1) & mask;
+    }
+  }
   const long long end = hi;
   while (lo < hi) {
     long long mid = (lo + hi) >> 1;
@@ -76,6 +98,28 @@ __device__ __forceinline__ bool is_filtered(const TopkArgs& a, int u, long long 
     if (v < cid) lo = mid + 1; else hi = mid;
   }
   return lo < end && (long long)a.filt_indices[lo] == cid;
+}
+
+// one wave per user: insert the row's indices into the user's table (slots pre-filled with -1)
+__global__ __launch_bounds__(256) void filter_hash_build_kernel(const long long* __restrict__ indptr, const int* __restrict__ indices,
+                                                                int n_users, int* __restrict__ hash) {
+  const int lane = threadIdx.x & 63;
+  const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (u >= n_users) return;
+  const long long lo = indptr[u], hi = indptr[u + 1];
+  if (hi == lo) return;
+  const int lg = filt_hash_lg(hi - lo);
+  int* tab = hash + 4 * lo + 4 * (long long)u;
+  const unsigned mask = (1u << lg) - 1u;
+  for (long long e = lo + lane; e < hi; e += 64) {
+    const int cid = indices[e];
+    unsigned h = filt_hash_of((unsigned)cid, lg);
+    for (;;) {
+      const int prev = atomicCAS(tab + h, -1, cid);
+      if (prev == -1 || prev == cid) break;
+      h = (h + 1) & mask;
+    }
+  }
 }
 
 // List storage pointer types.  LDS lists MUST be addressed through address_space(3) pointers: with generic
@@ -95,6 +139,7 @@ struct SelState {
   float worst_s[TU]; long long worst_p[TU]; int worst_slot[TU]; int cnt[TU]; float thr[TU];
   float g_seen[TU];          // last value of the shared bound this lane has observed / published
   fptr ls[TU]; iptr lp[TU];  // this lane's list storage per user tile (LDS for small k, else global)
+  long long fbase[TU]; int flg[TU];   // this lane's filter hash table (bind_filter)
   __device__ __forceinline__ void init() {
 #pragma unroll
     for (int tu = 0; tu < TU; ++tu) {
@@ -134,15 +179,31 @@ struct SelState {
       }
     }
   }
-  // LDS lists: scores [8][UB][k] then positions [8][UB][k] behind the staging ring
+  // LDS lists: scores [8][UB][kp] then positions [8][UB][kp] behind the staging ring, kp = k rounded up to 4 so that a
+  // list is a whole number of 16-byte groups (the worst-entry scan reads it with ds_read_b128); the pad entries hold
+  // +inf scores: they are never the worst entry and never counted
   __device__ __forceinline__ void bind_lds(float* base, int k, int wave, int lane) {
     if constexpr (LL) {
       constexpr int UB = 32 * TU;
+      const int kp = (k + 3) & ~3;
       fptr b = (fptr)base;
 #pragma unroll
       for (int tu = 0; tu < TU; ++tu) {
-        const int L = ((wave * 2 + (lane >> 5)) * UB + tu * 32 + (lane & 31)) * k;
-        ls[tu] = b + L; lp[tu] = (iptr)(b + LISTS_PER_WG * UB * k) + L;
+        const int L = ((wave * 2 + (lane >> 5)) * UB + tu * 32 + (lane & 31)) * kp;
+        ls[tu] = b + L; lp[tu] = (iptr)(b + LISTS_PER_WG * UB * kp) + L;
+        for (int e = k; e < kp; ++e) { ls[tu][e] = INFINITY; lp[tu][e] = -1; }
+      }
+    }
+  }
+  // per-lane view of this user's filter hash table (base slot, log2 size; lg < 0: no filter rows)
+  __device__ __forceinline__ void bind_filter(const TopkArgs& a, int user0, int lane) {
+#pragma unroll
+    for (int tu = 0; tu < TU; ++tu) {
+      fbase[tu] = 0; flg[tu] = -1;
+      const int u = user0 + tu * 32 + (lane & 31);
+      if (a.filt_hash != nullptr && u < a.n_users) {
+        const long long lo = a.filt_indptr[u], hi = a.filt_indptr[u + 1];
+        if (hi > lo) { fbase[tu] = 4 * lo + 4 * (long long)(u + a.filt_u0); flg[tu] = filt_hash_lg(hi - lo); }
       }
     }
   }
@@ -207,7 +268,21 @@ __device__ __forceinline__ void select_block(const TopkArgs& a, SelState<TU, LL>
         bool take = (st.cnt[tu] < a.k) || better(s, p, st.worst_s[tu], st.worst_p[tu]);
         if (!take) continue;
         const long long cid = a.whitelist ? a.whitelist[p] : p + a.id_offset;
-        if (is_filtered(a, u, cid)) continue;
+        if (a.filt_hash != nullptr) {   // O(1) probe of the user's hash set (table view cached per lane)
+          bool hit = false;
+          if (st.flg[tu] >= 0) {
+            const int* tab = a.filt_hash + st.fbase[tu];
+            const unsigned mask = (1u << st.flg[tu]) - 1u;
+            unsigned h = filt_hash_of((unsigned)cid, st.flg[tu]);
+            for (;;) {
+              const int v = tab[h];
+              if (v == (int)cid) { hit = true; break; }
+              if (v < 0) break;
+              h = (h + 1) & mask;
+            }
+          }
+          if (hit) continue;
+        } else if (is_filtered(a, u, cid)) continue;
         if (st.cnt[tu] < a.k) {
           lsc[st.cnt[tu]] = s;
           lps[st.cnt[tu]] = (int)p;
@@ -217,10 +292,33 @@ __device__ __forceinline__ void select_block(const TopkArgs& a, SelState<TU, LL>
           lps[st.worst_slot[tu]] = (int)p;
         }
         if (st.cnt[tu] == a.k) {  // list full: (re)locate its worst entry and publish the bound
-          float ws = lsc[0]; long long wp = lps[0]; int wslot = 0;
-          for (int e = 1; e < a.k; ++e) {
-            float es = lsc[e]; long long ep = lps[e];
-            if (better(ws, wp, es, ep)) { ws = es; wp = ep; wslot = e; }
+          float ws; long long wp; int wslot;
+          if constexpr (LL) {
+            // whole list in flight at once (<= 4 + 4 ds_read_b128), then a register scan: a scalar loop over a runtime
+            // k serialises k dependent LDS round trips on every insert
+            typedef __attribute__((address_space(3))) f32x4* fptr4;
+            typedef __attribute__((address_space(3))) i32x4* iptr4;
+            const int kp = (a.k + 3) & ~3;
+            f32x4 sv[K_LDS_LISTS / 4]; i32x4 pv[K_LDS_LISTS / 4];
+#pragma unroll
+            for (int q = 0; q < K_LDS_LISTS / 4; ++q)
+              if (4 * q < kp) { sv[q] = *((fptr4)lsc + q); pv[q] = *((iptr4)lps + q); }
+            ws = INFINITY; wp = -1; wslot = 0;
+#pragma unroll
+            for (int q = 0; q < K_LDS_LISTS / 4; ++q)
+              if (4 * q < kp) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  const float es = sv[q][i]; const long long ep = pv[q][i];
+                  if (4 * q + i < a.k && ((4 * q + i == 0) || better(ws, wp, es, ep))) { ws = es; wp = ep; wslot = 4 * q + i; }
+                }
+              }
+          } else {
+            ws = lsc[0]; wp = lps[0]; wslot = 0;
+            for (int e = 1; e < a.k; ++e) {
+              float es = lsc[e]; long long ep = lps[e];
+              if (better(ws, wp, es, ep)) { ws = es; wp = ep; wslot = e; }
+            }
           }
           st.worst_s[tu] = ws; st.worst_p[tu] = wp; st.worst_slot[tu] = wslot;
           st.thr[tu] = fmaxf(st.thr[tu], ws);
@@ -282,6 +380,7 @@ __global__ __launch_bounds__(NTHREADS) void topk_staged_kernel(TopkArgs a) {
   SelState<TU, false> st;
   st.init();
   st.bind_global(a, list_id, user0, lane);
+  st.bind_filter(a, user0, lane);
   if (a.resume) st.resume(a, list_id, user0, lane, false);
 
   const float* urow[TU]; int ur_r[TU];
@@ -462,6 +561,7 @@ __global__ __launch_bounds__(NTHREADS + NLD * 64) void topk_stream_kernel(TopkAr
   if (computes) {
     st.bind_lds(smem + NS * STAGE, a.k, cwave, lane);
     st.bind_global(a, list_id, user0, lane);
+    st.bind_filter(a, user0, lane);
     if (a.resume) st.resume(a, list_id, user0, lane, LL);
   }
   if (T == 0) { if (computes && !a.resume) publish_counts<TU, LL>(a, st, list_id, user0, lane, false); return; }
@@ -757,10 +857,9 @@ int env_int(const char* name, int dflt) {
 }
 
 constexpr size_t LDS_PER_CU = 160 * 1024;
-constexpr int K_LDS_LISTS = 16;  // lists live in LDS up to this k
 
-inline size_t stream_lds_bytes(int tu, int ns, int k_lds) {
-  return (size_t)ns * (IB * KC + 32 * tu * KC + 128) * sizeof(float) + (size_t)LISTS_PER_WG * 32 * tu * k_lds * 8;
+inline size_t stream_lds_bytes(int tu, int ns, int k_lds) {   // LDS lists use a stride of k rounded up to 4 entries
+  return (size_t)ns * (IB * KC + 32 * tu * KC + 128) * sizeof(float) + (size_t)LISTS_PER_WG * 32 * tu * ((k_lds + 3) & ~3) * 8;
 }
 
 struct Plan {
@@ -904,10 +1003,26 @@ size_t rt_topk_workspace_bytes(int32_t n_users, int64_t n_candidates, int32_t k,
   return make_plan(n_users, n_candidates, (int)kk, users_per_pass).total;
 }
 
+// bytes of the per-user hash tables over a filter CSR with `nnz` indices
+size_t rt_filter_hash_bytes(int32_t n_users, int64_t nnz) { return 4 * (4 * (size_t)nnz + 4 * (size_t)n_users + 4); }
+
+// Build the tables rt_topk_score probes instead of binary-searching the CSR rows (optional; pass NULL to skip them).
+int rt_filter_hash_build(const int64_t* filt_indptr, const int32_t* filt_indices, int32_t n_users, int64_t nnz, int32_t* hash,
+                         hipStream_t stream) {
+  (void)hipGetLastError();
+  if (n_users < 0 || nnz < 0 || nnz >= (1LL << 29)) return RT_ERR_INVALID_ARG;
+  if (n_users == 0) return RT_OK;
+  RT_CHECK_HIP(hipMemsetAsync(hash, 0xFF, rt_filter_hash_bytes(n_users, nnz), stream));
+  filter_hash_build_kernel<<<(n_users + 3) / 4, 256, 0, stream>>>(reinterpret_cast<const long long*>(filt_indptr), filt_indices,
+                                                                   n_users, hash);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
 int rt_topk_score(const float* users, int64_t user_stride, const int64_t* user_rows, int32_t n_users,
                   const float* items, int64_t item_stride, const int64_t* whitelist, int64_t n_candidates,
                   int64_t candidate_id_offset, int32_t d, int32_t distance, int32_t k,
-                  const int64_t* filt_indptr, const int32_t* filt_indices,
+                  const int64_t* filt_indptr, const int32_t* filt_indices, const int32_t* filt_hash,
                   int64_t* out_ids, float* out_scores, int32_t* out_counts,
                   void* workspace, size_t workspace_bytes, int32_t users_per_pass, hipStream_t stream) {
   (void)hipGetLastError();  // do not inherit a stale error from the caller's earlier HIP calls
@@ -941,6 +1056,7 @@ int rt_topk_score(const float* users, int64_t user_stride, const int64_t* user_r
     a.d = d; a.distance = distance; a.k = k;
     a.filt_indptr = filt_indptr ? reinterpret_cast<const long long*>(filt_indptr) + u0 : nullptr;
     a.filt_indices = filt_indices;
+    a.filt_hash = filt_indptr ? filt_hash : nullptr; a.filt_u0 = u0;
     a.list_scores = reinterpret_cast<float*>(ws + P.o_scores);
     a.list_pos = reinterpret_cast<int*>(ws + P.o_pos);
     a.list_counts = reinterpret_cast<int*>(ws + P.o_counts);

@@ -41,6 +41,21 @@ class DeviceCSR:
 
     def __init__(self, indptr: torch.Tensor, indices: torch.Tensor, shape: tp.Tuple[int, int]):
         self.indptr, self.indices, self.shape = indptr, indices, shape
+        self._hash: tp.Optional[torch.Tensor] = None
+
+    def hash_tables(self) -> torch.Tensor:
+        """Per-user hash sets over the rows (built once on the device): the selection slow path of `rt_topk_score`
+        tests membership in 1-2 loads instead of a binary search of the CSR row."""
+        if self._hash is None:
+            lib = _lib.load()
+            n_users = self.shape[0]
+            nnz = int(self.indptr[-1].item()) if n_users else 0
+            h = torch.empty((lib.rt_filter_hash_bytes(n_users, nnz) // 4,), dtype=torch.int32, device=self.indptr.device)
+            with torch.cuda.device(self.indptr.device):
+                _lib.check(lib.rt_filter_hash_build(_lib.ptr(self.indptr), _lib.ptr(self.indices), n_users, nnz, _lib.ptr(h),
+                                                    _lib.current_stream()), "rt_filter_hash_build")
+            self._hash = h
+        return self._hash
 
     @classmethod
     def from_scipy(cls, csr: sparse.csr_matrix, device: tp.Union[torch.device, str]) -> "DeviceCSR":
@@ -201,11 +216,14 @@ class HipRanker:
         if not (n_subj == self.subjects_factors.shape[0] and np.array_equal(subject_ids, np.arange(n_subj))):
             rows_t = torch.from_numpy(subject_ids.astype(np.int64)).to(dev)
 
-        indptr_t = indices_t = None
+        indptr_t = indices_t = hash_t = None
         if filter_pairs_csr is not None:
             dcsr = filter_pairs_csr if isinstance(filter_pairs_csr, DeviceCSR) else DeviceCSR.from_scipy(
                 filter_pairs_csr, dev)
             indptr_t, indices_t = dcsr.indptr, dcsr.indices
+            # many users against a small catalog: the per-block selection slow path dominates, give it O(1) lookups
+            if n_subj * 64 >= n_cand:
+                hash_t = dcsr.hash_tables()
 
         upp = 0 if self.batch_size is None else int(self.batch_size)
         ws_bytes = self._lib.rt_topk_workspace_bytes(n_subj, n_cand, kk, upp)
@@ -218,7 +236,7 @@ class HipRanker:
                 self.objects_factors.data_ptr() + 4 * id_offset * self.objects_factors.stride(0),
                 self.objects_factors.stride(0), _lib.ptr(whitelist_t), n_cand, id_offset,
                 self.objects_factors.shape[1], _DIST_CODE[self.distance], kk,
-                _lib.ptr(indptr_t), _lib.ptr(indices_t),
+                _lib.ptr(indptr_t), _lib.ptr(indices_t), _lib.ptr(hash_t),
                 _lib.ptr(ids_t), _lib.ptr(scores_t), _lib.ptr(counts_t),
                 _lib.ptr(self._workspace), self._workspace.numel(), upp, _lib.current_stream(),
             )
