@@ -262,7 +262,7 @@ def run_train(args, rank, world):
         fl = sum(2.0 * m * n * k for _, (m, n, k) in calls)
         ms = sum(t for t, _ in calls)
         tf = fl / (ms * 1e-3) / 1e12
-        roof = {"kernel": "gemm_kernel (rt_gemm: all forward/dgrad/wgrad products of the step)", "bound": "mfma",
+        roof = {"kernel": "gemm_dma_kernel (rt_gemm: all forward/dgrad/wgrad products of the step)", "bound": "mfma",
                 "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),
                 "traffic": load_traffic("train_gemm"), "avg_launch_ms": round(ms / len(calls), 4),
                 "algorithmic_flops_per_launch": fl / len(calls), "launches_per_step": len(calls) / 3.0}
