@@ -177,6 +177,7 @@ def make_sasrec(V, d, H, n_blocks, L, dropout, loss, n_neg, device="cuda"):
     from rectools_amd import nn as hnn
 
     n_tokens = V + 1
+    torch.manual_seed(31)  # before construction: biases / LayerNorm / embeddings take their default init from this stream
     item_model = hnn.SumOfEmbeddingsConstructor(n_tokens, [hnn.IdEmbeddingsItemNet(d, n_tokens, 0.0)])
     pos = hnn.LearnableInversePositionalEncoding(True, L, d)
     layers = hnn.SASRecTransformerLayers(n_blocks, d, H, dropout)
@@ -230,6 +231,7 @@ def run_train(args, rank, world):
     lm = make_sasrec(V, d, H, nb, L, 0.2, "sampled_softmax", n_neg)
     lm.train()
     opt = hl.FlatAdam(lm.torch_model, lr=1e-3)
+    opt.broadcast_parameters()  # N > 1: replicas start from rank 0's weights, as DDP does
     n_batches = min(args.steps + args.warmup, 24)
     batches = make_train_batches(n_batches, B, L, V, n_neg, rank)
     state = {"i": 0, "loss": None}

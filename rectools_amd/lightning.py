@@ -143,6 +143,15 @@ class FlatAdam:
             self._flat_g = torch.zeros_like(self.flat_p)
         return self._flat_g
 
+    def broadcast_parameters(self, src: int = 0) -> None:
+        """Data-parallel start: every replica takes rank `src`'s parameters and moments (what DDP does when it wraps a
+        module).  One broadcast per flat buffer; a no-op without an initialised process group."""
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            for buf in (self.flat_p, self.m, self.v):
+                dist.broadcast(buf, src=src)
+
     def zero_grad(self) -> None:
         for p in self.params:
             p.grad = None  # the next backward's gradient tensors are adopted as they are

@@ -150,6 +150,7 @@ class TransformerModelBase:
         self.lightning_model.to(device)
         hl.xavier_normal_init(self.lightning_model.torch_model)  # on_train_start (lightning.py:296-299)
         self.optimizer = hl.FlatAdam(self.lightning_model.torch_model, lr=self.lr, betas=(0.9, 0.98))
+        self.optimizer.broadcast_parameters()   # data parallel: replicas start from rank 0's weights (DDP semantics)
         self.epochs_done = 0
         self.history = []
 

@@ -1,0 +1,72 @@
+"""Data-parallel training step on the GPU path with world_size 2: two processes share the one GPU of the test box and
+exchange gradients through gloo (RCCL refuses two ranks on one device; the collective is not what is under test).
+Checks the product code of `FlatAdam.step(world)`: side-stream join -> gradient packing -> ONE all-reduce -> flat Adam
+kernel with the 1/world scale, i.e. every replica lands on Adam(mean of the per-rank gradients) and stays in sync."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    from rectools_amd import lightning as hl
+    from rectools_amd import ops
+
+    V, d, H, nb, L, B, n_neg = 300, 64, 2, 2, 24, 16, 8
+    lm = bench.make_sasrec(V, d, H, nb, L, 0.1, "sampled_softmax", n_neg)       # same seed: identical replicas
+    lm.train()
+    if rank == 1:   # replicas that drifted apart before the start must be pulled back by the broadcast
+        with torch.no_grad():
+            for prm in lm.torch_model.parameters():
+                if prm.ndim == 1:
+                    prm.add_(0.05)
+    opt = hl.FlatAdam(lm.torch_model, lr=1e-2)
+    opt.broadcast_parameters()
+    p0 = {n: p.detach().clone() for n, p in lm.torch_model.named_parameters()}
+    batch = bench.make_train_batches(1, B, L, V, n_neg, rank)[0]                 # rank-dependent data
+    ops.RNG.next_step()
+    opt.zero_grad()
+    lm.training_loss(batch).backward()
+    local = {n: p.grad.detach().clone() for n, p in lm.torch_model.named_parameters()}
+    opt.step(world)
+    torch.cuda.synchronize()
+    for n, p in lm.torch_model.named_parameters():
+        g = local[n].clone()
+        dist.all_reduce(g)                                                       # independent of the product path
+        g /= world
+        want = p0[n] - 1e-2 * g / (g.abs() + 1e-8)                               # first Adam step: m_hat = g, v_hat = g^2
+        torch.testing.assert_close(p.detach(), want, rtol=2e-4, atol=2e-6, msg=lambda m, n=n: f"{n}: {m}")
+    bad = []
+    for n, p in lm.torch_model.named_parameters():                               # replicas stay bit-identical
+        for what, t in (("init", p0[n]), ("after", p.detach())):
+            both = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(both, t.contiguous())
+            if not torch.equal(both[0], both[1]):
+                bad.append((what, n, float((both[0] - both[1]).abs().max())))
+    assert not bad, bad
+    np.save(os.path.join(out_dir, f"ok{rank}.npy"), np.ones(1))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_matches_mean_gradient_adam(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}.npy").exists() for r in range(world))
