@@ -99,6 +99,20 @@ int rt_gemm(const float* A, int64_t lda, int32_t a_kc, const float* B, int64_t l
 int rt_colsum(const float* X, int64_t ld, int32_t M, int32_t N, float* out, rt_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * K1  batch collation on the device.  The session store of the reference's SequenceDataset
+ * (data_preparator.py:39-99) as CSR: offsets [n_sessions+1], items / weights / unix_ts flat, ordered by time inside a
+ * session.  One launch cuts a batch `idx` [B] out of it, bit-identical to the reference's collate functions:
+ *   mode 0 SASRec train (sasrec.py:86-104): x = tail[:-1], y = tail[1:], yw = weights[1:] of the last L+1 items,
+ *          left padded; ts_out [B,L+1] optional (left pad repeats the first kept timestamp)
+ *   mode 1 SASRec recommend (sasrec.py:149-166): last L items;  mode 2: with timestamps (last L+1, final row = context)
+ *   mode 3 BERT4Rec train (bert4rec.py:109-153): last L items, probs [B,L] uniform draws and rand_ids [B,L] random item
+ *          ids decide MASK / random / keep;  mode 4 BERT4Rec recommend (bert4rec.py:182-193): last L-1 items + MASK
+ * ------------------------------------------------------------------------------------------------ */
+int rt_collate(const int64_t* offsets, const int64_t* items, const float* weights, const int64_t* unix_ts, const int64_t* idx,
+               int32_t B, int32_t L, int32_t mode, const float* probs, const int64_t* rand_ids, float mask_prob,
+               int64_t mask_id, int64_t* x, int64_t* y, float* yw, int64_t* ts_out, rt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K2  embedding gather + inverse positional encoding + dropout
  * out[m,:] = dropout(table[ids[m]] * scale + pos[L-1-(m mod L)])     (pos may be NULL)
  * Replaces `item_embs[sessions]` (torch_backbone.py:245), LearnableInversePositionalEncoding.forward

@@ -56,6 +56,47 @@ class SequenceStore:
         return self.items[self.offsets[i]:self.offsets[i + 1]], self.weights[self.offsets[i]:self.offsets[i + 1]]
 
 
+class DeviceSequenceStore:
+    """`SequenceStore` resident in HBM (int64 offsets / items / timestamps, fp32 weights): `rt_collate` cuts batches out
+    of it on the device — no per-step host gather, no H2D copy.  No CPU fallback."""
+
+    def __init__(self, store: SequenceStore, device: tp.Any) -> None:
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            from . import _lib
+
+            raise _lib.HipLibraryError("DeviceSequenceStore needs a HIP device (no CPU fallback)")
+        self.offsets = torch.from_numpy(np.ascontiguousarray(store.offsets, dtype=np.int64)).to(dev)
+        self.items = torch.from_numpy(np.ascontiguousarray(store.items, dtype=np.int64)).to(dev)
+        self.weights = torch.from_numpy(np.ascontiguousarray(store.weights, dtype=np.float32)).to(dev)
+        self.unix_ts = None if store.unix_ts is None else torch.from_numpy(np.ascontiguousarray(store.unix_ts, dtype=np.int64)).to(dev)
+        self.device, self.n = dev, len(store)
+
+    def __len__(self) -> int:
+        return self.n
+
+
+def _device_collate(dstore: DeviceSequenceStore, idx: torch.Tensor, L: int, mode: int, with_ts: bool, probs=None,
+                    rand_ids=None, mask_prob: float = 0.0, mask_id: int = 0) -> tp.Dict[str, torch.Tensor]:
+    from . import ops
+
+    B = int(idx.numel())
+    dev = dstore.device
+    train = mode in (0, 3)
+    x = torch.empty((B, L), dtype=torch.int64, device=dev)
+    y = torch.empty((B, L), dtype=torch.int64, device=dev) if train else None
+    yw = torch.empty((B, L), dtype=torch.float32, device=dev) if train else None
+    ts = torch.empty((B, L + 1), dtype=torch.int64, device=dev) if with_ts else None
+    ops._c("rt_collate", dstore.offsets, dstore.items, dstore.weights, dstore.unix_ts if with_ts else None, idx, B, L, mode,
+           probs, rand_ids, float(mask_prob), int(mask_id), x, y, yw, ts)
+    out = {"x": x}
+    if train:
+        out["y"], out["yw"] = y, yw
+    if with_ts:
+        out["unix_ts"] = ts
+    return out
+
+
 def _tail_layout(lengths: np.ndarray, keep: int) -> tp.Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """For sessions truncated to their last `keep` elements: (row index, position inside the kept tail, kept length)."""
     kept = np.minimum(lengths, keep)
@@ -199,6 +240,13 @@ class TransformerDataPreparatorBase:
     def collate_recommend(self, store: SequenceStore, idx: np.ndarray) -> tp.Dict[str, np.ndarray]:
         raise NotImplementedError()
 
+    # device-side twins of the two hot collates (same outputs as the host functions above, as device tensors)
+    def collate_train_device(self, dstore: "DeviceSequenceStore", idx: torch.Tensor) -> tp.Dict[str, torch.Tensor]:
+        raise NotImplementedError()
+
+    def collate_recommend_device(self, dstore: "DeviceSequenceStore", idx: torch.Tensor) -> tp.Dict[str, torch.Tensor]:
+        raise NotImplementedError()
+
 
 def _gather_tails(store: SequenceStore, idx: np.ndarray, keep: int):
     """Flat views of the last `keep` elements of the selected sessions."""
@@ -234,6 +282,12 @@ class SASRecDataPreparator(TransformerDataPreparatorBase):
             t = np.where(pad, first[:, None], t)
             out["unix_ts"] = t
         return out
+
+    def collate_train_device(self, dstore: DeviceSequenceStore, idx: torch.Tensor) -> tp.Dict[str, torch.Tensor]:
+        return _device_collate(dstore, idx, self.session_max_len, 0, self.add_unix_ts)
+
+    def collate_recommend_device(self, dstore: DeviceSequenceStore, idx: torch.Tensor) -> tp.Dict[str, torch.Tensor]:
+        return _device_collate(dstore, idx, self.session_max_len, 2 if self.add_unix_ts else 1, self.add_unix_ts)
 
     def collate_val(self, store: SequenceStore, idx: np.ndarray) -> tp.Dict[str, np.ndarray]:
         """sasrec.py:118-147: inputs are the zero-weight interactions, target the first non-zero-weight one."""
@@ -301,6 +355,37 @@ class BERT4RecDataPreparator(TransformerDataPreparatorBase):
             else:
                 target[j] = 0
         return masked, target
+
+    def collate_train_with_draws(self, store: SequenceStore, idx: np.ndarray, probs: np.ndarray, rand_ids: np.ndarray,
+                                 first_border: float = 0.8, second_border: float = 0.9) -> tp.Dict[str, np.ndarray]:
+        """`collate_train` as a pure function of the random draws (probs [B,L] uniform, rand_ids [B,L] item ids, both
+        indexed by output column): the statement the device kernel (`rt_collate` mode 3) is checked against."""
+        B, L = len(idx), self.session_max_len
+        x = np.zeros((B, L), np.int64); y = np.zeros((B, L), np.int64); yw = np.zeros((B, L), np.float32)
+        mask_id = self.extra_token_ids[MASKING_VALUE]
+        mp = np.float32(self.mask_prob)
+        for i, u in enumerate(idx):
+            ses, w = store.session(int(u))
+            ses, w = ses[-L:], w[-L:]
+            c0 = L - len(ses)
+            pr = probs[i, c0:].astype(np.float32)
+            hit = pr < mp
+            pj = pr / mp
+            masked = np.where(hit & (pj < np.float32(first_border)), mask_id,
+                              np.where(hit & (pj < np.float32(second_border)), rand_ids[i, c0:], ses))
+            x[i, c0:] = masked
+            y[i, c0:] = np.where(hit, ses, 0)
+            yw[i, c0:] = w
+        return {"x": x, "y": y, "yw": yw}
+
+    def collate_train_device(self, dstore: DeviceSequenceStore, idx: torch.Tensor) -> tp.Dict[str, torch.Tensor]:
+        B, L = int(idx.numel()), self.session_max_len
+        probs = torch.rand((B, L), dtype=torch.float32, device=dstore.device)
+        rand_ids = torch.randint(self.n_item_extra_tokens, self.item_id_map.size, (B, L), dtype=torch.int64, device=dstore.device)
+        return _device_collate(dstore, idx, L, 3, False, probs, rand_ids, self.mask_prob, self.extra_token_ids[MASKING_VALUE])
+
+    def collate_recommend_device(self, dstore: DeviceSequenceStore, idx: torch.Tensor) -> tp.Dict[str, torch.Tensor]:
+        return _device_collate(dstore, idx, self.session_max_len, 4, False, mask_id=self.extra_token_ids[MASKING_VALUE])
 
     def collate_train(self, store: SequenceStore, idx: np.ndarray) -> tp.Dict[str, np.ndarray]:
         B, L = len(idx), self.session_max_len

@@ -23,8 +23,8 @@ import torch
 from . import lightning as hl
 from . import nn as hnn
 from . import ops
-from .data_preparator import (BERT4RecDataPreparator, SASRecDataPreparator, SequenceStore, TransformerDataPreparatorBase,
-                              epoch_permutation, shard_indices)
+from .data_preparator import (BERT4RecDataPreparator, DeviceSequenceStore, SASRecDataPreparator, SequenceStore,
+                              TransformerDataPreparatorBase, epoch_permutation, shard_indices)
 from .dataset import Columns
 from .rank import DeviceCSR, Distance, HipRanker
 
@@ -177,7 +177,9 @@ class TransformerModelBase:
 
     # ---- training -----------------------------------------------------------------------------------------
     def _to_device(self, batch: tp.Dict[str, np.ndarray], device: torch.device, train: bool) -> tp.Dict[str, torch.Tensor]:
-        out = {k: torch.from_numpy(v).to(device, non_blocking=True) for k, v in batch.items()}
+        return self._add_negatives({k: torch.from_numpy(v).to(device, non_blocking=True) for k, v in batch.items()}, device)
+
+    def _add_negatives(self, out: tp.Dict[str, torch.Tensor], device: torch.device) -> tp.Dict[str, torch.Tensor]:
         if hl.requires_negatives(self.loss) and "y" in out:
             B = out["x"].shape[0]
             shape = (B, self.session_max_len if out["y"].shape[1] > 1 else 1, self.n_negatives)
@@ -190,16 +192,18 @@ class TransformerModelBase:
         device = next(lm.parameters()).device
         rank, world = _dist_info()
         store = dp.train_store()
+        dstore = DeviceSequenceStore(store, device)   # sessions resident in HBM: batches are cut on the device (rt_collate)
         val_store = dp.val_store()
         seed = 0 if self.seed is None else int(self.seed)
         for epoch in range(first, last):
             lm.train()
             perm = epoch_permutation(len(store), epoch, seed, dp.shuffle_train)
             mine = shard_indices(perm, rank, world)
+            mine_t = torch.from_numpy(np.ascontiguousarray(mine, dtype=np.int64)).to(device)   # one small H2D per epoch
             total = torch.zeros((), device=device)
             n_batches = 0
             for b0 in range(0, len(mine), self.batch_size):
-                batch = self._to_device(dp.collate_train(store, mine[b0:b0 + self.batch_size]), device, True)
+                batch = self._add_negatives(dp.collate_train_device(dstore, mine_t[b0:b0 + self.batch_size]), device)
                 ops.RNG.next_step()
                 opt.zero_grad()
                 loss = lm.training_loss(batch)
@@ -246,10 +250,11 @@ class TransformerModelBase:
         assert lm is not None
         lm.eval()
         outs = []
+        dstore = DeviceSequenceStore(store, device)
+        all_idx = torch.arange(len(store), dtype=torch.int64, device=device)
         with torch.no_grad():
             for b0 in range(0, len(store), self.recommend_batch_size):
-                idx = np.arange(b0, min(b0 + self.recommend_batch_size, len(store)))
-                batch = {k: torch.from_numpy(v).to(device) for k, v in self.data_preparator.collate_recommend(store, idx).items()}
+                batch = self.data_preparator.collate_recommend_device(dstore, all_idx[b0:b0 + self.recommend_batch_size])
                 enc = lm.torch_model.encode_sessions(batch)
                 outs.append(enc[:, -1, :].contiguous())
         return torch.cat(outs) if outs else torch.zeros((0, self.n_factors), device=device)
