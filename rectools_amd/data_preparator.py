@@ -75,6 +75,15 @@ class DeviceSequenceStore:
     def __len__(self) -> int:
         return self.n
 
+    @classmethod
+    def from_device(cls, offsets: torch.Tensor, items: torch.Tensor, weights: torch.Tensor,
+                    unix_ts: tp.Optional[torch.Tensor]) -> "DeviceSequenceStore":
+        """Wrap arrays that were built on the device (recommend(): sessions sorted and grouped there)."""
+        self = cls.__new__(cls)
+        self.offsets, self.items, self.weights, self.unix_ts = offsets, items, weights, unix_ts
+        self.device, self.n = offsets.device, int(offsets.numel()) - 1
+        return self
+
 
 def _device_collate(dstore: DeviceSequenceStore, idx: torch.Tensor, L: int, mode: int, with_ts: bool, probs=None,
                     rand_ids=None, mask_prob: float = 0.0, mask_id: int = 0) -> tp.Dict[str, torch.Tensor]:

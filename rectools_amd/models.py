@@ -292,6 +292,11 @@ class TransformerModelBase:
             if on_unsupported_targets == "warn":
                 warnings.warn("Model doesn't support recommendations for cold users, but some of given users are cold")
             users = users[known]
+        if context is None and not self.data_preparator.add_unix_ts and not (self.data_preparator.extra_cols or []):
+            fast = self._recommend_device_glue(users, dataset, k, filter_viewed, items_to_recommend, add_rank_col,
+                                               on_unsupported_targets)
+            if fast is not None:
+                return fast
         with warnings.catch_warnings():
             if on_unsupported_targets == "ignore":
                 warnings.simplefilter("ignore")
@@ -310,6 +315,80 @@ class TransformerModelBase:
             filt = DeviceCSR.from_scipy(rec_ds.get_user_item_matrix(include_weights=False)[user_ids], device)
         ids, scores, counts, _ = ranker.rank_device(user_ids, k=k, filter_pairs_csr=filt, sorted_object_whitelist=whitelist)
         return self._assemble(rec_ds.user_id_map.convert_to_external(user_ids), ids, scores, counts, add_rank_col, Columns.User)
+
+    def _recommend_device_glue(self, users: np.ndarray, dataset: tp.Any, k: int, filter_viewed: bool,
+                               items_to_recommend: tp.Optional[tp.Any], add_rank_col: bool,
+                               on_unsupported_targets: str) -> tp.Optional[pd.DataFrame]:
+        """recommend() without the pandas / scipy round trips of the reference's glue (`models/base.py:
+        502-519,735-791`, `data_preparator.py:354-424`, `dataset.py:314-348`): the interactions table is uploaded once,
+        and filtering to (requested users x known items), the time-ordered session store, the viewed-items CSR and the
+        user encodings are all produced on the device.  Same rows, order and values as the reference-shaped path below
+        (tests/test_models_gpu.py compares the two).  Returns None when the request needs that path (duplicated users)."""
+        dp, lm = self.data_preparator, self.lightning_model
+        assert lm is not None
+        device = next(lm.parameters()).device
+        df = dataset.interactions.df
+        req = dataset.user_id_map.convert_to_internal(users, strict=False)
+        if len(np.unique(req)) != len(req):
+            return None
+        whitelist = self._whitelist(items_to_recommend)
+        empty = self._frame(np.array([], users.dtype), np.array([], object), np.array([], np.float32), add_rank_col, Columns.User)
+        if len(req) == 0 or len(whitelist) == 0:
+            return empty
+        # dataset item id -> model item id (-1: unknown to the model); small host map, the rest happens on the device
+        lookup = pd.Series(dp.item_id_map.to_internal).reindex(dataset.item_id_map.external_ids).fillna(-1).values.astype(np.int64)
+        n_ds_users, n_req, V = dataset.user_id_map.size, len(req), dp.item_id_map.size
+        to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device, non_blocking=True)  # noqa: E731
+        u_t = to_dev(df[Columns.User].values.astype(np.int64, copy=False))
+        i_t = to_dev(df[Columns.Item].values.astype(np.int64, copy=False))
+        t_t = to_dev(df[Columns.Datetime].values.astype("datetime64[ns]").view(np.int64))
+        w_t = to_dev(df[Columns.Weight].values.astype(np.float32, copy=False))
+        req_row = torch.full((n_ds_users,), -1, dtype=torch.int64, device=device)
+        req_row[to_dev(req.astype(np.int64))] = torch.arange(n_req, dtype=torch.int64, device=device)
+        row = req_row[u_t]
+        mitem = to_dev(lookup)[i_t]
+        keep = (row >= 0) & (mitem >= 0)
+        row, mitem, t_k, w_k = row[keep], mitem[keep], t_t[keep], w_t[keep]
+        # the reference's session order: stable sort by time, then grouped by user (data_preparator.py:73-99)
+        o1 = torch.sort(t_k, stable=True).indices
+        o2 = torch.sort(row[o1], stable=True).indices
+        order = o1[o2]
+        row_s, item_s, w_s = row[order], mitem[order], w_k[order]
+        counts = torch.bincount(row_s, minlength=n_req)
+        valid = counts > 0
+        n_valid = int(valid.sum())
+        n_cold = n_req - n_valid
+        if n_cold > 0 and on_unsupported_targets != "ignore":
+            warnings.warn(f"{n_cold} target users were considered cold because of missing known items")
+        if n_valid == 0:
+            return empty
+        offsets = torch.zeros((n_req + 1,), dtype=torch.int64, device=device)
+        torch.cumsum(counts, 0, out=offsets[1:])
+        dstore = DeviceSequenceStore.from_device(offsets, item_s, w_s, None)
+        valid_rows = torch.nonzero(valid).reshape(-1)
+        lm.eval()
+        outs = []
+        with torch.no_grad():
+            for b0 in range(0, n_valid, self.recommend_batch_size):
+                batch = dp.collate_recommend_device(dstore, valid_rows[b0:b0 + self.recommend_batch_size])
+                outs.append(lm.torch_model.encode_sessions(batch)[:, -1, :].contiguous())
+        user_embs = torch.cat(outs)
+        item_embs = lm.torch_model.item_model.table.detach()
+        ranker = HipRanker(lm.torch_model.similarity_module.distance, device, user_embs, item_embs)
+        filt = None
+        if filter_viewed:  # CSR of the distinct (user, item) pairs, rows in request order, indices ascending
+            new_row = torch.cumsum(valid.to(torch.int64), 0) - 1
+            key = torch.unique(new_row[row_s] * V + item_s)          # sorted
+            frow = torch.div(key, V, rounding_mode="floor")
+            indptr = torch.zeros((n_valid + 1,), dtype=torch.int64, device=device)
+            torch.cumsum(torch.bincount(frow, minlength=n_valid), 0, out=indptr[1:])
+            indices = (key - frow * V).to(torch.int32)
+            if indices.numel() == 0:
+                indices = torch.zeros((1,), dtype=torch.int32, device=device)
+            filt = DeviceCSR(indptr, indices, (n_valid, V))
+        ids, scores, cnt, _ = ranker.rank_device(np.arange(n_valid), k=k, filter_pairs_csr=filt, sorted_object_whitelist=whitelist)
+        ext_users = np.asarray(users)[valid.cpu().numpy()]
+        return self._assemble(ext_users, ids, scores, cnt, add_rank_col, Columns.User)
 
     def recommend_to_items(self, target_items: tp.Any, dataset: tp.Any, k: int, filter_itself: bool = True,
                            items_to_recommend: tp.Optional[tp.Any] = None, add_rank_col: bool = True,
@@ -351,7 +430,10 @@ class TransformerModelBase:
         valid = (np.arange(kk)[None, :] < counts[:, None]) & (scores > -np.inf)
         tt = np.repeat(ext_users, kk).reshape(len(ext_users), kk)[valid]
         ii = self.data_preparator.item_id_map.convert_to_external(ids[valid])
-        return self._frame(tt, ii, scores[valid], add_rank_col, target_col)
+        df = pd.DataFrame({target_col: tt, Columns.Item: ii, Columns.Score: scores[valid].astype(np.float32)})
+        if add_rank_col:  # valid entries lead every row: rank = running count inside the row (models/base.py:788-789)
+            df[Columns.Rank] = (np.cumsum(valid, axis=1)[valid]).astype(np.int64)
+        return df
 
     @staticmethod
     def _frame(targets: np.ndarray, items: np.ndarray, scores: np.ndarray, add_rank_col: bool, target_col: str) -> pd.DataFrame:

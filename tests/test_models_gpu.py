@@ -110,3 +110,41 @@ def test_fit_partial_equals_fit_and_cold_users():
     assert set(r["user_id"]) == {10}
     with pytest.raises(ValueError):
         a.recommend(users=[10], dataset=ds, k=0, filter_viewed=False)
+
+
+def test_recommend_device_glue_equals_reference_shaped_path():
+    """recommend() builds sessions, the viewed filter and the encodings on the device; the pandas /
+    scipy path that mirrors the reference line by line must give the same frame: users in request order, users whose
+    history holds no item known to the model dropped with a warning, viewed filter and whitelist applied."""
+    import warnings
+
+    from rectools_amd.dataset import Dataset
+    from rectools_amd.models import SASRecModel
+
+    rng = np.random.default_rng(0)
+    n_users, n_items, n = 300, 120, 6000
+    df = pd.DataFrame({"user_id": rng.integers(0, n_users, n) * 3 + 7, "item_id": rng.integers(0, n_items, n) + 1000,
+                       "weight": 1.0, "datetime": pd.to_datetime("2022-01-01") + pd.to_timedelta(rng.integers(0, 50_000, n), unit="m")})
+    train = Dataset.construct(df[df["item_id"] < 1000 + 80])          # the model knows 80 of the 120 items
+    full_df = pd.concat([df, pd.DataFrame({"user_id": [5, 5], "item_id": [1100, 1101], "weight": 1.0,
+                                           "datetime": pd.to_datetime(["2022-02-01", "2022-02-02"])})])
+    full = Dataset.construct(full_df)                                  # user 5 has only unknown items: cold at recommend time
+    model = SASRecModel(n_factors=32, n_blocks=2, n_heads=2, session_max_len=12, lr=0.01, batch_size=64, epochs=2,
+                        loss="sampled_softmax", n_negatives=4, seed=1).fit(train)
+    users = np.r_[rng.permutation(full.user_id_map.external_ids)[:150], 5]
+    for kw in (dict(k=5, filter_viewed=True), dict(k=3, filter_viewed=False, items_to_recommend=np.arange(1000, 1040)),
+               dict(k=200, filter_viewed=True)):
+        with warnings.catch_warnings(record=True) as w_fast:
+            warnings.simplefilter("always")
+            fast = model.recommend(users=users, dataset=full, **kw)
+        orig = model._recommend_device_glue
+        model._recommend_device_glue = lambda *a, **k: None            # force the reference-shaped path
+        try:
+            with warnings.catch_warnings(record=True) as w_slow:
+                warnings.simplefilter("always")
+                slow = model.recommend(users=users, dataset=full, **kw)
+        finally:
+            model._recommend_device_glue = orig
+        assert 5 not in set(fast["user_id"]) and len(w_fast) >= 1 and len(w_slow) >= 1
+        assert fast[["user_id", "item_id", "rank"]].equals(slow[["user_id", "item_id", "rank"]])
+        np.testing.assert_allclose(fast["score"].values, slow["score"].values, rtol=1e-5, atol=1e-6)
