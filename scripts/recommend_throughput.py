@@ -19,4 +19,4 @@ torch.cuda.synchronize()
 t0 = time.perf_counter(); reco = model.recommend(users, ds, k=10, filter_viewed=True); torch.cuda.synchronize(); t1 = time.perf_counter()
 print(f"recommend {len(users)} users: {t1 - t0:.3f} s -> {len(users) / (t1 - t0):.0f} users/s, {len(reco)} rows")
 pr = cProfile.Profile(); pr.enable(); model.recommend(users, ds, k=10, filter_viewed=True); torch.cuda.synchronize(); pr.disable()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(22); print(s.getvalue()[:4200])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(16); print(s.getvalue()[:4200])
