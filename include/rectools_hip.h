@@ -124,7 +124,7 @@ int rt_collate(const int64_t* offsets, const int64_t* items, const float* weight
  * ------------------------------------------------------------------------------------------------ */
 int rt_embed_fwd(const int64_t* ids, const float* table, const float* pos, float scale, int32_t M, int32_t L,
                  int32_t d, float p, uint64_t seed, uint64_t stream_id, float* out, rt_stream_t stream);
-size_t rt_embed_bwd_workspace_bytes(int32_t M, int32_t V);
+size_t rt_embed_bwd_workspace_bytes(int32_t M, int32_t V, int32_t d);
 int rt_embed_bwd(const int64_t* ids, const float* gout, float scale, int32_t M, int32_t L, int32_t d, int32_t V, float p,
                  uint64_t seed, uint64_t stream_id, float* gtable, float* gpos, void* workspace, size_t workspace_bytes,
                  rt_stream_t stream);
@@ -215,7 +215,7 @@ int rt_hstu_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, c
 int rt_sampled_loss_fwd(const float* sess, int64_t ld_sess, const float* table, const int64_t* y, const int64_t* neg,
                         const float* w, int32_t M, int32_t N, int32_t d, int32_t loss, int32_t cosine, float logits_t,
                         double gbce_beta, float* logits, float* loss_pos, rt_stream_t stream);
-size_t rt_sampled_loss_bwd_workspace_bytes(int32_t M, int32_t N, int32_t V);
+size_t rt_sampled_loss_bwd_workspace_bytes(int32_t M, int32_t N, int32_t V, int32_t d);
 int rt_sampled_loss_fwd_train(const float* sess, int64_t ld_sess, const float* table, const int64_t* y, const int64_t* neg,
                               const float* w, int32_t M, int32_t N, int32_t d, int32_t V, int32_t loss, int32_t cosine,
                               float logits_t, double gbce_beta, float* logits, float* loss_pos, float* d_sess_unit,

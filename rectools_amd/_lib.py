@@ -34,7 +34,7 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_colsum": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "rt_collate": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_f32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rt_embed_fwd": (c_i32, [c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_f32, c_u64, c_u64, c_vp, c_vp]),
-    "rt_embed_bwd_workspace_bytes": (c_sz, [c_i32, c_i32]),
+    "rt_embed_bwd_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32]),
     "rt_embed_bwd": (c_i32, [c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_u64, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "rt_layernorm_fwd": (c_i32, [c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "rt_layernorm_bwd_workspace_bytes": (c_sz, [c_i32, c_i32]),
@@ -54,7 +54,7 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_hstu_attn_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rt_hstu_attn_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "rt_sampled_loss_fwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f64, c_vp, c_vp, c_vp]),
-    "rt_sampled_loss_bwd_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32]),
+    "rt_sampled_loss_bwd_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
     "rt_sampled_loss_fwd_train": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f64, c_vp, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp]),
     "rt_sampled_loss_bwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_f32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_sz, c_vp]),
     "rt_loss_reduce": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),

@@ -629,11 +629,11 @@ __device__ __forceinline__ int tile_for(int it, int wave, int n_t, bool causal, 
 }
 
 // rows [0, Lp) of two [L, hd] matrices -> LDS [Lp][HD + 4] each; rows past L and columns past hd are zero-filled.
-// A dependent round trip costs ~2 us, so every thread keeps 4 + 4 float4 loads in flight.
+// A dependent round trip costs ~2 us, so every thread keeps 8 + 8 float4 loads in flight (one round for L = 200, hd = 64).
 template <int HD>
 __device__ __forceinline__ void stage_rows2(const float* baseA, long long ldA, float* dstA, const float* baseB, long long ldB,
                                             float* dstB, int L, int Lp, int hd, int tid, int nthreads) {
-  constexpr int U = 4, PER_ROW = HD / 4, LD = HD + 4;
+  constexpr int U = 8, PER_ROW = HD / 4, LD = HD + 4;
   const int total = Lp * PER_ROW;
   for (int i0 = tid; i0 < total; i0 += U * nthreads) {
     f32x4 va[U], vb[U];

@@ -49,7 +49,8 @@ struct SampledArgs {
   int* pairs;                             // [M*(1+N)] (position, candidate) pairs grouped by candidate id
   int* blocksum;                          // scan scratch
   int* rank;                              // [M, 1+N] rank of every pair inside its candidate id
-  int* heavy_count; int* heavy_ids;       // rows with > HEAVY_T pairs, reduced by a whole workgroup each
+  int* heavy_count; int* heavy_ids; int* heavy_chunk;   // chunk list of the rows with > HEAVY_T pairs (rt_scan.h)
+  float* slab; float* slab_bsum;          // [chunks][d] partial rows of those chunks, [chunks] partial cosine sums
 };
 
 __device__ __forceinline__ float group16_sum(float v) {  // sum over the 16 lanes of a quarter-wave
@@ -340,7 +341,8 @@ __global__ __launch_bounds__(256) void pairs_scatter_kernel(SampledArgs a) {
 // A wave accumulates the pairs [beg, end) with stride-free contiguous access, 4 gather chains in flight.
 constexpr int HEAVY_T = 128;     // ids with more pairs than this go to the workgroup-per-id kernel (popularity skew:
                                  // a Zipf catalog gives its top item ~9% of all positives -> one wave would serialise them)
-constexpr int HEAVY_WAVES = 16;
+constexpr int HEAVY_CH = 128;    // pairs per chunk of a popular row: one 4-wave workgroup, two rounds of 16 gathers per wave
+constexpr int HEAVY_WAVES = 4;
 
 template <int D4, int U>
 __device__ __forceinline__ void accumulate_pairs_u(const SampledArgs& a, int& k, int end, int lane,
@@ -414,38 +416,48 @@ __device__ __forceinline__ void finish_table_row(const SampledArgs& a, int id, i
   }
 }
 
-// one wave per table row; rows with more than HEAVY_T pairs are queued for the heavy kernel instead
+// one wave per table row; a popular row (cursor >= 0) only combines the partial rows its chunks left in the slab
 template <int D4>
 __global__ __launch_bounds__(256) void sampled_bwd_rows_kernel(SampledArgs a) {
+  constexpr int NA = (D4 + 3) / 4;
   const int lane = threadIdx.x & 63;
   const int id = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (id >= a.V) return;
   const int beg = a.offsets[id], end = a.offsets[id + 1];
-  if (end - beg > HEAVY_T) {
-    if (lane == 0) a.heavy_ids[atomicAdd(a.heavy_count, 1)] = id;
-    return;
-  }
-  f32x4 acc[(D4 + 3) / 4];
+  f32x4 acc[NA];
 #pragma unroll
-  for (int i = 0; i < (D4 + 3) / 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < NA; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
-  accumulate_pairs<D4>(a, beg, end, lane, acc, bsum);
+  const int slot = a.cursor[id];
+  if (slot >= 0) {
+    const int n_ch = (end - beg + HEAVY_CH - 1) / HEAVY_CH;
+    for (int c = 0; c < n_ch; ++c) {   // fixed order: deterministic given the pair order
+      bsum += a.slab_bsum[slot + c];
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int col = lane * 4 + 256 * i;
+        if (col < a.d) acc[i] += *reinterpret_cast<const f32x4*>(a.slab + (long long)(slot + c) * a.d + col);
+      }
+    }
+  } else {
+    accumulate_pairs<D4>(a, beg, end, lane, acc, bsum);
+  }
   finish_table_row<D4>(a, id, lane, end > beg, acc, bsum);
 }
 
-// one 16-wave workgroup per heavy row: every wave reduces a contiguous slice, partials combined through LDS in a
-// fixed order by wave 0
+// one 4-wave workgroup per chunk of a popular row: 32 pairs per wave, combined through LDS, partial row -> slab
 template <int D4>
 __global__ __launch_bounds__(HEAVY_WAVES * 64) void sampled_bwd_heavy_kernel(SampledArgs a) {
   constexpr int NA = (D4 + 3) / 4;
   __shared__ f32x4 s_part[HEAVY_WAVES][NA][64];
   __shared__ float s_bsum[HEAVY_WAVES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n_heavy = *a.heavy_count;
-  for (int h = blockIdx.x; h < n_heavy; h += gridDim.x) {
+  const int n_chunks = *a.heavy_count;
+  for (int h = blockIdx.x; h < n_chunks; h += gridDim.x) {
     const int id = a.heavy_ids[h];
-    const int beg = a.offsets[id], end = a.offsets[id + 1];
-    const int per = ((end - beg + HEAVY_WAVES - 1) / HEAVY_WAVES + 15) & ~15;
+    const int beg = a.offsets[id] + a.heavy_chunk[h] * HEAVY_CH;
+    const int end = min(beg + HEAVY_CH, a.offsets[id + 1]);
+    const int per = HEAVY_CH / HEAVY_WAVES;
     const int wb = min(beg + wave * per, end), we = min(wb + per, end);
     f32x4 acc[NA];
 #pragma unroll
@@ -457,15 +469,14 @@ __global__ __launch_bounds__(HEAVY_WAVES * 64) void sampled_bwd_heavy_kernel(Sam
     if (lane == 0) s_bsum[wave] = bsum;
     __syncthreads();
     if (wave == 0) {
-      bsum = 0.f;
 #pragma unroll
-      for (int i = 0; i < NA; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int w = 0; w < HEAVY_WAVES; ++w) {
-        bsum += s_bsum[w];
-#pragma unroll
-        for (int i = 0; i < NA; ++i) acc[i] += s_part[w][i][lane];
+      for (int i = 0; i < NA; ++i) {
+        const int col = lane * 4 + 256 * i;
+        if (col < a.d)
+          *reinterpret_cast<f32x4*>(a.slab + (long long)h * a.d + col) =
+              (s_part[0][i][lane] + s_part[1][i][lane]) + (s_part[2][i][lane] + s_part[3][i][lane]);
       }
-      finish_table_row<D4>(a, id, lane, true, acc, bsum);
+      if (lane == 0) a.slab_bsum[h] = (s_bsum[0] + s_bsum[1]) + (s_bsum[2] + s_bsum[3]);
     }
     __syncthreads();
   }
@@ -601,6 +612,10 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
     *reinterpret_cast<f32x4*>(o + c) = *reinterpret_cast<const f32x4*>(src + (long long)r * lds_ + c);
 }
 
+// upper bound on the chunks of popular rows among `n_pairs` pairs: every chunk but the last of a row is full, and a row
+// needs more than HEAVY_T pairs to have chunks at all
+inline long long heavy_chunk_cap(long long n_pairs) { return n_pairs / HEAVY_CH + n_pairs / HEAVY_T + 2; }
+
 // stage: 0 = inference forward, 1 = training forward (logits, loss, unit gradients, ranks), 2 = backward
 template <int D4>
 int launch_sampled(const SampledArgs& a, int stage, hipStream_t stream) {
@@ -621,16 +636,18 @@ int launch_sampled(const SampledArgs& a, int stage, hipStream_t stream) {
   }
   agg_rank_kernel<<<(a.M + AGG_T - 1) / AGG_T, AGG_T, 0, stream>>>(a.y, a.M, a.count, a.rank, a.N + 1);
   RT_CHECK_LAUNCH();
-  { const int rc = exclusive_scan_counts(a.count, n, a.offsets, a.cursor, a.blocksum, stream); if (rc != RT_OK) return rc; }
+  {
+    const int rc = exclusive_scan_counts(a.count, n, a.offsets, a.cursor, a.blocksum, stream, HEAVY_T, HEAVY_CH, a.heavy_count,
+                                         a.heavy_ids, a.heavy_chunk);
+    if (rc != RT_OK) return rc;
+  }
   pairs_scatter_kernel<<<blocks, 256, 0, stream>>>(a);
+  RT_CHECK_LAUNCH();
+  const long long max_chunks = heavy_chunk_cap((long long)a.M * (a.N + 1));
+  sampled_bwd_heavy_kernel<D4><<<(int)min(max_chunks, (long long)rt_num_cus() * 8), HEAVY_WAVES * 64, 0, stream>>>(a);
   RT_CHECK_LAUNCH();
   sampled_bwd_rows_kernel<D4><<<(a.V + 3) / 4, 256, 0, stream>>>(a);
   RT_CHECK_LAUNCH();
-  const long long max_heavy = (long long)a.M * (a.N + 1) / HEAVY_T;
-  if (max_heavy > 0) {
-    sampled_bwd_heavy_kernel<D4><<<(int)min(max_heavy, (long long)rt_num_cus()), HEAVY_WAVES * 64, 0, stream>>>(a);
-    RT_CHECK_LAUNCH();
-  }
   return RT_OK;
 }
 int dispatch_sampled(const SampledArgs& a, int stage, hipStream_t stream) {
@@ -642,9 +659,12 @@ int dispatch_sampled(const SampledArgs& a, int stage, hipStream_t stream) {
 }
 
 // workspace shared by the training forward and the backward
-void carve_workspace(SampledArgs& a, void* workspace, int M, int N, int V) {
+void carve_workspace(SampledArgs& a, void* workspace, int M, int N, int V, int d) {
   const size_t C = (size_t)N + 1, n = (size_t)V + 1;
+  const size_t cap = (size_t)heavy_chunk_cap((long long)M * (long long)C);
   float* f = reinterpret_cast<float*>(workspace);
+  a.slab = f; f += cap * (size_t)d;   // first: 16-byte aligned rows
+  a.slab_bsum = f; f += cap;
   a.glog = f; f += (size_t)M * C;
   a.inv_ns = f; f += M;
   int* ip = reinterpret_cast<int*>(f);
@@ -652,7 +672,8 @@ void carve_workspace(SampledArgs& a, void* workspace, int M, int N, int V) {
   a.rank = ip; ip += (size_t)M * C;
   a.count = ip; ip += n;
   a.heavy_count = ip; ip += 1;   // directly behind count: one memset clears both
-  a.heavy_ids = ip; ip += (size_t)M * C / HEAVY_T + 1;
+  a.heavy_ids = ip; ip += cap;
+  a.heavy_chunk = ip; ip += cap;
   a.offsets = ip; ip += n;
   a.cursor = ip; ip += n;
   a.blocksum = ip;
@@ -677,10 +698,11 @@ int rt_sampled_loss_fwd(const float* sess, int64_t ld_sess, const float* table, 
 }
 
 // Host arithmetic: bytes of the scratch that rt_sampled_loss_fwd_train fills and rt_sampled_loss_bwd consumes.
-size_t rt_sampled_loss_bwd_workspace_bytes(int32_t M, int32_t N, int32_t V) {
+size_t rt_sampled_loss_bwd_workspace_bytes(int32_t M, int32_t N, int32_t V, int32_t d) {
   const size_t C = (size_t)N + 1, n = (size_t)V + 1;
   const size_t nb = (n + SCAN_T * SCAN_E - 1) / (SCAN_T * SCAN_E);
-  return 4 * ((size_t)M * C * 3 + (size_t)M + 3 * n + nb + 64 + 2 + (size_t)M * C / HEAVY_T);
+  const size_t cap = (size_t)heavy_chunk_cap((long long)M * (long long)C);
+  return 4 * ((size_t)M * C * 3 + (size_t)M + 3 * n + nb + 64 + 2 + cap * ((size_t)d + 3));
 }
 
 // Training forward: everything rt_sampled_loss_fwd writes, plus — in `workspace` — the unit gradient of every logit,
@@ -694,13 +716,13 @@ int rt_sampled_loss_fwd_train(const float* sess, int64_t ld_sess, const float* t
   if (M <= 0) return RT_OK;
   if ((d & 3) || N < 0 || loss < LOSS_BCE || loss > LOSS_SAMPLED_SOFTMAX || (ld_sess & 3) || (ld_du & 3)) return RT_ERR_INVALID_ARG;
   if ((long long)M * (N + 1) >= (1LL << 31)) return RT_ERR_UNSUPPORTED;
-  if (workspace == nullptr || workspace_bytes < rt_sampled_loss_bwd_workspace_bytes(M, N, V)) return RT_ERR_WORKSPACE;
+  if (workspace == nullptr || workspace_bytes < rt_sampled_loss_bwd_workspace_bytes(M, N, V, d)) return RT_ERR_WORKSPACE;
   SampledArgs a{};
   a.sess = sess; a.ld_sess = ld_sess; a.table = table; a.y = reinterpret_cast<const long long*>(y);
   a.neg = reinterpret_cast<const long long*>(neg); a.w = w; a.M = M; a.N = N; a.d = d; a.V = V; a.loss = loss; a.cosine = cosine;
   a.inv_t = 1.0f / logits_t; a.gbce_beta = gbce_beta; a.logits = logits; a.loss_pos = loss_pos;
   a.norm = nullptr; a.gscale = 1.f; a.d_sess = d_sess_unit; a.ld_dsess = ld_du;
-  carve_workspace(a, workspace, M, N, V);
+  carve_workspace(a, workspace, M, N, V, d);
   return dispatch_sampled(a, 1, stream);
 }
 
@@ -715,13 +737,13 @@ int rt_sampled_loss_bwd(const float* sess, int64_t ld_sess, const float* table, 
   if (M <= 0) return RT_OK;
   if ((d & 3) || N < 0 || (ld_sess & 3) || (ld_dsess & 3) || (ld_du & 3)) return RT_ERR_INVALID_ARG;
   if ((long long)M * (N + 1) >= (1LL << 31)) return RT_ERR_UNSUPPORTED;
-  if (workspace == nullptr || workspace_bytes < rt_sampled_loss_bwd_workspace_bytes(M, N, V)) return RT_ERR_WORKSPACE;
+  if (workspace == nullptr || workspace_bytes < rt_sampled_loss_bwd_workspace_bytes(M, N, V, d)) return RT_ERR_WORKSPACE;
   SampledArgs a{};
   a.sess = sess; a.ld_sess = ld_sess; a.table = table; a.y = reinterpret_cast<const long long*>(y);
   a.neg = reinterpret_cast<const long long*>(neg); a.M = M; a.N = N; a.d = d; a.V = V; a.cosine = cosine;
   a.inv_t = 1.0f / logits_t; a.logits = const_cast<float*>(logits); a.norm = norm; a.gscale = gscale;
   a.d_table = d_table;
-  carve_workspace(a, workspace, M, N, V);
+  carve_workspace(a, workspace, M, N, V, d);
   scale_rows_kernel<<<rt_num_cus() * 4, 256, 0, stream>>>(d_sess_unit, ld_du, d_sess, ld_dsess, M, d, norm, gscale);
   RT_CHECK_LAUNCH();
   return dispatch_sampled(a, 2, stream);

@@ -47,17 +47,20 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restr
 
 // Backward of K2 without float atomics (device-scope atomics on gfx950 resolve memory-side and made the old scatter
 // 5x slower than the data movement): positions are counting-sorted by item id, one wave reduces each table row
-// (a 16-wave workgroup for rows hit by more than EMB_HEAVY_T positions — popularity skew), and the positional
+// (rows hit by more than EMB_HEAVY_T positions — popularity skew — are cut into chunks, each reduced by its own
+// workgroup into a slab row that the row's wave then combines), and the positional
 // gradient is a strided column sum with one workgroup per position.  g = dropped gout (mask regenerated).
 //   gtable[id] = scale * sum_{m: ids[m] == id} g[m]   (row 0 = padding_idx stays 0: item_net.py:260-264)
 //   gpos[L-1-l] = sum_b g[b*L + l]
-constexpr int EMB_HEAVY_T = 128, EMB_HEAVY_WAVES = 16;
+constexpr int EMB_HEAVY_T = 128, EMB_HEAVY_CH = 128, EMB_HEAVY_WAVES = 4;   // popular rows are cut into 128-position chunks (rt_scan.h)
+inline long long emb_chunk_cap(long long M) { return M / EMB_HEAVY_CH + M / EMB_HEAVY_T + 2; }
 
 struct EmbBwdArgs {
   const long long* ids; const float* gout; float scale; int M, L, d, V; float p;
   unsigned long long seed, stream;
   float* gtable; float* gpos;
-  int* count; int* offsets; int* cursor; int* blocksum; int* order; int* rank; int* heavy_count; int* heavy_ids;
+  int* count; int* offsets; int* cursor; int* blocksum; int* order; int* rank; int* heavy_count; int* heavy_ids; int* heavy_chunk;
+  float* slab;   // [chunks][d] partial rows of the popular ids
 };
 
 __global__ __launch_bounds__(256) void embed_order_kernel(EmbBwdArgs a) {
@@ -107,14 +110,21 @@ __global__ __launch_bounds__(256) void embed_bwd_rows_kernel(EmbBwdArgs a) {
   const int id = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (id >= a.V) return;
   const int beg = a.offsets[id], end = a.offsets[id + 1];
-  if (end - beg > EMB_HEAVY_T) {
-    if (lane == 0) a.heavy_ids[atomicAdd(a.heavy_count, 1)] = id;
-    return;
-  }
   f32x4 acc[NDV];
 #pragma unroll
   for (int i = 0; i < NDV; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  embed_accumulate<NDV>(a, beg, end, lane, acc);
+  const int slot = a.cursor[id];
+  if (slot >= 0) {   // popular id: combine the partial rows of its chunks (fixed order)
+    const int n_ch = (end - beg + EMB_HEAVY_CH - 1) / EMB_HEAVY_CH;
+    for (int c = 0; c < n_ch; ++c)
+#pragma unroll
+      for (int i = 0; i < NDV; ++i) {
+        const int col = lane * 4 + 256 * i;
+        if (col < a.d) acc[i] += *reinterpret_cast<const f32x4*>(a.slab + (long long)(slot + c) * a.d + col);
+      }
+  } else {
+    embed_accumulate<NDV>(a, beg, end, lane, acc);
+  }
 #pragma unroll
   for (int i = 0; i < NDV; ++i) {
     const int c = lane * 4 + 256 * i;
@@ -122,15 +132,17 @@ __global__ __launch_bounds__(256) void embed_bwd_rows_kernel(EmbBwdArgs a) {
   }
 }
 
+// one 4-wave workgroup per chunk of a popular id: 32 positions per wave, LDS combine, partial row -> slab
 template <int NDV>
 __global__ __launch_bounds__(EMB_HEAVY_WAVES * 64) void embed_bwd_heavy_kernel(EmbBwdArgs a) {
   __shared__ f32x4 s_part[EMB_HEAVY_WAVES][NDV][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n_heavy = *a.heavy_count;
-  for (int h = blockIdx.x; h < n_heavy; h += gridDim.x) {
+  const int n_chunks = *a.heavy_count;
+  for (int h = blockIdx.x; h < n_chunks; h += gridDim.x) {
     const int id = a.heavy_ids[h];
-    const int beg = a.offsets[id], end = a.offsets[id + 1];
-    const int per = ((end - beg + EMB_HEAVY_WAVES - 1) / EMB_HEAVY_WAVES + 15) & ~15;
+    const int beg = a.offsets[id] + a.heavy_chunk[h] * EMB_HEAVY_CH;
+    const int end = min(beg + EMB_HEAVY_CH, a.offsets[id + 1]);
+    const int per = EMB_HEAVY_CH / EMB_HEAVY_WAVES;
     const int wb = min(beg + wave * per, end), we = min(wb + per, end);
     f32x4 acc[NDV];
 #pragma unroll
@@ -142,10 +154,10 @@ __global__ __launch_bounds__(EMB_HEAVY_WAVES * 64) void embed_bwd_heavy_kernel(E
     if (wave == 0) {
 #pragma unroll
       for (int i = 0; i < NDV; ++i) {
-        f32x4 t = {0.f, 0.f, 0.f, 0.f};
-        for (int w = 0; w < EMB_HEAVY_WAVES; ++w) t += s_part[w][i][lane];
         const int c = lane * 4 + 256 * i;
-        if (c < a.d) *reinterpret_cast<f32x4*>(a.gtable + (long long)id * a.d + c) = t * a.scale;
+        if (c < a.d)
+          *reinterpret_cast<f32x4*>(a.slab + (long long)h * a.d + c) =
+              (s_part[0][i][lane] + s_part[1][i][lane]) + (s_part[2][i][lane] + s_part[3][i][lane]);
       }
     }
     __syncthreads();
@@ -196,16 +208,17 @@ int launch_embed_bwd(const EmbBwdArgs& a, hipStream_t stream) {
   RT_CHECK_HIP(hipMemsetAsync(a.count, 0, sizeof(int) * ((size_t)n + 1), stream));   // + heavy_count
   agg_rank_kernel<<<(a.M + AGG_T - 1) / AGG_T, AGG_T, 0, stream>>>(a.ids, a.M, a.count, a.rank, 1);
   RT_CHECK_LAUNCH();
-  { const int rc = exclusive_scan_counts(a.count, n, a.offsets, a.cursor, a.blocksum, stream); if (rc != RT_OK) return rc; }
+  {
+    const int rc = exclusive_scan_counts(a.count, n, a.offsets, a.cursor, a.blocksum, stream, EMB_HEAVY_T, EMB_HEAVY_CH,
+                                         a.heavy_count, a.heavy_ids, a.heavy_chunk);
+    if (rc != RT_OK) return rc;
+  }
   embed_order_kernel<<<(a.M + 255) / 256, 256, 0, stream>>>(a);
+  RT_CHECK_LAUNCH();
+  embed_bwd_heavy_kernel<NDV><<<(int)min(emb_chunk_cap(a.M), (long long)rt_num_cus() * 8), EMB_HEAVY_WAVES * 64, 0, stream>>>(a);
   RT_CHECK_LAUNCH();
   embed_bwd_rows_kernel<NDV><<<(a.V + 3) / 4, 256, 0, stream>>>(a);
   RT_CHECK_LAUNCH();
-  const int max_heavy = a.M / EMB_HEAVY_T;
-  if (max_heavy > 0) {
-    embed_bwd_heavy_kernel<NDV><<<min(max_heavy, rt_num_cus()), EMB_HEAVY_WAVES * 64, 0, stream>>>(a);
-    RT_CHECK_LAUNCH();
-  }
   if (a.gpos) {
     embed_bwd_pos_kernel<NDV><<<a.L, 256, 0, stream>>>(a);
     RT_CHECK_LAUNCH();
@@ -572,9 +585,9 @@ int rt_embed_fwd(const int64_t* ids, const float* table, const float* pos, float
 }
 
 // Host arithmetic: bytes of the int scratch rt_embed_bwd needs.
-size_t rt_embed_bwd_workspace_bytes(int32_t M, int32_t V) {
-  const size_t n = (size_t)V + 1;
-  return 4 * (3 * n + 1 + scan_blocks(n) + 64 + 2 * (size_t)M + (size_t)M / EMB_HEAVY_T + 2);
+size_t rt_embed_bwd_workspace_bytes(int32_t M, int32_t V, int32_t d) {
+  const size_t n = (size_t)V + 1, cap = (size_t)emb_chunk_cap(M);
+  return 4 * (cap * ((size_t)d + 2) + 3 * n + 1 + scan_blocks(n) + 64 + 2 * (size_t)M + 4);
 }
 
 // gtable [V,d] and gpos [L,d] (optional) are fully overwritten; M must be a multiple of L when gpos is given.
@@ -583,12 +596,13 @@ int rt_embed_bwd(const int64_t* ids, const float* gout, float scale, int32_t M, 
                  hipStream_t stream) {
   (void)hipGetLastError();
   if ((d & 3) != 0 || L <= 0 || V <= 0 || M < 0 || d > 1024 || (gpos && (M % L) != 0)) return RT_ERR_INVALID_ARG;
-  if (workspace == nullptr || workspace_bytes < rt_embed_bwd_workspace_bytes(M, V)) return RT_ERR_WORKSPACE;
+  if (workspace == nullptr || workspace_bytes < rt_embed_bwd_workspace_bytes(M, V, d)) return RT_ERR_WORKSPACE;
   EmbBwdArgs a{};
   a.ids = reinterpret_cast<const long long*>(ids); a.gout = gout; a.scale = scale; a.M = M; a.L = L; a.d = d; a.V = V; a.p = p;
   a.seed = seed; a.stream = stream_id; a.gtable = gtable; a.gpos = gpos;
-  const size_t n = (size_t)V + 1;
-  int* ip = reinterpret_cast<int*>(workspace);
+  const size_t n = (size_t)V + 1, cap = (size_t)emb_chunk_cap(M);
+  a.slab = reinterpret_cast<float*>(workspace);   // first: 16-byte aligned rows
+  int* ip = reinterpret_cast<int*>(a.slab + cap * (size_t)d);
   a.count = ip; ip += n;
   a.heavy_count = ip; ip += 1;          // directly behind count: one memset clears both
   a.offsets = ip; ip += n;
@@ -596,7 +610,8 @@ int rt_embed_bwd(const int64_t* ids, const float* gout, float scale, int32_t M, 
   a.blocksum = ip; ip += scan_blocks(n) + 64;
   a.order = ip; ip += M;
   a.rank = ip; ip += M;
-  a.heavy_ids = ip;
+  a.heavy_ids = ip; ip += cap;
+  a.heavy_chunk = ip;
   if (d <= 256) return launch_embed_bwd<1>(a, stream);
   if (d <= 512) return launch_embed_bwd<2>(a, stream);
   return launch_embed_bwd<4>(a, stream);

@@ -58,9 +58,23 @@ __global__ __launch_bounds__(1024) void scan_blocksums_kernel(int* __restrict__ 
     __syncthreads();
   }
 }
-__global__ void scan_add_kernel(int* __restrict__ offsets, int* __restrict__ cursor, const int* __restrict__ blocksum, int n) {
+// Finalises the scan and cuts POPULAR keys into chunks: a key with more than `heavy_t` entries gets ceil(count / chunk)
+// consecutive slots of the chunk list (heavy_key / heavy_chunk) and cursor[key] = its first slot; every other key gets
+// cursor[key] = -1.  A chunk is reduced by its own workgroup into a partial row (slab), so the cost of a popular key is
+// spread over the chip instead of serialising on one wave or one workgroup.
+__global__ void scan_add_kernel(int* __restrict__ offsets, int* __restrict__ cursor, const int* __restrict__ blocksum, int n,
+                                const int* __restrict__ count, int heavy_t, int chunk, int* __restrict__ heavy_count,
+                                int* __restrict__ heavy_key, int* __restrict__ heavy_chunk) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { const int o = offsets[i] + blocksum[i / (SCAN_T * SCAN_E)]; offsets[i] = o; cursor[i] = o; }
+  if (i >= n) return;
+  offsets[i] = offsets[i] + blocksum[i / (SCAN_T * SCAN_E)];
+  int slot = -1;
+  if (heavy_count != nullptr && count[i] > heavy_t) {
+    const int n_ch = (count[i] + chunk - 1) / chunk;
+    slot = atomicAdd(heavy_count, n_ch);
+    for (int c = 0; c < n_ch; ++c) { heavy_key[slot + c] = i; heavy_chunk[slot + c] = c; }
+  }
+  cursor[i] = slot;
 }
 
 // ---- workgroup-aggregated histogram / scatter of skewed keys -------------------------------------------------------
@@ -102,15 +116,18 @@ __global__ __launch_bounds__(AGG_T) void agg_rank_kernel(const long long* __rest
   if (slot >= 0) rank[(long long)i * stride] = t.base[slot] + r;
 }
 
-// offsets[i] = sum(count[0..i)), cursor = copy of offsets (scatter cursors); blocksum: ceil(n/4096) + 1 ints of scratch
+// offsets[i] = sum(count[0..i)); cursor[i] = first chunk slot of a popular key or -1; blocksum: ceil(n/4096) + 1 ints of scratch
 inline size_t scan_blocks(size_t n) { return (n + SCAN_T * SCAN_E - 1) / (SCAN_T * SCAN_E); }
-inline int exclusive_scan_counts(const int* count, int n, int* offsets, int* cursor, int* blocksum, hipStream_t stream) {
+inline int exclusive_scan_counts(const int* count, int n, int* offsets, int* cursor, int* blocksum, hipStream_t stream,
+                                 int heavy_t = 0, int chunk = 1, int* heavy_count = nullptr, int* heavy_key = nullptr,
+                                 int* heavy_chunk = nullptr) {
   const int nb = (int)scan_blocks((size_t)n);
   scan_local_kernel<<<nb, SCAN_T, 0, stream>>>(count, n, offsets, blocksum);
   RT_CHECK_LAUNCH();
   scan_blocksums_kernel<<<1, 1024, 0, stream>>>(blocksum, nb);
   RT_CHECK_LAUNCH();
-  scan_add_kernel<<<(n + 255) / 256, 256, 0, stream>>>(offsets, cursor, blocksum, n);
+  scan_add_kernel<<<(n + 255) / 256, 256, 0, stream>>>(offsets, cursor, blocksum, n, count, heavy_t, chunk, heavy_count, heavy_key,
+                                                       heavy_chunk);
   RT_CHECK_LAUNCH();
   return RT_OK;
 }

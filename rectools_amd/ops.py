@@ -257,7 +257,7 @@ class _Embed(torch.autograd.Function):
         gpos = None
         if pshape is not None:  # rows [0, L) are written; a longer table keeps zero gradient behind them
             gpos = (torch.empty if pshape[0] == L else torch.zeros)(pshape, dtype=torch.float32, device=gout.device)
-        ws_bytes = _lib.load().rt_embed_bwd_workspace_bytes(M, V)
+        ws_bytes = _lib.load().rt_embed_bwd_workspace_bytes(M, V, tshape[1])
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=gout.device)
         _c("rt_embed_bwd", ids, gout, float(scale), M, L, tshape[1], V, float(p), seed, sid, gtable, gpos, ws, ws_bytes)
         return gtable, gpos, None, None, None, None
@@ -699,7 +699,7 @@ class _SampledLoss(torch.autograd.Function):
         out = torch.empty((2,), dtype=torch.float32, device=dev)
         train = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         if train:  # one pass over the candidate rows also yields the unit gradients the backward needs
-            ws_bytes = _lib.load().rt_sampled_loss_bwd_workspace_bytes(M, N, V)
+            ws_bytes = _lib.load().rt_sampled_loss_bwd_workspace_bytes(M, N, V, d)
             ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
             du = torch.empty((M, d), dtype=torch.float32, device=dev)
             _c("rt_sampled_loss_fwd_train", sess, sess.stride(0), table, y, neg, w, M, N, d, V, loss, int(cosine),

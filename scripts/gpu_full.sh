@@ -16,6 +16,7 @@ prof() { name=$1; shift
   head -12 gpurun_out/prof_$name.md | cut -c1-160
 }
 prof train --workload train --steps 10 --warmup 3
+RT_SIDE_STREAM=0 prof train_single_stream --workload train --steps 10 --warmup 3   # kernel durations without wgrad overlap: what bench.py's roofline pass times
 prof topk5m --workload topk5m --steps 4 --warmup 1
 prof recommend --workload recommend --steps 5 --warmup 1
 pmc() { name=$1; ctr=$2; shift; shift
@@ -35,5 +36,5 @@ PY
 }
 pmc topk5m_fetch FETCH_SIZE --workload topk5m --steps 2 --warmup 1
 pmc topk5m_write WRITE_SIZE --workload topk5m --steps 2 --warmup 1
-pmc train_fetch FETCH_SIZE --workload train --steps 3 --warmup 1
+bash scripts/gpu_pmc_train.sh > /dev/null 2>&1; head -4 gpurun_out/pmc_train_FETCH_SIZE.txt; head -3 gpurun_out/pmc_train_WRITE_SIZE.txt
 find gpurun_out -name "*.db" -size +20M -delete; find gpurun_out -name "*.csv" -size +5M -delete
