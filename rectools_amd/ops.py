@@ -95,12 +95,23 @@ def _side_enabled() -> bool:
     return os.environ.get("RT_SIDE_STREAM", "1") != "0" and _TIMING is None   # per-call timing needs one stream
 
 
+def _steals_grad(*params: tp.Optional[torch.Tensor]) -> bool:
+    """True when autograd will simply ADOPT the gradient tensors returned for these parameters (leaf tensors without an
+    existing `.grad`): no kernel touches them before the end-of-backward join, so they may still be in flight on the
+    side stream.  Slices / views of parameters, or gradient accumulation into an existing `.grad`, run autograd kernels
+    on the main stream right after the node returns — then the node has to join before returning."""
+    return all(p is None or (p.is_leaf and p.grad is None) for p in params)
+
+
 class _OnSide:
     """Context: run the enclosed launches on the side stream, ordered after everything issued so far on the current one.
-    Tensors touched inside must be passed to `uses()` so that the caching allocator does not recycle them early."""
+    Tensors touched inside must be passed to `uses()` so that the caching allocator does not recycle them early.
+    defer=True leaves the results in flight until the end of the backward pass; defer=False requires `join_now()`
+    before the autograd node returns."""
 
-    def __init__(self, dev: torch.device) -> None:
+    def __init__(self, dev: torch.device, defer: bool = True) -> None:
         self.dev = dev
+        self.defer = defer
         self.enabled = _side_enabled()
 
     def __enter__(self) -> "_OnSide":
@@ -112,9 +123,10 @@ class _OnSide:
             self.side = side
             self.ctx = torch.cuda.stream(side)
             self.ctx.__enter__()
-            if not _SIDE_DIRTY:  # join when the autograd engine has issued the whole backward pass
-                torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
-            _SIDE_DIRTY.add(self.dev)
+            if self.defer:
+                if not _SIDE_DIRTY:  # join when the autograd engine has issued the whole backward pass
+                    torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+                _SIDE_DIRTY.add(self.dev)
         return self
 
     def uses(self, *tensors: torch.Tensor) -> None:
@@ -125,6 +137,10 @@ class _OnSide:
     def __exit__(self, *exc: tp.Any) -> None:
         if self.enabled:
             self.ctx.__exit__(*exc)
+
+    def join_now(self) -> None:
+        if self.enabled and not self.defer:
+            torch.cuda.current_stream(self.dev).wait_event(self.side.record_event())
 
 
 def join_side_streams() -> None:
@@ -167,13 +183,13 @@ class _Linear(torch.autograd.Function):
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
         _gemm(x, x.stride(0), 1, weight, weight.stride(0), 1, y, N, bias, residual,
               0 if residual is None else residual.stride(0), M, N, K, 1 if relu else 0)
-        ctx.save_for_backward(x, weight, y if relu else None)
+        ctx.save_for_backward(x, weight, y if relu else None, bias)
         ctx.has_bias, ctx.has_res, ctx.relu = bias is not None, residual is not None, relu
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight, y = ctx.saved_tensors
+        x, weight, y, bias = ctx.saved_tensors
         M, K = x.shape
         N = weight.shape[0]
         dy = dy.contiguous()
@@ -182,18 +198,24 @@ class _Linear(torch.autograd.Function):
             _c("rt_act_dropout_bwd", dy, y, ACT_RELU, 0.0, 0, 0, dy.numel(), dz)
             dy = dz
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
-            _gemm(dy, N, 1, weight, weight.stride(0), 0, dx, K, None, None, 0, M, K, N)  # dx = dy @ W
+        sd = None
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1]:   # issued first, on the side stream: it overlaps the dgrad product below
             dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
             if want_db:  # db = colsum(dy) rides on the dy^T tiles of the wgrad product
                 db = torch.empty((N,), dtype=torch.float32, device=dy.device)
-            _gemm(dy, N, 0, x, x.stride(0), 0, dw, K, None, None, 0, N, K, M, 0, _wgrad_splits(M), db)  # dW = dy^T @ x
+            sd = _OnSide(dy.device, defer=_steals_grad(weight, bias if want_db else None))
+            with sd:
+                sd.uses(*(t for t in (dy, x, dw, db) if t is not None))
+                _gemm(dy, N, 0, x, x.stride(0), 0, dw, K, None, None, 0, N, K, M, 0, _wgrad_splits(M), db)  # dW = dy^T @ x
         elif want_db:
             db = torch.zeros((N,), dtype=torch.float32, device=dy.device)
             _c("rt_colsum", dy, N, M, N, db)
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+            _gemm(dy, N, 1, weight, weight.stride(0), 0, dx, K, None, None, 0, M, K, N)  # dx = dy @ W
+        if sd is not None:
+            sd.join_now()   # parameter slices / accumulating grads: autograd touches dw right after this node
         dres = dy if (ctx.has_res and ctx.needs_input_grad[3]) else None
         return dx, dw, db, dres, None
 
@@ -221,10 +243,14 @@ class _MatmulNN(torch.autograd.Function):
         M, K = x.shape
         N = p.shape[1]
         dy = dy.contiguous()
+        dp = torch.empty((K, N), dtype=torch.float32, device=dy.device)
+        sd = _OnSide(dy.device, defer=_steals_grad(p))
+        with sd:
+            sd.uses(x, dy, dp)
+            _gemm(x, x.stride(0), 0, dy, N, 0, dp, N, None, None, 0, K, N, M, 0, _wgrad_splits(M))  # dP = x^T @ dy
         dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
         _gemm(dy, N, 1, p, N, 1, dx, K, None, None, 0, M, K, N)  # dx = dy @ P^T : B(k', n) = P[k'*N + n] (kc)
-        dp = torch.empty((K, N), dtype=torch.float32, device=dy.device)
-        _gemm(x, x.stride(0), 0, dy, N, 0, dp, N, None, None, 0, K, N, M, 0, _wgrad_splits(M))  # dP = x^T @ dy
+        sd.join_now()
         return dx, dp
 
 
@@ -560,6 +586,11 @@ class _SASRecLayer(torch.autograd.Function):
         dev = g_out.device
         new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
         sp = _wgrad_splits(M)
+        # weight gradients stay in flight on the side stream only if autograd merely adopts them (see _steals_grad);
+        # saved 1-D parameters are not kept, so the check covers the matrices — biases / LN vectors of one block are
+        # leaves exactly when its matrices are
+        defer = _steals_grad(ln1_w, in_w, out_w, ln2_w, w1, w2)
+        side_ctxs = []
 
         def ln_bwd(dy, x, w, mean, rstd):
             dx, dw, db = new(M, d), new(d), new(d)
@@ -575,7 +606,8 @@ class _SASRecLayer(torch.autograd.Function):
         else:
             g_o = g_out
         d_w2, d_b2 = new(d, dff), new(d)
-        with _OnSide(dev) as sd:   # weight gradients leave the critical path (see _OnSide)
+        with _OnSide(dev, defer) as sd:   # weight gradients leave the critical path (see _OnSide)
+            side_ctxs.append(sd)
             sd.uses(g_o, hdrop, d_w2, d_b2)
             _gemm(g_o, d, 0, hdrop, dff, 0, d_w2, dff, None, None, 0, d, dff, M, 0, sp, d_b2)
         g_hd = new(M, dff)
@@ -583,7 +615,8 @@ class _SASRecLayer(torch.autograd.Function):
         g_h = new(M, dff)   # dropout mask and relu'(h) in one pass (relu'(z) == [h > 0])
         _c("rt_act_dropout_bwd", g_hd, h, ACT_RELU, float(p), seed_h[0], seed_h[1], g_hd.numel(), g_h)
         d_w1, d_b1 = new(dff, d), new(dff)
-        with _OnSide(dev) as sd:
+        with _OnSide(dev, defer) as sd:
+            side_ctxs.append(sd)
             sd.uses(g_h, f, d_w1, d_b1)
             _gemm(g_h, dff, 0, f, d, 0, d_w1, d, None, None, 0, dff, d, M, 0, sp, d_b1)
         g_f = new(M, d)     # residual branch (g_out) added in the dgrad epilogue
@@ -591,7 +624,8 @@ class _SASRecLayer(torch.autograd.Function):
         g_y, d_ln2w, d_ln2b = ln_bwd(g_f, y, ln2_w, mean2, rstd2)
         # ---- attention: y = q + Wo A + bo
         d_wo, d_bo = new(d, d), new(d)
-        with _OnSide(dev) as sd:
+        with _OnSide(dev, defer) as sd:
+            side_ctxs.append(sd)
             sd.uses(g_y, A, d_wo, d_bo)
             _gemm(g_y, d, 0, A, d, 0, d_wo, d, None, None, 0, d, d, M, 0, sp, d_bo)
         g_A = new(M, d)
@@ -600,7 +634,8 @@ class _SASRecLayer(torch.autograd.Function):
         _c("rt_mha_bwd", Q, d, KV, 2 * d, KV[:, d:], 2 * d, A, d, g_A, d, lse, ids, B, H, L, d // H, int(causal), int(keypad),
            float(p), seed_a, gQ, d, gKV, 2 * d, gKV[:, d:], 2 * d, delta)
         d_in_w, d_in_b = new(3 * d, d), new(3 * d)
-        with _OnSide(dev) as sd:
+        with _OnSide(dev, defer) as sd:
+            side_ctxs.append(sd)
             sd.uses(gQ, gKV, q, x0, d_in_w, d_in_b)
             _gemm(gQ, d, 0, q, d, 0, d_in_w, d, None, None, 0, d, d, M, 0, sp, d_in_b)
             _gemm(gKV, 2 * d, 0, x0, d, 0, d_in_w[d:], d, None, None, 0, 2 * d, d, M, 0, sp, d_in_b[d:])
@@ -611,6 +646,8 @@ class _SASRecLayer(torch.autograd.Function):
         _gemm(gKV, 2 * d, 1, in_w[d:], d, 0, g_x0, d, None, g_x0a, d, M, d, 2 * d)
         g_x = new(M, d)
         _c("rt_mul_mask", g_x0, None, ids, d, g_x0.numel(), g_x)
+        if side_ctxs:
+            side_ctxs[-1].join_now()   # no-op when deferred; one event covers every product queued on the side stream
         return (g_x, None, d_ln1w, d_ln1b, d_in_w, d_in_b, d_wo, d_bo, d_ln2w, d_ln2b, d_w1, d_b1, d_w2, d_b2, None)
 
 

@@ -341,3 +341,29 @@ def test_flat_adam_segments_match_torch_adam():
         opt.step(); ref_opt.step()
     for p, q in zip(ref_params, mine):
         torch.testing.assert_close(q.detach().cpu(), p.detach(), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_side_stream_weight_gradients_survive_accumulation_and_parameter_slices():
+    """Weight-gradient GEMMs run on a second HIP stream.  They may stay in flight until the end of the backward pass only
+    when autograd merely adopts the tensors; accumulating into an existing `.grad` (second backward without zeroing) and
+    parameter slices (the packed in_proj of the modular attention path) make autograd kernels read them right away."""
+    from rectools_amd import nn as hnn
+    from rectools_amd import ops
+
+    torch.manual_seed(0)
+    B, L, d, H = 4, 128, 128, 2
+    layer = hnn.SASRecTransformerLayer(d, H, 0.0).cuda().train()
+    ids = torch.randint(1, 50, (B, L)).cuda()
+    x = rnd(B * L, d, seed=2).cuda()
+    gout = rnd(B * L, d, seed=3).cuda()
+    for fused in (True, False):
+        for prm in layer.parameters():
+            prm.grad = None
+        fwd = (lambda: layer(x, ids, B, L, True, False)) if fused else \
+              (lambda: layer.forward_modular(ops.mul_mask(x, None, ids), ids, B, L, True, False))
+        fwd().backward(gout)
+        once = {k: v.grad.clone() for k, v in layer.named_parameters()}
+        fwd().backward(gout)                                     # accumulates into the existing .grad tensors
+        for k, v in layer.named_parameters():
+            close(v.grad, 2 * once[k], rtol=1e-5, atol_rel=1e-6, msg=f"accumulated d{k} (fused={fused})")
