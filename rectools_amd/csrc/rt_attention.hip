@@ -98,16 +98,29 @@ __device__ __forceinline__ void load_row_frags(const float* base, long long ld, 
   }
 }
 
-// stage a [32 rows][HD] tile (rows row0..row0+31 of `base`, columns >= hd zero-filled) into LDS with row stride HD + 4:
-// every later LDS read of the tile is unconditional, whatever the real head dim
+// Tiles are [32 rows][HD] (columns >= hd zero-filled) in LDS with row stride HD + 4: every later LDS read of a tile is
+// unconditional, whatever the real head dim.
+// The streaming kernels prefetch the NEXT tile into registers while the current one is being consumed (a global round
+// trip is ~2 us: staging synchronously exposed it once per tile).  A tile is 32 x HD/4 float4 = HD/32 per thread.
 template <int HD>
-__device__ __forceinline__ void stage_tile(const float* base, long long ld, int row0, int n_rows, int hd, float* dst, int tid) {
-  constexpr int PER_ROW = HD / 4, LD = HD + 4;
-  for (int i = tid; i < TK * PER_ROW; i += AT) {
+__device__ __forceinline__ void load_tile_regs(const float* base, long long ld, int row0, int n_rows, int hd, int tid,
+                                               f32x4 (&regs)[HD / 32]) {
+  constexpr int PER_ROW = HD / 4;
+#pragma unroll
+  for (int j = 0; j < HD / 32; ++j) {
+    const int i = tid + j * AT;
     const int r = i / PER_ROW, c = (i % PER_ROW) * 4;
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    f32x4 v = (row0 + r < n_rows && c < hd) ? *reinterpret_cast<const f32x4*>(base + (long long)(row0 + r) * ld + c) : z;
-    *reinterpret_cast<f32x4*>(dst + r * LD + c) = v;
+    regs[j] = (row0 + r < n_rows && c < hd) ? *reinterpret_cast<const f32x4*>(base + (long long)(row0 + r) * ld + c) : z;
+  }
+}
+template <int HD>
+__device__ __forceinline__ void store_tile_regs(float* dst, int tid, const f32x4 (&regs)[HD / 32]) {
+  constexpr int PER_ROW = HD / 4, LD = HD + 4;
+#pragma unroll
+  for (int j = 0; j < HD / 32; ++j) {
+    const int i = tid + j * AT;
+    *reinterpret_cast<f32x4*>(dst + (i / PER_ROW) * LD + (i % PER_ROW) * 4) = regs[j];
   }
 }
 
@@ -468,12 +481,19 @@ __global__ __launch_bounds__(AT) void attn_fwd_kernel(AttnArgs a) {
   __syncthreads();
   if (MODE == MODE_HSTU && a.ts && qq < a.L) t_q1 = hl.ts[qq + 1];
 
+  f32x4 kreg[HD / 32], vreg[HD / 32];
+  load_tile_regs<HD>(kb, a.ldk, 0, a.L, a.hd, tid, kreg);
+  load_tile_regs<HD>(vb, a.ldv, 0, a.L, a.hd, tid, vreg);
   for (int kt = 0; kt < n_kt; ++kt) {
     __syncthreads();
-    stage_tile<HD>(kb, a.ldk, kt * TK, a.L, a.hd, Ks, tid);
-    stage_tile<HD>(vb, a.ldv, kt * TK, a.L, a.hd, Vs, tid);
+    store_tile_regs<HD>(Ks, tid, kreg);
+    store_tile_regs<HD>(Vs, tid, vreg);
     if (tid < TK) { const int kk = kt * TK + tid; aux[tid] = (kk < a.L && idb[kk] != 0) ? 0.f : 1.f; }
     __syncthreads();
+    if (kt + 1 < n_kt) {   // next tile in flight under this tile's math
+      load_tile_regs<HD>(kb, a.ldk, (kt + 1) * TK, a.L, a.hd, tid, kreg);
+      load_tile_regs<HD>(vb, a.ldv, (kt + 1) * TK, a.L, a.hd, tid, vreg);
+    }
     if (q0 >= a.L || kt > my_last_kt) continue;  // nothing to do for this wave (barriers above are uniform)
     fwd_pair<MODE, HD>(a, Ks, Vs, aux, kt, qq, q_is_pad, t_q1, bh, col, half, qf, hl, oacc, m_run, l_run);
   }
@@ -528,12 +548,19 @@ __global__ __launch_bounds__(AT) void attn_bwd_dq_kernel(AttnArgs a) {
   __syncthreads();
   if (MODE == MODE_HSTU && a.ts && qq < a.L) t_q1 = hl.ts[qq + 1];
 
+  f32x4 kreg[HD / 32], vreg[HD / 32];
+  load_tile_regs<HD>(kb, a.ldk, 0, a.L, a.hd, tid, kreg);
+  load_tile_regs<HD>(vb, a.ldv, 0, a.L, a.hd, tid, vreg);
   for (int kt = 0; kt < n_kt; ++kt) {
     __syncthreads();
-    stage_tile<HD>(kb, a.ldk, kt * TK, a.L, a.hd, Ks, tid);
-    stage_tile<HD>(vb, a.ldv, kt * TK, a.L, a.hd, Vs, tid);
+    store_tile_regs<HD>(Ks, tid, kreg);
+    store_tile_regs<HD>(Vs, tid, vreg);
     if (tid < TK) { const int kk = kt * TK + tid; aux[tid] = (kk < a.L && idb[kk] != 0) ? 0.f : 1.f; }
     __syncthreads();
+    if (kt + 1 < n_kt) {
+      load_tile_regs<HD>(kb, a.ldk, (kt + 1) * TK, a.L, a.hd, tid, kreg);
+      load_tile_regs<HD>(vb, a.ldv, (kt + 1) * TK, a.L, a.hd, tid, vreg);
+    }
     if (q0 >= a.L || kt > my_last_kt) continue;
     dq_pair<MODE, HD>(a, Ks, Vs, aux, kt, qq, q_is_pad, t_q1, bh, col, half, qf, gf, lse_q, delta_q, hl, dqacc);
   }
@@ -587,10 +614,13 @@ __global__ __launch_bounds__(AT) void attn_bwd_dkv_kernel(AttnArgs a) {
   long long t_k = 0;
   if (MODE == MODE_HSTU && a.ts && kk < a.L) t_k = hl.ts[kk];
 
+  f32x4 qreg[HD / 32], greg[HD / 32];
+  load_tile_regs<HD>(qb, a.ldq, first_qt * TK, a.L, a.hd, tid, qreg);
+  load_tile_regs<HD>(gb, a.lddo, first_qt * TK, a.L, a.hd, tid, greg);
   for (int qt = first_qt; qt < n_qt; ++qt) {
     __syncthreads();
-    stage_tile<HD>(qb, a.ldq, qt * TK, a.L, a.hd, Qs, tid);
-    stage_tile<HD>(gb, a.lddo, qt * TK, a.L, a.hd, Gs, tid);
+    store_tile_regs<HD>(Qs, tid, qreg);
+    store_tile_regs<HD>(Gs, tid, greg);
     if (tid < TK) {
       const int q = qt * TK + tid;
       aux[tid] = (MODE == MODE_SOFTMAX && q < a.L) ? a.lse[(long long)bh * a.L + q] : 0.f;
@@ -598,6 +628,10 @@ __global__ __launch_bounds__(AT) void attn_bwd_dkv_kernel(AttnArgs a) {
       aux[2 * TK + tid] = (q < a.L && idb[q] != 0) ? 0.f : 1.f;
     }
     __syncthreads();
+    if (qt + 1 < n_qt) {
+      load_tile_regs<HD>(qb, a.ldq, (qt + 1) * TK, a.L, a.hd, tid, qreg);
+      load_tile_regs<HD>(gb, a.lddo, (qt + 1) * TK, a.L, a.hd, tid, greg);
+    }
     if (k0 >= a.L || qt < my_first_qt) continue;
     dkv_pair<MODE, HD>(a, Qs, Gs, aux, aux + TK, aux + 2 * TK, qt, kk, k_is_pad, t_k, bh, col, half, kf, vf, hl, dkacc, dvacc);
   }

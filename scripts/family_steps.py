@@ -17,7 +17,10 @@ cases = [
     ("HSTU d256 nb2 L512 rel time+pos, sampled_softmax N=128 (config 4 shape)", lambda: HSTUModel(n_factors=256, n_blocks=2, n_heads=4, session_max_len=512, loss="sampled_softmax", n_negatives=128, batch_size=64, epochs=1, deterministic=False), 2048, 100_000, 300.0, 3000),
     ("eSASRec: SASRec + LiGR d512 nb2 L200 sampled_softmax N=128 (config 5 train)", lambda: SASRecModel(n_factors=512, n_blocks=2, n_heads=8, session_max_len=200, loss="sampled_softmax", n_negatives=128, batch_size=128, epochs=1, deterministic=False, transformer_layers_type=hnn.LiGRLayers), 4096, 200_000, 144.0, 2000),
 ]
+only = sys.argv[1:]
 for name, make, n_users, n_items, mean_len, max_len in cases:
+    if only and not any(o.lower() in name.lower() for o in only):
+        continue
     ds = dataset(n_users, n_items, mean_len, max_len, seed=11)
     model = make()
     model.fit(ds); torch.cuda.synchronize()                       # epoch 1 includes warm-up / dataset processing
