@@ -140,9 +140,10 @@ int rt_layernorm_bwd(const float* dy, const float* x, const float* w, const floa
                      rt_stream_t stream);
 
 /* element-wise streams (n = number of floats, multiple of 4).  kind: 0 none, 1 relu, 2 gelu(erf), 3 silu, 4 sigmoid.
- * y = dropout(act(z)) and its backward (net_blocks.py:63-64; hstu.py:257; dropouts at sasrec.py:228, net_blocks.py:258-260) */
-int rt_act_dropout_fwd(const float* z, int32_t kind, float p, uint64_t seed, uint64_t stream_id, int64_t n, float* y,
-                       rt_stream_t stream);
+ * y = dropout(act(z)) [+ residual] and its backward (net_blocks.py:63-64; hstu.py:257; dropouts at sasrec.py:228,
+ * net_blocks.py:258-260); `residual` (nullable) fuses the skip connection that follows the dropout */
+int rt_act_dropout_fwd(const float* z, int32_t kind, float p, uint64_t seed, uint64_t stream_id, int64_t n,
+                       const float* residual, float* y, rt_stream_t stream);
 int rt_act_dropout_bwd(const float* dy, const float* z, int32_t kind, float p, uint64_t seed, uint64_t stream_id,
                        int64_t n, float* dz, rt_stream_t stream);
 /* y = dropout(silu(a) * b)   (SwigluFeedForward, net_blocks.py:108) */

@@ -392,15 +392,17 @@ __device__ __forceinline__ float act_df(float z, int kind) {
   }
 }
 
-// y = drop(act(z))            (dz = drop(dy) * act'(z) with the same seed/stream)
+// y = drop(act(z)) [+ r]      (dz = drop(dy) * act'(z) with the same seed/stream; the residual passes dy through)
 __global__ void act_dropout_fwd_kernel(const f32x4* __restrict__ z, int kind, float p, unsigned long long seed,
-                                       unsigned long long stream, long long n4, f32x4* __restrict__ y) {
+                                       unsigned long long stream, long long n4, const f32x4* __restrict__ r,
+                                       f32x4* __restrict__ y) {
   const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     f32x4 v = z[i];
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = act_f(v[j], kind);
     if (p > 0.f) v = drop4(v, seed, stream, (unsigned long long)i, p, inv_keep);
+    if (r != nullptr) v += r[i];
     y[i] = v;
   }
 }
@@ -665,13 +667,14 @@ int rt_layernorm_bwd(const float* dy, const float* x, const float* w, const floa
   return RT_OK;
 }
 
-int rt_act_dropout_fwd(const float* z, int32_t kind, float p, uint64_t seed, uint64_t stream_id, int64_t n, float* y,
-                       hipStream_t stream) {
+int rt_act_dropout_fwd(const float* z, int32_t kind, float p, uint64_t seed, uint64_t stream_id, int64_t n,
+                       const float* residual, float* y, hipStream_t stream) {
   (void)hipGetLastError();
   if (n <= 0) return RT_OK;
   if ((n & 3) != 0) return RT_ERR_INVALID_ARG;
   act_dropout_fwd_kernel<<<stream_grid(n / 4), 256, 0, stream>>>(reinterpret_cast<const f32x4*>(z), kind, p, seed, stream_id,
-                                                                 n / 4, reinterpret_cast<f32x4*>(y));
+                                                                 n / 4, reinterpret_cast<const f32x4*>(residual),
+                                                                 reinterpret_cast<f32x4*>(y));
   RT_CHECK_LAUNCH();
   return RT_OK;
 }

@@ -331,7 +331,7 @@ class _ActDropout(torch.autograd.Function):
         z = z.contiguous()
         y = torch.empty_like(z)
         seed, sid = RNG.next() if p > 0 else (0, 0)
-        _c("rt_act_dropout_fwd", z, kind, float(p), seed, sid, z.numel(), y)
+        _c("rt_act_dropout_fwd", z, kind, float(p), seed, sid, z.numel(), None, y)
         ctx.save_for_backward(z)
         ctx.meta = (kind, p, seed, sid)
         return y
@@ -559,14 +559,12 @@ class _SASRecLayer(torch.autograd.Function):
         if p > 0:
             seed_h = RNG.next()
             hdrop = new(M, dff)
-            _c("rt_act_dropout_fwd", h, ACT_NONE, float(p), seed_h[0], seed_h[1], h.numel(), hdrop)
+            _c("rt_act_dropout_fwd", h, ACT_NONE, float(p), seed_h[0], seed_h[1], h.numel(), None, hdrop)
             o = new(M, d)
             _gemm(hdrop, dff, 1, w2, dff, 1, o, d, b2, None, 0, M, d, dff)
             seed_o = RNG.next()
-            od = new(M, d)
-            _c("rt_act_dropout_fwd", o, ACT_NONE, float(p), seed_o[0], seed_o[1], o.numel(), od)
-            out = new(M, d)
-            _c("rt_axpy", od, 1.0, f, od.numel(), out)
+            out = new(M, d)   # dropout and the skip connection in one pass
+            _c("rt_act_dropout_fwd", o, ACT_NONE, float(p), seed_o[0], seed_o[1], o.numel(), f, out)
         else:
             hdrop = h
             out = new(M, d)
