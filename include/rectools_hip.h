@@ -113,6 +113,29 @@ int rt_collate(const int64_t* offsets, const int64_t* items, const float* weight
                int64_t mask_id, int64_t* x, int64_t* y, float* yw, int64_t* ts_out, rt_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * K1b item-row producer for feature-aware item nets.
+ *   table[i,:] = ids_emb[i,:] + dropout( sum_j cat_emb[emb_bag_inputs[offsets[i] + j], :] ),  j < input_lengths[i]
+ * Replaces SumOfEmbeddingsConstructor.forward / get_all_embeddings (item_net.py:361-368,463-482) over
+ * IdEmbeddingsItemNet (item_net.py:266-281; ids_emb may be NULL for a features-only net) and CatFeaturesItemNet
+ * (item_net.py:101-132: nn.EmbeddingBag(mode="sum") then nn.Dropout).  `emb_bag_inputs`, `offsets` [V] and
+ * `input_lengths` [V] are the reference module's own int64 buffers (item_net.py:96-98).  ids_emb / out [V,d],
+ * cat_emb [F,d]; d % 4 == 0.
+ * Backward: d ids_emb = d table (identity, not a kernel); d cat_emb [F,d] is reduced over the TRANSPOSED structure,
+ * which is static and prepared once by the host: `t_items` [nnz] = item ids grouped by feature value (ascending
+ * item id inside a group), cut into `n_chunks` chunks that never straddle a group, chunk c = t_items[chunk_ptr[c] :
+ * chunk_ptr[c+1]]; feature value f owns chunks feat_chunk_ptr[f] .. feat_chunk_ptr[f+1] (none => zero gradient).
+ * Every d_cat row is written exactly once, sums run in a fixed order (no float atomics).  The dropout mask is
+ * regenerated from (seed, stream_id).  Workspace: rt_bag_sum_bwd_workspace_bytes = n_chunks * d * 4.
+ * ------------------------------------------------------------------------------------------------ */
+int rt_bag_sum_fwd(const float* ids_emb, const float* cat_emb, const int64_t* emb_bag_inputs, const int64_t* offsets,
+                   const int64_t* input_lengths, int32_t V, int32_t d, float p, uint64_t seed, uint64_t stream_id,
+                   float* out, rt_stream_t stream);
+size_t rt_bag_sum_bwd_workspace_bytes(int64_t n_chunks, int32_t d);
+int rt_bag_sum_bwd(const float* d_out, const int64_t* t_items, const int64_t* chunk_ptr, int64_t n_chunks,
+                   const int64_t* feat_chunk_ptr, int32_t F, int32_t d, float p, uint64_t seed, uint64_t stream_id,
+                   float* d_cat, void* workspace, size_t workspace_bytes, rt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K2  embedding gather + inverse positional encoding + dropout
  * out[m,:] = dropout(table[ids[m]] * scale + pos[L-1-(m mod L)])     (pos may be NULL)
  * Replaces `item_embs[sessions]` (torch_backbone.py:245), LearnableInversePositionalEncoding.forward

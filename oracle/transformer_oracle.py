@@ -3,7 +3,8 @@ TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
 
 Restates, as explicit math on a flat `{reference parameter name: tensor}` dict:
 
-  embed + positions      item_net.py:266-281,463-482 ; net_blocks.py:374-400 ; torch_backbone.py:241-247
+  item table             item_net.py:101-132 (CatFeaturesItemNet: EmbeddingBag sum), 266-281, 463-482 (sum of blocks)
+  embed + positions      net_blocks.py:374-400 ; torch_backbone.py:241-247
   masks                  torch_backbone.py:172-218,249-257  (causal / key-padding / merged with zero diagonal)
   multi-head attention   torch.nn.MultiheadAttention as called at sasrec.py:221-224, net_blocks.py:247-255,
                          ligr.py:90-98  (packed in_proj, 1/sqrt(hd) scaling, additive -inf mask, out_proj)
@@ -31,6 +32,8 @@ Batch = tp.Dict[str, torch.Tensor]
 
 ITEM_EMB = "item_model.item_net_blocks.0.ids_emb.weight"
 POS_EMB = "pos_encoding_layer.pos_emb.weight"
+CAT_BLOCK = "item_model.item_net_blocks.1."          # CatFeaturesItemNet as the second block (the models' default order)
+CAT_EMB = CAT_BLOCK + "embedding_bag.weight"
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -42,9 +45,25 @@ def layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float) ->
     return (x - mu) / torch.sqrt(var + eps) * w + b
 
 
-def embed_sessions(p: Params, x: torch.Tensor, use_scale: bool) -> torch.Tensor:
-    """item_embs[sessions] (* sqrt(d)) + pos_emb[L-1-j]  (torch_backbone.py:245-246, net_blocks.py:388-399)."""
+def item_table(p: Params) -> torch.Tensor:
+    """`SumOfEmbeddingsConstructor.get_all_embeddings()` (item_net.py:361-368,463-482): id embeddings, plus — when the
+    parameter dict holds a CatFeaturesItemNet block — the sum of the embeddings of every (feature, value) id the item
+    carries: `EmbeddingBag(mode="sum")` over `emb_bag_inputs[offsets[i] : offsets[i] + input_lengths[i]]`
+    (item_net.py:101-132; values / weights of the feature matrix are not used, only its pattern)."""
     emb = p[ITEM_EMB]
+    if CAT_EMB not in p:
+        return emb
+    inputs, offsets, lens = p[CAT_BLOCK + "emb_bag_inputs"], p[CAT_BLOCK + "offsets"], p[CAT_BLOCK + "input_lengths"]
+    rows = []
+    for i in range(emb.shape[0]):      # plain loop: this is the checker, catalogues here are small
+        vals = inputs[int(offsets[i]): int(offsets[i]) + int(lens[i])]
+        rows.append(p[CAT_EMB][vals].sum(dim=0))
+    return emb + torch.stack(rows)
+
+
+def embed_sessions(p: Params, x: torch.Tensor, use_scale: bool, table: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
+    """item_embs[sessions] (* sqrt(d)) + pos_emb[L-1-j]  (torch_backbone.py:245-246, net_blocks.py:388-399)."""
+    emb = item_table(p) if table is None else table
     seqs = emb[x]
     L, d = x.shape[1], emb.shape[1]
     if use_scale:
@@ -203,11 +222,11 @@ def stu_layers(seqs, tl_mask, batch: Batch, p: Params, n_blocks: int, n_heads: i
 # ----------------------------------------------------------------------------------------------------
 # backbone / logits / losses
 # ----------------------------------------------------------------------------------------------------
-def encode_sessions(cfg: dict, p: Params, batch: Batch) -> torch.Tensor:
+def encode_sessions(cfg: dict, p: Params, batch: Batch, table: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
     """TransformerTorchBackbone.encode_sessions (torch_backbone.py:220-260)."""
     x = batch["x"]
     tl_mask = (x != 0).unsqueeze(-1).float()
-    seqs = embed_sessions(p, x, cfg.get("use_scale", False))
+    seqs = embed_sessions(p, x, cfg.get("use_scale", False), table)
     kind = cfg["layers"]
     if kind == "stu":
         return stu_layers(seqs, tl_mask, batch, p, cfg["n_blocks"], cfg["H"])
@@ -231,8 +250,8 @@ def _l2norm(e: torch.Tensor) -> torch.Tensor:
 
 def batch_logits(cfg: dict, p: Params, batch: Batch) -> torch.Tensor:
     """`get_batch_logits` (lightning.py:301-309): logits / logits_t."""
-    sess = encode_sessions(cfg, p, batch)
-    items = p[ITEM_EMB]
+    items = item_table(p)        # once per forward, shared by the encoder and the logits (torch_backbone.py:290-293)
+    sess = encode_sessions(cfg, p, batch, items)
     if cfg["dist"] == "cosine":
         sess, items = _l2norm(sess), _l2norm(items)
     if cfg["loss"] == "softmax":
@@ -299,10 +318,10 @@ def training_loss(cfg: dict, p: Params, batch: Batch) -> torch.Tensor:
 
 
 def loss_and_grads(cfg: dict, params: Params, batch: Batch) -> tp.Tuple[torch.Tensor, Params]:
-    p = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    p = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in params.items()}
     loss = training_loss(cfg, p, batch)
     loss.backward()
-    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in p.items()}
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in p.items() if v.is_floating_point()}
     # nn.Embedding(padding_idx=0): the PAD row receives no gradient from the *gather* (item_net.py:260-264)
     # — but it does from the full-catalog / candidate logits, exactly as autograd computes here? No:
     # padding_idx zeroes only the gradient flowing through `ids_emb(items)`; the reference materialises the
@@ -327,6 +346,9 @@ class AdamState:
         bc1 = 1 - self.b1 ** self.t
         bc2 = 1 - self.b2 ** self.t
         for k, p in params.items():
+            if k not in grads:          # integer buffers (item-feature structure) are not optimised
+                out[k] = p
+                continue
             g = grads[k]
             m = self.m.get(k, torch.zeros_like(p)) * self.b1 + (1 - self.b1) * g
             v = self.v.get(k, torch.zeros_like(p)) * self.b2 + (1 - self.b2) * g * g

@@ -16,8 +16,9 @@ import warnings
 import numpy as np
 import pandas as pd
 import torch
+from scipy import sparse
 
-from .dataset import Columns, Dataset, IdMap, Interactions
+from .dataset import Columns, Dataset, IdMap, Interactions, SparseFeatures
 
 PADDING_VALUE = "PAD"
 MASKING_VALUE = "MASK"
@@ -178,7 +179,12 @@ class TransformerDataPreparatorBase:
         item_id_map = IdMap.from_values(np.array(list(self.item_extra_tokens), dtype=object))
         item_id_map = item_id_map.add_ids(interactions[Columns.Item])
         final = Interactions.from_raw(interactions, user_id_map, item_id_map, keep_extra_cols=True)
-        self.train_dataset = Dataset(user_id_map, item_id_map, final)
+        item_features = None
+        if getattr(dataset, "item_features", None) is not None:
+            item_features = self._process_features_for_id_map(dataset.item_features, dataset.item_id_map, item_id_map,
+                                                              self.n_item_extra_tokens)
+        # user features are dropped: the models do not use them (data_preparator.py:261)
+        self.train_dataset = Dataset(user_id_map, item_id_map, final, item_features=item_features)
         self.item_id_map = item_id_map
         self.extra_token_ids = dict(zip(self.item_extra_tokens, item_id_map.convert_to_internal(list(self.item_extra_tokens))))
         self.val_interactions = None
@@ -190,6 +196,18 @@ class TransformerDataPreparatorBase:
             val_inter[Columns.Weight] = 0
             val_inter = pd.concat([val_inter, val_targets], axis=0)
             self.val_interactions = Interactions.from_raw(val_inter, user_id_map, item_id_map, keep_extra_cols=True).df
+
+    @staticmethod
+    def _process_features_for_id_map(raw_features: tp.Any, raw_id_map: tp.Any, id_map: IdMap, n_extra_tokens: int) -> tp.Any:
+        """Item features re-indexed to the model's item ids, with empty rows for the extra tokens
+        (data_preparator.py:194-212).  Sparse features only (the only kind `CatFeaturesItemNet` reads)."""
+        if not hasattr(raw_features, "get_cat_features"):
+            return None   # dense features: no categorical columns, the feature block is skipped (item_net.py:138-143)
+        raw_internal = raw_id_map.convert_to_internal(id_map.get_external_sorted_by_internal()[n_extra_tokens:])
+        taken = raw_features.take(raw_internal)
+        vals = sparse.csr_matrix(taken.values)
+        full = sparse.vstack([sparse.csr_matrix((n_extra_tokens, vals.shape[1]), dtype=vals.dtype), vals], format="csr")
+        return SparseFeatures.from_iterables(full, taken.names)
 
     def train_store(self) -> SequenceStore:
         return SequenceStore.from_interactions(self.train_dataset.interactions.df)

@@ -1,9 +1,11 @@
-"""Minimal host-side mirror of `rectools.dataset` — only what the transformer fit()/recommend() path touches.
+"""Minimal host-side mirror of `rectools.dataset` — only what the transformer fit()/recommend() path touches
+(interactions, id maps, and sparse item features for `CatFeaturesItemNet`).
 
 The engine accepts the reference's own `rectools.dataset.Dataset` unchanged (duck typing: `.user_id_map`,
 `.item_id_map`, `.interactions.df`, `.get_raw_interactions()`, `.get_user_item_matrix()`); this module exists so that
 the package is usable (tests, bench, smoke) where `rectools` is not installed.  Semantics follow
-rectools/dataset/identifiers.py:29-242, interactions.py:30-201 and dataset.py:108-348; no code is shared.
+rectools/dataset/identifiers.py:29-242, interactions.py:30-201, features.py:172-468 and dataset.py:108-348; no code
+is shared.
 """
 from __future__ import annotations
 
@@ -130,8 +132,92 @@ class Interactions:
         return m
 
 
+DIRECT_FEATURE_VALUE = "__is_direct_feature"   # second element of a direct (non-categorical) feature's name
+
+
+class SparseFeatures:
+    """Sparse feature matrix [n_objects, n_columns] + column names `(feature, value)` (features.py:172-468).
+
+    Direct features keep their numeric value in one column named `(feature, DIRECT_FEATURE_VALUE)`; a categorical
+    feature becomes one column per distinct value (one-hot, duplicates counted, times weight)."""
+
+    def __init__(self, values: sparse.csr_matrix, names: tp.Sequence[tp.Tuple[tp.Any, tp.Any]]) -> None:
+        names = tuple(names)
+        if values.shape[1] != len(names):
+            raise ValueError("Number of feature names must be equal to the number of columns of the values matrix")
+        self.values, self.names = values, names
+
+    @classmethod
+    def from_iterables(cls, values: sparse.csr_matrix, names: tp.Iterable[tp.Tuple[tp.Any, tp.Any]]) -> "SparseFeatures":
+        return cls(sparse.csr_matrix(values).astype(np.float32), tuple(names))
+
+    @classmethod
+    def from_flatten(cls, df: pd.DataFrame, id_map: IdMap, cat_features: tp.Iterable[tp.Any] = (), id_col: str = "id",
+                     feature_col: str = "feature", value_col: str = "value", weight_col: str = "weight") -> "SparseFeatures":
+        """features.py:254-376.  Column order: direct features (first-appearance order), then for every categorical
+        feature in `cat_features` order its values in first-appearance order."""
+        missing = {id_col, feature_col, value_col} - set(df.columns)
+        if missing:
+            raise KeyError(f"Missed columns {missing}")
+        try:
+            ids = id_map.convert_to_internal(df[id_col].values)
+        except KeyError as e:
+            raise KeyError("All ids in `df` must be present in `id_map`") from e
+        try:
+            weights = df[weight_col].values.astype(float) if weight_col in df else np.ones(len(df))
+        except ValueError as e:
+            raise TypeError("Weights must be numeric") from e
+        feats, vals = df[feature_col].values, df[value_col].values
+        cat_features = list(cat_features)
+        n = id_map.size
+        is_cat = pd.Series(feats).isin(cat_features).values
+        blocks, names = [], []
+        direct = ~is_cat
+        direct_names = pd.unique(feats[direct])
+        col = pd.Series(np.arange(len(direct_names)), index=direct_names)
+        try:
+            dvals = vals[direct].astype(np.float32) if direct.any() else np.zeros(0, np.float32)
+        except ValueError as e:
+            raise TypeError("Values of direct features must be numeric") from e
+        blocks.append(sparse.csr_matrix((dvals * weights[direct], (ids[direct], col.reindex(feats[direct]).values.astype(np.int64)
+                                                                if direct.any() else np.zeros(0, np.int64))),
+                                        shape=(n, len(direct_names))))
+        names.extend((f, DIRECT_FEATURE_VALUE) for f in direct_names)
+        for cf in cat_features:
+            sel = feats == cf
+            uniq = pd.unique(vals[sel])
+            vcol = pd.Series(np.arange(len(uniq)), index=uniq)
+            cols = vcol.reindex(vals[sel]).values.astype(np.int64) if sel.any() else np.zeros(0, np.int64)
+            blocks.append(sparse.csr_matrix((weights[sel], (ids[sel], cols)), shape=(n, len(uniq))))
+            names.extend((cf, v) for v in uniq)
+        csr = sparse.hstack(blocks, format="csr")
+        csr.sum_duplicates()
+        return cls.from_iterables(csr, names)
+
+    def get_sparse(self) -> sparse.csr_matrix:
+        return self.values
+
+    def take(self, ids: tp.Any) -> "SparseFeatures":
+        return SparseFeatures(self.values[np.asarray(ids)], self.names)
+
+    def __len__(self) -> int:
+        return self.values.shape[0]
+
+    @property
+    def cat_col_mask(self) -> np.ndarray:
+        return np.array([name[1] != DIRECT_FEATURE_VALUE for name in self.names], dtype=bool)
+
+    @property
+    def cat_feature_indices(self) -> np.ndarray:
+        return np.arange(len(self.names))[self.cat_col_mask]
+
+    def get_cat_features(self) -> "SparseFeatures":
+        idx = self.cat_feature_indices
+        return SparseFeatures(self.values[:, idx], tuple(self.names[i] for i in idx))
+
+
 class Dataset:
-    """Container of id maps and interactions (rectools/dataset/dataset.py:108-348, interactions-only subset)."""
+    """Container of id maps, interactions and (optionally) sparse item features (rectools/dataset/dataset.py:108-348)."""
 
     def __init__(self, user_id_map: IdMap, item_id_map: IdMap, interactions: Interactions, user_features: tp.Any = None,
                  item_features: tp.Any = None) -> None:
@@ -139,12 +225,23 @@ class Dataset:
         self.user_features, self.item_features = user_features, item_features
 
     @classmethod
-    def construct(cls, interactions_df: pd.DataFrame, keep_extra_cols: bool = False, **kwargs: tp.Any) -> "Dataset":
-        if kwargs.get("user_features_df") is not None or kwargs.get("item_features_df") is not None:
-            raise NotImplementedError("features are outside the accelerated path (SURVEY.md §2.1)")
+    def construct(cls, interactions_df: pd.DataFrame, keep_extra_cols: bool = False, item_features_df: tp.Optional[pd.DataFrame] = None,
+                  cat_item_features: tp.Iterable[tp.Any] = (), make_dense_item_features: bool = False,
+                  **kwargs: tp.Any) -> "Dataset":
+        """dataset.py:208-281.  Items that appear only in `item_features_df` are appended to the item id map ("warm"
+        items, dataset.py:295).  User features are not used by the transformer models (data_preparator.py:261) and dense
+        item features have no categorical columns (item_net.py:138-143): both are rejected here."""
+        if kwargs.get("user_features_df") is not None or make_dense_item_features:
+            raise NotImplementedError("user features / dense item features are outside the accelerated path (SURVEY.md §2.1)")
         user_id_map = IdMap.from_values(interactions_df[Columns.User].values)
         item_id_map = IdMap.from_values(interactions_df[Columns.Item].values)
-        return cls(user_id_map, item_id_map, Interactions.from_raw(interactions_df, user_id_map, item_id_map, keep_extra_cols))
+        interactions = Interactions.from_raw(interactions_df, user_id_map, item_id_map, keep_extra_cols)
+        item_features = None
+        if item_features_df is not None:
+            id_col = Columns.Item if Columns.Item in item_features_df else "id"
+            item_id_map = item_id_map.add_ids(item_features_df[id_col].values)
+            item_features = SparseFeatures.from_flatten(item_features_df, item_id_map, cat_item_features, id_col=id_col)
+        return cls(user_id_map, item_id_map, interactions, item_features=item_features)
 
     @property
     def n_hot_users(self) -> int:
@@ -152,10 +249,11 @@ class Dataset:
 
     @property
     def n_hot_items(self) -> int:
-        return self.item_id_map.size
+        """Items with interactions (dataset.py:188-199); items known only from features come after them."""
+        return int(self.interactions.df[Columns.Item].max()) + 1 if len(self.interactions.df) else 0
 
-    def get_hot_item_features(self) -> None:
-        return None
+    def get_hot_item_features(self) -> tp.Any:
+        return None if self.item_features is None else self.item_features.take(np.arange(self.n_hot_items))
 
     def get_user_item_matrix(self, include_weights: bool = True, include_warm_users: bool = False,
                              include_warm_items: bool = False, dtype: tp.Any = np.float32) -> sparse.csr_matrix:

@@ -64,9 +64,15 @@ class TransformerLossModule(nn.Module):
     def cosine(self) -> bool:
         return self.torch_model.similarity_module.distance == Distance.COSINE
 
-    def _loss_from_sessions(self, sess2d: torch.Tensor, y: torch.Tensor, w: torch.Tensor,
+    def _encode(self, batch: Batch) -> tp.Tuple[torch.Tensor, torch.Tensor]:
+        """-> (catalog matrix, session encodings).  The catalog matrix is taken ONCE per step and shared by the session
+        encoder and the loss (torch_backbone.py:290-293): with a feature-aware item net each read is a fused pass with its
+        own dropout mask."""
+        table = self.torch_model.item_model.get_all_embeddings()
+        return table, self.torch_model.encode_sessions(batch, table)
+
+    def _loss_from_sessions(self, table: torch.Tensor, sess2d: torch.Tensor, y: torch.Tensor, w: torch.Tensor,
                             negatives: tp.Optional[torch.Tensor]) -> tp.Tuple[torch.Tensor, tp.Optional[torch.Tensor]]:
-        table = self.torch_model.item_model.table
         y = y.reshape(-1)
         w = w.reshape(-1).contiguous()
         if self.loss == "softmax":
@@ -82,25 +88,25 @@ class TransformerLossModule(nn.Module):
         return ops.sampled_loss(sess2d, table, y, negatives, w, kind, self.cosine, self.logits_t, beta)
 
     def training_loss(self, batch: Batch) -> torch.Tensor:
-        sess = self.torch_model.encode_sessions(batch)
+        table, sess = self._encode(batch)
         B, L, d = sess.shape
-        loss, _ = self._loss_from_sessions(sess.view(B * L, d), batch["y"], batch["yw"], batch.get("negatives"))
+        loss, _ = self._loss_from_sessions(table, sess.view(B * L, d), batch["y"], batch["yw"], batch.get("negatives"))
         return loss
 
     def validation_loss(self, batch: Batch) -> torch.Tensor:
         """Last position only (lightning.py:340-349): y, yw [B,1]; negatives [B,1,N]."""
-        sess = self.torch_model.encode_sessions(batch)
+        table, sess = self._encode(batch)
         last = sess[:, -1, :]
-        loss, _ = self._loss_from_sessions(last, batch["y"], batch["yw"], batch.get("negatives"))
+        loss, _ = self._loss_from_sessions(table, last, batch["y"], batch["yw"], batch.get("negatives"))
         return loss
 
     def batch_logits(self, batch: Batch) -> torch.Tensor:
         """[B, L, 1+N] (sampled losses) — the values the reference's get_batch_logits returns; parity checks only."""
         if self.loss == "softmax":
             raise NotImplementedError("full-catalog logits are never materialised for all positions; use training_loss")
-        sess = self.torch_model.encode_sessions(batch)
+        table, sess = self._encode(batch)
         B, L, d = sess.shape
-        _, logits = self._loss_from_sessions(sess.view(B * L, d), batch["y"], batch["yw"], batch["negatives"])
+        _, logits = self._loss_from_sessions(table, sess.view(B * L, d), batch["y"], batch["yw"], batch["negatives"])
         return logits.view(B, L, -1)
 
 

@@ -76,6 +76,9 @@ class TransformerModelBase:
         recommend_batch_size: int = 256, recommend_torch_device: tp.Optional[str] = None,
         train_min_user_interactions: int = 2,
         similarity_module_type: tp.Type[hnn.DistanceSimilarityModule] = hnn.DistanceSimilarityModule,
+        item_net_block_types: tp.Sequence[tp.Type[torch.nn.Module]] = (hnn.IdEmbeddingsItemNet, hnn.CatFeaturesItemNet),
+        item_net_constructor_type: tp.Type[hnn.SumOfEmbeddingsConstructor] = hnn.SumOfEmbeddingsConstructor,
+        item_net_constructor_kwargs: tp.Optional[dict] = None,
         get_val_mask_func: tp.Optional[tp.Callable] = None, get_val_mask_func_kwargs: tp.Optional[dict] = None,
         data_preparator_kwargs: tp.Optional[dict] = None, transformer_layers_kwargs: tp.Optional[dict] = None,
         pos_encoding_kwargs: tp.Optional[dict] = None, lightning_module_kwargs: tp.Optional[dict] = None,
@@ -93,7 +96,8 @@ class TransformerModelBase:
             transformer_layers_kwargs=transformer_layers_kwargs, pos_encoding_kwargs=pos_encoding_kwargs,
             lightning_module_kwargs=lightning_module_kwargs, similarity_module_kwargs=similarity_module_kwargs, seed=seed,
             data_preparator_type=data_preparator_type, transformer_layers_type=transformer_layers_type,
-            similarity_module_type=similarity_module_type,
+            similarity_module_type=similarity_module_type, item_net_block_types=tuple(item_net_block_types),
+            item_net_constructor_type=item_net_constructor_type, item_net_constructor_kwargs=item_net_constructor_kwargs,
         )
         self._params.update(kwargs)
         for k, v in self._params.items():
@@ -129,12 +133,39 @@ class TransformerModelBase:
         kw.setdefault("distance", self.u2i_dist_default)
         return self.similarity_module_type(**kw)
 
-    def _build_model_from_dataset(self, dataset: tp.Any) -> None:
+    def _init_item_model(self, item_net_schema: tp.Optional[tp.List[dict]]) -> hnn.SumOfEmbeddingsConstructor:
+        """Item net from the processed train dataset (base.py:317-326), or — when restoring a checkpoint — from the shapes
+        recorded with it (the role of `from_dataset_schema`, item_net.py:193-228: buffers are placeholders that the state
+        dict overwrites)."""
+        kw = self._kw(self.item_net_constructor_kwargs)
+        if item_net_schema is None:
+            return self.item_net_constructor_type.from_dataset(self.data_preparator.train_dataset, self.n_factors,
+                                                               self.dropout_rate, self.item_net_block_types, **kw)
+        n_tokens = self.data_preparator.item_id_map.size
+        blocks: tp.List[torch.nn.Module] = []
+        for spec in item_net_schema:
+            if spec["kind"] == "ids":
+                blocks.append(hnn.IdEmbeddingsItemNet(self.n_factors, n_tokens, self.dropout_rate))
+            else:
+                zeros = torch.zeros(n_tokens, dtype=torch.int64)
+                blocks.append(hnn.CatFeaturesItemNet(torch.zeros(spec["nnz"], dtype=torch.int64), zeros, zeros.clone(),
+                                                     spec["n_cat_feature_values"], self.n_factors, self.dropout_rate))
+        return self.item_net_constructor_type(n_tokens, blocks, **kw)
+
+    def _item_net_schema(self) -> tp.List[dict]:
+        out = []
+        for block in self.lightning_model.torch_model.item_model.item_net_blocks:
+            if isinstance(block, hnn.CatFeaturesItemNet):
+                out.append({"kind": "cat", "nnz": int(block.emb_bag_inputs.numel()), "n_cat_feature_values": block.n_cat_feature_values})
+            else:
+                out.append({"kind": "ids"})
+        return out
+
+    def _build_model_from_dataset(self, dataset: tp.Any, item_net_schema: tp.Optional[tp.List[dict]] = None) -> None:
         self.data_preparator.process_dataset_train(dataset)
         if self.seed is not None:  # before ANY parameter is created: 1-D parameters keep their constructor init
             torch.manual_seed(self.seed)
-        n_tokens = self.data_preparator.item_id_map.size
-        item_model = hnn.SumOfEmbeddingsConstructor(n_tokens, [hnn.IdEmbeddingsItemNet(self.n_factors, n_tokens, self.dropout_rate)])
+        item_model = self._init_item_model(item_net_schema)
         pkw = self._kw(self.pos_encoding_kwargs)
         pkw.setdefault("use_scale_factor", self.use_scale_factor_default)
         pos = hnn.LearnableInversePositionalEncoding(self.use_pos_emb, self.session_max_len, self.n_factors, **pkw)
@@ -244,7 +275,15 @@ class TransformerModelBase:
         return self
 
     # ---- inference ----------------------------------------------------------------------------------------
-    def _user_embeddings(self, store: SequenceStore, device: torch.device) -> torch.Tensor:
+    def _item_embeddings(self) -> torch.Tensor:
+        """Catalog matrix in eval mode, produced once per recommend call (lightning.py:386-389)."""
+        lm = self.lightning_model
+        assert lm is not None
+        lm.eval()
+        with torch.no_grad():
+            return lm.torch_model.item_model.get_all_embeddings().detach()
+
+    def _user_embeddings(self, store: SequenceStore, device: torch.device, item_embs: torch.Tensor) -> torch.Tensor:
         """Last-slot encodings of every session, eval mode, kept on the device (lightning.py:378-400)."""
         lm = self.lightning_model
         assert lm is not None
@@ -255,7 +294,7 @@ class TransformerModelBase:
         with torch.no_grad():
             for b0 in range(0, len(store), self.recommend_batch_size):
                 batch = self.data_preparator.collate_recommend_device(dstore, all_idx[b0:b0 + self.recommend_batch_size])
-                enc = lm.torch_model.encode_sessions(batch)
+                enc = lm.torch_model.encode_sessions(batch, item_embs)
                 outs.append(enc[:, -1, :].contiguous())
         return torch.cat(outs) if outs else torch.zeros((0, self.n_factors), device=device)
 
@@ -307,8 +346,8 @@ class TransformerModelBase:
         store = SequenceStore.from_interactions(rec_ds.interactions.df, sort_users=True)  # session i <-> internal user i
         if len(user_ids) == 0 or len(whitelist) == 0:
             return self._frame(np.array([], users.dtype), np.array([], object), np.array([], np.float32), add_rank_col, Columns.User)
-        user_embs = self._user_embeddings(store, device)
-        item_embs = self.lightning_model.torch_model.item_model.table.detach()
+        item_embs = self._item_embeddings()
+        user_embs = self._user_embeddings(store, device, item_embs)
         ranker = HipRanker(self.lightning_model.torch_model.similarity_module.distance, device, user_embs, item_embs)
         filt = None
         if filter_viewed:
@@ -366,14 +405,13 @@ class TransformerModelBase:
         torch.cumsum(counts, 0, out=offsets[1:])
         dstore = DeviceSequenceStore.from_device(offsets, item_s, w_s, None)
         valid_rows = torch.nonzero(valid).reshape(-1)
-        lm.eval()
+        item_embs = self._item_embeddings()
         outs = []
         with torch.no_grad():
             for b0 in range(0, n_valid, self.recommend_batch_size):
                 batch = dp.collate_recommend_device(dstore, valid_rows[b0:b0 + self.recommend_batch_size])
-                outs.append(lm.torch_model.encode_sessions(batch)[:, -1, :].contiguous())
+                outs.append(lm.torch_model.encode_sessions(batch, item_embs)[:, -1, :].contiguous())
         user_embs = torch.cat(outs)
-        item_embs = lm.torch_model.item_model.table.detach()
         ranker = HipRanker(lm.torch_model.similarity_module.distance, device, user_embs, item_embs)
         filt = None
         if filter_viewed:  # CSR of the distinct (user, item) pairs, rows in request order, indices ascending
@@ -407,7 +445,7 @@ class TransformerModelBase:
         target_ids = dp.item_id_map.convert_to_internal(target_items)
         whitelist = self._whitelist(items_to_recommend)
         device = next(self.lightning_model.parameters()).device
-        item_embs = self.lightning_model.torch_model.item_model.table.detach()
+        item_embs = self._item_embeddings()
         ranker = HipRanker(Distance.COSINE, device, item_embs, item_embs)
         kk = k + 1 if filter_itself else k
         ids, scores, counts, _ = ranker.rank_device(target_ids, k=kk, sorted_object_whitelist=whitelist)
@@ -448,6 +486,8 @@ class TransformerModelBase:
         for k, v in self._params.items():
             if isinstance(v, type) or callable(v) and not isinstance(v, (int, float, str, bool)) and v is not None:
                 cfg[k] = _full_path(v) if simple_types else v
+            elif isinstance(v, (tuple, list)) and v and all(isinstance(t, type) for t in v):
+                cfg[k] = [_full_path(t) for t in v] if simple_types else tuple(v)   # item_net_block_types (base.py:95-109)
             else:
                 cfg[k] = v
         return cfg
@@ -466,9 +506,12 @@ class TransformerModelBase:
     def from_config(cls, config: tp.Dict[str, tp.Any]) -> "TransformerModelBase":
         cfg = dict(config)
         klass = _import_object(cfg.pop("cls", cls))
-        for key in ("data_preparator_type", "transformer_layers_type", "similarity_module_type", "get_val_mask_func"):
+        for key in ("data_preparator_type", "transformer_layers_type", "similarity_module_type", "get_val_mask_func",
+                    "item_net_constructor_type"):
             if cfg.get(key) is not None:
                 cfg[key] = _import_object(cfg[key])
+        if cfg.get("item_net_block_types") is not None:
+            cfg["item_net_block_types"] = tuple(_import_object(t) for t in cfg["item_net_block_types"])
         return klass(**cfg)
 
     def __getstate__(self) -> tp.Dict[str, tp.Any]:
@@ -479,7 +522,7 @@ class TransformerModelBase:
             torch.save({"state_dict": {k: v.detach().cpu() for k, v in self.lightning_model.torch_model.state_dict().items()},
                         "optimizer": {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in self.optimizer.state_dict().items()},
                         "item_external_ids": self.data_preparator.item_id_map.external_ids,
-                        "extra_token_ids": self.data_preparator.extra_token_ids}, buf)
+                        "extra_token_ids": self.data_preparator.extra_token_ids, "item_net_schema": self._item_net_schema()}, buf)
             state["checkpoint"] = buf.getvalue()
         return state
 
@@ -494,11 +537,11 @@ class TransformerModelBase:
             ck = torch.load(io.BytesIO(state["checkpoint"]), map_location="cpu", weights_only=False)
             self.data_preparator.item_id_map = IdMap(ck["item_external_ids"])
             self.data_preparator.extra_token_ids = ck["extra_token_ids"]
-            self._build_from_item_map()
+            self._build_from_item_map(ck.get("item_net_schema", [{"kind": "ids"}]))
             self.lightning_model.torch_model.load_state_dict({k: v.to(self._device()) for k, v in ck["state_dict"].items()})
             self.optimizer.load_state_dict({k: (v.to(self._device()) if isinstance(v, torch.Tensor) else v) for k, v in ck["optimizer"].items()})
 
-    def _build_from_item_map(self) -> None:
+    def _build_from_item_map(self, item_net_schema: tp.List[dict]) -> None:
         class _Stub:  # builds modules of the right sizes without re-processing a dataset
             pass
 
@@ -506,10 +549,10 @@ class TransformerModelBase:
         dp_process = self.data_preparator.process_dataset_train
         self.data_preparator.process_dataset_train = lambda ds: None  # type: ignore
         try:
-            self._build_model_from_dataset(None)
+            self._build_model_from_dataset(None, item_net_schema)
         finally:
             self.data_preparator.process_dataset_train = dp_process  # type: ignore
-        assert self.lightning_model.torch_model.item_model.table.shape[0] == n_tokens
+        assert self.lightning_model.torch_model.item_model.n_items == n_tokens
 
     def save(self, path: str) -> int:
         data = pickle.dumps(self)

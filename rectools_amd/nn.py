@@ -20,7 +20,9 @@ from __future__ import annotations
 
 import math
 import typing as tp
+import warnings
 
+import numpy as np
 import torch
 from torch import nn
 
@@ -98,25 +100,112 @@ class IdEmbeddingsItemNet(nn.Module):
         self.n_items = n_items
         self.ids_emb = EmbeddingParams(n_items, n_factors)
 
+    @classmethod
+    def from_dataset(cls, dataset: tp.Any, n_factors: int, dropout_rate: float, **kwargs: tp.Any) -> "IdEmbeddingsItemNet":
+        return cls(n_factors, dataset.item_id_map.size, dropout_rate)
+
     @property
     def out_dim(self) -> int:
         return self.ids_emb.weight.shape[1]
 
 
+class CatFeaturesItemNet(nn.Module):
+    """Item embeddings from categorical item features (item_net.py:60-233): an embedding per (feature, value) pair,
+    summed over the pairs an item carries (`nn.EmbeddingBag(mode="sum")`), then dropout.
+
+    Parameter / buffer names and shapes are the reference's (`embedding_bag.weight`, `offsets`, `emb_bag_inputs`,
+    `input_lengths`), so state dicts are interchangeable.  There is no per-call gather of the structure
+    (`_get_item_inputs_offsets`, item_net.py:123-132): the kernels read the three buffers in place."""
+
+    def __init__(self, emb_bag_inputs: torch.Tensor, input_lengths: torch.Tensor, offsets: torch.Tensor,
+                 n_cat_feature_values: int, n_factors: int, dropout_rate: float, **kwargs: tp.Any) -> None:
+        super().__init__()
+        self.n_cat_feature_values = n_cat_feature_values
+        self.embedding_bag = EmbeddingParams(n_cat_feature_values, n_factors)
+        self.dropout_rate = dropout_rate
+        self.register_buffer("offsets", offsets.to(torch.int64))
+        self.register_buffer("emb_bag_inputs", emb_bag_inputs.to(torch.int64))
+        self.register_buffer("input_lengths", input_lengths.to(torch.int64))
+        self._structure: tp.Optional[ops.BagStructure] = None
+
+    @classmethod
+    def from_dataset(cls, dataset: tp.Any, n_factors: int, dropout_rate: float, **kwargs: tp.Any) -> tp.Optional["CatFeaturesItemNet"]:
+        """item_net.py:149-191: None (block skipped, with the reference's warnings) unless the dataset carries sparse
+        item features with at least one categorical column."""
+        feats = getattr(dataset, "item_features", None)
+        if feats is None:
+            warnings.warn("Ignoring `CatFeaturesItemNet` block because dataset doesn't contain item features.")
+            return None
+        if not hasattr(feats, "get_cat_features"):
+            warnings.warn("Ignoring `CatFeaturesItemNet` block because dataset item features are dense and "
+                          "one-hot-encoded categorical features were not created when constructing dataset.")
+            return None
+        cat = feats.get_cat_features()
+        if len(cat.names) == 0:
+            warnings.warn("Ignoring `CatFeaturesItemNet` block because dataset item features do not contain categorical features.")
+        if cat.values.size == 0:
+            return None
+        csr = cat.values.tocsr()
+        indptr = torch.as_tensor(np.asarray(csr.indptr), dtype=torch.int64)
+        return cls(emb_bag_inputs=torch.as_tensor(np.asarray(csr.indices), dtype=torch.int64), offsets=indptr[:-1],
+                   input_lengths=torch.diff(indptr), n_cat_feature_values=len(cat.names), n_factors=n_factors,
+                   dropout_rate=dropout_rate)
+
+    def structure(self) -> ops.BagStructure:
+        if self._structure is None or self._structure.inputs.device != self.emb_bag_inputs.device:
+            self._structure = ops.BagStructure(self.emb_bag_inputs, self.offsets, self.input_lengths, self.n_cat_feature_values)
+        return self._structure
+
+    def _load_from_state_dict(self, *args: tp.Any, **kwargs: tp.Any) -> None:
+        super()._load_from_state_dict(*args, **kwargs)
+        self._structure = None     # the buffers may describe another catalog now
+
+    @property
+    def out_dim(self) -> int:
+        return self.embedding_bag.weight.shape[1]
+
+
 class SumOfEmbeddingsConstructor(nn.Module):
-    """Item-net constructor (item_net.py:451-487).  Only id embeddings are accelerated (one block)."""
+    """Item-net constructor (item_net.py:289-487): the catalog matrix is the sum of its blocks' embeddings.
+
+    With id embeddings only, the parameter itself is the matrix (no `get_all_embeddings()` copy).  With a
+    CatFeaturesItemNet block the matrix is produced by one fused pass (`ops.item_table`, K1b): every read of `table` runs it (with a
+    fresh dropout mask in training), so callers take it ONCE per step / per recommend() call and pass it on, as the
+    reference's backbone does with `get_all_embeddings()` (torch_backbone.py:290-291)."""
 
     def __init__(self, n_items: int, item_net_blocks: tp.Sequence[nn.Module]) -> None:
         super().__init__()
-        if len(item_net_blocks) != 1 or not isinstance(item_net_blocks[0], IdEmbeddingsItemNet):
-            raise NotImplementedError("the MI355X engine implements IdEmbeddingsItemNet item nets only")
+        if len(item_net_blocks) == 0:
+            raise ValueError("At least one type of net to calculate item embeddings should be provided.")
+        ids = [b for b in item_net_blocks if isinstance(b, IdEmbeddingsItemNet)]
+        cats = [b for b in item_net_blocks if isinstance(b, CatFeaturesItemNet)]
+        if len(ids) > 1 or len(cats) > 1 or len(ids) + len(cats) != len(item_net_blocks):
+            raise NotImplementedError("the MI355X engine implements at most one IdEmbeddingsItemNet and one CatFeaturesItemNet block")
         self.n_items = n_items
-        self.n_item_blocks = 1
+        self.n_item_blocks = len(item_net_blocks)
         self.item_net_blocks = nn.ModuleList(item_net_blocks)
+        # positions, not references: a second attribute holding a block would register it twice in the state dict
+        self._ids_at = item_net_blocks.index(ids[0]) if ids else None
+        self._cat_at = item_net_blocks.index(cats[0]) if cats else None
+
+    @classmethod
+    def from_dataset(cls, dataset: tp.Any, n_factors: int, dropout_rate: float,
+                     item_net_block_types: tp.Sequence[tp.Type[nn.Module]], **kwargs: tp.Any) -> "SumOfEmbeddingsConstructor":
+        blocks = []
+        for block_type in item_net_block_types:
+            block = block_type.from_dataset(dataset, n_factors, dropout_rate, **kwargs)
+            if block is not None:
+                blocks.append(block)
+        return cls(dataset.item_id_map.size, blocks)
 
     @property
     def table(self) -> torch.Tensor:
-        return self.item_net_blocks[0].ids_emb.weight
+        ids_w = self.item_net_blocks[self._ids_at].ids_emb.weight if self._ids_at is not None else None
+        if self._cat_at is None:
+            return ids_w
+        cat = self.item_net_blocks[self._cat_at]
+        p = cat.dropout_rate if self.training else 0.0
+        return ops.item_table(ids_w, cat.embedding_bag.weight, cat.structure(), p)
 
     def get_all_embeddings(self) -> torch.Tensor:
         """The table itself (the reference re-materialises it with a gather every call, item_net.py:361-368)."""

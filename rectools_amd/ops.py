@@ -295,6 +295,77 @@ def embed(table: torch.Tensor, pos: tp.Optional[torch.Tensor], ids: torch.Tensor
     return _Embed.apply(table, pos, ids.reshape(-1), L, scale, p)
 
 
+class BagStructure:
+    """Static item -> category-value structure of a CatFeaturesItemNet, plus its transpose cut into chunks for the
+    backward reduction (include/rectools_hip.h, K1b).  Built once per model from the reference's three buffers."""
+
+    CHUNK = 128   # entries per wave of the backward's first pass
+
+    def __init__(self, emb_bag_inputs: torch.Tensor, offsets: torch.Tensor, input_lengths: torch.Tensor, n_values: int) -> None:
+        import numpy as np
+
+        dev = emb_bag_inputs.device
+        inp = emb_bag_inputs.detach().cpu().numpy().astype(np.int64)
+        off = offsets.detach().cpu().numpy().astype(np.int64)
+        lens = input_lengths.detach().cpu().numpy().astype(np.int64)
+        if off.shape != lens.shape or (lens < 0).any() or (off < 0).any() or (len(off) and (off + lens).max() > len(inp)):
+            raise ValueError("CatFeaturesItemNet: offsets / input_lengths do not describe slices of emb_bag_inputs")
+        # (item, value) pairs in the order the forward reads them
+        item_of = np.repeat(np.arange(len(off), dtype=np.int64), lens)
+        pos = (np.arange(int(lens.sum()), dtype=np.int64) - np.repeat(np.cumsum(lens) - lens, lens)) + np.repeat(off, lens)
+        val_of = inp[pos]
+        if len(val_of) and (val_of.min() < 0 or val_of.max() >= n_values):
+            raise ValueError("CatFeaturesItemNet: emb_bag_inputs holds ids outside [0, n_cat_feature_values)")
+        order = np.lexsort((item_of, val_of))     # grouped by value, ascending item id inside a group
+        t_items, t_vals = item_of[order], val_of[order]
+        counts = np.bincount(t_vals, minlength=n_values).astype(np.int64)
+        starts = np.cumsum(counts) - counts
+        n_ch = (counts + self.CHUNK - 1) // self.CHUNK
+        feat_chunk_ptr = np.concatenate([[0], np.cumsum(n_ch)]).astype(np.int64)
+        ch_val = np.repeat(np.arange(n_values, dtype=np.int64), n_ch)
+        ch_idx = np.arange(int(n_ch.sum()), dtype=np.int64) - np.repeat(feat_chunk_ptr[:-1], n_ch)
+        ch_start = starts[ch_val] + ch_idx * self.CHUNK
+        ch_end = np.minimum(ch_start + self.CHUNK, starts[ch_val] + counts[ch_val])
+        chunk_ptr = np.concatenate([ch_start, ch_end[-1:]]) if len(ch_start) else np.zeros(1, np.int64)
+        self.n_values, self.n_chunks = n_values, int(len(ch_start))
+        self.t_items = torch.from_numpy(np.ascontiguousarray(t_items)).to(dev)
+        self.chunk_ptr = torch.from_numpy(np.ascontiguousarray(chunk_ptr.astype(np.int64))).to(dev)
+        self.feat_chunk_ptr = torch.from_numpy(feat_chunk_ptr).to(dev)
+        self.inputs = emb_bag_inputs.to(torch.int64).contiguous()
+        self.offsets = offsets.to(torch.int64).contiguous()
+        self.lengths = input_lengths.to(torch.int64).contiguous()
+
+
+class _ItemTable(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids_emb, cat_emb, bag, p):
+        V, d = bag.offsets.numel(), cat_emb.shape[1]
+        if ids_emb is not None and tuple(ids_emb.shape) != (V, d):
+            raise ValueError(f"item table: id embeddings {tuple(ids_emb.shape)} do not match the feature structure ({V}, {d})")
+        out = torch.empty((V, d), dtype=torch.float32, device=cat_emb.device)
+        seed, sid = RNG.next() if p > 0 else (0, 0)
+        _c("rt_bag_sum_fwd", ids_emb, cat_emb, bag.inputs, bag.offsets, bag.lengths, V, d, float(p), seed, sid, out)
+        ctx.meta = (bag, p, seed, sid, ids_emb is not None, tuple(cat_emb.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, dE):
+        bag, p, seed, sid, has_ids, cshape = ctx.meta
+        dE = dE.contiguous()
+        d_cat = torch.empty(cshape, dtype=torch.float32, device=dE.device)    # every row is written by the kernel
+        ws_bytes = _lib.load().rt_bag_sum_bwd_workspace_bytes(bag.n_chunks, cshape[1])
+        ws = torch.empty((max(ws_bytes, 4),), dtype=torch.uint8, device=dE.device)
+        _c("rt_bag_sum_bwd", dE, bag.t_items, bag.chunk_ptr, bag.n_chunks, bag.feat_chunk_ptr, cshape[0], cshape[1], float(p),
+           seed, sid, d_cat, ws, ws_bytes)
+        return (dE if has_ids else None), d_cat, None, None
+
+
+def item_table(ids_emb: tp.Optional[torch.Tensor], cat_emb: torch.Tensor, bag: BagStructure, p: float) -> torch.Tensor:
+    """[V,d] catalog matrix = ids_emb + dropout(bag sums of cat_emb) (item_net.py:101-132,266-281,463-482)."""
+    _chk(cat_emb, "item_table")
+    return _ItemTable.apply(ids_emb, cat_emb, bag, p)
+
+
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, eps):

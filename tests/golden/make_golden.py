@@ -2,7 +2,7 @@
 
 Run in the build container only (the reference tree does not exist on the GPU box):
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [ranker] [transformer] [collate]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [ranker] [transformer [only=<substring>]] [collate]
 
 Outputs (committed):  tests/golden/ranker_*.npz, tests/golden/transformer_*.npz, tests/golden/collate_*.npz
 Every file stores the exact inputs next to the reference's outputs, so the oracle (`oracle/`) and the HIP
@@ -121,12 +121,13 @@ def make_ranker() -> None:
 
 if __name__ == "__main__":
     what = sys.argv[1:] or ["ranker", "transformer", "collate"]
+    only = next((w.split("=", 1)[1] for w in what if w.startswith("only=")), "")   # e.g. `transformer only=catfeat`
     if "ranker" in what:
         make_ranker()
     if "transformer" in what:
         from make_golden_transformer import make_transformer  # type: ignore
 
-        make_transformer()
+        make_transformer(only)
     if "collate" in what:
         from make_golden_transformer import make_collate  # type: ignore
 

@@ -51,12 +51,38 @@ def _variants():
         add(f"hstu_time{int(rt)}_pos{int(rp)}", layers="stu", dist="cosine", loss="sampled_softmax", N=4,
             use_scale=True, logits_t=0.05, rel_time=rt, rel_pos=rp)
     add("hstu_softmax_dot", layers="stu", dist="dot", loss="softmax", use_scale=True, rel_time=True, rel_pos=True)
+    # feature-aware item net: IdEmbeddingsItemNet + CatFeaturesItemNet (item_net.py:60-233), F (feature, value) pairs
+    add("sasrec_catfeat_sampled", loss="sampled_softmax", N=5, cat=dict(F=13, max_per_item=4))
+    add("sasrec_catfeat_softmax_cos", dist="cosine", weights="rand", cat=dict(F=7, max_per_item=3))
+    add("bert4rec_catfeat_bce", layers="preln", causal=False, keypad=True, n_extra=2, loss="BCE", cat=dict(F=9, max_per_item=5))
+    add("sasrec_catfeat_mid", V=300, B=5, L=40, d=64, H=4, loss="gBCE", N=7, cat=dict(F=40, max_per_item=6))
     return out
+
+
+def make_cat_structure(cfg, gen: torch.Generator):
+    """Item -> category-value structure in the layout CatFeaturesItemNet.from_dataset produces (item_net.py:171-181):
+    CSR over the catalog, extra-token rows empty (data_preparator.py:203-208), indices ascending inside a row.  Some
+    items carry no category at all; value 0 is popular (tags every third item)."""
+    n_tokens, F, mx = cfg["V"] + cfg["n_extra"], cfg["cat"]["F"], cfg["cat"]["max_per_item"]
+    rows = []
+    for i in range(n_tokens):
+        if i < cfg["n_extra"]:
+            rows.append([])
+            continue
+        n = int(torch.randint(0, mx + 1, (1,), generator=gen))
+        vals = set(torch.randint(0, F, (n,), generator=gen).tolist())
+        if i % 3 == 0:
+            vals.add(0)
+        rows.append(sorted(vals))
+    lens = torch.tensor([len(r) for r in rows], dtype=torch.long)
+    offsets = torch.cumsum(lens, 0) - lens
+    inputs = torch.tensor([v for r in rows for v in r], dtype=torch.long)
+    return inputs, lens, offsets
 
 
 def build_reference(cfg):
     """Instantiate the reference torch modules directly (no Dataset needed)."""
-    from rectools.models.nn.item_net import IdEmbeddingsItemNet, SumOfEmbeddingsConstructor
+    from rectools.models.nn.item_net import CatFeaturesItemNet, IdEmbeddingsItemNet, SumOfEmbeddingsConstructor
     from rectools.models.nn.transformers.hstu import STULayers
     from rectools.models.nn.transformers.lightning import TransformerLightningModule
     from rectools.models.nn.transformers.ligr import LiGRLayers
@@ -66,7 +92,12 @@ def build_reference(cfg):
     from rectools.models.nn.transformers.torch_backbone import TransformerTorchBackbone
 
     n_tokens = cfg["V"] + cfg["n_extra"]
-    item_model = SumOfEmbeddingsConstructor(n_tokens, [IdEmbeddingsItemNet(cfg["d"], n_tokens, 0.0)])
+    blocks = [IdEmbeddingsItemNet(cfg["d"], n_tokens, 0.0)]
+    if cfg.get("cat"):
+        inputs, lens, offsets = make_cat_structure(cfg, torch.Generator().manual_seed(cfg["seed"] + 7))
+        blocks.append(CatFeaturesItemNet(emb_bag_inputs=inputs, input_lengths=lens, offsets=offsets,
+                                         n_cat_feature_values=cfg["cat"]["F"], n_factors=cfg["d"], dropout_rate=0.0))
+    item_model = SumOfEmbeddingsConstructor(n_tokens, blocks)
     pos = LearnableInversePositionalEncoding(True, cfg["L"], cfg["d"], use_scale_factor=cfg["use_scale"])
     kind = cfg["layers"]
     if kind == "sasrec":
@@ -144,10 +175,13 @@ def make_batch(cfg, gen: torch.Generator):
     return batch
 
 
-def make_transformer() -> None:
+def make_transformer(only: str = "") -> None:
+    """`only`: substring filter on the variant name (existing fixtures are not rewritten when new variants are added)."""
     from oracle import ref_shims
 
     for name, cfg in _variants().items():
+        if only and only not in name:
+            continue
         ref_shims.seed_all(cfg["seed"])
         lm = build_reference(cfg)
         lm._xavier_normal_init()

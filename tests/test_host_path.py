@@ -121,3 +121,102 @@ def test_config_roundtrip_and_errors():
 
         with pytest.raises(_lib.HipLibraryError):  # no silent CPU fallback
             m.fit(Dataset.construct(_interactions()))
+
+
+# ---- item features ------------------------------------------------------------------------
+def _item_features():
+    return pd.DataFrame(
+        [[11, "f1", "f1val1"], [11, "f2", "f2val1"], [12, "f1", "f1val1"], [12, "f2", "f2val2"], [13, "f1", "f1val1"],
+         [13, "f2", "f2val3"], [11, "f3", 0], [12, "f3", 1], [13, "f3", 2], [16, "f3", 6], [14, "f2", "f2val1"],
+         [14, "f2", "f2val3"], [99, "f1", "f1val9"]], columns=["id", "feature", "value"])
+
+
+def _feature_interactions():   # the reference's `dataset_item_features` fixture (test_sasrec.py:106-143)
+    return pd.DataFrame(
+        [[10, 13, 1, "2021-11-30"], [10, 11, 1, "2021-11-29"], [10, 12, 1, "2021-11-29"], [30, 11, 1, "2021-11-27"],
+         [30, 13, 2, "2021-11-26"], [40, 11, 1, "2021-11-25"], [40, 14, 1, "2021-11-26"], [50, 16, 1, "2021-11-25"],
+         [10, 14, 1, "2021-11-28"], [10, 16, 1, "2021-11-27"], [20, 13, 9, "2021-11-28"]],
+        columns=["user_id", "item_id", "weight", "datetime"])
+
+
+def test_sparse_item_features_layout_and_train_reindexing():
+    """Known answers produced by the unmodified reference on the same two frames (Dataset.construct ->
+    SASRecDataPreparator.process_dataset_train -> CatFeaturesItemNet.from_dataset; features.py:254-376,
+    data_preparator.py:194-212, item_net.py:149-191)."""
+    from rectools_amd.data_preparator import BERT4RecDataPreparator, SASRecDataPreparator
+    from rectools_amd.dataset import DIRECT_FEATURE_VALUE, Dataset
+    from rectools_amd.nn import CatFeaturesItemNet
+
+    ds = Dataset.construct(_feature_interactions(), item_features_df=_item_features(), cat_item_features=["f1", "f2"])
+    assert ds.item_id_map.external_ids.tolist() == [13, 11, 12, 14, 16, 99] and ds.n_hot_items == 5   # 99: features only
+    assert ds.item_features.names == (("f3", DIRECT_FEATURE_VALUE), ("f1", "f1val1"), ("f1", "f1val9"), ("f2", "f2val1"),
+                                      ("f2", "f2val2"), ("f2", "f2val3"))
+    cat = ds.item_features.get_cat_features()
+    assert cat.values.indptr.tolist() == [0, 2, 4, 6, 8, 8, 9] and len(cat.names) == 5
+    dp = SASRecDataPreparator(session_max_len=3, batch_size=4)
+    dp.process_dataset_train(ds)
+    assert list(dp.item_id_map.external_ids) == ["PAD", 11, 13, 14, 12]
+    net = CatFeaturesItemNet.from_dataset(dp.train_dataset, 8, 0.0)
+    assert net.emb_bag_inputs.tolist() == [0, 2, 0, 4, 2, 4, 0, 3]
+    assert net.offsets.tolist() == [0, 0, 2, 4, 6] and net.input_lengths.tolist() == [0, 2, 2, 2, 2]
+    assert net.n_cat_feature_values == 5 and tuple(net.embedding_bag.weight.shape) == (5, 8)
+    dpb = BERT4RecDataPreparator(session_max_len=3, batch_size=4)
+    dpb.process_dataset_train(ds)
+    netb = CatFeaturesItemNet.from_dataset(dpb.train_dataset, 8, 0.0)
+    assert netb.offsets.tolist() == [0, 0, 0, 2, 4, 6] and netb.input_lengths.tolist() == [0, 0, 2, 2, 2, 2]   # PAD, MASK empty
+
+
+def test_item_net_blocks_names_warnings_and_config():
+    from rectools_amd import nn as hnn
+    from rectools_amd.data_preparator import SASRecDataPreparator
+    from rectools_amd.dataset import Dataset
+    from rectools_amd.models import SASRecModel
+
+    dp = SASRecDataPreparator(session_max_len=3, batch_size=4)
+    dp.process_dataset_train(Dataset.construct(_feature_interactions()))
+    with pytest.warns(UserWarning, match="doesn't contain item features"):
+        item_model = hnn.SumOfEmbeddingsConstructor.from_dataset(dp.train_dataset, 8, 0.1, (hnn.IdEmbeddingsItemNet, hnn.CatFeaturesItemNet))
+    assert item_model.n_item_blocks == 1 and list(item_model.state_dict()) == ["item_net_blocks.0.ids_emb.weight"]
+    ds = Dataset.construct(_feature_interactions(), item_features_df=_item_features(), cat_item_features=["f1", "f2"])
+    dp.process_dataset_train(ds)
+    item_model = hnn.SumOfEmbeddingsConstructor.from_dataset(dp.train_dataset, 8, 0.1, (hnn.IdEmbeddingsItemNet, hnn.CatFeaturesItemNet))
+    # the reference's names (SURVEY.md Appendix B; item_net.py:93-98): state dicts are interchangeable
+    assert sorted(item_model.state_dict()) == sorted([
+        "item_net_blocks.0.ids_emb.weight", "item_net_blocks.1.embedding_bag.weight", "item_net_blocks.1.offsets",
+        "item_net_blocks.1.emb_bag_inputs", "item_net_blocks.1.input_lengths"])
+    with pytest.raises(ValueError):
+        hnn.SumOfEmbeddingsConstructor(5, [])
+    m = SASRecModel(n_factors=8, item_net_block_types=(hnn.IdEmbeddingsItemNet,))
+    cfg = m.get_config()
+    assert cfg["item_net_block_types"] == ["rectools_amd.nn.IdEmbeddingsItemNet"]
+    assert cfg["item_net_constructor_type"] == "rectools_amd.nn.SumOfEmbeddingsConstructor"
+    assert SASRecModel.from_config(cfg).item_net_block_types == (hnn.IdEmbeddingsItemNet,)
+    assert SASRecModel().item_net_block_types == (hnn.IdEmbeddingsItemNet, hnn.CatFeaturesItemNet)   # sasrec.py default
+
+
+def test_bag_structure_transpose_and_chunks():
+    """Host side of K1b's backward: the chunked transpose must enumerate, per category value, exactly the items carrying
+    it, in ascending order, in chunks of at most BagStructure.CHUNK entries."""
+    from rectools_amd import ops
+
+    g = torch.Generator().manual_seed(4)
+    V, F_ = 900, 12
+    rows = [sorted(set(torch.randint(1, F_ - 1, (int(torch.randint(0, 5, (1,), generator=g)),), generator=g).tolist())
+                   | ({0} if i % 2 else set())) for i in range(V)]
+    rows[0] = []
+    lens = torch.tensor([len(r) for r in rows], dtype=torch.int64)
+    inputs = torch.tensor([v for r in rows for v in r], dtype=torch.int64)
+    bag = ops.BagStructure(inputs, torch.cumsum(lens, 0) - lens, lens, F_)
+    t, cp, fp = bag.t_items.numpy(), bag.chunk_ptr.numpy(), bag.feat_chunk_ptr.numpy()
+    assert len(cp) == bag.n_chunks + 1 and fp[-1] == bag.n_chunks and bag.n_chunks > F_ - 1
+    item_of = np.repeat(np.arange(V), lens.numpy())
+    for f in range(F_):
+        exp = np.sort(item_of[inputs.numpy() == f])
+        got = np.concatenate([t[cp[c]:cp[c + 1]] for c in range(fp[f], fp[f + 1])]) if fp[f + 1] > fp[f] else np.zeros(0, np.int64)
+        assert np.array_equal(exp, got)
+        assert all(0 < cp[c + 1] - cp[c] <= ops.BagStructure.CHUNK for c in range(fp[f], fp[f + 1]))
+    assert fp[F_] - fp[F_ - 1] == 0      # the last value tags no item: no chunks, zero gradient row
+    with pytest.raises(ValueError):
+        ops.BagStructure(torch.tensor([0, F_]), torch.tensor([0]), torch.tensor([2]), F_)     # id out of range
+    with pytest.raises(ValueError):
+        ops.BagStructure(torch.tensor([0]), torch.tensor([0]), torch.tensor([2]), F_)         # slice past the end

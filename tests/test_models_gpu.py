@@ -69,8 +69,9 @@ def test_fit_recommend_contract(kind, loss):
     from rectools_amd.data_preparator import SequenceStore
 
     store = SequenceStore.from_interactions(rec_ds.interactions.df, sort_users=True)
-    ue = model._user_embeddings(store, dev).cpu().numpy()
-    ie = model.torch_model.item_model.table.detach().cpu().numpy()
+    ie_dev = model._item_embeddings()
+    ue = model._user_embeddings(store, dev, ie_dev).cpu().numpy()
+    ie = ie_dev.cpu().numpy()
     uids = rec_ds.user_id_map.convert_to_internal(users, strict=False)
     csr = rec_ds.get_user_item_matrix(include_weights=False)[uids]
     dist = "cosine" if kind == "hstu" else "dot"
@@ -86,6 +87,63 @@ def test_fit_recommend_contract(kind, loss):
     clone = type(model).loads(model.dumps())
     reco2 = clone.recommend(users=users, dataset=ds, k=3, filter_viewed=True, context=context)
     pd.testing.assert_frame_equal(reco, reco2)
+
+
+def item_features():
+    return pd.DataFrame(
+        [[11, "f1", "f1val1"], [11, "f2", "f2val1"], [12, "f1", "f1val1"], [12, "f2", "f2val2"], [13, "f1", "f1val1"],
+         [13, "f2", "f2val3"], [11, "f3", 0], [12, "f3", 1], [13, "f3", 2], [16, "f3", 6], [14, "f2", "f2val1"], [17, "f2", "f2val3"]],
+        columns=["id", "feature", "value"])
+
+
+@pytest.mark.parametrize("kind", ["sasrec", "bert"])
+def test_fit_recommend_with_item_features(kind):
+    """Feature-aware item net (default `item_net_block_types`, test_sasrec.py:463-489): the catalog matrix is
+    ids_emb + bag sums of the category embeddings; both tables train; recommend() ranks over the composed matrix;
+    persistence restores the feature structure."""
+    from rectools_amd import nn as hnn
+    from rectools_amd.data_preparator import SequenceStore
+    from rectools_amd.dataset import Dataset
+    from rectools_amd.models import BERT4RecModel, SASRecModel
+
+    ds = Dataset.construct(interactions(), item_features_df=item_features(), cat_item_features=["f1", "f2"])
+    common = dict(n_factors=32, n_blocks=2, n_heads=2, session_max_len=4, lr=0.01, batch_size=4, epochs=3, loss="sampled_softmax",
+                  n_negatives=3, seed=32, dropout_rate=0.2)
+    model = SASRecModel(use_key_padding_mask=True, **common) if kind == "sasrec" else BERT4RecModel(mask_prob=0.6, **common)
+    model._build_model_from_dataset(ds)
+    blocks = model.torch_model.item_model.item_net_blocks
+    assert isinstance(blocks[0], hnn.IdEmbeddingsItemNet) and isinstance(blocks[1], hnn.CatFeaturesItemNet)
+    assert blocks[1].embedding_bag.weight.shape[0] == 4        # f1val1, f2val1..3 (f3 is a direct feature)
+    cat0 = blocks[1].embedding_bag.weight.detach().clone()
+    model.fit(ds)
+    blocks = model.torch_model.item_model.item_net_blocks
+    assert float((blocks[1].embedding_bag.weight.detach() - cat0).abs().max()) > 1e-4      # the category table is trained
+    assert all(np.isfinite(h["train_loss"]) for h in model.history)
+    users = np.array([10, 30, 40])
+    reco = model.recommend(users=users, dataset=ds, k=3, filter_viewed=True)
+    _check_frame(reco, 3, users)
+    # composed matrix == oracle restatement on the trained parameters, and the ranking runs over it
+    from oracle import transformer_oracle as T
+
+    sd = {k: v.detach().cpu() for k, v in model.torch_model.state_dict().items()}
+    ie_dev = model._item_embeddings()
+    np.testing.assert_allclose(ie_dev.cpu().numpy(), T.item_table(sd).numpy(), rtol=1e-5, atol=1e-6)
+    dev = ie_dev.device
+    rec_ds = model.data_preparator.transform_dataset_u2i(ds, users, None)
+    store = SequenceStore.from_interactions(rec_ds.interactions.df, sort_users=True)
+    ue = model._user_embeddings(store, dev, ie_dev).cpu().numpy()
+    uids = rec_ds.user_id_map.convert_to_internal(users, strict=False)
+    csr = rec_ds.get_user_item_matrix(include_weights=False)[uids]
+    su, it, sc = ranker_oracle.rank(ue, ie_dev.cpu().numpy(), uids, k=3, filter_pairs_csr=csr, distance="dot",
+                                    sorted_object_whitelist=model.data_preparator.get_known_items_sorted_internal_ids())
+    assert reco["item_id"].tolist() == model.data_preparator.item_id_map.convert_to_external(it).tolist()
+    np.testing.assert_allclose(reco["score"].values, sc, rtol=1e-4, atol=1e-5)
+    clone = type(model).loads(model.dumps())
+    assert isinstance(clone.torch_model.item_model.item_net_blocks[1], hnn.CatFeaturesItemNet)
+    pd.testing.assert_frame_equal(reco, clone.recommend(users=users, dataset=ds, k=3, filter_viewed=True))
+    # ids-only models ignore the features of the dataset
+    plain = SASRecModel(item_net_block_types=(hnn.IdEmbeddingsItemNet,), **common).fit(ds)
+    assert plain.torch_model.item_model.n_item_blocks == 1
 
 
 def test_fit_partial_equals_fit_and_cold_users():

@@ -115,6 +115,85 @@ def test_embed_backward_sorted_reduction(V, L, B, d, hot):
     close(ggot[0], gref[0], rtol=1e-3, msg="embed dtable"); close(ggot[1], gref[1], rtol=1e-3, msg="embed dpos")
 
 
+def _bag_case(V, F_, max_per_item, seed, popular):
+    """Item -> category-value CSR: empty rows, ascending ids per row; `popular` values tag most items (several backward
+    chunks each); the last value is carried by no item (zero gradient row)."""
+    g = torch.Generator().manual_seed(seed)
+    rows = []
+    for i in range(V):
+        n = int(torch.randint(0, max_per_item + 1, (1,), generator=g))
+        vals = set(torch.randint(0, max(F_ - 1, 1), (n,), generator=g).tolist()) if F_ > 1 else set()
+        for pv in popular:
+            if float(torch.rand(1, generator=g)) < 0.8:
+                vals.add(pv)
+        rows.append(sorted(vals) if i > 0 else [])      # row 0: PAD, no features
+    lens = torch.tensor([len(r) for r in rows], dtype=torch.int64)
+    return torch.tensor([v for r in rows for v in r], dtype=torch.int64), torch.cumsum(lens, 0) - lens, lens
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V,F_,d,mx,popular,with_ids", [(700, 23, 256, 5, (0, 3), True), (50, 6, 16, 2, (), True),
+                                                        (1200, 9, 512, 3, (1,), False), (5, 1, 4, 0, (), True)])
+def test_item_table_bag_sum(V, F_, d, mx, popular, with_ids):
+    """K1b: ids_emb + EmbeddingBag-sum of the category embeddings (item_net.py:101-132,463-482) and its backward over the
+    chunked transposed structure, against the oracle's plain restatement."""
+    from rectools_amd import ops
+
+    inputs, offsets, lens = _bag_case(V, F_, mx, 7, popular)
+    ids_w, cat_w = rnd(V, d, seed=1), rnd(F_, d, seed=2)
+    P = T.CAT_BLOCK
+
+    def ref_fn(iw, cw):
+        p = {T.ITEM_EMB: iw if with_ids else torch.zeros(V, d), T.CAT_EMB: cw, P + "emb_bag_inputs": inputs,
+             P + "offsets": offsets, P + "input_lengths": lens}
+        return T.item_table(p)
+
+    ref, gref = grads_of(ref_fn, [ids_w, cat_w])
+    bag = ops.BagStructure(inputs.cuda(), offsets.cuda(), lens.cuda(), F_)
+    if popular:
+        assert bag.n_chunks > F_       # popular values are cut into several chunks
+    got, ggot = grads_of(lambda iw, cw: ops.item_table(iw if with_ids else None, cw, bag, 0.0), [ids_w.cuda(), cat_w.cuda()])
+    close(got, ref, msg="item table")
+    close(ggot[1], gref[1], rtol=1e-3, msg="d cat_emb")
+    if with_ids:
+        close(ggot[0], gref[0], msg="d ids_emb")
+    else:
+        assert ggot[0] is None
+    if F_ > 1:
+        assert float(ggot[1][F_ - 1].abs().max()) == 0.0     # value carried by no item
+
+
+@pytest.mark.gpu
+def test_item_table_dropout_mask_is_regenerated_in_backward():
+    """Dropout acts on the bag sums only (item_net.py:117-119); backward must re-create the forward's mask."""
+    from rectools_amd import ops
+
+    V, F_, d, p = 300, 5, 64, 0.4
+    inputs, offsets, lens = _bag_case(V, F_, 3, 11, (0,))
+    bag = ops.BagStructure(inputs.cuda(), offsets.cuda(), lens.cuda(), F_)
+    ids_w = rnd(V, d, seed=1).cuda().requires_grad_(True)
+    cat_w = (rnd(F_, d, seed=2).abs() + 0.5).cuda().requires_grad_(True)     # positive: a zero bag sum means "dropped"
+    ops.RNG.step, ops.RNG._stream = 3, 0
+    out = ops.item_table(ids_w, cat_w, bag, p)
+    with torch.no_grad():
+        clean = ops.item_table(ids_w, cat_w, bag, 0.0) - ids_w
+        bagpart = out - ids_w
+        has = (lens > 0).cuda()[:, None].expand(V, d)
+        kept = (bagpart.abs() > 1e-6) & has
+        frac = float(kept[has].float().mean())
+        assert abs(frac - (1 - p)) < 0.03, frac
+        close(bagpart[kept], (clean / (1 - p))[kept], msg="kept entries are scaled by 1/(1-p)")
+    g = rnd(V, d, seed=5).cuda()
+    out.backward(g)
+    close(ids_w.grad, g, msg="id embeddings see the whole gradient")
+    # expected d cat: scatter of the masked, scaled gradient rows over the structure
+    gm = (g * kept.float() / (1 - p)).cpu()
+    exp = torch.zeros(F_, d)
+    item_of = torch.repeat_interleave(torch.arange(V), lens)
+    exp.index_add_(0, inputs, gm[item_of])
+    close(cat_w.grad, exp, rtol=1e-3, msg="d cat_emb under dropout")
+
+
 @pytest.mark.parametrize("kind,fn", [(1, F.relu), (2, F.gelu), (3, F.silu), (4, torch.sigmoid)])
 def test_activations_swiglu_gate(kind, fn):
     from rectools_amd import ops

@@ -17,12 +17,35 @@ pytestmark = pytest.mark.gpu
 NAMES = list_transformer_golden()
 
 
+def cat_structure(n_tokens, n_extra, F, max_per_item, seed):
+    """Seeded item -> category-value CSR (extra-token rows empty, value 0 tags every third item: a popular value
+    that spans several backward chunks at the larger sizes)."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    lens = torch.randint(0, max_per_item + 1, (n_tokens,), generator=g)
+    rows = []
+    for i in range(n_tokens):
+        vals = set() if i < n_extra else set(torch.randint(0, F, (int(lens[i]),), generator=g).tolist())
+        if i >= n_extra and i % 3 == 0:
+            vals.add(0)
+        rows.append(sorted(vals))
+    lens = torch.tensor([len(r) for r in rows], dtype=torch.int64)
+    return torch.tensor([v for r in rows for v in r], dtype=torch.int64), lens, torch.cumsum(lens, 0) - lens
+
+
 def build_hip_model(cfg, params=None):
     from rectools_amd import lightning as hl
     from rectools_amd import nn as hnn
 
     n_tokens = cfg["V"] + cfg["n_extra"]
-    item_model = hnn.SumOfEmbeddingsConstructor(n_tokens, [hnn.IdEmbeddingsItemNet(cfg["d"], n_tokens, 0.0)])
+    blocks = [hnn.IdEmbeddingsItemNet(cfg["d"], n_tokens, 0.0)]
+    if cfg.get("cat"):   # feature-aware item net: structure from the golden state dict, or seeded for the random cases
+        pre = "item_model.item_net_blocks.1."
+        if params is not None:
+            st = (params[pre + "emb_bag_inputs"], params[pre + "input_lengths"], params[pre + "offsets"])
+        else:
+            st = cat_structure(n_tokens, cfg["n_extra"], cfg["cat"]["F"], cfg["cat"]["max_per_item"], cfg["cat"].get("seed", 0))
+        blocks.append(hnn.CatFeaturesItemNet(st[0], st[1], st[2], cfg["cat"]["F"], cfg["d"], cfg["cat"].get("dropout", 0.0)))
+    item_model = hnn.SumOfEmbeddingsConstructor(n_tokens, blocks)
     pos = hnn.LearnableInversePositionalEncoding(True, cfg["L"], cfg["d"], use_scale_factor=cfg.get("use_scale", False))
     kind = cfg["layers"]
     p = cfg.get("dropout", 0.0)
@@ -72,7 +95,7 @@ def test_golden_reference_vectors(name):
     opt.zero_grad()
     loss = lm.training_loss(dbatch)
     loss.backward()
-    assert abs(float(loss) - ex["loss"]) <= 2e-5 * abs(ex["loss"]) + 2e-6, (float(loss), ex["loss"])
+    assert abs(float(loss.detach()) - ex["loss"]) <= 2e-5 * abs(ex["loss"]) + 2e-6, (float(loss.detach()), ex["loss"])
     grads = {n: p.grad.detach().clone() for n, p in lm.torch_model.named_parameters()}
     assert set(grads) == set(g_ref)
     for k in g_ref:
@@ -124,6 +147,10 @@ CASES = [
                                    layer_kwargs=dict(ff_factors_multiplier=4, ff_activation="swiglu", bias_in_ff=False))),
     ("hstu_L96_d128", _random_case("stu", "sampled_softmax", "cosine", 96, 128, 4, 3, 300, 8, 6, logits_t=0.05)),
     ("hstu_L130_d64", _random_case("stu", "BCE", "dot", 130, 64, 2, 2, 300, 4, 7)),
+    ("sasrec_catfeat_d256", _random_case("sasrec", "sampled_softmax", "dot", 60, 256, 4, 3, 900, 8, 8,
+                                         cat=dict(F=37, max_per_item=5, seed=1))),
+    ("bert_catfeat_softmax_cos", _random_case("preln", "softmax", "cosine", 48, 64, 2, 3, 500, 1, 9, causal=False, keypad=True,
+                                              cat=dict(F=11, max_per_item=3, seed=2))),
 ]
 
 
