@@ -116,6 +116,20 @@ def _tail_layout(lengths: np.ndarray, keep: int) -> tp.Tuple[np.ndarray, np.ndar
     return rows, pos, kept
 
 
+class CatalogUniformSampler:
+    """Negatives drawn uniformly from the real items, without rejecting positives (negative_sampler.py:49-73).  The draw
+    happens on the device the batch lives on (the reference draws on the host inside its collate function)."""
+
+    def __init__(self, n_negatives: int, **kwargs: tp.Any) -> None:
+        self.n_negatives = n_negatives
+
+    def get_negatives(self, batch_dict: tp.Dict[str, torch.Tensor], lowest_id: int, highest_id: int,
+                      session_len_limit: tp.Optional[int] = None, **kwargs: tp.Any) -> torch.Tensor:
+        x = batch_dict["x"]
+        session_len = session_len_limit if session_len_limit is not None else x.shape[1]
+        return torch.randint(lowest_id, highest_id, (x.shape[0], session_len, self.n_negatives), device=x.device)
+
+
 class TransformerDataPreparatorBase:
     train_session_max_len_addition: int = 0
     item_extra_tokens: tp.Sequence[tp.Hashable] = (PADDING_VALUE,)

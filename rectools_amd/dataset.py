@@ -50,6 +50,10 @@ class IdMap:
         return len(self.external_ids)
 
     @property
+    def external_dtype(self) -> tp.Any:
+        return self.external_ids.dtype
+
+    @property
     def to_internal(self) -> pd.Series:
         if self._to_internal is None:
             self._to_internal = pd.Series(np.arange(self.size), index=self.external_ids)
@@ -243,9 +247,27 @@ class Dataset:
             item_features = SparseFeatures.from_flatten(item_features_df, item_id_map, cat_item_features, id_col=id_col)
         return cls(user_id_map, item_id_map, interactions, item_features=item_features)
 
+    def get_schema(self) -> tp.Dict[str, tp.Any]:
+        """Dataset statistics in the reference's JSON-able layout (dataset.py:139-174): what a checkpoint needs to rebuild
+        the item net without the dataset (`items.n_hot`, the sparse feature names / categorical columns / stored values)."""
+        def entity(n_hot: int, id_map: IdMap, features: tp.Any) -> tp.Dict[str, tp.Any]:
+            fs = None
+            if features is not None:
+                plain = lambda v: v.item() if hasattr(v, "item") and not isinstance(v, (str, bytes)) else v  # noqa: E731
+                fs = {"names": [[plain(a), plain(b)] for a, b in features.names], "kind": "sparse",
+                      "cat_feature_indices": features.cat_feature_indices.tolist(),
+                      "cat_n_stored_values": int(features.get_cat_features().values.nnz)}
+            return {"n_hot": int(n_hot), "id_map": {"size": int(id_map.size), "dtype": np.dtype(id_map.external_dtype).str},
+                    "features": fs}
+
+        return {"n_interactions": int(self.interactions.df.shape[0]),
+                "users": entity(self.n_hot_users, self.user_id_map, None),
+                "items": entity(self.n_hot_items, self.item_id_map, self.item_features)}
+
     @property
     def n_hot_users(self) -> int:
-        return self.user_id_map.size
+        """Users with interactions (dataset.py:176-184)."""
+        return int(self.interactions.df[Columns.User].max()) + 1 if len(self.interactions.df) else 0
 
     @property
     def n_hot_items(self) -> int:

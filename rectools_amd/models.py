@@ -20,6 +20,7 @@ import numpy as np
 import pandas as pd
 import torch
 
+from . import checkpoint as ckpt
 from . import lightning as hl
 from . import nn as hnn
 from . import ops
@@ -43,6 +44,8 @@ def _full_path(obj: tp.Any) -> str:
 def _import_object(path: tp.Union[str, tp.Any]) -> tp.Any:
     if not isinstance(path, str):
         return path
+    if "." not in path:      # the reference writes bare model class names into its configs ("SASRecModel")
+        return getattr(importlib.import_module(__name__), path)
     module, name = path.rsplit(".", 1)
     return getattr(importlib.import_module(module), name)
 
@@ -105,6 +108,7 @@ class TransformerModelBase:
         if hl.requires_negatives(loss) is None:
             raise ValueError(f"loss {loss} is not supported")
         self.is_fitted = False
+        self.dataset_schema: tp.Dict[str, tp.Any] = {}
         self.lightning_model: tp.Optional[hl.TransformerLossModule] = None
         self.optimizer: tp.Optional[hl.FlatAdam] = None
         self.epochs_done = 0
@@ -152,15 +156,6 @@ class TransformerModelBase:
                                                      spec["n_cat_feature_values"], self.n_factors, self.dropout_rate))
         return self.item_net_constructor_type(n_tokens, blocks, **kw)
 
-    def _item_net_schema(self) -> tp.List[dict]:
-        out = []
-        for block in self.lightning_model.torch_model.item_model.item_net_blocks:
-            if isinstance(block, hnn.CatFeaturesItemNet):
-                out.append({"kind": "cat", "nnz": int(block.emb_bag_inputs.numel()), "n_cat_feature_values": block.n_cat_feature_values})
-            else:
-                out.append({"kind": "ids"})
-        return out
-
     def _build_model_from_dataset(self, dataset: tp.Any, item_net_schema: tp.Optional[tp.List[dict]] = None) -> None:
         self.data_preparator.process_dataset_train(dataset)
         if self.seed is not None:  # before ANY parameter is created: 1-D parameters keep their constructor init
@@ -184,6 +179,8 @@ class TransformerModelBase:
         self.optimizer.broadcast_parameters()   # data parallel: replicas start from rank 0's weights (DDP semantics)
         self.epochs_done = 0
         self.history = []
+        if dataset is not None:   # kept for checkpoints (hyper_parameters.dataset_schema, base.py:470-473)
+            self.dataset_schema = self.data_preparator.train_dataset.get_schema()
 
     def _device(self) -> str:
         if self.recommend_torch_device is not None and str(self.recommend_torch_device) != "cpu":
@@ -514,37 +511,85 @@ class TransformerModelBase:
             cfg["item_net_block_types"] = tuple(_import_object(t) for t in cfg["item_net_block_types"])
         return klass(**cfg)
 
+    # ---- persistence: Lightning-layout checkpoints (checkpoint.py; base.py:591-724) --------------------------
     def __getstate__(self) -> tp.Dict[str, tp.Any]:
-        state = {"config": self.get_config(simple_types=False), "is_fitted": self.is_fitted, "epochs_done": self.epochs_done,
-                 "history": self.history}
+        """base.py:656-668: a fitted model pickles as its checkpoint, an unfitted one as its config."""
         if self.lightning_model is not None:
             buf = io.BytesIO()
-            torch.save({"state_dict": {k: v.detach().cpu() for k, v in self.lightning_model.torch_model.state_dict().items()},
-                        "optimizer": {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in self.optimizer.state_dict().items()},
-                        "item_external_ids": self.data_preparator.item_id_map.external_ids,
-                        "extra_token_ids": self.data_preparator.extra_token_ids, "item_net_schema": self._item_net_schema()}, buf)
-            state["checkpoint"] = buf.getvalue()
-        return state
+            torch.save(ckpt.to_checkpoint(self, reference_paths=False), buf)
+            return {"fitted_checkpoint": buf.getvalue(), "is_fitted": self.is_fitted}
+        return {"model_config": self.get_config(simple_types=True)}
 
     def __setstate__(self, state: tp.Dict[str, tp.Any]) -> None:
-        cfg = dict(state["config"])
-        cfg.pop("cls", None)
-        self.__init__(**cfg)
-        self.is_fitted, self.epochs_done, self.history = state["is_fitted"], state["epochs_done"], state["history"]
-        if "checkpoint" in state:
-            from .dataset import IdMap
+        if "fitted_checkpoint" in state:
+            checkpoint = torch.load(io.BytesIO(state["fitted_checkpoint"]), map_location="cpu", weights_only=False)
+            loaded = self._model_from_checkpoint(checkpoint)
+            loaded.is_fitted = state.get("is_fitted", True)
+        else:
+            loaded = self.from_config(state["model_config"])
+        self.__dict__.update(loaded.__dict__)
 
-            ck = torch.load(io.BytesIO(state["checkpoint"]), map_location="cpu", weights_only=False)
-            self.data_preparator.item_id_map = IdMap(ck["item_external_ids"])
-            self.data_preparator.extra_token_ids = ck["extra_token_ids"]
-            self._build_from_item_map(ck.get("item_net_schema", [{"kind": "ids"}]))
-            self.lightning_model.torch_model.load_state_dict({k: v.to(self._device()) for k, v in ck["state_dict"].items()})
-            self.optimizer.load_state_dict({k: (v.to(self._device()) if isinstance(v, torch.Tensor) else v) for k, v in ck["optimizer"].items()})
+    @classmethod
+    def _model_from_checkpoint(cls, checkpoint: tp.Dict[str, tp.Any]) -> "TransformerModelBase":
+        """base.py:591-654 without a Trainer: config -> model, item ids -> data preparator, dataset schema -> item net,
+        then weights and Adam moments."""
+        from .dataset import IdMap
+
+        hyper = checkpoint["hyper_parameters"]
+        config = ckpt.translate_config(dict(hyper["model_config"]))
+        config.pop("cls", None)       # the class the method is called on decides (the reference stores a short name)
+        loaded = cls.from_config(config)
+        dp = loaded.data_preparator
+        ext = hyper["item_external_ids"]
+        dp.item_id_map = IdMap(np.asarray(ext, dtype=object) if any(isinstance(v, str) for v in ext) else np.asarray(ext))
+        dp.extra_token_ids = dict(zip(dp.item_extra_tokens, dp.item_id_map.convert_to_internal(list(dp.item_extra_tokens))))
+        loaded.dataset_schema = hyper.get("dataset_schema") or {}
+        loaded._build_from_item_map(ckpt.item_net_schema(loaded.dataset_schema))
+        device = loaded._device()
+        weights = ckpt.strip_state_dict(checkpoint["state_dict"])
+        loaded.torch_model.load_state_dict({k: v.to(device) for k, v in weights.items()})
+        if checkpoint.get("optimizer_states"):
+            mine = [n for n, p in loaded.torch_model.named_parameters() if p.requires_grad]
+            theirs = [k for k in weights if k in set(mine)]
+            ckpt.load_adam_state_dict(loaded.optimizer, checkpoint["optimizer_states"][0], theirs, mine)
+        loaded.epochs_done = int(checkpoint.get("epoch", 0))
+        loaded.history = list((checkpoint.get("rectools_amd") or {}).get("history", []))
+        loaded.is_fitted = True
+        return loaded
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path: str, map_location: tp.Optional[tp.Any] = None,
+                             model_params_update: tp.Optional[tp.Dict[str, tp.Any]] = None) -> "TransformerModelBase":
+        """base.py:678-711.  Reads checkpoints written by `save_to_checkpoint` here AND Lightning checkpoints of the
+        reference's models (class paths are translated).  `model_params_update`: flat `a.b` keys overriding
+        `hyper_parameters.model_config` (e.g. to drop a `get_trainer_func` that cannot be imported)."""
+        checkpoint = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+        if model_params_update:
+            config = dict(checkpoint["hyper_parameters"]["model_config"])
+            for key, value in model_params_update.items():
+                node = config
+                parts = key.split(".")
+                for part in parts[:-1]:
+                    node[part] = dict(node.get(part) or {})
+                    node = node[part]
+                node[parts[-1]] = value
+            checkpoint["hyper_parameters"]["model_config"] = config
+        return cls._model_from_checkpoint(checkpoint)
+
+    def load_weights_from_checkpoint(self, checkpoint_path: str) -> None:
+        """base.py:713-724: weights only, into an already fitted model."""
+        if self.lightning_model is None:
+            raise RuntimeError("Model weights cannot be loaded from checkpoint into unfitted model")
+        checkpoint = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+        device = self._device()
+        self.torch_model.load_state_dict({k: v.to(device) for k, v in ckpt.strip_state_dict(checkpoint["state_dict"]).items()})
+
+    def save_to_checkpoint(self, checkpoint_path: str, reference_paths: bool = True) -> None:
+        """What `fit_trainer.save_checkpoint(path)` does for the reference (base.py:660-662), in the same dict layout."""
+        torch.save(ckpt.to_checkpoint(self, reference_paths=reference_paths), checkpoint_path)
 
     def _build_from_item_map(self, item_net_schema: tp.List[dict]) -> None:
-        class _Stub:  # builds modules of the right sizes without re-processing a dataset
-            pass
-
+        """Modules of the right sizes without a dataset (the data preparator already holds the item id map)."""
         n_tokens = self.data_preparator.item_id_map.size
         dp_process = self.data_preparator.process_dataset_train
         self.data_preparator.process_dataset_train = lambda ds: None  # type: ignore

@@ -2,9 +2,9 @@
 
 Run in the build container only (the reference tree does not exist on the GPU box):
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [ranker] [transformer [only=<substring>]] [collate]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [ranker] [transformer [only=<substring>]] [collate] [checkpoints]
 
-Outputs (committed):  tests/golden/ranker_*.npz, tests/golden/transformer_*.npz, tests/golden/collate_*.npz
+Outputs (committed):  tests/golden/ranker_*.npz, transformer_*.npz, collate_*.npz, ckpt_*.ckpt
 Every file stores the exact inputs next to the reference's outputs, so the oracle (`oracle/`) and the HIP
 path can both be checked against them without the reference being present.
 """
@@ -120,7 +120,7 @@ def make_ranker() -> None:
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["ranker", "transformer", "collate"]
+    what = sys.argv[1:] or ["ranker", "transformer", "collate", "checkpoints"]
     only = next((w.split("=", 1)[1] for w in what if w.startswith("only=")), "")   # e.g. `transformer only=catfeat`
     if "ranker" in what:
         make_ranker()
@@ -132,3 +132,7 @@ if __name__ == "__main__":
         from make_golden_transformer import make_collate  # type: ignore
 
         make_collate()
+    if "checkpoints" in what:
+        from make_golden_transformer import make_checkpoints  # type: ignore
+
+        make_checkpoints()

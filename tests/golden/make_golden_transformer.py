@@ -280,3 +280,74 @@ def make_collate() -> None:
     out["L"] = np.array(L)
     np.savez_compressed(os.path.join(HERE, "collate_golden.npz"), **out)
     print("collate: ok")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Checkpoint fixtures: the reference's models trained through the shimmed Trainer, stored in the
+# layout of `Trainer.save_checkpoint` — assembled from the reference's own objects because pytorch_lightning itself is
+# not installed: state_dict = lightning_model.state_dict(), optimizer_states = [its torch.optim.Adam.state_dict()],
+# hyper_parameters = the constructor arguments `save_hyperparameters(ignore=[torch_model, data_preparator])` records
+# (lightning.py:75-121).  "expected" (not a Lightning key) holds the reference's own recommend() / recommend_to_items()
+# frames for the loaded model to reproduce.
+# ------------------------------------------------------------------------------------------------------------------
+def checkpoint_frames():
+    import pandas as pd
+
+    interactions = pd.DataFrame(
+        [[10, 13, 1, "2021-11-30"], [10, 11, 1, "2021-11-29"], [10, 12, 1, "2021-11-29"], [30, 11, 1, "2021-11-27"],
+         [30, 12, 2, "2021-11-26"], [30, 15, 1, "2021-11-25"], [40, 11, 1, "2021-11-25"], [40, 17, 1, "2021-11-26"],
+         [50, 16, 1, "2021-11-25"], [10, 14, 1, "2021-11-28"], [10, 16, 1, "2021-11-27"], [20, 13, 9, "2021-11-28"]],
+        columns=["user_id", "item_id", "weight", "datetime"])
+    features = pd.DataFrame(
+        [[11, "f1", "f1val1"], [11, "f2", "f2val1"], [12, "f1", "f1val1"], [12, "f2", "f2val2"], [13, "f1", "f1val1"],
+         [13, "f2", "f2val3"], [11, "f3", 0], [12, "f3", 1], [13, "f3", 2], [16, "f3", 6], [14, "f2", "f2val1"], [17, "f2", "f2val3"]],
+        columns=["id", "feature", "value"])
+    return interactions, features
+
+
+def make_checkpoints() -> None:
+    import pandas as pd
+    from rectools.dataset import Dataset
+    from rectools.models import BERT4RecModel, SASRecModel
+    from rectools.models.nn.item_net import IdEmbeddingsItemNet
+
+    from oracle import ref_shims
+
+    interactions, features = checkpoint_frames()
+    cases = {
+        "sasrec_catfeat": (SASRecModel, dict(n_factors=32, n_blocks=2, n_heads=2, session_max_len=4, lr=0.01, batch_size=4, epochs=3,
+                                             loss="sampled_softmax", n_negatives=3, use_key_padding_mask=True, deterministic=True),
+                           True),
+        "bert4rec_ids": (BERT4RecModel, dict(n_factors=32, n_blocks=1, n_heads=2, session_max_len=4, lr=0.01, batch_size=4, epochs=2,
+                                             loss="softmax", mask_prob=0.5, deterministic=True,
+                                             item_net_block_types=(IdEmbeddingsItemNet,)), False),
+    }
+    users = [10, 30, 40]
+    for name, (klass, kw, with_features) in cases.items():
+        ref_shims.seed_all(32)
+        ds = (Dataset.construct(interactions, item_features_df=features, cat_item_features=["f1", "f2"]) if with_features
+              else Dataset.construct(interactions))
+        model = klass(**kw)
+        model.fit(ds)
+        lm = model.lightning_model
+        hyper = dict(model_config=lm.model_config, dataset_schema=lm.dataset_schema, item_external_ids=list(lm.item_external_ids),
+                     item_extra_tokens=tuple(lm.item_extra_tokens), lr=lm.lr, gbce_t=lm.gbce_t, loss=lm.loss, verbose=lm.verbose,
+                     train_loss_name=lm.train_loss_name, val_loss_name=lm.val_loss_name, adam_betas=tuple(lm.adam_betas),
+                     logits_t=lm.logits_t)
+        n_steps = int(next(iter(lm.optimizer.state_dict()["state"].values()))["step"])
+        expected = {}
+        for tag, rk in (("filter", dict(k=3, filter_viewed=True)), ("nofilter", dict(k=4, filter_viewed=False)),
+                        ("whitelist", dict(k=2, filter_viewed=False, items_to_recommend=[11, 13, 17]))):
+            r = model.recommend(users=users, dataset=ds, **rk)
+            expected[tag] = {c: r[c].tolist() for c in r.columns}
+        i2i = model.recommend_to_items(target_items=[11, 12], dataset=ds, k=2)
+        expected["i2i"] = {c: i2i[c].tolist() for c in i2i.columns}
+        ckpt = {
+            "epoch": kw["epochs"], "global_step": n_steps, "pytorch-lightning_version": "shimmed",
+            "state_dict": {k: v.detach().clone() for k, v in lm.state_dict().items()},
+            "loops": {}, "callbacks": {}, "optimizer_states": [lm.optimizer.state_dict()], "lr_schedulers": [],
+            "hparams_name": "kwargs", "hyper_parameters": hyper, "expected": expected,
+        }
+        torch.save(ckpt, os.path.join(HERE, f"ckpt_{name}.ckpt"))
+        print(f"checkpoint {name}: {len(ckpt['state_dict'])} tensors, {n_steps} optimizer steps, "
+              f"items {hyper['item_external_ids']}, reco {expected['filter']['item_id']}")
