@@ -352,6 +352,25 @@ class TransformerModelBase:
         ids, scores, counts, _ = ranker.rank_device(user_ids, k=k, filter_pairs_csr=filt, sorted_object_whitelist=whitelist)
         return self._assemble(rec_ds.user_id_map.convert_to_external(user_ids), ids, scores, counts, add_rank_col, Columns.User)
 
+    def recommend_distributed(self, users: tp.Any, dataset: tp.Any, k: int, filter_viewed: bool, **kwargs: tp.Any) -> pd.DataFrame:
+        """recommend() over all ranks of an initialised process group: users are independent, every rank
+        holds the whole catalog, so rank r ranks the r-th contiguous slice of `users` on its own GPU and the frames are
+        gathered (one `all_gather_object` of the result frames — no collective on the data path).  Every rank returns the
+        full frame, rows in the order a single-process `recommend(users, ...)` produces.  The reference's recommend() is
+        single-device (lightning.py:371-376)."""
+        import torch.distributed as dist
+
+        rank, world = _dist_info()
+        users = np.asarray(users)
+        if world == 1:
+            return self.recommend(users, dataset, k, filter_viewed, **kwargs)
+        bounds = np.linspace(0, len(users), world + 1).astype(np.int64)
+        part = self.recommend(users[bounds[rank]:bounds[rank + 1]], dataset, k, filter_viewed, **kwargs)
+        parts: tp.List[tp.Optional[pd.DataFrame]] = [None] * world
+        dist.all_gather_object(parts, part)
+        return pd.concat([p for p in parts if p is not None and len(p)], ignore_index=True) if any(
+            p is not None and len(p) for p in parts) else part
+
     def _recommend_device_glue(self, users: np.ndarray, dataset: tp.Any, k: int, filter_viewed: bool,
                                items_to_recommend: tp.Optional[tp.Any], add_rank_col: bool,
                                on_unsupported_targets: str) -> tp.Optional[pd.DataFrame]:

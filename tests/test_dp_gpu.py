@@ -70,3 +70,39 @@ def test_two_rank_step_matches_mean_gradient_adam(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}.npy").exists() for r in range(world))
+
+
+def _reco_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import pandas as pd
+
+    from rectools_amd.dataset import Dataset
+    from rectools_amd.models import SASRecModel
+
+    rng = np.random.default_rng(3)
+    n = 4000
+    df = pd.DataFrame({"user_id": rng.integers(0, 200, n) * 2 + 5, "item_id": rng.integers(0, 90, n) + 100, "weight": 1.0,
+                       "datetime": pd.to_datetime("2022-01-01") + pd.to_timedelta(rng.integers(0, 40_000, n), unit="m")})
+    ds = Dataset.construct(df)
+    # fit() under the process group = data-parallel training: both replicas end with the same weights
+    model = SASRecModel(n_factors=32, n_blocks=1, n_heads=2, session_max_len=10, batch_size=32, epochs=1, loss="sampled_softmax",
+                        n_negatives=4, seed=5).fit(ds)
+    users = rng.permutation(ds.user_id_map.external_ids)[:101]                   # odd count: uneven slices
+    for kw in (dict(k=5, filter_viewed=True), dict(k=3, filter_viewed=False, items_to_recommend=np.arange(100, 130))):
+        whole = model.recommend(users=users, dataset=ds, **kw)                     # single-process path on this rank
+        sharded = model.recommend_distributed(users, ds, **kw)                     # slice per rank + gather
+        pd.testing.assert_frame_equal(sharded, whole)
+    only_one = model.recommend_distributed(users[:1], ds, k=2, filter_viewed=False)   # rank 0's slice is empty
+    assert only_one["user_id"].nunique() == 1 and len(only_one) == 2
+    np.save(os.path.join(out_dir, f"reco_ok{rank}.npy"), np.ones(1))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_recommend_shards_users_and_matches_single_process(tmp_path):
+    world = 2
+    mp.spawn(_reco_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"reco_ok{r}.npy").exists() for r in range(world))
