@@ -35,8 +35,15 @@ def dist_setup(n_gpus: int):
     if world > 1:
         import torch.distributed as dist
 
+        # RT_BENCH_BACKEND=gloo lets the N>1 path run on a box with fewer GPUs than ranks (scripts/gpu_full.sh does that
+        # with 2 ranks on the one GPU of the test box); the driver's multi-GPU runs use nccl = RCCL, one rank per GPU.
+        backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+        local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     if world != n_gpus:

@@ -9,6 +9,12 @@ timeout 600 python bench.py > gpurun_out/bench_train.json 2> gpurun_out/bench_tr
 timeout 300 python bench.py --workload recommend --no-cpu-baseline > gpurun_out/bench_recommend.json 2>/dev/null; cut -c1-700 gpurun_out/bench_recommend.json
 timeout 300 python bench.py --workload topk5m > gpurun_out/bench_topk5m.json 2>/dev/null; cut -c1-900 gpurun_out/bench_topk5m.json
 timeout 300 python bench.py --workload topk5m --users-per-step 1024 --users-per-pass 128 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/bench_topk5m_u1024.json 2>/dev/null; cut -c1-500 gpurun_out/bench_topk5m_u1024.json
+# the N>1 code path of bench.py (barrier, max over ranks, gradient all-reduce, aggregate value) with 2 ranks on this box's one GPU
+for w in train recommend; do
+  RT_BENCH_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
+    bench.py --gpus 2 --workload $w --steps 5 --warmup 2 > gpurun_out/bench_${w}_2ranks_1gpu.json 2> gpurun_out/bench_${w}_2ranks_1gpu.err
+  tail -c 600 gpurun_out/bench_${w}_2ranks_1gpu.json | cut -c1-600; echo
+done
 prof() { name=$1; shift
   rm -rf gpurun_out/prof_$name
   (cd /tmp && timeout 400 rocprofv3 --kernel-trace -d $R/gpurun_out/prof_$name -o p -- python $R/bench.py --no-cpu-baseline "$@" > $R/gpurun_out/prof_$name.log 2>&1)
