@@ -107,6 +107,14 @@ class TransformerModelBase:
             setattr(self, k, v)
         if hl.requires_negatives(loss) is None:
             raise ValueError(f"loss {loss} is not supported")
+        if n_factors % n_heads != 0:
+            raise ValueError("n_factors must be divisible by n_heads without remainder")   # nn.MultiheadAttention's own check
+        head = n_factors // n_heads
+        if n_factors % 4 != 0 or head % 8 != 0 or head > 128:
+            # the kernels move float4 columns and tile heads in 8-column groups (include/rectools_hip.h); fail at
+            # construction with the reason instead of a status code from the first launch of fit()
+            raise NotImplementedError(f"the HIP kernels need n_factors % 4 == 0 and a head size (n_factors / n_heads) that is a "
+                                      f"multiple of 8 and at most 128; got n_factors={n_factors}, n_heads={n_heads}")
         self.is_fitted = False
         self.dataset_schema: tp.Dict[str, tp.Any] = {}
         self.lightning_model: tp.Optional[hl.TransformerLossModule] = None

@@ -4,6 +4,8 @@ Module / parameter names and shapes are IDENTICAL to the reference (SURVEY.md Ap
 interchange with `rectools.models.nn.transformers.*`:
 
   item_model.item_net_blocks.0.ids_emb.weight            IdEmbeddingsItemNet            item_net.py:236-281
+  item_model.item_net_blocks.1.embedding_bag.weight      CatFeaturesItemNet (+ buffers offsets, emb_bag_inputs,
+                                                         input_lengths)                  item_net.py:60-233
   pos_encoding_layer.pos_emb.weight                      LearnableInversePositionalEncoding  net_blocks.py:346-400
   transformer_layers.transformer_blocks.i.*              SASRecTransformerLayers        sasrec.py:169-304
                                                          PreLNTransformerLayers         net_blocks.py:188-335
@@ -13,8 +15,8 @@ interchange with `rectools.models.nn.transformers.*`:
 
 What differs from the reference's plug-in signatures: layer stacks receive the flattened `[B*L, d]` activations
 plus the item ids (masks are derived in-kernel from ids and indices; no `[B*H, L, L]` mask tensor is ever
-built, torch_backbone.py:172-218,249-257), and the item table is read in place (no `get_all_embeddings()` copy,
-item_net.py:361-368).
+built, torch_backbone.py:172-218,249-257), and an ids-only item table is read in place (no `get_all_embeddings()`
+copy, item_net.py:361-368); with a category-feature block the catalog matrix is one fused pass per step (K1b).
 """
 from __future__ import annotations
 

@@ -201,7 +201,7 @@ def test_reference_checkpoint_loads_and_reproduces_reference_recommendations(nam
 def test_unfitted_model_pickles_as_config():
     from rectools_amd.models import NotFittedError, SASRecModel
 
-    m = SASRecModel.loads(SASRecModel(n_factors=16, loss="BCE").dumps())
-    assert m.n_factors == 16 and m.loss == "BCE" and not m.is_fitted
+    m = SASRecModel.loads(SASRecModel(n_factors=32, loss="BCE").dumps())
+    assert m.n_factors == 32 and m.loss == "BCE" and not m.is_fitted
     with pytest.raises(NotFittedError):
         m.recommend([1], None, 3, False)

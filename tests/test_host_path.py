@@ -114,6 +114,11 @@ def test_config_roundtrip_and_errors():
         SASRecModel(loss="hinge")
     with pytest.raises(ValueError):
         HSTUModel(n_factors=30, n_heads=4)
+    with pytest.raises(ValueError):
+        SASRecModel(n_factors=30, n_heads=4)
+    for bad in (dict(n_factors=36, n_heads=3), dict(n_factors=20, n_heads=1), dict(n_factors=512, n_heads=2)):
+        with pytest.raises(NotImplementedError, match="head size"):   # shapes the kernels do not tile: refused up front
+            SASRecModel(**bad)
     with pytest.raises(NotFittedError):
         m.recommend([1], None, 3, False)
     if not torch.cuda.is_available():
@@ -186,7 +191,7 @@ def test_item_net_blocks_names_warnings_and_config():
         "item_net_blocks.1.emb_bag_inputs", "item_net_blocks.1.input_lengths"])
     with pytest.raises(ValueError):
         hnn.SumOfEmbeddingsConstructor(5, [])
-    m = SASRecModel(n_factors=8, item_net_block_types=(hnn.IdEmbeddingsItemNet,))
+    m = SASRecModel(n_factors=32, item_net_block_types=(hnn.IdEmbeddingsItemNet,))
     cfg = m.get_config()
     assert cfg["item_net_block_types"] == ["rectools_amd.nn.IdEmbeddingsItemNet"]
     assert cfg["item_net_constructor_type"] == "rectools_amd.nn.SumOfEmbeddingsConstructor"
