@@ -276,10 +276,57 @@ def make_collate() -> None:
             br = dp._collate_fn_recommend(rb)
             for k, v in br.items():
                 out[f"{tag}{sfx}/recommend/{k}"] = v.numpy()
+    # SASRec validation collate (sasrec.py:118-147): zero-weight interactions are the input, the first weighted one the target
+    val_sessions = [
+        ([3, 5, 2, 7, 9, 4, 6], [0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 2.0], list(range(10, 80, 10))),   # L + 2 items: the longest a val session gets
+        ([8, 2], [0.0, 1.0], [100, 200]),
+        ([4, 4, 6, 5, 9], [0.0, 0.0, 0.0, 3.0, 1.0], [5, 6, 7, 8, 9]),
+    ]
+    for ts in (False, True):
+        ref_shims.seed_all(32)
+        dp = SASRecDataPreparator(session_max_len=L, batch_size=4, dataloader_num_workers=0, n_negatives=None, add_unix_ts=ts)
+        dp.item_id_map = types.SimpleNamespace(size=12)
+        b = dp._collate_fn_val([(s, w, {"unix_ts": t}) for s, w, t in val_sessions])
+        for k, v in b.items():
+            out[f"sasrec_val{'_ts' if ts else ''}/{k}"] = v.numpy()
+    out["val_sessions"] = np.array(json.dumps(val_sessions))
+
+    # BERT4Rec (bert4rec.py:109-193): masking draws come from np.random, in the order rand(len) per session then one
+    # randint per randomly replaced element — a seeded restatement must land on the same batch
+    from rectools.models.nn.transformers.bert4rec import MASKING_VALUE
+    from rectools.models.nn.transformers.constants import PADDING_VALUE
+
+    bert_sessions = [
+        ([3, 5, 2, 7, 9], [1.0, 1.0, 2.0, 1.0, 0.5]),
+        ([8, 2], [1.0, 3.0]),
+        ([4, 4, 6, 5, 9], [1.0, 1.0, 1.0, 1.0, 1.0]),
+        ([10, 11, 7], [2.0, 1.0, 1.0]),
+    ]
+    for mask_prob, seed in ((0.5, 32), (0.9, 7)):
+        dp = BERT4RecDataPreparator(session_max_len=L, batch_size=4, dataloader_num_workers=0, n_negatives=None,
+                                    train_min_user_interactions=2, mask_prob=mask_prob)
+        dp.item_id_map = types.SimpleNamespace(size=12)
+        dp.extra_token_ids = {PADDING_VALUE: 0, MASKING_VALUE: 1}
+        ref_shims.seed_all(seed)
+        b = dp._collate_fn_train([(list(s), list(w), {}) for s, w in bert_sessions])
+        for k, v in b.items():
+            out[f"bert4rec_p{mask_prob}_s{seed}/train/{k}"] = v.numpy()
+    dp = BERT4RecDataPreparator(session_max_len=L, batch_size=4, dataloader_num_workers=0, n_negatives=None,
+                                train_min_user_interactions=2, mask_prob=0.5)
+    dp.item_id_map = types.SimpleNamespace(size=12)
+    dp.extra_token_ids = {PADDING_VALUE: 0, MASKING_VALUE: 1}
+    long_sessions = bert_sessions + [([2, 3, 4, 5, 6, 7, 8], [1.0] * 7)]
+    b = dp._collate_fn_recommend([(list(s), list(w), {}) for s, w in long_sessions])
+    out["bert4rec/recommend/x"] = b["x"].numpy()
+    b = dp._collate_fn_val([(list(s), list(w), {}) for s, w, _ in val_sessions])
+    for k, v in b.items():
+        out[f"bert4rec/val/{k}"] = v.numpy()
+    out["bert_sessions"] = np.array(json.dumps(bert_sessions))
+    out["bert_long_sessions"] = np.array(json.dumps(long_sessions))
     out["sessions"] = np.array(json.dumps(sessions))
     out["L"] = np.array(L)
     np.savez_compressed(os.path.join(HERE, "collate_golden.npz"), **out)
-    print("collate: ok")
+    print("collate: ok", sorted(k for k in out if k.startswith("bert") or "val" in k))
 
 
 # ------------------------------------------------------------------------------------------------------------------

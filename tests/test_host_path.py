@@ -70,6 +70,52 @@ def test_collates_match_reference_outputs():
             np.testing.assert_array_equal(got[k], z[f"sasrec_noneg{sfx}/recommend/{k}"], err_msg=f"recommend {k} ts={ts}")
 
 
+def _store(sessions, with_ts):
+    from rectools_amd.data_preparator import SequenceStore
+
+    items = [np.array(s[0]) for s in sessions]
+    weights = [np.array(s[1], np.float32) for s in sessions]
+    offs = np.r_[0, np.cumsum([len(i) for i in items])]
+    ts = np.concatenate([np.array(s[2]) for s in sessions]) if with_ts else None
+    return SequenceStore(offs, np.concatenate(items), np.concatenate(weights), ts, np.arange(len(items)))
+
+
+def test_validation_and_bert4rec_collates_match_reference_outputs():
+    """Known answers from the unmodified reference (tests/golden/make_golden_transformer.py::make_collate):
+    SASRec `_collate_fn_val` (sasrec.py:118-147, with and without timestamps) and BERT4Rec `_collate_fn_train` under a
+    seeded np.random (bert4rec.py:109-153: same draw order => same masked batch), `_collate_fn_val`, `_collate_fn_recommend`."""
+    from rectools_amd.data_preparator import BERT4RecDataPreparator, SASRecDataPreparator
+    from rectools_amd.dataset import IdMap
+
+    z = np.load(os.path.join(GOLDEN_DIR, "collate_golden.npz"), allow_pickle=False)
+    L = int(z["L"])
+    val_sessions = json.loads(str(z["val_sessions"]))
+    for ts in (False, True):
+        dp = SASRecDataPreparator(session_max_len=L, batch_size=4, add_unix_ts=ts)
+        got = dp.collate_val(_store(val_sessions, ts), np.arange(len(val_sessions)))
+        tag = "sasrec_val_ts" if ts else "sasrec_val"
+        assert set(got) == {k.split("/", 1)[1] for k in z.files if k.startswith(tag + "/")}
+        for k, v in got.items():
+            np.testing.assert_array_equal(v, z[f"{tag}/{k}"], err_msg=f"{tag} {k}")
+    bert_sessions = json.loads(str(z["bert_sessions"]))
+    ids = IdMap(np.array(["PAD", "MASK"] + list(range(10)), dtype=object))       # size 12, as in the generator
+    for mask_prob, seed in ((0.5, 32), (0.9, 7)):
+        dp = BERT4RecDataPreparator(session_max_len=L, batch_size=4, mask_prob=mask_prob)
+        dp.item_id_map, dp.extra_token_ids = ids, {"PAD": 0, "MASK": 1}
+        np.random.seed(seed)
+        got = dp.collate_train(_store(bert_sessions, False), np.arange(len(bert_sessions)))
+        for k in ("x", "y", "yw"):
+            np.testing.assert_array_equal(got[k], z[f"bert4rec_p{mask_prob}_s{seed}/train/{k}"], err_msg=f"bert train {k} p={mask_prob}")
+    dp = BERT4RecDataPreparator(session_max_len=L, batch_size=4, mask_prob=0.5)
+    dp.item_id_map, dp.extra_token_ids = ids, {"PAD": 0, "MASK": 1}
+    long_sessions = json.loads(str(z["bert_long_sessions"]))
+    got = dp.collate_recommend(_store(long_sessions, False), np.arange(len(long_sessions)))
+    np.testing.assert_array_equal(got["x"], z["bert4rec/recommend/x"])
+    got = dp.collate_val(_store(val_sessions, False), np.arange(len(val_sessions)))
+    for k in ("x", "y", "yw"):
+        np.testing.assert_array_equal(got[k], z[f"bert4rec/val/{k}"], err_msg=f"bert val {k}")
+
+
 def test_bert4rec_collates():
     from rectools_amd.data_preparator import BERT4RecDataPreparator, SequenceStore
     from rectools_amd.dataset import IdMap
