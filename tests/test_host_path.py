@@ -271,3 +271,65 @@ def test_bag_structure_transpose_and_chunks():
         ops.BagStructure(torch.tensor([0, F_]), torch.tensor([0]), torch.tensor([2]), F_)     # id out of range
     with pytest.raises(ValueError):
         ops.BagStructure(torch.tensor([0]), torch.tensor([0]), torch.tensor([2]), F_)         # slice past the end
+
+
+# ---- the reference's own known-answer tests for the data preparator (tests/models/nn/transformers/test_data_preparator.py) ----
+def _kat_interactions():
+    return pd.DataFrame(
+        [[10, 13, 1, "2021-11-30", 0], [10, 11, 1, "2021-11-29", 2], [10, 12, 1, "2021-11-29", 3], [30, 11, 1, "2021-11-27", 4],
+         [30, 12, 2, "2021-11-26", 1], [30, 15, 1, "2021-11-25", 0], [40, 11, 1, "2021-11-25", 1], [40, 17, 1, "2021-11-26", 1],
+         [50, 16, 1, "2021-11-25", 2], [10, 14, 1, "2021-11-28", 2], [10, 16, 1, "2021-11-27", 1], [20, 13, 9, "2021-11-28", 1]],
+        columns=["user_id", "item_id", "weight", "datetime", "extra_column"])
+
+
+def _interaction_set(df):
+    cols = ["user_id", "item_id", "weight", "datetime", "extra_column"]
+    d = df[cols].copy()
+    d["datetime"] = pd.to_datetime(d["datetime"])
+    return sorted(map(tuple, d.astype({"weight": float}).values.tolist()))
+
+
+def test_reference_kat_sequence_store_from_interactions():
+    """test_data_preparator.py:26-79: sessions ordered by time inside a user, users sorted."""
+    from rectools_amd.data_preparator import SequenceStore
+
+    df = pd.DataFrame(
+        [[0, 13, 1, "2021-11-30", 0], [0, 11, 1, "2021-11-29", 1], [0, 12, 4, "2021-11-29", 1], [1, 11, 1, "2021-11-27", 0],
+         [1, 12, 2, "2021-11-26", 1], [1, 15, 1, "2021-11-25", 1], [2, 11, 1, "2021-11-25", 2], [2, 17, 8, "2021-11-26", 1],
+         [3, 16, 1, "2021-11-25", 0], [0, 14, 1, "2021-11-28", 0]],
+        columns=["user_id", "item_id", "weight", "datetime", "extra_column"])
+    df["datetime"] = pd.to_datetime(df["datetime"])
+    store = SequenceStore.from_interactions(df, sort_users=True)
+    sessions = [store.session(i) for i in range(len(store))]
+    assert [s[0].tolist() for s in sessions] == [[14, 11, 12, 13], [15, 12, 11], [11, 17], [16]]
+    assert [s[1].tolist() for s in sessions] == [[1, 1, 4, 1], [1, 2, 1], [1, 8], [1]]
+
+
+def test_reference_kat_process_train_and_transform_datasets():
+    """test_data_preparator.py:137-275: id maps and interaction sets after process_dataset_train (users with fewer than two
+    interactions dropped, PAD first), transform_dataset_u2i (requested users, known items) and transform_dataset_i2i."""
+    from rectools_amd.data_preparator import TransformerDataPreparatorBase
+    from rectools_amd.dataset import Dataset
+
+    ds = Dataset.construct(_kat_interactions(), keep_extra_cols=True)
+    dp = TransformerDataPreparatorBase(session_max_len=4, batch_size=4, extra_cols=["extra_column"])
+    dp.process_dataset_train(ds)
+    train = dp.train_dataset
+    assert train.user_id_map.external_ids.tolist() == [30, 40, 10]
+    assert list(train.item_id_map.external_ids) == ["PAD", 15, 11, 12, 17, 14, 13]
+    assert _interaction_set(train.interactions.df) == _interaction_set(pd.DataFrame(
+        [[0, 1, 1.0, "2021-11-25", 0], [1, 2, 1.0, "2021-11-25", 1], [0, 3, 2.0, "2021-11-26", 1], [1, 4, 1.0, "2021-11-26", 1],
+         [0, 2, 1.0, "2021-11-27", 4], [2, 5, 1.0, "2021-11-28", 2], [2, 2, 1.0, "2021-11-29", 2], [2, 3, 1.0, "2021-11-29", 3],
+         [2, 6, 1.0, "2021-11-30", 0]], columns=["user_id", "item_id", "weight", "datetime", "extra_column"]))
+    u2i = dp.transform_dataset_u2i(ds, [10, 20])
+    assert u2i.user_id_map.external_ids.tolist() == [10, 20]
+    assert list(u2i.item_id_map.external_ids) == ["PAD", 15, 11, 12, 17, 14, 13]
+    assert _interaction_set(u2i.interactions.df) == _interaction_set(pd.DataFrame(
+        [[0, 6, 1.0, "2021-11-30", 0], [0, 2, 1.0, "2021-11-29", 2], [0, 3, 1.0, "2021-11-29", 3], [0, 5, 1.0, "2021-11-28", 2],
+         [1, 6, 9.0, "2021-11-28", 1]], columns=["user_id", "item_id", "weight", "datetime", "extra_column"]))
+    i2i = dp.transform_dataset_i2i(ds)
+    assert i2i.user_id_map.external_ids.tolist() == [10, 30, 40, 50, 20]
+    assert _interaction_set(i2i.interactions.df) == _interaction_set(pd.DataFrame(
+        [[0, 6, 1.0, "2021-11-30", 0], [0, 2, 1.0, "2021-11-29", 2], [0, 3, 1.0, "2021-11-29", 3], [1, 2, 1.0, "2021-11-27", 4],
+         [1, 3, 2.0, "2021-11-26", 1], [1, 1, 1.0, "2021-11-25", 0], [2, 2, 1.0, "2021-11-25", 1], [2, 4, 1.0, "2021-11-26", 1],
+         [0, 5, 1.0, "2021-11-28", 2], [4, 6, 9.0, "2021-11-28", 1]], columns=["user_id", "item_id", "weight", "datetime", "extra_column"]))
