@@ -333,3 +333,32 @@ def test_reference_kat_process_train_and_transform_datasets():
         [[0, 6, 1.0, "2021-11-30", 0], [0, 2, 1.0, "2021-11-29", 2], [0, 3, 1.0, "2021-11-29", 3], [1, 2, 1.0, "2021-11-27", 4],
          [1, 3, 2.0, "2021-11-26", 1], [1, 1, 1.0, "2021-11-25", 0], [2, 2, 1.0, "2021-11-25", 1], [2, 4, 1.0, "2021-11-26", 1],
          [0, 5, 1.0, "2021-11-28", 2], [4, 6, 9.0, "2021-11-28", 1]], columns=["user_id", "item_id", "weight", "datetime", "extra_column"]))
+
+
+def test_reference_kat_cat_features_item_net_from_dataset():
+    """tests/models/nn/test_item_net.py:85-165: the structure buffers CatFeaturesItemNet.from_dataset builds from a raw
+    (un-preprocessed) dataset: item 11 carries no category, the others two each; 5 distinct (feature, value) pairs."""
+    from rectools_amd.dataset import Dataset
+    from rectools_amd.nn import CatFeaturesItemNet, IdEmbeddingsItemNet
+
+    inter = pd.DataFrame([[10, 11], [10, 12], [10, 14], [20, 11], [20, 12], [20, 13], [30, 11], [30, 12], [30, 14], [30, 15],
+                          [40, 11], [40, 15], [40, 17]], columns=["user_id", "item_id"])
+    inter["weight"], inter["datetime"] = 1, "2021-09-09"
+    feats = pd.DataFrame(
+        [[12, "f1", "f1val1"], [12, "f2", "f2val2"], [13, "f1", "f1val1"], [13, "f2", "f2val3"], [14, "f1", "f1val2"],
+         [14, "f2", "f2val1"], [15, "f1", "f1val2"], [15, "f2", "f2val2"], [17, "f1", "f1val2"], [17, "f2", "f2val3"],
+         [16, "f1", "f1val2"], [16, "f2", "f2val3"], [12, "f3", 1], [13, "f3", 2], [14, "f3", 3], [15, "f3", 4], [17, "f3", 5],
+         [16, "f3", 6]], columns=["id", "feature", "value"])
+    ds = Dataset.construct(inter, item_features_df=feats, cat_item_features=["f1", "f2"])
+    for n_factors in (12, 100):
+        net = CatFeaturesItemNet.from_dataset(ds, n_factors=n_factors, dropout_rate=0.5)
+        assert net.n_cat_feature_values == 5 and net.out_dim == n_factors
+        assert net.offsets.tolist() == [0, 0, 2, 4, 6, 8, 10]
+        assert net.emb_bag_inputs.tolist() == [0, 2, 1, 4, 0, 3, 1, 2, 1, 3, 1, 3]
+        assert net.input_lengths.tolist() == [0, 2, 2, 2, 2, 2, 2]
+    ids_net = IdEmbeddingsItemNet.from_dataset(ds, n_factors=12, dropout_rate=0.5)
+    assert ids_net.n_items == ds.item_id_map.size and ids_net.out_dim == 12
+    # no categorical columns -> the block is skipped (test_item_net.py:181-233)
+    only_direct = Dataset.construct(inter, item_features_df=feats[feats["feature"] == "f3"])
+    with pytest.warns(UserWarning, match="do not contain categorical features"):
+        assert CatFeaturesItemNet.from_dataset(only_direct, n_factors=12, dropout_rate=0.5) is None
