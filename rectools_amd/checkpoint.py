@@ -51,6 +51,7 @@ CLASS_PATHS: tp.Dict[str, str] = {
     _REF + "transformers.net_blocks.LearnableInversePositionalEncoding": "rectools_amd.nn.LearnableInversePositionalEncoding",
     _REF + "transformers.torch_backbone.TransformerTorchBackbone": "rectools_amd.nn.TransformerTorchBackbone",
     _REF + "transformers.lightning.TransformerLightningModule": "rectools_amd.lightning.TransformerLossModule",
+    _REF + "transformers.utils.leave_one_out_mask": "rectools_amd.utils.leave_one_out_mask",
     _REF + "item_net.IdEmbeddingsItemNet": "rectools_amd.nn.IdEmbeddingsItemNet",
     _REF + "item_net.CatFeaturesItemNet": "rectools_amd.nn.CatFeaturesItemNet",
     _REF + "item_net.SumOfEmbeddingsConstructor": "rectools_amd.nn.SumOfEmbeddingsConstructor",
