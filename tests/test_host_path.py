@@ -443,3 +443,43 @@ def test_reference_kat_leave_one_out_mask(swap, expected_index, expected_item, v
     val = df[leave_one_out_mask(df, val_users)]
     assert list(val.index) == expected_index
     assert val.loc[max(swap), "item_id"] == expected_item
+
+
+def test_reference_kat_bert4rec_batches():
+    """test_bert4rec.py:706-937: recommend / validation batches, and the train batches under seed_everything(32) — the
+    masking draws come from np.random in the reference's order (rand per session, randint per replaced element), so the
+    seeded host collate reproduces them, random replacements included.  (Row order of the multi-session batch is the
+    reference dataloader's torch shuffle: users 10, 30, 40 = sessions 2, 0, 1.)"""
+    from rectools_amd.data_preparator import BERT4RecDataPreparator, SequenceStore
+    from rectools_amd.dataset import Dataset
+
+    ds = Dataset.construct(_interactions())
+    dp = BERT4RecDataPreparator(session_max_len=4, n_negatives=1, batch_size=4, train_min_user_interactions=2, mask_prob=0.5)
+    dp.process_dataset_train(ds)
+    store = dp.train_store()
+    np.random.seed(32)
+    got = dp.collate_train(store, np.array([2, 0, 1]))
+    assert got["x"].tolist() == [[6, 1, 4, 7], [0, 2, 4, 1], [0, 0, 3, 5]]
+    assert got["y"].tolist() == [[0, 3, 0, 0], [0, 0, 0, 3], [0, 0, 0, 0]]
+    assert got["yw"].tolist() == [[1, 1, 1, 1], [0, 1, 2, 1], [0, 0, 1, 1]]
+    rec = dp.transform_dataset_i2i(ds)
+    rstore = SequenceStore.from_interactions(rec.interactions.df, sort_users=True)
+    assert dp.collate_recommend(rstore, np.arange(len(rstore)))["x"].tolist() == [[3, 4, 7, 1], [2, 4, 3, 1], [0, 3, 5, 1], [0, 0, 7, 1]]
+
+    one = pd.DataFrame([[10, i, 1, "2021-11-30"] for i in (1, 2, 3, 4, 5, 6, 7, 8, 9, 13, 2, 3, 3, 4, 11)],
+                       columns=["user_id", "item_id", "weight", "datetime"])
+    dp1 = BERT4RecDataPreparator(session_max_len=15, n_negatives=None, batch_size=14, train_min_user_interactions=2, mask_prob=0.5)
+    dp1.process_dataset_train(Dataset.construct(one))
+    np.random.seed(32)
+    got = dp1.collate_train(dp1.train_store(), np.arange(1))
+    assert got["x"].tolist() == [[2, 1, 4, 5, 6, 7, 1, 9, 10, 11, 1, 1, 4, 6, 12]]
+    assert got["y"].tolist() == [[0, 3, 0, 0, 0, 0, 8, 0, 0, 0, 3, 4, 0, 5, 0]]
+    assert got["yw"].tolist() == [[1.0] * 15]
+
+    for val_users in ([10, 30], [30]):
+        dpv = BERT4RecDataPreparator(session_max_len=4, n_negatives=2, train_min_user_interactions=2, mask_prob=0.5, batch_size=4,
+                                     get_val_mask_func=_leave_one_out_mask, get_val_mask_func_kwargs={"val_users": val_users})
+        dpv.process_dataset_train(ds)
+        vstore = dpv.val_store()
+        got = dpv.collate_val(vstore, np.arange(len(vstore)))
+        assert got["x"].tolist() == [[0, 2, 4, 1]] and got["y"].tolist() == [[3]] and got["yw"].tolist() == [[1.0]]
