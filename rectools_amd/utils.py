@@ -24,3 +24,16 @@ def leave_one_out_mask(interactions: pd.DataFrame, val_users: tp.Union[tp.Sequen
     elif val_users is None:
         return last.values
     return (interactions[Columns.User].isin(val_users) & last).values
+
+
+def get_context(df: pd.DataFrame) -> pd.DataFrame:
+    """One row per user — the user's EARLIEST row by datetime — to be passed as `context` to `recommend()` of models that
+    need the time of the recommendation request (HSTU with relative time attention).  `rectools/dataset/context.py:22-51`:
+    a missing weight column becomes 1.0, datetimes are parsed, the item column is dropped."""
+    df = df.copy()
+    if Columns.Weight not in df.columns:
+        df[Columns.Weight] = 1.0
+    df[Columns.Weight] = df[Columns.Weight].astype(float)
+    df[Columns.Datetime] = pd.to_datetime(df[Columns.Datetime])
+    context = df.loc[df.groupby(Columns.User)[Columns.Datetime].idxmin()]
+    return context.drop(columns=[Columns.Item]) if Columns.Item in context else context

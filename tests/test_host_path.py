@@ -483,3 +483,14 @@ def test_reference_kat_bert4rec_batches():
         vstore = dpv.val_store()
         got = dpv.collate_val(vstore, np.arange(len(vstore)))
         assert got["x"].tolist() == [[0, 2, 4, 1]] and got["y"].tolist() == [[3]] and got["yw"].tolist() == [[1.0]]
+
+
+def test_get_context_takes_each_users_earliest_row():
+    """rectools/dataset/context.py:22-51."""
+    from rectools_amd.utils import get_context
+
+    df = pd.DataFrame({"user_id": [10, 10, 20, 30, 30], "item_id": [1, 2, 3, 4, 5],
+                       "datetime": ["2021-12-12", "2021-12-10", "2021-12-11", "2021-12-14", "2021-12-13"]})
+    ctx = get_context(df)
+    assert list(ctx.columns) == ["user_id", "datetime", "weight"] and ctx["user_id"].tolist() == [10, 20, 30]
+    assert ctx["datetime"].tolist() == list(pd.to_datetime(["2021-12-10", "2021-12-11", "2021-12-13"])) and ctx["weight"].tolist() == [1.0] * 3
