@@ -355,8 +355,10 @@ def checkpoint_frames():
 def make_checkpoints() -> None:
     import pandas as pd
     from rectools.dataset import Dataset
-    from rectools.models import BERT4RecModel, SASRecModel
+    from rectools.dataset.context import get_context
+    from rectools.models import BERT4RecModel, HSTUModel, SASRecModel
     from rectools.models.nn.item_net import IdEmbeddingsItemNet
+    from rectools.models.nn.transformers.ligr import LiGRLayers
 
     from oracle import ref_shims
 
@@ -368,8 +370,16 @@ def make_checkpoints() -> None:
         "bert4rec_ids": (BERT4RecModel, dict(n_factors=32, n_blocks=1, n_heads=2, session_max_len=4, lr=0.01, batch_size=4, epochs=2,
                                              loss="softmax", mask_prob=0.5, deterministic=True,
                                              item_net_block_types=(IdEmbeddingsItemNet,)), False),
+        "hstu_time_pos": (HSTUModel, dict(n_factors=32, n_blocks=2, n_heads=2, session_max_len=4, lr=0.01, batch_size=4, epochs=3,
+                                          loss="sampled_softmax", n_negatives=3, deterministic=True, relative_time_attention=True,
+                                          relative_pos_attention=True, item_net_block_types=(IdEmbeddingsItemNet,)), False),
+        "esasrec_ligr": (SASRecModel, dict(n_factors=32, n_blocks=2, n_heads=2, session_max_len=4, lr=0.01, batch_size=4, epochs=2,
+                                           loss="gBCE", n_negatives=2, deterministic=True, transformer_layers_type=LiGRLayers,
+                                           transformer_layers_kwargs=dict(ff_factors_multiplier=4, ff_activation="swiglu", bias_in_ff=False),
+                                           item_net_block_types=(IdEmbeddingsItemNet,)), False),
     }
     users = [10, 30, 40]
+    context_df = pd.DataFrame({"user_id": users, "datetime": ["2021-12-12", "2021-12-13", "2021-12-12"]})
     for name, (klass, kw, with_features) in cases.items():
         ref_shims.seed_all(32)
         ds = (Dataset.construct(interactions, item_features_df=features, cat_item_features=["f1", "f2"]) if with_features
@@ -385,7 +395,8 @@ def make_checkpoints() -> None:
         expected = {}
         for tag, rk in (("filter", dict(k=3, filter_viewed=True)), ("nofilter", dict(k=4, filter_viewed=False)),
                         ("whitelist", dict(k=2, filter_viewed=False, items_to_recommend=[11, 13, 17]))):
-            r = model.recommend(users=users, dataset=ds, **rk)
+            ctx = get_context(context_df) if model.require_recommend_context else None
+            r = model.recommend(users=users, dataset=ds, context=ctx, **rk)
             expected[tag] = {c: r[c].tolist() for c in r.columns}
         i2i = model.recommend_to_items(target_items=[11, 12], dataset=ds, k=2)
         expected["i2i"] = {c: i2i[c].tolist() for c in i2i.columns}

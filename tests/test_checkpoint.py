@@ -14,7 +14,7 @@ import torch
 
 from conftest import GOLDEN_DIR
 
-CKPTS = ["sasrec_catfeat", "bert4rec_ids"]
+CKPTS = ["sasrec_catfeat", "bert4rec_ids", "hstu_time_pos", "esasrec_ligr"]
 
 
 def _load(name):
@@ -44,9 +44,18 @@ def _dataset(name):
 
 
 def _model_class(name):
-    from rectools_amd.models import BERT4RecModel, SASRecModel
+    from rectools_amd.models import BERT4RecModel, HSTUModel, SASRecModel
 
-    return SASRecModel if name.startswith("sasrec") else BERT4RecModel
+    return {"sasrec_catfeat": SASRecModel, "bert4rec_ids": BERT4RecModel, "hstu_time_pos": HSTUModel, "esasrec_ligr": SASRecModel}[name]
+
+
+def _context(model):
+    """HSTU with relative time attention ranks "as of" a request time (hstu.py:719-729): one context row per user."""
+    from rectools_amd.utils import get_context
+
+    if not model.require_recommend_context:
+        return None
+    return get_context(pd.DataFrame({"user_id": [10, 30, 40], "datetime": ["2021-12-12", "2021-12-13", "2021-12-12"]}))
 
 
 # ---- CPU -----------------------------------------------------------------------------------------------------
@@ -68,6 +77,7 @@ def test_reference_config_translates_to_importable_classes(name):
     model = _model_class(name).from_config({k: v for k, v in cfg.items() if k != "cls"})
     assert model.n_factors == 32 and model.loss == ref_cfg["loss"] and model.session_max_len == 4
     assert [t.__name__ for t in model.item_net_block_types] == [p.rsplit(".", 1)[1] for p in ref_cfg["item_net_block_types"]]
+    assert model.transformer_layers_type.__name__ == ref_cfg["transformer_layers_type"].rsplit(".", 1)[1]
 
 
 @pytest.mark.parametrize("name", CKPTS)
@@ -159,10 +169,11 @@ def test_reference_checkpoint_loads_and_reproduces_reference_recommendations(nam
     for k, v in ref["state_dict"].items():
         assert torch.equal(sd[k[len(ckpt.STATE_PREFIX):]].cpu(), v), k
     ds = _dataset(name)
-    users, exp = [10, 30, 40], ref["expected"]
-    _assert_frame(model.recommend(users=users, dataset=ds, k=3, filter_viewed=True), exp["filter"])
-    _assert_frame(model.recommend(users=users, dataset=ds, k=4, filter_viewed=False), exp["nofilter"])
-    _assert_frame(model.recommend(users=users, dataset=ds, k=2, filter_viewed=False, items_to_recommend=[11, 13, 17]), exp["whitelist"])
+    users, exp, ctx = [10, 30, 40], ref["expected"], _context(model)
+    _assert_frame(model.recommend(users=users, dataset=ds, k=3, filter_viewed=True, context=ctx), exp["filter"])
+    _assert_frame(model.recommend(users=users, dataset=ds, k=4, filter_viewed=False, context=ctx), exp["nofilter"])
+    _assert_frame(model.recommend(users=users, dataset=ds, k=2, filter_viewed=False, items_to_recommend=[11, 13, 17], context=ctx),
+                  exp["whitelist"])
     _assert_frame(model.recommend_to_items(target_items=[11, 12], dataset=ds, k=2), exp["i2i"])
     # Adam moments arrived (matched by name) and go back out bit-identically, in Lightning's layout
     out = ckpt.to_checkpoint(model)
@@ -182,9 +193,9 @@ def test_reference_checkpoint_loads_and_reproduces_reference_recommendations(nam
     p2 = str(tmp_path / "again.ckpt")
     model.save_to_checkpoint(p2)
     again = klass.load_from_checkpoint(p2)
-    _assert_frame(again.recommend(users=users, dataset=ds, k=3, filter_viewed=True), exp["filter"])
+    _assert_frame(again.recommend(users=users, dataset=ds, k=3, filter_viewed=True, context=ctx), exp["filter"])
     clone = klass.loads(model.dumps())
-    _assert_frame(clone.recommend(users=users, dataset=ds, k=3, filter_viewed=True), exp["filter"])
+    _assert_frame(clone.recommend(users=users, dataset=ds, k=3, filter_viewed=True, context=ctx), exp["filter"])
     before = {k: v.clone() for k, v in again.torch_model.state_dict().items()}
     again.fit_partial(ds, max_epochs=1)
     assert again.epochs_done == ref["epoch"] + 1 and again.optimizer.step_count > ref["global_step"]
@@ -194,7 +205,7 @@ def test_reference_checkpoint_loads_and_reproduces_reference_recommendations(nam
     other = klass.load_from_checkpoint(p2, model_params_update={"lr": 0.5})
     assert other.lr == 0.5
     again.load_weights_from_checkpoint(path)
-    _assert_frame(again.recommend(users=users, dataset=ds, k=3, filter_viewed=True), exp["filter"])
+    _assert_frame(again.recommend(users=users, dataset=ds, k=3, filter_viewed=True, context=ctx), exp["filter"])
 
 
 @pytest.mark.gpu
