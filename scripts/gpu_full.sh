@@ -15,6 +15,7 @@ for w in train recommend; do
     bench.py --gpus 2 --workload $w --steps 5 --warmup 2 > gpurun_out/bench_${w}_2ranks_1gpu.json 2> gpurun_out/bench_${w}_2ranks_1gpu.err
   tail -c 600 gpurun_out/bench_${w}_2ranks_1gpu.json | cut -c1-600; echo
 done
+timeout 200 python scripts/itemnet_bench.py > gpurun_out/itemnet_bench.txt 2>/dev/null; cat gpurun_out/itemnet_bench.txt | cut -c1-200
 prof() { name=$1; shift
   rm -rf gpurun_out/prof_$name
   (cd /tmp && timeout 400 rocprofv3 --kernel-trace -d $R/gpurun_out/prof_$name -o p -- python $R/bench.py --no-cpu-baseline "$@" > $R/gpurun_out/prof_$name.log 2>&1)
