@@ -130,6 +130,7 @@ class FlatAdam:
         self.m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.v = torch.zeros(total, dtype=torch.float32, device=dev)
         self._flat_g: tp.Optional[torch.Tensor] = None   # allocated on first use (data-parallel runs only)
+        self._g_views: tp.Optional[tp.List[torch.Tensor]] = None
         self.params = params
         self._offsets: tp.List[int] = []
         ofs = 0
@@ -163,14 +164,20 @@ class FlatAdam:
             p.grad = None  # the next backward's gradient tensors are adopted as they are
 
     def gather_gradients(self) -> torch.Tensor:
-        """Pack the per-parameter gradients into the flat buffer (zeros where a parameter got none)."""
+        """Pack the per-parameter gradients into the flat buffer (zeros where a parameter got none): ONE multi-tensor copy
+        launch for all of them instead of a copy kernel per parameter (28 launches at C2 right before the collective)."""
         fg = self.flat_g
-        for p, ofs in zip(self.params, self._offsets):
-            seg = fg[ofs:ofs + p.numel()]
+        if self._g_views is None:
+            self._g_views = [fg[ofs:ofs + p.numel()].view_as(p) for p, ofs in zip(self.params, self._offsets)]
+        views, grads = [], []
+        for p, view in zip(self.params, self._g_views):
             if p.grad is None:
-                seg.zero_()
+                view.zero_()
             else:
-                seg.copy_(p.grad.reshape(-1))
+                views.append(view)
+                grads.append(p.grad if p.grad.dtype == torch.float32 else p.grad.float())
+        if views:
+            torch._foreach_copy_(views, grads)   # pylint: disable=protected-access
         return fg
 
     def reduce_gradients(self, world_size: int = 1) -> float:
