@@ -1,0 +1,92 @@
+"""Live cross-checks against the UNMODIFIED reference, run only where `/root/reference` exists (the build container; the
+GPU box has no reference tree, so everything here is CPU-only and skipped there).  The committed golden vectors pin fixed
+cases; these tests fuzz the host path against the reference itself on random inputs."""
+import types
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from oracle import ref_shims
+
+pytestmark = pytest.mark.skipif(not ref_shims.reference_available(), reason="reference tree not present")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _shims():
+    ref_shims.install()
+
+
+def _random_frames(seed, n_users=25, n_items=40, n=400):
+    rng = np.random.default_rng(seed)
+    inter = pd.DataFrame({"user_id": rng.integers(0, n_users, n) * 3 + 1, "item_id": rng.integers(0, n_items, n) + 100,
+                          "weight": rng.integers(1, 4, n).astype(float),
+                          "datetime": pd.to_datetime("2022-01-01") + pd.to_timedelta(rng.integers(0, 5000, n), unit="h")})
+    items = np.unique(inter["item_id"])
+    feats = pd.concat([
+        pd.DataFrame({"id": np.repeat(items, 2), "feature": "genre", "value": rng.integers(0, 6, 2 * len(items))}),
+        pd.DataFrame({"id": items[::2], "feature": "studio", "value": rng.integers(0, 9, len(items[::2])).astype(str)}),
+        pd.DataFrame({"id": items, "feature": "year", "value": rng.integers(1990, 2020, len(items))})])
+    return inter, feats
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_reference_dataset_is_accepted_and_processed_like_ours(seed):
+    """The engine takes a `rectools.dataset.Dataset` as it is (duck typing): processing it, or our own mirror built from
+    the same frames, gives the item id order, the feature structure and the schema the REFERENCE's preparator derives."""
+    from rectools.dataset import Dataset as RefDataset
+    from rectools.models.nn.item_net import CatFeaturesItemNet as RefCat
+    from rectools.models.nn.transformers.sasrec import SASRecDataPreparator as RefPreparator
+
+    from rectools_amd.data_preparator import SASRecDataPreparator
+    from rectools_amd.dataset import Dataset
+    from rectools_amd.nn import CatFeaturesItemNet
+
+    inter, feats = _random_frames(seed)
+    kw = dict(item_features_df=feats, cat_item_features=["genre", "studio"])
+    ref_ds, my_ds = RefDataset.construct(inter, **kw), Dataset.construct(inter, **kw)
+    ref_dp = RefPreparator(session_max_len=6, batch_size=8, dataloader_num_workers=0)
+    ref_dp.process_dataset_train(ref_ds)
+    ref_net = RefCat.from_dataset(ref_dp.train_dataset, 8, 0.0)
+    for ds in (ref_ds, my_ds):
+        dp = SASRecDataPreparator(session_max_len=6, batch_size=8)
+        dp.process_dataset_train(ds)
+        assert list(dp.item_id_map.external_ids) == list(ref_dp.item_id_map.external_ids)
+        assert dp.train_dataset.user_id_map.external_ids.tolist() == ref_dp.train_dataset.user_id_map.external_ids.tolist()
+        net = CatFeaturesItemNet.from_dataset(dp.train_dataset, 8, 0.0)
+        assert net.emb_bag_inputs.tolist() == ref_net.emb_bag_inputs.tolist()
+        assert net.offsets.tolist() == ref_net.offsets.tolist() and net.input_lengths.tolist() == ref_net.input_lengths.tolist()
+        assert net.n_cat_feature_values == ref_net.n_cat_feature_values
+        assert dp.train_dataset.get_schema() == ref_dp.train_dataset.get_schema()
+        # same sessions, hence same train batches (the reference's collate on its own SequenceDataset vs ours on the CSR store)
+        store = dp.train_store()
+        ref_seq = ref_dp.get_dataloader_train().dataset
+        ref_batch = ref_dp._collate_fn_train([ref_seq[i] for i in range(len(ref_seq))])    # pylint: disable=protected-access
+        got = dp.collate_train(store, np.arange(len(store)))
+        for k in ("x", "y", "yw"):
+            np.testing.assert_array_equal(got[k], ref_batch[k].numpy(), err_msg=k)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_recommend_dataset_transform_matches_reference(seed):
+    """transform_dataset_u2i + recommend collate on random frames (incl. users / items unknown to the model)."""
+    from rectools.dataset import Dataset as RefDataset
+    from rectools.models.nn.transformers.sasrec import SASRecDataPreparator as RefPreparator
+
+    from rectools_amd.data_preparator import SASRecDataPreparator, SequenceStore
+    from rectools_amd.dataset import Dataset
+
+    inter, _ = _random_frames(seed + 10)
+    train = inter[inter["item_id"] < 130]
+    ref_dp = RefPreparator(session_max_len=5, batch_size=8, dataloader_num_workers=0)
+    ref_dp.process_dataset_train(RefDataset.construct(train))
+    dp = SASRecDataPreparator(session_max_len=5, batch_size=8)
+    dp.process_dataset_train(Dataset.construct(train))
+    users = np.unique(inter["user_id"])[::2]
+    ref_rec = ref_dp.transform_dataset_u2i(RefDataset.construct(inter), users)
+    rec = dp.transform_dataset_u2i(Dataset.construct(inter), users)
+    assert rec.user_id_map.external_ids.tolist() == ref_rec.user_id_map.external_ids.tolist()
+    ref_loader = ref_dp.get_dataloader_recommend(ref_rec, 1000)
+    ref_x = next(iter(ref_loader))["x"].numpy()
+    store = SequenceStore.from_interactions(rec.interactions.df, sort_users=True)
+    np.testing.assert_array_equal(dp.collate_recommend(store, np.arange(len(store)))["x"], ref_x)
