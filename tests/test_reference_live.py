@@ -90,3 +90,67 @@ def test_recommend_dataset_transform_matches_reference(seed):
     ref_x = next(iter(ref_loader))["x"].numpy()
     store = SequenceStore.from_interactions(rec.interactions.df, sort_users=True)
     np.testing.assert_array_equal(dp.collate_recommend(store, np.arange(len(store)))["x"], ref_x)
+
+
+def _fuzz_configs():
+    import itertools
+
+    rng = np.random.default_rng(123)
+    layer_kinds = ["sasrec", "preln", "ligr", "stu"]
+    losses = ["softmax", "BCE", "gBCE", "sampled_softmax"]
+    out = []
+    for i, (layers, loss) in enumerate(itertools.product(layer_kinds, losses)):
+        H = int(rng.choice([1, 2, 4]))
+        d = H * int(rng.choice([8, 16]))
+        cfg = dict(V=int(rng.integers(20, 90)), B=int(rng.integers(2, 6)), L=int(rng.integers(3, 20)), d=d, H=H,
+                   n_blocks=int(rng.integers(1, 3)), N=int(rng.integers(1, 6)), loss=loss, dist=str(rng.choice(["dot", "cosine"])),
+                   logits_t=float(rng.choice([1.0, 0.1])), causal=layers != "preln", keypad=bool(rng.integers(0, 2)) or layers == "preln",
+                   layers=layers, n_extra=2 if layers == "preln" else 1, gbce_t=float(rng.choice([0.2, 0.75])), lr=1e-3,
+                   use_scale=layers == "stu", layer_kwargs={}, weights=str(rng.choice(["ones", "rand"])), seed=1000 + i)
+        if layers == "ligr":
+            cfg["layer_kwargs"] = dict(ff_factors_multiplier=int(rng.choice([2, 4])), ff_activation=str(rng.choice(["swiglu", "gelu", "relu"])),
+                                       bias_in_ff=bool(rng.integers(0, 2)))
+        if layers == "stu":
+            cfg.update(rel_time=bool(rng.integers(0, 2)), rel_pos=bool(rng.integers(0, 2)), keypad=False)
+        if rng.integers(0, 3) == 0 and layers != "stu":
+            cfg["cat"] = dict(F=int(rng.integers(3, 12)), max_per_item=int(rng.integers(1, 5)))
+        out.append(cfg)
+    return out
+
+
+@pytest.mark.parametrize("cfg", _fuzz_configs(), ids=lambda c: f"{c['layers']}-{c['loss']}-{c['dist']}")
+def test_oracle_matches_live_reference_on_random_configs(cfg):
+    """The oracle (plain restatement) against the reference's own modules on 16 random configurations — every layer family
+    × every loss, random sizes / heads / masks / temperatures / feature nets: loss, every gradient, eval encodings."""
+    import os
+    import sys
+
+    import torch
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_golden_transformer import build_reference, make_batch  # type: ignore
+
+    from oracle import transformer_oracle as T
+
+    ref_shims.seed_all(cfg["seed"])
+    lm = build_reference(cfg)
+    lm._xavier_normal_init()    # pylint: disable=protected-access
+    g = torch.Generator().manual_seed(cfg["seed"] + 1)
+    with torch.no_grad():
+        for _, p in lm.torch_model.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+    batch = make_batch(cfg, g)
+    params = {k: v.detach().clone() for k, v in lm.torch_model.state_dict().items()}
+    lm.train()
+    loss = lm.training_step({k: v.clone() for k, v in batch.items()}, 0)
+    loss.backward()
+    loss_o, grads_o = T.loss_and_grads(cfg, params, batch)
+    assert abs(float(loss_o) - float(loss.detach())) <= 1e-5 + 1e-5 * abs(float(loss.detach()))
+    for n, p in lm.torch_model.named_parameters():
+        ref_g = p.grad if p.grad is not None else torch.zeros_like(p)
+        torch.testing.assert_close(grads_o[n], ref_g, rtol=2e-3, atol=2e-6, msg=lambda m, n=n: f"{n}: {m}")
+    lm.eval()
+    with torch.no_grad():
+        enc = lm.torch_model.encode_sessions({k: v.clone() for k, v in batch.items()}, lm.torch_model.item_model.get_all_embeddings())
+        torch.testing.assert_close(T.encode_sessions(cfg, params, batch), enc, rtol=1e-4, atol=2e-5)
