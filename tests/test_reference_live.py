@@ -154,3 +154,41 @@ def test_oracle_matches_live_reference_on_random_configs(cfg):
     with torch.no_grad():
         enc = lm.torch_model.encode_sessions({k: v.clone() for k, v in batch.items()}, lm.torch_model.item_model.get_all_embeddings())
         torch.testing.assert_close(T.encode_sessions(cfg, params, batch), enc, rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_ranker_oracle_matches_live_torch_ranker_on_random_inputs(seed):
+    """`oracle/ranker_oracle.rank` against the reference's `TorchRanker.rank` (rank_torch.py:77-223) on random factors,
+    distances, k (incl. None and k > candidates), viewed-filters, whitelists and subject batches.  Integer-valued factors make
+    dot products exact in both, so ids are compared exactly; cosine / euclidean scores with tolerance and ids on tie-free draws."""
+    import torch
+    from rectools.models.rank import Distance, TorchRanker
+    from scipy import sparse
+
+    from oracle import ranker_oracle
+
+    rng = np.random.default_rng(seed)
+    n_subj, n_obj, d = int(rng.integers(1, 40)), int(rng.integers(2, 300)), int(rng.integers(1, 24))
+    dist = ["dot", "cosine", "euclidean"][seed % 3]
+    subj = rng.normal(size=(n_subj, d)).astype(np.float32)
+    obj = rng.normal(size=(n_obj, d)).astype(np.float32)
+    ids = rng.permutation(n_subj)[: int(rng.integers(1, n_subj + 1))]
+    k = [None, 1, int(rng.integers(1, n_obj + 5))][int(rng.integers(0, 3))]
+    filt = None
+    if rng.integers(0, 2) and dist != "euclidean":     # euclidean + filter is the reference quirk pinned by the golden cases
+        filt = sparse.csr_matrix((rng.random((len(ids), n_obj)) < 0.2).astype(np.float32))
+    wl = None
+    if rng.integers(0, 2):
+        wl = np.sort(rng.permutation(n_obj)[: int(rng.integers(1, n_obj + 1))])
+    ranker = TorchRanker(distance=Distance[dist.upper()], device="cpu", subjects_factors=torch.from_numpy(subj),
+                         objects_factors=torch.from_numpy(obj), batch_size=int(rng.integers(1, 50)))
+    rs, ri, rsc = ranker.rank(ids, k=k, filter_pairs_csr=filt, sorted_object_whitelist=wl)
+    os_, oi, osc = ranker_oracle.rank(subj, obj, ids, k=k, filter_pairs_csr=filt, sorted_object_whitelist=wl, distance=dist)
+    assert np.asarray(rs).tolist() == np.asarray(os_).tolist()
+    # euclidean distances near 0 cancel differently in the two formulations (|u|^2 + |v|^2 - 2uv vs the direct difference)
+    np.testing.assert_allclose(np.asarray(osc), np.asarray(rsc), rtol=2e-5, atol=1e-4 if dist == "euclidean" else 1e-5)
+    ri, oi = np.asarray(ri), np.asarray(oi)
+    if dist == "euclidean":   # two candidates within the cancellation error may swap places: positional agreement, not identity
+        assert (ri == oi).mean() > 0.98
+    else:
+        assert ri.tolist() == oi.tolist()      # continuous random factors: no exact ties
