@@ -524,7 +524,11 @@ __device__ __forceinline__ void wait_vmcnt() {
 // cycles in the wave that issues it (address VALU + the piece itself); with 6 pieces per 16 MFMAs that is a third of
 // a compute wave's time at 32 users per launch, exactly the regime where the kernel should be HBM-bound.  A loader
 // shares its SIMD's issue port with one compute wave, but its pieces overlap that wave's MFMA execution.
-template <int TU, int NS, bool WL, bool LL, int NLD>
+// BF = true: the SAME ring over a bf16 image of users and catalog (rows of d/2 "floats" = d bf16: `a.d`, the strides and
+// the 16-byte DMA pieces count floats as before); one 16-byte LDS read is then one k = 16 operand of
+// v_mfma_f32_32x32x16_bf16 (fp32 accumulate) instead of four k = 2 fp32 operands — the coarse pass of the two-stage
+// top-k (rt_topk_score_bf16).  Dot products only: cosine runs on pre-normalised images.
+template <int TU, int NS, bool WL, bool LL, int NLD, bool BF = false>
 __global__ __launch_bounds__(NTHREADS + NLD * 64) void topk_stream_kernel(TopkArgs a) {
   constexpr int NISS = NLD ? NLD : 4;      // issuing waves
   constexpr int IPI = 16 / NISS;           // item pieces per issuer and stage (128 rows x 32 floats = 16 KiB = 16 pieces)
@@ -695,14 +699,21 @@ __global__ __launch_bounds__(NTHREADS + NLD * 64) void topk_stream_kernel(TopkAr
 #pragma unroll
       for (int s = 0; s < KC / 8; ++s) {
         f32x4 av = *reinterpret_cast<const f32x4*>(Ab + (((2 * s + half) ^ a_swz) << 2));
-        nrm_i += av[0] * av[0] + av[1] * av[1] + av[2] * av[2] + av[3] * av[3];
+        if constexpr (!BF) nrm_i += av[0] * av[0] + av[1] * av[1] + av[2] * av[2] + av[3] * av[3];
 #pragma unroll
         for (int tu = 0; tu < TU; ++tu) {
           f32x4 bv = *reinterpret_cast<const f32x4*>(Ub + tu * 32 * KC + (((2 * s + half) ^ u_swz[tu]) << 2));
-          nrm_u[tu] += bv[0] * bv[0] + bv[1] * bv[1] + bv[2] * bv[2] + bv[3] * bv[3];
+          if constexpr (BF) {
+            // both operands take their 8 bf16 from the same 16-byte slot, so the k positions pair up whatever the
+            // instruction's own numbering of them is (the sum over k is order-free)
+            acc[tu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
+                                                              acc[tu], 0, 0, 0);
+          } else {
+            nrm_u[tu] += bv[0] * bv[0] + bv[1] * bv[1] + bv[2] * bv[2] + bv[3] * bv[3];
 #pragma unroll
-          for (int t = 0; t < 4; ++t)
-            acc[tu] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc[tu], 0, 0, 0);
+            for (int t = 0; t < 4; ++t)
+              acc[tu] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc[tu], 0, 0, 0);
+          }
         }
       }
     }
@@ -930,18 +941,27 @@ inline Plan make_plan(int n_users, long long n_cand, int k, int users_per_pass) 
   return P;
 }
 
-template <int TU, int NS, bool WL, bool LL, int NLD>
+template <int TU, int NS, bool WL, bool LL, int NLD, bool BF = false>
 int launch_stream_nld(const TopkArgs& a, dim3 grid, hipStream_t stream) {
   const size_t lds = stream_lds_bytes(TU, NS, LL ? a.k : 0);
   static size_t attr_lds = 0;
   if (lds > 64 * 1024 && lds > attr_lds) {
-    RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_stream_kernel<TU, NS, WL, LL, NLD>),
+    RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_stream_kernel<TU, NS, WL, LL, NLD, BF>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_lds = lds;
   }
-  topk_stream_kernel<TU, NS, WL, LL, NLD><<<grid, NTHREADS + NLD * 64, lds, stream>>>(a);
+  topk_stream_kernel<TU, NS, WL, LL, NLD, BF><<<grid, NTHREADS + NLD * 64, lds, stream>>>(a);
   RT_CHECK_LAUNCH();
   return RT_OK;
+}
+// bf16 coarse pass: lists in global memory (it keeps K_c = 64 > K_LDS_LISTS entries), deepest ring that fits beside
+// nothing else (make_plan's choice for k_lds = 0: 6 stages for the 32- / 64-user tiles, 4 for the 128-user tile).
+constexpr int bf16_stages(int tu) { return tu == 4 ? 4 : 6; }
+template <int TU>
+int launch_stream_bf16(const TopkArgs& a, dim3 grid, hipStream_t stream) {
+  constexpr int NS = bf16_stages(TU), NLD = TU <= 2 ? 2 : 0;
+  return a.whitelist ? launch_stream_nld<TU, NS, true, false, NLD, true>(a, grid, stream)
+                     : launch_stream_nld<TU, NS, false, false, NLD, true>(a, grid, stream);
 }
 // RT_TOPK_LOADERS: 0 = every wave issues and computes, 2 = two dedicated loader waves (default for the small user tiles
 // that are HBM-bound; the 128-user tile is MFMA-bound and keeps its issue slots for compute waves only)
@@ -1019,15 +1039,17 @@ int rt_filter_hash_build(const int64_t* filt_indptr, const int32_t* filt_indices
   return RT_OK;
 }
 
-int rt_topk_score(const float* users, int64_t user_stride, const int64_t* user_rows, int32_t n_users,
-                  const float* items, int64_t item_stride, const int64_t* whitelist, int64_t n_candidates,
-                  int64_t candidate_id_offset, int32_t d, int32_t distance, int32_t k,
-                  const int64_t* filt_indptr, const int32_t* filt_indices, const int32_t* filt_hash,
-                  int64_t* out_ids, float* out_scores, int32_t* out_counts,
-                  void* workspace, size_t workspace_bytes, int32_t users_per_pass, hipStream_t stream) {
+// `bf16`: users / items point at bf16 images whose rows hold d floats' worth of bytes (2 d bf16 values): dot products only.
+static int topk_score_impl(const float* users, int64_t user_stride, const int64_t* user_rows, int32_t n_users,
+                           const float* items, int64_t item_stride, const int64_t* whitelist, int64_t n_candidates,
+                           int64_t candidate_id_offset, int32_t d, int32_t distance, int32_t k,
+                           const int64_t* filt_indptr, const int32_t* filt_indices, const int32_t* filt_hash,
+                           int64_t* out_ids, float* out_scores, int32_t* out_counts,
+                           void* workspace, size_t workspace_bytes, int32_t users_per_pass, bool bf16, hipStream_t stream) {
   (void)hipGetLastError();  // do not inherit a stale error from the caller's earlier HIP calls
   if (n_users < 0 || n_candidates < 0 || d <= 0 || (d & 3) != 0 || k <= 0) return RT_ERR_INVALID_ARG;
   if (distance < DIST_DOT || distance > DIST_EUCLID) return RT_ERR_INVALID_ARG;
+  if (bf16 && (distance != DIST_DOT || d % KC != 0)) return RT_ERR_UNSUPPORTED;
   if ((user_stride & 3) != 0 || (item_stride & 3) != 0) return RT_ERR_INVALID_ARG;
   if (((uintptr_t)users & 15) != 0 || ((uintptr_t)items & 15) != 0) return RT_ERR_INVALID_ARG;
   if (n_candidates >= (1LL << 31)) return RT_ERR_UNSUPPORTED;
@@ -1036,11 +1058,12 @@ int rt_topk_score(const float* users, int64_t user_stride, const int64_t* user_r
   if (n_candidates == 0) {
     return hipMemsetAsync(out_counts, 0, sizeof(int32_t) * (size_t)n_users, stream) == hipSuccess ? RT_OK : RT_ERR_LAUNCH;
   }
-  const Plan P = make_plan(n_users, n_candidates, k, users_per_pass);
+  Plan P = make_plan(n_users, n_candidates, k, users_per_pass);
   if (workspace == nullptr || workspace_bytes < P.total) return RT_ERR_WORKSPACE;
+  if (bf16) { P.lds_lists = false; P.ns = bf16_stages(P.tu); }   // the instantiations launch_stream_bf16 carries
   char* ws = reinterpret_cast<char*>(workspace);
   const int impl = env_int("RT_TOPK_IMPL", 2);
-  const bool stream_ok = (impl == 2) && (d % KC == 0);
+  const bool stream_ok = bf16 || ((impl == 2) && (d % KC == 0));
 
   for (int u0 = 0; u0 < n_users; u0 += P.users_per_launch) {
     const int nb = (n_users - u0) < P.users_per_launch ? (n_users - u0) : P.users_per_launch;
@@ -1075,6 +1098,11 @@ int rt_topk_score(const float* users, int64_t user_stride, const int64_t* user_r
     m.n_lists = P.n_lists; m.n_users_pad = P.n_users_pad; m.k = k; m.n_users = nb;
     auto run_phase = [&](long long b0, long long b1, int n_seg, int resume) -> int {
       a.blk_begin = b0; a.blk_end = b1; a.n_seg = n_seg; a.resume = resume;
+      if (bf16) {
+        if (P.tu == 1) return launch_stream_bf16<1>(a, grid, stream);
+        if (P.tu == 2) return launch_stream_bf16<2>(a, grid, stream);
+        return launch_stream_bf16<4>(a, grid, stream);
+      }
       if (stream_ok) return launch_stream_any(P.tu, P.ns, a, grid, P.lds_lists, stream);
       if (P.tu == 1) return launch_staged<1>(a, grid, stream);
       if (P.tu == 2) return launch_staged<2>(a, grid, stream);
@@ -1106,6 +1134,32 @@ int rt_topk_score(const float* users, int64_t user_stride, const int64_t* user_r
     RT_CHECK_LAUNCH();
   }
   return RT_OK;
+}
+
+int rt_topk_score(const float* users, int64_t user_stride, const int64_t* user_rows, int32_t n_users,
+                  const float* items, int64_t item_stride, const int64_t* whitelist, int64_t n_candidates,
+                  int64_t candidate_id_offset, int32_t d, int32_t distance, int32_t k,
+                  const int64_t* filt_indptr, const int32_t* filt_indices, const int32_t* filt_hash,
+                  int64_t* out_ids, float* out_scores, int32_t* out_counts,
+                  void* workspace, size_t workspace_bytes, int32_t users_per_pass, hipStream_t stream) {
+  return topk_score_impl(users, user_stride, user_rows, n_users, items, item_stride, whitelist, n_candidates, candidate_id_offset, d,
+                         distance, k, filt_indptr, filt_indices, filt_hash, out_ids, out_scores, out_counts, workspace,
+                         workspace_bytes, users_per_pass, false, stream);
+}
+
+// Coarse pass of the two-stage top-k: the same selection over bf16 images (rt_to_bf16_rows) of users [n_users, d] (dense,
+// already gathered) and of the catalog [*, d]; strides count bf16 elements; d % 64 == 0; dot products (cosine callers pass
+// normalised images).  out_scores are the COARSE scores, best first; workspace as rt_topk_workspace_bytes(n_users, n, k, upp).
+int rt_topk_score_bf16(const uint16_t* users_bf16, int64_t user_stride, int32_t n_users, const uint16_t* items_bf16,
+                       int64_t item_stride, const int64_t* whitelist, int64_t n_candidates, int64_t candidate_id_offset, int32_t d,
+                       int32_t k, const int64_t* filt_indptr, const int32_t* filt_indices, const int32_t* filt_hash,
+                       int64_t* out_ids, float* out_scores, int32_t* out_counts, void* workspace, size_t workspace_bytes,
+                       int32_t users_per_pass, hipStream_t stream) {
+  if (d <= 0 || d % (2 * KC) != 0 || (user_stride & 7) != 0 || (item_stride & 7) != 0) return RT_ERR_INVALID_ARG;
+  return topk_score_impl(reinterpret_cast<const float*>(users_bf16), user_stride / 2, nullptr, n_users,
+                         reinterpret_cast<const float*>(items_bf16), item_stride / 2, whitelist, n_candidates, candidate_id_offset,
+                         d / 2, DIST_DOT, k, filt_indptr, filt_indices, filt_hash, out_ids, out_scores, out_counts, workspace,
+                         workspace_bytes, users_per_pass, true, stream);
 }
 
 }  // extern "C"

@@ -11,6 +11,7 @@ no per-batch H2D/D2H.  There is no CPU fallback: without the HIP library / a GPU
 """
 from __future__ import annotations
 
+import os
 import typing as tp
 from enum import Enum
 
@@ -107,6 +108,7 @@ class HipRanker:
         objects_factors: tp.Union[np.ndarray, torch.Tensor],
         batch_size: tp.Optional[int] = None,
         dtype: tp.Optional[torch.dtype] = torch.float32,
+        two_stage: tp.Optional[bool] = None,
     ):
         if dtype not in (None, torch.float32):
             raise NotImplementedError("HipRanker computes in float32 only")
@@ -124,6 +126,11 @@ class HipRanker:
         if self.subjects_factors.shape[1] != self.objects_factors.shape[1]:
             raise ValueError("subjects and objects factors must have the same number of columns")
         self._workspace: tp.Optional[torch.Tensor] = None
+        # two-stage top-k (bf16 coarse pass + exact fp32 rescoring, include/rectools_hip.h K12b): opt-in
+        self.two_stage = (os.environ.get("RT_TOPK_TWO_STAGE", "0") == "1") if two_stage is None else bool(two_stage)
+        self._shadow: tp.Optional[torch.Tensor] = None        # bf16 image of objects_factors (normalised rows for cosine)
+        self._max_item_norm = 0.0
+        self.two_stage_stats = {"calls": 0, "fallbacks": 0}
 
     def _to_device(self, tensor: tp.Union[np.ndarray, sparse.csr_matrix, torch.Tensor]) -> torch.Tensor:
         # mirrors TorchRanker._normalize_tensor (rank_torch.py:210-223), then moves to the device once
@@ -135,6 +142,74 @@ class HipRanker:
         if tensor.dim() != 2:
             raise ValueError("factors must be 2-dimensional")
         return _pad4(tensor)
+
+    # ---- two-stage top-k ---------------------------------------------------------------------------------
+    COARSE_KEEP = 64          # K_c: candidates kept per user by coarse score
+
+    def _two_stage_applies(self, kk: int, n_cand: int) -> bool:
+        d = self.objects_factors.shape[1]
+        return (self.two_stage and self.distance in (Distance.DOT, Distance.COSINE) and d % 64 == 0 and d <= 2048
+                and 2 * kk <= self.COARSE_KEEP and n_cand >= 8 * self.COARSE_KEEP)
+
+    def _bf16_image(self, src: torch.Tensor, rows: tp.Optional[torch.Tensor], n_rows: int) -> tp.Tuple[torch.Tensor, torch.Tensor]:
+        d = src.shape[1]
+        img = torch.empty((n_rows, d), dtype=torch.bfloat16, device=self.device)
+        norms = torch.empty((n_rows,), dtype=torch.float32, device=self.device)
+        status = self._lib.rt_to_bf16_rows(_lib.ptr(src), src.stride(0), _lib.ptr(rows), n_rows, d,
+                                           1 if self.distance == Distance.COSINE else 0, _lib.ptr(img), _lib.ptr(norms),
+                                           _lib.current_stream())
+        _lib.check(status, "rt_to_bf16_rows")
+        return img, norms
+
+    def _rank_two_stage(self, ids_t, scores_t, counts_t, rows_t, n_subj, whitelist_t, n_cand, id_offset, kk, indptr_t, indices_t,
+                        hash_t, upp) -> bool:
+        """Coarse bf16 pass keeping K_c candidates per user, a per-user proof that nothing else can be in the exact top-k,
+        exact fp32 rescoring of the candidates.  Returns False (nothing written) when the proof fails for some user — the
+        caller then ranks the call with the exact kernel."""
+        d, kc, dev = self.objects_factors.shape[1], self.COARSE_KEEP, self.device
+        self.two_stage_stats["calls"] += 1
+        with torch.cuda.device(dev):
+            if self._shadow is None:
+                self._shadow, item_norms = self._bf16_image(self.objects_factors, None, self.objects_factors.shape[0])
+                self._max_item_norm = float(item_norms.max())
+            users_img, user_norms = self._bf16_image(self.subjects_factors, rows_t, n_subj)
+            c_ids = torch.empty((n_subj, kc), dtype=torch.int64, device=dev)
+            c_scores = torch.empty((n_subj, kc), dtype=torch.float32, device=dev)
+            c_counts = torch.zeros((n_subj,), dtype=torch.int32, device=dev)
+            ws_bytes = self._lib.rt_topk_workspace_bytes(n_subj, n_cand, kc, upp)
+            if self._workspace is None or self._workspace.numel() < ws_bytes:
+                self._workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+            status = self._lib.rt_topk_score_bf16(
+                _lib.ptr(users_img), d, n_subj, self._shadow.data_ptr() + 2 * id_offset * d, d, _lib.ptr(whitelist_t), n_cand,
+                id_offset, d, kc, _lib.ptr(indptr_t), _lib.ptr(indices_t), _lib.ptr(hash_t), _lib.ptr(c_ids), _lib.ptr(c_scores),
+                _lib.ptr(c_counts), _lib.ptr(self._workspace), self._workspace.numel(), upp, _lib.current_stream())
+            _lib.check(status, "rt_topk_score_bf16")
+            # |coarse - exact| <= c |u| |v|  (bf16 rounding of both operands + fp32 accumulation), 1 % slack
+            c = 1.01 * (2.0 ** -8 + 2.0 ** -18 + d * 2.0 ** -24)
+            if self.distance == Distance.COSINE:
+                eps = torch.full((n_subj,), c * 1.001 + 1e-6, dtype=torch.float32, device=dev)     # unit rows
+            else:
+                eps = c * user_norms * self._max_item_norm
+            full = c_counts >= kc
+            proven = (~full) | (c_scores[:, kc - 1] < c_scores[:, kk - 1] - 2.0 * eps)
+            if not bool(proven.all()):
+                self.two_stage_stats["fallbacks"] += 1
+                return False
+            exact = torch.empty((n_subj, kc), dtype=torch.float32, device=dev)
+            status = self._lib.rt_topk_rescore(
+                _lib.ptr(self.subjects_factors), self.subjects_factors.stride(0), _lib.ptr(rows_t), n_subj,
+                _lib.ptr(self.objects_factors), self.objects_factors.stride(0), d, _DIST_CODE[self.distance], _lib.ptr(c_ids),
+                _lib.ptr(c_counts), kc, _lib.ptr(exact), _lib.current_stream())
+            _lib.check(status, "rt_topk_rescore")
+            # best exact score first; exact ties -> lower catalog row first (the exact kernel's rule)
+            valid = torch.arange(kc, device=dev)[None, :] < c_counts[:, None]
+            order_id = torch.sort(torch.where(valid, c_ids, torch.full_like(c_ids, 2 ** 62)), dim=1, stable=True).indices
+            by_id_scores = torch.gather(exact, 1, order_id)
+            order = torch.sort(by_id_scores, dim=1, descending=True, stable=True).indices[:, :kk]
+            ids_t.copy_(torch.gather(torch.gather(c_ids, 1, order_id), 1, order))
+            scores_t.copy_(torch.gather(by_id_scores, 1, order))
+            counts_t.copy_(torch.clamp(c_counts, max=kk))
+        return True
 
     def rank(
         self,
@@ -226,6 +301,11 @@ class HipRanker:
                 hash_t = dcsr.hash_tables()
 
         upp = 0 if self.batch_size is None else int(self.batch_size)
+        if self._two_stage_applies(kk, n_cand):
+            done = self._rank_two_stage(ids_t, scores_t, counts_t, rows_t, n_subj, whitelist_t, n_cand, id_offset, kk,
+                                        indptr_t, indices_t, hash_t, upp)
+            if done:
+                return ids_t, scores_t, counts_t, subject_ids
         ws_bytes = self._lib.rt_topk_workspace_bytes(n_subj, n_cand, kk, upp)
         if self._workspace is None or self._workspace.numel() < ws_bytes:
             self._workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)

@@ -1,0 +1,114 @@
+"""Two-stage exact top-k (bf16 coarse pass + fp32 rescoring; include/rectools_hip.h K12b, rank.HipRanker(two_stage=True)).
+
+OPT-IN: the path is not the default and these tests run only with RT_TEST_TWO_STAGE=1 until the kernels have been
+validated on hardware (scripts/gpu_two_stage.sh).  The contract is the exact path's: same ids, order and fp32 scores."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from scipy import sparse
+
+from oracle import ranker_oracle
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("RT_TEST_TWO_STAGE") != "1", reason="two-stage top-k is opt-in (RT_TEST_TWO_STAGE=1)")]
+
+
+def _factors(n_subj, n_obj, d, seed):
+    rng = np.random.default_rng(seed)
+    return rng.normal(size=(n_subj, d)).astype(np.float32), (rng.normal(size=(n_obj, d)) * rng.uniform(0.5, 2.0, (n_obj, 1))).astype(np.float32)
+
+
+CASES = [
+    # distance, d, n_obj, n_subj, batch (users per pass), k, filter, whitelist
+    ("dot", 64, 20_000, 40, 32, 10, False, None),
+    ("dot", 256, 131_109, 70, 64, 10, True, None),
+    ("cosine", 128, 50_003, 33, 32, 5, True, "sparse"),
+    ("cosine", 512, 30_000, 200, 128, 32, False, "range"),
+    ("dot", 64, 9_000, 130, 128, 1, True, "range"),
+]
+
+
+@pytest.mark.parametrize("dist,d,n_obj,n_subj,batch,k,with_filter,wl_kind", CASES)
+def test_two_stage_equals_exact_path(dist, d, n_obj, n_subj, batch, k, with_filter, wl_kind):
+    from rectools_amd.rank import HipRanker
+
+    subj, obj = _factors(n_subj, n_obj, d, seed=n_obj % 97)
+    rng = np.random.default_rng(5)
+    ids = rng.permutation(n_subj)[: max(1, n_subj - 3)]
+    filt = None
+    if with_filter:
+        filt = sparse.random(len(ids), n_obj, density=0.002, format="csr", random_state=7, dtype=np.float32)
+    wl = None
+    if wl_kind == "sparse":
+        wl = np.sort(rng.permutation(n_obj)[: n_obj // 2])
+    elif wl_kind == "range":
+        wl = np.arange(1000, n_obj - 500)
+    exact = HipRanker(dist, "cuda", subj, obj, batch_size=batch, two_stage=False)
+    fast = HipRanker(dist, "cuda", subj, obj, batch_size=batch, two_stage=True)
+    e_ids, e_sc, e_cnt, _ = exact.rank_device(ids, k, filt, wl)
+    f_ids, f_sc, f_cnt, _ = fast.rank_device(ids, k, filt, wl)
+    assert fast.two_stage_stats == {"calls": 1, "fallbacks": 0}
+    assert torch.equal(e_cnt, f_cnt)
+    valid = torch.arange(e_ids.shape[1], device="cuda")[None, :] < e_cnt[:, None]
+    assert torch.equal(e_ids[valid], f_ids[valid])
+    torch.testing.assert_close(f_sc[valid], e_sc[valid], rtol=2e-5, atol=1e-5)
+    # and against the CPU oracle on the first users
+    s_o, i_o, sc_o = ranker_oracle.rank(subj, obj, ids[:5], k=k, filter_pairs_csr=None if filt is None else filt[:5],
+                                        sorted_object_whitelist=wl, distance=dist)
+    got = f_ids[:5][valid[:5]].cpu().numpy()
+    assert got.tolist() == np.asarray(i_o).tolist()
+
+
+def test_two_stage_falls_back_when_the_margin_cannot_be_proven():
+    """A catalog of near-duplicates: more than K_c items sit inside the coarse error window of the k-th score, so the proof
+    fails and the call is ranked by the exact kernel — same result, one fallback recorded."""
+    from rectools_amd.rank import HipRanker
+
+    rng = np.random.default_rng(1)
+    base = rng.normal(size=(50, 64)).astype(np.float32)
+    obj = np.repeat(base, 400, axis=0) * (1.0 + 1e-4 * rng.normal(size=(20_000, 1))).astype(np.float32)
+    subj = rng.normal(size=(20, 64)).astype(np.float32)
+    exact = HipRanker("dot", "cuda", subj, obj, two_stage=False)
+    fast = HipRanker("dot", "cuda", subj, obj, two_stage=True)
+    e_ids, e_sc, e_cnt, _ = exact.rank_device(np.arange(20), 10)
+    f_ids, f_sc, f_cnt, _ = fast.rank_device(np.arange(20), 10)
+    assert fast.two_stage_stats == {"calls": 1, "fallbacks": 1}
+    assert torch.equal(e_ids, f_ids) and torch.equal(e_sc, f_sc)
+
+
+def test_bf16_image_and_rescore_kernels():
+    """rt_to_bf16_rows == torch's round-to-nearest-even bf16 cast (+ norms, + gather, + normalisation); rt_topk_rescore ==
+    fp32 dot / cosine of the gathered rows."""
+    from rectools_amd import _lib
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(300, 192, generator=g) * torch.logspace(-3, 3, 300)[:, None]).cuda()
+    rows = torch.randperm(300, generator=g)[:77].cuda()
+    for normalize in (0, 1):
+        img = torch.empty((77, 192), dtype=torch.bfloat16, device="cuda")
+        norms = torch.empty((77,), dtype=torch.float32, device="cuda")
+        _lib.check(lib.rt_to_bf16_rows(x.data_ptr(), x.stride(0), rows.data_ptr(), 77, 192, normalize, img.data_ptr(), norms.data_ptr(),
+                                       _lib.current_stream()), "rt_to_bf16_rows")
+        src = x[rows]
+        torch.testing.assert_close(norms, src.norm(dim=1), rtol=1e-5, atol=0)
+        want = (src / src.norm(dim=1, keepdim=True).clamp_min(1e-8)) if normalize else src
+        if normalize:   # the kernel scales by the reciprocal: allow one bf16 ulp
+            torch.testing.assert_close(img.float(), want.to(torch.bfloat16).float(), rtol=2 ** -7, atol=0)
+        else:
+            assert torch.equal(img, want.to(torch.bfloat16))
+    users, items = torch.randn(9, 192, generator=g).cuda(), x
+    cand = torch.randint(0, 300, (9, 12), generator=g).cuda()
+    counts = torch.tensor([12, 0, 5, 12, 1, 7, 12, 3, 11], dtype=torch.int32).cuda()
+    for dist in (0, 1):
+        out = torch.empty((9, 12), dtype=torch.float32, device="cuda")
+        _lib.check(lib.rt_topk_rescore(users.data_ptr(), users.stride(0), None, 9, items.data_ptr(), items.stride(0), 192, dist,
+                                       cand.data_ptr(), counts.data_ptr(), 12, out.data_ptr(), _lib.current_stream()), "rt_topk_rescore")
+        ref = torch.einsum("ud,ukd->uk", users, items[cand])
+        if dist == 1:
+            ref = ref / users.norm(dim=1, keepdim=True).clamp_min(1e-8) / items[cand].norm(dim=2).clamp_min(1e-8)
+        valid = torch.arange(12, device="cuda")[None, :] < counts[:, None]
+        torch.testing.assert_close(out[valid], ref[valid], rtol=2e-5, atol=2e-5)
+        assert bool(torch.isinf(out[~valid]).all())
