@@ -10,6 +10,7 @@ negative_sampler.py:58-73; parity is distributional, as the reference itself res
 """
 from __future__ import annotations
 
+import os
 import typing as tp
 import warnings
 
@@ -178,8 +179,93 @@ class TransformerDataPreparatorBase:
         return (df.sort_values(Columns.Datetime, kind="stable").groupby(Columns.User, sort=False)
                 .tail(self.session_max_len + self.train_session_max_len_addition))
 
+    # ---- array fast path of process_dataset_train ------------------------------------------------------
+    def _fast_path_applies(self, dataset: tp.Any) -> bool:
+        if self.get_val_mask_func is not None or (self.extra_cols or []) or os.environ.get("RT_PREP", "arrays") == "pandas":
+            return False   # a validation mask is a user callable over the raw frame; extra columns ride along in pandas
+        df = getattr(getattr(dataset, "interactions", None), "df", None)
+        if df is None or len(df) == 0:
+            return False
+        return (pd.api.types.is_integer_dtype(df[Columns.User].dtype) and pd.api.types.is_integer_dtype(df[Columns.Item].dtype)
+                and pd.api.types.is_datetime64_any_dtype(df[Columns.Datetime].dtype))
+
+    @staticmethod
+    def _first_appearance(x: torch.Tensor, n_values: int) -> tp.Tuple[torch.Tensor, torch.Tensor]:
+        """Distinct values of `x` in order of first appearance (what `pd.unique` returns) and the value -> rank lookup."""
+        big = x.numel()
+        first = torch.full((n_values,), big, dtype=torch.int64, device=x.device)
+        first.scatter_reduce_(0, x, torch.arange(big, dtype=torch.int64, device=x.device), reduce="amin", include_self=True)
+        vals = torch.nonzero(first < big).reshape(-1)
+        uniq = vals[torch.sort(first[vals]).indices]
+        lookup = torch.full((n_values,), -1, dtype=torch.int64, device=x.device)
+        lookup[uniq] = torch.arange(uniq.numel(), dtype=torch.int64, device=x.device)
+        return uniq, lookup
+
+    def _process_dataset_train_arrays(self, dataset: tp.Any) -> None:
+        """The same result as the frame-based path below (data_preparator.py:214-284), computed with sorts / scans over the
+        interaction columns instead of pandas groupby: at ML-20M scale the frame path costs several epochs of GPU training.
+        Works on the dataset's INTERNAL ids (integers whatever the external id type) and translates only the distinct ids.
+        RT_PREP_DEVICE selects where the sorts run (default cpu; the ops are torch ops, identical on a HIP device)."""
+        dev = torch.device(os.environ.get("RT_PREP_DEVICE", "cpu"))
+        df = dataset.interactions.df
+        as_t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
+        u = as_t(df[Columns.User].values.astype(np.int64, copy=False))
+        it = as_t(df[Columns.Item].values.astype(np.int64, copy=False))
+        t_ns = df[Columns.Datetime].values.astype("datetime64[ns]").view(np.int64)
+        t = as_t(t_ns)
+        n_src_users, n_src_items = int(u.max()) + 1, int(it.max()) + 1
+        # users with enough interactions (value_counts over ALL their interactions)
+        cnt = torch.bincount(u, minlength=n_src_users)
+        idx0 = torch.nonzero(cnt[u] >= self.train_min_user_interactions).reshape(-1)
+        # stable sort by time, then the last (L + addition) rows of every user — in time order, as groupby(...).tail keeps them
+        rows_time = idx0[torch.sort(t[idx0], stable=True).indices]
+        u1 = u[rows_time]
+        o2 = torch.sort(u1, stable=True).indices
+        ends = torch.cumsum(torch.bincount(u1, minlength=n_src_users), 0)
+        pos = torch.arange(o2.numel(), dtype=torch.int64, device=dev)
+        keep_grouped = (ends[u1[o2]] - 1 - pos) < (self.session_max_len + self.train_session_max_len_addition)
+        keep_time = torch.zeros(o2.numel(), dtype=torch.bool, device=dev)
+        keep_time[o2[keep_grouped]] = True
+        rows = rows_time[keep_time]
+        uf, itf = u[rows], it[rows]
+        uniq_u, look_u = self._first_appearance(uf, n_src_users)
+        uniq_i, look_i = self._first_appearance(itf, n_src_items)
+        ext_users = np.asarray(dataset.user_id_map.external_ids)[uniq_u.cpu().numpy()]
+        ext_items = np.asarray(dataset.item_id_map.external_ids)[uniq_i.cpu().numpy()]
+        user_id_map = IdMap.from_values(ext_users)
+        item_id_map = IdMap.from_values(np.array(list(self.item_extra_tokens), dtype=object)).add_ids(ext_items)
+        if item_id_map.size != self.n_item_extra_tokens + len(ext_items):   # an item shares its id with an extra token
+            raise ValueError("item ids collide with the extra tokens of the model")
+        new_u, new_i = look_u[uf], look_i[itf] + self.n_item_extra_tokens
+        rows_np = rows.cpu().numpy()
+        frame = {Columns.User: new_u.cpu().numpy(), Columns.Item: new_i.cpu().numpy(),
+                 Columns.Weight: df[Columns.Weight].values[rows_np].astype(float),
+                 Columns.Datetime: t_ns[rows_np].view("datetime64[ns]")}
+        if self.add_unix_ts:
+            frame["unix_ts"] = (t_ns[rows_np] / 10**9).astype("int64")      # the frame path's arithmetic (_to_unix_ts)
+        final = Interactions(pd.DataFrame(frame, copy=False))
+        item_features = None
+        if getattr(dataset, "item_features", None) is not None:
+            item_features = self._process_features_for_id_map(dataset.item_features, dataset.item_id_map, item_id_map,
+                                                              self.n_item_extra_tokens)
+        self.train_dataset = Dataset(user_id_map, item_id_map, final, item_features=item_features)
+        self.item_id_map = item_id_map
+        self.extra_token_ids = dict(zip(self.item_extra_tokens, item_id_map.convert_to_internal(list(self.item_extra_tokens))))
+        self.val_interactions = None
+        # the session store falls out of one more stable sort (users in id-map order = order of first appearance in time)
+        o3 = torch.sort(new_u, stable=True).indices.cpu().numpy()
+        users_sorted = frame[Columns.User][o3]
+        change = np.flatnonzero(np.r_[True, users_sorted[1:] != users_sorted[:-1]])
+        self._train_store = SequenceStore(np.r_[change, len(users_sorted)].astype(np.int64), frame[Columns.Item][o3].astype(np.int64),
+                                          frame[Columns.Weight][o3].astype(np.float32),
+                                          frame["unix_ts"][o3].astype(np.int64) if self.add_unix_ts else None, users_sorted[change])
+
     def process_dataset_train(self, dataset: tp.Any) -> None:
         """data_preparator.py:229-284 — PAD (and MASK) first in the item id map so that PAD == 0."""
+        self._train_store = None
+        if dataset is not None and self._fast_path_applies(dataset):
+            self._process_dataset_train_arrays(dataset)
+            return
         raw = dataset.get_raw_interactions()
         if self.add_unix_ts:
             raw["unix_ts"] = self._to_unix_ts(raw[Columns.Datetime])
@@ -224,6 +310,8 @@ class TransformerDataPreparatorBase:
         return SparseFeatures.from_iterables(full, taken.names)
 
     def train_store(self) -> SequenceStore:
+        if getattr(self, "_train_store", None) is not None:
+            return self._train_store
         return SequenceStore.from_interactions(self.train_dataset.interactions.df)
 
     def val_store(self) -> tp.Optional[SequenceStore]:

@@ -494,3 +494,44 @@ def test_get_context_takes_each_users_earliest_row():
     ctx = get_context(df)
     assert list(ctx.columns) == ["user_id", "datetime", "weight"] and ctx["user_id"].tolist() == [10, 20, 30]
     assert ctx["datetime"].tolist() == list(pd.to_datetime(["2021-12-10", "2021-12-11", "2021-12-13"])) and ctx["weight"].tolist() == [1.0] * 3
+
+
+@pytest.mark.parametrize("seed,string_ids,with_ts,bert", [(0, False, False, False), (1, True, True, False), (2, False, True, True), (3, True, False, True)])
+def test_array_fast_path_equals_frame_path(seed, string_ids, with_ts, bert, monkeypatch):
+    """process_dataset_train computed with sorts / scans over the interaction columns must give exactly what the frame
+    (pandas groupby) path gives: id maps, the interactions frame row for row, and the session store — with ties in time,
+    users below the interaction minimum, sessions longer than the window, string external ids."""
+    from rectools_amd.data_preparator import BERT4RecDataPreparator, SASRecDataPreparator, SequenceStore
+    from rectools_amd.dataset import Dataset
+
+    rng = np.random.default_rng(seed)
+    n = 3000
+    users = rng.zipf(1.5, n).clip(max=120)                 # a few heavy users (truncated tails), many singletons (dropped)
+    items = rng.integers(0, 60, n)
+    df = pd.DataFrame({"user_id": users * 7 + 3, "item_id": items + 500, "weight": rng.integers(1, 5, n).astype(float),
+                       "datetime": pd.to_datetime("2022-03-01") + pd.to_timedelta(rng.integers(0, 40, n), unit="D")})   # many time ties
+    if string_ids:
+        df["user_id"] = "u" + df["user_id"].astype(str)
+        df["item_id"] = "i" + df["item_id"].astype(str)
+    ds = Dataset.construct(df)
+    klass = BERT4RecDataPreparator if bert else SASRecDataPreparator
+    kw = dict(session_max_len=7, batch_size=8, train_min_user_interactions=3)
+    if not bert:
+        kw["add_unix_ts"] = with_ts
+    fast, slow = klass(**kw), klass(**kw)
+    fast.process_dataset_train(ds)
+    assert fast._train_store is not None                   # the array path ran
+    monkeypatch.setenv("RT_PREP", "pandas")
+    slow.process_dataset_train(ds)
+    assert slow._train_store is None
+    assert list(fast.item_id_map.external_ids) == list(slow.item_id_map.external_ids)
+    assert list(fast.train_dataset.user_id_map.external_ids) == list(slow.train_dataset.user_id_map.external_ids)
+    assert fast.extra_token_ids == slow.extra_token_ids
+    pd.testing.assert_frame_equal(fast.train_dataset.interactions.df.reset_index(drop=True),
+                                  slow.train_dataset.interactions.df.reset_index(drop=True))
+    a, b = fast.train_store(), SequenceStore.from_interactions(slow.train_dataset.interactions.df)
+    for name in ("offsets", "items", "weights", "users"):
+        np.testing.assert_array_equal(getattr(a, name), getattr(b, name), err_msg=name)
+    if a.unix_ts is not None or b.unix_ts is not None:
+        np.testing.assert_array_equal(a.unix_ts, b.unix_ts)
+    assert fast.train_dataset.get_schema() == slow.train_dataset.get_schema()
