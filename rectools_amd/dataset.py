@@ -237,9 +237,21 @@ class Dataset:
         item features have no categorical columns (item_net.py:138-143): both are rejected here."""
         if kwargs.get("user_features_df") is not None or make_dense_item_features:
             raise NotImplementedError("user features / dense item features are outside the accelerated path (SURVEY.md §2.1)")
-        user_id_map = IdMap.from_values(interactions_df[Columns.User].values)
-        item_id_map = IdMap.from_values(interactions_df[Columns.Item].values)
-        interactions = Interactions.from_raw(interactions_df, user_id_map, item_id_map, keep_extra_cols)
+        # one factorize per id column gives the id map (distinct values in order of appearance, what IdMap.from_values
+        # keeps) AND the internal ids, instead of a unique pass followed by a hash-map lookup per row
+        u_codes, u_uniques = pd.factorize(interactions_df[Columns.User].values)
+        i_codes, i_uniques = pd.factorize(interactions_df[Columns.Item].values)
+        if (u_codes < 0).any() or (i_codes < 0).any():
+            raise ValueError("user / item ids must not be missing values")
+        user_id_map, item_id_map = IdMap(u_uniques), IdMap(i_uniques)
+        frame = {Columns.User: u_codes.astype(np.int64, copy=False), Columns.Item: i_codes.astype(np.int64, copy=False),
+                 Columns.Weight: interactions_df[Columns.Weight].astype(float).values,
+                 Columns.Datetime: pd.to_datetime(interactions_df[Columns.Datetime]).values}
+        if keep_extra_cols:
+            for c in interactions_df.columns:
+                if c not in Columns.Interactions:
+                    frame[c] = interactions_df[c].values
+        interactions = Interactions(pd.DataFrame(frame, copy=False))
         item_features = None
         if item_features_df is not None:
             id_col = Columns.Item if Columns.Item in item_features_df else "id"
