@@ -1,4 +1,5 @@
-"""Helpers of the transformer path that are part of the reference's public surface (`rectools/models/nn/transformers/utils.py`)."""
+"""Helpers of the transformer path that belong to the reference's public surface
+(`rectools/models/nn/transformers/utils.py`, `rectools/dataset/context.py`), restated on arrays."""
 from __future__ import annotations
 
 import typing as tp
@@ -12,28 +13,35 @@ from .dataset import Columns
 def leave_one_out_mask(interactions: pd.DataFrame, val_users: tp.Union[tp.Sequence[tp.Any], np.ndarray, int, None] = None) -> np.ndarray:
     """Validation mask for `get_val_mask_func`: True at each user's LAST interaction by time (utils.py:23-58).
 
-    Ties in time go to the row that comes last in the frame (rank method "first", ascending, then the maximum rank).
-    `val_users`: None = every user, an int = that many users drawn with `np.random.choice` without replacement (the
-    reference's RNG use), otherwise the explicit user ids."""
-    groups = interactions.groupby(Columns.User)
-    time_order = groups[Columns.Datetime].rank(method="first", ascending=True).astype(int)
-    n_interactions = groups[Columns.Datetime].transform("size").astype(int)
-    last = (n_interactions - time_order) == 0
+    Interactions that share the latest timestamp: the one that comes last in the frame is the target (the reference ranks
+    with method "first" and takes the maximum rank).  `val_users`: None = every user; an int = that many users drawn with
+    `np.random.choice(..., replace=False)` over the users in order of appearance (the reference's RNG use, so a seeded
+    run picks the same users); otherwise the explicit user ids."""
+    n = len(interactions)
+    user_col = interactions[Columns.User].values
+    by_time = np.argsort(interactions[Columns.Datetime].values, kind="stable")     # ties keep their frame order
+    codes, distinct = pd.factorize(user_col[by_time])
+    last_seen = np.full(len(distinct), -1, dtype=np.int64)
+    last_seen[codes] = np.arange(n)                  # repeated index: the last assignment stays = last row in time order
+    mask = np.zeros(n, dtype=bool)
+    mask[by_time[last_seen]] = True
+    if val_users is None:
+        return mask
     if isinstance(val_users, (int, np.integer)):
-        val_users = np.random.choice(interactions[Columns.User].unique(), size=int(val_users), replace=False)
-    elif val_users is None:
-        return last.values
-    return (interactions[Columns.User].isin(val_users) & last).values
+        val_users = np.random.choice(pd.unique(user_col), size=int(val_users), replace=False)
+    return mask & np.isin(user_col, np.asarray(val_users))
 
 
 def get_context(df: pd.DataFrame) -> pd.DataFrame:
-    """One row per user — the user's EARLIEST row by datetime — to be passed as `context` to `recommend()` of models that
-    need the time of the recommendation request (HSTU with relative time attention).  `rectools/dataset/context.py:22-51`:
-    a missing weight column becomes 1.0, datetimes are parsed, the item column is dropped."""
-    df = df.copy()
-    if Columns.Weight not in df.columns:
-        df[Columns.Weight] = 1.0
-    df[Columns.Weight] = df[Columns.Weight].astype(float)
-    df[Columns.Datetime] = pd.to_datetime(df[Columns.Datetime])
-    context = df.loc[df.groupby(Columns.User)[Columns.Datetime].idxmin()]
-    return context.drop(columns=[Columns.Item]) if Columns.Item in context else context
+    """One row per user — the user's EARLIEST row by datetime (the first such row on ties), users ascending — to be passed as
+    `context` to `recommend()` of models that rank "as of" a request time (HSTU with relative time attention).
+    `rectools/dataset/context.py:22-51`: a missing weight column becomes 1.0, the item column is not part of a context."""
+    out = df.drop(columns=[Columns.Item], errors="ignore").copy()
+    if Columns.Weight in out.columns:
+        out[Columns.Weight] = out[Columns.Weight].astype(float)
+    else:
+        out[Columns.Weight] = 1.0
+    out[Columns.Datetime] = pd.to_datetime(out[Columns.Datetime])
+    earliest_first = out.iloc[np.argsort(out[Columns.Datetime].values, kind="stable")]
+    first_rows = earliest_first[~earliest_first.duplicated(subset=Columns.User, keep="first")]
+    return first_rows.iloc[np.argsort(first_rows[Columns.User].values, kind="stable")]

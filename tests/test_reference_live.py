@@ -192,3 +192,23 @@ def test_ranker_oracle_matches_live_torch_ranker_on_random_inputs(seed):
         assert (ri == oi).mean() > 0.98
     else:
         assert ri.tolist() == oi.tolist()      # continuous random factors: no exact ties
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_utils_match_reference_on_random_frames(seed):
+    """`leave_one_out_mask` (with every kind of `val_users`, incl. the seeded np.random draw) and `get_context`."""
+    from rectools.dataset.context import get_context as ref_context
+    from rectools.models.nn.transformers.utils import leave_one_out_mask as ref_mask
+
+    from rectools_amd.utils import get_context, leave_one_out_mask
+
+    rng = np.random.default_rng(seed)
+    n = 500
+    df = pd.DataFrame({"user_id": rng.integers(0, 40, n), "item_id": rng.integers(0, 30, n), "weight": 1.0,
+                       "datetime": pd.to_datetime("2022-01-01") + pd.to_timedelta(rng.integers(0, 25, n), unit="D")})   # many ties
+    for val_users in (None, 7, list(rng.permutation(40)[:9])):
+        np.random.seed(seed); want = ref_mask(df, val_users)
+        np.random.seed(seed); got = leave_one_out_mask(df, val_users)
+        np.testing.assert_array_equal(got, want)
+    for frame in (df, df.drop(columns=["weight"]), df.drop(columns=["item_id"])):
+        pd.testing.assert_frame_equal(get_context(frame), ref_context(frame))
