@@ -47,3 +47,35 @@ if __name__ == "__main__":
     for kind in ("gauss", "trained-like"):
         for d in (64, 256, 512):
             run(n, d, 16, 10, kind)
+
+
+def append_form(n_items, d, n_users, k, prefix, kind, seed=0):
+    """Second form: how many items pass `coarse >= seeded bound - 2 eps` (the candidate buffer load per user) when the bound
+    is the k-th best coarse score of a catalog prefix (the threshold-seeding phase of the kernel)."""
+    rng = np.random.default_rng(seed)
+    if kind == "gauss":
+        items = rng.normal(size=(n_items, d)).astype(np.float32)
+        users = rng.normal(size=(n_users, d)).astype(np.float32)
+    else:
+        basis = rng.normal(size=(16, d)).astype(np.float32)
+        items = (rng.normal(size=(n_items, 16)).astype(np.float32) @ basis) * (0.2 + rng.pareto(3.0, (n_items, 1))).astype(np.float32)
+        items += 0.1 * rng.normal(size=(n_items, d)).astype(np.float32)
+        users = rng.normal(size=(n_users, 16)).astype(np.float32) @ basis
+    coarse = to_bf16(users) @ to_bf16(items).T
+    c = 2.0 ** -8 + 2.0 ** -18 + d * 2.0 ** -24
+    eps = c * np.linalg.norm(users, axis=1) * np.linalg.norm(items, axis=1).max()
+    seed_thr = np.sort(coarse[:, :prefix], axis=1)[:, -k]
+    final_thr = np.sort(coarse, axis=1)[:, -k]
+    upper = (coarse >= (seed_thr - 2 * eps)[:, None]).sum(1)     # if the bound never improved after seeding
+    lower = (coarse >= (final_thr - 2 * eps)[:, None]).sum(1)    # with the final bound from the start
+    eps_item = c * np.linalg.norm(users, axis=1)[:, None] * np.linalg.norm(items, axis=1)[None, :]     # per-item margin
+    upper_item = (coarse + 2 * eps_item >= seed_thr[:, None]).sum(1)
+    print(f"append {kind:12s} items={n_items} d={d} prefix={prefix}: candidates per user between {lower.mean():.0f} (final bound) and "
+          f"{upper.mean():.0f} mean / {upper.max()} max (seeded bound only, global-norm margin); per-item margin with the seeded bound: "
+          f"{upper_item.mean():.0f} mean / {upper_item.max()} max")
+
+
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "append":
+    for kind in ("gauss", "trained-like"):
+        for d in (64, 512):
+            append_form(n, d, 8, 10, max(n // 76, 1000), kind)      # 65 k of 5 M = 1/76 of the catalog seeds the bound
