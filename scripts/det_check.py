@@ -1,5 +1,5 @@
 import sys; sys.path.insert(0,'.'); sys.path.insert(0,'tests')
-import numpy as np, torch
+import torch
 from test_models_gpu import interactions
 from rectools_amd.dataset import Dataset
 from rectools_amd.models import SASRecModel

@@ -1,7 +1,7 @@
 """End-to-end SASRecModel.fit() throughput (host collate + H2D + step) vs the resident-batch step loop of bench.py."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, pandas as pd, torch
+import pandas as pd, torch
 from rectools_amd import synth
 from rectools_amd.dataset import Dataset, Columns
 from rectools_amd.models import SASRecModel

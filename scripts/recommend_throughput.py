@@ -1,7 +1,7 @@
 """End-to-end SASRecModel.recommend() (dataset transform + encode + rank + frame) for all users of a synthetic dataset."""
 import os, sys, time, cProfile, pstats, io
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, pandas as pd, torch
+import pandas as pd, torch
 from rectools_amd import synth
 from rectools_amd.dataset import Dataset, Columns
 from rectools_amd.models import SASRecModel

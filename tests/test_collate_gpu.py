@@ -56,7 +56,6 @@ def test_sasrec_device_collates_equal_host(L, with_ts):
 @pytest.mark.parametrize("L,mask_prob", [(6, 0.5), (50, 0.15), (200, 0.3)])
 def test_bert4rec_device_collates_equal_host_given_the_draws(L, mask_prob):
     from rectools_amd import data_preparator as dpm
-    from rectools_amd import ops
 
     store = _store(200, L, 500, seed=10 + L, with_ts=False)    # BERT4Rec train sessions hold at most L items
     dp = _prep(dpm.BERT4RecDataPreparator, L, mask_prob=mask_prob)

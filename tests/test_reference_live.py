@@ -1,7 +1,6 @@
 """Live cross-checks against the UNMODIFIED reference, run only where `/root/reference` exists (the build container; the
 GPU box has no reference tree, so everything here is CPU-only and skipped there).  The committed golden vectors pin fixed
 cases; these tests fuzz the host path against the reference itself on random inputs."""
-import types
 
 import numpy as np
 import pandas as pd
