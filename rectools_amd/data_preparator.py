@@ -44,8 +44,8 @@ class SequenceStore:
         if sort_users:
             order = np.argsort(users, kind="stable")
         else:
-            first_pos = pd.Series(np.arange(len(users))).groupby(users, sort=False).transform("min").values
-            order = np.argsort(first_pos, kind="stable")
+            codes, _ = pd.factorize(users)                   # codes count users in order of first appearance
+            order = np.argsort(codes, kind="stable")
         users = users[order]
         items = d[Columns.Item].values[order].astype(np.int64)
         weights = d[Columns.Weight].values[order].astype(np.float32)
