@@ -181,8 +181,8 @@ class TransformerDataPreparatorBase:
 
     # ---- array fast path of process_dataset_train ------------------------------------------------------
     def _fast_path_applies(self, dataset: tp.Any) -> bool:
-        if self.get_val_mask_func is not None or (self.extra_cols or []) or os.environ.get("RT_PREP", "arrays") == "pandas":
-            return False   # a validation mask is a user callable over the raw frame; extra columns ride along in pandas
+        if (self.extra_cols or []) or os.environ.get("RT_PREP", "arrays") == "pandas":
+            return False   # extra interaction columns ride along in pandas
         df = getattr(getattr(dataset, "interactions", None), "df", None)
         if df is None or len(df) == 0:
             return False
@@ -201,7 +201,7 @@ class TransformerDataPreparatorBase:
         lookup[uniq] = torch.arange(uniq.numel(), dtype=torch.int64, device=x.device)
         return uniq, lookup
 
-    def _process_dataset_train_arrays(self, dataset: tp.Any) -> None:
+    def _process_dataset_train_arrays(self, dataset: tp.Any, train_rows: tp.Optional[np.ndarray] = None) -> None:
         """The same result as the frame-based path below (data_preparator.py:214-284), computed with sorts / scans over the
         interaction columns instead of pandas groupby: at ML-20M scale the frame path costs several epochs of GPU training.
         Works on the dataset's INTERNAL ids (integers whatever the external id type) and translates only the distinct ids.
@@ -215,8 +215,13 @@ class TransformerDataPreparatorBase:
         t = as_t(t_ns)
         n_src_users, n_src_items = int(u.max()) + 1, int(it.max()) + 1
         # users with enough interactions (value_counts over ALL their interactions)
-        cnt = torch.bincount(u, minlength=n_src_users)
-        idx0 = torch.nonzero(cnt[u] >= self.train_min_user_interactions).reshape(-1)
+        if train_rows is not None:      # validation targets are taken out first (data_preparator.py:236-242)
+            src = as_t(np.flatnonzero(train_rows))
+            cnt = torch.bincount(u[src], minlength=n_src_users)
+            idx0 = src[cnt[u[src]] >= self.train_min_user_interactions]
+        else:
+            cnt = torch.bincount(u, minlength=n_src_users)
+            idx0 = torch.nonzero(cnt[u] >= self.train_min_user_interactions).reshape(-1)
         # stable sort by time, then the last (L + addition) rows of every user — in time order, as groupby(...).tail keeps them
         rows_time = idx0[torch.sort(t[idx0], stable=True).indices]
         u1 = u[rows_time]
@@ -260,11 +265,33 @@ class TransformerDataPreparatorBase:
                                           frame[Columns.Weight][o3].astype(np.float32),
                                           frame["unix_ts"][o3].astype(np.int64) if self.add_unix_ts else None, users_sorted[change])
 
+    def _process_with_val_mask_arrays(self, dataset: tp.Any) -> None:
+        """Validation mask (a user callable over the RAW frame, so that frame is still produced) + the array path for the
+        training rows; the validation sessions are cut from the processed training frame (data_preparator.py:236-284)."""
+        raw = dataset.get_raw_interactions()
+        val_mask = np.asarray(self.get_val_mask_func(raw, **self.get_val_mask_func_kwargs), dtype=bool)
+        self._process_dataset_train_arrays(dataset, train_rows=~val_mask)
+        user_id_map, item_id_map = self.train_dataset.user_id_map, self.item_id_map
+        val_targets = raw[val_mask]
+        if self.add_unix_ts:
+            val_targets = val_targets.assign(unix_ts=self._to_unix_ts(val_targets[Columns.Datetime]))
+        val_targets = val_targets[val_targets[Columns.User].isin(user_id_map.external_ids)
+                                  & val_targets[Columns.Item].isin(item_id_map.external_ids)]
+        train_df = self.train_dataset.interactions.df
+        val_users = user_id_map.convert_to_internal(val_targets[Columns.User].unique())
+        history = train_df[np.isin(train_df[Columns.User].values, val_users)].copy()
+        history[Columns.Weight] = 0.0
+        targets = Interactions.from_raw(val_targets, user_id_map, item_id_map, keep_extra_cols=True).df
+        self.val_interactions = pd.concat([history, targets[history.columns]], axis=0).reset_index(drop=True)
+
     def process_dataset_train(self, dataset: tp.Any) -> None:
         """data_preparator.py:229-284 — PAD (and MASK) first in the item id map so that PAD == 0."""
         self._train_store = None
         if dataset is not None and self._fast_path_applies(dataset):
-            self._process_dataset_train_arrays(dataset)
+            if self.get_val_mask_func is None:
+                self._process_dataset_train_arrays(dataset)
+            else:
+                self._process_with_val_mask_arrays(dataset)
             return
         raw = dataset.get_raw_interactions()
         if self.add_unix_ts:

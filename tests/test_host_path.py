@@ -496,8 +496,11 @@ def test_get_context_takes_each_users_earliest_row():
     assert ctx["datetime"].tolist() == list(pd.to_datetime(["2021-12-10", "2021-12-11", "2021-12-13"])) and ctx["weight"].tolist() == [1.0] * 3
 
 
-@pytest.mark.parametrize("seed,string_ids,with_ts,bert", [(0, False, False, False), (1, True, True, False), (2, False, True, True), (3, True, False, True)])
-def test_array_fast_path_equals_frame_path(seed, string_ids, with_ts, bert, monkeypatch):
+@pytest.mark.parametrize("seed,string_ids,with_ts,bert,val", [(0, False, False, False, False), (1, True, True, False, False),
+                                                              (2, False, True, True, False), (3, True, False, True, False),
+                                                              (4, False, True, False, True), (5, True, False, True, True),
+                                                              (6, False, False, False, True)])
+def test_array_fast_path_equals_frame_path(seed, string_ids, with_ts, bert, val, monkeypatch):
     """process_dataset_train computed with sorts / scans over the interaction columns must give exactly what the frame
     (pandas groupby) path gives: id maps, the interactions frame row for row, and the session store — with ties in time,
     users below the interaction minimum, sessions longer than the window, string external ids."""
@@ -518,6 +521,10 @@ def test_array_fast_path_equals_frame_path(seed, string_ids, with_ts, bert, monk
     kw = dict(session_max_len=7, batch_size=8, train_min_user_interactions=3)
     if not bert:
         kw["add_unix_ts"] = with_ts
+    if val:     # leave-one-out targets for a subset of the users (some of them dropped from training, some unknown items)
+        from rectools_amd.utils import leave_one_out_mask
+
+        kw.update(get_val_mask_func=leave_one_out_mask, get_val_mask_func_kwargs={"val_users": list(pd.unique(df["user_id"])[::3])})
     fast, slow = klass(**kw), klass(**kw)
     fast.process_dataset_train(ds)
     assert fast._train_store is not None                   # the array path ran
@@ -535,3 +542,8 @@ def test_array_fast_path_equals_frame_path(seed, string_ids, with_ts, bert, monk
     if a.unix_ts is not None or b.unix_ts is not None:
         np.testing.assert_array_equal(a.unix_ts, b.unix_ts)
     assert fast.train_dataset.get_schema() == slow.train_dataset.get_schema()
+    if val:
+        assert fast.val_interactions is not None and len(fast.val_interactions) > 0
+        pd.testing.assert_frame_equal(fast.val_interactions.reset_index(drop=True), slow.val_interactions.reset_index(drop=True))
+    else:
+        assert fast.val_interactions is None and slow.val_interactions is None
