@@ -58,3 +58,12 @@ def test_product_fails_loudly_without_gpu():
         HipRanker("dot", "cpu", np.zeros((1, 4), np.float32), np.zeros((2, 4), np.float32))
     with pytest.raises(_lib.HipLibraryError):
         HipRanker("dot", "cuda", np.zeros((1, 4), np.float32), np.zeros((2, 4), np.float32))
+
+
+def test_docs_quote_the_current_entry_point_count():
+    """DESIGN.md / INTEGRATION.md / README.md state how many C entry points the library has: keep them honest."""
+    n = len(_declared_symbols())
+    for name, pattern in (("DESIGN.md", r"\((\d+) `extern \"C\"` entry points"), ("INTEGRATION.md", r"\((\d+) `extern \"C\"` functions"),
+                          ("README.md", r"\((\d+) C entry points\)")):
+        m = re.search(pattern, open(os.path.join(ROOT, name)).read())
+        assert m and int(m.group(1)) == n, f"{name} quotes {m.group(1) if m else None} entry points, the header declares {n}"
