@@ -137,6 +137,12 @@ int rt_collate(const int64_t* offsets, const int64_t* items, const float* weight
                int32_t B, int32_t L, int32_t mode, const float* probs, const int64_t* rand_ids, float mask_prob,
                int64_t mask_id, int64_t* x, int64_t* y, float* yw, int64_t* ts_out, rt_stream_t stream);
 
+/* a11  uniform negatives on the device — CatalogUniformSampler.get_negatives (negative_sampler.py:58-73):
+ * out[e] uniform over item ids [low, high), e < n (the [B, L | 1, N] tensor, flat), no rejection of positives.
+ * Philox4x32-10 keyed by (seed, offset): the same pair always yields the same batch; pass the step counter as `offset`.
+ * `out` 16-byte aligned. */
+int rt_sample_negatives(int64_t low, int64_t high, int64_t n, uint64_t seed, uint64_t offset, int64_t* out, rt_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K1b item-row producer for feature-aware item nets.
  *   table[i,:] = ids_emb[i,:] + dropout( sum_j cat_emb[emb_bag_inputs[offsets[i] + j], :] ),  j < input_lengths[i]

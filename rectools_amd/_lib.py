@@ -36,6 +36,7 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_gemm": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_sz, c_vp]),
     "rt_colsum": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "rt_collate": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_f32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "rt_sample_negatives": (c_i32, [c_i64, c_i64, c_i64, c_u64, c_u64, c_vp, c_vp]),
     "rt_bag_sum_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_u64, c_u64, c_vp, c_vp]),
     "rt_bag_sum_bwd_workspace_bytes": (c_sz, [c_i64, c_i32]),
     "rt_bag_sum_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_f32, c_u64, c_u64, c_vp, c_vp, c_sz, c_vp]),

@@ -49,7 +49,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB_PATH  # prebuilt library matches the sources (the case on the GPU box)
     os.makedirs(OBJ_DIR, exist_ok=True)
     objs = []
-    relink = force or not os.path.exists(LIB_PATH)
+    relink = True   # we only get here when the library is missing or its digest differs (e.g. a source was removed)
     procs = []
     for src in _sources():
         base = os.path.splitext(os.path.basename(src))[0]

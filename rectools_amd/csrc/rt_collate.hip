@@ -80,9 +80,46 @@ __global__ __launch_bounds__(256) void collate_kernel(CollateArgs a) {
   }
 }
 
+// a11 — CatalogUniformSampler.get_negatives (negative_sampler.py:58-73): n ids uniform in [low, high), no rejection of
+// positives.  Counter-based (Philox4x32-10): element e is word (e & 3) of philox(seed, subsequence = e >> 2, offset), so a
+// batch is a pure function of (seed, offset) — reproducible whatever the launch geometry — and `offset` (the step counter)
+// gives every batch a fresh stream.  A 32-bit word r maps to low + floor(r * range / 2^32) (bias <= range / 2^32, against
+// the reference's `random() % range`, which is biased the same way).
+__global__ __launch_bounds__(256) void sample_negatives_kernel(long long low, unsigned range, long long n4, long long n,
+                                                                unsigned long long seed, unsigned long long offset,
+                                                                long long* __restrict__ out) {
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long long)gridDim.x * 256) {
+    const uint4 r = philox4x32(seed, (unsigned long long)q, offset);
+    long long v[4];
+    v[0] = low + (long long)__umulhi(r.x, range); v[1] = low + (long long)__umulhi(r.y, range);
+    v[2] = low + (long long)__umulhi(r.z, range); v[3] = low + (long long)__umulhi(r.w, range);
+    const long long e = 4 * q;
+    if (e + 3 < n) {   // out is 16-byte aligned (checked by the entry point) and e = 4q: both stores are aligned
+      *reinterpret_cast<longlong2*>(out + e) = make_longlong2(v[0], v[1]);
+      *reinterpret_cast<longlong2*>(out + e + 2) = make_longlong2(v[2], v[3]);
+    } else {
+      for (int j = 0; j < 4 && e + j < n; ++j) out[e + j] = v[j];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int rt_sample_negatives(int64_t low, int64_t high, int64_t n, uint64_t seed, uint64_t offset, int64_t* out, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (n < 0 || high <= low || high - low > 0xFFFFFFFFLL) return RT_ERR_INVALID_ARG;
+  if (n == 0) return RT_OK;
+  if (out == nullptr || ((uintptr_t)out & 15) != 0) return RT_ERR_INVALID_ARG;
+  const long long n4 = (n + 3) / 4;
+  long long blocks = (n4 + 255) / 256;
+  if (blocks > 16 * rt_num_cus()) blocks = 16 * rt_num_cus();
+  sample_negatives_kernel<<<(int)blocks, 256, 0, stream>>>(low, (unsigned)(high - low), n4, n, seed, offset,
+                                                            reinterpret_cast<long long*>(out));
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
 
 // mode: 0 SASRec train, 1 SASRec recommend, 2 SASRec recommend with timestamps (last row = context), 3 BERT4Rec train,
 // 4 BERT4Rec recommend.  Unused outputs / inputs may be NULL (y, yw outside the train modes; ts_out / unix_ts without

@@ -785,10 +785,11 @@ int rt_adam_step_segments(float* p, float* m, float* v, int32_t n_seg, const int
   if (n_seg < 0 || step < 1) return RT_ERR_INVALID_ARG;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  for (int s0 = 0; s0 < n_seg; s0 += ADAM_SEGS) {
+  for (int s0 = 0; s0 < n_seg;) {   // s0 resumes where the previous launch stopped (skipped segments do not count)
     AdamSegs sg{};
     int chunks = 0, k = 0;
-    for (int s = s0; s < n_seg && k < ADAM_SEGS; ++s) {
+    int s = s0;
+    for (; s < n_seg && k < ADAM_SEGS; ++s) {
       if ((offsets[s] & 3) != 0 || lens[s] < 0) return RT_ERR_INVALID_ARG;
       if (lens[s] == 0 || grads[s] == nullptr) continue;
       sg.grad[k] = grads[s]; sg.ofs4[k] = offsets[s] / 4; sg.len[k] = lens[s];
@@ -797,6 +798,7 @@ int rt_adam_step_segments(float* p, float* m, float* v, int32_t n_seg, const int
       ++k;
     }
     sg.first_chunk[k] = chunks; sg.n = k;
+    s0 = s;
     if (k == 0) continue;
     adam_segs_kernel<<<chunks, 256, 0, stream>>>(p, m, v, sg, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, grad_scale);
     RT_CHECK_LAUNCH();

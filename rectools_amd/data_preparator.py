@@ -117,18 +117,42 @@ def _tail_layout(lengths: np.ndarray, keep: int) -> tp.Tuple[np.ndarray, np.ndar
     return rows, pos, kept
 
 
-class CatalogUniformSampler:
-    """Negatives drawn uniformly from the real items, without rejecting positives (negative_sampler.py:49-73).  The draw
-    happens on the device the batch lives on (the reference draws on the host inside its collate function)."""
+class TransformerNegativeSamplerBase:
+    """Plug-in seam of the reference (negative_sampler.py:23-46): subclass and pass as `negative_sampler_type`."""
 
     def __init__(self, n_negatives: int, **kwargs: tp.Any) -> None:
         self.n_negatives = n_negatives
 
     def get_negatives(self, batch_dict: tp.Dict[str, torch.Tensor], lowest_id: int, highest_id: int,
                       session_len_limit: tp.Optional[int] = None, **kwargs: tp.Any) -> torch.Tensor:
+        raise NotImplementedError()
+
+
+class CatalogUniformSampler(TransformerNegativeSamplerBase):
+    """Negatives drawn uniformly from the real items [lowest_id, highest_id), without rejecting positives
+    (negative_sampler.py:49-73).  The reference draws with `torch.randint` on the host inside its collate function and
+    ships 26 MB per C2 batch over PCIe; here `rt_sample_negatives` (Philox4x32-10, csrc/rt_collate.hip) fills the
+    [B, L | 1, N] tensor on the device the batch lives on.  Batch number c of a sampler seeded s is a pure function of
+    (s, c): reproducible, and different for every batch.  Parity with the reference is distributional (it resamples every
+    batch from torch's global generator)."""
+
+    def __init__(self, n_negatives: int, seed: int = 0, **kwargs: tp.Any) -> None:
+        super().__init__(n_negatives)
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.calls = 0
+
+    def get_negatives(self, batch_dict: tp.Dict[str, torch.Tensor], lowest_id: int, highest_id: int,
+                      session_len_limit: tp.Optional[int] = None, **kwargs: tp.Any) -> torch.Tensor:
+        from . import _lib, ops
+
         x = batch_dict["x"]
+        if not x.is_cuda:
+            raise _lib.HipLibraryError("CatalogUniformSampler draws on the HIP device of the batch (no CPU fallback)")
         session_len = session_len_limit if session_len_limit is not None else x.shape[1]
-        return torch.randint(lowest_id, highest_id, (x.shape[0], session_len, self.n_negatives), device=x.device)
+        out = torch.empty((x.shape[0], session_len, self.n_negatives), dtype=torch.int64, device=x.device)
+        self.calls += 1
+        ops._c("rt_sample_negatives", int(lowest_id), int(highest_id), out.numel(), self.seed, self.calls, out)
+        return out
 
 
 class TransformerDataPreparatorBase:
@@ -383,9 +407,14 @@ class TransformerDataPreparatorBase:
         return Dataset(dataset.user_id_map, self.item_id_map, Interactions.from_raw(raw, dataset.user_id_map, self.item_id_map, True))
 
     # ---- batches ----------------------------------------------------------------------------------------
-    def sample_negatives(self, shape: tp.Tuple[int, ...], device: tp.Any, generator: tp.Optional[torch.Generator] = None) -> torch.Tensor:
-        """CatalogUniformSampler.get_negatives (negative_sampler.py:58-73): uniform over real items, no rejection."""
-        return torch.randint(self.n_item_extra_tokens, self.item_id_map.size, shape, device=device, generator=generator)
+    def add_negatives(self, batch: tp.Dict[str, torch.Tensor], validation: bool = False) -> tp.Dict[str, torch.Tensor]:
+        """What the reference's collates do after building x / y / yw (sasrec.py:99-103,141-146; bert4rec.py:150-156,
+        175-181): `negatives` [B, L, N] for a training batch, [B, 1, N] for a validation batch, from the plugged sampler."""
+        if self.negative_sampler is not None:
+            batch["negatives"] = self.negative_sampler.get_negatives(
+                batch, lowest_id=self.n_item_extra_tokens, highest_id=self.item_id_map.size,
+                session_len_limit=1 if validation else None)
+        return batch
 
     def collate_train(self, store: SequenceStore, idx: np.ndarray) -> tp.Dict[str, np.ndarray]:
         raise NotImplementedError()

@@ -24,8 +24,9 @@ from . import checkpoint as ckpt
 from . import lightning as hl
 from . import nn as hnn
 from . import ops
-from .data_preparator import (BERT4RecDataPreparator, DeviceSequenceStore, SASRecDataPreparator, SequenceStore,
-                              TransformerDataPreparatorBase, epoch_permutation, shard_indices)
+from .data_preparator import (BERT4RecDataPreparator, CatalogUniformSampler, DeviceSequenceStore, SASRecDataPreparator,
+                              SequenceStore, TransformerDataPreparatorBase, TransformerNegativeSamplerBase, epoch_permutation,
+                              shard_indices)
 from .dataset import Columns
 from .rank import DeviceCSR, Distance, HipRanker
 
@@ -86,6 +87,8 @@ class TransformerModelBase:
         data_preparator_kwargs: tp.Optional[dict] = None, transformer_layers_kwargs: tp.Optional[dict] = None,
         pos_encoding_kwargs: tp.Optional[dict] = None, lightning_module_kwargs: tp.Optional[dict] = None,
         similarity_module_kwargs: tp.Optional[dict] = None, seed: tp.Optional[int] = None,
+        negative_sampler_type: tp.Type[TransformerNegativeSamplerBase] = CatalogUniformSampler,
+        negative_sampler_kwargs: tp.Optional[dict] = None,
         **kwargs: tp.Any,
     ) -> None:
         self._params = dict(
@@ -101,6 +104,7 @@ class TransformerModelBase:
             data_preparator_type=data_preparator_type, transformer_layers_type=transformer_layers_type,
             similarity_module_type=similarity_module_type, item_net_block_types=tuple(item_net_block_types),
             item_net_constructor_type=item_net_constructor_type, item_net_constructor_kwargs=item_net_constructor_kwargs,
+            negative_sampler_type=negative_sampler_type, negative_sampler_kwargs=negative_sampler_kwargs,
         )
         self._params.update(kwargs)
         for k, v in self._params.items():
@@ -127,11 +131,21 @@ class TransformerModelBase:
     def _kw(self, d: tp.Optional[dict]) -> dict:
         return dict(d) if d else {}
 
+    def _init_negative_sampler(self) -> TransformerNegativeSamplerBase:
+        """transformers/base.py:382-386.  The stock sampler is seeded from the model seed (and the rank, so that
+        data-parallel replicas draw different negatives, as the reference's per-process generators do)."""
+        kw = self._kw(self.negative_sampler_kwargs)
+        if self.negative_sampler_type is CatalogUniformSampler and "seed" not in kw:
+            kw["seed"] = (0 if self.seed is None else int(self.seed)) * 1000003 + _dist_info()[0]
+        return self.negative_sampler_type(n_negatives=self.n_negatives, **kw)
+
     def _init_data_preparator(self) -> None:
+        requires_negatives = bool(hl.requires_negatives(self.loss))
         self.data_preparator = self.data_preparator_type(
             session_max_len=self.session_max_len, batch_size=self.batch_size, dataloader_num_workers=self.dataloader_num_workers,
             train_min_user_interactions=self.train_min_user_interactions,
-            n_negatives=self.n_negatives if hl.requires_negatives(self.loss) else None,
+            n_negatives=self.n_negatives if requires_negatives else None,
+            negative_sampler=self._init_negative_sampler() if requires_negatives else None,
             get_val_mask_func=self.get_val_mask_func, get_val_mask_func_kwargs=self.get_val_mask_func_kwargs,
             **self._kw(self.data_preparator_kwargs),
         )
@@ -212,15 +226,9 @@ class TransformerModelBase:
         return False
 
     # ---- training -----------------------------------------------------------------------------------------
-    def _to_device(self, batch: tp.Dict[str, np.ndarray], device: torch.device, train: bool) -> tp.Dict[str, torch.Tensor]:
-        return self._add_negatives({k: torch.from_numpy(v).to(device, non_blocking=True) for k, v in batch.items()}, device)
-
-    def _add_negatives(self, out: tp.Dict[str, torch.Tensor], device: torch.device) -> tp.Dict[str, torch.Tensor]:
-        if hl.requires_negatives(self.loss) and "y" in out:
-            B = out["x"].shape[0]
-            shape = (B, self.session_max_len if out["y"].shape[1] > 1 else 1, self.n_negatives)
-            out["negatives"] = self.data_preparator.sample_negatives(shape, device)
-        return out
+    def _to_device(self, batch: tp.Dict[str, np.ndarray], device: torch.device, validation: bool) -> tp.Dict[str, torch.Tensor]:
+        out = {k: torch.from_numpy(v).to(device, non_blocking=True) for k, v in batch.items()}
+        return self.data_preparator.add_negatives(out, validation=validation)
 
     def _run_epochs(self, first: int, last: int) -> None:
         lm, opt, dp = self.lightning_model, self.optimizer, self.data_preparator
@@ -239,7 +247,7 @@ class TransformerModelBase:
             total = torch.zeros((), device=device)
             n_batches = 0
             for b0 in range(0, len(mine), self.batch_size):
-                batch = self._add_negatives(dp.collate_train_device(dstore, mine_t[b0:b0 + self.batch_size]), device)
+                batch = dp.add_negatives(dp.collate_train_device(dstore, mine_t[b0:b0 + self.batch_size]))
                 ops.RNG.next_step()
                 opt.zero_grad()
                 loss = lm.training_loss(batch)
@@ -253,7 +261,7 @@ class TransformerModelBase:
                 vt, vn = torch.zeros((), device=device), 0
                 with torch.no_grad():
                     for b0 in range(0, len(val_store), self.batch_size):
-                        vb = self._to_device(dp.collate_val(val_store, np.arange(b0, min(b0 + self.batch_size, len(val_store)))), device, False)
+                        vb = self._to_device(dp.collate_val(val_store, np.arange(b0, min(b0 + self.batch_size, len(val_store)))), device, True)
                         vt += lm.validation_loss(vb)
                         vn += 1
                 rec[self.val_loss_name] = float(vt) / max(vn, 1)
@@ -531,7 +539,7 @@ class TransformerModelBase:
         cfg = dict(config)
         klass = _import_object(cfg.pop("cls", cls))
         for key in ("data_preparator_type", "transformer_layers_type", "similarity_module_type", "get_val_mask_func",
-                    "item_net_constructor_type"):
+                    "item_net_constructor_type", "negative_sampler_type"):
             if cfg.get(key) is not None:
                 cfg[key] = _import_object(cfg[key])
         if cfg.get("item_net_block_types") is not None:

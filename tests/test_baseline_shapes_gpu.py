@@ -1,0 +1,221 @@
+"""GPU parity at the shapes BASELINE.json quotes its numbers on (the bench's own launch geometries), against the oracle.
+
+The per-kernel / golden tests run small shapes; the heavy-row reducers of the sampled loss, the streaming attention
+family at L = 512, the d = 512 ring depth of the top-k kernel and the d = 512 LiGR block only engage at the sizes below:
+  * C2  SASRec d256 L200, sampled_softmax N=128 over V=26,744 items, Zipf-popular targets (B = 32 sequences)
+  * C4  HSTU L=512, hd=64, H=4: relative-bias attention (streaming family) and one full STU training step
+  * C5  eSASRec: LiGR (SwiGLU) block at d=512; `rt_topk_score` at d=512 on a 300k-row catalog, filter + whitelist,
+        every users-per-pass tile (16 / 32 / 64 / 128)
+Tolerances as in the small-shape tests (fp32, different summation orders); top-k ids/order must be IDENTICAL.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+from scipy import sparse
+
+from oracle import ranker_oracle
+from oracle import transformer_oracle as T
+from test_ops_gpu import close, grads_of, rnd
+from test_rank_gpu import CASES as RANK_CASES
+from test_transformer_gpu import _close, _random_case, build_hip_model
+
+pytestmark = pytest.mark.gpu
+
+
+def _zipf_ids(shape, V, gen, alpha=1.0):
+    """Item ids in [1, V] with Zipf(alpha) popularity over a fixed random permutation (SURVEY.md §8d inputs)."""
+    p = 1.0 / torch.arange(1, V + 1, dtype=torch.float64) ** alpha
+    perm = torch.randperm(V, generator=gen) + 1
+    n = int(np.prod(shape))
+    return perm[torch.multinomial(p / p.sum(), n, replacement=True, generator=gen)].reshape(shape)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# C5: top-k at d = 512 (ring depth / stage geometry of the 5M x 512 run), every user tile
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("upp", [16, 32, 64, 128])
+@pytest.mark.parametrize("distance", ["dot", "cosine"])
+def test_topk_d512_300k_filter_whitelist_vs_oracle(distance, upp):
+    from rectools_amd.rank import HipRanker
+
+    g = torch.Generator().manual_seed(21)
+    n_items, d, n_users = 300_000, 512, 150
+    users = torch.randn(n_users, d, generator=g).numpy()
+    items = torch.randn(n_items, d, generator=g).numpy()
+    rs = np.random.RandomState(5)
+    wl = np.sort(rs.choice(n_items, size=n_items - 4321, replace=False))
+    filt = sparse.random(n_users, n_items, density=0.0004, format="csr", random_state=rs, data_rvs=lambda n: np.ones(n))
+    sids = np.arange(n_users)
+    ranker = HipRanker(distance, "cuda", users, items, batch_size=upp)
+    gu, gi, gs = ranker.rank(sids, k=10, filter_pairs_csr=filt, sorted_object_whitelist=wl)
+    eu, ei, es = ranker_oracle.rank(users, items, sids, k=10, filter_pairs_csr=filt, sorted_object_whitelist=wl, distance=distance)
+    np.testing.assert_array_equal(gu, eu)
+    np.testing.assert_array_equal(gi, ei)          # identical ids AND order (Gaussian factors: tie-free)
+    np.testing.assert_allclose(gs, es, rtol=5e-5, atol=5e-5)
+
+
+def test_topk_users_per_launch_16_equals_32():
+    """The 16-user tile (HBM-bound regime of the 5M x 512 run) against the 32-user tile: identical ids and order; scores
+    equal to fp32 rounding (the two MFMA shapes associate the k products differently)."""
+    from rectools_amd.rank import HipRanker
+
+    g = torch.Generator(device="cuda").manual_seed(3)
+    items = torch.randn(200_000, 512, generator=g, device="cuda")
+    users = torch.randn(16, 512, generator=g, device="cuda")
+    a = HipRanker("dot", "cuda", users, items, batch_size=16).rank_device(np.arange(16), k=10)
+    b = HipRanker("dot", "cuda", users, items, batch_size=32).rank_device(np.arange(16), k=10)
+    assert torch.equal(a[0], b[0])
+    torch.testing.assert_close(a[1], b[1], rtol=2e-6, atol=2e-5)
+
+
+def test_reference_kats_need_no_near_tie_swaps():
+    """The 52 reference cases must come back in the reference's order without using the near-tie allowance of
+    `_assert_same_ranking`, except where the reference's own scores are EXACTLY tied (torch.topk leaves that order open)."""
+    from rectools_amd.rank import HipRanker
+
+    swaps = []
+    for case in RANK_CASES:
+        ranker = HipRanker(case["distance"], "cuda", case["users"], case["items"])
+        gu, gi, gs = ranker.rank(case["sids"], k=case["k"], filter_pairs_csr=case["filt"], sorted_object_whitelist=case["wl"])
+        ei, es, eu = case["ref_items"], case["ref_scores"], case["ref_subjects"]
+        for j in np.nonzero(gi != ei)[0]:
+            cand = np.nonzero((eu == eu[j]) & (ei == gi[j]))[0]
+            exact_tie = cand.size == 1 and es[cand[0]] == es[j]
+            if not exact_tie:
+                swaps.append((case["tag"], int(j)))
+    assert not swaps, f"order differs from the reference outside exact ties: {swaps[:10]}"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# C4: HSTU at L = 512, hd = 64, H = 4 (streaming attention family)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_hstu_attention_L512_hd64():
+    from rectools_amd import ops
+
+    B, L, d, H = 2, 512, 256, 4
+    hd = d // H
+    g = torch.Generator().manual_seed(L)
+    ids = torch.randint(1, 50, (B, L), generator=g); ids[0, : L // 4] = 0
+    ts = torch.cumsum(torch.randint(0, 3_000_000, (B, L + 1), generator=g), 1) + 1_300_000_000
+    q, k, v = rnd(B * L, d, seed=1) * 0.5, rnd(B * L, d, seed=2) * 0.5, rnd(B * L, d, seed=3)
+    tw, pw = rnd(129, seed=4) * 0.5, rnd(2 * L - 1, seed=5) * 0.5
+    m = (ids != 0).float()
+
+    def ref_fn(q, k, v, tw, pw):
+        rab = T.rel_attn_bias({"x.time_weights": tw, "x.pos_weights": pw}, "x.", {"x": ids, "unix_ts": ts}, L)
+        qh, kh, vh = (t.view(B, L, H, hd) for t in (q, k, v))
+        a = F.silu(torch.einsum("bnhd,bmhd->bhnm", qh, kh) + rab[:, None]) / L
+        a = a * torch.tril(torch.ones(L, L))[None, None] * (m[:, None, :, None] * m[:, None, None, :])
+        return torch.einsum("bhnm,bmhd->bnhd", a, vh).reshape(B * L, d)
+
+    ref, gref = grads_of(ref_fn, [q, k, v, tw, pw])
+    thr = ops.hstu_time_thresholds().cuda()
+    got, ggot = grads_of(lambda q, k, v, tw, pw: ops.hstu_attn(q, k, v, tw, pw, ids.cuda(), ts.cuda(), thr, B, H, L),
+                         [t.cuda() for t in (q, k, v, tw, pw)])
+    close(got, ref, rtol=5e-4, atol_rel=5e-5, msg="hstu fwd")
+    for i, n in enumerate(("dq", "dk", "dv", "dtw", "dpw")):
+        close(ggot[i], gref[i], rtol=2e-3, atol_rel=2e-4, msg=f"hstu {n}")
+
+
+def test_softmax_attention_L512_hd64():
+    """The softmax family on the same streaming geometry (SASRec / BERT4Rec with session_max_len = 512)."""
+    from rectools_amd import ops
+
+    B, L, d, H = 2, 512, 256, 4
+    hd = d // H
+    ids = torch.randint(1, 50, (B, L), generator=torch.Generator().manual_seed(7)); ids[1, : L // 3] = 0
+    q, k, v = rnd(B * L, d, seed=1), rnd(B * L, d, seed=2), rnd(B * L, d, seed=3)
+    mask = T.attention_mask(ids, True, True)
+
+    def ref_fn(q, k, v):
+        qh, kh, vh = (t.view(B, L, H, hd).transpose(1, 2) for t in (q, k, v))
+        s = qh @ kh.transpose(-1, -2) / math.sqrt(hd) + mask[:, None]
+        return (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B * L, d)
+
+    ref, gref = grads_of(ref_fn, [q, k, v])
+    got, ggot = grads_of(lambda q, k, v: ops.mha(q, k, v, ids.cuda(), B, H, L, True, True, 0.0), [q.cuda(), k.cuda(), v.cuda()])
+    close(got, ref, rtol=5e-4, atol_rel=5e-5, msg="mha fwd")
+    for i, n in enumerate("qkv"):
+        close(ggot[i], gref[i], rtol=2e-3, atol_rel=2e-4, msg=f"mha d{n}")
+
+
+def _step_vs_oracle(cfg, batch, grad_rtol=1e-2):
+    from rectools_amd import lightning as hl
+
+    torch.manual_seed(100)
+    lm = build_hip_model(cfg)
+    hl.xavier_normal_init(lm.torch_model)
+    with torch.no_grad():
+        for _, p in lm.torch_model.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    params = {k: v.detach().cpu().clone() for k, v in lm.torch_model.state_dict().items()}
+    loss_ref, g_ref = T.loss_and_grads(cfg, params, batch)
+    dbatch = {k: v.cuda() for k, v in batch.items()}
+    lm.train()
+    lm.zero_grad()
+    loss = lm.training_loss(dbatch)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(loss_ref)) <= 5e-5 * abs(float(loss_ref)) + 5e-6, (float(loss.detach()), float(loss_ref))
+    for n, p in lm.torch_model.named_parameters():
+        _close(p.grad, g_ref[n], grad_rtol, 2e-5 if g_ref[n].abs().max() > 1e-6 else 1.0, f"grad {n}")
+
+
+def test_stu_training_step_L512_d256_H4():
+    """C4 model shape: HSTU, relative time + position bias, cosine, sampled_softmax, logits_t 0.05; B = 2 sequences."""
+    cfg, batch = _random_case("stu", "sampled_softmax", "cosine", 512, 256, 4, 2, 600, 16, 31, logits_t=0.05)
+    _step_vs_oracle(cfg, batch)
+
+
+def test_ligr_training_step_d512():
+    """C5 model shape: SASRec data path on LiGR blocks (SwiGLU, no FFN bias, multiplier 4) at d = 512, H = 4 (hd = 128)."""
+    cfg, batch = _random_case("ligr", "sampled_softmax", "dot", 64, 512, 4, 3, 700, 16, 32,
+                              layer_kwargs=dict(ff_factors_multiplier=4, ff_activation="swiglu", bias_in_ff=False))
+    _step_vs_oracle(cfg, batch)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# C2: the bench's own loss / embedding geometry — V = 26,744, N = 128, Zipf-popular ids (heavy-row reducers engage)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_sampled_softmax_V26744_N128_zipf_targets():
+    from rectools_amd import ops
+
+    M, d, V, N = 32 * 200, 256, 26_745, 128
+    g = torch.Generator().manual_seed(1)
+    sess, table = rnd(M, d, seed=2) * 0.3, rnd(V, d, seed=3) * 0.3
+    y = _zipf_ids((M,), V - 1, g)
+    y[torch.rand(M, generator=g) < 0.28] = 0          # left padding share of ML-20M-shaped batches
+    neg = torch.randint(1, V, (M, N), generator=g)
+    w = (y != 0).float()
+    assert int(torch.bincount(y[y > 0]).max()) > 300   # the most popular target owns several reducer chunks
+
+    def ref_fn(sess, table):
+        cand = torch.cat([y[:, None], neg], 1)
+        lg = torch.einsum("mcd,md->mc", table[cand], sess)[None]
+        return T.sampled_softmax_loss(lg, y[None], w[None]).reshape(1)
+
+    ref, gref = grads_of(ref_fn, [sess, table])
+    got, ggot = grads_of(lambda s, e: ops.sampled_loss(s, e, y.cuda(), neg.cuda(), w.cuda(), ops.LOSS_SAMPLED_SOFTMAX, False, 1.0, 0.0)[0].reshape(1),
+                         [sess.cuda(), table.cuda()])
+    close(got, ref, rtol=2e-5, atol_rel=1e-6, msg="loss")
+    gref[1][0] = 0
+    close(ggot[0], gref[0], rtol=2e-3, atol_rel=2e-4, msg="d_sess")
+    close(ggot[1], gref[1], rtol=2e-3, atol_rel=2e-4, msg="d_table")
+
+
+def test_sasrec_training_step_C2_shape_zipf():
+    """One whole C2 training step (d256, 2 blocks, 4 heads, L200, sampled_softmax N=128, V=26,744) on 32 Zipf-popular
+    sequences: loss and EVERY parameter gradient (incl. the embedding-table gradient through both heavy-row reducers)."""
+    L, d, H, B, V, N = 200, 256, 4, 32, 26_744, 128
+    cfg, batch = _random_case("sasrec", "sampled_softmax", "dot", L, d, H, B, V, N, 41)
+    g = torch.Generator().manual_seed(42)
+    seq = _zipf_ids((B, L + 1), V, g)
+    lens = torch.randint(20, L + 1, (B,), generator=g); lens[0] = L
+    pad = torch.arange(L)[None, :] < (L - lens)[:, None]
+    batch["x"] = seq[:, :-1].masked_fill(pad, 0)
+    batch["y"] = seq[:, 1:].masked_fill(pad, 0)
+    batch["yw"] = (batch["y"] != 0).float()
+    _step_vs_oracle(cfg, batch)

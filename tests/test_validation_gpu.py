@@ -1,17 +1,10 @@
-"""Training with a validation mask on the GPU path (leave-one-out targets, last-position loss: lightning.py:340-349).
-
-Written at the end of round 1 without GPU budget left to run it: gated behind RT_TEST_UNVALIDATED=1 so that the first GPU
-visit of the next round can run it (`RT_TEST_UNVALIDATED=1 python -m pytest tests/test_validation_gpu.py`) and then drop
-the gate."""
-import os
-
+"""Training with a validation mask on the GPU path (leave-one-out targets, last-position loss: lightning.py:340-349)."""
 import numpy as np
 import pandas as pd
 import pytest
 import torch
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("RT_TEST_UNVALIDATED") != "1", reason="not yet run on hardware (RT_TEST_UNVALIDATED=1)")]
+pytestmark = pytest.mark.gpu
 
 
 def _frame(seed=0, n_users=60, n_items=40, n=1500):
