@@ -168,14 +168,23 @@ class TransformerModelBase:
             return self.item_net_constructor_type.from_dataset(self.data_preparator.train_dataset, self.n_factors,
                                                                self.dropout_rate, self.item_net_block_types, **kw)
         n_tokens = self.data_preparator.item_id_map.size
+        by_kind = {spec["kind"]: spec for spec in item_net_schema}
         blocks: tp.List[torch.nn.Module] = []
-        for spec in item_net_schema:
-            if spec["kind"] == "ids":
-                blocks.append(hnn.IdEmbeddingsItemNet(self.n_factors, n_tokens, self.dropout_rate))
-            else:
+        # the configured block types in their configured ORDER decide the module list (`from_dataset_schema`,
+        # item_net.py:413-460): an ids-only model fitted on a dataset WITH categorical features has no feature block, and
+        # (Cat, Id) order puts the feature block at index 0 — the state dict's `item_net_blocks.N.*` keys follow that
+        for block_type in self.item_net_block_types:
+            if isinstance(block_type, type) and issubclass(block_type, hnn.IdEmbeddingsItemNet):
+                blocks.append(block_type(self.n_factors, n_tokens, self.dropout_rate))
+            elif isinstance(block_type, type) and issubclass(block_type, hnn.CatFeaturesItemNet):
+                spec = by_kind.get("cat")
+                if spec is None:
+                    continue    # no categorical item features in the dataset: the block is skipped, as at fit time
                 zeros = torch.zeros(n_tokens, dtype=torch.int64)
-                blocks.append(hnn.CatFeaturesItemNet(torch.zeros(spec["nnz"], dtype=torch.int64), zeros, zeros.clone(),
-                                                     spec["n_cat_feature_values"], self.n_factors, self.dropout_rate))
+                blocks.append(block_type(torch.zeros(spec["nnz"], dtype=torch.int64), zeros, zeros.clone(),
+                                         spec["n_cat_feature_values"], self.n_factors, self.dropout_rate))
+            else:
+                raise NotImplementedError(f"item net block {block_type!r} cannot be rebuilt from a dataset schema")
         return self.item_net_constructor_type(n_tokens, blocks, **kw)
 
     def _build_model_from_dataset(self, dataset: tp.Any, item_net_schema: tp.Optional[tp.List[dict]] = None) -> None:
@@ -201,6 +210,11 @@ class TransformerModelBase:
         self.optimizer.broadcast_parameters()   # data parallel: replicas start from rank 0's weights (DDP semantics)
         self.epochs_done = 0
         self.history = []
+        self._train_data_ready = dataset is not None
+        # dropout streams: keyed by the model seed and the rank (replicas must not share masks), restarted with the model
+        ops.RNG.seed = ((0 if self.seed is None else int(self.seed)) * 0x9E3779B97F4A7C15 + 0xD1B54A32D192ED03 * _dist_info()[0]) \
+            & 0xFFFFFFFFFFFFFFFF
+        ops.RNG.step = 0
         if dataset is not None:   # kept for checkpoints (hyper_parameters.dataset_schema, base.py:470-473)
             self.dataset_schema = self.data_preparator.train_dataset.get_schema()
 
@@ -239,6 +253,7 @@ class TransformerModelBase:
         dstore = DeviceSequenceStore(store, device)   # sessions resident in HBM: batches are cut on the device (rt_collate)
         val_store = dp.val_store()
         seed = 0 if self.seed is None else int(self.seed)
+        ops.RNG.step = opt.step_count   # fit_partial / restored models continue the dropout streams where training stopped
         for epoch in range(first, last):
             lm.train()
             perm = epoch_permutation(len(store), epoch, seed, dp.shuffle_train)
@@ -262,13 +277,44 @@ class TransformerModelBase:
                 with torch.no_grad():
                     for b0 in range(0, len(val_store), self.batch_size):
                         vb = self._to_device(dp.collate_val(val_store, np.arange(b0, min(b0 + self.batch_size, len(val_store)))), device, True)
-                        vt += lm.validation_loss(vb)
-                        vn += 1
+                        nb = int(vb["x"].shape[0])     # Lightning's epoch mean weights every batch by its size
+                        vt += lm.validation_loss(vb) * nb
+                        vn += nb
                 rec[self.val_loss_name] = float(vt) / max(vn, 1)
             self.history.append(rec)
+            if rank == 0:
+                self._log_epoch(rec, opt.step_count)
             if self.verbose and rank == 0:
                 print(rec)
             self.epochs_done = epoch + 1
+
+    def _log_epoch(self, rec: tp.Dict[str, float], global_step: int) -> None:
+        """Per-epoch metrics file in the layout of Lightning's CSVLogger (`<dir>/version_N/metrics.csv`, columns
+        `epoch,step,train_loss,val_loss`; one row per logged metric group, validation first — what `self.log(..., on_epoch=
+        True)` of lightning.py:320,358 produces).  Directory: `csv_log_dir=` model argument; the reference's default trainer
+        logs only when verbose > 0 (base.py:375), to `lightning_logs/`."""
+        import os
+
+        log_dir = self._params.get("csv_log_dir") or ("lightning_logs" if self.verbose > 0 else None)
+        if log_dir is None:
+            return
+        if getattr(self, "_csv_path", None) is None or rec["epoch"] == 0:
+            os.makedirs(log_dir, exist_ok=True)
+            taken = [int(n.split("_")[1]) for n in os.listdir(log_dir) if n.startswith("version_") and n.split("_")[1].isdigit()]
+            vdir = os.path.join(log_dir, f"version_{max(taken) + 1 if taken else 0}")
+            os.makedirs(vdir)
+            self._csv_path = os.path.join(vdir, "metrics.csv")
+            with open(self._csv_path, "w") as f:
+                f.write(f"epoch,step,{self.train_loss_name},{self.val_loss_name}\n")
+        with open(self._csv_path, "a") as f:
+            step = global_step - 1
+            if self.val_loss_name in rec:
+                f.write(f"{rec['epoch']},{step},,{rec[self.val_loss_name]}\n")
+            f.write(f"{rec['epoch']},{step},{rec[self.train_loss_name]},\n")
+
+    @property
+    def log_path(self) -> tp.Optional[str]:
+        return getattr(self, "_csv_path", None)
 
     def fit(self, dataset: tp.Any) -> "TransformerModelBase":
         """Fit from scratch (models/base.py:326-341 -> transformers/base.py:481-489)."""
@@ -281,8 +327,17 @@ class TransformerModelBase:
         """Continue training for `max_epochs` more epochs (transformers/base.py:505-533)."""
         if not self.is_fitted:
             self._build_model_from_dataset(dataset)
-        else:
+        elif not getattr(self, "_train_data_ready", False):
+            # restored from a checkpoint / pickle: the training sessions have to be rebuilt (transformers/base.py:520-523),
+            # and they must index the SAME embedding rows the restored weights were trained on
+            known = np.asarray(self.data_preparator.item_id_map.external_ids)
             self.data_preparator.process_dataset_train(dataset)
+            now = np.asarray(self.data_preparator.item_id_map.external_ids)
+            if len(known) != len(now) or not (known == now).all():
+                raise ValueError("fit_partial: the dataset maps items to other embedding rows than the restored model was trained "
+                                 "with (different items, or a different order of first appearance)")
+            self._train_data_ready = True
+        # else: a model fitted in this process keeps its processed train dataset, as the reference does (base.py:505-533)
         self._run_epochs(self.epochs_done, self.epochs_done + max_epochs)
         self.is_fitted = True
         return self

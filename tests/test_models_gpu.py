@@ -144,6 +144,19 @@ def test_fit_recommend_with_item_features(kind):
     # ids-only models ignore the features of the dataset
     plain = SASRecModel(item_net_block_types=(hnn.IdEmbeddingsItemNet,), **common).fit(ds)
     assert plain.torch_model.item_model.n_item_blocks == 1
+    # ... and persistence rebuilds the CONFIGURED blocks in their configured order, not "ids + cat whenever the dataset
+    # has categorical features" (from_dataset_schema, item_net.py:413-460)
+    again = SASRecModel.loads(plain.dumps())
+    assert again.torch_model.item_model.n_item_blocks == 1
+    pd.testing.assert_frame_equal(plain.recommend(users=users, dataset=ds, k=3, filter_viewed=True),
+                                  again.recommend(users=users, dataset=ds, k=3, filter_viewed=True))
+    swapped = SASRecModel(item_net_block_types=(hnn.CatFeaturesItemNet, hnn.IdEmbeddingsItemNet), **common).fit(ds)
+    blocks = swapped.torch_model.item_model.item_net_blocks
+    assert isinstance(blocks[0], hnn.CatFeaturesItemNet) and isinstance(blocks[1], hnn.IdEmbeddingsItemNet)
+    back = SASRecModel.loads(swapped.dumps())
+    assert isinstance(back.torch_model.item_model.item_net_blocks[0], hnn.CatFeaturesItemNet)
+    pd.testing.assert_frame_equal(swapped.recommend(users=users, dataset=ds, k=3, filter_viewed=True),
+                                  back.recommend(users=users, dataset=ds, k=3, filter_viewed=True))
 
 
 def test_fit_partial_equals_fit_and_cold_users():

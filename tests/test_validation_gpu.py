@@ -49,3 +49,25 @@ def test_validation_loss_matches_the_oracle(kind, loss):
             tot += float(T.softmax_loss(logits.unsqueeze(1), batch["y"], batch["yw"]))
         n += 1
     assert abs(tot / n - model.history[-1]["val_loss"]) <= 2e-4 * abs(tot / n) + 2e-5
+
+
+def test_csv_metrics_log_has_the_lightning_columns(tmp_path):
+    """`epoch,step,train_loss,val_loss` rows per epoch (what Lightning's CSVLogger writes for lightning.py:320,358)."""
+    from rectools_amd.dataset import Dataset
+    from rectools_amd.models import SASRecModel
+    from rectools_amd.utils import leave_one_out_mask
+
+    model = SASRecModel(n_factors=32, n_blocks=1, n_heads=2, session_max_len=6, batch_size=16, epochs=3, loss="softmax", seed=3,
+                        get_val_mask_func=leave_one_out_mask, get_val_mask_func_kwargs={"val_users": 25}, csv_log_dir=str(tmp_path))
+    model.fit(Dataset.construct(_frame()))
+    assert model.log_path == str(tmp_path / "version_0" / "metrics.csv")
+    log = pd.read_csv(model.log_path)
+    assert list(log.columns) == ["epoch", "step", "train_loss", "val_loss"]
+    tr, va = log.dropna(subset=["train_loss"]), log.dropna(subset=["val_loss"])
+    assert tr["epoch"].tolist() == [0, 1, 2] and va["epoch"].tolist() == [0, 1, 2]
+    np.testing.assert_allclose(tr["train_loss"].values, [h["train_loss"] for h in model.history], rtol=1e-6)
+    np.testing.assert_allclose(va["val_loss"].values, [h["val_loss"] for h in model.history], rtol=1e-6)
+    steps_per_epoch = model.optimizer.step_count // 3
+    assert tr["step"].tolist() == [steps_per_epoch * (e + 1) - 1 for e in range(3)]
+    model.fit(Dataset.construct(_frame()))          # a second fit opens the next version directory
+    assert model.log_path == str(tmp_path / "version_1" / "metrics.csv")
