@@ -3,12 +3,19 @@
 
     python bench.py --gpus N --steps K --warmup W [--workload auto|train|recommend|topk5m]
 
-One "step" = one pass of the hot path over one batch of synthetic input resident in HBM:
-  * train      : one SASRec training step (collated batch -> fwd -> loss -> bwd -> Adam [-> RCCL all-reduce])
-                 on BASELINE.json configs[1] (d=256, 2 blocks, L=200, sampled_softmax, ML-20M-shaped);
-  * recommend  : top-k (k=10, filter_viewed) for one batch of users against the ML-20M-shaped catalog;
-  * topk5m     : top-k over the 5M x 512 synthetic catalog (BASELINE.json configs[4], the HBM-roofline run).
-Rank 0 prints ONE JSON line.  N>1 is launched by torch.distributed.run (one rank per GPU, RCCL).
+BASELINE.json's metric is "train seqs/sec + recommend() users/sec@k=10, SASRec d=256 ML-20M" plus the HBM-roofline run of
+the full-catalog top-k.  The default (`auto`) run therefore has three legs and prints ONE JSON line on rank 0:
+  * train (the headline `value`; K timed steps after W warm-up steps): the product loop of `SASRecModel.fit()` on
+    BASELINE.json configs[1] (d=256, 2 blocks, 4 heads, L=200, dropout 0.2, sampled_softmax N=128, ML-20M-shaped data):
+    the model is built by the public API from a synthetic `Dataset`, and one step = `models._TrainLoop.step()` =
+    device collate out of the HBM-resident session store (rt_collate) -> negatives (rt_sample_negatives) -> forward ->
+    loss -> backward -> [RCCL all-reduce ->] fused Adam — nothing pre-collated, nothing replayed;
+  * `recommend` sub-record: top-k (k=10, filter_viewed) of 16,384 users per step against the 26,744 x 256 catalog, and
+    `recommend_e2e`: one `model.recommend()` call through the public API (session encoding + top-k + frame assembly);
+  * `topk5m` sub-record: top-k over the 5M x 512 synthetic catalog (BASELINE.json configs[4], the HBM-roofline run).
+Each leg carries its own `roofline` (HIP events on the launch stream) and `cpu_baseline` (the oracle on the host cores).
+`--workload train|recommend|topk5m` runs one leg alone (profiling scripts).  N>1 is launched by torch.distributed.run
+(one rank per GPU, RCCL); every rank runs every leg on its own shard, `value`s are whole-job aggregates.
 """
 from __future__ import annotations
 
@@ -146,11 +153,11 @@ def cpu_baseline_topk(items_t: torch.Tensor, users_t: torch.Tensor, filt, budget
     return done / el, done
 
 
-def run_topk(args, rank, world, n_items, d, users_per_step, upp, with_filter, name):
+def run_topk(steps, warmup, rank, world, n_items, d, users_per_step, upp, with_filter, name):
     """One step = one rt_topk_score launch sequence over `users_per_step` users (inputs resident in HBM)."""
     step, ranker, info = make_topk_workload(n_items, d, users_per_step, upp, rank, with_filter, seed=0)
-    wall, ev_ms = timed_steps(step, args.steps, args.warmup, world)
-    users_total = users_per_step * args.steps * world
+    wall, ev_ms = timed_steps(step, steps, warmup, world)
+    users_total = users_per_step * steps * world
     value = users_total / wall
     # algorithmic bytes / flops of ONE launch (SURVEY.md §8d): catalog read once for the whole user batch
     bytes_per_launch = topk_bytes(n_items, d, users_per_step, 10, info["nnz"])
@@ -162,7 +169,7 @@ def run_topk(args, rank, world, n_items, d, users_per_step, upp, with_filter, na
     if n_items * d * 4 <= 200e6:
         hbm_bound = False  # catalog resident in L2 / Infinity Cache: the HBM roof does not apply
     roof = {
-        "kernel": "topk_stream_kernel + topk_merge_kernel (one rt_topk_score call)",
+        "kernel": "rt_topk_score call (seed prefix + topk stream kernel + merge; HIP events around the whole call)",
         "bound": "hbm" if hbm_bound else "mfma",
         "achieved": round(gbs if hbm_bound else tfs, 2),
         "peak": HBM_PEAK_GBS if hbm_bound else MFMA_F32_PEAK_TF,
@@ -176,50 +183,17 @@ def run_topk(args, rank, world, n_items, d, users_per_step, upp, with_filter, na
     return value, wall, roof, info
 
 
-# ---------------------------------------------------------------------------------------------------
-# training workload (BASELINE.json configs[1]: SASRec d=256, 2 blocks, L=200, sampled_softmax, ML-20M-shaped)
-# ---------------------------------------------------------------------------------------------------
-def make_sasrec(V, d, H, n_blocks, L, dropout, loss, n_neg, device="cuda"):
-    from rectools_amd import lightning as hl
-    from rectools_amd import nn as hnn
+def make_ml20m_dataset(seed: int = 0):
+    """ML-20M-shaped synthetic interactions (138,493 users / 26,744 items / ~19.9 M rows) as a `Dataset`."""
+    import pandas as pd
 
-    n_tokens = V + 1
-    torch.manual_seed(31)  # before construction: biases / LayerNorm / embeddings take their default init from this stream
-    item_model = hnn.SumOfEmbeddingsConstructor(n_tokens, [hnn.IdEmbeddingsItemNet(d, n_tokens, 0.0)])
-    pos = hnn.LearnableInversePositionalEncoding(True, L, d)
-    layers = hnn.SASRecTransformerLayers(n_blocks, d, H, dropout)
-    bb = hnn.TransformerTorchBackbone(H, dropout, item_model, pos, layers, hnn.DistanceSimilarityModule("dot"), True, False)
-    lm = hl.TransformerLossModule(bb, loss, n_neg, 0.2, 1.0, 1).to(device)
-    torch.manual_seed(32)
-    hl.xavier_normal_init(lm.torch_model)
-    return lm
-
-
-def make_train_batches(n_batches, B, L, V, n_neg, rank, seed=0):
-    """SASRec training batches (x, y, yw, negatives) from ML-20M-shaped synthetic histories, collated exactly as
-    SASRecDataPreparator._collate_fn_train does (sasrec.py:86-104): last L+1 items, left padding, shift by one."""
     from rectools_amd import synth
+    from rectools_amd.dataset import Dataset
 
-    n_users = n_batches * B
-    u, it, _ = synth.gen_interactions(n_users, V, mean_len=144.0, min_len=20, max_len=9254, seed=seed + 17 * rank)
-    it = it + 1  # internal ids: 0 is PAD
-    bounds = np.concatenate([[0], np.cumsum(np.bincount(u, minlength=n_users))])
-    x = np.zeros((n_users, L), np.int64)
-    y = np.zeros((n_users, L), np.int64)
-    for i in range(n_users):
-        ses = it[bounds[i]:bounds[i + 1]][-(L + 1):]
-        x[i, L - (len(ses) - 1):] = ses[:-1]
-        y[i, L - (len(ses) - 1):] = ses[1:]
-    rng = np.random.default_rng(seed + 5 + rank)
-    out = []
-    for b in range(n_batches):
-        sl = slice(b * B, (b + 1) * B)
-        yb = torch.from_numpy(y[sl])
-        batch = {"x": torch.from_numpy(x[sl]).cuda(), "y": yb.cuda(), "yw": (yb != 0).float().cuda()}
-        if n_neg:
-            batch["negatives"] = torch.from_numpy(rng.integers(1, V + 1, size=(B, L, n_neg))).cuda()
-        out.append(batch)
-    return out
+    shape = {k: v for k, v in synth.ML_20M.items() if k in ("n_users", "n_items", "mean_len", "min_len", "max_len")}
+    u, it, ts = synth.gen_interactions(seed=seed, **shape)
+    df = pd.DataFrame({"user_id": u, "item_id": it, "weight": 1.0, "datetime": pd.to_datetime(ts, unit="s")})
+    return Dataset.construct(df)
 
 
 def sasrec_step_flops(B, L, d, n_blocks, n_neg):
@@ -230,54 +204,60 @@ def sasrec_step_flops(B, L, d, n_blocks, n_neg):
 
 
 def run_train(args, rank, world):
-    from rectools_amd import lightning as hl
-    from rectools_amd import ops, synth
+    from rectools_amd import ops
+    from rectools_amd.models import SASRecModel
 
-    V, d, H, nb, L, B = synth.ML_20M["n_items"], 256, 4, 2, 200, 128
+    d, H, nb, L, B = 256, 4, 2, 200, 128
     n_neg = args.n_negatives
-    lm = make_sasrec(V, d, H, nb, L, 0.2, "sampled_softmax", n_neg)
-    lm.train()
-    opt = hl.FlatAdam(lm.torch_model, lr=1e-3)
-    opt.broadcast_parameters()  # N > 1: replicas start from rank 0's weights, as DDP does
-    n_batches = min(args.steps + args.warmup, 24)
-    batches = make_train_batches(n_batches, B, L, V, n_neg, rank)
-    state = {"i": 0, "loss": None}
+    t0 = time.perf_counter()
+    ds = make_ml20m_dataset()
+    model = SASRecModel(n_factors=d, n_blocks=nb, n_heads=H, session_max_len=L, dropout_rate=0.2, loss="sampled_softmax",
+                        n_negatives=n_neg, batch_size=B, lr=1e-3, epochs=1, seed=32)
+    model._build_model_from_dataset(ds)      # what fit() does before its first epoch (process dataset, build, xavier, broadcast)
+    prep_s = time.perf_counter() - t0
+    V = model.data_preparator.item_id_map.size - 1
+    loop = model.training_loop()
+    model.lightning_model.train()
+    loop.begin_epoch(0)
+    state = {"loss": None}
 
     def step():
-        batch = batches[state["i"] % n_batches]
-        state["i"] += 1
-        ops.RNG.next_step()
-        opt.zero_grad()
-        loss = lm.training_loss(batch)
-        loss.backward()
-        opt.step(world)
-        state["loss"] = loss
+        state["loss"] = loop.step()
 
     wall, ev_ms = timed_steps(step, args.steps, args.warmup, world)
     value = B * args.steps * world / wall
-    # ---- roofline pass: 3 more steps with HIP events around every rt_* launch (on the launch stream) ----
-    ops.start_timing()
-    for _ in range(3):
-        step()
-    rec = ops.stop_timing()
+    # ---- roofline pass: 3 more steps with HIP events (on the launch stream) around every rt_* call.  By default the
+    # weight-gradient products stay on their side stream, as in the timed region (durations then include the overlap, and
+    # agree with rocprofv3 of this command); `single_stream_ms` repeats the pass with everything on one stream.
+    def instrumented(single_stream):
+        ops.start_timing(single_stream=single_stream)
+        for _ in range(3):
+            step()
+        return ops.stop_timing()
+
+    rec = instrumented(False)
+    rec1 = instrumented(True)
     per_kernel = {k: (sum(t for t, _ in v) / 3.0, len(v) / 3.0) for k, v in rec.items()}
+    per_kernel1 = {k: sum(t for t, _ in v) / 3.0 for k, v in rec1.items()}
     total_k = sum(t for t, _ in per_kernel.values())
     dom = max(per_kernel, key=lambda k: per_kernel[k][0])
-    breakdown = {k: {"ms_per_step": round(t, 4), "calls_per_step": c} for k, (t, c) in
-                 sorted(per_kernel.items(), key=lambda kv: -kv[1][0])}
+    breakdown = {k: {"ms_per_step": round(t, 4), "calls_per_step": c, "single_stream_ms": round(per_kernel1.get(k, 0.0), 4)}
+                 for k, (t, c) in sorted(per_kernel.items(), key=lambda kv: -kv[1][0])}
     roof = None
     if dom == "rt_gemm":
         calls = rec["rt_gemm"]
         fl = sum(2.0 * m * n * k for _, (m, n, k) in calls)
         ms = sum(t for t, _ in calls)
         tf = fl / (ms * 1e-3) / 1e12
+        ms1 = sum(t for t, _ in rec1["rt_gemm"])
         roof = {"kernel": "gemm_dma_kernel (rt_gemm: all forward/dgrad/wgrad products of the step)", "bound": "mfma",
                 "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),
                 "traffic": load_traffic("train_gemm"), "avg_launch_ms": round(ms / len(calls), 4),
-                "algorithmic_flops_per_launch": fl / len(calls), "launches_per_step": len(calls) / 3.0}
+                "algorithmic_flops_per_launch": fl / len(calls), "launches_per_step": len(calls) / 3.0,
+                "single_stream": {"avg_launch_ms": round(ms1 / len(calls), 4), "achieved": round(fl / (ms1 * 1e-3) / 1e12, 2)}}
     else:
         M = B * L
-        if dom in ("rt_sampled_loss_fwd", "rt_sampled_loss_bwd"):
+        if dom.startswith("rt_sampled_loss"):
             byts = M * 0.72 * (1 + n_neg) * (4.0 * d + 8.0) * (2.0 if dom.endswith("bwd") else 1.0) + 4.0 * M * d
         else:
             byts = 8.0 * M * d
@@ -288,33 +268,56 @@ def run_train(args, rank, world):
                 "algorithmic_bytes_per_launch": byts}
     roof["kernel_ms_per_step"] = round(total_k, 3)
     roof["step_flops_dense"] = sasrec_step_flops(B, L, d, nb, n_neg)
-    info = dict(lm=lm, batches=batches, V=V, d=d, H=H, nb=nb, L=L, B=B, n_neg=n_neg, breakdown=breakdown,
-                loss=float(state["loss"]))
+    roof["step_TFLOPs"] = round(roof["step_flops_dense"] / (wall / args.steps) / 1e12, 2)
+    info = dict(model=model, ds=ds, loop=loop, V=V, d=d, H=H, nb=nb, L=L, B=B, n_neg=n_neg, breakdown=breakdown,
+                loss=float(state["loss"].detach()), prep_s=prep_s, steps_per_epoch=loop.batches_left() + loop.pos // B)
     return value, wall, roof, info
 
 
 def cpu_baseline_train(info, budget_s=25.0):
-    """The oracle (plain torch fp32 restatement of the reference step, CPU) on the same model/batches:
-    forward + backward + dense Adam, timed on the host cores."""
+    """The oracle (plain torch fp32 restatement of the reference step, CPU; the reference tree itself does not exist on the
+    GPU box) on the same model and on batches cut by the same product collate + sampler: forward + backward + dense Adam,
+    timed on the host cores on a bounded sample (32-sequence sub-batches)."""
     from oracle import transformer_oracle as T
 
+    model, loop = info["model"], info["loop"]
     cfg = dict(V=info["V"], B=info["B"], L=info["L"], d=info["d"], H=info["H"], n_blocks=info["nb"], N=info["n_neg"],
                loss="sampled_softmax", dist="dot", logits_t=1.0, causal=True, keypad=False, layers="sasrec", n_extra=1,
                gbce_t=0.2, lr=1e-3)
-    params = {k: v.detach().cpu().clone() for k, v in info["lm"].torch_model.state_dict().items()}
+    params = {k: v.detach().cpu().clone() for k, v in model.torch_model.state_dict().items()}
     adam = T.AdamState(lr=1e-3)
     bsub = 32  # bounded sample: 32 sequences per CPU step
+    dp = model.data_preparator
+    batches = []
+    for i in range(2):
+        idx = loop.mine_t[i * bsub:(i + 1) * bsub]
+        batches.append({k: v.cpu() for k, v in dp.add_negatives(dp.collate_train_device(loop.dstore, idx)).items()})
     t0 = time.perf_counter()
     n = 0
     while True:
-        b = {k: v[:bsub].cpu() for k, v in info["batches"][n % len(info["batches"])].items()}
-        _, grads = T.loss_and_grads(cfg, params, b)
+        _, grads = T.loss_and_grads(cfg, params, batches[n % len(batches)])
         params = adam.step(params, grads)
         n += 1
         el = time.perf_counter() - t0
         if el > budget_s or n >= 6:
             break
-    return bsub * n / el, f"oracle/transformer_oracle (torch CPU fp32) fwd+bwd+Adam, {n} steps of {bsub} sequences"
+    return bsub * n / el, (f"oracle/transformer_oracle (torch CPU fp32 restatement; the reference tree is absent on the GPU box) "
+                           f"fwd+bwd+Adam, {n} steps of {bsub} sequences (sub-batches of the GPU run's B=128)")
+
+
+def run_recommend_e2e(info, n_users=16384):
+    """One `model.recommend()` call through the public API: id mapping, device glue (sessions, viewed CSR), session encoding,
+    exact top-k, result frame.  Wall clock of the whole call (it ends with the D2H of the results)."""
+    model, ds = info["model"], info["ds"]
+    users = np.asarray(ds.user_id_map.external_ids)[:n_users]
+    model.is_fitted = True
+    model.recommend(users=users[:2048], dataset=ds, k=10, filter_viewed=True)   # warm-up (allocator, hash tables)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reco = model.recommend(users=users, dataset=ds, k=10, filter_viewed=True)
+    el = time.perf_counter() - t0
+    return {"value": round(len(users) / el, 1), "unit": "users/s", "users": int(len(users)), "seconds": round(el, 4),
+            "rows": int(len(reco)), "what": "SASRecModel.recommend(users, dataset, k=10, filter_viewed=True), public API, one call"}
 
 
 def load_traffic(name: str):
@@ -328,87 +331,109 @@ def load_traffic(name: str):
     return None
 
 
+def topk_leg(kind, args, rank, world, cpu_baseline):
+    """-> sub-record of one top-k leg: `recommend` (C2 catalog, 16,384 users/step, viewed filter) or `topk5m` (C5)."""
+    from rectools_amd import synth
+
+    if kind == "recommend":
+        V, d = synth.ML_20M["n_items"], 256
+        ups = args.users_per_step or 16384
+        upp = args.users_per_pass or 64
+        steps, warmup = args.rec_steps, 3
+        metric = "recommend() users/sec @k=10 (SASRec d=256, ML-20M-shaped catalog, filter_viewed)"
+        workload = f"recommend top-k: 26744 items x d256 fp32, {ups} users/step, k=10, viewed-filter CSR"
+        name, with_filter = "recommend_ml20m", True
+    else:
+        V, d = 5_000_000, 512
+        ups = args.users_per_step or 16   # 16 users/launch: the HBM-bound regime (AI = B/2 flop/B; 32 users is the fp32 ridge)
+        upp = args.users_per_pass or (16 if ups <= 16 else 32 if ups <= 32 else 64)
+        steps, warmup = args.topk_steps, 2
+        metric = "full-catalog top-k users/sec @k=10 (5M x 512 fp32 catalog)"
+        workload = f"top-k scoring: 5,000,000 items x d512 fp32 (10.24 GB), {ups} users/step, k=10"
+        name, with_filter = "topk5m", False
+    value, wall, roof, info = run_topk(steps, warmup, rank, world, V, d, ups, upp, with_filter, name)
+    rec = {"metric": metric, "value": round(value, 2), "unit": "users/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": round(wall / steps * 1e3, 4), "dtype": "fp32",
+           "config": {"workload": workload, "users_per_step": ups, "users_per_register_tile": upp, "parallelism": f"dp{world}"},
+           "roofline": roof, "cpu_baseline": None}
+    if cpu_baseline:
+        torch.cuda.synchronize()
+        small = info["n_items"] <= 100_000
+        v, n = cpu_baseline_topk(info["items"] if small else info["items"][:200_000], info["users_t"], info["filt"])
+        scale = 1.0 if small else 200_000 / info["n_items"]
+        rec["cpu_baseline"] = {"value": round(v * scale, 2), "unit": "users/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"oracle/ranker_oracle.rank (numpy restatement of TorchRanker.rank) on {n} users"
+                                         + ("" if small else f", first 200k catalog rows, rate scaled by {scale:.3f}")}
+    del info
+    torch.cuda.empty_cache()
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps of the headline leg (default 200 train steps)")
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="auto", choices=["auto", "train", "recommend", "topk5m"])
-    ap.add_argument("--users-per-pass", type=int, default=0, help="register tile: 32/64/128 users (0 = auto)")
+    ap.add_argument("--users-per-pass", type=int, default=0, help="register tile: 16/32/64/128 users (0 = auto)")
     ap.add_argument("--users-per-step", type=int, default=0)
     ap.add_argument("--n-negatives", type=int, default=128, help="sampled_softmax negatives (tutorial setting 128)")
+    ap.add_argument("--rec-steps", type=int, default=20, help="timed steps of the recommend sub-leg")
+    ap.add_argument("--topk-steps", type=int, default=5, help="timed steps of the topk5m sub-leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     rank, world, local = dist_setup(args.gpus)
 
-    from rectools_amd import _lib, synth
+    from rectools_amd import _lib
 
     _lib.load()  # fail loudly if the HIP extension is missing
     workload = args.workload
-    if workload == "auto":
-        workload = "train"
+    cpu_ok = rank == 0 and world == 1 and not args.no_cpu_baseline
+    env = {k: v for k, v in sorted(os.environ.items()) if k.startswith("RT_")}   # every engine knob that is set
 
-    extra = {}
-    cpu = None
-    if workload == "train":
-        if args.steps is None:
-            args.steps = 30
-        if args.warmup is None:
-            args.warmup = 5
-        value, wall, roof, info = run_train(args, rank, world)
-        metric, unit = "train seqs/sec (SASRec d=256 n_blocks=2 L=200 sampled_softmax, ML-20M-shaped)", "seqs/s"
-        config = {"workload": f"SASRec fit() step: B=128/GPU x L=200, d=256, 2 blocks, 4 heads, dropout 0.2, sampled_softmax "
-                              f"N={args.n_negatives}, V=26744 items, fwd+bwd+Adam" + (" + RCCL all-reduce" if world > 1 else ""),
-                  "global_batch": 128 * world, "seq_len": 200, "parallelism": f"dp{world}", "n_negatives": args.n_negatives}
-        extra["kernel_breakdown"] = info["breakdown"]
-        extra["final_loss"] = round(info["loss"], 5)
-        if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            v, what = cpu_baseline_train(info)
-            cpu = {"value": round(v, 2), "unit": unit, "cores": torch.get_num_threads(), "kind": "port", "sample": what}
-    elif workload == "recommend":
-        if args.steps is None:
-            args.steps = 20
-        if args.warmup is None:
-            args.warmup = 3
-        V, d = synth.ML_20M["n_items"], 256
-        users_per_step = args.users_per_step or 16384
-        upp = args.users_per_pass or 64
-        value, wall, roof, info = run_topk(args, rank, world, V, d, users_per_step, upp, True, "recommend_ml20m")
-        metric, unit = "recommend() users/sec @k=10 (SASRec d=256, ML-20M-shaped catalog, filter_viewed)", "users/s"
-        config = {"workload": f"recommend top-k: 26744 items x d256 fp32, {users_per_step} users/step, k=10, viewed-filter CSR",
-                  "users_per_step": users_per_step, "users_per_register_tile": upp, "parallelism": f"dp{world}"}
-    elif workload == "topk5m":
-        if args.steps is None:
-            args.steps = 3
-        if args.warmup is None:
-            args.warmup = 1
-        V, d = 5_000_000, 512
-        users_per_step = args.users_per_step or 32  # 32 users/launch: the HBM-bound regime (AI = B/2 flop/B)
-        upp = args.users_per_pass or (32 if users_per_step <= 32 else 64)
-        value, wall, roof, info = run_topk(args, rank, world, V, d, users_per_step, upp, False, "topk5m")
-        metric, unit = "full-catalog top-k users/sec @k=10 (5M x 512 fp32 catalog)", "users/s"
-        config = {"workload": f"top-k scoring: 5,000,000 items x d512 fp32 (10.24 GB), {users_per_step} users/step, k=10",
-                  "users_per_step": users_per_step, "users_per_register_tile": upp, "parallelism": f"dp{world}"}
+    if workload in ("recommend", "topk5m"):   # one top-k leg alone: its record is the line
+        if args.steps is not None:
+            args.rec_steps = args.topk_steps = args.steps
+        out = topk_leg(workload, args, rank, world, cpu_ok)
+        if args.warmup is not None:
+            out["warmup_requested"] = args.warmup
+        out.update({"n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
+                    "env": env})
     else:
-        raise SystemExit("train workload is not built yet in this revision")
-
-    if workload != "train" and rank == 0 and world == 1 and not args.no_cpu_baseline:
-        torch.cuda.synchronize()
-        v, n = cpu_baseline_topk(info["items"] if info["n_items"] <= 100_000 else info["items"][:200_000],
-                                 info["users_t"], info["filt"])
-        scale = 1.0 if info["n_items"] <= 100_000 else 200_000 / info["n_items"]
-        cpu = {"value": round(v * scale, 2), "unit": unit, "cores": torch.get_num_threads(), "kind": "port",
-               "sample": f"oracle/ranker_oracle.rank (numpy) on {n} users"
-                         + ("" if scale == 1.0 else f", first 200k catalog rows, rate scaled by {scale:.3f}")}
+        if args.steps is None:
+            args.steps = 200      # SURVEY.md §8d: 200 timed steps after 20 warm-up
+        if args.warmup is None:
+            args.warmup = 20
+        value, wall, roof, info = run_train(args, rank, world)
+        out = {
+            "metric": "train seqs/sec (SASRec d=256 n_blocks=2 L=200 sampled_softmax, ML-20M-shaped) "
+                      "[+ recommend() users/sec@k=10 and 5Mx512 top-k in the sub-records]",
+            "value": round(value, 2), "unit": "seqs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "fp32", "data": "synthetic",
+            "config": {"workload": f"SASRecModel.fit() steady-state step (models._TrainLoop.step): device collate from the HBM session "
+                                   f"store + on-device negatives + fwd + bwd + Adam" + (" + RCCL all-reduce" if world > 1 else "")
+                                   + f"; B=128/GPU x L=200, d=256, 2 blocks, 4 heads, dropout 0.2, sampled_softmax "
+                                   f"N={args.n_negatives}, V={info['V']} items, {info['steps_per_epoch']} steps/epoch",
+                       "global_batch": 128 * world, "seq_len": 200, "parallelism": f"dp{world}", "n_negatives": args.n_negatives,
+                       "dataset_prep_s": round(info["prep_s"], 2)},
+            "roofline": roof, "cpu_baseline": None,
+            "kernel_breakdown": info["breakdown"], "final_loss": round(info["loss"], 5),
+        }
+        if cpu_ok:
+            v, what = cpu_baseline_train(info)
+            out["cpu_baseline"] = {"value": round(v, 2), "unit": "seqs/s", "cores": torch.get_num_threads(), "kind": "port",
+                                   "sample": what}
+        if workload == "auto":
+            if world == 1:
+                out["recommend_e2e"] = run_recommend_e2e(info)
+            del info
+            torch.cuda.empty_cache()
+            out["recommend"] = topk_leg("recommend", args, rank, world, cpu_ok)
+            out["topk5m"] = topk_leg("topk5m", args, rank, world, cpu_ok)
+        out["env"] = env
 
     if rank == 0:
-        out = {
-            "metric": metric, "value": round(value, 2), "unit": unit, "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
-            "config": config, "roofline": roof, "cpu_baseline": cpu,
-        }
-        out.update(extra)
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

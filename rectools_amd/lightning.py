@@ -150,12 +150,12 @@ class FlatAdam:
             self._flat_g = torch.zeros_like(self.flat_p)
         return self._flat_g
 
-    def broadcast_parameters(self, src: int = 0) -> None:
+    def broadcast_parameters(self, src: int = 0, force: bool = False) -> None:
         """Data-parallel start: every replica takes rank `src`'s parameters and moments (what DDP does when it wraps a
         module).  One broadcast per flat buffer; a no-op without an initialised process group."""
         import torch.distributed as dist
 
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force):
             for buf in (self.flat_p, self.m, self.v):
                 dist.broadcast(buf, src=src)
 
@@ -180,24 +180,28 @@ class FlatAdam:
             torch._foreach_copy_(views, grads)   # pylint: disable=protected-access
         return fg
 
-    def reduce_gradients(self, world_size: int = 1) -> float:
+    def reduce_gradients(self, world_size: int = 1, force: bool = False) -> float:
         """Data-parallel gradient exchange: ONE sum all-reduce of the flat gradient buffer (RCCL over xGMI on GPUs,
         gloo in the CPU tests).  Returns the scale that turns the sum into DDP's mean; it is folded into the Adam
-        kernel instead of a separate pass over the buffer."""
-        if world_size <= 1:
+        kernel instead of a separate pass over the buffer.  `force` runs the collective with a single rank too (the
+        RCCL smoke test of a one-GPU box)."""
+        if world_size <= 1 and not force:
             return 1.0
         import torch.distributed as dist
 
         dist.all_reduce(self.gather_gradients(), op=dist.ReduceOp.SUM)
-        return 1.0 / world_size
+        return 1.0 / max(world_size, 1)
 
-    def step(self, world_size: int = 1) -> None:
+    def step(self, world_size: int = 1, flat: bool = False) -> None:
+        """One Adam step.  world_size > 1 (or flat=True): pack -> all-reduce -> Adam over the flat buffers; otherwise the
+        segmented kernel reads every gradient through its own pointer."""
         if self.flat_p.is_cuda:
             ops.join_side_streams()   # weight gradients may still be in flight on the wgrad stream
-        scale = self.reduce_gradients(world_size)
+        flat = flat or world_size > 1
+        scale = self.reduce_gradients(world_size, force=flat)
         self.step_count += 1
         hyper = (self.step_count, float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(scale))
-        if world_size > 1:
+        if flat:
             ops._c("rt_adam_step", self.flat_p, self.flat_g, self.m, self.v, self.flat_p.numel(), *hyper)
             return
         import ctypes

@@ -59,6 +59,50 @@ def _dist_info() -> tp.Tuple[int, int]:
     return 0, 1
 
 
+class _TrainLoop:
+    """One rank's training stream: the session store lives in HBM (`DeviceSequenceStore`), an epoch is a permutation of
+    the sessions sharded DistributedSampler-style, and `step()` is one optimiser step on the next batch — device collate
+    (`rt_collate`), negatives (`rt_sample_negatives` through the plugged sampler), forward + loss + backward, gradient
+    exchange and the fused Adam kernel (lightning.py:311-321 + sasrec.py:86-104 + negative_sampler.py:58-73 per step)."""
+
+    def __init__(self, model: "TransformerModelBase") -> None:
+        lm, opt = model.lightning_model, model.optimizer
+        assert lm is not None and opt is not None
+        self.model, self.lm, self.opt, self.dp = model, lm, opt, model.data_preparator
+        self.device = next(lm.parameters()).device
+        self.rank, self.world = _dist_info()
+        self.store = self.dp.train_store()
+        self.dstore = DeviceSequenceStore(self.store, self.device)
+        self.seed = 0 if model.seed is None else int(model.seed)
+        self.batch_size = model.batch_size
+        self.epoch = -1
+        self.mine_t: tp.Optional[torch.Tensor] = None
+        self.pos = 0
+
+    def begin_epoch(self, epoch: int) -> None:
+        perm = epoch_permutation(len(self.store), epoch, self.seed, self.dp.shuffle_train)
+        mine = shard_indices(perm, self.rank, self.world)
+        self.mine_t = torch.from_numpy(np.ascontiguousarray(mine, dtype=np.int64)).to(self.device)   # one small H2D per epoch
+        self.epoch, self.pos = epoch, 0
+
+    def batches_left(self) -> int:
+        return 0 if self.mine_t is None else -(-(int(self.mine_t.numel()) - self.pos) // self.batch_size)
+
+    def step(self) -> torch.Tensor:
+        """One training step on the next batch of the current epoch (rolls over to the next epoch when it is used up)."""
+        if self.batches_left() == 0:
+            self.begin_epoch(self.epoch + 1)
+        idx = self.mine_t[self.pos:self.pos + self.batch_size]
+        self.pos += self.batch_size
+        batch = self.dp.add_negatives(self.dp.collate_train_device(self.dstore, idx))
+        ops.RNG.next_step()
+        self.opt.zero_grad()
+        loss = self.lm.training_loss(batch)
+        loss.backward()
+        self.opt.step(self.world)
+        return loss
+
+
 class TransformerModelBase:
     """Config shell + native training loop + device-resident recommend."""
 
@@ -244,31 +288,26 @@ class TransformerModelBase:
         out = {k: torch.from_numpy(v).to(device, non_blocking=True) for k, v in batch.items()}
         return self.data_preparator.add_negatives(out, validation=validation)
 
+    def training_loop(self) -> "_TrainLoop":
+        """The per-step machinery of fit(): sessions resident in HBM, device collate, negatives, fwd + bwd, fused Adam
+        (+ gradient all-reduce).  `_run_epochs` drives it epoch by epoch; `bench.py` times exactly this object's `step()`."""
+        return _TrainLoop(self)
+
     def _run_epochs(self, first: int, last: int) -> None:
         lm, opt, dp = self.lightning_model, self.optimizer, self.data_preparator
         assert lm is not None and opt is not None
         device = next(lm.parameters()).device
-        rank, world = _dist_info()
-        store = dp.train_store()
-        dstore = DeviceSequenceStore(store, device)   # sessions resident in HBM: batches are cut on the device (rt_collate)
+        loop = self.training_loop()
+        rank = loop.rank
         val_store = dp.val_store()
-        seed = 0 if self.seed is None else int(self.seed)
         ops.RNG.step = opt.step_count   # fit_partial / restored models continue the dropout streams where training stopped
         for epoch in range(first, last):
             lm.train()
-            perm = epoch_permutation(len(store), epoch, seed, dp.shuffle_train)
-            mine = shard_indices(perm, rank, world)
-            mine_t = torch.from_numpy(np.ascontiguousarray(mine, dtype=np.int64)).to(device)   # one small H2D per epoch
+            loop.begin_epoch(epoch)
             total = torch.zeros((), device=device)
             n_batches = 0
-            for b0 in range(0, len(mine), self.batch_size):
-                batch = dp.add_negatives(dp.collate_train_device(dstore, mine_t[b0:b0 + self.batch_size]))
-                ops.RNG.next_step()
-                opt.zero_grad()
-                loss = lm.training_loss(batch)
-                loss.backward()
-                opt.step(world)
-                total += loss.detach()
+            while loop.batches_left() > 0:
+                total += loop.step().detach()
                 n_batches += 1
             rec = {"epoch": epoch, self.train_loss_name: float(total) / max(n_batches, 1)}
             if val_store is not None:

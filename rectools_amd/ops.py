@@ -23,9 +23,16 @@ LOSS_BCE, LOSS_GBCE, LOSS_SAMPLED_SOFTMAX = 0, 1, 2
 _TIMING: tp.Optional[tp.Dict[str, tp.List[tp.Tuple[torch.cuda.Event, torch.cuda.Event, tp.Any]]]] = None
 
 
-def start_timing() -> None:
-    global _TIMING
+_TIMING_SINGLE_STREAM = True
+
+
+def start_timing(single_stream: bool = True) -> None:
+    """Record a HIP event pair around every `rt_*` launch, on the stream it is launched on.  single_stream=True also
+    routes the weight-gradient products to the main stream (undisturbed kernel durations); False keeps the side stream
+    of the product configuration (durations then include the overlap with the main stream's kernels)."""
+    global _TIMING, _TIMING_SINGLE_STREAM
     _TIMING = {}
+    _TIMING_SINGLE_STREAM = single_stream
 
 
 def stop_timing() -> tp.Dict[str, tp.List[tp.Tuple[float, tp.Any]]]:
@@ -92,7 +99,7 @@ _SIDE_DIRTY: tp.Set[torch.device] = set()
 def _side_enabled() -> bool:
     import os
 
-    return os.environ.get("RT_SIDE_STREAM", "1") != "0" and _TIMING is None   # per-call timing needs one stream
+    return os.environ.get("RT_SIDE_STREAM", "1") != "0" and (_TIMING is None or not _TIMING_SINGLE_STREAM)
 
 
 def _steals_grad(*params: tp.Optional[torch.Tensor]) -> bool:

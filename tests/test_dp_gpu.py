@@ -22,10 +22,10 @@ def _free_port():
 
 def _worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    sys.path.insert(0, ROOT)
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    import bench
+    import helpers_dp as bench
     from rectools_amd import lightning as hl
     from rectools_amd import ops
 
@@ -106,3 +106,56 @@ def test_two_rank_recommend_shards_users_and_matches_single_process(tmp_path):
     world = 2
     mp.spawn(_reco_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"reco_ok{r}.npy").exists() for r in range(world))
+
+
+def _nccl_worker(rank, world, port, out_dir):
+    """The RCCL code path itself: `init_process_group("nccl", device_id=...)` as bench.py does it, parameter broadcast, the
+    packed-gradient all-reduce, the flat Adam kernel on the reduced buffer, barrier, teardown — one rank per visible GPU
+    (a single rank on the one-GPU test box: the collectives still go through RCCL's stream and launch machinery)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    import helpers_dp
+    from rectools_amd import lightning as hl
+    from rectools_amd import ops
+
+    V, d, H, nb, L, B, n_neg = 300, 64, 2, 2, 24, 16, 8
+    lm = helpers_dp.make_sasrec(V, d, H, nb, L, 0.1, "sampled_softmax", n_neg, device=f"cuda:{rank}")
+    lm.train()
+    opt = hl.FlatAdam(lm.torch_model, lr=1e-2)
+    opt.broadcast_parameters(force=True)
+    p0 = {n: p.detach().clone() for n, p in lm.torch_model.named_parameters()}
+    with torch.cuda.device(rank):
+        batch = helpers_dp.make_train_batches(1, B, L, V, n_neg, rank)[0]
+    losses = []
+    for it in range(3):                                   # several steps: the side-stream join / RCCL stream ordering repeats
+        ops.RNG.next_step()
+        opt.zero_grad()
+        loss = lm.training_loss(batch)
+        loss.backward()
+        if it == 0:
+            local = {n: p.grad.detach().clone() for n, p in lm.torch_model.named_parameters()}
+        opt.step(world, flat=True)
+        losses.append(float(loss.detach()))
+        if it == 0:
+            torch.cuda.synchronize()
+            for n, p in lm.torch_model.named_parameters():
+                g = local[n].clone()
+                dist.all_reduce(g)
+                g /= world
+                want = p0[n] - 1e-2 * g / (g.abs() + 1e-8)
+                torch.testing.assert_close(p.detach(), want, rtol=2e-4, atol=2e-6, msg=lambda m, n=n: f"{n}: {m}")
+    assert losses[2] < losses[0], losses                  # same batch three times: the loss must go down
+    t = torch.tensor([float(rank + 1)], device=f"cuda:{rank}")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)              # bench.py's max-over-ranks
+    assert float(t) == world
+    dist.barrier()
+    np.save(os.path.join(out_dir, f"nccl_ok{rank}.npy"), np.ones(1))
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_step_on_every_visible_gpu(tmp_path):
+    world = min(torch.cuda.device_count(), 2)
+    mp.spawn(_nccl_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"nccl_ok{r}.npy").exists() for r in range(world))
