@@ -61,6 +61,7 @@ struct TopkArgs {
   int resume;                    // 1: lists already hold entries from an earlier phase
   int rotate;
   int debug;  // ablation switch (RT_TOPK_DEBUG): 1 = skip selection
+  int list_base;                 // 16-user tile: merged list of workgroup sx is list `list_base + sx`
 };
 
 __device__ __forceinline__ bool better(float s, long long p, float s2, long long p2) {
@@ -374,7 +375,6 @@ __global__ __launch_bounds__(NTHREADS) void topk_staged_kernel(TopkArgs a) {
   const int user0 = blockIdx.y * UB;
 
   const int n_chunks = (a.d + KC - 1) / KC;
-  const int rot = a.rotate ? (int)((blockIdx.x * 5u + blockIdx.y * 3u) % (unsigned)n_chunks) : 0;
 
   const int list_id = blockIdx.x * LISTS_PER_WG + wave * 2 + half;
   SelState<TU, false> st;
@@ -400,6 +400,9 @@ __global__ __launch_bounds__(NTHREADS) void topk_staged_kernel(TopkArgs a) {
 
   for (long long blk = a.blk_begin + blockIdx.x; blk < a.blk_end && (int)blockIdx.x < S; blk += S) {
     const long long pos0 = blk * IB;
+    // chunk order rotated by the ITEM BLOCK (not by the workgroup): concurrent workgroups still start on different
+    // 128-byte columns, and the k order in which a score is summed no longer depends on the launch geometry
+    const int rot = a.rotate ? (int)((unsigned long long)(blk * 5) % (unsigned)n_chunks) : 0;
     const float* irow[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -551,7 +554,7 @@ __global__ __launch_bounds__(NTHREADS + NLD * 64) void topk_stream_kernel(TopkAr
 
   const long long n_blocks = a.blk_end - a.blk_begin;
   const int n_chunks = a.d / KC;
-  const int rot = a.rotate ? (int)((blockIdx.x * 5u + blockIdx.y * 3u) % (unsigned)n_chunks) : 0;
+  int rot = 0;   // chunk rotation of the block being ISSUED: a function of the item block only (see topk_staged_kernel)
   const long long my_blocks = ((int)blockIdx.x < S && n_blocks > blockIdx.x) ? (n_blocks - blockIdx.x + S - 1) / S : 0;
   const long long T = my_blocks * n_chunks;  // flattened (block, chunk) steps of this workgroup
 
@@ -593,6 +596,7 @@ __global__ __launch_bounds__(NTHREADS + NLD * 64) void topk_stream_kernel(TopkAr
   const float* i_src[IPI];
   auto set_item_rows = [&](long long blk_local) {
     const long long pos0 = (a.blk_begin + blockIdx.x + blk_local * S) * IB;
+    rot = a.rotate ? (int)((unsigned long long)((a.blk_begin + blockIdx.x + blk_local * S) * 5) % (unsigned)n_chunks) : 0;
     long long p[IPI];
 #pragma unroll
     for (int j = 0; j < IPI; ++j) {
@@ -855,6 +859,431 @@ __global__ __launch_bounds__(NT_MERGE) void topk_seed_kernel(MergeArgs m, unsign
   if (tid == 0) atomicMax(gthr + u, f32_to_key(prev_s));
 }
 
+// ------------------------------------------------------------------------------------------------
+// Engine 3: the 16-USER tile — the HBM-bound regime of the exact fp32 formulation.
+//
+// With 32 users per catalog pass the LDS-DMA ring (1.66 ms for 10.24 GB) and the exact-fp32 MFMA work (1.8 ms) are equally
+// long and contend (2.6-2.8 ms together).  Scoring 16 users per pass with v_mfma_f32_16x16x4_f32 halves the matrix work
+// per byte streamed (AI = 8 flop/B, half the fp32 ridge), so the pass is bound by HBM alone.  Same ring, same swizzle,
+// same dedicated loader waves as engine 2; what changes:
+//   * MFMA roles: A = 16 items x 4 k, B = 4 k x 16 users; lane l feeds A[item l&15][k] and B[k][user l&15] for
+//     k = 16s + 4(l>>4) + t, t = 0..3 — again ONE ds_read_b128 per operand and lane for 4 MFMA steps (conflict-free under the
+//     ring's XOR swizzle for the b128 lane groups of gfx950).  A compute wave owns 32 item rows = 2 accumulators.
+//   * D layout: lane l holds user l&15, item rows 4(l>>4) + r of each 16-row sub-tile: 8 scores of ONE user per lane, so
+//     selection stays lane-local; a workgroup keeps 16 lists per user (4 waves x 4 lane groups) in LDS.
+//   * the user tile is 2 KiB per stage instead of 4, which buys a 7-stage ring next to the lists (one workgroup per CU).
+//   * each workgroup MERGES its 16 lists per user into one k-entry list before it leaves (LDS, wave-level argmax rounds):
+//     the seed / final selection kernels then see S lists per user instead of 16 S, and run in microseconds
+//     (topk_select_kernel) — at a 1.8 ms pass the old 80 + 65 us seed and merge kernels were 8 % of the call.
+//   * no `resume`: the seeding prefix (2 item blocks per workgroup, all workgroups) keeps its own merged lists, which
+//     simply take part in the final selection next to the main pass's lists.
+// Scores are the same k-ordered fmaf chains up to association: (k, k+4, k+8, k+12) per MFMA here, (k, k+4) in engine 2.
+// ------------------------------------------------------------------------------------------------
+constexpr int UB16 = 16;          // users per tile
+constexpr int LISTS16 = 16;       // lists per workgroup and user: 4 compute waves x 4 lane groups
+constexpr int SG16 = 128;         // shared-bound copy (uints) per stage, two 64-lane dword pieces
+constexpr int STAGE16 = IB * KC + UB16 * KC + SG16;   // floats per ring stage
+
+inline size_t stream16_lds_bytes(int ns, int k) {
+  const int kp = (k + 3) & ~3;
+  return (size_t)ns * STAGE16 * sizeof(float) + (size_t)LISTS16 * UB16 * kp * 8 + (size_t)LISTS16 * UB16 * 4;
+}
+
+struct Sel16 {
+  typedef ListTypes<true>::fptr fptr;
+  typedef ListTypes<true>::iptr iptr;
+  float worst_s; long long worst_p; int worst_slot; int cnt; float thr; float g_seen;
+  fptr ls; iptr lp;
+  long long fbase; int flg;
+};
+
+__device__ __forceinline__ void select_block16(const TopkArgs& a, Sel16& st, const f32x4 (&acc)[2], const float (&nrm_i)[2],
+                                               float nrm_u, long long pos0, int user0, int lane, int wave,
+                                               const unsigned* g_lds) {
+  const int col = lane & 15, grp = lane >> 4;
+  const bool need_norm = a.distance != DIST_DOT;
+  float ni_full[2] = {0.f, 0.f}, nu_full = 0.f, inv_u = 1.f;
+  if (need_norm) {   // lanes c, c+16, c+32, c+48 hold the four k-quarters of row / user c
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      float v = nrm_i[it];
+      v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+      ni_full[it] = v;
+    }
+    float v = nrm_u;
+    v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    nu_full = v;
+    inv_u = 1.0f / fmaxf(sqrtf(nu_full), 1e-8f);
+  }
+  const int u = user0 + col;
+  const bool uvalid = u < a.n_users;
+  if (uvalid) {  // refresh from the shared per-user bound (LDS copy brought in by the DMA ring)
+    const float g = key_to_f32(g_lds[col]);
+    st.g_seen = fmaxf(st.g_seen, g);
+    st.thr = fmaxf(st.thr, g);
+  }
+  float sc[8];
+  unsigned cmask = 0;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = it * 16 + 4 * grp + r;
+      float s = acc[it][r];
+      if (need_norm) {
+        const float ni = __shfl(ni_full[it], 4 * grp + r, 64);   // lane (row & 15) holds that row's norm
+        if (a.distance == DIST_COSINE) s = s * inv_u * (1.0f / fmaxf(sqrtf(ni), 1e-8f));
+        else s = -sqrtf(fmaxf(nu_full + ni - 2.0f * s, 0.f));
+      }
+      sc[it * 4 + r] = s;
+      const long long p = pos0 + wave * 32 + row;
+      if (uvalid && p < a.n_cand && s >= st.thr) cmask |= (1u << (it * 4 + r));
+    }
+  }
+  if (__any(cmask != 0)) {
+    const Sel16::fptr lsc = st.ls; const Sel16::iptr lps = st.lp;
+    while (cmask != 0) {
+      const int q = __ffs(cmask) - 1;
+      cmask &= cmask - 1;
+      float s = sc[0];
+#pragma unroll
+      for (int i = 1; i < 8; ++i) s = (q == i) ? sc[i] : s;  // static-index select: no scratch
+      const int row = (q >> 2) * 16 + 4 * grp + (q & 3);
+      const long long p = pos0 + wave * 32 + row;
+      if (!(s >= st.thr)) continue;  // threshold may have risen inside this loop
+      const bool take = (st.cnt < a.k) || better(s, p, st.worst_s, st.worst_p);
+      if (!take) continue;
+      const long long cid = a.whitelist ? a.whitelist[p] : p + a.id_offset;
+      if (a.filt_hash != nullptr) {
+        bool hit = false;
+        if (st.flg >= 0) {
+          const int* tab = a.filt_hash + st.fbase;
+          const unsigned mask = (1u << st.flg) - 1u;
+          unsigned h = filt_hash_of((unsigned)cid, st.flg);
+          for (;;) {
+            const int v = tab[h];
+            if (v == (int)cid) { hit = true; break; }
+            if (v < 0) break;
+            h = (h + 1) & mask;
+          }
+        }
+        if (hit) continue;
+      } else if (is_filtered(a, u, cid)) continue;
+      if (st.cnt < a.k) {
+        lsc[st.cnt] = s; lps[st.cnt] = (int)p; st.cnt += 1;
+      } else {
+        lsc[st.worst_slot] = s; lps[st.worst_slot] = (int)p;
+      }
+      if (st.cnt == a.k) {  // list full: (re)locate its worst entry (whole list in flight, then a register scan)
+        typedef __attribute__((address_space(3))) f32x4* fptr4;
+        typedef __attribute__((address_space(3))) i32x4* iptr4;
+        const int kp = (a.k + 3) & ~3;
+        f32x4 sv[K_LDS_LISTS / 4]; i32x4 pv[K_LDS_LISTS / 4];
+#pragma unroll
+        for (int j = 0; j < K_LDS_LISTS / 4; ++j)
+          if (4 * j < kp) { sv[j] = *((fptr4)lsc + j); pv[j] = *((iptr4)lps + j); }
+        float ws = INFINITY; long long wp = -1; int wslot = 0;
+#pragma unroll
+        for (int j = 0; j < K_LDS_LISTS / 4; ++j)
+          if (4 * j < kp) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float es = sv[j][i]; const long long ep = pv[j][i];
+              if (4 * j + i < a.k && ((4 * j + i == 0) || better(ws, wp, es, ep))) { ws = es; wp = ep; wslot = 4 * j + i; }
+            }
+          }
+        st.worst_s = ws; st.worst_p = wp; st.worst_slot = wslot;
+        st.thr = fmaxf(st.thr, ws);
+      }
+    }
+    if (st.cnt == a.k && st.worst_s > st.g_seen) {   // publish at most once per block and list
+      atomicMax(a.gthr + u, f32_to_key(st.worst_s));
+      st.g_seen = st.worst_s;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // leave the slow path with an empty VMEM scoreboard (see select_block)
+  }
+}
+
+template <int NS, bool WL>
+__global__ __launch_bounds__(NTHREADS + 128) void topk_stream16_kernel(TopkArgs a) {
+  constexpr int IPI = 8;                 // item pieces per loader and stage (16 pieces of 8 rows)
+  constexpr int SA = IB * KC, SU = UB16 * KC;
+  constexpr int NL = IPI + 1 + 1;        // LDS-DMA instructions per loader and stage: items, one user piece, the bound copy
+  static_assert(NL * (NS - 2) < 64, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [NS][STAGE16] | list scores | list positions | counts
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 15, grp = lane >> 4;
+  const int S = a.n_seg;
+  const int user0 = blockIdx.y * UB16;
+  const int kp = (a.k + 3) & ~3;
+
+  const long long n_blocks = a.blk_end - a.blk_begin;
+  const int n_chunks = a.d / KC;
+  const long long my_blocks = ((int)blockIdx.x < S && n_blocks > blockIdx.x) ? (n_blocks - blockIdx.x + S - 1) / S : 0;
+  const long long T = my_blocks * n_chunks;
+
+  const bool issuer = wave >= 4;
+  const int iw = wave - 4;
+  const int cwave = issuer ? 0 : wave;
+  float* const lists_s = smem + NS * STAGE16;                            // [16 lists][16 users][kp]
+  int* const lists_p = reinterpret_cast<int*>(lists_s + LISTS16 * UB16 * kp);
+  int* const lists_c = lists_p + LISTS16 * UB16 * kp;                    // [16 lists][16 users]
+  const long long out_list = (long long)(a.list_base + blockIdx.x) * a.n_users_pad;
+
+  if (T == 0) {   // no item block for this workgroup in this launch: its merged lists are empty
+    if (tid < UB16) a.list_counts[out_list + user0 + tid] = 0;
+    return;
+  }
+
+  if (issuer) {
+    // ---- loader waves: keep the ring full, one barrier per chunk in step with the compute waves ----
+    const int l_row8 = lane >> 3, l_slot = lane & 7;
+    int i_row[IPI]; int i_colofs[IPI];
+#pragma unroll
+    for (int j = 0; j < IPI; ++j) {
+      i_row[j] = (iw * IPI + j) * 8 + l_row8;
+      i_colofs[j] = (l_slot ^ ((i_row[j] >> 1) & 7)) * 4;
+    }
+    const int u_row = iw * 8 + l_row8;
+    int uu = user0 + u_row;
+    if (uu >= a.n_users) uu = a.n_users - 1;    // clamp: padded user columns are never selected
+    const long long usrc = a.user_rows ? a.user_rows[uu] : (long long)uu;
+    const float* u_src = a.users + usrc * a.user_stride + (l_slot ^ ((u_row >> 1) & 7)) * 4;
+    int g_idx = user0 + lane;
+    if (g_idx >= a.n_users_pad) g_idx = a.n_users_pad - 1;
+    const unsigned* g_src = a.gthr + g_idx;
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+
+    const float* i_src[IPI];
+    int rot = 0;
+    auto set_item_rows = [&](long long blk_local) {
+      const long long blk = a.blk_begin + blockIdx.x + blk_local * S;
+      rot = a.rotate ? (int)((unsigned long long)(blk * 5) % (unsigned)n_chunks) : 0;
+      long long p[IPI];
+#pragma unroll
+      for (int j = 0; j < IPI; ++j) {
+        p[j] = blk * IB + i_row[j];
+        if (p[j] >= a.n_cand) p[j] = a.n_cand - 1;  // clamp: rows past the end are masked at selection
+      }
+      if (WL) {   // whitelist indirection through inline asm with its own wait (see topk_stream_kernel)
+#pragma unroll
+        for (int j0 = 0; j0 < IPI; j0 += 4) {
+          long long s0, s1, s2, s3;
+          asm volatile(
+              "global_load_dwordx2 %0, %4, off\n\tglobal_load_dwordx2 %1, %5, off\n\t"
+              "global_load_dwordx2 %2, %6, off\n\tglobal_load_dwordx2 %3, %7, off\n\ts_waitcnt vmcnt(0)"
+              : "=&v"(s0), "=&v"(s1), "=&v"(s2), "=&v"(s3)
+              : "v"(a.whitelist + p[j0]), "v"(a.whitelist + p[j0 + 1]), "v"(a.whitelist + p[j0 + 2]), "v"(a.whitelist + p[j0 + 3])
+              : "memory");
+          p[j0] = s0; p[j0 + 1] = s1; p[j0 + 2] = s2; p[j0 + 3] = s3;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < IPI; ++j) i_src[j] = a.items + p[j] * a.item_stride + i_colofs[j];
+    };
+    long long iss_blk = 0, issued = 0; int iss_c = 0, iss_stage = 0;
+    set_item_rows(0);
+    auto issue_next = [&]() {
+      int cc = iss_c + rot; if (cc >= n_chunks) cc -= n_chunks;
+      const unsigned sbase = smem_base + (unsigned)(iss_stage * STAGE16 * 4);
+      const int kofs = cc * KC;
+#pragma unroll
+      for (int j = 0; j < IPI; ++j) dma16(i_src[j] + kofs, sbase + (unsigned)((iw * IPI + j) * 8 * KC * 4));
+      dma16(u_src + kofs, sbase + (unsigned)((SA + iw * 8 * KC) * 4));
+      dma4(g_src, sbase + (unsigned)((SA + SU + iw * 64) * 4));
+      iss_stage = (iss_stage + 1 == NS) ? 0 : iss_stage + 1;
+      ++issued; ++iss_c;
+      if (iss_c == n_chunks) { iss_c = 0; ++iss_blk; if (iss_blk < my_blocks) set_item_rows(iss_blk); }
+    };
+#pragma unroll 1
+    for (int s = 0; s < NS - 1; ++s) if (issued < T) issue_next();
+#pragma unroll 1
+    for (long long g = 0; g < T; ++g) {
+      if (issued - g == NS - 1) wait_vmcnt<NL*(NS - 2)>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();   // chunk g is in LDS; the compute waves are done with chunk g-1
+      asm volatile("" ::: "memory");
+      if (issued < T) issue_next();
+    }
+  } else {
+    // ---- compute waves ----
+    Sel16 st;
+    st.worst_s = -INFINITY; st.worst_p = -1; st.worst_slot = 0; st.cnt = 0; st.thr = -INFINITY; st.g_seen = -INFINITY;
+    {
+      const int L = ((cwave * 4 + grp) * UB16 + col) * kp;
+      st.ls = (Sel16::fptr)lists_s + L;
+      st.lp = (Sel16::iptr)lists_p + L;
+      for (int e = a.k; e < kp; ++e) { st.ls[e] = INFINITY; st.lp[e] = -1; }
+      st.fbase = 0; st.flg = -1;
+      const int u = user0 + col;
+      if (a.filt_hash != nullptr && u < a.n_users) {
+        const long long lo = a.filt_indptr[u], hi = a.filt_indptr[u + 1];
+        if (hi > lo) { st.fbase = 4 * lo + 4 * (long long)(u + a.filt_u0); st.flg = filt_hash_lg(hi - lo); }
+      }
+    }
+    f32x4 acc[2];
+    float nrm_i[2] = {0.f, 0.f}; float nrm_u = 0.f;
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[it][r] = 0.f;
+    // fragment read offsets (swizzled): item rows cwave*32 + it*16 + col, user row col; 16-byte slot 4s + grp
+    int a_off[2], a_swz[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int row = cwave * 32 + it * 16 + col;
+      a_off[it] = row * KC; a_swz[it] = (row >> 1) & 7;
+    }
+    const int u_off = SA + col * KC, u_swz = (col >> 1) & 7;
+    const bool need_norm = a.distance != DIST_DOT;
+
+    int cons_stage = 0;
+#pragma unroll 1
+    for (long long blk_local = 0; blk_local < my_blocks; ++blk_local) {
+      const unsigned* g_lds = nullptr;
+#pragma unroll 1
+      for (int c = 0; c < n_chunks; ++c) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const float* sbase = smem + cons_stage * STAGE16;
+        cons_stage = (cons_stage + 1 == NS) ? 0 : cons_stage + 1;
+        g_lds = reinterpret_cast<const unsigned*>(sbase + SA + SU);
+#pragma unroll
+        for (int s = 0; s < KC / 16; ++s) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(sbase + u_off + (((4 * s + grp) ^ u_swz) << 2));
+          const f32x4 av0 = *reinterpret_cast<const f32x4*>(sbase + a_off[0] + (((4 * s + grp) ^ a_swz[0]) << 2));
+          const f32x4 av1 = *reinterpret_cast<const f32x4*>(sbase + a_off[1] + (((4 * s + grp) ^ a_swz[1]) << 2));
+          if (need_norm) {   // wave-uniform: dot products skip the row-norm arithmetic
+            nrm_u += bv[0] * bv[0] + bv[1] * bv[1] + bv[2] * bv[2] + bv[3] * bv[3];
+            nrm_i[0] += av0[0] * av0[0] + av0[1] * av0[1] + av0[2] * av0[2] + av0[3] * av0[3];
+            nrm_i[1] += av1[0] * av1[0] + av1[1] * av1[1] + av1[2] * av1[2] + av1[3] * av1[3];
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {   // two independent accumulators alternate: the 40-cycle dependent latency is hidden
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[t], bv[t], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[t], bv[t], acc[1], 0, 0, 0);
+          }
+        }
+      }
+      const long long pos0 = (a.blk_begin + blockIdx.x + blk_local * S) * IB;
+      select_block16(a, st, acc, nrm_i, nrm_u, pos0, user0, lane, cwave, g_lds);
+      nrm_i[0] = nrm_i[1] = 0.f; nrm_u = 0.f;
+#pragma unroll
+      for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[it][r] = 0.f;
+    }
+    lists_c[(cwave * 4 + grp) * UB16 + col] = st.cnt;
+  }
+
+  // ---- workgroup-level merge: 16 lists per user -> ONE list of <= k entries, best first, into the global list array ----
+  __syncthreads();
+  if (issuer) return;
+  for (int uu = 0; uu < 4; ++uu) {
+    const int ul = cwave * 4 + uu;               // user handled by this wave in this round
+    const int u = user0 + ul;
+    if (u >= a.n_users_pad) break;
+    const int list = lane >> 2, q4 = lane & 3;  // lane -> (list, quarter of its kp entries)
+    const int cnt = lists_c[list * UB16 + ul];
+    const int epl = kp >> 2;                    // entries per lane (kp <= 16 -> <= 4)
+    float es[4]; long long ep[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = q4 * epl + j;
+      const bool ok = j < epl && e < cnt;
+      es[j] = ok ? lists_s[(list * UB16 + ul) * kp + e] : -INFINITY;
+      ep[j] = ok ? (long long)lists_p[(list * UB16 + ul) * kp + e] : 0x7fffffffffffffffLL;
+    }
+    int n_out = 0;
+    for (int r = 0; r < a.k; ++r) {
+      float bs = -INFINITY; long long bp = 0x7fffffffffffffffLL;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (better(es[j], ep[j], bs, bp)) { bs = es[j]; bp = ep[j]; }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float os = __shfl_xor(bs, o, 64); const long long op = __shfl_xor(bp, o, 64);
+        if (better(os, op, bs, bp)) { bs = os; bp = op; }
+      }
+      if (bp == 0x7fffffffffffffffLL) break;    // wave-uniform: nothing left
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (ep[j] == bp) { es[j] = -INFINITY; ep[j] = 0x7fffffffffffffffLL; }   // positions are unique: exactly one entry leaves
+      if (lane == 0 && u < a.n_users) {
+        a.list_scores[(out_list + u) * a.k + r] = bs;
+        a.list_pos[(out_list + u) * a.k + r] = (int)bp;
+      }
+      ++n_out;
+    }
+    if (lane == 0) a.list_counts[out_list + u] = (u < a.n_users) ? n_out : 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Selection over the merged per-workgroup lists (16-user path): one workgroup of 256 threads per user, every thread holds
+// LPT whole lists in registers (one round of loads), then k rounds of block-wide arg-best.  SEED: publish the k-th best of
+// the seeding prefix as the shared bound; otherwise write the final (id, score) rows, best first, ties to the lower position.
+// ------------------------------------------------------------------------------------------------
+template <int LPT, bool SEED>
+__global__ __launch_bounds__(256) void topk_select_kernel(MergeArgs m, int first_list, int n_lists, unsigned* gthr) {
+  const int u = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ float s_ws[2][4]; __shared__ long long s_wp[2][4];
+  float es[LPT][K_LDS_LISTS]; int ep[LPT][K_LDS_LISTS];   // positions < 2^31 - 1 (rt_topk_score refuses larger catalogs)
+#pragma unroll
+  for (int j = 0; j < LPT; ++j) {
+    const int l = tid + j * 256;
+    const int c = l < n_lists ? m.list_counts[(long long)(first_list + l) * m.n_users_pad + u] : 0;
+    const long long lb = ((long long)(first_list + l) * m.n_users_pad + u) * m.k;
+#pragma unroll
+    for (int e = 0; e < K_LDS_LISTS; ++e) {
+      const bool ok = e < c;
+      es[j][e] = ok ? m.list_scores[lb + e] : -INFINITY;
+      ep[j][e] = ok ? m.list_pos[lb + e] : 0x7fffffff;
+    }
+  }
+  int n_out = 0;
+  float last_s = -INFINITY;
+  for (int r = 0; r < m.k; ++r) {
+    float bs = -INFINITY; long long bp = 0x7fffffffffffffffLL;
+#pragma unroll
+    for (int j = 0; j < LPT; ++j)
+#pragma unroll
+      for (int e = 0; e < K_LDS_LISTS; ++e)
+        if (ep[j][e] != 0x7fffffff && better(es[j][e], ep[j][e], bs, bp)) { bs = es[j][e]; bp = ep[j][e]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float os = __shfl_xor(bs, o, 64); const long long op = __shfl_xor(bp, o, 64);
+      if (better(os, op, bs, bp)) { bs = os; bp = op; }
+    }
+    if (lane == 0) { s_ws[r & 1][wave] = bs; s_wp[r & 1][wave] = bp; }
+    __syncthreads();
+    bs = s_ws[r & 1][0]; bp = s_wp[r & 1][0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (better(s_ws[r & 1][w], s_wp[r & 1][w], bs, bp)) { bs = s_ws[r & 1][w]; bp = s_wp[r & 1][w]; }
+    if (bp == 0x7fffffffffffffffLL) break;   // block-uniform: fewer than k candidates
+#pragma unroll
+    for (int j = 0; j < LPT; ++j)
+#pragma unroll
+      for (int e = 0; e < K_LDS_LISTS; ++e)
+        if ((long long)ep[j][e] == bp) { es[j][e] = -INFINITY; ep[j][e] = 0x7fffffff; }
+    if (!SEED && tid == 0) {
+      m.out_ids[(long long)u * m.k + r] = m.whitelist ? m.whitelist[bp] : bp + m.id_offset;
+      m.out_scores[(long long)u * m.k + r] = (m.distance == DIST_EUCLID) ? -bs : bs;
+    }
+    last_s = bs;
+    ++n_out;
+  }
+  if (tid == 0) {
+    if (SEED) { if (n_out == m.k) atomicMax(gthr + u, f32_to_key(last_s)); }
+    else m.out_counts[u] = n_out;
+  }
+}
+
 __global__ void fill_u32_kernel(unsigned* p, unsigned v, long long n) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -998,6 +1427,79 @@ int launch_stream_any(int tu, int ns, const TopkArgs& a, dim3 grid, bool ll, hip
   return launch_stream_ns<4>(ns, a, grid, ll, stream);
 }
 
+// ---- 16-user tile: plan and launch -------------------------------------------------------------------------------
+struct Plan16 {
+  int S, n_tiles, n_users_pad, users_per_launch, ns;
+  long long seed_blocks;     // item blocks of the seeding prefix (2 per workgroup), 0 = single phase
+  size_t o_gthr, o_scores, o_pos, o_counts, total;
+};
+
+inline bool wants_tile16(int n_users, int k, int users_per_pass) {
+  if (k > K_LDS_LISTS) return false;                       // its lists live in LDS
+  if (users_per_pass > 0) return users_per_pass <= 16;
+  return n_users <= 16;                                    // auto: a launch that fits one 16-user tile is HBM-bound
+}
+
+inline Plan16 make_plan16(int n_users, long long n_cand, int k) {
+  Plan16 P;
+  P.users_per_launch = n_users < MAX_USERS_PER_LAUNCH ? n_users : MAX_USERS_PER_LAUNCH;
+  P.n_tiles = (P.users_per_launch + UB16 - 1) / UB16;
+  P.n_users_pad = P.n_tiles * UB16;
+  const long long n_blocks = (n_cand + IB - 1) / IB;
+  P.ns = 3;
+  for (int ns = 7; ns >= 3; --ns)
+    if (stream16_lds_bytes(ns, k) <= LDS_PER_CU) { P.ns = ns; break; }
+  const int ns_env = env_int("RT_TOPK_STAGES", 0);
+  if (ns_env >= 3 && ns_env <= 7 && stream16_lds_bytes(ns_env, k) <= LDS_PER_CU) P.ns = ns_env;
+  long long S = ((long long)rt_num_cus() + P.n_tiles - 1) / P.n_tiles;   // one workgroup per CU owns the whole LDS
+  if (S > n_blocks) S = n_blocks;
+  if (S < 1) S = 1;
+  if (S > 512) S = 512;                                    // topk_select_kernel holds <= 4 x 256 lists per user
+  P.S = (int)S;
+  P.seed_blocks = 0;
+  if (env_int("RT_TOPK_SEED", 1) != 0 && n_blocks >= 32 * S && P.n_tiles <= 16) P.seed_blocks = 2 * S;
+  size_t o = 0;
+  P.o_gthr = o; o = align_up(o + (size_t)P.n_users_pad * 4, 256);
+  const size_t ent = (size_t)2 * P.S * P.n_users_pad * (size_t)k;     // list region of the main pass + of the seeding prefix
+  P.o_scores = o; o = align_up(o + ent * 4, 256);
+  P.o_pos = o; o = align_up(o + ent * 4, 256);
+  P.o_counts = o; o = align_up(o + (size_t)2 * P.S * P.n_users_pad * 4, 256);
+  P.total = o;
+  return P;
+}
+
+template <int NS, bool WL>
+int launch_stream16_t(const TopkArgs& a, dim3 grid, hipStream_t stream) {
+  const size_t lds = stream16_lds_bytes(NS, a.k);
+  static size_t attr_lds = 0;
+  if (lds > 64 * 1024 && lds > attr_lds) {
+    RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_stream16_kernel<NS, WL>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_lds = lds;
+  }
+  topk_stream16_kernel<NS, WL><<<grid, NTHREADS + 128, lds, stream>>>(a);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+template <bool WL>
+int launch_stream16_ns(int ns, const TopkArgs& a, dim3 grid, hipStream_t stream) {
+  switch (ns) {
+    case 3: return launch_stream16_t<3, WL>(a, grid, stream);
+    case 4: return launch_stream16_t<4, WL>(a, grid, stream);
+    case 5: return launch_stream16_t<5, WL>(a, grid, stream);
+    case 6: return launch_stream16_t<6, WL>(a, grid, stream);
+    default: return launch_stream16_t<7, WL>(a, grid, stream);
+  }
+}
+template <bool SEED>
+int launch_select(const MergeArgs& m, int first_list, int n_lists, unsigned* gthr, int n_users, hipStream_t stream) {
+  if (n_lists <= 256) topk_select_kernel<1, SEED><<<n_users, 256, 0, stream>>>(m, first_list, n_lists, gthr);
+  else if (n_lists <= 512) topk_select_kernel<2, SEED><<<n_users, 256, 0, stream>>>(m, first_list, n_lists, gthr);
+  else topk_select_kernel<4, SEED><<<n_users, 256, 0, stream>>>(m, first_list, n_lists, gthr);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
 template <int TU>
 int launch_staged(const TopkArgs& a, dim3 grid, hipStream_t stream) {
   constexpr int UB = 32 * TU;
@@ -1020,7 +1522,12 @@ extern "C" {
 size_t rt_topk_workspace_bytes(int32_t n_users, int64_t n_candidates, int32_t k, int32_t users_per_pass) {
   if (n_users <= 0 || n_candidates <= 0 || k <= 0) return 256;
   long long kk = k < n_candidates ? k : n_candidates;
-  return make_plan(n_users, n_candidates, (int)kk, users_per_pass).total;
+  size_t need = make_plan(n_users, n_candidates, (int)kk, users_per_pass).total;   // also the fallback when d % 32 != 0
+  if (wants_tile16(n_users, (int)kk, users_per_pass)) {
+    const size_t need16 = make_plan16(n_users, n_candidates, (int)kk).total;
+    if (need16 > need) need = need16;
+  }
+  return need;
 }
 
 // bytes of the per-user hash tables over a filter CSR with `nnz` indices
@@ -1058,12 +1565,67 @@ static int topk_score_impl(const float* users, int64_t user_stride, const int64_
   if (n_candidates == 0) {
     return hipMemsetAsync(out_counts, 0, sizeof(int32_t) * (size_t)n_users, stream) == hipSuccess ? RT_OK : RT_ERR_LAUNCH;
   }
+  const int impl = env_int("RT_TOPK_IMPL", 2);
+  const bool stream_ok = bf16 || ((impl == 2) && (d % KC == 0));
+  char* ws = reinterpret_cast<char*>(workspace);
+  if (!bf16 && stream_ok && wants_tile16(n_users, k, users_per_pass)) {
+    // ---- 16-user tile (engine 3): [seeding prefix -> seed] -> main pass -> selection over the merged lists ----
+    const Plan16 Q = make_plan16(n_users, n_candidates, k);
+    if (workspace == nullptr || workspace_bytes < Q.total) return RT_ERR_WORKSPACE;
+    const long long n_blocks = (n_candidates + IB - 1) / IB;
+    for (int u0 = 0; u0 < n_users; u0 += Q.users_per_launch) {
+      const int nb = (n_users - u0) < Q.users_per_launch ? (n_users - u0) : Q.users_per_launch;
+      const int n_tiles = (nb + UB16 - 1) / UB16;
+      TopkArgs a{};
+      a.users = user_rows ? users : users + (long long)u0 * user_stride;
+      a.user_stride = user_stride;
+      a.user_rows = user_rows ? reinterpret_cast<const long long*>(user_rows) + u0 : nullptr;
+      a.n_users = nb;
+      a.items = items; a.item_stride = item_stride;
+      a.whitelist = reinterpret_cast<const long long*>(whitelist);
+      a.n_cand = n_candidates; a.id_offset = whitelist ? 0 : candidate_id_offset;
+      a.d = d; a.distance = distance; a.k = k;
+      a.filt_indptr = filt_indptr ? reinterpret_cast<const long long*>(filt_indptr) + u0 : nullptr;
+      a.filt_indices = filt_indices;
+      a.filt_hash = filt_indptr ? filt_hash : nullptr; a.filt_u0 = u0;
+      a.list_scores = reinterpret_cast<float*>(ws + Q.o_scores);
+      a.list_pos = reinterpret_cast<int*>(ws + Q.o_pos);
+      a.list_counts = reinterpret_cast<int*>(ws + Q.o_counts);
+      a.n_users_pad = Q.n_users_pad;
+      a.gthr = reinterpret_cast<unsigned*>(ws + Q.o_gthr);
+      a.rotate = env_int("RT_TOPK_ROTATE", 1);
+      a.debug = 0;
+      a.n_seg = Q.S; a.resume = 0;
+      fill_u32_kernel<<<(Q.n_users_pad + 255) / 256, 256, 0, stream>>>(a.gthr, 0x007FFFFFu /* key(-inf) */, Q.n_users_pad);
+      RT_CHECK_LAUNCH();
+      dim3 grid(Q.S, n_tiles);
+      MergeArgs m{};
+      m.list_scores = a.list_scores; m.list_pos = a.list_pos; m.list_counts = a.list_counts;
+      m.n_users_pad = Q.n_users_pad; m.k = k; m.n_users = nb;
+      m.whitelist = a.whitelist; m.id_offset = a.id_offset; m.distance = distance;
+      m.out_ids = reinterpret_cast<long long*>(out_ids) + (long long)u0 * k;
+      m.out_scores = out_scores + (long long)u0 * k;
+      m.out_counts = out_counts + u0;
+      int rc, n_lists = Q.S;
+      if (Q.seed_blocks > 0) {   // seeding prefix: lists [S, 2S); its k-th best per user becomes the shared bound
+        a.blk_begin = 0; a.blk_end = Q.seed_blocks; a.list_base = Q.S;
+        rc = a.whitelist ? launch_stream16_ns<true>(Q.ns, a, grid, stream) : launch_stream16_ns<false>(Q.ns, a, grid, stream);
+        if (rc != RT_OK) return rc;
+        rc = launch_select<true>(m, Q.S, Q.S, a.gthr, nb, stream);
+        if (rc != RT_OK) return rc;
+        n_lists = 2 * Q.S;
+      }
+      a.blk_begin = Q.seed_blocks; a.blk_end = n_blocks; a.list_base = 0;
+      rc = a.whitelist ? launch_stream16_ns<true>(Q.ns, a, grid, stream) : launch_stream16_ns<false>(Q.ns, a, grid, stream);
+      if (rc != RT_OK) return rc;
+      rc = launch_select<false>(m, 0, n_lists, nullptr, nb, stream);
+      if (rc != RT_OK) return rc;
+    }
+    return RT_OK;
+  }
   Plan P = make_plan(n_users, n_candidates, k, users_per_pass);
   if (workspace == nullptr || workspace_bytes < P.total) return RT_ERR_WORKSPACE;
   if (bf16) { P.lds_lists = false; P.ns = bf16_stages(P.tu); }   // the instantiations launch_stream_bf16 carries
-  char* ws = reinterpret_cast<char*>(workspace);
-  const int impl = env_int("RT_TOPK_IMPL", 2);
-  const bool stream_ok = bf16 || ((impl == 2) && (d % KC == 0));
 
   for (int u0 = 0; u0 < n_users; u0 += P.users_per_launch) {
     const int nb = (n_users - u0) < P.users_per_launch ? (n_users - u0) : P.users_per_launch;
@@ -1086,7 +1648,11 @@ static int topk_score_impl(const float* users, int64_t user_stride, const int64_
     a.n_users_pad = P.n_users_pad;
     a.gthr = reinterpret_cast<unsigned*>(ws + P.o_gthr);
     a.rotate = env_int("RT_TOPK_ROTATE", 1);
-    a.debug = env_int("RT_TOPK_DEBUG", 0);
+#ifdef RT_ABLATION_BUILD
+    a.debug = env_int("RT_TOPK_DEBUG", 0);   // 1 = skip selection: only exists in ablation builds (-DRT_ABLATION_BUILD)
+#else
+    a.debug = 0;
+#endif
 
     fill_u32_kernel<<<(P.n_users_pad + 255) / 256, 256, 0, stream>>>(a.gthr, 0x007FFFFFu /* key(-inf) */,
                                                                      P.n_users_pad);
