@@ -61,7 +61,9 @@ struct TopkArgs {
   int resume;                    // 1: lists already hold entries from an earlier phase
   int rotate;
   int debug;  // ablation switch (RT_TOPK_DEBUG): 1 = skip selection
-  int list_base;                 // 16-user tile: merged list of workgroup sx is list `list_base + sx`
+  int list_base;                 // 16-user tile: merged list of workgroup sx is list `list_base + sx` of `n_lists_total`
+  int n_lists_total;             //   merged lists are stored [user][list][k] (a user's lists are contiguous for the selection)
+  int use_bound;                 // 16-user tile: 0 = seeding prefix (the shared bound is neither read nor published)
 };
 
 __device__ __forceinline__ bool better(float s, long long p, float s2, long long p2) {
@@ -917,7 +919,7 @@ __device__ __forceinline__ void select_block16(const TopkArgs& a, Sel16& st, con
   }
   const int u = user0 + col;
   const bool uvalid = u < a.n_users;
-  if (uvalid) {  // refresh from the shared per-user bound (LDS copy brought in by the DMA ring)
+  if (uvalid && a.use_bound) {  // refresh from the shared per-user bound (LDS copy brought in by the DMA ring)
     const float g = key_to_f32(g_lds[col]);
     st.g_seen = fmaxf(st.g_seen, g);
     st.thr = fmaxf(st.thr, g);
@@ -996,7 +998,9 @@ __device__ __forceinline__ void select_block16(const TopkArgs& a, Sel16& st, con
         st.thr = fmaxf(st.thr, ws);
       }
     }
-    if (st.cnt == a.k && st.worst_s > st.g_seen) {   // publish at most once per block and list
+    // publish at most once per block and list.  NOT in the seeding prefix: there every list fills up in its second block,
+    // and 4096 lists x 16 users of atomics on ONE 64-byte line serialise in L2 (200 us for a pass that streams in 30)
+    if (a.use_bound && st.cnt == a.k && st.worst_s > st.g_seen) {
       atomicMax(a.gthr + u, f32_to_key(st.worst_s));
       st.g_seen = st.worst_s;
     }
@@ -1031,10 +1035,10 @@ __global__ __launch_bounds__(NTHREADS + 128) void topk_stream16_kernel(TopkArgs 
   float* const lists_s = smem + NS * STAGE16;                            // [16 lists][16 users][kp]
   int* const lists_p = reinterpret_cast<int*>(lists_s + LISTS16 * UB16 * kp);
   int* const lists_c = lists_p + LISTS16 * UB16 * kp;                    // [16 lists][16 users]
-  const long long out_list = (long long)(a.list_base + blockIdx.x) * a.n_users_pad;
+  const int out_list = a.list_base + blockIdx.x;   // merged list (user u, out_list) lives at [u * n_lists_total + out_list]
 
   if (T == 0) {   // no item block for this workgroup in this launch: its merged lists are empty
-    if (tid < UB16) a.list_counts[out_list + user0 + tid] = 0;
+    if (tid < UB16) a.list_counts[(long long)(user0 + tid) * a.n_lists_total + out_list] = 0;
     return;
   }
 
@@ -1213,47 +1217,51 @@ __global__ __launch_bounds__(NTHREADS + 128) void topk_stream16_kernel(TopkArgs 
       for (int j = 0; j < 4; ++j)
         if (ep[j] == bp) { es[j] = -INFINITY; ep[j] = 0x7fffffffffffffffLL; }   // positions are unique: exactly one entry leaves
       if (lane == 0 && u < a.n_users) {
-        a.list_scores[(out_list + u) * a.k + r] = bs;
-        a.list_pos[(out_list + u) * a.k + r] = (int)bp;
+        a.list_scores[((long long)u * a.n_lists_total + out_list) * a.k + r] = bs;
+        a.list_pos[((long long)u * a.n_lists_total + out_list) * a.k + r] = (int)bp;
       }
       ++n_out;
     }
-    if (lane == 0) a.list_counts[out_list + u] = (u < a.n_users) ? n_out : 0;
+    if (lane == 0) a.list_counts[(long long)u * a.n_lists_total + out_list] = (u < a.n_users) ? n_out : 0;
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Selection over the merged per-workgroup lists (16-user path): one workgroup of 256 threads per user, every thread holds
-// LPT whole lists in registers (one round of loads), then k rounds of block-wide arg-best.  SEED: publish the k-th best of
-// the seeding prefix as the shared bound; otherwise write the final (id, score) rows, best first, ties to the lower position.
+// Selection over the merged per-workgroup lists (16-user path): one workgroup of 256 threads per user.  The user's lists
+// ([list][k], each sorted best first by the workgroup merge) are copied into LDS with coalesced loads; a thread owns the
+// HEADS of up to 4 lists, and each of the k rounds is one block-wide arg-best over the heads (wave shuffles + 4 partials),
+// after which the winning list advances.  SEED: store the k-th best of the seeding prefix as the shared bound (or -inf);
+// otherwise write the final (id, score) rows, best first, ties to the lower position.
 // ------------------------------------------------------------------------------------------------
-template <int LPT, bool SEED>
-__global__ __launch_bounds__(256) void topk_select_kernel(MergeArgs m, int first_list, int n_lists, unsigned* gthr) {
+template <bool SEED>
+__global__ __launch_bounds__(256) void topk_select_kernel(MergeArgs m, int first_list, int n_lists, int n_lists_total, unsigned* gthr) {
+  extern __shared__ __attribute__((aligned(16))) float sel_smem[];   // scores [n_lists * k] | positions [n_lists * k]
   const int u = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   __shared__ float s_ws[2][4]; __shared__ long long s_wp[2][4];
-  float es[LPT][K_LDS_LISTS]; int ep[LPT][K_LDS_LISTS];   // positions < 2^31 - 1 (rt_topk_score refuses larger catalogs)
+  float* ss = sel_smem; int* sp = reinterpret_cast<int*>(sel_smem + (long long)n_lists * m.k);
+  const long long base = ((long long)u * n_lists_total + first_list) * m.k;
+  for (int i = tid; i < n_lists * m.k; i += 256) { ss[i] = m.list_scores[base + i]; sp[i] = m.list_pos[base + i]; }
+  int cnt[4], head[4];
 #pragma unroll
-  for (int j = 0; j < LPT; ++j) {
-    const int l = tid + j * 256;
-    const int c = l < n_lists ? m.list_counts[(long long)(first_list + l) * m.n_users_pad + u] : 0;
-    const long long lb = ((long long)(first_list + l) * m.n_users_pad + u) * m.k;
-#pragma unroll
-    for (int e = 0; e < K_LDS_LISTS; ++e) {
-      const bool ok = e < c;
-      es[j][e] = ok ? m.list_scores[lb + e] : -INFINITY;
-      ep[j][e] = ok ? m.list_pos[lb + e] : 0x7fffffff;
-    }
+  for (int j = 0; j < 4; ++j) {
+    const int l = tid + 256 * j;
+    cnt[j] = l < n_lists ? m.list_counts[(long long)u * n_lists_total + first_list + l] : 0;
+    head[j] = 0;
   }
+  __syncthreads();
   int n_out = 0;
   float last_s = -INFINITY;
   for (int r = 0; r < m.k; ++r) {
-    float bs = -INFINITY; long long bp = 0x7fffffffffffffffLL;
+    float bs = -INFINITY; long long bp = 0x7fffffffffffffffLL; int bj = 0;
 #pragma unroll
-    for (int j = 0; j < LPT; ++j)
-#pragma unroll
-      for (int e = 0; e < K_LDS_LISTS; ++e)
-        if (ep[j][e] != 0x7fffffff && better(es[j][e], ep[j][e], bs, bp)) { bs = es[j][e]; bp = ep[j][e]; }
+    for (int j = 0; j < 4; ++j)
+      if (head[j] < cnt[j]) {
+        const int e = (tid + 256 * j) * m.k + head[j];
+        const float es = ss[e]; const long long ep = sp[e];
+        if (better(es, ep, bs, bp)) { bs = es; bp = ep; bj = j; }
+      }
+    const long long my_p = bp;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const float os = __shfl_xor(bs, o, 64); const long long op = __shfl_xor(bp, o, 64);
@@ -1266,11 +1274,10 @@ __global__ __launch_bounds__(256) void topk_select_kernel(MergeArgs m, int first
     for (int w = 1; w < 4; ++w)
       if (better(s_ws[r & 1][w], s_wp[r & 1][w], bs, bp)) { bs = s_ws[r & 1][w]; bp = s_wp[r & 1][w]; }
     if (bp == 0x7fffffffffffffffLL) break;   // block-uniform: fewer than k candidates
+    if (my_p == bp) {                        // positions are unique: exactly one thread owns the winner
 #pragma unroll
-    for (int j = 0; j < LPT; ++j)
-#pragma unroll
-      for (int e = 0; e < K_LDS_LISTS; ++e)
-        if ((long long)ep[j][e] == bp) { es[j][e] = -INFINITY; ep[j][e] = 0x7fffffff; }
+      for (int j = 0; j < 4; ++j) head[j] += (j == bj) ? 1 : 0;
+    }
     if (!SEED && tid == 0) {
       m.out_ids[(long long)u * m.k + r] = m.whitelist ? m.whitelist[bp] : bp + m.id_offset;
       m.out_scores[(long long)u * m.k + r] = (m.distance == DIST_EUCLID) ? -bs : bs;
@@ -1279,7 +1286,7 @@ __global__ __launch_bounds__(256) void topk_select_kernel(MergeArgs m, int first
     ++n_out;
   }
   if (tid == 0) {
-    if (SEED) { if (n_out == m.k) atomicMax(gthr + u, f32_to_key(last_s)); }
+    if (SEED) gthr[u] = f32_to_key(n_out == m.k ? last_s : -INFINITY);   // plain store: nothing else touches the bound yet
     else m.out_counts[u] = n_out;
   }
 }
@@ -1454,7 +1461,7 @@ inline Plan16 make_plan16(int n_users, long long n_cand, int k) {
   long long S = ((long long)rt_num_cus() + P.n_tiles - 1) / P.n_tiles;   // one workgroup per CU owns the whole LDS
   if (S > n_blocks) S = n_blocks;
   if (S < 1) S = 1;
-  if (S > 512) S = 512;                                    // topk_select_kernel holds <= 4 x 256 lists per user
+  if (S > 512) S = 512;                                    // topk_select_kernel: a thread owns the heads of <= 4 lists
   P.S = (int)S;
   P.seed_blocks = 0;
   if (env_int("RT_TOPK_SEED", 1) != 0 && n_blocks >= 32 * S && P.n_tiles <= 16) P.seed_blocks = 2 * S;
@@ -1492,10 +1499,15 @@ int launch_stream16_ns(int ns, const TopkArgs& a, dim3 grid, hipStream_t stream)
   }
 }
 template <bool SEED>
-int launch_select(const MergeArgs& m, int first_list, int n_lists, unsigned* gthr, int n_users, hipStream_t stream) {
-  if (n_lists <= 256) topk_select_kernel<1, SEED><<<n_users, 256, 0, stream>>>(m, first_list, n_lists, gthr);
-  else if (n_lists <= 512) topk_select_kernel<2, SEED><<<n_users, 256, 0, stream>>>(m, first_list, n_lists, gthr);
-  else topk_select_kernel<4, SEED><<<n_users, 256, 0, stream>>>(m, first_list, n_lists, gthr);
+int launch_select(const MergeArgs& m, int first_list, int n_lists, int n_lists_total, unsigned* gthr, int n_users, hipStream_t stream) {
+  const size_t lds = (size_t)n_lists * m.k * 8;
+  static size_t attr_lds = 0;
+  if (lds > 64 * 1024 && lds > attr_lds) {
+    RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_select_kernel<SEED>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_lds = lds;
+  }
+  topk_select_kernel<SEED><<<n_users, 256, lds, stream>>>(m, first_list, n_lists, n_lists_total, gthr);
   RT_CHECK_LAUNCH();
   return RT_OK;
 }
@@ -1596,8 +1608,11 @@ static int topk_score_impl(const float* users, int64_t user_stride, const int64_
       a.rotate = env_int("RT_TOPK_ROTATE", 1);
       a.debug = 0;
       a.n_seg = Q.S; a.resume = 0;
-      fill_u32_kernel<<<(Q.n_users_pad + 255) / 256, 256, 0, stream>>>(a.gthr, 0x007FFFFFu /* key(-inf) */, Q.n_users_pad);
-      RT_CHECK_LAUNCH();
+      a.n_lists_total = Q.seed_blocks > 0 ? 2 * Q.S : Q.S;
+      if (Q.seed_blocks == 0 || Q.n_users_pad > nb) {   // with a seeding prefix the seed kernel stores the bound of every real user
+        fill_u32_kernel<<<(Q.n_users_pad + 255) / 256, 256, 0, stream>>>(a.gthr, 0x007FFFFFu /* key(-inf) */, Q.n_users_pad);
+        RT_CHECK_LAUNCH();
+      }
       dim3 grid(Q.S, n_tiles);
       MergeArgs m{};
       m.list_scores = a.list_scores; m.list_pos = a.list_pos; m.list_counts = a.list_counts;
@@ -1608,17 +1623,17 @@ static int topk_score_impl(const float* users, int64_t user_stride, const int64_
       m.out_counts = out_counts + u0;
       int rc, n_lists = Q.S;
       if (Q.seed_blocks > 0) {   // seeding prefix: lists [S, 2S); its k-th best per user becomes the shared bound
-        a.blk_begin = 0; a.blk_end = Q.seed_blocks; a.list_base = Q.S;
+        a.blk_begin = 0; a.blk_end = Q.seed_blocks; a.list_base = Q.S; a.use_bound = 0;
         rc = a.whitelist ? launch_stream16_ns<true>(Q.ns, a, grid, stream) : launch_stream16_ns<false>(Q.ns, a, grid, stream);
         if (rc != RT_OK) return rc;
-        rc = launch_select<true>(m, Q.S, Q.S, a.gthr, nb, stream);
+        rc = launch_select<true>(m, Q.S, Q.S, a.n_lists_total, a.gthr, nb, stream);
         if (rc != RT_OK) return rc;
         n_lists = 2 * Q.S;
       }
-      a.blk_begin = Q.seed_blocks; a.blk_end = n_blocks; a.list_base = 0;
+      a.blk_begin = Q.seed_blocks; a.blk_end = n_blocks; a.list_base = 0; a.use_bound = 1;
       rc = a.whitelist ? launch_stream16_ns<true>(Q.ns, a, grid, stream) : launch_stream16_ns<false>(Q.ns, a, grid, stream);
       if (rc != RT_OK) return rc;
-      rc = launch_select<false>(m, 0, n_lists, nullptr, nb, stream);
+      rc = launch_select<false>(m, 0, n_lists, a.n_lists_total, nullptr, nb, stream);
       if (rc != RT_OK) return rc;
     }
     return RT_OK;
