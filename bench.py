@@ -183,39 +183,90 @@ def run_topk(steps, warmup, rank, world, n_items, d, users_per_step, upp, with_f
     return value, wall, roof, info
 
 
-def make_ml20m_dataset(seed: int = 0):
-    """ML-20M-shaped synthetic interactions (138,493 users / 26,744 items / ~19.9 M rows) as a `Dataset`."""
+def make_dataset(n_users: int, n_items: int, mean_len: float, min_len: int, max_len: int, seed: int = 0, clip_len=None):
+    """Synthetic interactions of a given shape (clipped log-normal lengths, Zipf popularity, monotone
+    timestamps) as a `Dataset`."""
     import pandas as pd
 
     from rectools_amd import synth
     from rectools_amd.dataset import Dataset
 
-    shape = {k: v for k, v in synth.ML_20M.items() if k in ("n_users", "n_items", "mean_len", "min_len", "max_len")}
-    u, it, ts = synth.gen_interactions(seed=seed, **shape)
+    u, it, ts = synth.gen_interactions(n_users, n_items, mean_len=mean_len, min_len=min_len, max_len=max_len, seed=seed,
+                                       clip_len=clip_len)
     df = pd.DataFrame({"user_id": u, "item_id": it, "weight": 1.0, "datetime": pd.to_datetime(ts, unit="s")})
     return Dataset.construct(df)
 
 
-def sasrec_step_flops(B, L, d, n_blocks, n_neg):
-    """Dense algorithmic flops of one training step (fwd + bwd = 3x fwd): SASRec block 12 L d^2 + 4 L^2 d."""
-    blk = 12.0 * L * d * d + 4.0 * L * L * d
-    loss = 2.0 * L * (1 + n_neg) * d
-    return 3.0 * B * (n_blocks * blk + loss)
+def make_ml20m_dataset(seed: int = 0):
+    """ML-20M-shaped: 138,493 users / 26,744 items / ~19.9 M rows."""
+    from rectools_amd import synth
+
+    shape = {k: v for k, v in synth.ML_20M.items() if k in ("n_users", "n_items", "mean_len", "min_len", "max_len")}
+    return make_dataset(seed=seed, **shape)
 
 
-def run_train(args, rank, world):
+def family_spec(kind: str, n_neg: int):
+    """(model, dataset maker, description, dense fwd flops per sequence and block, loss flops per sequence) of a training leg.
+    Block flops per SURVEY.md §8d: SASRec 12Ld^2+4L^2d, PreLN 24Ld^2+4L^2d, LiGR(swiglu x4) 36Ld^2+4L^2d,
+    STU 2Ld*4Hhd + 4L^2*H*hd + 2L*H*hd*d."""
+    from rectools_amd import nn as hnn
+    from rectools_amd.models import BERT4RecModel, HSTUModel, SASRecModel
+
+    if kind == "train":      # BASELINE.json configs[1]
+        d, H, nb, L, B = 256, 4, 2, 200, 128
+        model = SASRecModel(n_factors=d, n_blocks=nb, n_heads=H, session_max_len=L, dropout_rate=0.2, loss="sampled_softmax",
+                            n_negatives=n_neg, batch_size=B, lr=1e-3, epochs=1, seed=32)
+        return dict(model=model, ds=make_ml20m_dataset, d=d, H=H, nb=nb, L=L, B=B, n_neg=n_neg,
+                    blk=12.0 * L * d * d + 4.0 * L * L * d, loss=2.0 * L * (1 + n_neg) * d,
+                    name="SASRec d=256 n_blocks=2 L=200 sampled_softmax, ML-20M-shaped",
+                    desc=f"B=128/GPU x L=200, d=256, 2 blocks, 4 heads, dropout 0.2, sampled_softmax N={n_neg}")
+    if kind == "bert4rec":   # BASELINE.json configs[2]
+        d, H, nb, L, B = 256, 4, 2, 200, 128
+        model = BERT4RecModel(n_factors=d, n_blocks=nb, n_heads=H, session_max_len=L, dropout_rate=0.2, loss="softmax",
+                              mask_prob=0.15, batch_size=B, lr=1e-3, epochs=1, seed=32)
+        V = 26_744 + 2
+        return dict(model=model, ds=make_ml20m_dataset, d=d, H=H, nb=nb, L=L, B=B, n_neg=0,
+                    blk=24.0 * L * d * d + 4.0 * L * L * d, loss=2.0 * 0.15 * L * V * d,
+                    name="BERT4Rec d=256 n_blocks=2 L=200 full softmax (mask_prob 0.15), ML-20M-shaped",
+                    desc="B=128/GPU x L=200, d=256, 2 Pre-LN blocks, 4 heads, dropout 0.2, full-catalog softmax over 26,746 classes "
+                         "on the ~15 % masked positions")
+    if kind == "hstu":       # BASELINE.json configs[3] (model shape; 1M items, 65,536 users resident instead of 10M)
+        d, H, nb, L, B = 256, 4, 2, 512, 128
+        hd = d // H
+        model = HSTUModel(n_factors=d, n_blocks=nb, n_heads=H, session_max_len=L, dropout_rate=0.2, loss="sampled_softmax",
+                          n_negatives=n_neg, batch_size=B, lr=1e-3, epochs=1, seed=32, relative_time_attention=True,
+                          relative_pos_attention=True, lightning_module_kwargs={"logits_t": 0.05})
+        return dict(model=model, ds=lambda: make_dataset(65_536, 1_000_000, 300.0, 20, 3000, seed=0, clip_len=513),
+                    d=d, H=H, nb=nb, L=L, B=B, n_neg=n_neg,
+                    blk=2.0 * L * d * 4 * H * hd + 4.0 * L * L * H * hd + 2.0 * L * H * hd * d, loss=2.0 * L * (1 + n_neg) * d,
+                    name="HSTU d=256 n_blocks=2 H=4 L=512 rel time+pos bias, cosine, sampled_softmax, 1M-item catalog",
+                    desc=f"B=128/GPU x L=512, d=256, 2 STU blocks, 4 heads (hd 64), relative time + position bias, cosine, logits_t "
+                         f"0.05, sampled_softmax N={n_neg}, V=1,000,000 items, 65,536 user sequences resident (the 10 M-user set "
+                         f"of the config is a host-side epoch length, not a per-step cost)")
+    if kind == "esasrec":    # BASELINE.json configs[4] model: SASRec data path on LiGR blocks, d=512; 1M-item table for training
+        d, H, nb, L, B = 512, 4, 2, 200, 128
+        model = SASRecModel(n_factors=d, n_blocks=nb, n_heads=H, session_max_len=L, dropout_rate=0.2, loss="sampled_softmax",
+                            n_negatives=n_neg, batch_size=B, lr=1e-3, epochs=1, seed=32, transformer_layers_type=hnn.LiGRLayers)
+        return dict(model=model, ds=lambda: make_dataset(65_536, 1_000_000, 144.0, 20, 2000, seed=0),
+                    d=d, H=H, nb=nb, L=L, B=B, n_neg=n_neg,
+                    blk=36.0 * L * d * d + 4.0 * L * L * d, loss=2.0 * L * (1 + n_neg) * d,
+                    name="eSASRec (SASRec + LiGR blocks) d=512 n_blocks=2 L=200 sampled_softmax, 1M-item catalog",
+                    desc=f"B=128/GPU x L=200, d=512, 2 LiGR blocks (SwiGLU x4), 4 heads (hd 128), dropout 0.2, sampled_softmax "
+                         f"N={n_neg}, V=1,000,000 items (the 5M x 512 catalog of the config is the SCORING run: `topk5m`)")
+    raise SystemExit(f"unknown training workload {kind}")
+
+
+def run_train(args, rank, world, kind="train"):
     from rectools_amd import ops
-    from rectools_amd.models import SASRecModel
 
-    d, H, nb, L, B = 256, 4, 2, 200, 128
-    n_neg = args.n_negatives
+    spec = family_spec(kind, args.n_negatives)
+    d, H, nb, L, B, n_neg = spec["d"], spec["H"], spec["nb"], spec["L"], spec["B"], spec["n_neg"]
     t0 = time.perf_counter()
-    ds = make_ml20m_dataset()
-    model = SASRecModel(n_factors=d, n_blocks=nb, n_heads=H, session_max_len=L, dropout_rate=0.2, loss="sampled_softmax",
-                        n_negatives=n_neg, batch_size=B, lr=1e-3, epochs=1, seed=32)
+    ds = spec["ds"]()
+    model = spec["model"]
     model._build_model_from_dataset(ds)      # what fit() does before its first epoch (process dataset, build, xavier, broadcast)
     prep_s = time.perf_counter() - t0
-    V = model.data_preparator.item_id_map.size - 1
+    V = model.data_preparator.item_id_map.size - model.data_preparator.n_item_extra_tokens
     loop = model.training_loop()
     model.lightning_model.train()
     loop.begin_epoch(0)
@@ -257,19 +308,29 @@ def run_train(args, rank, world):
                 "single_stream": {"avg_launch_ms": round(ms1 / len(calls), 4), "achieved": round(fl / (ms1 * 1e-3) / 1e12, 2)}}
     else:
         M = B * L
-        if dom.startswith("rt_sampled_loss"):
+        if dom in ("rt_mha_fwd", "rt_mha_bwd", "rt_hstu_attn_fwd", "rt_hstu_attn_bwd"):
+            fl = 4.0 * L * L * d * B * (2.5 if dom.endswith("bwd") else 1.0)       # dense; causal-useful half is executed
+            ms = per_kernel[dom][0] / per_kernel[dom][1]
+            tf = fl / (ms * 1e-3) / 1e12
+            roof = {"kernel": dom + " (dense 4 L^2 d flops per sequence and block; bwd x2.5)", "bound": "mfma", "achieved": round(tf, 2),
+                    "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4), "traffic": None,
+                    "avg_launch_ms": round(ms, 4), "algorithmic_flops_per_launch": fl}
+        elif dom.startswith("rt_sampled_loss"):
             byts = M * 0.72 * (1 + n_neg) * (4.0 * d + 8.0) * (2.0 if dom.endswith("bwd") else 1.0) + 4.0 * M * d
+        elif dom.startswith("rt_adam"):
+            byts = 5.0 * 4.0 * sum(p.numel() for p in model.torch_model.parameters())     # K13: 5 passes over the parameters
         else:
             byts = 8.0 * M * d
-        ms = per_kernel[dom][0] / per_kernel[dom][1]
-        gbs = byts / (ms * 1e-3) / 1e9
-        roof = {"kernel": dom, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": load_traffic("train_" + dom), "avg_launch_ms": round(ms, 4),
-                "algorithmic_bytes_per_launch": byts}
+        if roof is None:
+            ms = per_kernel[dom][0] / per_kernel[dom][1]
+            gbs = byts / (ms * 1e-3) / 1e9
+            roof = {"kernel": dom, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": load_traffic("train_" + dom), "avg_launch_ms": round(ms, 4),
+                    "algorithmic_bytes_per_launch": byts}
     roof["kernel_ms_per_step"] = round(total_k, 3)
-    roof["step_flops_dense"] = sasrec_step_flops(B, L, d, nb, n_neg)
+    roof["step_flops_dense"] = 3.0 * B * (nb * spec["blk"] + spec["loss"])     # fwd + bwd = 3 x fwd
     roof["step_TFLOPs"] = round(roof["step_flops_dense"] / (wall / args.steps) / 1e12, 2)
-    info = dict(model=model, ds=ds, loop=loop, V=V, d=d, H=H, nb=nb, L=L, B=B, n_neg=n_neg, breakdown=breakdown,
+    info = dict(model=model, ds=ds, loop=loop, V=V, d=d, H=H, nb=nb, L=L, B=B, n_neg=n_neg, breakdown=breakdown, spec=spec,
                 loss=float(state["loss"].detach()), prep_s=prep_s, steps_per_epoch=loop.batches_left() + loop.pos // B)
     return value, wall, roof, info
 
@@ -374,7 +435,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps of the headline leg (default 200 train steps)")
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="auto", choices=["auto", "train", "recommend", "topk5m"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "train", "recommend", "topk5m", "bert4rec", "hstu", "esasrec"])
     ap.add_argument("--users-per-pass", type=int, default=0, help="register tile: 16/32/64/128 users (0 = auto)")
     ap.add_argument("--users-per-step", type=int, default=0)
     ap.add_argument("--n-negatives", type=int, default=128, help="sampled_softmax negatives (tutorial setting 128)")
@@ -401,26 +462,27 @@ def main():
                     "env": env})
     else:
         if args.steps is None:
-            args.steps = 200      # 200 timed steps after 20 warm-up
+            args.steps = 200 if workload in ("auto", "train") else 40     # 200 timed steps after 20 warm-up
         if args.warmup is None:
-            args.warmup = 20
-        value, wall, roof, info = run_train(args, rank, world)
+            args.warmup = 20 if workload in ("auto", "train") else 5
+        kind = "train" if workload == "auto" else workload
+        value, wall, roof, info = run_train(args, rank, world, kind)
+        spec = info["spec"]
         out = {
-            "metric": "train seqs/sec (SASRec d=256 n_blocks=2 L=200 sampled_softmax, ML-20M-shaped) "
-                      "[+ recommend() users/sec@k=10 and 5Mx512 top-k in the sub-records]",
+            "metric": f"train seqs/sec ({spec['name']})"
+                      + (" [+ recommend() users/sec@k=10 and 5Mx512 top-k in the sub-records]" if workload == "auto" else ""),
             "value": round(value, 2), "unit": "seqs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp32", "data": "synthetic",
             "config": {"workload": f"SASRecModel.fit() steady-state step (models._TrainLoop.step): device collate from the HBM session "
                                    f"store + on-device negatives + fwd + bwd + Adam" + (" + RCCL all-reduce" if world > 1 else "")
-                                   + f"; B=128/GPU x L=200, d=256, 2 blocks, 4 heads, dropout 0.2, sampled_softmax "
-                                   f"N={args.n_negatives}, V={info['V']} items, {info['steps_per_epoch']} steps/epoch",
-                       "global_batch": 128 * world, "seq_len": 200, "parallelism": f"dp{world}", "n_negatives": args.n_negatives,
+                                   + f"; {spec['desc']}, V={info['V']} items, {info['steps_per_epoch']} steps/epoch",
+                       "global_batch": info["B"] * world, "seq_len": info["L"], "parallelism": f"dp{world}", "n_negatives": info["n_neg"],
                        "dataset_prep_s": round(info["prep_s"], 2)},
             "roofline": roof, "cpu_baseline": None,
             "kernel_breakdown": info["breakdown"], "final_loss": round(info["loss"], 5),
         }
-        if cpu_ok:
+        if cpu_ok and kind == "train":
             v, what = cpu_baseline_train(info)
             out["cpu_baseline"] = {"value": round(v, 2), "unit": "seqs/s", "cores": torch.get_num_threads(), "kind": "port",
                                    "sample": what}

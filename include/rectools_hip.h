@@ -275,6 +275,8 @@ int rt_sampled_loss_fwd_train(const float* sess, int64_t ld_sess, const float* t
                               const float* w, int32_t M, int32_t N, int32_t d, int32_t V, int32_t loss, int32_t cosine,
                               float logits_t, double gbce_beta, float* logits, float* loss_pos, float* d_sess_unit,
                               int64_t ld_du, void* workspace, size_t workspace_bytes, rt_stream_t stream);
+/* d_sess or d_table may be NULL: the two halves are independent (d_sess is a scaled copy of d_sess_unit; d_table consumes the
+ * ranks in `workspace`, so ask for it exactly once per forward) and may be issued on different streams. */
 int rt_sampled_loss_bwd(const float* sess, int64_t ld_sess, const float* table, const int64_t* y, const int64_t* neg,
                         int32_t M, int32_t N, int32_t d, int32_t V, int32_t cosine, float logits_t, const float* logits,
                         const float* norm, float gscale, const float* d_sess_unit, int64_t ld_du, float* d_sess,

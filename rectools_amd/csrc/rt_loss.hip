@@ -744,8 +744,11 @@ int rt_sampled_loss_bwd(const float* sess, int64_t ld_sess, const float* table, 
   a.inv_t = 1.0f / logits_t; a.logits = const_cast<float*>(logits); a.norm = norm; a.gscale = gscale;
   a.d_table = d_table;
   carve_workspace(a, workspace, M, N, V, d);
-  scale_rows_kernel<<<rt_num_cus() * 4, 256, 0, stream>>>(d_sess_unit, ld_du, d_sess, ld_dsess, M, d, norm, gscale);
-  RT_CHECK_LAUNCH();
+  if (d_sess != nullptr) {   // position side: a scaled copy of what the training forward accumulated
+    scale_rows_kernel<<<rt_num_cus() * 4, 256, 0, stream>>>(d_sess_unit, ld_du, d_sess, ld_dsess, M, d, norm, gscale);
+    RT_CHECK_LAUNCH();
+  }
+  if (d_table == nullptr) return RT_OK;   // table side asked for separately (e.g. on another stream: it is needed only by Adam)
   return dispatch_sampled(a, 2, stream);
 }
 

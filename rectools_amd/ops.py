@@ -835,8 +835,12 @@ class _SampledLoss(torch.autograd.Function):
         V = table.shape[0]
         d_sess = torch.empty((M, d), dtype=torch.float32, device=sess.device)
         d_table = torch.empty_like(table)
-        _c("rt_sampled_loss_bwd", sess, sess.stride(0), table, y, neg, M, N, d, V, int(cosine), float(logits_t), logits,
-           out[1:], float(gloss), du, d, d_sess, d, d_table, ws, ws.numel())
+        g = float(gloss)
+        args = (sess, sess.stride(0), table, y, neg, M, N, d, V, int(cosine), float(logits_t), logits, out[1:], g, du, d)
+        # One call on the main stream.  The table half (counting sort + gathered row reductions, memory-bound) was tried on the
+        # side stream under the MFMA-bound layer backward (rt_sampled_loss_bwd accepts either output as NULL for that):
+        # measured 3.12 vs 3.06 ms/step at C2 — the co-running gather slows the GEMMs by more than it hides.
+        _c("rt_sampled_loss_bwd", *args, d_sess, d, d_table, ws, ws.numel())
         return d_sess, d_table, None, None, None, None, None, None, None
 
 
@@ -848,37 +852,59 @@ def sampled_loss(sess: torch.Tensor, table: torch.Tensor, y: torch.Tensor, neg: 
                               logits_t, gbce_beta)
 
 
+def _padded_table(table: torch.Tensor) -> tp.Optional[torch.Tensor]:
+    """[Vp, d] view over a table whose owner (lightning.FlatAdam) keeps zero rows behind it up to a multiple of 128, or None."""
+    rows = getattr(table, "_rt_rows_padded", None)
+    if rows is None or not table.is_contiguous() or rows < table.shape[0] or rows % 128 != 0 or table.shape[1] % 32 != 0:
+        return None
+    need = (table.storage_offset() + rows * table.shape[1]) * table.element_size()
+    if table.untyped_storage().nbytes() < need:
+        return None
+    return torch.as_strided(table.detach(), (rows, table.shape[1]), (table.shape[1], 1), table.storage_offset())
+
+
 class _SoftmaxLoss(torch.autograd.Function):
-    """Full-catalog softmax CE over the active positions (lightning.py:145-162)."""
+    """Full-catalog softmax CE over the active positions (lightning.py:145-162).
+
+    The three products (logits = S E^T, dS = G E, dE = G^T S) run over R active rows and V catalog rows — neither a
+    multiple of the 128-wide GEMM tile in general, which would send 114 GFLOP per C3 step through the ragged-edge kernel.
+    When the table owns zero rows up to Vp (a multiple of 128, see `_padded_table`) the active rows are padded with zero
+    rows to Rp as well: every product is then an exact tile grid (LDS-DMA GEMM), the pad rows / columns of the logits are
+    exact zeros (zero operand rows) and never enter the softmax (`rt_softmax_ce_rows` walks R x V)."""
 
     @staticmethod
     def forward(ctx, sess, table, act_idx, y_act, w_act, logits_t, M_total):
         R = act_idx.numel()
         V, d = table.shape
-        s_act = torch.empty((R, d), dtype=torch.float32, device=sess.device)
+        tp_ = _padded_table(table)
+        Vp = V if tp_ is None else tp_.shape[0]
+        Rp = R if tp_ is None else (R + 127) // 128 * 128
+        tab = table if tp_ is None else tp_
+        s_act = (torch.empty if Rp == R else torch.zeros)((Rp, d), dtype=torch.float32, device=sess.device)
         _c("rt_gather_rows", sess, sess.stride(0), act_idx, R, d, s_act, d)
-        logits = torch.empty((R, V), dtype=torch.float32, device=sess.device)
-        _gemm(s_act, d, 1, table, table.stride(0), 1, logits, V, None, None, 0, R, V, d)
+        logits = torch.empty((Rp, Vp), dtype=torch.float32, device=sess.device)
+        _gemm(s_act, d, 1, tab, tab.stride(0), 1, logits, Vp, None, None, 0, Rp, Vp, d)
         loss_pos = torch.empty((R,), dtype=torch.float32, device=sess.device)
         lse = torch.empty((R,), dtype=torch.float32, device=sess.device)
         out = torch.empty((2,), dtype=torch.float32, device=sess.device)
-        _c("rt_softmax_ce_rows", logits, V, R, V, y_act, w_act, float(logits_t), 0, None, 1.0, loss_pos, lse)
+        _c("rt_softmax_ce_rows", logits, Vp, R, V, y_act, w_act, float(logits_t), 0, None, 1.0, loss_pos, lse)
         _c("rt_loss_reduce", loss_pos, y_act, R, 0, out)
-        ctx.save_for_backward(s_act, table, act_idx, y_act, w_act, logits, lse, out)
-        ctx.meta = (logits_t, M_total, sess.shape[1])
+        ctx.save_for_backward(s_act, tab, act_idx, y_act, w_act, logits, lse, out)
+        ctx.meta = (logits_t, M_total, sess.shape[1], R, V)
         return out[0]
 
     @staticmethod
     def backward(ctx, gloss):
-        s_act, table, act_idx, y_act, w_act, logits, lse, out = ctx.saved_tensors
-        logits_t, M_total, d = ctx.meta
-        R, V = logits.shape
-        # logits := (softmax - onehot) * w * g / (norm * t), in place (the buffer is ours)
-        _c("rt_softmax_ce_rows", logits, V, R, V, y_act, w_act, float(logits_t), 1, out[1:], float(gloss), None, lse)
-        ds_act = torch.empty((R, d), dtype=torch.float32, device=logits.device)
-        _gemm(logits, V, 1, table, table.stride(0), 0, ds_act, d, None, None, 0, R, d, V)       # dS = G @ E
-        d_table = torch.empty_like(table)
-        _gemm(logits, V, 0, s_act, d, 0, d_table, d, None, None, 0, V, d, R, 0, _wgrad_splits(R))  # dE = G^T @ S
+        s_act, tab, act_idx, y_act, w_act, logits, lse, out = ctx.saved_tensors
+        logits_t, M_total, d, R, V = ctx.meta
+        Rp, Vp = logits.shape
+        # logits := (softmax - onehot) * w * g / (norm * t), in place (the buffer is ours); pad rows / columns stay zero
+        _c("rt_softmax_ce_rows", logits, Vp, R, V, y_act, w_act, float(logits_t), 1, out[1:], float(gloss), None, lse)
+        ds_act = torch.empty((Rp, d), dtype=torch.float32, device=logits.device)
+        _gemm(logits, Vp, 1, tab, tab.stride(0), 0, ds_act, d, None, None, 0, Rp, d, Vp)       # dS = G @ E
+        d_tab = torch.empty((Vp, d), dtype=torch.float32, device=logits.device)
+        _gemm(logits, Vp, 0, s_act, d, 0, d_tab, d, None, None, 0, Vp, d, Rp, 0, _wgrad_splits(Rp))  # dE = G^T @ S
+        d_table = d_tab[:V]
         d_table[0].zero_()  # padding_idx row never receives gradient (item_net.py:260-264)
         d_sess = torch.zeros((M_total, d), dtype=torch.float32, device=logits.device)
         _c("rt_scatter_rows", ds_act, d, act_idx, R, d, d_sess, d)
