@@ -75,16 +75,40 @@ __device__ __forceinline__ float drop_keep(unsigned long long seed, unsigned bh,
 __device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
 __device__ __forceinline__ float silu_df(float z) { float s = 1.f / (1.f + __expf(-z)); return s * (1.f + z * (1.f - s)); }
 
-// hstu bucket of |dt| via the host-computed thresholds (exactly the reference's float32 log/0.301 truncation)
+// hstu bucket of |dt| = largest b with thr[b] <= |dt|, thr = the host-computed integer thresholds (exactly the reference's
+// float32 log/0.301 truncation).  A fast-log estimate lands within one bucket of the answer; the two neighbouring
+// thresholds (two independent LDS reads) settle it — the 8 dependent LDS round trips of a binary search per score element
+// made the HSTU kernels LDS-latency bound.  (The estimate's error is ~1e-3 buckets: log2 hardware approximation on values
+// <= 146, so it is off by one only next to a threshold and never by two.)
 __device__ __forceinline__ int time_bucket(const long long* thr, long long dt) {
-  long long x = dt < 0 ? -dt : dt;
-  int lo = 0, hi = NBUCK - 1;  // largest b with thr[b] <= x
-  while (lo < hi) {
-    int mid = (lo + hi + 1) >> 1;
-    if (thr[mid] <= x) lo = mid; else hi = mid - 1;
-  }
-  return lo;
+  const long long x = dt < 0 ? -dt : dt;
+  int b = (int)(__logf(fmaxf((float)x, 1.f)) * (1.0f / 0.301f));
+  b = b < 0 ? 0 : (b > NBUCK - 1 ? NBUCK - 1 : b);
+  const long long t0 = thr[b], t1 = thr[b < NBUCK - 1 ? b + 1 : b];
+  if (t0 > x) b -= 1;
+  else if (b < NBUCK - 1 && t1 <= x) b += 1;
+  return b < 0 ? 0 : b;
 }
+
+// Run-length accumulator of the time-bias gradient of ONE query lane: timestamps are monotone inside a session, so along the
+// keys of a query the bucket index is monotone too and equal buckets come in runs.  One LDS atomic per RUN instead of one per
+// score element (16 per 32x32 tile and lane, with up to 32 lanes of an instruction hitting the same bucket).
+struct TimeGradRun {
+  int cur; float acc;
+  __device__ __forceinline__ void init() { cur = -1; acc = 0.f; }
+  __device__ __forceinline__ void add(float* dtw, int b, float v) {
+    if (b != cur) {
+      if (cur >= 0) atomicAdd(dtw + cur, acc);
+      cur = b; acc = v;
+    } else {
+      acc += v;
+    }
+  }
+  __device__ __forceinline__ void flush(float* dtw) {
+    if (cur >= 0) atomicAdd(dtw + cur, acc);
+    cur = -1; acc = 0.f;
+  }
+};
 
 // load the B-operand fragments (rows of Q / dO / K / V for `row`), hd/8 float4 per lane, zero past `L`
 template <int HDV>
@@ -261,7 +285,7 @@ template <int MODE, int HD, bool EDGE = true>
 __device__ __forceinline__ void dq_pair(const AttnArgs& a, const float* Kt, const float* Vt, const float* kflag,
                                         int kt, int qq, bool q_is_pad, long long t_q1, int bh, int col, int half,
                                         const f32x4 (&qf)[HD / 8], const f32x4 (&gf)[HD / 8], float lse_q, float delta_q,
-                                        const HstuLds& hl, f32x16 (&dqacc)[HD / 32]) {
+                                        const HstuLds& hl, f32x16 (&dqacc)[HD / 32], TimeGradRun& trun) {
   constexpr int HDV = HD / 8, NT = HD / 32, lds_ld = HD + 4;
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   f32x16 sacc, pacc;
@@ -286,13 +310,13 @@ __device__ __forceinline__ void dq_pair(const AttnArgs& a, const float* Kt, cons
     const bool kpad = EDGE && kflag[row_of(r, half)] != 0.f;
     float dsc = 1.f;
     if (MODE == MODE_SOFTMAX && a.p_drop > 0.f) dsc = drop_keep(a.seed, (unsigned)bh, (unsigned)qq, (unsigned)kk, a.p_drop, inv_keep);
-    bool dead; float bias = 0.f;
+    bool dead; float bias = 0.f; int tb = 0;
     if (MODE == MODE_SOFTMAX) {
       dead = EDGE && ((kk >= a.L) | (qq >= a.L) | masked(a, qq, kk, kpad));
     } else {
       dead = (kk >= a.L) | (qq >= a.L) | (kk > qq) | q_is_pad | kpad;
       if (!dead) {
-        if (a.time_w) bias += hl.tw[time_bucket(hl.thr, t_q1 - hl.ts[kk])];
+        if (a.time_w) { tb = time_bucket(hl.thr, t_q1 - hl.ts[kk]); bias += hl.tw[tb]; }
         if (a.pos_w) bias += hl.pw[(a.L - 1) + kk - qq];
       }
     }
@@ -300,7 +324,7 @@ __device__ __forceinline__ void dq_pair(const AttnArgs& a, const float* Kt, cons
     tile_p_ds<MODE>(a, sacc[r], pacc[r], lse_q, delta_q, dead, bias, dsc, pu, ds[r]);
     if (MODE == MODE_HSTU && !dead) {
       // relative-bias gradients: rab is shared by the heads, so every head adds its dS (hstu.py:276)
-      if (a.d_time_w) atomicAdd(hl.dtw + time_bucket(hl.thr, t_q1 - hl.ts[kk]), ds[r]);
+      if (a.d_time_w) trun.add(hl.dtw, tb, ds[r]);
       if (a.d_pos_w) atomicAdd(hl.dpw + (a.L - 1) + kk - qq, ds[r]);
     }
   }
@@ -551,6 +575,7 @@ __global__ __launch_bounds__(AT) void attn_bwd_dq_kernel(AttnArgs a) {
   f32x4 kreg[HD / 32], vreg[HD / 32];
   load_tile_regs<HD>(kb, a.ldk, 0, a.L, a.hd, tid, kreg);
   load_tile_regs<HD>(vb, a.ldv, 0, a.L, a.hd, tid, vreg);
+  TimeGradRun trun; trun.init();
   for (int kt = 0; kt < n_kt; ++kt) {
     __syncthreads();
     store_tile_regs<HD>(Ks, tid, kreg);
@@ -562,9 +587,10 @@ __global__ __launch_bounds__(AT) void attn_bwd_dq_kernel(AttnArgs a) {
       load_tile_regs<HD>(vb, a.ldv, (kt + 1) * TK, a.L, a.hd, tid, vreg);
     }
     if (q0 >= a.L || kt > my_last_kt) continue;
-    dq_pair<MODE, HD>(a, Ks, Vs, aux, kt, qq, q_is_pad, t_q1, bh, col, half, qf, gf, lse_q, delta_q, hl, dqacc);
+    dq_pair<MODE, HD>(a, Ks, Vs, aux, kt, qq, q_is_pad, t_q1, bh, col, half, qf, gf, lse_q, delta_q, hl, dqacc, trun);
   }
   if (MODE == MODE_HSTU) {
+    if (a.d_time_w) trun.flush(hl.dtw);
     __syncthreads();
     hstu_flush_grads(a, hl, tid, AT);
   }
@@ -796,16 +822,18 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(AttnArgs a) {
       for (int r = 0; r < 16; ++r) dqacc[t][r] = 0.f;
     const int last_kt = a.causal ? qt : n_t - 1;
     const bool q_inside = (qt + 1) * TK <= a.L;
+    TimeGradRun trun; trun.init();
 #pragma unroll 1
     for (int kt = 0; kt <= last_kt; ++kt) {
       const bool interior = MODE == MODE_SOFTMAX && !a.no_interior && !a.keypad && q_inside && (kt + 1) * TK <= a.L && (!a.causal || kt < qt);
       if (interior)
         dq_pair<MODE, HD, false>(a, Ks + kt * TK * lds_ld, Vs + kt * TK * lds_ld, kflag + kt * TK, kt, qq, q_is_pad, t_q1,
-                                 bh, col, half, qf, gf, lse_q, delta_q, hl, dqacc);
+                                 bh, col, half, qf, gf, lse_q, delta_q, hl, dqacc, trun);
       else
         dq_pair<MODE, HD, true>(a, Ks + kt * TK * lds_ld, Vs + kt * TK * lds_ld, kflag + kt * TK, kt, qq, q_is_pad, t_q1,
-                                bh, col, half, qf, gf, lse_q, delta_q, hl, dqacc);
+                                bh, col, half, qf, gf, lse_q, delta_q, hl, dqacc, trun);
     }
+    if (MODE == MODE_HSTU && a.d_time_w) trun.flush(hl.dtw);
     store_rows_T<HD>(a.dq + rowbase * a.lddq + h * a.hd, a.lddq, qq, a.L, a.hd, half, dqacc);
   }
   if (MODE == MODE_HSTU) {
