@@ -55,6 +55,58 @@ struct AttnArgs {
 
 __device__ __forceinline__ int row_of(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
+// ---- LDS-DMA plumbing of the resident kernels' loader wave (same idiom as rt_gemm.hip / rt_topk.hip) ----------------
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
+}
+// 64 lanes x 16 B from per-lane global addresses to LDS [dst, dst + 1 KiB); inline asm keeps the asynchronous LDS write out
+// of hipcc's waitcnt bookkeeping
+__device__ __forceinline__ void dma16(const float* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// LDS tile addressing.  SWZ = false: rows of HD + 4 floats (register-staged tiles: the pad spreads the banks).
+// SWZ = true: unpadded rows of HD floats written by LDS-DMA (a DMA instruction fills 1 KiB of consecutive LDS bytes, so rows
+// cannot be padded); the 16-byte slot q of row r lives at slot q ^ swz(r), which keeps both access patterns conflict-free:
+// the ds_read_b128 fragment reads (16-lane groups walk 16 distinct rows at one logical slot) and the scalar reads along a row.
+template <int HD> __device__ __forceinline__ int swz_of(int row) { return HD == 32 ? ((row >> 1) & 7) : (row & 15); }
+template <int HD, bool SWZ> __device__ __forceinline__ int slot_off(int row, int q) {     // float offset of slot q of `row`
+  return SWZ ? row * HD + ((q ^ swz_of<HD>(row)) << 2) : row * (HD + 4) + (q << 2);
+}
+template <int HD, bool SWZ> __device__ __forceinline__ int elem_off(int row, int dd) {    // float offset of element dd of `row`
+  return SWZ ? row * HD + ((((dd >> 2) ^ swz_of<HD>(row)) << 2) | (dd & 3)) : row * (HD + 4) + dd;
+}
+// The second product of every tile pair reads element (row_of(t, half), nt * 32 + col) of a tile for t = 0..15: with the
+// swizzle that is 16 x NT different XORs per lane if computed naively (it cost the backward kernels their last free
+// registers).  The XOR splits into a lane part that takes only FOUR values over t and a compile-time part, so a lane keeps
+// four base offsets and every read is base[j(t)] + constant — an immediate offset again, like the padded layout.
+//   HD = 64 (swz = row & 15):       row & 15 = (t & 3) | half << 2 | ((t >> 2) & 1) << 3;  slot = nt * 8 + (col >> 2)
+//   HD = 32 (swz = (row >> 1) & 7): swz = ((t >> 1) & 1) | half << 1 | ((t >> 2) & 1) << 2; slot = col >> 2
+template <int HD> struct SwzLane {
+  int w[4];
+  __device__ __forceinline__ void init(int col, int half) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int x = HD == 32 ? ((j & 1) | (half << 1) | ((j >> 1) << 2)) : (j | (half << 2));
+      w[j] = 4 * half * HD + ((((col >> 2) ^ x) << 2) | (col & 3));
+    }
+  }
+  __device__ __forceinline__ int off(int t, int nt) const {   // t, nt compile-time after unrolling
+    const int j = HD == 32 ? (((t >> 1) & 1) | (((t >> 2) & 1) << 1)) : (t & 3);
+    const int c = ((t & 3) + 8 * (t >> 2)) * HD + (HD == 32 ? 0 : (((nt * 8) ^ (((t >> 2) & 1) << 3)) << 2));
+    return w[j] + c;
+  }
+};
+
 // Is (query qq, key kk) masked out?  Mirrors torch_backbone.py:249-257 and _merge_masks (:172-218): causal `kk > qq`,
 // key padding, and — when both are on — the diagonal forced open.  Branch-free (the flags are wave-uniform 0/1).
 __device__ __forceinline__ bool masked(const AttnArgs& a, int qq, int kk, bool key_is_pad) {
@@ -160,11 +212,11 @@ struct HstuLds {
 // forward: S^T = K Q^T (rows = keys, cols = queries), online softmax / silu, O^T += V^T P^T
 // EDGE = false: the tile pair lies fully inside [0,L) x [0,L) and nothing in it is masked (softmax mode without the
 // key-padding mask, strictly below the causal diagonal) — all mask logic compiles away.
-template <int MODE, int HD, bool EDGE = true>
+template <int MODE, int HD, bool EDGE = true, bool SWZ = false>
 __device__ __forceinline__ void fwd_pair(const AttnArgs& a, const float* Kt, const float* Vt, const float* kflag,
                                          int kt, int qq, bool q_is_pad, long long t_q1, int bh, int col, int half,
                                          const f32x4 (&qf)[HD / 8], const HstuLds& hl, f32x16 (&oacc)[HD / 32],
-                                         float& m_run, float& l_run) {
+                                         float& m_run, float& l_run, const SwzLane<HD>& sl = SwzLane<HD>()) {
   constexpr int HDV = HD / 8, NT = HD / 32, lds_ld = HD + 4;
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   f32x16 sacc;
@@ -173,7 +225,7 @@ __device__ __forceinline__ void fwd_pair(const AttnArgs& a, const float* Kt, con
 #pragma unroll
   for (int s = 0; s < HDV; ++s) {
     {
-      f32x4 kf = *reinterpret_cast<const f32x4*>(Kt + col * lds_ld + 8 * s + 4 * half);
+      f32x4 kf = *reinterpret_cast<const f32x4*>(Kt + slot_off<HD, SWZ>(col, 2 * s + half));
 #pragma unroll
       for (int t = 0; t < 4; ++t) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t], qf[s][t], sacc, 0, 0, 0);
     }
@@ -232,7 +284,7 @@ __device__ __forceinline__ void fwd_pair(const AttnArgs& a, const float* Kt, con
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int dd = nt * 32 + col;
-      const float vv = Vt[krow * lds_ld + dd];
+      const float vv = SWZ ? Vt[sl.off(t, nt)] : Vt[elem_off<HD, false>(krow, dd)];
       oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, p[t], oacc[nt], 0, 0, 0);
     }
   }
@@ -281,11 +333,12 @@ __device__ __forceinline__ void tile_p_ds(const AttnArgs& a, float s_raw, float 
 }
 
 // backward dQ: S^T, dP^T (rows = keys, cols = queries), dS, dQ^T += K^T dS^T
-template <int MODE, int HD, bool EDGE = true>
+template <int MODE, int HD, bool EDGE = true, bool SWZ = false>
 __device__ __forceinline__ void dq_pair(const AttnArgs& a, const float* Kt, const float* Vt, const float* kflag,
                                         int kt, int qq, bool q_is_pad, long long t_q1, int bh, int col, int half,
                                         const f32x4 (&qf)[HD / 8], const f32x4 (&gf)[HD / 8], float lse_q, float delta_q,
-                                        const HstuLds& hl, f32x16 (&dqacc)[HD / 32], TimeGradRun& trun) {
+                                        const HstuLds& hl, f32x16 (&dqacc)[HD / 32], TimeGradRun& trun,
+                                        const SwzLane<HD>& sl = SwzLane<HD>()) {
   constexpr int HDV = HD / 8, NT = HD / 32, lds_ld = HD + 4;
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   f32x16 sacc, pacc;
@@ -294,8 +347,8 @@ __device__ __forceinline__ void dq_pair(const AttnArgs& a, const float* Kt, cons
 #pragma unroll
   for (int s = 0; s < HDV; ++s) {
     {
-      f32x4 kf = *reinterpret_cast<const f32x4*>(Kt + col * lds_ld + 8 * s + 4 * half);
-      f32x4 vf = *reinterpret_cast<const f32x4*>(Vt + col * lds_ld + 8 * s + 4 * half);
+      f32x4 kf = *reinterpret_cast<const f32x4*>(Kt + slot_off<HD, SWZ>(col, 2 * s + half));
+      f32x4 vf = *reinterpret_cast<const f32x4*>(Vt + slot_off<HD, SWZ>(col, 2 * s + half));
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t], qf[s][t], sacc, 0, 0, 0);
@@ -335,7 +388,7 @@ __device__ __forceinline__ void dq_pair(const AttnArgs& a, const float* Kt, cons
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int dd = nt * 32 + col;
-      const float kv = Kt[krow * lds_ld + dd];
+      const float kv = SWZ ? Kt[sl.off(t, nt)] : Kt[elem_off<HD, false>(krow, dd)];
       dqacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, ds[t], dqacc[nt], 0, 0, 0);
     }
   }
@@ -343,12 +396,12 @@ __device__ __forceinline__ void dq_pair(const AttnArgs& a, const float* Kt, cons
 
 // backward dK/dV: S, dP (rows = queries from LDS, cols = keys), dV^T += dO^T P, dK^T += Q^T dS
 // qaux: [0,32) lse, [32,64) delta, [64,96) query pad flags of the tile
-template <int MODE, int HD, bool EDGE = true>
+template <int MODE, int HD, bool EDGE = true, bool SWZ = false>
 __device__ __forceinline__ void dkv_pair(const AttnArgs& a, const float* Qt, const float* Gt, const float* q_lse,
                                          const float* q_delta, const float* q_flag, int qt, int kk, bool k_is_pad,
                                          long long t_k, int bh, int col, int half, const f32x4 (&kf)[HD / 8],
                                          const f32x4 (&vf)[HD / 8], const HstuLds& hl, f32x16 (&dkacc)[HD / 32],
-                                         f32x16 (&dvacc)[HD / 32]) {
+                                         f32x16 (&dvacc)[HD / 32], const SwzLane<HD>& sl = SwzLane<HD>()) {
   constexpr int HDV = HD / 8, NT = HD / 32, lds_ld = HD + 4;
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   f32x16 sacc, pacc;
@@ -357,8 +410,8 @@ __device__ __forceinline__ void dkv_pair(const AttnArgs& a, const float* Qt, con
 #pragma unroll
   for (int s = 0; s < HDV; ++s) {
     {
-      f32x4 qf = *reinterpret_cast<const f32x4*>(Qt + col * lds_ld + 8 * s + 4 * half);
-      f32x4 gf = *reinterpret_cast<const f32x4*>(Gt + col * lds_ld + 8 * s + 4 * half);
+      f32x4 qf = *reinterpret_cast<const f32x4*>(Qt + slot_off<HD, SWZ>(col, 2 * s + half));
+      f32x4 gf = *reinterpret_cast<const f32x4*>(Gt + slot_off<HD, SWZ>(col, 2 * s + half));
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[t], kf[s][t], sacc, 0, 0, 0);
@@ -391,8 +444,9 @@ __device__ __forceinline__ void dkv_pair(const AttnArgs& a, const float* Qt, con
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int dd = nt * 32 + col;
-      const float gv = Gt[qrow * lds_ld + dd];
-      const float qv = Qt[qrow * lds_ld + dd];
+      const int eo = SWZ ? sl.off(t, nt) : elem_off<HD, false>(qrow, dd);
+      const float gv = Gt[eo];
+      const float qv = Qt[eo];
       dvacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, pu[t], dvacc[nt], 0, 0, 0);
       dkacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qv, ds[t], dkacc[nt], 0, 0, 0);
     }
@@ -688,6 +742,22 @@ __device__ __forceinline__ int tile_for(int it, int wave, int n_t, bool causal, 
   return cost_up ? t : n_t - 1 - t;
 }
 
+// Schedule of the loader-wave variant (NW = 8: waves 0..6 compute, wave 7 streams the tiles): causal tiles are dealt in
+// rounds of 7, heaviest first, to waves 0,1,2,3,6,5,4 — the SIMD pairs (0,4) (1,5) (2,6) get heavy + light, SIMD 3 carries
+// one middle tile next to the loader.  For n_t <= 7 (L <= 224) this is exactly tile_for<8>'s deal, whose wave 7 sits idle.
+__device__ __forceinline__ int tile_for7(int it, int wave, int n_t, bool causal, bool cost_up) {
+  if (!causal) { const int t = wave + it * 7; return t < n_t ? t : -1; }
+  const int slot = wave < 4 ? wave : 10 - wave;        // 4 -> 6, 5 -> 5, 6 -> 4
+  const int idx = it * 7 + slot;                       // position in heaviest-first order
+  if (idx >= n_t) return -1;
+  return cost_up ? n_t - 1 - idx : idx;                // cost_up: the last tile is the heaviest; else tile 0 is
+}
+template <int NW, bool DMA>
+__device__ __forceinline__ int sched_tile(int it, int wave, int n_t, bool causal, bool cost_up) {
+  if constexpr (DMA) return tile_for7(it, wave, n_t, causal, cost_up);
+  else return tile_for<NW>(it, wave, n_t, causal, cost_up);
+}
+
 // rows [0, Lp) of two [L, hd] matrices -> LDS [Lp][HD + 4] each; rows past L and columns past hd are zero-filled.
 // A dependent round trip costs ~2 us, so every thread keeps 8 + 8 float4 loads in flight (one round for L = 200, hd = 64).
 template <int HD>
@@ -718,17 +788,70 @@ __device__ __forceinline__ void stage_rows2(const float* baseA, long long ldA, f
   }
 }
 
-template <int MODE, int HD, int NW>
+// ---- LDS-DMA staging of the resident tiles by a dedicated loader wave (DMA = true; head dim == HD in {32, 64}) ----------
+// The register-staged prologue (stage_rows2 + barrier) leaves the matrix pipe idle while 115 KB per (batch, head) arrive: at
+// the C2 shape that was 35 of the forward kernel's 76 us.  Here wave NW streams the two matrices tile by tile (32 rows,
+// K and V together) with global_load_lds_dwordx4 into unpadded, XOR-swizzled rows and raises a per-tile LDS flag once a tile
+// has landed (counted vmcnt; <= 3 tiles in flight; the block stays at 8 waves = 2 per SIMD, so the 256-VGPR budget of the
+// backward kernels is untouched — a ninth wave would cap them at 168 and spill); the compute waves only poll the flag of the tile they are about to
+// read, so the first query tiles start after ONE key tile and the rest of the load hides under their MFMAs.  No barrier
+// after the prologue one; rows past L are clamped copies of row L - 1 (every tile pair that can see them is an EDGE pair
+// and masks them).
+constexpr int DMA_WINDOW = 3;   // tiles in flight: 3 x 16 pieces (HD = 64) stays below the 6-bit vmcnt
+typedef volatile __attribute__((address_space(3))) int* lds_flag_ptr;   // explicit LDS pointer: ds_read / ds_write, not flat
+
+template <int HD>
+__device__ __forceinline__ void res_loader(const float* A, long long ldA, const float* Ab_lds, const float* B, long long ldB,
+                                           const float* Bb_lds, int L, int n_t, bool descending, lds_flag_ptr tflag, int lane) {
+  constexpr int SPR = HD / 4;              // 16-byte slots per row
+  constexpr int RPP = 64 / SPR;            // rows per 1 KiB piece
+  constexpr int PPM = TK / RPP;            // pieces per matrix and tile
+  constexpr int PPT = 2 * PPM;             // pieces per tile (both matrices)
+  static_assert(DMA_WINDOW * PPT < 64, "vmcnt is a 6-bit counter");
+  const int lrow = lane / SPR, lslot = lane % SPR;
+  const unsigned a_base = __builtin_amdgcn_readfirstlane(lds_addr(Ab_lds));
+  const unsigned b_base = __builtin_amdgcn_readfirstlane(lds_addr(Bb_lds));
+  auto issue_tile = [&](int t) {
+#pragma unroll
+    for (int j = 0; j < PPM; ++j) {
+      const int row = t * TK + j * RPP + lrow;
+      const int src = row < L ? row : L - 1;
+      const int logical = lslot ^ swz_of<HD>(row);
+      const unsigned dst = (unsigned)((t * TK + j * RPP) * HD * 4);
+      dma16(A + (long long)src * ldA + logical * 4, a_base + dst);
+      dma16(B + (long long)src * ldB + logical * 4, b_base + dst);
+    }
+  };
+  int issued = 0;
+  for (; issued < DMA_WINDOW && issued < n_t; ++issued) issue_tile(descending ? n_t - 1 - issued : issued);
+#pragma unroll 1
+  for (int i = 0; i < n_t; ++i) {
+    const int rem = issued - i - 1;        // tiles that may stay in flight while tile i is declared landed
+    if (rem >= 2) wait_vmcnt<2 * PPT>();
+    else if (rem == 1) wait_vmcnt<PPT>();
+    else wait_vmcnt<0>();
+    tflag[descending ? n_t - 1 - i : i] = 1;
+    if (issued < n_t) { issue_tile(descending ? n_t - 1 - issued : issued); ++issued; }
+  }
+}
+__device__ __forceinline__ void wait_tile(lds_flag_ptr tflag, int t) {
+  while (tflag[t] == 0) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");   // tile reads stay behind the poll
+}
+
+template <int MODE, int HD, int NW, bool DMA>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(AttnArgs a) {
-  constexpr int HDV = HD / 8, NT = HD / 32, NTH = NW * 64;
+  constexpr int HDV = HD / 8, NT = HD / 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n_t = (a.L + TK - 1) / TK, Lp = n_t * TK;
-  constexpr int lds_ld = HD + 4;
-  float* Ks = smem;                       // [Lp][hd+4]
-  float* Vs = Ks + Lp * lds_ld;           // [Lp][hd+4]
+  constexpr int lds_ld = DMA ? HD : HD + 4;
+  const int NTH = blockDim.x;
+  float* Ks = smem;                       // [Lp][lds_ld]
+  float* Vs = Ks + Lp * lds_ld;           // [Lp][lds_ld]
   float* kflag = Vs + Lp * lds_ld;        // [Lp] key pad flags
+  lds_flag_ptr tflag = (lds_flag_ptr)(kflag + Lp);   // [n_t] tile-landed flags (DMA)
   HstuLds hl{};
-  if (MODE == MODE_HSTU) hstu_carve(kflag + Lp, a.L, false, hl);
+  if (MODE == MODE_HSTU) hstu_carve(kflag + Lp + ((n_t + 3) & ~3), a.L, false, hl);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile loops and LDS tile bases stay scalar
@@ -737,14 +860,22 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(AttnArgs a) {
   const long long rowbase = (long long)b * a.L;
   const float* qb = a.q + rowbase * a.ldq + h * a.hd;
   const long long* idb = a.ids + rowbase;
-  stage_rows2<HD>(a.k + rowbase * a.ldk + h * a.hd, a.ldk, Ks, a.v + rowbase * a.ldv + h * a.hd, a.ldv, Vs, a.L, Lp, a.hd, tid, NTH);
+  if (!DMA) stage_rows2<HD>(a.k + rowbase * a.ldk + h * a.hd, a.ldk, Ks, a.v + rowbase * a.ldv + h * a.hd, a.ldv, Vs, a.L, Lp, a.hd, tid, NTH);
   for (int i = tid; i < Lp; i += NTH) kflag[i] = (i < a.L && idb[i] != 0) ? 0.f : 1.f;
+  if (DMA && tid < n_t) tflag[tid] = 0;
   if (MODE == MODE_HSTU) hstu_fill(a, hl, b, tid, NTH);
   __syncthreads();
+  if constexpr (DMA) if (wave == NW - 1) {
+    res_loader<HD>(a.k + rowbase * a.ldk + h * a.hd, a.ldk, Ks, a.v + rowbase * a.ldv + h * a.hd, a.ldv, Vs, a.L, n_t, false,
+                   tflag, lane);
+    return;
+  }
+  int ready = -1;   // highest key tile this wave has seen landed
+  SwzLane<HD> sl; sl.init(col, half);
 
 #pragma unroll 1
   for (int it = 0;; ++it) {
-    const int qt = tile_for<NW>(it, wave, n_t, a.causal != 0, true);
+    const int qt = sched_tile<NW, DMA>(it, wave, n_t, a.causal != 0, true);
     if (qt < 0) break;
     const int qq = qt * TK + col;
     f32x4 qf[HDV];
@@ -762,29 +893,32 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(AttnArgs a) {
     const bool q_inside = (qt + 1) * TK <= a.L;
 #pragma unroll 1
     for (int kt = 0; kt <= last_kt; ++kt) {
+      if (DMA && kt > ready) { wait_tile(tflag, kt); ready = kt; }
       const bool interior = MODE == MODE_SOFTMAX && !a.no_interior && !a.keypad && q_inside && (kt + 1) * TK <= a.L && (!a.causal || kt < qt);
       if (interior)
-        fwd_pair<MODE, HD, false>(a, Ks + kt * TK * lds_ld, Vs + kt * TK * lds_ld, kflag + kt * TK, kt, qq, q_is_pad, t_q1,
-                                  bh, col, half, qf, hl, oacc, m_run, l_run);
+        fwd_pair<MODE, HD, false, DMA>(a, Ks + kt * TK * lds_ld, Vs + kt * TK * lds_ld, kflag + kt * TK, kt, qq, q_is_pad, t_q1,
+                                       bh, col, half, qf, hl, oacc, m_run, l_run, sl);
       else
-        fwd_pair<MODE, HD, true>(a, Ks + kt * TK * lds_ld, Vs + kt * TK * lds_ld, kflag + kt * TK, kt, qq, q_is_pad, t_q1,
-                                 bh, col, half, qf, hl, oacc, m_run, l_run);
+        fwd_pair<MODE, HD, true, DMA>(a, Ks + kt * TK * lds_ld, Vs + kt * TK * lds_ld, kflag + kt * TK, kt, qq, q_is_pad, t_q1,
+                                      bh, col, half, qf, hl, oacc, m_run, l_run, sl);
     }
     fwd_store<MODE, HD>(a, bh, qq, half, rowbase, h, oacc, m_run, l_run);
   }
 }
 
-template <int MODE, int HD, int NW>
+template <int MODE, int HD, int NW, bool DMA>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(AttnArgs a) {
-  constexpr int HDV = HD / 8, NT = HD / 32, NTH = NW * 64;
+  constexpr int HDV = HD / 8, NT = HD / 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n_t = (a.L + TK - 1) / TK, Lp = n_t * TK;
-  constexpr int lds_ld = HD + 4;
+  constexpr int lds_ld = DMA ? HD : HD + 4;
+  const int NTH = blockDim.x;
   float* Ks = smem;
   float* Vs = Ks + Lp * lds_ld;
   float* kflag = Vs + Lp * lds_ld;
+  lds_flag_ptr tflag = (lds_flag_ptr)(kflag + Lp);
   HstuLds hl{};
-  if (MODE == MODE_HSTU) hstu_carve(kflag + Lp, a.L, true, hl);
+  if (MODE == MODE_HSTU) hstu_carve(kflag + Lp + ((n_t + 3) & ~3), a.L, true, hl);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile loops and LDS tile bases stay scalar
@@ -794,47 +928,58 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(AttnArgs a) {
   const float* qb = a.q + rowbase * a.ldq + h * a.hd;
   const float* gb = a.dout + rowbase * a.lddo + h * a.hd;
   const long long* idb = a.ids + rowbase;
-  stage_rows2<HD>(a.k + rowbase * a.ldk + h * a.hd, a.ldk, Ks, a.v + rowbase * a.ldv + h * a.hd, a.ldv, Vs, a.L, Lp, a.hd, tid, NTH);
+  if (!DMA) stage_rows2<HD>(a.k + rowbase * a.ldk + h * a.hd, a.ldk, Ks, a.v + rowbase * a.ldv + h * a.hd, a.ldv, Vs, a.L, Lp, a.hd, tid, NTH);
   for (int i = tid; i < Lp; i += NTH) kflag[i] = (i < a.L && idb[i] != 0) ? 0.f : 1.f;
+  if (DMA && tid < n_t) tflag[tid] = 0;
   if (MODE == MODE_HSTU) hstu_fill(a, hl, b, tid, NTH);
   __syncthreads();
-
+  bool is_loader = false;
+  if constexpr (DMA) is_loader = wave == NW - 1;
+  if (is_loader) {
+    if constexpr (DMA)
+      res_loader<HD>(a.k + rowbase * a.ldk + h * a.hd, a.ldk, Ks, a.v + rowbase * a.ldv + h * a.hd, a.ldv, Vs, a.L, n_t, false,
+                     tflag, lane);
+  } else {
+    int ready = -1;
+    SwzLane<HD> sl; sl.init(col, half);
 #pragma unroll 1
-  for (int it = 0;; ++it) {
-    const int qt = tile_for<NW>(it, wave, n_t, a.causal != 0, true);
-    if (qt < 0) break;
-    const int qq = qt * TK + col;
-    f32x4 qf[HDV], gf[HDV];
-    load_row_frags<HDV>(qb, a.ldq, qq, a.L, a.hd, half, qf);
-    load_row_frags<HDV>(gb, a.lddo, qq, a.L, a.hd, half, gf);
-    const bool q_is_pad = (qq < a.L) ? (idb[qq] == 0) : true;
-    float lse_q = 0.f, delta_q = 0.f;
-    if (MODE == MODE_SOFTMAX) {
-      if (qq < a.L) lse_q = a.lse[(long long)bh * a.L + qq];
-      delta_q = delta_from_frags<HDV>(a, a.o + rowbase * a.ldo + h * a.hd, qq, half, bh, gf);
-    }
-    long long t_q1 = 0;
-    if (MODE == MODE_HSTU && a.ts && qq < a.L) t_q1 = hl.ts[qq + 1];
-    f32x16 dqacc[NT];
+    for (int it = 0;; ++it) {
+      const int qt = sched_tile<NW, DMA>(it, wave, n_t, a.causal != 0, true);
+      if (qt < 0) break;
+      const int qq = qt * TK + col;
+      f32x4 qf[HDV], gf[HDV];
+      load_row_frags<HDV>(qb, a.ldq, qq, a.L, a.hd, half, qf);
+      load_row_frags<HDV>(gb, a.lddo, qq, a.L, a.hd, half, gf);
+      const bool q_is_pad = (qq < a.L) ? (idb[qq] == 0) : true;
+      float lse_q = 0.f, delta_q = 0.f;
+      if (MODE == MODE_SOFTMAX) {
+        if (qq < a.L) lse_q = a.lse[(long long)bh * a.L + qq];
+        delta_q = delta_from_frags<HDV>(a, a.o + rowbase * a.ldo + h * a.hd, qq, half, bh, gf);
+      }
+      long long t_q1 = 0;
+      if (MODE == MODE_HSTU && a.ts && qq < a.L) t_q1 = hl.ts[qq + 1];
+      f32x16 dqacc[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dqacc[t][r] = 0.f;
-    const int last_kt = a.causal ? qt : n_t - 1;
-    const bool q_inside = (qt + 1) * TK <= a.L;
-    TimeGradRun trun; trun.init();
+        for (int r = 0; r < 16; ++r) dqacc[t][r] = 0.f;
+      const int last_kt = a.causal ? qt : n_t - 1;
+      const bool q_inside = (qt + 1) * TK <= a.L;
+      TimeGradRun trun; trun.init();
 #pragma unroll 1
-    for (int kt = 0; kt <= last_kt; ++kt) {
-      const bool interior = MODE == MODE_SOFTMAX && !a.no_interior && !a.keypad && q_inside && (kt + 1) * TK <= a.L && (!a.causal || kt < qt);
-      if (interior)
-        dq_pair<MODE, HD, false>(a, Ks + kt * TK * lds_ld, Vs + kt * TK * lds_ld, kflag + kt * TK, kt, qq, q_is_pad, t_q1,
-                                 bh, col, half, qf, gf, lse_q, delta_q, hl, dqacc, trun);
-      else
-        dq_pair<MODE, HD, true>(a, Ks + kt * TK * lds_ld, Vs + kt * TK * lds_ld, kflag + kt * TK, kt, qq, q_is_pad, t_q1,
-                                bh, col, half, qf, gf, lse_q, delta_q, hl, dqacc, trun);
+      for (int kt = 0; kt <= last_kt; ++kt) {
+        if (DMA && kt > ready) { wait_tile(tflag, kt); ready = kt; }
+        const bool interior = MODE == MODE_SOFTMAX && !a.no_interior && !a.keypad && q_inside && (kt + 1) * TK <= a.L && (!a.causal || kt < qt);
+        if (interior)
+          dq_pair<MODE, HD, false, DMA>(a, Ks + kt * TK * lds_ld, Vs + kt * TK * lds_ld, kflag + kt * TK, kt, qq, q_is_pad, t_q1,
+                                        bh, col, half, qf, gf, lse_q, delta_q, hl, dqacc, trun, sl);
+        else
+          dq_pair<MODE, HD, true, DMA>(a, Ks + kt * TK * lds_ld, Vs + kt * TK * lds_ld, kflag + kt * TK, kt, qq, q_is_pad, t_q1,
+                                       bh, col, half, qf, gf, lse_q, delta_q, hl, dqacc, trun, sl);
+      }
+      if (MODE == MODE_HSTU && a.d_time_w) trun.flush(hl.dtw);
+      store_rows_T<HD>(a.dq + rowbase * a.lddq + h * a.hd, a.lddq, qq, a.L, a.hd, half, dqacc);
     }
-    if (MODE == MODE_HSTU && a.d_time_w) trun.flush(hl.dtw);
-    store_rows_T<HD>(a.dq + rowbase * a.lddq + h * a.hd, a.lddq, qq, a.L, a.hd, half, dqacc);
   }
   if (MODE == MODE_HSTU) {
     __syncthreads();
@@ -842,19 +987,21 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(AttnArgs a) {
   }
 }
 
-template <int MODE, int HD, int NW>
+template <int MODE, int HD, int NW, bool DMA>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_res_kernel(AttnArgs a) {
-  constexpr int HDV = HD / 8, NT = HD / 32, NTH = NW * 64;
+  constexpr int HDV = HD / 8, NT = HD / 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n_t = (a.L + TK - 1) / TK, Lp = n_t * TK;
-  constexpr int lds_ld = HD + 4;
-  float* Qs = smem;                        // [Lp][hd+4]
-  float* Gs = Qs + Lp * lds_ld;            // [Lp][hd+4] dO
+  constexpr int lds_ld = DMA ? HD : HD + 4;
+  const int NTH = blockDim.x;
+  float* Qs = smem;                        // [Lp][lds_ld]
+  float* Gs = Qs + Lp * lds_ld;            // [Lp][lds_ld] dO
   float* s_lse = Gs + Lp * lds_ld;         // [Lp]
   float* s_delta = s_lse + Lp;             // [Lp]
   float* qflag = s_delta + Lp;             // [Lp] query pad flags
+  lds_flag_ptr tflag = (lds_flag_ptr)(qflag + Lp);
   HstuLds hl{};
-  if (MODE == MODE_HSTU) hstu_carve(qflag + Lp, a.L, false, hl);
+  if (MODE == MODE_HSTU) hstu_carve(qflag + Lp + ((n_t + 3) & ~3), a.L, false, hl);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile loops and LDS tile bases stay scalar
@@ -864,18 +1011,26 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_res_kernel(AttnArgs a) {
   const float* kb = a.k + rowbase * a.ldk + h * a.hd;
   const float* vb = a.v + rowbase * a.ldv + h * a.hd;
   const long long* idb = a.ids + rowbase;
-  stage_rows2<HD>(a.q + rowbase * a.ldq + h * a.hd, a.ldq, Qs, a.dout + rowbase * a.lddo + h * a.hd, a.lddo, Gs, a.L, Lp, a.hd, tid, NTH);
+  if (!DMA) stage_rows2<HD>(a.q + rowbase * a.ldq + h * a.hd, a.ldq, Qs, a.dout + rowbase * a.lddo + h * a.hd, a.lddo, Gs, a.L, Lp, a.hd, tid, NTH);
   for (int i = tid; i < Lp; i += NTH) {
     s_lse[i] = (MODE == MODE_SOFTMAX && i < a.L) ? a.lse[(long long)bh * a.L + i] : 0.f;
     s_delta[i] = (MODE == MODE_SOFTMAX && i < a.L) ? a.delta[(long long)bh * a.L + i] : 0.f;
     qflag[i] = (i < a.L && idb[i] != 0) ? 0.f : 1.f;
   }
+  if (DMA && tid < n_t) tflag[tid] = 0;
   if (MODE == MODE_HSTU) hstu_fill(a, hl, b, tid, NTH);
   __syncthreads();
+  if constexpr (DMA) if (wave == NW - 1) {   // query tiles arrive last-first: a key tile needs the query tiles at and behind it
+    res_loader<HD>(a.q + rowbase * a.ldq + h * a.hd, a.ldq, Qs, a.dout + rowbase * a.lddo + h * a.hd, a.lddo, Gs, a.L, n_t, true,
+                   tflag, lane);
+    return;
+  }
+  int ready = n_t;   // lowest query tile this wave has seen landed
+  SwzLane<HD> sl; sl.init(col, half);
 
 #pragma unroll 1
   for (int it = 0;; ++it) {
-    const int ktile = tile_for<NW>(it, wave, n_t, a.causal != 0, false);
+    const int ktile = sched_tile<NW, DMA>(it, wave, n_t, a.causal != 0, false);
     if (ktile < 0) break;
     const int kk = ktile * TK + col;
     f32x4 kf[HDV], vf[HDV];
@@ -892,14 +1047,15 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_res_kernel(AttnArgs a) {
     const int first_qt = a.causal ? ktile : 0;
     const bool k_inside = (ktile + 1) * TK <= a.L;
 #pragma unroll 1
-    for (int qt = first_qt; qt < n_t; ++qt) {
+    for (int qt = n_t - 1; qt >= first_qt; --qt) {
+      if (DMA && qt < ready) { wait_tile(tflag, qt); ready = qt; }
       const bool interior = MODE == MODE_SOFTMAX && !a.no_interior && !a.keypad && k_inside && (qt + 1) * TK <= a.L && (!a.causal || ktile < qt);
       if (interior)
-        dkv_pair<MODE, HD, false>(a, Qs + qt * TK * lds_ld, Gs + qt * TK * lds_ld, s_lse + qt * TK, s_delta + qt * TK,
-                                  qflag + qt * TK, qt, kk, k_is_pad, t_k, bh, col, half, kf, vf, hl, dkacc, dvacc);
+        dkv_pair<MODE, HD, false, DMA>(a, Qs + qt * TK * lds_ld, Gs + qt * TK * lds_ld, s_lse + qt * TK, s_delta + qt * TK,
+                                       qflag + qt * TK, qt, kk, k_is_pad, t_k, bh, col, half, kf, vf, hl, dkacc, dvacc, sl);
       else
-        dkv_pair<MODE, HD, true>(a, Qs + qt * TK * lds_ld, Gs + qt * TK * lds_ld, s_lse + qt * TK, s_delta + qt * TK,
-                                 qflag + qt * TK, qt, kk, k_is_pad, t_k, bh, col, half, kf, vf, hl, dkacc, dvacc);
+        dkv_pair<MODE, HD, true, DMA>(a, Qs + qt * TK * lds_ld, Gs + qt * TK * lds_ld, s_lse + qt * TK, s_delta + qt * TK,
+                                      qflag + qt * TK, qt, kk, k_is_pad, t_k, bh, col, half, kf, vf, hl, dkacc, dvacc, sl);
     }
     store_rows_T<HD>(a.dk + rowbase * a.lddk + h * a.hd, a.lddk, kk, a.L, a.hd, half, dkacc);
     store_rows_T<HD>(a.dv + rowbase * a.lddv + h * a.hd, a.lddv, kk, a.L, a.hd, half, dvacc);
@@ -913,9 +1069,21 @@ inline size_t stream_lds_bytes(int hd /* padded: HD */, int L, int aux_floats, b
   return ((size_t)2 * TK * (hd + 4) + aux_floats + (hstu ? hstu_lds_floats(L, grads) : 0)) * 4 + 64;
 }
 inline size_t res_lds_bytes(int hd, int L, int aux_rows, bool hstu, bool grads) {
-  const size_t Lp = (size_t)((L + TK - 1) / TK) * TK;
-  return ((size_t)2 * Lp * (hd + 4) + aux_rows * Lp + (hstu ? hstu_lds_floats(L, grads) : 0)) * 4 + 64;
+  const size_t Lp = (size_t)((L + TK - 1) / TK) * TK;   // + Lp/32 tile flags (rounded up to 4) of the DMA variant
+  return ((size_t)2 * Lp * (hd + 4) + aux_rows * Lp + (Lp / TK + 3) + (hstu ? hstu_lds_floats(L, grads) : 0)) * 4 + 64;
 }
+// RT_ATTN_DMA=1 selects the loader-wave variant of the resident kernels.  OFF by default: measured on MI355X at the C2 shape
+// (B 128, H 4, L 200, hd 64, p 0.2; whole GPU test suite green with it on) it is a wash — forward 78.4 vs 76.7 us, backward
+// 282 vs 292 us in isolation, 0.46 vs 0.42 ms/step of rt_mha_bwd inside the training step.  The register-staged prologue is
+// ONE load round trip (14 float4 per thread in flight, ~5 us), not the 17 us the ablation suggested; what bounds these
+// kernels is the causal schedule itself: 28 tile pairs on 4 SIMDs as 8 + 8 + 8 + 4, each pair a 32-MFMA dependent chain,
+// a softmax / dropout VALU phase and a second 32-MFMA phase.
+inline bool attn_allow_dma() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("RT_ATTN_DMA"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v == 1;
+}
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 // RT_ATTN_IMPL=stream forces the streaming family (tests / A-B measurements)
 inline bool attn_allow_resident() {
   static int v = -1;
@@ -933,8 +1101,16 @@ int launch_fwd(const AttnArgs& a, hipStream_t stream) {
   constexpr int NW = HD <= 64 ? 8 : 4;
   const size_t rl = res_lds_bytes(HD, a.L, 1, MODE == MODE_HSTU, false);
   if (rl <= LDS_LIMIT && attn_allow_resident()) {
-    { const int rc = set_lds(&attn_fwd_res_kernel<MODE, HD, NW>, rl); if (rc != RT_OK) return rc; }
-    attn_fwd_res_kernel<MODE, HD, NW><<<a.B * a.H, NW * 64, rl, stream>>>(a);
+    if constexpr (HD <= 64) {   // loader-wave variant: exact head dim, 16-byte aligned rows
+      if (a.hd == HD && attn_allow_dma() && al16(a.k) && al16(a.v)) {
+        { const int rc = set_lds(&attn_fwd_res_kernel<MODE, HD, NW, true>, rl); if (rc != RT_OK) return rc; }
+        attn_fwd_res_kernel<MODE, HD, NW, true><<<a.B * a.H, NW * 64, rl, stream>>>(a);
+        RT_CHECK_LAUNCH();
+        return RT_OK;
+      }
+    }
+    { const int rc = set_lds(&attn_fwd_res_kernel<MODE, HD, NW, false>, rl); if (rc != RT_OK) return rc; }
+    attn_fwd_res_kernel<MODE, HD, NW, false><<<a.B * a.H, NW * 64, rl, stream>>>(a);
     RT_CHECK_LAUNCH();
     return RT_OK;
   }
@@ -951,18 +1127,22 @@ int launch_bwd(const AttnArgs& a, hipStream_t stream) {
   const size_t r1 = res_lds_bytes(HD, a.L, 1, MODE == MODE_HSTU, true);
   const size_t r2 = res_lds_bytes(HD, a.L, 3, MODE == MODE_HSTU, false);
   if (r1 <= LDS_LIMIT && r2 <= LDS_LIMIT && attn_allow_resident()) {
-    { const int rc = set_lds(&attn_bwd_dq_res_kernel<MODE, HD, NW>, r1); if (rc != RT_OK) return rc; }
-    { const int rc = set_lds(&attn_bwd_dkv_res_kernel<MODE, HD, NW>, r2); if (rc != RT_OK) return rc; }
-    attn_bwd_dq_res_kernel<MODE, HD, NW><<<a.B * a.H, NW * 64, r1, stream>>>(a);
-    RT_CHECK_LAUNCH();
-    static int dkv_nw = -1;
-    if (dkv_nw < 0) { const char* e = getenv("RT_ATTN_DKV_NW"); dkv_nw = (e && atoi(e) == 4) ? 4 : NW; }
-    if (dkv_nw == 4 && NW == 8) {
-      { const int rc = set_lds(&attn_bwd_dkv_res_kernel<MODE, HD, 4>, r2); if (rc != RT_OK) return rc; }
-      attn_bwd_dkv_res_kernel<MODE, HD, 4><<<a.B * a.H, 256, r2, stream>>>(a);
-    } else {
-      attn_bwd_dkv_res_kernel<MODE, HD, NW><<<a.B * a.H, NW * 64, r2, stream>>>(a);
+    if constexpr (HD <= 64) {
+      if (a.hd == HD && attn_allow_dma() && al16(a.k) && al16(a.v) && al16(a.q) && al16(a.dout)) {
+        { const int rc = set_lds(&attn_bwd_dq_res_kernel<MODE, HD, NW, true>, r1); if (rc != RT_OK) return rc; }
+        { const int rc = set_lds(&attn_bwd_dkv_res_kernel<MODE, HD, NW, true>, r2); if (rc != RT_OK) return rc; }
+        attn_bwd_dq_res_kernel<MODE, HD, NW, true><<<a.B * a.H, NW * 64, r1, stream>>>(a);
+        RT_CHECK_LAUNCH();
+        attn_bwd_dkv_res_kernel<MODE, HD, NW, true><<<a.B * a.H, NW * 64, r2, stream>>>(a);
+        RT_CHECK_LAUNCH();
+        return RT_OK;
+      }
     }
+    { const int rc = set_lds(&attn_bwd_dq_res_kernel<MODE, HD, NW, false>, r1); if (rc != RT_OK) return rc; }
+    { const int rc = set_lds(&attn_bwd_dkv_res_kernel<MODE, HD, NW, false>, r2); if (rc != RT_OK) return rc; }
+    attn_bwd_dq_res_kernel<MODE, HD, NW, false><<<a.B * a.H, NW * 64, r1, stream>>>(a);
+    RT_CHECK_LAUNCH();
+    attn_bwd_dkv_res_kernel<MODE, HD, NW, false><<<a.B * a.H, NW * 64, r2, stream>>>(a);
     RT_CHECK_LAUNCH();
     return RT_OK;
   }
