@@ -403,7 +403,7 @@ def topk_leg(kind, args, rank, world, cpu_baseline):
         steps, warmup = args.rec_steps, 3
         metric = "recommend() users/sec @k=10 (SASRec d=256, ML-20M-shaped catalog, filter_viewed)"
         workload = f"recommend top-k: 26744 items x d256 fp32, {ups} users/step, k=10, viewed-filter CSR"
-        name, with_filter = "recommend_ml20m", True
+        name, with_filter = "recommend_ml20m", os.environ.get("RT_BENCH_NO_FILTER") != "1"   # (diagnostic: cost of the viewed-items test)
     else:
         V, d = 5_000_000, 512
         ups = args.users_per_step or 16   # 16 users/launch: the HBM-bound regime (AI = B/2 flop/B; 32 users is the fp32 ridge)
