@@ -179,9 +179,11 @@ int rt_bag_sum_bwd(const float* d_out, const int64_t* t_items, const int64_t* ch
 int rt_embed_fwd(const int64_t* ids, const float* table, const float* pos, float scale, int32_t M, int32_t L,
                  int32_t d, float p, uint64_t seed, uint64_t stream_id, float* out, rt_stream_t stream);
 size_t rt_embed_bwd_workspace_bytes(int32_t M, int32_t V, int32_t d);
+/* accumulate = 1: gtable already holds another gradient of the same table (the loss's, lightning.py:311-321 — autograd
+ * would add the two with a [V,d] kernel): rows occurring in `ids` are added to in place, no other row is touched. */
 int rt_embed_bwd(const int64_t* ids, const float* gout, float scale, int32_t M, int32_t L, int32_t d, int32_t V, float p,
-                 uint64_t seed, uint64_t stream_id, float* gtable, float* gpos, void* workspace, size_t workspace_bytes,
-                 rt_stream_t stream);
+                 uint64_t seed, uint64_t stream_id, float* gtable, int32_t accumulate, float* gpos, void* workspace,
+                 size_t workspace_bytes, rt_stream_t stream);
 
 /* K3  LayerNorm over rows of [M,d] (nn.LayerNorm call sites: sasrec.py:221,226,303; net_blocks.py:247,257;
  * ligr.py:90,102; hstu.py:256,291).  mean/rstd [M] are saved for the backward; dx/dw/db are overwritten

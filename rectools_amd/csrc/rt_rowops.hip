@@ -59,6 +59,7 @@ struct EmbBwdArgs {
   const long long* ids; const float* gout; float scale; int M, L, d, V; float p;
   unsigned long long seed, stream;
   float* gtable; float* gpos;
+  int accumulate;   // 1: gtable already holds another gradient of the same table: rows with positions are ADDED to, others left alone
   int* count; int* offsets; int* cursor; int* blocksum; int* order; int* rank; int* heavy_count; int* heavy_ids; int* heavy_chunk;
   float* slab;   // [chunks][d] partial rows of the popular ids
 };
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(256) void embed_bwd_rows_kernel(EmbBwdArgs a) {
   const int id = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (id >= a.V) return;
   const int beg = a.offsets[id], end = a.offsets[id + 1];
+  if (a.accumulate && beg == end) return;   // untouched row of an accumulation target: nothing to add, nothing to write
   f32x4 acc[NDV];
 #pragma unroll
   for (int i = 0; i < NDV; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -128,7 +130,10 @@ __global__ __launch_bounds__(256) void embed_bwd_rows_kernel(EmbBwdArgs a) {
 #pragma unroll
   for (int i = 0; i < NDV; ++i) {
     const int c = lane * 4 + 256 * i;
-    if (c < a.d) *reinterpret_cast<f32x4*>(a.gtable + (long long)id * a.d + c) = acc[i] * a.scale;
+    if (c < a.d) {
+      f32x4* dst = reinterpret_cast<f32x4*>(a.gtable + (long long)id * a.d + c);
+      *dst = a.accumulate ? *dst + acc[i] * a.scale : acc[i] * a.scale;   // one wave owns the row: no race
+    }
   }
 }
 
@@ -593,15 +598,17 @@ size_t rt_embed_bwd_workspace_bytes(int32_t M, int32_t V, int32_t d) {
 }
 
 // gtable [V,d] and gpos [L,d] (optional) are fully overwritten; M must be a multiple of L when gpos is given.
+// accumulate = 1: gtable already holds another gradient of the same table (the loss's): the rows that occur in `ids` are
+// added to in place and no other row is touched — no second [V,d] tensor, no [V,d] add (3 GB of traffic at V = 1M, d = 256).
 int rt_embed_bwd(const int64_t* ids, const float* gout, float scale, int32_t M, int32_t L, int32_t d, int32_t V, float p,
-                 uint64_t seed, uint64_t stream_id, float* gtable, float* gpos, void* workspace, size_t workspace_bytes,
-                 hipStream_t stream) {
+                 uint64_t seed, uint64_t stream_id, float* gtable, int32_t accumulate, float* gpos, void* workspace,
+                 size_t workspace_bytes, hipStream_t stream) {
   (void)hipGetLastError();
   if ((d & 3) != 0 || L <= 0 || V <= 0 || M < 0 || d > 1024 || (gpos && (M % L) != 0)) return RT_ERR_INVALID_ARG;
   if (workspace == nullptr || workspace_bytes < rt_embed_bwd_workspace_bytes(M, V, d)) return RT_ERR_WORKSPACE;
   EmbBwdArgs a{};
   a.ids = reinterpret_cast<const long long*>(ids); a.gout = gout; a.scale = scale; a.M = M; a.L = L; a.d = d; a.V = V; a.p = p;
-  a.seed = seed; a.stream = stream_id; a.gtable = gtable; a.gpos = gpos;
+  a.seed = seed; a.stream = stream_id; a.gtable = gtable; a.gpos = gpos; a.accumulate = accumulate;
   const size_t n = (size_t)V + 1, cap = (size_t)emb_chunk_cap(M);
   a.slab = reinterpret_cast<float*>(workspace);   // first: 16-byte aligned rows
   int* ip = reinterpret_cast<int*>(a.slab + cap * (size_t)d);

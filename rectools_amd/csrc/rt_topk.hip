@@ -64,6 +64,7 @@ struct TopkArgs {
   int list_base;                 // 16-user tile: merged list of workgroup sx is list `list_base + sx` of `n_lists_total`
   int n_lists_total;             //   merged lists are stored [user][list][k] (a user's lists are contiguous for the selection)
   int use_bound;                 // 16-user tile: 0 = seeding prefix (the shared bound is neither read nor published)
+  int bloom;                     // engine 2: 1 = a 1024-bit Bloom filter per user of the tile sits in LDS behind the lists
 };
 
 __device__ __forceinline__ bool better(float s, long long p, float s2, long long p2) {
@@ -143,11 +144,13 @@ struct SelState {
   float g_seen[TU];          // last value of the shared bound this lane has observed / published
   fptr ls[TU]; iptr lp[TU];  // this lane's list storage per user tile (LDS for small k, else global)
   long long fbase[TU]; int flg[TU];   // this lane's filter hash table (bind_filter)
+  typedef __attribute__((address_space(3))) const unsigned* bptr;
+  bptr bl[TU];               // this lane's user's Bloom filter words (32 x 32 bits) when TopkArgs::bloom
   __device__ __forceinline__ void init() {
 #pragma unroll
     for (int tu = 0; tu < TU; ++tu) {
       worst_s[tu] = -INFINITY; worst_p[tu] = -1; worst_slot[tu] = 0; cnt[tu] = 0; thr[tu] = -INFINITY;
-      g_seen[tu] = -INFINITY; ls[tu] = nullptr; lp[tu] = nullptr;
+      g_seen[tu] = -INFINITY; ls[tu] = nullptr; lp[tu] = nullptr; bl[tu] = nullptr;
     }
   }
   // continue lists left by an earlier phase (global image; copied into the bound storage if that is LDS)
@@ -273,7 +276,13 @@ __device__ __forceinline__ void select_block(const TopkArgs& a, SelState<TU, LL>
         const long long cid = a.whitelist ? a.whitelist[p] : p + a.id_offset;
         if (a.filt_hash != nullptr) {   // O(1) probe of the user's hash set (table view cached per lane)
           bool hit = false;
-          if (st.flg[tu] >= 0) {
+          bool maybe = st.flg[tu] >= 0;
+          if (a.bloom && maybe) {   // two bits of the user's LDS Bloom filter: a clear bit proves "not viewed" without the
+            // global-memory probe below (a dependent L2 / Infinity-Cache round trip inside the serialised slow path)
+            const unsigned h1 = ((unsigned)cid * 0x9E3779B1u) >> 22, h2 = ((unsigned)cid * 0x85EBCA77u) >> 22;
+            maybe = ((st.bl[tu][h1 >> 5] >> (h1 & 31)) & (st.bl[tu][h2 >> 5] >> (h2 & 31)) & 1u) != 0;
+          }
+          if (maybe) {
             const int* tab = a.filt_hash + st.fbase[tu];
             const unsigned mask = (1u << st.flg[tu]) - 1u;
             unsigned h = filt_hash_of((unsigned)cid, st.flg[tu]);
@@ -574,6 +583,34 @@ __global__ __launch_bounds__(NTHREADS + NLD * 64) void topk_stream_kernel(TopkAr
     if (a.resume) st.resume(a, list_id, user0, lane, LL);
   }
   if (T == 0) { if (computes && !a.resume) publish_counts<TU, LL>(a, st, list_id, user0, lane, false); return; }
+
+  if (a.bloom) {
+    // Per-user Bloom filters of the viewed items (1024 bits, two hash functions: ~6 % false positives at 144 items) behind
+    // the lists: built once per workgroup from the CSR rows of its UB users; the slow path consults them before the exact
+    // hash-set probe in global memory.  Every wave (loaders included) takes part; both barriers precede the ring.
+    typedef __attribute__((address_space(3))) unsigned* wptr;
+    const int kp_l = (a.k + 3) & ~3;
+    wptr bl = (wptr)(smem + NS * STAGE + (LL ? 2 * LISTS_PER_WG * UB * kp_l : 0));
+    constexpr int NWV = (NTHREADS + NLD * 64) / 64;
+    for (int i = tid; i < UB * 32; i += NWV * 64) bl[i] = 0u;
+    __syncthreads();
+    for (int ul = wave; ul < UB; ul += NWV) {
+      const int u = user0 + ul;
+      if (u >= a.n_users) continue;
+      const long long lo = a.filt_indptr[u], hi = a.filt_indptr[u + 1];
+      for (long long e = lo + lane; e < hi; e += 64) {
+        const unsigned cid = (unsigned)a.filt_indices[e];
+        const unsigned h1 = (cid * 0x9E3779B1u) >> 22, h2 = (cid * 0x85EBCA77u) >> 22;
+        atomicOr((unsigned*)(bl + ul * 32 + (h1 >> 5)), 1u << (h1 & 31));   // generic pointer: before the ring starts
+        atomicOr((unsigned*)(bl + ul * 32 + (h2 >> 5)), 1u << (h2 & 31));
+      }
+    }
+    __syncthreads();
+    if (computes) {
+#pragma unroll
+      for (int tu = 0; tu < TU; ++tu) st.bl[tu] = (typename SelState<TU, LL>::bptr)(bl + (tu * 32 + (lane & 31)) * 32);
+    }
+  }
 
   // ---- DMA source assignment ----
   // items: piece j of issuer w fills rows (w*IPI+j)*8 .. +7 ; lane -> row + (lane>>3), slot lane&7
@@ -1378,8 +1415,12 @@ inline Plan make_plan(int n_users, long long n_cand, int k, int users_per_pass) 
 }
 
 template <int TU, int NS, bool WL, bool LL, int NLD, bool BF = false>
-int launch_stream_nld(const TopkArgs& a, dim3 grid, hipStream_t stream) {
-  const size_t lds = stream_lds_bytes(TU, NS, LL ? a.k : 0);
+int launch_stream_nld(const TopkArgs& a_in, dim3 grid, hipStream_t stream) {
+  TopkArgs a = a_in;
+  size_t lds = stream_lds_bytes(TU, NS, LL ? a.k : 0);
+  // per-user Bloom filters of the viewed items, if the filter comes with hash sets and 128 B per user still fit in LDS
+  a.bloom = (!BF && a.filt_hash != nullptr && env_int("RT_TOPK_BLOOM", 1) != 0 && lds + (size_t)32 * TU * 128 <= LDS_PER_CU) ? 1 : 0;
+  if (a.bloom) lds += (size_t)32 * TU * 128;
   static size_t attr_lds = 0;
   if (lds > 64 * 1024 && lds > attr_lds) {
     RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_stream_kernel<TU, NS, WL, LL, NLD, BF>),

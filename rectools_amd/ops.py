@@ -268,6 +268,17 @@ def matmul_nn(x: torch.Tensor, p: torch.Tensor) -> torch.Tensor:
 # --------------------------------------------------------------------------------------------------
 # row-wise
 # --------------------------------------------------------------------------------------------------
+# Gradient sink of an item table: the loss node writes d(loss)/d(table) [V,d] first; the embedding node — the LAST node of
+# every backward pass — then adds its rows INTO that tensor (rt_embed_bwd accumulate) and returns no gradient of its own,
+# instead of producing a second [V,d] tensor that autograd would add with a full-size kernel.  Keyed by the table's storage.
+_TABLE_GRAD_SINK: tp.Dict[int, torch.Tensor] = {}
+
+
+def _offer_table_grad(table: torch.Tensor, d_table: torch.Tensor) -> None:
+    if d_table.is_contiguous() and d_table.shape == table.shape:
+        _TABLE_GRAD_SINK[table.data_ptr()] = d_table
+
+
 class _Embed(torch.autograd.Function):
     @staticmethod
     def forward(ctx, table, pos, ids, L, scale, p):
@@ -278,6 +289,8 @@ class _Embed(torch.autograd.Function):
         _c("rt_embed_fwd", ids, table, pos, float(scale), M, L, d, float(p), seed, sid, out)
         ctx.save_for_backward(ids)
         ctx.meta = (table.shape, None if pos is None else pos.shape, L, scale, p, seed, sid)
+        ctx.table_ptr = table.data_ptr()
+        _TABLE_GRAD_SINK.pop(ctx.table_ptr, None)   # a sink left over from an aborted backward pass must not be reused
         return out
 
     @staticmethod
@@ -286,14 +299,18 @@ class _Embed(torch.autograd.Function):
         tshape, pshape, L, scale, p, seed, sid = ctx.meta
         gout = gout.contiguous()
         M, V = ids.numel(), tshape[0]
-        gtable = torch.empty(tshape, dtype=torch.float32, device=gout.device)   # every row is written by the kernel
+        sink = _TABLE_GRAD_SINK.pop(ctx.table_ptr, None)
+        if sink is not None and (tuple(sink.shape) != tuple(tshape) or sink.device != gout.device):
+            sink = None
+        gtable = sink if sink is not None else torch.empty(tshape, dtype=torch.float32, device=gout.device)
         gpos = None
         if pshape is not None:  # rows [0, L) are written; a longer table keeps zero gradient behind them
             gpos = (torch.empty if pshape[0] == L else torch.zeros)(pshape, dtype=torch.float32, device=gout.device)
         ws_bytes = _lib.load().rt_embed_bwd_workspace_bytes(M, V, tshape[1])
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=gout.device)
-        _c("rt_embed_bwd", ids, gout, float(scale), M, L, tshape[1], V, float(p), seed, sid, gtable, gpos, ws, ws_bytes)
-        return gtable, gpos, None, None, None, None
+        _c("rt_embed_bwd", ids, gout, float(scale), M, L, tshape[1], V, float(p), seed, sid, gtable, 1 if sink is not None else 0,
+           gpos, ws, ws_bytes)
+        return (None if sink is not None else gtable), gpos, None, None, None, None
 
 
 def embed(table: torch.Tensor, pos: tp.Optional[torch.Tensor], ids: torch.Tensor, L: int, scale: float,
@@ -841,6 +858,7 @@ class _SampledLoss(torch.autograd.Function):
         # side stream under the MFMA-bound layer backward (rt_sampled_loss_bwd accepts either output as NULL for that):
         # measured 3.12 vs 3.06 ms/step at C2 — the co-running gather slows the GEMMs by more than it hides.
         _c("rt_sampled_loss_bwd", *args, d_sess, d, d_table, ws, ws.numel())
+        _offer_table_grad(table, d_table)
         return d_sess, d_table, None, None, None, None, None, None, None
 
 
@@ -906,6 +924,7 @@ class _SoftmaxLoss(torch.autograd.Function):
         _gemm(logits, Vp, 0, s_act, d, 0, d_tab, d, None, None, 0, Vp, d, Rp, 0, _wgrad_splits(Rp))  # dE = G^T @ S
         d_table = d_tab[:V]
         d_table[0].zero_()  # padding_idx row never receives gradient (item_net.py:260-264)
+        _offer_table_grad(tab[:V], d_table)
         d_sess = torch.zeros((M_total, d), dtype=torch.float32, device=logits.device)
         _c("rt_scatter_rows", ds_act, d, act_idx, R, d, d_sess, d)
         return d_sess, d_table, None, None, None, None, None
