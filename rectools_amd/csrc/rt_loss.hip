@@ -46,7 +46,8 @@ struct SampledArgs {
   float* glog;                            // [M, 1+N] dL/d(raw similarity) of every (position, candidate)
   float* inv_ns;                          // [M] 1 / max(||session||, eps)   (cosine)
   int* count; int* offsets; int* cursor;  // [V+1] counting-sort state over candidate ids
-  int* pairs;                             // [M*(1+N)] (position, candidate) pairs grouped by candidate id
+  int2* pairs;                            // [M*(1+N)] (position m, unit gradient bits) records grouped by candidate id
+  float* bterm;                           // [M*(1+N)] cosine only: the pair's share of sum_j g_j cos_j (chain rule of e/|e|)
   int* blocksum;                          // scan scratch
   int* rank;                              // [M, 1+N] rank of every pair inside its candidate id
   int* heavy_count; int* heavy_ids; int* heavy_chunk;   // chunk list of the rows with > HEAVY_T pairs (rt_scan.h)
@@ -86,7 +87,26 @@ __device__ __forceinline__ void gbce_transform(double z, double beta, double& f,
 // backward scales by gscale / norm once both exist.  Also takes the counting-sort ranks of the negatives.
 // SM = sampled softmax (fp32 only); !SM = BCE / gBCE (fp64 transforms) — separate instances keep the fp64 temporaries out
 // of the softmax kernel's register budget.
-template <int D4, bool TRAIN, bool SM>
+// One table row slice (D4 float4 per lane) through inline asm: hipcc's own waitcnt bookkeeping turns every attempt at software
+// pipelining of these gathers into `s_waitcnt vmcnt(0)` (one row per quarter-wave in flight); asm loads are invisible to it
+// and `gather_wait<N>` — which names the destination registers as in/out operands, so no use can be scheduled above it —
+// waits until at most N younger loads are outstanding (loads return in order).
+template <int D4>
+__device__ __forceinline__ void gather_issue(const float* row, int sub, f32x4 (&e)[D4]) {
+#pragma unroll
+  for (int i = 0; i < D4; ++i)
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(e[i]) : "v"(row + (sub + 16 * i) * 4) : "memory");
+}
+template <int N, int D4>
+__device__ __forceinline__ void gather_wait(f32x4 (&e)[D4]) {
+  if constexpr (D4 == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(e[0]) : "n"(N) : "memory");
+  else if constexpr (D4 == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(e[0]), "+v"(e[1]) : "n"(N) : "memory");
+  else if constexpr (D4 == 4) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]) : "n"(N) : "memory");
+  else asm volatile("s_waitcnt vmcnt(%8)" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]) : "n"(N) : "memory");
+}
+
+// FAST (d == 64 D4 and 1 + N <= 260, decided on the host): the pipelined gather loop below; otherwise the generic loop.
+template <int D4, bool TRAIN, bool SM, bool FAST = false>
 __global__ __launch_bounds__(256) void sampled_fwd_kernel(SampledArgs a) {
   __shared__ float s_z[4][260];
   __shared__ int s_cid[4][260];
@@ -136,6 +156,83 @@ __global__ __launch_bounds__(256) void sampled_fwd_kernel(SampledArgs a) {
     for (int i = 0; i < D4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
+  if constexpr (FAST) {
+    // ---- pipelined gather.  One iteration = 4 candidate rows (one per quarter-wave).  The generic loop below keeps ONE row
+    // per quarter-wave in flight and pays a full memory round trip per iteration (it used to pay a second one for a returning
+    // rank atomic): 33 dependent round trips per position made the C2 forward latency-bound (281 us for 3.4 GB of gather,
+    // 1.6 GB of it from the fabric).  Here the rows of PF iterations are in flight; slots past the last candidate (and the
+    // PF - 1 look-ahead iterations past the end) read the PAD row with weight 0, so the in-flight count is constant and the
+    // wait is a compile-time vmcnt; logits go to LDS and leave in one coalesced store after the loop.
+    constexpr int PF = D4 <= 4 ? 3 : 2;
+    const int n_it = (C + 3) >> 2;
+    auto row_of_it = [&](int it) -> const float* {
+      const int j = it * 4 + grp;
+      const long long cid = (j < C) ? (long long)s_cid[wave][j] : 0;
+      return a.table + cid * (long long)a.d;
+    };
+    auto consume = [&](int it, const f32x4 (&ev)[D4]) {
+      const int j = it * 4 + grp;
+      const bool valid = j < C;
+      float dot = 0.f, ee = 0.f;
+#pragma unroll
+      for (int i = 0; i < D4; ++i) {
+        dot += ev[i][0] * sv[i][0] + ev[i][1] * sv[i][1] + ev[i][2] * sv[i][2] + ev[i][3] * sv[i][3];
+        ee += ev[i][0] * ev[i][0] + ev[i][1] * ev[i][1] + ev[i][2] * ev[i][2] + ev[i][3] * ev[i][3];
+      }
+      dot = group16_sum(dot);
+      ee = group16_sum(ee);
+      const float einv = a.cosine ? 1.0f / fmaxf(sqrtf(ee), EPS_COS) : 1.0f;
+      float z = dot;
+      if (a.cosine) z = z * inv_ns * einv;
+      z *= a.inv_t;
+      if (valid && sub == 0) s_z[wave][j] = z;
+      if (TRAIN) {
+        float wj;   // weight of e_hat_j in d s_hat, up to the factors applied after the loop
+        if (SM) {
+          const float m_new = valid ? fmaxf(m_run, z) : m_run;
+          const float alpha = (m_new == -INFINITY) ? 1.f : __expf(m_run - m_new);
+          wj = valid ? __expf(z - m_new) : 0.f;
+          l_run = l_run * alpha + wj;
+          m_run = m_new;
+#pragma unroll
+          for (int i = 0; i < D4; ++i) acc[i] *= alpha;
+        } else {
+          double zd = (double)z, gd;
+          if (j == 0) {
+            double df = 1.0;
+            if (a.loss == LOSS_GBCE) { double f; gbce_transform(zd, a.gbce_beta, f, df); zd = f; }
+            gd = (sigmoid_d(zd) - 1.0) * df;
+          } else {
+            gd = sigmoid_d(zd);
+          }
+          wj = valid ? (float)(gd / (double)C) : 0.f;
+        }
+        const float we = wj * einv;
+#pragma unroll
+        for (int i = 0; i < D4; ++i) acc[i] += ev[i] * we;
+      }
+    };
+    // everything the compiler tracks (session row, ids) has landed before the first asm load: vmcnt starts at 0
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    f32x4 evb[PF][D4];
+#pragma unroll
+    for (int u = 0; u < PF - 1; ++u) gather_issue<D4>(row_of_it(u), sub, evb[u]);
+#pragma unroll 1
+    for (int it0 = 0; it0 < n_it; it0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int it = it0 + u;
+        gather_issue<D4>(row_of_it(it + PF - 1), sub, evb[(u + PF - 1) % PF]);   // look-ahead (PAD row past the end)
+        gather_wait<(PF - 1) * D4, D4>(evb[u]);
+        if (it < n_it) consume(it, evb[u]);
+      }
+    }
+    // Drain the look-ahead loads.  The wait must NAME the buffers: once the last `consume` is done the compiler considers their
+    // registers dead and would hand them to the address arithmetic below while PF - 1 loads are still on their way into them
+    // (seen on hardware as HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION: a table row landed in a pointer).
+#pragma unroll
+    for (int u = 0; u < PF; ++u) gather_wait<0, D4>(evb[u]);
+  } else {
 #pragma unroll 2
   for (int j0 = 0; j0 < C; j0 += 4) {
     const int j = j0 + grp;
@@ -164,7 +261,6 @@ __global__ __launch_bounds__(256) void sampled_fwd_kernel(SampledArgs a) {
     if (valid && sub == 0) {
       if (j < 260) s_z[wave][j] = z;
       zrow[j] = z;
-      if (TRAIN && j != 0 && cid != 0) a.rank[m * C + j] = atomicAdd(a.count + cid, 1);   // rank of this pair inside its id
     }
     if (TRAIN) {
       float wj;   // weight of e_hat_j in d s_hat, up to the factors applied after the loop
@@ -192,10 +288,18 @@ __global__ __launch_bounds__(256) void sampled_fwd_kernel(SampledArgs a) {
       for (int i = 0; i < D4; ++i) acc[i] += ev[i] * we;
     }
   }
+  }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
+  if constexpr (FAST) { for (int j = lane; j < C; j += 64) zrow[j] = s_z[wave][j]; }   // logits row: one coalesced store
+  if (TRAIN) {   // counting-sort ranks of the negatives (targets are ranked by agg_rank_kernel): independent atomics, all in flight
+    for (int j = 1 + lane; j < C; j += 64) {
+      const long long cid = (j < 260) ? (long long)s_cid[wave][j] : a.neg[(long long)m * a.N + (j - 1)];
+      if (cid != 0) a.rank[m * C + j] = atomicAdd(a.count + cid, 1);
+    }
+  }
   const float wgt = a.w[m];
   auto zat = [&](int j) -> float { return j < 260 ? s_z[wave][j] : zrow[j]; };
   float out, mx = 0.f, se = 1.f;
@@ -331,9 +435,18 @@ __global__ __launch_bounds__(256) void pairs_scatter_kernel(SampledArgs a) {
   const long long yy = a.y[m];
   if (yy == 0) return;
   const int C = a.N + 1;
-  for (int j = lane; j < C; j += 64) {   // slot = start of the id's segment + the rank taken when it was counted
+  // slot = start of the id's segment + the rank taken when it was counted.  The record carries everything the row reduction
+  // needs — the position and the (cosine: 1/|s| scaled) unit gradient — so that reduction is a TWO-deep chain
+  // (record -> session row) of wave-uniform scalar loads and row gathers instead of three dependent vector loads.
+  const float inv_ns_m = a.cosine ? a.inv_ns[m] : 1.f;
+  for (int j = lane; j < C; j += 64) {
     const long long cid = (j == 0) ? yy : a.neg[(long long)m * a.N + (j - 1)];
-    if (cid != 0) a.pairs[a.offsets[cid] + a.rank[m * C + j]] = m * C + j;
+    if (cid != 0) {
+      const int slot = a.offsets[cid] + a.rank[m * C + j];
+      const float g = a.glog[m * C + j];
+      a.pairs[slot] = make_int2(m, __float_as_int(g * inv_ns_m));
+      if (a.cosine) a.bterm[slot] = g * (a.logits[m * C + j] / a.inv_t);   // logits = cos / t
+    }
   }
 }
 
@@ -344,21 +457,18 @@ constexpr int HEAVY_T = 128;     // ids with more pairs than this go to the work
 constexpr int HEAVY_CH = 128;    // pairs per chunk of a popular row: one 4-wave workgroup, two rounds of 16 gathers per wave
 constexpr int HEAVY_WAVES = 4;
 
-template <int D4, int U>
+template <int D4, int U, bool COS>
 __device__ __forceinline__ void accumulate_pairs_u(const SampledArgs& a, int& k, int end, int lane,
                                                    f32x4 (&acc)[(D4 + 3) / 4], float& bsum) {
   constexpr int NA = (D4 + 3) / 4;
-  const int C = a.N + 1;
-  for (; k + U <= end; k += U) {   // U independent (pair -> gradient -> session row) chains in flight
-    int pr[U]; float g[U]; const float* sr[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) pr[u] = a.pairs[k + u];
+  for (; k + U <= end; k += U) {   // U independent (record -> session row) chains in flight; k is wave-uniform: scalar loads
+    float g[U]; const float* sr[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int m = pr[u] / C;
-      g[u] = a.glog[pr[u]];
-      if (a.cosine) { bsum += g[u] * (a.logits[pr[u]] / a.inv_t); g[u] *= a.inv_ns[m]; }   // logits = cos / t
-      sr[u] = a.sess + (long long)m * a.ld_sess;
+      const int2 rec = a.pairs[k + u];
+      g[u] = __int_as_float(rec.y);
+      if (COS) bsum += a.bterm[k + u];
+      sr[u] = a.sess + (long long)rec.x * a.ld_sess;
     }
     f32x4 v[U][NA];
 #pragma unroll
@@ -380,9 +490,15 @@ template <int D4>
 __device__ __forceinline__ void accumulate_pairs(const SampledArgs& a, int beg, int end, int lane,
                                                  f32x4 (&acc)[(D4 + 3) / 4], float& bsum) {
   int k = beg;
-  accumulate_pairs_u<D4, (D4 <= 4 ? 16 : 8)>(a, k, end, lane, acc, bsum);
-  accumulate_pairs_u<D4, 4>(a, k, end, lane, acc, bsum);
-  accumulate_pairs_u<D4, 1>(a, k, end, lane, acc, bsum);
+  if (a.cosine) {
+    accumulate_pairs_u<D4, (D4 <= 4 ? 16 : 8), true>(a, k, end, lane, acc, bsum);
+    accumulate_pairs_u<D4, 4, true>(a, k, end, lane, acc, bsum);
+    accumulate_pairs_u<D4, 1, true>(a, k, end, lane, acc, bsum);
+  } else {
+    accumulate_pairs_u<D4, (D4 <= 4 ? 16 : 8), false>(a, k, end, lane, acc, bsum);
+    accumulate_pairs_u<D4, 4, false>(a, k, end, lane, acc, bsum);
+    accumulate_pairs_u<D4, 1, false>(a, k, end, lane, acc, bsum);
+  }
 }
 
 // cosine: e -> e/|e| chain rule, then the single store of the row
@@ -421,7 +537,7 @@ template <int D4>
 __global__ __launch_bounds__(256) void sampled_bwd_rows_kernel(SampledArgs a) {
   constexpr int NA = (D4 + 3) / 4;
   const int lane = threadIdx.x & 63;
-  const int id = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int id = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));   // wave-uniform: offsets / records are scalar loads
   if (id >= a.V) return;
   const int beg = a.offsets[id], end = a.offsets[id + 1];
   f32x4 acc[NA];
@@ -451,7 +567,7 @@ __global__ __launch_bounds__(HEAVY_WAVES * 64) void sampled_bwd_heavy_kernel(Sam
   constexpr int NA = (D4 + 3) / 4;
   __shared__ f32x4 s_part[HEAVY_WAVES][NA][64];
   __shared__ float s_bsum[HEAVY_WAVES];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n_chunks = *a.heavy_count;
   for (int h = blockIdx.x; h < n_chunks; h += gridDim.x) {
     const int id = a.heavy_ids[h];
@@ -616,21 +732,39 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
 // needs more than HEAVY_T pairs to have chunks at all
 inline long long heavy_chunk_cap(long long n_pairs) { return n_pairs / HEAVY_CH + n_pairs / HEAVY_T + 2; }
 
+// RT_LOSS_FAST=0 keeps the generic gather loop of the forward kernels (A-B measurements)
+inline bool fwd_fast_allowed() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("RT_LOSS_FAST"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
+
 // stage: 0 = inference forward, 1 = training forward (logits, loss, unit gradients, ranks), 2 = backward
 template <int D4>
 int launch_sampled(const SampledArgs& a, int stage, hipStream_t stream) {
   const int blocks = (a.M + 3) / 4;
+  const bool fast = a.d == D4 * 64 && a.N + 1 <= 260 && fwd_fast_allowed();
   if (stage == 0) {
-    if (a.loss == LOSS_SAMPLED_SOFTMAX) sampled_fwd_kernel<D4, false, true><<<blocks, 256, 0, stream>>>(a);
-    else sampled_fwd_kernel<D4, false, false><<<blocks, 256, 0, stream>>>(a);
+    if (a.loss == LOSS_SAMPLED_SOFTMAX) {
+      if (fast) sampled_fwd_kernel<D4, false, true, true><<<blocks, 256, 0, stream>>>(a);
+      else sampled_fwd_kernel<D4, false, true><<<blocks, 256, 0, stream>>>(a);
+    } else {
+      if (fast) sampled_fwd_kernel<D4, false, false, true><<<blocks, 256, 0, stream>>>(a);
+      else sampled_fwd_kernel<D4, false, false><<<blocks, 256, 0, stream>>>(a);
+    }
     RT_CHECK_LAUNCH();
     return RT_OK;
   }
   const int n = a.V + 1;
   if (stage == 1) {
     RT_CHECK_HIP(hipMemsetAsync(a.count, 0, sizeof(int) * ((size_t)n + 1), stream));   // + heavy_count
-    if (a.loss == LOSS_SAMPLED_SOFTMAX) sampled_fwd_kernel<D4, true, true><<<blocks, 256, 0, stream>>>(a);
-    else sampled_fwd_kernel<D4, true, false><<<blocks, 256, 0, stream>>>(a);
+    if (a.loss == LOSS_SAMPLED_SOFTMAX) {
+      if (fast) sampled_fwd_kernel<D4, true, true, true><<<blocks, 256, 0, stream>>>(a);
+      else sampled_fwd_kernel<D4, true, true><<<blocks, 256, 0, stream>>>(a);
+    } else {
+      if (fast) sampled_fwd_kernel<D4, true, false, true><<<blocks, 256, 0, stream>>>(a);
+      else sampled_fwd_kernel<D4, true, false><<<blocks, 256, 0, stream>>>(a);
+    }
     RT_CHECK_LAUNCH();
     return RT_OK;
   }
@@ -667,8 +801,10 @@ void carve_workspace(SampledArgs& a, void* workspace, int M, int N, int V, int d
   a.slab_bsum = f; f += cap;
   a.glog = f; f += (size_t)M * C;
   a.inv_ns = f; f += M;
+  a.bterm = f; f += (size_t)M * C;
+  if (reinterpret_cast<uintptr_t>(f) & 7) f += 1;                   // the records are 8-byte loads
   int* ip = reinterpret_cast<int*>(f);
-  a.pairs = ip; ip += (size_t)M * C;
+  a.pairs = reinterpret_cast<int2*>(ip); ip += 2 * (size_t)M * C;
   a.rank = ip; ip += (size_t)M * C;
   a.count = ip; ip += n;
   a.heavy_count = ip; ip += 1;   // directly behind count: one memset clears both
@@ -702,7 +838,7 @@ size_t rt_sampled_loss_bwd_workspace_bytes(int32_t M, int32_t N, int32_t V, int3
   const size_t C = (size_t)N + 1, n = (size_t)V + 1;
   const size_t nb = (n + SCAN_T * SCAN_E - 1) / (SCAN_T * SCAN_E);
   const size_t cap = (size_t)heavy_chunk_cap((long long)M * (long long)C);
-  return 4 * ((size_t)M * C * 3 + (size_t)M + 3 * n + nb + 64 + 2 + cap * ((size_t)d + 3));
+  return 4 * ((size_t)M * C * 5 + (size_t)M + 3 * n + nb + 64 + 4 + cap * ((size_t)d + 3));
 }
 
 // Training forward: everything rt_sampled_loss_fwd writes, plus — in `workspace` — the unit gradient of every logit,
