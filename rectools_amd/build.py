@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(PKG_DIR, "librectools_hip.so")
 OBJ_DIR = os.path.join(CSRC, "_obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+FLAGS += os.environ.get("RT_EXTRA_HIPCC_FLAGS", "").split()   # diagnostic builds (e.g. -DRT_ATTN_TRACE); part of the digests
 
 
 def _sources():

@@ -107,6 +107,15 @@ template <int HD> struct SwzLane {
   }
 };
 
+// With the swizzle the HD/8 fragment reads of a tile pair sit at HD/8 different per-lane offsets (slot ^ swz(row) is not
+// base + immediate); hipcc hoists all of them out of the tile loop as loop invariants and then spills them — reloads that put
+// `s_waitcnt vmcnt(0)` inside the loop and drain the DMA ring.  Making the lane id opaque per pair keeps the two VALU ops per
+// ds_read_b128 inside the loop instead (nothing next to the 4-8 MFMAs each read feeds).
+template <bool ON> __device__ __forceinline__ int opaque_if(int x) {
+  if (ON) asm volatile("" : "+v"(x));
+  return x;
+}
+
 // Is (query qq, key kk) masked out?  Mirrors torch_backbone.py:249-257 and _merge_masks (:172-218): causal `kk > qq`,
 // key padding, and — when both are on — the diagonal forced open.  Branch-free (the flags are wave-uniform 0/1).
 __device__ __forceinline__ bool masked(const AttnArgs& a, int qq, int kk, bool key_is_pad) {
@@ -212,32 +221,105 @@ struct HstuLds {
 // forward: S^T = K Q^T (rows = keys, cols = queries), online softmax / silu, O^T += V^T P^T
 // EDGE = false: the tile pair lies fully inside [0,L) x [0,L) and nothing in it is masked (softmax mode without the
 // key-padding mask, strictly below the causal diagonal) — all mask logic compiles away.
+// Instruction order inside a pair is pinned with scheduling fences (`sched_barrier(0)`: nothing moves across).  hipcc's own
+// order put every LDS operand read directly in front of the MFMAs that consume it — `ds_read; s_waitcnt lgkmcnt(0); 2-4 MFMAs`
+// — so each group of MFMAs paid a full LDS round trip with the matrix pipe idle (measured: a tile pair cost ~2.6x its MFMA
+// time in all three kernel families).  Here the operands of step s + 2 are requested while the MFMAs of step s run, and
+// everything that does not depend on the scores (dropout hashes, pad flags, the HSTU relative bias) is sliced into the S
+// chain, where the wave issues it under its own running MFMAs.
+#define RT_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// Optional in-kernel timeline (build with -DRT_ATTN_TRACE, scripts/gpu_diag_attn.sh): s_memtime stamps of ONE wave at the
+// phase boundaries of its tile pairs, read back through rt_debug_attn_trace.  Compiled out of the product library.
+#ifdef RT_ATTN_TRACE
+__device__ unsigned long long g_attn_trace[4096];
+#define RT_TMARK(on, idx) do { if (on) { RT_FENCE(); const unsigned long long t__ = __builtin_amdgcn_s_memtime(); RT_FENCE(); \
+    if ((threadIdx.x & 63) == 0) g_attn_trace[(idx)] = t__; } } while (0)
+#define RT_TDEP(on, x) do { if (on) { const int d__ = __builtin_amdgcn_readfirstlane(__float_as_int(x)); asm volatile("" ::"s"(d__)); } } while (0)
+#else
+#define RT_TMARK(on, idx) do { } while (0)
+#define RT_TDEP(on, x) do { } while (0)
+#endif
+
 template <int MODE, int HD, bool EDGE = true, bool SWZ = false>
 __device__ __forceinline__ void fwd_pair(const AttnArgs& a, const float* Kt, const float* Vt, const float* kflag,
                                          int kt, int qq, bool q_is_pad, long long t_q1, int bh, int col, int half,
                                          const f32x4 (&qf)[HD / 8], const HstuLds& hl, f32x16 (&oacc)[HD / 32],
-                                         float& m_run, float& l_run, const SwzLane<HD>& sl = SwzLane<HD>()) {
+                                         float& m_run, float& l_run, const SwzLane<HD>& sl = SwzLane<HD>(), int tr = -1) {
   constexpr int HDV = HD / 8, NT = HD / 32, lds_ld = HD + 4;
+  constexpr int EPS = 16 / HDV > 0 ? 16 / HDV : 1;     // score elements handled per S step (side work)
+  RT_TMARK(tr >= 0, tr);
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   f32x16 sacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+  const int colx = opaque_if<SWZ>(col);
+  SwzLane<HD> slx;
+  if (SWZ) slx.init(colx, opaque_if<SWZ>(half));   // rebuilt per pair: four loop-invariant registers less to spill
+  auto read_k = [&](int s) { return *reinterpret_cast<const f32x4*>(Kt + slot_off<HD, SWZ>(colx, 2 * s + half)); };
+  auto read_v = [&](int t, int nt) {
+    return SWZ ? Vt[slx.off(t, nt)] : Vt[elem_off<HD, false>(row_of(t, half), nt * 32 + col)];
+  };
+  // side work of one score element (independent of the score itself)
+  unsigned keep = 0xFFFFu, dead = 0u;   // bit r: element r survives dropout / is masked out
+  float bias[16];
+  auto side = [&](int r) {
+    const int kk = kt * TK + row_of(r, half);
+    if (MODE == MODE_SOFTMAX) {
+      if (EDGE) {
+        const bool kpad = kflag[row_of(r, half)] != 0.f;   // unconditional LDS read: no exec-mask branch per element
+        if ((kk >= a.L) | masked(a, qq, kk, kpad)) dead |= 1u << r;
+      }
+      // branch-free also for p = 0 (every element is kept and scaled by exactly 1)
+      if (drop_keep(a.seed, (unsigned)bh, (unsigned)qq, (unsigned)kk, a.p_drop, 1.f) == 0.f) keep &= ~(1u << r);
+    } else {
+      const bool d = (kk >= a.L) | (qq >= a.L) | (kk > qq) | q_is_pad | (kflag[row_of(r, half)] != 0.f);
+      float bv = 0.f;
+      if (!d) {
+        if (a.time_w) bv += hl.tw[time_bucket(hl.thr, t_q1 - hl.ts[kk])];
+        if (a.pos_w) bv += hl.pw[(a.L - 1) + kk - qq];
+      }
+      bias[r] = bv;
+      if (d) dead |= 1u << r;
+    }
+  };
+
+  // ---- S^T = K Q^T: one dependent chain of HD/2 MFMAs; K fragments two steps ahead
+  f32x4 kfr[HDV];
+  kfr[0] = read_k(0);
+  if (HDV > 1) kfr[1] = read_k(1);
+  RT_FENCE();
 #pragma unroll
   for (int s = 0; s < HDV; ++s) {
-    {
-      f32x4 kf = *reinterpret_cast<const f32x4*>(Kt + slot_off<HD, SWZ>(col, 2 * s + half));
 #pragma unroll
-      for (int t = 0; t < 4; ++t) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t], qf[s][t], sacc, 0, 0, 0);
-    }
+    for (int t = 0; t < 4; ++t) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kfr[s][t], qf[s][t], sacc, 0, 0, 0);
+    if (s + 2 < HDV) kfr[s + 2] = read_k(s + 2);
+#pragma unroll
+    for (int e = 0; e < EPS; ++e) if (s * EPS + e < 16) side(s * EPS + e);
+    RT_FENCE();
   }
+  if (HDV * EPS < 16) {   // (HD = 128 has more steps than elements; HD = 32 fewer: finish the rest here)
+#pragma unroll
+    for (int r = HDV * EPS; r < 16; ++r) side(r);
+  }
+  RT_TDEP(tr >= 0, sacc[15]);
+  RT_TMARK(tr >= 0, tr + 1);
+  // first V operands: in flight under the tail of the S chain and the softmax arithmetic.  The second product walks ONE
+  // accumulator at a time (all 16 key rows into oacc[0], then oacc[1], ...): measured with s_memtime stamps, MFMAs that keep
+  // accumulating into the same registers issue every ~80 cycles, while alternating between two accumulators costs ~106 per
+  // MFMA (the accumulator is written back and re-read) — the 2 x 16 interleaved form took 3410 cycles, this one ~2600.
+  constexpr int NV = 16 * NT, VA = 4;                  // V operands are requested VA MFMAs ahead
+  float vq[NV];
+#pragma unroll
+  for (int i = 0; i < VA; ++i) vq[i] = read_v(i % 16, i / 16);
+  RT_FENCE();
+
   float p[16];
   if (MODE == MODE_SOFTMAX) {
     float mx = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int kk = kt * TK + row_of(r, half);
-      const bool kpad = kflag[row_of(r, half)] != 0.f;   // unconditional LDS read: no short-circuit, no exec-mask branch per element
-      const bool msk = EDGE && ((kk >= a.L) | masked(a, qq, kk, kpad));
+      const bool msk = EDGE && ((dead >> r) & 1u);
       const float sv = msk ? -INFINITY : sacc[r] * a.scale;
       p[r] = sv;
       mx = fmaxf(mx, sv);
@@ -258,36 +340,25 @@ __device__ __forceinline__ void fwd_pair(const AttnArgs& a, const float* Kt, con
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
-    if (a.p_drop > 0.f) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        p[r] *= drop_keep(a.seed, (unsigned)bh, (unsigned)qq, (unsigned)(kt * TK + row_of(r, half)), a.p_drop, inv_keep);
-    }
+    for (int r = 0; r < 16; ++r) p[r] = ((keep >> r) & 1u) ? p[r] * inv_keep : 0.f;
   } else {
     const float inv_l = 1.0f / (float)a.L;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int kk = kt * TK + row_of(r, half);
-      const bool dead = (kk >= a.L) | (qq >= a.L) | (kk > qq) | q_is_pad | (kflag[row_of(r, half)] != 0.f);
-      float bias = 0.f;
-      if (!dead) {
-        if (a.time_w) bias += hl.tw[time_bucket(hl.thr, t_q1 - hl.ts[kk])];
-        if (a.pos_w) bias += hl.pw[(a.L - 1) + kk - qq];
-      }
-      p[r] = dead ? 0.f : silu_f(sacc[r] + bias) * inv_l;
-    }
+    for (int r = 0; r < 16; ++r) p[r] = ((dead >> r) & 1u) ? 0.f : silu_f(sacc[r] + bias[r]) * inv_l;
   }
-  // O^T tile(s): rows = dd (A operand: V from LDS), cols = queries (B operand = p registers)
+  RT_FENCE();
+  RT_TDEP(tr >= 0, p[15]);
+  RT_TMARK(tr >= 0, tr + 2);
+  // ---- O^T tile(s): rows = dd (A operand: V from LDS), cols = queries (B operand = p registers)
 #pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    const int krow = row_of(t, half);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int dd = nt * 32 + col;
-      const float vv = SWZ ? Vt[sl.off(t, nt)] : Vt[elem_off<HD, false>(krow, dd)];
-      oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, p[t], oacc[nt], 0, 0, 0);
-    }
+  for (int i = 0; i < NV; ++i) {
+    oacc[i / 16] = __builtin_amdgcn_mfma_f32_32x32x2f32(vq[i], p[i % 16], oacc[i / 16], 0, 0, 0);
+    if (i + VA < NV) vq[i + VA] = read_v((i + VA) % 16, (i + VA) / 16);
+    RT_FENCE();
   }
+  RT_TDEP(tr >= 0, oacc[NT - 1][15]);
+  RT_TMARK(tr >= 0, tr + 3);
 }
 
 template <int MODE, int HD>
@@ -333,6 +404,8 @@ __device__ __forceinline__ void tile_p_ds(const AttnArgs& a, float s_raw, float 
 }
 
 // backward dQ: S^T, dP^T (rows = keys, cols = queries), dS, dQ^T += K^T dS^T
+// Same pinned order as fwd_pair: K / V fragments two steps ahead of the two interleaved MFMA chains, the per-element side work
+// (dropout hash, masks, HSTU bias) sliced into those chains, the K operands of the second product VD steps ahead.
 template <int MODE, int HD, bool EDGE = true, bool SWZ = false>
 __device__ __forceinline__ void dq_pair(const AttnArgs& a, const float* Kt, const float* Vt, const float* kflag,
                                         int kt, int qq, bool q_is_pad, long long t_q1, int bh, int col, int half,
@@ -340,57 +413,91 @@ __device__ __forceinline__ void dq_pair(const AttnArgs& a, const float* Kt, cons
                                         const HstuLds& hl, f32x16 (&dqacc)[HD / 32], TimeGradRun& trun,
                                         const SwzLane<HD>& sl = SwzLane<HD>()) {
   constexpr int HDV = HD / 8, NT = HD / 32, lds_ld = HD + 4;
+  constexpr int EPS = 16 / HDV > 0 ? 16 / HDV : 1;
+  constexpr int VD = NT == 1 ? 4 : (NT == 2 ? 2 : 1);
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   f32x16 sacc, pacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+  const int colx = opaque_if<SWZ>(col);
+  SwzLane<HD> slx;
+  if (SWZ) slx.init(colx, opaque_if<SWZ>(half));   // rebuilt per pair: four loop-invariant registers less to spill
+  auto read_f = [&](const float* T, int s) { return *reinterpret_cast<const f32x4*>(T + slot_off<HD, SWZ>(colx, 2 * s + half)); };
+  auto read_k = [&](int t, int nt) {
+    return SWZ ? Kt[slx.off(t, nt)] : Kt[elem_off<HD, false>(row_of(t, half), nt * 32 + col)];
+  };
+  unsigned keep = 0xFFFFu, dead = 0u;
+  float bias[16];
+  int tbk[16];
+  auto side = [&](int r) {
+    const int kk = kt * TK + row_of(r, half);
+    const bool kpad = EDGE && kflag[row_of(r, half)] != 0.f;
+    if (MODE == MODE_SOFTMAX) {
+      if (EDGE && ((kk >= a.L) | (qq >= a.L) | masked(a, qq, kk, kpad))) dead |= 1u << r;
+      if (drop_keep(a.seed, (unsigned)bh, (unsigned)qq, (unsigned)kk, a.p_drop, 1.f) == 0.f) keep &= ~(1u << r);
+    } else {
+      const bool d = (kk >= a.L) | (qq >= a.L) | (kk > qq) | q_is_pad | kpad;
+      float bv = 0.f; int tb = 0;
+      if (!d) {
+        if (a.time_w) { tb = time_bucket(hl.thr, t_q1 - hl.ts[kk]); bv += hl.tw[tb]; }
+        if (a.pos_w) bv += hl.pw[(a.L - 1) + kk - qq];
+      }
+      bias[r] = bv; tbk[r] = tb;
+      if (d) dead |= 1u << r;
+    }
+  };
+
+  f32x4 kfr[HDV], vfr[HDV];
+  kfr[0] = read_f(Kt, 0); vfr[0] = read_f(Vt, 0);
+  if (HDV > 1) { kfr[1] = read_f(Kt, 1); vfr[1] = read_f(Vt, 1); }
+  RT_FENCE();
 #pragma unroll
   for (int s = 0; s < HDV; ++s) {
-    {
-      f32x4 kf = *reinterpret_cast<const f32x4*>(Kt + slot_off<HD, SWZ>(col, 2 * s + half));
-      f32x4 vf = *reinterpret_cast<const f32x4*>(Vt + slot_off<HD, SWZ>(col, 2 * s + half));
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t], qf[s][t], sacc, 0, 0, 0);
-        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[t], gf[s][t], pacc, 0, 0, 0);
-      }
+    for (int t = 0; t < 4; ++t) {
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kfr[s][t], qf[s][t], sacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vfr[s][t], gf[s][t], pacc, 0, 0, 0);
     }
+    if (s + 2 < HDV) { kfr[s + 2] = read_f(Kt, s + 2); vfr[s + 2] = read_f(Vt, s + 2); }
+#pragma unroll
+    for (int e = 0; e < EPS; ++e) if (s * EPS + e < 16) side(s * EPS + e);
+    RT_FENCE();
   }
+  if (HDV * EPS < 16) {
+#pragma unroll
+    for (int r = HDV * EPS; r < 16; ++r) side(r);
+  }
+  float kq[16][NT];
+#pragma unroll
+  for (int t = 0; t < VD; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) kq[t][nt] = read_k(t, nt);
+  RT_FENCE();
+
   float ds[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int kk = kt * TK + row_of(r, half);
-    const bool kpad = EDGE && kflag[row_of(r, half)] != 0.f;
-    float dsc = 1.f;
-    if (MODE == MODE_SOFTMAX && a.p_drop > 0.f) dsc = drop_keep(a.seed, (unsigned)bh, (unsigned)qq, (unsigned)kk, a.p_drop, inv_keep);
-    bool dead; float bias = 0.f; int tb = 0;
-    if (MODE == MODE_SOFTMAX) {
-      dead = EDGE && ((kk >= a.L) | (qq >= a.L) | masked(a, qq, kk, kpad));
-    } else {
-      dead = (kk >= a.L) | (qq >= a.L) | (kk > qq) | q_is_pad | kpad;
-      if (!dead) {
-        if (a.time_w) { tb = time_bucket(hl.thr, t_q1 - hl.ts[kk]); bias += hl.tw[tb]; }
-        if (a.pos_w) bias += hl.pw[(a.L - 1) + kk - qq];
-      }
-    }
+    const bool dd_ = (MODE == MODE_SOFTMAX) ? (EDGE && ((dead >> r) & 1u)) : (((dead >> r) & 1u) != 0);
+    const float dsc = (MODE == MODE_SOFTMAX) ? (((keep >> r) & 1u) ? inv_keep : 0.f) : 1.f;
     float pu;
-    tile_p_ds<MODE>(a, sacc[r], pacc[r], lse_q, delta_q, dead, bias, dsc, pu, ds[r]);
-    if (MODE == MODE_HSTU && !dead) {
+    tile_p_ds<MODE>(a, sacc[r], pacc[r], lse_q, delta_q, dd_, MODE == MODE_HSTU ? bias[r] : 0.f, dsc, pu, ds[r]);
+    if (MODE == MODE_HSTU && !dd_) {
       // relative-bias gradients: rab is shared by the heads, so every head adds its dS (hstu.py:276)
-      if (a.d_time_w) trun.add(hl.dtw, tb, ds[r]);
-      if (a.d_pos_w) atomicAdd(hl.dpw + (a.L - 1) + kk - qq, ds[r]);
+      if (a.d_time_w) trun.add(hl.dtw, tbk[r], ds[r]);
+      if (a.d_pos_w) atomicAdd(hl.dpw + (a.L - 1) + kt * TK + row_of(r, half) - qq, ds[r]);
     }
   }
+  RT_FENCE();
   // dQ^T += K^T dS^T : rows = dd (A operand: K from LDS), cols = queries (B operand = dS registers)
 #pragma unroll
   for (int t = 0; t < 16; ++t) {
-    const int krow = row_of(t, half);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int dd = nt * 32 + col;
-      const float kv = SWZ ? Kt[sl.off(t, nt)] : Kt[elem_off<HD, false>(krow, dd)];
-      dqacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, ds[t], dqacc[nt], 0, 0, 0);
+    for (int nt = 0; nt < NT; ++nt) dqacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kq[t][nt], ds[t], dqacc[nt], 0, 0, 0);
+    if (t + VD < 16) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) kq[t + VD][nt] = read_k(t + VD, nt);
     }
+    RT_FENCE();
   }
 }
 
@@ -403,53 +510,85 @@ __device__ __forceinline__ void dkv_pair(const AttnArgs& a, const float* Qt, con
                                          const f32x4 (&vf)[HD / 8], const HstuLds& hl, f32x16 (&dkacc)[HD / 32],
                                          f32x16 (&dvacc)[HD / 32], const SwzLane<HD>& sl = SwzLane<HD>()) {
   constexpr int HDV = HD / 8, NT = HD / 32, lds_ld = HD + 4;
+  constexpr int EPS = 16 / HDV > 0 ? 16 / HDV : 1;
+  constexpr int VD = NT == 1 ? 2 : 1;      // 2 NT MFMAs per t-step here: one step ahead covers an LDS round trip
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   f32x16 sacc, pacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+  const int colx = opaque_if<SWZ>(col);
+  SwzLane<HD> slx;
+  if (SWZ) slx.init(colx, opaque_if<SWZ>(half));   // rebuilt per pair: four loop-invariant registers less to spill
+  auto read_f = [&](const float* T, int s) { return *reinterpret_cast<const f32x4*>(T + slot_off<HD, SWZ>(colx, 2 * s + half)); };
+  auto elem = [&](int t, int nt) { return SWZ ? slx.off(t, nt) : elem_off<HD, false>(row_of(t, half), nt * 32 + col); };
+  unsigned keep = 0xFFFFu, dead = 0u;
+  float bias[16];
+  auto side = [&](int r) {
+    const int qrow = row_of(r, half);
+    const int q = qt * TK + qrow;
+    if (MODE == MODE_SOFTMAX) {
+      if (EDGE && ((kk >= a.L) | (q >= a.L) | masked(a, q, kk, k_is_pad))) dead |= 1u << r;
+      if (drop_keep(a.seed, (unsigned)bh, (unsigned)q, (unsigned)kk, a.p_drop, 1.f) == 0.f) keep &= ~(1u << r);
+    } else {
+      const bool d = (kk >= a.L) | (q >= a.L) | (kk > q) | k_is_pad | (q_flag[qrow] != 0.f);
+      float bv = 0.f;
+      if (!d) {
+        if (a.time_w) bv += hl.tw[time_bucket(hl.thr, hl.ts[q + 1] - t_k)];
+        if (a.pos_w) bv += hl.pw[(a.L - 1) + kk - q];
+      }
+      bias[r] = bv;
+      if (d) dead |= 1u << r;
+    }
+  };
+
+  // (fragments ONE step ahead here: a step is 8 MFMAs = 512 cycles, and this kernel has no registers to spare)
+  f32x4 qfr[HDV], gfr[HDV];
+  qfr[0] = read_f(Qt, 0); gfr[0] = read_f(Gt, 0);
+  RT_FENCE();
 #pragma unroll
   for (int s = 0; s < HDV; ++s) {
-    {
-      f32x4 qf = *reinterpret_cast<const f32x4*>(Qt + slot_off<HD, SWZ>(col, 2 * s + half));
-      f32x4 gf = *reinterpret_cast<const f32x4*>(Gt + slot_off<HD, SWZ>(col, 2 * s + half));
+    if (s + 1 < HDV) { qfr[s + 1] = read_f(Qt, s + 1); gfr[s + 1] = read_f(Gt, s + 1); }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[t], kf[s][t], sacc, 0, 0, 0);
-        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(gf[t], vf[s][t], pacc, 0, 0, 0);
-      }
+    for (int t = 0; t < 4; ++t) {
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qfr[s][t], kf[s][t], sacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(gfr[s][t], vf[s][t], pacc, 0, 0, 0);
     }
+#pragma unroll
+    for (int e = 0; e < EPS; ++e) if (s * EPS + e < 16) side(s * EPS + e);
+    RT_FENCE();
   }
+  if (HDV * EPS < 16) {
+#pragma unroll
+    for (int r = HDV * EPS; r < 16; ++r) side(r);
+  }
+  float gq[16][NT], qq_[16][NT];
+#pragma unroll
+  for (int t = 0; t < VD; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { const int eo = elem(t, nt); gq[t][nt] = Gt[eo]; qq_[t][nt] = Qt[eo]; }
+  RT_FENCE();
+
   float pu[16], ds[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int qrow = row_of(r, half);
-    const int q = qt * TK + qrow;
-    float dsc = 1.f;
-    if (MODE == MODE_SOFTMAX && a.p_drop > 0.f) dsc = drop_keep(a.seed, (unsigned)bh, (unsigned)q, (unsigned)kk, a.p_drop, inv_keep);
-    bool dead; float bias = 0.f;
-    if (MODE == MODE_SOFTMAX) {
-      dead = EDGE && ((kk >= a.L) | (q >= a.L) | masked(a, q, kk, k_is_pad));
-    } else {
-      dead = (kk >= a.L) | (q >= a.L) | (kk > q) | k_is_pad | (q_flag[qrow] != 0.f);
-      if (!dead) {
-        if (a.time_w) bias += hl.tw[time_bucket(hl.thr, hl.ts[q + 1] - t_k)];
-        if (a.pos_w) bias += hl.pw[(a.L - 1) + kk - q];
-      }
-    }
-    tile_p_ds<MODE>(a, sacc[r], pacc[r], q_lse[qrow], q_delta[qrow], dead, bias, dsc, pu[r], ds[r]);
+    const bool dd_ = (MODE == MODE_SOFTMAX) ? (EDGE && ((dead >> r) & 1u)) : (((dead >> r) & 1u) != 0);
+    const float dsc = (MODE == MODE_SOFTMAX) ? (((keep >> r) & 1u) ? inv_keep : 0.f) : 1.f;
+    tile_p_ds<MODE>(a, sacc[r], pacc[r], q_lse[row_of(r, half)], q_delta[row_of(r, half)], dd_, MODE == MODE_HSTU ? bias[r] : 0.f, dsc,
+                    pu[r], ds[r]);
   }
+  RT_FENCE();
 #pragma unroll
   for (int t = 0; t < 16; ++t) {
-    const int qrow = row_of(t, half);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const int dd = nt * 32 + col;
-      const int eo = SWZ ? sl.off(t, nt) : elem_off<HD, false>(qrow, dd);
-      const float gv = Gt[eo];
-      const float qv = Qt[eo];
-      dvacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, pu[t], dvacc[nt], 0, 0, 0);
-      dkacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qv, ds[t], dkacc[nt], 0, 0, 0);
+      dvacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(gq[t][nt], pu[t], dvacc[nt], 0, 0, 0);
+      dkacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qq_[t][nt], ds[t], dkacc[nt], 0, 0, 0);
     }
+    if (t + VD < 16) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) { const int eo = elem(t + VD, nt); gq[t + VD][nt] = Gt[eo]; qq_[t + VD][nt] = Qt[eo]; }
+    }
+    RT_FENCE();
   }
 }
 
@@ -860,11 +999,16 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(AttnArgs a) {
   const long long rowbase = (long long)b * a.L;
   const float* qb = a.q + rowbase * a.ldq + h * a.hd;
   const long long* idb = a.ids + rowbase;
+  const bool tron = (bh == 1 || bh == 300) && wave == 0;   // (RT_ATTN_TRACE builds only)
+  const int trb = bh == 1 ? 0 : 256;
+  RT_TMARK(tron, trb + 0);
   if (!DMA) stage_rows2<HD>(a.k + rowbase * a.ldk + h * a.hd, a.ldk, Ks, a.v + rowbase * a.ldv + h * a.hd, a.ldv, Vs, a.L, Lp, a.hd, tid, NTH);
+  RT_TMARK(tron, trb + 1);
   for (int i = tid; i < Lp; i += NTH) kflag[i] = (i < a.L && idb[i] != 0) ? 0.f : 1.f;
   if (DMA && tid < n_t) tflag[tid] = 0;
   if (MODE == MODE_HSTU) hstu_fill(a, hl, b, tid, NTH);
   __syncthreads();
+  RT_TMARK(tron, trb + 2);
   if constexpr (DMA) if (wave == NW - 1) {
     res_loader<HD>(a.k + rowbase * a.ldk + h * a.hd, a.ldk, Ks, a.v + rowbase * a.ldv + h * a.hd, a.ldv, Vs, a.L, n_t, false,
                    tflag, lane);
@@ -895,15 +1039,19 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(AttnArgs a) {
     for (int kt = 0; kt <= last_kt; ++kt) {
       if (DMA && kt > ready) { wait_tile(tflag, kt); ready = kt; }
       const bool interior = MODE == MODE_SOFTMAX && !a.no_interior && !a.keypad && q_inside && (kt + 1) * TK <= a.L && (!a.causal || kt < qt);
+      const int tr = (tron && it == 0) ? trb + 16 + kt * 4 : -1;
       if (interior)
         fwd_pair<MODE, HD, false, DMA>(a, Ks + kt * TK * lds_ld, Vs + kt * TK * lds_ld, kflag + kt * TK, kt, qq, q_is_pad, t_q1,
-                                       bh, col, half, qf, hl, oacc, m_run, l_run, sl);
+                                       bh, col, half, qf, hl, oacc, m_run, l_run, sl, tr);
       else
         fwd_pair<MODE, HD, true, DMA>(a, Ks + kt * TK * lds_ld, Vs + kt * TK * lds_ld, kflag + kt * TK, kt, qq, q_is_pad, t_q1,
-                                      bh, col, half, qf, hl, oacc, m_run, l_run, sl);
+                                      bh, col, half, qf, hl, oacc, m_run, l_run, sl, tr);
     }
+    RT_TMARK(tron && it == 0, trb + 3);
     fwd_store<MODE, HD>(a, bh, qq, half, rowbase, h, oacc, m_run, l_run);
+    RT_TMARK(tron && it == 0, trb + 4);
   }
+  RT_TMARK(tron, trb + 5);
 }
 
 template <int MODE, int HD, int NW, bool DMA>
@@ -1065,6 +1213,341 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_res_kernel(AttnArgs a) {
   }
 }
 
+// ===================================================================================================
+// ring family: grid = ceil(L/128) * B*H workgroups of 4 waves (one per SIMD); wave slot w owns ONE 32-row tile (queries
+// for forward / dQ, keys for dK/dV) and the tiles of the other operand pair (K,V or Q,dO) stream through an NS-stage LDS ring
+// filled by global_load_lds_dwordx4 (all four waves issue their share of every tile; counted vmcnt, ONE raw barrier per
+// tile, no VGPR staging).  A workgroup needs 48 KiB of LDS (hd 64) instead of the resident family's 120 KiB and ~150-250
+// VGPRs, so 2-3 workgroups share a CU and 2-3 waves share a SIMD: one wave's softmax / dropout VALU phase, its tile
+// prologue (row-fragment loads) and epilogue (stores) run under the MFMA phases of its neighbours — the overlap the
+// resident kernels (7 + 1 tile pairs on the two waves of a SIMD, every phase serial) could not get, and the streaming
+// kernels (register-staged tiles, two barriers per tile, 200-330 VGPRs = one wave per SIMD) lost again.
+// Tiles are unpadded XOR-swizzled rows (slot_off / elem_off with SWZ = true); rows past L are clamped copies of row L - 1
+// (every pair that can see them is an EDGE pair and masks them).  Needs hd == HD in {32, 64} and 16-byte aligned rows.
+// ===================================================================================================
+constexpr int RING_NS = 3;
+
+// keep a value loaded from global memory out of the ring loop's waitcnt bookkeeping: the compiler has to wait for it HERE
+// (otherwise its own `s_waitcnt vmcnt(0)` lands in front of the first use inside the loop and drains the DMA ring per tile)
+__device__ __forceinline__ void pin(f32x4& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(int& x) { asm volatile("" : "+v"(x)); }
+
+template <int HD, int NS>
+struct RingIo {
+  static constexpr int SPR = HD / 4;            // 16-byte slots per row
+  static constexpr int RPP = 64 / SPR;          // rows per 1 KiB piece (one DMA instruction)
+  static constexpr int PPM = TK / RPP;          // pieces per matrix tile
+  static constexpr int PW = PPM / 4;            // pieces per wave and matrix (hd 64: 2, hd 32: 1)
+  static constexpr int NL = 2 * PW;             // DMA instructions per wave and stage
+  static constexpr int TILE_F = TK * HD;        // floats per matrix tile
+  static constexpr int STAGE_F = 2 * TILE_F;    // a stage = tile of A (K or Q) | tile of B (V or dO)
+  static_assert(PW >= 1 && NL * (NS - 1) < 64, "ring geometry");
+  const float* A; const float* B; long long ldA, ldB;
+  int L, row_in_tile[PW], colf[PW];
+  unsigned lds0;                                // LDS byte address of this wave's first piece of stage 0 (wave-uniform)
+  int issued, stage;
+
+  __device__ __forceinline__ void init(const float* A_, long long ldA_, const float* B_, long long ldB_, int L_,
+                                       const float* ring, int wave, int lane) {
+    A = A_; B = B_; ldA = ldA_; ldB = ldB_; L = L_;
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      const int r = (wave * PW + j) * RPP + lane / SPR;
+      row_in_tile[j] = r;
+      colf[j] = ((lane % SPR) ^ swz_of<HD>(r)) << 2;     // physical slot lane % SPR holds logical slot (lane % SPR) ^ swz(row)
+    }
+    lds0 = __builtin_amdgcn_readfirstlane(lds_addr(ring)) + (unsigned)(wave * PW * 1024);
+    issued = 0; stage = 0;
+  }
+  __device__ __forceinline__ void issue(int tile) {
+    const unsigned sb = lds0 + (unsigned)(stage * STAGE_F * 4);
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      const int row = tile * TK + row_in_tile[j];
+      const int src = row < L ? row : L - 1;
+      dma16(A + (long long)src * ldA + colf[j], sb + j * 1024);
+      dma16(B + (long long)src * ldB + colf[j], sb + TILE_F * 4 + j * 1024);
+    }
+    stage = (stage + 1 == NS) ? 0 : stage + 1;
+    ++issued;
+  }
+  // this wave's pieces of the st-th issued stage have landed; up to NS - 2 younger stages stay in flight
+  __device__ __forceinline__ void wait_landed(int st) {
+    const int rem = issued - st - 1;
+    if (NS >= 4 && rem >= 2) wait_vmcnt<2 * NL>();
+    else if (rem >= 1) wait_vmcnt<NL>();
+    else wait_vmcnt<0>();
+  }
+};
+
+// workgroup -> (tile group x, batch*head).  Consecutive workgroup ids go to the 8 XCDs round-robin: the n_x groups of one
+// (batch, head) read the same K,V / Q,dO rows, so they are placed 8 ids apart — same XCD (one L2), adjacent in time; the
+// heaviest group (most tile pairs under the causal mask) goes first.
+__device__ __forceinline__ void ring_block(int n_x, int BH, bool heavy_is_last, int& x, int& bh) {
+  const int id = blockIdx.x;
+  int j;
+  if ((BH & 7) == 0) { j = id >> 3; bh = (j / n_x) * 8 + (id & 7); }
+  else { j = id; bh = j / n_x; }
+  x = heavy_is_last ? n_x - 1 - (j % n_x) : (j % n_x);
+}
+
+template <int MODE, int HD, int NS>
+__global__ __launch_bounds__(AT) __attribute__((amdgpu_waves_per_eu(2))) void attn_fwd_ring_kernel(AttnArgs a) {
+  constexpr int HDV = HD / 8, NT = HD / 32;
+  using R = RingIo<HD, NS>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n_t = (a.L + TK - 1) / TK, Lp = n_t * TK;
+  float* ring = smem;                               // [NS][K tile | V tile]
+  float* kflag = ring + NS * R::STAGE_F;            // [Lp] key pad flags
+  HstuLds hl{};
+  if (MODE == MODE_HSTU) hstu_carve(kflag + Lp, a.L, false, hl);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 31, half = lane >> 5;
+  int x, bh;
+  ring_block((n_t + 3) / 4, a.B * a.H, true, x, bh);
+  const int b = bh / a.H, h = bh % a.H;
+  const int qt = x * 4 + ((wave + bh) & 3);          // the slot -> SIMD pairing rotates with bh: every SIMD sees every tile cost
+  const int q0 = qt * TK, qq = q0 + col;
+  const long long rowbase = (long long)b * a.L;
+  const float* qb = a.q + rowbase * a.ldq + h * a.hd;
+  const long long* idb = a.ids + rowbase;
+  RT_TMARK((bh == 1 || bh == 300) && qt == n_t - 1, (bh == 1 ? 512 : 768) + 0);
+  for (int i = tid; i < Lp; i += AT) kflag[i] = (i < a.L && idb[i] != 0) ? 0.f : 1.f;
+  if (MODE == MODE_HSTU) hstu_fill(a, hl, b, tid, AT);
+
+  f32x4 qf[HDV];
+  load_row_frags<HDV>(qb, a.ldq, qq, a.L, a.hd, half, qf);
+  int q_pad_i = (qq < a.L) ? (idb[qq] == 0) : 1;
+#pragma unroll
+  for (int s = 0; s < HDV; ++s) pin(qf[s]);
+  pin(q_pad_i);
+  const bool q_is_pad = q_pad_i != 0;
+  f32x16 oacc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int wg_q_last = min(a.L, (x * 4 + 4) * TK) - 1;
+  const int n_kt = a.causal ? (wg_q_last / TK + 1) : n_t;     // key tiles this workgroup walks
+  const int my_last_kt = a.causal ? min(n_kt - 1, qt) : n_kt - 1;
+  const bool active = q0 < a.L;
+  const bool q_inside = (qt + 1) * TK <= a.L;
+  __syncthreads();
+  long long t_q1 = 0;
+  if (MODE == MODE_HSTU && a.ts && qq < a.L) t_q1 = hl.ts[qq + 1];
+  SwzLane<HD> sl; sl.init(col, half);
+
+  R io;
+  io.init(a.k + rowbase * a.ldk + h * a.hd, a.ldk, a.v + rowbase * a.ldv + h * a.hd, a.ldv, a.L, ring, wave, lane);
+#pragma unroll 1
+  for (int s = 0; s < NS - 1; ++s) if (io.issued < n_kt) io.issue(io.issued);
+  int cons = 0;
+  const bool tron = (bh == 1 || bh == 300) && qt == n_t - 1;   // (RT_ATTN_TRACE builds only)
+  const int trb = bh == 1 ? 512 : 768;
+  RT_TMARK(tron, trb + 1);
+#pragma unroll 1
+  for (int kt = 0; kt < n_kt; ++kt) {
+    RT_TMARK(tron, trb + 16 + kt * 8 + 4);
+    io.wait_landed(kt);
+    RT_TMARK(tron, trb + 16 + kt * 8 + 5);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    RT_TMARK(tron, trb + 16 + kt * 8 + 6);
+    if (io.issued < n_kt) io.issue(io.issued);       // refills the stage consumed at step kt - 1
+    const float* Kt = ring + cons * R::STAGE_F;
+    cons = (cons + 1 == NS) ? 0 : cons + 1;
+    if (!active || kt > my_last_kt) continue;        // barriers above are uniform
+    const bool interior = MODE == MODE_SOFTMAX && !a.no_interior && !a.keypad && q_inside && (kt + 1) * TK <= a.L && (!a.causal || kt < qt);
+    const int tr = tron ? trb + 16 + kt * 8 : -1;
+    if (interior)
+      fwd_pair<MODE, HD, false, true>(a, Kt, Kt + R::TILE_F, kflag + kt * TK, kt, qq, q_is_pad, t_q1, bh, col, half, qf, hl, oacc,
+                                      m_run, l_run, sl, tr);
+    else
+      fwd_pair<MODE, HD, true, true>(a, Kt, Kt + R::TILE_F, kflag + kt * TK, kt, qq, q_is_pad, t_q1, bh, col, half, qf, hl, oacc,
+                                     m_run, l_run, sl, tr);
+  }
+  RT_TMARK(tron, trb + 3);
+  if (!active) return;
+  fwd_store<MODE, HD>(a, bh, qq, half, rowbase, h, oacc, m_run, l_run);
+  RT_TMARK(tron, trb + 4);
+}
+
+template <int MODE, int HD, int NS>
+__global__ __launch_bounds__(AT) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dq_ring_kernel(AttnArgs a) {
+  constexpr int HDV = HD / 8, NT = HD / 32;
+  using R = RingIo<HD, NS>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n_t = (a.L + TK - 1) / TK, Lp = n_t * TK;
+  float* ring = smem;
+  float* kflag = ring + NS * R::STAGE_F;
+  HstuLds hl{};
+  if (MODE == MODE_HSTU) hstu_carve(kflag + Lp, a.L, true, hl);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 31, half = lane >> 5;
+  int x, bh;
+  ring_block((n_t + 3) / 4, a.B * a.H, true, x, bh);
+  const int b = bh / a.H, h = bh % a.H;
+  const int qt = x * 4 + ((wave + bh) & 3);
+  const int q0 = qt * TK, qq = q0 + col;
+  const long long rowbase = (long long)b * a.L;
+  const float* qb = a.q + rowbase * a.ldq + h * a.hd;
+  const float* gb = a.dout + rowbase * a.lddo + h * a.hd;
+  const long long* idb = a.ids + rowbase;
+  for (int i = tid; i < Lp; i += AT) kflag[i] = (i < a.L && idb[i] != 0) ? 0.f : 1.f;
+  if (MODE == MODE_HSTU) hstu_fill(a, hl, b, tid, AT);
+
+  f32x4 qf[HDV], gf[HDV];
+  load_row_frags<HDV>(qb, a.ldq, qq, a.L, a.hd, half, qf);
+  load_row_frags<HDV>(gb, a.lddo, qq, a.L, a.hd, half, gf);
+  int q_pad_i = (qq < a.L) ? (idb[qq] == 0) : 1;
+  float lse_q = 0.f, delta_q = 0.f;
+  if (MODE == MODE_SOFTMAX) {
+    if (qq < a.L) lse_q = a.lse[(long long)bh * a.L + qq];
+    delta_q = delta_from_frags<HDV>(a, a.o + rowbase * a.ldo + h * a.hd, qq, half, bh, gf);
+  }
+#pragma unroll
+  for (int s = 0; s < HDV; ++s) { pin(qf[s]); pin(gf[s]); }
+  pin(q_pad_i); pin(lse_q); pin(delta_q);
+  const bool q_is_pad = q_pad_i != 0;
+  f32x16 dqacc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqacc[t][r] = 0.f;
+
+  const int wg_q_last = min(a.L, (x * 4 + 4) * TK) - 1;
+  const int n_kt = a.causal ? (wg_q_last / TK + 1) : n_t;
+  const int my_last_kt = a.causal ? min(n_kt - 1, qt) : n_kt - 1;
+  const bool active = q0 < a.L;
+  const bool q_inside = (qt + 1) * TK <= a.L;
+  __syncthreads();
+  long long t_q1 = 0;
+  if (MODE == MODE_HSTU && a.ts && qq < a.L) t_q1 = hl.ts[qq + 1];
+  SwzLane<HD> sl; sl.init(col, half);
+  TimeGradRun trun; trun.init();
+
+  R io;
+  io.init(a.k + rowbase * a.ldk + h * a.hd, a.ldk, a.v + rowbase * a.ldv + h * a.hd, a.ldv, a.L, ring, wave, lane);
+#pragma unroll 1
+  for (int s = 0; s < NS - 1; ++s) if (io.issued < n_kt) io.issue(io.issued);
+  int cons = 0;
+#pragma unroll 1
+  for (int kt = 0; kt < n_kt; ++kt) {
+    io.wait_landed(kt);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (io.issued < n_kt) io.issue(io.issued);
+    const float* Kt = ring + cons * R::STAGE_F;
+    cons = (cons + 1 == NS) ? 0 : cons + 1;
+    if (!active || kt > my_last_kt) continue;
+    const bool interior = MODE == MODE_SOFTMAX && !a.no_interior && !a.keypad && q_inside && (kt + 1) * TK <= a.L && (!a.causal || kt < qt);
+    if (interior)
+      dq_pair<MODE, HD, false, true>(a, Kt, Kt + R::TILE_F, kflag + kt * TK, kt, qq, q_is_pad, t_q1, bh, col, half, qf, gf, lse_q,
+                                     delta_q, hl, dqacc, trun, sl);
+    else
+      dq_pair<MODE, HD, true, true>(a, Kt, Kt + R::TILE_F, kflag + kt * TK, kt, qq, q_is_pad, t_q1, bh, col, half, qf, gf, lse_q,
+                                    delta_q, hl, dqacc, trun, sl);
+  }
+  if (MODE == MODE_HSTU) {
+    if (a.d_time_w) trun.flush(hl.dtw);
+    __syncthreads();
+    hstu_flush_grads(a, hl, tid, AT);
+  }
+  if (!active) return;
+  store_rows_T<HD>(a.dq + rowbase * a.lddq + h * a.hd, a.lddq, qq, a.L, a.hd, half, dqacc);
+}
+
+template <int MODE, int HD, int NS>
+__global__ __launch_bounds__(AT) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_ring_kernel(AttnArgs a) {
+  constexpr int HDV = HD / 8, NT = HD / 32;
+  using R = RingIo<HD, NS>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n_t = (a.L + TK - 1) / TK, Lp = n_t * TK;
+  float* ring = smem;                               // [NS][Q tile | dO tile]
+  float* s_lse = ring + NS * R::STAGE_F;            // [Lp]
+  float* s_delta = s_lse + Lp;                      // [Lp]
+  float* qflag = s_delta + Lp;                      // [Lp] query pad flags
+  HstuLds hl{};
+  if (MODE == MODE_HSTU) hstu_carve(qflag + Lp, a.L, false, hl);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 31, half = lane >> 5;
+  int x, bh;
+  ring_block((n_t + 3) / 4, a.B * a.H, !a.causal, x, bh);   // causal: key group 0 sees every query tile -> heaviest, first
+  const int b = bh / a.H, h = bh % a.H;
+  const int ktile = x * 4 + ((wave + bh) & 3);
+  const int k0 = ktile * TK, kk = k0 + col;
+  const long long rowbase = (long long)b * a.L;
+  const float* kb = a.k + rowbase * a.ldk + h * a.hd;
+  const float* vb = a.v + rowbase * a.ldv + h * a.hd;
+  const long long* idb = a.ids + rowbase;
+  for (int i = tid; i < Lp; i += AT) {
+    s_lse[i] = (MODE == MODE_SOFTMAX && i < a.L) ? a.lse[(long long)bh * a.L + i] : 0.f;
+    s_delta[i] = (MODE == MODE_SOFTMAX && i < a.L) ? a.delta[(long long)bh * a.L + i] : 0.f;
+    qflag[i] = (i < a.L && idb[i] != 0) ? 0.f : 1.f;
+  }
+  if (MODE == MODE_HSTU) hstu_fill(a, hl, b, tid, AT);
+
+  f32x4 kf[HDV], vf[HDV];
+  load_row_frags<HDV>(kb, a.ldk, kk, a.L, a.hd, half, kf);
+  load_row_frags<HDV>(vb, a.ldv, kk, a.L, a.hd, half, vf);
+  int k_pad_i = (kk < a.L) ? (idb[kk] == 0) : 1;
+#pragma unroll
+  for (int s = 0; s < HDV; ++s) { pin(kf[s]); pin(vf[s]); }
+  pin(k_pad_i);
+  const bool k_is_pad = k_pad_i != 0;
+  f32x16 dkacc[NT], dvacc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dkacc[t][r] = 0.f; dvacc[t][r] = 0.f; }
+
+  const int first_qt = a.causal ? x * 4 : 0;        // queries at or behind the first key of the workgroup
+  const int n_steps = n_t - first_qt;
+  const int my_first_qt = a.causal ? ktile : 0;
+  const bool active = k0 < a.L;
+  const bool k_inside = (ktile + 1) * TK <= a.L;
+  __syncthreads();
+  long long t_k = 0;
+  if (MODE == MODE_HSTU && a.ts && kk < a.L) t_k = hl.ts[kk];
+  SwzLane<HD> sl; sl.init(col, half);
+
+  R io;
+  io.init(a.q + rowbase * a.ldq + h * a.hd, a.ldq, a.dout + rowbase * a.lddo + h * a.hd, a.lddo, a.L, ring, wave, lane);
+#pragma unroll 1
+  for (int s = 0; s < NS - 1; ++s) if (io.issued < n_steps) io.issue(first_qt + io.issued);
+  int cons = 0;
+#pragma unroll 1
+  for (int st = 0; st < n_steps; ++st) {
+    const int qt = first_qt + st;
+    io.wait_landed(st);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (io.issued < n_steps) io.issue(first_qt + io.issued);
+    const float* Qt = ring + cons * R::STAGE_F;
+    cons = (cons + 1 == NS) ? 0 : cons + 1;
+    if (!active || qt < my_first_qt) continue;
+    const bool interior = MODE == MODE_SOFTMAX && !a.no_interior && !a.keypad && k_inside && (qt + 1) * TK <= a.L && (!a.causal || ktile < qt);
+    if (interior)
+      dkv_pair<MODE, HD, false, true>(a, Qt, Qt + R::TILE_F, s_lse + qt * TK, s_delta + qt * TK, qflag + qt * TK, qt, kk, k_is_pad,
+                                      t_k, bh, col, half, kf, vf, hl, dkacc, dvacc, sl);
+    else
+      dkv_pair<MODE, HD, true, true>(a, Qt, Qt + R::TILE_F, s_lse + qt * TK, s_delta + qt * TK, qflag + qt * TK, qt, kk, k_is_pad,
+                                     t_k, bh, col, half, kf, vf, hl, dkacc, dvacc, sl);
+  }
+  if (!active) return;
+  store_rows_T<HD>(a.dk + rowbase * a.lddk + h * a.hd, a.lddk, kk, a.L, a.hd, half, dkacc);
+  store_rows_T<HD>(a.dv + rowbase * a.lddv + h * a.hd, a.lddv, kk, a.L, a.hd, half, dvacc);
+}
+
 // ---- launch -----------------------------------------------------------------------------------------
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
@@ -1087,23 +1570,57 @@ inline bool attn_allow_dma() {
   return v == 1;
 }
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-// RT_ATTN_IMPL=stream forces the streaming family (tests / A-B measurements)
-inline bool attn_allow_resident() {
+// RT_ATTN_IMPL = auto (default) | ring | res | stream — A/B measurements and the tests that pin one family.
+//   auto:   resident where K,V fit the LDS (every default config: measured faster there, 76 vs 96 us forward at the C2 shape),
+//           else the ring kernels where they apply (hd == 32 / 64, aligned rows: 383 vs 445 us forward, 1.22 vs 1.48 ms backward
+//           at L = 512 against the streaming family), else streaming
+//   ring:   ring wherever it applies     res: same as auto     stream: register-staged streaming family only
+enum { IMPL_AUTO = 0, IMPL_RING = 1, IMPL_RES = 2, IMPL_STREAM = 3 };
+inline int attn_impl() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("RT_ATTN_IMPL"); v = (e && e[0] == 's') ? 0 : 1; }
-  return v == 1;
+  if (v < 0) {
+    const char* e = getenv("RT_ATTN_IMPL");
+    v = IMPL_AUTO;
+    if (e && e[0] == 's') v = IMPL_STREAM;
+    else if (e && e[0] == 'r' && e[1] == 'i') v = IMPL_RING;
+    else if (e && e[0] == 'r') v = IMPL_RES;
+  }
+  return v;
 }
 template <typename K>
 inline int set_lds(K kernel, size_t lds) {
   if (lds > 64 * 1024) RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   return RT_OK;
 }
+inline size_t ring_lds_bytes(int hd, int L, int aux_rows, bool hstu, bool grads) {
+  const size_t Lp = (size_t)((L + TK - 1) / TK) * TK;
+  return ((size_t)RING_NS * 2 * TK * hd + aux_rows * Lp + (hstu ? hstu_lds_floats(L, grads) : 0)) * 4 + 64;
+}
+template <int HD> inline bool ring_ok(const AttnArgs& a, bool bwd) {
+  if (HD > 64 || a.hd != HD) return false;
+  if (!al16(a.k) || !al16(a.v) || (a.ldk & 3) || (a.ldv & 3)) return false;
+  if (bwd && (!al16(a.q) || !al16(a.dout) || (a.ldq & 3) || (a.lddo & 3))) return false;
+  return true;
+}
 
 template <int MODE, int HD>
 int launch_fwd(const AttnArgs& a, hipStream_t stream) {
   constexpr int NW = HD <= 64 ? 8 : 4;
+  const int impl = attn_impl();
   const size_t rl = res_lds_bytes(HD, a.L, 1, MODE == MODE_HSTU, false);
-  if (rl <= LDS_LIMIT && attn_allow_resident()) {
+  const bool res_fits = rl <= LDS_LIMIT;
+  if constexpr (HD <= 64) {
+    const size_t gl = ring_lds_bytes(HD, a.L, 1, MODE == MODE_HSTU, false);
+    const bool want_ring = impl == IMPL_RING || ((impl == IMPL_AUTO || impl == IMPL_RES) && !res_fits);
+    if (want_ring && ring_ok<HD>(a, false) && gl <= LDS_LIMIT) {
+      { const int rc = set_lds(&attn_fwd_ring_kernel<MODE, HD, RING_NS>, gl); if (rc != RT_OK) return rc; }
+      const int n_x = ((a.L + TK - 1) / TK + 3) / 4;
+      attn_fwd_ring_kernel<MODE, HD, RING_NS><<<n_x * a.B * a.H, AT, gl, stream>>>(a);
+      RT_CHECK_LAUNCH();
+      return RT_OK;
+    }
+  }
+  if (res_fits && impl != IMPL_STREAM) {
     if constexpr (HD <= 64) {   // loader-wave variant: exact head dim, 16-byte aligned rows
       if (a.hd == HD && attn_allow_dma() && al16(a.k) && al16(a.v)) {
         { const int rc = set_lds(&attn_fwd_res_kernel<MODE, HD, NW, true>, rl); if (rc != RT_OK) return rc; }
@@ -1127,9 +1644,26 @@ int launch_fwd(const AttnArgs& a, hipStream_t stream) {
 template <int MODE, int HD>
 int launch_bwd(const AttnArgs& a, hipStream_t stream) {
   constexpr int NW = HD <= 64 ? 8 : 4;
+  const int impl = attn_impl();
   const size_t r1 = res_lds_bytes(HD, a.L, 1, MODE == MODE_HSTU, true);
   const size_t r2 = res_lds_bytes(HD, a.L, 3, MODE == MODE_HSTU, false);
-  if (r1 <= LDS_LIMIT && r2 <= LDS_LIMIT && attn_allow_resident()) {
+  const bool res_fits = r1 <= LDS_LIMIT && r2 <= LDS_LIMIT;
+  if constexpr (HD <= 64) {
+    const size_t g1 = ring_lds_bytes(HD, a.L, 1, MODE == MODE_HSTU, true);
+    const size_t g2 = ring_lds_bytes(HD, a.L, 3, MODE == MODE_HSTU, false);
+    const bool want_ring = impl == IMPL_RING || ((impl == IMPL_AUTO || impl == IMPL_RES) && !res_fits);
+    if (want_ring && ring_ok<HD>(a, true) && g1 <= LDS_LIMIT && g2 <= LDS_LIMIT) {
+      { const int rc = set_lds(&attn_bwd_dq_ring_kernel<MODE, HD, RING_NS>, g1); if (rc != RT_OK) return rc; }
+      { const int rc = set_lds(&attn_bwd_dkv_ring_kernel<MODE, HD, RING_NS>, g2); if (rc != RT_OK) return rc; }
+      const int n_x = ((a.L + TK - 1) / TK + 3) / 4;
+      attn_bwd_dq_ring_kernel<MODE, HD, RING_NS><<<n_x * a.B * a.H, AT, g1, stream>>>(a);
+      RT_CHECK_LAUNCH();
+      attn_bwd_dkv_ring_kernel<MODE, HD, RING_NS><<<n_x * a.B * a.H, AT, g2, stream>>>(a);
+      RT_CHECK_LAUNCH();
+      return RT_OK;
+    }
+  }
+  if (res_fits && impl != IMPL_STREAM) {
     if constexpr (HD <= 64) {
       if (a.hd == HD && attn_allow_dma() && al16(a.k) && al16(a.v) && al16(a.q) && al16(a.dout)) {
         { const int rc = set_lds(&attn_bwd_dq_res_kernel<MODE, HD, NW, true>, r1); if (rc != RT_OK) return rc; }
@@ -1186,9 +1720,47 @@ inline bool bad_common(int B, int H, int L, int hd, int64_t ldq, int64_t ldk, in
   return B <= 0 || H <= 0 || L <= 0 || hd <= 0 || (hd & 7) != 0 || hd > 128 || (ldq & 3) || (ldk & 3) || (ldv & 3);
 }
 
+#ifdef RT_ATTN_TRACE
+__global__ void occ_probe_kernel(unsigned long long* out, int spin) {
+  extern __shared__ float sm[];
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID
+  const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+  sm[threadIdx.x] = (float)threadIdx.x;
+  while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)spin) __builtin_amdgcn_s_sleep(8);
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) {
+    out[blockIdx.x * 4 + 0] = t0; out[blockIdx.x * 4 + 1] = t1; out[blockIdx.x * 4 + 2] = hw; out[blockIdx.x * 4 + 3] = xcc;
+  }
+  if (sm[(threadIdx.x + 1) % blockDim.x] < 0.f) out[0] = 0;
+}
+#endif
+
 }  // namespace
 
 extern "C" {
+
+#ifdef RT_ATTN_TRACE
+// occupancy probe: n_wgs workgroups of `threads` threads with `lds_bytes` of dynamic LDS spin for `spin` clock ticks and
+// record (start, end, HW_ID, XCC_ID): the host counts how many were resident on one CU at the same time
+int rt_debug_occupancy(int n_wgs, int threads, int lds_bytes, int spin, unsigned long long* out_host) {
+  unsigned long long* d = nullptr;
+  RT_CHECK_HIP(hipMalloc(&d, sizeof(unsigned long long) * 4 * (size_t)n_wgs));
+  if (lds_bytes > 64 * 1024)
+    RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&occ_probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+  occ_probe_kernel<<<n_wgs, threads, lds_bytes, 0>>>(d, spin);
+  RT_CHECK_LAUNCH();
+  RT_CHECK_HIP(hipDeviceSynchronize());
+  RT_CHECK_HIP(hipMemcpy(out_host, d, sizeof(unsigned long long) * 4 * (size_t)n_wgs, hipMemcpyDeviceToHost));
+  RT_CHECK_HIP(hipFree(d));
+  return RT_OK;
+}
+int rt_debug_attn_trace(unsigned long long* out_host, int n) {
+  if (hipDeviceSynchronize() != hipSuccess) return RT_ERR_LAUNCH;
+  RT_CHECK_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_attn_trace), sizeof(unsigned long long) * (size_t)n));
+  return RT_OK;
+}
+#endif
 
 // softmax attention forward.  q,k,v: [B*L, ld*] with head h at columns [h*hd, (h+1)*hd).  ids: [B,L].
 int rt_mha_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,

@@ -179,6 +179,16 @@ def _wgrad_splits(k_rows: int) -> int:
     return max(1, min(64, k_rows // 384))
 
 
+def _deep_k_splits(M: int, N: int, K: int) -> int:
+    """Split-K factor of a product with a small output and a deep reduction (the dS = G E product of the full-softmax loss:
+    3,840 x 256 outputs = 60 tiles, K = 26,752 — unsplit it ran on 60 of 256 CUs for 1.7 ms).  Aim at ~3 workgroups per CU
+    with slices of at least 512."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles >= 256 or K < 2048:
+        return 1
+    return max(1, min(K // 512, -(-768 // tiles), 64))
+
+
 class _Linear(torch.autograd.Function):
     """y = x @ W^T (+ b) (+ residual) (relu).  x [M,K] (row stride free), W [N,K] contiguous."""
 
@@ -919,7 +929,7 @@ class _SoftmaxLoss(torch.autograd.Function):
         # logits := (softmax - onehot) * w * g / (norm * t), in place (the buffer is ours); pad rows / columns stay zero
         _c("rt_softmax_ce_rows", logits, Vp, R, V, y_act, w_act, float(logits_t), 1, out[1:], float(gloss), None, lse)
         ds_act = torch.empty((Rp, d), dtype=torch.float32, device=logits.device)
-        _gemm(logits, Vp, 1, tab, tab.stride(0), 0, ds_act, d, None, None, 0, Rp, d, Vp)       # dS = G @ E
+        _gemm(logits, Vp, 1, tab, tab.stride(0), 0, ds_act, d, None, None, 0, Rp, d, Vp, 0, _deep_k_splits(Rp, d, Vp))  # dS = G @ E
         d_tab = torch.empty((Vp, d), dtype=torch.float32, device=logits.device)
         _gemm(logits, Vp, 0, s_act, d, 0, d_tab, d, None, None, 0, Vp, d, Rp, 0, _wgrad_splits(Rp))  # dE = G^T @ S
         d_table = d_tab[:V]
