@@ -194,6 +194,13 @@ size_t rt_layernorm_bwd_workspace_bytes(int32_t M, int32_t d);
 int rt_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rstd, int32_t M,
                      int32_t d, float* dx, float* dw, float* db, void* workspace, size_t workspace_bytes,
                      rt_stream_t stream);
+/* The same backward with the passes around a LayerNorm of a transformer block fused (the reference leaves them to autograd:
+ * `seqs *= timeline_mask`, the skip connection's gradient add; sasrec.py:300, net_blocks.py:244-259, hstu.py:256,291):
+ * mask_dy: dy rows with ids[row] == 0 read as zero;  res (nullable): dx += res;  mask_dx: dx rows with ids[row] == 0
+ * written as zero.  ids [M] int64, required when a mask flag is set. */
+int rt_layernorm_bwd_fused(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
+                           const float* res, const int64_t* ids, int32_t mask_dy, int32_t mask_dx, int32_t M, int32_t d,
+                           float* dx, float* dw, float* db, void* workspace, size_t workspace_bytes, rt_stream_t stream);
 
 /* element-wise streams (n = number of floats, multiple of 4).  kind: 0 none, 1 relu, 2 gelu(erf), 3 silu, 4 sigmoid.
  * y = dropout(act(z)) [+ residual] and its backward (net_blocks.py:63-64; hstu.py:257; dropouts at sasrec.py:228,
@@ -216,6 +223,10 @@ int rt_gate_bwd(const float* dy, const float* gz, const float* a, float p, uint6
 int rt_axpy(const float* a, float alpha, const float* b, int64_t n, float* y, rt_stream_t stream);
 /* y = a * b * (ids[row] != 0); b, ids optional  (`seqs *= timeline_mask`, sasrec.py:300; hstu.py:256,291) */
 int rt_mul_mask(const float* a, const float* b, const int64_t* ids, int32_t d, int64_t n, float* y, rt_stream_t stream);
+/* the same over `rows` rows of width d with row strides (floats): operands / results may be column slices of a packed
+ * projection buffer (HSTU's u, v, q, k = uvqk.split(...), hstu.py:259-262) */
+int rt_mul_mask_ld(const float* a, int64_t lda, const float* b, int64_t ldb, const int64_t* ids, int64_t rows, int32_t d,
+                   float* y, int64_t ldy, rt_stream_t stream);
 
 /* K13 one dense Adam step over flat fp32 buffers (torch.optim.Adam semantics, lightning.py:214-218);
  * grad_scale multiplies g first (1/world_size after a sum all-reduce). */

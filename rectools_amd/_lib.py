@@ -46,6 +46,8 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_layernorm_fwd": (c_i32, [c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "rt_layernorm_bwd_workspace_bytes": (c_sz, [c_i32, c_i32]),
     "rt_layernorm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "rt_layernorm_bwd_fused": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp,
+                                       c_sz, c_vp]),
     "rt_act_dropout_fwd": (c_i32, [c_vp, c_i32, c_f32, c_u64, c_u64, c_i64, c_vp, c_vp, c_vp]),
     "rt_act_dropout_bwd": (c_i32, [c_vp, c_vp, c_i32, c_f32, c_u64, c_u64, c_i64, c_vp, c_vp]),
     "rt_swiglu_fwd": (c_i32, [c_vp, c_vp, c_f32, c_u64, c_u64, c_i64, c_vp, c_vp]),
@@ -54,6 +56,7 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_gate_bwd": (c_i32, [c_vp, c_vp, c_vp, c_f32, c_u64, c_u64, c_i64, c_vp, c_vp, c_vp]),
     "rt_axpy": (c_i32, [c_vp, c_f32, c_vp, c_i64, c_vp, c_vp]),
     "rt_mul_mask": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_vp]),
+    "rt_mul_mask_ld": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp]),
     "rt_adam_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp]),
     "rt_adam_step_segments": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp]),
     "rt_mha_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_vp, c_i64, c_vp, c_vp]),

@@ -123,15 +123,19 @@ __device__ __forceinline__ bool masked(const AttnArgs& a, int qq, int kk, bool k
   return (c & (kk > qq)) | (kp & key_is_pad & !(c & (kk == qq)));
 }
 
-// Attention dropout mask: one 32-bit mix per (head, query, key) element (murmur3 finaliser over a seeded counter).
-// Philox costs ~70 VALU per call and made the dK/dV kernel VALU-bound (16 calls per 32x32 tile per lane);
-// this is ~10 VALU per element and identical in all three kernels.
-__device__ __forceinline__ float drop_keep(unsigned long long seed, unsigned bh, unsigned q, unsigned key, float p,
-                                           float inv_keep) {
-  unsigned x = (unsigned)seed ^ (q * 0x9E3779B1u) ^ (key * 0x85EBCA77u) ^ (bh * 0xC2B2AE3Du) ^ (unsigned)(seed >> 32);
-  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
-  return ((float)(x >> 8) * (1.0f / 16777216.0f) >= p) ? inv_keep : 0.f;
+// Attention dropout mask: ONE 32-bit mix per (head, query, PAIR of adjacent keys); key 2j takes the low, key 2j+1 the high 16
+// bits, each compared with p * 65536.  History: Philox cost ~70 VALU per call and made the dK/dV kernel VALU-bound; a murmur3
+// finaliser per element (two v_mul_lo_u32 = two quarter-rate instructions) still cost ~1100 of a tile pair's ~9000 cycles —
+// and on this hardware the VALU time of a pair ADDS to its MFMA time, so every VALU slot counts.  One
+// xorshift-multiply round over multiplied counters, shared by two elements, is ~8 issue slots per element instead of ~19.
+// Identical in all three kernels (the backward kernels regenerate the mask).
+__device__ __forceinline__ unsigned drop_hash(unsigned long long seed, unsigned bh, unsigned q, unsigned key_pair) {
+  unsigned x = (unsigned)seed ^ (q * 0x9E3779B1u) ^ (key_pair * 0x85EBCA77u) ^ (bh * 0xC2B2AE3Du) ^ (unsigned)(seed >> 32);
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15;
+  return x;
 }
+__device__ __forceinline__ unsigned drop_thr16(float p) { return (unsigned)(p * 65536.0f); }   // p = 0: every element is kept
+__device__ __forceinline__ bool drop_kept(unsigned x, unsigned sub, unsigned thr16) { return ((x >> (16u * sub)) & 0xFFFFu) >= thr16; }
 
 __device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
 __device__ __forceinline__ float silu_df(float z) { float s = 1.f / (1.f + __expf(-z)); return s * (1.f + z * (1.f - s)); }
@@ -262,6 +266,8 @@ __device__ __forceinline__ void fwd_pair(const AttnArgs& a, const float* Kt, con
   };
   // side work of one score element (independent of the score itself)
   unsigned keep = 0xFFFFu, dead = 0u;   // bit r: element r survives dropout / is masked out
+  unsigned hx = 0u;
+  const unsigned thr16 = drop_thr16(a.p_drop);
   float bias[16];
   auto side = [&](int r) {
     const int kk = kt * TK + row_of(r, half);
@@ -270,8 +276,9 @@ __device__ __forceinline__ void fwd_pair(const AttnArgs& a, const float* Kt, con
         const bool kpad = kflag[row_of(r, half)] != 0.f;   // unconditional LDS read: no exec-mask branch per element
         if ((kk >= a.L) | masked(a, qq, kk, kpad)) dead |= 1u << r;
       }
-      // branch-free also for p = 0 (every element is kept and scaled by exactly 1)
-      if (drop_keep(a.seed, (unsigned)bh, (unsigned)qq, (unsigned)kk, a.p_drop, 1.f) == 0.f) keep &= ~(1u << r);
+      // branch-free also for p = 0 (every element is kept and scaled by exactly 1); elements r, r + 1 are keys kk, kk + 1
+      if ((r & 1) == 0) hx = drop_hash(a.seed, (unsigned)bh, (unsigned)qq, (unsigned)kk >> 1);
+      if (!drop_kept(hx, r & 1, thr16)) keep &= ~(1u << r);
     } else {
       const bool d = (kk >= a.L) | (qq >= a.L) | (kk > qq) | q_is_pad | (kflag[row_of(r, half)] != 0.f);
       float bv = 0.f;
@@ -426,7 +433,8 @@ __device__ __forceinline__ void dq_pair(const AttnArgs& a, const float* Kt, cons
   auto read_k = [&](int t, int nt) {
     return SWZ ? Kt[slx.off(t, nt)] : Kt[elem_off<HD, false>(row_of(t, half), nt * 32 + col)];
   };
-  unsigned keep = 0xFFFFu, dead = 0u;
+  unsigned keep = 0xFFFFu, dead = 0u, hx = 0u;
+  const unsigned thr16 = drop_thr16(a.p_drop);
   float bias[16];
   int tbk[16];
   auto side = [&](int r) {
@@ -434,7 +442,8 @@ __device__ __forceinline__ void dq_pair(const AttnArgs& a, const float* Kt, cons
     const bool kpad = EDGE && kflag[row_of(r, half)] != 0.f;
     if (MODE == MODE_SOFTMAX) {
       if (EDGE && ((kk >= a.L) | (qq >= a.L) | masked(a, qq, kk, kpad))) dead |= 1u << r;
-      if (drop_keep(a.seed, (unsigned)bh, (unsigned)qq, (unsigned)kk, a.p_drop, 1.f) == 0.f) keep &= ~(1u << r);
+      if ((r & 1) == 0) hx = drop_hash(a.seed, (unsigned)bh, (unsigned)qq, (unsigned)kk >> 1);
+      if (!drop_kept(hx, r & 1, thr16)) keep &= ~(1u << r);
     } else {
       const bool d = (kk >= a.L) | (qq >= a.L) | (kk > qq) | q_is_pad | kpad;
       float bv = 0.f; int tb = 0;
@@ -522,13 +531,14 @@ __device__ __forceinline__ void dkv_pair(const AttnArgs& a, const float* Qt, con
   auto read_f = [&](const float* T, int s) { return *reinterpret_cast<const f32x4*>(T + slot_off<HD, SWZ>(colx, 2 * s + half)); };
   auto elem = [&](int t, int nt) { return SWZ ? slx.off(t, nt) : elem_off<HD, false>(row_of(t, half), nt * 32 + col); };
   unsigned keep = 0xFFFFu, dead = 0u;
+  const unsigned thr16 = drop_thr16(a.p_drop);
   float bias[16];
   auto side = [&](int r) {
     const int qrow = row_of(r, half);
     const int q = qt * TK + qrow;
     if (MODE == MODE_SOFTMAX) {
       if (EDGE && ((kk >= a.L) | (q >= a.L) | masked(a, q, kk, k_is_pad))) dead |= 1u << r;
-      if (drop_keep(a.seed, (unsigned)bh, (unsigned)q, (unsigned)kk, a.p_drop, 1.f) == 0.f) keep &= ~(1u << r);
+      if (!drop_kept(drop_hash(a.seed, (unsigned)bh, (unsigned)q, (unsigned)kk >> 1), (unsigned)kk & 1u, thr16)) keep &= ~(1u << r);
     } else {
       const bool d = (kk >= a.L) | (q >= a.L) | (kk > q) | k_is_pad | (q_flag[qrow] != 0.f);
       float bv = 0.f;
@@ -1002,6 +1012,11 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(AttnArgs a) {
   const bool tron = (bh == 1 || bh == 300) && wave == 0;   // (RT_ATTN_TRACE builds only)
   const int trb = bh == 1 ? 0 : 256;
   RT_TMARK(tron, trb + 0);
+  // the wave's first query tile: its row fragments are requested BEFORE the K,V staging (timeline: issued after the barrier,
+  // this load was ~7,000 idle cycles in front of the first tile pair of every workgroup)
+  f32x4 qf[HDV];
+  int qt = sched_tile<NW, DMA>(0, wave, n_t, a.causal != 0, true);
+  load_row_frags<HDV>(qb, a.ldq, (qt < 0 ? 0 : qt) * TK + col, qt < 0 ? 0 : a.L, a.hd, half, qf);
   if (!DMA) stage_rows2<HD>(a.k + rowbase * a.ldk + h * a.hd, a.ldk, Ks, a.v + rowbase * a.ldv + h * a.hd, a.ldv, Vs, a.L, Lp, a.hd, tid, NTH);
   RT_TMARK(tron, trb + 1);
   for (int i = tid; i < Lp; i += NTH) kflag[i] = (i < a.L && idb[i] != 0) ? 0.f : 1.f;
@@ -1019,11 +1034,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(AttnArgs a) {
 
 #pragma unroll 1
   for (int it = 0;; ++it) {
-    const int qt = sched_tile<NW, DMA>(it, wave, n_t, a.causal != 0, true);
     if (qt < 0) break;
     const int qq = qt * TK + col;
-    f32x4 qf[HDV];
-    load_row_frags<HDV>(qb, a.ldq, qq, a.L, a.hd, half, qf);
     const bool q_is_pad = (qq < a.L) ? (idb[qq] == 0) : true;
     long long t_q1 = 0;
     if (MODE == MODE_HSTU && a.ts && qq < a.L) t_q1 = hl.ts[qq + 1];
@@ -1050,6 +1062,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(AttnArgs a) {
     RT_TMARK(tron && it == 0, trb + 3);
     fwd_store<MODE, HD>(a, bh, qq, half, rowbase, h, oacc, m_run, l_run);
     RT_TMARK(tron && it == 0, trb + 4);
+    qt = sched_tile<NW, DMA>(it + 1, wave, n_t, a.causal != 0, true);
+    if (qt >= 0) load_row_frags<HDV>(qb, a.ldq, qt * TK + col, a.L, a.hd, half, qf);
   }
   RT_TMARK(tron, trb + 5);
 }
@@ -1076,6 +1090,11 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(AttnArgs a) {
   const float* qb = a.q + rowbase * a.ldq + h * a.hd;
   const float* gb = a.dout + rowbase * a.lddo + h * a.hd;
   const long long* idb = a.ids + rowbase;
+  // row fragments of the wave's first query tile: requested before the K,V staging (see the forward kernel)
+  f32x4 qf[HDV], gf[HDV];
+  int qt = sched_tile<NW, DMA>(0, wave, n_t, a.causal != 0, true);
+  load_row_frags<HDV>(qb, a.ldq, (qt < 0 ? 0 : qt) * TK + col, qt < 0 ? 0 : a.L, a.hd, half, qf);
+  load_row_frags<HDV>(gb, a.lddo, (qt < 0 ? 0 : qt) * TK + col, qt < 0 ? 0 : a.L, a.hd, half, gf);
   if (!DMA) stage_rows2<HD>(a.k + rowbase * a.ldk + h * a.hd, a.ldk, Ks, a.v + rowbase * a.ldv + h * a.hd, a.ldv, Vs, a.L, Lp, a.hd, tid, NTH);
   for (int i = tid; i < Lp; i += NTH) kflag[i] = (i < a.L && idb[i] != 0) ? 0.f : 1.f;
   if (DMA && tid < n_t) tflag[tid] = 0;
@@ -1092,12 +1111,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(AttnArgs a) {
     SwzLane<HD> sl; sl.init(col, half);
 #pragma unroll 1
     for (int it = 0;; ++it) {
-      const int qt = sched_tile<NW, DMA>(it, wave, n_t, a.causal != 0, true);
       if (qt < 0) break;
       const int qq = qt * TK + col;
-      f32x4 qf[HDV], gf[HDV];
-      load_row_frags<HDV>(qb, a.ldq, qq, a.L, a.hd, half, qf);
-      load_row_frags<HDV>(gb, a.lddo, qq, a.L, a.hd, half, gf);
       const bool q_is_pad = (qq < a.L) ? (idb[qq] == 0) : true;
       float lse_q = 0.f, delta_q = 0.f;
       if (MODE == MODE_SOFTMAX) {
@@ -1127,6 +1142,11 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(AttnArgs a) {
       }
       if (MODE == MODE_HSTU && a.d_time_w) trun.flush(hl.dtw);
       store_rows_T<HD>(a.dq + rowbase * a.lddq + h * a.hd, a.lddq, qq, a.L, a.hd, half, dqacc);
+      qt = sched_tile<NW, DMA>(it + 1, wave, n_t, a.causal != 0, true);
+      if (qt >= 0) {
+        load_row_frags<HDV>(qb, a.ldq, qt * TK + col, a.L, a.hd, half, qf);
+        load_row_frags<HDV>(gb, a.lddo, qt * TK + col, a.L, a.hd, half, gf);
+      }
     }
   }
   if (MODE == MODE_HSTU) {
@@ -1159,6 +1179,11 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_res_kernel(AttnArgs a) {
   const float* kb = a.k + rowbase * a.ldk + h * a.hd;
   const float* vb = a.v + rowbase * a.ldv + h * a.hd;
   const long long* idb = a.ids + rowbase;
+  // row fragments of the wave's first key tile: requested before the Q,dO staging (see the forward kernel)
+  f32x4 kf[HDV], vf[HDV];
+  int ktile = sched_tile<NW, DMA>(0, wave, n_t, a.causal != 0, false);
+  load_row_frags<HDV>(kb, a.ldk, (ktile < 0 ? 0 : ktile) * TK + col, ktile < 0 ? 0 : a.L, a.hd, half, kf);
+  load_row_frags<HDV>(vb, a.ldv, (ktile < 0 ? 0 : ktile) * TK + col, ktile < 0 ? 0 : a.L, a.hd, half, vf);
   if (!DMA) stage_rows2<HD>(a.q + rowbase * a.ldq + h * a.hd, a.ldq, Qs, a.dout + rowbase * a.lddo + h * a.hd, a.lddo, Gs, a.L, Lp, a.hd, tid, NTH);
   for (int i = tid; i < Lp; i += NTH) {
     s_lse[i] = (MODE == MODE_SOFTMAX && i < a.L) ? a.lse[(long long)bh * a.L + i] : 0.f;
@@ -1178,12 +1203,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_res_kernel(AttnArgs a) {
 
 #pragma unroll 1
   for (int it = 0;; ++it) {
-    const int ktile = sched_tile<NW, DMA>(it, wave, n_t, a.causal != 0, false);
     if (ktile < 0) break;
     const int kk = ktile * TK + col;
-    f32x4 kf[HDV], vf[HDV];
-    load_row_frags<HDV>(kb, a.ldk, kk, a.L, a.hd, half, kf);
-    load_row_frags<HDV>(vb, a.ldv, kk, a.L, a.hd, half, vf);
     const bool k_is_pad = (kk < a.L) ? (idb[kk] == 0) : true;
     long long t_k = 0;
     if (MODE == MODE_HSTU && a.ts && kk < a.L) t_k = hl.ts[kk];
@@ -1210,6 +1231,11 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_res_kernel(AttnArgs a) {
     }
     store_rows_T<HD>(a.dk + rowbase * a.lddk + h * a.hd, a.lddk, kk, a.L, a.hd, half, dkacc);
     store_rows_T<HD>(a.dv + rowbase * a.lddv + h * a.hd, a.lddv, kk, a.L, a.hd, half, dvacc);
+    ktile = sched_tile<NW, DMA>(it + 1, wave, n_t, a.causal != 0, false);
+    if (ktile >= 0) {
+      load_row_frags<HDV>(kb, a.ldk, ktile * TK + col, a.L, a.hd, half, kf);
+      load_row_frags<HDV>(vb, a.ldv, ktile * TK + col, a.L, a.hd, half, vf);
+    }
   }
 }
 

@@ -268,11 +268,17 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 // dx = rstd * (dy*w - mean(dy*w) - xhat * mean(dy*w*xhat));  dw += sum dy*xhat;  db += sum dy
 // Each wave keeps the dw/db partial sums of its columns in registers over its rows (NDV float4 per lane,
 // d <= 256*NDV); the 4 waves are combined through LDS and one atomicAdd per column leaves the block.
+// Optional fusions of the passes that surround a LayerNorm in the backward of a transformer block (`res`, `ids` nullable):
+//   mask_dy: rows with ids[row] == 0 take dy = 0 (the forward multiplied the LayerNorm OUTPUT by the row mask)
+//   res:     dx += res (the LayerNorm input also fed a skip connection)       mask_dx: rows with ids[row] == 0 get dx = 0
 template <int NDV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ w, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, int M, int d, int rows_per_block,
-                                                            float* __restrict__ dx, float* __restrict__ partial) {
+                                                            float* __restrict__ dx, float* __restrict__ partial,
+                                                            const float* __restrict__ res = nullptr,
+                                                            const long long* __restrict__ ids = nullptr, int mask_dy = 0,
+                                                            int mask_dx = 0) {
   extern __shared__ float red[];  // [4 waves][2][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r0 = blockIdx.x * rows_per_block;
@@ -291,6 +297,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     const int mb = has2 ? m2 : m;
     const float mu[2] = {mean[m], mean[mb]}, rs[2] = {rstd[m], rstd[mb]};
     const long long ro[2] = {(long long)m * d, (long long)mb * d};
+    const bool pad[2] = {ids != nullptr && ids[m] == 0, ids != nullptr && ids[mb] == 0};
     f32x4 g[2][NDV], xh[2][NDV];
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
 #pragma unroll
@@ -299,7 +306,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       for (int i = 0; i < NDV; ++i) {
         const int c = lane * 4 + 256 * i;
         f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        g[u][i] = (c < d) ? *reinterpret_cast<const f32x4*>(dy + ro[u] + c) : z;
+        g[u][i] = (c < d && !(mask_dy && pad[u])) ? *reinterpret_cast<const f32x4*>(dy + ro[u] + c) : z;
         xh[u][i] = (c < d) ? *reinterpret_cast<const f32x4*>(x + ro[u] + c) : z;
       }
 #pragma unroll
@@ -323,6 +330,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         const int c = lane * 4 + 256 * i;
         if (c < d) {
           f32x4 o = (g[u][i] * wv[i] - s1[u] - xh[u][i] * s2[u]) * rs[u];
+          if (res != nullptr) o += *reinterpret_cast<const f32x4*>(res + ro[u] + c);
+          if (mask_dx && pad[u]) o = f32x4{0.f, 0.f, 0.f, 0.f};
           *reinterpret_cast<f32x4*>(dx + ro[u] + c) = o;
           pw[i] += g[u][i] * xh[u][i];
           pb[i] += g[u][i];
@@ -509,6 +518,19 @@ __global__ void mul_kernel(const f32x4* __restrict__ a, const f32x4* __restrict_
   }
 }
 
+// y[r, :] = a[r, :] * b[r, :] * (ids[r] != 0) with row strides (operands / results that are column slices of packed buffers)
+__global__ void mul_ld_kernel(const float* __restrict__ a, long long lda, const float* __restrict__ b, long long ldb,
+                              const long long* __restrict__ ids, int d4, long long n4, float* __restrict__ y, long long ldy) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / d4;
+    const int c = (int)(i - r * d4) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(a + r * lda + c);
+    if (b) v *= *reinterpret_cast<const f32x4*>(b + r * ldb + c);
+    if (ids && ids[r] == 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(y + r * ldy + c) = v;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // K13 Adam on flat buffers
 // ---------------------------------------------------------------------------------------------------
@@ -650,9 +672,21 @@ size_t rt_layernorm_bwd_workspace_bytes(int32_t M, int32_t d) {
 }
 
 // dx [M,d], dw [d], db [d] are fully overwritten (deterministic two-stage reduction, no atomics).
+int rt_layernorm_bwd_fused(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
+                           const float* res, const int64_t* ids, int32_t mask_dy, int32_t mask_dx, int32_t M, int32_t d,
+                           float* dx, float* dw, float* db, void* workspace, size_t workspace_bytes, hipStream_t stream);
 int rt_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rstd, int32_t M,
                      int32_t d, float* dx, float* dw, float* db, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  return rt_layernorm_bwd_fused(dy, x, w, mean, rstd, nullptr, nullptr, 0, 0, M, d, dx, dw, db, workspace, workspace_bytes, stream);
+}
+// Same with the surrounding passes fused: dy rows of padded positions read as zero (mask_dy), dx += res, dx rows of padded
+// positions written as zero (mask_dx); res / ids nullable.
+int rt_layernorm_bwd_fused(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
+                           const float* res, const int64_t* ids, int32_t mask_dy, int32_t mask_dx, int32_t M, int32_t d,
+                           float* dx, float* dw, float* db, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   (void)hipGetLastError();
+  if ((mask_dy || mask_dx) && ids == nullptr) return RT_ERR_INVALID_ARG;
+  const long long* idp = reinterpret_cast<const long long*>(ids);
   if ((d & 3) != 0) return RT_ERR_INVALID_ARG;
   if (d > 1024) return RT_ERR_UNSUPPORTED;
   if (M <= 0) {
@@ -665,9 +699,9 @@ int rt_layernorm_bwd(const float* dy, const float* x, const float* w, const floa
   const int blocks = ln_bwd_blocks(M, rpb);
   float* partial = reinterpret_cast<float*>(workspace);
   const size_t lds = 8 * (size_t)d * sizeof(float);
-  if (d <= 256) layernorm_bwd_kernel<1><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, partial);
-  else if (d <= 512) layernorm_bwd_kernel<2><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, partial);
-  else layernorm_bwd_kernel<4><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, partial);
+  if (d <= 256) layernorm_bwd_kernel<1><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, partial, res, idp, mask_dy, mask_dx);
+  else if (d <= 512) layernorm_bwd_kernel<2><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, partial, res, idp, mask_dy, mask_dx);
+  else layernorm_bwd_kernel<4><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, partial, res, idp, mask_dy, mask_dx);
   RT_CHECK_LAUNCH();
   layernorm_bwd_reduce_kernel<<<(2 * d + 15) / 16, 256, 0, stream>>>(partial, blocks, d, dw, db);
   RT_CHECK_LAUNCH();
@@ -763,6 +797,19 @@ int rt_mul_mask(const float* a, const float* b, const int64_t* ids, int32_t d, i
   mul_kernel<<<stream_grid(n / 4), 256, 0, stream>>>(reinterpret_cast<const f32x4*>(a), reinterpret_cast<const f32x4*>(b),
                                                      reinterpret_cast<const long long*>(ids), d / 4, n / 4,
                                                      reinterpret_cast<f32x4*>(y));
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+// y[r, 0:d] = a[r, 0:d] * b[r, 0:d] * (ids[r] != 0) for `rows` rows with row strides lda / ldb / ldy (floats, multiples of 4):
+// operands and results may be column slices of packed projection buffers (HSTU's u / v / q / k; hstu.py:259-291)
+int rt_mul_mask_ld(const float* a, int64_t lda, const float* b, int64_t ldb, const int64_t* ids, int64_t rows, int32_t d,
+                   float* y, int64_t ldy, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (rows <= 0 || d <= 0) return RT_OK;
+  if ((d & 3) != 0 || (lda & 3) != 0 || (ldy & 3) != 0 || (b != nullptr && (ldb & 3) != 0)) return RT_ERR_INVALID_ARG;
+  const long long n4 = (long long)rows * (d / 4);
+  mul_ld_kernel<<<stream_grid(n4), 256, 0, stream>>>(a, lda, b, ldb, reinterpret_cast<const long long*>(ids), d / 4, n4, y, ldy);
   RT_CHECK_LAUNCH();
   return RT_OK;
 }

@@ -423,6 +423,19 @@ class STULayer(nn.Module):
         self.p_mlp, self.p_attn = dropout_rate, attn_dropout_rate
 
     def forward(self, seqs, ids, B, L, batch, thr):
+        """`seqs` comes in unmasked: the row mask (hstu.py:256) is the first step of the fused block."""
+        if self.output_mlp.bias is not None:
+            tw = self.rel_attn.time_weights if self.rel_attn.relative_time_attention else None
+            pw = self.rel_attn.pos_weights if self.rel_attn.relative_pos_attention else None
+            return ops.stu_layer(seqs, ids, batch.get("unix_ts") if tw is not None else None, thr, B, L, self.n_heads, self.hd,
+                                 self.p_attn if self.training else 0.0, self.p_mlp if self.training else 0.0,
+                                 (self.norm_input.weight, self.norm_input.bias, self.norm_input.eps), self.uvqk_proj, tw, pw,
+                                 (self.norm_attn_output.weight, self.norm_attn_output.bias, self.norm_attn_output.eps),
+                                 (self.output_mlp.weight, self.output_mlp.bias))
+        return self.forward_modular(ops.mul_mask(seqs, None, ids), ids, B, L, batch, thr)
+
+    def forward_modular(self, seqs, ids, B, L, batch, thr):
+        """Same block out of the individual autograd ops (`seqs` already masked); the cross-check of the fused node."""
         hh = self.n_heads * self.hd
         normed = ops.mul_mask(self.norm_input(seqs), None, ids)
         uvqk = ops.act_dropout(ops.matmul_nn(normed, self.uvqk_proj), ops.ACT_SILU, 0.0)
@@ -449,8 +462,7 @@ class STULayers(TransformerLayersBase):
 
     def forward(self, seqs, ids, B, L, causal, keypad, batch):
         for blk in self.stu_blocks:
-            seqs = ops.mul_mask(seqs, None, ids)
-            seqs = blk(seqs, ids, B, L, batch, self.time_thr)
+            seqs = blk(seqs, ids, B, L, batch, self.time_thr)   # seqs * mask happens inside the block
         return ops.mul_mask(seqs, None, ids)
 
 

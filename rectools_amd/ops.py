@@ -824,6 +824,139 @@ def hstu_attn(q, k, v, time_w, pos_w, ids, ts, thr, B: int, H: int, L: int) -> t
     return _HstuAttn.apply(q, k, v, time_w, pos_w, ids.reshape(-1), ts, thr, B, H, L)
 
 
+class _STULayer(torch.autograd.Function):
+    """One STU block (hstu.py:225-295) as a single autograd node.
+
+        x0 = x * m;  n = LN_in(x0) * m;  [u v q k] = silu(n P);  a = hstu_attn(q, k, v, rab);  a' = dropout(a)
+        o = dropout(u * LN_attn(a') * m);  out = o Wo^T + bo + x0            (m = the row mask `ids != 0`)
+
+    Same kernels as the modular path (`nn.STULayer.forward_modular`); what the node adds is the backward data flow: the
+    gradients of u, v, q, k are WRITTEN into the column slices of one [M, 4 H hd] buffer (autograd's SliceBackward built four
+    zero-filled buffers of that size, copied a slice into each and added them: 0.95 + 0.34 + 0.28 ms of at:: kernels per C4
+    step), u is read in place through a row stride, and the mask / skip-connection passes around LN_in ride inside its
+    backward kernel (`rt_layernorm_bwd_fused`).
+    """
+
+    @staticmethod
+    def forward(ctx, x, ids, ts, thr, ln1_w, ln1_b, uvqk_p, tw, pw, ln2_w, ln2_b, out_w, out_b, meta):
+        B, L, H, hd, p_attn, p_mlp, eps1, eps2 = meta
+        x = x.contiguous()
+        M, d = x.shape
+        hh = H * hd
+        dev = x.device
+        new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
+        x0 = new(M, d)
+        _c("rt_mul_mask", x, None, ids, d, x.numel(), x0)
+        n1, mean1, rstd1 = new(M, d), new(M), new(M)
+        _c("rt_layernorm_fwd", x0, ln1_w, ln1_b, float(eps1), M, d, n1, mean1, rstd1)
+        _c("rt_mul_mask", n1, None, ids, d, n1.numel(), n1)          # in place: n1 = LN(x0) * m
+        z = new(M, 4 * hh)
+        _gemm(n1, d, 1, uvqk_p, 4 * hh, 0, z, 4 * hh, None, None, 0, M, 4 * hh, d)
+        uvqk = new(M, 4 * hh)
+        _c("rt_act_dropout_fwd", z, ACT_SILU, 0.0, 0, 0, z.numel(), None, uvqk)
+        attn = new(M, hh)
+        has_t = tw is not None
+        _c("rt_hstu_attn_fwd", uvqk[:, 2 * hh:], 4 * hh, uvqk[:, 3 * hh:], 4 * hh, uvqk[:, hh:], 4 * hh, ids, ts if has_t else None,
+           tw, thr if has_t else None, pw, B, H, L, hd, attn, hh)
+        seed_a = seed_m = (0, 0)
+        attn_d = attn
+        if p_attn > 0:
+            seed_a = RNG.next()
+            attn_d = new(M, hh)
+            _c("rt_act_dropout_fwd", attn, ACT_NONE, float(p_attn), seed_a[0], seed_a[1], attn.numel(), None, attn_d)
+        la, mean2, rstd2 = new(M, hh), new(M), new(M)
+        _c("rt_layernorm_fwd", attn_d, ln2_w, ln2_b, float(eps2), M, hh, la, mean2, rstd2)
+        o_in = new(M, hh)
+        _c("rt_mul_mask_ld", uvqk, 4 * hh, la, hh, ids, M, hh, o_in, hh)      # u * LN(a') * m, u read in place
+        o_d = o_in
+        if p_mlp > 0:
+            seed_m = RNG.next()
+            o_d = new(M, hh)
+            _c("rt_act_dropout_fwd", o_in, ACT_NONE, float(p_mlp), seed_m[0], seed_m[1], o_in.numel(), None, o_d)
+        out = new(M, d)
+        _gemm(o_d, hh, 1, out_w, hh, 1, out, d, out_b, x0, d, M, d, hh)
+        ctx.save_for_backward(ids, ts, thr, x0, n1, z, uvqk, attn_d, la, o_d, mean1, rstd1, mean2, rstd2, ln1_w, uvqk_p, tw, pw,
+                              ln2_w, out_w)
+        ctx.meta = (B, L, H, hd, p_attn, p_mlp, seed_a, seed_m)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (ids, ts, thr, x0, n1, z, uvqk, attn_d, la, o_d, mean1, rstd1, mean2, rstd2, ln1_w, uvqk_p, tw, pw, ln2_w,
+         out_w) = ctx.saved_tensors
+        B, L, H, hd, p_attn, p_mlp, seed_a, seed_m = ctx.meta
+        g_out = g_out.contiguous()
+        M, d = g_out.shape
+        hh = H * hd
+        dev = g_out.device
+        new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
+        sp = _wgrad_splits(M)
+        defer = _steals_grad(ln1_w, uvqk_p, ln2_w, out_w)
+        lib = _lib.load()
+        side = []
+        # ---- out = o_d Wo^T + bo + x0
+        d_wo, d_bo = new(d, hh), new(d)
+        with _OnSide(dev, defer) as sd:
+            side.append(sd)
+            sd.uses(g_out, o_d, d_wo, d_bo)
+            _gemm(g_out, d, 0, o_d, hh, 0, d_wo, hh, None, None, 0, d, hh, M, 0, sp, d_bo)
+        g_od = new(M, hh)
+        _gemm(g_out, d, 1, out_w, hh, 0, g_od, hh, None, None, 0, M, hh, d)
+        if p_mlp > 0:
+            g_oin = new(M, hh)
+            _c("rt_act_dropout_bwd", g_od, g_od, ACT_NONE, float(p_mlp), seed_m[0], seed_m[1], g_od.numel(), g_oin)
+        else:
+            g_oin = g_od
+        # ---- o_in = u * la * m : the u gradient goes straight into its column slice of the packed gradient
+        g_uvqk = new(M, 4 * hh)
+        _c("rt_mul_mask_ld", g_oin, hh, la, hh, ids, M, hh, g_uvqk, 4 * hh)
+        g_la = new(M, hh)
+        _c("rt_mul_mask_ld", g_oin, hh, uvqk, 4 * hh, ids, M, hh, g_la, hh)
+        g_ad, d_ln2w, d_ln2b = new(M, hh), new(hh), new(hh)
+        ws_bytes = lib.rt_layernorm_bwd_workspace_bytes(M, hh)
+        ws = torch.empty((max(ws_bytes, 4),), dtype=torch.uint8, device=dev)
+        _c("rt_layernorm_bwd", g_la, attn_d, ln2_w, mean2, rstd2, M, hh, g_ad, d_ln2w, d_ln2b, ws, ws_bytes)
+        if p_attn > 0:
+            g_attn = new(M, hh)
+            _c("rt_act_dropout_bwd", g_ad, g_ad, ACT_NONE, float(p_attn), seed_a[0], seed_a[1], g_ad.numel(), g_attn)
+        else:
+            g_attn = g_ad
+        has_t = tw is not None
+        dtw = None if tw is None else torch.zeros_like(tw)
+        dpw = None if pw is None else torch.zeros_like(pw)
+        _c("rt_hstu_attn_bwd", uvqk[:, 2 * hh:], 4 * hh, uvqk[:, 3 * hh:], 4 * hh, uvqk[:, hh:], 4 * hh, g_attn, hh, ids,
+           ts if has_t else None, tw, thr if has_t else None, pw, B, H, L, hd, g_uvqk[:, 2 * hh:], 4 * hh, g_uvqk[:, 3 * hh:], 4 * hh,
+           g_uvqk[:, hh:], 4 * hh, dtw, dpw)
+        g_z = new(M, 4 * hh)
+        _c("rt_act_dropout_bwd", g_uvqk, z, ACT_SILU, 0.0, 0, 0, g_uvqk.numel(), g_z)
+        d_p = new(d, 4 * hh)
+        with _OnSide(dev, defer) as sd:
+            side.append(sd)
+            sd.uses(n1, g_z, d_p)
+            _gemm(n1, d, 0, g_z, 4 * hh, 0, d_p, 4 * hh, None, None, 0, d, 4 * hh, M, 0, sp)       # dP = n^T g_z
+        g_n = new(M, d)
+        _gemm(g_z, 4 * hh, 1, uvqk_p, 4 * hh, 1, g_n, d, None, None, 0, M, d, 4 * hh)              # g_n = g_z P^T
+        # ---- n = LN(x0) * m, x0 = x * m (+ the skip connection): one kernel
+        g_x, d_ln1w, d_ln1b = new(M, d), new(d), new(d)
+        ws_bytes = lib.rt_layernorm_bwd_workspace_bytes(M, d)
+        ws = torch.empty((max(ws_bytes, 4),), dtype=torch.uint8, device=dev)
+        _c("rt_layernorm_bwd_fused", g_n, x0, ln1_w, mean1, rstd1, g_out, ids, 1, 1, M, d, g_x, d_ln1w, d_ln1b, ws, ws_bytes)
+        if side:
+            side[-1].join_now()
+        return (g_x, None, None, None, d_ln1w, d_ln1b, d_p, dtw, dpw, d_ln2w, d_ln2b, d_wo, d_bo, None)
+
+
+def stu_layer(x: torch.Tensor, ids: torch.Tensor, ts: tp.Optional[torch.Tensor], thr: torch.Tensor, B: int, L: int, H: int,
+              hd: int, p_attn: float, p_mlp: float, ln_in: tp.Tuple[torch.Tensor, torch.Tensor, float], uvqk_proj: torch.Tensor,
+              time_w: tp.Optional[torch.Tensor], pos_w: tp.Optional[torch.Tensor],
+              ln_attn: tp.Tuple[torch.Tensor, torch.Tensor, float], out_mlp: tp.Tuple[torch.Tensor, torch.Tensor]) -> torch.Tensor:
+    """Fused STU block on [B*L, d] activations (input row mask included); parameters as (weight, bias[, eps])."""
+    for t in (x, ln_in[0], uvqk_proj, ln_attn[0], out_mlp[0]):
+        _chk(t, "stu_layer")
+    return _STULayer.apply(x, ids.reshape(-1), ts, thr, ln_in[0], ln_in[1], uvqk_proj, time_w, pos_w, ln_attn[0], ln_attn[1],
+                           out_mlp[0], out_mlp[1], (B, L, H, hd, float(p_attn), float(p_mlp), ln_in[2], ln_attn[2]))
+
+
 # --------------------------------------------------------------------------------------------------
 # losses
 # --------------------------------------------------------------------------------------------------

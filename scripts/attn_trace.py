@@ -24,6 +24,7 @@ for p in (0.2, 0.0):
     lib.rt_debug_attn_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
     rc = lib.rt_debug_attn_trace(buf, 1024)
     t = np.array(buf, dtype=np.uint64).astype(np.int64)
+    print(f"p={p}: bh=300 starts {t[256] - t[0]} ticks after bh=1 starts; bh=1 exits at {t[5] - t[0]}, bh=300 exits at {t[261] - t[0]}")
     for base, name in ((0, "bh=1 (first round)"), (256, "bh=300 (second round)")):
         m = t[base:base + 6] - t[base]
         print(f"p={p} {name}: s_memtime ticks (100 MHz => x24 core cycles at 2.4 GHz): start 0 | K,V staged {m[1]} | barrier {m[2]} | "
@@ -31,8 +32,9 @@ for p in (0.2, 0.0):
         rows = []
         for kt in range(7):
             x = t[base + 16 + kt * 4: base + 16 + kt * 4 + 4]
-            rows.append((int(x[0] - t[base]), int(x[1] - x[0]), int(x[2] - x[1]), int(x[3] - x[2])))
-        print("   per pair (start, S, softmax, PV):", rows)
+            nxt = t[base + 16 + (kt + 1) * 4]
+            rows.append((int(x[0] - t[base]), int(x[1] - x[0]), int(x[3] - x[1]), int(x[2] - x[3]), int(nxt - x[2])))
+        print("   per step (start, stage1, stage2, tail, to-next-top):", rows)
     for base, name in ((512, "ring bh=1"), (768, "ring bh=300")):
         if t[base] == 0:
             continue

@@ -404,6 +404,45 @@ def test_fused_sasrec_layer_matches_modular_ops(B, L, d, H, p):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("p,L,rt,rp", [(0.0, 70, True, True), (0.3, 130, True, False), (0.0, 40, False, True)])
+def test_fused_stu_layer_matches_modular_path(p, L, rt, rp):
+    """ops.stu_layer (one autograd node: packed u/v/q/k gradient, strided u, LayerNorm backward with the mask and skip passes
+    fused) against the same block assembled from the individual ops — same dropout streams, so p > 0 compares exactly too."""
+    from rectools_amd import nn as hnn
+    from rectools_amd import ops
+
+    torch.manual_seed(0)
+    B, d, H, hd = 3, 64, 2, 32
+    layer = hnn.STULayer(d, H, hd, hd, L, rt, rp, p, p, 1e-6).cuda().train()
+    with torch.no_grad():
+        for prm in layer.parameters():
+            prm.data.add_(0.1 * torch.randn_like(prm))
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(1, 50, (B, L), generator=g); ids[0, : L // 3] = 0
+    ts = torch.cumsum(torch.randint(0, 3_000_000, (B, L + 1), generator=g), 1) + 1_300_000_000
+    ids, batch = ids.cuda(), {"unix_ts": ts.cuda()}
+    thr = ops.hstu_time_thresholds().cuda()
+    x = rnd(B * L, d, seed=2).cuda()
+    gout = rnd(B * L, d, seed=3).cuda()
+
+    def run(fused):
+        ops.RNG.step, ops.RNG._stream = 7, 0
+        for prm in layer.parameters():
+            prm.grad = None
+        xi = x.clone().requires_grad_(True)
+        out = layer(xi, ids, B, L, batch, thr) if fused else layer.forward_modular(ops.mul_mask(xi, None, ids), ids, B, L, batch, thr)
+        out.backward(gout)
+        return out.detach(), xi.grad, {k: v.grad.clone() for k, v in layer.named_parameters()}
+
+    o1, gx1, gp1 = run(True)
+    o2, gx2, gp2 = run(False)
+    close(o1, o2, rtol=1e-5, atol_rel=1e-6, msg="fused stu fwd")
+    close(gx1, gx2, rtol=1e-4, atol_rel=1e-5, msg="fused stu dx")
+    for k in gp2:
+        close(gp1[k], gp2[k], rtol=1e-4, atol_rel=1e-5, msg=f"fused stu d{k}")
+
+
+@pytest.mark.gpu
 def test_flat_adam_segments_match_torch_adam():
     """Segmented Adam: ragged parameter sizes, an unaligned gradient view, a parameter without gradient, 3 steps."""
     from rectools_amd import lightning as hl
