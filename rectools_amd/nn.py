@@ -75,9 +75,10 @@ class MultiheadAttnParams(nn.Module):
     def forward(self, q_in: torch.Tensor, kv_in: tp.Optional[torch.Tensor], ids: torch.Tensor, B: int, L: int,
                 causal: bool, keypad: bool, p: float, residual: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
         d = self.d
-        if kv_in is None:  # self-attention on one input: one packed GEMM
+        if kv_in is None:  # self-attention on one input: one packed GEMM, one packed gradient
             qkv = ops.linear(q_in, self.in_proj_weight, self.in_proj_bias)
-            q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+            o = ops.mha_packed(qkv, ids, B, self.n_heads, L, causal, keypad, p)
+            return self.out_proj(o, residual=residual)
         else:  # SASRec: Q from LN(x), K/V from x (sasrec.py:221-224)
             q = ops.linear(q_in, self.in_proj_weight[:d], self.in_proj_bias[:d])
             kv = ops.linear(kv_in, self.in_proj_weight[d:], self.in_proj_bias[d:])
@@ -330,14 +331,16 @@ class PreLNTransformerLayer(nn.Module):
 
     def forward(self, seqs, ids, B, L, causal, keypad):
         p = self.p if self.training else 0.0
-        h = self.layer_norm_1(seqs)
+        ln1, ln2 = self.layer_norm_1, self.layer_norm_2
+        h, skip = ops.layer_norm_skip(seqs, ln1.weight, ln1.bias, ln1.eps)     # skip = seqs, its gradient rides in LN1's backward
         if p > 0:
-            seqs = ops.add(seqs, ops.dropout(self.multi_head_attn(h, None, ids, B, L, causal, keypad, p), p))
-            f = self.feed_forward(self.layer_norm_2(seqs))
-            seqs = ops.add(seqs, ops.dropout(f, p))
+            seqs = ops.dropout_add(self.multi_head_attn(h, None, ids, B, L, causal, keypad, p), skip, p)
+            g, skip = ops.layer_norm_skip(seqs, ln2.weight, ln2.bias, ln2.eps)
+            seqs = ops.dropout_add(self.feed_forward(g), skip, p)
             return ops.dropout(seqs, p)  # dropout_3 (net_blocks.py:260)
-        seqs = self.multi_head_attn(h, None, ids, B, L, causal, keypad, 0.0, residual=seqs)
-        return self.feed_forward(self.layer_norm_2(seqs), residual=seqs)
+        seqs = self.multi_head_attn(h, None, ids, B, L, causal, keypad, 0.0, residual=skip)
+        g, skip = ops.layer_norm_skip(seqs, ln2.weight, ln2.bias, ln2.eps)
+        return self.feed_forward(g, residual=skip)
 
 
 class PreLNTransformerLayers(TransformerLayersBase):
@@ -368,10 +371,12 @@ class LiGRLayer(nn.Module):
 
     def forward(self, seqs, ids, B, L, causal, keypad):
         p = self.p if self.training else 0.0
-        h = self.layer_norm_1(seqs)
+        ln1, ln2 = self.layer_norm_1, self.layer_norm_2
+        h, seqs = ops.layer_norm_skip(seqs, ln1.weight, ln1.bias, ln1.eps)   # gradients of the other consumers ride in LN1's backward
         a = self.multi_head_attn(h, None, ids, B, L, causal, keypad, p)
         seqs = ops.gate(seqs, self.gating_linear_1(seqs), a, p)      # seqs + sigmoid(Wg1 seqs) * drop(mha)
-        f = self.feed_forward(self.layer_norm_2(seqs))
+        g, seqs = ops.layer_norm_skip(seqs, ln2.weight, ln2.bias, ln2.eps)
+        f = self.feed_forward(g)
         return ops.gate(seqs, self.gating_linear_2(seqs), f, p)      # seqs + sigmoid(Wg2 seqs) * drop(ffn)
 
 

@@ -426,6 +426,70 @@ class _LayerNorm(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class _LayerNormSkip(torch.autograd.Function):
+    """(LN(x), x): the second output is the skip branch of a pre-LN block.  Its gradient is added inside the LayerNorm backward
+    kernel (`rt_layernorm_bwd_fused`, res) instead of by a full-size add kernel that autograd issues for a tensor with two
+    consumers."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        x = x.contiguous()
+        M, d = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty((M,), dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        _c("rt_layernorm_fwd", x, w, b, float(eps), M, d, y, mean, rstd)
+        ctx.save_for_backward(x, w, mean, rstd)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        x, w, mean, rstd = ctx.saved_tensors
+        M, d = x.shape
+        if dy is None:
+            return dskip, None, None, None
+        dy = dy.contiguous()
+        res = None if dskip is None else dskip.contiguous()
+        dx, dw, db = torch.empty_like(x), torch.empty_like(w), torch.empty_like(w)
+        ws_bytes = _lib.load().rt_layernorm_bwd_workspace_bytes(M, d)
+        ws = torch.empty((max(ws_bytes, 4),), dtype=torch.uint8, device=x.device)
+        _c("rt_layernorm_bwd_fused", dy, x, w, mean, rstd, res, None, 0, 0, M, d, dx, dw, db, ws, ws_bytes)
+        return dx, dw, db, None
+
+
+def layer_norm_skip(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float) -> tp.Tuple[torch.Tensor, torch.Tensor]:
+    """-> (LayerNorm(x), x'): use x' for the skip connection / every other consumer of x."""
+    return _LayerNormSkip.apply(_chk(x, "layer_norm_skip"), w, b, eps)
+
+
+class _DropoutAdd(torch.autograd.Function):
+    """residual + dropout(x) in one pass (net_blocks.py:257-259)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, p):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        seed = RNG.next() if p > 0 else (0, 0)
+        _c("rt_act_dropout_fwd", x, ACT_NONE, float(p), seed[0], seed[1], x.numel(), residual.contiguous(), y)
+        ctx.meta = (p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed = ctx.meta
+        dy = dy.contiguous()
+        if p > 0:
+            dx = torch.empty_like(dy)
+            _c("rt_act_dropout_bwd", dy, dy, ACT_NONE, float(p), seed[0], seed[1], dy.numel(), dx)
+        else:
+            dx = dy
+        return dx, dy, None
+
+
+def dropout_add(x: torch.Tensor, residual: torch.Tensor, p: float) -> torch.Tensor:
+    return _DropoutAdd.apply(_chk(x, "dropout_add"), residual, p)
+
+
 def layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float) -> torch.Tensor:
     return _LayerNorm.apply(x, w, b, eps)
 
@@ -619,6 +683,47 @@ def mha(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, ids: torch.Tensor, B:
         keypad: bool, p: float) -> torch.Tensor:
     """Softmax attention over [B*L, d] projections (column slices of packed buffers are fine)."""
     return _MHA.apply(q, k, v, ids.reshape(-1), B, H, L, causal, keypad, p)
+
+
+class _MHAPacked(torch.autograd.Function):
+    """Self-attention on a packed in_proj output qkv [M, 3d] (net_blocks.py:248-255, ligr.py:91-98).  The backward WRITES dq, dk,
+    dv into the column slices of one [M, 3d] gradient; with three sliced views of qkv, autograd's SliceBackward builds three
+    zero-filled [M, 3d] buffers, copies a slice into each and adds them (5 % of the BERT4Rec step in at:: kernels)."""
+
+    @staticmethod
+    def forward(ctx, qkv, ids, B, H, L, causal, keypad, p):
+        M, d3 = qkv.shape
+        d = d3 // 3
+        hd = d // H
+        o = torch.empty((M, d), dtype=torch.float32, device=qkv.device)
+        lse = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
+        seed = 0
+        if p > 0:
+            s0, sid = RNG.next()
+            seed = (s0 + 0xD1B54A32D192ED03 * sid) & 0xFFFFFFFFFFFFFFFF
+        _c("rt_mha_fwd", qkv, d3, qkv[:, d:], d3, qkv[:, 2 * d:], d3, ids, B, H, L, hd, int(causal), int(keypad), float(p), seed, o, d,
+           lse)
+        ctx.save_for_backward(qkv, o, lse, ids)
+        ctx.meta = (B, H, L, hd, causal, keypad, p, seed)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, o, lse, ids = ctx.saved_tensors
+        B, H, L, hd, causal, keypad, p, seed = ctx.meta
+        d = H * hd
+        d3 = 3 * d
+        do = do.contiguous()
+        g = torch.empty_like(qkv)
+        delta = torch.empty((B, H, L), dtype=torch.float32, device=do.device)
+        _c("rt_mha_bwd", qkv, d3, qkv[:, d:], d3, qkv[:, 2 * d:], d3, o, d, do, d, lse, ids, B, H, L, hd, int(causal), int(keypad),
+           float(p), seed, g, d3, g[:, d:], d3, g[:, 2 * d:], d3, delta)
+        return g, None, None, None, None, None, None, None
+
+
+def mha_packed(qkv: torch.Tensor, ids: torch.Tensor, B: int, H: int, L: int, causal: bool, keypad: bool, p: float) -> torch.Tensor:
+    """Softmax self-attention over a packed [B*L, 3d] projection (q | k | v column blocks)."""
+    return _MHAPacked.apply(_chk(qkv, "mha_packed").contiguous(), ids.reshape(-1), B, H, L, causal, keypad, p)
 
 
 class _SASRecLayer(torch.autograd.Function):
