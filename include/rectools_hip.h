@@ -254,6 +254,12 @@ int rt_mha_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const f
                int32_t B, int32_t H, int32_t L, int32_t hd, int32_t causal, int32_t keypad, float p_drop, uint64_t seed,
                float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv, float* delta,
                rt_stream_t stream);
+/* Inference shortcut of the same attention: ONLY the last query (position L-1) of every session — recommend() reads
+ * `session_embs[:, -1, :]` (lightning.py:393-397), so the final block needs one query row per session.  q [B, ldq] = one
+ * projected query row per session, k / v as above, o [B, ldo].  No dropout; masks as rt_mha_fwd applies them to query L-1. */
+int rt_mha_last_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const int64_t* ids,
+                    int32_t B, int32_t H, int32_t L, int32_t hd, int32_t causal, int32_t keypad, float* o, int64_t ldo,
+                    rt_stream_t stream);
 
 /* K5/K6  HSTU pointwise attention with in-kernel relative time/position bias (hstu.py:84-128, 270-288).
  * ts [B,L+1] int64 (NULL: no time bias); time_w [129]; time_thr [129] = smallest |dt| of each bucket, computed on

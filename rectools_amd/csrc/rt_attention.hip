@@ -1746,6 +1746,72 @@ inline bool bad_common(int B, int H, int L, int hd, int64_t ldq, int64_t ldk, in
   return B <= 0 || H <= 0 || L <= 0 || hd <= 0 || (hd & 7) != 0 || hd > 128 || (ldq & 3) || (ldk & 3) || (ldv & 3);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Inference: attention of the LAST query of every session only.  recommend() reads `session_embs[:, -1, :]`
+// (lightning.py:393-397), so the final transformer block needs one query row per session: scores of q_last against all L
+// keys, softmax, one weighted sum of the value rows.  One workgroup of 4 waves per (batch, head): phase 1 lane = key
+// (dot products over hd), phase 2 lane = head-dim column (walk over the keys, probabilities from LDS).  Memory-bound:
+// K,V are read once, 2 * L * hd * 4 bytes per (batch, head).  Same masks as rt_mha_fwd for the query L - 1.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_last_query_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [L] probabilities | [4] partial max | [4] partial sum | [4][hd] partial o
+  float* prob = smem;
+  float* red = smem + ((a.L + 3) & ~3);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
+  const long long rowbase = (long long)b * a.L;
+  const float* qv = a.q + (long long)b * a.ldq + h * a.hd;          // q: [B, ldq], ONE row per session
+  const float* kb = a.k + rowbase * a.ldk + h * a.hd;
+  const float* vb = a.v + rowbase * a.ldv + h * a.hd;
+  const long long* idb = a.ids + rowbase;
+  const int qq = a.L - 1;
+  // ---- scores
+  float mx = -INFINITY;
+  for (int j = tid; j < a.L; j += 256) {
+    float sdot = 0.f;
+    for (int c = 0; c < a.hd; c += 4) {
+      const f32x4 kk4 = *reinterpret_cast<const f32x4*>(kb + (long long)j * a.ldk + c);
+      const f32x4 q4 = *reinterpret_cast<const f32x4*>(qv + c);
+      sdot += kk4[0] * q4[0] + kk4[1] * q4[1] + kk4[2] * q4[2] + kk4[3] * q4[3];
+    }
+    const bool msk = masked(a, qq, j, idb[j] == 0);
+    const float sv = msk ? -INFINITY : sdot * a.scale;
+    prob[j] = sv;
+    mx = fmaxf(mx, sv);
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float ps = 0.f;
+  for (int j = tid; j < a.L; j += 256) {
+    const float e = (prob[j] == -INFINITY) ? 0.f : __expf(prob[j] - mx);
+    prob[j] = e;
+    ps += e;
+  }
+  ps = wave_sum(ps);
+  if (lane == 0) red[4 + wave] = ps;
+  __syncthreads();
+  const float l = (red[4] + red[5]) + (red[6] + red[7]);
+  const float inv = l > 0.f ? 1.f / l : 0.f;
+  // ---- o = sum_j p_j v_j : thread -> (column group, key phase); 16-byte columns, the key phases are combined through LDS
+  const int ncol4 = a.hd / 4;                      // float4 columns per row (hd % 8 == 0)
+  const int phases = 256 / ncol4;                  // key phases that fit the workgroup
+  const int c4 = tid % ncol4, ph = tid / ncol4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (ph < phases)
+    for (int j = ph; j < a.L; j += phases) acc += *reinterpret_cast<const f32x4*>(vb + (long long)j * a.ldv + c4 * 4) * prob[j];
+  __syncthreads();                                 // prob is dead after this point: reuse the LDS for the partial sums
+  f32x4* part = reinterpret_cast<f32x4*>(smem);
+  if (ph < phases) part[ph * ncol4 + c4] = acc;
+  __syncthreads();
+  if (tid < ncol4) {
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    for (int p2 = 0; p2 < phases; ++p2) o += part[p2 * ncol4 + tid];
+    *reinterpret_cast<f32x4*>(a.o + (long long)b * a.ldo + h * a.hd + tid * 4) = o * inv;
+  }
+}
+
 #ifdef RT_ATTN_TRACE
 __global__ void occ_probe_kernel(unsigned long long* out, int spin) {
   extern __shared__ float sm[];
@@ -1799,6 +1865,28 @@ int rt_mha_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const f
   a.ids = reinterpret_cast<const long long*>(ids); a.B = B; a.H = H; a.L = L; a.hd = hd;
   a.causal = causal; a.keypad = keypad; a.scale = 1.0f / sqrtf((float)hd); a.p_drop = p_drop; a.seed = seed;
   return dispatch_fwd<MODE_SOFTMAX>(a, stream);
+}
+
+// softmax attention of the LAST query (position L - 1) of every session: q [B, ldq] holds ONE projected query row per session,
+// k / v [B*L, ld*] as in rt_mha_fwd, o [B, ldo].  Eval only (no dropout); masks as rt_mha_fwd applies them to query L - 1.
+int rt_mha_last_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const int64_t* ids,
+                    int32_t B, int32_t H, int32_t L, int32_t hd, int32_t causal, int32_t keypad, float* o, int64_t ldo,
+                    hipStream_t stream) {
+  (void)hipGetLastError();
+  if (bad_common(B, H, L, hd, ldq, ldk, ldv) || (ldo & 3) || misaligned16(o) || misaligned16(q) || misaligned16(k) || misaligned16(v))
+    return RT_ERR_INVALID_ARG;
+  AttnArgs a{};
+  a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.o = o; a.ldo = ldo;
+  a.ids = reinterpret_cast<const long long*>(ids); a.B = B; a.H = H; a.L = L; a.hd = hd;
+  a.causal = causal; a.keypad = keypad; a.scale = 1.0f / sqrtf((float)hd);
+  const size_t prob_f = (size_t)((L + 3) & ~3) + 8;
+  const size_t part_f = (size_t)256 * 4;           // [phases][hd/4] float4 = 256 float4 at most
+  const size_t lds = (prob_f > part_f ? prob_f : part_f) * sizeof(float);
+  if (lds > LDS_LIMIT) return RT_ERR_UNSUPPORTED;
+  { const int rc = set_lds(&attn_last_query_kernel, lds); if (rc != RT_OK) return rc; }
+  attn_last_query_kernel<<<B * H, 256, lds, stream>>>(a);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
 }
 
 // softmax attention backward.  delta: [B,H,L] workspace (rowsum(dO*O), filled by the dQ kernel).  dq/dk/dv fully overwritten.

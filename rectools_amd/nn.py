@@ -294,6 +294,18 @@ class SASRecTransformerLayer(nn.Module):
                 (ff.ff_linear_1.weight, ff.ff_linear_1.bias), (ff.ff_linear_2.weight, ff.ff_linear_2.bias))
         return self.forward_modular(ops.mul_mask(seqs, None, ids), ids, B, L, causal, keypad)
 
+    def forward_last(self, seqs, ids, B, L, causal, keypad):
+        """Inference: the block's output at the last position of every session only, [B, d] (see ops.sasrec_layer_last)."""
+        ff, mha = self.feed_forward, self.multi_head_attn
+        if self.training or torch.is_grad_enabled() or ff.ff_linear_1.bias is None or ff.ff_linear_2.bias is None or ff.activation != "relu":
+            return self(seqs, ids, B, L, causal, keypad).view(B, L, -1)[:, -1, :].contiguous()
+        return ops.sasrec_layer_last(
+            seqs, ids, B, L, mha.n_heads, causal, keypad,
+            (self.q_layer_norm.weight, self.q_layer_norm.bias, self.q_layer_norm.eps),
+            (mha.in_proj_weight, mha.in_proj_bias), (mha.out_proj.weight, mha.out_proj.bias),
+            (self.ff_layer_norm.weight, self.ff_layer_norm.bias, self.ff_layer_norm.eps),
+            (ff.ff_linear_1.weight, ff.ff_linear_1.bias), (ff.ff_linear_2.weight, ff.ff_linear_2.bias))
+
     def forward_modular(self, seqs, ids, B, L, causal, keypad):
         """Same block out of the individual autograd ops (`seqs` already masked); kept as the cross-check of the fused node."""
         p = self.p if self.training else 0.0
@@ -318,6 +330,16 @@ class SASRecTransformerLayers(TransformerLayersBase):
             seqs = blk(seqs, ids, B, L, causal, keypad)   # seqs *= timeline_mask (sasrec.py:300) happens inside
         seqs = ops.mul_mask(seqs, None, ids)
         return self.last_layernorm(seqs)
+
+    def forward_last(self, seqs, ids, B, L, causal, keypad, batch):
+        """Inference: [B, d] encodings of the last position (what recommend() keeps of `encode_sessions`, lightning.py:393-397):
+        every block but the final one runs in full, the final one on one query row per session."""
+        blocks = list(self.transformer_blocks)
+        for blk in blocks[:-1]:
+            seqs = blk(seqs, ids, B, L, causal, keypad)
+        last = blocks[-1].forward_last(seqs, ids, B, L, causal, keypad)
+        last = ops.mul_mask(last, None, ids.view(B, L)[:, L - 1].contiguous())
+        return self.last_layernorm(last)
 
 
 class PreLNTransformerLayer(nn.Module):
@@ -517,3 +539,19 @@ class TransformerTorchBackbone(nn.Module):
         seqs = ops.embed(table, pos, ids, L, scale, self.dropout_rate if self.training else 0.0)
         seqs = self.transformer_layers(seqs, ids, B, L, self.use_causal_attn, self.use_key_padding_mask, batch)
         return seqs.view(B, L, d)
+
+    def encode_last(self, batch: Batch, item_embs: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
+        """-> [B, d] = encode_sessions(batch)[:, -1, :], the only rows recommend() uses (lightning.py:393-397).  Layer stacks
+        that offer `forward_last` (SASRec) run their final block on one query row per session."""
+        fast = getattr(self.transformer_layers, "forward_last", None)
+        if fast is None or self.training or torch.is_grad_enabled():
+            return self.encode_sessions(batch, item_embs)[:, -1, :].contiguous()
+        x = batch["x"]
+        B, L = x.shape
+        table = self.item_model.table if item_embs is None else item_embs
+        d = table.shape[1]
+        pos = self.pos_encoding_layer.pos_emb.weight if self.pos_encoding_layer.pos_emb is not None else None
+        scale = float(d) ** 0.5 if self.pos_encoding_layer.use_scale_factor else 1.0
+        ids = x.reshape(-1)
+        seqs = ops.embed(table, pos, ids, L, scale, 0.0)
+        return fast(seqs, ids, B, L, self.use_causal_attn, self.use_key_padding_mask, batch)

@@ -871,6 +871,44 @@ def sasrec_layer(x: torch.Tensor, ids: torch.Tensor, B: int, L: int, H: int, cau
                               (B, L, H, bool(causal), bool(keypad), float(p), ln1[2], ln2[2]))
 
 
+def sasrec_layer_last(x: torch.Tensor, ids: torch.Tensor, B: int, L: int, H: int, causal: bool, keypad: bool,
+                      ln1: tp.Tuple[torch.Tensor, torch.Tensor, float], in_proj: tp.Tuple[torch.Tensor, torch.Tensor],
+                      out_proj: tp.Tuple[torch.Tensor, torch.Tensor], ln2: tp.Tuple[torch.Tensor, torch.Tensor, float],
+                      ff1: tp.Tuple[torch.Tensor, torch.Tensor], ff2: tp.Tuple[torch.Tensor, torch.Tensor]) -> torch.Tensor:
+    """Inference only: the SASRec block's output at the LAST position of every session, [B, d].
+
+    recommend() keeps `session_embs[:, -1, :]` (lightning.py:393-397); in the final block only the key / value projection
+    needs every position — the query projection, the attention (`rt_mha_last_fwd`), out_proj and the feed-forward run on
+    one row per session.  Row for row the same arithmetic as `sasrec_layer` (the GEMM's k order does not depend on M)."""
+    x = _chk(x, "sasrec_layer_last").contiguous()
+    M, d = x.shape
+    dev = x.device
+    new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
+    ids_flat = ids.reshape(-1)
+    in_w, in_b = in_proj
+    x0 = new(M, d)
+    _c("rt_mul_mask", x, None, ids_flat, d, x.numel(), x0)
+    KV = new(M, 2 * d)
+    _gemm(x0, d, 1, in_w[d:], d, 1, KV, 2 * d, in_b[d:], None, 0, M, 2 * d, d)
+    x0_last = x0.view(B, L, d)[:, L - 1, :].contiguous()
+    q, mean, rstd = new(B, d), new(B), new(B)
+    _c("rt_layernorm_fwd", x0_last, ln1[0], ln1[1], float(ln1[2]), B, d, q, mean, rstd)
+    Q = new(B, d)
+    _gemm(q, d, 1, in_w, d, 1, Q, d, in_b, None, 0, B, d, d)
+    A = new(B, d)
+    _c("rt_mha_last_fwd", Q, d, KV, 2 * d, KV[:, d:], 2 * d, ids_flat, B, H, L, d // H, int(causal), int(keypad), A, d)
+    y = new(B, d)
+    _gemm(A, d, 1, out_proj[0], d, 1, y, d, out_proj[1], q, d, B, d, d)
+    f = new(B, d)
+    _c("rt_layernorm_fwd", y, ln2[0], ln2[1], float(ln2[2]), B, d, f, mean, rstd)
+    dff = ff1[0].shape[0]
+    h = new(B, dff)
+    _gemm(f, d, 1, ff1[0], d, 1, h, dff, ff1[1], None, 0, B, dff, d, 1)
+    out = new(B, d)
+    _gemm(h, dff, 1, ff2[0], dff, 1, out, d, ff2[1], f, d, B, d, dff)
+    return out
+
+
 def hstu_time_thresholds(num_buckets: int = 128) -> torch.Tensor:
     """thr[b] = smallest |dt| >= 0 whose reference bucket clamp(trunc(log(max(1,|dt|)) / 0.301), 0, nb) is >= b.
 

@@ -219,3 +219,34 @@ def test_recommend_device_glue_equals_reference_shaped_path():
         assert 5 not in set(fast["user_id"]) and len(w_fast) >= 1 and len(w_slow) >= 1
         assert fast[["user_id", "item_id", "rank"]].equals(slow[["user_id", "item_id", "rank"]])
         np.testing.assert_allclose(fast["score"].values, slow["score"].values, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("causal,keypad,B", [(True, False, 5), (True, True, 256), (False, True, 130)])
+def test_encode_last_equals_last_row_of_encode_sessions(causal, keypad, B):
+    """Inference shortcut (final SASRec block on one query row per session, rt_mha_last_fwd) against the full forward pass."""
+    import torch
+
+    from rectools_amd import nn as hnn
+
+    torch.manual_seed(0)
+    V, L, d, H = 300, 70, 64, 2
+    item_model = hnn.SumOfEmbeddingsConstructor(V, [hnn.IdEmbeddingsItemNet(d, V, 0.0)])
+    pos = hnn.LearnableInversePositionalEncoding(True, L, d)
+    layers = hnn.SASRecTransformerLayers(2, d, H, 0.2)
+    model = hnn.TransformerTorchBackbone(H, 0.2, item_model, pos, layers, hnn.DistanceSimilarityModule("dot"), use_causal_attn=causal,
+                                         use_key_padding_mask=keypad).cuda().eval()
+    with torch.no_grad():
+        for prm in model.parameters():
+            if prm.ndim == 1:
+                prm.add_(0.1 * torch.randn_like(prm))
+    g = torch.Generator().manual_seed(1)
+    x = torch.randint(1, V, (B, L), generator=g)
+    for b in range(B):                       # left padding of random length (the last slot is always a real item)
+        x[b, : int(torch.randint(0, L - 1, (1,), generator=g))] = 0
+    batch = {"x": x.cuda()}
+    with torch.no_grad():
+        full = model.encode_sessions(batch)[:, -1, :]
+        last = model.encode_last(batch)
+    assert last.shape == full.shape
+    torch.testing.assert_close(last, full, rtol=2e-5, atol=2e-6)
