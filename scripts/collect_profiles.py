@@ -18,7 +18,7 @@ KEEP = [
 ] + [(f"rocprof_kernel_trace_{n}.md", f"rocprof_kernel_trace_{n}.md") for n in
      ("train", "train_single_stream", "topk5m", "recommend", "bert4rec", "hstu", "esasrec")] + [
     (f"pmc_{w}_{c}.txt", f"pmc_{w}_{c}.txt") for w in ("topk5m", "train") for c in ("FETCH_SIZE", "WRITE_SIZE")] + [
-    (f"sq_{n}.md", f"sq_counters_{n}.md") for n in ("attention", "topk5m", "recommend")]
+    (f"sq_{n}.md", f"sq_counters_{n}.md") for n in ("attention", "attention_l512", "topk5m", "recommend")]
 
 
 def parse_pmc(path):

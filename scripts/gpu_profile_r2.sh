@@ -84,6 +84,7 @@ for k,c in agg.items():
 PY
 }
 sq attention attn_ python $R/scripts/attn_bench.py
+sq attention_l512 attn_ python $R/scripts/attn_bench.py --L 512 --n 5
 sq topk5m topk_stream python $R/bench.py --workload topk5m --steps 3 --no-cpu-baseline
 sq recommend topk_stream python $R/bench.py --workload recommend --steps 3 --no-cpu-baseline
 
