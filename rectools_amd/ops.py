@@ -175,8 +175,16 @@ def _gemm(A, lda, a_kc, B, ldb, b_kc, C, ldc, bias, R, ldr, M, N, K, relu=0, spl
        tag=(M, N, K))
 
 
-def _wgrad_splits(k_rows: int) -> int:
-    return max(1, min(64, k_rows // 384))
+def _wgrad_splits(k_rows: int, out_rows: int = 0, out_cols: int = 0) -> int:
+    """Split-K factor of a weight-gradient product dW [out_rows, out_cols] = sum over k_rows.  Small outputs (256 x 256 = 4
+    tiles at C2) need every slice they can get to fill 256 CUs; large ones (eSASRec's 2048 x 512 = 64 tiles) were cut into 64
+    slices of 12 k-steps each, 4096 workgroups whose slab writes and 64-way combine cost more than the parallelism bought:
+    aim at ~6 workgroups per CU."""
+    sp = max(1, min(64, k_rows // 384))
+    if out_rows > 0 and out_cols > 0:
+        tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
+        sp = max(1, min(sp, -(-1536 // tiles)))
+    return sp
 
 
 def _deep_k_splits(M: int, N: int, K: int) -> int:
@@ -224,7 +232,7 @@ class _Linear(torch.autograd.Function):
             sd = _OnSide(dy.device, defer=_steals_grad(weight, bias if want_db else None))
             with sd:
                 sd.uses(*(t for t in (dy, x, dw, db) if t is not None))
-                _gemm(dy, N, 0, x, x.stride(0), 0, dw, K, None, None, 0, N, K, M, 0, _wgrad_splits(M), db)  # dW = dy^T @ x
+                _gemm(dy, N, 0, x, x.stride(0), 0, dw, K, None, None, 0, N, K, M, 0, _wgrad_splits(M, N, K), db)  # dW = dy^T @ x
         elif want_db:
             db = torch.zeros((N,), dtype=torch.float32, device=dy.device)
             _c("rt_colsum", dy, N, M, N, db)
@@ -264,7 +272,7 @@ class _MatmulNN(torch.autograd.Function):
         sd = _OnSide(dy.device, defer=_steals_grad(p))
         with sd:
             sd.uses(x, dy, dp)
-            _gemm(x, x.stride(0), 0, dy, N, 0, dp, N, None, None, 0, K, N, M, 0, _wgrad_splits(M))  # dP = x^T @ dy
+            _gemm(x, x.stride(0), 0, dy, N, 0, dp, N, None, None, 0, K, N, M, 0, _wgrad_splits(M, K, N))  # dP = x^T @ dy
         dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
         _gemm(dy, N, 1, p, N, 1, dx, K, None, None, 0, M, K, N)  # dx = dy @ P^T : B(k', n) = P[k'*N + n] (kc)
         sd.join_now()
@@ -1207,7 +1215,7 @@ class _SoftmaxLoss(torch.autograd.Function):
         ds_act = torch.empty((Rp, d), dtype=torch.float32, device=logits.device)
         _gemm(logits, Vp, 1, tab, tab.stride(0), 0, ds_act, d, None, None, 0, Rp, d, Vp, 0, _deep_k_splits(Rp, d, Vp))  # dS = G @ E
         d_tab = torch.empty((Vp, d), dtype=torch.float32, device=logits.device)
-        _gemm(logits, Vp, 0, s_act, d, 0, d_tab, d, None, None, 0, Vp, d, Rp, 0, _wgrad_splits(Rp))  # dE = G^T @ S
+        _gemm(logits, Vp, 0, s_act, d, 0, d_tab, d, None, None, 0, Vp, d, Rp, 0, _wgrad_splits(Rp, Vp, d))  # dE = G^T @ S
         d_table = d_tab[:V]
         d_table[0].zero_()  # padding_idx row never receives gradient (item_net.py:260-264)
         _offer_table_grad(tab[:V], d_table)
