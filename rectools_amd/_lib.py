@@ -135,9 +135,20 @@ def ptr(t) -> tp.Optional[int]:
     return t.data_ptr()
 
 
+_RAW_STREAM = None
+
+
 def current_stream() -> int:
+    """Raw handle of torch's current HIP stream on the current device.  `torch.cuda.current_stream().cuda_stream` builds a Stream
+    object per call (8 us of the 17 us a ctypes launch costs on the host; ~100 launches per training step); the private raw
+    getter is two orders of magnitude cheaper and is what torch's own extensions use."""
+    global _RAW_STREAM
     import torch
 
+    if _RAW_STREAM is None:
+        _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", False)   # pylint: disable=protected-access
+    if _RAW_STREAM:
+        return _RAW_STREAM(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -1068,6 +1068,122 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_res_kernel(AttnArgs a) {
   RT_TMARK(tron, trb + 5);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Cooperative resident forward (causal, n_t <= 8): the two waves that share a SIMD (w and w + 4) split the work of their SIMD
+// evenly.  The plain resident schedule gives wave w the heavy query tile n_t-1-w (n_t-w tile pairs) and wave w+4 the light
+// tile w (w+1 pairs): 7 + 1, 6 + 2, 5 + 3 at L = 200, so the SIMD runs ONE wave for most of the kernel.  The ring timeline
+// (profiles/r2_attention_timeline.txt) shows two busy waves on a SIMD finish a tile pair every ~6,250 cycles against ~9,000
+// for a wave alone.  Here wave w+4 ("B") first takes the key tiles [0, nb) of the heavy tile, publishes its partial
+// (running max, sum and O^T accumulators, register for register: both waves use the same lane layout) in LDS, then does its
+// own light tile; wave w ("A") takes key tiles [nb, last] and merges B's partial before the store.  nb balances the two.
+// ---------------------------------------------------------------------------------------------------
+template <int MODE, int HD>
+__global__ __launch_bounds__(512) void attn_fwd_coop_kernel(AttnArgs a) {
+  constexpr int HDV = HD / 8, NT = HD / 32, NTH = 512, lds_ld = HD + 4;
+  constexpr int PR = NT * 16 + 2;                 // partial: NT accumulators + m + l, per lane
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n_t = (a.L + TK - 1) / TK, Lp = n_t * TK;
+  float* Ks = smem;                               // [Lp][lds_ld]
+  float* Vs = Ks + Lp * lds_ld;                   // [Lp][lds_ld]
+  float* kflag = Vs + Lp * lds_ld;                // [Lp]
+  float* scr = kflag + Lp;                        // [4][PR][64] partials of the B waves
+  lds_flag_ptr pflag = (lds_flag_ptr)(scr + 4 * PR * 64);   // [4]
+  HstuLds hl{};
+  if (MODE == MODE_HSTU) hstu_carve(scr + 4 * PR * 64 + 4, a.L, false, hl);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 31, half = lane >> 5;
+  const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
+  const long long rowbase = (long long)b * a.L;
+  const float* qb = a.q + rowbase * a.ldq + h * a.hd;
+  const long long* idb = a.ids + rowbase;
+
+  const int p = wave & 3;
+  const bool isB = wave >= 4;
+  const int th = n_t - 1 - p, tl = p;
+  const bool has_heavy = th >= 0, has_light = tl < th;
+  const int cost_h = th + 1, cost_l = has_light ? tl + 1 : 0;
+  const int nb = !has_heavy ? 0 : (has_light ? max(0, (cost_h - cost_l) / 2) : cost_h / 2);
+
+  // row fragments of the first tile this wave works on, requested before the staging
+  f32x4 qf[HDV];
+  const int first_tile = !has_heavy ? -1 : (isB ? (nb > 0 ? th : (has_light ? tl : -1)) : th);
+  load_row_frags<HDV>(qb, a.ldq, (first_tile < 0 ? 0 : first_tile) * TK + col, first_tile < 0 ? 0 : a.L, a.hd, half, qf);
+  stage_rows2<HD>(a.k + rowbase * a.ldk + h * a.hd, a.ldk, Ks, a.v + rowbase * a.ldv + h * a.hd, a.ldv, Vs, a.L, Lp, a.hd, tid, NTH);
+  for (int i = tid; i < Lp; i += NTH) kflag[i] = (i < a.L && idb[i] != 0) ? 0.f : 1.f;
+  if (tid < 4) pflag[tid] = 0;
+  if (MODE == MODE_HSTU) hstu_fill(a, hl, b, tid, NTH);
+  __syncthreads();
+  if (first_tile < 0) return;
+  SwzLane<HD> sl; sl.init(col, half);
+
+  f32x16 oacc[NT];
+  float m_run, l_run;
+  auto run_tile = [&](int qt, int kt0, int kt1) {   // key tiles [kt0, kt1] of query tile qt into (oacc, m_run, l_run)
+    const int qq = qt * TK + col;
+    const bool q_is_pad = (qq < a.L) ? (idb[qq] == 0) : true;
+    long long t_q1 = 0;
+    if (MODE == MODE_HSTU && a.ts && qq < a.L) t_q1 = hl.ts[qq + 1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+    m_run = -INFINITY; l_run = 0.f;
+    const bool q_inside = (qt + 1) * TK <= a.L;
+#pragma unroll 1
+    for (int kt = kt0; kt <= kt1; ++kt) {
+      const bool interior = MODE == MODE_SOFTMAX && !a.no_interior && !a.keypad && q_inside && (kt + 1) * TK <= a.L && kt < qt;
+      if (interior)
+        fwd_pair<MODE, HD, false, false>(a, Ks + kt * TK * lds_ld, Vs + kt * TK * lds_ld, kflag + kt * TK, kt, qq, q_is_pad, t_q1,
+                                         bh, col, half, qf, hl, oacc, m_run, l_run, sl);
+      else
+        fwd_pair<MODE, HD, true, false>(a, Ks + kt * TK * lds_ld, Vs + kt * TK * lds_ld, kflag + kt * TK, kt, qq, q_is_pad, t_q1,
+                                        bh, col, half, qf, hl, oacc, m_run, l_run, sl);
+    }
+  };
+  float* my_scr = scr + p * PR * 64 + lane;
+
+  if (!isB) {
+    run_tile(th, nb, th);
+    if (nb > 0) {
+      while (pflag[p] == 0) __builtin_amdgcn_s_sleep(2);
+      asm volatile("" ::: "memory");
+      const float mB = my_scr[(NT * 16) * 64], lB = my_scr[(NT * 16 + 1) * 64];
+      float aA = 1.f, aB = 1.f;
+      if (MODE == MODE_SOFTMAX) {
+        const float m = fmaxf(m_run, mB);
+        aA = (m == -INFINITY) ? 1.f : __expf(m_run - m);
+        aB = (m == -INFINITY) ? 1.f : __expf(mB - m);
+        l_run = l_run * aA + lB * aB;
+        m_run = m;
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[t][r] = oacc[t][r] * aA + my_scr[(t * 16 + r) * 64] * aB;
+    }
+    fwd_store<MODE, HD>(a, bh, th * TK + col, half, rowbase, h, oacc, m_run, l_run);
+  } else {
+    if (nb > 0) {
+      run_tile(th, 0, nb - 1);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) my_scr[(t * 16 + r) * 64] = oacc[t][r];
+      my_scr[(NT * 16) * 64] = m_run;
+      my_scr[(NT * 16 + 1) * 64] = l_run;
+      __threadfence_block();
+      if (lane == 0) pflag[p] = 1;
+      if (has_light) load_row_frags<HDV>(qb, a.ldq, tl * TK + col, a.L, a.hd, half, qf);
+    }
+    if (has_light) {
+      run_tile(tl, 0, tl);
+      fwd_store<MODE, HD>(a, bh, tl * TK + col, half, rowbase, h, oacc, m_run, l_run);
+    }
+  }
+}
+
 template <int MODE, int HD, int NW, bool DMA>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_res_kernel(AttnArgs a) {
   constexpr int HDV = HD / 8, NT = HD / 32;
@@ -1596,6 +1712,12 @@ inline bool attn_allow_dma() {
   return v == 1;
 }
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// RT_ATTN_COOP=0 restores the plain heavy + light deal of the resident forward kernel (A/B measurements)
+inline bool attn_allow_coop() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("RT_ATTN_COOP"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
 // RT_ATTN_IMPL = auto (default) | ring | res | stream — A/B measurements and the tests that pin one family.
 //   auto:   resident where K,V fit the LDS (every default config: measured faster there, 76 vs 96 us forward at the C2 shape),
 //           else the ring kernels where they apply (hd == 32 / 64, aligned rows: 383 vs 445 us forward, 1.22 vs 1.48 ms backward
@@ -1642,6 +1764,16 @@ int launch_fwd(const AttnArgs& a, hipStream_t stream) {
       { const int rc = set_lds(&attn_fwd_ring_kernel<MODE, HD, RING_NS>, gl); if (rc != RT_OK) return rc; }
       const int n_x = ((a.L + TK - 1) / TK + 3) / 4;
       attn_fwd_ring_kernel<MODE, HD, RING_NS><<<n_x * a.B * a.H, AT, gl, stream>>>(a);
+      RT_CHECK_LAUNCH();
+      return RT_OK;
+    }
+  }
+  if constexpr (HD <= 64) {   // cooperative resident forward: causal, at most 8 tiles (one round of the 8 waves), LDS permitting
+    const int n_t = (a.L + TK - 1) / TK;
+    const size_t cl = rl + (size_t)(4 * (HD / 2 + 2) * 64 + 8) * 4;
+    if (res_fits && impl != IMPL_STREAM && a.causal && n_t >= 2 && n_t <= 8 && cl <= LDS_LIMIT && attn_allow_coop()) {
+      { const int rc = set_lds(&attn_fwd_coop_kernel<MODE, HD>, cl); if (rc != RT_OK) return rc; }
+      attn_fwd_coop_kernel<MODE, HD><<<a.B * a.H, 512, cl, stream>>>(a);
       RT_CHECK_LAUNCH();
       return RT_OK;
     }

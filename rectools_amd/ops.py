@@ -43,16 +43,21 @@ def stop_timing() -> tp.Dict[str, tp.List[tp.Tuple[float, tp.Any]]]:
     return {k: [(a.elapsed_time(b), tag) for a, b, tag in v] for k, v in rec.items()}
 
 
+_FN: tp.Dict[str, tp.Any] = {}   # bound C entry points (one getattr per name instead of one per launch)
+
+
 def _c(name: str, *args: tp.Any, tag: tp.Any = None) -> None:
     """Call `rt_<name>(*args, stream)`; tensors are passed as raw device pointers."""
-    lib = _lib.load()
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(_lib.load(), name)
     conv = [a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args]
     if _TIMING is None:
-        status = getattr(lib, name)(*conv, _lib.current_stream())
+        status = fn(*conv, _lib.current_stream())
     else:  # events on the stream the kernel is launched on (torch's current stream)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        status = getattr(lib, name)(*conv, _lib.current_stream())
+        status = fn(*conv, _lib.current_stream())
         e1.record()
         _TIMING.setdefault(name, []).append((e0, e1, tag))
     _lib.check(status, name)
