@@ -190,6 +190,10 @@ int rt_embed_bwd(const int64_t* ids, const float* gout, float scale, int32_t M, 
  * (per-block partial sums in `workspace`, then a fixed-order reduction: deterministic, no float atomics). */
 int rt_layernorm_fwd(const float* x, const float* w, const float* b, float eps, int32_t M, int32_t d, float* y,
                      float* mean, float* rstd, rt_stream_t stream);
+/* y = LN(x * (ids != 0)): the timeline mask in front of a LayerNorm applied on the fly (sasrec.py:300,313); x0 (nullable)
+ * receives the masked rows (the LayerNorm input the backward reads). */
+int rt_layernorm_fwd_masked(const float* x, const int64_t* ids, const float* w, const float* b, float eps, int32_t M, int32_t d,
+                            float* x0, float* y, float* mean, float* rstd, rt_stream_t stream);
 size_t rt_layernorm_bwd_workspace_bytes(int32_t M, int32_t d);
 int rt_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rstd, int32_t M,
                      int32_t d, float* dx, float* dw, float* db, void* workspace, size_t workspace_bytes,

@@ -234,29 +234,34 @@ int launch_embed_bwd(const EmbBwdArgs& a, hipStream_t stream) {
 // ---------------------------------------------------------------------------------------------------
 // K3 LayerNorm (one wave per row).  Optional fused multiplier: y = LN(x) * mul (HSTU: u * LN(attn), hstu.py:291)
 // ---------------------------------------------------------------------------------------------------
+// ids (nullable): the row mask `x * (ids != 0)` applied to the INPUT on the fly (`seqs *= timeline_mask` in front of a LayerNorm,
+// sasrec.py:300 / :313); x0 (nullable) receives the masked rows the backward pass needs.
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ b, float eps, int M, int d,
                                                             float* __restrict__ y, float* __restrict__ mean,
-                                                            float* __restrict__ rstd) {
+                                                            float* __restrict__ rstd, const long long* __restrict__ ids = nullptr,
+                                                            float* __restrict__ x0 = nullptr) {
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= M) return;
   const float* xr = x + (long long)m * d;
+  const float keep = (ids != nullptr && ids[m] == 0) ? 0.f : 1.f;
   float s = 0.f;
   for (int c = lane * 4; c < d; c += 256) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+    f32x4 v = *reinterpret_cast<const f32x4*>(xr + c) * keep;
+    if (x0 != nullptr) *reinterpret_cast<f32x4*>(x0 + (long long)m * d + c) = v;
     s += v[0] + v[1] + v[2] + v[3];
   }
   const float mu = wave_sum(s) / d;
   float q = 0.f;
   for (int c = lane * 4; c < d; c += 256) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+    f32x4 v = *reinterpret_cast<const f32x4*>(xr + c) * keep;
     v -= mu;
     q += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
   }
   const float rs = 1.0f / sqrtf(wave_sum(q) / d + eps);
   for (int c = lane * 4; c < d; c += 256) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+    f32x4 v = *reinterpret_cast<const f32x4*>(xr + c) * keep;
     f32x4 ww = *reinterpret_cast<const f32x4*>(w + c);
     f32x4 bb = *reinterpret_cast<const f32x4*>(b + c);
     v = (v - mu) * rs * ww + bb;
@@ -654,6 +659,17 @@ int rt_layernorm_fwd(const float* x, const float* w, const float* b, float eps, 
   if (M <= 0) return RT_OK;
   if ((d & 3) != 0) return RT_ERR_INVALID_ARG;
   layernorm_fwd_kernel<<<(M + 3) / 4, 256, 0, stream>>>(x, w, b, eps, M, d, y, mean, rstd);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+// LayerNorm of the row-masked input: y = LN(x * (ids != 0)); x0 (nullable) = the masked input (what the backward reads).
+int rt_layernorm_fwd_masked(const float* x, const int64_t* ids, const float* w, const float* b, float eps, int32_t M, int32_t d,
+                            float* x0, float* y, float* mean, float* rstd, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (M <= 0) return RT_OK;
+  if ((d & 3) != 0 || ids == nullptr) return RT_ERR_INVALID_ARG;
+  layernorm_fwd_kernel<<<(M + 3) / 4, 256, 0, stream>>>(x, w, b, eps, M, d, y, mean, rstd, reinterpret_cast<const long long*>(ids), x0);
   RT_CHECK_LAUNCH();
   return RT_OK;
 }

@@ -328,8 +328,8 @@ class SASRecTransformerLayers(TransformerLayersBase):
     def forward(self, seqs, ids, B, L, causal, keypad, batch):
         for blk in self.transformer_blocks:
             seqs = blk(seqs, ids, B, L, causal, keypad)   # seqs *= timeline_mask (sasrec.py:300) happens inside
-        seqs = ops.mul_mask(seqs, None, ids)
-        return self.last_layernorm(seqs)
+        ln = self.last_layernorm
+        return ops.layer_norm_masked(seqs, ids, ln.weight, ln.bias, ln.eps)   # seqs * mask, then the last LayerNorm
 
     def forward_last(self, seqs, ids, B, L, causal, keypad, batch):
         """Inference: [B, d] encodings of the last position (what recommend() keeps of `encode_sessions`, lightning.py:393-397):

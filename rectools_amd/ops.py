@@ -439,6 +439,37 @@ class _LayerNorm(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class _LayerNormMasked(torch.autograd.Function):
+    """LN(x * (ids != 0)) — the timeline mask in front of the stack's last LayerNorm (sasrec.py:313-314) applied inside the
+    LayerNorm kernels: forward reads x once, backward writes the masked dx directly."""
+
+    @staticmethod
+    def forward(ctx, x, ids, w, b, eps):
+        x = x.contiguous()
+        M, d = x.shape
+        x0, y = torch.empty_like(x), torch.empty_like(x)
+        mean = torch.empty((M,), dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        _c("rt_layernorm_fwd_masked", x, ids, w, b, float(eps), M, d, x0, y, mean, rstd)
+        ctx.save_for_backward(x0, ids, w, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x0, ids, w, mean, rstd = ctx.saved_tensors
+        M, d = x0.shape
+        dy = dy.contiguous()
+        dx, dw, db = torch.empty_like(x0), torch.empty_like(w), torch.empty_like(w)
+        ws_bytes = _lib.load().rt_layernorm_bwd_workspace_bytes(M, d)
+        ws = torch.empty((max(ws_bytes, 4),), dtype=torch.uint8, device=x0.device)
+        _c("rt_layernorm_bwd_fused", dy, x0, w, mean, rstd, None, ids, 0, 1, M, d, dx, dw, db, ws, ws_bytes)
+        return dx, None, dw, db, None
+
+
+def layer_norm_masked(x: torch.Tensor, ids: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float) -> torch.Tensor:
+    return _LayerNormMasked.apply(_chk(x, "layer_norm_masked"), ids.reshape(-1), w, b, eps)
+
+
 class _LayerNormSkip(torch.autograd.Function):
     """(LN(x), x): the second output is the skip branch of a pre-LN block.  Its gradient is added inside the LayerNorm backward
     kernel (`rt_layernorm_bwd_fused`, res) instead of by a full-size add kernel that autograd issues for a tensor with two
@@ -758,10 +789,8 @@ class _SASRecLayer(torch.autograd.Function):
         dff = w1.shape[0]
         dev = x.device
         new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
-        x0 = new(M, d)
-        _c("rt_mul_mask", x, None, ids, d, x.numel(), x0)
-        q, mean1, rstd1 = new(M, d), new(M), new(M)
-        _c("rt_layernorm_fwd", x0, ln1_w, ln1_b, float(eps1), M, d, q, mean1, rstd1)
+        x0, q, mean1, rstd1 = new(M, d), new(M, d), new(M), new(M)
+        _c("rt_layernorm_fwd_masked", x, ids, ln1_w, ln1_b, float(eps1), M, d, x0, q, mean1, rstd1)   # x0 = x * mask, q = LN1(x0)
         Q, KV = new(M, d), new(M, 2 * d)
         _gemm(q, d, 1, in_w, d, 1, Q, d, in_b, None, 0, M, d, d)
         _gemm(x0, d, 1, in_w[d:], d, 1, KV, 2 * d, in_b[d:], None, 0, M, 2 * d, d)
@@ -862,11 +891,12 @@ class _SASRecLayer(torch.autograd.Function):
             _gemm(gKV, 2 * d, 0, x0, d, 0, d_in_w[d:], d, None, None, 0, 2 * d, d, M, 0, sp, d_in_b[d:])
         g_q = new(M, d)     # q feeds the query projection and the residual: g_q = gQ Wq + g_y
         _gemm(gQ, d, 1, in_w, d, 0, g_q, d, None, g_y, d, M, d, d)
-        g_x0a, d_ln1w, d_ln1b = ln_bwd(g_q, x0, ln1_w, mean1, rstd1)
-        g_x0 = new(M, d)    # x0 feeds LN1 and the key/value projection: g_x0 = gKV Wkv + LN1'(g_q)
-        _gemm(gKV, 2 * d, 1, in_w[d:], d, 0, g_x0, d, None, g_x0a, d, M, d, 2 * d)
-        g_x = new(M, d)
-        _c("rt_mul_mask", g_x0, None, ids, d, g_x0.numel(), g_x)
+        g_kv = new(M, d)    # x0 feeds LN1 and the key/value projection: g_x = mask * (gKV Wkv + LN1'(g_q)), the sum and the
+        _gemm(gKV, 2 * d, 1, in_w[d:], d, 0, g_kv, d, None, None, 0, M, d, 2 * d)      # mask ride in the LayerNorm backward kernel
+        g_x, d_ln1w, d_ln1b = new(M, d), new(d), new(d)
+        ws_bytes = _lib.load().rt_layernorm_bwd_workspace_bytes(M, d)
+        ws = torch.empty((max(ws_bytes, 4),), dtype=torch.uint8, device=dev)
+        _c("rt_layernorm_bwd_fused", g_q, x0, ln1_w, mean1, rstd1, g_kv, ids, 0, 1, M, d, g_x, d_ln1w, d_ln1b, ws, ws_bytes)
         if side_ctxs:
             side_ctxs[-1].join_now()   # no-op when deferred; one event covers every product queued on the side stream
         return (g_x, None, d_ln1w, d_ln1b, d_in_w, d_in_b, d_wo, d_bo, d_ln2w, d_ln2b, d_w1, d_b1, d_w2, d_b2, None)
