@@ -295,13 +295,14 @@ def run_train(args, rank, world, kind="train"):
     breakdown = {k: {"ms_per_step": round(t, 4), "calls_per_step": c, "single_stream_ms": round(per_kernel1.get(k, 0.0), 4)}
                  for k, (t, c) in sorted(per_kernel.items(), key=lambda kv: -kv[1][0])}
     roof = None
-    if dom == "rt_gemm":
-        calls = rec["rt_gemm"]
+    if dom in ("rt_gemm", "rt_gemm_grouped"):
+        # every launch of the GEMM kernel family: single products and grouped launches (tag = (sum of M N K, 1, 1))
+        calls = rec.get("rt_gemm", []) + rec.get("rt_gemm_grouped", [])
         fl = sum(2.0 * m * n * k for _, (m, n, k) in calls)
         ms = sum(t for t, _ in calls)
         tf = fl / (ms * 1e-3) / 1e12
-        ms1 = sum(t for t, _ in rec1["rt_gemm"])
-        roof = {"kernel": "gemm_dma_kernel (rt_gemm: all forward/dgrad/wgrad products of the step)", "bound": "mfma",
+        ms1 = sum(t for t, _ in rec1.get("rt_gemm", []) + rec1.get("rt_gemm_grouped", []))
+        roof = {"kernel": "gemm_dma_kernel (rt_gemm / rt_gemm_grouped: all forward/dgrad/wgrad products of the step)", "bound": "mfma",
                 "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),
                 "traffic": load_traffic("train_gemm"), "avg_launch_ms": round(ms / len(calls), 4),
                 "algorithmic_flops_per_launch": fl / len(calls), "launches_per_step": len(calls) / 3.0,

@@ -120,6 +120,14 @@ int rt_gemm(const float* A, int64_t lda, int32_t a_kc, const float* B, int64_t l
             float* C, int64_t ldc, const float* bias, const float* R, int64_t ldr, float* a_rowsum,
             int32_t M, int32_t N, int32_t K, int32_t relu, int32_t split_k, void* workspace, size_t workspace_bytes,
             rt_stream_t stream);
+/* Up to 4 independent products of the same operand layouts in ONE launch (tile ranges back to back: the tail of one product is
+ * filled by the head of the next — the q and k/v projections of a block, sasrec.py:221-224, or two data-gradient products).
+ * Problems off the exact-tile path are executed as consecutive rt_gemm calls; results are identical either way. */
+typedef struct rt_gemm_problem {
+  const float* A; int64_t lda; const float* B; int64_t ldb; float* C; int64_t ldc;
+  const float* bias; const float* R; int64_t ldr; int32_t M, N, K, relu;
+} rt_gemm_problem;
+int rt_gemm_grouped(const rt_gemm_problem* problems, int32_t n, int32_t a_kc, int32_t b_kc, rt_stream_t stream);
 /* out[n] += sum_m X[m,n]  (bias gradients; caller zero-fills out) */
 int rt_colsum(const float* X, int64_t ld, int32_t M, int32_t N, float* out, rt_stream_t stream);
 

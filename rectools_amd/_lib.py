@@ -34,6 +34,7 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_topk_rescore": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "rt_gemm_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
     "rt_gemm": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_sz, c_vp]),
+    "rt_gemm_grouped": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp]),
     "rt_colsum": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "rt_collate": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_f32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rt_sample_negatives": (c_i32, [c_i64, c_i64, c_i64, c_u64, c_u64, c_vp, c_vp]),
@@ -78,6 +79,13 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
 }
 
 _lib: tp.Optional[ctypes.CDLL] = None
+
+
+class GemmProblem(ctypes.Structure):
+    """`rt_gemm_problem` of include/rectools_hip.h (one product of an rt_gemm_grouped launch)."""
+
+    _fields_ = [("A", c_vp), ("lda", c_i64), ("B", c_vp), ("ldb", c_i64), ("C", c_vp), ("ldc", c_i64), ("bias", c_vp), ("R", c_vp),
+                ("ldr", c_i64), ("M", c_i32), ("N", c_i32), ("K", c_i32), ("relu", c_i32)]
 
 
 class HipLibraryError(RuntimeError):

@@ -317,8 +317,7 @@ __device__ __forceinline__ f32x4 read_frag_swz(const float* S, int row, int s, i
 }
 
 template <bool AKC, bool BKC, int NS>
-__global__ __launch_bounds__(GT) void gemm_dma_kernel(GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // [NS][A tile | B tile]
+__device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int t, float* smem) {
   constexpr int STAGE_F = 2 * TILE_F;
   constexpr int NL = 8;   // DMA instructions per wave per stage
 
@@ -328,7 +327,6 @@ __global__ __launch_bounds__(GT) void gemm_dma_kernel(GemmArgs g) {
 
   const int n_tn = g.N / BN;
   const int n_tiles = (g.M / BM) * n_tn;
-  int t = blockIdx.x;
   {
     const int nx = 8, q = n_tiles / nx, r = n_tiles % nx, xcd = t % nx, idx = t / nx;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -439,6 +437,26 @@ __global__ __launch_bounds__(GT) void gemm_dma_kernel(GemmArgs g) {
         dst[(long long)(mb + (r & 3) + 8 * (r >> 2)) * ldd + n] = v;
       }
     }
+}
+
+template <bool AKC, bool BKC, int NS>
+__global__ __launch_bounds__(GT) void gemm_dma_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [NS][A tile | B tile]
+  gemm_dma_body<AKC, BKC, NS>(g, blockIdx.x, smem);
+}
+
+// Grouped launch: up to 4 independent products with the same operand layouts in ONE grid (tile ranges back to back).  A
+// training product of the C2 step is 400 tiles on 512 half-CU slots: its last tiles run on a machine that is draining, and
+// the next launch starts on an empty one; the query + key/value projections of a block (400 + 800 tiles) and the two
+// independent data-gradient products at the end of its backward share one grid instead, so the tail of one is filled by the
+// head of the next.  No split-K in a group.
+struct GemmGroup { GemmArgs g[4]; int tile_end[4]; int n; };
+template <bool AKC, bool BKC, int NS>
+__global__ __launch_bounds__(GT) void gemm_dma_group_kernel(GemmGroup gg) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int t = blockIdx.x;
+  const int p = (t >= gg.tile_end[0]) + (t >= gg.tile_end[1]) + (t >= gg.tile_end[2]);
+  gemm_dma_body<AKC, BKC, NS>(gg.g[p], t - (p > 0 ? gg.tile_end[p - 1] : 0), smem);
 }
 
 // (A 224 x 128-tile variant for the M = 25,600 products — 230 workgroups, one per CU, instead of 400 on 512 half-CU slots —
@@ -640,6 +658,64 @@ int rt_gemm(const float* A, int64_t lda, int32_t a_kc, const float* B, int64_t l
   }
   RT_CHECK_LAUNCH();
   return RT_OK;
+}
+
+// Up to 4 independent products C_i = A_i . B_i^T (+bias_i) (+R_i) (relu_i) in ONE launch (see gemm_dma_group_kernel).  All problems
+// must share the operand layouts and sit on the exact-tile path (M, N multiples of 128, K of 32, 16-byte aligned operands);
+// anything else is executed as consecutive rt_gemm calls — same results either way.
+struct rt_gemm_problem {
+  const float* A; int64_t lda; const float* B; int64_t ldb; float* C; int64_t ldc;
+  const float* bias; const float* R; int64_t ldr; int32_t M, N, K, relu;
+};
+int rt_gemm_grouped(const rt_gemm_problem* problems, int32_t n, int32_t a_kc, int32_t b_kc, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (problems == nullptr || n < 1 || n > 4) return RT_ERR_INVALID_ARG;
+  const int impl = gemm_impl();
+  bool group = impl != 0 && n > 1;
+  for (int i = 0; i < n && group; ++i) {
+    const rt_gemm_problem& q = problems[i];
+    group = q.M > 0 && q.N > 0 && (q.M % BM) == 0 && (q.N % BN) == 0 && (q.K % BK) == 0 && q.K > 0 && (q.lda & 3) == 0 &&
+            (q.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(q.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(q.B) & 15) == 0 &&
+            q.A != nullptr && q.B != nullptr && q.C != nullptr;
+  }
+  if (!group) {
+    for (int i = 0; i < n; ++i) {
+      const rt_gemm_problem& q = problems[i];
+      const int rc = rt_gemm(q.A, q.lda, a_kc, q.B, q.ldb, b_kc, q.C, q.ldc, q.bias, q.R, q.ldr, nullptr, q.M, q.N, q.K, q.relu, 1,
+                             nullptr, 0, stream);
+      if (rc != RT_OK) return rc;
+    }
+    return RT_OK;
+  }
+  GemmGroup gg{};
+  int tiles = 0;
+  for (int i = 0; i < 4; ++i) {
+    if (i < n) {
+      const rt_gemm_problem& q = problems[i];
+      GemmArgs& g = gg.g[i];
+      g.A = q.A; g.lda = q.lda; g.B = q.B; g.ldb = q.ldb; g.C = q.C; g.ldc = q.ldc; g.bias = q.bias; g.R = q.R; g.ldr = q.ldr;
+      g.M = q.M; g.N = q.N; g.K = q.K; g.relu = q.relu;
+      tiles += (q.M / BM) * (q.N / BN);
+    }
+    gg.tile_end[i] = tiles;
+  }
+  gg.n = n;
+  const size_t lds = (size_t)2 * 2 * TILE_F * sizeof(float);
+  auto launch = [&](auto kernel) -> int {
+    static bool attr[4] = {false, false, false, false};
+    const int li = (a_kc ? 2 : 0) + (b_kc ? 1 : 0);
+    if (!attr[li]) {
+      RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr[li] = true;
+    }
+    kernel<<<tiles, GT, lds, stream>>>(gg);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+  };
+  if (a_kc && b_kc) return launch(&gemm_dma_group_kernel<true, true, 2>);
+  if (a_kc && !b_kc) return launch(&gemm_dma_group_kernel<true, false, 2>);
+  if (!a_kc && b_kc) return launch(&gemm_dma_group_kernel<false, true, 2>);
+  return launch(&gemm_dma_group_kernel<false, false, 2>);
 }
 
 // out[n] += sum_m X[m,n]  (caller zero-fills `out`)

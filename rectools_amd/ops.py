@@ -180,6 +180,20 @@ def _gemm(A, lda, a_kc, B, ldb, b_kc, C, ldc, bias, R, ldr, M, N, K, relu=0, spl
        tag=(M, N, K))
 
 
+def _gemm_group(problems: tp.Sequence[tp.Tuple], a_kc: int, b_kc: int) -> None:
+    """ONE launch for up to 4 independent products (A, lda, B, ldb, C, ldc, bias, R, ldr, M, N, K, relu) of the same operand
+    layouts (`rt_gemm_grouped`): the tail tiles of one product run next to the head tiles of the next."""
+    import ctypes
+
+    arr = (_lib.GemmProblem * len(problems))()
+    ptr = lambda t: None if t is None else t.data_ptr()   # noqa: E731
+    for q, (A, lda, B, ldb, C, ldc, bias, R, ldr, M, N, K, relu) in zip(arr, problems):
+        q.A, q.lda, q.B, q.ldb, q.C, q.ldc = ptr(A), lda, ptr(B), ldb, ptr(C), ldc
+        q.bias, q.R, q.ldr, q.M, q.N, q.K, q.relu = ptr(bias), ptr(R), ldr, M, N, K, relu
+    _c("rt_gemm_grouped", ctypes.cast(arr, ctypes.c_void_p), len(problems), a_kc, b_kc,
+       tag=(sum(p[9] * p[10] * p[11] for p in problems), 1, 1))
+
+
 def _wgrad_splits(k_rows: int, out_rows: int = 0, out_cols: int = 0) -> int:
     """Split-K factor of a weight-gradient product dW [out_rows, out_cols] = sum over k_rows.  Small outputs (256 x 256 = 4
     tiles at C2) need every slice they can get to fill 256 CUs; large ones (eSASRec's 2048 x 512 = 64 tiles) were cut into 64
@@ -792,8 +806,8 @@ class _SASRecLayer(torch.autograd.Function):
         x0, q, mean1, rstd1 = new(M, d), new(M, d), new(M), new(M)
         _c("rt_layernorm_fwd_masked", x, ids, ln1_w, ln1_b, float(eps1), M, d, x0, q, mean1, rstd1)   # x0 = x * mask, q = LN1(x0)
         Q, KV = new(M, d), new(M, 2 * d)
-        _gemm(q, d, 1, in_w, d, 1, Q, d, in_b, None, 0, M, d, d)
-        _gemm(x0, d, 1, in_w[d:], d, 1, KV, 2 * d, in_b[d:], None, 0, M, 2 * d, d)
+        _gemm_group([(q, d, in_w, d, Q, d, in_b, None, 0, M, d, d, 0),                       # Q = LN1(x0) Wq^T + bq
+                     (x0, d, in_w[d:], d, KV, 2 * d, in_b[d:], None, 0, M, 2 * d, d, 0)], 1, 1)  # K,V = x0 Wkv^T + bkv
         A, lse = new(M, d), new(B, H, L)
         seed_a = 0
         if p > 0:
@@ -889,10 +903,11 @@ class _SASRecLayer(torch.autograd.Function):
             sd.uses(gQ, gKV, q, x0, d_in_w, d_in_b)
             _gemm(gQ, d, 0, q, d, 0, d_in_w, d, None, None, 0, d, d, M, 0, sp, d_in_b)
             _gemm(gKV, 2 * d, 0, x0, d, 0, d_in_w[d:], d, None, None, 0, 2 * d, d, M, 0, sp, d_in_b[d:])
-        g_q = new(M, d)     # q feeds the query projection and the residual: g_q = gQ Wq + g_y
-        _gemm(gQ, d, 1, in_w, d, 0, g_q, d, None, g_y, d, M, d, d)
-        g_kv = new(M, d)    # x0 feeds LN1 and the key/value projection: g_x = mask * (gKV Wkv + LN1'(g_q)), the sum and the
-        _gemm(gKV, 2 * d, 1, in_w[d:], d, 0, g_kv, d, None, None, 0, M, d, 2 * d)      # mask ride in the LayerNorm backward kernel
+        # q feeds the query projection and the residual: g_q = gQ Wq + g_y; x0 feeds LN1 and the key/value projection:
+        # g_x = mask * (gKV Wkv + LN1'(g_q)) — the sum and the mask ride in the LayerNorm backward kernel.  One launch for both.
+        g_q, g_kv = new(M, d), new(M, d)
+        _gemm_group([(gQ, d, in_w, d, g_q, d, None, g_y, d, M, d, d, 0),
+                     (gKV, 2 * d, in_w[d:], d, g_kv, d, None, None, 0, M, d, 2 * d, 0)], 1, 0)
         g_x, d_ln1w, d_ln1b = new(M, d), new(d), new(d)
         ws_bytes = _lib.load().rt_layernorm_bwd_workspace_bytes(M, d)
         ws = torch.empty((max(ws_bytes, 4),), dtype=torch.uint8, device=dev)
