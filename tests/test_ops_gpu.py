@@ -491,3 +491,102 @@ def test_side_stream_weight_gradients_survive_accumulation_and_parameter_slices(
         for k, v in layer.named_parameters():
             close(v.grad, 2 * once[k], rtol=1e-5, atol_rel=1e-6, msg=f"accumulated d{k} (fused={fused})")
 
+
+
+# ---- round-2 entry points, each against a plain torch fp32 reference ------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("shapes,a_kc,b_kc", [
+    ([(256, 128, 64), (512, 256, 64)], 1, 1),            # exact tiles: ONE grouped launch
+    ([(256, 128, 128), (256, 128, 256), (128, 384, 32)], 1, 0),
+    ([(300, 77, 40), (256, 128, 64)], 1, 1),             # one ragged problem: executed as consecutive rt_gemm calls
+    ([(25600, 256, 256), (25600, 512, 256)], 1, 1),      # the q + k/v projections of a C2 block
+])
+def test_gemm_grouped_equals_reference(shapes, a_kc, b_kc):
+    from rectools_amd import ops
+
+    probs, refs, outs = [], [], []
+    for i, (M, N, K) in enumerate(shapes):
+        A = rnd(M, K, seed=10 + i).cuda()
+        Bm = rnd(N, K, seed=20 + i, scale=0.2).cuda()            # logical B [N, K]
+        bias = rnd(N, seed=30 + i).cuda() if i % 2 == 0 else None
+        R = rnd(M, N, seed=40 + i).cuda() if i % 2 == 1 else None
+        C = torch.empty(M, N, device="cuda")
+        if b_kc:
+            Bst, ldb = Bm, K                                       # k-contiguous: [N, K] row-major
+        else:
+            Bst, ldb = Bm.t().contiguous(), N                      # row-contiguous: element (n, k) at n + k * ld
+        probs.append((A, K, Bst, ldb, C, N, bias, R, N if R is not None else 0, M, N, K, 1 if i == 0 else 0))
+        ref = A.double() @ Bm.double().t()
+        if bias is not None:
+            ref = ref + bias.double()
+        if R is not None:
+            ref = ref + R.double()
+        if i == 0:
+            ref = ref.clamp_min(0)
+        refs.append(ref.float()); outs.append(C)
+    ops._gemm_group(probs, a_kc, b_kc)
+    for i, (got, ref) in enumerate(zip(outs, refs)):
+        close(got, ref, rtol=2e-4, atol_rel=2e-5, msg=f"grouped gemm problem {i}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,d", [(37, 64), (1000, 256), (513, 512)])
+def test_layernorm_masked_and_fused_backward(M, d):
+    """rt_layernorm_fwd_masked / rt_layernorm_bwd_fused (row masks on dy and dx, skip-connection add) vs autograd."""
+    from rectools_amd import _lib, ops
+
+    x, w, b = rnd(M, d, seed=1), 1 + 0.1 * rnd(d, seed=2), 0.1 * rnd(d, seed=3)
+    ids = torch.randint(0, 3, (M,), generator=torch.Generator().manual_seed(4))        # ~1/3 padded rows
+    dy, res = rnd(M, d, seed=5), rnd(M, d, seed=6)
+    mask = (ids != 0).float()[:, None]
+    # forward: y = LN(x * mask), x0 = x * mask
+    x0, y = torch.empty(M, d, device="cuda"), torch.empty(M, d, device="cuda")
+    mean, rstd = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    ops._c("rt_layernorm_fwd_masked", x.cuda(), ids.cuda(), w.cuda(), b.cuda(), 1e-5, M, d, x0, y, mean, rstd)
+    close(x0, x * mask, rtol=0, atol_rel=0, msg="masked input")
+    close(y, F.layer_norm(x * mask, (d,), w, b, 1e-5), msg="masked layernorm")
+    # backward with every fusion on: dx = mask * (LN'(mask * dy) + res)
+    xr = (x * mask).clone().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    F.layer_norm(xr, (d,), wr, br, 1e-5).backward(dy * mask)
+    dx, dw, db = torch.empty(M, d, device="cuda"), torch.empty(d, device="cuda"), torch.empty(d, device="cuda")
+    ws_bytes = _lib.load().rt_layernorm_bwd_workspace_bytes(M, d)
+    ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device="cuda")
+    ops._c("rt_layernorm_bwd_fused", dy.cuda(), x0, w.cuda(), mean, rstd, res.cuda(), ids.cuda(), 1, 1, M, d, dx, dw, db, ws, ws_bytes)
+    close(dx, (xr.grad + res) * mask, rtol=1e-3, msg="fused dx")
+    close(dw, wr.grad, rtol=1e-3, msg="fused dw")
+    close(db, br.grad, rtol=1e-3, msg="fused db")
+
+
+@pytest.mark.gpu
+def test_mul_mask_ld_strided_slices():
+    from rectools_amd import ops
+
+    M, hh = 300, 64
+    packed = rnd(M, 4 * hh, seed=1).cuda()
+    other = rnd(M, hh, seed=2).cuda()
+    ids = torch.randint(0, 2, (M,), generator=torch.Generator().manual_seed(3)).cuda()
+    out = torch.zeros(M, 4 * hh, device="cuda")
+    # read the second column block of `packed`, write into the third column block of `out`
+    ops._c("rt_mul_mask_ld", packed[:, hh:], 4 * hh, other, hh, ids, M, hh, out[:, 2 * hh:], 4 * hh)
+    ref = torch.zeros_like(out)
+    ref[:, 2 * hh:3 * hh] = packed[:, hh:2 * hh] * other * (ids != 0).float()[:, None]
+    close(out, ref, rtol=0, atol_rel=0, msg="strided mul_mask")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,d,H,causal,keypad", [(8, 16, 2, True, False), (70, 128, 4, False, True), (200, 256, 4, True, True), (300, 64, 1, True, False)])
+def test_mha_last_query_equals_full_attention(L, d, H, causal, keypad):
+    """rt_mha_last_fwd (one query row per session) vs the last row of rt_mha_fwd."""
+    from rectools_amd import ops
+
+    B = 5
+    g = torch.Generator().manual_seed(L)
+    ids = torch.randint(1, 50, (B, L), generator=g); ids[0, : L // 3] = 0; ids[1, : L - 1] = 0
+    q, k, v = rnd(B * L, d, seed=1).cuda(), rnd(B * L, d, seed=2).cuda(), rnd(B * L, d, seed=3).cuda()
+    ids = ids.cuda()
+    full = ops.mha(q, k, v, ids, B, H, L, causal, keypad, 0.0).view(B, L, d)[:, -1, :]
+    q_last = q.view(B, L, d)[:, -1, :].contiguous()
+    out = torch.empty(B, d, device="cuda")
+    ops._c("rt_mha_last_fwd", q_last, d, k, d, v, d, ids.reshape(-1), B, H, L, d // H, int(causal), int(keypad), out, d)
+    close(out, full, rtol=2e-5, atol_rel=2e-6, msg="last-query attention")
