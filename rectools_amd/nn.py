@@ -394,12 +394,13 @@ class LiGRLayer(nn.Module):
     def forward(self, seqs, ids, B, L, causal, keypad):
         p = self.p if self.training else 0.0
         ln1, ln2 = self.layer_norm_1, self.layer_norm_2
-        h, seqs = ops.layer_norm_skip(seqs, ln1.weight, ln1.bias, ln1.eps)   # gradients of the other consumers ride in LN1's backward
+        g1, g2 = self.gating_linear_1, self.gating_linear_2
+        h, seqs = ops.layer_norm_skip(seqs, ln1.weight, ln1.bias, ln1.eps)   # the skip branch's gradient rides in LN1's backward
         a = self.multi_head_attn(h, None, ids, B, L, causal, keypad, p)
-        seqs = ops.gate(seqs, self.gating_linear_1(seqs), a, p)      # seqs + sigmoid(Wg1 seqs) * drop(mha)
+        seqs = ops.gated_residual(seqs, g1.weight, g1.bias, a, p)    # seqs + sigmoid(Wg1 seqs + bg1) * drop(mha): one node
         g, seqs = ops.layer_norm_skip(seqs, ln2.weight, ln2.bias, ln2.eps)
         f = self.feed_forward(g)
-        return ops.gate(seqs, self.gating_linear_2(seqs), f, p)      # seqs + sigmoid(Wg2 seqs) * drop(ffn)
+        return ops.gated_residual(seqs, g2.weight, g2.bias, f, p)    # seqs + sigmoid(Wg2 seqs + bg2) * drop(ffn)
 
 
 class LiGRLayers(TransformerLayersBase):

@@ -635,6 +635,48 @@ def gate(x: torch.Tensor, gz: torch.Tensor, a: torch.Tensor, p: float) -> torch.
     return _Gate.apply(x, gz, a, p)
 
 
+class _GatedResidual(torch.autograd.Function):
+    """y = x + sigmoid(x Wg^T + bg) * dropout(a)   (ligr.py:99-105): the gating linear and the gate as ONE node.  x has a single
+    consumer then, and its two gradient contributions (the skip connection and the gating linear's data gradient) meet in the
+    residual epilogue of the dgrad GEMM instead of in a full-size add kernel issued by autograd."""
+
+    @staticmethod
+    def forward(ctx, x, wg, bg, a, p):
+        x, a = x.contiguous(), a.contiguous()
+        M, d = x.shape
+        gz = torch.empty_like(x)
+        _gemm(x, d, 1, wg, d, 1, gz, d, bg, None, 0, M, d, d)
+        y = torch.empty_like(x)
+        seed, sid = RNG.next() if p > 0 else (0, 0)
+        _c("rt_gate_fwd", x, gz, a, float(p), seed, sid, x.numel(), y)
+        ctx.save_for_backward(x, wg, gz, a)
+        ctx.meta = (p, seed, sid, bg is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wg, gz, a = ctx.saved_tensors
+        p, seed, sid, has_bias = ctx.meta
+        dy = dy.contiguous()
+        M, d = x.shape
+        dgz, da = torch.empty_like(gz), torch.empty_like(a)
+        _c("rt_gate_bwd", dy, gz, a, float(p), seed, sid, gz.numel(), dgz, da)
+        dw = torch.empty_like(wg)
+        db = torch.empty((d,), dtype=torch.float32, device=dy.device) if has_bias else None
+        sd = _OnSide(dy.device, defer=_steals_grad(wg))
+        with sd:
+            sd.uses(*(t for t in (dgz, x, dw, db) if t is not None))
+            _gemm(dgz, d, 0, x, d, 0, dw, d, None, None, 0, d, d, M, 0, _wgrad_splits(M, d, d), db)
+        dx = torch.empty_like(x)
+        _gemm(dgz, d, 1, wg, d, 0, dx, d, None, dy, d, M, d, d)       # dgz Wg + dy (the skip connection)
+        sd.join_now()
+        return dx, dw, db, da, None
+
+
+def gated_residual(x: torch.Tensor, wg: torch.Tensor, bg: tp.Optional[torch.Tensor], a: torch.Tensor, p: float) -> torch.Tensor:
+    return _GatedResidual.apply(_chk(x, "gated_residual"), wg, bg, a, p)
+
+
 class _MulMask(torch.autograd.Function):
     """y = a * b * (ids != 0); b / ids optional"""
 
