@@ -330,6 +330,22 @@ int rt_gather_rows(const float* src, int64_t ld_src, const int64_t* idx, int32_t
 int rt_scatter_rows(const float* src, int64_t ld_src, const int64_t* idx, int32_t R, int32_t d, float* dst, int64_t ld_dst,
                     rt_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Data-parallel gradient exchange over RCCL (the reference delegates it to Lightning's DDP,
+ * transformers/base.py:367-380: one all-reduce of the gradients per step).  One process per GPU; the current HIP device is
+ * the rank's GPU.  rt_dp_unique_id: 128 opaque bytes made by ONE rank and handed to all ranks out of band;
+ * rt_dp_init: collective, returns the communicator; rt_dp_allreduce: buf[0:n] <- sum over ranks (in place, fp32,
+ * asynchronous on `stream`; DDP's 1/world is applied by rt_adam_step's grad_scale); rt_dp_broadcast: rank `root`'s buffer to
+ * every rank (parameters and moments at the start of fit); rt_dp_finalize frees the communicator.  RCCL is resolved at run
+ * time (dlopen: the copy torch already loaded, else RT_RCCL_LIB / librccl.so); RT_ERR_UNSUPPORTED if none is found.
+ * ------------------------------------------------------------------------------------------------ */
+int rt_dp_unique_id(void* out128);
+int rt_dp_init(const void* uid128, int32_t rank, int32_t world, void** comm_out);
+int rt_dp_allreduce(void* comm, float* buf, int64_t n, rt_stream_t stream);
+int rt_dp_broadcast(void* comm, float* buf, int64_t n, int32_t root, rt_stream_t stream);
+int rt_dp_finalize(void* comm);
+const char* rt_dp_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

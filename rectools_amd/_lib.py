@@ -25,6 +25,12 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_version": (c_i32, []),
     "rt_device_cu_count": (c_i32, []),
     "rt_last_error": (ctypes.c_char_p, []),
+    "rt_dp_unique_id": (c_i32, [c_vp]),
+    "rt_dp_init": (c_i32, [c_vp, c_i32, c_i32, c_vp]),
+    "rt_dp_allreduce": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    "rt_dp_broadcast": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp]),
+    "rt_dp_finalize": (c_i32, [c_vp]),
+    "rt_dp_last_error": (ctypes.c_char_p, []),
     "rt_topk_workspace_bytes": (c_sz, [c_i32, c_i64, c_i32, c_i32]),
     "rt_filter_hash_bytes": (c_sz, [c_i32, c_i64]),
     "rt_filter_hash_build": (c_i32, [c_vp, c_vp, c_i32, c_i64, c_vp, c_vp]),

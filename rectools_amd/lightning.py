@@ -110,6 +110,47 @@ class TransformerLossModule(nn.Module):
         return logits.view(B, L, -1)
 
 
+class RcclExchange:
+    """The gradient exchange through the library's own RCCL entry points (`rt_dp_*`, include/rectools_hip.h) instead of
+    torch.distributed's collectives: one `ncclAllReduce` on the stream the gradient kernels ran on.  The 128-byte unique id is
+    made by rank 0 and handed to the other ranks through the already initialised torch.distributed group (any backend: it only
+    carries the id); opt-in with `RT_DP_BACKEND=rccl`, the default exchange stays `dist.all_reduce` (which is RCCL too)."""
+
+    def __init__(self, rank: int, world: int) -> None:
+        import ctypes
+
+        from . import _lib
+
+        self._lib = _lib.load()
+        self.rank, self.world = rank, world
+        uid = ctypes.create_string_buffer(128)
+        if rank == 0:
+            _lib.check(self._lib.rt_dp_unique_id(uid), "rt_dp_unique_id")
+        if world > 1:
+            import torch.distributed as dist
+
+            box = [bytes(uid.raw)]
+            dist.broadcast_object_list(box, src=0)
+            uid = ctypes.create_string_buffer(box[0], 128)
+        comm = ctypes.c_void_p()
+        status = self._lib.rt_dp_init(uid, rank, world, ctypes.byref(comm))
+        if status != 0:
+            raise _lib.HipLibraryError(f"rt_dp_init failed ({status}): {(self._lib.rt_dp_last_error() or b'').decode()}")
+        self.comm = comm
+
+    def all_reduce(self, buf: torch.Tensor) -> None:
+        ops._c("rt_dp_allreduce", self.comm, buf, buf.numel())
+
+    def broadcast(self, buf: torch.Tensor, src: int = 0) -> None:
+        ops._c("rt_dp_broadcast", self.comm, buf, buf.numel(), src)
+
+    def close(self) -> None:
+        if self.comm is not None:
+            torch.cuda.synchronize()
+            self._lib.rt_dp_finalize(self.comm)
+            self.comm = None
+
+
 class FlatAdam:
     """All parameters and Adam moments live in flat fp32 buffers; one fused kernel per step.
 
@@ -154,6 +195,11 @@ class FlatAdam:
             ofs += sz
         self.lr, self.betas, self.eps = lr, betas, eps
         self.step_count = 0
+        self.exchange: tp.Optional[RcclExchange] = None   # set by use_rccl_exchange(): rt_dp_* instead of torch.distributed
+
+    def use_rccl_exchange(self, rank: int, world: int) -> None:
+        """Route the gradient all-reduce and the parameter broadcast through `rt_dp_*` (collective: every rank calls it)."""
+        self.exchange = RcclExchange(rank, world)
 
     @property
     def flat_g(self) -> torch.Tensor:
@@ -166,7 +212,10 @@ class FlatAdam:
         module).  One broadcast per flat buffer; a no-op without an initialised process group."""
         import torch.distributed as dist
 
-        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force):
+        if self.exchange is not None:
+            for buf in (self.flat_p, self.m, self.v):
+                self.exchange.broadcast(buf, src)
+        elif dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force):
             for buf in (self.flat_p, self.m, self.v):
                 dist.broadcast(buf, src=src)
 
@@ -198,6 +247,9 @@ class FlatAdam:
         RCCL smoke test of a one-GPU box)."""
         if world_size <= 1 and not force:
             return 1.0
+        if self.exchange is not None:
+            self.exchange.all_reduce(self.gather_gradients())
+            return 1.0 / max(world_size, 1)
         import torch.distributed as dist
 
         dist.all_reduce(self.gather_gradients(), op=dist.ReduceOp.SUM)

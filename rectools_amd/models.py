@@ -10,6 +10,8 @@ recommend() keeps user and item embeddings on the device and ranks them with the
 """
 from __future__ import annotations
 
+import os
+
 import importlib
 import io
 import pickle
@@ -251,6 +253,8 @@ class TransformerModelBase:
         self.lightning_model.to(device)
         hl.xavier_normal_init(self.lightning_model.torch_model)  # on_train_start (lightning.py:296-299)
         self.optimizer = hl.FlatAdam(self.lightning_model.torch_model, lr=self.lr, betas=(0.9, 0.98))
+        if os.environ.get("RT_DP_BACKEND", "torch") == "rccl" and _dist_info()[1] > 1 and device.type == "cuda":
+            self.optimizer.use_rccl_exchange(*_dist_info())   # gradient exchange through rt_dp_* (include/rectools_hip.h)
         self.optimizer.broadcast_parameters()   # data parallel: replicas start from rank 0's weights (DDP semantics)
         self.epochs_done = 0
         self.history = []

@@ -159,3 +159,38 @@ def test_rccl_backend_step_on_every_visible_gpu(tmp_path):
     world = min(torch.cuda.device_count(), 2)
     mp.spawn(_nccl_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"nccl_ok{r}.npy").exists() for r in range(world))
+
+
+@pytest.mark.gpu
+def test_rt_dp_entry_points_single_rank():
+    """The library's own RCCL binding (rt_dp_unique_id / init / allreduce / broadcast / finalize): a 1-rank communicator on this
+    GPU — the all-reduce of one rank is the identity — and FlatAdam stepping through it equals the plain step."""
+    import torch
+
+    from rectools_amd import lightning as hl
+
+    ex = hl.RcclExchange(0, 1)
+    x = torch.randn(1 << 20, device="cuda")
+    ref = x.clone()
+    ex.all_reduce(x)
+    ex.broadcast(x, 0)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(x, ref, rtol=0, atol=0)
+    ex.close()
+
+    torch.manual_seed(0)
+    def make():
+        torch.manual_seed(1)
+        return torch.nn.ParameterList([torch.nn.Parameter(torch.randn(s, device="cuda")) for s in [(64, 32), (32,), (128, 64)]])
+    pa, pb = make(), make()
+    oa, ob = hl.FlatAdam(pa, lr=1e-2), hl.FlatAdam(pb, lr=1e-2)
+    ob.use_rccl_exchange(0, 1)
+    grads = [torch.randn_like(p) for p in pa]
+    for opt, ps in ((oa, pa), (ob, pb)):
+        for p, g in zip(ps, grads):
+            p.grad = g.clone()
+    oa.step()                               # one GPU: segmented kernel, no collective
+    ob.step(world_size=1, flat=True)        # pack -> rt_dp_allreduce (1 rank: identity) -> flat Adam kernel
+    for a, b in zip(pa, pb):
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7)
+    ob.exchange.close()
