@@ -87,6 +87,24 @@ class MultiheadAttnParams(nn.Module):
         return self.out_proj(o, residual=residual)
 
 
+def _take_last(x: torch.Tensor, B: int, L: int) -> torch.Tensor:
+    """[B*L, d] -> [B, d]: the row of the last position of every session."""
+    return x.view(B, L, -1)[:, L - 1, :].contiguous()
+
+
+def _attend_last(mha: MultiheadAttnParams, kv_in: torch.Tensor, q_last: torch.Tensor, ids: torch.Tensor, B: int, L: int,
+                 causal: bool, keypad: bool) -> torch.Tensor:
+    """Inference: attention output (before out_proj) of the LAST query of every session.  Keys / values are projected for every
+    position of `kv_in` [B*L, d], the query for `q_last` [B, d] only (`rt_mha_last_fwd`)."""
+    d = mha.d
+    kv = ops.linear(kv_in, mha.in_proj_weight[d:], mha.in_proj_bias[d:])          # [B*L, 2d]
+    q = ops.linear(q_last, mha.in_proj_weight[:d], mha.in_proj_bias[:d])          # [B, d]
+    out = torch.empty((B, d), dtype=torch.float32, device=q.device)
+    ops._c("rt_mha_last_fwd", q, d, kv, 2 * d, kv[:, d:], 2 * d, ids.reshape(-1), B, mha.n_heads, L, d // mha.n_heads,   # pylint: disable=protected-access
+           int(causal), int(keypad), out, d)
+    return out
+
+
 # ---- item net / positions -----------------------------------------------------------------------------
 class EmbeddingParams(nn.Module):
     def __init__(self, n: int, d: int) -> None:
@@ -365,6 +383,15 @@ class PreLNTransformerLayer(nn.Module):
         return self.feed_forward(g, residual=skip)
 
 
+    def forward_last(self, seqs, ids, B, L, causal, keypad):
+        """Inference: the block's output at the last position of every session, [B, d].  Only LN_1 and the key / value projection
+        see every position; the query, out_proj, LN_2 and the 4x feed-forward (two thirds of the block's flops) run on B rows."""
+        h = self.layer_norm_1(seqs)
+        a = _attend_last(self.multi_head_attn, h, _take_last(h, B, L), ids, B, L, causal, keypad)
+        x1 = self.multi_head_attn.out_proj(a, residual=_take_last(seqs, B, L))
+        return self.feed_forward(self.layer_norm_2(x1), residual=x1)
+
+
 class PreLNTransformerLayers(TransformerLayersBase):
     def __init__(self, n_blocks: int, n_factors: int, n_heads: int, dropout_rate: float, ff_factors_multiplier: int = 4,
                  **kwargs: tp.Any) -> None:
@@ -377,6 +404,13 @@ class PreLNTransformerLayers(TransformerLayersBase):
         for blk in self.transformer_blocks:
             seqs = blk(seqs, ids, B, L, causal, keypad)
         return seqs
+
+    def forward_last(self, seqs, ids, B, L, causal, keypad, batch):
+        """Inference: [B, d] encodings of the last position (lightning.py:393-397); the final block on one query row per session."""
+        blocks = list(self.transformer_blocks)
+        for blk in blocks[:-1]:
+            seqs = blk(seqs, ids, B, L, causal, keypad)
+        return blocks[-1].forward_last(seqs, ids, B, L, causal, keypad)
 
 
 class LiGRLayer(nn.Module):
@@ -403,6 +437,16 @@ class LiGRLayer(nn.Module):
         return ops.gated_residual(seqs, g2.weight, g2.bias, f, p)    # seqs + sigmoid(Wg2 seqs + bg2) * drop(ffn)
 
 
+    def forward_last(self, seqs, ids, B, L, causal, keypad):
+        """Inference: the block's output at the last position of every session, [B, d] (see PreLNTransformerLayer.forward_last)."""
+        h = self.layer_norm_1(seqs)
+        a = self.multi_head_attn.out_proj(_attend_last(self.multi_head_attn, h, _take_last(h, B, L), ids, B, L, causal, keypad))
+        x = _take_last(seqs, B, L)
+        x = ops.gate(x, self.gating_linear_1(x), a, 0.0)
+        f = self.feed_forward(self.layer_norm_2(x))
+        return ops.gate(x, self.gating_linear_2(x), f, 0.0)
+
+
 class LiGRLayers(TransformerLayersBase):
     def __init__(self, n_blocks: int, n_factors: int, n_heads: int, dropout_rate: float, ff_factors_multiplier: int = 4,
                  ff_activation: str = "swiglu", bias_in_ff: bool = False, **kwargs: tp.Any) -> None:
@@ -416,6 +460,13 @@ class LiGRLayers(TransformerLayersBase):
         for blk in self.transformer_blocks:
             seqs = blk(seqs, ids, B, L, causal, keypad)
         return seqs
+
+    def forward_last(self, seqs, ids, B, L, causal, keypad, batch):
+        """Inference: [B, d] encodings of the last position; the final block on one query row per session."""
+        blocks = list(self.transformer_blocks)
+        for blk in blocks[:-1]:
+            seqs = blk(seqs, ids, B, L, causal, keypad)
+        return blocks[-1].forward_last(seqs, ids, B, L, causal, keypad)
 
 
 class RelativeAttentionBias(nn.Module):

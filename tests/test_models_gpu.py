@@ -222,9 +222,10 @@ def test_recommend_device_glue_equals_reference_shaped_path():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["sasrec", "preln", "ligr", "ligr_gelu"])
 @pytest.mark.parametrize("causal,keypad,B", [(True, False, 5), (True, True, 256), (False, True, 130)])
-def test_encode_last_equals_last_row_of_encode_sessions(causal, keypad, B):
-    """Inference shortcut (final SASRec block on one query row per session, rt_mha_last_fwd) against the full forward pass."""
+def test_encode_last_equals_last_row_of_encode_sessions(causal, keypad, B, kind):
+    """Inference shortcut (final block on one query row per session, rt_mha_last_fwd) against the full forward pass."""
     import torch
 
     from rectools_amd import nn as hnn
@@ -233,7 +234,10 @@ def test_encode_last_equals_last_row_of_encode_sessions(causal, keypad, B):
     V, L, d, H = 300, 70, 64, 2
     item_model = hnn.SumOfEmbeddingsConstructor(V, [hnn.IdEmbeddingsItemNet(d, V, 0.0)])
     pos = hnn.LearnableInversePositionalEncoding(True, L, d)
-    layers = hnn.SASRecTransformerLayers(2, d, H, 0.2)
+    layers = {"sasrec": lambda: hnn.SASRecTransformerLayers(2, d, H, 0.2),
+              "preln": lambda: hnn.PreLNTransformerLayers(2, d, H, 0.2),
+              "ligr": lambda: hnn.LiGRLayers(2, d, H, 0.2),
+              "ligr_gelu": lambda: hnn.LiGRLayers(2, d, H, 0.2, ff_activation="gelu", bias_in_ff=True)}[kind]()
     model = hnn.TransformerTorchBackbone(H, 0.2, item_model, pos, layers, hnn.DistanceSimilarityModule("dot"), use_causal_attn=causal,
                                          use_key_padding_mask=keypad).cuda().eval()
     with torch.no_grad():
