@@ -286,6 +286,10 @@ int rt_hstu_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, c
                      const int64_t* time_thr, const float* pos_w, int32_t B, int32_t H, int32_t L, int32_t hd,
                      float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv, float* d_time_w,
                      float* d_pos_w, rt_stream_t stream);
+/* the same for the LAST query of every session only (inference, see rt_mha_last_fwd): q [B, ldq], o [B, ldo] */
+int rt_hstu_attn_last_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const int64_t* ids,
+                          const int64_t* ts, const float* time_w, const int64_t* time_thr, const float* pos_w, int32_t B,
+                          int32_t H, int32_t L, int32_t hd, float* o, int64_t ldo, rt_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K8/K9  negative-sampled losses without the [B,L,1+N,d] gather (similarity.py:88-95 + lightning.py:164-212).

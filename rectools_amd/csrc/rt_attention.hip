@@ -1885,6 +1885,7 @@ inline bool bad_common(int B, int H, int L, int hd, int64_t ldq, int64_t ldk, in
 // (dot products over hd), phase 2 lane = head-dim column (walk over the keys, probabilities from LDS).  Memory-bound:
 // K,V are read once, 2 * L * hd * 4 bytes per (batch, head).  Same masks as rt_mha_fwd for the query L - 1.
 // ---------------------------------------------------------------------------------------------------
+template <int MODE>
 __global__ __launch_bounds__(256) void attn_last_query_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [L] probabilities | [4] partial max | [4] partial sum | [4][hd] partial o
   float* prob = smem;
@@ -1898,34 +1899,59 @@ __global__ __launch_bounds__(256) void attn_last_query_kernel(AttnArgs a) {
   const long long* idb = a.ids + rowbase;
   const int qq = a.L - 1;
   // ---- scores
-  float mx = -INFINITY;
-  for (int j = tid; j < a.L; j += 256) {
-    float sdot = 0.f;
-    for (int c = 0; c < a.hd; c += 4) {
-      const f32x4 kk4 = *reinterpret_cast<const f32x4*>(kb + (long long)j * a.ldk + c);
-      const f32x4 q4 = *reinterpret_cast<const f32x4*>(qv + c);
-      sdot += kk4[0] * q4[0] + kk4[1] * q4[1] + kk4[2] * q4[2] + kk4[3] * q4[3];
+  float inv = 1.f;
+  if (MODE == MODE_SOFTMAX) {
+    float mx = -INFINITY;
+    for (int j = tid; j < a.L; j += 256) {
+      float sdot = 0.f;
+      for (int c = 0; c < a.hd; c += 4) {
+        const f32x4 kk4 = *reinterpret_cast<const f32x4*>(kb + (long long)j * a.ldk + c);
+        const f32x4 q4 = *reinterpret_cast<const f32x4*>(qv + c);
+        sdot += kk4[0] * q4[0] + kk4[1] * q4[1] + kk4[2] * q4[2] + kk4[3] * q4[3];
+      }
+      const bool msk = masked(a, qq, j, idb[j] == 0);
+      const float sv = msk ? -INFINITY : sdot * a.scale;
+      prob[j] = sv;
+      mx = fmaxf(mx, sv);
     }
-    const bool msk = masked(a, qq, j, idb[j] == 0);
-    const float sv = msk ? -INFINITY : sdot * a.scale;
-    prob[j] = sv;
-    mx = fmaxf(mx, sv);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float ps = 0.f;
+    for (int j = tid; j < a.L; j += 256) {
+      const float e = (prob[j] == -INFINITY) ? 0.f : __expf(prob[j] - mx);
+      prob[j] = e;
+      ps += e;
+    }
+    ps = wave_sum(ps);
+    if (lane == 0) red[4 + wave] = ps;
+    __syncthreads();
+    const float l = (red[4] + red[5]) + (red[6] + red[7]);
+    inv = l > 0.f ? 1.f / l : 0.f;
+  } else {
+    // HSTU (hstu.py:270-288) for the query L-1: silu(q.k + rab) / L over the non-padded keys (every key is <= the query)
+    const bool q_pad = idb[qq] == 0;
+    const long long* tsb = a.ts ? a.ts + (long long)b * (a.L + 1) : nullptr;
+    const long long t_q1 = tsb ? tsb[qq + 1] : 0;
+    const float inv_l = 1.0f / (float)a.L;
+    for (int j = tid; j < a.L; j += 256) {
+      float sdot = 0.f;
+      for (int c = 0; c < a.hd; c += 4) {
+        const f32x4 kk4 = *reinterpret_cast<const f32x4*>(kb + (long long)j * a.ldk + c);
+        const f32x4 q4 = *reinterpret_cast<const f32x4*>(qv + c);
+        sdot += kk4[0] * q4[0] + kk4[1] * q4[1] + kk4[2] * q4[2] + kk4[3] * q4[3];
+      }
+      const bool dead = q_pad | (idb[j] == 0);
+      float bias = 0.f;
+      if (!dead) {
+        if (a.time_w) bias += a.time_w[time_bucket(a.time_thr, t_q1 - tsb[j])];
+        if (a.pos_w) bias += a.pos_w[(a.L - 1) + j - qq];
+      }
+      prob[j] = dead ? 0.f : silu_f(sdot + bias) * inv_l;
+    }
+    __syncthreads();
   }
-  mx = wave_max(mx);
-  if (lane == 0) red[wave] = mx;
-  __syncthreads();
-  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  float ps = 0.f;
-  for (int j = tid; j < a.L; j += 256) {
-    const float e = (prob[j] == -INFINITY) ? 0.f : __expf(prob[j] - mx);
-    prob[j] = e;
-    ps += e;
-  }
-  ps = wave_sum(ps);
-  if (lane == 0) red[4 + wave] = ps;
-  __syncthreads();
-  const float l = (red[4] + red[5]) + (red[6] + red[7]);
-  const float inv = l > 0.f ? 1.f / l : 0.f;
   // ---- o = sum_j p_j v_j : thread -> (column group, key phase); 16-byte columns, the key phases are combined through LDS
   const int ncol4 = a.hd / 4;                      // float4 columns per row (hd % 8 == 0)
   const int phases = 256 / ncol4;                  // key phases that fit the workgroup
@@ -2015,8 +2041,31 @@ int rt_mha_last_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, co
   const size_t part_f = (size_t)256 * 4;           // [phases][hd/4] float4 = 256 float4 at most
   const size_t lds = (prob_f > part_f ? prob_f : part_f) * sizeof(float);
   if (lds > LDS_LIMIT) return RT_ERR_UNSUPPORTED;
-  { const int rc = set_lds(&attn_last_query_kernel, lds); if (rc != RT_OK) return rc; }
-  attn_last_query_kernel<<<B * H, 256, lds, stream>>>(a);
+  { const int rc = set_lds(&attn_last_query_kernel<MODE_SOFTMAX>, lds); if (rc != RT_OK) return rc; }
+  attn_last_query_kernel<MODE_SOFTMAX><<<B * H, 256, lds, stream>>>(a);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+// HSTU pointwise attention of the LAST query of every session (see rt_mha_last_fwd); relative bias as in rt_hstu_attn_fwd.
+int rt_hstu_attn_last_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const int64_t* ids,
+                          const int64_t* ts, const float* time_w, const int64_t* time_thr, const float* pos_w, int32_t B,
+                          int32_t H, int32_t L, int32_t hd, float* o, int64_t ldo, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (bad_common(B, H, L, hd, ldq, ldk, ldv) || (ldo & 3) || misaligned16(o) || misaligned16(q) || misaligned16(k) || misaligned16(v))
+    return RT_ERR_INVALID_ARG;
+  if ((time_w != nullptr) != (ts != nullptr) || (time_w != nullptr) != (time_thr != nullptr)) return RT_ERR_INVALID_ARG;
+  AttnArgs a{};
+  a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.o = o; a.ldo = ldo;
+  a.ids = reinterpret_cast<const long long*>(ids); a.B = B; a.H = H; a.L = L; a.hd = hd; a.causal = 1; a.keypad = 0;
+  a.ts = reinterpret_cast<const long long*>(ts); a.time_w = time_w;
+  a.time_thr = reinterpret_cast<const long long*>(time_thr); a.pos_w = pos_w;
+  const size_t prob_f = (size_t)((L + 3) & ~3) + 8;
+  const size_t part_f = (size_t)256 * 4;
+  const size_t lds = (prob_f > part_f ? prob_f : part_f) * sizeof(float);
+  if (lds > LDS_LIMIT) return RT_ERR_UNSUPPORTED;
+  { const int rc = set_lds(&attn_last_query_kernel<MODE_HSTU>, lds); if (rc != RT_OK) return rc; }
+  attn_last_query_kernel<MODE_HSTU><<<B * H, 256, lds, stream>>>(a);
   RT_CHECK_LAUNCH();
   return RT_OK;
 }

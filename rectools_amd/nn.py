@@ -513,6 +513,36 @@ class STULayer(nn.Module):
                                  (self.output_mlp.weight, self.output_mlp.bias))
         return self.forward_modular(ops.mul_mask(seqs, None, ids), ids, B, L, batch, thr)
 
+    def forward_last(self, seqs, ids, B, L, batch, thr):
+        """Inference: the block's output at the last position of every session, [B, d].  v and k are projected for every position
+        (two column blocks of `uvqk_proj`, read in place through a row stride), u and q for the last row only; the attention of
+        that row is `rt_hstu_attn_last_fwd`."""
+        hh, d = self.n_heads * self.hd, seqs.shape[1]
+        M = seqs.shape[0]
+        dev = seqs.device
+        new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
+        ids_flat = ids.reshape(-1)
+        ids_last = ids.view(B, L)[:, L - 1].contiguous()
+        x0 = ops.mul_mask(seqs, None, ids_flat)
+        normed = ops.mul_mask(self.norm_input(x0), None, ids_flat)
+        P = self.uvqk_proj                                                        # [d, 4 hh]: u | v | q | k column blocks
+        vk = new(2, M, hh)
+        for i, c0 in enumerate((hh, 3 * hh)):                                     # v, k of every position
+            ops._gemm(normed, d, 1, P[:, c0:], 4 * hh, 0, vk[i], hh, None, None, 0, M, hh, d)   # pylint: disable=protected-access
+        vk = ops.act_dropout(vk.view(2 * M, hh), ops.ACT_SILU, 0.0).view(2, M, hh)
+        n_last = _take_last(normed, B, L)
+        uq = new(2, B, hh)
+        for i, c0 in enumerate((0, 2 * hh)):                                      # u, q of the last position
+            ops._gemm(n_last, d, 1, P[:, c0:], 4 * hh, 0, uq[i], hh, None, None, 0, B, hh, d)   # pylint: disable=protected-access
+        uq = ops.act_dropout(uq.view(2 * B, hh), ops.ACT_SILU, 0.0).view(2, B, hh)
+        tw = self.rel_attn.time_weights if self.rel_attn.relative_time_attention else None
+        pw = self.rel_attn.pos_weights if self.rel_attn.relative_pos_attention else None
+        attn = new(B, hh)
+        ops._c("rt_hstu_attn_last_fwd", uq[1], hh, vk[1], hh, vk[0], hh, ids_flat, batch.get("unix_ts") if tw is not None else None,   # pylint: disable=protected-access
+               tw, thr if tw is not None else None, pw, B, self.n_heads, L, self.hd, attn, hh)
+        o_in = ops.mul_mask(uq[0], self.norm_attn_output(attn), ids_last)
+        return self.output_mlp(o_in, residual=_take_last(x0, B, L))
+
     def forward_modular(self, seqs, ids, B, L, batch, thr):
         """Same block out of the individual autograd ops (`seqs` already masked); the cross-check of the fused node."""
         hh = self.n_heads * self.hd
@@ -543,6 +573,14 @@ class STULayers(TransformerLayersBase):
         for blk in self.stu_blocks:
             seqs = blk(seqs, ids, B, L, batch, self.time_thr)   # seqs * mask happens inside the block
         return ops.mul_mask(seqs, None, ids)
+
+    def forward_last(self, seqs, ids, B, L, causal, keypad, batch):
+        """Inference: [B, d] encodings of the last position; the final STU block on one query row per session."""
+        blocks = list(self.stu_blocks)
+        for blk in blocks[:-1]:
+            seqs = blk(seqs, ids, B, L, batch, self.time_thr)
+        last = blocks[-1].forward_last(seqs, ids, B, L, batch, self.time_thr)
+        return ops.mul_mask(last, None, ids.view(B, L)[:, L - 1].contiguous())
 
 
 # ---- similarity + backbone ------------------------------------------------------------------------------
