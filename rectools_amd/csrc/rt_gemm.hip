@@ -16,6 +16,7 @@
 // k-contiguous operand is fetched from LDS with one ds_read_b128 per 4 MFMAs.
 #include "rt_common.h"
 #include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -316,7 +317,36 @@ __device__ __forceinline__ f32x4 read_frag_swz(const float* S, int row, int s, i
   }
 }
 
-template <bool AKC, bool BKC, int NS>
+// ---- bf16x6 inner loop (opt-in, RT_GEMM_SPLIT=bf16x6) ------------------------------------------------------------
+// An fp32 value is the EXACT sum of three bf16 values: h = its top 16 bits, m = the top 16 bits of x - h, l = x - h - m
+// (24 significand bits = 8 + 8 + 8; the two subtractions are exact).  a*b = (ah + am + al)(bh + bm + bl); the six terms
+// down to 2^-16 relative (hh, hm, mh, hl, lh, mm) go through v_mfma_f32_32x32x16_bf16 into the fp32 accumulator — the bf16
+// pipe does 16x the flops of the f32-input MFMA per cycle, so six products cost 6/16 of the exact instruction.  The
+// dropped terms (ml, lm, ll) are 2^-24 |a||b| and below: one fp32 rounding unit per product, the size of the rounding
+// the exact kernel commits when it adds the product to its accumulator.  Same LDS images and DMA ring as the exact loop;
+// a lane feeds the same (row, k) elements, 8 per 16-k block: k = 16u + 8v + 4*half + t (A and B permuted alike).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct Split3 { bf16x8 h, m, l; };
+__device__ __forceinline__ Split3 split_bf16x3(const f32x4& x0, const f32x4& x1) {
+  u32x4 ph, pm, pl;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {           // packs the element pairs (x[2q'], x[2q'+1]) of x0 then x1
+    const float a = q < 2 ? x0[2 * q] : x1[2 * q - 4], b = q < 2 ? x0[2 * q + 1] : x1[2 * q - 3];
+    const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+    const float ra = a - __uint_as_float(ua & 0xFFFF0000u), rb = b - __uint_as_float(ub & 0xFFFF0000u);
+    const unsigned va = __float_as_uint(ra), vb = __float_as_uint(rb);
+    const float la = ra - __uint_as_float(va & 0xFFFF0000u), lb = rb - __uint_as_float(vb & 0xFFFF0000u);
+    ph[q] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);     // {b[31:16], a[31:16]}: truncation = the bf16 of the top half
+    pm[q] = __builtin_amdgcn_perm(vb, va, 0x07060302u);
+    pl[q] = __builtin_amdgcn_perm(__float_as_uint(lb), __float_as_uint(la), 0x07060302u);   // exact: <= 8 significant bits left
+  }
+  Split3 r;
+  r.h = __builtin_bit_cast(bf16x8, ph); r.m = __builtin_bit_cast(bf16x8, pm); r.l = __builtin_bit_cast(bf16x8, pl);
+  return r;
+}
+
+template <bool AKC, bool BKC, int NS, bool X6 = false>
 __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int t, float* smem) {
   constexpr int STAGE_F = 2 * TILE_F;
   constexpr int NL = 8;   // DMA instructions per wave per stage
@@ -390,6 +420,26 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int t, float* s
       for (int kk = 0; kk < BK; ++kk)
         rowsum += Ab[kk * BM + ((((tid >> 2) ^ (((kk >> 2) & 1) << 3)) << 2) | (tid & 3))];
     }
+    if constexpr (X6) {
+#pragma unroll
+      for (int u = 0; u < BK / 16; ++u) {
+        Split3 as[2], bs[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          as[i] = split_bf16x3(read_frag_swz<AKC>(Ab, wm * 64 + i * 32 + col, 2 * u, half),
+                               read_frag_swz<AKC>(Ab, wm * 64 + i * 32 + col, 2 * u + 1, half));
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          bs[j] = split_bf16x3(read_frag_swz<BKC>(Bb, wn * 64 + j * 32 + col, 2 * u, half),
+                               read_frag_swz<BKC>(Bb, wn * 64 + j * 32 + col, 2 * u + 1, half));
+        // smallest terms first; the four accumulators take turns inside a term (no back-to-back dependent MFMAs)
+#define RT_X6_TERM(PA, PB)                                                                                            \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                        \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[i].PA, bs[j].PB, acc[i][j], 0, 0, 0);
+        RT_X6_TERM(l, h) RT_X6_TERM(h, l) RT_X6_TERM(m, m) RT_X6_TERM(m, h) RT_X6_TERM(h, m) RT_X6_TERM(h, h)
+#undef RT_X6_TERM
+      }
+    } else {
 #pragma unroll
     for (int s = 0; s < BK / 8; ++s) {
       f32x4 af[2], bf[2];
@@ -404,6 +454,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int t, float* s
 #pragma unroll
           for (int j = 0; j < 2; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][tt], bf[j][tt], acc[i][j], 0, 0, 0);
+    }
     }
   }
 
@@ -439,10 +490,10 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int t, float* s
     }
 }
 
-template <bool AKC, bool BKC, int NS>
+template <bool AKC, bool BKC, int NS, bool X6 = false>
 __global__ __launch_bounds__(GT) void gemm_dma_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [NS][A tile | B tile]
-  gemm_dma_body<AKC, BKC, NS>(g, blockIdx.x, smem);
+  gemm_dma_body<AKC, BKC, NS, X6>(g, blockIdx.x, smem);
 }
 
 // Grouped launch: up to 4 independent products with the same operand layouts in ONE grid (tile ranges back to back).  A
@@ -451,12 +502,12 @@ __global__ __launch_bounds__(GT) void gemm_dma_kernel(GemmArgs g) {
 // independent data-gradient products at the end of its backward share one grid instead, so the tail of one is filled by the
 // head of the next.  No split-K in a group.
 struct GemmGroup { GemmArgs g[4]; int tile_end[4]; int n; };
-template <bool AKC, bool BKC, int NS>
+template <bool AKC, bool BKC, int NS, bool X6 = false>
 __global__ __launch_bounds__(GT) void gemm_dma_group_kernel(GemmGroup gg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int t = blockIdx.x;
   const int p = (t >= gg.tile_end[0]) + (t >= gg.tile_end[1]) + (t >= gg.tile_end[2]);
-  gemm_dma_body<AKC, BKC, NS>(gg.g[p], t - (p > 0 ? gg.tile_end[p - 1] : 0), smem);
+  gemm_dma_body<AKC, BKC, NS, X6>(gg.g[p], t - (p > 0 ? gg.tile_end[p - 1] : 0), smem);
 }
 
 // (A 224 x 128-tile variant for the M = 25,600 products — 230 workgroups, one per CU, instead of 400 on 512 half-CU slots —
@@ -550,26 +601,32 @@ int launch_gemm(const GemmArgs& g, int splits, hipStream_t stream) {
   return RT_OK;
 }
 
-template <bool AKC, bool BKC, int NS>
+template <bool AKC, bool BKC, int NS, bool X6 = false>
 int launch_gemm_dma(const GemmArgs& g, int splits, hipStream_t stream) {
   const size_t lds = (size_t)NS * 2 * TILE_F * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_kernel<AKC, BKC, NS>),
+    RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_kernel<AKC, BKC, NS, X6>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = true;
   }
   dim3 grid((g.M / BM) * (g.N / BN), 1, splits);
-  gemm_dma_kernel<AKC, BKC, NS><<<grid, GT, lds, stream>>>(g);
+  gemm_dma_kernel<AKC, BKC, NS, X6><<<grid, GT, lds, stream>>>(g);
   RT_CHECK_LAUNCH();
   return RT_OK;
 }
-template <int NS>
+template <int NS, bool X6 = false>
 int launch_gemm_dma_ns(const GemmArgs& g, bool a_kc, bool b_kc, int splits, hipStream_t stream) {
-  if (a_kc && b_kc) return launch_gemm_dma<true, true, NS>(g, splits, stream);
-  if (a_kc && !b_kc) return launch_gemm_dma<true, false, NS>(g, splits, stream);
-  if (!a_kc && b_kc) return launch_gemm_dma<false, true, NS>(g, splits, stream);
-  return launch_gemm_dma<false, false, NS>(g, splits, stream);
+  if (a_kc && b_kc) return launch_gemm_dma<true, true, NS, X6>(g, splits, stream);
+  if (a_kc && !b_kc) return launch_gemm_dma<true, false, NS, X6>(g, splits, stream);
+  if (!a_kc && b_kc) return launch_gemm_dma<false, true, NS, X6>(g, splits, stream);
+  return launch_gemm_dma<false, false, NS, X6>(g, splits, stream);
+}
+// RT_GEMM_SPLIT=bf16x6: the exact-tile products run their inner loop on the bf16 matrix pipe (see split_bf16x3)
+// (read per call, not cached: the parity test flips it inside one process)
+bool gemm_x6() {
+  const char* e = getenv("RT_GEMM_SPLIT");
+  return e != nullptr && strcmp(e, "bf16x6") == 0;
 }
 
 // RT_GEMM_IMPL: 0 = generic register-staged kernel only; 2/3/4 = stages of the DMA ring on exact tile grids
@@ -638,7 +695,9 @@ int rt_gemm(const float* A, int64_t lda, int32_t a_kc, const float* B, int64_t l
       RT_CHECK_LAUNCH();
     }
   }
-  if (exact) {
+  if (exact && gemm_x6()) {
+    rc = launch_gemm_dma_ns<2, true>(g, a_kc != 0, b_kc != 0, splits, stream);
+  } else if (exact) {
     rc = impl == 2   ? launch_gemm_dma_ns<2>(g, a_kc != 0, b_kc != 0, splits, stream)
          : impl == 3 ? launch_gemm_dma_ns<3>(g, a_kc != 0, b_kc != 0, splits, stream)
                      : launch_gemm_dma_ns<4>(g, a_kc != 0, b_kc != 0, splits, stream);
@@ -701,9 +760,10 @@ int rt_gemm_grouped(const rt_gemm_problem* problems, int32_t n, int32_t a_kc, in
   }
   gg.n = n;
   const size_t lds = (size_t)2 * 2 * TILE_F * sizeof(float);
+  const bool x6 = gemm_x6();
   auto launch = [&](auto kernel) -> int {
-    static bool attr[4] = {false, false, false, false};
-    const int li = (a_kc ? 2 : 0) + (b_kc ? 1 : 0);
+    static bool attr[8] = {false, false, false, false, false, false, false, false};
+    const int li = (a_kc ? 2 : 0) + (b_kc ? 1 : 0) + (x6 ? 4 : 0);
     if (!attr[li]) {
       RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       attr[li] = true;
@@ -712,6 +772,12 @@ int rt_gemm_grouped(const rt_gemm_problem* problems, int32_t n, int32_t a_kc, in
     RT_CHECK_LAUNCH();
     return RT_OK;
   };
+  if (x6) {
+    if (a_kc && b_kc) return launch(&gemm_dma_group_kernel<true, true, 2, true>);
+    if (a_kc && !b_kc) return launch(&gemm_dma_group_kernel<true, false, 2, true>);
+    if (!a_kc && b_kc) return launch(&gemm_dma_group_kernel<false, true, 2, true>);
+    return launch(&gemm_dma_group_kernel<false, false, 2, true>);
+  }
   if (a_kc && b_kc) return launch(&gemm_dma_group_kernel<true, true, 2>);
   if (a_kc && !b_kc) return launch(&gemm_dma_group_kernel<true, false, 2>);
   if (!a_kc && b_kc) return launch(&gemm_dma_group_kernel<false, true, 2>);

@@ -272,7 +272,10 @@ class TransformerModelBase:
         import os
 
         if torch.cuda.is_available():
-            return f"cuda:{os.environ.get('LOCAL_RANK', '0')}" if "LOCAL_RANK" in os.environ else "cuda"
+            if "LOCAL_RANK" not in os.environ:
+                return "cuda"
+            # one process per GPU; more ranks than devices (the 2-ranks-on-1-GPU gloo test box) wrap around
+            return f"cuda:{int(os.environ['LOCAL_RANK']) % torch.cuda.device_count()}"
         from . import _lib
 
         raise _lib.HipLibraryError("no HIP device visible: the MI355X engine cannot run (no CPU fallback)")

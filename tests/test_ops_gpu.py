@@ -590,3 +590,42 @@ def test_mha_last_query_equals_full_attention(L, d, H, causal, keypad):
     out = torch.empty(B, d, device="cuda")
     ops._c("rt_mha_last_fwd", q_last, d, k, d, v, d, ids.reshape(-1), B, H, L, d // H, int(causal), int(keypad), out, d)
     close(out, full, rtol=2e-5, atol_rel=2e-6, msg="last-query attention")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 1), (0, 0)])
+@pytest.mark.parametrize("M,N,K,split_k", [(256, 128, 64, 1), (25600, 256, 256, 1), (256, 256, 25600, 16)])
+def test_gemm_bf16x6_split_is_fp32_accurate(M, N, K, split_k, a_kc, b_kc, monkeypatch):
+    """RT_GEMM_SPLIT=bf16x6 (opt-in): every product of an exact 3-way bf16 split down to 2^-16, on the bf16 matrix pipe.
+    The error against an fp64 product must be of the size of the exact fp32 kernel's own (both bounded relative to
+    sum_k |a||b|), for all four operand layouts, the split-K combine and the grouped launch."""
+    from rectools_amd import ops
+
+    A = rnd(M, K, seed=1).cuda()                                   # logical A [M, K], B [N, K]
+    Bm = rnd(N, K, seed=2, scale=0.3).cuda()
+    A[0, :8] = torch.tensor([1e-20, -3e19, 1.0, -1.0, 0.0, 2.0 ** -120, 65504.0, 1.0 + 2.0 ** -23]).cuda()   # exponent range
+    Ast, lda = (A, K) if a_kc else (A.t().contiguous(), M)
+    Bst, ldb = (Bm, K) if b_kc else (Bm.t().contiguous(), N)
+    ref = A.double() @ Bm.double().t()
+    scale = A.double().abs() @ Bm.double().abs().t() + 1e-300
+
+    def run():
+        C = torch.empty(M, N, device="cuda")
+        ops._gemm(Ast, lda, a_kc, Bst, ldb, b_kc, C, N, None, None, 0, M, N, K, 0, split_k)
+        return C
+
+    exact = run()
+    monkeypatch.setenv("RT_GEMM_SPLIT", "bf16x6")
+    split = run()
+    if split_k == 1 and a_kc:
+        C2 = torch.empty(M, N, device="cuda")                      # grouped launch, same switch
+        ops._gemm_group([(Ast, lda, Bst, ldb, split.new_empty(M, N), N, None, None, 0, M, N, K, 0),
+                         (Ast, lda, Bst, ldb, C2, N, None, None, 0, M, N, K, 0)], a_kc, b_kc)
+        assert torch.equal(C2, split), "grouped bf16x6 launch differs from the single launch"
+    monkeypatch.delenv("RT_GEMM_SPLIT")
+    assert torch.equal(run(), exact), "the switch must not leak into the exact kernel"
+    e_exact = float(((exact.double() - ref).abs() / scale).max())
+    e_split = float(((split.double() - ref).abs() / scale).max())
+    assert not torch.equal(split, exact) or M * N <= 256 * 128, "bf16x6 path did not run (bitwise equal to the exact kernel)"
+    bound = 2.0 ** -24 * (3 + 2 * (K // max(split_k, 1)) ** 0.5)   # 3 dropped-term units + random-walk accumulation rounding
+    assert e_split < bound, f"bf16x6 error {e_split:.2e} (exact kernel {e_exact:.2e}, bound {bound:.2e})"
