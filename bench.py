@@ -33,6 +33,12 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 MFMA_F32_PEAK_TF = 157.3
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md)
+# The exact-tile GEMMs compute every fp32 product as six bf16-MFMA products of an exact 3-way bf16 split (rt_gemm.hip:
+# split_bf16x3; error against fp64 <= the f32-input MFMA kernel's, tests/test_ops_gpu.py): an algorithmic fp32 flop costs six
+# bf16 flops, so the pipe's peak for this kernel is 2500 / 6.  RT_GEMM_SPLIT=exact runs v_mfma_f32_32x32x2_f32 (157.3 TF).
+GEMM_X6 = os.environ.get("RT_GEMM_SPLIT", "bf16x6") != "exact"
+GEMM_PEAK_TF = MFMA_BF16_PEAK_TF / 6.0 if GEMM_X6 else MFMA_F32_PEAK_TF
 
 
 def dist_setup(n_gpus: int):
@@ -303,7 +309,10 @@ def run_train(args, rank, world, kind="train"):
         tf = fl / (ms * 1e-3) / 1e12
         ms1 = sum(t for t, _ in rec1.get("rt_gemm", []) + rec1.get("rt_gemm_grouped", []))
         roof = {"kernel": "gemm_dma_kernel (rt_gemm / rt_gemm_grouped: all forward/dgrad/wgrad products of the step)", "bound": "mfma",
-                "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),
+                "achieved": round(tf, 2), "peak": round(GEMM_PEAK_TF, 1), "unit": "TFLOP/s", "frac": round(tf / GEMM_PEAK_TF, 4),
+                "arithmetic": ("fp32 via 6 bf16-MFMA products of an exact 3-way bf16 split, fp32 accumulate: peak = 2500 TF bf16 / 6; "
+                               f"against the f32-input MFMA peak (157.3 TF) the same rate is {tf / MFMA_F32_PEAK_TF:.3f}")
+                              if GEMM_X6 else "f32-input MFMA (v_mfma_f32_32x32x2_f32)",
                 "traffic": load_traffic("train_gemm"), "avg_launch_ms": round(ms / len(calls), 4),
                 "algorithmic_flops_per_launch": fl / len(calls), "launches_per_step": len(calls) / 3.0,
                 "single_stream": {"avg_launch_ms": round(ms1 / len(calls), 4), "achieved": round(fl / (ms1 * 1e-3) / 1e12, 2)}}
@@ -480,7 +489,10 @@ def main():
                                    f"store + on-device negatives + fwd + bwd + Adam" + (" + RCCL all-reduce" if world > 1 else "")
                                    + f"; {spec['desc']}, V={info['V']} items, {info['steps_per_epoch']} steps/epoch",
                        "global_batch": info["B"] * world, "seq_len": info["L"], "parallelism": f"dp{world}", "n_negatives": info["n_neg"],
-                       "dataset_prep_s": round(info["prep_s"], 2)},
+                       "dataset_prep_s": round(info["prep_s"], 2),
+                       "gemm_arithmetic": "fp32 in / fp32 out; products as 6 bf16-MFMA terms of an exact 3-way bf16 split, fp32 "
+                                          "accumulate (fp32-accurate; RT_GEMM_SPLIT=exact = f32-input MFMA)" if GEMM_X6
+                                          else "f32-input MFMA (exact fp32)"},
             "roofline": roof, "cpu_baseline": None,
             "kernel_breakdown": info["breakdown"], "final_loss": round(info["loss"], 5),
         }

@@ -317,7 +317,7 @@ __device__ __forceinline__ f32x4 read_frag_swz(const float* S, int row, int s, i
   }
 }
 
-// ---- bf16x6 inner loop (opt-in, RT_GEMM_SPLIT=bf16x6) ------------------------------------------------------------
+// ---- bf16x6 inner loop (default; RT_GEMM_SPLIT=exact opts out) ------------------------------------------------------------
 // An fp32 value is the EXACT sum of three bf16 values: h = its top 16 bits, m = the top 16 bits of x - h, l = x - h - m
 // (24 significand bits = 8 + 8 + 8; the two subtractions are exact).  a*b = (ah + am + al)(bh + bm + bl); the six terms
 // down to 2^-16 relative (hh, hm, mh, hl, lh, mm) go through v_mfma_f32_32x32x16_bf16 into the fp32 accumulator — the bf16
@@ -622,11 +622,11 @@ int launch_gemm_dma_ns(const GemmArgs& g, bool a_kc, bool b_kc, int splits, hipS
   if (!a_kc && b_kc) return launch_gemm_dma<false, true, NS, X6>(g, splits, stream);
   return launch_gemm_dma<false, false, NS, X6>(g, splits, stream);
 }
-// RT_GEMM_SPLIT=bf16x6: the exact-tile products run their inner loop on the bf16 matrix pipe (see split_bf16x3)
-// (read per call, not cached: the parity test flips it inside one process)
+// the exact-tile products run their inner loop on the bf16 matrix pipe (see split_bf16x3) unless
+// RT_GEMM_SPLIT=exact keeps the f32-input MFMA (read per call, not cached: the parity test flips it inside one process)
 bool gemm_x6() {
   const char* e = getenv("RT_GEMM_SPLIT");
-  return e != nullptr && strcmp(e, "bf16x6") == 0;
+  return e == nullptr || strcmp(e, "exact") != 0;
 }
 
 // RT_GEMM_IMPL: 0 = generic register-staged kernel only; 2/3/4 = stages of the DMA ring on exact tile grids

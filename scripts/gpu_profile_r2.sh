@@ -3,7 +3,8 @@
 # model families, HBM-traffic PMC passes (FETCH_SIZE / WRITE_SIZE, separate passes, kernel-trace only) and the SQ counters of
 # the attention and top-k kernels.  Everything lands under gpurun_out/r2/ (summaries are then copied into profiles/).
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-R=$PWD; O=$R/gpurun_out/r2; mkdir -p $O; export TMPDIR=/tmp
+R=$PWD; O=$R/gpurun_out/${R2_OUT:-r2}; mkdir -p $O; export TMPDIR=/tmp
+LEAN=${R2_LEAN:-}   # R2_LEAN=1: only what the GEMM arithmetic touches (train traces + PMC, family lines)
 
 # ---- 1. the line the driver records (defaults: 200 train steps after 20 warm-up, + recommend + topk5m legs)
 timeout 900 python bench.py > $O/bench_auto.json 2> $O/bench_auto.err; echo "bench auto rc=$?"
@@ -24,11 +25,13 @@ prof() { name=$1; shift
 }
 prof train --workload train --steps 20 --warmup 5
 RT_SIDE_STREAM=0 prof train_single_stream --workload train --steps 20 --warmup 5
+if [ -z "$LEAN" ]; then
 prof topk5m --workload topk5m --steps 6
 prof recommend --workload recommend --steps 6
 prof bert4rec --workload bert4rec --steps 10 --warmup 3
 prof hstu --workload hstu --steps 10 --warmup 3
 prof esasrec --workload esasrec --steps 10 --warmup 3
+fi
 
 # ---- 3. family bench lines (kept)
 for w in bert4rec hstu esasrec; do
@@ -55,8 +58,10 @@ for k,v in sorted(agg.items(), key=lambda kv:-sum(kv[1]))[:14]:
     print(f"{sys.argv[2]} {k:70s} calls={len(v)} avg={sum(v)/len(v):.1f} max={max(v):.1f} sum={sum(v):.1f}")
 PY
 }
+if [ -z "$LEAN" ]; then
 pmc topk5m FETCH_SIZE --workload topk5m --steps 3
 pmc topk5m WRITE_SIZE --workload topk5m --steps 3
+fi
 RT_SIDE_STREAM=0 pmc train FETCH_SIZE --workload train --steps 3 --warmup 1
 RT_SIDE_STREAM=0 pmc train WRITE_SIZE --workload train --steps 3 --warmup 1
 
@@ -83,15 +88,17 @@ for k,c in agg.items():
     print(f"| `{k}` | {len(c['GRBM_GUI_ACTIVE'])} | {gui:.0f} | {m('SQ_BUSY_CYCLES'):.0f} | {mf:.0f} | {mf/(gui/8*1024):.3f} | {m('SQ_ACTIVE_INST_VALU'):.0f} | {m('SQ_ACTIVE_INST_LDS'):.0f} | {m('SQ_LDS_BANK_CONFLICT'):.0f} |")
 PY
 }
+if [ -z "$LEAN" ]; then
 sq attention attn_ python $R/scripts/attn_bench.py
 sq attention_l512 attn_ python $R/scripts/attn_bench.py --L 512 --n 5
 sq topk5m topk_stream python $R/bench.py --workload topk5m --steps 3 --no-cpu-baseline
 sq recommend topk_stream python $R/bench.py --workload recommend --steps 3 --no-cpu-baseline
+fi
 
 # ---- 6. the N > 1 code path of bench.py on this one-GPU box (2 ranks over gloo; NOT a scaling number)
-RT_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
+[ -z "$LEAN" ] && RT_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
   bench.py --gpus 2 --steps 10 --warmup 3 > $O/bench_auto_2ranks_on_1gpu_gloo.json 2> $O/bench_auto_2ranks_on_1gpu_gloo.err
-tail -c 400 $O/bench_auto_2ranks_on_1gpu_gloo.json; echo
+[ -z "$LEAN" ] && { tail -c 400 $O/bench_auto_2ranks_on_1gpu_gloo.json; echo; }
 
 find $O -name "*.db" -delete; find $O -name "*.csv" -size +2M -delete; find $O -name "*agent_info.csv" -delete
 du -sh $O

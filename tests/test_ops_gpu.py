@@ -596,7 +596,8 @@ def test_mha_last_query_equals_full_attention(L, d, H, causal, keypad):
 @pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 1), (0, 0)])
 @pytest.mark.parametrize("M,N,K,split_k", [(256, 128, 64, 1), (25600, 256, 256, 1), (256, 256, 25600, 16)])
 def test_gemm_bf16x6_split_is_fp32_accurate(M, N, K, split_k, a_kc, b_kc, monkeypatch):
-    """RT_GEMM_SPLIT=bf16x6 (opt-in): every product of an exact 3-way bf16 split down to 2^-16, on the bf16 matrix pipe.
+    """The default inner loop of the exact-tile GEMM: every product of an exact 3-way bf16 split down to 2^-16, on the bf16
+    matrix pipe (RT_GEMM_SPLIT=exact selects the f32-input MFMA instead).
     The error against an fp64 product must be of the size of the exact fp32 kernel's own (both bounded relative to
     sum_k |a||b|), for all four operand layouts, the split-K combine and the grouped launch."""
     from rectools_amd import ops
@@ -614,15 +615,16 @@ def test_gemm_bf16x6_split_is_fp32_accurate(M, N, K, split_k, a_kc, b_kc, monkey
         ops._gemm(Ast, lda, a_kc, Bst, ldb, b_kc, C, N, None, None, 0, M, N, K, 0, split_k)
         return C
 
+    monkeypatch.setenv("RT_GEMM_SPLIT", "exact")
     exact = run()
-    monkeypatch.setenv("RT_GEMM_SPLIT", "bf16x6")
+    monkeypatch.delenv("RT_GEMM_SPLIT")                            # the default
     split = run()
     if split_k == 1 and a_kc:
         C2 = torch.empty(M, N, device="cuda")                      # grouped launch, same switch
         ops._gemm_group([(Ast, lda, Bst, ldb, split.new_empty(M, N), N, None, None, 0, M, N, K, 0),
                          (Ast, lda, Bst, ldb, C2, N, None, None, 0, M, N, K, 0)], a_kc, b_kc)
         assert torch.equal(C2, split), "grouped bf16x6 launch differs from the single launch"
-    monkeypatch.delenv("RT_GEMM_SPLIT")
+    monkeypatch.setenv("RT_GEMM_SPLIT", "exact")
     assert torch.equal(run(), exact), "the switch must not leak into the exact kernel"
     e_exact = float(((exact.double() - ref).abs() / scale).max())
     e_split = float(((split.double() - ref).abs() / scale).max())
