@@ -114,6 +114,11 @@ int rt_topk_rescore(const float* users, int64_t user_stride, const int64_t* user
  * slabs in a fixed order into C (deterministic, no float atomics; R / relu then not allowed).
  * a_rowsum (optional, [M]; row-contiguous A only): also returns sum_k A(m,k) — the bias gradient db = colsum(dy)
  * of a wgrad product dW = dy^T x, taken from the A tiles already staged in LDS (no second pass over dy).
+ * Arithmetic: fp32 in, fp32 accumulate, fp32 out.  On exact tile grids (M, N multiples of 128, K of 32, 16-byte aligned
+ * operands) every fp32 product is formed as six bf16 matrix-pipe products of an EXACT 3-way bf16 split of both operands
+ * (all terms down to 2^-16 relative; what is dropped is below one fp32 rounding of the product) — error against an fp64
+ * product at or below that of the f32-input MFMA (v_mfma_f32_32x32x2_f32), which ragged shapes use and which the
+ * environment variable RT_GEMM_SPLIT=exact selects everywhere.
  * ------------------------------------------------------------------------------------------------ */
 size_t rt_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t split_k);
 int rt_gemm(const float* A, int64_t lda, int32_t a_kc, const float* B, int64_t ldb, int32_t b_kc,
