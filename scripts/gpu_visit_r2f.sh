@@ -3,10 +3,10 @@
 cd /root/repo; O=gpurun_out/${1:-r2f}; mkdir -p $O
 export TMPDIR=/tmp
 timeout 300 python -m pytest tests/test_ops_gpu.py -q -m gpu -k "bf16x6 or gemm or linear" -x 2>&1 | tail -5 | tee $O/pytest_bf16x6.txt
-timeout 200 python scripts/gemm_bench.py 2>&1 | tail -6 | tee $O/gemm_bench_exact.txt
-RT_GEMM_SPLIT=bf16x6 timeout 200 python scripts/gemm_bench.py 2>&1 | tail -6 | tee $O/gemm_bench_bf16x6.txt
-timeout 200 python bench.py --workload train --steps 100 --no-cpu-baseline > $O/bench_train_exact.json 2> $O/bench_train_exact.err
-RT_GEMM_SPLIT=bf16x6 timeout 200 python bench.py --workload train --steps 100 --no-cpu-baseline > $O/bench_train_bf16x6.json 2> $O/bench_train_bf16x6.err
+RT_GEMM_SPLIT=exact timeout 200 python scripts/gemm_bench.py 2>&1 | tail -6 | tee $O/gemm_bench_exact.txt
+timeout 200 python scripts/gemm_bench.py 2>&1 | tail -6 | tee $O/gemm_bench_bf16x6.txt
+RT_GEMM_SPLIT=exact timeout 200 python bench.py --workload train --steps 100 --no-cpu-baseline > $O/bench_train_exact.json 2> $O/bench_train_exact.err
+timeout 200 python bench.py --workload train --steps 100 --no-cpu-baseline > $O/bench_train_bf16x6.json 2> $O/bench_train_bf16x6.err
 python - $O <<'P'
 import json, sys
 for t in ("exact", "bf16x6"):
