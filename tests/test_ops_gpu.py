@@ -467,6 +467,31 @@ def test_flat_adam_segments_match_torch_adam():
 
 
 @pytest.mark.gpu
+def test_flat_adam_more_segments_than_one_launch_with_missing_gradients():
+    """rt_adam_step_segments batches 48 segments per launch and skips parameters without a gradient: a skipped segment must
+    not make the next launch revisit segments of the previous one (a second Adam update in one step)."""
+    from rectools_amd import lightning as hl
+
+    torch.manual_seed(1)
+    shapes = [(3 + i % 5, 4) if i % 3 else (17 + i,) for i in range(110)]            # 110 segments = 3 launches
+    no_grad = {0, 7, 46, 47, 48, 49, 95, 96, 109}                                     # around both batch boundaries
+    ref_params = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    mine = torch.nn.ParameterList([torch.nn.Parameter(p.detach().clone().cuda()) for p in ref_params])
+    ref_opt = torch.optim.Adam(ref_params, lr=1e-2, betas=(0.9, 0.98), eps=1e-8)
+    opt = hl.FlatAdam(mine, lr=1e-2, betas=(0.9, 0.98), eps=1e-8)
+    for step in range(2):
+        opt.zero_grad(); ref_opt.zero_grad(set_to_none=True)
+        for i, (p, q) in enumerate(zip(ref_params, mine)):
+            if i in no_grad:
+                continue
+            gr = torch.randn(p.shape, generator=torch.Generator().manual_seed(1000 * step + i))
+            p.grad = gr.clone(); q.grad = gr.cuda()
+        opt.step(); ref_opt.step()
+    for i, (p, q) in enumerate(zip(ref_params, mine)):
+        torch.testing.assert_close(q.detach().cpu(), p.detach(), rtol=1e-5, atol=1e-7, msg=f"parameter {i}")
+
+
+@pytest.mark.gpu
 def test_side_stream_weight_gradients_survive_accumulation_and_parameter_slices():
     """Weight-gradient GEMMs run on a second HIP stream.  They may stay in flight until the end of the backward pass only
     when autograd merely adopts the tensors; accumulating into an existing `.grad` (second backward without zeroing) and
