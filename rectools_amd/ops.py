@@ -9,6 +9,7 @@ All activations are 2-D `[M, d]` (M = batch * session_max_len).
 from __future__ import annotations
 
 import math
+import os
 import typing as tp
 
 import torch
@@ -194,12 +195,15 @@ def _gemm_group(problems: tp.Sequence[tp.Tuple], a_kc: int, b_kc: int) -> None:
        tag=(sum(p[9] * p[10] * p[11] for p in problems), 1, 1))
 
 
+_WGRAD_SPLIT_CAP = int(os.environ.get("RT_WGRAD_SPLITS", "64"))   # experiment knob: upper bound of the wgrad split-K factor
+
+
 def _wgrad_splits(k_rows: int, out_rows: int = 0, out_cols: int = 0) -> int:
     """Split-K factor of a weight-gradient product dW [out_rows, out_cols] = sum over k_rows.  Small outputs (256 x 256 = 4
     tiles at C2) need every slice they can get to fill 256 CUs; large ones (eSASRec's 2048 x 512 = 64 tiles) were cut into 64
     slices of 12 k-steps each, 4096 workgroups whose slab writes and 64-way combine cost more than the parallelism bought:
     aim at ~6 workgroups per CU."""
-    sp = max(1, min(64, k_rows // 384))
+    sp = max(1, min(_WGRAD_SPLIT_CAP, k_rows // 384))
     if out_rows > 0 and out_cols > 0:
         tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
         sp = max(1, min(sp, -(-1536 // tiles)))
