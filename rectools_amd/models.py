@@ -412,27 +412,67 @@ class TransformerModelBase:
                 outs.append(lm.torch_model.encode_last(batch, item_embs))
         return torch.cat(outs) if outs else torch.zeros((0, self.n_factors), device=device)
 
-    def _device_interactions(self, dataset: tp.Any, device: torch.device) -> tp.Tuple[torch.Tensor, ...]:
-        """(user, item, time, weight) columns of `dataset.interactions.df` resident in HBM.  Uploading them was 30 of the 104 ms of
-        a 16,384-user recommend() at ML-20M scale (19.8 M rows: 555 MB over PCIe + a float64 -> float32 pass); a Dataset is not
-        mutated after construction, so the device copies are kept on its `interactions` object per device and reused by later
-        calls (the frame's identity and length are checked)."""
-        inter = dataset.interactions
+    @staticmethod
+    def _build_session_index(u_t: torch.Tensor, i_t: torch.Tensor, t_t: torch.Tensor, w_t: torch.Tensor, lookup_t: torch.Tensor,
+                             n_users: int, V: int) -> tp.Tuple[torch.Tensor, ...]:
+        """Session store + viewed-items CSR of EVERY user of a Dataset, on the device the columns live on (plain tensor ops).
+
+        Rows = the Dataset's internal user ids.  Items are model ids (`lookup_t`: dataset item id -> model item id, -1 = unknown
+        to the model, dropped); a user's interactions keep the reference's session order — stable sort by time, grouped by
+        user (data_preparator.py:73-99); the CSR holds each user's DISTINCT items ascending (dataset.py:314-348)."""
+        mitem = lookup_t[i_t]
+        keep = mitem >= 0
+        u, m, t, w = u_t[keep], mitem[keep], t_t[keep], w_t[keep]
+        o1 = torch.sort(t, stable=True).indices
+        o2 = torch.sort(u[o1], stable=True).indices
+        order = o1[o2]
+        u_s, item_s, w_s = u[order], m[order], w[order]
+        offsets = torch.zeros((n_users + 1,), dtype=torch.int64, device=u_t.device)
+        torch.cumsum(torch.bincount(u_s, minlength=n_users), 0, out=offsets[1:])
+        key = torch.unique(u_s * V + item_s)                         # sorted: (user, item) pairs, distinct
+        frow = torch.div(key, V, rounding_mode="floor")
+        indptr = torch.zeros((n_users + 1,), dtype=torch.int64, device=u_t.device)
+        torch.cumsum(torch.bincount(frow, minlength=n_users), 0, out=indptr[1:])
+        indices = (key - frow * V).to(torch.int32)
+        return offsets, item_s, w_s, indptr, indices
+
+    @staticmethod
+    def _select_csr_rows(indptr: torch.Tensor, indices: torch.Tensor, rows: torch.Tensor) -> tp.Tuple[torch.Tensor, torch.Tensor]:
+        """CSR of the given rows, in the given order (indices of a row stay ascending)."""
+        lens = indptr[rows + 1] - indptr[rows]
+        new_indptr = torch.zeros((rows.numel() + 1,), dtype=torch.int64, device=indptr.device)
+        torch.cumsum(lens, 0, out=new_indptr[1:])
+        total = int(new_indptr[-1])
+        src = torch.repeat_interleave(indptr[rows] - new_indptr[:-1], lens, output_size=total) \
+            + torch.arange(total, dtype=torch.int64, device=indptr.device)
+        return new_indptr, indices[src]
+
+    def _device_session_index(self, dataset: tp.Any, device: torch.device) -> tp.Tuple[torch.Tensor, ...]:
+        """`_build_session_index` of `dataset` for this model's item map, resident in HBM.  At ML-20M scale (19.8 M rows) the
+        per-call upload (555 MB over PCIe), the float64 -> float32 pass and the filter / sort / unique over the whole table were
+        most of what a 16,384-user recommend() spent outside the encoder; neither a Dataset nor a fitted model's item map is
+        mutated after construction, so the index is built by the first call and kept on the Dataset's `interactions` object
+        (per device and item map; the objects the key names are referenced by the cache entry, so an id cannot be reused
+        while the entry lives).  The raw columns are only temporaries of the build."""
+        inter, dp = dataset.interactions, self.data_preparator
         df = inter.df
-        key = (str(device), id(df), len(df))
-        cache = getattr(inter, "_rt_device_columns", None)
+        key = (str(device), id(df), len(df), id(dp.item_id_map), id(dataset.item_id_map), id(dataset.user_id_map))
+        cache = getattr(inter, "_rt_session_index", None)
         if cache is not None and cache[0] == key:
             return cache[1]
         to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device, non_blocking=True)  # noqa: E731
-        cols = (to_dev(df[Columns.User].values.astype(np.int64, copy=False)),
-                to_dev(df[Columns.Item].values.astype(np.int64, copy=False)),
-                to_dev(df[Columns.Datetime].values.astype("datetime64[ns]").view(np.int64)),
-                to_dev(df[Columns.Weight].values.astype(np.float32, copy=False)))
+        # dataset item id -> model item id (-1: unknown to the model)
+        lookup = pd.Series(dp.item_id_map.to_internal).reindex(dataset.item_id_map.external_ids).fillna(-1).values.astype(np.int64)
+        index = self._build_session_index(
+            to_dev(df[Columns.User].values.astype(np.int64, copy=False)), to_dev(df[Columns.Item].values.astype(np.int64, copy=False)),
+            to_dev(df[Columns.Datetime].values.astype("datetime64[ns]").view(np.int64)),
+            to_dev(df[Columns.Weight].values.astype(np.float32, copy=False)), to_dev(lookup),
+            dataset.user_id_map.size, dp.item_id_map.size)
         try:
-            inter._rt_device_columns = (key, cols)   # pylint: disable=protected-access
+            inter._rt_session_index = (key, index, (df, dp.item_id_map, dataset.item_id_map, dataset.user_id_map))   # pylint: disable=protected-access
         except AttributeError:   # a duck-typed Interactions object with __slots__: no cache
             pass
-        return cols
+        return index
 
     def _encode_batch_size(self) -> int:
         """Sessions per encoder launch in recommend().  `recommend_batch_size` (reference default 256) is a memory knob of the
@@ -520,14 +560,13 @@ class TransformerModelBase:
                                items_to_recommend: tp.Optional[tp.Any], add_rank_col: bool,
                                on_unsupported_targets: str) -> tp.Optional[pd.DataFrame]:
         """recommend() without the pandas / scipy round trips of the reference's glue (`models/base.py:
-        502-519,735-791`, `data_preparator.py:354-424`, `dataset.py:314-348`): the interactions table is uploaded once,
-        and filtering to (requested users x known items), the time-ordered session store, the viewed-items CSR and the
-        user encodings are all produced on the device.  Same rows, order and values as the reference-shaped path below
-        (tests/test_models_gpu.py compares the two).  Returns None when the request needs that path (duplicated users)."""
+        502-519,735-791`, `data_preparator.py:354-424`, `dataset.py:314-348`): the Dataset's time-ordered session store and
+        viewed-items CSR (known items only) are built ONCE on the device (`_device_session_index`); a call selects the requested
+        users' rows from them, encodes and ranks on the device.  Same rows, order and values as the reference-shaped path
+        below (tests/test_models_gpu.py compares the two).  Returns None when the request needs that path (duplicated users)."""
         dp, lm = self.data_preparator, self.lightning_model
         assert lm is not None
         device = next(lm.parameters()).device
-        df = dataset.interactions.df
         req = dataset.user_id_map.convert_to_internal(users, strict=False)
         if len(np.unique(req)) != len(req):
             return None
@@ -535,34 +574,18 @@ class TransformerModelBase:
         empty = self._frame(np.array([], users.dtype), np.array([], object), np.array([], np.float32), add_rank_col, Columns.User)
         if len(req) == 0 or len(whitelist) == 0:
             return empty
-        # dataset item id -> model item id (-1: unknown to the model); small host map, the rest happens on the device
-        lookup = pd.Series(dp.item_id_map.to_internal).reindex(dataset.item_id_map.external_ids).fillna(-1).values.astype(np.int64)
-        n_ds_users, n_req, V = dataset.user_id_map.size, len(req), dp.item_id_map.size
-        to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device, non_blocking=True)  # noqa: E731
-        u_t, i_t, t_t, w_t = self._device_interactions(dataset, device)
-        req_row = torch.full((n_ds_users,), -1, dtype=torch.int64, device=device)
-        req_row[to_dev(req.astype(np.int64))] = torch.arange(n_req, dtype=torch.int64, device=device)
-        row = req_row[u_t]
-        mitem = to_dev(lookup)[i_t]
-        keep = (row >= 0) & (mitem >= 0)
-        row, mitem, t_k, w_k = row[keep], mitem[keep], t_t[keep], w_t[keep]
-        # the reference's session order: stable sort by time, then grouped by user (data_preparator.py:73-99)
-        o1 = torch.sort(t_k, stable=True).indices
-        o2 = torch.sort(row[o1], stable=True).indices
-        order = o1[o2]
-        row_s, item_s, w_s = row[order], mitem[order], w_k[order]
-        counts = torch.bincount(row_s, minlength=n_req)
-        valid = counts > 0
-        n_valid = int(valid.sum())
+        n_req, V = len(req), dp.item_id_map.size
+        offsets, item_s, w_s, f_indptr, f_indices = self._device_session_index(dataset, device)
+        req_t = torch.from_numpy(np.ascontiguousarray(req.astype(np.int64))).to(device, non_blocking=True)
+        valid = (offsets[req_t + 1] - offsets[req_t]) > 0            # users with at least one item the model knows
+        valid_rows = req_t[valid]                                   # rows of the session index, request order
+        n_valid = int(valid_rows.numel())
         n_cold = n_req - n_valid
         if n_cold > 0 and on_unsupported_targets != "ignore":
             warnings.warn(f"{n_cold} target users were considered cold because of missing known items")
         if n_valid == 0:
             return empty
-        offsets = torch.zeros((n_req + 1,), dtype=torch.int64, device=device)
-        torch.cumsum(counts, 0, out=offsets[1:])
         dstore = DeviceSequenceStore.from_device(offsets, item_s, w_s, None)
-        valid_rows = torch.nonzero(valid).reshape(-1)
         item_embs = self._item_embeddings()
         outs = []
         with torch.no_grad():
@@ -574,12 +597,7 @@ class TransformerModelBase:
         ranker = HipRanker(lm.torch_model.similarity_module.distance, device, user_embs, item_embs)
         filt = None
         if filter_viewed:  # CSR of the distinct (user, item) pairs, rows in request order, indices ascending
-            new_row = torch.cumsum(valid.to(torch.int64), 0) - 1
-            key = torch.unique(new_row[row_s] * V + item_s)          # sorted
-            frow = torch.div(key, V, rounding_mode="floor")
-            indptr = torch.zeros((n_valid + 1,), dtype=torch.int64, device=device)
-            torch.cumsum(torch.bincount(frow, minlength=n_valid), 0, out=indptr[1:])
-            indices = (key - frow * V).to(torch.int32)
+            indptr, indices = self._select_csr_rows(f_indptr, f_indices, valid_rows)
             if indices.numel() == 0:
                 indices = torch.zeros((1,), dtype=torch.int32, device=device)
             filt = DeviceCSR(indptr, indices, (n_valid, V))

@@ -547,3 +547,45 @@ def test_array_fast_path_equals_frame_path(seed, string_ids, with_ts, bert, val,
         pd.testing.assert_frame_equal(fast.val_interactions.reset_index(drop=True), slow.val_interactions.reset_index(drop=True))
     else:
         assert fast.val_interactions is None and slow.val_interactions is None
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_recommend_session_index_equals_per_request_construction(seed):
+    """recommend()'s device glue selects the requested users from a session store + viewed-items CSR built once per Dataset
+    (`models._build_session_index`, `_select_csr_rows`: plain tensor ops, run here on CPU tensors).  They must equal what the
+    reference's per-call glue produces for any request: interactions filtered to (requested users x items the model knows),
+    stable sort by time, grouped by user (data_preparator.py:73-99, 354-424), and the distinct items per user ascending
+    (dataset.py:314-348)."""
+    from rectools_amd.models import TransformerModelBase as M
+
+    rng = np.random.default_rng(seed)
+    n_users, n_ds_items, V, n = 40, 30, 25, 600
+    u = rng.integers(0, n_users, n); u[u == 7] = 8                         # user 7 has no interactions at all
+    i = rng.integers(0, n_ds_items, n)
+    t = rng.integers(0, 50, n)                                             # many equal timestamps: stability matters
+    w = rng.random(n).astype(np.float32)
+    lookup = rng.permutation(np.r_[np.arange(1, V), -np.ones(n_ds_items - V + 1, np.int64)])   # some dataset items unknown
+    i[u == 11] = int(np.flatnonzero(lookup < 0)[0])                        # user 11 only has unknown items -> cold
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))                # noqa: E731
+    offsets, items, weights, indptr, indices = M._build_session_index(T(u), T(i), T(t), T(w), T(lookup), n_users, V)
+    for req in (rng.permutation(n_users)[:17], np.array([7, 11, 3]), np.arange(n_users)):
+        # ---- the per-request construction (numpy restatement of the reference-shaped glue)
+        exp_sessions, exp_w, exp_filter = [], [], []
+        for r in req:
+            rows = np.flatnonzero((u == r) & (lookup[i] >= 0))
+            rows = rows[np.argsort(t[rows], kind="stable")]
+            exp_sessions.append(lookup[i[rows]]); exp_w.append(w[rows]); exp_filter.append(np.unique(lookup[i[rows]]))
+        # ---- selection from the index
+        req_t = T(req.astype(np.int64))
+        valid = (offsets[req_t + 1] - offsets[req_t]) > 0
+        assert valid.tolist() == [len(s_) > 0 for s_ in exp_sessions]
+        rows = req_t[valid]
+        for r, es, ew in zip(req, exp_sessions, exp_w):
+            got = items[offsets[r]:offsets[r + 1]].numpy()
+            assert np.array_equal(got, es), f"session of user {r}"
+            assert np.array_equal(weights[offsets[r]:offsets[r + 1]].numpy(), ew)
+        sub_ptr, sub_idx = M._select_csr_rows(indptr, indices, rows)
+        exp_valid = [f for f in exp_filter if len(f)]
+        assert sub_ptr.tolist() == np.r_[0, np.cumsum([len(f) for f in exp_valid])].tolist()
+        assert sub_idx.dtype == torch.int32
+        assert np.array_equal(sub_idx.numpy(), np.concatenate(exp_valid) if exp_valid else np.array([], np.int32))
