@@ -280,9 +280,14 @@ def run_train(args, rank, world, kind="train"):
 
     def step():
         state["loss"] = loop.step()
+        state["seqs"].append(loop.sequences_done)
 
+    state["seqs"] = []
     wall, ev_ms = timed_steps(step, args.steps, args.warmup, world)
-    value = B * args.steps * world / wall
+    # sequences of the timed steps as counted by the loop (an epoch's last batch is short: 17,312 sessions per rank at 8 ranks
+    # = 135 full batches + 32 sessions); every rank holds an equally long shard, so the job total is this rank's count x ranks
+    seqs = state["seqs"][args.warmup + args.steps - 1] - (state["seqs"][args.warmup - 1] if args.warmup > 0 else 0)
+    value = seqs * world / wall
     # ---- roofline pass: 3 more steps with HIP events (on the launch stream) around every rt_* call.  By default the
     # weight-gradient products stay on their side stream, as in the timed region (durations then include the overlap, and
     # agree with rocprofv3 of this command); `single_stream_ms` repeats the pass with everything on one stream.

@@ -80,6 +80,7 @@ class _TrainLoop:
         self.epoch = -1
         self.mine_t: tp.Optional[torch.Tensor] = None
         self.pos = 0
+        self.sequences_done = 0   # sessions consumed by step() so far (the last batch of an epoch may be short)
 
     def begin_epoch(self, epoch: int) -> None:
         perm = epoch_permutation(len(self.store), epoch, self.seed, self.dp.shuffle_train)
@@ -95,6 +96,7 @@ class _TrainLoop:
         if self.batches_left() == 0:
             self.begin_epoch(self.epoch + 1)
         idx = self.mine_t[self.pos:self.pos + self.batch_size]
+        self.sequences_done += min(self.batch_size, int(self.mine_t.numel()) - self.pos)
         self.pos += self.batch_size
         batch = self.dp.add_negatives(self.dp.collate_train_device(self.dstore, idx))
         ops.RNG.next_step()

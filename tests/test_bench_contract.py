@@ -15,7 +15,7 @@ REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 def _lines():
     prof = os.path.join(ROOT, "profiles")
     for name in sorted(os.listdir(prof)):
-        if name.startswith("r1_bench_") and name.endswith(".json"):
+        if name[:1] == "r" and "_bench_" in name[:12] and name.endswith(".json"):     # r1_bench_*.json, r2_bench_*.json, ...
             text = [l for l in open(os.path.join(prof, name)).read().splitlines() if l.startswith("{")]
             assert len(text) == 1, f"{name}: rank 0 must print exactly ONE JSON line"
             yield name, json.loads(text[0])
