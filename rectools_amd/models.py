@@ -91,13 +91,19 @@ class _TrainLoop:
     def batches_left(self) -> int:
         return 0 if self.mine_t is None else -(-(int(self.mine_t.numel()) - self.pos) // self.batch_size)
 
-    def step(self) -> torch.Tensor:
-        """One training step on the next batch of the current epoch (rolls over to the next epoch when it is used up)."""
+    def _next_indices(self) -> torch.Tensor:
+        """Session indices of the next batch (rolls over to the next epoch when the current one is used up)."""
         if self.batches_left() == 0:
             self.begin_epoch(self.epoch + 1)
+        assert self.mine_t is not None
         idx = self.mine_t[self.pos:self.pos + self.batch_size]
-        self.sequences_done += min(self.batch_size, int(self.mine_t.numel()) - self.pos)
+        self.sequences_done += int(idx.numel())
         self.pos += self.batch_size
+        return idx
+
+    def step(self) -> torch.Tensor:
+        """One training step on the next batch of the current epoch (rolls over to the next epoch when it is used up)."""
+        idx = self._next_indices()
         batch = self.dp.add_negatives(self.dp.collate_train_device(self.dstore, idx))
         ops.RNG.next_step()
         self.opt.zero_grad()

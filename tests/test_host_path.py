@@ -589,3 +589,23 @@ def test_recommend_session_index_equals_per_request_construction(seed):
         assert sub_ptr.tolist() == np.r_[0, np.cumsum([len(f) for f in exp_valid])].tolist()
         assert sub_idx.dtype == torch.int32
         assert np.array_equal(sub_idx.numpy(), np.concatenate(exp_valid) if exp_valid else np.array([], np.int32))
+
+
+def test_train_loop_batches_roll_over_epochs_and_count_sequences():
+    """`models._TrainLoop._next_indices`: batches of an epoch's shard in order, a short last batch, roll-over into the next epoch
+    and the running count of consumed sessions (what bench.py divides by the wall clock)."""
+    from rectools_amd import models
+
+    loop = models._TrainLoop.__new__(models._TrainLoop)
+    loop.batch_size, loop.epoch, loop.mine_t, loop.pos, loop.sequences_done = 4, -1, None, 0, 0
+    shards = {0: torch.arange(10), 1: torch.arange(100, 106)}
+
+    def begin_epoch(epoch):
+        loop.mine_t, loop.epoch, loop.pos = shards[epoch], epoch, 0
+
+    loop.begin_epoch = begin_epoch
+    got, counts = [], []
+    for _ in range(5):
+        got.append(loop._next_indices().tolist()); counts.append(loop.sequences_done)
+    assert got == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9], [100, 101, 102, 103], [104, 105]]
+    assert counts == [4, 8, 10, 14, 16] and loop.epoch == 1 and loop.batches_left() == 0
