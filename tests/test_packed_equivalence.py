@@ -32,24 +32,25 @@ def _params(d, H, n_blocks, L, V, seed):
     return p
 
 
-def _padded(p, x, n_blocks, H):
+def _padded(p, x, n_blocks, H, keypad=False):
     """The reference-shaped computation (oracle): embeddings + inverse positions, SASRec blocks on the padded window."""
     L = x.shape[1]
     seqs = p["emb"][x] + p[T.POS_EMB][torch.arange(L - 1, -1, -1)][None]
     tl = (x != 0).unsqueeze(-1).to(seqs.dtype)
-    mask = T.attention_mask(x, True, False).to(seqs.dtype)
+    mask = T.attention_mask(x, True, keypad).to(seqs.dtype)
     return T.sasrec_layers(seqs, tl, mask, p, n_blocks, H)
 
 
-def _packed(p, x, n_blocks, H):
-    """Only the real rows of every session; the pads enter as one virtual key with multiplicity n_pad."""
+def _packed(p, x, n_blocks, H, keypad=False):
+    """Only the real rows of every session; the pads enter as one virtual key with multiplicity n_pad (none under key-padding
+    masks: the reference hides them from every real query, torch_backbone.py:254)."""
     B, L = x.shape
     d = p["emb"].shape[1]
     hd = d // H
     outs = []
     for b in range(B):
         ids = x[b][x[b] != 0]
-        n, n_pad = len(ids), L - len(ids)
+        n, n_pad = len(ids), (0 if keypad else L - len(ids))
         if n == 0:
             outs.append(torch.zeros(0, d, dtype=p["emb"].dtype))
             continue
@@ -78,8 +79,9 @@ def _packed(p, x, n_blocks, H):
     return outs
 
 
+@pytest.mark.parametrize("keypad", [False, True])
 @pytest.mark.parametrize("seed,H,n_blocks", [(0, 2, 2), (1, 1, 1), (2, 4, 3)])
-def test_packed_sasrec_stack_equals_padded_reference(seed, H, n_blocks):
+def test_packed_sasrec_stack_equals_padded_reference(seed, H, n_blocks, keypad):
     d, L, V, B = 16, 12, 30, 6
     g = torch.Generator().manual_seed(100 + seed)
     lens = [L, 1, 5, 0, 9, 2]                                      # full, single item, typical, empty, ...
@@ -90,14 +92,14 @@ def test_packed_sasrec_stack_equals_padded_reference(seed, H, n_blocks):
     p = _params(d, H, n_blocks, L, V, seed)
     gout = torch.randn(B, L, d, generator=g, dtype=torch.float64)
 
-    full = _padded(p, x, n_blocks, H)
+    full = _padded(p, x, n_blocks, H, keypad)
     real = x != 0
     (full * gout)[real].sum().backward()
     grads_padded = {k: v.grad.clone() for k, v in p.items()}
     for v in p.values():
         v.grad = None
 
-    packed = _packed(p, x, n_blocks, H)
+    packed = _packed(p, x, n_blocks, H, keypad)
     loss = sum((o * gout[b][real[b]]).sum() for b, o in enumerate(packed))
     loss.backward()
     for b, o in enumerate(packed):
