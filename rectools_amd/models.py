@@ -648,11 +648,25 @@ class TransformerModelBase:
 
     def _assemble(self, ext_users: np.ndarray, ids: torch.Tensor, scores: torch.Tensor, counts: torch.Tensor, add_rank_col: bool,
                   target_col: str) -> pd.DataFrame:
-        ids, scores, counts = ids.cpu().numpy(), scores.cpu().numpy(), counts.cpu().numpy()
-        kk = ids.shape[1]
+        return self._assemble_frame(ext_users, ids.cpu().numpy(), scores.cpu().numpy(), counts.cpu().numpy(),
+                                    self.data_preparator.item_id_map, add_rank_col, target_col)
+
+    @staticmethod
+    def _assemble_frame(ext_users: np.ndarray, ids: np.ndarray, scores: np.ndarray, counts: np.ndarray, item_id_map: tp.Any,
+                        add_rank_col: bool, target_col: str) -> pd.DataFrame:
+        """Ranker output ([n, k] ids / scores, valid entries leading every row, `counts` of them) -> the reference's long frame
+        (models/base.py:735-791).  When every row is full — the usual case — the mask, the masked gathers and the running count
+        are skipped (half of the 5 ms this takes for 16,384 x 10)."""
+        n, kk = ids.shape
+        if n and bool((counts >= kk).all()) and bool((scores > -np.inf).all()):
+            df = pd.DataFrame({target_col: np.repeat(ext_users, kk), Columns.Item: item_id_map.convert_to_external(ids.reshape(-1)),
+                               Columns.Score: scores.reshape(-1).astype(np.float32, copy=False)})
+            if add_rank_col:
+                df[Columns.Rank] = np.tile(np.arange(1, kk + 1, dtype=np.int64), n)
+            return df
         valid = (np.arange(kk)[None, :] < counts[:, None]) & (scores > -np.inf)
         tt = np.repeat(ext_users, kk).reshape(len(ext_users), kk)[valid]
-        ii = self.data_preparator.item_id_map.convert_to_external(ids[valid])
+        ii = item_id_map.convert_to_external(ids[valid])
         df = pd.DataFrame({target_col: tt, Columns.Item: ii, Columns.Score: scores[valid].astype(np.float32)})
         if add_rank_col:  # valid entries lead every row: rank = running count inside the row (models/base.py:788-789)
             df[Columns.Rank] = (np.cumsum(valid, axis=1)[valid]).astype(np.int64)

@@ -609,3 +609,30 @@ def test_train_loop_batches_roll_over_epochs_and_count_sequences():
         got.append(loop._next_indices().tolist()); counts.append(loop.sequences_done)
     assert got == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9], [100, 101, 102, 103], [104, 105]]
     assert counts == [4, 8, 10, 14, 16] and loop.epoch == 1 and loop.batches_left() == 0
+
+
+@pytest.mark.parametrize("add_rank", [True, False])
+def test_assemble_frame_fast_path_equals_the_masked_path(add_rank):
+    """`models._assemble_frame`: the all-rows-full shortcut must build the frame the general (masked) path builds, and rows that
+    are not full (fewer candidates than k, -inf scores) must take the general path."""
+    from rectools_amd.dataset import Columns, IdMap
+    from rectools_amd.models import TransformerModelBase as M
+
+    rng = np.random.default_rng(0)
+    n, k, V = 50, 6, 40
+    item_map = IdMap(np.arange(V) * 2 + 100)
+    ids = rng.integers(0, V, (n, k)); scores = -np.sort(-rng.random((n, k)).astype(np.float32), 1)
+    users = np.array([f"u{i}" for i in range(n)], dtype=object)
+    full = M._assemble_frame(users, ids, scores, np.full(n, k, np.int32), item_map, add_rank, Columns.User)
+    # the same data through the masked path: one extra, invalid column makes no row "full"
+    ids2 = np.c_[ids, np.zeros(n, np.int64)]; scores2 = np.c_[scores, np.full(n, -np.inf, np.float32)]
+    masked = M._assemble_frame(users, ids2, scores2, np.full(n, k, np.int32), item_map, add_rank, Columns.User)
+    pd.testing.assert_frame_equal(full, masked)
+    assert len(full) == n * k and full[Columns.Score].dtype == np.float32
+    if add_rank:
+        assert full[Columns.Rank].dtype == np.int64 and full[Columns.Rank].tolist()[:k] == list(range(1, k + 1))
+    counts = np.full(n, k, np.int32); counts[3] = 2
+    short = M._assemble_frame(users, ids, scores, counts, item_map, add_rank, Columns.User)
+    assert len(short) == n * k - (k - 2) and (short[Columns.User] == "u3").sum() == 2
+    empty = M._assemble_frame(users[:0], ids[:0], scores[:0], counts[:0], item_map, add_rank, Columns.User)
+    assert len(empty) == 0
