@@ -278,6 +278,37 @@ int rt_mha_last_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, co
                     int32_t B, int32_t H, int32_t L, int32_t hd, int32_t causal, int32_t keypad, float* o, int64_t ldo,
                     rt_stream_t stream);
 
+/* K4v  The same causal softmax attention over PACKED sessions (no padding rows; forward only — the recommend() encoder).  Session b
+ * owns rows cu_seqlens[b] .. cu_seqlens[b+1]-1 of q / k / v / o, oldest item first.  What the reference's left-padded window adds
+ * (torch_backbone.py:245-260, sasrec.py:186-231: pad keys are visible to every real query of a causal SASRec block) is closed-form:
+ * a pad key / value row equals the projection bias in every session and block (the block input is masked to 0), so ONE virtual
+ * key per query — logit q.bk / sqrt(hd), value bv, multiplicity window - n_b — reproduces the padded softmax.  bk / bv [H*hd] =
+ * in_proj_bias[d:2d] / [2d:3d]; pass NULL for both when pad keys are masked (key-padding masks).  max_len >= the longest session
+ * (sizes the LDS image; RT_ERR_UNSUPPORTED when 2 * roundup32(max_len) * (hd + 1) floats exceed 160 KB: take the padded entry
+ * points then); window = the reference's session_max_len.  rt_mha_varlen_fwd: hd in {32, 64}. */
+int rt_mha_varlen_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                      const int64_t* cu_seqlens, const float* bk, const float* bv, int32_t B, int32_t H, int32_t hd,
+                      int32_t max_len, int32_t window, float* o, int64_t ldo, rt_stream_t stream);
+/* Training pair of the packed attention.  Forward: + attention dropout (counter-based masks keyed by (seed, session*H + head,
+ * query, key pair), numbered inside the session; the window's pad keys are dropped one by one like real keys, numbered behind
+ * them) and lse [N, H].  Backward: dq / dk / dv rows of the sessions fully overwritten; delta [N, H] workspace; dbv_part
+ * [B, H*hd] (or NULL) receives per-session partials of the value-bias gradient contributed by the pad keys — sum over B and add
+ * to the bias gradient of the real rows.  The key-bias gradient of the padded window is identically zero (b_k shifts every logit
+ * of a query alike), so a caller on packed rows zeroes it instead of taking colsum(dk). */
+int rt_mha_varlen_train_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                            const int64_t* cu_seqlens, const float* bk, const float* bv, int32_t B, int32_t H, int32_t hd,
+                            int32_t max_len, int32_t window, float p_drop, uint64_t seed, float* o, int64_t ldo, float* lse,
+                            rt_stream_t stream);
+int rt_mha_varlen_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* o, int64_t ldo,
+                      const float* dout, int64_t lddo, const float* lse, const int64_t* cu_seqlens, const float* bk, const float* bv,
+                      int32_t B, int32_t H, int32_t hd, int32_t max_len, int32_t window, float p_drop, uint64_t seed, float* dq,
+                      int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv, float* delta, float* dbv_part,
+                      rt_stream_t stream);
+/* ... for the LAST query of every session only: q [B, ldq] one projected query row per session, o [B, ldo] (cf. rt_mha_last_fwd) */
+int rt_mha_varlen_last_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                           const int64_t* cu_seqlens, const float* bk, const float* bv, int32_t B, int32_t H, int32_t hd,
+                           int32_t max_len, int32_t window, float* o, int64_t ldo, rt_stream_t stream);
+
 /* K5/K6  HSTU pointwise attention with in-kernel relative time/position bias (hstu.py:84-128, 270-288).
  * ts [B,L+1] int64 (NULL: no time bias); time_w [129]; time_thr [129] = smallest |dt| of each bucket, computed on
  * the host with the reference's float32 log(|dt|)/0.301 truncation; pos_w [2L-1] (NULL: no position bias).

@@ -25,12 +25,6 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_version": (c_i32, []),
     "rt_device_cu_count": (c_i32, []),
     "rt_last_error": (ctypes.c_char_p, []),
-    "rt_dp_unique_id": (c_i32, [c_vp]),
-    "rt_dp_init": (c_i32, [c_vp, c_i32, c_i32, c_vp]),
-    "rt_dp_allreduce": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
-    "rt_dp_broadcast": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp]),
-    "rt_dp_finalize": (c_i32, [c_vp]),
-    "rt_dp_last_error": (ctypes.c_char_p, []),
     "rt_topk_workspace_bytes": (c_sz, [c_i32, c_i64, c_i32, c_i32]),
     "rt_filter_hash_bytes": (c_sz, [c_i32, c_i64]),
     "rt_filter_hash_build": (c_i32, [c_vp, c_vp, c_i32, c_i64, c_vp, c_vp]),
@@ -54,8 +48,7 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_layernorm_fwd_masked": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rt_layernorm_bwd_workspace_bytes": (c_sz, [c_i32, c_i32]),
     "rt_layernorm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
-    "rt_layernorm_bwd_fused": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp,
-                                       c_sz, c_vp]),
+    "rt_layernorm_bwd_fused": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "rt_act_dropout_fwd": (c_i32, [c_vp, c_i32, c_f32, c_u64, c_u64, c_i64, c_vp, c_vp, c_vp]),
     "rt_act_dropout_bwd": (c_i32, [c_vp, c_vp, c_i32, c_f32, c_u64, c_u64, c_i64, c_vp, c_vp]),
     "rt_swiglu_fwd": (c_i32, [c_vp, c_vp, c_f32, c_u64, c_u64, c_i64, c_vp, c_vp]),
@@ -68,11 +61,15 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_adam_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp]),
     "rt_adam_step_segments": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp]),
     "rt_mha_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_vp, c_i64, c_vp, c_vp]),
-    "rt_mha_last_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rt_mha_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    "rt_mha_last_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
+    "rt_mha_varlen_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
+    "rt_mha_varlen_train_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_vp, c_i64, c_vp, c_vp]),
+    "rt_mha_varlen_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "rt_mha_varlen_last_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rt_hstu_attn_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
-    "rt_hstu_attn_last_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rt_hstu_attn_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "rt_hstu_attn_last_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rt_sampled_loss_fwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f64, c_vp, c_vp, c_vp]),
     "rt_sampled_loss_bwd_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
     "rt_sampled_loss_fwd_train": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f64, c_vp, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp]),
@@ -83,6 +80,12 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_l2norm_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rt_gather_rows": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rt_scatter_rows": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp]),
+    "rt_dp_unique_id": (c_i32, [c_vp]),
+    "rt_dp_init": (c_i32, [c_vp, c_i32, c_i32, c_vp]),
+    "rt_dp_allreduce": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    "rt_dp_broadcast": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp]),
+    "rt_dp_finalize": (c_i32, [c_vp]),
+    "rt_dp_last_error": (ctypes.c_char_p, []),
 }
 
 _lib: tp.Optional[ctypes.CDLL] = None

@@ -93,6 +93,16 @@ class TransformerLossModule(nn.Module):
         loss, _ = self._loss_from_sessions(table, sess.view(B * L, d), batch["y"], batch["yw"], batch.get("negatives"))
         return loss
 
+    def training_loss_packed(self, pbatch: Batch) -> torch.Tensor:
+        """`training_loss` on a packed batch: x / y / yw / dist [Np], negatives [Np, N] (rows behind the last
+        session: id 0, target 0 — the loss ignores them), cu [B+1], window.  Same value and gradients as the padded batch of the
+        same sessions (tests/test_packed_gpu.py)."""
+        table = self.torch_model.item_model.get_all_embeddings()
+        B = int(pbatch["cu"].numel()) - 1
+        sess = self.torch_model.encode_packed_train(pbatch["x"], pbatch["dist"], pbatch["cu"], B, int(pbatch["window"]), table)
+        loss, _ = self._loss_from_sessions(table, sess, pbatch["y"], pbatch["yw"], pbatch.get("negatives"))
+        return loss
+
     def validation_loss(self, batch: Batch) -> torch.Tensor:
         """Last position only (lightning.py:340-349): y, yw [B,1]; negatives [B,1,N]."""
         table, sess = self._encode(batch)

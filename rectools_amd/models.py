@@ -81,6 +81,12 @@ class _TrainLoop:
         self.mine_t: tp.Optional[torch.Tensor] = None
         self.pos = 0
         self.sequences_done = 0   # sessions consumed by step() so far (the last batch of an epoch may be short)
+        # packed training batches (no padding rows): opt-in while the path is young
+        tm = lm.torch_model
+        self.packed = (os.environ.get("RT_PACKED_TRAIN", "0") == "1" and type(self.dp).__name__ == "SASRecDataPreparator"
+                       and not self.dp.add_unix_ts and not (self.dp.extra_cols or [])
+                       and getattr(tm.transformer_layers, "packed_ok", None) is not None
+                       and tm.transformer_layers.packed_ok(model.n_factors, self.dp.session_max_len, tm.use_causal_attn))
 
     def begin_epoch(self, epoch: int) -> None:
         perm = epoch_permutation(len(self.store), epoch, self.seed, self.dp.shuffle_train)
@@ -101,13 +107,27 @@ class _TrainLoop:
         self.pos += self.batch_size
         return idx
 
+    def _packed_batch(self, idx: torch.Tensor) -> tp.Dict[str, tp.Any]:
+        """The SASRec training batch of the sessions `idx` without padding rows: x / y / yw / dist padded to the 128-row GEMM
+        tile with (id 0, target 0) rows, negatives from the plugged sampler for every row."""
+        L = self.dp.session_max_len
+        cu, x, y, yw, dist = hnn.pack_train_items(self.dstore.offsets, self.dstore.items, self.dstore.weights, idx, L)
+        n = int(x.numel())
+        tail = (n + 127) // 128 * 128 - n
+        pad = lambda t: torch.nn.functional.pad(t, (0, tail))   # noqa: E731
+        batch: tp.Dict[str, tp.Any] = {"x": pad(x), "y": pad(y), "yw": pad(yw), "dist": pad(dist), "cu": cu, "window": L}
+        if self.dp.negative_sampler is not None:
+            batch["negatives"] = self.dp.negative_sampler.get_negatives(
+                {"x": batch["x"].view(-1, 1)}, lowest_id=self.dp.n_item_extra_tokens, highest_id=self.dp.item_id_map.size)
+        return batch
+
     def step(self) -> torch.Tensor:
         """One training step on the next batch of the current epoch (rolls over to the next epoch when it is used up)."""
         idx = self._next_indices()
-        batch = self.dp.add_negatives(self.dp.collate_train_device(self.dstore, idx))
+        batch = self._packed_batch(idx) if self.packed else self.dp.add_negatives(self.dp.collate_train_device(self.dstore, idx))
         ops.RNG.next_step()
         self.opt.zero_grad()
-        loss = self.lm.training_loss(batch)
+        loss = self.lm.training_loss_packed(batch) if self.packed else self.lm.training_loss(batch)
         loss.backward()
         self.opt.step(self.world)
         return loss
@@ -598,7 +618,13 @@ class TransformerModelBase:
         outs = []
         with torch.no_grad():
             bs = self._encode_batch_size()
+            # packed encoder (no padding rows: 45 % of the [B, L] window at ML-20M scale) where the stack offers it; RT_PACKED=0
+            # keeps the padded window.  Same encodings up to fp32 rounding (tests/test_models_gpu.py).
+            packed = os.environ.get("RT_PACKED", "1") != "0" and lm.torch_model.can_encode_packed(item_embs.shape[1], dp.session_max_len)
             for b0 in range(0, n_valid, bs):
+                if packed:
+                    outs.append(lm.torch_model.encode_last_packed(offsets, item_s, valid_rows[b0:b0 + bs], dp.session_max_len, item_embs))
+                    continue
                 batch = dp.collate_recommend_device(dstore, valid_rows[b0:b0 + bs])
                 outs.append(lm.torch_model.encode_last(batch, item_embs))   # last-position encodings, [b, d]
         user_embs = torch.cat(outs)

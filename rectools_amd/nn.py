@@ -324,6 +324,50 @@ class SASRecTransformerLayer(nn.Module):
             (self.ff_layer_norm.weight, self.ff_layer_norm.bias, self.ff_layer_norm.eps),
             (ff.ff_linear_1.weight, ff.ff_linear_1.bias), (ff.ff_linear_2.weight, ff.ff_linear_2.bias))
 
+    def packed_ok(self) -> bool:
+        ff = self.feed_forward
+        return ff.ff_linear_1.bias is not None and ff.ff_linear_2.bias is not None and ff.activation == "relu"
+
+    def forward_packed(self, seqs, cu, B, window, pad_keys, last_rows=None):
+        """Inference over packed sessions (no padding rows; see ops.sasrec_layer_packed): [Np, d], or [B, d] with `last_rows`."""
+        ff, mha = self.feed_forward, self.multi_head_attn
+        return ops.sasrec_layer_packed(
+            seqs, cu, B, mha.n_heads, window, pad_keys, last_rows,
+            (self.q_layer_norm.weight, self.q_layer_norm.bias, self.q_layer_norm.eps),
+            (mha.in_proj_weight, mha.in_proj_bias), (mha.out_proj.weight, mha.out_proj.bias),
+            (self.ff_layer_norm.weight, self.ff_layer_norm.bias, self.ff_layer_norm.eps),
+            (ff.ff_linear_1.weight, ff.ff_linear_1.bias), (ff.ff_linear_2.weight, ff.ff_linear_2.bias))
+
+    def forward_packed_train(self, seqs, cu, B, window, pad_keys):
+        """The block on packed rows with autograd (training): ONE autograd node (`ops.sasrec_layer_packed_train`) when the feed-forward
+        is the fused kind (ReLU, biases), else the individual ops."""
+        ff, mha = self.feed_forward, self.multi_head_attn
+        if not self.packed_ok():
+            return self.forward_packed_modular(seqs, cu, B, window, pad_keys)
+        return ops.sasrec_layer_packed_train(
+            seqs, cu, B, mha.n_heads, window, pad_keys, self.p if self.training else 0.0,
+            (self.q_layer_norm.weight, self.q_layer_norm.bias, self.q_layer_norm.eps),
+            (mha.in_proj_weight, mha.in_proj_bias), (mha.out_proj.weight, mha.out_proj.bias),
+            (self.ff_layer_norm.weight, self.ff_layer_norm.bias, self.ff_layer_norm.eps),
+            (ff.ff_linear_1.weight, ff.ff_linear_1.bias), (ff.ff_linear_2.weight, ff.ff_linear_2.bias))
+
+    def forward_packed_modular(self, seqs, cu, B, window, pad_keys):
+        """The same block out of the individual autograd ops (as `forward_modular`; the cross-check of the fused packed node).  No
+        masks: there are no pad rows; the pad keys of the reference's window are the virtual key of `ops.mha_varlen`."""
+        p = self.p if self.training else 0.0
+        mha, d = self.multi_head_attn, seqs.shape[1]
+        q = self.q_layer_norm(seqs)
+        in_w, in_b = mha.in_proj_weight, mha.in_proj_bias
+        Q = ops.linear(q, in_w[:d], in_b[:d])
+        KV = ops.linear(seqs, in_w[d:], in_b[d:])                      # K | V from the raw block input (sasrec.py:221-224)
+        bk, bv = (in_b[d:2 * d], in_b[2 * d:]) if pad_keys else (None, None)
+        att = ops.mha_varlen(Q, KV, bk, bv, cu, B, mha.n_heads, window, p)
+        seqs = mha.out_proj(att, residual=q)
+        ff_in = self.ff_layer_norm(seqs)
+        if p > 0:
+            return ops.add(ops.dropout(self.feed_forward(ff_in), p), ff_in)
+        return self.feed_forward(ff_in, residual=ff_in)
+
     def forward_modular(self, seqs, ids, B, L, causal, keypad):
         """Same block out of the individual autograd ops (`seqs` already masked); kept as the cross-check of the fused node."""
         p = self.p if self.training else 0.0
@@ -357,6 +401,29 @@ class SASRecTransformerLayers(TransformerLayersBase):
             seqs = blk(seqs, ids, B, L, causal, keypad)
         last = blocks[-1].forward_last(seqs, ids, B, L, causal, keypad)
         last = ops.mul_mask(last, None, ids.view(B, L)[:, L - 1].contiguous())
+        return self.last_layernorm(last)
+
+    def packed_ok(self, n_factors: int, window: int, causal: bool) -> bool:
+        """Can recommend() encode packed sessions with this stack?  Causal attention (the closed form of the pad keys needs left
+        padding + a causal mask, or no pad keys at all), ReLU feed-forward with biases, head size 32 / 64, K / V image in LDS."""
+        blocks = list(self.transformer_blocks)
+        return bool(blocks) and causal and all(b.packed_ok() for b in blocks) and \
+            ops.mha_varlen_supported(blocks[0].multi_head_attn.n_heads, n_factors, window)
+
+    def forward_packed_train(self, seqs, cu, B, window, keypad):
+        """Training forward over packed rows, [Np, d] (every row is a real position or belongs to the unused tail)."""
+        for blk in self.transformer_blocks:
+            seqs = blk.forward_packed_train(seqs, cu, B, window, not keypad)
+        return self.last_layernorm(seqs)
+
+    def forward_last_packed(self, seqs, cu, B, window, keypad):
+        """[B, d] encodings of the last position from PACKED rows: every block input is the real rows only — the
+        reference masks pad rows to zero before each block (sasrec.py:300) and their only trace, the pad keys a causal block
+        without key-padding masks shows to every query, is the virtual key of `rt_mha_varlen_*`."""
+        blocks = list(self.transformer_blocks)
+        for blk in blocks[:-1]:
+            seqs = blk.forward_packed(seqs, cu, B, window, not keypad)
+        last = blocks[-1].forward_packed(seqs, cu, B, window, not keypad, last_rows=cu[1:] - 1)
         return self.last_layernorm(last)
 
 
@@ -600,6 +667,40 @@ class DistanceSimilarityModule(nn.Module):
         return item_embs
 
 
+def pack_last_items(offsets: torch.Tensor, items: torch.Tensor, rows: torch.Tensor, window: int) -> tp.Tuple[torch.Tensor, ...]:
+    """The last `window` items of the sessions `rows` of a CSR store as ONE packed block (plain tensor ops, any device):
+    -> cu [B+1] (session b = packed rows cu[b] .. cu[b+1]-1, oldest first), ids [N], dist [N] = distance of a row from its
+    session's end (the index of its positional row: inverse positions, net_blocks.py:388-399)."""
+    dev = offsets.device
+    B = int(rows.numel())
+    lens = torch.clamp(offsets[rows + 1] - offsets[rows], max=window)
+    cu = torch.zeros((B + 1,), dtype=torch.int64, device=dev)
+    torch.cumsum(lens, 0, out=cu[1:])
+    N = int(cu[-1])
+    sess = torch.repeat_interleave(torch.arange(B, dtype=torch.int64, device=dev), lens, output_size=N)
+    j = torch.arange(N, dtype=torch.int64, device=dev) - cu[sess]
+    ids = items[(offsets[rows + 1] - lens)[sess] + j]
+    return cu, ids, lens[sess] - 1 - j
+
+
+def pack_train_items(offsets: torch.Tensor, items: torch.Tensor, weights: torch.Tensor, rows: torch.Tensor,
+                     window: int) -> tp.Tuple[torch.Tensor, ...]:
+    """The SASRec training batch of the sessions `rows` (sasrec.py:86-104: the last window + 1 items; x = all but the last, y = all
+    but the first, yw = the weights of y) as ONE packed block without padding rows: -> cu [B+1], x [N], y [N], yw [N], dist [N]
+    (distance of a row from its session's last INPUT position = the index of its positional row).  Sessions with fewer than two
+    items contribute no rows (the reference drops them at fit time, `train_min_user_interactions`)."""
+    dev = offsets.device
+    B = int(rows.numel())
+    lens = torch.clamp(offsets[rows + 1] - offsets[rows] - 1, min=0, max=window)          # input positions per session
+    cu = torch.zeros((B + 1,), dtype=torch.int64, device=dev)
+    torch.cumsum(lens, 0, out=cu[1:])
+    N = int(cu[-1])
+    sess = torch.repeat_interleave(torch.arange(B, dtype=torch.int64, device=dev), lens, output_size=N)
+    j = torch.arange(N, dtype=torch.int64, device=dev) - cu[sess]
+    src = (offsets[rows + 1] - 1 - lens)[sess] + j                                       # x = tail[:-1]
+    return cu, items[src], items[src + 1], weights[src + 1], lens[sess] - 1 - j
+
+
 class TransformerTorchBackbone(nn.Module):
     """encode_sessions / training loss of the reference backbone (torch_backbone.py:118-286) on the HIP ops."""
 
@@ -629,6 +730,50 @@ class TransformerTorchBackbone(nn.Module):
         seqs = ops.embed(table, pos, ids, L, scale, self.dropout_rate if self.training else 0.0)
         seqs = self.transformer_layers(seqs, ids, B, L, self.use_causal_attn, self.use_key_padding_mask, batch)
         return seqs.view(B, L, d)
+
+    def can_encode_packed(self, n_factors: int, window: int) -> bool:
+        """Does `encode_last_packed` serve this backbone (inference, a layer stack with a packed forward, see its `packed_ok`)?"""
+        ok = getattr(self.transformer_layers, "packed_ok", None)
+        return ok is not None and not self.training and not torch.is_grad_enabled() and ok(n_factors, window, self.use_causal_attn)
+
+    def encode_last_packed(self, offsets: torch.Tensor, items: torch.Tensor, rows: torch.Tensor, window: int,
+                           item_embs: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
+        """-> [B, d] = `encode_last` of the sessions `rows` of a CSR session store (`offsets`, `items`: model item ids, oldest
+        first), without ever building the padded [B, L] batch: the last `window` items of every session are gathered into ONE
+        packed row block (embedding + positional row by distance from the session's end, torch_backbone.py:245-246 /
+        net_blocks.py:388-399 with inverse positions) and the stack runs on those rows only.  Every session must hold at least
+        one item."""
+        table = self.item_model.table if item_embs is None else item_embs
+        d = table.shape[1]
+        B = int(rows.numel())
+        cu, ids, dist = pack_last_items(offsets, items, rows, window)
+        N = int(ids.numel())
+        Np = (N + 127) // 128 * 128
+        x = torch.zeros((Np, d), dtype=torch.float32, device=table.device)
+        scale = float(d) ** 0.5 if self.pos_encoding_layer.use_scale_factor else 1.0
+        emb = table.index_select(0, ids)
+        if scale != 1.0:
+            emb = emb * scale
+        if self.pos_encoding_layer.pos_emb is not None:
+            emb = emb + self.pos_encoding_layer.pos_emb.weight.index_select(0, dist)
+        x[:N] = emb
+        return self.transformer_layers.forward_last_packed(x, cu, B, window, self.use_key_padding_mask)
+
+    def encode_packed_train(self, ids: torch.Tensor, dist: torch.Tensor, cu: torch.Tensor, B: int, window: int,
+                            item_embs: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Training twin of `encode_sessions` on packed rows: ids / dist [Np] (tail rows: id 0, dist 0), -> [Np, d].  Embedding
+        rows through `ops.embed` (its backward is the counting-sort scatter; pad id 0 has no gradient), positional rows by the
+        distance from the session's end, then the embedding dropout (torch_backbone.py:245-247)."""
+        table = self.item_model.table if item_embs is None else item_embs
+        d = table.shape[1]
+        scale = float(d) ** 0.5 if self.pos_encoding_layer.use_scale_factor else 1.0
+        seqs = ops.embed(table, None, ids, 1, scale, 0.0)
+        if self.pos_encoding_layer.pos_emb is not None:
+            seqs = ops.add(seqs, self.pos_encoding_layer.pos_emb.weight.index_select(0, dist))
+        p = self.dropout_rate if self.training else 0.0
+        if p > 0:
+            seqs = ops.dropout(seqs, p)
+        return self.transformer_layers.forward_packed_train(seqs, cu, B, window, self.use_key_padding_mask)
 
     def encode_last(self, batch: Batch, item_embs: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
         """-> [B, d] = encode_sessions(batch)[:, -1, :], the only rows recommend() uses (lightning.py:393-397).  Layer stacks

@@ -975,6 +975,146 @@ def sasrec_layer(x: torch.Tensor, ids: torch.Tensor, B: int, L: int, H: int, cau
                               (B, L, H, bool(causal), bool(keypad), float(p), ln1[2], ln2[2]))
 
 
+class _SASRecLayerPacked(torch.autograd.Function):
+    """`_SASRecLayer` on PACKED rows: x [Np, d] holds the real positions of B sessions (rows cu[b] .. cu[b+1]-1) and
+    an unused tail up to the 128-row tile.  No masks anywhere — there are no pad rows; the pad keys the reference's window shows
+    to every query are the virtual key of `rt_mha_varlen_*` (`pad_keys`).  Same products, epilogue fusions and side-stream
+    weight gradients as the padded node; the bias gradient of the key / value projection takes the pad keys' share (zero in
+    total for b_k, the partials of `rt_mha_varlen_bwd` for b_v)."""
+
+    @staticmethod
+    def forward(ctx, x, cu, ln1_w, ln1_b, in_w, in_b, out_w, out_b, ln2_w, ln2_b, w1, b1, w2, b2, meta):
+        B, H, window, pad_keys, p, eps1, eps2 = meta
+        x = x.contiguous()
+        M, d = x.shape
+        dff = w1.shape[0]
+        dev = x.device
+        new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
+        q, mean1, rstd1 = new(M, d), new(M), new(M)
+        _c("rt_layernorm_fwd", x, ln1_w, ln1_b, float(eps1), M, d, q, mean1, rstd1)
+        Q, KV = new(M, d), new(M, 2 * d)
+        _gemm_group([(q, d, in_w, d, Q, d, in_b, None, 0, M, d, d, 0),
+                     (x, d, in_w[d:], d, KV, 2 * d, in_b[d:], None, 0, M, 2 * d, d, 0)], 1, 1)
+        A = torch.zeros((M, d), dtype=torch.float32, device=dev)        # the kernel writes the sessions' rows only
+        lse = torch.zeros((M, H), dtype=torch.float32, device=dev)
+        seed_a = 0
+        if p > 0:
+            s0, sid = RNG.next()
+            seed_a = (s0 + 0xD1B54A32D192ED03 * sid) & 0xFFFFFFFFFFFFFFFF
+        hd = d // H
+        bk, bv = (in_b[d:2 * d], in_b[2 * d:]) if pad_keys else (None, None)
+        _c("rt_mha_varlen_train_fwd", Q, d, KV, 2 * d, KV[:, d:], 2 * d, cu, bk, bv, B, H, hd, window, window, float(p), seed_a, A, d, lse)
+        y = new(M, d)
+        _gemm(A, d, 1, out_w, d, 1, y, d, out_b, q, d, M, d, d)
+        f, mean2, rstd2 = new(M, d), new(M), new(M)
+        _c("rt_layernorm_fwd", y, ln2_w, ln2_b, float(eps2), M, d, f, mean2, rstd2)
+        h = new(M, dff)
+        _gemm(f, d, 1, w1, d, 1, h, dff, b1, None, 0, M, dff, d, 1)
+        seed_h = seed_o = (0, 0)
+        if p > 0:
+            seed_h = RNG.next()
+            hdrop = new(M, dff)
+            _c("rt_act_dropout_fwd", h, ACT_NONE, float(p), seed_h[0], seed_h[1], h.numel(), None, hdrop)
+            o = new(M, d)
+            _gemm(hdrop, dff, 1, w2, dff, 1, o, d, b2, None, 0, M, d, dff)
+            seed_o = RNG.next()
+            out = new(M, d)
+            _c("rt_act_dropout_fwd", o, ACT_NONE, float(p), seed_o[0], seed_o[1], o.numel(), f, out)
+        else:
+            hdrop = h
+            out = new(M, d)
+            _gemm(h, dff, 1, w2, dff, 1, out, d, b2, f, d, M, d, dff)
+        ctx.save_for_backward(cu, x, q, Q, KV, A, lse, y, f, h, hdrop, mean1, rstd1, mean2, rstd2,
+                              ln1_w, in_w, in_b, out_w, ln2_w, w1, w2)
+        ctx.meta = (B, H, window, pad_keys, p, seed_a, seed_h, seed_o)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (cu, x, q, Q, KV, A, lse, y, f, h, hdrop, mean1, rstd1, mean2, rstd2, ln1_w, in_w, in_b, out_w, ln2_w, w1, w2) = ctx.saved_tensors
+        B, H, window, pad_keys, p, seed_a, seed_h, seed_o = ctx.meta
+        g_out = g_out.contiguous()
+        M, d = g_out.shape
+        dff = w1.shape[0]
+        dev = g_out.device
+        new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
+        sp = _wgrad_splits(M)
+        defer = _steals_grad(ln1_w, in_w, out_w, ln2_w, w1, w2)
+        side_ctxs = []
+
+        def ln_bwd(dy, xx, w, mean, rstd, res=None):
+            dx, dw, db = new(M, d), new(d), new(d)
+            ws_bytes = _lib.load().rt_layernorm_bwd_workspace_bytes(M, d)
+            ws = torch.empty((max(ws_bytes, 4),), dtype=torch.uint8, device=dev)
+            _c("rt_layernorm_bwd_fused", dy, xx, w, mean, rstd, res, None, 0, 0, M, d, dx, dw, db, ws, ws_bytes)
+            return dx, dw, db
+
+        # ---- feed-forward
+        if p > 0:
+            g_o = new(M, d)
+            _c("rt_act_dropout_bwd", g_out, g_out, ACT_NONE, float(p), seed_o[0], seed_o[1], g_out.numel(), g_o)
+        else:
+            g_o = g_out
+        d_w2, d_b2 = new(d, dff), new(d)
+        with _OnSide(dev, defer) as sd:
+            side_ctxs.append(sd)
+            sd.uses(g_o, hdrop, d_w2, d_b2)
+            _gemm(g_o, d, 0, hdrop, dff, 0, d_w2, dff, None, None, 0, d, dff, M, 0, sp, d_b2)
+        g_hd = new(M, dff)
+        _gemm(g_o, d, 1, w2, dff, 0, g_hd, dff, None, None, 0, M, dff, d)
+        g_h = new(M, dff)
+        _c("rt_act_dropout_bwd", g_hd, h, ACT_RELU, float(p), seed_h[0], seed_h[1], g_hd.numel(), g_h)
+        d_w1, d_b1 = new(dff, d), new(dff)
+        with _OnSide(dev, defer) as sd:
+            side_ctxs.append(sd)
+            sd.uses(g_h, f, d_w1, d_b1)
+            _gemm(g_h, dff, 0, f, d, 0, d_w1, d, None, None, 0, dff, d, M, 0, sp, d_b1)
+        g_f = new(M, d)
+        _gemm(g_h, dff, 1, w1, d, 0, g_f, d, None, g_out, d, M, d, dff)
+        g_y, d_ln2w, d_ln2b = ln_bwd(g_f, y, ln2_w, mean2, rstd2)
+        # ---- attention: y = q + Wo A + bo
+        d_wo, d_bo = new(d, d), new(d)
+        with _OnSide(dev, defer) as sd:
+            side_ctxs.append(sd)
+            sd.uses(g_y, A, d_wo, d_bo)
+            _gemm(g_y, d, 0, A, d, 0, d_wo, d, None, None, 0, d, d, M, 0, sp, d_bo)
+        g_A = new(M, d)
+        _gemm(g_y, d, 1, out_w, d, 0, g_A, d, None, None, 0, M, d, d)
+        gQ = torch.zeros((M, d), dtype=torch.float32, device=dev)      # rows behind the sessions must read as zero in the wgrads
+        gKV = torch.zeros((M, 2 * d), dtype=torch.float32, device=dev)
+        delta = new(M, H)
+        part = new(B, d) if pad_keys else None
+        bk, bv = (in_b[d:2 * d], in_b[2 * d:]) if pad_keys else (None, None)
+        _c("rt_mha_varlen_bwd", Q, d, KV, 2 * d, KV[:, d:], 2 * d, A, d, g_A, d, lse, cu, bk, bv, B, H, d // H, window, window, float(p),
+           seed_a, gQ, d, gKV, 2 * d, gKV[:, d:], 2 * d, delta, part)
+        d_in_w, d_in_b = new(3 * d, d), new(3 * d)
+        with _OnSide(dev, defer) as sd:
+            side_ctxs.append(sd)
+            sd.uses(gQ, gKV, q, x, d_in_w, d_in_b)
+            _gemm(gQ, d, 0, q, d, 0, d_in_w, d, None, None, 0, d, d, M, 0, sp, d_in_b)
+            _gemm(gKV, 2 * d, 0, x, d, 0, d_in_w[d:], d, None, None, 0, 2 * d, d, M, 0, sp, d_in_b[d:])
+            if pad_keys:   # the pad keys' share: b_k has no gradient in total (it shifts every logit of a query alike), b_v gets theirs
+                sd.uses(part)
+                d_in_b[d:2 * d].zero_()
+                d_in_b[2 * d:] += part.sum(0)
+        g_q, g_kv = new(M, d), new(M, d)
+        _gemm_group([(gQ, d, in_w, d, g_q, d, None, g_y, d, M, d, d, 0),
+                     (gKV, 2 * d, in_w[d:], d, g_kv, d, None, None, 0, M, d, 2 * d, 0)], 1, 0)
+        g_x, d_ln1w, d_ln1b = ln_bwd(g_q, x, ln1_w, mean1, rstd1, res=g_kv)     # g_x = LN1'(g_q) + gKV Wkv
+        if side_ctxs:
+            side_ctxs[-1].join_now()
+        return (g_x, None, d_ln1w, d_ln1b, d_in_w, d_in_b, d_wo, d_bo, d_ln2w, d_ln2b, d_w1, d_b1, d_w2, d_b2, None)
+
+
+def sasrec_layer_packed_train(x: torch.Tensor, cu: torch.Tensor, B: int, H: int, window: int, pad_keys: bool, p: float,
+                              ln1: tp.Tuple[torch.Tensor, torch.Tensor, float], in_proj: tp.Tuple[torch.Tensor, torch.Tensor],
+                              out_proj: tp.Tuple[torch.Tensor, torch.Tensor], ln2: tp.Tuple[torch.Tensor, torch.Tensor, float],
+                              ff1: tp.Tuple[torch.Tensor, torch.Tensor], ff2: tp.Tuple[torch.Tensor, torch.Tensor]) -> torch.Tensor:
+    return _SASRecLayerPacked.apply(_chk(x, "sasrec_layer_packed_train"), cu, ln1[0], ln1[1], in_proj[0], in_proj[1], out_proj[0],
+                                    out_proj[1], ln2[0], ln2[1], ff1[0], ff1[1], ff2[0], ff2[1],
+                                    (B, H, window, pad_keys, p, ln1[2], ln2[2]))
+
+
 def sasrec_layer_last(x: torch.Tensor, ids: torch.Tensor, B: int, L: int, H: int, causal: bool, keypad: bool,
                       ln1: tp.Tuple[torch.Tensor, torch.Tensor, float], in_proj: tp.Tuple[torch.Tensor, torch.Tensor],
                       out_proj: tp.Tuple[torch.Tensor, torch.Tensor], ln2: tp.Tuple[torch.Tensor, torch.Tensor, float],
@@ -1010,6 +1150,108 @@ def sasrec_layer_last(x: torch.Tensor, ids: torch.Tensor, B: int, L: int, H: int
     _gemm(f, d, 1, ff1[0], d, 1, h, dff, ff1[1], None, 0, B, dff, d, 1)
     out = new(B, d)
     _gemm(h, dff, 1, ff2[0], dff, 1, out, d, ff2[1], f, d, B, d, dff)
+    return out
+
+
+class _MHAVarlen(torch.autograd.Function):
+    """Causal softmax attention over PACKED sessions with the window's pad keys as one virtual key (`rt_mha_varlen_train_fwd` /
+    `rt_mha_varlen_bwd`).  q [Np, d]; kv [Np, 2d] (k | v column blocks); cu [B+1]; bk / bv [d] or None (pad keys masked).
+    Gradients: dq, dkv, and for bk / bv the pad keys' share (the real rows' share arrives through the projection's bias
+    gradient; for bk the two cancel exactly)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, bk, bv, cu, B, H, window, p):
+        Np, d = q.shape
+        hd = d // H
+        o = torch.zeros((Np, d), dtype=torch.float32, device=q.device)           # rows behind the last session stay zero
+        lse = torch.zeros((Np, H), dtype=torch.float32, device=q.device)
+        seed = 0
+        if p > 0:
+            s0, sid = RNG.next()
+            seed = (s0 + 0xD1B54A32D192ED03 * sid) & 0xFFFFFFFFFFFFFFFF
+        _c("rt_mha_varlen_train_fwd", q, d, kv, 2 * d, kv[:, d:], 2 * d, cu, bk, bv, B, H, hd, window, window, float(p), seed, o, d, lse)
+        ctx.save_for_backward(q, kv, bk, bv, cu, o, lse)
+        ctx.meta = (B, H, window, p, seed)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, kv, bk, bv, cu, o, lse = ctx.saved_tensors
+        B, H, window, p, seed = ctx.meta
+        Np, d = q.shape
+        hd = d // H
+        do = do.contiguous()
+        dq, dkv = torch.zeros_like(q), torch.zeros_like(kv)
+        delta = torch.empty((Np, H), dtype=torch.float32, device=q.device)
+        part = torch.empty((B, d), dtype=torch.float32, device=q.device) if bv is not None else None
+        _c("rt_mha_varlen_bwd", q, d, kv, 2 * d, kv[:, d:], 2 * d, o, d, do, d, lse, cu, bk, bv, B, H, hd, window, window, float(p), seed,
+           dq, d, dkv, 2 * d, dkv[:, d:], 2 * d, delta, part)
+        # the pad keys' share of d_bk: the key bias shifts every logit of a query alike, so the gradient summed over ALL keys of
+        # the window is zero — the pads carry exactly minus what the real key rows carry
+        dbk = -dkv[:, :d].sum(0) if bk is not None else None
+        dbv = part.sum(0) if part is not None else None
+        return dq, dkv, dbk, dbv, None, None, None, None, None
+
+
+def mha_varlen(q: torch.Tensor, kv: torch.Tensor, bk: tp.Optional[torch.Tensor], bv: tp.Optional[torch.Tensor], cu: torch.Tensor, B: int,
+               H: int, window: int, p: float) -> torch.Tensor:
+    return _MHAVarlen.apply(_chk(q, "mha_varlen").contiguous(), _chk(kv, "mha_varlen").contiguous(), bk, bv, cu, B, H, window, p)
+
+
+def mha_varlen_supported(n_heads: int, d: int, window: int) -> bool:
+    """`rt_mha_varlen_fwd` serves head sizes 32 / 64 whose K / V image of one (session, head) fits the 160 KB of LDS."""
+    hd = d // n_heads
+    return hd in (32, 64) and d % n_heads == 0 and 2 * ((window + 31) // 32 * 32) * (hd + 1) * 4 <= 160 * 1024
+
+
+def sasrec_layer_packed(x: torch.Tensor, cu: torch.Tensor, B: int, H: int, window: int, pad_keys: bool, last_rows: tp.Optional[torch.Tensor],
+                        ln1: tp.Tuple[torch.Tensor, torch.Tensor, float], in_proj: tp.Tuple[torch.Tensor, torch.Tensor],
+                        out_proj: tp.Tuple[torch.Tensor, torch.Tensor], ln2: tp.Tuple[torch.Tensor, torch.Tensor, float],
+                        ff1: tp.Tuple[torch.Tensor, torch.Tensor], ff2: tp.Tuple[torch.Tensor, torch.Tensor]) -> torch.Tensor:
+    """Inference only: one causal SASRec block (sasrec.py:186-231) over PACKED sessions — `x` [Np, d] holds the real positions
+    only (session b = rows cu[b] .. cu[b+1]-1, oldest first; Np = the row count rounded up to the 128-row GEMM tile, tail rows
+    arbitrary).  The pad keys the reference's left-padded window shows to every query enter as one virtual key per query
+    (`rt_mha_varlen_fwd`; `pad_keys` = the block runs without key-padding masks).  last_rows None: the block's output for
+    every row, [Np, d]; last_rows [B] (= cu[1:] - 1): only the last position of every session, [B, d] — the key / value
+    projection is then the only product over all rows (cf. `sasrec_layer_last`)."""
+    x = _chk(x, "sasrec_layer_packed").contiguous()
+    Np, d = x.shape
+    dev = x.device
+    new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
+    in_w, in_b = in_proj
+    hd = d // H
+    bk = in_b[d:2 * d] if pad_keys else None
+    bv = in_b[2 * d:] if pad_keys else None
+    mean, rstd = new(Np), new(Np)
+    if last_rows is None:
+        q = new(Np, d)
+        _c("rt_layernorm_fwd", x, ln1[0], ln1[1], float(ln1[2]), Np, d, q, mean, rstd)
+        Q, KV = new(Np, d), new(Np, 2 * d)
+        _gemm_group([(q, d, in_w, d, Q, d, in_b, None, 0, Np, d, d, 0),
+                     (x, d, in_w[d:], d, KV, 2 * d, in_b[d:], None, 0, Np, 2 * d, d, 0)], 1, 1)
+        A = torch.zeros((Np, d), dtype=torch.float32, device=dev)          # tail rows are not written by the kernel
+        _c("rt_mha_varlen_fwd", Q, d, KV, 2 * d, KV[:, d:], 2 * d, cu, bk, bv, B, H, hd, window, window, A, d)
+        rows = Np
+    else:
+        KV = new(Np, 2 * d)
+        _gemm(x, d, 1, in_w[d:], d, 1, KV, 2 * d, in_b[d:], None, 0, Np, 2 * d, d)
+        x_last = x.index_select(0, last_rows)
+        rows = B
+        q = new(B, d)
+        _c("rt_layernorm_fwd", x_last, ln1[0], ln1[1], float(ln1[2]), B, d, q, mean, rstd)
+        Q = new(B, d)
+        _gemm(q, d, 1, in_w, d, 1, Q, d, in_b, None, 0, B, d, d)
+        A = new(B, d)
+        _c("rt_mha_varlen_last_fwd", Q, d, KV, 2 * d, KV[:, d:], 2 * d, cu, bk, bv, B, H, hd, window, window, A, d)
+    y = new(rows, d)
+    _gemm(A, d, 1, out_proj[0], d, 1, y, d, out_proj[1], q, d, rows, d, d)
+    f = new(rows, d)
+    _c("rt_layernorm_fwd", y, ln2[0], ln2[1], float(ln2[2]), rows, d, f, mean, rstd)
+    dff = ff1[0].shape[0]
+    h = new(rows, dff)
+    _gemm(f, d, 1, ff1[0], d, 1, h, dff, ff1[1], None, 0, rows, dff, d, 1)
+    out = new(rows, d)
+    _gemm(h, dff, 1, ff2[0], dff, 1, out, d, ff2[1], f, d, rows, d, dff)
     return out
 
 

@@ -5,7 +5,7 @@
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 O=gpurun_out/packed; mkdir -p $O; export TMPDIR=/tmp
 # 1. kernels and paths against their references (stop at the first failure: the order goes from kernels to models)
-timeout 400 python -m pytest tests/test_packed_gpu.py -q -x -p no:cacheprovider 2>&1 | tail -15 | tee $O/pytest_packed.txt
+timeout 400 python -m pytest tests/test_packed_gpu.py -q --maxfail=30 --tb=short -p no:cacheprovider 2>&1 | tail -60 | tee $O/pytest_packed.txt
 # 2. recommend() end to end with and without the packed encoder (bench: short legs)
 for packed in 1 0; do
   RT_PACKED=$packed timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --rec-steps 3 --topk-steps 1 > $O/bench_auto_packed$packed.json 2> $O/bench_auto_packed$packed.err

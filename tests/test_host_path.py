@@ -591,6 +591,25 @@ def test_recommend_session_index_equals_per_request_construction(seed):
         assert np.array_equal(sub_idx.numpy(), np.concatenate(exp_valid) if exp_valid else np.array([], np.int32))
 
 
+def test_pack_last_items_equals_a_loop_over_sessions():
+    """`nn.pack_last_items` (the packed recommend() encoder's batch): last `window` items per session, oldest first, with the
+    distance from the session's end that indexes the inverse positional rows."""
+    from rectools_amd.nn import pack_last_items
+
+    rng = np.random.default_rng(3)
+    lens = np.array([0, 5, 1, 12, 30, 7, 0, 8])
+    offsets = np.r_[0, np.cumsum(lens)]
+    items = rng.integers(1, 100, offsets[-1])
+    rows = np.array([4, 1, 3, 2, 7])                       # sessions with >= 1 item, arbitrary order
+    for window in (1, 8, 64):
+        cu, ids, dist = pack_last_items(torch.from_numpy(offsets), torch.from_numpy(items), torch.from_numpy(rows), window)
+        exp_ids, exp_dist, exp_cu = [], [], [0]
+        for r in rows:
+            tail = items[offsets[r]:offsets[r + 1]][-window:]
+            exp_ids += tail.tolist(); exp_dist += list(range(len(tail) - 1, -1, -1)); exp_cu.append(exp_cu[-1] + len(tail))
+        assert cu.tolist() == exp_cu and ids.tolist() == exp_ids and dist.tolist() == exp_dist
+
+
 def test_train_loop_batches_roll_over_epochs_and_count_sequences():
     """`models._TrainLoop._next_indices`: batches of an epoch's shard in order, a short last batch, roll-over into the next epoch
     and the running count of consumed sessions (what bench.py divides by the wall clock)."""
@@ -609,6 +628,28 @@ def test_train_loop_batches_roll_over_epochs_and_count_sequences():
         got.append(loop._next_indices().tolist()); counts.append(loop.sequences_done)
     assert got == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9], [100, 101, 102, 103], [104, 105]]
     assert counts == [4, 8, 10, 14, 16] and loop.epoch == 1 and loop.batches_left() == 0
+
+
+def test_pack_train_items_equals_the_padded_train_collate():
+    """`nn.pack_train_items` against the reference-shaped SASRec train collate (sasrec.py:86-104): the non-pad positions of x / y /
+    yw of the padded [B, L] batch, row for row, plus the inverse positional index."""
+    from rectools_amd.nn import pack_train_items
+
+    rng = np.random.default_rng(5)
+    lens = np.array([2, 9, 1, 30, 17, 3, 0])
+    offsets = np.r_[0, np.cumsum(lens)]
+    items = rng.integers(1, 100, offsets[-1]); weights = rng.random(offsets[-1]).astype(np.float32)
+    rows = np.array([3, 0, 4, 1, 5, 2])
+    for L in (4, 16, 64):
+        cu, x, y, yw, dist = pack_train_items(torch.from_numpy(offsets), torch.from_numpy(items), torch.from_numpy(weights),
+                                              torch.from_numpy(rows), L)
+        ex, ey, ew, ed, ecu = [], [], [], [], [0]
+        for r in rows:
+            tail, tw = items[offsets[r]:offsets[r + 1]][-(L + 1):], weights[offsets[r]:offsets[r + 1]][-(L + 1):]
+            xs, ys, ws = tail[:-1], tail[1:], tw[1:]
+            ex += xs.tolist(); ey += ys.tolist(); ew += ws.tolist(); ed += list(range(len(xs) - 1, -1, -1)); ecu.append(ecu[-1] + len(xs))
+        assert cu.tolist() == ecu and x.tolist() == ex and y.tolist() == ey and dist.tolist() == ed
+        assert np.array_equal(yw.numpy(), np.array(ew, np.float32))
 
 
 @pytest.mark.parametrize("add_rank", [True, False])
