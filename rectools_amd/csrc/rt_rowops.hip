@@ -245,23 +245,26 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= M) return;
   const float* xr = x + (long long)m * d;
-  const float keep = (ids != nullptr && ids[m] == 0) ? 0.f : 1.f;
+  // a SELECT, not a multiply by 0: a non-finite value in a padded row must become an exact zero (as rt_mul_mask and the backward's
+  // mask_dx do), not NaN — SASRec's causal-only attention lets real queries see those rows as keys
+  const bool pad = ids != nullptr && ids[m] == 0;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   float s = 0.f;
   for (int c = lane * 4; c < d; c += 256) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(xr + c) * keep;
+    f32x4 v = pad ? zero4 : *reinterpret_cast<const f32x4*>(xr + c);
     if (x0 != nullptr) *reinterpret_cast<f32x4*>(x0 + (long long)m * d + c) = v;
     s += v[0] + v[1] + v[2] + v[3];
   }
   const float mu = wave_sum(s) / d;
   float q = 0.f;
   for (int c = lane * 4; c < d; c += 256) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(xr + c) * keep;
+    f32x4 v = pad ? zero4 : *reinterpret_cast<const f32x4*>(xr + c);
     v -= mu;
     q += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
   }
   const float rs = 1.0f / sqrtf(wave_sum(q) / d + eps);
   for (int c = lane * 4; c < d; c += 256) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(xr + c) * keep;
+    f32x4 v = pad ? zero4 : *reinterpret_cast<const f32x4*>(xr + c);
     f32x4 ww = *reinterpret_cast<const f32x4*>(w + c);
     f32x4 bb = *reinterpret_cast<const f32x4*>(b + c);
     v = (v - mu) * rs * ww + bb;

@@ -49,16 +49,31 @@ class TransformerLossModule(nn.Module):
     """Backbone + loss.  `n_item_extra_tokens` real-item offset is only needed for gBCE (lightning.py:202)."""
 
     def __init__(self, torch_model: TransformerTorchBackbone, loss: str = "softmax", n_negatives: tp.Optional[int] = None,
-                 gbce_t: float = 0.2, logits_t: float = 1.0, n_item_extra_tokens: int = 1) -> None:
+                 gbce_t: float = 0.2, logits_t: float = 1.0, n_item_extra_tokens: int = 1, **kwargs: tp.Any) -> None:
+        """The leading arguments are this engine's; `**kwargs` takes the rest of the reference constructor's keyword set
+        (lightning.py:75-91: model_config, dataset_schema, item_external_ids, item_extra_tokens, data_preparator, lr, verbose,
+        train_loss_name, val_loss_name, adam_betas) — `models._build_model_from_dataset` instantiates the class given as
+        `lightning_module_type` with exactly those keywords, so a subclass written against the reference's signature plugs in.
+        They are kept as attributes (the optimiser and the loop live in `FlatAdam` / `models._TrainLoop`)."""
         super().__init__()
-        if loss not in LOSSES:
-            raise ValueError(f"loss {loss} is not supported")  # lightning.py:328
+        if loss not in LOSSES and type(self)._loss_from_sessions is TransformerLossModule._loss_from_sessions:
+            raise ValueError(f"loss {loss} is not supported")  # lightning.py:328 (a subclass with its own loss may name it freely)
         self.torch_model = torch_model
         self.loss = loss
         self.n_negatives = n_negatives
         self.gbce_t = gbce_t
         self.logits_t = logits_t
         self.n_item_extra_tokens = n_item_extra_tokens
+        for name in ("model_config", "dataset_schema", "item_external_ids", "item_extra_tokens", "data_preparator", "lr", "verbose",
+                     "train_loss_name", "val_loss_name", "adam_betas"):
+            if name in kwargs:
+                object.__setattr__(self, name, kwargs.pop(name))   # plain attributes (the data preparator is not a sub-module)
+        self.extra_kwargs = kwargs
+
+    @staticmethod
+    def requires_negatives(loss: str) -> tp.Optional[bool]:
+        """lightning.py:115-124 — consulted by the model before it builds the data preparator (transformers/base.py:354)."""
+        return requires_negatives(loss)
 
     @property
     def cosine(self) -> bool:
@@ -126,13 +141,15 @@ class RcclExchange:
     made by rank 0 and handed to the other ranks through the already initialised torch.distributed group (any backend: it only
     carries the id); opt-in with `RT_DP_BACKEND=rccl`, the default exchange stays `dist.all_reduce` (which is RCCL too)."""
 
-    def __init__(self, rank: int, world: int) -> None:
+    def __init__(self, rank: int, world: int, device: tp.Optional[torch.device] = None) -> None:
         import ctypes
 
         from . import _lib
 
         self._lib = _lib.load()
         self.rank, self.world = rank, world
+        if device is not None:   # ncclCommInitRank binds the CURRENT HIP device: make it the one the parameters live on
+            torch.cuda.set_device(device)
         uid = ctypes.create_string_buffer(128)
         if rank == 0:
             _lib.check(self._lib.rt_dp_unique_id(uid), "rt_dp_unique_id")
@@ -148,17 +165,31 @@ class RcclExchange:
             raise _lib.HipLibraryError(f"rt_dp_init failed ({status}): {(self._lib.rt_dp_last_error() or b'').decode()}")
         self.comm = comm
 
+    def _call(self, name: str, *args: tp.Any) -> None:
+        from . import _lib
+
+        try:
+            ops._c(name, *args)
+        except _lib.HipLibraryError as e:    # the exchange keeps its own error text (RCCL's, not the kernels')
+            raise _lib.HipLibraryError(f"{e}; rt_dp_last_error: {(self._lib.rt_dp_last_error() or b'').decode()}") from e
+
     def all_reduce(self, buf: torch.Tensor) -> None:
-        ops._c("rt_dp_allreduce", self.comm, buf, buf.numel())
+        self._call("rt_dp_allreduce", self.comm, buf, buf.numel())
 
     def broadcast(self, buf: torch.Tensor, src: int = 0) -> None:
-        ops._c("rt_dp_broadcast", self.comm, buf, buf.numel(), src)
+        self._call("rt_dp_broadcast", self.comm, buf, buf.numel(), src)
 
     def close(self) -> None:
         if self.comm is not None:
             torch.cuda.synchronize()
             self._lib.rt_dp_finalize(self.comm)
             self.comm = None
+
+    def __del__(self) -> None:
+        try:
+            self.close()
+        except Exception:   # interpreter shutdown: the runtime may be gone already
+            pass
 
 
 class FlatAdam:
@@ -209,7 +240,7 @@ class FlatAdam:
 
     def use_rccl_exchange(self, rank: int, world: int) -> None:
         """Route the gradient all-reduce and the parameter broadcast through `rt_dp_*` (collective: every rank calls it)."""
-        self.exchange = RcclExchange(rank, world)
+        self.exchange = RcclExchange(rank, world, self.flat_p.device)
 
     @property
     def flat_g(self) -> torch.Tensor:

@@ -86,6 +86,7 @@ class _TrainLoop:
         self.packed = (os.environ.get("RT_PACKED_TRAIN", "0") == "1" and type(self.dp).__name__ == "SASRecDataPreparator"
                        and not self.dp.add_unix_ts and not (self.dp.extra_cols or [])
                        and getattr(tm.transformer_layers, "packed_ok", None) is not None
+                       and getattr(tm, "_fused_pos", lambda: False)()
                        and tm.transformer_layers.packed_ok(model.n_factors, self.dp.session_max_len, tm.use_causal_attn))
 
     def begin_epoch(self, epoch: int) -> None:
@@ -163,8 +164,19 @@ class TransformerModelBase:
         similarity_module_kwargs: tp.Optional[dict] = None, seed: tp.Optional[int] = None,
         negative_sampler_type: tp.Type[TransformerNegativeSamplerBase] = CatalogUniformSampler,
         negative_sampler_kwargs: tp.Optional[dict] = None,
+        pos_encoding_type: tp.Type[torch.nn.Module] = hnn.LearnableInversePositionalEncoding,
+        lightning_module_type: tp.Type[hl.TransformerLossModule] = hl.TransformerLossModule,
+        backbone_type: tp.Type[hnn.TransformerTorchBackbone] = hnn.TransformerTorchBackbone,
+        backbone_kwargs: tp.Optional[dict] = None,
+        get_trainer_func: tp.Optional[tp.Callable] = None, get_trainer_func_kwargs: tp.Optional[dict] = None,
         **kwargs: tp.Any,
     ) -> None:
+        if get_trainer_func is not None:
+            # transformers/base.py:368-380 hands fit() to a user-built pytorch_lightning.Trainer.  This engine has no Lightning
+            # Trainer (the loop is `_TrainLoop`: device collate, fused Adam, RCCL exchange): refuse instead of training some other way
+            raise NotImplementedError("get_trainer_func: the MI355X engine trains with its own loop (models._TrainLoop), a custom "
+                                      "pytorch_lightning.Trainer cannot be honoured; pass None (epochs / deterministic / verbose and "
+                                      "`csv_log_dir` cover the default trainer's settings)")
         self._params = dict(
             n_blocks=n_blocks, n_heads=n_heads, n_factors=n_factors, use_pos_emb=use_pos_emb, use_causal_attn=use_causal_attn,
             use_key_padding_mask=use_key_padding_mask, dropout_rate=dropout_rate, session_max_len=session_max_len,
@@ -179,11 +191,13 @@ class TransformerModelBase:
             similarity_module_type=similarity_module_type, item_net_block_types=tuple(item_net_block_types),
             item_net_constructor_type=item_net_constructor_type, item_net_constructor_kwargs=item_net_constructor_kwargs,
             negative_sampler_type=negative_sampler_type, negative_sampler_kwargs=negative_sampler_kwargs,
+            pos_encoding_type=pos_encoding_type, lightning_module_type=lightning_module_type, backbone_type=backbone_type,
+            backbone_kwargs=backbone_kwargs, get_trainer_func=None, get_trainer_func_kwargs=get_trainer_func_kwargs,
         )
         self._params.update(kwargs)
         for k, v in self._params.items():
             setattr(self, k, v)
-        if hl.requires_negatives(loss) is None:
+        if self._requires_negatives() is None:
             raise ValueError(f"loss {loss} is not supported")
         if n_factors % n_heads != 0:
             raise ValueError("n_factors must be divisible by n_heads without remainder")   # nn.MultiheadAttention's own check
@@ -213,8 +227,13 @@ class TransformerModelBase:
             kw["seed"] = (0 if self.seed is None else int(self.seed)) * 1000003 + _dist_info()[0]
         return self.negative_sampler_type(n_negatives=self.n_negatives, **kw)
 
+    def _requires_negatives(self) -> tp.Optional[bool]:
+        """`self.lightning_module_type.requires_negatives(self.loss)` (transformers/base.py:354): a plugged module decides."""
+        fn = getattr(self.lightning_module_type, "requires_negatives", None)
+        return hl.requires_negatives(self.loss) if fn is None else fn(self.loss)
+
     def _init_data_preparator(self) -> None:
-        requires_negatives = bool(hl.requires_negatives(self.loss))
+        requires_negatives = bool(self._requires_negatives())
         self.data_preparator = self.data_preparator_type(
             session_max_len=self.session_max_len, batch_size=self.batch_size, dataloader_num_workers=self.dataloader_num_workers,
             train_min_user_interactions=self.train_min_user_interactions,
@@ -268,15 +287,21 @@ class TransformerModelBase:
         item_model = self._init_item_model(item_net_schema)
         pkw = self._kw(self.pos_encoding_kwargs)
         pkw.setdefault("use_scale_factor", self.use_scale_factor_default)
-        pos = hnn.LearnableInversePositionalEncoding(self.use_pos_emb, self.session_max_len, self.n_factors, **pkw)
-        backbone = hnn.TransformerTorchBackbone(
+        # the plug-in seams of transformers/base.py:407-449: every module is built from the class the caller handed over
+        pos = self.pos_encoding_type(self.use_pos_emb, self.session_max_len, self.n_factors, **pkw)
+        backbone = self.backbone_type(
             n_heads=self.n_heads, dropout_rate=self.dropout_rate, item_model=item_model, pos_encoding_layer=pos,
             transformer_layers=self._init_transformer_layers(), similarity_module=self._init_similarity_module(),
-            use_causal_attn=self.use_causal_attn, use_key_padding_mask=self.use_key_padding_mask)
-        lkw = self._kw(self.lightning_module_kwargs)
-        self.lightning_model = hl.TransformerLossModule(
-            backbone, self.loss, self.n_negatives if hl.requires_negatives(self.loss) else None, self.gbce_t,
-            lkw.get("logits_t", 1.0), self.data_preparator.n_item_extra_tokens)
+            use_causal_attn=self.use_causal_attn, use_key_padding_mask=self.use_key_padding_mask, **self._kw(self.backbone_kwargs))
+        dp = self.data_preparator
+        self.lightning_model = self.lightning_module_type(
+            torch_model=backbone, model_config=self.get_config(simple_types=True),
+            dataset_schema=dp.train_dataset.get_schema() if dataset is not None else dict(self.dataset_schema),
+            item_external_ids=dp.item_id_map.external_ids, item_extra_tokens=dp.item_extra_tokens, data_preparator=dp,
+            lr=self.lr, gbce_t=self.gbce_t, loss=self.loss, verbose=self.verbose, train_loss_name=self.train_loss_name,
+            val_loss_name=self.val_loss_name, adam_betas=(0.9, 0.98),
+            n_negatives=self.n_negatives if self._requires_negatives() else None, n_item_extra_tokens=dp.n_item_extra_tokens,
+            **self._kw(self.lightning_module_kwargs))
         device = torch.device(self._device())
         self.lightning_model.to(device)
         hl.xavier_normal_init(self.lightning_model.torch_model)  # on_train_start (lightning.py:296-299)
@@ -287,6 +312,7 @@ class TransformerModelBase:
         self.epochs_done = 0
         self.history = []
         self._train_data_ready = dataset is not None
+        self._train_dataset_ref = dataset
         # dropout streams: keyed by the model seed and the rank (replicas must not share masks), restarted with the model
         ops.RNG.seed = ((0 if self.seed is None else int(self.seed)) * 0x9E3779B97F4A7C15 + 0xD1B54A32D192ED03 * _dist_info()[0]) \
             & 0xFFFFFFFFFFFFFFFF
@@ -336,6 +362,9 @@ class TransformerModelBase:
         rank = loop.rank
         val_store = dp.val_store()
         ops.RNG.step = opt.step_count   # fit_partial / restored models continue the dropout streams where training stopped
+        sampler = getattr(dp, "negative_sampler", None)
+        if isinstance(sampler, CatalogUniformSampler) and sampler.calls < opt.step_count:
+            sampler.calls = opt.step_count   # ... and the negative draws: a restored sampler must not replay batch 1, 2, ...
         for epoch in range(first, last):
             lm.train()
             loop.begin_epoch(epoch)
@@ -401,20 +430,42 @@ class TransformerModelBase:
         """Continue training for `max_epochs` more epochs (transformers/base.py:505-533)."""
         if not self.is_fitted:
             self._build_model_from_dataset(dataset)
-        elif not getattr(self, "_train_data_ready", False):
-            # restored from a checkpoint / pickle: the training sessions have to be rebuilt (transformers/base.py:520-523),
-            # and they must index the SAME embedding rows the restored weights were trained on
-            known = np.asarray(self.data_preparator.item_id_map.external_ids)
-            self.data_preparator.process_dataset_train(dataset)
-            now = np.asarray(self.data_preparator.item_id_map.external_ids)
-            if len(known) != len(now) or not (known == now).all():
-                raise ValueError("fit_partial: the dataset maps items to other embedding rows than the restored model was trained "
-                                 "with (different items, or a different order of first appearance)")
-            self._train_data_ready = True
-        # else: a model fitted in this process keeps its processed train dataset, as the reference does (base.py:505-533)
+        else:
+            # the reference re-processes the dataset it is handed on EVERY call (transformers/base.py:515-520: "assumed that dataset
+            # is same as in `fit`") — new interactions of known items are picked up; a restored model (checkpoint / pickle) has to
+            # rebuild its training sessions anyway (base.py:520-523).  The dataset must index the SAME embedding rows the weights
+            # were trained on: checked on a copy of the preparator's state, committed only when it holds.
+            self._reprocess_train_dataset(dataset)
         self._run_epochs(self.epochs_done, self.epochs_done + max_epochs)
         self.is_fitted = True
         return self
+
+    def _reprocess_train_dataset(self, dataset: tp.Any) -> None:
+        """`data_preparator.process_dataset_train(dataset)` for a model that already holds weights: validate before mutating — if
+        the dataset maps items to other embedding rows the preparator is left exactly as it was and ValueError is raised (a caller
+        that catches it must not end up with trained weights paired with a different item map)."""
+        dp = self.data_preparator
+        same = getattr(self, "_train_data_ready", False) and getattr(self, "_train_dataset_ref", None) is dataset
+        if same:
+            return      # the very Dataset object the sessions were cut from (Datasets are immutable): nothing to redo
+        keep = ("item_id_map", "train_dataset", "extra_token_ids", "val_interactions", "_train_store")
+        snapshot = {k: getattr(dp, k) for k in keep if hasattr(dp, k)}
+        known = np.asarray(dp.item_id_map.external_ids)
+        try:
+            dp.process_dataset_train(dataset)
+            now = np.asarray(dp.item_id_map.external_ids)
+            if len(known) != len(now) or not (known == now).all():
+                raise ValueError("fit_partial: the dataset maps items to other embedding rows than the model was trained with "
+                                 "(different items, or a different order of first appearance)")
+        except Exception:
+            for k in keep:
+                if k in snapshot:
+                    setattr(dp, k, snapshot[k])
+                elif hasattr(dp, k):
+                    delattr(dp, k)
+            raise
+        self._train_data_ready = True
+        self._train_dataset_ref = dataset
 
     # ---- inference ----------------------------------------------------------------------------------------
     def _item_embeddings(self) -> torch.Tensor:
@@ -732,7 +783,8 @@ class TransformerModelBase:
         cfg = dict(config)
         klass = _import_object(cfg.pop("cls", cls))
         for key in ("data_preparator_type", "transformer_layers_type", "similarity_module_type", "get_val_mask_func",
-                    "item_net_constructor_type", "negative_sampler_type"):
+                    "item_net_constructor_type", "negative_sampler_type", "pos_encoding_type", "lightning_module_type",
+                    "backbone_type"):
             if cfg.get(key) is not None:
                 cfg[key] = _import_object(cfg[key])
         if cfg.get("item_net_block_types") is not None:
@@ -766,6 +818,12 @@ class TransformerModelBase:
         hyper = checkpoint["hyper_parameters"]
         config = ckpt.translate_config(dict(hyper["model_config"]))
         config.pop("cls", None)       # the class the method is called on decides (the reference stores a short name)
+        if config.get("get_trainer_func") is not None:
+            # a reference checkpoint trained under a custom Lightning Trainer: weights, moments and config restore as they are, the
+            # trainer factory cannot (this engine has its own loop) — said aloud, never silently
+            warnings.warn(f"checkpoint names get_trainer_func={config['get_trainer_func']!r}: dropped, fit_partial() of the restored "
+                          f"model runs the engine's own training loop")
+            config["get_trainer_func"] = None
         loaded = cls.from_config(config)
         dp = loaded.data_preparator
         ext = hyper["item_external_ids"]

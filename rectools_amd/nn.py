@@ -240,6 +240,17 @@ class LearnableInversePositionalEncoding(nn.Module):
         self.pos_emb = EmbeddingParams(session_max_len, n_factors) if use_pos_emb else None
         self.use_scale_factor = use_scale_factor
 
+    def forward(self, sessions: torch.Tensor) -> torch.Tensor:
+        """net_blocks.py:374-400 on [B, L, d] item embeddings, out of torch ops.  The stock backbone never calls it — the scale
+        and the inverse positional rows ride inside `rt_embed_fwd` (`TransformerTorchBackbone._fused_pos`); it serves subclasses
+        that extend the encoding and call `super().forward`."""
+        _, L, d = sessions.shape
+        if self.use_scale_factor:
+            sessions = sessions * (d ** 0.5)
+        if self.pos_emb is not None:
+            sessions = sessions + self.pos_emb.weight[:L].flip(0)[None]
+        return sessions
+
 
 # ---- feed-forward networks ----------------------------------------------------------------------------
 class PointWiseFeedForward(nn.Module):
@@ -718,23 +729,40 @@ class TransformerTorchBackbone(nn.Module):
         self.n_heads = n_heads
         self.dropout_rate = dropout_rate
 
+    def _fused_pos(self) -> bool:
+        """The stock positional encoding (scale + inverse learnable rows) is fused into `rt_embed_fwd`; any other class plugged
+        through `pos_encoding_type` (transformers/base.py:407-413) — a subclass that overrides `forward` included — is CALLED
+        on the [B, L, d] item embeddings, as the reference does (torch_backbone.py:245-246)."""
+        pe = self.pos_encoding_layer
+        return isinstance(pe, LearnableInversePositionalEncoding) and type(pe).forward is LearnableInversePositionalEncoding.forward
+
+    def _embed_sessions(self, table: torch.Tensor, ids: torch.Tensor, B: int, L: int, p: float) -> torch.Tensor:
+        """[B*L, d] = dropout(pos_encoding(item embeddings)) (torch_backbone.py:245-247)."""
+        d = table.shape[1]
+        if self._fused_pos():
+            pos = self.pos_encoding_layer.pos_emb.weight if self.pos_encoding_layer.pos_emb is not None else None
+            scale = float(d) ** 0.5 if self.pos_encoding_layer.use_scale_factor else 1.0
+            return ops.embed(table, pos, ids, L, scale, p)
+        seqs = ops.embed(table, None, ids, L, 1.0, 0.0).view(B, L, d)
+        seqs = self.pos_encoding_layer(seqs).reshape(B * L, d)
+        return ops.dropout(seqs, p) if p > 0 else seqs
+
     def encode_sessions(self, batch: Batch, item_embs: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
         """-> [B, L, d] session encodings (torch_backbone.py:220-260)."""
         x = batch["x"]
         B, L = x.shape
         table = self.item_model.table if item_embs is None else item_embs
         d = table.shape[1]
-        pos = self.pos_encoding_layer.pos_emb.weight if self.pos_encoding_layer.pos_emb is not None else None
-        scale = float(d) ** 0.5 if self.pos_encoding_layer.use_scale_factor else 1.0
         ids = x.reshape(-1)
-        seqs = ops.embed(table, pos, ids, L, scale, self.dropout_rate if self.training else 0.0)
+        seqs = self._embed_sessions(table, ids, B, L, self.dropout_rate if self.training else 0.0)
         seqs = self.transformer_layers(seqs, ids, B, L, self.use_causal_attn, self.use_key_padding_mask, batch)
         return seqs.view(B, L, d)
 
     def can_encode_packed(self, n_factors: int, window: int) -> bool:
         """Does `encode_last_packed` serve this backbone (inference, a layer stack with a packed forward, see its `packed_ok`)?"""
         ok = getattr(self.transformer_layers, "packed_ok", None)
-        return ok is not None and not self.training and not torch.is_grad_enabled() and ok(n_factors, window, self.use_causal_attn)
+        return ok is not None and self._fused_pos() and not self.training and not torch.is_grad_enabled() \
+            and ok(n_factors, window, self.use_causal_attn)
 
     def encode_last_packed(self, offsets: torch.Tensor, items: torch.Tensor, rows: torch.Tensor, window: int,
                            item_embs: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -784,9 +812,6 @@ class TransformerTorchBackbone(nn.Module):
         x = batch["x"]
         B, L = x.shape
         table = self.item_model.table if item_embs is None else item_embs
-        d = table.shape[1]
-        pos = self.pos_encoding_layer.pos_emb.weight if self.pos_encoding_layer.pos_emb is not None else None
-        scale = float(d) ** 0.5 if self.pos_encoding_layer.use_scale_factor else 1.0
         ids = x.reshape(-1)
-        seqs = ops.embed(table, pos, ids, L, scale, 0.0)
+        seqs = self._embed_sessions(table, ids, B, L, 0.0)
         return fast(seqs, ids, B, L, self.use_causal_attn, self.use_key_padding_mask, batch)

@@ -1490,7 +1490,8 @@ class _SampledLoss(torch.autograd.Function):
         # side stream under the MFMA-bound layer backward (rt_sampled_loss_bwd accepts either output as NULL for that):
         # measured 3.12 vs 3.06 ms/step at C2 — the co-running gather slows the GEMMs by more than it hides.
         _c("rt_sampled_loss_bwd", *args, d_sess, d, d_table, ws, ws.numel())
-        _offer_table_grad(table, d_table)
+        if ctx.needs_input_grad[1]:   # only a gradient autograd will hand to the table can serve as the embedding node's sink
+            _offer_table_grad(table, d_table)
         return d_sess, d_table, None, None, None, None, None, None, None
 
 
@@ -1556,7 +1557,8 @@ class _SoftmaxLoss(torch.autograd.Function):
         _gemm(logits, Vp, 0, s_act, d, 0, d_tab, d, None, None, 0, Vp, d, Rp, 0, _wgrad_splits(Rp, Vp, d))  # dE = G^T @ S
         d_table = d_tab[:V]
         d_table[0].zero_()  # padding_idx row never receives gradient (item_net.py:260-264)
-        _offer_table_grad(tab[:V], d_table)
+        if ctx.needs_input_grad[1]:
+            _offer_table_grad(tab[:V], d_table)
         d_sess = torch.zeros((M_total, d), dtype=torch.float32, device=logits.device)
         _c("rt_scatter_rows", ds_act, d, act_idx, R, d, d_sess, d)
         return d_sess, d_table, None, None, None, None, None
