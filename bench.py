@@ -41,28 +41,67 @@ GEMM_X6 = os.environ.get("RT_GEMM_SPLIT", "bf16x6") != "exact"
 GEMM_PEAK_TF = MFMA_BF16_PEAK_TF / 6.0 if GEMM_X6 else MFMA_F32_PEAK_TF
 
 
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n_gpus: int) -> None:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves — re-exec under
+    `torch.distributed.run --nnodes=1 --nproc-per-node N` on 127.0.0.1 (the driver's own form) and hand its exit code back.  With
+    fewer visible devices than ranks (a 1-GPU test box) the ranks share devices and rendezvous over gloo (RCCL refuses two ranks
+    on one device); the line then says so (`dist.backend`, `dist.devices_visible`) — it is a path check, not a scaling number."""
+    if n_gpus <= 1 or "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return
+    import subprocess
+
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if os.environ.get("RT_BENCH_DRY_RUN") != "1" and torch.cuda.is_available() and torch.cuda.device_count() < n_gpus:
+        env.setdefault("RT_BENCH_BACKEND", "gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def dist_setup(n_gpus: int):
+    """-> (rank, world, local device index, description of the process group for the line).  The world size the line reports is
+    what the initialised process group says — never the `--gpus` argument — and a mismatch between the two is an error."""
+    self_launch(n_gpus)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    dry = os.environ.get("RT_BENCH_DRY_RUN") == "1"      # tests/test_bench_contract.py: launcher + rendezvous + line, no device work
+    info = {"backend": None, "world_size": 1, "devices_visible": 0 if dry else torch.cuda.device_count(), "rccl_ranks": 0,
+            "launcher": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ or "WORLD_SIZE" in os.environ else "single process"}
     if world > 1:
         import torch.distributed as dist
 
-        # RT_BENCH_BACKEND=gloo lets the N>1 path run on a box with fewer GPUs than ranks (scripts/gpu_full.sh does that
-        # with 2 ranks on the one GPU of the test box); the driver's multi-GPU runs use nccl = RCCL, one rank per GPU.
-        backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
-        local = local % torch.cuda.device_count()
-        torch.cuda.set_device(local)
+        # RT_BENCH_BACKEND=gloo lets the N>1 path run on a box with fewer GPUs than ranks; the driver's multi-GPU runs use nccl =
+        # RCCL, one rank per GPU.
+        backend = "gloo" if dry else os.environ.get("RT_BENCH_BACKEND", "nccl")
+        if not dry:
+            local = local % torch.cuda.device_count()
+            torch.cuda.set_device(local)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
-    else:
+        # what the communicator itself says: every rank contributes 1 (over RCCL when the backend is nccl)
+        ones = torch.ones(1, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        info.update(backend=backend, world_size=dist.get_world_size(), rccl_ranks=int(ones.item()) if backend == "nccl" else 0,
+                    ranks_counted_by_allreduce=int(ones.item()))
+        world = dist.get_world_size()
+    elif not dry:
         torch.cuda.set_device(0)
     if world != n_gpus:
-        if rank == 0:
-            print(f"[bench] warning: --gpus {n_gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    return rank, world, local
+        raise SystemExit(f"[bench] --gpus {n_gpus} but the process group has {world} rank(s): refusing to report n_gpus={n_gpus} "
+                         f"(launch with torch.distributed.run --nproc-per-node {n_gpus}, or plain `python bench.py --gpus {n_gpus}`)")
+    return rank, world, local, info
 
 
 def barrier_sync(world: int):
@@ -464,7 +503,15 @@ def main():
     ap.add_argument("--topk-steps", type=int, default=5, help="timed steps of the topk5m sub-leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
-    rank, world, local = dist_setup(args.gpus)
+    rank, world, local, dist_info = dist_setup(args.gpus)
+    if os.environ.get("RT_BENCH_DRY_RUN") == "1":   # launcher / rendezvous / line shape only (CPU test of the N > 1 start-up)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "dist": dist_info}))
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.destroy_process_group()
+        return
 
     from rectools_amd import _lib
 
@@ -518,6 +565,7 @@ def main():
             out["recommend"] = topk_leg("recommend", args, rank, world, cpu_ok)
             out["topk5m"] = topk_leg("topk5m", args, rank, world, cpu_ok)
         out["env"] = env
+    out["dist"] = dist_info
 
     if rank == 0:
         print(json.dumps(out))

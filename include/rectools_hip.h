@@ -150,6 +150,16 @@ int rt_collate(const int64_t* offsets, const int64_t* items, const float* weight
                int32_t B, int32_t L, int32_t mode, const float* probs, const int64_t* rand_ids, float mask_prob,
                int64_t mask_id, int64_t* x, int64_t* y, float* yw, int64_t* ts_out, rt_stream_t stream);
 
+/* Packed (padding-free) SASRec batch, DESIGN.md §9.0 — the rows of the batch are the REAL positions only (the reference builds the
+ * left-padded [B, L] window, sasrec.py:86-104,149-166; 28 % / 45 % of its rows are padding at ML-20M scale).  Session idx[b] owns
+ * rows cu_seqlens[b] .. cu_seqlens[b+1]-1, oldest first; the caller cuts cu_seqlens [B+1] from the store's offsets on the host
+ * (cu[b+1] - cu[b] = min(length - train, window)) — the row count sizes every buffer of the step, so the host knows it without a
+ * device round trip.  rows >= cu[B]: the outputs' row count (tail rows: id 0, target 0, weight 0, dist 0).  train = 1: x = kept
+ * tail[:-1], y = tail[1:], yw = weights of y; train = 0: x = the last items.  dist [rows] = distance of a row from its session's
+ * end = the index of its positional row (net_blocks.py:388-399). */
+int rt_collate_packed(const int64_t* offsets, const int64_t* items, const float* weights, const int64_t* idx, const int64_t* cu_seqlens,
+                      int32_t B, int32_t rows, int32_t train, int64_t* x, int64_t* y, float* yw, int64_t* dist, rt_stream_t stream);
+
 /* a11  uniform negatives on the device — CatalogUniformSampler.get_negatives (negative_sampler.py:58-73):
  * out[e] uniform over item ids [low, high), e < n (the [B, L | 1, N] tensor, flat), no rejection of positives.
  * Philox4x32-10 keyed by (seed, offset): the same pair always yields the same batch; pass the step counter as `offset`.
@@ -197,6 +207,15 @@ size_t rt_embed_bwd_workspace_bytes(int32_t M, int32_t V, int32_t d);
 int rt_embed_bwd(const int64_t* ids, const float* gout, float scale, int32_t M, int32_t L, int32_t d, int32_t V, float p,
                  uint64_t seed, uint64_t stream_id, float* gtable, int32_t accumulate, float* gpos, void* workspace,
                  size_t workspace_bytes, rt_stream_t stream);
+
+/* K2 on packed rows: out[m,:] = dropout(table[ids[m]] * scale + pos[dist[m]]) (dist from rt_collate_packed; pos may be NULL).
+ * Backward: gtable as rt_embed_bwd; gpos [L,d] (optional, fully overwritten): gpos[t] = sum over the sessions longer than t of
+ * the gradient row at distance t from the session's end (cu_seqlens [B+1]). */
+int rt_embed_packed_fwd(const int64_t* ids, const int64_t* dist, const float* table, const float* pos, float scale, int32_t M,
+                        int32_t d, float p, uint64_t seed, uint64_t stream_id, float* out, rt_stream_t stream);
+int rt_embed_packed_bwd(const int64_t* ids, const int64_t* cu_seqlens, int32_t B, const float* gout, float scale, int32_t M, int32_t L,
+                        int32_t d, int32_t V, float p, uint64_t seed, uint64_t stream_id, float* gtable, int32_t accumulate,
+                        float* gpos, void* workspace, size_t workspace_bytes, rt_stream_t stream);
 
 /* K3  LayerNorm over rows of [M,d] (nn.LayerNorm call sites: sasrec.py:221,226,303; net_blocks.py:247,257;
  * ligr.py:90,102; hstu.py:256,291).  mean/rstd [M] are saved for the backward; dx/dw/db are overwritten

@@ -80,6 +80,39 @@ __global__ __launch_bounds__(256) void collate_kernel(CollateArgs a) {
   }
 }
 
+// Packed (padding-free) batches, DESIGN.md §9.0: the rows of a batch are the REAL positions only.  Session b of the batch owns rows
+// cu[b] .. cu[b+1]-1 (oldest first); cu is cut on the host from the store's offsets (the row count sizes every buffer of the step, so
+// the host has to know it anyway — computing it there keeps the step free of device -> host synchronisation).  One thread per row:
+// binary search of the row's session in cu, then the same index arithmetic as the padded collate.  Rows behind cu[B] (the tail up
+// to the 128-row GEMM tile) get id 0 / target 0 / weight 0 / dist 0.
+struct PackedArgs {
+  const long long* offsets; const long long* items; const float* weights; const long long* idx; const long long* cu;
+  int B, rows, train;
+  long long* x; long long* y; float* yw; long long* dist;
+};
+
+__global__ __launch_bounds__(256) void collate_packed_kernel(PackedArgs a) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= a.rows) return;
+  long long xi = 0, yi = 0, di = 0; float w = 0.f;
+  if (r < a.cu[a.B]) {
+    int lo = 0, hi = a.B;                 // largest b with cu[b] <= r
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (a.cu[mid] <= r) lo = mid; else hi = mid;
+    }
+    const long long c0 = a.cu[lo], n = a.cu[lo + 1] - c0, j = r - c0;
+    const long long end = a.offsets[a.idx[lo] + 1];
+    // train: the kept tail is n + 1 items, x = all but the last, y = all but the first (sasrec.py:86-104); recommend: the last n items
+    const long long src = end - n - (a.train ? 1 : 0) + j;
+    xi = a.items[src];
+    di = n - 1 - j;
+    if (a.train) { yi = a.items[src + 1]; w = a.weights[src + 1]; }
+  }
+  a.x[r] = xi; a.dist[r] = di;
+  if (a.train) { a.y[r] = yi; a.yw[r] = w; }
+}
+
 // a11 — CatalogUniformSampler.get_negatives (negative_sampler.py:58-73): n ids uniform in [low, high), no rejection of
 // positives.  Counter-based (Philox4x32-10): element e is word (e & 3) of philox(seed, subsequence = e >> 2, offset), so a
 // batch is a pure function of (seed, offset) — reproducible whatever the launch geometry — and `offset` (the step counter)
@@ -117,6 +150,28 @@ int rt_sample_negatives(int64_t low, int64_t high, int64_t n, uint64_t seed, uin
   if (blocks > 16 * rt_num_cus()) blocks = 16 * rt_num_cus();
   sample_negatives_kernel<<<(int)blocks, 256, 0, stream>>>(low, (unsigned)(high - low), n4, n, seed, offset,
                                                             reinterpret_cast<long long*>(out));
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+// Packed SASRec batch (no padding rows): cu_seqlens [B+1] (device; cu[b+1] - cu[b] = min(session length - train, window) rows of
+// session idx[b], cut by the caller from the store's offsets), rows = the row count of the outputs (>= cu[B]; the tail is zero
+// filled).  train = 1: x / y / yw as sasrec.py:86-104 (y, yw, weights required); train = 0: x = the last items (recommend).
+// dist [rows] = distance of a row from its session's end (the index of its positional row, net_blocks.py:388-399).
+int rt_collate_packed(const int64_t* offsets, const int64_t* items, const float* weights, const int64_t* idx, const int64_t* cu_seqlens,
+                      int32_t B, int32_t rows, int32_t train, int64_t* x, int64_t* y, float* yw, int64_t* dist, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (B < 0 || rows < 0) return RT_ERR_INVALID_ARG;
+  if (rows == 0) return RT_OK;
+  if (offsets == nullptr || items == nullptr || idx == nullptr || cu_seqlens == nullptr || x == nullptr || dist == nullptr)
+    return RT_ERR_INVALID_ARG;
+  if (train && (y == nullptr || yw == nullptr || weights == nullptr)) return RT_ERR_INVALID_ARG;
+  PackedArgs a{};
+  a.offsets = reinterpret_cast<const long long*>(offsets); a.items = reinterpret_cast<const long long*>(items); a.weights = weights;
+  a.idx = reinterpret_cast<const long long*>(idx); a.cu = reinterpret_cast<const long long*>(cu_seqlens); a.B = B; a.rows = rows;
+  a.train = train ? 1 : 0; a.x = reinterpret_cast<long long*>(x); a.y = reinterpret_cast<long long*>(y); a.yw = yw;
+  a.dist = reinterpret_cast<long long*>(dist);
+  collate_packed_kernel<<<(rows + 255) / 256, 256, 0, stream>>>(a);
   RT_CHECK_LAUNCH();
   return RT_OK;
 }

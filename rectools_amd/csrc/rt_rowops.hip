@@ -27,14 +27,15 @@ __device__ __forceinline__ f32x4 drop4(f32x4 v, unsigned long long seed, unsigne
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restrict__ ids, const float* __restrict__ table,
                                                         const float* __restrict__ pos, float scale, int M, int L, int d,
                                                         float p, unsigned long long seed, unsigned long long stream,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, const long long* __restrict__ dist = nullptr) {
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= M) return;
   const long long id = ids[m];
   const int l = m % L;
   const float* trow = table + id * (long long)d;
-  const float* prow = pos ? pos + (long long)(L - 1 - l) * d : nullptr;
+  // positional row: by the slot of the padded window, or (packed rows) by the row's distance from its session's end
+  const float* prow = pos ? pos + (dist ? dist[m] : (long long)(L - 1 - l)) * d : nullptr;
   const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
   for (int c = lane * 4; c < d; c += 256) {
     f32x4 v = *reinterpret_cast<const f32x4*>(trow + c);
@@ -60,6 +61,7 @@ struct EmbBwdArgs {
   unsigned long long seed, stream;
   float* gtable; float* gpos;
   int accumulate;   // 1: gtable already holds another gradient of the same table: rows with positions are ADDED to, others left alone
+  const long long* cu; int B;   // packed rows (cu != nullptr): session b = rows cu[b] .. cu[b+1]-1, positional row = distance from its end
   int* count; int* offsets; int* cursor; int* blocksum; int* order; int* rank; int* heavy_count; int* heavy_ids; int* heavy_chunk;
   float* slab;   // [chunks][d] partial rows of the popular ids
 };
@@ -175,14 +177,19 @@ __global__ __launch_bounds__(256) void embed_bwd_pos_kernel(EmbBwdArgs a) {
   __shared__ f32x4 s_part[4][NDV][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l = blockIdx.x;
-  const int B = a.M / a.L;
+  const int B = a.cu ? a.B : a.M / a.L;
   const float inv_keep = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
   f32x4 acc[NDV];
 #pragma unroll
   for (int i = 0; i < NDV; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
   for (int b = wave; b < B; b += 4) {
-    const long long m = (long long)b * a.L + l;
+    long long m = (long long)b * a.L + l;
+    if (a.cu) {   // packed: the row at distance (L-1-l) from the end of session b, if the session is that long
+      const long long e = a.cu[b + 1];
+      m = e - 1 - (a.L - 1 - l);
+      if (m < a.cu[b]) continue;
+    }
 #pragma unroll
     for (int i = 0; i < NDV; ++i) {
       const int c = lane * 4 + 256 * i;
@@ -621,6 +628,19 @@ int rt_embed_fwd(const int64_t* ids, const float* table, const float* pos, float
   return RT_OK;
 }
 
+// Packed rows: as rt_embed_fwd, the positional row of row m is pos[dist[m]] (dist = distance of the row from its
+// session's end, int64 [M]); rows with id 0 (the unused tail up to the GEMM tile) read table row 0 and are ignored downstream.
+int rt_embed_packed_fwd(const int64_t* ids, const int64_t* dist, const float* table, const float* pos, float scale, int32_t M,
+                        int32_t d, float p, uint64_t seed, uint64_t stream_id, float* out, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (M <= 0) return RT_OK;
+  if ((d & 3) != 0 || (pos != nullptr && dist == nullptr)) return RT_ERR_INVALID_ARG;
+  embed_fwd_kernel<<<(M + 3) / 4, 256, 0, stream>>>(reinterpret_cast<const long long*>(ids), table, pos, scale, M, 1, d, p, seed,
+                                                     stream_id, out, reinterpret_cast<const long long*>(dist));
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
 // Host arithmetic: bytes of the int scratch rt_embed_bwd needs.
 size_t rt_embed_bwd_workspace_bytes(int32_t M, int32_t V, int32_t d) {
   const size_t n = (size_t)V + 1, cap = (size_t)emb_chunk_cap(M);
@@ -644,6 +664,36 @@ int rt_embed_bwd(const int64_t* ids, const float* gout, float scale, int32_t M, 
   int* ip = reinterpret_cast<int*>(a.slab + cap * (size_t)d);
   a.count = ip; ip += n;
   a.heavy_count = ip; ip += 1;          // directly behind count: one memset clears both
+  a.offsets = ip; ip += n;
+  a.cursor = ip; ip += n;
+  a.blocksum = ip; ip += scan_blocks(n) + 64;
+  a.order = ip; ip += M;
+  a.rank = ip; ip += M;
+  a.heavy_ids = ip; ip += cap;
+  a.heavy_chunk = ip;
+  if (d <= 256) return launch_embed_bwd<1>(a, stream);
+  if (d <= 512) return launch_embed_bwd<2>(a, stream);
+  return launch_embed_bwd<4>(a, stream);
+}
+
+// Backward of rt_embed_packed_fwd: gtable as rt_embed_bwd; gpos [L, d] (optional, fully overwritten): gpos[t] = sum over the
+// sessions longer than t of the gradient row at distance t from the session's end (cu_seqlens [B+1], rows of session b =
+// cu[b] .. cu[b+1]-1).  Workspace: rt_embed_bwd_workspace_bytes(M, V, d).
+int rt_embed_packed_bwd(const int64_t* ids, const int64_t* cu_seqlens, int32_t B, const float* gout, float scale, int32_t M, int32_t L,
+                        int32_t d, int32_t V, float p, uint64_t seed, uint64_t stream_id, float* gtable, int32_t accumulate,
+                        float* gpos, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  (void)hipGetLastError();
+  if ((d & 3) != 0 || L <= 0 || V <= 0 || M < 0 || B < 0 || d > 1024 || (gpos && cu_seqlens == nullptr)) return RT_ERR_INVALID_ARG;
+  if (workspace == nullptr || workspace_bytes < rt_embed_bwd_workspace_bytes(M, V, d)) return RT_ERR_WORKSPACE;
+  EmbBwdArgs a{};
+  a.ids = reinterpret_cast<const long long*>(ids); a.gout = gout; a.scale = scale; a.M = M; a.L = L; a.d = d; a.V = V; a.p = p;
+  a.seed = seed; a.stream = stream_id; a.gtable = gtable; a.gpos = gpos; a.accumulate = accumulate;
+  a.cu = reinterpret_cast<const long long*>(cu_seqlens); a.B = B;
+  const size_t n = (size_t)V + 1, cap = (size_t)emb_chunk_cap(M);
+  a.slab = reinterpret_cast<float*>(workspace);
+  int* ip = reinterpret_cast<int*>(a.slab + cap * (size_t)d);
+  a.count = ip; ip += n;
+  a.heavy_count = ip; ip += 1;
   a.offsets = ip; ip += n;
   a.cursor = ip; ip += n;
   a.blocksum = ip; ip += scan_blocks(n) + 64;

@@ -94,6 +94,19 @@ class _TrainLoop:
         mine = shard_indices(perm, self.rank, self.world)
         self.mine_t = torch.from_numpy(np.ascontiguousarray(mine, dtype=np.int64)).to(self.device)   # one small H2D per epoch
         self.epoch, self.pos = epoch, 0
+        if self.packed:
+            # packed row offsets of EVERY batch of the epoch, cut on the host from the store's offsets (numpy, vectorised) and
+            # uploaded once: a step then needs no device -> host round trip to learn its row count
+            B, L = self.batch_size, self.dp.session_max_len
+            off = np.asarray(self.store.offsets, dtype=np.int64)
+            lens = np.clip(off[mine + 1] - off[mine] - 1, 0, L)
+            nb = -(-len(mine) // B)
+            grid = np.zeros((nb, B), dtype=np.int64)
+            grid.reshape(-1)[:len(mine)] = lens
+            cu = np.zeros((nb, B + 1), dtype=np.int64)
+            np.cumsum(grid, axis=1, out=cu[:, 1:])
+            self._cu_host = cu
+            self._cu_dev = torch.from_numpy(cu).to(self.device)
 
     def batches_left(self) -> int:
         return 0 if self.mine_t is None else -(-(int(self.mine_t.numel()) - self.pos) // self.batch_size)
@@ -109,17 +122,19 @@ class _TrainLoop:
         return idx
 
     def _packed_batch(self, idx: torch.Tensor) -> tp.Dict[str, tp.Any]:
-        """The SASRec training batch of the sessions `idx` without padding rows: x / y / yw / dist padded to the 128-row GEMM
-        tile with (id 0, target 0) rows, negatives from the plugged sampler for every row."""
-        L = self.dp.session_max_len
-        cu, x, y, yw, dist = hnn.pack_train_items(self.dstore.offsets, self.dstore.items, self.dstore.weights, idx, L)
-        n = int(x.numel())
-        tail = (n + 127) // 128 * 128 - n
-        pad = lambda t: torch.nn.functional.pad(t, (0, tail))   # noqa: E731
-        batch: tp.Dict[str, tp.Any] = {"x": pad(x), "y": pad(y), "yw": pad(yw), "dist": pad(dist), "cu": cu, "window": L}
+        """The SASRec training batch of the sessions `idx` without padding rows (`rt_collate_packed`): x / y / yw / dist over the
+        real positions, padded to the 128-row GEMM tile with (id 0, target 0) rows; negatives from the plugged sampler for every
+        row.  Row offsets and row count come from the epoch's host-side table."""
+        bi = self.pos // self.batch_size - 1          # `_next_indices` has advanced `pos` past this batch
+        nb = int(idx.numel())
+        n = int(self._cu_host[bi, nb])
+        rows = max((n + 127) // 128 * 128, 128)
+        cu = self._cu_dev[bi, :nb + 1]
+        x, y, yw, dist = ops.collate_packed(self.dstore.offsets, self.dstore.items, self.dstore.weights, idx, cu, rows, train=True)
+        batch: tp.Dict[str, tp.Any] = {"x": x, "y": y, "yw": yw, "dist": dist, "cu": cu, "window": self.dp.session_max_len}
         if self.dp.negative_sampler is not None:
             batch["negatives"] = self.dp.negative_sampler.get_negatives(
-                {"x": batch["x"].view(-1, 1)}, lowest_id=self.dp.n_item_extra_tokens, highest_id=self.dp.item_id_map.size)
+                {"x": x.view(-1, 1)}, lowest_id=self.dp.n_item_extra_tokens, highest_id=self.dp.item_id_map.size)
         return batch
 
     def step(self) -> torch.Tensor:
@@ -516,12 +531,15 @@ class TransformerModelBase:
         return offsets, item_s, w_s, indptr, indices
 
     @staticmethod
-    def _select_csr_rows(indptr: torch.Tensor, indices: torch.Tensor, rows: torch.Tensor) -> tp.Tuple[torch.Tensor, torch.Tensor]:
-        """CSR of the given rows, in the given order (indices of a row stay ascending)."""
+    def _select_csr_rows(indptr: torch.Tensor, indices: torch.Tensor, rows: torch.Tensor,
+                         total: tp.Optional[int] = None) -> tp.Tuple[torch.Tensor, torch.Tensor]:
+        """CSR of the given rows, in the given order (indices of a row stay ascending).  `total`: the entry count when the caller
+        knows it (from host offsets) — saves the device -> host round trip that sizes the result."""
         lens = indptr[rows + 1] - indptr[rows]
         new_indptr = torch.zeros((rows.numel() + 1,), dtype=torch.int64, device=indptr.device)
         torch.cumsum(lens, 0, out=new_indptr[1:])
-        total = int(new_indptr[-1])
+        if total is None:
+            total = int(new_indptr[-1])
         src = torch.repeat_interleave(indptr[rows] - new_indptr[:-1], lens, output_size=total) \
             + torch.arange(total, dtype=torch.int64, device=indptr.device)
         return new_indptr, indices[src]
@@ -547,6 +565,9 @@ class TransformerModelBase:
             to_dev(df[Columns.Datetime].values.astype("datetime64[ns]").view(np.int64)),
             to_dev(df[Columns.Weight].values.astype(np.float32, copy=False)), to_dev(lookup),
             dataset.user_id_map.size, dp.item_id_map.size)
+        # host copies of the two offset arrays (n_users + 1 int64 each, one D2H per Dataset): a request computes its row counts —
+        # encoder rows, filter entries — from them, so no step of a recommend() call waits on the device to size a buffer
+        index = tuple(index) + (index[0].cpu().numpy(), index[3].cpu().numpy())
         try:
             inter._rt_session_index = (key, index, (df, dp.item_id_map, dataset.item_id_map, dataset.user_id_map))   # pylint: disable=protected-access
         except AttributeError:   # a duck-typed Interactions object with __slots__: no cache
@@ -654,40 +675,53 @@ class TransformerModelBase:
         if len(req) == 0 or len(whitelist) == 0:
             return empty
         n_req, V = len(req), dp.item_id_map.size
-        offsets, item_s, w_s, f_indptr, f_indices = self._device_session_index(dataset, device)
-        req_t = torch.from_numpy(np.ascontiguousarray(req.astype(np.int64))).to(device, non_blocking=True)
-        valid = (offsets[req_t + 1] - offsets[req_t]) > 0            # users with at least one item the model knows
-        valid_rows = req_t[valid]                                   # rows of the session index, request order
-        n_valid = int(valid_rows.numel())
+        offsets, item_s, w_s, f_indptr, f_indices, off_h, fptr_h = self._device_session_index(dataset, device)
+        req = np.ascontiguousarray(req.astype(np.int64))
+        lens_h = off_h[req + 1] - off_h[req]
+        valid_h = lens_h > 0                                        # users with at least one item the model knows
+        rows_h = req[valid_h]                                       # rows of the session index, request order
+        n_valid = int(len(rows_h))
         n_cold = n_req - n_valid
         if n_cold > 0 and on_unsupported_targets != "ignore":
             warnings.warn(f"{n_cold} target users were considered cold because of missing known items")
         if n_valid == 0:
             return empty
+        valid_rows = torch.from_numpy(rows_h).to(device, non_blocking=True)
         dstore = DeviceSequenceStore.from_device(offsets, item_s, w_s, None)
         item_embs = self._item_embeddings()
         outs = []
         with torch.no_grad():
             bs = self._encode_batch_size()
             # packed encoder (no padding rows: 45 % of the [B, L] window at ML-20M scale) where the stack offers it; RT_PACKED=0
-            # keeps the padded window.  Same encodings up to fp32 rounding (tests/test_models_gpu.py).
+            # keeps the padded window.  Same encodings up to fp32 rounding (tests/test_packed_gpu.py).
             packed = os.environ.get("RT_PACKED", "1") != "0" and lm.torch_model.can_encode_packed(item_embs.shape[1], dp.session_max_len)
-            for b0 in range(0, n_valid, bs):
+            if packed:   # packed row offsets of every encoder launch, cut on the host, one upload
+                L = dp.session_max_len
+                n_launch = -(-n_valid // bs)
+                grid = np.zeros((n_launch, bs), dtype=np.int64)
+                grid.reshape(-1)[:n_valid] = np.minimum(lens_h[valid_h], L)
+                cu_h = np.zeros((n_launch, bs + 1), dtype=np.int64)
+                np.cumsum(grid, axis=1, out=cu_h[:, 1:])
+                cu_d = torch.from_numpy(cu_h).to(device, non_blocking=True)
+            for bi, b0 in enumerate(range(0, n_valid, bs)):
+                nb = min(bs, n_valid - b0)
                 if packed:
-                    outs.append(lm.torch_model.encode_last_packed(offsets, item_s, valid_rows[b0:b0 + bs], dp.session_max_len, item_embs))
+                    outs.append(lm.torch_model.encode_last_packed(offsets, item_s, valid_rows[b0:b0 + nb], dp.session_max_len, item_embs,
+                                                                  cu=cu_d[bi, :nb + 1], n_rows=int(cu_h[bi, nb])))
                     continue
-                batch = dp.collate_recommend_device(dstore, valid_rows[b0:b0 + bs])
+                batch = dp.collate_recommend_device(dstore, valid_rows[b0:b0 + nb])
                 outs.append(lm.torch_model.encode_last(batch, item_embs))   # last-position encodings, [b, d]
         user_embs = torch.cat(outs)
         ranker = HipRanker(lm.torch_model.similarity_module.distance, device, user_embs, item_embs)
         filt = None
         if filter_viewed:  # CSR of the distinct (user, item) pairs, rows in request order, indices ascending
-            indptr, indices = self._select_csr_rows(f_indptr, f_indices, valid_rows)
+            flens = fptr_h[rows_h + 1] - fptr_h[rows_h]
+            indptr, indices = self._select_csr_rows(f_indptr, f_indices, valid_rows, total=int(flens.sum()))
             if indices.numel() == 0:
                 indices = torch.zeros((1,), dtype=torch.int32, device=device)
             filt = DeviceCSR(indptr, indices, (n_valid, V))
         ids, scores, cnt, _ = ranker.rank_device(np.arange(n_valid), k=k, filter_pairs_csr=filt, sorted_object_whitelist=whitelist)
-        ext_users = np.asarray(users)[valid.cpu().numpy()]
+        ext_users = np.asarray(users)[valid_h]
         return self._assemble(ext_users, ids, scores, cnt, add_rank_col, Columns.User)
 
     def recommend_to_items(self, target_items: tp.Any, dataset: tp.Any, k: int, filter_itself: bool = True,

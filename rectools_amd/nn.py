@@ -765,42 +765,40 @@ class TransformerTorchBackbone(nn.Module):
             and ok(n_factors, window, self.use_causal_attn)
 
     def encode_last_packed(self, offsets: torch.Tensor, items: torch.Tensor, rows: torch.Tensor, window: int,
-                           item_embs: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
+                           item_embs: tp.Optional[torch.Tensor] = None, cu: tp.Optional[torch.Tensor] = None,
+                           n_rows: tp.Optional[int] = None) -> torch.Tensor:
         """-> [B, d] = `encode_last` of the sessions `rows` of a CSR session store (`offsets`, `items`: model item ids, oldest
         first), without ever building the padded [B, L] batch: the last `window` items of every session are gathered into ONE
         packed row block (embedding + positional row by distance from the session's end, torch_backbone.py:245-246 /
         net_blocks.py:388-399 with inverse positions) and the stack runs on those rows only.  Every session must hold at least
-        one item."""
+        one item.  `cu` [B+1] / `n_rows` = cu[-1]: the packed row offsets cut by the caller on the HOST (no device round trip);
+        without them they are taken from the device offsets (one synchronisation)."""
         table = self.item_model.table if item_embs is None else item_embs
         d = table.shape[1]
         B = int(rows.numel())
-        cu, ids, dist = pack_last_items(offsets, items, rows, window)
-        N = int(ids.numel())
-        Np = (N + 127) // 128 * 128
-        x = torch.zeros((Np, d), dtype=torch.float32, device=table.device)
+        if cu is None or n_rows is None:
+            lens = torch.clamp(offsets[rows + 1] - offsets[rows], max=window)
+            cu = torch.zeros((B + 1,), dtype=torch.int64, device=offsets.device)
+            torch.cumsum(lens, 0, out=cu[1:])
+            n_rows = int(cu[-1])
+        Np = (n_rows + 127) // 128 * 128
+        ids, dist = ops.collate_packed(offsets, items, None, rows, cu, Np, train=False)
+        pos = self.pos_encoding_layer.pos_emb.weight if self.pos_encoding_layer.pos_emb is not None else None
         scale = float(d) ** 0.5 if self.pos_encoding_layer.use_scale_factor else 1.0
-        emb = table.index_select(0, ids)
-        if scale != 1.0:
-            emb = emb * scale
-        if self.pos_encoding_layer.pos_emb is not None:
-            emb = emb + self.pos_encoding_layer.pos_emb.weight.index_select(0, dist)
-        x[:N] = emb
+        x = torch.empty((Np, d), dtype=torch.float32, device=table.device)
+        ops._c("rt_embed_packed_fwd", ids, dist, table, pos, float(scale), Np, d, 0.0, 0, 0, x)
         return self.transformer_layers.forward_last_packed(x, cu, B, window, self.use_key_padding_mask)
 
     def encode_packed_train(self, ids: torch.Tensor, dist: torch.Tensor, cu: torch.Tensor, B: int, window: int,
                             item_embs: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Training twin of `encode_sessions` on packed rows: ids / dist [Np] (tail rows: id 0, dist 0), -> [Np, d].  Embedding
-        rows through `ops.embed` (its backward is the counting-sort scatter; pad id 0 has no gradient), positional rows by the
-        distance from the session's end, then the embedding dropout (torch_backbone.py:245-247)."""
+        """Training twin of `encode_sessions` on packed rows: ids / dist [Np] (tail rows: id 0, dist 0), -> [Np, d].  ONE fused
+        pass (`ops.embed_packed`): embedding rows (pad id 0 has no gradient), positional rows by the distance from the session's
+        end, the embedding dropout (torch_backbone.py:245-247)."""
         table = self.item_model.table if item_embs is None else item_embs
         d = table.shape[1]
         scale = float(d) ** 0.5 if self.pos_encoding_layer.use_scale_factor else 1.0
-        seqs = ops.embed(table, None, ids, 1, scale, 0.0)
-        if self.pos_encoding_layer.pos_emb is not None:
-            seqs = ops.add(seqs, self.pos_encoding_layer.pos_emb.weight.index_select(0, dist))
-        p = self.dropout_rate if self.training else 0.0
-        if p > 0:
-            seqs = ops.dropout(seqs, p)
+        pos = self.pos_encoding_layer.pos_emb.weight if self.pos_encoding_layer.pos_emb is not None else None
+        seqs = ops.embed_packed(table, pos, ids, dist, cu, B, window, scale, self.dropout_rate if self.training else 0.0)
         return self.transformer_layers.forward_packed_train(seqs, cu, B, window, self.use_key_padding_mask)
 
     def encode_last(self, batch: Batch, item_embs: tp.Optional[torch.Tensor] = None) -> torch.Tensor:

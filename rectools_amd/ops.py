@@ -360,6 +360,61 @@ def embed(table: torch.Tensor, pos: tp.Optional[torch.Tensor], ids: torch.Tensor
     return _Embed.apply(table, pos, ids.reshape(-1), L, scale, p)
 
 
+class _EmbedPacked(torch.autograd.Function):
+    """`_Embed` on packed rows (`rt_embed_packed_fwd / _bwd`): the positional row of a row is pos[dist[row]]."""
+
+    @staticmethod
+    def forward(ctx, table, pos, ids, dist, cu, B, L, scale, p):
+        M = ids.numel()
+        d = table.shape[1]
+        out = torch.empty((M, d), dtype=torch.float32, device=table.device)
+        seed, sid = RNG.next() if p > 0 else (0, 0)
+        _c("rt_embed_packed_fwd", ids, dist, table, pos, float(scale), M, d, float(p), seed, sid, out)
+        ctx.save_for_backward(ids, cu)
+        ctx.meta = (table.shape, None if pos is None else pos.shape, B, L, scale, p, seed, sid)
+        ctx.table_ptr = table.data_ptr()
+        _TABLE_GRAD_SINK.pop(ctx.table_ptr, None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        ids, cu = ctx.saved_tensors
+        tshape, pshape, B, L, scale, p, seed, sid = ctx.meta
+        gout = gout.contiguous()
+        M, V = ids.numel(), tshape[0]
+        sink = _TABLE_GRAD_SINK.pop(ctx.table_ptr, None)
+        if sink is not None and (tuple(sink.shape) != tuple(tshape) or sink.device != gout.device):
+            sink = None
+        gtable = sink if sink is not None else torch.empty(tshape, dtype=torch.float32, device=gout.device)
+        gpos = None
+        if pshape is not None:
+            gpos = (torch.empty if pshape[0] == L else torch.zeros)(pshape, dtype=torch.float32, device=gout.device)
+        ws_bytes = _lib.load().rt_embed_bwd_workspace_bytes(M, V, tshape[1])
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=gout.device)
+        _c("rt_embed_packed_bwd", ids, cu, B, gout, float(scale), M, L, tshape[1], V, float(p), seed, sid, gtable,
+           1 if sink is not None else 0, gpos, ws, ws_bytes)
+        return (None if sink is not None else gtable), gpos, None, None, None, None, None, None, None
+
+
+def embed_packed(table: torch.Tensor, pos: tp.Optional[torch.Tensor], ids: torch.Tensor, dist: torch.Tensor, cu: torch.Tensor, B: int,
+                 L: int, scale: float, p: float) -> torch.Tensor:
+    """[Np, d] = dropout(table[ids] * scale + pos[dist]) over packed rows (ids / dist [Np] from `rt_collate_packed`; cu [B+1])."""
+    return _EmbedPacked.apply(table, pos, ids.reshape(-1), dist.reshape(-1), cu, B, L, scale, p)
+
+
+def collate_packed(offsets: torch.Tensor, items: torch.Tensor, weights: tp.Optional[torch.Tensor], idx: torch.Tensor, cu: torch.Tensor,
+                   rows: int, train: bool) -> tp.Tuple[torch.Tensor, ...]:
+    """`rt_collate_packed`: -> (x, dist) or, train, (x, y, yw, dist), each [rows] (rows >= cu[-1], the tail zero-filled)."""
+    dev = offsets.device
+    B = int(idx.numel())
+    x = torch.empty((rows,), dtype=torch.int64, device=dev)
+    dist = torch.empty((rows,), dtype=torch.int64, device=dev)
+    y = torch.empty((rows,), dtype=torch.int64, device=dev) if train else None
+    yw = torch.empty((rows,), dtype=torch.float32, device=dev) if train else None
+    _c("rt_collate_packed", offsets, items, weights if train else None, idx, cu, B, rows, 1 if train else 0, x, y, yw, dist)
+    return (x, y, yw, dist) if train else (x, dist)
+
+
 class BagStructure:
     """Static item -> category-value structure of a CatFeaturesItemNet, plus its transpose cut into chunks for the
     backward reduction (include/rectools_hip.h, K1b).  Built once per model from the reference's three buffers."""

@@ -1,0 +1,17 @@
+"""Print the headline numbers of a bench.py JSON line (used by scripts/gpu/visit.sh)."""
+import json
+import sys
+
+try:
+    j = json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")][-1])
+except Exception as e:  # noqa: BLE001
+    print("no bench line:", e); sys.exit(0)
+print("value", j.get("value"), j.get("unit"), "ms/step", j.get("ms_per_step"), "loss", j.get("final_loss"), "env", j.get("env"))
+for k in ("recommend_e2e", "recommend", "topk5m", "train_exact_gemm", "topk5m_u4096"):
+    if isinstance(j.get(k), dict):
+        r = j[k].get("roofline") or {}
+        print(" ", k, j[k].get("value"), j[k].get("unit"), "frac", r.get("frac"), {a: b for a, b in j[k].items() if a.startswith("phase")})
+r = j.get("roofline") or {}
+print("  roofline", r.get("kernel", "")[:50], r.get("achieved"), r.get("unit"), "frac", r.get("frac"))
+for k, v in list((j.get("kernel_breakdown") or {}).items())[:24]:
+    print("   %-30s %8.4f ms  x%5.1f  single %8.4f" % (k, v["ms_per_step"], v["calls_per_step"], v["single_stream_ms"]))

@@ -56,3 +56,40 @@ def test_bench_fails_loudly_without_a_gpu():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
                        timeout=300)
     assert p.returncode != 0 and not any(l.startswith("{") for l in p.stdout.splitlines())   # no number without the HIP path
+
+
+def _run_bench(args, env_extra, timeout=600):
+    env = dict(os.environ, **env_extra)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def test_bench_gpus_n_starts_n_ranks_itself():
+    """`python bench.py --gpus 2` (no torchrun around it) re-launches itself as 2 ranks and reports the world size the process
+    group has; a world size that contradicts --gpus is refused.  Dry run: launcher + gloo rendezvous + line, no device work."""
+    p = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1"], {"RT_BENCH_DRY_RUN": "1"})
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, p.stderr[-2000:]
+    assert lines[0]["n_gpus"] == 2 and lines[0]["dist"]["world_size"] == 2 and lines[0]["dist"]["ranks_counted_by_allreduce"] == 2
+    env = dict(os.environ, RT_BENCH_DRY_RUN="1", WORLD_SIZE="1", RANK="0")
+    q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120, env=env)
+    assert q.returncode != 0 and "refusing to report n_gpus=2" in (q.stderr + q.stdout)
+    assert not any(l.startswith("{") for l in q.stdout.splitlines())
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_runs_end_to_end_on_one_box():
+    """The whole N > 1 bench path from a bare `python bench.py --gpus 2`: on a box with one GPU the two ranks share it and
+    rendezvous over gloo (the line says so); with two or more devices it is RCCL, one rank per GPU."""
+    import torch
+
+    p = _run_bench(["--gpus", "2", "--workload", "train", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"], {})
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, (p.stdout[-1500:], p.stderr[-3000:])
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["dist"]["world_size"] == 2 and line["config"]["global_batch"] == 256
+    assert line["dist"]["backend"] == ("nccl" if torch.cuda.device_count() >= 2 else "gloo")
+    if line["dist"]["backend"] == "nccl":
+        assert line["dist"]["rccl_ranks"] == 2
+    assert line["value"] > 0 and line["final_loss"] > 0

@@ -259,3 +259,72 @@ def test_fused_packed_block_equals_the_modular_packed_block(p, pad_keys):
     else:          # statistics only: same scale of outputs and gradients (the masks differ)
         for a, b in ((res["fused"][0], res["modular"][0]), (res["fused"][1], res["modular"][1])):
             assert torch.isfinite(a).all() and 0.5 < float(a.norm() / b.norm()) < 2.0
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_collate_packed_kernel_equals_the_tensor_op_restatement(train):
+    """`rt_collate_packed` (one launch, row offsets cut on the host) against `nn.pack_train_items` / `pack_last_items` (plain torch
+    ops pinned to the reference's collate in tests/test_host_path.py): bit-identical x / y / yw / dist, zero tail."""
+    from rectools_amd import nn as hnn
+    from rectools_amd import ops
+
+    rng = np.random.default_rng(5)
+    L, V = 50, 1000
+    lens = np.r_[rng.integers(2, 3 * L, 300), 2, L, L + 1, L + 2, 1 if not train else 2]
+    offsets_h = np.r_[0, np.cumsum(lens)].astype(np.int64)
+    offsets = torch.tensor(offsets_h).cuda()
+    items = torch.tensor(rng.integers(1, V, int(lens.sum())), dtype=torch.int64).cuda()
+    weights = torch.tensor(rng.random(int(lens.sum())).astype(np.float32) + 0.5).cuda()
+    idx_h = rng.permutation(len(lens))[:200].astype(np.int64)
+    idx = torch.tensor(idx_h).cuda()
+    n_h = np.clip(offsets_h[idx_h + 1] - offsets_h[idx_h] - (1 if train else 0), 0, L)      # what the host side of the loop computes
+    cu_h = np.r_[0, np.cumsum(n_h)].astype(np.int64)
+    N = int(cu_h[-1]); rows = (N + 127) // 128 * 128
+    cu = torch.tensor(cu_h).cuda()
+    if train:
+        x, y, yw, dist = ops.collate_packed(offsets, items, weights, idx, cu, rows, train=True)
+        cu_r, x_r, y_r, yw_r, dist_r = hnn.pack_train_items(offsets, items, weights, idx, L)
+        assert torch.equal(y[:N], y_r) and torch.equal(yw[:N], yw_r) and float(yw[N:].abs().sum()) == 0 and int(y[N:].abs().sum()) == 0
+    else:
+        x, dist = ops.collate_packed(offsets, items, None, idx, cu, rows, train=False)
+        cu_r, x_r, dist_r = hnn.pack_last_items(offsets, items, idx, L)
+    assert torch.equal(cu, cu_r) and torch.equal(x[:N], x_r) and torch.equal(dist[:N], dist_r)
+    assert int(x[N:].abs().sum()) == 0 and int(dist[N:].abs().sum()) == 0
+
+
+def test_packed_train_loop_takes_the_steps_of_the_padded_loop(monkeypatch):
+    """The product loop with RT_PACKED_TRAIN=1 (host-cut row offsets, rt_collate_packed, fused packed embedding, packed blocks) against
+    the padded loop on the same model and data, dropout 0 and a deterministic sampler: equal losses step by step, equal parameters."""
+    from rectools_amd.data_preparator import TransformerNegativeSamplerBase
+    from rectools_amd.dataset import Dataset
+    from rectools_amd.models import SASRecModel
+
+    class RowHashSampler(TransformerNegativeSamplerBase):
+        """Negatives as a pure function of the row's input item (so the padded and the packed batch draw the same ones)."""
+
+        def get_negatives(self, batch_dict, lowest_id, highest_id, session_len_limit=None, **kwargs):
+            x = batch_dict["x"]
+            j = torch.arange(self.n_negatives, device=x.device, dtype=torch.int64)
+            return lowest_id + (x[..., None] * 7919 + j * 104729 + 13) % (highest_id - lowest_id)
+
+    rng = np.random.default_rng(1)
+    n_users, n_items, n = 150, 90, 5000
+    df = pd.DataFrame({"user_id": rng.integers(0, n_users, n), "item_id": rng.integers(0, n_items, n) + 100, "weight": 1.0,
+                       "datetime": pd.to_datetime("2022-01-01") + pd.to_timedelta(rng.integers(0, 500_000, n), unit="m")})
+    ds = Dataset.construct(df)
+    kw = dict(n_factors=64, n_blocks=2, n_heads=2, session_max_len=24, lr=0.005, batch_size=32, dropout_rate=0.0, loss="sampled_softmax",
+              n_negatives=6, seed=5, epochs=1, negative_sampler_type=RowHashSampler)
+    losses, params = {}, {}
+    for packed in ("0", "1"):
+        monkeypatch.setenv("RT_PACKED_TRAIN", packed)
+        m = SASRecModel(**kw)
+        m._build_model_from_dataset(ds)
+        loop = m.training_loop()
+        assert loop.packed == (packed == "1")
+        m.lightning_model.train()
+        loop.begin_epoch(0)
+        losses[packed] = [float(loop.step()) for _ in range(9)]       # runs over the epoch's end (5 batches) into the next one
+        params[packed] = {k: v.detach().clone() for k, v in m.torch_model.state_dict().items()}
+    np.testing.assert_allclose(losses["1"], losses["0"], rtol=2e-4)
+    for k, v in params["0"].items():
+        torch.testing.assert_close(params["1"][k], v, rtol=5e-3, atol=5e-4, msg=lambda s, k=k: f"{k}: {s}")
