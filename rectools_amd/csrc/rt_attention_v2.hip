@@ -1,0 +1,334 @@
+// K4v2 — softmax self-attention over PACKED sessions on the bf16 matrix pipe, fp32-accurate.
+//
+// Same contract as rt_attention_varlen.hip (causal attention inside every session of a packed batch, the reference's left-pad keys as
+// ONE virtual key per query: sasrec.py:186-231, torch_backbone.py:245-260), different arithmetic and geometry:
+//
+//  * every fp32 product is six v_mfma_f32_16x16x32_bf16 products of an EXACT three-way bf16 split (x = h + m + l, the GEMM's scheme,
+//    rt_gemm.hip): terms hh, hm, mh, mm, hl, lh accumulate in fp32; the dropped terms are <= 2 * 2^-24 |a||b| — one fp32 rounding.
+//    The f32-input MFMA the first kernels used runs at the fp32 VECTOR rate on the FMA lanes (MI355X_MICROARCH.md): its time ADDS to the
+//    softmax arithmetic; the bf16 pipe is 16x faster per flop (6/16 after the split) and runs beside the VALU.
+//  * operands are split ONCE, when a (session, head)'s rows are staged into LDS, into three bf16 planes per row (h | m | l, row-interleaved:
+//    row r, plane p at r * 3 * ROWB + p * ROWB): no split arithmetic inside the tile loop except for the 8 probabilities a lane produces.
+//  * an LDS image serves BOTH operand orientations: rows as MFMA rows through ds_read_b128 (S = K Q^T, dP = V dO^T), and rows as the
+//    reduction index through ds_read_b64_tr_b16, the gfx950 transpose read (O^T = V^T P^T, dQ^T = K^T dS^T, dK^T = Q^T dS, dV^T = dO^T P):
+//    lane i of a 16-lane group receives column i of the [4 rows][16 columns] block whose 16 eight-byte chunks the group's lanes address
+//    (result element e of lane i = element (i & 3) of the chunk supplied by lane 4e + (i >> 2); probed on hardware,
+//    scripts/microbench/tr16_probe.hip).  An XOR swizzle of the 16-byte unit index by row bits 1-2 makes both patterns bank-conflict
+//    free (scripts/attn/swizzle_search.py, bank model of MI355X_MICROARCH.md §LDS).
+//  * tiles: 16 OWNER rows per wave-tile (a lane owns one query — or, in the dK/dV pass, one key — four lanes share it and hold
+//    different reduction slots), 32 partner rows per step.  v_mfma_f32_16x16x32_bf16 leaves the 4 x 2 scores of a lane in registers in
+//    exactly the slot order the next product's B operand wants, so probabilities / dS never leave the registers.  16-row owner tiles
+//    deal a causal triangle to 8 waves within 15 % of even (13 tiles of weight 1..7 at 200 rows) without merging partial results.
+//  * rows behind a session's end read a ZERO row kept behind every image (index n): a partner tile never needs a bounds branch.
+#include "rt_varlen.h"
+
+namespace {
+using namespace rt_varlen;
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+#define RT_LDS __attribute__((address_space(3)))
+
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+
+struct P3 { bf16x8 h, m, l; };   // the three bf16 planes of 8 fp32 values (one MFMA operand each)
+
+// (a, b) -> the packed bf16 pairs {b, a} of the three planes.  Truncation of the top half IS the bf16; both subtractions are exact.
+__device__ __forceinline__ void split2(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+  const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+  const float ra = a - __uint_as_float(ua & 0xFFFF0000u), rb = b - __uint_as_float(ub & 0xFFFF0000u);
+  const unsigned va = __float_as_uint(ra), vb = __float_as_uint(rb);
+  const float la = ra - __uint_as_float(va & 0xFFFF0000u), lb = rb - __uint_as_float(vb & 0xFFFF0000u);
+  h = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+  m = __builtin_amdgcn_perm(vb, va, 0x07060302u);
+  l = __builtin_amdgcn_perm(__float_as_uint(lb), __float_as_uint(la), 0x07060302u);
+}
+__device__ __forceinline__ P3 split8(const float (&x)[8]) {
+  u32x4 ph, pm, pl;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { unsigned h, m, l; split2(x[2 * q], x[2 * q + 1], h, m, l); ph[q] = h; pm[q] = m; pl[q] = l; }
+  P3 r;
+  r.h = __builtin_bit_cast(bf16x8, ph); r.m = __builtin_bit_cast(bf16x8, pm); r.l = __builtin_bit_cast(bf16x8, pl);
+  return r;
+}
+
+// six-term product: acc += A * B for fp32-accurate A, B given as planes (smallest terms first)
+__device__ __forceinline__ f32x4 mfma6(const P3& A, const P3& B, f32x4 acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A.l, B.h, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A.h, B.l, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A.m, B.m, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A.m, B.h, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A.h, B.m, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A.h, B.h, acc, 0, 0, 0);
+  return acc;
+}
+
+template <int HD> struct Lay {
+  static constexpr int ROWB = HD * 2;        // bytes of one plane row
+  static constexpr int ROW3 = 3 * ROWB;      // bytes of one image row (h | m | l)
+  static constexpr int NS = HD / 32;         // MFMA k-steps over the head dimension
+  static constexpr int NCB = HD / 16;        // 16-column blocks of the head dimension
+  // XOR mask of the 16-byte unit index of row r (scripts/attn/swizzle_search.py)
+  __device__ static __forceinline__ unsigned swz(int r) { return HD == 64 ? (unsigned)(r & 6) : (unsigned)((r >> 1) & 2); }
+  static size_t image_bytes(int max_len) { return (size_t)(max_len + 1) * ROW3; }   // + the zero row
+};
+
+// Stage rows [0, n) of a [*, ld] fp32 matrix (columns [0, HD) of this head) into an LDS image: value * scale, split into planes.
+// Row n of the image is zero-filled.
+template <int HD>
+__device__ __forceinline__ void stage_image(const float* __restrict__ src, long long ld, int n, float scale, unsigned char* img, int tid,
+                                            int nthreads) {
+  using L = Lay<HD>;
+  constexpr int C4 = HD / 4;
+  const int total = n * C4;
+#pragma unroll 4
+  for (int idx = tid; idx < total; idx += nthreads) {
+    const int r = idx / C4, c4 = idx % C4;
+    const f32x4 x = *reinterpret_cast<const f32x4*>(src + (long long)r * ld + c4 * 4) * scale;
+    u32x2 h, m, l;
+    { unsigned a, b, c; split2(x[0], x[1], a, b, c); h[0] = a; m[0] = b; l[0] = c; }
+    { unsigned a, b, c; split2(x[2], x[3], a, b, c); h[1] = a; m[1] = b; l[1] = c; }
+    unsigned char* p = img + r * L::ROW3 + (((unsigned)c4 ^ (L::swz(r) << 1)) << 3);
+    *reinterpret_cast<u32x2*>(p) = h;
+    *reinterpret_cast<u32x2*>(p + L::ROWB) = m;
+    *reinterpret_cast<u32x2*>(p + 2 * L::ROWB) = l;
+  }
+  for (int w = tid; w < L::ROW3 / 8; w += nthreads) *reinterpret_cast<u32x2*>(img + n * L::ROW3 + w * 8) = u32x2{0u, 0u};
+}
+
+// 8 fp32 values of one row for the reduction slots of lane group g: columns 32 s + 8 g + (0..7), times scale, as planes
+template <int HD>
+__device__ __forceinline__ void load_owner_planes(const float* __restrict__ row, int g, float scale, P3 (&out)[HD / 32]) {
+#pragma unroll
+  for (int s = 0; s < HD / 32; ++s) {
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(row + 32 * s + 8 * g), x1 = *reinterpret_cast<const f32x4*>(row + 32 * s + 8 * g + 4);
+    const float x[8] = {x0[0] * scale, x0[1] * scale, x0[2] * scale, x0[3] * scale, x1[0] * scale, x1[1] * scale, x1[2] * scale, x1[3] * scale};
+    out[s] = split8(x);
+  }
+}
+
+// acc[kb][r] = sum_c img[t0 + 16 kb + 4 g + r][c] * owner[lane & 15][c]  (kb = 0, 1; r = 0..3): the partner rows are the MFMA rows
+template <int HD>
+__device__ __forceinline__ void rows_times_owner(const unsigned char* img, int t0, int n, const P3 (&own)[HD / 32], int i, int g,
+                                                 f32x4 (&acc)[2]) {
+  using L = Lay<HD>;
+  f32x4 part[2][HD / 32];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    const int r = min(t0 + 16 * kb + i, n);
+    const unsigned char* base = img + r * L::ROW3;
+    const unsigned x = L::swz(r);
+#pragma unroll
+    for (int s = 0; s < HD / 32; ++s) {
+      const unsigned char* p = base + ((((unsigned)(4 * s + g)) ^ x) << 4);
+      P3 A;
+      A.h = *reinterpret_cast<const bf16x8*>(p);
+      A.m = *reinterpret_cast<const bf16x8*>(p + L::ROWB);
+      A.l = *reinterpret_cast<const bf16x8*>(p + 2 * L::ROWB);
+      part[kb][s] = mfma6(A, own[s], f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+  }
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    acc[kb] = part[kb][0];
+#pragma unroll
+    for (int s = 1; s < HD / 32; ++s) acc[kb] += part[kb][s];
+  }
+}
+
+__device__ __forceinline__ s16x4 tr_read(const unsigned char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((RT_LDS s16x4*)(p));
+}
+
+// acc[cb][r] += sum over the 32 partner rows of img[row][16 cb + 4 g + r] * slots(row), where the lane's 8 slots are the rows
+// t0 + 16 kb + 4 g + e (slot 4 kb + e): the partner rows are the REDUCTION index (transpose read)
+template <int HD>
+__device__ __forceinline__ void cols_times_slots(const unsigned char* img, int t0, int n, const P3& slots, int i, int g,
+                                                 f32x4 (&acc)[HD / 16]) {
+  using L = Lay<HD>;
+  const int j = i >> 2, t = i & 3;
+  const unsigned char* rb[2]; unsigned xs[2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    const int k = min(t0 + 16 * kb + 4 * g + j, n);
+    rb[kb] = img + k * L::ROW3;
+    xs[kb] = L::swz(k) << 1;
+  }
+  P3 A[HD / 16];
+#pragma unroll
+  for (int cb = 0; cb < HD / 16; ++cb) {
+    const unsigned c = (unsigned)(4 * cb + t);
+    const unsigned char* p0 = rb[0] + ((c ^ xs[0]) << 3);
+    const unsigned char* p1 = rb[1] + ((c ^ xs[1]) << 3);
+    s16x8 vh, vm, vl;
+    { const s16x4 a = tr_read(p0), b = tr_read(p1); vh = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+    { const s16x4 a = tr_read(p0 + L::ROWB), b = tr_read(p1 + L::ROWB); vm = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+    { const s16x4 a = tr_read(p0 + 2 * L::ROWB), b = tr_read(p1 + 2 * L::ROWB); vl = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+    A[cb].h = __builtin_bit_cast(bf16x8, vh); A[cb].m = __builtin_bit_cast(bf16x8, vm); A[cb].l = __builtin_bit_cast(bf16x8, vl);
+  }
+  // the HD / 16 accumulators take turns inside a term: no back-to-back dependent MFMAs
+#define RT_V2_TERM(PA, PB)                                                                                   \
+  _Pragma("unroll") for (int cb = 0; cb < HD / 16; ++cb)                                                     \
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[cb].PA, slots.PB, acc[cb], 0, 0, 0);
+  RT_V2_TERM(l, h) RT_V2_TERM(h, l) RT_V2_TERM(m, m) RT_V2_TERM(m, h) RT_V2_TERM(h, m) RT_V2_TERM(h, h)
+#undef RT_V2_TERM
+}
+
+__device__ __forceinline__ float quad_max(float v) {   // over the 4 lanes (lane & 15 equal) that share an owner row
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+// o-th heaviest owner tile -> wave, in a zigzag of period 2 NW: wave w takes o = w, 2 NW - 1 - w, 2 NW + w, ...
+template <int NW, typename F>
+__device__ __forceinline__ void for_my_tiles(int wave, int n_tiles, F&& body) {
+  for (int base = 0; base < n_tiles; base += 2 * NW) {
+    const int o1 = base + wave, o2 = base + 2 * NW - 1 - wave;
+    if (o1 < n_tiles) body(n_tiles - 1 - o1);
+    if (o2 < n_tiles) body(n_tiles - 1 - o2);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// forward: a lane owns a query (4 lanes per query hold different keys / different head-dim columns)
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int HD, int NW, bool TRAIN>
+__global__ __launch_bounds__(NW * 64) void v2_fwd_kernel(VarlenArgs a) {
+  using L = Lay<HD>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const long long row0 = a.cu[b];
+  const int n = (int)(a.cu[b + 1] - row0);
+  if (n <= 0) return;
+  unsigned char* Kimg = smem;
+  unsigned char* Vimg = smem + (size_t)(n + 1) * L::ROW3;
+  stage_image<HD>(a.k + row0 * a.ldk + h * HD, a.ldk, n, 1.f, Kimg, tid, NW * 64);
+  stage_image<HD>(a.v + row0 * a.ldv + h * HD, a.ldv, n, 1.f, Vimg, tid, NW * 64);
+  __syncthreads();
+
+  const int n_pad = a.window > n ? a.window - n : 0;
+  const bool pads = a.bk != nullptr && a.bv != nullptr && n_pad > 0;
+  const unsigned thr16 = TRAIN ? drop_thr16(a.p_drop) : 0u;
+  const float inv_keep = (TRAIN && a.p_drop > 0.f) ? 1.f / (1.f - a.p_drop) : 1.f;
+  const float qscale = a.scale * LOG2E;          // scores live in the base-2 domain: p = exp2(s' - m')
+
+  for_my_tiles<NW>(wave, (n + 15) >> 4, [&](int qt) {
+    const int qrow = qt * 16 + i;
+    const bool qok = qrow < n;
+    const long long grow = row0 + (qok ? qrow : n - 1);
+    P3 Qp[L::NS];
+    load_owner_planes<HD>(a.q + grow * a.ldq + h * HD, g, qscale, Qp);
+    float m = -INFINITY, lsum = 0.f;             // lsum: this lane's share of the row sum (its own keys), reduced at the end
+    f32x4 oT[L::NCB];
+#pragma unroll
+    for (int cb = 0; cb < L::NCB; ++cb) oT[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int kt_last = (qt * 16 + 15) >> 5;
+
+    for (int kt = 0; kt <= kt_last; ++kt) {
+      f32x4 sT[2];
+      rows_times_owner<HD>(Kimg, kt * 32, n, Qp, i, g, sT);      // sT[kb][r]: key kt*32 + 16 kb + 4 g + r
+      float sc[8];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sc[4 * kb + r] = sT[kb][r];
+      if (kt == kt_last) {                                       // the causal edge (keys behind the session's end lie behind it too)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int key = kt * 32 + 16 * (e >> 2) + 4 * g + (e & 3);
+          sc[e] = key <= qrow ? sc[e] : -INFINITY;
+        }
+      }
+      float mx = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7])));
+      mx = fmaxf(m, quad_max(mx));                               // finite: every query sees key kt*32 of every tile it visits
+      const float alpha = __builtin_amdgcn_exp2f(m - mx);
+      float ps = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sc[e] = __builtin_amdgcn_exp2f(sc[e] - mx); ps += sc[e]; }
+      lsum = lsum * alpha + ps;
+      m = mx;
+      if (TRAIN && thr16 != 0u) {      // dropout acts on the normalised probabilities: the row sum above stays undropped
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const unsigned key = (unsigned)(kt * 32 + 16 * (e >> 2) + 4 * g + (e & 3));
+          const unsigned hsh = drop_hash(a.seed, (unsigned)blockIdx.x, (unsigned)qrow, key >> 1);
+          sc[e] = (hsh & 0xFFFFu) >= thr16 ? sc[e] * inv_keep : 0.f;
+          sc[e + 1] = (hsh >> 16) >= thr16 ? sc[e + 1] * inv_keep : 0.f;
+        }
+      }
+#pragma unroll
+      for (int cb = 0; cb < L::NCB; ++cb) oT[cb] *= alpha;
+      const P3 Pp = split8(sc);
+      cols_times_slots<HD>(Vimg, kt * 32, n, Pp, i, g, oT);      // oT[cb][r]: column 16 cb + 4 g + r of query `qrow`
+    }
+
+    if (pads) {   // the window's pad keys: one virtual key, logit q.b_k / sqrt(hd), value b_v, multiplicity n_pad
+      float dp = 0.f;
+      const float* qp = a.q + grow * a.ldq + h * HD;
+#pragma unroll
+      for (int s = 0; s < L::NS; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dp += qp[32 * s + 8 * g + e] * a.bk[h * HD + 32 * s + 8 * g + e];
+      dp = quad_sum(dp) * qscale;
+      const float mx = fmaxf(m, dp);
+      const float alpha = __builtin_amdgcn_exp2f(m - mx);
+      const float e1 = __builtin_amdgcn_exp2f(dp - mx);
+      lsum = lsum * alpha + (g == 0 ? (float)n_pad * e1 : 0.f);
+      m = mx;
+      float wv = (float)n_pad * e1;
+      if (TRAIN && thr16 != 0u) {   // value side: the pads that survive the dropout, counted by the four lanes of the query
+        int kept = 0;
+        for (int kk = n + g; kk < n + n_pad; kk += 4) kept += drop_kept(a.seed, (unsigned)blockIdx.x, (unsigned)qrow, (unsigned)kk, thr16) ? 1 : 0;
+        kept += __shfl_xor(kept, 16, 64);
+        kept += __shfl_xor(kept, 32, 64);
+        wv = (float)kept * inv_keep * e1;
+      }
+#pragma unroll
+      for (int cb = 0; cb < L::NCB; ++cb) {
+        const f32x4 bv4 = *reinterpret_cast<const f32x4*>(a.bv + h * HD + 16 * cb + 4 * g);
+        oT[cb] = oT[cb] * alpha + bv4 * wv;
+      }
+    }
+
+    const float l = quad_sum(lsum);
+    if (qok) {
+      if (a.lse != nullptr && g == 0) a.lse[(row0 + qrow) * a.H + h] = (m + __builtin_amdgcn_logf(l)) * LN2;
+      const float inv = l > 0.f ? 1.f / l : 0.f;
+      float* op = a.o + (row0 + qrow) * a.ldo + h * HD;
+#pragma unroll
+      for (int cb = 0; cb < L::NCB; ++cb) *reinterpret_cast<f32x4*>(op + 16 * cb + 4 * g) = oT[cb] * inv;
+    }
+  });
+}
+
+template <int HD, int NW, bool TRAIN>
+int launch_fwd(const VarlenArgs& a, int max_len, hipStream_t stream) {
+  const size_t lds = 2 * Lay<HD>::image_bytes(max_len);
+  if (lds > 160 * 1024) return RT_ERR_UNSUPPORTED;
+  auto kern = &v2_fwd_kernel<HD, NW, TRAIN>;
+  RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  kern<<<a.B * a.H, NW * 64, lds, stream>>>(a);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+}  // namespace
+
+int rt_v2_varlen_fwd(const rt_varlen::VarlenArgs& a, int max_len, bool train, hipStream_t stream) {
+  if (a.hd == 64) return train ? launch_fwd<64, 8, true>(a, max_len, stream) : launch_fwd<64, 8, false>(a, max_len, stream);
+  if (a.hd == 32) return train ? launch_fwd<32, 8, true>(a, max_len, stream) : launch_fwd<32, 8, false>(a, max_len, stream);
+  return RT_ERR_UNSUPPORTED;
+}
+
+int rt_v2_varlen_bwd(const rt_varlen::VarlenArgs& a, int max_len, hipStream_t stream) {
+  (void)a; (void)max_len; (void)stream;
+  return RT_ERR_UNSUPPORTED;
+}

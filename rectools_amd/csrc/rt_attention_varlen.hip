@@ -16,45 +16,14 @@
 // the keys row_of(r, 0) and row_of(r, 1), which is exactly what the two lane halves hold in accumulator register r), and the
 // rescale factor of the online softmax is a per-lane scalar for S^T, P^T and O^T alike.  v_mfma_f32_32x32x2_f32: exact fp32.
 #include "rt_common.h"
+#include "rt_varlen.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
+using namespace rt_varlen;
 
 constexpr int VT = 256;   // threads per workgroup (4 waves)
-
-struct VarlenArgs {
-  const float* q; const float* k; const float* v; long long ldq, ldk, ldv;
-  float* o; long long ldo;
-  const long long* cu;                 // [B+1] first packed row of every session
-  const float* bk; const float* bv;    // [H*hd] key / value projection biases = the pad key / value row; null: no pad keys
-  int B, H, hd, window;                // window = the reference's session_max_len: n_pad = window - n_b
-  float scale;                         // 1 / sqrt(hd)
-  // training
-  float p_drop; unsigned long long seed;
-  float* lse;                          // [N, H] log-sum-exp of every query (written by the forward when not null)
-  const float* dout; long long lddo;   // backward input
-  float* delta;                        // [N, H] rowsum(dO * O): written by the dQ kernel, read by the dK/dV kernel
-  float* dq; float* dk; float* dv; long long lddq, lddk, lddv;
-  float* dbv_part;                     // [B, H*hd] per-session partial of the value-bias gradient from the pad keys (or null)
-};
-
-// Attention dropout mask, same construction as rt_attention.hip: ONE 32-bit mix per (head, query, PAIR of adjacent keys), 16 bits
-// per key compared with p * 65536.  Queries and keys are numbered inside their session; the window's pad keys take the key
-// numbers n .. n + n_pad - 1 behind the real ones.  The three kernels regenerate the same masks.
-__device__ __forceinline__ unsigned drop_hash(unsigned long long seed, unsigned bh, unsigned q, unsigned key_pair) {
-  unsigned x = (unsigned)seed ^ (q * 0x9E3779B1u) ^ (key_pair * 0x85EBCA77u) ^ (bh * 0xC2B2AE3Du) ^ (unsigned)(seed >> 32);
-  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15;
-  return x;
-}
-__device__ __forceinline__ unsigned drop_thr16(float p) { return (unsigned)(p * 65536.0f); }
-__device__ __forceinline__ bool drop_kept(unsigned long long seed, unsigned bh, unsigned q, unsigned key, unsigned thr16) {
-  return ((drop_hash(seed, bh, q, key >> 1) >> (16u * (key & 1u))) & 0xFFFFu) >= thr16;
-}
-// how many of the n_pad pad keys of query q survive the dropout
-__device__ __forceinline__ int pads_kept(unsigned long long seed, unsigned bh, unsigned q, int n, int n_pad, unsigned thr16) {
-  int kept = 0;
-  for (int kk = n; kk < n + n_pad; ++kk) kept += drop_kept(seed, bh, q, (unsigned)kk, thr16) ? 1 : 0;
-  return kept;
-}
 
 __device__ __forceinline__ int row_of(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
@@ -513,6 +482,17 @@ __global__ __launch_bounds__(VT) void attn_varlen_last_kernel(VarlenArgs a, int 
 
 constexpr size_t VARLEN_LDS_LIMIT = 160 * 1024;
 
+// RT_VARLEN_IMPL=v1 keeps the first-form kernels of this file (f32-input MFMA); default: the bf16-plane kernels of rt_attention_v2.hip
+// wherever they serve the shape (they answer RT_ERR_UNSUPPORTED otherwise).  RT_VARLEN_IMPL=v2fwd / v2bwd: only that pass (A/B runs).
+int v2_mode() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("RT_VARLEN_IMPL");
+    mode = (e == nullptr || e[0] == 0) ? 3 : (!strcmp(e, "v1") ? 0 : !strcmp(e, "v2fwd") ? 1 : !strcmp(e, "v2bwd") ? 2 : 3);
+  }
+  return mode;
+}
+
 template <typename K>
 int set_lds(K kernel, size_t lds) {
   RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -547,6 +527,10 @@ int rt_mha_varlen_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, 
   a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.o = o; a.ldo = ldo;
   a.cu = reinterpret_cast<const long long*>(cu_seqlens); a.bk = bk; a.bv = bv; a.B = B; a.H = H; a.hd = hd; a.window = window;
   a.scale = 1.0f / sqrtf((float)hd);
+  if (v2_mode() & 1) {
+    const int rc = rt_v2_varlen_fwd(a, max_len, false, stream);
+    if (rc != RT_ERR_UNSUPPORTED) return rc;
+  }
   const size_t lds = (size_t)2 * ((max_len + 31) & ~31) * (hd + 1) * sizeof(float);
   if (lds > VARLEN_LDS_LIMIT) return RT_ERR_UNSUPPORTED;
   if (hd == 64) {
@@ -576,6 +560,10 @@ int rt_mha_varlen_train_fwd(const float* q, int64_t ldq, const float* k, int64_t
   a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.o = o; a.ldo = ldo;
   a.cu = reinterpret_cast<const long long*>(cu_seqlens); a.bk = bk; a.bv = bv; a.B = B; a.H = H; a.hd = hd; a.window = window;
   a.scale = 1.0f / sqrtf((float)hd); a.p_drop = p_drop; a.seed = seed; a.lse = lse;
+  if (v2_mode() & 1) {
+    const int rc = rt_v2_varlen_fwd(a, max_len, true, stream);
+    if (rc != RT_ERR_UNSUPPORTED) return rc;
+  }
   const size_t lds = (size_t)2 * ((max_len + 31) & ~31) * (hd + 1) * sizeof(float);
   if (lds > VARLEN_LDS_LIMIT) return RT_ERR_UNSUPPORTED;
   if (hd == 64) {
@@ -612,6 +600,10 @@ int rt_mha_varlen_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, 
   a.scale = 1.0f / sqrtf((float)hd); a.p_drop = p_drop; a.seed = seed; a.lse = const_cast<float*>(lse);
   a.dout = dout; a.lddo = lddo; a.delta = delta; a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   a.dbv_part = dbv_part;
+  if (v2_mode() & 2) {
+    const int rc = rt_v2_varlen_bwd(a, max_len, stream);
+    if (rc != RT_ERR_UNSUPPORTED) return rc;
+  }
   const size_t n32 = (size_t)((max_len + 31) & ~31);
   const size_t lds_dq = (2 * n32 * (hd + 1) + 4 * (size_t)hd) * sizeof(float);
   const size_t lds_kv = (2 * n32 * (hd + 1) + 2 * n32) * sizeof(float);

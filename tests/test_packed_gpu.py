@@ -326,5 +326,11 @@ def test_packed_train_loop_takes_the_steps_of_the_padded_loop(monkeypatch):
         losses[packed] = [float(loop.step()) for _ in range(9)]       # runs over the epoch's end (5 batches) into the next one
         params[packed] = {k: v.detach().clone() for k, v in m.torch_model.state_dict().items()}
     np.testing.assert_allclose(losses["1"], losses["0"], rtol=2e-4)
+    d = kw["n_factors"]
     for k, v in params["0"].items():
-        torch.testing.assert_close(params["1"][k], v, rtol=5e-3, atol=5e-4, msg=lambda s, k=k: f"{k}: {s}")
+        a, b = params["1"][k], v
+        if k.endswith("in_proj_bias"):
+            # the key bias has NO gradient (it shifts every logit of a query alike): the packed path writes exact zeros where the padded
+            # one accumulates rounding noise that Adam turns into O(lr) steps — compare the q and v thirds
+            a, b = torch.cat([a[:d], a[2 * d:]]), torch.cat([b[:d], b[2 * d:]])
+        torch.testing.assert_close(a, b, rtol=5e-3, atol=5e-4, msg=lambda s, k=k: f"{k}: {s}")
