@@ -186,12 +186,13 @@ __device__ __forceinline__ float quad_sum(float v) {
 }
 
 // o-th heaviest owner tile -> wave, in a zigzag of period 2 NW: wave w takes o = w, 2 NW - 1 - w, 2 NW + w, ...
-template <int NW, typename F>
+// HEAVY_LAST: the tile with the largest index is the heaviest (query tiles: they see every earlier key); else tile 0 is (key tiles).
+template <int NW, bool HEAVY_LAST, typename F>
 __device__ __forceinline__ void for_my_tiles(int wave, int n_tiles, F&& body) {
   for (int base = 0; base < n_tiles; base += 2 * NW) {
     const int o1 = base + wave, o2 = base + 2 * NW - 1 - wave;
-    if (o1 < n_tiles) body(n_tiles - 1 - o1);
-    if (o2 < n_tiles) body(n_tiles - 1 - o2);
+    if (o1 < n_tiles) body(HEAVY_LAST ? n_tiles - 1 - o1 : o1);
+    if (o2 < n_tiles) body(HEAVY_LAST ? n_tiles - 1 - o2 : o2);
   }
 }
 
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(NW * 64) void v2_fwd_kernel(VarlenArgs a) {
   const float inv_keep = (TRAIN && a.p_drop > 0.f) ? 1.f / (1.f - a.p_drop) : 1.f;
   const float qscale = a.scale * LOG2E;          // scores live in the base-2 domain: p = exp2(s' - m')
 
-  for_my_tiles<NW>(wave, (n + 15) >> 4, [&](int qt) {
+  for_my_tiles<NW, true>(wave, (n + 15) >> 4, [&](int qt) {
     const int qrow = qt * 16 + i;
     const bool qok = qrow < n;
     const long long grow = row0 + (qok ? qrow : n - 1);
@@ -309,6 +310,256 @@ __global__ __launch_bounds__(NW * 64) void v2_fwd_kernel(VarlenArgs a) {
   });
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// backward, pass 1: dQ, delta = rowsum(dO * O), and the pad keys' share of the value-bias gradient.  A lane owns a query, as in the
+// forward: S^T and dP^T = V dO^T are recomputed per key tile (K and V rows as MFMA rows), dS^T = P (drop * dP - delta) stays in
+// registers and feeds dQ^T = K^T dS^T (K rows as the reduction index: transpose reads of the SAME image).
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void v2_bwd_dq_kernel(VarlenArgs a) {
+  using L = Lay<HD>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const long long row0 = a.cu[b];
+  const int n = (int)(a.cu[b + 1] - row0);
+  float* dbv = a.dbv_part != nullptr ? a.dbv_part + (long long)b * a.H * HD + h * HD : nullptr;
+  if (n <= 0) {
+    if (dbv != nullptr && tid < HD) dbv[tid] = 0.f;
+    return;
+  }
+  unsigned char* Kimg = smem;
+  unsigned char* Vimg = smem + (size_t)(n + 1) * L::ROW3;
+  stage_image<HD>(a.k + row0 * a.ldk + h * HD, a.ldk, n, 1.f, Kimg, tid, NW * 64);
+  stage_image<HD>(a.v + row0 * a.ldv + h * HD, a.ldv, n, 1.f, Vimg, tid, NW * 64);
+  __syncthreads();
+
+  const int n_pad = a.window > n ? a.window - n : 0;
+  const bool pads = a.bk != nullptr && a.bv != nullptr && n_pad > 0;
+  const unsigned thr16 = drop_thr16(a.p_drop);
+  const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+  const float qscale = a.scale * LOG2E;
+  f32x4 dbv_acc[L::NCB];                  // this lane's queries' share of d_bv, columns 16 cb + 4 g + r
+#pragma unroll
+  for (int cb = 0; cb < L::NCB; ++cb) dbv_acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for_my_tiles<NW, true>(wave, (n + 15) >> 4, [&](int qt) {
+    const int qrow = qt * 16 + i;
+    const bool qok = qrow < n;
+    const long long grow = row0 + (qok ? qrow : n - 1);
+    const float* qp = a.q + grow * a.ldq + h * HD;
+    const float* dop = a.dout + grow * a.lddo + h * HD;
+    const float* op = a.o + grow * a.ldo + h * HD;
+    P3 Qp[L::NS], Dp[L::NS];
+    load_owner_planes<HD>(qp, g, qscale, Qp);
+    load_owner_planes<HD>(dop, g, qok ? 1.f : 0.f, Dp);
+    float dl = 0.f;                         // delta = rowsum(dO * O): 16 of the HD columns per lane
+#pragma unroll
+    for (int s = 0; s < L::NS; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dl += dop[32 * s + 8 * g + e] * op[32 * s + 8 * g + e];
+    dl = qok ? quad_sum(dl) : 0.f;
+    const float lse2 = a.lse[grow * a.H + h] * LOG2E;
+    if (qok && g == 0) a.delta[grow * a.H + h] = dl;
+    f32x4 dqT[L::NCB];
+#pragma unroll
+    for (int cb = 0; cb < L::NCB; ++cb) dqT[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int kt_last = (qt * 16 + 15) >> 5;
+
+    for (int kt = 0; kt <= kt_last; ++kt) {
+      f32x4 sT[2], dpT[2];
+      rows_times_owner<HD>(Kimg, kt * 32, n, Qp, i, g, sT);
+      rows_times_owner<HD>(Vimg, kt * 32, n, Dp, i, g, dpT);
+      float ds[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int key = kt * 32 + 16 * (e >> 2) + 4 * g + (e & 3);
+        const float pr = (kt < kt_last || key <= qrow) ? __builtin_amdgcn_exp2f(sT[e >> 2][e & 3] - lse2) : 0.f;
+        ds[e] = pr;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        float d0 = dpT[e >> 2][e & 3], d1 = dpT[e >> 2][(e & 3) + 1];
+        if (thr16 != 0u) {
+          const unsigned key = (unsigned)(kt * 32 + 16 * (e >> 2) + 4 * g + (e & 3));
+          const unsigned hsh = drop_hash(a.seed, (unsigned)blockIdx.x, (unsigned)qrow, key >> 1);
+          d0 = (hsh & 0xFFFFu) >= thr16 ? d0 * inv_keep : 0.f;
+          d1 = (hsh >> 16) >= thr16 ? d1 * inv_keep : 0.f;
+        }
+        ds[e] *= d0 - dl;                   // dS^T
+        ds[e + 1] *= d1 - dl;
+      }
+      const P3 Sp = split8(ds);
+      cols_times_slots<HD>(Kimg, kt * 32, n, Sp, i, g, dqT);   // dQ^T[c][q] += sum_j K[j][c] dS^T[j][q]  (scale at the store)
+    }
+
+    if (pads) {   // the virtual pad key: dS_p = P_p (drop * dO.b_v - delta), dq += dS_p b_k, d_b_v += drop * P_p * dO
+      float sp = 0.f, dpp = 0.f;
+#pragma unroll
+      for (int s = 0; s < L::NS; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = 32 * s + 8 * g + e;
+          sp += qp[c] * a.bk[h * HD + c];
+          dpp += dop[c] * a.bv[h * HD + c];
+        }
+      sp = quad_sum(sp) * qscale;
+      dpp = qok ? quad_sum(dpp) : 0.f;
+      const float e1 = __builtin_amdgcn_exp2f(sp - lse2);                        // one pad key's probability
+      float kept = (float)n_pad;
+      if (thr16 != 0u) {
+        int kc = 0;
+        for (int kk = n + g; kk < n + n_pad; kk += 4) kc += drop_kept(a.seed, (unsigned)blockIdx.x, (unsigned)qrow, (unsigned)kk, thr16) ? 1 : 0;
+        kc += __shfl_xor(kc, 16, 64);
+        kc += __shfl_xor(kc, 32, 64);
+        kept = (float)kc * inv_keep;
+      }
+      const float dsp = e1 * (kept * dpp - (float)n_pad * dl);
+      const float wv = qok ? e1 * kept : 0.f;                                    // dropped pad mass that multiplied b_v
+#pragma unroll
+      for (int cb = 0; cb < L::NCB; ++cb) {
+        const f32x4 bk4 = *reinterpret_cast<const f32x4*>(a.bk + h * HD + 16 * cb + 4 * g);
+        dqT[cb] += bk4 * dsp;
+        if (dbv != nullptr) dbv_acc[cb] += *reinterpret_cast<const f32x4*>(dop + 16 * cb + 4 * g) * wv;
+      }
+    }
+
+    if (qok) {
+      float* dqp = a.dq + grow * a.lddq + h * HD;
+#pragma unroll
+      for (int cb = 0; cb < L::NCB; ++cb) *reinterpret_cast<f32x4*>(dqp + 16 * cb + 4 * g) = dqT[cb] * a.scale;
+    }
+  });
+
+  if (dbv != nullptr) {   // reduce d_bv over the queries: the 16 lanes of a group, then the waves through LDS (the images are dead)
+#pragma unroll
+    for (int cb = 0; cb < L::NCB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = dbv_acc[cb][r];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        dbv_acc[cb][r] = v;
+      }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);          // [NW][HD]
+    if (i == 0)
+#pragma unroll
+      for (int cb = 0; cb < L::NCB; ++cb) *reinterpret_cast<f32x4*>(red + wave * HD + 16 * cb + 4 * g) = dbv_acc[cb];
+    __syncthreads();
+    if (tid < HD) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) v += red[w * HD + tid];
+      dbv[tid] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// backward, pass 2: dK, dV.  A lane owns a KEY: S = Q K^T and dP = dO V^T (Q / dO rows as MFMA rows, the key's K / V fragment in
+// registers) leave 2 x 4 queries of key `lane & 15` per lane; P~ and dS feed dV^T = dO^T P~ and dK^T = Q^T dS through transpose reads of
+// the same two images.  Q is staged pre-scaled by log2(e) / sqrt(hd): dK comes out times log2(e) and is scaled back at the store.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void v2_bwd_dkv_kernel(VarlenArgs a) {
+  using L = Lay<HD>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const long long row0 = a.cu[b];
+  const int n = (int)(a.cu[b + 1] - row0);
+  if (n <= 0) return;
+  const int n32 = (n + 31) & ~31;
+  unsigned char* Qimg = smem;
+  unsigned char* Dimg = smem + (size_t)(n + 1) * L::ROW3;
+  float* Ls = reinterpret_cast<float*>(smem + 2 * (size_t)(n + 1) * L::ROW3);   // [n32] lse * log2(e)   (16-byte aligned: ROW3 % 16 == 0)
+  float* Dl = Ls + n32;                                                         // [n32] delta
+  const float qscale = a.scale * LOG2E;
+  stage_image<HD>(a.q + row0 * a.ldq + h * HD, a.ldq, n, qscale, Qimg, tid, NW * 64);
+  stage_image<HD>(a.dout + row0 * a.lddo + h * HD, a.lddo, n, 1.f, Dimg, tid, NW * 64);
+  for (int r = tid; r < n32; r += NW * 64) {
+    Ls[r] = r < n ? a.lse[(row0 + r) * a.H + h] * LOG2E : 0.f;
+    Dl[r] = r < n ? a.delta[(row0 + r) * a.H + h] : 0.f;
+  }
+  __syncthreads();
+
+  const unsigned thr16 = drop_thr16(a.p_drop);
+  const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+  const int qt_last = (n - 1) >> 5;
+
+  for_my_tiles<NW, false>(wave, (n + 15) >> 4, [&](int kt) {
+    const int krow = kt * 16 + i;            // this lane's key (valid if < n)
+    const bool kok = krow < n;
+    const long long grow = row0 + (kok ? krow : n - 1);
+    P3 Kp[L::NS], Vp[L::NS];
+    load_owner_planes<HD>(a.k + grow * a.ldk + h * HD, g, 1.f, Kp);
+    load_owner_planes<HD>(a.v + grow * a.ldv + h * HD, g, 1.f, Vp);
+    f32x4 dkT[L::NCB], dvT[L::NCB];
+#pragma unroll
+    for (int cb = 0; cb < L::NCB; ++cb) { dkT[cb] = f32x4{0.f, 0.f, 0.f, 0.f}; dvT[cb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int qt_first = (kt * 16) >> 5;
+
+    for (int qt = qt_first; qt <= qt_last; ++qt) {     // causal: query tiles at or behind the key tile
+      f32x4 sm[2], dpm[2];                             // S[q][key], dP[q][key]: register (qb, r) = query qt*32 + 16 qb + 4 g + r
+      rows_times_owner<HD>(Qimg, qt * 32, n, Kp, i, g, sm);
+      rows_times_owner<HD>(Dimg, qt * 32, n, Vp, i, g, dpm);
+      const bool edge = qt == qt_first || qt == qt_last;
+      float pd[8], ds[8];
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        const f32x4 ls4 = *reinterpret_cast<const f32x4*>(Ls + qt * 32 + 16 * qb + 4 * g);
+        const f32x4 dl4 = *reinterpret_cast<const f32x4*>(Dl + qt * 32 + 16 * qb + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qr = qt * 32 + 16 * qb + 4 * g + r;
+          float pr = __builtin_amdgcn_exp2f(sm[qb][r] - ls4[r]);
+          if (edge) pr = (krow <= qr && qr < n && kok) ? pr : 0.f;
+          float keepf = 1.f;
+          if (thr16 != 0u)
+            keepf = drop_kept(a.seed, (unsigned)blockIdx.x, (unsigned)qr, (unsigned)krow, thr16) ? inv_keep : 0.f;
+          pd[4 * qb + r] = pr * keepf;                               // dropped probabilities (for dV)
+          ds[4 * qb + r] = pr * (dpm[qb][r] * keepf - dl4[r]);       // dS
+        }
+      }
+      const P3 Pp = split8(pd);
+      cols_times_slots<HD>(Dimg, qt * 32, n, Pp, i, g, dvT);    // dV^T[c][key] += sum_q dO[q][c] P~[q][key]
+      const P3 Sp = split8(ds);
+      cols_times_slots<HD>(Qimg, qt * 32, n, Sp, i, g, dkT);    // dK^T[c][key] += sum_q Q'[q][c] dS[q][key]
+    }
+
+    if (kok) {
+      float* dkp = a.dk + grow * a.lddk + h * HD;
+      float* dvp = a.dv + grow * a.lddv + h * HD;
+#pragma unroll
+      for (int cb = 0; cb < L::NCB; ++cb) {
+        *reinterpret_cast<f32x4*>(dkp + 16 * cb + 4 * g) = dkT[cb] * LN2;     // Q' = Q * scale * log2(e): scale is in, log2(e) comes out
+        *reinterpret_cast<f32x4*>(dvp + 16 * cb + 4 * g) = dvT[cb];
+      }
+    }
+  });
+}
+
+template <int HD, int NW>
+int launch_bwd(const VarlenArgs& a, int max_len, hipStream_t stream) {
+  const size_t img = 2 * Lay<HD>::image_bytes(max_len);
+  const size_t lds_dq = img > (size_t)NW * HD * 4 ? img : (size_t)NW * HD * 4;
+  const size_t lds_kv = img + 2 * (size_t)((max_len + 31) & ~31) * sizeof(float);
+  if (lds_dq > 160 * 1024 || lds_kv > 160 * 1024) return RT_ERR_UNSUPPORTED;
+  auto kq = &v2_bwd_dq_kernel<HD, NW>;
+  auto kkv = &v2_bwd_dkv_kernel<HD, NW>;
+  RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kq), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq));
+  RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kkv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv));
+  kq<<<a.B * a.H, NW * 64, lds_dq, stream>>>(a);
+  RT_CHECK_LAUNCH();
+  kkv<<<a.B * a.H, NW * 64, lds_kv, stream>>>(a);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
 template <int HD, int NW, bool TRAIN>
 int launch_fwd(const VarlenArgs& a, int max_len, hipStream_t stream) {
   const size_t lds = 2 * Lay<HD>::image_bytes(max_len);
@@ -329,6 +580,7 @@ int rt_v2_varlen_fwd(const rt_varlen::VarlenArgs& a, int max_len, bool train, hi
 }
 
 int rt_v2_varlen_bwd(const rt_varlen::VarlenArgs& a, int max_len, hipStream_t stream) {
-  (void)a; (void)max_len; (void)stream;
+  if (a.hd == 64) return launch_bwd<64, 8>(a, max_len, stream);
+  if (a.hd == 32) return launch_bwd<32, 8>(a, max_len, stream);
   return RT_ERR_UNSUPPORTED;
 }
