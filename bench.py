@@ -134,9 +134,11 @@ def timed_steps(step_fn, steps: int, warmup: int, world: int):
         evs[i][0].record()
         step_fn()
         evs[i][1].record()
+    issue = time.perf_counter() - t0      # the host has issued every launch of the timed steps (the device may still be working)
     barrier_sync(world)
     wall = time.perf_counter() - t0
     ev_ms = [a.elapsed_time(b) for a, b in evs]
+    timed_steps.host_issue_ms = issue / steps * 1e3
     return max_over_ranks(wall, world), float(np.mean(ev_ms))
 
 
@@ -382,6 +384,7 @@ def run_train(args, rank, world, kind="train"):
                     "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": load_traffic("train_" + dom), "avg_launch_ms": round(ms, 4),
                     "algorithmic_bytes_per_launch": byts}
     roof["kernel_ms_per_step"] = round(total_k, 3)
+    roof["host_issue_ms_per_step"] = round(getattr(timed_steps, "host_issue_ms", 0.0), 4)   # ~= ms_per_step: the step is launch-bound
     roof["step_flops_dense"] = 3.0 * B * (nb * spec["blk"] + spec["loss"])     # fwd + bwd = 3 x fwd
     roof["step_TFLOPs"] = round(roof["step_flops_dense"] / (wall / args.steps) / 1e12, 2)
     info = dict(model=model, ds=ds, loop=loop, V=V, d=d, H=H, nb=nb, L=L, B=B, n_neg=n_neg, breakdown=breakdown, spec=spec,

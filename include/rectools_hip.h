@@ -328,6 +328,44 @@ int rt_mha_varlen_last_fwd(const float* q, int64_t ldq, const float* k, int64_t 
                            const int64_t* cu_seqlens, const float* bk, const float* bv, int32_t B, int32_t H, int32_t hd,
                            int32_t max_len, int32_t window, float* o, int64_t ldo, rt_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Native executor of one PACKED SASRec block (sasrec.py:186-231, :300; csrc/rt_block.hip): the whole launch sequence of the block's
+ * training forward, its backward and its inference form behind ONE call each — the reference leaves the sequence to the autograd
+ * engine and the Python interpreter; at C2 the interpreter needed longer to issue a step than the GPU to run it.
+ * rows: row count of x / out (rows_real of them belong to sessions, the rest is the unused tail up to the 128-row GEMM tile);
+ * cu [B+1]; window = session_max_len; pad_keys: no key-padding masks, the window's pad keys are the attention's virtual key.
+ * Parameters are the reference's state_dict tensors of the block.  seed_* / sid_*: dropout streams.
+ *   _fwd:   out [rows,d]; `saved` (rt_sasrec_block_saved_floats floats) keeps the activations for the backward.
+ *   _bwd:   g_x [rows,d]; `grads` = flat parameter gradient in the order ln1_w, ln1_b, in_w, in_b, out_w, out_b, ln2_w, ln2_b, w1, b1,
+ *           w2, b2 at rt_sasrec_block_grad_offsets (13 entries, the last = total floats).  Weight gradients are issued on a
+ *           library-owned side stream when use_side != 0: call rt_side_join(stream) before reading `grads`; x, saved, g_out,
+ *           scratch (rt_sasrec_block_bwd_scratch_bytes) and grads must stay alive until then.
+ *   _infer: eval mode; last_rows == NULL: out [rows,d]; last_rows [B]: the output at those rows only, out [B,d] (what
+ *           recommend() keeps, lightning.py:393-397); scratch: rt_sasrec_block_infer_scratch_floats floats.
+ * rt_timing_enable(1|2) brackets every internal launch with HIP events (2: weight gradients on the caller's stream);
+ * rt_timing_collect synchronises and returns (id, ms, M N K) records: ids 0 gemm, 1 gemm_grouped, 2 layernorm_fwd, 3 layernorm_bwd,
+ * 4 act_dropout_fwd, 5 act_dropout_bwd, 6 mha_varlen_train_fwd, 7 mha_varlen_bwd, 8 mha_varlen_last_fwd, 9 misc.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct rt_sasrec_block {
+  int32_t rows, rows_real, B, H, d, dff, window, pad_keys;
+  float p_drop, eps1, eps2;
+  uint64_t seed_attn, seed_h, sid_h, seed_o, sid_o;
+  const int64_t* cu;
+  const float *ln1_w, *ln1_b, *in_w, *in_b, *out_w, *out_b, *ln2_w, *ln2_b, *w1, *b1, *w2, *b2;
+} rt_sasrec_block;
+size_t rt_sasrec_block_saved_floats(int32_t rows, int32_t d, int32_t dff, int32_t H, int32_t with_dropout);
+size_t rt_sasrec_block_bwd_scratch_bytes(int32_t rows, int32_t B, int32_t d, int32_t dff, int32_t H, int32_t wgrad_splits);
+void rt_sasrec_block_grad_offsets(int32_t d, int32_t dff, int64_t* offsets13);
+int rt_sasrec_block_packed_fwd(const rt_sasrec_block* blk, const float* x, float* saved, float* out, rt_stream_t stream);
+int rt_sasrec_block_packed_bwd(const rt_sasrec_block* blk, const float* x, const float* saved, const float* g_out, float* g_x, float* grads,
+                               void* scratch, size_t scratch_bytes, int32_t wgrad_splits, int32_t use_side, rt_stream_t stream);
+size_t rt_sasrec_block_infer_scratch_floats(int32_t rows, int32_t B, int32_t d, int32_t dff, int32_t last_only);
+int rt_sasrec_block_packed_infer(const rt_sasrec_block* blk, const float* x, const int64_t* last_rows, float* scratch, float* out,
+                                 rt_stream_t stream);
+int rt_side_join(rt_stream_t stream);
+int rt_timing_enable(int32_t mode);
+int rt_timing_collect(int32_t* ids, float* ms, int64_t* tags, int32_t max_records, int32_t* n_out);
+
 /* K5/K6  HSTU pointwise attention with in-kernel relative time/position bias (hstu.py:84-128, 270-288).
  * ts [B,L+1] int64 (NULL: no time bias); time_w [129]; time_thr [129] = smallest |dt| of each bucket, computed on
  * the host with the reference's float32 log(|dt|)/0.301 truncation; pos_w [2L-1] (NULL: no position bias).

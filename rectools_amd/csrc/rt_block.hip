@@ -1,0 +1,397 @@
+// Native executor of one PACKED SASRec block (sasrec.py:186-231, :300): the whole launch sequence of the block's forward, of its
+// backward and of its inference form behind ONE C call each.
+//
+// Why: with the padding rows gone and the attention on the bf16 pipe, a C2 training step holds ~1.7 ms of GPU work in ~60 kernel
+// launches — and Python needed 2.0-2.3 ms to issue them (ctypes call + torch.empty per buffer + stream / event objects for the
+// weight-gradient side stream): `host_issue_ms_per_step` equalled `ms_per_step` in bench.py, the step was launch-bound on the HOST.
+// Here the sequence is issued by compiled code (3-4 us per launch); Python hands over three buffers per block (saved activations,
+// scratch, flat parameter gradient) and the parameter pointers.  Same kernels, same order, same arithmetic as
+// `ops._SASRecLayerPacked` (kept as the cross-check: tests/test_packed_gpu.py::test_native_block_equals_the_python_block).
+//
+// Weight gradients leave the critical path on a library-owned side stream (fork: event on the caller's stream; join: rt_side_join,
+// called once before the optimiser step).  The caller keeps the three buffers and the block input alive until the join.
+// Optional HIP-event instrumentation (rt_timing_*) brackets every internal launch for bench.py's roofline pass.
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "rt_common.h"
+
+extern "C" {
+struct rt_gemm_problem {
+  const float* A; int64_t lda; const float* B; int64_t ldb; float* C; int64_t ldc;
+  const float* bias; const float* R; int64_t ldr; int32_t M, N, K, relu;
+};
+size_t rt_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t split_k);
+int rt_gemm(const float* A, int64_t lda, int32_t a_kc, const float* B, int64_t ldb, int32_t b_kc, float* C, int64_t ldc, const float* bias,
+            const float* R, int64_t ldr, float* a_rowsum, int32_t M, int32_t N, int32_t K, int32_t relu, int32_t split_k, void* workspace,
+            size_t workspace_bytes, hipStream_t stream);
+int rt_gemm_grouped(const rt_gemm_problem* problems, int32_t n, int32_t a_kc, int32_t b_kc, hipStream_t stream);
+int rt_colsum(const float* X, int64_t ld, int32_t M, int32_t N, float* out, hipStream_t stream);
+int rt_layernorm_fwd(const float* x, const float* w, const float* b, float eps, int32_t M, int32_t d, float* y, float* mean, float* rstd,
+                     hipStream_t stream);
+size_t rt_layernorm_bwd_workspace_bytes(int32_t M, int32_t d);
+int rt_layernorm_bwd_fused(const float* dy, const float* x, const float* w, const float* mean, const float* rstd, const float* res,
+                           const int64_t* ids, int32_t mask_dy, int32_t mask_dx, int32_t M, int32_t d, float* dx, float* dw, float* db,
+                           void* workspace, size_t workspace_bytes, hipStream_t stream);
+int rt_act_dropout_fwd(const float* z, int32_t kind, float p, uint64_t seed, uint64_t stream_id, int64_t n, const float* residual,
+                       float* y, hipStream_t stream);
+int rt_act_dropout_bwd(const float* dy, const float* z, int32_t kind, float p, uint64_t seed, uint64_t stream_id, int64_t n, float* dz,
+                       hipStream_t stream);
+int rt_mha_varlen_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const int64_t* cu_seqlens,
+                      const float* bk, const float* bv, int32_t B, int32_t H, int32_t hd, int32_t max_len, int32_t window, float* o,
+                      int64_t ldo, hipStream_t stream);
+int rt_mha_varlen_train_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                            const int64_t* cu_seqlens, const float* bk, const float* bv, int32_t B, int32_t H, int32_t hd,
+                            int32_t max_len, int32_t window, float p_drop, uint64_t seed, float* o, int64_t ldo, float* lse,
+                            hipStream_t stream);
+int rt_mha_varlen_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* o, int64_t ldo,
+                      const float* dout, int64_t lddo, const float* lse, const int64_t* cu_seqlens, const float* bk, const float* bv,
+                      int32_t B, int32_t H, int32_t hd, int32_t max_len, int32_t window, float p_drop, uint64_t seed, float* dq,
+                      int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv, float* delta, float* dbv_part, hipStream_t stream);
+int rt_mha_varlen_last_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                           const int64_t* cu_seqlens, const float* bk, const float* bv, int32_t B, int32_t H, int32_t hd, int32_t max_len,
+                           int32_t window, float* o, int64_t ldo, hipStream_t stream);
+int rt_gather_rows(const float* src, int64_t ld_src, const int64_t* idx, int32_t R, int32_t d, float* dst, int64_t ld_dst,
+                   hipStream_t stream);
+}
+
+namespace {
+
+// ---- HIP-event instrumentation of the internal launches ---------------------------------------------------------------------------
+struct TimeRec { int id; long long m, n, k; hipEvent_t e0, e1; };
+bool g_timing = false;
+bool g_single_stream = false;     // instrumentation mode 2: weight gradients on the caller's stream
+std::vector<TimeRec> g_recs;
+
+struct Timed {   // RAII bracket around one internal launch (no-op unless rt_timing_enable(1))
+  hipStream_t s; bool on; TimeRec r;
+  Timed(int id, long long m, long long n, long long k, hipStream_t stream) : s(stream), on(g_timing) {
+    if (!on) return;
+    r.id = id; r.m = m; r.n = n; r.k = k;
+    hipEventCreate(&r.e0); hipEventCreate(&r.e1);
+    hipEventRecord(r.e0, s);
+  }
+  ~Timed() {
+    if (!on) return;
+    hipEventRecord(r.e1, s);
+    g_recs.push_back(r);
+  }
+};
+enum { T_GEMM = 0, T_GEMM_GROUPED = 1, T_LN_FWD = 2, T_LN_BWD = 3, T_DROP_FWD = 4, T_DROP_BWD = 5, T_ATTN_FWD = 6, T_ATTN_BWD = 7,
+       T_ATTN_LAST = 8, T_MISC = 9 };
+
+// ---- the weight-gradient side stream (one per device, owned by the library) -------------------------------------------------------
+struct Side { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool dirty = false; };
+Side g_side[16];
+bool side_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("RT_SIDE_STREAM"); on = (e != nullptr && e[0] == '0') ? 0 : 1; }
+  return on == 1 && !g_single_stream;
+}
+Side* side_of_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  Side& s = g_side[dev];
+  if (s.stream == nullptr) {
+    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    hipEventCreateWithFlags(&s.fork, hipEventDisableTiming);
+    hipEventCreateWithFlags(&s.join, hipEventDisableTiming);
+  }
+  return &s;
+}
+
+#define RT_TRY(call)                 \
+  do {                               \
+    const int rc__ = (call);         \
+    if (rc__ != RT_OK) return rc__;  \
+  } while (0)
+
+inline size_t al(size_t floats) { return (floats + 63) & ~(size_t)63; }   // 256-byte aligned regions
+
+}  // namespace
+
+extern "C" {
+
+// ---- instrumentation ---------------------------------------------------------------------------------------------------------------
+// mode 0: off; 1: record an event pair around every internal launch of the block executor; 2: the same with the weight gradients on the
+// caller's stream (undisturbed kernel durations).  rt_timing_collect synchronises the device, copies the records out
+// (ids: 0 gemm, 1 gemm_grouped, 2 layernorm_fwd, 3 layernorm_bwd, 4 act_dropout_fwd, 5 act_dropout_bwd, 6 mha_varlen_fwd,
+// 7 mha_varlen_bwd, 8 mha_varlen_last_fwd, 9 misc; tags [n][3] = the GEMM's M, N, K or 0) and clears them.
+int rt_timing_enable(int32_t mode) {
+  g_timing = mode != 0;
+  g_single_stream = mode == 2;
+  return RT_OK;
+}
+int rt_timing_collect(int32_t* ids, float* ms, int64_t* tags, int32_t max_records, int32_t* n_out) {
+  RT_CHECK_HIP(hipDeviceSynchronize());
+  int n = 0;
+  for (auto& r : g_recs) {
+    float t = 0.f;
+    hipEventElapsedTime(&t, r.e0, r.e1);
+    if (n < max_records && ids != nullptr) { ids[n] = r.id; ms[n] = t; tags[3 * n] = r.m; tags[3 * n + 1] = r.n; tags[3 * n + 2] = r.k; ++n; }
+    hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+  }
+  g_recs.clear();
+  if (n_out != nullptr) *n_out = n;
+  return RT_OK;
+}
+
+// The caller's stream waits for every weight-gradient product issued on the side stream since the last join (no-op when none).
+int rt_side_join(hipStream_t stream) {
+  Side* s = side_of_current_device();
+  if (s == nullptr || !s->dirty) return RT_OK;
+  RT_CHECK_HIP(hipEventRecord(s->join, s->stream));
+  RT_CHECK_HIP(hipStreamWaitEvent(stream, s->join, 0));
+  s->dirty = false;
+  return RT_OK;
+}
+
+// One packed SASRec block.  rows: the row count of x / out (multiple of 128 for the exact-tile GEMM path; rows_real of them belong to
+// sessions, the rest is the unused tail); cu_seqlens [B+1]; window = session_max_len; pad_keys: the block runs without key-padding
+// masks, the window's pad keys are the virtual key of the attention.  Parameters as in the reference's state_dict (Appendix B).
+struct rt_sasrec_block {
+  int32_t rows, rows_real, B, H, d, dff, window, pad_keys;
+  float p_drop, eps1, eps2;
+  uint64_t seed_attn, seed_h, sid_h, seed_o, sid_o;     // dropout streams (ops.RNG)
+  const int64_t* cu;
+  const float *ln1_w, *ln1_b, *in_w, *in_b, *out_w, *out_b, *ln2_w, *ln2_b, *w1, *b1, *w2, *b2;
+};
+
+// floats of the activation record the forward keeps for the backward
+size_t rt_sasrec_block_saved_floats(int32_t rows, int32_t d, int32_t dff, int32_t H, int32_t with_dropout) {
+  const size_t M = (size_t)rows;
+  return al(M * d) * 6 /* q Q A y f + spare */ + al(M * 2 * d) /* KV */ + al(M * dff) * (with_dropout ? 2 : 1) /* h, hdrop */ +
+         al(M * H) /* lse */ + 4 * al(M) /* mean1 rstd1 mean2 rstd2 */;
+}
+// bytes of the backward's scratch (data gradients, attention workspace, LayerNorm partials, the split-K slabs of the side stream)
+size_t rt_sasrec_block_bwd_scratch_bytes(int32_t rows, int32_t B, int32_t d, int32_t dff, int32_t H, int32_t wgrad_splits) {
+  const size_t M = (size_t)rows;
+  size_t fl = al(M * d) * 7 /* g_o g_f g_y g_A gQ g_q g_kv */ + al(M * dff) * 2 /* g_hd g_h */ + al(M * 2 * d) /* gKV */ + al(M * H) /* delta */ +
+              al((size_t)B * d) /* part */;
+  size_t by = fl * 4 + 2 * ((rt_layernorm_bwd_workspace_bytes(rows, d) + 255) & ~(size_t)255);
+  size_t sk = 0;
+  const int spl = wgrad_splits > 1 ? wgrad_splits : 1;
+  const size_t cands[5] = {rt_gemm_workspace_bytes(d, dff, rows, spl), rt_gemm_workspace_bytes(dff, d, rows, spl), rt_gemm_workspace_bytes(d, d, rows, spl),
+                           rt_gemm_workspace_bytes(2 * d, d, rows, spl), 0};
+  for (size_t c : cands) sk = c > sk ? c : sk;
+  return by + ((sk + 255) & ~(size_t)255) + 256;
+}
+
+namespace {
+struct SavedView {
+  float *q, *Q, *A, *y, *f, *KV, *h, *hdrop, *lse, *mean1, *rstd1, *mean2, *rstd2;
+};
+SavedView carve_saved(const rt_sasrec_block& b, float* base) {
+  const size_t M = (size_t)b.rows;
+  SavedView v;
+  float* p = base;
+  v.q = p; p += al(M * b.d); v.Q = p; p += al(M * b.d); v.A = p; p += al(M * b.d); v.y = p; p += al(M * b.d); v.f = p; p += al(M * b.d);
+  p += al(M * b.d);   // spare
+  v.KV = p; p += al(M * 2 * b.d);
+  v.h = p; p += al(M * b.dff);
+  if (b.p_drop > 0.f) { v.hdrop = p; p += al(M * b.dff); } else v.hdrop = v.h;
+  v.lse = p; p += al(M * b.H);
+  v.mean1 = p; p += al(M); v.rstd1 = p; p += al(M); v.mean2 = p; p += al(M); v.rstd2 = p; p += al(M);
+  return v;
+}
+int zero_tail(float* base, const rt_sasrec_block& b, int cols, hipStream_t s) {   // rows behind the sessions must read as finite zeros
+  if (b.rows_real >= b.rows) return RT_OK;
+  RT_CHECK_HIP(hipMemsetAsync(base + (size_t)b.rows_real * cols, 0, (size_t)(b.rows - b.rows_real) * cols * sizeof(float), s));
+  return RT_OK;
+}
+}  // namespace
+
+// Training forward: out [rows, d] = block(x) (no masks: there are no pad rows); saved: rt_sasrec_block_saved_floats floats.
+int rt_sasrec_block_packed_fwd(const rt_sasrec_block* blk, const float* x, float* saved, float* out, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (blk == nullptr || x == nullptr || saved == nullptr || out == nullptr) return RT_ERR_INVALID_ARG;
+  const rt_sasrec_block& b = *blk;
+  const int M = b.rows, d = b.d, dff = b.dff, hd = d / b.H;
+  if (M <= 0 || d <= 0 || b.H <= 0 || d % b.H != 0 || b.cu == nullptr) return RT_ERR_INVALID_ARG;
+  const SavedView v = carve_saved(b, saved);
+  { Timed t(T_LN_FWD, 0, 0, 0, stream); RT_TRY(rt_layernorm_fwd(x, b.ln1_w, b.ln1_b, b.eps1, M, d, v.q, v.mean1, v.rstd1, stream)); }
+  {
+    rt_gemm_problem pr[2] = {{v.q, d, b.in_w, d, v.Q, d, b.in_b, nullptr, 0, M, d, d, 0},                                  // Q = LN1(x) Wq^T + bq
+                             {x, d, b.in_w + (size_t)d * d, d, v.KV, 2 * d, b.in_b + d, nullptr, 0, M, 2 * d, d, 0}};      // K | V = x Wkv^T + bkv
+    Timed t(T_GEMM_GROUPED, (long long)M * d * d + (long long)M * 2 * d * d, 1, 1, stream);
+    RT_TRY(rt_gemm_grouped(pr, 2, 1, 1, stream));
+  }
+  RT_TRY(zero_tail(v.A, b, d, stream));
+  const float* bk = b.pad_keys ? b.in_b + d : nullptr;
+  const float* bv = b.pad_keys ? b.in_b + 2 * d : nullptr;
+  { Timed t(T_ATTN_FWD, 0, 0, 0, stream);
+    RT_TRY(rt_mha_varlen_train_fwd(v.Q, d, v.KV, 2 * d, v.KV + d, 2 * d, b.cu, bk, bv, b.B, b.H, hd, b.window, b.window, b.p_drop, b.seed_attn,
+                                   v.A, d, v.lse, stream)); }
+  { Timed t(T_GEMM, M, d, d, stream);
+    RT_TRY(rt_gemm(v.A, d, 1, b.out_w, d, 1, v.y, d, b.out_b, v.q, d, nullptr, M, d, d, 0, 1, nullptr, 0, stream)); }   // y = q + Wo A + bo
+  { Timed t(T_LN_FWD, 0, 0, 0, stream); RT_TRY(rt_layernorm_fwd(v.y, b.ln2_w, b.ln2_b, b.eps2, M, d, v.f, v.mean2, v.rstd2, stream)); }
+  { Timed t(T_GEMM, M, dff, d, stream);
+    RT_TRY(rt_gemm(v.f, d, 1, b.w1, d, 1, v.h, dff, b.b1, nullptr, 0, nullptr, M, dff, d, 1, 1, nullptr, 0, stream)); }  // h = relu(W1 f + b1)
+  if (b.p_drop > 0.f) {
+    { Timed t(T_DROP_FWD, 0, 0, 0, stream);
+      RT_TRY(rt_act_dropout_fwd(v.h, 0, b.p_drop, b.seed_h, b.sid_h, (int64_t)M * dff, nullptr, v.hdrop, stream)); }
+    float* o = v.q + 5 * al((size_t)M * d);   // the spare region: o = W2 hdrop + b2 (dead after the next launch)
+    { Timed t(T_GEMM, M, d, dff, stream);
+      RT_TRY(rt_gemm(v.hdrop, dff, 1, b.w2, dff, 1, o, d, b.b2, nullptr, 0, nullptr, M, d, dff, 0, 1, nullptr, 0, stream)); }
+    { Timed t(T_DROP_FWD, 0, 0, 0, stream);
+      RT_TRY(rt_act_dropout_fwd(o, 0, b.p_drop, b.seed_o, b.sid_o, (int64_t)M * d, v.f, out, stream)); }              // out = f + dropout(o)
+  } else {
+    Timed t(T_GEMM, M, d, dff, stream);
+    RT_TRY(rt_gemm(v.h, dff, 1, b.w2, dff, 1, out, d, b.b2, v.f, d, nullptr, M, d, dff, 0, 1, nullptr, 0, stream));
+  }
+  return RT_OK;
+}
+
+// Backward: g_x [rows, d] and the flat parameter gradient `grads` in the order ln1_w, ln1_b, in_w, in_b, out_w, out_b, ln2_w, ln2_b,
+// w1, b1, w2, b2 (each segment starts at a multiple of 4 floats: rt_sasrec_block_grad_offsets).  Weight gradients are issued on the
+// side stream (use_side != 0 and RT_SIDE_STREAM != 0): call rt_side_join before reading them; scratch / saved / x / g_out must stay
+// alive until then.
+void rt_sasrec_block_grad_offsets(int32_t d, int32_t dff, int64_t* offsets13) {
+  const int64_t sizes[12] = {d, d, 3LL * d * d, 3LL * d, (int64_t)d * d, d, d, d, (int64_t)dff * d, dff, (int64_t)d * dff, d};
+  int64_t o = 0;
+  for (int i = 0; i < 12; ++i) { offsets13[i] = o; o += (sizes[i] + 3) & ~3LL; }
+  offsets13[12] = o;
+}
+
+int rt_sasrec_block_packed_bwd(const rt_sasrec_block* blk, const float* x, const float* saved, const float* g_out, float* g_x, float* grads,
+                               void* scratch, size_t scratch_bytes, int32_t wgrad_splits, int32_t use_side, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (blk == nullptr || x == nullptr || saved == nullptr || g_out == nullptr || g_x == nullptr || grads == nullptr || scratch == nullptr)
+    return RT_ERR_INVALID_ARG;
+  const rt_sasrec_block& b = *blk;
+  const int M = b.rows, d = b.d, dff = b.dff, hd = d / b.H;
+  const int sp = wgrad_splits > 1 ? wgrad_splits : 1;
+  if (scratch_bytes < rt_sasrec_block_bwd_scratch_bytes(M, b.B, d, dff, b.H, sp)) return RT_ERR_WORKSPACE;
+  const SavedView v = carve_saved(b, const_cast<float*>(saved));
+  int64_t go[13];
+  rt_sasrec_block_grad_offsets(d, dff, go);
+  float *d_ln1w = grads + go[0], *d_ln1b = grads + go[1], *d_in_w = grads + go[2], *d_in_b = grads + go[3], *d_wo = grads + go[4],
+        *d_bo = grads + go[5], *d_ln2w = grads + go[6], *d_ln2b = grads + go[7], *d_w1 = grads + go[8], *d_b1 = grads + go[9],
+        *d_w2 = grads + go[10], *d_b2 = grads + go[11];
+  // scratch carve-up
+  float* p = reinterpret_cast<float*>(scratch);
+  const size_t Md = al((size_t)M * d), Mf = al((size_t)M * dff);
+  float* g_o = p; p += Md; float* g_f = p; p += Md; float* g_y = p; p += Md; float* g_A = p; p += Md; float* gQ = p; p += Md;
+  float* g_q = p; p += Md; float* g_kv = p; p += Md;
+  float* g_hd = p; p += Mf; float* g_h = p; p += Mf;
+  float* gKV = p; p += al((size_t)M * 2 * d);
+  float* delta = p; p += al((size_t)M * b.H);
+  float* part = p; p += al((size_t)b.B * d);
+  unsigned char* bp = reinterpret_cast<unsigned char*>(p);
+  const size_t lnws = (rt_layernorm_bwd_workspace_bytes(M, d) + 255) & ~(size_t)255;
+  void* ln_ws1 = bp; bp += lnws; void* ln_ws2 = bp; bp += lnws;
+  void* sk_ws = bp;
+  const size_t sk_bytes = scratch_bytes - (size_t)(bp - reinterpret_cast<unsigned char*>(scratch));
+
+  Side* side = (use_side && side_enabled()) ? side_of_current_device() : nullptr;
+  hipStream_t ws = side != nullptr ? side->stream : stream;     // where the weight gradients go
+  auto fork = [&]() -> int {                                     // the side stream sees everything issued so far on `stream`
+    if (side == nullptr) return RT_OK;
+    RT_CHECK_HIP(hipEventRecord(side->fork, stream));
+    RT_CHECK_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
+    side->dirty = true;
+    return RT_OK;
+  };
+  auto wgrad = [&](const float* dy, int ldy, const float* in, int ldin, float* dw, int n_out, int n_in, float* db) -> int {
+    Timed t(T_GEMM, n_out, n_in, M, ws);
+    return rt_gemm(dy, ldy, 0, in, ldin, 0, dw, n_in, nullptr, nullptr, 0, db, n_out, n_in, M, 0, sp, sp > 1 ? sk_ws : nullptr,
+                   sp > 1 ? sk_bytes : 0, ws);                   // dW = dy^T in, db = colsum(dy) from the staged dy^T tiles
+  };
+
+  // ---- feed-forward: out = f + dropout(o), o = W2 hdrop + b2, hdrop = dropout(relu(W1 f + b1))
+  const float* g_o_c = g_out;
+  if (b.p_drop > 0.f) {
+    Timed t(T_DROP_BWD, 0, 0, 0, stream);
+    RT_TRY(rt_act_dropout_bwd(g_out, g_out, 0, b.p_drop, b.seed_o, b.sid_o, (int64_t)M * d, g_o, stream));
+    g_o_c = g_o;
+  }
+  RT_TRY(fork());
+  RT_TRY(wgrad(g_o_c, d, v.hdrop, dff, d_w2, d, dff, d_b2));
+  { Timed t(T_GEMM, M, dff, d, stream);
+    RT_TRY(rt_gemm(g_o_c, d, 1, b.w2, dff, 0, g_hd, dff, nullptr, nullptr, 0, nullptr, M, dff, d, 0, 1, nullptr, 0, stream)); }
+  { Timed t(T_DROP_BWD, 0, 0, 0, stream);   // dropout mask and relu'(h) in one pass
+    RT_TRY(rt_act_dropout_bwd(g_hd, v.h, 1, b.p_drop, b.seed_h, b.sid_h, (int64_t)M * dff, g_h, stream)); }
+  RT_TRY(fork());
+  RT_TRY(wgrad(g_h, dff, v.f, d, d_w1, dff, d, d_b1));
+  { Timed t(T_GEMM, M, d, dff, stream);     // residual branch (g_out) added in the dgrad epilogue
+    RT_TRY(rt_gemm(g_h, dff, 1, b.w1, d, 0, g_f, d, nullptr, g_out, d, nullptr, M, d, dff, 0, 1, nullptr, 0, stream)); }
+  { Timed t(T_LN_BWD, 0, 0, 0, stream);
+    RT_TRY(rt_layernorm_bwd_fused(g_f, v.y, b.ln2_w, v.mean2, v.rstd2, nullptr, nullptr, 0, 0, M, d, g_y, d_ln2w, d_ln2b, ln_ws1, lnws, stream)); }
+  // ---- attention: y = q + Wo A + bo
+  RT_TRY(fork());
+  RT_TRY(wgrad(g_y, d, v.A, d, d_wo, d, d, d_bo));
+  { Timed t(T_GEMM, M, d, d, stream);
+    RT_TRY(rt_gemm(g_y, d, 1, b.out_w, d, 0, g_A, d, nullptr, nullptr, 0, nullptr, M, d, d, 0, 1, nullptr, 0, stream)); }
+  RT_TRY(zero_tail(gQ, b, d, stream));      // rows behind the sessions must read as zero in the weight gradients
+  RT_TRY(zero_tail(gKV, b, 2 * d, stream));
+  const float* bk = b.pad_keys ? b.in_b + d : nullptr;
+  const float* bv = b.pad_keys ? b.in_b + 2 * d : nullptr;
+  { Timed t(T_ATTN_BWD, 0, 0, 0, stream);
+    RT_TRY(rt_mha_varlen_bwd(v.Q, d, v.KV, 2 * d, v.KV + d, 2 * d, v.A, d, g_A, d, v.lse, b.cu, bk, bv, b.B, b.H, hd, b.window, b.window, b.p_drop,
+                             b.seed_attn, gQ, d, gKV, 2 * d, gKV + d, 2 * d, delta, b.pad_keys ? part : nullptr, stream)); }
+  RT_TRY(fork());
+  RT_TRY(wgrad(gQ, d, v.q, d, d_in_w, d, d, d_in_b));
+  RT_TRY(wgrad(gKV, 2 * d, x, d, d_in_w + (size_t)d * d, 2 * d, d, d_in_b + d));
+  if (b.pad_keys) {   // the pad keys' share: b_k has no gradient in total (it shifts every logit of a query alike), b_v gets theirs
+    Timed t(T_MISC, 0, 0, 0, ws);
+    RT_CHECK_HIP(hipMemsetAsync(d_in_b + d, 0, (size_t)d * sizeof(float), ws));
+    RT_TRY(rt_colsum(part, d, b.B, d, d_in_b + 2 * d, ws));
+  }
+  {
+    rt_gemm_problem pr[2] = {{gQ, d, b.in_w, d, g_q, d, nullptr, g_y, d, M, d, d, 0},                                      // g_q = gQ Wq + g_y
+                             {gKV, 2 * d, b.in_w + (size_t)d * d, d, g_kv, d, nullptr, nullptr, 0, M, d, 2 * d, 0}};       // g_kv = gKV Wkv
+    Timed t(T_GEMM_GROUPED, (long long)M * d * d + (long long)M * d * 2 * d, 1, 1, stream);
+    RT_TRY(rt_gemm_grouped(pr, 2, 1, 0, stream));
+  }
+  { Timed t(T_LN_BWD, 0, 0, 0, stream);     // g_x = LN1'(g_q) + g_kv
+    RT_TRY(rt_layernorm_bwd_fused(g_q, x, b.ln1_w, v.mean1, v.rstd1, g_kv, nullptr, 0, 0, M, d, g_x, d_ln1w, d_ln1b, ln_ws2, lnws, stream)); }
+  return RT_OK;
+}
+
+// Inference (recommend(): eval mode, no dropout).  last_rows == NULL: out [rows, d] for every row.  last_rows [B] (= cu[1:] - 1): the
+// block's output at the LAST position of every session only, out [B, d] — the key / value projection is then the only product over
+// all rows (lightning.py:393-397 keeps session_embs[:, -1, :]).  scratch: rt_sasrec_block_infer_scratch_floats floats.
+size_t rt_sasrec_block_infer_scratch_floats(int32_t rows, int32_t B, int32_t d, int32_t dff, int32_t last_only) {
+  const size_t M = (size_t)rows, R = last_only ? (size_t)B : M;
+  return (last_only ? al(R * d) : 0) /* x_last */ + al(R * d) * 5 /* q Q A y f */ + al(M * 2 * d) /* KV */ + al(R * dff) /* h */ + 2 * al(R);
+}
+int rt_sasrec_block_packed_infer(const rt_sasrec_block* blk, const float* x, const int64_t* last_rows, float* scratch, float* out,
+                                 hipStream_t stream) {
+  (void)hipGetLastError();
+  if (blk == nullptr || x == nullptr || scratch == nullptr || out == nullptr) return RT_ERR_INVALID_ARG;
+  const rt_sasrec_block& b = *blk;
+  const int M = b.rows, d = b.d, dff = b.dff, hd = d / b.H;
+  const bool last = last_rows != nullptr;
+  const int R = last ? b.B : M;
+  float* p = scratch;
+  const float* xin = x;
+  if (last) { float* xl = p; p += al((size_t)R * d); RT_TRY(rt_gather_rows(x, d, last_rows, R, d, xl, d, stream)); xin = xl; }
+  float* q = p; p += al((size_t)R * d); float* Q = p; p += al((size_t)R * d); float* A = p; p += al((size_t)R * d);
+  float* y = p; p += al((size_t)R * d); float* f = p; p += al((size_t)R * d);
+  float* KV = p; p += al((size_t)M * 2 * d);
+  float* h = p; p += al((size_t)R * dff);
+  float* mean = p; p += al((size_t)R); float* rstd = p;
+  const float* bk = b.pad_keys ? b.in_b + d : nullptr;
+  const float* bv = b.pad_keys ? b.in_b + 2 * d : nullptr;
+  RT_TRY(rt_layernorm_fwd(xin, b.ln1_w, b.ln1_b, b.eps1, R, d, q, mean, rstd, stream));
+  if (!last) {
+    rt_gemm_problem pr[2] = {{q, d, b.in_w, d, Q, d, b.in_b, nullptr, 0, M, d, d, 0},
+                             {x, d, b.in_w + (size_t)d * d, d, KV, 2 * d, b.in_b + d, nullptr, 0, M, 2 * d, d, 0}};
+    RT_TRY(rt_gemm_grouped(pr, 2, 1, 1, stream));
+    { rt_sasrec_block bb = b; RT_TRY(zero_tail(A, bb, d, stream)); }
+    RT_TRY(rt_mha_varlen_fwd(Q, d, KV, 2 * d, KV + d, 2 * d, b.cu, bk, bv, b.B, b.H, hd, b.window, b.window, A, d, stream));
+  } else {
+    RT_TRY(rt_gemm(x, d, 1, b.in_w + (size_t)d * d, d, 1, KV, 2 * d, b.in_b + d, nullptr, 0, nullptr, M, 2 * d, d, 0, 1, nullptr, 0, stream));
+    RT_TRY(rt_gemm(q, d, 1, b.in_w, d, 1, Q, d, b.in_b, nullptr, 0, nullptr, R, d, d, 0, 1, nullptr, 0, stream));
+    RT_TRY(rt_mha_varlen_last_fwd(Q, d, KV, 2 * d, KV + d, 2 * d, b.cu, bk, bv, b.B, b.H, hd, b.window, b.window, A, d, stream));
+  }
+  RT_TRY(rt_gemm(A, d, 1, b.out_w, d, 1, y, d, b.out_b, q, d, nullptr, R, d, d, 0, 1, nullptr, 0, stream));
+  RT_TRY(rt_layernorm_fwd(y, b.ln2_w, b.ln2_b, b.eps2, R, d, f, mean, rstd, stream));
+  RT_TRY(rt_gemm(f, d, 1, b.w1, d, 1, h, dff, b.b1, nullptr, 0, nullptr, R, dff, d, 1, 1, nullptr, 0, stream));
+  RT_TRY(rt_gemm(h, dff, 1, b.w2, dff, 1, out, d, b.b2, f, d, nullptr, R, d, dff, 0, 1, nullptr, 0, stream));
+  return RT_OK;
+}
+
+}  // extern "C"

@@ -81,9 +81,10 @@ class _TrainLoop:
         self.mine_t: tp.Optional[torch.Tensor] = None
         self.pos = 0
         self.sequences_done = 0   # sessions consumed by step() so far (the last batch of an epoch may be short)
-        # packed training batches (no padding rows): opt-in while the path is young
+        # packed training batches (no padding rows): the default wherever the stack offers it (causal SASRec blocks,
+        # head size 32 / 64); RT_PACKED_TRAIN=0 keeps the padded [B, L] window (the cross-check of tests/test_packed_gpu.py)
         tm = lm.torch_model
-        self.packed = (os.environ.get("RT_PACKED_TRAIN", "0") == "1" and type(self.dp).__name__ == "SASRecDataPreparator"
+        self.packed = (os.environ.get("RT_PACKED_TRAIN", "1") != "0" and type(self.dp).__name__ == "SASRecDataPreparator"
                        and not self.dp.add_unix_ts and not (self.dp.extra_cols or [])
                        and getattr(tm.transformer_layers, "packed_ok", None) is not None
                        and getattr(tm, "_fused_pos", lambda: False)()
@@ -107,6 +108,27 @@ class _TrainLoop:
             np.cumsum(grid, axis=1, out=cu[:, 1:])
             self._cu_host = cu
             self._cu_dev = torch.from_numpy(cu).to(self.device)
+            self._reserve_step_memory(int(cu[:, -1].max()))
+
+    def _reserve_step_memory(self, max_rows: int) -> None:
+        """Packed batches change their row count every step, and torch's caching allocator answers a size it has not seen with a
+        synchronous hipMalloc — dozens of them over the first steps of a run.  The host knows the epoch's largest batch: take ONE
+        block that covers a step of that size and hand it back, the allocator then carves every request of every step out of it
+        (large blocks are split and re-merged).  ~45 row-sized fp32 buffers are live at the peak of a 2-block step."""
+        if self.device.type != "cuda" or getattr(self, "_reserved_rows", 0) >= max_rows:
+            return
+        d = int(self.model.n_factors)
+        n_blocks = max(int(self.model.n_blocks), 1)
+        n_neg = int(self.model.n_negatives or 0) if self.dp.negative_sampler is not None else 0
+        rows = (max_rows + 127) // 128 * 128
+        per_row = 4 * d * (12 * n_blocks + 12) + (8 + 4) * (n_neg + 1) + 64
+        table = 4 * d * int(self.dp.item_id_map.size) * 3
+        try:
+            block = torch.empty((int(rows * per_row * 1.25) + table,), dtype=torch.uint8, device=self.device)
+            del block
+        except RuntimeError:     # not enough free memory for the reservation: the allocator grows step by step instead
+            pass
+        self._reserved_rows = max_rows
 
     def batches_left(self) -> int:
         return 0 if self.mine_t is None else -(-(int(self.mine_t.numel()) - self.pos) // self.batch_size)
@@ -131,7 +153,7 @@ class _TrainLoop:
         rows = max((n + 127) // 128 * 128, 128)
         cu = self._cu_dev[bi, :nb + 1]
         x, y, yw, dist = ops.collate_packed(self.dstore.offsets, self.dstore.items, self.dstore.weights, idx, cu, rows, train=True)
-        batch: tp.Dict[str, tp.Any] = {"x": x, "y": y, "yw": yw, "dist": dist, "cu": cu, "window": self.dp.session_max_len}
+        batch: tp.Dict[str, tp.Any] = {"x": x, "y": y, "yw": yw, "dist": dist, "cu": cu, "window": self.dp.session_max_len, "n_rows": n}
         if self.dp.negative_sampler is not None:
             batch["negatives"] = self.dp.negative_sampler.get_negatives(
                 {"x": x.view(-1, 1)}, lowest_id=self.dp.n_item_extra_tokens, highest_id=self.dp.item_id_map.size)

@@ -339,7 +339,7 @@ class SASRecTransformerLayer(nn.Module):
         ff = self.feed_forward
         return ff.ff_linear_1.bias is not None and ff.ff_linear_2.bias is not None and ff.activation == "relu"
 
-    def forward_packed(self, seqs, cu, B, window, pad_keys, last_rows=None):
+    def forward_packed(self, seqs, cu, B, window, pad_keys, last_rows=None, rows_real=None):
         """Inference over packed sessions (no padding rows; see ops.sasrec_layer_packed): [Np, d], or [B, d] with `last_rows`."""
         ff, mha = self.feed_forward, self.multi_head_attn
         return ops.sasrec_layer_packed(
@@ -347,9 +347,9 @@ class SASRecTransformerLayer(nn.Module):
             (self.q_layer_norm.weight, self.q_layer_norm.bias, self.q_layer_norm.eps),
             (mha.in_proj_weight, mha.in_proj_bias), (mha.out_proj.weight, mha.out_proj.bias),
             (self.ff_layer_norm.weight, self.ff_layer_norm.bias, self.ff_layer_norm.eps),
-            (ff.ff_linear_1.weight, ff.ff_linear_1.bias), (ff.ff_linear_2.weight, ff.ff_linear_2.bias))
+            (ff.ff_linear_1.weight, ff.ff_linear_1.bias), (ff.ff_linear_2.weight, ff.ff_linear_2.bias), rows_real=rows_real)
 
-    def forward_packed_train(self, seqs, cu, B, window, pad_keys):
+    def forward_packed_train(self, seqs, cu, B, window, pad_keys, rows_real=None):
         """The block on packed rows with autograd (training): ONE autograd node (`ops.sasrec_layer_packed_train`) when the feed-forward
         is the fused kind (ReLU, biases), else the individual ops."""
         ff, mha = self.feed_forward, self.multi_head_attn
@@ -360,7 +360,7 @@ class SASRecTransformerLayer(nn.Module):
             (self.q_layer_norm.weight, self.q_layer_norm.bias, self.q_layer_norm.eps),
             (mha.in_proj_weight, mha.in_proj_bias), (mha.out_proj.weight, mha.out_proj.bias),
             (self.ff_layer_norm.weight, self.ff_layer_norm.bias, self.ff_layer_norm.eps),
-            (ff.ff_linear_1.weight, ff.ff_linear_1.bias), (ff.ff_linear_2.weight, ff.ff_linear_2.bias))
+            (ff.ff_linear_1.weight, ff.ff_linear_1.bias), (ff.ff_linear_2.weight, ff.ff_linear_2.bias), rows_real=rows_real)
 
     def forward_packed_modular(self, seqs, cu, B, window, pad_keys):
         """The same block out of the individual autograd ops (as `forward_modular`; the cross-check of the fused packed node).  No
@@ -421,20 +421,21 @@ class SASRecTransformerLayers(TransformerLayersBase):
         return bool(blocks) and causal and all(b.packed_ok() for b in blocks) and \
             ops.mha_varlen_supported(blocks[0].multi_head_attn.n_heads, n_factors, window)
 
-    def forward_packed_train(self, seqs, cu, B, window, keypad):
-        """Training forward over packed rows, [Np, d] (every row is a real position or belongs to the unused tail)."""
+    def forward_packed_train(self, seqs, cu, B, window, keypad, rows_real=None):
+        """Training forward over packed rows, [Np, d] (every row is a real position or belongs to the unused tail).  rows_real: the
+        number of session rows when the caller knows it on the host (selects the native block executor)."""
         for blk in self.transformer_blocks:
-            seqs = blk.forward_packed_train(seqs, cu, B, window, not keypad)
+            seqs = blk.forward_packed_train(seqs, cu, B, window, not keypad, rows_real)
         return self.last_layernorm(seqs)
 
-    def forward_last_packed(self, seqs, cu, B, window, keypad):
+    def forward_last_packed(self, seqs, cu, B, window, keypad, rows_real=None):
         """[B, d] encodings of the last position from PACKED rows: every block input is the real rows only — the
         reference masks pad rows to zero before each block (sasrec.py:300) and their only trace, the pad keys a causal block
         without key-padding masks shows to every query, is the virtual key of `rt_mha_varlen_*`."""
         blocks = list(self.transformer_blocks)
         for blk in blocks[:-1]:
-            seqs = blk.forward_packed(seqs, cu, B, window, not keypad)
-        last = blocks[-1].forward_packed(seqs, cu, B, window, not keypad, last_rows=cu[1:] - 1)
+            seqs = blk.forward_packed(seqs, cu, B, window, not keypad, rows_real=rows_real)
+        last = blocks[-1].forward_packed(seqs, cu, B, window, not keypad, last_rows=cu[1:] - 1, rows_real=rows_real)
         return self.last_layernorm(last)
 
 
@@ -787,10 +788,10 @@ class TransformerTorchBackbone(nn.Module):
         scale = float(d) ** 0.5 if self.pos_encoding_layer.use_scale_factor else 1.0
         x = torch.empty((Np, d), dtype=torch.float32, device=table.device)
         ops._c("rt_embed_packed_fwd", ids, dist, table, pos, float(scale), Np, d, 0.0, 0, 0, x)
-        return self.transformer_layers.forward_last_packed(x, cu, B, window, self.use_key_padding_mask)
+        return self.transformer_layers.forward_last_packed(x, cu, B, window, self.use_key_padding_mask, rows_real=n_rows)
 
     def encode_packed_train(self, ids: torch.Tensor, dist: torch.Tensor, cu: torch.Tensor, B: int, window: int,
-                            item_embs: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
+                            item_embs: tp.Optional[torch.Tensor] = None, rows_real: tp.Optional[int] = None) -> torch.Tensor:
         """Training twin of `encode_sessions` on packed rows: ids / dist [Np] (tail rows: id 0, dist 0), -> [Np, d].  ONE fused
         pass (`ops.embed_packed`): embedding rows (pad id 0 has no gradient), positional rows by the distance from the session's
         end, the embedding dropout (torch_backbone.py:245-247)."""
@@ -799,7 +800,7 @@ class TransformerTorchBackbone(nn.Module):
         scale = float(d) ** 0.5 if self.pos_encoding_layer.use_scale_factor else 1.0
         pos = self.pos_encoding_layer.pos_emb.weight if self.pos_encoding_layer.pos_emb is not None else None
         seqs = ops.embed_packed(table, pos, ids, dist, cu, B, window, scale, self.dropout_rate if self.training else 0.0)
-        return self.transformer_layers.forward_packed_train(seqs, cu, B, window, self.use_key_padding_mask)
+        return self.transformer_layers.forward_packed_train(seqs, cu, B, window, self.use_key_padding_mask, rows_real)
 
     def encode_last(self, batch: Batch, item_embs: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
         """-> [B, d] = encode_sessions(batch)[:, -1, :], the only rows recommend() uses (lightning.py:393-397).  Layer stacks

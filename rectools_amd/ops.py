@@ -34,6 +34,7 @@ def start_timing(single_stream: bool = True) -> None:
     global _TIMING, _TIMING_SINGLE_STREAM
     _TIMING = {}
     _TIMING_SINGLE_STREAM = single_stream
+    _lib.load().rt_timing_enable(2 if single_stream else 1)     # the native block executor brackets its internal launches itself
 
 
 def stop_timing() -> tp.Dict[str, tp.List[tp.Tuple[float, tp.Any]]]:
@@ -41,7 +42,25 @@ def stop_timing() -> tp.Dict[str, tp.List[tp.Tuple[float, tp.Any]]]:
     global _TIMING
     rec, _TIMING = _TIMING or {}, None
     torch.cuda.synchronize()
-    return {k: [(a.elapsed_time(b), tag) for a, b, tag in v] for k, v in rec.items()}
+    out = {k: [(a.elapsed_time(b), tag) for a, b, tag in v] for k, v in rec.items()}
+    out.pop("rt_sasrec_block_packed_fwd", None)      # the executor's own records (below) itemise these calls
+    out.pop("rt_sasrec_block_packed_bwd", None)
+    import ctypes
+
+    lib = _lib.load()
+    cap = 1 << 16
+    ids, ms, tags, n = (ctypes.c_int32 * cap)(), (ctypes.c_float * cap)(), (ctypes.c_int64 * (3 * cap))(), ctypes.c_int32(0)
+    lib.rt_timing_collect(ids, ms, tags, cap, ctypes.byref(n))
+    lib.rt_timing_enable(0)
+    for i in range(n.value):
+        name = _NATIVE_TIMING_NAMES.get(ids[i], "rt_misc")
+        out.setdefault(name, []).append((float(ms[i]), (int(tags[3 * i]), int(tags[3 * i + 1]), int(tags[3 * i + 2]))))
+    return out
+
+
+_NATIVE_TIMING_NAMES = {0: "rt_gemm", 1: "rt_gemm_grouped", 2: "rt_layernorm_fwd", 3: "rt_layernorm_bwd_fused", 4: "rt_act_dropout_fwd",
+                        5: "rt_act_dropout_bwd", 6: "rt_mha_varlen_train_fwd", 7: "rt_mha_varlen_bwd", 8: "rt_mha_varlen_last_fwd",
+                        9: "rt_misc"}
 
 
 _FN: tp.Dict[str, tp.Any] = {}   # bound C entry points (one getattr per name instead of one per launch)
@@ -156,11 +175,18 @@ class _OnSide:
             torch.cuda.current_stream(self.dev).wait_event(self.side.record_event())
 
 
+_NATIVE_KEEPALIVE: tp.List[tp.Any] = []   # buffers the native executor's side stream may still be reading (until the next join)
+
+
 def join_side_streams() -> None:
-    """Main stream waits for every weight-gradient product issued on a side stream."""
+    """Main stream waits for every weight-gradient product issued on a side stream — torch's (the Python autograd nodes) and the
+    library's own (the native block executor, csrc/rt_block.hip)."""
     for dev in list(_SIDE_DIRTY):
         torch.cuda.current_stream(dev).wait_event(_SIDE[dev].record_event())
     _SIDE_DIRTY.clear()
+    if _NATIVE_KEEPALIVE:
+        _c("rt_side_join")
+        _NATIVE_KEEPALIVE.clear()
 
 
 # --------------------------------------------------------------------------------------------------
@@ -1161,10 +1187,100 @@ class _SASRecLayerPacked(torch.autograd.Function):
         return (g_x, None, d_ln1w, d_ln1b, d_in_w, d_in_b, d_wo, d_bo, d_ln2w, d_ln2b, d_w1, d_b1, d_w2, d_b2, None)
 
 
+_GRAD_OFFSETS: tp.Dict[tp.Tuple[int, int], tp.List[int]] = {}
+
+
+def _block_desc(rows: int, rows_real: int, cu: torch.Tensor, B: int, H: int, d: int, dff: int, window: int, pad_keys: bool, p: float,
+                eps1: float, eps2: float, seeds: tp.Tuple[int, int, int, int, int], params: tp.Sequence[torch.Tensor]) -> "_lib.SasrecBlock":
+    blk = _lib.SasrecBlock()
+    blk.rows, blk.rows_real, blk.B, blk.H, blk.d, blk.dff, blk.window, blk.pad_keys = rows, rows_real, B, H, d, dff, window, int(pad_keys)
+    blk.p_drop, blk.eps1, blk.eps2 = float(p), float(eps1), float(eps2)
+    blk.seed_attn, blk.seed_h, blk.sid_h, blk.seed_o, blk.sid_o = seeds
+    blk.cu = cu.data_ptr()
+    (blk.ln1_w, blk.ln1_b, blk.in_w, blk.in_b, blk.out_w, blk.out_b, blk.ln2_w, blk.ln2_b, blk.w1, blk.b1, blk.w2,
+     blk.b2) = [t.data_ptr() for t in params]
+    return blk
+
+
+class _SASRecLayerPackedNative(torch.autograd.Function):
+    """`_SASRecLayerPacked` issued by the native executor (`rt_sasrec_block_packed_fwd / _bwd`, csrc/rt_block.hip): ONE C call per
+    direction instead of ~10 / ~18 ctypes launches with a torch.empty per buffer — same kernels, same order, same dropout streams
+    (the node draws them from `RNG` exactly as the Python node does).  The activations live in one `saved` buffer, the data
+    gradients in one scratch buffer, the twelve parameter gradients are views of one flat buffer."""
+
+    @staticmethod
+    def forward(ctx, x, cu, ln1_w, ln1_b, in_w, in_b, out_w, out_b, ln2_w, ln2_b, w1, b1, w2, b2, meta):
+        import ctypes
+
+        B, H, window, pad_keys, p, eps1, eps2, rows_real = meta
+        x = x.contiguous()
+        M, d = x.shape
+        dff = w1.shape[0]
+        lib = _lib.load()
+        seed_a, seed_h, seed_o = 0, (0, 0), (0, 0)
+        if p > 0:       # the same draws, in the same order, as the Python node
+            s0, sid = RNG.next()
+            seed_a = (s0 + 0xD1B54A32D192ED03 * sid) & 0xFFFFFFFFFFFFFFFF
+            seed_h = RNG.next()
+            seed_o = RNG.next()
+        params = (ln1_w, ln1_b, in_w, in_b, out_w, out_b, ln2_w, ln2_b, w1, b1, w2, b2)
+        blk = _block_desc(M, rows_real, cu, B, H, d, dff, window, pad_keys, p, eps1, eps2, (seed_a, seed_h[0], seed_h[1], seed_o[0], seed_o[1]),
+                          params)
+        saved = torch.empty((lib.rt_sasrec_block_saved_floats(M, d, dff, H, 1 if p > 0 else 0),), dtype=torch.float32, device=x.device)
+        out = torch.empty((M, d), dtype=torch.float32, device=x.device)
+        _c("rt_sasrec_block_packed_fwd", ctypes.addressof(blk), x, saved, out)
+        ctx.save_for_backward(x, cu, saved, *params)
+        ctx.blk_meta = (B, H, window, pad_keys, p, eps1, eps2, rows_real, (seed_a, seed_h[0], seed_h[1], seed_o[0], seed_o[1]))
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        import ctypes
+
+        x, cu, saved, *params = ctx.saved_tensors
+        B, H, window, pad_keys, p, eps1, eps2, rows_real, seeds = ctx.blk_meta
+        g_out = g_out.contiguous()
+        M, d = g_out.shape
+        dff = params[8].shape[0]
+        dev = g_out.device
+        lib = _lib.load()
+        blk = _block_desc(M, rows_real, cu, B, H, d, dff, window, pad_keys, p, eps1, eps2, seeds, params)
+        key = (d, dff)
+        offs = _GRAD_OFFSETS.get(key)
+        if offs is None:
+            arr = (ctypes.c_int64 * 13)()
+            lib.rt_sasrec_block_grad_offsets(d, dff, arr)
+            offs = _GRAD_OFFSETS[key] = list(arr)
+        sp = _wgrad_splits(M)
+        scratch_bytes = lib.rt_sasrec_block_bwd_scratch_bytes(M, B, d, dff, H, sp)
+        scratch = torch.empty((scratch_bytes,), dtype=torch.uint8, device=dev)
+        grads = torch.empty((offs[12],), dtype=torch.float32, device=dev)
+        g_x = torch.empty((M, d), dtype=torch.float32, device=dev)
+        use_side = _side_enabled() and _steals_grad(*params)
+        _c("rt_sasrec_block_packed_bwd", ctypes.addressof(blk), x, saved, g_out, g_x, grads, scratch, scratch_bytes, sp, 1 if use_side else 0)
+        if use_side:   # the side stream may read these until the join at the end of the backward pass (FlatAdam.step / callback)
+            if not _NATIVE_KEEPALIVE:
+                torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+            _NATIVE_KEEPALIVE.append((x, saved, g_out, scratch, grads))
+        views = [grads[offs[i]:offs[i] + t.numel()].view_as(t) for i, t in enumerate(params)]
+        return (g_x, None, *views, None)
+
+
+def native_block_enabled() -> bool:
+    return os.environ.get("RT_NATIVE_BLOCK", "1") != "0"
+
+
 def sasrec_layer_packed_train(x: torch.Tensor, cu: torch.Tensor, B: int, H: int, window: int, pad_keys: bool, p: float,
                               ln1: tp.Tuple[torch.Tensor, torch.Tensor, float], in_proj: tp.Tuple[torch.Tensor, torch.Tensor],
                               out_proj: tp.Tuple[torch.Tensor, torch.Tensor], ln2: tp.Tuple[torch.Tensor, torch.Tensor, float],
-                              ff1: tp.Tuple[torch.Tensor, torch.Tensor], ff2: tp.Tuple[torch.Tensor, torch.Tensor]) -> torch.Tensor:
+                              ff1: tp.Tuple[torch.Tensor, torch.Tensor], ff2: tp.Tuple[torch.Tensor, torch.Tensor],
+                              rows_real: tp.Optional[int] = None) -> torch.Tensor:
+    """One packed SASRec block with autograd.  rows_real (the number of rows that belong to sessions; host-side knowledge of the
+    caller) selects the native executor; without it the Python node issues the same kernels one by one."""
+    if native_block_enabled() and rows_real is not None and x.shape[0] % 128 == 0:
+        return _SASRecLayerPackedNative.apply(_chk(x, "sasrec_layer_packed_train"), cu, ln1[0], ln1[1], in_proj[0], in_proj[1], out_proj[0],
+                                              out_proj[1], ln2[0], ln2[1], ff1[0], ff1[1], ff2[0], ff2[1],
+                                              (B, H, window, pad_keys, p, ln1[2], ln2[2], int(rows_real)))
     return _SASRecLayerPacked.apply(_chk(x, "sasrec_layer_packed_train"), cu, ln1[0], ln1[1], in_proj[0], in_proj[1], out_proj[0],
                                     out_proj[1], ln2[0], ln2[1], ff1[0], ff1[1], ff2[0], ff2[1],
                                     (B, H, window, pad_keys, p, ln1[2], ln2[2]))
@@ -1262,7 +1378,8 @@ def mha_varlen_supported(n_heads: int, d: int, window: int) -> bool:
 def sasrec_layer_packed(x: torch.Tensor, cu: torch.Tensor, B: int, H: int, window: int, pad_keys: bool, last_rows: tp.Optional[torch.Tensor],
                         ln1: tp.Tuple[torch.Tensor, torch.Tensor, float], in_proj: tp.Tuple[torch.Tensor, torch.Tensor],
                         out_proj: tp.Tuple[torch.Tensor, torch.Tensor], ln2: tp.Tuple[torch.Tensor, torch.Tensor, float],
-                        ff1: tp.Tuple[torch.Tensor, torch.Tensor], ff2: tp.Tuple[torch.Tensor, torch.Tensor]) -> torch.Tensor:
+                        ff1: tp.Tuple[torch.Tensor, torch.Tensor], ff2: tp.Tuple[torch.Tensor, torch.Tensor],
+                        rows_real: tp.Optional[int] = None) -> torch.Tensor:
     """Inference only: one causal SASRec block (sasrec.py:186-231) over PACKED sessions — `x` [Np, d] holds the real positions
     only (session b = rows cu[b] .. cu[b+1]-1, oldest first; Np = the row count rounded up to the 128-row GEMM tile, tail rows
     arbitrary).  The pad keys the reference's left-padded window shows to every query enter as one virtual key per query
@@ -1275,6 +1392,18 @@ def sasrec_layer_packed(x: torch.Tensor, cu: torch.Tensor, B: int, H: int, windo
     new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
     in_w, in_b = in_proj
     hd = d // H
+    if native_block_enabled() and rows_real is not None and Np % 128 == 0 and ff1[1] is not None and ff2[1] is not None:
+        import ctypes   # the same launch sequence as below, issued by the native executor (csrc/rt_block.hip): ONE call per block
+
+        lib = _lib.load()
+        dff = ff1[0].shape[0]
+        blk = _block_desc(Np, int(rows_real), cu, B, H, d, dff, window, pad_keys, 0.0, ln1[2], ln2[2], (0, 0, 0, 0, 0),
+                          (ln1[0], ln1[1], in_w, in_b, out_proj[0], out_proj[1], ln2[0], ln2[1], ff1[0], ff1[1], ff2[0], ff2[1]))
+        last = last_rows is not None
+        scratch = new(lib.rt_sasrec_block_infer_scratch_floats(Np, B, d, dff, 1 if last else 0))
+        out = new(B if last else Np, d)
+        _c("rt_sasrec_block_packed_infer", ctypes.addressof(blk), x, last_rows, scratch, out)
+        return out
     bk = in_b[d:2 * d] if pad_keys else None
     bv = in_b[2 * d:] if pad_keys else None
     mean, rstd = new(Np), new(Np)

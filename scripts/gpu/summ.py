@@ -12,6 +12,6 @@ for k in ("recommend_e2e", "recommend", "topk5m", "train_exact_gemm", "topk5m_u4
         r = j[k].get("roofline") or {}
         print(" ", k, j[k].get("value"), j[k].get("unit"), "frac", r.get("frac"), {a: b for a, b in j[k].items() if a.startswith("phase")})
 r = j.get("roofline") or {}
-print("  roofline", r.get("kernel", "")[:50], r.get("achieved"), r.get("unit"), "frac", r.get("frac"))
+print("  roofline", r.get("kernel", "")[:50], r.get("achieved"), r.get("unit"), "frac", r.get("frac"), "host_issue_ms", r.get("host_issue_ms_per_step"))
 for k, v in list((j.get("kernel_breakdown") or {}).items())[:24]:
     print("   %-30s %8.4f ms  x%5.1f  single %8.4f" % (k, v["ms_per_step"], v["calls_per_step"], v["single_stream_ms"]))

@@ -4,7 +4,7 @@ import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 hdr = open(os.path.join(ROOT, "include", "rectools_hip.h")).read()
-n = len(set(re.findall(r"^\s*(?:int|size_t|int32_t|const char\*)\s+(rt_\w+)\s*\(", hdr, flags=re.M)))
+n = len(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", hdr, flags=re.S))))   # as tests/test_abi.py counts
 for name, pat, fmt in (("DESIGN.md", r"\((\d+) `extern \"C\"` entry points", '({} `extern "C"` entry points'),
                        ("INTEGRATION.md", r"\((\d+) `extern \"C\"` functions", '({} `extern "C"` functions'),
                        ("README.md", r"\((\d+) C entry points\)", "({} C entry points)")):

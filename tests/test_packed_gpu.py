@@ -334,3 +334,53 @@ def test_packed_train_loop_takes_the_steps_of_the_padded_loop(monkeypatch):
             # one accumulates rounding noise that Adam turns into O(lr) steps — compare the q and v thirds
             a, b = torch.cat([a[:d], a[2 * d:]]), torch.cat([b[:d], b[2 * d:]])
         torch.testing.assert_close(a, b, rtol=5e-3, atol=5e-4, msg=lambda s, k=k: f"{k}: {s}")
+
+
+@pytest.mark.parametrize("p,pad_keys", [(0.0, True), (0.25, True), (0.25, False)])
+def test_native_block_equals_the_python_block(p, pad_keys, monkeypatch):
+    """`rt_sasrec_block_packed_fwd / _bwd` (the launch sequence issued by compiled code, csrc/rt_block.hip) against the Python autograd
+    node that issues the same kernels one by one, same dropout streams: output, input gradient, every parameter gradient — and the
+    inference form against the Python inference block, for every row and for the last rows only."""
+    from rectools_amd import nn as hnn
+    from rectools_amd import ops
+
+    torch.manual_seed(13)
+    d, H, window = 64, 2, 40
+    lens = [40, 1, 17, 33, 8, 25, 39, 2, 40, 31]
+    B, N = len(lens), sum(lens)
+    Np = (N + 127) // 128 * 128
+    cu = torch.tensor(np.r_[0, np.cumsum(lens)], dtype=torch.int64).cuda()
+    layer = hnn.SASRecTransformerLayer(d, H, p).cuda().train()
+    for prm in layer.parameters():
+        if prm.dim() == 1:
+            torch.nn.init.normal_(prm, std=0.3)
+    x0 = torch.randn(Np, d); x0[N:] = 0
+    gout = torch.randn(Np, d); gout[N:] = 0
+    res = {}
+    for name, native in (("native", "1"), ("python", "0")):
+        monkeypatch.setenv("RT_NATIVE_BLOCK", native)
+        for prm in layer.parameters():
+            prm.grad = None
+        ops.RNG.seed, ops.RNG.step, ops.RNG._stream = 4242, 9, 0
+        x = x0.cuda().requires_grad_(True)
+        out = layer.forward_packed_train(x, cu, B, window, pad_keys, rows_real=N)
+        out.backward(gout.cuda())
+        ops.join_side_streams()
+        torch.cuda.synchronize()
+        res[name] = (out.detach()[:N].clone(), x.grad[:N].clone(), {k: v.grad.clone() for k, v in layer.named_parameters()})
+    torch.testing.assert_close(res["native"][0], res["python"][0], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(res["native"][1], res["python"][1], rtol=1e-5, atol=1e-6)
+    for k in res["python"][2]:
+        torch.testing.assert_close(res["native"][2][k], res["python"][2][k], rtol=1e-4, atol=1e-6 * (float(res["python"][2][k].abs().max()) + 1e-12),
+                                   msg=lambda s, k=k: f"gradient of {k}: {s}")
+    layer.eval()
+    with torch.no_grad():
+        inf = {}
+        for name, native in (("native", "1"), ("python", "0")):
+            monkeypatch.setenv("RT_NATIVE_BLOCK", native)
+            full = layer.forward_packed(x0.cuda(), cu, B, window, pad_keys, rows_real=N)
+            last = layer.forward_packed(x0.cuda(), cu, B, window, pad_keys, last_rows=cu[1:] - 1, rows_real=N)
+            inf[name] = (full[:N].clone(), last.clone())
+        torch.testing.assert_close(inf["native"][0], inf["python"][0], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(inf["native"][1], inf["python"][1], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(inf["native"][1], inf["native"][0][(cu[1:] - 1)], rtol=2e-4, atol=2e-5)

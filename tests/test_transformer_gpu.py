@@ -195,6 +195,7 @@ def test_dropout_is_consistent_between_forward_and_backward():
     lm = build_hip_model(cfg)
     dbatch = {k: v.cuda() for k, v in batch.items()}
     lm.train()
+    ops.RNG.seed = 20240531      # the streams' key is global state: pin it (the probe crosses ReLU kinks, its error depends on the masks)
 
     def run():
         ops.RNG.step, ops.RNG._stream = 7, 0
@@ -207,12 +208,12 @@ def test_dropout_is_consistent_between_forward_and_backward():
     g = w.grad.detach().clone()
     direction = torch.randn_like(w)
     direction /= direction.norm()
-    eps = 1e-2
+    eps = 3e-3
     with torch.no_grad():
         w.add_(eps * direction); lp = float(run()); w.sub_(2 * eps * direction); lm_ = float(run()); w.add_(eps * direction)
     fd = (lp - lm_) / (2 * eps)
     an = float((g * direction).sum())
-    assert abs(fd - an) <= 5e-2 * max(abs(fd), abs(an)) + 1e-4, (fd, an)
+    assert abs(fd - an) <= 5e-2 * max(abs(fd), abs(an)) + 3e-4, (fd, an)
     # and the same streams reproduce the same loss, different steps do not
     a, b = float(run()), float(run())
     assert a == b
