@@ -363,6 +363,9 @@ size_t rt_sasrec_block_infer_scratch_floats(int32_t rows, int32_t B, int32_t d, 
 int rt_sasrec_block_packed_infer(const rt_sasrec_block* blk, const float* x, const int64_t* last_rows, float* scratch, float* out,
                                  rt_stream_t stream);
 int rt_side_join(rt_stream_t stream);
+/* the side stream for the caller's own optimiser-only work: it waits for `stream`'s current position; *side_out = its handle, or
+ * NULL when disabled (launch on `stream` then).  Joined by rt_side_join. */
+int rt_side_fork(rt_stream_t stream, void** side_out);
 int rt_timing_enable(int32_t mode);
 int rt_timing_collect(int32_t* ids, float* ms, int64_t* tags, int32_t max_records, int32_t* n_out);
 

@@ -17,7 +17,17 @@ import sys
 import types
 import typing as tp
 
-REFERENCE_ROOT = os.environ.get("RECTOOLS_REFERENCE_ROOT", "/root/reference")
+def _find_reference_root() -> str:
+    """`/root/reference` in the build container; on the GPU box the staged, git-ignored copy `oracle/_ref` (oracle/make_ref.py)."""
+    env = os.environ.get("RECTOOLS_REFERENCE_ROOT")
+    if env:
+        return env
+    if os.path.isdir("/root/reference/rectools"):
+        return "/root/reference"
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref")
+
+
+REFERENCE_ROOT = _find_reference_root()
 
 
 def reference_available() -> bool:

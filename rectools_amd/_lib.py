@@ -92,6 +92,7 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_sasrec_block_infer_scratch_floats": (c_sz, [c_i32, c_i32, c_i32, c_i32, c_i32]),
     "rt_sasrec_block_packed_infer": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rt_side_join": (c_i32, [c_vp]),
+    "rt_side_fork": (c_i32, [c_vp, c_vp]),
     "rt_timing_enable": (c_i32, [c_i32]),
     "rt_timing_collect": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_vp]),
     "rt_dp_unique_id": (c_i32, [c_vp]),

@@ -70,12 +70,12 @@ struct Timed {   // RAII bracket around one internal launch (no-op unless rt_tim
   Timed(int id, long long m, long long n, long long k, hipStream_t stream) : s(stream), on(g_timing) {
     if (!on) return;
     r.id = id; r.m = m; r.n = n; r.k = k;
-    hipEventCreate(&r.e0); hipEventCreate(&r.e1);
-    hipEventRecord(r.e0, s);
+    (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
+    (void)hipEventRecord(r.e0, s);
   }
   ~Timed() {
     if (!on) return;
-    hipEventRecord(r.e1, s);
+    (void)hipEventRecord(r.e1, s);
     g_recs.push_back(r);
   }
 };
@@ -96,8 +96,8 @@ Side* side_of_current_device() {
   Side& s = g_side[dev];
   if (s.stream == nullptr) {
     if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    hipEventCreateWithFlags(&s.fork, hipEventDisableTiming);
-    hipEventCreateWithFlags(&s.join, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&s.fork, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&s.join, hipEventDisableTiming);
   }
   return &s;
 }
@@ -129,9 +129,9 @@ int rt_timing_collect(int32_t* ids, float* ms, int64_t* tags, int32_t max_record
   int n = 0;
   for (auto& r : g_recs) {
     float t = 0.f;
-    hipEventElapsedTime(&t, r.e0, r.e1);
+    (void)hipEventElapsedTime(&t, r.e0, r.e1);
     if (n < max_records && ids != nullptr) { ids[n] = r.id; ms[n] = t; tags[3 * n] = r.m; tags[3 * n + 1] = r.n; tags[3 * n + 2] = r.k; ++n; }
-    hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+    (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
   }
   g_recs.clear();
   if (n_out != nullptr) *n_out = n;
@@ -145,6 +145,21 @@ int rt_side_join(hipStream_t stream) {
   RT_CHECK_HIP(hipEventRecord(s->join, s->stream));
   RT_CHECK_HIP(hipStreamWaitEvent(stream, s->join, 0));
   s->dirty = false;
+  return RT_OK;
+}
+
+// The side stream as a service to the caller's own launches (the loss's table-gradient half, the embedding backward: results only the
+// optimiser reads): rt_side_fork makes the side stream wait for everything issued so far on `stream` and returns its handle through
+// *side_out (NULL when the side stream is disabled: launch on `stream` then); work issued on it is joined by rt_side_join.
+int rt_side_fork(hipStream_t stream, void** side_out) {
+  if (side_out == nullptr) return RT_ERR_INVALID_ARG;
+  *side_out = nullptr;
+  Side* s = side_enabled() ? side_of_current_device() : nullptr;
+  if (s == nullptr) return RT_OK;
+  RT_CHECK_HIP(hipEventRecord(s->fork, stream));
+  RT_CHECK_HIP(hipStreamWaitEvent(s->stream, s->fork, 0));
+  s->dirty = true;
+  *side_out = s->stream;
   return RT_OK;
 }
 

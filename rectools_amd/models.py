@@ -689,6 +689,18 @@ class TransformerModelBase:
         dp, lm = self.data_preparator, self.lightning_model
         assert lm is not None
         device = next(lm.parameters()).device
+        import time as _time
+
+        plog = getattr(self, "phase_log", None)     # bench.py: {} -> seconds per phase of THIS call (device-synchronised ticks)
+        t_last = [_time.perf_counter()]
+
+        def tick(name: str) -> None:
+            if plog is not None:
+                torch.cuda.synchronize(device)
+                now = _time.perf_counter()
+                plog[name] = plog.get(name, 0.0) + now - t_last[0]
+                t_last[0] = now
+
         req = dataset.user_id_map.convert_to_internal(users, strict=False)
         if len(np.unique(req)) != len(req):
             return None
@@ -711,6 +723,7 @@ class TransformerModelBase:
         valid_rows = torch.from_numpy(rows_h).to(device, non_blocking=True)
         dstore = DeviceSequenceStore.from_device(offsets, item_s, w_s, None)
         item_embs = self._item_embeddings()
+        tick("glue")
         outs = []
         with torch.no_grad():
             bs = self._encode_batch_size()
@@ -734,6 +747,7 @@ class TransformerModelBase:
                 batch = dp.collate_recommend_device(dstore, valid_rows[b0:b0 + nb])
                 outs.append(lm.torch_model.encode_last(batch, item_embs))   # last-position encodings, [b, d]
         user_embs = torch.cat(outs)
+        tick("encoder")
         ranker = HipRanker(lm.torch_model.similarity_module.distance, device, user_embs, item_embs)
         filt = None
         if filter_viewed:  # CSR of the distinct (user, item) pairs, rows in request order, indices ascending
@@ -743,8 +757,11 @@ class TransformerModelBase:
                 indices = torch.zeros((1,), dtype=torch.int32, device=device)
             filt = DeviceCSR(indptr, indices, (n_valid, V))
         ids, scores, cnt, _ = ranker.rank_device(np.arange(n_valid), k=k, filter_pairs_csr=filt, sorted_object_whitelist=whitelist)
+        tick("ranker")
         ext_users = np.asarray(users)[valid_h]
-        return self._assemble(ext_users, ids, scores, cnt, add_rank_col, Columns.User)
+        frame = self._assemble(ext_users, ids, scores, cnt, add_rank_col, Columns.User)
+        tick("frame")
+        return frame
 
     def recommend_to_items(self, target_items: tp.Any, dataset: tp.Any, k: int, filter_itself: bool = True,
                            items_to_recommend: tp.Optional[tp.Any] = None, add_rank_col: bool = True,

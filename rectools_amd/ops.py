@@ -66,13 +66,16 @@ _NATIVE_TIMING_NAMES = {0: "rt_gemm", 1: "rt_gemm_grouped", 2: "rt_layernorm_fwd
 _FN: tp.Dict[str, tp.Any] = {}   # bound C entry points (one getattr per name instead of one per launch)
 
 
-def _c(name: str, *args: tp.Any, tag: tp.Any = None) -> None:
-    """Call `rt_<name>(*args, stream)`; tensors are passed as raw device pointers."""
+def _c(name: str, *args: tp.Any, tag: tp.Any = None, stream: tp.Optional[int] = None) -> None:
+    """Call `rt_<name>(*args, stream)`; tensors are passed as raw device pointers.  stream: a raw HIP stream handle (the library's
+    side stream, `_native_side_fork`); default torch's current stream."""
     fn = _FN.get(name)
     if fn is None:
         fn = _FN[name] = getattr(_lib.load(), name)
     conv = [a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args]
-    if _TIMING is None:
+    if stream is not None:
+        status = fn(*conv, stream)
+    elif _TIMING is None:
         status = fn(*conv, _lib.current_stream())
     else:  # events on the stream the kernel is launched on (torch's current stream)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -81,6 +84,23 @@ def _c(name: str, *args: tp.Any, tag: tp.Any = None) -> None:
         e1.record()
         _TIMING.setdefault(name, []).append((e0, e1, tag))
     _lib.check(status, name)
+
+
+def _native_side_fork() -> tp.Optional[int]:
+    """Fork the library's side stream off torch's current stream (`rt_side_fork`): -> its raw handle, or None when the side stream
+    is off (RT_SIDE_STREAM=0, single-stream instrumentation).  Launch optimiser-only work on it with `_c(..., stream=handle)`, keep
+    every tensor it touches in `_NATIVE_KEEPALIVE`; `join_side_streams()` (end of backward / FlatAdam.step) joins it."""
+    import ctypes
+
+    if not _side_enabled():
+        return None
+    h = ctypes.c_void_p()
+    _lib.check(_lib.load().rt_side_fork(_lib.current_stream(), ctypes.byref(h)), "rt_side_fork")
+    if not h.value:
+        return None
+    if not _NATIVE_KEEPALIVE:
+        torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+    return h.value
 
 
 def _chk(t: torch.Tensor, what: str) -> torch.Tensor:
@@ -187,6 +207,7 @@ def join_side_streams() -> None:
     if _NATIVE_KEEPALIVE:
         _c("rt_side_join")
         _NATIVE_KEEPALIVE.clear()
+    _TABLE_GRAD_ON_SIDE.clear()
 
 
 # --------------------------------------------------------------------------------------------------
@@ -339,6 +360,8 @@ def matmul_nn(x: torch.Tensor, p: torch.Tensor) -> torch.Tensor:
 # every backward pass — then adds its rows INTO that tensor (rt_embed_bwd accumulate) and returns no gradient of its own,
 # instead of producing a second [V,d] tensor that autograd would add with a full-size kernel.  Keyed by the table's storage.
 _TABLE_GRAD_SINK: tp.Dict[int, torch.Tensor] = {}
+_TABLE_GRAD_ON_SIDE: tp.Set[int] = set()      # sinks whose loss half is in flight on the side stream: the embedding adds there too
+_LOSS_TABLE_ON_SIDE = os.environ.get("RT_LOSS_SIDE", "0") == "1"   # opt-in: measured equal (69.3 vs 70.2 k seqs/s at C2): the gathers contend
 
 
 def _offer_table_grad(table: torch.Tensor, d_table: torch.Tensor) -> None:
@@ -375,8 +398,16 @@ class _Embed(torch.autograd.Function):
             gpos = (torch.empty if pshape[0] == L else torch.zeros)(pshape, dtype=torch.float32, device=gout.device)
         ws_bytes = _lib.load().rt_embed_bwd_workspace_bytes(M, V, tshape[1])
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=gout.device)
+        side = None
+        if sink is not None and sink.data_ptr() in _TABLE_GRAD_ON_SIDE:   # the sink's loss half runs on the side stream: follow it there
+            _TABLE_GRAD_ON_SIDE.discard(sink.data_ptr())
+            side = _native_side_fork()
+            if side is None:
+                join_side_streams()
         _c("rt_embed_bwd", ids, gout, float(scale), M, L, tshape[1], V, float(p), seed, sid, gtable, 1 if sink is not None else 0,
-           gpos, ws, ws_bytes)
+           gpos, ws, ws_bytes, stream=side)
+        if side is not None:
+            _NATIVE_KEEPALIVE.append((ids, gout, ws))         # not gtable / gpos: autograd must adopt them, not clone them
         return (None if sink is not None else gtable), gpos, None, None, None, None
 
 
@@ -417,8 +448,18 @@ class _EmbedPacked(torch.autograd.Function):
             gpos = (torch.empty if pshape[0] == L else torch.zeros)(pshape, dtype=torch.float32, device=gout.device)
         ws_bytes = _lib.load().rt_embed_bwd_workspace_bytes(M, V, tshape[1])
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=gout.device)
+        side = None
+        if sink is not None and sink.data_ptr() in _TABLE_GRAD_ON_SIDE:
+            # the sink's loss half is still in flight on the side stream: add the lookup's rows there, behind it (this is the last
+            # node of the backward pass and only the optimiser reads the result)
+            _TABLE_GRAD_ON_SIDE.discard(sink.data_ptr())
+            side = _native_side_fork()
+            if side is None:
+                join_side_streams()
         _c("rt_embed_packed_bwd", ids, cu, B, gout, float(scale), M, L, tshape[1], V, float(p), seed, sid, gtable,
-           1 if sink is not None else 0, gpos, ws, ws_bytes)
+           1 if sink is not None else 0, gpos, ws, ws_bytes, stream=side)
+        if side is not None:
+            _NATIVE_KEEPALIVE.append((ids, cu, gout, ws))     # not gtable / gpos: autograd must adopt them, not clone them
         return (None if sink is not None else gtable), gpos, None, None, None, None, None, None, None
 
 
@@ -1673,7 +1714,19 @@ class _SampledLoss(torch.autograd.Function):
         # One call on the main stream.  The table half (counting sort + gathered row reductions, memory-bound) was tried on the
         # side stream under the MFMA-bound layer backward (rt_sampled_loss_bwd accepts either output as NULL for that):
         # measured 3.12 vs 3.06 ms/step at C2 — the co-running gather slows the GEMMs by more than it hides.
-        _c("rt_sampled_loss_bwd", *args, d_sess, d, d_table, ws, ws.numel())
+        side = _native_side_fork() if (_LOSS_TABLE_ON_SIDE and ctx.needs_input_grad[1] and _steals_grad(table)) else None
+        if side is None:
+            _c("rt_sampled_loss_bwd", *args, d_sess, d, d_table, ws, ws.numel())
+        else:
+            # the session half is the critical path (it feeds the whole layer backward); the table half — counting sort + gathered row
+            # reductions, read only by the optimiser — runs beside it on the library's side stream.  (Round 2 measured this slower when
+            # the main stream was GEMM-bound end to end; with packed rows and the bf16 attention the main stream is the long pole.)
+            _c("rt_sampled_loss_bwd", *args, d_sess, d, None, ws, ws.numel())
+            _c("rt_sampled_loss_bwd", *args, None, d, d_table, ws, ws.numel(), stream=side)
+            # NOT d_table: an extra reference would make autograd's AccumulateGrad clone it (on the main stream, before the side stream
+            # has written it) instead of adopting it; as `table.grad` it outlives the join anyway
+            _NATIVE_KEEPALIVE.append((sess, table, y, neg, logits, out, du, ws))
+            _TABLE_GRAD_ON_SIDE.add(d_table.data_ptr())
         if ctx.needs_input_grad[1]:   # only a gradient autograd will hand to the table can serve as the embedding node's sink
             _offer_table_grad(table, d_table)
         return d_sess, d_table, None, None, None, None, None, None, None

@@ -7,10 +7,15 @@ try:
 except Exception as e:  # noqa: BLE001
     print("no bench line:", e); sys.exit(0)
 print("value", j.get("value"), j.get("unit"), "ms/step", j.get("ms_per_step"), "loss", j.get("final_loss"), "env", j.get("env"))
-for k in ("recommend_e2e", "recommend", "topk5m", "train_exact_gemm", "topk5m_u4096"):
+for k in ("train_exact_gemm", "recommend", "topk5m", "topk5m_u4096"):
     if isinstance(j.get(k), dict):
         r = j[k].get("roofline") or {}
-        print(" ", k, j[k].get("value"), j[k].get("unit"), "frac", r.get("frac"), {a: b for a, b in j[k].items() if a.startswith("phase")})
+        cb = j[k].get("cpu_baseline") or {}
+        print(" ", k, j[k].get("value"), j[k].get("unit"), "frac", r.get("frac"), r.get("achieved"), r.get("unit"),
+              {a: b for a, b in j[k].items() if a.startswith("phase")}, "kernel", (j[k].get("ranker_kernel") or {}).get("value"),
+              "cpu", cb.get("kind"), cb.get("value"))
+cb = j.get("cpu_baseline") or {}
+print("  cpu_baseline", cb.get("kind"), cb.get("value"), cb.get("unit"), "cores", cb.get("cores"))
 r = j.get("roofline") or {}
 print("  roofline", r.get("kernel", "")[:50], r.get("achieved"), r.get("unit"), "frac", r.get("frac"), "host_issue_ms", r.get("host_issue_ms_per_step"))
 for k, v in list((j.get("kernel_breakdown") or {}).items())[:24]:
