@@ -443,6 +443,11 @@ int rt_dp_unique_id(void* out128);
 int rt_dp_init(const void* uid128, int32_t rank, int32_t world, void** comm_out);
 int rt_dp_allreduce(void* comm, float* buf, int64_t n, rt_stream_t stream);
 int rt_dp_broadcast(void* comm, float* buf, int64_t n, int32_t root, rt_stream_t stream);
+/* Sharded-optimiser exchange for table-dominated models (gradient of 1-10 GB per step): reduce-scatter the flat gradient (recv[0:n] <-
+ * sum over ranks of send[rank*n : (rank+1)*n]), run rt_adam_step on the rank's slice of (p, m, v), all-gather the parameter slices
+ * (recv[r*n : (r+1)*n] <- rank r's send[0:n]; send may alias the rank's own slice of recv).  n = padded total / world. */
+int rt_dp_reduce_scatter(void* comm, const float* send, float* recv, int64_t n, rt_stream_t stream);
+int rt_dp_allgather(void* comm, const float* send, float* recv, int64_t n, rt_stream_t stream);
 int rt_dp_finalize(void* comm);
 const char* rt_dp_last_error(void);
 

@@ -99,6 +99,8 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_dp_init": (c_i32, [c_vp, c_i32, c_i32, c_vp]),
     "rt_dp_allreduce": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     "rt_dp_broadcast": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp]),
+    "rt_dp_reduce_scatter": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "rt_dp_allgather": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "rt_dp_finalize": (c_i32, [c_vp]),
     "rt_dp_last_error": (ctypes.c_char_p, []),
 }

@@ -79,11 +79,17 @@ def adam_state_dict(opt: tp.Any) -> tp.Dict[str, tp.Any]:
     """`torch.optim.Adam.state_dict()` of a `FlatAdam`: per-parameter exp_avg / exp_avg_sq / step, in parameter order."""
     state: tp.Dict[int, tp.Dict[str, torch.Tensor]] = {}
     if opt.step_count > 0:
+        m, v = opt.m, opt.v
+        if getattr(opt, "sharded", False):   # sharded exchange: a rank maintains only its slice of the moments — gather (collective)
+            import torch.distributed as dist
+
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                m, v = opt.full_moments(dist.get_world_size(), dist.get_rank())
         for i, (p, ofs) in enumerate(zip(opt.params, opt._offsets)):   # pylint: disable=protected-access
             n = p.numel()
             state[i] = {"step": torch.tensor(float(opt.step_count)),
-                        "exp_avg": opt.m[ofs:ofs + n].detach().reshape(p.shape).cpu().clone(),
-                        "exp_avg_sq": opt.v[ofs:ofs + n].detach().reshape(p.shape).cpu().clone()}
+                        "exp_avg": m[ofs:ofs + n].detach().reshape(p.shape).cpu().clone(),
+                        "exp_avg_sq": v[ofs:ofs + n].detach().reshape(p.shape).cpu().clone()}
     group = {"lr": float(opt.lr), "betas": tuple(float(b) for b in opt.betas), "eps": float(opt.eps), "weight_decay": 0,
              "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
              "fused": None, "params": list(range(len(opt.params)))}

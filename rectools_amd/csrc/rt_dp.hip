@@ -23,6 +23,8 @@ struct RcclApi {
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclBroadcast) Broadcast = nullptr;
+  decltype(&ncclReduceScatter) ReduceScatter = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   bool tried = false;
@@ -47,6 +49,8 @@ bool load_rccl() {
   g_rccl.CommInitRank = reinterpret_cast<decltype(&ncclCommInitRank)>(dlsym(h, "ncclCommInitRank"));
   g_rccl.AllReduce = reinterpret_cast<decltype(&ncclAllReduce)>(dlsym(h, "ncclAllReduce"));
   g_rccl.Broadcast = reinterpret_cast<decltype(&ncclBroadcast)>(dlsym(h, "ncclBroadcast"));
+  g_rccl.ReduceScatter = reinterpret_cast<decltype(&ncclReduceScatter)>(dlsym(h, "ncclReduceScatter"));
+  g_rccl.AllGather = reinterpret_cast<decltype(&ncclAllGather)>(dlsym(h, "ncclAllGather"));
   g_rccl.CommDestroy = reinterpret_cast<decltype(&ncclCommDestroy)>(dlsym(h, "ncclCommDestroy"));
   g_rccl.GetErrorString = reinterpret_cast<decltype(&ncclGetErrorString)>(dlsym(h, "ncclGetErrorString"));
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.Broadcast || !g_rccl.CommDestroy) {
@@ -106,6 +110,25 @@ int rt_dp_broadcast(void* comm, float* buf, int64_t n, int32_t root, hipStream_t
   if (n == 0) return RT_OK;
   if (!load_rccl()) return RT_ERR_UNSUPPORTED;
   return nccl_status(g_rccl.Broadcast(buf, buf, (size_t)n, ncclFloat32, root, reinterpret_cast<ncclComm_t>(comm), stream), "ncclBroadcast");
+}
+
+// The exchange for table-dominated models (C4 1 GB, C5-train 10 GB of gradient per step): every rank keeps only ITS
+// 1/world slice of the reduced gradient, runs Adam on that slice of (p, m, v) — the moments never leave their shard — and the updated
+// parameter slices are gathered back.  Same bytes on the links as the all-reduce, 1/world of the optimiser pass per GPU.
+// rt_dp_reduce_scatter: recv[0:n] <- sum over ranks of send[rank * n : (rank + 1) * n]  (send holds world * n floats).
+int rt_dp_reduce_scatter(void* comm, const float* send, float* recv, int64_t n, hipStream_t stream) {
+  if (comm == nullptr || n < 0 || (n > 0 && (send == nullptr || recv == nullptr))) return RT_ERR_INVALID_ARG;
+  if (n == 0) return RT_OK;
+  if (!load_rccl() || !g_rccl.ReduceScatter) return RT_ERR_UNSUPPORTED;
+  return nccl_status(g_rccl.ReduceScatter(send, recv, (size_t)n, ncclFloat32, ncclSum, reinterpret_cast<ncclComm_t>(comm), stream),
+                     "ncclReduceScatter");
+}
+// rt_dp_allgather: recv[r * n : (r + 1) * n] <- rank r's send[0:n]  (recv holds world * n floats; send may be the rank's own slice of recv).
+int rt_dp_allgather(void* comm, const float* send, float* recv, int64_t n, hipStream_t stream) {
+  if (comm == nullptr || n < 0 || (n > 0 && (send == nullptr || recv == nullptr))) return RT_ERR_INVALID_ARG;
+  if (n == 0) return RT_OK;
+  if (!load_rccl() || !g_rccl.AllGather) return RT_ERR_UNSUPPORTED;
+  return nccl_status(g_rccl.AllGather(send, recv, (size_t)n, ncclFloat32, reinterpret_cast<ncclComm_t>(comm), stream), "ncclAllGather");
 }
 
 int rt_dp_finalize(void* comm) {

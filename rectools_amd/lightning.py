@@ -180,6 +180,12 @@ class RcclExchange:
     def broadcast(self, buf: torch.Tensor, src: int = 0) -> None:
         self._call("rt_dp_broadcast", self.comm, buf, buf.numel(), src)
 
+    def reduce_scatter(self, send: torch.Tensor, recv: torch.Tensor) -> None:
+        self._call("rt_dp_reduce_scatter", self.comm, send, recv, recv.numel())
+
+    def all_gather(self, send: torch.Tensor, recv: torch.Tensor) -> None:
+        self._call("rt_dp_allgather", self.comm, send, recv, send.numel())
+
     def close(self) -> None:
         if self.comm is not None:
             torch.cuda.synchronize()
@@ -217,7 +223,8 @@ class FlatAdam:
             return (p.numel() + 3) // 4 * 4
 
         sizes = [seg_floats(p) for p in params]
-        total = sum(sizes)
+        self.n_used = sum(sizes)
+        total = (self.n_used + 1023) // 1024 * 1024     # evenly divisible by any power-of-two world size (sharded exchange); tail = zeros
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.v = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -238,6 +245,12 @@ class FlatAdam:
         self.lr, self.betas, self.eps = lr, betas, eps
         self.step_count = 0
         self.exchange: tp.Optional[RcclExchange] = None   # set by use_rccl_exchange(): rt_dp_* instead of torch.distributed
+        # RT_DP_EXCHANGE = allreduce | sharded | auto (sharded from 256 MB of gradient per step: the table-dominated configurations)
+        import os
+
+        mode = os.environ.get("RT_DP_EXCHANGE", "auto")
+        self.sharded = mode == "sharded" or (mode == "auto" and total * 4 >= (256 << 20))
+        self._g_shard: tp.Optional[torch.Tensor] = None
 
     def use_rccl_exchange(self, rank: int, world: int) -> None:
         """Route the gradient all-reduce and the parameter broadcast through `rt_dp_*` (collective: every rank calls it)."""
@@ -297,17 +310,80 @@ class FlatAdam:
         dist.all_reduce(self.gather_gradients(), op=dist.ReduceOp.SUM)
         return 1.0 / max(world_size, 1)
 
+    def _adam_flat(self, p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, hyper: tp.Tuple) -> None:
+        """`rt_adam_step` over (a slice of) the flat buffers (the seam the gloo tests replace with a torch restatement)."""
+        ops._c("rt_adam_step", p, g, m, v, p.numel(), *hyper)
+
+    def shard_bounds(self, world_size: int, rank: int) -> tp.Tuple[int, int]:
+        n = self.flat_p.numel() // world_size
+        return rank * n, (rank + 1) * n
+
+    def step_sharded(self, world_size: int, rank: int) -> None:
+        """The exchange that scales when the gradient is dominated by a large table: reduce-scatter the flat gradient —
+        every rank receives the SUM of its 1/world slice only —, Adam on that slice of (p, m, v) (the moments of the other slices are
+        never touched on this rank), all-gather of the updated parameter slices.  Same link traffic as the all-reduce
+        (2 (N-1)/N of the buffer), 1/N of the 5-stream optimiser pass per GPU.  Replicas stay bit-identical: every rank receives the
+        same parameter bytes.  gloo (CPU tests, ranks sharing a GPU) has no reduce-scatter: all-reduce + slice there."""
+        import torch.distributed as dist
+
+        if self.flat_p.numel() % world_size != 0:
+            raise ValueError(f"sharded exchange: world size {world_size} does not divide the flat buffer ({self.flat_p.numel()} floats)")
+        lo, hi = self.shard_bounds(world_size, rank)
+        fg = self.gather_gradients()
+        if self._g_shard is None or self._g_shard.numel() != hi - lo:
+            self._g_shard = torch.empty(hi - lo, dtype=torch.float32, device=fg.device)
+        if self.exchange is not None:
+            self.exchange.reduce_scatter(fg, self._g_shard)
+        elif dist.get_backend() == "nccl":
+            dist.reduce_scatter_tensor(self._g_shard, fg, op=dist.ReduceOp.SUM)
+        else:
+            dist.all_reduce(fg, op=dist.ReduceOp.SUM)
+            self._g_shard.copy_(fg[lo:hi])
+        self.step_count += 1
+        hyper = (self.step_count, float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), 1.0 / world_size)
+        self._adam_flat(self.flat_p[lo:hi], self._g_shard, self.m[lo:hi], self.v[lo:hi], hyper)
+        if self.exchange is not None:
+            self.exchange.all_gather(self.flat_p[lo:hi], self.flat_p)
+        elif dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(self.flat_p, self.flat_p[lo:hi].clone())
+        else:
+            parts = [torch.empty(hi - lo, dtype=torch.float32, device=fg.device) for _ in range(world_size)]
+            dist.all_gather(parts, self.flat_p[lo:hi].clone())
+            for r, part in enumerate(parts):
+                self.flat_p[r * (hi - lo):(r + 1) * (hi - lo)].copy_(part)
+
+    def full_moments(self, world_size: int = 1, rank: int = 0) -> tp.Tuple[torch.Tensor, torch.Tensor]:
+        """(m, v) over the whole flat buffer.  Under the sharded exchange a rank maintains only its own slice: gather the others
+        (checkpoints, `state_dict`)."""
+        if not self.sharded or world_size <= 1:
+            return self.m, self.v
+        import torch.distributed as dist
+
+        lo, hi = self.shard_bounds(world_size, rank)
+        out = []
+        for buf in (self.m, self.v):
+            parts = [torch.empty(hi - lo, dtype=torch.float32, device=buf.device) for _ in range(world_size)]
+            dist.all_gather(parts, buf[lo:hi].clone())
+            out.append(torch.cat(parts))
+        return out[0], out[1]
+
     def step(self, world_size: int = 1, flat: bool = False) -> None:
-        """One Adam step.  world_size > 1 (or flat=True): pack -> all-reduce -> Adam over the flat buffers; otherwise the
-        segmented kernel reads every gradient through its own pointer."""
+        """One Adam step.  world_size > 1 (or flat=True): pack -> all-reduce -> Adam over the flat buffers (or, `self.sharded`, the
+        reduce-scatter / sharded Adam / all-gather exchange); otherwise the segmented kernel reads every gradient through its own
+        pointer."""
         if self.flat_p.is_cuda:
             ops.join_side_streams()   # weight gradients may still be in flight on the wgrad stream
+        if world_size > 1 and self.sharded:
+            import torch.distributed as dist
+
+            self.step_sharded(world_size, dist.get_rank())
+            return
         flat = flat or world_size > 1
         scale = self.reduce_gradients(world_size, force=flat)
         self.step_count += 1
         hyper = (self.step_count, float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(scale))
         if flat:
-            ops._c("rt_adam_step", self.flat_p, self.flat_g, self.m, self.v, self.flat_p.numel(), *hyper)
+            self._adam_flat(self.flat_p, self.flat_g, self.m, self.v, hyper)
             return
         import ctypes
 

@@ -47,3 +47,53 @@ def test_flat_gradient_allreduce_and_sharding(tmp_path):
     a, b = np.load(tmp_path / "shard0.npy"), np.load(tmp_path / "shard1.npy")
     assert len(a) == len(b) == 6                                  # 11 samples padded to 12
     assert set(a.tolist()) | set(b.tolist()) == set(range(11))
+
+
+def _torch_adam(p, g, m, v, hyper):
+    """torch restatement of rt_adam_step (lightning.py:214-218: Adam, eps outside the bias-corrected sqrt as torch.optim.Adam)."""
+    step, lr, b1, b2, eps, scale = hyper
+    g = g * scale
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    denom = (v / (1 - b2 ** step)).sqrt_().add_(eps)
+    p.addcdiv_(m / (1 - b1 ** step), denom, value=-lr)
+
+
+def _worker_sharded(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rectools_amd.lightning import FlatAdam
+
+    results = {}
+    for mode in ("allreduce", "sharded"):
+        os.environ["RT_DP_EXCHANGE"] = mode
+        torch.manual_seed(0)
+        model = torch.nn.Sequential(torch.nn.Embedding(1500, 8), torch.nn.Linear(8, 5), torch.nn.Linear(5, 3))   # table >= 1024 rows: padded segment
+        opt = FlatAdam(model, lr=1e-2)
+        opt._adam_flat = lambda p, g, m, v, hyper: _torch_adam(p, g, m, v, hyper)      # the HIP kernel's seam (no GPU in this test)
+        assert opt.sharded == (mode == "sharded") and opt.flat_p.numel() % 1024 == 0
+        for step in range(3):
+            opt.zero_grad()
+            ids = torch.arange(40) * (rank + 2) % 1500
+            model(ids).pow(2).sum().mul(rank + 1.0).backward()                       # rank-dependent gradients
+            opt.step(world, flat=True)
+        lo, hi = opt.shard_bounds(world, rank)
+        m_full, v_full = opt.full_moments(world, rank)
+        results[mode] = (opt.flat_p.clone(), m_full.clone(), v_full.clone(), opt.m.clone())
+        if mode == "sharded":      # the moments outside the rank's own slice are never touched on this rank
+            other = torch.ones_like(opt.m, dtype=torch.bool); other[lo:hi] = False
+            assert float(opt.m[other].abs().max()) == 0.0 and float(opt.m[lo:hi].abs().max()) > 0.0
+    for a, b in zip(results["allreduce"][:3], results["sharded"][:3]):
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7)                         # same parameters, same (gathered) moments
+    mine = [torch.zeros_like(results["sharded"][0]) for _ in range(world)]
+    dist.all_gather(mine, results["sharded"][0])
+    assert all(torch.equal(mine[0], t) for t in mine)                                  # replicas stay bit-identical
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_exchange_equals_the_allreduce_exchange(tmp_path):
+    """reduce-scatter -> Adam on the rank's 1/N slice of (p, m, v) -> all-gather of the parameters (FlatAdam.step_sharded) against the
+    all-reduce exchange, world 2 over gloo, 3 steps: same parameters on every rank, same moments once gathered."""
+    world = 2
+    mp.spawn(_worker_sharded, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)

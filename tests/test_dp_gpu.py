@@ -20,7 +20,8 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, exchange="allreduce"):
+    os.environ["RT_DP_EXCHANGE"] = exchange
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     torch.cuda.set_device(0)
@@ -66,9 +67,12 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_step_matches_mean_gradient_adam(tmp_path):
+@pytest.mark.parametrize("exchange", ["allreduce", "sharded"])
+def test_two_rank_step_matches_mean_gradient_adam(tmp_path, exchange):
+    """`sharded`: reduce-scatter -> rt_adam_step on the rank's 1/N slice of (p, m, v) -> all-gather of the parameters
+    (FlatAdam.step_sharded; over gloo with both ranks on this GPU): the same first Adam step, replicas bit-identical."""
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), exchange), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}.npy").exists() for r in range(world))
 
 
@@ -194,3 +198,22 @@ def test_rt_dp_entry_points_single_rank():
     for a, b in zip(pa, pb):
         torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7)
     ob.exchange.close()
+    # the sharded exchange's two collectives on the 1-rank communicator (identity), and a sharded step through them
+    ex = hl.RcclExchange(0, 1)
+    src = torch.randn(4096, device="cuda")
+    dst = torch.zeros(4096, device="cuda")
+    ex.reduce_scatter(src, dst)
+    out = torch.zeros(4096, device="cuda")
+    ex.all_gather(dst, out)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out, src, rtol=0, atol=0)
+    ex.close()
+    pc = make()
+    oc = hl.FlatAdam(pc, lr=1e-2)
+    oc.use_rccl_exchange(0, 1)
+    for p, g in zip(pc, grads):
+        p.grad = g.clone()
+    oc.step_sharded(1, 0)                   # rt_dp_reduce_scatter -> rt_adam_step on the (whole) slice -> rt_dp_allgather
+    for a, c in zip(pa, pc):
+        torch.testing.assert_close(a, c, rtol=1e-6, atol=1e-7)
+    oc.exchange.close()

@@ -85,8 +85,12 @@ def test_engine_follows_the_reference_trajectory_and_recommends_the_same_items()
     assert bool((counts.cpu().numpy() == 10).all())
     ref_ids, ref_scores = z["rec_items"], z["rec_scores"]
     shared = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(ids, ref_ids))
-    assert shared >= 0.99 * ref_ids.size, shared / ref_ids.size
     same_rank = float((ids == ref_ids).mean())
+    loss_err = float(np.max(np.abs(np.asarray(losses) - z["loss"]) / np.abs(z["loss"])))
+    # the actual numbers, so that a slide from 99.9 % to 99.0 % is visible in the test output (pytest -s; profiles/r3_parity_numbers.txt)
+    print(f"[trajectory C1] 48 steps: max relative loss error {loss_err:.2e}; trained model vs the reference's frames: "
+          f"{shared / ref_ids.size:.4%} of the (user, item) top-10 pairs shared, {same_rank:.4%} at the same rank")
+    assert shared >= 0.99 * ref_ids.size, shared / ref_ids.size
     assert same_rank >= 0.97, same_rank
     m = ids == ref_ids
     np.testing.assert_allclose(scores[m], ref_scores[m], rtol=2e-3, atol=2e-3)
