@@ -125,6 +125,18 @@ int rt_gemm(const float* A, int64_t lda, int32_t a_kc, const float* B, int64_t l
             float* C, int64_t ldc, const float* bias, const float* R, int64_t ldr, float* a_rowsum,
             int32_t M, int32_t N, int32_t K, int32_t relu, int32_t split_k, void* workspace, size_t workspace_bytes,
             rt_stream_t stream);
+/* K7w  the same products with a PRE-SPLIT weight operand (csrc/rt_gemm_wp.hip): rt_split_planes writes the exact three-way bf16 split of
+ * a contiguous fp32 range (every weight of a layer stack in one launch; plane p at planes + p * plane_stride, n % 4 == 0, plane_stride % 8
+ * == 0), rt_gemm_wp computes up to 4 products C[M,N] = A[M,K] . W' (+ bias) (+ R) (relu) in one launch from the planes: w_tr = 0:
+ * W'(n,k) = W[n*ldw + k] (y = x W^T, nn.Linear forward); w_tr = 1: W'(n,k) = W[k*ldw + n] (dx = dy W).  Only the activation operand is
+ * split in registers: half the split arithmetic of rt_gemm's loop, same six bf16 products per fp32 product.  Exact tile grids only
+ * (M, N % 128 == 0, K % 32 == 0, 16-byte aligned): otherwise RT_ERR_UNSUPPORTED and the caller takes rt_gemm. */
+int rt_split_planes(const float* src, int64_t n, uint16_t* planes, int64_t plane_stride, rt_stream_t stream);
+typedef struct rt_gemm_wp_problem {
+  const float* A; int64_t lda; const uint16_t* W; int64_t plane_stride, ldw; float* C; int64_t ldc;
+  const float* bias; const float* R; int64_t ldr; int32_t M, N, K, relu;
+} rt_gemm_wp_problem;
+int rt_gemm_wp(const rt_gemm_wp_problem* problems, int32_t n, int32_t w_tr, rt_stream_t stream);
 /* Up to 4 independent products of the same operand layouts in ONE launch (tile ranges back to back: the tail of one product is
  * filled by the head of the next — the q and k/v projections of a block, sasrec.py:221-224, or two data-gradient products).
  * Problems off the exact-tile path are executed as consecutive rt_gemm calls; results are identical either way. */
@@ -352,6 +364,9 @@ typedef struct rt_sasrec_block {
   uint64_t seed_attn, seed_h, sid_h, seed_o, sid_o;
   const int64_t* cu;
   const float *ln1_w, *ln1_b, *in_w, *in_b, *out_w, *out_b, *ln2_w, *ln2_b, *w1, *b1, *w2, *b2;
+  /* optional bf16 planes of in_w / out_w / w1 / w2 (rt_split_planes; plane p at + p * wp_stride elements), NULL: rt_gemm everywhere */
+  const uint16_t *in_wp, *out_wp, *w1_wp, *w2_wp;
+  int64_t wp_stride;
 } rt_sasrec_block;
 size_t rt_sasrec_block_saved_floats(int32_t rows, int32_t d, int32_t dff, int32_t H, int32_t with_dropout);
 size_t rt_sasrec_block_bwd_scratch_bytes(int32_t rows, int32_t B, int32_t d, int32_t dff, int32_t H, int32_t wgrad_splits);

@@ -84,6 +84,8 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_embed_packed_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_f32, c_u64, c_u64, c_vp, c_vp]),
     "rt_embed_packed_bwd": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_f32, c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_u64, c_vp, c_i32, c_vp,
                                     c_vp, c_sz, c_vp]),
+    "rt_split_planes": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "rt_gemm_wp": (c_i32, [c_vp, c_i32, c_i32, c_vp]),
     "rt_sasrec_block_saved_floats": (c_sz, [c_i32, c_i32, c_i32, c_i32, c_i32]),
     "rt_sasrec_block_bwd_scratch_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32]),
     "rt_sasrec_block_grad_offsets": (None, [c_i32, c_i32, c_vp]),
@@ -121,7 +123,15 @@ class SasrecBlock(ctypes.Structure):
     _fields_ = [(n, c_i32) for n in ("rows", "rows_real", "B", "H", "d", "dff", "window", "pad_keys")] + \
                [(n, c_f32) for n in ("p_drop", "eps1", "eps2")] + \
                [(n, c_u64) for n in ("seed_attn", "seed_h", "sid_h", "seed_o", "sid_o")] + \
-               [(n, c_vp) for n in ("cu", "ln1_w", "ln1_b", "in_w", "in_b", "out_w", "out_b", "ln2_w", "ln2_b", "w1", "b1", "w2", "b2")]
+               [(n, c_vp) for n in ("cu", "ln1_w", "ln1_b", "in_w", "in_b", "out_w", "out_b", "ln2_w", "ln2_b", "w1", "b1", "w2", "b2",
+                                    "in_wp", "out_wp", "w1_wp", "w2_wp")] + [("wp_stride", c_i64)]
+
+
+class GemmWpProblem(ctypes.Structure):
+    """`rt_gemm_wp_problem` of include/rectools_hip.h."""
+
+    _fields_ = [("A", c_vp), ("lda", c_i64), ("W", c_vp), ("plane_stride", c_i64), ("ldw", c_i64), ("C", c_vp), ("ldc", c_i64),
+                ("bias", c_vp), ("R", c_vp), ("ldr", c_i64), ("M", c_i32), ("N", c_i32), ("K", c_i32), ("relu", c_i32)]
 
 
 class HipLibraryError(RuntimeError):

@@ -55,6 +55,14 @@ int rt_mha_varlen_last_fwd(const float* q, int64_t ldq, const float* k, int64_t 
                            int32_t window, float* o, int64_t ldo, hipStream_t stream);
 int rt_gather_rows(const float* src, int64_t ld_src, const int64_t* idx, int32_t R, int32_t d, float* dst, int64_t ld_dst,
                    hipStream_t stream);
+struct rt_gemm_wp_problem {
+  const float* A; int64_t lda;
+  const uint16_t* W; int64_t plane_stride, ldw;
+  float* C; int64_t ldc;
+  const float* bias; const float* R; int64_t ldr;
+  int32_t M, N, K, relu;
+};
+int rt_gemm_wp(const rt_gemm_wp_problem* problems, int32_t n, int32_t w_tr, hipStream_t stream);
 }
 
 namespace {
@@ -172,6 +180,10 @@ struct rt_sasrec_block {
   uint64_t seed_attn, seed_h, sid_h, seed_o, sid_o;     // dropout streams (ops.RNG)
   const int64_t* cu;
   const float *ln1_w, *ln1_b, *in_w, *in_b, *out_w, *out_b, *ln2_w, *ln2_b, *w1, *b1, *w2, *b2;
+  // optional: the bf16 planes of the four weight matrices (rt_split_planes over the stack's parameter range; same element offsets as
+  // the fp32 weights, plane p at + p * wp_stride).  NULL: every product takes rt_gemm (both operands split in registers).
+  const uint16_t *in_wp, *out_wp, *w1_wp, *w2_wp;
+  int64_t wp_stride;
 };
 
 // floats of the activation record the forward keeps for the backward
@@ -195,6 +207,14 @@ size_t rt_sasrec_block_bwd_scratch_bytes(int32_t rows, int32_t B, int32_t d, int
 }
 
 namespace {
+// y = A W'^T-or-W' (+ bias) (+ R) (relu) through the pre-split weight planes when the block carries them and the shape is an exact tile
+// grid; RT_ERR_UNSUPPORTED -> the caller's rt_gemm call.  w_tr = 0: forward (W [N,K]); 1: data gradient (W [K,N], ldw = N).
+int wp_one(const float* A, int lda, const uint16_t* W, int64_t stride, int ldw, int w_tr, float* C, int ldc, const float* bias, const float* R,
+           int ldr, int M, int N, int K, int relu, hipStream_t s) {
+  if (W == nullptr) return RT_ERR_UNSUPPORTED;
+  rt_gemm_wp_problem pr{A, lda, W, stride, ldw, C, ldc, bias, R, ldr, M, N, K, relu};
+  return rt_gemm_wp(&pr, 1, w_tr, s);
+}
 struct SavedView {
   float *q, *Q, *A, *y, *f, *KV, *h, *hdrop, *lse, *mean1, *rstd1, *mean2, *rstd2;
 };
@@ -228,10 +248,19 @@ int rt_sasrec_block_packed_fwd(const rt_sasrec_block* blk, const float* x, float
   const SavedView v = carve_saved(b, saved);
   { Timed t(T_LN_FWD, 0, 0, 0, stream); RT_TRY(rt_layernorm_fwd(x, b.ln1_w, b.ln1_b, b.eps1, M, d, v.q, v.mean1, v.rstd1, stream)); }
   {
-    rt_gemm_problem pr[2] = {{v.q, d, b.in_w, d, v.Q, d, b.in_b, nullptr, 0, M, d, d, 0},                                  // Q = LN1(x) Wq^T + bq
-                             {x, d, b.in_w + (size_t)d * d, d, v.KV, 2 * d, b.in_b + d, nullptr, 0, M, 2 * d, d, 0}};      // K | V = x Wkv^T + bkv
     Timed t(T_GEMM_GROUPED, (long long)M * d * d + (long long)M * 2 * d * d, 1, 1, stream);
-    RT_TRY(rt_gemm_grouped(pr, 2, 1, 1, stream));
+    int rc = RT_ERR_UNSUPPORTED;
+    if (b.in_wp != nullptr) {
+      rt_gemm_wp_problem wp[2] = {{v.q, d, b.in_wp, b.wp_stride, d, v.Q, d, b.in_b, nullptr, 0, M, d, d, 0},
+                                  {x, d, b.in_wp + (size_t)d * d, b.wp_stride, d, v.KV, 2 * d, b.in_b + d, nullptr, 0, M, 2 * d, d, 0}};
+      rc = rt_gemm_wp(wp, 2, 0, stream);
+    }
+    if (rc == RT_ERR_UNSUPPORTED) {
+      rt_gemm_problem pr[2] = {{v.q, d, b.in_w, d, v.Q, d, b.in_b, nullptr, 0, M, d, d, 0},                                // Q = LN1(x) Wq^T + bq
+                               {x, d, b.in_w + (size_t)d * d, d, v.KV, 2 * d, b.in_b + d, nullptr, 0, M, 2 * d, d, 0}};    // K | V = x Wkv^T + bkv
+      rc = rt_gemm_grouped(pr, 2, 1, 1, stream);
+    }
+    RT_TRY(rc);
   }
   RT_TRY(zero_tail(v.A, b, d, stream));
   const float* bk = b.pad_keys ? b.in_b + d : nullptr;
@@ -239,22 +268,30 @@ int rt_sasrec_block_packed_fwd(const rt_sasrec_block* blk, const float* x, float
   { Timed t(T_ATTN_FWD, 0, 0, 0, stream);
     RT_TRY(rt_mha_varlen_train_fwd(v.Q, d, v.KV, 2 * d, v.KV + d, 2 * d, b.cu, bk, bv, b.B, b.H, hd, b.window, b.window, b.p_drop, b.seed_attn,
                                    v.A, d, v.lse, stream)); }
-  { Timed t(T_GEMM, M, d, d, stream);
-    RT_TRY(rt_gemm(v.A, d, 1, b.out_w, d, 1, v.y, d, b.out_b, v.q, d, nullptr, M, d, d, 0, 1, nullptr, 0, stream)); }   // y = q + Wo A + bo
+  { Timed t(T_GEMM, M, d, d, stream);                                                                                   // y = q + Wo A + bo
+    int rc = wp_one(v.A, d, b.out_wp, b.wp_stride, d, 0, v.y, d, b.out_b, v.q, d, M, d, d, 0, stream);
+    if (rc == RT_ERR_UNSUPPORTED) rc = rt_gemm(v.A, d, 1, b.out_w, d, 1, v.y, d, b.out_b, v.q, d, nullptr, M, d, d, 0, 1, nullptr, 0, stream);
+    RT_TRY(rc); }
   { Timed t(T_LN_FWD, 0, 0, 0, stream); RT_TRY(rt_layernorm_fwd(v.y, b.ln2_w, b.ln2_b, b.eps2, M, d, v.f, v.mean2, v.rstd2, stream)); }
-  { Timed t(T_GEMM, M, dff, d, stream);
-    RT_TRY(rt_gemm(v.f, d, 1, b.w1, d, 1, v.h, dff, b.b1, nullptr, 0, nullptr, M, dff, d, 1, 1, nullptr, 0, stream)); }  // h = relu(W1 f + b1)
+  { Timed t(T_GEMM, M, dff, d, stream);                                                                                 // h = relu(W1 f + b1)
+    int rc = wp_one(v.f, d, b.w1_wp, b.wp_stride, d, 0, v.h, dff, b.b1, nullptr, 0, M, dff, d, 1, stream);
+    if (rc == RT_ERR_UNSUPPORTED) rc = rt_gemm(v.f, d, 1, b.w1, d, 1, v.h, dff, b.b1, nullptr, 0, nullptr, M, dff, d, 1, 1, nullptr, 0, stream);
+    RT_TRY(rc); }
   if (b.p_drop > 0.f) {
     { Timed t(T_DROP_FWD, 0, 0, 0, stream);
       RT_TRY(rt_act_dropout_fwd(v.h, 0, b.p_drop, b.seed_h, b.sid_h, (int64_t)M * dff, nullptr, v.hdrop, stream)); }
     float* o = v.q + 5 * al((size_t)M * d);   // the spare region: o = W2 hdrop + b2 (dead after the next launch)
     { Timed t(T_GEMM, M, d, dff, stream);
-      RT_TRY(rt_gemm(v.hdrop, dff, 1, b.w2, dff, 1, o, d, b.b2, nullptr, 0, nullptr, M, d, dff, 0, 1, nullptr, 0, stream)); }
+      int rc = wp_one(v.hdrop, dff, b.w2_wp, b.wp_stride, dff, 0, o, d, b.b2, nullptr, 0, M, d, dff, 0, stream);
+      if (rc == RT_ERR_UNSUPPORTED) rc = rt_gemm(v.hdrop, dff, 1, b.w2, dff, 1, o, d, b.b2, nullptr, 0, nullptr, M, d, dff, 0, 1, nullptr, 0, stream);
+      RT_TRY(rc); }
     { Timed t(T_DROP_FWD, 0, 0, 0, stream);
       RT_TRY(rt_act_dropout_fwd(o, 0, b.p_drop, b.seed_o, b.sid_o, (int64_t)M * d, v.f, out, stream)); }              // out = f + dropout(o)
   } else {
     Timed t(T_GEMM, M, d, dff, stream);
-    RT_TRY(rt_gemm(v.h, dff, 1, b.w2, dff, 1, out, d, b.b2, v.f, d, nullptr, M, d, dff, 0, 1, nullptr, 0, stream));
+    int rc = wp_one(v.h, dff, b.w2_wp, b.wp_stride, dff, 0, out, d, b.b2, v.f, d, M, d, dff, 0, stream);
+    if (rc == RT_ERR_UNSUPPORTED) rc = rt_gemm(v.h, dff, 1, b.w2, dff, 1, out, d, b.b2, v.f, d, nullptr, M, d, dff, 0, 1, nullptr, 0, stream);
+    RT_TRY(rc);
   }
   return RT_OK;
 }
@@ -324,21 +361,27 @@ int rt_sasrec_block_packed_bwd(const rt_sasrec_block* blk, const float* x, const
   }
   RT_TRY(fork());
   RT_TRY(wgrad(g_o_c, d, v.hdrop, dff, d_w2, d, dff, d_b2));
-  { Timed t(T_GEMM, M, dff, d, stream);
-    RT_TRY(rt_gemm(g_o_c, d, 1, b.w2, dff, 0, g_hd, dff, nullptr, nullptr, 0, nullptr, M, dff, d, 0, 1, nullptr, 0, stream)); }
+  { Timed t(T_GEMM, M, dff, d, stream);                                                       // g_hd = g_o W2  (W2 [d, dff])
+    int rc = wp_one(g_o_c, d, b.w2_wp, b.wp_stride, dff, 1, g_hd, dff, nullptr, nullptr, 0, M, dff, d, 0, stream);
+    if (rc == RT_ERR_UNSUPPORTED) rc = rt_gemm(g_o_c, d, 1, b.w2, dff, 0, g_hd, dff, nullptr, nullptr, 0, nullptr, M, dff, d, 0, 1, nullptr, 0, stream);
+    RT_TRY(rc); }
   { Timed t(T_DROP_BWD, 0, 0, 0, stream);   // dropout mask and relu'(h) in one pass
     RT_TRY(rt_act_dropout_bwd(g_hd, v.h, 1, b.p_drop, b.seed_h, b.sid_h, (int64_t)M * dff, g_h, stream)); }
   RT_TRY(fork());
   RT_TRY(wgrad(g_h, dff, v.f, d, d_w1, dff, d, d_b1));
-  { Timed t(T_GEMM, M, d, dff, stream);     // residual branch (g_out) added in the dgrad epilogue
-    RT_TRY(rt_gemm(g_h, dff, 1, b.w1, d, 0, g_f, d, nullptr, g_out, d, nullptr, M, d, dff, 0, 1, nullptr, 0, stream)); }
+  { Timed t(T_GEMM, M, d, dff, stream);     // g_f = g_h W1 + g_out: the residual branch rides in the dgrad epilogue
+    int rc = wp_one(g_h, dff, b.w1_wp, b.wp_stride, d, 1, g_f, d, nullptr, g_out, d, M, d, dff, 0, stream);
+    if (rc == RT_ERR_UNSUPPORTED) rc = rt_gemm(g_h, dff, 1, b.w1, d, 0, g_f, d, nullptr, g_out, d, nullptr, M, d, dff, 0, 1, nullptr, 0, stream);
+    RT_TRY(rc); }
   { Timed t(T_LN_BWD, 0, 0, 0, stream);
     RT_TRY(rt_layernorm_bwd_fused(g_f, v.y, b.ln2_w, v.mean2, v.rstd2, nullptr, nullptr, 0, 0, M, d, g_y, d_ln2w, d_ln2b, ln_ws1, lnws, stream)); }
   // ---- attention: y = q + Wo A + bo
   RT_TRY(fork());
   RT_TRY(wgrad(g_y, d, v.A, d, d_wo, d, d, d_bo));
   { Timed t(T_GEMM, M, d, d, stream);
-    RT_TRY(rt_gemm(g_y, d, 1, b.out_w, d, 0, g_A, d, nullptr, nullptr, 0, nullptr, M, d, d, 0, 1, nullptr, 0, stream)); }
+    int rc = wp_one(g_y, d, b.out_wp, b.wp_stride, d, 1, g_A, d, nullptr, nullptr, 0, M, d, d, 0, stream);
+    if (rc == RT_ERR_UNSUPPORTED) rc = rt_gemm(g_y, d, 1, b.out_w, d, 0, g_A, d, nullptr, nullptr, 0, nullptr, M, d, d, 0, 1, nullptr, 0, stream);
+    RT_TRY(rc); }
   RT_TRY(zero_tail(gQ, b, d, stream));      // rows behind the sessions must read as zero in the weight gradients
   RT_TRY(zero_tail(gKV, b, 2 * d, stream));
   const float* bk = b.pad_keys ? b.in_b + d : nullptr;
@@ -355,10 +398,19 @@ int rt_sasrec_block_packed_bwd(const rt_sasrec_block* blk, const float* x, const
     RT_TRY(rt_colsum(part, d, b.B, d, d_in_b + 2 * d, ws));
   }
   {
-    rt_gemm_problem pr[2] = {{gQ, d, b.in_w, d, g_q, d, nullptr, g_y, d, M, d, d, 0},                                      // g_q = gQ Wq + g_y
-                             {gKV, 2 * d, b.in_w + (size_t)d * d, d, g_kv, d, nullptr, nullptr, 0, M, d, 2 * d, 0}};       // g_kv = gKV Wkv
     Timed t(T_GEMM_GROUPED, (long long)M * d * d + (long long)M * d * 2 * d, 1, 1, stream);
-    RT_TRY(rt_gemm_grouped(pr, 2, 1, 0, stream));
+    int rc = RT_ERR_UNSUPPORTED;
+    if (b.in_wp != nullptr) {
+      rt_gemm_wp_problem wp[2] = {{gQ, d, b.in_wp, b.wp_stride, d, g_q, d, nullptr, g_y, d, M, d, d, 0},
+                                  {gKV, 2 * d, b.in_wp + (size_t)d * d, b.wp_stride, d, g_kv, d, nullptr, nullptr, 0, M, d, 2 * d, 0}};
+      rc = rt_gemm_wp(wp, 2, 1, stream);
+    }
+    if (rc == RT_ERR_UNSUPPORTED) {
+      rt_gemm_problem pr[2] = {{gQ, d, b.in_w, d, g_q, d, nullptr, g_y, d, M, d, d, 0},                                    // g_q = gQ Wq + g_y
+                               {gKV, 2 * d, b.in_w + (size_t)d * d, d, g_kv, d, nullptr, nullptr, 0, M, d, 2 * d, 0}};     // g_kv = gKV Wkv
+      rc = rt_gemm_grouped(pr, 2, 1, 0, stream);
+    }
+    RT_TRY(rc);
   }
   { Timed t(T_LN_BWD, 0, 0, 0, stream);     // g_x = LN1'(g_q) + g_kv
     RT_TRY(rt_layernorm_bwd_fused(g_q, x, b.ln1_w, v.mean1, v.rstd1, g_kv, nullptr, 0, 0, M, d, g_x, d_ln1w, d_ln1b, ln_ws2, lnws, stream)); }
@@ -391,21 +443,36 @@ int rt_sasrec_block_packed_infer(const rt_sasrec_block* blk, const float* x, con
   const float* bk = b.pad_keys ? b.in_b + d : nullptr;
   const float* bv = b.pad_keys ? b.in_b + 2 * d : nullptr;
   RT_TRY(rt_layernorm_fwd(xin, b.ln1_w, b.ln1_b, b.eps1, R, d, q, mean, rstd, stream));
+  auto lin = [&](const float* A, int lda, const float* W, const uint16_t* Wp, int ldw, float* C, int ldc, const float* bias, const float* R, int ldr,
+                 int rows, int N, int K, int relu) -> int {      // one forward product: pre-split planes where the shape allows
+    int rc = wp_one(A, lda, Wp, b.wp_stride, ldw, 0, C, ldc, bias, R, ldr, rows, N, K, relu, stream);
+    if (rc == RT_ERR_UNSUPPORTED) rc = rt_gemm(A, lda, 1, W, ldw, 1, C, ldc, bias, R, ldr, nullptr, rows, N, K, relu, 1, nullptr, 0, stream);
+    return rc;
+  };
   if (!last) {
-    rt_gemm_problem pr[2] = {{q, d, b.in_w, d, Q, d, b.in_b, nullptr, 0, M, d, d, 0},
-                             {x, d, b.in_w + (size_t)d * d, d, KV, 2 * d, b.in_b + d, nullptr, 0, M, 2 * d, d, 0}};
-    RT_TRY(rt_gemm_grouped(pr, 2, 1, 1, stream));
+    int rc = RT_ERR_UNSUPPORTED;
+    if (b.in_wp != nullptr) {
+      rt_gemm_wp_problem wp[2] = {{q, d, b.in_wp, b.wp_stride, d, Q, d, b.in_b, nullptr, 0, M, d, d, 0},
+                                  {x, d, b.in_wp + (size_t)d * d, b.wp_stride, d, KV, 2 * d, b.in_b + d, nullptr, 0, M, 2 * d, d, 0}};
+      rc = rt_gemm_wp(wp, 2, 0, stream);
+    }
+    if (rc == RT_ERR_UNSUPPORTED) {
+      rt_gemm_problem pr[2] = {{q, d, b.in_w, d, Q, d, b.in_b, nullptr, 0, M, d, d, 0},
+                               {x, d, b.in_w + (size_t)d * d, d, KV, 2 * d, b.in_b + d, nullptr, 0, M, 2 * d, d, 0}};
+      rc = rt_gemm_grouped(pr, 2, 1, 1, stream);
+    }
+    RT_TRY(rc);
     { rt_sasrec_block bb = b; RT_TRY(zero_tail(A, bb, d, stream)); }
     RT_TRY(rt_mha_varlen_fwd(Q, d, KV, 2 * d, KV + d, 2 * d, b.cu, bk, bv, b.B, b.H, hd, b.window, b.window, A, d, stream));
   } else {
-    RT_TRY(rt_gemm(x, d, 1, b.in_w + (size_t)d * d, d, 1, KV, 2 * d, b.in_b + d, nullptr, 0, nullptr, M, 2 * d, d, 0, 1, nullptr, 0, stream));
-    RT_TRY(rt_gemm(q, d, 1, b.in_w, d, 1, Q, d, b.in_b, nullptr, 0, nullptr, R, d, d, 0, 1, nullptr, 0, stream));
+    RT_TRY(lin(x, d, b.in_w + (size_t)d * d, b.in_wp != nullptr ? b.in_wp + (size_t)d * d : nullptr, d, KV, 2 * d, b.in_b + d, nullptr, 0, M, 2 * d, d, 0));
+    RT_TRY(lin(q, d, b.in_w, b.in_wp, d, Q, d, b.in_b, nullptr, 0, R, d, d, 0));
     RT_TRY(rt_mha_varlen_last_fwd(Q, d, KV, 2 * d, KV + d, 2 * d, b.cu, bk, bv, b.B, b.H, hd, b.window, b.window, A, d, stream));
   }
-  RT_TRY(rt_gemm(A, d, 1, b.out_w, d, 1, y, d, b.out_b, q, d, nullptr, R, d, d, 0, 1, nullptr, 0, stream));
+  RT_TRY(lin(A, d, b.out_w, b.out_wp, d, y, d, b.out_b, q, d, R, d, d, 0));
   RT_TRY(rt_layernorm_fwd(y, b.ln2_w, b.ln2_b, b.eps2, R, d, f, mean, rstd, stream));
-  RT_TRY(rt_gemm(f, d, 1, b.w1, d, 1, h, dff, b.b1, nullptr, 0, nullptr, R, dff, d, 1, 1, nullptr, 0, stream));
-  RT_TRY(rt_gemm(h, dff, 1, b.w2, dff, 1, out, d, b.b2, f, d, nullptr, R, d, dff, 0, 1, nullptr, 0, stream));
+  RT_TRY(lin(f, d, b.w1, b.w1_wp, d, h, dff, b.b1, nullptr, 0, R, dff, d, 1));
+  RT_TRY(lin(h, dff, b.w2, b.w2_wp, dff, out, d, b.b2, f, d, R, d, dff, 0));
   return RT_OK;
 }
 

@@ -339,7 +339,7 @@ class SASRecTransformerLayer(nn.Module):
         ff = self.feed_forward
         return ff.ff_linear_1.bias is not None and ff.ff_linear_2.bias is not None and ff.activation == "relu"
 
-    def forward_packed(self, seqs, cu, B, window, pad_keys, last_rows=None, rows_real=None):
+    def forward_packed(self, seqs, cu, B, window, pad_keys, last_rows=None, rows_real=None, planes=None):
         """Inference over packed sessions (no padding rows; see ops.sasrec_layer_packed): [Np, d], or [B, d] with `last_rows`."""
         ff, mha = self.feed_forward, self.multi_head_attn
         return ops.sasrec_layer_packed(
@@ -347,9 +347,9 @@ class SASRecTransformerLayer(nn.Module):
             (self.q_layer_norm.weight, self.q_layer_norm.bias, self.q_layer_norm.eps),
             (mha.in_proj_weight, mha.in_proj_bias), (mha.out_proj.weight, mha.out_proj.bias),
             (self.ff_layer_norm.weight, self.ff_layer_norm.bias, self.ff_layer_norm.eps),
-            (ff.ff_linear_1.weight, ff.ff_linear_1.bias), (ff.ff_linear_2.weight, ff.ff_linear_2.bias), rows_real=rows_real)
+            (ff.ff_linear_1.weight, ff.ff_linear_1.bias), (ff.ff_linear_2.weight, ff.ff_linear_2.bias), rows_real=rows_real, planes=planes)
 
-    def forward_packed_train(self, seqs, cu, B, window, pad_keys, rows_real=None):
+    def forward_packed_train(self, seqs, cu, B, window, pad_keys, rows_real=None, planes=None):
         """The block on packed rows with autograd (training): ONE autograd node (`ops.sasrec_layer_packed_train`) when the feed-forward
         is the fused kind (ReLU, biases), else the individual ops."""
         ff, mha = self.feed_forward, self.multi_head_attn
@@ -360,7 +360,7 @@ class SASRecTransformerLayer(nn.Module):
             (self.q_layer_norm.weight, self.q_layer_norm.bias, self.q_layer_norm.eps),
             (mha.in_proj_weight, mha.in_proj_bias), (mha.out_proj.weight, mha.out_proj.bias),
             (self.ff_layer_norm.weight, self.ff_layer_norm.bias, self.ff_layer_norm.eps),
-            (ff.ff_linear_1.weight, ff.ff_linear_1.bias), (ff.ff_linear_2.weight, ff.ff_linear_2.bias), rows_real=rows_real)
+            (ff.ff_linear_1.weight, ff.ff_linear_1.bias), (ff.ff_linear_2.weight, ff.ff_linear_2.bias), rows_real=rows_real, planes=planes)
 
     def forward_packed_modular(self, seqs, cu, B, window, pad_keys):
         """The same block out of the individual autograd ops (as `forward_modular`; the cross-check of the fused packed node).  No
@@ -424,18 +424,35 @@ class SASRecTransformerLayers(TransformerLayersBase):
     def forward_packed_train(self, seqs, cu, B, window, keypad, rows_real=None):
         """Training forward over packed rows, [Np, d] (every row is a real position or belongs to the unused tail).  rows_real: the
         number of session rows when the caller knows it on the host (selects the native block executor)."""
+        planes = self._fresh_planes() if rows_real is not None else None
         for blk in self.transformer_blocks:
-            seqs = blk.forward_packed_train(seqs, cu, B, window, not keypad, rows_real)
+            seqs = blk.forward_packed_train(seqs, cu, B, window, not keypad, rows_real, planes)
         return self.last_layernorm(seqs)
+
+    def _fresh_planes(self):
+        """bf16 planes of the stack's weights for the pre-split-weight GEMM (`ops.WeightPlanes`, csrc/rt_gemm_wp.hip), re-split NOW (one
+        launch over the stack's few MB of parameters): whatever changed the weights since the last pass — the optimiser, a checkpoint,
+        a test poking a parameter — the planes the blocks are about to read are current.  None when the parameters are not views of one
+        flat buffer."""
+        if not ops.weight_planes_enabled():
+            return None
+        key = tuple(p.data_ptr() for p in self.parameters())
+        cached = getattr(self, "_planes_cache", None)
+        if cached is None or cached[0] != key:
+            cached = (key, ops.WeightPlanes(list(self.parameters())))
+            object.__setattr__(self, "_planes_cache", cached)
+        cached[1].refresh()
+        return cached[1] if cached[1].ok else None
 
     def forward_last_packed(self, seqs, cu, B, window, keypad, rows_real=None):
         """[B, d] encodings of the last position from PACKED rows: every block input is the real rows only — the
         reference masks pad rows to zero before each block (sasrec.py:300) and their only trace, the pad keys a causal block
         without key-padding masks shows to every query, is the virtual key of `rt_mha_varlen_*`."""
         blocks = list(self.transformer_blocks)
+        planes = self._fresh_planes() if rows_real is not None else None
         for blk in blocks[:-1]:
-            seqs = blk.forward_packed(seqs, cu, B, window, not keypad, rows_real=rows_real)
-        last = blocks[-1].forward_packed(seqs, cu, B, window, not keypad, last_rows=cu[1:] - 1, rows_real=rows_real)
+            seqs = blk.forward_packed(seqs, cu, B, window, not keypad, rows_real=rows_real, planes=planes)
+        last = blocks[-1].forward_packed(seqs, cu, B, window, not keypad, last_rows=cu[1:] - 1, rows_real=rows_real, planes=planes)
         return self.last_layernorm(last)
 
 

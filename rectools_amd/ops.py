@@ -1231,9 +1231,58 @@ class _SASRecLayerPacked(torch.autograd.Function):
 _GRAD_OFFSETS: tp.Dict[tp.Tuple[int, int], tp.List[int]] = {}
 
 
+class WeightPlanes:
+    """The bf16 planes (exact three-way split, `rt_split_planes`) of ONE contiguous fp32 parameter range — every weight of a layer stack
+    whose parameters live in a flat buffer (`lightning.FlatAdam`).  `refresh()` re-splits the range (one launch, a few microseconds:
+    the range is a few MB) and is called at the start of every forward pass of the stack, so the planes can never be stale;
+    `of(weight)` = the plane-0 pointer of a weight inside the range, or None."""
+
+    def __init__(self, params: tp.Sequence[torch.Tensor]) -> None:
+        ps = [p for p in params if p.is_cuda and p.dtype == torch.float32]
+        self.ok = False
+        if not ps:
+            return
+        base = ps[0].untyped_storage().data_ptr()
+        if any(p.untyped_storage().data_ptr() != base or not p.is_contiguous() for p in ps):
+            return      # parameters in separate allocations (no flat buffer): the stack runs without planes
+        lo = min(p.data_ptr() for p in ps)
+        hi = max(p.data_ptr() + p.numel() * 4 for p in ps)
+        if lo % 16 != 0:
+            return
+        self.lo, self.n = lo, ((hi - lo) // 4 + 3) // 4 * 4
+        end = base + ps[0].untyped_storage().nbytes()
+        if lo + self.n * 4 > end:
+            self.n = (end - lo) // 16 * 4
+        self.stride = (self.n + 7) // 8 * 8
+        self.planes = torch.empty((3 * self.stride,), dtype=torch.int16, device=ps[0].device)
+        self.ok = True
+
+    def refresh(self) -> None:
+        if self.ok:
+            _c("rt_split_planes", self.lo, self.n, self.planes, self.stride)
+
+    def of(self, w: torch.Tensor) -> tp.Optional[int]:
+        if not self.ok:
+            return None
+        off = w.data_ptr() - self.lo
+        if off < 0 or off % 16 != 0 or off + w.numel() * 4 > self.n * 4:
+            return None
+        return self.planes.data_ptr() + off // 2
+
+
+def weight_planes_enabled() -> bool:
+    return os.environ.get("RT_WEIGHT_PLANES", "1") != "0"
+
+
 def _block_desc(rows: int, rows_real: int, cu: torch.Tensor, B: int, H: int, d: int, dff: int, window: int, pad_keys: bool, p: float,
-                eps1: float, eps2: float, seeds: tp.Tuple[int, int, int, int, int], params: tp.Sequence[torch.Tensor]) -> "_lib.SasrecBlock":
+                eps1: float, eps2: float, seeds: tp.Tuple[int, int, int, int, int], params: tp.Sequence[torch.Tensor],
+                planes: tp.Optional[WeightPlanes] = None) -> "_lib.SasrecBlock":
     blk = _lib.SasrecBlock()
+    if planes is not None and planes.ok and weight_planes_enabled():
+        ptrs = [planes.of(params[i]) for i in (2, 4, 8, 10)]          # in_w, out_w, w1, w2
+        if all(q is not None for q in ptrs):
+            blk.in_wp, blk.out_wp, blk.w1_wp, blk.w2_wp = ptrs
+            blk.wp_stride = planes.stride
     blk.rows, blk.rows_real, blk.B, blk.H, blk.d, blk.dff, blk.window, blk.pad_keys = rows, rows_real, B, H, d, dff, window, int(pad_keys)
     blk.p_drop, blk.eps1, blk.eps2 = float(p), float(eps1), float(eps2)
     blk.seed_attn, blk.seed_h, blk.sid_h, blk.seed_o, blk.sid_o = seeds
@@ -1253,7 +1302,7 @@ class _SASRecLayerPackedNative(torch.autograd.Function):
     def forward(ctx, x, cu, ln1_w, ln1_b, in_w, in_b, out_w, out_b, ln2_w, ln2_b, w1, b1, w2, b2, meta):
         import ctypes
 
-        B, H, window, pad_keys, p, eps1, eps2, rows_real = meta
+        B, H, window, pad_keys, p, eps1, eps2, rows_real, planes = meta
         x = x.contiguous()
         M, d = x.shape
         dff = w1.shape[0]
@@ -1266,12 +1315,12 @@ class _SASRecLayerPackedNative(torch.autograd.Function):
             seed_o = RNG.next()
         params = (ln1_w, ln1_b, in_w, in_b, out_w, out_b, ln2_w, ln2_b, w1, b1, w2, b2)
         blk = _block_desc(M, rows_real, cu, B, H, d, dff, window, pad_keys, p, eps1, eps2, (seed_a, seed_h[0], seed_h[1], seed_o[0], seed_o[1]),
-                          params)
+                          params, planes)
         saved = torch.empty((lib.rt_sasrec_block_saved_floats(M, d, dff, H, 1 if p > 0 else 0),), dtype=torch.float32, device=x.device)
         out = torch.empty((M, d), dtype=torch.float32, device=x.device)
         _c("rt_sasrec_block_packed_fwd", ctypes.addressof(blk), x, saved, out)
         ctx.save_for_backward(x, cu, saved, *params)
-        ctx.blk_meta = (B, H, window, pad_keys, p, eps1, eps2, rows_real, (seed_a, seed_h[0], seed_h[1], seed_o[0], seed_o[1]))
+        ctx.blk_meta = (B, H, window, pad_keys, p, eps1, eps2, rows_real, (seed_a, seed_h[0], seed_h[1], seed_o[0], seed_o[1]), planes)
         return out
 
     @staticmethod
@@ -1279,13 +1328,13 @@ class _SASRecLayerPackedNative(torch.autograd.Function):
         import ctypes
 
         x, cu, saved, *params = ctx.saved_tensors
-        B, H, window, pad_keys, p, eps1, eps2, rows_real, seeds = ctx.blk_meta
+        B, H, window, pad_keys, p, eps1, eps2, rows_real, seeds, planes = ctx.blk_meta
         g_out = g_out.contiguous()
         M, d = g_out.shape
         dff = params[8].shape[0]
         dev = g_out.device
         lib = _lib.load()
-        blk = _block_desc(M, rows_real, cu, B, H, d, dff, window, pad_keys, p, eps1, eps2, seeds, params)
+        blk = _block_desc(M, rows_real, cu, B, H, d, dff, window, pad_keys, p, eps1, eps2, seeds, params, planes)
         key = (d, dff)
         offs = _GRAD_OFFSETS.get(key)
         if offs is None:
@@ -1315,13 +1364,13 @@ def sasrec_layer_packed_train(x: torch.Tensor, cu: torch.Tensor, B: int, H: int,
                               ln1: tp.Tuple[torch.Tensor, torch.Tensor, float], in_proj: tp.Tuple[torch.Tensor, torch.Tensor],
                               out_proj: tp.Tuple[torch.Tensor, torch.Tensor], ln2: tp.Tuple[torch.Tensor, torch.Tensor, float],
                               ff1: tp.Tuple[torch.Tensor, torch.Tensor], ff2: tp.Tuple[torch.Tensor, torch.Tensor],
-                              rows_real: tp.Optional[int] = None) -> torch.Tensor:
+                              rows_real: tp.Optional[int] = None, planes: tp.Optional[WeightPlanes] = None) -> torch.Tensor:
     """One packed SASRec block with autograd.  rows_real (the number of rows that belong to sessions; host-side knowledge of the
     caller) selects the native executor; without it the Python node issues the same kernels one by one."""
     if native_block_enabled() and rows_real is not None and x.shape[0] % 128 == 0:
         return _SASRecLayerPackedNative.apply(_chk(x, "sasrec_layer_packed_train"), cu, ln1[0], ln1[1], in_proj[0], in_proj[1], out_proj[0],
                                               out_proj[1], ln2[0], ln2[1], ff1[0], ff1[1], ff2[0], ff2[1],
-                                              (B, H, window, pad_keys, p, ln1[2], ln2[2], int(rows_real)))
+                                              (B, H, window, pad_keys, p, ln1[2], ln2[2], int(rows_real), planes))
     return _SASRecLayerPacked.apply(_chk(x, "sasrec_layer_packed_train"), cu, ln1[0], ln1[1], in_proj[0], in_proj[1], out_proj[0],
                                     out_proj[1], ln2[0], ln2[1], ff1[0], ff1[1], ff2[0], ff2[1],
                                     (B, H, window, pad_keys, p, ln1[2], ln2[2]))
@@ -1420,7 +1469,7 @@ def sasrec_layer_packed(x: torch.Tensor, cu: torch.Tensor, B: int, H: int, windo
                         ln1: tp.Tuple[torch.Tensor, torch.Tensor, float], in_proj: tp.Tuple[torch.Tensor, torch.Tensor],
                         out_proj: tp.Tuple[torch.Tensor, torch.Tensor], ln2: tp.Tuple[torch.Tensor, torch.Tensor, float],
                         ff1: tp.Tuple[torch.Tensor, torch.Tensor], ff2: tp.Tuple[torch.Tensor, torch.Tensor],
-                        rows_real: tp.Optional[int] = None) -> torch.Tensor:
+                        rows_real: tp.Optional[int] = None, planes: tp.Optional[WeightPlanes] = None) -> torch.Tensor:
     """Inference only: one causal SASRec block (sasrec.py:186-231) over PACKED sessions — `x` [Np, d] holds the real positions
     only (session b = rows cu[b] .. cu[b+1]-1, oldest first; Np = the row count rounded up to the 128-row GEMM tile, tail rows
     arbitrary).  The pad keys the reference's left-padded window shows to every query enter as one virtual key per query
@@ -1439,7 +1488,7 @@ def sasrec_layer_packed(x: torch.Tensor, cu: torch.Tensor, B: int, H: int, windo
         lib = _lib.load()
         dff = ff1[0].shape[0]
         blk = _block_desc(Np, int(rows_real), cu, B, H, d, dff, window, pad_keys, 0.0, ln1[2], ln2[2], (0, 0, 0, 0, 0),
-                          (ln1[0], ln1[1], in_w, in_b, out_proj[0], out_proj[1], ln2[0], ln2[1], ff1[0], ff1[1], ff2[0], ff2[1]))
+                          (ln1[0], ln1[1], in_w, in_b, out_proj[0], out_proj[1], ln2[0], ln2[1], ff1[0], ff1[1], ff2[0], ff2[1]), planes)
         last = last_rows is not None
         scratch = new(lib.rt_sasrec_block_infer_scratch_floats(Np, B, d, dff, 1 if last else 0))
         out = new(B if last else Np, d)

@@ -656,3 +656,59 @@ def test_gemm_bf16x6_split_is_fp32_accurate(M, N, K, split_k, a_kc, b_kc, monkey
     assert not torch.equal(split, exact) or M * N <= 256 * 128, "bf16x6 path did not run (bitwise equal to the exact kernel)"
     bound = 2.0 ** -24 * (3 + 2 * (K // max(split_k, 1)) ** 0.5)   # 3 dropped-term units + random-walk accumulation rounding
     assert e_split < bound, f"bf16x6 error {e_split:.2e} (exact kernel {e_exact:.2e}, bound {bound:.2e})"
+
+
+@pytest.mark.parametrize("w_tr", [0, 1])
+def test_gemm_with_presplit_weight_planes_is_fp32_accurate(w_tr):
+    """`rt_split_planes` + `rt_gemm_wp` (csrc/rt_gemm_wp.hip: weights split once into three bf16 planes, activations split in registers,
+    six bf16 MFMA products per fp32 product; w_tr = 1 reads the planes through the transpose LDS read) against an fp64 product: error at
+    the level of the f32-input MFMA kernel, for a single product with bias + residual + relu and for a grouped launch of two products
+    that share one plane buffer (the q / kv projections of a block); the planes themselves reassemble the weights exactly."""
+    import ctypes
+
+    from rectools_amd import _lib, ops
+
+    torch.manual_seed(3 + w_tr)
+    M, d = 384, 256
+    W = (torch.randn(3 * d, d) * torch.logspace(-2, 1, 3 * d)[:, None]).cuda()       # in_proj-like [3d, d], rows spanning the exponent range
+    n = W.numel()
+    stride = (n + 7) // 8 * 8
+    planes = torch.empty(3 * stride, dtype=torch.int16, device="cuda")
+    ops._c("rt_split_planes", W, n, planes, stride)
+    pl = planes.view(3, stride)[:, :n].view(torch.bfloat16).float().view(3, 3 * d, d)
+    assert torch.equal(pl[0] + pl[1] + pl[2], W)                                      # exact three-way split
+
+    def run(problems):
+        arr = (_lib.GemmWpProblem * len(problems))()
+        for q, (A, Wp, ldw, C, bias, R, Mq, Nq, Kq, relu) in zip(arr, problems):
+            q.A, q.lda, q.W, q.plane_stride, q.ldw, q.C, q.ldc = A.data_ptr(), A.stride(0), Wp, stride, ldw, C.data_ptr(), C.stride(0)
+            q.bias, q.R, q.ldr = (None if bias is None else bias.data_ptr()), (None if R is None else R.data_ptr()), (0 if R is None else R.stride(0))
+            q.M, q.N, q.K, q.relu = Mq, Nq, Kq, relu
+        ops._c("rt_gemm_wp", ctypes.cast(arr, ctypes.c_void_p), len(problems), w_tr)
+
+    def err(got, ref):
+        return float((got.double() - ref).abs().max() / ref.abs().max())
+
+    bias, R = torch.randn(d).cuda(), torch.randn(M, d).cuda()
+    if w_tr == 0:      # y = x W^T: Wq = rows [0, d), Wkv = rows [d, 3d)
+        x = torch.randn(M, d).cuda()
+        yq, ykv = torch.empty(M, d, device="cuda"), torch.empty(M, 2 * d, device="cuda")
+        run([(x, planes.data_ptr(), d, yq, bias, R, M, d, d, 1), (x, planes.data_ptr() + 2 * d * d, d, ykv, None, None, M, 2 * d, d, 0)])
+        ref_q = torch.relu(x.double() @ W[:d].double().t() + bias.double() + R.double())
+        ref_kv = x.double() @ W[d:].double().t()
+        assert err(yq, ref_q) < 2e-6 and err(ykv, ref_kv) < 2e-6, (err(yq, ref_q), err(ykv, ref_kv))
+        y1 = torch.empty(M, d, device="cuda")
+        run([(x, planes.data_ptr(), d, y1, None, None, M, d, d, 0)])
+        y2 = torch.empty(M, d, device="cuda")
+        ops._gemm(x, d, 1, W, d, 1, y2, d, None, None, 0, M, d, d)                    # rt_gemm (both operands split in registers)
+        torch.testing.assert_close(y1, y2, rtol=1e-5, atol=1e-6 * float(y2.abs().max()))
+    else:              # dx = dy W: g_q = gQ Wq (+ residual), g_kv = gKV Wkv
+        gQ, gKV = torch.randn(M, d).cuda(), torch.randn(M, 2 * d).cuda()
+        g_q, g_kv = torch.empty(M, d, device="cuda"), torch.empty(M, d, device="cuda")
+        run([(gQ, planes.data_ptr(), d, g_q, None, R, M, d, d, 0), (gKV, planes.data_ptr() + 2 * d * d, d, g_kv, None, None, M, d, 2 * d, 0)])
+        ref_q = gQ.double() @ W[:d].double() + R.double()
+        ref_kv = gKV.double() @ W[d:].double()
+        assert err(g_q, ref_q) < 2e-6 and err(g_kv, ref_kv) < 2e-6, (err(g_q, ref_q), err(g_kv, ref_kv))
+    bad = torch.empty(100, d, device="cuda")      # not an exact tile grid: refused (the caller falls back to rt_gemm), never computed otherwise
+    with pytest.raises(NotImplementedError):
+        run([(torch.randn(100, d).cuda(), planes.data_ptr(), d, bad, None, None, 100, d, d, 0)])

@@ -384,3 +384,51 @@ def test_native_block_equals_the_python_block(p, pad_keys, monkeypatch):
         torch.testing.assert_close(inf["native"][0], inf["python"][0], rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(inf["native"][1], inf["python"][1], rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(inf["native"][1], inf["native"][0][(cu[1:] - 1)], rtol=2e-4, atol=2e-5)
+
+
+def test_native_block_with_weight_planes_equals_the_python_block(monkeypatch):
+    """The native block on PRE-SPLIT weight planes (parameters in a FlatAdam flat buffer -> `ops.WeightPlanes`, rt_gemm_wp forward and
+    data-gradient products) against the Python node on rt_gemm: output, input gradient and parameter gradients to fp32 rounding; stale
+    planes are impossible — a parameter poked between two passes changes the next pass."""
+    from rectools_amd import lightning as hl
+    from rectools_amd import nn as hnn
+    from rectools_amd import ops
+
+    torch.manual_seed(17)
+    d, H, window = 128, 2, 64
+    lens = [64, 3, 40, 33, 17, 64, 50, 9, 28, 61, 12]
+    B, N = len(lens), sum(lens)
+    Np = (N + 127) // 128 * 128
+    cu = torch.tensor(np.r_[0, np.cumsum(lens)], dtype=torch.int64).cuda()
+    stack = hnn.SASRecTransformerLayers(2, d, H, 0.0).cuda().train()
+    for prm in stack.parameters():
+        if prm.dim() == 1:
+            torch.nn.init.normal_(prm, std=0.3)
+    hl.FlatAdam(stack, lr=1e-3)                                  # parameters become views of one flat buffer
+    x0 = torch.randn(Np, d); x0[N:] = 0
+    gout = torch.randn(Np, d); gout[N:] = 0
+    res = {}
+    for name, native in (("planes", "1"), ("python", "0")):
+        monkeypatch.setenv("RT_NATIVE_BLOCK", native)
+        for prm in stack.parameters():
+            prm.grad = None
+        x = x0.cuda().requires_grad_(True)
+        out = stack.forward_packed_train(x, cu, B, window, False, rows_real=N)
+        out.backward(gout.cuda())
+        ops.join_side_streams(); torch.cuda.synchronize()
+        res[name] = (out.detach()[:N].clone(), x.grad[:N].clone(), {k: v.grad.clone() for k, v in stack.named_parameters()})
+    assert stack._planes_cache[1].ok
+    torch.testing.assert_close(res["planes"][0], res["python"][0], rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(res["planes"][1], res["python"][1], rtol=2e-4, atol=2e-6 * float(res["python"][1].abs().max()))
+    for k in res["python"][2]:
+        torch.testing.assert_close(res["planes"][2][k], res["python"][2][k], rtol=2e-4, atol=2e-6 * (float(res["python"][2][k].abs().max()) + 1e-12),
+                                   msg=lambda s, k=k: f"gradient of {k}: {s}")
+    monkeypatch.setenv("RT_NATIVE_BLOCK", "1")
+    with torch.no_grad():
+        a = stack.forward_packed_train(x0.cuda(), cu, B, window, False, rows_real=N)[:N].clone()
+        stack.transformer_blocks[0].feed_forward.ff_linear_1.weight.mul_(1.5)        # poke a weight: the next pass re-splits
+        b = stack.forward_packed_train(x0.cuda(), cu, B, window, False, rows_real=N)[:N].clone()
+        monkeypatch.setenv("RT_WEIGHT_PLANES", "0")
+        c = stack.forward_packed_train(x0.cuda(), cu, B, window, False, rows_real=N)[:N].clone()
+    assert float((a - b).abs().max()) > 1e-3
+    torch.testing.assert_close(b, c, rtol=2e-5, atol=2e-6)
