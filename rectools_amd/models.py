@@ -104,11 +104,14 @@ class _TrainLoop:
             nb = -(-len(mine) // B)
             grid = np.zeros((nb, B), dtype=np.int64)
             grid.reshape(-1)[:len(mine)] = lens
-            cu = np.zeros((nb, B + 1), dtype=np.int64)
-            np.cumsum(grid, axis=1, out=cu[:, 1:])
+            cu = np.zeros((nb, B + 2), dtype=np.int64)
+            np.cumsum(grid, axis=1, out=cu[:, 1:B + 1])
+            # one more entry per batch: the end of the unused tail (rows up to the 128-row GEMM tile).  The attention kernels take the
+            # tail as one more "session" — its rows get finite values and zero gradients instead of three memsets per block and step
+            cu[:, B + 1] = np.maximum((cu[:, B] + 127) // 128 * 128, 128)
             self._cu_host = cu
             self._cu_dev = torch.from_numpy(cu).to(self.device)
-            self._reserve_step_memory(int(cu[:, -1].max()))
+            self._reserve_step_memory(int(cu[:, B + 1].max()))
 
     def _reserve_step_memory(self, max_rows: int) -> None:
         """Packed batches change their row count every step, and torch's caching allocator answers a size it has not seen with a
@@ -152,8 +155,11 @@ class _TrainLoop:
         n = int(self._cu_host[bi, nb])
         rows = max((n + 127) // 128 * 128, 128)
         cu = self._cu_dev[bi, :nb + 1]
+        full = nb == self.batch_size
         x, y, yw, dist = ops.collate_packed(self.dstore.offsets, self.dstore.items, self.dstore.weights, idx, cu, rows, train=True)
         batch: tp.Dict[str, tp.Any] = {"x": x, "y": y, "yw": yw, "dist": dist, "cu": cu, "window": self.dp.session_max_len, "n_rows": n}
+        if full and rows > n and rows - n <= self.dp.session_max_len:
+            batch["cu_attn"] = self._cu_dev[bi]        # [B + 2]: the sessions + the tail as a session of its own (see begin_epoch)
         if self.dp.negative_sampler is not None:
             batch["negatives"] = self.dp.negative_sampler.get_negatives(
                 {"x": x.view(-1, 1)}, lowest_id=self.dp.n_item_extra_tokens, highest_id=self.dp.item_id_map.size)

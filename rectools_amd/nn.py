@@ -808,7 +808,8 @@ class TransformerTorchBackbone(nn.Module):
         return self.transformer_layers.forward_last_packed(x, cu, B, window, self.use_key_padding_mask, rows_real=n_rows)
 
     def encode_packed_train(self, ids: torch.Tensor, dist: torch.Tensor, cu: torch.Tensor, B: int, window: int,
-                            item_embs: tp.Optional[torch.Tensor] = None, rows_real: tp.Optional[int] = None) -> torch.Tensor:
+                            item_embs: tp.Optional[torch.Tensor] = None, rows_real: tp.Optional[int] = None,
+                            cu_attn: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
         """Training twin of `encode_sessions` on packed rows: ids / dist [Np] (tail rows: id 0, dist 0), -> [Np, d].  ONE fused
         pass (`ops.embed_packed`): embedding rows (pad id 0 has no gradient), positional rows by the distance from the session's
         end, the embedding dropout (torch_backbone.py:245-247)."""
@@ -817,6 +818,10 @@ class TransformerTorchBackbone(nn.Module):
         scale = float(d) ** 0.5 if self.pos_encoding_layer.use_scale_factor else 1.0
         pos = self.pos_encoding_layer.pos_emb.weight if self.pos_encoding_layer.pos_emb is not None else None
         seqs = ops.embed_packed(table, pos, ids, dist, cu, B, window, scale, self.dropout_rate if self.training else 0.0)
+        if cu_attn is not None and rows_real is not None:
+            # cu_attn [B + 2]: the unused tail of the row block as one more session of the attention — every row of every buffer of
+            # the blocks is then written with finite values (zero gradients flow into the tail), no tail memsets
+            return self.transformer_layers.forward_packed_train(seqs, cu_attn, B + 1, window, self.use_key_padding_mask, int(seqs.shape[0]))
         return self.transformer_layers.forward_packed_train(seqs, cu, B, window, self.use_key_padding_mask, rows_real)
 
     def encode_last(self, batch: Batch, item_embs: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
