@@ -102,6 +102,14 @@ class _TrainLoop:
             off = np.asarray(self.store.offsets, dtype=np.int64)
             lens = np.clip(off[mine + 1] - off[mine] - 1, 0, L)
             nb = -(-len(mine) // B)
+            # longest session first INSIDE every batch (which sessions form a batch is untouched; their order in it carries no
+            # meaning for the loss): the attention kernels run one workgroup per (session, head) in row order, a workgroup's work grows
+            # with the square of its session's length, and 512 workgroups on 256 CUs finish earliest when the heavy ones start first
+            # (longest-processing-time order) — in random order the last CU to finish was handed two long sessions back to back
+            key = (np.arange(len(mine)) // B) * (L + 1) + (L - lens)
+            srt = np.argsort(key, kind="stable")
+            mine, lens = mine[srt], lens[srt]
+            self.mine_t = torch.from_numpy(np.ascontiguousarray(mine, dtype=np.int64)).to(self.device)
             grid = np.zeros((nb, B), dtype=np.int64)
             grid.reshape(-1)[:len(mine)] = lens
             cu = np.zeros((nb, B + 2), dtype=np.int64)
@@ -736,23 +744,29 @@ class TransformerModelBase:
             # packed encoder (no padding rows: 45 % of the [B, L] window at ML-20M scale) where the stack offers it; RT_PACKED=0
             # keeps the padded window.  Same encodings up to fp32 rounding (tests/test_packed_gpu.py).
             packed = os.environ.get("RT_PACKED", "1") != "0" and lm.torch_model.can_encode_packed(item_embs.shape[1], dp.session_max_len)
+            unsort = None
             if packed:   # packed row offsets of every encoder launch, cut on the host, one upload
                 L = dp.session_max_len
                 n_launch = -(-n_valid // bs)
+                lens_v = np.minimum(lens_h[valid_h], L)
+                enc_rows = valid_rows     # request order: an encoder launch holds >= 1024 sessions x heads = 16 workgroup rounds — sorting them
+                #                           by length (as the 128-session training batches are) bought nothing and cost a host argsort
                 grid = np.zeros((n_launch, bs), dtype=np.int64)
-                grid.reshape(-1)[:n_valid] = np.minimum(lens_h[valid_h], L)
+                grid.reshape(-1)[:n_valid] = lens_v
                 cu_h = np.zeros((n_launch, bs + 1), dtype=np.int64)
                 np.cumsum(grid, axis=1, out=cu_h[:, 1:])
                 cu_d = torch.from_numpy(cu_h).to(device, non_blocking=True)
             for bi, b0 in enumerate(range(0, n_valid, bs)):
                 nb = min(bs, n_valid - b0)
                 if packed:
-                    outs.append(lm.torch_model.encode_last_packed(offsets, item_s, valid_rows[b0:b0 + nb], dp.session_max_len, item_embs,
+                    outs.append(lm.torch_model.encode_last_packed(offsets, item_s, enc_rows[b0:b0 + nb], dp.session_max_len, item_embs,
                                                                   cu=cu_d[bi, :nb + 1], n_rows=int(cu_h[bi, nb])))
                     continue
                 batch = dp.collate_recommend_device(dstore, valid_rows[b0:b0 + nb])
                 outs.append(lm.torch_model.encode_last(batch, item_embs))   # last-position encodings, [b, d]
         user_embs = torch.cat(outs)
+        if unsort is not None:
+            user_embs = user_embs.index_select(0, unsort)
         tick("encoder")
         ranker = HipRanker(lm.torch_model.similarity_module.distance, device, user_embs, item_embs)
         filt = None
