@@ -1,6 +1,7 @@
-"""Copy the evidence of `scripts/gpu_profile_r2.sh` (gpurun_out/r2/) into profiles/ (tracked) and rebuild profiles/traffic.json
-from the PMC passes.  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request, so fetches are
-doubled (MI355X_MICROARCH.md, HBM section)."""
+"""Copy the evidence of a `scripts/gpu/visit.sh r3 ...` visit (gpurun_out/r3/, see profiles/README.md for the command) into profiles/
+(tracked), derive the matrix-pipe busy shares from the SQ pass and rebuild profiles/traffic.json from the FETCH_SIZE / WRITE_SIZE passes.
+FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request, so fetches of wide streaming reads are doubled
+(MI355X_MICROARCH.md, HBM section)."""
 import json
 import os
 import re
@@ -8,28 +9,27 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "r2")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r3"
+SRC = os.path.join(ROOT, "gpurun_out", TAG)
 DST = os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r2"
-
-KEEP = [
-    ("bench_auto.json", "bench_auto.json"), ("bench_bert4rec.json", "bench_bert4rec.json"), ("bench_hstu.json", "bench_hstu.json"),
-    ("bench_esasrec.json", "bench_esasrec.json"), ("bench_auto_2ranks_on_1gpu_gloo.json", "bench_auto_2ranks_on_1gpu_gloo.json"),
-] + [(f"rocprof_kernel_trace_{n}.md", f"rocprof_kernel_trace_{n}.md") for n in
-     ("train", "train_single_stream", "topk5m", "recommend", "bert4rec", "hstu", "esasrec")] + [
-    (f"pmc_{w}_{c}.txt", f"pmc_{w}_{c}.txt") for w in ("topk5m", "train") for c in ("FETCH_SIZE", "WRITE_SIZE")] + [
-    (f"sq_{n}.md", f"sq_counters_{n}.md") for n in ("attention", "attention_l512", "topk5m", "recommend")]
+KEEP = [("1_bench.json", "bench_auto.json"), ("2_prof.md", "rocprof_kernel_trace_train.md"), ("3_bench.json", "bench_train_single_stream.json"),
+        ("4_pmc.txt", "pmc_train_FETCH_SIZE.txt"), ("5_pmc.txt", "pmc_train_WRITE_SIZE.txt"), ("6_pmc.txt", "sq_counters_train_raw.txt"),
+        ("7_prof.md", "rocprof_kernel_trace_topk5m.md"), ("8_pmc.txt", "pmc_topk5m_FETCH_SIZE.txt"), ("9_pmc.txt", "pmc_topk5m_WRITE_SIZE.txt")]
 
 
-def parse_pmc(path):
-    """-> {kernel prefix: (calls, avg KiB)}"""
+def parse(path):
+    """-> {kernel: {counter: (n, avg)}}"""
     out = {}
     if not os.path.exists(path):
         return out
     for line in open(path):
-        m = re.match(r"\w+ (.+?)\s+calls=(\d+) avg=([\d.]+) max=([\d.]+) sum=([\d.]+)", line)
-        if m:
-            out[m.group(1).strip()] = (int(m.group(2)), float(m.group(3)), float(m.group(5)))
+        m = re.match(r"(.+?)\s{2,}(\w+: n=.*)$", line.rstrip())
+        if not m:
+            continue
+        d = {}
+        for c in re.finditer(r"(\w+): n=(\d+) avg=([\d.e+-]+)", m.group(2)):
+            d[c.group(1)] = (int(c.group(2)), float(c.group(3)))
+        out[m.group(1).strip()] = d
     return out
 
 
@@ -37,34 +37,62 @@ def main():
     for src, dst in KEEP:
         p = os.path.join(SRC, src)
         if os.path.exists(p):
-            shutil.copyfile(p, os.path.join(DST, f"{TAG}_{dst}"))
+            text = open(p).read()
+            if src.endswith(".json"):
+                text = "\n".join(l for l in text.splitlines() if l.startswith("{")) + "\n"
+            open(os.path.join(DST, f"{TAG}_{dst}"), "w").write(text)
         else:
             print("missing", src)
-    traffic = {"_note": "HBM bytes per launch of the dominant kernel of each bench leg, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate "
-                        "passes (kernel-trace only); FETCH_SIZE (KiB) doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128-B request), "
-                        "WRITE_SIZE in KiB.  topk5m: whole rt_topk_score call (seeding prefix + main pass of topk_stream16_kernel + the two "
-                        "selection kernels), algorithmic 10.24e9.  train_gemm: average rt_gemm launch (the three gemm_dma_kernel operand "
-                        "layouts)."}
-    f, w = parse_pmc(os.path.join(SRC, "pmc_topk5m_FETCH_SIZE.txt")), parse_pmc(os.path.join(SRC, "pmc_topk5m_WRITE_SIZE.txt"))
-    if f:
-        calls = [v for k, v in f.items() if "topk_select_kernel<false>" in k]
-        n_calls = calls[0][0] if calls else 1
-        fetch = sum(v[2] for k, v in f.items() if "topk_" in k) / n_calls * 1024 * 2
-        write = sum(v[2] for k, v in w.items() if "topk_" in k) / n_calls * 1024
+    sq = parse(os.path.join(SRC, "6_pmc.txt"))
+    rows = ["GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs: matrix-pipe busy share = MFMA_BUSY / (GUI_ACTIVE / 8 x 1024); "
+            "SQ_ACTIVE_INST_* and SQ_WAVE_CYCLES count quad-cycles (x 4 = cycles).",
+            "| kernel | launches | GRBM_GUI_ACTIVE | SQ_VALU_MFMA_BUSY_CYCLES | matrix-pipe busy share | VALU active share | LDS active share | mean waves per SIMD | LDS bank conflict / LDS active |",
+            "|---|---|---|---|---|---|---|---|---|"]
+    for k, c in sq.items():
+        if not any(t in k for t in ("v2_", "gemm_", "sampled_", "layernorm", "adam", "embed_bwd_rows")):
+            continue
+        g = c.get("GRBM_GUI_ACTIVE", (0, 0))[1]
+        if g <= 0:
+            continue
+        simd_cycles = g / 8 * 1024
+        mf = c.get("SQ_VALU_MFMA_BUSY_CYCLES", (0, 0))[1]
+        valu = c.get("SQ_ACTIVE_INST_VALU", (0, 0))[1] * 4
+        lds = c.get("SQ_ACTIVE_INST_LDS", (0, 0))[1] * 4
+        wav = c.get("SQ_WAVE_CYCLES", (0, 0))[1] * 4
+        conf = c.get("SQ_LDS_BANK_CONFLICT", (0, 0))[1]
+        rows.append(f"| `{k[:60]}` | {c['GRBM_GUI_ACTIVE'][0]} | {g:.0f} | {mf:.0f} | {mf / simd_cycles:.3f} | {valu / simd_cycles:.3f} | {lds / (g / 8 * 256):.3f} | "
+                    f"{wav / simd_cycles:.2f} | {conf / max(lds / 4, 1):.4f} |")
+    open(os.path.join(DST, f"{TAG}_sq_counters_train.md"), "w").write("\n".join(rows) + "\n")
+    f, w = parse(os.path.join(SRC, "4_pmc.txt")), parse(os.path.join(SRC, "5_pmc.txt"))
+    tf, tw = parse(os.path.join(SRC, "8_pmc.txt")), parse(os.path.join(SRC, "9_pmc.txt"))
+
+    def kib(tab, pat, counter):
+        return [(v[counter][0], v[counter][1]) for k, v in tab.items() if pat in k and counter in v]
+
+    traffic = {"_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (kernel-trace only, "
+                        f"`scripts/gpu/visit.sh {TAG}`); FETCH_SIZE (KiB) doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128-B request), "
+                        "WRITE_SIZE in KiB.  topk5m: whole rt_topk_score call = 2 launches of topk_stream16_kernel (seeding prefix + main pass) "
+                        "+ the two selection kernels, algorithmic 10.24e9.  train_gemm: average launch over the GEMM kernel family of the step "
+                        "(gemm_wp_kernel forward / dgrad products, gemm_dma_kernel weight gradients)."}
+    t = kib(tf, "topk_stream16", "FETCH_SIZE")
+    if t:
+        calls = max(1, sum(n for n, _ in kib(tf, "topk_select_kernel<false>", "FETCH_SIZE")))
+        fetch = sum(n * a for k, v in tf.items() if "topk_" in k for n, a in [v["FETCH_SIZE"]]) / calls * 1024 * 2
+        write = sum(n * a for k, v in tw.items() if "topk_" in k for n, a in [v["WRITE_SIZE"]]) / calls * 1024
         traffic["topk5m"] = int(fetch + write)
-    f, w = parse_pmc(os.path.join(SRC, "pmc_train_FETCH_SIZE.txt")), parse_pmc(os.path.join(SRC, "pmc_train_WRITE_SIZE.txt"))
-    if f:
-        g_f = [(v[0], v[2]) for k, v in f.items() if "gemm_dma_kernel" in k]
-        g_w = [(v[0], v[2]) for k, v in w.items() if "gemm_dma_kernel" in k]
-        n = sum(c for c, _ in g_f)
-        traffic["train_gemm"] = int((sum(s for _, s in g_f) * 2 + sum(s for _, s in g_w)) / n * 1024)
-        for name, key in (("sampled_fwd_kernel", "train_rt_sampled_loss_fwd_train"), ("sampled_bwd_rows_kernel", "train_rt_sampled_loss_bwd")):
-            ff = [v for k, v in f.items() if name in k]
-            ww = [v for k, v in w.items() if name in k]
-            if ff:
-                traffic[key] = int((ff[0][1] * 2 + (ww[0][1] if ww else 0)) * 1024)
+    gf = [x for pat in ("gemm_wp_kernel", "gemm_dma_kernel", "gemm_dma_group") for x in kib(f, pat, "FETCH_SIZE")]
+    gw = [x for pat in ("gemm_wp_kernel", "gemm_dma_kernel", "gemm_dma_group") for x in kib(w, pat, "WRITE_SIZE")]
+    if gf:
+        n = sum(c for c, _ in gf)
+        traffic["train_gemm"] = int((sum(c * a for c, a in gf) * 2 + sum(c * a for c, a in gw)) / n * 1024)
+    for key, pat in (("train_rt_sampled_loss_fwd_train", "sampled_fwd_kernel"), ("train_rt_sampled_loss_bwd", "sampled_bwd_rows_kernel"),
+                     ("train_v2_fwd_kernel", "v2_fwd_kernel"), ("train_v2_bwd_dq_kernel", "v2_bwd_dq_kernel"), ("train_v2_bwd_dkv_kernel", "v2_bwd_dkv_kernel")):
+        a, b = kib(f, pat, "FETCH_SIZE"), kib(w, pat, "WRITE_SIZE")
+        if a:
+            traffic[key] = int((a[0][1] * 2 + (b[0][1] if b else 0)) * 1024)
     json.dump(traffic, open(os.path.join(DST, "traffic.json"), "w"), indent=1)
-    print(json.dumps(traffic, indent=1)[:600])
+    print(json.dumps(traffic, indent=1))
+    print(open(os.path.join(DST, f"{TAG}_sq_counters_train.md")).read())
 
 
 if __name__ == "__main__":
