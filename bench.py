@@ -543,6 +543,7 @@ def main():
     ap.add_argument("--rec-steps", type=int, default=20, help="timed steps of the recommend sub-leg")
     ap.add_argument("--topk-steps", type=int, default=5, help="timed steps of the topk5m sub-leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-families", action="store_true", help="skip the BERT4Rec / HSTU / eSASRec sub-records of the auto run")
     args = ap.parse_args()
     rank, world, local, dist_info = dist_setup(args.gpus)
     if os.environ.get("RT_BENCH_DRY_RUN") == "1":   # launcher / rendezvous / line shape only (CPU test of the N > 1 start-up)
@@ -635,6 +636,22 @@ def main():
             big = argparse.Namespace(**vars(args))
             big.users_per_step, big.users_per_pass, big.topk_steps = 4096, 64, 2
             out["topk5m_u4096"] = topk_leg("topk5m", big, rank, world, False)   # >= 4096 users over 5M x 512 (the MFMA regime)
+            if not args.no_families:
+                # the other BASELINE configs' model families at their stated shapes (configs[2..4]: BERT4Rec d256 L200 full softmax; HSTU d256
+                # L512 relative time + position bias, 1 M items; eSASRec = SASRec on LiGR blocks, d512, 1 M items): the same product loop, 10
+                # timed steps each — short on purpose (the line must finish within minutes); `--workload <family>` runs one at length
+                fam = argparse.Namespace(**vars(args))
+                fam.steps, fam.warmup = 10, 3
+                out["families"] = {}
+                for kind_f in ("bert4rec", "hstu", "esasrec"):
+                    v_f, wall_f, roof_f, info_f = run_train(fam, rank, world, kind_f)
+                    out["families"][kind_f] = {"metric": f"train seqs/sec ({info_f['spec']['name']})", "value": round(v_f, 2), "unit": "seqs/s",
+                                                "steps": fam.steps, "warmup": fam.warmup, "ms_per_step": round(wall_f / fam.steps * 1e3, 4),
+                                                "config": {"workload": info_f["spec"]["desc"], "global_batch": info_f["B"] * world},
+                                                "roofline": {k: roof_f[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac") if k in roof_f},
+                                                "final_loss": round(info_f["loss"], 5)}
+                    del info_f
+                    torch.cuda.empty_cache()
         out["env"] = env
     out["dist"] = dist_info
 

@@ -14,6 +14,8 @@ for k in ("train_exact_gemm", "recommend", "topk5m", "topk5m_u4096"):
         print(" ", k, j[k].get("value"), j[k].get("unit"), "frac", r.get("frac"), r.get("achieved"), r.get("unit"),
               {a: b for a, b in j[k].items() if a.startswith("phase")}, "kernel", (j[k].get("ranker_kernel") or {}).get("value"),
               "cpu", cb.get("kind"), cb.get("value"))
+for k, v in (j.get("families") or {}).items():
+    print("  family", k, v.get("value"), v.get("unit"), "ms/step", v.get("ms_per_step"), "roofline", (v.get("roofline") or {}).get("kernel", "")[:30], (v.get("roofline") or {}).get("frac"))
 cb = j.get("cpu_baseline") or {}
 print("  cpu_baseline", cb.get("kind"), cb.get("value"), cb.get("unit"), "cores", cb.get("cores"))
 r = j.get("roofline") or {}
