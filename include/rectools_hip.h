@@ -171,6 +171,15 @@ int rt_collate(const int64_t* offsets, const int64_t* items, const float* weight
  * end = the index of its positional row (net_blocks.py:388-399). */
 int rt_collate_packed(const int64_t* offsets, const int64_t* items, const float* weights, const int64_t* idx, const int64_t* cu_seqlens,
                       int32_t B, int32_t rows, int32_t train, int64_t* x, int64_t* y, float* yw, int64_t* dist, rt_stream_t stream);
+/* ... the BERT4Rec batch on packed rows (bert4rec.py:109-153, 182-193).  train = 1: cu[b+1] - cu[b] = min(length, window) rows; probs /
+ * rand_ids [B, window] are the draws of rt_collate mode 3, read at the row's padded position (b, window - n + j) — the packed batch
+ * masks what the padded one masks; y = the item where the position was picked, else 0.  draw_rows [B] or NULL: the row of the draws
+ * session b reads (NULL = b; a loop that re-orders a batch keeps every session on the draws of its original slot).  train = 0:
+ * min(length, window - 1) + 1 rows, the last one the MASK token. */
+int rt_collate_packed_bert(const int64_t* offsets, const int64_t* items, const float* weights, const int64_t* idx, const int64_t* cu_seqlens,
+                           int32_t B, int32_t rows, int32_t window, int32_t train, const float* probs, const int64_t* rand_ids,
+                           const int64_t* draw_rows, float mask_prob, int64_t mask_id, int64_t* x, int64_t* y, float* yw, int64_t* dist,
+                           rt_stream_t stream);
 
 /* a11  uniform negatives on the device — CatalogUniformSampler.get_negatives (negative_sampler.py:58-73):
  * out[e] uniform over item ids [low, high), e < n (the [B, L | 1, N] tensor, flat), no rejection of positives.
@@ -335,6 +344,16 @@ int rt_mha_varlen_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, 
                       int32_t B, int32_t H, int32_t hd, int32_t max_len, int32_t window, float p_drop, uint64_t seed, float* dq,
                       int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv, float* delta, float* dbv_part,
                       rt_stream_t stream);
+/* Bidirectional attention inside every packed session (no causal mask, no pad keys): BERT4Rec's key-padding-masked window
+ * (torch_backbone.py:254, bert4rec.py:200) on packed rows.  lse != NULL: training forward (dropout, lse [N,H] kept); NULL: inference.
+ * bf16-plane kernels only (hd 32 / 64, 12 * hd * (max_len + 1) bytes of LDS <= 160 KB), RT_ERR_UNSUPPORTED otherwise. */
+int rt_mha_varlen_bidir_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const int64_t* cu_seqlens,
+                            int32_t B, int32_t H, int32_t hd, int32_t max_len, float p_drop, uint64_t seed, float* o, int64_t ldo, float* lse,
+                            rt_stream_t stream);
+int rt_mha_varlen_bidir_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* o, int64_t ldo,
+                            const float* dout, int64_t lddo, const float* lse, const int64_t* cu_seqlens, int32_t B, int32_t H, int32_t hd,
+                            int32_t max_len, float p_drop, uint64_t seed, float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv,
+                            int64_t lddv, float* delta, rt_stream_t stream);
 /* ... for the LAST query of every session only: q [B, ldq] one projected query row per session, o [B, ldo] (cf. rt_mha_last_fwd) */
 int rt_mha_varlen_last_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                            const int64_t* cu_seqlens, const float* bk, const float* bv, int32_t B, int32_t H, int32_t hd,

@@ -66,6 +66,9 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_mha_varlen_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rt_mha_varlen_train_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_vp, c_i64, c_vp, c_vp]),
     "rt_mha_varlen_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "rt_mha_varlen_bidir_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_vp, c_i64, c_vp, c_vp]),
+    "rt_mha_varlen_bidir_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
+                                        c_f32, c_u64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "rt_mha_varlen_last_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rt_hstu_attn_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rt_hstu_attn_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
@@ -81,6 +84,8 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_gather_rows": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rt_scatter_rows": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rt_collate_packed": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "rt_collate_packed_bert": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_i64, c_vp, c_vp,
+                                       c_vp, c_vp, c_vp]),
     "rt_embed_packed_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_f32, c_u64, c_u64, c_vp, c_vp]),
     "rt_embed_packed_bwd": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_f32, c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_u64, c_vp, c_i32, c_vp,
                                     c_vp, c_sz, c_vp]),

@@ -199,7 +199,9 @@ __device__ __forceinline__ void for_my_tiles(int wave, int n_tiles, F&& body) {
 // ---------------------------------------------------------------------------------------------------------------------------------
 // forward: a lane owns a query (4 lanes per query hold different keys / different head-dim columns)
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int HD, int NW, bool TRAIN>
+// CAUSAL = false: every query sees every key of its session (BERT4Rec: the reference masks the window's pad keys, bert4rec.py:200 /
+// torch_backbone.py:254 — on packed rows they simply do not exist); no virtual pad key then.
+template <int HD, int NW, bool TRAIN, bool CAUSAL = true>
 __global__ __launch_bounds__(NW * 64) void v2_fwd_kernel(VarlenArgs a) {
   using L = Lay<HD>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -216,12 +218,12 @@ __global__ __launch_bounds__(NW * 64) void v2_fwd_kernel(VarlenArgs a) {
   __syncthreads();
 
   const int n_pad = a.window > n ? a.window - n : 0;
-  const bool pads = a.bk != nullptr && a.bv != nullptr && n_pad > 0;
+  const bool pads = CAUSAL && a.bk != nullptr && a.bv != nullptr && n_pad > 0;
   const unsigned thr16 = TRAIN ? drop_thr16(a.p_drop) : 0u;
   const float inv_keep = (TRAIN && a.p_drop > 0.f) ? 1.f / (1.f - a.p_drop) : 1.f;
   const float qscale = a.scale * LOG2E;          // scores live in the base-2 domain: p = exp2(s' - m')
 
-  for_my_tiles<NW, true>(wave, (n + 15) >> 4, [&](int qt) {
+  for_my_tiles<NW, CAUSAL>(wave, (n + 15) >> 4, [&](int qt) {
     const int qrow = qt * 16 + i;
     const bool qok = qrow < n;
     const long long grow = row0 + (qok ? qrow : n - 1);
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(NW * 64) void v2_fwd_kernel(VarlenArgs a) {
     f32x4 oT[L::NCB];
 #pragma unroll
     for (int cb = 0; cb < L::NCB; ++cb) oT[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int kt_last = (qt * 16 + 15) >> 5;
+    const int kt_last = CAUSAL ? (qt * 16 + 15) >> 5 : (n - 1) >> 5;
 
     for (int kt = 0; kt <= kt_last; ++kt) {
       f32x4 sT[2];
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(NW * 64) void v2_fwd_kernel(VarlenArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int key = kt * 32 + 16 * (e >> 2) + 4 * g + (e & 3);
-          sc[e] = key <= qrow ? sc[e] : -INFINITY;
+          sc[e] = (CAUSAL ? key <= qrow : key < n) ? sc[e] : -INFINITY;
         }
       }
       float mx = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7])));
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(NW * 64) void v2_fwd_kernel(VarlenArgs a) {
 // forward: S^T and dP^T = V dO^T are recomputed per key tile (K and V rows as MFMA rows), dS^T = P (drop * dP - delta) stays in
 // registers and feeds dQ^T = K^T dS^T (K rows as the reduction index: transpose reads of the SAME image).
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int HD, int NW>
+template <int HD, int NW, bool CAUSAL = true>
 __global__ __launch_bounds__(NW * 64) void v2_bwd_dq_kernel(VarlenArgs a) {
   using L = Lay<HD>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(NW * 64) void v2_bwd_dq_kernel(VarlenArgs a) {
   __syncthreads();
 
   const int n_pad = a.window > n ? a.window - n : 0;
-  const bool pads = a.bk != nullptr && a.bv != nullptr && n_pad > 0;
+  const bool pads = CAUSAL && a.bk != nullptr && a.bv != nullptr && n_pad > 0;
   const unsigned thr16 = drop_thr16(a.p_drop);
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   const float qscale = a.scale * LOG2E;
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(NW * 64) void v2_bwd_dq_kernel(VarlenArgs a) {
 #pragma unroll
   for (int cb = 0; cb < L::NCB; ++cb) dbv_acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for_my_tiles<NW, true>(wave, (n + 15) >> 4, [&](int qt) {
+  for_my_tiles<NW, CAUSAL>(wave, (n + 15) >> 4, [&](int qt) {
     const int qrow = qt * 16 + i;
     const bool qok = qrow < n;
     const long long grow = row0 + (qok ? qrow : n - 1);
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(NW * 64) void v2_bwd_dq_kernel(VarlenArgs a) {
     f32x4 dqT[L::NCB];
 #pragma unroll
     for (int cb = 0; cb < L::NCB; ++cb) dqT[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int kt_last = (qt * 16 + 15) >> 5;
+    const int kt_last = CAUSAL ? (qt * 16 + 15) >> 5 : (n - 1) >> 5;
 
     for (int kt = 0; kt <= kt_last; ++kt) {
       f32x4 sT[2], dpT[2];
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(NW * 64) void v2_bwd_dq_kernel(VarlenArgs a) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int key = kt * 32 + 16 * (e >> 2) + 4 * g + (e & 3);
-        const float pr = (kt < kt_last || key <= qrow) ? __builtin_amdgcn_exp2f(sT[e >> 2][e & 3] - lse2) : 0.f;
+        const float pr = (kt < kt_last || (CAUSAL ? key <= qrow : key < n)) ? __builtin_amdgcn_exp2f(sT[e >> 2][e & 3] - lse2) : 0.f;
         ds[e] = pr;
       }
 #pragma unroll
@@ -463,7 +465,7 @@ __global__ __launch_bounds__(NW * 64) void v2_bwd_dq_kernel(VarlenArgs a) {
 // registers) leave 2 x 4 queries of key `lane & 15` per lane; P~ and dS feed dV^T = dO^T P~ and dK^T = Q^T dS through transpose reads of
 // the same two images.  Q is staged pre-scaled by log2(e) / sqrt(hd): dK comes out times log2(e) and is scaled back at the store.
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int HD, int NW>
+template <int HD, int NW, bool CAUSAL = true>
 __global__ __launch_bounds__(NW * 64) void v2_bwd_dkv_kernel(VarlenArgs a) {
   using L = Lay<HD>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -491,7 +493,7 @@ __global__ __launch_bounds__(NW * 64) void v2_bwd_dkv_kernel(VarlenArgs a) {
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   const int qt_last = (n - 1) >> 5;
 
-  for_my_tiles<NW, false>(wave, (n + 15) >> 4, [&](int kt) {
+  for_my_tiles<NW, false>(wave, (n + 15) >> 4, [&](int kt) {   // (bidirectional: every key tile weighs the same, any order is even)
     const int krow = kt * 16 + i;            // this lane's key (valid if < n)
     const bool kok = krow < n;
     const long long grow = row0 + (kok ? krow : n - 1);
@@ -501,7 +503,7 @@ __global__ __launch_bounds__(NW * 64) void v2_bwd_dkv_kernel(VarlenArgs a) {
     f32x4 dkT[L::NCB], dvT[L::NCB];
 #pragma unroll
     for (int cb = 0; cb < L::NCB; ++cb) { dkT[cb] = f32x4{0.f, 0.f, 0.f, 0.f}; dvT[cb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    const int qt_first = (kt * 16) >> 5;
+    const int qt_first = CAUSAL ? (kt * 16) >> 5 : 0;
 
     for (int qt = qt_first; qt <= qt_last; ++qt) {     // causal: query tiles at or behind the key tile
       f32x4 sm[2], dpm[2];                             // S[q][key], dP[q][key]: register (qb, r) = query qt*32 + 16 qb + 4 g + r
@@ -517,7 +519,7 @@ __global__ __launch_bounds__(NW * 64) void v2_bwd_dkv_kernel(VarlenArgs a) {
         for (int r = 0; r < 4; ++r) {
           const int qr = qt * 32 + 16 * qb + 4 * g + r;
           float pr = __builtin_amdgcn_exp2f(sm[qb][r] - ls4[r]);
-          if (edge) pr = (krow <= qr && qr < n && kok) ? pr : 0.f;
+          if (edge) pr = ((!CAUSAL || krow <= qr) && qr < n && kok) ? pr : 0.f;
           float keepf = 1.f;
           if (thr16 != 0u)
             keepf = drop_kept(a.seed, (unsigned)blockIdx.x, (unsigned)qr, (unsigned)krow, thr16) ? inv_keep : 0.f;
@@ -543,14 +545,14 @@ __global__ __launch_bounds__(NW * 64) void v2_bwd_dkv_kernel(VarlenArgs a) {
   });
 }
 
-template <int HD, int NW>
+template <int HD, int NW, bool CAUSAL = true>
 int launch_bwd(const VarlenArgs& a, int max_len, hipStream_t stream) {
   const size_t img = 2 * Lay<HD>::image_bytes(max_len);
   const size_t lds_dq = img > (size_t)NW * HD * 4 ? img : (size_t)NW * HD * 4;
   const size_t lds_kv = img + 2 * (size_t)((max_len + 31) & ~31) * sizeof(float);
   if (lds_dq > 160 * 1024 || lds_kv > 160 * 1024) return RT_ERR_UNSUPPORTED;
-  auto kq = &v2_bwd_dq_kernel<HD, NW>;
-  auto kkv = &v2_bwd_dkv_kernel<HD, NW>;
+  auto kq = &v2_bwd_dq_kernel<HD, NW, CAUSAL>;
+  auto kkv = &v2_bwd_dkv_kernel<HD, NW, CAUSAL>;
   RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kq), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq));
   RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kkv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv));
   kq<<<a.B * a.H, NW * 64, lds_dq, stream>>>(a);
@@ -560,11 +562,11 @@ int launch_bwd(const VarlenArgs& a, int max_len, hipStream_t stream) {
   return RT_OK;
 }
 
-template <int HD, int NW, bool TRAIN>
+template <int HD, int NW, bool TRAIN, bool CAUSAL = true>
 int launch_fwd(const VarlenArgs& a, int max_len, hipStream_t stream) {
   const size_t lds = 2 * Lay<HD>::image_bytes(max_len);
   if (lds > 160 * 1024) return RT_ERR_UNSUPPORTED;
-  auto kern = &v2_fwd_kernel<HD, NW, TRAIN>;
+  auto kern = &v2_fwd_kernel<HD, NW, TRAIN, CAUSAL>;
   RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   kern<<<a.B * a.H, NW * 64, lds, stream>>>(a);
   RT_CHECK_LAUNCH();
@@ -582,5 +584,17 @@ int rt_v2_varlen_fwd(const rt_varlen::VarlenArgs& a, int max_len, bool train, hi
 int rt_v2_varlen_bwd(const rt_varlen::VarlenArgs& a, int max_len, hipStream_t stream) {
   if (a.hd == 64) return launch_bwd<64, 8>(a, max_len, stream);
   if (a.hd == 32) return launch_bwd<32, 8>(a, max_len, stream);
+  return RT_ERR_UNSUPPORTED;
+}
+
+// bidirectional (no causal mask, no pad keys): BERT4Rec's key-padding-masked window on packed rows
+int rt_v2_bidir_fwd(const rt_varlen::VarlenArgs& a, int max_len, bool train, hipStream_t stream) {
+  if (a.hd == 64) return train ? launch_fwd<64, 8, true, false>(a, max_len, stream) : launch_fwd<64, 8, false, false>(a, max_len, stream);
+  if (a.hd == 32) return train ? launch_fwd<32, 8, true, false>(a, max_len, stream) : launch_fwd<32, 8, false, false>(a, max_len, stream);
+  return RT_ERR_UNSUPPORTED;
+}
+int rt_v2_bidir_bwd(const rt_varlen::VarlenArgs& a, int max_len, hipStream_t stream) {
+  if (a.hd == 64) return launch_bwd<64, 8, false>(a, max_len, stream);
+  if (a.hd == 32) return launch_bwd<32, 8, false>(a, max_len, stream);
   return RT_ERR_UNSUPPORTED;
 }

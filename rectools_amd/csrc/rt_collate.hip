@@ -113,6 +113,49 @@ __global__ __launch_bounds__(256) void collate_packed_kernel(PackedArgs a) {
   if (a.train) { a.y[r] = yi; a.yw[r] = w; }
 }
 
+// BERT4Rec on packed rows (bert4rec.py:109-153 / 182-193): train — session b shows its last n = cu[b+1] - cu[b] items, the masking draws
+// are read at the PADDED position of the row (b, window - n + j), so that the packed batch masks exactly what `rt_collate` mode 3 masks
+// when it is fed the same [B, window] draws; recommend — n - 1 history items and the MASK token as the last row.
+struct PackedBertArgs {
+  PackedArgs p;
+  int window; const float* probs; const long long* rand_ids; const long long* draw_rows; float mask_prob; long long mask_id;
+};
+
+__global__ __launch_bounds__(256) void collate_packed_bert_kernel(PackedBertArgs q) {
+  const PackedArgs& a = q.p;
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= a.rows) return;
+  long long xi = 0, yi = 0, di = 0; float w = 0.f;
+  if (r < a.cu[a.B]) {
+    int lo = 0, hi = a.B;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (a.cu[mid] <= r) lo = mid; else hi = mid;
+    }
+    const long long c0 = a.cu[lo], n = a.cu[lo + 1] - c0, j = r - c0;
+    const long long end = a.offsets[a.idx[lo] + 1];
+    di = n - 1 - j;
+    if (a.train) {
+      const long long src = end - n + j;
+      const long long it = a.items[src];
+      w = a.weights[src];
+      const long long o = (q.draw_rows != nullptr ? q.draw_rows[lo] : (long long)lo) * q.window + (q.window - n + j);
+      const float pr = q.probs[o];
+      xi = it;
+      if (pr < q.mask_prob) {
+        yi = it;
+        const float pj = pr / q.mask_prob;
+        if (pj < 0.8f) xi = q.mask_id;
+        else if (pj < 0.9f) xi = q.rand_ids[o];
+      }
+    } else {
+      xi = j == n - 1 ? q.mask_id : a.items[end - (n - 1) + j];
+    }
+  }
+  a.x[r] = xi; a.dist[r] = di;
+  if (a.train) { a.y[r] = yi; a.yw[r] = w; }
+}
+
 // a11 — CatalogUniformSampler.get_negatives (negative_sampler.py:58-73): n ids uniform in [low, high), no rejection of
 // positives.  Counter-based (Philox4x32-10): element e is word (e & 3) of philox(seed, subsequence = e >> 2, offset), so a
 // batch is a pure function of (seed, offset) — reproducible whatever the launch geometry — and `offset` (the step counter)
@@ -172,6 +215,32 @@ int rt_collate_packed(const int64_t* offsets, const int64_t* items, const float*
   a.train = train ? 1 : 0; a.x = reinterpret_cast<long long*>(x); a.y = reinterpret_cast<long long*>(y); a.yw = yw;
   a.dist = reinterpret_cast<long long*>(dist);
   collate_packed_kernel<<<(rows + 255) / 256, 256, 0, stream>>>(a);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+// Packed BERT4Rec batch.  train = 1: cu[b+1] - cu[b] = min(session length, window) rows; probs / rand_ids [B, window] are the draws of
+// `rt_collate` mode 3 (read at the row's padded position), y = the item where the position was picked, else 0.  draw_rows [B] or NULL:
+// the row of probs / rand_ids session b reads (a loop that re-orders the sessions of a batch keeps every session on the draws of its
+// original slot); NULL = b.  train = 0: min(session length, window - 1) + 1 rows, the last one the MASK token (bert4rec.py:182-193).
+int rt_collate_packed_bert(const int64_t* offsets, const int64_t* items, const float* weights, const int64_t* idx, const int64_t* cu_seqlens,
+                           int32_t B, int32_t rows, int32_t window, int32_t train, const float* probs, const int64_t* rand_ids,
+                           const int64_t* draw_rows, float mask_prob, int64_t mask_id, int64_t* x, int64_t* y, float* yw, int64_t* dist, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (B < 0 || rows < 0 || window <= 0) return RT_ERR_INVALID_ARG;
+  if (rows == 0) return RT_OK;
+  if (offsets == nullptr || items == nullptr || idx == nullptr || cu_seqlens == nullptr || x == nullptr || dist == nullptr)
+    return RT_ERR_INVALID_ARG;
+  if (train && (y == nullptr || yw == nullptr || weights == nullptr || probs == nullptr || rand_ids == nullptr)) return RT_ERR_INVALID_ARG;
+  PackedBertArgs q{};
+  PackedArgs& a = q.p;
+  a.offsets = reinterpret_cast<const long long*>(offsets); a.items = reinterpret_cast<const long long*>(items); a.weights = weights;
+  a.idx = reinterpret_cast<const long long*>(idx); a.cu = reinterpret_cast<const long long*>(cu_seqlens); a.B = B; a.rows = rows;
+  a.train = train ? 1 : 0; a.x = reinterpret_cast<long long*>(x); a.y = reinterpret_cast<long long*>(y); a.yw = yw;
+  a.dist = reinterpret_cast<long long*>(dist);
+  q.window = window; q.probs = probs; q.rand_ids = reinterpret_cast<const long long*>(rand_ids);
+  q.draw_rows = reinterpret_cast<const long long*>(draw_rows); q.mask_prob = mask_prob; q.mask_id = mask_id;
+  collate_packed_bert_kernel<<<(rows + 255) / 256, 256, 0, stream>>>(q);
   RT_CHECK_LAUNCH();
   return RT_OK;
 }

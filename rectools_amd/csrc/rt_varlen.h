@@ -47,3 +47,5 @@ __device__ __forceinline__ int pads_kept(unsigned long long seed, unsigned bh, u
 // Each returns RT_ERR_UNSUPPORTED when the shape does not fit (the caller then takes the first-form kernels).
 int rt_v2_varlen_fwd(const rt_varlen::VarlenArgs& a, int max_len, bool train, hipStream_t stream);
 int rt_v2_varlen_bwd(const rt_varlen::VarlenArgs& a, int max_len, hipStream_t stream);
+int rt_v2_bidir_fwd(const rt_varlen::VarlenArgs& a, int max_len, bool train, hipStream_t stream);
+int rt_v2_bidir_bwd(const rt_varlen::VarlenArgs& a, int max_len, hipStream_t stream);

@@ -26,7 +26,7 @@ from . import checkpoint as ckpt
 from . import lightning as hl
 from . import nn as hnn
 from . import ops
-from .data_preparator import (BERT4RecDataPreparator, CatalogUniformSampler, DeviceSequenceStore, SASRecDataPreparator,
+from .data_preparator import (MASKING_VALUE, BERT4RecDataPreparator, CatalogUniformSampler, DeviceSequenceStore, SASRecDataPreparator,
                               SequenceStore, TransformerDataPreparatorBase, TransformerNegativeSamplerBase, epoch_permutation,
                               shard_indices)
 from .dataset import Columns
@@ -61,6 +61,10 @@ def _dist_info() -> tp.Tuple[int, int]:
     return 0, 1
 
 
+# the data preparators whose batches have a packed (padding-free) twin on the device: `rt_collate_packed` / `rt_collate_packed_bert`
+_PACKED_PREPARATORS = ("SASRecDataPreparator", "BERT4RecDataPreparator")
+
+
 class _TrainLoop:
     """One rank's training stream: the session store lives in HBM (`DeviceSequenceStore`), an epoch is a permutation of
     the sessions sharded DistributedSampler-style, and `step()` is one optimiser step on the next batch — device collate
@@ -84,11 +88,13 @@ class _TrainLoop:
         # packed training batches (no padding rows): the default wherever the stack offers it (causal SASRec blocks,
         # head size 32 / 64); RT_PACKED_TRAIN=0 keeps the padded [B, L] window (the cross-check of tests/test_packed_gpu.py)
         tm = lm.torch_model
-        self.packed = (os.environ.get("RT_PACKED_TRAIN", "1") != "0" and type(self.dp).__name__ == "SASRecDataPreparator"
+        self.bert = type(self.dp).__name__ == "BERT4RecDataPreparator"
+        self.packed = (os.environ.get("RT_PACKED_TRAIN", "1") != "0" and type(self.dp).__name__ in _PACKED_PREPARATORS
                        and not self.dp.add_unix_ts and not (self.dp.extra_cols or [])
                        and getattr(tm.transformer_layers, "packed_ok", None) is not None
                        and getattr(tm, "_fused_pos", lambda: False)()
-                       and tm.transformer_layers.packed_ok(model.n_factors, self.dp.session_max_len, tm.use_causal_attn))
+                       and tm.transformer_layers.packed_ok(model.n_factors, self.dp.session_max_len, tm.use_causal_attn,
+                                                           tm.use_key_padding_mask))
 
     def begin_epoch(self, epoch: int) -> None:
         perm = epoch_permutation(len(self.store), epoch, self.seed, self.dp.shuffle_train)
@@ -100,7 +106,7 @@ class _TrainLoop:
             # uploaded once: a step then needs no device -> host round trip to learn its row count
             B, L = self.batch_size, self.dp.session_max_len
             off = np.asarray(self.store.offsets, dtype=np.int64)
-            lens = np.clip(off[mine + 1] - off[mine] - 1, 0, L)
+            lens = np.clip(off[mine + 1] - off[mine] - (0 if self.bert else 1), 0, L)   # SASRec: x = tail[:-1]; BERT4Rec: the tail itself
             nb = -(-len(mine) // B)
             # longest session first INSIDE every batch (which sessions form a batch is untouched; their order in it carries no
             # meaning for the loss): the attention kernels run one workgroup per (session, head) in row order, a workgroup's work grows
@@ -109,6 +115,8 @@ class _TrainLoop:
             key = (np.arange(len(mine)) // B) * (L + 1) + (L - lens)
             srt = np.argsort(key, kind="stable")
             mine, lens = mine[srt], lens[srt]
+            # BERT4Rec draws its masks per slot of the batch: every session keeps the draws of the slot the unsorted batch gave it
+            self._slots = torch.from_numpy(np.ascontiguousarray(srt % B, dtype=np.int64)).to(self.device) if self.bert else None
             self.mine_t = torch.from_numpy(np.ascontiguousarray(mine, dtype=np.int64)).to(self.device)
             grid = np.zeros((nb, B), dtype=np.int64)
             grid.reshape(-1)[:len(mine)] = lens
@@ -164,7 +172,15 @@ class _TrainLoop:
         rows = max((n + 127) // 128 * 128, 128)
         cu = self._cu_dev[bi, :nb + 1]
         full = nb == self.batch_size
-        x, y, yw, dist = ops.collate_packed(self.dstore.offsets, self.dstore.items, self.dstore.weights, idx, cu, rows, train=True)
+        if self.bert:   # the draws of `BERT4RecDataPreparator.collate_train_device`, in its order: the packed batch masks the same positions
+            L = self.dp.session_max_len
+            probs = torch.rand((nb, L), dtype=torch.float32, device=self.device)
+            rand_ids = torch.randint(self.dp.n_item_extra_tokens, self.dp.item_id_map.size, (nb, L), dtype=torch.int64, device=self.device)
+            x, y, yw, dist = ops.collate_packed_bert(self.dstore.offsets, self.dstore.items, self.dstore.weights, idx, cu, rows, L, True,
+                                                     self.dp.extra_token_ids[MASKING_VALUE], probs, rand_ids, self.dp.mask_prob,
+                                                     draw_rows=self._slots[self.pos - self.batch_size:self.pos - self.batch_size + nb])
+        else:
+            x, y, yw, dist = ops.collate_packed(self.dstore.offsets, self.dstore.items, self.dstore.weights, idx, cu, rows, train=True)
         batch: tp.Dict[str, tp.Any] = {"x": x, "y": y, "yw": yw, "dist": dist, "cu": cu, "window": self.dp.session_max_len, "n_rows": n}
         if full and rows > n and rows - n <= self.dp.session_max_len:
             batch["cu_attn"] = self._cu_dev[bi]        # [B + 2]: the sessions + the tail as a session of its own (see begin_epoch)
@@ -743,12 +759,14 @@ class TransformerModelBase:
             bs = self._encode_batch_size()
             # packed encoder (no padding rows: 45 % of the [B, L] window at ML-20M scale) where the stack offers it; RT_PACKED=0
             # keeps the padded window.  Same encodings up to fp32 rounding (tests/test_packed_gpu.py).
-            packed = os.environ.get("RT_PACKED", "1") != "0" and lm.torch_model.can_encode_packed(item_embs.shape[1], dp.session_max_len)
+            packed = os.environ.get("RT_PACKED", "1") != "0" and type(dp).__name__ in _PACKED_PREPARATORS \
+                and not dp.add_unix_ts and lm.torch_model.can_encode_packed(item_embs.shape[1], dp.session_max_len)
+            mask_id = dp.extra_token_ids[MASKING_VALUE] if type(dp).__name__ == "BERT4RecDataPreparator" else None
             unsort = None
             if packed:   # packed row offsets of every encoder launch, cut on the host, one upload
                 L = dp.session_max_len
                 n_launch = -(-n_valid // bs)
-                lens_v = np.minimum(lens_h[valid_h], L)
+                lens_v = np.minimum(lens_h[valid_h], L) if mask_id is None else np.minimum(lens_h[valid_h], L - 1) + 1
                 enc_rows = valid_rows     # request order: an encoder launch holds >= 1024 sessions x heads = 16 workgroup rounds — sorting them
                 #                           by length (as the 128-session training batches are) bought nothing and cost a host argsort
                 grid = np.zeros((n_launch, bs), dtype=np.int64)
@@ -760,7 +778,7 @@ class TransformerModelBase:
                 nb = min(bs, n_valid - b0)
                 if packed:
                     outs.append(lm.torch_model.encode_last_packed(offsets, item_s, enc_rows[b0:b0 + nb], dp.session_max_len, item_embs,
-                                                                  cu=cu_d[bi, :nb + 1], n_rows=int(cu_h[bi, nb])))
+                                                                  cu=cu_d[bi, :nb + 1], n_rows=int(cu_h[bi, nb]), mask_id=mask_id))
                     continue
                 batch = dp.collate_recommend_device(dstore, valid_rows[b0:b0 + nb])
                 outs.append(lm.torch_model.encode_last(batch, item_embs))   # last-position encodings, [b, d]

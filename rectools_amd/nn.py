@@ -414,14 +414,14 @@ class SASRecTransformerLayers(TransformerLayersBase):
         last = ops.mul_mask(last, None, ids.view(B, L)[:, L - 1].contiguous())
         return self.last_layernorm(last)
 
-    def packed_ok(self, n_factors: int, window: int, causal: bool) -> bool:
+    def packed_ok(self, n_factors: int, window: int, causal: bool, keypad: bool = False) -> bool:
         """Can recommend() encode packed sessions with this stack?  Causal attention (the closed form of the pad keys needs left
         padding + a causal mask, or no pad keys at all), ReLU feed-forward with biases, head size 32 / 64, K / V image in LDS."""
         blocks = list(self.transformer_blocks)
         return bool(blocks) and causal and all(b.packed_ok() for b in blocks) and \
             ops.mha_varlen_supported(blocks[0].multi_head_attn.n_heads, n_factors, window)
 
-    def forward_packed_train(self, seqs, cu, B, window, keypad, rows_real=None):
+    def forward_packed_train(self, seqs, cu, B, window, keypad, rows_real=None, causal=True):
         """Training forward over packed rows, [Np, d] (every row is a real position or belongs to the unused tail).  rows_real: the
         number of session rows when the caller knows it on the host (selects the native block executor)."""
         planes = self._fresh_planes() if rows_real is not None else None
@@ -444,7 +444,7 @@ class SASRecTransformerLayers(TransformerLayersBase):
         cached[1].refresh()
         return cached[1] if cached[1].ok else None
 
-    def forward_last_packed(self, seqs, cu, B, window, keypad, rows_real=None):
+    def forward_last_packed(self, seqs, cu, B, window, keypad, rows_real=None, causal=True):
         """[B, d] encodings of the last position from PACKED rows: every block input is the real rows only — the
         reference masks pad rows to zero before each block (sasrec.py:300) and their only trace, the pad keys a causal block
         without key-padding masks shows to every query, is the virtual key of `rt_mha_varlen_*`."""
@@ -487,6 +487,38 @@ class PreLNTransformerLayer(nn.Module):
         x1 = self.multi_head_attn.out_proj(a, residual=_take_last(seqs, B, L))
         return self.feed_forward(self.layer_norm_2(x1), residual=x1)
 
+    def forward_packed(self, seqs, cu, B, window, causal, covers_all_rows=False):
+        """The block over PACKED sessions ([Np, d], real positions only): with key-padding masks the reference's pad positions are
+        seen by no real query (net_blocks.py:236-262 under torch_backbone.py:254's mask), so dropping their rows changes nothing for
+        the real ones.  Same ops as `forward`; the attention is `ops.mha_varlen_qkv` on the packed in_proj output."""
+        p = self.p if self.training else 0.0
+        ln1, ln2, mha = self.layer_norm_1, self.layer_norm_2, self.multi_head_attn
+        h, skip = ops.layer_norm_skip(seqs, ln1.weight, ln1.bias, ln1.eps)
+        qkv = ops.linear(h, mha.in_proj_weight, mha.in_proj_bias)
+        a = ops.mha_varlen_qkv(qkv, cu, B, mha.n_heads, window, causal, p, covers_all_rows)
+        if p > 0:
+            seqs = ops.dropout_add(mha.out_proj(a), skip, p)
+            g, skip = ops.layer_norm_skip(seqs, ln2.weight, ln2.bias, ln2.eps)
+            seqs = ops.dropout_add(self.feed_forward(g), skip, p)
+            return ops.dropout(seqs, p)  # dropout_3 (net_blocks.py:260)
+        seqs = mha.out_proj(a, residual=skip)
+        g, skip = ops.layer_norm_skip(seqs, ln2.weight, ln2.bias, ln2.eps)
+        return self.feed_forward(g, residual=skip)
+
+    def forward_last_packed(self, seqs, cu, B, window, causal):
+        """Inference: the block's output at the last row of every packed session, [B, d] (cf. `forward_last`): keys / values of every
+        row, one query per session (`rt_mha_varlen_last_fwd`: the last query sees its whole session, causal or not)."""
+        mha, d = self.multi_head_attn, seqs.shape[1]
+        last_rows = cu[1:B + 1] - 1
+        h = self.layer_norm_1(seqs)
+        kv = ops.linear(h, mha.in_proj_weight[d:], mha.in_proj_bias[d:])            # [Np, 2d]
+        q = ops.linear(h.index_select(0, last_rows), mha.in_proj_weight[:d], mha.in_proj_bias[:d])
+        a = torch.empty((B, d), dtype=torch.float32, device=seqs.device)
+        ops._c("rt_mha_varlen_last_fwd", q, d, kv, 2 * d, kv[:, d:], 2 * d, cu, None, None, B, mha.n_heads, d // mha.n_heads,   # pylint: disable=protected-access
+               window, window, a, d)
+        x1 = mha.out_proj(a, residual=seqs.index_select(0, last_rows))
+        return self.feed_forward(self.layer_norm_2(x1), residual=x1)
+
 
 class PreLNTransformerLayers(TransformerLayersBase):
     def __init__(self, n_blocks: int, n_factors: int, n_heads: int, dropout_rate: float, ff_factors_multiplier: int = 4,
@@ -507,6 +539,28 @@ class PreLNTransformerLayers(TransformerLayersBase):
         for blk in blocks[:-1]:
             seqs = blk(seqs, ids, B, L, causal, keypad)
         return blocks[-1].forward_last(seqs, ids, B, L, causal, keypad)
+
+    def packed_ok(self, n_factors: int, window: int, causal: bool, keypad: bool = False) -> bool:
+        """Packed rows serve this stack when the pad positions are masked as keys (BERT4Rec's default, bert4rec.py:331): nothing
+        re-masks the rows between Pre-LN blocks (net_blocks.py:290-310), so without the key-padding mask the pad rows carry state
+        that real queries read, and the padded window has to stay."""
+        blocks = list(self.transformer_blocks)
+        if not blocks or not keypad:
+            return False
+        heads = blocks[0].multi_head_attn.n_heads
+        return ops.mha_varlen_supported(heads, n_factors, window) if causal else ops.mha_bidir_supported(heads, n_factors, window)
+
+    def forward_packed_train(self, seqs, cu, B, window, keypad, rows_real=None, causal=False):
+        covers = rows_real is not None and int(rows_real) == int(seqs.shape[0])
+        for blk in self.transformer_blocks:
+            seqs = blk.forward_packed(seqs, cu, B, window, causal, covers)
+        return seqs
+
+    def forward_last_packed(self, seqs, cu, B, window, keypad, rows_real=None, causal=False):
+        blocks = list(self.transformer_blocks)
+        for blk in blocks[:-1]:
+            seqs = blk.forward_packed(seqs, cu, B, window, causal)
+        return blocks[-1].forward_last_packed(seqs, cu, B, window, causal)
 
 
 class LiGRLayer(nn.Module):
@@ -780,32 +834,39 @@ class TransformerTorchBackbone(nn.Module):
         """Does `encode_last_packed` serve this backbone (inference, a layer stack with a packed forward, see its `packed_ok`)?"""
         ok = getattr(self.transformer_layers, "packed_ok", None)
         return ok is not None and self._fused_pos() and not self.training and not torch.is_grad_enabled() \
-            and ok(n_factors, window, self.use_causal_attn)
+            and ok(n_factors, window, self.use_causal_attn, self.use_key_padding_mask)
 
     def encode_last_packed(self, offsets: torch.Tensor, items: torch.Tensor, rows: torch.Tensor, window: int,
                            item_embs: tp.Optional[torch.Tensor] = None, cu: tp.Optional[torch.Tensor] = None,
-                           n_rows: tp.Optional[int] = None) -> torch.Tensor:
+                           n_rows: tp.Optional[int] = None, mask_id: tp.Optional[int] = None) -> torch.Tensor:
         """-> [B, d] = `encode_last` of the sessions `rows` of a CSR session store (`offsets`, `items`: model item ids, oldest
         first), without ever building the padded [B, L] batch: the last `window` items of every session are gathered into ONE
         packed row block (embedding + positional row by distance from the session's end, torch_backbone.py:245-246 /
         net_blocks.py:388-399 with inverse positions) and the stack runs on those rows only.  Every session must hold at least
         one item.  `cu` [B+1] / `n_rows` = cu[-1]: the packed row offsets cut by the caller on the HOST (no device round trip);
-        without them they are taken from the device offsets (one synchronisation)."""
+        without them they are taken from the device offsets (one synchronisation).  mask_id: the BERT4Rec batch instead — the last
+        window - 1 items and the MASK token as the last row of every session (bert4rec.py:182-193)."""
         table = self.item_model.table if item_embs is None else item_embs
         d = table.shape[1]
         B = int(rows.numel())
         if cu is None or n_rows is None:
             lens = torch.clamp(offsets[rows + 1] - offsets[rows], max=window)
+            if mask_id is not None:
+                lens = torch.clamp(offsets[rows + 1] - offsets[rows], max=window - 1) + 1
             cu = torch.zeros((B + 1,), dtype=torch.int64, device=offsets.device)
             torch.cumsum(lens, 0, out=cu[1:])
             n_rows = int(cu[-1])
         Np = (n_rows + 127) // 128 * 128
-        ids, dist = ops.collate_packed(offsets, items, None, rows, cu, Np, train=False)
+        if mask_id is None:
+            ids, dist = ops.collate_packed(offsets, items, None, rows, cu, Np, train=False)
+        else:
+            ids, dist = ops.collate_packed_bert(offsets, items, None, rows, cu, Np, window, False, mask_id)
         pos = self.pos_encoding_layer.pos_emb.weight if self.pos_encoding_layer.pos_emb is not None else None
         scale = float(d) ** 0.5 if self.pos_encoding_layer.use_scale_factor else 1.0
         x = torch.empty((Np, d), dtype=torch.float32, device=table.device)
         ops._c("rt_embed_packed_fwd", ids, dist, table, pos, float(scale), Np, d, 0.0, 0, 0, x)
-        return self.transformer_layers.forward_last_packed(x, cu, B, window, self.use_key_padding_mask, rows_real=n_rows)
+        return self.transformer_layers.forward_last_packed(x, cu, B, window, self.use_key_padding_mask, rows_real=n_rows,
+                                                           causal=self.use_causal_attn)
 
     def encode_packed_train(self, ids: torch.Tensor, dist: torch.Tensor, cu: torch.Tensor, B: int, window: int,
                             item_embs: tp.Optional[torch.Tensor] = None, rows_real: tp.Optional[int] = None,
@@ -821,8 +882,10 @@ class TransformerTorchBackbone(nn.Module):
         if cu_attn is not None and rows_real is not None:
             # cu_attn [B + 2]: the unused tail of the row block as one more session of the attention — every row of every buffer of
             # the blocks is then written with finite values (zero gradients flow into the tail), no tail memsets
-            return self.transformer_layers.forward_packed_train(seqs, cu_attn, B + 1, window, self.use_key_padding_mask, int(seqs.shape[0]))
-        return self.transformer_layers.forward_packed_train(seqs, cu, B, window, self.use_key_padding_mask, rows_real)
+            return self.transformer_layers.forward_packed_train(seqs, cu_attn, B + 1, window, self.use_key_padding_mask, int(seqs.shape[0]),
+                                                                causal=self.use_causal_attn)
+        return self.transformer_layers.forward_packed_train(seqs, cu, B, window, self.use_key_padding_mask, rows_real,
+                                                            causal=self.use_causal_attn)
 
     def encode_last(self, batch: Batch, item_embs: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
         """-> [B, d] = encode_sessions(batch)[:, -1, :], the only rows recommend() uses (lightning.py:393-397).  Layer stacks

@@ -482,6 +482,22 @@ def collate_packed(offsets: torch.Tensor, items: torch.Tensor, weights: tp.Optio
     return (x, y, yw, dist) if train else (x, dist)
 
 
+def collate_packed_bert(offsets: torch.Tensor, items: torch.Tensor, weights: tp.Optional[torch.Tensor], idx: torch.Tensor, cu: torch.Tensor,
+                        rows: int, window: int, train: bool, mask_id: int, probs: tp.Optional[torch.Tensor] = None,
+                        rand_ids: tp.Optional[torch.Tensor] = None, mask_prob: float = 0.0,
+                        draw_rows: tp.Optional[torch.Tensor] = None) -> tp.Tuple[torch.Tensor, ...]:
+    """`rt_collate_packed_bert`: -> (x, dist) or, train, (x, y, yw, dist), each [rows]."""
+    dev = offsets.device
+    B = int(idx.numel())
+    x = torch.empty((rows,), dtype=torch.int64, device=dev)
+    dist = torch.empty((rows,), dtype=torch.int64, device=dev)
+    y = torch.empty((rows,), dtype=torch.int64, device=dev) if train else None
+    yw = torch.empty((rows,), dtype=torch.float32, device=dev) if train else None
+    _c("rt_collate_packed_bert", offsets, items, weights if train else None, idx, cu, B, rows, int(window), 1 if train else 0,
+       probs, rand_ids, draw_rows, float(mask_prob), int(mask_id), x, y, yw, dist)
+    return (x, y, yw, dist) if train else (x, dist)
+
+
 class BagStructure:
     """Static item -> category-value structure of a CatFeaturesItemNet, plus its transpose cut into chunks for the
     backward reduction (include/rectools_hip.h, K1b).  Built once per model from the reference's three buffers."""
@@ -1457,6 +1473,78 @@ class _MHAVarlen(torch.autograd.Function):
 def mha_varlen(q: torch.Tensor, kv: torch.Tensor, bk: tp.Optional[torch.Tensor], bv: tp.Optional[torch.Tensor], cu: torch.Tensor, B: int,
                H: int, window: int, p: float) -> torch.Tensor:
     return _MHAVarlen.apply(_chk(q, "mha_varlen").contiguous(), _chk(kv, "mha_varlen").contiguous(), bk, bv, cu, B, H, window, p)
+
+
+class _MHAVarlenQKV(torch.autograd.Function):
+    """Softmax attention over PACKED sessions from one packed projection qkv [Np, 3d] (q | k | v column blocks, the layout
+    `nn.MultiheadAttention`'s in_proj produces), key-padding-masked windows (no pad keys).  causal: `rt_mha_varlen_train_fwd` /
+    `_bwd`; bidirectional (BERT4Rec, bert4rec.py:200): `rt_mha_varlen_bidir_fwd` / `_bwd`.  cu [B+1] (the unused tail of the row block
+    may ride along as one more session, see `TransformerTorchBackbone.encode_packed_train`)."""
+
+    @staticmethod
+    def forward(ctx, qkv, cu, B, H, window, causal, p, covers_all_rows):
+        Np, d3 = qkv.shape
+        d = d3 // 3
+        hd = d // H
+        alloc = torch.empty if covers_all_rows else torch.zeros                 # rows behind the last session stay zero
+        o = alloc((Np, d), dtype=torch.float32, device=qkv.device)
+        lse = alloc((Np, H), dtype=torch.float32, device=qkv.device)
+        seed = 0
+        if p > 0:
+            s0, sid = RNG.next()
+            seed = (s0 + 0xD1B54A32D192ED03 * sid) & 0xFFFFFFFFFFFFFFFF
+        q, k, v = qkv, qkv[:, d:], qkv[:, 2 * d:]
+        if causal:
+            _c("rt_mha_varlen_train_fwd", q, d3, k, d3, v, d3, cu, None, None, B, H, hd, window, window, float(p), seed, o, d, lse)
+        else:
+            _c("rt_mha_varlen_bidir_fwd", q, d3, k, d3, v, d3, cu, B, H, hd, window, float(p), seed, o, d, lse)
+        ctx.save_for_backward(qkv, cu, o, lse)
+        ctx.meta = (B, H, window, causal, p, seed, covers_all_rows)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, cu, o, lse = ctx.saved_tensors
+        B, H, window, causal, p, seed, covers_all_rows = ctx.meta
+        Np, d3 = qkv.shape
+        d = d3 // 3
+        hd = d // H
+        do = do.contiguous()
+        dqkv = (torch.empty_like if covers_all_rows else torch.zeros_like)(qkv)
+        delta = torch.empty((Np, H), dtype=torch.float32, device=qkv.device)
+        q, k, v = qkv, qkv[:, d:], qkv[:, 2 * d:]
+        if causal:
+            _c("rt_mha_varlen_bwd", q, d3, k, d3, v, d3, o, d, do, d, lse, cu, None, None, B, H, hd, window, window, float(p), seed,
+               dqkv, d3, dqkv[:, d:], d3, dqkv[:, 2 * d:], d3, delta, None)
+        else:
+            _c("rt_mha_varlen_bidir_bwd", q, d3, k, d3, v, d3, o, d, do, d, lse, cu, B, H, hd, window, float(p), seed,
+               dqkv, d3, dqkv[:, d:], d3, dqkv[:, 2 * d:], d3, delta)
+        return dqkv, None, None, None, None, None, None, None
+
+
+def mha_varlen_qkv(qkv: torch.Tensor, cu: torch.Tensor, B: int, H: int, window: int, causal: bool, p: float,
+                   covers_all_rows: bool = False) -> torch.Tensor:
+    return _MHAVarlenQKV.apply(_chk(qkv, "mha_varlen_qkv").contiguous(), cu, B, H, window, bool(causal), p, bool(covers_all_rows))
+
+
+def mha_varlen_qkv_infer(qkv: torch.Tensor, cu: torch.Tensor, B: int, H: int, window: int, causal: bool) -> torch.Tensor:
+    """Inference twin of `mha_varlen_qkv` (no lse, no dropout)."""
+    Np, d3 = qkv.shape
+    d = d3 // 3
+    o = torch.zeros((Np, d), dtype=torch.float32, device=qkv.device)
+    if causal:
+        _c("rt_mha_varlen_fwd", qkv, d3, qkv[:, d:], d3, qkv[:, 2 * d:], d3, cu, None, None, B, H, d // H, window, window, o, d)
+    else:
+        _c("rt_mha_varlen_bidir_fwd", qkv, d3, qkv[:, d:], d3, qkv[:, 2 * d:], d3, cu, B, H, d // H, window, 0.0, 0, o, d, None)
+    return o
+
+
+def mha_bidir_supported(n_heads: int, d: int, window: int) -> bool:
+    """`rt_mha_varlen_bidir_*` (bf16-plane kernels): head size 32 / 64, Q-or-K and V images of one (session, head) in the 160 KB of LDS
+    (backward: two images + lse / delta rows)."""
+    hd = d // n_heads
+    n32 = (window + 31) // 32 * 32
+    return hd in (32, 64) and d % n_heads == 0 and 2 * (window + 1) * 6 * hd + 8 * n32 <= 160 * 1024
 
 
 def mha_varlen_supported(n_heads: int, d: int, window: int) -> bool:
