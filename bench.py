@@ -167,7 +167,7 @@ def make_topk_workload(n_items: int, d: int, users_per_step: int, upp: int, rank
         nnz = int(filt.nnz)
     from rectools_amd.rank import DeviceCSR
 
-    ranker = HipRanker("dot", "cuda", users, items, batch_size=upp)
+    ranker = HipRanker("dot", "cuda", users, items, batch_size=upp or None)   # 0: the library's choice (two-stage top-k from 128 users up)
     sids = np.arange(users_per_step)
     # inputs resident in HBM before the timed region: factors, and the viewed-items CSR
     dfilt = DeviceCSR.from_scipy(filt, "cuda") if filt is not None else None
@@ -218,20 +218,27 @@ def run_topk(steps, warmup, rank, world, n_items, d, users_per_step, upp, with_f
     t = ev_ms * 1e-3
     gbs = bytes_per_launch / t / 1e9
     tfs = flops_per_launch / t / 1e12
-    hbm_bound = (bytes_per_launch / (HBM_PEAK_GBS * 1e9)) >= (flops_per_launch / (MFMA_F32_PEAK_TF * 1e12))
+    two_stage = ranker.two_stage_stats["calls"] > 0
+    # two-stage calls (rt_topk_score_two_stage) score on the bf16 matrix pipe: (h + m)(h' + m') = four bf16 products per fp32 product,
+    # so the pipe's roof for ALGORITHMIC fp32 flops is 2,500 / 4 TF; single-stage calls run the f32-input instruction (157.3 TF)
+    mfma_peak = MFMA_BF16_PEAK_TF / 4.0 if two_stage else MFMA_F32_PEAK_TF
+    hbm_bound = (bytes_per_launch / (HBM_PEAK_GBS * 1e9)) >= (flops_per_launch / (mfma_peak * 1e12))
     if n_items * d * 4 <= 200e6:
         hbm_bound = False  # catalog resident in L2 / Infinity Cache: the HBM roof does not apply
     roof = {
-        "kernel": "rt_topk_score call (seed prefix + topk stream kernel + merge; HIP events around the whole call)",
+        "kernel": ("rt_topk_score_two_stage call (users' hm image + coarse stream kernel on v_mfma_f32_32x32x16_bf16 + merge + exact pass "
+                   "over 64 candidates per user + the read of the proof flags; HIP events around the whole call)") if two_stage else
+                  "rt_topk_score call (seed prefix + topk stream kernel + merge; HIP events around the whole call)",
         "bound": "hbm" if hbm_bound else "mfma",
         "achieved": round(gbs if hbm_bound else tfs, 2),
-        "peak": HBM_PEAK_GBS if hbm_bound else MFMA_F32_PEAK_TF,
+        "peak": HBM_PEAK_GBS if hbm_bound else round(mfma_peak, 1),
         "unit": "GB/s" if hbm_bound else "TFLOP/s",
-        "frac": round((gbs / HBM_PEAK_GBS) if hbm_bound else (tfs / MFMA_F32_PEAK_TF), 4),
+        "frac": round((gbs / HBM_PEAK_GBS) if hbm_bound else (tfs / mfma_peak), 4),
+        "two_stage": dict(ranker.two_stage_stats) if two_stage else None,
         "traffic": load_traffic(name),
         "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_flops_per_launch": flops_per_launch,
         "avg_launch_ms": round(ev_ms, 4), "hbm_GBps": round(gbs, 1), "mfma_f32_TFLOPs": round(tfs, 2),
-        "users_per_launch": users_per_step, "users_per_register_tile": upp,
+        "users_per_launch": users_per_step, "users_per_register_tile": upp or "library default",
     }
     return value, wall, roof, info
 
@@ -501,7 +508,7 @@ def topk_leg(kind, args, rank, world, cpu_baseline):
     if kind == "recommend":
         V, d = synth.ML_20M["n_items"], 256
         ups = args.users_per_step or 16384
-        upp = args.users_per_pass or 64
+        upp = args.users_per_pass   # 0 = the library's choice
         steps, warmup = args.rec_steps, 3
         metric = "recommend() users/sec @k=10 (SASRec d=256, ML-20M-shaped catalog, filter_viewed)"
         workload = f"recommend top-k: 26744 items x d256 fp32, {ups} users/step, k=10, viewed-filter CSR"
@@ -509,7 +516,7 @@ def topk_leg(kind, args, rank, world, cpu_baseline):
     else:
         V, d = 5_000_000, 512
         ups = args.users_per_step or 16   # 16 users/launch: the HBM-bound regime (AI = B/2 flop/B; 32 users is the fp32 ridge)
-        upp = args.users_per_pass or (16 if ups <= 16 else 32 if ups <= 32 else 64)
+        upp = args.users_per_pass or (16 if ups <= 16 else 32 if ups <= 32 else 64 if ups < 128 else 0)
         steps, warmup = args.topk_steps, 2
         metric = "full-catalog top-k users/sec @k=10 (5M x 512 fp32 catalog)"
         workload = f"top-k scoring: 5,000,000 items x d512 fp32 (10.24 GB), {ups} users/step, k=10"
@@ -517,7 +524,7 @@ def topk_leg(kind, args, rank, world, cpu_baseline):
     value, wall, roof, info = run_topk(steps, warmup, rank, world, V, d, ups, upp, with_filter, name)
     rec = {"metric": metric, "value": round(value, 2), "unit": "users/s", "steps": steps, "warmup": warmup,
            "ms_per_step": round(wall / steps * 1e3, 4), "dtype": "fp32",
-           "config": {"workload": workload, "users_per_step": ups, "users_per_register_tile": upp, "parallelism": f"dp{world}"},
+           "config": {"workload": workload, "users_per_step": ups, "users_per_register_tile": upp or "library default", "parallelism": f"dp{world}"},
            "roofline": roof, "cpu_baseline": None}
     if cpu_baseline:
         torch.cuda.synchronize()

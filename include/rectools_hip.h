@@ -80,29 +80,31 @@ int rt_topk_score(const float* users, int64_t user_stride, const int64_t* user_r
 
 
 /* ------------------------------------------------------------------------------------------------
- * K12b  Two-stage exact top-k (OPT-IN, `HipRanker(..., two_stage=True)` / RT_TOPK_TWO_STAGE=1; the default path is
- * rt_topk_score).  Same result contract as rt_topk_score — the ids / order / fp32 scores TorchRanker.rank produces
- * (rank_torch.py:77-223) — but fp32 arithmetic is spent only on candidates that can still be in the top-k:
- *   1. rt_to_bf16_rows: bf16 images (round to nearest even) of the catalog (once per ranker) and of the users (per call),
- *      L2-normalised for cosine, plus the fp32 row norms.  dst [n_rows, d] dense, `rows` optional gather (NULL = 0..n-1).
- *   2. rt_topk_score_bf16: the streaming kernel of rt_topk_score over the images, v_mfma_f32_32x32x16_bf16 with fp32
- *      accumulation, keeping the best K_c >= k candidates by COARSE score (viewed-filter / whitelist as in rt_topk_score).
- *      |coarse - exact| <= c |u| |v| with c = 2^-8 + 2^-18 + d 2^-24, so when the K_c-th coarse score lies below the k-th
- *      by more than 2 c |u| max|v| nothing outside the candidates can be in the exact top-k (the host checks this per
- *      user and re-ranks with rt_topk_score otherwise).  Strides count bf16 elements; d % 64 == 0.
- *   3. rt_topk_rescore: exact fp32 scores (distance 0 dot / 1 cosine, the formulas of rt_topk_score) of the candidates:
- *      cand_ids [n_users, kc] catalog rows, cand_counts [n_users] valid entries per user (the rest get -inf).
+ * K12c  Two-stage exact top-k for dot products — the regime where rt_topk_score is bound by the f32-input matrix instruction
+ * (recommend(): thousands of users per catalog pass).  Same result contract as rt_topk_score — the ids / order / fp32 scores
+ * TorchRanker.rank produces (rank_torch.py:77-223) — with the f32-input instruction spent only on candidates:
+ *   1. rt_to_hm_rows: "hm image" of fp32 rows — every value x becomes the word (h << 16) | m, h = bf16 truncation of x, m = bf16
+ *      truncation of x - h (|x - h - m| < 2^-15 |x|) — plus the rows' fp32 L2 norms.  Same row geometry as the source (dst_stride in
+ *      32-bit words >= d); `rows` optional gather (NULL = 0..n-1).  The catalog's image is built once per ranker, the users' per call.
+ *   2. rt_topk_score_two_stage: stage 1 streams the images through rt_topk_score's selection machinery (viewed filter / whitelist as
+ *      there) with two v_mfma_f32_32x32x16_bf16 per four k — (h + m)(h' + m'), a quarter of the matrix-pipe time — and hands the k_cand
+ *      (32 or 64) best COARSE candidates per user to stage 2, which scores them again in the exact arithmetic of rt_topk_score's 32-wide
+ *      engine (same instruction, same k order: bit-identical scores) and orders them (score desc, position asc).
+ *      |coarse - exact| <= (2^-14 + 5 d 2^-24) |u| |v|; every pair stage 1 dropped had a coarse score <= tau_u (the shared bound at the
+ *      end of the pass, and the worst candidate's coarse score when the candidate set is full), so out_unproven[u] = 0 — the k-th exact
+ *      score clears tau_u by more than that error — PROVES the outputs of user u are exactly rt_topk_score's; out_unproven[u] = 1 (ties
+ *      or near-ties at the k-th place): rank those users with rt_topk_score.  users_hm [n_users, d] dense in call order; items_hm strided
+ *      and offset like `items`; d % 32 == 0, k <= 16.  Workspace: rt_topk_two_stage_workspace_bytes.
  * ------------------------------------------------------------------------------------------------ */
-int rt_to_bf16_rows(const float* src, int64_t src_stride, const int64_t* rows, int32_t n_rows, int32_t d, int32_t normalize,
-                    uint16_t* dst, float* norms, rt_stream_t stream);
-int rt_topk_score_bf16(const uint16_t* users_bf16, int64_t user_stride, int32_t n_users, const uint16_t* items_bf16,
-                       int64_t item_stride, const int64_t* whitelist, int64_t n_candidates, int64_t candidate_id_offset, int32_t d,
-                       int32_t k, const int64_t* filt_indptr, const int32_t* filt_indices, const int32_t* filt_hash,
-                       int64_t* out_ids, float* out_scores, int32_t* out_counts, void* workspace, size_t workspace_bytes,
-                       int32_t users_per_pass, rt_stream_t stream);
-int rt_topk_rescore(const float* users, int64_t user_stride, const int64_t* user_rows, int32_t n_users, const float* items,
-                    int64_t item_stride, int32_t d, int32_t distance, const int64_t* cand_ids, const int32_t* cand_counts,
-                    int32_t kc, float* out_scores, rt_stream_t stream);
+int rt_to_hm_rows(const float* src, int64_t src_stride, const int64_t* rows, int64_t n_rows, int32_t d, uint32_t* dst, int64_t dst_stride,
+                  float* norms, rt_stream_t stream);
+size_t rt_topk_two_stage_workspace_bytes(int32_t n_users, int64_t n_candidates, int32_t k, int32_t k_cand, int32_t users_per_pass);
+int rt_topk_score_two_stage(const float* users, int64_t user_stride, const int64_t* user_rows, int32_t n_users, const float* items,
+                            int64_t item_stride, const uint32_t* users_hm, const uint32_t* items_hm, const float* user_norms,
+                            float max_item_norm, const int64_t* whitelist, int64_t n_candidates, int64_t candidate_id_offset, int32_t d,
+                            int32_t k, int32_t k_cand, const int64_t* filt_indptr, const int32_t* filt_indices, const int32_t* filt_hash,
+                            int64_t* out_ids, float* out_scores, int32_t* out_counts, int32_t* out_unproven, void* workspace,
+                            size_t workspace_bytes, int32_t users_per_pass, rt_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K7  dense fp32 GEMM (f32-input MFMA):  C[M,N] = A . B^T (+ bias[n]) (+ R[m,n]) (relu)

@@ -14,6 +14,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));   // one 16-byte operand of v_mfma_f32_32x32x16_bf16
 
 // Last HIP failure seen by this library (file:line + hipGetErrorString), readable through rt_last_error().

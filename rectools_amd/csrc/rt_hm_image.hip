@@ -1,0 +1,69 @@
+// Two-stage exact top-k, the image builder (the coarse pass is topk_stream_kernel<..., HM = true>, the exact pass topk_replay_kernel,
+// both in rt_topk.hip):
+//   rt_to_hm_rows   fp32 rows -> "hm image": every value x becomes the 32-bit word (h << 16) | m with h = the bf16 TRUNCATION of x and
+//                   m = the bf16 truncation of x - h (exact subtraction), so x = h + m + l with |l| < 2^-15 |x|; plus the fp32 L2 norm of
+//                   every row (the coarse pass's error bound is c |u| |v|).  Same row geometry as the source: the streaming kernel reads
+//                   an image exactly as it reads fp32 rows.
+// The reference scores every (user, item) pair in fp32 (rank_torch.py:194-208); here the fp32-input matrix instruction is spent only on
+// candidates that can still be in the top-k.
+#include "rt_common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ unsigned hm_word(float x) {
+  const unsigned b = __float_as_uint(x);
+  const unsigned h = b & 0xFFFF0000u;
+  const float r = x - __uint_as_float(h);            // exact: the low 16 significand bits of x
+  return h | (__float_as_uint(r) >> 16);
+}
+
+// one wave per row; a lane owns float4 columns lane*4 + 256*t (d <= 2048)
+__global__ __launch_bounds__(256) void to_hm_rows_kernel(const float* __restrict__ src, long long src_stride,
+                                                         const long long* __restrict__ rows, long long n_rows, int d,
+                                                         unsigned* __restrict__ dst, long long dst_stride, float* __restrict__ norms) {
+  const int lane = threadIdx.x & 63;
+  const long long r = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  if (r >= n_rows) return;
+  const long long sr = rows ? rows[r] : r;
+  const float* x = src + sr * src_stride;
+  float ss = 0.f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int c = lane * 4 + 256 * t;
+    if (c < d) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + c);
+      ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+      u32x4 w;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[j] = hm_word(v[j]);
+      *reinterpret_cast<u32x4*>(dst + r * dst_stride + c) = w;
+    }
+  }
+  const float nrm = sqrtf(wave_sum_f(ss));
+  if (norms != nullptr && lane == 0) norms[r] = nrm;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_to_hm_rows(const float* src, int64_t src_stride, const int64_t* rows, int64_t n_rows, int32_t d, uint32_t* dst, int64_t dst_stride,
+                  float* norms, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (n_rows <= 0) return RT_OK;
+  if (src == nullptr || dst == nullptr || d <= 0 || (d & 3) != 0 || d > 2048 || (src_stride & 3) != 0 || (dst_stride & 3) != 0 ||
+      dst_stride < d || ((uintptr_t)src & 15) != 0 || ((uintptr_t)dst & 15) != 0 || n_rows > 0x7FFFFFFFLL * 4)
+    return RT_ERR_INVALID_ARG;
+  to_hm_rows_kernel<<<(unsigned)((n_rows + 3) / 4), 256, 0, stream>>>(src, src_stride, reinterpret_cast<const long long*>(rows), n_rows, d,
+                                                                      dst, dst_stride, norms);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+}  // extern "C"

@@ -538,11 +538,12 @@ __device__ __forceinline__ void wait_vmcnt() {
 // cycles in the wave that issues it (address VALU + the piece itself); with 6 pieces per 16 MFMAs that is a third of
 // a compute wave's time at 32 users per launch, exactly the regime where the kernel should be HBM-bound.  A loader
 // shares its SIMD's issue port with one compute wave, but its pieces overlap that wave's MFMA execution.
-// BF = true: the SAME ring over a bf16 image of users and catalog (rows of d/2 "floats" = d bf16: `a.d`, the strides and
-// the 16-byte DMA pieces count floats as before); one 16-byte LDS read is then one k = 16 operand of
-// v_mfma_f32_32x32x16_bf16 (fp32 accumulate) instead of four k = 2 fp32 operands — the coarse pass of the two-stage
-// top-k (rt_topk_score_bf16).  Dot products only: cosine runs on pre-normalised images.
-template <int TU, int NS, bool WL, bool LL, int NLD, bool BF = false>
+// HM = true: the coarse pass of the two-stage top-k (rt_topk_score_two_stage).  Users and catalog are "hm images" (rt_to_hm_rows): every
+// fp32 value x replaced by the 32-bit word (h << 16) | m, h = bf16 truncation of x, m = bf16 truncation of x - h (x - h - m < 2^-15 |x|).
+// Same geometry as the fp32 rows — same ring, same strides, same swizzle — and one 16-byte LDS read is one k = 16 operand of
+// v_mfma_f32_32x32x16_bf16 holding (m, h) pairs of four k positions: A . B sums h h' + m m', A with its halves swapped . B sums
+// h m' + m h': two bf16 instructions (a quarter of the matrix-pipe time of the four f32-input ones) give (h + m)(h' + m').  Dot products only.
+template <int TU, int NS, bool WL, bool LL, int NLD, bool HM = false>
 __global__ __launch_bounds__(NTHREADS + NLD * 64) void topk_stream_kernel(TopkArgs a) {
   constexpr int NISS = NLD ? NLD : 4;      // issuing waves
   constexpr int IPI = 16 / NISS;           // item pieces per issuer and stage (128 rows x 32 floats = 16 KiB = 16 pieces)
@@ -742,15 +743,25 @@ __global__ __launch_bounds__(NTHREADS + NLD * 64) void topk_stream_kernel(TopkAr
 #pragma unroll
       for (int s = 0; s < KC / 8; ++s) {
         f32x4 av = *reinterpret_cast<const f32x4*>(Ab + (((2 * s + half) ^ a_swz) << 2));
-        if constexpr (!BF) nrm_i += av[0] * av[0] + av[1] * av[1] + av[2] * av[2] + av[3] * av[3];
+        bf16x8 a_hm, a_mh;
+        if constexpr (HM) {
+          const u32x4 w = __builtin_bit_cast(u32x4, av);
+          u32x4 x;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) x[t] = __builtin_amdgcn_alignbit(w[t], w[t], 16);   // (h, m) -> (m, h)
+          a_hm = __builtin_bit_cast(bf16x8, w); a_mh = __builtin_bit_cast(bf16x8, x);
+        } else {
+          nrm_i += av[0] * av[0] + av[1] * av[1] + av[2] * av[2] + av[3] * av[3];
+        }
 #pragma unroll
         for (int tu = 0; tu < TU; ++tu) {
           f32x4 bv = *reinterpret_cast<const f32x4*>(Ub + tu * 32 * KC + (((2 * s + half) ^ u_swz[tu]) << 2));
-          if constexpr (BF) {
-            // both operands take their 8 bf16 from the same 16-byte slot, so the k positions pair up whatever the
+          if constexpr (HM) {
+            // both operands take their four (m, h) pairs from the same 16-byte slot, so the k positions pair up whatever the
             // instruction's own numbering of them is (the sum over k is order-free)
-            acc[tu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
-                                                              acc[tu], 0, 0, 0);
+            const bf16x8 b8 = __builtin_bit_cast(bf16x8, bv);
+            acc[tu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mh, b8, acc[tu], 0, 0, 0);   // h m' + m h'
+            acc[tu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hm, b8, acc[tu], 0, 0, 0);   // h h' + m m'
           } else {
             nrm_u[tu] += bv[0] * bv[0] + bv[1] * bv[1] + bv[2] * bv[2] + bv[3] * bv[3];
 #pragma unroll
@@ -783,6 +794,8 @@ struct MergeArgs {
   float* compact_scores; int* compact_pos; long long compact_cap;  // per-user scratch
   const long long* whitelist; long long id_offset; int distance;
   long long* out_ids; float* out_scores; int* out_counts;
+  int out_k;          // entries extracted per user (0 = k).  The two-stage coarse pass takes k_cand >= k of them ...
+  int* out_pos;       // ... as candidate POSITIONS [n_users][out_k] (the exact pass needs them) instead of ids
 };
 
 template <int NT_MERGE>
@@ -821,8 +834,29 @@ __global__ __launch_bounds__(NT_MERGE) void topk_merge_kernel(MergeArgs m) {
   }
   __syncthreads();
 
+  const int out_k = m.out_k > 0 ? m.out_k : m.k;
+  const int n_out = total < out_k ? total : out_k;
+  // few entries (recommend(): thousands of users, a handful of lists each): rank sort — every thread counts the entries ahead of its
+  // own, one pass, no block-wide rounds
+  constexpr int RANK_SORT_MAX = 1024;
+  if (total <= RANK_SORT_MAX) {
+    __shared__ float r_s[RANK_SORT_MAX]; __shared__ int r_p[RANK_SORT_MAX];
+    for (int e = tid; e < total; e += NT_MERGE) { r_s[e] = cs[e]; r_p[e] = cp[e]; }
+    __syncthreads();
+    for (int e = tid; e < total; e += NT_MERGE) {
+      const float se = r_s[e]; const long long pe = r_p[e];
+      int rank = 0;
+      for (int o = 0; o < total; ++o) rank += better(r_s[o], (long long)r_p[o], se, pe) ? 1 : 0;
+      if (rank < n_out) {
+        if (m.out_pos != nullptr) m.out_pos[(long long)u * out_k + rank] = (int)pe;
+        else m.out_ids[(long long)u * out_k + rank] = m.whitelist ? m.whitelist[pe] : pe + m.id_offset;
+        m.out_scores[(long long)u * out_k + rank] = (m.distance == DIST_EUCLID) ? -se : se;
+      }
+    }
+    if (tid == 0) m.out_counts[u] = n_out;
+    return;
+  }
   // pass 2: k rounds of block-wide arg-best strictly below the previous winner
-  const int n_out = total < m.k ? total : m.k;
   float prev_s = INFINITY; long long prev_p = -1;
   for (int r = 0; r < n_out; ++r) {
     float bs = -INFINITY; long long bp = 0x7fffffffffffffffLL;
@@ -843,8 +877,9 @@ __global__ __launch_bounds__(NT_MERGE) void topk_merge_kernel(MergeArgs m) {
       for (int w = 1; w < NT_MERGE / 64; ++w)
         if (better(s_ws[w], s_wp[w], fs, fp)) { fs = s_ws[w]; fp = s_wp[w]; }
       s_bs = fs; s_bp = fp;
-      m.out_ids[(long long)u * m.k + r] = m.whitelist ? m.whitelist[fp] : fp + m.id_offset;
-      m.out_scores[(long long)u * m.k + r] = (m.distance == DIST_EUCLID) ? -fs : fs;
+      if (m.out_pos != nullptr) m.out_pos[(long long)u * out_k + r] = (int)fp;
+      else m.out_ids[(long long)u * out_k + r] = m.whitelist ? m.whitelist[fp] : fp + m.id_offset;
+      m.out_scores[(long long)u * out_k + r] = (m.distance == DIST_EUCLID) ? -fs : fs;
     }
     __syncthreads();
     prev_s = s_bs; prev_p = s_bp;
@@ -1333,6 +1368,99 @@ __global__ void fill_u32_kernel(unsigned* p, unsigned v, long long n) {
   if (i < n) p[i] = v;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Two-stage top-k, the exact pass: the candidates the coarse (hm) pass kept are scored again IN THE ARITHMETIC OF ENGINE 2 — the same
+// v_mfma_f32_32x32x2_f32 chain over the same k order (chunk rotation of the candidate's item block, then (k, k + 4) pairs inside a chunk) —
+// so a candidate's exact score is bit for bit what topk_stream_kernel computes for it, and the k best of them in (score desc, position asc)
+// order are what rt_topk_score returns whenever the candidate set provably holds the exact top-k.
+// One workgroup per user, one wave per 32 candidates.  Lane column j feeds row j of A with candidate j and column j of B with the user,
+// BOTH walked in candidate j's chunk order: the diagonal of the 32 x 32 tile holds the 32 scores (every output element of the instruction
+// depends on its own row and column only).
+// Proof of completeness per user: every (user, item) pair the coarse pass dropped had a coarse score <= tau = max(shared bound at the end
+// of the pass, worst coarse score among the candidates when the candidate set is full); |coarse - exact| <= eps = err_coef |u| max|v|
+// (rt_topk_score_two_stage); so with e_k = the k-th best exact score among the candidates, e_k - eps > tau means nothing outside can
+// reach e_k.  Users for whom that fails are flagged in out_unproven (their outputs are still the best k candidates, not proven complete).
+// ------------------------------------------------------------------------------------------------
+struct ReplayArgs {
+  const float* users; long long user_stride; const long long* user_rows;
+  const float* items; long long item_stride; const long long* whitelist; long long id_offset;
+  int d, k, kc, rotate;
+  const int* cand_pos; const float* cand_coarse; const int* cand_counts;   // [n_users][kc], best coarse first
+  const unsigned* gthr; const float* user_norms; float max_item_norm, err_coef;
+  long long* out_ids; float* out_scores; int* out_counts; int* out_unproven;
+};
+
+template <int NW>   // waves per user = kc / 32
+__global__ __launch_bounds__(64 * NW) void topk_replay_kernel(ReplayArgs r) {
+  const int u = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int col = lane & 31, half = lane >> 5;
+  __shared__ float s_sc[32 * NW]; __shared__ int s_pos[32 * NW];
+  __shared__ float s_ek;
+  const int cnt = r.cand_counts[u];
+  const int ci = wave * 32 + col;
+  const bool cv = ci < cnt;
+  const int pos = cnt > 0 ? r.cand_pos[(long long)u * r.kc + (cv ? ci : 0)] : 0;        // idle columns repeat candidate 0
+  const long long irow = r.whitelist ? r.whitelist[pos] : (long long)pos;
+  const int n_chunks = r.d / KC;
+  const int rot = r.rotate ? (int)((unsigned long long)((long long)(pos / IB) * 5) % (unsigned)n_chunks) : 0;
+  const float* ip = r.items + irow * r.item_stride;
+  const float* up = r.users + (r.user_rows ? r.user_rows[u] : (long long)u) * r.user_stride;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  if (wave * 32 < cnt) {
+#pragma unroll 1
+    for (int c = 0; c < n_chunks; ++c) {
+      int cc = c + rot; if (cc >= n_chunks) cc -= n_chunks;
+      f32x4 av[KC / 8], bv[KC / 8];
+#pragma unroll
+      for (int s = 0; s < KC / 8; ++s) {
+        av[s] = *reinterpret_cast<const f32x4*>(ip + cc * KC + (2 * s + half) * 4);
+        bv[s] = *reinterpret_cast<const f32x4*>(up + cc * KC + (2 * s + half) * 4);
+      }
+#pragma unroll
+      for (int s = 0; s < KC / 8; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][t], bv[s][t], acc, 0, 0, 0);
+    }
+  }
+  // the diagonal: element (i, i) sits in the lane with column i and half (i >> 2) & 1, register (i & 3) + 4 (i >> 3)
+  if (half == ((col >> 2) & 1)) {
+    const int rr = (col & 3) + 4 * (col >> 3);
+    float sc = acc[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) sc = (rr == i) ? acc[i] : sc;
+    s_sc[ci] = cv ? sc : -INFINITY;
+    s_pos[ci] = cv ? pos : 0x7fffffff;
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  // rank sort of the <= 32 NW entries by (score desc, position asc): lane e counts the entries ahead of its own
+  const int n_out = cnt < r.k ? cnt : r.k;
+  float ek = -INFINITY;
+  for (int e = lane; e < 32 * NW; e += 64) {
+    const float se = s_sc[e]; const long long pe = s_pos[e];
+    int rank = 0;
+    for (int o = 0; o < 32 * NW; ++o) rank += better(s_sc[o], (long long)s_pos[o], se, pe) ? 1 : 0;
+    if (e < cnt && rank < n_out) {
+      r.out_ids[(long long)u * r.k + rank] = r.whitelist ? r.whitelist[pe] : pe + r.id_offset;
+      r.out_scores[(long long)u * r.k + rank] = se;
+      if (rank == r.k - 1) ek = se;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ek = fmaxf(ek, __shfl_xor(ek, o, 64));
+  if (lane == 0) {
+    r.out_counts[u] = n_out;
+    float tau = key_to_f32(r.gthr[u]);
+    if (cnt == r.kc) tau = fmaxf(tau, r.cand_coarse[(long long)u * r.kc + r.kc - 1]);
+    const float eps = r.err_coef * r.user_norms[u] * r.max_item_norm;
+    const bool proven = (tau == -INFINITY) || (cnt >= r.k && ek - eps > tau);
+    r.out_unproven[u] = proven ? 0 : 1;
+  }
+}
+
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 int env_int(const char* name, int dflt) {
@@ -1414,65 +1542,58 @@ inline Plan make_plan(int n_users, long long n_cand, int k, int users_per_pass) 
   return P;
 }
 
-template <int TU, int NS, bool WL, bool LL, int NLD, bool BF = false>
+template <int TU, int NS, bool WL, bool LL, int NLD, bool HM = false>
 int launch_stream_nld(const TopkArgs& a_in, dim3 grid, hipStream_t stream) {
   TopkArgs a = a_in;
   size_t lds = stream_lds_bytes(TU, NS, LL ? a.k : 0);
   // per-user Bloom filters of the viewed items, if the filter comes with hash sets and 128 B per user still fit in LDS
-  a.bloom = (!BF && a.filt_hash != nullptr && env_int("RT_TOPK_BLOOM", 1) != 0 && lds + (size_t)32 * TU * 128 <= LDS_PER_CU) ? 1 : 0;
+  a.bloom = (a.filt_hash != nullptr && env_int("RT_TOPK_BLOOM", 1) != 0 && lds + (size_t)32 * TU * 128 <= LDS_PER_CU) ? 1 : 0;
   if (a.bloom) lds += (size_t)32 * TU * 128;
   static size_t attr_lds = 0;
   if (lds > 64 * 1024 && lds > attr_lds) {
-    RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_stream_kernel<TU, NS, WL, LL, NLD, BF>),
+    RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_stream_kernel<TU, NS, WL, LL, NLD, HM>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_lds = lds;
   }
-  topk_stream_kernel<TU, NS, WL, LL, NLD, BF><<<grid, NTHREADS + NLD * 64, lds, stream>>>(a);
+  topk_stream_kernel<TU, NS, WL, LL, NLD, HM><<<grid, NTHREADS + NLD * 64, lds, stream>>>(a);
   RT_CHECK_LAUNCH();
   return RT_OK;
 }
-// bf16 coarse pass: lists in global memory (it keeps K_c = 64 > K_LDS_LISTS entries), deepest ring that fits beside
-// nothing else (make_plan's choice for k_lds = 0: 6 stages for the 32- / 64-user tiles, 4 for the 128-user tile).
-constexpr int bf16_stages(int tu) { return tu == 4 ? 4 : 6; }
-template <int TU>
-int launch_stream_bf16(const TopkArgs& a, dim3 grid, hipStream_t stream) {
-  constexpr int NS = bf16_stages(TU), NLD = TU <= 2 ? 2 : 0;
-  return a.whitelist ? launch_stream_nld<TU, NS, true, false, NLD, true>(a, grid, stream)
-                     : launch_stream_nld<TU, NS, false, false, NLD, true>(a, grid, stream);
-}
 // RT_TOPK_LOADERS: 0 = every wave issues and computes, 2 = two dedicated loader waves (default for the small user tiles
 // that are HBM-bound; the 128-user tile is MFMA-bound and keeps its issue slots for compute waves only)
-template <int TU, int NS, bool WL, bool LL>
+template <int TU, int NS, bool WL, bool LL, bool HM>
 int launch_stream_impl(const TopkArgs& a, dim3 grid, hipStream_t stream) {
-  static const int loaders = env_int("RT_TOPK_LOADERS", TU <= 2 ? 2 : 0);
-  if constexpr (TU <= 2) {   // vmcnt is a 6-bit counter: (8 + 2 TU + 1) pieces x (NS - 2) stages must stay below 64
-    if (loaders == 2) return launch_stream_nld<TU, NS, WL, LL, 2>(a, grid, stream);
+  // the coarse pass spends a quarter of the matrix time per chunk: the DMA issue slots weigh as much as the MFMAs even at 128 users
+  static const int loaders = HM ? env_int("RT_TOPK_LOADERS_HM", 2) : env_int("RT_TOPK_LOADERS", TU <= 2 ? 2 : 0);
+  if constexpr (TU <= 2 || (HM && (8 + 2 * TU + 1) * (NS - 2) < 64)) {   // vmcnt is a 6-bit counter: (8 + 2 TU + 1) pieces x (NS - 2) stages must stay below 64
+    if (loaders == 2) return launch_stream_nld<TU, NS, WL, LL, 2, HM>(a, grid, stream);
   }
-  return launch_stream_nld<TU, NS, WL, LL, 0>(a, grid, stream);
+  return launch_stream_nld<TU, NS, WL, LL, 0, HM>(a, grid, stream);
 }
-template <int TU, int NS>
+template <int TU, int NS, bool HM>
 int launch_stream(const TopkArgs& a, dim3 grid, bool lds_lists, hipStream_t stream) {
   if (a.whitelist) {
-    return lds_lists ? launch_stream_impl<TU, NS, true, true>(a, grid, stream)
-                     : launch_stream_impl<TU, NS, true, false>(a, grid, stream);
+    return lds_lists ? launch_stream_impl<TU, NS, true, true, HM>(a, grid, stream)
+                     : launch_stream_impl<TU, NS, true, false, HM>(a, grid, stream);
   }
-  return lds_lists ? launch_stream_impl<TU, NS, false, true>(a, grid, stream)
-                   : launch_stream_impl<TU, NS, false, false>(a, grid, stream);
+  return lds_lists ? launch_stream_impl<TU, NS, false, true, HM>(a, grid, stream)
+                   : launch_stream_impl<TU, NS, false, false, HM>(a, grid, stream);
 }
 
-template <int TU>
+template <int TU, bool HM>
 int launch_stream_ns(int ns, const TopkArgs& a, dim3 grid, bool ll, hipStream_t stream) {
   switch (ns) {
-    case 3: return launch_stream<TU, 3>(a, grid, ll, stream);
-    case 4: return launch_stream<TU, 4>(a, grid, ll, stream);
-    case 5: return launch_stream<TU, 5>(a, grid, ll, stream);
-    default: return launch_stream<TU, 6>(a, grid, ll, stream);
+    case 3: return launch_stream<TU, 3, HM>(a, grid, ll, stream);
+    case 4: return launch_stream<TU, 4, HM>(a, grid, ll, stream);
+    case 5: return launch_stream<TU, 5, HM>(a, grid, ll, stream);
+    default: return launch_stream<TU, 6, HM>(a, grid, ll, stream);
   }
 }
+template <bool HM>
 int launch_stream_any(int tu, int ns, const TopkArgs& a, dim3 grid, bool ll, hipStream_t stream) {
-  if (tu == 1) return launch_stream_ns<1>(ns, a, grid, ll, stream);
-  if (tu == 2) return launch_stream_ns<2>(ns, a, grid, ll, stream);
-  return launch_stream_ns<4>(ns, a, grid, ll, stream);
+  if (tu == 1) return launch_stream_ns<1, HM>(ns, a, grid, ll, stream);
+  if (tu == 2) return launch_stream_ns<2, HM>(ns, a, grid, ll, stream);
+  return launch_stream_ns<4, HM>(ns, a, grid, ll, stream);
 }
 
 // ---- 16-user tile: plan and launch -------------------------------------------------------------------------------
@@ -1599,17 +1720,33 @@ int rt_filter_hash_build(const int64_t* filt_indptr, const int32_t* filt_indices
   return RT_OK;
 }
 
-// `bf16`: users / items point at bf16 images whose rows hold d floats' worth of bytes (2 d bf16 values): dot products only.
+// Two-stage call (rt_topk_score_two_stage): the streaming pass runs over the hm images with k-entry lists as usual, the merge hands
+// out the k_cand best coarse candidates per user as positions, the exact pass (topk_replay_kernel) scores and orders them.
+struct TwoStage {
+  const float* users_hm; const float* items_hm;     // images: users dense [n_users, d] (row u = user u of the call), items strided like `items`
+  const float* user_norms; float max_item_norm;
+  int k_cand; int* out_unproven;
+};
+// list capacity of the coarse pass: a pair is dropped when it falls below its list's worst kept entry, and the proof needs that bound to
+// stay below the k-th exact score — k entries per list would put the bound AT the best score for k = 1 and leave no room when one list
+// happens to hold all of a user's top k; the spare entries up to the next multiple of four (the LDS lists are padded to it anyway, at
+// least one) keep the bound below the (k + 1)-th best score
+inline int two_stage_list_k(int k) { const int kl = (k + 4) & ~3; return kl < K_LDS_LISTS ? kl : K_LDS_LISTS; }
+inline size_t two_stage_extra_bytes(int users_per_launch, int k_cand) {
+  return align_up((size_t)users_per_launch * k_cand * 4, 256) * 2 + align_up((size_t)users_per_launch * 4, 256);
+}
+
 static int topk_score_impl(const float* users, int64_t user_stride, const int64_t* user_rows, int32_t n_users,
                            const float* items, int64_t item_stride, const int64_t* whitelist, int64_t n_candidates,
                            int64_t candidate_id_offset, int32_t d, int32_t distance, int32_t k,
                            const int64_t* filt_indptr, const int32_t* filt_indices, const int32_t* filt_hash,
                            int64_t* out_ids, float* out_scores, int32_t* out_counts,
-                           void* workspace, size_t workspace_bytes, int32_t users_per_pass, bool bf16, hipStream_t stream) {
+                           void* workspace, size_t workspace_bytes, int32_t users_per_pass, const TwoStage* ts, hipStream_t stream) {
   (void)hipGetLastError();  // do not inherit a stale error from the caller's earlier HIP calls
   if (n_users < 0 || n_candidates < 0 || d <= 0 || (d & 3) != 0 || k <= 0) return RT_ERR_INVALID_ARG;
   if (distance < DIST_DOT || distance > DIST_EUCLID) return RT_ERR_INVALID_ARG;
-  if (bf16 && (distance != DIST_DOT || d % KC != 0)) return RT_ERR_UNSUPPORTED;
+  if (ts != nullptr && (distance != DIST_DOT || d % KC != 0 || k > K_LDS_LISTS || (ts->k_cand != 32 && ts->k_cand != 64) || ts->k_cand < k))
+    return RT_ERR_UNSUPPORTED;
   if ((user_stride & 3) != 0 || (item_stride & 3) != 0) return RT_ERR_INVALID_ARG;
   if (((uintptr_t)users & 15) != 0 || ((uintptr_t)items & 15) != 0) return RT_ERR_INVALID_ARG;
   if (n_candidates >= (1LL << 31)) return RT_ERR_UNSUPPORTED;
@@ -1619,9 +1756,9 @@ static int topk_score_impl(const float* users, int64_t user_stride, const int64_
     return hipMemsetAsync(out_counts, 0, sizeof(int32_t) * (size_t)n_users, stream) == hipSuccess ? RT_OK : RT_ERR_LAUNCH;
   }
   const int impl = env_int("RT_TOPK_IMPL", 2);
-  const bool stream_ok = bf16 || ((impl == 2) && (d % KC == 0));
+  const bool stream_ok = ts != nullptr || ((impl == 2) && (d % KC == 0));
   char* ws = reinterpret_cast<char*>(workspace);
-  if (!bf16 && stream_ok && wants_tile16(n_users, k, users_per_pass)) {
+  if (ts == nullptr && stream_ok && wants_tile16(n_users, k, users_per_pass)) {
     // ---- 16-user tile (engine 3): [seeding prefix -> seed] -> main pass -> selection over the merged lists ----
     const Plan16 Q = make_plan16(n_users, n_candidates, k);
     if (workspace == nullptr || workspace_bytes < Q.total) return RT_ERR_WORKSPACE;
@@ -1679,9 +1816,11 @@ static int topk_score_impl(const float* users, int64_t user_stride, const int64_
     }
     return RT_OK;
   }
+  const int k_out = k;                        // two-stage: the lists hold more than the k entries the caller asked for
+  if (ts != nullptr) k = two_stage_list_k(k);
   Plan P = make_plan(n_users, n_candidates, k, users_per_pass);
-  if (workspace == nullptr || workspace_bytes < P.total) return RT_ERR_WORKSPACE;
-  if (bf16) { P.lds_lists = false; P.ns = bf16_stages(P.tu); }   // the instantiations launch_stream_bf16 carries
+  const size_t ws_need = P.total + (ts ? two_stage_extra_bytes(P.users_per_launch, ts->k_cand) : 0);
+  if (workspace == nullptr || workspace_bytes < ws_need) return RT_ERR_WORKSPACE;
 
   for (int u0 = 0; u0 < n_users; u0 += P.users_per_launch) {
     const int nb = (n_users - u0) < P.users_per_launch ? (n_users - u0) : P.users_per_launch;
@@ -1692,6 +1831,10 @@ static int topk_score_impl(const float* users, int64_t user_stride, const int64_
     a.user_rows = user_rows ? reinterpret_cast<const long long*>(user_rows) + u0 : nullptr;
     a.n_users = nb;
     a.items = items; a.item_stride = item_stride;
+    if (ts != nullptr) {   // the coarse pass streams the images (users: dense rows in call order)
+      a.users = ts->users_hm + (long long)u0 * d; a.user_stride = d; a.user_rows = nullptr;
+      a.items = ts->items_hm;
+    }
     a.whitelist = reinterpret_cast<const long long*>(whitelist);
     a.n_cand = n_candidates; a.id_offset = whitelist ? 0 : candidate_id_offset;
     a.d = d; a.distance = distance; a.k = k;
@@ -1720,12 +1863,8 @@ static int topk_score_impl(const float* users, int64_t user_stride, const int64_
     m.n_lists = P.n_lists; m.n_users_pad = P.n_users_pad; m.k = k; m.n_users = nb;
     auto run_phase = [&](long long b0, long long b1, int n_seg, int resume) -> int {
       a.blk_begin = b0; a.blk_end = b1; a.n_seg = n_seg; a.resume = resume;
-      if (bf16) {
-        if (P.tu == 1) return launch_stream_bf16<1>(a, grid, stream);
-        if (P.tu == 2) return launch_stream_bf16<2>(a, grid, stream);
-        return launch_stream_bf16<4>(a, grid, stream);
-      }
-      if (stream_ok) return launch_stream_any(P.tu, P.ns, a, grid, P.lds_lists, stream);
+      if (ts != nullptr) return launch_stream_any<true>(P.tu, P.ns, a, grid, P.lds_lists, stream);
+      if (stream_ok) return launch_stream_any<false>(P.tu, P.ns, a, grid, P.lds_lists, stream);
       if (P.tu == 1) return launch_staged<1>(a, grid, stream);
       if (P.tu == 2) return launch_staged<2>(a, grid, stream);
       return launch_staged<4>(a, grid, stream);
@@ -1751,9 +1890,33 @@ static int topk_score_impl(const float* users, int64_t user_stride, const int64_
     m.out_ids = reinterpret_cast<long long*>(out_ids) + (long long)u0 * k;
     m.out_scores = out_scores + (long long)u0 * k;
     m.out_counts = out_counts + u0;
+    ReplayArgs r{};
+    if (ts != nullptr) {   // candidates (positions, coarse scores, counts) behind the plan's buffers
+      char* extra = ws + P.total;
+      const size_t cand_bytes = align_up((size_t)P.users_per_launch * ts->k_cand * 4, 256);
+      r.cand_pos = reinterpret_cast<int*>(extra); r.cand_coarse = reinterpret_cast<float*>(extra + cand_bytes);
+      r.cand_counts = reinterpret_cast<int*>(extra + 2 * cand_bytes);
+      m.out_k = ts->k_cand; m.out_pos = const_cast<int*>(r.cand_pos); m.out_scores = const_cast<float*>(r.cand_coarse);
+      m.out_counts = const_cast<int*>(r.cand_counts); m.out_ids = nullptr;
+    }
     if (m.n_lists >= 256) topk_merge_kernel<1024><<<nb, 1024, 0, stream>>>(m);
     else topk_merge_kernel<256><<<nb, 256, 0, stream>>>(m);
     RT_CHECK_LAUNCH();
+    if (ts != nullptr) {
+      r.users = user_rows ? users : users + (long long)u0 * user_stride; r.user_stride = user_stride;
+      r.user_rows = user_rows ? reinterpret_cast<const long long*>(user_rows) + u0 : nullptr;
+      r.items = items; r.item_stride = item_stride; r.whitelist = a.whitelist; r.id_offset = a.id_offset;
+      r.d = d; r.k = k_out; r.kc = ts->k_cand; r.rotate = a.rotate;
+      r.gthr = a.gthr; r.user_norms = ts->user_norms + u0; r.max_item_norm = ts->max_item_norm;
+      // |coarse - exact| <= (2^-14 [the dropped l parts] + 4 d 2^-24 [fp32 accumulation of the 4 d bf16 products]
+      //                      + d 2^-24 [the exact chain's own rounding]) sum_k |u_k v_k|, with 3 % slack (norms are fp32 too)
+      r.err_coef = 1.03f * (6.103515625e-5f + 5.0f * (float)d * 5.9604644775390625e-8f);
+      r.out_ids = reinterpret_cast<long long*>(out_ids) + (long long)u0 * k_out; r.out_scores = out_scores + (long long)u0 * k_out;
+      r.out_counts = out_counts + u0; r.out_unproven = ts->out_unproven + u0;
+      if (ts->k_cand == 64) topk_replay_kernel<2><<<nb, 128, 0, stream>>>(r);
+      else topk_replay_kernel<1><<<nb, 64, 0, stream>>>(r);
+      RT_CHECK_LAUNCH();
+    }
   }
   return RT_OK;
 }
@@ -1766,22 +1929,39 @@ int rt_topk_score(const float* users, int64_t user_stride, const int64_t* user_r
                   void* workspace, size_t workspace_bytes, int32_t users_per_pass, hipStream_t stream) {
   return topk_score_impl(users, user_stride, user_rows, n_users, items, item_stride, whitelist, n_candidates, candidate_id_offset, d,
                          distance, k, filt_indptr, filt_indices, filt_hash, out_ids, out_scores, out_counts, workspace,
-                         workspace_bytes, users_per_pass, false, stream);
+                         workspace_bytes, users_per_pass, nullptr, stream);
 }
 
-// Coarse pass of the two-stage top-k: the same selection over bf16 images (rt_to_bf16_rows) of users [n_users, d] (dense,
-// already gathered) and of the catalog [*, d]; strides count bf16 elements; d % 64 == 0; dot products (cosine callers pass
-// normalised images).  out_scores are the COARSE scores, best first; workspace as rt_topk_workspace_bytes(n_users, n, k, upp).
-int rt_topk_score_bf16(const uint16_t* users_bf16, int64_t user_stride, int32_t n_users, const uint16_t* items_bf16,
-                       int64_t item_stride, const int64_t* whitelist, int64_t n_candidates, int64_t candidate_id_offset, int32_t d,
-                       int32_t k, const int64_t* filt_indptr, const int32_t* filt_indices, const int32_t* filt_hash,
-                       int64_t* out_ids, float* out_scores, int32_t* out_counts, void* workspace, size_t workspace_bytes,
-                       int32_t users_per_pass, hipStream_t stream) {
-  if (d <= 0 || d % (2 * KC) != 0 || (user_stride & 7) != 0 || (item_stride & 7) != 0) return RT_ERR_INVALID_ARG;
-  return topk_score_impl(reinterpret_cast<const float*>(users_bf16), user_stride / 2, nullptr, n_users,
-                         reinterpret_cast<const float*>(items_bf16), item_stride / 2, whitelist, n_candidates, candidate_id_offset,
-                         d / 2, DIST_DOT, k, filt_indptr, filt_indices, filt_hash, out_ids, out_scores, out_counts, workspace,
-                         workspace_bytes, users_per_pass, true, stream);
+size_t rt_topk_two_stage_workspace_bytes(int32_t n_users, int64_t n_candidates, int32_t k, int32_t k_cand, int32_t users_per_pass) {
+  if (n_users <= 0 || n_candidates <= 0 || k <= 0 || k_cand <= 0) return 0;
+  const Plan P = make_plan(n_users, n_candidates, two_stage_list_k(k), users_per_pass);
+  return P.total + two_stage_extra_bytes(P.users_per_launch, k_cand);
+}
+
+// Two-stage exact top-k for dot products (the MFMA-bound regime: many users per catalog pass).  Stage 1 = the streaming selection of
+// rt_topk_score over hm images (rt_to_hm_rows; two bf16 matrix instructions per four k instead of four f32-input ones), keeping the
+// k_cand (32 or 64) best COARSE candidates per user; stage 2 = their exact scores in the arithmetic of rt_topk_score's 32-wide engine,
+// ordered (score desc, position asc).  out_unproven[u] = 0: the k results of user u are exactly rt_topk_score's (ids, order, score
+// bits); 1: the candidate set could not be proven complete for u (ties or near-ties at the k-th place closer than the coarse error
+// bound) — rank those users with rt_topk_score.  users_hm [n_users, d] dense in call order; items_hm strided and offset like `items`;
+// user_norms [n_users] and max_item_norm = L2 norms (rt_to_hm_rows).  d % 32 == 0, k <= 16 <= k_cand.
+int rt_topk_score_two_stage(const float* users, int64_t user_stride, const int64_t* user_rows, int32_t n_users, const float* items,
+                            int64_t item_stride, const uint32_t* users_hm, const uint32_t* items_hm, const float* user_norms,
+                            float max_item_norm, const int64_t* whitelist, int64_t n_candidates, int64_t candidate_id_offset, int32_t d,
+                            int32_t k, int32_t k_cand, const int64_t* filt_indptr, const int32_t* filt_indices, const int32_t* filt_hash,
+                            int64_t* out_ids, float* out_scores, int32_t* out_counts, int32_t* out_unproven, void* workspace,
+                            size_t workspace_bytes, int32_t users_per_pass, hipStream_t stream) {
+  if (users_hm == nullptr || items_hm == nullptr || user_norms == nullptr || out_unproven == nullptr || !(max_item_norm >= 0.f) ||
+      ((uintptr_t)users_hm & 15) != 0 || ((uintptr_t)items_hm & 15) != 0)
+    return RT_ERR_INVALID_ARG;
+  if (n_users > 0 && n_candidates == 0) {
+    if (hipMemsetAsync(out_unproven, 0, sizeof(int32_t) * (size_t)n_users, stream) != hipSuccess) return RT_ERR_LAUNCH;
+  }
+  TwoStage ts{reinterpret_cast<const float*>(users_hm), reinterpret_cast<const float*>(items_hm), user_norms, max_item_norm, k_cand,
+              out_unproven};
+  return topk_score_impl(users, user_stride, user_rows, n_users, items, item_stride, whitelist, n_candidates, candidate_id_offset, d,
+                         DIST_DOT, k, filt_indptr, filt_indices, filt_hash, out_ids, out_scores, out_counts, workspace, workspace_bytes,
+                         users_per_pass, &ts, stream);
 }
 
 }  // extern "C"

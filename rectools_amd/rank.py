@@ -126,11 +126,14 @@ class HipRanker:
         if self.subjects_factors.shape[1] != self.objects_factors.shape[1]:
             raise ValueError("subjects and objects factors must have the same number of columns")
         self._workspace: tp.Optional[torch.Tensor] = None
-        # two-stage top-k (bf16 coarse pass + exact fp32 rescoring, include/rectools_hip.h K12b): opt-in
-        self.two_stage = (os.environ.get("RT_TOPK_TWO_STAGE", "0") == "1") if two_stage is None else bool(two_stage)
-        self._shadow: tp.Optional[torch.Tensor] = None        # bf16 image of objects_factors (normalised rows for cosine)
+        # two-stage top-k (include/rectools_hip.h K12c): hm-image coarse pass + exact pass over the candidates, with a per-user proof
+        # that the result is the single-stage kernel's.  None = where it pays (dot products, many users per call); RT_TOPK_TWO_STAGE=0/1
+        # forces it off / on wherever it applies
+        env = os.environ.get("RT_TOPK_TWO_STAGE", "auto")
+        self.two_stage: tp.Optional[bool] = (None if env == "auto" else env == "1") if two_stage is None else bool(two_stage)
+        self._items_hm: tp.Optional[torch.Tensor] = None      # hm image of objects_factors (rt_to_hm_rows), built on first use
         self._max_item_norm = 0.0
-        self.two_stage_stats = {"calls": 0, "fallbacks": 0}
+        self.two_stage_stats = {"calls": 0, "fallbacks": 0, "unproven_users": 0}
 
     def _to_device(self, tensor: tp.Union[np.ndarray, sparse.csr_matrix, torch.Tensor]) -> torch.Tensor:
         # mirrors TorchRanker._normalize_tensor (rank_torch.py:210-223), then moves to the device once
@@ -144,72 +147,84 @@ class HipRanker:
         return _pad4(tensor)
 
     # ---- two-stage top-k ---------------------------------------------------------------------------------
-    COARSE_KEEP = 64          # K_c: candidates kept per user by coarse score
+    CANDIDATES = 64           # k_cand: coarse candidates handed to the exact pass per user
+    TWO_STAGE_MIN_USERS = 128  # below this the single-stage engines are bound by HBM, not by the matrix pipe: nothing to win
 
-    def _two_stage_applies(self, kk: int, n_cand: int) -> bool:
+    def _two_stage_applies(self, kk: int, n_cand: int, n_subj: int) -> bool:
         d = self.objects_factors.shape[1]
-        return (self.two_stage and self.distance in (Distance.DOT, Distance.COSINE) and d % 64 == 0 and d <= 2048
-                and 2 * kk <= self.COARSE_KEEP and n_cand >= 8 * self.COARSE_KEEP)
+        if self.two_stage is False or self.distance != Distance.DOT or d % 32 != 0 or d > 2048 or kk > 16 or n_cand < 8 * self.CANDIDATES:
+            return False
+        return True if self.two_stage else n_subj >= int(os.environ.get("RT_TOPK_TWO_STAGE_MIN_USERS", self.TWO_STAGE_MIN_USERS))
 
-    def _bf16_image(self, src: torch.Tensor, rows: tp.Optional[torch.Tensor], n_rows: int) -> tp.Tuple[torch.Tensor, torch.Tensor]:
+    def _hm_image(self, src: torch.Tensor, rows: tp.Optional[torch.Tensor], n_rows: int) -> tp.Tuple[torch.Tensor, torch.Tensor]:
         d = src.shape[1]
-        img = torch.empty((n_rows, d), dtype=torch.bfloat16, device=self.device)
+        img = torch.empty((n_rows, d), dtype=torch.int32, device=self.device)
         norms = torch.empty((n_rows,), dtype=torch.float32, device=self.device)
-        status = self._lib.rt_to_bf16_rows(_lib.ptr(src), src.stride(0), _lib.ptr(rows), n_rows, d,
-                                           1 if self.distance == Distance.COSINE else 0, _lib.ptr(img), _lib.ptr(norms),
-                                           _lib.current_stream())
-        _lib.check(status, "rt_to_bf16_rows")
+        status = self._lib.rt_to_hm_rows(_lib.ptr(src), src.stride(0), _lib.ptr(rows), n_rows, d, _lib.ptr(img), d, _lib.ptr(norms),
+                                         _lib.current_stream())
+        _lib.check(status, "rt_to_hm_rows")
         return img, norms
 
+    def _rank_exact(self, ids_t, scores_t, counts_t, rows_t, u0, n, whitelist_t, n_cand, id_offset, kk, indptr_t, indices_t, hash_t,
+                    upp) -> None:
+        """`rt_topk_score` for the users [u0, u0 + n) of the call, written into their rows of the outputs."""
+        S, O = self.subjects_factors, self.objects_factors
+        ws_bytes = self._lib.rt_topk_workspace_bytes(n, n_cand, kk, upp)
+        if self._workspace is None or self._workspace.numel() < ws_bytes:
+            self._workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=self.device)
+        off = lambda t, elems, size: None if t is None else t.data_ptr() + elems * size   # noqa: E731
+        with torch.cuda.device(self.device):
+            status = self._lib.rt_topk_score(
+                S.data_ptr() + (0 if rows_t is not None else 4 * u0 * S.stride(0)), S.stride(0), off(rows_t, u0, 8), n,
+                O.data_ptr() + 4 * id_offset * O.stride(0), O.stride(0), _lib.ptr(whitelist_t), n_cand, id_offset, O.shape[1],
+                _DIST_CODE[self.distance], kk,
+                # the filter of user u0 + i: indptr entry u0 + i; its hash table sits 4 (indptr[u] + u) ints into the hash array
+                off(indptr_t, u0, 8), _lib.ptr(indices_t), off(hash_t, 4 * u0, 4),
+                ids_t.data_ptr() + 8 * u0 * kk, scores_t.data_ptr() + 4 * u0 * kk, counts_t.data_ptr() + 4 * u0,
+                _lib.ptr(self._workspace), self._workspace.numel(), upp, _lib.current_stream())
+        _lib.check(status, "rt_topk_score")
+
     def _rank_two_stage(self, ids_t, scores_t, counts_t, rows_t, n_subj, whitelist_t, n_cand, id_offset, kk, indptr_t, indices_t,
-                        hash_t, upp) -> bool:
-        """Coarse bf16 pass keeping K_c candidates per user, a per-user proof that nothing else can be in the exact top-k,
-        exact fp32 rescoring of the candidates.  Returns False (nothing written) when the proof fails for some user — the
-        caller then ranks the call with the exact kernel."""
-        d, kc, dev = self.objects_factors.shape[1], self.COARSE_KEEP, self.device
+                        hash_t, upp) -> None:
+        """Coarse pass over the hm images + exact pass over CANDIDATES candidates per user (`rt_topk_score_two_stage`); users whose
+        result the kernel could not prove complete are ranked again by the single-stage kernel (one device -> host read of the
+        flags: the only synchronisation of the call)."""
+        S, O = self.subjects_factors, self.objects_factors
+        d, kc, dev = O.shape[1], self.CANDIDATES, self.device
         self.two_stage_stats["calls"] += 1
+        # users per catalog pass: 128 (lists in global memory, half the ring traffic per flop) pays on catalogs long enough that the
+        # selection slow path is rare; small catalogs keep the 64-user tile with its LDS lists
+        upp2 = upp if upp > 0 else int(os.environ.get("RT_TOPK_TWO_STAGE_UPP", "128" if n_cand >= 500_000 else "64"))
         with torch.cuda.device(dev):
-            if self._shadow is None:
-                self._shadow, item_norms = self._bf16_image(self.objects_factors, None, self.objects_factors.shape[0])
+            if self._items_hm is None:
+                self._items_hm, item_norms = self._hm_image(O, None, O.shape[0])
                 self._max_item_norm = float(item_norms.max())
-            users_img, user_norms = self._bf16_image(self.subjects_factors, rows_t, n_subj)
-            c_ids = torch.empty((n_subj, kc), dtype=torch.int64, device=dev)
-            c_scores = torch.empty((n_subj, kc), dtype=torch.float32, device=dev)
-            c_counts = torch.zeros((n_subj,), dtype=torch.int32, device=dev)
-            ws_bytes = self._lib.rt_topk_workspace_bytes(n_subj, n_cand, kc, upp)
+            users_hm, user_norms = self._hm_image(S, rows_t, n_subj)
+            unproven = torch.empty((n_subj,), dtype=torch.int32, device=dev)
+            ws_bytes = self._lib.rt_topk_two_stage_workspace_bytes(n_subj, n_cand, kk, kc, upp2)
             if self._workspace is None or self._workspace.numel() < ws_bytes:
                 self._workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-            status = self._lib.rt_topk_score_bf16(
-                _lib.ptr(users_img), d, n_subj, self._shadow.data_ptr() + 2 * id_offset * d, d, _lib.ptr(whitelist_t), n_cand,
-                id_offset, d, kc, _lib.ptr(indptr_t), _lib.ptr(indices_t), _lib.ptr(hash_t), _lib.ptr(c_ids), _lib.ptr(c_scores),
-                _lib.ptr(c_counts), _lib.ptr(self._workspace), self._workspace.numel(), upp, _lib.current_stream())
-            _lib.check(status, "rt_topk_score_bf16")
-            # |coarse - exact| <= c |u| |v|  (bf16 rounding of both operands + fp32 accumulation), 1 % slack
-            c = 1.01 * (2.0 ** -8 + 2.0 ** -18 + d * 2.0 ** -24)
-            if self.distance == Distance.COSINE:
-                eps = torch.full((n_subj,), c * 1.001 + 1e-6, dtype=torch.float32, device=dev)     # unit rows
-            else:
-                eps = c * user_norms * self._max_item_norm
-            full = c_counts >= kc
-            proven = (~full) | (c_scores[:, kc - 1] < c_scores[:, kk - 1] - 2.0 * eps)
-            if not bool(proven.all()):
-                self.two_stage_stats["fallbacks"] += 1
-                return False
-            exact = torch.empty((n_subj, kc), dtype=torch.float32, device=dev)
-            status = self._lib.rt_topk_rescore(
-                _lib.ptr(self.subjects_factors), self.subjects_factors.stride(0), _lib.ptr(rows_t), n_subj,
-                _lib.ptr(self.objects_factors), self.objects_factors.stride(0), d, _DIST_CODE[self.distance], _lib.ptr(c_ids),
-                _lib.ptr(c_counts), kc, _lib.ptr(exact), _lib.current_stream())
-            _lib.check(status, "rt_topk_rescore")
-            # best exact score first; exact ties -> lower catalog row first (the exact kernel's rule)
-            valid = torch.arange(kc, device=dev)[None, :] < c_counts[:, None]
-            order_id = torch.sort(torch.where(valid, c_ids, torch.full_like(c_ids, 2 ** 62)), dim=1, stable=True).indices
-            by_id_scores = torch.gather(exact, 1, order_id)
-            order = torch.sort(by_id_scores, dim=1, descending=True, stable=True).indices[:, :kk]
-            ids_t.copy_(torch.gather(torch.gather(c_ids, 1, order_id), 1, order))
-            scores_t.copy_(torch.gather(by_id_scores, 1, order))
-            counts_t.copy_(torch.clamp(c_counts, max=kk))
-        return True
+            status = self._lib.rt_topk_score_two_stage(
+                _lib.ptr(S), S.stride(0), _lib.ptr(rows_t), n_subj, O.data_ptr() + 4 * id_offset * O.stride(0), O.stride(0),
+                _lib.ptr(users_hm), self._items_hm.data_ptr() + 4 * id_offset * d, _lib.ptr(user_norms), self._max_item_norm,
+                _lib.ptr(whitelist_t), n_cand, id_offset, d, kk, kc, _lib.ptr(indptr_t), _lib.ptr(indices_t), _lib.ptr(hash_t),
+                _lib.ptr(ids_t), _lib.ptr(scores_t), _lib.ptr(counts_t), _lib.ptr(unproven), _lib.ptr(self._workspace),
+                self._workspace.numel(), upp2, _lib.current_stream())
+            _lib.check(status, "rt_topk_score_two_stage")
+            bad = torch.nonzero(unproven).reshape(-1).cpu().numpy()
+        if len(bad) == 0:
+            return
+        self.two_stage_stats["unproven_users"] += int(len(bad))
+        if 8 * len(bad) > n_subj:       # the catalog defeats the coarse pass (near-duplicates): the whole call on the exact kernel
+            self.two_stage_stats["fallbacks"] += 1
+            self._rank_exact(ids_t, scores_t, counts_t, rows_t, 0, n_subj, whitelist_t, n_cand, id_offset, kk, indptr_t, indices_t,
+                             hash_t, upp)
+            return
+        starts = bad[np.r_[True, np.diff(bad) > 1]]
+        ends = bad[np.r_[np.diff(bad) > 1, True]] + 1
+        for u0, u1 in zip(starts, ends):    # runs of consecutive unproven users, on the 32-wide engine the exact pass mirrors
+            self._rank_exact(ids_t, scores_t, counts_t, rows_t, int(u0), int(u1 - u0), whitelist_t, n_cand, id_offset, kk, indptr_t,
+                             indices_t, hash_t, upp if upp > 16 else 32)
 
     def rank(
         self,
@@ -301,24 +316,10 @@ class HipRanker:
                 hash_t = dcsr.hash_tables()
 
         upp = 0 if self.batch_size is None else int(self.batch_size)
-        if self._two_stage_applies(kk, n_cand):
-            done = self._rank_two_stage(ids_t, scores_t, counts_t, rows_t, n_subj, whitelist_t, n_cand, id_offset, kk,
-                                        indptr_t, indices_t, hash_t, upp)
-            if done:
-                return ids_t, scores_t, counts_t, subject_ids
-        ws_bytes = self._lib.rt_topk_workspace_bytes(n_subj, n_cand, kk, upp)
-        if self._workspace is None or self._workspace.numel() < ws_bytes:
-            self._workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-
-        with torch.cuda.device(dev):
-            status = self._lib.rt_topk_score(
-                _lib.ptr(self.subjects_factors), self.subjects_factors.stride(0), _lib.ptr(rows_t), n_subj,
-                self.objects_factors.data_ptr() + 4 * id_offset * self.objects_factors.stride(0),
-                self.objects_factors.stride(0), _lib.ptr(whitelist_t), n_cand, id_offset,
-                self.objects_factors.shape[1], _DIST_CODE[self.distance], kk,
-                _lib.ptr(indptr_t), _lib.ptr(indices_t), _lib.ptr(hash_t),
-                _lib.ptr(ids_t), _lib.ptr(scores_t), _lib.ptr(counts_t),
-                _lib.ptr(self._workspace), self._workspace.numel(), upp, _lib.current_stream(),
-            )
-        _lib.check(status, "rt_topk_score")
+        if self._two_stage_applies(kk, n_cand, n_subj):
+            self._rank_two_stage(ids_t, scores_t, counts_t, rows_t, n_subj, whitelist_t, n_cand, id_offset, kk, indptr_t, indices_t,
+                                 hash_t, upp)
+        else:
+            self._rank_exact(ids_t, scores_t, counts_t, rows_t, 0, n_subj, whitelist_t, n_cand, id_offset, kk, indptr_t, indices_t,
+                             hash_t, upp)
         return ids_t, scores_t, counts_t, subject_ids

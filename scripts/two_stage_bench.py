@@ -1,36 +1,60 @@
-"""Two-stage vs exact top-k on the 5M x 512 catalog (HIP events around HipRanker.rank_device; k = 10, dot)."""
+"""Two-stage vs single-stage top-k at the shapes the bench quotes: python scripts/two_stage_bench.py [c5|c2] ...
+c5: 5,000,000 x 512 catalog, 4096 users; c2: 26,744 x 256 catalog, 16,384 users, viewed filter (~144 items per user)."""
 import os
 import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from rectools_amd.rank import HipRanker  # noqa: E402
+from rectools_amd.rank import DeviceCSR, HipRanker
 
-V, d = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (5_000_000, 512)
-dev = torch.device("cuda:0")
-g = torch.Generator(device=dev).manual_seed(0)
-items = torch.randn(V, d, device=dev, generator=g)
-for n_users, batch in ((32, 32), (1024, 128)):
-    users = torch.randn(n_users, d, device=dev, generator=g)
-    res = {}
-    for mode in (False, True):
-        r = HipRanker("dot", dev, users, items, batch_size=batch, two_stage=mode)
-        ids = np.arange(n_users)
-        out = r.rank_device(ids, 10)          # warm-up (builds the bf16 image once)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 3
-        e0.record()
-        for _ in range(reps):
-            out = r.rank_device(ids, 10)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
-        res[mode] = (ms, out[0].clone(), out[1].clone(), dict(r.two_stage_stats))
-        del r
-    same = torch.equal(res[False][1], res[True][1])
-    err = float((res[False][2] - res[True][2]).abs().max())
-    print(f"V={V} d={d} users={n_users}: exact {res[False][0]:.2f} ms, two-stage {res[True][0]:.2f} ms ({res[False][0]/res[True][0]:.1f}x), "
-          f"ids equal {same}, max |score diff| {err:.2e}, stats {res[True][3]}", flush=True)
+
+def timed(fn, n=3):
+    fn(); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(n):
+        t = time.perf_counter(); fn(); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t)
+    return best * 1e3
+
+
+def main():
+    which = sys.argv[1:] or ["c2", "c5"]
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for w in which:
+        if w == "c5":
+            V, d, U, filt = 5_000_000, 512, 4096, None
+        else:
+            V, d, U = 26_744, 256, 16_384
+            rng = np.random.default_rng(0)
+            indptr = np.r_[0, np.cumsum(rng.integers(20, 270, U))].astype(np.int64)
+            indices = np.concatenate([np.sort(rng.choice(V, int(n), replace=False)) for n in np.diff(indptr)]).astype(np.int32)
+            filt = DeviceCSR(torch.from_numpy(indptr).cuda(), torch.from_numpy(indices).cuda(), (U, V))
+        items = torch.empty((V, d), device="cuda")
+        for r0 in range(0, V, 500_000):
+            items[r0:r0 + 500_000] = torch.randn((min(500_000, V - r0), d), device="cuda", generator=g)
+        users = torch.randn((U, d), device="cuda", generator=g)
+        ids = np.arange(U)
+        res = {}
+        for name, kw in (("single upp64", dict(two_stage=False, batch_size=64)), ("single upp128", dict(two_stage=False, batch_size=128)),
+                         ("two-stage upp64", dict(two_stage=True, batch_size=64)), ("two-stage upp128", dict(two_stage=True, batch_size=128))):
+            r = HipRanker("dot", "cuda", users, items, **kw)
+            ms = timed(lambda: r.rank_device(ids, 10, filt))   # noqa: B023
+            out = r.rank_device(ids, 10, filt)
+            res[name] = out
+            print(f"{w} {name:18s} {ms:9.3f} ms  {U / ms * 1e3:10.0f} users/s  {2.0 * U * V * d / ms / 1e9:7.1f} TF  stats {r.two_stage_stats}", flush=True)
+        if w == "c2":     # what the selection slow path costs: no viewed filter, and k = 1 (few inserts)
+            for name, kw in (("single upp64", dict(two_stage=False, batch_size=64)), ("two-stage upp64", dict(two_stage=True, batch_size=64))):
+                r = HipRanker("dot", "cuda", users, items, **kw)
+                print(f"c2 {name:18s} no filter {timed(lambda: r.rank_device(ids, 10, None)):7.3f} ms   k=1 with filter "   # noqa: B023
+                      f"{timed(lambda: r.rank_device(ids, 1, filt)):7.3f} ms", flush=True)   # noqa: B023
+        a, b = res["single upp64"], res["two-stage upp128"]
+        print(f"{w} ids equal {bool(torch.equal(a[0], b[0]))} score bits equal {bool(torch.equal(a[1].view(torch.int32), b[1].view(torch.int32)))}")
+        del items, users, res
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

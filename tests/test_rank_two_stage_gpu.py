@@ -1,10 +1,6 @@
-"""Two-stage exact top-k (bf16 coarse pass + fp32 rescoring; include/rectools_hip.h K12b, rank.HipRanker(two_stage=True)).
-
-OPT-IN: the path is not the default (it is correct but, in this first form, slower than the exact kernel — DESIGN.md §9.1)
-and these tests run only with RT_TEST_TWO_STAGE=1 (scripts/gpu_two_stage.sh).  The contract is the exact path's: same
-ids, order and fp32 scores.  First hardware visit: cases 1-3 passed, case 4 needed its (legitimate) fallback."""
-import os
-
+"""Two-stage exact top-k (include/rectools_hip.h K12c, rank.HipRanker): the hm-image coarse pass + the exact pass over 64 candidates
+per user must return what the single-stage kernel returns — ids, order and score BITS (the exact pass replays the 32-wide engine's
+instruction chain) — with a per-user proof, and fall back to the single-stage kernel for users where the proof cannot be given."""
 import numpy as np
 import pytest
 import torch
@@ -12,8 +8,7 @@ from scipy import sparse
 
 from oracle import ranker_oracle
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("RT_TEST_TWO_STAGE") != "1", reason="two-stage top-k is opt-in (RT_TEST_TWO_STAGE=1)")]
+pytestmark = pytest.mark.gpu
 
 
 def _factors(n_subj, n_obj, d, seed):
@@ -22,17 +17,19 @@ def _factors(n_subj, n_obj, d, seed):
 
 
 CASES = [
-    # distance, d, n_obj, n_subj, batch (users per pass), k, filter, whitelist
-    ("dot", 64, 20_000, 40, 32, 10, False, None),
-    ("dot", 256, 131_109, 70, 64, 10, True, None),
-    ("cosine", 128, 50_003, 33, 32, 5, True, "sparse"),
-    ("cosine", 512, 30_000, 200, 128, 32, False, "range"),     # k = 32 of K_c = 64: the proof fails for some users -> exact fallback
-    ("dot", 64, 9_000, 130, 128, 1, True, "range"),
+    # d, n_obj, n_subj, batch (users per pass), k, filter, whitelist
+    (64, 20_000, 140, 64, 10, False, None),
+    (256, 131_109, 300, 128, 10, True, None),
+    (128, 50_003, 133, 64, 5, True, "sparse"),
+    (512, 30_000, 200, 128, 16, False, "range"),
+    (64, 9_000, 130, 128, 1, True, "range"),
+    (96, 26_744, 1000, None, 10, True, "range"),       # the recommend() shape: library defaults
+    (32, 4_000, 70, 32, 3, False, None),
 ]
 
 
-@pytest.mark.parametrize("dist,d,n_obj,n_subj,batch,k,with_filter,wl_kind", CASES)
-def test_two_stage_equals_exact_path(dist, d, n_obj, n_subj, batch, k, with_filter, wl_kind):
+@pytest.mark.parametrize("d,n_obj,n_subj,batch,k,with_filter,wl_kind", CASES)
+def test_two_stage_returns_the_single_stage_result_bit_for_bit(d, n_obj, n_subj, batch, k, with_filter, wl_kind):
     from rectools_amd.rank import HipRanker
 
     subj, obj = _factors(n_subj, n_obj, d, seed=n_obj % 97)
@@ -46,70 +43,85 @@ def test_two_stage_equals_exact_path(dist, d, n_obj, n_subj, batch, k, with_filt
         wl = np.sort(rng.permutation(n_obj)[: n_obj // 2])
     elif wl_kind == "range":
         wl = np.arange(1000, n_obj - 500)
-    exact = HipRanker(dist, "cuda", subj, obj, batch_size=batch, two_stage=False)
-    fast = HipRanker(dist, "cuda", subj, obj, batch_size=batch, two_stage=True)
+    exact = HipRanker("dot", "cuda", subj, obj, batch_size=batch if batch else 64, two_stage=False)
+    fast = HipRanker("dot", "cuda", subj, obj, batch_size=batch, two_stage=True)
     e_ids, e_sc, e_cnt, _ = exact.rank_device(ids, k, filt, wl)
     f_ids, f_sc, f_cnt, _ = fast.rank_device(ids, k, filt, wl)
-    assert fast.two_stage_stats["calls"] == 1 and (fast.two_stage_stats["fallbacks"] == 0 or k > 10)
+    assert fast.two_stage_stats["calls"] == 1 and fast.two_stage_stats["unproven_users"] == 0, fast.two_stage_stats
     assert torch.equal(e_cnt, f_cnt)
     valid = torch.arange(e_ids.shape[1], device="cuda")[None, :] < e_cnt[:, None]
     assert torch.equal(e_ids[valid], f_ids[valid])
-    torch.testing.assert_close(f_sc[valid], e_sc[valid], rtol=2e-5, atol=1e-5)
-    # and against the CPU oracle on the first users
+    assert torch.equal(f_sc[valid].view(torch.int32), e_sc[valid].view(torch.int32))          # the same bits
     s_o, i_o, sc_o = ranker_oracle.rank(subj, obj, ids[:5], k=k, filter_pairs_csr=None if filt is None else filt[:5],
-                                        sorted_object_whitelist=wl, distance=dist)
-    got = f_ids[:5][valid[:5]].cpu().numpy()
-    assert got.tolist() == np.asarray(i_o).tolist()
+                                        sorted_object_whitelist=wl, distance="dot")
+    assert f_ids[:5][valid[:5]].cpu().numpy().tolist() == np.asarray(i_o).tolist()              # and the CPU oracle's order
 
 
-def test_two_stage_falls_back_when_the_margin_cannot_be_proven():
-    """A catalog of near-duplicates: more than K_c items sit inside the coarse error window of the k-th score, so the proof
-    fails and the call is ranked by the exact kernel — same result, one fallback recorded."""
+def test_two_stage_is_the_default_for_many_users_and_dot_products_only():
+    from rectools_amd.rank import HipRanker
+
+    subj, obj = _factors(300, 20_000, 64, 3)
+    r = HipRanker("dot", "cuda", subj, obj)
+    r.rank_device(np.arange(300), 10)
+    assert r.two_stage_stats["calls"] == 1
+    r.rank_device(np.arange(40), 10)                        # few users: the HBM-bound single-stage engines
+    assert r.two_stage_stats["calls"] == 1
+    c = HipRanker("cosine", "cuda", subj, obj, two_stage=True)
+    c.rank_device(np.arange(300), 10)
+    assert c.two_stage_stats["calls"] == 0
+
+
+def test_users_whose_result_cannot_be_proven_are_ranked_by_the_single_stage_kernel():
+    """Exact duplicates of the best items (ties at the k-th place) and a block of near-duplicates inside the coarse error window: the
+    proof fails for the affected users — flagged per user, re-ranked by the single-stage kernel, same bits in the end."""
     from rectools_amd.rank import HipRanker
 
     rng = np.random.default_rng(1)
-    base = rng.normal(size=(50, 64)).astype(np.float32)
-    obj = np.repeat(base, 400, axis=0) * (1.0 + 1e-4 * rng.normal(size=(20_000, 1))).astype(np.float32)
-    subj = rng.normal(size=(20, 64)).astype(np.float32)
-    exact = HipRanker("dot", "cuda", subj, obj, two_stage=False)
-    fast = HipRanker("dot", "cuda", subj, obj, two_stage=True)
-    e_ids, e_sc, e_cnt, _ = exact.rank_device(np.arange(20), 10)
-    f_ids, f_sc, f_cnt, _ = fast.rank_device(np.arange(20), 10)
-    assert fast.two_stage_stats == {"calls": 1, "fallbacks": 1}
-    assert torch.equal(e_ids, f_ids) and torch.equal(e_sc, f_sc)
+    d, n_obj = 64, 30_000
+    obj = rng.normal(size=(n_obj, d)).astype(np.float32)
+    subj = rng.normal(size=(200, d)).astype(np.float32)
+    # users 0..9 point at item 17's direction; items 100..229 are 130 copies of item 17 (more than the 64 candidates): their top-10 ties
+    obj[100:230] = obj[17]
+    subj[:10] = obj[17][None, :] * rng.uniform(0.5, 2.0, (10, 1)).astype(np.float32)
+    # users 20..24: 150 near-duplicates (relative spread 1e-6, far inside the coarse error) of their best direction
+    obj[1000:1150] = obj[33][None, :] * (1.0 + 1e-6 * rng.normal(size=(150, 1))).astype(np.float32)
+    subj[20:25] = obj[33][None, :] * rng.uniform(0.5, 2.0, (5, 1)).astype(np.float32)
+    exact = HipRanker("dot", "cuda", subj, obj, batch_size=64, two_stage=False)
+    fast = HipRanker("dot", "cuda", subj, obj, batch_size=64, two_stage=True)
+    e_ids, e_sc, e_cnt, _ = exact.rank_device(np.arange(200), 10)
+    f_ids, f_sc, f_cnt, _ = fast.rank_device(np.arange(200), 10)
+    st = fast.two_stage_stats
+    assert st["calls"] == 1 and st["fallbacks"] == 0 and 15 <= st["unproven_users"] <= 40, st
+    assert torch.equal(e_ids, f_ids) and torch.equal(e_sc.view(torch.int32), f_sc.view(torch.int32)) and torch.equal(e_cnt, f_cnt)
+    # a catalog made of near-duplicates only defeats the coarse pass for everybody: the whole call goes to the single-stage kernel
+    base = rng.normal(size=(50, d)).astype(np.float32)
+    obj2 = np.repeat(base, 400, axis=0) * (1.0 + 1e-6 * rng.normal(size=(20_000, 1))).astype(np.float32)
+    exact2 = HipRanker("dot", "cuda", subj, obj2, batch_size=64, two_stage=False)
+    fast2 = HipRanker("dot", "cuda", subj, obj2, batch_size=64, two_stage=True)
+    e2 = exact2.rank_device(np.arange(200), 10)
+    f2 = fast2.rank_device(np.arange(200), 10)
+    assert fast2.two_stage_stats["fallbacks"] == 1
+    assert torch.equal(e2[0], f2[0]) and torch.equal(e2[1].view(torch.int32), f2[1].view(torch.int32))
 
 
-def test_bf16_image_and_rescore_kernels():
-    """rt_to_bf16_rows == torch's round-to-nearest-even bf16 cast (+ norms, + gather, + normalisation); rt_topk_rescore ==
-    fp32 dot / cosine of the gathered rows."""
+def test_hm_image_kernel():
+    """rt_to_hm_rows: word = (h << 16) | m with h, m the bf16 truncations of x and x - h; x - h - m below 2^-15 |x|; norms; gather."""
     from rectools_amd import _lib
 
     lib = _lib.load()
-    g = torch.Generator().manual_seed(0)
-    x = (torch.randn(300, 192, generator=g) * torch.logspace(-3, 3, 300)[:, None]).cuda()
-    rows = torch.randperm(300, generator=g)[:77].cuda()
-    for normalize in (0, 1):
-        img = torch.empty((77, 192), dtype=torch.bfloat16, device="cuda")
-        norms = torch.empty((77,), dtype=torch.float32, device="cuda")
-        _lib.check(lib.rt_to_bf16_rows(x.data_ptr(), x.stride(0), rows.data_ptr(), 77, 192, normalize, img.data_ptr(), norms.data_ptr(),
-                                       _lib.current_stream()), "rt_to_bf16_rows")
-        src = x[rows]
-        torch.testing.assert_close(norms, src.norm(dim=1), rtol=1e-5, atol=0)
-        want = (src / src.norm(dim=1, keepdim=True).clamp_min(1e-8)) if normalize else src
-        if normalize:   # the kernel scales by the reciprocal: allow one bf16 ulp
-            torch.testing.assert_close(img.float(), want.to(torch.bfloat16).float(), rtol=2 ** -7, atol=0)
-        else:
-            assert torch.equal(img, want.to(torch.bfloat16))
-    users, items = torch.randn(9, 192, generator=g).cuda(), x
-    cand = torch.randint(0, 300, (9, 12), generator=g).cuda()
-    counts = torch.tensor([12, 0, 5, 12, 1, 7, 12, 3, 11], dtype=torch.int32).cuda()
-    for dist in (0, 1):
-        out = torch.empty((9, 12), dtype=torch.float32, device="cuda")
-        _lib.check(lib.rt_topk_rescore(users.data_ptr(), users.stride(0), None, 9, items.data_ptr(), items.stride(0), 192, dist,
-                                       cand.data_ptr(), counts.data_ptr(), 12, out.data_ptr(), _lib.current_stream()), "rt_topk_rescore")
-        ref = torch.einsum("ud,ukd->uk", users, items[cand])
-        if dist == 1:
-            ref = ref / users.norm(dim=1, keepdim=True).clamp_min(1e-8) / items[cand].norm(dim=2).clamp_min(1e-8)
-        valid = torch.arange(12, device="cuda")[None, :] < counts[:, None]
-        torch.testing.assert_close(out[valid], ref[valid], rtol=2e-5, atol=2e-5)
-        assert bool(torch.isinf(out[~valid]).all())
+    torch.manual_seed(0)
+    x = (torch.randn(300, 192) * torch.logspace(-3, 3, 300)[:, None]).cuda()
+    x[5, :7] = 0.0
+    rows = torch.randperm(300)[:77].cuda()
+    img = torch.empty(77, 192, dtype=torch.int32, device="cuda")
+    norms = torch.empty(77, device="cuda")
+    _lib.check(lib.rt_to_hm_rows(x.data_ptr(), x.stride(0), rows.data_ptr(), 77, 192, img.data_ptr(), 192, norms.data_ptr(),
+                                 _lib.current_stream()), "rt_to_hm_rows")
+    src = x[rows]
+    h = (img & -65536).view(torch.float32)
+    m = (img << 16).view(torch.float32)
+    assert torch.equal(h, (src.view(torch.int32) & -65536).view(torch.float32))
+    r = src - h
+    assert torch.equal(m, (r.view(torch.int32) & -65536).view(torch.float32))
+    assert bool(((src - h - m).abs() <= src.abs() * 2.0 ** -15).all())
+    torch.testing.assert_close(norms, src.double().norm(dim=1).float(), rtol=1e-5, atol=0)
