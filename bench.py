@@ -377,12 +377,23 @@ def run_train(args, rank, world, kind="train"):
                 "single_stream": {"avg_launch_ms": round(ms1 / len(calls), 4), "achieved": round(fl / (ms1 * 1e-3) / 1e12, 2)}}
     else:
         M = B * L
-        if dom in ("rt_mha_fwd", "rt_mha_bwd", "rt_hstu_attn_fwd", "rt_hstu_attn_bwd"):
-            fl = 4.0 * L * L * d * B * (2.5 if dom.endswith("bwd") else 1.0)       # dense; causal-useful half is executed
+        attn = ("rt_mha_fwd", "rt_mha_bwd", "rt_hstu_attn_fwd", "rt_hstu_attn_bwd", "rt_mha_varlen_train_fwd", "rt_mha_varlen_bwd",
+                "rt_mha_varlen_bidir_fwd", "rt_mha_varlen_bidir_bwd", "rt_hstu_attn_varlen_fwd", "rt_hstu_attn_varlen_bwd")
+        if dom in attn:
+            n2, what = float(L * L), "dense 4 L^2 d flops per sequence and block"
+            if "varlen" in dom:      # packed sessions: the dense square of every session's OWN length (mean over the resident sessions)
+                off = np.asarray(loop.store.offsets, dtype=np.int64)
+                n = np.clip(off[1:] - off[:-1] - (0 if loop.bert else 1), 0, L).astype(np.float64)
+                n2, what = float((n * n).mean()), "packed sessions: dense 4 n^2 d flops per session and block, n = its real length"
+            fl = 4.0 * n2 * d * B * (2.5 if dom.endswith("bwd") else 1.0)       # dense; causal-useful half is executed
             ms = per_kernel[dom][0] / per_kernel[dom][1]
             tf = fl / (ms * 1e-3) / 1e12
-            roof = {"kernel": dom + " (dense 4 L^2 d flops per sequence and block; bwd x2.5)", "bound": "mfma", "achieved": round(tf, 2),
-                    "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4), "traffic": None,
+            # the bf16-plane kernels (rt_attention_v2.hip: head sizes 32 / 64 of the softmax families) run six bf16 products per fp32
+            # product; everything else is on the f32-input instruction
+            x6 = dom.startswith("rt_mha_varlen") and d // H in (32, 64) and os.environ.get("RT_VARLEN_IMPL", "") != "v1"
+            peak = MFMA_BF16_PEAK_TF / 6.0 if x6 else MFMA_F32_PEAK_TF
+            roof = {"kernel": dom + f" ({what}; bwd x2.5)", "bound": "mfma", "achieved": round(tf, 2),
+                    "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(tf / peak, 4), "traffic": None,
                     "avg_launch_ms": round(ms, 4), "algorithmic_flops_per_launch": fl}
         elif dom.startswith("rt_sampled_loss"):
             byts = M * 0.72 * (1 + n_neg) * (4.0 * d + 8.0) * (2.0 if dom.endswith("bwd") else 1.0) + 4.0 * M * d

@@ -173,6 +173,11 @@ int rt_collate(const int64_t* offsets, const int64_t* items, const float* weight
  * end = the index of its positional row (net_blocks.py:388-399). */
 int rt_collate_packed(const int64_t* offsets, const int64_t* items, const float* weights, const int64_t* idx, const int64_t* cu_seqlens,
                       int32_t B, int32_t rows, int32_t train, int64_t* x, int64_t* y, float* yw, int64_t* dist, rt_stream_t stream);
+/* ... the timestamps of a packed SASRec-style batch (sasrec.py:96-104 with `add_unix_ts`): session b gets its kept tail's
+ * cu[b+1] - cu[b] + 1 timestamps at ts_out[cu[b] + b ..] (the rows' items and the target of the last row:
+ * what the padded [B, L+1] batch holds behind its left pad).  n_out = cu[B] + B entries (the caller knows cu[B] on the host). */
+int rt_collate_packed_ts(const int64_t* offsets, const int64_t* unix_ts, const int64_t* idx, const int64_t* cu_seqlens, int32_t B,
+                         int64_t n_out, int64_t* ts_out, rt_stream_t stream);
 /* ... the BERT4Rec batch on packed rows (bert4rec.py:109-153, 182-193).  train = 1: cu[b+1] - cu[b] = min(length, window) rows; probs /
  * rand_ids [B, window] are the draws of rt_collate mode 3, read at the row's padded position (b, window - n + j) — the packed batch
  * masks what the padded one masks; y = the item where the position was picked, else 0.  draw_rows [B] or NULL: the row of the draws
@@ -418,6 +423,20 @@ int rt_hstu_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, c
                      const int64_t* time_thr, const float* pos_w, int32_t B, int32_t H, int32_t L, int32_t hd,
                      float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv, float* d_time_w,
                      float* d_pos_w, rt_stream_t stream);
+/* ... over PACKED sessions (no pad rows): session b owns rows cu_seqlens[b] .. cu_seqlens[b+1]-1 of q / k / v / o and
+ * the cu[b+1] - cu[b] + 1 timestamps ts[cu[b] + b ..] (rt_collate_packed_ts); window = session_max_len (the 1 / L of hstu.py:284 and the
+ * position table [2 window - 1]).  The reference zeroes pad rows before the bias-free projection (hstu.py:256-262): a pad key's v row is
+ * silu(0) = 0, it contributes nothing, so the packed form equals the padded one on every real row.  Ring kernels only (hd 32 / 64,
+ * 16-byte aligned rows), RT_ERR_UNSUPPORTED otherwise. */
+int rt_hstu_attn_varlen_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                            const int64_t* cu_seqlens, const int64_t* ts, const float* time_w, const int64_t* time_thr,
+                            const float* pos_w, int32_t B, int32_t H, int32_t window, int32_t hd, float* o, int64_t ldo,
+                            rt_stream_t stream);
+int rt_hstu_attn_varlen_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                            const float* dout, int64_t lddo, const int64_t* cu_seqlens, const int64_t* ts, const float* time_w,
+                            const int64_t* time_thr, const float* pos_w, int32_t B, int32_t H, int32_t window, int32_t hd,
+                            float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv, float* d_time_w,
+                            float* d_pos_w, rt_stream_t stream);
 /* the same for the LAST query of every session only (inference, see rt_mha_last_fwd): q [B, ldq], o [B, ldo] */
 int rt_hstu_attn_last_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const int64_t* ids,
                           const int64_t* ts, const float* time_w, const int64_t* time_thr, const float* pos_w, int32_t B,

@@ -73,6 +73,10 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_mha_varlen_last_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rt_hstu_attn_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rt_hstu_attn_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "rt_hstu_attn_varlen_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64,
+                                        c_vp]),
+    "rt_hstu_attn_varlen_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,
+                                        c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "rt_hstu_attn_last_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rt_sampled_loss_fwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f64, c_vp, c_vp, c_vp]),
     "rt_sampled_loss_bwd_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
@@ -85,6 +89,7 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_gather_rows": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rt_scatter_rows": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rt_collate_packed": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "rt_collate_packed_ts": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_vp]),
     "rt_collate_packed_bert": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_i64, c_vp, c_vp,
                                        c_vp, c_vp, c_vp]),
     "rt_embed_packed_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_f32, c_u64, c_u64, c_vp, c_vp]),

@@ -51,7 +51,18 @@ struct AttnArgs {
   const long long* time_thr;               // [129] smallest |dt| that falls in bucket >= b (host-computed)
   const float* pos_w;                      // [2L-1] (null: no position bias)
   float* d_time_w; float* d_pos_w;         // backward accumulators
+  // packed sessions (ring kernels, hstu mode): session b owns rows cu[b] .. cu[b+1]-1 of q / k / v / o (no pad rows, ids == NULL) and the
+  // cu[b+1] - cu[b] + 1 timestamps ts[cu[b] + b ..]; L = the window (grid geometry), Lw = the window of the bias tables and of 1 / L.
+  // A kernel turns its copy of the arguments into the view of ITS session (session_view): L becomes the session's length.
+  const long long* cu; int Lw;
 };
+__device__ __forceinline__ int win(const AttnArgs& a) { return a.Lw > 0 ? a.Lw : a.L; }
+__device__ __forceinline__ long long session_view(AttnArgs& a, int b) {
+  if (a.cu == nullptr) return (long long)b * a.L;
+  const long long r0 = a.cu[b];
+  a.Lw = a.L; a.L = (int)(a.cu[b + 1] - r0);
+  return r0;
+}
 
 __device__ __forceinline__ int row_of(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
@@ -284,7 +295,7 @@ __device__ __forceinline__ void fwd_pair(const AttnArgs& a, const float* Kt, con
       float bv = 0.f;
       if (!d) {
         if (a.time_w) bv += hl.tw[time_bucket(hl.thr, t_q1 - hl.ts[kk])];
-        if (a.pos_w) bv += hl.pw[(a.L - 1) + kk - qq];
+        if (a.pos_w) bv += hl.pw[(win(a) - 1) + kk - qq];
       }
       bias[r] = bv;
       if (d) dead |= 1u << r;
@@ -350,7 +361,7 @@ __device__ __forceinline__ void fwd_pair(const AttnArgs& a, const float* Kt, con
 #pragma unroll
     for (int r = 0; r < 16; ++r) p[r] = ((keep >> r) & 1u) ? p[r] * inv_keep : 0.f;
   } else {
-    const float inv_l = 1.0f / (float)a.L;
+    const float inv_l = 1.0f / (float)win(a);
 #pragma unroll
     for (int r = 0; r < 16; ++r) p[r] = ((dead >> r) & 1u) ? 0.f : silu_f(sacc[r] + bias[r]) * inv_l;
   }
@@ -403,7 +414,7 @@ __device__ __forceinline__ void tile_p_ds(const AttnArgs& a, float s_raw, float 
     p_used = pn * drop_scale;                       // what multiplied V in the forward pass
     ds = pn * (dp * drop_scale - delta_q) * a.scale; // d/d(raw q.k)
   } else {
-    const float inv_l = 1.0f / (float)a.L;
+    const float inv_l = 1.0f / (float)win(a);
     const float z = s_raw + bias;
     p_used = dead ? 0.f : silu_f(z) * inv_l;
     ds = dead ? 0.f : dp * inv_l * silu_df(z);
@@ -449,7 +460,7 @@ __device__ __forceinline__ void dq_pair(const AttnArgs& a, const float* Kt, cons
       float bv = 0.f; int tb = 0;
       if (!d) {
         if (a.time_w) { tb = time_bucket(hl.thr, t_q1 - hl.ts[kk]); bv += hl.tw[tb]; }
-        if (a.pos_w) bv += hl.pw[(a.L - 1) + kk - qq];
+        if (a.pos_w) bv += hl.pw[(win(a) - 1) + kk - qq];
       }
       bias[r] = bv; tbk[r] = tb;
       if (d) dead |= 1u << r;
@@ -493,7 +504,7 @@ __device__ __forceinline__ void dq_pair(const AttnArgs& a, const float* Kt, cons
     if (MODE == MODE_HSTU && !dd_) {
       // relative-bias gradients: rab is shared by the heads, so every head adds its dS (hstu.py:276)
       if (a.d_time_w) trun.add(hl.dtw, tbk[r], ds[r]);
-      if (a.d_pos_w) atomicAdd(hl.dpw + (a.L - 1) + kt * TK + row_of(r, half) - qq, ds[r]);
+      if (a.d_pos_w) atomicAdd(hl.dpw + (win(a) - 1) + kt * TK + row_of(r, half) - qq, ds[r]);
     }
   }
   RT_FENCE();
@@ -544,7 +555,7 @@ __device__ __forceinline__ void dkv_pair(const AttnArgs& a, const float* Qt, con
       float bv = 0.f;
       if (!d) {
         if (a.time_w) bv += hl.tw[time_bucket(hl.thr, hl.ts[q + 1] - t_k)];
-        if (a.pos_w) bv += hl.pw[(a.L - 1) + kk - q];
+        if (a.pos_w) bv += hl.pw[(win(a) - 1) + kk - q];
       }
       bias[r] = bv;
       if (d) dead |= 1u << r;
@@ -648,16 +659,18 @@ __device__ __forceinline__ void hstu_fill(const AttnArgs& a, const HstuLds& hl, 
   float* tw = const_cast<float*>(hl.tw); float* pw = const_cast<float*>(hl.pw);
   long long* thr = const_cast<long long*>(hl.thr); long long* ts = const_cast<long long*>(hl.ts);
   if (a.time_w) for (int i = tid; i < NBUCK; i += nthreads) { tw[i] = a.time_w[i]; thr[i] = a.time_thr[i]; }
-  if (a.pos_w) for (int i = tid; i < 2 * a.L - 1; i += nthreads) pw[i] = a.pos_w[i];
-  if (a.ts) for (int i = tid; i < a.L + 1; i += nthreads) ts[i] = a.ts[(long long)b * (a.L + 1) + i];
+  const int W = win(a);
+  if (a.pos_w) for (int i = tid; i < 2 * W - 1; i += nthreads) pw[i] = a.pos_w[i];
+  const long long* tsb = a.cu ? a.ts + a.cu[b] + b : a.ts + (long long)b * (a.L + 1);    // (a.L + 1 timestamps either way)
+  if (a.ts) for (int i = tid; i < a.L + 1; i += nthreads) ts[i] = tsb[i];
   if (hl.dtw) {
     for (int i = tid; i < NBUCK + 3; i += nthreads) hl.dtw[i] = 0.f;
-    for (int i = tid; i < ((2 * a.L + 3) & ~3); i += nthreads) hl.dpw[i] = 0.f;
+    for (int i = tid; i < ((2 * W + 3) & ~3); i += nthreads) hl.dpw[i] = 0.f;
   }
 }
 __device__ __forceinline__ void hstu_flush_grads(const AttnArgs& a, const HstuLds& hl, int tid, int nthreads) {
   if (a.d_time_w) for (int i = tid; i < NBUCK; i += nthreads) if (hl.dtw[i] != 0.f) atomicAdd(a.d_time_w + i, hl.dtw[i]);
-  if (a.d_pos_w) for (int i = tid; i < 2 * a.L - 1; i += nthreads) if (hl.dpw[i] != 0.f) atomicAdd(a.d_pos_w + i, hl.dpw[i]);
+  if (a.d_pos_w) for (int i = tid; i < 2 * win(a) - 1; i += nthreads) if (hl.dpw[i] != 0.f) atomicAdd(a.d_pos_w + i, hl.dpw[i]);
 }
 constexpr int hstu_lds_floats(int L, bool with_grads) {
   return (NBUCK + 3) + ((2 * L + 3) & ~3) + 2 * (NBUCK + 1) + 2 * (L + 2) + (with_grads ? (NBUCK + 3) + ((2 * L + 3) & ~3) : 0);
@@ -1453,16 +1466,18 @@ __global__ __launch_bounds__(AT) __attribute__((amdgpu_waves_per_eu(2))) void at
   const int b = bh / a.H, h = bh % a.H;
   const int qt = x * 4 + ((wave + bh) & 3);          // the slot -> SIMD pairing rotates with bh: every SIMD sees every tile cost
   const int q0 = qt * TK, qq = q0 + col;
-  const long long rowbase = (long long)b * a.L;
+  const long long rowbase = session_view(a, b);      // packed sessions: a.L is this session's length from here on
+  if (x * 4 * TK >= a.L) return;                     // (packed: query groups behind a short session's end; uniform, before any barrier)
+  const int n_ts = (a.L + TK - 1) / TK;
   const float* qb = a.q + rowbase * a.ldq + h * a.hd;
-  const long long* idb = a.ids + rowbase;
+  const long long* idb = a.ids ? a.ids + rowbase : nullptr;
   RT_TMARK((bh == 1 || bh == 300) && qt == n_t - 1, (bh == 1 ? 512 : 768) + 0);
-  for (int i = tid; i < Lp; i += AT) kflag[i] = (i < a.L && idb[i] != 0) ? 0.f : 1.f;
+  for (int i = tid; i < Lp; i += AT) kflag[i] = (i < a.L && (idb == nullptr || idb[i] != 0)) ? 0.f : 1.f;
   if (MODE == MODE_HSTU) hstu_fill(a, hl, b, tid, AT);
 
   f32x4 qf[HDV];
   load_row_frags<HDV>(qb, a.ldq, qq, a.L, a.hd, half, qf);
-  int q_pad_i = (qq < a.L) ? (idb[qq] == 0) : 1;
+  int q_pad_i = (qq < a.L) ? (idb != nullptr && idb[qq] == 0) : 1;
 #pragma unroll
   for (int s = 0; s < HDV; ++s) pin(qf[s]);
   pin(q_pad_i);
@@ -1475,7 +1490,7 @@ __global__ __launch_bounds__(AT) __attribute__((amdgpu_waves_per_eu(2))) void at
   float m_run = -INFINITY, l_run = 0.f;
 
   const int wg_q_last = min(a.L, (x * 4 + 4) * TK) - 1;
-  const int n_kt = a.causal ? (wg_q_last / TK + 1) : n_t;     // key tiles this workgroup walks
+  const int n_kt = a.causal ? (wg_q_last / TK + 1) : n_ts;    // key tiles this workgroup walks
   const int my_last_kt = a.causal ? min(n_kt - 1, qt) : n_kt - 1;
   const bool active = q0 < a.L;
   const bool q_inside = (qt + 1) * TK <= a.L;
@@ -1538,17 +1553,19 @@ __global__ __launch_bounds__(AT) __attribute__((amdgpu_waves_per_eu(2))) void at
   const int b = bh / a.H, h = bh % a.H;
   const int qt = x * 4 + ((wave + bh) & 3);
   const int q0 = qt * TK, qq = q0 + col;
-  const long long rowbase = (long long)b * a.L;
+  const long long rowbase = session_view(a, b);
+  if (x * 4 * TK >= a.L) return;
+  const int n_ts = (a.L + TK - 1) / TK;
   const float* qb = a.q + rowbase * a.ldq + h * a.hd;
   const float* gb = a.dout + rowbase * a.lddo + h * a.hd;
-  const long long* idb = a.ids + rowbase;
-  for (int i = tid; i < Lp; i += AT) kflag[i] = (i < a.L && idb[i] != 0) ? 0.f : 1.f;
+  const long long* idb = a.ids ? a.ids + rowbase : nullptr;
+  for (int i = tid; i < Lp; i += AT) kflag[i] = (i < a.L && (idb == nullptr || idb[i] != 0)) ? 0.f : 1.f;
   if (MODE == MODE_HSTU) hstu_fill(a, hl, b, tid, AT);
 
   f32x4 qf[HDV], gf[HDV];
   load_row_frags<HDV>(qb, a.ldq, qq, a.L, a.hd, half, qf);
   load_row_frags<HDV>(gb, a.lddo, qq, a.L, a.hd, half, gf);
-  int q_pad_i = (qq < a.L) ? (idb[qq] == 0) : 1;
+  int q_pad_i = (qq < a.L) ? (idb != nullptr && idb[qq] == 0) : 1;
   float lse_q = 0.f, delta_q = 0.f;
   if (MODE == MODE_SOFTMAX) {
     if (qq < a.L) lse_q = a.lse[(long long)bh * a.L + qq];
@@ -1565,7 +1582,7 @@ __global__ __launch_bounds__(AT) __attribute__((amdgpu_waves_per_eu(2))) void at
     for (int r = 0; r < 16; ++r) dqacc[t][r] = 0.f;
 
   const int wg_q_last = min(a.L, (x * 4 + 4) * TK) - 1;
-  const int n_kt = a.causal ? (wg_q_last / TK + 1) : n_t;
+  const int n_kt = a.causal ? (wg_q_last / TK + 1) : n_ts;
   const int my_last_kt = a.causal ? min(n_kt - 1, qt) : n_kt - 1;
   const bool active = q0 < a.L;
   const bool q_inside = (qt + 1) * TK <= a.L;
@@ -1627,21 +1644,23 @@ __global__ __launch_bounds__(AT) __attribute__((amdgpu_waves_per_eu(2))) void at
   const int b = bh / a.H, h = bh % a.H;
   const int ktile = x * 4 + ((wave + bh) & 3);
   const int k0 = ktile * TK, kk = k0 + col;
-  const long long rowbase = (long long)b * a.L;
+  const long long rowbase = session_view(a, b);
+  if (x * 4 * TK >= a.L) return;
+  const int n_ts = (a.L + TK - 1) / TK;
   const float* kb = a.k + rowbase * a.ldk + h * a.hd;
   const float* vb = a.v + rowbase * a.ldv + h * a.hd;
-  const long long* idb = a.ids + rowbase;
+  const long long* idb = a.ids ? a.ids + rowbase : nullptr;
   for (int i = tid; i < Lp; i += AT) {
     s_lse[i] = (MODE == MODE_SOFTMAX && i < a.L) ? a.lse[(long long)bh * a.L + i] : 0.f;
     s_delta[i] = (MODE == MODE_SOFTMAX && i < a.L) ? a.delta[(long long)bh * a.L + i] : 0.f;
-    qflag[i] = (i < a.L && idb[i] != 0) ? 0.f : 1.f;
+    qflag[i] = (i < a.L && (idb == nullptr || idb[i] != 0)) ? 0.f : 1.f;
   }
   if (MODE == MODE_HSTU) hstu_fill(a, hl, b, tid, AT);
 
   f32x4 kf[HDV], vf[HDV];
   load_row_frags<HDV>(kb, a.ldk, kk, a.L, a.hd, half, kf);
   load_row_frags<HDV>(vb, a.ldv, kk, a.L, a.hd, half, vf);
-  int k_pad_i = (kk < a.L) ? (idb[kk] == 0) : 1;
+  int k_pad_i = (kk < a.L) ? (idb != nullptr && idb[kk] == 0) : 1;
 #pragma unroll
   for (int s = 0; s < HDV; ++s) { pin(kf[s]); pin(vf[s]); }
   pin(k_pad_i);
@@ -1653,7 +1672,7 @@ __global__ __launch_bounds__(AT) __attribute__((amdgpu_waves_per_eu(2))) void at
     for (int r = 0; r < 16; ++r) { dkacc[t][r] = 0.f; dvacc[t][r] = 0.f; }
 
   const int first_qt = a.causal ? x * 4 : 0;        // queries at or behind the first key of the workgroup
-  const int n_steps = n_t - first_qt;
+  const int n_steps = n_ts - first_qt;
   const int my_first_qt = a.causal ? ktile : 0;
   const bool active = k0 < a.L;
   const bool k_inside = (ktile + 1) * TK <= a.L;
@@ -1759,7 +1778,7 @@ int launch_fwd(const AttnArgs& a, hipStream_t stream) {
   const bool res_fits = rl <= LDS_LIMIT;
   if constexpr (HD <= 64) {
     const size_t gl = ring_lds_bytes(HD, a.L, 1, MODE == MODE_HSTU, false);
-    const bool want_ring = impl == IMPL_RING || ((impl == IMPL_AUTO || impl == IMPL_RES) && !res_fits);
+    const bool want_ring = a.cu != nullptr || impl == IMPL_RING || ((impl == IMPL_AUTO || impl == IMPL_RES) && !res_fits);
     if (want_ring && ring_ok<HD>(a, false) && gl <= LDS_LIMIT) {
       { const int rc = set_lds(&attn_fwd_ring_kernel<MODE, HD, RING_NS>, gl); if (rc != RT_OK) return rc; }
       const int n_x = ((a.L + TK - 1) / TK + 3) / 4;
@@ -1768,6 +1787,7 @@ int launch_fwd(const AttnArgs& a, hipStream_t stream) {
       return RT_OK;
     }
   }
+  if (a.cu != nullptr) return RT_ERR_UNSUPPORTED;   // packed sessions are served by the ring kernels only
   if constexpr (HD <= 64) {   // cooperative resident forward: causal, at most 8 tiles (one round of the 8 waves), LDS permitting
     const int n_t = (a.L + TK - 1) / TK;
     const size_t cl = rl + (size_t)(4 * (HD / 2 + 2) * 64 + 8) * 4;
@@ -1809,7 +1829,7 @@ int launch_bwd(const AttnArgs& a, hipStream_t stream) {
   if constexpr (HD <= 64) {
     const size_t g1 = ring_lds_bytes(HD, a.L, 1, MODE == MODE_HSTU, true);
     const size_t g2 = ring_lds_bytes(HD, a.L, 3, MODE == MODE_HSTU, false);
-    const bool want_ring = impl == IMPL_RING || ((impl == IMPL_AUTO || impl == IMPL_RES) && !res_fits);
+    const bool want_ring = a.cu != nullptr || impl == IMPL_RING || ((impl == IMPL_AUTO || impl == IMPL_RES) && !res_fits);
     if (want_ring && ring_ok<HD>(a, true) && g1 <= LDS_LIMIT && g2 <= LDS_LIMIT) {
       { const int rc = set_lds(&attn_bwd_dq_ring_kernel<MODE, HD, RING_NS>, g1); if (rc != RT_OK) return rc; }
       { const int rc = set_lds(&attn_bwd_dkv_ring_kernel<MODE, HD, RING_NS>, g2); if (rc != RT_OK) return rc; }
@@ -1821,6 +1841,7 @@ int launch_bwd(const AttnArgs& a, hipStream_t stream) {
       return RT_OK;
     }
   }
+  if (a.cu != nullptr) return RT_ERR_UNSUPPORTED;
   if (res_fits && impl != IMPL_STREAM) {
     if constexpr (HD <= 64) {
       if (a.hd == HD && attn_allow_dma() && al16(a.k) && al16(a.v) && al16(a.q) && al16(a.dout)) {
@@ -2118,6 +2139,46 @@ int rt_hstu_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, c
   a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.dout = dout; a.lddo = lddo;
   a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   a.ids = reinterpret_cast<const long long*>(ids); a.B = B; a.H = H; a.L = L; a.hd = hd; a.causal = 1; a.keypad = 0;
+  a.ts = reinterpret_cast<const long long*>(ts); a.time_w = time_w;
+  a.time_thr = reinterpret_cast<const long long*>(time_thr); a.pos_w = pos_w;
+  a.d_time_w = d_time_w; a.d_pos_w = d_pos_w;
+  return dispatch_bwd<MODE_HSTU>(a, stream);
+}
+
+// HSTU attention over PACKED sessions (no pad rows): session b owns rows cu_seqlens[b] .. cu_seqlens[b+1]-1 of q / k / v / o and the
+// cu[b+1] - cu[b] + 1 timestamps ts[cu[b] + b ..] (its items' and the next action's, the layout of the padded [B, L+1] batch without
+// the left pad); window = the reference's session_max_len (1 / L of hstu.py:284, the position table [2 window - 1]).  The reference
+// zeroes the pad rows before every projection and the projection has no bias (hstu.py:256-262), so a pad key's v row is silu(0) = 0 and
+// contributes nothing: dropping the pad rows changes no real row.  Ring kernels only (hd 32 / 64, 16-byte aligned rows), else
+// RT_ERR_UNSUPPORTED.
+int rt_hstu_attn_varlen_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                            const int64_t* cu_seqlens, const int64_t* ts, const float* time_w, const int64_t* time_thr,
+                            const float* pos_w, int32_t B, int32_t H, int32_t window, int32_t hd, float* o, int64_t ldo,
+                            hipStream_t stream) {
+  (void)hipGetLastError();
+  if (bad_common(B, H, window, hd, ldq, ldk, ldv) || (ldo & 3) || misaligned16(o) || cu_seqlens == nullptr) return RT_ERR_INVALID_ARG;
+  if ((time_w != nullptr) != (ts != nullptr) || (time_w != nullptr) != (time_thr != nullptr)) return RT_ERR_INVALID_ARG;
+  AttnArgs a{};
+  a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.o = o; a.ldo = ldo;
+  a.ids = nullptr; a.cu = reinterpret_cast<const long long*>(cu_seqlens); a.B = B; a.H = H; a.L = window; a.Lw = window; a.hd = hd;
+  a.causal = 1; a.keypad = 0;
+  a.ts = reinterpret_cast<const long long*>(ts); a.time_w = time_w;
+  a.time_thr = reinterpret_cast<const long long*>(time_thr); a.pos_w = pos_w;
+  return dispatch_fwd<MODE_HSTU>(a, stream);
+}
+int rt_hstu_attn_varlen_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                            const float* dout, int64_t lddo, const int64_t* cu_seqlens, const int64_t* ts, const float* time_w,
+                            const int64_t* time_thr, const float* pos_w, int32_t B, int32_t H, int32_t window, int32_t hd,
+                            float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv, float* d_time_w,
+                            float* d_pos_w, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (bad_common(B, H, window, hd, ldq, ldk, ldv) || (lddo & 3) || (lddq & 3) || (lddk & 3) || (lddv & 3) || misaligned16(dq) ||
+      misaligned16(dk) || misaligned16(dv) || cu_seqlens == nullptr) return RT_ERR_INVALID_ARG;
+  AttnArgs a{};
+  a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.dout = dout; a.lddo = lddo;
+  a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+  a.ids = nullptr; a.cu = reinterpret_cast<const long long*>(cu_seqlens); a.B = B; a.H = H; a.L = window; a.Lw = window; a.hd = hd;
+  a.causal = 1; a.keypad = 0;
   a.ts = reinterpret_cast<const long long*>(ts); a.time_w = time_w;
   a.time_thr = reinterpret_cast<const long long*>(time_thr); a.pos_w = pos_w;
   a.d_time_w = d_time_w; a.d_pos_w = d_pos_w;

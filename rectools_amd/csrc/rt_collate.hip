@@ -113,6 +113,23 @@ __global__ __launch_bounds__(256) void collate_packed_kernel(PackedArgs a) {
   if (a.train) { a.y[r] = yi; a.yw[r] = w; }
 }
 
+// timestamps of a packed training batch: one thread per output entry; session b owns entries cu[b] + b .. cu[b+1] + b (its n rows' items
+// and the target of the last row = the last n + 1 timestamps of the session)
+__global__ __launch_bounds__(256) void collate_packed_ts_kernel(const long long* __restrict__ offsets, const long long* __restrict__ unix_ts,
+                                                                const long long* __restrict__ idx, const long long* __restrict__ cu, int B,
+                                                                long long n_out, long long* __restrict__ ts_out) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_out || e >= cu[B] + B) return;
+  int lo = 0, hi = B;                     // largest b with cu[b] + b <= e
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (cu[mid] + mid <= e) lo = mid; else hi = mid;
+  }
+  const long long n = cu[lo + 1] - cu[lo], j = e - cu[lo] - lo;      // j in [0, n]
+  const long long end = offsets[idx[lo] + 1];
+  ts_out[e] = unix_ts[end - (n + 1) + j];
+}
+
 // BERT4Rec on packed rows (bert4rec.py:109-153 / 182-193): train — session b shows its last n = cu[b+1] - cu[b] items, the masking draws
 // are read at the PADDED position of the row (b, window - n + j), so that the packed batch masks exactly what `rt_collate` mode 3 masks
 // when it is fed the same [B, window] draws; recommend — n - 1 history items and the MASK token as the last row.
@@ -219,6 +236,20 @@ int rt_collate_packed(const int64_t* offsets, const int64_t* items, const float*
   return RT_OK;
 }
 
+// Timestamps of a packed training batch: n_out = cu[B] + B entries (the caller knows cu[B] on the host), session b's n + 1 at cu[b] + b.
+// Every session must hold at least n + 1 items (it does: n = min(length - 1, window)).
+int rt_collate_packed_ts(const int64_t* offsets, const int64_t* unix_ts, const int64_t* idx, const int64_t* cu_seqlens, int32_t B,
+                         int64_t n_out, int64_t* ts_out, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (B < 0 || n_out < 0) return RT_ERR_INVALID_ARG;
+  if (n_out == 0) return RT_OK;
+  if (offsets == nullptr || unix_ts == nullptr || idx == nullptr || cu_seqlens == nullptr || ts_out == nullptr) return RT_ERR_INVALID_ARG;
+  collate_packed_ts_kernel<<<(unsigned)((n_out + 255) / 256), 256, 0, stream>>>(
+      reinterpret_cast<const long long*>(offsets), reinterpret_cast<const long long*>(unix_ts), reinterpret_cast<const long long*>(idx),
+      reinterpret_cast<const long long*>(cu_seqlens), B, n_out, reinterpret_cast<long long*>(ts_out));
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
 // Packed BERT4Rec batch.  train = 1: cu[b+1] - cu[b] = min(session length, window) rows; probs / rand_ids [B, window] are the draws of
 // `rt_collate` mode 3 (read at the row's padded position), y = the item where the position was picked, else 0.  draw_rows [B] or NULL:
 // the row of probs / rand_ids session b reads (a loop that re-orders the sessions of a batch keeps every session on the draws of its

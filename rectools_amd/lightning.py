@@ -115,7 +115,7 @@ class TransformerLossModule(nn.Module):
         table = self.torch_model.item_model.get_all_embeddings()
         B = int(pbatch["cu"].numel()) - 1
         sess = self.torch_model.encode_packed_train(pbatch["x"], pbatch["dist"], pbatch["cu"], B, int(pbatch["window"]), table,
-                                                    rows_real=pbatch.get("n_rows"), cu_attn=pbatch.get("cu_attn"))
+                                                    rows_real=pbatch.get("n_rows"), cu_attn=pbatch.get("cu_attn"), ts=pbatch.get("ts"))
         loss, _ = self._loss_from_sessions(table, sess, pbatch["y"], pbatch["yw"], pbatch.get("negatives"))
         return loss
 

@@ -89,8 +89,9 @@ class _TrainLoop:
         # head size 32 / 64); RT_PACKED_TRAIN=0 keeps the padded [B, L] window (the cross-check of tests/test_packed_gpu.py)
         tm = lm.torch_model
         self.bert = type(self.dp).__name__ == "BERT4RecDataPreparator"
+        self.stu = isinstance(tm.transformer_layers, hnn.STULayers)      # the only stack that reads the batch's timestamps
         self.packed = (os.environ.get("RT_PACKED_TRAIN", "1") != "0" and type(self.dp).__name__ in _PACKED_PREPARATORS
-                       and not self.dp.add_unix_ts and not (self.dp.extra_cols or [])
+                       and (not self.dp.add_unix_ts or (self.stu and not self.bert)) and not (self.dp.extra_cols or [])
                        and getattr(tm.transformer_layers, "packed_ok", None) is not None
                        and getattr(tm, "_fused_pos", lambda: False)()
                        and tm.transformer_layers.packed_ok(model.n_factors, self.dp.session_max_len, tm.use_causal_attn,
@@ -182,7 +183,9 @@ class _TrainLoop:
         else:
             x, y, yw, dist = ops.collate_packed(self.dstore.offsets, self.dstore.items, self.dstore.weights, idx, cu, rows, train=True)
         batch: tp.Dict[str, tp.Any] = {"x": x, "y": y, "yw": yw, "dist": dist, "cu": cu, "window": self.dp.session_max_len, "n_rows": n}
-        if full and rows > n and rows - n <= self.dp.session_max_len:
+        if self.dp.add_unix_ts:      # the n + 1 timestamps of every session (sasrec.py:96-104: the rows' items and the last row's target)
+            batch["ts"] = ops.collate_packed_ts(self.dstore.offsets, self.dstore.unix_ts, idx, cu, n)
+        if full and rows > n and rows - n <= self.dp.session_max_len and not self.stu:
             batch["cu_attn"] = self._cu_dev[bi]        # [B + 2]: the sessions + the tail as a session of its own (see begin_epoch)
         if self.dp.negative_sampler is not None:
             batch["negatives"] = self.dp.negative_sampler.get_negatives(

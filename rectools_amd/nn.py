@@ -693,6 +693,22 @@ class STULayer(nn.Module):
         o_in = ops.mul_mask(uq[0], self.norm_attn_output(attn), ids_last)
         return self.output_mlp(o_in, residual=_take_last(x0, B, L))
 
+    def forward_packed(self, seqs, cu, B, window, ts, thr):
+        """The block over PACKED sessions ([Np, d], real positions only).  The reference zeroes pad rows before the bias-free projection
+        (hstu.py:256-262): their u / v / q / k are silu(0) = 0, a pad key adds nothing to any query — the packed rows see exactly what
+        they see in the padded window.  The ops of `forward_modular` without the masks; attention = `ops.hstu_attn_varlen`."""
+        hh = self.n_heads * self.hd
+        normed = self.norm_input(seqs)
+        uvqk = ops.act_dropout(ops.matmul_nn(normed, self.uvqk_proj), ops.ACT_SILU, 0.0)
+        u, v, q, k = uvqk[:, :hh], uvqk[:, hh:2 * hh], uvqk[:, 2 * hh:3 * hh], uvqk[:, 3 * hh:]
+        tw = self.rel_attn.time_weights if self.rel_attn.relative_time_attention else None
+        pw = self.rel_attn.pos_weights if self.rel_attn.relative_pos_attention else None
+        attn = ops.hstu_attn_varlen(q, k, v, tw, pw, cu, ts if tw is not None else None, thr, B, self.n_heads, window)
+        attn = ops.dropout(attn, self.p_attn if self.training else 0.0)
+        o_in = ops.mul_mask(u, self.norm_attn_output(attn), None)         # u * LN(attn)
+        o_in = ops.dropout(o_in, self.p_mlp if self.training else 0.0)
+        return self.output_mlp(o_in, residual=seqs)
+
     def forward_modular(self, seqs, ids, B, L, batch, thr):
         """Same block out of the individual autograd ops (`seqs` already masked); the cross-check of the fused node."""
         hh = self.n_heads * self.hd
@@ -731,6 +747,21 @@ class STULayers(TransformerLayersBase):
             seqs = blk(seqs, ids, B, L, batch, self.time_thr)
         last = blocks[-1].forward_last(seqs, ids, B, L, batch, self.time_thr)
         return ops.mul_mask(last, None, ids.view(B, L)[:, L - 1].contiguous())
+
+    def packed_ok(self, n_factors: int, window: int, causal: bool, keypad: bool = False) -> bool:
+        """Packed rows serve the STU stack as it is: pad rows are zeroed before every bias-free projection, so they add nothing to a
+        real row (`STULayer.forward_packed`)."""
+        blocks = list(self.stu_blocks)
+        return bool(blocks) and ops.hstu_varlen_supported(blocks[0].n_heads, blocks[0].hd, window) and window == blocks[0].L
+
+    def forward_packed_train(self, seqs, cu, B, window, keypad, rows_real=None, causal=True, ts=None):
+        for blk in self.stu_blocks:
+            seqs = blk.forward_packed(seqs, cu, B, window, ts, self.time_thr)
+        return seqs
+
+    def forward_last_packed(self, seqs, cu, B, window, keypad, rows_real=None, causal=True, ts=None):
+        """[B, d]: the packed blocks on every row, then the last row of every session."""
+        return self.forward_packed_train(seqs, cu, B, window, keypad, ts=ts).index_select(0, cu[1:B + 1] - 1)
 
 
 # ---- similarity + backbone ------------------------------------------------------------------------------
@@ -870,7 +901,7 @@ class TransformerTorchBackbone(nn.Module):
 
     def encode_packed_train(self, ids: torch.Tensor, dist: torch.Tensor, cu: torch.Tensor, B: int, window: int,
                             item_embs: tp.Optional[torch.Tensor] = None, rows_real: tp.Optional[int] = None,
-                            cu_attn: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
+                            cu_attn: tp.Optional[torch.Tensor] = None, ts: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
         """Training twin of `encode_sessions` on packed rows: ids / dist [Np] (tail rows: id 0, dist 0), -> [Np, d].  ONE fused
         pass (`ops.embed_packed`): embedding rows (pad id 0 has no gradient), positional rows by the distance from the session's
         end, the embedding dropout (torch_backbone.py:245-247)."""
@@ -884,8 +915,9 @@ class TransformerTorchBackbone(nn.Module):
             # the blocks is then written with finite values (zero gradients flow into the tail), no tail memsets
             return self.transformer_layers.forward_packed_train(seqs, cu_attn, B + 1, window, self.use_key_padding_mask, int(seqs.shape[0]),
                                                                 causal=self.use_causal_attn)
+        kw = {} if ts is None else {"ts": ts}     # (the STU stack's relative time bias: packed timestamps, `ops.collate_packed_ts`)
         return self.transformer_layers.forward_packed_train(seqs, cu, B, window, self.use_key_padding_mask, rows_real,
-                                                            causal=self.use_causal_attn)
+                                                            causal=self.use_causal_attn, **kw)
 
     def encode_last(self, batch: Batch, item_embs: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
         """-> [B, d] = encode_sessions(batch)[:, -1, :], the only rows recommend() uses (lightning.py:393-397).  Layer stacks

@@ -1671,6 +1671,54 @@ class _HstuAttn(torch.autograd.Function):
         return dqkv[0], dqkv[1], dqkv[2], dtw, dpw, None, None, None, None, None, None
 
 
+class _HstuAttnVarlen(torch.autograd.Function):
+    """HSTU attention over PACKED sessions (`rt_hstu_attn_varlen_fwd` / `_bwd`): q / k / v [Np, d] (column blocks of one projection are
+    fine: row strides are passed on), cu [B+1], ts [cu[B] + B] (n + 1 timestamps per session) or None.  Rows behind cu[B] stay zero."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, time_w, pos_w, cu, ts, thr, B, H, window):
+        Np, d = q.shape
+        hd = d // H
+        o = torch.zeros((Np, d), dtype=torch.float32, device=q.device)
+        _c("rt_hstu_attn_varlen_fwd", q, q.stride(0), k, k.stride(0), v, v.stride(0), cu, ts if time_w is not None else None,
+           time_w, thr if time_w is not None else None, pos_w, B, H, window, hd, o, d)
+        ctx.save_for_backward(q, k, v, time_w, pos_w, cu, ts, thr)
+        ctx.meta = (B, H, window, hd)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, time_w, pos_w, cu, ts, thr = ctx.saved_tensors
+        B, H, window, hd = ctx.meta
+        Np, d = q.shape
+        do = do.contiguous()
+        dqkv = torch.zeros((3, Np, d), dtype=torch.float32, device=do.device)
+        dtw = None if time_w is None else torch.zeros_like(time_w)
+        dpw = None if pos_w is None else torch.zeros_like(pos_w)
+        _c("rt_hstu_attn_varlen_bwd", q, q.stride(0), k, k.stride(0), v, v.stride(0), do, d, cu,
+           ts if time_w is not None else None, time_w, thr if time_w is not None else None, pos_w, B, H, window, hd,
+           dqkv[0], d, dqkv[1], d, dqkv[2], d, dtw, dpw)
+        return dqkv[0], dqkv[1], dqkv[2], dtw, dpw, None, None, None, None, None, None
+
+
+def hstu_attn_varlen(q, k, v, time_w, pos_w, cu, ts, thr, B: int, H: int, window: int) -> torch.Tensor:
+    return _HstuAttnVarlen.apply(q, k, v, time_w, pos_w, cu, ts, thr, B, H, window)
+
+
+def hstu_varlen_supported(n_heads: int, hd: int, window: int) -> bool:
+    """The ring kernels behind `rt_hstu_attn_varlen_*`: head size 32 / 64; their LDS (4-stage ring + flags + bias tables) fits any window
+    the position table allows here."""
+    return hd in (32, 64) and window <= 2048
+
+
+def collate_packed_ts(offsets: torch.Tensor, unix_ts: torch.Tensor, idx: torch.Tensor, cu: torch.Tensor, n_rows: int) -> torch.Tensor:
+    """`rt_collate_packed_ts`: the n + 1 timestamps of every session of a packed training batch, [n_rows + B] (session b at cu[b] + b)."""
+    B = int(idx.numel())
+    out = torch.empty((n_rows + B,), dtype=torch.int64, device=offsets.device)
+    _c("rt_collate_packed_ts", offsets, unix_ts, idx, cu, B, n_rows + B, out)
+    return out
+
+
 def hstu_attn(q, k, v, time_w, pos_w, ids, ts, thr, B: int, H: int, L: int) -> torch.Tensor:
     return _HstuAttn.apply(q, k, v, time_w, pos_w, ids.reshape(-1), ts, thr, B, H, L)
 
