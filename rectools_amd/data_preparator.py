@@ -565,7 +565,7 @@ class BERT4RecDataPreparator(TransformerDataPreparatorBase):
 
     def collate_train_device(self, dstore: DeviceSequenceStore, idx: torch.Tensor) -> tp.Dict[str, torch.Tensor]:
         B, L = int(idx.numel()), self.session_max_len
-        probs = torch.rand((B, L), dtype=torch.float32, device=dstore.device)
+        probs = torch.rand((B, L), dtype=torch.float32).to(dstore.device)      # host draws, as the reference's collate (bert4rec.py:109-127)
         rand_ids = torch.randint(self.n_item_extra_tokens, self.item_id_map.size, (B, L), dtype=torch.int64, device=dstore.device)
         return _device_collate(dstore, idx, L, 3, False, probs, rand_ids, self.mask_prob, self.extra_token_ids[MASKING_VALUE])
 

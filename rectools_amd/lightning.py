@@ -87,13 +87,17 @@ class TransformerLossModule(nn.Module):
         return table, self.torch_model.encode_sessions(batch, table)
 
     def _loss_from_sessions(self, table: torch.Tensor, sess2d: torch.Tensor, y: torch.Tensor, w: torch.Tensor,
-                            negatives: tp.Optional[torch.Tensor]) -> tp.Tuple[torch.Tensor, tp.Optional[torch.Tensor]]:
+                            negatives: tp.Optional[torch.Tensor], n_targets: tp.Optional[int] = None
+                            ) -> tp.Tuple[torch.Tensor, tp.Optional[torch.Tensor]]:
         y = y.reshape(-1)
         w = w.reshape(-1).contiguous()
         if self.loss == "softmax":
             if self.cosine:
                 sess2d, table = ops.l2norm(sess2d), ops.l2norm(table)
-            act = torch.nonzero(y, as_tuple=False).reshape(-1)  # positions with a target (ignore_index = 0)
+            if n_targets is not None:   # the caller counted the targets on the host: no device -> host round trip for the size
+                act = torch.nonzero_static(y, size=int(n_targets)).reshape(-1)
+            else:
+                act = torch.nonzero(y, as_tuple=False).reshape(-1)  # positions with a target (ignore_index = 0)
             return ops.softmax_loss(sess2d, table, act, y[act].contiguous(), w[act].contiguous(), self.logits_t), None
         kind = {"BCE": ops.LOSS_BCE, "gBCE": ops.LOSS_GBCE, "sampled_softmax": ops.LOSS_SAMPLED_SOFTMAX}[self.loss]
         beta = 0.0
@@ -116,7 +120,9 @@ class TransformerLossModule(nn.Module):
         B = int(pbatch["cu"].numel()) - 1
         sess = self.torch_model.encode_packed_train(pbatch["x"], pbatch["dist"], pbatch["cu"], B, int(pbatch["window"]), table,
                                                     rows_real=pbatch.get("n_rows"), cu_attn=pbatch.get("cu_attn"), ts=pbatch.get("ts"))
-        loss, _ = self._loss_from_sessions(table, sess, pbatch["y"], pbatch["yw"], pbatch.get("negatives"))
+        stock = type(self)._loss_from_sessions is TransformerLossModule._loss_from_sessions    # (a plugged loss keeps its own signature)
+        kw = {"n_targets": pbatch["n_targets"]} if stock and pbatch.get("n_targets") is not None and self.loss == "softmax" else {}
+        loss, _ = self._loss_from_sessions(table, sess, pbatch["y"], pbatch["yw"], pbatch.get("negatives"), **kw)
         return loss
 
     def validation_loss(self, batch: Batch) -> torch.Tensor:

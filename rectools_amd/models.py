@@ -117,7 +117,8 @@ class _TrainLoop:
             srt = np.argsort(key, kind="stable")
             mine, lens = mine[srt], lens[srt]
             # BERT4Rec draws its masks per slot of the batch: every session keeps the draws of the slot the unsorted batch gave it
-            self._slots = torch.from_numpy(np.ascontiguousarray(srt % B, dtype=np.int64)).to(self.device) if self.bert else None
+            self._slots_host = np.ascontiguousarray(srt % B, dtype=np.int64)
+            self._slots = torch.from_numpy(self._slots_host).to(self.device) if self.bert else None
             self.mine_t = torch.from_numpy(np.ascontiguousarray(mine, dtype=np.int64)).to(self.device)
             grid = np.zeros((nb, B), dtype=np.int64)
             grid.reshape(-1)[:len(mine)] = lens
@@ -175,7 +176,15 @@ class _TrainLoop:
         full = nb == self.batch_size
         if self.bert:   # the draws of `BERT4RecDataPreparator.collate_train_device`, in its order: the packed batch masks the same positions
             L = self.dp.session_max_len
-            probs = torch.rand((nb, L), dtype=torch.float32, device=self.device)
+            probs_h = torch.rand((nb, L), dtype=torch.float32)      # drawn on the host (as `collate_train_device` does): the number of
+            #                                                           masked positions sizes the loss's buffers, and the host can count
+            #                                                           them here instead of asking the device (`torch.nonzero`: a sync)
+            slots_h = self._slots_host[self.pos - self.batch_size:self.pos - self.batch_size + nb]
+            n_of_row = np.zeros((nb,), dtype=np.int64)
+            n_of_row[slots_h] = np.diff(self._cu_host[bi, :nb + 1])
+            hit = (probs_h.numpy() < np.float32(self.dp.mask_prob)) & (np.arange(L)[None, :] >= (L - n_of_row)[:, None])
+            n_targets = int(hit.sum())
+            probs = probs_h.to(self.device, non_blocking=True)
             rand_ids = torch.randint(self.dp.n_item_extra_tokens, self.dp.item_id_map.size, (nb, L), dtype=torch.int64, device=self.device)
             x, y, yw, dist = ops.collate_packed_bert(self.dstore.offsets, self.dstore.items, self.dstore.weights, idx, cu, rows, L, True,
                                                      self.dp.extra_token_ids[MASKING_VALUE], probs, rand_ids, self.dp.mask_prob,
@@ -183,6 +192,8 @@ class _TrainLoop:
         else:
             x, y, yw, dist = ops.collate_packed(self.dstore.offsets, self.dstore.items, self.dstore.weights, idx, cu, rows, train=True)
         batch: tp.Dict[str, tp.Any] = {"x": x, "y": y, "yw": yw, "dist": dist, "cu": cu, "window": self.dp.session_max_len, "n_rows": n}
+        if self.bert:
+            batch["n_targets"] = n_targets
         if self.dp.add_unix_ts:      # the n + 1 timestamps of every session (sasrec.py:96-104: the rows' items and the last row's target)
             batch["ts"] = ops.collate_packed_ts(self.dstore.offsets, self.dstore.unix_ts, idx, cu, n)
         if full and rows > n and rows - n <= self.dp.session_max_len and not self.stu:
