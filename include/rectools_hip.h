@@ -403,6 +403,26 @@ int rt_sasrec_block_packed_bwd(const rt_sasrec_block* blk, const float* x, const
 size_t rt_sasrec_block_infer_scratch_floats(int32_t rows, int32_t B, int32_t d, int32_t dff, int32_t last_only);
 int rt_sasrec_block_packed_infer(const rt_sasrec_block* blk, const float* x, const int64_t* last_rows, float* scratch, float* out,
                                  rt_stream_t stream);
+
+/* One packed Pre-LN block (net_blocks.py:223-262, BERT4Rec's stack) under key-padding masks — packed rows have no pad keys:
+ *   h = LN1(x); qkv = h Win^T + bin; A = attention(qkv) (causal = 0: every query sees its whole session, rt_mha_varlen_bidir_*);
+ *   x1 = x + drop(A Wo^T + bo); g = LN2(x1); a = drop(gelu(g W1^T + b1)); x2 = x1 + drop(a W2^T + b2); out = drop(x2).
+ * Same conventions as rt_sasrec_block (rows / rows_real / cu / planes); the five dropout streams in forward order.  The flat parameter
+ * gradient uses rt_sasrec_block_grad_offsets(d, dff) (in_w is [3d, d] in both).  Training forward / backward only. */
+typedef struct rt_preln_block {
+  int32_t rows, rows_real, B, H, d, dff, window, causal;
+  float p_drop, eps1, eps2;
+  uint64_t seed_attn, seed1, sid1, seed_h, sid_h, seed2, sid2, seed3, sid3;
+  const int64_t* cu;
+  const float *ln1_w, *ln1_b, *in_w, *in_b, *out_w, *out_b, *ln2_w, *ln2_b, *w1, *b1, *w2, *b2;
+  const uint16_t *in_wp, *out_wp, *w1_wp, *w2_wp;
+  int64_t wp_stride;
+} rt_preln_block;
+size_t rt_preln_block_saved_floats(int32_t rows, int32_t d, int32_t dff, int32_t H);
+size_t rt_preln_block_bwd_scratch_bytes(int32_t rows, int32_t d, int32_t dff, int32_t H, int32_t wgrad_splits);
+int rt_preln_block_packed_fwd(const rt_preln_block* blk, const float* x, float* saved, float* out, rt_stream_t stream);
+int rt_preln_block_packed_bwd(const rt_preln_block* blk, const float* x, const float* saved, const float* g_out, float* g_x, float* grads,
+                              void* scratch, size_t scratch_bytes, int32_t wgrad_splits, int32_t use_side, rt_stream_t stream);
 int rt_side_join(rt_stream_t stream);
 /* the side stream for the caller's own optimiser-only work: it waits for `stream`'s current position; *side_out = its handle, or
  * NULL when disabled (launch on `stream` then).  Joined by rt_side_join. */

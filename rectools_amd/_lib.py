@@ -103,6 +103,10 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_sasrec_block_packed_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rt_sasrec_block_packed_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_i32, c_i32, c_vp]),
     "rt_sasrec_block_infer_scratch_floats": (c_sz, [c_i32, c_i32, c_i32, c_i32, c_i32]),
+    "rt_preln_block_saved_floats": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
+    "rt_preln_block_bwd_scratch_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32, c_i32]),
+    "rt_preln_block_packed_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "rt_preln_block_packed_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_i32, c_i32, c_vp]),
     "rt_sasrec_block_packed_infer": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rt_side_join": (c_i32, [c_vp]),
     "rt_side_fork": (c_i32, [c_vp, c_vp]),
@@ -134,6 +138,16 @@ class SasrecBlock(ctypes.Structure):
     _fields_ = [(n, c_i32) for n in ("rows", "rows_real", "B", "H", "d", "dff", "window", "pad_keys")] + \
                [(n, c_f32) for n in ("p_drop", "eps1", "eps2")] + \
                [(n, c_u64) for n in ("seed_attn", "seed_h", "sid_h", "seed_o", "sid_o")] + \
+               [(n, c_vp) for n in ("cu", "ln1_w", "ln1_b", "in_w", "in_b", "out_w", "out_b", "ln2_w", "ln2_b", "w1", "b1", "w2", "b2",
+                                    "in_wp", "out_wp", "w1_wp", "w2_wp")] + [("wp_stride", c_i64)]
+
+
+class PreLNBlock(ctypes.Structure):
+    """`rt_preln_block` of include/rectools_hip.h."""
+
+    _fields_ = [(n, c_i32) for n in ("rows", "rows_real", "B", "H", "d", "dff", "window", "causal")] + \
+               [(n, c_f32) for n in ("p_drop", "eps1", "eps2")] + \
+               [(n, c_u64) for n in ("seed_attn", "seed1", "sid1", "seed_h", "sid_h", "seed2", "sid2", "seed3", "sid3")] + \
                [(n, c_vp) for n in ("cu", "ln1_w", "ln1_b", "in_w", "in_b", "out_w", "out_b", "ln2_w", "ln2_b", "w1", "b1", "w2", "b2",
                                     "in_wp", "out_wp", "w1_wp", "w2_wp")] + [("wp_stride", c_i64)]
 

@@ -53,6 +53,13 @@ int rt_mha_varlen_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, 
 int rt_mha_varlen_last_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                            const int64_t* cu_seqlens, const float* bk, const float* bv, int32_t B, int32_t H, int32_t hd, int32_t max_len,
                            int32_t window, float* o, int64_t ldo, hipStream_t stream);
+int rt_mha_varlen_bidir_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const int64_t* cu_seqlens,
+                            int32_t B, int32_t H, int32_t hd, int32_t max_len, float p_drop, uint64_t seed, float* o, int64_t ldo, float* lse,
+                            hipStream_t stream);
+int rt_mha_varlen_bidir_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* o, int64_t ldo,
+                            const float* dout, int64_t lddo, const float* lse, const int64_t* cu_seqlens, int32_t B, int32_t H, int32_t hd,
+                            int32_t max_len, float p_drop, uint64_t seed, float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv,
+                            int64_t lddv, float* delta, hipStream_t stream);
 int rt_gather_rows(const float* src, int64_t ld_src, const int64_t* idx, int32_t R, int32_t d, float* dst, int64_t ld_dst,
                    hipStream_t stream);
 struct rt_gemm_wp_problem {
@@ -88,7 +95,7 @@ struct Timed {   // RAII bracket around one internal launch (no-op unless rt_tim
   }
 };
 enum { T_GEMM = 0, T_GEMM_GROUPED = 1, T_LN_FWD = 2, T_LN_BWD = 3, T_DROP_FWD = 4, T_DROP_BWD = 5, T_ATTN_FWD = 6, T_ATTN_BWD = 7,
-       T_ATTN_LAST = 8, T_MISC = 9 };
+       T_ATTN_LAST = 8, T_MISC = 9, T_ATTN_BIDIR_FWD = 10, T_ATTN_BIDIR_BWD = 11 };
 
 // ---- the weight-gradient side stream (one per device, owned by the library) -------------------------------------------------------
 struct Side { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool dirty = false; };
@@ -126,7 +133,7 @@ extern "C" {
 // mode 0: off; 1: record an event pair around every internal launch of the block executor; 2: the same with the weight gradients on the
 // caller's stream (undisturbed kernel durations).  rt_timing_collect synchronises the device, copies the records out
 // (ids: 0 gemm, 1 gemm_grouped, 2 layernorm_fwd, 3 layernorm_bwd, 4 act_dropout_fwd, 5 act_dropout_bwd, 6 mha_varlen_fwd,
-// 7 mha_varlen_bwd, 8 mha_varlen_last_fwd, 9 misc; tags [n][3] = the GEMM's M, N, K or 0) and clears them.
+// 7 mha_varlen_bwd, 8 mha_varlen_last_fwd, 9 misc, 10 / 11 mha_varlen_bidir_fwd / _bwd; tags [n][3] = the GEMM's M, N, K or 0) and clears them.
 int rt_timing_enable(int32_t mode) {
   g_timing = mode != 0;
   g_single_stream = mode == 2;
@@ -414,6 +421,203 @@ int rt_sasrec_block_packed_bwd(const rt_sasrec_block* blk, const float* x, const
   }
   { Timed t(T_LN_BWD, 0, 0, 0, stream);     // g_x = LN1'(g_q) + g_kv
     RT_TRY(rt_layernorm_bwd_fused(g_q, x, b.ln1_w, v.mean1, v.rstd1, g_kv, nullptr, 0, 0, M, d, g_x, d_ln1w, d_ln1b, ln_ws2, lnws, stream)); }
+  return RT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// One packed Pre-LN block (net_blocks.py:223-262: BERT4Rec's stack) with key-padding masks — on packed rows the pad keys do not exist.
+//   h = LN1(x); qkv = h Win^T + bin; A = attention(qkv) (bidirectional, or causal); x1 = x + drop1(A Wo^T + bo);
+//   g = LN2(x1); a = drop_h(gelu(g W1^T + b1)); x2 = x1 + drop2(a W2^T + b2); out = drop3(x2)
+// Same kernels, order and dropout streams as `nn.PreLNTransformerLayer.forward_packed` (the cross-check of the test suite).
+// ------------------------------------------------------------------------------------------------------------------------------------
+struct rt_preln_block {
+  int32_t rows, rows_real, B, H, d, dff, window, causal;
+  float p_drop, eps1, eps2;
+  uint64_t seed_attn, seed1, sid1, seed_h, sid_h, seed2, sid2, seed3, sid3;     // dropout streams in forward order (ops.RNG)
+  const int64_t* cu;
+  const float *ln1_w, *ln1_b, *in_w, *in_b, *out_w, *out_b, *ln2_w, *ln2_b, *w1, *b1, *w2, *b2;
+  const uint16_t *in_wp, *out_wp, *w1_wp, *w2_wp;      // optional bf16 planes of the weights (see rt_sasrec_block)
+  int64_t wp_stride;
+};
+
+size_t rt_preln_block_saved_floats(int32_t rows, int32_t d, int32_t dff, int32_t H) {
+  const size_t M = (size_t)rows;
+  return al(M * d) * 6 /* h A x1 g + two spares */ + al(M * 3 * d) /* qkv */ + al(M * dff) * 2 /* z a */ + al(M * H) /* lse */ + 4 * al(M);
+}
+size_t rt_preln_block_bwd_scratch_bytes(int32_t rows, int32_t d, int32_t dff, int32_t H, int32_t wgrad_splits) {
+  const size_t M = (size_t)rows;
+  const size_t fl = al(M * d) * 7 /* g_x2 g_f g_g g_x1 g_mo g_A g_h */ + al(M * dff) * 2 /* g_a g_z */ + al(M * 3 * d) /* dqkv */ + al(M * H) /* delta */;
+  size_t by = fl * 4 + 2 * ((rt_layernorm_bwd_workspace_bytes(rows, d) + 255) & ~(size_t)255);
+  size_t sk = 0;
+  const int spl = wgrad_splits > 1 ? wgrad_splits : 1;
+  const size_t cands[4] = {rt_gemm_workspace_bytes(d, dff, rows, spl), rt_gemm_workspace_bytes(dff, d, rows, spl), rt_gemm_workspace_bytes(d, d, rows, spl),
+                           rt_gemm_workspace_bytes(3 * d, d, rows, spl)};
+  for (size_t c : cands) sk = c > sk ? c : sk;
+  return by + ((sk + 255) & ~(size_t)255) + 256;
+}
+
+namespace {
+struct PreLNSaved { float *h, *A, *x1, *g, *spare, *spare2, *qkv, *z, *a, *lse, *mean1, *rstd1, *mean2, *rstd2; };
+PreLNSaved carve_preln(const rt_preln_block& b, float* base) {
+  const size_t M = (size_t)b.rows;
+  PreLNSaved v;
+  float* p = base;
+  v.h = p; p += al(M * b.d); v.A = p; p += al(M * b.d); v.x1 = p; p += al(M * b.d); v.g = p; p += al(M * b.d); v.spare = p; p += al(M * b.d); v.spare2 = p; p += al(M * b.d);
+  v.qkv = p; p += al(M * 3 * b.d);
+  v.z = p; p += al(M * b.dff); v.a = p; p += al(M * b.dff);
+  v.lse = p; p += al(M * b.H);
+  v.mean1 = p; p += al(M); v.rstd1 = p; p += al(M); v.mean2 = p; p += al(M); v.rstd2 = p; p += al(M);
+  return v;
+}
+// forward product y = A W^T (+ bias) (+ R): pre-split planes where the block carries them and the shape is an exact tile grid
+int fwd_gemm(const float* A, int lda, const float* W, const uint16_t* Wp, int64_t wps, int ldw, float* C, int ldc, const float* bias,
+             const float* R, int ldr, int M, int N, int K, hipStream_t s) {
+  Timed t(T_GEMM, M, N, K, s);
+  int rc = wp_one(A, lda, Wp, wps, ldw, 0, C, ldc, bias, R, ldr, M, N, K, 0, s);
+  if (rc == RT_ERR_UNSUPPORTED) rc = rt_gemm(A, lda, 1, W, ldw, 1, C, ldc, bias, R, ldr, nullptr, M, N, K, 0, 1, nullptr, 0, s);
+  return rc;
+}
+// data gradient dx = dy W (+ R), W [N_out, N_in] row-major
+int dgrad_gemm(const float* dy, int ldy, const float* W, const uint16_t* Wp, int64_t wps, int n_out, int n_in, float* dx, const float* R, int M,
+               hipStream_t s) {
+  Timed t(T_GEMM, M, n_in, n_out, s);
+  int rc = wp_one(dy, ldy, Wp, wps, n_in, 1, dx, n_in, nullptr, R, n_in, M, n_in, n_out, 0, s);
+  if (rc == RT_ERR_UNSUPPORTED) rc = rt_gemm(dy, ldy, 1, W, n_in, 0, dx, n_in, nullptr, R, n_in, nullptr, M, n_in, n_out, 0, 1, nullptr, 0, s);
+  return rc;
+}
+}  // namespace
+
+int rt_preln_block_packed_fwd(const rt_preln_block* blk, const float* x, float* saved, float* out, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (blk == nullptr || x == nullptr || saved == nullptr || out == nullptr) return RT_ERR_INVALID_ARG;
+  const rt_preln_block& b = *blk;
+  const int M = b.rows, d = b.d, dff = b.dff, hd = d / b.H;
+  if (M <= 0 || d <= 0 || b.H <= 0 || d % b.H != 0 || b.cu == nullptr) return RT_ERR_INVALID_ARG;
+  const PreLNSaved v = carve_preln(b, saved);
+  const int64_t nd = (int64_t)M * d, nf = (int64_t)M * dff;
+  { Timed t(T_LN_FWD, 0, 0, 0, stream); RT_TRY(rt_layernorm_fwd(x, b.ln1_w, b.ln1_b, b.eps1, M, d, v.h, v.mean1, v.rstd1, stream)); }
+  RT_TRY(fwd_gemm(v.h, d, b.in_w, b.in_wp, b.wp_stride, d, v.qkv, 3 * d, b.in_b, nullptr, 0, M, 3 * d, d, stream));
+  if (b.rows_real < b.rows) {   // rows behind the sessions must read as finite zeros
+    RT_CHECK_HIP(hipMemsetAsync(v.A + (size_t)b.rows_real * d, 0, (size_t)(b.rows - b.rows_real) * d * sizeof(float), stream));
+    RT_CHECK_HIP(hipMemsetAsync(v.lse + (size_t)b.rows_real * b.H, 0, (size_t)(b.rows - b.rows_real) * b.H * sizeof(float), stream));
+  }
+  if (b.causal) {
+    Timed t(T_ATTN_FWD, 0, 0, 0, stream);
+    RT_TRY(rt_mha_varlen_train_fwd(v.qkv, 3 * d, v.qkv + d, 3 * d, v.qkv + 2 * d, 3 * d, b.cu, nullptr, nullptr, b.B, b.H, hd, b.window, b.window,
+                                   b.p_drop, b.seed_attn, v.A, d, v.lse, stream));
+  } else {
+    Timed t(T_ATTN_BIDIR_FWD, 0, 0, 0, stream);
+    RT_TRY(rt_mha_varlen_bidir_fwd(v.qkv, 3 * d, v.qkv + d, 3 * d, v.qkv + 2 * d, 3 * d, b.cu, b.B, b.H, hd, b.window, b.p_drop, b.seed_attn, v.A, d,
+                                   v.lse, stream));
+  }
+  if (b.p_drop > 0.f) {
+    RT_TRY(fwd_gemm(v.A, d, b.out_w, b.out_wp, b.wp_stride, d, v.spare, d, b.out_b, nullptr, 0, M, d, d, stream));            // mo = A Wo^T + bo
+    { Timed t(T_DROP_FWD, 0, 0, 0, stream); RT_TRY(rt_act_dropout_fwd(v.spare, 0, b.p_drop, b.seed1, b.sid1, nd, x, v.x1, stream)); }   // x1 = x + drop(mo)
+  } else {
+    RT_TRY(fwd_gemm(v.A, d, b.out_w, b.out_wp, b.wp_stride, d, v.x1, d, b.out_b, x, d, M, d, d, stream));
+  }
+  { Timed t(T_LN_FWD, 0, 0, 0, stream); RT_TRY(rt_layernorm_fwd(v.x1, b.ln2_w, b.ln2_b, b.eps2, M, d, v.g, v.mean2, v.rstd2, stream)); }
+  RT_TRY(fwd_gemm(v.g, d, b.w1, b.w1_wp, b.wp_stride, d, v.z, dff, b.b1, nullptr, 0, M, dff, d, stream));                       // z = g W1^T + b1
+  { Timed t(T_DROP_FWD, 0, 0, 0, stream); RT_TRY(rt_act_dropout_fwd(v.z, 2 /* gelu */, b.p_drop, b.seed_h, b.sid_h, nf, nullptr, v.a, stream)); }
+  if (b.p_drop > 0.f) {
+    RT_TRY(fwd_gemm(v.a, dff, b.w2, b.w2_wp, b.wp_stride, dff, v.spare, d, b.b2, nullptr, 0, M, d, dff, stream));              // f = a W2^T + b2
+    { Timed t(T_DROP_FWD, 0, 0, 0, stream); RT_TRY(rt_act_dropout_fwd(v.spare, 0, b.p_drop, b.seed2, b.sid2, nd, v.x1, v.spare2, stream)); }   // x2 = x1 + drop(f)
+    { Timed t(T_DROP_FWD, 0, 0, 0, stream); RT_TRY(rt_act_dropout_fwd(v.spare2, 0, b.p_drop, b.seed3, b.sid3, nd, nullptr, out, stream)); }   // dropout_3 (net_blocks.py:260)
+  } else {
+    RT_TRY(fwd_gemm(v.a, dff, b.w2, b.w2_wp, b.wp_stride, dff, out, d, b.b2, v.x1, d, M, d, dff, stream));
+  }
+  return RT_OK;
+}
+
+// Backward: g_x [rows, d] and the flat parameter gradient in the order and offsets of rt_sasrec_block_grad_offsets(d, dff) (ln1_w, ln1_b,
+// in_w [3d, d], in_b, out_w, out_b, ln2_w, ln2_b, w1, b1, w2, b2).  Weight gradients on the side stream as in rt_sasrec_block_packed_bwd.
+int rt_preln_block_packed_bwd(const rt_preln_block* blk, const float* x, const float* saved, const float* g_out, float* g_x, float* grads,
+                              void* scratch, size_t scratch_bytes, int32_t wgrad_splits, int32_t use_side, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (blk == nullptr || x == nullptr || saved == nullptr || g_out == nullptr || g_x == nullptr || grads == nullptr || scratch == nullptr)
+    return RT_ERR_INVALID_ARG;
+  const rt_preln_block& b = *blk;
+  const int M = b.rows, d = b.d, dff = b.dff, hd = d / b.H;
+  const int sp = wgrad_splits > 1 ? wgrad_splits : 1;
+  if (scratch_bytes < rt_preln_block_bwd_scratch_bytes(M, d, dff, b.H, sp)) return RT_ERR_WORKSPACE;
+  const PreLNSaved v = carve_preln(b, const_cast<float*>(saved));
+  int64_t go[13];
+  rt_sasrec_block_grad_offsets(d, dff, go);
+  float *d_ln1w = grads + go[0], *d_ln1b = grads + go[1], *d_in_w = grads + go[2], *d_in_b = grads + go[3], *d_wo = grads + go[4],
+        *d_bo = grads + go[5], *d_ln2w = grads + go[6], *d_ln2b = grads + go[7], *d_w1 = grads + go[8], *d_b1 = grads + go[9],
+        *d_w2 = grads + go[10], *d_b2 = grads + go[11];
+  float* p = reinterpret_cast<float*>(scratch);
+  const size_t Md = al((size_t)M * d), Mf = al((size_t)M * dff);
+  float* g_x2 = p; p += Md; float* g_f = p; p += Md; float* g_g = p; p += Md; float* g_x1 = p; p += Md; float* g_mo = p; p += Md;
+  float* g_A = p; p += Md; float* g_h = p; p += Md;
+  float* g_a = p; p += Mf; float* g_z = p; p += Mf;
+  float* dqkv = p; p += al((size_t)M * 3 * d);
+  float* delta = p; p += al((size_t)M * b.H);
+  unsigned char* bp = reinterpret_cast<unsigned char*>(p);
+  const size_t lnws = (rt_layernorm_bwd_workspace_bytes(M, d) + 255) & ~(size_t)255;
+  void* ln_ws1 = bp; bp += lnws; void* ln_ws2 = bp; bp += lnws;
+  void* sk_ws = bp;
+  const size_t sk_bytes = scratch_bytes - (size_t)(bp - reinterpret_cast<unsigned char*>(scratch));
+  const int64_t nd = (int64_t)M * d, nf = (int64_t)M * dff;
+
+  Side* side = (use_side && side_enabled()) ? side_of_current_device() : nullptr;
+  hipStream_t ws = side != nullptr ? side->stream : stream;
+  auto fork = [&]() -> int {
+    if (side == nullptr) return RT_OK;
+    RT_CHECK_HIP(hipEventRecord(side->fork, stream));
+    RT_CHECK_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
+    side->dirty = true;
+    return RT_OK;
+  };
+  auto wgrad = [&](const float* dy, int ldy, const float* in, int ldin, float* dw, int n_out, int n_in, float* db) -> int {
+    Timed t(T_GEMM, n_out, n_in, M, ws);
+    return rt_gemm(dy, ldy, 0, in, ldin, 0, dw, n_in, nullptr, nullptr, 0, db, n_out, n_in, M, 0, sp, sp > 1 ? sk_ws : nullptr,
+                   sp > 1 ? sk_bytes : 0, ws);
+  };
+
+  // ---- out = drop3(x2), x2 = x1 + drop2(f), f = a W2^T + b2, a = drop_h(gelu(z)), z = g W1^T + b1, g = LN2(x1)
+  const float* g_x2c = g_out;    // gradient of x2 (= of x1 through the skip)
+  const float* g_fc = g_out;     // gradient of f
+  if (b.p_drop > 0.f) {
+    { Timed t(T_DROP_BWD, 0, 0, 0, stream); RT_TRY(rt_act_dropout_bwd(g_out, g_out, 0, b.p_drop, b.seed3, b.sid3, nd, g_x2, stream)); }
+    { Timed t(T_DROP_BWD, 0, 0, 0, stream); RT_TRY(rt_act_dropout_bwd(g_x2, g_x2, 0, b.p_drop, b.seed2, b.sid2, nd, g_f, stream)); }
+    g_x2c = g_x2; g_fc = g_f;
+  }
+  RT_TRY(fork());
+  RT_TRY(wgrad(g_fc, d, v.a, dff, d_w2, d, dff, d_b2));
+  RT_TRY(dgrad_gemm(g_fc, d, b.w2, b.w2_wp, b.wp_stride, d, dff, g_a, nullptr, M, stream));                        // g_a = g_f W2
+  { Timed t(T_DROP_BWD, 0, 0, 0, stream); RT_TRY(rt_act_dropout_bwd(g_a, v.z, 2 /* gelu */, b.p_drop, b.seed_h, b.sid_h, nf, g_z, stream)); }
+  RT_TRY(fork());
+  RT_TRY(wgrad(g_z, dff, v.g, d, d_w1, dff, d, d_b1));
+  RT_TRY(dgrad_gemm(g_z, dff, b.w1, b.w1_wp, b.wp_stride, dff, d, g_g, nullptr, M, stream));                       // g_g = g_z W1
+  { Timed t(T_LN_BWD, 0, 0, 0, stream);     // g_x1 = LN2'(g_g) + g_x2 (the skip)
+    RT_TRY(rt_layernorm_bwd_fused(g_g, v.x1, b.ln2_w, v.mean2, v.rstd2, g_x2c, nullptr, 0, 0, M, d, g_x1, d_ln2w, d_ln2b, ln_ws1, lnws, stream)); }
+  // ---- x1 = x + drop1(mo), mo = A Wo^T + bo, A = attention(qkv), qkv = h Win^T + bin, h = LN1(x)
+  const float* g_moc = g_x1;
+  if (b.p_drop > 0.f) {
+    Timed t(T_DROP_BWD, 0, 0, 0, stream);
+    RT_TRY(rt_act_dropout_bwd(g_x1, g_x1, 0, b.p_drop, b.seed1, b.sid1, nd, g_mo, stream));
+    g_moc = g_mo;
+  }
+  RT_TRY(fork());
+  RT_TRY(wgrad(g_moc, d, v.A, d, d_wo, d, d, d_bo));
+  RT_TRY(dgrad_gemm(g_moc, d, b.out_w, b.out_wp, b.wp_stride, d, d, g_A, nullptr, M, stream));                     // g_A = g_mo Wo
+  if (b.rows_real < b.rows)     // rows behind the sessions must read as zero in the weight gradients
+    RT_CHECK_HIP(hipMemsetAsync(dqkv + (size_t)b.rows_real * 3 * d, 0, (size_t)(b.rows - b.rows_real) * 3 * d * sizeof(float), stream));
+  if (b.causal) {
+    Timed t(T_ATTN_BWD, 0, 0, 0, stream);
+    RT_TRY(rt_mha_varlen_bwd(v.qkv, 3 * d, v.qkv + d, 3 * d, v.qkv + 2 * d, 3 * d, v.A, d, g_A, d, v.lse, b.cu, nullptr, nullptr, b.B, b.H, hd, b.window,
+                             b.window, b.p_drop, b.seed_attn, dqkv, 3 * d, dqkv + d, 3 * d, dqkv + 2 * d, 3 * d, delta, nullptr, stream));
+  } else {
+    Timed t(T_ATTN_BIDIR_BWD, 0, 0, 0, stream);
+    RT_TRY(rt_mha_varlen_bidir_bwd(v.qkv, 3 * d, v.qkv + d, 3 * d, v.qkv + 2 * d, 3 * d, v.A, d, g_A, d, v.lse, b.cu, b.B, b.H, hd, b.window, b.p_drop,
+                                   b.seed_attn, dqkv, 3 * d, dqkv + d, 3 * d, dqkv + 2 * d, 3 * d, delta, stream));
+  }
+  RT_TRY(fork());
+  RT_TRY(wgrad(dqkv, 3 * d, v.h, d, d_in_w, 3 * d, d, d_in_b));
+  RT_TRY(dgrad_gemm(dqkv, 3 * d, b.in_w, b.in_wp, b.wp_stride, 3 * d, d, g_h, nullptr, M, stream));                // g_h = dqkv Win
+  { Timed t(T_LN_BWD, 0, 0, 0, stream);     // g_x = LN1'(g_h) + g_x1 (the skip)
+    RT_TRY(rt_layernorm_bwd_fused(g_h, x, b.ln1_w, v.mean1, v.rstd1, g_x1, nullptr, 0, 0, M, d, g_x, d_ln1w, d_ln1b, ln_ws2, lnws, stream)); }
   return RT_OK;
 }
 

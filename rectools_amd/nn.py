@@ -299,6 +299,22 @@ class TransformerLayersBase(nn.Module):
                 batch: Batch) -> torch.Tensor:
         raise NotImplementedError()
 
+    def _fresh_planes(self):
+        """bf16 planes of the stack's weights for the pre-split-weight GEMM (`ops.WeightPlanes`, csrc/rt_gemm_wp.hip), re-split NOW (one
+        launch over the stack's few MB of parameters): whatever changed the weights since the last pass — the optimiser, a checkpoint,
+        a test poking a parameter — the planes the blocks are about to read are current.  None when the parameters are not views of one
+        flat buffer."""
+        if not ops.weight_planes_enabled():
+            return None
+        key = tuple(p.data_ptr() for p in self.parameters())
+        cached = getattr(self, "_planes_cache", None)
+        if cached is None or cached[0] != key:
+            cached = (key, ops.WeightPlanes(list(self.parameters())))
+            object.__setattr__(self, "_planes_cache", cached)
+        cached[1].refresh()
+        return cached[1] if cached[1].ok else None
+
+
 
 class SASRecTransformerLayer(nn.Module):
     def __init__(self, n_factors: int, n_heads: int, dropout_rate: float) -> None:
@@ -429,21 +445,6 @@ class SASRecTransformerLayers(TransformerLayersBase):
             seqs = blk.forward_packed_train(seqs, cu, B, window, not keypad, rows_real, planes)
         return self.last_layernorm(seqs)
 
-    def _fresh_planes(self):
-        """bf16 planes of the stack's weights for the pre-split-weight GEMM (`ops.WeightPlanes`, csrc/rt_gemm_wp.hip), re-split NOW (one
-        launch over the stack's few MB of parameters): whatever changed the weights since the last pass — the optimiser, a checkpoint,
-        a test poking a parameter — the planes the blocks are about to read are current.  None when the parameters are not views of one
-        flat buffer."""
-        if not ops.weight_planes_enabled():
-            return None
-        key = tuple(p.data_ptr() for p in self.parameters())
-        cached = getattr(self, "_planes_cache", None)
-        if cached is None or cached[0] != key:
-            cached = (key, ops.WeightPlanes(list(self.parameters())))
-            object.__setattr__(self, "_planes_cache", cached)
-        cached[1].refresh()
-        return cached[1] if cached[1].ok else None
-
     def forward_last_packed(self, seqs, cu, B, window, keypad, rows_real=None, causal=True):
         """[B, d] encodings of the last position from PACKED rows: every block input is the real rows only — the
         reference masks pad rows to zero before each block (sasrec.py:300) and their only trace, the pad keys a causal block
@@ -505,6 +506,18 @@ class PreLNTransformerLayer(nn.Module):
         g, skip = ops.layer_norm_skip(seqs, ln2.weight, ln2.bias, ln2.eps)
         return self.feed_forward(g, residual=skip)
 
+    def native_ok(self) -> bool:
+        ff = self.feed_forward
+        return isinstance(ff, PointWiseFeedForward) and ff.activation == "gelu" and ff.ff_linear_1.bias is not None and \
+            ff.ff_linear_2.bias is not None and self.multi_head_attn.out_proj.bias is not None
+
+    def forward_packed_native(self, seqs, cu, B, window, causal, rows_real, planes=None):
+        ff, mha, ln1, ln2 = self.feed_forward, self.multi_head_attn, self.layer_norm_1, self.layer_norm_2
+        return ops.preln_layer_packed_train(
+            seqs, cu, B, mha.n_heads, window, causal, self.p if self.training else 0.0, (ln1.weight, ln1.bias, ln1.eps),
+            (mha.in_proj_weight, mha.in_proj_bias), (mha.out_proj.weight, mha.out_proj.bias), (ln2.weight, ln2.bias, ln2.eps),
+            (ff.ff_linear_1.weight, ff.ff_linear_1.bias), (ff.ff_linear_2.weight, ff.ff_linear_2.bias), rows_real, planes)
+
     def forward_last_packed(self, seqs, cu, B, window, causal):
         """Inference: the block's output at the last row of every packed session, [B, d] (cf. `forward_last`): keys / values of every
         row, one query per session (`rt_mha_varlen_last_fwd`: the last query sees its whole session, causal or not)."""
@@ -552,8 +565,14 @@ class PreLNTransformerLayers(TransformerLayersBase):
 
     def forward_packed_train(self, seqs, cu, B, window, keypad, rows_real=None, causal=False):
         covers = rows_real is not None and int(rows_real) == int(seqs.shape[0])
+        native = ops.native_block_enabled() and rows_real is not None and seqs.shape[0] % 128 == 0 and \
+            all(blk.native_ok() for blk in self.transformer_blocks)
+        planes = self._fresh_planes() if native else None
         for blk in self.transformer_blocks:
-            seqs = blk.forward_packed(seqs, cu, B, window, causal, covers)
+            if native:     # the block's launch sequence issued by the native executor (csrc/rt_block.hip: rt_preln_block_packed_*)
+                seqs = blk.forward_packed_native(seqs, cu, B, window, causal, int(rows_real), planes)
+            else:
+                seqs = blk.forward_packed(seqs, cu, B, window, causal, covers)
         return seqs
 
     def forward_last_packed(self, seqs, cu, B, window, keypad, rows_real=None, causal=False):

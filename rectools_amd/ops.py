@@ -60,7 +60,7 @@ def stop_timing() -> tp.Dict[str, tp.List[tp.Tuple[float, tp.Any]]]:
 
 _NATIVE_TIMING_NAMES = {0: "rt_gemm", 1: "rt_gemm_grouped", 2: "rt_layernorm_fwd", 3: "rt_layernorm_bwd_fused", 4: "rt_act_dropout_fwd",
                         5: "rt_act_dropout_bwd", 6: "rt_mha_varlen_train_fwd", 7: "rt_mha_varlen_bwd", 8: "rt_mha_varlen_last_fwd",
-                        9: "rt_misc"}
+                        9: "rt_misc", 10: "rt_mha_varlen_bidir_fwd", 11: "rt_mha_varlen_bidir_bwd"}
 
 
 _FN: tp.Dict[str, tp.Any] = {}   # bound C entry points (one getattr per name instead of one per launch)
@@ -1370,6 +1370,96 @@ class _SASRecLayerPackedNative(torch.autograd.Function):
             _NATIVE_KEEPALIVE.append((x, saved, g_out, scratch, grads))
         views = [grads[offs[i]:offs[i] + t.numel()].view_as(t) for i, t in enumerate(params)]
         return (g_x, None, *views, None)
+
+
+class _PreLNLayerPackedNative(torch.autograd.Function):
+    """One packed Pre-LN block issued by the native executor (`rt_preln_block_packed_fwd / _bwd`, csrc/rt_block.hip): ONE C call per
+    direction instead of ~11 / ~20 launches from Python — same kernels, order and dropout streams as
+    `nn.PreLNTransformerLayer.forward_packed` (the cross-check: tests/test_packed_bert_gpu.py)."""
+
+    @staticmethod
+    def _desc(M, cu, params, meta, seeds):
+        B, H, window, causal, p, eps1, eps2, rows_real, planes = meta
+        d, dff = params[2].shape[1], params[8].shape[0]
+        blk = _lib.PreLNBlock()
+        if planes is not None and planes.ok and weight_planes_enabled():
+            ptrs = [planes.of(params[i]) for i in (2, 4, 8, 10)]
+            if all(q is not None for q in ptrs):
+                blk.in_wp, blk.out_wp, blk.w1_wp, blk.w2_wp = ptrs
+                blk.wp_stride = planes.stride
+        blk.rows, blk.rows_real, blk.B, blk.H, blk.d, blk.dff, blk.window, blk.causal = M, rows_real, B, H, d, dff, window, int(causal)
+        blk.p_drop, blk.eps1, blk.eps2 = float(p), float(eps1), float(eps2)
+        (blk.seed_attn, blk.seed1, blk.sid1, blk.seed_h, blk.sid_h, blk.seed2, blk.sid2, blk.seed3, blk.sid3) = seeds
+        blk.cu = cu.data_ptr()
+        (blk.ln1_w, blk.ln1_b, blk.in_w, blk.in_b, blk.out_w, blk.out_b, blk.ln2_w, blk.ln2_b, blk.w1, blk.b1, blk.w2,
+         blk.b2) = [t.data_ptr() for t in params]
+        return blk
+
+    @staticmethod
+    def forward(ctx, x, cu, ln1_w, ln1_b, in_w, in_b, out_w, out_b, ln2_w, ln2_b, w1, b1, w2, b2, meta):
+        import ctypes
+
+        p = meta[4]
+        x = x.contiguous()
+        M, d = x.shape
+        dff = w1.shape[0]
+        lib = _lib.load()
+        seeds = (0,) * 9
+        if p > 0:       # the draws of the Python block, in its order: attention, dropout after it, the feed-forward's, after it, dropout_3
+            s0, sid = RNG.next()
+            s1, sh, s2, s3 = RNG.next(), RNG.next(), RNG.next(), RNG.next()
+            seeds = ((s0 + 0xD1B54A32D192ED03 * sid) & 0xFFFFFFFFFFFFFFFF, s1[0], s1[1], sh[0], sh[1], s2[0], s2[1], s3[0], s3[1])
+        params = (ln1_w, ln1_b, in_w, in_b, out_w, out_b, ln2_w, ln2_b, w1, b1, w2, b2)
+        blk = _PreLNLayerPackedNative._desc(M, cu, params, meta, seeds)
+        saved = torch.empty((lib.rt_preln_block_saved_floats(M, d, dff, meta[1]),), dtype=torch.float32, device=x.device)
+        out = torch.empty((M, d), dtype=torch.float32, device=x.device)
+        _c("rt_preln_block_packed_fwd", ctypes.addressof(blk), x, saved, out)
+        ctx.save_for_backward(x, cu, saved, *params)
+        ctx.blk_meta = (meta, seeds)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        import ctypes
+
+        x, cu, saved, *params = ctx.saved_tensors
+        meta, seeds = ctx.blk_meta
+        g_out = g_out.contiguous()
+        M, d = g_out.shape
+        dff = params[8].shape[0]
+        dev = g_out.device
+        lib = _lib.load()
+        blk = _PreLNLayerPackedNative._desc(M, cu, params, meta, seeds)
+        key = (d, dff)
+        offs = _GRAD_OFFSETS.get(key)
+        if offs is None:
+            arr = (ctypes.c_int64 * 13)()
+            lib.rt_sasrec_block_grad_offsets(d, dff, arr)
+            offs = _GRAD_OFFSETS[key] = list(arr)
+        sp = _wgrad_splits(M)
+        scratch_bytes = lib.rt_preln_block_bwd_scratch_bytes(M, d, dff, meta[1], sp)
+        scratch = torch.empty((scratch_bytes,), dtype=torch.uint8, device=dev)
+        grads = torch.empty((offs[12],), dtype=torch.float32, device=dev)
+        g_x = torch.empty((M, d), dtype=torch.float32, device=dev)
+        use_side = _side_enabled() and _steals_grad(*params)
+        _c("rt_preln_block_packed_bwd", ctypes.addressof(blk), x, saved, g_out, g_x, grads, scratch, scratch_bytes, sp, 1 if use_side else 0)
+        if use_side:
+            if not _NATIVE_KEEPALIVE:
+                torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+            _NATIVE_KEEPALIVE.append((x, saved, g_out, scratch, grads))
+        views = [grads[offs[i]:offs[i] + t.numel()].view_as(t) for i, t in enumerate(params)]
+        return (g_x, None, *views, None)
+
+
+def preln_layer_packed_train(x: torch.Tensor, cu: torch.Tensor, B: int, H: int, window: int, causal: bool, p: float,
+                             ln1: tp.Tuple[torch.Tensor, torch.Tensor, float], in_proj: tp.Tuple[torch.Tensor, torch.Tensor],
+                             out_proj: tp.Tuple[torch.Tensor, torch.Tensor], ln2: tp.Tuple[torch.Tensor, torch.Tensor, float],
+                             ff1: tp.Tuple[torch.Tensor, torch.Tensor], ff2: tp.Tuple[torch.Tensor, torch.Tensor], rows_real: int,
+                             planes: tp.Optional[WeightPlanes] = None) -> torch.Tensor:
+    """One packed Pre-LN block with autograd through the native executor (biases everywhere, GELU feed-forward)."""
+    return _PreLNLayerPackedNative.apply(_chk(x, "preln_layer_packed_train"), cu, ln1[0], ln1[1], in_proj[0], in_proj[1], out_proj[0],
+                                         out_proj[1], ln2[0], ln2[1], ff1[0], ff1[1], ff2[0], ff2[1],
+                                         (B, H, window, causal, p, ln1[2], ln2[2], int(rows_real), planes))
 
 
 def native_block_enabled() -> bool:

@@ -255,3 +255,43 @@ def test_pre_ln_stack_without_key_padding_mask_keeps_the_padded_window(monkeypat
     m = BERT4RecModel(n_factors=64, n_blocks=1, n_heads=2, session_max_len=24, batch_size=32, use_key_padding_mask=False, seed=1)
     m._build_model_from_dataset(ds)
     assert m.training_loop().packed is False
+
+
+@pytest.mark.parametrize("p,causal", [(0.0, False), (0.25, False), (0.25, True)])
+def test_native_preln_block_equals_the_python_block(p, causal, monkeypatch):
+    """`rt_preln_block_packed_fwd / _bwd` (the block's launch sequence issued by compiled code, csrc/rt_block.hip) against the Python
+    path that issues the same kernels one by one with the same dropout streams: output, input gradient, every parameter gradient; with
+    the parameters in a FlatAdam buffer the native path also runs on the pre-split weight planes."""
+    from rectools_amd import lightning as hl
+    from rectools_amd import nn as hnn
+    from rectools_amd import ops
+
+    torch.manual_seed(17)
+    d, H, window = 64, 2, 40
+    lens = [40, 1, 17, 33, 8, 25, 39, 2, 40, 31]
+    B, N = len(lens), sum(lens)
+    Np = (N + 127) // 128 * 128
+    cu = torch.tensor(np.r_[0, np.cumsum(lens)], dtype=torch.int64).cuda()
+    stack = hnn.PreLNTransformerLayers(2, d, H, p).cuda().train()
+    for prm in stack.parameters():
+        if prm.dim() == 1:
+            torch.nn.init.normal_(prm, std=0.3)
+    opt = hl.FlatAdam(stack, lr=1e-3)                      # parameters become views of one flat buffer: weight planes apply
+    x0 = torch.randn(Np, d); x0[N:] = 0
+    gout = torch.randn(Np, d); gout[N:] = 0
+    res = {}
+    for name, native in (("native", "1"), ("python", "0")):
+        monkeypatch.setenv("RT_NATIVE_BLOCK", native)
+        opt.zero_grad()
+        ops.RNG.seed, ops.RNG.step, ops.RNG._stream = 4242, 9, 0
+        x = x0.cuda().requires_grad_(True)
+        out = stack.forward_packed_train(x, cu, B, window, True, rows_real=N, causal=causal)
+        out.backward(gout.cuda())
+        ops.join_side_streams()
+        torch.cuda.synchronize()
+        res[name] = (out.detach()[:N].clone(), x.grad[:N].clone(), {k: v.grad.clone() for k, v in stack.named_parameters()})
+    torch.testing.assert_close(res["native"][0], res["python"][0], rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(res["native"][1], res["python"][1], rtol=2e-5, atol=2e-6)
+    for k in res["python"][2]:
+        torch.testing.assert_close(res["native"][2][k], res["python"][2][k], rtol=2e-4, atol=2e-6 * (float(res["python"][2][k].abs().max()) + 1e-12),
+                                   msg=lambda s, k=k: f"gradient of {k}: {s}")
