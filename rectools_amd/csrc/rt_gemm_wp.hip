@@ -15,6 +15,8 @@
 // Tiles: 128 x 128 per 256-thread workgroup, 2 x 2 waves of 2 x 2 v_mfma_f32_32x32x16_bf16 tiles, BK = 32, two stages of
 // (16 KB fp32 activations + 3 x 8 KB weight planes) = 80 KB: two workgroups per CU.  Exact tile grids only (M, N % 128, K % 32,
 // 16-byte aligned operands): other shapes answer RT_ERR_UNSUPPORTED and the caller takes rt_gemm.
+#include <stdlib.h>
+
 #include "rt_common.h"
 
 namespace {
@@ -78,8 +80,13 @@ __device__ __forceinline__ f32x4 read_a(const unsigned char* S, int row, int c) 
   return *reinterpret_cast<const f32x4*>(S + row * (BK * 4) + ((c ^ ((row >> 1) & 7)) << 4));
 }
 
-template <bool BTR>
+// Wave layout.  RI x CJ = the 32 x 32 MFMA tiles of a wave.  2 x 2 (waves as a 2 x 2 grid): every activation fragment is read — and SPLIT —
+// by the two waves of its row pair.  1 x 4 (waves stacked along M, each across the whole tile width): every activation row belongs to ONE
+// wave, so the split — the only VALU work left in this kernel — is done once per element; the weight planes are read by all four waves
+// instead (LDS reads only: they need no arithmetic).
+template <bool BTR, int RI>
 __global__ __launch_bounds__(GT) void gemm_wp_kernel(WpGroup gg) {
+  constexpr int CJ = 4 / RI;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int t = blockIdx.x;
   const int p = (t >= gg.tile_end[0]) + (t >= gg.tile_end[1]) + (t >= gg.tile_end[2]);
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(GT) void gemm_wp_kernel(WpGroup gg) {
   const WpArgs& g = gg.g[p];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, half = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = RI == 2 ? wave >> 1 : wave, wn = RI == 2 ? wave & 1 : 0;
   const int n_tn = g.N / BN;
   const int n_tiles = (g.M / BM) * n_tn;
   {   // consecutive tiles of one XCD share weight planes and neighbouring activation rows in that XCD's L2
@@ -140,11 +147,11 @@ __global__ __launch_bounds__(GT) void gemm_wp_kernel(WpGroup gg) {
   constexpr int NL = 10;   // DMA instructions per wave and stage
   if (issued < n_steps) issue_next();
 
-  f32x16 acc[2][2];
+  f32x16 acc[RI][CJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < RI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < CJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -160,16 +167,16 @@ __global__ __launch_bounds__(GT) void gemm_wp_kernel(WpGroup gg) {
     cons_stage ^= 1;
 #pragma unroll
     for (int u = 0; u < BK / 16; ++u) {
-      Split3 as[2], bs[2];
+      Split3 as[RI], bs[CJ];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {                   // k = 16 u + 8 half + (0..7): chunks 4u + 2 half, 4u + 2 half + 1
-        const int row = wm * 64 + i * 32 + col;
+      for (int i = 0; i < RI; ++i) {                  // k = 16 u + 8 half + (0..7): chunks 4u + 2 half, 4u + 2 half + 1
+        const int row = wm * (32 * RI) + i * 32 + col;
         as[i] = split_bf16x3(read_a(Ab, row, 4 * u + 2 * half), read_a(Ab, row, 4 * u + 2 * half + 1));
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < CJ; ++j) {
         if (!BTR) {
-          const int n = wn * 64 + j * 32 + col;
+          const int n = wn * (32 * CJ) + j * 32 + col;
           const unsigned char* q = Bb + n * (BK * 2) + ((((unsigned)(2 * u + half)) ^ ((n >> 2) & 3)) << 4);
           bs[j].h = *reinterpret_cast<const bf16x8*>(q);
           bs[j].m = *reinterpret_cast<const bf16x8*>(q + P_TILE_B);
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(GT) void gemm_wp_kernel(WpGroup gg) {
         } else {
           // 16-lane group G reads [4 k rows][16 n columns]: lane i supplies row (i >> 2), 4 columns 4 (i & 3) and receives column i
           const int i16 = lane & 15, G = lane >> 4;
-          const int ncol = wn * 64 + j * 32 + (G & 1) * 16 + 4 * (i16 & 3);       // first of this lane's 4 columns
+          const int ncol = wn * (32 * CJ) + j * 32 + (G & 1) * 16 + 4 * (i16 & 3);   // first of this lane's 4 columns
           s16x8 v[3];
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl) {
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(GT) void gemm_wp_kernel(WpGroup gg) {
         }
       }
 #define RT_WP_TERM(PA, PB)                                                                                     \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                  \
+  _Pragma("unroll") for (int i = 0; i < RI; ++i) _Pragma("unroll") for (int j = 0; j < CJ; ++j)                \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[i].PA, bs[j].PB, acc[i][j], 0, 0, 0);
       RT_WP_TERM(l, h) RT_WP_TERM(h, l) RT_WP_TERM(m, m) RT_WP_TERM(m, h) RT_WP_TERM(h, m) RT_WP_TERM(h, h)
 #undef RT_WP_TERM
@@ -204,11 +211,11 @@ __global__ __launch_bounds__(GT) void gemm_wp_kernel(WpGroup gg) {
 
   // epilogue (tiles are exact): bias, residual, relu
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < RI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wn * 64 + j * 32 + col;
-      const int mb = m0 + wm * 64 + i * 32 + 4 * half;
+    for (int j = 0; j < CJ; ++j) {
+      const int n = n0 + wn * (32 * CJ) + j * 32 + col;
+      const int mb = m0 + wm * (32 * RI) + i * 32 + 4 * half;
       const float bv = g.bias != nullptr ? g.bias[n] : 0.f;
       float rv[16];
       if (g.R != nullptr) {
@@ -302,15 +309,15 @@ int rt_gemm_wp(const rt_gemm_wp_problem* problems, int32_t n, int32_t w_tr, hipS
     gg.tile_end[i] = tiles;
   }
   const size_t lds = (size_t)NS * STAGE_B;
-  if (w_tr) {
-    RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    gemm_wp_kernel<true><<<tiles, GT, lds, stream>>>(gg);
-  } else {
-    RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    gemm_wp_kernel<false><<<tiles, GT, lds, stream>>>(gg);
-  }
-  RT_CHECK_LAUNCH();
-  return RT_OK;
+  static const int layout = [] { const char* e = getenv("RT_GEMM_WP_LAYOUT"); return e ? atoi(e) : 1; }();   // 1: waves 4 x 1, 2: 2 x 2
+  auto go = [&](auto kern) -> int {
+    RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    kern<<<tiles, GT, lds, stream>>>(gg);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+  };
+  if (layout == 2) return w_tr ? go(&gemm_wp_kernel<true, 2>) : go(&gemm_wp_kernel<false, 2>);
+  return w_tr ? go(&gemm_wp_kernel<true, 1>) : go(&gemm_wp_kernel<false, 1>);
 }
 
 }  // extern "C"

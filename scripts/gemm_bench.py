@@ -19,7 +19,10 @@ def time_it(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3   # us
 
 out = {}
-for (M, N, K) in [(25600, 256, 256), (25600, 512, 256), (25600, 768, 256), (8192, 8192, 8192), (25600, 1024, 256)]:
+SHAPES = [(25600, 256, 256), (25600, 512, 256), (25600, 768, 256), (8192, 8192, 8192), (25600, 1024, 256)]
+if len(sys.argv) > 1:      # "MxNxK,MxNxK,..."
+    SHAPES = [tuple(int(v) for v in t.split("x")) for t in sys.argv[1].split(",")]
+for (M, N, K) in SHAPES:
     x, w, b = rnd(M, K), rnd(N, K), rnd(N)
     dy = rnd(M, N)
     y = torch.empty(M, N, device=dev); dx = torch.empty(M, K, device=dev); dw = torch.empty(N, K, device=dev)

@@ -26,7 +26,10 @@ def time_it(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for (M, N, K) in [(18432, 256, 256), (147456, 256, 256), (147456, 512, 256), (8192, 8192, 8192)]:
+SHAPES = [(18432, 256, 256), (147456, 256, 256), (147456, 512, 256), (8192, 8192, 8192)]
+if len(sys.argv) > 1:
+    SHAPES = [tuple(int(v) for v in t.split('x')) for t in sys.argv[1].split(',')]
+for (M, N, K) in SHAPES:
     x, w, dy = rnd(M, K), rnd(N, K), rnd(M, N)
     y, dx = torch.empty(M, N, device=dev), torch.empty(M, K, device=dev)
     n = w.numel(); stride = (n + 7) // 8 * 8
