@@ -21,6 +21,7 @@ copy, item_net.py:361-368); with a category-feature block the catalog matrix is 
 from __future__ import annotations
 
 import math
+import os
 import typing as tp
 import warnings
 
@@ -712,10 +713,19 @@ class STULayer(nn.Module):
         o_in = ops.mul_mask(uq[0], self.norm_attn_output(attn), ids_last)
         return self.output_mlp(o_in, residual=_take_last(x0, B, L))
 
-    def forward_packed(self, seqs, cu, B, window, ts, thr):
+    def forward_packed(self, seqs, cu, B, window, ts, thr, rows_real=None):
         """The block over PACKED sessions ([Np, d], real positions only).  The reference zeroes pad rows before the bias-free projection
         (hstu.py:256-262): their u / v / q / k are silu(0) = 0, a pad key adds nothing to any query — the packed rows see exactly what
-        they see in the padded window.  The ops of `forward_modular` without the masks; attention = `ops.hstu_attn_varlen`."""
+        they see in the padded window.  With the row count known on the host: ONE autograd node (`ops.stu_layer_packed`); else the ops
+        of `forward_modular` without the masks, attention = `ops.hstu_attn_varlen`."""
+        if rows_real is not None and self.output_mlp.bias is not None and os.environ.get("RT_STU_FUSED", "1") != "0":
+            tw = self.rel_attn.time_weights if self.rel_attn.relative_time_attention else None
+            pw = self.rel_attn.pos_weights if self.rel_attn.relative_pos_attention else None
+            return ops.stu_layer_packed(seqs, cu, rows_real, ts if tw is not None else None, thr, B, window, self.n_heads, self.hd,
+                                        self.p_attn if self.training else 0.0, self.p_mlp if self.training else 0.0,
+                                        (self.norm_input.weight, self.norm_input.bias, self.norm_input.eps), self.uvqk_proj, tw, pw,
+                                        (self.norm_attn_output.weight, self.norm_attn_output.bias, self.norm_attn_output.eps),
+                                        (self.output_mlp.weight, self.output_mlp.bias))
         hh = self.n_heads * self.hd
         normed = self.norm_input(seqs)
         uvqk = ops.act_dropout(ops.matmul_nn(normed, self.uvqk_proj), ops.ACT_SILU, 0.0)
@@ -775,7 +785,7 @@ class STULayers(TransformerLayersBase):
 
     def forward_packed_train(self, seqs, cu, B, window, keypad, rows_real=None, causal=True, ts=None):
         for blk in self.stu_blocks:
-            seqs = blk.forward_packed(seqs, cu, B, window, ts, self.time_thr)
+            seqs = blk.forward_packed(seqs, cu, B, window, ts, self.time_thr, rows_real)
         return seqs
 
     def forward_last_packed(self, seqs, cu, B, window, keypad, rows_real=None, causal=True, ts=None):

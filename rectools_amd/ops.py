@@ -1824,29 +1824,44 @@ class _STULayer(torch.autograd.Function):
     zero-filled buffers of that size, copied a slice into each and added them: 0.95 + 0.34 + 0.28 ms of at:: kernels per C4
     step), u is read in place through a row stride, and the mask / skip-connection passes around LN_in ride inside its
     backward kernel (`rt_layernorm_bwd_fused`).
+
+    Packed sessions (`meta` carries cu / rows_real, ids is None; `stu_layer_packed`): no pad rows, so m = 1 everywhere — the mask
+    passes drop out, the attention is `rt_hstu_attn_varlen_*`, and the rows behind the last session are kept at zero where a weight
+    gradient sums over all rows.
     """
 
     @staticmethod
     def forward(ctx, x, ids, ts, thr, ln1_w, ln1_b, uvqk_p, tw, pw, ln2_w, ln2_b, out_w, out_b, meta):
-        B, L, H, hd, p_attn, p_mlp, eps1, eps2 = meta
+        B, L, H, hd, p_attn, p_mlp, eps1, eps2 = meta[:8]
+        cu, rows_real = (meta[8], meta[9]) if len(meta) > 8 else (None, None)
         x = x.contiguous()
         M, d = x.shape
         hh = H * hd
         dev = x.device
         new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
-        x0 = new(M, d)
-        _c("rt_mul_mask", x, None, ids, d, x.numel(), x0)
+        if cu is None:
+            x0 = new(M, d)
+            _c("rt_mul_mask", x, None, ids, d, x.numel(), x0)
+        else:
+            x0 = x
         n1, mean1, rstd1 = new(M, d), new(M), new(M)
         _c("rt_layernorm_fwd", x0, ln1_w, ln1_b, float(eps1), M, d, n1, mean1, rstd1)
-        _c("rt_mul_mask", n1, None, ids, d, n1.numel(), n1)          # in place: n1 = LN(x0) * m
+        if cu is None:
+            _c("rt_mul_mask", n1, None, ids, d, n1.numel(), n1)          # in place: n1 = LN(x0) * m
         z = new(M, 4 * hh)
         _gemm(n1, d, 1, uvqk_p, 4 * hh, 0, z, 4 * hh, None, None, 0, M, 4 * hh, d)
         uvqk = new(M, 4 * hh)
         _c("rt_act_dropout_fwd", z, ACT_SILU, 0.0, 0, 0, z.numel(), None, uvqk)
         attn = new(M, hh)
         has_t = tw is not None
-        _c("rt_hstu_attn_fwd", uvqk[:, 2 * hh:], 4 * hh, uvqk[:, 3 * hh:], 4 * hh, uvqk[:, hh:], 4 * hh, ids, ts if has_t else None,
-           tw, thr if has_t else None, pw, B, H, L, hd, attn, hh)
+        if cu is None:
+            _c("rt_hstu_attn_fwd", uvqk[:, 2 * hh:], 4 * hh, uvqk[:, 3 * hh:], 4 * hh, uvqk[:, hh:], 4 * hh, ids, ts if has_t else None,
+               tw, thr if has_t else None, pw, B, H, L, hd, attn, hh)
+        else:
+            if rows_real < M:
+                attn[rows_real:].zero_()                      # rows behind the last session: finite zeros
+            _c("rt_hstu_attn_varlen_fwd", uvqk[:, 2 * hh:], 4 * hh, uvqk[:, 3 * hh:], 4 * hh, uvqk[:, hh:], 4 * hh, cu, ts if has_t else None,
+               tw, thr if has_t else None, pw, B, H, L, hd, attn, hh)
         seed_a = seed_m = (0, 0)
         attn_d = attn
         if p_attn > 0:
@@ -1865,15 +1880,15 @@ class _STULayer(torch.autograd.Function):
         out = new(M, d)
         _gemm(o_d, hh, 1, out_w, hh, 1, out, d, out_b, x0, d, M, d, hh)
         ctx.save_for_backward(ids, ts, thr, x0, n1, z, uvqk, attn_d, la, o_d, mean1, rstd1, mean2, rstd2, ln1_w, uvqk_p, tw, pw,
-                              ln2_w, out_w)
-        ctx.meta = (B, L, H, hd, p_attn, p_mlp, seed_a, seed_m)
+                              ln2_w, out_w, cu)
+        ctx.meta = (B, L, H, hd, p_attn, p_mlp, seed_a, seed_m, rows_real)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
         (ids, ts, thr, x0, n1, z, uvqk, attn_d, la, o_d, mean1, rstd1, mean2, rstd2, ln1_w, uvqk_p, tw, pw, ln2_w,
-         out_w) = ctx.saved_tensors
-        B, L, H, hd, p_attn, p_mlp, seed_a, seed_m = ctx.meta
+         out_w, cu) = ctx.saved_tensors
+        B, L, H, hd, p_attn, p_mlp, seed_a, seed_m, rows_real = ctx.meta
         g_out = g_out.contiguous()
         M, d = g_out.shape
         hh = H * hd
@@ -1913,9 +1928,16 @@ class _STULayer(torch.autograd.Function):
         has_t = tw is not None
         dtw = None if tw is None else torch.zeros_like(tw)
         dpw = None if pw is None else torch.zeros_like(pw)
-        _c("rt_hstu_attn_bwd", uvqk[:, 2 * hh:], 4 * hh, uvqk[:, 3 * hh:], 4 * hh, uvqk[:, hh:], 4 * hh, g_attn, hh, ids,
-           ts if has_t else None, tw, thr if has_t else None, pw, B, H, L, hd, g_uvqk[:, 2 * hh:], 4 * hh, g_uvqk[:, 3 * hh:], 4 * hh,
-           g_uvqk[:, hh:], 4 * hh, dtw, dpw)
+        if cu is None:
+            _c("rt_hstu_attn_bwd", uvqk[:, 2 * hh:], 4 * hh, uvqk[:, 3 * hh:], 4 * hh, uvqk[:, hh:], 4 * hh, g_attn, hh, ids,
+               ts if has_t else None, tw, thr if has_t else None, pw, B, H, L, hd, g_uvqk[:, 2 * hh:], 4 * hh, g_uvqk[:, 3 * hh:], 4 * hh,
+               g_uvqk[:, hh:], 4 * hh, dtw, dpw)
+        else:
+            if rows_real < M:
+                g_uvqk[rows_real:, hh:].zero_()               # the kernel writes session rows only; dP sums over every row
+            _c("rt_hstu_attn_varlen_bwd", uvqk[:, 2 * hh:], 4 * hh, uvqk[:, 3 * hh:], 4 * hh, uvqk[:, hh:], 4 * hh, g_attn, hh, cu,
+               ts if has_t else None, tw, thr if has_t else None, pw, B, H, L, hd, g_uvqk[:, 2 * hh:], 4 * hh, g_uvqk[:, 3 * hh:], 4 * hh,
+               g_uvqk[:, hh:], 4 * hh, dtw, dpw)
         g_z = new(M, 4 * hh)
         _c("rt_act_dropout_bwd", g_uvqk, z, ACT_SILU, 0.0, 0, 0, g_uvqk.numel(), g_z)
         d_p = new(d, 4 * hh)
@@ -1929,7 +1951,8 @@ class _STULayer(torch.autograd.Function):
         g_x, d_ln1w, d_ln1b = new(M, d), new(d), new(d)
         ws_bytes = lib.rt_layernorm_bwd_workspace_bytes(M, d)
         ws = torch.empty((max(ws_bytes, 4),), dtype=torch.uint8, device=dev)
-        _c("rt_layernorm_bwd_fused", g_n, x0, ln1_w, mean1, rstd1, g_out, ids, 1, 1, M, d, g_x, d_ln1w, d_ln1b, ws, ws_bytes)
+        msk = 1 if cu is None else 0
+        _c("rt_layernorm_bwd_fused", g_n, x0, ln1_w, mean1, rstd1, g_out, ids, msk, msk, M, d, g_x, d_ln1w, d_ln1b, ws, ws_bytes)
         if side:
             side[-1].join_now()
         return (g_x, None, None, None, d_ln1w, d_ln1b, d_p, dtw, dpw, d_ln2w, d_ln2b, d_wo, d_bo, None)
@@ -1944,6 +1967,18 @@ def stu_layer(x: torch.Tensor, ids: torch.Tensor, ts: tp.Optional[torch.Tensor],
         _chk(t, "stu_layer")
     return _STULayer.apply(x, ids.reshape(-1), ts, thr, ln_in[0], ln_in[1], uvqk_proj, time_w, pos_w, ln_attn[0], ln_attn[1],
                            out_mlp[0], out_mlp[1], (B, L, H, hd, float(p_attn), float(p_mlp), ln_in[2], ln_attn[2]))
+
+
+def stu_layer_packed(x: torch.Tensor, cu: torch.Tensor, rows_real: int, ts: tp.Optional[torch.Tensor], thr: torch.Tensor, B: int, window: int,
+                     H: int, hd: int, p_attn: float, p_mlp: float, ln_in: tp.Tuple[torch.Tensor, torch.Tensor, float], uvqk_proj: torch.Tensor,
+                     time_w: tp.Optional[torch.Tensor], pos_w: tp.Optional[torch.Tensor],
+                     ln_attn: tp.Tuple[torch.Tensor, torch.Tensor, float], out_mlp: tp.Tuple[torch.Tensor, torch.Tensor]) -> torch.Tensor:
+    """The fused STU block on PACKED rows [Np, d] (session b = rows cu[b] .. cu[b+1]-1, rows_real = cu[B]; ts = the packed timestamps
+    of `collate_packed_ts`): `_STULayer` without the masks, on `rt_hstu_attn_varlen_*`."""
+    for t in (x, ln_in[0], uvqk_proj, ln_attn[0], out_mlp[0]):
+        _chk(t, "stu_layer_packed")
+    return _STULayer.apply(x, None, ts, thr, ln_in[0], ln_in[1], uvqk_proj, time_w, pos_w, ln_attn[0], ln_attn[1], out_mlp[0], out_mlp[1],
+                           (B, window, H, hd, float(p_attn), float(p_mlp), ln_in[2], ln_attn[2], cu, int(rows_real)))
 
 
 # --------------------------------------------------------------------------------------------------

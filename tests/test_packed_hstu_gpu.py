@@ -138,15 +138,16 @@ def test_packed_hstu_loss_and_gradients_equal_the_padded_batch(loss, time):
         padded["negatives"], packed["negatives"] = neg_p, pad(neg_p[real].t()).t().contiguous()
     lp = lm.training_loss(padded); lp.backward()
     g_padded = {k: v.grad.clone() for k, v in lm.named_parameters() if v.grad is not None}
-    for v in lm.parameters():
-        v.grad = None
-    lq = lm.training_loss_packed(packed); lq.backward()
-    torch.testing.assert_close(lq.detach(), lp.detach(), rtol=1e-4, atol=1e-6)
-    for k, v in lm.named_parameters():
-        if k in g_padded:
-            got = v.grad if v.grad is not None else torch.zeros_like(v)
-            torch.testing.assert_close(got, g_padded[k], rtol=2e-3, atol=2e-5 * (float(g_padded[k].abs().max()) + 1e-12),
-                                       msg=lambda s, k=k: f"gradient of {k}: {s}")
+    for pb in (packed, dict(packed, n_rows=N)):        # the individual ops, and (row count known on the host) the fused packed node
+        for v in lm.parameters():
+            v.grad = None
+        lq = lm.training_loss_packed(pb); lq.backward()
+        torch.testing.assert_close(lq.detach(), lp.detach(), rtol=1e-4, atol=1e-6)
+        for k, v in lm.named_parameters():
+            if k in g_padded:
+                got = v.grad if v.grad is not None else torch.zeros_like(v)
+                torch.testing.assert_close(got, g_padded[k], rtol=2e-3, atol=2e-5 * (float(g_padded[k].abs().max()) + 1e-12),
+                                           msg=lambda s, k=k: f"gradient of {k}: {s}")
 
 
 def test_packed_hstu_train_loop_takes_the_steps_of_the_padded_loop(monkeypatch):
