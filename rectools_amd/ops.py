@@ -1287,7 +1287,8 @@ class WeightPlanes:
 
 
 def weight_planes_enabled() -> bool:
-    return os.environ.get("RT_WEIGHT_PLANES", "1") != "0"
+    """Pre-split weight planes (K7w) are bf16x6 arithmetic: RT_GEMM_SPLIT=exact (every product on the f32-input MFMA) switches them off."""
+    return os.environ.get("RT_WEIGHT_PLANES", "1") != "0" and os.environ.get("RT_GEMM_SPLIT", "") != "exact"
 
 
 def _block_desc(rows: int, rows_real: int, cu: torch.Tensor, B: int, H: int, d: int, dff: int, window: int, pad_keys: bool, p: float,

@@ -14,7 +14,9 @@ SRC = os.path.join(ROOT, "gpurun_out", TAG)
 DST = os.path.join(ROOT, "profiles")
 KEEP = [("1_bench.json", "bench_auto.json"), ("2_prof.md", "rocprof_kernel_trace_train.md"), ("3_bench.json", "bench_train_single_stream.json"),
         ("4_pmc.txt", "pmc_train_FETCH_SIZE.txt"), ("5_pmc.txt", "pmc_train_WRITE_SIZE.txt"), ("6_pmc.txt", "sq_counters_train_raw.txt"),
-        ("7_prof.md", "rocprof_kernel_trace_topk5m.md"), ("8_pmc.txt", "pmc_topk5m_FETCH_SIZE.txt"), ("9_pmc.txt", "pmc_topk5m_WRITE_SIZE.txt")]
+        ("7_prof.md", "rocprof_kernel_trace_topk5m.md"), ("8_pmc.txt", "pmc_topk5m_FETCH_SIZE.txt"), ("9_pmc.txt", "pmc_topk5m_WRITE_SIZE.txt"),
+        ("10_prof.md", "rocprof_kernel_trace_topk5m_u4096_two_stage.md"), ("11_prof.md", "rocprof_kernel_trace_bert4rec.md"),
+        ("12_prof.md", "rocprof_kernel_trace_hstu.md"), ("13_prof.md", "rocprof_kernel_trace_recommend.md")]
 
 
 def parse(path):
