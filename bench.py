@@ -531,7 +531,7 @@ def topk_leg(kind, args, rank, world, cpu_baseline):
         steps, warmup = args.topk_steps, 2
         metric = "full-catalog top-k users/sec @k=10 (5M x 512 fp32 catalog)"
         workload = f"top-k scoring: 5,000,000 items x d512 fp32 (10.24 GB), {ups} users/step, k=10"
-        name, with_filter = "topk5m", False
+        name, with_filter = ("topk5m" if ups <= 64 else f"topk5m_u{ups}"), False      # (the PMC traffic on file is the 16-user launch's)
     value, wall, roof, info = run_topk(steps, warmup, rank, world, V, d, ups, upp, with_filter, name)
     rec = {"metric": metric, "value": round(value, 2), "unit": "users/s", "steps": steps, "warmup": warmup,
            "ms_per_step": round(wall / steps * 1e3, 4), "dtype": "fp32",
@@ -652,7 +652,7 @@ def main():
                 out["recommend"] = kernel_leg
             out["topk5m"] = topk_leg("topk5m", args, rank, world, cpu_ok)
             big = argparse.Namespace(**vars(args))
-            big.users_per_step, big.users_per_pass, big.topk_steps = 4096, 64, 2
+            big.users_per_step, big.users_per_pass, big.topk_steps = 4096, 0, 2     # users per pass: the library's choice
             out["topk5m_u4096"] = topk_leg("topk5m", big, rank, world, False)   # >= 4096 users over 5M x 512 (the MFMA regime)
             if not args.no_families:
                 # the other BASELINE configs' model families at their stated shapes (configs[2..4]: BERT4Rec d256 L200 full softmax; HSTU d256
