@@ -145,7 +145,28 @@ def test_softmax_attention_L512_hd64():
 MEASURED = {}     # test name -> {tensor: max |got - oracle| / max |oracle|}: printed (pytest -s / on failure) and kept for profiles/
 
 
-def _step_vs_oracle(cfg, batch, grad_rtol=1e-3, name="step"):
+def _pack(batch):
+    """The padded [B, L] batch as the packed batch `training_loss_packed` takes (real positions only, 128-row tile tail of zeros; the
+    row count known on the host selects the native block executors / the fused packed STU node)."""
+    x = batch["x"].cuda()
+    B, L = x.shape
+    real = x != 0
+    N = int(real.sum()); tail = (N + 127) // 128 * 128 - N
+    pad = lambda t: torch.nn.functional.pad(t, (0, tail))   # noqa: E731
+    lens = real.sum(1)
+    cu = torch.zeros(B + 1, dtype=torch.int64, device="cuda"); cu[1:] = torch.cumsum(lens, 0)
+    dist = (L - 1 - torch.arange(L, device="cuda"))[None, :].expand(B, L)
+    out = {"x": pad(x[real]), "y": pad(batch["y"].cuda()[real]), "yw": pad(batch["yw"].cuda()[real]), "dist": pad(dist[real]), "cu": cu,
+           "window": L, "n_rows": N}
+    if "negatives" in batch:
+        out["negatives"] = pad(batch["negatives"].cuda()[real].t()).t().contiguous()
+    if "unix_ts" in batch:
+        ts = batch["unix_ts"].cuda()
+        out["ts"] = torch.cat([ts[b, L - int(n):] for b, n in enumerate(lens.tolist())])
+    return out
+
+
+def _step_vs_oracle(cfg, batch, grad_rtol=1e-3, name="step", packed=False):
     """One whole training step against the oracle: loss to 5e-5, every parameter gradient to rtol 1e-3 of its own value (entries below
     2e-5 of the tensor's maximum: absolute) — what is measured is ~1e-5 of the tensor scale; the measured maxima are recorded."""
     from rectools_amd import lightning as hl
@@ -162,8 +183,16 @@ def _step_vs_oracle(cfg, batch, grad_rtol=1e-3, name="step"):
     dbatch = {k: v.cuda() for k, v in batch.items()}
     lm.train()
     lm.zero_grad()
-    loss = lm.training_loss(dbatch)
+    if packed:      # the padding-free path of the same step, straight against the oracle
+        tm = lm.torch_model
+        assert tm.transformer_layers.packed_ok(cfg["d"], cfg["L"], tm.use_causal_attn, tm.use_key_padding_mask)
+        loss = lm.training_loss_packed(_pack(batch))
+    else:
+        loss = lm.training_loss(dbatch)
     loss.backward()
+    from rectools_amd import ops
+
+    ops.join_side_streams()
     assert abs(float(loss.detach()) - float(loss_ref)) <= 5e-5 * abs(float(loss_ref)) + 5e-6, (float(loss.detach()), float(loss_ref))
     rec = MEASURED.setdefault(name, {"loss_rel": abs(float(loss.detach()) - float(loss_ref)) / abs(float(loss_ref))})
     for n, p in lm.torch_model.named_parameters():
@@ -175,10 +204,12 @@ def _step_vs_oracle(cfg, batch, grad_rtol=1e-3, name="step"):
         _close(p.grad, g_ref[n], grad_rtol, 2e-5 if g_ref[n].abs().max() > 1e-6 else 1.0, f"grad {n}")
 
 
-def test_stu_training_step_L512_d256_H4():
-    """C4 model shape: HSTU, relative time + position bias, cosine, sampled_softmax, logits_t 0.05; B = 2 sequences."""
+@pytest.mark.parametrize("packed", [False, True])
+def test_stu_training_step_L512_d256_H4(packed):
+    """C4 model shape: HSTU, relative time + position bias, cosine, sampled_softmax, logits_t 0.05; B = 2 sequences — through the padded
+    window and through the packed rows (session-aware ring attention, fused packed STU node)."""
     cfg, batch = _random_case("stu", "sampled_softmax", "cosine", 512, 256, 4, 2, 600, 16, 31, logits_t=0.05)
-    _step_vs_oracle(cfg, batch, name="C4 STU L512")
+    _step_vs_oracle(cfg, batch, name="C4 STU L512" + (" packed" if packed else ""), packed=packed)
 
 
 def test_ligr_training_step_d512():
@@ -188,7 +219,8 @@ def test_ligr_training_step_d512():
     _step_vs_oracle(cfg, batch, name="C5 LiGR d512")
 
 
-def test_bert4rec_training_step_C3_shape():
+@pytest.mark.parametrize("packed", [False, True])
+def test_bert4rec_training_step_C3_shape(packed):
     """BASELINE config 3: BERT4Rec d256, 2 Pre-LN blocks, 4 heads, L200, key-padding masks, mask_prob 0.15, FULL softmax over the
     26,744-item catalog (+ PAD + MASK = 26,746 classes: the padded-to-128 exact-tile GEMMs, the -inf-masked pad columns and the
     split-K dS product of `ops._SoftmaxLoss`), B = 16 sequences: loss and every parameter gradient against the oracle."""
@@ -209,7 +241,7 @@ def test_bert4rec_training_step_C3_shape():
     batch["x"], batch["y"] = x, y
     batch["yw"] = (y != 0).float() * (0.5 + torch.rand(B, L, generator=g))
     assert 0.10 < float(masked.sum()) / float(real.sum()) < 0.20
-    _step_vs_oracle(cfg, batch, name="C3 BERT4Rec")
+    _step_vs_oracle(cfg, batch, name="C3 BERT4Rec" + (" packed" if packed else ""), packed=packed)
 
 
 @pytest.mark.parametrize("causal,keypad", [(True, False), (False, True), (True, True)])
@@ -265,7 +297,8 @@ def test_sampled_softmax_V26744_N128_zipf_targets():
     close(ggot[1], gref[1], rtol=2e-3, atol_rel=2e-4, msg="d_table")
 
 
-def test_sasrec_training_step_C2_shape_zipf():
+@pytest.mark.parametrize("packed", [False, True])
+def test_sasrec_training_step_C2_shape_zipf(packed):
     """One whole C2 training step (d256, 2 blocks, 4 heads, L200, sampled_softmax N=128, V=26,744) on 32 Zipf-popular
     sequences: loss and EVERY parameter gradient (incl. the embedding-table gradient through both heavy-row reducers)."""
     L, d, H, B, V, N = 200, 256, 4, 32, 26_744, 128
@@ -277,4 +310,4 @@ def test_sasrec_training_step_C2_shape_zipf():
     batch["x"] = seq[:, :-1].masked_fill(pad, 0)
     batch["y"] = seq[:, 1:].masked_fill(pad, 0)
     batch["yw"] = (batch["y"] != 0).float()
-    _step_vs_oracle(cfg, batch, name="C2 SASRec")
+    _step_vs_oracle(cfg, batch, name="C2 SASRec" + (" packed" if packed else ""), packed=packed)
