@@ -125,3 +125,31 @@ def test_hm_image_kernel():
     assert torch.equal(m, (r.view(torch.int32) & -65536).view(torch.float32))
     assert bool(((src - h - m).abs() <= src.abs() * 2.0 ** -15).all())
     torch.testing.assert_close(norms, src.double().norm(dim=1).float(), rtol=1e-5, atol=0)
+
+
+def test_two_stage_with_fewer_than_k_candidates_left_by_the_filter():
+    """Users whose viewed-items filter leaves fewer than k (or exactly zero) candidates: counts, ids and score bits as the single-stage
+    kernel — nothing was dropped, so the short result is proven complete."""
+    from rectools_amd.rank import HipRanker
+
+    rng = np.random.default_rng(3)
+    n_obj, d, n_subj, k = 2_000, 64, 150, 10
+    subj, obj = _factors(n_subj, n_obj, d, 5)
+    rows, cols = [], []
+    for u in range(n_subj):
+        keep = rng.integers(0, 25) if u % 3 else 0          # every third user keeps nothing, the others 0..24 items
+        seen = rng.permutation(n_obj)[: n_obj - keep]
+        rows.append(np.full(len(seen), u)); cols.append(seen)
+    filt = sparse.csr_matrix((np.ones(sum(len(c) for c in cols), np.float32), (np.concatenate(rows), np.concatenate(cols))),
+                             shape=(n_subj, n_obj))
+    exact = HipRanker("dot", "cuda", subj, obj, batch_size=64, two_stage=False)
+    fast = HipRanker("dot", "cuda", subj, obj, batch_size=64, two_stage=True)
+    e_ids, e_sc, e_cnt, _ = exact.rank_device(np.arange(n_subj), k, filt)
+    f_ids, f_sc, f_cnt, _ = fast.rank_device(np.arange(n_subj), k, filt)
+    assert fast.two_stage_stats["calls"] == 1 and fast.two_stage_stats["fallbacks"] == 0
+    assert torch.equal(e_cnt, f_cnt) and int(e_cnt.min()) == 0 and 0 < int((e_cnt < k).sum()) < n_subj
+    valid = torch.arange(k, device="cuda")[None, :] < e_cnt[:, None]
+    assert torch.equal(e_ids[valid], f_ids[valid]) and torch.equal(e_sc[valid].view(torch.int32), f_sc[valid].view(torch.int32))
+    # the numpy front end drops the empty rows the same way in both modes
+    a, b = exact.rank(np.arange(n_subj), k, filt), fast.rank(np.arange(n_subj), k, filt)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
