@@ -175,9 +175,10 @@ int rt_collate_packed(const int64_t* offsets, const int64_t* items, const float*
                       int32_t B, int32_t rows, int32_t train, int64_t* x, int64_t* y, float* yw, int64_t* dist, rt_stream_t stream);
 /* ... the timestamps of a packed SASRec-style batch (sasrec.py:96-104 with `add_unix_ts`): session b gets its kept tail's
  * cu[b+1] - cu[b] + 1 timestamps at ts_out[cu[b] + b ..] (the rows' items and the target of the last row:
- * what the padded [B, L+1] batch holds behind its left pad).  n_out = cu[B] + B entries (the caller knows cu[B] on the host). */
-int rt_collate_packed_ts(const int64_t* offsets, const int64_t* unix_ts, const int64_t* idx, const int64_t* cu_seqlens, int32_t B,
-                         int64_t n_out, int64_t* ts_out, rt_stream_t stream);
+ * what the padded [B, L+1] batch holds behind its left pad).  ctx [B] != NULL (recommend with a context, sasrec.py:149-166): the last
+ * cu[b+1] - cu[b] items' timestamps followed by ctx[b], the time of the request.  n_out = cu[B] + B entries (the caller knows cu[B]). */
+int rt_collate_packed_ts(const int64_t* offsets, const int64_t* unix_ts, const int64_t* idx, const int64_t* cu_seqlens, const int64_t* ctx,
+                         int32_t B, int64_t n_out, int64_t* ts_out, rt_stream_t stream);
 /* ... the BERT4Rec batch on packed rows (bert4rec.py:109-153, 182-193).  train = 1: cu[b+1] - cu[b] = min(length, window) rows; probs /
  * rand_ids [B, window] are the draws of rt_collate mode 3, read at the row's padded position (b, window - n + j) — the packed batch
  * masks what the padded one masks; y = the item where the position was picked, else 0.  draw_rows [B] or NULL: the row of the draws

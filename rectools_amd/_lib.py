@@ -89,7 +89,7 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_gather_rows": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rt_scatter_rows": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rt_collate_packed": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "rt_collate_packed_ts": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_vp]),
+    "rt_collate_packed_ts": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_vp]),
     "rt_collate_packed_bert": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_i64, c_vp, c_vp,
                                        c_vp, c_vp, c_vp]),
     "rt_embed_packed_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_f32, c_u64, c_u64, c_vp, c_vp]),

@@ -116,8 +116,9 @@ __global__ __launch_bounds__(256) void collate_packed_kernel(PackedArgs a) {
 // timestamps of a packed training batch: one thread per output entry; session b owns entries cu[b] + b .. cu[b+1] + b (its n rows' items
 // and the target of the last row = the last n + 1 timestamps of the session)
 __global__ __launch_bounds__(256) void collate_packed_ts_kernel(const long long* __restrict__ offsets, const long long* __restrict__ unix_ts,
-                                                                const long long* __restrict__ idx, const long long* __restrict__ cu, int B,
-                                                                long long n_out, long long* __restrict__ ts_out) {
+                                                                const long long* __restrict__ idx, const long long* __restrict__ cu,
+                                                                const long long* __restrict__ ctx, int B, long long n_out,
+                                                                long long* __restrict__ ts_out) {
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   if (e >= n_out || e >= cu[B] + B) return;
   int lo = 0, hi = B;                     // largest b with cu[b] + b <= e
@@ -127,7 +128,9 @@ __global__ __launch_bounds__(256) void collate_packed_ts_kernel(const long long*
   }
   const long long n = cu[lo + 1] - cu[lo], j = e - cu[lo] - lo;      // j in [0, n]
   const long long end = offsets[idx[lo] + 1];
-  ts_out[e] = unix_ts[end - (n + 1) + j];
+  // train: the session's last n + 1 timestamps; recommend (ctx): its last n items' and the request's own (sasrec.py:149-166 with the
+  // context row data_preparator.py:384-394 appends behind the history)
+  ts_out[e] = ctx == nullptr ? unix_ts[end - (n + 1) + j] : (j < n ? unix_ts[end - n + j] : ctx[lo]);
 }
 
 // BERT4Rec on packed rows (bert4rec.py:109-153 / 182-193): train — session b shows its last n = cu[b+1] - cu[b] items, the masking draws
@@ -236,17 +239,18 @@ int rt_collate_packed(const int64_t* offsets, const int64_t* items, const float*
   return RT_OK;
 }
 
-// Timestamps of a packed training batch: n_out = cu[B] + B entries (the caller knows cu[B] on the host), session b's n + 1 at cu[b] + b.
-// Every session must hold at least n + 1 items (it does: n = min(length - 1, window)).
-int rt_collate_packed_ts(const int64_t* offsets, const int64_t* unix_ts, const int64_t* idx, const int64_t* cu_seqlens, int32_t B,
-                         int64_t n_out, int64_t* ts_out, hipStream_t stream) {
+// Timestamps of a packed batch: n_out = cu[B] + B entries (the caller knows cu[B] on the host), session b's n + 1 at cu[b] + b.
+// ctx == NULL (training): the session's last n + 1 timestamps (it holds them: n = min(length - 1, window)).  ctx [B] (recommend with a
+// context): the last n items' timestamps followed by ctx[b], the time of the request.
+int rt_collate_packed_ts(const int64_t* offsets, const int64_t* unix_ts, const int64_t* idx, const int64_t* cu_seqlens, const int64_t* ctx,
+                         int32_t B, int64_t n_out, int64_t* ts_out, hipStream_t stream) {
   (void)hipGetLastError();
   if (B < 0 || n_out < 0) return RT_ERR_INVALID_ARG;
   if (n_out == 0) return RT_OK;
   if (offsets == nullptr || unix_ts == nullptr || idx == nullptr || cu_seqlens == nullptr || ts_out == nullptr) return RT_ERR_INVALID_ARG;
   collate_packed_ts_kernel<<<(unsigned)((n_out + 255) / 256), 256, 0, stream>>>(
       reinterpret_cast<const long long*>(offsets), reinterpret_cast<const long long*>(unix_ts), reinterpret_cast<const long long*>(idx),
-      reinterpret_cast<const long long*>(cu_seqlens), B, n_out, reinterpret_cast<long long*>(ts_out));
+      reinterpret_cast<const long long*>(cu_seqlens), reinterpret_cast<const long long*>(ctx), B, n_out, reinterpret_cast<long long*>(ts_out));
   RT_CHECK_LAUNCH();
   return RT_OK;
 }

@@ -586,7 +586,7 @@ class TransformerModelBase:
         o1 = torch.sort(t, stable=True).indices
         o2 = torch.sort(u[o1], stable=True).indices
         order = o1[o2]
-        u_s, item_s, w_s = u[order], m[order], w[order]
+        u_s, item_s, w_s, t_s = u[order], m[order], w[order], t[order]
         offsets = torch.zeros((n_users + 1,), dtype=torch.int64, device=u_t.device)
         torch.cumsum(torch.bincount(u_s, minlength=n_users), 0, out=offsets[1:])
         key = torch.unique(u_s * V + item_s)                         # sorted: (user, item) pairs, distinct
@@ -594,7 +594,7 @@ class TransformerModelBase:
         indptr = torch.zeros((n_users + 1,), dtype=torch.int64, device=u_t.device)
         torch.cumsum(torch.bincount(frow, minlength=n_users), 0, out=indptr[1:])
         indices = (key - frow * V).to(torch.int32)
-        return offsets, item_s, w_s, indptr, indices
+        return offsets, item_s, w_s, indptr, indices, t_s
 
     @staticmethod
     def _select_csr_rows(indptr: torch.Tensor, indices: torch.Tensor, rows: torch.Tensor,
@@ -633,7 +633,17 @@ class TransformerModelBase:
             dataset.user_id_map.size, dp.item_id_map.size)
         # host copies of the two offset arrays (n_users + 1 int64 each, one D2H per Dataset): a request computes its row counts —
         # encoder rows, filter entries — from them, so no step of a recommend() call waits on the device to size a buffer
-        index = tuple(index) + (index[0].cpu().numpy(), index[3].cpu().numpy())
+        offsets_d, t_ns = index[0], index[5]
+        ts_s = last_ns_h = None
+        if dp.add_unix_ts:
+            # the sessions' timestamps in seconds, by the arithmetic of `_to_unix_ts` (float64 division, truncation), and every user's
+            # last interaction time (ns, host): a request's context must not lie before it (it is the LAST row of the session then)
+            ts_s = (t_ns.double() / 10**9).to(torch.int64)
+            last = torch.full((dataset.user_id_map.size,), torch.iinfo(torch.int64).min, dtype=torch.int64, device=device)
+            has = offsets_d[1:] > offsets_d[:-1]
+            last[has] = t_ns[offsets_d[1:][has] - 1]
+            last_ns_h = last.cpu().numpy()
+        index = tuple(index[:5]) + (index[0].cpu().numpy(), index[3].cpu().numpy(), ts_s, last_ns_h)
         try:
             inter._rt_session_index = (key, index, (df, dp.item_id_map, dataset.item_id_map, dataset.user_id_map))   # pylint: disable=protected-access
         except AttributeError:   # a duck-typed Interactions object with __slots__: no cache
@@ -679,9 +689,15 @@ class TransformerModelBase:
             if on_unsupported_targets == "warn":
                 warnings.warn("Model doesn't support recommendations for cold users, but some of given users are cold")
             users = users[known]
-        if context is None and not self.data_preparator.add_unix_ts and not (self.data_preparator.extra_cols or []):
+        dp_ = self.data_preparator
+        plain = context is None and not dp_.add_unix_ts
+        # a model that reads timestamps (HSTU) takes the device path when its stack packs: the request's context time becomes the last
+        # timestamp of every packed session (`rt_collate_packed_ts`)
+        timed = context is not None and dp_.add_unix_ts and type(dp_).__name__ == "SASRecDataPreparator" and \
+            isinstance(self.torch_model.transformer_layers, hnn.STULayers) and os.environ.get("RT_PACKED", "1") != "0"
+        if (plain or timed) and not (dp_.extra_cols or []):
             fast = self._recommend_device_glue(users, dataset, k, filter_viewed, items_to_recommend, add_rank_col,
-                                               on_unsupported_targets)
+                                               on_unsupported_targets, context if timed else None)
             if fast is not None:
                 return fast
         with warnings.catch_warnings():
@@ -724,7 +740,7 @@ class TransformerModelBase:
 
     def _recommend_device_glue(self, users: np.ndarray, dataset: tp.Any, k: int, filter_viewed: bool,
                                items_to_recommend: tp.Optional[tp.Any], add_rank_col: bool,
-                               on_unsupported_targets: str) -> tp.Optional[pd.DataFrame]:
+                               on_unsupported_targets: str, context: tp.Optional[pd.DataFrame] = None) -> tp.Optional[pd.DataFrame]:
         """recommend() without the pandas / scipy round trips of the reference's glue (`models/base.py:
         502-519,735-791`, `data_preparator.py:354-424`, `dataset.py:314-348`): the Dataset's time-ordered session store and
         viewed-items CSR (known items only) are built ONCE on the device (`_device_session_index`); a call selects the requested
@@ -753,7 +769,7 @@ class TransformerModelBase:
         if len(req) == 0 or len(whitelist) == 0:
             return empty
         n_req, V = len(req), dp.item_id_map.size
-        offsets, item_s, w_s, f_indptr, f_indices, off_h, fptr_h = self._device_session_index(dataset, device)
+        offsets, item_s, w_s, f_indptr, f_indices, off_h, fptr_h, ts_s, last_ns_h = self._device_session_index(dataset, device)
         req = np.ascontiguousarray(req.astype(np.int64))
         lens_h = off_h[req + 1] - off_h[req]
         valid_h = lens_h > 0                                        # users with at least one item the model knows
@@ -764,6 +780,17 @@ class TransformerModelBase:
             warnings.warn(f"{n_cold} target users were considered cold because of missing known items")
         if n_valid == 0:
             return empty
+        ctx_d = None
+        if context is not None:      # data_preparator.transform_dataset_u2i's checks, then the request times of the valid users
+            if not pd.Series(np.asarray(users)).isin(context[Columns.User].unique()).all():
+                raise ValueError("No context for some target users")
+            if context.duplicated(subset=Columns.User).any():
+                raise ValueError("Duplicated user entries found in context. Each user must have exactly one context row.")
+            when = context.set_index(Columns.User)[Columns.Datetime].reindex(np.asarray(users)[valid_h])
+            ctx_ns = pd.to_datetime(when).values.astype("datetime64[ns]").astype("int64")
+            if ts_s is None or last_ns_h is None or bool((ctx_ns < last_ns_h[rows_h]).any()):
+                return None      # a context that is not the session's last row: the reference-shaped path sorts it where it falls
+            ctx_d = torch.from_numpy(dp._to_unix_ts(when)).to(device, non_blocking=True)    # pylint: disable=protected-access
         valid_rows = torch.from_numpy(rows_h).to(device, non_blocking=True)
         dstore = DeviceSequenceStore.from_device(offsets, item_s, w_s, None)
         item_embs = self._item_embeddings()
@@ -774,7 +801,9 @@ class TransformerModelBase:
             # packed encoder (no padding rows: 45 % of the [B, L] window at ML-20M scale) where the stack offers it; RT_PACKED=0
             # keeps the padded window.  Same encodings up to fp32 rounding (tests/test_packed_gpu.py).
             packed = os.environ.get("RT_PACKED", "1") != "0" and type(dp).__name__ in _PACKED_PREPARATORS \
-                and not dp.add_unix_ts and lm.torch_model.can_encode_packed(item_embs.shape[1], dp.session_max_len)
+                and (not dp.add_unix_ts or ctx_d is not None) and lm.torch_model.can_encode_packed(item_embs.shape[1], dp.session_max_len)
+            if ctx_d is not None and not packed:
+                return None
             mask_id = dp.extra_token_ids[MASKING_VALUE] if type(dp).__name__ == "BERT4RecDataPreparator" else None
             unsort = None
             if packed:   # packed row offsets of every encoder launch, cut on the host, one upload
@@ -791,8 +820,9 @@ class TransformerModelBase:
             for bi, b0 in enumerate(range(0, n_valid, bs)):
                 nb = min(bs, n_valid - b0)
                 if packed:
+                    kw = {} if ctx_d is None else {"ts_store": ts_s, "ts_ctx": ctx_d[b0:b0 + nb]}
                     outs.append(lm.torch_model.encode_last_packed(offsets, item_s, enc_rows[b0:b0 + nb], dp.session_max_len, item_embs,
-                                                                  cu=cu_d[bi, :nb + 1], n_rows=int(cu_h[bi, nb]), mask_id=mask_id))
+                                                                  cu=cu_d[bi, :nb + 1], n_rows=int(cu_h[bi, nb]), mask_id=mask_id, **kw))
                     continue
                 batch = dp.collate_recommend_device(dstore, valid_rows[b0:b0 + nb])
                 outs.append(lm.torch_model.encode_last(batch, item_embs))   # last-position encodings, [b, d]

@@ -898,14 +898,16 @@ class TransformerTorchBackbone(nn.Module):
 
     def encode_last_packed(self, offsets: torch.Tensor, items: torch.Tensor, rows: torch.Tensor, window: int,
                            item_embs: tp.Optional[torch.Tensor] = None, cu: tp.Optional[torch.Tensor] = None,
-                           n_rows: tp.Optional[int] = None, mask_id: tp.Optional[int] = None) -> torch.Tensor:
+                           n_rows: tp.Optional[int] = None, mask_id: tp.Optional[int] = None,
+                           ts_store: tp.Optional[torch.Tensor] = None, ts_ctx: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
         """-> [B, d] = `encode_last` of the sessions `rows` of a CSR session store (`offsets`, `items`: model item ids, oldest
         first), without ever building the padded [B, L] batch: the last `window` items of every session are gathered into ONE
         packed row block (embedding + positional row by distance from the session's end, torch_backbone.py:245-246 /
         net_blocks.py:388-399 with inverse positions) and the stack runs on those rows only.  Every session must hold at least
         one item.  `cu` [B+1] / `n_rows` = cu[-1]: the packed row offsets cut by the caller on the HOST (no device round trip);
         without them they are taken from the device offsets (one synchronisation).  mask_id: the BERT4Rec batch instead — the last
-        window - 1 items and the MASK token as the last row of every session (bert4rec.py:182-193)."""
+        window - 1 items and the MASK token as the last row of every session (bert4rec.py:182-193).  ts_store / ts_ctx: the store's
+        timestamps (seconds) and the request time of every session — the packed timestamps a relative time bias reads."""
         table = self.item_model.table if item_embs is None else item_embs
         d = table.shape[1]
         B = int(rows.numel())
@@ -925,8 +927,11 @@ class TransformerTorchBackbone(nn.Module):
         scale = float(d) ** 0.5 if self.pos_encoding_layer.use_scale_factor else 1.0
         x = torch.empty((Np, d), dtype=torch.float32, device=table.device)
         ops._c("rt_embed_packed_fwd", ids, dist, table, pos, float(scale), Np, d, 0.0, 0, 0, x)
+        kw = {}
+        if ts_store is not None:     # a stack with a relative time bias (HSTU): the sessions' timestamps + the request's, packed
+            kw["ts"] = ops.collate_packed_ts(offsets, ts_store, rows, cu, n_rows, ctx=ts_ctx)
         return self.transformer_layers.forward_last_packed(x, cu, B, window, self.use_key_padding_mask, rows_real=n_rows,
-                                                           causal=self.use_causal_attn)
+                                                           causal=self.use_causal_attn, **kw)
 
     def encode_packed_train(self, ids: torch.Tensor, dist: torch.Tensor, cu: torch.Tensor, B: int, window: int,
                             item_embs: tp.Optional[torch.Tensor] = None, rows_real: tp.Optional[int] = None,

@@ -1802,11 +1802,13 @@ def hstu_varlen_supported(n_heads: int, hd: int, window: int) -> bool:
     return hd in (32, 64) and window <= 2048
 
 
-def collate_packed_ts(offsets: torch.Tensor, unix_ts: torch.Tensor, idx: torch.Tensor, cu: torch.Tensor, n_rows: int) -> torch.Tensor:
-    """`rt_collate_packed_ts`: the n + 1 timestamps of every session of a packed training batch, [n_rows + B] (session b at cu[b] + b)."""
+def collate_packed_ts(offsets: torch.Tensor, unix_ts: torch.Tensor, idx: torch.Tensor, cu: torch.Tensor, n_rows: int,
+                      ctx: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`rt_collate_packed_ts`: the n + 1 timestamps of every session of a packed batch, [n_rows + B] (session b at cu[b] + b); training:
+    the session's last n + 1, recommend (`ctx` [B]): its last n items' and the request's."""
     B = int(idx.numel())
     out = torch.empty((n_rows + B,), dtype=torch.int64, device=offsets.device)
-    _c("rt_collate_packed_ts", offsets, unix_ts, idx, cu, B, n_rows + B, out)
+    _c("rt_collate_packed_ts", offsets, unix_ts, idx, cu, ctx, B, n_rows + B, out)
     return out
 
 

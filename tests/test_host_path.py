@@ -567,7 +567,8 @@ def test_recommend_session_index_equals_per_request_construction(seed):
     lookup = rng.permutation(np.r_[np.arange(1, V), -np.ones(n_ds_items - V + 1, np.int64)])   # some dataset items unknown
     i[u == 11] = int(np.flatnonzero(lookup < 0)[0])                        # user 11 only has unknown items -> cold
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a))                # noqa: E731
-    offsets, items, weights, indptr, indices = M._build_session_index(T(u), T(i), T(t), T(w), T(lookup), n_users, V)
+    offsets, items, weights, indptr, indices, t_sorted = M._build_session_index(T(u), T(i), T(t), T(w), T(lookup), n_users, V)
+    assert all(bool((t_sorted[offsets[r]:offsets[r + 1]].diff() >= 0).all()) for r in range(n_users))       # sessions are time-ordered
     for req in (rng.permutation(n_users)[:17], np.array([7, 11, 3]), np.arange(n_users)):
         # ---- the per-request construction (numpy restatement of the reference-shaped glue)
         exp_sessions, exp_w, exp_filter = [], [], []

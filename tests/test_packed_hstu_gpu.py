@@ -182,3 +182,55 @@ def test_packed_hstu_train_loop_takes_the_steps_of_the_padded_loop(monkeypatch):
     np.testing.assert_allclose(losses["1"], losses["0"], rtol=3e-4)
     for k, v in params["0"].items():
         torch.testing.assert_close(params["1"][k], v, rtol=5e-3, atol=5e-4, msg=lambda s, k=k: f"{k}: {s}")
+
+
+def test_hstu_recommend_with_context_on_the_device_path_equals_the_reference_shaped_path():
+    """HSTUModel.recommend(context=...) through the device glue (session index with timestamps, packed STU encoder, the request's time
+    as the last timestamp of every packed session) against the pandas / numpy path that mirrors the reference line by line: same users,
+    items and ranks, scores to fp32 rounding; a context that lies BEFORE a user's last interaction is not the session's last row, and
+    the call takes the reference-shaped path for it."""
+    import warnings
+
+    from rectools_amd.dataset import Dataset
+    from rectools_amd.models import HSTUModel
+
+    rng = np.random.default_rng(0)
+    n_users, n_items, n = 200, 120, 5000
+    df = pd.DataFrame({"user_id": rng.integers(0, n_users, n) * 3 + 7, "item_id": rng.integers(0, n_items, n) + 1000, "weight": 1.0,
+                       "datetime": pd.to_datetime("2022-01-01") + pd.to_timedelta(rng.integers(0, 50_000, n), unit="m")})
+    train = Dataset.construct(df[df["item_id"] < 1000 + 90])
+    full = Dataset.construct(df)
+    model = HSTUModel(n_factors=64, n_blocks=2, n_heads=2, session_max_len=16, lr=0.01, batch_size=64, epochs=1, loss="sampled_softmax",
+                      n_negatives=4, seed=1).fit(train)
+    users = rng.permutation(full.user_id_map.external_ids)[:120]
+    when = pd.to_datetime("2022-03-01") + pd.to_timedelta(rng.integers(0, 10_000, len(users)), unit="m")
+    context = pd.DataFrame({"user_id": users, "datetime": when})
+    calls = {"fast": 0}
+    orig = model._recommend_device_glue
+
+    def counting(*a, **k):
+        out = orig(*a, **k)
+        calls["fast"] += out is not None
+        return out
+
+    for kw in (dict(k=5, filter_viewed=True), dict(k=3, filter_viewed=False, items_to_recommend=np.arange(1000, 1040))):
+        model._recommend_device_glue = counting
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            fast = model.recommend(users=users, dataset=full, context=context, **kw)
+            model._recommend_device_glue = lambda *a, **k: None
+            slow = model.recommend(users=users, dataset=full, context=context, **kw)
+        model._recommend_device_glue = orig
+        assert fast[["user_id", "item_id", "rank"]].equals(slow[["user_id", "item_id", "rank"]])
+        np.testing.assert_allclose(fast["score"].values, slow["score"].values, rtol=2e-5, atol=2e-6)
+    assert calls["fast"] == 2
+    early = context.copy()
+    early.loc[0, "datetime"] = pd.to_datetime("2021-06-01")                 # before that user's history: the glue declines
+    model._recommend_device_glue = counting
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = model.recommend(users=users, dataset=full, context=early, k=4, filter_viewed=True)
+    model._recommend_device_glue = orig
+    assert calls["fast"] == 2 and len(a) > 0
+    with pytest.raises(ValueError):
+        model.recommend(users=users, dataset=full, context=context.iloc[1:], k=4, filter_viewed=True)      # no context for a target user
