@@ -501,6 +501,32 @@ def run_recommend_e2e(info, n_users=16384):
                     "are built on the device by the FIRST recommend() on it (`first_call_seconds_2048_users`, 19.8 M rows) and reused"}
 
 
+def family_recommend(info, kind: str, n_users: int = 8192):
+    """recommend() of another model family through the public API: users / wall clock of one whole call (best of 2 after a warm-up).
+    HSTU needs the request's context (one row per user: a time behind every history)."""
+    import pandas as pd
+
+    model, ds = info["model"], info["ds"]
+    users = np.asarray(ds.user_id_map.external_ids)[:n_users]
+    model.is_fitted = True
+    kw = {}
+    if kind == "hstu":
+        last = pd.to_datetime(ds.interactions.df["datetime"]).max()
+        kw["context"] = pd.DataFrame({"user_id": users, "datetime": last + pd.Timedelta(days=1)})
+    model.recommend(users=users[:1024], dataset=ds, k=10, filter_viewed=True, **kw)
+    model.recommend(users=users, dataset=ds, k=10, filter_viewed=True, **kw)
+    best = None
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reco = model.recommend(users=users, dataset=ds, k=10, filter_viewed=True, **kw)
+        el = time.perf_counter() - t0
+        best = el if best is None else min(best, el)
+    return {"value": round(len(users) / best, 1), "unit": "users/s", "users": int(len(users)), "seconds": round(best, 5), "rows": int(len(reco)),
+            "what": f"{type(model).__name__}.recommend(users, dataset, k=10, filter_viewed=True" + (", context" if kw else "") +
+                    "), public API, device path (packed encoder, two-stage exact top-k), best of 2 whole calls"}
+
+
 def load_traffic(name: str):
     """PMC-measured HBM bytes per launch (profiles/traffic.json, written from rocprofv3 --pmc passes)."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
@@ -668,6 +694,8 @@ def main():
                                                 "config": {"workload": info_f["spec"]["desc"], "global_batch": info_f["B"] * world},
                                                 "roofline": {k: roof_f[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac") if k in roof_f},
                                                 "final_loss": round(info_f["loss"], 5)}
+                    if kind_f in ("bert4rec", "hstu") and world == 1:      # the families whose recommend() takes the packed device path
+                        out["families"][kind_f]["recommend"] = family_recommend(info_f, kind_f)
                     del info_f
                     torch.cuda.empty_cache()
         out["env"] = env

@@ -80,12 +80,14 @@ int rt_topk_score(const float* users, int64_t user_stride, const int64_t* user_r
 
 
 /* ------------------------------------------------------------------------------------------------
- * K12c  Two-stage exact top-k for dot products — the regime where rt_topk_score is bound by the f32-input matrix instruction
+ * K12c  Two-stage exact top-k for dot products and cosine similarity (distance 0 / 1) — the regime where rt_topk_score is bound by the f32-input matrix instruction
  * (recommend(): thousands of users per catalog pass).  Same result contract as rt_topk_score — the ids / order / fp32 scores
  * TorchRanker.rank produces (rank_torch.py:77-223) — with the f32-input instruction spent only on candidates:
  *   1. rt_to_hm_rows: "hm image" of fp32 rows — every value x becomes the word (h << 16) | m, h = bf16 truncation of x, m = bf16
  *      truncation of x - h (|x - h - m| < 2^-15 |x|) — plus the rows' fp32 L2 norms.  Same row geometry as the source (dst_stride in
- *      32-bit words >= d); `rows` optional gather (NULL = 0..n-1).  The catalog's image is built once per ranker, the users' per call.
+ *      32-bit words >= d); `rows` optional gather (NULL = 0..n-1); normalize = 1: the image of the L2-normalised row (cosine: stage 1
+ *      ranks dot products of unit rows, stage 2 evaluates the exact cosine of the fp32 rows).  The catalog's image is built once per
+ *      ranker, the users' per call.
  *   2. rt_topk_score_two_stage: stage 1 streams the images through rt_topk_score's selection machinery (viewed filter / whitelist as
  *      there) with two v_mfma_f32_32x32x16_bf16 per four k — (h + m)(h' + m'), a quarter of the matrix-pipe time — and hands the k_cand
  *      (32 or 64) best COARSE candidates per user to stage 2, which scores them again in the exact arithmetic of rt_topk_score's 32-wide
@@ -96,15 +98,15 @@ int rt_topk_score(const float* users, int64_t user_stride, const int64_t* user_r
  *      or near-ties at the k-th place): rank those users with rt_topk_score.  users_hm [n_users, d] dense in call order; items_hm strided
  *      and offset like `items`; d % 32 == 0, k <= 16.  Workspace: rt_topk_two_stage_workspace_bytes.
  * ------------------------------------------------------------------------------------------------ */
-int rt_to_hm_rows(const float* src, int64_t src_stride, const int64_t* rows, int64_t n_rows, int32_t d, uint32_t* dst, int64_t dst_stride,
-                  float* norms, rt_stream_t stream);
+int rt_to_hm_rows(const float* src, int64_t src_stride, const int64_t* rows, int64_t n_rows, int32_t d, int32_t normalize, uint32_t* dst,
+                  int64_t dst_stride, float* norms, rt_stream_t stream);
 size_t rt_topk_two_stage_workspace_bytes(int32_t n_users, int64_t n_candidates, int32_t k, int32_t k_cand, int32_t users_per_pass);
 int rt_topk_score_two_stage(const float* users, int64_t user_stride, const int64_t* user_rows, int32_t n_users, const float* items,
                             int64_t item_stride, const uint32_t* users_hm, const uint32_t* items_hm, const float* user_norms,
                             float max_item_norm, const int64_t* whitelist, int64_t n_candidates, int64_t candidate_id_offset, int32_t d,
-                            int32_t k, int32_t k_cand, const int64_t* filt_indptr, const int32_t* filt_indices, const int32_t* filt_hash,
-                            int64_t* out_ids, float* out_scores, int32_t* out_counts, int32_t* out_unproven, void* workspace,
-                            size_t workspace_bytes, int32_t users_per_pass, rt_stream_t stream);
+                            int32_t distance, int32_t k, int32_t k_cand, const int64_t* filt_indptr, const int32_t* filt_indices,
+                            const int32_t* filt_hash, int64_t* out_ids, float* out_scores, int32_t* out_counts, int32_t* out_unproven,
+                            void* workspace, size_t workspace_bytes, int32_t users_per_pass, rt_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K7  dense fp32 GEMM (f32-input MFMA):  C[M,N] = A . B^T (+ bias[n]) (+ R[m,n]) (relu)

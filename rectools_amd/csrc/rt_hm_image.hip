@@ -25,7 +25,7 @@ __device__ __forceinline__ unsigned hm_word(float x) {
 
 // one wave per row; a lane owns float4 columns lane*4 + 256*t (d <= 2048)
 __global__ __launch_bounds__(256) void to_hm_rows_kernel(const float* __restrict__ src, long long src_stride,
-                                                         const long long* __restrict__ rows, long long n_rows, int d,
+                                                         const long long* __restrict__ rows, long long n_rows, int d, int normalize,
                                                          unsigned* __restrict__ dst, long long dst_stride, float* __restrict__ norms) {
   const int lane = threadIdx.x & 63;
   const long long r = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -33,35 +33,42 @@ __global__ __launch_bounds__(256) void to_hm_rows_kernel(const float* __restrict
   const long long sr = rows ? rows[r] : r;
   const float* x = src + sr * src_stride;
   float ss = 0.f;
+  f32x4 v[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int c = lane * 4 + 256 * t;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    v[t] = c < d ? *reinterpret_cast<const f32x4*>(x + c) : z;
+    ss += v[t][0] * v[t][0] + v[t][1] * v[t][1] + v[t][2] * v[t][2] + v[t][3] * v[t][3];
+  }
+  const float nrm = sqrtf(wave_sum_f(ss));
+  if (norms != nullptr && lane == 0) norms[r] = nrm;
+  const float sc = normalize ? 1.0f / fmaxf(nrm, 1e-8f) : 1.0f;      // cosine: the image of the unit row (the exact pass divides as rt_topk_score does)
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     const int c = lane * 4 + 256 * t;
     if (c < d) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(x + c);
-      ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
       u32x4 w;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) w[j] = hm_word(v[j]);
+      for (int j = 0; j < 4; ++j) w[j] = hm_word(v[t][j] * sc);
       *reinterpret_cast<u32x4*>(dst + r * dst_stride + c) = w;
     }
   }
-  const float nrm = sqrtf(wave_sum_f(ss));
-  if (norms != nullptr && lane == 0) norms[r] = nrm;
 }
 
 }  // namespace
 
 extern "C" {
 
-int rt_to_hm_rows(const float* src, int64_t src_stride, const int64_t* rows, int64_t n_rows, int32_t d, uint32_t* dst, int64_t dst_stride,
-                  float* norms, hipStream_t stream) {
+int rt_to_hm_rows(const float* src, int64_t src_stride, const int64_t* rows, int64_t n_rows, int32_t d, int32_t normalize, uint32_t* dst,
+                  int64_t dst_stride, float* norms, hipStream_t stream) {
   (void)hipGetLastError();
   if (n_rows <= 0) return RT_OK;
   if (src == nullptr || dst == nullptr || d <= 0 || (d & 3) != 0 || d > 2048 || (src_stride & 3) != 0 || (dst_stride & 3) != 0 ||
       dst_stride < d || ((uintptr_t)src & 15) != 0 || ((uintptr_t)dst & 15) != 0 || n_rows > 0x7FFFFFFFLL * 4)
     return RT_ERR_INVALID_ARG;
   to_hm_rows_kernel<<<(unsigned)((n_rows + 3) / 4), 256, 0, stream>>>(src, src_stride, reinterpret_cast<const long long*>(rows), n_rows, d,
-                                                                      dst, dst_stride, norms);
+                                                                      normalize, dst, dst_stride, norms);
   RT_CHECK_LAUNCH();
   return RT_OK;
 }

@@ -67,6 +67,12 @@ struct TopkArgs {
   int bloom;                     // engine 2: 1 = a 1024-bit Bloom filter per user of the tile sits in LDS behind the lists
 };
 
+// acc + |v|^2 as one fixed fma chain: engine 2 and the two-stage exact pass (topk_replay_kernel) must round a row norm alike
+__device__ __forceinline__ float sumsq4(float acc, const f32x4& v) {
+  acc = __builtin_fmaf(v[0], v[0], acc); acc = __builtin_fmaf(v[1], v[1], acc);
+  acc = __builtin_fmaf(v[2], v[2], acc); return __builtin_fmaf(v[3], v[3], acc);
+}
+
 __device__ __forceinline__ bool better(float s, long long p, float s2, long long p2) {
   return (s > s2) || (s == s2 && p < p2);
 }
@@ -751,7 +757,7 @@ __global__ __launch_bounds__(NTHREADS + NLD * 64) void topk_stream_kernel(TopkAr
           for (int t = 0; t < 4; ++t) x[t] = __builtin_amdgcn_alignbit(w[t], w[t], 16);   // (h, m) -> (m, h)
           a_hm = __builtin_bit_cast(bf16x8, w); a_mh = __builtin_bit_cast(bf16x8, x);
         } else {
-          nrm_i += av[0] * av[0] + av[1] * av[1] + av[2] * av[2] + av[3] * av[3];
+          nrm_i = sumsq4(nrm_i, av);
         }
 #pragma unroll
         for (int tu = 0; tu < TU; ++tu) {
@@ -763,7 +769,7 @@ __global__ __launch_bounds__(NTHREADS + NLD * 64) void topk_stream_kernel(TopkAr
             acc[tu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mh, b8, acc[tu], 0, 0, 0);   // h m' + m h'
             acc[tu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hm, b8, acc[tu], 0, 0, 0);   // h h' + m m'
           } else {
-            nrm_u[tu] += bv[0] * bv[0] + bv[1] * bv[1] + bv[2] * bv[2] + bv[3] * bv[3];
+            nrm_u[tu] = sumsq4(nrm_u[tu], bv);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
               acc[tu] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc[tu], 0, 0, 0);
@@ -1384,7 +1390,7 @@ __global__ void fill_u32_kernel(unsigned* p, unsigned v, long long n) {
 struct ReplayArgs {
   const float* users; long long user_stride; const long long* user_rows;
   const float* items; long long item_stride; const long long* whitelist; long long id_offset;
-  int d, k, kc, rotate;
+  int d, k, kc, rotate, cosine;
   const int* cand_pos; const float* cand_coarse; const int* cand_counts;   // [n_users][kc], best coarse first
   const unsigned* gthr; const float* user_norms; float max_item_norm, err_coef;
   long long* out_ids; float* out_scores; int* out_counts; int* out_unproven;
@@ -1409,6 +1415,7 @@ __global__ __launch_bounds__(64 * NW) void topk_replay_kernel(ReplayArgs r) {
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float nrm_i = 0.f, nrm_u = 0.f;      // cosine: the row norms as engine 2 accumulates them (this lane's half of the k positions, chunk order)
   if (wave * 32 < cnt) {
 #pragma unroll 1
     for (int c = 0; c < n_chunks; ++c) {
@@ -1420,17 +1427,24 @@ __global__ __launch_bounds__(64 * NW) void topk_replay_kernel(ReplayArgs r) {
         bv[s] = *reinterpret_cast<const f32x4*>(up + cc * KC + (2 * s + half) * 4);
       }
 #pragma unroll
-      for (int s = 0; s < KC / 8; ++s)
+      for (int s = 0; s < KC / 8; ++s) {
+        nrm_i = sumsq4(nrm_i, av[s]); nrm_u = sumsq4(nrm_u, bv[s]);
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][t], bv[s][t], acc, 0, 0, 0);
+      }
     }
   }
+  const float ni_full = nrm_i + __shfl_xor(nrm_i, 32, 64), nu_full = nrm_u + __shfl_xor(nrm_u, 32, 64);   // as select_block
   // the diagonal: element (i, i) sits in the lane with column i and half (i >> 2) & 1, register (i & 3) + 4 (i >> 3)
   if (half == ((col >> 2) & 1)) {
     const int rr = (col & 3) + 4 * (col >> 3);
     float sc = acc[0];
 #pragma unroll
     for (int i = 1; i < 16; ++i) sc = (rr == i) ? acc[i] : sc;
+    if (r.cosine) {                       // select_block's expression, term for term
+      const float inv_u = 1.0f / fmaxf(sqrtf(nu_full), 1e-8f);
+      sc = sc * inv_u * (1.0f / fmaxf(sqrtf(ni_full), 1e-8f));
+    }
     s_sc[ci] = cv ? sc : -INFINITY;
     s_pos[ci] = cv ? pos : 0x7fffffff;
   }
@@ -1455,7 +1469,8 @@ __global__ __launch_bounds__(64 * NW) void topk_replay_kernel(ReplayArgs r) {
     r.out_counts[u] = n_out;
     float tau = key_to_f32(r.gthr[u]);
     if (cnt == r.kc) tau = fmaxf(tau, r.cand_coarse[(long long)u * r.kc + r.kc - 1]);
-    const float eps = r.err_coef * r.user_norms[u] * r.max_item_norm;
+    // cosine: the coarse pass scored unit rows (|u| = |v| = 1 up to the 2 ulp of the normalisation, 2^-22 on the dot product)
+    const float eps = r.cosine ? r.err_coef + 3e-7f : r.err_coef * r.user_norms[u] * r.max_item_norm;
     const bool proven = (tau == -INFINITY) || (cnt >= r.k && ek - eps > tau);
     r.out_unproven[u] = proven ? 0 : 1;
   }
@@ -1726,6 +1741,7 @@ struct TwoStage {
   const float* users_hm; const float* items_hm;     // images: users dense [n_users, d] (row u = user u of the call), items strided like `items`
   const float* user_norms; float max_item_norm;
   int k_cand; int* out_unproven;
+  int cosine;      // the images hold L2-normalised rows: stage 1 ranks their dot products, stage 2 the exact cosine of the fp32 rows
 };
 // list capacity of the coarse pass: a pair is dropped when it falls below its list's worst kept entry, and the proof needs that bound to
 // stay below the k-th exact score — k entries per list would put the bound AT the best score for k = 1 and leave no room when one list
@@ -1745,7 +1761,7 @@ static int topk_score_impl(const float* users, int64_t user_stride, const int64_
   (void)hipGetLastError();  // do not inherit a stale error from the caller's earlier HIP calls
   if (n_users < 0 || n_candidates < 0 || d <= 0 || (d & 3) != 0 || k <= 0) return RT_ERR_INVALID_ARG;
   if (distance < DIST_DOT || distance > DIST_EUCLID) return RT_ERR_INVALID_ARG;
-  if (ts != nullptr && (distance != DIST_DOT || d % KC != 0 || k > K_LDS_LISTS || (ts->k_cand != 32 && ts->k_cand != 64) || ts->k_cand < k))
+  if (ts != nullptr && ((distance != DIST_DOT && distance != DIST_COSINE) || d % KC != 0 || k > K_LDS_LISTS || (ts->k_cand != 32 && ts->k_cand != 64) || ts->k_cand < k))
     return RT_ERR_UNSUPPORTED;
   if ((user_stride & 3) != 0 || (item_stride & 3) != 0) return RT_ERR_INVALID_ARG;
   if (((uintptr_t)users & 15) != 0 || ((uintptr_t)items & 15) != 0) return RT_ERR_INVALID_ARG;
@@ -1837,7 +1853,7 @@ static int topk_score_impl(const float* users, int64_t user_stride, const int64_
     }
     a.whitelist = reinterpret_cast<const long long*>(whitelist);
     a.n_cand = n_candidates; a.id_offset = whitelist ? 0 : candidate_id_offset;
-    a.d = d; a.distance = distance; a.k = k;
+    a.d = d; a.distance = ts != nullptr ? DIST_DOT : distance; a.k = k;     // (two-stage: the coarse pass ranks dot products of the images)
     a.filt_indptr = filt_indptr ? reinterpret_cast<const long long*>(filt_indptr) + u0 : nullptr;
     a.filt_indices = filt_indices;
     a.filt_hash = filt_indptr ? filt_hash : nullptr; a.filt_u0 = u0;
@@ -1886,7 +1902,7 @@ static int topk_score_impl(const float* users, int64_t user_stride, const int64_
     m.compact_scores = reinterpret_cast<float*>(ws + P.o_cscores);
     m.compact_pos = reinterpret_cast<int*>(ws + P.o_cpos);
     m.compact_cap = (long long)P.n_lists * k;
-    m.whitelist = a.whitelist; m.id_offset = a.id_offset; m.distance = distance;
+    m.whitelist = a.whitelist; m.id_offset = a.id_offset; m.distance = a.distance;
     m.out_ids = reinterpret_cast<long long*>(out_ids) + (long long)u0 * k;
     m.out_scores = out_scores + (long long)u0 * k;
     m.out_counts = out_counts + u0;
@@ -1906,7 +1922,7 @@ static int topk_score_impl(const float* users, int64_t user_stride, const int64_
       r.users = user_rows ? users : users + (long long)u0 * user_stride; r.user_stride = user_stride;
       r.user_rows = user_rows ? reinterpret_cast<const long long*>(user_rows) + u0 : nullptr;
       r.items = items; r.item_stride = item_stride; r.whitelist = a.whitelist; r.id_offset = a.id_offset;
-      r.d = d; r.k = k_out; r.kc = ts->k_cand; r.rotate = a.rotate;
+      r.d = d; r.k = k_out; r.kc = ts->k_cand; r.rotate = a.rotate; r.cosine = ts->cosine;
       r.gthr = a.gthr; r.user_norms = ts->user_norms + u0; r.max_item_norm = ts->max_item_norm;
       // |coarse - exact| <= (2^-14 [the dropped l parts] + 4 d 2^-24 [fp32 accumulation of the 4 d bf16 products]
       //                      + d 2^-24 [the exact chain's own rounding]) sum_k |u_k v_k|, with 3 % slack (norms are fp32 too)
@@ -1938,7 +1954,9 @@ size_t rt_topk_two_stage_workspace_bytes(int32_t n_users, int64_t n_candidates, 
   return P.total + two_stage_extra_bytes(P.users_per_launch, k_cand);
 }
 
-// Two-stage exact top-k for dot products (the MFMA-bound regime: many users per catalog pass).  Stage 1 = the streaming selection of
+// Two-stage exact top-k for dot products and cosine similarity (the MFMA-bound regime: many users per catalog pass).  Cosine: the images
+// hold L2-NORMALISED rows (rt_to_hm_rows normalize = 1), stage 1 ranks their dot products, stage 2 evaluates rt_topk_score's cosine
+// expression on the fp32 rows with the row norms accumulated as engine 2 accumulates them.  Stage 1 = the streaming selection of
 // rt_topk_score over hm images (rt_to_hm_rows; two bf16 matrix instructions per four k instead of four f32-input ones), keeping the
 // k_cand (32 or 64) best COARSE candidates per user; stage 2 = their exact scores in the arithmetic of rt_topk_score's 32-wide engine,
 // ordered (score desc, position asc).  out_unproven[u] = 0: the k results of user u are exactly rt_topk_score's (ids, order, score
@@ -1948,19 +1966,20 @@ size_t rt_topk_two_stage_workspace_bytes(int32_t n_users, int64_t n_candidates, 
 int rt_topk_score_two_stage(const float* users, int64_t user_stride, const int64_t* user_rows, int32_t n_users, const float* items,
                             int64_t item_stride, const uint32_t* users_hm, const uint32_t* items_hm, const float* user_norms,
                             float max_item_norm, const int64_t* whitelist, int64_t n_candidates, int64_t candidate_id_offset, int32_t d,
-                            int32_t k, int32_t k_cand, const int64_t* filt_indptr, const int32_t* filt_indices, const int32_t* filt_hash,
-                            int64_t* out_ids, float* out_scores, int32_t* out_counts, int32_t* out_unproven, void* workspace,
-                            size_t workspace_bytes, int32_t users_per_pass, hipStream_t stream) {
+                            int32_t distance, int32_t k, int32_t k_cand, const int64_t* filt_indptr, const int32_t* filt_indices,
+                            const int32_t* filt_hash, int64_t* out_ids, float* out_scores, int32_t* out_counts, int32_t* out_unproven,
+                            void* workspace, size_t workspace_bytes, int32_t users_per_pass, hipStream_t stream) {
   if (users_hm == nullptr || items_hm == nullptr || user_norms == nullptr || out_unproven == nullptr || !(max_item_norm >= 0.f) ||
       ((uintptr_t)users_hm & 15) != 0 || ((uintptr_t)items_hm & 15) != 0)
     return RT_ERR_INVALID_ARG;
+  if (distance != DIST_DOT && distance != DIST_COSINE) return RT_ERR_UNSUPPORTED;
   if (n_users > 0 && n_candidates == 0) {
     if (hipMemsetAsync(out_unproven, 0, sizeof(int32_t) * (size_t)n_users, stream) != hipSuccess) return RT_ERR_LAUNCH;
   }
   TwoStage ts{reinterpret_cast<const float*>(users_hm), reinterpret_cast<const float*>(items_hm), user_norms, max_item_norm, k_cand,
-              out_unproven};
+              out_unproven, distance == DIST_COSINE ? 1 : 0};
   return topk_score_impl(users, user_stride, user_rows, n_users, items, item_stride, whitelist, n_candidates, candidate_id_offset, d,
-                         DIST_DOT, k, filt_indptr, filt_indices, filt_hash, out_ids, out_scores, out_counts, workspace, workspace_bytes,
+                         distance, k, filt_indptr, filt_indices, filt_hash, out_ids, out_scores, out_counts, workspace, workspace_bytes,
                          users_per_pass, &ts, stream);
 }
 

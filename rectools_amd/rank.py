@@ -152,7 +152,8 @@ class HipRanker:
 
     def _two_stage_applies(self, kk: int, n_cand: int, n_subj: int) -> bool:
         d = self.objects_factors.shape[1]
-        if self.two_stage is False or self.distance != Distance.DOT or d % 32 != 0 or d > 2048 or kk > 16 or n_cand < 8 * self.CANDIDATES:
+        if self.two_stage is False or self.distance not in (Distance.DOT, Distance.COSINE) or d % 32 != 0 or d > 2048 or kk > 16 \
+                or n_cand < 8 * self.CANDIDATES:
             return False
         return True if self.two_stage else n_subj >= int(os.environ.get("RT_TOPK_TWO_STAGE_MIN_USERS", self.TWO_STAGE_MIN_USERS))
 
@@ -160,8 +161,8 @@ class HipRanker:
         d = src.shape[1]
         img = torch.empty((n_rows, d), dtype=torch.int32, device=self.device)
         norms = torch.empty((n_rows,), dtype=torch.float32, device=self.device)
-        status = self._lib.rt_to_hm_rows(_lib.ptr(src), src.stride(0), _lib.ptr(rows), n_rows, d, _lib.ptr(img), d, _lib.ptr(norms),
-                                         _lib.current_stream())
+        status = self._lib.rt_to_hm_rows(_lib.ptr(src), src.stride(0), _lib.ptr(rows), n_rows, d, 1 if self.distance == Distance.COSINE else 0,
+                                         _lib.ptr(img), d, _lib.ptr(norms), _lib.current_stream())
         _lib.check(status, "rt_to_hm_rows")
         return img, norms
 
@@ -207,7 +208,8 @@ class HipRanker:
             status = self._lib.rt_topk_score_two_stage(
                 _lib.ptr(S), S.stride(0), _lib.ptr(rows_t), n_subj, O.data_ptr() + 4 * id_offset * O.stride(0), O.stride(0),
                 _lib.ptr(users_hm), self._items_hm.data_ptr() + 4 * id_offset * d, _lib.ptr(user_norms), self._max_item_norm,
-                _lib.ptr(whitelist_t), n_cand, id_offset, d, kk, kc, _lib.ptr(indptr_t), _lib.ptr(indices_t), _lib.ptr(hash_t),
+                _lib.ptr(whitelist_t), n_cand, id_offset, d, _DIST_CODE[self.distance], kk, kc, _lib.ptr(indptr_t), _lib.ptr(indices_t),
+                _lib.ptr(hash_t),
                 _lib.ptr(ids_t), _lib.ptr(scores_t), _lib.ptr(counts_t), _lib.ptr(unproven), _lib.ptr(self._workspace),
                 self._workspace.numel(), upp2, _lib.current_stream())
             _lib.check(status, "rt_topk_score_two_stage")

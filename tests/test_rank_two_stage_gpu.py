@@ -28,8 +28,9 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("dist", ["dot", "cosine"])
 @pytest.mark.parametrize("d,n_obj,n_subj,batch,k,with_filter,wl_kind", CASES)
-def test_two_stage_returns_the_single_stage_result_bit_for_bit(d, n_obj, n_subj, batch, k, with_filter, wl_kind):
+def test_two_stage_returns_the_single_stage_result_bit_for_bit(d, n_obj, n_subj, batch, k, with_filter, wl_kind, dist):
     from rectools_amd.rank import HipRanker
 
     subj, obj = _factors(n_subj, n_obj, d, seed=n_obj % 97)
@@ -43,8 +44,8 @@ def test_two_stage_returns_the_single_stage_result_bit_for_bit(d, n_obj, n_subj,
         wl = np.sort(rng.permutation(n_obj)[: n_obj // 2])
     elif wl_kind == "range":
         wl = np.arange(1000, n_obj - 500)
-    exact = HipRanker("dot", "cuda", subj, obj, batch_size=batch if batch else 64, two_stage=False)
-    fast = HipRanker("dot", "cuda", subj, obj, batch_size=batch, two_stage=True)
+    exact = HipRanker(dist, "cuda", subj, obj, batch_size=batch if batch else 64, two_stage=False)
+    fast = HipRanker(dist, "cuda", subj, obj, batch_size=batch, two_stage=True)
     e_ids, e_sc, e_cnt, _ = exact.rank_device(ids, k, filt, wl)
     f_ids, f_sc, f_cnt, _ = fast.rank_device(ids, k, filt, wl)
     assert fast.two_stage_stats["calls"] == 1 and fast.two_stage_stats["unproven_users"] == 0, fast.two_stage_stats
@@ -53,11 +54,11 @@ def test_two_stage_returns_the_single_stage_result_bit_for_bit(d, n_obj, n_subj,
     assert torch.equal(e_ids[valid], f_ids[valid])
     assert torch.equal(f_sc[valid].view(torch.int32), e_sc[valid].view(torch.int32))          # the same bits
     s_o, i_o, sc_o = ranker_oracle.rank(subj, obj, ids[:5], k=k, filter_pairs_csr=None if filt is None else filt[:5],
-                                        sorted_object_whitelist=wl, distance="dot")
+                                        sorted_object_whitelist=wl, distance=dist)
     assert f_ids[:5][valid[:5]].cpu().numpy().tolist() == np.asarray(i_o).tolist()              # and the CPU oracle's order
 
 
-def test_two_stage_is_the_default_for_many_users_and_dot_products_only():
+def test_two_stage_is_the_default_for_many_users_with_dot_and_cosine():
     from rectools_amd.rank import HipRanker
 
     subj, obj = _factors(300, 20_000, 64, 3)
@@ -66,9 +67,12 @@ def test_two_stage_is_the_default_for_many_users_and_dot_products_only():
     assert r.two_stage_stats["calls"] == 1
     r.rank_device(np.arange(40), 10)                        # few users: the HBM-bound single-stage engines
     assert r.two_stage_stats["calls"] == 1
-    c = HipRanker("cosine", "cuda", subj, obj, two_stage=True)
+    c = HipRanker("cosine", "cuda", subj, obj)
     c.rank_device(np.arange(300), 10)
-    assert c.two_stage_stats["calls"] == 0
+    assert c.two_stage_stats["calls"] == 1                  # cosine too (unit-row images, exact cosine in the second stage)
+    e = HipRanker("euclidean", "cuda", subj, obj, two_stage=True)
+    e.rank_device(np.arange(300), 10)
+    assert e.two_stage_stats["calls"] == 0
 
 
 def test_users_whose_result_cannot_be_proven_are_ranked_by_the_single_stage_kernel():
@@ -115,7 +119,7 @@ def test_hm_image_kernel():
     rows = torch.randperm(300)[:77].cuda()
     img = torch.empty(77, 192, dtype=torch.int32, device="cuda")
     norms = torch.empty(77, device="cuda")
-    _lib.check(lib.rt_to_hm_rows(x.data_ptr(), x.stride(0), rows.data_ptr(), 77, 192, img.data_ptr(), 192, norms.data_ptr(),
+    _lib.check(lib.rt_to_hm_rows(x.data_ptr(), x.stride(0), rows.data_ptr(), 77, 192, 0, img.data_ptr(), 192, norms.data_ptr(),
                                  _lib.current_stream()), "rt_to_hm_rows")
     src = x[rows]
     h = (img & -65536).view(torch.float32)
@@ -125,6 +129,11 @@ def test_hm_image_kernel():
     assert torch.equal(m, (r.view(torch.int32) & -65536).view(torch.float32))
     assert bool(((src - h - m).abs() <= src.abs() * 2.0 ** -15).all())
     torch.testing.assert_close(norms, src.double().norm(dim=1).float(), rtol=1e-5, atol=0)
+    unit = torch.empty_like(img)                             # normalize = 1: the image of the unit rows
+    _lib.check(lib.rt_to_hm_rows(x.data_ptr(), x.stride(0), rows.data_ptr(), 77, 192, 1, unit.data_ptr(), 192, norms.data_ptr(),
+                                 _lib.current_stream()), "rt_to_hm_rows")
+    uh, um = (unit & -65536).view(torch.float32), (unit << 16).view(torch.float32)
+    torch.testing.assert_close((uh + um).double().norm(dim=1), torch.ones(77, dtype=torch.float64, device="cuda"), rtol=1e-4, atol=0)
 
 
 def test_two_stage_with_fewer_than_k_candidates_left_by_the_filter():
