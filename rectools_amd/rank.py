@@ -148,7 +148,8 @@ class HipRanker:
 
     # ---- two-stage top-k ---------------------------------------------------------------------------------
     CANDIDATES = 64           # k_cand: coarse candidates handed to the exact pass per user
-    TWO_STAGE_MIN_USERS = 128  # below this the single-stage engines are bound by HBM, not by the matrix pipe: nothing to win
+    TWO_STAGE_MIN_USERS = 17   # up to 16 users the 16-user tile of the single-stage kernel streams the catalog at the HBM roofline; from 17 up
+    #                            the matrix pipe binds and the coarse pass wins (5 M x 512: 32 users 2.36 vs 2.77 ms, 64 users 2.60 vs 4.08 ms)
 
     def _two_stage_applies(self, kk: int, n_cand: int, n_subj: int) -> bool:
         d = self.objects_factors.shape[1]

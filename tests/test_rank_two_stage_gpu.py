@@ -65,7 +65,7 @@ def test_two_stage_is_the_default_for_many_users_with_dot_and_cosine():
     r = HipRanker("dot", "cuda", subj, obj)
     r.rank_device(np.arange(300), 10)
     assert r.two_stage_stats["calls"] == 1
-    r.rank_device(np.arange(40), 10)                        # few users: the HBM-bound single-stage engines
+    r.rank_device(np.arange(12), 10)                        # few users: the HBM-bound 16-user tile of the single-stage kernel
     assert r.two_stage_stats["calls"] == 1
     c = HipRanker("cosine", "cuda", subj, obj)
     c.rank_device(np.arange(300), 10)
