@@ -219,6 +219,12 @@ def run_topk(steps, warmup, rank, world, n_items, d, users_per_step, upp, with_f
     gbs = bytes_per_launch / t / 1e9
     tfs = flops_per_launch / t / 1e12
     two_stage = ranker.two_stage_stats["calls"] > 0
+    h_only = ranker.two_stage_stats.get("h_only_calls", 0) > 0
+    if h_only:
+        # the coarse pass streams a one-plane bf16 image of the catalog: the bytes this formulation has to move per launch are the image's
+        # (2 B per value) + the users + the outputs; the fp32 rows are touched for 64 candidates per user only
+        bytes_per_launch = 2.0 * d * n_items + 4.0 * d * users_per_step + 12.0 * users_per_step * 10 + 4.0 * d * 64 * users_per_step
+        gbs = bytes_per_launch / t / 1e9
     # two-stage calls (rt_topk_score_two_stage) score on the bf16 matrix pipe: (h + m)(h' + m') = four bf16 products per fp32 product,
     # so the pipe's roof for ALGORITHMIC fp32 flops is 2,500 / 4 TF; single-stage calls run the f32-input instruction (157.3 TF)
     mfma_peak = MFMA_BF16_PEAK_TF / 4.0 if two_stage else MFMA_F32_PEAK_TF
@@ -226,8 +232,9 @@ def run_topk(steps, warmup, rank, world, n_items, d, users_per_step, upp, with_f
     if n_items * d * 4 <= 200e6:
         hbm_bound = False  # catalog resident in L2 / Infinity Cache: the HBM roof does not apply
     roof = {
-        "kernel": ("rt_topk_score_two_stage call (users' hm image + coarse stream kernel on v_mfma_f32_32x32x16_bf16 + merge + exact pass "
-                   "over 64 candidates per user + the read of the proof flags; HIP events around the whole call)") if two_stage else
+        "kernel": ("rt_topk_score_two_stage call (users' image + coarse stream kernel on v_mfma_f32_32x32x16_bf16" +
+                   (" over the ONE-plane bf16 image of the catalog (half the fp32 bytes; exactness from the exact pass + per-user proof)" if h_only else "") +
+                   " + merge + exact pass over 64 candidates per user + the read of the proof flags; HIP events around the whole call)") if two_stage else
                   "rt_topk_score call (seed prefix + topk stream kernel + merge; HIP events around the whole call)",
         "bound": "hbm" if hbm_bound else "mfma",
         "achieved": round(gbs if hbm_bound else tfs, 2),
@@ -235,6 +242,7 @@ def run_topk(steps, warmup, rank, world, n_items, d, users_per_step, upp, with_f
         "unit": "GB/s" if hbm_bound else "TFLOP/s",
         "frac": round((gbs / HBM_PEAK_GBS) if hbm_bound else (tfs / mfma_peak), 4),
         "two_stage": dict(ranker.two_stage_stats) if two_stage else None,
+        "fp32_catalog_equivalent_GBps": round(topk_bytes(n_items, d, users_per_step, 10, info["nnz"]) / t / 1e9, 1) if h_only else None,
         "traffic": load_traffic(name),
         "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_flops_per_launch": flops_per_launch,
         "avg_launch_ms": round(ev_ms, 4), "hbm_GBps": round(gbs, 1), "mfma_f32_TFLOPs": round(tfs, 2),

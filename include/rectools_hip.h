@@ -87,7 +87,9 @@ int rt_topk_score(const float* users, int64_t user_stride, const int64_t* user_r
  *      truncation of x - h (|x - h - m| < 2^-15 |x|) — plus the rows' fp32 L2 norms.  Same row geometry as the source (dst_stride in
  *      32-bit words >= d); `rows` optional gather (NULL = 0..n-1); normalize = 1: the image of the L2-normalised row (cosine: stage 1
  *      ranks dot products of unit rows, stage 2 evaluates the exact cosine of the fp32 rows).  The catalog's image is built once per
- *      ranker, the users' per call.
+ *      ranker, the users' per call.  normalize bit 1 (values 2 / 3): the H-ONLY image — one round-to-nearest bf16 per value, rows of d / 2
+ *      words (dst_stride >= d / 2): half the bytes, for passes bound by HBM (h_only = 1 in rt_topk_score_two_stage: coarse error
+ *      2^-8 |u| |v|, items_hm rows item_stride / 2 words apart, d % 64 == 0).
  *   2. rt_topk_score_two_stage: stage 1 streams the images through rt_topk_score's selection machinery (viewed filter / whitelist as
  *      there) with two v_mfma_f32_32x32x16_bf16 per four k — (h + m)(h' + m'), a quarter of the matrix-pipe time — and hands the k_cand
  *      (32 or 64) best COARSE candidates per user to stage 2, which scores them again in the exact arithmetic of rt_topk_score's 32-wide
@@ -102,7 +104,7 @@ int rt_to_hm_rows(const float* src, int64_t src_stride, const int64_t* rows, int
                   int64_t dst_stride, float* norms, rt_stream_t stream);
 size_t rt_topk_two_stage_workspace_bytes(int32_t n_users, int64_t n_candidates, int32_t k, int32_t k_cand, int32_t users_per_pass);
 int rt_topk_score_two_stage(const float* users, int64_t user_stride, const int64_t* user_rows, int32_t n_users, const float* items,
-                            int64_t item_stride, const uint32_t* users_hm, const uint32_t* items_hm, const float* user_norms,
+                            int64_t item_stride, const uint32_t* users_hm, const uint32_t* items_hm, int32_t h_only, const float* user_norms,
                             float max_item_norm, const int64_t* whitelist, int64_t n_candidates, int64_t candidate_id_offset, int32_t d,
                             int32_t distance, int32_t k, int32_t k_cand, const int64_t* filt_indptr, const int32_t* filt_indices,
                             const int32_t* filt_hash, int64_t* out_ids, float* out_scores, int32_t* out_counts, int32_t* out_unproven,

@@ -43,15 +43,23 @@ __global__ __launch_bounds__(256) void to_hm_rows_kernel(const float* __restrict
   }
   const float nrm = sqrtf(wave_sum_f(ss));
   if (norms != nullptr && lane == 0) norms[r] = nrm;
-  const float sc = normalize ? 1.0f / fmaxf(nrm, 1e-8f) : 1.0f;      // cosine: the image of the unit row (the exact pass divides as rt_topk_score does)
+  const float sc = (normalize & 1) ? 1.0f / fmaxf(nrm, 1e-8f) : 1.0f;      // cosine: the image of the unit row (the exact pass divides as rt_topk_score does)
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     const int c = lane * 4 + 256 * t;
     if (c < d) {
-      u32x4 w;
+      if (normalize & 2) {      // h-only image: one round-to-nearest bf16 per value, rows of d / 2 words
+        unsigned short o[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) w[j] = hm_word(v[t][j] * sc);
-      *reinterpret_cast<u32x4*>(dst + r * dst_stride + c) = w;
+        for (int j = 0; j < 4; ++j) o[j] = __builtin_bit_cast(unsigned short, (__bf16)(v[t][j] * sc));
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u32x2*>(dst + r * dst_stride + c / 2) = u32x2{(unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16)};
+      } else {
+        u32x4 w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = hm_word(v[t][j] * sc);
+        *reinterpret_cast<u32x4*>(dst + r * dst_stride + c) = w;
+      }
     }
   }
 }
@@ -65,7 +73,7 @@ int rt_to_hm_rows(const float* src, int64_t src_stride, const int64_t* rows, int
   (void)hipGetLastError();
   if (n_rows <= 0) return RT_OK;
   if (src == nullptr || dst == nullptr || d <= 0 || (d & 3) != 0 || d > 2048 || (src_stride & 3) != 0 || (dst_stride & 3) != 0 ||
-      dst_stride < d || ((uintptr_t)src & 15) != 0 || ((uintptr_t)dst & 15) != 0 || n_rows > 0x7FFFFFFFLL * 4)
+      dst_stride < ((normalize & 2) ? d / 2 : d) || ((uintptr_t)src & 15) != 0 || ((uintptr_t)dst & 15) != 0 || n_rows > 0x7FFFFFFFLL * 4)
     return RT_ERR_INVALID_ARG;
   to_hm_rows_kernel<<<(unsigned)((n_rows + 3) / 4), 256, 0, stream>>>(src, src_stride, reinterpret_cast<const long long*>(rows), n_rows, d,
                                                                       normalize, dst, dst_stride, norms);

@@ -65,6 +65,7 @@ struct TopkArgs {
   int n_lists_total;             //   merged lists are stored [user][list][k] (a user's lists are contiguous for the selection)
   int use_bound;                 // 16-user tile: 0 = seeding prefix (the shared bound is neither read nor published)
   int bloom;                     // engine 2: 1 = a 1024-bit Bloom filter per user of the tile sits in LDS behind the lists
+  int h_only;                    // HM kernels: 1 = the images hold ONE bf16 (round-to-nearest) per value (rows of d / 2 words): one MFMA per slot
 };
 
 // acc + |v|^2 as one fixed fma chain: engine 2 and the two-stage exact pass (topk_replay_kernel) must round a row norm alike
@@ -766,8 +767,8 @@ __global__ __launch_bounds__(NTHREADS + NLD * 64) void topk_stream_kernel(TopkAr
             // both operands take their four (m, h) pairs from the same 16-byte slot, so the k positions pair up whatever the
             // instruction's own numbering of them is (the sum over k is order-free)
             const bf16x8 b8 = __builtin_bit_cast(bf16x8, bv);
-            acc[tu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mh, b8, acc[tu], 0, 0, 0);   // h m' + m h'
-            acc[tu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hm, b8, acc[tu], 0, 0, 0);   // h h' + m m'
+            if (!a.h_only) acc[tu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mh, b8, acc[tu], 0, 0, 0);   // h m' + m h'
+            acc[tu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hm, b8, acc[tu], 0, 0, 0);   // h h' + m m'  (h-only image: eight k per slot)
           } else {
             nrm_u[tu] = sumsq4(nrm_u[tu], bv);
 #pragma unroll
@@ -803,6 +804,47 @@ struct MergeArgs {
   int out_k;          // entries extracted per user (0 = k).  The two-stage coarse pass takes k_cand >= k of them ...
   int* out_pos;       // ... as candidate POSITIONS [n_users][out_k] (the exact pass needs them) instead of ids
 };
+
+// Block-wide radix select: the ordered key (f32_to_key) of the `need`-th largest of the scores `each(f)` enumerates (f(score) once per entry
+// and thread), need >= 1 and <= their count.  Three passes over the entries (11 + 11 + 10 bits, most significant first): a 2048-bin
+// histogram in LDS, the bin that holds the need-th largest found by one thread walking it from the top.  The selection kernels walked the
+// candidates once per RESULT before (k or 64 block-wide rounds: 240 us for 16 users x 24 k candidates); this is three walks.
+template <int NT, typename Each>
+__device__ __forceinline__ unsigned block_kth_largest_key(int need, Each each, unsigned* hist /* [2048 + 64] LDS */, unsigned* s_bcast /* [2] LDS */) {
+  unsigned prefix = 0u;      // the bits fixed so far (high part of the key)
+  int fixed = 0;             // how many
+#pragma unroll 1
+  for (int pass = 0; pass < 3; ++pass) {
+    const int bits = pass < 2 ? 11 : 10, shift = 32 - fixed - bits;
+    for (int i = threadIdx.x; i < 2048; i += NT) hist[i] = 0u;
+    __syncthreads();
+    each([&](float sc) {
+      const unsigned key = f32_to_key(sc);
+      if (fixed == 0 || (key >> (32 - fixed)) == prefix) atomicAdd(&hist[(key >> shift) & ((1u << bits) - 1u)], 1u);
+    });
+    __syncthreads();
+    // the bin of the need-th largest, walking from the top: 64 threads sum 32 bins each, one thread walks the 64 sums and then the 32
+    // bins of the group it stops in (a single thread walking 2048 bins paid 2048 dependent LDS round trips per pass)
+    unsigned* sup = hist + 2048;                            // [64] group sums (the caller's array has room: 2048 + 64)
+    if (threadIdx.x < 64) {
+      unsigned t = 0u;
+      for (int i = 0; i < 32; ++i) t += hist[threadIdx.x * 32 + i];
+      sup[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int cum = 0, g = ((1 << bits) >> 5) - 1;
+      for (; g > 0; --g) { if (cum + (int)sup[g] >= need) break; cum += (int)sup[g]; }
+      int b = g * 32 + 31;
+      for (; b > g * 32; --b) { if (cum + (int)hist[b] >= need) break; cum += (int)hist[b]; }
+      s_bcast[0] = (unsigned)b; s_bcast[1] = (unsigned)(need - cum);
+    }
+    __syncthreads();
+    prefix = (prefix << bits) | s_bcast[0]; need = (int)s_bcast[1]; fixed += bits;
+    __syncthreads();
+  }
+  return prefix;
+}
 
 template <int NT_MERGE>
 __global__ __launch_bounds__(NT_MERGE) void topk_merge_kernel(MergeArgs m) {
@@ -862,6 +904,38 @@ __global__ __launch_bounds__(NT_MERGE) void topk_merge_kernel(MergeArgs m) {
     if (tid == 0) m.out_counts[u] = n_out;
     return;
   }
+  {
+    // many entries (a few users against a long catalog: thousands of lists): radix-select the n_out-th largest score, gather the entries
+    // at or above it (n_out plus the ties of the last place) and rank-sort those
+    __shared__ unsigned r_hist[2048 + 64]; __shared__ unsigned r_bc[2];
+    __shared__ float g_s[RANK_SORT_MAX]; __shared__ int g_p[RANK_SORT_MAX]; __shared__ int g_n;
+    const unsigned kth = block_kth_largest_key<NT_MERGE>(n_out, [&](auto f) { for (int e = tid; e < total; e += NT_MERGE) f(cs[e]); }, r_hist, r_bc);
+    if (tid == 0) g_n = 0;
+    __syncthreads();
+    for (int e = tid; e < total; e += NT_MERGE) {
+      const float sc = cs[e];
+      if (f32_to_key(sc) >= kth) {
+        const int at = atomicAdd(&g_n, 1);
+        if (at < RANK_SORT_MAX) { g_s[at] = sc; g_p[at] = cp[e]; }
+      }
+    }
+    __syncthreads();
+    const int gn = g_n;
+    if (gn <= RANK_SORT_MAX) {      // (more ties than that at the last place: the rounds below)
+      for (int e = tid; e < gn; e += NT_MERGE) {
+        const float se = g_s[e]; const long long pe = g_p[e];
+        int rank = 0;
+        for (int o = 0; o < gn; ++o) rank += better(g_s[o], (long long)g_p[o], se, pe) ? 1 : 0;
+        if (rank < n_out) {
+          if (m.out_pos != nullptr) m.out_pos[(long long)u * out_k + rank] = (int)pe;
+          else m.out_ids[(long long)u * out_k + rank] = m.whitelist ? m.whitelist[pe] : pe + m.id_offset;
+          m.out_scores[(long long)u * out_k + rank] = (m.distance == DIST_EUCLID) ? -se : se;
+        }
+      }
+      if (tid == 0) m.out_counts[u] = n_out;
+      return;
+    }
+  }
   // pass 2: k rounds of block-wide arg-best strictly below the previous winner
   float prev_s = INFINITY; long long prev_p = -1;
   for (int r = 0; r < n_out; ++r) {
@@ -898,9 +972,8 @@ __global__ __launch_bounds__(NT_MERGE) void topk_merge_kernel(MergeArgs m) {
 template <int NT_MERGE>
 __global__ __launch_bounds__(NT_MERGE) void topk_seed_kernel(MergeArgs m, unsigned* gthr) {
   const int u = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  __shared__ float s_ws[NT_MERGE / 64]; __shared__ long long s_wp[NT_MERGE / 64];
-  __shared__ float s_bs; __shared__ long long s_bp; __shared__ int s_total;
+  const int tid = threadIdx.x;
+  __shared__ int s_total;
   int my = 0;
   for (int l = tid; l < m.n_lists; l += NT_MERGE) my += m.list_counts[(long long)l * m.n_users_pad + u];
   if (tid == 0) s_total = 0;
@@ -908,35 +981,16 @@ __global__ __launch_bounds__(NT_MERGE) void topk_seed_kernel(MergeArgs m, unsign
   atomicAdd(&s_total, my);
   __syncthreads();
   if (s_total < m.k) return;
-  float prev_s = INFINITY; long long prev_p = -1;
-  for (int r = 0; r < m.k; ++r) {
-    float bs = -INFINITY; long long bp = 0x7fffffffffffffffLL;
+  // the k-th largest score of the prefix lists by radix select (three walks over the entries instead of k)
+  __shared__ unsigned r_hist[2048 + 64]; __shared__ unsigned r_bc[2];
+  const unsigned kth = block_kth_largest_key<NT_MERGE>(m.k, [&](auto f) {
     for (int l = tid; l < m.n_lists; l += NT_MERGE) {
       const int c = m.list_counts[(long long)l * m.n_users_pad + u];
       const long long lb = ((long long)l * m.n_users_pad + u) * m.k;
-      for (int e = 0; e < c; ++e) {
-        float sc = m.list_scores[lb + e]; long long p = m.list_pos[lb + e];
-        bool below = (r == 0) || better(prev_s, prev_p, sc, p);
-        if (below && better(sc, p, bs, bp)) { bs = sc; bp = p; }
-      }
+      for (int e = 0; e < c; ++e) f(m.list_scores[lb + e]);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      float os = __shfl_xor(bs, o, 64); long long op = __shfl_xor(bp, o, 64);
-      if (better(os, op, bs, bp)) { bs = os; bp = op; }
-    }
-    if (lane == 0) { s_ws[wave] = bs; s_wp[wave] = bp; }
-    __syncthreads();
-    if (tid == 0) {
-      float fs = s_ws[0]; long long fp = s_wp[0];
-      for (int w = 1; w < NT_MERGE / 64; ++w)
-        if (better(s_ws[w], s_wp[w], fs, fp)) { fs = s_ws[w]; fp = s_wp[w]; }
-      s_bs = fs; s_bp = fp;
-    }
-    __syncthreads();
-    prev_s = s_bs; prev_p = s_bp;
-  }
-  if (tid == 0) atomicMax(gthr + u, f32_to_key(prev_s));
+  }, r_hist, r_bc);
+  if (tid == 0) atomicMax(gthr + u, kth);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1742,6 +1796,8 @@ struct TwoStage {
   const float* user_norms; float max_item_norm;
   int k_cand; int* out_unproven;
   int cosine;      // the images hold L2-normalised rows: stage 1 ranks their dot products, stage 2 the exact cosine of the fp32 rows
+  int h_only;      // the images hold ONE bf16 (RNE) per value — half the bytes of the catalog: the HBM-bound regime (a few users per pass)
+  long long items_img_stride;   // row stride of items_hm in 32-bit words (hm: = item_stride; h-only: bf16 stride / 2)
 };
 // list capacity of the coarse pass: a pair is dropped when it falls below its list's worst kept entry, and the proof needs that bound to
 // stay below the k-th exact score — k entries per list would put the bound AT the best score for k = 1 and leave no room when one list
@@ -1761,6 +1817,7 @@ static int topk_score_impl(const float* users, int64_t user_stride, const int64_
   (void)hipGetLastError();  // do not inherit a stale error from the caller's earlier HIP calls
   if (n_users < 0 || n_candidates < 0 || d <= 0 || (d & 3) != 0 || k <= 0) return RT_ERR_INVALID_ARG;
   if (distance < DIST_DOT || distance > DIST_EUCLID) return RT_ERR_INVALID_ARG;
+  if (ts != nullptr && ts->h_only && d % (2 * KC) != 0) return RT_ERR_UNSUPPORTED;
   if (ts != nullptr && ((distance != DIST_DOT && distance != DIST_COSINE) || d % KC != 0 || k > K_LDS_LISTS || (ts->k_cand != 32 && ts->k_cand != 64) || ts->k_cand < k))
     return RT_ERR_UNSUPPORTED;
   if ((user_stride & 3) != 0 || (item_stride & 3) != 0) return RT_ERR_INVALID_ARG;
@@ -1847,13 +1904,14 @@ static int topk_score_impl(const float* users, int64_t user_stride, const int64_
     a.user_rows = user_rows ? reinterpret_cast<const long long*>(user_rows) + u0 : nullptr;
     a.n_users = nb;
     a.items = items; a.item_stride = item_stride;
+    const int d_img = (ts != nullptr && ts->h_only) ? d / 2 : d;      // words per image row
     if (ts != nullptr) {   // the coarse pass streams the images (users: dense rows in call order)
-      a.users = ts->users_hm + (long long)u0 * d; a.user_stride = d; a.user_rows = nullptr;
-      a.items = ts->items_hm;
+      a.users = ts->users_hm + (long long)u0 * d_img; a.user_stride = d_img; a.user_rows = nullptr;
+      a.items = ts->items_hm; a.item_stride = ts->items_img_stride; a.h_only = ts->h_only;
     }
     a.whitelist = reinterpret_cast<const long long*>(whitelist);
     a.n_cand = n_candidates; a.id_offset = whitelist ? 0 : candidate_id_offset;
-    a.d = d; a.distance = ts != nullptr ? DIST_DOT : distance; a.k = k;     // (two-stage: the coarse pass ranks dot products of the images)
+    a.d = d_img; a.distance = ts != nullptr ? DIST_DOT : distance; a.k = k;     // (two-stage: the coarse pass ranks dot products of the images)
     a.filt_indptr = filt_indptr ? reinterpret_cast<const long long*>(filt_indptr) + u0 : nullptr;
     a.filt_indices = filt_indices;
     a.filt_hash = filt_indptr ? filt_hash : nullptr; a.filt_u0 = u0;
@@ -1927,6 +1985,8 @@ static int topk_score_impl(const float* users, int64_t user_stride, const int64_
       // |coarse - exact| <= (2^-14 [the dropped l parts] + 4 d 2^-24 [fp32 accumulation of the 4 d bf16 products]
       //                      + d 2^-24 [the exact chain's own rounding]) sum_k |u_k v_k|, with 3 % slack (norms are fp32 too)
       r.err_coef = 1.03f * (6.103515625e-5f + 5.0f * (float)d * 5.9604644775390625e-8f);
+      // h-only images: each operand rounded to nearest bf16 (2^-9 relative) -> 2^-8 + 2^-18 on a product; d bf16 products accumulated
+      if (ts->h_only) r.err_coef = 1.03f * (3.90625e-3f + 3.814697265625e-6f + 2.0f * (float)d * 5.9604644775390625e-8f);
       r.out_ids = reinterpret_cast<long long*>(out_ids) + (long long)u0 * k_out; r.out_scores = out_scores + (long long)u0 * k_out;
       r.out_counts = out_counts + u0; r.out_unproven = ts->out_unproven + u0;
       if (ts->k_cand == 64) topk_replay_kernel<2><<<nb, 128, 0, stream>>>(r);
@@ -1963,8 +2023,10 @@ size_t rt_topk_two_stage_workspace_bytes(int32_t n_users, int64_t n_candidates, 
 // bits); 1: the candidate set could not be proven complete for u (ties or near-ties at the k-th place closer than the coarse error
 // bound) — rank those users with rt_topk_score.  users_hm [n_users, d] dense in call order; items_hm strided and offset like `items`;
 // user_norms [n_users] and max_item_norm = L2 norms (rt_to_hm_rows).  d % 32 == 0, k <= 16 <= k_cand.
+// h_only = 1: the images hold ONE round-to-nearest bf16 per value (rt_to_hm_rows mode 2 / 3; rows of item_stride bf16 values, users dense
+// d) — half the catalog bytes per pass, for the regime where the pass is bound by HBM (a few users); coarse error 2^-8 |u| |v|, d % 64 == 0.
 int rt_topk_score_two_stage(const float* users, int64_t user_stride, const int64_t* user_rows, int32_t n_users, const float* items,
-                            int64_t item_stride, const uint32_t* users_hm, const uint32_t* items_hm, const float* user_norms,
+                            int64_t item_stride, const uint32_t* users_hm, const uint32_t* items_hm, int32_t h_only, const float* user_norms,
                             float max_item_norm, const int64_t* whitelist, int64_t n_candidates, int64_t candidate_id_offset, int32_t d,
                             int32_t distance, int32_t k, int32_t k_cand, const int64_t* filt_indptr, const int32_t* filt_indices,
                             const int32_t* filt_hash, int64_t* out_ids, float* out_scores, int32_t* out_counts, int32_t* out_unproven,
@@ -1977,7 +2039,8 @@ int rt_topk_score_two_stage(const float* users, int64_t user_stride, const int64
     if (hipMemsetAsync(out_unproven, 0, sizeof(int32_t) * (size_t)n_users, stream) != hipSuccess) return RT_ERR_LAUNCH;
   }
   TwoStage ts{reinterpret_cast<const float*>(users_hm), reinterpret_cast<const float*>(items_hm), user_norms, max_item_norm, k_cand,
-              out_unproven, distance == DIST_COSINE ? 1 : 0};
+              out_unproven, distance == DIST_COSINE ? 1 : 0, h_only ? 1 : 0, h_only ? item_stride / 2 : item_stride};
+  if (h_only && (item_stride & 7) != 0) return RT_ERR_INVALID_ARG;      // (the bf16 image mirrors the fp32 rows: stride item_stride bf16 values)
   return topk_score_impl(users, user_stride, user_rows, n_users, items, item_stride, whitelist, n_candidates, candidate_id_offset, d,
                          distance, k, filt_indptr, filt_indices, filt_hash, out_ids, out_scores, out_counts, workspace, workspace_bytes,
                          users_per_pass, &ts, stream);

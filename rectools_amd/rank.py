@@ -132,8 +132,10 @@ class HipRanker:
         env = os.environ.get("RT_TOPK_TWO_STAGE", "auto")
         self.two_stage: tp.Optional[bool] = (None if env == "auto" else env == "1") if two_stage is None else bool(two_stage)
         self._items_hm: tp.Optional[torch.Tensor] = None      # hm image of objects_factors (rt_to_hm_rows), built on first use
+        self._items_h: tp.Optional[torch.Tensor] = None       # h-only (one bf16 per value) image: the HBM-bound regime
+        self._h_only_off = os.environ.get("RT_TOPK_H_ONLY", "1") == "0"
         self._max_item_norm = 0.0
-        self.two_stage_stats = {"calls": 0, "fallbacks": 0, "unproven_users": 0}
+        self.two_stage_stats = {"calls": 0, "fallbacks": 0, "unproven_users": 0, "h_only_calls": 0}
 
     def _to_device(self, tensor: tp.Union[np.ndarray, sparse.csr_matrix, torch.Tensor]) -> torch.Tensor:
         # mirrors TorchRanker._normalize_tensor (rank_torch.py:210-223), then moves to the device once
@@ -156,14 +158,28 @@ class HipRanker:
         if self.two_stage is False or self.distance not in (Distance.DOT, Distance.COSINE) or d % 32 != 0 or d > 2048 or kk > 16 \
                 or n_cand < 8 * self.CANDIDATES:
             return False
-        return True if self.two_stage else n_subj >= int(os.environ.get("RT_TOPK_TWO_STAGE_MIN_USERS", self.TWO_STAGE_MIN_USERS))
+        return True if self.two_stage else (n_subj >= int(os.environ.get("RT_TOPK_TWO_STAGE_MIN_USERS", self.TWO_STAGE_MIN_USERS))
+                                            or self._h_only_applies(n_subj))
 
-    def _hm_image(self, src: torch.Tensor, rows: tp.Optional[torch.Tensor], n_rows: int) -> tp.Tuple[torch.Tensor, torch.Tensor]:
+    H_ONLY_MAX_USERS = 32          # one 32-user tile per pass: the pass is bound by the bytes of the catalog it streams
+    H_ONLY_MIN_BYTES = 256 << 20   # ... when the catalog does not live in L2 / Infinity Cache
+
+    def _h_only_applies(self, n_subj: int) -> bool:
+        """The h-only coarse pass (one bf16 per value: half the catalog bytes) for the HBM-bound regime; switched off for a ranker whose
+        catalog defeated its wider error bound once (near-duplicate items)."""
+        O = self.objects_factors
+        return (not self._h_only_off and n_subj <= self.H_ONLY_MAX_USERS and O.shape[1] % 64 == 0 and O.stride(0) == O.shape[1]
+                and O.numel() * 4 >= self.H_ONLY_MIN_BYTES)
+
+    def _hm_image(self, src: torch.Tensor, rows: tp.Optional[torch.Tensor], n_rows: int, h_only: bool = False
+                  ) -> tp.Tuple[torch.Tensor, torch.Tensor]:
         d = src.shape[1]
-        img = torch.empty((n_rows, d), dtype=torch.int32, device=self.device)
+        w = d // 2 if h_only else d
+        img = torch.empty((n_rows, w), dtype=torch.int32, device=self.device)
         norms = torch.empty((n_rows,), dtype=torch.float32, device=self.device)
-        status = self._lib.rt_to_hm_rows(_lib.ptr(src), src.stride(0), _lib.ptr(rows), n_rows, d, 1 if self.distance == Distance.COSINE else 0,
-                                         _lib.ptr(img), d, _lib.ptr(norms), _lib.current_stream())
+        mode = (1 if self.distance == Distance.COSINE else 0) | (2 if h_only else 0)
+        status = self._lib.rt_to_hm_rows(_lib.ptr(src), src.stride(0), _lib.ptr(rows), n_rows, d, mode,
+                                         _lib.ptr(img), w, _lib.ptr(norms), _lib.current_stream())
         _lib.check(status, "rt_to_hm_rows")
         return img, norms
 
@@ -197,18 +213,29 @@ class HipRanker:
         # users per catalog pass: 128 (lists in global memory, half the ring traffic per flop) pays on catalogs long enough that the
         # selection slow path is rare; small catalogs keep the 64-user tile with its LDS lists
         upp2 = upp if upp > 0 else int(os.environ.get("RT_TOPK_TWO_STAGE_UPP", "128" if n_cand >= 500_000 else "64"))
+        h_only = self._h_only_applies(n_subj)
         with torch.cuda.device(dev):
-            if self._items_hm is None:
-                self._items_hm, item_norms = self._hm_image(O, None, O.shape[0])
-                self._max_item_norm = float(item_norms.max())
-            users_hm, user_norms = self._hm_image(S, rows_t, n_subj)
+            if h_only:
+                self.two_stage_stats["h_only_calls"] += 1
+                upp2 = 32
+                if self._items_h is None:
+                    self._items_h, item_norms = self._hm_image(O, None, O.shape[0], h_only=True)
+                    self._max_item_norm = float(item_norms.max())
+                items_img, img_row_bytes = self._items_h, 2 * d
+            else:
+                if self._items_hm is None:
+                    self._items_hm, item_norms = self._hm_image(O, None, O.shape[0])
+                    self._max_item_norm = float(item_norms.max())
+                items_img, img_row_bytes = self._items_hm, 4 * d
+            users_hm, user_norms = self._hm_image(S, rows_t, n_subj, h_only=h_only)
             unproven = torch.empty((n_subj,), dtype=torch.int32, device=dev)
             ws_bytes = self._lib.rt_topk_two_stage_workspace_bytes(n_subj, n_cand, kk, kc, upp2)
             if self._workspace is None or self._workspace.numel() < ws_bytes:
                 self._workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
             status = self._lib.rt_topk_score_two_stage(
                 _lib.ptr(S), S.stride(0), _lib.ptr(rows_t), n_subj, O.data_ptr() + 4 * id_offset * O.stride(0), O.stride(0),
-                _lib.ptr(users_hm), self._items_hm.data_ptr() + 4 * id_offset * d, _lib.ptr(user_norms), self._max_item_norm,
+                _lib.ptr(users_hm), items_img.data_ptr() + img_row_bytes * id_offset, 1 if h_only else 0, _lib.ptr(user_norms),
+                self._max_item_norm,
                 _lib.ptr(whitelist_t), n_cand, id_offset, d, _DIST_CODE[self.distance], kk, kc, _lib.ptr(indptr_t), _lib.ptr(indices_t),
                 _lib.ptr(hash_t),
                 _lib.ptr(ids_t), _lib.ptr(scores_t), _lib.ptr(counts_t), _lib.ptr(unproven), _lib.ptr(self._workspace),
@@ -220,8 +247,10 @@ class HipRanker:
         self.two_stage_stats["unproven_users"] += int(len(bad))
         if 8 * len(bad) > n_subj:       # the catalog defeats the coarse pass (near-duplicates): the whole call on the exact kernel
             self.two_stage_stats["fallbacks"] += 1
+            if h_only:                  # ... and the one-plane image is not tried again on this catalog (the (h, m) image is)
+                self._h_only_off = True
             self._rank_exact(ids_t, scores_t, counts_t, rows_t, 0, n_subj, whitelist_t, n_cand, id_offset, kk, indptr_t, indices_t,
-                             hash_t, upp)
+                             hash_t, upp if upp > 16 else 32)      # the 32-wide engine: the arithmetic the exact pass mirrors
             return
         starts = bad[np.r_[True, np.diff(bad) > 1]]
         ends = bad[np.r_[np.diff(bad) > 1, True]] + 1

@@ -162,3 +162,44 @@ def test_two_stage_with_fewer_than_k_candidates_left_by_the_filter():
     # the numpy front end drops the empty rows the same way in both modes
     a, b = exact.rank(np.arange(n_subj), k, filt), fast.rank(np.arange(n_subj), k, filt)
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("dist", ["dot", "cosine"])
+@pytest.mark.parametrize("n_subj,with_filter", [(16, False), (32, True), (5, False)])
+def test_h_only_coarse_pass_for_a_few_users_returns_the_single_stage_bits(n_subj, with_filter, dist):
+    """The HBM-bound regime (a few users against a catalog that does not fit the caches): the coarse pass streams a ONE-plane bf16 image
+    (half the catalog bytes, coarse error 2^-8 |u| |v|), the exact pass and the proof are the same — ids, order and score bits of the
+    32-wide single-stage engine."""
+    from rectools_amd.rank import HipRanker
+
+    n_obj, d, k = 600_000, 128, 10                         # 307 MB of fp32 rows
+    g = torch.Generator(device="cuda").manual_seed(n_subj)
+    obj = torch.randn((n_obj, d), device="cuda", generator=g) * (0.5 + 1.5 * torch.rand((n_obj, 1), device="cuda", generator=g))
+    subj = torch.randn((n_subj, d), device="cuda", generator=g)
+    filt = sparse.random(n_subj, n_obj, density=0.0005, format="csr", random_state=3, dtype=np.float32) if with_filter else None
+    exact = HipRanker(dist, "cuda", subj, obj, batch_size=32, two_stage=False)
+    fast = HipRanker(dist, "cuda", subj, obj)
+    e_ids, e_sc, e_cnt, _ = exact.rank_device(np.arange(n_subj), k, filt)
+    f_ids, f_sc, f_cnt, _ = fast.rank_device(np.arange(n_subj), k, filt)
+    st = fast.two_stage_stats
+    assert st["calls"] == 1 and st["h_only_calls"] == 1 and st["unproven_users"] == 0, st
+    assert torch.equal(e_cnt, f_cnt) and torch.equal(e_ids, f_ids) and torch.equal(e_sc.view(torch.int32), f_sc.view(torch.int32))
+
+
+def test_h_only_is_dropped_for_a_catalog_that_defeats_its_bound():
+    """Near-duplicate items closer than the one-plane bound: the call falls back to the single-stage kernel (same result) and the ranker
+    stops using the one-plane image; the (h, m) image still serves larger calls."""
+    from rectools_amd.rank import HipRanker
+
+    g = torch.Generator(device="cuda").manual_seed(1)
+    base = torch.randn((300, 128), device="cuda", generator=g)
+    obj = base.repeat_interleave(2000, dim=0) * (1.0 + 1e-4 * torch.randn((600_000, 1), device="cuda", generator=g))
+    subj = torch.randn((8, 128), device="cuda", generator=g)
+    exact = HipRanker("dot", "cuda", subj, obj, batch_size=32, two_stage=False)
+    fast = HipRanker("dot", "cuda", subj, obj)
+    e = exact.rank_device(np.arange(8), 10)
+    f = fast.rank_device(np.arange(8), 10)
+    assert fast.two_stage_stats["h_only_calls"] == 1 and fast.two_stage_stats["fallbacks"] == 1 and fast._h_only_off
+    assert torch.equal(e[0], f[0]) and torch.equal(e[1].view(torch.int32), f[1].view(torch.int32))
+    fast.rank_device(np.arange(8), 10)
+    assert fast.two_stage_stats["h_only_calls"] == 1          # not tried again
