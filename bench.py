@@ -562,7 +562,7 @@ def topk_leg(kind, args, rank, world, cpu_baseline):
         V, d = 5_000_000, 512
         ups = args.users_per_step or 16   # 16 users/launch: the HBM-bound regime (AI = B/2 flop/B; 32 users is the fp32 ridge)
         upp = args.users_per_pass or (16 if ups <= 16 else 32 if ups <= 32 else 64 if ups < 128 else 0)
-        steps, warmup = args.topk_steps, 2
+        steps, warmup = args.topk_steps, (2 if ups > 64 else 5)
         metric = "full-catalog top-k users/sec @k=10 (5M x 512 fp32 catalog)"
         workload = f"top-k scoring: 5,000,000 items x d512 fp32 (10.24 GB), {ups} users/step, k=10"
         name, with_filter = ("topk5m" if ups <= 64 else f"topk5m_u{ups}"), False      # (the PMC traffic on file is the 16-user launch's)
@@ -593,7 +593,7 @@ def main():
     ap.add_argument("--users-per-step", type=int, default=0)
     ap.add_argument("--n-negatives", type=int, default=128, help="sampled_softmax negatives (tutorial setting 128)")
     ap.add_argument("--rec-steps", type=int, default=20, help="timed steps of the recommend sub-leg")
-    ap.add_argument("--topk-steps", type=int, default=5, help="timed steps of the topk5m sub-leg")
+    ap.add_argument("--topk-steps", type=int, default=40, help="timed steps of the topk5m sub-leg (a step is ~1.2 ms: enough of them that one host hiccup does not set the figure)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-families", action="store_true", help="skip the BERT4Rec / HSTU / eSASRec sub-records of the auto run")
     args = ap.parse_args()
