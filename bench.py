@@ -225,9 +225,10 @@ def run_topk(steps, warmup, rank, world, n_items, d, users_per_step, upp, with_f
         # (2 B per value) + the users + the outputs; the fp32 rows are touched for 64 candidates per user only
         bytes_per_launch = 2.0 * d * n_items + 4.0 * d * users_per_step + 12.0 * users_per_step * 10 + 4.0 * d * 64 * users_per_step
         gbs = bytes_per_launch / t / 1e9
-    # two-stage calls (rt_topk_score_two_stage) score on the bf16 matrix pipe: (h + m)(h' + m') = four bf16 products per fp32 product,
-    # so the pipe's roof for ALGORITHMIC fp32 flops is 2,500 / 4 TF; single-stage calls run the f32-input instruction (157.3 TF)
-    mfma_peak = MFMA_BF16_PEAK_TF / 4.0 if two_stage else MFMA_F32_PEAK_TF
+    # two-stage calls (rt_topk_score_two_stage) score on the bf16 matrix pipe: over the (h, m) images (h + m)(h' + m') = four bf16 products
+    # per fp32 product, so the pipe's roof for ALGORITHMIC fp32 flops is 2,500 / 4 TF; over the one-plane image one product: 2,500 TF;
+    # single-stage calls run the f32-input instruction (157.3 TF)
+    mfma_peak = MFMA_BF16_PEAK_TF if h_only else MFMA_BF16_PEAK_TF / 4.0 if two_stage else MFMA_F32_PEAK_TF
     hbm_bound = (bytes_per_launch / (HBM_PEAK_GBS * 1e9)) >= (flops_per_launch / (mfma_peak * 1e12))
     if n_items * d * 4 <= 200e6:
         hbm_bound = False  # catalog resident in L2 / Infinity Cache: the HBM roof does not apply
@@ -243,6 +244,9 @@ def run_topk(steps, warmup, rank, world, n_items, d, users_per_step, upp, with_f
         "frac": round((gbs / HBM_PEAK_GBS) if hbm_bound else (tfs / mfma_peak), 4),
         "two_stage": dict(ranker.two_stage_stats) if two_stage else None,
         "fp32_catalog_equivalent_GBps": round(topk_bytes(n_items, d, users_per_step, 10, info["nnz"]) / t / 1e9, 1) if h_only else None,
+        # the one-plane pass walks the image once per 64-user tile (tiles of one XCD walk it together through that XCD's L2): what the
+        # compute units pull through the LDS ring per second — the figure that bounds the many-user launch, not the pipe
+        "image_ring_GBps": round(2.0 * d * n_items * max(1, (users_per_step + 63) // 64) / t / 1e9, 1) if h_only and users_per_step > 32 else None,
         "traffic": load_traffic(name),
         "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_flops_per_launch": flops_per_launch,
         "avg_launch_ms": round(ev_ms, 4), "hbm_GBps": round(gbs, 1), "mfma_f32_TFLOPs": round(tfs, 2),

@@ -134,6 +134,7 @@ class HipRanker:
         self._items_hm: tp.Optional[torch.Tensor] = None      # hm image of objects_factors (rt_to_hm_rows), built on first use
         self._items_h: tp.Optional[torch.Tensor] = None       # h-only (one bf16 per value) image: the HBM-bound regime
         self._h_only_off = os.environ.get("RT_TOPK_H_ONLY", "1") == "0"
+        self._h_only_strikes = 0
         self._max_item_norm = 0.0
         self.two_stage_stats = {"calls": 0, "fallbacks": 0, "unproven_users": 0, "h_only_calls": 0}
 
@@ -153,6 +154,8 @@ class HipRanker:
     TWO_STAGE_MIN_USERS = 17   # up to 16 users the 16-user tile of the single-stage kernel streams the catalog at the HBM roofline; from 17 up
     #                            the matrix pipe binds and the coarse pass wins (5 M x 512: 32 users 2.36 vs 2.77 ms, 64 users 2.60 vs 4.08 ms)
 
+    RUNS_PER_USERS = 150      # one-plane pass: more than n_users / 150 separate runs of unproven users cost more than the (h, m) pass again
+
     def _two_stage_applies(self, kk: int, n_cand: int, n_subj: int) -> bool:
         d = self.objects_factors.shape[1]
         if self.two_stage is False or self.distance not in (Distance.DOT, Distance.COSINE) or d % 32 != 0 or d > 2048 or kk > 16 \
@@ -161,15 +164,20 @@ class HipRanker:
         return True if self.two_stage else (n_subj >= int(os.environ.get("RT_TOPK_TWO_STAGE_MIN_USERS", self.TWO_STAGE_MIN_USERS))
                                             or self._h_only_applies(n_subj))
 
-    H_ONLY_MAX_USERS = 32          # one 32-user tile per pass: the pass is bound by the bytes of the catalog it streams
-    H_ONLY_MIN_BYTES = 256 << 20   # ... when the catalog does not live in L2 / Infinity Cache
+    H_ONLY_MIN_BYTES = 256 << 20   # up to 16 users the one-plane pass only pays when the catalog does not live in L2 / Infinity Cache
 
     def _h_only_applies(self, n_subj: int) -> bool:
-        """The h-only coarse pass (one bf16 per value: half the catalog bytes) for the HBM-bound regime; switched off for a ranker whose
-        catalog defeated its wider error bound once (near-duplicate items)."""
+        """The one-plane coarse pass (ONE bf16 per value: half the bytes of the (h, m) image and a quarter of its matrix-pipe work, coarse
+        error 2^-8 |u| |v|).  A few users against a big catalog: the pass is bound by the bytes it streams (5 M x 512, 16 users: 1.16 vs
+        1.77 ms for the fp32 rows).  Many users: the (h, m) pass is bound by its four bf16 products per fp32 product (5 M x 512, 4096
+        users: 58.6 vs 101.6 ms; 26,744 x 256, 16,384 users: 2.47 vs 3.08 ms).  Switched off for a ranker whose catalog defeated the
+        wider error bound (near-duplicate items): the (h, m) image serves it from then on."""
         O = self.objects_factors
-        return (not self._h_only_off and n_subj <= self.H_ONLY_MAX_USERS and O.shape[1] % 64 == 0 and O.stride(0) == O.shape[1]
-                and O.numel() * 4 >= self.H_ONLY_MIN_BYTES)
+        if self._h_only_off or O.shape[1] % 64 != 0 or O.stride(0) != O.shape[1]:
+            return False
+        if n_subj >= int(os.environ.get("RT_TOPK_TWO_STAGE_MIN_USERS", self.TWO_STAGE_MIN_USERS)):
+            return True
+        return O.numel() * 4 >= int(os.environ.get("RT_TOPK_H_ONLY_MIN_BYTES", self.H_ONLY_MIN_BYTES))
 
     def _hm_image(self, src: torch.Tensor, rows: tp.Optional[torch.Tensor], n_rows: int, h_only: bool = False
                   ) -> tp.Tuple[torch.Tensor, torch.Tensor]:
@@ -212,12 +220,14 @@ class HipRanker:
         self.two_stage_stats["calls"] += 1
         # users per catalog pass: 128 (lists in global memory, half the ring traffic per flop) pays on catalogs long enough that the
         # selection slow path is rare; small catalogs keep the 64-user tile with its LDS lists
-        upp2 = upp if upp > 0 else int(os.environ.get("RT_TOPK_TWO_STAGE_UPP", "128" if n_cand >= 500_000 else "64"))
         h_only = self._h_only_applies(n_subj)
+        # (the one-plane pass re-reads the catalog image once per user tile and is bound by that stream: 64-user tiles with their LDS lists)
+        upp2 = upp if upp > 0 else int(os.environ.get("RT_TOPK_TWO_STAGE_UPP", "128" if n_cand >= 500_000 and not h_only else "64"))
         with torch.cuda.device(dev):
             if h_only:
                 self.two_stage_stats["h_only_calls"] += 1
-                upp2 = 32
+                if n_subj <= 32:
+                    upp2 = 32
                 if self._items_h is None:
                     self._items_h, item_norms = self._hm_image(O, None, O.shape[0], h_only=True)
                     self._max_item_norm = float(item_norms.max())
@@ -245,18 +255,34 @@ class HipRanker:
         if len(bad) == 0:
             return
         self.two_stage_stats["unproven_users"] += int(len(bad))
-        if 8 * len(bad) > n_subj:       # the catalog defeats the coarse pass (near-duplicates): the whole call on the exact kernel
-            self.two_stage_stats["fallbacks"] += 1
-            if h_only:                  # ... and the one-plane image is not tried again on this catalog (the (h, m) image is)
-                self._h_only_off = True
-            self._rank_exact(ids_t, scores_t, counts_t, rows_t, 0, n_subj, whitelist_t, n_cand, id_offset, kk, indptr_t, indices_t,
-                             hash_t, upp if upp > 16 else 32)      # the 32-wide engine: the arithmetic the exact pass mirrors
-            return
         starts = bad[np.r_[True, np.diff(bad) > 1]]
         ends = bad[np.r_[np.diff(bad) > 1, True]] + 1
-        for u0, u1 in zip(starts, ends):    # runs of consecutive unproven users, on the 32-wide engine the exact pass mirrors
+        wide = n_subj >= self.TWO_STAGE_MIN_USERS or self.two_stage is True
+        exact_upp = upp if upp > 16 else 32      # the 32-wide engine: the arithmetic the exact pass mirrors
+        if h_only and wide and (8 * len(bad) > n_subj or len(starts) > max(2, n_subj // self.RUNS_PER_USERS)):
+            # the one-plane bound is too wide for this catalog (or leaves more single runs — a catalog pass each — than a second coarse
+            # pass costs): the whole call again over the (h, m) image, whose bound is 2^-8 of this one
+            self.two_stage_stats["fallbacks"] += 1
+            self._h_only_strikes += 1
+            if 8 * len(bad) > n_subj or self._h_only_strikes >= 2:
+                self._h_only_off = True
+            saved, self._h_only_off = self._h_only_off, True
+            try:
+                self._rank_two_stage(ids_t, scores_t, counts_t, rows_t, n_subj, whitelist_t, n_cand, id_offset, kk, indptr_t, indices_t,
+                                     hash_t, upp)
+            finally:
+                self._h_only_off = saved
+            return
+        if 8 * len(bad) > n_subj:       # the catalog defeats the coarse pass (near-duplicates): the whole call on the exact kernel
+            self.two_stage_stats["fallbacks"] += 1
+            if h_only:                  # ... and the one-plane image is not tried again on this catalog
+                self._h_only_off = True
+            self._rank_exact(ids_t, scores_t, counts_t, rows_t, 0, n_subj, whitelist_t, n_cand, id_offset, kk, indptr_t, indices_t,
+                             hash_t, exact_upp)
+            return
+        for u0, u1 in zip(starts, ends):    # runs of consecutive unproven users, on the 32-wide engine
             self._rank_exact(ids_t, scores_t, counts_t, rows_t, int(u0), int(u1 - u0), whitelist_t, n_cand, id_offset, kk, indptr_t,
-                             indices_t, hash_t, upp if upp > 16 else 32)
+                             indices_t, hash_t, exact_upp)
 
     def rank(
         self,

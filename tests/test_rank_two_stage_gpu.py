@@ -28,9 +28,11 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("plane", ["h", "hm"])
 @pytest.mark.parametrize("dist", ["dot", "cosine"])
 @pytest.mark.parametrize("d,n_obj,n_subj,batch,k,with_filter,wl_kind", CASES)
-def test_two_stage_returns_the_single_stage_result_bit_for_bit(d, n_obj, n_subj, batch, k, with_filter, wl_kind, dist):
+def test_two_stage_returns_the_single_stage_result_bit_for_bit(d, n_obj, n_subj, batch, k, with_filter, wl_kind, dist, plane):
+    """plane "h": the one-plane coarse image (the default where the row width allows it: d % 64 == 0); "hm": the two-plane image."""
     from rectools_amd.rank import HipRanker
 
     subj, obj = _factors(n_subj, n_obj, d, seed=n_obj % 97)
@@ -46,9 +48,14 @@ def test_two_stage_returns_the_single_stage_result_bit_for_bit(d, n_obj, n_subj,
         wl = np.arange(1000, n_obj - 500)
     exact = HipRanker(dist, "cuda", subj, obj, batch_size=batch if batch else 64, two_stage=False)
     fast = HipRanker(dist, "cuda", subj, obj, batch_size=batch, two_stage=True)
+    if plane == "hm":
+        fast._h_only_off = True
+    elif d % 64 != 0:
+        pytest.skip("the one-plane image needs d % 64 == 0: this shape runs on the (h, m) image either way")
     e_ids, e_sc, e_cnt, _ = exact.rank_device(ids, k, filt, wl)
     f_ids, f_sc, f_cnt, _ = fast.rank_device(ids, k, filt, wl)
     assert fast.two_stage_stats["calls"] == 1 and fast.two_stage_stats["unproven_users"] == 0, fast.two_stage_stats
+    assert fast.two_stage_stats["h_only_calls"] == (1 if plane == "h" else 0)
     assert torch.equal(e_cnt, f_cnt)
     valid = torch.arange(e_ids.shape[1], device="cuda")[None, :] < e_cnt[:, None]
     assert torch.equal(e_ids[valid], f_ids[valid])
@@ -75,7 +82,8 @@ def test_two_stage_is_the_default_for_many_users_with_dot_and_cosine():
     assert e.two_stage_stats["calls"] == 0
 
 
-def test_users_whose_result_cannot_be_proven_are_ranked_by_the_single_stage_kernel():
+@pytest.mark.parametrize("plane", ["h", "hm"])
+def test_users_whose_result_cannot_be_proven_are_ranked_by_the_single_stage_kernel(plane):
     """Exact duplicates of the best items (ties at the k-th place) and a block of near-duplicates inside the coarse error window: the
     proof fails for the affected users — flagged per user, re-ranked by the single-stage kernel, same bits in the end."""
     from rectools_amd.rank import HipRanker
@@ -92,19 +100,25 @@ def test_users_whose_result_cannot_be_proven_are_ranked_by_the_single_stage_kern
     subj[20:25] = obj[33][None, :] * rng.uniform(0.5, 2.0, (5, 1)).astype(np.float32)
     exact = HipRanker("dot", "cuda", subj, obj, batch_size=64, two_stage=False)
     fast = HipRanker("dot", "cuda", subj, obj, batch_size=64, two_stage=True)
+    fast._h_only_off = plane == "hm"
     e_ids, e_sc, e_cnt, _ = exact.rank_device(np.arange(200), 10)
     f_ids, f_sc, f_cnt, _ = fast.rank_device(np.arange(200), 10)
     st = fast.two_stage_stats
-    assert st["calls"] == 1 and st["fallbacks"] == 0 and 15 <= st["unproven_users"] <= 40, st
+    if plane == "hm":
+        assert st["calls"] == 1 and st["fallbacks"] == 0 and 15 <= st["unproven_users"] <= 40, st
+    else:   # the one-plane bound is 2^8 wider: whatever it leaves unproven is re-ranked (by runs, or by the (h, m) pass again)
+        assert st["h_only_calls"] == 1 and st["unproven_users"] >= 15, st
     assert torch.equal(e_ids, f_ids) and torch.equal(e_sc.view(torch.int32), f_sc.view(torch.int32)) and torch.equal(e_cnt, f_cnt)
     # a catalog made of near-duplicates only defeats the coarse pass for everybody: the whole call goes to the single-stage kernel
     base = rng.normal(size=(50, d)).astype(np.float32)
     obj2 = np.repeat(base, 400, axis=0) * (1.0 + 1e-6 * rng.normal(size=(20_000, 1))).astype(np.float32)
     exact2 = HipRanker("dot", "cuda", subj, obj2, batch_size=64, two_stage=False)
     fast2 = HipRanker("dot", "cuda", subj, obj2, batch_size=64, two_stage=True)
+    fast2._h_only_off = plane == "hm"
     e2 = exact2.rank_device(np.arange(200), 10)
     f2 = fast2.rank_device(np.arange(200), 10)
-    assert fast2.two_stage_stats["fallbacks"] == 1
+    # "h": one-plane pass -> (h, m) pass -> single-stage kernel, and the one-plane image is not tried again on this catalog
+    assert fast2.two_stage_stats["fallbacks"] == (1 if plane == "hm" else 2) and fast2._h_only_off
     assert torch.equal(e2[0], f2[0]) and torch.equal(e2[1].view(torch.int32), f2[1].view(torch.int32))
 
 
@@ -184,6 +198,28 @@ def test_h_only_coarse_pass_for_a_few_users_returns_the_single_stage_bits(n_subj
     st = fast.two_stage_stats
     assert st["calls"] == 1 and st["h_only_calls"] == 1 and st["unproven_users"] == 0, st
     assert torch.equal(e_cnt, f_cnt) and torch.equal(e_ids, f_ids) and torch.equal(e_sc.view(torch.int32), f_sc.view(torch.int32))
+
+
+def test_one_plane_pass_with_many_users_falls_back_to_the_two_plane_pass():
+    """Many users, a catalog of 100-fold near-duplicates (relative spread 1e-3): more look-alikes than the 64 candidates inside the
+    one-plane bound (2^-8 |u| |v|), but well apart under the (h, m) bound (2^-16): the call is repeated over the (h, m) image — proven
+    there — and the ranker keeps to that image afterwards."""
+    from rectools_amd.rank import HipRanker
+
+    g = torch.Generator(device="cuda").manual_seed(2)
+    base = torch.randn((600, 128), device="cuda", generator=g)
+    obj = base.repeat_interleave(100, dim=0) * (1.0 + 1e-3 * torch.randn((60_000, 1), device="cuda", generator=g))
+    subj = torch.randn((256, 128), device="cuda", generator=g)
+    exact = HipRanker("dot", "cuda", subj, obj, batch_size=64, two_stage=False)
+    fast = HipRanker("dot", "cuda", subj, obj)
+    e = exact.rank_device(np.arange(256), 10)
+    f = fast.rank_device(np.arange(256), 10)
+    st = fast.two_stage_stats
+    assert st["h_only_calls"] == 1 and st["calls"] == 2 and st["fallbacks"] == 1 and fast._h_only_off, st
+    assert st["unproven_users"] >= 200, st        # all of them from the one-plane pass
+    assert torch.equal(e[0], f[0]) and torch.equal(e[1].view(torch.int32), f[1].view(torch.int32)) and torch.equal(e[2], f[2])
+    fast.rank_device(np.arange(256), 10)
+    assert fast.two_stage_stats["h_only_calls"] == 1 and fast.two_stage_stats["calls"] == 3
 
 
 def test_h_only_is_dropped_for_a_catalog_that_defeats_its_bound():
