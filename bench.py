@@ -180,6 +180,13 @@ def make_topk_workload(n_items: int, d: int, users_per_step: int, upp: int, rank
                               filt=filt)
 
 
+def quiesce_host(seconds: float = 1.0) -> None:
+    """After a CPU-baseline leg: let the 128 OpenMP workers of the reference's torch ops finish spinning before the next GPU leg is timed
+    (a leg that started right behind a baseline ran at 2.92 instead of 1.93 ms per step in 2 of 5 driver-form runs, the 16-user top-k at
+    3.2 instead of 1.1 ms once: the launching thread was competing for its core)."""
+    time.sleep(seconds)
+
+
 def cpu_baseline_topk(items_t: torch.Tensor, users_t: torch.Tensor, filt, budget_s: float = 15.0):
     """-> (users/s, users ranked, kind, sample): the unmodified reference's TorchRanker(device="cpu").rank when the reference is on this
     box (oracle/cpu_reference.py), else the numpy port (oracle/ranker_oracle), on a bounded user sample."""
@@ -582,6 +589,7 @@ def topk_leg(kind, args, rank, world, cpu_baseline):
         scale = 1.0 if small else 200_000 / info["n_items"]
         rec["cpu_baseline"] = {"value": round(v * scale, 2), "unit": "users/s", "cores": torch.get_num_threads(), "kind": kind,
                                "sample": what + ("" if small else f"; first 200k catalog rows, rate scaled by {scale:.3f}")}
+        quiesce_host()
     del info
     torch.cuda.empty_cache()
     return rec
@@ -654,6 +662,7 @@ def main():
         if cpu_ok and kind == "train":
             v, kind_b, what = cpu_baseline_train(info)
             out["cpu_baseline"] = {"value": round(v, 2), "unit": "seqs/s", "cores": torch.get_num_threads(), "kind": kind_b, "sample": what}
+            quiesce_host()
         if workload == "auto":
             # the same loop with the GEMMs on the f32-input MFMA (RT_GEMM_SPLIT=exact is read per call): the number to compare when the
             # bf16x6 arithmetic of the default line is questioned ("carry it as a sub-record of the driver line")
