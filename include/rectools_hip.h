@@ -89,7 +89,7 @@ int rt_topk_score(const float* users, int64_t user_stride, const int64_t* user_r
  *      ranks dot products of unit rows, stage 2 evaluates the exact cosine of the fp32 rows).  The catalog's image is built once per
  *      ranker, the users' per call.  normalize bit 1 (values 2 / 3): the H-ONLY image — one round-to-nearest bf16 per value, rows of d / 2
  *      words (dst_stride >= d / 2): half the bytes, for passes bound by HBM (h_only = 1 in rt_topk_score_two_stage: coarse error
- *      2^-8 |u| |v|, items_hm rows item_stride / 2 words apart, d % 64 == 0).
+ *      2^-7 |u| |v|, items_hm rows item_stride / 2 words apart, d % 64 == 0).
  *   2. rt_topk_score_two_stage: stage 1 streams the images through rt_topk_score's selection machinery (viewed filter / whitelist as
  *      there) with two v_mfma_f32_32x32x16_bf16 per four k — (h + m)(h' + m'), a quarter of the matrix-pipe time — and hands the k_cand
  *      (32 or 64) best COARSE candidates per user to stage 2, which scores them again in the exact arithmetic of rt_topk_score's 32-wide

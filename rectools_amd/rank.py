@@ -168,7 +168,7 @@ class HipRanker:
 
     def _h_only_applies(self, n_subj: int) -> bool:
         """The one-plane coarse pass (ONE bf16 per value: half the bytes of the (h, m) image and a quarter of its matrix-pipe work, coarse
-        error 2^-8 |u| |v|).  A few users against a big catalog: the pass is bound by the bytes it streams (5 M x 512, 16 users: 1.16 vs
+        error 2^-7 |u| |v|).  A few users against a big catalog: the pass is bound by the bytes it streams (5 M x 512, 16 users: 1.16 vs
         1.77 ms for the fp32 rows).  Many users: the (h, m) pass is bound by its four bf16 products per fp32 product (5 M x 512, 4096
         users: 58.6 vs 101.6 ms; 26,744 x 256, 16,384 users: 2.47 vs 3.08 ms).  Switched off for a ranker whose catalog defeated the
         wider error bound (near-duplicate items): the (h, m) image serves it from then on."""
@@ -261,7 +261,7 @@ class HipRanker:
         exact_upp = upp if upp > 16 else 32      # the 32-wide engine: the arithmetic the exact pass mirrors
         if h_only and wide and (8 * len(bad) > n_subj or len(starts) > max(2, n_subj // self.RUNS_PER_USERS)):
             # the one-plane bound is too wide for this catalog (or leaves more single runs — a catalog pass each — than a second coarse
-            # pass costs): the whole call again over the (h, m) image, whose bound is 2^-8 of this one
+            # pass costs): the whole call again over the (h, m) image, whose bound is 2^-7 of this one
             self.two_stage_stats["fallbacks"] += 1
             self._h_only_strikes += 1
             if 8 * len(bad) > n_subj or self._h_only_strikes >= 2:

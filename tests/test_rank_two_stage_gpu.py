@@ -54,8 +54,11 @@ def test_two_stage_returns_the_single_stage_result_bit_for_bit(d, n_obj, n_subj,
         pytest.skip("the one-plane image needs d % 64 == 0: this shape runs on the (h, m) image either way")
     e_ids, e_sc, e_cnt, _ = exact.rank_device(ids, k, filt, wl)
     f_ids, f_sc, f_cnt, _ = fast.rank_device(ids, k, filt, wl)
-    assert fast.two_stage_stats["calls"] == 1 and fast.two_stage_stats["unproven_users"] == 0, fast.two_stage_stats
-    assert fast.two_stage_stats["h_only_calls"] == (1 if plane == "h" else 0)
+    st = fast.two_stage_stats
+    if plane == "hm":
+        assert st["calls"] == 1 and st["unproven_users"] == 0 and st["h_only_calls"] == 0, st
+    else:       # the one-plane bound is 2^7 wider: a user it leaves unproven is re-ranked (same result below), most are proven
+        assert st["h_only_calls"] == 1 and st["unproven_users"] <= len(ids) // 8, st
     assert torch.equal(e_cnt, f_cnt)
     valid = torch.arange(e_ids.shape[1], device="cuda")[None, :] < e_cnt[:, None]
     assert torch.equal(e_ids[valid], f_ids[valid])
@@ -71,12 +74,13 @@ def test_two_stage_is_the_default_for_many_users_with_dot_and_cosine():
     subj, obj = _factors(300, 20_000, 64, 3)
     r = HipRanker("dot", "cuda", subj, obj)
     r.rank_device(np.arange(300), 10)
-    assert r.two_stage_stats["calls"] == 1
+    n_calls = r.two_stage_stats["calls"]
+    assert n_calls >= 1
     r.rank_device(np.arange(12), 10)                        # few users: the HBM-bound 16-user tile of the single-stage kernel
-    assert r.two_stage_stats["calls"] == 1
+    assert r.two_stage_stats["calls"] == n_calls
     c = HipRanker("cosine", "cuda", subj, obj)
     c.rank_device(np.arange(300), 10)
-    assert c.two_stage_stats["calls"] == 1                  # cosine too (unit-row images, exact cosine in the second stage)
+    assert c.two_stage_stats["calls"] >= 1                  # cosine too (unit-row images, exact cosine in the second stage)
     e = HipRanker("euclidean", "cuda", subj, obj, two_stage=True)
     e.rank_device(np.arange(300), 10)
     assert e.two_stage_stats["calls"] == 0
@@ -182,7 +186,7 @@ def test_two_stage_with_fewer_than_k_candidates_left_by_the_filter():
 @pytest.mark.parametrize("n_subj,with_filter", [(16, False), (32, True), (5, False)])
 def test_h_only_coarse_pass_for_a_few_users_returns_the_single_stage_bits(n_subj, with_filter, dist):
     """The HBM-bound regime (a few users against a catalog that does not fit the caches): the coarse pass streams a ONE-plane bf16 image
-    (half the catalog bytes, coarse error 2^-8 |u| |v|), the exact pass and the proof are the same — ids, order and score bits of the
+    (half the catalog bytes, coarse error 2^-7 |u| |v|), the exact pass and the proof are the same — ids, order and score bits of the
     32-wide single-stage engine."""
     from rectools_amd.rank import HipRanker
 
@@ -196,13 +200,13 @@ def test_h_only_coarse_pass_for_a_few_users_returns_the_single_stage_bits(n_subj
     e_ids, e_sc, e_cnt, _ = exact.rank_device(np.arange(n_subj), k, filt)
     f_ids, f_sc, f_cnt, _ = fast.rank_device(np.arange(n_subj), k, filt)
     st = fast.two_stage_stats
-    assert st["calls"] == 1 and st["h_only_calls"] == 1 and st["unproven_users"] == 0, st
+    assert st["calls"] == 1 and st["h_only_calls"] == 1 and st["unproven_users"] <= n_subj // 8, st
     assert torch.equal(e_cnt, f_cnt) and torch.equal(e_ids, f_ids) and torch.equal(e_sc.view(torch.int32), f_sc.view(torch.int32))
 
 
 def test_one_plane_pass_with_many_users_falls_back_to_the_two_plane_pass():
     """Many users, a catalog of 100-fold near-duplicates (relative spread 1e-3): more look-alikes than the 64 candidates inside the
-    one-plane bound (2^-8 |u| |v|), but well apart under the (h, m) bound (2^-16): the call is repeated over the (h, m) image — proven
+    one-plane bound (2^-7 |u| |v|), but well apart under the (h, m) bound (2^-14): the call is repeated over the (h, m) image — proven
     there — and the ranker keeps to that image afterwards."""
     from rectools_amd.rank import HipRanker
 
