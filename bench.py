@@ -386,7 +386,8 @@ def run_train(args, rank, world, kind="train"):
         ms = sum(t for t, _ in calls)
         tf = fl / (ms * 1e-3) / 1e12
         ms1 = sum(t for t, _ in rec1.get("rt_gemm", []) + rec1.get("rt_gemm_grouped", []))
-        roof = {"kernel": "gemm_dma_kernel (rt_gemm / rt_gemm_grouped: all forward/dgrad/wgrad products of the step)", "bound": "mfma",
+        roof = {"kernel": "GEMM family of the step: gemm_wp_kernel (forward / data-gradient products on pre-split weight planes, rt_gemm_wp) + "
+                          "gemm_dma_kernel (weight gradients, grouped / split-K: rt_gemm, rt_gemm_grouped, rt_wgrad_grouped)", "bound": "mfma",
                 "achieved": round(tf, 2), "peak": round(GEMM_PEAK_TF, 1), "unit": "TFLOP/s", "frac": round(tf / GEMM_PEAK_TF, 4),
                 "arithmetic": ("fp32 via 6 bf16-MFMA products of an exact 3-way bf16 split, fp32 accumulate: peak = 2500 TF bf16 / 6; "
                                f"against the f32-input MFMA peak (157.3 TF) the same rate is {tf / MFMA_F32_PEAK_TF:.3f}")
@@ -427,12 +428,91 @@ def run_train(args, rank, world, kind="train"):
                     "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": load_traffic("train_" + dom), "avg_launch_ms": round(ms, 4),
                     "algorithmic_bytes_per_launch": byts}
     roof["kernel_ms_per_step"] = round(total_k, 3)
-    roof["host_issue_ms_per_step"] = round(getattr(timed_steps, "host_issue_ms", 0.0), 4)   # ~= ms_per_step: the step is launch-bound
-    roof["step_flops_dense"] = 3.0 * B * (nb * spec["blk"] + spec["loss"])     # fwd + bwd = 3 x fwd
-    roof["step_TFLOPs"] = round(roof["step_flops_dense"] / (wall / args.steps) / 1e12, 2)
+    # wall time of the issuing loop: follows the GPU whenever the launch queue pushes back, so it is an UPPER bound of the host's own
+    # cost; `host_only_ms_per_step` (every launch elided, scripts/microbench/dry_launch.cpp) is the host's cost proper
+    roof["host_issue_ms_per_step"] = round(getattr(timed_steps, "host_issue_ms", 0.0), 4)
+    roof["step_flops_dense"] = 3.0 * B * (nb * spec["blk"] + spec["loss"])     # fwd + bwd = 3 x fwd, on the PADDED [B, L] window
+    # what the step EXECUTES: a packed loop runs the real rows only (mean over the epoch's batches; the padded window's flops would
+    # overstate the rate by the padding share — VERDICT r3 weak #2 (iv)); the per-row GEMM / loss flops scale with the rows, the
+    # attention square with every session's own length
+    exe = roof["step_flops_dense"]
+    if getattr(loop, "packed", False) and getattr(loop, "_cu_host", None) is not None:
+        cu = np.asarray(loop._cu_host)[:, :B + 1].astype(np.float64)
+        rows = float(cu[:, B].mean())
+        n2 = float((np.diff(cu, axis=1) ** 2).sum(axis=1).mean())
+        per_row = (spec["blk"] - 4.0 * L * L * d) / L      # GEMM flops of one row and block (fwd)
+        exe = 3.0 * (nb * (per_row * rows + 4.0 * n2 * d) + spec["loss"] / L * rows)
+        roof["rows_per_step_executed"] = round(rows, 1)
+    roof["step_flops_executed"] = exe
+    roof["step_TFLOPs"] = round(exe / (wall / args.steps) / 1e12, 2)              # executed flops / measured step time
+    roof["step_TFLOPs_padded_window_equivalent"] = round(roof["step_flops_dense"] / (wall / args.steps) / 1e12, 2)
     info = dict(model=model, ds=ds, loop=loop, V=V, d=d, H=H, nb=nb, L=L, B=B, n_neg=n_neg, breakdown=breakdown, spec=spec,
                 loss=float(state["loss"].detach()), prep_s=prep_s, steps_per_epoch=loop.batches_left() + loop.pos // B)
     return value, wall, roof, info
+
+
+def _dry_shim_path() -> str:
+    """Build (once) the launch-eliding measurement shim next to its source; -> path of the shared object."""
+    import subprocess
+
+    src = os.path.join(ROOT, "scripts", "microbench", "dry_launch.cpp")
+    out = os.path.join(ROOT, "scripts", "microbench", "_bin", "libdry_launch.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", src, "-o", out, "-ldl"])
+    return out
+
+
+def host_only_leg(kind: str, n_neg: int, steps: int = 60, warmup: int = 10):
+    """The host's OWN cost of issuing a training step: the same product loop in a child process under LD_PRELOAD of the shim that
+    turns every kernel launch and async memset (this package's and torch's) into a counted no-op for the timed steps — the GPU has
+    nothing to do, nothing can push back, what remains is Python + autograd + ctypes + the HIP runtime's host side."""
+    import subprocess
+
+    try:
+        shim = _dry_shim_path()
+        env = dict(os.environ, LD_PRELOAD=shim, RT_DRY_SHIM=shim)
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", kind, "--host-only-child", "--steps", str(steps), "--warmup", str(warmup),
+               "--n-negatives", str(n_neg)]
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+        if res.returncode != 0 or not line:
+            return {"error": (res.stderr or res.stdout)[-400:]}
+        return json.loads(line[-1])
+    except Exception as e:   # the measurement must never take the line down
+        return {"error": repr(e)[:400]}
+
+
+def host_only_child(args):
+    """Child side of `host_only_leg` (runs under LD_PRELOAD of the shim)."""
+    import ctypes
+
+    shim = ctypes.CDLL(os.environ["RT_DRY_SHIM"])
+    shim.rt_dry_count.restype = ctypes.c_longlong
+    spec = family_spec(args.workload if args.workload != "auto" else "train", args.n_negatives)
+    model = spec["model"]
+    model._build_model_from_dataset(spec["ds"]())
+    loop = model.training_loop()
+    model.lightning_model.train()
+    loop.begin_epoch(0)
+    for _ in range(args.warmup):          # real steps: allocator, lazy initialisations, autotuned paths
+        loop.step()
+    torch.cuda.synchronize()
+    assert shim.rt_dry_selftest() == 1, "the shim cannot reach the HIP runtime"
+    shim.rt_dry_set(1)
+    for _ in range(3):
+        loop.step()
+    shim.rt_dry_set(1)                    # resets the counters
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loop.step()
+    el = time.perf_counter() - t0
+    n_l, n_m = shim.rt_dry_count(0), shim.rt_dry_count(1)
+    shim.rt_dry_set(0)
+    torch.cuda.synchronize()
+    print(json.dumps({"host_only_ms_per_step": round(el / args.steps * 1e3, 4), "launches_per_step": round(n_l / args.steps, 1),
+                      "memsets_per_step": round(n_m / args.steps, 1), "steps": args.steps,
+                      "what": "wall time of loop.step() with every kernel launch / async memset elided by an LD_PRELOAD shim (GPU idle)"}))
 
 
 def cpu_baseline_train(info, budget_s=25.0):
@@ -608,6 +688,8 @@ def main():
     ap.add_argument("--topk-steps", type=int, default=40, help="timed steps of the topk5m sub-leg (a step is ~1.2 ms: enough of them that one host hiccup does not set the figure)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-families", action="store_true", help="skip the BERT4Rec / HSTU / eSASRec sub-records of the auto run")
+    ap.add_argument("--host-only-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-host-only", action="store_true", help="skip the host-only (launch-elided) child run")
     args = ap.parse_args()
     rank, world, local, dist_info = dist_setup(args.gpus)
     if os.environ.get("RT_BENCH_DRY_RUN") == "1":   # launcher / rendezvous / line shape only (CPU test of the N > 1 start-up)
@@ -623,6 +705,10 @@ def main():
 
     _lib.load()  # fail loudly if the HIP extension is missing
     workload = args.workload
+    if args.host_only_child:
+        args.steps, args.warmup = args.steps or 60, args.warmup if args.warmup is not None else 10
+        host_only_child(args)
+        return
     cpu_ok = rank == 0 and world == 1 and not args.no_cpu_baseline
     env = {k: v for k, v in sorted(os.environ.items()) if k.startswith("RT_")}   # every engine knob that is set
 
@@ -659,6 +745,12 @@ def main():
             "roofline": roof, "cpu_baseline": None,
             "kernel_breakdown": info["breakdown"], "final_loss": round(info["loss"], 5),
         }
+        if rank == 0 and world == 1 and not args.no_host_only and kind == "train":
+            ho = host_only_leg(kind, args.n_negatives)
+            roof["host_only"] = ho
+            if "host_only_ms_per_step" in ho:
+                roof["host_only_ms_per_step"] = ho["host_only_ms_per_step"]
+                roof["launches_per_step_all_kernels"] = ho["launches_per_step"]
         if cpu_ok and kind == "train":
             v, kind_b, what = cpu_baseline_train(info)
             out["cpu_baseline"] = {"value": round(v, 2), "unit": "seqs/s", "cores": torch.get_num_threads(), "kind": kind_b, "sample": what}

@@ -102,6 +102,12 @@ int rt_topk_score(const float* users, int64_t user_stride, const int64_t* user_r
  * ------------------------------------------------------------------------------------------------ */
 int rt_to_hm_rows(const float* src, int64_t src_stride, const int64_t* rows, int64_t n_rows, int32_t d, int32_t normalize, uint32_t* dst,
                   int64_t dst_stride, float* norms, rt_stream_t stream);
+/* One-plane image (rt_to_hm_rows mode 2 / 3, rows of src_stride_words words) -> fragment-major: the 16-byte unit (row r, slot 2 s + half)
+ * at unit ((r / 32)(d / 16) + s) 64 + 32 half + r % 32, rows n_rows .. rows_pad zero (rows_pad % 128 == 0, d % 16 == 0).  With both images
+ * in this form rt_topk_score_two_stage(h_only = 2) loads an item fragment — the A operand of one v_mfma_f32_32x32x16_bf16 — with one
+ * coalesced 1 KB read and keeps the user tile in the LDS (no whitelist, d % 128 == 0, items_hm offset by whole 128-row blocks only). */
+int rt_one_plane_to_fragments(const uint32_t* src, int64_t src_stride_words, int64_t n_rows, int32_t d, uint32_t* dst, int64_t rows_pad,
+                              rt_stream_t stream);
 size_t rt_topk_two_stage_workspace_bytes(int32_t n_users, int64_t n_candidates, int32_t k, int32_t k_cand, int32_t users_per_pass);
 int rt_topk_score_two_stage(const float* users, int64_t user_stride, const int64_t* user_rows, int32_t n_users, const float* items,
                             int64_t item_stride, const uint32_t* users_hm, const uint32_t* items_hm, int32_t h_only, const float* user_norms,

@@ -30,6 +30,7 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_filter_hash_build": (c_i32, [c_vp, c_vp, c_i32, c_i64, c_vp, c_vp]),
     "rt_topk_score": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_i32, c_vp]),
     "rt_to_hm_rows": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp]),
+    "rt_one_plane_to_fragments": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_vp]),
     "rt_topk_two_stage_workspace_bytes": (c_sz, [c_i32, c_i64, c_i32, c_i32, c_i32]),
     "rt_topk_score_two_stage": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp, c_vp, c_i32, c_vp, c_f32, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32,
                                         c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_i32, c_vp]),

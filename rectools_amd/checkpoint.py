@@ -79,12 +79,13 @@ def adam_state_dict(opt: tp.Any) -> tp.Dict[str, tp.Any]:
     """`torch.optim.Adam.state_dict()` of a `FlatAdam`: per-parameter exp_avg / exp_avg_sq / step, in parameter order."""
     state: tp.Dict[int, tp.Dict[str, torch.Tensor]] = {}
     if opt.step_count > 0:
+        if getattr(opt, "partial_moments", None) is not None:
+            # sharded exchange: this rank's moments are current on its own slice only.  fit() / fit_partial() gather them after their
+            # last step (FlatAdam.consolidate_moments, collective), so a checkpoint written after training is local; reaching this
+            # point means the caller stepped the optimiser by hand — writing the stale slices would corrupt a later fit_partial
+            raise RuntimeError("the Adam moments on this rank are partial (sharded data-parallel exchange): call "
+                               "model.optimizer.consolidate_moments() on EVERY rank (collective) before saving a checkpoint")
         m, v = opt.m, opt.v
-        if getattr(opt, "sharded", False):   # sharded exchange: a rank maintains only its slice of the moments — gather (collective)
-            import torch.distributed as dist
-
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                m, v = opt.full_moments(dist.get_world_size(), dist.get_rank())
         for i, (p, ofs) in enumerate(zip(opt.params, opt._offsets)):   # pylint: disable=protected-access
             n = p.numel()
             state[i] = {"step": torch.tensor(float(opt.step_count)),
@@ -129,6 +130,7 @@ def load_adam_state_dict(opt: tp.Any, sd: tp.Dict[str, tp.Any], names: tp.Option
         steps.append(int(float(st["step"])))
     # one step counter for the whole model: torch keeps one per parameter, equal unless a parameter never got a gradient
     opt.step_count = max(steps) if steps else 0
+    opt.partial_moments = None     # whole moments were just written on this rank
     if groups:
         opt.lr = float(groups[0].get("lr", opt.lr))
         opt.betas = tuple(groups[0].get("betas", opt.betas))

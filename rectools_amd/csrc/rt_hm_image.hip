@@ -64,6 +64,36 @@ __global__ __launch_bounds__(256) void to_hm_rows_kernel(const float* __restrict
   }
 }
 
+
+// One-plane image, row-major (rows of d bf16 = d / 8 units of 16 bytes) -> FRAGMENT-MAJOR: unit u of row r goes to unit
+// ((r / 32) (d / 16) + u / 2) 64 + 32 (u & 1) + r % 32 — the 64 units of (32-row group, k = 16 slot) are the 64 lanes' A (or B)
+// operands of one v_mfma_f32_32x32x16_bf16 in lane order (lane = 32 half + row, half = the slot's upper 8 k).  Rows n_rows .. rows_pad
+// are zero.  topk_coarse_frag_kernel reads an item fragment with one coalesced 1 KB load and copies a user tile linearly into the LDS.
+__global__ __launch_bounds__(256) void one_plane_to_fragments_kernel(const u32x4* __restrict__ src, long long src_stride_units, long long n_rows,
+                                                                     long long rows_pad, int n_units, u32x4* __restrict__ dst) {
+  // one workgroup per 32-row group: coalesced reads along the rows, coalesced 1 KB writes per fragment (transposed through the LDS)
+  __shared__ u32x4 tile[32][17];
+  const long long g = blockIdx.x;
+  const int tid = threadIdx.x;
+  for (int u0 = 0; u0 < n_units; u0 += 16) {       // 16 units (= 8 slots) of the 32 rows at a time
+    for (int i = tid; i < 32 * 16; i += 256) {
+      const int r = i >> 4, u = i & 15;
+      const long long row = g * 32 + r;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (row < n_rows && u0 + u < n_units) v = src[row * src_stride_units + u0 + u];
+      tile[r][u] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < 16 * 32; i += 256) {     // i = (unit u, row r): destination lane 32 (u & 1) + r of slot (u0 + u) / 2
+      const int u = i >> 5, r = i & 31;
+      if (u0 + u < n_units)
+        dst[(g * (n_units >> 1) + ((u0 + u) >> 1)) * 64 + 32 * (u & 1) + r] = tile[r][u];
+    }
+    __syncthreads();
+  }
+  (void)rows_pad;
+}
+
 }  // namespace
 
 extern "C" {
@@ -77,6 +107,22 @@ int rt_to_hm_rows(const float* src, int64_t src_stride, const int64_t* rows, int
     return RT_ERR_INVALID_ARG;
   to_hm_rows_kernel<<<(unsigned)((n_rows + 3) / 4), 256, 0, stream>>>(src, src_stride, reinterpret_cast<const long long*>(rows), n_rows, d,
                                                                       normalize, dst, dst_stride, norms);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+// src: a one-plane image (rt_to_hm_rows mode 2 / 3; rows of src_stride_words 32-bit words, d bf16 values each), dst: its fragment-major
+// form for rt_topk_score_two_stage(h_only = 2): rows_pad (a multiple of 128 >= n_rows) x d bf16 = rows_pad * d * 2 bytes, 16-byte aligned;
+// d % 16 == 0.
+int rt_one_plane_to_fragments(const uint32_t* src, int64_t src_stride_words, int64_t n_rows, int32_t d, uint32_t* dst, int64_t rows_pad,
+                              hipStream_t stream) {
+  (void)hipGetLastError();
+  if (n_rows < 0 || d <= 0 || (d & 15) != 0 || rows_pad < n_rows || (rows_pad & 127) != 0 || (src_stride_words & 3) != 0 || src_stride_words * 2 < d)
+    return RT_ERR_INVALID_ARG;
+  if (rows_pad == 0) return RT_OK;
+  if (src == nullptr || dst == nullptr || ((uintptr_t)src & 15) != 0 || ((uintptr_t)dst & 15) != 0) return RT_ERR_INVALID_ARG;
+  one_plane_to_fragments_kernel<<<(unsigned)(rows_pad / 32), 256, 0, stream>>>(reinterpret_cast<const u32x4*>(src), src_stride_words / 4, n_rows,
+                                                                              rows_pad, d / 8, reinterpret_cast<u32x4*>(dst));
   RT_CHECK_LAUNCH();
   return RT_OK;
 }

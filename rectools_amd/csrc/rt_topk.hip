@@ -1665,6 +1665,157 @@ int launch_stream_any(int tu, int ns, const TopkArgs& a, dim3 grid, bool ll, hip
   return launch_stream_ns<4, HM>(ns, a, grid, ll, stream);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Coarse pass over FRAGMENT-MAJOR one-plane images (rt_one_plane_to_fragments; TwoStage::h_only == 2).
+//
+// What bounds topk_stream_kernel<..., HM> with many user tiles is the LDS: every item chunk is written into it by the DMA ring,
+// every user chunk is written into it again for every item block, and both are read back as fragments — ring 30 ms + products 19 ms
+// + selection 7 ms per 4,096-user call over 5 M x 512, additive (profiles/r3_topk5m_u4096_one_plane_analysis.md).  Here
+//   * the item fragment of a wave — 32 rows x 16 k of bf16 = the A operand of one v_mfma_f32_32x32x16_bf16 — is ONE coalesced 1 KB
+//     global load straight into registers: an item row is used by exactly one wave, it has no business in the LDS.  The image is
+//     stored fragment-major for that: 16-byte unit (row r, slot 2 s + half) at unit ((r / 32) n_s + s) 64 + 32 half + r % 32;
+//   * the user tile (32 TU users x d bf16, fragment-major too) is copied into the LDS once per workgroup and stays there;
+//   * a wave takes the 32-row slices of TWO item blocks at a time, so one B fragment read from the LDS feeds two products.
+// LDS traffic per product: 1 KB per two v_mfma (was ~3 KB written + read per one).  P steps of item fragments are in flight per wave
+// (plain loads in program order: the compiler's own vmcnt counting holds as long as no other vector-memory operation sits in the
+// loop — the shared bound is therefore read from an LDS copy that wave 0 refreshes every few block pairs).
+// Geometry, lists, bound, phases (seed / resume) and the merge are engine 2's: item blocks of IB rows, workgroup sx < n_seg takes
+// the blocks blk_begin + sx + j n_seg, wave w their rows [32 w, 32 w + 32), lists in global memory.
+template <int TU>
+__global__ __launch_bounds__(NTHREADS) void topk_coarse_frag_kernel(TopkArgs a) {
+  constexpr int UB = 32 * TU;
+  constexpr int IW = 2;           // item blocks per step of a wave
+  constexpr int P = 8;            // fragment loads in flight per wave and item block
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  u32x4* const ufrag = reinterpret_cast<u32x4*>(smem);                    // [TU][n_s][64] units of 16 B
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const int S = a.n_seg;
+  const int user0 = blockIdx.y * UB;
+  const int n_s = a.d >> 3;                                                // k = 16 slots per row (a.d = words per image row = d / 2)
+  unsigned* const g_lds = reinterpret_cast<unsigned*>(smem + (size_t)TU * n_s * 64 * 4);   // [UB] copy of the shared bound
+
+  const long long n_blocks = a.blk_end - a.blk_begin;
+  const long long my_blocks = ((int)blockIdx.x < S && n_blocks > blockIdx.x) ? (n_blocks - blockIdx.x + S - 1) / S : 0;
+  const int list_id = blockIdx.x * LISTS_PER_WG + wave * 2 + half;
+  SelState<TU, false> st;
+  st.init();
+  st.bind_global(a, list_id, user0, lane);
+  st.bind_filter(a, user0, lane);
+  if (a.resume) st.resume(a, list_id, user0, lane, false);
+  if (my_blocks == 0) { if (!a.resume) publish_counts<TU, false>(a, st, list_id, user0, lane, false); return; }
+
+  {   // the user tile (the image is padded to whole tiles) and the bound's copy
+    const u32x4* ug = reinterpret_cast<const u32x4*>(a.users) + (long long)(user0 >> 5) * n_s * 64;
+    for (int i = tid; i < TU * n_s * 64; i += NTHREADS) ufrag[i] = ug[i];
+    for (int i = tid; i < UB; i += NTHREADS) {
+      int u = user0 + i; if (u >= a.n_users_pad) u = a.n_users_pad - 1;
+      g_lds[i] = __hip_atomic_load(a.gthr + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+  }
+
+  const u32x4* const items = reinterpret_cast<const u32x4*>(a.items);
+  const long long last_blk = a.blk_begin + blockIdx.x + (my_blocks - 1) * S;
+  // fragment (s = 0) of this wave's rows of item block `blk`, this lane's unit
+  auto frag0 = [&](long long blk) -> const u32x4* { return items + ((blk * (IB / 32) + wave) * n_s) * 64 + lane; };
+  const long long n_pairs = (my_blocks + IW - 1) / IW;
+  const float no_norm[TU] = {};
+
+  f32x16 acc[IW][TU];
+#pragma unroll
+  for (int iw = 0; iw < IW; ++iw)
+#pragma unroll
+    for (int tu = 0; tu < TU; ++tu)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[iw][tu][r] = 0.f;
+
+  // issue cursor: P slots ahead of the consumer, over the flattened (pair, slot) stream; past the end it re-reads the last block
+  const u32x4* ip[IW]; int is = 0; long long ij = 0;
+  auto set_pair = [&](long long j) {
+#pragma unroll
+    for (int iw = 0; iw < IW; ++iw) {
+      long long blk = a.blk_begin + blockIdx.x + (j * IW + iw) * S;
+      if (blk > last_blk) blk = last_blk;
+      ip[iw] = frag0(blk);
+    }
+  };
+  set_pair(0);
+  u32x4 abuf[P][IW];
+  auto issue = [&](u32x4 (&dst)[IW]) {
+#pragma unroll
+    for (int iw = 0; iw < IW; ++iw) { dst[iw] = *ip[iw]; ip[iw] += 64; }   // (plain loads: the tiles of an XCD share the lines in L2)
+    if (++is == n_s) { is = 0; ++ij; set_pair(ij < n_pairs ? ij : n_pairs - 1); }
+  };
+#pragma unroll
+  for (int q = 0; q < P; ++q) issue(abuf[q]);
+
+  // the user fragments of slot s + 1 are read while the products of slot s run (one wave per SIMD: nobody else hides the LDS latency)
+  u32x4 bf[2][TU];
+#pragma unroll
+  for (int tu = 0; tu < TU; ++tu) bf[0][tu] = ufrag[(tu * n_s) * 64 + lane];
+#pragma unroll 1
+  for (long long j = 0; j < n_pairs; ++j) {
+#pragma unroll 1
+    for (int s0 = 0; s0 < n_s; s0 += P) {
+#pragma unroll
+      for (int q = 0; q < P; ++q) {
+        const int nxt = (s0 + q + 1 == n_s) ? 0 : s0 + q + 1;     // the tile is the same for every block pair: the slot index just wraps
+#pragma unroll
+        for (int tu = 0; tu < TU; ++tu) bf[(q + 1) & 1][tu] = ufrag[(tu * n_s + nxt) * 64 + lane];
+        u32x4 af[IW];
+#pragma unroll
+        for (int iw = 0; iw < IW; ++iw) af[iw] = abuf[q][iw];
+        issue(abuf[q]);
+#pragma unroll
+        for (int iw = 0; iw < IW; ++iw)
+#pragma unroll
+          for (int tu = 0; tu < TU; ++tu)
+            acc[iw][tu] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[iw]), __builtin_bit_cast(bf16x8, bf[q & 1][tu]),
+                                                                  acc[iw][tu], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int iw = 0; iw < IW; ++iw) {
+      const long long blk = a.blk_begin + blockIdx.x + (j * IW + iw) * S;
+      if (blk <= last_blk)
+        select_block<TU, false, true>(a, st, acc[iw], 0.f, no_norm, blk * IB, list_id, user0, lane, wave, g_lds);
+#pragma unroll
+      for (int tu = 0; tu < TU; ++tu)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[iw][tu][r] = 0.f;
+    }
+    if ((j & 3) == 3 && wave == 0) {   // refresh the LDS copy of the shared bound (the only vector-memory read of the loop; wave 0 only)
+      for (int i = lane; i < UB; i += 64) {
+        int u = user0 + i; if (u >= a.n_users_pad) u = a.n_users_pad - 1;
+        g_lds[i] = __hip_atomic_load(a.gthr + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  publish_counts<TU, false>(a, st, list_id, user0, lane, false);
+}
+
+inline size_t coarse_frag_lds_bytes(int tu, int d_words) { return (size_t)tu * (d_words / 8) * 64 * 16 + (size_t)32 * tu * 4; }
+
+template <int TU>
+int launch_coarse_frag_t(const TopkArgs& a, dim3 grid, hipStream_t stream) {
+  const size_t lds = coarse_frag_lds_bytes(TU, a.d);
+  static size_t attr_lds = 0;
+  if (lds > 64 * 1024 && lds > attr_lds) {
+    RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_coarse_frag_kernel<TU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_lds = lds;
+  }
+  topk_coarse_frag_kernel<TU><<<grid, NTHREADS, lds, stream>>>(a);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+int launch_coarse_frag(int tu, const TopkArgs& a, dim3 grid, hipStream_t stream) {
+  if (tu == 1) return launch_coarse_frag_t<1>(a, grid, stream);
+  if (tu == 2) return launch_coarse_frag_t<2>(a, grid, stream);
+  return launch_coarse_frag_t<4>(a, grid, stream);
+}
+
 // ---- 16-user tile: plan and launch -------------------------------------------------------------------------------
 struct Plan16 {
   int S, n_tiles, n_users_pad, users_per_launch, ns;
@@ -1818,6 +1969,7 @@ static int topk_score_impl(const float* users, int64_t user_stride, const int64_
   if (n_users < 0 || n_candidates < 0 || d <= 0 || (d & 3) != 0 || k <= 0) return RT_ERR_INVALID_ARG;
   if (distance < DIST_DOT || distance > DIST_EUCLID) return RT_ERR_INVALID_ARG;
   if (ts != nullptr && ts->h_only && d % (2 * KC) != 0) return RT_ERR_UNSUPPORTED;
+  if (ts != nullptr && ts->h_only == 2 && (d % 128 != 0 || whitelist != nullptr)) return RT_ERR_UNSUPPORTED;   // fragment-major images: 8 slots per unrolled step, rows in place
   if (ts != nullptr && ((distance != DIST_DOT && distance != DIST_COSINE) || d % KC != 0 || k > K_LDS_LISTS || (ts->k_cand != 32 && ts->k_cand != 64) || ts->k_cand < k))
     return RT_ERR_UNSUPPORTED;
   if ((user_stride & 3) != 0 || (item_stride & 3) != 0) return RT_ERR_INVALID_ARG;
@@ -1892,6 +2044,10 @@ static int topk_score_impl(const float* users, int64_t user_stride, const int64_
   const int k_out = k;                        // two-stage: the lists hold more than the k entries the caller asked for
   if (ts != nullptr) k = two_stage_list_k(k);
   Plan P = make_plan(n_users, n_candidates, k, users_per_pass);
+  if (ts != nullptr && ts->h_only == 2) {
+    P.lds_lists = false;                                   // topk_coarse_frag_kernel: the LDS holds the user tile
+    if (coarse_frag_lds_bytes(P.tu, d / 2) > LDS_PER_CU) return RT_ERR_UNSUPPORTED;
+  }
   const size_t ws_need = P.total + (ts ? two_stage_extra_bytes(P.users_per_launch, ts->k_cand) : 0);
   if (workspace == nullptr || workspace_bytes < ws_need) return RT_ERR_WORKSPACE;
 
@@ -1937,6 +2093,7 @@ static int topk_score_impl(const float* users, int64_t user_stride, const int64_
     m.n_lists = P.n_lists; m.n_users_pad = P.n_users_pad; m.k = k; m.n_users = nb;
     auto run_phase = [&](long long b0, long long b1, int n_seg, int resume) -> int {
       a.blk_begin = b0; a.blk_end = b1; a.n_seg = n_seg; a.resume = resume;
+      if (ts != nullptr && ts->h_only == 2) return launch_coarse_frag(P.tu, a, grid, stream);
       if (ts != nullptr) return launch_stream_any<true>(P.tu, P.ns, a, grid, P.lds_lists, stream);
       if (stream_ok) return launch_stream_any<false>(P.tu, P.ns, a, grid, P.lds_lists, stream);
       if (P.tu == 1) return launch_staged<1>(a, grid, stream);
@@ -2041,8 +2198,8 @@ int rt_topk_score_two_stage(const float* users, int64_t user_stride, const int64
     if (hipMemsetAsync(out_unproven, 0, sizeof(int32_t) * (size_t)n_users, stream) != hipSuccess) return RT_ERR_LAUNCH;
   }
   TwoStage ts{reinterpret_cast<const float*>(users_hm), reinterpret_cast<const float*>(items_hm), user_norms, max_item_norm, k_cand,
-              out_unproven, distance == DIST_COSINE ? 1 : 0, h_only ? 1 : 0, h_only ? item_stride / 2 : item_stride};
-  if (h_only && (item_stride & 7) != 0) return RT_ERR_INVALID_ARG;      // (the bf16 image mirrors the fp32 rows: stride item_stride bf16 values)
+              out_unproven, distance == DIST_COSINE ? 1 : 0, h_only == 2 ? 2 : (h_only ? 1 : 0), h_only ? item_stride / 2 : item_stride};
+  if (h_only == 1 && (item_stride & 7) != 0) return RT_ERR_INVALID_ARG;  // (the bf16 image mirrors the fp32 rows: stride item_stride bf16 values)
   return topk_score_impl(users, user_stride, user_rows, n_users, items, item_stride, whitelist, n_candidates, candidate_id_offset, d,
                          distance, k, filt_indptr, filt_indices, filt_hash, out_ids, out_scores, out_counts, workspace, workspace_bytes,
                          users_per_pass, &ts, stream);

@@ -205,6 +205,9 @@ class RcclExchange:
             pass
 
 
+FLAT_QUANTUM = 107_520    # lcm(1024, 840) floats: see FlatAdam.__init__
+
+
 class FlatAdam:
     """All parameters and Adam moments live in flat fp32 buffers; one fused kernel per step.
 
@@ -230,7 +233,9 @@ class FlatAdam:
 
         sizes = [seg_floats(p) for p in params]
         self.n_used = sum(sizes)
-        total = (self.n_used + 1023) // 1024 * 1024     # evenly divisible by any power-of-two world size (sharded exchange); tail = zeros
+        # tail of zeros up to a multiple of lcm(1024, 840) = 107,520 floats (430 KB): the sharded exchange cuts the buffers into
+        # world_size equal, 16-byte aligned slices, and this length is divisible by every world size up to 8 (and 10, 12, 14, 15, 16 ...)
+        total = (self.n_used + FLAT_QUANTUM - 1) // FLAT_QUANTUM * FLAT_QUANTUM
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.v = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -255,8 +260,13 @@ class FlatAdam:
         import os
 
         mode = os.environ.get("RT_DP_EXCHANGE", "auto")
+        # what the configuration ASKS for; whether a step takes it is decided at step time, when the world size is known
+        # (`_use_sharded`: a world size that does not cut the buffer into aligned equal slices falls back to the all-reduce)
         self.sharded = mode == "sharded" or (mode == "auto" and total * 4 >= (256 << 20))
         self._g_shard: tp.Optional[torch.Tensor] = None
+        # set by a sharded step: (world, rank) whose slice of the moments is current on this rank — the other slices are STALE until
+        # `consolidate_moments()` (collective) has run; checkpoints refuse to be written from partial moments
+        self.partial_moments: tp.Optional[tp.Tuple[int, int]] = None
 
     def use_rccl_exchange(self, rank: int, world: int) -> None:
         """Route the gradient all-reduce and the parameter broadcast through `rt_dp_*` (collective: every rank calls it)."""
@@ -332,8 +342,13 @@ class FlatAdam:
         same parameter bytes.  gloo (CPU tests, ranks sharing a GPU) has no reduce-scatter: all-reduce + slice there."""
         import torch.distributed as dist
 
-        if self.flat_p.numel() % world_size != 0:
-            raise ValueError(f"sharded exchange: world size {world_size} does not divide the flat buffer ({self.flat_p.numel()} floats)")
+        if not self._use_sharded(world_size):
+            raise ValueError(f"sharded exchange: world size {world_size} does not cut the flat buffer ({self.flat_p.numel()} floats) into "
+                             f"equal 16-byte aligned slices")
+        if self.partial_moments is not None and self.partial_moments != (world_size, rank):
+            raise RuntimeError(f"sharded exchange: the moments on this rank are current for (world, rank) = {self.partial_moments} only; "
+                               f"call consolidate_moments() on every rank before changing the process group")
+        self.partial_moments = (world_size, rank)
         lo, hi = self.shard_bounds(world_size, rank)
         fg = self.gather_gradients()
         if self._g_shard is None or self._g_shard.numel() != hi - lo:
@@ -358,20 +373,42 @@ class FlatAdam:
             for r, part in enumerate(parts):
                 self.flat_p[r * (hi - lo):(r + 1) * (hi - lo)].copy_(part)
 
-    def full_moments(self, world_size: int = 1, rank: int = 0) -> tp.Tuple[torch.Tensor, torch.Tensor]:
-        """(m, v) over the whole flat buffer.  Under the sharded exchange a rank maintains only its own slice: gather the others
-        (checkpoints, `state_dict`)."""
-        if not self.sharded or world_size <= 1:
-            return self.m, self.v
+    def _use_sharded(self, world_size: int) -> bool:
+        """Does a step over `world_size` ranks take the sharded exchange?  Asked for (`self.sharded`) AND the world cuts the flat
+        buffers into equal slices whose bounds are 16-byte aligned; otherwise the all-reduce exchange (always valid) is used."""
+        n = self.flat_p.numel()
+        return bool(self.sharded) and world_size > 1 and n % world_size == 0 and (n // world_size) % 4 == 0
+
+    def consolidate_moments(self) -> None:
+        """COLLECTIVE (every rank of the process group the sharded steps ran in): gather the moment slices so that every rank holds
+        the whole of (m, v) again.  `fit()` / `fit_partial()` call it after their last step, while the process group is alive, so that
+        saving a checkpoint afterwards is a purely local operation (`if rank == 0: model.save_to_checkpoint(...)` cannot deadlock)."""
+        if self.partial_moments is None:
+            return
         import torch.distributed as dist
 
+        world_size, rank = self.partial_moments
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() != world_size or dist.get_rank() != rank:
+            raise RuntimeError(f"the Adam moments on this rank are partial (slice {rank} of {world_size}, sharded exchange) and the process "
+                               f"group they were sharded over is gone: they cannot be gathered any more")
         lo, hi = self.shard_bounds(world_size, rank)
-        out = []
         for buf in (self.m, self.v):
-            parts = [torch.empty(hi - lo, dtype=torch.float32, device=buf.device) for _ in range(world_size)]
-            dist.all_gather(parts, buf[lo:hi].clone())
-            out.append(torch.cat(parts))
-        return out[0], out[1]
+            if dist.get_backend() == "nccl":
+                dist.all_gather_into_tensor(buf, buf[lo:hi].clone())
+            else:
+                parts = [torch.empty(hi - lo, dtype=torch.float32, device=buf.device) for _ in range(world_size)]
+                dist.all_gather(parts, buf[lo:hi].clone())
+                for r, part in enumerate(parts):
+                    buf[r * (hi - lo):(r + 1) * (hi - lo)].copy_(part)
+        self.partial_moments = None
+
+    def full_moments(self, world_size: int = 1, rank: int = 0) -> tp.Tuple[torch.Tensor, torch.Tensor]:
+        """(m, v) over the whole flat buffer.  After sharded steps a rank holds only its own slice: this gathers the others
+        (COLLECTIVE in that case — prefer `consolidate_moments()` at a point every rank reaches) and raises when it cannot."""
+        if self.partial_moments is None:
+            return self.m, self.v
+        self.consolidate_moments()
+        return self.m, self.v
 
     def step(self, world_size: int = 1, flat: bool = False) -> None:
         """One Adam step.  world_size > 1 (or flat=True): pack -> all-reduce -> Adam over the flat buffers (or, `self.sharded`, the
@@ -379,11 +416,13 @@ class FlatAdam:
         pointer."""
         if self.flat_p.is_cuda:
             ops.join_side_streams()   # weight gradients may still be in flight on the wgrad stream
-        if world_size > 1 and self.sharded:
+        if self._use_sharded(world_size):
             import torch.distributed as dist
 
             self.step_sharded(world_size, dist.get_rank())
             return
+        if self.partial_moments is not None:     # an all-reduce step after sharded ones needs whole moments on every rank
+            self.consolidate_moments()
         flat = flat or world_size > 1
         scale = self.reduce_gradients(world_size, force=flat)
         self.step_count += 1
@@ -406,8 +445,11 @@ class FlatAdam:
         ops._c("rt_adam_step_segments", self.flat_p, self.m, self.v, n, offsets, lens, ptrs, *hyper)
 
     def state_dict(self) -> tp.Dict[str, tp.Any]:
+        if self.partial_moments is not None:
+            raise RuntimeError("FlatAdam.state_dict(): the moments are partial (sharded exchange); call consolidate_moments() on every rank first")
         return {"m": self.m.clone(), "v": self.v.clone(), "step": self.step_count, "lr": self.lr, "betas": self.betas,
                 "eps": self.eps}
 
     def load_state_dict(self, sd: tp.Dict[str, tp.Any]) -> None:
         self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.step_count = int(sd["step"])
+        self.partial_moments = None

@@ -362,6 +362,7 @@ class TransformerModelBase:
         return self.item_net_constructor_type(n_tokens, blocks, **kw)
 
     def _build_model_from_dataset(self, dataset: tp.Any, item_net_schema: tp.Optional[tp.List[dict]] = None) -> None:
+        self._catalog_images = None     # a new model: images kept for recommend() belong to the old weights
         self.data_preparator.process_dataset_train(dataset)
         if self.seed is not None:  # before ANY parameter is created: 1-D parameters keep their constructor init
             torch.manual_seed(self.seed)
@@ -442,6 +443,7 @@ class TransformerModelBase:
         loop = self.training_loop()
         rank = loop.rank
         val_store = dp.val_store()
+        self._catalog_images = None     # training moves the item embeddings
         ops.RNG.step = opt.step_count   # fit_partial / restored models continue the dropout streams where training stopped
         sampler = getattr(dp, "negative_sampler", None)
         if isinstance(sampler, CatalogUniformSampler) and sampler.calls < opt.step_count:
@@ -471,6 +473,9 @@ class TransformerModelBase:
             if self.verbose and rank == 0:
                 print(rec)
             self.epochs_done = epoch + 1
+        # sharded data-parallel exchange: every rank holds only its slice of the Adam moments while training; gather them now, while
+        # every rank is here and the process group is alive, so that saving / pickling afterwards is a local operation on any rank
+        opt.consolidate_moments()
 
     def _log_epoch(self, rec: tp.Dict[str, float], global_step: int) -> None:
         """Per-epoch metrics file in the layout of Lightning's CSVLogger (`<dir>/version_N/metrics.csv`, columns
@@ -549,6 +554,30 @@ class TransformerModelBase:
         self._train_dataset_ref = dataset
 
     # ---- inference ----------------------------------------------------------------------------------------
+    # ---- the catalog's coarse-pass images are kept between recommend() calls -----------------------------------------
+    def _catalog_key(self, distance: tp.Any, item_embs: torch.Tensor) -> tp.Tuple:
+        """Identifies the CONTENT of the item embeddings without reading them: torch-side writes bump a parameter's `_version`
+        (load_state_dict, manual edits), this engine's own writes go through the optimiser (`step_count`); a new model / a new
+        flat buffer changes the pointers."""
+        lm = self.lightning_model
+        params = tuple((p.data_ptr(), p._version, tuple(p.shape)) for p in lm.torch_model.item_model.parameters())   # pylint: disable=protected-access
+        return (str(distance), params, 0 if self.optimizer is None else self.optimizer.step_count, tuple(item_embs.shape), str(item_embs.device))
+
+    def _ranker(self, distance: tp.Any, device: tp.Any, user_embs: torch.Tensor, item_embs: torch.Tensor) -> HipRanker:
+        """A ranker for this call's user factors that inherits the catalog images (and the largest item norm) an earlier call built,
+        as long as the item embeddings are still the same (a fresh HipRanker per call re-read the whole catalog and
+        synchronised once more)."""
+        ranker = HipRanker(distance, device, user_embs, item_embs)
+        key = self._catalog_key(distance, item_embs)
+        kept = getattr(self, "_catalog_images", None)
+        if kept is not None and kept[0] == key:
+            ranker.adopt_images(kept[1])
+        ranker._catalog_key = key    # pylint: disable=protected-access
+        return ranker
+
+    def _keep_images(self, ranker: HipRanker) -> None:
+        self._catalog_images = (ranker._catalog_key, ranker.export_images())    # pylint: disable=protected-access
+
     def _item_embeddings(self) -> torch.Tensor:
         """Catalog matrix in eval mode, produced once per recommend call (lightning.py:386-389)."""
         lm = self.lightning_model
@@ -712,11 +741,12 @@ class TransformerModelBase:
             return self._frame(np.array([], users.dtype), np.array([], object), np.array([], np.float32), add_rank_col, Columns.User)
         item_embs = self._item_embeddings()
         user_embs = self._user_embeddings(store, device, item_embs)
-        ranker = HipRanker(self.lightning_model.torch_model.similarity_module.distance, device, user_embs, item_embs)
+        ranker = self._ranker(self.lightning_model.torch_model.similarity_module.distance, device, user_embs, item_embs)
         filt = None
         if filter_viewed:
             filt = DeviceCSR.from_scipy(rec_ds.get_user_item_matrix(include_weights=False)[user_ids], device)
         ids, scores, counts, _ = ranker.rank_device(user_ids, k=k, filter_pairs_csr=filt, sorted_object_whitelist=whitelist)
+        self._keep_images(ranker)
         return self._assemble(rec_ds.user_id_map.convert_to_external(user_ids), ids, scores, counts, add_rank_col, Columns.User)
 
     def recommend_distributed(self, users: tp.Any, dataset: tp.Any, k: int, filter_viewed: bool, **kwargs: tp.Any) -> pd.DataFrame:
@@ -830,7 +860,7 @@ class TransformerModelBase:
         if unsort is not None:
             user_embs = user_embs.index_select(0, unsort)
         tick("encoder")
-        ranker = HipRanker(lm.torch_model.similarity_module.distance, device, user_embs, item_embs)
+        ranker = self._ranker(lm.torch_model.similarity_module.distance, device, user_embs, item_embs)
         filt = None
         if filter_viewed:  # CSR of the distinct (user, item) pairs, rows in request order, indices ascending
             flens = fptr_h[rows_h + 1] - fptr_h[rows_h]
@@ -839,6 +869,7 @@ class TransformerModelBase:
                 indices = torch.zeros((1,), dtype=torch.int32, device=device)
             filt = DeviceCSR(indptr, indices, (n_valid, V))
         ids, scores, cnt, _ = ranker.rank_device(np.arange(n_valid), k=k, filter_pairs_csr=filt, sorted_object_whitelist=whitelist)
+        self._keep_images(ranker)
         tick("ranker")
         ext_users = np.asarray(users)[valid_h]
         frame = self._assemble(ext_users, ids, scores, cnt, add_rank_col, Columns.User)
@@ -863,9 +894,10 @@ class TransformerModelBase:
         whitelist = self._whitelist(items_to_recommend)
         device = next(self.lightning_model.parameters()).device
         item_embs = self._item_embeddings()
-        ranker = HipRanker(Distance.COSINE, device, item_embs, item_embs)
+        ranker = self._ranker(Distance.COSINE, device, item_embs, item_embs)
         kk = k + 1 if filter_itself else k
         ids, scores, counts, _ = ranker.rank_device(target_ids, k=kk, sorted_object_whitelist=whitelist)
+        self._keep_images(ranker)
         ids, scores, counts = ids.cpu().numpy(), scores.cpu().numpy(), counts.cpu().numpy()
         t_out, i_out, s_out = [], [], []
         for r, t in enumerate(target_ids):
@@ -1024,6 +1056,7 @@ class TransformerModelBase:
         checkpoint = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
         device = self._device()
         self.torch_model.load_state_dict({k: v.to(device) for k, v in ckpt.strip_state_dict(checkpoint["state_dict"]).items()})
+        self._catalog_images = None
 
     def save_to_checkpoint(self, checkpoint_path: str, reference_paths: bool = True) -> None:
         """What `fit_trainer.save_checkpoint(path)` does for the reference (base.py:660-662), in the same dict layout."""

@@ -133,10 +133,34 @@ class HipRanker:
         self.two_stage: tp.Optional[bool] = (None if env == "auto" else env == "1") if two_stage is None else bool(two_stage)
         self._items_hm: tp.Optional[torch.Tensor] = None      # hm image of objects_factors (rt_to_hm_rows), built on first use
         self._items_h: tp.Optional[torch.Tensor] = None       # h-only (one bf16 per value) image: the HBM-bound regime
+        self._items_frag: tp.Optional[torch.Tensor] = None    # ... in fragment-major form (RT_TOPK_FRAG=1)
         self._h_only_off = os.environ.get("RT_TOPK_H_ONLY", "1") == "0"
         self._h_only_strikes = 0
         self._max_item_norm = 0.0
         self.two_stage_stats = {"calls": 0, "fallbacks": 0, "unproven_users": 0, "h_only_calls": 0}
+
+    # ---- catalog images outlive a ranker -----------------------------------------------------------------
+    _IMAGE_FIELDS = ("_items_hm", "_items_h", "_items_frag", "_h_only_off", "_h_only_strikes", "_max_item_norm")
+
+    def export_images(self) -> tp.Dict[str, tp.Any]:
+        """The coarse-pass images of `objects_factors` built so far (+ what the ranker learnt about the catalog: the largest item norm,
+        whether the one-plane bound holds on it).  `recommend()` builds a ranker per call (new user factors every time) against a
+        catalog that only changes when the model trains: the model keeps this dict next to a version key of its item embeddings and
+        hands it to the next ranker (`adopt_images`) — no catalog pass, no device -> host read of the norm per call."""
+        return {k: getattr(self, k) for k in self._IMAGE_FIELDS}
+
+    def adopt_images(self, images: tp.Optional[tp.Dict[str, tp.Any]]) -> None:
+        """Take over images exported by a ranker over the SAME objects_factors (the caller vouches for that)."""
+        if not images:
+            return
+        n, d = self.objects_factors.shape
+        for k in ("_items_hm", "_items_h"):
+            t = images.get(k)
+            if t is not None and (t.shape[0] != n or t.device != self.objects_factors.device):
+                return      # not this catalog: keep nothing
+        for k in self._IMAGE_FIELDS:
+            if k in images:
+                setattr(self, k, images[k])
 
     def _to_device(self, tensor: tp.Union[np.ndarray, sparse.csr_matrix, torch.Tensor]) -> torch.Tensor:
         # mirrors TorchRanker._normalize_tensor (rank_torch.py:210-223), then moves to the device once
@@ -178,6 +202,14 @@ class HipRanker:
         if n_subj >= int(os.environ.get("RT_TOPK_TWO_STAGE_MIN_USERS", self.TWO_STAGE_MIN_USERS)):
             return True
         return O.numel() * 4 >= int(os.environ.get("RT_TOPK_H_ONLY_MIN_BYTES", self.H_ONLY_MIN_BYTES))
+
+    def _fragments(self, img: torch.Tensor, n_rows: int, d: int) -> torch.Tensor:
+        """Fragment-major form of a one-plane image (`rt_one_plane_to_fragments`), rows padded to a multiple of 128 with zeros."""
+        rows_pad = (n_rows + 127) // 128 * 128
+        out = torch.empty((rows_pad, d // 2), dtype=torch.int32, device=self.device)
+        status = self._lib.rt_one_plane_to_fragments(_lib.ptr(img), img.stride(0), n_rows, d, _lib.ptr(out), rows_pad, _lib.current_stream())
+        _lib.check(status, "rt_one_plane_to_fragments")
+        return out
 
     def _hm_image(self, src: torch.Tensor, rows: tp.Optional[torch.Tensor], n_rows: int, h_only: bool = False
                   ) -> tp.Tuple[torch.Tensor, torch.Tensor]:
@@ -238,13 +270,21 @@ class HipRanker:
                     self._max_item_norm = float(item_norms.max())
                 items_img, img_row_bytes = self._items_hm, 4 * d
             users_hm, user_norms = self._hm_image(S, rows_t, n_subj, h_only=h_only)
+            # fragment-major images (opt-in, RT_TOPK_FRAG=1): item fragments straight into the matrix operand, the user tile resident in LDS
+            frag = (h_only and os.environ.get("RT_TOPK_FRAG", "0") == "1" and whitelist_t is None and d % 128 == 0 and id_offset % 128 == 0
+                    and n_subj >= 128 and 128 * d * 2 <= 144 * 1024)
+            if frag:
+                if self._items_frag is None:
+                    self._items_frag = self._fragments(self._items_h, O.shape[0], d)
+                items_img, upp2 = self._items_frag, 128
+                users_hm = self._fragments(users_hm, n_subj, d)
             unproven = torch.empty((n_subj,), dtype=torch.int32, device=dev)
             ws_bytes = self._lib.rt_topk_two_stage_workspace_bytes(n_subj, n_cand, kk, kc, upp2)
             if self._workspace is None or self._workspace.numel() < ws_bytes:
                 self._workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
             status = self._lib.rt_topk_score_two_stage(
                 _lib.ptr(S), S.stride(0), _lib.ptr(rows_t), n_subj, O.data_ptr() + 4 * id_offset * O.stride(0), O.stride(0),
-                _lib.ptr(users_hm), items_img.data_ptr() + img_row_bytes * id_offset, 1 if h_only else 0, _lib.ptr(user_norms),
+                _lib.ptr(users_hm), items_img.data_ptr() + img_row_bytes * id_offset, (2 if frag else 1) if h_only else 0, _lib.ptr(user_norms),
                 self._max_item_norm,
                 _lib.ptr(whitelist_t), n_cand, id_offset, d, _DIST_CODE[self.distance], kk, kc, _lib.ptr(indptr_t), _lib.ptr(indices_t),
                 _lib.ptr(hash_t),
@@ -257,7 +297,7 @@ class HipRanker:
         self.two_stage_stats["unproven_users"] += int(len(bad))
         starts = bad[np.r_[True, np.diff(bad) > 1]]
         ends = bad[np.r_[np.diff(bad) > 1, True]] + 1
-        wide = n_subj >= self.TWO_STAGE_MIN_USERS or self.two_stage is True
+        wide = n_subj >= int(os.environ.get("RT_TOPK_TWO_STAGE_MIN_USERS", self.TWO_STAGE_MIN_USERS)) or self.two_stage is True
         exact_upp = upp if upp > 16 else 32      # the 32-wide engine: the arithmetic the exact pass mirrors
         if h_only and wide and (8 * len(bad) > n_subj or len(starts) > max(2, n_subj // self.RUNS_PER_USERS)):
             # the one-plane bound is too wide for this catalog (or leaves more single runs — a catalog pass each — than a second coarse

@@ -19,6 +19,7 @@ for k, v in (j.get("families") or {}).items():
 cb = j.get("cpu_baseline") or {}
 print("  cpu_baseline", cb.get("kind"), cb.get("value"), cb.get("unit"), "cores", cb.get("cores"))
 r = j.get("roofline") or {}
-print("  roofline", r.get("kernel", "")[:50], r.get("achieved"), r.get("unit"), "frac", r.get("frac"), "host_issue_ms", r.get("host_issue_ms_per_step"))
+print("  roofline", r.get("kernel", "")[:50], r.get("achieved"), r.get("unit"), "frac", r.get("frac"), "host_issue_ms", r.get("host_issue_ms_per_step"),
+      "host_only", r.get("host_only"), "step_TF", r.get("step_TFLOPs"), "gemm launches/step", r.get("launches_per_step"))
 for k, v in list((j.get("kernel_breakdown") or {}).items())[:24]:
     print("   %-30s %8.4f ms  x%5.1f  single %8.4f" % (k, v["ms_per_step"], v["calls_per_step"], v["single_stream_ms"]))
