@@ -149,6 +149,23 @@ typedef struct rt_gemm_wp_problem {
   const float* bias; const float* R; int64_t ldr; int32_t M, N, K, relu;
 } rt_gemm_wp_problem;
 int rt_gemm_wp(const rt_gemm_wp_problem* problems, int32_t n, int32_t w_tr, rt_stream_t stream);
+/* K7f  the feed-forward half of a SASRec block as ONE launch per direction (csrc/rt_ffn.hip; replaces sasrec.py:225-229 +
+ * net_blocks.py:63-64 = LayerNorm, Linear, ReLU, Dropout, Linear, Dropout, skip).  A workgroup owns 64 rows from the LayerNorm input to
+ * the block output; both products run the K7w loop on the pre-split planes of W1 [dff, d] / W2 [d, dff], masks are applied in the
+ * epilogues (the same (seed, stream, float4-group) hash as rt_act_dropout_*), the intermediate goes through L2 only.
+ *   fwd: f = LN(y) (+ mean, rstd [M]); hdrop [M, dff] = drop(relu(f W1^T + b1)); out [M, d] = f + drop(hdrop W2^T + b2)
+ *   bwd: g_o [M, d] = drop'(g_out) (p > 0 only; else g_o is not written and g_out stands for it); g_h [M, dff] = [hdrop != 0] / (1 - p)
+ *        * (g_o W2); g_f [M, d] = g_h W1 + g_out.  Weight gradients (g_o^T hdrop, g_h^T f) and the LayerNorm backward stay with the caller.
+ * Shapes: M % 64 == 0, d % 128 == 0 (<= 1024), dff % 128 == 0, contiguous 16-byte aligned arrays; otherwise RT_ERR_UNSUPPORTED
+ * (rt_ffn_fused_supported answers without launching). */
+int rt_ffn_fused_supported(int32_t M, int32_t d, int32_t dff);
+int rt_ffn_fused_fwd(const float* y, const float* ln_w, const float* ln_b, float eps, float* f, float* mean, float* rstd,
+                     const uint16_t* w1_planes, const uint16_t* w2_planes, int64_t plane_stride, const float* b1, const float* b2,
+                     float* hdrop, float* out, int32_t M, int32_t d, int32_t dff, float p, uint64_t seed_h, uint64_t sid_h,
+                     uint64_t seed_o, uint64_t sid_o, rt_stream_t stream);
+int rt_ffn_fused_bwd(const float* g_out, const float* hdrop, const uint16_t* w1_planes, const uint16_t* w2_planes, int64_t plane_stride,
+                     float* g_o, float* g_h, float* g_f, int32_t M, int32_t d, int32_t dff, float p, uint64_t seed_o, uint64_t sid_o,
+                     rt_stream_t stream);
 /* Up to 4 independent products of the same operand layouts in ONE launch (tile ranges back to back: the tail of one product is
  * filled by the head of the next — the q and k/v projections of a block, sasrec.py:221-224, or two data-gradient products).
  * Problems off the exact-tile path are executed as consecutive rt_gemm calls; results are identical either way. */

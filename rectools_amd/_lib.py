@@ -32,13 +32,20 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_to_hm_rows": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp]),
     "rt_one_plane_to_fragments": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_vp]),
     "rt_topk_two_stage_workspace_bytes": (c_sz, [c_i32, c_i64, c_i32, c_i32, c_i32]),
-    "rt_topk_score_two_stage": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp, c_vp, c_i32, c_vp, c_f32, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32,
-                                        c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_i32, c_vp]),
+    "rt_topk_score_two_stage": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp, c_vp, c_i32, c_vp, c_f32, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_i32, c_vp]),
     "rt_gemm_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
     "rt_gemm": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_sz, c_vp]),
+    "rt_split_planes": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "rt_gemm_wp": (c_i32, [c_vp, c_i32, c_i32, c_vp]),
+    "rt_ffn_fused_supported": (c_i32, [c_i32, c_i32, c_i32]),
+    "rt_ffn_fused_fwd": (c_i32, [c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_u64, c_u64, c_u64, c_u64, c_vp]),
+    "rt_ffn_fused_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_u64, c_u64, c_vp]),
     "rt_gemm_grouped": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp]),
     "rt_colsum": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "rt_collate": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_f32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "rt_collate_packed": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "rt_collate_packed_ts": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_vp]),
+    "rt_collate_packed_bert": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rt_sample_negatives": (c_i32, [c_i64, c_i64, c_i64, c_u64, c_u64, c_vp, c_vp]),
     "rt_bag_sum_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_u64, c_u64, c_vp, c_vp]),
     "rt_bag_sum_bwd_workspace_bytes": (c_sz, [c_i64, c_i32]),
@@ -46,6 +53,8 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_embed_fwd": (c_i32, [c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_f32, c_u64, c_u64, c_vp, c_vp]),
     "rt_embed_bwd_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32]),
     "rt_embed_bwd": (c_i32, [c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_u64, c_vp, c_i32, c_vp, c_vp, c_sz, c_vp]),
+    "rt_embed_packed_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_f32, c_u64, c_u64, c_vp, c_vp]),
+    "rt_embed_packed_bwd": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_f32, c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_u64, c_vp, c_i32, c_vp, c_vp, c_sz, c_vp]),
     "rt_layernorm_fwd": (c_i32, [c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "rt_layernorm_fwd_masked": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rt_layernorm_bwd_workspace_bytes": (c_sz, [c_i32, c_i32]),
@@ -69,15 +78,27 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_mha_varlen_train_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_vp, c_i64, c_vp, c_vp]),
     "rt_mha_varlen_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "rt_mha_varlen_bidir_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_vp, c_i64, c_vp, c_vp]),
-    "rt_mha_varlen_bidir_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
-                                        c_f32, c_u64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    "rt_mha_varlen_bidir_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "rt_mha_varlen_last_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
+    "rt_sasrec_block_saved_floats": (c_sz, [c_i32, c_i32, c_i32, c_i32, c_i32]),
+    "rt_sasrec_block_bwd_scratch_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32]),
+    "rt_sasrec_block_grad_offsets": (None, [c_i32, c_i32, c_vp]),
+    "rt_sasrec_block_packed_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "rt_sasrec_block_packed_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_i32, c_i32, c_vp]),
+    "rt_sasrec_block_infer_scratch_floats": (c_sz, [c_i32, c_i32, c_i32, c_i32, c_i32]),
+    "rt_sasrec_block_packed_infer": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "rt_preln_block_saved_floats": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
+    "rt_preln_block_bwd_scratch_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32, c_i32]),
+    "rt_preln_block_packed_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "rt_preln_block_packed_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_i32, c_i32, c_vp]),
+    "rt_side_join": (c_i32, [c_vp]),
+    "rt_side_fork": (c_i32, [c_vp, c_vp]),
+    "rt_timing_enable": (c_i32, [c_i32]),
+    "rt_timing_collect": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_vp]),
     "rt_hstu_attn_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rt_hstu_attn_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
-    "rt_hstu_attn_varlen_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64,
-                                        c_vp]),
-    "rt_hstu_attn_varlen_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,
-                                        c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "rt_hstu_attn_varlen_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
+    "rt_hstu_attn_varlen_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "rt_hstu_attn_last_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rt_sampled_loss_fwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f64, c_vp, c_vp, c_vp]),
     "rt_sampled_loss_bwd_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
@@ -89,30 +110,6 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_l2norm_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rt_gather_rows": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rt_scatter_rows": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp]),
-    "rt_collate_packed": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "rt_collate_packed_ts": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_vp]),
-    "rt_collate_packed_bert": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_i64, c_vp, c_vp,
-                                       c_vp, c_vp, c_vp]),
-    "rt_embed_packed_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_f32, c_u64, c_u64, c_vp, c_vp]),
-    "rt_embed_packed_bwd": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_f32, c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_u64, c_vp, c_i32, c_vp,
-                                    c_vp, c_sz, c_vp]),
-    "rt_split_planes": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp]),
-    "rt_gemm_wp": (c_i32, [c_vp, c_i32, c_i32, c_vp]),
-    "rt_sasrec_block_saved_floats": (c_sz, [c_i32, c_i32, c_i32, c_i32, c_i32]),
-    "rt_sasrec_block_bwd_scratch_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32]),
-    "rt_sasrec_block_grad_offsets": (None, [c_i32, c_i32, c_vp]),
-    "rt_sasrec_block_packed_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "rt_sasrec_block_packed_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_i32, c_i32, c_vp]),
-    "rt_sasrec_block_infer_scratch_floats": (c_sz, [c_i32, c_i32, c_i32, c_i32, c_i32]),
-    "rt_preln_block_saved_floats": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
-    "rt_preln_block_bwd_scratch_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32, c_i32]),
-    "rt_preln_block_packed_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "rt_preln_block_packed_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_i32, c_i32, c_vp]),
-    "rt_sasrec_block_packed_infer": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "rt_side_join": (c_i32, [c_vp]),
-    "rt_side_fork": (c_i32, [c_vp, c_vp]),
-    "rt_timing_enable": (c_i32, [c_i32]),
-    "rt_timing_collect": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_vp]),
     "rt_dp_unique_id": (c_i32, [c_vp]),
     "rt_dp_init": (c_i32, [c_vp, c_i32, c_i32, c_vp]),
     "rt_dp_allreduce": (c_i32, [c_vp, c_vp, c_i64, c_vp]),

@@ -70,6 +70,14 @@ struct rt_gemm_wp_problem {
   int32_t M, N, K, relu;
 };
 int rt_gemm_wp(const rt_gemm_wp_problem* problems, int32_t n, int32_t w_tr, hipStream_t stream);
+int rt_ffn_fused_supported(int32_t M, int32_t d, int32_t dff);
+int rt_ffn_fused_fwd(const float* y, const float* ln_w, const float* ln_b, float eps, float* f, float* mean, float* rstd,
+                     const uint16_t* w1_planes, const uint16_t* w2_planes, int64_t plane_stride, const float* b1, const float* b2, float* hdrop,
+                     float* out, int32_t M, int32_t d, int32_t dff, float p, uint64_t seed_h, uint64_t sid_h, uint64_t seed_o, uint64_t sid_o,
+                     hipStream_t stream);
+int rt_ffn_fused_bwd(const float* g_out, const float* hdrop, const uint16_t* w1_planes, const uint16_t* w2_planes, int64_t plane_stride,
+                     float* g_o, float* g_h, float* g_f, int32_t M, int32_t d, int32_t dff, float p, uint64_t seed_o, uint64_t sid_o,
+                     hipStream_t stream);
 }
 
 namespace {
@@ -95,7 +103,7 @@ struct Timed {   // RAII bracket around one internal launch (no-op unless rt_tim
   }
 };
 enum { T_GEMM = 0, T_GEMM_GROUPED = 1, T_LN_FWD = 2, T_LN_BWD = 3, T_DROP_FWD = 4, T_DROP_BWD = 5, T_ATTN_FWD = 6, T_ATTN_BWD = 7,
-       T_ATTN_LAST = 8, T_MISC = 9, T_ATTN_BIDIR_FWD = 10, T_ATTN_BIDIR_BWD = 11 };
+       T_ATTN_LAST = 8, T_MISC = 9, T_ATTN_BIDIR_FWD = 10, T_ATTN_BIDIR_BWD = 11, T_FFN_FWD = 12, T_FFN_BWD = 13 };
 
 // ---- the weight-gradient side stream (one per device, owned by the library) -------------------------------------------------------
 struct Side { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool dirty = false; };
@@ -133,7 +141,8 @@ extern "C" {
 // mode 0: off; 1: record an event pair around every internal launch of the block executor; 2: the same with the weight gradients on the
 // caller's stream (undisturbed kernel durations).  rt_timing_collect synchronises the device, copies the records out
 // (ids: 0 gemm, 1 gemm_grouped, 2 layernorm_fwd, 3 layernorm_bwd, 4 act_dropout_fwd, 5 act_dropout_bwd, 6 mha_varlen_fwd,
-// 7 mha_varlen_bwd, 8 mha_varlen_last_fwd, 9 misc, 10 / 11 mha_varlen_bidir_fwd / _bwd; tags [n][3] = the GEMM's M, N, K or 0) and clears them.
+// 7 mha_varlen_bwd, 8 mha_varlen_last_fwd, 9 misc, 10 / 11 mha_varlen_bidir_fwd / _bwd, 12 / 13 ffn_fused_fwd / _bwd (tag = (M, 2 dff, d): both
+// products); tags [n][3] = the GEMM's M, N, K or 0) and clears them.
 int rt_timing_enable(int32_t mode) {
   g_timing = mode != 0;
   g_single_stream = mode == 2;
@@ -222,6 +231,13 @@ int wp_one(const float* A, int lda, const uint16_t* W, int64_t stride, int ldw, 
   rt_gemm_wp_problem pr{A, lda, W, stride, ldw, C, ldc, bias, R, ldr, M, N, K, relu};
   return rt_gemm_wp(&pr, 1, w_tr, s);
 }
+// The feed-forward half as one launch per direction (rt_ffn.hip) — a pure function of the block's shape and planes, so that the forward and
+// the backward of a step always agree (the fused forward keeps hdrop only: the unfused backward would read an h nobody wrote).
+// RT_FFN_FUSED=0 keeps the five-launch sequence (the cross-check of tests/test_packed_gpu.py).
+bool ffn_fused(const rt_sasrec_block& b) {
+  static const int on = [] { const char* e = getenv("RT_FFN_FUSED"); return (e != nullptr && e[0] == '0') ? 0 : 1; }();
+  return on == 1 && b.w1_wp != nullptr && b.w2_wp != nullptr && rt_ffn_fused_supported(b.rows, b.d, b.dff) == 1;
+}
 struct SavedView {
   float *q, *Q, *A, *y, *f, *KV, *h, *hdrop, *lse, *mean1, *rstd1, *mean2, *rstd2;
 };
@@ -279,6 +295,12 @@ int rt_sasrec_block_packed_fwd(const rt_sasrec_block* blk, const float* x, float
     int rc = wp_one(v.A, d, b.out_wp, b.wp_stride, d, 0, v.y, d, b.out_b, v.q, d, M, d, d, 0, stream);
     if (rc == RT_ERR_UNSUPPORTED) rc = rt_gemm(v.A, d, 1, b.out_w, d, 1, v.y, d, b.out_b, v.q, d, nullptr, M, d, d, 0, 1, nullptr, 0, stream);
     RT_TRY(rc); }
+  if (ffn_fused(b)) {   // LN2 -> W1 -> relu -> dropout -> W2 -> dropout -> + f in one launch
+    Timed t(T_FFN_FWD, M, 2 * dff, d, stream);
+    RT_TRY(rt_ffn_fused_fwd(v.y, b.ln2_w, b.ln2_b, b.eps2, v.f, v.mean2, v.rstd2, b.w1_wp, b.w2_wp, b.wp_stride, b.b1, b.b2, v.hdrop, out, M, d, dff,
+                            b.p_drop, b.seed_h, b.sid_h, b.seed_o, b.sid_o, stream));
+    return RT_OK;
+  }
   { Timed t(T_LN_FWD, 0, 0, 0, stream); RT_TRY(rt_layernorm_fwd(v.y, b.ln2_w, b.ln2_b, b.eps2, M, d, v.f, v.mean2, v.rstd2, stream)); }
   { Timed t(T_GEMM, M, dff, d, stream);                                                                                 // h = relu(W1 f + b1)
     int rc = wp_one(v.f, d, b.w1_wp, b.wp_stride, d, 0, v.h, dff, b.b1, nullptr, 0, M, dff, d, 1, stream);
@@ -360,6 +382,14 @@ int rt_sasrec_block_packed_bwd(const rt_sasrec_block* blk, const float* x, const
   };
 
   // ---- feed-forward: out = f + dropout(o), o = W2 hdrop + b2, hdrop = dropout(relu(W1 f + b1))
+  if (ffn_fused(b)) {   // g_o, g_h, g_f from one launch; both weight gradients fork behind it
+    const float* g_o_c = b.p_drop > 0.f ? g_o : g_out;
+    { Timed t(T_FFN_BWD, M, 2 * dff, d, stream);
+      RT_TRY(rt_ffn_fused_bwd(g_out, v.hdrop, b.w1_wp, b.w2_wp, b.wp_stride, g_o, g_h, g_f, M, d, dff, b.p_drop, b.seed_o, b.sid_o, stream)); }
+    RT_TRY(fork());
+    RT_TRY(wgrad(g_o_c, d, v.hdrop, dff, d_w2, d, dff, d_b2));
+    RT_TRY(wgrad(g_h, dff, v.f, d, d_w1, dff, d, d_b1));
+  } else {
   const float* g_o_c = g_out;
   if (b.p_drop > 0.f) {
     Timed t(T_DROP_BWD, 0, 0, 0, stream);
@@ -380,6 +410,7 @@ int rt_sasrec_block_packed_bwd(const rt_sasrec_block* blk, const float* x, const
     int rc = wp_one(g_h, dff, b.w1_wp, b.wp_stride, d, 1, g_f, d, nullptr, g_out, d, M, d, dff, 0, stream);
     if (rc == RT_ERR_UNSUPPORTED) rc = rt_gemm(g_h, dff, 1, b.w1, d, 0, g_f, d, nullptr, g_out, d, nullptr, M, d, dff, 0, 1, nullptr, 0, stream);
     RT_TRY(rc); }
+  }
   { Timed t(T_LN_BWD, 0, 0, 0, stream);
     RT_TRY(rt_layernorm_bwd_fused(g_f, v.y, b.ln2_w, v.mean2, v.rstd2, nullptr, nullptr, 0, 0, M, d, g_y, d_ln2w, d_ln2b, ln_ws1, lnws, stream)); }
   // ---- attention: y = q + Wo A + bo

@@ -91,6 +91,42 @@ __device__ __forceinline__ float u32_to_unit(unsigned x) {  // [0,1)
   return (float)(x >> 8) * (1.0f / 16777216.0f);
 }
 
+// ---- element-dropout masks (row kernels, GEMM epilogues): hash of a counter, 16 bits per element ----------
+// Philox4x32-10 costs 40 quarter-rate 32-bit multiplies per four elements (~840 issue cycles per wave call) — more than the matrix
+// work of a fused GEMM epilogue that has to regenerate a mask.  A dropout mask needs decorrelation, not cryptographic strength:
+// two avalanche finalisers (murmur3's fmix32, lowbias32) over (counter, seed, stream) give 64 bits per float4 group for five
+// multiplies; an element is kept when its 16-bit field >= p * 65536 (the attention kernels' construction, rt_varlen.h).  Forward
+// and backward kernels regenerate the same mask from (seed, stream, index of the float4 group).  Philox stays where the draw IS
+// the product (negative sampling, rt_collate.hip).
+__device__ __forceinline__ unsigned rt_fmix32(unsigned x) {
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ unsigned rt_lowbias32(unsigned x) {
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint2 rt_drop_bits(unsigned long long seed, unsigned long long stream, unsigned long long idx4) {
+  const unsigned k0 = (unsigned)seed ^ ((unsigned)stream * 0x9E3779B1u) ^ (unsigned)(stream >> 32);
+  const unsigned k1 = (unsigned)(seed >> 32) + ((unsigned)stream ^ 0xC2B2AE3Du) * 0x85EBCA77u;
+  const unsigned lo = (unsigned)idx4, hi = (unsigned)(idx4 >> 32);
+  const unsigned a = rt_fmix32((lo * 0x9E3779B1u) ^ k0 ^ (hi * 0x27D4EB2Fu));
+  const unsigned b = rt_lowbias32(a + k1 + lo);
+  return make_uint2(a, b);
+}
+__device__ __forceinline__ unsigned rt_drop_thr16(float p) { return (unsigned)(p * 65536.0f); }
+// v[j] kept (and scaled by 1 / (1 - p)) or zeroed, j = 0..3: element j of float4 group idx4
+__device__ __forceinline__ f32x4 rt_drop4(f32x4 v, unsigned long long seed, unsigned long long stream, unsigned long long idx4, float p,
+                                           float inv_keep) {
+  const uint2 r = rt_drop_bits(seed, stream, idx4);
+  const unsigned thr = rt_drop_thr16(p);
+  v[0] = ((r.x & 0xFFFFu) >= thr) ? v[0] * inv_keep : 0.f;
+  v[1] = ((r.x >> 16) >= thr) ? v[1] * inv_keep : 0.f;
+  v[2] = ((r.y & 0xFFFFu) >= thr) ? v[2] * inv_keep : 0.f;
+  v[3] = ((r.y >> 16) >= thr) ? v[3] * inv_keep : 0.f;
+  return v;
+}
+
 static inline int rt_num_cus() {
   static int cus = 0;
   if (cus == 0) {

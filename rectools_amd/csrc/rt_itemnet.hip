@@ -17,12 +17,7 @@ namespace {
 
 __device__ __forceinline__ f32x4 bag_drop4(f32x4 v, unsigned long long seed, unsigned long long stream,
                                             unsigned long long idx4, float p, float inv_keep) {
-  uint4 r = philox4x32(seed, stream, idx4);
-  v[0] = (u32_to_unit(r.x) >= p) ? v[0] * inv_keep : 0.f;
-  v[1] = (u32_to_unit(r.y) >= p) ? v[1] * inv_keep : 0.f;
-  v[2] = (u32_to_unit(r.z) >= p) ? v[2] * inv_keep : 0.f;
-  v[3] = (u32_to_unit(r.w) >= p) ? v[3] * inv_keep : 0.f;
-  return v;
+  return rt_drop4(v, seed, stream, idx4, p, inv_keep);
 }
 
 // One wave per catalog row; a lane owns float4 columns lane*4 + 256*t.  The row's feature ids are wave-uniform

@@ -4,7 +4,7 @@
 //   K3  LayerNorm                                sasrec.py:221,226,303; net_blocks.py:247,257; ligr.py:90,102; hstu.py:256,291
 //   K13 Adam                                     lightning.py:214-218 (torch.optim.Adam, betas (0.9,0.98), eps 1e-8)
 //   dropout / activations / gates / row masks    net_blocks.py:63-64,108-109; ligr.py:99-105; sasrec.py:228,300; hstu.py:257,291
-// Dropout masks are counter-based (Philox4x32 keyed by (seed, element/4)): the backward kernels regenerate
+// Dropout masks are counter-based (rt_common.h rt_drop4: a hash of (seed, stream, element/4)): the backward kernels regenerate
 // the forward mask from the same (seed, stream) pair instead of storing it.
 #include "rt_common.h"
 #include "rt_scan.h"
@@ -13,12 +13,7 @@ namespace {
 
 __device__ __forceinline__ f32x4 drop4(f32x4 v, unsigned long long seed, unsigned long long stream,
                                         unsigned long long idx4, float p, float inv_keep) {
-  uint4 r = philox4x32(seed, stream, idx4);
-  v[0] = (u32_to_unit(r.x) >= p) ? v[0] * inv_keep : 0.f;
-  v[1] = (u32_to_unit(r.y) >= p) ? v[1] * inv_keep : 0.f;
-  v[2] = (u32_to_unit(r.z) >= p) ? v[2] * inv_keep : 0.f;
-  v[3] = (u32_to_unit(r.w) >= p) ? v[3] * inv_keep : 0.f;
-  return v;
+  return rt_drop4(v, seed, stream, idx4, p, inv_keep);      // rt_common.h: 16 hash bits per element
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -65,6 +65,18 @@ def _dist_info() -> tp.Tuple[int, int]:
 _PACKED_PREPARATORS = ("SASRecDataPreparator", "BERT4RecDataPreparator")
 
 
+def _packed_hooks_are_stock(lm: tp.Any) -> bool:
+    """The packed training step calls `training_loss_packed` -> `encode_packed_train` instead of the reference-shaped hooks
+    `training_loss` -> `_encode` -> `encode_sessions`.  A plugged `lightning_module_type` / `backbone_type` that overrides one of
+    those hooks (and does not bring its own packed twin) must therefore keep the padded path — the one its override runs on."""
+    tl, tm = type(lm), type(lm.torch_model)
+    base_l, base_b = hl.TransformerLossModule, hnn.TransformerTorchBackbone
+    loss_ok = (tl.training_loss is base_l.training_loss and tl._encode is base_l._encode) \
+        or tl.training_loss_packed is not base_l.training_loss_packed      # pylint: disable=protected-access
+    enc_ok = tm.encode_sessions is base_b.encode_sessions or tm.encode_packed_train is not base_b.encode_packed_train
+    return loss_ok and enc_ok
+
+
 class _TrainLoop:
     """One rank's training stream: the session store lives in HBM (`DeviceSequenceStore`), an epoch is a permutation of
     the sessions sharded DistributedSampler-style, and `step()` is one optimiser step on the next batch — device collate
@@ -93,7 +105,7 @@ class _TrainLoop:
         self.packed = (os.environ.get("RT_PACKED_TRAIN", "1") != "0" and type(self.dp).__name__ in _PACKED_PREPARATORS
                        and (not self.dp.add_unix_ts or (self.stu and not self.bert)) and not (self.dp.extra_cols or [])
                        and getattr(tm.transformer_layers, "packed_ok", None) is not None
-                       and getattr(tm, "_fused_pos", lambda: False)()
+                       and getattr(tm, "_fused_pos", lambda: False)() and _packed_hooks_are_stock(lm)
                        and tm.transformer_layers.packed_ok(model.n_factors, self.dp.session_max_len, tm.use_causal_attn,
                                                            tm.use_key_padding_mask))
 

@@ -893,7 +893,11 @@ class TransformerTorchBackbone(nn.Module):
     def can_encode_packed(self, n_factors: int, window: int) -> bool:
         """Does `encode_last_packed` serve this backbone (inference, a layer stack with a packed forward, see its `packed_ok`)?"""
         ok = getattr(self.transformer_layers, "packed_ok", None)
-        return ok is not None and self._fused_pos() and not self.training and not torch.is_grad_enabled() \
+        # a plugged backbone that overrides the reference-shaped encoders (and brings no packed twin) keeps the path its override runs on
+        cls, base = type(self), TransformerTorchBackbone
+        stock = (cls.encode_sessions is base.encode_sessions and cls.encode_last is base.encode_last) \
+            or cls.encode_last_packed is not base.encode_last_packed
+        return ok is not None and stock and self._fused_pos() and not self.training and not torch.is_grad_enabled() \
             and ok(n_factors, window, self.use_causal_attn, self.use_key_padding_mask)
 
     def encode_last_packed(self, offsets: torch.Tensor, items: torch.Tensor, rows: torch.Tensor, window: int,
@@ -957,8 +961,8 @@ class TransformerTorchBackbone(nn.Module):
         """-> [B, d] = encode_sessions(batch)[:, -1, :], the only rows recommend() uses (lightning.py:393-397).  Layer stacks
         that offer `forward_last` (SASRec) run their final block on one query row per session."""
         fast = getattr(self.transformer_layers, "forward_last", None)
-        if fast is None or self.training or torch.is_grad_enabled():
-            return self.encode_sessions(batch, item_embs)[:, -1, :].contiguous()
+        if fast is None or self.training or torch.is_grad_enabled() or type(self).encode_sessions is not TransformerTorchBackbone.encode_sessions:
+            return self.encode_sessions(batch, item_embs)[:, -1, :].contiguous()      # (a subclass's encode_sessions is the one that runs)
         x = batch["x"]
         B, L = x.shape
         table = self.item_model.table if item_embs is None else item_embs

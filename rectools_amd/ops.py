@@ -60,7 +60,7 @@ def stop_timing() -> tp.Dict[str, tp.List[tp.Tuple[float, tp.Any]]]:
 
 _NATIVE_TIMING_NAMES = {0: "rt_gemm", 1: "rt_gemm_grouped", 2: "rt_layernorm_fwd", 3: "rt_layernorm_bwd_fused", 4: "rt_act_dropout_fwd",
                         5: "rt_act_dropout_bwd", 6: "rt_mha_varlen_train_fwd", 7: "rt_mha_varlen_bwd", 8: "rt_mha_varlen_last_fwd",
-                        9: "rt_misc", 10: "rt_mha_varlen_bidir_fwd", 11: "rt_mha_varlen_bidir_bwd"}
+                        9: "rt_misc", 10: "rt_mha_varlen_bidir_fwd", 11: "rt_mha_varlen_bidir_bwd", 12: "rt_ffn_fused_fwd", 13: "rt_ffn_fused_bwd"}
 
 
 _FN: tp.Dict[str, tp.Any] = {}   # bound C entry points (one getattr per name instead of one per launch)

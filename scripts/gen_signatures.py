@@ -4,7 +4,7 @@ import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TYPES = {"int32_t": "c_i32", "int64_t": "c_i64", "float": "c_f32", "double": "c_f64", "uint64_t": "c_u64", "size_t": "c_sz",
-         "rt_stream_t": "c_vp", "int": "c_i32"}
+         "rt_stream_t": "c_vp", "int": "c_i32", "void": "None", "uint32_t": "c_u32"}
 
 
 def ctype(decl: str) -> str:

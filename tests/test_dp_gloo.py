@@ -68,21 +68,33 @@ def _worker_sharded(rank, world, port, out_dir):
     for mode in ("allreduce", "sharded"):
         os.environ["RT_DP_EXCHANGE"] = mode
         torch.manual_seed(0)
-        model = torch.nn.Sequential(torch.nn.Embedding(1500, 8), torch.nn.Linear(8, 5), torch.nn.Linear(5, 3))   # table >= 1024 rows: padded segment
+        model = torch.nn.Sequential(torch.nn.Embedding(30000, 8), torch.nn.Linear(8, 5), torch.nn.Linear(5, 3))   # table >= 1024 rows: padded segment; 240 k floats: every rank's slice holds parameters
         opt = FlatAdam(model, lr=1e-2)
         opt._adam_flat = lambda p, g, m, v, hyper: _torch_adam(p, g, m, v, hyper)      # the HIP kernel's seam (no GPU in this test)
         assert opt.sharded == (mode == "sharded") and opt.flat_p.numel() % 1024 == 0
         for step in range(3):
             opt.zero_grad()
-            ids = torch.arange(40) * (rank + 2) % 1500
+            ids = torch.arange(4000) * (7 * rank + 5) % 30000
             model(ids).pow(2).sum().mul(rank + 1.0).backward()                       # rank-dependent gradients
             opt.step(world, flat=True)
         lo, hi = opt.shard_bounds(world, rank)
+        if mode == "sharded":      # the moments outside the rank's own slice are never touched on this rank
+            assert opt.partial_moments == (world, rank)
+            other = torch.ones_like(opt.m, dtype=torch.bool); other[lo:hi] = False
+            assert float(opt.m[other].abs().max()) == 0.0 and (float(opt.m[lo:hi].abs().max()) > 0.0) == (lo < opt.n_used)
+            # ... and a checkpoint / state_dict written from them would resume from corrupt Adam state: refused until gathered
+            from rectools_amd import checkpoint as ckpt
+            for fn in (lambda: ckpt.adam_state_dict(opt), opt.state_dict):
+                try:
+                    fn()
+                    raise AssertionError("partial moments were written out")
+                except RuntimeError as e:
+                    assert "consolidate_moments" in str(e)
+            opt.consolidate_moments()      # collective: what fit() does after its last step
+            assert opt.partial_moments is None
+            ckpt.adam_state_dict(opt)       # local from here on (any single rank may save)
         m_full, v_full = opt.full_moments(world, rank)
         results[mode] = (opt.flat_p.clone(), m_full.clone(), v_full.clone(), opt.m.clone())
-        if mode == "sharded":      # the moments outside the rank's own slice are never touched on this rank
-            other = torch.ones_like(opt.m, dtype=torch.bool); other[lo:hi] = False
-            assert float(opt.m[other].abs().max()) == 0.0 and float(opt.m[lo:hi].abs().max()) > 0.0
     for a, b in zip(results["allreduce"][:3], results["sharded"][:3]):
         torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7)                         # same parameters, same (gathered) moments
     mine = [torch.zeros_like(results["sharded"][0]) for _ in range(world)]
@@ -92,8 +104,25 @@ def _worker_sharded(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_sharded_exchange_equals_the_allreduce_exchange(tmp_path):
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_exchange_equals_the_allreduce_exchange(tmp_path, world):
     """reduce-scatter -> Adam on the rank's 1/N slice of (p, m, v) -> all-gather of the parameters (FlatAdam.step_sharded) against the
-    all-reduce exchange, world 2 over gloo, 3 steps: same parameters on every rank, same moments once gathered."""
-    world = 2
+    all-reduce exchange, world 2 and 3 over gloo (3 does not divide a power-of-two buffer: the flat buffers are padded to a multiple
+    of lcm(1024, 840) floats), 3 steps: same parameters on every rank, same moments once gathered; partial moments are never
+    written out."""
     mp.spawn(_worker_sharded, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+
+
+def test_a_world_size_that_does_not_cut_the_buffer_falls_back_to_the_allreduce():
+    from rectools_amd.lightning import FLAT_QUANTUM, FlatAdam
+
+    os.environ["RT_DP_EXCHANGE"] = "sharded"
+    try:
+        opt = FlatAdam(torch.nn.Linear(6, 5), lr=1e-3)
+    finally:
+        os.environ.pop("RT_DP_EXCHANGE", None)
+    assert opt.sharded and opt.flat_p.numel() % FLAT_QUANTUM == 0
+    assert all(opt._use_sharded(w) for w in (2, 3, 4, 5, 6, 7, 8, 16)) and not opt._use_sharded(11) and not opt._use_sharded(1)

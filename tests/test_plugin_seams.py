@@ -146,6 +146,53 @@ def test_plugged_classes_are_the_ones_that_run():
     pd.testing.assert_frame_equal(clone.recommend(users=np.array([10, 30, 40]), dataset=ds, k=3, filter_viewed=True), reco)
 
 
+class ShiftedBackbone(hnn.TransformerTorchBackbone):
+    """Overrides the reference-shaped encoder hook (torch_backbone.py:220-260)."""
+    calls = 0
+
+    def encode_sessions(self, batch, item_embs=None):
+        ShiftedBackbone.calls += 1
+        return super().encode_sessions(batch, item_embs)
+
+
+@pytest.mark.gpu
+def test_overridden_hooks_run_where_the_stack_would_otherwise_pack():
+    """packed training calls `training_loss_packed` / `encode_packed_train`, packed recommend `encode_last_packed` — a
+    subclass overriding `training_loss` or `encode_sessions` was bypassed whenever the stack packs (stock positional encoding, head
+    size 32 / 64).  With such a subclass plugged in the loop must keep the padded path, on which the override runs."""
+    from rectools_amd.dataset import Dataset
+    from rectools_amd.models import SASRecModel
+
+    ds = Dataset.construct(_interactions())
+    common = dict(n_factors=64, n_blocks=1, n_heads=2, session_max_len=4, lr=0.01, batch_size=4, epochs=1, loss="sampled_softmax",
+                  n_negatives=3, seed=32, dropout_rate=0.0)      # head size 32, stock positional encoding: the stack packs
+    stock = SASRecModel(**common)
+    stock._build_model_from_dataset(ds)
+    assert stock.training_loop().packed
+    plugged = SASRecModel(lightning_module_type=ScaledLossModule, lightning_module_kwargs={"loss_scale": 3.0}, **common)
+    plugged._build_model_from_dataset(ds)
+    plugged.torch_model.load_state_dict(stock.torch_model.state_dict())
+    loop_a, loop_b = stock.training_loop(), plugged.training_loop()
+    assert not loop_b.packed
+    stock.lightning_model.train(); plugged.lightning_model.train()
+    loop_a.begin_epoch(0); loop_b.begin_epoch(0)
+    la, lb = float(loop_a.step()), float(loop_b.step())
+    assert plugged.lightning_model.seen == 1 and abs(lb - 3.0 * la) <= 2e-5 * abs(lb)      # packed == padded up to fp32 rounding
+    # a backbone that overrides encode_sessions: training AND recommend() go through it
+    ShiftedBackbone.calls = 0
+    m = SASRecModel(backbone_type=ShiftedBackbone, **common)
+    m._build_model_from_dataset(ds)
+    assert not m.training_loop().packed
+    m.fit(ds)
+    n_train = ShiftedBackbone.calls
+    assert n_train > 0
+    m.torch_model.eval()
+    with torch.no_grad():
+        assert not m.torch_model.can_encode_packed(64, 4)
+    reco = m.recommend(users=np.array([10, 30, 40]), dataset=ds, k=3, filter_viewed=True)
+    assert len(reco) > 0
+
+
 @pytest.mark.gpu
 def test_custom_positional_encoding_equals_the_fused_stock_path_when_it_restates_it():
     """A subclass that overrides forward() with the stock formula takes the modular path (embed -> forward -> dropout) and must
