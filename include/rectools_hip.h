@@ -137,6 +137,17 @@ int rt_gemm(const float* A, int64_t lda, int32_t a_kc, const float* B, int64_t l
             float* C, int64_t ldc, const float* bias, const float* R, int64_t ldr, float* a_rowsum,
             int32_t M, int32_t N, int32_t K, int32_t relu, int32_t split_k, void* workspace, size_t workspace_bytes,
             rt_stream_t stream);
+/* Up to 6 WEIGHT GRADIENTS over the same rows in two launches (all products split-K in one grid + one combine): dW_i [n_out_i, n_in_i]
+ * (contiguous) = dy_i^T in_i, db_i [n_out_i] = column sums of dy_i (nullable) — the five weight gradients of a transformer block
+ * (lightning.py:296-321: what loss.backward() produces for sasrec.py:191-194's Linear layers) instead of a product and a combine each.
+ * splits: upper bound of the split-K factor.  Exact-tile shapes only (n_out, n_in % 128, rows % 32, 16-byte aligned), otherwise
+ * RT_ERR_UNSUPPORTED (the caller issues rt_gemm per product).  Same slices and fixed-order combine as rt_gemm(split_k). */
+typedef struct rt_wgrad_problem {
+  const float* dy; int64_t ldy; const float* in; int64_t ldin; float* dw; float* db; int32_t n_out, n_in;
+} rt_wgrad_problem;
+size_t rt_wgrad_grouped_workspace_bytes(const rt_wgrad_problem* problems, int32_t n, int32_t rows, int32_t splits);
+int rt_wgrad_grouped(const rt_wgrad_problem* problems, int32_t n, int32_t rows, int32_t splits, void* workspace, size_t workspace_bytes,
+                     rt_stream_t stream);
 /* K7w  the same products with a PRE-SPLIT weight operand (csrc/rt_gemm_wp.hip): rt_split_planes writes the exact three-way bf16 split of
  * a contiguous fp32 range (every weight of a layer stack in one launch; plane p at planes + p * plane_stride, n % 4 == 0, plane_stride % 8
  * == 0), rt_gemm_wp computes up to 4 products C[M,N] = A[M,K] . W' (+ bias) (+ R) (relu) in one launch from the planes: w_tr = 0:
@@ -166,6 +177,24 @@ int rt_ffn_fused_fwd(const float* y, const float* ln_w, const float* ln_b, float
 int rt_ffn_fused_bwd(const float* g_out, const float* hdrop, const uint16_t* w1_planes, const uint16_t* w2_planes, int64_t plane_stride,
                      float* g_o, float* g_h, float* g_f, int32_t M, int32_t d, int32_t dff, float p, uint64_t seed_o, uint64_t sid_o,
                      rt_stream_t stream);
+/* The whole tail of a packed SASRec block behind its attention as ONE launch per direction (same kernel family, three products):
+ *   fwd: y = q + attn Wo^T + bo; f = LN2(y); hdrop = drop(relu(f W1^T + b1)); out = f + drop(hdrop W2^T + b2)   (sasrec.py:224-229)
+ *        training != 0 writes y, f, mean, rstd, hdrop (the backward's inputs); training == 0 (p must be 0; y, mean, rstd, hdrop may be
+ *        NULL) writes `out` and the scratch rows `f` only — a row crosses the memory pipe 3 times instead of 12 (recommend()).
+ *   bwd: g_o, g_h as rt_ffn_fused_bwd; g_y [M, d] = LN2'(g_h W1 + g_out; y, mean, rstd, ln_w) with the rows still on chip; g_A [M, d] =
+ *        g_y Wo.  ln_partial [rt_block_tail_partial_floats(M, d)]: per-workgroup shares of d ln_w / d ln_b, summed by
+ *        rt_layernorm_bwd_reduce(ln_partial, M / 64, d, dw, db).  The three weight gradients stay with the caller.
+ * wo_planes: planes of the out-projection weight [d, d], same plane_stride as w1_planes / w2_planes.  Shapes as rt_ffn_fused_*. */
+int rt_block_tail_fwd(const float* attn, const float* q, const uint16_t* wo_planes, const float* bo, const float* ln_w, const float* ln_b,
+                      float eps, float* y, float* f, float* mean, float* rstd, const uint16_t* w1_planes, const uint16_t* w2_planes,
+                      int64_t plane_stride, const float* b1, const float* b2, float* hdrop, float* out, int32_t M, int32_t d, int32_t dff,
+                      float p, uint64_t seed_h, uint64_t sid_h, uint64_t seed_o, uint64_t sid_o, int32_t training, rt_stream_t stream);
+int rt_block_tail_bwd(const float* g_out, const float* hdrop, const float* y, const float* mean, const float* rstd, const float* ln_w,
+                      const uint16_t* wo_planes, const uint16_t* w1_planes, const uint16_t* w2_planes, int64_t plane_stride, float* g_o,
+                      float* g_h, float* g_y, float* g_A, float* ln_partial, int32_t M, int32_t d, int32_t dff, float p, uint64_t seed_o,
+                      uint64_t sid_o, rt_stream_t stream);
+size_t rt_block_tail_partial_floats(int32_t M, int32_t d);
+int rt_layernorm_bwd_reduce(const float* partial, int32_t blocks, int32_t d, float* dw, float* db, rt_stream_t stream);
 /* Up to 4 independent products of the same operand layouts in ONE launch (tile ranges back to back: the tail of one product is
  * filled by the head of the next — the q and k/v projections of a block, sasrec.py:221-224, or two data-gradient products).
  * Problems off the exact-tile path are executed as consecutive rt_gemm calls; results are identical either way. */

@@ -35,11 +35,17 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_topk_score_two_stage": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp, c_vp, c_i32, c_vp, c_f32, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_i32, c_vp]),
     "rt_gemm_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
     "rt_gemm": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_sz, c_vp]),
+    "rt_wgrad_grouped_workspace_bytes": (c_sz, [c_vp, c_i32, c_i32, c_i32]),
+    "rt_wgrad_grouped": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_sz, c_vp]),
     "rt_split_planes": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp]),
     "rt_gemm_wp": (c_i32, [c_vp, c_i32, c_i32, c_vp]),
     "rt_ffn_fused_supported": (c_i32, [c_i32, c_i32, c_i32]),
     "rt_ffn_fused_fwd": (c_i32, [c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_u64, c_u64, c_u64, c_u64, c_vp]),
     "rt_ffn_fused_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_u64, c_u64, c_vp]),
+    "rt_block_tail_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_u64, c_u64, c_u64, c_u64, c_i32, c_vp]),
+    "rt_block_tail_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_u64, c_u64, c_vp]),
+    "rt_block_tail_partial_floats": (c_sz, [c_i32, c_i32]),
+    "rt_layernorm_bwd_reduce": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "rt_gemm_grouped": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp]),
     "rt_colsum": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "rt_collate": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_f32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),

@@ -78,6 +78,19 @@ int rt_ffn_fused_fwd(const float* y, const float* ln_w, const float* ln_b, float
 int rt_ffn_fused_bwd(const float* g_out, const float* hdrop, const uint16_t* w1_planes, const uint16_t* w2_planes, int64_t plane_stride,
                      float* g_o, float* g_h, float* g_f, int32_t M, int32_t d, int32_t dff, float p, uint64_t seed_o, uint64_t sid_o,
                      hipStream_t stream);
+int rt_block_tail_fwd(const float* attn, const float* q, const uint16_t* wo_planes, const float* bo, const float* ln_w, const float* ln_b,
+                      float eps, float* y, float* f, float* mean, float* rstd, const uint16_t* w1_planes, const uint16_t* w2_planes,
+                      int64_t plane_stride, const float* b1, const float* b2, float* hdrop, float* out, int32_t M, int32_t d, int32_t dff, float p,
+                      uint64_t seed_h, uint64_t sid_h, uint64_t seed_o, uint64_t sid_o, int32_t training, hipStream_t stream);
+int rt_block_tail_bwd(const float* g_out, const float* hdrop, const float* y, const float* mean, const float* rstd, const float* ln_w,
+                      const uint16_t* wo_planes, const uint16_t* w1_planes, const uint16_t* w2_planes, int64_t plane_stride, float* g_o,
+                      float* g_h, float* g_y, float* g_A, float* ln_partial, int32_t M, int32_t d, int32_t dff, float p, uint64_t seed_o,
+                      uint64_t sid_o, hipStream_t stream);
+int rt_layernorm_bwd_reduce(const float* partial, int32_t blocks, int32_t d, float* dw, float* db, hipStream_t stream);
+struct rt_wgrad_problem { const float* dy; int64_t ldy; const float* in; int64_t ldin; float* dw; float* db; int32_t n_out, n_in; };
+size_t rt_wgrad_grouped_workspace_bytes(const rt_wgrad_problem* problems, int32_t n, int32_t rows, int32_t splits);
+int rt_wgrad_grouped(const rt_wgrad_problem* problems, int32_t n, int32_t rows, int32_t splits, void* workspace, size_t workspace_bytes,
+                     hipStream_t stream);
 }
 
 namespace {
@@ -219,6 +232,14 @@ size_t rt_sasrec_block_bwd_scratch_bytes(int32_t rows, int32_t B, int32_t d, int
   const size_t cands[5] = {rt_gemm_workspace_bytes(d, dff, rows, spl), rt_gemm_workspace_bytes(dff, d, rows, spl), rt_gemm_workspace_bytes(d, d, rows, spl),
                            rt_gemm_workspace_bytes(2 * d, d, rows, spl), 0};
   for (size_t c : cands) sk = c > sk ? c : sk;
+  {   // the grouped weight-gradient launches (rt_wgrad_grouped): {W2, W1, Wo} behind the block's tail, {Wq, Wkv} behind the attention
+    const rt_wgrad_problem ga[3] = {{nullptr, 0, nullptr, 0, nullptr, nullptr, d, dff}, {nullptr, 0, nullptr, 0, nullptr, nullptr, dff, d},
+                                    {nullptr, 0, nullptr, 0, nullptr, nullptr, d, d}};
+    const rt_wgrad_problem gb[2] = {{nullptr, 0, nullptr, 0, nullptr, nullptr, d, d}, {nullptr, 0, nullptr, 0, nullptr, nullptr, 2 * d, d}};
+    const size_t a = rt_wgrad_grouped_workspace_bytes(ga, 3, rows, spl), b2 = rt_wgrad_grouped_workspace_bytes(gb, 2, rows, spl);
+    sk = a > sk ? a : sk;
+    sk = b2 > sk ? b2 : sk;
+  }
   return by + ((sk + 255) & ~(size_t)255) + 256;
 }
 
@@ -234,10 +255,16 @@ int wp_one(const float* A, int lda, const uint16_t* W, int64_t stride, int ldw, 
 // The feed-forward half as one launch per direction (rt_ffn.hip) — a pure function of the block's shape and planes, so that the forward and
 // the backward of a step always agree (the fused forward keeps hdrop only: the unfused backward would read an h nobody wrote).
 // RT_FFN_FUSED=0 keeps the five-launch sequence (the cross-check of tests/test_packed_gpu.py).
-bool ffn_fused(const rt_sasrec_block& b) {
-  static const int on = [] { const char* e = getenv("RT_FFN_FUSED"); return (e != nullptr && e[0] == '0') ? 0 : 1; }();
-  return on == 1 && b.w1_wp != nullptr && b.w2_wp != nullptr && rt_ffn_fused_supported(b.rows, b.d, b.dff) == 1;
+// RT_FFN_FUSED: 0 = the separate launches; 1 = the feed-forward half fused (LN2 .. skip: two products); 2 (default) = the block's whole
+// tail behind the attention fused (out-projection .. skip, and in the backward down to the attention's output gradient: three products).
+int ffn_mode() {
+  static const int m = [] { const char* e = getenv("RT_FFN_FUSED"); return e != nullptr && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 2; }();
+  return m;
 }
+bool ffn_fused(const rt_sasrec_block& b) {
+  return ffn_mode() >= 1 && b.w1_wp != nullptr && b.w2_wp != nullptr && rt_ffn_fused_supported(b.rows, b.d, b.dff) == 1;
+}
+bool tail_fused(const rt_sasrec_block& b) { return ffn_mode() == 2 && ffn_fused(b) && b.out_wp != nullptr; }
 struct SavedView {
   float *q, *Q, *A, *y, *f, *KV, *h, *hdrop, *lse, *mean1, *rstd1, *mean2, *rstd2;
 };
@@ -291,6 +318,12 @@ int rt_sasrec_block_packed_fwd(const rt_sasrec_block* blk, const float* x, float
   { Timed t(T_ATTN_FWD, 0, 0, 0, stream);
     RT_TRY(rt_mha_varlen_train_fwd(v.Q, d, v.KV, 2 * d, v.KV + d, 2 * d, b.cu, bk, bv, b.B, b.H, hd, b.window, b.window, b.p_drop, b.seed_attn,
                                    v.A, d, v.lse, stream)); }
+  if (tail_fused(b)) {   // out-projection + skip -> LN2 -> W1 -> relu -> dropout -> W2 -> dropout -> + f in one launch
+    Timed t(T_FFN_FWD, M, 2 * dff + d, d, stream);
+    RT_TRY(rt_block_tail_fwd(v.A, v.q, b.out_wp, b.out_b, b.ln2_w, b.ln2_b, b.eps2, v.y, v.f, v.mean2, v.rstd2, b.w1_wp, b.w2_wp, b.wp_stride, b.b1,
+                             b.b2, v.hdrop, out, M, d, dff, b.p_drop, b.seed_h, b.sid_h, b.seed_o, b.sid_o, 1, stream));
+    return RT_OK;
+  }
   { Timed t(T_GEMM, M, d, d, stream);                                                                                   // y = q + Wo A + bo
     int rc = wp_one(v.A, d, b.out_wp, b.wp_stride, d, 0, v.y, d, b.out_b, v.q, d, M, d, d, 0, stream);
     if (rc == RT_ERR_UNSUPPORTED) rc = rt_gemm(v.A, d, 1, b.out_w, d, 1, v.y, d, b.out_b, v.q, d, nullptr, M, d, d, 0, 1, nullptr, 0, stream);
@@ -381,7 +414,35 @@ int rt_sasrec_block_packed_bwd(const rt_sasrec_block* blk, const float* x, const
                    sp > 1 ? sk_bytes : 0, ws);                   // dW = dy^T in, db = colsum(dy) from the staged dy^T tiles
   };
 
-  // ---- feed-forward: out = f + dropout(o), o = W2 hdrop + b2, hdrop = dropout(relu(W1 f + b1))
+  // several weight gradients of the same rows as ONE split-K launch + one combine (RT_WGRAD_GROUPED=0: a product and a combine each)
+  static const int grouped_on = [] { const char* e = getenv("RT_WGRAD_GROUPED"); return (e != nullptr && e[0] == '0') ? 0 : 1; }();
+  auto wgrads = [&](const rt_wgrad_problem* pr, int n) -> int {
+    int rc = RT_ERR_UNSUPPORTED;
+    if (grouped_on && (d % 128) == 0 && (dff % 128) == 0) {
+      long long fl = 0;
+      for (int i = 0; i < n; ++i) fl += (long long)pr[i].n_out * pr[i].n_in;
+      Timed t(T_GEMM_GROUPED, fl * M, 1, 1, ws);
+      rc = rt_wgrad_grouped(pr, n, M, sp, sk_ws, sk_bytes, ws);
+    }
+    if (rc == RT_ERR_UNSUPPORTED) {
+      for (int i = 0; i < n; ++i) RT_TRY(wgrad(pr[i].dy, (int)pr[i].ldy, pr[i].in, (int)pr[i].ldin, pr[i].dw, pr[i].n_out, pr[i].n_in, pr[i].db));
+      rc = RT_OK;
+    }
+    return rc;
+  };
+
+  // ---- feed-forward: out = f + dropout(o), o = W2 hdrop + b2, hdrop = dropout(relu(W1 f + b1)); attention output: y = q + Wo A + bo
+  if (tail_fused(b)) {   // g_o, g_h, g_y (LN2 backward on chip) and g_A from one launch; the three weight gradients fork behind it
+    const float* g_o_c = b.p_drop > 0.f ? g_o : g_out;
+    float* ln_part = reinterpret_cast<float*>(ln_ws1);      // (M / 64 partials fit the LayerNorm backward's own workspace)
+    { Timed t(T_FFN_BWD, M, 2 * dff + d, d, stream);
+      RT_TRY(rt_block_tail_bwd(g_out, v.hdrop, v.y, v.mean2, v.rstd2, b.ln2_w, b.out_wp, b.w1_wp, b.w2_wp, b.wp_stride, g_o, g_h, g_y, g_A, ln_part, M, d,
+                               dff, b.p_drop, b.seed_o, b.sid_o, stream)); }
+    RT_TRY(fork());
+    { Timed t(T_MISC, 0, 0, 0, ws); RT_TRY(rt_layernorm_bwd_reduce(ln_part, M / 64, d, d_ln2w, d_ln2b, ws)); }
+    const rt_wgrad_problem pr[3] = {{g_o_c, d, v.hdrop, dff, d_w2, d_b2, d, dff}, {g_h, dff, v.f, d, d_w1, d_b1, dff, d}, {g_y, d, v.A, d, d_wo, d_bo, d, d}};
+    RT_TRY(wgrads(pr, 3));
+  } else {
   if (ffn_fused(b)) {   // g_o, g_h, g_f from one launch; both weight gradients fork behind it
     const float* g_o_c = b.p_drop > 0.f ? g_o : g_out;
     { Timed t(T_FFN_BWD, M, 2 * dff, d, stream);
@@ -420,6 +481,7 @@ int rt_sasrec_block_packed_bwd(const rt_sasrec_block* blk, const float* x, const
     int rc = wp_one(g_y, d, b.out_wp, b.wp_stride, d, 1, g_A, d, nullptr, nullptr, 0, M, d, d, 0, stream);
     if (rc == RT_ERR_UNSUPPORTED) rc = rt_gemm(g_y, d, 1, b.out_w, d, 0, g_A, d, nullptr, nullptr, 0, nullptr, M, d, d, 0, 1, nullptr, 0, stream);
     RT_TRY(rc); }
+  }
   RT_TRY(zero_tail(gQ, b, d, stream));      // rows behind the sessions must read as zero in the weight gradients
   RT_TRY(zero_tail(gKV, b, 2 * d, stream));
   const float* bk = b.pad_keys ? b.in_b + d : nullptr;
@@ -428,8 +490,10 @@ int rt_sasrec_block_packed_bwd(const rt_sasrec_block* blk, const float* x, const
     RT_TRY(rt_mha_varlen_bwd(v.Q, d, v.KV, 2 * d, v.KV + d, 2 * d, v.A, d, g_A, d, v.lse, b.cu, bk, bv, b.B, b.H, hd, b.window, b.window, b.p_drop,
                              b.seed_attn, gQ, d, gKV, 2 * d, gKV + d, 2 * d, delta, b.pad_keys ? part : nullptr, stream)); }
   RT_TRY(fork());
-  RT_TRY(wgrad(gQ, d, v.q, d, d_in_w, d, d, d_in_b));
-  RT_TRY(wgrad(gKV, 2 * d, x, d, d_in_w + (size_t)d * d, 2 * d, d, d_in_b + d));
+  {
+    const rt_wgrad_problem pr[2] = {{gQ, d, v.q, d, d_in_w, d_in_b, d, d}, {gKV, 2 * d, x, d, d_in_w + (size_t)d * d, d_in_b + d, 2 * d, d}};
+    RT_TRY(wgrads(pr, 2));
+  }
   if (b.pad_keys) {   // the pad keys' share: b_k has no gradient in total (it shifts every logit of a query alike), b_v gets theirs
     Timed t(T_MISC, 0, 0, 0, ws);
     RT_CHECK_HIP(hipMemsetAsync(d_in_b + d, 0, (size_t)d * sizeof(float), ws));
@@ -703,6 +767,12 @@ int rt_sasrec_block_packed_infer(const rt_sasrec_block* blk, const float* x, con
     RT_TRY(lin(x, d, b.in_w + (size_t)d * d, b.in_wp != nullptr ? b.in_wp + (size_t)d * d : nullptr, d, KV, 2 * d, b.in_b + d, nullptr, 0, M, 2 * d, d, 0));
     RT_TRY(lin(q, d, b.in_w, b.in_wp, d, Q, d, b.in_b, nullptr, 0, R, d, d, 0));
     RT_TRY(rt_mha_varlen_last_fwd(Q, d, KV, 2 * d, KV + d, 2 * d, b.cu, bk, bv, b.B, b.H, hd, b.window, b.window, A, d, stream));
+  }
+  if (ffn_mode() == 2 && b.out_wp != nullptr && b.w1_wp != nullptr && b.w2_wp != nullptr && rt_ffn_fused_supported(R, d, dff) == 1) {
+    // the block's tail with the rows resident on chip: attn and q in, out out (+ the scratch rows f) — no y, h, statistics
+    RT_TRY(rt_block_tail_fwd(A, q, b.out_wp, b.out_b, b.ln2_w, b.ln2_b, b.eps2, nullptr, f, nullptr, nullptr, b.w1_wp, b.w2_wp, b.wp_stride, b.b1, b.b2,
+                             nullptr, out, R, d, dff, 0.f, 0, 0, 0, 0, 0, stream));
+    return RT_OK;
   }
   RT_TRY(lin(A, d, b.out_w, b.out_wp, d, y, d, b.out_b, q, d, R, d, d, 0));
   RT_TRY(rt_layernorm_fwd(y, b.ln2_w, b.ln2_b, b.eps2, R, d, f, mean, rstd, stream));

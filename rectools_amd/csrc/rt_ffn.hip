@@ -51,10 +51,13 @@ struct FfnArgs {
   long long plane_stride;
   // forward
   const float *y, *ln_w, *ln_b, *b1, *b2;
-  float *f, *mean, *rstd, *hdrop, *out;
+  float *f, *mean, *rstd, *hdrop, *out, *y_out;
+  const float *attn, *q, *bo;        // first = 0: the out-projection's operand rows, its skip branch and bias
+  const unsigned short* wop;         // bf16 planes of Wo [d, d]
+  int first, last;
   // backward
   const float *g_out, *hd;
-  float *g_o, *g_h, *g_f;
+  float *g_o, *g_h, *g_f, *g_y, *g_A, *ln_partial;
   int probe;      // ablation builds only (-DRT_ABLATION_BUILD, RT_FFN_PROBE): 1 no prologue stores, 2 no first-epilogue stores, 4 no second epilogue, 8 no MFMA, 16 no DMA, 32 no operand reads
 };
 
@@ -95,60 +98,60 @@ __device__ __forceinline__ Split3 split_bf16x3(const f32x4& x0, const f32x4& x1)
 // The activation image: row r (0..63) of the current product's operand, K floats, 16-byte unit u stored at u ^ (r & 15).
 __device__ __forceinline__ unsigned a_off(int row, int unit, int rs) { return (unsigned)(row * rs + ((unit ^ (row & 15)) << 4)); }
 
-// ---- loader side: the weight stream of both products as ONE sequence of stages ----------------------------------------------------------
-struct WStream {
-  const unsigned short* src[2][2];   // [product][piece]: this lane's 16-byte unit of pieces 2 lw, 2 lw + 1 at (pass 0, k 0)
-  long long ldw[2];
-  int KS[2], T[2];
+// ---- loader side: the weight stream of the chain's products as ONE sequence of stages ----------------------------------------------------
+struct WStream {                     // the CURRENT product's sources only: a table of all three would be indexed by the compiler
+  //                                    through scratch memory, and scratch traffic counts in the vmcnt the ring's run-ahead is metered with
+  const unsigned short *sa, *sb;     // this lane's 16-byte unit of pieces 2 lw, 2 lw + 1 at (pass 0, k 0)
+  long long ldw;
+  int KS, T;                         // ring stages per pass / of the whole product
   long long plane_stride;
   unsigned base;                     // LDS byte address of this loader wave's first piece in ring slot 0
   int g, kk, pass, slot, issued;
   bool no_dma;
 };
 template <bool BTR>
-__device__ __forceinline__ void wstream_init(WStream& w, int lw, int lane, const unsigned short* Wa, long long ldwa, int Ka, int Na,
-                                             const unsigned short* Wb, long long ldwb, int Kb, int Nb, long long plane_stride, unsigned ring_lds) {
-#pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    const unsigned short* W = g == 0 ? Wa : Wb;
-    const long long ldw = g == 0 ? ldwa : ldwb;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int q = (lw * 2 + j) * 64 + lane;                    // 16-byte unit of the plane tile
-      if (!BTR) {
-        const int row = q >> 2, c = (q & 3) ^ ((row >> 2) & 3);   // [128 n][4 units]: unit c of row n stored at c ^ ((n>>2)&3)
-        w.src[g][j] = W + (long long)row * ldw + c * 8;
-      } else {
-        const int row = q >> 4, u = (q & 15) ^ ((row & 3) << 2);  // [32 k][16 units]: unit u of row k stored at u ^ ((k&3)<<2)
-        w.src[g][j] = W + (long long)row * ldw + u * 8;
-      }
-    }
-    w.ldw[g] = ldw;
+__device__ __forceinline__ const unsigned short* wsrc(const unsigned short* W, long long ldw, int lw, int lane, int j) {
+  const int q = (lw * 2 + j) * 64 + lane;                    // 16-byte unit of the plane tile
+  if (!BTR) {
+    const int row = q >> 2, c = (q & 3) ^ ((row >> 2) & 3);   // [128 n][4 units]: unit c of row n stored at c ^ ((n>>2)&3)
+    return W + (long long)row * ldw + c * 8;
   }
-  w.KS[0] = Ka / BK; w.T[0] = w.KS[0] * (Na / BN);
-  w.KS[1] = Kb / BK; w.T[1] = w.KS[1] * (Nb / BN);
-  w.plane_stride = plane_stride;
-  w.base = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)(lw * 2 * 1024));
-  w.g = 0; w.kk = 0; w.pass = 0; w.slot = 0; w.issued = 0; w.no_dma = false;
+  const int row = q >> 4, u = (q & 15) ^ ((row & 3) << 2);    // [32 k][16 units]: unit u of row k stored at u ^ ((k&3)<<2)
+  return W + (long long)row * ldw + u * 8;
+}
+// weight, row stride, K and N of product g of the chain (forward: Wo, W1, W2; backward: W2, W1, Wo — read as [k][n])
+template <bool FWD>
+__device__ __forceinline__ void product_of(const FfnArgs& a, int g, const unsigned short*& W, long long& ldw, int& K, int& N) {
+  const int d = a.d, dff = a.dff;
+  if (g == 0) { W = FWD ? a.wop : a.w2p; ldw = FWD ? d : dff; K = d; N = FWD ? d : dff; }
+  else if (g == 1) { W = a.w1p; ldw = d; K = FWD ? d : dff; N = FWD ? dff : d; }
+  else { W = FWD ? a.w2p : a.wop; ldw = FWD ? dff : d; K = FWD ? dff : d; N = d; }
 }
 template <bool BTR>
-__device__ __forceinline__ void wstream_issue(WStream& w) {
-  const int g = w.g;
-  const long long ldw = g == 0 ? w.ldw[0] : w.ldw[1];
-  const int KSg = g == 0 ? w.KS[0] : w.KS[1], Tg = g == 0 ? w.T[0] : w.T[1];
-  const long long bo = BTR ? (long long)w.kk * BK * ldw + (long long)w.pass * BN : (long long)w.pass * BN * ldw + (long long)w.kk * BK;
+__device__ __forceinline__ void wstream_open(WStream& w, const FfnArgs& a, int g, int lw, int lane) {
+  const unsigned short* W; long long ldw; int K, N;
+  product_of<!BTR>(a, g, W, ldw, K, N);
+  w.sa = wsrc<BTR>(W, ldw, lw, lane, 0);
+  w.sb = wsrc<BTR>(W, ldw, lw, lane, 1);
+  w.ldw = ldw; w.KS = K / BK; w.T = w.KS * (N / BN);
+  w.g = g; w.kk = 0; w.pass = 0;
+}
+template <bool BTR>
+__device__ __forceinline__ void wstream_issue(WStream& w, const FfnArgs& a, int lw, int lane) {
+  const long long bo = BTR ? (long long)w.kk * BK * w.ldw + (long long)w.pass * BN : (long long)w.pass * BN * w.ldw + (long long)w.kk * BK;
   const unsigned sb = w.base + (unsigned)(w.slot * W_STAGE_B);
+  if (!w.no_dma) {
 #pragma unroll
-  for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      if (!w.no_dma) dma16((g == 0 ? w.src[0][j] : w.src[1][j]) + bo + pl * w.plane_stride, sb + pl * P_TILE_B + j * 1024);
+    for (int pl = 0; pl < 3; ++pl) {
+      dma16(w.sa + bo + pl * w.plane_stride, sb + pl * P_TILE_B);
+      dma16(w.sb + bo + pl * w.plane_stride, sb + pl * P_TILE_B + 1024);
+    }
+  }
   ++w.issued;
   if (++w.slot == NSTG) w.slot = 0;
-  (void)0;
-  if (++w.kk == KSg) {
+  if (++w.kk == w.KS) {
     w.kk = 0;
-    if ((w.pass + 1) * KSg == Tg) { w.pass = 0; w.g = 1; } else ++w.pass;
+    if ((w.pass + 1) * w.KS == w.T) wstream_open<BTR>(w, a, w.g + 1, lw, lane); else ++w.pass;
   }
 }
 
@@ -228,8 +231,42 @@ __device__ __forceinline__ void compute_pass(const unsigned char* A, int rs, con
 #define RT_PROBEA(bit) false
 #endif
 constexpr int NPMAX = 2;      // passes per product the register budget covers (d, dff <= 256)
+constexpr int RED_B = 4 * 2 * 256 * 4;   // LayerNorm-backward partials of the four compute waves: [4][2][256] floats
 
-template <int MODE>   // 0: forward, 1: backward
+// LayerNorm of 8 rows held as one float4 per lane (layernorm_fwd_kernel's arithmetic: sum -> mean -> centred squares -> rstd ->
+// (v - mu) rs w + b), the rows' reductions interleaved; v <- LN(v), mu / rs per row.
+__device__ __forceinline__ void ln8(f32x4 (&v)[8], bool on, int d, float eps, const f32x4& ww, const f32x4& bb, float (&mu)[8], float (&rs)[8]) {
+  float q[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) mu[r] = 0.f + (v[r][0] + v[r][1] + v[r][2] + v[r][3]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) mu[r] += __shfl_xor(mu[r], o, 64);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    mu[r] = mu[r] / d;
+    q[r] = 0.f;
+    if (on) {
+      const f32x4 t = v[r] - mu[r];
+      q[r] += t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) q[r] += __shfl_xor(q[r], o, 64);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    rs[r] = 1.0f / sqrtf(q[r] / d + eps);
+    if (on) v[r] = (v[r] - mu[r]) * rs[r] * ww + bb;
+  }
+}
+
+// MODE 0: forward (training: every intermediate the backward needs is written), 1: backward, 2: forward without the saves (inference)
+// a.first: 0 = the chain starts at the out-projection (three products), 1 = at the feed-forward input (two products; MODE 0 / 2)
+// a.last (MODE 1): 2 = stop at g_f, 3 = through the LayerNorm backward and the out-projection's data gradient
+template <int MODE>
 __global__ __launch_bounds__(GT) void ffn_kernel(FfnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -241,70 +278,55 @@ __global__ __launch_bounds__(GT) void ffn_kernel(FfnArgs a) {
   const int KA = d > dff ? d : dff;
   unsigned char* A = smem;                                   // [64][K] fp32 operand rows of the current product
   unsigned char* ring = smem + BM * KA * 4;
-  // products: forward  (A = f, K = d, N = dff, W1 as [n][k]) then (A = hdrop, K = dff, N = d, W2 as [n][k])
-  //           backward (A = g_o, K = d, N = dff, W2 [d, dff] as [k][n]) then (A = g_h, K = dff, N = d, W1 [dff, d] as [k][n])
+  float* red = reinterpret_cast<float*>(ring + NSTG * W_STAGE_B);
   constexpr bool BTR = MODE == 1;
-  const int K1 = d, N1 = dff, K2 = dff, N2 = d;
-  const int NP1 = N1 / BN, NP2 = N2 / BN, KS1 = K1 / BK, KS2 = K2 / BK;
+  constexpr bool FWD = MODE != 1;
+  // products  forward : [0] y = q + attn Wo^T + bo (K = d, N = d)   [1] hdrop = drop(relu(f W1^T + b1)) (K = d, N = dff)   [2] out = f + drop(hdrop W2^T + b2)
+  //           backward: [0] g_h = mask (g_o W2) (K = d, N = dff)    [1] g_f = g_h W1 + g_out (K = dff, N = d)            [2] g_A = g_y Wo (K = d, N = d)
+  const int first = FWD ? a.first : 0, last = FWD ? 3 : a.last;
+  const int K0 = d, K1 = FWD ? d : dff, K2 = FWD ? dff : d, N0 = FWD ? d : dff, N1 = FWD ? dff : d, N2 = d;
+  const int c4 = lane * 4;
+  const bool on = c4 < d;                                    // d = 128: half of the lanes hold a row's columns
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
   WStream ws;
   if (loader) {    // the ring runs ahead of the prologue: the weights do not depend on it
-    if (MODE == 0) wstream_init<BTR>(ws, cw, lane, a.w1p, d, K1, N1, a.w2p, dff, K2, N2, a.plane_stride, lds_addr(ring));
-    else wstream_init<BTR>(ws, cw, lane, a.w2p, dff, K1, N1, a.w1p, d, K2, N2, a.plane_stride, lds_addr(ring));
+    ws.plane_stride = a.plane_stride;
+    ws.base = __builtin_amdgcn_readfirstlane(lds_addr(ring) + (unsigned)(cw * 2 * 1024));
+    ws.slot = 0; ws.issued = 0; ws.no_dma = false;
+    wstream_open<BTR>(ws, a, first, cw, lane);
 #ifdef RT_ABLATION_BUILD
     ws.no_dma = (a.probe & 16) != 0;
 #endif
-    wstream_issue<BTR>(ws);
-    wstream_issue<BTR>(ws);
+    wstream_issue<BTR>(ws, a, cw, lane);
+    wstream_issue<BTR>(ws, a, cw, lane);
   }
 
-  // ---- prologue over the workgroup's 64 rows (8 per wave): the rows go to memory (saved for the other direction) AND into the LDS image
+  // ---- prologue over the workgroup's 64 rows (8 per wave): the first product's operand rows into the LDS image
   {
-    const int rs = K1 * 4;
+    const int rs = d * 4;
     f32x4 v[8];
-    const int c = lane * 4;
-    const bool on = c < d;                                   // d = 128: half of the lanes hold a row's columns
-    const float* src = MODE == 0 ? a.y : a.g_out;
+    const float* src = !FWD ? a.g_out : (first == 0 ? a.attn : a.y);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      v[r] = on ? *reinterpret_cast<const f32x4*>(src + (long long)(m0 + wave * 8 + r) * d + c) : z;
-    }
-    if (MODE == 0) {
-      // f = LN2(y): layernorm_fwd_kernel's arithmetic (sum -> mean -> centred squares -> rstd -> (v - mu) rs w + b), 8 rows interleaved
-      float s[8], q[8];
-#pragma unroll
-      for (int r = 0; r < 8; ++r) s[r] = 0.f + (v[r][0] + v[r][1] + v[r][2] + v[r][3]);
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int r = 0; r < 8; ++r) s[r] += __shfl_xor(s[r], o, 64);
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        s[r] = s[r] / d;                                     // mu
-        q[r] = 0.f;
-        if (on) {
-          const f32x4 t = v[r] - s[r];
-          q[r] += t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3];
-        }
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int r = 0; r < 8; ++r) q[r] += __shfl_xor(q[r], o, 64);
-      f32x4 ww = {0.f, 0.f, 0.f, 0.f}, bb = ww;
-      if (on) { ww = *reinterpret_cast<const f32x4*>(a.ln_w + c); bb = *reinterpret_cast<const f32x4*>(a.ln_b + c); }
+    for (int r = 0; r < 8; ++r) v[r] = on ? *reinterpret_cast<const f32x4*>(src + (long long)(m0 + wave * 8 + r) * d + c4) : zero4;
+    if (FWD && first == 1) {                                 // f = LN2(y)
+      float mu[8], rsd[8];
+      f32x4 ww = zero4, bb = zero4;
+      if (on) { ww = *reinterpret_cast<const f32x4*>(a.ln_w + c4); bb = *reinterpret_cast<const f32x4*>(a.ln_b + c4); }
+      ln8(v, on, d, a.eps, ww, bb, mu, rsd);
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const int lr = wave * 8 + r, m = m0 + lr;
-        const float rs_ = 1.0f / sqrtf(q[r] / d + a.eps);
         if (on) {
-          const f32x4 fv = (v[r] - s[r]) * rs_ * ww + bb;
-          if (!RT_PROBEA(1)) *reinterpret_cast<f32x4*>(a.f + (long long)m * d + c) = fv;
-          *reinterpret_cast<f32x4*>(A + a_off(lr, lane, rs)) = fv;
+          if (!RT_PROBEA(1)) *reinterpret_cast<f32x4*>(a.f + (long long)m * d + c4) = v[r];
+          *reinterpret_cast<f32x4*>(A + a_off(lr, lane, rs)) = v[r];
         }
-        if (lane == 0) { a.mean[m] = s[r]; a.rstd[m] = rs_; }
+        if (MODE == 0 && lane == 0) { a.mean[m] = mu[r]; a.rstd[m] = rsd[r]; }
       }
+    } else if (FWD) {                                        // the attention's output rows as they are
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        if (on) *reinterpret_cast<f32x4*>(A + a_off(wave * 8 + r, lane, rs)) = v[r];
     } else {
       // g_o = drop'(g_out) with the mask of the forward's output dropout (stream seed_o / sid_o, keyed by the float4 group of [M, d])
 #pragma unroll
@@ -313,8 +335,8 @@ __global__ __launch_bounds__(GT) void ffn_kernel(FfnArgs a) {
         if (on) {
           f32x4 gv = v[r];
           if (a.p > 0.f) {
-            gv = rt_drop4(gv, a.seed_o, a.sid_o, ((unsigned long long)m * d + c) >> 2, a.p, inv_keep);
-            if (!RT_PROBEA(1)) *reinterpret_cast<f32x4*>(a.g_o + (long long)m * d + c) = gv;
+            gv = rt_drop4(gv, a.seed_o, a.sid_o, ((unsigned long long)m * d + c4) >> 2, a.p, inv_keep);
+            if (!RT_PROBEA(1)) *reinterpret_cast<f32x4*>(a.g_o + (long long)m * d + c4) = gv;
           }
           *reinterpret_cast<f32x4*>(A + a_off(lr, lane, rs)) = gv;
         }
@@ -325,18 +347,25 @@ __global__ __launch_bounds__(GT) void ffn_kernel(FfnArgs a) {
   __syncthreads();                   // B0: the operand rows of the first product are in the LDS
 
   if (loader) {
-    // ---- weight stream: stage gi is published by barrier S_gi; stage gi + 2 is issued right behind it into the slot stage gi - 1 left
-    const int T1 = ws.T[0], T = ws.T[0] + ws.T[1];
+    // ---- weight stream: stage gi is published by barrier S_gi; stage gi + 2 is issued right behind it into the slot stage gi - 1 left.
+    // Between two products the compute waves rewrite the operand image: two barriers, three where a LayerNorm pass runs on the image
+    // (forward: behind the out-projection; backward: behind g_f) — the loaders only keep count; the ring keeps flying
+    const int T0 = (K0 / BK) * (N0 / BN), T1 = (K1 / BK) * (N1 / BN), T2 = (K2 / BK) * (N2 / BN);
+    const int T = (first == 0 ? T0 : 0) + T1 + (last == 3 ? T2 : 0);
+    int bound = first == 0 ? T0 : T1, seg = first;
 #pragma unroll 1
     for (int gi = 0; gi < T; ++gi) {
       if (gi + 1 < ws.issued) wait_vmcnt<PIECES>(); else wait_vmcnt<0>();      // everything but the youngest stage has landed
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (ws.issued < T) wstream_issue<BTR>(ws);
-      if (gi == T1 - 1) {            // between the products the compute waves rewrite the operand image (barriers X1, X2); the ring keeps flying
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_barrier();
+      if (ws.issued < T) wstream_issue<BTR>(ws, a, cw, lane);
+      if (gi == bound - 1 && gi + 1 < T) {
+        const int nb = (FWD ? seg == 0 : seg == 1) ? 3 : 2;
+#pragma unroll 1
+        for (int i = 0; i < nb; ++i) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        ++seg;
+        bound += seg == 1 ? T1 : T2;
       }
     }
     return;
@@ -347,50 +376,18 @@ __global__ __launch_bounds__(GT) void ffn_kernel(FfnArgs a) {
   const int lrow = wm * 32 + col;
   int slot = 0;
   f32x16 acc[2];
-  f32x4 keep[NPMAX][2][4];              // the first product's results (all passes): the second product's operand rows
-#pragma unroll
-  for (int pass = 0; pass < NPMAX; ++pass) {
-    if (pass < NP1) {
-      compute_pass<BTR>(A, K1 * 4, ring, slot, KS1, lane, wm, wn, acc, a.probe);
-      f32x4 x4[2][4];
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = pass * BN + wn * 64 + j * 32 + 8 * g + 4 * half;
-          x4[j][g] = MODE == 0 ? *reinterpret_cast<const f32x4*>(a.b1 + n) : *reinterpret_cast<const f32x4*>(a.hd + (long long)m * dff + n);
-        }
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = pass * BN + wn * 64 + j * 32 + 8 * g + 4 * half;
-          f32x4 v = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
-          if (MODE == 0) {              // hdrop = drop(relu(f W1^T + b1))
-            v += x4[j][g];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            if (a.p > 0.f) v = rt_drop4(v, a.seed_h, a.sid_h, ((unsigned long long)m * dff + n) >> 2, a.p, inv_keep);
-            if (!RT_PROBEA(2)) *reinterpret_cast<f32x4*>(a.hdrop + (long long)m * dff + n) = v;
-          } else {                      // g_h = [hdrop != 0] / keep * (g_o W2)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = x4[j][g][e] != 0.f ? v[e] * inv_keep : 0.f;
-            if (!RT_PROBEA(2)) *reinterpret_cast<f32x4*>(a.g_h + (long long)m * dff + n) = v;
-          }
-          keep[pass][j][g] = v;
-        }
-    }
-  }
-  // X1: every compute wave has read its last operand fragment of the first product.  LDS-only synchronisation: the epilogue's global
-  // stores keep draining under the second product (a __syncthreads would wait for them)
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  {
-    const int rs = K2 * 4;
+  f32x4 keep[NPMAX][2][4];              // a product's results (all passes): the next product's operand rows
+  auto lds_sync = [&]() {               // LDS-only synchronisation: the epilogues' global stores keep draining
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  auto publish = [&](int K_next, int np) {      // X1: every wave has read its last fragment; the kept rows become the image; X2
+    lds_sync();
+    const int rs = K_next * 4;
 #pragma unroll
     for (int pass = 0; pass < NPMAX; ++pass)
-      if (pass < NP1) {
+      if (pass < np) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -399,44 +396,179 @@ __global__ __launch_bounds__(GT) void ffn_kernel(FfnArgs a) {
             *reinterpret_cast<f32x4*>(A + a_off(lrow, n >> 2, rs)) = keep[pass][j][g];
           }
       }
+    lds_sync();
+  };
+#define RT_FOR_TILE(body)                                                                      \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int g = 0; g < 4; ++g) { \
+    const int n = pass * BN + wn * 64 + j * 32 + 8 * g + 4 * half;                             \
+    body                                                                                       \
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // X2: the second product's operand rows are in the LDS
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
+#define RT_ACC4 f32x4{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]}
+
+  if (FWD) {
+    if (first == 0) {
+      // ---- [0] y = q + attn Wo^T + bo, then f = LN2(y) on the image
+#pragma unroll
+      for (int pass = 0; pass < NPMAX; ++pass)
+        if (pass < N0 / BN) {
+          compute_pass<BTR>(A, K0 * 4, ring, slot, K0 / BK, lane, wm, wn, acc, a.probe);
+          f32x4 qv[2][4];
+          RT_FOR_TILE(qv[j][g] = *reinterpret_cast<const f32x4*>(a.q + (long long)m * d + n);)
+          RT_FOR_TILE(
+            f32x4 v = RT_ACC4;
+            v += *reinterpret_cast<const f32x4*>(a.bo + n);
+            v += qv[j][g];
+            if (MODE == 0) *reinterpret_cast<f32x4*>(a.y_out + (long long)m * d + n) = v;
+            keep[pass][j][g] = v;)
+        }
+      publish(K1, N0 / BN);
+      {   // LayerNorm over the image: 16 rows per compute wave, in place; f (and the statistics) also go to memory
+        const int rs = K1 * 4;
+        f32x4 ww = zero4, bb = zero4;
+        if (on) { ww = *reinterpret_cast<const f32x4*>(a.ln_w + c4); bb = *reinterpret_cast<const f32x4*>(a.ln_b + c4); }
 #pragma unroll 1
-  for (int pass = 0; pass < NP2; ++pass) {
-    compute_pass<BTR>(A, K2 * 4, ring, slot, KS2, lane, wm, wn, acc, a.probe);
-    if (RT_PROBEA(4)) { if (acc[0][0] == 12345.f) a.mean[0] = acc[1][3]; continue; }
-    const float* res = MODE == 0 ? a.f : a.g_out;      // the skip branch: f (forward), g_out (backward)
-    f32x4 rv[2][4], bv[2][4];
+        for (int r0 = 0; r0 < 16; r0 += 8) {
+          f32x4 v[8];
+          float mu[8], rsd[8];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+          for (int r = 0; r < 8; ++r) v[r] = on ? *reinterpret_cast<const f32x4*>(A + a_off(cw * 16 + r0 + r, lane, rs)) : zero4;
+          ln8(v, on, d, a.eps, ww, bb, mu, rsd);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = pass * BN + wn * 64 + j * 32 + 8 * g + 4 * half;
-        rv[j][g] = *reinterpret_cast<const f32x4*>(res + (long long)m * d + n);
-        if (MODE == 0) bv[j][g] = *reinterpret_cast<const f32x4*>(a.b2 + n);
+          for (int r = 0; r < 8; ++r) {
+            const int lr = cw * 16 + r0 + r, mm = m0 + lr;
+            if (on) {
+              *reinterpret_cast<f32x4*>(A + a_off(lr, lane, rs)) = v[r];
+              *reinterpret_cast<f32x4*>(a.f + (long long)mm * d + c4) = v[r];
+            }
+            if (MODE == 0 && lane == 0) { a.mean[mm] = mu[r]; a.rstd[mm] = rsd[r]; }
+          }
+        }
+        lds_sync();                     // X3
       }
+    }
+    // ---- [1] hdrop = drop(relu(f W1^T + b1))
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int pass = 0; pass < NPMAX; ++pass)
+      if (pass < N1 / BN) {
+        compute_pass<BTR>(A, K1 * 4, ring, slot, K1 / BK, lane, wm, wn, acc, a.probe);
+        RT_FOR_TILE(
+          f32x4 v = RT_ACC4;
+          v += *reinterpret_cast<const f32x4*>(a.b1 + n);
+          _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          if (a.p > 0.f) v = rt_drop4(v, a.seed_h, a.sid_h, ((unsigned long long)m * dff + n) >> 2, a.p, inv_keep);
+          if (MODE == 0 && !RT_PROBEA(2)) *reinterpret_cast<f32x4*>(a.hdrop + (long long)m * dff + n) = v;
+          keep[pass][j][g] = v;)
+      }
+    publish(K2, N1 / BN);
+    // ---- [2] out = f + drop(hdrop W2^T + b2)
+#pragma unroll 1
+    for (int pass = 0; pass < N2 / BN; ++pass) {
+      compute_pass<BTR>(A, K2 * 4, ring, slot, K2 / BK, lane, wm, wn, acc, a.probe);
+      if (RT_PROBEA(4)) { if (acc[0][0] == 12345.f) a.out[0] = acc[1][3]; continue; }
+      f32x4 fv[2][4];
+      RT_FOR_TILE(fv[j][g] = *reinterpret_cast<const f32x4*>(a.f + (long long)m * d + n);)
+      RT_FOR_TILE(
+        f32x4 v = RT_ACC4;
+        v += *reinterpret_cast<const f32x4*>(a.b2 + n);
+        if (a.p > 0.f) v = rt_drop4(v, a.seed_o, a.sid_o, ((unsigned long long)m * d + n) >> 2, a.p, inv_keep);
+        v += fv[j][g];
+        *reinterpret_cast<f32x4*>(a.out + (long long)m * d + n) = v;)
+    }
+  } else {
+    // ---- [0] g_h = [hdrop != 0] / keep * (g_o W2)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = pass * BN + wn * 64 + j * 32 + 8 * g + 4 * half;
-        f32x4 v = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
-        if (MODE == 0) {                // out = f + drop(hdrop W2^T + b2)
-          v += bv[j][g];
-          if (a.p > 0.f) v = rt_drop4(v, a.seed_o, a.sid_o, ((unsigned long long)m * d + n) >> 2, a.p, inv_keep);
+    for (int pass = 0; pass < NPMAX; ++pass)
+      if (pass < N0 / BN) {
+        compute_pass<BTR>(A, K0 * 4, ring, slot, K0 / BK, lane, wm, wn, acc, a.probe);
+        f32x4 hv[2][4];
+        RT_FOR_TILE(hv[j][g] = *reinterpret_cast<const f32x4*>(a.hd + (long long)m * dff + n);)
+        RT_FOR_TILE(
+          f32x4 v;
+          _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = hv[j][g][e] != 0.f ? acc[j][4 * g + e] * inv_keep : 0.f;
+          if (!RT_PROBEA(2)) *reinterpret_cast<f32x4*>(a.g_h + (long long)m * dff + n) = v;
+          keep[pass][j][g] = v;)
+      }
+    publish(K1, N0 / BN);
+    // ---- [1] g_f = g_h W1 + g_out
+#pragma unroll
+    for (int pass = 0; pass < NPMAX; ++pass)
+      if (pass < N1 / BN) {
+        compute_pass<BTR>(A, K1 * 4, ring, slot, K1 / BK, lane, wm, wn, acc, a.probe);
+        if (RT_PROBEA(4)) { if (acc[0][0] == 12345.f) a.g_f[0] = acc[1][3]; continue; }
+        f32x4 rv[2][4];
+        RT_FOR_TILE(rv[j][g] = *reinterpret_cast<const f32x4*>(a.g_out + (long long)m * d + n);)
+        RT_FOR_TILE(
+          f32x4 v = RT_ACC4;
           v += rv[j][g];
-          *reinterpret_cast<f32x4*>(a.out + (long long)m * d + n) = v;
-        } else {                        // g_f = g_h W1 + g_out
-          v += rv[j][g];
-          *reinterpret_cast<f32x4*>(a.g_f + (long long)m * d + n) = v;
+          if (last == 2) *reinterpret_cast<f32x4*>(a.g_f + (long long)m * d + n) = v;
+          keep[pass][j][g] = v;)
+      }
+    if (last == 3) {
+      publish(K2, N1 / BN);
+      {   // LayerNorm backward over the image (layernorm_bwd_kernel's arithmetic): g_y in place and to memory, this workgroup's
+          // share of d ln_w / d ln_b to partial[blockIdx][2][d] (summed by rt_layernorm_bwd_reduce)
+        const int rs = K2 * 4;
+        const f32x4 wv = on ? *reinterpret_cast<const f32x4*>(a.ln_w + c4) : zero4;
+        f32x4 pw = zero4, pb = zero4;
+#pragma unroll 1
+        for (int r0 = 0; r0 < 16; r0 += 8) {
+          f32x4 gq[8], xh[8];
+          float mu[8], rsd[8], s1[8], s2[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const int lr = cw * 16 + r0 + r, mm = m0 + lr;
+            mu[r] = a.mean[mm]; rsd[r] = a.rstd[mm];
+            gq[r] = on ? *reinterpret_cast<const f32x4*>(A + a_off(lr, lane, rs)) : zero4;
+            xh[r] = on ? *reinterpret_cast<const f32x4*>(a.y + (long long)mm * d + c4) : zero4;
+          }
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            xh[r] = on ? (xh[r] - mu[r]) * rsd[r] : zero4;
+            const f32x4 gw = gq[r] * wv;
+            s1[r] = 0.f + (gw[0] + gw[1] + gw[2] + gw[3]);
+            s2[r] = 0.f + (gw[0] * xh[r][0] + gw[1] * xh[r][1] + gw[2] * xh[r][2] + gw[3] * xh[r][3]);
+          }
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { s1[r] += __shfl_xor(s1[r], o, 64); s2[r] += __shfl_xor(s2[r], o, 64); }
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const int lr = cw * 16 + r0 + r, mm = m0 + lr;
+            s1[r] = s1[r] / d; s2[r] = s2[r] / d;
+            if (on) {
+              const f32x4 o4 = (gq[r] * wv - s1[r] - xh[r] * s2[r]) * rsd[r];
+              *reinterpret_cast<f32x4*>(A + a_off(lr, lane, rs)) = o4;
+              *reinterpret_cast<f32x4*>(a.g_y + (long long)mm * d + c4) = o4;
+              pw += gq[r] * xh[r];
+              pb += gq[r];
+            }
+          }
+        }
+        if (on) {
+          *reinterpret_cast<f32x4*>(red + (cw * 2 + 0) * d + c4) = pw;
+          *reinterpret_cast<f32x4*>(red + (cw * 2 + 1) * d + c4) = pb;
+        }
+        lds_sync();                     // X3: g_y rows and the four waves' partials are in the LDS
+        float* part = a.ln_partial + (long long)blockIdx.x * 2 * d;
+        for (int c = cw * 64 + lane; c < d; c += 256) {
+          part[c] = (red[0 * d + c] + red[2 * d + c]) + (red[4 * d + c] + red[6 * d + c]);
+          part[d + c] = (red[1 * d + c] + red[3 * d + c]) + (red[5 * d + c] + red[7 * d + c]);
         }
       }
+      // ---- [2] g_A = g_y Wo
+#pragma unroll 1
+      for (int pass = 0; pass < N2 / BN; ++pass) {
+        compute_pass<BTR>(A, K2 * 4, ring, slot, K2 / BK, lane, wm, wn, acc, a.probe);
+        RT_FOR_TILE(*reinterpret_cast<f32x4*>(a.g_A + (long long)m * d + n) = RT_ACC4;)
+      }
+    }
   }
+#undef RT_FOR_TILE
+#undef RT_ACC4
 }
 
-size_t lds_bytes(int d, int dff) { return (size_t)BM * (d > dff ? d : dff) * 4 + (size_t)NSTG * W_STAGE_B; }
+size_t lds_bytes(int d, int dff) { return (size_t)BM * (d > dff ? d : dff) * 4 + (size_t)NSTG * W_STAGE_B + RED_B; }
 bool shape_ok(int M, int d, int dff, long long plane_stride) {
   return M > 0 && M % BM == 0 && d % BN == 0 && dff % BN == 0 && d <= 256 && dff <= NPMAX * BN && lds_bytes(d, dff) <= 160 * 1024 &&
          (plane_stride & 7) == 0;
@@ -460,8 +592,8 @@ int launch(const FfnArgs& a, hipStream_t stream) {
 
 extern "C" {
 
-// 1 when rt_ffn_fused_fwd / _bwd serve the shape (rows a multiple of 64, d and dff 128 or 256: the operand rows of a product stay in the LDS): the block executor
-// asks once per call and takes the five-launch sequence otherwise.
+// 1 when the row-resident chain kernels serve the shape (rows a multiple of 64, d and dff 128 or 256: the operand rows of a product stay
+// in the LDS): the block executor asks once per call and takes the separate launches otherwise.
 int rt_ffn_fused_supported(int32_t M, int32_t d, int32_t dff) { return shape_ok(M, d, dff, 0) ? 1 : 0; }
 
 // Forward of the feed-forward half on M packed rows: f = LN(y; ln_w, ln_b, eps) (+ mean, rstd [M]), hdrop [M, dff] = drop(relu(f W1^T +
@@ -480,9 +612,9 @@ int rt_ffn_fused_fwd(const float* y, const float* ln_w, const float* ln_b, float
   if (mis(y) || mis(ln_w) || mis(ln_b) || mis(f) || mis(w1_planes) || mis(w2_planes) || mis(b1) || mis(b2) || mis(hdrop) || mis(out))
     return RT_ERR_INVALID_ARG;
   FfnArgs a{};
-  a.M = M; a.d = d; a.dff = dff; a.p = p; a.eps = eps;
+  a.M = M; a.d = d; a.dff = dff; a.p = p; a.eps = eps; a.first = 1; a.last = 3;
   a.seed_h = seed_h; a.sid_h = sid_h; a.seed_o = seed_o; a.sid_o = sid_o;
-  a.w1p = w1_planes; a.w2p = w2_planes; a.plane_stride = plane_stride;
+  a.w1p = w1_planes; a.w2p = w2_planes; a.wop = w1_planes; a.plane_stride = plane_stride;
   a.y = y; a.ln_w = ln_w; a.ln_b = ln_b; a.b1 = b1; a.b2 = b2; a.f = f; a.mean = mean; a.rstd = rstd; a.hdrop = hdrop; a.out = out;
   return launch<0>(a, stream);
 }
@@ -500,10 +632,65 @@ int rt_ffn_fused_bwd(const float* g_out, const float* hdrop, const uint16_t* w1_
   if (!shape_ok(M, d, dff, plane_stride)) return RT_ERR_UNSUPPORTED;
   if (mis(g_out) || mis(hdrop) || mis(w1_planes) || mis(w2_planes) || mis(g_o) || mis(g_h) || mis(g_f)) return RT_ERR_INVALID_ARG;
   FfnArgs a{};
-  a.M = M; a.d = d; a.dff = dff; a.p = p;
+  a.M = M; a.d = d; a.dff = dff; a.p = p; a.first = 0; a.last = 2;
   a.seed_o = seed_o; a.sid_o = sid_o;
-  a.w1p = w1_planes; a.w2p = w2_planes; a.plane_stride = plane_stride;
+  a.w1p = w1_planes; a.w2p = w2_planes; a.wop = w1_planes; a.plane_stride = plane_stride;
   a.g_out = g_out; a.hd = hdrop; a.g_o = g_o; a.g_h = g_h; a.g_f = g_f;
+  return launch<1>(a, stream);
+}
+
+// The whole tail of a packed SASRec block behind its attention (sasrec.py:224-229) as ONE launch:
+//   y = q + attn Wo^T + bo;  f = LN2(y);  hdrop = drop(relu(f W1^T + b1));  out = f + drop(hdrop W2^T + b2)
+// training != 0: y, f, mean, rstd, hdrop are written (what rt_block_tail_bwd reads).  training == 0 (recommend(): p must be 0): only `out`
+// and the scratch rows `f` are written — y, mean, rstd, hdrop may be NULL; a row then crosses the memory pipe three times (attn and q in,
+// out out) instead of twelve.  wo_planes: the planes of the out-projection's weight [d, d], same plane_stride as w1 / w2.
+int rt_block_tail_fwd(const float* attn, const float* q, const uint16_t* wo_planes, const float* bo, const float* ln_w, const float* ln_b,
+                      float eps, float* y, float* f, float* mean, float* rstd, const uint16_t* w1_planes, const uint16_t* w2_planes,
+                      int64_t plane_stride, const float* b1, const float* b2, float* hdrop, float* out, int32_t M, int32_t d, int32_t dff, float p,
+                      uint64_t seed_h, uint64_t sid_h, uint64_t seed_o, uint64_t sid_o, int32_t training, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (attn == nullptr || q == nullptr || wo_planes == nullptr || bo == nullptr || ln_w == nullptr || ln_b == nullptr || f == nullptr ||
+      w1_planes == nullptr || w2_planes == nullptr || b1 == nullptr || b2 == nullptr || out == nullptr || p < 0.f || p >= 1.f)
+    return RT_ERR_INVALID_ARG;
+  if (training ? (y == nullptr || mean == nullptr || rstd == nullptr || hdrop == nullptr) : p != 0.f) return RT_ERR_INVALID_ARG;
+  if (!shape_ok(M, d, dff, plane_stride)) return RT_ERR_UNSUPPORTED;
+  if (mis(attn) || mis(q) || mis(wo_planes) || mis(bo) || mis(ln_w) || mis(ln_b) || mis(y) || mis(f) || mis(w1_planes) || mis(w2_planes) ||
+      mis(b1) || mis(b2) || mis(hdrop) || mis(out))
+    return RT_ERR_INVALID_ARG;
+  FfnArgs a{};
+  a.M = M; a.d = d; a.dff = dff; a.p = p; a.eps = eps; a.first = 0; a.last = 3;
+  a.seed_h = seed_h; a.sid_h = sid_h; a.seed_o = seed_o; a.sid_o = sid_o;
+  a.w1p = w1_planes; a.w2p = w2_planes; a.wop = wo_planes; a.plane_stride = plane_stride;
+  a.attn = attn; a.q = q; a.bo = bo; a.y_out = y; a.ln_w = ln_w; a.ln_b = ln_b; a.b1 = b1; a.b2 = b2; a.f = f; a.mean = mean; a.rstd = rstd;
+  a.hdrop = hdrop; a.out = out;
+  return training ? launch<0>(a, stream) : launch<2>(a, stream);
+}
+
+size_t rt_block_tail_partial_floats(int32_t M, int32_t d) { return M > 0 && d > 0 ? (size_t)(M / BM) * 2 * (size_t)d : 0; }
+
+// Its backward down to the attention's output: g_o (p > 0 only), g_h as rt_ffn_fused_bwd; then, with the rows still in the LDS, the
+// LayerNorm backward g_y = LN2'(g_f; y, mean, rstd, ln_w) — g_f itself never leaves the chip — and g_A [M, d] = g_y Wo.  ln_partial
+// [(M / 64) * 2 * d floats]: every workgroup's share of d ln_w / d ln_b; rt_layernorm_bwd_reduce(ln_partial, M / 64, d, ...) sums them.
+// The three weight gradients (g_o^T hdrop, g_h^T f, g_y^T attn) stay with the caller.
+int rt_block_tail_bwd(const float* g_out, const float* hdrop, const float* y, const float* mean, const float* rstd, const float* ln_w,
+                      const uint16_t* wo_planes, const uint16_t* w1_planes, const uint16_t* w2_planes, int64_t plane_stride, float* g_o,
+                      float* g_h, float* g_y, float* g_A, float* ln_partial, int32_t M, int32_t d, int32_t dff, float p, uint64_t seed_o,
+                      uint64_t sid_o, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (g_out == nullptr || hdrop == nullptr || y == nullptr || mean == nullptr || rstd == nullptr || ln_w == nullptr || wo_planes == nullptr ||
+      w1_planes == nullptr || w2_planes == nullptr || g_h == nullptr || g_y == nullptr || g_A == nullptr || ln_partial == nullptr ||
+      (p > 0.f && g_o == nullptr) || p < 0.f || p >= 1.f)
+    return RT_ERR_INVALID_ARG;
+  if (!shape_ok(M, d, dff, plane_stride)) return RT_ERR_UNSUPPORTED;
+  if (mis(g_out) || mis(hdrop) || mis(y) || mis(ln_w) || mis(wo_planes) || mis(w1_planes) || mis(w2_planes) || mis(g_o) || mis(g_h) ||
+      mis(g_y) || mis(g_A) || mis(ln_partial))
+    return RT_ERR_INVALID_ARG;
+  FfnArgs a{};
+  a.M = M; a.d = d; a.dff = dff; a.p = p; a.first = 0; a.last = 3;
+  a.seed_o = seed_o; a.sid_o = sid_o;
+  a.w1p = w1_planes; a.w2p = w2_planes; a.wop = wo_planes; a.plane_stride = plane_stride;
+  a.g_out = g_out; a.hd = hdrop; a.y = y; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd); a.ln_w = ln_w;
+  a.g_o = g_o; a.g_h = g_h; a.g_y = g_y; a.g_A = g_A; a.ln_partial = ln_partial;
   return launch<1>(a, stream);
 }
 

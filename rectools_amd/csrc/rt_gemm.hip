@@ -347,7 +347,7 @@ __device__ __forceinline__ Split3 split_bf16x3(const f32x4& x0, const f32x4& x1)
 }
 
 template <bool AKC, bool BKC, int NS, bool X6 = false>
-__device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int t, float* smem) {
+__device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int t, float* smem, int zs, int nz) {     // zs of nz split-K slices
   constexpr int STAGE_F = 2 * TILE_F;
   constexpr int NL = 8;   // DMA instructions per wave per stage
 
@@ -365,7 +365,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int t, float* s
 
   int k_begin = 0, k_end = g.K;
   if (g.k_per_split > 0) {
-    k_begin = blockIdx.z * g.k_per_split;
+    k_begin = zs * g.k_per_split;
     k_end = min(k_begin + g.k_per_split, g.K);
     if (k_begin >= k_end) return;
   }
@@ -462,9 +462,9 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int t, float* s
   const bool direct = g.k_per_split == 0;
   if (!AKC && want_rowsum && tid < BM) {
     if (direct) g.a_rowsum[m0 + tid] = rowsum;
-    else g.slabs[(long long)gridDim.z * g.M * g.N + (long long)blockIdx.z * g.M + m0 + tid] = rowsum;
+    else g.slabs[(long long)nz * g.M * g.N + (long long)zs * g.M + m0 + tid] = rowsum;
   }
-  float* dst = direct ? g.C : g.slabs + (long long)blockIdx.z * g.M * g.N;
+  float* dst = direct ? g.C : g.slabs + (long long)zs * g.M * g.N;
   const long long ldd = direct ? g.ldc : g.N;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -493,7 +493,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, int t, float* s
 template <bool AKC, bool BKC, int NS, bool X6 = false>
 __global__ __launch_bounds__(GT) void gemm_dma_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [NS][A tile | B tile]
-  gemm_dma_body<AKC, BKC, NS, X6>(g, blockIdx.x, smem);
+  gemm_dma_body<AKC, BKC, NS, X6>(g, blockIdx.x, smem, blockIdx.z, gridDim.z);
 }
 
 // Grouped launch: up to 4 independent products with the same operand layouts in ONE grid (tile ranges back to back).  A
@@ -507,7 +507,21 @@ __global__ __launch_bounds__(GT) void gemm_dma_group_kernel(GemmGroup gg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int t = blockIdx.x;
   const int p = (t >= gg.tile_end[0]) + (t >= gg.tile_end[1]) + (t >= gg.tile_end[2]);
-  gemm_dma_body<AKC, BKC, NS, X6>(gg.g[p], t - (p > 0 ? gg.tile_end[p - 1] : 0), smem);
+  gemm_dma_body<AKC, BKC, NS, X6>(gg.g[p], t - (p > 0 ? gg.tile_end[p - 1] : 0), smem, 0, 1);
+}
+
+// Grouped WEIGHT GRADIENTS: up to 6 products dW_i [n_out_i, n_in_i] = dy_i^T in_i over the same rows, every one split-K over grid.y, in
+// ONE launch (tile ranges back to back) — the five weight gradients of a transformer block were ten launches (a product and its combine
+// each) of 4 - 8 tiles x ~34 slices; together they are 24 tiles whose slices fill the machine once.  A second launch combines all slabs.
+struct WgradGroup { GemmArgs g[6]; int tile_end[6]; int n; };
+template <int NS, bool X6>
+__global__ __launch_bounds__(GT) void wgrad_group_kernel(WgradGroup gg) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int t = blockIdx.x;
+  int p = 0;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) p += t >= gg.tile_end[i] ? 1 : 0;
+  gemm_dma_body<false, false, NS, X6>(gg.g[p], t - (p > 0 ? gg.tile_end[p - 1] : 0), smem, blockIdx.y, gridDim.y);
 }
 
 // (A 224 x 128-tile variant for the M = 25,600 products — 230 workgroups, one per CU, instead of 400 on 512 half-CU slots —
@@ -553,6 +567,32 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   } else {
     a_rowsum[i] = t[0]; a_rowsum[i + 1] = t[1]; a_rowsum[i + 2] = t[2]; a_rowsum[i + 3] = t[3];
   }
+}
+// the same combine for every product of a grouped weight-gradient launch: block ranges back to back (main blocks, then row-sum blocks,
+// per product)
+struct ReduceGroup { const float* slabs[6]; float* C[6]; float* rowsum[6]; int M[6], N[6], blk_end[6]; int n, splits; };
+__global__ __launch_bounds__(256) void splitk_reduce_group_kernel(ReduceGroup rg) {
+  __shared__ f32x4 red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int b = blockIdx.x, p = 0;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) p += b >= rg.blk_end[i] ? 1 : 0;
+  b -= p > 0 ? rg.blk_end[p - 1] : 0;
+  const int M = rg.M[p], N = rg.N[p];
+  const long long mn = (long long)M * N;
+  const int n_main = (int)((mn / 4 + 63) / 64);
+  const bool main = b < n_main;
+  const long long i = ((long long)(main ? b : b - n_main) * 64 + lane) * 4;
+  const long long count = main ? mn : (long long)M;
+  const float* base = main ? rg.slabs[p] : rg.slabs[p] + (long long)rg.splits * mn;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (i < count) s = sum_slabs(base + i, count, rg.splits, w);
+  red[w][lane] = s;
+  __syncthreads();
+  if (w != 0 || i >= count) return;
+  const f32x4 t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  float* dst = main ? rg.C[p] + i : rg.rowsum[p] + i;            // dW is contiguous [n_out, n_in]
+  dst[0] = t[0]; dst[1] = t[1]; dst[2] = t[2]; dst[3] = t[3];
 }
 __global__ __launch_bounds__(256) void splitk_reduce_scalar_kernel(const float* __restrict__ slabs, int splits, long long mn, int N,
                                                                    const float* __restrict__ bias, float* __restrict__ C,
@@ -782,6 +822,82 @@ int rt_gemm_grouped(const rt_gemm_problem* problems, int32_t n, int32_t a_kc, in
   if (a_kc && !b_kc) return launch(&gemm_dma_group_kernel<true, false, 2>);
   if (!a_kc && b_kc) return launch(&gemm_dma_group_kernel<false, true, 2>);
   return launch(&gemm_dma_group_kernel<false, false, 2>);
+}
+
+// Up to 6 weight gradients over the same `rows` rows in two launches (products + combine): dW_i [n_out_i, n_in_i] (contiguous) =
+// dy_i^T in_i, db_i [n_out_i] = column sums of dy_i (nullable).  splits: upper bound of the split-K factor (the library lowers it so
+// that the launch is about two workgroups per CU).  Exact-tile shapes only (n_out, n_in multiples of 128, rows of 32, 16-byte aligned
+// operands): otherwise RT_ERR_UNSUPPORTED and the caller issues rt_gemm per product.  Results equal rt_gemm's with the same split
+// factor (same slices, same fixed-order combine).
+struct rt_wgrad_problem { const float* dy; int64_t ldy; const float* in; int64_t ldin; float* dw; float* db; int32_t n_out, n_in; };
+static int wgrad_group_splits(const rt_wgrad_problem* problems, int n, int rows, int splits, int* kps_out) {
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) tiles += (problems[i].n_out / BM) * (problems[i].n_in / BN);
+  int sp = splits > 1 ? splits : 1;
+  const int want = (2 * rt_num_cus() + tiles - 1) / (tiles > 0 ? tiles : 1);
+  if (sp > want) sp = want;
+  if (sp < 1) sp = 1;
+  int kps = (rows + sp - 1) / sp;
+  kps = (kps + BK - 1) / BK * BK;
+  *kps_out = kps;
+  return (rows + kps - 1) / kps;
+}
+size_t rt_wgrad_grouped_workspace_bytes(const rt_wgrad_problem* problems, int32_t n, int32_t rows, int32_t splits) {
+  if (problems == nullptr || n < 1 || n > 6 || rows <= 0) return 0;
+  int kps;
+  const int sp = wgrad_group_splits(problems, n, rows, splits, &kps);
+  size_t fl = 0;
+  for (int i = 0; i < n; ++i) fl += (size_t)sp * ((size_t)problems[i].n_out * problems[i].n_in + problems[i].n_out);
+  return fl * sizeof(float);
+}
+int rt_wgrad_grouped(const rt_wgrad_problem* problems, int32_t n, int32_t rows, int32_t splits, void* workspace, size_t workspace_bytes,
+                     hipStream_t stream) {
+  (void)hipGetLastError();
+  if (problems == nullptr || n < 1 || n > 6 || rows <= 0) return RT_ERR_INVALID_ARG;
+  if (gemm_impl() == 0 || (rows % BK) != 0) return RT_ERR_UNSUPPORTED;
+  for (int i = 0; i < n; ++i) {
+    const rt_wgrad_problem& q = problems[i];
+    if (q.dy == nullptr || q.in == nullptr || q.dw == nullptr) return RT_ERR_INVALID_ARG;
+    if (q.n_out <= 0 || q.n_in <= 0 || (q.n_out % BM) != 0 || (q.n_in % BN) != 0 || (q.ldy & 3) != 0 || (q.ldin & 3) != 0 ||
+        (reinterpret_cast<uintptr_t>(q.dy) & 15) != 0 || (reinterpret_cast<uintptr_t>(q.in) & 15) != 0 ||
+        (reinterpret_cast<uintptr_t>(q.dw) & 15) != 0 || (reinterpret_cast<uintptr_t>(q.db) & 15) != 0)
+      return RT_ERR_UNSUPPORTED;
+  }
+  int kps;
+  const int sp = wgrad_group_splits(problems, n, rows, splits, &kps);
+  if (workspace == nullptr || workspace_bytes < rt_wgrad_grouped_workspace_bytes(problems, n, rows, splits)) return RT_ERR_WORKSPACE;
+  WgradGroup gg{};
+  ReduceGroup rg{};
+  float* ws = reinterpret_cast<float*>(workspace);
+  int tiles = 0, blks = 0;
+  for (int i = 0; i < 6; ++i) {
+    if (i < n) {
+      const rt_wgrad_problem& q = problems[i];
+      GemmArgs& g = gg.g[i];
+      g.A = q.dy; g.lda = q.ldy; g.B = q.in; g.ldb = q.ldin; g.C = q.dw; g.ldc = q.n_in; g.M = q.n_out; g.N = q.n_in; g.K = rows;
+      g.k_per_split = kps; g.slabs = ws; g.a_rowsum = q.db;      // (k_per_split > 0 also with one slice: the slab path, then the combine)
+      rg.slabs[i] = ws; rg.C[i] = q.dw; rg.rowsum[i] = q.db; rg.M[i] = q.n_out; rg.N[i] = q.n_in;
+      ws += (size_t)sp * ((size_t)q.n_out * q.n_in + q.n_out);
+      tiles += (q.n_out / BM) * (q.n_in / BN);
+      const long long mn = (long long)q.n_out * q.n_in;
+      blks += (int)((mn / 4 + 63) / 64) + (q.db != nullptr ? (q.n_out / 4 + 63) / 64 : 0);
+    }
+    gg.tile_end[i] = tiles;
+    rg.blk_end[i] = blks;
+  }
+  gg.n = n; rg.n = n; rg.splits = sp;
+  const size_t lds = (size_t)2 * 2 * TILE_F * sizeof(float);
+  auto launch = [&](auto kernel) -> int {
+    RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    kernel<<<dim3(tiles, sp), GT, lds, stream>>>(gg);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+  };
+  const int rc = gemm_x6() ? launch(&wgrad_group_kernel<2, true>) : launch(&wgrad_group_kernel<2, false>);
+  if (rc != RT_OK) return rc;
+  splitk_reduce_group_kernel<<<blks, 256, 0, stream>>>(rg);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
 }
 
 // out[n] += sum_m X[m,n]  (caller zero-fills `out`)

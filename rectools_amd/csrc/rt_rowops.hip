@@ -772,6 +772,16 @@ int rt_layernorm_bwd_fused(const float* dy, const float* x, const float* w, cons
   return RT_OK;
 }
 
+// dw[c] = sum_b partial[b][0][c], db[c] = sum_b partial[b][1][c] over `blocks` partials of 2 d floats (fixed order): the second stage of
+// the LayerNorm backward for callers that produce the per-block partials themselves (rt_block_tail_bwd).
+int rt_layernorm_bwd_reduce(const float* partial, int32_t blocks, int32_t d, float* dw, float* db, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (partial == nullptr || dw == nullptr || db == nullptr || blocks <= 0 || d <= 0) return RT_ERR_INVALID_ARG;
+  layernorm_bwd_reduce_kernel<<<(2 * d + 15) / 16, 256, 0, stream>>>(partial, blocks, d, dw, db);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
 int rt_act_dropout_fwd(const float* z, int32_t kind, float p, uint64_t seed, uint64_t stream_id, int64_t n,
                        const float* residual, float* y, hipStream_t stream) {
   (void)hipGetLastError();
