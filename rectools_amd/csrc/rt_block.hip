@@ -768,8 +768,13 @@ int rt_sasrec_block_packed_infer(const rt_sasrec_block* blk, const float* x, con
     RT_TRY(lin(q, d, b.in_w, b.in_wp, d, Q, d, b.in_b, nullptr, 0, R, d, d, 0));
     RT_TRY(rt_mha_varlen_last_fwd(Q, d, KV, 2 * d, KV + d, 2 * d, b.cu, bk, bv, b.B, b.H, hd, b.window, b.window, A, d, stream));
   }
-  if (ffn_mode() == 2 && b.out_wp != nullptr && b.w1_wp != nullptr && b.w2_wp != nullptr && rt_ffn_fused_supported(R, d, dff) == 1) {
-    // the block's tail with the rows resident on chip: attn and q in, out out (+ the scratch rows f) — no y, h, statistics
+  // The block's tail with the rows resident on chip (attn and q in, out out, + the scratch rows f — no y, h, statistics) pays while the
+  // launch is a round or two of 64-row workgroups: every workgroup streams all three weights (1.2 MB of planes) for its 64 rows, twice the
+  // weight traffic per row of the 128 x 128-tile products — at recommend()'s 10^5..10^6 rows per launch the separate products win
+  // (visit v4j of round 4: encoder 23.7 vs 21.4 ms per 16,384 users)
+  static const int infer_tail_rows = [] { const char* e = getenv("RT_INFER_TAIL_MAX_ROWS"); return e ? atoi(e) : 2 * 64 * rt_num_cus(); }();
+  if (ffn_mode() == 2 && R <= infer_tail_rows && b.out_wp != nullptr && b.w1_wp != nullptr && b.w2_wp != nullptr &&
+      rt_ffn_fused_supported(R, d, dff) == 1) {
     RT_TRY(rt_block_tail_fwd(A, q, b.out_wp, b.out_b, b.ln2_w, b.ln2_b, b.eps2, nullptr, f, nullptr, nullptr, b.w1_wp, b.w2_wp, b.wp_stride, b.b1, b.b2,
                              nullptr, out, R, d, dff, 0.f, 0, 0, 0, 0, 0, stream));
     return RT_OK;

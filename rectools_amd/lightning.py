@@ -342,7 +342,8 @@ class FlatAdam:
         same parameter bytes.  gloo (CPU tests, ranks sharing a GPU) has no reduce-scatter: all-reduce + slice there."""
         import torch.distributed as dist
 
-        if not self._use_sharded(world_size):
+        n_flat = self.flat_p.numel()
+        if world_size < 1 or n_flat % world_size != 0 or (n_flat // world_size) % 4 != 0:
             raise ValueError(f"sharded exchange: world size {world_size} does not cut the flat buffer ({self.flat_p.numel()} floats) into "
                              f"equal 16-byte aligned slices")
         if self.partial_moments is not None and self.partial_moments != (world_size, rank):

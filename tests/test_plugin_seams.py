@@ -156,7 +156,7 @@ class ShiftedBackbone(hnn.TransformerTorchBackbone):
 
 
 @pytest.mark.gpu
-def test_overridden_hooks_run_where_the_stack_would_otherwise_pack():
+def test_overridden_hooks_run_where_the_stack_would_otherwise_pack(monkeypatch):
     """packed training calls `training_loss_packed` / `encode_packed_train`, packed recommend `encode_last_packed` — a
     subclass overriding `training_loss` or `encode_sessions` was bypassed whenever the stack packs (stock positional encoding, head
     size 32 / 64).  With such a subclass plugged in the loop must keep the padded path, on which the override runs."""
@@ -172,12 +172,16 @@ def test_overridden_hooks_run_where_the_stack_would_otherwise_pack():
     plugged = SASRecModel(lightning_module_type=ScaledLossModule, lightning_module_kwargs={"loss_scale": 3.0}, **common)
     plugged._build_model_from_dataset(ds)
     plugged.torch_model.load_state_dict(stock.torch_model.state_dict())
-    loop_a, loop_b = stock.training_loop(), plugged.training_loop()
+    loop_b = plugged.training_loop()
     assert not loop_b.packed
+    monkeypatch.setenv("RT_PACKED_TRAIN", "0")       # the stock model on the padded window too: same batches, same negatives
+    loop_a = stock.training_loop()
+    monkeypatch.delenv("RT_PACKED_TRAIN")
+    assert not loop_a.packed
     stock.lightning_model.train(); plugged.lightning_model.train()
     loop_a.begin_epoch(0); loop_b.begin_epoch(0)
     la, lb = float(loop_a.step()), float(loop_b.step())
-    assert plugged.lightning_model.seen == 1 and abs(lb - 3.0 * la) <= 2e-5 * abs(lb)      # packed == padded up to fp32 rounding
+    assert plugged.lightning_model.seen == 1 and abs(lb - 3.0 * la) <= 2e-5 * abs(lb)
     # a backbone that overrides encode_sessions: training AND recommend() go through it
     ShiftedBackbone.calls = 0
     m = SASRecModel(backbone_type=ShiftedBackbone, **common)
