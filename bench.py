@@ -180,6 +180,55 @@ def make_topk_workload(n_items: int, d: int, users_per_step: int, upp: int, rank
                               filt=filt)
 
 
+def topk_extras(info, users_per_step: int, upp: int):
+    """What the timed two-stage call does not show: the one-time cost and footprint of the catalog's coarse-pass image(s)
+    — built by the first call on a catalog, kept by the model between recommend() calls (models._catalog_images) — and, for the
+    16-user launch, the single-stage kernel on the fp32 rows (the path that reads the 10.24 GB catalog itself)."""
+    from rectools_amd.rank import HipRanker
+
+    items, users = info["items"], info["users_t"]
+    n, d = items.shape
+    sids = np.arange(users_per_step)
+    out = {}
+    r = HipRanker("dot", "cuda", users, items, batch_size=upp or None)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    r.rank_device(sids, k=10)            # first call on this ranker: builds the image(s), then ranks
+    e1.record()
+    torch.cuda.synchronize()
+    first_ms = e0.elapsed_time(e1)
+    e0.record()
+    r.rank_device(sids, k=10)
+    e1.record()
+    torch.cuda.synchronize()
+    imgs = [getattr(r, a) for a in ("_items_h", "_items_hm", "_items_frag")]
+    out["image_build_ms"] = round(first_ms - e0.elapsed_time(e1), 3)
+    out["image_bytes"] = int(sum(t.numel() * t.element_size() for t in imgs if t is not None))
+    out["image_kinds"] = [a for a, t in zip(("one_plane", "hm", "fragment_major"), imgs) if t is not None]
+    del r, imgs
+    if users_per_step <= 64:
+        single = HipRanker("dot", "cuda", users, items, batch_size=upp or None, two_stage=False)
+        for _ in range(3):
+            single.rank_device(sids, k=10)
+        torch.cuda.synchronize()
+        reps = 10
+        e0.record()
+        for _ in range(reps):
+            single.rank_device(sids, k=10)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        byts = topk_bytes(n, d, users_per_step, 10, 0)
+        out["single_stage"] = {"kernel": "rt_topk_score (fp32 rows, f32-input MFMA, 16-user tile): reads the catalog itself, no image",
+                               "ms_per_step": round(ms, 4), "users_per_s": round(users_per_step / ms * 1e3, 1),
+                               "achieved": round(byts / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(byts / ms / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": byts}
+        del single
+    torch.cuda.empty_cache()
+    return out
+
+
 def quiesce_host(seconds: float = 1.0) -> None:
     """After a CPU-baseline leg: let the 128 OpenMP workers of the reference's torch ops finish spinning before the next GPU leg is timed
     (a leg that started right behind a baseline ran at 2.92 instead of 1.93 ms per step in 2 of 5 driver-form runs, the 16-user top-k at
@@ -662,6 +711,8 @@ def topk_leg(kind, args, rank, world, cpu_baseline):
            "ms_per_step": round(wall / steps * 1e3, 4), "dtype": "fp32",
            "config": {"workload": workload, "users_per_step": ups, "users_per_register_tile": upp or "library default", "parallelism": f"dp{world}"},
            "roofline": roof, "cpu_baseline": None}
+    if kind != "recommend" and rank == 0:
+        rec["roofline"].update(topk_extras(info, ups, upp))
     if cpu_baseline:
         torch.cuda.synchronize()
         small = info["n_items"] <= 100_000

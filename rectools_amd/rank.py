@@ -178,6 +178,7 @@ class HipRanker:
     TWO_STAGE_MIN_USERS = 17   # up to 16 users the 16-user tile of the single-stage kernel streams the catalog at the HBM roofline; from 17 up
     #                            the matrix pipe binds and the coarse pass wins (5 M x 512: 32 users 2.36 vs 2.77 ms, 64 users 2.60 vs 4.08 ms)
 
+    FRAG_MIN_ITEMS = 500_000  # catalogs from which the fragment-major coarse pass is the default for >= 128 users per call
     RUNS_PER_USERS = 150      # one-plane pass: more than n_users / 150 separate runs of unproven users cost more than the (h, m) pass again
 
     def _two_stage_applies(self, kk: int, n_cand: int, n_subj: int) -> bool:
@@ -270,9 +271,12 @@ class HipRanker:
                     self._max_item_norm = float(item_norms.max())
                 items_img, img_row_bytes = self._items_hm, 4 * d
             users_hm, user_norms = self._hm_image(S, rows_t, n_subj, h_only=h_only)
-            # fragment-major images (opt-in, RT_TOPK_FRAG=1): item fragments straight into the matrix operand, the user tile resident in LDS
-            frag = (h_only and os.environ.get("RT_TOPK_FRAG", "0") == "1" and whitelist_t is None and d % 128 == 0 and id_offset % 128 == 0
-                    and n_subj >= 128 and 128 * d * 2 <= 144 * 1024)
+            # fragment-major images: item fragments straight into the matrix operand, the user tile resident in LDS (round 4, visit v4a:
+            # 5 M x 512, 4,096 users 58.7 -> 42.0 ms, ids / counts / score bits unchanged).  Default from FRAG_MIN_ITEMS items up — the
+            # second image costs another 2 d bytes per item and one more catalog pass to build; RT_TOPK_FRAG=0 / 1 forces it off / on
+            frag_env = os.environ.get("RT_TOPK_FRAG", "auto")
+            frag = (h_only and (frag_env == "1" or (frag_env == "auto" and O.shape[0] >= self.FRAG_MIN_ITEMS)) and whitelist_t is None
+                    and d % 128 == 0 and id_offset % 128 == 0 and n_subj >= 128 and 128 * d * 2 <= 144 * 1024)
             if frag:
                 if self._items_frag is None:
                     self._items_frag = self._fragments(self._items_h, O.shape[0], d)

@@ -8,7 +8,13 @@ import pytest
 import torch
 from scipy import sparse
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("RT_TOPK_FRAG", "0") != "1", reason="opt-in path: RT_TOPK_FRAG=1")]
+pytestmark = [pytest.mark.gpu]
+
+
+@pytest.fixture(autouse=True)
+def _frag_on(monkeypatch):
+    """The fragment-major pass is the default from 500 k items up; these shapes are smaller: force it."""
+    monkeypatch.setenv("RT_TOPK_FRAG", "1")
 
 
 def fragments_numpy(img: np.ndarray, rows_pad: int) -> np.ndarray:

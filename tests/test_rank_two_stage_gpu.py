@@ -243,3 +243,45 @@ def test_h_only_is_dropped_for_a_catalog_that_defeats_its_bound():
     assert torch.equal(e[0], f[0]) and torch.equal(e[1].view(torch.int32), f[1].view(torch.int32))
     fast.rank_device(np.arange(8), 10)
     assert fast.two_stage_stats["h_only_calls"] == 1          # not tried again
+
+
+@pytest.mark.parametrize("n_subj", [16, 4096])
+def test_two_stage_at_the_baseline_catalog_5m_x_512(n_subj):
+    """BASELINE.json configs[4] at its stated size (5,000,000 x 512 fp32 = 10.24 GB), 16 users (the HBM-bound launch) and 4,096 users
+    (the matrix-bound one; fragment-major coarse pass), viewed-items filter on: the two-stage path returns the single-stage kernel's
+    ids, counts and score BITS for every user, and the CPU oracle's ids on a 200,000-row slice for 32 users (this
+    equality existed only in builder-side scripts)."""
+    from rectools_amd.rank import HipRanker
+
+    if torch.cuda.mem_get_info()[0] < 60 << 30:
+        pytest.skip("needs ~40 GB of free HBM (catalog + two images + workspaces)")
+    n_obj, d, k = 5_000_000, 512, 10
+    g = torch.Generator(device="cuda").manual_seed(11)
+    obj = torch.randn((n_obj, d), device="cuda", generator=g)
+    subj = torch.randn((n_subj, d), device="cuda", generator=g)
+    ids = np.arange(n_subj)
+    nnz_per_user = 50
+    rng = np.random.default_rng(5)
+    cols = rng.integers(0, n_obj, size=(n_subj, nnz_per_user))
+    filt = sparse.csr_matrix((np.ones(n_subj * nnz_per_user, np.float32), (np.repeat(ids, nnz_per_user), cols.reshape(-1))), shape=(n_subj, n_obj))
+    filt.sum_duplicates()
+    fast = HipRanker("dot", "cuda", subj, obj)
+    f_ids, f_sc, f_cnt, _ = fast.rank_device(ids, k, filt)
+    st = dict(fast.two_stage_stats)
+    assert st["calls"] >= 1 and st["h_only_calls"] >= 1 and st["fallbacks"] == 0, st
+    if n_subj >= 128:
+        assert fast._items_frag is not None          # the fragment-major coarse pass is the default at this catalog size
+    # (the exact pass replays the 32- / 64-user engines' instruction chain: those are the single-stage kernels whose BITS it returns; the
+    # 16-user tile accumulates in another order — same ids, scores a rounding unit apart)
+    exact = HipRanker("dot", "cuda", subj, obj, batch_size=32 if n_subj <= 32 else 64, two_stage=False)
+    e_ids, e_sc, e_cnt, _ = exact.rank_device(ids, k, filt)
+    assert torch.equal(e_cnt, f_cnt) and int(e_cnt.min()) == k
+    assert torch.equal(e_ids, f_ids)
+    assert torch.equal(e_sc.view(torch.int32), f_sc.view(torch.int32))
+    del fast, exact
+    # the oracle on a slice of the catalog for (up to) 32 users: same ids, same order
+    m, n_slice = min(32, n_subj), 200_000
+    sub = HipRanker("dot", "cuda", subj[:m], obj[:n_slice], two_stage=True)
+    s_ids, _, s_cnt, _ = sub.rank_device(np.arange(m), k, filt[:m, :n_slice])
+    _, i_o, _ = ranker_oracle.rank(subj[:m].cpu().numpy(), obj[:n_slice].cpu().numpy(), np.arange(m), k=k, filter_pairs_csr=filt[:m, :n_slice])
+    assert s_ids.cpu().numpy().reshape(-1).tolist() == np.asarray(i_o).tolist()
