@@ -8,10 +8,10 @@ import torch
 
 from rectools_amd import ops
 
-M, d, N = 25600, 256, 128
+M, d, N = int(os.environ.get('PROBE_M', 25600)), 256, 128
 g = torch.Generator().manual_seed(0)
 sess = (torch.randn(M, d, generator=g) * 0.3).cuda().requires_grad_(True)
-for V in (2000, 3500, 7000, 26744, 200000):
+for V in tuple(int(v) for v in os.environ.get('PROBE_V', '2000,3500,7000,26744,200000').split(',')):
     table = (torch.randn(V, d, generator=g) * 0.3).cuda().requires_grad_(True)
     y = torch.randint(1, V, (M,), generator=g).cuda()
     y[torch.rand(M, generator=g).cuda() < 0.28] = 0

@@ -307,6 +307,33 @@ def test_sampled_loss_popularity_skew(cosine):
     _sampled_case("sampled_softmax", cosine, M=1500, d=128, V=400, N=5, hot=True)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("cosine", [False, True])
+def test_sampled_softmax_xcd_sliced_forward(cosine, monkeypatch):
+    """The XCD-sliced training forward (rt_loss.hip: the table cut into eight id ranges, one per XCD's L2; a position's softmax merged from
+    eight partial states) at a shape where it applies (a 4.2 MB table, 2,048 positions): against the oracle, and against the unsliced
+    kernel — same loss and logit gradients (the logits are bit-identical), d_sess / d_table to fp32 rounding."""
+    from rectools_amd import ops
+
+    M, d, V, N, t = 2048, 256, 4200, 128, 0.7
+    g = torch.Generator().manual_seed(4)
+    sess, table = rnd(M, d, seed=5), rnd(V, d, seed=6)
+    y = torch.randint(1, V, (M,), generator=g); y[::7] = 0
+    neg = torch.randint(1, V, (M, N), generator=g)
+    w = (0.5 + torch.rand(M, generator=g)) * (y != 0)
+    out = {}
+    for sliced in ("1", "0"):
+        monkeypatch.setenv("RT_LOSS_SLICED", sliced)
+        out[sliced] = grads_of(lambda s, e: ops.sampled_loss(s, e, y.cuda(), neg.cuda(), w.cuda(), 2, cosine, t, 0.0)[0].reshape(1),
+                               [sess.cuda(), table.cuda()])
+    (l1, g1), (l0, g0) = out["1"], out["0"]
+    assert torch.equal(l1, l0)                                                     # loss: from the same logits by the same arithmetic
+    close(g1[0], g0[0], rtol=1e-4, atol_rel=1e-6, msg="d_sess sliced vs unsliced")
+    close(g1[1], g0[1], rtol=1e-4, atol_rel=1e-6, msg="d_table sliced vs unsliced")
+    monkeypatch.setenv("RT_LOSS_SLICED", "1")
+    _sampled_case("sampled_softmax", cosine, M=M, d=d, V=V, N=N, hot=False)       # the sliced path against the oracle
+
+
 def _sampled_case(loss, cosine, M, d, V, N, hot):
     from rectools_amd import lightning as hl
     from rectools_amd import ops
