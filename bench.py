@@ -381,6 +381,15 @@ def family_spec(kind: str, n_neg: int):
                     name="eSASRec (SASRec + LiGR blocks) d=512 n_blocks=2 L=200 sampled_softmax, 1M-item catalog",
                     desc=f"B=128/GPU x L=200, d=512, 2 LiGR blocks (SwiGLU x4), 4 heads (hd 128), dropout 0.2, sampled_softmax "
                          f"N={n_neg}, V=1,000,000 items (the 5M x 512 catalog of the config is the SCORING run: `topk5m`)")
+    if kind == "esasrec_kpm":   # the same model with use_key_padding_mask=True: the configuration under which the LiGR stack packs exactly
+        spec = family_spec("esasrec", n_neg)
+        d, H, nb, L, B = 512, 4, 2, 200, 128
+        spec["model"] = SASRecModel(n_factors=d, n_blocks=nb, n_heads=H, session_max_len=L, dropout_rate=0.2, loss="sampled_softmax",
+                                    n_negatives=n_neg, batch_size=B, lr=1e-3, epochs=1, seed=32, transformer_layers_type=hnn.LiGRLayers,
+                                    use_key_padding_mask=True)
+        spec["name"] += ", use_key_padding_mask=True (packed rows)"
+        spec["desc"] += "; use_key_padding_mask=True: no real query sees a pad key, the stack runs on packed rows (72 % of B x L)"
+        return spec
     raise SystemExit(f"unknown training workload {kind}")
 
 
@@ -731,7 +740,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps of the headline leg (default 200 train steps)")
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="auto", choices=["auto", "train", "recommend", "topk5m", "bert4rec", "hstu", "esasrec"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "train", "recommend", "topk5m", "bert4rec", "hstu", "esasrec", "esasrec_kpm"])
     ap.add_argument("--users-per-pass", type=int, default=0, help="register tile: 16/32/64/128 users (0 = auto)")
     ap.add_argument("--users-per-step", type=int, default=0)
     ap.add_argument("--n-negatives", type=int, default=128, help="sampled_softmax negatives (tutorial setting 128)")
@@ -851,7 +860,7 @@ def main():
                 fam = argparse.Namespace(**vars(args))
                 fam.steps, fam.warmup = 10, 3
                 out["families"] = {}
-                for kind_f in ("bert4rec", "hstu", "esasrec"):
+                for kind_f in ("bert4rec", "hstu", "esasrec", "esasrec_kpm"):
                     v_f, wall_f, roof_f, info_f = run_train(fam, rank, world, kind_f)
                     out["families"][kind_f] = {"metric": f"train seqs/sec ({info_f['spec']['name']})", "value": round(v_f, 2), "unit": "seqs/s",
                                                 "steps": fam.steps, "warmup": fam.warmup, "ms_per_step": round(wall_f / fam.steps * 1e3, 4),

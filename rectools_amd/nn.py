@@ -607,6 +607,26 @@ class LiGRLayer(nn.Module):
         return ops.gated_residual(seqs, g2.weight, g2.bias, f, p)    # seqs + sigmoid(Wg2 seqs + bg2) * drop(ffn)
 
 
+    def forward_packed(self, seqs, B, window, causal, pad_idx, pad_ids, n_real):
+        """The block over PACKED rows ([Np, d]: real positions + the unused tail of the row block) — exact under key-padding masks: no
+        real query sees a pad key, and nothing else couples rows (ligr.py:66-106 is LayerNorm, Linear, gates, SwiGLU: row-wise).  The
+        attention kernels of this head size work on the [B, L] window: the packed in_proj output is scattered into it (`pad_idx`; pad
+        slots zero, masked as keys through `pad_ids`) and the attention output gathered back — every GEMM, LayerNorm, gate and dropout
+        of the block runs on the packed rows only."""
+        p = self.p if self.training else 0.0
+        ln1, ln2, mha = self.layer_norm_1, self.layer_norm_2, self.multi_head_attn
+        g1, g2 = self.gating_linear_1, self.gating_linear_2
+        h, seqs = ops.layer_norm_skip(seqs, ln1.weight, ln1.bias, ln1.eps)
+        qkv = ops.linear(h, mha.in_proj_weight, mha.in_proj_bias)
+        qkv_w = ops.scatter_rows(qkv, pad_idx, B * window + 1)
+        a_w = ops.mha_packed(qkv_w[:B * window], pad_ids[:B * window], B, mha.n_heads, window, causal, True, p)
+        a = ops.gather_rows(_with_dump_row(a_w), pad_idx)
+        a = mha.out_proj(a)
+        seqs = ops.gated_residual(seqs, g1.weight, g1.bias, a, p)
+        g, seqs = ops.layer_norm_skip(seqs, ln2.weight, ln2.bias, ln2.eps)
+        f = self.feed_forward(g)
+        return ops.gated_residual(seqs, g2.weight, g2.bias, f, p)
+
     def forward_last(self, seqs, ids, B, L, causal, keypad):
         """Inference: the block's output at the last position of every session, [B, d] (see PreLNTransformerLayer.forward_last)."""
         h = self.layer_norm_1(seqs)
@@ -637,6 +657,31 @@ class LiGRLayers(TransformerLayersBase):
         for blk in blocks[:-1]:
             seqs = blk(seqs, ids, B, L, causal, keypad)
         return blocks[-1].forward_last(seqs, ids, B, L, causal, keypad)
+
+    def packed_ok(self, n_factors: int, window: int, causal: bool, keypad: bool = False) -> bool:
+        """Packed rows serve the LiGR stack when pad positions are masked as keys (`use_key_padding_mask=True`): without the mask the
+        pad rows of this stack carry state that real queries read (nothing re-zeroes them between blocks, ligr.py:161-191), and the
+        padded window has to stay — which is the reference's default for SASRec-style models, eSASRec included."""
+        return bool(keypad) and len(self.transformer_blocks) > 0 and os.environ.get("RT_PACKED_LIGR", "1") != "0"
+
+    def forward_packed_train(self, seqs, cu, B, window, keypad, rows_real=None, causal=True):
+        n_real = int(rows_real) if rows_real is not None else None
+        pad_idx, pad_ids = ops.padded_index(cu, B, window, int(seqs.shape[0]))
+        for blk in self.transformer_blocks:
+            seqs = blk.forward_packed(seqs, B, window, causal, pad_idx, pad_ids, n_real)
+        return seqs
+
+    def forward_last_packed(self, seqs, cu, B, window, keypad, rows_real=None, causal=True):
+        """Inference over packed rows: all blocks on the packed rows, then the last row of every session."""
+        pad_idx, pad_ids = ops.padded_index(cu, B, window, int(seqs.shape[0]))
+        for blk in self.transformer_blocks:
+            seqs = blk.forward_packed(seqs, B, window, causal, pad_idx, pad_ids, None)
+        return seqs.index_select(0, cu[1:B + 1] - 1)
+
+
+def _with_dump_row(x: torch.Tensor) -> torch.Tensor:
+    """[n, d] -> [n + 1, d] with a zero row behind it: the slot the unused tail rows of a packed block gather from."""
+    return torch.nn.functional.pad(x, (0, 0, 0, 1))
 
 
 class RelativeAttentionBias(nn.Module):

@@ -2114,6 +2114,76 @@ class _SoftmaxLoss(torch.autograd.Function):
         return d_sess, d_table, None, None, None, None, None
 
 
+# ---- packed rows <-> padded window (for stacks whose attention kernels work on the [B, L] window) ------------------------
+def padded_index(cu: torch.Tensor, B: int, window: int, n_rows: int) -> tp.Tuple[torch.Tensor, torch.Tensor]:
+    """Where every packed row sits in the left-padded [B, window] layout: -> (idx [n_rows] int64, ids [B * window + 1] int64).
+    Session b = packed rows cu[b] .. cu[b+1] - 1 occupies the LAST cu[b+1] - cu[b] slots of window b; rows behind cu[B] (the unused
+    tail of the row block) go to the extra slot B * window, which no real query reads.  ids: 1 at occupied slots, 0 at pad slots —
+    what the window kernels derive their masks from.  Device ops only (no host round trip)."""
+    dev = cu.device
+    r = torch.arange(n_rows, dtype=torch.int64, device=dev)
+    b = torch.searchsorted(cu[1:B + 1].contiguous(), r, right=True)                 # session of every row; B for the tail rows
+    bc = b.clamp(max=B - 1)
+    idx = bc * window + (window - (cu[bc + 1] - cu[bc])) + (r - cu[bc])
+    idx = torch.where(b >= B, torch.full_like(idx, B * window), idx)
+    ids = torch.zeros((B * window + 1,), dtype=torch.int64, device=dev)
+    ids[idx] = 1
+    ids[B * window] = 0
+    return idx, ids
+
+
+class _ScatterRows(torch.autograd.Function):
+    """out [n_out, d] = 0; out[idx[r]] = src[r] (idx unique except for rows sent to a dump slot).  Backward: gather."""
+
+    @staticmethod
+    def forward(ctx, src, idx, n_out):
+        src = src.contiguous()
+        R, d = src.shape
+        out = torch.zeros((n_out, d), dtype=torch.float32, device=src.device)
+        _c("rt_scatter_rows", src, d, idx, R, d, out, d)
+        ctx.save_for_backward(idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        g = g.contiguous()
+        R, d = idx.numel(), g.shape[1]
+        out = torch.empty((R, d), dtype=torch.float32, device=g.device)
+        _c("rt_gather_rows", g, d, idx, R, d, out, d)
+        return out, None, None
+
+
+class _GatherRows(torch.autograd.Function):
+    """out[r] = src[idx[r]].  Backward: scatter into zeros (rows sharing a dump slot collide there: that slot's gradient is unused)."""
+
+    @staticmethod
+    def forward(ctx, src, idx):
+        src = src.contiguous()
+        R, d = idx.numel(), src.shape[1]
+        out = torch.empty((R, d), dtype=torch.float32, device=src.device)
+        _c("rt_gather_rows", src, d, idx, R, d, out, d)
+        ctx.save_for_backward(idx)
+        ctx.n_src = src.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        g = g.contiguous()
+        out = torch.zeros((ctx.n_src, g.shape[1]), dtype=torch.float32, device=g.device)
+        _c("rt_scatter_rows", g, g.shape[1], idx, idx.numel(), g.shape[1], out, g.shape[1])
+        return out, None
+
+
+def scatter_rows(src: torch.Tensor, idx: torch.Tensor, n_out: int) -> torch.Tensor:
+    return _ScatterRows.apply(_chk(src, "scatter_rows"), idx, n_out)
+
+
+def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    return _GatherRows.apply(_chk(src, "gather_rows"), idx)
+
+
 def softmax_loss(sess: torch.Tensor, table: torch.Tensor, act_idx: torch.Tensor, y_act: torch.Tensor, w_act: torch.Tensor,
                  logits_t: float) -> torch.Tensor:
     """sess [M,d] (already L2-normalised for cosine), table [V,d]; act_idx = positions with y != 0 (int64, ascending)."""

@@ -220,6 +220,23 @@ def test_ligr_training_step_d512():
 
 
 @pytest.mark.parametrize("packed", [False, True])
+def test_ligr_training_step_d512_key_padding_mask(packed):
+    """The same stack with `use_key_padding_mask=True` — the configuration under which LiGR packs exactly (no real query sees a pad key;
+    ligr.py:66-106 is row-wise otherwise) — through the padded window and through the packed rows (every GEMM / LayerNorm / gate on the
+    real rows only, the attention on the window they are scattered into), both straight against the oracle."""
+    cfg, batch = _random_case("ligr", "sampled_softmax", "dot", 64, 512, 4, 3, 700, 16, 33, keypad=True,
+                              layer_kwargs=dict(ff_factors_multiplier=4, ff_activation="swiglu", bias_in_ff=False))
+    _step_vs_oracle(cfg, batch, name="C5 LiGR d512 kpm" + (" packed" if packed else ""), packed=packed)
+
+
+def test_ligr_without_key_padding_mask_keeps_the_padded_window():
+    cfg, _ = _random_case("ligr", "sampled_softmax", "dot", 64, 512, 4, 3, 700, 16, 32,
+                          layer_kwargs=dict(ff_factors_multiplier=4, ff_activation="swiglu", bias_in_ff=False))
+    tm = build_hip_model(cfg).torch_model
+    assert not tm.transformer_layers.packed_ok(cfg["d"], cfg["L"], True, False) and tm.transformer_layers.packed_ok(cfg["d"], cfg["L"], True, True)
+
+
+@pytest.mark.parametrize("packed", [False, True])
 def test_bert4rec_training_step_C3_shape(packed):
     """BASELINE config 3: BERT4Rec d256, 2 Pre-LN blocks, 4 heads, L200, key-padding masks, mask_prob 0.15, FULL softmax over the
     26,744-item catalog (+ PAD + MASK = 26,746 classes: the padded-to-128 exact-tile GEMMs, the -inf-masked pad columns and the
