@@ -267,6 +267,8 @@ class FlatAdam:
         # set by a sharded step: (world, rank) whose slice of the moments is current on this rank — the other slices are STALE until
         # `consolidate_moments()` (collective) has run; checkpoints refuse to be written from partial moments
         self.partial_moments: tp.Optional[tp.Tuple[int, int]] = None
+        # bench.py --gpus N: device-side duration of every step's gradient exchange (pack + collective[s]), HIP events on the step's stream
+        self.exchange_events: tp.Optional[tp.List[tp.Tuple[tp.Any, tp.Any]]] = None
 
     def use_rccl_exchange(self, rank: int, world: int) -> None:
         """Route the gradient all-reduce and the parameter broadcast through `rt_dp_*` (collective: every rank calls it)."""
@@ -417,15 +419,25 @@ class FlatAdam:
         pointer."""
         if self.flat_p.is_cuda:
             ops.join_side_streams()   # weight gradients may still be in flight on the wgrad stream
+        timed = self.exchange_events is not None and self.flat_p.is_cuda and world_size > 1
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         if self._use_sharded(world_size):
             import torch.distributed as dist
 
             self.step_sharded(world_size, dist.get_rank())
+            if timed:      # (reduce-scatter + sharded Adam + all-gather: the sharded exchange has no seam between them)
+                e1.record()
+                self.exchange_events.append((e0, e1))
             return
         if self.partial_moments is not None:     # an all-reduce step after sharded ones needs whole moments on every rank
             self.consolidate_moments()
         flat = flat or world_size > 1
         scale = self.reduce_gradients(world_size, force=flat)
+        if timed:
+            e1.record()
+            self.exchange_events.append((e0, e1))
         self.step_count += 1
         hyper = (self.step_count, float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(scale))
         if flat:

@@ -20,7 +20,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, out_dir, exchange="allreduce"):
+def _worker(rank, world, port, out_dir, exchange="allreduce", shape="small"):
     os.environ["RT_DP_EXCHANGE"] = exchange
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -30,7 +30,8 @@ def _worker(rank, world, port, out_dir, exchange="allreduce"):
     from rectools_amd import lightning as hl
     from rectools_amd import ops
 
-    V, d, H, nb, L, B, n_neg = 300, 64, 2, 2, 24, 16, 8
+    # "c2": the BASELINE configs[1] model (26,744 items, d 256, 2 blocks, L 200, N 128; 31 MB of gradient), 8 sequences per rank
+    V, d, H, nb, L, B, n_neg = (300, 64, 2, 2, 24, 16, 8) if shape == "small" else (26_744, 256, 4, 2, 200, 8, 128)
     lm = bench.make_sasrec(V, d, H, nb, L, 0.1, "sampled_softmax", n_neg)       # same seed: identical replicas
     lm.train()
     if rank == 1:   # replicas that drifted apart before the start must be pulled back by the broadcast
@@ -67,12 +68,14 @@ def _worker(rank, world, port, out_dir, exchange="allreduce"):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("shape", ["small", "c2"])
 @pytest.mark.parametrize("exchange", ["allreduce", "sharded"])
-def test_two_rank_step_matches_mean_gradient_adam(tmp_path, exchange):
+def test_two_rank_step_matches_mean_gradient_adam(tmp_path, exchange, shape):
     """`sharded`: reduce-scatter -> rt_adam_step on the rank's 1/N slice of (p, m, v) -> all-gather of the parameters
-    (FlatAdam.step_sharded; over gloo with both ranks on this GPU): the same first Adam step, replicas bit-identical."""
+    (FlatAdam.step_sharded; over gloo with both ranks on this GPU): the same first Adam step, replicas bit-identical — on a small model
+    and at the C2 model size (the HIP Adam kernel on a 15.5 MB slice of the 31 MB flat buffers)."""
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), exchange), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), exchange, shape), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}.npy").exists() for r in range(world))
 
 
