@@ -899,6 +899,19 @@ def main():
                         out["families"][kind_f]["recommend"] = family_recommend(info_f, kind_f)
                     del info_f
                     torch.cuda.empty_cache()
+            if not args.no_families and rank == 0 and world == 1:
+                # BASELINE configs[3] nearer its stated size: the host path of HSTUModel.fit() (Dataset.construct, process_dataset_train,
+                # store upload, epoch bookkeeping) + 20 product steps at 2 M users x 1 M items, in a child process (its 15 GB of host
+                # memory go back to the system); `families.hstu` above is the model-shape leg (65,536 users with long histories)
+                import subprocess
+
+                try:
+                    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "c4_scale.py"), "2000000", "40", "20"],
+                                         capture_output=True, text=True, timeout=400)
+                    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+                    out["families"]["hstu_2m_users"] = json.loads(line[-1]) if line else {"error": (res.stderr or res.stdout)[-300:]}
+                except Exception as e:      # never take the line down
+                    out["families"]["hstu_2m_users"] = {"error": repr(e)[:300]}
         out["env"] = env
         if dp_train is not None:
             dist_info["train"] = dp_train
