@@ -513,15 +513,22 @@ __global__ __launch_bounds__(GT) void gemm_dma_group_kernel(GemmGroup gg) {
 // Grouped WEIGHT GRADIENTS: up to 6 products dW_i [n_out_i, n_in_i] = dy_i^T in_i over the same rows, every one split-K over grid.y, in
 // ONE launch (tile ranges back to back) — the five weight gradients of a transformer block were ten launches (a product and its combine
 // each) of 4 - 8 tiles x ~34 slices; together they are 24 tiles whose slices fill the machine once.  A second launch combines all slabs.
-struct WgradGroup { GemmArgs g[6]; int tile_end[6]; int n; };
+// Workgroup -> (tile, slice): every tile of ONE K-slice on the SAME XCD.  A slice's rows of dy_i / in_i (a few hundred KB each) are read
+// by all column tiles of all products that share them — {g_o, hdrop, g_h, f, g_y, A} x two column tiles each behind a block's tail —;
+// with the natural (tile fastest) order the round-robin dispatch spreads those readers over the eight XCDs and every one of them fetches
+// the slice from HBM again (PMC: 201 MB per launch for 100 MB of operands).  Workgroup w runs on XCD w % 8: slice = 8 (w / 8 / tiles) +
+// w % 8, tile = (w / 8) % tiles — the slice's tiles are 8 apart in w, close in time, and the second reader hits that XCD's L2.
+struct WgradGroup { GemmArgs g[6]; int tile_end[6]; int n, tiles, splits; };
 template <int NS, bool X6>
 __global__ __launch_bounds__(GT) void wgrad_group_kernel(WgradGroup gg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int t = blockIdx.x;
+  const int w = blockIdx.x, xcd = w & 7, q = w >> 3;
+  const int t = q % gg.tiles, zs = (q / gg.tiles) * 8 + xcd;
+  if (zs >= gg.splits) return;
   int p = 0;
 #pragma unroll
   for (int i = 0; i < 5; ++i) p += t >= gg.tile_end[i] ? 1 : 0;
-  gemm_dma_body<false, false, NS, X6>(gg.g[p], t - (p > 0 ? gg.tile_end[p - 1] : 0), smem, blockIdx.y, gridDim.y);
+  gemm_dma_body<false, false, NS, X6>(gg.g[p], t - (p > 0 ? gg.tile_end[p - 1] : 0), smem, zs, gg.splits);
 }
 
 // (A 224 x 128-tile variant for the M = 25,600 products — 230 workgroups, one per CU, instead of 400 on 512 half-CU slots —
@@ -885,11 +892,11 @@ int rt_wgrad_grouped(const rt_wgrad_problem* problems, int32_t n, int32_t rows, 
     gg.tile_end[i] = tiles;
     rg.blk_end[i] = blks;
   }
-  gg.n = n; rg.n = n; rg.splits = sp;
+  gg.n = n; gg.tiles = tiles; gg.splits = sp; rg.n = n; rg.splits = sp;
   const size_t lds = (size_t)2 * 2 * TILE_F * sizeof(float);
   auto launch = [&](auto kernel) -> int {
     RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    kernel<<<dim3(tiles, sp), GT, lds, stream>>>(gg);
+    kernel<<<8 * tiles * ((sp + 7) / 8), GT, lds, stream>>>(gg);
     RT_CHECK_LAUNCH();
     return RT_OK;
   };

@@ -15,8 +15,10 @@ DST = os.path.join(ROOT, "profiles")
 KEEP = [("1_bench.json", "bench_auto.json"), ("2_prof.md", "rocprof_kernel_trace_train.md"), ("3_bench.json", "bench_train_single_stream.json"),
         ("4_pmc.txt", "pmc_train_FETCH_SIZE.txt"), ("5_pmc.txt", "pmc_train_WRITE_SIZE.txt"), ("6_pmc.txt", "sq_counters_train_raw.txt"),
         ("7_prof.md", "rocprof_kernel_trace_topk5m.md"), ("8_pmc.txt", "pmc_topk5m_FETCH_SIZE.txt"), ("9_pmc.txt", "pmc_topk5m_WRITE_SIZE.txt"),
-        ("10_prof.md", "rocprof_kernel_trace_topk5m_u4096_two_stage.md"), ("11_prof.md", "rocprof_kernel_trace_bert4rec.md"),
-        ("12_prof.md", "rocprof_kernel_trace_hstu.md"), ("13_prof.md", "rocprof_kernel_trace_recommend.md")]
+        ("10_prof.md", "rocprof_kernel_trace_topk5m_u4096.md"), ("11_prof.md", "rocprof_kernel_trace_bert4rec.md"),
+        ("12_prof.md", "rocprof_kernel_trace_hstu.md"), ("13_prof.md", "rocprof_kernel_trace_recommend.md"),
+        ("14_pmc.txt", "pmc_topk5m_u4096_FETCH_SIZE.txt"), ("15_prof.md", "rocprof_kernel_trace_esasrec_kpm.md"),
+        ("16_pytest.txt", "pytest_gpu_final_tree.txt")]
 
 
 def parse(path):
@@ -51,7 +53,7 @@ def main():
             "| kernel | launches | GRBM_GUI_ACTIVE | SQ_VALU_MFMA_BUSY_CYCLES | matrix-pipe busy share | VALU active share | LDS active share | mean waves per SIMD | LDS bank conflict / LDS active |",
             "|---|---|---|---|---|---|---|---|---|"]
     for k, c in sq.items():
-        if not any(t in k for t in ("v2_", "gemm_", "sampled_", "layernorm", "adam", "embed_bwd_rows")):
+        if not any(t in k for t in ("v2_", "gemm_", "wgrad_", "ffn_", "sampled_", "layernorm", "adam", "embed_bwd_rows")):
             continue
         g = c.get("GRBM_GUI_ACTIVE", (0, 0))[1]
         if g <= 0:
@@ -73,22 +75,39 @@ def main():
 
     traffic = {"_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (kernel-trace only, "
                         f"`scripts/gpu/visit.sh {TAG}`); FETCH_SIZE (KiB) doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128-B request), "
-                        "WRITE_SIZE in KiB.  topk5m: whole rt_topk_score call = 2 launches of topk_stream16_kernel (seeding prefix + main pass) "
-                        "+ the two selection kernels, algorithmic 10.24e9.  train_gemm: average launch over the GEMM kernel family of the step "
+                        "WRITE_SIZE in KiB.  topk5m: whole two-stage call at 16 users = 2 launches of the one-plane stream kernel + merge / seed / replay (image 5.12e9); "
+                        "topk5m_single_stage: rt_topk_score on the fp32 rows (10.24e9); topk5m_u4096: the fragment-major coarse pass + merge + replay (fetch only).  train_gemm: average launch over the GEMM kernel family of the step "
                         "(gemm_wp_kernel forward / dgrad products, gemm_dma_kernel weight gradients)."}
-    t = kib(tf, "topk_stream16", "FETCH_SIZE")
-    if t:
-        calls = max(1, sum(n for n, _ in kib(tf, "topk_select_kernel<false>", "FETCH_SIZE")))
-        fetch = sum(n * a for k, v in tf.items() if "topk_" in k for n, a in [v["FETCH_SIZE"]]) / calls * 1024 * 2
-        write = sum(n * a for k, v in tw.items() if "topk_" in k for n, a in [v["WRITE_SIZE"]]) / calls * 1024
-        traffic["topk5m"] = int(fetch + write)
-    gf = [x for pat in ("gemm_wp_kernel", "gemm_dma_kernel", "gemm_dma_group") for x in kib(f, pat, "FETCH_SIZE")]
-    gw = [x for pat in ("gemm_wp_kernel", "gemm_dma_kernel", "gemm_dma_group") for x in kib(w, pat, "WRITE_SIZE")]
+    # the 16-user launch: the two-stage call = 2 launches of the one-plane stream kernel (seeding prefix + main pass) + merge / seed / replay;
+    # the bench's `single_stage` extra = 2 launches of topk_stream16_kernel over the fp32 rows.  (FETCH x 2: the gfx950 correction)
+    def per_call(tab_f, tab_w, main_pat, small_pats, launches_per_call=2):
+        m = kib(tab_f, main_pat, "FETCH_SIZE")
+        if not m:
+            return None
+        calls = m[0][0] / launches_per_call
+        fetch = sum(v["FETCH_SIZE"][0] * v["FETCH_SIZE"][1] for k, v in tab_f.items() if (main_pat in k or any(p in k for p in small_pats)) and "FETCH_SIZE" in v)
+        write = sum(v["WRITE_SIZE"][0] * v["WRITE_SIZE"][1] for k, v in tab_w.items() if (main_pat in k or any(p in k for p in small_pats)) and "WRITE_SIZE" in v)
+        return int((fetch * 2 + write) / calls * 1024)
+
+    v = per_call(tf, tw, "topk_stream_kernel<1, 6", ("topk_merge_kernel", "topk_seed_kernel", "topk_replay_kernel"))
+    if v:
+        traffic["topk5m"] = v
+    v = per_call(tf, tw, "topk_stream16_kernel", ())
+    if v:
+        traffic["topk5m_single_stage"] = v
+    u4 = parse(os.path.join(SRC, "14_pmc.txt"))
+    v = per_call(u4, {}, "topk_coarse_frag_kernel", ("topk_merge_kernel", "topk_replay_kernel"), launches_per_call=1)
+    if v:
+        traffic["topk5m_u4096"] = v
+    fam = ("gemm_wp_kernel", "gemm_dma_kernel", "gemm_dma_group", "wgrad_group_kernel", "ffn_kernel")
+    gf = [x for pat in fam for x in kib(f, pat, "FETCH_SIZE")]
+    gw = [x for pat in fam for x in kib(w, pat, "WRITE_SIZE")]
     if gf:
         n = sum(c for c, _ in gf)
         traffic["train_gemm"] = int((sum(c * a for c, a in gf) * 2 + sum(c * a for c, a in gw)) / n * 1024)
     for key, pat in (("train_rt_sampled_loss_fwd_train", "sampled_fwd_kernel"), ("train_rt_sampled_loss_bwd", "sampled_bwd_rows_kernel"),
-                     ("train_v2_fwd_kernel", "v2_fwd_kernel"), ("train_v2_bwd_dq_kernel", "v2_bwd_dq_kernel"), ("train_v2_bwd_dkv_kernel", "v2_bwd_dkv_kernel")):
+                     ("train_v2_fwd_kernel", "v2_fwd_kernel"), ("train_v2_bwd_dq_kernel", "v2_bwd_dq_kernel"), ("train_v2_bwd_dkv_kernel", "v2_bwd_dkv_kernel"),
+                     ("train_ffn_kernel_fwd", "ffn_kernel<0>"), ("train_ffn_kernel_bwd", "ffn_kernel<1>"), ("train_wgrad_group_kernel", "wgrad_group_kernel")):
         a, b = kib(f, pat, "FETCH_SIZE"), kib(w, pat, "WRITE_SIZE")
         if a:
             traffic[key] = int((a[0][1] * 2 + (b[0][1] if b else 0)) * 1024)
