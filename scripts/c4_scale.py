@@ -57,12 +57,12 @@ t0 = time.perf_counter()
 model._build_model_from_dataset(ds)        # (processes the dataset once more: what fit() does)
 out["build_model_from_dataset_s"] = round(time.perf_counter() - t0, 2)
 torch.cuda.synchronize()
-free0 = torch.cuda.mem_get_info()[0]
 t0 = time.perf_counter()
 loop = model.training_loop()
 torch.cuda.synchronize()
 out["device_store_upload_s"] = round(time.perf_counter() - t0, 3)
-out["device_store_bytes"] = int(free0 - torch.cuda.mem_get_info()[0])
+ds_ = loop.dstore
+out["device_store_bytes"] = int(sum(t.numel() * t.element_size() for t in (ds_.offsets, ds_.items, ds_.weights, ds_.unix_ts) if t is not None))
 model.lightning_model.train()
 t0 = time.perf_counter()
 loop.begin_epoch(0)
