@@ -579,7 +579,9 @@ __global__ __launch_bounds__(NTHREADS + NLD * 64) void topk_stream_kernel(TopkAr
 
   const bool issuer = NLD ? wave >= 4 : true;
   const bool computes = NLD ? wave < 4 : true;
-  const int iw = NLD ? wave - 4 : wave;   // index among the issuing waves
+  const int iw = NLD ? (wave >= 4 ? wave - 4 : 0) : wave;   // index among the issuing waves (0 in a compute wave of the loader form: its
+  //                                                           source addresses below are never used, but they are COMPUTED — a negative index
+  //                                                           read user_rows[-32 .. -1], a fault when the array starts an allocator segment)
   const int cwave = computes ? wave : 0;
   const int list_id = blockIdx.x * LISTS_PER_WG + cwave * 2 + half;
   SelState<TU, LL> st;

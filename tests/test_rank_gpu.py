@@ -145,3 +145,33 @@ def test_large_catalog_properties():
     near[:, 1:] |= near_tie
     near[:, :-1] |= near_tie
     assert bool((same | near).all())
+
+
+def test_user_row_indices_at_the_start_of_an_allocation():
+    """Regression (round 4).  In the loader form of the streaming kernel (waves 4, 5 issue the LDS-DMA ring) the four COMPUTE waves also
+    computed — and never used — DMA source addresses, from an issuer index of wave - 4 < 0: they read user_rows[-32 .. -1].  Harmless
+    inside an allocator segment, a GPU memory fault when the index array is the first block of one (seen once in about five runs of the
+    full suite; `scripts/debug/stress_recommend.py` reproduced it at will).  Here the indices start an allocation of their own."""
+    from rectools_amd.rank import HipRanker
+
+    g = torch.Generator().manual_seed(5)
+    users, items = torch.randn(150, 32, generator=g).numpy(), torch.randn(81, 32, generator=g).numpy()
+    rs = np.random.RandomState(4)
+    filt = sparse.random(150, 81, density=0.15, format="csr", random_state=rs, data_rvs=lambda n: np.ones(n))
+    sids = rs.permutation(150)
+    ranker = HipRanker("dot", "cuda", users, items)
+    inner, keep = ranker._rank_exact, []
+
+    def rows_first_in_their_allocation(ids_t, scores_t, counts_t, rows_t, *rest):
+        block = torch.empty(32 << 20, dtype=torch.uint8, device="cuda")      # blocks this large are never carved out of a shared segment
+        mine = block[: rows_t.numel() * 8].view(torch.int64)
+        mine.copy_(rows_t)
+        keep.append(block)
+        return inner(ids_t, scores_t, counts_t, mine, *rest)
+
+    ranker._rank_exact = rows_first_in_their_allocation
+    got = ranker.rank(sids, k=5, filter_pairs_csr=filt[sids])
+    torch.cuda.synchronize()
+    assert keep, "the exact engine was expected to serve this call"
+    exp = ranker_oracle.rank(users, items, sids, k=5, filter_pairs_csr=filt[sids], distance="dot")
+    _assert_same_ranking(got, exp)
