@@ -291,7 +291,11 @@ size_t rt_embed_bwd_workspace_bytes(int32_t M, int32_t V, int32_t d);
  * would add the two with a [V,d] kernel): rows occurring in `ids` are added to in place, no other row is touched. */
 int rt_embed_bwd(const int64_t* ids, const float* gout, float scale, int32_t M, int32_t L, int32_t d, int32_t V, float p,
                  uint64_t seed, uint64_t stream_id, float* gtable, int32_t accumulate, float* gpos, void* workspace,
-                 size_t workspace_bytes, rt_stream_t stream);
+                 size_t workspace_bytes, int32_t prepared, rt_stream_t stream);
+/* The counting sort of the rows by id depends on `ids` alone: run ahead of the backward pass (on another stream it keeps eight small
+ * launches out of the tail of a training step) it fills `workspace`; rt_embed_bwd / rt_embed_packed_bwd called with prepared = 1 on the
+ * SAME workspace and ids then start at the row reductions (prepared = 0: they sort themselves). */
+int rt_embed_bwd_prepare(const int64_t* ids, int32_t M, int32_t d, int32_t V, void* workspace, size_t workspace_bytes, rt_stream_t stream);
 
 /* K2 on packed rows: out[m,:] = dropout(table[ids[m]] * scale + pos[dist[m]]) (dist from rt_collate_packed; pos may be NULL).
  * Backward: gtable as rt_embed_bwd; gpos [L,d] (optional, fully overwritten): gpos[t] = sum over the sessions longer than t of
@@ -300,7 +304,7 @@ int rt_embed_packed_fwd(const int64_t* ids, const int64_t* dist, const float* ta
                         int32_t d, float p, uint64_t seed, uint64_t stream_id, float* out, rt_stream_t stream);
 int rt_embed_packed_bwd(const int64_t* ids, const int64_t* cu_seqlens, int32_t B, const float* gout, float scale, int32_t M, int32_t L,
                         int32_t d, int32_t V, float p, uint64_t seed, uint64_t stream_id, float* gtable, int32_t accumulate,
-                        float* gpos, void* workspace, size_t workspace_bytes, rt_stream_t stream);
+                        float* gpos, void* workspace, size_t workspace_bytes, int32_t prepared, rt_stream_t stream);
 
 /* K3  LayerNorm over rows of [M,d] (nn.LayerNorm call sites: sasrec.py:221,226,303; net_blocks.py:247,257;
  * ligr.py:90,102; hstu.py:256,291).  mean/rstd [M] are saved for the backward; dx/dw/db are overwritten
@@ -537,13 +541,20 @@ size_t rt_sampled_loss_bwd_workspace_bytes(int32_t M, int32_t N, int32_t V, int3
 int rt_sampled_loss_fwd_train(const float* sess, int64_t ld_sess, const float* table, const int64_t* y, const int64_t* neg,
                               const float* w, int32_t M, int32_t N, int32_t d, int32_t V, int32_t loss, int32_t cosine,
                               float logits_t, double gbce_beta, float* logits, float* loss_pos, float* d_sess_unit,
-                              int64_t ld_du, void* workspace, size_t workspace_bytes, rt_stream_t stream);
+                              int64_t ld_du, void* workspace, size_t workspace_bytes, int32_t prepared, rt_stream_t stream);
+/* The counting sort of the (position, candidate) pairs by candidate id depends on y / neg alone: run ahead of the forward pass (on
+ * another stream: six small launches that would otherwise sit between the forward and the backward kernels) it leaves the ranks, the
+ * segment offsets and the popular ids' chunks in `workspace`; fwd_train / bwd called with prepared = 1 on the SAME workspace skip their
+ * share (the forward writes the pair records, the backward starts at the row reductions).  RT_ERR_UNSUPPORTED while the XCD-sliced
+ * forward is switched on (RT_LOSS_SLICED=1): use prepared = 0 then. */
+int rt_sampled_loss_prepare(const int64_t* y, const int64_t* neg, int32_t M, int32_t N, int32_t d, int32_t V, void* workspace,
+                            size_t workspace_bytes, rt_stream_t stream);
 /* d_sess or d_table may be NULL: the two halves are independent (d_sess is a scaled copy of d_sess_unit; d_table consumes the
  * ranks in `workspace`, so ask for it exactly once per forward) and may be issued on different streams. */
 int rt_sampled_loss_bwd(const float* sess, int64_t ld_sess, const float* table, const int64_t* y, const int64_t* neg,
                         int32_t M, int32_t N, int32_t d, int32_t V, int32_t cosine, float logits_t, const float* logits,
                         const float* norm, float gscale, const float* d_sess_unit, int64_t ld_du, float* d_sess,
-                        int64_t ld_dsess, float* d_table, void* workspace, size_t workspace_bytes, rt_stream_t stream);
+                        int64_t ld_dsess, float* d_table, void* workspace, size_t workspace_bytes, int32_t prepared, rt_stream_t stream);
 /* out[0] = sum(loss_pos)/normaliser, out[1] = normaliser; mode 0: count(loss_pos > 0) (lightning.py:159-161),
  * mode 1: count(y != 0) (lightning.py:197-198) */
 int rt_loss_reduce(const float* loss_pos, const int64_t* y, int32_t M, int32_t mode, float* out, rt_stream_t stream);

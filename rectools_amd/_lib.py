@@ -58,9 +58,10 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_bag_sum_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_f32, c_u64, c_u64, c_vp, c_vp, c_sz, c_vp]),
     "rt_embed_fwd": (c_i32, [c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_f32, c_u64, c_u64, c_vp, c_vp]),
     "rt_embed_bwd_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32]),
-    "rt_embed_bwd": (c_i32, [c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_u64, c_vp, c_i32, c_vp, c_vp, c_sz, c_vp]),
+    "rt_embed_bwd": (c_i32, [c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_u64, c_vp, c_i32, c_vp, c_vp, c_sz, c_i32, c_vp]),
+    "rt_embed_bwd_prepare": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_sz, c_vp]),
     "rt_embed_packed_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_f32, c_u64, c_u64, c_vp, c_vp]),
-    "rt_embed_packed_bwd": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_f32, c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_u64, c_vp, c_i32, c_vp, c_vp, c_sz, c_vp]),
+    "rt_embed_packed_bwd": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_f32, c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_u64, c_vp, c_i32, c_vp, c_vp, c_sz, c_i32, c_vp]),
     "rt_layernorm_fwd": (c_i32, [c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "rt_layernorm_fwd_masked": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rt_layernorm_bwd_workspace_bytes": (c_sz, [c_i32, c_i32]),
@@ -108,8 +109,9 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_hstu_attn_last_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rt_sampled_loss_fwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f64, c_vp, c_vp, c_vp]),
     "rt_sampled_loss_bwd_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
-    "rt_sampled_loss_fwd_train": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f64, c_vp, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp]),
-    "rt_sampled_loss_bwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_f32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_sz, c_vp]),
+    "rt_sampled_loss_fwd_train": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f64, c_vp, c_vp, c_vp, c_i64, c_vp, c_sz, c_i32, c_vp]),
+    "rt_sampled_loss_prepare": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_sz, c_vp]),
+    "rt_sampled_loss_bwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_f32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_sz, c_i32, c_vp]),
     "rt_loss_reduce": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
     "rt_softmax_ce_rows": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_f32, c_i32, c_vp, c_f32, c_vp, c_vp, c_vp]),
     "rt_l2norm_fwd": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp]),

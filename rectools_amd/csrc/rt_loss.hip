@@ -50,6 +50,8 @@ struct SampledArgs {
   float* bterm;                           // [M*(1+N)] cosine only: the pair's share of sum_j g_j cos_j (chain rule of e/|e|)
   int* blocksum;                          // scan scratch
   int* rank;                              // [M, 1+N] rank of every pair inside its candidate id
+  int prepared;                           // the counting sort of the candidate ids ran ahead (rt_sampled_loss_prepare): ranks and segment
+                                          // offsets exist before the training forward, which then writes the pair records itself
   int* heavy_count; int* heavy_ids; int* heavy_chunk;   // chunk list of the rows with > HEAVY_T pairs (rt_scan.h)
   float* slab; float* slab_bsum;          // [chunks][d] partial rows of those chunks, [chunks] partial cosine sums
   float* part; float* part_ml;            // XCD-sliced forward: [M][8][d] partial accumulators, [M][8][2] partial (max, sum)
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(256) void sampled_fwd_kernel(SampledArgs a) {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
   if constexpr (FAST) { for (int j = lane; j < C; j += 64) zrow[j] = s_z[wave][j]; }   // logits row: one coalesced store
-  if (TRAIN) {   // counting-sort ranks of the negatives (targets are ranked by agg_rank_kernel): independent atomics, all in flight
+  if (TRAIN && !a.prepared) {   // counting-sort ranks of the negatives (targets are ranked by agg_rank_kernel): independent atomics, all in flight
     for (int j = 1 + lane; j < C; j += 64) {
       const long long cid = (j < 260) ? (long long)s_cid[wave][j] : a.neg[(long long)m * a.N + (j - 1)];
       if (cid != 0) a.rank[m * C + j] = atomicAdd(a.count + cid, 1);
@@ -350,6 +352,14 @@ __global__ __launch_bounds__(256) void sampled_fwd_kernel(SampledArgs a) {
       g = (float)(gd / (double)C) * gs;
     }
     grow[j] = g;
+    if (a.prepared) {   // the record pairs_scatter_kernel would write: the segment offsets and this pair's rank are known already
+      const long long cid = (j == 0) ? yy : ((j < 260) ? (long long)s_cid[wave][j] : a.neg[(long long)m * a.N + (j - 1)]);
+      if (cid != 0) {
+        const int slot = a.offsets[cid] + a.rank[m * C + j];
+        a.pairs[slot] = make_int2(m, __float_as_int(g * inv_ns));       // (inv_ns == 1 unless cosine)
+        if (a.cosine) a.bterm[slot] = g * (zat(j) / a.inv_t);            // logits = cos / t
+      }
+    }
   }
   if (lane == 0) a.inv_ns[m] = inv_ns;
 
@@ -703,6 +713,18 @@ __global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict
   }
 }
 
+// ---- counting sort, ahead of the forward pass (rt_sampled_loss_prepare): the ranks of the negatives, as the training forward takes them ----
+__global__ __launch_bounds__(256) void sampled_rank_kernel(SampledArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= a.M || a.y[m] == 0) return;          // inactive positions have no pairs
+  const int C = a.N + 1;
+  for (int j = 1 + lane; j < C; j += 64) {
+    const long long cid = a.neg[(long long)m * a.N + (j - 1)];
+    if (cid != 0) a.rank[m * C + j] = atomicAdd(a.count + cid, 1);
+  }
+}
+
 // ---- counting sort over candidate ids: exclusive scan of count[0..V] (rt_scan.h), then scatter of the pairs ----
 __global__ __launch_bounds__(256) void pairs_scatter_kernel(SampledArgs a) {
   const int lane = threadIdx.x & 63;
@@ -1032,9 +1054,18 @@ int launch_sampled(const SampledArgs& a, int stage, hipStream_t stream) {
     return RT_OK;
   }
   const int n = a.V + 1;
+  if (stage == 3) {   // the counting sort of the candidate ids, ahead of the forward pass: counts + ranks, segment offsets, popular-id chunks
+    RT_CHECK_HIP(hipMemsetAsync(a.count, 0, sizeof(int) * (((size_t)n + 1 + 15) & ~(size_t)15), stream));   // + heavy_count (+ the pad)
+    sampled_rank_kernel<<<blocks, 256, 0, stream>>>(a);
+    RT_CHECK_LAUNCH();
+    agg_rank_kernel<<<(a.M + AGG_T - 1) / AGG_T, AGG_T, 0, stream>>>(a.y, a.M, a.count, a.rank, a.N + 1);
+    RT_CHECK_LAUNCH();
+    return exclusive_scan_counts(a.count, n, a.offsets, a.cursor, a.blocksum, stream, HEAVY_T, HEAVY_CH, a.heavy_count, a.heavy_ids,
+                                 a.heavy_chunk);
+  }
   if (stage == 1) {
-    RT_CHECK_HIP(hipMemsetAsync(a.count, 0, sizeof(int) * ((size_t)n + 1), stream));   // + heavy_count
-    if (a.loss == LOSS_SAMPLED_SOFTMAX && a.part != nullptr && sliced_applies(a.M, a.N, a.V, a.d)) {
+    if (!a.prepared) RT_CHECK_HIP(hipMemsetAsync(a.count, 0, sizeof(int) * (((size_t)n + 1 + 15) & ~(size_t)15), stream));   // + heavy_count (+ the pad)
+    if (a.loss == LOSS_SAMPLED_SOFTMAX && a.part != nullptr && !a.prepared && sliced_applies(a.M, a.N, a.V, a.d)) {
       const int Vs = (a.V + NSL - 1) / NSL;
       sampled_fwd_sliced_kernel<D4><<<blocks * NSL, 256, 0, stream>>>(a, Vs);
       RT_CHECK_LAUNCH();
@@ -1049,15 +1080,15 @@ int launch_sampled(const SampledArgs& a, int stage, hipStream_t stream) {
     RT_CHECK_LAUNCH();
     return RT_OK;
   }
-  agg_rank_kernel<<<(a.M + AGG_T - 1) / AGG_T, AGG_T, 0, stream>>>(a.y, a.M, a.count, a.rank, a.N + 1);
-  RT_CHECK_LAUNCH();
-  {
+  if (!a.prepared) {   // (prepared: the sort ran ahead of the forward pass, which wrote the pair records itself)
+    agg_rank_kernel<<<(a.M + AGG_T - 1) / AGG_T, AGG_T, 0, stream>>>(a.y, a.M, a.count, a.rank, a.N + 1);
+    RT_CHECK_LAUNCH();
     const int rc = exclusive_scan_counts(a.count, n, a.offsets, a.cursor, a.blocksum, stream, HEAVY_T, HEAVY_CH, a.heavy_count,
                                          a.heavy_ids, a.heavy_chunk);
     if (rc != RT_OK) return rc;
+    pairs_scatter_kernel<<<blocks, 256, 0, stream>>>(a);
+    RT_CHECK_LAUNCH();
   }
-  pairs_scatter_kernel<<<blocks, 256, 0, stream>>>(a);
-  RT_CHECK_LAUNCH();
   const long long max_chunks = heavy_chunk_cap((long long)a.M * (a.N + 1));
   sampled_bwd_heavy_kernel<D4><<<(int)min(max_chunks, (long long)rt_num_cus() * 8), HEAVY_WAVES * 64, 0, stream>>>(a);
   RT_CHECK_LAUNCH();
@@ -1087,8 +1118,10 @@ void carve_workspace(SampledArgs& a, void* workspace, int M, int N, int V, int d
   int* ip = reinterpret_cast<int*>(f);
   a.pairs = reinterpret_cast<int2*>(ip); ip += 2 * (size_t)M * C;
   a.rank = ip; ip += (size_t)M * C;
-  a.count = ip; ip += n;
-  a.heavy_count = ip; ip += 1;   // directly behind count: one memset clears both
+  ip = reinterpret_cast<int*>((reinterpret_cast<uintptr_t>(ip) + 255) & ~(uintptr_t)255);   // the cleared region starts on a 256-byte line and
+  a.count = ip; ip += n;                                                                    // is a multiple of 64 bytes long: ONE fill kernel
+  a.heavy_count = ip; ip += 1;   // directly behind count: one memset clears both          // (an unaligned memset is three: head, body, tail)
+  ip += (16 - ((n + 1) & 15)) & 15;
   a.heavy_ids = ip; ip += cap;
   a.heavy_chunk = ip; ip += cap;
   a.offsets = ip; ip += n;
@@ -1128,7 +1161,26 @@ size_t rt_sampled_loss_bwd_workspace_bytes(int32_t M, int32_t N, int32_t V, int3
   const size_t nb = (n + SCAN_T * SCAN_E - 1) / (SCAN_T * SCAN_E);
   const size_t cap = (size_t)heavy_chunk_cap((long long)M * (long long)C);
   const size_t sliced = sliced_applies(M, N, V, d) ? (size_t)M * NSL * ((size_t)d + 2) + 8 : 0;
-  return 4 * ((size_t)M * C * 5 + (size_t)M + 3 * n + nb + 64 + 4 + cap * ((size_t)d + 3) + sliced);
+  return 4 * ((size_t)M * C * 5 + (size_t)M + 3 * n + nb + 64 + 4 + cap * ((size_t)d + 3) + sliced) + 256 + 64;   // (+ the aligned cleared region)
+}
+
+// The counting sort of the (position, candidate) pairs by candidate id depends on the ids alone: called ahead of the forward pass (on
+// another stream: a handful of small launches that would otherwise sit between the forward and the backward kernels), it leaves the
+// ranks, the segment offsets and the popular ids' chunks in `workspace`; rt_sampled_loss_fwd_train / _bwd called with prepared = 1 on
+// the SAME workspace then skip their share of it (the forward writes the pair records, the backward starts at the row reductions).
+// RT_ERR_UNSUPPORTED where the XCD-sliced forward is switched on (RT_LOSS_SLICED=1): call the entry points with prepared = 0 then.
+int rt_sampled_loss_prepare(const int64_t* y, const int64_t* neg, int32_t M, int32_t N, int32_t d, int32_t V, void* workspace,
+                            size_t workspace_bytes, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (M <= 0) return RT_OK;
+  if ((d & 3) || N < 0 || y == nullptr || (N > 0 && neg == nullptr)) return RT_ERR_INVALID_ARG;
+  if ((long long)M * (N + 1) >= (1LL << 31)) return RT_ERR_UNSUPPORTED;
+  if (sliced_applies(M, N, V, d)) return RT_ERR_UNSUPPORTED;
+  if (workspace == nullptr || workspace_bytes < rt_sampled_loss_bwd_workspace_bytes(M, N, V, d)) return RT_ERR_WORKSPACE;
+  SampledArgs a{};
+  a.y = reinterpret_cast<const long long*>(y); a.neg = reinterpret_cast<const long long*>(neg); a.M = M; a.N = N; a.d = d; a.V = V;
+  carve_workspace(a, workspace, M, N, V, d);
+  return dispatch_sampled(a, 3, stream);
 }
 
 // Training forward: everything rt_sampled_loss_fwd writes, plus — in `workspace` — the unit gradient of every logit,
@@ -1137,7 +1189,7 @@ size_t rt_sampled_loss_bwd_workspace_bytes(int32_t M, int32_t N, int32_t V, int3
 int rt_sampled_loss_fwd_train(const float* sess, int64_t ld_sess, const float* table, const int64_t* y, const int64_t* neg,
                               const float* w, int32_t M, int32_t N, int32_t d, int32_t V, int32_t loss, int32_t cosine,
                               float logits_t, double gbce_beta, float* logits, float* loss_pos, float* d_sess_unit,
-                              int64_t ld_du, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                              int64_t ld_du, void* workspace, size_t workspace_bytes, int32_t prepared, hipStream_t stream) {
   (void)hipGetLastError();
   if (M <= 0) return RT_OK;
   if ((d & 3) || N < 0 || loss < LOSS_BCE || loss > LOSS_SAMPLED_SOFTMAX || (ld_sess & 3) || (ld_du & 3)) return RT_ERR_INVALID_ARG;
@@ -1147,7 +1199,7 @@ int rt_sampled_loss_fwd_train(const float* sess, int64_t ld_sess, const float* t
   a.sess = sess; a.ld_sess = ld_sess; a.table = table; a.y = reinterpret_cast<const long long*>(y);
   a.neg = reinterpret_cast<const long long*>(neg); a.w = w; a.M = M; a.N = N; a.d = d; a.V = V; a.loss = loss; a.cosine = cosine;
   a.inv_t = 1.0f / logits_t; a.gbce_beta = gbce_beta; a.logits = logits; a.loss_pos = loss_pos;
-  a.norm = nullptr; a.gscale = 1.f; a.d_sess = d_sess_unit; a.ld_dsess = ld_du;
+  a.norm = nullptr; a.gscale = 1.f; a.d_sess = d_sess_unit; a.ld_dsess = ld_du; a.prepared = prepared != 0;
   carve_workspace(a, workspace, M, N, V, d);
   return dispatch_sampled(a, 1, stream);
 }
@@ -1158,7 +1210,7 @@ int rt_sampled_loss_fwd_train(const float* sess, int64_t ld_sess, const float* t
 int rt_sampled_loss_bwd(const float* sess, int64_t ld_sess, const float* table, const int64_t* y, const int64_t* neg,
                         int32_t M, int32_t N, int32_t d, int32_t V, int32_t cosine, float logits_t, const float* logits,
                         const float* norm, float gscale, const float* d_sess_unit, int64_t ld_du, float* d_sess,
-                        int64_t ld_dsess, float* d_table, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                        int64_t ld_dsess, float* d_table, void* workspace, size_t workspace_bytes, int32_t prepared, hipStream_t stream) {
   (void)hipGetLastError();
   if (M <= 0) return RT_OK;
   if ((d & 3) || N < 0 || (ld_sess & 3) || (ld_dsess & 3) || (ld_du & 3)) return RT_ERR_INVALID_ARG;
@@ -1168,7 +1220,7 @@ int rt_sampled_loss_bwd(const float* sess, int64_t ld_sess, const float* table, 
   a.sess = sess; a.ld_sess = ld_sess; a.table = table; a.y = reinterpret_cast<const long long*>(y);
   a.neg = reinterpret_cast<const long long*>(neg); a.M = M; a.N = N; a.d = d; a.V = V; a.cosine = cosine;
   a.inv_t = 1.0f / logits_t; a.logits = const_cast<float*>(logits); a.norm = norm; a.gscale = gscale;
-  a.d_table = d_table;
+  a.d_table = d_table; a.prepared = prepared != 0;
   carve_workspace(a, workspace, M, N, V, d);
   if (d_sess != nullptr) {   // position side: a scaled copy of what the training forward accumulated
     scale_rows_kernel<<<rt_num_cus() * 4, 256, 0, stream>>>(d_sess_unit, ld_du, d_sess, ld_dsess, M, d, norm, gscale);

@@ -209,10 +209,10 @@ __global__ __launch_bounds__(256) void embed_bwd_pos_kernel(EmbBwdArgs a) {
   }
 }
 
-template <int NDV>
-int launch_embed_bwd(const EmbBwdArgs& a, hipStream_t stream) {
+// the counting sort of the rows by id (depends on the ids alone: rt_embed_bwd_prepare runs it ahead of the backward pass)
+int launch_embed_order(const EmbBwdArgs& a, hipStream_t stream) {
   const int n = a.V + 1;
-  RT_CHECK_HIP(hipMemsetAsync(a.count, 0, sizeof(int) * ((size_t)n + 1), stream));   // + heavy_count
+  RT_CHECK_HIP(hipMemsetAsync(a.count, 0, sizeof(int) * (((size_t)n + 1 + 15) & ~(size_t)15), stream));   // + heavy_count (+ the pad)
   agg_rank_kernel<<<(a.M + AGG_T - 1) / AGG_T, AGG_T, 0, stream>>>(a.ids, a.M, a.count, a.rank, 1);
   RT_CHECK_LAUNCH();
   {
@@ -222,6 +222,14 @@ int launch_embed_bwd(const EmbBwdArgs& a, hipStream_t stream) {
   }
   embed_order_kernel<<<(a.M + 255) / 256, 256, 0, stream>>>(a);
   RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+template <int NDV>
+int launch_embed_bwd(const EmbBwdArgs& a, bool prepared, hipStream_t stream) {
+  if (!prepared) {
+    const int rc = launch_embed_order(a, stream);
+    if (rc != RT_OK) return rc;
+  }
   embed_bwd_heavy_kernel<NDV><<<(int)min(emb_chunk_cap(a.M), (long long)rt_num_cus() * 8), EMB_HEAVY_WAVES * 64, 0, stream>>>(a);
   RT_CHECK_LAUNCH();
   embed_bwd_rows_kernel<NDV><<<(a.V + 3) / 4, 256, 0, stream>>>(a);
@@ -639,7 +647,41 @@ int rt_embed_packed_fwd(const int64_t* ids, const int64_t* dist, const float* ta
 // Host arithmetic: bytes of the int scratch rt_embed_bwd needs.
 size_t rt_embed_bwd_workspace_bytes(int32_t M, int32_t V, int32_t d) {
   const size_t n = (size_t)V + 1, cap = (size_t)emb_chunk_cap(M);
-  return 4 * (cap * ((size_t)d + 2) + 3 * n + 1 + scan_blocks(n) + 64 + 2 * (size_t)M + 4);
+  return 4 * (cap * ((size_t)d + 2) + 3 * n + 1 + scan_blocks(n) + 64 + 2 * (size_t)M + 4) + 256 + 64;   // (+ the aligned cleared region)
+}
+
+}  // extern "C"
+namespace {
+void carve_embed_workspace(EmbBwdArgs& a, void* workspace, int M, int V, int d) {
+  const size_t n = (size_t)V + 1, cap = (size_t)emb_chunk_cap(M);
+  a.slab = reinterpret_cast<float*>(workspace);   // first: 16-byte aligned rows
+  int* ip = reinterpret_cast<int*>(a.slab + cap * (size_t)d);
+  ip = reinterpret_cast<int*>((reinterpret_cast<uintptr_t>(ip) + 255) & ~(uintptr_t)255);   // the cleared region: 256-byte aligned, a multiple
+  a.count = ip; ip += n;                                                                    // of 64 bytes long — ONE fill kernel (an unaligned
+  a.heavy_count = ip; ip += 1;          // directly behind count: one memset clears both    // memset is three: head, body, tail)
+  ip += (16 - ((n + 1) & 15)) & 15;
+  a.offsets = ip; ip += n;
+  a.cursor = ip; ip += n;
+  a.blocksum = ip; ip += scan_blocks(n) + 64;
+  a.order = ip; ip += M;
+  a.rank = ip; ip += M;
+  a.heavy_ids = ip; ip += cap;
+  a.heavy_chunk = ip;
+}
+}  // namespace
+extern "C" {
+
+// The rows' counting sort by id, ahead of the backward pass (it depends on the ids alone; on another stream it leaves eight small
+// launches out of the tail of a training step): fills `workspace`; rt_embed_bwd / rt_embed_packed_bwd called with prepared = 1 on the
+// SAME workspace and the same ids start at the row reductions.
+int rt_embed_bwd_prepare(const int64_t* ids, int32_t M, int32_t d, int32_t V, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  (void)hipGetLastError();
+  if ((d & 3) != 0 || V <= 0 || M < 0 || d > 1024 || ids == nullptr) return RT_ERR_INVALID_ARG;
+  if (workspace == nullptr || workspace_bytes < rt_embed_bwd_workspace_bytes(M, V, d)) return RT_ERR_WORKSPACE;
+  EmbBwdArgs a{};
+  a.ids = reinterpret_cast<const long long*>(ids); a.M = M; a.d = d; a.V = V;
+  carve_embed_workspace(a, workspace, M, V, d);
+  return launch_embed_order(a, stream);
 }
 
 // gtable [V,d] and gpos [L,d] (optional) are fully overwritten; M must be a multiple of L when gpos is given.
@@ -647,28 +689,17 @@ size_t rt_embed_bwd_workspace_bytes(int32_t M, int32_t V, int32_t d) {
 // added to in place and no other row is touched — no second [V,d] tensor, no [V,d] add (3 GB of traffic at V = 1M, d = 256).
 int rt_embed_bwd(const int64_t* ids, const float* gout, float scale, int32_t M, int32_t L, int32_t d, int32_t V, float p,
                  uint64_t seed, uint64_t stream_id, float* gtable, int32_t accumulate, float* gpos, void* workspace,
-                 size_t workspace_bytes, hipStream_t stream) {
+                 size_t workspace_bytes, int32_t prepared, hipStream_t stream) {
   (void)hipGetLastError();
   if ((d & 3) != 0 || L <= 0 || V <= 0 || M < 0 || d > 1024 || (gpos && (M % L) != 0)) return RT_ERR_INVALID_ARG;
   if (workspace == nullptr || workspace_bytes < rt_embed_bwd_workspace_bytes(M, V, d)) return RT_ERR_WORKSPACE;
   EmbBwdArgs a{};
   a.ids = reinterpret_cast<const long long*>(ids); a.gout = gout; a.scale = scale; a.M = M; a.L = L; a.d = d; a.V = V; a.p = p;
   a.seed = seed; a.stream = stream_id; a.gtable = gtable; a.gpos = gpos; a.accumulate = accumulate;
-  const size_t n = (size_t)V + 1, cap = (size_t)emb_chunk_cap(M);
-  a.slab = reinterpret_cast<float*>(workspace);   // first: 16-byte aligned rows
-  int* ip = reinterpret_cast<int*>(a.slab + cap * (size_t)d);
-  a.count = ip; ip += n;
-  a.heavy_count = ip; ip += 1;          // directly behind count: one memset clears both
-  a.offsets = ip; ip += n;
-  a.cursor = ip; ip += n;
-  a.blocksum = ip; ip += scan_blocks(n) + 64;
-  a.order = ip; ip += M;
-  a.rank = ip; ip += M;
-  a.heavy_ids = ip; ip += cap;
-  a.heavy_chunk = ip;
-  if (d <= 256) return launch_embed_bwd<1>(a, stream);
-  if (d <= 512) return launch_embed_bwd<2>(a, stream);
-  return launch_embed_bwd<4>(a, stream);
+  carve_embed_workspace(a, workspace, M, V, d);
+  if (d <= 256) return launch_embed_bwd<1>(a, prepared != 0, stream);
+  if (d <= 512) return launch_embed_bwd<2>(a, prepared != 0, stream);
+  return launch_embed_bwd<4>(a, prepared != 0, stream);
 }
 
 // Backward of rt_embed_packed_fwd: gtable as rt_embed_bwd; gpos [L, d] (optional, fully overwritten): gpos[t] = sum over the
@@ -676,7 +707,7 @@ int rt_embed_bwd(const int64_t* ids, const float* gout, float scale, int32_t M, 
 // cu[b] .. cu[b+1]-1).  Workspace: rt_embed_bwd_workspace_bytes(M, V, d).
 int rt_embed_packed_bwd(const int64_t* ids, const int64_t* cu_seqlens, int32_t B, const float* gout, float scale, int32_t M, int32_t L,
                         int32_t d, int32_t V, float p, uint64_t seed, uint64_t stream_id, float* gtable, int32_t accumulate,
-                        float* gpos, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                        float* gpos, void* workspace, size_t workspace_bytes, int32_t prepared, hipStream_t stream) {
   (void)hipGetLastError();
   if ((d & 3) != 0 || L <= 0 || V <= 0 || M < 0 || B < 0 || d > 1024 || (gpos && cu_seqlens == nullptr)) return RT_ERR_INVALID_ARG;
   if (workspace == nullptr || workspace_bytes < rt_embed_bwd_workspace_bytes(M, V, d)) return RT_ERR_WORKSPACE;
@@ -684,21 +715,10 @@ int rt_embed_packed_bwd(const int64_t* ids, const int64_t* cu_seqlens, int32_t B
   a.ids = reinterpret_cast<const long long*>(ids); a.gout = gout; a.scale = scale; a.M = M; a.L = L; a.d = d; a.V = V; a.p = p;
   a.seed = seed; a.stream = stream_id; a.gtable = gtable; a.gpos = gpos; a.accumulate = accumulate;
   a.cu = reinterpret_cast<const long long*>(cu_seqlens); a.B = B;
-  const size_t n = (size_t)V + 1, cap = (size_t)emb_chunk_cap(M);
-  a.slab = reinterpret_cast<float*>(workspace);
-  int* ip = reinterpret_cast<int*>(a.slab + cap * (size_t)d);
-  a.count = ip; ip += n;
-  a.heavy_count = ip; ip += 1;
-  a.offsets = ip; ip += n;
-  a.cursor = ip; ip += n;
-  a.blocksum = ip; ip += scan_blocks(n) + 64;
-  a.order = ip; ip += M;
-  a.rank = ip; ip += M;
-  a.heavy_ids = ip; ip += cap;
-  a.heavy_chunk = ip;
-  if (d <= 256) return launch_embed_bwd<1>(a, stream);
-  if (d <= 512) return launch_embed_bwd<2>(a, stream);
-  return launch_embed_bwd<4>(a, stream);
+  carve_embed_workspace(a, workspace, M, V, d);
+  if (d <= 256) return launch_embed_bwd<1>(a, prepared != 0, stream);
+  if (d <= 512) return launch_embed_bwd<2>(a, prepared != 0, stream);
+  return launch_embed_bwd<4>(a, prepared != 0, stream);
 }
 
 int rt_layernorm_fwd(const float* x, const float* w, const float* b, float eps, int32_t M, int32_t d, float* y,

@@ -103,6 +103,30 @@ def _native_side_fork() -> tp.Optional[int]:
     return h.value
 
 
+_PREP_KEEPALIVE: tp.List[tp.Any] = []     # buffers of work issued on the side stream during the FORWARD pass (see `_side_fork_forward`)
+
+
+def _side_fork_forward() -> tp.Optional[int]:
+    """`_native_side_fork` for work issued during the forward pass — the counting sorts that depend on the batch's ids alone
+    (`prepare_sampled_pairs`, `_EmbedPacked.forward`).  No autograd callback can be queued there: the consumer joins
+    (`join_side_streams()` in front of the kernel that reads the result, unless it runs on the side stream itself)."""
+    import ctypes
+
+    if not _side_enabled():
+        return None
+    h = ctypes.c_void_p()
+    _lib.check(_lib.load().rt_side_fork(_lib.current_stream(), ctypes.byref(h)), "rt_side_fork")
+    return h.value or None
+
+
+def _prepare_ahead(what: str = "embed") -> bool:
+    """RT_PREPARE_AHEAD: 0 keeps the counting sorts where they were (inside the backward entry points); 1 (default) sorts the embedding's
+    rows ahead of time; 2 also the sampled losses' pairs — opt-in: measured neutral at C2 (84.7 vs 84.5 k seqs/s): the 1.7 M rank atomics
+    that hide under the forward kernel's gathers cost 83 us as a kernel of their own, as much as the launches they take out of the way."""
+    v = os.environ.get("RT_PREPARE_AHEAD", "1")
+    return v != "0" if what == "embed" else v == "2"
+
+
 def _chk(t: torch.Tensor, what: str) -> torch.Tensor:
     if not t.is_cuda or t.dtype != torch.float32:
         raise _lib.HipLibraryError(f"{what}: expected a float32 HIP tensor (no CPU fallback), got {t.dtype} on {t.device}")
@@ -204,9 +228,10 @@ def join_side_streams() -> None:
     for dev in list(_SIDE_DIRTY):
         torch.cuda.current_stream(dev).wait_event(_SIDE[dev].record_event())
     _SIDE_DIRTY.clear()
-    if _NATIVE_KEEPALIVE:
+    if _NATIVE_KEEPALIVE or _PREP_KEEPALIVE:
         _c("rt_side_join")
         _NATIVE_KEEPALIVE.clear()
+        _PREP_KEEPALIVE.clear()
     _TABLE_GRAD_ON_SIDE.clear()
 
 
@@ -361,7 +386,30 @@ def matmul_nn(x: torch.Tensor, p: torch.Tensor) -> torch.Tensor:
 # instead of producing a second [V,d] tensor that autograd would add with a full-size kernel.  Keyed by the table's storage.
 _TABLE_GRAD_SINK: tp.Dict[int, torch.Tensor] = {}
 _TABLE_GRAD_ON_SIDE: tp.Set[int] = set()      # sinks whose loss half is in flight on the side stream: the embedding adds there too
-_LOSS_TABLE_ON_SIDE = os.environ.get("RT_LOSS_SIDE", "0") == "1"   # opt-in: measured equal (69.3 vs 70.2 k seqs/s at C2): the gathers contend
+# The table half of the sampled losses' backward (counting sort + gathered row reductions: read by the optimiser only) on the side stream,
+# the embedding backward behind it.  Round 3 measured it equal (69.3 vs 70.2 k seqs/s at C2: the gathers contend with the layer backward);
+# with the row-resident chain kernels (212 workgroups on 256 CUs) and the embedding's sort done ahead of time (RT_PREPARE_AHEAD) it is
+# 85.1 vs 81.9 k seqs/s on one box, 84.1 vs 83.2 k on another (round 4).  RT_LOSS_SIDE=0 keeps everything on the main stream.
+_LOSS_TABLE_ON_SIDE = os.environ.get("RT_LOSS_SIDE", "1") == "1"
+
+
+# Tables whose lookup ran in THIS forward pass (weak references, keyed by storage): only then will an embedding node pick the loss's table
+# gradient up as its sink and drop the extra reference `_TABLE_GRAD_SINK` holds — without a consumer that reference makes autograd's
+# AccumulateGrad CLONE the gradient on the main stream, which must not happen while the side stream is still writing it (seen as a
+# rare wrong d_table in a loss-only test once the side stream became the default for the loss's table half).
+_TABLE_SINK_EXPECTED: tp.Dict[int, tp.Any] = {}
+
+
+def _expect_table_sink(table: torch.Tensor) -> None:
+    import weakref
+
+    _TABLE_SINK_EXPECTED[table.data_ptr()] = weakref.ref(table)
+
+
+def _table_sink_expected(table: torch.Tensor) -> bool:
+    r = _TABLE_SINK_EXPECTED.pop(table.data_ptr(), None)
+    t = None if r is None else r()
+    return t is not None and t.data_ptr() == table.data_ptr() and t.shape == table.shape
 
 
 def _offer_table_grad(table: torch.Tensor, d_table: torch.Tensor) -> None:
@@ -381,6 +429,8 @@ class _Embed(torch.autograd.Function):
         ctx.meta = (table.shape, None if pos is None else pos.shape, L, scale, p, seed, sid)
         ctx.table_ptr = table.data_ptr()
         _TABLE_GRAD_SINK.pop(ctx.table_ptr, None)   # a sink left over from an aborted backward pass must not be reused
+        if ctx.needs_input_grad[0]:
+            _expect_table_sink(table)
         return out
 
     @staticmethod
@@ -405,7 +455,7 @@ class _Embed(torch.autograd.Function):
             if side is None:
                 join_side_streams()
         _c("rt_embed_bwd", ids, gout, float(scale), M, L, tshape[1], V, float(p), seed, sid, gtable, 1 if sink is not None else 0,
-           gpos, ws, ws_bytes, stream=side)
+           gpos, ws, ws_bytes, 0, stream=side)
         if side is not None:
             _NATIVE_KEEPALIVE.append((ids, gout, ws))         # not gtable / gpos: autograd must adopt them, not clone them
         return (None if sink is not None else gtable), gpos, None, None, None, None
@@ -427,15 +477,27 @@ class _EmbedPacked(torch.autograd.Function):
         out = torch.empty((M, d), dtype=torch.float32, device=table.device)
         seed, sid = RNG.next() if p > 0 else (0, 0)
         _c("rt_embed_packed_fwd", ids, dist, table, pos, float(scale), M, d, float(p), seed, sid, out)
-        ctx.save_for_backward(ids, cu)
+        ws = None
+        if ctx.needs_input_grad[0] and _prepare_ahead():
+            # the backward's counting sort of the rows by id depends on `ids` alone: issued NOW on the side stream it is long done when
+            # the backward pass arrives (eight small launches less in the tail of a step)
+            ws_bytes = _lib.load().rt_embed_bwd_workspace_bytes(M, table.shape[0], d)
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=table.device)
+            side = _side_fork_forward()
+            _c("rt_embed_bwd_prepare", ids, M, d, table.shape[0], ws, ws_bytes, stream=side)
+            if side is not None:
+                _PREP_KEEPALIVE.append((ids, ws))
+        ctx.save_for_backward(ids, cu, *(() if ws is None else (ws,)))
         ctx.meta = (table.shape, None if pos is None else pos.shape, B, L, scale, p, seed, sid)
         ctx.table_ptr = table.data_ptr()
         _TABLE_GRAD_SINK.pop(ctx.table_ptr, None)
+        if ctx.needs_input_grad[0]:
+            _expect_table_sink(table)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        ids, cu = ctx.saved_tensors
+        ids, cu, *prep = ctx.saved_tensors
         tshape, pshape, B, L, scale, p, seed, sid = ctx.meta
         gout = gout.contiguous()
         M, V = ids.numel(), tshape[0]
@@ -447,7 +509,7 @@ class _EmbedPacked(torch.autograd.Function):
         if pshape is not None:
             gpos = (torch.empty if pshape[0] == L else torch.zeros)(pshape, dtype=torch.float32, device=gout.device)
         ws_bytes = _lib.load().rt_embed_bwd_workspace_bytes(M, V, tshape[1])
-        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=gout.device)
+        ws = prep[0] if prep else torch.empty((ws_bytes,), dtype=torch.uint8, device=gout.device)
         side = None
         if sink is not None and sink.data_ptr() in _TABLE_GRAD_ON_SIDE:
             # the sink's loss half is still in flight on the side stream: add the lookup's rows there, behind it (this is the last
@@ -456,8 +518,10 @@ class _EmbedPacked(torch.autograd.Function):
             side = _native_side_fork()
             if side is None:
                 join_side_streams()
+        if prep and side is None and _PREP_KEEPALIVE:
+            join_side_streams()          # the sort ran on the side stream and nothing has joined it yet (no sampled loss in this step)
         _c("rt_embed_packed_bwd", ids, cu, B, gout, float(scale), M, L, tshape[1], V, float(p), seed, sid, gtable,
-           1 if sink is not None else 0, gpos, ws, ws_bytes, stream=side)
+           1 if sink is not None else 0, gpos, ws, ws_bytes, 1 if prep else 0, stream=side)
         if side is not None:
             _NATIVE_KEEPALIVE.append((ids, cu, gout, ws))     # not gtable / gpos: autograd must adopt them, not clone them
         return (None if sink is not None else gtable), gpos, None, None, None, None, None, None, None
@@ -1987,6 +2051,40 @@ def stu_layer_packed(x: torch.Tensor, cu: torch.Tensor, rows_real: int, ts: tp.O
 # --------------------------------------------------------------------------------------------------
 # losses
 # --------------------------------------------------------------------------------------------------
+_PREPARED_PAIRS: tp.Dict[tp.Tuple, torch.Tensor] = {}   # at most ONE entry: the workspace `prepare_sampled_pairs` filled for this step's batch
+
+
+def _pairs_key(y: torch.Tensor, neg: torch.Tensor, V: int, d: int) -> tp.Tuple:
+    return (RNG.step, y.data_ptr(), neg.data_ptr(), int(y.numel()), int(neg.shape[-1]), int(V), int(d))
+
+
+def prepare_sampled_pairs(y: torch.Tensor, neg: torch.Tensor, V: int, d: int) -> None:
+    """The sampled losses' counting sort of the (position, candidate) pairs by candidate id — needed by the backward pass only, a
+    function of the ids only — issued on the side stream as soon as the batch exists (`rt_sampled_loss_prepare`): six small launches
+    leave the gap between the forward and the backward kernels of a training step, and the training forward writes the pair records
+    itself.  `sampled_loss` finds the workspace through (step, the two tensors' storage, sizes); any mismatch (another y / neg, a
+    loss that is never called) just leaves it unused."""
+    _PREPARED_PAIRS.clear()
+    if not _prepare_ahead("loss") or not (y.is_cuda and neg.is_cuda and y.dtype == torch.int64 and neg.dtype == torch.int64):
+        return
+    y1 = y.reshape(-1)
+    M = int(y1.numel())
+    if M == 0 or not y1.is_contiguous() or not neg.is_contiguous() or neg.numel() % M != 0:
+        return
+    neg2 = neg.reshape(M, -1)
+    N = int(neg2.shape[1])
+    ws_bytes = _lib.load().rt_sampled_loss_bwd_workspace_bytes(M, N, int(V), int(d))
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=y.device)
+    side = _side_fork_forward()
+    try:
+        _c("rt_sampled_loss_prepare", y1, neg2, M, N, int(d), int(V), ws, ws_bytes, stream=side)
+    except NotImplementedError:          # (the XCD-sliced forward keeps its own order)
+        return
+    if side is not None:
+        _PREP_KEEPALIVE.append((y1, neg2, ws))
+    _PREPARED_PAIRS[_pairs_key(y1, neg2, V, d)] = ws
+
+
 class _SampledLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, sess, table, y, neg, w, loss, cosine, logits_t, beta):
@@ -2000,10 +2098,17 @@ class _SampledLoss(torch.autograd.Function):
         train = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         if train:  # one pass over the candidate rows also yields the unit gradients the backward needs
             ws_bytes = _lib.load().rt_sampled_loss_bwd_workspace_bytes(M, N, V, d)
-            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+            ws = _PREPARED_PAIRS.pop(_pairs_key(y, neg, V, d), None)       # sorted ahead of the forward pass (`prepare_sampled_pairs`)?
+            prepared = ws is not None and ws.numel() >= ws_bytes
+            if prepared:
+                if _PREP_KEEPALIVE:
+                    join_side_streams()                                     # (the sort ran on the side stream)
+            else:
+                ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
             du = torch.empty((M, d), dtype=torch.float32, device=dev)
             _c("rt_sampled_loss_fwd_train", sess, sess.stride(0), table, y, neg, w, M, N, d, V, loss, int(cosine),
-               float(logits_t), float(beta), logits, loss_pos, du, d, ws, ws_bytes)
+               float(logits_t), float(beta), logits, loss_pos, du, d, ws, ws_bytes, 1 if prepared else 0)
+            ctx.prepared = prepared
             ctx.save_for_backward(sess, table, y, neg, logits, out, du, ws)
         else:
             _c("rt_sampled_loss_fwd", sess, sess.stride(0), table, y, neg, w, M, N, d, loss, int(cosine), float(logits_t),
@@ -2011,6 +2116,7 @@ class _SampledLoss(torch.autograd.Function):
         _c("rt_loss_reduce", loss_pos, y, M, 0 if loss == LOSS_SAMPLED_SOFTMAX else 1, out)
         ctx.meta = (cosine, logits_t)
         ctx.mark_non_differentiable(logits)
+        ctx.set_materialize_grads(False)     # no [M, 1 + N] zeros for the logits' unused gradient at the start of every backward pass
         return out[0], logits
 
     @staticmethod
@@ -2020,25 +2126,32 @@ class _SampledLoss(torch.autograd.Function):
         M, d = sess.shape
         N = neg.shape[-1]
         V = table.shape[0]
+        if gloss is None:                    # (set_materialize_grads(False): nothing asked for the loss)
+            return (None,) * 9
         d_sess = torch.empty((M, d), dtype=torch.float32, device=sess.device)
         d_table = torch.empty_like(table)
-        g = float(gloss)
-        args = (sess, sess.stride(0), table, y, neg, M, N, d, V, int(cosine), float(logits_t), logits, out[1:], g, du, d)
+        # The upstream gradient stays on the device: the kernels divide by norm[0], so the quotient normaliser / upstream does what
+        # `float(gloss)` did — without the device -> host copy that made the host wait for the whole forward pass at the start of every
+        # backward pass (one tiny elementwise launch instead; the host may now run steps ahead of the device)
+        norm_eff = out[1:] / gloss.reshape(1).to(torch.float32)
+        args = (sess, sess.stride(0), table, y, neg, M, N, d, V, int(cosine), float(logits_t), logits, norm_eff, 1.0, du, d)
+        prep = 1 if getattr(ctx, "prepared", False) else 0
         # One call on the main stream.  The table half (counting sort + gathered row reductions, memory-bound) was tried on the
         # side stream under the MFMA-bound layer backward (rt_sampled_loss_bwd accepts either output as NULL for that):
         # measured 3.12 vs 3.06 ms/step at C2 — the co-running gather slows the GEMMs by more than it hides.
-        side = _native_side_fork() if (_LOSS_TABLE_ON_SIDE and ctx.needs_input_grad[1] and _steals_grad(table)) else None
+        side = _native_side_fork() if (_LOSS_TABLE_ON_SIDE and ctx.needs_input_grad[1] and _steals_grad(table)
+                                       and _table_sink_expected(table)) else None
         if side is None:
-            _c("rt_sampled_loss_bwd", *args, d_sess, d, d_table, ws, ws.numel())
+            _c("rt_sampled_loss_bwd", *args, d_sess, d, d_table, ws, ws.numel(), prep)
         else:
             # the session half is the critical path (it feeds the whole layer backward); the table half — counting sort + gathered row
             # reductions, read only by the optimiser — runs beside it on the library's side stream.  (Round 2 measured this slower when
             # the main stream was GEMM-bound end to end; with packed rows and the bf16 attention the main stream is the long pole.)
-            _c("rt_sampled_loss_bwd", *args, d_sess, d, None, ws, ws.numel())
-            _c("rt_sampled_loss_bwd", *args, None, d, d_table, ws, ws.numel(), stream=side)
+            _c("rt_sampled_loss_bwd", *args, d_sess, d, None, ws, ws.numel(), prep)
+            _c("rt_sampled_loss_bwd", *args, None, d, d_table, ws, ws.numel(), prep, stream=side)
             # NOT d_table: an extra reference would make autograd's AccumulateGrad clone it (on the main stream, before the side stream
             # has written it) instead of adopting it; as `table.grad` it outlives the join anyway
-            _NATIVE_KEEPALIVE.append((sess, table, y, neg, logits, out, du, ws))
+            _NATIVE_KEEPALIVE.append((sess, table, y, neg, logits, out, du, ws, norm_eff))
             _TABLE_GRAD_ON_SIDE.add(d_table.data_ptr())
         if ctx.needs_input_grad[1]:   # only a gradient autograd will hand to the table can serve as the embedding node's sink
             _offer_table_grad(table, d_table)
@@ -2100,7 +2213,8 @@ class _SoftmaxLoss(torch.autograd.Function):
         logits_t, M_total, d, R, V = ctx.meta
         Rp, Vp = logits.shape
         # logits := (softmax - onehot) * w * g / (norm * t), in place (the buffer is ours); pad rows / columns stay zero
-        _c("rt_softmax_ce_rows", logits, Vp, R, V, y_act, w_act, float(logits_t), 1, out[1:], float(gloss), None, lse)
+        norm_eff = out[1:] / gloss.reshape(1).to(torch.float32)    # the upstream gradient stays on the device (see _SampledLoss.backward)
+        _c("rt_softmax_ce_rows", logits, Vp, R, V, y_act, w_act, float(logits_t), 1, norm_eff, 1.0, None, lse)
         ds_act = torch.empty((Rp, d), dtype=torch.float32, device=logits.device)
         _gemm(logits, Vp, 1, tab, tab.stride(0), 0, ds_act, d, None, None, 0, Rp, d, Vp, 0, _deep_k_splits(Rp, d, Vp))  # dS = G @ E
         d_tab = torch.empty((Vp, d), dtype=torch.float32, device=logits.device)

@@ -22,7 +22,8 @@ for step in "$@"; do
     bench) timeout 600 python bench.py $arg > $O/${i}_bench.json 2> $O/${i}_bench.err; tail -c 800 $O/${i}_bench.err; python scripts/gpu/summ.py $O/${i}_bench.json ;;
     env)   vars=${arg%%:*}; rest=${arg#*:}; env $(echo $vars | tr ',' ' ') timeout 600 python bench.py $rest > $O/${i}_bench.json 2> $O/${i}_bench.err; tail -c 800 $O/${i}_bench.err; python scripts/gpu/summ.py $O/${i}_bench.json ;;
     prof)  rm -rf $O/${i}_prof; (cd /tmp && timeout 600 rocprofv3 --kernel-trace -d $R/$O/${i}_prof -o p -- python $R/bench.py --no-cpu-baseline $arg > $R/$O/${i}_prof.json 2> $R/$O/${i}_prof.err)
-           python scripts/prof_summary.py $(find $O/${i}_prof -name "*.db" | head -1) 45 > $O/${i}_prof.md 2>&1; head -34 $O/${i}_prof.md | cut -c1-180 ;;
+           python scripts/prof_summary.py $(find $O/${i}_prof -name "*.db" | head -1) 45 > $O/${i}_prof.md 2>&1; head -34 $O/${i}_prof.md | cut -c1-180
+           python scripts/prof_summary.py $(find $O/${i}_prof -name "*.db" | head -1) --timeline > $O/${i}_timeline.txt 2>&1 ;;
     pmc)   ctr=${arg%%:*}; rest=${arg#*:}; rm -rf $O/${i}_pmc
            (cd /tmp && RT_SIDE_STREAM=0 timeout 600 rocprofv3 --kernel-trace --pmc $(echo $ctr | tr ',' ' ') --output-format csv -d $R/$O/${i}_pmc -o p -- python $R/bench.py --no-cpu-baseline $rest > $R/$O/${i}_pmc.log 2>&1)
            f=$(find $O/${i}_pmc -name "*counter_collection.csv" | head -1)
