@@ -2188,6 +2188,8 @@ class _SoftmaxLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, sess, table, act_idx, y_act, w_act, logits_t, M_total):
+        if _PREP_KEEPALIVE:          # the embedding's sort (side stream, issued at the start of the forward pass) is long done: joining it
+            join_side_streams()      # HERE costs nothing, joining it in the embedding backward would wait for the weight gradients
         R = act_idx.numel()
         V, d = table.shape
         tp_ = _padded_table(table)
