@@ -222,7 +222,10 @@ class _TrainLoop:
         ops.RNG.next_step()
         self.opt.zero_grad()
         loss = self.lm.training_loss_packed(batch) if self.packed else self.lm.training_loss(batch)
-        loss.backward()
+        one = getattr(self, "_root_grad", None)
+        if one is None or one.device != loss.device or one.shape != loss.shape:
+            one = self._root_grad = torch.ones_like(loss)      # the root gradient, made once (autograd fills a fresh one per call: a launch)
+        loss.backward(one)
         self.opt.step(self.world)
         return loss
 
