@@ -883,10 +883,10 @@ def main():
             out["topk5m_u4096"] = topk_leg("topk5m", big, rank, world, False)   # >= 4096 users over 5M x 512 (the MFMA regime)
             if not args.no_families:
                 # the other BASELINE configs' model families at their stated shapes (configs[2..4]: BERT4Rec d256 L200 full softmax; HSTU d256
-                # L512 relative time + position bias, 1 M items; eSASRec = SASRec on LiGR blocks, d512, 1 M items): the same product loop, 10
+                # L512 relative time + position bias, 1 M items; eSASRec = SASRec on LiGR blocks, d512, 1 M items): the same product loop, 20
                 # timed steps each — short on purpose (the line must finish within minutes); `--workload <family>` runs one at length
                 fam = argparse.Namespace(**vars(args))
-                fam.steps, fam.warmup = 10, 3
+                fam.steps, fam.warmup = 20, 6
                 out["families"] = {}
                 for kind_f in ("bert4rec", "hstu", "esasrec", "esasrec_kpm"):
                     v_f, wall_f, roof_f, info_f = run_train(fam, rank, world, kind_f)

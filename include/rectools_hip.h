@@ -488,6 +488,11 @@ int rt_side_join(rt_stream_t stream);
 /* the side stream for the caller's own optimiser-only work: it waits for `stream`'s current position; *side_out = its handle, or
  * NULL when disabled (launch on `stream` then).  Joined by rt_side_join. */
 int rt_side_fork(rt_stream_t stream, void** side_out);
+/* A point on the side stream that a launch on another stream can wait for without waiting for what the side stream is given afterwards
+ * (rt_side_join waits for everything issued so far): rt_side_mark records it, rt_side_wait_mark makes `stream` wait for the latest one
+ * (no-op when none was recorded since the last join). */
+int rt_side_mark(void);
+int rt_side_wait_mark(rt_stream_t stream);
 int rt_timing_enable(int32_t mode);
 int rt_timing_collect(int32_t* ids, float* ms, int64_t* tags, int32_t max_records, int32_t* n_out);
 

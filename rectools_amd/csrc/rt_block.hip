@@ -119,7 +119,7 @@ enum { T_GEMM = 0, T_GEMM_GROUPED = 1, T_LN_FWD = 2, T_LN_BWD = 3, T_DROP_FWD = 
        T_ATTN_LAST = 8, T_MISC = 9, T_ATTN_BIDIR_FWD = 10, T_ATTN_BIDIR_BWD = 11, T_FFN_FWD = 12, T_FFN_BWD = 13 };
 
 // ---- the weight-gradient side stream (one per device, owned by the library) -------------------------------------------------------
-struct Side { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool dirty = false; };
+struct Side { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr, mark = nullptr; bool dirty = false, marked = false; };
 Side g_side[16];
 bool side_enabled() {
   static int on = -1;
@@ -131,9 +131,18 @@ Side* side_of_current_device() {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
   Side& s = g_side[dev];
   if (s.stream == nullptr) {
-    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    // LOW priority: what runs here is needed by the optimiser only.  At equal priority the dispatcher keeps refilling the CUs' wave slots
+    // with the side stream's small-footprint workgroups (the loss's row reductions: 8 waves per SIMD) and a main-stream kernel that needs
+    // a whole CU's LDS waits for a slot: v2_bwd_dq 227 us instead of 67 beside sampled_bwd_rows (profiles/r4_timeline_train.txt).
+    // RT_SIDE_PRIORITY=normal keeps the default priority.
+    const char* e = getenv("RT_SIDE_PRIORITY");
+    int least = 0, greatest = 0;
+    const bool low = (e == nullptr || e[0] != 'n') && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest;
+    const hipError_t rc = low ? hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, least) : hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+    if (rc != hipSuccess) return nullptr;
     (void)hipEventCreateWithFlags(&s.fork, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&s.join, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&s.mark, hipEventDisableTiming);
   }
   return &s;
 }
@@ -181,7 +190,25 @@ int rt_side_join(hipStream_t stream) {
   if (s == nullptr || !s->dirty) return RT_OK;
   RT_CHECK_HIP(hipEventRecord(s->join, s->stream));
   RT_CHECK_HIP(hipStreamWaitEvent(stream, s->join, 0));
-  s->dirty = false;
+  s->dirty = false; s->marked = false;
+  return RT_OK;
+}
+
+// A point on the side stream that a later launch on another stream can wait for WITHOUT waiting for what the side stream is given
+// afterwards (rt_side_join waits for everything issued so far): rt_side_mark records it, rt_side_wait_mark makes `stream` wait for the
+// latest one (no-op when none was recorded since the last join).  The embedding backward uses the pair: it needs the loss's table
+// gradient (side stream, early in the backward pass), not the weight gradients queued behind it.
+int rt_side_mark(void) {
+  Side* s = side_of_current_device();
+  if (s == nullptr || s->stream == nullptr) return RT_OK;
+  RT_CHECK_HIP(hipEventRecord(s->mark, s->stream));
+  s->marked = true;
+  return RT_OK;
+}
+int rt_side_wait_mark(hipStream_t stream) {
+  Side* s = side_of_current_device();
+  if (s == nullptr || !s->marked) return RT_OK;
+  RT_CHECK_HIP(hipStreamWaitEvent(stream, s->mark, 0));
   return RT_OK;
 }
 

@@ -77,53 +77,49 @@ __global__ void scan_add_kernel(int* __restrict__ offsets, int* __restrict__ cur
   cursor[i] = slot;
 }
 
-// The whole scan in ONE launch for histograms of up to 64 K bins (the C2 catalog: 26,745): one 1024-thread workgroup walks the bins in
-// 4096-element rounds with a running carry and finalises each bin on the spot (what scan_add_kernel does).  The three-launch form costs
-// three dependent ~5 us launches for ~100 KB of data — twice per training step (the loss's pairs, the embedding's rows).
+// The whole scan in ONE launch for histograms of up to 32 K bins (the C2 catalog: 26,745): one 1024-thread workgroup, every thread owns
+// E = ceil(n / 1024) CONSECUTIVE bins — ONE round of loads, a block-wide scan of the 1024 thread totals, one round of stores with each
+// bin finalised on the spot (what scan_add_kernel does).  The three-launch form costs three dependent ~5 us launches for ~100 KB of data,
+// twice per training step; a first single-launch form that walked the bins in 4096-element rounds with a carry paid a dependent global
+// round trip per round (26 us for 7 rounds, profiles/r4_timeline_train.txt).
+constexpr int SCAN1_E = 32;
 __global__ __launch_bounds__(SCAN_T) void scan_single_kernel(const int* __restrict__ count, int n, int* __restrict__ offsets,
                                                              int* __restrict__ cursor, int heavy_t, int chunk, int* __restrict__ heavy_count,
                                                              int* __restrict__ heavy_key, int* __restrict__ heavy_chunk) {
   __shared__ int s_w[SCAN_T / 64];
-  __shared__ int s_carry;
-  if (threadIdx.x == 0) s_carry = 0;
-  __syncthreads();
+  const int E = (n + SCAN_T - 1) / SCAN_T;               // <= SCAN1_E (host)
+  const int base = threadIdx.x * E;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int b0 = 0; b0 < n; b0 += SCAN_T * SCAN_E) {
-    const int base = b0 + threadIdx.x * SCAN_E;
-    int v[SCAN_E], t = 0;
+  int v[SCAN1_E], t = 0;
 #pragma unroll
-    for (int e = 0; e < SCAN_E; ++e) { v[e] = (base + e < n) ? count[base + e] : 0; t += v[e]; }
-    int incl = t;
+  for (int e = 0; e < SCAN1_E; ++e) { v[e] = (e < E && base + e < n) ? count[base + e] : 0; t += v[e]; }
+  int incl = t;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
-    if (lane == 63) s_w[wave] = incl;
-    __syncthreads();
-    if (wave == 0) {
-      int x = (lane < SCAN_T / 64) ? s_w[lane] : 0, inc = x;
+  for (int o = 1; o < 64; o <<= 1) { int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  if (wave == 0) {
+    int x = (lane < SCAN_T / 64) ? s_w[lane] : 0, inc = x;
 #pragma unroll
-      for (int o = 1; o < 16; o <<= 1) { int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
-      if (lane < SCAN_T / 64) s_w[lane] = inc - x;   // exclusive prefix of the wave totals
-    }
-    __syncthreads();
-    int run = s_carry + s_w[wave] + incl - t;
+    for (int o = 1; o < 16; o <<= 1) { int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+    if (lane < SCAN_T / 64) s_w[lane] = inc - x;         // exclusive prefix of the wave totals
+  }
+  __syncthreads();
+  int run = s_w[wave] + incl - t;
 #pragma unroll
-    for (int e = 0; e < SCAN_E; ++e) {
-      const int i = base + e;
-      if (i < n) {
-        offsets[i] = run;
-        int slot = -1;
-        if (heavy_count != nullptr && v[e] > heavy_t) {
-          const int n_ch = (v[e] + chunk - 1) / chunk;
-          slot = atomicAdd(heavy_count, n_ch);
-          for (int c = 0; c < n_ch; ++c) { heavy_key[slot + c] = i; heavy_chunk[slot + c] = c; }
-        }
-        cursor[i] = slot;
+  for (int e = 0; e < SCAN1_E; ++e) {
+    const int i = base + e;
+    if (e < E && i < n) {
+      offsets[i] = run;
+      int slot = -1;
+      if (heavy_count != nullptr && v[e] > heavy_t) {
+        const int n_ch = (v[e] + chunk - 1) / chunk;
+        slot = atomicAdd(heavy_count, n_ch);
+        for (int c = 0; c < n_ch; ++c) { heavy_key[slot + c] = i; heavy_chunk[slot + c] = c; }
       }
-      run += v[e];
+      cursor[i] = slot;
     }
-    __syncthreads();                                   // every thread has read s_carry
-    if (threadIdx.x == SCAN_T - 1) s_carry = run;      // = the old carry + this round's total
-    __syncthreads();
+    run += v[e];
   }
 }
 
@@ -171,7 +167,7 @@ inline size_t scan_blocks(size_t n) { return (n + SCAN_T * SCAN_E - 1) / (SCAN_T
 inline int exclusive_scan_counts(const int* count, int n, int* offsets, int* cursor, int* blocksum, hipStream_t stream,
                                  int heavy_t = 0, int chunk = 1, int* heavy_count = nullptr, int* heavy_key = nullptr,
                                  int* heavy_chunk = nullptr) {
-  if (n <= 65536) {
+  if (n <= SCAN1_E * SCAN_T) {
     scan_single_kernel<<<1, SCAN_T, 0, stream>>>(count, n, offsets, cursor, heavy_t, chunk, heavy_count, heavy_key, heavy_chunk);
     RT_CHECK_LAUNCH();
     return RT_OK;

@@ -510,15 +510,21 @@ class _EmbedPacked(torch.autograd.Function):
             gpos = (torch.empty if pshape[0] == L else torch.zeros)(pshape, dtype=torch.float32, device=gout.device)
         ws_bytes = _lib.load().rt_embed_bwd_workspace_bytes(M, V, tshape[1])
         ws = prep[0] if prep else torch.empty((ws_bytes,), dtype=torch.uint8, device=gout.device)
-        side = None
+        side, prep_joined = None, False
         if sink is not None and sink.data_ptr() in _TABLE_GRAD_ON_SIDE:
-            # the sink's loss half is still in flight on the side stream: add the lookup's rows there, behind it (this is the last
-            # node of the backward pass and only the optimiser reads the result)
             _TABLE_GRAD_ON_SIDE.discard(sink.data_ptr())
-            side = _native_side_fork()
-            if side is None:
-                join_side_streams()
-        if prep and side is None and _PREP_KEEPALIVE:
+            if os.environ.get("RT_EMBED_BWD", "main") == "side":
+                # the sink's loss half is in flight on the side stream: add the lookup's rows there, behind it — and behind the weight
+                # gradients queued since (measured: the side stream then ends 78 us after the main one, profiles/r4_timeline_train.txt)
+                side = _native_side_fork()
+                if side is None:
+                    join_side_streams()
+            else:
+                # on the main stream, behind the point the loss's table half (and the rows' counting sort, issued before it) reached on
+                # the side stream — not behind the weight gradients that stream was given afterwards
+                _lib.check(_lib.load().rt_side_wait_mark(_lib.current_stream()), "rt_side_wait_mark")
+                prep_joined = True
+        if prep and side is None and _PREP_KEEPALIVE and not prep_joined:
             join_side_streams()          # the sort ran on the side stream and nothing has joined it yet (no sampled loss in this step)
         _c("rt_embed_packed_bwd", ids, cu, B, gout, float(scale), M, L, tshape[1], V, float(p), seed, sid, gtable,
            1 if sink is not None else 0, gpos, ws, ws_bytes, 1 if prep else 0, stream=side)
@@ -2149,6 +2155,7 @@ class _SampledLoss(torch.autograd.Function):
             # the main stream was GEMM-bound end to end; with packed rows and the bf16 attention the main stream is the long pole.)
             _c("rt_sampled_loss_bwd", *args, d_sess, d, None, ws, ws.numel(), prep)
             _c("rt_sampled_loss_bwd", *args, None, d, d_table, ws, ws.numel(), prep, stream=side)
+            _lib.check(_lib.load().rt_side_mark(), "rt_side_mark")      # the embedding backward waits for THIS point, not for the weight gradients behind it
             # NOT d_table: an extra reference would make autograd's AccumulateGrad clone it (on the main stream, before the side stream
             # has written it) instead of adopting it; as `table.grad` it outlives the join anyway
             _NATIVE_KEEPALIVE.append((sess, table, y, neg, logits, out, du, ws, norm_eff))
