@@ -66,6 +66,7 @@ struct TopkArgs {
   int use_bound;                 // 16-user tile: 0 = seeding prefix (the shared bound is neither read nor published)
   int bloom;                     // engine 2: 1 = a 1024-bit Bloom filter per user of the tile sits in LDS behind the lists
   int h_only;                    // HM kernels: 1 = the images hold ONE bf16 (round-to-nearest) per value (rows of d / 2 words): one MFMA per slot
+  int xmap_gx, xmap_gy;          // topk_coarse_frag_kernel on a 1-D grid: the (segments, user tiles) grid it stands for (0, 0: plain 2-D grid)
 };
 
 // acc + |v|^2 as one fixed fma chain: engine 2 and the two-stage exact pass (topk_replay_kernel) must round a row norm alike
@@ -1694,13 +1695,25 @@ __global__ __launch_bounds__(NTHREADS) void topk_coarse_frag_kernel(TopkArgs a) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5;
   const int S = a.n_seg;
-  const int user0 = blockIdx.y * UB;
+  // Workgroup -> (segment sx, user tile ty).  A segment's item blocks are read by EVERY user tile; on the plain 2-D grid the tiles of a
+  // segment are n_seg workgroups apart — resident at different times, on whichever XCD their linear index lands — and each streams its
+  // share of the image from HBM again (PMC: 92 GB per 4,096-user launch for a 5.12 GB image).  1-D grid: workgroup w runs on XCD w % 8;
+  // that XCD owns the segments sx = 8 i + w % 8 and walks them tile after tile, so the 32 CUs of an XCD hold the user tiles of ONE
+  // segment at a time, reading the same item blocks in step: one HBM fetch, the others hit that XCD's L2.
+  int sx = blockIdx.x, ty = blockIdx.y;
+  if (a.xmap_gy > 0) {
+    const int w = blockIdx.x, q = w >> 3;
+    sx = (q / a.xmap_gy) * 8 + (w & 7);
+    ty = q % a.xmap_gy;
+    if (sx >= a.xmap_gx) return;
+  }
+  const int user0 = ty * UB;
   const int n_s = a.d >> 3;                                                // k = 16 slots per row (a.d = words per image row = d / 2)
   unsigned* const g_lds = reinterpret_cast<unsigned*>(smem + (size_t)TU * n_s * 64 * 4);   // [UB] copy of the shared bound
 
   const long long n_blocks = a.blk_end - a.blk_begin;
-  const long long my_blocks = ((int)blockIdx.x < S && n_blocks > blockIdx.x) ? (n_blocks - blockIdx.x + S - 1) / S : 0;
-  const int list_id = blockIdx.x * LISTS_PER_WG + wave * 2 + half;
+  const long long my_blocks = (sx < S && n_blocks > sx) ? (n_blocks - sx + S - 1) / S : 0;
+  const int list_id = sx * LISTS_PER_WG + wave * 2 + half;
   SelState<TU, false> st;
   st.init();
   st.bind_global(a, list_id, user0, lane);
@@ -1719,7 +1732,7 @@ __global__ __launch_bounds__(NTHREADS) void topk_coarse_frag_kernel(TopkArgs a) 
   }
 
   const u32x4* const items = reinterpret_cast<const u32x4*>(a.items);
-  const long long last_blk = a.blk_begin + blockIdx.x + (my_blocks - 1) * S;
+  const long long last_blk = a.blk_begin + sx + (my_blocks - 1) * S;
   // fragment (s = 0) of this wave's rows of item block `blk`, this lane's unit
   auto frag0 = [&](long long blk) -> const u32x4* { return items + ((blk * (IB / 32) + wave) * n_s) * 64 + lane; };
   const long long n_pairs = (my_blocks + IW - 1) / IW;
@@ -1738,7 +1751,7 @@ __global__ __launch_bounds__(NTHREADS) void topk_coarse_frag_kernel(TopkArgs a) 
   auto set_pair = [&](long long j) {
 #pragma unroll
     for (int iw = 0; iw < IW; ++iw) {
-      long long blk = a.blk_begin + blockIdx.x + (j * IW + iw) * S;
+      long long blk = a.blk_begin + sx + (j * IW + iw) * S;
       if (blk > last_blk) blk = last_blk;
       ip[iw] = frag0(blk);
     }
@@ -1780,7 +1793,7 @@ __global__ __launch_bounds__(NTHREADS) void topk_coarse_frag_kernel(TopkArgs a) 
     }
 #pragma unroll
     for (int iw = 0; iw < IW; ++iw) {
-      const long long blk = a.blk_begin + blockIdx.x + (j * IW + iw) * S;
+      const long long blk = a.blk_begin + sx + (j * IW + iw) * S;
       if (blk <= last_blk)
         select_block<TU, false, true>(a, st, acc[iw], 0.f, no_norm, blk * IB, list_id, user0, lane, wave, g_lds);
 #pragma unroll
@@ -1801,7 +1814,12 @@ __global__ __launch_bounds__(NTHREADS) void topk_coarse_frag_kernel(TopkArgs a) 
 inline size_t coarse_frag_lds_bytes(int tu, int d_words) { return (size_t)tu * (d_words / 8) * 64 * 16 + (size_t)32 * tu * 4; }
 
 template <int TU>
-int launch_coarse_frag_t(const TopkArgs& a, dim3 grid, hipStream_t stream) {
+int launch_coarse_frag_t(const TopkArgs& a0, dim3 grid, hipStream_t stream) {
+  TopkArgs a = a0;
+  if (grid.y > 1 && env_int("RT_TOPK_XCD_MAP", 1) != 0) {     // 1-D grid, XCD-owned segments (see the kernel); RT_TOPK_XCD_MAP=0: the plain grid
+    a.xmap_gx = (int)grid.x; a.xmap_gy = (int)grid.y;
+    grid = dim3(8u * ((grid.x + 7u) / 8u) * grid.y, 1u, 1u);
+  }
   const size_t lds = coarse_frag_lds_bytes(TU, a.d);
   static size_t attr_lds = 0;
   if (lds > 64 * 1024 && lds > attr_lds) {
