@@ -23,7 +23,9 @@
 // reduction lane-local plus a single cross-half shuffle, and let the probability / dS accumulator registers be
 // fed straight back as the B operand of the second product (reduction index permuted consistently, as in K7/K12).
 #include "rt_common.h"
+#include "rt_varlen.h"
 #include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -2151,6 +2153,27 @@ int rt_hstu_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, c
 // zeroes the pad rows before every projection and the projection has no bias (hstu.py:256-262), so a pad key's v row is silu(0) = 0 and
 // contributes nothing: dropping the pad rows changes no real row.  Ring kernels only (hd 32 / 64, 16-byte aligned rows), else
 // RT_ERR_UNSUPPORTED.
+}  // extern "C"
+namespace {
+// The packed HSTU attention runs on the bf16-plane kernels (K6v2, rt_attention_v2.hip) where they apply (hd 32 / 64): 21.6 vs 18.8 k
+// seqs/s on the C4-shaped step.  RT_HSTU_ATTN=ring keeps the f32-input ring kernels of this file.  Read per call (A-B runs and the
+// parity tests flip it inside one process).
+bool hstu_v2_wanted() {
+  const char* e = getenv("RT_HSTU_ATTN");
+  return e == nullptr || strcmp(e, "ring") != 0;
+}
+rt_varlen::HstuV2Args hstu_v2_args(const AttnArgs& a) {
+  rt_varlen::HstuV2Args v{};
+  v.q = a.q; v.k = a.k; v.v = a.v; v.ldq = a.ldq; v.ldk = a.ldk; v.ldv = a.ldv; v.o = a.o; v.ldo = a.ldo;
+  v.cu = a.cu; v.ts = a.ts; v.time_w = a.time_w; v.time_thr = a.time_thr; v.pos_w = a.pos_w;
+  v.B = a.B; v.H = a.H; v.hd = a.hd; v.Lw = a.Lw;
+  v.dout = a.dout; v.lddo = a.lddo; v.dq = a.dq; v.dk = a.dk; v.dv = a.dv; v.lddq = a.lddq; v.lddk = a.lddk; v.lddv = a.lddv;
+  v.d_time_w = a.d_time_w; v.d_pos_w = a.d_pos_w;
+  return v;
+}
+}  // namespace
+extern "C" {
+
 int rt_hstu_attn_varlen_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                             const int64_t* cu_seqlens, const int64_t* ts, const float* time_w, const int64_t* time_thr,
                             const float* pos_w, int32_t B, int32_t H, int32_t window, int32_t hd, float* o, int64_t ldo,
@@ -2164,6 +2187,10 @@ int rt_hstu_attn_varlen_fwd(const float* q, int64_t ldq, const float* k, int64_t
   a.causal = 1; a.keypad = 0;
   a.ts = reinterpret_cast<const long long*>(ts); a.time_w = time_w;
   a.time_thr = reinterpret_cast<const long long*>(time_thr); a.pos_w = pos_w;
+  if (hstu_v2_wanted() && (hd == 32 || hd == 64)) {
+    const int rc = rt_v2_hstu_fwd(hstu_v2_args(a), stream);
+    if (rc != RT_ERR_UNSUPPORTED) return rc;
+  }
   return dispatch_fwd<MODE_HSTU>(a, stream);
 }
 int rt_hstu_attn_varlen_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
@@ -2182,6 +2209,10 @@ int rt_hstu_attn_varlen_bwd(const float* q, int64_t ldq, const float* k, int64_t
   a.ts = reinterpret_cast<const long long*>(ts); a.time_w = time_w;
   a.time_thr = reinterpret_cast<const long long*>(time_thr); a.pos_w = pos_w;
   a.d_time_w = d_time_w; a.d_pos_w = d_pos_w;
+  if (hstu_v2_wanted() && (hd == 32 || hd == 64)) {
+    const int rc = rt_v2_hstu_bwd(hstu_v2_args(a), stream);
+    if (rc != RT_ERR_UNSUPPORTED) return rc;
+  }
   return dispatch_bwd<MODE_HSTU>(a, stream);
 }
 

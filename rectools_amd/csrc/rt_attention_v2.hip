@@ -573,7 +573,349 @@ int launch_fwd(const VarlenArgs& a, int max_len, hipStream_t stream) {
   return RT_OK;
 }
 
+
+// =================================================================================================================================
+// K6v2 — HSTU's pointwise attention (hstu.py:270-288: silu(q k^T + rab) / L, causal, the relative time / position bias rab of
+// hstu.py:84-128 computed in-kernel) on the geometry above.  No softmax: a query's output is a plain SUM over its keys, so a session
+// longer than one LDS image is walked in CHUNKS of HCH partner rows — the owner rows' accumulators are carried through memory between
+// chunks (each lane re-reads what it wrote itself), nothing has to be renormalised.  The f32-input ring kernels (rt_attention.hip) spend
+// 64 quarter-rate matrix instructions per 32 x 32 tile pair and split nothing; here the K / V (Q / dO) rows are split once per chunk
+// and every product is six bf16 instructions.  First measured at the very end of round 4: the C4-shaped HSTU step 6.81 -> 5.93 ms
+// (18.8 -> 21.6 k seqs/s; forward 0.27 -> 0.18 ms per layer), parity against the padded ring kernels and the oracle on the first run
+// (tests/test_packed_hstu_gpu.py parametrised over both; RT_HSTU_ATTN=ring keeps the ring kernels).  Untuned: chunk size, the bias
+// arithmetic per element (~40 VALU) and the dK/dV pass's 220 registers are where the next factor is.
+// =================================================================================================================================
+constexpr int HCH = 192;         // partner rows per chunk (6 tiles of 32): two hd-64 images = 148 KB
+constexpr int NBUCK = 129;       // time buckets (num_buckets + 1), as rt_attention.hip
+
+// rt_attention.hip's bucket search, bit for bit (largest b with thr[b] <= |dt|: fast-log estimate, two neighbouring thresholds settle it)
+__device__ __forceinline__ int hstu_bucket(const long long* thr, long long dt) {
+  const long long x = dt < 0 ? -dt : dt;
+  int b = (int)(__logf(fmaxf((float)x, 1.f)) * (1.0f / 0.301f));
+  b = b < 0 ? 0 : (b > NBUCK - 1 ? NBUCK - 1 : b);
+  const long long t0 = thr[b], t1 = thr[b < NBUCK - 1 ? b + 1 : b];
+  if (t0 > x) b -= 1;
+  else if (b < NBUCK - 1 && t1 <= x) b += 1;
+  return b < 0 ? 0 : b;
+}
+__device__ __forceinline__ float hstu_silu(float z) { return z / (1.f + __expf(-z)); }
+__device__ __forceinline__ float hstu_silu_d(float z) { const float s = 1.f / (1.f + __expf(-z)); return s * (1.f + z * (1.f - s)); }
+
+// LDS behind the two images: the chunk's partner timestamps, the three tables, (backward) the two bias-gradient accumulators
+struct HstuLdsV2 {
+  unsigned char* img0; unsigned char* img1;
+  long long* ts_p;       // [HCH] timestamps of the chunk's partner rows (keys: ts[k]; dK/dV pass: queries' ts[q + 1])
+  long long* thr;        // [NBUCK]
+  float* tw;             // [NBUCK + 3]
+  float* pw;             // [2 Lw - 1 (+ pad)]
+  float* dtw; float* dpw;
+};
+template <int HD>
+__device__ __forceinline__ HstuLdsV2 hstu_carve(unsigned char* smem, int Lw) {
+  using L = Lay<HD>;
+  HstuLdsV2 l;
+  l.img0 = smem; l.img1 = smem + (size_t)(HCH + 1) * L::ROW3;
+  unsigned char* p = smem + 2 * (size_t)(HCH + 1) * L::ROW3;           // ROW3 is a multiple of 64: 8-byte aligned
+  l.ts_p = reinterpret_cast<long long*>(p); p += HCH * 8;
+  l.thr = reinterpret_cast<long long*>(p); p += NBUCK * 8;
+  l.tw = reinterpret_cast<float*>(p); p += (NBUCK + 3) * 4;
+  l.pw = reinterpret_cast<float*>(p); p += (size_t)(2 * Lw) * 4;
+  l.dtw = reinterpret_cast<float*>(p); p += (NBUCK + 3) * 4;
+  l.dpw = reinterpret_cast<float*>(p);
+  return l;
+}
+template <int HD> inline size_t hstu_lds_bytes(int Lw, bool grads) {
+  return 2 * (size_t)(HCH + 1) * Lay<HD>::ROW3 + HCH * 8 + NBUCK * 8 + (NBUCK + 3) * 4 + (size_t)(2 * Lw) * 4 +
+         (grads ? (NBUCK + 3) * 4 + (size_t)(2 * Lw) * 4 : 0);
+}
+__device__ __forceinline__ void hstu_load_tables(const HstuV2Args& a, const HstuLdsV2& l, int tid, int nthreads, bool grads) {
+  for (int j = tid; j < NBUCK; j += nthreads) {
+    l.thr[j] = a.time_thr != nullptr ? a.time_thr[j] : 0;
+    l.tw[j] = a.time_w != nullptr ? a.time_w[j] : 0.f;
+    if (grads) l.dtw[j] = 0.f;
+  }
+  for (int j = tid; j < 2 * a.Lw - 1; j += nthreads) {
+    l.pw[j] = a.pos_w != nullptr ? a.pos_w[j] : 0.f;
+    if (grads) l.dpw[j] = 0.f;
+  }
+}
+
+// Run-length accumulator of one lane's time-bias gradient (rt_attention.hip's TimeGradRun): along a lane's keys the bucket is monotone
+// (timestamps are), equal buckets come in runs: one LDS atomic per run instead of one per score element.
+struct BucketRun {
+  int cur; float acc;
+  __device__ __forceinline__ void init() { cur = -1; acc = 0.f; }
+  __device__ __forceinline__ void add(float* dtw, int b, float v) {
+    if (b != cur) { if (cur >= 0) atomicAdd(dtw + cur, acc); cur = b; acc = v; } else acc += v;
+  }
+  __device__ __forceinline__ void flush(float* dtw) { if (cur >= 0) atomicAdd(dtw + cur, acc); cur = -1; acc = 0.f; }
+};
+
+// ---- forward: a lane owns a query; chunks of keys ------------------------------------------------------------------------------------
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void v2_hstu_fwd_kernel(HstuV2Args a) {
+  using L = Lay<HD>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const long long row0 = a.cu[b];
+  const int n = (int)(a.cu[b + 1] - row0);
+  if (n <= 0) return;
+  const HstuLdsV2 l = hstu_carve<HD>(smem, a.Lw);
+  const long long* tsb = a.ts != nullptr ? a.ts + row0 + b : nullptr;
+  const bool tbias = tsb != nullptr && a.time_w != nullptr, pbias = a.pos_w != nullptr;
+  hstu_load_tables(a, l, tid, NW * 64, false);
+  const float inv_l = 1.0f / (float)a.Lw;
+  const int n_tiles = (n + 15) >> 4;
+
+  for (int c0 = 0; c0 < n; c0 += HCH) {
+    const int len = min(HCH, n - c0);
+    __syncthreads();                                  // the previous chunk's readers are done (first chunk: nothing to wait for)
+    stage_image<HD>(a.k + (row0 + c0) * a.ldk + h * HD, a.ldk, len, 1.f, l.img0, tid, NW * 64);
+    stage_image<HD>(a.v + (row0 + c0) * a.ldv + h * HD, a.ldv, len, 1.f, l.img1, tid, NW * 64);
+    if (tbias) for (int j = tid; j < len; j += NW * 64) l.ts_p[j] = tsb[c0 + j];
+    __syncthreads();
+
+    for_my_tiles<NW, true>(wave, n_tiles, [&](int qt) {
+      if (qt * 16 + 15 < c0) return;                  // every query of the tile lies before the chunk's keys
+      const int qrow = qt * 16 + i;
+      const bool qok = qrow < n;
+      const int qsafe = qok ? qrow : n - 1;
+      const long long grow = row0 + qsafe;
+      P3 Qp[L::NS];
+      load_owner_planes<HD>(a.q + grow * a.ldq + h * HD, g, 1.f, Qp);
+      const long long t_q1 = tbias ? tsb[qsafe + 1] : 0;
+      f32x4 oT[L::NCB];
+      float* op = a.o + grow * a.ldo + h * HD;
+#pragma unroll
+      for (int cb = 0; cb < L::NCB; ++cb)
+        oT[cb] = (c0 > 0 && qok) ? *reinterpret_cast<const f32x4*>(op + 16 * cb + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const int t_last = min((qt * 16 + 15 - c0) >> 5, (len - 1) >> 5);        // last 32-key tile of the chunk this query tile sees
+      for (int t = 0; t <= t_last; ++t) {
+        f32x4 sT[2];
+        rows_times_owner<HD>(l.img0, t * 32, len, Qp, i, g, sT);
+        float pr[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int kl = t * 32 + 16 * (e >> 2) + 4 * g + (e & 3), key = c0 + kl;
+          const bool valid = qok && kl < len && key <= qrow;
+          float bias = 0.f;
+          if (tbias) bias += l.tw[hstu_bucket(l.thr, t_q1 - l.ts_p[min(kl, len - 1)])];
+          if (pbias) bias += l.pw[max(a.Lw - 1 + key - qrow, 0)];
+          pr[e] = valid ? hstu_silu(sT[e >> 2][e & 3] + bias) * inv_l : 0.f;
+        }
+        const P3 Pp = split8(pr);
+        cols_times_slots<HD>(l.img1, t * 32, len, Pp, i, g, oT);
+      }
+      if (qok) {
+#pragma unroll
+        for (int cb = 0; cb < L::NCB; ++cb) *reinterpret_cast<f32x4*>(op + 16 * cb + 4 * g) = oT[cb];
+      }
+    });
+  }
+}
+
+// ---- backward, pass 1: dQ and the bias gradients.  A lane owns a query; chunks of keys ------------------------------------------------
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void v2_hstu_bwd_dq_kernel(HstuV2Args a) {
+  using L = Lay<HD>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const long long row0 = a.cu[b];
+  const int n = (int)(a.cu[b + 1] - row0);
+  if (n <= 0) return;
+  const HstuLdsV2 l = hstu_carve<HD>(smem, a.Lw);
+  const long long* tsb = a.ts != nullptr ? a.ts + row0 + b : nullptr;
+  const bool tbias = tsb != nullptr && a.time_w != nullptr, pbias = a.pos_w != nullptr;
+  const bool tgrad = tbias && a.d_time_w != nullptr, pgrad = pbias && a.d_pos_w != nullptr;
+  hstu_load_tables(a, l, tid, NW * 64, true);
+  const float inv_l = 1.0f / (float)a.Lw;
+  const int n_tiles = (n + 15) >> 4;
+
+  for (int c0 = 0; c0 < n; c0 += HCH) {
+    const int len = min(HCH, n - c0);
+    __syncthreads();
+    stage_image<HD>(a.k + (row0 + c0) * a.ldk + h * HD, a.ldk, len, 1.f, l.img0, tid, NW * 64);
+    stage_image<HD>(a.v + (row0 + c0) * a.ldv + h * HD, a.ldv, len, 1.f, l.img1, tid, NW * 64);
+    if (tbias) for (int j = tid; j < len; j += NW * 64) l.ts_p[j] = tsb[c0 + j];
+    __syncthreads();
+
+    for_my_tiles<NW, true>(wave, n_tiles, [&](int qt) {
+      if (qt * 16 + 15 < c0) return;
+      const int qrow = qt * 16 + i;
+      const bool qok = qrow < n;
+      const int qsafe = qok ? qrow : n - 1;
+      const long long grow = row0 + qsafe;
+      P3 Qp[L::NS], Dp[L::NS];
+      load_owner_planes<HD>(a.q + grow * a.ldq + h * HD, g, 1.f, Qp);
+      load_owner_planes<HD>(a.dout + grow * a.lddo + h * HD, g, qok ? 1.f : 0.f, Dp);
+      const long long t_q1 = tbias ? tsb[qsafe + 1] : 0;
+      f32x4 dqT[L::NCB];
+      float* dqp = a.dq + grow * a.lddq + h * HD;
+#pragma unroll
+      for (int cb = 0; cb < L::NCB; ++cb)
+        dqT[cb] = (c0 > 0 && qok) ? *reinterpret_cast<const f32x4*>(dqp + 16 * cb + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+      BucketRun run;
+      run.init();
+      const int t_last = min((qt * 16 + 15 - c0) >> 5, (len - 1) >> 5);
+      for (int t = 0; t <= t_last; ++t) {
+        f32x4 sT[2], dpT[2];
+        rows_times_owner<HD>(l.img0, t * 32, len, Qp, i, g, sT);
+        rows_times_owner<HD>(l.img1, t * 32, len, Dp, i, g, dpT);
+        float ds[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int kl = t * 32 + 16 * (e >> 2) + 4 * g + (e & 3), key = c0 + kl;
+          const bool valid = qok && kl < len && key <= qrow;
+          float bias = 0.f;
+          int bk = 0;
+          const int pidx = max(a.Lw - 1 + key - qrow, 0);
+          if (tbias) { bk = hstu_bucket(l.thr, t_q1 - l.ts_p[min(kl, len - 1)]); bias += l.tw[bk]; }
+          if (pbias) bias += l.pw[pidx];
+          const float z = sT[e >> 2][e & 3] + bias;
+          ds[e] = valid ? dpT[e >> 2][e & 3] * inv_l * hstu_silu_d(z) : 0.f;
+          if (valid) {
+            if (tgrad) run.add(l.dtw, bk, ds[e]);
+            if (pgrad) atomicAdd(l.dpw + pidx, ds[e]);          // the 16 queries of a lane group hit 16 different slots
+          }
+        }
+        const P3 Sp = split8(ds);
+        cols_times_slots<HD>(l.img0, t * 32, len, Sp, i, g, dqT);       // dQ^T[c][q] += sum_j K[j][c] dS^T[j][q]
+      }
+      if (tgrad) run.flush(l.dtw);
+      if (qok) {
+#pragma unroll
+        for (int cb = 0; cb < L::NCB; ++cb) *reinterpret_cast<f32x4*>(dqp + 16 * cb + 4 * g) = dqT[cb];
+      }
+    });
+  }
+  __syncthreads();
+  if (tgrad) for (int j = tid; j < NBUCK; j += NW * 64) { const float v = l.dtw[j]; if (v != 0.f) atomicAdd(a.d_time_w + j, v); }
+  if (pgrad) for (int j = tid; j < 2 * a.Lw - 1; j += NW * 64) { const float v = l.dpw[j]; if (v != 0.f) atomicAdd(a.d_pos_w + j, v); }
+}
+
+// ---- backward, pass 2: dK, dV.  A lane owns a key; chunks of QUERIES (images of Q and dO) ---------------------------------------------
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void v2_hstu_bwd_dkv_kernel(HstuV2Args a) {
+  using L = Lay<HD>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const long long row0 = a.cu[b];
+  const int n = (int)(a.cu[b + 1] - row0);
+  if (n <= 0) return;
+  const HstuLdsV2 l = hstu_carve<HD>(smem, a.Lw);
+  const long long* tsb = a.ts != nullptr ? a.ts + row0 + b : nullptr;
+  const bool tbias = tsb != nullptr && a.time_w != nullptr, pbias = a.pos_w != nullptr;
+  hstu_load_tables(a, l, tid, NW * 64, false);
+  const float inv_l = 1.0f / (float)a.Lw;
+  const int n_tiles = (n + 15) >> 4;
+
+  for (int c0 = 0; c0 < n; c0 += HCH) {                 // queries [c0, c0 + len)
+    const int len = min(HCH, n - c0);
+    __syncthreads();
+    stage_image<HD>(a.q + (row0 + c0) * a.ldq + h * HD, a.ldq, len, 1.f, l.img0, tid, NW * 64);
+    stage_image<HD>(a.dout + (row0 + c0) * a.lddo + h * HD, a.lddo, len, 1.f, l.img1, tid, NW * 64);
+    if (tbias) for (int j = tid; j < len; j += NW * 64) l.ts_p[j] = tsb[c0 + j + 1];     // a query's time is its NEXT stamp (hstu.py:96-104)
+    __syncthreads();
+
+    for_my_tiles<NW, false>(wave, n_tiles, [&](int kt) {
+      if (kt * 16 > c0 + len - 1) return;               // every key of the tile lies behind the chunk's queries
+      const int krow = kt * 16 + i;
+      const bool kok = krow < n;
+      const int ksafe = kok ? krow : n - 1;
+      const long long grow = row0 + ksafe;
+      P3 Kp[L::NS], Vp[L::NS];
+      load_owner_planes<HD>(a.k + grow * a.ldk + h * HD, g, 1.f, Kp);
+      load_owner_planes<HD>(a.v + grow * a.ldv + h * HD, g, 1.f, Vp);
+      const long long t_k = tbias ? tsb[ksafe] : 0;
+      // the first chunk that holds a query >= this tile's first key starts the accumulation; later chunks continue it
+      const bool first = c0 <= kt * 16;
+      f32x4 dkT[L::NCB], dvT[L::NCB];
+      float* dkp = a.dk + grow * a.lddk + h * HD;
+      float* dvp = a.dv + grow * a.lddv + h * HD;
+#pragma unroll
+      for (int cb = 0; cb < L::NCB; ++cb) {
+        dkT[cb] = (!first && kok) ? *reinterpret_cast<const f32x4*>(dkp + 16 * cb + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+        dvT[cb] = (!first && kok) ? *reinterpret_cast<const f32x4*>(dvp + 16 * cb + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      const int t_first = max(kt * 16 - c0, 0) >> 5;    // first 32-query tile of the chunk that holds a query >= the tile's first key
+      const int t_end = (len - 1) >> 5;
+      for (int t = t_first; t <= t_end; ++t) {
+        f32x4 sm[2], dpm[2];                            // S[q][key], dP[q][key]: register (qb, r) = query c0 + 32 t + 16 qb + 4 g + r
+        rows_times_owner<HD>(l.img0, t * 32, len, Kp, i, g, sm);
+        rows_times_owner<HD>(l.img1, t * 32, len, Vp, i, g, dpm);
+        float pd[8], ds[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int ql = t * 32 + 16 * (e >> 2) + 4 * g + (e & 3), q = c0 + ql;
+          const bool valid = kok && ql < len && krow <= q;
+          float bias = 0.f;
+          if (tbias) bias += l.tw[hstu_bucket(l.thr, l.ts_p[min(ql, len - 1)] - t_k)];
+          if (pbias) bias += l.pw[max(a.Lw - 1 + krow - q, 0)];
+          const float z = sm[e >> 2][e & 3] + bias;
+          pd[e] = valid ? hstu_silu(z) * inv_l : 0.f;
+          ds[e] = valid ? dpm[e >> 2][e & 3] * inv_l * hstu_silu_d(z) : 0.f;
+        }
+        const P3 Pp = split8(pd);
+        cols_times_slots<HD>(l.img1, t * 32, len, Pp, i, g, dvT);       // dV^T[c][key] += sum_q dO[q][c] P[q][key]
+        const P3 Sp = split8(ds);
+        cols_times_slots<HD>(l.img0, t * 32, len, Sp, i, g, dkT);       // dK^T[c][key] += sum_q Q[q][c] dS[q][key]
+      }
+      if (kok) {
+#pragma unroll
+        for (int cb = 0; cb < L::NCB; ++cb) {
+          *reinterpret_cast<f32x4*>(dkp + 16 * cb + 4 * g) = dkT[cb];
+          *reinterpret_cast<f32x4*>(dvp + 16 * cb + 4 * g) = dvT[cb];
+        }
+      }
+    });
+  }
+}
+
+template <int HD>
+int launch_hstu_fwd(const HstuV2Args& a, hipStream_t stream) {
+  constexpr int NW = 8;
+  const size_t lds = hstu_lds_bytes<HD>(a.Lw, false);
+  if (lds > 160 * 1024) return RT_ERR_UNSUPPORTED;
+  auto kern = &v2_hstu_fwd_kernel<HD, NW>;
+  RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  kern<<<a.B * a.H, NW * 64, lds, stream>>>(a);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+template <int HD>
+int launch_hstu_bwd(const HstuV2Args& a, hipStream_t stream) {
+  constexpr int NW = 8;
+  const size_t lds_q = hstu_lds_bytes<HD>(a.Lw, true), lds_kv = hstu_lds_bytes<HD>(a.Lw, false);
+  if (lds_q > 160 * 1024) return RT_ERR_UNSUPPORTED;
+  auto kq = &v2_hstu_bwd_dq_kernel<HD, NW>;
+  auto kkv = &v2_hstu_bwd_dkv_kernel<HD, NW>;
+  RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kq), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q));
+  RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kkv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv));
+  kq<<<a.B * a.H, NW * 64, lds_q, stream>>>(a);
+  RT_CHECK_LAUNCH();
+  kkv<<<a.B * a.H, NW * 64, lds_kv, stream>>>(a);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
 }  // namespace
+
+int rt_v2_hstu_fwd(const rt_varlen::HstuV2Args& a, hipStream_t stream) {
+  if (a.hd == 64) return launch_hstu_fwd<64>(a, stream);
+  if (a.hd == 32) return launch_hstu_fwd<32>(a, stream);
+  return RT_ERR_UNSUPPORTED;
+}
+int rt_v2_hstu_bwd(const rt_varlen::HstuV2Args& a, hipStream_t stream) {
+  if (a.hd == 64) return launch_hstu_bwd<64>(a, stream);
+  if (a.hd == 32) return launch_hstu_bwd<32>(a, stream);
+  return RT_ERR_UNSUPPORTED;
+}
 
 int rt_v2_varlen_fwd(const rt_varlen::VarlenArgs& a, int max_len, bool train, hipStream_t stream) {
   if (a.hd == 64) return train ? launch_fwd<64, 8, true>(a, max_len, stream) : launch_fwd<64, 8, false>(a, max_len, stream);

@@ -41,7 +41,24 @@ __device__ __forceinline__ int pads_kept(unsigned long long seed, unsigned bh, u
 }
 
 
+// K6v2 (rt_attention_v2.hip): HSTU's pointwise attention silu(q k^T + rab) / L over packed sessions on the bf16-plane geometry of K4v2.
+struct HstuV2Args {
+  const float* q; const float* k; const float* v; long long ldq, ldk, ldv;
+  float* o; long long ldo;
+  const long long* cu;                 // [B+1] first packed row of every session
+  const long long* ts;                 // session b's n_b + 1 timestamps start at ts[cu[b] + b] (null: no time bias)
+  const float* time_w; const long long* time_thr; const float* pos_w;   // [129], [129], [2 Lw - 1] (pos_w null: no position bias)
+  int B, H, hd, Lw;                    // Lw = the window (session_max_len): 1 / Lw and the position table's centre
+  const float* dout; long long lddo;
+  float* dq; float* dk; float* dv; long long lddq, lddk, lddv;
+  float* d_time_w; float* d_pos_w;     // accumulators (atomics; the caller zero-fills)
+};
+
 }  // namespace rt_varlen
+
+// K6v2: RT_ERR_UNSUPPORTED for head sizes other than 32 / 64 or a window whose tables do not fit the LDS beside two 192-row images.
+int rt_v2_hstu_fwd(const rt_varlen::HstuV2Args& a, hipStream_t stream);
+int rt_v2_hstu_bwd(const rt_varlen::HstuV2Args& a, hipStream_t stream);
 
 // rt_attention_v2.hip: the bf16-plane kernels behind the same entry points (hd 32 / 64, one (session, head) image within 160 KB of LDS).
 // Each returns RT_ERR_UNSUPPORTED when the shape does not fit (the caller then takes the first-form kernels).
