@@ -493,9 +493,10 @@ def run_train(args, rank, world, kind="train"):
             fl = 4.0 * n2 * d * B * (2.5 if dom.endswith("bwd") else 1.0)       # dense; causal-useful half is executed
             ms = per_kernel[dom][0] / per_kernel[dom][1]
             tf = fl / (ms * 1e-3) / 1e12
-            # the bf16-plane kernels (rt_attention_v2.hip: head sizes 32 / 64 of the softmax families) run six bf16 products per fp32
+            # the bf16-plane kernels (rt_attention_v2.hip: head sizes 32 / 64 of the softmax families and of packed HSTU) run six bf16 products per fp32
             # product; everything else is on the f32-input instruction
-            x6 = dom.startswith("rt_mha_varlen") and d // H in (32, 64) and os.environ.get("RT_VARLEN_IMPL", "") != "v1"
+            x6 = (dom.startswith("rt_mha_varlen") and d // H in (32, 64) and os.environ.get("RT_VARLEN_IMPL", "") != "v1") or \
+                 (dom.startswith("rt_hstu_attn_varlen") and d // H in (32, 64) and os.environ.get("RT_HSTU_ATTN", "") != "ring")   # K6v2
             peak = MFMA_BF16_PEAK_TF / 6.0 if x6 else MFMA_F32_PEAK_TF
             roof = {"kernel": dom + f" ({what}; bwd x2.5)", "bound": "mfma", "achieved": round(tf, 2),
                     "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(tf / peak, 4), "traffic": None,

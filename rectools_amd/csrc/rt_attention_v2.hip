@@ -600,6 +600,13 @@ __device__ __forceinline__ int hstu_bucket(const long long* thr, long long dt) {
 }
 __device__ __forceinline__ float hstu_silu(float z) { return z / (1.f + __expf(-z)); }
 __device__ __forceinline__ float hstu_silu_d(float z) { const float s = 1.f / (1.f + __expf(-z)); return s * (1.f + z * (1.f - s)); }
+// both from ONE sigmoid (the dK/dV pass needs the probability and the derivative of the same element); p is hstu_silu's value up to the
+// rounding of z * s against z / (1 + e)
+__device__ __forceinline__ void hstu_silu_both(float z, float& p, float& d) {
+  const float s = 1.f / (1.f + __expf(-z));
+  p = z * s;
+  d = s * (1.f + z * (1.f - s));
+}
 
 // LDS behind the two images: the chunk's partner timestamps, the three tables, (backward) the two bias-gradient accumulators
 struct HstuLdsV2 {
@@ -858,8 +865,10 @@ __global__ __launch_bounds__(NW * 64) void v2_hstu_bwd_dkv_kernel(HstuV2Args a) 
           if (tbias) bias += l.tw[hstu_bucket(l.thr, l.ts_p[min(ql, len - 1)] - t_k)];
           if (pbias) bias += l.pw[max(a.Lw - 1 + krow - q, 0)];
           const float z = sm[e >> 2][e & 3] + bias;
-          pd[e] = valid ? hstu_silu(z) * inv_l : 0.f;
-          ds[e] = valid ? dpm[e >> 2][e & 3] * inv_l * hstu_silu_d(z) : 0.f;
+          float pz, dz;
+          hstu_silu_both(z, pz, dz);
+          pd[e] = valid ? pz * inv_l : 0.f;
+          ds[e] = valid ? dpm[e >> 2][e & 3] * inv_l * dz : 0.f;
         }
         const P3 Pp = split8(pd);
         cols_times_slots<HD>(l.img1, t * 32, len, Pp, i, g, dvT);       // dV^T[c][key] += sum_q dO[q][c] P[q][key]
