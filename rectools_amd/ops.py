@@ -2142,17 +2142,15 @@ class _SampledLoss(torch.autograd.Function):
         norm_eff = out[1:] / gloss.reshape(1).to(torch.float32)
         args = (sess, sess.stride(0), table, y, neg, M, N, d, V, int(cosine), float(logits_t), logits, norm_eff, 1.0, du, d)
         prep = 1 if getattr(ctx, "prepared", False) else 0
-        # One call on the main stream.  The table half (counting sort + gathered row reductions, memory-bound) was tried on the
-        # side stream under the MFMA-bound layer backward (rt_sampled_loss_bwd accepts either output as NULL for that):
-        # measured 3.12 vs 3.06 ms/step at C2 — the co-running gather slows the GEMMs by more than it hides.
+        # rt_sampled_loss_bwd accepts either output as NULL: the session half feeds the layer backward (main stream), the table half —
+        # read by the optimiser only — goes to the side stream when autograd will merely adopt its result AND an embedding lookup of
+        # this forward pass will pick it up as its sink (see `_TABLE_SINK_EXPECTED`); otherwise one call on the main stream.
         side = _native_side_fork() if (_LOSS_TABLE_ON_SIDE and ctx.needs_input_grad[1] and _steals_grad(table)
                                        and _table_sink_expected(table)) else None
         if side is None:
             _c("rt_sampled_loss_bwd", *args, d_sess, d, d_table, ws, ws.numel(), prep)
         else:
-            # the session half is the critical path (it feeds the whole layer backward); the table half — counting sort + gathered row
-            # reductions, read only by the optimiser — runs beside it on the library's side stream.  (Round 2 measured this slower when
-            # the main stream was GEMM-bound end to end; with packed rows and the bf16 attention the main stream is the long pole.)
+            # (round 2 measured this slower, round 3 equal; with the chain kernels of round 4 it is +4 % on the C2 step: `_LOSS_TABLE_ON_SIDE`)
             _c("rt_sampled_loss_bwd", *args, d_sess, d, None, ws, ws.numel(), prep)
             _c("rt_sampled_loss_bwd", *args, None, d, d_table, ws, ws.numel(), prep, stream=side)
             _lib.check(_lib.load().rt_side_mark(), "rt_side_mark")      # the embedding backward waits for THIS point, not for the weight gradients behind it
