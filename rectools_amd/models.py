@@ -939,20 +939,23 @@ class TransformerModelBase:
         """Ranker output ([n, k] ids / scores, valid entries leading every row, `counts` of them) -> the reference's long frame
         (models/base.py:735-791).  When every row is full — the usual case — the mask, the masked gathers and the running count
         are skipped (half of the 5 ms this takes for 16,384 x 10)."""
+        # The columns are handed to pandas in ONE call and adopted as they are (copy=False; every array is freshly made here): building
+        # the frame column by column copied each of them once more and consolidated the blocks when the rank column arrived (1.0 of the
+        # 2.0 ms this took for 16,384 x 10 on the build host; 0.06 ms now)
         n, kk = ids.shape
         if n and bool((counts >= kk).all()) and bool((scores > -np.inf).all()):
-            df = pd.DataFrame({target_col: np.repeat(ext_users, kk), Columns.Item: item_id_map.convert_to_external(ids.reshape(-1)),
-                               Columns.Score: scores.reshape(-1).astype(np.float32, copy=False)})
+            cols = {target_col: np.repeat(ext_users, kk), Columns.Item: item_id_map.convert_to_external(ids.reshape(-1)),
+                    Columns.Score: scores.reshape(-1).astype(np.float32)}      # (a copy: the frame must not alias the caller's array)
             if add_rank_col:
-                df[Columns.Rank] = np.tile(np.arange(1, kk + 1, dtype=np.int64), n)
-            return df
+                cols[Columns.Rank] = np.tile(np.arange(1, kk + 1, dtype=np.int64), n)
+            return pd.DataFrame(cols, copy=False)
         valid = (np.arange(kk)[None, :] < counts[:, None]) & (scores > -np.inf)
         tt = np.repeat(ext_users, kk).reshape(len(ext_users), kk)[valid]
         ii = item_id_map.convert_to_external(ids[valid])
-        df = pd.DataFrame({target_col: tt, Columns.Item: ii, Columns.Score: scores[valid].astype(np.float32)})
+        cols = {target_col: tt, Columns.Item: ii, Columns.Score: scores[valid].astype(np.float32)}
         if add_rank_col:  # valid entries lead every row: rank = running count inside the row (models/base.py:788-789)
-            df[Columns.Rank] = (np.cumsum(valid, axis=1)[valid]).astype(np.int64)
-        return df
+            cols[Columns.Rank] = (np.cumsum(valid, axis=1)[valid]).astype(np.int64)
+        return pd.DataFrame(cols, copy=False)
 
     @staticmethod
     def _frame(targets: np.ndarray, items: np.ndarray, scores: np.ndarray, add_rank_col: bool, target_col: str) -> pd.DataFrame:
