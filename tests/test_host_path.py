@@ -678,3 +678,26 @@ def test_assemble_frame_fast_path_equals_the_masked_path(add_rank):
     assert len(short) == n * k - (k - 2) and (short[Columns.User] == "u3").sum() == 2
     empty = M._assemble_frame(users[:0], ids[:0], scores[:0], counts[:0], item_map, add_rank, Columns.User)
     assert len(empty) == 0
+
+
+def test_table_sink_expectation_needs_a_live_lookup_of_the_same_table():
+    """`ops._table_sink_expected` gates the side-stream path of the loss's table gradient (round 4: without an embedding node that picks
+    the gradient up, autograd cloned it while the side stream was still writing it): true only for a table whose lookup registered in
+    this forward pass and is still alive; one-shot; a dead or different tensor behind the same key does not count."""
+    from rectools_amd import ops
+
+    t = torch.zeros(6, 4)
+    assert not ops._table_sink_expected(t)                      # nothing registered
+    ops._expect_table_sink(t)
+    assert ops._table_sink_expected(t)
+    assert not ops._table_sink_expected(t)                      # consumed
+    ops._expect_table_sink(t)
+    view = t[:3]                                                # same storage start, another shape: not the table the lookup saw
+    assert not ops._table_sink_expected(view)
+    u = torch.zeros(6, 4)
+    ops._expect_table_sink(u)
+    dead = ops._TABLE_SINK_EXPECTED.pop(u.data_ptr())
+    del u                                                       # the registered tensor died ...
+    w = torch.zeros(6, 4)
+    ops._TABLE_SINK_EXPECTED[w.data_ptr()] = dead               # ... and another table now lives at a key that still holds its entry
+    assert dead() is None and not ops._table_sink_expected(w)   # (allocator reuse of an address: the case the weak reference guards)
