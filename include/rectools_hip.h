@@ -327,6 +327,17 @@ int rt_layernorm_bwd_fused(const float* dy, const float* x, const float* w, cons
                            const float* res, const int64_t* ids, int32_t mask_dy, int32_t mask_dx, int32_t M, int32_t d,
                            float* dx, float* dw, float* db, void* workspace, size_t workspace_bytes, rt_stream_t stream);
 
+/* The same LayerNorm over rows that carry ZERO COLUMNS: column c of a row exists iff (c % grp) < grp_real (grp % 4 == 0, d % grp == 0).
+ * A model width or head size the kernels cannot tile (n_factors = 50; heads of 25 — the reference accepts any n_factors % n_heads == 0,
+ * hstu.py:606-607) runs on rows padded with zero columns, head by head (rectools_amd.nn.DimPlan): statistics, outputs and gradients are
+ * those of nn.LayerNorm over the d / grp * grp_real real columns; the other columns of y / dx / dw / db are written as zeros.
+ * ids / x0 (both nullable) as rt_layernorm_fwd_masked; res / ids / mask_dy / mask_dx as rt_layernorm_bwd_fused (same workspace). */
+int rt_layernorm_fwd_cols(const float* x, const int64_t* ids, const float* w, const float* b, float eps, int32_t M, int32_t d, int32_t grp,
+                          int32_t grp_real, float* x0, float* y, float* mean, float* rstd, rt_stream_t stream);
+int rt_layernorm_bwd_cols(const float* dy, const float* x, const float* w, const float* mean, const float* rstd, const float* res,
+                          const int64_t* ids, int32_t mask_dy, int32_t mask_dx, int32_t M, int32_t d, int32_t grp, int32_t grp_real,
+                          float* dx, float* dw, float* db, void* workspace, size_t workspace_bytes, rt_stream_t stream);
+
 /* element-wise streams (n = number of floats, multiple of 4).  kind: 0 none, 1 relu, 2 gelu(erf), 3 silu, 4 sigmoid.
  * y = dropout(act(z)) [+ residual] and its backward (net_blocks.py:63-64; hstu.py:257; dropouts at sasrec.py:228,
  * net_blocks.py:258-260); `residual` (nullable) fuses the skip connection that follows the dropout */
@@ -385,6 +396,20 @@ int rt_mha_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const f
 int rt_mha_last_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const int64_t* ids,
                     int32_t B, int32_t H, int32_t L, int32_t hd, int32_t causal, int32_t keypad, float* o, int64_t ldo,
                     rt_stream_t stream);
+
+/* The three entry points above with the logit scale given by the caller (scale <= 0: 1 / sqrt(hd), torch.nn.MultiheadAttention's): a head
+ * padded with zero columns up to a size the kernels tile (hd % 8 == 0) keeps the scale of its REAL size. */
+int rt_mha_fwd_scaled(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                      const int64_t* ids, int32_t B, int32_t H, int32_t L, int32_t hd, float scale, int32_t causal, int32_t keypad,
+                      float p_drop, uint64_t seed, float* o, int64_t ldo, float* lse, rt_stream_t stream);
+int rt_mha_bwd_scaled(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                      const float* o, int64_t ldo, const float* dout, int64_t lddo, const float* lse, const int64_t* ids,
+                      int32_t B, int32_t H, int32_t L, int32_t hd, float scale, int32_t causal, int32_t keypad, float p_drop, uint64_t seed,
+                      float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv, float* delta,
+                      rt_stream_t stream);
+int rt_mha_last_fwd_scaled(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const int64_t* ids,
+                           int32_t B, int32_t H, int32_t L, int32_t hd, float scale, int32_t causal, int32_t keypad, float* o, int64_t ldo,
+                           rt_stream_t stream);
 
 /* K4v  The same causal softmax attention over PACKED sessions (no padding rows; forward only — the recommend() encoder).  Session b
  * owns rows cu_seqlens[b] .. cu_seqlens[b+1]-1 of q / k / v / o, oldest item first.  What the reference's left-padded window adds
@@ -497,9 +522,10 @@ int rt_timing_enable(int32_t mode);
 int rt_timing_collect(int32_t* ids, float* ms, int64_t* tags, int32_t max_records, int32_t* n_out);
 
 /* K5/K6  HSTU pointwise attention with in-kernel relative time/position bias (hstu.py:84-128, 270-288).
- * ts [B,L+1] int64 (NULL: no time bias); time_w [129]; time_thr [129] = smallest |dt| of each bucket, computed on
+ * ts [B,L+1] int64 (NULL: no time bias); time_w [n], n = num_buckets + 1; time_thr [148] = smallest |dt| of each of the 147 buckets an
+ * int64 difference can fall in (unclamped), then n: a later bucket reads time_w[n - 1] — the reference's clamp — computed on
  * the host with the reference's float32 log(|dt|)/0.301 truncation; pos_w [2L-1] (NULL: no position bias).
- * Backward accumulates d_time_w [129] / d_pos_w [2L-1] (caller zero-fills). */
+ * Backward accumulates d_time_w [n] / d_pos_w [2L-1] (caller zero-fills). */
 int rt_hstu_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                      const int64_t* ids, const int64_t* ts, const float* time_w, const int64_t* time_thr,
                      const float* pos_w, int32_t B, int32_t H, int32_t L, int32_t hd, float* o, int64_t ldo,

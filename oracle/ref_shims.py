@@ -136,6 +136,11 @@ def _install_lightning() -> None:
         def fit(self, model: LightningModule, train_dataloaders: tp.Any = None, val_dataloaders: tp.Any = None,
                 ckpt_path: tp.Any = None) -> None:
             self.lightning_module = model
+            # accelerator="gpu" (explicitly: the default stays on the host, where the golden fixtures are generated): the module and
+            # every batch move to the device, as Lightning's accelerator connector / transfer_batch_to_device do
+            on_gpu = str(self.kwargs.get("accelerator", "cpu")) in ("gpu", "cuda") and torch.cuda.is_available()
+            if on_gpu:
+                model.to("cuda")
             model.train()
             opt = model.configure_optimizers()
             n_epochs = self.fit_loop.max_epochs if self.fit_loop.max_epochs is not None else 1
@@ -146,6 +151,8 @@ def _install_lightning() -> None:
                 if epoch > start:
                     it = iter(train_dataloaders)
                 for i, batch in enumerate(it):
+                    if on_gpu:
+                        batch = {k: v.to("cuda") for k, v in batch.items()}
                     opt.zero_grad()
                     loss = model.training_step(batch, i)
                     loss.backward()

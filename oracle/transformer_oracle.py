@@ -187,8 +187,8 @@ def time_buckets(unix_ts: torch.Tensor, num_buckets: int = 128) -> torch.Tensor:
 def rel_attn_bias(p: Params, prefix: str, batch: Batch, L: int) -> torch.Tensor:
     B = batch["x"].shape[0]
     rab = torch.zeros(B, L, L)
-    if (prefix + "time_weights") in p:
-        rab = rab + p[prefix + "time_weights"][time_buckets(batch["unix_ts"])]
+    if (prefix + "time_weights") in p:     # num_buckets = the length of the weight vector - 1 (hstu.py:75-78)
+        rab = rab + p[prefix + "time_weights"][time_buckets(batch["unix_ts"], p[prefix + "time_weights"].numel() - 1)]
     if (prefix + "pos_weights") in p:
         i = torch.arange(L)[:, None]
         j = torch.arange(L)[None, :]
@@ -196,24 +196,28 @@ def rel_attn_bias(p: Params, prefix: str, batch: Batch, L: int) -> torch.Tensor:
     return rab
 
 
-def stu_layers(seqs, tl_mask, batch: Batch, p: Params, n_blocks: int, n_heads: int) -> torch.Tensor:
+def stu_layers(seqs, tl_mask, batch: Batch, p: Params, n_blocks: int, n_heads: int, lin: tp.Optional[int] = None,
+               att: tp.Optional[int] = None) -> torch.Tensor:
+    """hstu.py:225-295,364-399.  lin / att: linear_hidden_dim (u, v) and attention_dim (q, k) per head; HSTUModel sets both to
+    n_factors // n_heads (hstu.py:662-669)."""
     B, L, d = seqs.shape
-    hd = d // n_heads
+    lin = d // n_heads if lin is None else lin
+    att = d // n_heads if att is None else att
     causal = torch.tril(torch.ones(L, L))  # (~attn_mask).int() of the ~tril mask (hstu.py:394)
     for i in range(n_blocks):
         pre = f"transformer_layers.stu_blocks.{i}."
         seqs = seqs * tl_mask
         normed = layer_norm(seqs, p[pre + "norm_input.weight"], p[pre + "norm_input.bias"], 1e-6) * tl_mask
         uvqk = F.silu(normed @ p[pre + "uvqk_proj"])
-        u, v, q, k = torch.split(uvqk, [hd * n_heads] * 4, dim=-1)
-        qh = q.view(B, L, n_heads, hd)
-        kh = k.view(B, L, n_heads, hd)
-        vh = v.reshape(B, L, n_heads, hd)
+        u, v, q, k = torch.split(uvqk, [lin * n_heads, lin * n_heads, att * n_heads, att * n_heads], dim=-1)   # hstu.py:259-268
+        qh = q.view(B, L, n_heads, att)
+        kh = k.view(B, L, n_heads, att)
+        vh = v.reshape(B, L, n_heads, lin)
         qk = torch.einsum("bnhd,bmhd->bhnm", qh, kh) + rel_attn_bias(p, pre + "rel_attn.", batch, L)[:, None]
         qk = F.silu(qk) / L
         pad2 = tl_mask.squeeze(-1)[:, None, :] * tl_mask  # [B, L, L]: m_i * m_j
         qk = qk * causal[None, None] * pad2[:, None]
-        attn = torch.einsum("bhnm,bmhd->bnhd", qk, vh).reshape(B, L, n_heads * hd)
+        attn = torch.einsum("bhnm,bmhd->bnhd", qk, vh).reshape(B, L, n_heads * lin)
         o_in = u * layer_norm(attn, p[pre + "norm_attn_output.weight"], p[pre + "norm_attn_output.bias"], 1e-6) * tl_mask
         seqs = o_in @ p[pre + "output_mlp.weight"].T + p[pre + "output_mlp.bias"] + seqs
     return seqs * tl_mask
@@ -229,7 +233,7 @@ def encode_sessions(cfg: dict, p: Params, batch: Batch, table: tp.Optional[torch
     seqs = embed_sessions(p, x, cfg.get("use_scale", False), table)
     kind = cfg["layers"]
     if kind == "stu":
-        return stu_layers(seqs, tl_mask, batch, p, cfg["n_blocks"], cfg["H"])
+        return stu_layers(seqs, tl_mask, batch, p, cfg["n_blocks"], cfg["H"], cfg.get("linear_hidden_dim"), cfg.get("attention_dim"))
     mask = attention_mask(x, cfg["causal"], cfg["keypad"])
     if kind == "sasrec":
         return sasrec_layers(seqs, tl_mask, mask, p, cfg["n_blocks"], cfg["H"])

@@ -85,12 +85,14 @@ def adam_state_dict(opt: tp.Any) -> tp.Dict[str, tp.Any]:
             # point means the caller stepped the optimiser by hand — writing the stale slices would corrupt a later fit_partial
             raise RuntimeError("the Adam moments on this rank are partial (sharded data-parallel exchange): call "
                                "model.optimizer.consolidate_moments() on EVERY rank (collective) before saving a checkpoint")
+        from .nn import unpad_tensor    # (parameters of a `nn.DimPlan` model carry zero columns: checkpoints speak the real shapes)
+
         m, v = opt.m, opt.v
         for i, (p, ofs) in enumerate(zip(opt.params, opt._offsets)):   # pylint: disable=protected-access
             n = p.numel()
             state[i] = {"step": torch.tensor(float(opt.step_count)),
-                        "exp_avg": m[ofs:ofs + n].detach().reshape(p.shape).cpu().clone(),
-                        "exp_avg_sq": v[ofs:ofs + n].detach().reshape(p.shape).cpu().clone()}
+                        "exp_avg": unpad_tensor(m[ofs:ofs + n].detach().reshape(p.shape), p).cpu().clone(),
+                        "exp_avg_sq": unpad_tensor(v[ofs:ofs + n].detach().reshape(p.shape), p).cpu().clone()}
     group = {"lr": float(opt.lr), "betas": tuple(float(b) for b in opt.betas), "eps": float(opt.eps), "weight_decay": 0,
              "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
              "fused": None, "params": list(range(len(opt.params)))}
@@ -105,6 +107,8 @@ def load_adam_state_dict(opt: tp.Any, sd: tp.Dict[str, tp.Any], names: tp.Option
     the parameter keys in the checkpoint's own state_dict — torch walks modules identically for `state_dict()` and
     `parameters()`), `opt_names` = this optimiser's parameter names: the state is then matched by name.  Without names
     both orders are assumed equal."""
+    from .nn import pad_tensor
+
     groups = sd.get("param_groups", [])
     order = [i for g in groups for i in g["params"]] or sorted(sd["state"])
     if len(order) != len(opt.params):
@@ -123,10 +127,11 @@ def load_adam_state_dict(opt: tp.Any, sd: tp.Dict[str, tp.Any], names: tp.Option
         if st is None:
             continue
         p, ofs = opt.params[target[pos]], opt._offsets[target[pos]]   # pylint: disable=protected-access
-        if tuple(st["exp_avg"].shape) != tuple(p.shape):
-            raise ValueError(f"optimizer state {key}: shape {tuple(st['exp_avg'].shape)} != parameter shape {tuple(p.shape)}")
-        opt.m[ofs:ofs + p.numel()].copy_(st["exp_avg"].reshape(-1))
-        opt.v[ofs:ofs + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
+        real_shape = tuple(getattr(p, "_rt_real_shape", p.shape))
+        if tuple(st["exp_avg"].shape) != real_shape:
+            raise ValueError(f"optimizer state {key}: shape {tuple(st['exp_avg'].shape)} != parameter shape {real_shape}")
+        opt.m[ofs:ofs + p.numel()].copy_(pad_tensor(st["exp_avg"], p).reshape(-1))
+        opt.v[ofs:ofs + p.numel()].copy_(pad_tensor(st["exp_avg_sq"], p).reshape(-1))
         steps.append(int(float(st["step"])))
     # one step counter for the whole model: torch keeps one per parameter, equal unless a parameter never got a gradient
     opt.step_count = max(steps) if steps else 0

@@ -32,7 +32,8 @@ namespace {
 enum { MODE_SOFTMAX = 0, MODE_HSTU = 1 };
 constexpr int AT = 256;        // threads per workgroup (4 waves)
 constexpr int TK = 32;         // keys / queries per tile
-constexpr int NBUCK = 129;     // hstu time buckets (num_buckets + 1)
+constexpr int NBUCK = 147;     // hstu time buckets: EVERY bucket an int64 difference can reach (ln(2^63) / 0.301 = 145.08), so one
+                               // kernel serves any `num_buckets` (hstu.py:47-82): the caller clamps through the weights it hands over
 
 struct AttnArgs {
   const float* q; const float* k; const float* v; long long ldq, ldk, ldv;
@@ -49,8 +50,8 @@ struct AttnArgs {
   float p_drop; unsigned long long seed;
   // hstu relative bias
   const long long* ts;                     // [B, L+1] unix timestamps (null: no time bias)
-  const float* time_w;                     // [129]
-  const long long* time_thr;               // [129] smallest |dt| that falls in bucket >= b (host-computed)
+  const float* time_w;                     // [time_thr[NBUCK]] = num_buckets + 1 entries
+  const long long* time_thr;               // [NBUCK + 1]: smallest |dt| that falls in bucket >= b (host-computed), then the entry count of time_w
   const float* pos_w;                      // [2L-1] (null: no position bias)
   float* d_time_w; float* d_pos_w;         // backward accumulators
   // packed sessions (ring kernels, hstu mode): session b owns rows cu[b] .. cu[b+1]-1 of q / k / v / o (no pad rows, ids == NULL) and the
@@ -660,7 +661,12 @@ __device__ __forceinline__ float* hstu_carve(float* p, int L, bool with_grads, H
 __device__ __forceinline__ void hstu_fill(const AttnArgs& a, const HstuLds& hl, int b, int tid, int nthreads) {
   float* tw = const_cast<float*>(hl.tw); float* pw = const_cast<float*>(hl.pw);
   long long* thr = const_cast<long long*>(hl.thr); long long* ts = const_cast<long long*>(hl.ts);
-  if (a.time_w) for (int i = tid; i < NBUCK; i += nthreads) { tw[i] = a.time_w[i]; thr[i] = a.time_thr[i]; }
+  // time_thr [NBUCK + 1]: the thresholds and, behind them, the number of entries of time_w (num_buckets + 1 <= NBUCK): the buckets past the
+  // model's last one read ITS weight — the reference's clamp(bucket, 0, num_buckets) (hstu.py:84-86) as a replicated table
+  if (a.time_w) {
+    const int nw = (int)a.time_thr[NBUCK];
+    for (int i = tid; i < NBUCK; i += nthreads) { tw[i] = a.time_w[i < nw ? i : nw - 1]; thr[i] = a.time_thr[i]; }
+  }
   const int W = win(a);
   if (a.pos_w) for (int i = tid; i < 2 * W - 1; i += nthreads) pw[i] = a.pos_w[i];
   const long long* tsb = a.cu ? a.ts + a.cu[b] + b : a.ts + (long long)b * (a.L + 1);    // (a.L + 1 timestamps either way)
@@ -671,7 +677,10 @@ __device__ __forceinline__ void hstu_fill(const AttnArgs& a, const HstuLds& hl, 
   }
 }
 __device__ __forceinline__ void hstu_flush_grads(const AttnArgs& a, const HstuLds& hl, int tid, int nthreads) {
-  if (a.d_time_w) for (int i = tid; i < NBUCK; i += nthreads) if (hl.dtw[i] != 0.f) atomicAdd(a.d_time_w + i, hl.dtw[i]);
+  if (a.d_time_w) {
+    const int nw = (int)a.time_thr[NBUCK];
+    for (int i = tid; i < NBUCK; i += nthreads) if (hl.dtw[i] != 0.f) atomicAdd(a.d_time_w + (i < nw ? i : nw - 1), hl.dtw[i]);
+  }
   if (a.d_pos_w) for (int i = tid; i < 2 * win(a) - 1; i += nthreads) if (hl.dpw[i] != 0.f) atomicAdd(a.d_pos_w + i, hl.dpw[i]);
 }
 constexpr int hstu_lds_floats(int L, bool with_grads) {
@@ -1968,7 +1977,7 @@ __global__ __launch_bounds__(256) void attn_last_query_kernel(AttnArgs a) {
       const bool dead = q_pad | (idb[j] == 0);
       float bias = 0.f;
       if (!dead) {
-        if (a.time_w) bias += a.time_w[time_bucket(a.time_thr, t_q1 - tsb[j])];
+        if (a.time_w) bias += a.time_w[min(time_bucket(a.time_thr, t_q1 - tsb[j]), (int)a.time_thr[NBUCK] - 1)];
         if (a.pos_w) bias += a.pos_w[(a.L - 1) + j - qq];
       }
       prob[j] = dead ? 0.f : silu_f(sdot + bias) * inv_l;
@@ -2035,16 +2044,34 @@ int rt_debug_attn_trace(unsigned long long* out_host, int n) {
 }
 #endif
 
+// (defined below)
+int rt_mha_fwd_scaled(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                      const int64_t* ids, int32_t B, int32_t H, int32_t L, int32_t hd, float scale, int32_t causal, int32_t keypad,
+                      float p_drop, uint64_t seed, float* o, int64_t ldo, float* lse, hipStream_t stream);
+int rt_mha_last_fwd_scaled(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const int64_t* ids,
+                           int32_t B, int32_t H, int32_t L, int32_t hd, float scale, int32_t causal, int32_t keypad, float* o, int64_t ldo,
+                           hipStream_t stream);
+int rt_mha_bwd_scaled(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                      const float* o, int64_t ldo, const float* dout, int64_t lddo, const float* lse, const int64_t* ids,
+                      int32_t B, int32_t H, int32_t L, int32_t hd, float scale, int32_t causal, int32_t keypad, float p_drop, uint64_t seed,
+                      float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv, float* delta,
+                      hipStream_t stream);
 // softmax attention forward.  q,k,v: [B*L, ld*] with head h at columns [h*hd, (h+1)*hd).  ids: [B,L].
 int rt_mha_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                const int64_t* ids, int32_t B, int32_t H, int32_t L, int32_t hd, int32_t causal, int32_t keypad,
                float p_drop, uint64_t seed, float* o, int64_t ldo, float* lse, hipStream_t stream) {
+  return rt_mha_fwd_scaled(q, ldq, k, ldk, v, ldv, ids, B, H, L, hd, 0.f, causal, keypad, p_drop, seed, o, ldo, lse, stream);
+}
+// ... with the logit scale given by the caller (scale <= 0: 1 / sqrt(hd)): heads padded with zero columns keep the scale of their real size
+int rt_mha_fwd_scaled(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                      const int64_t* ids, int32_t B, int32_t H, int32_t L, int32_t hd, float scale, int32_t causal, int32_t keypad,
+                      float p_drop, uint64_t seed, float* o, int64_t ldo, float* lse, hipStream_t stream) {
   (void)hipGetLastError();
   if (bad_common(B, H, L, hd, ldq, ldk, ldv) || (ldo & 3) || misaligned16(o)) return RT_ERR_INVALID_ARG;
   AttnArgs a{};
   a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.o = o; a.ldo = ldo; a.lse = lse;
   a.ids = reinterpret_cast<const long long*>(ids); a.B = B; a.H = H; a.L = L; a.hd = hd;
-  a.causal = causal; a.keypad = keypad; a.scale = 1.0f / sqrtf((float)hd); a.p_drop = p_drop; a.seed = seed;
+  a.causal = causal; a.keypad = keypad; a.scale = scale > 0.f ? scale : 1.0f / sqrtf((float)hd); a.p_drop = p_drop; a.seed = seed;
   return dispatch_fwd<MODE_SOFTMAX>(a, stream);
 }
 
@@ -2053,13 +2080,18 @@ int rt_mha_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const f
 int rt_mha_last_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const int64_t* ids,
                     int32_t B, int32_t H, int32_t L, int32_t hd, int32_t causal, int32_t keypad, float* o, int64_t ldo,
                     hipStream_t stream) {
+  return rt_mha_last_fwd_scaled(q, ldq, k, ldk, v, ldv, ids, B, H, L, hd, 0.f, causal, keypad, o, ldo, stream);
+}
+int rt_mha_last_fwd_scaled(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const int64_t* ids,
+                           int32_t B, int32_t H, int32_t L, int32_t hd, float scale, int32_t causal, int32_t keypad, float* o, int64_t ldo,
+                           hipStream_t stream) {
   (void)hipGetLastError();
   if (bad_common(B, H, L, hd, ldq, ldk, ldv) || (ldo & 3) || misaligned16(o) || misaligned16(q) || misaligned16(k) || misaligned16(v))
     return RT_ERR_INVALID_ARG;
   AttnArgs a{};
   a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.o = o; a.ldo = ldo;
   a.ids = reinterpret_cast<const long long*>(ids); a.B = B; a.H = H; a.L = L; a.hd = hd;
-  a.causal = causal; a.keypad = keypad; a.scale = 1.0f / sqrtf((float)hd);
+  a.causal = causal; a.keypad = keypad; a.scale = scale > 0.f ? scale : 1.0f / sqrtf((float)hd);
   const size_t prob_f = (size_t)((L + 3) & ~3) + 8;
   const size_t part_f = (size_t)256 * 4;           // [phases][hd/4] float4 = 256 float4 at most
   const size_t lds = (prob_f > part_f ? prob_f : part_f) * sizeof(float);
@@ -2099,6 +2131,14 @@ int rt_mha_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const f
                int32_t B, int32_t H, int32_t L, int32_t hd, int32_t causal, int32_t keypad, float p_drop, uint64_t seed,
                float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv, float* delta,
                hipStream_t stream) {
+  return rt_mha_bwd_scaled(q, ldq, k, ldk, v, ldv, o, ldo, dout, lddo, lse, ids, B, H, L, hd, 0.f, causal, keypad, p_drop, seed, dq, lddq, dk,
+                           lddk, dv, lddv, delta, stream);
+}
+int rt_mha_bwd_scaled(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                      const float* o, int64_t ldo, const float* dout, int64_t lddo, const float* lse, const int64_t* ids,
+                      int32_t B, int32_t H, int32_t L, int32_t hd, float scale, int32_t causal, int32_t keypad, float p_drop, uint64_t seed,
+                      float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv, float* delta,
+                      hipStream_t stream) {
   (void)hipGetLastError();
   if (bad_common(B, H, L, hd, ldq, ldk, ldv) || (ldo & 3) || (lddo & 3) || (lddq & 3) || (lddk & 3) || (lddv & 3) ||
       misaligned16(dq) || misaligned16(dk) || misaligned16(dv)) return RT_ERR_INVALID_ARG;
@@ -2107,12 +2147,12 @@ int rt_mha_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const f
   a.lse = const_cast<float*>(lse); a.delta = delta; a.o = const_cast<float*>(o); a.ldo = ldo;
   a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   a.ids = reinterpret_cast<const long long*>(ids); a.B = B; a.H = H; a.L = L; a.hd = hd;
-  a.causal = causal; a.keypad = keypad; a.scale = 1.0f / sqrtf((float)hd); a.p_drop = p_drop; a.seed = seed;
+  a.causal = causal; a.keypad = keypad; a.scale = scale > 0.f ? scale : 1.0f / sqrtf((float)hd); a.p_drop = p_drop; a.seed = seed;
   return dispatch_bwd<MODE_SOFTMAX>(a, stream);
 }
 
 // HSTU pointwise attention forward (always causal, padded queries and keys masked).
-// ts: [B, L+1] int64 or null; time_w [129] / time_thr [129] or null; pos_w [2L-1] or null.
+// ts: [B, L+1] int64 or null; time_w [n] / time_thr [148] (147 thresholds, then n) or null; pos_w [2L-1] or null.
 int rt_hstu_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                      const int64_t* ids, const int64_t* ts, const float* time_w, const int64_t* time_thr,
                      const float* pos_w, int32_t B, int32_t H, int32_t L, int32_t hd, float* o, int64_t ldo,
@@ -2128,7 +2168,7 @@ int rt_hstu_attn_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, c
   return dispatch_fwd<MODE_HSTU>(a, stream);
 }
 
-// HSTU attention backward: dq/dk/dv overwritten; d_time_w [129] / d_pos_w [2L-1] are ACCUMULATED into (caller zeroes).
+// HSTU attention backward: dq/dk/dv overwritten; d_time_w [n] / d_pos_w [2L-1] are ACCUMULATED into (caller zeroes).
 int rt_hstu_attn_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                      const float* dout, int64_t lddo, const int64_t* ids, const int64_t* ts, const float* time_w,
                      const int64_t* time_thr, const float* pos_w, int32_t B, int32_t H, int32_t L, int32_t hd,

@@ -586,7 +586,7 @@ int launch_fwd(const VarlenArgs& a, int max_len, hipStream_t stream) {
 // arithmetic per element (~40 VALU) and the dK/dV pass's 220 registers are where the next factor is.
 // =================================================================================================================================
 constexpr int HCH = 192;         // partner rows per chunk (6 tiles of 32): two hd-64 images = 148 KB
-constexpr int NBUCK = 129;       // time buckets (num_buckets + 1), as rt_attention.hip
+constexpr int NBUCK = 147;       // time buckets (every bucket an int64 difference can reach), as rt_attention.hip
 
 // rt_attention.hip's bucket search, bit for bit (largest b with thr[b] <= |dt|: fast-log estimate, two neighbouring thresholds settle it)
 __device__ __forceinline__ int hstu_bucket(const long long* thr, long long dt) {
@@ -636,9 +636,10 @@ template <int HD> inline size_t hstu_lds_bytes(int Lw, bool grads) {
          (grads ? (NBUCK + 3) * 4 + (size_t)(2 * Lw) * 4 : 0);
 }
 __device__ __forceinline__ void hstu_load_tables(const HstuV2Args& a, const HstuLdsV2& l, int tid, int nthreads, bool grads) {
+  const int nw = a.time_thr != nullptr ? (int)a.time_thr[NBUCK] : 1;     // entries of time_w; later buckets read the last one (hstu_fill)
   for (int j = tid; j < NBUCK; j += nthreads) {
     l.thr[j] = a.time_thr != nullptr ? a.time_thr[j] : 0;
-    l.tw[j] = a.time_w != nullptr ? a.time_w[j] : 0.f;
+    l.tw[j] = a.time_w != nullptr ? a.time_w[j < nw ? j : nw - 1] : 0.f;
     if (grads) l.dtw[j] = 0.f;
   }
   for (int j = tid; j < 2 * a.Lw - 1; j += nthreads) {
@@ -800,7 +801,10 @@ __global__ __launch_bounds__(NW * 64) void v2_hstu_bwd_dq_kernel(HstuV2Args a) {
     });
   }
   __syncthreads();
-  if (tgrad) for (int j = tid; j < NBUCK; j += NW * 64) { const float v = l.dtw[j]; if (v != 0.f) atomicAdd(a.d_time_w + j, v); }
+  if (tgrad) {
+    const int nw = (int)a.time_thr[NBUCK];
+    for (int j = tid; j < NBUCK; j += NW * 64) { const float v = l.dtw[j]; if (v != 0.f) atomicAdd(a.d_time_w + (j < nw ? j : nw - 1), v); }
+  }
   if (pgrad) for (int j = tid; j < 2 * a.Lw - 1; j += NW * 64) { const float v = l.dpw[j]; if (v != 0.f) atomicAdd(a.d_pos_w + j, v); }
 }
 

@@ -246,15 +246,25 @@ int launch_embed_bwd(const EmbBwdArgs& a, bool prepared, hipStream_t stream) {
 // ---------------------------------------------------------------------------------------------------
 // ids (nullable): the row mask `x * (ids != 0)` applied to the INPUT on the fly (`seqs *= timeline_mask` in front of a LayerNorm,
 // sasrec.py:300 / :313); x0 (nullable) receives the masked rows the backward pass needs.
+// COLS: only the columns c with (c % grp) < grp_real exist (a model whose width / head size the kernels cannot tile runs on rows padded
+// with zero columns, head by head: rt_layernorm_*_cols) — statistics over the real columns only, zeros written to the others.
+__device__ __forceinline__ f32x4 ln_keep_cols(f32x4 v, int c, int grp, int grp_real) {
+  const int r = c % grp;      // grp % 4 == 0: the four columns of a float4 lie in one group
+  v[0] = r < grp_real ? v[0] : 0.f;      v[1] = r + 1 < grp_real ? v[1] : 0.f;
+  v[2] = r + 2 < grp_real ? v[2] : 0.f;  v[3] = r + 3 < grp_real ? v[3] : 0.f;
+  return v;
+}
+template <bool COLS = false>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ b, float eps, int M, int d,
                                                             float* __restrict__ y, float* __restrict__ mean,
                                                             float* __restrict__ rstd, const long long* __restrict__ ids = nullptr,
-                                                            float* __restrict__ x0 = nullptr) {
+                                                            float* __restrict__ x0 = nullptr, int grp = 0, int grp_real = 0) {
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= M) return;
   const float* xr = x + (long long)m * d;
+  const int n_cols = COLS ? d / grp * grp_real : d;
   // a SELECT, not a multiply by 0: a non-finite value in a padded row must become an exact zero (as rt_mul_mask and the backward's
   // mask_dx do), not NaN — SASRec's causal-only attention lets real queries see those rows as keys
   const bool pad = ids != nullptr && ids[m] == 0;
@@ -262,22 +272,25 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   float s = 0.f;
   for (int c = lane * 4; c < d; c += 256) {
     f32x4 v = pad ? zero4 : *reinterpret_cast<const f32x4*>(xr + c);
+    if (COLS) v = ln_keep_cols(v, c, grp, grp_real);
     if (x0 != nullptr) *reinterpret_cast<f32x4*>(x0 + (long long)m * d + c) = v;
     s += v[0] + v[1] + v[2] + v[3];
   }
-  const float mu = wave_sum(s) / d;
+  const float mu = wave_sum(s) / n_cols;
   float q = 0.f;
   for (int c = lane * 4; c < d; c += 256) {
     f32x4 v = pad ? zero4 : *reinterpret_cast<const f32x4*>(xr + c);
     v -= mu;
+    if (COLS) v = ln_keep_cols(v, c, grp, grp_real);
     q += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
   }
-  const float rs = 1.0f / sqrtf(wave_sum(q) / d + eps);
+  const float rs = 1.0f / sqrtf(wave_sum(q) / n_cols + eps);
   for (int c = lane * 4; c < d; c += 256) {
     f32x4 v = pad ? zero4 : *reinterpret_cast<const f32x4*>(xr + c);
     f32x4 ww = *reinterpret_cast<const f32x4*>(w + c);
     f32x4 bb = *reinterpret_cast<const f32x4*>(b + c);
     v = (v - mu) * rs * ww + bb;
+    if (COLS) v = ln_keep_cols(v, c, grp, grp_real);
     *reinterpret_cast<f32x4*>(y + (long long)m * d + c) = v;
   }
   if (lane == 0) { mean[m] = mu; rstd[m] = rs; }
@@ -289,14 +302,15 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 // Optional fusions of the passes that surround a LayerNorm in the backward of a transformer block (`res`, `ids` nullable):
 //   mask_dy: rows with ids[row] == 0 take dy = 0 (the forward multiplied the LayerNorm OUTPUT by the row mask)
 //   res:     dx += res (the LayerNorm input also fed a skip connection)       mask_dx: rows with ids[row] == 0 get dx = 0
-template <int NDV>
+template <int NDV, bool COLS = false>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ w, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, int M, int d, int rows_per_block,
                                                             float* __restrict__ dx, float* __restrict__ partial,
                                                             const float* __restrict__ res = nullptr,
                                                             const long long* __restrict__ ids = nullptr, int mask_dy = 0,
-                                                            int mask_dx = 0) {
+                                                            int mask_dx = 0, int grp = 0, int grp_real = 0) {
+  const int n_cols = COLS ? d / grp * grp_real : d;
   extern __shared__ float red[];  // [4 waves][2][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r0 = blockIdx.x * rows_per_block;
@@ -326,6 +340,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         f32x4 z = {0.f, 0.f, 0.f, 0.f};
         g[u][i] = (c < d && !(mask_dy && pad[u])) ? *reinterpret_cast<const f32x4*>(dy + ro[u] + c) : z;
         xh[u][i] = (c < d) ? *reinterpret_cast<const f32x4*>(x + ro[u] + c) : z;
+        if (COLS && c < d) g[u][i] = ln_keep_cols(g[u][i], c, grp, grp_real);
       }
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -334,12 +349,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         const int c = lane * 4 + 256 * i;
         f32x4 z = {0.f, 0.f, 0.f, 0.f};
         xh[u][i] = (c < d) ? (xh[u][i] - mu[u]) * rs[u] : z;
+        if (COLS && c < d) xh[u][i] = ln_keep_cols(xh[u][i], c, grp, grp_real);
         f32x4 gw = g[u][i] * wv[i];
         s1[u] += gw[0] + gw[1] + gw[2] + gw[3];
         s2[u] += gw[0] * xh[u][i][0] + gw[1] * xh[u][i][1] + gw[2] * xh[u][i][2] + gw[3] * xh[u][i][3];
       }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) { s1[u] = wave_sum(s1[u]) / d; s2[u] = wave_sum(s2[u]) / d; }
+    for (int u = 0; u < 2; ++u) { s1[u] = wave_sum(s1[u]) / n_cols; s2[u] = wave_sum(s2[u]) / n_cols; }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       if (u == 1 && !has2) break;
@@ -349,6 +365,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         if (c < d) {
           f32x4 o = (g[u][i] * wv[i] - s1[u] - xh[u][i] * s2[u]) * rs[u];
           if (res != nullptr) o += *reinterpret_cast<const f32x4*>(res + ro[u] + c);
+          if (COLS) o = ln_keep_cols(o, c, grp, grp_real);
           if (mask_dx && pad[u]) o = f32x4{0.f, 0.f, 0.f, 0.f};
           *reinterpret_cast<f32x4*>(dx + ro[u] + c) = o;
           pw[i] += g[u][i] * xh[u][i];
@@ -726,7 +743,7 @@ int rt_layernorm_fwd(const float* x, const float* w, const float* b, float eps, 
   (void)hipGetLastError();
   if (M <= 0) return RT_OK;
   if ((d & 3) != 0) return RT_ERR_INVALID_ARG;
-  layernorm_fwd_kernel<<<(M + 3) / 4, 256, 0, stream>>>(x, w, b, eps, M, d, y, mean, rstd);
+  layernorm_fwd_kernel<false><<<(M + 3) / 4, 256, 0, stream>>>(x, w, b, eps, M, d, y, mean, rstd);
   RT_CHECK_LAUNCH();
   return RT_OK;
 }
@@ -737,7 +754,21 @@ int rt_layernorm_fwd_masked(const float* x, const int64_t* ids, const float* w, 
   (void)hipGetLastError();
   if (M <= 0) return RT_OK;
   if ((d & 3) != 0 || ids == nullptr) return RT_ERR_INVALID_ARG;
-  layernorm_fwd_kernel<<<(M + 3) / 4, 256, 0, stream>>>(x, w, b, eps, M, d, y, mean, rstd, reinterpret_cast<const long long*>(ids), x0);
+  layernorm_fwd_kernel<false><<<(M + 3) / 4, 256, 0, stream>>>(x, w, b, eps, M, d, y, mean, rstd, reinterpret_cast<const long long*>(ids), x0);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+// LayerNorm over rows that carry ZERO COLUMNS (rt_layernorm_fwd_cols / _bwd_cols, include/rectools_hip.h): column c exists iff
+// (c % grp) < grp_real; ids / x0 as rt_layernorm_fwd_masked (both nullable).
+static bool bad_cols(int d, int grp, int grp_real) { return (d & 3) != 0 || grp <= 0 || (grp & 3) != 0 || d % grp != 0 || grp_real <= 0 || grp_real > grp; }
+int rt_layernorm_fwd_cols(const float* x, const int64_t* ids, const float* w, const float* b, float eps, int32_t M, int32_t d, int32_t grp,
+                          int32_t grp_real, float* x0, float* y, float* mean, float* rstd, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (M <= 0) return RT_OK;
+  if (bad_cols(d, grp, grp_real)) return RT_ERR_INVALID_ARG;
+  layernorm_fwd_kernel<true><<<(M + 3) / 4, 256, 0, stream>>>(x, w, b, eps, M, d, y, mean, rstd, reinterpret_cast<const long long*>(ids), x0, grp,
+                                                             grp_real);
   RT_CHECK_LAUNCH();
   return RT_OK;
 }
@@ -765,9 +796,23 @@ int rt_layernorm_bwd(const float* dy, const float* x, const float* w, const floa
 }
 // Same with the surrounding passes fused: dy rows of padded positions read as zero (mask_dy), dx += res, dx rows of padded
 // positions written as zero (mask_dx); res / ids nullable.
+static int layernorm_bwd_any(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
+                           const float* res, const int64_t* ids, int32_t mask_dy, int32_t mask_dx, int32_t M, int32_t d, int32_t grp,
+                           int32_t grp_real, float* dx, float* dw, float* db, void* workspace, size_t workspace_bytes, hipStream_t stream);
 int rt_layernorm_bwd_fused(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
                            const float* res, const int64_t* ids, int32_t mask_dy, int32_t mask_dx, int32_t M, int32_t d,
                            float* dx, float* dw, float* db, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  return layernorm_bwd_any(dy, x, w, mean, rstd, res, ids, mask_dy, mask_dx, M, d, 0, 0, dx, dw, db, workspace, workspace_bytes, stream);
+}
+int rt_layernorm_bwd_cols(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
+                          const float* res, const int64_t* ids, int32_t mask_dy, int32_t mask_dx, int32_t M, int32_t d, int32_t grp,
+                          int32_t grp_real, float* dx, float* dw, float* db, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (bad_cols(d, grp, grp_real)) return RT_ERR_INVALID_ARG;
+  return layernorm_bwd_any(dy, x, w, mean, rstd, res, ids, mask_dy, mask_dx, M, d, grp, grp_real, dx, dw, db, workspace, workspace_bytes, stream);
+}
+static int layernorm_bwd_any(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
+                           const float* res, const int64_t* ids, int32_t mask_dy, int32_t mask_dx, int32_t M, int32_t d, int32_t grp,
+                           int32_t grp_real, float* dx, float* dw, float* db, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   (void)hipGetLastError();
   if ((mask_dy || mask_dx) && ids == nullptr) return RT_ERR_INVALID_ARG;
   const long long* idp = reinterpret_cast<const long long*>(ids);
@@ -783,7 +828,11 @@ int rt_layernorm_bwd_fused(const float* dy, const float* x, const float* w, cons
   const int blocks = ln_bwd_blocks(M, rpb);
   float* partial = reinterpret_cast<float*>(workspace);
   const size_t lds = 8 * (size_t)d * sizeof(float);
-  if (d <= 256) layernorm_bwd_kernel<1><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, partial, res, idp, mask_dy, mask_dx);
+  if (grp > 0) {
+    if (d <= 256) layernorm_bwd_kernel<1, true><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, partial, res, idp, mask_dy, mask_dx, grp, grp_real);
+    else if (d <= 512) layernorm_bwd_kernel<2, true><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, partial, res, idp, mask_dy, mask_dx, grp, grp_real);
+    else layernorm_bwd_kernel<4, true><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, partial, res, idp, mask_dy, mask_dx, grp, grp_real);
+  } else if (d <= 256) layernorm_bwd_kernel<1><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, partial, res, idp, mask_dy, mask_dx);
   else if (d <= 512) layernorm_bwd_kernel<2><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, partial, res, idp, mask_dy, mask_dx);
   else layernorm_bwd_kernel<4><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, partial, res, idp, mask_dy, mask_dx);
   RT_CHECK_LAUNCH();

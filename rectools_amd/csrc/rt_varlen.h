@@ -47,7 +47,7 @@ struct HstuV2Args {
   float* o; long long ldo;
   const long long* cu;                 // [B+1] first packed row of every session
   const long long* ts;                 // session b's n_b + 1 timestamps start at ts[cu[b] + b] (null: no time bias)
-  const float* time_w; const long long* time_thr; const float* pos_w;   // [129], [129], [2 Lw - 1] (pos_w null: no position bias)
+  const float* time_w; const long long* time_thr; const float* pos_w;   // [n], [148] (thresholds, then n), [2 Lw - 1] (pos_w null: no position bias)
   int B, H, hd, Lw;                    // Lw = the window (session_max_len): 1 / Lw and the position table's centre
   const float* dout; long long lddo;
   float* dq; float* dk; float* dv; long long lddq, lddk, lddv;

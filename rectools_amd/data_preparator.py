@@ -225,14 +225,44 @@ class TransformerDataPreparatorBase:
         lookup[uniq] = torch.arange(uniq.numel(), dtype=torch.int64, device=x.device)
         return uniq, lookup
 
+    prep_device: tp.Optional[tp.Union[str, torch.device]] = None      # set by the model: the device ITS parameters will live on
+
+    def _prep_device(self) -> torch.device:
+        """Where the sorts of `process_dataset_train` run: RT_PREP_DEVICE (override) > the device the model handed over (`prep_device`:
+        its own `recommend_torch_device` / LOCAL_RANK's GPU — under torchrun every rank sorts on ITS GPU, not all of them on GPU 0) > the
+        current HIP device of a stand-alone preparator > the host."""
+        env = os.environ.get("RT_PREP_DEVICE")
+        if env:
+            return torch.device(env)
+        if self.prep_device is not None:
+            return torch.device(self.prep_device)
+        return torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
     def _process_dataset_train_arrays(self, dataset: tp.Any, train_rows: tp.Optional[np.ndarray] = None) -> None:
         """The same result as the frame-based path below (data_preparator.py:214-284), computed with sorts / scans over the
         interaction columns instead of pandas groupby: at ML-20M scale the frame path costs several epochs of GPU training.
         Works on the dataset's INTERNAL ids (integers whatever the external id type) and translates only the distinct ids.
-        RT_PREP_DEVICE selects where the sorts run (default: the HIP device when one is visible; the ops are torch ops, identical on both)."""
-        # default: the HIP device when there is one (2 M users x 1 M items, 78.8 M interactions on the MI355X box: 4.8 s against 14.0 s
-        # on its 128 host threads — profiles/r4_c4_scale.json); the same torch ops either way, stable sorts: same result
-        dev = torch.device(os.environ.get("RT_PREP_DEVICE") or ("cuda" if torch.cuda.is_available() else "cpu"))
+        The ops are torch ops, identical on host and device (stable sorts: same result): they run on `_prep_device()` (2 M users x 1 M
+        items, 78.8 M interactions on the MI355X box: 4.8 s against 14.0 s on its 128 host threads — profiles/r4_c4_scale.json) and are
+        repeated on the host when the device cannot serve them — out of memory beside another process's tables, or
+        `torch.use_deterministic_algorithms(True)`, under which the device's `bincount` / `scatter_reduce_` refuse to run."""
+        dev = self._prep_device()
+        if dev.type != "cpu":
+            try:
+                self._process_dataset_train_arrays_on(dev, dataset, train_rows)
+                return
+            except torch.cuda.OutOfMemoryError:
+                warnings.warn(f"process_dataset_train: out of memory on {dev}; the dataset is processed on the host instead")
+                torch.cuda.empty_cache()
+            except RuntimeError as err:
+                if "deterministic" not in str(err):
+                    raise
+                warnings.warn(f"process_dataset_train: {dev} has no deterministic implementation of a step "
+                              f"(torch.use_deterministic_algorithms is on); the dataset is processed on the host instead")
+            dev = torch.device("cpu")
+        self._process_dataset_train_arrays_on(dev, dataset, train_rows)
+
+    def _process_dataset_train_arrays_on(self, dev: torch.device, dataset: tp.Any, train_rows: tp.Optional[np.ndarray] = None) -> None:
         df = dataset.interactions.df
         as_t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
         u = as_t(df[Columns.User].values.astype(np.int64, copy=False))

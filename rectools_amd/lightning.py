@@ -75,6 +75,16 @@ class TransformerLossModule(nn.Module):
         """lightning.py:115-124 — consulted by the model before it builds the data preparator (transformers/base.py:354)."""
         return requires_negatives(loss)
 
+    # LightningModule.log / log_dict as far as the engine's loop goes: a callback of a user-built Trainer (`models._trainer_plan`) logs
+    # its metrics here; the loop copies them into the epoch's history record, the CSV row and `trainer.callback_metrics`
+    def log(self, name: str, value: tp.Any, *args: tp.Any, **kwargs: tp.Any) -> None:
+        metrics = self.__dict__.setdefault("logged_metrics", {})
+        metrics[name] = float(value.detach()) if isinstance(value, torch.Tensor) else float(value)
+
+    def log_dict(self, dictionary: tp.Mapping[str, tp.Any], *args: tp.Any, **kwargs: tp.Any) -> None:
+        for name, value in dictionary.items():
+            self.log(name, value)
+
     @property
     def cosine(self) -> bool:
         return self.torch_model.similarity_module.distance == Distance.COSINE

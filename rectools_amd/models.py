@@ -267,12 +267,9 @@ class TransformerModelBase:
         get_trainer_func: tp.Optional[tp.Callable] = None, get_trainer_func_kwargs: tp.Optional[dict] = None,
         **kwargs: tp.Any,
     ) -> None:
-        if get_trainer_func is not None:
-            # transformers/base.py:368-380 hands fit() to a user-built pytorch_lightning.Trainer.  This engine has no Lightning
-            # Trainer (the loop is `_TrainLoop`: device collate, fused Adam, RCCL exchange): refuse instead of training some other way
-            raise NotImplementedError("get_trainer_func: the MI355X engine trains with its own loop (models._TrainLoop), a custom "
-                                      "pytorch_lightning.Trainer cannot be honoured; pass None (epochs / deterministic / verbose and "
-                                      "`csv_log_dir` cover the default trainer's settings)")
+        # get_trainer_func (transformers/base.py:367-380): the reference hands fit() to the pytorch_lightning.Trainer this factory returns.
+        # The engine keeps its own loop (`_TrainLoop`: device collate, fused Adam, RCCL exchange) and takes from that object what a loop
+        # can honour — see `_trainer_plan`; the factory is called at fit time (it may need a package this environment does not have)
         self._params = dict(
             n_blocks=n_blocks, n_heads=n_heads, n_factors=n_factors, use_pos_emb=use_pos_emb, use_causal_attn=use_causal_attn,
             use_key_padding_mask=use_key_padding_mask, dropout_rate=dropout_rate, session_max_len=session_max_len,
@@ -288,7 +285,7 @@ class TransformerModelBase:
             item_net_constructor_type=item_net_constructor_type, item_net_constructor_kwargs=item_net_constructor_kwargs,
             negative_sampler_type=negative_sampler_type, negative_sampler_kwargs=negative_sampler_kwargs,
             pos_encoding_type=pos_encoding_type, lightning_module_type=lightning_module_type, backbone_type=backbone_type,
-            backbone_kwargs=backbone_kwargs, get_trainer_func=None, get_trainer_func_kwargs=get_trainer_func_kwargs,
+            backbone_kwargs=backbone_kwargs, get_trainer_func=get_trainer_func, get_trainer_func_kwargs=get_trainer_func_kwargs,
         )
         self._params.update(kwargs)
         for k, v in self._params.items():
@@ -297,12 +294,7 @@ class TransformerModelBase:
             raise ValueError(f"loss {loss} is not supported")
         if n_factors % n_heads != 0:
             raise ValueError("n_factors must be divisible by n_heads without remainder")   # nn.MultiheadAttention's own check
-        head = n_factors // n_heads
-        if n_factors % 4 != 0 or head % 8 != 0 or head > 128:
-            # the kernels move float4 columns and tile heads in 8-column groups (include/rectools_hip.h); fail at
-            # construction with the reason instead of a status code from the first launch of fit()
-            raise NotImplementedError(f"the HIP kernels need n_factors % 4 == 0 and a head size (n_factors / n_heads) that is a "
-                                      f"multiple of 8 and at most 128; got n_factors={n_factors}, n_heads={n_heads}")
+        self._dim_plan()     # fail at construction, with the reason, for what no padding makes the kernels tile (a head wider than 128)
         self.is_fitted = False
         self.dataset_schema: tp.Dict[str, tp.Any] = {}
         self.lightning_model: tp.Optional[hl.TransformerLossModule] = None
@@ -339,22 +331,47 @@ class TransformerModelBase:
             **self._kw(self.data_preparator_kwargs),
         )
 
-    def _init_transformer_layers(self) -> hnn.TransformerLayersBase:
-        return self.transformer_layers_type(n_blocks=self.n_blocks, n_factors=self.n_factors, n_heads=self.n_heads,
-                                            dropout_rate=self.dropout_rate, **self._kw(self.transformer_layers_kwargs))
+    def _dim_plan(self) -> tp.Optional[hnn.DimPlan]:
+        """How this model's sizes map onto sizes the kernels tile (`nn.DimPlan`): None when they do as they are (n_factors % 4 == 0, head
+        size a multiple of 8, at most 128; HSTU: linear_hidden_dim == attention_dim).  Otherwise the stock modules are built padded
+        with zero columns; a PLUGGED layer stack / item net / positional encoding / backbone is built by the caller's own class at the
+        caller's own sizes and cannot be padded from outside: NotImplementedError names the constraint."""
+        tkw = self._kw(self.transformer_layers_kwargs)
+        stu = self.transformer_layers_type is hnn.STULayers
+        plan = hnn.DimPlan.make(self.n_factors, self.n_heads, "stu", tkw.get("linear_hidden_dim"), tkw.get("attention_dim")) if stu \
+            else hnn.DimPlan.make(self.n_factors, self.n_heads, "mha")
+        if plan is None:
+            return None
+        stock = (self.transformer_layers_type in (hnn.SASRecTransformerLayers, hnn.PreLNTransformerLayers, hnn.LiGRLayers, hnn.STULayers)
+                 and self.pos_encoding_type is hnn.LearnableInversePositionalEncoding and self.backbone_type is hnn.TransformerTorchBackbone
+                 and self.item_net_constructor_type is hnn.SumOfEmbeddingsConstructor
+                 and all(t in (hnn.IdEmbeddingsItemNet, hnn.CatFeaturesItemNet) for t in self.item_net_block_types))
+        if not stock:
+            raise NotImplementedError(f"the HIP kernels need n_factors % 4 == 0 and a head size (n_factors / n_heads) that is a multiple of 8 and "
+                                      f"at most 128; got n_factors={self.n_factors}, n_heads={self.n_heads}.  The stock modules run such sizes "
+                                      f"padded with zero columns (nn.DimPlan); plugged module classes cannot be padded from outside")
+        return plan
+
+    def _init_transformer_layers(self, plan: tp.Optional[hnn.DimPlan] = None) -> hnn.TransformerLayersBase:
+        tkw = self._kw(self.transformer_layers_kwargs)
+        if plan is not None and plan.kind == "stu":
+            tkw.update(linear_hidden_dim=plan.hd_pad, attention_dim=plan.hd_pad)
+        return self.transformer_layers_type(n_blocks=self.n_blocks, n_factors=self.n_factors if plan is None else plan.d_pad,
+                                            n_heads=self.n_heads, dropout_rate=self.dropout_rate, **tkw)
 
     def _init_similarity_module(self) -> hnn.DistanceSimilarityModule:
         kw = self._kw(self.similarity_module_kwargs)
         kw.setdefault("distance", self.u2i_dist_default)
         return self.similarity_module_type(**kw)
 
-    def _init_item_model(self, item_net_schema: tp.Optional[tp.List[dict]]) -> hnn.SumOfEmbeddingsConstructor:
+    def _init_item_model(self, item_net_schema: tp.Optional[tp.List[dict]], n_factors: tp.Optional[int] = None) -> hnn.SumOfEmbeddingsConstructor:
         """Item net from the processed train dataset (base.py:317-326), or — when restoring a checkpoint — from the shapes
         recorded with it (the role of `from_dataset_schema`, item_net.py:193-228: buffers are placeholders that the state
-        dict overwrites)."""
+        dict overwrites).  n_factors: the width to build (a `DimPlan`'s padded width; default: the model's)."""
         kw = self._kw(self.item_net_constructor_kwargs)
+        n_factors = self.n_factors if n_factors is None else n_factors
         if item_net_schema is None:
-            return self.item_net_constructor_type.from_dataset(self.data_preparator.train_dataset, self.n_factors,
+            return self.item_net_constructor_type.from_dataset(self.data_preparator.train_dataset, n_factors,
                                                                self.dropout_rate, self.item_net_block_types, **kw)
         n_tokens = self.data_preparator.item_id_map.size
         by_kind = {spec["kind"]: spec for spec in item_net_schema}
@@ -364,32 +381,36 @@ class TransformerModelBase:
         # (Cat, Id) order puts the feature block at index 0 — the state dict's `item_net_blocks.N.*` keys follow that
         for block_type in self.item_net_block_types:
             if isinstance(block_type, type) and issubclass(block_type, hnn.IdEmbeddingsItemNet):
-                blocks.append(block_type(self.n_factors, n_tokens, self.dropout_rate))
+                blocks.append(block_type(n_factors, n_tokens, self.dropout_rate))
             elif isinstance(block_type, type) and issubclass(block_type, hnn.CatFeaturesItemNet):
                 spec = by_kind.get("cat")
                 if spec is None:
                     continue    # no categorical item features in the dataset: the block is skipped, as at fit time
                 zeros = torch.zeros(n_tokens, dtype=torch.int64)
                 blocks.append(block_type(torch.zeros(spec["nnz"], dtype=torch.int64), zeros, zeros.clone(),
-                                         spec["n_cat_feature_values"], self.n_factors, self.dropout_rate))
+                                         spec["n_cat_feature_values"], n_factors, self.dropout_rate))
             else:
                 raise NotImplementedError(f"item net block {block_type!r} cannot be rebuilt from a dataset schema")
         return self.item_net_constructor_type(n_tokens, blocks, **kw)
 
     def _build_model_from_dataset(self, dataset: tp.Any, item_net_schema: tp.Optional[tp.List[dict]] = None) -> None:
         self._catalog_images = None     # a new model: images kept for recommend() belong to the old weights
+        self._hand_prep_device()
         self.data_preparator.process_dataset_train(dataset)
         if self.seed is not None:  # before ANY parameter is created: 1-D parameters keep their constructor init
             torch.manual_seed(self.seed)
-        item_model = self._init_item_model(item_net_schema)
-        pkw = self._kw(self.pos_encoding_kwargs)
-        pkw.setdefault("use_scale_factor", self.use_scale_factor_default)
-        # the plug-in seams of transformers/base.py:407-449: every module is built from the class the caller handed over
-        pos = self.pos_encoding_type(self.use_pos_emb, self.session_max_len, self.n_factors, **pkw)
-        backbone = self.backbone_type(
-            n_heads=self.n_heads, dropout_rate=self.dropout_rate, item_model=item_model, pos_encoding_layer=pos,
-            transformer_layers=self._init_transformer_layers(), similarity_module=self._init_similarity_module(),
-            use_causal_attn=self.use_causal_attn, use_key_padding_mask=self.use_key_padding_mask, **self._kw(self.backbone_kwargs))
+        plan = self._dim_plan()
+        backbone = self._make_backbone(item_net_schema, None)
+        if plan is not None:
+            # sizes the kernels cannot tile (nn.DimPlan).  `backbone` above is the model at its REAL sizes, on the host: constructor
+            # initialisation + xavier (lightning.py:296-299) happen there, exactly as for any model; the model that computes is built
+            # with zero columns behind the real ones and takes the real one's state through the padding hooks
+            hl.xavier_normal_init(backbone)
+            real_state = backbone.state_dict()
+            backbone = self._make_backbone(item_net_schema, plan)
+            hnn.apply_dim_plan(backbone, plan)
+            backbone.load_state_dict(real_state)
+            del real_state
         dp = self.data_preparator
         self.lightning_model = self.lightning_module_type(
             torch_model=backbone, model_config=self.get_config(simple_types=True),
@@ -401,7 +422,8 @@ class TransformerModelBase:
             **self._kw(self.lightning_module_kwargs))
         device = torch.device(self._device())
         self.lightning_model.to(device)
-        hl.xavier_normal_init(self.lightning_model.torch_model)  # on_train_start (lightning.py:296-299)
+        if plan is None:
+            hl.xavier_normal_init(self.lightning_model.torch_model)  # on_train_start (lightning.py:296-299)
         self.optimizer = hl.FlatAdam(self.lightning_model.torch_model, lr=self.lr, betas=(0.9, 0.98))
         if os.environ.get("RT_DP_BACKEND", "torch") == "rccl" and _dist_info()[1] > 1 and device.type == "cuda":
             self.optimizer.use_rccl_exchange(*_dist_info())   # gradient exchange through rt_dp_* (include/rectools_hip.h)
@@ -416,6 +438,27 @@ class TransformerModelBase:
         ops.RNG.step = 0
         if dataset is not None:   # kept for checkpoints (hyper_parameters.dataset_schema, base.py:470-473)
             self.dataset_schema = self.data_preparator.train_dataset.get_schema()
+
+    def _hand_prep_device(self) -> None:
+        """The preparator sorts the interaction columns where the model's parameters will live (`recommend_torch_device`, else
+        LOCAL_RANK's GPU) — not on "the current device", which under torchrun is GPU 0 for every rank."""
+        try:
+            self.data_preparator.prep_device = self._device()
+        except Exception:      # pylint: disable=broad-except   # no HIP device: the build below says so; processing itself runs anywhere
+            self.data_preparator.prep_device = None
+
+    def _make_backbone(self, item_net_schema: tp.Optional[tp.List[dict]], plan: tp.Optional[hnn.DimPlan]) -> hnn.TransformerTorchBackbone:
+        """The torch model out of the classes the caller handed over — the plug-in seams of transformers/base.py:407-449 — at the
+        model's own sizes (plan None) or at a `DimPlan`'s padded ones."""
+        width = self.n_factors if plan is None else plan.d_pad
+        item_model = self._init_item_model(item_net_schema, width)
+        pkw = self._kw(self.pos_encoding_kwargs)
+        pkw.setdefault("use_scale_factor", self.use_scale_factor_default)
+        pos = self.pos_encoding_type(self.use_pos_emb, self.session_max_len, width, **pkw)
+        return self.backbone_type(
+            n_heads=self.n_heads, dropout_rate=self.dropout_rate, item_model=item_model, pos_encoding_layer=pos,
+            transformer_layers=self._init_transformer_layers(plan), similarity_module=self._init_similarity_module(),
+            use_causal_attn=self.use_causal_attn, use_key_padding_mask=self.use_key_padding_mask, **self._kw(self.backbone_kwargs))
 
     def _device(self) -> str:
         if self.recommend_torch_device is not None and str(self.recommend_torch_device) != "cpu":
@@ -451,10 +494,68 @@ class TransformerModelBase:
         (+ gradient all-reduce).  `_run_epochs` drives it epoch by epoch; `bench.py` times exactly this object's `step()`."""
         return _TrainLoop(self)
 
-    def _run_epochs(self, first: int, last: int) -> None:
+    # what the engine's loop takes from a user-built Trainer, and what it calls on its callbacks (all duck-typed: no Lightning import)
+    _TRAINER_HOOKS = ("on_fit_start", "on_train_start", "on_train_epoch_start", "on_train_epoch_end", "on_validation_start",
+                      "on_validation_batch_end", "on_validation_epoch_end", "on_validation_end", "on_train_end", "on_fit_end")
+
+    def _trainer_plan(self) -> tp.Optional[tp.Dict[str, tp.Any]]:
+        """`get_trainer_func(**get_trainer_func_kwargs)` (transformers/base.py:367-380) read as a PLAN for the engine's own loop.
+
+        Honoured: `max_epochs` / `min_epochs` (fit() trains max_epochs epochs, at least min_epochs once a callback sets
+        `trainer.should_stop`), the logger's directory (`trainer.logger.log_dir` / `save_dir` -> the per-epoch CSV, the layout of
+        Lightning's CSVLogger), `enable_progress_bar` (a line per epoch, as verbose > 0), `deterministic` (applied by the Trainer's own
+        constructor; every kernel of the engine but the HSTU bias gradients reduces in a fixed order anyway), and the hooks of
+        USER-DEFINED callbacks — any object in `trainer.callbacks` whose class does not come from pytorch_lightning / lightning — called
+        as `hook(trainer, lightning_model[, outputs, batch, batch_idx])` where the loop reaches the matching point.
+        Not honoured, said once per fit in a warning: accelerator / devices / strategy / precision / gradient clipping / accumulation /
+        limit_* / profilers, and Lightning's built-in callbacks (EarlyStopping, ModelCheckpoint, ...), which drive Lightning's own loop
+        objects; `fit_trainer.save_checkpoint` is `model.save_to_checkpoint` here."""
+        if self.get_trainer_func is None:
+            return None
+        trainer = self.get_trainer_func(**self._kw(self.get_trainer_func_kwargs))
+        own, foreign = [], []
+        for cb in list(getattr(trainer, "callbacks", None) or []):
+            mod = type(cb).__module__ or ""
+            (foreign if mod.split(".")[0] in ("pytorch_lightning", "lightning", "lightning_fabric") else own).append(cb)
+        logger = getattr(trainer, "logger", None)
+        log_dir = None
+        for attr in ("log_dir", "save_dir"):
+            if logger is not None and isinstance(getattr(logger, attr, None), str):
+                log_dir = getattr(logger, attr)
+                break
+        plan = {"trainer": trainer, "max_epochs": getattr(trainer, "max_epochs", None), "min_epochs": getattr(trainer, "min_epochs", None),
+                "callbacks": own, "log_dir": log_dir,
+                "progress": bool(getattr(trainer, "enable_progress_bar", False) or getattr(trainer, "progress_bar_callback", None))}
+        ignored = ", ".join(sorted({type(cb).__name__ for cb in foreign}))
+        warnings.warn("get_trainer_func: the MI355X engine trains with its own loop (models._TrainLoop).  Taken from the Trainer: max_epochs="
+                      f"{plan['max_epochs']}, min_epochs={plan['min_epochs']}, logger directory={log_dir!r}, {len(own)} user-defined callback(s)"
+                      f" (hooks: {', '.join(self._TRAINER_HOOKS)}).  Everything else it configures (accelerator, devices, strategy, precision, "
+                      "gradient clipping / accumulation, limit_*, profiler) is ignored"
+                      + (f"; Lightning's own callbacks are not run: {ignored}" if ignored else ""))
+        self.fit_trainer = trainer
+        return plan
+
+    @staticmethod
+    def _call_hooks(plan: tp.Optional[tp.Dict[str, tp.Any]], hook: str, lm: tp.Any, *args: tp.Any) -> None:
+        if plan is None:
+            return
+        for cb in plan["callbacks"]:
+            fn = getattr(cb, hook, None)
+            if callable(fn):
+                fn(plan["trainer"], lm, *args)
+
+    def _run_epochs(self, first: int, last: int, plan: tp.Optional[tp.Dict[str, tp.Any]] = None, min_last: tp.Optional[int] = None) -> None:
+        """Epochs first .. last - 1.  plan: `_trainer_plan()` of a user-built Trainer; min_last: with it, the epoch count after which
+        `trainer.should_stop` (set by a callback) ends training early."""
         lm, opt, dp = self.lightning_model, self.optimizer, self.data_preparator
         assert lm is not None and opt is not None
         device = next(lm.parameters()).device
+        if plan is not None and plan["log_dir"] and not self._params.get("csv_log_dir"):
+            self._params["csv_log_dir"] = plan["log_dir"]
+        verbose = self.verbose or (plan is not None and plan["progress"])
+        trainer = None if plan is None else plan["trainer"]
+        self._call_hooks(plan, "on_fit_start", lm)
+        self._call_hooks(plan, "on_train_start", lm)
         loop = self.training_loop()
         rank = loop.rank
         val_store = dp.val_store()
@@ -466,6 +567,7 @@ class TransformerModelBase:
         for epoch in range(first, last):
             lm.train()
             loop.begin_epoch(epoch)
+            self._call_hooks(plan, "on_train_epoch_start", lm)
             total = torch.zeros((), device=device)
             n_batches = 0
             while loop.batches_left() > 0:
@@ -476,21 +578,43 @@ class TransformerModelBase:
                 lm.eval()
                 vt, vn = torch.zeros((), device=device), 0
                 with torch.no_grad():
-                    for b0 in range(0, len(val_store), self.batch_size):
+                    if plan is not None and plan["callbacks"]:      # lightning.py:329-333: the catalog matrix a validation callback reads
+                        lm.item_embs = lm.torch_model.item_model.get_all_embeddings()
+                    self._call_hooks(plan, "on_validation_start", lm)
+                    for bi, b0 in enumerate(range(0, len(val_store), self.batch_size)):
                         vb = self._to_device(dp.collate_val(val_store, np.arange(b0, min(b0 + self.batch_size, len(val_store)))), device, True)
                         nb = int(vb["x"].shape[0])     # Lightning's epoch mean weights every batch by its size
-                        vt += lm.validation_loss(vb) * nb
+                        vloss = lm.validation_loss(vb)
+                        vt += vloss * nb
                         vn += nb
+                        self._call_hooks(plan, "on_validation_batch_end", lm, {"loss": vloss}, vb, bi)
+                    self._call_hooks(plan, "on_validation_epoch_end", lm)
+                    self._call_hooks(plan, "on_validation_end", lm)
+                    if hasattr(lm, "item_embs"):
+                        del lm.item_embs
                 rec[self.val_loss_name] = float(vt) / max(vn, 1)
+            rec.update({k: v for k, v in getattr(lm, "logged_metrics", {}).items() if k not in rec})   # what callbacks logged this epoch
             self.history.append(rec)
+            if plan is not None:          # the metrics a callback's early-stopping logic reads (Lightning: trainer.callback_metrics)
+                try:
+                    metrics = getattr(trainer, "callback_metrics", None)
+                    if isinstance(metrics, dict):
+                        metrics.update({k: torch.as_tensor(v) for k, v in rec.items() if k != "epoch"})
+                except Exception:      # a real Lightning Trainer's connector: read-only
+                    pass
+            self._call_hooks(plan, "on_train_epoch_end", lm)
             if rank == 0:
                 self._log_epoch(rec, opt.step_count)
-            if self.verbose and rank == 0:
+            if verbose and rank == 0:
                 print(rec)
             self.epochs_done = epoch + 1
+            if plan is not None and bool(getattr(trainer, "should_stop", False)) and self.epochs_done >= (min_last or first):
+                break
         # sharded data-parallel exchange: every rank holds only its slice of the Adam moments while training; gather them now, while
         # every rank is here and the process group is alive, so that saving / pickling afterwards is a local operation on any rank
         opt.consolidate_moments()
+        self._call_hooks(plan, "on_train_end", lm)
+        self._call_hooks(plan, "on_fit_end", lm)
 
     def _log_epoch(self, rec: tp.Dict[str, float], global_step: int) -> None:
         """Per-epoch metrics file in the layout of Lightning's CSVLogger (`<dir>/version_N/metrics.csv`, columns
@@ -523,7 +647,12 @@ class TransformerModelBase:
     def fit(self, dataset: tp.Any) -> "TransformerModelBase":
         """Fit from scratch (models/base.py:326-341 -> transformers/base.py:481-489)."""
         self._build_model_from_dataset(dataset)
-        self._run_epochs(0, self.epochs)
+        plan = self._trainer_plan()
+        if plan is None:
+            self._run_epochs(0, self.epochs)
+        else:     # the Trainer's epoch counts stand for the default trainer's max_epochs = min_epochs = self.epochs (base.py:369-371)
+            n = int(plan["max_epochs"]) if plan["max_epochs"] is not None and int(plan["max_epochs"]) >= 0 else self.epochs
+            self._run_epochs(0, n, plan, min_last=int(plan["min_epochs"] or 0))
         self.is_fitted = True
         return self
 
@@ -537,7 +666,8 @@ class TransformerModelBase:
             # rebuild its training sessions anyway (base.py:520-523).  The dataset must index the SAME embedding rows the weights
             # were trained on: checked on a copy of the preparator's state, committed only when it holds.
             self._reprocess_train_dataset(dataset)
-        self._run_epochs(self.epochs_done, self.epochs_done + max_epochs)
+        plan = self._trainer_plan()       # (epoch counts: the call's own arguments, transformers/base.py:527-529)
+        self._run_epochs(self.epochs_done, self.epochs_done + max_epochs, plan, min_last=self.epochs_done + min_epochs)
         self.is_fitted = True
         return self
 
@@ -549,6 +679,7 @@ class TransformerModelBase:
         same = getattr(self, "_train_data_ready", False) and getattr(self, "_train_dataset_ref", None) is dataset
         if same:
             return      # the very Dataset object the sessions were cut from (Datasets are immutable): nothing to redo
+        self._hand_prep_device()
         keep = ("item_id_map", "train_dataset", "extra_token_ids", "val_interactions", "_train_store")
         snapshot = {k: getattr(dp, k) for k in keep if hasattr(dp, k)}
         known = np.asarray(dp.item_id_map.external_ids)
@@ -992,7 +1123,7 @@ class TransformerModelBase:
         klass = _import_object(cfg.pop("cls", cls))
         for key in ("data_preparator_type", "transformer_layers_type", "similarity_module_type", "get_val_mask_func",
                     "item_net_constructor_type", "negative_sampler_type", "pos_encoding_type", "lightning_module_type",
-                    "backbone_type"):
+                    "backbone_type", "get_trainer_func"):
             if cfg.get(key) is not None:
                 cfg[key] = _import_object(cfg[key])
         if cfg.get("item_net_block_types") is not None:
@@ -1027,11 +1158,14 @@ class TransformerModelBase:
         config = ckpt.translate_config(dict(hyper["model_config"]))
         config.pop("cls", None)       # the class the method is called on decides (the reference stores a short name)
         if config.get("get_trainer_func") is not None:
-            # a reference checkpoint trained under a custom Lightning Trainer: weights, moments and config restore as they are, the
-            # trainer factory cannot (this engine has its own loop) — said aloud, never silently
-            warnings.warn(f"checkpoint names get_trainer_func={config['get_trainer_func']!r}: dropped, fit_partial() of the restored "
-                          f"model runs the engine's own training loop")
-            config["get_trainer_func"] = None
+            # a checkpoint trained under a user-built Trainer: the factory is restored when its dotted path imports here (fit_partial()
+            # of the restored model then reads it again, `_trainer_plan`), dropped aloud when it does not
+            try:
+                _import_object(config["get_trainer_func"])
+            except Exception:      # pylint: disable=broad-except
+                warnings.warn(f"checkpoint names get_trainer_func={config['get_trainer_func']!r}, which cannot be imported here: dropped, "
+                              f"fit_partial() of the restored model runs the engine's loop with the model's own epoch settings")
+                config["get_trainer_func"] = None
         loaded = cls.from_config(config)
         dp = loaded.data_preparator
         ext = hyper["item_external_ids"]

@@ -20,6 +20,7 @@ copy, item_net.py:361-368); with a category-feature block the catalog matrix is 
 """
 from __future__ import annotations
 
+import dataclasses
 import math
 import os
 import typing as tp
@@ -56,9 +57,10 @@ class LayerNormParams(nn.Module):
         self.weight = nn.Parameter(torch.ones(d))
         self.bias = nn.Parameter(torch.zeros(d))
         self.eps = eps
+        self.cols: tp.Optional[tp.Tuple[int, int]] = None    # (grp, grp_real) when the rows carry zero columns (`DimPlan`)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return ops.layer_norm(x, self.weight, self.bias, self.eps)
+        return ops.layer_norm(x, self.weight, self.bias, self.eps, self.cols)
 
 
 class MultiheadAttnParams(nn.Module):
@@ -72,19 +74,20 @@ class MultiheadAttnParams(nn.Module):
         nn.init.xavier_uniform_(self.in_proj_weight)
         nn.init.zeros_(self.out_proj.bias)
         self.d, self.n_heads = d, n_heads
+        self.scale = 0.0      # logit scale; 0 = 1 / sqrt(d / n_heads).  Heads padded with zero columns keep the scale of their real size
 
     def forward(self, q_in: torch.Tensor, kv_in: tp.Optional[torch.Tensor], ids: torch.Tensor, B: int, L: int,
                 causal: bool, keypad: bool, p: float, residual: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
         d = self.d
         if kv_in is None:  # self-attention on one input: one packed GEMM, one packed gradient
             qkv = ops.linear(q_in, self.in_proj_weight, self.in_proj_bias)
-            o = ops.mha_packed(qkv, ids, B, self.n_heads, L, causal, keypad, p)
+            o = ops.mha_packed(qkv, ids, B, self.n_heads, L, causal, keypad, p, self.scale)
             return self.out_proj(o, residual=residual)
         else:  # SASRec: Q from LN(x), K/V from x (sasrec.py:221-224)
             q = ops.linear(q_in, self.in_proj_weight[:d], self.in_proj_bias[:d])
             kv = ops.linear(kv_in, self.in_proj_weight[d:], self.in_proj_bias[d:])
             k, v = kv[:, :d], kv[:, d:]
-        o = ops.mha(q, k, v, ids, B, self.n_heads, L, causal, keypad, p)
+        o = ops.mha(q, k, v, ids, B, self.n_heads, L, causal, keypad, p, self.scale)
         return self.out_proj(o, residual=residual)
 
 
@@ -101,8 +104,8 @@ def _attend_last(mha: MultiheadAttnParams, kv_in: torch.Tensor, q_last: torch.Te
     kv = ops.linear(kv_in, mha.in_proj_weight[d:], mha.in_proj_bias[d:])          # [B*L, 2d]
     q = ops.linear(q_last, mha.in_proj_weight[:d], mha.in_proj_bias[:d])          # [B, d]
     out = torch.empty((B, d), dtype=torch.float32, device=q.device)
-    ops._c("rt_mha_last_fwd", q, d, kv, 2 * d, kv[:, d:], 2 * d, ids.reshape(-1), B, mha.n_heads, L, d // mha.n_heads,   # pylint: disable=protected-access
-           int(causal), int(keypad), out, d)
+    ops._c("rt_mha_last_fwd_scaled", q, d, kv, 2 * d, kv[:, d:], 2 * d, ids.reshape(-1), B, mha.n_heads, L, d // mha.n_heads,   # pylint: disable=protected-access
+           float(mha.scale), int(causal), int(keypad), out, d)
     return out
 
 
@@ -247,7 +250,7 @@ class LearnableInversePositionalEncoding(nn.Module):
         that extend the encoding and call `super().forward`."""
         _, L, d = sessions.shape
         if self.use_scale_factor:
-            sessions = sessions * (d ** 0.5)
+            sessions = sessions * (float(getattr(self, "d_real", None) or d) ** 0.5)
         if self.pos_emb is not None:
             sessions = sessions + self.pos_emb.weight[:L].flip(0)[None]
         return sessions
@@ -325,12 +328,13 @@ class SASRecTransformerLayer(nn.Module):
         self.ff_layer_norm = LayerNormParams(n_factors)
         self.feed_forward = PointWiseFeedForward(n_factors, n_factors, dropout_rate, "relu")
         self.p = dropout_rate
+        self.generic = False      # `DimPlan`: zero-padded columns -> the block runs out of the individual ops (column-aware LayerNorm)
 
     def forward(self, seqs, ids, B, L, causal, keypad):
         """`seqs` comes in unmasked: the timeline mask (sasrec.py:300) is the first step of the fused block."""
         p = self.p if self.training else 0.0
         ff = self.feed_forward
-        if ff.ff_linear_1.bias is not None and ff.ff_linear_2.bias is not None and ff.activation == "relu":
+        if not self.generic and ff.ff_linear_1.bias is not None and ff.ff_linear_2.bias is not None and ff.activation == "relu":
             mha = self.multi_head_attn
             return ops.sasrec_layer(
                 seqs, ids, B, L, mha.n_heads, causal, keypad, p,
@@ -343,7 +347,8 @@ class SASRecTransformerLayer(nn.Module):
     def forward_last(self, seqs, ids, B, L, causal, keypad):
         """Inference: the block's output at the last position of every session only, [B, d] (see ops.sasrec_layer_last)."""
         ff, mha = self.feed_forward, self.multi_head_attn
-        if self.training or torch.is_grad_enabled() or ff.ff_linear_1.bias is None or ff.ff_linear_2.bias is None or ff.activation != "relu":
+        if self.generic or self.training or torch.is_grad_enabled() or ff.ff_linear_1.bias is None or ff.ff_linear_2.bias is None \
+                or ff.activation != "relu":
             return self(seqs, ids, B, L, causal, keypad).view(B, L, -1)[:, -1, :].contiguous()
         return ops.sasrec_layer_last(
             seqs, ids, B, L, mha.n_heads, causal, keypad,
@@ -354,7 +359,7 @@ class SASRecTransformerLayer(nn.Module):
 
     def packed_ok(self) -> bool:
         ff = self.feed_forward
-        return ff.ff_linear_1.bias is not None and ff.ff_linear_2.bias is not None and ff.activation == "relu"
+        return not self.generic and ff.ff_linear_1.bias is not None and ff.ff_linear_2.bias is not None and ff.activation == "relu"
 
     def forward_packed(self, seqs, cu, B, window, pad_keys, last_rows=None, rows_real=None, planes=None):
         """Inference over packed sessions (no padding rows; see ops.sasrec_layer_packed): [Np, d], or [B, d] with `last_rows`."""
@@ -419,7 +424,7 @@ class SASRecTransformerLayers(TransformerLayersBase):
         for blk in self.transformer_blocks:
             seqs = blk(seqs, ids, B, L, causal, keypad)   # seqs *= timeline_mask (sasrec.py:300) happens inside
         ln = self.last_layernorm
-        return ops.layer_norm_masked(seqs, ids, ln.weight, ln.bias, ln.eps)   # seqs * mask, then the last LayerNorm
+        return ops.layer_norm_masked(seqs, ids, ln.weight, ln.bias, ln.eps, ln.cols)   # seqs * mask, then the last LayerNorm
 
     def forward_last(self, seqs, ids, B, L, causal, keypad, batch):
         """Inference: [B, d] encodings of the last position (what recommend() keeps of `encode_sessions`, lightning.py:393-397):
@@ -466,18 +471,19 @@ class PreLNTransformerLayer(nn.Module):
         self.layer_norm_2 = LayerNormParams(n_factors)
         self.feed_forward = PointWiseFeedForward(n_factors, n_factors * ff_factors_multiplier, dropout_rate, "gelu")
         self.p = dropout_rate
+        self.generic = False      # `DimPlan`: zero-padded columns (no packed rows, no native executor)
 
     def forward(self, seqs, ids, B, L, causal, keypad):
         p = self.p if self.training else 0.0
         ln1, ln2 = self.layer_norm_1, self.layer_norm_2
-        h, skip = ops.layer_norm_skip(seqs, ln1.weight, ln1.bias, ln1.eps)     # skip = seqs, its gradient rides in LN1's backward
+        h, skip = ops.layer_norm_skip(seqs, ln1.weight, ln1.bias, ln1.eps, ln1.cols)     # skip = seqs, its gradient rides in LN1's backward
         if p > 0:
             seqs = ops.dropout_add(self.multi_head_attn(h, None, ids, B, L, causal, keypad, p), skip, p)
-            g, skip = ops.layer_norm_skip(seqs, ln2.weight, ln2.bias, ln2.eps)
+            g, skip = ops.layer_norm_skip(seqs, ln2.weight, ln2.bias, ln2.eps, ln2.cols)
             seqs = ops.dropout_add(self.feed_forward(g), skip, p)
             return ops.dropout(seqs, p)  # dropout_3 (net_blocks.py:260)
         seqs = self.multi_head_attn(h, None, ids, B, L, causal, keypad, 0.0, residual=skip)
-        g, skip = ops.layer_norm_skip(seqs, ln2.weight, ln2.bias, ln2.eps)
+        g, skip = ops.layer_norm_skip(seqs, ln2.weight, ln2.bias, ln2.eps, ln2.cols)
         return self.feed_forward(g, residual=skip)
 
 
@@ -559,7 +565,7 @@ class PreLNTransformerLayers(TransformerLayersBase):
         re-masks the rows between Pre-LN blocks (net_blocks.py:290-310), so without the key-padding mask the pad rows carry state
         that real queries read, and the padded window has to stay."""
         blocks = list(self.transformer_blocks)
-        if not blocks or not keypad:
+        if not blocks or not keypad or any(b.generic for b in blocks):
             return False
         heads = blocks[0].multi_head_attn.n_heads
         return ops.mha_varlen_supported(heads, n_factors, window) if causal else ops.mha_bidir_supported(heads, n_factors, window)
@@ -594,15 +600,16 @@ class LiGRLayer(nn.Module):
         self.gating_linear_1 = LinearParams(n_factors, n_factors)
         self.gating_linear_2 = LinearParams(n_factors, n_factors)
         self.p = dropout_rate
+        self.generic = False      # `DimPlan`: zero-padded columns (no packed rows)
 
     def forward(self, seqs, ids, B, L, causal, keypad):
         p = self.p if self.training else 0.0
         ln1, ln2 = self.layer_norm_1, self.layer_norm_2
         g1, g2 = self.gating_linear_1, self.gating_linear_2
-        h, seqs = ops.layer_norm_skip(seqs, ln1.weight, ln1.bias, ln1.eps)   # the skip branch's gradient rides in LN1's backward
+        h, seqs = ops.layer_norm_skip(seqs, ln1.weight, ln1.bias, ln1.eps, ln1.cols)   # the skip branch's gradient rides in LN1's backward
         a = self.multi_head_attn(h, None, ids, B, L, causal, keypad, p)
         seqs = ops.gated_residual(seqs, g1.weight, g1.bias, a, p)    # seqs + sigmoid(Wg1 seqs + bg1) * drop(mha): one node
-        g, seqs = ops.layer_norm_skip(seqs, ln2.weight, ln2.bias, ln2.eps)
+        g, seqs = ops.layer_norm_skip(seqs, ln2.weight, ln2.bias, ln2.eps, ln2.cols)
         f = self.feed_forward(g)
         return ops.gated_residual(seqs, g2.weight, g2.bias, f, p)    # seqs + sigmoid(Wg2 seqs + bg2) * drop(ffn)
 
@@ -662,7 +669,8 @@ class LiGRLayers(TransformerLayersBase):
         """Packed rows serve the LiGR stack when pad positions are masked as keys (`use_key_padding_mask=True`): without the mask the
         pad rows of this stack carry state that real queries read (nothing re-zeroes them between blocks, ligr.py:161-191), and the
         padded window has to stay — which is the reference's default for SASRec-style models, eSASRec included."""
-        return bool(keypad) and len(self.transformer_blocks) > 0 and os.environ.get("RT_PACKED_LIGR", "1") != "0"
+        return bool(keypad) and len(self.transformer_blocks) > 0 and not any(b.generic for b in self.transformer_blocks) \
+            and os.environ.get("RT_PACKED_LIGR", "1") != "0"
 
     def forward_packed_train(self, seqs, cu, B, window, keypad, rows_real=None, causal=True):
         n_real = int(rows_real) if rows_real is not None else None
@@ -690,8 +698,7 @@ class RelativeAttentionBias(nn.Module):
     def __init__(self, session_max_len: int, relative_time_attention: bool, relative_pos_attention: bool,
                  num_buckets: int = 128) -> None:
         super().__init__()
-        if num_buckets != 128:
-            raise NotImplementedError("the HIP HSTU kernel is built for num_buckets = 128")
+        self.num_buckets = num_buckets      # any value: the kernels search the unclamped bucket, `ops.hstu_time_thresholds` carries the clamp
         if relative_time_attention:
             self.time_weights = nn.Parameter(torch.empty(num_buckets + 1).normal_(mean=0, std=0.02))
         if relative_pos_attention:
@@ -703,14 +710,18 @@ class RelativeAttentionBias(nn.Module):
 class STULayer(nn.Module):
     def __init__(self, n_factors: int, n_heads: int, linear_hidden_dim: int, attention_dim: int, session_max_len: int,
                  relative_time_attention: bool, relative_pos_attention: bool, attn_dropout_rate: float, dropout_rate: float,
-                 epsilon: float) -> None:
+                 epsilon: float, num_buckets: int = 128) -> None:
         super().__init__()
-        if linear_hidden_dim != attention_dim:
-            raise NotImplementedError("the HIP HSTU kernel needs linear_hidden_dim == attention_dim")
-        self.rel_attn = RelativeAttentionBias(session_max_len, relative_time_attention, relative_pos_attention)
+        # linear_hidden_dim != attention_dim: the kernels run ONE head size for u / v and q / k.  Such a block is a parameter holder only
+        # (the real-size twin of a `DimPlan` model: models._build_model_from_dataset pads both head sizes to one the kernels tile)
+        self.lin = linear_hidden_dim
+        self.generic = False      # `DimPlan`: zero-padded columns -> the block runs out of the individual ops
+        self.rel_attn = RelativeAttentionBias(session_max_len, relative_time_attention, relative_pos_attention, num_buckets)
         self.n_heads, self.hd, self.L = n_heads, attention_dim, session_max_len
-        self.uvqk_proj = nn.Parameter(torch.empty(n_factors, 4 * n_heads * attention_dim))
-        nn.init.normal_(self.uvqk_proj, std=0.02)
+        self.uvqk_proj = nn.Parameter(torch.empty(n_factors, 2 * n_heads * linear_hidden_dim + 2 * n_heads * attention_dim))
+        # the reference leaves this parameter uninitialised until xavier (hstu.py:207-214: torch.empty) and so draws nothing here; a private
+        # generator keeps the global stream where the reference's is (same seed -> same 1-D parameters as the reference's model)
+        nn.init.normal_(self.uvqk_proj, std=0.02, generator=torch.Generator().manual_seed(0))
         self.output_mlp = LinearParams(n_heads * linear_hidden_dim, n_factors)
         self.norm_input = LayerNormParams(n_factors, eps=epsilon)
         self.norm_attn_output = LayerNormParams(n_heads * linear_hidden_dim, eps=epsilon)
@@ -718,7 +729,10 @@ class STULayer(nn.Module):
 
     def forward(self, seqs, ids, B, L, batch, thr):
         """`seqs` comes in unmasked: the row mask (hstu.py:256) is the first step of the fused block."""
-        if self.output_mlp.bias is not None:
+        if self.lin != self.hd:
+            raise NotImplementedError("the HIP HSTU kernels run one head size for u / v and q / k: linear_hidden_dim != attention_dim runs "
+                                      "through `nn.DimPlan` (models.HSTUModel / transformer_layers_type=STULayers build it)")
+        if self.output_mlp.bias is not None and not self.generic:
             tw = self.rel_attn.time_weights if self.rel_attn.relative_time_attention else None
             pw = self.rel_attn.pos_weights if self.rel_attn.relative_pos_attention else None
             return ops.stu_layer(seqs, ids, batch.get("unix_ts") if tw is not None else None, thr, B, L, self.n_heads, self.hd,
@@ -732,6 +746,8 @@ class STULayer(nn.Module):
         """Inference: the block's output at the last position of every session, [B, d].  v and k are projected for every position
         (two column blocks of `uvqk_proj`, read in place through a row stride), u and q for the last row only; the attention of
         that row is `rt_hstu_attn_last_fwd`."""
+        if self.generic:
+            return _take_last(self(seqs, ids, B, L, batch, thr), B, L)
         hh, d = self.n_heads * self.hd, seqs.shape[1]
         M = seqs.shape[0]
         dev = seqs.device
@@ -801,13 +817,16 @@ class STULayer(nn.Module):
 class STULayers(TransformerLayersBase):
     def __init__(self, n_blocks: int, n_factors: int, n_heads: int, linear_hidden_dim: int, attention_dim: int,
                  session_max_len: int, relative_time_attention: bool, relative_pos_attention: bool,
-                 attn_dropout_rate: float = 0.0, dropout_rate: float = 0.2, epsilon: float = 1e-6, **kwargs: tp.Any) -> None:
+                 attn_dropout_rate: float = 0.0, dropout_rate: float = 0.2, epsilon: float = 1e-6, num_buckets: int = 128,
+                 **kwargs: tp.Any) -> None:
+        """num_buckets: `RelativeAttentionBias`'s (hstu.py:63-71; the reference's STULayer always builds it with the default 128)."""
         super().__init__()
         self.n_blocks = n_blocks
         self.stu_blocks = nn.ModuleList([
             STULayer(n_factors, n_heads, linear_hidden_dim, attention_dim, session_max_len, relative_time_attention,
-                     relative_pos_attention, attn_dropout_rate, dropout_rate, epsilon) for _ in range(n_blocks)])
-        self.register_buffer("time_thr", ops.hstu_time_thresholds(), persistent=False)
+                     relative_pos_attention, attn_dropout_rate, dropout_rate, epsilon, num_buckets) for _ in range(n_blocks)])
+        nb = self.stu_blocks[0].rel_attn.num_buckets if n_blocks > 0 else 128
+        self.register_buffer("time_thr", ops.hstu_time_thresholds(nb), persistent=False)
 
     def forward(self, seqs, ids, B, L, causal, keypad, batch):
         for blk in self.stu_blocks:
@@ -826,7 +845,8 @@ class STULayers(TransformerLayersBase):
         """Packed rows serve the STU stack as it is: pad rows are zeroed before every bias-free projection, so they add nothing to a
         real row (`STULayer.forward_packed`)."""
         blocks = list(self.stu_blocks)
-        return bool(blocks) and ops.hstu_varlen_supported(blocks[0].n_heads, blocks[0].hd, window) and window == blocks[0].L
+        return bool(blocks) and not any(b.generic for b in blocks) and ops.hstu_varlen_supported(blocks[0].n_heads, blocks[0].hd, window) \
+            and window == blocks[0].L
 
     def forward_packed_train(self, seqs, cu, B, window, keypad, rows_real=None, causal=True, ts=None):
         for blk in self.stu_blocks:
@@ -905,6 +925,13 @@ class TransformerTorchBackbone(nn.Module):
         self.use_key_padding_mask = use_key_padding_mask
         self.n_heads = n_heads
         self.dropout_rate = dropout_rate
+        self.d_real: tp.Optional[int] = None     # `DimPlan`: n_factors of the model when the tables carry zero columns behind it
+
+    def _pos_scale(self, table: torch.Tensor) -> float:
+        """sqrt(n_factors) of `use_scale_factor` (net_blocks.py:390-391) — of the model's width, not of a zero-padded table's."""
+        if not self.pos_encoding_layer.use_scale_factor:
+            return 1.0
+        return float(self.d_real if self.d_real is not None else table.shape[1]) ** 0.5
 
     def _fused_pos(self) -> bool:
         """The stock positional encoding (scale + inverse learnable rows) is fused into `rt_embed_fwd`; any other class plugged
@@ -918,8 +945,7 @@ class TransformerTorchBackbone(nn.Module):
         d = table.shape[1]
         if self._fused_pos():
             pos = self.pos_encoding_layer.pos_emb.weight if self.pos_encoding_layer.pos_emb is not None else None
-            scale = float(d) ** 0.5 if self.pos_encoding_layer.use_scale_factor else 1.0
-            return ops.embed(table, pos, ids, L, scale, p)
+            return ops.embed(table, pos, ids, L, self._pos_scale(table), p)
         seqs = ops.embed(table, None, ids, L, 1.0, 0.0).view(B, L, d)
         seqs = self.pos_encoding_layer(seqs).reshape(B * L, d)
         return ops.dropout(seqs, p) if p > 0 else seqs
@@ -973,7 +999,7 @@ class TransformerTorchBackbone(nn.Module):
         else:
             ids, dist = ops.collate_packed_bert(offsets, items, None, rows, cu, Np, window, False, mask_id)
         pos = self.pos_encoding_layer.pos_emb.weight if self.pos_encoding_layer.pos_emb is not None else None
-        scale = float(d) ** 0.5 if self.pos_encoding_layer.use_scale_factor else 1.0
+        scale = self._pos_scale(table)
         x = torch.empty((Np, d), dtype=torch.float32, device=table.device)
         ops._c("rt_embed_packed_fwd", ids, dist, table, pos, float(scale), Np, d, 0.0, 0, 0, x)
         kw = {}
@@ -989,8 +1015,7 @@ class TransformerTorchBackbone(nn.Module):
         pass (`ops.embed_packed`): embedding rows (pad id 0 has no gradient), positional rows by the distance from the session's
         end, the embedding dropout (torch_backbone.py:245-247)."""
         table = self.item_model.table if item_embs is None else item_embs
-        d = table.shape[1]
-        scale = float(d) ** 0.5 if self.pos_encoding_layer.use_scale_factor else 1.0
+        scale = self._pos_scale(table)
         pos = self.pos_encoding_layer.pos_emb.weight if self.pos_encoding_layer.pos_emb is not None else None
         seqs = ops.embed_packed(table, pos, ids, dist, cu, B, window, scale, self.dropout_rate if self.training else 0.0)
         if cu_attn is not None and rows_real is not None:
@@ -1014,3 +1039,169 @@ class TransformerTorchBackbone(nn.Module):
         ids = x.reshape(-1)
         seqs = self._embed_sessions(table, ids, B, L, 0.0)
         return fast(seqs, ids, B, L, self.use_causal_attn, self.use_key_padding_mask, batch)
+
+
+# ---- models whose width / head size the kernels cannot tile: zero-padded columns ---------------------------------------------------
+@dataclasses.dataclass(frozen=True)
+class DimPlan:
+    """The reference accepts any `n_factors % n_heads == 0` (nn.MultiheadAttention's own check; hstu.py:606-607) — its published HSTU
+    quality numbers come from n_factors = 50 with 1 and 2 heads.  The kernels move float4 columns and tile heads in
+    8-column groups.  A `DimPlan` runs such a model at sizes the kernels tile, EXACTLY: every activation row and every parameter carries
+    zero columns / rows behind its real ones, head by head —
+
+      * a zero column of the residual stream meets zero weight columns in every product and stays zero through every skip connection;
+        LayerNorm takes its statistics over the real columns only and writes zeros to the others (`rt_layernorm_*_cols`);
+      * zero q / k columns add nothing to a logit (softmax scale = 1 / sqrt(REAL head size): `rt_mha_*_scaled`), zero v columns give zero
+        output columns; relu / gelu / silu / SwiGLU map 0 to 0, a sigmoid gate multiplies a zero branch;
+      * every gradient of a padded entry is a product with one of those zeros, so Adam (m = v = 0 -> update 0) keeps them at zero.
+
+    `state_dict()` / `load_state_dict()` / the checkpoints' Adam state speak the REAL shapes (hooks below): reference checkpoints
+    interchange.  Initialisation happens at the real shapes (models._build_model_from_dataset builds the real-size twin on the host)."""
+    d: int                # n_factors
+    d_pad: int
+    n_heads: int
+    qk: int               # real head size of q / k (softmax stacks: n_factors // n_heads; STU: attention_dim)
+    vo: int               # real head size of v / the attention output (STU: linear_hidden_dim)
+    hd_pad: int           # the head size the kernels run, both kinds
+    kind: str             # "mha" (SASRec / Pre-LN / LiGR blocks) | "stu"
+
+    @property
+    def row_cols(self) -> tp.Optional[tp.Tuple[int, int]]:
+        return None if self.d_pad == self.d else (self.d_pad, self.d)
+
+    @property
+    def head_cols(self) -> tp.Optional[tp.Tuple[int, int]]:
+        return None if self.hd_pad == self.vo else (self.hd_pad, self.vo)
+
+    @staticmethod
+    def make(n_factors: int, n_heads: int, kind: str = "mha", linear_hidden_dim: tp.Optional[int] = None,
+             attention_dim: tp.Optional[int] = None) -> tp.Optional["DimPlan"]:
+        """None when the kernels tile the model as it is."""
+        up8 = lambda n: (n + 7) // 8 * 8  # noqa: E731
+        hd = n_factors // n_heads
+        if kind == "mha":
+            if hd % 8 == 0 and hd <= 128:
+                return None
+            plan = DimPlan(n_factors, n_heads * up8(hd), n_heads, hd, hd, up8(hd), "mha")
+        else:
+            lin = hd if linear_hidden_dim is None else int(linear_hidden_dim)
+            att = hd if attention_dim is None else int(attention_dim)
+            if lin == att and lin % 8 == 0 and lin <= 128 and n_factors % 4 == 0:
+                return None
+            plan = DimPlan(n_factors, n_factors if n_factors % 4 == 0 else up8(n_factors), n_heads, att, lin, up8(max(lin, att)), "stu")
+        if plan.hd_pad > 128:
+            raise NotImplementedError(f"the HIP attention kernels hold a head of at most 128 columns; got a head size of {max(plan.qk, plan.vo)} "
+                                      f"(n_factors={n_factors}, n_heads={n_heads}): use more heads")
+        return plan
+
+    # real position -> padded position, per axis kind
+    def axis(self, kind: tp.Optional[str], n_pad: int) -> tp.Optional[torch.Tensor]:
+        H, hp = self.n_heads, self.hd_pad
+        heads = lambda r, base=0: (base + torch.arange(H)[:, None] * hp + torch.arange(r)[None, :]).reshape(-1)  # noqa: E731
+        if kind is None:
+            return None
+        if kind == "D":
+            return torch.arange(self.d)
+        if kind == "F":           # hidden width of a feed-forward: multiplier x n_factors
+            return torch.arange(n_pad // self.d_pad * self.d)
+        if kind == "HV":
+            return heads(self.vo)
+        if kind == "QKV":         # nn.MultiheadAttention's packed in_proj: q | k | v, each H heads
+            return torch.cat([heads(self.qk, i * H * hp) for i in range(3)])
+        if kind == "UVQK":        # hstu.py:259-262: u | v (linear_hidden_dim) | q | k (attention_dim)
+            return torch.cat([heads(self.vo, 0), heads(self.vo, H * hp), heads(self.qk, 2 * H * hp), heads(self.qk, 3 * H * hp)])
+        raise ValueError(kind)
+
+
+def _set_axes(plan: DimPlan, p: tp.Optional[torch.Tensor], *kinds: tp.Optional[str]) -> None:
+    if p is None:
+        return
+    axes = tuple(plan.axis(k, int(n)) for k, n in zip(kinds, p.shape))
+    if all(a is None or int(a.numel()) == int(n) for a, n in zip(axes, p.shape)):
+        return        # nothing padded on any axis of this parameter
+    p._rt_axes = axes                                                           # pylint: disable=protected-access
+    p._rt_real_shape = tuple(int(n) if a is None else int(a.numel()) for a, n in zip(axes, p.shape))   # pylint: disable=protected-access
+
+
+def unpad_tensor(t: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+    """The REAL entries of `t` (shaped like the padded parameter `like`); `t` itself when `like` carries no padding."""
+    axes = getattr(like, "_rt_axes", None)
+    if axes is None:
+        return t
+    for dim, idx in enumerate(axes):
+        if idx is not None:
+            t = t.index_select(dim, idx.to(t.device))
+    return t
+
+
+def pad_tensor(real: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+    """`real` (the parameter's real shape) placed into zeros of the padded parameter's shape; `real` itself without padding."""
+    axes = getattr(like, "_rt_axes", None)
+    if axes is None:
+        return real
+    if tuple(real.shape) != tuple(like._rt_real_shape):      # pylint: disable=protected-access
+        raise ValueError(f"expected a tensor of shape {tuple(like._rt_real_shape)}, got {tuple(real.shape)}")   # pylint: disable=protected-access
+    out = torch.zeros(tuple(like.shape), dtype=real.dtype, device=real.device)
+    index = []
+    for dim, (idx, n) in enumerate(zip(axes, like.shape)):
+        ix = (torch.arange(n) if idx is None else idx).to(real.device)
+        index.append(ix.view([-1 if i == dim else 1 for i in range(len(axes))]))
+    out[tuple(index)] = real
+    return out
+
+
+def _unpad_state_hook(module: nn.Module, state_dict: tp.Dict[str, torch.Tensor], prefix: str, local_metadata: tp.Any) -> None:
+    for name, p in module.named_parameters():
+        if getattr(p, "_rt_axes", None) is not None and prefix + name in state_dict:
+            state_dict[prefix + name] = unpad_tensor(state_dict[prefix + name], p)
+
+
+def _pad_state_hook(module: nn.Module, state_dict: tp.Dict[str, torch.Tensor], prefix: str, *args: tp.Any) -> None:
+    for name, p in module.named_parameters():
+        t = state_dict.get(prefix + name)
+        if t is not None and getattr(p, "_rt_axes", None) is not None and tuple(t.shape) != tuple(p.shape):
+            state_dict[prefix + name] = pad_tensor(t, p)
+
+
+def apply_dim_plan(backbone: "TransformerTorchBackbone", plan: DimPlan) -> None:
+    """Mark a backbone BUILT AT THE PADDED SIZES (n_factors = plan.d_pad; STU head sizes = plan.hd_pad) as carrying zero columns: which
+    entries of every parameter are real, the column patterns of its LayerNorms, the softmax scale of its real head size, the generic
+    (op-by-op, padded-window) form of its blocks, and the state-dict hooks that translate to and from the real shapes."""
+    row, head = plan.row_cols, plan.head_cols
+    backbone.d_real = plan.d
+    if backbone.pos_encoding_layer is not None:
+        backbone.pos_encoding_layer.d_real = plan.d
+    for m in backbone.modules():
+        if isinstance(m, EmbeddingParams):                    # item ids, category values, positions: [n, n_factors]
+            _set_axes(plan, m.weight, None, "D")
+        elif isinstance(m, LayerNormParams):
+            m.cols = row
+            _set_axes(plan, m.weight, "D"); _set_axes(plan, m.bias, "D")
+        elif isinstance(m, MultiheadAttnParams):
+            m.scale = 1.0 / math.sqrt(plan.qk)
+            _set_axes(plan, m.in_proj_weight, "QKV", "D"); _set_axes(plan, m.in_proj_bias, "QKV")
+            _set_axes(plan, m.out_proj.weight, "D", "HV"); _set_axes(plan, m.out_proj.bias, "D")
+        elif isinstance(m, (PointWiseFeedForward, SwigluFeedForward)):
+            for lin in (m.ff_linear_1, getattr(m, "ff_linear_3", None)):
+                if lin is not None:
+                    _set_axes(plan, lin.weight, "F", "D"); _set_axes(plan, lin.bias, "F")
+            _set_axes(plan, m.ff_linear_2.weight, "D", "F"); _set_axes(plan, m.ff_linear_2.bias, "D")
+        if isinstance(m, LiGRLayer):
+            for lin in (m.gating_linear_1, m.gating_linear_2):
+                _set_axes(plan, lin.weight, "D", "D"); _set_axes(plan, lin.bias, "D")
+        if isinstance(m, (SASRecTransformerLayer, PreLNTransformerLayer, LiGRLayer, STULayer)):
+            m.generic = True
+    for m in backbone.modules():      # (after the generic pass: the STU block's second LayerNorm runs over the heads' columns)
+        if isinstance(m, STULayer):
+            _set_axes(plan, m.uvqk_proj, "D", "UVQK")
+            _set_axes(plan, m.output_mlp.weight, "D", "HV"); _set_axes(plan, m.output_mlp.bias, "D")
+            ln = m.norm_attn_output
+            ln.cols = head
+            for t in (ln.weight, ln.bias):
+                for attr in ("_rt_axes", "_rt_real_shape"):
+                    if hasattr(t, attr):
+                        delattr(t, attr)
+                _set_axes(plan, t, "HV")
+    backbone.register_state_dict_post_hook(_unpad_state_hook)
+    backbone.register_load_state_dict_pre_hook(_pad_state_hook)
+    backbone.dim_plan = plan

@@ -639,16 +639,37 @@ def item_table(ids_emb: tp.Optional[torch.Tensor], cat_emb: torch.Tensor, bag: B
     return _ItemTable.apply(ids_emb, cat_emb, bag, p)
 
 
+def _ln_fwd(x, ids, w, b, eps, M, d, x0, y, mean, rstd, cols):
+    """One LayerNorm forward launch.  cols = (grp, grp_real): the rows carry zero columns — column c exists iff c % grp < grp_real
+    (`nn.DimPlan`: a model width / head size the kernels cannot tile runs padded) — statistics over the real columns only."""
+    if cols is not None:
+        _c("rt_layernorm_fwd_cols", x, ids, w, b, float(eps), M, d, int(cols[0]), int(cols[1]), x0, y, mean, rstd)
+    elif ids is not None:
+        _c("rt_layernorm_fwd_masked", x, ids, w, b, float(eps), M, d, x0, y, mean, rstd)
+    else:
+        _c("rt_layernorm_fwd", x, w, b, float(eps), M, d, y, mean, rstd)
+
+
+def _ln_bwd(dy, x, w, mean, rstd, res, ids, mask_dy, mask_dx, M, d, dx, dw, db, cols):
+    ws_bytes = _lib.load().rt_layernorm_bwd_workspace_bytes(M, d)
+    ws = torch.empty((max(ws_bytes, 4),), dtype=torch.uint8, device=x.device)
+    if cols is not None:
+        _c("rt_layernorm_bwd_cols", dy, x, w, mean, rstd, res, ids, mask_dy, mask_dx, M, d, int(cols[0]), int(cols[1]), dx, dw, db, ws, ws_bytes)
+    else:
+        _c("rt_layernorm_bwd_fused", dy, x, w, mean, rstd, res, ids, mask_dy, mask_dx, M, d, dx, dw, db, ws, ws_bytes)
+
+
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, eps):
+    def forward(ctx, x, w, b, eps, cols=None):
         x = x.contiguous()
         M, d = x.shape
         y = torch.empty_like(x)
         mean = torch.empty((M,), dtype=torch.float32, device=x.device)
         rstd = torch.empty((M,), dtype=torch.float32, device=x.device)
-        _c("rt_layernorm_fwd", x, w, b, float(eps), M, d, y, mean, rstd)
+        _ln_fwd(x, None, w, b, eps, M, d, None, y, mean, rstd, cols)
         ctx.save_for_backward(x, w, mean, rstd)
+        ctx.cols = cols
         return y
 
     @staticmethod
@@ -659,10 +680,8 @@ class _LayerNorm(torch.autograd.Function):
         dx = torch.empty_like(x)
         dw = torch.empty_like(w)
         db = torch.empty_like(w)
-        ws_bytes = _lib.load().rt_layernorm_bwd_workspace_bytes(M, d)
-        ws = torch.empty((max(ws_bytes, 4),), dtype=torch.uint8, device=x.device)
-        _c("rt_layernorm_bwd", dy, x, w, mean, rstd, M, d, dx, dw, db, ws, ws_bytes)
-        return dx, dw, db, None
+        _ln_bwd(dy, x, w, mean, rstd, None, None, 0, 0, M, d, dx, dw, db, ctx.cols)
+        return dx, dw, db, None, None
 
 
 class _LayerNormMasked(torch.autograd.Function):
@@ -670,14 +689,15 @@ class _LayerNormMasked(torch.autograd.Function):
     LayerNorm kernels: forward reads x once, backward writes the masked dx directly."""
 
     @staticmethod
-    def forward(ctx, x, ids, w, b, eps):
+    def forward(ctx, x, ids, w, b, eps, cols=None):
         x = x.contiguous()
         M, d = x.shape
         x0, y = torch.empty_like(x), torch.empty_like(x)
         mean = torch.empty((M,), dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
-        _c("rt_layernorm_fwd_masked", x, ids, w, b, float(eps), M, d, x0, y, mean, rstd)
+        _ln_fwd(x, ids, w, b, eps, M, d, x0, y, mean, rstd, cols)
         ctx.save_for_backward(x0, ids, w, mean, rstd)
+        ctx.cols = cols
         return y
 
     @staticmethod
@@ -686,14 +706,13 @@ class _LayerNormMasked(torch.autograd.Function):
         M, d = x0.shape
         dy = dy.contiguous()
         dx, dw, db = torch.empty_like(x0), torch.empty_like(w), torch.empty_like(w)
-        ws_bytes = _lib.load().rt_layernorm_bwd_workspace_bytes(M, d)
-        ws = torch.empty((max(ws_bytes, 4),), dtype=torch.uint8, device=x0.device)
-        _c("rt_layernorm_bwd_fused", dy, x0, w, mean, rstd, None, ids, 0, 1, M, d, dx, dw, db, ws, ws_bytes)
-        return dx, None, dw, db, None
+        _ln_bwd(dy, x0, w, mean, rstd, None, ids, 0, 1, M, d, dx, dw, db, ctx.cols)
+        return dx, None, dw, db, None, None
 
 
-def layer_norm_masked(x: torch.Tensor, ids: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float) -> torch.Tensor:
-    return _LayerNormMasked.apply(_chk(x, "layer_norm_masked"), ids.reshape(-1), w, b, eps)
+def layer_norm_masked(x: torch.Tensor, ids: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float,
+                      cols: tp.Optional[tp.Tuple[int, int]] = None) -> torch.Tensor:
+    return _LayerNormMasked.apply(_chk(x, "layer_norm_masked"), ids.reshape(-1), w, b, eps, cols)
 
 
 class _LayerNormSkip(torch.autograd.Function):
@@ -702,14 +721,15 @@ class _LayerNormSkip(torch.autograd.Function):
     consumers."""
 
     @staticmethod
-    def forward(ctx, x, w, b, eps):
+    def forward(ctx, x, w, b, eps, cols=None):
         x = x.contiguous()
         M, d = x.shape
         y = torch.empty_like(x)
         mean = torch.empty((M,), dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
-        _c("rt_layernorm_fwd", x, w, b, float(eps), M, d, y, mean, rstd)
+        _ln_fwd(x, None, w, b, eps, M, d, None, y, mean, rstd, cols)
         ctx.save_for_backward(x, w, mean, rstd)
+        ctx.cols = cols
         return y, x.view_as(x)
 
     @staticmethod
@@ -717,19 +737,18 @@ class _LayerNormSkip(torch.autograd.Function):
         x, w, mean, rstd = ctx.saved_tensors
         M, d = x.shape
         if dy is None:
-            return dskip, None, None, None
+            return dskip, None, None, None, None
         dy = dy.contiguous()
         res = None if dskip is None else dskip.contiguous()
         dx, dw, db = torch.empty_like(x), torch.empty_like(w), torch.empty_like(w)
-        ws_bytes = _lib.load().rt_layernorm_bwd_workspace_bytes(M, d)
-        ws = torch.empty((max(ws_bytes, 4),), dtype=torch.uint8, device=x.device)
-        _c("rt_layernorm_bwd_fused", dy, x, w, mean, rstd, res, None, 0, 0, M, d, dx, dw, db, ws, ws_bytes)
-        return dx, dw, db, None
+        _ln_bwd(dy, x, w, mean, rstd, res, None, 0, 0, M, d, dx, dw, db, ctx.cols)
+        return dx, dw, db, None, None
 
 
-def layer_norm_skip(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float) -> tp.Tuple[torch.Tensor, torch.Tensor]:
+def layer_norm_skip(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float,
+                    cols: tp.Optional[tp.Tuple[int, int]] = None) -> tp.Tuple[torch.Tensor, torch.Tensor]:
     """-> (LayerNorm(x), x'): use x' for the skip connection / every other consumer of x."""
-    return _LayerNormSkip.apply(_chk(x, "layer_norm_skip"), w, b, eps)
+    return _LayerNormSkip.apply(_chk(x, "layer_norm_skip"), w, b, eps, cols)
 
 
 class _DropoutAdd(torch.autograd.Function):
@@ -760,8 +779,8 @@ def dropout_add(x: torch.Tensor, residual: torch.Tensor, p: float) -> torch.Tens
     return _DropoutAdd.apply(_chk(x, "dropout_add"), residual, p)
 
 
-def layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float) -> torch.Tensor:
-    return _LayerNorm.apply(x, w, b, eps)
+def layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float, cols: tp.Optional[tp.Tuple[int, int]] = None) -> torch.Tensor:
+    return _LayerNorm.apply(x, w, b, eps, cols)
 
 
 class _ActDropout(torch.autograd.Function):
@@ -963,7 +982,7 @@ def l2norm(x: torch.Tensor) -> torch.Tensor:
 # --------------------------------------------------------------------------------------------------
 class _MHA(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, ids, B, H, L, causal, keypad, p):
+    def forward(ctx, q, k, v, ids, B, H, L, causal, keypad, p, scale=0.0):
         d = q.shape[1]
         hd = d // H
         o = torch.empty((B * L, d), dtype=torch.float32, device=q.device)
@@ -972,29 +991,30 @@ class _MHA(torch.autograd.Function):
         if p > 0:
             s0, sid = RNG.next()
             seed = (s0 + 0xD1B54A32D192ED03 * sid) & 0xFFFFFFFFFFFFFFFF
-        _c("rt_mha_fwd", q, q.stride(0), k, k.stride(0), v, v.stride(0), ids, B, H, L, hd, int(causal), int(keypad),
+        _c("rt_mha_fwd_scaled", q, q.stride(0), k, k.stride(0), v, v.stride(0), ids, B, H, L, hd, float(scale), int(causal), int(keypad),
            float(p), seed, o, d, lse)
         ctx.save_for_backward(q, k, v, o, lse, ids)
-        ctx.meta = (B, H, L, hd, causal, keypad, p, seed)
+        ctx.meta = (B, H, L, hd, causal, keypad, p, seed, scale)
         return o
 
     @staticmethod
     def backward(ctx, do):
         q, k, v, o, lse, ids = ctx.saved_tensors
-        B, H, L, hd, causal, keypad, p, seed = ctx.meta
+        B, H, L, hd, causal, keypad, p, seed, scale = ctx.meta
         d = H * hd
         do = do.contiguous()
         dqkv = torch.empty((3, B * L, d), dtype=torch.float32, device=do.device)
         delta = torch.empty((B, H, L), dtype=torch.float32, device=do.device)
-        _c("rt_mha_bwd", q, q.stride(0), k, k.stride(0), v, v.stride(0), o, d, do, d, lse, ids, B, H, L, hd, int(causal),
+        _c("rt_mha_bwd_scaled", q, q.stride(0), k, k.stride(0), v, v.stride(0), o, d, do, d, lse, ids, B, H, L, hd, float(scale), int(causal),
            int(keypad), float(p), seed, dqkv[0], d, dqkv[1], d, dqkv[2], d, delta)
-        return dqkv[0], dqkv[1], dqkv[2], None, None, None, None, None, None, None
+        return dqkv[0], dqkv[1], dqkv[2], None, None, None, None, None, None, None, None
 
 
 def mha(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, ids: torch.Tensor, B: int, H: int, L: int, causal: bool,
-        keypad: bool, p: float) -> torch.Tensor:
-    """Softmax attention over [B*L, d] projections (column slices of packed buffers are fine)."""
-    return _MHA.apply(q, k, v, ids.reshape(-1), B, H, L, causal, keypad, p)
+        keypad: bool, p: float, scale: float = 0.0) -> torch.Tensor:
+    """Softmax attention over [B*L, d] projections (column slices of packed buffers are fine).  scale: the logit scale (0 = 1 / sqrt(head
+    size): `torch.nn.MultiheadAttention`'s; a head padded with zero columns passes the scale of its real size)."""
+    return _MHA.apply(q, k, v, ids.reshape(-1), B, H, L, causal, keypad, p, scale)
 
 
 class _MHAPacked(torch.autograd.Function):
@@ -1003,7 +1023,7 @@ class _MHAPacked(torch.autograd.Function):
     zero-filled [M, 3d] buffers, copies a slice into each and adds them (5 % of the BERT4Rec step in at:: kernels)."""
 
     @staticmethod
-    def forward(ctx, qkv, ids, B, H, L, causal, keypad, p):
+    def forward(ctx, qkv, ids, B, H, L, causal, keypad, p, scale=0.0):
         M, d3 = qkv.shape
         d = d3 // 3
         hd = d // H
@@ -1013,29 +1033,30 @@ class _MHAPacked(torch.autograd.Function):
         if p > 0:
             s0, sid = RNG.next()
             seed = (s0 + 0xD1B54A32D192ED03 * sid) & 0xFFFFFFFFFFFFFFFF
-        _c("rt_mha_fwd", qkv, d3, qkv[:, d:], d3, qkv[:, 2 * d:], d3, ids, B, H, L, hd, int(causal), int(keypad), float(p), seed, o, d,
-           lse)
+        _c("rt_mha_fwd_scaled", qkv, d3, qkv[:, d:], d3, qkv[:, 2 * d:], d3, ids, B, H, L, hd, float(scale), int(causal), int(keypad), float(p),
+           seed, o, d, lse)
         ctx.save_for_backward(qkv, o, lse, ids)
-        ctx.meta = (B, H, L, hd, causal, keypad, p, seed)
+        ctx.meta = (B, H, L, hd, causal, keypad, p, seed, scale)
         return o
 
     @staticmethod
     def backward(ctx, do):
         qkv, o, lse, ids = ctx.saved_tensors
-        B, H, L, hd, causal, keypad, p, seed = ctx.meta
+        B, H, L, hd, causal, keypad, p, seed, scale = ctx.meta
         d = H * hd
         d3 = 3 * d
         do = do.contiguous()
         g = torch.empty_like(qkv)
         delta = torch.empty((B, H, L), dtype=torch.float32, device=do.device)
-        _c("rt_mha_bwd", qkv, d3, qkv[:, d:], d3, qkv[:, 2 * d:], d3, o, d, do, d, lse, ids, B, H, L, hd, int(causal), int(keypad),
-           float(p), seed, g, d3, g[:, d:], d3, g[:, 2 * d:], d3, delta)
-        return g, None, None, None, None, None, None, None
+        _c("rt_mha_bwd_scaled", qkv, d3, qkv[:, d:], d3, qkv[:, 2 * d:], d3, o, d, do, d, lse, ids, B, H, L, hd, float(scale), int(causal),
+           int(keypad), float(p), seed, g, d3, g[:, d:], d3, g[:, 2 * d:], d3, delta)
+        return g, None, None, None, None, None, None, None, None
 
 
-def mha_packed(qkv: torch.Tensor, ids: torch.Tensor, B: int, H: int, L: int, causal: bool, keypad: bool, p: float) -> torch.Tensor:
-    """Softmax self-attention over a packed [B*L, 3d] projection (q | k | v column blocks)."""
-    return _MHAPacked.apply(_chk(qkv, "mha_packed").contiguous(), ids.reshape(-1), B, H, L, causal, keypad, p)
+def mha_packed(qkv: torch.Tensor, ids: torch.Tensor, B: int, H: int, L: int, causal: bool, keypad: bool, p: float,
+               scale: float = 0.0) -> torch.Tensor:
+    """Softmax self-attention over a packed [B*L, 3d] projection (q | k | v column blocks); scale as `mha`."""
+    return _MHAPacked.apply(_chk(qkv, "mha_packed").contiguous(), ids.reshape(-1), B, H, L, causal, keypad, p, scale)
 
 
 class _SASRecLayer(torch.autograd.Function):
@@ -1778,30 +1799,38 @@ def sasrec_layer_packed(x: torch.Tensor, cu: torch.Tensor, B: int, H: int, windo
     return out
 
 
+HSTU_BUCKETS = 147      # csrc NBUCK: every bucket an int64 difference can reach (ln(2^63) / 0.301 = 145.08 -> buckets 0 .. 145, and one spare)
+
+
 def hstu_time_thresholds(num_buckets: int = 128) -> torch.Tensor:
-    """thr[b] = smallest |dt| >= 0 whose reference bucket clamp(trunc(log(max(1,|dt|)) / 0.301), 0, nb) is >= b.
+    """[148] int64: thr[b] (b < 147) = smallest |dt| >= 0 whose UNCLAMPED reference bucket trunc(log(max(1,|dt|)) / 0.301) is >= b, and behind
+    them the number of entries of the model's `time_weights` the kernels may index (num_buckets + 1, at most 146).  The kernels find the unclamped bucket and read
+    the weight of min(bucket, num_buckets): the reference's clamp(bucket, 0, num_buckets) (hstu.py:84-86) for ANY `num_buckets`.
 
-    Computed with the reference's own float32 torch ops (hstu.py:84-86) so that bucket edges are bit-identical.
+    Computed with the reference's own float32 torch ops so that bucket edges are bit-identical.
     """
-    def bucket(x: torch.Tensor) -> torch.Tensor:
-        return torch.clamp((torch.log(torch.abs(x).clamp(min=1)) / 0.301).long(), 0, num_buckets)
+    top = HSTU_BUCKETS - 1
+    i64max = torch.iinfo(torch.int64).max
 
-    thr = torch.zeros(num_buckets + 1, dtype=torch.int64)
-    for b in range(1, num_buckets + 1):
-        guess = math.exp(0.301 * b)
-        if guess > 4e18:
-            thr[b] = torch.iinfo(torch.int64).max
+    def bucket(x: int) -> int:
+        return int(torch.clamp((torch.log(torch.abs(torch.tensor([x])).clamp(min=1)) / 0.301).long(), 0, top)[0])
+
+    reach = bucket(i64max)       # 145: the last bucket any difference falls in
+    thr = torch.zeros(HSTU_BUCKETS + 1, dtype=torch.int64)
+    for b in range(1, top + 1):
+        if b > reach:
+            thr[b] = i64max
             continue
-        lo, hi = max(1, int(guess * 0.5)), int(guess * 2.0) + 2
-        while int(bucket(torch.tensor([hi]))[0]) < b and hi < 4e18:
-            hi *= 2
+        guess = math.exp(0.301 * b)
+        lo, hi = max(1, int(guess * 0.5)), min(int(guess * 2.0) + 2, i64max)
         while lo < hi:  # smallest x in [lo, hi] with bucket(x) >= b (bucket is monotone in x)
             mid = (lo + hi) // 2
-            if int(bucket(torch.tensor([mid]))[0]) >= b:
+            if bucket(mid) >= b:
                 hi = mid
             else:
                 lo = mid + 1
         thr[b] = lo
+    thr[HSTU_BUCKETS] = min(int(num_buckets), reach) + 1      # (the spare bucket 146 — |dt| = 2^63 - 1 itself — reads the weight of 145)
     return thr
 
 

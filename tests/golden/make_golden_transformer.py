@@ -109,8 +109,8 @@ def build_reference(cfg):
                             **cfg["layer_kwargs"])
     elif kind == "stu":
         hd = cfg["d"] // cfg["H"]
-        layers = STULayers(n_blocks=cfg["n_blocks"], n_factors=cfg["d"], n_heads=cfg["H"], linear_hidden_dim=hd,
-                           attention_dim=hd, session_max_len=cfg["L"], relative_time_attention=cfg["rel_time"],
+        layers = STULayers(n_blocks=cfg["n_blocks"], n_factors=cfg["d"], n_heads=cfg["H"], linear_hidden_dim=cfg.get("linear_hidden_dim", hd),
+                           attention_dim=cfg.get("attention_dim", hd), session_max_len=cfg["L"], relative_time_attention=cfg["rel_time"],
                            relative_pos_attention=cfg["rel_pos"], attn_dropout_rate=0.0, dropout_rate=0.0)
     else:
         raise ValueError(kind)

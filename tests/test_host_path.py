@@ -162,9 +162,20 @@ def test_config_roundtrip_and_errors():
         HSTUModel(n_factors=30, n_heads=4)
     with pytest.raises(ValueError):
         SASRecModel(n_factors=30, n_heads=4)
-    for bad in (dict(n_factors=36, n_heads=3), dict(n_factors=20, n_heads=1), dict(n_factors=512, n_heads=2)):
-        with pytest.raises(NotImplementedError, match="head size"):   # shapes the kernels do not tile: refused up front
-            SASRecModel(**bad)
+    # sizes the kernels do not tile run padded with zero columns (nn.DimPlan; tests/test_dim_plan*.py) — the reference accepts any
+    # n_factors % n_heads == 0; what stays refused, up front and with the reason: a head wider than 128 columns, and odd sizes for
+    # PLUGGED module classes (the caller's own classes cannot be padded from outside)
+    for odd in (dict(n_factors=36, n_heads=3), dict(n_factors=20, n_heads=1), dict(n_factors=50, n_heads=2)):
+        assert SASRecModel(**odd)._dim_plan() is not None and HSTUModel(**odd)._dim_plan() is not None
+    assert SASRecModel()._dim_plan() is None and HSTUModel()._dim_plan() is None
+    with pytest.raises(NotImplementedError, match="128"):
+        SASRecModel(n_factors=512, n_heads=2)
+
+    class MyLayers(SASRecModel().transformer_layers_type):
+        pass
+
+    with pytest.raises(NotImplementedError, match="plugged"):
+        SASRecModel(n_factors=50, n_heads=2, transformer_layers_type=MyLayers)
     with pytest.raises(NotFittedError):
         m.recommend([1], None, 3, False)
     if not torch.cuda.is_available():
@@ -701,3 +712,20 @@ def test_table_sink_expectation_needs_a_live_lookup_of_the_same_table():
     w = torch.zeros(6, 4)
     ops._TABLE_SINK_EXPECTED[w.data_ptr()] = dead               # ... and another table now lives at a key that still holds its entry
     assert dead() is None and not ops._table_sink_expected(w)   # (allocator reuse of an address: the case the weak reference guards)
+
+
+@pytest.mark.parametrize("num_buckets", [16, 128, 200])
+def test_hstu_time_thresholds_match_reference_formula(num_buckets):
+    """The table the kernels search (unclamped buckets) + its trailer (entries of the model's weight vector) reproduce the reference's
+    clamp(trunc(log(max(1, |dt|)) / 0.301), 0, num_buckets) (hstu.py:84-86) for any `num_buckets`."""
+    from rectools_amd import ops
+
+    table = ops.hstu_time_thresholds(num_buckets)
+    assert table.shape == (ops.HSTU_BUCKETS + 1,)
+    thr, n_w = table[:-1], int(table[-1])
+    assert n_w == min(num_buckets, 145) + 1           # 145 = the bucket of 2^63 - 1: no difference falls in a later one
+    x = torch.cat([torch.arange(0, 5000), (torch.rand(200000, generator=torch.Generator().manual_seed(0), dtype=torch.float64) * 43.6).exp().long(),
+                   thr[thr < 2 ** 62], (thr[(thr > 1) & (thr < 2 ** 62)] - 1), torch.tensor([torch.iinfo(torch.int64).max])])
+    ref = torch.clamp((torch.log(torch.abs(x).clamp(min=1)) / 0.301).long(), 0, num_buckets)
+    got = torch.clamp((thr[None, :] <= x[:, None]).sum(1) - 1, max=n_w - 1)      # what the kernels do: unclamped bucket, last weight repeated
+    assert torch.equal(ref, got)

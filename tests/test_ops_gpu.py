@@ -283,17 +283,6 @@ def test_hstu_attention(L, d, H, rt, rp):
     if rp: close(ggot[4], gref[4], rtol=2e-3, atol_rel=2e-4, msg="hstu dpw")
 
 
-def test_hstu_time_thresholds_match_reference_formula():
-    from rectools_amd import ops
-
-    thr = ops.hstu_time_thresholds()
-    x = torch.cat([torch.arange(0, 5000), (torch.rand(200000, generator=torch.Generator().manual_seed(0), dtype=torch.float64) * 40).exp().long(),
-                   thr[thr < 2 ** 62], (thr[(thr > 1) & (thr < 2 ** 62)] - 1)])
-    ref = torch.clamp((torch.log(torch.abs(x).clamp(min=1)) / 0.301).long(), 0, 128)
-    got = (thr[None, :] <= x[:, None]).sum(1) - 1
-    assert torch.equal(ref, got)
-
-
 @pytest.mark.parametrize("loss", ["BCE", "gBCE", "sampled_softmax"])
 @pytest.mark.parametrize("cosine", [False, True])
 def test_sampled_losses(loss, cosine):

@@ -1,6 +1,10 @@
 """The reference's plug-in seams (transformers/base.py:215-222,278-286,368-380,407,430,449): `pos_encoding_type`, `backbone_type`,
 `lightning_module_type` are instantiated from the class handed over (as `transformer_layers_type` / `negative_sampler_type` are),
-`get_trainer_func` is refused unless None; all of it round-trips through `get_config` / `from_config`."""
+`get_trainer_func` is read as a plan for the engine's own loop (epoch counts, logger directory, user-defined callbacks); all of it
+round-trips through `get_config` / `from_config`."""
+import types
+import warnings
+
 import numpy as np
 import pandas as pd
 import pytest
@@ -68,14 +72,95 @@ def test_seams_are_constructor_arguments_and_round_trip_through_configs():
     assert d["backbone_type"] == "rectools_amd.nn.TransformerTorchBackbone"
 
 
-def test_get_trainer_func_is_refused_not_swallowed():
+class EpochRecorder:
+    """A user-defined callback, duck-typed against pytorch_lightning.Callback: records the hooks the loop reaches, logs a metric the
+    way the reference's tutorial callbacks do (`pl_module.log_dict`), and asks for an early stop."""
+
+    def __init__(self, stop_after=None):
+        self.events, self.stop_after, self.val_batches = [], stop_after, 0
+
+    def on_fit_start(self, trainer, pl_module):
+        self.events.append("fit_start")
+
+    def on_train_start(self, trainer, pl_module):
+        self.events.append("train_start")
+
+    def on_train_epoch_start(self, trainer, pl_module):
+        self.events.append("epoch_start")
+
+    def on_validation_batch_end(self, trainer, pl_module, outputs, batch, batch_idx, dataloader_idx=0):
+        assert torch.isfinite(outputs["loss"]) and batch["x"].is_cuda and pl_module.item_embs.shape[0] == pl_module.torch_model.item_model.n_items
+        self.val_batches += 1
+
+    def on_validation_epoch_end(self, trainer, pl_module):
+        pl_module.log_dict({"recall@10": 0.25 + 0.01 * len(self.events)}, on_step=False, on_epoch=True, prog_bar=True)
+
+    def on_train_epoch_end(self, trainer, pl_module):
+        self.events.append("epoch_end")
+        done = self.events.count("epoch_end")
+        assert "train_loss" in trainer.callback_metrics
+        if self.stop_after is not None and done >= self.stop_after:
+            trainer.should_stop = True
+
+    def on_train_end(self, trainer, pl_module):
+        self.events.append("train_end")
+
+
+_RECORDER = EpochRecorder()
+
+
+def duck_trainer(max_epochs=3, min_epochs=1, log_dir=None, callbacks=None):
+    """What a `get_trainer_func` returns, as far as the engine reads it (no pytorch_lightning in this image)."""
+    logger = types.SimpleNamespace(log_dir=log_dir) if log_dir else None
+    return types.SimpleNamespace(max_epochs=max_epochs, min_epochs=min_epochs, callbacks=list(callbacks if callbacks is not None else [_RECORDER]),
+                                 logger=logger, enable_progress_bar=False, callback_metrics={}, should_stop=False)
+
+
+def test_get_trainer_func_is_kept_in_configs():
     from rectools_amd.models import BERT4RecModel, SASRecModel
 
-    with pytest.raises(NotImplementedError, match="get_trainer_func"):
-        SASRecModel(get_trainer_func=lambda **kw: None)
-    with pytest.raises(NotImplementedError, match="get_trainer_func"):
-        BERT4RecModel.from_config({"get_trainer_func": "tests.test_plugin_seams.ScaledLossModule"})
+    m = SASRecModel(get_trainer_func=duck_trainer, get_trainer_func_kwargs={"max_epochs": 2})
+    cfg = m.get_config()
+    assert cfg["get_trainer_func"].endswith("test_plugin_seams.duck_trainer") and cfg["get_trainer_func_kwargs"] == {"max_epochs": 2}
+    assert SASRecModel.from_config(cfg).get_trainer_func is duck_trainer
+    assert BERT4RecModel.from_config({"get_trainer_func": "test_plugin_seams.duck_trainer"}).get_trainer_func is duck_trainer
     SASRecModel(get_trainer_func=None, get_trainer_func_kwargs=None)
+
+
+@pytest.mark.gpu
+def test_get_trainer_func_drives_the_engine_loop(tmp_path):
+    """transformers/base.py:367-380: a user-built Trainer.  Epoch counts, the logger's directory and user-defined callbacks are honoured
+    by the engine's own loop; the rest is named in ONE warning per fit; `should_stop` ends training once min_epochs are done."""
+    from rectools_amd.dataset import Dataset
+    from rectools_amd.models import SASRecModel
+    from rectools_amd.utils import leave_one_out_mask
+
+    ds = Dataset.construct(_interactions())
+    rec = EpochRecorder(stop_after=2)
+    common = dict(n_factors=32, n_blocks=1, n_heads=2, session_max_len=4, lr=0.01, batch_size=4, epochs=7, seed=32, dropout_rate=0.0,
+                  get_val_mask_func=leave_one_out_mask)
+    model = SASRecModel(get_trainer_func=duck_trainer,
+                        get_trainer_func_kwargs=dict(max_epochs=5, min_epochs=3, log_dir=str(tmp_path / "logs"), callbacks=[rec]), **common)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        model.fit(ds)
+    msgs = [str(w.message) for w in caught if "get_trainer_func" in str(w.message)]
+    assert len(msgs) == 1 and "max_epochs=5" in msgs[0] and "accelerator" in msgs[0]
+    # asked to stop after 2 epochs, min_epochs = 3: three epochs ran (not the model's `epochs` = 7, not max_epochs = 5)
+    assert model.epochs_done == 3 and len(model.history) == 3 and rec.events.count("epoch_end") == 3
+    assert rec.events[:3] == ["fit_start", "train_start", "epoch_start"] and rec.events[-1] == "train_end" and rec.val_batches > 0
+    assert all("recall@10" in h and "val_loss" in h for h in model.history)      # what the callback logged lands in the epoch records
+    assert model.log_path is not None and model.log_path.startswith(str(tmp_path / "logs"))
+    assert model.fit_trainer.callback_metrics["train_loss"].ndim == 0
+    # fit_partial reads the factory again and takes its epoch counts from the call (transformers/base.py:527-529)
+    rec.stop_after, n_before = None, rec.events.count("epoch_end")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model.fit_partial(ds, min_epochs=1, max_epochs=2)
+    assert model.epochs_done == 5 and rec.events.count("epoch_end") == n_before + 2
+    # a checkpoint keeps the factory's dotted path when it imports
+    clone = SASRecModel.loads(model.dumps())
+    assert clone.get_trainer_func is duck_trainer
 
 
 def test_a_plugged_lightning_module_decides_whether_negatives_are_sampled():

@@ -114,10 +114,22 @@ def _fuzz_configs():
         if rng.integers(0, 3) == 0 and layers != "stu":
             cfg["cat"] = dict(F=int(rng.integers(3, 12)), max_per_item=int(rng.integers(1, 5)))
         out.append(cfg)
+    # sizes the kernels do not tile (the engine runs them through nn.DimPlan; tests/test_dim_plan_gpu.py compares it with the oracle at these
+    # sizes): the reference's published HSTU configuration n_factors = 50 with 1 and 2 heads, odd head sizes of every family, and an STU
+    # stack whose u / v and q / k head sizes differ
+    for j, (layers, d, H, extra) in enumerate([("stu", 50, 1, {}), ("stu", 50, 2, {}), ("sasrec", 50, 2, {}), ("preln", 36, 3, {}),
+                                               ("ligr", 40, 2, {}), ("stu", 32, 2, dict(linear_hidden_dim=12, attention_dim=20))]):
+        cfg = dict(V=60, B=3, L=11, d=d, H=H, n_blocks=2, N=3, loss=["sampled_softmax", "softmax", "BCE", "gBCE"][j % 4],
+                   dist="cosine" if layers == "stu" else "dot", logits_t=1.0, causal=layers != "preln", keypad=layers == "preln", layers=layers,
+                   n_extra=2 if layers == "preln" else 1, gbce_t=0.2, lr=1e-3, use_scale=layers == "stu", layer_kwargs={}, weights="rand",
+                   seed=2000 + j, rel_time=True, rel_pos=True, **extra)
+        if layers == "ligr":
+            cfg["layer_kwargs"] = dict(ff_factors_multiplier=4, ff_activation="swiglu", bias_in_ff=False)
+        out.append(cfg)
     return out
 
 
-@pytest.mark.parametrize("cfg", _fuzz_configs(), ids=lambda c: f"{c['layers']}-{c['loss']}-{c['dist']}")
+@pytest.mark.parametrize("cfg", _fuzz_configs(), ids=lambda c: f"{c['layers']}-{c['loss']}-{c['dist']}-d{c['d']}h{c['H']}")
 def test_oracle_matches_live_reference_on_random_configs(cfg):
     """The oracle (plain restatement) against the reference's own modules on 16 random configurations — every layer family
     × every loss, random sizes / heads / masks / temperatures / feature nets: loss, every gradient, eval encodings."""
@@ -211,3 +223,32 @@ def test_utils_match_reference_on_random_frames(seed):
         np.testing.assert_array_equal(got, want)
     for frame in (df, df.drop(columns=["weight"]), df.drop(columns=["item_id"])):
         pd.testing.assert_frame_equal(get_context(frame), ref_context(frame))
+
+
+@pytest.mark.parametrize("kind", ["sasrec", "preln", "ligr", "stu"])
+def test_layer_stacks_draw_their_constructor_init_like_the_reference(kind):
+    """Same seed -> same parameter names in the same order and the SAME 1-D parameters (biases keep their constructor init, SURVEY A.5;
+    everything of dim > 1 is re-drawn by xavier afterwards): the engine's stacks consume the global RNG stream exactly as the reference's
+    modules do, so a reference model with the HIP stacks plugged in (rectools_amd.reference_plugins) starts from the reference's weights."""
+    import torch
+    from rectools.models.nn.transformers.hstu import STULayers as RefSTU
+    from rectools.models.nn.transformers.ligr import LiGRLayers as RefLiGR
+    from rectools.models.nn.transformers.net_blocks import PreLNTransformerLayers as RefPreLN
+    from rectools.models.nn.transformers.sasrec import SASRecTransformerLayers as RefSASRec
+
+    from rectools_amd import nn as hnn
+
+    kw = dict(n_blocks=2, n_factors=32, n_heads=2, dropout_rate=0.1)
+    if kind == "stu":
+        kw.update(linear_hidden_dim=16, attention_dim=16, session_max_len=8, relative_time_attention=True, relative_pos_attention=True)
+    ref_cls, cls = {"sasrec": (RefSASRec, hnn.SASRecTransformerLayers), "preln": (RefPreLN, hnn.PreLNTransformerLayers),
+                    "ligr": (RefLiGR, hnn.LiGRLayers), "stu": (RefSTU, hnn.STULayers)}[kind]
+    torch.manual_seed(3); ref = ref_cls(**kw)
+    torch.manual_seed(3); mine = cls(**kw)
+    after_ref = torch.rand(1)
+    torch.manual_seed(3); cls(**kw)
+    assert torch.equal(after_ref, torch.rand(1)) or kind != "stu"      # (the stream ends where the reference's does)
+    for (n, p), (m, q) in zip(ref.named_parameters(), mine.named_parameters()):
+        assert n == m and p.shape == q.shape
+        if p.dim() == 1:
+            assert torch.equal(p, q), n

@@ -32,10 +32,19 @@ def cat_structure(n_tokens, n_extra, F, max_per_item, seed):
     return torch.tensor([v for r in rows for v in r], dtype=torch.int64), lens, torch.cumsum(lens, 0) - lens
 
 
-def build_hip_model(cfg, params=None):
+def build_hip_model(cfg, params=None, device="cuda", real_size=False):
+    """The engine's torch model for an oracle-style config.  Sizes the kernels do not tile (cfg d / H, or an STU stack with
+    linear_hidden_dim != attention_dim) are built through `nn.DimPlan` — padded with zero columns, state dicts in the real shapes —
+    as models._build_model_from_dataset does; real_size=True builds the real-size parameter holder instead (host only)."""
     from rectools_amd import lightning as hl
     from rectools_amd import nn as hnn
 
+    stu = cfg["layers"] == "stu"
+    plan = None if real_size else hnn.DimPlan.make(cfg["d"], cfg["H"], "stu" if stu else "mha", cfg.get("linear_hidden_dim"),
+                                                  cfg.get("attention_dim"))
+    real_cfg, hd_real = cfg, cfg["d"] // cfg["H"]
+    if plan is not None:
+        cfg = dict(cfg, d=plan.d_pad, linear_hidden_dim=plan.hd_pad, attention_dim=plan.hd_pad)
     n_tokens = cfg["V"] + cfg["n_extra"]
     blocks = [hnn.IdEmbeddingsItemNet(cfg["d"], n_tokens, 0.0)]
     if cfg.get("cat"):   # feature-aware item net: structure from the golden state dict, or seeded for the random cases
@@ -56,15 +65,17 @@ def build_hip_model(cfg, params=None):
     elif kind == "ligr":
         layers = hnn.LiGRLayers(cfg["n_blocks"], cfg["d"], cfg["H"], p, **cfg["layer_kwargs"])
     else:
-        hd = cfg["d"] // cfg["H"]
-        layers = hnn.STULayers(cfg["n_blocks"], cfg["d"], cfg["H"], hd, hd, cfg["L"], cfg["rel_time"], cfg["rel_pos"],
-                               attn_dropout_rate=0.0, dropout_rate=p)
+        layers = hnn.STULayers(cfg["n_blocks"], cfg["d"], cfg["H"], cfg.get("linear_hidden_dim", hd_real), cfg.get("attention_dim", hd_real),
+                               cfg["L"], cfg["rel_time"], cfg["rel_pos"], attn_dropout_rate=0.0, dropout_rate=p,
+                               **({"num_buckets": cfg["num_buckets"]} if "num_buckets" in cfg else {}))
     sim = hnn.DistanceSimilarityModule(cfg["dist"])
     bb = hnn.TransformerTorchBackbone(cfg["H"], p, item_model, pos, layers, sim, cfg["causal"], cfg["keypad"])
+    if plan is not None:
+        hnn.apply_dim_plan(bb, plan)
     lm = hl.TransformerLossModule(bb, cfg["loss"], cfg["N"], cfg["gbce_t"], cfg.get("logits_t", 1.0), cfg["n_extra"])
-    lm = lm.cuda()
+    lm = lm.to(device)
     if params is not None:
-        missing, unexpected = lm.torch_model.load_state_dict({k: v.cuda() for k, v in params.items()}, strict=True)
+        missing, unexpected = lm.torch_model.load_state_dict({k: v.to(device) for k, v in params.items()}, strict=True)
     return lm
 
 
