@@ -309,6 +309,7 @@ class FlatAdam:
     def zero_grad(self) -> None:
         for p in self.params:
             p.grad = None  # the next backward's gradient tensors are adopted as they are
+        ops.clear_step_expectations()
 
     def gather_gradients(self) -> torch.Tensor:
         """Pack the per-parameter gradients into the flat buffer (zeros where a parameter got none): ONE multi-tensor copy

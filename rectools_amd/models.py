@@ -707,7 +707,23 @@ class TransformerModelBase:
         flat buffer changes the pointers."""
         lm = self.lightning_model
         params = tuple((p.data_ptr(), p._version, tuple(p.shape)) for p in lm.torch_model.item_model.parameters())   # pylint: disable=protected-access
-        return (str(distance), params, 0 if self.optimizer is None else self.optimizer.step_count, tuple(item_embs.shape), str(item_embs.device))
+        # ... and a cheap look AT them for the writes neither counter sees (`param.data.copy_()`, a raw pointer write, ADVICE r4): the sum
+        # of ~1,024 evenly spaced rows, one small reduction + one scalar read per recommend() call
+        stash = getattr(self, "_item_probe", None)       # taken by `_item_embeddings()`, before the encoder was queued (no mid-call sync)
+        probe = stash[1] if stash is not None and stash[0] == (item_embs.data_ptr(), tuple(item_embs.shape)) else self._probe(item_embs)
+        return (str(distance), params, 0 if self.optimizer is None else self.optimizer.step_count, tuple(item_embs.shape), str(item_embs.device),
+                probe)
+
+    @staticmethod
+    def _probe(item_embs: torch.Tensor) -> float:
+        V = int(item_embs.shape[0])
+        return float(item_embs[:: max(1, V // 1024)].sum(dtype=torch.float64)) if V else 0.0
+
+    def invalidate_catalog_images(self) -> None:
+        """Drop the catalog's coarse-pass images kept between recommend() calls (hm + one-plane + fragment forms: up to ~8 d bytes per
+        item, ~20 GB at 5 M x 512).  Call after writing item embeddings behind torch's back; they are also never kept when larger than
+        RT_CATALOG_IMAGES_MAX_GB (default 64) — every call then rebuilds them (2.6 ms at 5 M x 512)."""
+        self._catalog_images = None
 
     def _ranker(self, distance: tp.Any, device: tp.Any, user_embs: torch.Tensor, item_embs: torch.Tensor) -> HipRanker:
         """A ranker for this call's user factors that inherits the catalog images (and the largest item norm) an earlier call built,
@@ -722,7 +738,22 @@ class TransformerModelBase:
         return ranker
 
     def _keep_images(self, ranker: HipRanker) -> None:
-        self._catalog_images = (ranker._catalog_key, ranker.export_images())    # pylint: disable=protected-access
+        images = ranker.export_images()
+        total = sum(int(t.numel()) * t.element_size() for t in self._tensors_of(images))
+        if total > float(os.environ.get("RT_CATALOG_IMAGES_MAX_GB", "64")) * 2 ** 30:
+            self._catalog_images = None
+            return
+        self._catalog_images = (ranker._catalog_key, images)    # pylint: disable=protected-access
+
+    @staticmethod
+    def _tensors_of(obj: tp.Any) -> tp.List[torch.Tensor]:
+        if isinstance(obj, torch.Tensor):
+            return [obj]
+        if isinstance(obj, dict):
+            obj = list(obj.values())
+        if isinstance(obj, (list, tuple)):
+            return [t for o in obj for t in TransformerModelBase._tensors_of(o)]
+        return []
 
     def _item_embeddings(self) -> torch.Tensor:
         """Catalog matrix in eval mode, produced once per recommend call (lightning.py:386-389)."""
@@ -730,7 +761,9 @@ class TransformerModelBase:
         assert lm is not None
         lm.eval()
         with torch.no_grad():
-            return lm.torch_model.item_model.get_all_embeddings().detach()
+            item_embs = lm.torch_model.item_model.get_all_embeddings().detach()
+        self._item_probe = ((item_embs.data_ptr(), tuple(item_embs.shape)), self._probe(item_embs))
+        return item_embs
 
     def _user_embeddings(self, store: SequenceStore, device: torch.device, item_embs: torch.Tensor) -> torch.Tensor:
         """Last-slot encodings of every session, eval mode, kept on the device (lightning.py:378-400)."""
@@ -830,9 +863,22 @@ class TransformerModelBase:
         reference's DataLoader; every row of the encoder is independent of the batch it travels in, so the engine groups at
         least 4,096 sessions per launch (≈ 0.43 M packed rows, ≈ 5 GB of scratch at d = 256: 634 k -> 654 k users/s against 1,024
         sessions per launch at C2, visit of round 4; RT_ENCODE_SESSIONS overrides)."""
-        import os
-
-        return max(int(self.recommend_batch_size), int(os.environ.get("RT_ENCODE_SESSIONS", "4096")))
+        env = os.environ.get("RT_ENCODE_SESSIONS")
+        if env:
+            return max(int(env), 1)
+        if int(self.recommend_batch_size) != 256:      # set by the caller (the reference's default is 256): its memory knob stands
+            return int(self.recommend_batch_size)
+        # the default: up to 4,096 sessions, fewer when the launch's scratch (~24 row-sized fp32 buffers of window x n_factors) would
+        # take more than a fifth of the free HBM (wide / long-window models, shared GPUs: ADVICE r4); a launch that still runs out of
+        # memory is halved and repeated (`_recommend_device_glue`)
+        sessions = 4096
+        if torch.cuda.is_available() and self.lightning_model is not None:
+            dev = next(self.lightning_model.parameters()).device
+            if dev.type == "cuda":
+                free, _ = torch.cuda.mem_get_info(dev)
+                per_session = 24 * 4 * int(self.session_max_len) * int(self.n_factors)
+                sessions = int(min(4096, max(256, free // 5 // max(per_session, 1))))
+        return max(int(self.recommend_batch_size), sessions)
 
     def _check(self, k: int) -> None:
         if not self.is_fitted:
@@ -974,9 +1020,10 @@ class TransformerModelBase:
         dstore = DeviceSequenceStore.from_device(offsets, item_s, w_s, None)
         item_embs = self._item_embeddings()
         tick("glue")
-        outs = []
-        with torch.no_grad():
-            bs = self._encode_batch_size()
+        unsort = None
+
+        def encode(bs: int) -> tp.Optional[tp.List[torch.Tensor]]:
+            outs: tp.List[torch.Tensor] = []
             # packed encoder (no padding rows: 45 % of the [B, L] window at ML-20M scale) where the stack offers it; RT_PACKED=0
             # keeps the padded window.  Same encodings up to fp32 rounding (tests/test_packed_gpu.py).
             packed = os.environ.get("RT_PACKED", "1") != "0" and type(dp).__name__ in _PACKED_PREPARATORS \
@@ -984,7 +1031,6 @@ class TransformerModelBase:
             if ctx_d is not None and not packed:
                 return None
             mask_id = dp.extra_token_ids[MASKING_VALUE] if type(dp).__name__ == "BERT4RecDataPreparator" else None
-            unsort = None
             if packed:   # packed row offsets of every encoder launch, cut on the host, one upload
                 L = dp.session_max_len
                 n_launch = -(-n_valid // bs)
@@ -1005,6 +1051,21 @@ class TransformerModelBase:
                     continue
                 batch = dp.collate_recommend_device(dstore, valid_rows[b0:b0 + nb])
                 outs.append(lm.torch_model.encode_last(batch, item_embs))   # last-position encodings, [b, d]
+            return outs
+
+        bs = self._encode_batch_size()
+        with torch.no_grad():
+            while True:      # a launch that does not fit beside what else lives on this GPU is halved and repeated
+                try:
+                    outs = encode(bs)
+                    break
+                except torch.cuda.OutOfMemoryError:
+                    if bs <= 64:
+                        raise
+                    bs //= 2
+                    torch.cuda.empty_cache()
+        if outs is None:
+            return None
         user_embs = torch.cat(outs)
         if unsort is not None:
             user_embs = user_embs.index_select(0, unsort)

@@ -104,6 +104,7 @@ def _native_side_fork() -> tp.Optional[int]:
 
 
 _PREP_KEEPALIVE: tp.List[tp.Any] = []     # buffers of work issued on the side stream during the FORWARD pass (see `_side_fork_forward`)
+_PREP_STEP = -1                            # RNG.step of the forward pass that filled it
 
 
 def _side_fork_forward() -> tp.Optional[int]:
@@ -403,13 +404,24 @@ _TABLE_SINK_EXPECTED: tp.Dict[int, tp.Any] = {}
 def _expect_table_sink(table: torch.Tensor) -> None:
     import weakref
 
-    _TABLE_SINK_EXPECTED[table.data_ptr()] = weakref.ref(table)
+    _TABLE_SINK_EXPECTED[table.data_ptr()] = (weakref.ref(table), RNG.step)
 
 
 def _table_sink_expected(table: torch.Tensor) -> bool:
+    """Did an embedding lookup of THIS forward pass register for the table's gradient?  An entry a previous step left behind — its
+    loss was a softmax / a plugged one, or its backward never ran — is not an expectation of this step: entries carry the
+    step counter of the dropout streams, and `clear_step_expectations()` (FlatAdam.zero_grad) drops what a finished step left."""
     r = _TABLE_SINK_EXPECTED.pop(table.data_ptr(), None)
-    t = None if r is None else r()
+    if r is None or r[1] != RNG.step:
+        return False
+    t = r[0]()
     return t is not None and t.data_ptr() == table.data_ptr() and t.shape == table.shape
+
+
+def clear_step_expectations() -> None:
+    """Start of a training step (`FlatAdam.zero_grad`): nothing a previous forward pass registered survives into this one."""
+    _TABLE_SINK_EXPECTED.clear()
+    _TABLE_GRAD_SINK.clear()
 
 
 def _offer_table_grad(table: torch.Tensor, d_table: torch.Tensor) -> None:
@@ -483,10 +495,16 @@ class _EmbedPacked(torch.autograd.Function):
             # the backward pass arrives (eight small launches less in the tail of a step)
             ws_bytes = _lib.load().rt_embed_bwd_workspace_bytes(M, table.shape[0], d)
             ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=table.device)
+            # buffers of earlier forward passes whose backward never came (evaluation under grad mode, a plugged loop): join and let
+            # them go instead of pinning one workspace per call
+            global _PREP_STEP
+            if _PREP_KEEPALIVE and (_PREP_STEP != RNG.step or len(_PREP_KEEPALIVE) >= 4):
+                join_side_streams()
             side = _side_fork_forward()
             _c("rt_embed_bwd_prepare", ids, M, d, table.shape[0], ws, ws_bytes, stream=side)
             if side is not None:
                 _PREP_KEEPALIVE.append((ids, ws))
+                _PREP_STEP = RNG.step
         ctx.save_for_backward(ids, cu, *(() if ws is None else (ws,)))
         ctx.meta = (table.shape, None if pos is None else pos.shape, B, L, scale, p, seed, sid)
         ctx.table_ptr = table.data_ptr()
