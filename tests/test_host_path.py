@@ -711,7 +711,15 @@ def test_table_sink_expectation_needs_a_live_lookup_of_the_same_table():
     del u                                                       # the registered tensor died ...
     w = torch.zeros(6, 4)
     ops._TABLE_SINK_EXPECTED[w.data_ptr()] = dead               # ... and another table now lives at a key that still holds its entry
-    assert dead() is None and not ops._table_sink_expected(w)   # (allocator reuse of an address: the case the weak reference guards)
+    assert dead[0]() is None and not ops._table_sink_expected(w)   # (allocator reuse of an address: the case the weak reference guards)
+    # an expectation belongs to the forward pass that registered it: a later step does not inherit it, and the start of a
+    # step (FlatAdam.zero_grad -> clear_step_expectations) drops what the previous one left
+    ops._expect_table_sink(t)
+    ops.RNG.next_step()
+    assert not ops._table_sink_expected(t)
+    ops._expect_table_sink(t)
+    ops.clear_step_expectations()
+    assert not ops._table_sink_expected(t) and not ops._TABLE_SINK_EXPECTED and not ops._TABLE_GRAD_SINK
 
 
 @pytest.mark.parametrize("num_buckets", [16, 128, 200])
