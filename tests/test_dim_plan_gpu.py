@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("name,case", ODD, ids=[c[0] for c in ODD])
 def test_padded_model_equals_the_oracle_at_the_real_sizes(name, case):
     from rectools_amd import lightning as hl
-    from rectools_amd.nn import unpad_tensor
+    from rectools_amd.nn import pad_tensor, unpad_tensor
 
     cfg, batch = case
     torch.manual_seed(100)
@@ -42,7 +42,7 @@ def test_padded_model_equals_the_oracle_at_the_real_sizes(name, case):
         enc = lm.torch_model.encode_sessions(dbatch)
         last = lm.torch_model.encode_last(dbatch)
     d = cfg["d"]
-    assert float(enc[..., d:].abs().max()) == 0.0                  # the padded columns of the residual stream stay exact zeros
+    assert enc.shape[-1] == d or float(enc[..., d:].abs().max()) == 0.0     # the padded columns of the residual stream stay exact zeros
     _close(enc[..., :d], enc_ref, 5e-4, 5e-5, "encode_sessions")
     _close(last[:, :d], enc_ref[:, -1], 5e-4, 5e-5, "encode_last")
     lm.train()
@@ -55,20 +55,24 @@ def test_padded_model_equals_the_oracle_at_the_real_sizes(name, case):
         g = unpad_tensor(p.grad, p)
         _close(g, g_ref[n], 1e-2, 2e-5 if g_ref[n].abs().max() > 1e-6 else 1.0, f"grad {n}")
         if getattr(p, "_rt_axes", None) is not None:               # every gradient of a padded entry is an exact zero ...
-            assert int((p.grad != 0).sum()) <= g_ref[n].numel(), n
-            assert float(p.grad.abs().sum()) == float(g.abs().sum()), n
+            pad_only = 1.0 - pad_tensor(torch.ones(p._rt_real_shape, device=p.device), p)
+            assert float((p.grad * pad_only).abs().max()) == 0.0, n
     before = {n: p.detach().clone() for n, p in lm.torch_model.named_parameters()}
     opt.step()
     torch.cuda.synchronize()
     for n, p in lm.torch_model.named_parameters():                 # ... and Adam leaves those entries at zero
         if getattr(p, "_rt_axes", None) is not None:
-            assert int((p != 0).sum()) <= g_ref[n].numel(), n
+            pad_only = 1.0 - pad_tensor(torch.ones(p._rt_real_shape, device=p.device), p)
+            assert float((p.detach() * pad_only).abs().max()) == 0.0, n
         assert not torch.equal(unpad_tensor(p.detach(), p), unpad_tensor(before[n], p)) or float(g_ref[n].abs().max()) == 0.0, n
     # the oracle's Adam on the oracle's gradients lands where the engine's step landed (real shapes)
-    after_ref = T.Adam(lr=1e-2).step(params, g_ref)
+    after_ref = T.AdamState(lr=1e-2).step(params, g_ref)
     got = lm.torch_model.state_dict()
     for n, _ in lm.torch_model.named_parameters():
-        torch.testing.assert_close(got[n].cpu(), after_ref[n], rtol=2e-2, atol=2e-3, msg=lambda m, n=n: f"adam {n}: {m}")
+        # (Adam's first step is lr * sign(g) wherever |g| >> eps: an entry whose true gradient is zero — the attention's key bias — moves
+        # by +-lr on rounding noise in either implementation; compare where the gradient is a gradient)
+        solid = g_ref[n].abs() > 1e-4 * float(g_ref[n].abs().max()) + 1e-7
+        torch.testing.assert_close(got[n].cpu()[solid], after_ref[n][solid], rtol=2e-2, atol=2e-3, msg=lambda m, n=n: f"adam {n}: {m}")
 
 
 def _frames(n_users=60, n_items=90, seed=0):

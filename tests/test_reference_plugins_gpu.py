@@ -66,7 +66,13 @@ def _compare(a, b):
     for k in sa:
         assert sa[k].shape == sb[k].shape, k
         if sa[k].is_floating_point():
-            torch.testing.assert_close(sb[k], sa[k], rtol=2e-3, atol=2e-4, msg=lambda m, k=k: f"{k} after training: {m}")
+            x, y = sb[k], sa[k]
+            if k.endswith("in_proj_bias"):
+                # the key bias shifts every logit of a query alike: its true gradient is ZERO, what each implementation computes is
+                # rounding noise — which Adam normalises to steps of the order of lr with a random sign.  Compare the q and v thirds
+                n = x.numel() // 3
+                x, y = torch.cat([x[:n], x[2 * n:]]), torch.cat([y[:n], y[2 * n:]])
+            torch.testing.assert_close(x, y, rtol=2e-3, atol=2e-4, msg=lambda m, k=k: f"{k} after training: {m}")
     assert len(ra) == len(rb) and (ra["user_id"].values == rb["user_id"].values).all()
     same = (ra["item_id"].values == rb["item_id"].values)
     assert same.mean() >= 0.97, f"only {same.mean():.3f} of the recommended items agree"      # (near-ties may swap neighbours)
