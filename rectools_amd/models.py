@@ -389,8 +389,13 @@ class TransformerModelBase:
                 zeros = torch.zeros(n_tokens, dtype=torch.int64)
                 blocks.append(block_type(torch.zeros(spec["nnz"], dtype=torch.int64), zeros, zeros.clone(),
                                          spec["n_cat_feature_values"], n_factors, self.dropout_rate))
+            elif callable(getattr(block_type, "from_dataset_schema", None)):     # a plugged block class: the reference's own hook
+                block = block_type.from_dataset_schema(self.dataset_schema, n_factors, self.dropout_rate)    # (item_net.py:44-52)
+                if block is not None:
+                    blocks.append(block)
             else:
-                raise NotImplementedError(f"item net block {block_type!r} cannot be rebuilt from a dataset schema")
+                raise NotImplementedError(f"item net block {block_type!r} cannot be rebuilt from a dataset schema: it offers no "
+                                          f"from_dataset_schema(dataset_schema, n_factors, dropout_rate)")
         return self.item_net_constructor_type(n_tokens, blocks, **kw)
 
     def _build_model_from_dataset(self, dataset: tp.Any, item_net_schema: tp.Optional[tp.List[dict]] = None) -> None:

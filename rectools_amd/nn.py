@@ -204,14 +204,19 @@ class SumOfEmbeddingsConstructor(nn.Module):
             raise ValueError("At least one type of net to calculate item embeddings should be provided.")
         ids = [b for b in item_net_blocks if isinstance(b, IdEmbeddingsItemNet)]
         cats = [b for b in item_net_blocks if isinstance(b, CatFeaturesItemNet)]
-        if len(ids) > 1 or len(cats) > 1 or len(ids) + len(cats) != len(item_net_blocks):
-            raise NotImplementedError("the MI355X engine implements at most one IdEmbeddingsItemNet and one CatFeaturesItemNet block")
+        for b in item_net_blocks:      # a plugged block class (item_net.py:26-57, ItemNetBase): it must be able to produce its [n_items, d] rows
+            if not isinstance(b, (IdEmbeddingsItemNet, CatFeaturesItemNet)) and not callable(getattr(b, "get_all_embeddings", None)):
+                raise TypeError(f"item net block {type(b).__name__} offers no get_all_embeddings(): the catalog matrix is the sum of the "
+                                f"blocks' [n_items, n_factors] rows (item_net.py:361-368)")
         self.n_items = n_items
         self.n_item_blocks = len(item_net_blocks)
         self.item_net_blocks = nn.ModuleList(item_net_blocks)
-        # positions, not references: a second attribute holding a block would register it twice in the state dict
+        # positions, not references: a second attribute holding a block would register it twice in the state dict.  The first id block and
+        # the first category block are produced by ONE fused pass (K1b); any further block of either kind — the reference sums whatever
+        # list it is given (item_net.py:463-482) — and any plugged block adds its rows to that
         self._ids_at = item_net_blocks.index(ids[0]) if ids else None
         self._cat_at = item_net_blocks.index(cats[0]) if cats else None
+        self._more_at = [i for i in range(len(item_net_blocks)) if i not in (self._ids_at, self._cat_at)]
 
     @classmethod
     def from_dataset(cls, dataset: tp.Any, n_factors: int, dropout_rate: float,
@@ -223,14 +228,26 @@ class SumOfEmbeddingsConstructor(nn.Module):
                 blocks.append(block)
         return cls(dataset.item_id_map.size, blocks)
 
+    def _rows_of(self, block: nn.Module) -> torch.Tensor:
+        if isinstance(block, IdEmbeddingsItemNet):
+            return block.ids_emb.weight
+        if isinstance(block, CatFeaturesItemNet):
+            return ops.item_table(None, block.embedding_bag.weight, block.structure(), block.dropout_rate if self.training else 0.0)
+        return block.get_all_embeddings()
+
     @property
     def table(self) -> torch.Tensor:
         ids_w = self.item_net_blocks[self._ids_at].ids_emb.weight if self._ids_at is not None else None
         if self._cat_at is None:
-            return ids_w
-        cat = self.item_net_blocks[self._cat_at]
-        p = cat.dropout_rate if self.training else 0.0
-        return ops.item_table(ids_w, cat.embedding_bag.weight, cat.structure(), p)
+            out = ids_w
+        else:
+            cat = self.item_net_blocks[self._cat_at]
+            p = cat.dropout_rate if self.training else 0.0
+            out = ops.item_table(ids_w, cat.embedding_bag.weight, cat.structure(), p)
+        for i in self._more_at:
+            rows = self._rows_of(self.item_net_blocks[i])
+            out = rows if out is None else ops.add(out, rows)
+        return out
 
     def get_all_embeddings(self) -> torch.Tensor:
         """The table itself (the reference re-materialises it with a gather every call, item_net.py:361-368)."""

@@ -255,3 +255,46 @@ def test_block_tail_backward_equals_the_separate_launches(M, d, dff, p):
     gA64, gw64 = torch.autograd.grad(out, (attn, lnw), D["g_out"])
     torch.testing.assert_close(g_A.double(), gA64, rtol=1e-5, atol=3e-5)
     torch.testing.assert_close(dw.double(), gw64, rtol=1e-4, atol=1e-4 * float(gw64.abs().max()))
+
+
+# ---- straight against the oracle (oracle/transformer_oracle.py restates sasrec.py:221-229 + net_blocks.py:21-64), no dropout ------------
+@pytest.mark.parametrize("M,d,dff", [(256, 256, 256), (13312, 256, 256), (384, 128, 256)])
+def test_chain_kernels_against_the_oracle(M, d, dff):
+    """`rt_ffn_fused_*` and `rt_block_tail_*` against the ORACLE's `layer_norm` / `ffn` (fp32 on the host, autograd for the gradients) —
+    not against the older kernels: forward outputs, the data gradients down to the attention output, d ln_w / d ln_b."""
+    from oracle import transformer_oracle as T
+    from rectools_amd import _lib, ops
+
+    lib = _lib.load()
+    t = _tail_inputs(M, d, dff, seed=11)
+    pl = _tail_planes(t)
+    c = {k: v.detach().cpu() for k, v in t.items()}
+    params = {"ff.ff_linear_1.weight": c["w1"], "ff.ff_linear_1.bias": c["b1"], "ff.ff_linear_2.weight": c["w2"], "ff.ff_linear_2.bias": c["b2"]}
+    attn, lnw, lnb = (c[k].clone().requires_grad_(True) for k in ("attn", "ln_w", "ln_b"))
+    y = c["q"] + attn @ c["wo"].T + c["bo"]                       # sasrec.py:224 (q + mha's out-projection)
+    y.retain_grad()
+    f = T.layer_norm(y, lnw, lnb, 1e-5)                             # :226
+    out = f + T.ffn(f, params, "ff.", "relu")                       # :227-229 without dropout
+    out.backward(c["g_out"])
+    # the whole tail
+    fw = _tail_fwd(t, pl, M, d, dff, 0.0, True)
+    g_h, g_y, g_A = (torch.empty(M, n, device="cuda") for n in (dff, d, d))
+    part = torch.empty(lib.rt_block_tail_partial_floats(M, d), device="cuda")
+    dw, db = torch.empty(d, device="cuda"), torch.empty(d, device="cuda")
+    ops._c("rt_block_tail_bwd", t["g_out"], fw["hdrop"], fw["y"], fw["mean"], fw["rstd"], t["ln_w"], pl["wop"], pl["w1p"], pl["w2p"], pl["stride"],
+           None, g_h, g_y, g_A, part, M, d, dff, 0.0, SEEDS["seed_o"], SEEDS["sid_o"])
+    ops._c("rt_layernorm_bwd_reduce", part, M // 64, d, dw, db)
+    # the feed-forward half alone, on the oracle's LayerNorm input
+    fz = _fused_fwd(dict(t, y=fw["y"]), M, d, dff, 0.0)
+    g_h2, g_f2 = torch.empty(M, dff, device="cuda"), torch.empty(M, d, device="cuda")
+    ops._c("rt_ffn_fused_bwd", t["g_out"], fz["hdrop"], fz["w1p"], fz["w2p"], fz["stride"], None, g_h2, g_f2, M, d, dff, 0.0,
+           SEEDS["seed_o"], SEEDS["sid_o"])
+    torch.cuda.synchronize()
+
+    def close(got, want, name, rtol=2e-4, rel=2e-5):
+        torch.testing.assert_close(got.cpu(), want, rtol=rtol, atol=rel * float(want.abs().max()), msg=lambda s: f"{name}: {s}")
+
+    close(fw["y"], y.detach(), "y"); close(fw["f"], f.detach(), "LN(y)"); close(fw["out"], out.detach(), "block output")
+    close(fz["out"], out.detach(), "feed-forward half: output")
+    close(g_y, y.grad, "d y", rtol=2e-3, rel=2e-4); close(g_A, attn.grad, "d attention output", rtol=2e-3, rel=2e-4)
+    close(dw, lnw.grad, "d ln_w", rtol=2e-3, rel=2e-4); close(db, lnb.grad, "d ln_b", rtol=2e-3, rel=2e-4)

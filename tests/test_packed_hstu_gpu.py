@@ -239,3 +239,52 @@ def test_hstu_recommend_with_context_on_the_device_path_equals_the_reference_sha
     assert calls["fast"] == 2 and len(a) > 0
     with pytest.raises(ValueError):
         model.recommend(users=users, dataset=full, context=context.iloc[1:], k=4, filter_viewed=True)      # no context for a target user
+
+
+@pytest.mark.parametrize("num_buckets", [128, 24])
+def test_hstu_varlen_chunked_sessions_against_the_oracle(num_buckets):
+    """K6v2 straight against the ORACLE (oracle/transformer_oracle.py: hstu.py:84-153,257-288 restated), not against the padded kernels:
+    11 sessions, nine of them longer than the 192 partner rows one chunk holds (193 .. 512 rows: two and three chunks, chunk edges at
+    and next to multiples of 32), time + position bias, outputs and every gradient incl. the two bias tables'.  num_buckets = 24: the
+    weight vector is shorter than the buckets the timestamps reach — the clamp of hstu.py:84-86 through the threshold table's trailer."""
+    import torch.nn.functional as F
+
+    from oracle import transformer_oracle as T
+    from rectools_amd import ops
+
+    H, hd, L = 4, 64, 512
+    d = H * hd
+    lens = [512, 193, 300, 257, 448, 200, 385, 511, 194, 64, 5]
+    B = len(lens)
+    ids, ts, qkv, real, cu, ts_packed = _sessions(lens, L, d, seed=77)
+    N = int(real.sum()); Np = (N + 127) // 128 * 128
+    g = torch.Generator().manual_seed(5)
+    tw0, pw0 = torch.randn(num_buckets + 1, generator=g) * 0.3, torch.randn(2 * L - 1, generator=g) * 0.3
+    gout = torch.randn(B * L, d, generator=g); gout[~real] = 0
+    m = (ids != 0).float()
+
+    def ref_fn(q, k, v, tw, pw):
+        rab = T.rel_attn_bias({"x.time_weights": tw, "x.pos_weights": pw}, "x.", {"x": ids, "unix_ts": ts}, L)
+        qh, kh, vh = (t.view(B, L, H, hd) for t in (q, k, v))
+        a = F.silu(torch.einsum("bnhd,bmhd->bhnm", qh, kh) + rab[:, None]) / L
+        a = a * torch.tril(torch.ones(L, L))[None, None] * (m[:, None, :, None] * m[:, None, None, :])
+        return torch.einsum("bhnm,bmhd->bnhd", a, vh).reshape(B * L, d)
+
+    ins = [t.clone().requires_grad_(True) for t in (qkv[0], qkv[1], qkv[2], tw0, pw0)]
+    ref = ref_fn(*ins)
+    ref.backward(gout)
+    pad = lambda t: F.pad(t, (0, 0, 0, Np - N))   # noqa: E731
+    packed = torch.cat([pad(t[real]) for t in qkv], dim=1).cuda().requires_grad_(True)
+    tw, pw = tw0.cuda().requires_grad_(True), pw0.cuda().requires_grad_(True)
+    thr = ops.hstu_time_thresholds(num_buckets).cuda()
+    out = ops.hstu_attn_varlen(packed[:, :d], packed[:, d:2 * d], packed[:, 2 * d:], tw, pw, cu.cuda(), ts_packed.cuda(), thr, B, H, L)
+    out.backward(pad(gout[real]).cuda())
+
+    def close(got, want, name, rtol=5e-4, atol_rel=5e-5):
+        torch.testing.assert_close(got.cpu(), want, rtol=rtol, atol=atol_rel * float(want.abs().max()) + 1e-9, msg=lambda s: f"{name}: {s}")
+
+    close(out[:N].detach(), ref.detach()[real], "out")
+    for i, name in enumerate(("dq", "dk", "dv")):
+        close(packed.grad[:N, i * d:(i + 1) * d], ins[i].grad[real], name, rtol=2e-3, atol_rel=2e-4)
+    close(tw.grad, ins[3].grad, "d time_weights", rtol=2e-3, atol_rel=2e-4)
+    close(pw.grad, ins[4].grad, "d pos_weights", rtol=2e-3, atol_rel=2e-4)

@@ -304,3 +304,44 @@ def test_custom_positional_encoding_equals_the_fused_stock_path_when_it_restates
     x[:, :2] = 0
     with torch.no_grad():
         torch.testing.assert_close(a.encode_sessions({"x": x}), b.encode_sessions({"x": x}), rtol=1e-5, atol=1e-6)
+
+
+class HashedRowsItemNet(torch.nn.Module):
+    """A plugged item-net block written against the reference's `ItemNetBase` (item_net.py:26-57): `from_dataset`, `get_all_embeddings`."""
+
+    def __init__(self, n_items, n_factors, buckets=7):
+        super().__init__()
+        self.table = torch.nn.Parameter(torch.randn(buckets, n_factors) * 0.1)
+        self.register_buffer("bucket_of", torch.arange(n_items) % buckets, persistent=False)
+
+    @classmethod
+    def from_dataset(cls, dataset, n_factors, dropout_rate, **kwargs):
+        return cls(dataset.item_id_map.size, n_factors)
+
+    def get_all_embeddings(self):
+        return self.table[self.bucket_of]
+
+
+@pytest.mark.gpu
+def test_item_net_is_the_sum_of_whatever_blocks_it_is_given():
+    """item_net.py:463-482 sums the block list as it is: two id blocks, a plugged block — the catalog matrix, the training gradients of
+    every block and recommend() follow."""
+    from rectools_amd.dataset import Dataset
+    from rectools_amd.models import SASRecModel
+
+    ds = Dataset.construct(_interactions())
+    model = SASRecModel(n_factors=32, n_blocks=1, n_heads=2, session_max_len=4, lr=0.01, batch_size=4, epochs=2, seed=3, dropout_rate=0.0,
+                        item_net_block_types=(hnn.IdEmbeddingsItemNet, hnn.IdEmbeddingsItemNet, HashedRowsItemNet))
+    model._build_model_from_dataset(ds)
+    im = model.torch_model.item_model
+    a, b, c = (im.item_net_blocks[i] for i in range(3))
+    want = a.ids_emb.weight + b.ids_emb.weight + c.get_all_embeddings()
+    torch.testing.assert_close(im.get_all_embeddings(), want, rtol=0, atol=1e-6)
+    before = [p.detach().clone() for p in (a.ids_emb.weight, b.ids_emb.weight, c.table)]
+    model._run_epochs(0, 2)
+    model.is_fitted = True
+    for p0, p in zip(before, (a.ids_emb.weight, b.ids_emb.weight, c.table)):
+        assert not torch.equal(p0, p.detach())                  # every block of the sum trains
+    torch.testing.assert_close(a.ids_emb.weight - before[0], b.ids_emb.weight - before[1], rtol=1e-5, atol=1e-7)   # same gradient, same Adam path
+    reco = model.recommend(users=np.array([10, 30, 40]), dataset=ds, k=3, filter_viewed=True)
+    assert len(reco) > 0 and np.isfinite(reco["score"]).all()
