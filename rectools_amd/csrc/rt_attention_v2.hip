@@ -98,6 +98,51 @@ __device__ __forceinline__ void stage_image(const float* __restrict__ src, long 
   for (int w = tid; w < L::ROW3 / 8; w += nthreads) *reinterpret_cast<u32x2*>(img + n * L::ROW3 + w * 8) = u32x2{0u, 0u};
 }
 
+// Two images in ONE pass: the loads of both (U float4 each per thread and round) are issued before any split arithmetic, so a round costs
+// one memory round trip instead of two (stage_image twice: ~4 dependent round trips for a 200-row session, the prologue of a workgroup
+// that sits alone on its CU).  U = 8: a 200-row session's 13 float4 per thread (512 threads, hd 64) and a 192-row chunk of the HSTU
+// kernels are ONE round — 64 registers that are dead before the tile loop starts.  Same LDS contents as two stage_image calls.
+template <int HD>
+__device__ __forceinline__ void stage_images2(const float* __restrict__ srcA, long long ldA, float scaleA, unsigned char* imgA,
+                                              const float* __restrict__ srcB, long long ldB, float scaleB, unsigned char* imgB,
+                                              int n, int tid, int nthreads) {
+  using L = Lay<HD>;
+  constexpr int C4 = HD / 4, U = 8;
+  const int total = n * C4;
+  auto put = [&](unsigned char* img, int idx, const f32x4& x) {
+    const int r = idx / C4, c4 = idx % C4;
+    u32x2 h, m, l;
+    { unsigned a, b, c; split2(x[0], x[1], a, b, c); h[0] = a; m[0] = b; l[0] = c; }
+    { unsigned a, b, c; split2(x[2], x[3], a, b, c); h[1] = a; m[1] = b; l[1] = c; }
+    unsigned char* p = img + r * L::ROW3 + (((unsigned)c4 ^ (L::swz(r) << 1)) << 3);
+    *reinterpret_cast<u32x2*>(p) = h;
+    *reinterpret_cast<u32x2*>(p + L::ROWB) = m;
+    *reinterpret_cast<u32x2*>(p + 2 * L::ROWB) = l;
+  };
+#pragma unroll 1
+  for (int idx0 = tid; idx0 < total; idx0 += U * nthreads) {
+    f32x4 xa[U], xb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = idx0 + u * nthreads;
+      if (idx < total) {
+        const int r = idx / C4, c4 = idx % C4;
+        xa[u] = *reinterpret_cast<const f32x4*>(srcA + (long long)r * ldA + c4 * 4);
+        xb[u] = *reinterpret_cast<const f32x4*>(srcB + (long long)r * ldB + c4 * 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = idx0 + u * nthreads;
+      if (idx < total) { put(imgA, idx, xa[u] * scaleA); put(imgB, idx, xb[u] * scaleB); }
+    }
+  }
+  for (int w = tid; w < L::ROW3 / 8; w += nthreads) {
+    *reinterpret_cast<u32x2*>(imgA + n * L::ROW3 + w * 8) = u32x2{0u, 0u};
+    *reinterpret_cast<u32x2*>(imgB + n * L::ROW3 + w * 8) = u32x2{0u, 0u};
+  }
+}
+
 // 8 fp32 values of one row for the reduction slots of lane group g: columns 32 s + 8 g + (0..7), times scale, as planes
 template <int HD>
 __device__ __forceinline__ void load_owner_planes(const float* __restrict__ row, int g, float scale, P3 (&out)[HD / 32]) {
@@ -213,8 +258,7 @@ __global__ __launch_bounds__(NW * 64) void v2_fwd_kernel(VarlenArgs a) {
   if (n <= 0) return;
   unsigned char* Kimg = smem;
   unsigned char* Vimg = smem + (size_t)(n + 1) * L::ROW3;
-  stage_image<HD>(a.k + row0 * a.ldk + h * HD, a.ldk, n, 1.f, Kimg, tid, NW * 64);
-  stage_image<HD>(a.v + row0 * a.ldv + h * HD, a.ldv, n, 1.f, Vimg, tid, NW * 64);
+  stage_images2<HD>(a.k + row0 * a.ldk + h * HD, a.ldk, 1.f, Kimg, a.v + row0 * a.ldv + h * HD, a.ldv, 1.f, Vimg, n, tid, NW * 64);
   __syncthreads();
 
   const int n_pad = a.window > n ? a.window - n : 0;
@@ -334,8 +378,7 @@ __global__ __launch_bounds__(NW * 64) void v2_bwd_dq_kernel(VarlenArgs a) {
   }
   unsigned char* Kimg = smem;
   unsigned char* Vimg = smem + (size_t)(n + 1) * L::ROW3;
-  stage_image<HD>(a.k + row0 * a.ldk + h * HD, a.ldk, n, 1.f, Kimg, tid, NW * 64);
-  stage_image<HD>(a.v + row0 * a.ldv + h * HD, a.ldv, n, 1.f, Vimg, tid, NW * 64);
+  stage_images2<HD>(a.k + row0 * a.ldk + h * HD, a.ldk, 1.f, Kimg, a.v + row0 * a.ldv + h * HD, a.ldv, 1.f, Vimg, n, tid, NW * 64);
   __syncthreads();
 
   const int n_pad = a.window > n ? a.window - n : 0;
@@ -481,8 +524,7 @@ __global__ __launch_bounds__(NW * 64) void v2_bwd_dkv_kernel(VarlenArgs a) {
   float* Ls = reinterpret_cast<float*>(smem + 2 * (size_t)(n + 1) * L::ROW3);   // [n32] lse * log2(e)   (16-byte aligned: ROW3 % 16 == 0)
   float* Dl = Ls + n32;                                                         // [n32] delta
   const float qscale = a.scale * LOG2E;
-  stage_image<HD>(a.q + row0 * a.ldq + h * HD, a.ldq, n, qscale, Qimg, tid, NW * 64);
-  stage_image<HD>(a.dout + row0 * a.lddo + h * HD, a.lddo, n, 1.f, Dimg, tid, NW * 64);
+  stage_images2<HD>(a.q + row0 * a.ldq + h * HD, a.ldq, qscale, Qimg, a.dout + row0 * a.lddo + h * HD, a.lddo, 1.f, Dimg, n, tid, NW * 64);
   for (int r = tid; r < n32; r += NW * 64) {
     Ls[r] = r < n ? a.lse[(row0 + r) * a.H + h] * LOG2E : 0.f;
     Dl[r] = r < n ? a.delta[(row0 + r) * a.H + h] : 0.f;
@@ -598,6 +640,30 @@ __device__ __forceinline__ int hstu_bucket(const long long* thr, long long dt) {
   else if (b < NBUCK - 1 && t1 <= x) b += 1;
   return b < 0 ? 0 : b;
 }
+// The buckets of a lane's eight partner rows of one tile (local rows kl(e) = t0 + 16 (e >> 2) + 4 g + (e & 3), ascending in e).  Timestamps
+// are nondecreasing inside a session (the preparator sorts them: data_preparator.py:73-99), so |dt| against ONE owner is monotone along
+// the partners and so is the bucket: when the first and the last of the eight agree, all eight do — two searches instead of eight
+// wherever the tile is far from the diagonal (bucket widths grow by a factor 1.35).  `owner_is_query`: dt = t_owner - ts_p[kl]; else
+// dt = ts_p[kl] - t_owner (the dK/dV pass: the partners are the queries).
+// `span_valid`: all eight pairs are causal pairs inside the session — only then is dt of one sign over the span (a masked partner on the
+// other side of the diagonal has the opposite sign, and |dt| is not monotone across it): otherwise every element is searched.
+__device__ __forceinline__ void hstu_buckets8(const long long* thr, const long long* ts_p, long long t_owner, bool owner_is_query, int t0, int g,
+                                              int len, bool span_valid, int (&bk)[8]) {
+  auto one = [&](int e) {
+    const int kl = min(t0 + 16 * (e >> 2) + 4 * g + (e & 3), len - 1);
+    const long long dt = owner_is_query ? t_owner - ts_p[kl] : ts_p[kl] - t_owner;
+    return hstu_bucket(thr, dt);
+  };
+  const int b0 = one(0), b7 = one(7);
+  bk[0] = b0; bk[7] = b7;
+  if (span_valid && b0 == b7) {
+#pragma unroll
+    for (int e = 1; e < 7; ++e) bk[e] = b0;
+  } else {
+#pragma unroll
+    for (int e = 1; e < 7; ++e) bk[e] = one(e);
+  }
+}
 __device__ __forceinline__ float hstu_silu(float z) { return z / (1.f + __expf(-z)); }
 __device__ __forceinline__ float hstu_silu_d(float z) { const float s = 1.f / (1.f + __expf(-z)); return s * (1.f + z * (1.f - s)); }
 // both from ONE sigmoid (the dK/dV pass needs the probability and the derivative of the same element); p is hstu_silu's value up to the
@@ -680,8 +746,7 @@ __global__ __launch_bounds__(NW * 64) void v2_hstu_fwd_kernel(HstuV2Args a) {
   for (int c0 = 0; c0 < n; c0 += HCH) {
     const int len = min(HCH, n - c0);
     __syncthreads();                                  // the previous chunk's readers are done (first chunk: nothing to wait for)
-    stage_image<HD>(a.k + (row0 + c0) * a.ldk + h * HD, a.ldk, len, 1.f, l.img0, tid, NW * 64);
-    stage_image<HD>(a.v + (row0 + c0) * a.ldv + h * HD, a.ldv, len, 1.f, l.img1, tid, NW * 64);
+    stage_images2<HD>(a.k + (row0 + c0) * a.ldk + h * HD, a.ldk, 1.f, l.img0, a.v + (row0 + c0) * a.ldv + h * HD, a.ldv, 1.f, l.img1, len, tid, NW * 64);
     if (tbias) for (int j = tid; j < len; j += NW * 64) l.ts_p[j] = tsb[c0 + j];
     __syncthreads();
 
@@ -704,12 +769,14 @@ __global__ __launch_bounds__(NW * 64) void v2_hstu_fwd_kernel(HstuV2Args a) {
         f32x4 sT[2];
         rows_times_owner<HD>(l.img0, t * 32, len, Qp, i, g, sT);
         float pr[8];
+        int bk8[8];
+        if (tbias) hstu_buckets8(l.thr, l.ts_p, t_q1, true, t * 32, g, len, qok && t * 32 + 19 + 4 * g < len && c0 + t * 32 + 19 + 4 * g <= qrow, bk8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int kl = t * 32 + 16 * (e >> 2) + 4 * g + (e & 3), key = c0 + kl;
           const bool valid = qok && kl < len && key <= qrow;
           float bias = 0.f;
-          if (tbias) bias += l.tw[hstu_bucket(l.thr, t_q1 - l.ts_p[min(kl, len - 1)])];
+          if (tbias) bias += l.tw[bk8[e]];
           if (pbias) bias += l.pw[max(a.Lw - 1 + key - qrow, 0)];
           pr[e] = valid ? hstu_silu(sT[e >> 2][e & 3] + bias) * inv_l : 0.f;
         }
@@ -746,8 +813,7 @@ __global__ __launch_bounds__(NW * 64) void v2_hstu_bwd_dq_kernel(HstuV2Args a) {
   for (int c0 = 0; c0 < n; c0 += HCH) {
     const int len = min(HCH, n - c0);
     __syncthreads();
-    stage_image<HD>(a.k + (row0 + c0) * a.ldk + h * HD, a.ldk, len, 1.f, l.img0, tid, NW * 64);
-    stage_image<HD>(a.v + (row0 + c0) * a.ldv + h * HD, a.ldv, len, 1.f, l.img1, tid, NW * 64);
+    stage_images2<HD>(a.k + (row0 + c0) * a.ldk + h * HD, a.ldk, 1.f, l.img0, a.v + (row0 + c0) * a.ldv + h * HD, a.ldv, 1.f, l.img1, len, tid, NW * 64);
     if (tbias) for (int j = tid; j < len; j += NW * 64) l.ts_p[j] = tsb[c0 + j];
     __syncthreads();
 
@@ -774,6 +840,8 @@ __global__ __launch_bounds__(NW * 64) void v2_hstu_bwd_dq_kernel(HstuV2Args a) {
         rows_times_owner<HD>(l.img0, t * 32, len, Qp, i, g, sT);
         rows_times_owner<HD>(l.img1, t * 32, len, Dp, i, g, dpT);
         float ds[8];
+        int bk8[8];
+        if (tbias) hstu_buckets8(l.thr, l.ts_p, t_q1, true, t * 32, g, len, qok && t * 32 + 19 + 4 * g < len && c0 + t * 32 + 19 + 4 * g <= qrow, bk8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int kl = t * 32 + 16 * (e >> 2) + 4 * g + (e & 3), key = c0 + kl;
@@ -781,7 +849,7 @@ __global__ __launch_bounds__(NW * 64) void v2_hstu_bwd_dq_kernel(HstuV2Args a) {
           float bias = 0.f;
           int bk = 0;
           const int pidx = max(a.Lw - 1 + key - qrow, 0);
-          if (tbias) { bk = hstu_bucket(l.thr, t_q1 - l.ts_p[min(kl, len - 1)]); bias += l.tw[bk]; }
+          if (tbias) { bk = bk8[e]; bias += l.tw[bk]; }
           if (pbias) bias += l.pw[pidx];
           const float z = sT[e >> 2][e & 3] + bias;
           ds[e] = valid ? dpT[e >> 2][e & 3] * inv_l * hstu_silu_d(z) : 0.f;
@@ -829,8 +897,7 @@ __global__ __launch_bounds__(NW * 64) void v2_hstu_bwd_dkv_kernel(HstuV2Args a) 
   for (int c0 = 0; c0 < n; c0 += HCH) {                 // queries [c0, c0 + len)
     const int len = min(HCH, n - c0);
     __syncthreads();
-    stage_image<HD>(a.q + (row0 + c0) * a.ldq + h * HD, a.ldq, len, 1.f, l.img0, tid, NW * 64);
-    stage_image<HD>(a.dout + (row0 + c0) * a.lddo + h * HD, a.lddo, len, 1.f, l.img1, tid, NW * 64);
+    stage_images2<HD>(a.q + (row0 + c0) * a.ldq + h * HD, a.ldq, 1.f, l.img0, a.dout + (row0 + c0) * a.lddo + h * HD, a.lddo, 1.f, l.img1, len, tid, NW * 64);
     if (tbias) for (int j = tid; j < len; j += NW * 64) l.ts_p[j] = tsb[c0 + j + 1];     // a query's time is its NEXT stamp (hstu.py:96-104)
     __syncthreads();
 
@@ -861,12 +928,14 @@ __global__ __launch_bounds__(NW * 64) void v2_hstu_bwd_dkv_kernel(HstuV2Args a) 
         rows_times_owner<HD>(l.img0, t * 32, len, Kp, i, g, sm);
         rows_times_owner<HD>(l.img1, t * 32, len, Vp, i, g, dpm);
         float pd[8], ds[8];
+        int bk8[8];
+        if (tbias) hstu_buckets8(l.thr, l.ts_p, t_k, false, t * 32, g, len, kok && t * 32 + 19 + 4 * g < len && krow <= c0 + t * 32 + 4 * g, bk8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int ql = t * 32 + 16 * (e >> 2) + 4 * g + (e & 3), q = c0 + ql;
           const bool valid = kok && ql < len && krow <= q;
           float bias = 0.f;
-          if (tbias) bias += l.tw[hstu_bucket(l.thr, l.ts_p[min(ql, len - 1)] - t_k)];
+          if (tbias) bias += l.tw[bk8[e]];
           if (pbias) bias += l.pw[max(a.Lw - 1 + krow - q, 0)];
           const float z = sm[e >> 2][e & 3] + bias;
           float pz, dz;

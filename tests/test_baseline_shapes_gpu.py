@@ -204,19 +204,22 @@ def _step_vs_oracle(cfg, batch, grad_rtol=1e-3, name="step", packed=False):
         _close(p.grad, g_ref[n], grad_rtol, 2e-5 if g_ref[n].abs().max() > 1e-6 else 1.0, f"grad {n}")
 
 
-@pytest.mark.parametrize("packed", [False, True])
-def test_stu_training_step_L512_d256_H4(packed):
-    """C4 model shape: HSTU, relative time + position bias, cosine, sampled_softmax, logits_t 0.05; B = 2 sequences — through the padded
-    window and through the packed rows (session-aware ring attention, fused packed STU node)."""
-    cfg, batch = _random_case("stu", "sampled_softmax", "cosine", 512, 256, 4, 2, 600, 16, 31, logits_t=0.05)
-    _step_vs_oracle(cfg, batch, name="C4 STU L512" + (" packed" if packed else ""), packed=packed)
+@pytest.mark.parametrize("packed,B", [(False, 2), (True, 2), (True, 8)])
+def test_stu_training_step_L512_d256_H4(packed, B):
+    """C4 model shape: HSTU, relative time + position bias, cosine, sampled_softmax, logits_t 0.05 — through the padded window and
+    through the packed rows (K6v2 bf16-plane attention, sessions longer than 192 rows in chunks; fused packed STU node), B = 2 and
+    B = 8 sequences of random lengths up to 512."""
+    cfg, batch = _random_case("stu", "sampled_softmax", "cosine", 512, 256, 4, B, 600, 16, 31, logits_t=0.05)
+    _step_vs_oracle(cfg, batch, name=f"C4 STU L512 B{B}" + (" packed" if packed else ""), packed=packed)
 
 
-def test_ligr_training_step_d512():
-    """C5 model shape: SASRec data path on LiGR blocks (SwiGLU, no FFN bias, multiplier 4) at d = 512, H = 4 (hd = 128)."""
-    cfg, batch = _random_case("ligr", "sampled_softmax", "dot", 64, 512, 4, 3, 700, 16, 32,
+@pytest.mark.parametrize("L,B", [(64, 3), (200, 4)])
+def test_ligr_training_step_d512(L, B):
+    """C5 model shape: SASRec data path on LiGR blocks (SwiGLU, no FFN bias, multiplier 4) at d = 512, H = 4 (hd = 128) — at a short
+    window and at the configuration's own L = 200 (the hd = 128 attention kernels' multi-tile geometry)."""
+    cfg, batch = _random_case("ligr", "sampled_softmax", "dot", L, 512, 4, B, 700, 16, 32,
                               layer_kwargs=dict(ff_factors_multiplier=4, ff_activation="swiglu", bias_in_ff=False))
-    _step_vs_oracle(cfg, batch, name="C5 LiGR d512")
+    _step_vs_oracle(cfg, batch, name=f"C5 LiGR d512 L{L}")
 
 
 @pytest.mark.parametrize("packed", [False, True])
