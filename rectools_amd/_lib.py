@@ -11,7 +11,8 @@ import os
 import typing as tp
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "librectools_hip.so")
+# RT_LIB_PATH: another build of the SAME library (diagnostic builds: -DRT_ABLATION_BUILD / -DRT_ATTN_TRACE, scripts/gpu/ablate.sh)
+LIB_PATH = os.environ.get("RT_LIB_PATH") or os.path.join(PKG_DIR, "librectools_hip.so")
 
 RT_OK, RT_ERR_INVALID_ARG, RT_ERR_WORKSPACE, RT_ERR_LAUNCH, RT_ERR_UNSUPPORTED = 0, 1, 2, 3, 4
 

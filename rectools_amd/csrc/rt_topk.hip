@@ -268,6 +268,9 @@ __device__ __forceinline__ void select_block(const TopkArgs& a, SelState<TU, LL>
       const long long p = pos0 + wave * 32 + row;
       if (uvalid && p < a.n_cand && s >= st.thr[tu]) cmask |= (1u << r);
     }
+#ifdef RT_ABLATION_BUILD
+    if (a.debug & 2) cmask = 0;      // (thresholds tested, nothing ever inserted)
+#endif
     if (__any(cmask != 0)) {
       // rare slow path: viewed-items check + replace-worst insert into this lane's list
       const typename ListTypes<LL>::fptr lsc = st.ls[tu]; const typename ListTypes<LL>::iptr lps = st.lp[tu];
@@ -1828,6 +1831,9 @@ __global__ __launch_bounds__(NTHREADS) void topk_coarse_frag_kernel(TopkArgs a) 
 #pragma unroll
     for (int iw = 0; iw < IW; ++iw) {
       const long long blk = a.blk_begin + sx + (j * IW + iw) * S;
+#ifdef RT_ABLATION_BUILD
+      if (a.debug & 1) { if (acc[iw][0][0] == 1.2345e-30f) a.gthr[0] = 0u; } else       // (no selection: the products only)
+#endif
       if (blk <= last_blk)
         select_block<TU, false, true>(a, st, acc[iw], 0.f, no_norm, blk * IB, list_id, user0, lane, wave, g_lds);
 #pragma unroll
