@@ -67,7 +67,6 @@ struct TopkArgs {
   int bloom;                     // engine 2: 1 = a 1024-bit Bloom filter per user of the tile sits in LDS behind the lists
   int h_only;                    // HM kernels: 1 = the images hold ONE bf16 (round-to-nearest) per value (rows of d / 2 words): one MFMA per slot
   int xmap_gx, xmap_gy;          // topk_coarse_frag_kernel on a 1-D grid: the (segments, user tiles) grid it stands for (0, 0: plain 2-D grid)
-  int pf_blocks;                 // ... and > 0: every wave touches its share of the item blocks this far ahead (pulls them into the XCD's L2)
 };
 
 // acc + |v|^2 as one fixed fma chain: engine 2 and the two-stage exact pass (topk_replay_kernel) must round a row norm alike
@@ -252,6 +251,14 @@ __device__ __forceinline__ void select_block(const TopkArgs& a, SelState<TU, LL>
     }
     float sc[16];
     unsigned cmask = 0;
+    if (!need_norm) {
+      // dot products: ONE maximum per tile decides whether any of the lane's 16 scores can enter its list (a measured 10 ms of the
+      // 4,096-user coarse pass went into 16 threshold + bounds tests per tile and block that almost never fire: with one wave per
+      // SIMD the vector work of the selection adds to the matrix time instead of hiding under it)
+      float mx = fmaxf(fmaxf(fmaxf(acc[tu][0], acc[tu][1]), fmaxf(acc[tu][2], acc[tu][3])), fmaxf(fmaxf(acc[tu][4], acc[tu][5]), fmaxf(acc[tu][6], acc[tu][7])));
+      mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(acc[tu][8], acc[tu][9]), fmaxf(acc[tu][10], acc[tu][11])), fmaxf(fmaxf(acc[tu][12], acc[tu][13]), fmaxf(acc[tu][14], acc[tu][15]))));
+      if (!__any(uvalid && mx >= st.thr[tu])) continue;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -1688,15 +1695,117 @@ int launch_stream_any(int tu, int ns, const TopkArgs& a, dim3 grid, bool ll, hip
 // loop — the shared bound is therefore read from an LDS copy that wave 0 refreshes every few block pairs).
 // Geometry, lists, bound, phases (seed / resume) and the merge are engine 2's: item blocks of IB rows, workgroup sx < n_seg takes
 // the blocks blk_begin + sx + j n_seg, wave w their rows [32 w, 32 w + 32), lists in global memory.
-//
-// L2 prefetch (pf_blocks > 0; XCD-mapped grid whose user tiles all fit one XCD).  The tiles of a segment sit on the CUs of ONE XCD and
-// walk the same item blocks in step, so every demand load of a block is the XCD's FIRST touch of its lines: all tiles wait for the same
-// HBM fetch (profiles/r4: ~4 us per load under that load x 64 KB in flight per CU = 4 TB/s of fragments, a fifth of the matrix pipe).
-// The 4 x tiles waves of the XCD share the job of touching the blocks `pf_blocks` ahead: one `global_load_dword` with a lane stride of
-// 128 bytes pulls 64 lines = 8 KB, a 128 KB block is 16 such loads, and wave gw = 4 ty + wave takes unit u = block * chunks + chunk
-// whenever u % n_waves == gw — at 32 tiles one load per wave and 8 blocks.  The load is an ordinary one (the compiler counts it in
-// vmcnt); its value is folded into a sink a whole block pair later, when it has long arrived: the wave stalls for it only as far as
-// loads return in order (the demand loads issued behind it, ~2 us once per 8 blocks).  The demand loads then hit the L2.
+// ---- selection of the fragment-major coarse pass: ONE list per user and WORKGROUP, in the LDS ------------------------------------------
+// Engine 2's selection (a list per lane, in global memory for this kernel: the LDS holds the user tile) cost the 4,096-user pass more
+// than its products — measured with the selection switched off (scripts/gpu/ablate.sh): products 19.6 ms, + threshold tests 10.2 ms,
+// + inserts 15.0 ms (+ 9 ms with a viewed filter).  An insert read the lane's list and the filter's hash table from global memory, and
+// loads return in order: every insert waited for the whole fragment pipeline of its wave (s_waitcnt vmcnt(0): ~4 us, twice per block
+// pair and wave).  Here the lists are the workgroup's: [UB][FRAG_KP] scores / positions behind the user tile, one spin lock, entry count
+// and threshold per user, the viewed items as a 512-bit Bloom filter per user.  An insert is LDS traffic only (lgkmcnt: the fragment
+// loads stay in flight); the exact probe of the filter's hash table — a global round trip — is left for candidates the Bloom filter
+// cannot clear.  One list per user instead of eight also means one threshold per user: the bound tightens eight times faster.
+// The thresholds every rejection used are published into `gthr` (no-return atomics) as before: the proof of the exact pass is unchanged.
+constexpr int FRAG_KP = 16;            // list stride (entries); the lists hold a.k <= FRAG_KP entries
+constexpr int FRAG_BLOOM_WORDS = 16;   // 512 bits per user
+
+typedef __attribute__((address_space(3))) unsigned* lds_u32p;
+typedef __attribute__((address_space(3))) int* lds_i32p;
+typedef __attribute__((address_space(3))) float* lds_f32p;
+
+struct FragSel {
+  lds_u32p thr;      // [UB] ordered keys: max(shared bound as last seen, the list's worst entry once it is full)
+  lds_i32p lock;     // [UB] 0 free / 1 held
+  lds_i32p cnt;      // [UB]
+  lds_f32p sc;       // [UB][FRAG_KP]
+  lds_i32p pos;      // [UB][FRAG_KP]
+  lds_u32p bloom;    // [UB][FRAG_BLOOM_WORDS] (only with a filter)
+};
+inline size_t frag_sel_lds_bytes(int ub) { return (size_t)ub * (4 + 4 + 4 + FRAG_KP * 8 + FRAG_BLOOM_WORDS * 4); }
+
+// one candidate (score s at catalog position p) of user `ul` (tile-local): the caller holds no lock; returns after the list is updated
+__device__ __forceinline__ void frag_insert(const TopkArgs& a, const FragSel& L, int ul, int u, float s, long long p) {
+  bool done = false;
+  while (!done) {
+    if (__hip_atomic_exchange(L.lock + ul, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
+      asm volatile("" ::: "memory");
+      int c = L.cnt[ul];
+      const lds_f32p ls = L.sc + ul * FRAG_KP; const lds_i32p lp = L.pos + ul * FRAG_KP;
+      bool changed = false;
+      if (c < a.k) {
+        ls[c] = s; lp[c] = (int)p; c += 1; L.cnt[ul] = c; changed = true;
+      } else {
+        float ws = ls[0]; long long wp = lp[0]; int wslot = 0;
+#pragma unroll
+        for (int e = 1; e < FRAG_KP; ++e)
+          if (e < a.k) { const float es = ls[e]; const long long ep = lp[e]; if (better(ws, wp, es, ep)) { ws = es; wp = ep; wslot = e; } }
+        if (better(s, p, ws, wp)) { ls[wslot] = s; lp[wslot] = (int)p; changed = true; }
+      }
+      if (changed && c == a.k) {      // the list is full: its worst entry bounds what it still accepts
+        float ws = ls[0]; long long wp = lp[0];
+#pragma unroll
+        for (int e = 1; e < FRAG_KP; ++e)
+          if (e < a.k) { const float es = ls[e]; const long long ep = lp[e]; if (better(ws, wp, es, ep)) { ws = es; wp = ep; } }
+        const unsigned key = f32_to_key(ws);
+        const unsigned old = __hip_atomic_fetch_max(L.thr + ul, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (key > old) (void)__hip_atomic_fetch_max(a.gthr + u, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // no return value: no wait
+      }
+      asm volatile("" ::: "memory");
+      __hip_atomic_store(L.lock + ul, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);    // (LDS operations of a wave execute in order)
+      done = true;
+    }
+  }
+}
+
+// absorb one finished item block of one wave: acc[tu][r] = score of row (r & 3) + 8 (r >> 2) + 4 half of the wave's 32 rows x user col
+template <int TU>
+__device__ __forceinline__ void frag_select_block(const TopkArgs& a, const FragSel& L, const f32x16 (&acc)[TU], long long pos0, int user0,
+                                                  int lane, int wave) {
+  const int col = lane & 31, half = lane >> 5;
+  const long long row0 = pos0 + wave * 32;
+  const int rows_left = (int)(a.n_cand - row0 < 32 ? (a.n_cand - row0 < 0 ? 0 : a.n_cand - row0) : 32);
+#pragma unroll
+  for (int tu = 0; tu < TU; ++tu) {
+    const int ul = tu * 32 + col, u = user0 + ul;
+    const bool uvalid = u < a.n_users;
+    float thr = key_to_f32(__hip_atomic_load(L.thr + ul, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));   // (other waves raise it)
+    float mx = fmaxf(fmaxf(fmaxf(acc[tu][0], acc[tu][1]), fmaxf(acc[tu][2], acc[tu][3])), fmaxf(fmaxf(acc[tu][4], acc[tu][5]), fmaxf(acc[tu][6], acc[tu][7])));
+    mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(acc[tu][8], acc[tu][9]), fmaxf(acc[tu][10], acc[tu][11])), fmaxf(fmaxf(acc[tu][12], acc[tu][13]), fmaxf(acc[tu][14], acc[tu][15]))));
+    if (!__any(uvalid && mx >= thr)) continue;
+    unsigned cmask = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (uvalid && row < rows_left && acc[tu][r] >= thr) cmask |= (1u << r);
+    }
+    // lanes l and l + 32 hold the same user (rows of the other half): one half at a time, so that no two lanes of a wave ever spin on
+    // the same lock
+    for (int hh = 0; hh < 2; ++hh) {
+      if (half != hh) continue;
+      while (cmask != 0) {
+        const int r = __ffs(cmask) - 1;
+        cmask &= cmask - 1;
+        float s = acc[tu][0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) s = (r == i) ? acc[tu][i] : s;      // static-index select: no scratch
+        thr = key_to_f32(__hip_atomic_load(L.thr + ul, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (!(s >= thr)) continue;                                         // the bound may have risen since the tile's test
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const long long p = row0 + row, cid = p + a.id_offset;
+        if (a.bloom) {      // viewed items: two bits of the user's Bloom filter clear most candidates without leaving the LDS
+          const unsigned h1 = ((unsigned)cid * 0x9E3779B1u) >> 23, h2 = ((unsigned)cid * 0x85EBCA77u) >> 23;
+          const lds_u32p bl = L.bloom + ul * FRAG_BLOOM_WORDS;
+          if (((bl[h1 >> 5] >> (h1 & 31)) & (bl[h2 >> 5] >> (h2 & 31)) & 1u) != 0) {
+            const bool hit = is_filtered(a, u, cid);                       // exact: hash-table probe in global memory (a round trip)
+            __builtin_amdgcn_s_waitcnt(0x0F70);                            // leave with an empty VMEM scoreboard (see select_block)
+            if (hit) continue;
+          }
+        }
+        frag_insert(a, L, ul, u, s, p);
+      }
+    }
+  }
+}
+
 template <int TU>
 __global__ __launch_bounds__(NTHREADS) void topk_coarse_frag_kernel(TopkArgs a) {
   constexpr int UB = 32 * TU;
@@ -1722,24 +1831,62 @@ __global__ __launch_bounds__(NTHREADS) void topk_coarse_frag_kernel(TopkArgs a) 
   }
   const int user0 = ty * UB;
   const int n_s = a.d >> 3;                                                // k = 16 slots per row (a.d = words per image row = d / 2)
-  unsigned* const g_lds = reinterpret_cast<unsigned*>(smem + (size_t)TU * n_s * 64 * 4);   // [UB] copy of the shared bound
+  // behind the user tile: the workgroup's selection state (FragSel)
+  FragSel L;
+  {
+    typedef __attribute__((address_space(3))) unsigned char* lds_bytep;
+    lds_bytep base = (lds_bytep)(smem) + (size_t)TU * n_s * 64 * 16;
+    L.thr = (lds_u32p)base; base += UB * 4;
+    L.lock = (lds_i32p)base; base += UB * 4;
+    L.cnt = (lds_i32p)base; base += UB * 4;
+    L.sc = (lds_f32p)base; base += UB * FRAG_KP * 4;
+    L.pos = (lds_i32p)base; base += UB * FRAG_KP * 4;
+    L.bloom = (lds_u32p)base;
+  }
 
   const long long n_blocks = a.blk_end - a.blk_begin;
   const long long my_blocks = (sx < S && n_blocks > sx) ? (n_blocks - sx + S - 1) / S : 0;
-  const int list_id = sx * LISTS_PER_WG + wave * 2 + half;
-  SelState<TU, false> st;
-  st.init();
-  st.bind_global(a, list_id, user0, lane);
-  st.bind_filter(a, user0, lane);
-  if (a.resume) st.resume(a, list_id, user0, lane, false);
-  if (my_blocks == 0) { if (!a.resume) publish_counts<TU, false>(a, st, list_id, user0, lane, false); return; }
+  // the workgroup's list of a user is list `slot` of its LISTS_PER_WG slots in the global arrays the merge kernels read (the other slots
+  // stay empty); a resumed phase (after the seeding prefix) fills slot 1 and leaves the prefix's slot 0 as it is
+  const int slot = a.resume ? 1 : 0;
+  auto publish = [&](bool with_lists) {
+    for (int i = tid; i < UB * LISTS_PER_WG; i += NTHREADS) {
+      const int ul = i % UB, sl = i / UB, u = user0 + ul;
+      if (u >= a.n_users || (a.resume && sl != slot)) continue;
+      a.list_counts[(long long)(sx * LISTS_PER_WG + sl) * a.n_users_pad + u] = (with_lists && sl == slot) ? L.cnt[ul] : 0;
+    }
+    if (with_lists)
+      for (int i = tid; i < UB * FRAG_KP; i += NTHREADS) {
+        const int ul = i / FRAG_KP, e = i % FRAG_KP, u = user0 + ul;
+        if (u >= a.n_users || e >= L.cnt[ul]) continue;
+        const long long dst = ((long long)(sx * LISTS_PER_WG + slot) * a.n_users_pad + u) * a.k + e;
+        a.list_scores[dst] = L.sc[i]; a.list_pos[dst] = L.pos[i];
+      }
+  };
+  if (my_blocks == 0) { publish(false); return; }
 
-  {   // the user tile (the image is padded to whole tiles) and the bound's copy
+  {   // the user tile (the image is padded to whole tiles), the bound, empty lists, the viewed items' Bloom filters
     const u32x4* ug = reinterpret_cast<const u32x4*>(a.users) + (long long)(user0 >> 5) * n_s * 64;
     for (int i = tid; i < TU * n_s * 64; i += NTHREADS) ufrag[i] = ug[i];
     for (int i = tid; i < UB; i += NTHREADS) {
       int u = user0 + i; if (u >= a.n_users_pad) u = a.n_users_pad - 1;
-      g_lds[i] = __hip_atomic_load(a.gthr + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      L.thr[i] = __hip_atomic_load(a.gthr + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      L.lock[i] = 0; L.cnt[i] = 0;
+    }
+    if (a.bloom) {
+      for (int i = tid; i < UB * FRAG_BLOOM_WORDS; i += NTHREADS) L.bloom[i] = 0u;
+      __syncthreads();
+      for (int ul = wave; ul < UB; ul += NTHREADS / 64) {
+        const int u = user0 + ul;
+        if (u >= a.n_users) continue;
+        const long long lo = a.filt_indptr[u], hi = a.filt_indptr[u + 1];
+        for (long long e = lo + lane; e < hi; e += 64) {
+          const unsigned cid = (unsigned)a.filt_indices[e];
+          const unsigned h1 = (cid * 0x9E3779B1u) >> 23, h2 = (cid * 0x85EBCA77u) >> 23;
+          (void)__hip_atomic_fetch_or(L.bloom + ul * FRAG_BLOOM_WORDS + (h1 >> 5), 1u << (h1 & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          (void)__hip_atomic_fetch_or(L.bloom + ul * FRAG_BLOOM_WORDS + (h2 >> 5), 1u << (h2 & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
     }
     __syncthreads();
   }
@@ -1749,8 +1896,6 @@ __global__ __launch_bounds__(NTHREADS) void topk_coarse_frag_kernel(TopkArgs a) 
   // fragment (s = 0) of this wave's rows of item block `blk`, this lane's unit
   auto frag0 = [&](long long blk) -> const u32x4* { return items + ((blk * (IB / 32) + wave) * n_s) * 64 + lane; };
   const long long n_pairs = (my_blocks + IW - 1) / IW;
-  const float no_norm[TU] = {};
-
   f32x16 acc[IW][TU];
 #pragma unroll
   for (int iw = 0; iw < IW; ++iw)
@@ -1779,36 +1924,12 @@ __global__ __launch_bounds__(NTHREADS) void topk_coarse_frag_kernel(TopkArgs a) 
 #pragma unroll
   for (int q = 0; q < P; ++q) issue(abuf[q]);
 
-  // L2 prefetch: this wave's share of the blocks ahead (see the kernel's header)
-  const int pf_chunks = (int)(((long long)IB * a.d * 4 + 8191) / 8192);
-  const int pf_waves = (NTHREADS / 64) * (a.xmap_gy > 0 ? a.xmap_gy : 1);
-  const int pf_me = ty * (NTHREADS / 64) + wave;
-  unsigned pf_val = 0u, pf_sink = 0u;
-  auto prefetch_block = [&](long long jb) {      // jb: index into this segment's blocks
-    if (jb >= my_blocks) return;
-    int c = (int)(((long long)pf_me - jb * pf_chunks) % pf_waves);
-    if (c < 0) c += pf_waves;
-    if (c < pf_chunks) {
-      long long off = (long long)c * 8192 + lane * 128;
-      const long long blk_bytes = (long long)IB * a.d * 4;
-      if (off >= blk_bytes) off = blk_bytes - 4;
-      const long long blk = a.blk_begin + sx + jb * S;
-      pf_val ^= *reinterpret_cast<const volatile unsigned*>(reinterpret_cast<const char*>(a.items) + blk * blk_bytes + off);
-    }
-  };
-  if (a.pf_blocks > 0)
-    for (int jb = 0; jb < a.pf_blocks; ++jb) prefetch_block(jb);
-
   // the user fragments of slot s + 1 are read while the products of slot s run (one wave per SIMD: nobody else hides the LDS latency)
   u32x4 bf[2][TU];
 #pragma unroll
   for (int tu = 0; tu < TU; ++tu) bf[0][tu] = ufrag[(tu * n_s) * 64 + lane];
 #pragma unroll 1
   for (long long j = 0; j < n_pairs; ++j) {
-    if (a.pf_blocks > 0) {
-      pf_sink ^= pf_val; pf_val = 0u;                       // (what the previous pair asked for: arrived long ago)
-      prefetch_block(j * IW + a.pf_blocks); prefetch_block(j * IW + 1 + a.pf_blocks);
-    }
 #pragma unroll 1
     for (int s0 = 0; s0 < n_s; s0 += P) {
 #pragma unroll
@@ -1834,25 +1955,25 @@ __global__ __launch_bounds__(NTHREADS) void topk_coarse_frag_kernel(TopkArgs a) 
 #ifdef RT_ABLATION_BUILD
       if (a.debug & 1) { if (acc[iw][0][0] == 1.2345e-30f) a.gthr[0] = 0u; } else       // (no selection: the products only)
 #endif
-      if (blk <= last_blk)
-        select_block<TU, false, true>(a, st, acc[iw], 0.f, no_norm, blk * IB, list_id, user0, lane, wave, g_lds);
+      if (blk <= last_blk) frag_select_block<TU>(a, L, acc[iw], blk * IB, user0, lane, wave);
 #pragma unroll
       for (int tu = 0; tu < TU; ++tu)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[iw][tu][r] = 0.f;
     }
-    if ((j & 3) == 3 && wave == 0) {   // refresh the LDS copy of the shared bound (the only vector-memory read of the loop; wave 0 only)
+    if ((j & 3) == 3 && wave == 0) {   // fold the shared bound (other segments' lists) into the thresholds: the only vector-memory read of the loop
       for (int i = lane; i < UB; i += 64) {
         int u = user0 + i; if (u >= a.n_users_pad) u = a.n_users_pad - 1;
-        g_lds[i] = __hip_atomic_load(a.gthr + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (void)__hip_atomic_fetch_max(L.thr + i, __hip_atomic_load(a.gthr + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
   }
-  if ((pf_sink ^ pf_val) == 0x9E3779B9u && a.n_users_pad < 0) a.gthr[0] = pf_sink;      // never true: keeps the prefetch loads alive
-  publish_counts<TU, false>(a, st, list_id, user0, lane, false);
+  __syncthreads();
+  publish(true);
 }
 
-inline size_t coarse_frag_lds_bytes(int tu, int d_words) { return (size_t)tu * (d_words / 8) * 64 * 16 + (size_t)32 * tu * 4; }
+inline size_t coarse_frag_lds_bytes(int tu, int d_words) { return (size_t)tu * (d_words / 8) * 64 * 16 + frag_sel_lds_bytes(32 * tu); }
 
 template <int TU>
 int launch_coarse_frag_t(const TopkArgs& a0, dim3 grid, hipStream_t stream) {
@@ -1860,9 +1981,8 @@ int launch_coarse_frag_t(const TopkArgs& a0, dim3 grid, hipStream_t stream) {
   if (grid.y > 1 && env_int("RT_TOPK_XCD_MAP", 1) != 0) {     // 1-D grid, XCD-owned segments (see the kernel); RT_TOPK_XCD_MAP=0: the plain grid
     a.xmap_gx = (int)grid.x; a.xmap_gy = (int)grid.y;
     grid = dim3(8u * ((grid.x + 7u) / 8u) * grid.y, 1u, 1u);
-    // the tiles of a segment run side by side on one XCD only while they all fit it (32 CUs, one workgroup each)
-    if (a.xmap_gy <= 32) a.pf_blocks = env_int("RT_TOPK_PF_BLOCKS", 12);
   }
+  a.bloom = (a.filt_indptr != nullptr && a.filt_indices != nullptr) ? 1 : 0;      // (512 bits per user in the LDS, in front of the exact test)
   const size_t lds = coarse_frag_lds_bytes(TU, a.d);
   static size_t attr_lds = 0;
   if (lds > 64 * 1024 && lds > attr_lds) {
@@ -2105,7 +2225,7 @@ static int topk_score_impl(const float* users, int64_t user_stride, const int64_
     return RT_OK;
   }
   const int k_out = k;                        // two-stage: the lists hold more than the k entries the caller asked for
-  if (ts != nullptr) k = two_stage_list_k(k);
+  if (ts != nullptr) k = ts->h_only == 2 ? FRAG_KP : two_stage_list_k(k);     // (the fragment pass keeps ONE list per user and workgroup: a longer one)
   Plan P = make_plan(n_users, n_candidates, k, users_per_pass);
   if (ts != nullptr && ts->h_only == 2) {
     P.lds_lists = false;                                   // topk_coarse_frag_kernel: the LDS holds the user tile
@@ -2232,7 +2352,7 @@ int rt_topk_score(const float* users, int64_t user_stride, const int64_t* user_r
 
 size_t rt_topk_two_stage_workspace_bytes(int32_t n_users, int64_t n_candidates, int32_t k, int32_t k_cand, int32_t users_per_pass) {
   if (n_users <= 0 || n_candidates <= 0 || k <= 0 || k_cand <= 0) return 0;
-  const Plan P = make_plan(n_users, n_candidates, two_stage_list_k(k), users_per_pass);
+  const Plan P = make_plan(n_users, n_candidates, FRAG_KP, users_per_pass);       // (the longest lists any coarse pass keeps)
   return P.total + two_stage_extra_bytes(P.users_per_launch, k_cand);
 }
 
