@@ -1723,10 +1723,13 @@ struct FragSel {
 inline size_t frag_sel_lds_bytes(int ub) { return (size_t)ub * (4 + 4 + 4 + FRAG_KP * 8 + FRAG_BLOOM_WORDS * 4); }
 
 // one candidate (score s at catalog position p) of user `ul` (tile-local): the caller holds no lock; returns after the list is updated
-__device__ __forceinline__ void frag_insert(const TopkArgs& a, const FragSel& L, int ul, int u, float s, long long p) {
-  bool done = false;
-  while (!done) {
-    if (__hip_atomic_exchange(L.lock + ul, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
+__device__ __forceinline__ void frag_insert(const TopkArgs& a, const FragSel& L, int ul, int u, float s, long long p, bool have) {
+  // The loop leaves on a WAVE-UNIFORM condition and the critical section sits inside it.  With a per-lane exit (`while (!done)`) the
+  // critical section is the loop's exit block: the compiler is free to run it after the loop has reconverged — a lane that holds a lock
+  // then waits for a lane of its own wave that spins on a lock held, the same way, in another wave (seen as a hang on hardware).
+  bool pending = have;              // (called by the whole wave: lanes without a candidate just keep the others company)
+  while (__any(pending)) {
+    if (pending && __hip_atomic_exchange(L.lock + ul, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
       asm volatile("" ::: "memory");
       int c = L.cnt[ul];
       const lds_f32p ls = L.sc + ul * FRAG_KP; const lds_i32p lp = L.pos + ul * FRAG_KP;
@@ -1751,7 +1754,7 @@ __device__ __forceinline__ void frag_insert(const TopkArgs& a, const FragSel& L,
       }
       asm volatile("" ::: "memory");
       __hip_atomic_store(L.lock + ul, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);    // (LDS operations of a wave execute in order)
-      done = true;
+      pending = false;
     }
   }
 }
@@ -1780,27 +1783,31 @@ __device__ __forceinline__ void frag_select_block(const TopkArgs& a, const FragS
     // lanes l and l + 32 hold the same user (rows of the other half): one half at a time, so that no two lanes of a wave ever spin on
     // the same lock
     for (int hh = 0; hh < 2; ++hh) {
-      if (half != hh) continue;
-      while (cmask != 0) {
-        const int r = __ffs(cmask) - 1;
-        cmask &= cmask - 1;
-        float s = acc[tu][0];
+      unsigned mine = half == hh ? cmask : 0u;
+      while (__any(mine != 0)) {       // wave-uniform: every lane takes every round (the lock loop inside needs the whole wave)
+        bool have = false;
+        float s = 0.f; long long p = 0;
+        if (mine != 0) {
+          const int r = __ffs(mine) - 1;
+          mine &= mine - 1;
+          s = acc[tu][0];
 #pragma unroll
-        for (int i = 1; i < 16; ++i) s = (r == i) ? acc[tu][i] : s;      // static-index select: no scratch
-        thr = key_to_f32(__hip_atomic_load(L.thr + ul, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-        if (!(s >= thr)) continue;                                         // the bound may have risen since the tile's test
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const long long p = row0 + row, cid = p + a.id_offset;
-        if (a.bloom) {      // viewed items: two bits of the user's Bloom filter clear most candidates without leaving the LDS
+          for (int i = 1; i < 16; ++i) s = (r == i) ? acc[tu][i] : s;      // static-index select: no scratch
+          thr = key_to_f32(__hip_atomic_load(L.thr + ul, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+          have = s >= thr;                                                   // (the bound may have risen since the tile's test)
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+          p = row0 + row;
+        }
+        if (a.bloom && have) {      // viewed items: two bits of the user's Bloom filter clear most candidates without leaving the LDS
+          const long long cid = p + a.id_offset;
           const unsigned h1 = ((unsigned)cid * 0x9E3779B1u) >> 23, h2 = ((unsigned)cid * 0x85EBCA77u) >> 23;
           const lds_u32p bl = L.bloom + ul * FRAG_BLOOM_WORDS;
           if (((bl[h1 >> 5] >> (h1 & 31)) & (bl[h2 >> 5] >> (h2 & 31)) & 1u) != 0) {
-            const bool hit = is_filtered(a, u, cid);                       // exact: hash-table probe in global memory (a round trip)
-            __builtin_amdgcn_s_waitcnt(0x0F70);                            // leave with an empty VMEM scoreboard (see select_block)
-            if (hit) continue;
+            have = !is_filtered(a, u, cid);                                  // exact: hash-table probe in global memory (a round trip)
+            __builtin_amdgcn_s_waitcnt(0x0F70);                              // leave with an empty VMEM scoreboard (see select_block)
           }
         }
-        frag_insert(a, L, ul, u, s, p);
+        frag_insert(a, L, ul, u, s, p, have);
       }
     }
   }
