@@ -67,6 +67,7 @@ struct TopkArgs {
   int bloom;                     // engine 2: 1 = a 1024-bit Bloom filter per user of the tile sits in LDS behind the lists
   int h_only;                    // HM kernels: 1 = the images hold ONE bf16 (round-to-nearest) per value (rows of d / 2 words): one MFMA per slot
   int xmap_gx, xmap_gy;          // topk_coarse_frag_kernel on a 1-D grid: the (segments, user tiles) grid it stands for (0, 0: plain 2-D grid)
+  int pf_blocks;                 // ... and > 0: every wave touches its share of the item blocks this far ahead (pulls them into the XCD's L2)
 };
 
 // acc + |v|^2 as one fixed fma chain: engine 2 and the two-stage exact pass (topk_replay_kernel) must round a row norm alike
@@ -1931,12 +1932,40 @@ __global__ __launch_bounds__(NTHREADS) void topk_coarse_frag_kernel(TopkArgs a) 
 #pragma unroll
   for (int q = 0; q < P; ++q) issue(abuf[q]);
 
+  // L2 prefetch (pf_blocks > 0): the user tiles of a segment sit on the CUs of ONE XCD and walk the same item blocks in step, so every
+  // demand load of a block is the XCD's FIRST touch of its lines and all tiles wait for the same HBM fetch.  The 4 x tiles waves of the
+  // XCD share the job of touching the blocks `pf_blocks` ahead: one dword load with a lane stride of 128 bytes pulls 64 lines = 8 KB, a
+  // 128 KB block is 16 such loads; wave gw = 4 ty + wave takes unit u = block * chunks + chunk whenever u % n_waves == gw.  An ordinary
+  // load (the compiler counts it in vmcnt) whose value is folded into a sink a whole block pair later.
+  const int pf_chunks = (int)(((long long)IB * a.d * 4 + 8191) / 8192);
+  const int pf_waves = (NTHREADS / 64) * (a.xmap_gy > 0 ? a.xmap_gy : 1);
+  const int pf_me = ty * (NTHREADS / 64) + wave;
+  unsigned pf_val = 0u, pf_sink = 0u;
+  auto prefetch_block = [&](long long jb) {      // jb: index into this segment's blocks
+    if (jb >= my_blocks) return;
+    int c = (int)(((long long)pf_me - jb * pf_chunks) % pf_waves);
+    if (c < 0) c += pf_waves;
+    if (c < pf_chunks) {
+      long long off = (long long)c * 8192 + lane * 128;
+      const long long blk_bytes = (long long)IB * a.d * 4;
+      if (off >= blk_bytes) off = blk_bytes - 4;
+      const long long blk = a.blk_begin + sx + jb * S;
+      pf_val ^= *reinterpret_cast<const volatile unsigned*>(reinterpret_cast<const char*>(a.items) + blk * blk_bytes + off);
+    }
+  };
+  if (a.pf_blocks > 0)
+    for (int jb = 0; jb < a.pf_blocks; ++jb) prefetch_block(jb);
+
   // the user fragments of slot s + 1 are read while the products of slot s run (one wave per SIMD: nobody else hides the LDS latency)
   u32x4 bf[2][TU];
 #pragma unroll
   for (int tu = 0; tu < TU; ++tu) bf[0][tu] = ufrag[(tu * n_s) * 64 + lane];
 #pragma unroll 1
   for (long long j = 0; j < n_pairs; ++j) {
+    if (a.pf_blocks > 0) {
+      pf_sink ^= pf_val; pf_val = 0u;                       // (what the previous pair asked for: arrived long ago)
+      prefetch_block(j * IW + a.pf_blocks); prefetch_block(j * IW + 1 + a.pf_blocks);
+    }
 #pragma unroll 1
     for (int s0 = 0; s0 < n_s; s0 += P) {
 #pragma unroll
@@ -1968,7 +1997,10 @@ __global__ __launch_bounds__(NTHREADS) void topk_coarse_frag_kernel(TopkArgs a) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[iw][tu][r] = 0.f;
     }
-    if ((j & 3) == 3 && wave == 0) {   // fold the shared bound (other segments' lists) into the thresholds: the only vector-memory read of the loop
+    // fold the shared bound (other segments' lists) into the thresholds: the only vector-memory read of the loop.  Its wave waits for the
+    // load behind its whole fragment pipeline (loads return in order): every 16 pairs, and the four waves take turns — the workgroup ends
+    // with its slowest wave
+    if ((j & 15) == 15 && wave == (int)((j >> 4) & 3)) {
       for (int i = lane; i < UB; i += 64) {
         int u = user0 + i; if (u >= a.n_users_pad) u = a.n_users_pad - 1;
         (void)__hip_atomic_fetch_max(L.thr + i, __hip_atomic_load(a.gthr + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
@@ -1976,6 +2008,7 @@ __global__ __launch_bounds__(NTHREADS) void topk_coarse_frag_kernel(TopkArgs a) 
       }
     }
   }
+  if ((pf_sink ^ pf_val) == 0x9E3779B9u && a.n_users_pad < 0) a.gthr[0] = pf_sink;      // never true: keeps the prefetch loads alive
   __syncthreads();
   publish(true);
 }
@@ -1988,6 +2021,8 @@ int launch_coarse_frag_t(const TopkArgs& a0, dim3 grid, hipStream_t stream) {
   if (grid.y > 1 && env_int("RT_TOPK_XCD_MAP", 1) != 0) {     // 1-D grid, XCD-owned segments (see the kernel); RT_TOPK_XCD_MAP=0: the plain grid
     a.xmap_gx = (int)grid.x; a.xmap_gy = (int)grid.y;
     grid = dim3(8u * ((grid.x + 7u) / 8u) * grid.y, 1u, 1u);
+    // the tiles of a segment run side by side on one XCD only while they all fit it (32 CUs, one workgroup each)
+    if (a.xmap_gy <= 32) a.pf_blocks = env_int("RT_TOPK_PF_BLOCKS", 0);
   }
   a.bloom = (a.filt_indptr != nullptr && a.filt_indices != nullptr) ? 1 : 0;      // (512 bits per user in the LDS, in front of the exact test)
   const size_t lds = coarse_frag_lds_bytes(TU, a.d);
