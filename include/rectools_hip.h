@@ -576,8 +576,7 @@ int rt_sampled_loss_fwd_train(const float* sess, int64_t ld_sess, const float* t
 /* The counting sort of the (position, candidate) pairs by candidate id depends on y / neg alone: run ahead of the forward pass (on
  * another stream: six small launches that would otherwise sit between the forward and the backward kernels) it leaves the ranks, the
  * segment offsets and the popular ids' chunks in `workspace`; fwd_train / bwd called with prepared = 1 on the SAME workspace skip their
- * share (the forward writes the pair records, the backward starts at the row reductions).  RT_ERR_UNSUPPORTED while the XCD-sliced
- * forward is switched on (RT_LOSS_SLICED=1): use prepared = 0 then. */
+ * share (the forward writes the pair records, the backward starts at the row reductions). */
 int rt_sampled_loss_prepare(const int64_t* y, const int64_t* neg, int32_t M, int32_t N, int32_t d, int32_t V, void* workspace,
                             size_t workspace_bytes, rt_stream_t stream);
 /* d_sess or d_table may be NULL: the two halves are independent (d_sess is a scaled copy of d_sess_unit; d_table consumes the

@@ -253,191 +253,11 @@ __global__ __launch_bounds__(GT + 64 * NLD) void gemm_wp_kernel(WpGroup gg) {
     }
 }
 
-// ---- K7w, second form: loader waves + a ring that runs ahead (round 4) --------------------------------------------------------------------
-// What rt_ffn.hip's ablation showed for the loop above: a workgroup that issues its own LDS-DMA and waits `vmcnt(0)` at every k-step keeps
-// the matrix pipe idle while pieces issue and land, and its C stores gate the ring (stores and DMA share the wave's counter).  Here the
-// roles are separate waves with separate counters: FOUR LOADER waves stream activation and weight tiles through an NSTG-stage ring and run
-// NSTG - 1 stages ahead — across tile boundaries: a workgroup walks tiles t, t + G, ... and the next tile's stages land under the current
-// tile's epilogue —, FOUR COMPUTE waves (stacked along M, 32 x 128 each) issue no vector-memory instruction in the loop and never wait for
-// their stores.  Same split, same six terms in the same order, same k order: bit-identical results.  The matrix instruction takes its
-// operands swapped (weights as rows), so a lane's accumulators are four CONSECUTIVE columns of one C row: 16-byte stores, bias / residual
-// reads.  NSTG = 3: 120 KB, one workgroup (8 waves) per CU — M-large products and tile counts up to one round; NSTG = 2: 80 KB, two per CU.
-constexpr int LW_GT = 512, LW_PIECES = 10;     // per loader wave and stage: 4 activation pieces + 2 x 3 weight pieces
-
-template <bool BTR>
-struct LwStream {
-  const WpGroup* gg;
-  int total, stride;                 // tiles of the launch; tiles between two tiles of this workgroup
-  int t, kk, KS, slot, lw, lane;
-  const float* a_src[4];
-  const unsigned short* b_src[2];
-  long long b_step, plane_stride;
-  unsigned base;
-  __device__ __forceinline__ bool more() const { return t < total; }
-  __device__ __forceinline__ void open_tile() {
-    int tt = t;
-    const int p = (tt >= gg->tile_end[0]) + (tt >= gg->tile_end[1]) + (tt >= gg->tile_end[2]);
-    tt -= p > 0 ? gg->tile_end[p - 1] : 0;
-    const WpArgs& g = gg->g[p];
-    const int n_tn = g.N / BN, n_tiles = (g.M / BM) * n_tn;
-    { const int nx = 8, q = n_tiles / nx, r = n_tiles % nx, xcd = tt % nx, idx = tt / nx;
-      tt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx; }
-    const int m0 = (tt / n_tn) * BM, n0 = (tt % n_tn) * BN;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = (lw * 4 + j) * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ ((row >> 1) & 7);
-      a_src[j] = g.A + (long long)(m0 + row) * g.lda + c * 4;
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int q = (lw * 2 + j) * 64 + lane;
-      if (!BTR) {
-        const int row = q >> 2, c = (q & 3) ^ ((row >> 2) & 3);
-        b_src[j] = g.W + (long long)(n0 + row) * g.ldw + c * 8;
-      } else {
-        const int row = q >> 4, u = (q & 15) ^ ((row & 3) << 2);
-        b_src[j] = g.W + (long long)row * g.ldw + n0 + u * 8;
-      }
-    }
-    b_step = BTR ? (long long)BK * g.ldw : BK;
-    plane_stride = g.plane_stride;
-    KS = g.K / BK;
-  }
-  template <int NSTG>
-  __device__ __forceinline__ void issue() {
-    if (kk == 0) open_tile();
-    const unsigned sb = base + (unsigned)(slot * STAGE_B);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { dma16(a_src[j], sb + (unsigned)((lw * 4 + j) * 1024)); a_src[j] += BK; }
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) dma16(b_src[j] + pl * plane_stride, sb + (unsigned)(A_TILE_B + pl * P_TILE_B + (lw * 2 + j) * 1024));
-#pragma unroll
-    for (int j = 0; j < 2; ++j) b_src[j] += b_step;
-    if (++slot == NSTG) slot = 0;
-    if (++kk == KS) { kk = 0; t += stride; }
-  }
-};
-
-template <bool BTR, int NSTG>
-__global__ __launch_bounds__(LW_GT) void gemm_wp_lw_kernel(WpGroup gg, int total) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cw = wave & 3, col = lane & 31, half = lane >> 5;
-  if (wave >= 4) {
-    LwStream<BTR> ls;
-    ls.gg = &gg; ls.total = total; ls.stride = gridDim.x; ls.t = blockIdx.x; ls.kk = 0; ls.KS = 1; ls.slot = 0; ls.lw = cw; ls.lane = lane;
-    ls.base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
-    int ahead = 0;                                       // stages issued and not yet published
-#pragma unroll
-    for (int i = 0; i < NSTG - 1; ++i)
-      if (ls.more()) { ls.template issue<NSTG>(); ++ahead; }
-#pragma unroll 1
-    for (int t = blockIdx.x; t < total; t += gridDim.x) {
-      int tt = t;
-      const int p = (tt >= gg.tile_end[0]) + (tt >= gg.tile_end[1]) + (tt >= gg.tile_end[2]);
-      const int KS = gg.g[p].K / BK;
-#pragma unroll 1
-      for (int kk = 0; kk < KS; ++kk) {
-        // the oldest stage in flight must have landed; the (up to NSTG - 2) younger ones may still be on their way
-        if (NSTG >= 3 && ahead >= 2) wait_vmcnt<LW_PIECES>(); else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        --ahead;
-        if (ls.more()) { ls.template issue<NSTG>(); ++ahead; }
-      }
-    }
-    return;
-  }
-  int slot = 0;
-#pragma unroll 1
-  for (int t0 = blockIdx.x; t0 < total; t0 += gridDim.x) {
-    int t = t0;
-    const int p = (t >= gg.tile_end[0]) + (t >= gg.tile_end[1]) + (t >= gg.tile_end[2]);
-    t -= p > 0 ? gg.tile_end[p - 1] : 0;
-    const WpArgs& g = gg.g[p];
-    const int n_tn = g.N / BN, n_tiles = (g.M / BM) * n_tn;
-    { const int nx = 8, q = n_tiles / nx, r = n_tiles % nx, xcd = t % nx, idx = t / nx;
-      t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx; }
-    const int m0 = (t / n_tn) * BM, n0 = (t % n_tn) * BN;
-    const int KS = g.K / BK;
-    f32x16 acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-#pragma unroll 1
-    for (int kk = 0; kk < KS; ++kk) {
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      const unsigned char* Ab = smem + slot * STAGE_B;
-      const unsigned char* Bb = Ab + A_TILE_B;
-      if (++slot == NSTG) slot = 0;
-#pragma unroll
-      for (int u = 0; u < BK / 16; ++u) {
-        const int row = cw * 32 + col;
-        const Split3 as = split_bf16x3(read_a(Ab, row, 4 * u + 2 * half), read_a(Ab, row, 4 * u + 2 * half + 1));
-        Split3 bs[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (!BTR) {
-            const int n = j * 32 + col;
-            const unsigned char* q = Bb + n * (BK * 2) + ((((unsigned)(2 * u + half)) ^ ((n >> 2) & 3)) << 4);
-            bs[j].h = *reinterpret_cast<const bf16x8*>(q);
-            bs[j].m = *reinterpret_cast<const bf16x8*>(q + P_TILE_B);
-            bs[j].l = *reinterpret_cast<const bf16x8*>(q + 2 * P_TILE_B);
-          } else {
-            const int i16 = lane & 15, G = lane >> 4;
-            const int ncol = j * 32 + (G & 1) * 16 + 4 * (i16 & 3);
-            s16x8 v[3];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-              s16x4 lo, hi;
-#pragma unroll
-              for (int e = 0; e < 2; ++e) {
-                const int k = 16 * u + 8 * half + 4 * e + (i16 >> 2);
-                const unsigned char* q = Bb + pl * P_TILE_B + k * (BN * 2) + ((((unsigned)(ncol >> 3)) ^ ((k & 3) << 2)) << 4) + ((ncol & 7) << 1);
-                const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((RT_LDS s16x4*)(q));
-                if (e == 0) lo = x; else hi = x;
-              }
-              v[pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            }
-            bs[j].h = __builtin_bit_cast(bf16x8, v[0]); bs[j].m = __builtin_bit_cast(bf16x8, v[1]); bs[j].l = __builtin_bit_cast(bf16x8, v[2]);
-          }
-        }
-#define RT_LW_TERM(PA, PB) \
-  _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bs[j].PB, as.PA, acc[j], 0, 0, 0);
-        RT_LW_TERM(l, h) RT_LW_TERM(h, l) RT_LW_TERM(m, m) RT_LW_TERM(m, h) RT_LW_TERM(h, m) RT_LW_TERM(h, h)
-#undef RT_LW_TERM
-      }
-    }
-    // epilogue: acc[j][4 g + e] = C[m0 + 32 cw + col][n0 + 32 j + 8 g + 4 half + e]; bias, residual, relu; 16-byte stores, never waited for
-    const long long m = m0 + cw * 32 + col;
-    f32x4 rv[4][4];
-    if (g.R != nullptr) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) rv[j][q] = *reinterpret_cast<const f32x4*>(g.R + m * g.ldr + n0 + j * 32 + 8 * q + 4 * half);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = n0 + j * 32 + 8 * q + 4 * half;
-        f32x4 v = {acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]};
-        if (g.bias != nullptr) v += *reinterpret_cast<const f32x4*>(g.bias + n);
-        if (g.R != nullptr) v += rv[j][q];
-        if (g.relu) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        *reinterpret_cast<f32x4*>(g.C + m * g.ldc + n) = v;
-      }
-  }
-}
+// (A second form — four loader waves feeding a ring that runs ahead across tile boundaries, four compute waves without a vector-memory
+// instruction in the loop, persistent tiles — was built in round 4 and measured equal to the loop above within 0 - 7 % at every shape of
+// the step and of the recommend encoder: what bounds these products is the CU's memory pipe (activation rows in, C rows out, the weight
+// planes through the L2, ~13 B/clk), not the issue cost of the DMA.  Removed in round 5 together with its switches; the lever is fewer
+// bytes per row: rt_ffn.hip.)
 
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, long long n4, long long n,
                                                            unsigned short* __restrict__ planes, long long plane_stride) {
@@ -513,47 +333,13 @@ int rt_gemm_wp(const rt_gemm_wp_problem* problems, int32_t n, int32_t w_tr, hipS
     }
     gg.tile_end[i] = tiles;
   }
-  // second form (loader waves, ring running ahead, persistent tiles): opt-in with RT_GEMM_WP_IMPL=lw.  Measured equal to the first form
-  // within 0 - 7 % at every shape of the step and of the recommend encoder (visit v4f of round 4): what bounds these products is the
-  // CU's memory pipe — activation rows in (HBM), C rows out (HBM) and the weight planes (L2) pass through it one after the other at
-  // ~13 B/clk — not the issue cost of the DMA nor the stores' hold on the counter.  The lever is fewer bytes per row (rt_ffn.hip).
-  static const int impl = [] { const char* e = getenv("RT_GEMM_WP_IMPL"); return (e != nullptr && e[0] == 'l') ? 2 : 1; }();
-  if (impl == 2) {
-    bool aligned = true;       // 16-byte C rows / bias / residual for the float4 epilogue
-    for (int i = 0; i < n; ++i) {
-      const WpArgs& a = gg.g[i];
-      aligned = aligned && (a.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0 &&
-                (reinterpret_cast<uintptr_t>(a.R) & 15) == 0 && (a.ldr & 3) == 0;
-    }
-    if (aligned) {
-      const int cus = rt_num_cus();
-      static const int force_stages = [] { const char* e = getenv("RT_GEMM_WP_STAGES"); return e ? atoi(e) : 0; }();
-      // one 120 KB workgroup (8 waves, up to 256 registers each) per CU; more tiles than CUs: a workgroup walks tiles t, t + G, ...
-      int stages = 3;
-      if (force_stages == 2 || force_stages == 3) stages = force_stages;
-      const int grid = tiles < cus ? tiles : cus;
-      const size_t lds2 = (size_t)stages * STAGE_B;
-      auto go2 = [&](auto kern) -> int {
-        RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-        kern<<<grid, LW_GT, lds2, stream>>>(gg, tiles);
-        RT_CHECK_LAUNCH();
-        return RT_OK;
-      };
-      if (stages == 3) return w_tr ? go2(&gemm_wp_lw_kernel<true, 3>) : go2(&gemm_wp_lw_kernel<false, 3>);
-      return w_tr ? go2(&gemm_wp_lw_kernel<true, 2>) : go2(&gemm_wp_lw_kernel<false, 2>);
-    }
-  }
   const size_t lds = (size_t)NS * STAGE_B;
-  static const int layout = [] { const char* e = getenv("RT_GEMM_WP_LAYOUT"); return e ? atoi(e) : 1; }();   // 1: waves 4 x 1, 2: 2 x 2
-  static const int loaders = [] { const char* e = getenv("RT_GEMM_WP_LOADERS"); return e ? atoi(e) : 0; }();   // 2: dedicated loader waves
   auto go = [&](auto kern, int threads) -> int {
     RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     kern<<<tiles, threads, lds, stream>>>(gg);
     RT_CHECK_LAUNCH();
     return RT_OK;
   };
-  if (layout == 2) return w_tr ? go(&gemm_wp_kernel<true, 2>, GT) : go(&gemm_wp_kernel<false, 2>, GT);
-  if (loaders == 2) return w_tr ? go(&gemm_wp_kernel<true, 1, 2>, GT + 128) : go(&gemm_wp_kernel<false, 1, 2>, GT + 128);
   return w_tr ? go(&gemm_wp_kernel<true, 1>, GT) : go(&gemm_wp_kernel<false, 1>, GT);
 }
 

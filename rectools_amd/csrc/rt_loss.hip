@@ -54,7 +54,6 @@ struct SampledArgs {
                                           // offsets exist before the training forward, which then writes the pair records itself
   int* heavy_count; int* heavy_ids; int* heavy_chunk;   // chunk list of the rows with > HEAVY_T pairs (rt_scan.h)
   float* slab; float* slab_bsum;          // [chunks][d] partial rows of those chunks, [chunks] partial cosine sums
-  float* part; float* part_ml;            // XCD-sliced forward: [M][8][d] partial accumulators, [M][8][2] partial (max, sum)
 };
 
 __device__ __forceinline__ float group16_sum(float v) {  // sum over the 16 lanes of a quarter-wave
@@ -425,280 +424,9 @@ __global__ __launch_bounds__(256) void sampled_fwd_kernel(SampledArgs a) {
   }
 }
 
-// ---- XCD-sliced training forward of the sampled softmax (round 4) -----------------------------------------------------------------------
-// What bounds the kernel above at the C2 shape is not the CU: 1.7 M row gathers of 1 KB out of a 27 MB table run at the rate the Infinity
-// Cache feeds the XCDs (scripts/microbench/gather_probe.hip: 8.2 TB/s with nothing but the gathers; 28.8 TB/s when the table fits ONE
-// XCD's 4 MB L2).  A workgroup's XCD is blockIdx.x % 8 (round-robin dispatch): here the table is cut into eight id ranges and the waves
-// of XCD s score, for EVERY position, only the candidates whose id falls into range s — 3.4 MB of rows that stay in that XCD's L2.  A
-// position's softmax is then spread over eight waves: each keeps an online-softmax state (max, sum, accumulator of exp(z - max) e_hat)
-// over its candidates and writes it out (1 KB + 8 B); sampled_fwd_merge_kernel combines the eight states per position — and does
-// everything that needs the whole logit row (loss, unit gradients of the logits), with the arithmetic of the kernel above.  Logits are
-// bit-identical to the unsliced kernel's; d_sess sums the same terms in another order.  Streams (ids, session rows, logits, partial
-// states) are issued non-temporal so that they do not push table rows out of the L2.
-constexpr int NSL = 8, SL_MAXC = 192;
-template <int D4>
-__global__ __launch_bounds__(256) void sampled_fwd_sliced_kernel(SampledArgs a, int Vs) {
-  __shared__ float s_z[4][SL_MAXC];
-  __shared__ int s_cid[4][SL_MAXC];
-  __shared__ int s_j[4][SL_MAXC];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int sl = blockIdx.x & (NSL - 1);
-  const int m = (blockIdx.x >> 3) * 4 + wave;
-  if (m >= a.M) return;
-  const int C = a.N + 1;
-  const long long yy = a.y[m];
-  if (yy == 0) return;                        // inactive position: the merge kernel writes its (zero) outputs
-  const int sub = lane & 15, grp = lane >> 4;
-  const int lo = sl * Vs, hi = min(lo + Vs, a.V);
-  // candidate ids of this position that fall into the slice -> LDS (compacted, with their slot j)
-  int n_s = 0;
-  for (int j0 = 0; j0 < C; j0 += 64) {
-    const int j = j0 + lane;
-    long long cid = -1;
-    if (j < C) cid = (j == 0) ? yy : __builtin_nontemporal_load(a.neg + (long long)m * a.N + (j - 1));
-    const bool in = cid >= lo && cid < hi;
-    const unsigned long long mask = __ballot(in);
-    if (in) {
-      const int pos = n_s + __popcll(mask & ((1ull << lane) - 1ull));
-      s_cid[wave][pos] = (int)cid;
-      s_j[wave][pos] = j;
-    }
-    n_s += __popcll(mask);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  // session slice of this lane: float4 index sub + 16*i
-  f32x4 sv[D4];
-  float ss = 0.f;
-  const float* srow = a.sess + (long long)m * a.ld_sess;
-#pragma unroll
-  for (int i = 0; i < D4; ++i) {
-    const int c = (sub + 16 * i) * 4;
-    f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    sv[i] = (c < a.d) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(srow + c)) : z;
-    ss += sv[i][0] * sv[i][0] + sv[i][1] * sv[i][1] + sv[i][2] * sv[i][2] + sv[i][3] * sv[i][3];
-  }
-  ss = group16_sum(ss);
-  const float inv_ns = a.cosine ? 1.0f / fmaxf(sqrtf(ss), EPS_COS) : 1.0f;
-
-  f32x4 acc[D4];
-  float m_run = -INFINITY, l_run = 0.f;
-#pragma unroll
-  for (int i = 0; i < D4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  constexpr int PF = D4 <= 4 ? 3 : 2;
-  const int n_it = (n_s + 3) >> 2;
-  auto row_of_it = [&](int it) -> const float* {
-    const int k = it * 4 + grp;
-    const long long cid = (k < n_s) ? (long long)s_cid[wave][k] : (long long)lo;      // look-ahead slots: a row of this slice, weight 0
-    return a.table + cid * (long long)a.d;
-  };
-  auto consume = [&](int it, const f32x4 (&ev)[D4]) {
-    const int k = it * 4 + grp;
-    const bool valid = k < n_s;
-    float dot = 0.f, ee = 0.f;
-#pragma unroll
-    for (int i = 0; i < D4; ++i) {
-      dot += ev[i][0] * sv[i][0] + ev[i][1] * sv[i][1] + ev[i][2] * sv[i][2] + ev[i][3] * sv[i][3];
-      ee += ev[i][0] * ev[i][0] + ev[i][1] * ev[i][1] + ev[i][2] * ev[i][2] + ev[i][3] * ev[i][3];
-    }
-    dot = group16_sum(dot);
-    ee = group16_sum(ee);
-    const float einv = a.cosine ? 1.0f / fmaxf(sqrtf(ee), EPS_COS) : 1.0f;
-    float z = dot;
-    if (a.cosine) z = z * inv_ns * einv;
-    z *= a.inv_t;
-    if (valid && sub == 0) s_z[wave][k] = z;
-    const float m_new = valid ? fmaxf(m_run, z) : m_run;
-    const float alpha = (m_new == -INFINITY) ? 1.f : __expf(m_run - m_new);
-    const float wj = valid ? __expf(z - m_new) : 0.f;
-    l_run = l_run * alpha + wj;
-    m_run = m_new;
-    const float we = wj * einv;
-#pragma unroll
-    for (int i = 0; i < D4; ++i) acc[i] = acc[i] * alpha + ev[i] * we;
-  };
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): everything the compiler tracks has landed before the first asm load
-  f32x4 evb[PF][D4];
-#pragma unroll
-  for (int u = 0; u < PF - 1; ++u) gather_issue<D4>(row_of_it(u), sub, evb[u]);
-#pragma unroll 1
-  for (int it0 = 0; it0 < n_it; it0 += PF) {
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      const int it = it0 + u;
-      gather_issue<D4>(row_of_it(it + PF - 1), sub, evb[(u + PF - 1) % PF]);
-      gather_wait<(PF - 1) * D4, D4>(evb[u]);
-      if (it < n_it) consume(it, evb[u]);
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < PF; ++u) gather_wait<0, D4>(evb[u]);     // (names the buffers: see the kernel above)
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  // logits of this slice's candidates, and the counting-sort ranks of its negatives
-  float* zrow = a.logits + (long long)m * C;
-  for (int k = lane; k < n_s; k += 64) {
-    const int j = s_j[wave][k];
-    __builtin_nontemporal_store(s_z[wave][k], zrow + j);
-    const int cid = s_cid[wave][k];
-    if (j >= 1 && cid != 0) a.rank[m * C + j] = atomicAdd(a.count + cid, 1);
-  }
-  // this wave's state: the four quarter-wave streams merged (unnormalised: relative to the wave's own maximum)
-  float mall = fmaxf(m_run, __shfl_xor(m_run, 16, 64));
-  mall = fmaxf(mall, __shfl_xor(mall, 32, 64));
-  const float sc = (m_run == -INFINITY) ? 0.f : __expf(m_run - mall);
-  float l = l_run * sc;
-  l += __shfl_xor(l, 16, 64);
-  l += __shfl_xor(l, 32, 64);
-  float* prow = a.part + ((long long)m * NSL + sl) * a.d;
-#pragma unroll
-  for (int i = 0; i < D4; ++i) {
-    f32x4 v;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float t = acc[i][e] * sc;
-      t += __shfl_xor(t, 16, 64);
-      t += __shfl_xor(t, 32, 64);
-      v[e] = t;
-    }
-    const int c = (sub + 16 * i) * 4;
-    if (grp == 0 && c < a.d) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(prow + c));
-  }
-  if (lane == 0) {
-    a.part_ml[((long long)m * NSL + sl) * 2] = mall;
-    a.part_ml[((long long)m * NSL + sl) * 2 + 1] = l;
-  }
-}
-
-// One wave per position: loss and unit logit gradients from the whole logit row (the arithmetic of sampled_fwd_kernel), the session
-// gradient from the eight slices' states.
-template <int D4>
-__global__ __launch_bounds__(256) void sampled_fwd_merge_kernel(SampledArgs a) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int m = blockIdx.x * 4 + wave;
-  if (m >= a.M) return;
-  const int C = a.N + 1;
-  const long long yy = a.y[m];
-  const int sub = lane & 15, grp = lane >> 4;
-  if (yy == 0) {
-    if (lane == 0) { a.loss_pos[m] = 0.f; a.inv_ns[m] = 1.f; }
-    if (grp == 0) {
-#pragma unroll
-      for (int i = 0; i < D4; ++i) {
-        const int c = (sub + 16 * i) * 4;
-        if (c < a.d) *reinterpret_cast<f32x4*>(a.d_sess + (long long)m * a.ld_dsess + c) = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    }
-    return;
-  }
-  const float* zrow = a.logits + (long long)m * C;
-  const float wgt = a.w[m];
-  float mx = -INFINITY;
-  for (int j = lane; j < C; j += 64) mx = fmaxf(mx, zrow[j]);
-  mx = wave_max(mx);
-  float se = 0.f;
-  for (int j = lane; j < C; j += 64) se += __expf(zrow[j] - mx);
-  se = wave_sum(se);
-  if (lane == 0) a.loss_pos[m] = (mx + __logf(se) - zrow[0]) * wgt;
-  const float gs = wgt * a.inv_t;
-  float* grow = a.glog + (long long)m * C;
-  for (int j = lane; j < C; j += 64) grow[j] = (__expf(zrow[j] - mx) / se - (j == 0 ? 1.f : 0.f)) * gs;
-  // session row (cosine: its norm)
-  f32x4 sv[D4];
-  float ss = 0.f;
-  const float* srow = a.sess + (long long)m * a.ld_sess;
-#pragma unroll
-  for (int i = 0; i < D4; ++i) {
-    const int c = (sub + 16 * i) * 4;
-    f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    sv[i] = (c < a.d) ? *reinterpret_cast<const f32x4*>(srow + c) : z;
-    ss += sv[i][0] * sv[i][0] + sv[i][1] * sv[i][1] + sv[i][2] * sv[i][2] + sv[i][3] * sv[i][3];
-  }
-  ss = group16_sum(ss);
-  const float ns = sqrtf(ss);
-  const float inv_ns = a.cosine ? 1.0f / fmaxf(ns, EPS_COS) : 1.0f;
-  if (lane == 0) a.inv_ns[m] = inv_ns;
-  // the eight states: quarter-wave g takes slices g and g + 4
-  const float* ml = a.part_ml + (long long)m * NSL * 2;
-  const float m0 = ml[2 * grp], l0 = ml[2 * grp + 1], m1 = ml[2 * (grp + 4)], l1 = ml[2 * (grp + 4) + 1];
-  float mall = fmaxf(m0, m1);
-  mall = fmaxf(mall, __shfl_xor(mall, 16, 64));
-  mall = fmaxf(mall, __shfl_xor(mall, 32, 64));
-  const float s0 = (m0 == -INFINITY) ? 0.f : __expf(m0 - mall), s1 = (m1 == -INFINITY) ? 0.f : __expf(m1 - mall);
-  float l = l0 * s0 + l1 * s1;
-  l += __shfl_xor(l, 16, 64);
-  l += __shfl_xor(l, 32, 64);
-  const float* p0 = a.part + ((long long)m * NSL + grp) * a.d;
-  const float* p1 = a.part + ((long long)m * NSL + grp + 4) * a.d;
-  f32x4 ds[D4];
-#pragma unroll
-  for (int i = 0; i < D4; ++i) {
-    const int c = (sub + 16 * i) * 4;
-    f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 a0 = (c < a.d) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p0 + c)) : z;
-    const f32x4 a1 = (c < a.d) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p1 + c)) : z;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float v = (a0[e] * s0 + a1[e] * s1) / l;
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      ds[i][e] = v;
-    }
-  }
-  {   // minus the positive's own row: d s_hat = sum_j softmax_j e_hat_j - e_hat_0
-    const float* er = a.table + yy * (long long)a.d;
-    f32x4 e0[D4];
-    float ee = 0.f;
-#pragma unroll
-    for (int i = 0; i < D4; ++i) {
-      const int c = (sub + 16 * i) * 4;
-      f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      e0[i] = (c < a.d) ? *reinterpret_cast<const f32x4*>(er + c) : z;
-      ee += e0[i][0] * e0[i][0] + e0[i][1] * e0[i][1] + e0[i][2] * e0[i][2] + e0[i][3] * e0[i][3];
-    }
-    ee = group16_sum(ee);
-    const float einv0 = a.cosine ? 1.0f / fmaxf(sqrtf(ee), EPS_COS) : 1.0f;
-#pragma unroll
-    for (int i = 0; i < D4; ++i) ds[i] -= e0[i] * einv0;
-  }
-#pragma unroll
-  for (int i = 0; i < D4; ++i) ds[i] *= gs;
-  if (a.cosine) {  // d s = (d s_hat - s_hat (s_hat . d s_hat)) / ns
-    float proj = 0.f;
-#pragma unroll
-    for (int i = 0; i < D4; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) proj += ds[i][e] * sv[i][e] * inv_ns;
-    proj = group16_sum(proj);
-#pragma unroll
-    for (int i = 0; i < D4; ++i) {
-      f32x4 sh = sv[i] * inv_ns;
-      ds[i] = (ns > EPS_COS) ? (ds[i] - sh * proj) * inv_ns : ds[i] * inv_ns;
-    }
-  }
-  if (grp == 0) {
-    float* drow = a.d_sess + (long long)m * a.ld_dsess;
-#pragma unroll
-    for (int i = 0; i < D4; ++i) {
-      const int c = (sub + 16 * i) * 4;
-      if (c < a.d) *reinterpret_cast<f32x4*>(drow + c) = ds[i];
-    }
-  }
-}
-
-// The sliced forward applies when an eighth of the table fits an XCD's L2 next to the streams (<= 3.6 MB) while the whole does not
-// (> 4 MB: every XCD would hold all of it anyway), the candidate row fits the LDS lists, and the loss is the sampled softmax.
-bool sliced_applies(int M, int N, int V, int d) {
-  // OPT-IN (RT_LOSS_SLICED=1).  Measured on MI355X (round 4, profiles/r4_loss_sliced_probe.txt): correct — and slower: 340 vs 264 us
-  // at the C2 step, ~266 us whatever the table size (4.6 .. 27 MB), i.e. bound by its own fixed cost (eight waves per position, each
-  // with an id read, a compaction, a session-row read and a 1 KB state to write), not by the gathers it makes L2-local.
-  const char* e = getenv("RT_LOSS_SLICED");      // read per call (a handful per step): tests switch it inside one process
-  const int on = (e != nullptr && e[0] == '1') ? 1 : 0;
-  const size_t bytes = (size_t)V * d * 4;
-  return on == 1 && N + 1 <= SL_MAXC && bytes > ((size_t)4 << 20) && bytes <= (size_t)NSL * 3600 * 1024 && M >= 1024;
-}
+// (An XCD-sliced forward — the table cut into eight id ranges, one per XCD's L2, a position's softmax merged from eight partial states —
+// was built and measured in round 4: correct, and slower (340 vs 264 us at the C2 step: bound by its own fixed cost, eight waves per
+// position; profiles/r4_loss_sliced_probe.txt).  Removed in round 5; the figures stay in DESIGN.md K8/K9.)
 
 // d_sess = unit gradient * gscale / norm
 __global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict__ src, long long ld_src, float* __restrict__ dst,
@@ -1065,12 +793,7 @@ int launch_sampled(const SampledArgs& a, int stage, hipStream_t stream) {
   }
   if (stage == 1) {
     if (!a.prepared) RT_CHECK_HIP(hipMemsetAsync(a.count, 0, sizeof(int) * (((size_t)n + 1 + 15) & ~(size_t)15), stream));   // + heavy_count (+ the pad)
-    if (a.loss == LOSS_SAMPLED_SOFTMAX && a.part != nullptr && !a.prepared && sliced_applies(a.M, a.N, a.V, a.d)) {
-      const int Vs = (a.V + NSL - 1) / NSL;
-      sampled_fwd_sliced_kernel<D4><<<blocks * NSL, 256, 0, stream>>>(a, Vs);
-      RT_CHECK_LAUNCH();
-      sampled_fwd_merge_kernel<D4><<<blocks, 256, 0, stream>>>(a);
-    } else if (a.loss == LOSS_SAMPLED_SOFTMAX) {
+    if (a.loss == LOSS_SAMPLED_SOFTMAX) {
       if (fast) sampled_fwd_kernel<D4, true, true, true><<<blocks, 256, 0, stream>>>(a);
       else sampled_fwd_kernel<D4, true, true><<<blocks, 256, 0, stream>>>(a);
     } else {
@@ -1127,14 +850,6 @@ void carve_workspace(SampledArgs& a, void* workspace, int M, int N, int V, int d
   a.offsets = ip; ip += n;
   a.cursor = ip; ip += n;
   a.blocksum = ip;
-  a.part = nullptr; a.part_ml = nullptr;
-  if (sliced_applies(M, N, V, d)) {       // the XCD-sliced forward's partial states, behind everything else (16-byte aligned)
-    const size_t nb = (n + SCAN_T * SCAN_E - 1) / (SCAN_T * SCAN_E);
-    uintptr_t q = reinterpret_cast<uintptr_t>(ip + nb + 64 + 4);
-    q = (q + 15) & ~(uintptr_t)15;
-    a.part = reinterpret_cast<float*>(q);
-    a.part_ml = a.part + (size_t)M * NSL * (size_t)d;
-  }
 }
 
 }  // namespace
@@ -1160,22 +875,19 @@ size_t rt_sampled_loss_bwd_workspace_bytes(int32_t M, int32_t N, int32_t V, int3
   const size_t C = (size_t)N + 1, n = (size_t)V + 1;
   const size_t nb = (n + SCAN_T * SCAN_E - 1) / (SCAN_T * SCAN_E);
   const size_t cap = (size_t)heavy_chunk_cap((long long)M * (long long)C);
-  const size_t sliced = sliced_applies(M, N, V, d) ? (size_t)M * NSL * ((size_t)d + 2) + 8 : 0;
-  return 4 * ((size_t)M * C * 5 + (size_t)M + 3 * n + nb + 64 + 4 + cap * ((size_t)d + 3) + sliced) + 256 + 64;   // (+ the aligned cleared region)
+  return 4 * ((size_t)M * C * 5 + (size_t)M + 3 * n + nb + 64 + 4 + cap * ((size_t)d + 3)) + 256 + 64;   // (+ the aligned cleared region)
 }
 
 // The counting sort of the (position, candidate) pairs by candidate id depends on the ids alone: called ahead of the forward pass (on
 // another stream: a handful of small launches that would otherwise sit between the forward and the backward kernels), it leaves the
 // ranks, the segment offsets and the popular ids' chunks in `workspace`; rt_sampled_loss_fwd_train / _bwd called with prepared = 1 on
 // the SAME workspace then skip their share of it (the forward writes the pair records, the backward starts at the row reductions).
-// RT_ERR_UNSUPPORTED where the XCD-sliced forward is switched on (RT_LOSS_SLICED=1): call the entry points with prepared = 0 then.
 int rt_sampled_loss_prepare(const int64_t* y, const int64_t* neg, int32_t M, int32_t N, int32_t d, int32_t V, void* workspace,
                             size_t workspace_bytes, hipStream_t stream) {
   (void)hipGetLastError();
   if (M <= 0) return RT_OK;
   if ((d & 3) || N < 0 || y == nullptr || (N > 0 && neg == nullptr)) return RT_ERR_INVALID_ARG;
   if ((long long)M * (N + 1) >= (1LL << 31)) return RT_ERR_UNSUPPORTED;
-  if (sliced_applies(M, N, V, d)) return RT_ERR_UNSUPPORTED;
   if (workspace == nullptr || workspace_bytes < rt_sampled_loss_bwd_workspace_bytes(M, N, V, d)) return RT_ERR_WORKSPACE;
   SampledArgs a{};
   a.y = reinterpret_cast<const long long*>(y); a.neg = reinterpret_cast<const long long*>(neg); a.M = M; a.N = N; a.d = d; a.V = V;

@@ -67,7 +67,6 @@ struct TopkArgs {
   int bloom;                     // engine 2: 1 = a 1024-bit Bloom filter per user of the tile sits in LDS behind the lists
   int h_only;                    // HM kernels: 1 = the images hold ONE bf16 (round-to-nearest) per value (rows of d / 2 words): one MFMA per slot
   int xmap_gx, xmap_gy;          // topk_coarse_frag_kernel on a 1-D grid: the (segments, user tiles) grid it stands for (0, 0: plain 2-D grid)
-  int pf_blocks;                 // ... and > 0: every wave touches its share of the item blocks this far ahead (pulls them into the XCD's L2)
 };
 
 // acc + |v|^2 as one fixed fma chain: engine 2 and the two-stage exact pass (topk_replay_kernel) must round a row norm alike
@@ -1701,7 +1700,8 @@ int launch_stream_any(int tu, int ns, const TopkArgs& a, dim3 grid, bool ll, hip
 // than its products — measured with the selection switched off (scripts/gpu/ablate.sh): products 19.6 ms, + threshold tests 10.2 ms,
 // + inserts 15.0 ms (+ 9 ms with a viewed filter).  An insert read the lane's list and the filter's hash table from global memory, and
 // loads return in order: every insert waited for the whole fragment pipeline of its wave (s_waitcnt vmcnt(0): ~4 us, twice per block
-// pair and wave).  Here the lists are the workgroup's: [UB][FRAG_KP] scores / positions behind the user tile, one spin lock, entry count
+// pair and wave).  (Touching the blocks ahead of the demand loads — every wave of an XCD pulling its share of the next 12 blocks into the
+// L2 — measured 19.3 vs 18.8 ms for the products alone: the loads are not what the waves wait for.)  Here the lists are the workgroup's: [UB][FRAG_KP] scores / positions behind the user tile, one spin lock, entry count
 // and threshold per user, the viewed items as a 512-bit Bloom filter per user.  An insert is LDS traffic only (lgkmcnt: the fragment
 // loads stay in flight); the exact probe of the filter's hash table — a global round trip — is left for candidates the Bloom filter
 // cannot clear.  One list per user instead of eight also means one threshold per user: the bound tightens eight times faster.
@@ -1932,40 +1932,12 @@ __global__ __launch_bounds__(NTHREADS) void topk_coarse_frag_kernel(TopkArgs a) 
 #pragma unroll
   for (int q = 0; q < P; ++q) issue(abuf[q]);
 
-  // L2 prefetch (pf_blocks > 0): the user tiles of a segment sit on the CUs of ONE XCD and walk the same item blocks in step, so every
-  // demand load of a block is the XCD's FIRST touch of its lines and all tiles wait for the same HBM fetch.  The 4 x tiles waves of the
-  // XCD share the job of touching the blocks `pf_blocks` ahead: one dword load with a lane stride of 128 bytes pulls 64 lines = 8 KB, a
-  // 128 KB block is 16 such loads; wave gw = 4 ty + wave takes unit u = block * chunks + chunk whenever u % n_waves == gw.  An ordinary
-  // load (the compiler counts it in vmcnt) whose value is folded into a sink a whole block pair later.
-  const int pf_chunks = (int)(((long long)IB * a.d * 4 + 8191) / 8192);
-  const int pf_waves = (NTHREADS / 64) * (a.xmap_gy > 0 ? a.xmap_gy : 1);
-  const int pf_me = ty * (NTHREADS / 64) + wave;
-  unsigned pf_val = 0u, pf_sink = 0u;
-  auto prefetch_block = [&](long long jb) {      // jb: index into this segment's blocks
-    if (jb >= my_blocks) return;
-    int c = (int)(((long long)pf_me - jb * pf_chunks) % pf_waves);
-    if (c < 0) c += pf_waves;
-    if (c < pf_chunks) {
-      long long off = (long long)c * 8192 + lane * 128;
-      const long long blk_bytes = (long long)IB * a.d * 4;
-      if (off >= blk_bytes) off = blk_bytes - 4;
-      const long long blk = a.blk_begin + sx + jb * S;
-      pf_val ^= *reinterpret_cast<const volatile unsigned*>(reinterpret_cast<const char*>(a.items) + blk * blk_bytes + off);
-    }
-  };
-  if (a.pf_blocks > 0)
-    for (int jb = 0; jb < a.pf_blocks; ++jb) prefetch_block(jb);
-
   // the user fragments of slot s + 1 are read while the products of slot s run (one wave per SIMD: nobody else hides the LDS latency)
   u32x4 bf[2][TU];
 #pragma unroll
   for (int tu = 0; tu < TU; ++tu) bf[0][tu] = ufrag[(tu * n_s) * 64 + lane];
 #pragma unroll 1
   for (long long j = 0; j < n_pairs; ++j) {
-    if (a.pf_blocks > 0) {
-      pf_sink ^= pf_val; pf_val = 0u;                       // (what the previous pair asked for: arrived long ago)
-      prefetch_block(j * IW + a.pf_blocks); prefetch_block(j * IW + 1 + a.pf_blocks);
-    }
 #pragma unroll 1
     for (int s0 = 0; s0 < n_s; s0 += P) {
 #pragma unroll
@@ -2008,7 +1980,6 @@ __global__ __launch_bounds__(NTHREADS) void topk_coarse_frag_kernel(TopkArgs a) 
       }
     }
   }
-  if ((pf_sink ^ pf_val) == 0x9E3779B9u && a.n_users_pad < 0) a.gthr[0] = pf_sink;      // never true: keeps the prefetch loads alive
   __syncthreads();
   publish(true);
 }
@@ -2018,11 +1989,9 @@ inline size_t coarse_frag_lds_bytes(int tu, int d_words) { return (size_t)tu * (
 template <int TU>
 int launch_coarse_frag_t(const TopkArgs& a0, dim3 grid, hipStream_t stream) {
   TopkArgs a = a0;
-  if (grid.y > 1 && env_int("RT_TOPK_XCD_MAP", 1) != 0) {     // 1-D grid, XCD-owned segments (see the kernel); RT_TOPK_XCD_MAP=0: the plain grid
+  if (grid.y > 1) {     // 1-D grid, XCD-owned segments (see the kernel)
     a.xmap_gx = (int)grid.x; a.xmap_gy = (int)grid.y;
     grid = dim3(8u * ((grid.x + 7u) / 8u) * grid.y, 1u, 1u);
-    // the tiles of a segment run side by side on one XCD only while they all fit it (32 CUs, one workgroup each)
-    if (a.xmap_gy <= 32) a.pf_blocks = env_int("RT_TOPK_PF_BLOCKS", 0);
   }
   a.bloom = (a.filt_indptr != nullptr && a.filt_indices != nullptr) ? 1 : 0;      // (512 bits per user in the LDS, in front of the exact test)
   const size_t lds = coarse_frag_lds_bytes(TU, a.d);

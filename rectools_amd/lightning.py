@@ -128,10 +128,6 @@ class TransformerLossModule(nn.Module):
         same sessions (tests/test_packed_gpu.py)."""
         table = self.torch_model.item_model.get_all_embeddings()
         B = int(pbatch["cu"].numel()) - 1
-        stock_loss = type(self)._loss_from_sessions is TransformerLossModule._loss_from_sessions
-        if stock_loss and self.loss != "softmax" and pbatch.get("negatives") is not None and torch.is_grad_enabled() and table.requires_grad:
-            # the loss's counting sort of the candidate ids needs the ids only: under the encoder, on the side stream
-            ops.prepare_sampled_pairs(pbatch["y"], pbatch["negatives"], table.shape[0], table.shape[1])
         sess = self.torch_model.encode_packed_train(pbatch["x"], pbatch["dist"], pbatch["cu"], B, int(pbatch["window"]), table,
                                                     rows_real=pbatch.get("n_rows"), cu_attn=pbatch.get("cu_attn"), ts=pbatch.get("ts"))
         stock = type(self)._loss_from_sessions is TransformerLossModule._loss_from_sessions    # (a plugged loss keeps its own signature)

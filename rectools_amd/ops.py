@@ -120,14 +120,6 @@ def _side_fork_forward() -> tp.Optional[int]:
     return h.value or None
 
 
-def _prepare_ahead(what: str = "embed") -> bool:
-    """RT_PREPARE_AHEAD: 0 keeps the counting sorts where they were (inside the backward entry points); 1 (default) sorts the embedding's
-    rows ahead of time; 2 also the sampled losses' pairs — opt-in: measured neutral at C2 (84.7 vs 84.5 k seqs/s): the 1.7 M rank atomics
-    that hide under the forward kernel's gathers cost 83 us as a kernel of their own, as much as the launches they take out of the way."""
-    v = os.environ.get("RT_PREPARE_AHEAD", "1")
-    return v != "0" if what == "embed" else v == "2"
-
-
 def _chk(t: torch.Tensor, what: str) -> torch.Tensor:
     if not t.is_cuda or t.dtype != torch.float32:
         raise _lib.HipLibraryError(f"{what}: expected a float32 HIP tensor (no CPU fallback), got {t.dtype} on {t.device}")
@@ -490,7 +482,7 @@ class _EmbedPacked(torch.autograd.Function):
         seed, sid = RNG.next() if p > 0 else (0, 0)
         _c("rt_embed_packed_fwd", ids, dist, table, pos, float(scale), M, d, float(p), seed, sid, out)
         ws = None
-        if ctx.needs_input_grad[0] and _prepare_ahead():
+        if ctx.needs_input_grad[0]:
             # the backward's counting sort of the rows by id depends on `ids` alone: issued NOW on the side stream it is long done when
             # the backward pass arrives (eight small launches less in the tail of a step)
             ws_bytes = _lib.load().rt_embed_bwd_workspace_bytes(M, table.shape[0], d)
@@ -528,26 +520,18 @@ class _EmbedPacked(torch.autograd.Function):
             gpos = (torch.empty if pshape[0] == L else torch.zeros)(pshape, dtype=torch.float32, device=gout.device)
         ws_bytes = _lib.load().rt_embed_bwd_workspace_bytes(M, V, tshape[1])
         ws = prep[0] if prep else torch.empty((ws_bytes,), dtype=torch.uint8, device=gout.device)
-        side, prep_joined = None, False
+        prep_joined = False
         if sink is not None and sink.data_ptr() in _TABLE_GRAD_ON_SIDE:
             _TABLE_GRAD_ON_SIDE.discard(sink.data_ptr())
-            if os.environ.get("RT_EMBED_BWD", "main") == "side":
-                # the sink's loss half is in flight on the side stream: add the lookup's rows there, behind it — and behind the weight
-                # gradients queued since (measured: the side stream then ends 78 us after the main one, profiles/r4_timeline_train.txt)
-                side = _native_side_fork()
-                if side is None:
-                    join_side_streams()
-            else:
-                # on the main stream, behind the point the loss's table half (and the rows' counting sort, issued before it) reached on
-                # the side stream — not behind the weight gradients that stream was given afterwards
-                _lib.check(_lib.load().rt_side_wait_mark(_lib.current_stream()), "rt_side_wait_mark")
-                prep_joined = True
-        if prep and side is None and _PREP_KEEPALIVE and not prep_joined:
+            # on the main stream, behind the point the loss's table half (and the rows' counting sort, issued before it) reached on the
+            # side stream — not behind the weight gradients that stream was given afterwards (queued on the side stream itself the
+            # embedding backward ended 78 us after the main stream: profiles/r4_timeline_train.txt)
+            _lib.check(_lib.load().rt_side_wait_mark(_lib.current_stream()), "rt_side_wait_mark")
+            prep_joined = True
+        if prep and _PREP_KEEPALIVE and not prep_joined:
             join_side_streams()          # the sort ran on the side stream and nothing has joined it yet (no sampled loss in this step)
         _c("rt_embed_packed_bwd", ids, cu, B, gout, float(scale), M, L, tshape[1], V, float(p), seed, sid, gtable,
-           1 if sink is not None else 0, gpos, ws, ws_bytes, 1 if prep else 0, stream=side)
-        if side is not None:
-            _NATIVE_KEEPALIVE.append((ids, cu, gout, ws))     # not gtable / gpos: autograd must adopt them, not clone them
+           1 if sink is not None else 0, gpos, ws, ws_bytes, 1 if prep else 0)
         return (None if sink is not None else gtable), gpos, None, None, None, None, None, None, None
 
 
@@ -2115,10 +2099,12 @@ def prepare_sampled_pairs(y: torch.Tensor, neg: torch.Tensor, V: int, d: int) ->
     """The sampled losses' counting sort of the (position, candidate) pairs by candidate id — needed by the backward pass only, a
     function of the ids only — issued on the side stream as soon as the batch exists (`rt_sampled_loss_prepare`): six small launches
     leave the gap between the forward and the backward kernels of a training step, and the training forward writes the pair records
-    itself.  `sampled_loss` finds the workspace through (step, the two tensors' storage, sizes); any mismatch (another y / neg, a
+    itself.  NOT called by the stock loop: measured neutral at C2 (84.7 vs 84.5 k seqs/s — the 1.7 M rank atomics that hide under the
+    forward kernel's gathers cost 83 us as a kernel of their own); kept as the binding of the entry point, pinned against the in-pass sort
+    by tests/test_ops_gpu.py.  `sampled_loss` finds the workspace through (step, the two tensors' storage, sizes); any mismatch (another y / neg, a
     loss that is never called) just leaves it unused."""
     _PREPARED_PAIRS.clear()
-    if not _prepare_ahead("loss") or not (y.is_cuda and neg.is_cuda and y.dtype == torch.int64 and neg.dtype == torch.int64):
+    if not (y.is_cuda and neg.is_cuda and y.dtype == torch.int64 and neg.dtype == torch.int64):
         return
     y1 = y.reshape(-1)
     M = int(y1.numel())
@@ -2129,10 +2115,7 @@ def prepare_sampled_pairs(y: torch.Tensor, neg: torch.Tensor, V: int, d: int) ->
     ws_bytes = _lib.load().rt_sampled_loss_bwd_workspace_bytes(M, N, int(V), int(d))
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=y.device)
     side = _side_fork_forward()
-    try:
-        _c("rt_sampled_loss_prepare", y1, neg2, M, N, int(d), int(V), ws, ws_bytes, stream=side)
-    except NotImplementedError:          # (the XCD-sliced forward keeps its own order)
-        return
+    _c("rt_sampled_loss_prepare", y1, neg2, M, N, int(d), int(V), ws, ws_bytes, stream=side)
     if side is not None:
         _PREP_KEEPALIVE.append((y1, neg2, ws))
     _PREPARED_PAIRS[_pairs_key(y1, neg2, V, d)] = ws

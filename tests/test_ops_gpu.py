@@ -296,31 +296,37 @@ def test_sampled_loss_popularity_skew(cosine):
     _sampled_case("sampled_softmax", cosine, M=1500, d=128, V=400, N=5, hot=True)
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize("cosine", [False, True])
-def test_sampled_softmax_xcd_sliced_forward(cosine, monkeypatch):
-    """The XCD-sliced training forward (rt_loss.hip: the table cut into eight id ranges, one per XCD's L2; a position's softmax merged from
-    eight partial states) at a shape where it applies (a 4.2 MB table, 2,048 positions): against the oracle, and against the unsliced
-    kernel — same loss and logit gradients (the logits are bit-identical), d_sess / d_table to fp32 rounding."""
+def test_sampled_loss_with_pairs_sorted_ahead_of_the_forward_pass(cosine):
+    """`rt_sampled_loss_prepare` (ops.prepare_sampled_pairs: the counting sort of the (position, candidate) pairs on the side stream, before
+    the forward pass; `rt_sampled_loss_fwd_train / _bwd(prepared = 1)`) against the sort inside the passes: same loss, same gradients."""
     from rectools_amd import ops
 
-    M, d, V, N, t = 2048, 256, 4200, 128, 0.7
-    g = torch.Generator().manual_seed(4)
-    sess, table = rnd(M, d, seed=5), rnd(V, d, seed=6)
+    M, d, V, N, t = 2048, 256, 4100, 128, 0.7
+    g = torch.Generator().manual_seed(5)
+    sess, emb = rnd(M, d, seed=1), rnd(V, d, seed=2, scale=0.3)
     y = torch.randint(1, V, (M,), generator=g); y[::7] = 0
     neg = torch.randint(1, V, (M, N), generator=g)
-    w = (0.5 + torch.rand(M, generator=g)) * (y != 0)
+    w = torch.rand(M, generator=g) + 0.5
     out = {}
-    for sliced in ("1", "0"):
-        monkeypatch.setenv("RT_LOSS_SLICED", sliced)
-        out[sliced] = grads_of(lambda s, e: ops.sampled_loss(s, e, y.cuda(), neg.cuda(), w.cuda(), 2, cosine, t, 0.0)[0].reshape(1),
-                               [sess.cuda(), table.cuda()])
-    (l1, g1), (l0, g0) = out["1"], out["0"]
-    assert torch.equal(l1, l0)                                                     # loss: from the same logits by the same arithmetic
-    close(g1[0], g0[0], rtol=1e-4, atol_rel=1e-6, msg="d_sess sliced vs unsliced")
-    close(g1[1], g0[1], rtol=1e-4, atol_rel=1e-6, msg="d_table sliced vs unsliced")
-    monkeypatch.setenv("RT_LOSS_SLICED", "1")
-    _sampled_case("sampled_softmax", cosine, M=M, d=d, V=V, N=N, hot=False)       # the sliced path against the oracle
+    for ahead in (False, True):
+        yd, nd = y.cuda(), neg.cuda()
+
+        def run(s, e):
+            ops.RNG.next_step()
+            if ahead:
+                ops.prepare_sampled_pairs(yd, nd, V, d)
+                assert len(ops._PREPARED_PAIRS) == 1
+            loss = ops.sampled_loss(s, e, yd, nd, w.cuda(), 2, cosine, t, 0.0)[0].reshape(1)
+            assert not ops._PREPARED_PAIRS           # consumed by the forward pass
+            return loss
+
+        out[ahead] = grads_of(run, [sess.cuda(), emb.cuda()])
+        ops.join_side_streams()
+    (l0, g0), (l1, g1) = out[False], out[True]
+    close(l1, l0, rtol=1e-6, atol_rel=1e-6, msg="loss")
+    close(g1[0], g0[0], rtol=1e-5, atol_rel=1e-6, msg="d_sess")
+    close(g1[1], g0[1], rtol=1e-5, atol_rel=1e-6, msg="d_table")
 
 
 def _sampled_case(loss, cosine, M, d, V, N, hot):
