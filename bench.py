@@ -904,18 +904,28 @@ def main():
                     del info_f
                     torch.cuda.empty_cache()
             if not args.no_families and rank == 0 and world == 1:
-                # BASELINE configs[3] nearer its stated size: the host path of HSTUModel.fit() (Dataset.construct, process_dataset_train,
-                # store upload, epoch bookkeeping) + 20 product steps at 2 M users x 1 M items, in a child process (its 15 GB of host
-                # memory go back to the system); `families.hstu` above is the model-shape leg (65,536 users with long histories)
+                # BASELINE configs[3] AT its stated size — 10 M users x 1 M items (393 M interactions) — when the host can hold it (62 GB of
+                # resident memory at the peak, measured: profiles/r5_c4_scale_10m.json), else at 2 M users: the host path of
+                # HSTUModel.fit() (Dataset.construct, process_dataset_train, store upload, epoch bookkeeping) + 20 product steps, in a child
+                # process (its memory goes back to the system); `families.hstu` above is the model-shape leg (65,536 users, long histories)
                 import subprocess
 
+                big = False
                 try:
-                    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "c4_scale.py"), "2000000", "40", "20"],
-                                         capture_output=True, text=True, timeout=400)
+                    import psutil
+
+                    big = psutil.virtual_memory().available >= 160 * 2 ** 30 and os.environ.get("RT_BENCH_C4_USERS", "") != "2000000"
+                except Exception:
+                    pass
+                n_c4 = 10_000_000 if big else 2_000_000
+                key = "hstu_10m_users" if big else "hstu_2m_users"
+                try:
+                    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "c4_scale.py"), str(n_c4), "40", "20"],
+                                         capture_output=True, text=True, timeout=600)
                     line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
-                    out["families"]["hstu_2m_users"] = json.loads(line[-1]) if line else {"error": (res.stderr or res.stdout)[-300:]}
+                    out["families"][key] = json.loads(line[-1]) if line else {"error": (res.stderr or res.stdout)[-300:]}
                 except Exception as e:      # never take the line down
-                    out["families"]["hstu_2m_users"] = {"error": repr(e)[:300]}
+                    out["families"][key] = {"error": repr(e)[:300]}
         out["env"] = env
         if dp_train is not None:
             dist_info["train"] = dp_train
