@@ -103,9 +103,8 @@ __device__ __forceinline__ void embed_accumulate(const EmbBwdArgs& a, int beg, i
 }
 
 template <int NDV>
-__global__ __launch_bounds__(256) void embed_bwd_rows_kernel(EmbBwdArgs a) {
+__device__ __forceinline__ void embed_bwd_rows_body(const EmbBwdArgs& a, int id) {
   const int lane = threadIdx.x & 63;
-  const int id = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (id >= a.V) return;
   const int beg = a.offsets[id], end = a.offsets[id + 1];
   if (a.accumulate && beg == end) return;   // untouched row of an accumulation target: nothing to add, nothing to write
@@ -132,6 +131,11 @@ __global__ __launch_bounds__(256) void embed_bwd_rows_kernel(EmbBwdArgs a) {
       *dst = a.accumulate ? *dst + acc[i] * a.scale : acc[i] * a.scale;   // one wave owns the row: no race
     }
   }
+}
+
+template <int NDV>
+__global__ __launch_bounds__(256) void embed_bwd_rows_kernel(EmbBwdArgs a) {
+  embed_bwd_rows_body<NDV>(a, blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 
 // one 4-wave workgroup per chunk of a popular id: 32 positions per wave, LDS combine, partial row -> slab
@@ -168,10 +172,8 @@ __global__ __launch_bounds__(EMB_HEAVY_WAVES * 64) void embed_bwd_heavy_kernel(E
 
 // one workgroup per position l: 4 waves stride the batch, lanes own float4 columns; fixed-order LDS combine
 template <int NDV>
-__global__ __launch_bounds__(256) void embed_bwd_pos_kernel(EmbBwdArgs a) {
-  __shared__ f32x4 s_part[4][NDV][64];
+__device__ __forceinline__ void embed_bwd_pos_body(const EmbBwdArgs& a, int l, f32x4 (&s_part)[4][NDV][64]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int l = blockIdx.x;
   const int B = a.cu ? a.B : a.M / a.L;
   const float inv_keep = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
   f32x4 acc[NDV];
@@ -209,6 +211,16 @@ __global__ __launch_bounds__(256) void embed_bwd_pos_kernel(EmbBwdArgs a) {
   }
 }
 
+// The row reductions (one wave per table row) with the positional rows' reduction riding in front: the first `pos_blocks` workgroups
+// of the launch run `embed_bwd_pos_body` — 200 light workgroups that took 18 us as a launch of their own at the end of a training step,
+// beside nothing; here the 6,687 row workgroups fill the machine around them.  Independent outputs (gpos / gtable).
+template <int NDV>
+__global__ __launch_bounds__(256) void embed_bwd_rows_pos_kernel(EmbBwdArgs a, int pos_blocks) {
+  __shared__ f32x4 s_part[4][NDV][64];
+  if ((int)blockIdx.x < pos_blocks) { embed_bwd_pos_body<NDV>(a, blockIdx.x, s_part); return; }
+  embed_bwd_rows_body<NDV>(a, ((int)blockIdx.x - pos_blocks) * 4 + (threadIdx.x >> 6));
+}
+
 // the counting sort of the rows by id (depends on the ids alone: rt_embed_bwd_prepare runs it ahead of the backward pass)
 int launch_embed_order(const EmbBwdArgs& a, hipStream_t stream) {
   const int n = a.V + 1;
@@ -232,12 +244,9 @@ int launch_embed_bwd(const EmbBwdArgs& a, bool prepared, hipStream_t stream) {
   }
   embed_bwd_heavy_kernel<NDV><<<(int)min(emb_chunk_cap(a.M), (long long)rt_num_cus() * 8), EMB_HEAVY_WAVES * 64, 0, stream>>>(a);
   RT_CHECK_LAUNCH();
-  embed_bwd_rows_kernel<NDV><<<(a.V + 3) / 4, 256, 0, stream>>>(a);
+  if (a.gpos) embed_bwd_rows_pos_kernel<NDV><<<(a.V + 3) / 4 + a.L, 256, 0, stream>>>(a, a.L);
+  else embed_bwd_rows_kernel<NDV><<<(a.V + 3) / 4, 256, 0, stream>>>(a);
   RT_CHECK_LAUNCH();
-  if (a.gpos) {
-    embed_bwd_pos_kernel<NDV><<<a.L, 256, 0, stream>>>(a);
-    RT_CHECK_LAUNCH();
-  }
   return RT_OK;
 }
 
