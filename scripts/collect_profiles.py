@@ -18,7 +18,8 @@ KEEP = [("1_bench.json", "bench_auto.json"), ("2_prof.md", "rocprof_kernel_trace
         ("10_prof.md", "rocprof_kernel_trace_topk5m_u4096.md"), ("11_prof.md", "rocprof_kernel_trace_bert4rec.md"),
         ("12_prof.md", "rocprof_kernel_trace_hstu.md"), ("13_prof.md", "rocprof_kernel_trace_recommend.md"),
         ("14_pmc.txt", "pmc_topk5m_u4096_FETCH_SIZE.txt"), ("15_prof.md", "rocprof_kernel_trace_esasrec_kpm.md"),
-        ("16_pytest.txt", "pytest_gpu_final_tree.txt")]
+        ("16_pytest.txt", "pytest_gpu_final_tree.txt"), ("17_pmc.txt", "sq_counters_topk5m_u4096_raw.txt"), ("2_timeline.txt", "timeline_train.txt"),
+        ("13_prof.md", "rocprof_kernel_trace_recommend.md")]
 
 
 def parse(path):
@@ -67,6 +68,24 @@ def main():
         rows.append(f"| `{k[:60]}` | {c['GRBM_GUI_ACTIVE'][0]} | {g:.0f} | {mf:.0f} | {mf / simd_cycles:.3f} | {valu / simd_cycles:.3f} | {lds / (g / 8 * 256):.3f} | "
                     f"{wav / simd_cycles:.2f} | {conf / max(lds / 4, 1):.4f} |")
     open(os.path.join(DST, f"{TAG}_sq_counters_train.md"), "w").write("\n".join(rows) + "\n")
+    sq2 = parse(os.path.join(SRC, "17_pmc.txt"))      # the 4,096-user top-k launch (round 5)
+    if sq2:
+        rows2 = rows[:3]
+        for k, c in sq2.items():
+            if not any(t in k for t in ("topk_", "to_hm_rows", "one_plane")):
+                continue
+            g = c.get("GRBM_GUI_ACTIVE", (0, 0))[1]
+            if g <= 0:
+                continue
+            simd_cycles = g / 8 * 1024
+            mf = c.get("SQ_VALU_MFMA_BUSY_CYCLES", (0, 0))[1]
+            valu = c.get("SQ_ACTIVE_INST_VALU", (0, 0))[1] * 4
+            lds = c.get("SQ_ACTIVE_INST_LDS", (0, 0))[1] * 4
+            wav = c.get("SQ_WAVE_CYCLES", (0, 0))[1] * 4
+            conf = c.get("SQ_LDS_BANK_CONFLICT", (0, 0))[1]
+            rows2.append(f"| `{k[:60]}` | {c['GRBM_GUI_ACTIVE'][0]} | {g:.0f} | {mf:.0f} | {mf / simd_cycles:.3f} | {valu / simd_cycles:.3f} | {lds / (g / 8 * 256):.3f} | "
+                         f"{wav / simd_cycles:.2f} | {conf / max(lds / 4, 1):.4f} |")
+        open(os.path.join(DST, f"{TAG}_sq_counters_topk5m_u4096.md"), "w").write("\n".join(rows2) + "\n")
     f, w = parse(os.path.join(SRC, "4_pmc.txt")), parse(os.path.join(SRC, "5_pmc.txt"))
     tf, tw = parse(os.path.join(SRC, "8_pmc.txt")), parse(os.path.join(SRC, "9_pmc.txt"))
 
