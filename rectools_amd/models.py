@@ -238,10 +238,10 @@ class _TrainLoop:
         main = torch.cuda.current_stream(self.device)
         side = _PREFETCH_STREAMS.get(self.device)
         if side is None:
-            # ONE per device and process, like the weight-gradient streams (ops._SIDE, csrc/rt_block.hip): a stream per loop walks the
-            # runtime's stream -> hardware-queue assignment, and a later loop's prefetch stream can land on the queue of the
-            # weight-gradient stream — its waits then sit in front of those products (HSTU C4: 17.4 k seqs/s as the fourth loop of a
-            # process against 21.9 k as the first, same kernels)
+            # ONE per device and process, like the weight-gradient streams (ops._SIDE, csrc/rt_block.hip).  Measured, mechanism not
+            # pinned down: with a stream per loop, the fourth loop of a process ran its weight-gradient products and the prefetch
+            # serialised (HSTU C4 17.4 k seqs/s against 21.9 k as the first loop, same kernels, GPU time 7.3 vs 5.8 ms per step;
+            # GPU_MAX_HW_QUEUES = 2 / 8 changes neither figure); with the one stream every loop runs like the first
             side = _PREFETCH_STREAMS[self.device] = torch.cuda.Stream(device=self.device)
         with torch.cuda.stream(side):
             batch = self._cut_batch()
