@@ -725,6 +725,23 @@ struct BucketRun {
   __device__ __forceinline__ void flush(float* dtw) { if (cur >= 0) atomicAdd(dtw + cur, acc); cur = -1; acc = 0.f; }
 };
 
+// Position-bias gradient of one 16-query x 4-key block of a lane row (queries i = 0 .. 15 across the row's lanes, a lane's four
+// consecutive keys j = 0 .. 3): element (i, j) belongs to slot base + j - i of d_pos_w, so the 64 values fall on 19 diagonals.  Summed along
+// the diagonals in registers with row shifts (DPP, no LDS): `main` of lane i = the diagonal through its element 3 (slot base + 3 - i, whole
+// for every lane: what a shift drops in at the row's start is zero), `wrap` of lanes 0 .. 2 = the three diagonals (-13, -14, -15) whose
+// elements the shifts push out of the row's end (slot base - 13 - i).  Two LDS atomics per block instead of four, 16 + 3 live lanes per row
+// instead of 64 values — the atomics were the dQ pass's largest non-matrix cost (one per valid score element).
+__device__ __forceinline__ float row_shr1(float v) {   // lane i of a 16-lane row takes lane i - 1's value, lane 0 takes zero
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row_ror1(float v) {   // ... lane 0 takes lane 15's
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, false));
+}
+__device__ __forceinline__ void diagonal_sums(const float* d4, int i, float& main, float& wrap) {
+  main = row_shr1(row_shr1(row_shr1(d4[0]) + d4[1]) + d4[2]) + d4[3];
+  wrap = row_ror1(row_ror1(row_ror1(i >= 13 ? d4[0] : 0.f) + (i >= 14 ? d4[1] : 0.f)) + (i >= 15 ? d4[2] : 0.f));
+}
+
 // ---- forward: a lane owns a query; chunks of keys ------------------------------------------------------------------------------------
 template <int HD, int NW>
 __global__ __launch_bounds__(NW * 64) void v2_hstu_fwd_kernel(HstuV2Args a) {
@@ -853,9 +870,16 @@ __global__ __launch_bounds__(NW * 64) void v2_hstu_bwd_dq_kernel(HstuV2Args a) {
           if (pbias) bias += l.pw[pidx];
           const float z = sT[e >> 2][e & 3] + bias;
           ds[e] = valid ? dpT[e >> 2][e & 3] * inv_l * hstu_silu_d(z) : 0.f;
-          if (valid) {
-            if (tgrad) run.add(l.dtw, bk, ds[e]);
-            if (pgrad) atomicAdd(l.dpw + pidx, ds[e]);          // the 16 queries of a lane group hit 16 different slots
+          if (valid && tgrad) run.add(l.dtw, bk, ds[e]);
+        }
+        if (pgrad) {
+#pragma unroll
+          for (int hb = 0; hb < 2; ++hb) {      // (invalid elements are zeros: a diagonal is valid or invalid as a whole up to the window's edges)
+            float dmain, dwrap;
+            diagonal_sums(ds + 4 * hb, i, dmain, dwrap);
+            const int base = a.Lw - 1 + c0 + t * 32 + 16 * hb + 4 * g - qt * 16;
+            if (dmain != 0.f) atomicAdd(l.dpw + min(max(base + 3 - i, 0), 2 * a.Lw - 2), dmain);
+            if (dwrap != 0.f) atomicAdd(l.dpw + min(max(base - 13 - i, 0), 2 * a.Lw - 2), dwrap);
           }
         }
         const P3 Sp = split8(ds);
