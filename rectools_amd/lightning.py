@@ -232,14 +232,14 @@ class FlatAdam:
         if not params:
             raise ValueError("no parameters to optimise")
         dev = params[0].device
-        # 16-byte aligned segments.  Large 2-D parameters (embedding tables) additionally own ZERO rows up to the next
+        # 32-byte aligned segments (a weight's bf16 planes then start on 16 bytes: `ops.WeightPlanes.of`).  Large 2-D parameters (embedding tables) additionally own ZERO rows up to the next
         # multiple of 128 behind their data (never touched by Adam: their gradient is zero): kernels that tile the table in
         # 128-row blocks — the full-catalog softmax GEMMs — may then read `_rt_rows_padded` rows and take the exact-tile
         # LDS-DMA path instead of the ragged-edge kernel (ops._SoftmaxLoss).
         def seg_floats(p: torch.Tensor) -> int:
             if p.dim() == 2 and p.shape[0] >= 1024 and p.shape[1] % 4 == 0:
                 return (p.shape[0] + 127) // 128 * 128 * p.shape[1]
-            return (p.numel() + 3) // 4 * 4
+            return (p.numel() + 7) // 8 * 8
 
         sizes = [seg_floats(p) for p in params]
         self.n_used = sum(sizes)
@@ -259,7 +259,7 @@ class FlatAdam:
             view.copy_(p.data)
             p.data = view
             p.grad = None
-            if sz > (p.numel() + 3) // 4 * 4:
+            if sz > (p.numel() + 7) // 8 * 8:
                 p._rt_rows_padded = sz // p.shape[1]
             self._offsets.append(ofs)
             ofs += sz

@@ -671,16 +671,18 @@ class LiGRLayers(TransformerLayersBase):
              for _ in range(n_blocks)])
 
     def forward(self, seqs, ids, B, L, causal, keypad, batch):
-        for blk in self.transformer_blocks:
-            seqs = blk(seqs, ids, B, L, causal, keypad)
+        with ops.active_planes(self._fresh_planes()):      # the blocks' Linear products read the pre-split weight planes (K7w)
+            for blk in self.transformer_blocks:
+                seqs = blk(seqs, ids, B, L, causal, keypad)
         return seqs
 
     def forward_last(self, seqs, ids, B, L, causal, keypad, batch):
         """Inference: [B, d] encodings of the last position; the final block on one query row per session."""
         blocks = list(self.transformer_blocks)
-        for blk in blocks[:-1]:
-            seqs = blk(seqs, ids, B, L, causal, keypad)
-        return blocks[-1].forward_last(seqs, ids, B, L, causal, keypad)
+        with ops.active_planes(self._fresh_planes()):
+            for blk in blocks[:-1]:
+                seqs = blk(seqs, ids, B, L, causal, keypad)
+            return blocks[-1].forward_last(seqs, ids, B, L, causal, keypad)
 
     def packed_ok(self, n_factors: int, window: int, causal: bool, keypad: bool = False) -> bool:
         """Packed rows serve the LiGR stack when pad positions are masked as keys (`use_key_padding_mask=True`): without the mask the
@@ -692,15 +694,17 @@ class LiGRLayers(TransformerLayersBase):
     def forward_packed_train(self, seqs, cu, B, window, keypad, rows_real=None, causal=True):
         n_real = int(rows_real) if rows_real is not None else None
         pad_idx, pad_ids = ops.padded_index(cu, B, window, int(seqs.shape[0]))
-        for blk in self.transformer_blocks:
-            seqs = blk.forward_packed(seqs, B, window, causal, pad_idx, pad_ids, n_real)
+        with ops.active_planes(self._fresh_planes()):
+            for blk in self.transformer_blocks:
+                seqs = blk.forward_packed(seqs, B, window, causal, pad_idx, pad_ids, n_real)
         return seqs
 
     def forward_last_packed(self, seqs, cu, B, window, keypad, rows_real=None, causal=True):
         """Inference over packed rows: all blocks on the packed rows, then the last row of every session."""
         pad_idx, pad_ids = ops.padded_index(cu, B, window, int(seqs.shape[0]))
-        for blk in self.transformer_blocks:
-            seqs = blk.forward_packed(seqs, B, window, causal, pad_idx, pad_ids, None)
+        with ops.active_planes(self._fresh_planes()):
+            for blk in self.transformer_blocks:
+                seqs = blk.forward_packed(seqs, B, window, causal, pad_idx, pad_ids, None)
         return seqs.index_select(0, cu[1:B + 1] - 1)
 
 
@@ -846,16 +850,18 @@ class STULayers(TransformerLayersBase):
         self.register_buffer("time_thr", ops.hstu_time_thresholds(nb), persistent=False)
 
     def forward(self, seqs, ids, B, L, causal, keypad, batch):
-        for blk in self.stu_blocks:
-            seqs = blk(seqs, ids, B, L, batch, self.time_thr)   # seqs * mask happens inside the block
+        with ops.active_planes(self._fresh_planes()):      # uvqk_proj / output_mlp products read the pre-split weight planes (K7w)
+            for blk in self.stu_blocks:
+                seqs = blk(seqs, ids, B, L, batch, self.time_thr)   # seqs * mask happens inside the block
         return ops.mul_mask(seqs, None, ids)
 
     def forward_last(self, seqs, ids, B, L, causal, keypad, batch):
         """Inference: [B, d] encodings of the last position; the final STU block on one query row per session."""
         blocks = list(self.stu_blocks)
-        for blk in blocks[:-1]:
-            seqs = blk(seqs, ids, B, L, batch, self.time_thr)
-        last = blocks[-1].forward_last(seqs, ids, B, L, batch, self.time_thr)
+        with ops.active_planes(self._fresh_planes()):
+            for blk in blocks[:-1]:
+                seqs = blk(seqs, ids, B, L, batch, self.time_thr)
+            last = blocks[-1].forward_last(seqs, ids, B, L, batch, self.time_thr)
         return ops.mul_mask(last, None, ids.view(B, L)[:, L - 1].contiguous())
 
     def packed_ok(self, n_factors: int, window: int, causal: bool, keypad: bool = False) -> bool:
@@ -866,8 +872,9 @@ class STULayers(TransformerLayersBase):
             and window == blocks[0].L
 
     def forward_packed_train(self, seqs, cu, B, window, keypad, rows_real=None, causal=True, ts=None):
-        for blk in self.stu_blocks:
-            seqs = blk.forward_packed(seqs, cu, B, window, ts, self.time_thr, rows_real)
+        with ops.active_planes(self._fresh_planes()):
+            for blk in self.stu_blocks:
+                seqs = blk.forward_packed(seqs, cu, B, window, ts, self.time_thr, rows_real)
         return seqs
 
     def forward_last_packed(self, seqs, cu, B, window, keypad, rows_real=None, causal=True, ts=None):

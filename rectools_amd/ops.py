@@ -66,7 +66,7 @@ _NATIVE_TIMING_NAMES = {0: "rt_gemm", 1: "rt_gemm_grouped", 2: "rt_layernorm_fwd
 _FN: tp.Dict[str, tp.Any] = {}   # bound C entry points (one getattr per name instead of one per launch)
 
 
-def _c(name: str, *args: tp.Any, tag: tp.Any = None, stream: tp.Optional[int] = None) -> None:
+def _c(name: str, *args: tp.Any, tag: tp.Any = None, stream: tp.Optional[int] = None, timed_as: tp.Optional[str] = None) -> None:
     """Call `rt_<name>(*args, stream)`; tensors are passed as raw device pointers.  stream: a raw HIP stream handle (the library's
     side stream, `_native_side_fork`); default torch's current stream."""
     fn = _FN.get(name)
@@ -82,7 +82,7 @@ def _c(name: str, *args: tp.Any, tag: tp.Any = None, stream: tp.Optional[int] = 
         e0.record()
         status = fn(*conv, _lib.current_stream())
         e1.record()
-        _TIMING.setdefault(name, []).append((e0, e1, tag))
+        _TIMING.setdefault(timed_as or name, []).append((e0, e1, tag))
     _lib.check(status, name)
 
 
@@ -285,6 +285,60 @@ def _deep_k_splits(M: int, N: int, K: int) -> int:
     return max(1, min(K // 512, -(-768 // tiles), 64))
 
 
+# ---- products against a weight whose bf16 planes are at hand (K7w outside the native executors) ---------------------------------------
+# A layer stack arms its planes around its forward pass (`active_planes`); the autograd nodes below look a weight up in them
+# (`WeightPlanes.of`) and keep what they found for their backward pass — the planes stay what they are until the stack's next forward
+# pass re-splits them, and the weights do not change between a forward pass and its backward pass.
+_ACTIVE_PLANES: tp.Optional["WeightPlanes"] = None
+
+
+class active_planes:      # pylint: disable=invalid-name
+    """`with ops.active_planes(planes):` — products of `ops.linear / matmul_nn / stu_layer*` inside read weights of `planes`' range from
+    the pre-split planes (`rt_gemm_wp`).  None = plain `rt_gemm` (also what every product outside such a block is)."""
+
+    def __init__(self, planes: tp.Optional["WeightPlanes"]) -> None:
+        self.planes = planes if planes is not None and planes.ok and weight_planes_enabled() else None
+
+    def __enter__(self) -> "active_planes":
+        global _ACTIVE_PLANES
+        self.prev, _ACTIVE_PLANES = _ACTIVE_PLANES, self.planes
+        return self
+
+    def __exit__(self, *exc: tp.Any) -> None:
+        global _ACTIVE_PLANES
+        _ACTIVE_PLANES = self.prev
+
+
+def _planes_of(w: torch.Tensor) -> tp.Optional[tp.Tuple[int, int, tp.Any]]:
+    """(plane-0 pointer, plane stride, keep-alive) of a weight inside the armed planes, else None."""
+    pl = _ACTIVE_PLANES
+    if pl is None or not w.is_contiguous():
+        return None
+    ptr = pl.of(w)
+    return None if ptr is None else (ptr, pl.stride, pl.planes)
+
+
+def _gemm_w(A, lda, W, ldw, w_kc, wp, C, ldc, bias, R, ldr, M, N, K, relu=0) -> None:
+    """C[M, N] = A[M, K] . W' (+ bias) (+ R) (relu), A rows K-contiguous; W' = W[N, K] (w_kc = 1) or W[K, N] (w_kc = 0).  With `wp`
+    (`_planes_of(W)`) and an exact tile grid in N and K the rows of the full 128-row tiles run on `rt_gemm_wp` (the weight's split read
+    from the planes: half the split arithmetic of `rt_gemm`'s loop, the same six bf16 products per fp32 product), the rows behind them —
+    and every product without planes — on `rt_gemm`."""
+    m0 = 0
+    if wp is not None and wp[0] % 16 == 0 and M >= 128 and N % 128 == 0 and K % 32 == 0 and lda % 4 == 0 and ldw % 8 == 0 and A.data_ptr() % 16 == 0 \
+            and C.data_ptr() % 16 == 0 and ldc % 4 == 0 and (R is None or (R.data_ptr() % 16 == 0 and ldr % 4 == 0)):
+        import ctypes
+
+        m0 = M // 128 * 128
+        arr = (_lib.GemmWpProblem * 1)()
+        q = arr[0]
+        q.A, q.lda, q.W, q.plane_stride, q.ldw, q.C, q.ldc = A.data_ptr(), lda, wp[0], wp[1], ldw, C.data_ptr(), ldc
+        q.bias, q.R, q.ldr = (None if bias is None else bias.data_ptr()), (None if R is None else R.data_ptr()), (0 if R is None else ldr)
+        q.M, q.N, q.K, q.relu = m0, N, K, relu
+        _c("rt_gemm_wp", ctypes.cast(arr, ctypes.c_void_p), 1, 0 if w_kc else 1, tag=(m0, N, K), timed_as="rt_gemm")
+    if m0 < M:
+        _gemm(A[m0:], lda, 1, W, ldw, w_kc, C[m0:], ldc, bias, None if R is None else R[m0:], ldr, M - m0, N, K, relu)
+
+
 class _Linear(torch.autograd.Function):
     """y = x @ W^T (+ b) (+ residual) (relu).  x [M,K] (row stride free), W [N,K] contiguous."""
 
@@ -294,10 +348,11 @@ class _Linear(torch.autograd.Function):
         M, K = x.shape
         N = weight.shape[0]
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-        _gemm(x, x.stride(0), 1, weight, weight.stride(0), 1, y, N, bias, residual,
-              0 if residual is None else residual.stride(0), M, N, K, 1 if relu else 0)
+        wp = _planes_of(weight) if x.stride(1) == 1 else None
+        _gemm_w(x, x.stride(0), weight, weight.stride(0), 1, wp, y, N, bias, residual,
+                0 if residual is None else residual.stride(0), M, N, K, 1 if relu else 0)
         ctx.save_for_backward(x, weight, y if relu else None, bias)
-        ctx.has_bias, ctx.has_res, ctx.relu = bias is not None, residual is not None, relu
+        ctx.has_bias, ctx.has_res, ctx.relu, ctx.wp = bias is not None, residual is not None, relu, wp
         return y
 
     @staticmethod
@@ -326,7 +381,7 @@ class _Linear(torch.autograd.Function):
             _c("rt_colsum", dy, N, M, N, db)
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
-            _gemm(dy, N, 1, weight, weight.stride(0), 0, dx, K, None, None, 0, M, K, N)  # dx = dy @ W
+            _gemm_w(dy, N, weight, weight.stride(0), 0, ctx.wp, dx, K, None, None, 0, M, K, N)  # dx = dy @ W
         if sd is not None:
             sd.join_now()   # parameter slices / accumulating grads: autograd touches dw right after this node
         dres = dy if (ctx.has_res and ctx.needs_input_grad[3]) else None
@@ -346,7 +401,8 @@ class _MatmulNN(torch.autograd.Function):
         M, K = x.shape
         N = p.shape[1]
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-        _gemm(x, x.stride(0), 1, p, N, 0, y, N, None, None, 0, M, N, K)
+        ctx.wp = _planes_of(p) if x.stride(1) == 1 else None
+        _gemm_w(x, x.stride(0), p, N, 0, ctx.wp, y, N, None, None, 0, M, N, K)
         ctx.save_for_backward(x, p)
         return y
 
@@ -362,7 +418,7 @@ class _MatmulNN(torch.autograd.Function):
             sd.uses(x, dy, dp)
             _gemm(x, x.stride(0), 0, dy, N, 0, dp, N, None, None, 0, K, N, M, 0, _wgrad_splits(M, K, N))  # dP = x^T @ dy
         dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
-        _gemm(dy, N, 1, p, N, 1, dx, K, None, None, 0, M, K, N)  # dx = dy @ P^T : B(k', n) = P[k'*N + n] (kc)
+        _gemm_w(dy, N, p, N, 1, ctx.wp, dx, K, None, None, 0, M, K, N)  # dx = dy @ P^T : B(k', n) = P[k'*N + n] (kc)
         sd.join_now()
         return dx, dp
 
@@ -1953,7 +2009,8 @@ class _STULayer(torch.autograd.Function):
         if cu is None:
             _c("rt_mul_mask", n1, None, ids, d, n1.numel(), n1)          # in place: n1 = LN(x0) * m
         z = new(M, 4 * hh)
-        _gemm(n1, d, 1, uvqk_p, 4 * hh, 0, z, 4 * hh, None, None, 0, M, 4 * hh, d)
+        wp_p, wp_o = _planes_of(uvqk_p), _planes_of(out_w)
+        _gemm_w(n1, d, uvqk_p, 4 * hh, 0, wp_p, z, 4 * hh, None, None, 0, M, 4 * hh, d)
         uvqk = new(M, 4 * hh)
         _c("rt_act_dropout_fwd", z, ACT_SILU, 0.0, 0, 0, z.numel(), None, uvqk)
         attn = new(M, hh)
@@ -1982,7 +2039,8 @@ class _STULayer(torch.autograd.Function):
             o_d = new(M, hh)
             _c("rt_act_dropout_fwd", o_in, ACT_NONE, float(p_mlp), seed_m[0], seed_m[1], o_in.numel(), None, o_d)
         out = new(M, d)
-        _gemm(o_d, hh, 1, out_w, hh, 1, out, d, out_b, x0, d, M, d, hh)
+        _gemm_w(o_d, hh, out_w, hh, 1, wp_o, out, d, out_b, x0, d, M, d, hh)
+        ctx.wp = (wp_p, wp_o)
         ctx.save_for_backward(ids, ts, thr, x0, n1, z, uvqk, attn_d, la, o_d, mean1, rstd1, mean2, rstd2, ln1_w, uvqk_p, tw, pw,
                               ln2_w, out_w, cu)
         ctx.meta = (B, L, H, hd, p_attn, p_mlp, seed_a, seed_m, rows_real)
@@ -2009,7 +2067,7 @@ class _STULayer(torch.autograd.Function):
             sd.uses(g_out, o_d, d_wo, d_bo)
             _gemm(g_out, d, 0, o_d, hh, 0, d_wo, hh, None, None, 0, d, hh, M, 0, sp, d_bo)
         g_od = new(M, hh)
-        _gemm(g_out, d, 1, out_w, hh, 0, g_od, hh, None, None, 0, M, hh, d)
+        _gemm_w(g_out, d, out_w, hh, 0, ctx.wp[1], g_od, hh, None, None, 0, M, hh, d)
         if p_mlp > 0:
             g_oin = new(M, hh)
             _c("rt_act_dropout_bwd", g_od, g_od, ACT_NONE, float(p_mlp), seed_m[0], seed_m[1], g_od.numel(), g_oin)
@@ -2050,7 +2108,7 @@ class _STULayer(torch.autograd.Function):
             sd.uses(n1, g_z, d_p)
             _gemm(n1, d, 0, g_z, 4 * hh, 0, d_p, 4 * hh, None, None, 0, d, 4 * hh, M, 0, sp)       # dP = n^T g_z
         g_n = new(M, d)
-        _gemm(g_z, 4 * hh, 1, uvqk_p, 4 * hh, 1, g_n, d, None, None, 0, M, d, 4 * hh)              # g_n = g_z P^T
+        _gemm_w(g_z, 4 * hh, uvqk_p, 4 * hh, 1, ctx.wp[0], g_n, d, None, None, 0, M, d, 4 * hh)   # g_n = g_z P^T
         # ---- n = LN(x0) * m, x0 = x * m (+ the skip connection): one kernel
         g_x, d_ln1w, d_ln1b = new(M, d), new(d), new(d)
         ws_bytes = lib.rt_layernorm_bwd_workspace_bytes(M, d)

@@ -734,3 +734,42 @@ def test_gemm_with_presplit_weight_planes_is_fp32_accurate(w_tr):
     bad = torch.empty(100, d, device="cuda")      # not an exact tile grid: refused (the caller falls back to rt_gemm), never computed otherwise
     with pytest.raises(NotImplementedError):
         run([(torch.randn(100, d).cuda(), planes.data_ptr(), d, bad, None, None, 100, d, d, 0)])
+
+
+@pytest.mark.parametrize("rows", [384, 389, 100])
+def test_linear_and_matmul_nn_read_the_armed_weight_planes(rows):
+    """`ops.active_planes` (K7w outside the native executors: the LiGR / STU stacks): a product whose weight lies in the armed planes runs
+    its full 128-row tiles on `rt_gemm_wp` and the rows behind them on `rt_gemm`; same six bf16 products per fp32 product, so the results
+    agree with the unarmed product to fp32 rounding — forward, data gradient (which reads the planes found in the forward pass) and
+    weight gradient.  389 rows: a tail behind three tiles; 100 rows: no full tile, `rt_gemm` only."""
+    from rectools_amd import lightning as hl
+    from rectools_amd import nn as hnn
+    from rectools_amd import ops
+
+    torch.manual_seed(5)
+    stack = hnn.LiGRLayers(1, 256, 2, 0.0).cuda()
+    hl.FlatAdam(stack, lr=1e-3)                        # parameters become views of one flat buffer
+    blk = stack.transformer_blocks[0]
+    w, b = blk.feed_forward.ff_linear_1.weight, blk.multi_head_attn.in_proj_bias[:256]
+    p_nn = blk.multi_head_attn.in_proj_weight[:256]   # a [K, N] operand for matmul_nn (a row slice: contiguous, inside the planes)
+    x = torch.randn(rows, 256, device="cuda", requires_grad=True)
+    res = torch.randn(rows, w.shape[0], device="cuda")
+
+    def run(armed):
+        for t in (x, w):
+            t.grad = None
+        planes = stack._fresh_planes() if armed else None
+        assert (planes is not None) == armed
+        with ops.active_planes(planes):
+            assert (ops._planes_of(w) is not None) == armed and (ops._planes_of(p_nn) is not None) == armed
+            y = ops.linear(x, w, None, res, relu=True)
+            z = ops.matmul_nn(x, p_nn)
+        (y.sum() + (z * z).sum()).backward()           # backward OUTSIDE the block: the nodes kept what they found
+        torch.cuda.synchronize()
+        return y.detach().clone(), z.detach().clone(), x.grad.clone(), w.grad.clone()
+
+    got, ref = run(True), run(False)
+    for a, r, what in zip(got, ref, ("linear", "matmul_nn", "dx", "dw")):
+        torch.testing.assert_close(a, r, rtol=2e-6, atol=2e-6 * float(r.abs().max()), msg=lambda m, what=what: f"{what}: {m}")
+    ref64 = torch.relu(x.detach().double() @ w.detach().double().t() + res.double())
+    assert float((got[0].double() - ref64).abs().max() / ref64.abs().max()) < 2e-6
