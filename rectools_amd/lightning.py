@@ -313,10 +313,27 @@ class FlatAdam:
         fg = self.flat_g
         if self._g_views is None:
             self._g_views = [fg[ofs:ofs + p.numel()].view_as(p) for p, ofs in zip(self.params, self._offsets)]
+            # large tables: from the next step on the sampled losses write the table's gradient INTO its segment (`ops._TABLE_GRAD_HOME`)
+            # — the copy below then skips it (1 GB per step at C4, 27 MB at C2)
+            import weakref
+
+            me = weakref.ref(self)      # (the registry must not keep the buffers of a dead optimiser alive)
+
+            def home(ofs: int, shape: torch.Size, n: int) -> tp.Optional[torch.Tensor]:
+                opt = me()
+                return None if opt is None or opt._flat_g is None else opt._flat_g[ofs:ofs + n].view(shape)
+
+            for p, ofs in zip(self.params, self._offsets):
+                if p.dim() == 2 and p.is_cuda and p.numel() >= (1 << 20):
+                    key = p.data_ptr()
+                    ops._TABLE_GRAD_HOME[key] = (lambda ofs=ofs, shape=p.shape, n=p.numel(): home(ofs, shape, n))
+                    weakref.finalize(self, ops._TABLE_GRAD_HOME.pop, key, None)
         views, grads = [], []
         for p, view in zip(self.params, self._g_views):
             if p.grad is None:
                 view.zero_()
+            elif p.grad.data_ptr() == view.data_ptr() and p.grad.shape == view.shape and p.grad.is_contiguous():
+                continue                                # produced in place
             else:
                 views.append(view)
                 grads.append(p.grad if p.grad.dtype == torch.float32 else p.grad.float())

@@ -472,6 +472,22 @@ def clear_step_expectations() -> None:
     _TABLE_GRAD_SINK.clear()
 
 
+# Data-parallel runs: where a table's dense gradient should be PRODUCED — its segment of the optimiser's flat gradient buffer
+# (`lightning.FlatAdam.gather_gradients` registers it) — so that packing the gradients for the collective does not copy the largest of
+# them (1 GB per step at C4).  Keyed by the table's data pointer; the value makes a FRESH view per call (autograd adopts a gradient
+# only while nobody else holds the tensor object).
+_TABLE_GRAD_HOME: tp.Dict[int, tp.Callable[[], tp.Optional[torch.Tensor]]] = {}
+
+
+def _new_table_grad(table: torch.Tensor) -> torch.Tensor:
+    home = _TABLE_GRAD_HOME.get(table.data_ptr())
+    if home is not None and table.is_leaf and table.grad is None:      # (a second backward pass of a step accumulates: not in place)
+        g = home()
+        if g is not None and g.shape == table.shape and g.device == table.device and g.dtype == table.dtype:
+            return g
+    return torch.empty_like(table)
+
+
 def _offer_table_grad(table: torch.Tensor, d_table: torch.Tensor) -> None:
     if d_table.is_contiguous() and d_table.shape == table.shape:
         _TABLE_GRAD_SINK[table.data_ptr()] = d_table
@@ -2223,7 +2239,7 @@ class _SampledLoss(torch.autograd.Function):
         if gloss is None:                    # (set_materialize_grads(False): nothing asked for the loss)
             return (None,) * 9
         d_sess = torch.empty((M, d), dtype=torch.float32, device=sess.device)
-        d_table = torch.empty_like(table)
+        d_table = _new_table_grad(table)     # (every row is written: zeros where no candidate fell)
         # The upstream gradient stays on the device: the kernels divide by norm[0], so the quotient normaliser / upstream does what
         # `float(gloss)` did — without the device -> host copy that made the host wait for the whole forward pass at the start of every
         # backward pass (one tiny elementwise launch instead; the host may now run steps ahead of the device)

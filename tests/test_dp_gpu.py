@@ -49,12 +49,37 @@ def _worker(rank, world, port, out_dir, exchange="allreduce", shape="small"):
     local = {n: p.grad.detach().clone() for n, p in lm.torch_model.named_parameters()}
     opt.step(world)
     torch.cuda.synchronize()
+    g1 = {}
     for n, p in lm.torch_model.named_parameters():
         g = local[n].clone()
         dist.all_reduce(g)                                                       # independent of the product path
         g /= world
+        g1[n] = g
         want = p0[n] - 1e-2 * g / (g.abs() + 1e-8)                               # first Adam step: m_hat = g, v_hat = g^2
         torch.testing.assert_close(p.detach(), want, rtol=2e-4, atol=2e-6, msg=lambda m, n=n: f"{n}: {m}")
+    if shape == "c2":
+        # SECOND step: from now on the sampled loss writes the item table's gradient into its segment of the flat gradient buffer
+        # (`ops._TABLE_GRAD_HOME`, registered by the first pack) and the pack skips it — same Adam step as from separate gradients
+        p1 = {n: p.detach().clone() for n, p in lm.torch_model.named_parameters()}
+        ops.RNG.next_step()
+        opt.zero_grad()
+        lm.training_loss(batch).backward()
+        table_name, table = max(lm.torch_model.named_parameters(), key=lambda kv: kv[1].numel())
+        i = [q is table for q in opt.params].index(True)
+        assert table.grad.data_ptr() == opt.flat_g.data_ptr() + 4 * opt._offsets[i], "the table's gradient was not produced in place"
+        local = {n: p.grad.detach().clone() for n, p in lm.torch_model.named_parameters()}
+        opt.step(world)
+        torch.cuda.synchronize()
+        b1, b2 = opt.betas
+        for n, p in lm.torch_model.named_parameters():
+            g = local[n].clone()
+            dist.all_reduce(g)
+            g /= world
+            m = (b1 * (1 - b1) * g1[n] + (1 - b1) * g) / (1 - b1 ** 2)
+            v = (b2 * (1 - b2) * g1[n] ** 2 + (1 - b2) * g ** 2) / (1 - b2 ** 2)
+            want = p1[n] - 1e-2 * m / (v.sqrt() + 1e-8)
+            solid = (g1[n].abs() + g.abs()) > 1e-7      # (entries both gradients leave at ~0 move by rounding noise over eps)
+            torch.testing.assert_close(p.detach()[solid], want[solid], rtol=5e-4, atol=5e-6, msg=lambda m_, n=n: f"second step, {n}: {m_}")
     bad = []
     for n, p in lm.torch_model.named_parameters():                               # replicas stay bit-identical
         for what, t in (("init", p0[n]), ("after", p.detach())):
