@@ -737,3 +737,49 @@ def test_hstu_time_thresholds_match_reference_formula(num_buckets):
     ref = torch.clamp((torch.log(torch.abs(x).clamp(min=1)) / 0.301).long(), 0, num_buckets)
     got = torch.clamp((thr[None, :] <= x[:, None]).sum(1) - 1, max=n_w - 1)      # what the kernels do: unclamped bucket, last weight repeated
     assert torch.equal(ref, got)
+
+
+def test_flat_adam_segments_start_on_32_bytes_and_keep_the_parameters():
+    """`lightning.FlatAdam`'s layout (host logic, any device): every parameter is a view of the flat buffer at an offset that is a multiple
+    of 8 floats — a weight's bf16 planes (`ops.WeightPlanes`: plane byte offset = float offset x 2) then start on 16 bytes, which
+    `rt_gemm_wp` needs; large tables own zero rows up to the next multiple of 128; the buffer's length divides by every world size the
+    sharded exchange cuts it into; values are kept."""
+    import torch
+
+    from rectools_amd import lightning as hl
+
+    torch.manual_seed(0)
+    mod = torch.nn.ParameterDict({
+        "table": torch.nn.Parameter(torch.randn(1030, 12)), "odd": torch.nn.Parameter(torch.randn(129)),
+        "w": torch.nn.Parameter(torch.randn(16, 24)), "b": torch.nn.Parameter(torch.randn(3))})
+    before = {k: v.detach().clone() for k, v in mod.items()}
+    opt = hl.FlatAdam(mod, lr=1e-3)
+    assert all(ofs % 8 == 0 for ofs in opt._offsets)
+    base = opt.flat_p.data_ptr()
+    for p, ofs in zip(opt.params, opt._offsets):
+        k = [n for n, q in mod.items() if q is p][0]
+        assert p.data_ptr() == base + 4 * ofs and torch.equal(p.detach(), before[k])
+    assert mod["table"]._rt_rows_padded == 1152 and not hasattr(mod["odd"], "_rt_rows_padded")
+    i = [q is mod["table"] for q in opt.params].index(True)
+    ends = sorted(opt._offsets + [opt.n_used])
+    tail = opt.flat_p[opt._offsets[i] + 1030 * 12:ends[ends.index(opt._offsets[i]) + 1]]
+    assert tail.numel() == (1152 - 1030) * 12 and float(tail.abs().max()) == 0.0          # the table's zero rows
+    assert opt.flat_p.numel() % hl.FLAT_QUANTUM == 0 and all(opt.flat_p.numel() % w == 0 for w in (2, 3, 4, 5, 6, 7, 8))
+
+
+def test_active_planes_is_a_no_op_without_planes():
+    """`ops.active_planes(None)` (a stack whose parameters are not on a GPU / not one flat buffer): nothing is armed, and the previous state
+    comes back on exit — nested stacks (a plugged stack calling another) cannot leave planes armed behind them."""
+    import torch
+
+    from rectools_amd import ops
+
+    w = torch.randn(8, 8)
+    assert ops._ACTIVE_PLANES is None
+    with ops.active_planes(None):
+        assert ops._ACTIVE_PLANES is None and ops._planes_of(w) is None
+        with ops.active_planes(None):
+            pass
+        assert ops._ACTIVE_PLANES is None
+    assert ops._ACTIVE_PLANES is None
+    assert ops.WeightPlanes([w]).ok is False                                                # CPU parameters: no planes
