@@ -143,6 +143,22 @@ def _install_lightning() -> None:
                 model.to("cuda")
             model.train()
             opt = model.configure_optimizers()
+            if ckpt_path is not None:
+                # Lightning restores a checkpoint BEFORE the fit loop starts (`_checkpoint_connector.restore_*` in `Trainer._run`):
+                # module weights (strict), optimizer states, the loops' progress — what `load_from_checkpoint`
+                # (transformers/base.py:591-654) relies on when it calls `fit(ckpt_path=...)` with an EMPTY stub dataloader; with no
+                # training batches the fit loop is skipped (`_FitLoop.skip`), so `on_train_start` (xavier) never runs
+                ck = torch.load(ckpt_path, map_location="cpu", weights_only=False)
+                model.load_state_dict(ck["state_dict"], strict=True)
+                if ck.get("optimizer_states"):
+                    opt.load_state_dict(ck["optimizer_states"][0])
+                self.fit_loop.epoch_progress.current.ready = int(ck.get("epoch", 0))
+                self.restored = {"epoch": ck.get("epoch"), "global_step": ck.get("global_step")}
+                try:
+                    if len(train_dataloaders) == 0:
+                        return
+                except TypeError:
+                    pass
             n_epochs = self.fit_loop.max_epochs if self.fit_loop.max_epochs is not None else 1
             it = iter(train_dataloaders)
             model.on_train_start()

@@ -82,5 +82,43 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def build_ablation(verbose: bool = False) -> str:
+    """The diagnostic twin `librectools_hip_ablation.so` (git-ignored, loaded through `RT_LIB_PATH`): the sources that carry
+    `RT_ABLATION_BUILD` switches compiled with `-DRT_ABLATION_BUILD`, every other object shared with the product build."""
+    build(verbose=verbose)
+    out = os.path.join(PKG_DIR, "librectools_hip_ablation.so")
+    abl_dir = os.path.join(OBJ_DIR, "abl")
+    os.makedirs(abl_dir, exist_ok=True)
+    objs, procs = [], []
+    for src in _sources():
+        base = os.path.splitext(os.path.basename(src))[0]
+        with open(src) as f:
+            switched = "RT_ABLATION_BUILD" in f.read()
+        if not switched:
+            objs.append(os.path.join(OBJ_DIR, base + ".o"))
+            continue
+        obj = os.path.join(abl_dir, base + ".o")
+        stamp, dig = obj + ".sha1", _digest(src)
+        objs.append(obj)
+        if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
+            continue
+        cmd = [HIPCC] + FLAGS + ["-DRT_ABLATION_BUILD", "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT), src, stamp, dig))
+    for p, src, stamp, dig in procs:
+        o, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(o.decode(errors="replace"))
+            raise RuntimeError(f"hipcc failed for {src}")
+        with open(stamp, "w") as f:
+            f.write(dig)
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    return out
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--ablation" in sys.argv:
+        print(build_ablation(verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

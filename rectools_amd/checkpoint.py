@@ -59,6 +59,7 @@ CLASS_PATHS: tp.Dict[str, str] = {
 _BACK = {v: k for k, v in CLASS_PATHS.items() if not k.startswith("rectools.models.SASRec") and not k.startswith("rectools.models.BERT")
          and not k.startswith("rectools.models.HSTU")}
 STATE_PREFIX = "torch_model."
+ENGINE_ONLY_PARAMS = ("seed", "csv_log_dir")     # model constructor arguments the reference's config classes do not have
 
 
 def translate_config(config: tp.Any, to_reference: bool = False) -> tp.Any:
@@ -154,11 +155,20 @@ def to_checkpoint(model: tp.Any, reference_paths: bool = True) -> tp.Dict[str, t
     if lm is None or opt is None:
         raise RuntimeError("only a fitted (or built) model has a checkpoint")
     config = model.get_config(simple_types=True)
+    engine_params = {}
     if reference_paths:
         config = translate_config(config, to_reference=True)
+        # the reference's config classes forbid unknown fields (`extra="forbid"`, models/base.py:74-80): constructor arguments only this
+        # engine knows travel beside the checkpoint's own keys, not inside `model_config` — found by the reference actually loading an
+        # engine-written file (tests/test_reference_live.py): `seed` made `load_from_checkpoint` fail validation
+        for key in ENGINE_ONLY_PARAMS:
+            if key in config:
+                engine_params[key] = config.pop(key)
     hyper = {
         "model_config": config, "dataset_schema": model.dataset_schema,
-        "item_external_ids": [_plain(v) for v in dp.item_id_map.external_ids.tolist()],
+        # the array itself, as Lightning's `save_hyperparameters` keeps what `_init_lightning_model` was handed (base.py:459-473): the
+        # reference's loader feeds it straight to `IdMap(item_external_ids)`, which needs an ndarray (a list has no `.size`)
+        "item_external_ids": np.array(dp.item_id_map.external_ids, copy=True),
         "item_extra_tokens": tuple(dp.item_extra_tokens), "lr": model.lr, "gbce_t": model.gbce_t, "loss": model.loss,
         "verbose": model.verbose, "train_loss_name": model.train_loss_name, "val_loss_name": model.val_loss_name,
         "adam_betas": tuple(opt.betas), "logits_t": lm.logits_t,
@@ -168,7 +178,7 @@ def to_checkpoint(model: tp.Any, reference_paths: bool = True) -> tp.Dict[str, t
         "state_dict": {STATE_PREFIX + k: v.detach().cpu().clone() for k, v in lm.torch_model.state_dict().items()},
         "loops": {}, "callbacks": {}, "optimizer_states": [adam_state_dict(opt)], "lr_schedulers": [],
         "hparams_name": "kwargs", "hyper_parameters": hyper,
-        "rectools_amd": {"history": list(model.history)},     # extra key: Lightning ignores what it does not know
+        "rectools_amd": {"history": list(model.history), "model_params": engine_params},     # extra key: Lightning ignores what it does not know
     }
 
 

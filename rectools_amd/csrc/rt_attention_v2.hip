@@ -20,226 +20,11 @@
 //    exactly the slot order the next product's B operand wants, so probabilities / dS never leave the registers.  16-row owner tiles
 //    deal a causal triangle to 8 waves within 15 % of even (13 tiles of weight 1..7 at 200 rows) without merging partial results.
 //  * rows behind a session's end read a ZERO row kept behind every image (index n): a partner tile never needs a bounds branch.
-#include "rt_varlen.h"
+#include "rt_attn_planes.h"
 
 namespace {
 using namespace rt_varlen;
-
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-#define RT_LDS __attribute__((address_space(3)))
-
-constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
-
-struct P3 { bf16x8 h, m, l; };   // the three bf16 planes of 8 fp32 values (one MFMA operand each)
-
-// (a, b) -> the packed bf16 pairs {b, a} of the three planes.  Truncation of the top half IS the bf16; both subtractions are exact.
-__device__ __forceinline__ void split2(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
-  const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
-  const float ra = a - __uint_as_float(ua & 0xFFFF0000u), rb = b - __uint_as_float(ub & 0xFFFF0000u);
-  const unsigned va = __float_as_uint(ra), vb = __float_as_uint(rb);
-  const float la = ra - __uint_as_float(va & 0xFFFF0000u), lb = rb - __uint_as_float(vb & 0xFFFF0000u);
-  h = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
-  m = __builtin_amdgcn_perm(vb, va, 0x07060302u);
-  l = __builtin_amdgcn_perm(__float_as_uint(lb), __float_as_uint(la), 0x07060302u);
-}
-__device__ __forceinline__ P3 split8(const float (&x)[8]) {
-  u32x4 ph, pm, pl;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) { unsigned h, m, l; split2(x[2 * q], x[2 * q + 1], h, m, l); ph[q] = h; pm[q] = m; pl[q] = l; }
-  P3 r;
-  r.h = __builtin_bit_cast(bf16x8, ph); r.m = __builtin_bit_cast(bf16x8, pm); r.l = __builtin_bit_cast(bf16x8, pl);
-  return r;
-}
-
-// six-term product: acc += A * B for fp32-accurate A, B given as planes (smallest terms first)
-__device__ __forceinline__ f32x4 mfma6(const P3& A, const P3& B, f32x4 acc) {
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A.l, B.h, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A.h, B.l, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A.m, B.m, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A.m, B.h, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A.h, B.m, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A.h, B.h, acc, 0, 0, 0);
-  return acc;
-}
-
-template <int HD> struct Lay {
-  static constexpr int ROWB = HD * 2;        // bytes of one plane row
-  static constexpr int ROW3 = 3 * ROWB;      // bytes of one image row (h | m | l)
-  static constexpr int NS = HD / 32;         // MFMA k-steps over the head dimension
-  static constexpr int NCB = HD / 16;        // 16-column blocks of the head dimension
-  // XOR mask of the 16-byte unit index of row r (scripts/attn/swizzle_search.py)
-  __device__ static __forceinline__ unsigned swz(int r) { return HD == 64 ? (unsigned)(r & 6) : (unsigned)((r >> 1) & 2); }
-  static size_t image_bytes(int max_len) { return (size_t)(max_len + 1) * ROW3; }   // + the zero row
-};
-
-// Stage rows [0, n) of a [*, ld] fp32 matrix (columns [0, HD) of this head) into an LDS image: value * scale, split into planes.
-// Row n of the image is zero-filled.
-template <int HD>
-__device__ __forceinline__ void stage_image(const float* __restrict__ src, long long ld, int n, float scale, unsigned char* img, int tid,
-                                            int nthreads) {
-  using L = Lay<HD>;
-  constexpr int C4 = HD / 4;
-  const int total = n * C4;
-#pragma unroll 4
-  for (int idx = tid; idx < total; idx += nthreads) {
-    const int r = idx / C4, c4 = idx % C4;
-    const f32x4 x = *reinterpret_cast<const f32x4*>(src + (long long)r * ld + c4 * 4) * scale;
-    u32x2 h, m, l;
-    { unsigned a, b, c; split2(x[0], x[1], a, b, c); h[0] = a; m[0] = b; l[0] = c; }
-    { unsigned a, b, c; split2(x[2], x[3], a, b, c); h[1] = a; m[1] = b; l[1] = c; }
-    unsigned char* p = img + r * L::ROW3 + (((unsigned)c4 ^ (L::swz(r) << 1)) << 3);
-    *reinterpret_cast<u32x2*>(p) = h;
-    *reinterpret_cast<u32x2*>(p + L::ROWB) = m;
-    *reinterpret_cast<u32x2*>(p + 2 * L::ROWB) = l;
-  }
-  for (int w = tid; w < L::ROW3 / 8; w += nthreads) *reinterpret_cast<u32x2*>(img + n * L::ROW3 + w * 8) = u32x2{0u, 0u};
-}
-
-// Two images in ONE pass: the loads of both (U float4 each per thread and round) are issued before any split arithmetic, so a round costs
-// one memory round trip instead of two (stage_image twice: ~4 dependent round trips for a 200-row session, the prologue of a workgroup
-// that sits alone on its CU).  U = 8: a 200-row session's 13 float4 per thread (512 threads, hd 64) and a 192-row chunk of the HSTU
-// kernels are ONE round — 64 registers that are dead before the tile loop starts.  Same LDS contents as two stage_image calls.
-template <int HD>
-__device__ __forceinline__ void stage_images2(const float* __restrict__ srcA, long long ldA, float scaleA, unsigned char* imgA,
-                                              const float* __restrict__ srcB, long long ldB, float scaleB, unsigned char* imgB,
-                                              int n, int tid, int nthreads) {
-  using L = Lay<HD>;
-  constexpr int C4 = HD / 4, U = 8;
-  const int total = n * C4;
-  auto put = [&](unsigned char* img, int idx, const f32x4& x) {
-    const int r = idx / C4, c4 = idx % C4;
-    u32x2 h, m, l;
-    { unsigned a, b, c; split2(x[0], x[1], a, b, c); h[0] = a; m[0] = b; l[0] = c; }
-    { unsigned a, b, c; split2(x[2], x[3], a, b, c); h[1] = a; m[1] = b; l[1] = c; }
-    unsigned char* p = img + r * L::ROW3 + (((unsigned)c4 ^ (L::swz(r) << 1)) << 3);
-    *reinterpret_cast<u32x2*>(p) = h;
-    *reinterpret_cast<u32x2*>(p + L::ROWB) = m;
-    *reinterpret_cast<u32x2*>(p + 2 * L::ROWB) = l;
-  };
-#pragma unroll 1
-  for (int idx0 = tid; idx0 < total; idx0 += U * nthreads) {
-    f32x4 xa[U], xb[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int idx = idx0 + u * nthreads;
-      if (idx < total) {
-        const int r = idx / C4, c4 = idx % C4;
-        xa[u] = *reinterpret_cast<const f32x4*>(srcA + (long long)r * ldA + c4 * 4);
-        xb[u] = *reinterpret_cast<const f32x4*>(srcB + (long long)r * ldB + c4 * 4);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int idx = idx0 + u * nthreads;
-      if (idx < total) { put(imgA, idx, xa[u] * scaleA); put(imgB, idx, xb[u] * scaleB); }
-    }
-  }
-  for (int w = tid; w < L::ROW3 / 8; w += nthreads) {
-    *reinterpret_cast<u32x2*>(imgA + n * L::ROW3 + w * 8) = u32x2{0u, 0u};
-    *reinterpret_cast<u32x2*>(imgB + n * L::ROW3 + w * 8) = u32x2{0u, 0u};
-  }
-}
-
-// 8 fp32 values of one row for the reduction slots of lane group g: columns 32 s + 8 g + (0..7), times scale, as planes
-template <int HD>
-__device__ __forceinline__ void load_owner_planes(const float* __restrict__ row, int g, float scale, P3 (&out)[HD / 32]) {
-#pragma unroll
-  for (int s = 0; s < HD / 32; ++s) {
-    const f32x4 x0 = *reinterpret_cast<const f32x4*>(row + 32 * s + 8 * g), x1 = *reinterpret_cast<const f32x4*>(row + 32 * s + 8 * g + 4);
-    const float x[8] = {x0[0] * scale, x0[1] * scale, x0[2] * scale, x0[3] * scale, x1[0] * scale, x1[1] * scale, x1[2] * scale, x1[3] * scale};
-    out[s] = split8(x);
-  }
-}
-
-// acc[kb][r] = sum_c img[t0 + 16 kb + 4 g + r][c] * owner[lane & 15][c]  (kb = 0, 1; r = 0..3): the partner rows are the MFMA rows
-template <int HD>
-__device__ __forceinline__ void rows_times_owner(const unsigned char* img, int t0, int n, const P3 (&own)[HD / 32], int i, int g,
-                                                 f32x4 (&acc)[2]) {
-  using L = Lay<HD>;
-  f32x4 part[2][HD / 32];
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    const int r = min(t0 + 16 * kb + i, n);
-    const unsigned char* base = img + r * L::ROW3;
-    const unsigned x = L::swz(r);
-#pragma unroll
-    for (int s = 0; s < HD / 32; ++s) {
-      const unsigned char* p = base + ((((unsigned)(4 * s + g)) ^ x) << 4);
-      P3 A;
-      A.h = *reinterpret_cast<const bf16x8*>(p);
-      A.m = *reinterpret_cast<const bf16x8*>(p + L::ROWB);
-      A.l = *reinterpret_cast<const bf16x8*>(p + 2 * L::ROWB);
-      part[kb][s] = mfma6(A, own[s], f32x4{0.f, 0.f, 0.f, 0.f});
-    }
-  }
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    acc[kb] = part[kb][0];
-#pragma unroll
-    for (int s = 1; s < HD / 32; ++s) acc[kb] += part[kb][s];
-  }
-}
-
-__device__ __forceinline__ s16x4 tr_read(const unsigned char* p) {
-  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((RT_LDS s16x4*)(p));
-}
-
-// acc[cb][r] += sum over the 32 partner rows of img[row][16 cb + 4 g + r] * slots(row), where the lane's 8 slots are the rows
-// t0 + 16 kb + 4 g + e (slot 4 kb + e): the partner rows are the REDUCTION index (transpose read)
-template <int HD>
-__device__ __forceinline__ void cols_times_slots(const unsigned char* img, int t0, int n, const P3& slots, int i, int g,
-                                                 f32x4 (&acc)[HD / 16]) {
-  using L = Lay<HD>;
-  const int j = i >> 2, t = i & 3;
-  const unsigned char* rb[2]; unsigned xs[2];
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    const int k = min(t0 + 16 * kb + 4 * g + j, n);
-    rb[kb] = img + k * L::ROW3;
-    xs[kb] = L::swz(k) << 1;
-  }
-  P3 A[HD / 16];
-#pragma unroll
-  for (int cb = 0; cb < HD / 16; ++cb) {
-    const unsigned c = (unsigned)(4 * cb + t);
-    const unsigned char* p0 = rb[0] + ((c ^ xs[0]) << 3);
-    const unsigned char* p1 = rb[1] + ((c ^ xs[1]) << 3);
-    s16x8 vh, vm, vl;
-    { const s16x4 a = tr_read(p0), b = tr_read(p1); vh = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
-    { const s16x4 a = tr_read(p0 + L::ROWB), b = tr_read(p1 + L::ROWB); vm = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
-    { const s16x4 a = tr_read(p0 + 2 * L::ROWB), b = tr_read(p1 + 2 * L::ROWB); vl = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
-    A[cb].h = __builtin_bit_cast(bf16x8, vh); A[cb].m = __builtin_bit_cast(bf16x8, vm); A[cb].l = __builtin_bit_cast(bf16x8, vl);
-  }
-  // the HD / 16 accumulators take turns inside a term: no back-to-back dependent MFMAs
-#define RT_V2_TERM(PA, PB)                                                                                   \
-  _Pragma("unroll") for (int cb = 0; cb < HD / 16; ++cb)                                                     \
-      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[cb].PA, slots.PB, acc[cb], 0, 0, 0);
-  RT_V2_TERM(l, h) RT_V2_TERM(h, l) RT_V2_TERM(m, m) RT_V2_TERM(m, h) RT_V2_TERM(h, m) RT_V2_TERM(h, h)
-#undef RT_V2_TERM
-}
-
-__device__ __forceinline__ float quad_max(float v) {   // over the 4 lanes (lane & 15 equal) that share an owner row
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  return fmaxf(v, __shfl_xor(v, 32, 64));
-}
-__device__ __forceinline__ float quad_sum(float v) {
-  v += __shfl_xor(v, 16, 64);
-  return v + __shfl_xor(v, 32, 64);
-}
-
-// o-th heaviest owner tile -> wave, in a zigzag of period 2 NW: wave w takes o = w, 2 NW - 1 - w, 2 NW + w, ...
-// HEAVY_LAST: the tile with the largest index is the heaviest (query tiles: they see every earlier key); else tile 0 is (key tiles).
-template <int NW, bool HEAVY_LAST, typename F>
-__device__ __forceinline__ void for_my_tiles(int wave, int n_tiles, F&& body) {
-  for (int base = 0; base < n_tiles; base += 2 * NW) {
-    const int o1 = base + wave, o2 = base + 2 * NW - 1 - wave;
-    if (o1 < n_tiles) body(HEAVY_LAST ? n_tiles - 1 - o1 : o1);
-    if (o2 < n_tiles) body(HEAVY_LAST ? n_tiles - 1 - o2 : o2);
-  }
-}
+using namespace rt_planes;
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // forward: a lane owns a query (4 lanes per query hold different keys / different head-dim columns)
@@ -258,8 +43,10 @@ __global__ __launch_bounds__(NW * 64) void v2_fwd_kernel(VarlenArgs a) {
   if (n <= 0) return;
   unsigned char* Kimg = smem;
   unsigned char* Vimg = smem + (size_t)(n + 1) * L::ROW3;
-  stage_images2<HD>(a.k + row0 * a.ldk + h * HD, a.ldk, 1.f, Kimg, a.v + row0 * a.ldv + h * HD, a.ldv, 1.f, Vimg, n, tid, NW * 64);
+  if (!RT_ABL(a, 1))
+    stage_images2<HD>(a.k + row0 * a.ldk + h * HD, a.ldk, 1.f, Kimg, a.v + row0 * a.ldv + h * HD, a.ldv, 1.f, Vimg, n, tid, NW * 64);
   __syncthreads();
+  if (RT_ABL(a, 2)) return;
 
   const int n_pad = a.window > n ? a.window - n : 0;
   const bool pads = CAUSAL && a.bk != nullptr && a.bv != nullptr && n_pad > 0;
@@ -272,7 +59,7 @@ __global__ __launch_bounds__(NW * 64) void v2_fwd_kernel(VarlenArgs a) {
     const bool qok = qrow < n;
     const long long grow = row0 + (qok ? qrow : n - 1);
     P3 Qp[L::NS];
-    load_owner_planes<HD>(a.q + grow * a.ldq + h * HD, g, qscale, Qp);
+    if (!RT_ABL(a, 64)) load_owner_planes<HD>(a.q + grow * a.ldq + h * HD, g, qscale, Qp);
     float m = -INFINITY, lsum = 0.f;             // lsum: this lane's share of the row sum (its own keys), reduced at the end
     f32x4 oT[L::NCB];
 #pragma unroll
@@ -281,12 +68,13 @@ __global__ __launch_bounds__(NW * 64) void v2_fwd_kernel(VarlenArgs a) {
 
     for (int kt = 0; kt <= kt_last; ++kt) {
       f32x4 sT[2];
-      rows_times_owner<HD>(Kimg, kt * 32, n, Qp, i, g, sT);      // sT[kb][r]: key kt*32 + 16 kb + 4 g + r
+      rows_times_owner<HD>(Kimg, kt * 32, n, Qp, i, g, sT, RT_ABLV(a));      // sT[kb][r]: key kt*32 + 16 kb + 4 g + r
       float sc[8];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) sc[4 * kb + r] = sT[kb][r];
+      if (!RT_ABL(a, 4)) {
       if (kt == kt_last) {                                       // the causal edge (keys behind the session's end lie behind it too)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -313,8 +101,9 @@ __global__ __launch_bounds__(NW * 64) void v2_fwd_kernel(VarlenArgs a) {
       }
 #pragma unroll
       for (int cb = 0; cb < L::NCB; ++cb) oT[cb] *= alpha;
-      const P3 Pp = split8(sc);
-      cols_times_slots<HD>(Vimg, kt * 32, n, Pp, i, g, oT);      // oT[cb][r]: column 16 cb + 4 g + r of query `qrow`
+      }
+      const P3 Pp = RT_SPLIT8(a, sc);
+      cols_times_slots<HD>(Vimg, kt * 32, n, Pp, i, g, oT, RT_ABLV(a));      // oT[cb][r]: column 16 cb + 4 g + r of query `qrow`
     }
 
     if (pads) {   // the window's pad keys: one virtual key, logit q.b_k / sqrt(hd), value b_v, multiplicity n_pad
@@ -346,7 +135,7 @@ __global__ __launch_bounds__(NW * 64) void v2_fwd_kernel(VarlenArgs a) {
     }
 
     const float l = quad_sum(lsum);
-    if (qok) {
+    if (qok && !RT_ABL(a, 128)) {
       if (a.lse != nullptr && g == 0) a.lse[(row0 + qrow) * a.H + h] = (m + __builtin_amdgcn_logf(l)) * LN2;
       const float inv = l > 0.f ? 1.f / l : 0.f;
       float* op = a.o + (row0 + qrow) * a.ldo + h * HD;
@@ -378,8 +167,10 @@ __global__ __launch_bounds__(NW * 64) void v2_bwd_dq_kernel(VarlenArgs a) {
   }
   unsigned char* Kimg = smem;
   unsigned char* Vimg = smem + (size_t)(n + 1) * L::ROW3;
-  stage_images2<HD>(a.k + row0 * a.ldk + h * HD, a.ldk, 1.f, Kimg, a.v + row0 * a.ldv + h * HD, a.ldv, 1.f, Vimg, n, tid, NW * 64);
+  if (!RT_ABL(a, 1))
+    stage_images2<HD>(a.k + row0 * a.ldk + h * HD, a.ldk, 1.f, Kimg, a.v + row0 * a.ldv + h * HD, a.ldv, 1.f, Vimg, n, tid, NW * 64);
   __syncthreads();
+  if (RT_ABL(a, 2)) return;
 
   const int n_pad = a.window > n ? a.window - n : 0;
   const bool pads = CAUSAL && a.bk != nullptr && a.bv != nullptr && n_pad > 0;
@@ -398,16 +189,18 @@ __global__ __launch_bounds__(NW * 64) void v2_bwd_dq_kernel(VarlenArgs a) {
     const float* dop = a.dout + grow * a.lddo + h * HD;
     const float* op = a.o + grow * a.ldo + h * HD;
     P3 Qp[L::NS], Dp[L::NS];
+    float dl = 0.f, lse2 = 0.f;             // delta = rowsum(dO * O): 16 of the HD columns per lane
+    if (!RT_ABL(a, 64)) {
     load_owner_planes<HD>(qp, g, qscale, Qp);
     load_owner_planes<HD>(dop, g, qok ? 1.f : 0.f, Dp);
-    float dl = 0.f;                         // delta = rowsum(dO * O): 16 of the HD columns per lane
 #pragma unroll
     for (int s = 0; s < L::NS; ++s)
 #pragma unroll
       for (int e = 0; e < 8; ++e) dl += dop[32 * s + 8 * g + e] * op[32 * s + 8 * g + e];
     dl = qok ? quad_sum(dl) : 0.f;
-    const float lse2 = a.lse[grow * a.H + h] * LOG2E;
+    lse2 = a.lse[grow * a.H + h] * LOG2E;
     if (qok && g == 0) a.delta[grow * a.H + h] = dl;
+    }
     f32x4 dqT[L::NCB];
 #pragma unroll
     for (int cb = 0; cb < L::NCB; ++cb) dqT[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -415,9 +208,13 @@ __global__ __launch_bounds__(NW * 64) void v2_bwd_dq_kernel(VarlenArgs a) {
 
     for (int kt = 0; kt <= kt_last; ++kt) {
       f32x4 sT[2], dpT[2];
-      rows_times_owner<HD>(Kimg, kt * 32, n, Qp, i, g, sT);
-      rows_times_owner<HD>(Vimg, kt * 32, n, Dp, i, g, dpT);
+      rows_times_owner<HD>(Kimg, kt * 32, n, Qp, i, g, sT, RT_ABLV(a));
+      rows_times_owner<HD>(Vimg, kt * 32, n, Dp, i, g, dpT, RT_ABLV(a));
       float ds[8];
+      if (RT_ABL(a, 4)) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ds[e] = sT[e >> 2][e & 3] + dpT[e >> 2][e & 3];
+      } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int key = kt * 32 + 16 * (e >> 2) + 4 * g + (e & 3);
@@ -436,8 +233,9 @@ __global__ __launch_bounds__(NW * 64) void v2_bwd_dq_kernel(VarlenArgs a) {
         ds[e] *= d0 - dl;                   // dS^T
         ds[e + 1] *= d1 - dl;
       }
-      const P3 Sp = split8(ds);
-      cols_times_slots<HD>(Kimg, kt * 32, n, Sp, i, g, dqT);   // dQ^T[c][q] += sum_j K[j][c] dS^T[j][q]  (scale at the store)
+      }
+      const P3 Sp = RT_SPLIT8(a, ds);
+      cols_times_slots<HD>(Kimg, kt * 32, n, Sp, i, g, dqT, RT_ABLV(a));   // dQ^T[c][q] += sum_j K[j][c] dS^T[j][q]  (scale at the store)
     }
 
     if (pads) {   // the virtual pad key: dS_p = P_p (drop * dO.b_v - delta), dq += dS_p b_k, d_b_v += drop * P_p * dO
@@ -471,7 +269,7 @@ __global__ __launch_bounds__(NW * 64) void v2_bwd_dq_kernel(VarlenArgs a) {
       }
     }
 
-    if (qok) {
+    if (qok && !RT_ABL(a, 128)) {
       float* dqp = a.dq + grow * a.lddq + h * HD;
 #pragma unroll
       for (int cb = 0; cb < L::NCB; ++cb) *reinterpret_cast<f32x4*>(dqp + 16 * cb + 4 * g) = dqT[cb] * a.scale;
@@ -524,12 +322,15 @@ __global__ __launch_bounds__(NW * 64) void v2_bwd_dkv_kernel(VarlenArgs a) {
   float* Ls = reinterpret_cast<float*>(smem + 2 * (size_t)(n + 1) * L::ROW3);   // [n32] lse * log2(e)   (16-byte aligned: ROW3 % 16 == 0)
   float* Dl = Ls + n32;                                                         // [n32] delta
   const float qscale = a.scale * LOG2E;
+  if (!RT_ABL(a, 1)) {
   stage_images2<HD>(a.q + row0 * a.ldq + h * HD, a.ldq, qscale, Qimg, a.dout + row0 * a.lddo + h * HD, a.lddo, 1.f, Dimg, n, tid, NW * 64);
   for (int r = tid; r < n32; r += NW * 64) {
     Ls[r] = r < n ? a.lse[(row0 + r) * a.H + h] * LOG2E : 0.f;
     Dl[r] = r < n ? a.delta[(row0 + r) * a.H + h] : 0.f;
   }
+  }
   __syncthreads();
+  if (RT_ABL(a, 2)) return;
 
   const unsigned thr16 = drop_thr16(a.p_drop);
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
@@ -540,8 +341,10 @@ __global__ __launch_bounds__(NW * 64) void v2_bwd_dkv_kernel(VarlenArgs a) {
     const bool kok = krow < n;
     const long long grow = row0 + (kok ? krow : n - 1);
     P3 Kp[L::NS], Vp[L::NS];
+    if (!RT_ABL(a, 64)) {
     load_owner_planes<HD>(a.k + grow * a.ldk + h * HD, g, 1.f, Kp);
     load_owner_planes<HD>(a.v + grow * a.ldv + h * HD, g, 1.f, Vp);
+    }
     f32x4 dkT[L::NCB], dvT[L::NCB];
 #pragma unroll
     for (int cb = 0; cb < L::NCB; ++cb) { dkT[cb] = f32x4{0.f, 0.f, 0.f, 0.f}; dvT[cb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -549,10 +352,14 @@ __global__ __launch_bounds__(NW * 64) void v2_bwd_dkv_kernel(VarlenArgs a) {
 
     for (int qt = qt_first; qt <= qt_last; ++qt) {     // causal: query tiles at or behind the key tile
       f32x4 sm[2], dpm[2];                             // S[q][key], dP[q][key]: register (qb, r) = query qt*32 + 16 qb + 4 g + r
-      rows_times_owner<HD>(Qimg, qt * 32, n, Kp, i, g, sm);
-      rows_times_owner<HD>(Dimg, qt * 32, n, Vp, i, g, dpm);
+      rows_times_owner<HD>(Qimg, qt * 32, n, Kp, i, g, sm, RT_ABLV(a));
+      rows_times_owner<HD>(Dimg, qt * 32, n, Vp, i, g, dpm, RT_ABLV(a));
       const bool edge = qt == qt_first || qt == qt_last;
       float pd[8], ds[8];
+      if (RT_ABL(a, 4)) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { pd[e] = sm[e >> 2][e & 3]; ds[e] = dpm[e >> 2][e & 3]; }
+      } else
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
         const f32x4 ls4 = *reinterpret_cast<const f32x4*>(Ls + qt * 32 + 16 * qb + 4 * g);
@@ -569,13 +376,13 @@ __global__ __launch_bounds__(NW * 64) void v2_bwd_dkv_kernel(VarlenArgs a) {
           ds[4 * qb + r] = pr * (dpm[qb][r] * keepf - dl4[r]);       // dS
         }
       }
-      const P3 Pp = split8(pd);
-      cols_times_slots<HD>(Dimg, qt * 32, n, Pp, i, g, dvT);    // dV^T[c][key] += sum_q dO[q][c] P~[q][key]
-      const P3 Sp = split8(ds);
-      cols_times_slots<HD>(Qimg, qt * 32, n, Sp, i, g, dkT);    // dK^T[c][key] += sum_q Q'[q][c] dS[q][key]
+      const P3 Pp = RT_SPLIT8(a, pd);
+      cols_times_slots<HD>(Dimg, qt * 32, n, Pp, i, g, dvT, RT_ABLV(a));    // dV^T[c][key] += sum_q dO[q][c] P~[q][key]
+      const P3 Sp = RT_SPLIT8(a, ds);
+      cols_times_slots<HD>(Qimg, qt * 32, n, Sp, i, g, dkT, RT_ABLV(a));    // dK^T[c][key] += sum_q Q'[q][c] dS[q][key]
     }
 
-    if (kok) {
+    if (kok && !RT_ABL(a, 128)) {
       float* dkp = a.dk + grow * a.lddk + h * HD;
       float* dvp = a.dv + grow * a.lddv + h * HD;
 #pragma unroll
@@ -587,6 +394,10 @@ __global__ __launch_bounds__(NW * 64) void v2_bwd_dkv_kernel(VarlenArgs a) {
   });
 }
 
+#ifdef RT_ABLATION_BUILD
+inline int v2_ablate_env() { const char* e = getenv("RT_V2_ABLATE"); return e != nullptr ? atoi(e) : 0; }
+#endif
+
 template <int HD, int NW, bool CAUSAL = true>
 int launch_bwd(const VarlenArgs& a, int max_len, hipStream_t stream) {
   const size_t img = 2 * Lay<HD>::image_bytes(max_len);
@@ -597,6 +408,14 @@ int launch_bwd(const VarlenArgs& a, int max_len, hipStream_t stream) {
   auto kkv = &v2_bwd_dkv_kernel<HD, NW, CAUSAL>;
   RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kq), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq));
   RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kkv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv));
+#ifdef RT_ABLATION_BUILD
+  VarlenArgs b = a;
+  b.ablate = v2_ablate_env();
+  if (!(b.ablate & 256)) kq<<<a.B * a.H, NW * 64, lds_dq, stream>>>(b);
+  if (!(b.ablate & 512)) kkv<<<a.B * a.H, NW * 64, lds_kv, stream>>>(b);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+#endif
   kq<<<a.B * a.H, NW * 64, lds_dq, stream>>>(a);
   RT_CHECK_LAUNCH();
   kkv<<<a.B * a.H, NW * 64, lds_kv, stream>>>(a);
@@ -610,6 +429,13 @@ int launch_fwd(const VarlenArgs& a, int max_len, hipStream_t stream) {
   if (lds > 160 * 1024) return RT_ERR_UNSUPPORTED;
   auto kern = &v2_fwd_kernel<HD, NW, TRAIN, CAUSAL>;
   RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#ifdef RT_ABLATION_BUILD
+  VarlenArgs b = a;
+  b.ablate = v2_ablate_env();
+  kern<<<a.B * a.H, NW * 64, lds, stream>>>(b);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+#endif
   kern<<<a.B * a.H, NW * 64, lds, stream>>>(a);
   RT_CHECK_LAUNCH();
   return RT_OK;
@@ -649,14 +475,18 @@ __device__ __forceinline__ int hstu_bucket(const long long* thr, long long dt) {
 // other side of the diagonal has the opposite sign, and |dt| is not monotone across it): otherwise every element is searched.
 __device__ __forceinline__ void hstu_buckets8(const long long* thr, const long long* ts_p, long long t_owner, bool owner_is_query, int t0, int g,
                                               int len, bool span_valid, int (&bk)[8]) {
-  auto one = [&](int e) {
+  auto dt_of = [&](int e) {
     const int kl = min(t0 + 16 * (e >> 2) + 4 * g + (e & 3), len - 1);
-    const long long dt = owner_is_query ? t_owner - ts_p[kl] : ts_p[kl] - t_owner;
-    return hstu_bucket(thr, dt);
+    return owner_is_query ? t_owner - ts_p[kl] : ts_p[kl] - t_owner;
   };
-  const int b0 = one(0), b7 = one(7);
+  auto one = [&](int e) { return hstu_bucket(thr, dt_of(e)); };
+  const long long dt0 = dt_of(0), dt7 = dt_of(7);
+  const int b0 = hstu_bucket(thr, dt0), b7 = hstu_bucket(thr, dt7);
   bk[0] = b0; bk[7] = b7;
-  if (span_valid && b0 == b7) {
+  // the shortcut needs |dt| monotone over the span: both ends on the expected side of zero (a context time BEFORE the last history
+  // stamp, or a preparator that does not sort by time, gives a V-shaped |dt| — then every element is searched, as the reference's
+  // per-element bucketize does: hstu.py:99-113)
+  if (span_valid && b0 == b7 && dt0 >= 0 && dt7 >= 0) {
 #pragma unroll
     for (int e = 1; e < 7; ++e) bk[e] = b0;
   } else {

@@ -1,0 +1,555 @@
+// K4v3 — the packed softmax attention as STREAMED chunks.  Same contract, arithmetic and register geometry as K4v2
+// (rt_attention_v2.hip: causal attention inside every session of a packed batch, the reference's left-pad keys as ONE virtual key per
+// query — sasrec.py:186-231, torch_backbone.py:245-260; six bf16 MFMAs of an exact three-way split per fp32 product; a lane owns a
+// query — in the dK/dV pass a key —, probabilities / dS feed the next product from registers), another decomposition of the work:
+//
+//  * K4v2 gave a (session, head) to ONE workgroup that held the whole session's K and V as LDS images (154 KB at 200 rows: one
+//    workgroup per CU).  The ablation of round 6 (profiles/r6_attn_ablation.md) showed what that costs: with the products, the softmax
+//    arithmetic or the memory traffic switched off the kernels kept 60–70 % of their time — the critical path is ONE long session on
+//    the four SIMDs of one CU (49 tile steps of a 200-row session against 11 per SIMD on average), twice per launch (512 workgroups on
+//    256 CUs), each behind its own staging prologue.
+//  * Here a workgroup is 4 waves = 64 OWNER rows of a (session, head) — one 16-row tile per wave, so the waves of a workgroup differ by
+//    at most one step — and the PARTNER rows stream through one 64-row chunk pair (two images, 48 KB at hd 64) that all four waves
+//    read: a 200-row session is 4 workgroups (10 chunk stagings instead of one 200-row one: the price), three workgroups share a CU,
+//    so one workgroup's staging runs under the others' products, and the launch has ~1,000 workgroups of at most 8 steps to balance
+//    over 256 CUs instead of 512 of up to 49.  The online softmax carries (m, l, O) in registers across chunks, as it did across tiles.
+//  * No LDS limit on the session length any more: any window runs (the whole-image kernels stopped at 207 rows of hd 64).
+//  * Heavy workgroups first: the causal forward / dQ pass launches the LAST owner block of every session first (it sees every chunk),
+//    the dK/dV pass the first key block.  Workgroups of one (session, head) are a multiple of 8 apart: same XCD, the chunks they share
+//    come out of one L2.
+//  * The pad keys' value-bias gradient (one row per session and head) is summed by extra workgroups of the dK/dV launch, one per
+//    (session, head), in a fixed order: no atomics, bit-reproducible like everything else in the step.
+#include "rt_attn_planes.h"
+
+namespace {
+using namespace rt_varlen;
+using namespace rt_planes;
+
+constexpr int CH = 64;     // partner rows per chunk (two 32-row steps) = owner rows per workgroup (4 waves x 16)
+constexpr int NT = 256;    // threads per workgroup
+
+// Rows [0, rows) of two [*, ld] fp32 matrices (columns [0, HD) of this head) -> two 64-row LDS images (value * scale, three bf16 planes,
+// K4v2's row layout and swizzle on the LOCAL row index); rows [rows, 64) are zero-filled.  Every load is issued before any split.
+template <int HD>
+__device__ __forceinline__ void stage_chunk2(const float* __restrict__ srcA, long long ldA, float scaleA, unsigned char* imgA,
+                                             const float* __restrict__ srcB, long long ldB, float scaleB, unsigned char* imgB, int rows, int tid) {
+  using L = Lay<HD>;
+  constexpr int C4 = HD / 4, U = CH * C4 / NT;      // float4 per thread and image: 4 (hd 64), 2 (hd 32)
+  f32x4 xa[U], xb[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int idx = tid + u * NT, r = idx / C4, c4 = idx % C4;
+    if (r < rows) {
+      xa[u] = *reinterpret_cast<const f32x4*>(srcA + (long long)r * ldA + c4 * 4);
+      xb[u] = *reinterpret_cast<const f32x4*>(srcB + (long long)r * ldB + c4 * 4);
+    } else {
+      xa[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      xb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  auto put = [&](unsigned char* img, int idx, const f32x4& x) {
+    const int r = idx / C4, c4 = idx % C4;
+    u32x2 h, m, l;
+    { unsigned a, b, c; split2(x[0], x[1], a, b, c); h[0] = a; m[0] = b; l[0] = c; }
+    { unsigned a, b, c; split2(x[2], x[3], a, b, c); h[1] = a; m[1] = b; l[1] = c; }
+    unsigned char* p = img + r * L::ROW3 + (((unsigned)c4 ^ (L::swz(r) << 1)) << 3);
+    *reinterpret_cast<u32x2*>(p) = h;
+    *reinterpret_cast<u32x2*>(p + L::ROWB) = m;
+    *reinterpret_cast<u32x2*>(p + 2 * L::ROWB) = l;
+  };
+#pragma unroll
+  for (int u = 0; u < U; ++u) { put(imgA, tid + u * NT, xa[u] * scaleA); put(imgB, tid + u * NT, xb[u] * scaleB); }
+}
+
+// blockIdx -> (owner block, session, head).  heavy_last: the LAST owner block of a session is the heaviest (causal queries) and is
+// launched first; else block 0 is (causal keys) / all weigh the same (bidirectional).
+struct Work { int ob, b, h, bh; };
+__device__ __forceinline__ Work work_of(const VarlenArgs& a, int n_ob, bool heavy_last) {
+  const int per = a.B * a.H, o = (int)blockIdx.x / per;
+  Work w;
+  w.ob = heavy_last ? n_ob - 1 - o : o;
+  w.bh = (int)blockIdx.x % per;
+  w.b = w.bh / a.H;
+  w.h = w.bh % a.H;
+  return w;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// forward: a lane owns a query; the session's keys / values stream through the chunk images
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int HD, bool TRAIN, bool CAUSAL>
+__global__ __launch_bounds__(NT, 3) void v3_fwd_kernel(VarlenArgs a, int n_ob) {
+  using L = Lay<HD>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const Work wk = work_of(a, n_ob, CAUSAL);
+  const int h = wk.h;
+  const long long row0 = a.cu[wk.b];
+  const int n = (int)(a.cu[wk.b + 1] - row0);
+  if (wk.ob * CH >= n) return;
+  unsigned char* Kimg = smem;
+  unsigned char* Vimg = smem + (size_t)CH * L::ROW3;
+
+  const int q0 = wk.ob * CH + 16 * wave;          // this wave's owner tile
+  const bool active = q0 < n;
+  const int qrow = q0 + i;
+  const bool qok = qrow < n;
+  const long long grow = row0 + (qok ? qrow : n - 1);
+  const int n_pad = a.window > n ? a.window - n : 0;
+  const bool pads = CAUSAL && a.bk != nullptr && a.bv != nullptr && n_pad > 0;
+  const unsigned thr16 = TRAIN ? drop_thr16(a.p_drop) : 0u;
+  const float inv_keep = (TRAIN && a.p_drop > 0.f) ? 1.f / (1.f - a.p_drop) : 1.f;
+  const float qscale = a.scale * LOG2E;          // scores live in the base-2 domain: p = exp2(s' - m')
+
+  // the owner rows' loads are issued here and split after the first chunk's barrier: they fly under the chunk's staging
+  f32x4 Qraw[L::NCB];
+  if (active && !RT_ABL(a, 64)) load_owner_raw<HD>(a.q + grow * a.ldq + h * HD, g, Qraw);
+  P3 Qp[L::NS];
+  float m = -INFINITY, lsum = 0.f;               // lsum: this lane's share of the row sum (its own keys), reduced at the end
+  f32x4 oT[L::NCB];
+#pragma unroll
+  for (int cb = 0; cb < L::NCB; ++cb) oT[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int n_chunks = CAUSAL ? wk.ob + 1 : (n + CH - 1) / CH;
+  for (int c = 0; c < n_chunks; ++c) {
+    if (c > 0 && !RT_ABL(a, 32)) __syncthreads();                  // the previous chunk's readers are done
+    if (!RT_ABL(a, 1))
+      stage_chunk2<HD>(a.k + (row0 + c * CH) * a.ldk + h * HD, a.ldk, 1.f, Kimg, a.v + (row0 + c * CH) * a.ldv + h * HD, a.ldv, 1.f, Vimg,
+                       min(CH, n - c * CH), tid);
+    if (!RT_ABL(a, 32)) __syncthreads();
+    if (!active || RT_ABL(a, 2)) continue;
+    if (c == 0 && !RT_ABL(a, 64)) split_owner_raw<HD>(Qraw, qscale, Qp);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int t0 = c * CH + 32 * s;            // first key of the step
+      if (CAUSAL ? t0 > q0 + 15 : t0 >= n) break;                 // (wave-uniform) nothing of the step is visible to the tile
+      f32x4 sT[2];
+      rows_times_owner<HD>(Kimg, 32 * s, CH, Qp, i, g, sT, RT_ABLV(a));      // sT[kb][r]: key t0 + 16 kb + 4 g + r
+      float sc[8];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sc[4 * kb + r] = sT[kb][r];
+      if (!RT_ABL(a, 4)) {
+        if (CAUSAL ? t0 + 31 > q0 : t0 + 31 >= n) {                // the causal edge (keys behind the session's end lie behind it too)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int key = t0 + 16 * (e >> 2) + 4 * g + (e & 3);
+            sc[e] = (CAUSAL ? key <= qrow : key < n) ? sc[e] : -INFINITY;
+          }
+        }
+        float mx = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7])));
+        mx = fmaxf(m, quad_max(mx));                               // finite: every query sees key t0 of every step it visits
+        const float alpha = __builtin_amdgcn_exp2f(m - mx);
+        float ps = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc[e] = __builtin_amdgcn_exp2f(sc[e] - mx); ps += sc[e]; }
+        lsum = lsum * alpha + ps;
+        m = mx;
+        if (TRAIN && thr16 != 0u) {      // dropout acts on the normalised probabilities: the row sum above stays undropped
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) {
+            const unsigned key = (unsigned)(t0 + 16 * (e >> 2) + 4 * g + (e & 3));
+            const unsigned hsh = drop_hash(a.seed, (unsigned)wk.bh, (unsigned)qrow, key >> 1);
+            sc[e] = (hsh & 0xFFFFu) >= thr16 ? sc[e] * inv_keep : 0.f;
+            sc[e + 1] = (hsh >> 16) >= thr16 ? sc[e + 1] * inv_keep : 0.f;
+          }
+        }
+#pragma unroll
+        for (int cb = 0; cb < L::NCB; ++cb) oT[cb] *= alpha;
+      }
+      const P3 Pp = RT_SPLIT8(a, sc);
+      cols_times_slots<HD>(Vimg, 32 * s, CH, Pp, i, g, oT, RT_ABLV(a));      // oT[cb][r]: column 16 cb + 4 g + r of query `qrow`
+    }
+  }
+  if (!active || RT_ABL(a, 2)) return;
+
+  if (pads) {   // the window's pad keys: one virtual key, logit q.b_k / sqrt(hd), value b_v, multiplicity n_pad
+    float dp = 0.f;
+    const float* qp = a.q + grow * a.ldq + h * HD;
+#pragma unroll
+    for (int s = 0; s < L::NS; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dp += qp[32 * s + 8 * g + e] * a.bk[h * HD + 32 * s + 8 * g + e];
+    dp = quad_sum(dp) * qscale;
+    const float mx = fmaxf(m, dp);
+    const float alpha = __builtin_amdgcn_exp2f(m - mx);
+    const float e1 = __builtin_amdgcn_exp2f(dp - mx);
+    lsum = lsum * alpha + (g == 0 ? (float)n_pad * e1 : 0.f);
+    m = mx;
+    float wv = (float)n_pad * e1;
+    if (TRAIN && thr16 != 0u) {   // value side: the pads that survive the dropout, counted by the four lanes of the query
+      const int kept = pads_kept_quad(a.seed, (unsigned)wk.bh, (unsigned)qrow, n, n_pad, thr16, g);
+      wv = (float)kept * inv_keep * e1;
+    }
+#pragma unroll
+    for (int cb = 0; cb < L::NCB; ++cb) {
+      const f32x4 bv4 = *reinterpret_cast<const f32x4*>(a.bv + h * HD + 16 * cb + 4 * g);
+      oT[cb] = oT[cb] * alpha + bv4 * wv;
+    }
+  }
+
+  const float l = quad_sum(lsum);
+  if (qok && !RT_ABL(a, 128)) {
+    if (a.lse != nullptr && g == 0) a.lse[(row0 + qrow) * a.H + h] = (m + __builtin_amdgcn_logf(l)) * LN2;
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    float* op = a.o + (row0 + qrow) * a.ldo + h * HD;
+#pragma unroll
+    for (int cb = 0; cb < L::NCB; ++cb) *reinterpret_cast<f32x4*>(op + 16 * cb + 4 * g) = oT[cb] * inv;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// backward, pass 1: dQ and delta = rowsum(dO * O).  A lane owns a query; S^T and dP^T = V dO^T are recomputed per step, dS^T = P (drop *
+// dP - delta) stays in registers and feeds dQ^T = K^T dS^T (transpose reads of the K image).
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(NT, 3) void v3_bwd_dq_kernel(VarlenArgs a, int n_ob) {
+  using L = Lay<HD>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const Work wk = work_of(a, n_ob, CAUSAL);
+  const int h = wk.h;
+  const long long row0 = a.cu[wk.b];
+  const int n = (int)(a.cu[wk.b + 1] - row0);
+  if (wk.ob * CH >= n) return;
+  unsigned char* Kimg = smem;
+  unsigned char* Vimg = smem + (size_t)CH * L::ROW3;
+
+  const int q0 = wk.ob * CH + 16 * wave;
+  const bool active = q0 < n;
+  const int qrow = q0 + i;
+  const bool qok = qrow < n;
+  const long long grow = row0 + (qok ? qrow : n - 1);
+  const int n_pad = a.window > n ? a.window - n : 0;
+  const bool pads = CAUSAL && a.bk != nullptr && a.bv != nullptr && n_pad > 0;
+  const unsigned thr16 = drop_thr16(a.p_drop);
+  const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+  const float qscale = a.scale * LOG2E;
+  const float* qp = a.q + grow * a.ldq + h * HD;
+  const float* dop = a.dout + grow * a.lddo + h * HD;
+  const float* op = a.o + grow * a.ldo + h * HD;
+
+  P3 Qp[L::NS], Dp[L::NS];
+  float dl = 0.f, lse2 = 0.f;                     // delta = rowsum(dO * O): 16 of the HD columns per lane
+  if (active && !RT_ABL(a, 64)) {
+    load_owner_planes<HD>(qp, g, qscale, Qp);
+    load_owner_planes<HD>(dop, g, qok ? 1.f : 0.f, Dp);
+#pragma unroll
+    for (int s = 0; s < L::NS; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dl += dop[32 * s + 8 * g + e] * op[32 * s + 8 * g + e];
+    dl = qok ? quad_sum(dl) : 0.f;
+    lse2 = a.lse[grow * a.H + h] * LOG2E;
+    if (qok && g == 0) a.delta[grow * a.H + h] = dl;
+  }
+  f32x4 dqT[L::NCB];
+#pragma unroll
+  for (int cb = 0; cb < L::NCB; ++cb) dqT[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int n_chunks = CAUSAL ? wk.ob + 1 : (n + CH - 1) / CH;
+  for (int c = 0; c < n_chunks; ++c) {
+    if (c > 0 && !RT_ABL(a, 32)) __syncthreads();
+    if (!RT_ABL(a, 1))
+      stage_chunk2<HD>(a.k + (row0 + c * CH) * a.ldk + h * HD, a.ldk, 1.f, Kimg, a.v + (row0 + c * CH) * a.ldv + h * HD, a.ldv, 1.f, Vimg,
+                       min(CH, n - c * CH), tid);
+    if (!RT_ABL(a, 32)) __syncthreads();
+    if (!active || RT_ABL(a, 2)) continue;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int t0 = c * CH + 32 * s;
+      if (CAUSAL ? t0 > q0 + 15 : t0 >= n) break;
+      f32x4 sT[2], dpT[2];
+      rows_times_owner<HD>(Kimg, 32 * s, CH, Qp, i, g, sT, RT_ABLV(a));
+      rows_times_owner<HD>(Vimg, 32 * s, CH, Dp, i, g, dpT, RT_ABLV(a));
+      float ds[8];
+      if (RT_ABL(a, 4)) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ds[e] = sT[e >> 2][e & 3] + dpT[e >> 2][e & 3];
+      } else {
+        const bool edge = CAUSAL ? t0 + 31 > q0 : t0 + 31 >= n;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int key = t0 + 16 * (e >> 2) + 4 * g + (e & 3);
+          ds[e] = (!edge || (CAUSAL ? key <= qrow : key < n)) ? __builtin_amdgcn_exp2f(sT[e >> 2][e & 3] - lse2) : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          float d0 = dpT[e >> 2][e & 3], d1 = dpT[e >> 2][(e & 3) + 1];
+          if (thr16 != 0u) {
+            const unsigned key = (unsigned)(t0 + 16 * (e >> 2) + 4 * g + (e & 3));
+            const unsigned hsh = drop_hash(a.seed, (unsigned)wk.bh, (unsigned)qrow, key >> 1);
+            d0 = (hsh & 0xFFFFu) >= thr16 ? d0 * inv_keep : 0.f;
+            d1 = (hsh >> 16) >= thr16 ? d1 * inv_keep : 0.f;
+          }
+          ds[e] *= d0 - dl;                   // dS^T
+          ds[e + 1] *= d1 - dl;
+        }
+      }
+      const P3 Sp = RT_SPLIT8(a, ds);
+      cols_times_slots<HD>(Kimg, 32 * s, CH, Sp, i, g, dqT, RT_ABLV(a));   // dQ^T[c][q] += sum_j K[j][c] dS^T[j][q]  (scale at the store)
+    }
+  }
+  if (!active || RT_ABL(a, 2)) return;
+
+  if (pads) {   // the virtual pad key: dS_p = P_p (drop * dO.b_v - delta), dq += dS_p b_k   (d_b_v: v3_pad_dbv, the dK/dV launch)
+    float sp = 0.f, dpp = 0.f;
+#pragma unroll
+    for (int s = 0; s < L::NS; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = 32 * s + 8 * g + e;
+        sp += qp[c] * a.bk[h * HD + c];
+        dpp += dop[c] * a.bv[h * HD + c];
+      }
+    sp = quad_sum(sp) * qscale;
+    dpp = qok ? quad_sum(dpp) : 0.f;
+    const float e1 = __builtin_amdgcn_exp2f(sp - lse2);                        // one pad key's probability
+    float kept = (float)n_pad;
+    if (thr16 != 0u) {
+      kept = (float)pads_kept_quad(a.seed, (unsigned)wk.bh, (unsigned)qrow, n, n_pad, thr16, g) * inv_keep;
+    }
+    const float dsp = e1 * (kept * dpp - (float)n_pad * dl);
+#pragma unroll
+    for (int cb = 0; cb < L::NCB; ++cb) {
+      const f32x4 bk4 = *reinterpret_cast<const f32x4*>(a.bk + h * HD + 16 * cb + 4 * g);
+      dqT[cb] += bk4 * dsp;
+    }
+  }
+  if (qok && !RT_ABL(a, 128)) {
+    float* dqp = a.dq + grow * a.lddq + h * HD;
+#pragma unroll
+    for (int cb = 0; cb < L::NCB; ++cb) *reinterpret_cast<f32x4*>(dqp + 16 * cb + 4 * g) = dqT[cb] * a.scale;
+  }
+}
+
+// The pad keys' share of the value-bias gradient of ONE (session, head): d_bv[c] = sum over the session's queries of (the pad keys'
+// dropped probability mass of the query) * dO[query][c] — what K4v2's dQ kernel summed over the queries it owned.  Needs lse only
+// (written by the forward): independent of the dQ pass.  One workgroup, fixed order.
+template <int HD>
+__device__ __forceinline__ void v3_pad_dbv(const VarlenArgs& a, int b, int h, float* red) {
+  using L = Lay<HD>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int bh = b * a.H + h;
+  const long long row0 = a.cu[b];
+  const int n = (int)(a.cu[b + 1] - row0);
+  float* dbv = a.dbv_part + (long long)b * a.H * HD + h * HD;
+  const int n_pad = a.window > n ? a.window - n : 0;
+  if (n <= 0 || n_pad <= 0) {
+    if (tid < HD) dbv[tid] = 0.f;
+    return;
+  }
+  const unsigned thr16 = drop_thr16(a.p_drop);
+  const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+  const float qscale = a.scale * LOG2E;
+  f32x4 acc[L::NCB];
+#pragma unroll
+  for (int cb = 0; cb < L::NCB; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int qt = wave; qt * 16 < n; qt += NT / 64) {
+    const int qrow = qt * 16 + i;
+    const bool qok = qrow < n;
+    const long long grow = row0 + (qok ? qrow : n - 1);
+    const float* qp = a.q + grow * a.ldq + h * HD;
+    const float* dop = a.dout + grow * a.lddo + h * HD;
+    float sp = 0.f;
+#pragma unroll
+    for (int s = 0; s < L::NS; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sp += qp[32 * s + 8 * g + e] * a.bk[h * HD + 32 * s + 8 * g + e];
+    sp = quad_sum(sp) * qscale;
+    const float e1 = __builtin_amdgcn_exp2f(sp - a.lse[grow * a.H + h] * LOG2E);
+    float kept = (float)n_pad;
+    if (thr16 != 0u) {
+      kept = (float)pads_kept_quad(a.seed, (unsigned)bh, (unsigned)qrow, n, n_pad, thr16, g) * inv_keep;
+    }
+    const float wv = qok ? e1 * kept : 0.f;                                    // dropped pad mass that multiplied b_v
+#pragma unroll
+    for (int cb = 0; cb < L::NCB; ++cb) acc[cb] += *reinterpret_cast<const f32x4*>(dop + 16 * cb + 4 * g) * wv;
+  }
+  // over the queries: the 16 lanes of a group, then the waves through LDS
+#pragma unroll
+  for (int cb = 0; cb < L::NCB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = acc[cb][r];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      acc[cb][r] = v;
+    }
+  if (i == 0)
+#pragma unroll
+    for (int cb = 0; cb < L::NCB; ++cb) *reinterpret_cast<f32x4*>(red + wave * HD + 16 * cb + 4 * g) = acc[cb];
+  __syncthreads();
+  if (tid < HD) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) v += red[w * HD + tid];
+    dbv[tid] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// backward, pass 2: dK, dV.  A lane owns a KEY; the session's queries stream through the chunk images (Q pre-scaled by log2(e) / sqrt(hd),
+// dO) with their lse / delta beside them.  Workgroups behind the key blocks sum the pad keys' value-bias gradient (v3_pad_dbv).
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(NT, 2) void v3_bwd_dkv_kernel(VarlenArgs a, int n_ob) {
+  using L = Lay<HD>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int per = a.B * a.H;
+  if ((int)blockIdx.x >= per * n_ob) {                    // (only launched when the batch has pad keys)
+    const int bh = (int)blockIdx.x - per * n_ob;
+    v3_pad_dbv<HD>(a, bh / a.H, bh % a.H, reinterpret_cast<float*>(smem));
+    return;
+  }
+  const Work wk = work_of(a, n_ob, false);                // key block 0 sees every query chunk: heaviest first as it is
+  const int h = wk.h;
+  const long long row0 = a.cu[wk.b];
+  const int n = (int)(a.cu[wk.b + 1] - row0);
+  if (wk.ob * CH >= n) return;
+  unsigned char* Qimg = smem;
+  unsigned char* Dimg = smem + (size_t)CH * L::ROW3;
+  float* Ls = reinterpret_cast<float*>(smem + 2 * (size_t)CH * L::ROW3);   // [64] lse * log2(e) of the chunk's queries
+  float* Dl = Ls + CH;                                                      // [64] delta
+  const float qscale = a.scale * LOG2E;
+
+  const int k0 = wk.ob * CH + 16 * wave;           // this wave's key tile
+  const bool active = k0 < n;
+  const int krow = k0 + i;
+  const bool kok = krow < n;
+  const long long grow = row0 + (kok ? krow : n - 1);
+  const unsigned thr16 = drop_thr16(a.p_drop);
+  const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+  P3 Kp[L::NS], Vp[L::NS];
+  if (active && !RT_ABL(a, 64)) {
+    load_owner_planes<HD>(a.k + grow * a.ldk + h * HD, g, 1.f, Kp);
+    load_owner_planes<HD>(a.v + grow * a.ldv + h * HD, g, 1.f, Vp);
+  }
+  f32x4 dkT[L::NCB], dvT[L::NCB];
+#pragma unroll
+  for (int cb = 0; cb < L::NCB; ++cb) { dkT[cb] = f32x4{0.f, 0.f, 0.f, 0.f}; dvT[cb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  const int n_chunks = (n + CH - 1) / CH;
+  for (int c = CAUSAL ? wk.ob : 0; c < n_chunks; ++c) {      // causal: query chunks at or behind the key block
+    if (c > (CAUSAL ? wk.ob : 0) && !RT_ABL(a, 32)) __syncthreads();
+    const int rows = min(CH, n - c * CH);
+    if (!RT_ABL(a, 1)) {
+      stage_chunk2<HD>(a.q + (row0 + c * CH) * a.ldq + h * HD, a.ldq, qscale, Qimg, a.dout + (row0 + c * CH) * a.lddo + h * HD, a.lddo, 1.f, Dimg,
+                       rows, tid);
+      if (tid < CH) {
+        Ls[tid] = tid < rows ? a.lse[(row0 + c * CH + tid) * a.H + h] * LOG2E : 0.f;
+        Dl[tid] = tid < rows ? a.delta[(row0 + c * CH + tid) * a.H + h] : 0.f;
+      }
+    }
+    if (!RT_ABL(a, 32)) __syncthreads();
+    if (!active || RT_ABL(a, 2)) continue;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int t0 = c * CH + 32 * s;              // first query of the step
+      if (t0 >= n) break;
+      if (CAUSAL && t0 + 31 < k0) continue;        // (wave-uniform) every query of the step lies before every key of the tile
+      f32x4 sm[2], dpm[2];                         // S[q][key], dP[q][key]: register (qb, r) = query t0 + 16 qb + 4 g + r
+      rows_times_owner<HD>(Qimg, 32 * s, CH, Kp, i, g, sm, RT_ABLV(a));
+      rows_times_owner<HD>(Dimg, 32 * s, CH, Vp, i, g, dpm, RT_ABLV(a));
+      const bool edge = (CAUSAL && t0 < k0 + 16) || t0 + 31 >= n || k0 + 15 >= n;
+      float pd[8], ds[8];
+      if (RT_ABL(a, 4)) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { pd[e] = sm[e >> 2][e & 3]; ds[e] = dpm[e >> 2][e & 3]; }
+      } else
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        const f32x4 ls4 = *reinterpret_cast<const f32x4*>(Ls + 32 * s + 16 * qb + 4 * g);
+        const f32x4 dl4 = *reinterpret_cast<const f32x4*>(Dl + 32 * s + 16 * qb + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qr = t0 + 16 * qb + 4 * g + r;
+          float pr = __builtin_amdgcn_exp2f(sm[qb][r] - ls4[r]);
+          if (edge) pr = ((!CAUSAL || krow <= qr) && qr < n && kok) ? pr : 0.f;
+          float keepf = 1.f;
+          if (thr16 != 0u)
+            keepf = drop_kept(a.seed, (unsigned)wk.bh, (unsigned)qr, (unsigned)krow, thr16) ? inv_keep : 0.f;
+          pd[4 * qb + r] = pr * keepf;                               // dropped probabilities (for dV)
+          ds[4 * qb + r] = pr * (dpm[qb][r] * keepf - dl4[r]);       // dS
+        }
+      }
+      const P3 Pp = RT_SPLIT8(a, pd);
+      cols_times_slots<HD>(Dimg, 32 * s, CH, Pp, i, g, dvT, RT_ABLV(a));    // dV^T[c][key] += sum_q dO[q][c] P~[q][key]
+      const P3 Sp = RT_SPLIT8(a, ds);
+      cols_times_slots<HD>(Qimg, 32 * s, CH, Sp, i, g, dkT, RT_ABLV(a));    // dK^T[c][key] += sum_q Q'[q][c] dS[q][key]
+    }
+  }
+  if (!active || RT_ABL(a, 2)) return;
+  if (kok && !RT_ABL(a, 128)) {
+    float* dkp = a.dk + grow * a.lddk + h * HD;
+    float* dvp = a.dv + grow * a.lddv + h * HD;
+#pragma unroll
+    for (int cb = 0; cb < L::NCB; ++cb) {
+      *reinterpret_cast<f32x4*>(dkp + 16 * cb + 4 * g) = dkT[cb] * LN2;     // Q' = Q * scale * log2(e): scale is in, log2(e) comes out
+      *reinterpret_cast<f32x4*>(dvp + 16 * cb + 4 * g) = dvT[cb];
+    }
+  }
+}
+
+#ifdef RT_ABLATION_BUILD
+inline int v3_ablate_env() { const char* e = getenv("RT_V2_ABLATE"); return e != nullptr ? atoi(e) : 0; }
+#endif
+
+template <int HD, bool TRAIN, bool CAUSAL>
+int launch_fwd(VarlenArgs a, int max_len, hipStream_t stream) {
+  const int n_ob = (max_len + CH - 1) / CH;
+  const size_t lds = 2 * (size_t)CH * Lay<HD>::ROW3;
+#ifdef RT_ABLATION_BUILD
+  a.ablate = v3_ablate_env();
+#endif
+  v3_fwd_kernel<HD, TRAIN, CAUSAL><<<a.B * a.H * n_ob, NT, lds, stream>>>(a, n_ob);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+template <int HD, bool CAUSAL>
+int launch_bwd(VarlenArgs a, int max_len, hipStream_t stream) {
+  const int n_ob = (max_len + CH - 1) / CH;
+  const size_t lds = 2 * (size_t)CH * Lay<HD>::ROW3, lds_kv = lds + 2 * CH * sizeof(float);
+  const bool pad_wgs = CAUSAL && a.dbv_part != nullptr && a.bk != nullptr && a.bv != nullptr;
+  int skip = 0;
+#ifdef RT_ABLATION_BUILD
+  a.ablate = v3_ablate_env();
+  skip = a.ablate;
+#endif
+  if (!(skip & 256)) v3_bwd_dq_kernel<HD, CAUSAL><<<a.B * a.H * n_ob, NT, lds, stream>>>(a, n_ob);
+  RT_CHECK_LAUNCH();
+  if (!(skip & 512)) v3_bwd_dkv_kernel<HD, CAUSAL><<<a.B * a.H * (n_ob + (pad_wgs ? 1 : 0)), NT, lds_kv, stream>>>(a, n_ob);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+}  // namespace
+
+// hd 32 / 64, any session length (the chunks stream): RT_ERR_UNSUPPORTED otherwise — the caller then takes the earlier kernels
+int rt_v3_varlen_fwd(const rt_varlen::VarlenArgs& a, int max_len, bool train, hipStream_t stream) {
+  if (a.hd == 64) return train ? launch_fwd<64, true, true>(a, max_len, stream) : launch_fwd<64, false, true>(a, max_len, stream);
+  if (a.hd == 32) return train ? launch_fwd<32, true, true>(a, max_len, stream) : launch_fwd<32, false, true>(a, max_len, stream);
+  return RT_ERR_UNSUPPORTED;
+}
+int rt_v3_varlen_bwd(const rt_varlen::VarlenArgs& a, int max_len, hipStream_t stream) {
+  if (a.hd == 64) return launch_bwd<64, true>(a, max_len, stream);
+  if (a.hd == 32) return launch_bwd<32, true>(a, max_len, stream);
+  return RT_ERR_UNSUPPORTED;
+}
+// bidirectional (no causal mask, no pad keys): BERT4Rec's key-padding-masked window on packed rows
+int rt_v3_bidir_fwd(const rt_varlen::VarlenArgs& a, int max_len, bool train, hipStream_t stream) {
+  if (a.hd == 64) return train ? launch_fwd<64, true, false>(a, max_len, stream) : launch_fwd<64, false, false>(a, max_len, stream);
+  if (a.hd == 32) return train ? launch_fwd<32, true, false>(a, max_len, stream) : launch_fwd<32, false, false>(a, max_len, stream);
+  return RT_ERR_UNSUPPORTED;
+}
+int rt_v3_bidir_bwd(const rt_varlen::VarlenArgs& a, int max_len, hipStream_t stream) {
+  if (a.hd == 64) return launch_bwd<64, false>(a, max_len, stream);
+  if (a.hd == 32) return launch_bwd<32, false>(a, max_len, stream);
+  return RT_ERR_UNSUPPORTED;
+}

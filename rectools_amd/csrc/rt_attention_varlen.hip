@@ -482,13 +482,16 @@ __global__ __launch_bounds__(VT) void attn_varlen_last_kernel(VarlenArgs a, int 
 
 constexpr size_t VARLEN_LDS_LIMIT = 160 * 1024;
 
-// RT_VARLEN_IMPL=v1 keeps the first-form kernels of this file (f32-input MFMA); default: the bf16-plane kernels of rt_attention_v2.hip
-// wherever they serve the shape (they answer RT_ERR_UNSUPPORTED otherwise).  RT_VARLEN_IMPL=v2fwd / v2bwd: only that pass (A/B runs).
-int v2_mode() {
+// Default: the streamed bf16-plane kernels of rt_attention_v3.hip (hd 32 / 64, any session length).  RT_VARLEN_IMPL (A/B runs): v2 = the
+// whole-session-image kernels of rt_attention_v2.hip wherever they serve the shape (they answer RT_ERR_UNSUPPORTED otherwise), v1 = the
+// first-form kernels of this file (f32-input MFMA); v2fwd / v2bwd / v3fwd / v3bwd: only that pass on the named family, v1 / v2 for the other.
+int v2_mode() {   // bit 0 / 1: v2 forward / backward, bit 2 / 3: v3 forward / backward
   static int mode = -1;
   if (mode < 0) {
     const char* e = getenv("RT_VARLEN_IMPL");
-    mode = (e == nullptr || e[0] == 0) ? 3 : (!strcmp(e, "v1") ? 0 : !strcmp(e, "v2fwd") ? 1 : !strcmp(e, "v2bwd") ? 2 : 3);
+    mode = (e == nullptr || e[0] == 0) ? 15
+           : !strcmp(e, "v1") ? 0 : !strcmp(e, "v2") ? 3 : !strcmp(e, "v2fwd") ? 1 : !strcmp(e, "v2bwd") ? 2
+           : !strcmp(e, "v3fwd") ? 3 | 4 : !strcmp(e, "v3bwd") ? 3 | 8 : 15;
   }
   return mode;
 }
@@ -527,6 +530,10 @@ int rt_mha_varlen_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, 
   a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.o = o; a.ldo = ldo;
   a.cu = reinterpret_cast<const long long*>(cu_seqlens); a.bk = bk; a.bv = bv; a.B = B; a.H = H; a.hd = hd; a.window = window;
   a.scale = 1.0f / sqrtf((float)hd);
+  if (v2_mode() & 4) {
+    const int rc = rt_v3_varlen_fwd(a, max_len, false, stream);
+    if (rc != RT_ERR_UNSUPPORTED) return rc;
+  }
   if (v2_mode() & 1) {
     const int rc = rt_v2_varlen_fwd(a, max_len, false, stream);
     if (rc != RT_ERR_UNSUPPORTED) return rc;
@@ -560,6 +567,10 @@ int rt_mha_varlen_train_fwd(const float* q, int64_t ldq, const float* k, int64_t
   a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.o = o; a.ldo = ldo;
   a.cu = reinterpret_cast<const long long*>(cu_seqlens); a.bk = bk; a.bv = bv; a.B = B; a.H = H; a.hd = hd; a.window = window;
   a.scale = 1.0f / sqrtf((float)hd); a.p_drop = p_drop; a.seed = seed; a.lse = lse;
+  if (v2_mode() & 4) {
+    const int rc = rt_v3_varlen_fwd(a, max_len, true, stream);
+    if (rc != RT_ERR_UNSUPPORTED) return rc;
+  }
   if (v2_mode() & 1) {
     const int rc = rt_v2_varlen_fwd(a, max_len, true, stream);
     if (rc != RT_ERR_UNSUPPORTED) return rc;
@@ -600,6 +611,10 @@ int rt_mha_varlen_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, 
   a.scale = 1.0f / sqrtf((float)hd); a.p_drop = p_drop; a.seed = seed; a.lse = const_cast<float*>(lse);
   a.dout = dout; a.lddo = lddo; a.delta = delta; a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   a.dbv_part = dbv_part;
+  if (v2_mode() & 8) {
+    const int rc = rt_v3_varlen_bwd(a, max_len, stream);
+    if (rc != RT_ERR_UNSUPPORTED) return rc;
+  }
   if (v2_mode() & 2) {
     const int rc = rt_v2_varlen_bwd(a, max_len, stream);
     if (rc != RT_ERR_UNSUPPORTED) return rc;
@@ -639,6 +654,10 @@ int rt_mha_varlen_bidir_fwd(const float* q, int64_t ldq, const float* k, int64_t
   a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.o = o; a.ldo = ldo;
   a.cu = reinterpret_cast<const long long*>(cu_seqlens); a.B = B; a.H = H; a.hd = hd; a.window = 0;
   a.scale = 1.0f / sqrtf((float)hd); a.p_drop = lse != nullptr ? p_drop : 0.f; a.seed = seed; a.lse = lse;
+  if (v2_mode() & 4) {
+    const int rc = rt_v3_bidir_fwd(a, max_len, lse != nullptr, stream);
+    if (rc != RT_ERR_UNSUPPORTED) return rc;
+  }
   return rt_v2_bidir_fwd(a, max_len, lse != nullptr, stream);
 }
 int rt_mha_varlen_bidir_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* o, int64_t ldo,
@@ -657,6 +676,10 @@ int rt_mha_varlen_bidir_bwd(const float* q, int64_t ldq, const float* k, int64_t
   a.cu = reinterpret_cast<const long long*>(cu_seqlens); a.B = B; a.H = H; a.hd = hd; a.window = 0;
   a.scale = 1.0f / sqrtf((float)hd); a.p_drop = p_drop; a.seed = seed; a.lse = const_cast<float*>(lse);
   a.dout = dout; a.lddo = lddo; a.delta = delta; a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+  if (v2_mode() & 8) {
+    const int rc = rt_v3_bidir_bwd(a, max_len, stream);
+    if (rc != RT_ERR_UNSUPPORTED) return rc;
+  }
   return rt_v2_bidir_bwd(a, max_len, stream);
 }
 

@@ -19,6 +19,7 @@ struct VarlenArgs {
   float* delta;                        // [N, H] rowsum(dO * O): written by the dQ kernel, read by the dK/dV kernel
   float* dq; float* dk; float* dv; long long lddq, lddk, lddv;
   float* dbv_part;                     // [B, H*hd] per-session partial of the value-bias gradient from the pad keys (or null)
+  int ablate;                          // read by -DRT_ABLATION_BUILD builds of rt_attention_v2.hip only (RT_V2_ABLATE), else 0
 };
 
 // Attention dropout mask, same construction as rt_attention.hip: ONE 32-bit mix per (head, query, PAIR of adjacent keys), 16 bits
@@ -66,3 +67,10 @@ int rt_v2_varlen_fwd(const rt_varlen::VarlenArgs& a, int max_len, bool train, hi
 int rt_v2_varlen_bwd(const rt_varlen::VarlenArgs& a, int max_len, hipStream_t stream);
 int rt_v2_bidir_fwd(const rt_varlen::VarlenArgs& a, int max_len, bool train, hipStream_t stream);
 int rt_v2_bidir_bwd(const rt_varlen::VarlenArgs& a, int max_len, hipStream_t stream);
+
+// rt_attention_v3.hip: the same kernels' arithmetic on STREAMED 64-row chunks (a workgroup = 64 owner rows of a (session, head)); hd 32 /
+// 64, any session length.
+int rt_v3_varlen_fwd(const rt_varlen::VarlenArgs& a, int max_len, bool train, hipStream_t stream);
+int rt_v3_varlen_bwd(const rt_varlen::VarlenArgs& a, int max_len, hipStream_t stream);
+int rt_v3_bidir_fwd(const rt_varlen::VarlenArgs& a, int max_len, bool train, hipStream_t stream);
+int rt_v3_bidir_bwd(const rt_varlen::VarlenArgs& a, int max_len, hipStream_t stream);

@@ -45,6 +45,23 @@ def gbce_beta(n_negatives: int, n_items: int, gbce_t: float) -> float:
     return alpha * (gbce_t * (1 - 1 / alpha) + 1 / alpha)
 
 
+class _PadRowNoGrad(torch.autograd.Function):
+    """Identity on the catalog matrix whose backward zeroes row 0: `nn.Embedding(padding_idx=0)` (item_net.py:260-264) — the reference
+    materialises the catalog THROUGH that lookup (`get_all_embeddings`, item_net.py:361-368), so the PAD row never receives a gradient,
+    not even from full-catalog logits.  The fused losses zero the row themselves; a plugged similarity module reads the table through
+    this node."""
+
+    @staticmethod
+    def forward(ctx, table):
+        return table.view_as(table)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.clone()
+        g[0] = 0
+        return g
+
+
 class TransformerLossModule(nn.Module):
     """Backbone + loss.  `n_item_extra_tokens` real-item offset is only needed for gBCE (lightning.py:202)."""
 
@@ -116,9 +133,78 @@ class TransformerLossModule(nn.Module):
             beta = gbce_beta(int(negatives.shape[-1]), n_items, self.gbce_t)
         return ops.sampled_loss(sess2d, table, y, negatives, w, kind, self.cosine, self.logits_t, beta)
 
+    # ---- a plugged similarity module (`similarity_module_type`, transformers/base.py:415-421) -------------------------------------
+    @property
+    def similarity_is_stock(self) -> bool:
+        """The fused loss kernels compute dot / cosine logits of the encoder's rows against the table's rows — what the stock
+        `DistanceSimilarityModule` defines.  Any other module is called for its logits (`_loss_via_similarity`)."""
+        from .nn import similarity_is_stock
+
+        return similarity_is_stock(self.torch_model.similarity_module)
+
+    def _logits_via_similarity(self, table: torch.Tensor, sess: torch.Tensor, y: torch.Tensor,
+                               negatives: tp.Optional[torch.Tensor]) -> torch.Tensor:
+        """`get_batch_logits` (lightning.py:301-309) with the similarity module's own `forward`: sess [B, L, d], y [B, L],
+        negatives [B, L, N] -> [B, L, 1 + N] (sampled losses) or [B, L, V] (softmax), divided by logits_t."""
+        sim = self.torch_model.similarity_module
+        if table.is_leaf and table.requires_grad:      # an ids-only item net hands out the parameter itself (nn.SumOfEmbeddingsConstructor)
+            table = _PadRowNoGrad.apply(table)
+        if requires_negatives(self.loss) or (requires_negatives(self.loss) is None and negatives is not None):
+            pos_neg = torch.cat([y.unsqueeze(-1), negatives], dim=-1)
+            return sim(sess, table, pos_neg) / self.logits_t
+        return sim(sess, table) / self.logits_t
+
+    # the reference's loss calculators on materialised logits (lightning.py:144-212), device tensor ops under autograd: the path of a
+    # plugged similarity module only — the stock step never materialises [B, L, V] or [B, L, 1 + N, d]
+    @staticmethod
+    def _calc_softmax_loss(logits: torch.Tensor, y: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+        loss = torch.nn.functional.cross_entropy(logits.transpose(1, 2), y, ignore_index=0, reduction="none") * w
+        return torch.sum(loss) / torch.sum((loss > 0).to(loss.dtype))
+
+    @staticmethod
+    def _calc_bce_loss(logits: torch.Tensor, y: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+        mask = y != 0
+        target = torch.zeros_like(logits)
+        target[:, :, 0] = 1
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, target, reduction="none")
+        loss = loss.mean(-1) * mask * w
+        return torch.sum(loss) / torch.sum(mask)
+
+    def _get_reduced_overconfidence_logits(self, logits: torch.Tensor, n_items: int, n_negatives: int) -> torch.Tensor:
+        dtype = torch.float64                                             # lightning.py:167
+        beta = gbce_beta(n_negatives, n_items, self.gbce_t)
+        pos, neg = logits[:, :, 0:1].to(dtype), logits[:, :, 1:].to(dtype)
+        eps = 1e-10
+        p = torch.clamp(torch.sigmoid(pos), eps, 1 - eps)
+        p = torch.clamp(p.pow(-beta), 1 + eps, torch.finfo(dtype).max)
+        p = torch.clamp(torch.div(1, (p - 1)), eps, torch.finfo(dtype).max)
+        return torch.cat([torch.log(p), neg], dim=-1)
+
+    def _calc_loss_from_logits(self, logits: torch.Tensor, y: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+        """`loss_calculator(logits, y, w)` (lightning.py:126-142).  Like the reference's `_calc_sampled_softmax_loss`
+        (lightning.py:207-212) the sampled softmax swaps columns 0 and 1 of `logits` IN PLACE."""
+        if self.loss == "softmax":
+            return self._calc_softmax_loss(logits, y, w)
+        if self.loss == "BCE":
+            return self._calc_bce_loss(logits, y, w)
+        if self.loss == "gBCE":
+            n_items = int(self.torch_model.item_model.n_items) - self.n_item_extra_tokens
+            return self._calc_bce_loss(self._get_reduced_overconfidence_logits(logits, n_items, int(logits.shape[-1]) - 1), y, w)
+        if self.loss == "sampled_softmax":
+            logits[:, :, [0, 1]] = logits[:, :, [1, 0]]
+            return self._calc_softmax_loss(logits, (y != 0).long(), w)
+        raise ValueError(f"loss {self.loss} is not supported")
+
+    def _loss_via_similarity(self, table: torch.Tensor, sess: torch.Tensor, y: torch.Tensor, w: torch.Tensor,
+                             negatives: tp.Optional[torch.Tensor]) -> tp.Tuple[torch.Tensor, torch.Tensor]:
+        logits = self._logits_via_similarity(table, sess, y, negatives)
+        return self._calc_loss_from_logits(logits, y, w), logits
+
     def training_loss(self, batch: Batch) -> torch.Tensor:
         table, sess = self._encode(batch)
         B, L, d = sess.shape
+        if not self.similarity_is_stock and type(self)._loss_from_sessions is TransformerLossModule._loss_from_sessions:
+            return self._loss_via_similarity(table, sess, batch["y"], batch["yw"], batch.get("negatives"))[0]
         loss, _ = self._loss_from_sessions(table, sess.view(B * L, d), batch["y"], batch["yw"], batch.get("negatives"))
         return loss
 
@@ -137,10 +223,36 @@ class TransformerLossModule(nn.Module):
 
     def validation_loss(self, batch: Batch) -> torch.Tensor:
         """Last position only (lightning.py:340-349): y, yw [B,1]; negatives [B,1,N]."""
+        return self.validation_step(batch, want_logits=False)["loss"]
+
+    def validation_step(self, batch: Batch, batch_idx: int = 0, want_logits: bool = True) -> tp.Dict[str, torch.Tensor]:
+        """`validation_step` (lightning.py:336-359): {"loss", "pos_neg_logits" [B, 1 + N] | "logits" [B, V]} — the outputs a
+        validation callback receives (`on_validation_batch_end`; examples/tutorials/utils.py:54-118 reads "logits").  Logits are
+        divided by logits_t; with the sampled softmax columns 0 and 1 come swapped, as the reference hands them on (its loss
+        calculator swaps them in place before the outputs are taken, lightning.py:209,346-352).  want_logits=False skips the
+        [B, V] product of the softmax loss (nobody listens)."""
         table, sess = self._encode(batch)
-        last = sess[:, -1, :]
-        loss, _ = self._loss_from_sessions(table, last, batch["y"], batch["yw"], batch.get("negatives"))
-        return loss
+        last = sess[:, -1:, :]
+        y, w, negatives = batch["y"], batch["yw"], batch.get("negatives")
+        sampled = negatives is not None and requires_negatives(self.loss) is not False
+        key = "pos_neg_logits" if sampled else "logits"
+        if type(self)._loss_from_sessions is not TransformerLossModule._loss_from_sessions:      # a plugged loss: its own values
+            loss, logits = self._loss_from_sessions(table, last[:, 0, :], y, w, negatives)
+            return {"loss": loss} if logits is None else {"loss": loss, key: logits}
+        if not self.similarity_is_stock:
+            loss, logits = self._loss_via_similarity(table, last, y, w, negatives)
+            return {"loss": loss, key: logits.squeeze()}
+        loss, logits = self._loss_from_sessions(table, last[:, 0, :], y, w, negatives)
+        out = {"loss": loss}
+        if sampled:
+            if self.loss == "sampled_softmax":
+                logits = logits.clone()
+                logits[:, [0, 1]] = logits[:, [1, 0]]
+            out[key] = logits.squeeze()
+        elif want_logits:
+            sim = self.torch_model.similarity_module
+            out[key] = (sim(last[:, 0, :].contiguous(), table) / self.logits_t).squeeze()
+        return out
 
     def batch_logits(self, batch: Batch) -> torch.Tensor:
         """[B, L, 1+N] (sampled losses) — the values the reference's get_batch_logits returns; parity checks only."""

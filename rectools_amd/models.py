@@ -61,6 +61,51 @@ def _dist_info() -> tp.Tuple[int, int]:
     return 0, 1
 
 
+class _AttrView:
+    """A checkpoint's `dataset_schema` dict with attribute access, nested: the reference hands `from_dataset_schema` a `DatasetSchema`
+    object and its blocks read `dataset_schema.items.n_hot`, `.items.features.cat_feature_indices` ... (item_net.py:44-52, 193-228;
+    ADVICE r5: a raw dict raised AttributeError there).  Attribute access wins over dict methods (`.items` is the ITEM schema, as on the
+    reference's object); subscripting, `in`, `len`, iteration, `.keys()`, `.get()` and `dict(view)` still read the mapping."""
+
+    def __init__(self, data: tp.Dict[str, tp.Any]) -> None:
+        object.__setattr__(self, "_data", data)
+
+    def __getattr__(self, name: str) -> tp.Any:
+        data = object.__getattribute__(self, "_data")
+        if name in data:
+            return _schema_view(data[name])
+        raise AttributeError(name)
+
+    def __getitem__(self, key: str) -> tp.Any:
+        return _schema_view(self._data[key])
+
+    def __contains__(self, key: object) -> bool:
+        return key in self._data
+
+    def __iter__(self) -> tp.Iterator[str]:
+        return iter(self._data)
+
+    def __len__(self) -> int:
+        return len(self._data)
+
+    def keys(self) -> tp.Any:
+        return self._data.keys()
+
+    def get(self, key: str, default: tp.Any = None) -> tp.Any:
+        return _schema_view(self._data.get(key, default))
+
+    def __repr__(self) -> str:
+        return f"_AttrView({self._data!r})"
+
+
+def _schema_view(obj: tp.Any) -> tp.Any:
+    if isinstance(obj, dict) and not isinstance(obj, _AttrView):
+        return _AttrView(obj)
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_schema_view(v) for v in obj)
+    return obj
+
+
 # the data preparators whose batches have a packed (padding-free) twin on the device: `rt_collate_packed` / `rt_collate_packed_bert`
 _PACKED_PREPARATORS = ("SASRecDataPreparator", "BERT4RecDataPreparator")
 
@@ -74,7 +119,9 @@ def _packed_hooks_are_stock(lm: tp.Any) -> bool:
     loss_ok = (tl.training_loss is base_l.training_loss and tl._encode is base_l._encode) \
         or tl.training_loss_packed is not base_l.training_loss_packed      # pylint: disable=protected-access
     enc_ok = tm.encode_sessions is base_b.encode_sessions or tm.encode_packed_train is not base_b.encode_packed_train
-    return loss_ok and enc_ok
+    # a plugged similarity module is called with the reference's shapes ([B, L, d] sessions, [B, L, 1 + N] candidates): padded batches
+    sim_ok = hnn.similarity_is_stock(lm.torch_model.similarity_module) or tl.training_loss_packed is not base_l.training_loss_packed
+    return loss_ok and enc_ok and sim_ok
 
 
 _PREFETCH_STREAMS: tp.Dict[torch.device, "torch.cuda.Stream"] = {}
@@ -362,7 +409,7 @@ class TransformerModelBase:
         fn = getattr(self.lightning_module_type, "requires_negatives", None)
         return hl.requires_negatives(self.loss) if fn is None else fn(self.loss)
 
-    def _init_data_preparator(self) -> None:
+    def _init_data_preparator(self, **extra: tp.Any) -> None:
         requires_negatives = bool(self._requires_negatives())
         self.data_preparator = self.data_preparator_type(
             session_max_len=self.session_max_len, batch_size=self.batch_size, dataloader_num_workers=self.dataloader_num_workers,
@@ -370,7 +417,7 @@ class TransformerModelBase:
             n_negatives=self.n_negatives if requires_negatives else None,
             negative_sampler=self._init_negative_sampler() if requires_negatives else None,
             get_val_mask_func=self.get_val_mask_func, get_val_mask_func_kwargs=self.get_val_mask_func_kwargs,
-            **self._kw(self.data_preparator_kwargs),
+            **extra, **self._kw(self.data_preparator_kwargs),
         )
 
     def _dim_plan(self) -> tp.Optional[hnn.DimPlan]:
@@ -378,7 +425,7 @@ class TransformerModelBase:
         size a multiple of 8, at most 128; HSTU: linear_hidden_dim == attention_dim).  Otherwise the stock modules are built padded
         with zero columns; a PLUGGED layer stack / item net / positional encoding / backbone is built by the caller's own class at the
         caller's own sizes and cannot be padded from outside: NotImplementedError names the constraint."""
-        tkw = self._kw(self.transformer_layers_kwargs)
+        tkw = self._layer_kwargs()
         stu = self.transformer_layers_type is hnn.STULayers
         plan = hnn.DimPlan.make(self.n_factors, self.n_heads, "stu", tkw.get("linear_hidden_dim"), tkw.get("attention_dim")) if stu \
             else hnn.DimPlan.make(self.n_factors, self.n_heads, "mha")
@@ -394,8 +441,15 @@ class TransformerModelBase:
                                       f"padded with zero columns (nn.DimPlan); plugged module classes cannot be padded from outside")
         return plan
 
+    def _layer_kwargs(self) -> tp.Dict[str, tp.Any]:
+        """Keyword arguments of the layer stack beyond (n_blocks, n_factors, n_heads, dropout_rate): `transformer_layers_kwargs`, plus
+        what a model kind derives from its own arguments (HSTU).  Derived values are added HERE, when the stack is built — never
+        written into `transformer_layers_kwargs`: that dict is part of the config the reference reads back (hstu.py:660-674 passes the
+        derived values itself, beside the kwargs)."""
+        return self._kw(self.transformer_layers_kwargs)
+
     def _init_transformer_layers(self, plan: tp.Optional[hnn.DimPlan] = None) -> hnn.TransformerLayersBase:
-        tkw = self._kw(self.transformer_layers_kwargs)
+        tkw = self._layer_kwargs()
         if plan is not None and plan.kind == "stu":
             tkw.update(linear_hidden_dim=plan.hd_pad, attention_dim=plan.hd_pad)
         return self.transformer_layers_type(n_blocks=self.n_blocks, n_factors=self.n_factors if plan is None else plan.d_pad,
@@ -432,7 +486,7 @@ class TransformerModelBase:
                 blocks.append(block_type(torch.zeros(spec["nnz"], dtype=torch.int64), zeros, zeros.clone(),
                                          spec["n_cat_feature_values"], n_factors, self.dropout_rate))
             elif callable(getattr(block_type, "from_dataset_schema", None)):     # a plugged block class: the reference's own hook
-                block = block_type.from_dataset_schema(self.dataset_schema, n_factors, self.dropout_rate)    # (item_net.py:44-52)
+                block = block_type.from_dataset_schema(_schema_view(self.dataset_schema), n_factors, self.dropout_rate)    # (item_net.py:44-52)
                 if block is not None:
                     blocks.append(block)
             else:
@@ -566,10 +620,15 @@ class TransformerModelBase:
             (foreign if mod.split(".")[0] in ("pytorch_lightning", "lightning", "lightning_fabric") else own).append(cb)
         logger = getattr(trainer, "logger", None)
         log_dir = None
-        for attr in ("log_dir", "save_dir"):
-            if logger is not None and isinstance(getattr(logger, attr, None), str):
-                log_dir = getattr(logger, attr)
-                break
+        if logger is not None:
+            # `_log_epoch` makes its own `version_N` directory: it wants the directory Lightning's CSVLogger numbers its versions IN
+            # (`save_dir/name`); a logger's `log_dir` already ends in `version_N` (metrics landed in version_N/version_M)
+            save_dir, name, ldir = (getattr(logger, a, None) for a in ("save_dir", "name", "log_dir"))
+            if isinstance(save_dir, str):
+                log_dir = os.path.join(save_dir, name) if isinstance(name, str) and name else save_dir
+            elif isinstance(ldir, str):
+                base = os.path.basename(os.path.normpath(ldir))
+                log_dir = os.path.dirname(os.path.normpath(ldir)) if base.startswith("version_") and base[8:].isdigit() else ldir
         plan = {"trainer": trainer, "max_epochs": getattr(trainer, "max_epochs", None), "min_epochs": getattr(trainer, "min_epochs", None),
                 "callbacks": own, "log_dir": log_dir,
                 "progress": bool(getattr(trainer, "enable_progress_bar", False) or getattr(trainer, "progress_bar_callback", None))}
@@ -597,8 +656,8 @@ class TransformerModelBase:
         lm, opt, dp = self.lightning_model, self.optimizer, self.data_preparator
         assert lm is not None and opt is not None
         device = next(lm.parameters()).device
-        if plan is not None and plan["log_dir"] and not self._params.get("csv_log_dir"):
-            self._params["csv_log_dir"] = plan["log_dir"]
+        # the Trainer's directory is this run's, not a hyper-parameter: it stays out of `_params` (get_config / checkpoints)
+        self._trainer_log_dir = plan["log_dir"] if plan is not None and plan["log_dir"] and not self._params.get("csv_log_dir") else None
         verbose = self.verbose or (plan is not None and plan["progress"])
         trainer = None if plan is None else plan["trainer"]
         self._call_hooks(plan, "on_fit_start", lm)
@@ -614,6 +673,8 @@ class TransformerModelBase:
         for epoch in range(first, last):
             lm.train()
             loop.begin_epoch(epoch)
+            if isinstance(getattr(lm, "__dict__", None), dict):
+                lm.__dict__["logged_metrics"] = {}      # a metric logged in an earlier epoch is not this epoch's
             self._call_hooks(plan, "on_train_epoch_start", lm)
             total = torch.zeros((), device=device)
             n_batches = 0
@@ -631,37 +692,79 @@ class TransformerModelBase:
                     for bi, b0 in enumerate(range(0, len(val_store), self.batch_size)):
                         vb = self._to_device(dp.collate_val(val_store, np.arange(b0, min(b0 + self.batch_size, len(val_store)))), device, True)
                         nb = int(vb["x"].shape[0])     # Lightning's epoch mean weights every batch by its size
-                        vloss = lm.validation_loss(vb)
+                        # lightning.py:336-359: the outputs a callback's `on_validation_batch_end` receives carry the logits
+                        # (the [B, V] product of the softmax loss only when a callback listens)
+                        listens = plan is not None and any(callable(getattr(cb, "on_validation_batch_end", None)) for cb in plan["callbacks"])
+                        step = getattr(lm, "validation_step", None)
+                        if callable(step) and getattr(type(lm), "validation_step", None) is hl.TransformerLossModule.validation_step:
+                            outputs = step(vb, bi, want_logits=listens)
+                        elif callable(step):                 # a plugged module's own step: the reference's signature (lightning.py:336)
+                            outputs = step(vb, bi)
+                        else:
+                            outputs = {"loss": lm.validation_loss(vb)}
+                        vloss = outputs["loss"]
                         vt += vloss * nb
                         vn += nb
-                        self._call_hooks(plan, "on_validation_batch_end", lm, {"loss": vloss}, vb, bi)
+                        self._call_hooks(plan, "on_validation_batch_end", lm, outputs, vb, bi)
                     self._call_hooks(plan, "on_validation_epoch_end", lm)
                     self._call_hooks(plan, "on_validation_end", lm)
                     if hasattr(lm, "item_embs"):
                         del lm.item_embs
                 rec[self.val_loss_name] = float(vt) / max(vn, 1)
-            rec.update({k: v for k, v in getattr(lm, "logged_metrics", {}).items() if k not in rec})   # what callbacks logged this epoch
+            if loop.world > 1:
+                # every rank's callbacks (early stopping, checkpoint-on-best) must see the SAME epoch metrics, or ranks decide differently
+                # and meet in different collectives (Lightning: `self.log(..., sync_dist)` / `reduce_boolean_decision`)
+                keys = [k for k in (self.train_loss_name, self.val_loss_name) if k in rec]
+                vals = self._all_reduce_host([rec[k] for k in keys], "mean", device)
+                rec.update(dict(zip(keys, vals)))
             self.history.append(rec)
-            if plan is not None:          # the metrics a callback's early-stopping logic reads (Lightning: trainer.callback_metrics)
+            def publish() -> None:     # the metrics a callback's early-stopping logic reads (Lightning: trainer.callback_metrics)
+                rec.update({k: v for k, v in getattr(lm, "logged_metrics", {}).items() if k not in rec})   # what callbacks logged this epoch
+                if plan is None:
+                    return
                 try:
                     metrics = getattr(trainer, "callback_metrics", None)
                     if isinstance(metrics, dict):
                         metrics.update({k: torch.as_tensor(v) for k, v in rec.items() if k != "epoch"})
-                except Exception:      # a real Lightning Trainer's connector: read-only
+                except Exception:      # a real Lightning Trainer's connector: read-only      # pylint: disable=broad-except
                     pass
+
+            publish()                  # validation callbacks have logged: `on_train_epoch_end` hooks read them
             self._call_hooks(plan, "on_train_epoch_end", lm)
+            publish()                  # ... and what `on_train_epoch_end` logs belongs to THIS epoch's record too
             if rank == 0:
                 self._log_epoch(rec, opt.step_count)
             if verbose and rank == 0:
                 print(rec)
             self.epochs_done = epoch + 1
-            if plan is not None and bool(getattr(trainer, "should_stop", False)) and self.epochs_done >= (min_last or first):
+            stop = plan is not None and bool(getattr(trainer, "should_stop", False))
+            if plan is not None and loop.world > 1:      # one rank asking to stop stops them all, in the same epoch
+                stop = self._all_reduce_host([1.0 if stop else 0.0], "max", device)[0] > 0.0
+                if stop:
+                    try:
+                        trainer.should_stop = True
+                    except Exception:      # pylint: disable=broad-except
+                        pass
+            if stop and self.epochs_done >= (min_last or first):
                 break
         # sharded data-parallel exchange: every rank holds only its slice of the Adam moments while training; gather them now, while
         # every rank is here and the process group is alive, so that saving / pickling afterwards is a local operation on any rank
         opt.consolidate_moments()
         self._call_hooks(plan, "on_train_end", lm)
         self._call_hooks(plan, "on_fit_end", lm)
+
+    @staticmethod
+    def _all_reduce_host(values: tp.Sequence[float], op: str, device: torch.device) -> tp.List[float]:
+        """A few host scalars reduced over the process group ("mean" | "max"); the tensor lives where the backend can reduce it."""
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or not values:
+            return [float(v) for v in values]
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+        if op == "mean":
+            t /= dist.get_world_size()
+        return [float(v) for v in t.cpu()]
 
     def _log_epoch(self, rec: tp.Dict[str, float], global_step: int) -> None:
         """Per-epoch metrics file in the layout of Lightning's CSVLogger (`<dir>/version_N/metrics.csv`, columns
@@ -670,7 +773,7 @@ class TransformerModelBase:
         logs only when verbose > 0 (base.py:375), to `lightning_logs/`."""
         import os
 
-        log_dir = self._params.get("csv_log_dir") or ("lightning_logs" if self.verbose > 0 else None)
+        log_dir = self._params.get("csv_log_dir") or getattr(self, "_trainer_log_dir", None) or ("lightning_logs" if self.verbose > 0 else None)
         if log_dir is None:
             return
         if getattr(self, "_csv_path", None) is None or rec["epoch"] == 0:
@@ -961,6 +1064,9 @@ class TransformerModelBase:
                 warnings.warn("Model doesn't support recommendations for cold users, but some of given users are cold")
             users = users[known]
         dp_ = self.data_preparator
+        if not hnn.similarity_is_stock(self.torch_model.similarity_module):
+            return self._recommend_via_similarity(users, dataset, k, filter_viewed, items_to_recommend, add_rank_col,
+                                                  on_unsupported_targets, context)
         plain = context is None and not dp_.add_unix_ts
         # a model that reads timestamps (HSTU) takes the device path when its stack packs: the request's context time becomes the last
         # timestamp of every packed session (`rt_collate_packed_ts`)
@@ -990,6 +1096,38 @@ class TransformerModelBase:
         ids, scores, counts, _ = ranker.rank_device(user_ids, k=k, filter_pairs_csr=filt, sorted_object_whitelist=whitelist)
         self._keep_images(ranker)
         return self._assemble(rec_ds.user_id_map.convert_to_external(user_ids), ids, scores, counts, add_rank_col, Columns.User)
+
+    def _recommend_via_similarity(self, users: np.ndarray, dataset: tp.Any, k: int, filter_viewed: bool,
+                                  items_to_recommend: tp.Optional[tp.Any], add_rank_col: bool, on_unsupported_targets: str,
+                                  context: tp.Optional[pd.DataFrame]) -> pd.DataFrame:
+        """recommend() of a model whose `similarity_module_type` is not the stock one: the module's own towers and its own
+        `_recommend_u2i` are called with the reference's arguments (lightning.py:378-428: user embeddings through
+        `session_tower_forward`, the catalog through `item_tower_forward`, then `similarity_module._recommend_u2i(user_embs, item_embs,
+        user_ids, k, sorted_item_ids_to_recommend, ui_csr_for_filter)`), its triplet becomes the frame (models/base.py:502-519)."""
+        with warnings.catch_warnings():
+            if on_unsupported_targets == "ignore":
+                warnings.simplefilter("ignore")
+            rec_ds = self.data_preparator.transform_dataset_u2i(dataset, users, context)
+        user_ids = rec_ds.user_id_map.convert_to_internal(users, strict=False)
+        whitelist = self._whitelist(items_to_recommend)
+        if len(user_ids) == 0 or len(whitelist) == 0:
+            return self._frame(np.array([], users.dtype), np.array([], object), np.array([], np.float32), add_rank_col, Columns.User)
+        lm = self.lightning_model
+        device = next(lm.parameters()).device
+        sim = lm.torch_model.similarity_module
+        store = SequenceStore.from_interactions(rec_ds.interactions.df, sort_users=True)  # session i <-> internal user i
+        item_embs = self._item_embeddings()
+        user_embs = self._user_embeddings(store, device, item_embs)
+        with torch.no_grad():
+            user_embs = sim.session_tower_forward(user_embs)
+            item_embs = sim.item_tower_forward(item_embs)
+            ui_csr = rec_ds.get_user_item_matrix(include_weights=False)[user_ids] if filter_viewed else None
+            uids, reco, scores = sim._recommend_u2i(          # pylint: disable=protected-access
+                user_embs=user_embs, item_embs=item_embs, user_ids=user_ids, k=k, sorted_item_ids_to_recommend=whitelist,
+                ui_csr_for_filter=ui_csr)
+        ext_u = rec_ds.user_id_map.convert_to_external(np.asarray(uids))
+        ext_i = self.data_preparator.item_id_map.convert_to_external(np.asarray(reco).astype(np.int64))
+        return self._frame(ext_u, ext_i, np.asarray(scores, dtype=np.float32), add_rank_col, Columns.User)
 
     def recommend_distributed(self, users: tp.Any, dataset: tp.Any, k: int, filter_viewed: bool, **kwargs: tp.Any) -> pd.DataFrame:
         """recommend() over all ranks of an initialised process group: users are independent, every rank
@@ -1265,6 +1403,8 @@ class TransformerModelBase:
         hyper = checkpoint["hyper_parameters"]
         config = ckpt.translate_config(dict(hyper["model_config"]))
         config.pop("cls", None)       # the class the method is called on decides (the reference stores a short name)
+        for key, value in ((checkpoint.get("rectools_amd") or {}).get("model_params") or {}).items():
+            config.setdefault(key, value)      # arguments only this engine has (`checkpoint.ENGINE_ONLY_PARAMS`) travel beside the config
         if config.get("get_trainer_func") is not None:
             # a checkpoint trained under a user-built Trainer: the factory is restored when its dotted path imports here (fit_partial()
             # of the restored model then reads it again, `_trainer_plan`), dropped aloud when it does not
@@ -1277,6 +1417,7 @@ class TransformerModelBase:
         loaded = cls.from_config(config)
         dp = loaded.data_preparator
         ext = hyper["item_external_ids"]
+        ext = ext.tolist() if isinstance(ext, np.ndarray) else list(ext)
         dp.item_id_map = IdMap(np.asarray(ext, dtype=object) if any(isinstance(v, str) for v in ext) else np.asarray(ext))
         dp.extra_token_ids = dict(zip(dp.item_extra_tokens, dp.item_id_map.convert_to_internal(list(dp.item_extra_tokens))))
         loaded.dataset_schema = hyper.get("dataset_schema") or {}
@@ -1386,8 +1527,6 @@ class BERT4RecModel(TransformerModelBase):
                  transformer_layers_type: tp.Type[hnn.TransformerLayersBase] = hnn.PreLNTransformerLayers,
                  data_preparator_type: tp.Type[TransformerDataPreparatorBase] = BERT4RecDataPreparator, **kwargs: tp.Any) -> None:
         self.mask_prob = mask_prob
-        dkw = dict(kwargs.pop("data_preparator_kwargs", None) or {})
-        dkw.setdefault("mask_prob", mask_prob)
         super().__init__(
             data_preparator_type=data_preparator_type, transformer_layers_type=transformer_layers_type, n_blocks=n_blocks,
             n_heads=n_heads, n_factors=n_factors, use_pos_emb=use_pos_emb, use_causal_attn=use_causal_attn,
@@ -1395,7 +1534,12 @@ class BERT4RecModel(TransformerModelBase):
             dataloader_num_workers=dataloader_num_workers, batch_size=batch_size, loss=loss, n_negatives=n_negatives, gbce_t=gbce_t,
             lr=lr, epochs=epochs, verbose=verbose, deterministic=deterministic, recommend_batch_size=recommend_batch_size,
             recommend_torch_device=recommend_torch_device, train_min_user_interactions=train_min_user_interactions,
-            data_preparator_kwargs=dkw, mask_prob=mask_prob, **kwargs)
+            mask_prob=mask_prob, **kwargs)
+
+    def _init_data_preparator(self, **extra: tp.Any) -> None:
+        """bert4rec.py:430-441: `mask_prob` is the model's own argument, handed to the preparator beside `data_preparator_kwargs` — it
+        must not be written INTO those kwargs (the config the reference reads back would then pass it twice)."""
+        super()._init_data_preparator(mask_prob=self.mask_prob, **extra)
 
 
 class HSTUModel(TransformerModelBase):
@@ -1419,12 +1563,6 @@ class HSTUModel(TransformerModelBase):
             warnings.warn("'use_key_padding_mask' is not supported for HSTU and enforced to False.")  # hstu.py:608-612
             use_key_padding_mask = False
         self.relative_time_attention, self.relative_pos_attention = relative_time_attention, relative_pos_attention
-        hd = n_factors // n_heads
-        tkw = dict(kwargs.pop("transformer_layers_kwargs", None) or {})
-        tkw.update(dict(linear_hidden_dim=hd, attention_dim=hd, session_max_len=session_max_len,
-                        relative_time_attention=relative_time_attention, relative_pos_attention=relative_pos_attention))
-        dkw = dict(kwargs.pop("data_preparator_kwargs", None) or {})
-        dkw.setdefault("add_unix_ts", relative_time_attention)
         super().__init__(
             data_preparator_type=data_preparator_type, transformer_layers_type=transformer_layers_type, n_blocks=n_blocks,
             n_heads=n_heads, n_factors=n_factors, use_pos_emb=use_pos_emb, use_causal_attn=use_causal_attn,
@@ -1432,8 +1570,25 @@ class HSTUModel(TransformerModelBase):
             dataloader_num_workers=dataloader_num_workers, batch_size=batch_size, loss=loss, n_negatives=n_negatives, gbce_t=gbce_t,
             lr=lr, epochs=epochs, verbose=verbose, deterministic=deterministic, recommend_batch_size=recommend_batch_size,
             recommend_torch_device=recommend_torch_device, train_min_user_interactions=train_min_user_interactions,
-            transformer_layers_kwargs=tkw, data_preparator_kwargs=dkw, relative_time_attention=relative_time_attention,
-            relative_pos_attention=relative_pos_attention, **kwargs)
+            relative_time_attention=relative_time_attention, relative_pos_attention=relative_pos_attention, **kwargs)
+
+    def _layer_kwargs(self) -> tp.Dict[str, tp.Any]:
+        """hstu.py:660-674: head size, window and the two bias switches derive from the model's own arguments.  Where the reference
+        passes them beside `transformer_layers_kwargs` (a duplicate there is a TypeError), this engine lets the kwargs override the head
+        sizes (`linear_hidden_dim != attention_dim`, hstu.py:186-221, through `nn.DimPlan`) — a superset; a config without such an
+        override is the reference's config."""
+        hd = self.n_factors // self.n_heads
+        tkw = dict(linear_hidden_dim=hd, attention_dim=hd)
+        tkw.update(self._kw(self.transformer_layers_kwargs))
+        tkw.update(session_max_len=self.session_max_len, relative_time_attention=self.relative_time_attention,
+                   relative_pos_attention=self.relative_pos_attention)
+        return tkw
+
+    def _init_data_preparator(self, **extra: tp.Any) -> None:
+        """hstu.py:676-694: a relative time bias needs the batches' timestamps."""
+        if self.relative_time_attention and "add_unix_ts" not in self._kw(self.data_preparator_kwargs):
+            extra["add_unix_ts"] = True
+        super()._init_data_preparator(**extra)
 
     @property
     def require_recommend_context(self) -> bool:

@@ -898,6 +898,65 @@ class DistanceSimilarityModule(nn.Module):
     def item_tower_forward(self, item_embs: torch.Tensor) -> torch.Tensor:
         return item_embs
 
+    # The reference's own methods (similarity.py:84-140).  The engine's stock training step and recommend() never call them — the
+    # logits live inside the fused loss kernels (`rt_sampled_loss_*`, `rt_gemm` + `rt_softmax_ce_rows`) and the ranker
+    # (`rt_topk_score*`) — but they ARE the seam: a subclass that overrides any of them is called exactly where the reference calls it
+    # (`similarity_is_stock`, lightning.TransformerLossModule._loss_via_similarity, models.TransformerModelBase.recommend), and a
+    # callback that asks the stock module for logits (examples/tutorials/utils.py:87-91) gets them.
+    def _get_full_catalog_logits(self, session_embs: torch.Tensor, item_embs: torch.Tensor) -> torch.Tensor:
+        lead = session_embs.shape[:-1]
+        s2 = session_embs.reshape(-1, session_embs.shape[-1])
+        if s2.is_cuda and s2.dtype == torch.float32 and item_embs.is_contiguous():
+            return ops.linear(s2.contiguous(), item_embs).view(*lead, item_embs.shape[0])       # session_embs @ item_embs.T (rt_gemm)
+        return session_embs @ item_embs.T
+
+    def _get_pos_neg_logits(self, session_embs: torch.Tensor, item_embs: torch.Tensor, candidate_item_ids: torch.Tensor) -> torch.Tensor:
+        pos_neg_embs = item_embs[candidate_item_ids]                       # [..., 1 + N, d]
+        return (pos_neg_embs * session_embs.unsqueeze(-2)).sum(-1)         # the same dot products as similarity.py:94, no [.., d, 1] matmul
+
+    def _get_embeddings_norm(self, embeddings: torch.Tensor) -> torch.Tensor:
+        if embeddings.is_cuda and embeddings.dtype == torch.float32:
+            return ops.l2norm(embeddings.reshape(-1, embeddings.shape[-1]).contiguous()).view(embeddings.shape)   # x / max(|x|, 1e-8)
+        norm = torch.norm(embeddings, p=2, dim=-1, keepdim=True)
+        return embeddings / torch.clamp(norm, min=1e-8)
+
+    def forward(self, session_embs: torch.Tensor, item_embs: torch.Tensor,
+                candidate_item_ids: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Logits of the sessions against the whole catalog ([..., V]) or against `candidate_item_ids` ([..., C] -> [..., C])
+        (similarity.py:100-113)."""
+        if self.distance == Distance.COSINE:
+            session_embs = self._get_embeddings_norm(session_embs)
+            item_embs = self._get_embeddings_norm(item_embs)
+        if candidate_item_ids is None:
+            return self._get_full_catalog_logits(session_embs, item_embs)
+        return self._get_pos_neg_logits(session_embs, item_embs, candidate_item_ids)
+
+    def _recommend_u2i(self, user_embs: torch.Tensor, item_embs: torch.Tensor, user_ids: np.ndarray, k: int,
+                       sorted_item_ids_to_recommend: np.ndarray, ui_csr_for_filter: tp.Any) -> tp.Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """similarity.py:115-140 on the HIP ranker: -> (user ids, item ids, scores), the reference's triplet."""
+        from .rank import HipRanker
+
+        ranker = HipRanker(self.distance, item_embs.device, user_embs[torch.as_tensor(user_ids, device=user_embs.device)], item_embs)
+        idx, reco, scores = ranker.rank(np.arange(len(user_ids)), k=k, filter_pairs_csr=ui_csr_for_filter,
+                                        sorted_object_whitelist=sorted_item_ids_to_recommend)
+        return np.asarray(user_ids)[idx], reco, scores
+
+
+_SIMILARITY_SEAM = ("forward", "session_tower_forward", "item_tower_forward", "_get_full_catalog_logits", "_get_pos_neg_logits",
+                    "_get_embeddings_norm", "_recommend_u2i")
+
+
+def similarity_is_stock(sim: tp.Any) -> bool:
+    """True when `sim` computes what the fused kernels compute: the stock `DistanceSimilarityModule`, or a subclass that overrides none
+    of the methods the reference calls (similarity.py:26-64) and owns no parameters.  Anything else — a learned temperature, projection
+    towers, another ranker — is CALLED, not approximated: training logits, validation outputs and recommend() go through its methods."""
+    if not isinstance(sim, DistanceSimilarityModule):
+        return False
+    cls = type(sim)
+    if any(getattr(cls, name, None) is not getattr(DistanceSimilarityModule, name) for name in _SIMILARITY_SEAM):
+        return False
+    return next(iter(sim.parameters()), None) is None
+
 
 def pack_last_items(offsets: torch.Tensor, items: torch.Tensor, rows: torch.Tensor, window: int) -> tp.Tuple[torch.Tensor, ...]:
     """The last `window` items of the sessions `rows` of a CSR store as ONE packed block (plain tensor ops, any device):

@@ -470,6 +470,7 @@ def clear_step_expectations() -> None:
     """Start of a training step (`FlatAdam.zero_grad`): nothing a previous forward pass registered survives into this one."""
     _TABLE_SINK_EXPECTED.clear()
     _TABLE_GRAD_SINK.clear()
+    _TABLE_HOME_CLAIMED.clear()
 
 
 # Data-parallel runs: where a table's dense gradient should be PRODUCED — its segment of the optimiser's flat gradient buffer
@@ -479,11 +480,19 @@ def clear_step_expectations() -> None:
 _TABLE_GRAD_HOME: tp.Dict[int, tp.Callable[[], tp.Optional[torch.Tensor]]] = {}
 
 
+_TABLE_HOME_CLAIMED: tp.Set[int] = set()      # tables whose home view was handed out in THIS step (reset by `clear_step_expectations`)
+
+
 def _new_table_grad(table: torch.Tensor) -> torch.Tensor:
-    home = _TABLE_GRAD_HOME.get(table.data_ptr())
-    if home is not None and table.is_leaf and table.grad is None:      # (a second backward pass of a step accumulates: not in place)
+    """The buffer a loss node writes the table's dense gradient into: the table's home in the flat gradient buffer — at most ONCE per
+    step.  A second loss node on the same leaf table in one backward pass (a plugged loss over two augmented views) gets its
+    own tensor: two nodes writing the same memory would hand autograd two aliases of it, summed to 2 dB instead of dA + dB."""
+    key = table.data_ptr()
+    home = _TABLE_GRAD_HOME.get(key)
+    if home is not None and key not in _TABLE_HOME_CLAIMED and table.is_leaf and table.grad is None:   # (a second backward pass accumulates: not in place)
         g = home()
         if g is not None and g.shape == table.shape and g.device == table.device and g.dtype == table.dtype:
+            _TABLE_HOME_CLAIMED.add(key)
             return g
     return torch.empty_like(table)
 

@@ -181,7 +181,8 @@ def test_reference_checkpoint_loads_and_reproduces_reference_recommendations(nam
                         "lr_schedulers", "hyper_parameters"}
     assert out["hyper_parameters"]["model_config"]["transformer_layers_type"] == ref["hyper_parameters"]["model_config"]["transformer_layers_type"]
     assert out["hyper_parameters"]["dataset_schema"] == ref["hyper_parameters"]["dataset_schema"]
-    assert out["hyper_parameters"]["item_external_ids"] == ref["hyper_parameters"]["item_external_ids"]
+    assert isinstance(out["hyper_parameters"]["item_external_ids"], np.ndarray)         # what the reference's IdMap(...) takes
+    assert list(out["hyper_parameters"]["item_external_ids"]) == list(ref["hyper_parameters"]["item_external_ids"])
     names_ref = [k for k in ref["state_dict"] if (k[len(ckpt.STATE_PREFIX):] in dict(model.torch_model.named_parameters()))]
     names_mine = [ckpt.STATE_PREFIX + n for n, _ in model.torch_model.named_parameters()]
     ref_state, my_state = ref["optimizer_states"][0]["state"], out["optimizer_states"][0]["state"]

@@ -126,3 +126,28 @@ def test_a_world_size_that_does_not_cut_the_buffer_falls_back_to_the_allreduce()
         os.environ.pop("RT_DP_EXCHANGE", None)
     assert opt.sharded and opt.flat_p.numel() % FLAT_QUANTUM == 0
     assert all(opt._use_sharded(w) for w in (2, 3, 4, 5, 6, 7, 8, 16)) and not opt._use_sharded(11) and not opt._use_sharded(1)
+
+
+def _worker_stop_flag(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rectools_amd.models import TransformerModelBase
+
+    dev = torch.device("cpu")
+    # only rank 1's callback asks to stop: every rank must leave the epoch loop together (a rank that stops alone meets
+    # `consolidate_moments()` while the others enter the next epoch's gradient exchange)
+    stop = TransformerModelBase._all_reduce_host([1.0 if rank == 1 else 0.0], "max", dev)[0] > 0.0
+    assert stop
+    assert not TransformerModelBase._all_reduce_host([0.0], "max", dev)[0] > 0.0
+    # ... and the epoch metrics the callbacks decide on are the mean over the ranks, identical everywhere
+    train, val = TransformerModelBase._all_reduce_host([1.0 + rank, 10.0 * (rank + 1)], "mean", dev)
+    assert abs(train - (1.0 + (world - 1) / 2)) < 1e-12 and abs(val - 10.0 * (world + 1) / 2) < 1e-12
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_early_stop_and_epoch_metrics_are_reduced_over_the_ranks(tmp_path):
+    mp.spawn(_worker_stop_flag, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    from rectools_amd.models import TransformerModelBase
+
+    assert TransformerModelBase._all_reduce_host([3.0, 4.0], "mean", torch.device("cpu")) == [3.0, 4.0]      # no process group: as given

@@ -345,3 +345,281 @@ def test_item_net_is_the_sum_of_whatever_blocks_it_is_given():
     torch.testing.assert_close(a.ids_emb.weight - before[0], b.ids_emb.weight - before[1], rtol=1e-5, atol=1e-7)   # same gradient, same Adam path
     reco = model.recommend(users=np.array([10, 30, 40]), dataset=ds, k=3, filter_viewed=True)
     assert len(reco) > 0 and np.isfinite(reco["score"]).all()
+
+
+# ---- similarity_module_type (transformers/base.py:415-421; the contract: similarity.py:26-64) -----------------------------------------
+class TemperatureSimilarity(hnn.DistanceSimilarityModule):
+    """A user's similarity module: the stock distances times a LEARNED scalar temperature, its own ranker scores scaled alike."""
+    u2i_calls = 0
+
+    def __init__(self, distance="dot", init_temperature=1.0, **kwargs):
+        super().__init__(distance, **kwargs)
+        self.log_t = torch.nn.Parameter(torch.tensor(float(np.log(init_temperature))))
+
+    def forward(self, session_embs, item_embs, candidate_item_ids=None):
+        return super().forward(session_embs, item_embs, candidate_item_ids) * torch.exp(self.log_t)
+
+    def _recommend_u2i(self, user_embs, item_embs, user_ids, k, sorted_item_ids_to_recommend, ui_csr_for_filter):
+        type(self).u2i_calls += 1
+        u, i, s = super()._recommend_u2i(user_embs, item_embs, user_ids, k, sorted_item_ids_to_recommend, ui_csr_for_filter)
+        return u, i, s * float(torch.exp(self.log_t))
+
+
+class RenamedSimilarity(hnn.DistanceSimilarityModule):
+    """Overrides nothing the reference calls: still served by the fused kernels."""
+    note = "mine"
+
+
+def test_only_a_module_that_restates_the_stock_methods_is_fused():
+    assert hnn.similarity_is_stock(hnn.DistanceSimilarityModule("cosine"))
+    assert hnn.similarity_is_stock(RenamedSimilarity("dot"))
+    assert not hnn.similarity_is_stock(TemperatureSimilarity("dot", 2.0))
+
+    class Tower(hnn.DistanceSimilarityModule):
+        def item_tower_forward(self, item_embs):
+            return item_embs * 2.0
+
+    assert not hnn.similarity_is_stock(Tower())
+    assert not hnn.similarity_is_stock(torch.nn.Identity())
+
+
+def _seam_case(loss, dist, seed, N=6, logits_t=1.0):
+    from test_transformer_gpu import _random_case
+
+    return _random_case("sasrec", loss, dist, 12, 32, 2, 3, 40, N, seed, logits_t=logits_t)
+
+
+@pytest.mark.parametrize("loss,dist", [("softmax", "dot"), ("sampled_softmax", "cosine"), ("BCE", "dot"), ("gBCE", "cosine")])
+def test_losses_on_materialised_logits_equal_the_oracle(loss, dist):
+    """The path of a plugged similarity module, host side (pure tensor ops: runs without a GPU): the stock module's `forward` and the
+    reference's loss calculators restated in `TransformerLossModule._calc_*` against the oracle's logits and losses."""
+    from oracle import transformer_oracle as T
+    from test_transformer_gpu import build_hip_model
+
+    cfg, batch = _seam_case(loss, dist, 3, logits_t=0.5)
+    torch.manual_seed(0)
+    lm = build_hip_model(cfg, device="cpu")
+    hl.xavier_normal_init(lm.torch_model)
+    params = {k: v.detach().clone() for k, v in lm.torch_model.state_dict().items()}
+    with torch.no_grad():
+        sess = T.encode_sessions(cfg, params, batch)
+        want_logits = T.batch_logits(cfg, params, batch)
+        want = T.training_loss(cfg, params, batch)
+        table = T.item_table(params)
+        got, logits = lm._loss_via_similarity(table, sess, batch["y"], batch["yw"], batch.get("negatives"))
+    if loss == "sampled_softmax":        # the reference's calculator swaps columns 0 and 1 in place (lightning.py:209)
+        logits = torch.cat([logits[..., 1:2], logits[..., 0:1], logits[..., 2:]], -1)
+    torch.testing.assert_close(logits, want_logits, rtol=1e-5, atol=1e-6)
+    assert abs(float(got) - float(want)) <= 1e-6 * abs(float(want)) + 1e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("loss,dist", [("softmax", "dot"), ("sampled_softmax", "cosine"), ("gBCE", "dot")])
+def test_a_learned_temperature_changes_the_loss_exactly_as_the_oracle_with_that_temperature(loss, dist):
+    """`logits * tau` is the oracle's `logits / logits_t` with logits_t / tau: loss, every parameter gradient and d loss / d log tau
+    (autograd through the oracle with logits_t as a tensor) — the plugged module's `forward` is what the training step calls."""
+    from oracle import transformer_oracle as T
+    from test_transformer_gpu import _close, build_hip_model
+
+    tau, t0 = 1.7, 0.5
+    cfg, batch = _seam_case(loss, dist, 5, logits_t=t0)
+    torch.manual_seed(100)
+    lm = build_hip_model(cfg)
+    hl.xavier_normal_init(lm.torch_model)
+    lm.torch_model.similarity_module = TemperatureSimilarity(dist, tau).cuda()
+    assert not lm.similarity_is_stock
+    params = {k: v.detach().cpu().clone() for k, v in lm.torch_model.state_dict().items() if "similarity_module" not in k}
+    log_t = torch.tensor(float(np.log(tau)), requires_grad=True)
+    p = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in params.items()}
+    loss_ref = T.training_loss(dict(cfg, logits_t=t0 / torch.exp(log_t)), p, batch)
+    loss_ref.backward()
+    dbatch = {k: v.cuda() for k, v in batch.items()}
+    lm.train()
+    lm.zero_grad()
+    got = lm.training_loss(dbatch)
+    got.backward()
+    assert abs(float(got) - float(loss_ref)) <= 5e-5 * abs(float(loss_ref)) + 5e-6, (float(got), float(loss_ref))
+    g_t = float(lm.torch_model.similarity_module.log_t.grad)
+    assert abs(g_t - float(log_t.grad)) <= 2e-3 * abs(float(log_t.grad)) + 1e-6, (g_t, float(log_t.grad))
+    for n, q in lm.torch_model.named_parameters():
+        if "similarity_module" in n:
+            continue
+        ref = p[n].grad if p[n].grad is not None else torch.zeros_like(p[n])
+        if n == "item_model.item_net_blocks.0.ids_emb.weight":
+            ref = ref.clone(); ref[0] = 0        # the PAD row never receives a gradient (item_net.py:260-264)
+        _close(q.grad, ref, 1e-2, 2e-5 if ref.abs().max() > 1e-6 else 1.0, f"grad {n}")
+    # validation outputs (lightning.py:336-359): the logits a callback receives are the plugged module's
+    lm.eval()
+    vb = {"x": dbatch["x"], "y": dbatch["y"][:, -1:], "yw": dbatch["yw"][:, -1:]}
+    if "negatives" in dbatch:
+        vb["negatives"] = dbatch["negatives"][:, -1:, :]
+    with torch.no_grad():
+        out = lm.validation_step(vb, 0)
+        want = T.batch_logits(dict(cfg, logits_t=t0 / tau), params, batch)[:, -1, :]
+    key = "logits" if loss == "softmax" else "pos_neg_logits"
+    assert set(out) == {"loss", key}
+    if loss == "sampled_softmax":      # handed on as the reference hands them on: columns 0 and 1 swapped in place by its loss calculator
+        want = torch.cat([want[:, 1:2], want[:, 0:1], want[:, 2:]], -1)
+    _close(out[key], want, 5e-4, 5e-5, key)
+
+
+class RecallAtK:
+    """A validation callback written against the reference's contract the way its tutorial's is (examples/tutorials/utils.py:34-133):
+    takes `outputs["logits"]` when the step hands them over, else asks `pl_module.torch_model.similarity_module(session_embs,
+    pl_module.item_embs)`; masks the items of `batch["x"]`; logs the mean hit rate through `pl_module.log_dict`."""
+
+    def __init__(self, k):
+        self.k, self.hits, self.from_outputs, self.from_module = k, [], 0, 0
+
+    def on_validation_batch_end(self, trainer, pl_module, outputs, batch, batch_idx, dataloader_idx=0):
+        if "logits" in outputs:
+            logits = outputs["logits"]
+            self.from_outputs += 1
+        else:
+            last = pl_module.torch_model.encode_sessions(batch, pl_module.item_embs)[:, -1, :]
+            logits = pl_module.torch_model.similarity_module(last, pl_module.item_embs)
+            self.from_module += 1
+        logits = logits.reshape(batch["x"].shape[0], -1)      # (`logits.squeeze()` of lightning.py:351 drops a batch of one)
+        assert logits.shape[1] == pl_module.torch_model.item_model.n_items
+        seen = torch.zeros_like(logits, dtype=torch.bool).scatter_(1, batch["x"], True)
+        seen[:, 0] = True
+        top = logits.masked_fill(seen, float("-inf")).topk(self.k).indices
+        self.hits.append((top == batch["y"]).any(1).float())
+
+    def on_validation_epoch_end(self, trainer, pl_module):
+        pl_module.log_dict({f"recall@{self.k}": float(torch.cat(self.hits).mean())}, on_step=False, on_epoch=True)
+        self.hits.clear()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("loss", ["softmax", "sampled_softmax"])
+def test_a_recall_callback_reads_the_validation_logits(loss):
+    from rectools_amd.dataset import Dataset
+    from rectools_amd.models import SASRecModel
+    from rectools_amd.utils import leave_one_out_mask
+
+    ds = Dataset.construct(_interactions())
+    cb = RecallAtK(3)
+    model = SASRecModel(n_factors=32, n_blocks=1, n_heads=2, session_max_len=4, lr=0.01, batch_size=4, seed=32, dropout_rate=0.0, loss=loss,
+                        n_negatives=3 if loss != "softmax" else 1, get_val_mask_func=leave_one_out_mask, get_trainer_func=duck_trainer,
+                        get_trainer_func_kwargs=dict(max_epochs=2, callbacks=[cb]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model.fit(ds)
+    assert (cb.from_outputs > 0) == (loss == "softmax") and (cb.from_module > 0) == (loss != "softmax")
+    assert all(0.0 <= h["recall@3"] <= 1.0 for h in model.history) and len(model.history) == 2
+    # the logits the callback saw rank like recommend() does: recall@n_items is 1 for every user whose target the model knows
+    lm = model.lightning_model
+    lm.eval()
+    with torch.no_grad():
+        table = lm.torch_model.item_model.get_all_embeddings()
+        x = torch.tensor([[0, 0, 13, 11]], device=table.device)
+        full = lm.torch_model.similarity_module(lm.torch_model.encode_sessions({"x": x}, table)[:, -1, :], table)
+        want = lm.torch_model.encode_sessions({"x": x}, table)[:, -1, :] @ table.T
+    torch.testing.assert_close(full, want, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_a_plugged_similarity_module_trains_and_recommends_through_its_own_methods():
+    """End to end: the temperature is a parameter of the flat Adam buffer and moves; the step's loss is the stock model's at logits_t =
+    1 / tau on the same weights; recommend() returns the module's own triplet (the stock items, scores times tau)."""
+    from rectools_amd.dataset import Dataset
+    from rectools_amd.models import SASRecModel
+
+    ds = Dataset.construct(_interactions())
+    common = dict(n_factors=64, n_blocks=1, n_heads=2, session_max_len=4, lr=0.01, batch_size=4, epochs=3, loss="sampled_softmax",
+                  n_negatives=3, seed=32, dropout_rate=0.0)
+    plugged = SASRecModel(similarity_module_type=TemperatureSimilarity, similarity_module_kwargs={"init_temperature": 2.0}, **common)
+    plugged._build_model_from_dataset(ds)
+    assert not plugged.training_loop().packed            # reference-shaped batches for a module written against the reference
+    stock = SASRecModel(lightning_module_kwargs={"logits_t": 0.5}, **common)
+    stock._build_model_from_dataset(ds)
+    sd = {k: v for k, v in plugged.torch_model.state_dict().items() if "similarity_module" not in k}
+    stock.torch_model.load_state_dict(sd)
+    import os
+    os.environ["RT_PACKED_TRAIN"] = "0"
+    try:
+        loop_a = stock.training_loop()
+    finally:
+        del os.environ["RT_PACKED_TRAIN"]
+    loop_b = plugged.training_loop()
+    stock.lightning_model.train(); plugged.lightning_model.train()
+    loop_a.begin_epoch(0); loop_b.begin_epoch(0)
+    la, lb = float(loop_a.step()), float(loop_b.step())
+    assert abs(la - lb) <= 2e-5 * abs(la), (la, lb)
+    sim = plugged.torch_model.similarity_module
+    assert float(sim.log_t) != float(np.log(2.0))         # Adam moved it
+    plugged._run_epochs(0, 3); plugged.is_fitted = True
+    tau = float(torch.exp(sim.log_t))
+    TemperatureSimilarity.u2i_calls = 0
+    users = np.array([10, 30, 40])
+    reco = plugged.recommend(users=users, dataset=ds, k=3, filter_viewed=True)
+    assert TemperatureSimilarity.u2i_calls == 1
+    twin = SASRecModel(**common)
+    twin._build_model_from_dataset(ds)
+    twin.torch_model.load_state_dict({k: v for k, v in plugged.torch_model.state_dict().items() if "similarity_module" not in k})
+    twin.is_fitted = True
+    want = twin.recommend(users=users, dataset=ds, k=3, filter_viewed=True)
+    assert list(reco.columns) == list(want.columns) and (reco["user_id"].values == want["user_id"].values).all()
+    assert (reco["item_id"].values == want["item_id"].values).all() and (reco["rank"].values == want["rank"].values).all()
+    np.testing.assert_allclose(reco["score"].values, want["score"].values * tau, rtol=1e-5)
+    # it survives persistence with its class and its learned value
+    clone = SASRecModel.loads(plugged.dumps())
+    assert isinstance(clone.torch_model.similarity_module, TemperatureSimilarity)
+    pd.testing.assert_frame_equal(clone.recommend(users=users, dataset=ds, k=3, filter_viewed=True), reco)
+
+
+# ---- round-5 advisor findings, host side ---------------------------------------------------------------------------------------------
+def test_the_trainer_logger_directory_is_the_one_versions_are_numbered_in():
+    """Lightning's CSVLogger: log_dir = save_dir/name/version_N.  `_log_epoch` numbers its own version directory, so the plan takes
+    save_dir/name (or log_dir's parent), and the run's directory never becomes a hyper-parameter of the model."""
+    from rectools_amd.models import SASRecModel
+
+    def trainer_with(logger):
+        return lambda: types.SimpleNamespace(max_epochs=1, min_epochs=1, callbacks=[], logger=logger, enable_progress_bar=False)
+
+    cases = [
+        (types.SimpleNamespace(save_dir="/tmp/x", name="lightning_logs", log_dir="/tmp/x/lightning_logs/version_3"), "/tmp/x/lightning_logs"),
+        (types.SimpleNamespace(save_dir="/tmp/x", name="", log_dir="/tmp/x/version_0"), "/tmp/x"),
+        (types.SimpleNamespace(log_dir="/tmp/y/z/version_12"), "/tmp/y/z"),
+        (types.SimpleNamespace(log_dir="/tmp/plain"), "/tmp/plain"),
+    ]
+    for logger, want in cases:
+        m = SASRecModel(get_trainer_func=trainer_with(logger))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            plan = m._trainer_plan()
+        assert plan["log_dir"] == want, (plan["log_dir"], want)
+        assert "csv_log_dir" not in m.get_config() or m.get_config()["csv_log_dir"] is None
+
+
+def test_a_checkpointed_dataset_schema_reads_like_the_reference_object():
+    from rectools_amd.models import _schema_view
+
+    schema = {"n_interactions": 5, "items": {"n_hot": 7, "features": {"kind": "sparse", "cat_feature_indices": [0, 2], "names": [["f", 1]]}},
+              "users": {"n_hot": 3, "features": None}}
+    v = _schema_view(schema)
+    assert v.items.n_hot == 7 and v.items.features.cat_feature_indices == [0, 2] and v.users.features is None
+    assert v["items"]["features"]["kind"] == "sparse" and "users" in v and len(v) == 3 and v.get("nope") is None
+    assert {k: v[k] for k in v.keys()}["n_interactions"] == 5                          # still readable as the mapping it was saved as
+    with pytest.raises(AttributeError):
+        v.items.nope
+
+
+def test_a_tables_home_in_the_flat_gradient_buffer_is_handed_out_once_per_step():
+    """Two loss nodes on one leaf table in one backward pass must not both write the table's segment of the flat gradient buffer
+    (autograd would add two aliases of the same memory: 2 dB instead of dA + dB)."""
+    from rectools_amd import ops
+
+    table = torch.nn.Parameter(torch.zeros(8, 4))
+    home = torch.zeros(8, 4)
+    ops._TABLE_GRAD_HOME[table.data_ptr()] = lambda: home[:]
+    try:
+        ops.clear_step_expectations()
+        a, b = ops._new_table_grad(table), ops._new_table_grad(table)
+        assert a.data_ptr() == home.data_ptr() and b.data_ptr() != home.data_ptr()
+        ops.clear_step_expectations()                                  # the next step's first node gets the home again
+        assert ops._new_table_grad(table).data_ptr() == home.data_ptr()
+    finally:
+        ops._TABLE_GRAD_HOME.pop(table.data_ptr(), None)
+        ops.clear_step_expectations()

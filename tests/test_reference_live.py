@@ -252,3 +252,68 @@ def test_layer_stacks_draw_their_constructor_init_like_the_reference(kind):
         assert n == m and p.shape == q.shape
         if p.dim() == 1:
             assert torch.equal(p, q), n
+
+
+# ---- SURVEY.md §8f-4, the other direction: the REFERENCE reads what the engine wrote ------------------------------------------------------
+_ENGINE_CKPTS = ["sasrec_catfeat", "bert4rec_ids", "hstu_time_pos", "esasrec_ligr"]
+
+
+@pytest.mark.parametrize("name", _ENGINE_CKPTS)
+def test_the_reference_loads_an_engine_written_checkpoint(name):
+    """tests/golden/engine_ckpt_<name>.ckpt was written by `rectools_amd`'s `save_to_checkpoint` on an MI355X after an epoch of the
+    engine's own training (tests/golden/make_engine_ckpt.py).  The unmodified reference's `load_from_checkpoint`
+    (transformers/base.py:591-654, through the shimmed Trainer, which restores module weights strictly and the torch.optim.Adam state as
+    Lightning does) must build its own classes from the engine's hyper-parameters, take every tensor, accept the optimizer state, and
+    recommend what the engine recommended."""
+    import os
+
+    import torch
+
+    from conftest import GOLDEN_DIR
+
+    path = os.path.join(GOLDEN_DIR, f"engine_ckpt_{name}.ckpt")
+    if not os.path.exists(path):
+        pytest.skip("engine-written fixture not generated yet (tests/golden/make_engine_ckpt.py on the GPU box)")
+    from rectools.dataset import Dataset as RefDataset
+    from rectools.models import BERT4RecModel, HSTUModel, SASRecModel
+    from rectools.dataset.context import get_context as ref_get_context
+
+    from test_checkpoint import _frames
+
+    klass = {"sasrec_catfeat": SASRecModel, "bert4rec_ids": BERT4RecModel, "hstu_time_pos": HSTUModel, "esasrec_ligr": SASRecModel}[name]
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    model = klass.load_from_checkpoint(path)
+    assert model.is_fitted and model.lightning_model.is_fitted
+    # its own classes, named by the engine's hyper-parameters
+    assert type(model.lightning_model).__module__.startswith("rectools.models.nn.transformers")
+    assert type(model.torch_model.transformer_layers).__module__.startswith("rectools.models.nn")
+    sd = model.lightning_model.state_dict()
+    assert sorted(sd) == sorted(ck["state_dict"])
+    for k, v in ck["state_dict"].items():
+        assert torch.equal(sd[k], v), k
+    # the optimizer state went into a torch.optim.Adam over the reference's parameters (load_state_dict validates groups and sizes)
+    opt = model.lightning_model.optimizer
+    state = opt.state_dict()["state"]
+    assert len(state) == len(ck["optimizer_states"][0]["state"]) > 0
+    params = [p for g in opt.param_groups for p in g["params"]]
+    for i, p in enumerate(params):
+        assert state[i]["exp_avg"].shape == p.shape and int(state[i]["step"]) == int(ck["global_step"])
+    assert model.fit_trainer.restored == {"epoch": ck["epoch"], "global_step": ck["global_step"]}
+    # and the frames: the reference's recommend() on the host against the engine's on the MI355X, same weights
+    interactions, features = _frames()
+    ds = (RefDataset.construct(interactions, item_features_df=features, cat_item_features=["f1", "f2"]) if name == "sasrec_catfeat"
+          else RefDataset.construct(interactions))
+    users = [10, 30, 40]
+    ctx = None
+    if model.require_recommend_context:
+        ctx = ref_get_context(pd.DataFrame({"user_id": users, "datetime": ["2021-12-12", "2021-12-13", "2021-12-12"]}))
+    exp = ck["expected_engine"]
+    for tag, rk in (("filter", dict(k=3, filter_viewed=True)), ("nofilter", dict(k=4, filter_viewed=False)),
+                    ("whitelist", dict(k=2, filter_viewed=False, items_to_recommend=[11, 13, 17]))):
+        got = model.recommend(users=users, dataset=ds, context=ctx, **rk)
+        assert got["user_id"].tolist() == exp[tag]["user_id"] and got["item_id"].tolist() == exp[tag]["item_id"], tag
+        assert got["rank"].tolist() == exp[tag]["rank"], tag
+        np.testing.assert_allclose(got["score"].values, np.asarray(exp[tag]["score"], np.float32), rtol=2e-4, atol=2e-5)
+    i2i = model.recommend_to_items(target_items=[11, 12], dataset=ds, k=2)
+    assert i2i["item_id"].tolist() == exp["i2i"]["item_id"]
+    np.testing.assert_allclose(i2i["score"].values, np.asarray(exp["i2i"]["score"], np.float32), rtol=2e-4, atol=2e-5)
