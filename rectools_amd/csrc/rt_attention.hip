@@ -2202,6 +2202,11 @@ bool hstu_v2_wanted() {
   const char* e = getenv("RT_HSTU_ATTN");
   return e == nullptr || strcmp(e, "ring") != 0;
 }
+// ... and of those the streamed decomposition (K6v3, rt_attention_v3.hip) unless RT_HSTU_ATTN=v2 asks for the whole-session workgroups
+bool hstu_v3_wanted() {
+  const char* e = getenv("RT_HSTU_ATTN");
+  return e == nullptr || (strcmp(e, "ring") != 0 && strcmp(e, "v2") != 0);
+}
 rt_varlen::HstuV2Args hstu_v2_args(const AttnArgs& a) {
   rt_varlen::HstuV2Args v{};
   v.q = a.q; v.k = a.k; v.v = a.v; v.ldq = a.ldq; v.ldk = a.ldk; v.ldv = a.ldv; v.o = a.o; v.ldo = a.ldo;
@@ -2227,6 +2232,10 @@ int rt_hstu_attn_varlen_fwd(const float* q, int64_t ldq, const float* k, int64_t
   a.causal = 1; a.keypad = 0;
   a.ts = reinterpret_cast<const long long*>(ts); a.time_w = time_w;
   a.time_thr = reinterpret_cast<const long long*>(time_thr); a.pos_w = pos_w;
+  if (hstu_v3_wanted() && (hd == 32 || hd == 64)) {
+    const int rc = rt_v3_hstu_fwd(hstu_v2_args(a), stream);
+    if (rc != RT_ERR_UNSUPPORTED) return rc;
+  }
   if (hstu_v2_wanted() && (hd == 32 || hd == 64)) {
     const int rc = rt_v2_hstu_fwd(hstu_v2_args(a), stream);
     if (rc != RT_ERR_UNSUPPORTED) return rc;
@@ -2249,6 +2258,10 @@ int rt_hstu_attn_varlen_bwd(const float* q, int64_t ldq, const float* k, int64_t
   a.ts = reinterpret_cast<const long long*>(ts); a.time_w = time_w;
   a.time_thr = reinterpret_cast<const long long*>(time_thr); a.pos_w = pos_w;
   a.d_time_w = d_time_w; a.d_pos_w = d_pos_w;
+  if (hstu_v3_wanted() && (hd == 32 || hd == 64)) {
+    const int rc = rt_v3_hstu_bwd(hstu_v2_args(a), stream);
+    if (rc != RT_ERR_UNSUPPORTED) return rc;
+  }
   if (hstu_v2_wanted() && (hd == 32 || hd == 64)) {
     const int rc = rt_v2_hstu_bwd(hstu_v2_args(a), stream);
     if (rc != RT_ERR_UNSUPPORTED) return rc;

@@ -454,56 +454,6 @@ int launch_fwd(const VarlenArgs& a, int max_len, hipStream_t stream) {
 // arithmetic per element (~40 VALU) and the dK/dV pass's 220 registers are where the next factor is.
 // =================================================================================================================================
 constexpr int HCH = 192;         // partner rows per chunk (6 tiles of 32): two hd-64 images = 148 KB
-constexpr int NBUCK = 147;       // time buckets (every bucket an int64 difference can reach), as rt_attention.hip
-
-// rt_attention.hip's bucket search, bit for bit (largest b with thr[b] <= |dt|: fast-log estimate, two neighbouring thresholds settle it)
-__device__ __forceinline__ int hstu_bucket(const long long* thr, long long dt) {
-  const long long x = dt < 0 ? -dt : dt;
-  int b = (int)(__logf(fmaxf((float)x, 1.f)) * (1.0f / 0.301f));
-  b = b < 0 ? 0 : (b > NBUCK - 1 ? NBUCK - 1 : b);
-  const long long t0 = thr[b], t1 = thr[b < NBUCK - 1 ? b + 1 : b];
-  if (t0 > x) b -= 1;
-  else if (b < NBUCK - 1 && t1 <= x) b += 1;
-  return b < 0 ? 0 : b;
-}
-// The buckets of a lane's eight partner rows of one tile (local rows kl(e) = t0 + 16 (e >> 2) + 4 g + (e & 3), ascending in e).  Timestamps
-// are nondecreasing inside a session (the preparator sorts them: data_preparator.py:73-99), so |dt| against ONE owner is monotone along
-// the partners and so is the bucket: when the first and the last of the eight agree, all eight do — two searches instead of eight
-// wherever the tile is far from the diagonal (bucket widths grow by a factor 1.35).  `owner_is_query`: dt = t_owner - ts_p[kl]; else
-// dt = ts_p[kl] - t_owner (the dK/dV pass: the partners are the queries).
-// `span_valid`: all eight pairs are causal pairs inside the session — only then is dt of one sign over the span (a masked partner on the
-// other side of the diagonal has the opposite sign, and |dt| is not monotone across it): otherwise every element is searched.
-__device__ __forceinline__ void hstu_buckets8(const long long* thr, const long long* ts_p, long long t_owner, bool owner_is_query, int t0, int g,
-                                              int len, bool span_valid, int (&bk)[8]) {
-  auto dt_of = [&](int e) {
-    const int kl = min(t0 + 16 * (e >> 2) + 4 * g + (e & 3), len - 1);
-    return owner_is_query ? t_owner - ts_p[kl] : ts_p[kl] - t_owner;
-  };
-  auto one = [&](int e) { return hstu_bucket(thr, dt_of(e)); };
-  const long long dt0 = dt_of(0), dt7 = dt_of(7);
-  const int b0 = hstu_bucket(thr, dt0), b7 = hstu_bucket(thr, dt7);
-  bk[0] = b0; bk[7] = b7;
-  // the shortcut needs |dt| monotone over the span: both ends on the expected side of zero (a context time BEFORE the last history
-  // stamp, or a preparator that does not sort by time, gives a V-shaped |dt| — then every element is searched, as the reference's
-  // per-element bucketize does: hstu.py:99-113)
-  if (span_valid && b0 == b7 && dt0 >= 0 && dt7 >= 0) {
-#pragma unroll
-    for (int e = 1; e < 7; ++e) bk[e] = b0;
-  } else {
-#pragma unroll
-    for (int e = 1; e < 7; ++e) bk[e] = one(e);
-  }
-}
-__device__ __forceinline__ float hstu_silu(float z) { return z / (1.f + __expf(-z)); }
-__device__ __forceinline__ float hstu_silu_d(float z) { const float s = 1.f / (1.f + __expf(-z)); return s * (1.f + z * (1.f - s)); }
-// both from ONE sigmoid (the dK/dV pass needs the probability and the derivative of the same element); p is hstu_silu's value up to the
-// rounding of z * s against z / (1 + e)
-__device__ __forceinline__ void hstu_silu_both(float z, float& p, float& d) {
-  const float s = 1.f / (1.f + __expf(-z));
-  p = z * s;
-  d = s * (1.f + z * (1.f - s));
-}
-
 // LDS behind the two images: the chunk's partner timestamps, the three tables, (backward) the two bias-gradient accumulators
 struct HstuLdsV2 {
   unsigned char* img0; unsigned char* img1;
@@ -542,34 +492,6 @@ __device__ __forceinline__ void hstu_load_tables(const HstuV2Args& a, const Hstu
     l.pw[j] = a.pos_w != nullptr ? a.pos_w[j] : 0.f;
     if (grads) l.dpw[j] = 0.f;
   }
-}
-
-// Run-length accumulator of one lane's time-bias gradient (rt_attention.hip's TimeGradRun): along a lane's keys the bucket is monotone
-// (timestamps are), equal buckets come in runs: one LDS atomic per run instead of one per score element.
-struct BucketRun {
-  int cur; float acc;
-  __device__ __forceinline__ void init() { cur = -1; acc = 0.f; }
-  __device__ __forceinline__ void add(float* dtw, int b, float v) {
-    if (b != cur) { if (cur >= 0) atomicAdd(dtw + cur, acc); cur = b; acc = v; } else acc += v;
-  }
-  __device__ __forceinline__ void flush(float* dtw) { if (cur >= 0) atomicAdd(dtw + cur, acc); cur = -1; acc = 0.f; }
-};
-
-// Position-bias gradient of one 16-query x 4-key block of a lane row (queries i = 0 .. 15 across the row's lanes, a lane's four
-// consecutive keys j = 0 .. 3): element (i, j) belongs to slot base + j - i of d_pos_w, so the 64 values fall on 19 diagonals.  Summed along
-// the diagonals in registers with row shifts (DPP, no LDS): `main` of lane i = the diagonal through its element 3 (slot base + 3 - i, whole
-// for every lane: what a shift drops in at the row's start is zero), `wrap` of lanes 0 .. 2 = the three diagonals (-13, -14, -15) whose
-// elements the shifts push out of the row's end (slot base - 13 - i).  Two LDS atomics per block instead of four, 16 + 3 live lanes per row
-// instead of 64 values — the atomics were the dQ pass's largest non-matrix cost (one per valid score element).
-__device__ __forceinline__ float row_shr1(float v) {   // lane i of a 16-lane row takes lane i - 1's value, lane 0 takes zero
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float row_ror1(float v) {   // ... lane 0 takes lane 15's
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, false));
-}
-__device__ __forceinline__ void diagonal_sums(const float* d4, int i, float& main, float& wrap) {
-  main = row_shr1(row_shr1(row_shr1(d4[0]) + d4[1]) + d4[2]) + d4[3];
-  wrap = row_ror1(row_ror1(row_ror1(i >= 13 ? d4[0] : 0.f) + (i >= 14 ? d4[1] : 0.f)) + (i >= 15 ? d4[2] : 0.f));
 }
 
 // ---- forward: a lane owns a query; chunks of keys ------------------------------------------------------------------------------------

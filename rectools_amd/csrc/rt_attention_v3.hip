@@ -529,6 +529,344 @@ int launch_bwd(VarlenArgs a, int max_len, hipStream_t stream) {
   return RT_OK;
 }
 
+
+// =================================================================================================================================
+// K6v3 — HSTU's pointwise attention (hstu.py:270-288: silu(q k^T + rab) / L, causal; rab of hstu.py:84-128 in-kernel) on the streamed
+// decomposition above.  K6v2 (rt_attention_v2.hip) gave a (session, head) to ONE workgroup: the launch lasted as long as its longest
+// session (a 512-row session is 280 tile steps on four SIMDs while the average SIMD of the chip holds ~14), and the owner rows'
+// accumulators travelled through memory between its 192-row chunks.  Here a 512-row session is 8 workgroups of 64 owner rows whose
+// accumulators stay in registers across the 64-row chunks; no softmax, so nothing is renormalised.  Tables: the chunk's partner
+// timestamps, the thresholds, the time weights, and the 127 position weights one (owner block, chunk) pair can reach live in the LDS
+// behind the two images (50.8 KB: three workgroups per CU; the dQ pass adds the two bias-gradient accumulators: 55.4 KB, two).
+// =================================================================================================================================
+struct HstuLds {
+  unsigned char* img0; unsigned char* img1;
+  long long* ts_p;       // [CH] timestamps of the chunk's partner rows
+  long long* thr;        // [NBUCK]
+  float* tw;             // [NBUCK + 3]
+  float* pw;             // [128]: pos_w[pw_base .. pw_base + 126] of this (owner block, chunk)
+  float* dtw; float* dpw;   // (dQ pass) [NBUCK + 3], [2 Lw]
+};
+template <int HD>
+__device__ __forceinline__ HstuLds hstu3_carve(unsigned char* smem, int Lw) {
+  using L = Lay<HD>;
+  HstuLds l;
+  l.img0 = smem; l.img1 = smem + (size_t)CH * L::ROW3;
+  unsigned char* p = smem + 2 * (size_t)CH * L::ROW3;
+  l.ts_p = reinterpret_cast<long long*>(p); p += CH * 8;
+  l.thr = reinterpret_cast<long long*>(p); p += NBUCK * 8;
+  l.tw = reinterpret_cast<float*>(p); p += (NBUCK + 3) * 4;
+  l.pw = reinterpret_cast<float*>(p); p += 128 * 4;
+  l.dtw = reinterpret_cast<float*>(p); p += (NBUCK + 3) * 4;
+  l.dpw = reinterpret_cast<float*>(p);
+  return l;
+}
+template <int HD> inline size_t hstu3_lds_bytes(int Lw, bool grads) {
+  return 2 * (size_t)CH * Lay<HD>::ROW3 + CH * 8 + NBUCK * 8 + (NBUCK + 3) * 4 + 128 * 4 + (grads ? (NBUCK + 3) * 4 + (size_t)(2 * Lw) * 4 : 0);
+}
+__device__ __forceinline__ void hstu3_load_tables(const HstuV2Args& a, const HstuLds& l, int tid, bool grads) {
+  const int nw = a.time_thr != nullptr ? (int)a.time_thr[NBUCK] : 1;     // entries of time_w; later buckets read the last one
+  for (int j = tid; j < NBUCK; j += NT) {
+    l.thr[j] = a.time_thr != nullptr ? a.time_thr[j] : 0;
+    l.tw[j] = a.time_w != nullptr ? a.time_w[j < nw ? j : nw - 1] : 0.f;
+    if (grads) l.dtw[j] = 0.f;
+  }
+  if (grads) for (int j = tid; j < 2 * a.Lw - 1; j += NT) l.dpw[j] = 0.f;
+}
+// the position weights of one (owner block, partner chunk) pair: slot Lw - 1 + key - query spans 127 values starting at `base`
+__device__ __forceinline__ void hstu3_load_pos(const HstuV2Args& a, const HstuLds& l, int base, int tid) {
+  if (tid < 128) l.pw[tid] = a.pos_w != nullptr ? a.pos_w[min(max(base + tid, 0), 2 * a.Lw - 2)] : 0.f;
+}
+__device__ __forceinline__ Work hstu3_work(const HstuV2Args& a, int n_ob, bool heavy_last) {
+  const int per = a.B * a.H, o = (int)blockIdx.x / per;
+  Work w;
+  w.ob = heavy_last ? n_ob - 1 - o : o;
+  w.bh = (int)blockIdx.x % per;
+  w.b = w.bh / a.H;
+  w.h = w.bh % a.H;
+  return w;
+}
+
+// ---- forward: a lane owns a query; the keys / values stream ----------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(NT, 3) void v3_hstu_fwd_kernel(HstuV2Args a, int n_ob) {
+  using L = Lay<HD>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const Work wk = hstu3_work(a, n_ob, true);
+  const int h = wk.h, b = wk.b;
+  const long long row0 = a.cu[b];
+  const int n = (int)(a.cu[b + 1] - row0);
+  if (wk.ob * CH >= n) return;
+  const HstuLds l = hstu3_carve<HD>(smem, a.Lw);
+  const long long* tsb = a.ts != nullptr ? a.ts + row0 + b : nullptr;
+  const bool tbias = tsb != nullptr && a.time_w != nullptr, pbias = a.pos_w != nullptr;
+  hstu3_load_tables(a, l, tid, false);
+  const float inv_l = 1.0f / (float)a.Lw;
+
+  const int q0 = wk.ob * CH + 16 * wave;
+  const bool active = q0 < n;
+  const int qrow = q0 + i;
+  const bool qok = qrow < n;
+  const int qsafe = qok ? qrow : n - 1;
+  const long long grow = row0 + qsafe;
+  f32x4 Qraw[L::NCB];
+  if (active) load_owner_raw<HD>(a.q + grow * a.ldq + h * HD, g, Qraw);
+  const long long t_q1 = (tbias && active) ? tsb[qsafe + 1] : 0;
+  P3 Qp[L::NS];
+  f32x4 oT[L::NCB];
+#pragma unroll
+  for (int cb = 0; cb < L::NCB; ++cb) oT[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int c = 0; c <= wk.ob; ++c) {
+    const int c0 = c * CH, len = min(CH, n - c0);
+    if (c > 0) __syncthreads();
+    stage_chunk2<HD>(a.k + (row0 + c0) * a.ldk + h * HD, a.ldk, 1.f, l.img0, a.v + (row0 + c0) * a.ldv + h * HD, a.ldv, 1.f, l.img1, len, tid);
+    if (tbias && tid < CH) l.ts_p[tid] = tsb[c0 + min(tid, len - 1)];
+    const int pw_base = a.Lw - 1 + c0 - (wk.ob * CH + CH - 1);
+    if (pbias) hstu3_load_pos(a, l, pw_base, tid);
+    __syncthreads();
+    if (!active) continue;
+    if (c == 0) split_owner_raw<HD>(Qraw, 1.f, Qp);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int t0 = 32 * s;                         // local first key of the step
+      if (c0 + t0 > q0 + 15 || t0 >= len) break;     // nothing of the step is visible to the tile
+      f32x4 sT[2];
+      rows_times_owner<HD>(l.img0, t0, CH, Qp, i, g, sT);
+      float pr[8];
+      int bk8[8];
+      if (tbias) hstu_buckets8(l.thr, l.ts_p, t_q1, true, t0, g, len, qok && t0 + 19 + 4 * g < len && c0 + t0 + 19 + 4 * g <= qrow, bk8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int kl = t0 + 16 * (e >> 2) + 4 * g + (e & 3), key = c0 + kl;
+        const bool valid = qok && kl < len && key <= qrow;
+        float bias = 0.f;
+        if (tbias) bias += l.tw[bk8[e]];
+        if (pbias) bias += l.pw[a.Lw - 1 + key - qrow - pw_base];
+        pr[e] = valid ? hstu_silu(sT[e >> 2][e & 3] + bias) * inv_l : 0.f;
+      }
+      const P3 Pp = split8(pr);
+      cols_times_slots<HD>(l.img1, t0, CH, Pp, i, g, oT);
+    }
+  }
+  if (active && qok) {
+    float* op = a.o + grow * a.ldo + h * HD;
+#pragma unroll
+    for (int cb = 0; cb < L::NCB; ++cb) *reinterpret_cast<f32x4*>(op + 16 * cb + 4 * g) = oT[cb];
+  }
+}
+
+// ---- backward, pass 1: dQ and the bias gradients.  A lane owns a query -----------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(NT, 2) void v3_hstu_bwd_dq_kernel(HstuV2Args a, int n_ob) {
+  using L = Lay<HD>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const Work wk = hstu3_work(a, n_ob, true);
+  const int h = wk.h, b = wk.b;
+  const long long row0 = a.cu[b];
+  const int n = (int)(a.cu[b + 1] - row0);
+  if (wk.ob * CH >= n) return;
+  const HstuLds l = hstu3_carve<HD>(smem, a.Lw);
+  const long long* tsb = a.ts != nullptr ? a.ts + row0 + b : nullptr;
+  const bool tbias = tsb != nullptr && a.time_w != nullptr, pbias = a.pos_w != nullptr;
+  const bool tgrad = tbias && a.d_time_w != nullptr, pgrad = pbias && a.d_pos_w != nullptr;
+  hstu3_load_tables(a, l, tid, true);
+  const float inv_l = 1.0f / (float)a.Lw;
+
+  const int q0 = wk.ob * CH + 16 * wave;
+  const bool active = q0 < n;
+  const int qrow = q0 + i;
+  const bool qok = qrow < n;
+  const int qsafe = qok ? qrow : n - 1;
+  const long long grow = row0 + qsafe;
+  f32x4 Qraw[L::NCB], Draw[L::NCB];
+  if (active) {
+    load_owner_raw<HD>(a.q + grow * a.ldq + h * HD, g, Qraw);
+    load_owner_raw<HD>(a.dout + grow * a.lddo + h * HD, g, Draw);
+  }
+  const long long t_q1 = (tbias && active) ? tsb[qsafe + 1] : 0;
+  P3 Qp[L::NS], Dp[L::NS];
+  f32x4 dqT[L::NCB];
+#pragma unroll
+  for (int cb = 0; cb < L::NCB; ++cb) dqT[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  BucketRun run;
+  run.init();
+
+  for (int c = 0; c <= wk.ob; ++c) {
+    const int c0 = c * CH, len = min(CH, n - c0);
+    if (c > 0) __syncthreads();
+    stage_chunk2<HD>(a.k + (row0 + c0) * a.ldk + h * HD, a.ldk, 1.f, l.img0, a.v + (row0 + c0) * a.ldv + h * HD, a.ldv, 1.f, l.img1, len, tid);
+    if (tbias && tid < CH) l.ts_p[tid] = tsb[c0 + min(tid, len - 1)];
+    const int pw_base = a.Lw - 1 + c0 - (wk.ob * CH + CH - 1);
+    if (pbias) hstu3_load_pos(a, l, pw_base, tid);
+    __syncthreads();
+    if (!active) continue;
+    if (c == 0) { split_owner_raw<HD>(Qraw, 1.f, Qp); split_owner_raw<HD>(Draw, qok ? 1.f : 0.f, Dp); }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int t0 = 32 * s;
+      if (c0 + t0 > q0 + 15 || t0 >= len) break;
+      f32x4 sT[2], dpT[2];
+      rows_times_owner<HD>(l.img0, t0, CH, Qp, i, g, sT);
+      rows_times_owner<HD>(l.img1, t0, CH, Dp, i, g, dpT);
+      float ds[8];
+      int bk8[8];
+      if (tbias) hstu_buckets8(l.thr, l.ts_p, t_q1, true, t0, g, len, qok && t0 + 19 + 4 * g < len && c0 + t0 + 19 + 4 * g <= qrow, bk8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int kl = t0 + 16 * (e >> 2) + 4 * g + (e & 3), key = c0 + kl;
+        const bool valid = qok && kl < len && key <= qrow;
+        float bias = 0.f;
+        int bk = 0;
+        if (tbias) { bk = bk8[e]; bias += l.tw[bk]; }
+        if (pbias) bias += l.pw[a.Lw - 1 + key - qrow - pw_base];
+        const float z = sT[e >> 2][e & 3] + bias;
+        ds[e] = valid ? dpT[e >> 2][e & 3] * inv_l * hstu_silu_d(z) : 0.f;
+        if (valid && tgrad) run.add(l.dtw, bk, ds[e]);
+      }
+      if (pgrad) {
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {      // (invalid elements are zeros: a diagonal is valid or invalid as a whole up to the window's edges)
+          float dmain, dwrap;
+          diagonal_sums(ds + 4 * hb, i, dmain, dwrap);
+          const int base = a.Lw - 1 + c0 + t0 + 16 * hb + 4 * g - q0;
+          if (dmain != 0.f) atomicAdd(l.dpw + min(max(base + 3 - i, 0), 2 * a.Lw - 2), dmain);
+          if (dwrap != 0.f) atomicAdd(l.dpw + min(max(base - 13 - i, 0), 2 * a.Lw - 2), dwrap);
+        }
+      }
+      const P3 Sp = split8(ds);
+      cols_times_slots<HD>(l.img0, t0, CH, Sp, i, g, dqT);       // dQ^T[c][q] += sum_j K[j][c] dS^T[j][q]
+    }
+  }
+  if (active) {
+    if (tgrad) run.flush(l.dtw);
+    if (qok) {
+      float* dqp = a.dq + grow * a.lddq + h * HD;
+#pragma unroll
+      for (int cb = 0; cb < L::NCB; ++cb) *reinterpret_cast<f32x4*>(dqp + 16 * cb + 4 * g) = dqT[cb];
+    }
+  }
+  __syncthreads();
+  if (tgrad) {
+    const int nw = (int)a.time_thr[NBUCK];
+    for (int j = tid; j < NBUCK; j += NT) { const float v = l.dtw[j]; if (v != 0.f) atomicAdd(a.d_time_w + (j < nw ? j : nw - 1), v); }
+  }
+  if (pgrad) for (int j = tid; j < 2 * a.Lw - 1; j += NT) { const float v = l.dpw[j]; if (v != 0.f) atomicAdd(a.d_pos_w + j, v); }
+}
+
+// ---- backward, pass 2: dK, dV.  A lane owns a key; the queries (Q, dO images, their next-action timestamps) stream ------------------------
+template <int HD>
+__global__ __launch_bounds__(NT, 2) void v3_hstu_bwd_dkv_kernel(HstuV2Args a, int n_ob) {
+  using L = Lay<HD>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const Work wk = hstu3_work(a, n_ob, false);             // key block 0 sees every query chunk: heaviest first as it is
+  const int h = wk.h, b = wk.b;
+  const long long row0 = a.cu[b];
+  const int n = (int)(a.cu[b + 1] - row0);
+  if (wk.ob * CH >= n) return;
+  const HstuLds l = hstu3_carve<HD>(smem, a.Lw);
+  const long long* tsb = a.ts != nullptr ? a.ts + row0 + b : nullptr;
+  const bool tbias = tsb != nullptr && a.time_w != nullptr, pbias = a.pos_w != nullptr;
+  hstu3_load_tables(a, l, tid, false);
+  const float inv_l = 1.0f / (float)a.Lw;
+
+  const int k0 = wk.ob * CH + 16 * wave;
+  const bool active = k0 < n;
+  const int krow = k0 + i;
+  const bool kok = krow < n;
+  const int ksafe = kok ? krow : n - 1;
+  const long long grow = row0 + ksafe;
+  f32x4 Kraw[L::NCB], Vraw[L::NCB];
+  if (active) {
+    load_owner_raw<HD>(a.k + grow * a.ldk + h * HD, g, Kraw);
+    load_owner_raw<HD>(a.v + grow * a.ldv + h * HD, g, Vraw);
+  }
+  const long long t_k = (tbias && active) ? tsb[ksafe] : 0;
+  P3 Kp[L::NS], Vp[L::NS];
+  f32x4 dkT[L::NCB], dvT[L::NCB];
+#pragma unroll
+  for (int cb = 0; cb < L::NCB; ++cb) { dkT[cb] = f32x4{0.f, 0.f, 0.f, 0.f}; dvT[cb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  const int n_chunks = (n + CH - 1) / CH;
+  for (int c = wk.ob; c < n_chunks; ++c) {               // query chunks at or behind the key block
+    const int c0 = c * CH, len = min(CH, n - c0);
+    if (c > wk.ob) __syncthreads();
+    stage_chunk2<HD>(a.q + (row0 + c0) * a.ldq + h * HD, a.ldq, 1.f, l.img0, a.dout + (row0 + c0) * a.lddo + h * HD, a.lddo, 1.f, l.img1, len, tid);
+    if (tbias && tid < CH) l.ts_p[tid] = tsb[c0 + min(tid, len - 1) + 1];     // a query's time is its NEXT stamp (hstu.py:96-104)
+    const int pw_base = a.Lw - 1 + wk.ob * CH - (c0 + CH - 1);
+    if (pbias) hstu3_load_pos(a, l, pw_base, tid);
+    __syncthreads();
+    if (!active) continue;
+    if (c == wk.ob) { split_owner_raw<HD>(Kraw, 1.f, Kp); split_owner_raw<HD>(Vraw, 1.f, Vp); }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int t0 = 32 * s;                         // local first query of the step
+      if (t0 >= len) break;
+      if (c0 + t0 + 31 < k0) continue;               // every query of the step lies before every key of the tile
+      f32x4 sm[2], dpm[2];                           // S[q][key], dP[q][key]: register (qb, r) = query c0 + t0 + 16 qb + 4 g + r
+      rows_times_owner<HD>(l.img0, t0, CH, Kp, i, g, sm);
+      rows_times_owner<HD>(l.img1, t0, CH, Vp, i, g, dpm);
+      float pd[8], ds[8];
+      int bk8[8];
+      if (tbias) hstu_buckets8(l.thr, l.ts_p, t_k, false, t0, g, len, kok && t0 + 19 + 4 * g < len && krow <= c0 + t0 + 4 * g, bk8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ql = t0 + 16 * (e >> 2) + 4 * g + (e & 3), q = c0 + ql;
+        const bool valid = kok && ql < len && krow <= q;
+        float bias = 0.f;
+        if (tbias) bias += l.tw[bk8[e]];
+        if (pbias) bias += l.pw[a.Lw - 1 + krow - q - pw_base];
+        const float z = sm[e >> 2][e & 3] + bias;
+        float pz, dz;
+        hstu_silu_both(z, pz, dz);
+        pd[e] = valid ? pz * inv_l : 0.f;
+        ds[e] = valid ? dpm[e >> 2][e & 3] * inv_l * dz : 0.f;
+      }
+      const P3 Pp = split8(pd);
+      cols_times_slots<HD>(l.img1, t0, CH, Pp, i, g, dvT);       // dV^T[c][key] += sum_q dO[q][c] P[q][key]
+      const P3 Sp = split8(ds);
+      cols_times_slots<HD>(l.img0, t0, CH, Sp, i, g, dkT);       // dK^T[c][key] += sum_q Q[q][c] dS[q][key]
+    }
+  }
+  if (active && kok) {
+    float* dkp = a.dk + grow * a.lddk + h * HD;
+    float* dvp = a.dv + grow * a.lddv + h * HD;
+#pragma unroll
+    for (int cb = 0; cb < L::NCB; ++cb) {
+      *reinterpret_cast<f32x4*>(dkp + 16 * cb + 4 * g) = dkT[cb];
+      *reinterpret_cast<f32x4*>(dvp + 16 * cb + 4 * g) = dvT[cb];
+    }
+  }
+}
+
+template <int HD>
+int launch_hstu_fwd(const HstuV2Args& a, hipStream_t stream) {
+  const int n_ob = (a.Lw + CH - 1) / CH;
+  v3_hstu_fwd_kernel<HD><<<a.B * a.H * n_ob, NT, hstu3_lds_bytes<HD>(a.Lw, false), stream>>>(a, n_ob);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+template <int HD>
+int launch_hstu_bwd(const HstuV2Args& a, hipStream_t stream) {
+  const int n_ob = (a.Lw + CH - 1) / CH;
+  const size_t lds_q = hstu3_lds_bytes<HD>(a.Lw, true);
+  if (lds_q > 64 * 1024) {
+    if (lds_q > 160 * 1024) return RT_ERR_UNSUPPORTED;
+    RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&v3_hstu_bwd_dq_kernel<HD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q));
+  }
+  v3_hstu_bwd_dq_kernel<HD><<<a.B * a.H * n_ob, NT, lds_q, stream>>>(a, n_ob);
+  RT_CHECK_LAUNCH();
+  v3_hstu_bwd_dkv_kernel<HD><<<a.B * a.H * n_ob, NT, hstu3_lds_bytes<HD>(a.Lw, false), stream>>>(a, n_ob);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
 }  // namespace
 
 // hd 32 / 64, any session length (the chunks stream): RT_ERR_UNSUPPORTED otherwise — the caller then takes the earlier kernels
@@ -551,5 +889,17 @@ int rt_v3_bidir_fwd(const rt_varlen::VarlenArgs& a, int max_len, bool train, hip
 int rt_v3_bidir_bwd(const rt_varlen::VarlenArgs& a, int max_len, hipStream_t stream) {
   if (a.hd == 64) return launch_bwd<64, false>(a, max_len, stream);
   if (a.hd == 32) return launch_bwd<32, false>(a, max_len, stream);
+  return RT_ERR_UNSUPPORTED;
+}
+
+// K6v3: hd 32 / 64, a session never longer than the window Lw (rt_attention.hip's packed entry points guarantee it)
+int rt_v3_hstu_fwd(const rt_varlen::HstuV2Args& a, hipStream_t stream) {
+  if (a.hd == 64) return launch_hstu_fwd<64>(a, stream);
+  if (a.hd == 32) return launch_hstu_fwd<32>(a, stream);
+  return RT_ERR_UNSUPPORTED;
+}
+int rt_v3_hstu_bwd(const rt_varlen::HstuV2Args& a, hipStream_t stream) {
+  if (a.hd == 64) return launch_hstu_bwd<64>(a, stream);
+  if (a.hd == 32) return launch_hstu_bwd<32>(a, stream);
   return RT_ERR_UNSUPPORTED;
 }

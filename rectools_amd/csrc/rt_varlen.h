@@ -74,3 +74,5 @@ int rt_v3_varlen_fwd(const rt_varlen::VarlenArgs& a, int max_len, bool train, hi
 int rt_v3_varlen_bwd(const rt_varlen::VarlenArgs& a, int max_len, hipStream_t stream);
 int rt_v3_bidir_fwd(const rt_varlen::VarlenArgs& a, int max_len, bool train, hipStream_t stream);
 int rt_v3_bidir_bwd(const rt_varlen::VarlenArgs& a, int max_len, hipStream_t stream);
+int rt_v3_hstu_fwd(const rt_varlen::HstuV2Args& a, hipStream_t stream);
+int rt_v3_hstu_bwd(const rt_varlen::HstuV2Args& a, hipStream_t stream);

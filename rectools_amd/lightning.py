@@ -45,6 +45,32 @@ def gbce_beta(n_negatives: int, n_items: int, gbce_t: float) -> float:
     return alpha * (gbce_t * (1 - 1 / alpha) + 1 / alpha)
 
 
+def fused_loss(table: torch.Tensor, sess2d: torch.Tensor, y: torch.Tensor, w: torch.Tensor, negatives: tp.Optional[torch.Tensor],
+               loss: str, cosine: bool, logits_t: float, gbce_t: float, n_item_extra_tokens: int,
+               n_targets: tp.Optional[int] = None) -> tp.Tuple[torch.Tensor, tp.Optional[torch.Tensor]]:
+    """`get_batch_logits` + the loss calculator (lightning.py:144-212, 301-321) as the fused kernels: -> (loss, logits [M, 1 + N] / logits_t
+    of the sampled losses | None).  table [V, d] (the catalog matrix of THIS step), sess2d [M, d] encoder rows, y / w [M], negatives
+    [M, N].  softmax: `rt_gemm` + `rt_softmax_ce_rows` over the positions with a target; BCE / gBCE / sampled softmax:
+    `rt_sampled_loss_*` (the [M, 1 + N, d] gather never exists).  Shared by `TransformerLossModule` and the reference-side
+    `reference_plugins.HipTransformerLightningModule`."""
+    y = y.reshape(-1)
+    w = w.reshape(-1).contiguous()
+    if loss == "softmax":
+        if cosine:
+            sess2d, table = ops.l2norm(sess2d), ops.l2norm(table)
+        if n_targets is not None:   # the caller counted the targets on the host: no device -> host round trip for the size
+            act = torch.nonzero_static(y, size=int(n_targets)).reshape(-1)
+        else:
+            act = torch.nonzero(y, as_tuple=False).reshape(-1)  # positions with a target (ignore_index = 0)
+        return ops.softmax_loss(sess2d, table, act, y[act].contiguous(), w[act].contiguous(), logits_t), None
+    kind = {"BCE": ops.LOSS_BCE, "gBCE": ops.LOSS_GBCE, "sampled_softmax": ops.LOSS_SAMPLED_SOFTMAX}[loss]
+    beta = 0.0
+    if loss == "gBCE":
+        n_items = table.shape[0] - n_item_extra_tokens
+        beta = gbce_beta(int(negatives.shape[-1]), n_items, gbce_t)
+    return ops.sampled_loss(sess2d, table, y, negatives, w, kind, cosine, logits_t, beta)
+
+
 class _PadRowNoGrad(torch.autograd.Function):
     """Identity on the catalog matrix whose backward zeroes row 0: `nn.Embedding(padding_idx=0)` (item_net.py:260-264) — the reference
     materialises the catalog THROUGH that lookup (`get_all_embeddings`, item_net.py:361-368), so the PAD row never receives a gradient,
@@ -116,22 +142,8 @@ class TransformerLossModule(nn.Module):
     def _loss_from_sessions(self, table: torch.Tensor, sess2d: torch.Tensor, y: torch.Tensor, w: torch.Tensor,
                             negatives: tp.Optional[torch.Tensor], n_targets: tp.Optional[int] = None
                             ) -> tp.Tuple[torch.Tensor, tp.Optional[torch.Tensor]]:
-        y = y.reshape(-1)
-        w = w.reshape(-1).contiguous()
-        if self.loss == "softmax":
-            if self.cosine:
-                sess2d, table = ops.l2norm(sess2d), ops.l2norm(table)
-            if n_targets is not None:   # the caller counted the targets on the host: no device -> host round trip for the size
-                act = torch.nonzero_static(y, size=int(n_targets)).reshape(-1)
-            else:
-                act = torch.nonzero(y, as_tuple=False).reshape(-1)  # positions with a target (ignore_index = 0)
-            return ops.softmax_loss(sess2d, table, act, y[act].contiguous(), w[act].contiguous(), self.logits_t), None
-        kind = {"BCE": ops.LOSS_BCE, "gBCE": ops.LOSS_GBCE, "sampled_softmax": ops.LOSS_SAMPLED_SOFTMAX}[self.loss]
-        beta = 0.0
-        if self.loss == "gBCE":
-            n_items = table.shape[0] - self.n_item_extra_tokens
-            beta = gbce_beta(int(negatives.shape[-1]), n_items, self.gbce_t)
-        return ops.sampled_loss(sess2d, table, y, negatives, w, kind, self.cosine, self.logits_t, beta)
+        return fused_loss(table, sess2d, y, w, negatives, self.loss, self.cosine, self.logits_t, self.gbce_t, self.n_item_extra_tokens,
+                          n_targets)
 
     # ---- a plugged similarity module (`similarity_module_type`, transformers/base.py:415-421) -------------------------------------
     @property

@@ -27,10 +27,11 @@ def _sessions(lens, L, d, seed):
     return ids, ts, qkv.reshape(3, B * L, d), real, cu, ts_packed
 
 
-@pytest.mark.parametrize("impl", ["ring", "v2"])
+@pytest.mark.parametrize("impl", ["ring", "v2", "v3"])
 @pytest.mark.parametrize("H,hd,L,time,pos", [(2, 32, 96, True, True), (4, 64, 130, True, False), (1, 64, 512, True, True), (2, 64, 70, False, True)])
 def test_hstu_varlen_attention_equals_the_padded_kernels(H, hd, L, time, pos, impl, monkeypatch):
-    """impl = "v2": the packed entry points on the bf16-plane kernels (K6v2, RT_HSTU_ATTN=v2; sessions longer than 192 rows walk the
+    """impl = "v3" (the default): the streamed bf16-plane kernels (K6v3: 64 owner rows per workgroup, 64-row chunks, accumulators in
+    registers); impl = "v2": the whole-session workgroups on the same arithmetic (K6v2, RT_HSTU_ATTN=v2; sessions longer than 192 rows walk the
     partner rows in chunks); the padded kernels that make the reference values do not read the switch."""
     from rectools_amd import ops
 

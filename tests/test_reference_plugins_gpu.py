@@ -44,16 +44,23 @@ def _seed(seed=32):
     random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
 
 
-def _run(model_cls, ds, users, plugged, context=None, **kw):
+_P = "rectools_amd.reference_plugins."
+
+
+def _run(model_cls, ds, users, plugged, context=None, everything=False, **kw):
+    """plugged: dotted path of a HIP layer stack (+ the HIP ranker); everything: the lightning module (fused losses, fused Adam) and the
+    id item net as well."""
     from rectools.models.nn.item_net import IdEmbeddingsItemNet
 
-    extra = {}
+    extra = {"item_net_block_types": (IdEmbeddingsItemNet,)}
     if plugged:
-        extra = dict(transformer_layers_type=plugged, similarity_module_type="rectools_amd.reference_plugins.HipDistanceSimilarityModule")
+        extra.update(transformer_layers_type=plugged, similarity_module_type=_P + "HipDistanceSimilarityModule")
+    if everything:
+        extra.update(lightning_module_type=_P + "HipTransformerLightningModule", item_net_block_types=(_P + "HipIdEmbeddingsItemNet",))
+    extra.update(kw)
     _seed()
     model = model_cls.from_config(dict(dropout_rate=0.0, epochs=2, batch_size=8, session_max_len=8, lr=3e-3, deterministic=False,
-                                       item_net_block_types=(IdEmbeddingsItemNet,), get_trainer_func=gpu_trainer,
-                                       recommend_torch_device="cuda", **extra, **kw))
+                                       get_trainer_func=gpu_trainer, recommend_torch_device="cuda", **extra))
     model.fit(ds)
     reco = model.recommend(users, ds, k=5, filter_viewed=True, **({"context": context} if context is not None else {}))
     state = {k: v.detach().cpu() for k, v in model.lightning_model.torch_model.state_dict().items()}
@@ -117,4 +124,69 @@ def test_reference_hstu_with_hip_plugins_trains_and_recommends_like_the_referenc
     kw = dict(n_factors=64, n_heads=2, n_blocks=2, loss="sampled_softmax", n_negatives=5)
     ref = _run(HSTUModel, ds, users, None, context=ctx, **kw)
     hip = _run(HSTUModel, ds, users, "rectools_amd.reference_plugins.HipSTULayers", context=ctx, **kw)
+    _compare(ref, hip)
+
+
+def test_reference_bert4rec_with_the_hip_pre_ln_stack():
+    """bert4rec.py:204-452 with `HipPreLNTransformerLayers`: the reference's own collate masks the items (numpy draws: the same in both
+    runs), the HIP stack encodes under the key-padding mask."""
+    from rectools.dataset import Dataset
+    from rectools.models import BERT4RecModel
+
+    from rectools_amd.reference_plugins import HipPreLNTransformerLayers
+
+    df = _frames(seed=4)
+    ds = Dataset.construct(df)
+    users = np.unique(df["user_id"])
+    kw = dict(n_factors=64, n_heads=2, n_blocks=2, loss="softmax", mask_prob=0.3)
+    ref = _run(BERT4RecModel, ds, users, None, **kw)
+    hip = _run(BERT4RecModel, ds, users, _P + "HipPreLNTransformerLayers", **kw)
+    assert isinstance(hip[0].lightning_model.torch_model.transformer_layers, HipPreLNTransformerLayers)
+    _compare(ref, hip)
+
+
+def test_reference_esasrec_with_the_hip_ligr_stack():
+    """SASRecModel + `LiGRLayers` (ligr.py:109-191, the eSASRec configuration of BASELINE config 5) with `HipLiGRLayers`."""
+    from rectools.dataset import Dataset
+    from rectools.models import SASRecModel
+
+    from rectools_amd.reference_plugins import HipLiGRLayers
+
+    df = _frames(seed=5)
+    ds = Dataset.construct(df)
+    users = np.unique(df["user_id"])
+    lkw = dict(ff_factors_multiplier=4, ff_activation="swiglu", bias_in_ff=False)
+    kw = dict(n_factors=64, n_heads=2, n_blocks=2, loss="sampled_softmax", n_negatives=5, transformer_layers_kwargs=lkw)
+    ref = _run(SASRecModel, ds, users, None, transformer_layers_type="rectools.models.nn.transformers.ligr.LiGRLayers", **kw)
+    hip = _run(SASRecModel, ds, users, _P + "HipLiGRLayers", **kw)
+    assert isinstance(hip[0].lightning_model.torch_model.transformer_layers, HipLiGRLayers)
+    _compare(ref, hip)
+
+
+@pytest.mark.parametrize("loss,dist", [("softmax", "dot"), ("sampled_softmax", "cosine"), ("gBCE", "dot")])
+def test_every_plug_in_at_once(loss, dist):
+    """Layer stack, ranker, lightning module (fused loss kernels + the fused Adam behind a torch.optim.Optimizer), id item net and the
+    device-side sampler selected together on the reference's SASRecModel — against the reference's stock classes fed the SAME negatives
+    (the sampler is plugged into both runs: the reference's own draws come from torch's global generator and cannot be replayed)."""
+    from rectools.dataset import Dataset
+    from rectools.models import SASRecModel
+
+    from rectools_amd import reference_plugins as rp
+
+    df = _frames(seed=6)
+    ds = Dataset.construct(df)
+    users = np.unique(df["user_id"])
+    kw = dict(n_factors=64, n_heads=2, n_blocks=2, loss=loss, n_negatives=6, negative_sampler_type=_P + "HipCatalogUniformSampler",
+              negative_sampler_kwargs={"seed": 11}, similarity_module_kwargs={"distance": dist}, lightning_module_kwargs={"logits_t": 0.5})
+    ref = _run(SASRecModel, ds, users, None, **kw)
+    hip = _run(SASRecModel, ds, users, _P + "HipSASRecTransformerLayers", everything=True, **kw)
+    lm = hip[0].lightning_model
+    assert isinstance(lm, rp.HipTransformerLightningModule) and isinstance(lm.optimizer, rp.FlatAdamOptimizer) and lm._fused()
+    assert isinstance(lm.torch_model.item_model.item_net_blocks[0], rp.HipIdEmbeddingsItemNet)
+    if loss != "softmax":
+        assert isinstance(hip[0].data_preparator.negative_sampler, rp.HipCatalogUniformSampler) and hip[0].data_preparator.negative_sampler.calls > 0
+    # the optimizer state the façade hands Lightning is torch.optim.Adam's: it loads into the stock run's optimizer and back
+    sd = lm.optimizer.state_dict()
+    ref[0].lightning_model.optimizer.load_state_dict(sd)
+    lm.optimizer.load_state_dict(ref[0].lightning_model.optimizer.state_dict())
     _compare(ref, hip)
