@@ -28,6 +28,21 @@ using namespace rt_planes;
 constexpr int CH = 64;     // partner rows per chunk (two 32-row steps) = owner rows per workgroup (4 waves x 16)
 constexpr int NT = 256;    // threads per workgroup
 
+// Ablation builds, RT_V2_ABLATE bit 1024: thread 0 of every workgroup of the forward kernel stamps s_memtime at its phase boundaries
+// (slot 0 entry, 1 session offsets read, 2 + 2 c chunk c staged (behind the barrier), 3 + 2 c chunk c computed, 14 epilogue done, 15 = n
+// << 32 | owner block; 13 / 12 = the device-wide 100 MHz clock at entry / exit) — read back through rt_v3_trace_read (scripts/attn_trace_v3.py): the launch's timeline as the device saw it.
+#ifdef RT_ABLATION_BUILD
+__device__ unsigned long long rt_v3_trace_buf[8192 * 16];
+#define RT_TR(a, slot, val)                                                                                      \
+  do {                                                                                                           \
+    if (RT_ABL(a, 1024) && threadIdx.x == 0 && (slot) < 16 && blockIdx.x < 8192) rt_v3_trace_buf[blockIdx.x * 16 + (slot)] = (val); \
+  } while (0)
+#define RT_NOW() __builtin_readcyclecounter()
+#else
+#define RT_TR(a, slot, val) do {} while (0)
+#define RT_NOW() 0ull
+#endif
+
 // Rows [0, rows) of two [*, ld] fp32 matrices (columns [0, HD) of this head) -> two 64-row LDS images (value * scale, three bf16 planes,
 // K4v2's row layout and swizzle on the LOCAL row index); rows [rows, 64) are zero-filled.  Every load is issued before any split.
 template <int HD>
@@ -83,10 +98,15 @@ __global__ __launch_bounds__(NT, 3) void v3_fwd_kernel(VarlenArgs a, int n_ob) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
+  RT_TR(a, 0, RT_NOW());
+  RT_TR(a, 13, __builtin_amdgcn_s_memrealtime());      // (the device-wide 100 MHz clock: s_memtime counts per XCD)
   const Work wk = work_of(a, n_ob, CAUSAL);
   const int h = wk.h;
   const long long row0 = a.cu[wk.b];
   const int n = (int)(a.cu[wk.b + 1] - row0);
+  RT_TR(a, 15, ((unsigned long long)(unsigned)n << 32) | (unsigned)wk.ob);
+  RT_TR(a, 1, RT_NOW());
+  RT_TR(a, 12, __builtin_amdgcn_s_memrealtime());      // (overwritten at the exit of a workgroup with rows)
   if (wk.ob * CH >= n) return;
   unsigned char* Kimg = smem;
   unsigned char* Vimg = smem + (size_t)CH * L::ROW3;
@@ -118,6 +138,7 @@ __global__ __launch_bounds__(NT, 3) void v3_fwd_kernel(VarlenArgs a, int n_ob) {
       stage_chunk2<HD>(a.k + (row0 + c * CH) * a.ldk + h * HD, a.ldk, 1.f, Kimg, a.v + (row0 + c * CH) * a.ldv + h * HD, a.ldv, 1.f, Vimg,
                        min(CH, n - c * CH), tid);
     if (!RT_ABL(a, 32)) __syncthreads();
+    RT_TR(a, 2 + 2 * c, RT_NOW());
     if (!active || RT_ABL(a, 2)) continue;
     if (c == 0 && !RT_ABL(a, 64)) split_owner_raw<HD>(Qraw, qscale, Qp);
 #pragma unroll
@@ -162,6 +183,7 @@ __global__ __launch_bounds__(NT, 3) void v3_fwd_kernel(VarlenArgs a, int n_ob) {
       const P3 Pp = RT_SPLIT8(a, sc);
       cols_times_slots<HD>(Vimg, 32 * s, CH, Pp, i, g, oT, RT_ABLV(a));      // oT[cb][r]: column 16 cb + 4 g + r of query `qrow`
     }
+    RT_TR(a, 3 + 2 * c, RT_NOW());
   }
   if (!active || RT_ABL(a, 2)) return;
 
@@ -198,6 +220,8 @@ __global__ __launch_bounds__(NT, 3) void v3_fwd_kernel(VarlenArgs a, int n_ob) {
 #pragma unroll
     for (int cb = 0; cb < L::NCB; ++cb) *reinterpret_cast<f32x4*>(op + 16 * cb + 4 * g) = oT[cb] * inv;
   }
+  RT_TR(a, 14, RT_NOW());
+  RT_TR(a, 12, __builtin_amdgcn_s_memrealtime());
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -903,3 +927,15 @@ int rt_v3_hstu_bwd(const rt_varlen::HstuV2Args& a, hipStream_t stream) {
   if (a.hd == 32) return launch_hstu_bwd<32>(a, stream);
   return RT_ERR_UNSUPPORTED;
 }
+
+#ifdef RT_ABLATION_BUILD
+// ablation builds only: the forward kernel's phase stamps (RT_V2_ABLATE bit 1024); zero-fills the buffer afterwards
+extern "C" int rt_v3_trace_read(void* dst, size_t bytes) {
+  const size_t n = bytes < sizeof(unsigned long long) * 8192 * 16 ? bytes : sizeof(unsigned long long) * 8192 * 16;
+  if (hipDeviceSynchronize() != hipSuccess) return RT_ERR_LAUNCH;
+  if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(rt_v3_trace_buf), n) != hipSuccess) return RT_ERR_LAUNCH;
+  static unsigned long long zeros[8192 * 16];
+  if (hipMemcpyToSymbol(HIP_SYMBOL(rt_v3_trace_buf), zeros, sizeof(zeros)) != hipSuccess) return RT_ERR_LAUNCH;
+  return RT_OK;
+}
+#endif

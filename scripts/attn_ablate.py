@@ -84,42 +84,47 @@ MODES = [
     (1 | 64 | 4 | 8 | 16 | 128 | 32, "... without the barriers (v3 only)"),
     (1 | 2 | 64, "launch + session offsets only (every workgroup leaves after its first barrier)"),
 ]
-if "--once" in sys.argv:      # a counter pass's target (rocprofv3 --pmc): 20 launches of each kernel as built, nothing else
-    for _ in range(20):
-        fwd(); bwd()
-    torch.cuda.synchronize()
-    print(f"rows {n} tiles {tiles}")
-    sys.exit(0)
-out = []
-out.append(f"kernels: RT_VARLEN_IMPL={os.environ.get('RT_VARLEN_IMPL', '(default: v3, streamed chunks)')}")
-out.append(f"one C2 batch: {B} sessions x {H} heads, {n} rows (mean {n / B:.0f}), {tiles} executed 16x32 tiles per product pair; "
-           f"useful GFLOP fwd {flop['fwd'] / 1e9:.2f} dq {flop['dq'] / 1e9:.2f} dkv {flop['dkv'] / 1e9:.2f}; "
-           f"algorithmic MB fwd {byts['fwd'] / 1e6:.0f} dq {byts['dq'] / 1e6:.0f} dkv {byts['dkv'] / 1e6:.0f}")
-out.append("")
-out.append("| RT_V2_ABLATE | what runs | v2_fwd µs | v2_bwd_dq µs | v2_bwd_dkv µs |")
-out.append("|---|---|---|---|---|")
-os.environ["RT_V2_ABLATE"] = "0"
-fwd(); bwd(); torch.cuda.synchronize()
-for bits, what in MODES:
-    os.environ["RT_V2_ABLATE"] = str(bits)
-    tf = time_it(fwd)
-    os.environ["RT_V2_ABLATE"] = str(bits | 512)
-    tq = time_it(bwd)
-    os.environ["RT_V2_ABLATE"] = str(bits | 256)
-    tk = time_it(bwd)
-    out.append(f"| {bits} | {what} | {tf:.1f} | {tq:.1f} | {tk:.1f} |")
-os.environ["RT_V2_ABLATE"] = "0"
-peak6 = 2500e12 / 6
-t0 = [float(x) for x in out[5].split("|")[3:6]]
-out.append("")
-out.append("as built, useful flops / time against 2500 / 6 TF: fwd %.3f  dq %.3f  dkv %.3f; algorithmic bytes / time: %.2f / %.2f / %.2f TB/s" % (
-    flop["fwd"] / t0[0] / 1e-6 / peak6, flop["dq"] / t0[1] / 1e-6 / peak6, flop["dkv"] / t0[2] / 1e-6 / peak6,
-    byts["fwd"] / t0[0] / 1e6, byts["dq"] / t0[1] / 1e6, byts["dkv"] / t0[2] / 1e6))
-# matrix-pipe floor: executed MFMA cycles (16 per v_mfma_f32_16x16x32_bf16 and SIMD, MI355X_MICROARCH.md) spread over 1,024 SIMDs at 2.4 GHz
-mf = {"fwd": 48, "dq": 72, "dkv": 96}
-out.append("matrix-pipe floor (executed tiles x MFMAs per tile x 16 cycles / 1024 SIMDs / 2.4 GHz): " +
-           "  ".join(f"{k} {tiles * v * 16 / 1024 / 2.4e3:.1f} µs" for k, v in mf.items()))
-txt = "\n".join(out)
-print(txt)
-if len(sys.argv) > 1 and not sys.argv[1].startswith("--"):
-    open(sys.argv[1], "w").write(txt + "\n")
+def main():
+    if "--once" in sys.argv:      # a counter pass's target (rocprofv3 --pmc): 20 launches of each kernel as built, nothing else
+        for _ in range(20):
+            fwd(); bwd()
+        torch.cuda.synchronize()
+        print(f"rows {n} tiles {tiles}")
+        sys.exit(0)
+    out = []
+    out.append(f"kernels: RT_VARLEN_IMPL={os.environ.get('RT_VARLEN_IMPL', '(default: v3, streamed chunks)')}")
+    out.append(f"one C2 batch: {B} sessions x {H} heads, {n} rows (mean {n / B:.0f}), {tiles} executed 16x32 tiles per product pair; "
+               f"useful GFLOP fwd {flop['fwd'] / 1e9:.2f} dq {flop['dq'] / 1e9:.2f} dkv {flop['dkv'] / 1e9:.2f}; "
+               f"algorithmic MB fwd {byts['fwd'] / 1e6:.0f} dq {byts['dq'] / 1e6:.0f} dkv {byts['dkv'] / 1e6:.0f}")
+    out.append("")
+    out.append("| RT_V2_ABLATE | what runs | v2_fwd µs | v2_bwd_dq µs | v2_bwd_dkv µs |")
+    out.append("|---|---|---|---|---|")
+    os.environ["RT_V2_ABLATE"] = "0"
+    fwd(); bwd(); torch.cuda.synchronize()
+    for bits, what in MODES:
+        os.environ["RT_V2_ABLATE"] = str(bits)
+        tf = time_it(fwd)
+        os.environ["RT_V2_ABLATE"] = str(bits | 512)
+        tq = time_it(bwd)
+        os.environ["RT_V2_ABLATE"] = str(bits | 256)
+        tk = time_it(bwd)
+        out.append(f"| {bits} | {what} | {tf:.1f} | {tq:.1f} | {tk:.1f} |")
+    os.environ["RT_V2_ABLATE"] = "0"
+    peak6 = 2500e12 / 6
+    t0 = [float(x) for x in out[5].split("|")[3:6]]
+    out.append("")
+    out.append("as built, useful flops / time against 2500 / 6 TF: fwd %.3f  dq %.3f  dkv %.3f; algorithmic bytes / time: %.2f / %.2f / %.2f TB/s" % (
+        flop["fwd"] / t0[0] / 1e-6 / peak6, flop["dq"] / t0[1] / 1e-6 / peak6, flop["dkv"] / t0[2] / 1e-6 / peak6,
+        byts["fwd"] / t0[0] / 1e6, byts["dq"] / t0[1] / 1e6, byts["dkv"] / t0[2] / 1e6))
+    # matrix-pipe floor: executed MFMA cycles (16 per v_mfma_f32_16x16x32_bf16 and SIMD, MI355X_MICROARCH.md) spread over 1,024 SIMDs at 2.4 GHz
+    mf = {"fwd": 48, "dq": 72, "dkv": 96}
+    out.append("matrix-pipe floor (executed tiles x MFMAs per tile x 16 cycles / 1024 SIMDs / 2.4 GHz): " +
+               "  ".join(f"{k} {tiles * v * 16 / 1024 / 2.4e3:.1f} µs" for k, v in mf.items()))
+    txt = "\n".join(out)
+    print(txt)
+    if len(sys.argv) > 1 and not sys.argv[1].startswith("--"):
+        open(sys.argv[1], "w").write(txt + "\n")
+
+
+if __name__ == "__main__":
+    main()
