@@ -2044,6 +2044,28 @@ int rt_debug_attn_trace(unsigned long long* out_host, int n) {
 }
 #endif
 
+}  // extern "C"
+namespace {
+// Without a key-padding mask every position of the [B, L] window is a real row for the attention (left pads carry the state the stack
+// gave them: ligr.py:161-191, net_blocks.py:290-310): the window IS B sessions of L rows, and the packed kernels serve it — hd 32 / 64 /
+// 128 on the bf16 matrix pipe instead of the f32-input MFMA of this file (default eSASRec: hd 128).  RT_VARLEN_IMPL=v1 / v2 keeps the
+// kernels of this file (A/B runs).  lse / delta: [B * L, H] instead of [B, H, L] — the same count, private to the forward / backward pair.
+bool window_on_planes(int hd) {
+  if (hd != 32 && hd != 64 && hd != 128) return false;
+  const char* e = getenv("RT_VARLEN_IMPL");
+  return e == nullptr || e[0] == 0 || strncmp(e, "v3", 2) == 0;
+}
+rt_varlen::VarlenArgs window_args(const AttnArgs& a) {
+  rt_varlen::VarlenArgs w{};
+  w.q = a.q; w.k = a.k; w.v = a.v; w.ldq = a.ldq; w.ldk = a.ldk; w.ldv = a.ldv; w.o = a.o; w.ldo = a.ldo;
+  w.cu = nullptr; w.uniform_len = a.L; w.B = a.B; w.H = a.H; w.hd = a.hd; w.window = 0;
+  w.scale = a.scale; w.p_drop = a.p_drop; w.seed = a.seed; w.lse = a.lse;
+  w.dout = a.dout; w.lddo = a.lddo; w.delta = a.delta; w.dq = a.dq; w.dk = a.dk; w.dv = a.dv; w.lddq = a.lddq; w.lddk = a.lddk; w.lddv = a.lddv;
+  return w;
+}
+}  // namespace
+extern "C" {
+
 // (defined below)
 int rt_mha_fwd_scaled(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                       const int64_t* ids, int32_t B, int32_t H, int32_t L, int32_t hd, float scale, int32_t causal, int32_t keypad,
@@ -2072,6 +2094,11 @@ int rt_mha_fwd_scaled(const float* q, int64_t ldq, const float* k, int64_t ldk, 
   a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.o = o; a.ldo = ldo; a.lse = lse;
   a.ids = reinterpret_cast<const long long*>(ids); a.B = B; a.H = H; a.L = L; a.hd = hd;
   a.causal = causal; a.keypad = keypad; a.scale = scale > 0.f ? scale : 1.0f / sqrtf((float)hd); a.p_drop = p_drop; a.seed = seed;
+  if (!keypad && window_on_planes(hd)) {      // the window as B sessions of L rows on the streamed bf16-plane kernels (K4v3)
+    rt_varlen::VarlenArgs w = window_args(a);
+    const int rc = causal ? rt_v3_varlen_fwd(w, L, p_drop > 0.f, stream) : rt_v3_bidir_fwd(w, L, p_drop > 0.f, stream);
+    if (rc != RT_ERR_UNSUPPORTED) return rc;
+  }
   return dispatch_fwd<MODE_SOFTMAX>(a, stream);
 }
 
@@ -2148,6 +2175,11 @@ int rt_mha_bwd_scaled(const float* q, int64_t ldq, const float* k, int64_t ldk, 
   a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   a.ids = reinterpret_cast<const long long*>(ids); a.B = B; a.H = H; a.L = L; a.hd = hd;
   a.causal = causal; a.keypad = keypad; a.scale = scale > 0.f ? scale : 1.0f / sqrtf((float)hd); a.p_drop = p_drop; a.seed = seed;
+  if (!keypad && window_on_planes(hd)) {
+    rt_varlen::VarlenArgs w = window_args(a);
+    const int rc = causal ? rt_v3_varlen_bwd(w, L, stream) : rt_v3_bidir_bwd(w, L, stream);
+    if (rc != RT_ERR_UNSUPPORTED) return rc;
+  }
   return dispatch_bwd<MODE_SOFTMAX>(a, stream);
 }
 

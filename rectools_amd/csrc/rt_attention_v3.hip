@@ -43,13 +43,29 @@ __device__ unsigned long long rt_v3_trace_buf[8192 * 16];
 #define RT_NOW() 0ull
 #endif
 
-// Rows [0, rows) of two [*, ld] fp32 matrices (columns [0, HD) of this head) -> two 64-row LDS images (value * scale, three bf16 planes,
+// Partner rows per chunk: 64 (two 32-row steps) up to hd 64; 32 at hd 128, where a row's three planes are 768 bytes (two 32-row images
+// = 48 KB, as two 64-row ones at hd 64).
+constexpr int chunk_rows(int hd) { return hd > 64 ? 32 : 64; }
+
+// Session b of a launch: rows cu[b] .. cu[b+1] - 1, or — cu == NULL — `uniform_len` rows each (the padded [B, L] window seen as B
+// sessions of L rows: rt_mha_fwd / rt_mha_bwd without a key-padding mask).
+__device__ __forceinline__ void session_rows(const VarlenArgs& a, int b, long long& row0, int& n) {
+  if (a.cu != nullptr) {
+    row0 = a.cu[b];
+    n = (int)(a.cu[b + 1] - row0);
+  } else {
+    row0 = (long long)b * a.uniform_len;
+    n = a.uniform_len;
+  }
+}
+
+// Rows [0, rows) of two [*, ld] fp32 matrices (columns [0, HD) of this head) -> two ROWS-row LDS images (value * scale, three bf16 planes,
 // K4v2's row layout and swizzle on the LOCAL row index); rows [rows, 64) are zero-filled.  Every load is issued before any split.
-template <int HD>
+template <int HD, int ROWS = CH>
 __device__ __forceinline__ void stage_chunk2(const float* __restrict__ srcA, long long ldA, float scaleA, unsigned char* imgA,
                                              const float* __restrict__ srcB, long long ldB, float scaleB, unsigned char* imgB, int rows, int tid) {
   using L = Lay<HD>;
-  constexpr int C4 = HD / 4, U = CH * C4 / NT;      // float4 per thread and image: 4 (hd 64), 2 (hd 32)
+  constexpr int C4 = HD / 4, U = ROWS * C4 / NT;      // float4 per thread and image: 4 (hd 64 / 64 rows, hd 128 / 32 rows), 2 (hd 32)
   f32x4 xa[U], xb[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -93,8 +109,9 @@ __device__ __forceinline__ Work work_of(const VarlenArgs& a, int n_ob, bool heav
 // forward: a lane owns a query; the session's keys / values stream through the chunk images
 // ---------------------------------------------------------------------------------------------------------------------------------
 template <int HD, bool TRAIN, bool CAUSAL>
-__global__ __launch_bounds__(NT, 3) void v3_fwd_kernel(VarlenArgs a, int n_ob) {
+__global__ __launch_bounds__(NT, HD > 64 ? 2 : 3) void v3_fwd_kernel(VarlenArgs a, int n_ob) {
   using L = Lay<HD>;
+  constexpr int CR = chunk_rows(HD);      // partner rows per chunk
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
@@ -102,14 +119,14 @@ __global__ __launch_bounds__(NT, 3) void v3_fwd_kernel(VarlenArgs a, int n_ob) {
   RT_TR(a, 13, __builtin_amdgcn_s_memrealtime());      // (the device-wide 100 MHz clock: s_memtime counts per XCD)
   const Work wk = work_of(a, n_ob, CAUSAL);
   const int h = wk.h;
-  const long long row0 = a.cu[wk.b];
-  const int n = (int)(a.cu[wk.b + 1] - row0);
+  long long row0; int n;
+  session_rows(a, wk.b, row0, n);
   RT_TR(a, 15, ((unsigned long long)(unsigned)n << 32) | (unsigned)wk.ob);
   RT_TR(a, 1, RT_NOW());
   RT_TR(a, 12, __builtin_amdgcn_s_memrealtime());      // (overwritten at the exit of a workgroup with rows)
   if (wk.ob * CH >= n) return;
   unsigned char* Kimg = smem;
-  unsigned char* Vimg = smem + (size_t)CH * L::ROW3;
+  unsigned char* Vimg = smem + (size_t)CR * L::ROW3;
 
   const int q0 = wk.ob * CH + 16 * wave;          // this wave's owner tile
   const bool active = q0 < n;
@@ -131,22 +148,22 @@ __global__ __launch_bounds__(NT, 3) void v3_fwd_kernel(VarlenArgs a, int n_ob) {
 #pragma unroll
   for (int cb = 0; cb < L::NCB; ++cb) oT[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int n_chunks = CAUSAL ? wk.ob + 1 : (n + CH - 1) / CH;
+  const int n_chunks = CAUSAL ? min(wk.ob * CH + CH - 1, n - 1) / CR + 1 : (n + CR - 1) / CR;
   for (int c = 0; c < n_chunks; ++c) {
     if (c > 0 && !RT_ABL(a, 32)) __syncthreads();                  // the previous chunk's readers are done
     if (!RT_ABL(a, 1))
-      stage_chunk2<HD>(a.k + (row0 + c * CH) * a.ldk + h * HD, a.ldk, 1.f, Kimg, a.v + (row0 + c * CH) * a.ldv + h * HD, a.ldv, 1.f, Vimg,
-                       min(CH, n - c * CH), tid);
+      stage_chunk2<HD, CR>(a.k + (row0 + c * CR) * a.ldk + h * HD, a.ldk, 1.f, Kimg, a.v + (row0 + c * CR) * a.ldv + h * HD, a.ldv, 1.f, Vimg,
+                           min(CR, n - c * CR), tid);
     if (!RT_ABL(a, 32)) __syncthreads();
     RT_TR(a, 2 + 2 * c, RT_NOW());
     if (!active || RT_ABL(a, 2)) continue;
     if (c == 0 && !RT_ABL(a, 64)) split_owner_raw<HD>(Qraw, qscale, Qp);
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int t0 = c * CH + 32 * s;            // first key of the step
+    for (int s = 0; s < CR / 32; ++s) {
+      const int t0 = c * CR + 32 * s;            // first key of the step
       if (CAUSAL ? t0 > q0 + 15 : t0 >= n) break;                 // (wave-uniform) nothing of the step is visible to the tile
       f32x4 sT[2];
-      rows_times_owner<HD>(Kimg, 32 * s, CH, Qp, i, g, sT, RT_ABLV(a));      // sT[kb][r]: key t0 + 16 kb + 4 g + r
+      rows_times_owner<HD>(Kimg, 32 * s, CR, Qp, i, g, sT, RT_ABLV(a));      // sT[kb][r]: key t0 + 16 kb + 4 g + r
       float sc[8];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -181,7 +198,7 @@ __global__ __launch_bounds__(NT, 3) void v3_fwd_kernel(VarlenArgs a, int n_ob) {
         for (int cb = 0; cb < L::NCB; ++cb) oT[cb] *= alpha;
       }
       const P3 Pp = RT_SPLIT8(a, sc);
-      cols_times_slots<HD>(Vimg, 32 * s, CH, Pp, i, g, oT, RT_ABLV(a));      // oT[cb][r]: column 16 cb + 4 g + r of query `qrow`
+      cols_times_slots<HD>(Vimg, 32 * s, CR, Pp, i, g, oT, RT_ABLV(a));      // oT[cb][r]: column 16 cb + 4 g + r of query `qrow`
     }
     RT_TR(a, 3 + 2 * c, RT_NOW());
   }
@@ -229,18 +246,19 @@ __global__ __launch_bounds__(NT, 3) void v3_fwd_kernel(VarlenArgs a, int n_ob) {
 // dP - delta) stays in registers and feeds dQ^T = K^T dS^T (transpose reads of the K image).
 // ---------------------------------------------------------------------------------------------------------------------------------
 template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(NT, 3) void v3_bwd_dq_kernel(VarlenArgs a, int n_ob) {
+__global__ __launch_bounds__(NT, HD > 64 ? 1 : 3) void v3_bwd_dq_kernel(VarlenArgs a, int n_ob) {
   using L = Lay<HD>;
+  constexpr int CR = chunk_rows(HD);      // partner rows per chunk
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
   const Work wk = work_of(a, n_ob, CAUSAL);
   const int h = wk.h;
-  const long long row0 = a.cu[wk.b];
-  const int n = (int)(a.cu[wk.b + 1] - row0);
+  long long row0; int n;
+  session_rows(a, wk.b, row0, n);
   if (wk.ob * CH >= n) return;
   unsigned char* Kimg = smem;
-  unsigned char* Vimg = smem + (size_t)CH * L::ROW3;
+  unsigned char* Vimg = smem + (size_t)CR * L::ROW3;
 
   const int q0 = wk.ob * CH + 16 * wave;
   const bool active = q0 < n;
@@ -273,21 +291,21 @@ __global__ __launch_bounds__(NT, 3) void v3_bwd_dq_kernel(VarlenArgs a, int n_ob
 #pragma unroll
   for (int cb = 0; cb < L::NCB; ++cb) dqT[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int n_chunks = CAUSAL ? wk.ob + 1 : (n + CH - 1) / CH;
+  const int n_chunks = CAUSAL ? min(wk.ob * CH + CH - 1, n - 1) / CR + 1 : (n + CR - 1) / CR;
   for (int c = 0; c < n_chunks; ++c) {
     if (c > 0 && !RT_ABL(a, 32)) __syncthreads();
     if (!RT_ABL(a, 1))
-      stage_chunk2<HD>(a.k + (row0 + c * CH) * a.ldk + h * HD, a.ldk, 1.f, Kimg, a.v + (row0 + c * CH) * a.ldv + h * HD, a.ldv, 1.f, Vimg,
-                       min(CH, n - c * CH), tid);
+      stage_chunk2<HD, CR>(a.k + (row0 + c * CR) * a.ldk + h * HD, a.ldk, 1.f, Kimg, a.v + (row0 + c * CR) * a.ldv + h * HD, a.ldv, 1.f, Vimg,
+                           min(CR, n - c * CR), tid);
     if (!RT_ABL(a, 32)) __syncthreads();
     if (!active || RT_ABL(a, 2)) continue;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int t0 = c * CH + 32 * s;
+    for (int s = 0; s < CR / 32; ++s) {
+      const int t0 = c * CR + 32 * s;
       if (CAUSAL ? t0 > q0 + 15 : t0 >= n) break;
       f32x4 sT[2], dpT[2];
-      rows_times_owner<HD>(Kimg, 32 * s, CH, Qp, i, g, sT, RT_ABLV(a));
-      rows_times_owner<HD>(Vimg, 32 * s, CH, Dp, i, g, dpT, RT_ABLV(a));
+      rows_times_owner<HD>(Kimg, 32 * s, CR, Qp, i, g, sT, RT_ABLV(a));
+      rows_times_owner<HD>(Vimg, 32 * s, CR, Dp, i, g, dpT, RT_ABLV(a));
       float ds[8];
       if (RT_ABL(a, 4)) {
 #pragma unroll
@@ -313,7 +331,7 @@ __global__ __launch_bounds__(NT, 3) void v3_bwd_dq_kernel(VarlenArgs a, int n_ob
         }
       }
       const P3 Sp = RT_SPLIT8(a, ds);
-      cols_times_slots<HD>(Kimg, 32 * s, CH, Sp, i, g, dqT, RT_ABLV(a));   // dQ^T[c][q] += sum_j K[j][c] dS^T[j][q]  (scale at the store)
+      cols_times_slots<HD>(Kimg, 32 * s, CR, Sp, i, g, dqT, RT_ABLV(a));   // dQ^T[c][q] += sum_j K[j][c] dS^T[j][q]  (scale at the store)
     }
   }
   if (!active || RT_ABL(a, 2)) return;
@@ -358,8 +376,8 @@ __device__ __forceinline__ void v3_pad_dbv(const VarlenArgs& a, int b, int h, fl
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
   const int bh = b * a.H + h;
-  const long long row0 = a.cu[b];
-  const int n = (int)(a.cu[b + 1] - row0);
+  long long row0; int n;
+  session_rows(a, b, row0, n);
   float* dbv = a.dbv_part + (long long)b * a.H * HD + h * HD;
   const int n_pad = a.window > n ? a.window - n : 0;
   if (n <= 0 || n_pad <= 0) {
@@ -420,8 +438,9 @@ __device__ __forceinline__ void v3_pad_dbv(const VarlenArgs& a, int b, int h, fl
 // dO) with their lse / delta beside them.  Workgroups behind the key blocks sum the pad keys' value-bias gradient (v3_pad_dbv).
 // ---------------------------------------------------------------------------------------------------------------------------------
 template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(NT, 2) void v3_bwd_dkv_kernel(VarlenArgs a, int n_ob) {
+__global__ __launch_bounds__(NT, HD > 64 ? 1 : 2) void v3_bwd_dkv_kernel(VarlenArgs a, int n_ob) {
   using L = Lay<HD>;
+  constexpr int CR = chunk_rows(HD);      // partner rows per chunk
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
@@ -433,13 +452,13 @@ __global__ __launch_bounds__(NT, 2) void v3_bwd_dkv_kernel(VarlenArgs a, int n_o
   }
   const Work wk = work_of(a, n_ob, false);                // key block 0 sees every query chunk: heaviest first as it is
   const int h = wk.h;
-  const long long row0 = a.cu[wk.b];
-  const int n = (int)(a.cu[wk.b + 1] - row0);
+  long long row0; int n;
+  session_rows(a, wk.b, row0, n);
   if (wk.ob * CH >= n) return;
   unsigned char* Qimg = smem;
-  unsigned char* Dimg = smem + (size_t)CH * L::ROW3;
-  float* Ls = reinterpret_cast<float*>(smem + 2 * (size_t)CH * L::ROW3);   // [64] lse * log2(e) of the chunk's queries
-  float* Dl = Ls + CH;                                                      // [64] delta
+  unsigned char* Dimg = smem + (size_t)CR * L::ROW3;
+  float* Ls = reinterpret_cast<float*>(smem + 2 * (size_t)CR * L::ROW3);   // [CR] lse * log2(e) of the chunk's queries
+  float* Dl = Ls + CR;                                                      // [CR] delta
   const float qscale = a.scale * LOG2E;
 
   const int k0 = wk.ob * CH + 16 * wave;           // this wave's key tile
@@ -458,28 +477,29 @@ __global__ __launch_bounds__(NT, 2) void v3_bwd_dkv_kernel(VarlenArgs a, int n_o
 #pragma unroll
   for (int cb = 0; cb < L::NCB; ++cb) { dkT[cb] = f32x4{0.f, 0.f, 0.f, 0.f}; dvT[cb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-  const int n_chunks = (n + CH - 1) / CH;
-  for (int c = CAUSAL ? wk.ob : 0; c < n_chunks; ++c) {      // causal: query chunks at or behind the key block
-    if (c > (CAUSAL ? wk.ob : 0) && !RT_ABL(a, 32)) __syncthreads();
-    const int rows = min(CH, n - c * CH);
+  const int n_chunks = (n + CR - 1) / CR;
+  const int c_first = CAUSAL ? wk.ob * CH / CR : 0;
+  for (int c = c_first; c < n_chunks; ++c) {                 // causal: query chunks at or behind the key block
+    if (c > c_first && !RT_ABL(a, 32)) __syncthreads();
+    const int rows = min(CR, n - c * CR);
     if (!RT_ABL(a, 1)) {
-      stage_chunk2<HD>(a.q + (row0 + c * CH) * a.ldq + h * HD, a.ldq, qscale, Qimg, a.dout + (row0 + c * CH) * a.lddo + h * HD, a.lddo, 1.f, Dimg,
-                       rows, tid);
-      if (tid < CH) {
-        Ls[tid] = tid < rows ? a.lse[(row0 + c * CH + tid) * a.H + h] * LOG2E : 0.f;
-        Dl[tid] = tid < rows ? a.delta[(row0 + c * CH + tid) * a.H + h] : 0.f;
+      stage_chunk2<HD, CR>(a.q + (row0 + c * CR) * a.ldq + h * HD, a.ldq, qscale, Qimg, a.dout + (row0 + c * CR) * a.lddo + h * HD, a.lddo, 1.f, Dimg,
+                           rows, tid);
+      if (tid < CR) {
+        Ls[tid] = tid < rows ? a.lse[(row0 + c * CR + tid) * a.H + h] * LOG2E : 0.f;
+        Dl[tid] = tid < rows ? a.delta[(row0 + c * CR + tid) * a.H + h] : 0.f;
       }
     }
     if (!RT_ABL(a, 32)) __syncthreads();
     if (!active || RT_ABL(a, 2)) continue;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int t0 = c * CH + 32 * s;              // first query of the step
+    for (int s = 0; s < CR / 32; ++s) {
+      const int t0 = c * CR + 32 * s;              // first query of the step
       if (t0 >= n) break;
       if (CAUSAL && t0 + 31 < k0) continue;        // (wave-uniform) every query of the step lies before every key of the tile
       f32x4 sm[2], dpm[2];                         // S[q][key], dP[q][key]: register (qb, r) = query t0 + 16 qb + 4 g + r
-      rows_times_owner<HD>(Qimg, 32 * s, CH, Kp, i, g, sm, RT_ABLV(a));
-      rows_times_owner<HD>(Dimg, 32 * s, CH, Vp, i, g, dpm, RT_ABLV(a));
+      rows_times_owner<HD>(Qimg, 32 * s, CR, Kp, i, g, sm, RT_ABLV(a));
+      rows_times_owner<HD>(Dimg, 32 * s, CR, Vp, i, g, dpm, RT_ABLV(a));
       const bool edge = (CAUSAL && t0 < k0 + 16) || t0 + 31 >= n || k0 + 15 >= n;
       float pd[8], ds[8];
       if (RT_ABL(a, 4)) {
@@ -503,9 +523,9 @@ __global__ __launch_bounds__(NT, 2) void v3_bwd_dkv_kernel(VarlenArgs a, int n_o
         }
       }
       const P3 Pp = RT_SPLIT8(a, pd);
-      cols_times_slots<HD>(Dimg, 32 * s, CH, Pp, i, g, dvT, RT_ABLV(a));    // dV^T[c][key] += sum_q dO[q][c] P~[q][key]
+      cols_times_slots<HD>(Dimg, 32 * s, CR, Pp, i, g, dvT, RT_ABLV(a));    // dV^T[c][key] += sum_q dO[q][c] P~[q][key]
       const P3 Sp = RT_SPLIT8(a, ds);
-      cols_times_slots<HD>(Qimg, 32 * s, CH, Sp, i, g, dkT, RT_ABLV(a));    // dK^T[c][key] += sum_q Q'[q][c] dS[q][key]
+      cols_times_slots<HD>(Qimg, 32 * s, CR, Sp, i, g, dkT, RT_ABLV(a));    // dK^T[c][key] += sum_q Q'[q][c] dS[q][key]
     }
   }
   if (!active || RT_ABL(a, 2)) return;
@@ -527,7 +547,7 @@ inline int v3_ablate_env() { const char* e = getenv("RT_V2_ABLATE"); return e !=
 template <int HD, bool TRAIN, bool CAUSAL>
 int launch_fwd(VarlenArgs a, int max_len, hipStream_t stream) {
   const int n_ob = (max_len + CH - 1) / CH;
-  const size_t lds = 2 * (size_t)CH * Lay<HD>::ROW3;
+  const size_t lds = 2 * (size_t)chunk_rows(HD) * Lay<HD>::ROW3;
 #ifdef RT_ABLATION_BUILD
   a.ablate = v3_ablate_env();
 #endif
@@ -539,7 +559,7 @@ int launch_fwd(VarlenArgs a, int max_len, hipStream_t stream) {
 template <int HD, bool CAUSAL>
 int launch_bwd(VarlenArgs a, int max_len, hipStream_t stream) {
   const int n_ob = (max_len + CH - 1) / CH;
-  const size_t lds = 2 * (size_t)CH * Lay<HD>::ROW3, lds_kv = lds + 2 * CH * sizeof(float);
+  const size_t lds = 2 * (size_t)chunk_rows(HD) * Lay<HD>::ROW3, lds_kv = lds + 2 * chunk_rows(HD) * sizeof(float);
   const bool pad_wgs = CAUSAL && a.dbv_part != nullptr && a.bk != nullptr && a.bv != nullptr;
   int skip = 0;
 #ifdef RT_ABLATION_BUILD
@@ -893,24 +913,28 @@ int launch_hstu_bwd(const HstuV2Args& a, hipStream_t stream) {
 
 }  // namespace
 
-// hd 32 / 64, any session length (the chunks stream): RT_ERR_UNSUPPORTED otherwise — the caller then takes the earlier kernels
+// hd 32 / 64 / 128, any session length (the chunks stream): RT_ERR_UNSUPPORTED otherwise — the caller then takes the earlier kernels
 int rt_v3_varlen_fwd(const rt_varlen::VarlenArgs& a, int max_len, bool train, hipStream_t stream) {
+  if (a.hd == 128) return train ? launch_fwd<128, true, true>(a, max_len, stream) : launch_fwd<128, false, true>(a, max_len, stream);
   if (a.hd == 64) return train ? launch_fwd<64, true, true>(a, max_len, stream) : launch_fwd<64, false, true>(a, max_len, stream);
   if (a.hd == 32) return train ? launch_fwd<32, true, true>(a, max_len, stream) : launch_fwd<32, false, true>(a, max_len, stream);
   return RT_ERR_UNSUPPORTED;
 }
 int rt_v3_varlen_bwd(const rt_varlen::VarlenArgs& a, int max_len, hipStream_t stream) {
+  if (a.hd == 128) return launch_bwd<128, true>(a, max_len, stream);
   if (a.hd == 64) return launch_bwd<64, true>(a, max_len, stream);
   if (a.hd == 32) return launch_bwd<32, true>(a, max_len, stream);
   return RT_ERR_UNSUPPORTED;
 }
 // bidirectional (no causal mask, no pad keys): BERT4Rec's key-padding-masked window on packed rows
 int rt_v3_bidir_fwd(const rt_varlen::VarlenArgs& a, int max_len, bool train, hipStream_t stream) {
+  if (a.hd == 128) return train ? launch_fwd<128, true, false>(a, max_len, stream) : launch_fwd<128, false, false>(a, max_len, stream);
   if (a.hd == 64) return train ? launch_fwd<64, true, false>(a, max_len, stream) : launch_fwd<64, false, false>(a, max_len, stream);
   if (a.hd == 32) return train ? launch_fwd<32, true, false>(a, max_len, stream) : launch_fwd<32, false, false>(a, max_len, stream);
   return RT_ERR_UNSUPPORTED;
 }
 int rt_v3_bidir_bwd(const rt_varlen::VarlenArgs& a, int max_len, hipStream_t stream) {
+  if (a.hd == 128) return launch_bwd<128, false>(a, max_len, stream);
   if (a.hd == 64) return launch_bwd<64, false>(a, max_len, stream);
   if (a.hd == 32) return launch_bwd<32, false>(a, max_len, stream);
   return RT_ERR_UNSUPPORTED;

@@ -80,7 +80,10 @@ template <int HD> struct Lay {
   static constexpr int NS = HD / 32;         // MFMA k-steps over the head dimension
   static constexpr int NCB = HD / 16;        // 16-column blocks of the head dimension
   // XOR mask of the 16-byte unit index of row r (scripts/attn/swizzle_search.py)
-  __device__ static __forceinline__ unsigned swz(int r) { return HD == 64 ? (unsigned)(r & 6) : (unsigned)((r >> 1) & 2); }
+  // (hd 128, 16 units per plane row: unit bit b + 1 <- row bit b, b = 0 .. 2 — `swizzle_search.py 128` finds it conflict free)
+  __device__ static __forceinline__ unsigned swz(int r) {
+    return HD == 128 ? (unsigned)((r & 7) << 1) : HD == 64 ? (unsigned)(r & 6) : (unsigned)((r >> 1) & 2);
+  }
   static size_t image_bytes(int max_len) { return (size_t)(max_len + 1) * ROW3; }   // + the zero row
 };
 

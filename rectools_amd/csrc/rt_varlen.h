@@ -20,6 +20,7 @@ struct VarlenArgs {
   float* dq; float* dk; float* dv; long long lddq, lddk, lddv;
   float* dbv_part;                     // [B, H*hd] per-session partial of the value-bias gradient from the pad keys (or null)
   int ablate;                          // read by -DRT_ABLATION_BUILD builds of rt_attention_v2.hip only (RT_V2_ABLATE), else 0
+  int uniform_len;                     // cu == NULL (rt_attention_v3.hip only): every session is `uniform_len` rows, session b starts at b * uniform_len
 };
 
 // Attention dropout mask, same construction as rt_attention.hip: ONE 32-bit mix per (head, query, PAIR of adjacent keys), 16 bits
