@@ -210,7 +210,11 @@ class _TrainLoop:
         n_blocks = max(int(self.model.n_blocks), 1)
         n_neg = int(self.model.n_negatives or 0) if self.dp.negative_sampler is not None else 0
         rows = (max_rows + 127) // 128 * 128
-        per_row = 4 * d * (12 * n_blocks + 12) + (8 + 4) * (n_neg + 1) + 64
+        # row-sized fp32 buffers live at the peak of a step, in units of d per block: the SASRec block keeps ~12; a Pre-LN block's 4d FFN,
+        # an STU block's 4 x (u, v, q, k) and a LiGR block's gates + three 4d SwiGLU rows keep more (forward state of every block + one
+        # block's backward temporaries) — too small a reservation and the allocator meets new sizes in the timed steps
+        units = {"LiGRLayers": 46, "STULayers": 28, "PreLNTransformerLayers": 24}.get(type(self.lm.torch_model.transformer_layers).__name__, 12)
+        per_row = 4 * d * (units * n_blocks + 12) + (8 + 4) * (n_neg + 1) + 64
         table = 4 * d * int(self.dp.item_id_map.size) * 3
         try:
             block = torch.empty((int(rows * per_row * 1.25) + table,), dtype=torch.uint8, device=self.device)
