@@ -503,9 +503,9 @@ def run_train(args, rank, world, kind="train"):
             fl = 4.0 * n2 * d * B * (2.5 if dom.endswith("bwd") else 1.0)       # dense; causal-useful half is executed
             ms = per_kernel[dom][0] / per_kernel[dom][1]
             tf = fl / (ms * 1e-3) / 1e12
-            # the bf16-plane kernels (rt_attention_v2.hip: head sizes 32 / 64 of the softmax families and of packed HSTU) run six bf16 products per fp32
+            # the bf16-plane kernels (rt_attention_v3.hip / _v2.hip: head sizes 32 / 64 / 128 of the softmax families, 32 / 64 of packed HSTU) run six bf16 products per fp32
             # product; everything else is on the f32-input instruction
-            x6 = (dom.startswith("rt_mha_varlen") and d // H in (32, 64) and os.environ.get("RT_VARLEN_IMPL", "") != "v1") or \
+            x6 = (dom.startswith("rt_mha_varlen") and d // H in (32, 64, 128)) or \
                  (dom.startswith("rt_hstu_attn_varlen") and d // H in (32, 64) and os.environ.get("RT_HSTU_ATTN", "") != "ring")   # K6v2
             peak = MFMA_BF16_PEAK_TF / 6.0 if x6 else MFMA_F32_PEAK_TF
             roof = {"kernel": dom + f" ({what}; bwd x2.5)", "bound": "mfma", "achieved": round(tf, 2),
@@ -878,7 +878,7 @@ def main():
                 out["train_exact_gemm"] = {"value": round(seqs_x * world / wall_x, 2), "unit": "seqs/s", "steps": 40, "warmup": 5,
                                            "ms_per_step": round(wall_x / 40 * 1e3, 4),
                                            "what": "the train leg with RT_GEMM_SPLIT=exact: every GEMM on v_mfma_f32_32x32x2_f32 (the "
-                                                   "packed attention keeps its bf16 planes: RT_VARLEN_IMPL=v1 selects the f32-input kernels)"}
+                                                   "packed attention keeps its bf16 planes)"}
             finally:
                 os.environ.pop("RT_GEMM_SPLIT", None)
             e2e = run_recommend_e2e(info) if world == 1 else None

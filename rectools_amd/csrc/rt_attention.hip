@@ -45,7 +45,7 @@ struct AttnArgs {
   const long long* ids;                    // [B,L] item ids (0 = PAD)
   int B, H, L, hd;
   int causal, keypad;
-  int no_interior;                         // debug knob (RT_ATTN_EDGE=0): always take the masked tile path
+  int no_interior;                         // debug knob: always take the masked tile path (0 in every launch)
   float scale;                             // 1/sqrt(hd) (softmax) ; unused for hstu
   float p_drop; unsigned long long seed;
   // hstu relative bias
@@ -1730,24 +1730,12 @@ inline size_t res_lds_bytes(int hd, int L, int aux_rows, bool hstu, bool grads) 
   const size_t Lp = (size_t)((L + TK - 1) / TK) * TK;   // + Lp/32 tile flags (rounded up to 4) of the DMA variant
   return ((size_t)2 * Lp * (hd + 4) + aux_rows * Lp + (Lp / TK + 3) + (hstu ? hstu_lds_floats(L, grads) : 0)) * 4 + 64;
 }
-// RT_ATTN_DMA=1 selects the loader-wave variant of the resident kernels.  OFF by default: measured on MI355X at the C2 shape
-// (B 128, H 4, L 200, hd 64, p 0.2; whole GPU test suite green with it on) it is a wash — forward 78.4 vs 76.7 us, backward
-// 282 vs 292 us in isolation, 0.46 vs 0.42 ms/step of rt_mha_bwd inside the training step.  The register-staged prologue is
-// ONE load round trip (14 float4 per thread in flight, ~5 us), not the 17 us the ablation suggested; what bounds these
-// kernels is the causal schedule itself: 28 tile pairs on 4 SIMDs as 8 + 8 + 8 + 4, each pair a 32-MFMA dependent chain,
-// a softmax / dropout VALU phase and a second 32-MFMA phase.
-inline bool attn_allow_dma() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("RT_ATTN_DMA"); v = (e && e[0] == '1') ? 1 : 0; }
-  return v == 1;
-}
+// The loader-wave variant of the resident kernels stays compiled out of the dispatch: measured on MI355X at the C2 shape (B 128, H 4,
+// L 200, hd 64, p 0.2; whole GPU test suite green with it on) it was a wash — forward 78.4 vs 76.7 us, backward 282 vs 292 us in
+// isolation (round 2; the switch RT_ATTN_DMA was retired in round 6).
+constexpr bool attn_allow_dma() { return false; }
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-// RT_ATTN_COOP=0 restores the plain heavy + light deal of the resident forward kernel (A/B measurements)
-inline bool attn_allow_coop() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("RT_ATTN_COOP"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v == 1;
-}
+constexpr bool attn_allow_coop() { return true; }      // (the co-operative deal of the resident forward kernel; RT_ATTN_COOP retired in round 6)
 // RT_ATTN_IMPL = auto (default) | ring | res | stream — A/B measurements and the tests that pin one family.
 //   auto:   resident where K,V fit the LDS (every default config: measured faster there, 76 vs 96 us forward at the C2 shape),
 //           else the ring kernels where they apply (hd == 32 / 64, aligned rows: 383 vs 445 us forward, 1.22 vs 1.48 ms backward
@@ -1885,11 +1873,7 @@ int launch_bwd(const AttnArgs& a, hipStream_t stream) {
   return RT_OK;
 }
 
-inline int attn_no_interior() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("RT_ATTN_EDGE"); v = (e && e[0] == '0') ? 1 : 0; }
-  return v;
-}
+constexpr int attn_no_interior() { return 0; }      // (1: always take the masked tile path — a debug knob, RT_ATTN_EDGE, retired in round 6)
 template <int MODE>
 int dispatch_fwd(const AttnArgs& a_in, hipStream_t s) {
   AttnArgs a = a_in; a.no_interior = attn_no_interior();

@@ -441,8 +441,8 @@ int rt_sasrec_block_packed_bwd(const rt_sasrec_block* blk, const float* x, const
                    sp > 1 ? sk_bytes : 0, ws);                   // dW = dy^T in, db = colsum(dy) from the staged dy^T tiles
   };
 
-  // several weight gradients of the same rows as ONE split-K launch + one combine (RT_WGRAD_GROUPED=0: a product and a combine each)
-  static const int grouped_on = [] { const char* e = getenv("RT_WGRAD_GROUPED"); return (e != nullptr && e[0] == '0') ? 0 : 1; }();
+  // several weight gradients of the same rows as ONE split-K launch + one combine (else: a product and a combine each)
+  constexpr int grouped_on = 1;
   auto wgrads = [&](const rt_wgrad_problem* pr, int n) -> int {
     int rc = RT_ERR_UNSUPPORTED;
     if (grouped_on && (d % 128) == 0 && (dff % 128) == 0) {

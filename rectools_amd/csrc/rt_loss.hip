@@ -758,12 +758,7 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
 // needs more than HEAVY_T pairs to have chunks at all
 inline long long heavy_chunk_cap(long long n_pairs) { return n_pairs / HEAVY_CH + n_pairs / HEAVY_T + 2; }
 
-// RT_LOSS_FAST=0 keeps the generic gather loop of the forward kernels (A-B measurements)
-inline bool fwd_fast_allowed() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("RT_LOSS_FAST"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v == 1;
-}
+constexpr bool fwd_fast_allowed() { return true; }      // (the generic gather loop stays for shapes the fast one does not tile)
 
 // stage: 0 = inference forward, 1 = training forward (logits, loss, unit gradients, ranks), 2 = backward
 template <int D4>

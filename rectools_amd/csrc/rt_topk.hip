@@ -1586,17 +1586,13 @@ inline Plan make_plan(int n_users, long long n_cand, int k, int users_per_pass) 
   // LDS budget decides ring depth, list placement and residency (160 KiB per CU).  The ring must keep
   // ~HBM latency x per-CU bandwidth (~80-100 KB) in flight, so: ONE workgroup per CU with the deepest ring
   // that fits (<= 6 stages); lists go to LDS when they still fit next to >= 4 stages.
-  P.lds_lists = (k <= K_LDS_LISTS) && env_int("RT_TOPK_LDS_LISTS", 1) != 0;
+  P.lds_lists = (k <= K_LDS_LISTS);
   if (P.lds_lists && stream_lds_bytes(P.tu, 4, k) > LDS_PER_CU) P.lds_lists = false;
   const int kl = P.lds_lists ? k : 0;
   P.wg_per_cu = 1;
   P.ns = 3;
   for (int ns = 6; ns >= 3; --ns)
     if (stream_lds_bytes(P.tu, ns, kl) <= LDS_PER_CU) { P.ns = ns; break; }
-  const int ns_env = env_int("RT_TOPK_STAGES", 0);
-  if (ns_env >= 3 && ns_env <= 6 && stream_lds_bytes(P.tu, ns_env, kl) <= LDS_PER_CU) P.ns = ns_env;
-  const int wg_env = env_int("RT_TOPK_WG_PER_CU", 0);
-  if (wg_env > 0 && wg_env * stream_lds_bytes(P.tu, P.ns, kl) <= LDS_PER_CU) P.wg_per_cu = wg_env;
   long long target = (long long)P.wg_per_cu * rt_num_cus();
   long long S = (target + P.n_tiles - 1) / P.n_tiles;
   if (S > n_blocks) S = n_blocks;
@@ -1610,7 +1606,7 @@ inline Plan make_plan(int n_users, long long n_cand, int k, int users_per_pass) 
   {
     const int ss = P.S < 64 ? P.S : 64;  // few workgroups x 8 blocks: short lists for the seed kernel
     const long long bs = (long long)ss * 8;
-    if (env_int("RT_TOPK_SEED", 1) != 0 && n_blocks >= 32 * bs && P.n_tiles <= 8) { P.S_seed = ss; P.blocks_seed = bs; }
+    if (n_blocks >= 32 * bs && P.n_tiles <= 8) { P.S_seed = ss; P.blocks_seed = bs; }
   }
   size_t o = 0;
   P.o_gthr = o; o = align_up(o + (size_t)P.n_users_pad * 4, 256);
@@ -1633,7 +1629,7 @@ int launch_stream_nld(const TopkArgs& a_in, dim3 grid, hipStream_t stream) {
   // (not for a phase of a few blocks per workgroup — the seeding prefix: building the filters costs every workgroup more than the handful of
   // exact probes they would save there; measured 168 vs 112 us for the 16-user prefix over 5 M x 512)
   const bool tiny_phase = (a.blk_end - a.blk_begin) <= 8LL * (a.n_seg > 0 ? a.n_seg : 1);
-  a.bloom = (a.filt_hash != nullptr && !tiny_phase && env_int("RT_TOPK_BLOOM", 1) != 0 && lds + (size_t)32 * TU * 128 <= LDS_PER_CU) ? 1 : 0;
+  a.bloom = (a.filt_hash != nullptr && !tiny_phase && lds + (size_t)32 * TU * 128 <= LDS_PER_CU) ? 1 : 0;
   if (a.bloom) lds += (size_t)32 * TU * 128;
   static size_t attr_lds = 0;
   if (lds > 64 * 1024 && lds > attr_lds) {
@@ -1645,12 +1641,12 @@ int launch_stream_nld(const TopkArgs& a_in, dim3 grid, hipStream_t stream) {
   RT_CHECK_LAUNCH();
   return RT_OK;
 }
-// RT_TOPK_LOADERS: 0 = every wave issues and computes, 2 = two dedicated loader waves (default for the small user tiles
+// Loader waves: two dedicated loader waves for the small user tiles (0 = every wave issues and computes)
 // that are HBM-bound; the 128-user tile is MFMA-bound and keeps its issue slots for compute waves only)
 template <int TU, int NS, bool WL, bool LL, bool HM>
 int launch_stream_impl(const TopkArgs& a, dim3 grid, hipStream_t stream) {
   // the coarse pass spends a quarter of the matrix time per chunk: the DMA issue slots weigh as much as the MFMAs even at 128 users
-  static const int loaders = HM ? env_int("RT_TOPK_LOADERS_HM", 2) : env_int("RT_TOPK_LOADERS", TU <= 2 ? 2 : 0);
+  static const int loaders = HM ? (2) : (TU <= 2 ? 2 : 0);
   if constexpr (TU <= 2 || (HM && (8 + 2 * TU + 1) * (NS - 2) < 64)) {   // vmcnt is a 6-bit counter: (8 + 2 TU + 1) pieces x (NS - 2) stages must stay below 64
     if (loaders == 2) return launch_stream_nld<TU, NS, WL, LL, 2, HM>(a, grid, stream);
   }
@@ -2042,15 +2038,13 @@ inline Plan16 make_plan16(int n_users, long long n_cand, int k) {
   P.ns = 3;
   for (int ns = 7; ns >= 3; --ns)
     if (stream16_lds_bytes(ns, k) <= LDS_PER_CU) { P.ns = ns; break; }
-  const int ns_env = env_int("RT_TOPK_STAGES", 0);
-  if (ns_env >= 3 && ns_env <= 7 && stream16_lds_bytes(ns_env, k) <= LDS_PER_CU) P.ns = ns_env;
   long long S = ((long long)rt_num_cus() + P.n_tiles - 1) / P.n_tiles;   // one workgroup per CU owns the whole LDS
   if (S > n_blocks) S = n_blocks;
   if (S < 1) S = 1;
   if (S > 512) S = 512;                                    // topk_select_kernel: a thread owns the heads of <= 4 lists
   P.S = (int)S;
   P.seed_blocks = 0;
-  if (env_int("RT_TOPK_SEED", 1) != 0 && n_blocks >= 32 * S && P.n_tiles <= 16) P.seed_blocks = 2 * S;
+  if (n_blocks >= 32 * S && P.n_tiles <= 16) P.seed_blocks = 2 * S;
   size_t o = 0;
   P.o_gthr = o; o = align_up(o + (size_t)P.n_users_pad * 4, 256);
   const size_t ent = (size_t)2 * P.S * P.n_users_pad * (size_t)k;     // list region of the main pass + of the seeding prefix
@@ -2184,8 +2178,7 @@ static int topk_score_impl(const float* users, int64_t user_stride, const int64_
   if (n_candidates == 0) {
     return hipMemsetAsync(out_counts, 0, sizeof(int32_t) * (size_t)n_users, stream) == hipSuccess ? RT_OK : RT_ERR_LAUNCH;
   }
-  const int impl = env_int("RT_TOPK_IMPL", 2);
-  const bool stream_ok = ts != nullptr || ((impl == 2) && (d % KC == 0));
+  const bool stream_ok = ts != nullptr || (d % KC == 0);      // else: the register-staged engine (any d)
   char* ws = reinterpret_cast<char*>(workspace);
   if (ts == nullptr && stream_ok && wants_tile16(n_users, k, users_per_pass)) {
     // ---- 16-user tile (engine 3): [seeding prefix -> seed] -> main pass -> selection over the merged lists ----
@@ -2212,7 +2205,7 @@ static int topk_score_impl(const float* users, int64_t user_stride, const int64_
       a.list_counts = reinterpret_cast<int*>(ws + Q.o_counts);
       a.n_users_pad = Q.n_users_pad;
       a.gthr = reinterpret_cast<unsigned*>(ws + Q.o_gthr);
-      a.rotate = env_int("RT_TOPK_ROTATE", 1);
+      a.rotate = 1;
       a.debug = 0;
       a.n_seg = Q.S; a.resume = 0;
       a.n_lists_total = Q.seed_blocks > 0 ? 2 * Q.S : Q.S;
@@ -2280,7 +2273,7 @@ static int topk_score_impl(const float* users, int64_t user_stride, const int64_
     a.list_counts = reinterpret_cast<int*>(ws + P.o_counts);
     a.n_users_pad = P.n_users_pad;
     a.gthr = reinterpret_cast<unsigned*>(ws + P.o_gthr);
-    a.rotate = env_int("RT_TOPK_ROTATE", 1);
+    a.rotate = 1;
 #ifdef RT_ABLATION_BUILD
     a.debug = env_int("RT_TOPK_DEBUG", 0);   // 1 = skip selection: only exists in ablation builds (-DRT_ABLATION_BUILD)
 #else

@@ -631,20 +631,24 @@ class LiGRLayer(nn.Module):
         return ops.gated_residual(seqs, g2.weight, g2.bias, f, p)    # seqs + sigmoid(Wg2 seqs + bg2) * drop(ffn)
 
 
-    def forward_packed(self, seqs, B, window, causal, pad_idx, pad_ids, n_real):
+    def forward_packed(self, seqs, B, window, causal, pad_idx, pad_ids, n_real, cu=None):
         """The block over PACKED rows ([Np, d]: real positions + the unused tail of the row block) — exact under key-padding masks: no
-        real query sees a pad key, and nothing else couples rows (ligr.py:66-106 is LayerNorm, Linear, gates, SwiGLU: row-wise).  The
-        attention kernels of this head size work on the [B, L] window: the packed in_proj output is scattered into it (`pad_idx`; pad
-        slots zero, masked as keys through `pad_ids`) and the attention output gathered back — every GEMM, LayerNorm, gate and dropout
-        of the block runs on the packed rows only."""
+        real query sees a pad key, and nothing else couples rows (ligr.py:66-106 is LayerNorm, Linear, gates, SwiGLU: row-wise).
+        cu given (head size 32 / 64 / 128: the streamed packed kernels, K4v3): the attention runs on the packed in_proj output as it
+        is.  Else the [B, L] window kernels: the packed in_proj output is scattered into the window (`pad_idx`; pad slots zero, masked
+        as keys through `pad_ids`) and the attention output gathered back.  Every GEMM, LayerNorm, gate and dropout of the block runs
+        on the packed rows only either way."""
         p = self.p if self.training else 0.0
         ln1, ln2, mha = self.layer_norm_1, self.layer_norm_2, self.multi_head_attn
         g1, g2 = self.gating_linear_1, self.gating_linear_2
         h, seqs = ops.layer_norm_skip(seqs, ln1.weight, ln1.bias, ln1.eps)
         qkv = ops.linear(h, mha.in_proj_weight, mha.in_proj_bias)
-        qkv_w = ops.scatter_rows(qkv, pad_idx, B * window + 1)
-        a_w = ops.mha_packed(qkv_w[:B * window], pad_ids[:B * window], B, mha.n_heads, window, causal, True, p)
-        a = ops.gather_rows(_with_dump_row(a_w), pad_idx)
+        if cu is not None:
+            a = ops.mha_varlen_qkv(qkv, cu, int(cu.numel()) - 1, mha.n_heads, window, causal, p, n_real is not None and int(n_real) == int(seqs.shape[0]))
+        else:
+            qkv_w = ops.scatter_rows(qkv, pad_idx, B * window + 1)
+            a_w = ops.mha_packed(qkv_w[:B * window], pad_ids[:B * window], B, mha.n_heads, window, causal, True, p)
+            a = ops.gather_rows(_with_dump_row(a_w), pad_idx)
         a = mha.out_proj(a)
         seqs = ops.gated_residual(seqs, g1.weight, g1.bias, a, p)
         g, seqs = ops.layer_norm_skip(seqs, ln2.weight, ln2.bias, ln2.eps)
@@ -688,23 +692,29 @@ class LiGRLayers(TransformerLayersBase):
         """Packed rows serve the LiGR stack when pad positions are masked as keys (`use_key_padding_mask=True`): without the mask the
         pad rows of this stack carry state that real queries read (nothing re-zeroes them between blocks, ligr.py:161-191), and the
         padded window has to stay — which is the reference's default for SASRec-style models, eSASRec included."""
-        return bool(keypad) and len(self.transformer_blocks) > 0 and not any(b.generic for b in self.transformer_blocks) \
-            and os.environ.get("RT_PACKED_LIGR", "1") != "0"
+        return bool(keypad) and len(self.transformer_blocks) > 0 and not any(b.generic for b in self.transformer_blocks)
+
+    def _packed_attention_on_rows(self, window: int, causal: bool) -> bool:
+        mha = self.transformer_blocks[0].multi_head_attn
+        d = int(mha.in_proj_weight.shape[1])
+        return ops.mha_varlen_supported(mha.n_heads, d, window) if causal else ops.mha_bidir_supported(mha.n_heads, d, window)
 
     def forward_packed_train(self, seqs, cu, B, window, keypad, rows_real=None, causal=True):
         n_real = int(rows_real) if rows_real is not None else None
-        pad_idx, pad_ids = ops.padded_index(cu, B, window, int(seqs.shape[0]))
+        on_rows = self._packed_attention_on_rows(window, causal)
+        pad_idx, pad_ids = (None, None) if on_rows else ops.padded_index(cu, B, window, int(seqs.shape[0]))
         with ops.active_planes(self._fresh_planes()):
             for blk in self.transformer_blocks:
-                seqs = blk.forward_packed(seqs, B, window, causal, pad_idx, pad_ids, n_real)
+                seqs = blk.forward_packed(seqs, B, window, causal, pad_idx, pad_ids, n_real, cu if on_rows else None)
         return seqs
 
     def forward_last_packed(self, seqs, cu, B, window, keypad, rows_real=None, causal=True):
         """Inference over packed rows: all blocks on the packed rows, then the last row of every session."""
-        pad_idx, pad_ids = ops.padded_index(cu, B, window, int(seqs.shape[0]))
+        on_rows = self._packed_attention_on_rows(window, causal)
+        pad_idx, pad_ids = (None, None) if on_rows else ops.padded_index(cu, B, window, int(seqs.shape[0]))
         with ops.active_planes(self._fresh_planes()):
             for blk in self.transformer_blocks:
-                seqs = blk.forward_packed(seqs, B, window, causal, pad_idx, pad_ids, None)
+                seqs = blk.forward_packed(seqs, B, window, causal, pad_idx, pad_ids, None, cu if on_rows else None)
         return seqs.index_select(0, cu[1:B + 1] - 1)
 
 
@@ -800,7 +810,7 @@ class STULayer(nn.Module):
         (hstu.py:256-262): their u / v / q / k are silu(0) = 0, a pad key adds nothing to any query — the packed rows see exactly what
         they see in the padded window.  With the row count known on the host: ONE autograd node (`ops.stu_layer_packed`); else the ops
         of `forward_modular` without the masks, attention = `ops.hstu_attn_varlen`."""
-        if rows_real is not None and self.output_mlp.bias is not None and os.environ.get("RT_STU_FUSED", "1") != "0":
+        if rows_real is not None and self.output_mlp.bias is not None:
             tw = self.rel_attn.time_weights if self.rel_attn.relative_time_attention else None
             pw = self.rel_attn.pos_weights if self.rel_attn.relative_pos_attention else None
             return ops.stu_layer_packed(seqs, cu, rows_real, ts if tw is not None else None, thr, B, window, self.n_heads, self.hd,

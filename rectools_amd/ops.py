@@ -260,7 +260,7 @@ def _gemm_group(problems: tp.Sequence[tp.Tuple], a_kc: int, b_kc: int) -> None:
        tag=(sum(p[9] * p[10] * p[11] for p in problems), 1, 1))
 
 
-_WGRAD_SPLIT_CAP = int(os.environ.get("RT_WGRAD_SPLITS", "64"))   # experiment knob: upper bound of the wgrad split-K factor
+_WGRAD_SPLIT_CAP = 64   # upper bound of the wgrad split-K factor
 
 
 def _wgrad_splits(k_rows: int, out_rows: int = 0, out_cols: int = 0) -> int:
@@ -438,8 +438,8 @@ _TABLE_GRAD_ON_SIDE: tp.Set[int] = set()      # sinks whose loss half is in flig
 # The table half of the sampled losses' backward (counting sort + gathered row reductions: read by the optimiser only) on the side stream,
 # the embedding backward behind it.  Round 3 measured it equal (69.3 vs 70.2 k seqs/s at C2: the gathers contend with the layer backward);
 # with the row-resident chain kernels (212 workgroups on 256 CUs) and the embedding's sort done ahead of time (RT_PREPARE_AHEAD) it is
-# 85.1 vs 81.9 k seqs/s on one box, 84.1 vs 83.2 k on another (round 4).  RT_LOSS_SIDE=0 keeps everything on the main stream.
-_LOSS_TABLE_ON_SIDE = os.environ.get("RT_LOSS_SIDE", "1") == "1"
+# 85.1 vs 81.9 k seqs/s on one box, 84.1 vs 83.2 k on another (round 4).  (The switch RT_LOSS_SIDE was retired in round 6.)
+_LOSS_TABLE_ON_SIDE = True
 
 
 # Tables whose lookup ran in THIS forward pass (weak references, keyed by storage): only then will an embedding node pick the loss's table
@@ -1805,17 +1805,14 @@ def mha_varlen_qkv_infer(qkv: torch.Tensor, cu: torch.Tensor, B: int, H: int, wi
 
 
 def mha_bidir_supported(n_heads: int, d: int, window: int) -> bool:
-    """`rt_mha_varlen_bidir_*` (bf16-plane kernels): head size 32 / 64, Q-or-K and V images of one (session, head) in the 160 KB of LDS
-    (backward: two images + lse / delta rows)."""
-    hd = d // n_heads
-    n32 = (window + 31) // 32 * 32
-    return hd in (32, 64) and d % n_heads == 0 and 2 * (window + 1) * 6 * hd + 8 * n32 <= 160 * 1024
+    """`rt_mha_varlen_bidir_*` (the streamed bf16-plane kernels, K4v3): head size 32 / 64 / 128, any window (the partner rows stream
+    through 48 KB of LDS; the whole-session-image kernels of round 3 stopped where two images filled the 160 KB)."""
+    return d % n_heads == 0 and d // n_heads in (32, 64, 128)
 
 
 def mha_varlen_supported(n_heads: int, d: int, window: int) -> bool:
-    """`rt_mha_varlen_fwd` serves head sizes 32 / 64 whose K / V image of one (session, head) fits the 160 KB of LDS."""
-    hd = d // n_heads
-    return hd in (32, 64) and d % n_heads == 0 and 2 * ((window + 31) // 32 * 32) * (hd + 1) * 4 <= 160 * 1024
+    """`rt_mha_varlen_fwd / _train_fwd / _bwd`: head size 32 / 64 / 128, any window (K4v3)."""
+    return d % n_heads == 0 and d // n_heads in (32, 64, 128)
 
 
 def sasrec_layer_packed(x: torch.Tensor, cu: torch.Tensor, B: int, H: int, window: int, pad_keys: bool, last_rows: tp.Optional[torch.Tensor],

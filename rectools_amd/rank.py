@@ -255,7 +255,7 @@ class HipRanker:
         # selection slow path is rare; small catalogs keep the 64-user tile with its LDS lists
         h_only = self._h_only_applies(n_subj)
         # (the one-plane pass re-reads the catalog image once per user tile and is bound by that stream: 64-user tiles with their LDS lists)
-        upp2 = upp if upp > 0 else int(os.environ.get("RT_TOPK_TWO_STAGE_UPP", "128" if n_cand >= 500_000 and not h_only else "64"))
+        upp2 = upp if upp > 0 else (128 if n_cand >= 500_000 and not h_only else 64)
         with torch.cuda.device(dev):
             if h_only:
                 self.two_stage_stats["h_only_calls"] += 1

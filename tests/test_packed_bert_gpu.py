@@ -60,31 +60,39 @@ def test_packed_qkv_attention_pair_equals_autograd_per_session(H, hd, p, causal)
         torch.testing.assert_close(inf[:N].cpu().double(), ref.detach(), **tol)
 
 
-def test_bidir_attention_at_the_catalog_window_and_its_limits():
-    """L = 200, hd = 64 (BASELINE config 3's head) fills 156 KB of LDS in the backward; head sizes the bf16-plane kernels do not
-    serve are refused with a status, not served some other way."""
+@pytest.mark.parametrize("H,hd,window,lens", [(4, 64, 200, [200, 1, 199, 200, 31, 128]),          # BASELINE config 3's head and window
+                                               (2, 128, 200, [200, 65, 1, 33, 130]),                 # a 128-column head (eSASRec's)
+                                               (2, 64, 400, [400, 257, 64, 399, 5])])                # a window the whole-image kernels refused
+def test_bidir_attention_at_the_catalog_window_and_its_limits(H, hd, window, lens):
+    """The streamed kernels (K4v3) serve head sizes 32 / 64 / 128 at any window — forward values and (through autograd of the fp64
+    restatement) all three gradients; head sizes they do not tile are refused with a status, not served some other way."""
     from rectools_amd import ops
 
     torch.manual_seed(0)
-    H, hd, window = 4, 64, 200
     d = H * hd
-    lens = [200, 1, 199, 200, 31, 128]
     N = sum(lens); Np = (N + 127) // 128 * 128
     qkv = (torch.randn(Np, 3 * d) * 0.5).cuda().requires_grad_(True)
     cu = torch.tensor(np.r_[0, np.cumsum(lens)], dtype=torch.int64).cuda()
     out = ops.mha_varlen_qkv(qkv, cu, len(lens), H, window, False, 0.0)
-    out.sum().backward()
-    x = qkv.detach().cpu().double()
-    r0 = 0
+    gout = torch.randn(Np, d).cuda()
+    gout[N:] = 0
+    out.backward(gout)
+    x = qkv.detach().cpu().double().requires_grad_(True)
+    r0, refs = 0, []
     for n in lens:
         qh, kh, vh = (x[r0:r0 + n, c * d:(c + 1) * d].view(n, H, hd).transpose(0, 1) for c in range(3))
-        ref = (torch.softmax(qh @ kh.transpose(-1, -2) / 8.0, -1) @ vh).transpose(0, 1).reshape(n, d)
-        torch.testing.assert_close(out[r0:r0 + n].detach().cpu().double(), ref, rtol=3e-4, atol=3e-5)
+        refs.append((torch.softmax(qh @ kh.transpose(-1, -2) / hd ** 0.5, -1) @ vh).transpose(0, 1).reshape(n, d))
         r0 += n
-    assert ops.mha_bidir_supported(4, 256, 200) and not ops.mha_bidir_supported(2, 256, 200) and not ops.mha_bidir_supported(4, 256, 400)
-    bad = torch.zeros(128, 3 * 128, device="cuda")
+    ref = torch.cat(refs)
+    torch.testing.assert_close(out[:N].detach().cpu().double(), ref.detach(), rtol=3e-4, atol=3e-5)
+    ref.backward(gout[:N].cpu().double())
+    g, gr = qkv.grad[:N].cpu().double(), x.grad[:N]
+    torch.testing.assert_close(g, gr, rtol=3e-4, atol=3e-4 * float(gr.abs().max()))
+    assert ops.mha_bidir_supported(4, 256, 200) and ops.mha_bidir_supported(2, 256, 200) and ops.mha_bidir_supported(4, 256, 4000)
+    assert not ops.mha_bidir_supported(16, 256, 200) and not ops.mha_bidir_supported(1, 256, 200)          # heads of 16 / 256 columns
+    bad = torch.zeros(128, 3 * 16, device="cuda")
     with pytest.raises(NotImplementedError):
-        ops.mha_varlen_qkv_infer(bad, cu[:2].clone(), 1, 1, 64, False)        # hd = 128
+        ops.mha_varlen_qkv_infer(bad, cu[:2].clone(), 1, 1, 64, False)        # hd = 16
 
 
 @pytest.mark.parametrize("train", [True, False])
