@@ -417,8 +417,8 @@ int rt_mha_last_fwd_scaled(const float* q, int64_t ldq, const float* k, int64_t 
  * a pad key / value row equals the projection bias in every session and block (the block input is masked to 0), so ONE virtual
  * key per query — logit q.bk / sqrt(hd), value bv, multiplicity window - n_b — reproduces the padded softmax.  bk / bv [H*hd] =
  * in_proj_bias[d:2d] / [2d:3d]; pass NULL for both when pad keys are masked (key-padding masks).  max_len >= the longest session
- * (sizes the LDS image; RT_ERR_UNSUPPORTED when 2 * roundup32(max_len) * (hd + 1) floats exceed 160 KB: take the padded entry
- * points then); window = the reference's session_max_len.  rt_mha_varlen_fwd: hd in {32, 64}. */
+ * (sizes the grid: ceil(max_len / 64) owner blocks per session and head; any length — the partner rows stream through 48 KB of LDS);
+ * window = the reference's session_max_len.  hd in {32, 64, 128}, RT_ERR_UNSUPPORTED otherwise. */
 int rt_mha_varlen_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                       const int64_t* cu_seqlens, const float* bk, const float* bv, int32_t B, int32_t H, int32_t hd,
                       int32_t max_len, int32_t window, float* o, int64_t ldo, rt_stream_t stream);
@@ -439,7 +439,7 @@ int rt_mha_varlen_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, 
                       rt_stream_t stream);
 /* Bidirectional attention inside every packed session (no causal mask, no pad keys): BERT4Rec's key-padding-masked window
  * (torch_backbone.py:254, bert4rec.py:200) on packed rows.  lse != NULL: training forward (dropout, lse [N,H] kept); NULL: inference.
- * bf16-plane kernels only (hd 32 / 64, 12 * hd * (max_len + 1) bytes of LDS <= 160 KB), RT_ERR_UNSUPPORTED otherwise. */
+ * hd in {32, 64, 128}, any max_len; RT_ERR_UNSUPPORTED otherwise. */
 int rt_mha_varlen_bidir_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const int64_t* cu_seqlens,
                             int32_t B, int32_t H, int32_t hd, int32_t max_len, float p_drop, uint64_t seed, float* o, int64_t ldo, float* lse,
                             rt_stream_t stream);
@@ -447,6 +447,25 @@ int rt_mha_varlen_bidir_bwd(const float* q, int64_t ldq, const float* k, int64_t
                             const float* dout, int64_t lddo, const float* lse, const int64_t* cu_seqlens, int32_t B, int32_t H, int32_t hd,
                             int32_t max_len, float p_drop, uint64_t seed, float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv,
                             int64_t lddv, float* delta, rt_stream_t stream);
+/* K4v3p  Causal attention over packed sessions BEHIND A SHARED PAD PREFIX.  A stack that neither masks pad keys nor re-zeroes pad rows
+ * between blocks (LiGR: ligr.py:161-191 — the reference's default eSASRec; Pre-LN without a key-padding mask: net_blocks.py:290-310)
+ * gives the left pads of its [B, L] window a state that real queries read (torch_backbone.py:245-260: causal mask only).  That state
+ * depends on the POSITION only — a pad row sees pad rows, and every session's pads start from the same rows (zero item row + positional
+ * row) — so the packed batch carries it once: session number n_prefixed of cu_seqlens is the window's `window` positions as pads (B
+ * counts it, and any sessions behind it, e.g. the unused tail of the row block).  Sessions 0 .. n_prefixed - 1 (n_b rows each) see the
+ * prefix's first window - n_b rows as keys in front of their own; keys and queries are numbered by window position (dropout masks).
+ * lse NULL: inference.  Backward: as rt_mha_varlen_bwd; the prefix rows' dk / dv receive the sum over the sessions behind them through
+ * `workspace` (rt_mha_varlen_prefix_bwd_workspace_bytes: 16 groups x window x 2 H hd floats; fixed summation order, no atomics).
+ * hd in {32, 64, 128}; max_len >= window. */
+int rt_mha_varlen_prefix_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                             const int64_t* cu_seqlens, int32_t B, int32_t n_prefixed, int32_t H, int32_t hd, int32_t max_len,
+                             int32_t window, float p_drop, uint64_t seed, float* o, int64_t ldo, float* lse, rt_stream_t stream);
+size_t rt_mha_varlen_prefix_bwd_workspace_bytes(int32_t window, int32_t H, int32_t hd);
+int rt_mha_varlen_prefix_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* o,
+                             int64_t ldo, const float* dout, int64_t lddo, const float* lse, const int64_t* cu_seqlens, int32_t B,
+                             int32_t n_prefixed, int32_t H, int32_t hd, int32_t max_len, int32_t window, float p_drop, uint64_t seed,
+                             float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv, float* delta, void* workspace,
+                             size_t workspace_bytes, rt_stream_t stream);
 /* ... for the LAST query of every session only: q [B, ldq] one projected query row per session, o [B, ldo] (cf. rt_mha_last_fwd) */
 int rt_mha_varlen_last_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                            const int64_t* cu_seqlens, const float* bk, const float* bv, int32_t B, int32_t H, int32_t hd,

@@ -63,7 +63,10 @@ __device__ __forceinline__ void session_rows(const VarlenArgs& a, int b, long lo
 // K4v2's row layout and swizzle on the LOCAL row index); rows [rows, 64) are zero-filled.  Every load is issued before any split.
 template <int HD, int ROWS = CH>
 __device__ __forceinline__ void stage_chunk2(const float* __restrict__ srcA, long long ldA, float scaleA, unsigned char* imgA,
-                                             const float* __restrict__ srcB, long long ldB, float scaleB, unsigned char* imgB, int rows, int tid) {
+                                             const float* __restrict__ srcB, long long ldB, float scaleB, unsigned char* imgB, int rows, int tid,
+                                             const float* __restrict__ preA = nullptr, const float* __restrict__ preB = nullptr, int n_pre = 0) {
+  // n_pre > 0 (a session behind a shared pad prefix, see `prefix_len`): the chunk's first n_pre rows come from preA / preB (rows 0 ..
+  // n_pre - 1 of them), the rows behind from srcA / srcB (rows 0 ..)
   using L = Lay<HD>;
   constexpr int C4 = HD / 4, U = ROWS * C4 / NT;      // float4 per thread and image: 4 (hd 64 / 64 rows, hd 128 / 32 rows), 2 (hd 32)
   f32x4 xa[U], xb[U];
@@ -71,8 +74,11 @@ __device__ __forceinline__ void stage_chunk2(const float* __restrict__ srcA, lon
   for (int u = 0; u < U; ++u) {
     const int idx = tid + u * NT, r = idx / C4, c4 = idx % C4;
     if (r < rows) {
-      xa[u] = *reinterpret_cast<const f32x4*>(srcA + (long long)r * ldA + c4 * 4);
-      xb[u] = *reinterpret_cast<const f32x4*>(srcB + (long long)r * ldB + c4 * 4);
+      const bool pre = r < n_pre;
+      const float* pa = pre ? preA + (long long)r * ldA : srcA + (long long)(r - n_pre) * ldA;
+      const float* pb = pre ? preB + (long long)r * ldB : srcB + (long long)(r - n_pre) * ldB;
+      xa[u] = *reinterpret_cast<const f32x4*>(pa + c4 * 4);
+      xb[u] = *reinterpret_cast<const f32x4*>(pb + c4 * 4);
     } else {
       xa[u] = f32x4{0.f, 0.f, 0.f, 0.f};
       xb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -90,6 +96,16 @@ __device__ __forceinline__ void stage_chunk2(const float* __restrict__ srcA, lon
   };
 #pragma unroll
   for (int u = 0; u < U; ++u) { put(imgA, tid + u * NT, xa[u] * scaleA); put(imgB, tid + u * NT, xb[u] * scaleB); }
+}
+
+// The shared pad prefix (VarlenArgs.prefix_sessions > 0): a stack that neither masks pad keys nor re-zeroes pad rows (LiGR, ligr.py:161-191;
+// Pre-LN without a key-padding mask, net_blocks.py:290-310) gives the left pads of its [B, L] window a state — which depends on the
+// position only: a pad row sees pad rows, and every session's pads start from the same rows (zero item row + positional row).  The
+// packed batch carries that state ONCE, as session number `prefix_sessions` (L rows: the window's positions 0 .. L - 1 as pads); a real
+// session of n rows sees its first n_pre = window - n rows as keys in front of its own.  Keys and queries are numbered by their
+// window position (virtual index): pad key j -> j, own row r -> n_pre + r.
+__device__ __forceinline__ int prefix_len(const VarlenArgs& a, int b, int n) {
+  return (a.prefix_sessions > 0 && b < a.prefix_sessions && a.window > n) ? a.window - n : 0;
 }
 
 // blockIdx -> (owner block, session, head).  heavy_last: the LAST owner block of a session is the heaviest (causal queries) and is
@@ -133,6 +149,9 @@ __global__ __launch_bounds__(NT, HD > 64 ? 2 : 3) void v3_fwd_kernel(VarlenArgs 
   const int qrow = q0 + i;
   const bool qok = qrow < n;
   const long long grow = row0 + (qok ? qrow : n - 1);
+  const int n_pre = CAUSAL ? prefix_len(a, wk.b, n) : 0;      // rows of the shared pad prefix in front of this session's keys
+  const long long pre0 = n_pre > 0 ? a.cu[a.prefix_sessions] : 0;
+  const int vq0 = n_pre + q0, vq = n_pre + qrow, nv = n_pre + n;      // window positions of the tile's first query / this lane's query; keys in all
   const int n_pad = a.window > n ? a.window - n : 0;
   const bool pads = CAUSAL && a.bk != nullptr && a.bv != nullptr && n_pad > 0;
   const unsigned thr16 = TRAIN ? drop_thr16(a.p_drop) : 0u;
@@ -148,20 +167,22 @@ __global__ __launch_bounds__(NT, HD > 64 ? 2 : 3) void v3_fwd_kernel(VarlenArgs 
 #pragma unroll
   for (int cb = 0; cb < L::NCB; ++cb) oT[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int n_chunks = CAUSAL ? min(wk.ob * CH + CH - 1, n - 1) / CR + 1 : (n + CR - 1) / CR;
+  const int n_chunks = CAUSAL ? min(n_pre + wk.ob * CH + CH - 1, nv - 1) / CR + 1 : (n + CR - 1) / CR;
   for (int c = 0; c < n_chunks; ++c) {
     if (c > 0 && !RT_ABL(a, 32)) __syncthreads();                  // the previous chunk's readers are done
-    if (!RT_ABL(a, 1))
-      stage_chunk2<HD, CR>(a.k + (row0 + c * CR) * a.ldk + h * HD, a.ldk, 1.f, Kimg, a.v + (row0 + c * CR) * a.ldv + h * HD, a.ldv, 1.f, Vimg,
-                           min(CR, n - c * CR), tid);
+    if (!RT_ABL(a, 1)) {
+      const int own0 = max(c * CR - n_pre, 0), pre_rows = min(max(n_pre - c * CR, 0), CR);      // (keys by window position: pads, then own rows)
+      stage_chunk2<HD, CR>(a.k + (row0 + own0) * a.ldk + h * HD, a.ldk, 1.f, Kimg, a.v + (row0 + own0) * a.ldv + h * HD, a.ldv, 1.f, Vimg,
+                           min(CR, nv - c * CR), tid, a.k + (pre0 + c * CR) * a.ldk + h * HD, a.v + (pre0 + c * CR) * a.ldv + h * HD, pre_rows);
+    }
     if (!RT_ABL(a, 32)) __syncthreads();
     RT_TR(a, 2 + 2 * c, RT_NOW());
     if (!active || RT_ABL(a, 2)) continue;
     if (c == 0 && !RT_ABL(a, 64)) split_owner_raw<HD>(Qraw, qscale, Qp);
 #pragma unroll
     for (int s = 0; s < CR / 32; ++s) {
-      const int t0 = c * CR + 32 * s;            // first key of the step
-      if (CAUSAL ? t0 > q0 + 15 : t0 >= n) break;                 // (wave-uniform) nothing of the step is visible to the tile
+      const int t0 = c * CR + 32 * s;            // first key of the step (window position)
+      if (CAUSAL ? t0 > vq0 + 15 : t0 >= n) break;                // (wave-uniform) nothing of the step is visible to the tile
       f32x4 sT[2];
       rows_times_owner<HD>(Kimg, 32 * s, CR, Qp, i, g, sT, RT_ABLV(a));      // sT[kb][r]: key t0 + 16 kb + 4 g + r
       float sc[8];
@@ -170,11 +191,11 @@ __global__ __launch_bounds__(NT, HD > 64 ? 2 : 3) void v3_fwd_kernel(VarlenArgs 
 #pragma unroll
         for (int r = 0; r < 4; ++r) sc[4 * kb + r] = sT[kb][r];
       if (!RT_ABL(a, 4)) {
-        if (CAUSAL ? t0 + 31 > q0 : t0 + 31 >= n) {                // the causal edge (keys behind the session's end lie behind it too)
+        if (CAUSAL ? t0 + 31 > vq0 : t0 + 31 >= n) {               // the causal edge (keys behind the session's end lie behind it too)
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const int key = t0 + 16 * (e >> 2) + 4 * g + (e & 3);
-            sc[e] = (CAUSAL ? key <= qrow : key < n) ? sc[e] : -INFINITY;
+            sc[e] = (CAUSAL ? key <= vq : key < n) ? sc[e] : -INFINITY;
           }
         }
         float mx = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7])));
@@ -189,7 +210,7 @@ __global__ __launch_bounds__(NT, HD > 64 ? 2 : 3) void v3_fwd_kernel(VarlenArgs 
 #pragma unroll
           for (int e = 0; e < 8; e += 2) {
             const unsigned key = (unsigned)(t0 + 16 * (e >> 2) + 4 * g + (e & 3));
-            const unsigned hsh = drop_hash(a.seed, (unsigned)wk.bh, (unsigned)qrow, key >> 1);
+            const unsigned hsh = drop_hash(a.seed, (unsigned)wk.bh, (unsigned)vq, key >> 1);
             sc[e] = (hsh & 0xFFFFu) >= thr16 ? sc[e] * inv_keep : 0.f;
             sc[e + 1] = (hsh >> 16) >= thr16 ? sc[e + 1] * inv_keep : 0.f;
           }
@@ -265,6 +286,9 @@ __global__ __launch_bounds__(NT, HD > 64 ? 1 : 3) void v3_bwd_dq_kernel(VarlenAr
   const int qrow = q0 + i;
   const bool qok = qrow < n;
   const long long grow = row0 + (qok ? qrow : n - 1);
+  const int n_pre = CAUSAL ? prefix_len(a, wk.b, n) : 0;      // (the shared pad prefix: see the forward kernel)
+  const long long pre0 = n_pre > 0 ? a.cu[a.prefix_sessions] : 0;
+  const int vq0 = n_pre + q0, vq = n_pre + qrow, nv = n_pre + n;
   const int n_pad = a.window > n ? a.window - n : 0;
   const bool pads = CAUSAL && a.bk != nullptr && a.bv != nullptr && n_pad > 0;
   const unsigned thr16 = drop_thr16(a.p_drop);
@@ -291,18 +315,20 @@ __global__ __launch_bounds__(NT, HD > 64 ? 1 : 3) void v3_bwd_dq_kernel(VarlenAr
 #pragma unroll
   for (int cb = 0; cb < L::NCB; ++cb) dqT[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int n_chunks = CAUSAL ? min(wk.ob * CH + CH - 1, n - 1) / CR + 1 : (n + CR - 1) / CR;
+  const int n_chunks = CAUSAL ? min(n_pre + wk.ob * CH + CH - 1, nv - 1) / CR + 1 : (n + CR - 1) / CR;
   for (int c = 0; c < n_chunks; ++c) {
     if (c > 0 && !RT_ABL(a, 32)) __syncthreads();
-    if (!RT_ABL(a, 1))
-      stage_chunk2<HD, CR>(a.k + (row0 + c * CR) * a.ldk + h * HD, a.ldk, 1.f, Kimg, a.v + (row0 + c * CR) * a.ldv + h * HD, a.ldv, 1.f, Vimg,
-                           min(CR, n - c * CR), tid);
+    if (!RT_ABL(a, 1)) {
+      const int own0 = max(c * CR - n_pre, 0), pre_rows = min(max(n_pre - c * CR, 0), CR);
+      stage_chunk2<HD, CR>(a.k + (row0 + own0) * a.ldk + h * HD, a.ldk, 1.f, Kimg, a.v + (row0 + own0) * a.ldv + h * HD, a.ldv, 1.f, Vimg,
+                           min(CR, nv - c * CR), tid, a.k + (pre0 + c * CR) * a.ldk + h * HD, a.v + (pre0 + c * CR) * a.ldv + h * HD, pre_rows);
+    }
     if (!RT_ABL(a, 32)) __syncthreads();
     if (!active || RT_ABL(a, 2)) continue;
 #pragma unroll
     for (int s = 0; s < CR / 32; ++s) {
-      const int t0 = c * CR + 32 * s;
-      if (CAUSAL ? t0 > q0 + 15 : t0 >= n) break;
+      const int t0 = c * CR + 32 * s;              // (window position of the step's first key)
+      if (CAUSAL ? t0 > vq0 + 15 : t0 >= n) break;
       f32x4 sT[2], dpT[2];
       rows_times_owner<HD>(Kimg, 32 * s, CR, Qp, i, g, sT, RT_ABLV(a));
       rows_times_owner<HD>(Vimg, 32 * s, CR, Dp, i, g, dpT, RT_ABLV(a));
@@ -311,18 +337,18 @@ __global__ __launch_bounds__(NT, HD > 64 ? 1 : 3) void v3_bwd_dq_kernel(VarlenAr
 #pragma unroll
         for (int e = 0; e < 8; ++e) ds[e] = sT[e >> 2][e & 3] + dpT[e >> 2][e & 3];
       } else {
-        const bool edge = CAUSAL ? t0 + 31 > q0 : t0 + 31 >= n;
+        const bool edge = CAUSAL ? t0 + 31 > vq0 : t0 + 31 >= n;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int key = t0 + 16 * (e >> 2) + 4 * g + (e & 3);
-          ds[e] = (!edge || (CAUSAL ? key <= qrow : key < n)) ? __builtin_amdgcn_exp2f(sT[e >> 2][e & 3] - lse2) : 0.f;
+          ds[e] = (!edge || (CAUSAL ? key <= vq : key < n)) ? __builtin_amdgcn_exp2f(sT[e >> 2][e & 3] - lse2) : 0.f;
         }
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
           float d0 = dpT[e >> 2][e & 3], d1 = dpT[e >> 2][(e & 3) + 1];
           if (thr16 != 0u) {
             const unsigned key = (unsigned)(t0 + 16 * (e >> 2) + 4 * g + (e & 3));
-            const unsigned hsh = drop_hash(a.seed, (unsigned)wk.bh, (unsigned)qrow, key >> 1);
+            const unsigned hsh = drop_hash(a.seed, (unsigned)wk.bh, (unsigned)vq, key >> 1);
             d0 = (hsh & 0xFFFFu) >= thr16 ? d0 * inv_keep : 0.f;
             d1 = (hsh >> 16) >= thr16 ? d1 * inv_keep : 0.f;
           }
@@ -468,6 +494,7 @@ __global__ __launch_bounds__(NT, HD > 64 ? 1 : 2) void v3_bwd_dkv_kernel(VarlenA
   const long long grow = row0 + (kok ? krow : n - 1);
   const unsigned thr16 = drop_thr16(a.p_drop);
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+  const int n_pre = CAUSAL ? prefix_len(a, wk.b, n) : 0;
   P3 Kp[L::NS], Vp[L::NS];
   if (active && !RT_ABL(a, 64)) {
     load_owner_planes<HD>(a.k + grow * a.ldk + h * HD, g, 1.f, Kp);
@@ -516,8 +543,8 @@ __global__ __launch_bounds__(NT, HD > 64 ? 1 : 2) void v3_bwd_dkv_kernel(VarlenA
           float pr = __builtin_amdgcn_exp2f(sm[qb][r] - ls4[r]);
           if (edge) pr = ((!CAUSAL || krow <= qr) && qr < n && kok) ? pr : 0.f;
           float keepf = 1.f;
-          if (thr16 != 0u)
-            keepf = drop_kept(a.seed, (unsigned)wk.bh, (unsigned)qr, (unsigned)krow, thr16) ? inv_keep : 0.f;
+          if (thr16 != 0u)      // (numbered by window position when the session sits behind a shared pad prefix)
+            keepf = drop_kept(a.seed, (unsigned)wk.bh, (unsigned)(n_pre + qr), (unsigned)(n_pre + krow), thr16) ? inv_keep : 0.f;
           pd[4 * qb + r] = pr * keepf;                               // dropped probabilities (for dV)
           ds[4 * qb + r] = pr * (dpm[qb][r] * keepf - dl4[r]);       // dS
         }
@@ -540,13 +567,126 @@ __global__ __launch_bounds__(NT, HD > 64 ? 1 : 2) void v3_bwd_dkv_kernel(VarlenA
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// backward, pass 3 (shared pad prefix only): the prefix rows' dK / dV from the sessions BEHIND the prefix.  A lane owns a prefix key
+// (window position j); the queries of session b see it iff j < n_pre(b) = window - n_b, all of them (every pad precedes every real row).
+// A workgroup = 64 prefix keys x one head x one GROUP of sessions (b = group, group + 16, ...): it streams those sessions' query
+// chunks like the dK/dV pass and writes ONE partial row block; v3_prefix_reduce_kernel adds the 16 groups' partials in a fixed order to
+// what the dK/dV pass wrote for the prefix session's own queries.  No atomics.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int PREFIX_GROUPS = 16;
+
+template <int HD>
+__global__ __launch_bounds__(NT, HD > 64 ? 1 : 2) void v3_prefix_dkv_kernel(VarlenArgs a, int n_kb) {
+  using L = Lay<HD>;
+  constexpr int CR = chunk_rows(HD);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int h = (int)blockIdx.x % a.H, kb = ((int)blockIdx.x / a.H) % n_kb, grp = (int)blockIdx.x / (a.H * n_kb);
+  const int Lw = a.window;
+  const long long pre0 = a.cu[a.prefix_sessions];
+  unsigned char* Qimg = smem;
+  unsigned char* Dimg = smem + (size_t)CR * L::ROW3;
+  float* Ls = reinterpret_cast<float*>(smem + 2 * (size_t)CR * L::ROW3);
+  float* Dl = Ls + CR;
+  const float qscale = a.scale * LOG2E;
+  const int k0 = kb * CH + 16 * wave;
+  const bool active = k0 < Lw;
+  const int krow = k0 + i;                     // the key's window position
+  const bool kok = krow < Lw;
+  const long long grow = pre0 + (kok ? krow : Lw - 1);
+  const unsigned thr16 = drop_thr16(a.p_drop);
+  const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
+  P3 Kp[L::NS], Vp[L::NS];
+  if (active) {
+    load_owner_planes<HD>(a.k + grow * a.ldk + h * HD, g, 1.f, Kp);
+    load_owner_planes<HD>(a.v + grow * a.ldv + h * HD, g, 1.f, Vp);
+  }
+  f32x4 dkT[L::NCB], dvT[L::NCB];
+#pragma unroll
+  for (int cb = 0; cb < L::NCB; ++cb) { dkT[cb] = f32x4{0.f, 0.f, 0.f, 0.f}; dvT[cb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  for (int b = grp; b < a.prefix_sessions; b += PREFIX_GROUPS) {
+    const long long row0 = a.cu[b];
+    const int n = (int)(a.cu[b + 1] - row0);
+    const int n_pre = Lw > n ? Lw - n : 0;
+    if (n <= 0 || kb * CH >= n_pre) continue;              // (uniform) none of this block's keys is a pad of session b
+    const unsigned bh = (unsigned)(b * a.H + h);
+    for (int c = 0; c * CR < n; ++c) {
+      __syncthreads();
+      const int rows = min(CR, n - c * CR);
+      stage_chunk2<HD, CR>(a.q + (row0 + c * CR) * a.ldq + h * HD, a.ldq, qscale, Qimg, a.dout + (row0 + c * CR) * a.lddo + h * HD, a.lddo, 1.f, Dimg,
+                           rows, tid);
+      if (tid < CR) {
+        Ls[tid] = tid < rows ? a.lse[(row0 + c * CR + tid) * a.H + h] * LOG2E : 0.f;
+        Dl[tid] = tid < rows ? a.delta[(row0 + c * CR + tid) * a.H + h] : 0.f;
+      }
+      __syncthreads();
+      if (!active || k0 >= n_pre) continue;                // (wave-uniform) this tile's keys all lie behind the session's pads
+#pragma unroll
+      for (int s = 0; s < CR / 32; ++s) {
+        const int t0 = c * CR + 32 * s;                    // first query (own row) of the step
+        if (t0 >= n) break;
+        f32x4 sm[2], dpm[2];
+        rows_times_owner<HD>(Qimg, 32 * s, CR, Kp, i, g, sm);
+        rows_times_owner<HD>(Dimg, 32 * s, CR, Vp, i, g, dpm);
+        float pd[8], ds[8];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+          const f32x4 ls4 = *reinterpret_cast<const f32x4*>(Ls + 32 * s + 16 * qb + 4 * g);
+          const f32x4 dl4 = *reinterpret_cast<const f32x4*>(Dl + 32 * s + 16 * qb + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int qr = t0 + 16 * qb + 4 * g + r;
+            float pr = (krow < n_pre && qr < n) ? __builtin_amdgcn_exp2f(sm[qb][r] - ls4[r]) : 0.f;
+            float keepf = 1.f;
+            if (thr16 != 0u) keepf = drop_kept(a.seed, bh, (unsigned)(n_pre + qr), (unsigned)krow, thr16) ? inv_keep : 0.f;
+            pd[4 * qb + r] = pr * keepf;
+            ds[4 * qb + r] = pr * (dpm[qb][r] * keepf - dl4[r]);
+          }
+        }
+        const P3 Pp = split8(pd);
+        cols_times_slots<HD>(Dimg, 32 * s, CR, Pp, i, g, dvT);
+        const P3 Sp = split8(ds);
+        cols_times_slots<HD>(Qimg, 32 * s, CR, Sp, i, g, dkT);
+      }
+    }
+  }
+  if (active && kok) {
+    float* wk_ = a.prefix_ws + ((long long)grp * Lw + krow) * (2 * a.H * HD) + h * HD;
+#pragma unroll
+    for (int cb = 0; cb < L::NCB; ++cb) {
+      *reinterpret_cast<f32x4*>(wk_ + 16 * cb + 4 * g) = dkT[cb] * LN2;
+      *reinterpret_cast<f32x4*>(wk_ + a.H * HD + 16 * cb + 4 * g) = dvT[cb];
+    }
+  }
+}
+
+// dk / dv rows of the prefix session += the 16 groups' partials, summed in group order
+__global__ __launch_bounds__(256) void v3_prefix_reduce_kernel(VarlenArgs a) {
+  const int j = blockIdx.x, Lw = a.window, w2 = 2 * a.H * a.hd, d = a.H * a.hd;
+  const long long row = a.cu[a.prefix_sessions] + j;
+  for (int c = threadIdx.x; c < w2; c += 256) {
+    float v = 0.f;
+    for (int grp = 0; grp < PREFIX_GROUPS; ++grp) v += a.prefix_ws[((long long)grp * Lw + j) * w2 + c];
+    float* dst = c < d ? a.dk + row * a.lddk + c : a.dv + row * a.lddv + (c - d);
+    *dst += v;
+  }
+}
+
 #ifdef RT_ABLATION_BUILD
 inline int v3_ablate_env() { const char* e = getenv("RT_V2_ABLATE"); return e != nullptr ? atoi(e) : 0; }
 #endif
 
+// Owner blocks per (session, head) of a launch.  At least two: the unused tail of a packed row block (up to 128 rows) rides along as
+// one more session whatever the window, and every row of it must be written (finite values: zero gradients flow in, but a weight
+// gradient sums 0 x whatever the row holds).
+inline int owner_blocks(int max_len) { const int n = (max_len + CH - 1) / CH; return n < 2 ? 2 : n; }
+
 template <int HD, bool TRAIN, bool CAUSAL>
 int launch_fwd(VarlenArgs a, int max_len, hipStream_t stream) {
-  const int n_ob = (max_len + CH - 1) / CH;
+  const int n_ob = owner_blocks(max_len);
   const size_t lds = 2 * (size_t)chunk_rows(HD) * Lay<HD>::ROW3;
 #ifdef RT_ABLATION_BUILD
   a.ablate = v3_ablate_env();
@@ -558,7 +698,7 @@ int launch_fwd(VarlenArgs a, int max_len, hipStream_t stream) {
 
 template <int HD, bool CAUSAL>
 int launch_bwd(VarlenArgs a, int max_len, hipStream_t stream) {
-  const int n_ob = (max_len + CH - 1) / CH;
+  const int n_ob = owner_blocks(max_len);
   const size_t lds = 2 * (size_t)chunk_rows(HD) * Lay<HD>::ROW3, lds_kv = lds + 2 * chunk_rows(HD) * sizeof(float);
   const bool pad_wgs = CAUSAL && a.dbv_part != nullptr && a.bk != nullptr && a.bv != nullptr;
   int skip = 0;
@@ -570,6 +710,14 @@ int launch_bwd(VarlenArgs a, int max_len, hipStream_t stream) {
   RT_CHECK_LAUNCH();
   if (!(skip & 512)) v3_bwd_dkv_kernel<HD, CAUSAL><<<a.B * a.H * (n_ob + (pad_wgs ? 1 : 0)), NT, lds_kv, stream>>>(a, n_ob);
   RT_CHECK_LAUNCH();
+  if (CAUSAL && a.prefix_sessions > 0) {      // the prefix rows' dK / dV from the sessions behind it
+    if (a.prefix_ws == nullptr) return RT_ERR_WORKSPACE;
+    const int n_kb = (a.window + CH - 1) / CH;
+    v3_prefix_dkv_kernel<HD><<<PREFIX_GROUPS * n_kb * a.H, NT, lds_kv, stream>>>(a, n_kb);
+    RT_CHECK_LAUNCH();
+    v3_prefix_reduce_kernel<<<a.window, 256, 0, stream>>>(a);
+    RT_CHECK_LAUNCH();
+  }
   return RT_OK;
 }
 
@@ -891,14 +1039,14 @@ __global__ __launch_bounds__(NT, 2) void v3_hstu_bwd_dkv_kernel(HstuV2Args a, in
 
 template <int HD>
 int launch_hstu_fwd(const HstuV2Args& a, hipStream_t stream) {
-  const int n_ob = (a.Lw + CH - 1) / CH;
+  const int n_ob = owner_blocks(a.Lw);
   v3_hstu_fwd_kernel<HD><<<a.B * a.H * n_ob, NT, hstu3_lds_bytes<HD>(a.Lw, false), stream>>>(a, n_ob);
   RT_CHECK_LAUNCH();
   return RT_OK;
 }
 template <int HD>
 int launch_hstu_bwd(const HstuV2Args& a, hipStream_t stream) {
-  const int n_ob = (a.Lw + CH - 1) / CH;
+  const int n_ob = owner_blocks(a.Lw);
   const size_t lds_q = hstu3_lds_bytes<HD>(a.Lw, true);
   if (lds_q > 64 * 1024) {
     if (lds_q > 160 * 1024) return RT_ERR_UNSUPPORTED;
@@ -963,3 +1111,5 @@ extern "C" int rt_v3_trace_read(void* dst, size_t bytes) {
   return RT_OK;
 }
 #endif
+
+size_t rt_v3_prefix_workspace_floats(int window, int H, int hd) { return (size_t)PREFIX_GROUPS * window * 2 * H * hd; }

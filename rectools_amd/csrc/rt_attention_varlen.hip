@@ -206,6 +206,46 @@ int rt_mha_varlen_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, 
   return rt_v3_varlen_bwd(a, max_len, stream);
 }
 
+// Causal attention over packed sessions behind a shared pad prefix (include/rectools_hip.h, K4v3p; rt_attention_v3.hip `prefix_len`).
+int rt_mha_varlen_prefix_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                             const int64_t* cu_seqlens, int32_t B, int32_t n_prefixed, int32_t H, int32_t hd, int32_t max_len,
+                             int32_t window, float p_drop, uint64_t seed, float* o, int64_t ldo, float* lse, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (bad_args(q, k, v, o, ldq, ldk, ldv, ldo, cu_seqlens, B, H, hd, max_len) || n_prefixed < 0 || n_prefixed >= B || window <= 0 ||
+      max_len < window || !(p_drop >= 0.f && p_drop < 1.f))
+    return RT_ERR_INVALID_ARG;
+  if (hd != 32 && hd != 64 && hd != 128) return RT_ERR_UNSUPPORTED;
+  VarlenArgs a{};
+  a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.o = o; a.ldo = ldo;
+  a.cu = reinterpret_cast<const long long*>(cu_seqlens); a.B = B; a.H = H; a.hd = hd; a.window = window; a.prefix_sessions = n_prefixed;
+  a.scale = 1.0f / sqrtf((float)hd); a.p_drop = lse != nullptr ? p_drop : 0.f; a.seed = seed; a.lse = lse;
+  return rt_v3_varlen_fwd(a, max_len, lse != nullptr && p_drop > 0.f, stream);
+}
+size_t rt_mha_varlen_prefix_bwd_workspace_bytes(int32_t window, int32_t H, int32_t hd) {
+  return window > 0 && H > 0 && hd > 0 ? rt_v3_prefix_workspace_floats(window, H, hd) * sizeof(float) : 0;
+}
+int rt_mha_varlen_prefix_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* o,
+                             int64_t ldo, const float* dout, int64_t lddo, const float* lse, const int64_t* cu_seqlens, int32_t B,
+                             int32_t n_prefixed, int32_t H, int32_t hd, int32_t max_len, int32_t window, float p_drop, uint64_t seed,
+                             float* dq, int64_t lddq, float* dk, int64_t lddk, float* dv, int64_t lddv, float* delta, void* workspace,
+                             size_t workspace_bytes, hipStream_t stream) {
+  (void)hipGetLastError();
+  auto mis = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+  if (bad_args(q, k, v, o, ldq, ldk, ldv, ldo, cu_seqlens, B, H, hd, max_len) || n_prefixed < 0 || n_prefixed >= B || window <= 0 ||
+      max_len < window || dout == nullptr || lse == nullptr || dq == nullptr || dk == nullptr || dv == nullptr || delta == nullptr ||
+      (lddo & 3) || (lddq & 3) || (lddk & 3) || (lddv & 3) || mis(dout) || mis(dq) || mis(dk) || mis(dv) || !(p_drop >= 0.f && p_drop < 1.f))
+    return RT_ERR_INVALID_ARG;
+  if (hd != 32 && hd != 64 && hd != 128) return RT_ERR_UNSUPPORTED;
+  if (workspace == nullptr || mis(workspace) || workspace_bytes < rt_mha_varlen_prefix_bwd_workspace_bytes(window, H, hd)) return RT_ERR_WORKSPACE;
+  VarlenArgs a{};
+  a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.o = const_cast<float*>(o); a.ldo = ldo;
+  a.cu = reinterpret_cast<const long long*>(cu_seqlens); a.B = B; a.H = H; a.hd = hd; a.window = window; a.prefix_sessions = n_prefixed;
+  a.scale = 1.0f / sqrtf((float)hd); a.p_drop = p_drop; a.seed = seed; a.lse = const_cast<float*>(lse);
+  a.dout = dout; a.lddo = lddo; a.delta = delta; a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+  a.prefix_ws = reinterpret_cast<float*>(workspace);
+  return rt_v3_varlen_bwd(a, max_len, stream);
+}
+
 // Bidirectional attention inside every packed session (no causal mask; BERT4Rec: the reference masks the pad keys of its window,
 // torch_backbone.py:254, bert4rec.py:200 — packed rows have none).  lse != NULL: training forward (attention dropout p_drop / seed, lse
 // [N, H] kept); lse == NULL: inference.  Served by the bf16-plane kernels only (hd 32 / 64, 2 * (max_len + 1) * 6 * hd bytes of LDS):

@@ -21,6 +21,9 @@ struct VarlenArgs {
   float* dbv_part;                     // [B, H*hd] per-session partial of the value-bias gradient from the pad keys (or null)
   int ablate;                          // read by -DRT_ABLATION_BUILD builds of rt_attention_v2.hip only (RT_V2_ABLATE), else 0
   int uniform_len;                     // cu == NULL (rt_attention_v3.hip only): every session is `uniform_len` rows, session b starts at b * uniform_len
+  int prefix_sessions;                 // > 0 (rt_attention_v3.hip, causal): sessions 0 .. prefix_sessions - 1 sit behind the shared pad prefix, session
+                                       // number prefix_sessions (`window` rows); a session of n rows sees the prefix's first window - n rows as keys
+  float* prefix_ws;                    // backward: [groups][window][2 * H * hd] partials of the prefix rows' dK | dV from the sessions behind it
 };
 
 // Attention dropout mask, same construction as rt_attention.hip: ONE 32-bit mix per (head, query, PAIR of adjacent keys), 16 bits
@@ -77,3 +80,4 @@ int rt_v3_bidir_fwd(const rt_varlen::VarlenArgs& a, int max_len, bool train, hip
 int rt_v3_bidir_bwd(const rt_varlen::VarlenArgs& a, int max_len, hipStream_t stream);
 int rt_v3_hstu_fwd(const rt_varlen::HstuV2Args& a, hipStream_t stream);
 int rt_v3_hstu_bwd(const rt_varlen::HstuV2Args& a, hipStream_t stream);
+size_t rt_v3_prefix_workspace_floats(int window, int H, int hd);      // VarlenArgs.prefix_ws of rt_v3_varlen_bwd with prefix_sessions > 0

@@ -227,7 +227,8 @@ class TransformerLossModule(nn.Module):
         table = self.torch_model.item_model.get_all_embeddings()
         B = int(pbatch["cu"].numel()) - 1
         sess = self.torch_model.encode_packed_train(pbatch["x"], pbatch["dist"], pbatch["cu"], B, int(pbatch["window"]), table,
-                                                    rows_real=pbatch.get("n_rows"), cu_attn=pbatch.get("cu_attn"), ts=pbatch.get("ts"))
+                                                    rows_real=pbatch.get("n_rows"), cu_attn=pbatch.get("cu_attn"), ts=pbatch.get("ts"),
+                                                    **({"n_prefixed": pbatch["n_prefixed"]} if pbatch.get("n_prefixed") is not None else {}))
         stock = type(self)._loss_from_sessions is TransformerLossModule._loss_from_sessions    # (a plugged loss keeps its own signature)
         kw = {"n_targets": pbatch["n_targets"]} if stock and pbatch.get("n_targets") is not None and self.loss == "softmax" else {}
         loss, _ = self._loss_from_sessions(table, sess, pbatch["y"], pbatch["yw"], pbatch.get("negatives"), **kw)

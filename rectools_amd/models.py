@@ -158,6 +158,12 @@ class _TrainLoop:
                        and getattr(tm, "_fused_pos", lambda: False)() and _packed_hooks_are_stock(lm)
                        and tm.transformer_layers.packed_ok(model.n_factors, self.dp.session_max_len, tm.use_causal_attn,
                                                            tm.use_key_padding_mask))
+        # a stack whose pad rows carry state (LiGR without key-padding masks: default eSASRec) packs behind a SHARED PAD PREFIX: the
+        # window's pad rows ride along once per batch as one more packed session (`nn.LiGRLayers.packed_mode`)
+        mode = getattr(tm.transformer_layers, "packed_mode", None)
+        self.prefix = bool(self.packed and not self.bert and mode is not None and
+                           mode(model.n_factors, self.dp.session_max_len, tm.use_causal_attn, tm.use_key_padding_mask) == "prefix")
+        self._prefix_dist: tp.Optional[torch.Tensor] = None
 
     # The next batch is cut while the current step's backward pass runs: collate + negative sampling are a handful of tiny launches that
     # depend on the store and the sampler's counter only — issued on their own stream right behind `loss.backward()` they run beside the
@@ -190,14 +196,16 @@ class _TrainLoop:
             self.mine_t = torch.from_numpy(np.ascontiguousarray(mine, dtype=np.int64)).to(self.device)
             grid = np.zeros((nb, B), dtype=np.int64)
             grid.reshape(-1)[:len(mine)] = lens
-            cu = np.zeros((nb, B + 2), dtype=np.int64)
+            cu = np.zeros((nb, B + (3 if self.prefix else 2)), dtype=np.int64)
             np.cumsum(grid, axis=1, out=cu[:, 1:B + 1])
+            if self.prefix:      # [.. real sessions .., + the window's pad rows as session B, + the tail]
+                cu[:, B + 1] = cu[:, B] + L
             # one more entry per batch: the end of the unused tail (rows up to the 128-row GEMM tile).  The attention kernels take the
             # tail as one more "session" — its rows get finite values and zero gradients instead of three memsets per block and step
-            cu[:, B + 1] = np.maximum((cu[:, B] + 127) // 128 * 128, 128)
+            cu[:, -1] = np.maximum((cu[:, -2] + 127) // 128 * 128, 128)
             self._cu_host = cu
             self._cu_dev = torch.from_numpy(cu).to(self.device)
-            self._reserve_step_memory(int(cu[:, B + 1].max()))
+            self._reserve_step_memory(int(cu[:, -1].max()))
 
     def _reserve_step_memory(self, max_rows: int) -> None:
         """Packed batches change their row count every step, and torch's caching allocator answers a size it has not seen with a
@@ -264,6 +272,24 @@ class _TrainLoop:
             x, y, yw, dist = ops.collate_packed_bert(self.dstore.offsets, self.dstore.items, self.dstore.weights, idx, cu, rows, L, True,
                                                      self.dp.extra_token_ids[MASKING_VALUE], probs, rand_ids, self.dp.mask_prob,
                                                      draw_rows=self._slots[self.pos - self.batch_size:self.pos - self.batch_size + nb])
+        elif self.prefix:
+            # the sessions, then the shared pad prefix: `window` rows of (id 0, no target, positions window - 1 .. 0) — collate_packed
+            # writes (id 0, target 0) behind the sessions anyway, the positions are set here
+            L = self.dp.session_max_len
+            rows = max((n + L + 127) // 128 * 128, 128)
+            x, y, yw, dist = ops.collate_packed(self.dstore.offsets, self.dstore.items, self.dstore.weights, idx, cu, rows, train=True)
+            if self._prefix_dist is None:
+                self._prefix_dist = torch.arange(L - 1, -1, -1, dtype=dist.dtype, device=self.device)
+            dist[n:n + L] = self._prefix_dist
+            tail = self._cu_dev[bi, -2:] if full else torch.tensor([n + L, rows], dtype=torch.int64, device=self.device)
+            cu_all = torch.cat([cu, tail])                       # [nb + 3]: sessions, prefix, tail
+            batch = {"x": x, "y": y, "yw": yw, "dist": dist, "cu": cu_all[:nb + 2], "window": L, "n_rows": n + L, "n_prefixed": nb}
+            if rows > n + L:
+                batch["cu_attn"] = cu_all
+            if self.dp.negative_sampler is not None:
+                batch["negatives"] = self.dp.negative_sampler.get_negatives(
+                    {"x": x.view(-1, 1)}, lowest_id=self.dp.n_item_extra_tokens, highest_id=self.dp.item_id_map.size)
+            return batch
         else:
             x, y, yw, dist = ops.collate_packed(self.dstore.offsets, self.dstore.items, self.dstore.weights, idx, cu, rows, train=True)
         batch: tp.Dict[str, tp.Any] = {"x": x, "y": y, "yw": yw, "dist": dist, "cu": cu, "window": self.dp.session_max_len, "n_rows": n}

@@ -631,7 +631,7 @@ class LiGRLayer(nn.Module):
         return ops.gated_residual(seqs, g2.weight, g2.bias, f, p)    # seqs + sigmoid(Wg2 seqs + bg2) * drop(ffn)
 
 
-    def forward_packed(self, seqs, B, window, causal, pad_idx, pad_ids, n_real, cu=None):
+    def forward_packed(self, seqs, B, window, causal, pad_idx, pad_ids, n_real, cu=None, n_prefixed=None):
         """The block over PACKED rows ([Np, d]: real positions + the unused tail of the row block) — exact under key-padding masks: no
         real query sees a pad key, and nothing else couples rows (ligr.py:66-106 is LayerNorm, Linear, gates, SwiGLU: row-wise).
         cu given (head size 32 / 64 / 128: the streamed packed kernels, K4v3): the attention runs on the packed in_proj output as it
@@ -643,8 +643,9 @@ class LiGRLayer(nn.Module):
         g1, g2 = self.gating_linear_1, self.gating_linear_2
         h, seqs = ops.layer_norm_skip(seqs, ln1.weight, ln1.bias, ln1.eps)
         qkv = ops.linear(h, mha.in_proj_weight, mha.in_proj_bias)
-        if cu is not None:
-            a = ops.mha_varlen_qkv(qkv, cu, int(cu.numel()) - 1, mha.n_heads, window, causal, p, n_real is not None and int(n_real) == int(seqs.shape[0]))
+        if cu is not None:      # (n_prefixed: the sessions sit behind the shared pad prefix, `ops.mha_varlen_qkv`)
+            a = ops.mha_varlen_qkv(qkv, cu, int(cu.numel()) - 1, mha.n_heads, window, causal, p,
+                                   n_real is not None and int(n_real) == int(seqs.shape[0]), n_prefixed=n_prefixed)
         else:
             qkv_w = ops.scatter_rows(qkv, pad_idx, B * window + 1)
             a_w = ops.mha_packed(qkv_w[:B * window], pad_ids[:B * window], B, mha.n_heads, window, causal, True, p)
@@ -688,33 +689,53 @@ class LiGRLayers(TransformerLayersBase):
                 seqs = blk(seqs, ids, B, L, causal, keypad)
             return blocks[-1].forward_last(seqs, ids, B, L, causal, keypad)
 
+    def packed_mode(self, n_factors: int, window: int, causal: bool, keypad: bool = False) -> tp.Optional[str]:
+        """How this stack runs on packed rows.  "rows": pad positions are masked as keys (`use_key_padding_mask=True`) — no real query
+        sees a pad, and nothing else couples rows (ligr.py:66-106 is LayerNorm, Linear, gates, SwiGLU).  "prefix": no key-padding mask
+        — the reference's default for SASRec-style models, eSASRec included: nothing re-zeroes the pad rows between blocks
+        (ligr.py:161-191), they carry a state that real queries read; that state depends on the POSITION only (a pad row sees pad
+        rows; every session's pads start from the same zero item row + positional row), so the batch carries the window's pad rows
+        ONCE, as one more packed session, and every real session attends to its first window - n rows (`ops.mha_varlen_qkv`
+        n_prefixed; causal attention on the streamed kernels only).  Exact without dropout; with dropout the pad rows' masks are
+        shared by the sessions of a batch where the reference draws them per session — every session's own marginal distribution,
+        hence the expected gradient, is the reference's.  None: the padded window."""
+        if len(self.transformer_blocks) == 0 or any(b.generic for b in self.transformer_blocks):
+            return None
+        if keypad:
+            return "rows"
+        if causal and self._packed_attention_on_rows(window, True) and os.environ.get("RT_PACKED_PREFIX", "1") != "0":
+            return "prefix"
+        return None
+
     def packed_ok(self, n_factors: int, window: int, causal: bool, keypad: bool = False) -> bool:
-        """Packed rows serve the LiGR stack when pad positions are masked as keys (`use_key_padding_mask=True`): without the mask the
-        pad rows of this stack carry state that real queries read (nothing re-zeroes them between blocks, ligr.py:161-191), and the
-        padded window has to stay — which is the reference's default for SASRec-style models, eSASRec included."""
-        return bool(keypad) and len(self.transformer_blocks) > 0 and not any(b.generic for b in self.transformer_blocks)
+        return self.packed_mode(n_factors, window, causal, keypad) is not None
 
     def _packed_attention_on_rows(self, window: int, causal: bool) -> bool:
         mha = self.transformer_blocks[0].multi_head_attn
         d = int(mha.in_proj_weight.shape[1])
         return ops.mha_varlen_supported(mha.n_heads, d, window) if causal else ops.mha_bidir_supported(mha.n_heads, d, window)
 
-    def forward_packed_train(self, seqs, cu, B, window, keypad, rows_real=None, causal=True):
+    def forward_packed_train(self, seqs, cu, B, window, keypad, rows_real=None, causal=True, n_prefixed=None):
+        """n_prefixed: session number n_prefixed of `cu` is the shared pad prefix (mode "prefix"), sessions before it sit behind it."""
+        if not keypad and n_prefixed is None:
+            raise ValueError("a LiGR stack without key-padding masks packs only behind a shared pad prefix (packed_mode 'prefix'): n_prefixed")
         n_real = int(rows_real) if rows_real is not None else None
-        on_rows = self._packed_attention_on_rows(window, causal)
+        on_rows = n_prefixed is not None or self._packed_attention_on_rows(window, causal)
         pad_idx, pad_ids = (None, None) if on_rows else ops.padded_index(cu, B, window, int(seqs.shape[0]))
         with ops.active_planes(self._fresh_planes()):
             for blk in self.transformer_blocks:
-                seqs = blk.forward_packed(seqs, B, window, causal, pad_idx, pad_ids, n_real, cu if on_rows else None)
+                seqs = blk.forward_packed(seqs, B, window, causal, pad_idx, pad_ids, n_real, cu if on_rows else None, n_prefixed)
         return seqs
 
-    def forward_last_packed(self, seqs, cu, B, window, keypad, rows_real=None, causal=True):
-        """Inference over packed rows: all blocks on the packed rows, then the last row of every session."""
-        on_rows = self._packed_attention_on_rows(window, causal)
+    def forward_last_packed(self, seqs, cu, B, window, keypad, rows_real=None, causal=True, n_prefixed=None):
+        """Inference over packed rows: all blocks on the packed rows, then the last row of every session (B: the real sessions)."""
+        if not keypad and n_prefixed is None:
+            raise ValueError("a LiGR stack without key-padding masks packs only behind a shared pad prefix (packed_mode 'prefix'): n_prefixed")
+        on_rows = n_prefixed is not None or self._packed_attention_on_rows(window, causal)
         pad_idx, pad_ids = (None, None) if on_rows else ops.padded_index(cu, B, window, int(seqs.shape[0]))
         with ops.active_planes(self._fresh_planes()):
             for blk in self.transformer_blocks:
-                seqs = blk.forward_packed(seqs, B, window, causal, pad_idx, pad_ids, None, cu if on_rows else None)
+                seqs = blk.forward_packed(seqs, B, window, causal, pad_idx, pad_ids, None, cu if on_rows else None, n_prefixed)
         return seqs.index_select(0, cu[1:B + 1] - 1)
 
 
@@ -1086,11 +1107,17 @@ class TransformerTorchBackbone(nn.Module):
             cu = torch.zeros((B + 1,), dtype=torch.int64, device=offsets.device)
             torch.cumsum(lens, 0, out=cu[1:])
             n_rows = int(cu[-1])
-        Np = (n_rows + 127) // 128 * 128
+        mode = getattr(self.transformer_layers, "packed_mode", None)
+        prefix = mask_id is None and mode is not None and \
+            mode(int(table.shape[1]), window, self.use_causal_attn, self.use_key_padding_mask) == "prefix"
+        Np = (n_rows + (window if prefix else 0) + 127) // 128 * 128
         if mask_id is None:
             ids, dist = ops.collate_packed(offsets, items, None, rows, cu, Np, train=False)
         else:
             ids, dist = ops.collate_packed_bert(offsets, items, None, rows, cu, Np, window, False, mask_id)
+        if prefix:      # the window's pad rows once, behind the sessions: ids 0 (the rows behind n_rows already are), positions window - 1 .. 0
+            dist[n_rows:n_rows + window] = torch.arange(window - 1, -1, -1, dtype=dist.dtype, device=dist.device)
+            cu = torch.cat([cu, cu[-1:] + window])
         pos = self.pos_encoding_layer.pos_emb.weight if self.pos_encoding_layer.pos_emb is not None else None
         scale = self._pos_scale(table)
         x = torch.empty((Np, d), dtype=torch.float32, device=table.device)
@@ -1098,12 +1125,16 @@ class TransformerTorchBackbone(nn.Module):
         kw = {}
         if ts_store is not None:     # a stack with a relative time bias (HSTU): the sessions' timestamps + the request's, packed
             kw["ts"] = ops.collate_packed_ts(offsets, ts_store, rows, cu, n_rows, ctx=ts_ctx)
+        if prefix:
+            kw["n_prefixed"] = B
+            n_rows = n_rows + window
         return self.transformer_layers.forward_last_packed(x, cu, B, window, self.use_key_padding_mask, rows_real=n_rows,
                                                            causal=self.use_causal_attn, **kw)
 
     def encode_packed_train(self, ids: torch.Tensor, dist: torch.Tensor, cu: torch.Tensor, B: int, window: int,
                             item_embs: tp.Optional[torch.Tensor] = None, rows_real: tp.Optional[int] = None,
-                            cu_attn: tp.Optional[torch.Tensor] = None, ts: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
+                            cu_attn: tp.Optional[torch.Tensor] = None, ts: tp.Optional[torch.Tensor] = None,
+                            n_prefixed: tp.Optional[int] = None) -> torch.Tensor:
         """Training twin of `encode_sessions` on packed rows: ids / dist [Np] (tail rows: id 0, dist 0), -> [Np, d].  ONE fused
         pass (`ops.embed_packed`): embedding rows (pad id 0 has no gradient), positional rows by the distance from the session's
         end, the embedding dropout (torch_backbone.py:245-247)."""
@@ -1111,12 +1142,13 @@ class TransformerTorchBackbone(nn.Module):
         scale = self._pos_scale(table)
         pos = self.pos_encoding_layer.pos_emb.weight if self.pos_encoding_layer.pos_emb is not None else None
         seqs = ops.embed_packed(table, pos, ids, dist, cu, B, window, scale, self.dropout_rate if self.training else 0.0)
+        pk = {} if n_prefixed is None else {"n_prefixed": int(n_prefixed)}      # (session n_prefixed of cu: the shared pad prefix, `LiGRLayers.packed_mode`)
         if cu_attn is not None and rows_real is not None:
             # cu_attn [B + 2]: the unused tail of the row block as one more session of the attention — every row of every buffer of
             # the blocks is then written with finite values (zero gradients flow into the tail), no tail memsets
             return self.transformer_layers.forward_packed_train(seqs, cu_attn, B + 1, window, self.use_key_padding_mask, int(seqs.shape[0]),
-                                                                causal=self.use_causal_attn)
-        kw = {} if ts is None else {"ts": ts}     # (the STU stack's relative time bias: packed timestamps, `ops.collate_packed_ts`)
+                                                                causal=self.use_causal_attn, **pk)
+        kw = dict(pk) if ts is None else dict(pk, ts=ts)     # (the STU stack's relative time bias: packed timestamps, `ops.collate_packed_ts`)
         return self.transformer_layers.forward_packed_train(seqs, cu, B, window, self.use_key_padding_mask, rows_real,
                                                             causal=self.use_causal_attn, **kw)
 

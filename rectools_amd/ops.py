@@ -1747,7 +1747,7 @@ class _MHAVarlenQKV(torch.autograd.Function):
     may ride along as one more session, see `TransformerTorchBackbone.encode_packed_train`)."""
 
     @staticmethod
-    def forward(ctx, qkv, cu, B, H, window, causal, p, covers_all_rows):
+    def forward(ctx, qkv, cu, B, H, window, causal, p, covers_all_rows, n_prefixed=None):
         Np, d3 = qkv.shape
         d = d3 // 3
         hd = d // H
@@ -1759,18 +1759,20 @@ class _MHAVarlenQKV(torch.autograd.Function):
             s0, sid = RNG.next()
             seed = (s0 + 0xD1B54A32D192ED03 * sid) & 0xFFFFFFFFFFFFFFFF
         q, k, v = qkv, qkv[:, d:], qkv[:, 2 * d:]
-        if causal:
+        if n_prefixed is not None:       # sessions 0 .. n_prefixed - 1 behind the shared pad prefix (session n_prefixed): causal only
+            _c("rt_mha_varlen_prefix_fwd", q, d3, k, d3, v, d3, cu, B, int(n_prefixed), H, hd, window, window, float(p), seed, o, d, lse)
+        elif causal:
             _c("rt_mha_varlen_train_fwd", q, d3, k, d3, v, d3, cu, None, None, B, H, hd, window, window, float(p), seed, o, d, lse)
         else:
             _c("rt_mha_varlen_bidir_fwd", q, d3, k, d3, v, d3, cu, B, H, hd, window, float(p), seed, o, d, lse)
         ctx.save_for_backward(qkv, cu, o, lse)
-        ctx.meta = (B, H, window, causal, p, seed, covers_all_rows)
+        ctx.meta = (B, H, window, causal, p, seed, covers_all_rows, n_prefixed)
         return o
 
     @staticmethod
     def backward(ctx, do):
         qkv, cu, o, lse = ctx.saved_tensors
-        B, H, window, causal, p, seed, covers_all_rows = ctx.meta
+        B, H, window, causal, p, seed, covers_all_rows, n_prefixed = ctx.meta
         Np, d3 = qkv.shape
         d = d3 // 3
         hd = d // H
@@ -1778,18 +1780,26 @@ class _MHAVarlenQKV(torch.autograd.Function):
         dqkv = (torch.empty_like if covers_all_rows else torch.zeros_like)(qkv)
         delta = torch.empty((Np, H), dtype=torch.float32, device=qkv.device)
         q, k, v = qkv, qkv[:, d:], qkv[:, 2 * d:]
-        if causal:
+        if n_prefixed is not None:
+            ws_bytes = _lib.load().rt_mha_varlen_prefix_bwd_workspace_bytes(window, H, hd)
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=qkv.device)
+            _c("rt_mha_varlen_prefix_bwd", q, d3, k, d3, v, d3, o, d, do, d, lse, cu, B, int(n_prefixed), H, hd, window, window, float(p), seed,
+               dqkv, d3, dqkv[:, d:], d3, dqkv[:, 2 * d:], d3, delta, ws, ws_bytes)
+        elif causal:
             _c("rt_mha_varlen_bwd", q, d3, k, d3, v, d3, o, d, do, d, lse, cu, None, None, B, H, hd, window, window, float(p), seed,
                dqkv, d3, dqkv[:, d:], d3, dqkv[:, 2 * d:], d3, delta, None)
         else:
             _c("rt_mha_varlen_bidir_bwd", q, d3, k, d3, v, d3, o, d, do, d, lse, cu, B, H, hd, window, float(p), seed,
                dqkv, d3, dqkv[:, d:], d3, dqkv[:, 2 * d:], d3, delta)
-        return dqkv, None, None, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None, None, None
 
 
 def mha_varlen_qkv(qkv: torch.Tensor, cu: torch.Tensor, B: int, H: int, window: int, causal: bool, p: float,
-                   covers_all_rows: bool = False) -> torch.Tensor:
-    return _MHAVarlenQKV.apply(_chk(qkv, "mha_varlen_qkv").contiguous(), cu, B, H, window, bool(causal), p, bool(covers_all_rows))
+                   covers_all_rows: bool = False, n_prefixed: tp.Optional[int] = None) -> torch.Tensor:
+    """n_prefixed: session number `n_prefixed` of cu is the SHARED PAD PREFIX (the window's `window` positions as pad rows, carried once
+    per batch) and sessions 0 .. n_prefixed - 1 see its first window - n_b rows as keys in front of their own — a causal stack that
+    neither masks pad keys nor re-zeroes pad rows (LiGR: the reference's default eSASRec) on packed rows (`rt_mha_varlen_prefix_*`)."""
+    return _MHAVarlenQKV.apply(_chk(qkv, "mha_varlen_qkv").contiguous(), cu, B, H, window, bool(causal), p, bool(covers_all_rows), n_prefixed)
 
 
 def mha_varlen_qkv_infer(qkv: torch.Tensor, cu: torch.Tensor, B: int, H: int, window: int, causal: bool) -> torch.Tensor:

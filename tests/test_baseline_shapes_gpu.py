@@ -145,19 +145,28 @@ def test_softmax_attention_L512_hd64():
 MEASURED = {}     # test name -> {tensor: max |got - oracle| / max |oracle|}: printed (pytest -s / on failure) and kept for profiles/
 
 
-def _pack(batch):
+def _pack(batch, prefix=False):
     """The padded [B, L] batch as the packed batch `training_loss_packed` takes (real positions only, 128-row tile tail of zeros; the
-    row count known on the host selects the native block executors / the fused packed STU node)."""
+    row count known on the host selects the native block executors / the fused packed STU node).  prefix: the window's pad rows ride
+    along once, as session B behind the real ones (id 0, no target, positions L - 1 .. 0) — `nn.LiGRLayers.packed_mode` "prefix"."""
     x = batch["x"].cuda()
     B, L = x.shape
     real = x != 0
-    N = int(real.sum()); tail = (N + 127) // 128 * 128 - N
+    N = int(real.sum())
+    rows_used = N + (L if prefix else 0)
+    tail = (rows_used + 127) // 128 * 128 - N
     pad = lambda t: torch.nn.functional.pad(t, (0, tail))   # noqa: E731
     lens = real.sum(1)
     cu = torch.zeros(B + 1, dtype=torch.int64, device="cuda"); cu[1:] = torch.cumsum(lens, 0)
     dist = (L - 1 - torch.arange(L, device="cuda"))[None, :].expand(B, L)
     out = {"x": pad(x[real]), "y": pad(batch["y"].cuda()[real]), "yw": pad(batch["yw"].cuda()[real]), "dist": pad(dist[real]), "cu": cu,
            "window": L, "n_rows": N}
+    if prefix:
+        out["dist"][N:N + L] = L - 1 - torch.arange(L, device="cuda")
+        full = torch.cat([cu, torch.tensor([N + L, N + tail], device="cuda")])
+        out.update(cu=full[:B + 2], n_rows=N + L, n_prefixed=B)
+        if tail > L:
+            out["cu_attn"] = full
     if "negatives" in batch:
         out["negatives"] = pad(batch["negatives"].cuda()[real].t()).t().contiguous()
     if "unix_ts" in batch:
@@ -186,7 +195,9 @@ def _step_vs_oracle(cfg, batch, grad_rtol=1e-3, name="step", packed=False):
     if packed:      # the padding-free path of the same step, straight against the oracle
         tm = lm.torch_model
         assert tm.transformer_layers.packed_ok(cfg["d"], cfg["L"], tm.use_causal_attn, tm.use_key_padding_mask)
-        loss = lm.training_loss_packed(_pack(batch))
+        mode = getattr(tm.transformer_layers, "packed_mode", None)
+        prefix = mode is not None and mode(cfg["d"], cfg["L"], tm.use_causal_attn, tm.use_key_padding_mask) == "prefix"
+        loss = lm.training_loss_packed(_pack(batch, prefix))
     else:
         loss = lm.training_loss(dbatch)
     loss.backward()
@@ -213,13 +224,16 @@ def test_stu_training_step_L512_d256_H4(packed, B):
     _step_vs_oracle(cfg, batch, name=f"C4 STU L512 B{B}" + (" packed" if packed else ""), packed=packed)
 
 
+@pytest.mark.parametrize("packed", [False, True], ids=["padded", "packed_behind_the_pad_prefix"])
 @pytest.mark.parametrize("L,B", [(64, 3), (200, 4)])
-def test_ligr_training_step_d512(L, B):
+def test_ligr_training_step_d512(L, B, packed):
     """C5 model shape: SASRec data path on LiGR blocks (SwiGLU, no FFN bias, multiplier 4) at d = 512, H = 4 (hd = 128) — at a short
-    window and at the configuration's own L = 200 (the hd = 128 attention kernels' multi-tile geometry)."""
+    window and at the configuration's own L = 200 — through the padded window and, the reference's DEFAULT (no key-padding mask: the
+    pad rows carry state), through packed rows behind ONE copy of the window's pad rows (`nn.LiGRLayers.packed_mode` "prefix"): loss and
+    every parameter gradient straight against the oracle's padded window."""
     cfg, batch = _random_case("ligr", "sampled_softmax", "dot", L, 512, 4, B, 700, 16, 32,
                               layer_kwargs=dict(ff_factors_multiplier=4, ff_activation="swiglu", bias_in_ff=False))
-    _step_vs_oracle(cfg, batch, name=f"C5 LiGR d512 L{L}")
+    _step_vs_oracle(cfg, batch, name=f"C5 LiGR d512 L{L}" + (" packed (pad prefix)" if packed else ""), packed=packed)
 
 
 @pytest.mark.parametrize("packed", [False, True])
@@ -232,11 +246,14 @@ def test_ligr_training_step_d512_key_padding_mask(packed):
     _step_vs_oracle(cfg, batch, name="C5 LiGR d512 kpm" + (" packed" if packed else ""), packed=packed)
 
 
-def test_ligr_without_key_padding_mask_keeps_the_padded_window():
+def test_ligr_packing_modes(monkeypatch):
     cfg, _ = _random_case("ligr", "sampled_softmax", "dot", 64, 512, 4, 3, 700, 16, 32,
                           layer_kwargs=dict(ff_factors_multiplier=4, ff_activation="swiglu", bias_in_ff=False))
-    tm = build_hip_model(cfg).torch_model
-    assert not tm.transformer_layers.packed_ok(cfg["d"], cfg["L"], True, False) and tm.transformer_layers.packed_ok(cfg["d"], cfg["L"], True, True)
+    layers = build_hip_model(cfg).torch_model.transformer_layers
+    assert layers.packed_mode(cfg["d"], cfg["L"], True, True) == "rows" and layers.packed_mode(cfg["d"], cfg["L"], True, False) == "prefix"
+    assert layers.packed_mode(cfg["d"], cfg["L"], False, False) is None          # (bidirectional without masks: every row sees every pad)
+    monkeypatch.setenv("RT_PACKED_PREFIX", "0")
+    assert layers.packed_mode(cfg["d"], cfg["L"], True, False) is None and not layers.packed_ok(cfg["d"], cfg["L"], True, False)
 
 
 @pytest.mark.parametrize("packed", [False, True])

@@ -432,3 +432,105 @@ def test_native_block_with_weight_planes_equals_the_python_block(monkeypatch):
         c = stack.forward_packed_train(x0.cuda(), cu, B, window, False, rows_real=N)[:N].clone()
     assert float((a - b).abs().max()) > 1e-3
     torch.testing.assert_close(b, c, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("H,hd,L,lens", [(2, 64, 200, [200, 1, 57, 64, 130, 199, 33]), (2, 128, 96, [96, 5, 40, 64, 95]),
+                                        (1, 32, 300, [300, 2, 129, 65, 256])])
+def test_attention_behind_a_shared_pad_prefix_equals_the_padded_window(H, hd, L, lens):
+    """`rt_mha_varlen_prefix_*` (K4v3p): sessions packed in front of ONE copy of the window's pad rows against the explicit left-padded
+    window of every session (causal mask only — torch_backbone.py:245-260 without a key-padding mask), fp64 autograd: outputs of every
+    real row and of the prefix's own rows, d q / d k / d v of every row — the prefix rows' gradients are the sum over the sessions that
+    read them.  The tail of the row block rides along as one more session, as in the training loop."""
+    from rectools_amd import ops
+
+    torch.manual_seed(L + hd)
+    d = H * hd
+    B = len(lens)
+    N = sum(lens)
+    Np = N + L + 96                                           # a non-empty tail behind the prefix (the loop's is below 128 rows)
+    qkv = (torch.randn(Np, 3 * d) * 0.5)
+    cu_h = np.r_[0, np.cumsum(lens), N + L, Np].astype(np.int64)     # B sessions, the prefix, the tail
+    gout = torch.randn(Np, d)
+    gout[N + L:] = 0                                          # nothing flows into the tail
+    x = qkv.double().requires_grad_(True)
+    outs = []
+    pre = x[N:N + L]
+    causal = torch.tril(torch.ones(L, L, dtype=torch.bool))
+
+    def window_attention(rows):
+        q, k, v = (rows[:, c * d:(c + 1) * d].view(L, H, hd).transpose(0, 1) for c in range(3))
+        s = (q @ k.transpose(-1, -2)) / hd ** 0.5
+        s = s.masked_fill(~causal, float("-inf"))
+        return (torch.softmax(s, -1) @ v).transpose(0, 1).reshape(L, d)
+
+    r0 = 0
+    for n in lens:
+        win = torch.cat([pre[:L - n], x[r0:r0 + n]])          # the session's left-padded window: the shared pad rows, then its own
+        outs.append(window_attention(win)[L - n:])
+        r0 += n
+    outs.append(window_attention(pre))                        # the prefix's own rows: pads see pads
+    ref = torch.cat(outs)
+    (ref * gout[:N + L].double()).sum().backward()
+
+    xd = qkv.cuda().requires_grad_(True)
+    cu = torch.tensor(cu_h).cuda()
+    out = ops.mha_varlen_qkv(xd, cu, B + 2, H, L, True, 0.0, True, n_prefixed=B)
+    out.backward(gout.cuda())
+    torch.testing.assert_close(out[:N + L].detach().cpu().double(), ref.detach(), rtol=3e-4, atol=3e-5)
+    g, gr = xd.grad[:N + L].cpu().double(), x.grad[:N + L]
+    torch.testing.assert_close(g, gr, rtol=3e-4, atol=3e-4 * float(gr.abs().max()))
+    assert float(xd.grad[N + L:].abs().max()) == 0.0          # zero gradients flow into the tail
+
+
+def test_default_esasrec_packs_behind_a_shared_pad_prefix(monkeypatch):
+    """SASRecModel on LiGR blocks WITHOUT a key-padding mask (the reference's default eSASRec): the product loop on packed rows behind the
+    shared pad prefix against the padded loop — same model, same data, dropout 0, a deterministic sampler: equal losses step by step
+    (over an epoch's end, short last batch included), equal parameters; then recommend() from packed sessions against the padded encoder."""
+    from rectools_amd import nn as hnn
+    from rectools_amd.data_preparator import TransformerNegativeSamplerBase
+    from rectools_amd.dataset import Dataset
+    from rectools_amd.models import SASRecModel
+
+    class RowHashSampler(TransformerNegativeSamplerBase):
+        def get_negatives(self, batch_dict, lowest_id, highest_id, session_len_limit=None, **kwargs):
+            x = batch_dict["x"]
+            j = torch.arange(self.n_negatives, device=x.device, dtype=torch.int64)
+            return lowest_id + (x[..., None] * 7919 + j * 104729 + 13) % (highest_id - lowest_id)
+
+    rng = np.random.default_rng(3)
+    n_users, n_items, n = 150, 90, 5000
+    df = pd.DataFrame({"user_id": rng.integers(0, n_users, n), "item_id": rng.integers(0, n_items, n) + 100, "weight": 1.0,
+                       "datetime": pd.to_datetime("2022-01-01") + pd.to_timedelta(rng.integers(0, 500_000, n), unit="m")})
+    ds = Dataset.construct(df)
+    kw = dict(n_factors=128, n_blocks=2, n_heads=2, session_max_len=40, lr=0.005, batch_size=32, dropout_rate=0.0, loss="sampled_softmax",
+              n_negatives=6, seed=5, epochs=1, negative_sampler_type=RowHashSampler, transformer_layers_type=hnn.LiGRLayers)
+    losses, params, models = {}, {}, {}
+    for packed in ("0", "1"):
+        monkeypatch.setenv("RT_PACKED_TRAIN", packed)
+        m = SASRecModel(**kw)
+        m._build_model_from_dataset(ds)
+        loop = m.training_loop()
+        assert loop.packed == (packed == "1") and loop.prefix == (packed == "1")
+        m.lightning_model.train()
+        loop.begin_epoch(0)
+        losses[packed] = [float(loop.step().detach()) for _ in range(9)]       # runs over the epoch's end (5 batches) into the next one
+        params[packed] = {k: v.detach().clone() for k, v in m.torch_model.state_dict().items()}
+        models[packed] = m
+    np.testing.assert_allclose(losses["1"], losses["0"], rtol=2e-4)
+    d = kw["n_factors"]
+    for k, v in params["0"].items():
+        a, b = params["1"][k], v
+        if k.endswith("in_proj_bias"):
+            # the key bias shifts every logit of a query alike: its true gradient is zero, what either path accumulates is rounding noise
+            # that Adam turns into O(lr) steps — compare the q and v thirds (as the SASRec loop test above does)
+            a, b = torch.cat([a[:d], a[2 * d:]]), torch.cat([b[:d], b[2 * d:]])
+        torch.testing.assert_close(a, b, rtol=5e-3, atol=5e-4, msg=lambda s, k=k: f"{k}: {s}")
+    monkeypatch.delenv("RT_PACKED_TRAIN")
+    m = models["1"]
+    m.is_fitted = True
+    users = ds.user_id_map.external_ids
+    fast = m.recommend(users=users, dataset=ds, k=7, filter_viewed=True)
+    monkeypatch.setenv("RT_PACKED", "0")
+    slow = m.recommend(users=users, dataset=ds, k=7, filter_viewed=True)
+    assert fast[["user_id", "item_id", "rank"]].equals(slow[["user_id", "item_id", "rank"]])
+    np.testing.assert_allclose(fast["score"].values, slow["score"].values, rtol=1e-4, atol=1e-5)
