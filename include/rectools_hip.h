@@ -529,6 +529,10 @@ int rt_preln_block_packed_fwd(const rt_preln_block* blk, const float* x, float* 
 int rt_preln_block_packed_bwd(const rt_preln_block* blk, const float* x, const float* saved, const float* g_out, float* g_x, float* grads,
                               void* scratch, size_t scratch_bytes, int32_t wgrad_splits, int32_t use_side, rt_stream_t stream);
 int rt_side_join(rt_stream_t stream);
+/* `stream` waits for everything issued so far on the side stream; the side stream's bookkeeping is left alone (rt_side_join still joins):
+ * a data-parallel step starts the exchange of the block weights' gradients from its own stream while the backward pass runs on
+ * (the reference: DDP's bucketed all-reduce behind `Trainer.fit`, transformers/base.py:367-380). */
+int rt_side_reach(rt_stream_t stream);
 /* the side stream for the caller's own optimiser-only work: it waits for `stream`'s current position; *side_out = its handle, or
  * NULL when disabled (launch on `stream` then).  Joined by rt_side_join. */
 int rt_side_fork(rt_stream_t stream, void** side_out);

@@ -119,7 +119,7 @@ enum { T_GEMM = 0, T_GEMM_GROUPED = 1, T_LN_FWD = 2, T_LN_BWD = 3, T_DROP_FWD = 
        T_ATTN_LAST = 8, T_MISC = 9, T_ATTN_BIDIR_FWD = 10, T_ATTN_BIDIR_BWD = 11, T_FFN_FWD = 12, T_FFN_BWD = 13 };
 
 // ---- the weight-gradient side stream (one per device, owned by the library) -------------------------------------------------------
-struct Side { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr, mark = nullptr; bool dirty = false, marked = false; };
+struct Side { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr, mark = nullptr, reach = nullptr; bool dirty = false, marked = false; };
 Side g_side[16];
 bool side_enabled() {
   static int on = -1;
@@ -142,6 +142,7 @@ Side* side_of_current_device() {
     if (rc != hipSuccess) return nullptr;
     (void)hipEventCreateWithFlags(&s.fork, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&s.join, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&s.reach, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&s.mark, hipEventDisableTiming);
   }
   return &s;
@@ -191,6 +192,17 @@ int rt_side_join(hipStream_t stream) {
   RT_CHECK_HIP(hipEventRecord(s->join, s->stream));
   RT_CHECK_HIP(hipStreamWaitEvent(stream, s->join, 0));
   s->dirty = false; s->marked = false;
+  return RT_OK;
+}
+
+// `stream` waits for everything issued so far on the side stream, and the side stream's bookkeeping stays as it is (the step's
+// rt_side_join still joins and clears): the early gradient exchange of a data-parallel step (lightning.FlatAdam.begin_early_exchange)
+// reads the block weights' gradients from its own stream while the caller's stream runs on.
+int rt_side_reach(hipStream_t stream) {
+  Side* s = side_of_current_device();
+  if (s == nullptr || !s->dirty) return RT_OK;
+  RT_CHECK_HIP(hipEventRecord(s->reach, s->stream));
+  RT_CHECK_HIP(hipStreamWaitEvent(stream, s->reach, 0));
   return RT_OK;
 }
 

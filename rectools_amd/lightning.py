@@ -11,6 +11,7 @@
 """
 from __future__ import annotations
 
+import os
 import typing as tp
 
 import torch
@@ -404,6 +405,14 @@ class FlatAdam:
         self.partial_moments: tp.Optional[tp.Tuple[int, int]] = None
         # bench.py --gpus N: device-side duration of every step's gradient exchange (pack + collective[s]), HIP events on the step's stream
         self.exchange_events: tp.Optional[tp.List[tp.Tuple[tp.Any, tp.Any]]] = None
+        # the EARLY bucket of the all-reduce exchange (`set_early_bucket`): first parameter index / float offset of the flat buffer's tail
+        # whose gradients exist before the backward pass ends; `_early`: the exchange in flight between `begin_early_exchange` and `step`
+        self.early_first: tp.Optional[int] = None
+        self.early_from: tp.Optional[int] = None
+        self._early: tp.Optional[tp.Tuple[tp.Any, tp.List[torch.Tensor], tp.Any]] = None
+        self._xs: tp.Optional["torch.cuda.Stream"] = None     # the exchange's own stream (made on first use)
+        self.early_enabled = os.environ.get("RT_DP_EARLY", "1") != "0"
+        self.early_stats = {"started": 0, "redone": 0}
 
     def use_rccl_exchange(self, rank: int, world: int) -> None:
         """Route the gradient all-reduce and the parameter broadcast through `rt_dp_*` (collective: every rank calls it)."""
@@ -428,13 +437,21 @@ class FlatAdam:
                 dist.broadcast(buf, src=src)
 
     def zero_grad(self) -> None:
+        if self._early is not None:      # an early exchange nobody finished (the step was abandoned): let it land, drop its result
+            work, _, done = self._early
+            self._early = None
+            if work is not None:
+                work.wait()
+            elif done is not None:
+                torch.cuda.current_stream(self.flat_p.device).wait_event(done)
         for p in self.params:
             p.grad = None  # the next backward's gradient tensors are adopted as they are
         ops.clear_step_expectations()
 
-    def gather_gradients(self) -> torch.Tensor:
+    def gather_gradients(self, first: int = 0, last: tp.Optional[int] = None) -> torch.Tensor:
         """Pack the per-parameter gradients into the flat buffer (zeros where a parameter got none): ONE multi-tensor copy
-        launch for all of them instead of a copy kernel per parameter (28 launches at C2 right before the collective)."""
+        launch for all of them instead of a copy kernel per parameter (28 launches at C2 right before the collective).
+        first / last: parameters [first, last) only (the two buckets of the early exchange)."""
         fg = self.flat_g
         if self._g_views is None:
             self._g_views = [fg[ofs:ofs + p.numel()].view_as(p) for p, ofs in zip(self.params, self._offsets)]
@@ -454,7 +471,7 @@ class FlatAdam:
                     ops._TABLE_GRAD_HOME[key] = (lambda ofs=ofs, shape=p.shape, n=p.numel(): home(ofs, shape, n))
                     weakref.finalize(self, ops._TABLE_GRAD_HOME.pop, key, None)
         views, grads = [], []
-        for p, view in zip(self.params, self._g_views):
+        for p, view in zip(self.params[first:last], self._g_views[first:last]):
             if p.grad is None:
                 view.zero_()
             elif p.grad.data_ptr() == view.data_ptr() and p.grad.shape == view.shape and p.grad.is_contiguous():
@@ -465,6 +482,111 @@ class FlatAdam:
         if views:
             torch._foreach_copy_(views, grads)   # pylint: disable=protected-access
         return fg
+
+    # ---- the early bucket of the all-reduce exchange ---------------------------------------------------------------------------------
+    def set_early_bucket(self, late: tp.Iterable[torch.Tensor]) -> None:
+        """`late`: the parameters whose gradients are complete only when the backward pass ENDS — the input embeddings (item net,
+        positions): the lookup's backward is the last node.  Every parameter behind the last of them in the flat buffer (the block
+        weights: 13 % of C2's gradient bytes) forms the EARLY bucket: `begin_early_exchange` starts its all-reduce while the
+        backward pass runs on, `step` exchanges the rest and runs Adam on the early bucket under that second collective — what DDP's
+        bucketed all-reduce does behind the reference's `Trainer.fit` (transformers/base.py:367-380).  The sharded exchange (table-
+        dominated gradients: the early bucket is < 1 % of the bytes there) keeps its single reduce-scatter."""
+        late_ids = {id(p) for p in late}
+        last = max((i for i, p in enumerate(self.params) if id(p) in late_ids), default=-1)
+        if 0 <= last < len(self.params) - 1:
+            self.early_first, self.early_from = last + 1, self._offsets[last + 1]
+        else:
+            self.early_first = self.early_from = None
+
+    def _exchange_stream(self) -> "torch.cuda.Stream":
+        if self._xs is None:
+            self._xs = torch.cuda.Stream(device=self.flat_p.device)
+        return self._xs
+
+    def begin_early_exchange(self, world_size: int, force: bool = False) -> bool:
+        """Called when every gradient of the early bucket EXISTS (a hook on the gradient of the blocks' input: the autograd engine has run
+        the blocks' nodes and their accumulators, the lookup's backward comes next).  Packs the bucket and starts its sum all-reduce
+        on the exchange stream, ordered behind the weight-gradient side streams (`ops.side_streams_reach`) — the calling stream is
+        not held up.  COLLECTIVE: every rank takes the same decision (it depends on the configuration only).  -> started?"""
+        import torch.distributed as dist
+
+        if (self.early_from is None or not self.early_enabled or (world_size <= 1 and not force) or self._early is not None
+                or self._use_sharded(world_size) or self.partial_moments is not None):      # (force: the one-rank RCCL smoke test)
+            return False
+        params = self.params[self.early_first:]
+        if any(p.grad is None for p in params):      # (a frozen / unused parameter: the step's own pack writes its zeros)
+            return False
+        fg = self.flat_g
+        cuda = fg.is_cuda
+        done = None
+        if cuda:
+            xs = self._exchange_stream()
+            xs.wait_stream(torch.cuda.current_stream(fg.device))
+            ops.side_streams_reach(xs)
+            ctx: tp.Any = torch.cuda.stream(xs)
+        else:
+            import contextlib
+
+            ctx = contextlib.nullcontext()
+        with ctx:
+            self.gather_gradients(self.early_first, None)
+            seg = fg[self.early_from:]
+            if self.exchange is not None:
+                self.exchange.all_reduce(seg)
+                work = None
+            else:
+                work = dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True)
+            if cuda:
+                done = xs.record_event()
+        self._early = (work, [p.grad for p in params], done)
+        self.early_stats["started"] += 1
+        return True
+
+    def _finish_early(self, world_size: int, hyper: tp.Tuple) -> None:
+        """The step behind `begin_early_exchange`: pack and exchange the LATE bucket (asynchronously), wait for the early one, Adam on
+        the early bucket while the late collective runs, wait, Adam on the late bucket."""
+        import torch.distributed as dist
+
+        work_b, grads_b, done_b = self._early      # type: ignore[misc]
+        self._early = None
+        fg, ef = self.flat_g, self.early_from
+        cuda = fg.is_cuda
+        params_b = self.params[self.early_first:]
+        stale = any(p.grad is not g for p, g in zip(params_b, grads_b))      # (somebody replaced a gradient behind the hook: e.g. a second backward)
+        self.gather_gradients(0, self.early_first)
+        late = fg[:ef]
+        work_t, done_t = None, None
+        if self.exchange is not None:      # one communicator: its collectives stay on ONE stream, in issue order
+            xs = self._exchange_stream()
+            xs.wait_stream(torch.cuda.current_stream(fg.device))
+            with torch.cuda.stream(xs):
+                self.exchange.all_reduce(late)
+                done_t = xs.record_event()
+        else:
+            work_t = dist.all_reduce(late, op=dist.ReduceOp.SUM, async_op=True)
+        if work_b is not None:
+            work_b.wait()
+        elif done_b is not None:
+            torch.cuda.current_stream(fg.device).wait_event(done_b)
+        if stale:      # exchange the bucket again from the gradients as they are now (the first sum is overwritten by the pack)
+            self.early_stats["redone"] += 1
+            if work_t is not None:
+                work_t.wait()
+            elif done_t is not None:
+                torch.cuda.current_stream(fg.device).wait_event(done_t)
+            self.gather_gradients(self.early_first, None)
+            if self.exchange is not None:
+                self.exchange.all_reduce(fg[ef:])
+            else:
+                dist.all_reduce(fg[ef:], op=dist.ReduceOp.SUM)
+            self._adam_flat(self.flat_p, fg, self.m, self.v, hyper)
+            return
+        self._adam_flat(self.flat_p[ef:], fg[ef:], self.m[ef:], self.v[ef:], hyper)
+        if work_t is not None:
+            work_t.wait()
+        elif done_t is not None:
+            torch.cuda.current_stream(fg.device).wait_event(done_t)
+        self._adam_flat(self.flat_p[:ef], late, self.m[:ef], self.v[:ef], hyper)
 
     def reduce_gradients(self, world_size: int = 1, force: bool = False) -> float:
         """Data-parallel gradient exchange: ONE sum all-reduce of the flat gradient buffer (RCCL over xGMI on GPUs,
@@ -586,6 +708,14 @@ class FlatAdam:
             return
         if self.partial_moments is not None:     # an all-reduce step after sharded ones needs whole moments on every rank
             self.consolidate_moments()
+        if self._early is not None:              # the early bucket is in flight (begin_early_exchange): the two-bucket step
+            self.step_count += 1
+            self._finish_early(world_size, (self.step_count, float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                            1.0 / max(world_size, 1)))
+            if timed:
+                e1.record()
+                self.exchange_events.append((e0, e1))
+            return
         flat = flat or world_size > 1
         scale = self.reduce_gradients(world_size, force=flat)
         if timed:

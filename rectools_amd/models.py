@@ -150,6 +150,12 @@ class _TrainLoop:
         # packed training batches (no padding rows): the default wherever the stack offers it (causal SASRec blocks,
         # head size 32 / 64); RT_PACKED_TRAIN=0 keeps the padded [B, L] window (the cross-check of tests/test_packed_gpu.py)
         tm = lm.torch_model
+        # data parallel, all-reduce exchange: the block weights' gradients leave while the lookup's backward still runs (FlatAdam.set_early_bucket)
+        tm.on_input_gradient = None
+        if self.world > 1 and hasattr(tm, "on_input_gradient"):
+            opt.set_early_bucket([*tm.item_model.parameters(), *tm.pos_encoding_layer.parameters()])
+            world = self.world
+            tm.on_input_gradient = lambda: opt.begin_early_exchange(world)
         self.bert = type(self.dp).__name__ == "BERT4RecDataPreparator"
         self.stu = isinstance(tm.transformer_layers, hnn.STULayers)      # the only stack that reads the batch's timestamps
         self.packed = (os.environ.get("RT_PACKED_TRAIN", "1") != "0" and type(self.dp).__name__ in _PACKED_PREPARATORS

@@ -1036,6 +1036,10 @@ class TransformerTorchBackbone(nn.Module):
         self.transformer_layers = transformer_layers
         self.similarity_module = similarity_module
         self.use_causal_attn = use_causal_attn
+        # called (no arguments) when a backward pass has produced every gradient BEHIND the blocks' input and is about to run the
+        # lookup's backward: a data-parallel loop starts the exchange of the block weights' gradients there (`lightning.FlatAdam.
+        # begin_early_exchange`).  A plain attribute: not a parameter, not in the state_dict.
+        self.on_input_gradient: tp.Optional[tp.Callable[[], None]] = None
         self.use_key_padding_mask = use_key_padding_mask
         self.n_heads = n_heads
         self.dropout_rate = dropout_rate
@@ -1054,6 +1058,16 @@ class TransformerTorchBackbone(nn.Module):
         pe = self.pos_encoding_layer
         return isinstance(pe, LearnableInversePositionalEncoding) and type(pe).forward is LearnableInversePositionalEncoding.forward
 
+    def _watch_input_gradient(self, seqs: torch.Tensor) -> torch.Tensor:
+        if self.on_input_gradient is not None and seqs.requires_grad:
+            notify = self.on_input_gradient
+
+            def hook(_g: torch.Tensor) -> None:      # (returns None: the gradient passes unchanged)
+                notify()
+
+            seqs.register_hook(hook)
+        return seqs
+
     def _embed_sessions(self, table: torch.Tensor, ids: torch.Tensor, B: int, L: int, p: float) -> torch.Tensor:
         """[B*L, d] = dropout(pos_encoding(item embeddings)) (torch_backbone.py:245-247)."""
         d = table.shape[1]
@@ -1071,7 +1085,7 @@ class TransformerTorchBackbone(nn.Module):
         table = self.item_model.table if item_embs is None else item_embs
         d = table.shape[1]
         ids = x.reshape(-1)
-        seqs = self._embed_sessions(table, ids, B, L, self.dropout_rate if self.training else 0.0)
+        seqs = self._watch_input_gradient(self._embed_sessions(table, ids, B, L, self.dropout_rate if self.training else 0.0))
         seqs = self.transformer_layers(seqs, ids, B, L, self.use_causal_attn, self.use_key_padding_mask, batch)
         return seqs.view(B, L, d)
 
@@ -1141,7 +1155,7 @@ class TransformerTorchBackbone(nn.Module):
         table = self.item_model.table if item_embs is None else item_embs
         scale = self._pos_scale(table)
         pos = self.pos_encoding_layer.pos_emb.weight if self.pos_encoding_layer.pos_emb is not None else None
-        seqs = ops.embed_packed(table, pos, ids, dist, cu, B, window, scale, self.dropout_rate if self.training else 0.0)
+        seqs = self._watch_input_gradient(ops.embed_packed(table, pos, ids, dist, cu, B, window, scale, self.dropout_rate if self.training else 0.0))
         pk = {} if n_prefixed is None else {"n_prefixed": int(n_prefixed)}      # (session n_prefixed of cu: the shared pad prefix, `LiGRLayers.packed_mode`)
         if cu_attn is not None and rows_real is not None:
             # cu_attn [B + 2]: the unused tail of the row block as one more session of the attention — every row of every buffer of

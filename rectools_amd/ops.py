@@ -228,6 +228,16 @@ def join_side_streams() -> None:
     _TABLE_GRAD_ON_SIDE.clear()
 
 
+def side_streams_reach(stream: "torch.cuda.Stream") -> None:
+    """`stream` waits for everything issued so far on the weight-gradient side streams; nothing is joined or released (the step's
+    `join_side_streams` still does that).  For a reader of the block weights' gradients that is not the main stream: the early
+    gradient exchange of a data-parallel step (`lightning.FlatAdam.begin_early_exchange`)."""
+    for dev in list(_SIDE_DIRTY):
+        stream.wait_event(_SIDE[dev].record_event())
+    if _NATIVE_KEEPALIVE or _PREP_KEEPALIVE:
+        _lib.check(_lib.load().rt_side_reach(stream.cuda_stream), "rt_side_reach")
+
+
 # --------------------------------------------------------------------------------------------------
 # dense
 # --------------------------------------------------------------------------------------------------

@@ -151,3 +151,75 @@ def test_early_stop_and_epoch_metrics_are_reduced_over_the_ranks(tmp_path):
     from rectools_amd.models import TransformerModelBase
 
     assert TransformerModelBase._all_reduce_host([3.0, 4.0], "mean", torch.device("cpu")) == [3.0, 4.0]      # no process group: as given
+
+
+def _worker_early(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rectools_amd.lightning import FlatAdam
+
+    class Net(torch.nn.Module):      # input embeddings (late: their gradient is the LAST of a backward pass) in front of "block" weights
+        def __init__(self):
+            super().__init__()
+            self.table = torch.nn.Embedding(3000, 8)
+            self.pos = torch.nn.Embedding(16, 8)
+            self.a, self.b = torch.nn.Linear(8, 8), torch.nn.Linear(8, 3)
+            self.on_input_gradient = None
+
+        def forward(self, ids):
+            x = self.table(ids) + self.pos(torch.arange(ids.shape[1]))
+            if self.on_input_gradient is not None:
+                notify = self.on_input_gradient
+                x.register_hook(lambda _g: notify())
+            return self.b(torch.tanh(self.a(x)))
+
+    results = {}
+    for mode in ("one_bucket", "early", "early_stale"):
+        os.environ["RT_DP_EXCHANGE"] = "allreduce"
+        torch.manual_seed(0)
+        net = Net()
+        opt = FlatAdam(net, lr=1e-2)
+        opt._adam_flat = lambda p, g, m, v, hyper: _torch_adam(p, g, m, v, hyper)
+        seen = []
+        if mode != "one_bucket":
+            opt.set_early_bucket([*net.table.parameters(), *net.pos.parameters()])
+            assert opt.early_first == 2 and opt.early_from == opt._offsets[2]      # a, b behind table, pos
+            def fire():
+                # every gradient of the early bucket exists, none of the late one does: the lookup's backward has not run yet
+                seen.append(([p.grad is not None for p in opt.params[opt.early_first:]], [p.grad is not None for p in opt.params[:opt.early_first]]))
+                assert opt.begin_early_exchange(world)
+            net.on_input_gradient = fire
+        for step in range(3):
+            opt.zero_grad()
+            ids = (torch.arange(64).view(4, 16) * (7 * rank + 5) + step) % 3000
+            net(ids).pow(2).sum().mul(rank + 1.0).backward()
+            if mode == "early_stale" and step == 1:      # somebody replaces a block gradient behind the hook: the bucket is exchanged again
+                net.a.weight.grad = net.a.weight.grad * 1.0
+            opt.step(world)
+        if mode != "one_bucket":
+            assert len(seen) == 3 and all(early == [True] * 4 and late == [False, False] for early, late in seen), seen
+            assert opt.early_stats == {"started": 3, "redone": 1 if mode == "early_stale" else 0}
+            assert opt._early is None
+        results[mode] = (opt.flat_p.clone(), opt.m.clone(), opt.v.clone())
+    for mode in ("early", "early_stale"):
+        for a, b in zip(results["one_bucket"], results[mode]):
+            assert torch.equal(a, b) if world == 2 else torch.allclose(a, b, rtol=1e-6, atol=1e-8)      # (a sum of two is order-free)
+    mine = [torch.zeros_like(results["early"][0]) for _ in range(world)]
+    dist.all_gather(mine, results["early"][0])
+    assert all(torch.equal(mine[0], t) for t in mine)                                  # replicas stay bit-identical
+    # an abandoned step (no opt.step behind the hook) is drained by the next zero_grad
+    opt.zero_grad()
+    net(torch.zeros(2, 16, dtype=torch.long)).sum().backward()
+    assert opt._early is not None
+    opt.zero_grad()
+    assert opt._early is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_early_bucket_exchange_equals_the_one_bucket_step(tmp_path, world):
+    """FlatAdam.set_early_bucket / begin_early_exchange: the block weights' all-reduce starts from a hook INSIDE the backward pass (before the
+    lookup's gradient exists), the late bucket follows in step(), Adam runs per bucket — same parameters and moments as the one-bucket
+    step on every rank; a gradient replaced behind the hook makes the step exchange the bucket again."""
+    mp.spawn(_worker_early, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)

@@ -20,7 +20,36 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+def _wire_early_bucket(lm, opt, world, force=False):
+    """What `models._TrainLoop` does for a data-parallel loop: the block weights' exchange starts from the gradient hook of the blocks' input."""
+    tm = lm.torch_model
+    opt.set_early_bucket([*tm.item_model.parameters(), *tm.pos_encoding_layer.parameters()])
+    assert opt.early_first is not None and opt.early_from > 0
+    log = []
+
+    def fire():
+        late = [p.grad is not None for p in opt.params[:opt.early_first] if p.ndim == 2 and p.shape[0] < 1024]      # (positions: no flat-buffer home)
+        early = [p.grad is not None for p in opt.params[opt.early_first:]]
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        assert opt.begin_early_exchange(world, force=force)
+        log.append((early, late, ev))
+
+    tm.on_input_gradient = fire
+    return log
+
+
+def _check_early_log(log, opt, steps):
+    """Every step took the two-bucket path; at the hook every block gradient existed and the lookup's had not been produced; the
+    lookup's backward kernels ran on the device AFTER the point the exchange was issued behind."""
+    assert opt.early_stats == {"started": steps, "redone": 0} and len(log) == steps, (opt.early_stats, len(log))
+    for early, late, _ in log:
+        assert all(early) and not any(late), (early, late)
+
+
 def _worker(rank, world, port, out_dir, exchange="allreduce", shape="small"):
+    early = exchange == "early"
+    exchange = "allreduce" if early else exchange
     os.environ["RT_DP_EXCHANGE"] = exchange
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -41,14 +70,19 @@ def _worker(rank, world, port, out_dir, exchange="allreduce", shape="small"):
                     prm.add_(0.05)
     opt = hl.FlatAdam(lm.torch_model, lr=1e-2)
     opt.broadcast_parameters()
+    log = _wire_early_bucket(lm, opt, world) if early else None
     p0 = {n: p.detach().clone() for n, p in lm.torch_model.named_parameters()}
     batch = bench.make_train_batches(1, B, L, V, n_neg, rank)[0]                 # rank-dependent data
     ops.RNG.next_step()
     opt.zero_grad()
     lm.training_loss(batch).backward()
+    bwd_end = torch.cuda.Event(enable_timing=True)
+    bwd_end.record()
     local = {n: p.grad.detach().clone() for n, p in lm.torch_model.named_parameters()}
     opt.step(world)
     torch.cuda.synchronize()
+    if early:
+        assert log[0][2].elapsed_time(bwd_end) > 0.0      # device time between the hook and the end of the backward pass: the lookup's backward
     g1 = {}
     for n, p in lm.torch_model.named_parameters():
         g = local[n].clone()
@@ -88,15 +122,20 @@ def _worker(rank, world, port, out_dir, exchange="allreduce", shape="small"):
             if not torch.equal(both[0], both[1]):
                 bad.append((what, n, float((both[0] - both[1]).abs().max())))
     assert not bad, bad
+    if early:
+        _check_early_log(log, opt, 2 if shape == "c2" else 1)
     np.save(os.path.join(out_dir, f"ok{rank}.npy"), np.ones(1))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("shape", ["small", "c2"])
-@pytest.mark.parametrize("exchange", ["allreduce", "sharded"])
+@pytest.mark.parametrize("exchange", ["allreduce", "sharded", "early"])
 def test_two_rank_step_matches_mean_gradient_adam(tmp_path, exchange, shape):
-    """`sharded`: reduce-scatter -> rt_adam_step on the rank's 1/N slice of (p, m, v) -> all-gather of the parameters
+    """`early`: the all-reduce exchange in two buckets — the block weights' all-reduce is started by the gradient hook of the blocks' input
+    (FlatAdam.begin_early_exchange: packed on the exchange stream behind the weight-gradient side streams), the embeddings' follows in
+    step(), Adam runs per bucket; asserted: every block gradient exists at the hook and no lookup gradient does, the device ran the lookup's
+    backward after the hook, same Adam step, replicas bit-identical.  `sharded`: reduce-scatter -> rt_adam_step on the rank's 1/N slice of (p, m, v) -> all-gather of the parameters
     (FlatAdam.step_sharded; over gloo with both ranks on this GPU): the same first Adam step, replicas bit-identical — on a small model
     and at the C2 model size (the HIP Adam kernel on a 15.5 MB slice of the 31 MB flat buffers)."""
     world = 2
@@ -157,6 +196,7 @@ def _nccl_worker(rank, world, port, out_dir):
     lm.train()
     opt = hl.FlatAdam(lm.torch_model, lr=1e-2)
     opt.broadcast_parameters(force=True)
+    log = _wire_early_bucket(lm, opt, world, force=True)      # the two-bucket exchange through RCCL's own streams (async collectives)
     p0 = {n: p.detach().clone() for n, p in lm.torch_model.named_parameters()}
     with torch.cuda.device(rank):
         batch = helpers_dp.make_train_batches(1, B, L, V, n_neg, rank)[0]
@@ -179,6 +219,7 @@ def _nccl_worker(rank, world, port, out_dir):
                 want = p0[n] - 1e-2 * g / (g.abs() + 1e-8)
                 torch.testing.assert_close(p.detach(), want, rtol=2e-4, atol=2e-6, msg=lambda m, n=n: f"{n}: {m}")
     assert losses[2] < losses[0], losses                  # same batch three times: the loss must go down
+    _check_early_log(log, opt, 3)
     t = torch.tensor([float(rank + 1)], device=f"cuda:{rank}")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)              # bench.py's max-over-ranks
     assert float(t) == world
