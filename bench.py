@@ -134,11 +134,14 @@ def gather_floats(x: float, world: int):
     return [float(o.item()) for o in out]
 
 
-def timed_steps(step_fn, steps: int, warmup: int, world: int):
+def timed_steps(step_fn, steps: int, warmup: int, world: int, finish=None):
     """W untimed + exactly K timed steps, bracketed by barrier + synchronize; per-step HIP events on the
-    current stream (the stream every rt_* kernel is launched on) give the kernel-side duration."""
+    current stream (the stream every rt_* kernel is launched on) give the kernel-side duration.  finish: called once behind the K
+    steps, INSIDE the timed region (the top-k legs: `HipRanker.settle()` — the one read of all the calls' proof flags)."""
     for _ in range(warmup):
         step_fn()
+    if finish is not None:
+        finish()
     barrier_sync(world)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     stats0 = torch.cuda.memory_stats()
@@ -148,6 +151,8 @@ def timed_steps(step_fn, steps: int, warmup: int, world: int):
         step_fn()
         evs[i][1].record()
     issue = time.perf_counter() - t0      # the host has issued every launch of the timed steps (the device may still be working)
+    if finish is not None:
+        finish()
     barrier_sync(world)
     wall = time.perf_counter() - t0
     ev_ms = [a.elapsed_time(b) for a, b in evs]
@@ -194,8 +199,8 @@ def make_topk_workload(n_items: int, d: int, users_per_step: int, upp: int, rank
     dfilt = DeviceCSR.from_scipy(filt, "cuda") if filt is not None else None
     state = {}
 
-    def step():
-        state["out"] = ranker.rank_device(sids, k=10, filter_pairs_csr=dfilt)
+    def step():      # calls queue back to back; their proof flags are read once, by ranker.settle() behind the timed steps (in the timed region)
+        state["out"] = ranker.rank_device(sids, k=10, filter_pairs_csr=dfilt, settle=False)
 
     return step, ranker, dict(n_items=n_items, d=d, users=users_per_step, nnz=nnz, items=items, users_t=users,
                               filt=filt)
@@ -286,7 +291,7 @@ def cpu_baseline_topk(items_t: torch.Tensor, users_t: torch.Tensor, filt, budget
 def run_topk(steps, warmup, rank, world, n_items, d, users_per_step, upp, with_filter, name):
     """One step = one rt_topk_score launch sequence over `users_per_step` users (inputs resident in HBM)."""
     step, ranker, info = make_topk_workload(n_items, d, users_per_step, upp, rank, with_filter, seed=0)
-    wall, ev_ms = timed_steps(step, steps, warmup, world)
+    wall, ev_ms = timed_steps(step, steps, warmup, world, finish=ranker.settle)
     users_total = users_per_step * steps * world
     value = users_total / wall
     # algorithmic bytes / flops of ONE launch (SURVEY.md §8d): catalog read once for the whole user batch
@@ -312,7 +317,7 @@ def run_topk(steps, warmup, rank, world, n_items, d, users_per_step, upp, with_f
     roof = {
         "kernel": ("rt_topk_score_two_stage call (users' image + coarse stream kernel on v_mfma_f32_32x32x16_bf16" +
                    (" over the ONE-plane bf16 image of the catalog (half the fp32 bytes; exactness from the exact pass + per-user proof)" if h_only else "") +
-                   " + merge + exact pass over 64 candidates per user + the read of the proof flags; HIP events around the whole call)") if two_stage else
+                   " + merge + exact pass over 64 candidates per user; HIP events around every call, calls issued back to back, the proof flags of all of them read once behind the last one — HipRanker.settle(), inside the timed region)") if two_stage else
                   "rt_topk_score call (seed prefix + topk stream kernel + merge; HIP events around the whole call)",
         "bound": "hbm" if hbm_bound else "mfma",
         "achieved": round(gbs if hbm_bound else tfs, 2),

@@ -1599,13 +1599,15 @@ inline Plan make_plan(int n_users, long long n_cand, int k, int users_per_pass) 
   if (S < 1) S = 1;
   P.S = (int)S;
   P.n_lists = P.S * LISTS_PER_WG;
-  // Threshold seeding (phase A): every workgroup first scores 2 blocks of a catalog prefix; the k-th best of
+  // Threshold seeding (phase A): the first workgroups score 2 blocks each of a catalog prefix; the k-th best of
   // that prefix (topk_seed_kernel) becomes the shared bound, so that in phase B a list sees ~1 candidate
   // instead of ~k*ln(blocks): the slow path (and its pipeline drain) becomes rare at wave level.
   P.S_seed = 0; P.blocks_seed = 0;
   {
-    const int ss = P.S < 64 ? P.S : 64;  // few workgroups x 8 blocks: short lists for the seed kernel
-    const long long bs = (long long)ss * 8;
+    // 128 workgroups x 2 blocks (round 6, 5 M x 512, 16 users: 1.112 ms per call against 1.140 with 64 x 8, 1.184 with 256 x 2 — the
+    // seed kernel's lists grow with the workgroups —, 1.336 without seeding; gpurun_out/r6_seed)
+    const int ss = P.S < 128 ? P.S : 128;
+    const long long bs = (long long)ss * 2;
     if (n_blocks >= 32 * bs && P.n_tiles <= 8) { P.S_seed = ss; P.blocks_seed = bs; }
   }
   size_t o = 0;

@@ -138,6 +138,7 @@ class HipRanker:
         self._h_only_strikes = 0
         self._max_item_norm = 0.0
         self.two_stage_stats = {"calls": 0, "fallbacks": 0, "unproven_users": 0, "h_only_calls": 0}
+        self._unsettled: tp.List[tp.Tuple[torch.Tensor, bool, tp.Tuple]] = []      # two-stage calls whose proof flags nobody has read yet (`settle`)
 
     # ---- catalog images outlive a ranker -----------------------------------------------------------------
     _IMAGE_FIELDS = ("_items_hm", "_items_h", "_items_frag", "_h_only_off", "_h_only_strikes", "_max_item_norm")
@@ -244,10 +245,10 @@ class HipRanker:
         _lib.check(status, "rt_topk_score")
 
     def _rank_two_stage(self, ids_t, scores_t, counts_t, rows_t, n_subj, whitelist_t, n_cand, id_offset, kk, indptr_t, indices_t,
-                        hash_t, upp) -> None:
+                        hash_t, upp, settle: bool = True) -> None:
         """Coarse pass over the hm images + exact pass over CANDIDATES candidates per user (`rt_topk_score_two_stage`); users whose
         result the kernel could not prove complete are ranked again by the single-stage kernel (one device -> host read of the
-        flags: the only synchronisation of the call)."""
+        flags: the only synchronisation of the call — `settle=False` leaves it to `settle()`)."""
         S, O = self.subjects_factors, self.objects_factors
         d, kc, dev = O.shape[1], self.CANDIDATES, self.device
         self.two_stage_stats["calls"] += 1
@@ -295,7 +296,32 @@ class HipRanker:
                 _lib.ptr(ids_t), _lib.ptr(scores_t), _lib.ptr(counts_t), _lib.ptr(unproven), _lib.ptr(self._workspace),
                 self._workspace.numel(), upp2, _lib.current_stream())
             _lib.check(status, "rt_topk_score_two_stage")
-            bad = torch.nonzero(unproven).reshape(-1).cpu().numpy()
+        args = (ids_t, scores_t, counts_t, rows_t, n_subj, whitelist_t, n_cand, id_offset, kk, indptr_t, indices_t, hash_t, upp)
+        if not settle:      # the caller reads the flags later, for all its calls at once
+            self._unsettled.append((unproven, h_only, args))
+            return
+        self._repair(np.flatnonzero(unproven.cpu().numpy()), h_only, args)
+
+    def settle(self) -> int:
+        """Finish every `rank_device(..., settle=False)` call issued so far: ONE device -> host read of all their proof flags, then
+        the users a coarse pass could not prove are ranked again into the tensors those calls returned.  Until then such a call's
+        results are the best k CANDIDATES (complete for every proven user — in practice all: `two_stage_stats`).  -> users repaired."""
+        pending, self._unsettled = self._unsettled, []
+        if not pending:
+            return 0
+        with torch.cuda.device(self.device):
+            flags = torch.cat([u for u, _, _ in pending]).cpu().numpy()
+        repaired, at = 0, 0
+        for unproven, h_only, args in pending:
+            bad = np.flatnonzero(flags[at:at + unproven.numel()])
+            at += unproven.numel()
+            repaired += len(bad)
+            self._repair(bad, h_only, args)
+        return repaired
+
+    def _repair(self, bad: np.ndarray, h_only: bool, args: tp.Tuple) -> None:
+        """Rank the users `bad` of a two-stage call again (see `_rank_two_stage`); `args`: that call's arguments."""
+        ids_t, scores_t, counts_t, rows_t, n_subj, whitelist_t, n_cand, id_offset, kk, indptr_t, indices_t, hash_t, upp = args
         if len(bad) == 0:
             return
         self.two_stage_stats["unproven_users"] += int(len(bad))
@@ -369,11 +395,13 @@ class HipRanker:
         k: tp.Optional[int] = None,
         filter_pairs_csr: tp.Union[None, sparse.csr_matrix, DeviceCSR] = None,
         sorted_object_whitelist: tp.Optional[np.ndarray] = None,
+        settle: bool = True,
     ) -> tp.Tuple[torch.Tensor, torch.Tensor, torch.Tensor, np.ndarray]:
         """Device-resident result: (ids [S,k] int64, scores [S,k] f32, counts [S] int32, subject_ids).
 
-        `filter_pairs_csr` may be a `DeviceCSR` prepared once (no per-call upload); nothing here
-        synchronises the device except the small id upload.
+        `filter_pairs_csr` may be a `DeviceCSR` prepared once (no per-call upload).  The two-stage path reads its per-user proof
+        flags on the host before it returns (the one synchronisation of a call); `settle=False` skips that read — calls then queue
+        back to back on the stream, and `settle()` reads the flags of all of them at once before anybody consumes the results.
         """
         subject_ids = np.asarray(subject_ids)
         if filter_pairs_csr is not None and filter_pairs_csr.shape[0] != len(subject_ids):
@@ -420,7 +448,7 @@ class HipRanker:
         upp = 0 if self.batch_size is None else int(self.batch_size)
         if self._two_stage_applies(kk, n_cand, n_subj):
             self._rank_two_stage(ids_t, scores_t, counts_t, rows_t, n_subj, whitelist_t, n_cand, id_offset, kk, indptr_t, indices_t,
-                                 hash_t, upp)
+                                 hash_t, upp, settle=settle)
         else:
             self._rank_exact(ids_t, scores_t, counts_t, rows_t, 0, n_subj, whitelist_t, n_cand, id_offset, kk, indptr_t, indices_t,
                              hash_t, upp)

@@ -126,6 +126,33 @@ def test_users_whose_result_cannot_be_proven_are_ranked_by_the_single_stage_kern
     assert torch.equal(e2[0], f2[0]) and torch.equal(e2[1].view(torch.int32), f2[1].view(torch.int32))
 
 
+def test_unsettled_calls_are_repaired_by_one_settle():
+    """`rank_device(..., settle=False)` returns without reading the proof flags (calls queue back to back on the stream);
+    `settle()` reads the flags of every such call at once and re-ranks the unproven users INTO the tensors the calls returned."""
+    from rectools_amd.rank import HipRanker
+
+    rng = np.random.default_rng(1)
+    d, n_obj = 64, 30_000
+    obj = rng.normal(size=(n_obj, d)).astype(np.float32)
+    subj = rng.normal(size=(200, d)).astype(np.float32)
+    obj[100:230] = obj[17]                                   # ties at the k-th place for users 0..9 (see the test above)
+    subj[:10] = obj[17][None, :] * rng.uniform(0.5, 2.0, (10, 1)).astype(np.float32)
+    exact = HipRanker("dot", "cuda", subj, obj, batch_size=64, two_stage=False)
+    fast = HipRanker("dot", "cuda", subj, obj, batch_size=64, two_stage=True)
+    fast._h_only_off = True
+    users = [np.arange(200), np.arange(100, 200), np.arange(0, 50)]      # the second call has no unproven user
+    want = [exact.rank_device(u, 10) for u in users]
+    got = [fast.rank_device(u, 10, settle=False) for u in users]
+    assert len(fast._unsettled) == 3 and fast.two_stage_stats["unproven_users"] == 0
+    repaired = fast.settle()
+    assert repaired >= 20 and fast.two_stage_stats["unproven_users"] == repaired and not fast._unsettled and fast.settle() == 0
+    for (e_ids, e_sc, e_cnt, _), (f_ids, f_sc, f_cnt, _) in zip(want, got):
+        assert torch.equal(e_ids, f_ids) and torch.equal(e_sc.view(torch.int32), f_sc.view(torch.int32)) and torch.equal(e_cnt, f_cnt)
+    # the default keeps the call self-contained
+    f_ids = fast.rank_device(users[0], 10)[0]
+    assert not fast._unsettled and torch.equal(f_ids, want[0][0])
+
+
 def test_hm_image_kernel():
     """rt_to_hm_rows: word = (h << 16) | m with h, m the bf16 truncations of x and x - h; x - h - m below 2^-15 |x|; norms; gather."""
     from rectools_amd import _lib
