@@ -326,6 +326,15 @@ int rt_layernorm_bwd(const float* dy, const float* x, const float* w, const floa
 int rt_layernorm_bwd_fused(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
                            const float* res, const int64_t* ids, int32_t mask_dy, int32_t mask_dx, int32_t M, int32_t d,
                            float* dx, float* dw, float* db, void* workspace, size_t workspace_bytes, rt_stream_t stream);
+/* The two halves of rt_layernorm_bwd_fused as calls of their own (same workspace): `rows` writes dx and the per-block partial sums of
+ * dw / db, `combine` reduces them into dw [d], db [d] in a fixed order.  dx is what the backward pass waits for; dw / db are read by the
+ * optimiser only, so `combine` may be issued on another stream behind an event (the block executors and the Python layer put it on
+ * the weight-gradient side stream: lightning.py:214-218 is its only reader). */
+int rt_layernorm_bwd_rows(const float* dy, const float* x, const float* w, const float* mean, const float* rstd, const float* res,
+                          const int64_t* ids, int32_t mask_dy, int32_t mask_dx, int32_t M, int32_t d, float* dx, void* workspace,
+                          size_t workspace_bytes, rt_stream_t stream);
+int rt_layernorm_bwd_combine(const void* workspace, size_t workspace_bytes, int32_t M, int32_t d, float* dw, float* db,
+                             rt_stream_t stream);
 
 /* The same LayerNorm over rows that carry ZERO COLUMNS: column c of a row exists iff (c % grp) < grp_real (grp % 4 == 0, d % grp == 0).
  * A model width or head size the kernels cannot tile (n_factors = 50; heads of 25 — the reference accepts any n_factors % n_heads == 0,
@@ -603,18 +612,20 @@ int rt_sampled_loss_fwd_train(const float* sess, int64_t ld_sess, const float* t
 int rt_sampled_loss_prepare(const int64_t* y, const int64_t* neg, int32_t M, int32_t N, int32_t d, int32_t V, void* workspace,
                             size_t workspace_bytes, rt_stream_t stream);
 /* d_sess or d_table may be NULL: the two halves are independent (d_sess is a scaled copy of d_sess_unit; d_table consumes the
- * ranks in `workspace`, so ask for it exactly once per forward) and may be issued on different streams. */
+ * ranks in `workspace`, so ask for it exactly once per forward) and may be issued on different streams.  The gradients are scaled by
+ * gscale * upstream[0] / norm[0]: `upstream` (nullable: 1) is dL/dloss ON THE DEVICE — autograd's root gradient is never read by the host. */
 int rt_sampled_loss_bwd(const float* sess, int64_t ld_sess, const float* table, const int64_t* y, const int64_t* neg,
                         int32_t M, int32_t N, int32_t d, int32_t V, int32_t cosine, float logits_t, const float* logits,
-                        const float* norm, float gscale, const float* d_sess_unit, int64_t ld_du, float* d_sess,
+                        const float* norm, float gscale, const float* upstream, const float* d_sess_unit, int64_t ld_du, float* d_sess,
                         int64_t ld_dsess, float* d_table, void* workspace, size_t workspace_bytes, int32_t prepared, rt_stream_t stream);
 /* out[0] = sum(loss_pos)/normaliser, out[1] = normaliser; mode 0: count(loss_pos > 0) (lightning.py:159-161),
  * mode 1: count(y != 0) (lightning.py:197-198) */
 int rt_loss_reduce(const float* loss_pos, const int64_t* y, int32_t M, int32_t mode, float* out, rt_stream_t stream);
 /* K10 full-catalog softmax rows (lightning.py:145-162) on the logits of the R active positions produced by rt_gemm:
- * grad = 0: loss_pos[r] = (lse - z_y) * w, lse[r];  grad = 1: logits := (softmax - onehot) * w * gscale / (norm * t) */
+ * grad = 0: loss_pos[r] = (lse - z_y) * w, lse[r];  grad = 1: logits := (softmax - onehot) * w * gscale * upstream[0] / (norm * t)
+ * (upstream: nullable device scalar, as in rt_sampled_loss_bwd) */
 int rt_softmax_ce_rows(float* logits, int64_t ld, int32_t R, int32_t V, const int64_t* y_act, const float* w_act,
-                       float logits_t, int32_t grad, const float* norm, float gscale, float* loss_pos, float* lse,
+                       float logits_t, int32_t grad, const float* norm, float gscale, const float* upstream, float* loss_pos, float* lse,
                        rt_stream_t stream);
 /* K11 L2 row normalisation with max(||x||, 1e-8) (similarity.py:97-100) and its backward */
 int rt_l2norm_fwd(const float* x, int64_t ldx, int32_t M, int32_t d, float* y, int64_t ldy, float* nrm, rt_stream_t stream);

@@ -68,6 +68,8 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_layernorm_bwd_workspace_bytes": (c_sz, [c_i32, c_i32]),
     "rt_layernorm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "rt_layernorm_bwd_fused": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "rt_layernorm_bwd_rows": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_sz, c_vp]),
+    "rt_layernorm_bwd_combine": (c_i32, [c_vp, c_sz, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "rt_layernorm_fwd_cols": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rt_layernorm_bwd_cols": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "rt_act_dropout_fwd": (c_i32, [c_vp, c_i32, c_f32, c_u64, c_u64, c_i64, c_vp, c_vp, c_vp]),
@@ -123,9 +125,9 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_sampled_loss_bwd_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
     "rt_sampled_loss_fwd_train": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f64, c_vp, c_vp, c_vp, c_i64, c_vp, c_sz, c_i32, c_vp]),
     "rt_sampled_loss_prepare": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_sz, c_vp]),
-    "rt_sampled_loss_bwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_f32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_sz, c_i32, c_vp]),
+    "rt_sampled_loss_bwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_f32, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_sz, c_i32, c_vp]),
     "rt_loss_reduce": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
-    "rt_softmax_ce_rows": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_f32, c_i32, c_vp, c_f32, c_vp, c_vp, c_vp]),
+    "rt_softmax_ce_rows": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_f32, c_i32, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp]),
     "rt_l2norm_fwd": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp]),
     "rt_l2norm_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rt_gather_rows": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp]),

@@ -32,6 +32,10 @@ int rt_colsum(const float* X, int64_t ld, int32_t M, int32_t N, float* out, hipS
 int rt_layernorm_fwd(const float* x, const float* w, const float* b, float eps, int32_t M, int32_t d, float* y, float* mean, float* rstd,
                      hipStream_t stream);
 size_t rt_layernorm_bwd_workspace_bytes(int32_t M, int32_t d);
+int rt_layernorm_bwd_rows(const float* dy, const float* x, const float* w, const float* mean, const float* rstd, const float* res,
+                          const int64_t* ids, int32_t mask_dy, int32_t mask_dx, int32_t M, int32_t d, float* dx, void* workspace,
+                          size_t workspace_bytes, hipStream_t stream);
+int rt_layernorm_bwd_combine(const void* workspace, size_t workspace_bytes, int32_t M, int32_t d, float* dw, float* db, hipStream_t stream);
 int rt_layernorm_bwd_fused(const float* dy, const float* x, const float* w, const float* mean, const float* rstd, const float* res,
                            const int64_t* ids, int32_t mask_dy, int32_t mask_dx, int32_t M, int32_t d, float* dx, float* dw, float* db,
                            void* workspace, size_t workspace_bytes, hipStream_t stream);
@@ -512,7 +516,10 @@ int rt_sasrec_block_packed_bwd(const rt_sasrec_block* blk, const float* x, const
     RT_TRY(rc); }
   }
   { Timed t(T_LN_BWD, 0, 0, 0, stream);
-    RT_TRY(rt_layernorm_bwd_fused(g_f, v.y, b.ln2_w, v.mean2, v.rstd2, nullptr, nullptr, 0, 0, M, d, g_y, d_ln2w, d_ln2b, ln_ws1, lnws, stream)); }
+    RT_TRY(rt_layernorm_bwd_rows(g_f, v.y, b.ln2_w, v.mean2, v.rstd2, nullptr, nullptr, 0, 0, M, d, g_y, ln_ws1, lnws, stream)); }
+  RT_TRY(fork());      // d ln_w / d ln_b are the optimiser's: their combine leaves the critical path
+  { Timed t(T_MISC, 0, 0, 0, ws);
+    RT_TRY(rt_layernorm_bwd_combine(ln_ws1, lnws, M, d, d_ln2w, d_ln2b, ws)); }
   // ---- attention: y = q + Wo A + bo
   RT_TRY(fork());
   RT_TRY(wgrad(g_y, d, v.A, d, d_wo, d, d, d_bo));
@@ -554,7 +561,10 @@ int rt_sasrec_block_packed_bwd(const rt_sasrec_block* blk, const float* x, const
     RT_TRY(rc);
   }
   { Timed t(T_LN_BWD, 0, 0, 0, stream);     // g_x = LN1'(g_q) + g_kv
-    RT_TRY(rt_layernorm_bwd_fused(g_q, x, b.ln1_w, v.mean1, v.rstd1, g_kv, nullptr, 0, 0, M, d, g_x, d_ln1w, d_ln1b, ln_ws2, lnws, stream)); }
+    RT_TRY(rt_layernorm_bwd_rows(g_q, x, b.ln1_w, v.mean1, v.rstd1, g_kv, nullptr, 0, 0, M, d, g_x, ln_ws2, lnws, stream)); }
+  RT_TRY(fork());      // d ln_w / d ln_b are the optimiser's: their combine leaves the critical path
+  { Timed t(T_MISC, 0, 0, 0, ws);
+    RT_TRY(rt_layernorm_bwd_combine(ln_ws2, lnws, M, d, d_ln1w, d_ln1b, ws)); }
   return RT_OK;
 }
 
@@ -725,7 +735,10 @@ int rt_preln_block_packed_bwd(const rt_preln_block* blk, const float* x, const f
   RT_TRY(wgrad(g_z, dff, v.g, d, d_w1, dff, d, d_b1));
   RT_TRY(dgrad_gemm(g_z, dff, b.w1, b.w1_wp, b.wp_stride, dff, d, g_g, nullptr, M, stream));                       // g_g = g_z W1
   { Timed t(T_LN_BWD, 0, 0, 0, stream);     // g_x1 = LN2'(g_g) + g_x2 (the skip)
-    RT_TRY(rt_layernorm_bwd_fused(g_g, v.x1, b.ln2_w, v.mean2, v.rstd2, g_x2c, nullptr, 0, 0, M, d, g_x1, d_ln2w, d_ln2b, ln_ws1, lnws, stream)); }
+    RT_TRY(rt_layernorm_bwd_rows(g_g, v.x1, b.ln2_w, v.mean2, v.rstd2, g_x2c, nullptr, 0, 0, M, d, g_x1, ln_ws1, lnws, stream)); }
+  RT_TRY(fork());      // d ln_w / d ln_b are the optimiser's: their combine leaves the critical path
+  { Timed t(T_MISC, 0, 0, 0, ws);
+    RT_TRY(rt_layernorm_bwd_combine(ln_ws1, lnws, M, d, d_ln2w, d_ln2b, ws)); }
   // ---- x1 = x + drop1(mo), mo = A Wo^T + bo, A = attention(qkv), qkv = h Win^T + bin, h = LN1(x)
   const float* g_moc = g_x1;
   if (b.p_drop > 0.f) {
@@ -751,7 +764,10 @@ int rt_preln_block_packed_bwd(const rt_preln_block* blk, const float* x, const f
   RT_TRY(wgrad(dqkv, 3 * d, v.h, d, d_in_w, 3 * d, d, d_in_b));
   RT_TRY(dgrad_gemm(dqkv, 3 * d, b.in_w, b.in_wp, b.wp_stride, 3 * d, d, g_h, nullptr, M, stream));                // g_h = dqkv Win
   { Timed t(T_LN_BWD, 0, 0, 0, stream);     // g_x = LN1'(g_h) + g_x1 (the skip)
-    RT_TRY(rt_layernorm_bwd_fused(g_h, x, b.ln1_w, v.mean1, v.rstd1, g_x1, nullptr, 0, 0, M, d, g_x, d_ln1w, d_ln1b, ln_ws2, lnws, stream)); }
+    RT_TRY(rt_layernorm_bwd_rows(g_h, x, b.ln1_w, v.mean1, v.rstd1, g_x1, nullptr, 0, 0, M, d, g_x, ln_ws2, lnws, stream)); }
+  RT_TRY(fork());      // d ln_w / d ln_b are the optimiser's: their combine leaves the critical path
+  { Timed t(T_MISC, 0, 0, 0, ws);
+    RT_TRY(rt_layernorm_bwd_combine(ln_ws2, lnws, M, d, d_ln1w, d_ln1b, ws)); }
   return RT_OK;
 }
 

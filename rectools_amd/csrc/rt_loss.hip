@@ -39,7 +39,8 @@ struct SampledArgs {
   float* loss_pos;                        // [M] weighted loss per position
   // backward
   const float* norm;                      // [1] normaliser produced by the reduction kernel
-  float gscale;                           // upstream dL/dloss
+  float gscale;                           // upstream dL/dloss (host side factor)
+  const float* upstream;                  // [1] upstream dL/dloss on the device (nullable): multiplies gscale — no host read, no divide launch
   float* d_sess; long long ld_dsess;      // [M, d] overwritten (training forward: UNIT gradient, upstream = norm = 1)
   float* d_table;                         // [V, d] overwritten (every row written exactly once)
   int V;
@@ -431,8 +432,8 @@ __global__ __launch_bounds__(256) void sampled_fwd_kernel(SampledArgs a) {
 // d_sess = unit gradient * gscale / norm
 __global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict__ src, long long ld_src, float* __restrict__ dst,
                                                          long long ld_dst, int M, int d, const float* __restrict__ norm,
-                                                         float gscale) {
-  const float sc = gscale / norm[0];
+                                                         float gscale, const float* __restrict__ upstream) {
+  const float sc = gscale * (upstream != nullptr ? upstream[0] : 1.f) / norm[0];
   const int per_row = d >> 2;
   const long long n4 = (long long)M * per_row;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
@@ -533,7 +534,7 @@ __device__ __forceinline__ void finish_table_row(const SampledArgs& a, int id, i
                                                  f32x4 (&acc)[(D4 + 3) / 4], float bsum) {
   constexpr int NA = (D4 + 3) / 4;
   float* dr = a.d_table + (long long)id * a.d;
-  const float sc = a.gscale / a.norm[0];   // glog holds unit gradients (training forward)
+  const float sc = a.gscale * (a.upstream != nullptr ? a.upstream[0] : 1.f) / a.norm[0];   // glog holds unit gradients (training forward)
   if (a.cosine && any) {
     const float* er = a.table + (long long)id * a.d;
     float ee = 0.f;
@@ -651,6 +652,7 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(const float* __restri
 __global__ __launch_bounds__(256) void softmax_ce_rows_kernel(float* __restrict__ logits, long long ld, int R, int V,
                                                               const long long* __restrict__ y_act, const float* __restrict__ w_act,
                                                               float inv_t, int grad, const float* __restrict__ norm, float gscale,
+                                                              const float* __restrict__ upstream,
                                                               float* __restrict__ loss_pos, float* __restrict__ lse_out) {
   const int r = blockIdx.x;
   if (r >= R) return;
@@ -681,7 +683,7 @@ __global__ __launch_bounds__(256) void softmax_ce_rows_kernel(float* __restrict_
     }
   } else {
     const float lse = lse_out[r];
-    const float coef = w_act[r] * gscale / norm[0] * inv_t;
+    const float coef = w_act[r] * (gscale * (upstream != nullptr ? upstream[0] : 1.f)) / norm[0] * inv_t;
     for (int j = tid; j < V; j += 256) {
       float p = __expf(row[j] * inv_t - lse);
       row[j] = (p - (j == yy ? 1.f : 0.f)) * coef;
@@ -916,7 +918,7 @@ int rt_sampled_loss_fwd_train(const float* sess, int64_t ld_sess, const float* t
 // by candidate id and each table row is reduced by one wave (a 16-wave workgroup for popular ids): no float atomics.
 int rt_sampled_loss_bwd(const float* sess, int64_t ld_sess, const float* table, const int64_t* y, const int64_t* neg,
                         int32_t M, int32_t N, int32_t d, int32_t V, int32_t cosine, float logits_t, const float* logits,
-                        const float* norm, float gscale, const float* d_sess_unit, int64_t ld_du, float* d_sess,
+                        const float* norm, float gscale, const float* upstream, const float* d_sess_unit, int64_t ld_du, float* d_sess,
                         int64_t ld_dsess, float* d_table, void* workspace, size_t workspace_bytes, int32_t prepared, hipStream_t stream) {
   (void)hipGetLastError();
   if (M <= 0) return RT_OK;
@@ -926,11 +928,11 @@ int rt_sampled_loss_bwd(const float* sess, int64_t ld_sess, const float* table, 
   SampledArgs a{};
   a.sess = sess; a.ld_sess = ld_sess; a.table = table; a.y = reinterpret_cast<const long long*>(y);
   a.neg = reinterpret_cast<const long long*>(neg); a.M = M; a.N = N; a.d = d; a.V = V; a.cosine = cosine;
-  a.inv_t = 1.0f / logits_t; a.logits = const_cast<float*>(logits); a.norm = norm; a.gscale = gscale;
+  a.inv_t = 1.0f / logits_t; a.logits = const_cast<float*>(logits); a.norm = norm; a.gscale = gscale; a.upstream = upstream;
   a.d_table = d_table; a.prepared = prepared != 0;
   carve_workspace(a, workspace, M, N, V, d);
   if (d_sess != nullptr) {   // position side: a scaled copy of what the training forward accumulated
-    scale_rows_kernel<<<rt_num_cus() * 4, 256, 0, stream>>>(d_sess_unit, ld_du, d_sess, ld_dsess, M, d, norm, gscale);
+    scale_rows_kernel<<<rt_num_cus() * 4, 256, 0, stream>>>(d_sess_unit, ld_du, d_sess, ld_dsess, M, d, norm, gscale, upstream);
     RT_CHECK_LAUNCH();
   }
   if (d_table == nullptr) return RT_OK;   // table side asked for separately (e.g. on another stream: it is needed only by Adam)
@@ -948,12 +950,12 @@ int rt_loss_reduce(const float* loss_pos, const int64_t* y, int32_t M, int32_t m
 // logits [R,V] (raw similarities of the R active rows) -> loss_pos [R], lse [R]  (grad = 0)
 //                                                      -> logits := (softmax - onehot) * w * gscale / (norm * t)  (grad = 1)
 int rt_softmax_ce_rows(float* logits, int64_t ld, int32_t R, int32_t V, const int64_t* y_act, const float* w_act,
-                       float logits_t, int32_t grad, const float* norm, float gscale, float* loss_pos, float* lse,
+                       float logits_t, int32_t grad, const float* norm, float gscale, const float* upstream, float* loss_pos, float* lse,
                        hipStream_t stream) {
   (void)hipGetLastError();
   if (R <= 0) return RT_OK;
   softmax_ce_rows_kernel<<<R, 256, 0, stream>>>(logits, ld, R, V, reinterpret_cast<const long long*>(y_act), w_act,
-                                                1.0f / logits_t, grad, norm, gscale, loss_pos, lse);
+                                                1.0f / logits_t, grad, norm, gscale, upstream, loss_pos, lse);
   RT_CHECK_LAUNCH();
   return RT_OK;
 }

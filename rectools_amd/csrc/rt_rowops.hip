@@ -807,7 +807,8 @@ int rt_layernorm_bwd(const float* dy, const float* x, const float* w, const floa
 // positions written as zero (mask_dx); res / ids nullable.
 static int layernorm_bwd_any(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
                            const float* res, const int64_t* ids, int32_t mask_dy, int32_t mask_dx, int32_t M, int32_t d, int32_t grp,
-                           int32_t grp_real, float* dx, float* dw, float* db, void* workspace, size_t workspace_bytes, hipStream_t stream);
+                           int32_t grp_real, float* dx, float* dw, float* db, void* workspace, size_t workspace_bytes, hipStream_t stream,
+                           bool combine = true);
 int rt_layernorm_bwd_fused(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
                            const float* res, const int64_t* ids, int32_t mask_dy, int32_t mask_dx, int32_t M, int32_t d,
                            float* dx, float* dw, float* db, void* workspace, size_t workspace_bytes, hipStream_t stream) {
@@ -821,7 +822,7 @@ int rt_layernorm_bwd_cols(const float* dy, const float* x, const float* w, const
 }
 static int layernorm_bwd_any(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
                            const float* res, const int64_t* ids, int32_t mask_dy, int32_t mask_dx, int32_t M, int32_t d, int32_t grp,
-                           int32_t grp_real, float* dx, float* dw, float* db, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                           int32_t grp_real, float* dx, float* dw, float* db, void* workspace, size_t workspace_bytes, hipStream_t stream, bool combine) {
   (void)hipGetLastError();
   if ((mask_dy || mask_dx) && ids == nullptr) return RT_ERR_INVALID_ARG;
   const long long* idp = reinterpret_cast<const long long*>(ids);
@@ -845,7 +846,34 @@ static int layernorm_bwd_any(const float* dy, const float* x, const float* w, co
   else if (d <= 512) layernorm_bwd_kernel<2><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, partial, res, idp, mask_dy, mask_dx);
   else layernorm_bwd_kernel<4><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, partial, res, idp, mask_dy, mask_dx);
   RT_CHECK_LAUNCH();
+  if (!combine) return RT_OK;      // (the caller combines the partial sums itself: rt_layernorm_bwd_combine, possibly on another stream)
   layernorm_bwd_reduce_kernel<<<(2 * d + 15) / 16, 256, 0, stream>>>(partial, blocks, d, dw, db);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+// The two halves of rt_layernorm_bwd_fused as calls of their own: `rows` writes dx and the per-block partial sums of dw / db into
+// `workspace`, `combine` reduces those into dw [d], db [d] (fixed order).  dx is what the backward pass waits for; dw / db are read by
+// the optimiser only — a caller may issue `combine` on another stream behind an event (the block executors: the weight-gradient side
+// stream, one launch and one kernel boundary less on the critical path per LayerNorm).
+int rt_layernorm_bwd_rows(const float* dy, const float* x, const float* w, const float* mean, const float* rstd, const float* res,
+                          const int64_t* ids, int32_t mask_dy, int32_t mask_dx, int32_t M, int32_t d, float* dx, void* workspace,
+                          size_t workspace_bytes, hipStream_t stream) {
+  if (M <= 0) return RT_OK;
+  return layernorm_bwd_any(dy, x, w, mean, rstd, res, ids, mask_dy, mask_dx, M, d, 0, 0, dx, nullptr, nullptr, workspace, workspace_bytes, stream,
+                           false);
+}
+int rt_layernorm_bwd_combine(const void* workspace, size_t workspace_bytes, int32_t M, int32_t d, float* dw, float* db, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (dw == nullptr || db == nullptr || (d & 3) != 0) return RT_ERR_INVALID_ARG;
+  if (M <= 0) {
+    RT_CHECK_HIP(hipMemsetAsync(dw, 0, sizeof(float) * d, stream));
+    RT_CHECK_HIP(hipMemsetAsync(db, 0, sizeof(float) * d, stream));
+    return RT_OK;
+  }
+  if (workspace == nullptr || workspace_bytes < rt_layernorm_bwd_workspace_bytes(M, d)) return RT_ERR_WORKSPACE;
+  int rpb;
+  const int blocks = ln_bwd_blocks(M, rpb);
+  layernorm_bwd_reduce_kernel<<<(2 * d + 15) / 16, 256, 0, stream>>>(reinterpret_cast<const float*>(workspace), blocks, d, dw, db);
   RT_CHECK_LAUNCH();
   return RT_OK;
 }

@@ -743,9 +743,19 @@ def _ln_fwd(x, ids, w, b, eps, M, d, x0, y, mean, rstd, cols):
         _c("rt_layernorm_fwd", x, w, b, float(eps), M, d, y, mean, rstd)
 
 
-def _ln_bwd(dy, x, w, mean, rstd, res, ids, mask_dy, mask_dx, M, d, dx, dw, db, cols):
+def _ln_bwd(dy, x, w, mean, rstd, res, ids, mask_dy, mask_dx, M, d, dx, dw, db, cols, bias=None):
+    """bias: the LayerNorm's bias parameter — when autograd will merely ADOPT dw / db (`_steals_grad(w, bias)`) their combine pass
+    (read by the optimiser only) goes to the library's side stream: one launch and one kernel boundary less between the row kernel
+    and the next backward kernel."""
     ws_bytes = _lib.load().rt_layernorm_bwd_workspace_bytes(M, d)
     ws = torch.empty((max(ws_bytes, 4),), dtype=torch.uint8, device=x.device)
+    if cols is None and bias is not None and M > 0 and _steals_grad(w, bias):
+        _c("rt_layernorm_bwd_rows", dy, x, w, mean, rstd, res, ids, mask_dy, mask_dx, M, d, dx, ws, ws_bytes)
+        side = _native_side_fork()            # (None: the side stream is off — the combine follows on this stream)
+        _c("rt_layernorm_bwd_combine", ws, ws_bytes, M, d, dw, db, stream=side)
+        if side is not None:
+            _NATIVE_KEEPALIVE.append(ws)      # NOT dw / db: an extra reference would make AccumulateGrad clone them (on the main stream)
+        return
     if cols is not None:
         _c("rt_layernorm_bwd_cols", dy, x, w, mean, rstd, res, ids, mask_dy, mask_dx, M, d, int(cols[0]), int(cols[1]), dx, dw, db, ws, ws_bytes)
     else:
@@ -762,7 +772,7 @@ class _LayerNorm(torch.autograd.Function):
         rstd = torch.empty((M,), dtype=torch.float32, device=x.device)
         _ln_fwd(x, None, w, b, eps, M, d, None, y, mean, rstd, cols)
         ctx.save_for_backward(x, w, mean, rstd)
-        ctx.cols = cols
+        ctx.cols, ctx.bias = cols, b
         return y
 
     @staticmethod
@@ -773,7 +783,7 @@ class _LayerNorm(torch.autograd.Function):
         dx = torch.empty_like(x)
         dw = torch.empty_like(w)
         db = torch.empty_like(w)
-        _ln_bwd(dy, x, w, mean, rstd, None, None, 0, 0, M, d, dx, dw, db, ctx.cols)
+        _ln_bwd(dy, x, w, mean, rstd, None, None, 0, 0, M, d, dx, dw, db, ctx.cols, bias=ctx.bias)
         return dx, dw, db, None, None
 
 
@@ -790,7 +800,7 @@ class _LayerNormMasked(torch.autograd.Function):
         rstd = torch.empty_like(mean)
         _ln_fwd(x, ids, w, b, eps, M, d, x0, y, mean, rstd, cols)
         ctx.save_for_backward(x0, ids, w, mean, rstd)
-        ctx.cols = cols
+        ctx.cols, ctx.bias = cols, b
         return y
 
     @staticmethod
@@ -799,7 +809,7 @@ class _LayerNormMasked(torch.autograd.Function):
         M, d = x0.shape
         dy = dy.contiguous()
         dx, dw, db = torch.empty_like(x0), torch.empty_like(w), torch.empty_like(w)
-        _ln_bwd(dy, x0, w, mean, rstd, None, ids, 0, 1, M, d, dx, dw, db, ctx.cols)
+        _ln_bwd(dy, x0, w, mean, rstd, None, ids, 0, 1, M, d, dx, dw, db, ctx.cols, bias=ctx.bias)
         return dx, None, dw, db, None, None
 
 
@@ -2266,11 +2276,11 @@ class _SampledLoss(torch.autograd.Function):
             return (None,) * 9
         d_sess = torch.empty((M, d), dtype=torch.float32, device=sess.device)
         d_table = _new_table_grad(table)     # (every row is written: zeros where no candidate fell)
-        # The upstream gradient stays on the device: the kernels divide by norm[0], so the quotient normaliser / upstream does what
-        # `float(gloss)` did — without the device -> host copy that made the host wait for the whole forward pass at the start of every
-        # backward pass (one tiny elementwise launch instead; the host may now run steps ahead of the device)
-        norm_eff = out[1:] / gloss.reshape(1).to(torch.float32)
-        args = (sess, sess.stride(0), table, y, neg, M, N, d, V, int(cosine), float(logits_t), logits, norm_eff, 1.0, du, d)
+        # The upstream gradient stays on the device: the kernels scale by upstream[0] / norm[0] themselves — no device -> host copy (it made
+        # the host wait for the whole forward pass at the start of every backward pass), and no divide launch between the loss and the
+        # first backward kernel either (round 6)
+        up = gloss.reshape(1) if gloss.dtype == torch.float32 else gloss.reshape(1).to(torch.float32)
+        args = (sess, sess.stride(0), table, y, neg, M, N, d, V, int(cosine), float(logits_t), logits, out[1:], 1.0, up, du, d)
         prep = 1 if getattr(ctx, "prepared", False) else 0
         # rt_sampled_loss_bwd accepts either output as NULL: the session half feeds the layer backward (main stream), the table half —
         # read by the optimiser only — goes to the side stream when autograd will merely adopt its result AND an embedding lookup of
@@ -2286,7 +2296,7 @@ class _SampledLoss(torch.autograd.Function):
             _lib.check(_lib.load().rt_side_mark(), "rt_side_mark")      # the embedding backward waits for THIS point, not for the weight gradients behind it
             # NOT d_table: an extra reference would make autograd's AccumulateGrad clone it (on the main stream, before the side stream
             # has written it) instead of adopting it; as `table.grad` it outlives the join anyway
-            _NATIVE_KEEPALIVE.append((sess, table, y, neg, logits, out, du, ws, norm_eff))
+            _NATIVE_KEEPALIVE.append((sess, table, y, neg, logits, out, du, ws, up))
             _TABLE_GRAD_ON_SIDE.add(d_table.data_ptr())
         if ctx.needs_input_grad[1]:   # only a gradient autograd will hand to the table can serve as the embedding node's sink
             _offer_table_grad(table, d_table)
@@ -2338,7 +2348,7 @@ class _SoftmaxLoss(torch.autograd.Function):
         loss_pos = torch.empty((R,), dtype=torch.float32, device=sess.device)
         lse = torch.empty((R,), dtype=torch.float32, device=sess.device)
         out = torch.empty((2,), dtype=torch.float32, device=sess.device)
-        _c("rt_softmax_ce_rows", logits, Vp, R, V, y_act, w_act, float(logits_t), 0, None, 1.0, loss_pos, lse)
+        _c("rt_softmax_ce_rows", logits, Vp, R, V, y_act, w_act, float(logits_t), 0, None, 1.0, None, loss_pos, lse)
         _c("rt_loss_reduce", loss_pos, y_act, R, 0, out)
         ctx.save_for_backward(s_act, tab, act_idx, y_act, w_act, logits, lse, out)
         ctx.meta = (logits_t, M_total, sess.shape[1], R, V)
@@ -2350,8 +2360,8 @@ class _SoftmaxLoss(torch.autograd.Function):
         logits_t, M_total, d, R, V = ctx.meta
         Rp, Vp = logits.shape
         # logits := (softmax - onehot) * w * g / (norm * t), in place (the buffer is ours); pad rows / columns stay zero
-        norm_eff = out[1:] / gloss.reshape(1).to(torch.float32)    # the upstream gradient stays on the device (see _SampledLoss.backward)
-        _c("rt_softmax_ce_rows", logits, Vp, R, V, y_act, w_act, float(logits_t), 1, norm_eff, 1.0, None, lse)
+        up = gloss.reshape(1) if gloss.dtype == torch.float32 else gloss.reshape(1).to(torch.float32)    # stays on the device (see _SampledLoss.backward)
+        _c("rt_softmax_ce_rows", logits, Vp, R, V, y_act, w_act, float(logits_t), 1, out[1:], 1.0, up, None, lse)
         ds_act = torch.empty((Rp, d), dtype=torch.float32, device=logits.device)
         _gemm(logits, Vp, 1, tab, tab.stride(0), 0, ds_act, d, None, None, 0, Rp, d, Vp, 0, _deep_k_splits(Rp, d, Vp))  # dS = G @ E
         d_tab = torch.empty((Vp, d), dtype=torch.float32, device=logits.device)
