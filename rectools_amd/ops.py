@@ -762,6 +762,19 @@ def _ln_bwd(dy, x, w, mean, rstd, res, ids, mask_dy, mask_dx, M, d, dx, dw, db, 
         _c("rt_layernorm_bwd_fused", dy, x, w, mean, rstd, res, ids, mask_dy, mask_dx, M, d, dx, dw, db, ws, ws_bytes)
 
 
+def _ln_bwd_split(dy, x, w, mean, rstd, res, ids, mask_dy, mask_dx, M, d, dx, dw, db, ws, ws_bytes, on_side: bool) -> None:
+    """`rt_layernorm_bwd_fused`, or — on_side: autograd will merely adopt dw / db — its row pass here and its combine pass on the library's
+    side stream (`rt_layernorm_bwd_rows` / `_combine`; `ws` is kept alive until the join)."""
+    if not on_side or M <= 0:
+        _c("rt_layernorm_bwd_fused", dy, x, w, mean, rstd, res, ids, mask_dy, mask_dx, M, d, dx, dw, db, ws, ws_bytes)
+        return
+    _c("rt_layernorm_bwd_rows", dy, x, w, mean, rstd, res, ids, mask_dy, mask_dx, M, d, dx, ws, ws_bytes)
+    side = _native_side_fork()
+    _c("rt_layernorm_bwd_combine", ws, ws_bytes, M, d, dw, db, stream=side)
+    if side is not None:
+        _NATIVE_KEEPALIVE.append(ws)
+
+
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, eps, cols=None):
@@ -2133,7 +2146,7 @@ class _STULayer(torch.autograd.Function):
         g_ad, d_ln2w, d_ln2b = new(M, hh), new(hh), new(hh)
         ws_bytes = lib.rt_layernorm_bwd_workspace_bytes(M, hh)
         ws = torch.empty((max(ws_bytes, 4),), dtype=torch.uint8, device=dev)
-        _c("rt_layernorm_bwd", g_la, attn_d, ln2_w, mean2, rstd2, M, hh, g_ad, d_ln2w, d_ln2b, ws, ws_bytes)
+        _ln_bwd_split(g_la, attn_d, ln2_w, mean2, rstd2, None, None, 0, 0, M, hh, g_ad, d_ln2w, d_ln2b, ws, ws_bytes, defer)
         if p_attn > 0:
             g_attn = new(M, hh)
             _c("rt_act_dropout_bwd", g_ad, g_ad, ACT_NONE, float(p_attn), seed_a[0], seed_a[1], g_ad.numel(), g_attn)
@@ -2166,7 +2179,9 @@ class _STULayer(torch.autograd.Function):
         ws_bytes = lib.rt_layernorm_bwd_workspace_bytes(M, d)
         ws = torch.empty((max(ws_bytes, 4),), dtype=torch.uint8, device=dev)
         msk = 1 if cu is None else 0
-        _c("rt_layernorm_bwd_fused", g_n, x0, ln1_w, mean1, rstd1, g_out, ids, msk, msk, M, d, g_x, d_ln1w, d_ln1b, ws, ws_bytes)
+        ws1_bytes = lib.rt_layernorm_bwd_workspace_bytes(M, d)      # (its own partial sums: the first LayerNorm's combine may still be in flight)
+        ws1 = torch.empty((max(ws1_bytes, 4),), dtype=torch.uint8, device=dev)
+        _ln_bwd_split(g_n, x0, ln1_w, mean1, rstd1, g_out, ids, msk, msk, M, d, g_x, d_ln1w, d_ln1b, ws1, ws1_bytes, defer)
         if side:
             side[-1].join_now()
         return (g_x, None, None, None, d_ln1w, d_ln1b, d_p, dtw, dpw, d_ln2w, d_ln2b, d_wo, d_bo, None)

@@ -19,7 +19,8 @@ KEEP = [("1_bench.json", "bench_auto.json"), ("2_prof.md", "rocprof_kernel_trace
         ("12_prof.md", "rocprof_kernel_trace_hstu.md"), ("13_prof.md", "rocprof_kernel_trace_recommend.md"),
         ("14_pmc.txt", "pmc_topk5m_u4096_FETCH_SIZE.txt"), ("15_prof.md", "rocprof_kernel_trace_esasrec_kpm.md"),
         ("16_pytest.txt", "pytest_gpu_final_tree.txt"), ("17_pmc.txt", "sq_counters_topk5m_u4096_raw.txt"), ("2_timeline.txt", "timeline_train.txt"),
-        ("13_prof.md", "rocprof_kernel_trace_recommend.md")]
+        ("13_prof.md", "rocprof_kernel_trace_recommend.md"), ("18_prof.md", "rocprof_kernel_trace_esasrec.md"),
+        ("19_pmc.txt", "sq_counters_hstu_raw.txt")]
 
 
 def parse(path):
@@ -54,7 +55,7 @@ def main():
             "| kernel | launches | GRBM_GUI_ACTIVE | SQ_VALU_MFMA_BUSY_CYCLES | matrix-pipe busy share | VALU active share | LDS active share | mean waves per SIMD | LDS bank conflict / LDS active |",
             "|---|---|---|---|---|---|---|---|---|"]
     for k, c in sq.items():
-        if not any(t in k for t in ("v2_", "gemm_", "wgrad_", "ffn_", "sampled_", "layernorm", "adam", "embed_bwd_rows")):
+        if not any(t in k for t in ("v2_", "v3_", "gemm_", "wgrad_", "ffn_", "sampled_", "layernorm", "adam", "embed_bwd_rows")):
             continue
         g = c.get("GRBM_GUI_ACTIVE", (0, 0))[1]
         if g <= 0:
@@ -125,7 +126,7 @@ def main():
         n = sum(c for c, _ in gf)
         traffic["train_gemm"] = int((sum(c * a for c, a in gf) * 2 + sum(c * a for c, a in gw)) / n * 1024)
     for key, pat in (("train_rt_sampled_loss_fwd_train", "sampled_fwd_kernel"), ("train_rt_sampled_loss_bwd", "sampled_bwd_rows_kernel"),
-                     ("train_v2_fwd_kernel", "v2_fwd_kernel"), ("train_v2_bwd_dq_kernel", "v2_bwd_dq_kernel"), ("train_v2_bwd_dkv_kernel", "v2_bwd_dkv_kernel"),
+                     ("train_v3_fwd_kernel", "v3_fwd_kernel"), ("train_v3_bwd_dq_kernel", "v3_bwd_dq_kernel"), ("train_v3_bwd_dkv_kernel", "v3_bwd_dkv_kernel"),
                      ("train_ffn_kernel_fwd", "ffn_kernel<0>"), ("train_ffn_kernel_bwd", "ffn_kernel<1>"), ("train_wgrad_group_kernel", "wgrad_group_kernel")):
         a, b = kib(f, pat, "FETCH_SIZE"), kib(w, pat, "WRITE_SIZE")
         if a:
