@@ -606,6 +606,64 @@ def test_layernorm_masked_and_fused_backward(M, d):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,d", [(37, 64), (1000, 256), (513, 512)])
+def test_layernorm_backward_in_two_calls_equals_the_fused_call(M, d):
+    """rt_layernorm_bwd_rows + rt_layernorm_bwd_combine (the combine on ANOTHER stream behind an event, as the block executors issue it)
+    == rt_layernorm_bwd_fused, bit for bit; and through the autograd op: dw / db adopted by a leaf parameter come from the side stream."""
+    from rectools_amd import _lib, ops
+
+    x, w = rnd(M, d, seed=1).cuda(), (1 + 0.1 * rnd(d, seed=2)).cuda()
+    ids = torch.randint(0, 3, (M,), generator=torch.Generator().manual_seed(4)).cuda()
+    dy, res = rnd(M, d, seed=5).cuda(), rnd(M, d, seed=6).cuda()
+    mean, rstd = x.mean(1), 1.0 / torch.sqrt(x.var(1, unbiased=False) + 1e-5)
+    ws_bytes = _lib.load().rt_layernorm_bwd_workspace_bytes(M, d)
+    new = lambda *s_: torch.empty(*s_, device="cuda")      # noqa: E731
+    ws_a, ws_b = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda"), torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+    dx_a, dw_a, db_a = new(M, d), new(d), new(d)
+    ops._c("rt_layernorm_bwd_fused", dy, x, w, mean, rstd, res, ids, 1, 1, M, d, dx_a, dw_a, db_a, ws_a, ws_bytes)
+    dx_b, dw_b, db_b = new(M, d), new(d), new(d)
+    ops._c("rt_layernorm_bwd_rows", dy, x, w, mean, rstd, res, ids, 1, 1, M, d, dx_b, ws_b, ws_bytes)
+    other = torch.cuda.Stream()
+    other.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(other):
+        ops._c("rt_layernorm_bwd_combine", ws_b, ws_bytes, M, d, dw_b, db_b)
+    torch.cuda.current_stream().wait_stream(other)
+    assert torch.equal(dx_a, dx_b) and torch.equal(dw_a, dw_b) and torch.equal(db_a, db_b)
+    # the autograd op: leaf parameters without a .grad -> the combine runs on the library's side stream, joined before anybody reads
+    wp, bp = torch.nn.Parameter(w.clone()), torch.nn.Parameter(torch.zeros(d, device="cuda"))
+    xr = x.clone().requires_grad_(True)
+    ops.layer_norm(xr, wp, bp, 1e-5).backward(dy)
+    ops.join_side_streams()
+    xt, wt, bt = x.clone().requires_grad_(True), w.clone().requires_grad_(True), torch.zeros(d, device="cuda", requires_grad=True)
+    F.layer_norm(xt, (d,), wt, bt, 1e-5).backward(dy)
+    close(xr.grad, xt.grad, rtol=1e-3, msg="dx"); close(wp.grad, wt.grad, rtol=1e-3, msg="dw"); close(bp.grad, bt.grad, rtol=1e-3, msg="db")
+
+
+@pytest.mark.gpu
+def test_loss_backward_reads_the_upstream_gradient_on_the_device():
+    """`loss.backward(g)` with g != 1 (a tensor on the device): the sampled loss and the full softmax scale their gradients by g inside
+    the kernels (rt_sampled_loss_bwd / rt_softmax_ce_rows `upstream`) — no host read, no divide launch; gradients = g x the unit ones."""
+    from rectools_amd import ops
+
+    M, d, V, N = 96, 64, 300, 7
+    g0 = torch.Generator().manual_seed(0)
+    table0 = (rnd(V, d, seed=1) * 0.3)
+    sess0 = rnd(M, d, seed=2) * 0.3
+    y = torch.randint(1, V, (M,), generator=g0); y[::5] = 0
+    neg = torch.randint(1, V, (M, N), generator=g0)
+    w = torch.ones(M)
+    grads = {}
+    for scale in (1.0, 2.5):
+        table, sess = table0.clone().cuda().requires_grad_(True), sess0.clone().cuda().requires_grad_(True)
+        loss, _ = ops.sampled_loss(sess, table, y.cuda(), neg.cuda(), w.cuda(), ops.LOSS_SAMPLED_SOFTMAX, False, 1.0)
+        loss.backward(torch.full_like(loss, scale))
+        ops.join_side_streams()
+        grads[scale] = (sess.grad.clone(), table.grad.clone())
+    close(grads[2.5][0], 2.5 * grads[1.0][0], rtol=1e-6, msg="d_sess scales with the upstream gradient")
+    close(grads[2.5][1], 2.5 * grads[1.0][1], rtol=1e-6, msg="d_table scales with the upstream gradient")
+
+
+@pytest.mark.gpu
 def test_mul_mask_ld_strided_slices():
     from rectools_amd import ops
 
