@@ -41,6 +41,7 @@ struct SampledArgs {
   const float* norm;                      // [1] normaliser produced by the reduction kernel
   float gscale;                           // upstream dL/dloss (host side factor)
   const float* upstream;                  // [1] upstream dL/dloss on the device (nullable): multiplies gscale — no host read, no divide launch
+  bool narrow_rows;                       // the table half was asked for on its own (see launch_sampled)
   float* d_sess; long long ld_dsess;      // [M, d] overwritten (training forward: UNIT gradient, upstream = norm = 1)
   float* d_table;                         // [V, d] overwritten (every row written exactly once)
   int V;
@@ -564,7 +565,8 @@ template <int D4>
 __global__ __launch_bounds__(256) void sampled_bwd_rows_kernel(SampledArgs a) {
   constexpr int NA = (D4 + 3) / 4;
   const int lane = threadIdx.x & 63;
-  const int id = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));   // wave-uniform: offsets / records are scalar loads
+  for (int blk = blockIdx.x; blk * 4 < a.V; blk += gridDim.x) {      // (a grid smaller than V / 4: persistent workgroups, see launch_sampled)
+  const int id = __builtin_amdgcn_readfirstlane(blk * 4 + (threadIdx.x >> 6));   // wave-uniform: offsets / records are scalar loads
   if (id >= a.V) return;
   const int beg = a.offsets[id], end = a.offsets[id + 1];
   f32x4 acc[NA];
@@ -586,6 +588,7 @@ __global__ __launch_bounds__(256) void sampled_bwd_rows_kernel(SampledArgs a) {
     accumulate_pairs<D4>(a, beg, end, lane, acc, bsum);
   }
   finish_table_row<D4>(a, id, lane, end > beg, acc, bsum);
+  }
 }
 
 // one 4-wave workgroup per chunk of a popular row: 32 pairs per wave, combined through LDS, partial row -> slab
@@ -812,7 +815,16 @@ int launch_sampled(const SampledArgs& a, int stage, hipStream_t stream) {
   const long long max_chunks = heavy_chunk_cap((long long)a.M * (a.N + 1));
   sampled_bwd_heavy_kernel<D4><<<(int)min(max_chunks, (long long)rt_num_cus() * 8), HEAVY_WAVES * 64, 0, stream>>>(a);
   RT_CHECK_LAUNCH();
-  sampled_bwd_rows_kernel<D4><<<(a.V + 3) / 4, 256, 0, stream>>>(a);
+  {
+    // A long catalog's row reducer asked for on its own (d_sess == NULL: the optimiser's half, issued on a side stream) runs beside the
+    // backward pass for most of its length: as one workgroup per 4 rows it fills every SIMD's wave slots and the attention backward's
+    // workgroups queue for them (HSTU C4: v3_hstu_bwd_dq 1,010 us beside it against 190 alone).  TWO persistent workgroups per CU leave
+    // the slots free: HSTU 23.1 -> 23.5 k, eSASRec 13.97 -> 14.16 k seqs/s on one box (gpurun_out/r6_rows3); short catalogs (C2: 6,687
+    // workgroups, 194 us) keep the wide grid — narrowed it stretches past the backward pass (86.2 -> 83.2 k).
+    int grid = (a.V + 3) / 4;
+    if (a.narrow_rows && grid >= 64 * rt_num_cus()) grid = 2 * rt_num_cus();
+    sampled_bwd_rows_kernel<D4><<<grid, 256, 0, stream>>>(a);
+  }
   RT_CHECK_LAUNCH();
   return RT_OK;
 }
@@ -929,7 +941,7 @@ int rt_sampled_loss_bwd(const float* sess, int64_t ld_sess, const float* table, 
   a.sess = sess; a.ld_sess = ld_sess; a.table = table; a.y = reinterpret_cast<const long long*>(y);
   a.neg = reinterpret_cast<const long long*>(neg); a.M = M; a.N = N; a.d = d; a.V = V; a.cosine = cosine;
   a.inv_t = 1.0f / logits_t; a.logits = const_cast<float*>(logits); a.norm = norm; a.gscale = gscale; a.upstream = upstream;
-  a.d_table = d_table; a.prepared = prepared != 0;
+  a.d_table = d_table; a.prepared = prepared != 0; a.narrow_rows = d_sess == nullptr;
   carve_workspace(a, workspace, M, N, V, d);
   if (d_sess != nullptr) {   // position side: a scaled copy of what the training forward accumulated
     scale_rows_kernel<<<rt_num_cus() * 4, 256, 0, stream>>>(d_sess_unit, ld_du, d_sess, ld_dsess, M, d, norm, gscale, upstream);
