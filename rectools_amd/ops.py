@@ -2224,8 +2224,9 @@ def prepare_sampled_pairs(y: torch.Tensor, neg: torch.Tensor, V: int, d: int) ->
     """The sampled losses' counting sort of the (position, candidate) pairs by candidate id — needed by the backward pass only, a
     function of the ids only — issued on the side stream as soon as the batch exists (`rt_sampled_loss_prepare`): six small launches
     leave the gap between the forward and the backward kernels of a training step, and the training forward writes the pair records
-    itself.  NOT called by the stock loop: measured neutral at C2 (84.7 vs 84.5 k seqs/s — the 1.7 M rank atomics that hide under the
-    forward kernel's gathers cost 83 us as a kernel of their own); kept as the binding of the entry point, pinned against the in-pass sort
+    itself.  NOT called by the stock loop: measured neutral at C2 in round 4 (84.7 vs 84.5 k seqs/s — the 1.7 M rank atomics that hide under the
+    forward kernel's gathers cost 83 us as a kernel of their own) and SLOWER in round 6 (81.4 vs 87.6 k: the sort's kernels now sit beside
+    the forward pass's three-per-CU attention workgroups); kept as the binding of the entry point, pinned against the in-pass sort
     by tests/test_ops_gpu.py.  `sampled_loss` finds the workspace through (step, the two tensors' storage, sizes); any mismatch (another y / neg, a
     loss that is never called) just leaves it unused."""
     _PREPARED_PAIRS.clear()
