@@ -98,6 +98,117 @@ __global__ __launch_bounds__(VT) void attn_varlen_last_kernel(VarlenArgs a, int 
 
 constexpr size_t VARLEN_LDS_LIMIT = 160 * 1024;
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The last query of every session WITHOUT the key / value projections of its rows (round 6: the final block of recommend()).
+//   logit_j  = q_h . (W_k,h x_j + b_k,h) / sqrt(hd) = (W_k,h^T q_h) . x_j / sqrt(hd) + const     (the constant cancels in the softmax;
+//                                                                                                   a pad key has x = 0: logit 0)
+//   output_h = sum_j p_j (W_v,h x_j + b_v,h)        = W_v,h (sum_j p_j x_j) + b_v,h               (sum_j p_j = 1, pads included)
+// The caller makes qk [B, H, d] = W_k,h^T q_h (a [B, hd] x [hd, d] product per head) and applies W_v,h to xbar [B, H, d] afterwards: the
+// only pass over ALL rows is this kernel's — it reads the block input x once per phase (1 KB per row at d = 256) where the projection
+// form wrote and re-read K | V (2 x that, after a [rows, d] x [d, 2d] product: 18 of the 104 ms of GEMM time of a whole-catalog recommend()).
+// One workgroup per session, HG heads per pass.  Phase 1: 16 lanes per row, the row's float4 units strided over them, HG dot products
+// reduced over the 16 lanes -> scores in LDS; softmax statistics; phase 2: thread = (16-byte column, row phase) as attn_varlen_last_kernel.
+// (The two small products INSIDE the kernel were built and measured: 685 us per 4,096-session launch against 159 + ~160 for the kernel and
+// the eight products around it — every workgroup then streams both weight matrices out of the L2 for a single session.)
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct LastXArgs {
+  const float* qk; const float* x; long long ldx; const long long* cu; float* xbar;
+  int B, H, d, window, pads; float scale;
+};
+
+template <int D64, int HG>      // d = 64 D64; HG heads per pass (H % HG == 0)
+__global__ __launch_bounds__(VT) void attn_last_x_kernel(LastXArgs a, int max_n) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NC4 = 16 * D64;                 // float4 units per row
+  constexpr int PH = VT / NC4 > 0 ? VT / NC4 : 1;      // row phases of phase 2 (D64 = 8: 2; 4: 4; 1: 16)
+  const int n4 = (max_n + 3) & ~3;
+  float* prob = smem;                            // [n4][HG]
+  float* red = smem + (size_t)n4 * HG;           // [2][4 waves][HG] max / sum
+  f32x4* part = reinterpret_cast<f32x4*>(red + 2 * 4 * HG + ((2 * 4 * HG) & 3 ? 4 - ((2 * 4 * HG) & 3) : 0));   // [PH][HG][NC4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, d = a.d;
+  const long long row0 = a.cu[b];
+  const int n = (int)(a.cu[b + 1] - row0);
+  float* ob = a.xbar + (long long)b * a.H * d;
+  if (n <= 0) {      // a session without items has no query: defined output (zeros), never consumed
+    for (int c = tid; c < a.H * d; c += VT) ob[c] = 0.f;
+    return;
+  }
+  const float* xb = a.x + row0 * a.ldx;
+  const int n_pad = a.window > n ? a.window - n : 0;
+  const bool pads = a.pads != 0 && n_pad > 0;
+  const int grp = tid >> 4, li = tid & 15;       // phase 1: 16 groups of 16 lanes
+  const int c4 = tid % NC4, ph = tid / NC4;      // phase 2
+  const int hs = tid % HG;                       // the head whose statistics this thread scans (VT % HG == 0)
+  for (int h0 = 0; h0 < a.H; h0 += HG) {
+    if (h0 > 0) __syncthreads();                 // the previous pass's partial sums are read
+    // ---- phase 1: scores
+    f32x4 qr[HG][D64];
+#pragma unroll
+    for (int h = 0; h < HG; ++h)
+#pragma unroll
+      for (int k = 0; k < D64; ++k)
+        qr[h][k] = *reinterpret_cast<const f32x4*>(a.qk + ((long long)b * a.H + h0 + h) * d + 4 * (li + 16 * k));
+    for (int j = grp; j < n; j += 16) {
+      f32x4 xr[D64];
+#pragma unroll
+      for (int k = 0; k < D64; ++k) xr[k] = *reinterpret_cast<const f32x4*>(xb + (long long)j * a.ldx + 4 * (li + 16 * k));
+#pragma unroll
+      for (int h = 0; h < HG; ++h) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < D64; ++k) s += xr[k][0] * qr[h][k][0] + xr[k][1] * qr[h][k][1] + xr[k][2] * qr[h][k][2] + xr[k][3] * qr[h][k][3];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);      // (offsets < 16 stay inside the 16-lane group)
+        if (li == 0) prob[j * HG + h] = s * a.scale;
+      }
+    }
+    __syncthreads();
+    // ---- softmax statistics per head: thread tid scans entries tid, tid + VT, ... (all of head tid % HG)
+    float mx = pads ? 0.f : -INFINITY;
+    for (int e = tid; e < n * HG; e += VT) mx = fmaxf(mx, prob[e]);
+#pragma unroll
+    for (int o = 32; o >= HG; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane < HG) red[wave * HG + lane] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[hs], red[HG + hs]), fmaxf(red[2 * HG + hs], red[3 * HG + hs]));
+    float ps = 0.f;
+    for (int e = tid; e < n * HG; e += VT) {
+      const float ex = __expf(prob[e] - mx);
+      prob[e] = ex;
+      ps += ex;
+    }
+#pragma unroll
+    for (int o = 32; o >= HG; o >>= 1) ps += __shfl_xor(ps, o, 64);
+    if (lane < HG) red[4 * HG + wave * HG + lane] = ps;
+    __syncthreads();
+    // ---- phase 2: xbar_h = sum_j p_j x_j
+    f32x4 acc[HG];
+#pragma unroll
+    for (int h = 0; h < HG; ++h) acc[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ph < PH)
+      for (int j = ph; j < n; j += PH) {
+        const f32x4 x4 = *reinterpret_cast<const f32x4*>(xb + (long long)j * a.ldx + 4 * c4);
+#pragma unroll
+        for (int h = 0; h < HG; ++h) acc[h] += x4 * prob[j * HG + h];
+      }
+    if (ph < PH)
+#pragma unroll
+      for (int h = 0; h < HG; ++h) part[(ph * HG + h) * NC4 + c4] = acc[h];
+    __syncthreads();
+    for (int e = tid; e < HG * NC4; e += VT) {
+      const int h = e / NC4, c = e % NC4;
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      for (int p2 = 0; p2 < PH; ++p2) o += part[(p2 * HG + h) * NC4 + c];
+      const float mh = fmaxf(fmaxf(red[h], red[HG + h]), fmaxf(red[2 * HG + h], red[3 * HG + h]));
+      float l = (red[4 * HG + h] + red[5 * HG + h]) + (red[6 * HG + h] + red[7 * HG + h]);
+      if (pads) l += (float)n_pad * __expf(-mh);            // the pad keys: logit 0, value b_v (applied by the caller through sum p = 1)
+      *reinterpret_cast<f32x4*>(ob + (long long)(h0 + h) * d + 4 * c) = o * (l > 0.f ? 1.f / l : 0.f);
+    }
+  }
+}
+
+
 // Default: the streamed bf16-plane kernels of rt_attention_v3.hip (hd 32 / 64 / 128, any session length).  RT_VARLEN_IMPL (A/B runs): v2 =
 // the whole-session-image kernels of rt_attention_v2.hip wherever they serve the shape (hd 32 / 64, two images within 160 KB of LDS; the
 // streamed kernels otherwise); v2fwd / v2bwd / v3fwd / v3bwd: only that pass on the named family.
@@ -116,6 +227,33 @@ template <typename K>
 int set_lds(K kernel, size_t lds) {
   RT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   return RT_OK;
+}
+
+// E [d, H d]: E[r, h d + c] = W[r, c] if r / hd == h else 0 — a per-head product [B, hd] x [hd, d] for all heads becomes ONE exact-tile
+// product [B, d] x [d, H d] (three quarters of it zeros: 2 GFLOP at B = 4,096, d = 256 — 20 us on the six-term loop against 4 x 40 us of
+// ragged-shape launches for the four heads' own products).
+__global__ __launch_bounds__(256) void expand_heads_kernel(const float* __restrict__ W, int d, int hd, int H, float* __restrict__ E) {
+  const int r = blockIdx.x;
+  const int hr = r / hd;
+  for (int c = threadIdx.x; c < H * d; c += 256) E[(long long)r * H * d + c] = (c / d == hr) ? W[(long long)r * d + (c % d)] : 0.f;
+}
+
+template <int D64, int HG>
+int launch_last_x(const LastXArgs& a, int max_len, hipStream_t stream) {
+  const size_t n4 = (size_t)((max_len + 3) & ~3);
+  constexpr int NC4 = 16 * D64, PH = VT / NC4 > 0 ? VT / NC4 : 1;
+  const size_t lds = (n4 * HG + 2 * 4 * HG + 4) * sizeof(float) + (size_t)PH * HG * NC4 * sizeof(f32x4);
+  if (lds > VARLEN_LDS_LIMIT) return RT_ERR_UNSUPPORTED;
+  { const int rc = set_lds(&attn_last_x_kernel<D64, HG>, lds); if (rc != RT_OK) return rc; }
+  attn_last_x_kernel<D64, HG><<<a.B, VT, lds, stream>>>(a, max_len);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+template <int D64>
+int launch_last_x_h(const LastXArgs& a, int max_len, hipStream_t stream) {
+  if (a.H % 4 == 0) return launch_last_x<D64, 4>(a, max_len, stream);
+  if (a.H % 2 == 0) return launch_last_x<D64, 2>(a, max_len, stream);
+  return launch_last_x<D64, 1>(a, max_len, stream);
 }
 
 bool bad_args(const float* q, const float* k, const float* v, const float* o, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
@@ -306,6 +444,38 @@ int rt_mha_varlen_last_fwd(const float* q, int64_t ldq, const float* k, int64_t 
   if (lds > VARLEN_LDS_LIMIT) return RT_ERR_UNSUPPORTED;
   { const int rc = set_lds(&attn_varlen_last_kernel, lds); if (rc != RT_OK) return rc; }
   attn_varlen_last_kernel<<<B * H, VT, lds, stream>>>(a, max_len);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+// The last query of every session from the block input itself (see attn_last_x_kernel): qk [B, H, d] = W_k,h^T q_h per session and
+// head, x packed rows [*, ldx], xbar [B, H, d] = sum_j softmax_j((qk . x_j) / sqrt(hd)) x_j.  pad_keys != 0: the window's pad keys take
+// part with logit 0 (their x is zero).  d in {64, 128, 256, 512}.
+int rt_mha_varlen_last_x_fwd(const float* qk, const float* x, int64_t ldx, const int64_t* cu_seqlens, int32_t B, int32_t H, int32_t d,
+                             int32_t max_len, int32_t window, int32_t pad_keys, float* xbar, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (qk == nullptr || x == nullptr || cu_seqlens == nullptr || xbar == nullptr || B < 0 || H <= 0 || d <= 0 || d % H != 0 || (ldx & 3) != 0 ||
+      max_len <= 0)
+    return RT_ERR_INVALID_ARG;
+  if (d != 64 && d != 128 && d != 256 && d != 512) return RT_ERR_UNSUPPORTED;
+  if (B == 0) return RT_OK;
+  LastXArgs a{};
+  a.qk = qk; a.x = x; a.ldx = ldx; a.cu = reinterpret_cast<const long long*>(cu_seqlens); a.xbar = xbar;
+  a.B = B; a.H = H; a.d = d; a.window = window; a.pads = pad_keys; a.scale = 1.0f / sqrtf((float)(d / H));
+  switch (d) {
+    case 64: return launch_last_x_h<1>(a, max_len, stream);
+    case 128: return launch_last_x_h<2>(a, max_len, stream);
+    case 256: return launch_last_x_h<4>(a, max_len, stream);
+    default: return launch_last_x_h<8>(a, max_len, stream);
+  }
+}
+
+// The head-expanded copy of a [d, d] projection weight for the two products around rt_mha_varlen_last_x_fwd (see expand_heads_kernel):
+// qk = Q E(W_k) (E as [K = d, N = H d]), attention output = xbar E(W_v)^T + b_v (E as [N = d, K = H d]).
+int rt_mha_last_x_expand(const float* W, int32_t d, int32_t H, float* E, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (W == nullptr || E == nullptr || d <= 0 || H <= 0 || d % H != 0) return RT_ERR_INVALID_ARG;
+  expand_heads_kernel<<<d, 256, 0, stream>>>(W, d, d / H, H, E);
   RT_CHECK_LAUNCH();
   return RT_OK;
 }

@@ -32,6 +32,9 @@ int rt_colsum(const float* X, int64_t ld, int32_t M, int32_t N, float* out, hipS
 int rt_layernorm_fwd(const float* x, const float* w, const float* b, float eps, int32_t M, int32_t d, float* y, float* mean, float* rstd,
                      hipStream_t stream);
 size_t rt_layernorm_bwd_workspace_bytes(int32_t M, int32_t d);
+int rt_mha_varlen_last_x_fwd(const float* qk, const float* x, int64_t ldx, const int64_t* cu_seqlens, int32_t B, int32_t H, int32_t d,
+                             int32_t max_len, int32_t window, int32_t pad_keys, float* xbar, hipStream_t stream);
+int rt_mha_last_x_expand(const float* W, int32_t d, int32_t H, float* E, hipStream_t stream);
 int rt_layernorm_bwd_rows(const float* dy, const float* x, const float* w, const float* mean, const float* rstd, const float* res,
                           const int64_t* ids, int32_t mask_dy, int32_t mask_dx, int32_t M, int32_t d, float* dx, void* workspace,
                           size_t workspace_bytes, hipStream_t stream);
@@ -776,7 +779,9 @@ int rt_preln_block_packed_bwd(const rt_preln_block* blk, const float* x, const f
 // all rows (lightning.py:393-397 keeps session_embs[:, -1, :]).  scratch: rt_sasrec_block_infer_scratch_floats floats.
 size_t rt_sasrec_block_infer_scratch_floats(int32_t rows, int32_t B, int32_t d, int32_t dff, int32_t last_only) {
   const size_t M = (size_t)rows, R = last_only ? (size_t)B : M;
-  return (last_only ? al(R * d) : 0) /* x_last */ + al(R * d) * 5 /* q Q A y f */ + al(M * 2 * d) /* KV */ + al(R * dff) /* h */ + 2 * al(R);
+  // (last_only: the KV area doubles as qk | xbar [B, H, d] each of the projection-free last-query form: H <= d / 32 heads)
+  const size_t kv = M * 2 * d, qx = last_only ? 2 * (R + d) * (size_t)(d / 32) * d : 0;      // (+ the two head-expanded weights)
+  return (last_only ? al(R * d) : 0) /* x_last */ + al(R * d) * 5 /* q Q A y f */ + al(kv > qx ? kv : qx) /* KV */ + al(R * dff) /* h */ + 2 * al(R);
 }
 int rt_sasrec_block_packed_infer(const rt_sasrec_block* blk, const float* x, const int64_t* last_rows, float* scratch, float* out,
                                  hipStream_t stream) {
@@ -791,7 +796,8 @@ int rt_sasrec_block_packed_infer(const rt_sasrec_block* blk, const float* x, con
   if (last) { float* xl = p; p += al((size_t)R * d); RT_TRY(rt_gather_rows(x, d, last_rows, R, d, xl, d, stream)); xin = xl; }
   float* q = p; p += al((size_t)R * d); float* Q = p; p += al((size_t)R * d); float* A = p; p += al((size_t)R * d);
   float* y = p; p += al((size_t)R * d); float* f = p; p += al((size_t)R * d);
-  float* KV = p; p += al((size_t)M * 2 * d);
+  float* KV = p;
+  { const size_t kv = (size_t)M * 2 * d, qx = last ? 2 * ((size_t)R + d) * (d / 32) * d : 0; p += al(kv > qx ? kv : qx); }
   float* h = p; p += al((size_t)R * dff);
   float* mean = p; p += al((size_t)R); float* rstd = p;
   const float* bk = b.pad_keys ? b.in_b + d : nullptr;
@@ -819,9 +825,27 @@ int rt_sasrec_block_packed_infer(const rt_sasrec_block* blk, const float* x, con
     { rt_sasrec_block bb = b; RT_TRY(zero_tail(A, bb, d, stream)); }
     RT_TRY(rt_mha_varlen_fwd(Q, d, KV, 2 * d, KV + d, 2 * d, b.cu, bk, bv, b.B, b.H, hd, b.window, b.window, A, d, stream));
   } else {
-    RT_TRY(lin(x, d, b.in_w + (size_t)d * d, b.in_wp != nullptr ? b.in_wp + (size_t)d * d : nullptr, d, KV, 2 * d, b.in_b + d, nullptr, 0, M, 2 * d, d, 0));
     RT_TRY(lin(q, d, b.in_w, b.in_wp, d, Q, d, b.in_b, nullptr, 0, R, d, d, 0));
-    RT_TRY(rt_mha_varlen_last_fwd(Q, d, KV, 2 * d, KV + d, 2 * d, b.cu, bk, bv, b.B, b.H, hd, b.window, b.window, A, d, stream));
+    // The last query needs no key / value ROWS: q_h . (W_k,h x_j + b_k,h) = (W_k,h^T q_h) . x_j + const and sum_j p_j (W_v,h x_j + b_v,h) =
+    // W_v,h (sum_j p_j x_j) + b_v,h — two [B, .] products per head around ONE pass over the block input (rt_mha_varlen_last_x_fwd) instead
+    // of the [rows, d] x [d, 2d] projection (the largest product of the final block) and a pass over its 2 KB-per-row output.
+    int rc = RT_ERR_UNSUPPORTED;
+    if (b.H <= d / 32 && hd >= 8 && (d == 64 || d == 128 || d == 256 || d == 512)) {
+      const size_t Hd = (size_t)b.H * d;
+      float* qk = KV; float* xbar = qk + (size_t)R * Hd; float* Ek = xbar + (size_t)R * Hd; float* Ev = Ek + (size_t)d * Hd;
+      // the per-head products as ONE exact-tile product each over head-expanded weights (rt_mha_last_x_expand: 2 x d x H d floats per call)
+      RT_TRY(rt_mha_last_x_expand(b.in_w + (size_t)d * d, d, b.H, Ek, stream));
+      RT_TRY(rt_mha_last_x_expand(b.in_w + 2 * (size_t)d * d, d, b.H, Ev, stream));
+      RT_TRY(rt_gemm(Q, d, 1, Ek, (int64_t)Hd, 0, qk, (int64_t)Hd, nullptr, nullptr, 0, nullptr, R, (int32_t)Hd, d, 0, 1, nullptr, 0, stream));
+      rc = rt_mha_varlen_last_x_fwd(qk, x, d, b.cu, b.B, b.H, d, b.window, b.window, b.pad_keys ? 1 : 0, xbar, stream);
+      if (rc == RT_OK)
+        rc = rt_gemm(xbar, (int64_t)Hd, 1, Ev, (int64_t)Hd, 1, A, d, b.in_b + 2 * d, nullptr, 0, nullptr, R, d, (int32_t)Hd, 0, 1, nullptr, 0, stream);
+    }
+    if (rc == RT_ERR_UNSUPPORTED) {      // (a width the projection-free kernel does not tile: keys and values of every row)
+      RT_TRY(lin(x, d, b.in_w + (size_t)d * d, b.in_wp != nullptr ? b.in_wp + (size_t)d * d : nullptr, d, KV, 2 * d, b.in_b + d, nullptr, 0, M, 2 * d, d, 0));
+      rc = rt_mha_varlen_last_fwd(Q, d, KV, 2 * d, KV + d, 2 * d, b.cu, bk, bv, b.B, b.H, hd, b.window, b.window, A, d, stream);
+    }
+    RT_TRY(rc);
   }
   // The block's tail with the rows resident on chip (attn and q in, out out, + the scratch rows f — no y, h, statistics) pays while the
   // launch is a round or two of 64-row workgroups: every workgroup streams all three weights (1.2 MB of planes) for its 64 rows, twice the

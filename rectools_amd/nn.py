@@ -548,11 +548,14 @@ class PreLNTransformerLayer(nn.Module):
         mha, d = self.multi_head_attn, seqs.shape[1]
         last_rows = cu[1:B + 1] - 1
         h = self.layer_norm_1(seqs)
-        kv = ops.linear(h, mha.in_proj_weight[d:], mha.in_proj_bias[d:])            # [Np, 2d]
         q = ops.linear(h.index_select(0, last_rows), mha.in_proj_weight[:d], mha.in_proj_bias[:d])
-        a = torch.empty((B, d), dtype=torch.float32, device=seqs.device)
-        ops._c("rt_mha_varlen_last_fwd", q, d, kv, 2 * d, kv[:, d:], 2 * d, cu, None, None, B, mha.n_heads, d // mha.n_heads,   # pylint: disable=protected-access
-               window, window, a, d)
+        if ops.mha_varlen_last_x_supported(d, mha.n_heads):      # the last query needs no key / value rows (round 6): one pass over h
+            a = ops.mha_varlen_last_x(q, h, mha.in_proj_weight, mha.in_proj_bias, cu, B, mha.n_heads, window, False)
+        else:
+            kv = ops.linear(h, mha.in_proj_weight[d:], mha.in_proj_bias[d:])            # [Np, 2d]
+            a = torch.empty((B, d), dtype=torch.float32, device=seqs.device)
+            ops._c("rt_mha_varlen_last_fwd", q, d, kv, 2 * d, kv[:, d:], 2 * d, cu, None, None, B, mha.n_heads, d // mha.n_heads,   # pylint: disable=protected-access
+                   window, window, a, d)
         x1 = mha.out_proj(a, residual=seqs.index_select(0, last_rows))
         return self.feed_forward(self.layer_norm_2(x1), residual=x1)
 

@@ -1900,16 +1900,19 @@ def sasrec_layer_packed(x: torch.Tensor, cu: torch.Tensor, B: int, H: int, windo
         _c("rt_mha_varlen_fwd", Q, d, KV, 2 * d, KV[:, d:], 2 * d, cu, bk, bv, B, H, hd, window, window, A, d)
         rows = Np
     else:
-        KV = new(Np, 2 * d)
-        _gemm(x, d, 1, in_w[d:], d, 1, KV, 2 * d, in_b[d:], None, 0, Np, 2 * d, d)
         x_last = x.index_select(0, last_rows)
         rows = B
         q = new(B, d)
         _c("rt_layernorm_fwd", x_last, ln1[0], ln1[1], float(ln1[2]), B, d, q, mean, rstd)
         Q = new(B, d)
         _gemm(q, d, 1, in_w, d, 1, Q, d, in_b, None, 0, B, d, d)
-        A = new(B, d)
-        _c("rt_mha_varlen_last_fwd", Q, d, KV, 2 * d, KV[:, d:], 2 * d, cu, bk, bv, B, H, hd, window, window, A, d)
+        if mha_varlen_last_x_supported(d, H):      # no key / value rows: one pass over the block input (as the native executor)
+            A = mha_varlen_last_x(Q, x, in_w, in_b, cu, B, H, window, pad_keys)
+        else:
+            KV = new(Np, 2 * d)
+            _gemm(x, d, 1, in_w[d:], d, 1, KV, 2 * d, in_b[d:], None, 0, Np, 2 * d, d)
+            A = new(B, d)
+            _c("rt_mha_varlen_last_fwd", Q, d, KV, 2 * d, KV[:, d:], 2 * d, cu, bk, bv, B, H, hd, window, window, A, d)
     y = new(rows, d)
     _gemm(A, d, 1, out_proj[0], d, 1, y, d, out_proj[1], q, d, rows, d, d)
     f = new(rows, d)
@@ -1920,6 +1923,31 @@ def sasrec_layer_packed(x: torch.Tensor, cu: torch.Tensor, B: int, H: int, windo
     out = new(rows, d)
     _gemm(h, dff, 1, ff2[0], dff, 1, out, d, ff2[1], f, d, rows, d, dff)
     return out
+
+
+def mha_varlen_last_x_supported(d: int, H: int) -> bool:
+    """Does `mha_varlen_last_x` serve this width (`rt_mha_varlen_last_x_fwd`: d in {64, 128, 256, 512}, whole 8-column head groups)?"""
+    return d in (64, 128, 256, 512) and H > 0 and d % H == 0 and (d // H) % 8 == 0 and H <= d // 32
+
+
+def mha_varlen_last_x(q_last: torch.Tensor, x_rows: torch.Tensor, in_w: torch.Tensor, in_b: torch.Tensor, cu: torch.Tensor, B: int, H: int,
+                      window: int, pad_keys: bool) -> torch.Tensor:
+    """Inference: the attention output [B, d] of the LAST query of every packed session WITHOUT projecting keys / values for the rows
+    (`rt_mha_varlen_last_x_fwd`, include/rectools_hip.h): q_last [B, d] = the projected queries, x_rows [Np, d] = what the key / value
+    projection would read (the block input, or its LayerNorm), in_w / in_b = the packed in_proj parameters [3d, d] / [3d].
+    q.(W_k x_j + b_k) = (W_k^T q).x_j + const and sum_j p_j (W_v x_j + b_v) = W_v (sum_j p_j x_j) + b_v: two [B, .] products over
+    head-expanded weights around one pass over x_rows."""
+    d = int(x_rows.shape[1])
+    dev = x_rows.device
+    new = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)  # noqa: E731
+    Ek, Ev = new(d, H * d), new(d, H * d)
+    _c("rt_mha_last_x_expand", in_w[d:2 * d], d, H, Ek)
+    _c("rt_mha_last_x_expand", in_w[2 * d:], d, H, Ev)
+    qk, xbar, A = new(B, H * d), new(B, H * d), new(B, d)
+    _gemm(q_last, int(q_last.stride(0)), 1, Ek, H * d, 0, qk, H * d, None, None, 0, B, H * d, d)
+    _c("rt_mha_varlen_last_x_fwd", qk, x_rows, int(x_rows.stride(0)), cu, B, H, d, window, window, 1 if pad_keys else 0, xbar)
+    _gemm(xbar, H * d, 1, Ev, H * d, 1, A, d, in_b[2 * d:], None, 0, B, d, H * d)
+    return A
 
 
 HSTU_BUCKETS = 147      # csrc NBUCK: every bucket an int64 difference can reach (ln(2^63) / 0.301 = 145.08 -> buckets 0 .. 145, and one spare)

@@ -664,6 +664,49 @@ def test_loss_backward_reads_the_upstream_gradient_on_the_device():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("d,H,window,pad_keys", [(256, 4, 200, True), (256, 4, 200, False), (64, 2, 50, True), (128, 1, 30, True), (512, 4, 200, True),
+                                                 (512, 8, 512, False), (192 + 64, 2, 20, True)])
+def test_last_query_without_key_value_rows(d, H, window, pad_keys):
+    """rt_mha_varlen_last_x_fwd (qk = W_k,h^T q_h in, xbar = sum_j p_j x_j out; the caller applies W_v,h) == rt_mha_varlen_last_fwd on the
+    projected keys / values of every row, incl. the window's pad keys (logit q.b_k, value b_v) — the two forms of the final block's
+    attention in recommend() (sasrec.py:221-224 at the last position)."""
+    from rectools_amd import ops
+
+    B, hd = 37, d // H
+    g = torch.Generator().manual_seed(d + H)
+    lens = torch.randint(1, window + 1, (B,), generator=g)
+    lens[0], lens[1] = window, 1
+    cu = torch.zeros(B + 1, dtype=torch.int64); cu[1:] = torch.cumsum(lens, 0)
+    n = int(cu[-1])
+    x = (rnd(n, d, seed=1) * 0.7).cuda()
+    Wk, Wv = (rnd(d, d, seed=2) * 0.1).cuda(), (rnd(d, d, seed=3) * 0.1).cuda()
+    bk, bv = (rnd(d, seed=4) * 0.3).cuda(), (rnd(d, seed=5) * 0.3).cuda()
+    q = rnd(B, d, seed=6).cuda()
+    cud = cu.cuda()
+    # the projection form: K | V of every row
+    K, V = x @ Wk.T + bk, x @ Wv.T + bv
+    want = torch.empty(B, d, device="cuda")
+    ops._c("rt_mha_varlen_last_fwd", q, d, K, d, V, d, cud, bk if pad_keys else None, bv if pad_keys else None, B, H, hd, window, window, want, d)
+    # the projection-free form
+    qk = torch.einsum("bhe,hed->bhd", q.view(B, H, hd), Wk.view(H, hd, d)).contiguous()
+    xbar = torch.empty(B, H, d, device="cuda")
+    ops._c("rt_mha_varlen_last_x_fwd", qk, x, d, cud, B, H, d, window, window, int(pad_keys), xbar)
+    got = torch.einsum("bhd,hed->bhe", xbar, Wv.view(H, hd, d)).reshape(B, d) + bv
+    close(got, want, rtol=2e-4, atol_rel=2e-5, msg="last query, projection-free")
+    # fp64 restatement of the reference's own formula for one session (nn.MultiheadAttention on the left-padded window)
+    b = 0 if not pad_keys else 2
+    nb, npad = int(lens[b]), (window - int(lens[b])) if pad_keys else 0
+    xs = x[int(cu[b]):int(cu[b + 1])].double().cpu()
+    xs = torch.cat([torch.zeros(npad, d, dtype=torch.float64), xs])
+    Kr, Vr = xs @ Wk.double().cpu().T + bk.double().cpu(), xs @ Wv.double().cpu().T + bv.double().cpu()
+    outs = []
+    for h in range(H):
+        sc = (Kr[:, h * hd:(h + 1) * hd] @ q[b, h * hd:(h + 1) * hd].double().cpu()) / hd ** 0.5
+        outs.append(torch.softmax(sc, 0) @ Vr[:, h * hd:(h + 1) * hd])
+    close(got[b].cpu().double(), torch.cat(outs), rtol=2e-4, atol_rel=2e-5, msg="last query vs fp64")
+
+
+@pytest.mark.gpu
 def test_mul_mask_ld_strided_slices():
     from rectools_amd import ops
 
