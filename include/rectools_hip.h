@@ -504,7 +504,11 @@ int rt_mha_last_x_expand(const float* W, int32_t d, int32_t H, float* E, rt_stre
  *           library-owned side stream when use_side != 0: call rt_side_join(stream) before reading `grads`; x, saved, g_out,
  *           scratch (rt_sasrec_block_bwd_scratch_bytes) and grads must stay alive until then.
  *   _infer: eval mode; last_rows == NULL: out [rows,d]; last_rows [B]: the output at those rows only, out [B,d] (what
- *           recommend() keeps, lightning.py:393-397); scratch: rt_sasrec_block_infer_scratch_floats floats.
+ *           recommend() keeps, lightning.py:393-397); scratch: rt_sasrec_block_infer_scratch_floats floats.  kv_in (nullable, with
+ *           last_rows == NULL): the block's keys | values [rows, 2d] handed in — the FIRST block of recommend() reads embedding row +
+ *           positional row, so W_kv (e + p) + b_kv = (W_kv e) + (W_kv p + b_kv) is a gather from two projected tables
+ *           (rt_embed_packed_fwd over them) and only the query projection runs over the rows.  With last_rows the final block needs no
+ *           key / value rows at all (rt_mha_varlen_last_x_fwd).
  * rt_timing_enable(1|2) brackets every internal launch with HIP events (2: weight gradients on the caller's stream);
  * rt_timing_collect synchronises and returns (id, ms, M N K) records: ids 0 gemm, 1 gemm_grouped, 2 layernorm_fwd, 3 layernorm_bwd,
  * 4 act_dropout_fwd, 5 act_dropout_bwd, 6 mha_varlen_train_fwd, 7 mha_varlen_bwd, 8 mha_varlen_last_fwd, 9 misc.
@@ -526,8 +530,8 @@ int rt_sasrec_block_packed_fwd(const rt_sasrec_block* blk, const float* x, float
 int rt_sasrec_block_packed_bwd(const rt_sasrec_block* blk, const float* x, const float* saved, const float* g_out, float* g_x, float* grads,
                                void* scratch, size_t scratch_bytes, int32_t wgrad_splits, int32_t use_side, rt_stream_t stream);
 size_t rt_sasrec_block_infer_scratch_floats(int32_t rows, int32_t B, int32_t d, int32_t dff, int32_t last_only);
-int rt_sasrec_block_packed_infer(const rt_sasrec_block* blk, const float* x, const int64_t* last_rows, float* scratch, float* out,
-                                 rt_stream_t stream);
+int rt_sasrec_block_packed_infer(const rt_sasrec_block* blk, const float* x, const float* kv_in, const int64_t* last_rows, float* scratch,
+                                 float* out, rt_stream_t stream);
 
 /* One packed Pre-LN block (net_blocks.py:223-262, BERT4Rec's stack) under key-padding masks — packed rows have no pad keys:
  *   h = LN1(x); qkv = h Win^T + bin; A = attention(qkv) (causal = 0: every query sees its whole session, rt_mha_varlen_bidir_*);

@@ -783,8 +783,8 @@ size_t rt_sasrec_block_infer_scratch_floats(int32_t rows, int32_t B, int32_t d, 
   const size_t kv = M * 2 * d, qx = last_only ? 2 * (R + d) * (size_t)(d / 32) * d : 0;      // (+ the two head-expanded weights)
   return (last_only ? al(R * d) : 0) /* x_last */ + al(R * d) * 5 /* q Q A y f */ + al(kv > qx ? kv : qx) /* KV */ + al(R * dff) /* h */ + 2 * al(R);
 }
-int rt_sasrec_block_packed_infer(const rt_sasrec_block* blk, const float* x, const int64_t* last_rows, float* scratch, float* out,
-                                 hipStream_t stream) {
+int rt_sasrec_block_packed_infer(const rt_sasrec_block* blk, const float* x, const float* kv_in, const int64_t* last_rows, float* scratch,
+                                 float* out, hipStream_t stream) {
   (void)hipGetLastError();
   if (blk == nullptr || x == nullptr || scratch == nullptr || out == nullptr) return RT_ERR_INVALID_ARG;
   const rt_sasrec_block& b = *blk;
@@ -809,7 +809,14 @@ int rt_sasrec_block_packed_infer(const rt_sasrec_block* blk, const float* x, con
     if (rc == RT_ERR_UNSUPPORTED) rc = rt_gemm(A, lda, 1, W, ldw, 1, C, ldc, bias, R, ldr, nullptr, rows, N, K, relu, 1, nullptr, 0, stream);
     return rc;
   };
-  if (!last) {
+  if (!last && kv_in != nullptr) {
+    // keys | values handed in ([rows, 2d]: the FIRST block of recommend(), whose input is embedding row + positional row — W_kv (e + p) +
+    // b = (W_kv e) + (W_kv p + b): two projected TABLES and a gather, models / nn.TransformerTorchBackbone.encode_last_packed): only the
+    // query projection runs over the rows
+    RT_TRY(lin(q, d, b.in_w, b.in_wp, d, Q, d, b.in_b, nullptr, 0, M, d, d, 0));
+    { rt_sasrec_block bb = b; RT_TRY(zero_tail(A, bb, d, stream)); }
+    RT_TRY(rt_mha_varlen_fwd(Q, d, kv_in, 2 * d, kv_in + d, 2 * d, b.cu, bk, bv, b.B, b.H, hd, b.window, b.window, A, d, stream));
+  } else if (!last) {
     int rc = RT_ERR_UNSUPPORTED;
     if (b.in_wp != nullptr) {
       rt_gemm_wp_problem wp[2] = {{q, d, b.in_wp, b.wp_stride, d, Q, d, b.in_b, nullptr, 0, M, d, d, 0},

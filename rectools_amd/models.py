@@ -1268,13 +1268,15 @@ class TransformerModelBase:
                 if packed:
                     kw = {} if ctx_d is None else {"ts_store": ts_s, "ts_ctx": ctx_d[b0:b0 + nb]}
                     outs.append(lm.torch_model.encode_last_packed(offsets, item_s, enc_rows[b0:b0 + nb], dp.session_max_len, item_embs,
-                                                                  cu=cu_d[bi, :nb + 1], n_rows=int(cu_h[bi, nb]), mask_id=mask_id, **kw))
+                                                                  cu=cu_d[bi, :nb + 1], n_rows=int(cu_h[bi, nb]), mask_id=mask_id,
+                                                                  cache=call_cache, **kw))
                     continue
                 batch = dp.collate_recommend_device(dstore, valid_rows[b0:b0 + nb])
                 outs.append(lm.torch_model.encode_last(batch, item_embs))   # last-position encodings, [b, d]
             return outs
 
         bs = self._encode_batch_size()
+        call_cache: tp.Dict[str, tp.Any] = {}      # what is valid for THIS call's fixed weights (nn.TransformerTorchBackbone.encode_last_packed)
         with torch.no_grad():
             while True:      # a launch that does not fit beside what else lives on this GPU is halved and repeated
                 try:

@@ -378,15 +378,17 @@ class SASRecTransformerLayer(nn.Module):
         ff = self.feed_forward
         return not self.generic and ff.ff_linear_1.bias is not None and ff.ff_linear_2.bias is not None and ff.activation == "relu"
 
-    def forward_packed(self, seqs, cu, B, window, pad_keys, last_rows=None, rows_real=None, planes=None):
-        """Inference over packed sessions (no padding rows; see ops.sasrec_layer_packed): [Np, d], or [B, d] with `last_rows`."""
+    def forward_packed(self, seqs, cu, B, window, pad_keys, last_rows=None, rows_real=None, planes=None, kv_in=None):
+        """Inference over packed sessions (no padding rows; see ops.sasrec_layer_packed): [Np, d], or [B, d] with `last_rows`.
+        kv_in: this block's keys | values [Np, 2d] made by the caller (`SASRecTransformerLayers.forward_last_packed`, first block)."""
         ff, mha = self.feed_forward, self.multi_head_attn
         return ops.sasrec_layer_packed(
             seqs, cu, B, mha.n_heads, window, pad_keys, last_rows,
             (self.q_layer_norm.weight, self.q_layer_norm.bias, self.q_layer_norm.eps),
             (mha.in_proj_weight, mha.in_proj_bias), (mha.out_proj.weight, mha.out_proj.bias),
             (self.ff_layer_norm.weight, self.ff_layer_norm.bias, self.ff_layer_norm.eps),
-            (ff.ff_linear_1.weight, ff.ff_linear_1.bias), (ff.ff_linear_2.weight, ff.ff_linear_2.bias), rows_real=rows_real, planes=planes)
+            (ff.ff_linear_1.weight, ff.ff_linear_1.bias), (ff.ff_linear_2.weight, ff.ff_linear_2.bias), rows_real=rows_real, planes=planes,
+            kv_in=kv_in)
 
     def forward_packed_train(self, seqs, cu, B, window, pad_keys, rows_real=None, planes=None):
         """The block on packed rows with autograd (training): ONE autograd node (`ops.sasrec_layer_packed_train`) when the feed-forward
@@ -468,14 +470,21 @@ class SASRecTransformerLayers(TransformerLayersBase):
             seqs = blk.forward_packed_train(seqs, cu, B, window, not keypad, rows_real, planes)
         return self.last_layernorm(seqs)
 
-    def forward_last_packed(self, seqs, cu, B, window, keypad, rows_real=None, causal=True):
+    accepts_first_kv = True      # (`TransformerTorchBackbone.encode_last_packed` asks before it builds the projected tables)
+
+    def forward_last_packed(self, seqs, cu, B, window, keypad, rows_real=None, causal=True, first_kv=None):
         """[B, d] encodings of the last position from PACKED rows: every block input is the real rows only — the
         reference masks pad rows to zero before each block (sasrec.py:300) and their only trace, the pad keys a causal block
-        without key-padding masks shows to every query, is the virtual key of `rt_mha_varlen_*`."""
+        without key-padding masks shows to every query, is the virtual key of `rt_mha_varlen_*`.  first_kv(in_proj_weight,
+        in_proj_bias) -> [Np, 2d]: the FIRST block's keys | values made from projected tables (its input is embedding row +
+        positional row, the key / value projection is linear: sasrec.py:221-224 reads the raw block input)."""
         blocks = list(self.transformer_blocks)
         planes = self._fresh_planes() if rows_real is not None else None
-        for blk in blocks[:-1]:
-            seqs = blk.forward_packed(seqs, cu, B, window, not keypad, rows_real=rows_real, planes=planes)
+        for i, blk in enumerate(blocks[:-1]):
+            kv_in = None
+            if i == 0 and first_kv is not None:
+                kv_in = first_kv(blk.multi_head_attn.in_proj_weight, blk.multi_head_attn.in_proj_bias)
+            seqs = blk.forward_packed(seqs, cu, B, window, not keypad, rows_real=rows_real, planes=planes, kv_in=kv_in)
         last = blocks[-1].forward_packed(seqs, cu, B, window, not keypad, last_rows=cu[1:] - 1, rows_real=rows_real, planes=planes)
         return self.last_layernorm(last)
 
@@ -1105,7 +1114,8 @@ class TransformerTorchBackbone(nn.Module):
     def encode_last_packed(self, offsets: torch.Tensor, items: torch.Tensor, rows: torch.Tensor, window: int,
                            item_embs: tp.Optional[torch.Tensor] = None, cu: tp.Optional[torch.Tensor] = None,
                            n_rows: tp.Optional[int] = None, mask_id: tp.Optional[int] = None,
-                           ts_store: tp.Optional[torch.Tensor] = None, ts_ctx: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
+                           ts_store: tp.Optional[torch.Tensor] = None, ts_ctx: tp.Optional[torch.Tensor] = None,
+                           cache: tp.Optional[tp.Dict[str, tp.Any]] = None) -> torch.Tensor:
         """-> [B, d] = `encode_last` of the sessions `rows` of a CSR session store (`offsets`, `items`: model item ids, oldest
         first), without ever building the padded [B, L] batch: the last `window` items of every session are gathered into ONE
         packed row block (embedding + positional row by distance from the session's end, torch_backbone.py:245-246 /
@@ -1113,7 +1123,9 @@ class TransformerTorchBackbone(nn.Module):
         one item.  `cu` [B+1] / `n_rows` = cu[-1]: the packed row offsets cut by the caller on the HOST (no device round trip);
         without them they are taken from the device offsets (one synchronisation).  mask_id: the BERT4Rec batch instead — the last
         window - 1 items and the MASK token as the last row of every session (bert4rec.py:182-193).  ts_store / ts_ctx: the store's
-        timestamps (seconds) and the request time of every session — the packed timestamps a relative time bias reads."""
+        timestamps (seconds) and the request time of every session — the packed timestamps a relative time bias reads.
+        cache: a dict the caller keeps for ONE recommend() call (weights fixed): the projected tables of the first block's keys /
+        values live there between the call's encoder launches."""
         table = self.item_model.table if item_embs is None else item_embs
         d = table.shape[1]
         B = int(rows.numel())
@@ -1145,8 +1157,23 @@ class TransformerTorchBackbone(nn.Module):
         if prefix:
             kw["n_prefixed"] = B
             n_rows = n_rows + window
-        return self.transformer_layers.forward_last_packed(x, cu, B, window, self.use_key_padding_mask, rows_real=n_rows,
-                                                           causal=self.use_causal_attn, **kw)
+        layers = self.transformer_layers
+        if (cache is not None and getattr(layers, "accepts_first_kv", False) and mask_id is None and not prefix and pos is not None
+                and len(getattr(layers, "transformer_blocks", ())) > 1 and ("kv_tables" in cache or Np >= int(table.shape[0]))):
+            # The first block's keys | values without a product over the rows: x = scale * E[id] + P[dist] and the projection is linear, so
+            # K | V = scale * (E W_kv^T)[id] + (P W_kv^T + b_kv)[dist] — two small products ONCE per recommend() call, then the embedding
+            # gather itself over the projected tables (2 KB per row written instead of a [rows, d] x [d, 2d] product: two thirds of the block's
+            # largest launch).  Worth it when the call's rows outnumber the catalog (a whole-catalog request: 15.6 M rows, 26,744 items).
+            def first_kv(in_w: torch.Tensor, in_b: torch.Tensor) -> torch.Tensor:
+                tabs = cache.get("kv_tables")
+                if tabs is None:
+                    tabs = cache["kv_tables"] = (ops.linear(table.contiguous(), in_w[d:], None), ops.linear(pos.contiguous(), in_w[d:], in_b[d:]))
+                kv = torch.empty((Np, 2 * d), dtype=torch.float32, device=table.device)
+                ops._c("rt_embed_packed_fwd", ids, dist, tabs[0], tabs[1], float(scale), Np, 2 * d, 0.0, 0, 0, kv)
+                return kv
+
+            kw["first_kv"] = first_kv
+        return layers.forward_last_packed(x, cu, B, window, self.use_key_padding_mask, rows_real=n_rows, causal=self.use_causal_attn, **kw)
 
     def encode_packed_train(self, ids: torch.Tensor, dist: torch.Tensor, cu: torch.Tensor, B: int, window: int,
                             item_embs: tp.Optional[torch.Tensor] = None, rows_real: tp.Optional[int] = None,

@@ -85,7 +85,14 @@ def test_encode_last_packed_equals_padded_encode_last(n_blocks, H, d, keypad):
             tail = items[offsets[r]:offsets[r + 1]][-L:]
             x[b, L - len(tail):] = tail
         padded = backbone.encode_last({"x": x})
+        # a recommend() call's cache: the FIRST block's keys | values gathered from projected tables (rows >= catalog rows here)
+        cache = {}
+        tabled = backbone.encode_last_packed(offsets, items, rows, L, cache=cache)
+        assert ("kv_tables" in cache) == (n_blocks > 1)
+        again = backbone.encode_last_packed(offsets, items, rows, L, cache=cache)      # (the second launch of a call reuses them)
     torch.testing.assert_close(packed, padded, rtol=2e-4, atol=2e-5 * float(padded.abs().max()))
+    torch.testing.assert_close(tabled, padded, rtol=2e-4, atol=2e-5 * float(padded.abs().max()))
+    assert torch.equal(tabled, again)
 
 
 def test_recommend_with_packed_encoder_equals_padded(monkeypatch):
