@@ -600,6 +600,12 @@ int rt_hstu_attn_varlen_bwd(const float* q, int64_t ldq, const float* k, int64_t
 int rt_hstu_attn_last_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const int64_t* ids,
                           const int64_t* ts, const float* time_w, const int64_t* time_thr, const float* pos_w, int32_t B,
                           int32_t H, int32_t L, int32_t hd, float* o, int64_t ldo, rt_stream_t stream);
+/* ... over PACKED sessions (round 6: the final STU block of recommend(), hstu.py:270-288 at the last position): k / v packed rows,
+ * cu_seqlens [B+1], ts packed as rt_hstu_attn_varlen_fwd reads it, window = session_max_len, max_len >= the longest session */
+int rt_hstu_attn_varlen_last_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                                 const int64_t* cu_seqlens, const int64_t* ts, const float* time_w, const int64_t* time_thr,
+                                 const float* pos_w, int32_t B, int32_t H, int32_t window, int32_t hd, int32_t max_len, float* o, int64_t ldo,
+                                 rt_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K8/K9  negative-sampled losses without the [B,L,1+N,d] gather (similarity.py:88-95 + lightning.py:164-212).

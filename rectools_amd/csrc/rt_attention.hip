@@ -1986,6 +1986,62 @@ __global__ __launch_bounds__(256) void attn_last_query_kernel(AttnArgs a) {
   }
 }
 
+// The same for PACKED sessions (round 6: recommend()'s final STU block): session b = rows cu[b] .. cu[b+1]-1 of k / v (oldest first), its
+// n + 1 timestamps start at ts[cu[b] + b]; the query is the session's last row (window position `window` - 1: key j of n sits
+// n - 1 - j positions before it), q [B, ldq] one row per session.  hstu.py:270-288 for that row: silu(q.k + rab) / window, summed over the
+// session's rows (a pad key's k, v are silu(0) = 0: it adds nothing).
+struct HstuLastVarlenArgs {
+  const float *q, *k, *v; long long ldq, ldk, ldv; float* o; long long ldo;
+  const long long *cu, *ts; const float* time_w; const long long* time_thr; const float* pos_w;
+  int B, H, window, hd;
+};
+__global__ __launch_bounds__(256) void hstu_last_varlen_kernel(HstuLastVarlenArgs a, int max_n) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [max_n] weights | then the partial sums
+  float* prob = smem;
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const long long row0 = a.cu[b];
+  const int n = (int)(a.cu[b + 1] - row0);
+  float* op = a.o + (long long)b * a.ldo + h * a.hd;
+  if (n <= 0) {
+    if (tid < a.hd) op[tid] = 0.f;
+    return;
+  }
+  const float* qv = a.q + (long long)b * a.ldq + h * a.hd;
+  const float* kb = a.k + row0 * a.ldk + h * a.hd;
+  const float* vb = a.v + row0 * a.ldv + h * a.hd;
+  const long long* tsb = a.ts ? a.ts + row0 + b : nullptr;
+  const long long t_q1 = tsb ? tsb[n] : 0;                 // the request's time: the stamp behind the last item
+  const float inv_l = 1.0f / (float)a.window;
+  for (int j = tid; j < n; j += 256) {
+    float sdot = 0.f;
+    for (int c = 0; c < a.hd; c += 4) {
+      const f32x4 kk4 = *reinterpret_cast<const f32x4*>(kb + (long long)j * a.ldk + c);
+      const f32x4 q4 = *reinterpret_cast<const f32x4*>(qv + c);
+      sdot += kk4[0] * q4[0] + kk4[1] * q4[1] + kk4[2] * q4[2] + kk4[3] * q4[3];
+    }
+    float bias = 0.f;
+    if (a.time_w) bias += a.time_w[min(time_bucket(a.time_thr, t_q1 - tsb[j]), (int)a.time_thr[NBUCK] - 1)];
+    if (a.pos_w) bias += a.pos_w[(a.window - 1) + j - (n - 1)];
+    prob[j] = silu_f(sdot + bias) * inv_l;
+  }
+  __syncthreads();
+  const int ncol4 = a.hd / 4, phases = 256 / ncol4;
+  const int c4 = tid % ncol4, ph = tid / ncol4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (ph < phases)
+    for (int j = ph; j < n; j += phases) acc += *reinterpret_cast<const f32x4*>(vb + (long long)j * a.ldv + c4 * 4) * prob[j];
+  __syncthreads();
+  f32x4* part = reinterpret_cast<f32x4*>(smem);
+  if (ph < phases) part[ph * ncol4 + c4] = acc;
+  __syncthreads();
+  if (tid < ncol4) {
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    for (int p2 = 0; p2 < phases; ++p2) o += part[p2 * ncol4 + tid];
+    *reinterpret_cast<f32x4*>(op + tid * 4) = o;
+  }
+}
+
 #ifdef RT_ATTN_TRACE
 __global__ void occ_probe_kernel(unsigned long long* out, int spin) {
   extern __shared__ float sm[];
@@ -2132,6 +2188,32 @@ int rt_hstu_attn_last_fwd(const float* q, int64_t ldq, const float* k, int64_t l
   if (lds > LDS_LIMIT) return RT_ERR_UNSUPPORTED;
   { const int rc = set_lds(&attn_last_query_kernel<MODE_HSTU>, lds); if (rc != RT_OK) return rc; }
   attn_last_query_kernel<MODE_HSTU><<<B * H, 256, lds, stream>>>(a);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
+// ... over PACKED sessions (hstu_last_varlen_kernel): k / v packed rows, cu_seqlens [B+1], ts packed (n_b + 1 stamps per session at
+// ts[cu[b] + b]), window = session_max_len (the 1 / window factor and the position table's centre), max_len >= the longest session.
+int rt_hstu_attn_varlen_last_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                                 const int64_t* cu_seqlens, const int64_t* ts, const float* time_w, const int64_t* time_thr,
+                                 const float* pos_w, int32_t B, int32_t H, int32_t window, int32_t hd, int32_t max_len, float* o, int64_t ldo,
+                                 hipStream_t stream) {
+  (void)hipGetLastError();
+  if (q == nullptr || k == nullptr || v == nullptr || o == nullptr || cu_seqlens == nullptr || B < 0 || H <= 0 || hd <= 0 || (hd & 7) != 0 ||
+      hd > 256 || window <= 0 || max_len <= 0 || (ldq & 3) || (ldk & 3) || (ldv & 3) || (ldo & 3) || misaligned16(o) || misaligned16(q) ||
+      misaligned16(k) || misaligned16(v))
+    return RT_ERR_INVALID_ARG;
+  if ((time_w != nullptr) != (ts != nullptr) || (time_w != nullptr) != (time_thr != nullptr)) return RT_ERR_INVALID_ARG;
+  if (B == 0) return RT_OK;
+  HstuLastVarlenArgs a{};
+  a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.o = o; a.ldo = ldo;
+  a.cu = reinterpret_cast<const long long*>(cu_seqlens); a.ts = reinterpret_cast<const long long*>(ts); a.time_w = time_w;
+  a.time_thr = reinterpret_cast<const long long*>(time_thr); a.pos_w = pos_w; a.B = B; a.H = H; a.window = window; a.hd = hd;
+  const size_t prob_f = (size_t)((max_len + 3) & ~3) + 8, part_f = (size_t)256 * 4;
+  const size_t lds = (prob_f > part_f ? prob_f : part_f) * sizeof(float);
+  if (lds > LDS_LIMIT) return RT_ERR_UNSUPPORTED;
+  { const int rc = set_lds(&hstu_last_varlen_kernel, lds); if (rc != RT_OK) return rc; }
+  hstu_last_varlen_kernel<<<B * H, 256, lds, stream>>>(a, max_len);
   RT_CHECK_LAUNCH();
   return RT_OK;
 }

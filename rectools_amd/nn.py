@@ -838,6 +838,33 @@ class STULayer(nn.Module):
         o_in = ops.mul_mask(uq[0], self.norm_attn_output(attn), ids_last)
         return self.output_mlp(o_in, residual=_take_last(x0, B, L))
 
+    def forward_last_packed(self, seqs, cu, B, window, ts, thr):
+        """Inference over PACKED sessions: the block's output at the last row of every session, [B, d] (cf. `forward_last`): v and k are
+        projected for every row, u and q for the last rows only, the attention of that row is `rt_hstu_attn_varlen_last_fwd`;
+        LayerNorm(attn), the gate and the output MLP run on B rows."""
+        hh, d = self.n_heads * self.hd, seqs.shape[1]
+        M = seqs.shape[0]
+        new = lambda *s_: torch.empty(s_, dtype=torch.float32, device=seqs.device)  # noqa: E731
+        last_rows = cu[1:B + 1] - 1
+        normed = self.norm_input(seqs)
+        P = self.uvqk_proj                                                        # [d, 4 hh]: u | v | q | k column blocks
+        vk = new(2, M, hh)
+        for i, c0 in enumerate((hh, 3 * hh)):                                     # v, k of every row
+            ops._gemm(normed, d, 1, P[:, c0:], 4 * hh, 0, vk[i], hh, None, None, 0, M, hh, d)   # pylint: disable=protected-access
+        vk = ops.act_dropout(vk.view(2 * M, hh), ops.ACT_SILU, 0.0).view(2, M, hh)
+        n_last = normed.index_select(0, last_rows)
+        uq = new(2, B, hh)
+        for i, c0 in enumerate((0, 2 * hh)):                                      # u, q of the last rows
+            ops._gemm(n_last, d, 1, P[:, c0:], 4 * hh, 0, uq[i], hh, None, None, 0, B, hh, d)   # pylint: disable=protected-access
+        uq = ops.act_dropout(uq.view(2 * B, hh), ops.ACT_SILU, 0.0).view(2, B, hh)
+        tw = self.rel_attn.time_weights if self.rel_attn.relative_time_attention else None
+        pw = self.rel_attn.pos_weights if self.rel_attn.relative_pos_attention else None
+        attn = new(B, hh)
+        ops._c("rt_hstu_attn_varlen_last_fwd", uq[1], hh, vk[1], hh, vk[0], hh, cu, ts if tw is not None else None, tw,   # pylint: disable=protected-access
+               thr if tw is not None else None, pw, B, self.n_heads, window, self.hd, window, attn, hh)
+        o_in = ops.mul_mask(uq[0], self.norm_attn_output(attn), None)
+        return self.output_mlp(o_in, residual=seqs.index_select(0, last_rows))
+
     def forward_packed(self, seqs, cu, B, window, ts, thr, rows_real=None):
         """The block over PACKED sessions ([Np, d], real positions only).  The reference zeroes pad rows before the bias-free projection
         (hstu.py:256-262): their u / v / q / k are silu(0) = 0, a pad key adds nothing to any query — the packed rows see exactly what
@@ -921,8 +948,15 @@ class STULayers(TransformerLayersBase):
         return seqs
 
     def forward_last_packed(self, seqs, cu, B, window, keypad, rows_real=None, causal=True, ts=None):
-        """[B, d]: the packed blocks on every row, then the last row of every session."""
-        return self.forward_packed_train(seqs, cu, B, window, keypad, ts=ts).index_select(0, cu[1:B + 1] - 1)
+        """[B, d]: the packed blocks on every row — the FINAL block on one query row per session (`STULayer.forward_last_packed`:
+        only its v / k projection and LayerNorm see every row)."""
+        blocks = list(self.stu_blocks)
+        if not blocks or blocks[-1].generic or blocks[-1].lin != blocks[-1].hd:
+            return self.forward_packed_train(seqs, cu, B, window, keypad, ts=ts).index_select(0, cu[1:B + 1] - 1)
+        with ops.active_planes(self._fresh_planes()):
+            for blk in blocks[:-1]:
+                seqs = blk.forward_packed(seqs, cu, B, window, ts, self.time_thr)
+            return blocks[-1].forward_last_packed(seqs, cu, B, window, ts, self.time_thr)
 
 
 # ---- similarity + backbone ------------------------------------------------------------------------------

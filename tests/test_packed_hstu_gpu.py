@@ -289,3 +289,31 @@ def test_hstu_varlen_chunked_sessions_against_the_oracle(num_buckets):
         close(packed.grad[:N, i * d:(i + 1) * d], ins[i].grad[real], name, rtol=2e-3, atol_rel=2e-4)
     close(tw.grad, ins[3].grad, "d time_weights", rtol=2e-3, atol_rel=2e-4)
     close(pw.grad, ins[4].grad, "d pos_weights", rtol=2e-3, atol_rel=2e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("time_bias,pos_bias", [(True, True), (False, True), (True, False), (False, False)])
+def test_final_stu_block_on_one_query_row_per_session(time_bias, pos_bias):
+    """`STULayers.forward_last_packed`: the final block with u / q, the attention (`rt_hstu_attn_varlen_last_fwd`), LayerNorm(attn), the gate
+    and the output MLP on ONE row per session == every block on every row, last rows taken (what it was until round 6)."""
+    from rectools_amd import nn as hnn
+
+    torch.manual_seed(3)
+    d, H, hd, L, B = 64, 2, 32, 50, 23
+    layers = hnn.STULayers(2, d, H, hd, hd, L, time_bias, pos_bias, 0.0, 0.0, 1e-6).cuda().eval()
+    for prm in layers.parameters():
+        if prm.dim() == 1:
+            torch.nn.init.normal_(prm, std=0.3)
+    rng = np.random.default_rng(0)
+    lens = rng.integers(1, L + 1, B); lens[0], lens[1] = L, 1
+    cu = torch.tensor(np.r_[0, np.cumsum(lens)], dtype=torch.int64).cuda()
+    n = int(cu[-1]); Np = (n + 127) // 128 * 128
+    x = torch.randn(Np, d, device="cuda") * 0.5
+    ts = None
+    if time_bias:      # n_b + 1 ascending stamps per session (the last one: the request's time), packed at cu[b] + b
+        parts = [np.sort(rng.integers(0, 10_000_000, int(m) + 1)) for m in lens]
+        ts = torch.tensor(np.concatenate(parts), dtype=torch.int64).cuda()
+    with torch.no_grad():
+        want = layers.forward_packed_train(x, cu, B, L, False, ts=ts).index_select(0, cu[1:B + 1] - 1)
+        got = layers.forward_last_packed(x, cu, B, L, False, ts=ts)
+    torch.testing.assert_close(got, want, rtol=2e-4, atol=2e-5 * float(want.abs().max()))
