@@ -863,6 +863,8 @@ def main():
             if "host_only_ms_per_step" in ho:
                 roof["host_only_ms_per_step"] = ho["host_only_ms_per_step"]
                 roof["launches_per_step_all_kernels"] = ho["launches_per_step"]
+        if kind in ("bert4rec", "hstu") and world == 1 and rank == 0:      # a family leg run alone carries its recommend() figure too
+            out["recommend"] = family_recommend(info, kind)
         if cpu_ok and kind == "train":
             v, kind_b, what = cpu_baseline_train(info)
             out["cpu_baseline"] = {"value": round(v, 2), "unit": "seqs/s", "cores": torch.get_num_threads(), "kind": kind_b, "sample": what}
