@@ -456,7 +456,11 @@ def run_train(args, rank, world, kind="train"):
         dp_report = {"per_rank_ms_per_step": timed_steps.per_rank_ms, "per_rank_device_ms_per_step": timed_steps.per_rank_device_ms,
                      "exchange_ms_per_step_per_rank": [round(v, 4) for v in gather_floats(ex_ms, world)],
                      "exchange": "sharded (reduce-scatter + Adam on the slice + all-gather)" if model.optimizer._use_sharded(world)
-                                 else "all-reduce of the flat gradient", "gradient_bytes": int(model.optimizer.flat_p.numel() * 4)}
+                                 else ("all-reduce in two buckets (block weights from the backward pass's gradient hook, embeddings behind it)"
+                                       if model.optimizer.early_stats["started"] > 0 else "all-reduce of the flat gradient"),
+                     "early_bucket": dict(model.optimizer.early_stats, bytes=int((model.optimizer.flat_p.numel() - (model.optimizer.early_from or
+                                                                                                          model.optimizer.flat_p.numel())) * 4)),
+                     "gradient_bytes": int(model.optimizer.flat_p.numel() * 4)}
     # sequences of the timed steps as counted by the loop (an epoch's last batch is short: 17,312 sessions per rank at 8 ranks
     # = 135 full batches + 32 sessions); every rank holds an equally long shard, so the job total is this rank's count x ranks
     seqs = state["seqs"][args.warmup + args.steps - 1] - (state["seqs"][args.warmup - 1] if args.warmup > 0 else 0)
