@@ -867,7 +867,7 @@ def main():
             if "host_only_ms_per_step" in ho:
                 roof["host_only_ms_per_step"] = ho["host_only_ms_per_step"]
                 roof["launches_per_step_all_kernels"] = ho["launches_per_step"]
-        if kind in ("bert4rec", "hstu") and world == 1 and rank == 0:      # a family leg run alone carries its recommend() figure too
+        if kind in ("bert4rec", "hstu", "esasrec") and world == 1 and rank == 0:      # a family leg run alone carries its recommend() figure too
             out["recommend"] = family_recommend(info, kind)
         if cpu_ok and kind == "train":
             v, kind_b, what = cpu_baseline_train(info)
@@ -927,7 +927,7 @@ def main():
                                                                                    "host_issue_ms_per_step", "device_ms_per_step", "allocator_in_timed_steps") if k in roof_f},
                                                 "final_loss": round(info_f["loss"], 5),
                                                 "kernel_breakdown": {k: v["ms_per_step"] for k, v in list(info_f["breakdown"].items())[:8]}}
-                    if kind_f in ("bert4rec", "hstu") and world == 1:      # the families whose recommend() takes the packed device path
+                    if kind_f in ("bert4rec", "hstu", "esasrec") and world == 1:      # the families whose recommend() takes the packed device path
                         out["families"][kind_f]["recommend"] = family_recommend(info_f, kind_f)
                     del info_f
                     torch.cuda.empty_cache()

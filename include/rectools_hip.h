@@ -483,9 +483,11 @@ int rt_mha_varlen_last_fwd(const float* q, int64_t ldq, const float* k, int64_t 
  * q_h.(W_k,h x_j + b_k,h) = (W_k,h^T q_h).x_j + const and sum_j p_j (W_v,h x_j + b_v,h) = W_v,h (sum_j p_j x_j) + b_v,h, so the caller hands
  * qk [B, H, d] = W_k,h^T q_h (one small product per head), the kernel makes ONE pass over the block input x (packed rows [*, ldx]) and
  * returns xbar [B, H, d] = sum_j softmax_j(qk.x_j / sqrt(d / H)) x_j, to which the caller applies W_v,h (+ b_v,h).  pad_keys != 0: the
- * window's pad keys take part with logit 0 (x = 0).  d in {64, 128, 256, 512}; other widths: RT_ERR_UNSUPPORTED (use the form above). */
+ * window's pad keys take part with logit 0 (x = 0).  prefix_row >= 0 (pad_keys = 0, max_len >= window): rows prefix_row .. + window - 1 of x
+ * are the window's pad rows carried ONCE (the shared pad prefix of rt_mha_varlen_prefix_fwd): a session of n rows sees the first window - n
+ * of them as keys in front of its own; -1: none.  d in {64, 128, 256, 512}; other widths: RT_ERR_UNSUPPORTED (use the form above). */
 int rt_mha_varlen_last_x_fwd(const float* qk, const float* x, int64_t ldx, const int64_t* cu_seqlens, int32_t B, int32_t H, int32_t d,
-                             int32_t max_len, int32_t window, int32_t pad_keys, float* xbar, rt_stream_t stream);
+                             int32_t max_len, int32_t window, int32_t pad_keys, int64_t prefix_row, float* xbar, rt_stream_t stream);
 /* E [d, H d] = the head-expanded copy of a [d, d] projection weight (E[r, h d + c] = W[r, c] if r / (d / H) == h else 0): with it the per-head
  * products around rt_mha_varlen_last_x_fwd are ONE exact-tile rt_gemm each — qk = Q E(W_k) (E as [K = d, N = H d]) and
  * attention output = xbar E(W_v)^T + b_v (E as [N = d, K = H d]). */

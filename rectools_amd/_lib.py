@@ -98,7 +98,7 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_mha_varlen_prefix_bwd_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32]),
     "rt_mha_varlen_prefix_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_u64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_sz, c_vp]),
     "rt_mha_varlen_last_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
-    "rt_mha_varlen_last_x_fwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "rt_mha_varlen_last_x_fwd": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp]),
     "rt_mha_last_x_expand": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp]),
     "rt_sasrec_block_saved_floats": (c_sz, [c_i32, c_i32, c_i32, c_i32, c_i32]),
     "rt_sasrec_block_bwd_scratch_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32]),

@@ -114,6 +114,9 @@ constexpr size_t VARLEN_LDS_LIMIT = 160 * 1024;
 struct LastXArgs {
   const float* qk; const float* x; long long ldx; const long long* cu; float* xbar;
   int B, H, d, window, pads; float scale;
+  long long prefix_row;      // >= 0: the first row of the shared pad prefix (`window` rows: the window's positions as pads, LiGR without
+  //                            key-padding masks — rt_attention_v3.hip `prefix_len`): a session of n rows sees its rows [0, window - n)
+  //                            as keys in front of its own; -1: none
 };
 
 template <int D64, int HG>      // d = 64 D64; HG heads per pass (H % HG == 0)
@@ -135,8 +138,11 @@ __global__ __launch_bounds__(VT) void attn_last_x_kernel(LastXArgs a, int max_n)
     return;
   }
   const float* xb = a.x + row0 * a.ldx;
+  const int n_pre = (a.prefix_row >= 0 && a.window > n) ? a.window - n : 0;      // keys taken from the shared pad prefix, in front of the own rows
+  const float* xpre = a.x + (a.prefix_row >= 0 ? a.prefix_row : 0) * a.ldx;
+  const int nk = n_pre + n;
   const int n_pad = a.window > n ? a.window - n : 0;
-  const bool pads = a.pads != 0 && n_pad > 0;
+  const bool pads = a.pads != 0 && n_pad > 0 && n_pre == 0;
   const int grp = tid >> 4, li = tid & 15;       // phase 1: 16 groups of 16 lanes
   const int c4 = tid % NC4, ph = tid / NC4;      // phase 2
   const int hs = tid % HG;                       // the head whose statistics this thread scans (VT % HG == 0)
@@ -149,10 +155,11 @@ __global__ __launch_bounds__(VT) void attn_last_x_kernel(LastXArgs a, int max_n)
 #pragma unroll
       for (int k = 0; k < D64; ++k)
         qr[h][k] = *reinterpret_cast<const f32x4*>(a.qk + ((long long)b * a.H + h0 + h) * d + 4 * (li + 16 * k));
-    for (int j = grp; j < n; j += 16) {
+    for (int j = grp; j < nk; j += 16) {
+      const float* xrow = j < n_pre ? xpre + (long long)j * a.ldx : xb + (long long)(j - n_pre) * a.ldx;
       f32x4 xr[D64];
 #pragma unroll
-      for (int k = 0; k < D64; ++k) xr[k] = *reinterpret_cast<const f32x4*>(xb + (long long)j * a.ldx + 4 * (li + 16 * k));
+      for (int k = 0; k < D64; ++k) xr[k] = *reinterpret_cast<const f32x4*>(xrow + 4 * (li + 16 * k));
 #pragma unroll
       for (int h = 0; h < HG; ++h) {
         float s = 0.f;
@@ -166,14 +173,14 @@ __global__ __launch_bounds__(VT) void attn_last_x_kernel(LastXArgs a, int max_n)
     __syncthreads();
     // ---- softmax statistics per head: thread tid scans entries tid, tid + VT, ... (all of head tid % HG)
     float mx = pads ? 0.f : -INFINITY;
-    for (int e = tid; e < n * HG; e += VT) mx = fmaxf(mx, prob[e]);
+    for (int e = tid; e < nk * HG; e += VT) mx = fmaxf(mx, prob[e]);
 #pragma unroll
     for (int o = 32; o >= HG; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     if (lane < HG) red[wave * HG + lane] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(red[hs], red[HG + hs]), fmaxf(red[2 * HG + hs], red[3 * HG + hs]));
     float ps = 0.f;
-    for (int e = tid; e < n * HG; e += VT) {
+    for (int e = tid; e < nk * HG; e += VT) {
       const float ex = __expf(prob[e] - mx);
       prob[e] = ex;
       ps += ex;
@@ -187,8 +194,8 @@ __global__ __launch_bounds__(VT) void attn_last_x_kernel(LastXArgs a, int max_n)
 #pragma unroll
     for (int h = 0; h < HG; ++h) acc[h] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (ph < PH)
-      for (int j = ph; j < n; j += PH) {
-        const f32x4 x4 = *reinterpret_cast<const f32x4*>(xb + (long long)j * a.ldx + 4 * c4);
+      for (int j = ph; j < nk; j += PH) {
+        const f32x4 x4 = *reinterpret_cast<const f32x4*>((j < n_pre ? xpre + (long long)j * a.ldx : xb + (long long)(j - n_pre) * a.ldx) + 4 * c4);
 #pragma unroll
         for (int h = 0; h < HG; ++h) acc[h] += x4 * prob[j * HG + h];
       }
@@ -450,16 +457,18 @@ int rt_mha_varlen_last_fwd(const float* q, int64_t ldq, const float* k, int64_t 
 
 // The last query of every session from the block input itself (see attn_last_x_kernel): qk [B, H, d] = W_k,h^T q_h per session and
 // head, x packed rows [*, ldx], xbar [B, H, d] = sum_j softmax_j((qk . x_j) / sqrt(hd)) x_j.  pad_keys != 0: the window's pad keys take
-// part with logit 0 (their x is zero).  d in {64, 128, 256, 512}.
+// part with logit 0 (their x is zero).  prefix_row >= 0 (with pad_keys = 0): the batch carries the window's pad rows once, from that row on —
+// a session of n rows sees rows [0, window - n) of them as keys in front of its own (LiGR without key-padding masks).  d in {64, 128, 256, 512}.
 int rt_mha_varlen_last_x_fwd(const float* qk, const float* x, int64_t ldx, const int64_t* cu_seqlens, int32_t B, int32_t H, int32_t d,
-                             int32_t max_len, int32_t window, int32_t pad_keys, float* xbar, hipStream_t stream) {
+                             int32_t max_len, int32_t window, int32_t pad_keys, int64_t prefix_row, float* xbar, hipStream_t stream) {
   (void)hipGetLastError();
   if (qk == nullptr || x == nullptr || cu_seqlens == nullptr || xbar == nullptr || B < 0 || H <= 0 || d <= 0 || d % H != 0 || (ldx & 3) != 0 ||
-      max_len <= 0)
+      max_len <= 0 || (prefix_row >= 0 && (pad_keys != 0 || max_len < window)))
     return RT_ERR_INVALID_ARG;
   if (d != 64 && d != 128 && d != 256 && d != 512) return RT_ERR_UNSUPPORTED;
   if (B == 0) return RT_OK;
   LastXArgs a{};
+  a.prefix_row = prefix_row;
   a.qk = qk; a.x = x; a.ldx = ldx; a.cu = reinterpret_cast<const long long*>(cu_seqlens); a.xbar = xbar;
   a.B = B; a.H = H; a.d = d; a.window = window; a.pads = pad_keys; a.scale = 1.0f / sqrtf((float)(d / H));
   switch (d) {

@@ -33,7 +33,7 @@ int rt_layernorm_fwd(const float* x, const float* w, const float* b, float eps, 
                      hipStream_t stream);
 size_t rt_layernorm_bwd_workspace_bytes(int32_t M, int32_t d);
 int rt_mha_varlen_last_x_fwd(const float* qk, const float* x, int64_t ldx, const int64_t* cu_seqlens, int32_t B, int32_t H, int32_t d,
-                             int32_t max_len, int32_t window, int32_t pad_keys, float* xbar, hipStream_t stream);
+                             int32_t max_len, int32_t window, int32_t pad_keys, int64_t prefix_row, float* xbar, hipStream_t stream);
 int rt_mha_last_x_expand(const float* W, int32_t d, int32_t H, float* E, hipStream_t stream);
 int rt_layernorm_bwd_rows(const float* dy, const float* x, const float* w, const float* mean, const float* rstd, const float* res,
                           const int64_t* ids, int32_t mask_dy, int32_t mask_dx, int32_t M, int32_t d, float* dx, void* workspace,
@@ -844,7 +844,7 @@ int rt_sasrec_block_packed_infer(const rt_sasrec_block* blk, const float* x, con
       RT_TRY(rt_mha_last_x_expand(b.in_w + (size_t)d * d, d, b.H, Ek, stream));
       RT_TRY(rt_mha_last_x_expand(b.in_w + 2 * (size_t)d * d, d, b.H, Ev, stream));
       RT_TRY(rt_gemm(Q, d, 1, Ek, (int64_t)Hd, 0, qk, (int64_t)Hd, nullptr, nullptr, 0, nullptr, R, (int32_t)Hd, d, 0, 1, nullptr, 0, stream));
-      rc = rt_mha_varlen_last_x_fwd(qk, x, d, b.cu, b.B, b.H, d, b.window, b.window, b.pad_keys ? 1 : 0, xbar, stream);
+      rc = rt_mha_varlen_last_x_fwd(qk, x, d, b.cu, b.B, b.H, d, b.window, b.window, b.pad_keys ? 1 : 0, -1, xbar, stream);
       if (rc == RT_OK)
         rc = rt_gemm(xbar, (int64_t)Hd, 1, Ev, (int64_t)Hd, 1, A, d, b.in_b + 2 * d, nullptr, 0, nullptr, R, d, (int32_t)Hd, 0, 1, nullptr, 0, stream);
     }

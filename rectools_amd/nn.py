@@ -668,6 +668,21 @@ class LiGRLayer(nn.Module):
         f = self.feed_forward(g)
         return ops.gated_residual(seqs, g2.weight, g2.bias, f, p)
 
+    def forward_last_packed(self, seqs, cu, B, window, prefix_row=-1):
+        """Inference over PACKED rows: the block's output at the last row of the B real sessions, [B, d] (cf. `forward_last`).  Only
+        LayerNorm_1 sees every row: the last query's attention needs no key / value rows (`ops.mha_varlen_last_x`; prefix_row >= 0: the
+        shared pad prefix of `LiGRLayers.packed_mode() == "prefix"` starts there), the out-projection, both gates, LayerNorm_2 and the
+        feed-forward run on B rows."""
+        mha, d = self.multi_head_attn, seqs.shape[1]
+        last_rows = cu[1:B + 1] - 1
+        h = self.layer_norm_1(seqs)
+        q = ops.linear(h.index_select(0, last_rows), mha.in_proj_weight[:d], mha.in_proj_bias[:d])
+        a = mha.out_proj(ops.mha_varlen_last_x(q, h, mha.in_proj_weight, mha.in_proj_bias, cu, B, mha.n_heads, window, False, prefix_row))
+        x = seqs.index_select(0, last_rows)
+        x = ops.gate(x, self.gating_linear_1(x), a, 0.0)
+        f = self.feed_forward(self.layer_norm_2(x))
+        return ops.gate(x, self.gating_linear_2(x), f, 0.0)
+
     def forward_last(self, seqs, ids, B, L, causal, keypad):
         """Inference: the block's output at the last position of every session, [B, d] (see PreLNTransformerLayer.forward_last)."""
         h = self.layer_norm_1(seqs)
@@ -745,9 +760,17 @@ class LiGRLayers(TransformerLayersBase):
             raise ValueError("a LiGR stack without key-padding masks packs only behind a shared pad prefix (packed_mode 'prefix'): n_prefixed")
         on_rows = n_prefixed is not None or self._packed_attention_on_rows(window, causal)
         pad_idx, pad_ids = (None, None) if on_rows else ops.padded_index(cu, B, window, int(seqs.shape[0]))
+        blocks = list(self.transformer_blocks)
+        d, heads = int(seqs.shape[1]), blocks[-1].multi_head_attn.n_heads
+        # the FINAL block on one query row per session (round 6): causal stacks only (the last query then sees exactly its session — and
+        # the pad prefix in front of it), with the row count known on the host when the prefix's first row has to be named
+        last_only = (on_rows and causal and not blocks[-1].generic and ops.mha_varlen_last_x_supported(d, heads)
+                     and (n_prefixed is None or rows_real is not None))
         with ops.active_planes(self._fresh_planes()):
-            for blk in self.transformer_blocks:
+            for blk in (blocks[:-1] if last_only else blocks):
                 seqs = blk.forward_packed(seqs, B, window, causal, pad_idx, pad_ids, None, cu if on_rows else None, n_prefixed)
+            if last_only:
+                return blocks[-1].forward_last_packed(seqs, cu, B, window, -1 if n_prefixed is None else int(rows_real) - window)
         return seqs.index_select(0, cu[1:B + 1] - 1)
 
 

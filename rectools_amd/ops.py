@@ -1937,12 +1937,13 @@ def mha_varlen_last_x_supported(d: int, H: int) -> bool:
 
 
 def mha_varlen_last_x(q_last: torch.Tensor, x_rows: torch.Tensor, in_w: torch.Tensor, in_b: torch.Tensor, cu: torch.Tensor, B: int, H: int,
-                      window: int, pad_keys: bool) -> torch.Tensor:
+                      window: int, pad_keys: bool, prefix_row: int = -1) -> torch.Tensor:
     """Inference: the attention output [B, d] of the LAST query of every packed session WITHOUT projecting keys / values for the rows
     (`rt_mha_varlen_last_x_fwd`, include/rectools_hip.h): q_last [B, d] = the projected queries, x_rows [Np, d] = what the key / value
     projection would read (the block input, or its LayerNorm), in_w / in_b = the packed in_proj parameters [3d, d] / [3d].
     q.(W_k x_j + b_k) = (W_k^T q).x_j + const and sum_j p_j (W_v x_j + b_v) = W_v (sum_j p_j x_j) + b_v: two [B, .] products over
-    head-expanded weights around one pass over x_rows."""
+    head-expanded weights around one pass over x_rows.  prefix_row >= 0: the shared pad prefix starts at that row of x_rows
+    (`LiGRLayers.packed_mode() == "prefix"`)."""
     d = int(x_rows.shape[1])
     dev = x_rows.device
     new = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)  # noqa: E731
@@ -1951,7 +1952,7 @@ def mha_varlen_last_x(q_last: torch.Tensor, x_rows: torch.Tensor, in_w: torch.Te
     _c("rt_mha_last_x_expand", in_w[2 * d:], d, H, Ev)
     qk, xbar, A = new(B, H * d), new(B, H * d), new(B, d)
     _gemm(q_last, int(q_last.stride(0)), 1, Ek, H * d, 0, qk, H * d, None, None, 0, B, H * d, d)
-    _c("rt_mha_varlen_last_x_fwd", qk, x_rows, int(x_rows.stride(0)), cu, B, H, d, window, window, 1 if pad_keys else 0, xbar)
+    _c("rt_mha_varlen_last_x_fwd", qk, x_rows, int(x_rows.stride(0)), cu, B, H, d, window, window, 1 if pad_keys else 0, int(prefix_row), xbar)
     _gemm(xbar, H * d, 1, Ev, H * d, 1, A, d, in_b[2 * d:], None, 0, B, d, H * d)
     return A
 

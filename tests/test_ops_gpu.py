@@ -690,7 +690,7 @@ def test_last_query_without_key_value_rows(d, H, window, pad_keys):
     # the projection-free form
     qk = torch.einsum("bhe,hed->bhd", q.view(B, H, hd), Wk.view(H, hd, d)).contiguous()
     xbar = torch.empty(B, H, d, device="cuda")
-    ops._c("rt_mha_varlen_last_x_fwd", qk, x, d, cud, B, H, d, window, window, int(pad_keys), xbar)
+    ops._c("rt_mha_varlen_last_x_fwd", qk, x, d, cud, B, H, d, window, window, int(pad_keys), -1, xbar)
     got = torch.einsum("bhd,hed->bhe", xbar, Wv.view(H, hd, d)).reshape(B, d) + bv
     close(got, want, rtol=2e-4, atol_rel=2e-5, msg="last query, projection-free")
     # fp64 restatement of the reference's own formula for one session (nn.MultiheadAttention on the left-padded window)

@@ -541,3 +541,39 @@ def test_default_esasrec_packs_behind_a_shared_pad_prefix(monkeypatch):
     slow = m.recommend(users=users, dataset=ds, k=7, filter_viewed=True)
     assert fast[["user_id", "item_id", "rank"]].equals(slow[["user_id", "item_id", "rank"]])
     np.testing.assert_allclose(fast["score"].values, slow["score"].values, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("mode", ["rows", "prefix"])
+def test_final_ligr_block_on_one_query_row_per_session(mode):
+    """`LiGRLayers.forward_last_packed`: the final block with LayerNorm_1 as its only pass over all rows (the last query's attention through
+    `rt_mha_varlen_last_x_fwd` — in "prefix" mode with the shared pad prefix's rows as keys in front of the session's own) == every block on
+    every row, last rows taken (what it was until round 6)."""
+    from rectools_amd import nn as hnn
+    from rectools_amd import ops
+
+    torch.manual_seed(4)
+    d, H, L, B = 128, 2, 40, 19
+    layers = hnn.LiGRLayers(2, d, H, 0.0).cuda().eval()
+    for prm in layers.parameters():
+        if prm.dim() == 1:
+            torch.nn.init.normal_(prm, std=0.3)
+    rng = np.random.default_rng(1)
+    lens = rng.integers(1, L + 1, B); lens[0], lens[1] = L, 1
+    n = int(lens.sum())
+    prefix = mode == "prefix"
+    cu_h = np.r_[0, np.cumsum(lens)]
+    if prefix:
+        cu_h = np.r_[cu_h, cu_h[-1] + L]
+    cu = torch.tensor(cu_h, dtype=torch.int64).cuda()
+    rows_real = n + (L if prefix else 0)
+    Np = (rows_real + 127) // 128 * 128
+    x = torch.randn(Np, d, device="cuda") * 0.5
+    kw = {"n_prefixed": B} if prefix else {}
+    with torch.no_grad():
+        got = layers.forward_last_packed(x, cu, B, L, not prefix, rows_real=rows_real, causal=True, **kw)
+        with ops.active_planes(layers._fresh_planes()):       # the all-rows form
+            seqs = x
+            for blk in layers.transformer_blocks:
+                seqs = blk.forward_packed(seqs, B, L, True, None, None, None, cu, B if prefix else None)
+        want = seqs.index_select(0, cu[1:B + 1] - 1)
+    torch.testing.assert_close(got, want, rtol=2e-4, atol=2e-5 * float(want.abs().max()))
