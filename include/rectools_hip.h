@@ -506,8 +506,9 @@ int rt_mha_last_x_expand(const float* W, int32_t d, int32_t H, float* E, rt_stre
  *           library-owned side stream when use_side != 0: call rt_side_join(stream) before reading `grads`; x, saved, g_out,
  *           scratch (rt_sasrec_block_bwd_scratch_bytes) and grads must stay alive until then.
  *   _infer: eval mode; last_rows == NULL: out [rows,d]; last_rows [B]: the output at those rows only, out [B,d] (what
- *           recommend() keeps, lightning.py:393-397); scratch: rt_sasrec_block_infer_scratch_floats floats.  kv_in (nullable, with
- *           last_rows == NULL): the block's keys | values [rows, 2d] handed in — the FIRST block of recommend() reads embedding row +
+ *           recommend() keeps, lightning.py:393-397); scratch: rt_sasrec_block_infer_scratch_floats floats.  q_in / Q_in / kv_in
+ *           (nullable, with last_rows == NULL; q_in and Q_in come together and need kv_in: x may then be NULL): LN1(x) [rows, d], the
+ *           projected queries [rows, d] and the block's keys | values [rows, 2d] handed in (rt_embed_block1_fwd) — the FIRST block of recommend() reads embedding row +
  *           positional row, so W_kv (e + p) + b_kv = (W_kv e) + (W_kv p + b_kv) is a gather from two projected tables
  *           (rt_embed_packed_fwd over them) and only the query projection runs over the rows.  With last_rows the final block needs no
  *           key / value rows at all (rt_mha_varlen_last_x_fwd).
@@ -532,8 +533,15 @@ int rt_sasrec_block_packed_fwd(const rt_sasrec_block* blk, const float* x, float
 int rt_sasrec_block_packed_bwd(const rt_sasrec_block* blk, const float* x, const float* saved, const float* g_out, float* g_x, float* grads,
                                void* scratch, size_t scratch_bytes, int32_t wgrad_splits, int32_t use_side, rt_stream_t stream);
 size_t rt_sasrec_block_infer_scratch_floats(int32_t rows, int32_t B, int32_t d, int32_t dff, int32_t last_only);
-int rt_sasrec_block_packed_infer(const rt_sasrec_block* blk, const float* x, const float* kv_in, const int64_t* last_rows, float* scratch,
-                                 float* out, rt_stream_t stream);
+int rt_sasrec_block_packed_infer(const rt_sasrec_block* blk, const float* x, const float* q_in, const float* Q_in, const float* kv_in,
+                                 const int64_t* last_rows, float* scratch, float* out, rt_stream_t stream);
+/* The first block's inputs for that call, made WITHOUT a product over the rows: x = scale E[id] + P[dist] in registers -> LayerNorm statistics
+ * -> q = LN1(x), Q = rstd (scale QE[id] + QP[dist] - mean wg) + wb, K | V = scale KVE[id] + KVP[dist], with the projected tables
+ * QE = (E diag(g)) W_q^T, QP = (P diag(g)) W_q^T, wg = W_q g, wb = W_q beta + b_q, KVE = E W_kv^T, KVP = P W_kv^T + b_kv made once per
+ * recommend() call (g / beta: LN1's weight / bias; sasrec.py:221-224 + net_blocks.py:388-399). */
+int rt_embed_block1_fwd(const int64_t* ids, const int64_t* dist, const float* E, const float* P, float scale, const float* ln_w, const float* ln_b,
+                        float eps, const float* QE, const float* QP, const float* wg, const float* wb, const float* KVE, const float* KVP, int32_t M,
+                        int32_t d, float* q_out, float* Q_out, float* KV_out, rt_stream_t stream);
 
 /* One packed Pre-LN block (net_blocks.py:223-262, BERT4Rec's stack) under key-padding masks — packed rows have no pad keys:
  *   h = LN1(x); qkv = h Win^T + bin; A = attention(qkv) (causal = 0: every query sees its whole session, rt_mha_varlen_bidir_*);

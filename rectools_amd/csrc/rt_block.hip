@@ -783,10 +783,13 @@ size_t rt_sasrec_block_infer_scratch_floats(int32_t rows, int32_t B, int32_t d, 
   const size_t kv = M * 2 * d, qx = last_only ? 2 * (R + d) * (size_t)(d / 32) * d : 0;      // (+ the two head-expanded weights)
   return (last_only ? al(R * d) : 0) /* x_last */ + al(R * d) * 5 /* q Q A y f */ + al(kv > qx ? kv : qx) /* KV */ + al(R * dff) /* h */ + 2 * al(R);
 }
-int rt_sasrec_block_packed_infer(const rt_sasrec_block* blk, const float* x, const float* kv_in, const int64_t* last_rows, float* scratch,
-                                 float* out, hipStream_t stream) {
+int rt_sasrec_block_packed_infer(const rt_sasrec_block* blk, const float* x, const float* q_in, const float* Q_in, const float* kv_in,
+                                 const int64_t* last_rows, float* scratch, float* out, hipStream_t stream) {
   (void)hipGetLastError();
-  if (blk == nullptr || x == nullptr || scratch == nullptr || out == nullptr) return RT_ERR_INVALID_ARG;
+  const bool pre = q_in != nullptr && Q_in != nullptr && kv_in != nullptr && last_rows == nullptr;      // LN1(x), Q and K | V handed in: x unused
+  if (blk == nullptr || (x == nullptr && !pre) || scratch == nullptr || out == nullptr || (q_in != nullptr) != (Q_in != nullptr) ||
+      (q_in != nullptr && !pre))
+    return RT_ERR_INVALID_ARG;
   const rt_sasrec_block& b = *blk;
   const int M = b.rows, d = b.d, dff = b.dff, hd = d / b.H;
   const bool last = last_rows != nullptr;
@@ -802,7 +805,8 @@ int rt_sasrec_block_packed_infer(const rt_sasrec_block* blk, const float* x, con
   float* mean = p; p += al((size_t)R); float* rstd = p;
   const float* bk = b.pad_keys ? b.in_b + d : nullptr;
   const float* bv = b.pad_keys ? b.in_b + 2 * d : nullptr;
-  RT_TRY(rt_layernorm_fwd(xin, b.ln1_w, b.ln1_b, b.eps1, R, d, q, mean, rstd, stream));
+  if (pre) { q = const_cast<float*>(q_in); Q = const_cast<float*>(Q_in); }      // (read only from here on)
+  else RT_TRY(rt_layernorm_fwd(xin, b.ln1_w, b.ln1_b, b.eps1, R, d, q, mean, rstd, stream));
   auto lin = [&](const float* A, int lda, const float* W, const uint16_t* Wp, int ldw, float* C, int ldc, const float* bias, const float* R, int ldr,
                  int rows, int N, int K, int relu) -> int {      // one forward product: pre-split planes where the shape allows
     int rc = wp_one(A, lda, Wp, b.wp_stride, ldw, 0, C, ldc, bias, R, ldr, rows, N, K, relu, stream);
@@ -813,7 +817,7 @@ int rt_sasrec_block_packed_infer(const rt_sasrec_block* blk, const float* x, con
     // keys | values handed in ([rows, 2d]: the FIRST block of recommend(), whose input is embedding row + positional row — W_kv (e + p) +
     // b = (W_kv e) + (W_kv p + b): two projected TABLES and a gather, models / nn.TransformerTorchBackbone.encode_last_packed): only the
     // query projection runs over the rows
-    RT_TRY(lin(q, d, b.in_w, b.in_wp, d, Q, d, b.in_b, nullptr, 0, M, d, d, 0));
+    if (!pre) RT_TRY(lin(q, d, b.in_w, b.in_wp, d, Q, d, b.in_b, nullptr, 0, M, d, d, 0));
     { rt_sasrec_block bb = b; RT_TRY(zero_tail(A, bb, d, stream)); }
     RT_TRY(rt_mha_varlen_fwd(Q, d, kv_in, 2 * d, kv_in + d, 2 * d, b.cu, bk, bv, b.B, b.H, hd, b.window, b.window, A, d, stream));
   } else if (!last) {

@@ -657,6 +657,88 @@ int rt_embed_fwd(const int64_t* ids, const float* table, const float* pos, float
   return RT_OK;
 }
 
+}  // extern "C"
+
+// The FIRST block of recommend() without a product over the rows (round 6).  Its input is x = scale E[id] + P[dist]; SASRec projects keys and
+// values from x and queries from LN1(x) (sasrec.py:221-224), all three LINEAR in the two table rows once the row's LayerNorm statistics
+// are known:   K | V = scale (E W_kv^T)[id] + (P W_kv^T + b_kv)[dist]
+//              Q     = rstd (scale (E G W_q^T)[id] + (P G W_q^T)[dist] - mean (W_q g)) + (W_q beta + b_q)      (G = diag(g), g / beta = LN1's)
+// One wave per row: x in registers -> mean / rstd -> q = LN1(x) (the block's skip branch) -> Q and K | V gathered from the PROJECTED tables
+// the caller made once per call.  Replaces the embedding kernel, LayerNorm_1, the query projection and the key / value projection
+// (8 KB read out of the cached tables + 4 KB written per row at d = 256).
+struct EmbedBlock1Args {
+  const long long *ids, *dist; const float *E, *P; float scale;
+  const float *ln_w, *ln_b; float eps;
+  const float *QE, *QP, *wg, *wb, *KVE, *KVP;
+  int M, d; float *q_out, *Q_out, *KV_out;
+};
+template <int NV>      // float4 per lane: d <= 256 NV
+__global__ __launch_bounds__(256) void embed_block1_kernel(EmbedBlock1Args a) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= a.M) return;
+  const int d = a.d;
+  const long long id = a.ids[m], pd = a.dist[m];
+  const float* er = a.E + id * (long long)d;
+  const float* pr = a.P + pd * (long long)d;
+  f32x4 x[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane * 4 + 256 * i;
+    x[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c < d) {
+      x[i] = *reinterpret_cast<const f32x4*>(er + c) * a.scale + *reinterpret_cast<const f32x4*>(pr + c);
+      s += x[i][0] + x[i][1] + x[i][2] + x[i][3];
+    }
+  }
+  const float mu = wave_sum(s) / d;
+  float q2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane * 4 + 256 * i;
+    if (c < d) { const f32x4 v = x[i] - mu; q2 += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]; }
+  }
+  const float rs = 1.0f / sqrtf(wave_sum(q2) / d + a.eps);      // (layernorm_fwd_kernel's own two passes)
+  const float* qe = a.QE + id * (long long)d;
+  const float* qp = a.QP + pd * (long long)d;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane * 4 + 256 * i;
+    if (c < d) {
+      const f32x4 ww = *reinterpret_cast<const f32x4*>(a.ln_w + c), bb = *reinterpret_cast<const f32x4*>(a.ln_b + c);
+      *reinterpret_cast<f32x4*>(a.q_out + (long long)m * d + c) = (x[i] - mu) * rs * ww + bb;
+      const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.wg + c), b4 = *reinterpret_cast<const f32x4*>(a.wb + c);
+      const f32x4 t = *reinterpret_cast<const f32x4*>(qe + c) * a.scale + *reinterpret_cast<const f32x4*>(qp + c) - g4 * mu;
+      *reinterpret_cast<f32x4*>(a.Q_out + (long long)m * d + c) = t * rs + b4;
+    }
+  }
+  const float* ke = a.KVE + id * (long long)(2 * d);
+  const float* kp = a.KVP + pd * (long long)(2 * d);
+  for (int c = lane * 4; c < 2 * d; c += 256)
+    *reinterpret_cast<f32x4*>(a.KV_out + (long long)m * 2 * d + c) = *reinterpret_cast<const f32x4*>(ke + c) * a.scale + *reinterpret_cast<const f32x4*>(kp + c);
+}
+
+extern "C" {
+int rt_embed_block1_fwd(const int64_t* ids, const int64_t* dist, const float* E, const float* P, float scale, const float* ln_w, const float* ln_b,
+                        float eps, const float* QE, const float* QP, const float* wg, const float* wb, const float* KVE, const float* KVP, int32_t M,
+                        int32_t d, float* q_out, float* Q_out, float* KV_out, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (M <= 0) return RT_OK;
+  if (ids == nullptr || dist == nullptr || E == nullptr || P == nullptr || ln_w == nullptr || ln_b == nullptr || QE == nullptr || QP == nullptr ||
+      wg == nullptr || wb == nullptr || KVE == nullptr || KVP == nullptr || q_out == nullptr || Q_out == nullptr || KV_out == nullptr || (d & 3) != 0)
+    return RT_ERR_INVALID_ARG;
+  if (d > 1024) return RT_ERR_UNSUPPORTED;
+  EmbedBlock1Args a{reinterpret_cast<const long long*>(ids), reinterpret_cast<const long long*>(dist), E, P, scale, ln_w, ln_b, eps, QE, QP, wg, wb,
+                    KVE, KVP, M, d, q_out, Q_out, KV_out};
+  const int grid = (M + 3) / 4;
+  if (d <= 256) embed_block1_kernel<1><<<grid, 256, 0, stream>>>(a);
+  else if (d <= 512) embed_block1_kernel<2><<<grid, 256, 0, stream>>>(a);
+  else embed_block1_kernel<4><<<grid, 256, 0, stream>>>(a);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
+}
+
 // Packed rows: as rt_embed_fwd, the positional row of row m is pos[dist[m]] (dist = distance of the row from its
 // session's end, int64 [M]); rows with id 0 (the unused tail up to the GEMM tile) read table row 0 and are ignored downstream.
 int rt_embed_packed_fwd(const int64_t* ids, const int64_t* dist, const float* table, const float* pos, float scale, int32_t M,

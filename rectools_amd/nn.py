@@ -378,9 +378,10 @@ class SASRecTransformerLayer(nn.Module):
         ff = self.feed_forward
         return not self.generic and ff.ff_linear_1.bias is not None and ff.ff_linear_2.bias is not None and ff.activation == "relu"
 
-    def forward_packed(self, seqs, cu, B, window, pad_keys, last_rows=None, rows_real=None, planes=None, kv_in=None):
+    def forward_packed(self, seqs, cu, B, window, pad_keys, last_rows=None, rows_real=None, planes=None, kv_in=None, q_in=None, Q_in=None):
         """Inference over packed sessions (no padding rows; see ops.sasrec_layer_packed): [Np, d], or [B, d] with `last_rows`.
-        kv_in: this block's keys | values [Np, 2d] made by the caller (`SASRecTransformerLayers.forward_last_packed`, first block)."""
+        kv_in (+ q_in, Q_in): this block's keys | values [Np, 2d] (and LN1(x), the projected queries) made by the caller
+        (`SASRecTransformerLayers.forward_last_packed`, first block)."""
         ff, mha = self.feed_forward, self.multi_head_attn
         return ops.sasrec_layer_packed(
             seqs, cu, B, mha.n_heads, window, pad_keys, last_rows,
@@ -388,7 +389,7 @@ class SASRecTransformerLayer(nn.Module):
             (mha.in_proj_weight, mha.in_proj_bias), (mha.out_proj.weight, mha.out_proj.bias),
             (self.ff_layer_norm.weight, self.ff_layer_norm.bias, self.ff_layer_norm.eps),
             (ff.ff_linear_1.weight, ff.ff_linear_1.bias), (ff.ff_linear_2.weight, ff.ff_linear_2.bias), rows_real=rows_real, planes=planes,
-            kv_in=kv_in)
+            kv_in=kv_in, q_in=q_in, Q_in=Q_in)
 
     def forward_packed_train(self, seqs, cu, B, window, pad_keys, rows_real=None, planes=None):
         """The block on packed rows with autograd (training): ONE autograd node (`ops.sasrec_layer_packed_train`) when the feed-forward
@@ -472,19 +473,22 @@ class SASRecTransformerLayers(TransformerLayersBase):
 
     accepts_first_kv = True      # (`TransformerTorchBackbone.encode_last_packed` asks before it builds the projected tables)
 
-    def forward_last_packed(self, seqs, cu, B, window, keypad, rows_real=None, causal=True, first_kv=None):
+    def forward_last_packed(self, seqs, cu, B, window, keypad, rows_real=None, causal=True, first_kv=None, first_pre=None):
         """[B, d] encodings of the last position from PACKED rows: every block input is the real rows only — the
         reference masks pad rows to zero before each block (sasrec.py:300) and their only trace, the pad keys a causal block
         without key-padding masks shows to every query, is the virtual key of `rt_mha_varlen_*`.  first_kv(in_proj_weight,
         in_proj_bias) -> [Np, 2d]: the FIRST block's keys | values made from projected tables (its input is embedding row +
-        positional row, the key / value projection is linear: sasrec.py:221-224 reads the raw block input)."""
+        positional row, the key / value projection is linear: sasrec.py:221-224 reads the raw block input).  first_pre(block) ->
+        (LN1(x), Q, K | V): all three of the first block's inputs from projected tables (`rt_embed_block1_fwd`); `seqs` is not read then."""
         blocks = list(self.transformer_blocks)
         planes = self._fresh_planes() if rows_real is not None else None
         for i, blk in enumerate(blocks[:-1]):
-            kv_in = None
-            if i == 0 and first_kv is not None:
+            kv_in = q_in = Q_in = None
+            if i == 0 and first_pre is not None:
+                q_in, Q_in, kv_in = first_pre(blk)
+            elif i == 0 and first_kv is not None:
                 kv_in = first_kv(blk.multi_head_attn.in_proj_weight, blk.multi_head_attn.in_proj_bias)
-            seqs = blk.forward_packed(seqs, cu, B, window, not keypad, rows_real=rows_real, planes=planes, kv_in=kv_in)
+            seqs = blk.forward_packed(seqs, cu, B, window, not keypad, rows_real=rows_real, planes=planes, kv_in=kv_in, q_in=q_in, Q_in=Q_in)
         last = blocks[-1].forward_packed(seqs, cu, B, window, not keypad, last_rows=cu[1:] - 1, rows_real=rows_real, planes=planes)
         return self.last_layernorm(last)
 
@@ -1207,8 +1211,8 @@ class TransformerTorchBackbone(nn.Module):
         pos = self.pos_encoding_layer.pos_emb.weight if self.pos_encoding_layer.pos_emb is not None else None
         scale = self._pos_scale(table)
         x = torch.empty((Np, d), dtype=torch.float32, device=table.device)
-        ops._c("rt_embed_packed_fwd", ids, dist, table, pos, float(scale), Np, d, 0.0, 0, 0, x)
         kw = {}
+        skip_embed = False
         if ts_store is not None:     # a stack with a relative time bias (HSTU): the sessions' timestamps + the request's, packed
             kw["ts"] = ops.collate_packed_ts(offsets, ts_store, rows, cu, n_rows, ctx=ts_ctx)
         if prefix:
@@ -1217,19 +1221,32 @@ class TransformerTorchBackbone(nn.Module):
         layers = self.transformer_layers
         if (cache is not None and getattr(layers, "accepts_first_kv", False) and mask_id is None and not prefix and pos is not None
                 and len(getattr(layers, "transformer_blocks", ())) > 1 and ("kv_tables" in cache or Np >= int(table.shape[0]))):
-            # The first block's keys | values without a product over the rows: x = scale * E[id] + P[dist] and the projection is linear, so
-            # K | V = scale * (E W_kv^T)[id] + (P W_kv^T + b_kv)[dist] — two small products ONCE per recommend() call, then the embedding
-            # gather itself over the projected tables (2 KB per row written instead of a [rows, d] x [d, 2d] product: two thirds of the block's
-            # largest launch).  Worth it when the call's rows outnumber the catalog (a whole-catalog request: 15.6 M rows, 26,744 items).
-            def first_kv(in_w: torch.Tensor, in_b: torch.Tensor) -> torch.Tensor:
+            # The first block's inputs without a product over the rows: x = scale * E[id] + P[dist], the key / value projection is linear in
+            # it and the query projection of LN1(x) is linear in it once the row's mean / rstd are known — K | V = scale * (E W_kv^T)[id] +
+            # (P W_kv^T + b_kv)[dist], Q = rstd * (scale * (E G W_q^T)[id] + (P G W_q^T)[dist] - mean * W_q g) + (W_q beta + b_q): six small
+            # products ONCE per recommend() call, then ONE gather kernel (`rt_embed_block1_fwd`) instead of the embedding kernel, LayerNorm_1
+            # and the block's [rows, d] x [d, 3d] projection.  Worth it when the call's rows outnumber the catalog (a whole-catalog request:
+            # 15.6 M rows, 26,744 items).
+            def first_pre(blk: nn.Module) -> tp.Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+                mha, ln = blk.multi_head_attn, blk.q_layer_norm
+                in_w, in_b = mha.in_proj_weight, mha.in_proj_bias
                 tabs = cache.get("kv_tables")
-                if tabs is None:
-                    tabs = cache["kv_tables"] = (ops.linear(table.contiguous(), in_w[d:], None), ops.linear(pos.contiguous(), in_w[d:], in_b[d:]))
+                if tabs is None:      # once per recommend() call: six small products over the catalog and the positions
+                    g = ln.weight
+                    tabs = cache["kv_tables"] = (
+                        ops.linear((table * g).contiguous(), in_w[:d], None), ops.linear((pos * g).contiguous(), in_w[:d], None),
+                        torch.mv(in_w[:d], g).contiguous(), (torch.mv(in_w[:d], ln.bias) + in_b[:d]).contiguous(),
+                        ops.linear(table.contiguous(), in_w[d:], None), ops.linear(pos.contiguous(), in_w[d:], in_b[d:]))
+                qn, Q = x, torch.empty((Np, d), dtype=torch.float32, device=table.device)      # (x's buffer takes LN1(x): x itself is never written)
                 kv = torch.empty((Np, 2 * d), dtype=torch.float32, device=table.device)
-                ops._c("rt_embed_packed_fwd", ids, dist, tabs[0], tabs[1], float(scale), Np, 2 * d, 0.0, 0, 0, kv)
-                return kv
+                ops._c("rt_embed_block1_fwd", ids, dist, table, pos, float(scale), ln.weight, ln.bias, float(ln.eps), tabs[0], tabs[1], tabs[2], tabs[3],
+                       tabs[4], tabs[5], Np, d, qn, Q, kv)
+                return qn, Q, kv
 
-            kw["first_kv"] = first_kv
+            kw["first_pre"] = first_pre
+            skip_embed = True
+        if not skip_embed:
+            ops._c("rt_embed_packed_fwd", ids, dist, table, pos, float(scale), Np, d, 0.0, 0, 0, x)
         return layers.forward_last_packed(x, cu, B, window, self.use_key_padding_mask, rows_real=n_rows, causal=self.use_causal_attn, **kw)
 
     def encode_packed_train(self, ids: torch.Tensor, dist: torch.Tensor, cu: torch.Tensor, B: int, window: int,

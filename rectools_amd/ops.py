@@ -1863,14 +1863,16 @@ def sasrec_layer_packed(x: torch.Tensor, cu: torch.Tensor, B: int, H: int, windo
                         out_proj: tp.Tuple[torch.Tensor, torch.Tensor], ln2: tp.Tuple[torch.Tensor, torch.Tensor, float],
                         ff1: tp.Tuple[torch.Tensor, torch.Tensor], ff2: tp.Tuple[torch.Tensor, torch.Tensor],
                         rows_real: tp.Optional[int] = None, planes: tp.Optional[WeightPlanes] = None,
-                        kv_in: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
+                        kv_in: tp.Optional[torch.Tensor] = None, q_in: tp.Optional[torch.Tensor] = None,
+                        Q_in: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
     """Inference only: one causal SASRec block (sasrec.py:186-231) over PACKED sessions — `x` [Np, d] holds the real positions
     only (session b = rows cu[b] .. cu[b+1]-1, oldest first; Np = the row count rounded up to the 128-row GEMM tile, tail rows
     arbitrary).  The pad keys the reference's left-padded window shows to every query enter as one virtual key per query
     (`rt_mha_varlen_fwd`; `pad_keys` = the block runs without key-padding masks).  last_rows None: the block's output for
     every row, [Np, d]; last_rows [B] (= cu[1:] - 1): only the last position of every session, [B, d] — no product over all rows is
     left then (`mha_varlen_last_x`).  kv_in [Np, 2d] (with last_rows None): the block's keys | values handed in (the first block of
-    recommend(): a gather from two projected tables, `nn.TransformerTorchBackbone.encode_last_packed`)."""
+    recommend(): a gather from two projected tables, `nn.TransformerTorchBackbone.encode_last_packed`); q_in / Q_in [Np, d] (with kv_in):
+    LN1(x) and the projected queries handed in as well (`rt_embed_block1_fwd`) — `x` is not read then."""
     x = _chk(x, "sasrec_layer_packed").contiguous()
     Np, d = x.shape
     dev = x.device
@@ -1887,18 +1889,24 @@ def sasrec_layer_packed(x: torch.Tensor, cu: torch.Tensor, B: int, H: int, windo
         last = last_rows is not None
         scratch = new(lib.rt_sasrec_block_infer_scratch_floats(Np, B, d, dff, 1 if last else 0))
         out = new(B if last else Np, d)
-        _c("rt_sasrec_block_packed_infer", ctypes.addressof(blk), x, kv_in if not last else None, last_rows, scratch, out)
+        pre = not last and kv_in is not None and q_in is not None and Q_in is not None
+        _c("rt_sasrec_block_packed_infer", ctypes.addressof(blk), x, q_in if pre else None, Q_in if pre else None,
+           kv_in if not last else None, last_rows, scratch, out)
         return out
     bk = in_b[d:2 * d] if pad_keys else None
     bv = in_b[2 * d:] if pad_keys else None
     mean, rstd = new(Np), new(Np)
     if last_rows is None:
-        q = new(Np, d)
-        _c("rt_layernorm_fwd", x, ln1[0], ln1[1], float(ln1[2]), Np, d, q, mean, rstd)
-        if kv_in is not None:
+        if kv_in is not None and q_in is not None and Q_in is not None:
+            q, Q, KV = q_in, Q_in, kv_in
+        elif kv_in is not None:
+            q = new(Np, d)
+            _c("rt_layernorm_fwd", x, ln1[0], ln1[1], float(ln1[2]), Np, d, q, mean, rstd)
             Q, KV = new(Np, d), kv_in
             _gemm(q, d, 1, in_w, d, 1, Q, d, in_b, None, 0, Np, d, d)
         else:
+            q = new(Np, d)
+            _c("rt_layernorm_fwd", x, ln1[0], ln1[1], float(ln1[2]), Np, d, q, mean, rstd)
             Q, KV = new(Np, d), new(Np, 2 * d)
             _gemm_group([(q, d, in_w, d, Q, d, in_b, None, 0, Np, d, d, 0),
                          (x, d, in_w[d:], d, KV, 2 * d, in_b[d:], None, 0, Np, 2 * d, d, 0)], 1, 1)
