@@ -681,17 +681,31 @@ __global__ __launch_bounds__(256) void embed_block1_kernel(EmbedBlock1Args a) {
   const long long id = a.ids[m], pd = a.dist[m];
   const float* er = a.E + id * (long long)d;
   const float* pr = a.P + pd * (long long)d;
-  f32x4 x[NV];
-  float s = 0.f;
+  const float* qe = a.QE + id * (long long)d;
+  const float* qp = a.QP + pd * (long long)d;
+  const float* ke = a.KVE + id * (long long)(2 * d);
+  const float* kp = a.KVP + pd * (long long)(2 * d);
+  // every table row of this output row is requested before anything is reduced: 8 loads of 16 bytes in flight per lane at d = 256
+  f32x4 x[NV], tq[NV], tk[2 * NV];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane * 4 + 256 * i;
-    x[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    x[i] = tq[i] = zero4;
     if (c < d) {
       x[i] = *reinterpret_cast<const f32x4*>(er + c) * a.scale + *reinterpret_cast<const f32x4*>(pr + c);
-      s += x[i][0] + x[i][1] + x[i][2] + x[i][3];
+      tq[i] = *reinterpret_cast<const f32x4*>(qe + c) * a.scale + *reinterpret_cast<const f32x4*>(qp + c);
     }
   }
+#pragma unroll
+  for (int i = 0; i < 2 * NV; ++i) {
+    const int c = lane * 4 + 256 * i;
+    tk[i] = zero4;
+    if (c < 2 * d) tk[i] = *reinterpret_cast<const f32x4*>(ke + c) * a.scale + *reinterpret_cast<const f32x4*>(kp + c);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += x[i][0] + x[i][1] + x[i][2] + x[i][3];      // (columns behind d hold zeros)
   const float mu = wave_sum(s) / d;
   float q2 = 0.f;
 #pragma unroll
@@ -700,8 +714,11 @@ __global__ __launch_bounds__(256) void embed_block1_kernel(EmbedBlock1Args a) {
     if (c < d) { const f32x4 v = x[i] - mu; q2 += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]; }
   }
   const float rs = 1.0f / sqrtf(wave_sum(q2) / d + a.eps);      // (layernorm_fwd_kernel's own two passes)
-  const float* qe = a.QE + id * (long long)d;
-  const float* qp = a.QP + pd * (long long)d;
+#pragma unroll
+  for (int i = 0; i < 2 * NV; ++i) {
+    const int c = lane * 4 + 256 * i;
+    if (c < 2 * d) *reinterpret_cast<f32x4*>(a.KV_out + (long long)m * 2 * d + c) = tk[i];
+  }
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane * 4 + 256 * i;
@@ -709,14 +726,9 @@ __global__ __launch_bounds__(256) void embed_block1_kernel(EmbedBlock1Args a) {
       const f32x4 ww = *reinterpret_cast<const f32x4*>(a.ln_w + c), bb = *reinterpret_cast<const f32x4*>(a.ln_b + c);
       *reinterpret_cast<f32x4*>(a.q_out + (long long)m * d + c) = (x[i] - mu) * rs * ww + bb;
       const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.wg + c), b4 = *reinterpret_cast<const f32x4*>(a.wb + c);
-      const f32x4 t = *reinterpret_cast<const f32x4*>(qe + c) * a.scale + *reinterpret_cast<const f32x4*>(qp + c) - g4 * mu;
-      *reinterpret_cast<f32x4*>(a.Q_out + (long long)m * d + c) = t * rs + b4;
+      *reinterpret_cast<f32x4*>(a.Q_out + (long long)m * d + c) = (tq[i] - g4 * mu) * rs + b4;
     }
   }
-  const float* ke = a.KVE + id * (long long)(2 * d);
-  const float* kp = a.KVP + pd * (long long)(2 * d);
-  for (int c = lane * 4; c < 2 * d; c += 256)
-    *reinterpret_cast<f32x4*>(a.KV_out + (long long)m * 2 * d + c) = *reinterpret_cast<const f32x4*>(ke + c) * a.scale + *reinterpret_cast<const f32x4*>(kp + c);
 }
 
 extern "C" {
