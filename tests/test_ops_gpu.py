@@ -707,6 +707,38 @@ def test_last_query_without_key_value_rows(d, H, window, pad_keys):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("d,V,L", [(256, 500, 200), (64, 90, 16), (512, 300, 50)])
+def test_first_block_inputs_from_projected_tables(d, V, L):
+    """rt_embed_block1_fwd: LN1(x), Q = W_q LN1(x) + b_q and K | V = W_kv x + b_kv of x = scale E[id] + P[dist] gathered from tables projected
+    once (Q = rstd (scale QE[id] + QP[dist] - mean W_q g) + W_q beta + b_q) == the embedding, LayerNorm and Linear ops on the rows."""
+    from rectools_amd import ops
+
+    M, scale, eps = 777, 1.7, 1e-8
+    g0 = torch.Generator().manual_seed(d)
+    E, P = (rnd(V, d, seed=1) * 0.5).cuda(), (rnd(L, d, seed=2) * 0.5).cuda()
+    E[0] = 0
+    ids = torch.randint(0, V, (M,), generator=g0).cuda()
+    dist = torch.randint(0, L, (M,), generator=g0).cuda()
+    g, beta = (1 + 0.2 * rnd(d, seed=3)).cuda(), (0.1 * rnd(d, seed=4)).cuda()
+    in_w, in_b = (rnd(3 * d, d, seed=5) * 0.1).cuda(), (rnd(3 * d, seed=6) * 0.2).cuda()
+    # the rows' own ops
+    x = E[ids] * scale + P[dist]
+    q_ref = F.layer_norm(x, (d,), g, beta, eps)
+    Q_ref = q_ref @ in_w[:d].T + in_b[:d]
+    KV_ref = x @ in_w[d:].T + in_b[d:]
+    # the projected tables (what nn.TransformerTorchBackbone.encode_last_packed builds once per recommend() call)
+    QE, QP = (E * g) @ in_w[:d].T, (P * g) @ in_w[:d].T
+    wg, wb = in_w[:d] @ g, in_w[:d] @ beta + in_b[:d]
+    KVE, KVP = E @ in_w[d:].T, P @ in_w[d:].T + in_b[d:]
+    q, Q, KV = torch.empty(M, d, device="cuda"), torch.empty(M, d, device="cuda"), torch.empty(M, 2 * d, device="cuda")
+    ops._c("rt_embed_block1_fwd", ids, dist, E, P, scale, g, beta, eps, QE.contiguous(), QP.contiguous(), wg.contiguous(), wb.contiguous(),
+           KVE.contiguous(), KVP.contiguous(), M, d, q, Q, KV)
+    close(q, q_ref, rtol=2e-4, atol_rel=2e-5, msg="LN1(x)")
+    close(Q, Q_ref, rtol=2e-4, atol_rel=2e-5, msg="queries")
+    close(KV, KV_ref, rtol=2e-4, atol_rel=2e-5, msg="keys | values")
+
+
+@pytest.mark.gpu
 def test_mul_mask_ld_strided_slices():
     from rectools_amd import ops
 
