@@ -542,6 +542,12 @@ int rt_sasrec_block_packed_infer(const rt_sasrec_block* blk, const float* x, con
 int rt_embed_block1_fwd(const int64_t* ids, const int64_t* dist, const float* E, const float* P, float scale, const float* ln_w, const float* ln_b,
                         float eps, const float* QE, const float* QP, const float* wg, const float* wb, const float* KVE, const float* KVP, int32_t M,
                         int32_t d, float* q_out, float* Q_out, float* KV_out, rt_stream_t stream);
+/* ... for a Pre-LN / LiGR first block (net_blocks.py:236-262, ligr.py:161-191: q, k AND v read LN1(x), the skip branch reads x): x [M, d]
+ * and qkv [M, 3d] = rstd (scale QKVE[id] + QKVP[dist] - mean wg) + wb with QKVE = (E diag(g)) W^T [V, 3d], QKVP = (P diag(g)) W^T [L, 3d],
+ * wg = W g, wb = W beta + b over the packed in_proj parameters W [3d, d], b [3d].  d <= 512. */
+int rt_embed_block1_preln_fwd(const int64_t* ids, const int64_t* dist, const float* E, const float* P, float scale, float eps, const float* QKVE,
+                              const float* QKVP, const float* wg, const float* wb, int32_t M, int32_t d, float* x_out, float* qkv_out,
+                              rt_stream_t stream);
 
 /* One packed Pre-LN block (net_blocks.py:223-262, BERT4Rec's stack) under key-padding masks — packed rows have no pad keys:
  *   h = LN1(x); qkv = h Win^T + bin; A = attention(qkv) (causal = 0: every query sees its whole session, rt_mha_varlen_bidir_*);

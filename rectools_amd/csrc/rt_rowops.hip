@@ -669,10 +669,12 @@ int rt_embed_fwd(const int64_t* ids, const float* table, const float* pos, float
 struct EmbedBlock1Args {
   const long long *ids, *dist; const float *E, *P; float scale;
   const float *ln_w, *ln_b; float eps;
-  const float *QE, *QP, *wg, *wb, *KVE, *KVP;
-  int M, d; float *q_out, *Q_out, *KV_out;
+  const float *QE, *QP, *wg, *wb, *KVE, *KVP;      // affine tables [V | L, AFF d], [AFF d] x 2; plain tables [V | L, PLN d]
+  int M, d; float *q_out, *Q_out, *KV_out, *x_out;  // LN1(x) [M, d] (nullable), affine [M, AFF d], plain [M, PLN d], x [M, d] (nullable)
 };
-template <int NV>      // float4 per lane: d <= 256 NV
+// AFF / PLN: widths of the affine (read LN1(x)) and the plain (read x) projections in units of d — SASRec: Q affine, K | V plain (1, 2);
+// Pre-LN / LiGR blocks: Q | K | V all read LN1(x) (3, 0) and the skip branch wants x itself (x_out).
+template <int NV, int AFF, int PLN>      // NV float4 per lane: d <= 256 NV
 __global__ __launch_bounds__(256) void embed_block1_kernel(EmbedBlock1Args a) {
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -681,27 +683,32 @@ __global__ __launch_bounds__(256) void embed_block1_kernel(EmbedBlock1Args a) {
   const long long id = a.ids[m], pd = a.dist[m];
   const float* er = a.E + id * (long long)d;
   const float* pr = a.P + pd * (long long)d;
-  const float* qe = a.QE + id * (long long)d;
-  const float* qp = a.QP + pd * (long long)d;
-  const float* ke = a.KVE + id * (long long)(2 * d);
-  const float* kp = a.KVP + pd * (long long)(2 * d);
+  const float* qe = a.QE + id * (long long)(AFF * d);
+  const float* qp = a.QP + pd * (long long)(AFF * d);
   // every table row of this output row is requested before anything is reduced: 8 loads of 16 bytes in flight per lane at d = 256
-  f32x4 x[NV], tq[NV], tk[2 * NV];
+  f32x4 x[NV], tq[AFF * NV], tk[PLN * NV > 0 ? PLN * NV : 1];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane * 4 + 256 * i;
-    x[i] = tq[i] = zero4;
-    if (c < d) {
-      x[i] = *reinterpret_cast<const f32x4*>(er + c) * a.scale + *reinterpret_cast<const f32x4*>(pr + c);
-      tq[i] = *reinterpret_cast<const f32x4*>(qe + c) * a.scale + *reinterpret_cast<const f32x4*>(qp + c);
-    }
+    x[i] = zero4;
+    if (c < d) x[i] = *reinterpret_cast<const f32x4*>(er + c) * a.scale + *reinterpret_cast<const f32x4*>(pr + c);
   }
 #pragma unroll
-  for (int i = 0; i < 2 * NV; ++i) {
+  for (int i = 0; i < AFF * NV; ++i) {
     const int c = lane * 4 + 256 * i;
-    tk[i] = zero4;
-    if (c < 2 * d) tk[i] = *reinterpret_cast<const f32x4*>(ke + c) * a.scale + *reinterpret_cast<const f32x4*>(kp + c);
+    tq[i] = zero4;
+    if (c < AFF * d) tq[i] = *reinterpret_cast<const f32x4*>(qe + c) * a.scale + *reinterpret_cast<const f32x4*>(qp + c);
+  }
+  if (PLN > 0) {
+    const float* ke = a.KVE + id * (long long)(PLN * d);
+    const float* kp = a.KVP + pd * (long long)(PLN * d);
+#pragma unroll
+    for (int i = 0; i < PLN * NV; ++i) {
+      const int c = lane * 4 + 256 * i;
+      tk[i] = zero4;
+      if (c < PLN * d) tk[i] = *reinterpret_cast<const f32x4*>(ke + c) * a.scale + *reinterpret_cast<const f32x4*>(kp + c);
+    }
   }
   float s = 0.f;
 #pragma unroll
@@ -714,21 +721,42 @@ __global__ __launch_bounds__(256) void embed_block1_kernel(EmbedBlock1Args a) {
     if (c < d) { const f32x4 v = x[i] - mu; q2 += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]; }
   }
   const float rs = 1.0f / sqrtf(wave_sum(q2) / d + a.eps);      // (layernorm_fwd_kernel's own two passes)
+  if (PLN > 0) {
 #pragma unroll
-  for (int i = 0; i < 2 * NV; ++i) {
-    const int c = lane * 4 + 256 * i;
-    if (c < 2 * d) *reinterpret_cast<f32x4*>(a.KV_out + (long long)m * 2 * d + c) = tk[i];
+    for (int i = 0; i < PLN * NV; ++i) {
+      const int c = lane * 4 + 256 * i;
+      if (c < PLN * d) *reinterpret_cast<f32x4*>(a.KV_out + (long long)m * PLN * d + c) = tk[i];
+    }
   }
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane * 4 + 256 * i;
     if (c < d) {
-      const f32x4 ww = *reinterpret_cast<const f32x4*>(a.ln_w + c), bb = *reinterpret_cast<const f32x4*>(a.ln_b + c);
-      *reinterpret_cast<f32x4*>(a.q_out + (long long)m * d + c) = (x[i] - mu) * rs * ww + bb;
-      const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.wg + c), b4 = *reinterpret_cast<const f32x4*>(a.wb + c);
-      *reinterpret_cast<f32x4*>(a.Q_out + (long long)m * d + c) = (tq[i] - g4 * mu) * rs + b4;
+      if (a.x_out != nullptr) *reinterpret_cast<f32x4*>(a.x_out + (long long)m * d + c) = x[i];
+      if (a.q_out != nullptr) {
+        const f32x4 ww = *reinterpret_cast<const f32x4*>(a.ln_w + c), bb = *reinterpret_cast<const f32x4*>(a.ln_b + c);
+        *reinterpret_cast<f32x4*>(a.q_out + (long long)m * d + c) = (x[i] - mu) * rs * ww + bb;
+      }
     }
   }
+#pragma unroll
+  for (int i = 0; i < AFF * NV; ++i) {
+    const int c = lane * 4 + 256 * i;
+    if (c < AFF * d) {
+      const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.wg + c), b4 = *reinterpret_cast<const f32x4*>(a.wb + c);
+      *reinterpret_cast<f32x4*>(a.Q_out + (long long)m * AFF * d + c) = (tq[i] - g4 * mu) * rs + b4;
+    }
+  }
+}
+
+template <int AFF, int PLN>
+int launch_embed_block1(const EmbedBlock1Args& a, hipStream_t stream) {
+  const int grid = (a.M + 3) / 4;
+  if (a.d <= 256) embed_block1_kernel<1, AFF, PLN><<<grid, 256, 0, stream>>>(a);
+  else if (a.d <= 512) embed_block1_kernel<2, AFF, PLN><<<grid, 256, 0, stream>>>(a);
+  else embed_block1_kernel<4, AFF, PLN><<<grid, 256, 0, stream>>>(a);
+  RT_CHECK_LAUNCH();
+  return RT_OK;
 }
 
 extern "C" {
@@ -742,13 +770,24 @@ int rt_embed_block1_fwd(const int64_t* ids, const int64_t* dist, const float* E,
     return RT_ERR_INVALID_ARG;
   if (d > 1024) return RT_ERR_UNSUPPORTED;
   EmbedBlock1Args a{reinterpret_cast<const long long*>(ids), reinterpret_cast<const long long*>(dist), E, P, scale, ln_w, ln_b, eps, QE, QP, wg, wb,
-                    KVE, KVP, M, d, q_out, Q_out, KV_out};
-  const int grid = (M + 3) / 4;
-  if (d <= 256) embed_block1_kernel<1><<<grid, 256, 0, stream>>>(a);
-  else if (d <= 512) embed_block1_kernel<2><<<grid, 256, 0, stream>>>(a);
-  else embed_block1_kernel<4><<<grid, 256, 0, stream>>>(a);
-  RT_CHECK_LAUNCH();
-  return RT_OK;
+                    KVE, KVP, M, d, q_out, Q_out, KV_out, nullptr};
+  return launch_embed_block1<1, 2>(a, stream);
+}
+// The Pre-LN form (net_blocks.py:236-262, ligr.py:161-191: queries, keys AND values read LN1(x), the skip branch reads x): x [M, d] and
+// qkv [M, 3d] = rstd (scale QKVE[id] + QKVP[dist] - mean W g) + (W beta + b) from the tables QKVE = (E diag(g)) W^T [V, 3d],
+// QKVP = (P diag(g)) W^T [L, 3d], wg = W g, wb = W beta + b (W / b: the packed in_proj parameters).
+int rt_embed_block1_preln_fwd(const int64_t* ids, const int64_t* dist, const float* E, const float* P, float scale, float eps, const float* QKVE,
+                              const float* QKVP, const float* wg, const float* wb, int32_t M, int32_t d, float* x_out, float* qkv_out,
+                              hipStream_t stream) {
+  (void)hipGetLastError();
+  if (M <= 0) return RT_OK;
+  if (ids == nullptr || dist == nullptr || E == nullptr || P == nullptr || QKVE == nullptr || QKVP == nullptr || wg == nullptr || wb == nullptr ||
+      x_out == nullptr || qkv_out == nullptr || (d & 3) != 0)
+    return RT_ERR_INVALID_ARG;
+  if (d > 512) return RT_ERR_UNSUPPORTED;      // (3 d / 256 float4 per lane held in registers)
+  EmbedBlock1Args a{reinterpret_cast<const long long*>(ids), reinterpret_cast<const long long*>(dist), E, P, scale, nullptr, nullptr, eps, QKVE, QKVP,
+                    wg, wb, nullptr, nullptr, M, d, nullptr, qkv_out, nullptr, x_out};
+  return launch_embed_block1<3, 0>(a, stream);
 }
 
 // Packed rows: as rt_embed_fwd, the positional row of row m is pos[dist[m]] (dist = distance of the row from its

@@ -472,6 +472,7 @@ class SASRecTransformerLayers(TransformerLayersBase):
         return self.last_layernorm(seqs)
 
     accepts_first_kv = True      # (`TransformerTorchBackbone.encode_last_packed` asks before it builds the projected tables)
+    accepts_first_pre = "sasrec"
 
     def forward_last_packed(self, seqs, cu, B, window, keypad, rows_real=None, causal=True, first_kv=None, first_pre=None):
         """[B, d] encodings of the last position from PACKED rows: every block input is the real rows only — the
@@ -525,14 +526,18 @@ class PreLNTransformerLayer(nn.Module):
         x1 = self.multi_head_attn.out_proj(a, residual=_take_last(seqs, B, L))
         return self.feed_forward(self.layer_norm_2(x1), residual=x1)
 
-    def forward_packed(self, seqs, cu, B, window, causal, covers_all_rows=False):
+    def forward_packed(self, seqs, cu, B, window, causal, covers_all_rows=False, qkv_in=None):
         """The block over PACKED sessions ([Np, d], real positions only): with key-padding masks the reference's pad positions are
         seen by no real query (net_blocks.py:236-262 under torch_backbone.py:254's mask), so dropping their rows changes nothing for
-        the real ones.  Same ops as `forward`; the attention is `ops.mha_varlen_qkv` on the packed in_proj output."""
+        the real ones.  Same ops as `forward`; the attention is `ops.mha_varlen_qkv` on the packed in_proj output.  qkv_in [Np, 3d]
+        (inference, first block): the in_proj output made by the caller from projected tables (`rt_embed_block1_preln_fwd`)."""
         p = self.p if self.training else 0.0
         ln1, ln2, mha = self.layer_norm_1, self.layer_norm_2, self.multi_head_attn
-        h, skip = ops.layer_norm_skip(seqs, ln1.weight, ln1.bias, ln1.eps)
-        qkv = ops.linear(h, mha.in_proj_weight, mha.in_proj_bias)
+        if qkv_in is not None:
+            skip, qkv = seqs, qkv_in
+        else:
+            h, skip = ops.layer_norm_skip(seqs, ln1.weight, ln1.bias, ln1.eps)
+            qkv = ops.linear(h, mha.in_proj_weight, mha.in_proj_bias)
         a = ops.mha_varlen_qkv(qkv, cu, B, mha.n_heads, window, causal, p, covers_all_rows)
         if p > 0:
             seqs = ops.dropout_add(mha.out_proj(a), skip, p)
@@ -615,10 +620,12 @@ class PreLNTransformerLayers(TransformerLayersBase):
                 seqs = blk.forward_packed(seqs, cu, B, window, causal, covers)
         return seqs
 
-    def forward_last_packed(self, seqs, cu, B, window, keypad, rows_real=None, causal=False):
+    accepts_first_pre = "preln"      # (`TransformerTorchBackbone.encode_last_packed`: x and the first block's in_proj output from projected tables)
+
+    def forward_last_packed(self, seqs, cu, B, window, keypad, rows_real=None, causal=False, first_pre=None):
         blocks = list(self.transformer_blocks)
-        for blk in blocks[:-1]:
-            seqs = blk.forward_packed(seqs, cu, B, window, causal)
+        for i, blk in enumerate(blocks[:-1]):
+            seqs = blk.forward_packed(seqs, cu, B, window, causal, qkv_in=first_pre(blk) if (i == 0 and first_pre is not None) else None)
         return blocks[-1].forward_last_packed(seqs, cu, B, window, causal)
 
 
@@ -647,7 +654,7 @@ class LiGRLayer(nn.Module):
         return ops.gated_residual(seqs, g2.weight, g2.bias, f, p)    # seqs + sigmoid(Wg2 seqs + bg2) * drop(ffn)
 
 
-    def forward_packed(self, seqs, B, window, causal, pad_idx, pad_ids, n_real, cu=None, n_prefixed=None):
+    def forward_packed(self, seqs, B, window, causal, pad_idx, pad_ids, n_real, cu=None, n_prefixed=None, qkv_in=None):
         """The block over PACKED rows ([Np, d]: real positions + the unused tail of the row block) — exact under key-padding masks: no
         real query sees a pad key, and nothing else couples rows (ligr.py:66-106 is LayerNorm, Linear, gates, SwiGLU: row-wise).
         cu given (head size 32 / 64 / 128: the streamed packed kernels, K4v3): the attention runs on the packed in_proj output as it
@@ -657,8 +664,11 @@ class LiGRLayer(nn.Module):
         p = self.p if self.training else 0.0
         ln1, ln2, mha = self.layer_norm_1, self.layer_norm_2, self.multi_head_attn
         g1, g2 = self.gating_linear_1, self.gating_linear_2
-        h, seqs = ops.layer_norm_skip(seqs, ln1.weight, ln1.bias, ln1.eps)
-        qkv = ops.linear(h, mha.in_proj_weight, mha.in_proj_bias)
+        if qkv_in is not None:      # (inference, first block: the in_proj output from projected tables, `rt_embed_block1_preln_fwd`)
+            qkv = qkv_in
+        else:
+            h, seqs = ops.layer_norm_skip(seqs, ln1.weight, ln1.bias, ln1.eps)
+            qkv = ops.linear(h, mha.in_proj_weight, mha.in_proj_bias)
         if cu is not None:      # (n_prefixed: the sessions sit behind the shared pad prefix, `ops.mha_varlen_qkv`)
             a = ops.mha_varlen_qkv(qkv, cu, int(cu.numel()) - 1, mha.n_heads, window, causal, p,
                                    n_real is not None and int(n_real) == int(seqs.shape[0]), n_prefixed=n_prefixed)
@@ -758,7 +768,9 @@ class LiGRLayers(TransformerLayersBase):
                 seqs = blk.forward_packed(seqs, B, window, causal, pad_idx, pad_ids, n_real, cu if on_rows else None, n_prefixed)
         return seqs
 
-    def forward_last_packed(self, seqs, cu, B, window, keypad, rows_real=None, causal=True, n_prefixed=None):
+    accepts_first_pre = "preln"
+
+    def forward_last_packed(self, seqs, cu, B, window, keypad, rows_real=None, causal=True, n_prefixed=None, first_pre=None):
         """Inference over packed rows: all blocks on the packed rows, then the last row of every session (B: the real sessions)."""
         if not keypad and n_prefixed is None:
             raise ValueError("a LiGR stack without key-padding masks packs only behind a shared pad prefix (packed_mode 'prefix'): n_prefixed")
@@ -771,8 +783,9 @@ class LiGRLayers(TransformerLayersBase):
         last_only = (on_rows and causal and not blocks[-1].generic and ops.mha_varlen_last_x_supported(d, heads)
                      and (n_prefixed is None or rows_real is not None))
         with ops.active_planes(self._fresh_planes()):
-            for blk in (blocks[:-1] if last_only else blocks):
-                seqs = blk.forward_packed(seqs, B, window, causal, pad_idx, pad_ids, None, cu if on_rows else None, n_prefixed)
+            for i, blk in enumerate(blocks[:-1] if last_only else blocks):
+                seqs = blk.forward_packed(seqs, B, window, causal, pad_idx, pad_ids, None, cu if on_rows else None, n_prefixed,
+                                          qkv_in=first_pre(blk) if (i == 0 and first_pre is not None and len(blocks) > 1) else None)
             if last_only:
                 return blocks[-1].forward_last_packed(seqs, cu, B, window, -1 if n_prefixed is None else int(rows_real) - window)
         return seqs.index_select(0, cu[1:B + 1] - 1)
@@ -1219,8 +1232,28 @@ class TransformerTorchBackbone(nn.Module):
             kw["n_prefixed"] = B
             n_rows = n_rows + window
         layers = self.transformer_layers
-        if (cache is not None and getattr(layers, "accepts_first_kv", False) and mask_id is None and not prefix and pos is not None
-                and len(getattr(layers, "transformer_blocks", ())) > 1 and ("kv_tables" in cache or Np >= int(table.shape[0]))):
+        kind = getattr(layers, "accepts_first_pre", None)
+        n_blk = len(getattr(layers, "transformer_blocks", ()))
+        if (cache is not None and kind == "preln" and pos is not None and n_blk > 1 and d <= 512 and not getattr(layers.transformer_blocks[0], "generic", False)
+                and ("qkv_tables" in cache or Np >= int(table.shape[0]))):
+            # A Pre-LN / LiGR first block reads LN1(x) for queries, keys AND values: all of its in_proj output is the affine gather
+            # (see the SASRec form below); the skip branch wants x itself, which the same kernel writes.
+            def first_pre_ln(blk: nn.Module) -> torch.Tensor:
+                mha, ln = blk.multi_head_attn, blk.layer_norm_1
+                in_w, in_b = mha.in_proj_weight, mha.in_proj_bias
+                tabs = cache.get("qkv_tables")
+                if tabs is None:
+                    g = ln.weight
+                    tabs = cache["qkv_tables"] = (ops.linear((table * g).contiguous(), in_w, None), ops.linear((pos * g).contiguous(), in_w, None),
+                                                  torch.mv(in_w, g).contiguous(), (torch.mv(in_w, ln.bias) + in_b).contiguous())
+                qkv = torch.empty((Np, 3 * d), dtype=torch.float32, device=table.device)
+                ops._c("rt_embed_block1_preln_fwd", ids, dist, table, pos, float(scale), float(ln.eps), tabs[0], tabs[1], tabs[2], tabs[3], Np, d, x, qkv)
+                return qkv
+
+            kw["first_pre"] = first_pre_ln
+            skip_embed = True
+        if (cache is not None and kind == "sasrec" and mask_id is None and not prefix and pos is not None
+                and n_blk > 1 and ("kv_tables" in cache or Np >= int(table.shape[0]))):
             # The first block's inputs without a product over the rows: x = scale * E[id] + P[dist], the key / value projection is linear in
             # it and the query projection of LN1(x) is linear in it once the row's mean / rstd are known — K | V = scale * (E W_kv^T)[id] +
             # (P W_kv^T + b_kv)[dist], Q = rstd * (scale * (E G W_q^T)[id] + (P G W_q^T)[dist] - mean * W_q g) + (W_q beta + b_q): six small
