@@ -299,6 +299,8 @@ class HipRanker:
         args = (ids_t, scores_t, counts_t, rows_t, n_subj, whitelist_t, n_cand, id_offset, kk, indptr_t, indices_t, hash_t, upp)
         if not settle:      # the caller reads the flags later, for all its calls at once
             self._unsettled.append((unproven, h_only, args))
+            if len(self._unsettled) >= 4096:      # (a caller that never settles must not pin every call's tensors for ever)
+                self.settle()
             return
         self._repair(np.flatnonzero(unproven.cpu().numpy()), h_only, args)
 
