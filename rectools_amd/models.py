@@ -1046,24 +1046,25 @@ class TransformerModelBase:
 
     def _encode_batch_size(self) -> int:
         """Sessions per encoder launch in recommend().  `recommend_batch_size` (reference default 256) is a memory knob of the
-        reference's DataLoader; every row of the encoder is independent of the batch it travels in, so the engine groups at
-        least 4,096 sessions per launch (≈ 0.43 M packed rows, ≈ 5 GB of scratch at d = 256: 634 k -> 654 k users/s against 1,024
-        sessions per launch at C2, visit of round 4; RT_ENCODE_SESSIONS overrides)."""
+        reference's DataLoader; every row of the encoder is independent of the batch it travels in, so the engine groups up to
+        8,192 sessions per launch (≈ 0.9 M packed rows, ≈ 12 GB of scratch at d = 256; round 6, all 138,493 users of C2: encoder 111.0 /
+        110.5 / 104.5 / 105.8 ms at 2,048 / 4,096 / 8,192 / 16,384 sessions per launch — with the final block on one row per session its
+        chain of small launches is paid per encoder launch; RT_ENCODE_SESSIONS overrides)."""
         env = os.environ.get("RT_ENCODE_SESSIONS")
         if env:
             return max(int(env), 1)
         if int(self.recommend_batch_size) != 256:      # set by the caller (the reference's default is 256): its memory knob stands
             return int(self.recommend_batch_size)
-        # the default: up to 4,096 sessions, fewer when the launch's scratch (~24 row-sized fp32 buffers of window x n_factors) would
+        # the default: up to 8,192 sessions, fewer when the launch's scratch (~24 row-sized fp32 buffers of window x n_factors) would
         # take more than a fifth of the free HBM (wide / long-window models, shared GPUs: ADVICE r4); a launch that still runs out of
         # memory is halved and repeated (`_recommend_device_glue`)
-        sessions = 4096
+        sessions = 8192
         if torch.cuda.is_available() and self.lightning_model is not None:
             dev = next(self.lightning_model.parameters()).device
             if dev.type == "cuda":
                 free, _ = torch.cuda.mem_get_info(dev)
                 per_session = 24 * 4 * int(self.session_max_len) * int(self.n_factors)
-                sessions = int(min(4096, max(256, free // 5 // max(per_session, 1))))
+                sessions = int(min(8192, max(256, free // 5 // max(per_session, 1))))
         return max(int(self.recommend_batch_size), sessions)
 
     def _check(self, k: int) -> None:

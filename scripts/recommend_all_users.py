@@ -1,6 +1,6 @@
 """SASRecModel.recommend() for ALL users of the ML-20M-shaped synthetic dataset (138,493 users, 26,744 items) at several
 encoder launch sizes (RT_ENCODE_SESSIONS): median of 5 whole calls each, phases of one instrumented call.
-   python scripts/recommend_all_users.py [sessions per encoder launch ...]"""
+   python scripts/recommend_all_users.py [sessions per encoder launch ... | 0 = the library's default]"""
 import os
 import sys
 import time
@@ -24,7 +24,10 @@ model.is_fitted = True
 users = np.asarray(ds.user_id_map.external_ids)
 model.recommend(users[:2048], ds, k=10, filter_viewed=True)
 for size in sizes:
-    os.environ["RT_ENCODE_SESSIONS"] = str(size)
+    if size > 0:
+        os.environ["RT_ENCODE_SESSIONS"] = str(size)
+    else:
+        os.environ.pop("RT_ENCODE_SESSIONS", None)      # 0: the library's default
     model.recommend(users, ds, k=10, filter_viewed=True)
     times = []
     for _ in range(5):
