@@ -549,6 +549,41 @@ int rt_embed_block1_preln_fwd(const int64_t* ids, const int64_t* dist, const flo
                               const float* QKVP, const float* wg, const float* wb, int32_t M, int32_t d, float* x_out, float* qkv_out,
                               rt_stream_t stream);
 
+/* One packed SASRec TRAINING STEP (lightning.py:311-321 around sasrec.py:271-304, the sampled losses lightning.py:164-212 and
+ * torch.optim.Adam, lightning.py:366-369): rt_embed_packed_fwd -> rt_sasrec_block_packed_fwd x n_blocks -> rt_layernorm_fwd ->
+ * rt_sampled_loss_fwd_train -> rt_loss_reduce -> rt_sampled_loss_bwd (session half on `stream`, table half on the library's side stream)
+ * -> rt_layernorm_bwd_rows / _combine -> rt_sasrec_block_packed_bwd x n_blocks -> rt_embed_packed_bwd (adds into the loss's table
+ * gradient) -> rt_side_join -> rt_adam_step_segments: the entry points above in the order the autograd nodes of rectools_amd/ops.py issue
+ * them, from compiled code (csrc/rt_step.hip).  No allocation: `arena` (rt_sasrec_step_arena_bytes) holds the parameter gradients
+ * (fixed layout) and every activation / workspace of a step of `rows` rows; it may be reused by the next step on the same stream.
+ *   rows: row count of the packed batch (multiple of 128); cu [B + 1]: the sessions' row offsets (the lookup's backward); cu_attn
+ *   [B_attn + 1] / rows_real: what the blocks' attention sees (B_attn = B + 1 and rows_real = rows when the unused tail of the row block
+ *   rides along as one more session, else cu / B / the sessions' row count); blocks [n_blocks]: parameter pointers, planes, eps1 / eps2
+ *   and the dropout streams of this step (geometry fields are filled in by the call); loss: 0 BCE, 1 gBCE, 2 sampled softmax;
+ *   upstream: device scalar d loss (1.0); loss_out: device [2] <- (loss, normaliser); pos may be NULL (pos_rows == window otherwise).
+ *   seg_role [n_seg]: which gradient segment i of the flat parameter buffer reads: 0 table, 1 pos, 2 / 3 the last LayerNorm's weight /
+ *   bias, 16 + 12 b + j = block b's parameter j in rt_sasrec_block_grad_offsets order, -1 none (the segment is skipped).
+ * rt_sasrec_step_run(phase): 1 = forward + loss + backward, 2 = join + Adam, 3 = both. */
+typedef struct rt_sasrec_step {
+  int32_t n_blocks, rows, rows_real, B, B_attn, V, d, dff, H, window, pad_keys, n_neg, loss, cosine, wgrad_splits, pos_rows;
+  float p_emb, p_blk, emb_scale, eps_last, logits_t;
+  double gbce_beta;
+  uint64_t seed_emb, sid_emb;
+  const int64_t *ids, *dist, *y, *neg, *cu, *cu_attn;
+  const float* yw;
+  const float *table, *pos, *lnf_w, *lnf_b;
+  const rt_sasrec_block* blocks;
+  const float* planes_src; int64_t planes_n; uint16_t* planes; int64_t planes_stride;     /* rt_split_planes of the stack's weights, or NULL */
+  const float* upstream;
+  float* loss_out;
+  void* arena; size_t arena_bytes;
+  float *flat_p, *adam_m, *adam_v;
+  int32_t n_seg; const int64_t *seg_offsets, *seg_lens; const int32_t* seg_role;
+  int32_t adam_step; float lr, beta1, beta2, adam_eps;
+} rt_sasrec_step;
+size_t rt_sasrec_step_arena_bytes(const rt_sasrec_step* step);
+int rt_sasrec_step_run(const rt_sasrec_step* step, int32_t phase, rt_stream_t stream);
+
 /* One packed Pre-LN block (net_blocks.py:223-262, BERT4Rec's stack) under key-padding masks — packed rows have no pad keys:
  *   h = LN1(x); qkv = h Win^T + bin; A = attention(qkv) (causal = 0: every query sees its whole session, rt_mha_varlen_bidir_*);
  *   x1 = x + drop(A Wo^T + bo); g = LN2(x1); a = drop(gelu(g W1^T + b1)); x2 = x1 + drop(a W2^T + b2); out = drop(x2).

@@ -109,6 +109,8 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_sasrec_block_packed_infer": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rt_embed_block1_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "rt_embed_block1_preln_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "rt_sasrec_step_arena_bytes": (c_sz, [c_vp]),
+    "rt_sasrec_step_run": (c_i32, [c_vp, c_i32, c_vp]),
     "rt_preln_block_saved_floats": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
     "rt_preln_block_bwd_scratch_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32, c_i32]),
     "rt_preln_block_packed_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -165,6 +167,19 @@ class SasrecBlock(ctypes.Structure):
                [(n, c_u64) for n in ("seed_attn", "seed_h", "sid_h", "seed_o", "sid_o")] + \
                [(n, c_vp) for n in ("cu", "ln1_w", "ln1_b", "in_w", "in_b", "out_w", "out_b", "ln2_w", "ln2_b", "w1", "b1", "w2", "b2",
                                     "in_wp", "out_wp", "w1_wp", "w2_wp")] + [("wp_stride", c_i64)]
+
+
+class SasrecStep(ctypes.Structure):
+    """`rt_sasrec_step` of include/rectools_hip.h (one packed SASRec training step: batch, parameters, arena, Adam segments)."""
+
+    _fields_ = [(n, c_i32) for n in ("n_blocks", "rows", "rows_real", "B", "B_attn", "V", "d", "dff", "H", "window", "pad_keys", "n_neg", "loss",
+                                     "cosine", "wgrad_splits", "pos_rows")] + \
+               [(n, c_f32) for n in ("p_emb", "p_blk", "emb_scale", "eps_last", "logits_t")] + [("gbce_beta", c_f64)] + \
+               [(n, c_u64) for n in ("seed_emb", "sid_emb")] + \
+               [(n, c_vp) for n in ("ids", "dist", "y", "neg", "cu", "cu_attn", "yw", "table", "pos", "lnf_w", "lnf_b", "blocks", "planes_src")] + \
+               [("planes_n", c_i64), ("planes", c_vp), ("planes_stride", c_i64), ("upstream", c_vp), ("loss_out", c_vp), ("arena", c_vp),
+                ("arena_bytes", c_sz), ("flat_p", c_vp), ("adam_m", c_vp), ("adam_v", c_vp), ("n_seg", c_i32), ("seg_offsets", c_vp),
+                ("seg_lens", c_vp), ("seg_role", c_vp), ("adam_step", c_i32), ("lr", c_f32), ("beta1", c_f32), ("beta2", c_f32), ("adam_eps", c_f32)]
 
 
 class PreLNBlock(ctypes.Structure):

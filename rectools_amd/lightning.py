@@ -749,3 +749,207 @@ class FlatAdam:
     def load_state_dict(self, sd: tp.Dict[str, tp.Any]) -> None:
         self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.step_count = int(sd["step"])
         self.partial_moments = None
+
+
+class NativeSasrecStep:
+    """The stock packed SASRec training step issued by ONE compiled call (`rt_sasrec_step_run`, csrc/rt_step.hip) instead of five
+    autograd nodes, ~22 ctypes calls and 18 `torch.empty` per step: same entry points, same order, same streams, same dropout draws
+    as `TransformerLossModule.training_loss_packed` + `loss.backward()` + `FlatAdam.step()` (lightning.py:311-321 of the reference) —
+    losses and parameters agree to the run-to-run noise of either path (tests/test_native_step_gpu.py), the autograd path is the
+    cross-check and what every other configuration runs.  RT_NATIVE_STEP=0 switches it off.
+
+    `plan(lm, opt)` returns None unless the model is exactly what the sequence restates: stock loss module / backbone / similarity,
+    `SASRecTransformerLayers` whose blocks take the native executor, an ids-only item net whose table is a leaf parameter, the stock
+    positional encoding, a sampled loss (BCE / gBCE / sampled softmax), one rank, every optimised parameter on that path.  The
+    gradients live in the step's arena (`p.grad` stays None)."""
+
+    def __init__(self) -> None:
+        self.desc: tp.Any = None
+
+    @staticmethod
+    def plan(lm: "TransformerLossModule", opt: "FlatAdam") -> tp.Optional["NativeSasrecStep"]:
+        import ctypes
+
+        from . import _lib
+        from . import nn as hnn
+
+        if os.environ.get("RT_NATIVE_STEP", "1") == "0" or not opt.flat_p.is_cuda or not ops.native_block_enabled():
+            return None
+        tl_cls, bb_cls = TransformerLossModule, TransformerTorchBackbone
+        tm = lm.torch_model
+        if (type(lm).training_loss_packed is not tl_cls.training_loss_packed or type(lm)._loss_from_sessions is not tl_cls._loss_from_sessions
+                or lm.loss not in ("BCE", "gBCE", "sampled_softmax") or not lm.similarity_is_stock):
+            return None
+        if (type(tm).encode_packed_train is not bb_cls.encode_packed_train or type(tm)._watch_input_gradient is not bb_cls._watch_input_gradient
+                or not tm._fused_pos() or tm.d_real is not None or not tm.use_causal_attn):
+            return None
+        tl = tm.transformer_layers
+        if type(tl).forward_packed_train is not hnn.SASRecTransformerLayers.forward_packed_train or tl.last_layernorm.cols is not None:
+            return None
+        blocks = list(tl.transformer_blocks)
+        if not blocks or len(blocks) > 16:
+            return None
+        for blk in blocks:
+            if (type(blk).forward_packed_train is not hnn.SASRecTransformerLayer.forward_packed_train or not blk.packed_ok()
+                    or blk.multi_head_attn.scale != 0.0 or blk.q_layer_norm.cols is not None or blk.ff_layer_norm.cols is not None
+                    or blk.p != blocks[0].p or blk.multi_head_attn.n_heads != blocks[0].multi_head_attn.n_heads
+                    or blk.feed_forward.ff_linear_1.weight.shape != blocks[0].feed_forward.ff_linear_1.weight.shape):
+                return None
+        im = tm.item_model
+        if type(im) is not hnn.SumOfEmbeddingsConstructor or im._ids_at is None or im._cat_at is not None or im._more_at:
+            return None
+        table = im.table
+        pos = tm.pos_encoding_layer.pos_emb.weight if tm.pos_encoding_layer.pos_emb is not None else None
+        if not (isinstance(table, nn.Parameter) and table.is_leaf and table.requires_grad and table.is_contiguous()):
+            return None
+        lnf = tl.last_layernorm
+
+        def block_params(blk: tp.Any) -> tp.List[torch.Tensor]:
+            mha, ff = blk.multi_head_attn, blk.feed_forward
+            return [blk.q_layer_norm.weight, blk.q_layer_norm.bias, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias,
+                    blk.ff_layer_norm.weight, blk.ff_layer_norm.bias, ff.ff_linear_1.weight, ff.ff_linear_1.bias, ff.ff_linear_2.weight,
+                    ff.ff_linear_2.bias]
+
+        role_of: tp.Dict[int, int] = {id(table): 0, id(lnf.weight): 2, id(lnf.bias): 3}
+        if pos is not None:
+            role_of[id(pos)] = 1
+        per_block = [block_params(b) for b in blocks]
+        for b, ps in enumerate(per_block):
+            for j, p in enumerate(ps):
+                role_of[id(p)] = 16 + 12 * b + j
+        if len(role_of) != 3 + (pos is not None) + 12 * len(blocks):       # (a parameter shared between two roles)
+            return None
+        roles = [role_of.get(id(p)) for p in opt.params]
+        if any(r is None for r in roles) or len(set(roles)) != len(role_of):  # every optimised parameter is on this path, and all of the path is optimised
+            return None
+        if any(p.dtype != torch.float32 or not p.is_contiguous() or p.device != opt.flat_p.device for p in opt.params):
+            return None
+        d = int(table.shape[1])
+        me = NativeSasrecStep()
+        me.lm, me.opt, me.tm, me.tl, me.blocks, me.table, me.pos, me.lnf = lm, opt, tm, tl, blocks, table, pos, lnf
+        me.per_block = per_block
+        n = len(opt.params)
+        me.seg_offsets = (ctypes.c_int64 * n)(*opt._offsets)
+        me.seg_lens = (ctypes.c_int64 * n)(*[p.numel() for p in opt.params])
+        me.seg_role = (ctypes.c_int32 * n)(*roles)
+        me.blk_arr = (_lib.SasrecBlock * len(blocks))()
+        s = me.desc = _lib.SasrecStep()
+        s.n_blocks, s.V, s.d, s.dff, s.H = len(blocks), int(table.shape[0]), d, int(per_block[0][8].shape[0]), int(blocks[0].multi_head_attn.n_heads)
+        s.pad_keys = int(not tm.use_key_padding_mask)
+        s.loss = {"BCE": ops.LOSS_BCE, "gBCE": ops.LOSS_GBCE, "sampled_softmax": ops.LOSS_SAMPLED_SOFTMAX}[lm.loss]
+        s.pos_rows = 0 if pos is None else int(pos.shape[0])
+        s.eps_last = float(lnf.eps)
+        s.blocks = ctypes.addressof(me.blk_arr)
+        s.n_seg = n
+        s.seg_offsets, s.seg_lens, s.seg_role = ctypes.addressof(me.seg_offsets), ctypes.addressof(me.seg_lens), ctypes.addressof(me.seg_role)
+        me.arena: tp.Optional[torch.Tensor] = None
+        me._reserve = 0
+        me._bytes = getattr(_lib.load(), "rt_sasrec_step_arena_bytes")
+        me.upstream = torch.ones((1,), dtype=torch.float32, device=opt.flat_p.device)
+        s.upstream = me.upstream.data_ptr()
+        me._bound: tp.Optional[tp.Tuple] = None
+        me._fn = getattr(_lib.load(), "rt_sasrec_step_run")
+        return me
+
+    def _bind(self) -> None:
+        """Parameter / optimiser pointers (re-read when the flat buffers or the planes moved: a checkpoint load, `.to()`)."""
+        opt, s = self.opt, self.desc
+        planes = self.tl._fresh_planes(refresh=False)
+        key = (opt.flat_p.data_ptr(), opt.m.data_ptr(), opt.v.data_ptr(), self.table.data_ptr(), None if planes is None else planes.planes.data_ptr())
+        if key == self._bound:
+            return
+        s.table, s.pos = self.table.data_ptr(), (None if self.pos is None else self.pos.data_ptr())
+        s.lnf_w, s.lnf_b = self.lnf.weight.data_ptr(), self.lnf.bias.data_ptr()
+        s.flat_p, s.adam_m, s.adam_v = opt.flat_p.data_ptr(), opt.m.data_ptr(), opt.v.data_ptr()
+        if planes is not None:
+            s.planes_src, s.planes_n, s.planes, s.planes_stride = planes.lo, planes.n, planes.planes.data_ptr(), planes.stride
+        else:
+            s.planes_src, s.planes_n, s.planes, s.planes_stride = None, 0, None, 0
+        for b, (blk, ps) in enumerate(zip(self.blocks, self.per_block)):
+            c = self.blk_arr[b]
+            (c.ln1_w, c.ln1_b, c.in_w, c.in_b, c.out_w, c.out_b, c.ln2_w, c.ln2_b, c.w1, c.b1, c.w2, c.b2) = [t.data_ptr() for t in ps]
+            c.eps1, c.eps2 = float(blk.q_layer_norm.eps), float(blk.ff_layer_norm.eps)
+            c.in_wp = c.out_wp = c.w1_wp = c.w2_wp = None
+            c.wp_stride = 0
+            if planes is not None:
+                ptrs = [planes.of(ps[i]) for i in (2, 4, 8, 10)]
+                if all(q is not None for q in ptrs):
+                    c.in_wp, c.out_wp, c.w1_wp, c.w2_wp = ptrs
+                    c.wp_stride = planes.stride
+        self._planes = planes
+        self._bound = key
+
+    def ready(self, batch: Batch) -> bool:
+        """Per step: training mode, the default two-stream issue without instrumentation, whole moments, a batch of the stock shape."""
+        lm, opt = self.lm, self.opt
+        return (lm.training and ops._TIMING is None and ops._side_enabled() and opt.partial_moments is None and opt._early is None
+                and batch.get("negatives") is not None and batch.get("n_rows") is not None and batch.get("ts") is None
+                and batch.get("n_prefixed") is None and int(batch["x"].shape[0]) % 128 == 0
+                and (self.pos is None or int(self.pos.shape[0]) == int(batch["window"])))
+
+    def forward_backward(self, batch: Batch) -> torch.Tensor:
+        """Phase 1 (forward, loss, backward) on torch's current stream -> the loss (a device scalar)."""
+        from . import _lib
+
+        self._bind()
+        s, tm, lm = self.desc, self.tm, self.lm
+        x, neg = batch["x"], batch["negatives"]
+        rows = int(x.shape[0])
+        B = int(batch["cu"].numel()) - 1
+        s.rows, s.B, s.window = rows, B, int(batch["window"])
+        cu_attn = batch.get("cu_attn")
+        if cu_attn is not None:      # the unused tail of the row block rides along as one more session of the attention
+            s.cu_attn, s.B_attn, s.rows_real = cu_attn.data_ptr(), B + 1, rows
+        else:
+            s.cu_attn, s.B_attn, s.rows_real = batch["cu"].data_ptr(), B, int(batch["n_rows"])
+        s.ids, s.dist, s.y, s.yw, s.cu = x.data_ptr(), batch["dist"].data_ptr(), batch["y"].data_ptr(), batch["yw"].data_ptr(), batch["cu"].data_ptr()
+        if neg.numel() % rows != 0 or not neg.is_contiguous() or not batch["yw"].is_contiguous():
+            raise ValueError("native step: negatives / weights are not contiguous [rows, N] / [rows] tensors")
+        s.neg, s.n_neg = neg.data_ptr(), neg.numel() // rows
+        s.cosine, s.logits_t = int(lm.cosine), float(lm.logits_t)
+        s.gbce_beta = gbce_beta(int(s.n_neg), int(s.V) - lm.n_item_extra_tokens, lm.gbce_t) if lm.loss == "gBCE" else 0.0
+        s.emb_scale = tm._pos_scale(self.table)
+        p_emb = float(tm.dropout_rate) if tm.training else 0.0
+        p_blk = float(self.blocks[0].p) if self.blocks[0].training else 0.0
+        s.p_emb, s.p_blk = p_emb, p_blk
+        # the dropout draws of the autograd nodes, in their order: the lookup, then (attention, hidden, output) of every block
+        s.seed_emb, s.sid_emb = ops.RNG.next() if p_emb > 0 else (0, 0)
+        for b in range(len(self.blocks)):
+            c = self.blk_arr[b]
+            if p_blk > 0:
+                s0, sid = ops.RNG.next()
+                c.seed_attn = (s0 + 0xD1B54A32D192ED03 * sid) & 0xFFFFFFFFFFFFFFFF
+                c.seed_h, c.sid_h = ops.RNG.next()
+                c.seed_o, c.sid_o = ops.RNG.next()
+            else:
+                c.seed_attn = c.seed_h = c.sid_h = c.seed_o = c.sid_o = 0
+        s.wgrad_splits = ops._wgrad_splits(rows)
+        import ctypes
+
+        need = int(self._bytes(ctypes.byref(s)))
+        if need <= 0:
+            raise _lib.HipLibraryError("rt_sasrec_step_arena_bytes: invalid step description")
+        if self.arena is None or need > int(self.arena.numel()):
+            # grows to the largest batch met (models._TrainLoop starts with the epoch's largest: `reserve`); the old block goes back to
+            # the allocator first — everything that read it was issued on this stream or joined into it (the previous step's Adam)
+            self.arena = None
+            self.arena = torch.empty((max(need, self._reserve),), dtype=torch.uint8, device=self.opt.flat_p.device)
+            s.arena, s.arena_bytes = self.arena.data_ptr(), int(self.arena.numel())
+        out = torch.empty((2,), dtype=torch.float32, device=self.opt.flat_p.device)
+        s.loss_out = out.data_ptr()
+        self._run(1)
+        return out[0]
+
+    def adam(self) -> None:
+        """Phase 2: join the weight-gradient stream, one segmented Adam launch over the flat buffers."""
+        opt, s = self.opt, self.desc
+        opt.step_count += 1
+        s.adam_step, s.lr, s.beta1, s.beta2, s.adam_eps = opt.step_count, float(opt.lr), float(opt.betas[0]), float(opt.betas[1]), float(opt.eps)
+        self._run(2)
+
+    def _run(self, phase: int) -> None:
+        import ctypes
+
+        from . import _lib
+
+        _lib.check(self._fn(ctypes.byref(self.desc), phase, _lib.current_stream()), "rt_sasrec_step_run")

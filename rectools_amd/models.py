@@ -170,6 +170,8 @@ class _TrainLoop:
         self.prefix = bool(self.packed and not self.bert and mode is not None and
                            mode(model.n_factors, self.dp.session_max_len, tm.use_causal_attn, tm.use_key_padding_mask) == "prefix")
         self._prefix_dist: tp.Optional[torch.Tensor] = None
+        self._native: tp.Optional[hl.NativeSasrecStep] = None
+        self._native_planned = False
 
     # The next batch is cut while the current step's backward pass runs: collate + negative sampling are a handful of tiny launches that
     # depend on the store and the sampler's counter only — issued on their own stream right behind `loss.backward()` they run beside the
@@ -178,6 +180,7 @@ class _TrainLoop:
 
     def begin_epoch(self, epoch: int) -> None:
         self._pending = None
+        self._native_planned = False      # (the model may have been touched between epochs: callbacks, a checkpoint load)
         perm = epoch_permutation(len(self.store), epoch, self.seed, self.dp.shuffle_train)
         mine = shard_indices(perm, self.rank, self.world)
         self.mine_t = torch.from_numpy(np.ascontiguousarray(mine, dtype=np.int64)).to(self.device)   # one small H2D per epoch
@@ -334,6 +337,16 @@ class _TrainLoop:
                 v.record_stream(main)
         self._pending = (batch, done)
 
+    def _native_step(self) -> tp.Optional[hl.NativeSasrecStep]:
+        """The compiled step of the stock packed SASRec configuration, or None (planned once per epoch: `begin_epoch` clears it)."""
+        if self._native_planned:
+            return self._native
+        self._native_planned = True
+        self._native = None
+        if self.packed and self.world == 1 and not (self.bert or self.prefix or self.stu) and self.device.type == "cuda":
+            self._native = hl.NativeSasrecStep.plan(self.lm, self.opt)
+        return self._native
+
     def step(self) -> torch.Tensor:
         """One training step on the next batch of the current epoch (rolls over to the next epoch when it is used up)."""
         pending = getattr(self, "_pending", None)
@@ -344,6 +357,13 @@ class _TrainLoop:
         else:
             batch = self._cut_batch()
         ops.RNG.next_step()
+        native = self._native_step()
+        if native is not None and native.ready(batch):
+            # the stock packed SASRec step: forward, loss, backward and Adam issued by compiled code (`lightning.NativeSasrecStep`)
+            loss = native.forward_backward(batch)
+            self._prefetch()
+            native.adam()
+            return loss
         self.opt.zero_grad()
         loss = self.lm.training_loss_packed(batch) if self.packed else self.lm.training_loss(batch)
         one = getattr(self, "_root_grad", None)

@@ -320,19 +320,24 @@ class TransformerLayersBase(nn.Module):
                 batch: Batch) -> torch.Tensor:
         raise NotImplementedError()
 
-    def _fresh_planes(self):
+    def _fresh_planes(self, refresh: bool = True):
         """bf16 planes of the stack's weights for the pre-split-weight GEMM (`ops.WeightPlanes`, csrc/rt_gemm_wp.hip), re-split NOW (one
         launch over the stack's few MB of parameters): whatever changed the weights since the last pass — the optimiser, a checkpoint,
         a test poking a parameter — the planes the blocks are about to read are current.  None when the parameters are not views of one
         flat buffer."""
         if not ops.weight_planes_enabled():
             return None
-        key = tuple(p.data_ptr() for p in self.parameters())
-        cached = getattr(self, "_planes_cache", None)
+        ps = self.__dict__.get("_planes_params")
+        if ps is None:      # the module walk is ~0.1 ms of host time: once, not per pass (the Parameter objects of a stack do not change)
+            ps = list(self.parameters())
+            object.__setattr__(self, "_planes_params", ps)
+        key = tuple([p.data_ptr() for p in ps])
+        cached = self.__dict__.get("_planes_cache")
         if cached is None or cached[0] != key:
-            cached = (key, ops.WeightPlanes(list(self.parameters())))
+            cached = (key, ops.WeightPlanes(ps))
             object.__setattr__(self, "_planes_cache", cached)
-        cached[1].refresh()
+        if refresh:      # (False: the caller re-splits the range itself — `lightning.NativeSasrecStep`, inside its one compiled call)
+            cached[1].refresh()
         return cached[1] if cached[1].ok else None
 
 
