@@ -537,6 +537,10 @@ def run_train(args, rank, world, kind="train"):
     # cost; `host_only_ms_per_step` (every launch elided, scripts/microbench/dry_launch.cpp) is the host's cost proper
     roof["host_issue_ms_per_step"] = round(getattr(timed_steps, "host_issue_ms", 0.0), 4)
     roof["allocator_in_timed_steps"] = getattr(timed_steps, "device_allocs", None)
+    # who issued the timed steps: the library (`rt_sasrec_step_run`: the stock packed SASRec step as one compiled call) or the autograd
+    # nodes of rectools_amd/ops.py (every other configuration, data-parallel runs, RT_NATIVE_STEP=0); the per-kernel pass above always
+    # runs through autograd (its event pairs bracket the Python-issued calls), same entry points in the same order
+    roof["step_issue"] = "rt_sasrec_step_run" if getattr(loop, "_native", None) is not None else "autograd"
     roof["device_ms_per_step"] = round(ev_ms, 4)      # HIP events around each timed step on the launch stream
     roof["step_flops_dense"] = 3.0 * B * (nb * spec["blk"] + spec["loss"])     # fwd + bwd = 3 x fwd, on the PADDED [B, L] window
     # what the step EXECUTES: a packed loop runs the real rows only (mean over the epoch's batches; the padded window's flops would

@@ -563,7 +563,7 @@ int rt_embed_block1_preln_fwd(const int64_t* ids, const int64_t* dist, const flo
  *   upstream: device scalar d loss (1.0); loss_out: device [2] <- (loss, normaliser); pos may be NULL (pos_rows == window otherwise).
  *   seg_role [n_seg]: which gradient segment i of the flat parameter buffer reads: 0 table, 1 pos, 2 / 3 the last LayerNorm's weight /
  *   bias, 16 + 12 b + j = block b's parameter j in rt_sasrec_block_grad_offsets order, -1 none (the segment is skipped).
- * rt_sasrec_step_run(phase): 1 = forward + loss + backward, 2 = join + Adam, 3 = both. */
+ * rt_sasrec_step_run(phase): 1 = forward + loss + backward, 2 = join + Adam, 3 = both (n_seg <= 1024). */
 typedef struct rt_sasrec_step {
   int32_t n_blocks, rows, rows_real, B, B_attn, V, d, dff, H, window, pad_keys, n_neg, loss, cosine, wgrad_splits, pos_rows;
   float p_emb, p_blk, emb_scale, eps_last, logits_t;
@@ -583,6 +583,8 @@ typedef struct rt_sasrec_step {
 } rt_sasrec_step;
 size_t rt_sasrec_step_arena_bytes(const rt_sasrec_step* step);
 int rt_sasrec_step_run(const rt_sasrec_step* step, int32_t phase, rt_stream_t stream);
+/* out [n_seg]: where phase 1 leaves the gradient of every segment (device pointers into the arena; NULL: none) — what phase 2 reads. */
+int rt_sasrec_step_grad_ptrs(const rt_sasrec_step* step, const float** out);
 
 /* One packed Pre-LN block (net_blocks.py:223-262, BERT4Rec's stack) under key-padding masks — packed rows have no pad keys:
  *   h = LN1(x); qkv = h Win^T + bin; A = attention(qkv) (causal = 0: every query sees its whole session, rt_mha_varlen_bidir_*);

@@ -111,6 +111,7 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_embed_block1_preln_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "rt_sasrec_step_arena_bytes": (c_sz, [c_vp]),
     "rt_sasrec_step_run": (c_i32, [c_vp, c_i32, c_vp]),
+    "rt_sasrec_step_grad_ptrs": (c_i32, [c_vp, c_vp]),
     "rt_preln_block_saved_floats": (c_sz, [c_i32, c_i32, c_i32, c_i32]),
     "rt_preln_block_bwd_scratch_bytes": (c_sz, [c_i32, c_i32, c_i32, c_i32, c_i32]),
     "rt_preln_block_packed_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp]),

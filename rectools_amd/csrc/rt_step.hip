@@ -91,6 +91,30 @@ size_t rt_sasrec_step_arena_bytes(const rt_sasrec_step* s) {
   return L.total;
 }
 
+// Where the step leaves the gradient of every segment of the flat parameter buffer (seg_role): out [n_seg] device pointers into the arena,
+// NULL for a segment without a gradient.  What phase 2 hands to rt_adam_step_segments; a caller that exchanges or inspects gradients
+// between the phases (tests against the oracle, a data-parallel pack) reads them here.
+int rt_sasrec_step_grad_ptrs(const rt_sasrec_step* sp, const float** out) {
+  if (sp == nullptr || out == nullptr) return RT_ERR_INVALID_ARG;
+  const rt_sasrec_step& s = *sp;
+  Layout L;
+  if (!layout_of(s, L)) return RT_ERR_INVALID_ARG;
+  if (s.arena == nullptr || s.arena_bytes < L.total || s.n_seg <= 0 || s.n_seg > 1024 || s.seg_role == nullptr) return RT_ERR_INVALID_ARG;
+  const float* gbase = static_cast<const float*>(s.arena);
+  for (int i = 0; i < s.n_seg; ++i) {
+    const int r = s.seg_role[i];
+    const float* p = nullptr;
+    if (r == 0) p = gbase + L.d_table;
+    else if (r == 1) p = s.pos != nullptr ? gbase + L.d_pos : nullptr;
+    else if (r == 2) p = gbase + L.d_lnf_w;
+    else if (r == 3) p = gbase + L.d_lnf_b;
+    else if (r >= 16 && r < 16 + 12 * s.n_blocks) p = gbase + L.d_blk[(r - 16) / 12] + L.blk_off[(r - 16) % 12];
+    else if (r != -1) return RT_ERR_INVALID_ARG;
+    out[i] = p;      // NULL: a parameter without a gradient is skipped, as torch.optim.Adam does
+  }
+  return RT_OK;
+}
+
 // phase & 1: forward + loss + backward (gradients land in the arena's gradient region; loss_out[0] = the loss);
 // phase & 2: rt_side_join + the segmented Adam step over (flat_p, adam_m, adam_v) reading those gradients.
 int rt_sasrec_step_run(const rt_sasrec_step* sp, int32_t phase, hipStream_t stream) {
@@ -168,17 +192,7 @@ int rt_sasrec_step_run(const rt_sasrec_step* sp, int32_t phase, hipStream_t stre
       return RT_ERR_INVALID_ARG;
     RT_TRY(rt_side_join(stream));
     const float* ptrs[1024];
-    for (int i = 0; i < s.n_seg; ++i) {
-      const int r = s.seg_role[i];
-      const float* p = nullptr;
-      if (r == 0) p = d_table;
-      else if (r == 1) p = d_pos;
-      else if (r == 2) p = gbase + L.d_lnf_w;
-      else if (r == 3) p = gbase + L.d_lnf_b;
-      else if (r >= 16 && r < 16 + 12 * nb) p = gbase + L.d_blk[(r - 16) / 12] + L.blk_off[(r - 16) % 12];
-      else if (r != -1) return RT_ERR_INVALID_ARG;
-      ptrs[i] = p;      // NULL: a parameter without a gradient is skipped, as torch.optim.Adam does
-    }
+    RT_TRY(rt_sasrec_step_grad_ptrs(sp, ptrs));
     RT_TRY(rt_adam_step_segments(s.flat_p, s.adam_m, s.adam_v, s.n_seg, s.seg_offsets, s.seg_lens, ptrs, s.adam_step, s.lr, s.beta1, s.beta2,
                                  s.adam_eps, 1.0f, stream));
   }

@@ -940,6 +940,29 @@ class NativeSasrecStep:
         self._run(1)
         return out[0]
 
+    def gradients(self) -> tp.List[tp.Optional[torch.Tensor]]:
+        """The gradients phase 1 left in the arena, one per `opt.params` entry (views; valid until the next `forward_backward`).
+        Weight gradients may still be in flight on the library's side stream: this joins it into torch's current stream first.
+        For checks against the oracle (tests, `__graft_entry__.smoke`) — the step itself hands the same pointers to Adam."""
+        import ctypes
+
+        from . import _lib
+
+        assert self.arena is not None, "no step has run"
+        ops._c("rt_side_join")      # (the C call forked the side stream itself: Python's keep-alive lists, which `ops.join_side_streams` consults, are empty)
+        n = len(self.opt.params)
+        ptrs = (ctypes.c_void_p * n)()
+        _lib.check(_lib.load().rt_sasrec_step_grad_ptrs(ctypes.byref(self.desc), ptrs), "rt_sasrec_step_grad_ptrs")
+        base = self.arena.data_ptr()
+        out: tp.List[tp.Optional[torch.Tensor]] = []
+        for p, q in zip(self.opt.params, ptrs):
+            if not q:
+                out.append(None)
+                continue
+            off = int(q) - base
+            out.append(self.arena[off:off + 4 * p.numel()].view(torch.float32).view_as(p))
+        return out
+
     def adam(self) -> None:
         """Phase 2: join the weight-gradient stream, one segmented Adam launch over the flat buffers."""
         opt, s = self.opt, self.desc

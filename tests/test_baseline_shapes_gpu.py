@@ -192,6 +192,34 @@ def _step_vs_oracle(cfg, batch, grad_rtol=1e-3, name="step", packed=False):
     dbatch = {k: v.cuda() for k, v in batch.items()}
     lm.train()
     lm.zero_grad()
+    if packed == "compiled":      # the step as fit() issues it for the stock SASRec configuration: rt_sasrec_step_run (csrc/rt_step.hip)
+        opt = hl.FlatAdam(lm.torch_model, lr=cfg["lr"])
+        native = hl.NativeSasrecStep.plan(lm, opt)
+        assert native is not None, "the stock configuration must take the compiled step"
+        pb = _pack(batch)
+        assert native.ready(pb)
+        loss = native.forward_backward(pb)
+        grads = dict(zip((id(p) for p in opt.params), native.gradients()))
+        assert abs(float(loss) - float(loss_ref)) <= 5e-5 * abs(float(loss_ref)) + 5e-6, (float(loss), float(loss_ref))
+        rec = MEASURED.setdefault(name, {"loss_rel": abs(float(loss) - float(loss_ref)) / abs(float(loss_ref))})
+        for n, p in lm.torch_model.named_parameters():
+            got = grads[id(p)]
+            assert got is not None, n
+            rec[n] = float((got - g_ref[n].to(got.device)).abs().max()) / (float(g_ref[n].abs().max()) + 1e-30)
+            _close(got, g_ref[n], grad_rtol, 2e-5 if g_ref[n].abs().max() > 1e-6 else 1.0, f"grad {n}")
+        print(f"[{name}] loss rel err {rec['loss_rel']:.2e}; max gradient error / tensor scale {max(v for k, v in rec.items() if k != 'loss_rel'):.1e}")
+        # ... and its Adam step against torch.optim.Adam's formula on the oracle's gradients (first step: m = (1 - b1) g, v = (1 - b2) g^2)
+        before = {n: p.detach().clone() for n, p in lm.torch_model.named_parameters()}
+        native.adam()
+        torch.cuda.synchronize()
+        b1, b2 = opt.betas
+        for n, p in lm.torch_model.named_parameters():
+            g = g_ref[n].to(p.device).double()
+            m_hat, v_hat = g, g * g                                 # (1 - b) g / (1 - b^1)
+            want = before[n].double() - cfg["lr"] * m_hat / (v_hat.sqrt() + opt.eps)
+            live = g.abs() > 1e-4 * g.abs().max()                   # (where |g| ~ eps the step is ill-conditioned in the gradient's last bits)
+            assert float((p.detach().double() - want)[live].abs().max()) <= 2e-2 * cfg["lr"], n
+        return
     if packed:      # the padding-free path of the same step, straight against the oracle
         tm = lm.torch_model
         assert tm.transformer_layers.packed_ok(cfg["d"], cfg["L"], tm.use_causal_attn, tm.use_key_padding_mask)
@@ -334,7 +362,16 @@ def test_sampled_softmax_V26744_N128_zipf_targets():
     close(ggot[1], gref[1], rtol=2e-3, atol_rel=2e-4, msg="d_table")
 
 
-@pytest.mark.parametrize("packed", [False, True])
+@pytest.mark.parametrize("loss,dist,kw", [("BCE", "dot", {}), ("gBCE", "dot", {"keypad": True}), ("sampled_softmax", "cosine", {"logits_t": 0.05})],
+                         ids=["bce", "gbce_keypad", "cosine_t005"])
+def test_compiled_sasrec_step_vs_oracle(loss, dist, kw):
+    """`lightning.NativeSasrecStep` (one compiled call per step) against the oracle at a small shape: the three sampled losses, with and
+    without key-padding masks, cosine similarity with the C4 temperature — loss, every gradient it leaves in its arena, its Adam step."""
+    cfg, batch = _random_case("sasrec", loss, dist, 64, 128, 2, 6, 900, 24, 77, **kw)
+    _step_vs_oracle(cfg, batch, name=f"compiled SASRec {loss} {dist}", packed="compiled")
+
+
+@pytest.mark.parametrize("packed", [False, True, "compiled"])
 def test_sasrec_training_step_C2_shape_zipf(packed):
     """One whole C2 training step (d256, 2 blocks, 4 heads, L200, sampled_softmax N=128, V=26,744) on 32 Zipf-popular
     sequences: loss and EVERY parameter gradient (incl. the embedding-table gradient through both heavy-row reducers)."""
@@ -347,4 +384,4 @@ def test_sasrec_training_step_C2_shape_zipf(packed):
     batch["x"] = seq[:, :-1].masked_fill(pad, 0)
     batch["y"] = seq[:, 1:].masked_fill(pad, 0)
     batch["yw"] = (batch["y"] != 0).float()
-    _step_vs_oracle(cfg, batch, name="C2 SASRec" + (" packed" if packed else ""), packed=packed)
+    _step_vs_oracle(cfg, batch, name="C2 SASRec" + (f" {packed}" if isinstance(packed, str) else " packed" if packed else ""), packed=packed)
