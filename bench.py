@@ -540,7 +540,7 @@ def run_train(args, rank, world, kind="train"):
     # who issued the timed steps: the library (`rt_sasrec_step_run`: the stock packed SASRec step as one compiled call) or the autograd
     # nodes of rectools_amd/ops.py (every other configuration, data-parallel runs, RT_NATIVE_STEP=0); the per-kernel pass above always
     # runs through autograd (its event pairs bracket the Python-issued calls), same entry points in the same order
-    roof["step_issue"] = "rt_sasrec_step_run" if getattr(loop, "_native", None) is not None else "autograd"
+    roof["step_issue"] = "rt_sasrec_step_run" if getattr(getattr(loop, "_native", None), "steps", 0) > 0 else "autograd"
     roof["device_ms_per_step"] = round(ev_ms, 4)      # HIP events around each timed step on the launch stream
     roof["step_flops_dense"] = 3.0 * B * (nb * spec["blk"] + spec["loss"])     # fwd + bwd = 3 x fwd, on the PADDED [B, L] window
     # what the step EXECUTES: a packed loop runs the real rows only (mean over the epoch's batches; the padded window's flops would

@@ -844,6 +844,7 @@ class NativeSasrecStep:
         s.seg_offsets, s.seg_lens, s.seg_role = ctypes.addressof(me.seg_offsets), ctypes.addressof(me.seg_lens), ctypes.addressof(me.seg_role)
         me.arena: tp.Optional[torch.Tensor] = None
         me._reserve = 0
+        me.steps = 0          # steps this plan has issued (bench.py's `roofline.step_issue`)
         me._bytes = getattr(_lib.load(), "rt_sasrec_step_arena_bytes")
         me.upstream = torch.ones((1,), dtype=torch.float32, device=opt.flat_p.device)
         s.upstream = me.upstream.data_ptr()
@@ -938,6 +939,7 @@ class NativeSasrecStep:
         out = torch.empty((2,), dtype=torch.float32, device=self.opt.flat_p.device)
         s.loss_out = out.data_ptr()
         self._run(1)
+        self.steps += 1
         return out[0]
 
     def gradients(self) -> tp.List[tp.Optional[torch.Tensor]]:
