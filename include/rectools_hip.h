@@ -551,7 +551,7 @@ int rt_embed_block1_preln_fwd(const int64_t* ids, const int64_t* dist, const flo
 
 /* One packed SASRec TRAINING STEP (lightning.py:311-321 around sasrec.py:271-304, the sampled losses lightning.py:164-212 and
  * torch.optim.Adam, lightning.py:366-369): rt_embed_packed_fwd -> rt_sasrec_block_packed_fwd x n_blocks -> rt_layernorm_fwd ->
- * rt_sampled_loss_fwd_train -> rt_loss_reduce -> rt_sampled_loss_bwd (session half on `stream`, table half on a library-owned stream of its own)
+ * rt_sampled_loss_fwd_train -> rt_loss_reduce -> rt_sampled_loss_bwd (session half on `stream`, table half on the library's side stream)
  * -> rt_layernorm_bwd_rows / _combine -> rt_sasrec_block_packed_bwd x n_blocks -> rt_embed_packed_bwd (adds into the loss's table
  * gradient) -> rt_side_join -> rt_adam_step_segments: the entry points above in the order the autograd nodes of rectools_amd/ops.py issue
  * them, from compiled code (csrc/rt_step.hip).  No allocation: `arena` (rt_sasrec_step_arena_bytes) holds the parameter gradients

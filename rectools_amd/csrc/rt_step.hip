@@ -4,8 +4,7 @@
 // Why: the block executors (rt_block.hip) left ~22 ctypes calls, 18 torch.empty and five autograd nodes per C2 step to Python —
 // 1.0 ms of host time per step (0.5 ms of it inside the autograd engine's backward: scripts/host_profile.py), which is the step's
 // wall time on the pool's slower hosts (1.45 ms of host issue against 1.39 ms of device time).  This file issues the SAME entry points
-// in the SAME order on the caller's stream and the library's weight-gradient side stream (plus a stream of its own for the loss's
-// table-gradient half, which shared the side stream in the autograd path) from compiled code; Python
+// in the SAME order on the same two streams (the caller's and the library's weight-gradient side stream) from compiled code; Python
 // hands over one descriptor and one arena.  `lightning.NativeSasrecStep` decides when a model is the stock one this sequence
 // restates; everything else keeps the autograd path, which is also this file's cross-check (tests/test_native_step_gpu.py: parameters
 // equal after N steps to the run-to-run noise of either path).
@@ -33,23 +32,6 @@ inline size_t alb(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
   } while (0)
 
 constexpr int MAX_BLOCKS = 16;
-
-// The stream the loss's table-gradient half runs on (one per device, low priority like the weight-gradient stream of rt_block.hip).
-struct LossStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, done = nullptr; };
-LossStream g_loss_stream[16];
-LossStream* loss_stream_of_current_device() {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  LossStream& l = g_loss_stream[dev];
-  if (l.stream == nullptr) {
-    int least = 0, greatest = 0;
-    const bool low = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest;
-    const hipError_t rc = low ? hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, least) : hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
-    if (rc != hipSuccess) { l.stream = nullptr; return nullptr; }
-    if (hipEventCreateWithFlags(&l.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&l.done, hipEventDisableTiming) != hipSuccess) return nullptr;
-  }
-  return &l;
-}
 
 struct Layout {
   // gradients (floats from the arena's start)
@@ -155,13 +137,10 @@ int rt_sasrec_step_run(const rt_sasrec_step* sp, int32_t phase, hipStream_t stre
   if (phase & 1) {
     // ---- forward ---------------------------------------------------------------------------------------------------------------
     RT_TRY(rt_embed_packed_fwd(s.ids, s.dist, s.table, s.pos, s.emb_scale, M, d, s.p_emb, s.seed_emb, s.sid_emb, F(L.x[0]), stream));
-    bool side_on = false;      // (false: RT_SIDE_STREAM=0 — everything on the caller's stream)
     {   // the counting sort of the rows by id (the lookup's backward reads it): a function of the ids alone, on the side stream now
       void* side = nullptr;
       RT_TRY(rt_side_fork(stream, &side));
-      side_on = side != nullptr;
-      RT_TRY(rt_embed_bwd_prepare(s.ids, M, d, s.V, base + L.emb_ws, L.emb_ws_bytes, side_on ? static_cast<hipStream_t>(side) : stream));
-      if (side_on) RT_TRY(rt_side_mark());      // the lookup's backward waits for THIS point of the side stream, not for the weight gradients behind it
+      RT_TRY(rt_embed_bwd_prepare(s.ids, M, d, s.V, base + L.emb_ws, L.emb_ws_bytes, side != nullptr ? static_cast<hipStream_t>(side) : stream));
     }
     if (s.planes != nullptr) RT_TRY(rt_split_planes(s.planes_src, s.planes_n, s.planes, s.planes_stride, stream));
     rt_sasrec_block blk[MAX_BLOCKS];
@@ -177,27 +156,22 @@ int rt_sasrec_step_run(const rt_sasrec_step* sp, int32_t phase, hipStream_t stre
     RT_TRY(rt_loss_reduce(F(L.loss_pos), s.y, M, s.loss == 2 ? 0 : 1, s.loss_out, stream));
 
     // ---- backward --------------------------------------------------------------------------------------------------------------
-    LossStream* ls = nullptr;
     {   // the loss: the session half feeds the blocks (caller's stream), the table half is read by the lookup's backward and the optimiser
-      if (!side_on) {
+      void* side = nullptr;
+      RT_TRY(rt_side_fork(stream, &side));
+      if (side == nullptr) {
         RT_TRY(rt_sampled_loss_bwd(F(L.y), d, s.table, s.y, s.neg, M, s.n_neg, d, s.V, s.cosine, s.logits_t, F(L.logits), s.loss_out + 1, 1.0f,
                                    s.upstream, F(L.du), d, F(L.d_sess), d, d_table, base + L.loss_ws, L.loss_ws_bytes, 0, stream));
       } else {
-        // ... on a stream of ITS OWN: on the weight-gradient stream its ~310 us chain (pair sort, row reductions) sat in front of the last
-        // block's weight gradients (C2: 87.1 -> 87.4 k seqs/s with the third stream, same box; WHEN the host issues it — here, behind the last
-        // block's backward or behind all of them — makes no difference: the launch is ordered by the event, not by the call)
-        ls = loss_stream_of_current_device();
-        if (ls == nullptr) return RT_ERR_LAUNCH;
         RT_TRY(rt_sampled_loss_bwd(F(L.y), d, s.table, s.y, s.neg, M, s.n_neg, d, s.V, s.cosine, s.logits_t, F(L.logits), s.loss_out + 1, 1.0f,
                                    s.upstream, F(L.du), d, F(L.d_sess), d, nullptr, base + L.loss_ws, L.loss_ws_bytes, 0, stream));
-        RT_CHECK_HIP(hipEventRecord(ls->fork, stream));
+        RT_TRY(rt_sampled_loss_bwd(F(L.y), d, s.table, s.y, s.neg, M, s.n_neg, d, s.V, s.cosine, s.logits_t, F(L.logits), s.loss_out + 1, 1.0f,
+                                   s.upstream, F(L.du), d, nullptr, d, d_table, base + L.loss_ws, L.loss_ws_bytes, 0, static_cast<hipStream_t>(side)));
+        RT_TRY(rt_side_mark());      // the lookup's backward waits for THIS point, not for the weight gradients queued behind it
+        // (Tried: this half on a third library stream, so that its ~310 us chain does not sit in front of the last block's weight gradients:
+        //  + 0.3 % on the C2 step — and a fourth hardware queue in the process, which cost the LATER loops of the same process 20 - 25 %
+        //  (HSTU 22.8 -> 17.7 k, eSASRec 13.8 -> 10.9 k seqs/s in the default bench line: their side / prefetch streams then share queues).)
       }
-    }
-    if (ls != nullptr) {
-      RT_CHECK_HIP(hipStreamWaitEvent(ls->stream, ls->fork, 0));
-      RT_TRY(rt_sampled_loss_bwd(F(L.y), d, s.table, s.y, s.neg, M, s.n_neg, d, s.V, s.cosine, s.logits_t, F(L.logits), s.loss_out + 1, 1.0f,
-                                 s.upstream, F(L.du), d, nullptr, d, d_table, base + L.loss_ws, L.loss_ws_bytes, 0, ls->stream));
-      RT_CHECK_HIP(hipEventRecord(ls->done, ls->stream));
     }
     {   // the last LayerNorm: rows here, the combine of dw / db (optimiser only) on the side stream
       RT_TRY(rt_layernorm_bwd_rows(F(L.d_sess), F(L.x[nb]), s.lnf_w, F(L.mean), F(L.rstd), nullptr, nullptr, 0, 0, M, d, F(L.g[nb]), base + L.ln_ws,
@@ -210,9 +184,6 @@ int rt_sasrec_step_run(const rt_sasrec_step* sp, int32_t phase, hipStream_t stre
     for (int b = nb - 1; b >= 0; --b)
       RT_TRY(rt_sasrec_block_packed_bwd(&blk[b], F(L.x[b]), F(L.saved[b]), F(L.g[b + 1]), F(L.g[b]), gbase + L.d_blk[b], base + L.scratch[b],
                                         L.scratch_bytes, s.wgrad_splits, 1, stream));
-    // the lookup's backward adds into the loss's table gradient and reads the sort the side stream made at the start of the step (the
-    // mark); everything behind these waits on `stream`, the Adam launch included, sees the table half
-    if (ls != nullptr) RT_CHECK_HIP(hipStreamWaitEvent(stream, ls->done, 0));
     RT_TRY(rt_side_wait_mark(stream));
     RT_TRY(rt_embed_packed_bwd(s.ids, s.cu, s.B, F(L.g[0]), s.emb_scale, M, s.window, d, s.V, s.p_emb, s.seed_emb, s.sid_emb, d_table, 1, d_pos,
                                base + L.emb_ws, L.emb_ws_bytes, 1, stream));
