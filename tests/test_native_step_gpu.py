@@ -1,6 +1,7 @@
 """`lightning.NativeSasrecStep` (csrc/rt_step.hip: the stock packed SASRec training step behind one compiled call) against the autograd
 path it restates — same entry points, order, streams and dropout draws — and its eligibility rules.  Two runs of EITHER path differ in
-the last bits of a few gradients (the loss's pair ranks and the bias column sums are taken with atomics: scripts/debug/native_step_diff.py
+the last bits of the item table's gradient (the sampled loss ranks the pairs of a candidate with atomics, the row reducer sums them in
+rank order: scripts/debug/grad_repro.py — every other gradient of a step is bit-reproducible; scripts/debug/native_step_diff.py
 shows autograd vs autograd, compiled vs compiled and compiled vs autograd differing alike, ~3e-7 after 14 steps), so the comparison is
 at that level: a wrong dropout stream, a missing gradient or a wrong Adam segment moves a parameter by the learning rate (4e-3) per step.
 Reference: lightning.py:311-321 (training_step), sasrec.py:271-304, lightning.py:164-212 (sampled losses)."""
