@@ -661,8 +661,9 @@ class TransformerModelBase:
         Honoured: `max_epochs` / `min_epochs` (fit() trains max_epochs epochs, at least min_epochs once a callback sets
         `trainer.should_stop`), the logger's directory (`trainer.logger.log_dir` / `save_dir` -> the per-epoch CSV, the layout of
         Lightning's CSVLogger), `enable_progress_bar` (a line per epoch, as verbose > 0), `deterministic` (applied by the Trainer's own
-        constructor; every kernel of the engine reduces in a fixed order but two: the sampled losses rank a candidate's pairs with atomics, so
-        the item table's gradient varies in its last bits from run to run — scripts/debug/grad_repro.py —, and the HSTU bias gradients), and the hooks of
+        constructor; the engine's reductions run in a fixed order but for three: the sampled losses rank a candidate's pairs with atomics (the
+        item table's gradient varies in its last bits from run to run), bias gradients' partial column sums meet in atomicAdds, and the HSTU
+        relative-bias gradients — scripts/debug/grad_repro.py), and the hooks of
         USER-DEFINED callbacks — any object in `trainer.callbacks` whose class does not come from pytorch_lightning / lightning — called
         as `hook(trainer, lightning_model[, outputs, batch, batch_idx])` where the loop reaches the matching point.
         Not honoured, said once per fit in a warning: accelerator / devices / strategy / precision / gradient clipping / accumulation /

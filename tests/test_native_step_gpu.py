@@ -1,7 +1,7 @@
 """`lightning.NativeSasrecStep` (csrc/rt_step.hip: the stock packed SASRec training step behind one compiled call) against the autograd
 path it restates — same entry points, order, streams and dropout draws — and its eligibility rules.  Two runs of EITHER path differ in
 the last bits of the item table's gradient (the sampled loss ranks the pairs of a candidate with atomics, the row reducer sums them in
-rank order: scripts/debug/grad_repro.py — every other gradient of a step is bit-reproducible; scripts/debug/native_step_diff.py
+rank order) and of the bias gradients (partial column sums meet in atomicAdds: colsum_kernel) — scripts/debug/grad_repro.py; scripts/debug/native_step_diff.py
 shows autograd vs autograd, compiled vs compiled and compiled vs autograd differing alike, ~3e-7 after 14 steps), so the comparison is
 at that level: a wrong dropout stream, a missing gradient or a wrong Adam segment moves a parameter by the learning rate (4e-3) per step.
 Reference: lightning.py:311-321 (training_step), sasrec.py:271-304, lightning.py:164-212 (sampled losses)."""
@@ -161,3 +161,88 @@ def test_native_step_follows_moved_buffers(monkeypatch):
         models[native] = m
         del old_v
     _assert_same_parameters(models[True], models[False])
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_compiled_step_fuzz_against_autograd(monkeypatch, seed):
+    """Random stock configurations (width, heads, window, depth, negatives, batch size, loss, dropout, positional rows, key-padding
+    masks): ONE step from the same parameters, batch and dropout streams through autograd and through the compiled call.  Same entry
+    points, same order, same arguments: the loss and every weight MATRIX's gradient agree BIT FOR BIT; the item table's gradient is summed
+    in the order the loss's atomics ranked a candidate's pairs and the bias gradients' partial column sums meet in atomicAdds (last bits);
+    the Adam step behind them likewise."""
+    import random
+
+    from rectools_amd import lightning as hl
+    from rectools_amd import ops
+    from rectools_amd.models import SASRecModel
+
+    r = random.Random(1000 + seed)
+    d = r.choice([32, 64, 128, 256])
+    hd = r.choice([h for h in (32, 64) if d % h == 0])
+    kw = dict(n_factors=d, n_heads=d // hd, session_max_len=r.choice([16, 50, 200]), n_blocks=r.choice([1, 2, 4]), n_negatives=r.choice([1, 16, 128]),
+              batch_size=r.choice([7, 32, 128]), loss=r.choice(["BCE", "gBCE", "sampled_softmax"]), dropout_rate=r.choice([0.0, 0.3]),
+              use_pos_emb=r.choice([True, False]), use_key_padding_mask=r.choice([True, False]))
+    monkeypatch.setenv("RT_NATIVE_STEP", "0")
+    m = SASRecModel(lr=0.004, seed=11, epochs=1, **kw)
+    m._build_model_from_dataset(_dataset())
+    loop = m.training_loop()
+    if not loop.packed:
+        pytest.skip(f"no packed loop for {kw}")
+    m.lightning_model.train()
+    loop.begin_epoch(0)
+    for _ in range(r.choice([0, 3])):      # (3: not the first batch, moments in place)
+        loop.step()
+    batch = loop._cut_batch()
+    opt, lm = loop.opt, loop.lm
+    step0 = ops.RNG.step + 1
+
+    def rewind():
+        ops.RNG.step, ops.RNG._stream = step0, 0
+
+    rewind()
+    opt.zero_grad()
+    loss_a = lm.training_loss_packed(batch)
+    loss_a.backward()
+    ops.join_side_streams()
+    grads_a = [None if p.grad is None else p.grad.detach().clone() for p in opt.params]
+    monkeypatch.setenv("RT_NATIVE_STEP", "1")
+    native = hl.NativeSasrecStep.plan(lm, opt)
+    assert native is not None and native.ready(batch), kw
+    rewind()
+    loss_n = native.forward_backward(batch)
+    grads_n = native.gradients()
+    assert torch.equal(loss_n.detach(), loss_a.detach()), (kw, float(loss_n), float(loss_a))
+    table = lm.torch_model.item_model.table
+    names = {id(p): n for n, p in lm.torch_model.named_parameters()}
+    for p, ga, gn in zip(opt.params, grads_a, grads_n):
+        assert (ga is None) == (gn is None), names[id(p)]
+        if ga is None:
+            continue
+        if p is table:
+            torch.testing.assert_close(gn, ga, rtol=0, atol=2e-6 * float(ga.abs().max()) + 1e-12, msg=lambda s: f"{kw}: table gradient: {s}")
+        elif p.dim() == 1:
+            # bias gradients are column sums whose partial sums meet in an atomicAdd (colsum_kernel, rt_gemm.hip): last bits vary with the
+            # order the workgroups arrive in; the KEY bias third has no gradient at all (cancellation noise around zero)
+            torch.testing.assert_close(gn, ga, rtol=0, atol=1e-6 * float(ga.abs().max()) + 1e-12, msg=lambda s, p=p: f"{kw}: {names[id(p)]}: {s}")
+        else:
+            bad = (gn != ga).nonzero()
+            assert bad.numel() == 0, (f"{kw}: {names[id(p)]}: {bad.shape[0]} of {ga.numel()} elements differ, "
+                                      f"max {float((gn - ga).abs().max()):.2e} of {float(ga.abs().max()):.2e}")
+    # the Adam step: the compiled phase 2 against FlatAdam.step on copies of the same state
+    state = [t.clone() for t in (opt.flat_p, opt.m, opt.v)]
+    count = opt.step_count
+    native.adam()
+    torch.cuda.synchronize()
+    after_n = [t.clone() for t in (opt.flat_p, opt.m, opt.v)]
+    for t, s0 in zip((opt.flat_p, opt.m, opt.v), state):
+        t.copy_(s0)
+    opt.step_count = count
+    opt.step(1)          # (reads p.grad: the autograd pass's tensors)
+    torch.cuda.synchronize()
+    for i, p in enumerate(opt.params):      # matrices but the table: the same bits; biases and the table: to their gradients' last bits
+        lo, hi = opt._offsets[i], opt._offsets[i] + p.numel()
+        for t_n, t_a in zip(after_n, (opt.flat_p, opt.m, opt.v)):
+            if p.dim() == 2 and p is not table:
+                assert torch.equal(t_n[lo:hi], t_a[lo:hi]), (kw, names[id(p)])
+            else:
+                torch.testing.assert_close(t_n[lo:hi], t_a[lo:hi], rtol=1e-3, atol=1e-5)
