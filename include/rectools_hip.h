@@ -610,6 +610,9 @@ int rt_side_join(rt_stream_t stream);
  * a data-parallel step starts the exchange of the block weights' gradients from its own stream while the backward pass runs on
  * (the reference: DDP's bucketed all-reduce behind `Trainer.fit`, transformers/base.py:367-380). */
 int rt_side_reach(rt_stream_t stream);
+/* The library's side stream itself (NULL through *side_out when RT_SIDE_STREAM=0): a binding with side work of its own wraps this stream
+ * instead of creating another (more streams than hardware queues = two of them share one). */
+int rt_side_stream(void** side_out);
 /* the side stream for the caller's own optimiser-only work: it waits for `stream`'s current position; *side_out = its handle, or
  * NULL when disabled (launch on `stream` then).  Joined by rt_side_join. */
 int rt_side_fork(rt_stream_t stream, void** side_out);

@@ -118,6 +118,7 @@ SIGNATURES: tp.Dict[str, tp.Tuple[tp.Any, tp.List[tp.Any]]] = {
     "rt_preln_block_packed_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_i32, c_i32, c_vp]),
     "rt_side_join": (c_i32, [c_vp]),
     "rt_side_reach": (c_i32, [c_vp]),
+    "rt_side_stream": (c_i32, [c_vp]),
     "rt_side_fork": (c_i32, [c_vp, c_vp]),
     "rt_side_mark": (c_i32, []),
     "rt_side_wait_mark": (c_i32, [c_vp]),

@@ -231,6 +231,18 @@ int rt_side_wait_mark(hipStream_t stream) {
   return RT_OK;
 }
 
+// The library's side stream itself (created on first use; NULL through *side_out when RT_SIDE_STREAM=0): a host binding that has side work of
+// its own (the next batch's collate, Python-issued weight gradients) wraps THIS stream instead of creating another — a process that owns
+// more streams than the device has hardware queues finds two of them sharing one, and which two is decided at run time (round 6: the HSTU
+// loop at 20.3 k seqs/s in one default bench line and 24.1 k in the next, its weight gradients serialised with the main stream in the first).
+int rt_side_stream(void** side_out) {
+  if (side_out == nullptr) return RT_ERR_INVALID_ARG;
+  *side_out = nullptr;
+  Side* s = side_enabled() ? side_of_current_device() : nullptr;
+  if (s != nullptr) *side_out = s->stream;
+  return RT_OK;
+}
+
 // The side stream as a service to the caller's own launches (the loss's table-gradient half, the embedding backward: results only the
 // optimiser reads): rt_side_fork makes the side stream wait for everything issued so far on `stream` and returns its handle through
 // *side_out (NULL when the side stream is disabled: launch on `stream` then); work issued on it is joined by rt_side_join.
