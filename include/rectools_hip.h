@@ -333,6 +333,11 @@ int rt_layernorm_bwd_fused(const float* dy, const float* x, const float* w, cons
 int rt_layernorm_bwd_rows(const float* dy, const float* x, const float* w, const float* mean, const float* rstd, const float* res,
                           const int64_t* ids, int32_t mask_dy, int32_t mask_dx, int32_t M, int32_t d, float* dx, void* workspace,
                           size_t workspace_bytes, rt_stream_t stream);
+/* rt_layernorm_bwd_rows over dy * (gscale * upstream[0] / norm[0]) — a sampled loss's unit gradient (d_sess_unit of
+ * rt_sampled_loss_fwd_train) taken as it is: the bits rt_sampled_loss_bwd's session half would write, without that launch. */
+int rt_layernorm_bwd_rows_scaled(const float* dy, const float* norm, float gscale, const float* upstream, const float* x, const float* w,
+                                 const float* mean, const float* rstd, int32_t M, int32_t d, float* dx, void* workspace,
+                                 size_t workspace_bytes, rt_stream_t stream);
 int rt_layernorm_bwd_combine(const void* workspace, size_t workspace_bytes, int32_t M, int32_t d, float* dw, float* db,
                              rt_stream_t stream);
 

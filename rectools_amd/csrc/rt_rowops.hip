@@ -305,6 +305,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   if (lane == 0) { mean[m] = mu; rstd[m] = rs; }
 }
 
+struct DyScale { const float* norm = nullptr; const float* upstream = nullptr; float gscale = 1.f; };
+
 // dx = rstd * (dy*w - mean(dy*w) - xhat * mean(dy*w*xhat));  dw += sum dy*xhat;  db += sum dy
 // Each wave keeps the dw/db partial sums of its columns in registers over its rows (NDV float4 per lane,
 // d <= 256*NDV); the 4 waves are combined through LDS and one atomicAdd per column leaves the block.
@@ -318,8 +320,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             float* __restrict__ dx, float* __restrict__ partial,
                                                             const float* __restrict__ res = nullptr,
                                                             const long long* __restrict__ ids = nullptr, int mask_dy = 0,
-                                                            int mask_dx = 0, int grp = 0, int grp_real = 0) {
+                                                            int mask_dx = 0, int grp = 0, int grp_real = 0, DyScale dsc = DyScale{}) {
   const int n_cols = COLS ? d / grp * grp_real : d;
+  // dy handed over UNSCALED (rt_layernorm_bwd_rows_scaled): dy * gscale * upstream[0] / norm[0] on load — the sampled loss's
+  // scale_rows_kernel, expression for expression, without its launch and without the round trip of the scaled rows through memory
+  const bool scaled = dsc.norm != nullptr;
+  const float dy_sc = scaled ? dsc.gscale * (dsc.upstream != nullptr ? dsc.upstream[0] : 1.f) / dsc.norm[0] : 1.f;
   extern __shared__ float red[];  // [4 waves][2][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r0 = blockIdx.x * rows_per_block;
@@ -348,6 +354,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         const int c = lane * 4 + 256 * i;
         f32x4 z = {0.f, 0.f, 0.f, 0.f};
         g[u][i] = (c < d && !(mask_dy && pad[u])) ? *reinterpret_cast<const f32x4*>(dy + ro[u] + c) : z;
+        if (scaled) g[u][i] = g[u][i] * dy_sc;
         xh[u][i] = (c < d) ? *reinterpret_cast<const f32x4*>(x + ro[u] + c) : z;
         if (COLS && c < d) g[u][i] = ln_keep_cols(g[u][i], c, grp, grp_real);
       }
@@ -941,7 +948,7 @@ int rt_layernorm_bwd(const float* dy, const float* x, const float* w, const floa
 static int layernorm_bwd_any(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
                            const float* res, const int64_t* ids, int32_t mask_dy, int32_t mask_dx, int32_t M, int32_t d, int32_t grp,
                            int32_t grp_real, float* dx, float* dw, float* db, void* workspace, size_t workspace_bytes, hipStream_t stream,
-                           bool combine = true);
+                           bool combine = true, DyScale dsc = DyScale{});
 int rt_layernorm_bwd_fused(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
                            const float* res, const int64_t* ids, int32_t mask_dy, int32_t mask_dx, int32_t M, int32_t d,
                            float* dx, float* dw, float* db, void* workspace, size_t workspace_bytes, hipStream_t stream) {
@@ -955,8 +962,10 @@ int rt_layernorm_bwd_cols(const float* dy, const float* x, const float* w, const
 }
 static int layernorm_bwd_any(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
                            const float* res, const int64_t* ids, int32_t mask_dy, int32_t mask_dx, int32_t M, int32_t d, int32_t grp,
-                           int32_t grp_real, float* dx, float* dw, float* db, void* workspace, size_t workspace_bytes, hipStream_t stream, bool combine) {
+                           int32_t grp_real, float* dx, float* dw, float* db, void* workspace, size_t workspace_bytes, hipStream_t stream, bool combine,
+                           DyScale dsc) {
   (void)hipGetLastError();
+  if (dsc.norm != nullptr && grp > 0) return RT_ERR_UNSUPPORTED;
   if ((mask_dy || mask_dx) && ids == nullptr) return RT_ERR_INVALID_ARG;
   const long long* idp = reinterpret_cast<const long long*>(ids);
   if ((d & 3) != 0) return RT_ERR_INVALID_ARG;
@@ -975,9 +984,9 @@ static int layernorm_bwd_any(const float* dy, const float* x, const float* w, co
     if (d <= 256) layernorm_bwd_kernel<1, true><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, partial, res, idp, mask_dy, mask_dx, grp, grp_real);
     else if (d <= 512) layernorm_bwd_kernel<2, true><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, partial, res, idp, mask_dy, mask_dx, grp, grp_real);
     else layernorm_bwd_kernel<4, true><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, partial, res, idp, mask_dy, mask_dx, grp, grp_real);
-  } else if (d <= 256) layernorm_bwd_kernel<1><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, partial, res, idp, mask_dy, mask_dx);
-  else if (d <= 512) layernorm_bwd_kernel<2><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, partial, res, idp, mask_dy, mask_dx);
-  else layernorm_bwd_kernel<4><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, partial, res, idp, mask_dy, mask_dx);
+  } else if (d <= 256) layernorm_bwd_kernel<1><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, partial, res, idp, mask_dy, mask_dx, 0, 0, dsc);
+  else if (d <= 512) layernorm_bwd_kernel<2><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, partial, res, idp, mask_dy, mask_dx, 0, 0, dsc);
+  else layernorm_bwd_kernel<4><<<blocks, 256, lds, stream>>>(dy, x, w, mean, rstd, M, d, rpb, dx, partial, res, idp, mask_dy, mask_dx, 0, 0, dsc);
   RT_CHECK_LAUNCH();
   if (!combine) return RT_OK;      // (the caller combines the partial sums itself: rt_layernorm_bwd_combine, possibly on another stream)
   layernorm_bwd_reduce_kernel<<<(2 * d + 15) / 16, 256, 0, stream>>>(partial, blocks, d, dw, db);
@@ -994,6 +1003,17 @@ int rt_layernorm_bwd_rows(const float* dy, const float* x, const float* w, const
   if (M <= 0) return RT_OK;
   return layernorm_bwd_any(dy, x, w, mean, rstd, res, ids, mask_dy, mask_dx, M, d, 0, 0, dx, nullptr, nullptr, workspace, workspace_bytes, stream,
                            false);
+}
+// rt_layernorm_bwd_rows over dy * (gscale * upstream[0] / norm[0]): the unit gradient of a sampled loss (rt_sampled_loss_fwd_train's
+// d_sess_unit) taken as it is — what rt_sampled_loss_bwd's session half would write first (same bits), without that launch.
+int rt_layernorm_bwd_rows_scaled(const float* dy, const float* norm, float gscale, const float* upstream, const float* x, const float* w,
+                                 const float* mean, const float* rstd, int32_t M, int32_t d, float* dx, void* workspace, size_t workspace_bytes,
+                                 hipStream_t stream) {
+  if (M <= 0) return RT_OK;
+  if (norm == nullptr) return RT_ERR_INVALID_ARG;
+  DyScale dsc;
+  dsc.norm = norm; dsc.upstream = upstream; dsc.gscale = gscale;
+  return layernorm_bwd_any(dy, x, w, mean, rstd, nullptr, nullptr, 0, 0, M, d, 0, 0, dx, nullptr, nullptr, workspace, workspace_bytes, stream, false, dsc);
 }
 int rt_layernorm_bwd_combine(const void* workspace, size_t workspace_bytes, int32_t M, int32_t d, float* dw, float* db, hipStream_t stream) {
   (void)hipGetLastError();

@@ -156,26 +156,21 @@ int rt_sasrec_step_run(const rt_sasrec_step* sp, int32_t phase, hipStream_t stre
     RT_TRY(rt_loss_reduce(F(L.loss_pos), s.y, M, s.loss == 2 ? 0 : 1, s.loss_out, stream));
 
     // ---- backward --------------------------------------------------------------------------------------------------------------
-    {   // the loss: the session half feeds the blocks (caller's stream), the table half is read by the lookup's backward and the optimiser
+    {   // the loss's table half (read by the lookup's backward and the optimiser) on the side stream; its session half is a scaled copy of
+        // the unit gradient the forward left — the last LayerNorm's backward takes the unit gradient itself and scales on load
       void* side = nullptr;
       RT_TRY(rt_side_fork(stream, &side));
-      if (side == nullptr) {
-        RT_TRY(rt_sampled_loss_bwd(F(L.y), d, s.table, s.y, s.neg, M, s.n_neg, d, s.V, s.cosine, s.logits_t, F(L.logits), s.loss_out + 1, 1.0f,
-                                   s.upstream, F(L.du), d, F(L.d_sess), d, d_table, base + L.loss_ws, L.loss_ws_bytes, 0, stream));
-      } else {
-        RT_TRY(rt_sampled_loss_bwd(F(L.y), d, s.table, s.y, s.neg, M, s.n_neg, d, s.V, s.cosine, s.logits_t, F(L.logits), s.loss_out + 1, 1.0f,
-                                   s.upstream, F(L.du), d, F(L.d_sess), d, nullptr, base + L.loss_ws, L.loss_ws_bytes, 0, stream));
-        RT_TRY(rt_sampled_loss_bwd(F(L.y), d, s.table, s.y, s.neg, M, s.n_neg, d, s.V, s.cosine, s.logits_t, F(L.logits), s.loss_out + 1, 1.0f,
-                                   s.upstream, F(L.du), d, nullptr, d, d_table, base + L.loss_ws, L.loss_ws_bytes, 0, static_cast<hipStream_t>(side)));
-        RT_TRY(rt_side_mark());      // the lookup's backward waits for THIS point, not for the weight gradients queued behind it
-        // (Tried: this half on a third library stream, so that its ~310 us chain does not sit in front of the last block's weight gradients:
-        //  + 0.3 % on the C2 step — and a fourth hardware queue in the process, which cost the LATER loops of the same process 20 - 25 %
-        //  (HSTU 22.8 -> 17.7 k, eSASRec 13.8 -> 10.9 k seqs/s in the default bench line: their side / prefetch streams then share queues).)
-      }
+      RT_TRY(rt_sampled_loss_bwd(F(L.y), d, s.table, s.y, s.neg, M, s.n_neg, d, s.V, s.cosine, s.logits_t, F(L.logits), s.loss_out + 1, 1.0f,
+                                 s.upstream, F(L.du), d, nullptr, d, d_table, base + L.loss_ws, L.loss_ws_bytes, 0,
+                                 side != nullptr ? static_cast<hipStream_t>(side) : stream));
+      if (side != nullptr) RT_TRY(rt_side_mark());      // the lookup's backward waits for THIS point, not for the weight gradients queued behind it
+      // (Tried: this half on a third library stream, so that its ~310 us chain does not sit in front of the last block's weight gradients:
+      //  + 0.3 % on the C2 step — and a fourth hardware queue in the process, which cost the LATER loops of the same process 20 - 25 %
+      //  (HSTU 22.8 -> 17.7 k, eSASRec 13.8 -> 10.9 k seqs/s in the default bench line: their side / prefetch streams then share queues).)
     }
     {   // the last LayerNorm: rows here, the combine of dw / db (optimiser only) on the side stream
-      RT_TRY(rt_layernorm_bwd_rows(F(L.d_sess), F(L.x[nb]), s.lnf_w, F(L.mean), F(L.rstd), nullptr, nullptr, 0, 0, M, d, F(L.g[nb]), base + L.ln_ws,
-                                   L.ln_ws_bytes, stream));
+      RT_TRY(rt_layernorm_bwd_rows_scaled(F(L.du), s.loss_out + 1, 1.0f, s.upstream, F(L.x[nb]), s.lnf_w, F(L.mean), F(L.rstd), M, d, F(L.g[nb]),
+                                          base + L.ln_ws, L.ln_ws_bytes, stream));
       void* side = nullptr;
       RT_TRY(rt_side_fork(stream, &side));
       RT_TRY(rt_layernorm_bwd_combine(base + L.ln_ws, L.ln_ws_bytes, M, d, gbase + L.d_lnf_w, gbase + L.d_lnf_b,
