@@ -38,7 +38,7 @@ struct Layout {
   size_t d_table, d_pos, d_lnf_w, d_lnf_b, d_blk[MAX_BLOCKS], grads_end;
   int64_t blk_off[13];
   // activations / workspaces (BYTES from the arena's start)
-  size_t x[MAX_BLOCKS + 1], saved[MAX_BLOCKS], y, mean, rstd, logits, loss_pos, du, loss_ws, emb_ws, d_sess, g[MAX_BLOCKS + 1], ln_ws,
+  size_t x[MAX_BLOCKS + 1], saved[MAX_BLOCKS], y, mean, rstd, logits, loss_pos, du, loss_ws, emb_ws, g[MAX_BLOCKS + 1], ln_ws,
       scratch[MAX_BLOCKS], total;
   size_t loss_ws_bytes, emb_ws_bytes, ln_ws_bytes, scratch_bytes;
 };
@@ -69,7 +69,6 @@ bool layout_of(const rt_sasrec_step& s, Layout& L) {
   L.loss_ws = take(L.loss_ws_bytes);
   L.emb_ws_bytes = rt_embed_bwd_workspace_bytes(s.rows, s.V, s.d);
   L.emb_ws = take(L.emb_ws_bytes);
-  L.d_sess = take(M * d * 4);
   // one data-gradient buffer per block boundary: the side stream still reads block b's g_out (its weight-gradient products) while
   // the caller's stream is already writing block b - 1's
   for (int b = 0; b <= s.n_blocks; ++b) L.g[b] = take(M * d * 4);
