@@ -914,7 +914,9 @@ int rt_wgrad_grouped(const rt_wgrad_problem* problems, int32_t n, int32_t rows, 
 int rt_colsum(const float* X, int64_t ld, int32_t M, int32_t N, float* out, hipStream_t stream) {
   (void)hipGetLastError();
   if (M <= 0 || N <= 0) return RT_OK;
-  int gy = (M + 63) / 64; if (gy > 512) gy = 512;
+  // few rows (the pad keys' share of a block's value-bias gradient: one row per session): ONE workgroup per 64 columns, so that a column
+  // meets exactly one atomicAdd and the sum does not depend on the order workgroups arrive in (bit-reproducible; 33 rows per wave at C2)
+  int gy = M <= 256 ? 1 : (M + 63) / 64; if (gy > 512) gy = 512;
   colsum_kernel<<<dim3((N + 63) / 64, gy), 256, 0, stream>>>(X, ld, M, N, out);
   RT_CHECK_LAUNCH();
   return RT_OK;
